@@ -1,0 +1,167 @@
+/*
+ * include/tlamc.h — C ABI of libtlamc.so, the MI355X-native explicit-state model checker
+ * for the spacejam/tla-rust specs.
+ *
+ * The reference has no FFI of its own: its boundary is the command line `tlc X.tla` with
+ * `X.cfg` beside it (reference Makefile:6-7, README.md:262,356) and TLC's stdout report
+ * (README.md:267-321).  BASELINE.json:north_star asks for a host (Rust in intent) that calls
+ * HIP "through a thin C-ABI FFI"; this header IS that FFI.  Every entry point below names the
+ * part of the reference's workflow it replaces.  Plain pointers and sizes only; the caller
+ * owns every *out buffer, the engine owns all device memory; no function throws or aborts
+ * across the boundary: each returns 0 or a negative MC_E* code (mc_strerror()).
+ *
+ * There is no CPU fallback behind this ABI: every function that computes needs a HIP device
+ * (gfx950) and fails with MC_EHIP without one.
+ */
+#ifndef TLAMC_H
+#define TLAMC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ error codes */
+#define MC_OK 0
+#define MC_EBADCFG (-1)    /* bad spec id / constants / configuration                        */
+#define MC_EHIP (-2)       /* HIP runtime error or no device                                 */
+#define MC_EOVERFLOW (-3)  /* a fixed-capacity slot array of the packed state overflowed     */
+#define MC_ETABLEFULL (-4) /* seen-set load factor exceeded                                  */
+#define MC_EARENA (-5)     /* state arena (frontier storage) exhausted                       */
+#define MC_ERCCL (-6)      /* exchange failure in sharded mode                               */
+#define MC_ESTATE (-7)     /* call sequence error                                            */
+#define MC_EPARSE (-8)     /* .cfg / .tla front-end error                                    */
+#define MC_ENOSPEC (-9)    /* module is not one of the lowered specs (or its text changed)   */
+
+/* ------------------------------------------------------------------ verdicts (TLC's outcomes) */
+#define MC_V_OK 0          /* "Model checking completed. No error has been found." (testout2:260) */
+#define MC_V_INVARIANT 1   /* an INVARIANT of the cfg is violated (pcal_intro.cfg:3)          */
+#define MC_V_ASSERT 2      /* "The first argument of Assert evaluated to FALSE" (README.md:268) */
+#define MC_V_DEADLOCK 3    /* p-manual §4.7.1 p.41                                            */
+#define MC_V_SPECERR 4     /* TLC would raise an evaluation error (index out of domain)       */
+#define MC_V_BUDGET 5      /* stopped by max_levels / max_distinct                            */
+
+/* ------------------------------------------------------------------ lowered specs */
+#define MC_SPEC_ATOMIC_ADD 1 /* reference atomic_add.tla:4-23, N adders + checker; params {N}          */
+#define MC_SPEC_PCAL_INTRO 2 /* reference pcal_intro.tla:4-23; params {variant, checkInv, MaxMoney, P}  */
+#define MC_SPEC_RAFT 3       /* reference examples/raft.tla:110-507 under specs/MCraft.tla;
+                                params {nServer, MaxClientRequests, MaxTerm, MaxLogLen, MaxMsgs,
+                                        invariantMask (1 NoTwoLeaders | 2 CommittedLogStable)}    */
+
+typedef struct {
+    uint32_t spec_id;
+    uint32_t nparams;
+    int64_t params[16];
+} mc_spec_desc;
+
+#define MC_F_DEADLOCK 1u /* check deadlock (TLC default on; serializableSnapshotIsolation.tla:57) */
+#define MC_F_TRACE 2u    /* keep (parent, action) per state so a counterexample can be rebuilt     */
+
+typedef struct {
+    int32_t device;          /* HIP device ordinal                                              */
+    uint32_t flags;          /* MC_F_*                                                          */
+    uint64_t table_capacity; /* seen-set slots, rounded up to a power of two (0 = default)      */
+    uint64_t arena_capacity; /* states kept resident in HBM (0 = default)                       */
+    uint64_t chunk_states;   /* frontier states expanded per launch (0 = default)               */
+    uint64_t max_levels;     /* 0 = unlimited                                                   */
+    uint64_t max_distinct;   /* 0 = unlimited; stop after the level whose cumulative D >= it    */
+    uint32_t shard_rank;     /* fingerprint-sharded mode: this engine's rank ...                */
+    uint32_t shard_count;    /* ... of shard_count (0 or 1 = single GPU)                        */
+} mc_config;
+
+#define MC_MAX_LEVELS 4096
+
+typedef struct {
+    uint64_t distinct;        /* "distinct states found"   (README.md:319)                      */
+    uint64_t generated;       /* "states generated"        (README.md:319)                      */
+    uint64_t queue_left;      /* "states left on queue"    (README.md:319)                      */
+    uint32_t depth;           /* "The depth of the complete state graph search is D." (README.md:320) */
+    int32_t verdict;          /* MC_V_*                                                         */
+    int32_t violated_invariant; /* index into the spec's invariant list, -1 if none             */
+    uint32_t trace_len;       /* states in the counterexample, 0 if none                        */
+    uint32_t levels;          /* entries valid in level_distinct[]                              */
+    uint32_t reserved;
+    double seconds;           /* init -> last level complete, device work included              */
+    uint64_t level_distinct[MC_MAX_LEVELS]; /* new distinct states per BFS level                */
+} mc_result;
+
+/* per-kernel timing, measured with HIP events on the engine's own stream */
+typedef struct {
+    uint64_t launches;
+    double ms_total;
+    uint64_t units;           /* states (expand/materialise) or candidates (insert) processed   */
+} mc_kernel_stat;
+typedef struct {
+    mc_kernel_stat expand, insert, materialise;
+    uint64_t state_bytes;     /* W: packed bytes per state in HBM                               */
+    uint64_t cand_cells;      /* candidate-matrix cells probed                                  */
+} mc_kernel_stats;
+
+typedef struct mc_engine mc_engine;
+
+/* ------------------------------------------------------------------ whole-run API
+ * Together these replace the BFS inside `tlc X.tla` (reference Makefile:6-7): initial-state
+ * enumeration, successor generation, fingerprinting, seen-set, invariant / Assert / deadlock
+ * checks, counters, depth and counterexample (README.md:267-321, testout2:1-266). */
+int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine **out);
+int mc_engine_run(mc_engine *e, mc_result *out);
+/* counterexample of the last run: states_out receives trace_len records of mc_state_bytes()
+ * bytes each (plain word order), actions_out the action id that produced each state (-1 for
+ * the initial state).  *n_inout: capacity in, count out. */
+int mc_engine_trace(mc_engine *e, uint8_t *states_out, int32_t *actions_out, size_t *n_inout);
+int mc_engine_kernel_stats(mc_engine *e, mc_kernel_stats *out);
+void mc_engine_destroy(mc_engine *e);
+
+/* ------------------------------------------------------------------ sharded (multi-GPU) step API
+ * One engine per GPU / process; the seen-set is partitioned by fingerprint high bits
+ * (owner = mc_fp_owner).  The caller (tla_rust_amd/sharded.py) moves the buckets between
+ * ranks with an all-to-all over RCCL/xGMI; all pointers are device pointers it allocated.
+ * Per level and per round:
+ *   expand     : frontier chunk -> candidate fingerprints bucketed by owner
+ *   (all-to-all of fingerprints)
+ *   probe      : owner inserts received fingerprints, answers one byte (1 = new) per fingerprint
+ *   (all-to-all of answers, reversed)
+ *   materialise: sender builds the full successor state of every "new" answer, bucketed by owner
+ *   (all-to-all of states)
+ *   ingest     : owner appends received states to its next-level frontier. */
+int mc_shard_begin(mc_engine *e);                                  /* Init: keep the initial states this rank owns */
+int mc_shard_level_size(mc_engine *e, uint64_t *frontier_states);  /* local frontier of the current level          */
+int mc_shard_expand(mc_engine *e, uint64_t first, uint64_t count,  /* chunk of the local frontier                  */
+                    uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts /* [shard_count] host */);
+int mc_shard_probe(mc_engine *e, const uint64_t *recv_fp, uint64_t n, uint8_t *answers);
+int mc_shard_materialise(mc_engine *e, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap,
+                         uint64_t *send_counts /* [shard_count] host, in states */);
+int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n);
+int mc_shard_end_level(mc_engine *e, uint64_t *new_local_states);  /* swap frontiers                                */
+int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict);
+
+/* ------------------------------------------------------------------ helpers (host only) */
+size_t mc_state_bytes(const mc_spec_desc *spec);                    /* W, 0 if the spec is invalid   */
+uint32_t mc_fp_owner(uint64_t fp, uint32_t shard_count);
+/* canonical TLA+ text of one packed state ("/\ var = value" lines, README.md:272-276) */
+int mc_state_format(const mc_spec_desc *spec, const uint8_t *state, char *buf, size_t cap);
+const char *mc_action_name(const mc_spec_desc *spec, int32_t action);
+const char *mc_strerror(int code);
+const char *mc_last_error(void);                                    /* detail of the last failure    */
+int mc_device_count(void);
+
+/* ------------------------------------------------------------------ front-end
+ * Replaces TLC's reading of X.cfg (grammar: examples/SpecifyingSystems/TLC/ConfigFileGrammar.tla:4-32)
+ * and its selection of Init/Next/invariants; the spec itself is selected by MODULE name
+ * (pcal_intro.tla:1) from the registry of hand-lowered specs. */
+typedef struct mc_cfg mc_cfg;
+int mc_cfg_parse(const char *text, size_t len, mc_cfg **out);
+void mc_cfg_free(mc_cfg *c);
+/* JSON rendering of the parsed cfg, for bindings and tests */
+int mc_cfg_json(const mc_cfg *c, char *buf, size_t cap);
+/* resolve module + cfg to a lowering; fails with MC_ENOSPEC for modules that are not lowered */
+int mc_spec_resolve(const char *module_name, const mc_cfg *c, mc_spec_desc *out);
+/* `tlc X.tla` end to end: read X.tla / X.cfg, run on `cfg->device`, write TLC's report text */
+int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report,
+                   size_t report_cap, mc_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

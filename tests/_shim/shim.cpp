@@ -1,0 +1,137 @@
+// tests/_shim/shim.cpp — TEST-ONLY host build of the device lowerings (tla_rust_amd/csrc/spec_*.h).
+//
+// There is no GPU in the development container, so the spec lowerings (which are MC_HD
+// host+device code) are compiled here with g++ and driven by a trivial sequential BFS with a
+// std::unordered_set of 64-bit fingerprints.  This lets `pytest -m "not gpu"` compare the
+// LOWERING (guards, successor construction, incremental fingerprints, state text) with the
+// independent oracle under oracle/ before a single GPU-minute is spent.  It is NOT part of
+// the product: libtlamc.so contains no CPU back-end and fails without a HIP device.
+//
+// The same step functions (expand / probe / materialise / ingest) are exported so the
+// multi-rank exchange logic of tla_rust_amd/sharded.py can be exercised with world_size-2
+// gloo tests on CPU.
+#include "../../tla_rust_amd/csrc/spec_registry.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+using namespace mc;
+
+struct ShimResult {
+    uint64_t distinct, generated, queue_left;
+    uint32_t depth;
+    int32_t verdict, violated_invariant;
+    uint32_t trace_len, levels;
+    uint64_t fp_mismatch;  // states whose stored fingerprint != full recomputation (must be 0)
+    uint64_t level_distinct[MC_MAX_LEVELS];
+};
+
+template <class S>
+static uint64_t stored_fp(const typename S::Params &p, const uint64_t *w) { return S::fp_of(p, CWordRef{w, 1}); }
+
+template <class S, class = void>
+struct FpCheck {
+    static bool ok(const typename S::Params &, const uint64_t *) { return true; }
+};
+template <class S>
+struct FpCheck<S, decltype((void)S::W_FP)> {
+    static bool ok(const typename S::Params &, const uint64_t *w) { return S::fp_recompute(CWordRef{w, 1}) == w[S::W_FP]; }
+};
+
+template <class S>
+static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t max_distinct, int check_deadlock,
+               const char *dump_path, ShimResult *r) {
+    constexpr int W = S::WORDS;
+    memset(r, 0, sizeof *r);
+    r->violated_invariant = -1;
+    std::vector<uint64_t> arena;
+    std::vector<uint32_t> parent;
+    std::unordered_set<uint64_t> seen;
+    FILE *dump = dump_path ? fopen(dump_path, "w") : nullptr;
+    std::vector<char> txt(1 << 16);
+    auto add_state = [&](const uint64_t *w, uint32_t par, uint32_t level) {
+        arena.insert(arena.end(), w, w + W);
+        parent.push_back(par);
+        r->distinct++;
+        r->level_distinct[level - 1]++;
+        if (!FpCheck<S>::ok(prm, w)) r->fp_mismatch++;
+        if (dump) {
+            int k = S::format(prm, w, txt.data(), txt.size());
+            for (int i = 0; i < k; i++) if (txt[i] == '\n') txt[i] = ' ';
+            fprintf(dump, "L%u %.*s\n", level, k, txt.data());
+        }
+    };
+    auto violation = [&](unsigned st, uint32_t trace_len) {
+        if (r->verdict) return;
+        r->verdict = (st & ST_ASSERT) ? MC_V_ASSERT : (st & ST_SPECERR) ? MC_V_SPECERR : MC_V_INVARIANT;
+        if (r->verdict == MC_V_INVARIANT) r->violated_invariant = (int)(st >> 8 & 255);
+        r->trace_len = trace_len;
+    };
+    uint64_t tmp[W];
+    const uint64_t ninit = S::num_init(prm);
+    for (uint64_t k = 0; k < ninit; k++) {
+        S::init(prm, k, WordRef{tmp, 1});
+        r->generated++;
+        const unsigned st = S::init_status(prm, CWordRef{tmp, 1});
+        if (st & ST_INVARIANT) violation(st, 1);
+        if (st & ST_OUT_OF_MODEL) continue;
+        if (seen.insert(stored_fp<S>(prm, tmp)).second) add_state(tmp, UINT32_MAX, 1);
+    }
+    uint64_t lo = 0, hi = r->distinct;
+    uint32_t level = 1;
+    int budget = 0;
+    while (hi > lo) {
+        if (r->verdict) break;
+        if (max_levels && level >= max_levels) { budget = 1; break; }
+        if (max_distinct && r->distinct >= max_distinct) { budget = 1; break; }
+        for (uint64_t i = lo; i < hi; i++) {
+            std::vector<uint64_t> cur(arena.begin() + i * W, arena.begin() + (i + 1) * W);  // arena may grow
+            CWordRef s{cur.data(), 1};
+            typename S::Local loc;
+            S::load(prm, s, loc);
+            const int ns = S::nslots(prm, loc);
+            uint64_t nsucc = 0;
+            for (int slot = 0; slot < ns; slot++) {
+                uint64_t fp = 0;
+                const unsigned st = S::eval(prm, loc, s, slot, fp);
+                if (!(st & ST_ENABLED)) continue;
+                nsucc++;
+                r->generated++;
+                if (st & ST_OVERFLOW) { if (dump) fclose(dump); return MC_EOVERFLOW; }
+                if (st & (ST_ASSERT | ST_SPECERR)) { violation(st, level); continue; }
+                if (st & ST_INVARIANT) violation(st, level + 1);
+                if (st & ST_OUT_OF_MODEL) continue;
+                if (seen.insert(fp).second) {
+                    S::apply(prm, s, slot, WordRef{tmp, 1});
+                    if (stored_fp<S>(prm, tmp) != fp) r->fp_mismatch++;
+                    add_state(tmp, (uint32_t)i, level + 1);
+                }
+            }
+            if (nsucc == 0 && check_deadlock && !r->verdict) { r->verdict = MC_V_DEADLOCK; r->trace_len = level; }
+        }
+        lo = hi;
+        hi = r->distinct;
+        if (hi > lo) level++;
+        if (level >= MC_MAX_LEVELS) break;
+    }
+    r->depth = level;
+    r->levels = level;
+    r->queue_left = hi - lo;
+    if (!r->verdict && budget) r->verdict = MC_V_BUDGET;
+    if (dump) fclose(dump);
+    return 0;
+}
+
+extern "C" int shim_run(const mc_spec_desc *d, uint64_t max_levels, uint64_t max_distinct, int check_deadlock,
+                        const char *dump_path, ShimResult *r) {
+    return dispatch_spec(d, [&](auto spec, const auto &prm) { return run(spec, prm, max_levels, max_distinct, check_deadlock, dump_path, r); });
+}
+
+extern "C" size_t shim_state_bytes(const mc_spec_desc *d) {
+    size_t n = 0;
+    dispatch_spec(d, [&](auto spec, const auto &) { n = sizeof(uint64_t) * decltype(spec)::WORDS; return 0; });
+    return n;
+}

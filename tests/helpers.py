@@ -1,0 +1,143 @@
+"""Test helpers: ctypes bindings of the CPU oracle (oracle/_build/liboracle.so) and of the
+test-only host build of the device lowerings (tests/_shim/_build/libshim.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+SHIM_DIR = ROOT / "tests" / "_shim"
+
+OR_MAX_LEVELS = 4096
+OR_MAX_TRACE = 4096
+VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
+
+
+class OrOptions(C.Structure):
+    _fields_ = [("max_levels", C.c_uint64), ("max_distinct", C.c_uint64), ("check_deadlock", C.c_int),
+                ("stop_on_violation", C.c_int), ("dump_path", C.c_char_p)]
+
+
+class OrResult(C.Structure):
+    _fields_ = [("distinct", C.c_uint64), ("generated", C.c_uint64), ("queue_left", C.c_uint64),
+                ("depth", C.c_uint32), ("verdict", C.c_int), ("violated_invariant", C.c_int),
+                ("level_distinct", C.c_uint64 * OR_MAX_LEVELS), ("level_generated", C.c_uint64 * OR_MAX_LEVELS),
+                ("trace_len", C.c_uint32), ("trace_action", C.c_int * OR_MAX_TRACE), ("seconds", C.c_double),
+                ("max_stat", C.c_uint64 * 8), ("arena_bytes", C.c_uint64)]
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", str(ORACLE_DIR)], check=True)
+    return ORACLE_DIR / "_build" / "liboracle.so"
+
+
+_oracle = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        so = ORACLE_DIR / "_build" / "liboracle.so"
+        if not so.exists():
+            build_oracle()
+        lib = C.CDLL(str(so))
+        lib.oracle_run.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(OrOptions), C.POINTER(OrResult)]
+        lib.oracle_run.restype = C.c_int
+        lib.oracle_trace_state.argtypes = [C.c_uint32]
+        lib.oracle_trace_state.restype = C.c_char_p
+        lib.oracle_action_name.argtypes = [C.c_char_p, C.c_int]
+        lib.oracle_action_name.restype = C.c_char_p
+        lib.oracle_last_error.restype = C.c_char_p
+        _oracle = lib
+    return _oracle
+
+
+def oracle_run(spec, params, max_levels=0, max_distinct=0, check_deadlock=True, stop=1, dump=None):
+    """Run the oracle; returns a dict with counts, verdict, per-level distinct and the trace."""
+    lib = oracle_lib()
+    p = (C.c_int64 * len(params))(*params)
+    opt = OrOptions(max_levels, max_distinct, int(check_deadlock), stop, dump.encode() if dump else None)
+    res = OrResult()
+    rc = lib.oracle_run(spec.encode(), p, len(params), C.byref(opt), C.byref(res))
+    if rc:
+        raise RuntimeError(lib.oracle_last_error().decode())
+    trace = [(res.trace_action[k], lib.oracle_trace_state(k).decode()) for k in range(res.trace_len)]
+    return dict(distinct=res.distinct, generated=res.generated, queue_left=res.queue_left, depth=res.depth,
+                verdict=VERDICTS[res.verdict], violated_invariant=res.violated_invariant,
+                levels=[res.level_distinct[i] for i in range(res.depth)], trace=trace, seconds=res.seconds,
+                max_stat=list(res.max_stat))
+
+
+# ---------------------------------------------------------------------------------- shim
+MC_MAX_LEVELS = 4096
+SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3}
+
+
+class McSpecDesc(C.Structure):
+    _fields_ = [("spec_id", C.c_uint32), ("nparams", C.c_uint32), ("params", C.c_int64 * 16)]
+
+
+def spec_desc(spec, params):
+    d = McSpecDesc()
+    d.spec_id = SPEC_IDS[spec]
+    d.nparams = len(params)
+    for i, v in enumerate(params):
+        d.params[i] = v
+    return d
+
+
+class ShimResult(C.Structure):
+    _fields_ = [("distinct", C.c_uint64), ("generated", C.c_uint64), ("queue_left", C.c_uint64),
+                ("depth", C.c_uint32), ("verdict", C.c_int32), ("violated_invariant", C.c_int32),
+                ("trace_len", C.c_uint32), ("levels", C.c_uint32), ("fp_mismatch", C.c_uint64),
+                ("level_distinct", C.c_uint64 * MC_MAX_LEVELS)]
+
+
+def build_shim():
+    out = SHIM_DIR / "_build"
+    out.mkdir(exist_ok=True)
+    so = out / "libshim.so"
+    srcs = [SHIM_DIR / "shim.cpp"] + list((ROOT / "tla_rust_amd" / "csrc").glob("*.h")) + [ROOT / "include" / "tlamc.h"]
+    if so.exists() and all(so.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return so
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(SHIM_DIR / "shim.cpp")], check=True)
+    return so
+
+
+_shim = None
+
+
+def shim_lib():
+    global _shim
+    if _shim is None:
+        lib = C.CDLL(str(build_shim()))
+        lib.shim_run.argtypes = [C.POINTER(McSpecDesc), C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.POINTER(ShimResult)]
+        lib.shim_run.restype = C.c_int
+        _shim = lib
+    return _shim
+
+
+def shim_run(spec, params, max_levels=0, max_distinct=0, check_deadlock=True, dump=None):
+    lib = shim_lib()
+    d = spec_desc(spec, params)
+    res = ShimResult()
+    rc = lib.shim_run(C.byref(d), max_levels, max_distinct, int(check_deadlock), dump.encode() if dump else None, C.byref(res))
+    if rc:
+        raise RuntimeError(f"shim_run failed: {rc}")
+    return dict(distinct=res.distinct, generated=res.generated, queue_left=res.queue_left, depth=res.depth,
+                verdict=VERDICTS[res.verdict], violated_invariant=res.violated_invariant, trace_len=res.trace_len,
+                levels=[res.level_distinct[i] for i in range(res.levels)], fp_mismatch=res.fp_mismatch)
+
+
+def read_dump(path):
+    """dump file -> {level: sorted list of state texts}"""
+    by_level = {}
+    with open(path) as f:
+        for line in f:
+            lvl, txt = line.rstrip("\n").split(" ", 1)
+            by_level.setdefault(int(lvl[1:]), []).append(txt)
+    return {k: sorted(v) for k, v in by_level.items()}

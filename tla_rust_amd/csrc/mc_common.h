@@ -1,0 +1,72 @@
+// mc_common.h — shared host/device definitions of the model-checking engine.
+//
+// Spec lowerings (spec_*.h) are written once as MC_HD functions: hipcc compiles them into the
+// gfx950 kernels of engine.hip, and the host pass compiles them for trace reconstruction and
+// state formatting (and tests/_shim builds them alone, without HIP, to compare the lowering
+// against the oracle on a CPU-only machine).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MC_HD __host__ __device__ __forceinline__
+#else
+#define MC_HD inline
+#endif
+
+namespace mc {
+
+// status bits returned by Spec::eval for one (state, slot) pair
+enum : unsigned {
+    ST_ENABLED = 1u,       // the action's guard holds: one successor is generated
+    ST_OUT_OF_MODEL = 2u,  // successor violates the CONSTRAINT: generated, not stored
+    ST_ASSERT = 4u,        // Assert(...) evaluated to FALSE while generating it
+    ST_INVARIANT = 8u,     // successor violates an INVARIANT (index in bits 8..15)
+    ST_SPECERR = 16u,      // TLC would raise an evaluation error
+    ST_OVERFLOW = 32u      // a fixed-capacity slot array of the packed state is full
+};
+
+// Strided view of one packed state.  In the HBM arena states are stored in blocks of 64,
+// word-major inside a block (word w of state (b,l) at ((b*WORDS + w)*64 + l)), so that a
+// wavefront whose lane l works on state (b,l) reads and writes 512 contiguous bytes per
+// word access.  Host buffers and exchange records are plain (stride 1).
+struct WordRef {
+    uint64_t *p;
+    size_t stride;
+    MC_HD uint64_t get(int w) const { return p[(size_t)w * stride]; }
+    MC_HD void set(int w, uint64_t v) const { p[(size_t)w * stride] = v; }
+};
+struct CWordRef {
+    const uint64_t *p;
+    size_t stride;
+    MC_HD uint64_t get(int w) const { return p[(size_t)w * stride]; }
+};
+
+MC_HD uint64_t fmix64(uint64_t h) {
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    return h;
+}
+// H(x, salt): contribution of one element to the additive (multiset) fingerprint.
+MC_HD uint64_t hmix(uint64_t x, uint64_t salt) { return fmix64(x ^ salt); }
+// fingerprint 0 is the seen-set's EMPTY marker
+MC_HD uint64_t fp_nonzero(uint64_t fp) { return fp ? fp : 0x9e3779b97f4a7c15ull; }
+
+MC_HD uint64_t salt_of(unsigned i) { return 0x9e3779b97f4a7c15ull * (2ull * i + 1ull) + 0x632be59bd9b4e019ull; }
+
+MC_HD uint32_t fp_owner(uint64_t fp, uint32_t shards) {
+    // high bits pick the owner, low bits index the owner's table
+    return shards <= 1 ? 0u : (uint32_t)(((fp >> 40) * (uint64_t)shards) >> 24);
+}
+
+MC_HD uint64_t bits_get(uint64_t w, int pos, int n) { return (w >> pos) & ((1ull << n) - 1ull); }
+MC_HD uint64_t bits_set(uint64_t w, int pos, int n, uint64_t v) {
+    const uint64_t m = ((1ull << n) - 1ull) << pos;
+    return (w & ~m) | ((v << pos) & m);
+}
+
+}  // namespace mc

@@ -1,0 +1,672 @@
+// spec_raft.h — device lowering of examples/raft.tla (reference examples/raft.tla:110-507) under
+// the model wrapper specs/MCraft.tla (+ specs/MCraft.cfg) of this repo.
+//
+// Packed state = WORDS 64-bit words (layout below).  The three set-valued history variables
+// (messages with its monotone key set, elections, allLogs) are kept as UNORDERED slot arrays:
+// equality of TLA+ values is decided by an additive (multiset) fingerprint
+//     fp = sum_w H(header word w, salt_w) + sum_m H(msg word, SALT_M) + sum_e He(e) + sum_l H(log, SALT_A)
+// which does not depend on slot order, so a successor is "parent with <= 2 message slots
+// changed, <= 1 election appended, <= NS logs appended, one server's words and the globals
+// rewritten" and its fingerprint is the parent's plus the differences — O(delta), not O(W).
+//
+// Semantic notes that change counts — all kept:
+//  0. raft.tla:392-393 vs :402/:75: the "already done" branch is enabled only when
+//     m.mcommitIndex = commitIndex[i].
+//  1. the bag is a map msg -> {0,1,2}; zero-count keys stay (raft.tla:117-129).
+//  2. UpdateTerm / return-to-follower / conflict / append do not consume the message.
+//  3. RequestVote(i,i) is allowed (raft.tla:209-217); AppendEntries needs i /= j (:223).
+//  4. voterLog[i] @@ (j :> mlog) keeps an existing entry (raft.tla:343-344).
+//  5. committedLog' = <<>> unless newCommitIndex > 1 (raft.tla:296-300).
+//  6. committedLogDecrease' uses lazy \/ (raft.tla:302-303).
+//  7. allLogs' = allLogs \cup {log[i]} over UNPRIMED logs (raft.tla:493).
+#pragma once
+#include "mc_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace mc {
+
+// -------------------------------------------------------------------------- log encoding
+// log word: bits 0..2 = Len, entry k (1-based) at bits 3+6(k-1).. : term (3 bits) | value << 3.
+namespace rlog {
+constexpr int LCAP = 5;
+MC_HD int len(uint64_t l) { return (int)(l & 7); }
+MC_HD unsigned entry(uint64_t l, int k) { return (unsigned)(l >> (3 + 6 * (k - 1))) & 63u; }
+MC_HD int eterm(unsigned e) { return (int)(e & 7u); }
+MC_HD int evalue(unsigned e) { return (int)(e >> 3); }
+MC_HD unsigned mk_entry(int term, int value) { return (unsigned)term | ((unsigned)value << 3); }
+MC_HD int last_term(uint64_t l) { return len(l) ? eterm(entry(l, len(l))) : 0; }                    // raft.tla:113
+MC_HD uint64_t append(uint64_t l, unsigned e) { return (l + 1) | ((uint64_t)e << (3 + 6 * len(l))); }  // Append
+MC_HD uint64_t prefix(uint64_t l, int k) { return k == 0 ? 0 : ((l & ((1ull << (3 + 6 * k)) - 1ull)) & ~7ull) | (uint64_t)k; }
+MC_HD uint64_t drop_last(uint64_t l) { return prefix(l, len(l) - 1); }
+}  // namespace rlog
+
+enum : int { R_FOLLOWER = 0, R_CANDIDATE = 1, R_LEADER = 2 };
+enum : int { M_RVREQ = 0, M_RVRESP = 1, M_AEREQ = 2, M_AERESP = 3 };
+enum : int { RA_RESTART, RA_TIMEOUT, RA_REQUESTVOTE, RA_BECOMELEADER, RA_CLIENTREQUEST, RA_ADVANCECOMMIT,
+             RA_APPENDENTRIES, RA_RECEIVE, RA_DUPLICATE, RA_DROP };
+
+struct RaftParams {
+    int n, max_client_requests, max_term, max_log_len, max_msgs, inv_mask;
+};
+
+template <int NS, int CM, int CE, int CA>
+struct SpecRaft {
+    using Params = RaftParams;
+    // ---------------------------------------------------------------- word layout
+    static constexpr int W_FP = 0;     // additive fingerprint of this state (raw sum)
+    static constexpr int W_GLOB = 1;   // clientRequests[0,3) decrease[3] nMsgs[8,16) nElec[16,20) nAll[24,32)
+    static constexpr int W_CLOG = 2;   // committedLog
+    static constexpr int SRV_WORDS = 2 + NS;
+    MC_HD static constexpr int W_SRV(int i) { return 3 + i * SRV_WORDS; }      // scalars of server i
+    MC_HD static constexpr int W_LOG(int i) { return W_SRV(i) + 1; }           // log[i]
+    MC_HD static constexpr int W_VLOG(int i, int j) { return W_SRV(i) + 2 + j; }  // voterLog[i][j]
+    static constexpr int W_MSG0 = 3 + NS * SRV_WORDS;                         // messages[CM]
+    static constexpr int EL_WORDS = 1 + NS;
+    static constexpr int W_EL0 = W_MSG0 + CM;                                 // elections[CE][1+NS]
+    static constexpr int W_ALL0 = W_EL0 + CE * EL_WORDS;                      // allLogs[CA]
+    static constexpr int WORDS = W_ALL0 + CA;
+    static constexpr int HDR_WORDS = W_MSG0;
+    // slots: Restart NS | Timeout NS | RequestVote NS^2 | BecomeLeader NS | ClientRequest NS |
+    //        AdvanceCommitIndex NS | AppendEntries NS^2 | per message k: Receive, Duplicate, Drop
+    static constexpr int FIX = 5 * NS + 2 * NS * NS;
+    static constexpr int MAX_SLOTS = FIX + 3 * CM;
+    static constexpr uint64_t SALT_M = 0x8f1bbcdc8f1bbcdcull, SALT_E = 0xca62c1d6ca62c1d6ull, SALT_A = 0x5a8279995a827999ull;
+
+    // server scalar word: term[0,3) state[3,5) votedFor[5,8) votesGranted[8,13) commitIndex[13,16)
+    //                     nextIndex[j] 4 bits at 16+4j, matchIndex[j] 3 bits at 36+3j
+    MC_HD static int sv_term(uint64_t v) { return (int)(v & 7); }
+    MC_HD static int sv_state(uint64_t v) { return (int)(v >> 3 & 3); }
+    MC_HD static int sv_voted(uint64_t v) { return (int)(v >> 5 & 7); }       // 0 = Nil, j+1
+    MC_HD static unsigned sv_granted(uint64_t v) { return (unsigned)(v >> 8 & 31); }
+    MC_HD static int sv_commit(uint64_t v) { return (int)(v >> 13 & 7); }
+    MC_HD static int sv_next(uint64_t v, int j) { return (int)(v >> (16 + 4 * j) & 15); }
+    MC_HD static int sv_match(uint64_t v, int j) { return (int)(v >> (36 + 3 * j) & 7); }
+    MC_HD static uint64_t sv_set_term(uint64_t v, int x) { return bits_set(v, 0, 3, (uint64_t)x); }
+    MC_HD static uint64_t sv_set_state(uint64_t v, int x) { return bits_set(v, 3, 2, (uint64_t)x); }
+    MC_HD static uint64_t sv_set_voted(uint64_t v, int x) { return bits_set(v, 5, 3, (uint64_t)x); }
+    MC_HD static uint64_t sv_set_granted(uint64_t v, unsigned x) { return bits_set(v, 8, 5, x); }
+    MC_HD static uint64_t sv_set_commit(uint64_t v, int x) { return bits_set(v, 13, 3, (uint64_t)x); }
+    MC_HD static uint64_t sv_set_next(uint64_t v, int j, int x) { return bits_set(v, 16 + 4 * j, 4, (uint64_t)x); }
+    MC_HD static uint64_t sv_set_match(uint64_t v, int j, int x) { return bits_set(v, 36 + 3 * j, 3, (uint64_t)x); }
+    MC_HD static uint64_t sv_reset_leader_vars(uint64_t v, int next) {        // nextIndex = next, matchIndex = 0 for all j
+        for (int j = 0; j < NS; j++) v = sv_set_match(sv_set_next(v, j, next), j, 0);
+        return v;
+    }
+    // globals
+    MC_HD static int g_creq(uint64_t g) { return (int)(g & 7); }
+    MC_HD static int g_decr(uint64_t g) { return (int)(g >> 3 & 1); }
+    MC_HD static int g_nm(uint64_t g) { return (int)(g >> 8 & 255); }
+    MC_HD static int g_ne(uint64_t g) { return (int)(g >> 16 & 15); }
+    MC_HD static int g_na(uint64_t g) { return (int)(g >> 24 & 255); }
+    // message word: count[0,2) type[2,4) term[4,7) src[7,10) dst[10,13) payload[13,..)
+    MC_HD static int m_count(uint64_t m) { return (int)(m & 3); }
+    MC_HD static int m_type(uint64_t m) { return (int)(m >> 2 & 3); }
+    MC_HD static int m_term(uint64_t m) { return (int)(m >> 4 & 7); }
+    MC_HD static int m_src(uint64_t m) { return (int)(m >> 7 & 7); }
+    MC_HD static int m_dst(uint64_t m) { return (int)(m >> 10 & 7); }
+    MC_HD static uint64_t m_head(int type, int term, int src, int dst) {
+        return ((uint64_t)type << 2) | ((uint64_t)term << 4) | ((uint64_t)src << 7) | ((uint64_t)dst << 10);
+    }
+    // RVReq : lastLogTerm[13,16) lastLogIndex[16,19)
+    // RVResp: granted[13] mlog[14,47)
+    // AEReq : prevIdx[13,16) prevTerm[16,19) nentries[19] entry[20,26) commitIdx[26,29) mlog[29,62)
+    // AEResp: success[13] matchIndex[14,17)
+    MC_HD static uint64_t mk_rvreq(int term, int llt, int lli, int src, int dst) {
+        return m_head(M_RVREQ, term, src, dst) | ((uint64_t)llt << 13) | ((uint64_t)lli << 16);
+    }
+    MC_HD static uint64_t mk_rvresp(int term, int granted, uint64_t mlog, int src, int dst) {
+        return m_head(M_RVRESP, term, src, dst) | ((uint64_t)granted << 13) | (mlog << 14);
+    }
+    MC_HD static uint64_t mk_aereq(int term, int pidx, int pterm, int nent, unsigned ent, int cidx, uint64_t mlog, int src, int dst) {
+        return m_head(M_AEREQ, term, src, dst) | ((uint64_t)pidx << 13) | ((uint64_t)pterm << 16) | ((uint64_t)nent << 19) |
+               ((uint64_t)ent << 20) | ((uint64_t)cidx << 26) | (mlog << 29);
+    }
+    MC_HD static uint64_t mk_aeresp(int term, int success, int midx, int src, int dst) {
+        return m_head(M_AERESP, term, src, dst) | ((uint64_t)success << 13) | ((uint64_t)midx << 14);
+    }
+    // election word 0: eterm[0,3) eleader[3,6) evotes[6,11) elog[11,44); words 1..NS: evoterLog[j]
+    MC_HD static uint64_t helec(const uint64_t *ew) {
+        uint64_t h = hmix(ew[0], SALT_E);
+        for (int q = 1; q <= NS; q++) h = hmix(ew[q] + h, SALT_E + (uint64_t)q);
+        return h;
+    }
+
+    static int make_params(const int64_t *p, unsigned np, Params &o) {
+        if (np < 5) return -1;
+        o.n = (int)p[0]; o.max_client_requests = (int)p[1]; o.max_term = (int)p[2];
+        o.max_log_len = (int)p[3]; o.max_msgs = (int)p[4];
+        o.inv_mask = np > 5 ? (int)p[5] : 1;
+        if (o.n != NS) return -1;
+        if (o.max_client_requests < 1 || o.max_client_requests - 1 > rlog::LCAP || o.max_client_requests > 7) return -1;
+        if (o.max_term < 1 || o.max_term > 6) return -1;  // term MaxTerm+1 must still fit 3 bits
+        if (o.max_log_len < 0 || o.max_msgs < 0) return -1;
+        return 0;
+    }
+
+    // ---------------------------------------------------------------- Init   raft.tla:156-179
+    MC_HD static uint64_t num_init(const Params &) { return 1; }
+    MC_HD static void init(const Params &, uint64_t, WordRef out) {
+        for (int w = 0; w < WORDS; w++) out.set(w, 0);
+        uint64_t sv = sv_reset_leader_vars(sv_set_term(0, 1), 1);  // currentTerm 1, Follower, Nil, {}, 0, next 1, match 0
+        uint64_t fp = 0;
+        for (int i = 0; i < NS; i++) out.set(W_SRV(i), sv);
+        out.set(W_GLOB, 1);  // clientRequests = 1
+        for (int w = 1; w < HDR_WORDS; w++) fp += hmix(out.get(w), salt_of((unsigned)w));
+        out.set(W_FP, fp);
+    }
+    template <class Ref>
+    MC_HD static uint64_t fp_of(const Params &, Ref s) { return fp_nonzero(s.get(W_FP)); }
+    // full recomputation of the fingerprint (tests: must equal the incrementally maintained one)
+    template <class Ref>
+    MC_HD static uint64_t fp_recompute(Ref s) {
+        uint64_t fp = 0;
+        for (int w = 1; w < HDR_WORDS; w++) fp += hmix(s.get(w), salt_of((unsigned)w));
+        const uint64_t g = s.get(W_GLOB);
+        for (int k = 0; k < g_nm(g); k++) fp += hmix(s.get(W_MSG0 + k), SALT_M);
+        for (int e = 0; e < g_ne(g); e++) {
+            uint64_t ew[EL_WORDS];
+            for (int q = 0; q < EL_WORDS; q++) ew[q] = s.get(W_EL0 + e * EL_WORDS + q);
+            fp += helec(ew);
+        }
+        for (int a = 0; a < g_na(g); a++) fp += hmix(s.get(W_ALL0 + a), SALT_A);
+        return fp;
+    }
+    template <class Ref>
+    MC_HD static unsigned init_status(const Params &, Ref) { return ST_ENABLED; }
+
+    // ---------------------------------------------------------------- per-parent cache
+    struct Local {
+        uint64_t fp, glob, clog;
+        uint64_t sv[NS], log[NS];
+        int nm, inflight;
+        int nadd;              // logs of {log[i]} not yet in allLogs (raft.tla:493), deduplicated
+        uint64_t addlog[NS];
+        uint64_t add_fp;       // sum of their contributions
+    };
+    template <class Ref>
+    MC_HD static void load(const Params &, Ref s, Local &l) {
+        l.fp = s.get(W_FP);
+        l.glob = s.get(W_GLOB);
+        l.clog = s.get(W_CLOG);
+        for (int i = 0; i < NS; i++) { l.sv[i] = s.get(W_SRV(i)); l.log[i] = s.get(W_LOG(i)); }
+        l.nm = g_nm(l.glob);
+        l.inflight = 0;
+        for (int k = 0; k < l.nm; k++) l.inflight += m_count(s.get(W_MSG0 + k));
+        // allLogs' = allLogs \cup {log[i] : i \in Server} — the same for every successor of this state
+        unsigned present = 0;
+        const int na = g_na(l.glob);
+        for (int a = 0; a < na; a++) {
+            const uint64_t x = s.get(W_ALL0 + a);
+            for (int i = 0; i < NS; i++) if (x == l.log[i]) present |= 1u << i;
+        }
+        l.nadd = 0;
+        l.add_fp = 0;
+        for (int i = 0; i < NS; i++) {
+            if (present >> i & 1) continue;
+            bool dup = false;
+            for (int q = 0; q < l.nadd; q++) dup |= l.addlog[q] == l.log[i];
+            if (dup) continue;
+            l.addlog[l.nadd++] = l.log[i];
+            l.add_fp += hmix(l.log[i], SALT_A);
+        }
+    }
+    MC_HD static int nslots(const Params &, const Local &l) { return FIX + 3 * l.nm; }
+
+    // ---------------------------------------------------------------- successor delta
+    struct Delta {
+        uint64_t glob, clog;
+        int srv;                 // the one server whose words change (-1: none)
+        uint64_t sv, log;
+        int vmode;               // 0 voterLog[srv] unchanged, 1 cleared, 2 one entry set
+        int vj; uint64_t vlog;
+        int nmop, midx[2];       // message slots rewritten (midx == nm: appended)
+        uint64_t mold[2], mnew[2];
+        bool eadd;
+        uint64_t ew[EL_WORDS];
+        int dinflight;
+    };
+
+    // Send(m) / WithMessage   raft.tla:117-121,138: increment (saturating at 2) or add with count 1
+    template <class Ref>
+    MC_HD static unsigned send(const Local &l, Ref s, uint64_t key_word /*count bits zero*/, Delta &d) {
+        int idx = l.nm;
+        uint64_t old = 0;
+        for (int k = 0; k < l.nm; k++) {
+            const uint64_t x = s.get(W_MSG0 + k);
+            if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; }
+        }
+        // a slot already rewritten by this delta (cannot happen: response key /= request key)
+        const int q = d.nmop++;
+        d.midx[q] = idx;
+        d.mold[q] = old;
+        if (idx < l.nm) {
+            const int c = m_count(old);
+            d.mnew[q] = c < 2 ? old + 1 : old;
+            d.dinflight += c < 2 ? 1 : 0;
+            return 0u;
+        }
+        d.mnew[q] = key_word | 1;
+        d.dinflight += 1;
+        return idx >= CM ? (unsigned)ST_OVERFLOW : 0u;
+    }
+    // Discard(m) / WithoutMessage on the slot the message was read from   raft.tla:125-129,142
+    MC_HD static void discard(int k, uint64_t mword, Delta &d) {
+        const int q = d.nmop++;
+        d.midx[q] = k;
+        d.mold[q] = mword;
+        const int c = m_count(mword);
+        d.mnew[q] = c > 0 ? mword - 1 : mword;
+        d.dinflight -= c > 0 ? 1 : 0;
+    }
+
+    MC_HD static bool in_quorum(unsigned set) { return 2 * __builtin_popcount(set) > NS; }  // raft.tla:110
+
+    // compute the successor of `slot`; returns status bits (0 = not enabled)
+    template <class Ref>
+    MC_HD static unsigned compute(const Params &prm, const Local &l, Ref s, int slot, Delta &d, int &action) {
+        d.glob = l.glob; d.clog = l.clog; d.srv = -1; d.sv = 0; d.log = 0; d.vmode = 0; d.vj = 0; d.vlog = 0;
+        d.nmop = 0; d.eadd = false; d.dinflight = 0;
+        unsigned st = ST_ENABLED;
+        if (slot < NS) {  // Restart(i)   raft.tla:186-194 (always enabled)
+            const int i = slot;
+            action = RA_RESTART;
+            d.srv = i; d.log = l.log[i];
+            d.sv = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(l.sv[i], R_FOLLOWER), 0), 0), 1);
+            d.vmode = 1;
+        } else if (slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
+            const int i = slot - NS;
+            action = RA_TIMEOUT;
+            const int stt = sv_state(l.sv[i]);
+            if (!(stt == R_FOLLOWER || stt == R_CANDIDATE)) return 0;
+            const int nt = sv_term(l.sv[i]) + 1;
+            if (nt > prm.max_term) st |= ST_OUT_OF_MODEL;
+            d.srv = i; d.log = l.log[i];
+            d.sv = sv_set_granted(sv_set_voted(sv_set_term(sv_set_state(l.sv[i], R_CANDIDATE), nt & 7), 0), 0);
+            d.vmode = 1;
+        } else if (slot < 2 * NS + NS * NS) {  // RequestVote(i, j)   raft.tla:209-217
+            const int q = slot - 2 * NS, i = q / NS, j = q % NS;
+            action = RA_REQUESTVOTE;
+            if (sv_state(l.sv[i]) != R_CANDIDATE) return 0;
+            st |= send(l, s, mk_rvreq(sv_term(l.sv[i]), rlog::last_term(l.log[i]), rlog::len(l.log[i]), i, j), d);
+        } else if (slot < 3 * NS + NS * NS) {  // BecomeLeader(i)   raft.tla:247-261
+            const int i = slot - (2 * NS + NS * NS);
+            action = RA_BECOMELEADER;
+            if (sv_state(l.sv[i]) != R_CANDIDATE || !in_quorum(sv_granted(l.sv[i]))) return 0;
+            d.srv = i; d.log = l.log[i];
+            d.sv = sv_reset_leader_vars(sv_set_state(l.sv[i], R_LEADER), rlog::len(l.log[i]) + 1);
+            d.ew[0] = (uint64_t)sv_term(l.sv[i]) | ((uint64_t)i << 3) | ((uint64_t)sv_granted(l.sv[i]) << 6) | (l.log[i] << 11);
+            for (int j = 0; j < NS; j++) d.ew[1 + j] = s.get(W_VLOG(i, j));
+            // elections \cup {...}: a set — an identical record changes nothing
+            bool present = false;
+            const int ne = g_ne(l.glob);
+            for (int e = 0; e < ne; e++) {
+                bool eq = true;
+                for (int q = 0; q < EL_WORDS; q++) eq &= s.get(W_EL0 + e * EL_WORDS + q) == d.ew[q];
+                present |= eq;
+            }
+            if (!present) {
+                d.eadd = true;
+                if (ne >= CE) st |= ST_OVERFLOW;
+                d.glob += 1ull << 16;
+            }
+        } else if (slot < 4 * NS + NS * NS) {  // ClientRequest(i)   raft.tla:264-274
+            const int i = slot - (3 * NS + NS * NS);
+            action = RA_CLIENTREQUEST;
+            const int creq = g_creq(l.glob);
+            if (sv_state(l.sv[i]) != R_LEADER || !(creq < prm.max_client_requests)) return 0;
+            if (rlog::len(l.log[i]) >= rlog::LCAP) return ST_ENABLED | ST_OVERFLOW;
+            d.srv = i; d.sv = l.sv[i];
+            d.log = rlog::append(l.log[i], rlog::mk_entry(sv_term(l.sv[i]), creq));
+            d.glob += 1;  // clientRequests' = clientRequests + 1
+            if (rlog::len(d.log) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
+        } else if (slot < 5 * NS + NS * NS) {  // AdvanceCommitIndex(i)   raft.tla:280-305
+            const int i = slot - (4 * NS + NS * NS);
+            action = RA_ADVANCECOMMIT;
+            if (sv_state(l.sv[i]) != R_LEADER) return 0;
+            const uint64_t lg = l.log[i];
+            int maxAgree = 0;
+            for (int index = 1; index <= rlog::len(lg); index++) {
+                unsigned agree = 1u << i;  // Agree(index) == {i} \cup {k : matchIndex[i][k] >= index}
+                for (int k = 0; k < NS; k++) if (sv_match(l.sv[i], k) >= index) agree |= 1u << k;
+                if (in_quorum(agree)) maxAgree = index;
+            }
+            const int nci = (maxAgree > 0 && rlog::eterm(rlog::entry(lg, maxAgree)) == sv_term(l.sv[i])) ? maxAgree : sv_commit(l.sv[i]);
+            uint64_t ncl = 0;
+            if (nci > 1) {
+                if (nci > rlog::len(lg)) return ST_ENABLED | ST_SPECERR;  // log[i][j] out of domain
+                ncl = rlog::prefix(lg, nci);
+            }
+            const int lc = rlog::len(l.clog);
+            bool decr = nci < lc;  // lazy \/ : the \E is evaluated only when nci >= Len(committedLog)
+            if (!decr && lc > 0) decr = (((l.clog ^ ncl) >> 3) & ((1ull << (6 * lc)) - 1ull)) != 0;
+            d.srv = i; d.log = lg; d.sv = sv_set_commit(l.sv[i], nci);
+            d.clog = ncl;
+            d.glob = bits_set(d.glob, 3, 1, decr ? 1 : 0);
+        } else if (slot < FIX) {  // AppendEntries(i, j)   raft.tla:222-244
+            const int q = slot - (5 * NS + NS * NS), i = q / NS, j = q % NS;
+            action = RA_APPENDENTRIES;
+            if (i == j || sv_state(l.sv[i]) != R_LEADER) return 0;
+            const uint64_t lg = l.log[i];
+            const int next = sv_next(l.sv[i], j), prevIdx = next - 1;
+            int prevTerm = 0;
+            if (prevIdx > 0) {
+                if (prevIdx > rlog::len(lg)) return ST_ENABLED | ST_SPECERR;
+                prevTerm = rlog::eterm(rlog::entry(lg, prevIdx));
+            }
+            const int lastEntry = rlog::len(lg) < next ? rlog::len(lg) : next;  // Min({Len(log[i]), nextIndex[i][j]})
+            const int nent = next <= lastEntry ? 1 : 0;                        // SubSeq(log[i], next, lastEntry)
+            const unsigned ent = nent ? rlog::entry(lg, next) : 0u;
+            const int ci = sv_commit(l.sv[i]) < lastEntry ? sv_commit(l.sv[i]) : lastEntry;
+            st |= send(l, s, mk_aereq(sv_term(l.sv[i]), prevIdx, prevTerm, nent, ent, ci, lg, i, j), d);
+        } else {
+            const int q = slot - FIX, k = q / 3, kind = q % 3;
+            if (k >= l.nm) return 0;
+            const uint64_t m = s.get(W_MSG0 + k);
+            const int cnt = m_count(m);
+            if (kind == 1) {  // DuplicateMessage(m), m \in SingleMessage(messages)   raft.tla:134-135,471-473
+                action = RA_DUPLICATE;
+                if (cnt != 1) return 0;
+                d.nmop = 1; d.midx[0] = k; d.mold[0] = m; d.mnew[0] = m + 1; d.dinflight = 1;
+            } else if (kind == 2) {  // DropMessage(m), m \in ValidMessage(messages)   raft.tla:131-132,476-478
+                action = RA_DROP;
+                if (cnt == 0) return 0;
+                discard(k, m, d);
+            } else {  // Receive(m), m \in ValidMessage(messages)   raft.tla:449-464
+                action = RA_RECEIVE;
+                if (cnt == 0) return 0;
+                const int i = m_dst(m), j = m_src(m), mterm = m_term(m), type = m_type(m);
+                const uint64_t svi = l.sv[i], lg = l.log[i];
+                const int term = sv_term(svi);
+                d.srv = i; d.sv = svi; d.log = lg;
+                if (mterm > term) {  // UpdateTerm   raft.tla:434-440 (message not consumed)
+                    d.sv = sv_set_voted(sv_set_state(sv_set_term(svi, mterm), R_FOLLOWER), 0);
+                    if (mterm > prm.max_term) st |= ST_OUT_OF_MODEL;
+                } else if (type == M_RVREQ) {  // HandleRequestVoteRequest   raft.tla:313-332
+                    const int llt = (int)(m >> 13 & 7), lli = (int)(m >> 16 & 7), lt = rlog::last_term(lg);
+                    const bool logOk = llt > lt || (llt == lt && lli >= rlog::len(lg));
+                    const bool grant = mterm == term && logOk && (sv_voted(svi) == 0 || sv_voted(svi) == j + 1);
+                    if (grant) d.sv = sv_set_voted(svi, j + 1);
+                    st |= send(l, s, mk_rvresp(term, grant ? 1 : 0, lg, i, j), d);  // Reply(response, m)
+                    discard(k, m, d);
+                } else if (type == M_RVRESP) {
+                    if (mterm == term) {  // HandleRequestVoteResponse   raft.tla:336-349
+                        if (m >> 13 & 1) {
+                            const unsigned vg = sv_granted(svi);
+                            d.sv = sv_set_granted(svi, vg | (1u << j));
+                            if (!(vg >> j & 1)) {  // voterLog[i] @@ (j :> m.mlog): existing entry wins
+                                d.vmode = 2; d.vj = j; d.vlog = (m >> 14) & ((1ull << 33) - 1ull);
+                            }
+                        }
+                    }  // else DropStaleResponse   raft.tla:443-446
+                    discard(k, m, d);
+                } else if (type == M_AEREQ) {  // HandleAppendEntriesRequest   raft.tla:355-417
+                    const int pidx = (int)(m >> 13 & 7), pterm = (int)(m >> 16 & 7), nent = (int)(m >> 19 & 1);
+                    const unsigned ent = (unsigned)(m >> 20 & 63);
+                    const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg);
+                    const bool logOk = pidx == 0 || (pidx > 0 && pidx <= len && pterm == rlog::eterm(rlog::entry(lg, pidx)));
+                    if (mterm < term || (mterm == term && stt == R_FOLLOWER && !logOk)) {  // reject   :361-373
+                        st |= send(l, s, mk_aeresp(term, 0, 0, i, j), d);
+                        discard(k, m, d);
+                    } else if (stt == R_CANDIDATE) {  // return to follower state   :374-378 (mterm = term here)
+                        d.sv = sv_set_state(svi, R_FOLLOWER);
+                    } else if (stt == R_FOLLOWER && logOk) {  // accept request   :379-416
+                        const int index = pidx + 1;
+                        if (nent == 0 || (len >= index && rlog::eterm(rlog::entry(lg, index)) == rlog::eterm(ent))) {
+                            // already done with request   :384-402; commitIndex' assigned AND UNCHANGED
+                            if (mci != sv_commit(svi)) return 0;
+                            st |= send(l, s, mk_aeresp(term, 1, pidx + nent, i, j), d);
+                            discard(k, m, d);
+                        } else if (len >= index) {  // conflict: remove 1 entry   :403-410
+                            d.log = rlog::drop_last(lg);
+                        } else if (len == pidx) {  // no conflict: append entry   :411-416
+                            if (len >= rlog::LCAP) return ST_ENABLED | ST_OVERFLOW;
+                            d.log = rlog::append(lg, ent);
+                            if (rlog::len(d.log) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
+                        } else {
+                            return 0;
+                        }
+                    } else {
+                        return 0;  // e.g. a Leader receiving AppendEntries of its own term
+                    }
+                } else {  // AppendEntriesResponse
+                    if (mterm == term) {  // HandleAppendEntriesResponse   raft.tla:421-431
+                        if (m >> 13 & 1) {
+                            const int mi = (int)(m >> 14 & 7);
+                            d.sv = sv_set_match(sv_set_next(svi, j, mi + 1), j, mi);
+                        } else {
+                            const int nx = sv_next(svi, j) - 1;
+                            d.sv = sv_set_next(svi, j, nx > 1 ? nx : 1);  // Max({nextIndex[i][j] - 1, 1})
+                        }
+                    }  // else DropStaleResponse
+                    discard(k, m, d);
+                }
+            }
+        }
+        // bookkeeping shared by every action: counts in the globals word
+        for (int q = 0; q < d.nmop; q++) if (d.midx[q] >= l.nm) d.glob += 1ull << 8;
+        if (l.nadd) {
+            if (g_na(l.glob) + l.nadd > CA) st |= ST_OVERFLOW;
+            d.glob += (uint64_t)l.nadd << 24;
+        }
+        if (l.inflight + d.dinflight > prm.max_msgs) st |= ST_OUT_OF_MODEL;
+        // invariants on the successor (the parent satisfies them, so only the changed server matters)
+        if ((prm.inv_mask & 1) && d.srv >= 0 && sv_state(d.sv) == R_LEADER) {  // NoTwoLeaders   raft.tla:500-507
+            for (int j = 0; j < NS; j++)
+                if (j != d.srv && sv_state(l.sv[j]) == R_LEADER && sv_term(l.sv[j]) == sv_term(d.sv)) st |= ST_INVARIANT;
+        }
+        if ((prm.inv_mask & 2) && !(st & ST_INVARIANT) && g_decr(d.glob)) st |= ST_INVARIANT | (1u << 8);  // CommittedLogStable
+        return st;
+    }
+
+    template <class Ref>
+    MC_HD static uint64_t delta_fp(const Local &l, Ref s, const Delta &d) {
+        uint64_t fp = l.fp + l.add_fp;
+        if (d.glob != l.glob) fp += hmix(d.glob, salt_of(W_GLOB)) - hmix(l.glob, salt_of(W_GLOB));
+        if (d.clog != l.clog) fp += hmix(d.clog, salt_of(W_CLOG)) - hmix(l.clog, salt_of(W_CLOG));
+        if (d.srv >= 0) {
+            const int i = d.srv;
+            if (d.sv != l.sv[i]) fp += hmix(d.sv, salt_of((unsigned)W_SRV(i))) - hmix(l.sv[i], salt_of((unsigned)W_SRV(i)));
+            if (d.log != l.log[i]) fp += hmix(d.log, salt_of((unsigned)W_LOG(i))) - hmix(l.log[i], salt_of((unsigned)W_LOG(i)));
+            if (d.vmode == 1) {
+                for (int j = 0; j < NS; j++) {
+                    const uint64_t x = s.get(W_VLOG(i, j));
+                    if (x) fp += hmix(0, salt_of((unsigned)W_VLOG(i, j))) - hmix(x, salt_of((unsigned)W_VLOG(i, j)));
+                }
+            } else if (d.vmode == 2 && d.vlog != 0) {
+                fp += hmix(d.vlog, salt_of((unsigned)W_VLOG(i, d.vj))) - hmix(0, salt_of((unsigned)W_VLOG(i, d.vj)));
+            }
+        }
+        for (int q = 0; q < d.nmop; q++) {
+            if (d.midx[q] < l.nm) fp -= hmix(d.mold[q], SALT_M);
+            fp += hmix(d.mnew[q], SALT_M);
+        }
+        if (d.eadd) fp += helec(d.ew);
+        return fp;
+    }
+
+    template <class Ref>
+    MC_HD static unsigned eval(const Params &prm, const Local &l, Ref s, int slot, uint64_t &fp) {
+        Delta d;
+        int action;
+        const unsigned st = compute(prm, l, s, slot, d, action);
+        if (!(st & ST_ENABLED)) return 0;
+        fp = fp_nonzero(delta_fp(l, s, d));
+        return st;
+    }
+    // re-evaluate `slot` on parent `s` and write the whole successor to `out`
+    template <class Ref>
+    MC_HD static unsigned apply(const Params &prm, Ref s, int slot, WordRef out) {
+        Local l;
+        load(prm, s, l);
+        Delta d;
+        int action;
+        const unsigned st = compute(prm, l, s, slot, d, action);
+        if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) {
+            for (int w = 0; w < WORDS; w++) out.set(w, s.get(w));
+            return st;
+        }
+        out.set(W_FP, delta_fp(l, s, d));
+        out.set(W_GLOB, d.glob);
+        out.set(W_CLOG, d.clog);
+        for (int i = 0; i < NS; i++) {
+            const bool me = i == d.srv;
+            out.set(W_SRV(i), me ? d.sv : l.sv[i]);
+            out.set(W_LOG(i), me ? d.log : l.log[i]);
+            for (int j = 0; j < NS; j++) {
+                uint64_t x = s.get(W_VLOG(i, j));
+                if (me && d.vmode == 1) x = 0;
+                if (me && d.vmode == 2 && j == d.vj) x = d.vlog;
+                out.set(W_VLOG(i, j), x);
+            }
+        }
+        const int nm2 = g_nm(d.glob);
+        for (int k = 0; k < CM; k++) {
+            uint64_t x = k < l.nm ? s.get(W_MSG0 + k) : 0;
+            for (int q = 0; q < d.nmop; q++) if (d.midx[q] == k) x = d.mnew[q];
+            out.set(W_MSG0 + k, k < nm2 ? x : 0);
+        }
+        const int ne = g_ne(l.glob);
+        for (int e = 0; e < CE; e++)
+            for (int q = 0; q < EL_WORDS; q++) {
+                uint64_t x = e < ne ? s.get(W_EL0 + e * EL_WORDS + q) : 0;
+                if (d.eadd && e == ne) x = d.ew[q];
+                out.set(W_EL0 + e * EL_WORDS + q, x);
+            }
+        const int na = g_na(l.glob);
+        for (int a = 0; a < CA; a++) {
+            uint64_t x = a < na ? s.get(W_ALL0 + a) : 0;
+            if (a >= na && a - na < l.nadd) x = l.addlog[a - na];
+            out.set(W_ALL0 + a, x);
+        }
+        return st;
+    }
+
+    // ---------------------------------------------------------------- host side: names and text
+    static int action_of(const Params &prm, const uint64_t *parent, int slot) {
+        Local l;
+        CWordRef s{parent, 1};
+        load(prm, s, l);
+        Delta d;
+        int action = -1;
+        compute(prm, l, s, slot, d, action);
+        return action;
+    }
+    static const char *action_name(int a) {
+        static const char *nm[] = {"Restart", "Timeout", "RequestVote", "BecomeLeader", "ClientRequest",
+                                   "AdvanceCommitIndex", "AppendEntries", "Receive", "DuplicateMessage", "DropMessage"};
+        return a >= 0 && a < 10 ? nm[a] : a < 0 ? "Initial predicate" : "?";
+    }
+
+    struct Txt {
+        char *b; size_t cap, k;
+        void put(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+            va_list ap;
+            va_start(ap, fmt);
+            if (k < cap) { int w = vsnprintf(b + k, cap - k, fmt, ap); if (w > 0) k += (size_t)w; if (k > cap) k = cap; }
+            va_end(ap);
+        }
+    };
+    static void t_log(Txt &o, uint64_t lg) {
+        const int n = rlog::len(lg);
+        if (!n) { o.put("<<>>"); return; }
+        o.put("<<");
+        for (int k = 1; k <= n; k++) { const unsigned e = rlog::entry(lg, k); o.put("%s[term |-> %d, value |-> %d]", k > 1 ? ", " : "", rlog::eterm(e), rlog::evalue(e)); }
+        o.put(">>");
+    }
+    static void t_servers(Txt &o, unsigned mask) {
+        o.put("{");
+        bool first = true;
+        for (int j = 0; j < NS; j++) if (mask >> j & 1) { o.put("%ss%d", first ? "" : ", ", j + 1); first = false; }
+        o.put("}");
+    }
+    static void t_vlog(Txt &o, unsigned dom, const uint64_t *v) {
+        if (!dom) { o.put("<<>>"); return; }
+        o.put("(");
+        bool first = true;
+        for (int j = 0; j < NS; j++) if (dom >> j & 1) { o.put("%ss%d :> ", first ? "" : " @@ ", j + 1); t_log(o, v[j]); first = false; }
+        o.put(")");
+    }
+    static void t_msg(Txt &o, uint64_t m) {
+        const int d = m_dst(m) + 1, sr = m_src(m) + 1, t = m_term(m);
+        switch (m_type(m)) {
+        case M_RVREQ:
+            o.put("[mdest |-> s%d, mlastLogIndex |-> %d, mlastLogTerm |-> %d, msource |-> s%d, mterm |-> %d, mtype |-> RequestVoteRequest]",
+                  d, (int)(m >> 16 & 7), (int)(m >> 13 & 7), sr, t);
+            break;
+        case M_RVRESP:
+            o.put("[mdest |-> s%d, mlog |-> ", d); t_log(o, (m >> 14) & ((1ull << 33) - 1ull));
+            o.put(", msource |-> s%d, mterm |-> %d, mtype |-> RequestVoteResponse, mvoteGranted |-> %s]", sr, t, (m >> 13 & 1) ? "TRUE" : "FALSE");
+            break;
+        case M_AEREQ: {
+            o.put("[mcommitIndex |-> %d, mdest |-> s%d, mentries |-> ", (int)(m >> 26 & 7), d);
+            const unsigned e = (unsigned)(m >> 20 & 63);
+            if (m >> 19 & 1) o.put("<<[term |-> %d, value |-> %d]>>", rlog::eterm(e), rlog::evalue(e)); else o.put("<<>>");
+            o.put(", mlog |-> "); t_log(o, (m >> 29) & ((1ull << 33) - 1ull));
+            o.put(", mprevLogIndex |-> %d, mprevLogTerm |-> %d, msource |-> s%d, mterm |-> %d, mtype |-> AppendEntriesRequest]",
+                  (int)(m >> 13 & 7), (int)(m >> 16 & 7), sr, t);
+            break;
+        }
+        default:
+            o.put("[mdest |-> s%d, mmatchIndex |-> %d, msource |-> s%d, msuccess |-> %s, mterm |-> %d, mtype |-> AppendEntriesResponse]",
+                  d, (int)(m >> 14 & 7), sr, (m >> 13 & 1) ? "TRUE" : "FALSE", t);
+        }
+    }
+    static int cmp_str(const void *a, const void *b) { return strcmp(*(char *const *)a, *(char *const *)b); }
+    static void t_sorted(Txt &o, char **it, int n, const char *open, const char *sep, const char *close, const char *empty) {
+        if (!n) { o.put("%s", empty); return; }
+        qsort(it, (size_t)n, sizeof *it, cmp_str);
+        o.put("%s", open);
+        for (int i = 0; i < n; i++) { o.put("%s%s", i ? sep : "", it[i]); free(it[i]); }
+        o.put("%s", close);
+    }
+    // canonical TLA+ text (same format as oracle/spec_raft.c:raft_print; sets sorted by text)
+    static int format(const Params &, const uint64_t *w, char *buf, size_t cap) {
+        static const char *stn[] = {"Follower", "Candidate", "Leader", "?"};
+        Txt o{buf, cap, 0};
+        char tmp[2048];
+        constexpr int MAXIT = CM > CA ? (CM > CE ? CM : CE) : (CA > CE ? CA : CE);
+        char *it[MAXIT];
+        const uint64_t g = w[W_GLOB];
+        o.put("/\\ messages = ");
+        for (int k = 0; k < g_nm(g); k++) { Txt e{tmp, sizeof tmp, 0}; t_msg(e, w[W_MSG0 + k]); e.put(" :> %d", m_count(w[W_MSG0 + k])); it[k] = strndup(tmp, e.k); }
+        t_sorted(o, it, g_nm(g), "(", " @@ ", ")", "<<>>");
+        o.put("\n/\\ elections = ");
+        for (int x = 0; x < g_ne(g); x++) {
+            Txt e{tmp, sizeof tmp, 0};
+            const uint64_t *ew = w + W_EL0 + x * EL_WORDS;
+            const unsigned votes = (unsigned)(ew[0] >> 6 & 31);
+            e.put("[eleader |-> s%d, elog |-> ", (int)(ew[0] >> 3 & 7) + 1); t_log(e, (ew[0] >> 11) & ((1ull << 33) - 1ull));
+            e.put(", eterm |-> %d, evoterLog |-> ", (int)(ew[0] & 7)); t_vlog(e, votes, ew + 1);
+            e.put(", evotes |-> "); t_servers(e, votes); e.put("]");
+            it[x] = strndup(tmp, e.k);
+        }
+        t_sorted(o, it, g_ne(g), "{", ", ", "}", "{}");
+        o.put("\n/\\ allLogs = ");
+        for (int a = 0; a < g_na(g); a++) { Txt e{tmp, sizeof tmp, 0}; t_log(e, w[W_ALL0 + a]); it[a] = strndup(tmp, e.k); }
+        t_sorted(o, it, g_na(g), "{", ", ", "}", "{}");
+#define MC_PER_SERVER(title, expr)                                                             \
+    o.put("\n/\\ " title " = (");                                                              \
+    for (int i = 0; i < NS; i++) { const uint64_t sv = w[W_SRV(i)]; (void)sv; o.put("%ss%d :> ", i ? " @@ " : "", i + 1); expr; } \
+    o.put(")");
+        MC_PER_SERVER("currentTerm", o.put("%d", sv_term(sv)));
+        MC_PER_SERVER("state", o.put("%s", stn[sv_state(sv)]));
+        MC_PER_SERVER("votedFor", if (sv_voted(sv)) o.put("s%d", sv_voted(sv)); else o.put("Nil"));
+        o.put("\n/\\ clientRequests = %d", g_creq(g));
+        MC_PER_SERVER("log", t_log(o, w[W_LOG(i)]));
+        MC_PER_SERVER("commitIndex", o.put("%d", sv_commit(sv)));
+        o.put("\n/\\ committedLog = "); t_log(o, w[W_CLOG]);
+        o.put("\n/\\ committedLogDecrease = %s", g_decr(g) ? "TRUE" : "FALSE");
+        MC_PER_SERVER("votesSent", o.put("FALSE"));
+        MC_PER_SERVER("votesGranted", t_servers(o, sv_granted(sv)));
+        MC_PER_SERVER("voterLog", t_vlog(o, sv_granted(sv), w + W_VLOG(i, 0)));
+        MC_PER_SERVER("nextIndex", { o.put("("); for (int j = 0; j < NS; j++) o.put("%ss%d :> %d", j ? " @@ " : "", j + 1, sv_next(sv, j)); o.put(")"); });
+        MC_PER_SERVER("matchIndex", { o.put("("); for (int j = 0; j < NS; j++) o.put("%ss%d :> %d", j ? " @@ " : "", j + 1, sv_match(sv, j)); o.put(")"); });
+#undef MC_PER_SERVER
+        return (int)o.k;
+    }
+};
+
+}  // namespace mc
