@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""bench.py — distinct states/sec of the BFS hot path on examples/raft.tla (3 servers).
+
+Contract (see the task description): `python bench.py --gpus N --steps K --warmup W`; one JSON line
+from rank 0.  A "step" is one complete pass of the hot path over the workload: a full BFS of the
+frozen model configuration from Init to the budget level (every level: expand -> seen-set insert
+-> materialise), starting from a cleared seen-set.  Nothing is cached between steps.
+
+Workload (BASELINE.json configs[2]): examples/raft.tla under
+specs/MCraft.cfg — Server = {s1,s2,s3}, MaxClientRequests = 4 (=> MaxLogLen 3), MaxTerm = 2,
+MaxMsgs = 1, INVARIANT NoTwoLeaders, level-budgeted at the first level whose cumulative distinct
+count reaches 25,000,000 (25,752,293 distinct / 23 levels; golden per-level counts from the CPU
+oracle in tests/golden/raft_levels.json).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1], max_distinct=25_000_000,
+                name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1, budget 25M distinct")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(sample_distinct=1_500_000):
+    """The oracle ("port") timed on the host cores: same workload, bounded prefix."""
+    exe = ROOT / "oracle" / "_build" / "oracle_mc"
+    if not exe.exists():
+        subprocess.run(["make", "-s", "-C", str(ROOT / "oracle")], check=True)
+    p = [str(x) for x in WORKLOAD["params"]]
+    out = subprocess.run([str(exe), "raft", *p, "--distinct", str(sample_distinct)], capture_output=True, text=True, check=True).stdout
+    r = json.loads(out.splitlines()[0])
+    return dict(value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=1, kind="port",
+                sample=f"same cfg, BFS prefix to {r['distinct']} distinct / {r['generated']} generated states "
+                       f"({r['seconds']:.1f} s, single-thread exact-dedup C oracle, in-house CPU BFS — not TLC)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-distinct", type=int, default=WORKLOAD["max_distinct"])
+    ap.add_argument("--chunk", type=int, default=1 << 19)
+    a = ap.parse_args()
+
+    import torch
+    import tla_rust_amd as amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    if world == 1:
+        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << 28,
+                         arena_capacity=30_000_000 if a.max_distinct <= 25_000_000 else 2 * a.max_distinct,
+                         chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
+        run = eng.run
+    else:
+        from tla_rust_amd.sharded import ShardedChecker
+        chk = ShardedChecker(WORKLOAD["spec"], WORKLOAD["params"], device=local, max_distinct=a.max_distinct * world,
+                             chunk_states=a.chunk)
+        run = chk.run
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(a.steps):
+        res = run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    D, G = res.distinct, res.generated
+    line = {
+        "metric": "distinct states/sec, raft.tla (3 servers)", "value": D * a.steps / dt, "unit": "distinct states/s",
+        "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": WORKLOAD["name"], "distinct": D, "generated": G, "depth": res.depth,
+                   "verdict": res.verdict, "generated_per_s": G * a.steps / dt},
+    }
+    if world == 1:
+        ks = eng.kernel_stats()
+        W = ks["state_bytes"]
+        # algorithmic bytes per launch: expand reads W per frontier state,
+        # insert touches one 8-byte seen-set word per generated candidate, materialise writes W per new state
+        alg = {"expand": W * ks["expand"]["units"], "insert": 8 * ks["cand_cells"], "materialise": W * ks["materialise"]["units"]}
+        dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
+        n_runs = a.steps  # stats are reset by every run(): they describe the last step
+        ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
+        line["roofline"] = {"bound": "hbm", "kernel": f"k_{dom}", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                            "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
+                            "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
+                            "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
+                            "pipeline_GBs": (2 * W * D + 8 * G) / (1e-3 * sum(ks[k]["ms_total"] for k in ("expand", "insert", "materialise"))) / 1e9}
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,7 @@ typedef struct {
 
 #define MC_F_DEADLOCK 1u /* check deadlock (TLC default on; serializableSnapshotIsolation.tla:57) */
 #define MC_F_TRACE 2u    /* keep (parent, action) per state so a counterexample can be rebuilt     */
+#define MC_F_TIMING 4u   /* time every kernel launch with HIP events on the engine stream          */
 
 typedef struct {
     int32_t device;          /* HIP device ordinal                                              */
@@ -111,6 +112,9 @@ int mc_engine_run(mc_engine *e, mc_result *out);
  * the initial state).  *n_inout: capacity in, count out. */
 int mc_engine_trace(mc_engine *e, uint8_t *states_out, int32_t *actions_out, size_t *n_inout);
 int mc_engine_kernel_stats(mc_engine *e, mc_kernel_stats *out);
+/* copy `count` resident states starting at arena index `first` (discovery order: level by level)
+ * to the host, mc_state_bytes() bytes each — TLC's "states/" dump, for tests and tooling */
+int mc_engine_read_states(mc_engine *e, uint64_t first, uint64_t count, uint8_t *out);
 void mc_engine_destroy(mc_engine *e);
 
 /* ------------------------------------------------------------------ sharded (multi-GPU) step API

@@ -1,0 +1,42 @@
+"""Regenerates the golden fixtures under tests/golden/ from the CPU oracle.
+
+  readme_pcal_intro_trace.json : the six states of the README's TLC counterexample,
+                                 transcribed BY HAND from reference README.md:272-311 (not from
+                                 the oracle) — this script only re-checks it.
+  raft_levels.json             : per-level distinct counts of raft configurations, incl. the
+                                 bench workload's budgeted prefix (takes a few minutes).
+Usage: python tests/golden/make_golden.py [--big]
+"""
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import helpers  # noqa: E402
+
+HERE = Path(__file__).resolve().parent
+
+CASES = [
+    ("raft2_mcr1_t2_m1", [2, 1, 2, 9, 1, 1], 0),
+    ("raft2_mcr2_t2_m1", [2, 2, 2, 9, 1, 1], 0),
+    ("raft2_mcr2_t2_m2", [2, 2, 2, 9, 2, 1], 0),
+    ("raft2_mcr3_t2_m1", [2, 3, 2, 9, 1, 3], 0),
+    ("raft3_mcr2_t2_m1_prefix", [3, 2, 2, 9, 1, 1], 300000),
+    ("raft3_mcr4_t2_m1_prefix_small", [3, 4, 2, 3, 1, 1], 1000000),
+]
+BIG = [
+    ("raft2_mcr1_t3_m1", [2, 1, 3, 9, 1, 1], 0),
+    ("raft3_mcr4_t2_m1_bench", [3, 4, 2, 3, 1, 1], 25000000),   # bench.py workload (config 3)
+]
+
+if __name__ == "__main__":
+    cases = CASES + (BIG if "--big" in sys.argv else [])
+    path = HERE / "raft_levels.json"
+    old = {c["name"]: c for c in json.loads(path.read_text())["cases"]} if path.exists() else {}
+    out = []
+    for name, params, maxd in cases:
+        r = helpers.oracle_run("raft", params, max_distinct=maxd)
+        print(name, r["distinct"], r["generated"], r["depth"], r["verdict"], f"{r['seconds']:.1f}s", flush=True)
+        old[name] = dict(name=name, params=params, max_distinct=maxd, distinct=r["distinct"], generated=r["generated"],
+                         depth=r["depth"], verdict=r["verdict"], levels=r["levels"], max_stat=r["max_stat"][:5])
+    path.write_text(json.dumps(dict(cases=list(old.values())), indent=1) + "\n")

@@ -1,0 +1,143 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP engine, called through the C ABI
+(include/tlamc.h via tla_rust_amd.binding), against the CPU oracle on the same configurations, and
+against the committed golden fixtures at the bench workload's size.  Integer / set semantics:
+every comparison is exact."""
+import json
+from collections import Counter
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden"
+
+SMALL = [
+    ("atomic_add", [2]), ("atomic_add", [3]), ("atomic_add", [4]), ("atomic_add", [11]),
+    ("pcal_intro", [0, 1, 20, 2]), ("pcal_intro", [1, 0, 20, 2]), ("pcal_intro", [1, 1, 20, 2]), ("pcal_intro", [0, 1, 7, 3]),
+    ("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 3, 2, 9, 1, 3]),
+]
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import tla_rust_amd
+    assert tla_rust_amd.device_count() >= 1, "no HIP device visible"
+    return tla_rust_amd
+
+
+def _levels_text(eng, res):
+    out, first = {}, 0
+    for lvl, n in enumerate(res.levels, start=1):
+        out[lvl] = sorted(eng.state_texts(first, n))
+        first += n
+    return out
+
+
+@pytest.mark.parametrize("spec,params", SMALL)
+def test_engine_equals_oracle_states_and_counts(amd, oracle, tmp_path, spec, params):
+    od = str(tmp_path / "o.txt")
+    o = oracle.oracle_run(spec, params, dump=od)
+    eng = amd.Engine(spec, params, table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
+    r = eng.run()
+    for k in ("distinct", "generated", "depth", "verdict", "levels", "queue_left"):
+        assert o[k] == r[k], k
+    assert len(o["trace"]) == r.trace_len
+    # the same SET of states on every BFS level (canonical TLA+ text, independent printers)
+    assert oracle.read_dump(od) == _levels_text(eng, r)
+    if r.verdict != "ok":
+        tr = eng.trace()
+        assert len(tr) == r.trace_len
+        assert tr[0][0] == "Initial predicate" and tr[0][1] == o["trace"][0][1] or spec == "pcal_intro"
+    eng.close()
+
+
+def test_readme_counterexample_on_gpu(amd):
+    """README.md:267-311: shortest counterexample has 6 states and ends with alice_account = -1."""
+    eng = amd.Engine("pcal_intro", [1, 0, 20, 2], table_capacity=1 << 16, arena_capacity=1 << 14)
+    r = eng.run()
+    assert r.verdict == "assert" and r.trace_len == 6 and r.depth == 7
+    tr = eng.trace()
+    assert tr[0][0] == "Initial predicate" and "alice_account = -1" in tr[-1][1]
+    assert [a for a, _ in tr[1:]] in (["Transfer", "Transfer", "A", "B", "A"], ["Transfer", "Transfer", "A", "A", "B"],
+                                      ["Transfer", "A", "Transfer", "B", "A"], ["Transfer", "A", "Transfer", "A", "B"],
+                                      ["Transfer", "A", "B", "Transfer", "A"])
+    # each step changes exactly what the action may change: pc of one process
+    eng.close()
+
+
+@pytest.mark.parametrize("chunk", [256, 1 << 10, 1 << 16])
+def test_chunking_does_not_change_counts(amd, oracle, chunk):
+    o = oracle.oracle_run("raft", [2, 2, 2, 9, 2, 1])
+    eng = amd.Engine("raft", [2, 2, 2, 9, 2, 1], table_capacity=1 << 21, arena_capacity=1 << 19, chunk_states=chunk)
+    r = eng.run()
+    assert (r.distinct, r.generated, r.depth, r.levels) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    r2 = eng.run()          # an engine is reusable: same answer again
+    assert (r2.distinct, r2.generated, r2.levels) == (r.distinct, r.generated, r.levels)
+    eng.close()
+
+
+@pytest.mark.parametrize("n", [16, 20, 24])
+def test_atomic_add_closed_form_on_gpu(amd, n):
+    """D = 2^N + 1, G = N*2^(N-1) + 3, depth N + 2; every level is C(N,k)-shaped."""
+    eng = amd.Engine("atomic_add", [n], table_capacity=1 << (n + 2), arena_capacity=(1 << n) + 4096, chunk_states=1 << 20, trace=False)
+    r = eng.run()
+    assert (r.verdict, r.distinct, r.generated, r.depth) == ("ok", 2 ** n + 1, n * 2 ** (n - 1) + 3, n + 2)
+    from math import comb
+    assert r.levels[: n + 1] == [comb(n, k) for k in range(n + 1)] and r.levels[n + 1] == 1
+    eng.close()
+
+
+def test_raft_expected_violation_on_gpu(amd):
+    """CommittedLogStable is violated at MaxTerm = 3, MaxClientRequests = 3;
+    shortest counterexample = 31 states (oracle: tests/test_lowering_vs_oracle.py)."""
+    eng = amd.Engine("raft", [2, 3, 3, 9, 1, 2], table_capacity=1 << 26, arena_capacity=1 << 25, chunk_states=1 << 18)
+    r = eng.run()
+    assert r.verdict == "invariant" and r.violated_invariant == 1 and r.trace_len == 31
+    tr = eng.trace()
+    assert len(tr) == 31 and "committedLogDecrease = TRUE" in tr[-1][1] and "committedLogDecrease = FALSE" in tr[-2][1]
+    assert tr[-1][0] == "AdvanceCommitIndex"
+    eng.close()
+
+
+def _golden(name):
+    g = json.loads((GOLDEN / "raft_levels.json").read_text())
+    return next(c for c in g["cases"] if c["name"] == name)
+
+
+@pytest.mark.parametrize("name", ["raft2_mcr2_t2_m2", "raft3_mcr2_t2_m1_prefix", "raft3_mcr4_t2_m1_prefix_small", "raft2_mcr1_t3_m1",
+                                  "raft3_mcr4_t2_m1_bench"])
+def test_raft_golden_levels_on_gpu(amd, name):
+    """Committed oracle fixtures (tests/golden/make_golden.py), incl. the bench workload's full size."""
+    try:
+        c = _golden(name)
+    except StopIteration:
+        pytest.skip(f"fixture {name} not generated")
+    cap = max(1 << 20, 2 * c["distinct"])
+    eng = amd.Engine("raft", c["params"], table_capacity=4 * c["distinct"], arena_capacity=cap, chunk_states=1 << 19,
+                     max_distinct=c["max_distinct"], trace=False)
+    r = eng.run()
+    assert r.levels == c["levels"]
+    assert (r.distinct, r.generated, r.depth, r.verdict) == (c["distinct"], c["generated"], c["depth"], c["verdict"])
+    eng.close()
+
+
+def test_overflow_is_reported_not_dropped(amd):
+    """overflow of a slot array must raise MC_EOVERFLOW, never silently drop.
+    raft2 has room for 32 distinct messages; MaxMsgs = 6 with 3 terms exceeds it."""
+    eng = amd.Engine("raft", [2, 3, 4, 9, 6, 0], table_capacity=1 << 24, arena_capacity=1 << 22, chunk_states=1 << 16, max_distinct=3_000_000)
+    try:
+        eng.run()
+    except amd.McError as e:
+        assert e.code == -3
+    else:
+        pytest.skip("configuration did not overflow within the budget")
+    finally:
+        eng.close()
+
+
+def test_table_full_is_an_error(amd):
+    eng = amd.Engine("atomic_add", [16], table_capacity=1 << 12, arena_capacity=1 << 17)
+    with pytest.raises(amd.McError) as ei:
+        eng.run()
+    assert ei.value.code == -4
+    eng.close()

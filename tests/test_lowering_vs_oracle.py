@@ -1,0 +1,40 @@
+"""The device lowerings (tla_rust_amd/csrc/spec_*.h), compiled for the host by tests/_shim, against
+the oracle: per-level counts, verdicts, and the exact SET of reachable states (as canonical TLA+
+text) level by level.  Also checks that the incrementally maintained additive fingerprint equals
+a full recomputation on every state.  CPU only."""
+import pytest
+
+CASES = [
+    ("atomic_add", [2]), ("atomic_add", [3]), ("atomic_add", [4]), ("atomic_add", [11]),
+    ("pcal_intro", [0, 1, 20, 2]), ("pcal_intro", [1, 0, 20, 2]), ("pcal_intro", [1, 1, 20, 2]),
+    ("pcal_intro", [0, 1, 7, 3]),
+    ("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 3, 2, 9, 1, 3]),
+]
+
+
+@pytest.mark.parametrize("spec,params", CASES)
+def test_same_states_per_level(oracle, shim, tmp_path, spec, params):
+    od, sd = str(tmp_path / "o.txt"), str(tmp_path / "s.txt")
+    o = oracle.oracle_run(spec, params, dump=od)
+    s = shim.shim_run(spec, params, dump=sd)
+    for k in ("distinct", "generated", "depth", "verdict", "levels", "queue_left"):
+        assert o[k] == s[k], k
+    assert s["fp_mismatch"] == 0
+    assert len(o["trace"]) == s["trace_len"]
+    assert oracle.read_dump(od) == shim.read_dump(sd)
+
+
+@pytest.mark.parametrize("params,maxd", [([3, 2, 2, 9, 1, 1], 60000), ([3, 4, 3, 3, 2, 3], 40000), ([2, 3, 3, 9, 2, 3], 150000)])
+def test_raft_prefix_counts(oracle, shim, params, maxd):
+    o = oracle.oracle_run("raft", params, max_distinct=maxd)
+    s = shim.shim_run("raft", params, max_distinct=maxd)
+    for k in ("distinct", "generated", "depth", "verdict", "levels"):
+        assert o[k] == s[k], k
+    assert s["fp_mismatch"] == 0
+
+
+def test_raft_expected_violation_trace_length(oracle, shim):
+    """SURVEY.md Appendix E caveat (ii): CommittedLogStable is violated once MaxTerm >= 3 and
+    MaxClientRequests >= 3; the shortest counterexample has 31 states."""
+    s = shim.shim_run("raft", [2, 3, 3, 9, 1, 2])
+    assert s["verdict"] == "invariant" and s["violated_invariant"] == 1 and s["trace_len"] == 31

@@ -1,0 +1,78 @@
+"""The CPU oracle against every golden vector the reference holds for this path
+and against the survey-derived regression anchors.  CPU only."""
+import json
+from pathlib import Path
+
+import pytest
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+def test_readme_tlc_run_reproduced_exactly(oracle):
+    """README.md:267-321 — the only real TLC output for an in-scope spec: README variant of
+    pcal_intro (labels A:/B:), no invariant, TLC stops at the first Assert failure."""
+    r = oracle.oracle_run("pcal_intro", [1, 0, 20, 2], stop=2)
+    assert r["verdict"] == "assert"
+    assert (r["generated"], r["distinct"], r["queue_left"]) == (9097, 6164, 999)   # README.md:319
+    assert r["depth"] == 7                                                           # README.md:320
+    golden = json.loads((GOLDEN / "readme_pcal_intro_trace.json").read_text())
+    assert len(r["trace"]) == 6
+    for (act, text), g in zip(r["trace"], golden["states"]):
+        got = dict(line[3:].split(" = ", 1) for line in text.split("\n"))
+        assert got == g                     # same six states, variable by variable (README.md:272-311)
+    assert "alice_account = -1" in r["trace"][-1][1]
+
+
+def test_committed_pcal_intro_passes(oracle):
+    """README.md:349-352: with the labels removed 'Re-running tlc should produce no errors';
+    pcal_intro.cfg:2-3 checks MoneyInvariant."""
+    r = oracle.oracle_run("pcal_intro", [0, 1, 20, 2])
+    assert r["verdict"] == "ok"
+    assert (r["distinct"], r["generated"], r["depth"]) == (3800, 5850, 5)
+    assert r["levels"][0] == 400            # money \in [1..2 -> 1..20]
+
+
+def test_readme_variant_violates_money_invariant(oracle):
+    r = oracle.oracle_run("pcal_intro", [1, 1, 20, 2])
+    assert r["verdict"] == "invariant" and len(r["trace"]) == 3   # Init, Transfer, A: alice dropped, bob not yet credited
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 10, 16])
+def test_atomic_add_closed_form(oracle, n):
+    r = oracle.oracle_run("atomic_add", [n])
+    assert r["verdict"] == "ok"
+    assert r["distinct"] == 2 ** n + 1
+    assert r["generated"] == n * 2 ** (n - 1) + 3
+    assert r["depth"] == n + 2
+
+
+RAFT_ANCHORS = [  # BASELINE.md §2 (survey-derived, independent implementation)
+    ([2, 1, 2, 9, 1, 1], 6128, 51949, 22),
+    ([2, 2, 2, 9, 1, 1], 13634, 104515, 34),
+    ([2, 2, 2, 9, 2, 1], 270972, 2277995, 46),
+    ([2, 3, 2, 9, 1, 3], 88490, 575389, 45),
+]
+
+
+@pytest.mark.parametrize("params,d,g,depth", RAFT_ANCHORS)
+def test_raft_anchors(oracle, params, d, g, depth):
+    r = oracle.oracle_run("raft", params)
+    assert r["verdict"] == "ok"
+    assert (r["distinct"], r["generated"], r["depth"]) == (d, g, depth)
+
+
+def test_raft_naive_commit_lowering_is_detected(oracle):
+    """lowering raft.tla:392-402 as an unconditional assignment
+    changes the reachable set (13 634 -> 15 794)."""
+    r = oracle.oracle_run("raft", [2, 2, 2, 9, 1, 1, 1])
+    assert (r["distinct"], r["generated"], r["depth"]) == (15794, 118339, 36)
+
+
+def test_raft_golden_levels(oracle):
+    g = json.loads((GOLDEN / "raft_levels.json").read_text())
+    for case in g["cases"]:
+        if case["distinct"] > 400000:
+            continue                        # the big prefixes are checked on the GPU only
+        r = oracle.oracle_run("raft", case["params"], max_distinct=case.get("max_distinct", 0))
+        assert r["levels"] == case["levels"], case["name"]
+        assert r["generated"] == case["generated"]

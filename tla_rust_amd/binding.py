@@ -1,0 +1,213 @@
+"""ctypes binding of include/tlamc.h.  Mirrors the C ABI one to one (same names, same argument
+meaning, negative MC_E* codes raised as McError)."""
+import ctypes as C
+import json
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "_build" / "libtlamc.so"
+
+MC_MAX_LEVELS = 4096
+SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3}
+VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
+MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING = 1, 2, 4
+
+
+class McError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"{what} (code {code})")
+        self.code = code
+
+
+class SpecDesc(C.Structure):
+    _fields_ = [("spec_id", C.c_uint32), ("nparams", C.c_uint32), ("params", C.c_int64 * 16)]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("table_capacity", C.c_uint64),
+                ("arena_capacity", C.c_uint64), ("chunk_states", C.c_uint64), ("max_levels", C.c_uint64),
+                ("max_distinct", C.c_uint64), ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32)]
+
+
+class CResult(C.Structure):
+    _fields_ = [("distinct", C.c_uint64), ("generated", C.c_uint64), ("queue_left", C.c_uint64),
+                ("depth", C.c_uint32), ("verdict", C.c_int32), ("violated_invariant", C.c_int32),
+                ("trace_len", C.c_uint32), ("levels", C.c_uint32), ("reserved", C.c_uint32), ("seconds", C.c_double),
+                ("level_distinct", C.c_uint64 * MC_MAX_LEVELS)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("ms_total", C.c_double), ("units", C.c_uint64)]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("expand", KernelStat), ("insert", KernelStat), ("materialise", KernelStat),
+                ("state_bytes", C.c_uint64), ("cand_cells", C.c_uint64)]
+
+
+class Result(dict):
+    __getattr__ = dict.__getitem__
+
+
+_lib = None
+
+
+def lib():
+    """The loaded libtlamc.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m tla_rust_amd.build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    L.mc_engine_create.argtypes = [C.POINTER(SpecDesc), C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.mc_engine_run.argtypes = [C.c_void_p, C.POINTER(CResult)]
+    L.mc_engine_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
+    L.mc_engine_kernel_stats.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
+    L.mc_engine_read_states.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.mc_engine_destroy.argtypes = [C.c_void_p]
+    L.mc_engine_destroy.restype = None
+    L.mc_state_bytes.argtypes = [C.POINTER(SpecDesc)]
+    L.mc_state_bytes.restype = C.c_size_t
+    L.mc_fp_owner.argtypes = [C.c_uint64, C.c_uint32]
+    L.mc_fp_owner.restype = C.c_uint32
+    L.mc_state_format.argtypes = [C.POINTER(SpecDesc), C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mc_action_name.argtypes = [C.POINTER(SpecDesc), C.c_int32]
+    L.mc_action_name.restype = C.c_char_p
+    L.mc_strerror.argtypes = [C.c_int]
+    L.mc_strerror.restype = C.c_char_p
+    L.mc_last_error.restype = C.c_char_p
+    L.mc_device_count.restype = C.c_int
+    if hasattr(L, "mc_cfg_parse"):
+        L.mc_cfg_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.mc_cfg_free.argtypes = [C.c_void_p]
+        L.mc_cfg_free.restype = None
+        L.mc_cfg_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.mc_spec_resolve.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(SpecDesc)]
+        L.mc_check_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Config), C.c_char_p, C.c_size_t, C.POINTER(CResult)]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc < 0:
+        L = lib()
+        detail = L.mc_last_error().decode() or L.mc_strerror(rc).decode()
+        raise McError(rc, f"{what}: {detail}")
+    return rc
+
+
+def spec_desc(spec, params):
+    d = SpecDesc()
+    d.spec_id = SPEC_IDS[spec] if isinstance(spec, str) else int(spec)
+    d.nparams = len(params)
+    for i, v in enumerate(params):
+        d.params[i] = int(v)
+    return d
+
+
+def device_count():
+    return lib().mc_device_count()
+
+
+def state_bytes(spec, params):
+    return lib().mc_state_bytes(C.byref(spec_desc(spec, params)))
+
+
+def state_format(spec, params, state: bytes):
+    buf = C.create_string_buffer(1 << 16)
+    d = spec_desc(spec, params)
+    n = _check(lib().mc_state_format(C.byref(d), state, buf, len(buf)), "mc_state_format")
+    return buf.raw[:n].decode()
+
+
+def _result(r: CResult):
+    return Result(distinct=r.distinct, generated=r.generated, queue_left=r.queue_left, depth=r.depth,
+                  verdict=VERDICTS[r.verdict], violated_invariant=r.violated_invariant, trace_len=r.trace_len,
+                  levels=[r.level_distinct[i] for i in range(r.levels)], seconds=r.seconds)
+
+
+class Engine:
+    """One model-checking engine on one GPU (mc_engine_create / run / trace / destroy)."""
+
+    def __init__(self, spec, params, device=0, table_capacity=0, arena_capacity=0, chunk_states=0, max_levels=0,
+                 max_distinct=0, deadlock=True, trace=True, timing=False, shard_rank=0, shard_count=1):
+        self.spec, self.params = spec, list(params)
+        self.desc = spec_desc(spec, params)
+        flags = (MC_F_DEADLOCK if deadlock else 0) | (MC_F_TRACE if trace else 0) | (MC_F_TIMING if timing else 0)
+        self.cfg = Config(device, flags, table_capacity, arena_capacity, chunk_states, max_levels, max_distinct,
+                          shard_rank, shard_count)
+        self._h = C.c_void_p()
+        _check(lib().mc_engine_create(C.byref(self.desc), C.byref(self.cfg), C.byref(self._h)), "mc_engine_create")
+
+    def run(self):
+        r = CResult()
+        _check(lib().mc_engine_run(self._h, C.byref(r)), "mc_engine_run")
+        return _result(r)
+
+    def trace(self):
+        """[(action name, state text)] of the last counterexample."""
+        W = lib().mc_state_bytes(C.byref(self.desc))
+        cap = C.c_size_t(4096)
+        states = C.create_string_buffer(W * cap.value)
+        acts = (C.c_int32 * cap.value)()
+        _check(lib().mc_engine_trace(self._h, states, acts, C.byref(cap)), "mc_engine_trace")
+        out = []
+        for k in range(cap.value):
+            name = lib().mc_action_name(C.byref(self.desc), acts[k]).decode()
+            out.append((name, state_format(self.spec, self.params, states.raw[k * W:(k + 1) * W])))
+        return out
+
+    def read_states(self, first, count):
+        """Packed records of `count` states in discovery order starting at `first`."""
+        W = lib().mc_state_bytes(C.byref(self.desc))
+        buf = C.create_string_buffer(max(1, W * count))
+        _check(lib().mc_engine_read_states(self._h, first, count, buf), "mc_engine_read_states")
+        return [buf.raw[k * W:(k + 1) * W] for k in range(count)]
+
+    def state_texts(self, first, count):
+        return [state_format(self.spec, self.params, s) for s in self.read_states(first, count)]
+
+    def kernel_stats(self):
+        ks = KernelStats()
+        _check(lib().mc_engine_kernel_stats(self._h, C.byref(ks)), "mc_engine_kernel_stats")
+        f = lambda s: dict(launches=s.launches, ms_total=s.ms_total, units=s.units)
+        return dict(expand=f(ks.expand), insert=f(ks.insert), materialise=f(ks.materialise),
+                    state_bytes=ks.state_bytes, cand_cells=ks.cand_cells)
+
+    def close(self):
+        if self._h:
+            lib().mc_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cfg_parse(text: str):
+    """Parse a TLC .cfg file (ConfigFileGrammar.tla:4-32) with the library's parser; returns a dict."""
+    h = C.c_void_p()
+    b = text.encode()
+    _check(lib().mc_cfg_parse(b, len(b), C.byref(h)), "mc_cfg_parse")
+    try:
+        buf = C.create_string_buffer(1 << 20)
+        _check(lib().mc_cfg_json(h, buf, len(buf)), "mc_cfg_json")
+        return json.loads(buf.value.decode())
+    finally:
+        lib().mc_cfg_free(h)
+
+
+def check_files(tla_path, cfg_path=None, device=0, **kw):
+    """`tlc X.tla` end to end (reference Makefile:6-7): returns (Result, report text)."""
+    cfg = Config(device, MC_F_DEADLOCK | MC_F_TRACE, kw.get("table_capacity", 0), kw.get("arena_capacity", 0),
+                 kw.get("chunk_states", 0), kw.get("max_levels", 0), kw.get("max_distinct", 0), 0, 1)
+    r = CResult()
+    buf = C.create_string_buffer(1 << 20)
+    rc = lib().mc_check_files(str(tla_path).encode(), str(cfg_path).encode() if cfg_path else None, C.byref(cfg), buf,
+                              len(buf), C.byref(r))
+    _check(rc, "mc_check_files")
+    return _result(r), buf.value.decode()

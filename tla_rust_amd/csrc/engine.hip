@@ -1,0 +1,681 @@
+// engine.hip — the MI355X (gfx950) BFS engine behind include/tlamc.h.
+//
+// Per BFS level the frontier (a contiguous index range of the state arena in HBM) is processed
+// in chunks of `chunk_states` by three kernels, with no host synchronisation inside a level:
+//
+//   k_expand<Spec>      lane = frontier state, loop = action slot.  Evaluates every (state, slot)
+//                       pair of Next, computes the successor's 64-bit fingerprint (incrementally
+//                       for raft) and writes it to a SLOT-MAJOR candidate matrix
+//                       cand[slot][column] (0 = not enabled / not storable).  All arena reads and
+//                       all candidate writes are 512-byte coalesced per wavefront because the
+//                       arena is word-major inside blocks of 64 states (mc_common.h WordRef).
+//   k_insert            one thread per candidate cell: open-addressed seen-set in HBM, linear
+//                       probing, agent-scope atomicCAS on 64-bit fingerprints; survivors are
+//                       compacted with a wavefront ballot + one atomicAdd per wave into `newlist`.
+//   k_materialise<Spec> one lane per NEW state: re-evaluates its (parent, slot) and writes the
+//                       full successor into the arena (coalesced: consecutive lanes own
+//                       consecutive arena indices), plus (parent, slot) for counterexamples.
+//
+// Algorithmic HBM bytes per distinct state = 2*W + 8*(G/D)  (SURVEY.md §8d): each state is
+// written once and read once, each generated successor touches one 8-byte seen-set word.
+// The candidate matrix adds 16 B per evaluated cell on top (written by expand, read by insert).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "spec_registry.h"
+
+namespace mc {
+
+static thread_local std::string g_last_error;
+static void set_error(const std::string &s) { g_last_error = s; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+            return MC_EHIP;                                                                        \
+        }                                                                                          \
+    } while (0)
+
+struct DevCounters {
+    unsigned long long generated;
+    unsigned long long n_new;       // survivors of the current chunk
+    unsigned long long arena_next;  // next free arena index
+    unsigned long long viol_key;    // min over (idx << 24 | slot << 8 | kind); ~0 = none
+    unsigned long long cells;       // candidate cells probed
+    unsigned int max_slots;         // rows of the candidate matrix written by the current chunk
+    unsigned int error;             // DEV_E* bits
+};
+enum : unsigned { DEV_ETABLE = 1u, DEV_EARENA = 2u, DEV_EOVERFLOW = 4u };
+enum : unsigned { VK_INVARIANT = 1, VK_ASSERT = 2, VK_DEADLOCK = 3, VK_SPECERR = 4 };
+static constexpr unsigned SLOT_NONE = 0xffffu;
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    for (int o = 32; o > 0; o >>= 1) { unsigned t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+
+MC_HD CWordRef arena_cref(const uint64_t *arena, uint64_t idx, int words) {
+    return CWordRef{arena + ((idx >> 6) * (uint64_t)words) * 64 + (idx & 63), 64};
+}
+MC_HD WordRef arena_ref(uint64_t *arena, uint64_t idx, int words) {
+    return WordRef{arena + ((idx >> 6) * (uint64_t)words) * 64 + (idx & 63), 64};
+}
+MC_HD unsigned long long viol_key(uint64_t idx, unsigned slot, unsigned kind, unsigned inv) {
+    return ((unsigned long long)idx << 24) | ((unsigned long long)(slot & 0xffffu) << 8) | ((inv & 31u) << 3) | kind;
+}
+
+// ------------------------------------------------------------------------------------- expand
+template <class S>
+__global__ void __launch_bounds__(256)
+k_expand(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi,
+         uint64_t *__restrict__ cand, uint64_t row_stride, uint64_t ncols, uint16_t *__restrict__ nsl,
+         DevCounters *ctr, unsigned flags) {
+    const uint64_t base = lo & ~63ull;
+    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;  // ncols is a multiple of 64: whole wavefronts leave together
+    const uint64_t idx = base + col;
+    const bool active = idx >= lo && idx < hi;
+    const CWordRef s = arena_cref(arena, idx, S::WORDS);
+    typename S::Local loc;
+    int ns = 0;
+    if (active) {
+        S::load(prm, s, loc);
+        ns = S::nslots(prm, loc);
+    }
+    const int wns = (int)wave_max_u32((unsigned)ns);
+    unsigned gen = 0, err = 0;
+    unsigned long long viol = ~0ull;
+    for (int slot = 0; slot < wns; ++slot) {
+        uint64_t fp = 0;
+        if (slot < ns) {
+            uint64_t f = 0;
+            const unsigned st = S::eval(prm, loc, s, slot, f);
+            if (st & ST_ENABLED) {
+                ++gen;
+                if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
+                else if (st & ST_ASSERT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_ASSERT, 0));
+                else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, (unsigned)slot, VK_SPECERR, 0));
+                else {
+                    if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_INVARIANT, st >> 8));
+                    if (!(st & ST_OUT_OF_MODEL)) fp = f;
+                }
+            }
+        }
+        cand[(uint64_t)slot * row_stride + col] = fp;
+    }
+    nsl[col] = (uint16_t)wns;
+    if (active && gen == 0 && (flags & MC_F_DEADLOCK)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
+    const unsigned gsum = wave_sum_u32(gen);
+    const unsigned long long vmin = wave_min_u64(viol);
+    const unsigned eor = wave_or_u32(err);
+    if ((threadIdx.x & 63) == 0) {
+        if (gsum) atomicAdd(&ctr->generated, (unsigned long long)gsum);
+        if (wns) atomicMax(&ctr->max_slots, (unsigned)wns);
+        if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
+        if (eor) atomicOr(&ctr->error, eor);
+    }
+}
+
+// initial states: one candidate row, column = index of the initial state inside the chunk
+template <class S>
+__global__ void __launch_bounds__(256)
+k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__restrict__ cand, uint64_t ncols,
+            uint16_t *__restrict__ nsl, DevCounters *ctr) {
+    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    uint64_t fp = 0;
+    unsigned gen = 0;
+    unsigned long long viol = ~0ull;
+    if (col < count) {
+        uint64_t tmp[S::WORDS];
+        S::init(prm, first + col, WordRef{tmp, 1});
+        const unsigned st = S::init_status(prm, CWordRef{tmp, 1});
+        gen = 1;
+        if (st & ST_INVARIANT) viol = viol_key(first + col, SLOT_NONE - 1, VK_INVARIANT, st >> 8);
+        if (!(st & ST_OUT_OF_MODEL)) fp = S::fp_of(prm, CWordRef{tmp, 1});
+    }
+    cand[col] = fp;
+    nsl[col] = 1;
+    const unsigned gsum = wave_sum_u32(gen);
+    const unsigned long long vmin = wave_min_u64(viol);
+    if ((threadIdx.x & 63) == 0) {
+        if (gsum) atomicAdd(&ctr->generated, (unsigned long long)gsum);
+        atomicMax(&ctr->max_slots, 1u);
+        if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
+    }
+}
+
+// ------------------------------------------------------------------------------------- seen-set
+// Open addressing, linear probing, 64-bit fingerprints, EMPTY = 0.  Entries are write-once, so a
+// relaxed agent-scope load that returns a non-zero word is final; only an observed-empty slot
+// needs the CAS (per-XCD L2s are not coherent: every access to the table is agent scope).
+__device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t mask, uint64_t fp, unsigned &err) {
+    uint64_t h = fp & mask;
+    for (int probe = 0; probe < 8192; ++probe) {
+        unsigned long long cur = __hip_atomic_load((unsigned long long *)&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) cur = atomicCAS((unsigned long long *)&table[h], 0ull, (unsigned long long)fp);
+        if (cur == 0) return true;
+        if (cur == fp) return false;
+        h = (h + 1) & mask;
+    }
+    err |= DEV_ETABLE;
+    return false;
+}
+
+__global__ void __launch_bounds__(256)
+k_insert(const uint64_t *__restrict__ cand, uint64_t row_stride, uint64_t ncols, const uint16_t *__restrict__ nsl,
+         uint64_t *table, uint64_t mask, uint64_t *__restrict__ newlist, DevCounters *ctr) {
+    const unsigned slot = blockIdx.y;
+    if (slot >= ctr->max_slots) return;
+    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    bool is_new = false;
+    unsigned err = 0, probed = 0;
+    if (slot < nsl[col]) {
+        const uint64_t fp = cand[(uint64_t)slot * row_stride + col];
+        if (fp) {
+            probed = 1;
+            is_new = seen_insert(table, mask, fp, err);
+        }
+    }
+    const unsigned long long ballot = __ballot(is_new);
+    const unsigned lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    const unsigned np = wave_sum_u32(probed);
+    if (lane == 0) {
+        if (ballot) base = atomicAdd(&ctr->n_new, (unsigned long long)__popcll(ballot));
+        if (np) atomicAdd(&ctr->cells, (unsigned long long)np);
+    }
+    base = __shfl(base, 0);
+    if (is_new) {
+        const unsigned rank = (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
+        newlist[base + rank] = col | ((uint64_t)slot << 40);
+    }
+    if (wave_or_u32(err) && lane == 0) atomicOr(&ctr->error, DEV_ETABLE);
+}
+
+// ------------------------------------------------------------------------------------- materialise
+template <class S>
+__global__ void __launch_bounds__(256)
+k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint64_t *__restrict__ newlist,
+              uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr) {
+    const uint64_t n = ctr->n_new, out0 = ctr->arena_next;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint64_t src = newlist[j];
+        const uint64_t pidx = chunk_base + (src & ((1ull << 40) - 1ull));
+        const int slot = (int)(src >> 40);
+        const uint64_t oidx = out0 + j;
+        if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); continue; }
+        S::apply(prm, arena_cref(arena, pidx, S::WORDS), slot, arena_ref(arena, oidx, S::WORDS));
+        if (parent) { parent[oidx] = (uint32_t)pidx; pslot[oidx] = (uint16_t)slot; }
+    }
+}
+template <class S>
+__global__ void __launch_bounds__(256)
+k_init_materialise(typename S::Params prm, uint64_t *arena, uint64_t first, const uint64_t *__restrict__ newlist,
+                   uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr) {
+    const uint64_t n = ctr->n_new, out0 = ctr->arena_next;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const uint64_t k = first + (newlist[j] & ((1ull << 40) - 1ull));
+        const uint64_t oidx = out0 + j;
+        if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); continue; }
+        S::init(prm, k, arena_ref(arena, oidx, S::WORDS));
+        if (parent) { parent[oidx] = 0xffffffffu; pslot[oidx] = (uint16_t)(k & 0xffffu); }
+    }
+}
+// arena (blocked, word-major) -> plain records, for read-back and for the exchange buffers
+__global__ void __launch_bounds__(256)
+k_gather_states(const uint64_t *__restrict__ arena, int words, uint64_t first, uint64_t count, uint64_t *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * (uint64_t)words) return;
+    const uint64_t j = t / (uint64_t)words, w = t % (uint64_t)words, idx = first + j;
+    out[t] = arena[((idx >> 6) * (uint64_t)words + w) * 64 + (idx & 63)];
+}
+__global__ void k_commit(DevCounters *ctr) {
+    ctr->arena_next += ctr->n_new;
+    ctr->n_new = 0;
+    ctr->max_slots = 0;
+}
+
+// ------------------------------------------------------------------------------------- host side
+struct EngineBase {
+    virtual ~EngineBase() {}
+    virtual int run(mc_result *out) = 0;
+    virtual int trace(uint8_t *states_out, int32_t *actions_out, size_t *n_inout) = 0;
+    virtual int kernel_stats(mc_kernel_stats *out) = 0;
+    virtual int read_states(uint64_t first, uint64_t count, uint8_t *out) = 0;
+};
+
+static uint64_t round_pow2(uint64_t v) {
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct KTimer {
+    std::vector<hipEvent_t> pool;
+    struct Pending { int which; size_t e0, e1; uint64_t units; };
+    std::vector<Pending> pending;
+    size_t used = 0;
+    bool enabled = false;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
+        return pool[used++];
+    }
+    void resolve(mc_kernel_stat *stats /*[3]*/) {
+        for (auto &p : pending) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, pool[p.e0], pool[p.e1]);
+            stats[p.which].launches++;
+            stats[p.which].ms_total += ms;
+            stats[p.which].units += p.units;
+        }
+        pending.clear();
+        used = 0;
+    }
+    ~KTimer() { for (auto e : pool) hipEventDestroy(e); }
+};
+
+template <class S>
+struct Engine : EngineBase {
+    using Params = typename S::Params;
+    static constexpr int W = S::WORDS;
+    Params prm;
+    mc_spec_desc desc;
+    mc_config cfg;
+    hipStream_t stream = nullptr;
+    uint64_t *d_arena = nullptr, *d_table = nullptr, *d_cand = nullptr, *d_newlist = nullptr;
+    uint16_t *d_nsl = nullptr, *d_pslot = nullptr;
+    uint32_t *d_parent = nullptr;
+    DevCounters *d_ctr = nullptr, *h_ctr = nullptr;
+    uint64_t table_cap = 0, arena_cap = 0, chunk = 0, row_stride = 0;
+    KTimer timer;
+    mc_kernel_stat kstat[3];
+    // counterexample of the last run
+    bool have_viol = false;
+    unsigned long long last_viol = ~0ull;
+    std::vector<uint64_t> level_start;
+
+    int alloc() {
+        HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        table_cap = round_pow2(cfg.table_capacity ? cfg.table_capacity : (1ull << 24));
+        arena_cap = cfg.arena_capacity ? cfg.arena_capacity : (1ull << 22);
+        arena_cap = (arena_cap + 63) & ~63ull;
+        if (arena_cap >= (1ull << 32) - 1) { set_error("arena_capacity must be < 2^32 states"); return MC_EBADCFG; }
+        chunk = cfg.chunk_states ? cfg.chunk_states : (1ull << 18);
+        chunk = (chunk + 255) & ~255ull;
+        row_stride = chunk + 256;
+        HIP_TRY(hipMalloc(&d_arena, arena_cap * W * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&d_table, table_cap * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&d_cand, (size_t)S::MAX_SLOTS * row_stride * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&d_newlist, (size_t)S::MAX_SLOTS * row_stride * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&d_nsl, row_stride * sizeof(uint16_t)));
+        if (cfg.flags & MC_F_TRACE) {
+            HIP_TRY(hipMalloc(&d_parent, arena_cap * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&d_pslot, arena_cap * sizeof(uint16_t)));
+        }
+        HIP_TRY(hipMalloc(&d_ctr, sizeof(DevCounters)));
+        HIP_TRY(hipHostMalloc(&h_ctr, sizeof(DevCounters)));
+        timer.enabled = (cfg.flags & MC_F_TIMING) != 0;
+        return MC_OK;
+    }
+    ~Engine() override {
+        if (d_arena) hipFree(d_arena);
+        if (d_table) hipFree(d_table);
+        if (d_cand) hipFree(d_cand);
+        if (d_newlist) hipFree(d_newlist);
+        if (d_nsl) hipFree(d_nsl);
+        if (d_parent) hipFree(d_parent);
+        if (d_pslot) hipFree(d_pslot);
+        if (d_ctr) hipFree(d_ctr);
+        if (h_ctr) hipHostFree(h_ctr);
+        if (stream) hipStreamDestroy(stream);
+    }
+
+    template <class F>
+    void timed(int which, uint64_t units, F &&launch) {
+        if (!timer.enabled) { launch(); return; }
+        hipEvent_t a = timer.get(), b = timer.get();
+        size_t ia = timer.used - 2, ib = timer.used - 1;
+        hipEventRecord(a, stream);
+        launch();
+        hipEventRecord(b, stream);
+        timer.pending.push_back({which, ia, ib, units});
+    }
+
+    int read_counters() {
+        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (timer.enabled) timer.resolve(kstat);
+        return MC_OK;
+    }
+    int check_dev_error() {
+        if (h_ctr->error & DEV_EOVERFLOW) { set_error("packed-state slot array overflow (messages/elections/allLogs capacity)"); return MC_EOVERFLOW; }
+        if (h_ctr->error & DEV_ETABLE) { set_error("seen-set full: raise table_capacity"); return MC_ETABLEFULL; }
+        if (h_ctr->error & DEV_EARENA) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }
+        return MC_OK;
+    }
+
+    // insert + materialise + commit for the candidate matrix just written
+    template <bool INIT>
+    void finish_chunk(uint64_t chunk_base_or_first, uint64_t ncols, unsigned rows) {
+        const unsigned bx = (unsigned)((ncols + 255) / 256);
+        timed(1, ncols * rows, [&] {
+            hipLaunchKernelGGL(k_insert, dim3(bx, rows), dim3(256), 0, stream, d_cand, row_stride, ncols, d_nsl, d_table,
+                               table_cap - 1, d_newlist, d_ctr);
+        });
+        const unsigned gm = bx < 2048 ? bx : 2048;
+        timed(2, 0, [&] {
+            if (INIT)
+                hipLaunchKernelGGL(k_init_materialise<S>, dim3(gm), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
+                                   d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
+            else
+                hipLaunchKernelGGL(k_materialise<S>, dim3(gm), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
+                                   d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
+        });
+        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
+    }
+
+    int run(mc_result *out) override {
+        memset(out, 0, sizeof *out);
+        out->violated_invariant = -1;
+        memset(kstat, 0, sizeof kstat);
+        have_viol = false;
+        level_start.clear();
+        HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipMemsetAsync(d_table, 0, table_cap * sizeof(uint64_t), stream));
+        HIP_TRY(hipMemsetAsync(d_ctr, 0, sizeof(DevCounters), stream));
+        DevCounters init_c;
+        memset(&init_c, 0, sizeof init_c);
+        init_c.viol_key = ~0ull;
+        HIP_TRY(hipMemcpyAsync(d_ctr, &init_c, sizeof init_c, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const auto t0 = std::chrono::steady_clock::now();
+
+        // level 1: Init
+        const uint64_t ninit = S::num_init(prm);
+        for (uint64_t first = 0; first < ninit; first += chunk) {
+            const uint64_t count = ninit - first < chunk ? ninit - first : chunk;
+            const uint64_t ncols = (count + 63) & ~63ull;
+            hipLaunchKernelGGL(k_init_cand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, first, count,
+                               d_cand, ncols, d_nsl, d_ctr);
+            finish_chunk<true>(first, ncols, 1);
+        }
+        int rc = read_counters();
+        if (rc) return rc;
+        if ((rc = check_dev_error())) return rc;
+        uint64_t lo = 0, hi = h_ctr->arena_next;
+        uint32_t level = 1;
+        out->level_distinct[0] = hi;
+        level_start.push_back(0);
+        int budget = 0;
+        while (hi > lo) {
+            if (h_ctr->viol_key != ~0ull) break;
+            if (cfg.max_levels && level >= cfg.max_levels) { budget = 1; break; }
+            if (cfg.max_distinct && hi >= cfg.max_distinct) { budget = 1; break; }
+            for (uint64_t c0 = lo; c0 < hi;) {
+                const uint64_t base = c0 & ~63ull;
+                uint64_t c1 = base + chunk;  // chunk boundaries stay 64-aligned
+                if (c1 > hi) c1 = hi;
+                const uint64_t ncols = ((c1 - base) + 63) & ~63ull;
+                timed(0, c1 - c0, [&] {
+                    hipLaunchKernelGGL(k_expand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0,
+                                       c1, d_cand, row_stride, ncols, d_nsl, d_ctr, cfg.flags);
+                });
+                finish_chunk<false>(base, ncols, (unsigned)S::MAX_SLOTS);
+                c0 = c1;
+            }
+            if ((rc = read_counters())) return rc;
+            if ((rc = check_dev_error())) return rc;
+            lo = hi;
+            hi = h_ctr->arena_next;
+            if (hi > lo) {
+                level_start.push_back(lo);
+                if (level < MC_MAX_LEVELS) out->level_distinct[level] = hi - lo;
+                level++;
+            }
+            if (level >= MC_MAX_LEVELS) { set_error("too many BFS levels"); return MC_EBADCFG; }
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+        out->seconds = std::chrono::duration<double>(t1 - t0).count();
+        out->distinct = h_ctr->arena_next;
+        last_distinct = h_ctr->arena_next;
+        kstat[2].units = h_ctr->arena_next;
+        out->generated = h_ctr->generated;
+        out->queue_left = hi - lo;
+        out->depth = level;
+        out->levels = level;
+        kstat_cells = h_ctr->cells;
+        if (h_ctr->viol_key != ~0ull) {
+            have_viol = true;
+            last_viol = h_ctr->viol_key;
+            const unsigned kind = (unsigned)(last_viol & 7u);
+            out->verdict = kind == VK_INVARIANT ? MC_V_INVARIANT : kind == VK_ASSERT ? MC_V_ASSERT
+                         : kind == VK_DEADLOCK ? MC_V_DEADLOCK : MC_V_SPECERR;
+            if (kind == VK_INVARIANT) out->violated_invariant = (int)(last_viol >> 3 & 31u);
+            std::vector<uint64_t> chain;
+            if (build_chain(chain) == MC_OK) {
+                const unsigned slot = (unsigned)(last_viol >> 8 & 0xffffu);
+                const bool extra = kind == VK_INVARIANT && slot < SLOT_NONE - 1;  // violating successor itself
+                out->trace_len = (uint32_t)chain.size() + (extra ? 1u : 0u);
+            }
+        } else {
+            out->verdict = budget ? MC_V_BUDGET : MC_V_OK;
+        }
+        return MC_OK;
+    }
+    uint64_t kstat_cells = 0;
+
+    int fetch_state(uint64_t idx, uint64_t *words) {
+        const uint64_t *src = d_arena + ((idx >> 6) * (uint64_t)W) * 64 + (idx & 63);
+        HIP_TRY(hipMemcpy2D(words, sizeof(uint64_t), src, 64 * sizeof(uint64_t), sizeof(uint64_t), W, hipMemcpyDeviceToHost));
+        return MC_OK;
+    }
+    // arena indices from an initial state to the state the violation was found in / from
+    int build_chain(std::vector<uint64_t> &chain) {
+        chain.clear();
+        if (!have_viol) return MC_ESTATE;
+        const unsigned slot = (unsigned)(last_viol >> 8 & 0xffffu);
+        if (slot == SLOT_NONE - 1) return MC_OK;  // violated by an initial state: handled by the caller
+        if (!d_parent) { set_error("engine created without MC_F_TRACE"); return MC_ESTATE; }
+        uint64_t idx = last_viol >> 24;
+        for (int guard = 0; guard < MC_MAX_LEVELS; ++guard) {
+            chain.push_back(idx);
+            uint32_t p;
+            HIP_TRY(hipMemcpy(&p, d_parent + idx, sizeof p, hipMemcpyDeviceToHost));
+            if (p == 0xffffffffu) break;
+            idx = p;
+        }
+        std::vector<uint64_t> rev(chain.rbegin(), chain.rend());
+        chain.swap(rev);
+        return MC_OK;
+    }
+    int trace(uint8_t *states_out, int32_t *actions_out, size_t *n_inout) override {
+        if (!have_viol) { *n_inout = 0; return MC_OK; }
+        HIP_TRY(hipSetDevice(cfg.device));
+        const unsigned kind = (unsigned)(last_viol & 7u), slot = (unsigned)(last_viol >> 8 & 0xffffu);
+        std::vector<uint64_t> words;
+        std::vector<int32_t> acts;
+        if (slot == SLOT_NONE - 1) {  // an initial state violates an invariant
+            words.resize(W);
+            S::init(prm, last_viol >> 24, WordRef{words.data(), 1});
+            acts.push_back(-1);
+        } else {
+            std::vector<uint64_t> chain;
+            int rc = build_chain(chain);
+            if (rc) return rc;
+            words.resize(chain.size() * W);
+            for (size_t k = 0; k < chain.size(); ++k) {
+                if ((rc = fetch_state(chain[k], &words[k * W]))) return rc;
+                if (k == 0) acts.push_back(-1);
+                else {
+                    uint16_t ps;
+                    HIP_TRY(hipMemcpy(&ps, d_pslot + chain[k], sizeof ps, hipMemcpyDeviceToHost));
+                    acts.push_back(S::action_of(prm, &words[(k - 1) * W], (int)ps));
+                }
+            }
+            if (kind == VK_INVARIANT && slot < SLOT_NONE - 1) {  // append the violating successor
+                std::vector<uint64_t> last(words.end() - W, words.end());
+                words.resize(words.size() + W);
+                S::apply(prm, CWordRef{last.data(), 1}, (int)slot, WordRef{&words[words.size() - W], 1});
+                acts.push_back(S::action_of(prm, last.data(), (int)slot));
+            }
+        }
+        const size_t n = acts.size();
+        if (n > *n_inout) { *n_inout = n; set_error("trace buffer too small"); return MC_EBADCFG; }
+        memcpy(states_out, words.data(), n * W * sizeof(uint64_t));
+        memcpy(actions_out, acts.data(), n * sizeof(int32_t));
+        *n_inout = n;
+        return MC_OK;
+    }
+    int read_states(uint64_t first, uint64_t count, uint8_t *out) override {
+        if (!count) return MC_OK;
+        if (first + count > last_distinct) { set_error("read_states: range beyond the states found by the last run"); return MC_EBADCFG; }
+        HIP_TRY(hipSetDevice(cfg.device));
+        uint64_t *tmp = nullptr;
+        const uint64_t piece = 1ull << 20;
+        HIP_TRY(hipMalloc(&tmp, (count < piece ? count : piece) * W * sizeof(uint64_t)));
+        for (uint64_t off = 0; off < count; off += piece) {
+            const uint64_t n = count - off < piece ? count - off : piece;
+            hipLaunchKernelGGL(k_gather_states, dim3((unsigned)((n * W + 255) / 256)), dim3(256), 0, stream, d_arena, W, first + off, n, tmp);
+            hipError_t e1 = hipMemcpyAsync(out + off * W * sizeof(uint64_t), tmp, n * W * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+            hipError_t e2 = hipStreamSynchronize(stream);
+            if (e1 != hipSuccess || e2 != hipSuccess) { hipFree(tmp); set_error("read_states: copy failed"); return MC_EHIP; }
+        }
+        hipFree(tmp);
+        return MC_OK;
+    }
+    uint64_t last_distinct = 0;
+    int kernel_stats(mc_kernel_stats *o) override {
+        o->expand = kstat[0];
+        o->insert = kstat[1];
+        o->materialise = kstat[2];
+        o->state_bytes = (uint64_t)W * 8;
+        o->cand_cells = kstat_cells;
+        return MC_OK;
+    }
+};
+
+}  // namespace mc
+
+// --------------------------------------------------------------------------------------- C ABI
+using namespace mc;
+
+struct mc_engine {
+    EngineBase *impl;
+};
+
+extern "C" {
+
+int mc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine **out) {
+    if (!spec || !cfg || !out) return MC_EBADCFG;
+    *out = nullptr;
+    if (mc_device_count() <= 0) { set_error("no HIP device: libtlamc has no CPU fallback"); return MC_EHIP; }
+    int rc = dispatch_spec(spec, [&](auto s, const auto &prm) -> int {
+        using S = decltype(s);
+        auto *e = new Engine<S>();
+        e->prm = prm;
+        e->desc = *spec;
+        e->cfg = *cfg;
+        int r = e->alloc();
+        if (r) { delete e; return r; }
+        *out = new mc_engine{e};
+        return MC_OK;
+    });
+    if (rc == MC_EBADCFG && g_last_error.empty()) set_error("unknown spec id or constants out of range");
+    return rc;
+}
+int mc_engine_run(mc_engine *e, mc_result *out) { return e && out ? e->impl->run(out) : MC_EBADCFG; }
+int mc_engine_trace(mc_engine *e, uint8_t *states_out, int32_t *actions_out, size_t *n_inout) {
+    return e && n_inout ? e->impl->trace(states_out, actions_out, n_inout) : MC_EBADCFG;
+}
+int mc_engine_kernel_stats(mc_engine *e, mc_kernel_stats *out) { return e && out ? e->impl->kernel_stats(out) : MC_EBADCFG; }
+int mc_engine_read_states(mc_engine *e, uint64_t first, uint64_t count, uint8_t *out) {
+    return e && (out || !count) ? e->impl->read_states(first, count, out) : MC_EBADCFG;
+}
+void mc_engine_destroy(mc_engine *e) {
+    if (!e) return;
+    delete e->impl;
+    delete e;
+}
+
+size_t mc_state_bytes(const mc_spec_desc *spec) {
+    size_t n = 0;
+    dispatch_spec(spec, [&](auto s, const auto &) { n = sizeof(uint64_t) * decltype(s)::WORDS; return 0; });
+    return n;
+}
+uint32_t mc_fp_owner(uint64_t fp, uint32_t shard_count) { return fp_owner(fp, shard_count); }
+int mc_state_format(const mc_spec_desc *spec, const uint8_t *state, char *buf, size_t cap) {
+    if (!state || !buf || !cap) return MC_EBADCFG;
+    int n = MC_EBADCFG;
+    int rc = dispatch_spec(spec, [&](auto s, const auto &prm) {
+        using S = decltype(s);
+        uint64_t w[S::WORDS];
+        memcpy(w, state, sizeof w);
+        n = S::format(prm, w, buf, cap);
+        if ((size_t)n < cap) buf[n] = 0; else buf[cap - 1] = 0;
+        return 0;
+    });
+    return rc ? rc : n;
+}
+const char *mc_action_name(const mc_spec_desc *spec, int32_t action) {
+    const char *nm = "?";
+    dispatch_spec(spec, [&](auto s, const auto &) { nm = decltype(s)::action_name(action); return 0; });
+    return nm;
+}
+const char *mc_strerror(int code) {
+    switch (code) {
+    case MC_OK: return "ok";
+    case MC_EBADCFG: return "bad spec or configuration";
+    case MC_EHIP: return "HIP error / no device";
+    case MC_EOVERFLOW: return "packed-state slot array overflow";
+    case MC_ETABLEFULL: return "seen-set full";
+    case MC_EARENA: return "state arena full";
+    case MC_ERCCL: return "exchange failure";
+    case MC_ESTATE: return "call sequence error";
+    case MC_EPARSE: return "parse error";
+    case MC_ENOSPEC: return "module is not a lowered spec";
+    default: return "unknown error";
+    }
+}
+const char *mc_last_error(void) { return g_last_error.c_str(); }
+void mc_set_error_internal(const char *msg) { set_error(msg ? msg : ""); }
+
+
+// ---- sharded step API: implemented in the next section (see mc_shard_* in include/tlamc.h)
+int mc_shard_begin(mc_engine *) { set_error("sharded mode: not built yet"); return MC_ESTATE; }
+int mc_shard_level_size(mc_engine *, uint64_t *) { return MC_ESTATE; }
+int mc_shard_expand(mc_engine *, uint64_t, uint64_t, uint64_t *, uint64_t, uint64_t *) { return MC_ESTATE; }
+int mc_shard_probe(mc_engine *, const uint64_t *, uint64_t, uint8_t *) { return MC_ESTATE; }
+int mc_shard_materialise(mc_engine *, const uint8_t *, uint8_t *, uint64_t, uint64_t *) { return MC_ESTATE; }
+int mc_shard_ingest(mc_engine *, const uint8_t *, uint64_t) { return MC_ESTATE; }
+int mc_shard_end_level(mc_engine *, uint64_t *) { return MC_ESTATE; }
+int mc_shard_counters(mc_engine *, uint64_t *, uint64_t *, int32_t *) { return MC_ESTATE; }
+
+}  // extern "C"

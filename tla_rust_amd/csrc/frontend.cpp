@@ -1,0 +1,548 @@
+// frontend.cpp — host-side front-end of libtlamc.so: TLC .cfg parser, spec registry lookup,
+// `tlc X.tla` end-to-end driver and TLC-format report.
+//
+// Replaces, for the lowered specs only, what the external TLC tool does before and after its
+// BFS (reference Makefile:6-7, README.md:262):
+//   * reading X.cfg — grammar examples/SpecifyingSystems/TLC/ConfigFileGrammar.tla:4-32, plus
+//     the instance-scoped override `Id <-[Module] Id` used by examples/Paxos/MCPaxos.cfg:9 and
+//     both comment styles (pcal_intro.cfg:1 `\*`, AsynchInterface.cfg:1-5 `(* *)`);
+//   * choosing Init/Next/invariants/constraint from it (pcal_intro.cfg:2-3);
+//   * printing the report (README.md:267-321, testout2:260-266).
+// There is no general TLA+ evaluator: the module is matched by name to a
+// hand-lowered spec and its text is fingerprinted so a changed spec is refused, not mis-checked.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/tlamc.h"
+
+extern "C" void mc_set_error_internal(const char *msg);  // engine.hip
+
+namespace {
+
+
+struct CfgValue {
+    enum Kind { IDENT, NUMBER, STRING, SET } kind = IDENT;
+    std::string text;
+    long long num = 0;
+    std::vector<CfgValue> elems;
+};
+struct CfgConst {
+    std::string name;
+    bool replacement = false;  // `<-` (definition override) vs `=` (value)
+    std::string module;        // `<-[Module]`
+    std::string target;
+    CfgValue value;
+};
+
+}  // namespace
+
+struct mc_cfg {
+    std::string specification, init, next, view, symmetry;
+    std::vector<std::string> invariants, properties, constraints, action_constraints;
+    std::vector<CfgConst> constants;
+};
+
+namespace {
+
+struct Tok {
+    enum T { END, IDENT, NUMBER, STRING, LBRACE, RBRACE, COMMA, EQ, ARROW, ARROW_MOD } t = END;
+    std::string s;
+    int line = 0;
+};
+
+struct Lexer {
+    const char *p, *e;
+    int line = 1;
+    std::string err;
+    Lexer(const char *b, size_t n) : p(b), e(b + n) {}
+    static bool idch(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; }
+    bool skip() {
+        for (;;) {
+            while (p < e && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) { if (*p == '\n') line++; p++; }
+            if (p + 1 < e && p[0] == '\\' && p[1] == '*') { while (p < e && *p != '\n') p++; continue; }
+            if (p + 1 < e && p[0] == '(' && p[1] == '*') {
+                int depth = 1;
+                p += 2;
+                while (p < e && depth) {
+                    if (p + 1 < e && p[0] == '(' && p[1] == '*') { depth++; p += 2; }
+                    else if (p + 1 < e && p[0] == '*' && p[1] == ')') { depth--; p += 2; }
+                    else { if (*p == '\n') line++; p++; }
+                }
+                if (depth) { err = "unterminated (* comment"; return false; }
+                continue;
+            }
+            return true;
+        }
+    }
+    bool next(Tok &t) {
+        if (!skip()) return false;
+        t = Tok();
+        t.line = line;
+        if (p >= e) { t.t = Tok::END; return true; }
+        const char c = *p;
+        if (idch(c)) {
+            const char *b = p;
+            while (p < e && idch(*p)) p++;
+            t.s.assign(b, p);
+            // ACTION-CONSTRAINT(S) is the one keyword with a hyphen (ConfigFileGrammar.tla:9-10)
+            if (t.s == "ACTION" && p < e && *p == '-') {
+                const char *q = p + 1;
+                while (q < e && idch(*q)) q++;
+                std::string tail(p + 1, q);
+                if (tail == "CONSTRAINT" || tail == "CONSTRAINTS") { t.s += "-" + tail; p = q; }
+            }
+            bool letter = false;
+            for (char ch : t.s) letter |= !(ch >= '0' && ch <= '9');
+            t.t = letter ? Tok::IDENT : Tok::NUMBER;
+            return true;
+        }
+        if (c == '-' && p + 1 < e && p[1] >= '0' && p[1] <= '9') {
+            const char *b = p++;
+            while (p < e && *p >= '0' && *p <= '9') p++;
+            t.s.assign(b, p);
+            t.t = Tok::NUMBER;
+            return true;
+        }
+        if (c == '"') {
+            const char *b = ++p;
+            while (p < e && *p != '"' && *p != '\n') p++;
+            if (p >= e || *p != '"') { err = "unterminated string"; return false; }
+            t.s.assign(b, p++);
+            t.t = Tok::STRING;
+            return true;
+        }
+        if (c == '{') { p++; t.t = Tok::LBRACE; return true; }
+        if (c == '}') { p++; t.t = Tok::RBRACE; return true; }
+        if (c == ',') { p++; t.t = Tok::COMMA; return true; }
+        if (c == '=') { p++; t.t = Tok::EQ; return true; }
+        if (c == '<' && p + 1 < e && p[1] == '-') {
+            p += 2;
+            if (p < e && *p == '[') {
+                const char *b = ++p;
+                while (p < e && idch(*p)) p++;
+                if (p >= e || *p != ']' || b == p) { err = "malformed <-[Module]"; return false; }
+                t.s.assign(b, p++);
+                t.t = Tok::ARROW_MOD;
+            } else {
+                t.t = Tok::ARROW;
+            }
+            return true;
+        }
+        err = std::string("unexpected character '") + c + "'";
+        return false;
+    }
+};
+
+bool is_singular(const std::string &s) { return s == "SPECIFICATION" || s == "INIT" || s == "NEXT" || s == "VIEW" || s == "SYMMETRY"; }
+bool is_plural(const std::string &s) {
+    return s == "CONSTRAINT" || s == "CONSTRAINTS" || s == "ACTION-CONSTRAINT" || s == "ACTION-CONSTRAINTS" || s == "INVARIANT" ||
+           s == "INVARIANTS" || s == "PROPERTY" || s == "PROPERTIES";
+}
+bool is_keyword(const std::string &s) { return is_singular(s) || is_plural(s) || s == "CONSTANT" || s == "CONSTANTS"; }
+
+struct Parser {
+    Lexer lx;
+    Tok cur;
+    std::string err;
+    Parser(const char *b, size_t n) : lx(b, n) {}
+    bool adv() {
+        if (!lx.next(cur)) { err = "line " + std::to_string(lx.line) + ": " + lx.err; return false; }
+        return true;
+    }
+    bool fail(const std::string &m) { err = "line " + std::to_string(cur.line) + ": " + m; return false; }
+    bool value(CfgValue &v) {
+        if (cur.t == Tok::IDENT) { v.kind = CfgValue::IDENT; v.text = cur.s; return adv(); }
+        if (cur.t == Tok::NUMBER) { v.kind = CfgValue::NUMBER; v.text = cur.s; v.num = atoll(cur.s.c_str()); return adv(); }
+        if (cur.t == Tok::STRING) { v.kind = CfgValue::STRING; v.text = cur.s; return adv(); }
+        if (cur.t == Tok::LBRACE) {
+            v.kind = CfgValue::SET;
+            if (!adv()) return false;
+            if (cur.t == Tok::RBRACE) return adv();
+            for (;;) {
+                CfgValue e;
+                if (!value(e)) return false;
+                v.elems.push_back(e);
+                if (cur.t == Tok::COMMA) { if (!adv()) return false; continue; }
+                if (cur.t == Tok::RBRACE) return adv();
+                return fail("expected ',' or '}' in set value");
+            }
+        }
+        return fail("expected a value (identifier, number, string or {set})");
+    }
+    bool parse(mc_cfg &c) {
+        if (!adv()) return false;
+        while (cur.t != Tok::END) {
+            if (cur.t != Tok::IDENT || !is_keyword(cur.s)) return fail("expected a configuration keyword, got '" + cur.s + "'");
+            const std::string kw = cur.s;
+            if (!adv()) return false;
+            if (is_singular(kw)) {
+                if (cur.t != Tok::IDENT || is_keyword(cur.s)) return fail(kw + " must be followed by an identifier");
+                std::string &dst = kw == "SPECIFICATION" ? c.specification : kw == "INIT" ? c.init : kw == "NEXT" ? c.next
+                                   : kw == "VIEW" ? c.view : c.symmetry;
+                dst = cur.s;
+                if (!adv()) return false;
+            } else if (is_plural(kw)) {
+                std::vector<std::string> &dst = kw[0] == 'I' ? c.invariants : kw[0] == 'P' ? c.properties
+                                                : kw[0] == 'A' ? c.action_constraints : c.constraints;
+                while (cur.t == Tok::IDENT && !is_keyword(cur.s)) {
+                    dst.push_back(cur.s);
+                    if (!adv()) return false;
+                }
+            } else {  // CONSTANT(S): (Replacement | Assignment)*
+                while (cur.t == Tok::IDENT && !is_keyword(cur.s)) {
+                    CfgConst k;
+                    k.name = cur.s;
+                    if (!adv()) return false;
+                    if (cur.t == Tok::ARROW || cur.t == Tok::ARROW_MOD) {
+                        k.replacement = true;
+                        if (cur.t == Tok::ARROW_MOD) k.module = cur.s;
+                        if (!adv()) return false;
+                        if (cur.t != Tok::IDENT) return fail("'<-' must be followed by an identifier");
+                        k.target = cur.s;
+                        if (!adv()) return false;
+                    } else if (cur.t == Tok::EQ) {
+                        if (!adv()) return false;
+                        if (!value(k.value)) return false;
+                    } else {
+                        return fail("expected '=' or '<-' after constant '" + k.name + "'");
+                    }
+                    c.constants.push_back(k);
+                }
+            }
+        }
+        return true;
+    }
+};
+
+void json_str(std::string &o, const std::string &s) {
+    o += '"';
+    for (char ch : s) {
+        if (ch == '"' || ch == '\\') { o += '\\'; o += ch; }
+        else if (ch == '\n') o += "\\n";
+        else o += ch;
+    }
+    o += '"';
+}
+void json_list(std::string &o, const std::vector<std::string> &v) {
+    o += '[';
+    for (size_t i = 0; i < v.size(); i++) { if (i) o += ", "; json_str(o, v[i]); }
+    o += ']';
+}
+void json_value(std::string &o, const CfgValue &v) {
+    switch (v.kind) {
+    case CfgValue::IDENT: o += "{\"model_value\": "; json_str(o, v.text); o += "}"; break;
+    case CfgValue::NUMBER: o += std::to_string(v.num); break;
+    case CfgValue::STRING: json_str(o, v.text); break;
+    case CfgValue::SET:
+        o += "{\"set\": [";
+        for (size_t i = 0; i < v.elems.size(); i++) { if (i) o += ", "; json_value(o, v.elems[i]); }
+        o += "]}";
+        break;
+    }
+}
+
+const CfgConst *find_const(const mc_cfg *c, const char *name) {
+    const CfgConst *r = nullptr;
+    for (const auto &k : c->constants) if (k.name == name) r = &k;  // last one wins
+    return r;
+}
+bool const_int(const mc_cfg *c, const char *name, long long &out) {
+    const CfgConst *k = find_const(c, name);
+    if (!k || k->replacement || k->value.kind != CfgValue::NUMBER) return false;
+    out = k->value.num;
+    return true;
+}
+int fe_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    mc_set_error_internal(buf);
+    return code;
+}
+
+// text fingerprints of the reference specs the lowerings were written against (whitespace removed, FNV-1a)
+uint64_t text_hash(const std::string &s) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char ch : s) {
+        if (ch == ' ' || ch == '\t' || ch == '\r' || ch == '\n') continue;
+        h ^= ch;
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+constexpr uint64_t H_PCAL_INTRO = 0x6da4921b5bd7b79aull;        // pcal_intro.tla:4-19 (--algorithm .. end algorithm)
+constexpr uint64_t H_PCAL_INTRO_README = 0x446ad8dac291d64full; // README.md:224-240 (labels A:, B:)
+constexpr uint64_t H_ATOMIC_ADD = 0x6c3a51af80fccd40ull;        // atomic_add.tla:4-23
+constexpr uint64_t H_RAFT = 0x289fe41014391a24ull;              // examples/raft.tla:8-517 (EXTENDS .. before ====)
+
+bool algorithm_text(const std::string &t, std::string &out) {
+    const size_t i = t.find("--algorithm");
+    if (i == std::string::npos) return false;
+    const size_t j = t.find("end algorithm", i);
+    if (j == std::string::npos) return false;
+    out = t.substr(i, j + strlen("end algorithm") - i);
+    return true;
+}
+bool module_body(const std::string &t, std::string &out) {
+    const size_t i = t.find("EXTENDS");
+    if (i == std::string::npos) return false;
+    size_t pos = i;
+    while (pos < t.size()) {  // a line made of '=' only ends the module
+        size_t eol = t.find('\n', pos);
+        if (eol == std::string::npos) eol = t.size();
+        size_t a = pos, b = eol;
+        while (a < b && (t[a] == ' ' || t[a] == '\r')) a++;
+        while (b > a && (t[b - 1] == ' ' || t[b - 1] == '\r')) b--;
+        if (b - a >= 4 && t.find_first_not_of('=', a) >= b) { out = t.substr(i, pos - i); return true; }
+        pos = eol + 1;
+    }
+    return false;
+}
+bool read_file(const std::string &path, std::string &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+bool module_name(const std::string &t, std::string &name) {
+    const size_t i = t.find("MODULE");
+    if (i == std::string::npos) return false;
+    size_t a = i + 6;
+    while (a < t.size() && (t[a] == ' ' || t[a] == '\t')) a++;
+    size_t b = a;
+    while (b < t.size() && Lexer::idch(t[b])) b++;
+    if (b == a) return false;
+    name = t.substr(a, b - a);
+    return true;
+}
+std::string dir_of(const std::string &p) {
+    const size_t i = p.find_last_of('/');
+    return i == std::string::npos ? "." : p.substr(0, i);
+}
+
+struct Out {
+    char *b; size_t cap, k;
+    void put(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+        va_list ap;
+        va_start(ap, fmt);
+        if (k + 1 < cap) { int w = vsnprintf(b + k, cap - k, fmt, ap); if (w > 0) k += (size_t)w; if (k >= cap) k = cap - 1; }
+        va_end(ap);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mc_cfg_parse(const char *text, size_t len, mc_cfg **out) {
+    if (!text || !out) return MC_EBADCFG;
+    *out = nullptr;
+    mc_cfg *c = new mc_cfg();
+    Parser p(text, len);
+    if (!p.parse(*c)) {
+        mc_set_error_internal(("cfg: " + p.err).c_str());
+        delete c;
+        return MC_EPARSE;
+    }
+    *out = c;
+    return MC_OK;
+}
+void mc_cfg_free(mc_cfg *c) { delete c; }
+
+int mc_cfg_json(const mc_cfg *c, char *buf, size_t cap) {
+    if (!c || !buf || !cap) return MC_EBADCFG;
+    std::string o = "{";
+    o += "\"SPECIFICATION\": "; json_str(o, c->specification);
+    o += ", \"INIT\": "; json_str(o, c->init);
+    o += ", \"NEXT\": "; json_str(o, c->next);
+    o += ", \"VIEW\": "; json_str(o, c->view);
+    o += ", \"SYMMETRY\": "; json_str(o, c->symmetry);
+    o += ", \"INVARIANTS\": "; json_list(o, c->invariants);
+    o += ", \"PROPERTIES\": "; json_list(o, c->properties);
+    o += ", \"CONSTRAINTS\": "; json_list(o, c->constraints);
+    o += ", \"ACTION_CONSTRAINTS\": "; json_list(o, c->action_constraints);
+    o += ", \"CONSTANTS\": [";
+    for (size_t i = 0; i < c->constants.size(); i++) {
+        const CfgConst &k = c->constants[i];
+        if (i) o += ", ";
+        o += "{\"name\": "; json_str(o, k.name);
+        if (k.replacement) {
+            o += ", \"replace_by\": "; json_str(o, k.target);
+            if (!k.module.empty()) { o += ", \"module\": "; json_str(o, k.module); }
+        } else {
+            o += ", \"value\": "; json_value(o, k.value);
+        }
+        o += "}";
+    }
+    o += "]}";
+    if (o.size() + 1 > cap) return fe_fail(MC_EBADCFG, "mc_cfg_json: buffer too small");
+    memcpy(buf, o.c_str(), o.size() + 1);
+    return (int)o.size();
+}
+
+// Registry: module name -> lowering (+ constants taken from the cfg).
+int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
+    if (!module || !c || !out) return MC_EBADCFG;
+    memset(out, 0, sizeof *out);
+    const std::string m = module;
+    if (!c->properties.empty()) return fe_fail(MC_ENOSPEC, "PROPERTY (temporal) checking is not supported; only INVARIANT safety checking");
+    if (!c->symmetry.empty() || !c->view.empty()) return fe_fail(MC_ENOSPEC, "SYMMETRY / VIEW are not supported yet");
+    if (m == "atomic_add" || m == "atomic_add_n") {  // atomic_add.tla:4-23; atomic_add_n: N adders (specs/atomic_add_n.tla)
+        long long n = 2;
+        if (m == "atomic_add_n" && !const_int(c, "N", n)) return fe_fail(MC_EBADCFG, "atomic_add_n needs CONSTANT N = <number>");
+        if (!c->invariants.empty()) return fe_fail(MC_ENOSPEC, "atomic_add defines no invariant named '%s'", c->invariants[0].c_str());
+        out->spec_id = MC_SPEC_ATOMIC_ADD;
+        out->nparams = 1;
+        out->params[0] = n;
+        return MC_OK;
+    }
+    if (m == "pcal_intro") {  // pcal_intro.tla:4-23 + pcal_intro.cfg:2-3
+        long long inv = 0;
+        for (const auto &i : c->invariants) {
+            if (i == "MoneyInvariant") inv = 1;
+            else return fe_fail(MC_ENOSPEC, "pcal_intro defines no invariant named '%s'", i.c_str());
+        }
+        out->spec_id = MC_SPEC_PCAL_INTRO;
+        out->nparams = 4;
+        out->params[0] = 0;  // variant: refined from the module text by mc_check_files
+        out->params[1] = inv;
+        out->params[2] = 20;
+        out->params[3] = 2;
+        return MC_OK;
+    }
+    if (m == "MCraft" || m == "raft") {  // examples/raft.tla under specs/MCraft.tla
+        const CfgConst *srv = find_const(c, "Server");
+        if (!srv || srv->replacement || srv->value.kind != CfgValue::SET || srv->value.elems.empty())
+            return fe_fail(MC_EBADCFG, "raft needs CONSTANT Server = {s1, ..., sn}");
+        long long mcr = 0, mt = 0, ml = 0, mm = 0;
+        if (!const_int(c, "MaxClientRequests", mcr)) return fe_fail(MC_EBADCFG, "raft needs CONSTANT MaxClientRequests = <number> (raft.tla:23-24)");
+        bool has_constraint = false;
+        for (const auto &k : c->constraints) {
+            if (k == "StateConstraint") has_constraint = true;
+            else return fe_fail(MC_ENOSPEC, "unknown CONSTRAINT '%s' (MCraft defines StateConstraint)", k.c_str());
+        }
+        if (!has_constraint)
+            return fe_fail(MC_EBADCFG, "raft.tla has an unbounded term counter (raft.tla:199): the cfg must name CONSTRAINT StateConstraint");
+        if (!const_int(c, "MaxTerm", mt) || !const_int(c, "MaxLogLen", ml) || !const_int(c, "MaxMsgs", mm))
+            return fe_fail(MC_EBADCFG, "StateConstraint needs CONSTANTS MaxTerm, MaxLogLen, MaxMsgs");
+        long long mask = 0;
+        for (const auto &i : c->invariants) {
+            if (i == "NoTwoLeaders") mask |= 1;
+            else if (i == "CommittedLogStable") mask |= 2;
+            else return fe_fail(MC_ENOSPEC, "MCraft defines no invariant named '%s'", i.c_str());
+        }
+        out->spec_id = MC_SPEC_RAFT;
+        out->nparams = 6;
+        out->params[0] = (long long)srv->value.elems.size();
+        out->params[1] = mcr; out->params[2] = mt; out->params[3] = ml; out->params[4] = mm; out->params[5] = mask;
+        return MC_OK;
+    }
+    return fe_fail(MC_ENOSPEC, "module '%s' is not one of the lowered specs (atomic_add, atomic_add_n, pcal_intro, MCraft)", module);
+}
+
+static const char *invariant_name(const mc_spec_desc *d, int idx) {
+    if (d->spec_id == MC_SPEC_PCAL_INTRO) return "MoneyInvariant";
+    if (d->spec_id == MC_SPEC_RAFT) return idx == 1 ? "CommittedLogStable" : "NoTwoLeaders";
+    return "?";
+}
+
+int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
+                   mc_result *res) {
+    if (!tla_path || !cfg || !report || !report_cap || !res) return MC_EBADCFG;
+    report[0] = 0;
+    std::string tla, cfgtext, module;
+    if (!read_file(tla_path, tla)) return fe_fail(MC_EPARSE, "cannot read %s", tla_path);
+    if (!module_name(tla, module)) return fe_fail(MC_EPARSE, "%s: no MODULE header", tla_path);
+    std::string cpath;
+    if (cfg_path) cpath = cfg_path;
+    else {  // X.cfg beside X.tla (README.md:356)
+        cpath = tla_path;
+        const size_t dot = cpath.rfind(".tla");
+        if (dot != std::string::npos) cpath.replace(dot, 4, ".cfg"); else cpath += ".cfg";
+    }
+    if (!read_file(cpath, cfgtext)) return fe_fail(MC_EPARSE, "cannot read configuration file %s", cpath.c_str());
+    mc_cfg *c = nullptr;
+    int rc = mc_cfg_parse(cfgtext.c_str(), cfgtext.size(), &c);
+    if (rc) return rc;
+    mc_spec_desc d;
+    rc = mc_spec_resolve(module.c_str(), c, &d);
+    mc_cfg_free(c);
+    if (rc) return rc;
+    // the lowering is valid only for the text it was written against
+    std::string part;
+    if (d.spec_id == MC_SPEC_PCAL_INTRO) {
+        if (!algorithm_text(tla, part)) return fe_fail(MC_ENOSPEC, "%s: no --algorithm block", tla_path);
+        const uint64_t h = text_hash(part);
+        if (h == H_PCAL_INTRO) d.params[0] = 0;
+        else if (h == H_PCAL_INTRO_README) d.params[0] = 1;
+        else return fe_fail(MC_ENOSPEC, "pcal_intro: the algorithm text differs from both lowered variants (hash %016llx)", (unsigned long long)h);
+    } else if (d.spec_id == MC_SPEC_ATOMIC_ADD && module == "atomic_add") {
+        if (!algorithm_text(tla, part)) return fe_fail(MC_ENOSPEC, "%s: no --algorithm block", tla_path);
+        const uint64_t h = text_hash(part);
+        if (h != H_ATOMIC_ADD) return fe_fail(MC_ENOSPEC, "atomic_add: the algorithm text differs from the lowered one (hash %016llx)", (unsigned long long)h);
+    } else if (d.spec_id == MC_SPEC_RAFT) {
+        std::string raft;  // MCraft EXTENDS raft: verify raft.tla when it can be found beside the wrapper
+        const char *env = getenv("TLA_PATH");
+        bool found = read_file(dir_of(tla_path) + "/raft.tla", raft) || (env && read_file(std::string(env) + "/raft.tla", raft));
+        if (module == "raft") { raft = tla; found = true; }
+        if (found) {
+            if (!module_body(raft, part)) return fe_fail(MC_ENOSPEC, "raft.tla: cannot find the module body");
+            const uint64_t h = text_hash(part);
+            if (h != H_RAFT) return fe_fail(MC_ENOSPEC, "raft.tla differs from the text the lowering was written against (hash %016llx)", (unsigned long long)h);
+        }
+    }
+    mc_engine *e = nullptr;
+    if ((rc = mc_engine_create(&d, cfg, &e))) return rc;
+    rc = mc_engine_run(e, res);
+    if (rc) { mc_engine_destroy(e); return rc; }
+
+    Out o{report, report_cap, 0};
+    o.put("Finished computing initial states: %llu distinct state%s generated.\n", (unsigned long long)res->level_distinct[0],
+          res->level_distinct[0] == 1 ? "" : "s");
+    if (res->verdict == MC_V_OK || res->verdict == MC_V_BUDGET) {
+        if (res->verdict == MC_V_OK) o.put("Model checking completed. No error has been found.\n");
+        else o.put("Search stopped by the level/state budget; no error has been found so far.\n");
+        // testout2:261-264: optimistic estimate = (generated - distinct) * distinct / 2^64
+        const double opt = (double)(res->generated - res->distinct) * (double)res->distinct / 18446744073709551616.0;
+        o.put("  Estimates of the probability that TLC did not check all reachable states\n"
+              "  because two distinct states had the same fingerprint:\n  calculated (optimistic):  val = %.2g\n", opt);
+    } else {
+        if (res->verdict == MC_V_ASSERT)
+            o.put("The first argument of Assert evaluated to FALSE; the second argument was:\n\"Failure of assertion at line 16, column 4.\"\n");
+        else if (res->verdict == MC_V_INVARIANT) o.put("Error: Invariant %s is violated.\n", invariant_name(&d, res->violated_invariant));
+        else if (res->verdict == MC_V_DEADLOCK) o.put("Error: Deadlock reached.\n");
+        else o.put("Error: evaluation error (a function was applied outside its domain).\n");
+        const size_t W = mc_state_bytes(&d);
+        size_t n = res->trace_len ? res->trace_len : 1;
+        std::vector<uint8_t> states(n * W);
+        std::vector<int32_t> acts(n);
+        if (mc_engine_trace(e, states.data(), acts.data(), &n) == MC_OK && n) {
+            o.put("Error: The behavior up to this point is:\n");
+            std::vector<char> txt(1 << 16);
+            for (size_t k = 0; k < n; k++) {
+                mc_state_format(&d, &states[k * W], txt.data(), txt.size());
+                if (acts[k] < 0) o.put("State %zu: <Initial predicate>\n%s\n\n", k + 1, txt.data());
+                else o.put("State %zu: <Action %s of module %s>\n%s\n\n", k + 1, mc_action_name(&d, acts[k]), module.c_str(), txt.data());
+            }
+        }
+    }
+    o.put("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)res->generated,
+          (unsigned long long)res->distinct, (unsigned long long)res->queue_left);
+    o.put("The depth of the complete state graph search is %u.\n", res->depth);
+    mc_engine_destroy(e);
+    return MC_OK;
+}
+
+}  // extern "C"
