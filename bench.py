@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-distinct", type=int, default=WORKLOAD["max_distinct"])
     ap.add_argument("--chunk", type=int, default=1 << 19)
+    ap.add_argument("--table-log2", type=int, default=28)
+    ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     a = ap.parse_args()
 
     import torch
@@ -64,7 +66,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     if world == 1:
-        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << 28,
+        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << a.table_log2, matrix=a.matrix,
                          arena_capacity=30_000_000 if a.max_distinct <= 25_000_000 else 2 * a.max_distinct,
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run

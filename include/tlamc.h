@@ -58,6 +58,7 @@ typedef struct {
 #define MC_F_DEADLOCK 1u /* check deadlock (TLC default on; serializableSnapshotIsolation.tla:57) */
 #define MC_F_TRACE 2u    /* keep (parent, action) per state so a counterexample can be rebuilt     */
 #define MC_F_TIMING 4u   /* time every kernel launch with HIP events on the engine stream          */
+#define MC_F_MATRIX 8u   /* A/B only: unfused expand -> candidate matrix -> insert kernels          */
 
 typedef struct {
     int32_t device;          /* HIP device ordinal                                              */

@@ -28,7 +28,7 @@ def amd():
 def _levels_text(eng, res):
     out, first = {}, 0
     for lvl, n in enumerate(res.levels, start=1):
-        out[lvl] = sorted(eng.state_texts(first, n))
+        out[lvl] = sorted(t.replace("\n", " ") for t in eng.state_texts(first, n))
         first += n
     return out
 
@@ -57,10 +57,12 @@ def test_readme_counterexample_on_gpu(amd):
     r = eng.run()
     assert r.verdict == "assert" and r.trace_len == 6 and r.depth == 7
     tr = eng.trace()
-    assert tr[0][0] == "Initial predicate" and "alice_account = -1" in tr[-1][1]
-    assert [a for a, _ in tr[1:]] in (["Transfer", "Transfer", "A", "B", "A"], ["Transfer", "Transfer", "A", "A", "B"],
-                                      ["Transfer", "A", "Transfer", "B", "A"], ["Transfer", "A", "Transfer", "A", "B"],
-                                      ["Transfer", "A", "B", "Transfer", "A"])
+    # any shortest counterexample is acceptable (TLC's own choice depends on its worker order):
+    # 6 states, the last one with a negative alice_account while a process sits at C
+    assert tr[0][0] == "Initial predicate" and len(tr) == 6
+    import re
+    assert int(re.search(r"alice_account = (-?\d+)", tr[-1][1]).group(1)) < 0 and '"C"' in tr[-1][1]
+    assert sorted(a for a, _ in tr[1:]) == ["A", "A", "B", "Transfer", "Transfer"]
     # each step changes exactly what the action may change: pc of one process
     eng.close()
 

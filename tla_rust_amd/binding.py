@@ -10,7 +10,7 @@ LIB_PATH = PKG / "_build" / "libtlamc.so"
 MC_MAX_LEVELS = 4096
 SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3}
 VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
-MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING = 1, 2, 4
+MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING, MC_F_MATRIX = 1, 2, 4, 8
 
 
 class McError(RuntimeError):
@@ -132,10 +132,11 @@ class Engine:
     """One model-checking engine on one GPU (mc_engine_create / run / trace / destroy)."""
 
     def __init__(self, spec, params, device=0, table_capacity=0, arena_capacity=0, chunk_states=0, max_levels=0,
-                 max_distinct=0, deadlock=True, trace=True, timing=False, shard_rank=0, shard_count=1):
+                 max_distinct=0, deadlock=True, trace=True, timing=False, matrix=False, shard_rank=0, shard_count=1):
         self.spec, self.params = spec, list(params)
         self.desc = spec_desc(spec, params)
-        flags = (MC_F_DEADLOCK if deadlock else 0) | (MC_F_TRACE if trace else 0) | (MC_F_TIMING if timing else 0)
+        flags = (MC_F_DEADLOCK if deadlock else 0) | (MC_F_TRACE if trace else 0) | (MC_F_TIMING if timing else 0) | \
+            (MC_F_MATRIX if matrix else 0)
         self.cfg = Config(device, flags, table_capacity, arena_capacity, chunk_states, max_levels, max_distinct,
                           shard_rank, shard_count)
         self._h = C.c_void_p()

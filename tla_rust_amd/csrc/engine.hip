@@ -211,6 +211,118 @@ k_insert(const uint64_t *__restrict__ cand, uint64_t row_stride, uint64_t ncols,
     if (wave_or_u32(err) && lane == 0) atomicOr(&ctr->error, DEV_ETABLE);
 }
 
+
+// ------------------------------------------------------------------------------------- fused expand + insert
+// Per-wavefront LDS ring queues turn the sparse stream of enabled successors into dense work:
+//   q   : (fingerprint, source) of generated successors waiting to be probed.  As soon as 64 are
+//         queued the whole wavefront probes the seen-set at once (64 independent HBM atomics in
+//         flight per wave instead of a few divergent ones).
+//   o   : sources of the survivors (new states); flushed to `newlist` 64 at a time with ONE
+//         atomicAdd per flush, so the global cursor sees (new states)/64 atomics.
+constexpr int QCAP = 128;  // ring capacity per wave (>= 2 * 64)
+
+struct WaveQueues {
+    uint64_t q_fp[QCAP], q_src[QCAP], o_src[QCAP];
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <class S>
+__global__ void __launch_bounds__(256)
+k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
+                uint64_t *table, uint64_t mask, uint64_t *__restrict__ newlist, DevCounters *ctr, unsigned flags) {
+    __shared__ WaveQueues wq[4];
+    const unsigned lane = threadIdx.x & 63;
+    WaveQueues &Q = wq[threadIdx.x >> 6];
+    const uint64_t base = lo & ~63ull;
+    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;  // whole wavefronts leave together (ncols % 64 == 0)
+    const uint64_t idx = base + col;
+    const bool active = idx >= lo && idx < hi;
+    const CWordRef s = arena_cref(arena, idx, S::WORDS);
+    typename S::Local loc;
+    int ns = 0;
+    if (active) {
+        S::load(prm, s, loc);
+        ns = S::nslots(prm, loc);
+    }
+    const int wns = (int)wave_max_u32((unsigned)ns);
+    unsigned gen = 0, err = 0, probes = 0;
+    unsigned long long viol = ~0ull;
+    unsigned qhead = 0, qn = 0, ohead = 0, on = 0;  // wave-uniform ring state
+
+    auto flush_out = [&](unsigned take) {  // append `take` survivors to the global new-list
+        unsigned long long pos = 0;
+        if (lane == 0) pos = atomicAdd(&ctr->n_new, (unsigned long long)take);
+        pos = __shfl(pos, 0);
+        if (lane < take) newlist[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
+        ohead = (ohead + take) & (QCAP - 1);
+        on -= take;
+    };
+    auto flush_probe = [&](unsigned take) {  // probe `take` queued fingerprints, one per lane
+        bool is_new = false;
+        uint64_t src = 0;
+        if (lane < take) {
+            const unsigned k = (qhead + lane) & (QCAP - 1);
+            src = Q.q_src[k];
+            is_new = seen_insert(table, mask, Q.q_fp[k], err);
+        }
+        qhead = (qhead + take) & (QCAP - 1);
+        qn -= take;
+        probes += take;
+        const unsigned long long b = __ballot(is_new);
+        if (is_new) Q.o_src[(ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1)] = src;
+        on += (unsigned)__popcll(b);
+        wave_lds_fence();
+        if (on >= 64) flush_out(64);
+    };
+
+    for (int slot = 0; slot < wns; ++slot) {
+        uint64_t fp = 0;
+        if (slot < ns) {
+            uint64_t f = 0;
+            const unsigned st = S::eval(prm, loc, s, slot, f);
+            if (st & ST_ENABLED) {
+                ++gen;
+                if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
+                else if (st & ST_ASSERT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_ASSERT, 0));
+                else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, (unsigned)slot, VK_SPECERR, 0));
+                else {
+                    if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_INVARIANT, st >> 8));
+                    if (!(st & ST_OUT_OF_MODEL)) fp = f;
+                }
+            }
+        }
+        const unsigned long long b = __ballot(fp != 0);
+        if (b) {
+            if (fp) {
+                const unsigned k = (qhead + qn + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
+                Q.q_fp[k] = fp;
+                Q.q_src[k] = col | ((uint64_t)slot << 40);
+            }
+            qn += (unsigned)__popcll(b);
+            wave_lds_fence();
+            if (qn >= 64) flush_probe(64);
+        }
+    }
+    if (qn) flush_probe(qn);
+    if (on) flush_out(on);
+
+    if (active && gen == 0 && (flags & MC_F_DEADLOCK)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
+    const unsigned gsum = wave_sum_u32(gen);
+    const unsigned long long vmin = wave_min_u64(viol);
+    const unsigned eor = wave_or_u32(err);
+    if (lane == 0) {
+        if (gsum) atomicAdd(&ctr->generated, (unsigned long long)gsum);
+        if (probes) atomicAdd(&ctr->cells, (unsigned long long)probes);
+        if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
+        if (eor) atomicOr(&ctr->error, eor);
+    }
+}
+
 // ------------------------------------------------------------------------------------- materialise
 template <class S>
 __global__ void __launch_bounds__(256)
@@ -337,6 +449,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipMalloc(&d_ctr, sizeof(DevCounters)));
         HIP_TRY(hipHostMalloc(&h_ctr, sizeof(DevCounters)));
         timer.enabled = (cfg.flags & MC_F_TIMING) != 0;
+        use_matrix = (cfg.flags & MC_F_MATRIX) != 0;
         return MC_OK;
     }
     ~Engine() override {
@@ -376,6 +489,16 @@ struct Engine : EngineBase {
         return MC_OK;
     }
 
+    bool use_matrix = false;
+    void finish_materialise(uint64_t chunk_base, uint64_t ncols) {
+        const unsigned bx = (unsigned)((ncols + 255) / 256);
+        const unsigned gm = bx < 2048 ? bx : 2048;
+        timed(2, 0, [&] {
+            hipLaunchKernelGGL(k_materialise<S>, dim3(gm), dim3(256), 0, stream, prm, d_arena, chunk_base, d_newlist, arena_cap,
+                               d_parent, d_pslot, d_ctr);
+        });
+        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
+    }
     // insert + materialise + commit for the candidate matrix just written
     template <bool INIT>
     void finish_chunk(uint64_t chunk_base_or_first, uint64_t ncols, unsigned rows) {
@@ -438,11 +561,19 @@ struct Engine : EngineBase {
                 uint64_t c1 = base + chunk;  // chunk boundaries stay 64-aligned
                 if (c1 > hi) c1 = hi;
                 const uint64_t ncols = ((c1 - base) + 63) & ~63ull;
-                timed(0, c1 - c0, [&] {
-                    hipLaunchKernelGGL(k_expand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0,
-                                       c1, d_cand, row_stride, ncols, d_nsl, d_ctr, cfg.flags);
-                });
-                finish_chunk<false>(base, ncols, (unsigned)S::MAX_SLOTS);
+                if (use_matrix) {  // two-kernel form: sparse candidate matrix + k_insert (kept for A/B measurements)
+                    timed(0, c1 - c0, [&] {
+                        hipLaunchKernelGGL(k_expand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena,
+                                           c0, c1, d_cand, row_stride, ncols, d_nsl, d_ctr, cfg.flags);
+                    });
+                    finish_chunk<false>(base, ncols, (unsigned)S::MAX_SLOTS);
+                } else {
+                    timed(0, c1 - c0, [&] {
+                        hipLaunchKernelGGL(k_expand_insert<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm,
+                                           d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, d_ctr, cfg.flags);
+                    });
+                    finish_materialise(base, ncols);
+                }
                 c0 = c1;
             }
             if ((rc = read_counters())) return rc;
