@@ -23,7 +23,10 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1], max_distinct=25_000_000,
+# params[6..8] = capacities of the messages / elections / allLogs slot arrays of the packed state:
+# the oracle's maxima over this prefix are 14 / 1 / 4 (tests/golden/raft_levels.json max_stat);
+# an overflow would raise MC_EOVERFLOW, never drop a state.  W = 18 + 16 + 2*4 + 8 = 50 words.
+WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 16, 2, 8], max_distinct=25_000_000,
                 name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1, budget 25M distinct")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -33,7 +36,7 @@ def cpu_baseline(sample_distinct=1_500_000):
     exe = ROOT / "oracle" / "_build" / "oracle_mc"
     if not exe.exists():
         subprocess.run(["make", "-s", "-C", str(ROOT / "oracle")], check=True)
-    p = [str(x) for x in WORKLOAD["params"]]
+    p = [str(x) for x in WORKLOAD["params"][:6]]
     out = subprocess.run([str(exe), "raft", *p, "--distinct", str(sample_distinct)], capture_output=True, text=True, check=True).stdout
     r = json.loads(out.splitlines()[0])
     return dict(value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=1, kind="port",

@@ -38,13 +38,13 @@ struct FpCheck {
 };
 template <class S>
 struct FpCheck<S, decltype((void)S::W_FP)> {
-    static bool ok(const typename S::Params &, const uint64_t *w) { return S::fp_recompute(CWordRef{w, 1}) == w[S::W_FP]; }
+    static bool ok(const typename S::Params &p, const uint64_t *w) { return S::fp_recompute(p, CWordRef{w, 1}) == w[S::W_FP]; }
 };
 
 template <class S>
 static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t max_distinct, int check_deadlock,
                const char *dump_path, ShimResult *r) {
-    constexpr int W = S::WORDS;
+    const int W = S::words(prm);
     memset(r, 0, sizeof *r);
     r->violated_invariant = -1;
     std::vector<uint64_t> arena;
@@ -70,7 +70,7 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
         if (r->verdict == MC_V_INVARIANT) r->violated_invariant = (int)(st >> 8 & 255);
         r->trace_len = trace_len;
     };
-    uint64_t tmp[W];
+    uint64_t tmp[S::MAX_WORDS];
     const uint64_t ninit = S::num_init(prm);
     for (uint64_t k = 0; k < ninit; k++) {
         S::init(prm, k, WordRef{tmp, 1});
@@ -132,6 +132,6 @@ extern "C" int shim_run(const mc_spec_desc *d, uint64_t max_levels, uint64_t max
 
 extern "C" size_t shim_state_bytes(const mc_spec_desc *d) {
     size_t n = 0;
-    dispatch_spec(d, [&](auto spec, const auto &) { n = sizeof(uint64_t) * decltype(spec)::WORDS; return 0; });
+    dispatch_spec(d, [&](auto spec, const auto &prm) { n = sizeof(uint64_t) * decltype(spec)::words(prm); return 0; });
     return n;
 }

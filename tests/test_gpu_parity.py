@@ -123,6 +123,26 @@ def test_raft_golden_levels_on_gpu(amd, name):
     eng.close()
 
 
+def test_bench_workload_with_tuned_capacities(amd):
+    """bench.py runs the same model with slot-array capacities sized from the oracle's maxima
+    (16 / 2 / 8 instead of the defaults 40 / 4 / 16): W changes, the state graph must not."""
+    c = _golden("raft3_mcr4_t2_m1_bench")
+    eng = amd.Engine("raft", c["params"] + [16, 2, 8], table_capacity=1 << 27, arena_capacity=30_000_000, chunk_states=1 << 19,
+                     max_distinct=c["max_distinct"], trace=False)
+    assert amd.state_bytes("raft", c["params"] + [16, 2, 8]) == 400
+    r = eng.run()
+    assert r.levels == c["levels"] and (r.distinct, r.generated) == (c["distinct"], c["generated"])
+    eng.close()
+
+
+def test_capacity_too_small_overflows(amd):
+    eng = amd.Engine("raft", [2, 2, 2, 9, 2, 1, 8, 1, 2], table_capacity=1 << 21, arena_capacity=1 << 19)
+    with pytest.raises(amd.McError) as ei:
+        eng.run()
+    assert ei.value.code == -3
+    eng.close()
+
+
 def test_overflow_is_reported_not_dropped(amd):
     """overflow of a slot array must raise MC_EOVERFLOW, never silently drop.
     raft2 has room for 32 distinct messages; MaxMsgs = 6 with 3 terms exceeds it."""

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -92,7 +93,7 @@ k_expand(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo
     if (col >= ncols) return;  // ncols is a multiple of 64: whole wavefronts leave together
     const uint64_t idx = base + col;
     const bool active = idx >= lo && idx < hi;
-    const CWordRef s = arena_cref(arena, idx, S::WORDS);
+    const CWordRef s = arena_cref(arena, idx, S::words(prm));
     typename S::Local loc;
     int ns = 0;
     if (active) {
@@ -133,23 +134,25 @@ k_expand(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo
     }
 }
 
-// initial states: one candidate row, column = index of the initial state inside the chunk
+// initial states: one candidate row, column = index of the initial state inside the chunk; the
+// states themselves are built once into `tmp` (plain records) and copied by k_init_materialise
 template <class S>
 __global__ void __launch_bounds__(256)
-k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__restrict__ cand, uint64_t ncols,
-            uint16_t *__restrict__ nsl, DevCounters *ctr) {
+k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__restrict__ tmp, uint64_t *__restrict__ cand,
+            uint64_t ncols, uint16_t *__restrict__ nsl, DevCounters *ctr) {
     const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncols) return;
     uint64_t fp = 0;
     unsigned gen = 0;
     unsigned long long viol = ~0ull;
     if (col < count) {
-        uint64_t tmp[S::WORDS];
-        S::init(prm, first + col, WordRef{tmp, 1});
-        const unsigned st = S::init_status(prm, CWordRef{tmp, 1});
+        const int W = S::words(prm);
+        S::init(prm, first + col, WordRef{tmp + col * (uint64_t)W, 1});
+        const CWordRef st_ref{tmp + col * (uint64_t)W, 1};
+        const unsigned st = S::init_status(prm, st_ref);
         gen = 1;
         if (st & ST_INVARIANT) viol = viol_key(first + col, SLOT_NONE - 1, VK_INVARIANT, st >> 8);
-        if (!(st & ST_OUT_OF_MODEL)) fp = S::fp_of(prm, CWordRef{tmp, 1});
+        if (!(st & ST_OUT_OF_MODEL)) fp = S::fp_of(prm, st_ref);
     }
     cand[col] = fp;
     nsl[col] = 1;
@@ -221,6 +224,14 @@ k_insert(const uint64_t *__restrict__ cand, uint64_t row_stride, uint64_t ncols,
 //         atomicAdd per flush, so the global cursor sees (new states)/64 atomics.
 constexpr int QCAP = 128;  // ring capacity per wave (>= 2 * 64)
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 struct WaveQueues {
     uint64_t q_fp[QCAP], q_src[QCAP], o_src[QCAP];
 };
@@ -242,7 +253,7 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     if (col >= ncols) return;  // whole wavefronts leave together (ncols % 64 == 0)
     const uint64_t idx = base + col;
     const bool active = idx >= lo && idx < hi;
-    const CWordRef s = arena_cref(arena, idx, S::WORDS);
+    const CWordRef s = arena_cref(arena, idx, S::words(prm));
     typename S::Local loc;
     int ns = 0;
     if (active) {
@@ -280,7 +291,7 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         if (on >= 64) flush_out(64);
     };
 
-    for (int slot = 0; slot < wns; ++slot) {
+    auto body = [&](int slot) __attribute__((always_inline)) {
         uint64_t fp = 0;
         if (slot < ns) {
             uint64_t f = 0;
@@ -307,7 +318,11 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             wave_lds_fence();
             if (qn >= 64) flush_probe(64);
         }
-    }
+    };
+    // slots whose action / server indices are compile-time constants: fully unrolled, so the
+    // spec's dispatch and register-array indexing fold away; the rest (per-message slots) loops
+    if (wns > 0) static_for<0, S::FIX_SLOTS>([&](auto c) __attribute__((always_inline)) { body(decltype(c)::value); });
+    for (int slot = S::FIX_SLOTS; slot < wns; ++slot) body(slot);
     if (qn) flush_probe(qn);
     if (on) flush_out(on);
 
@@ -336,22 +351,25 @@ k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, cons
         const int slot = (int)(src >> 40);
         const uint64_t oidx = out0 + j;
         if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); continue; }
-        S::apply(prm, arena_cref(arena, pidx, S::WORDS), slot, arena_ref(arena, oidx, S::WORDS));
+        S::apply(prm, arena_cref(arena, pidx, S::words(prm)), slot, arena_ref(arena, oidx, S::words(prm)));
         if (parent) { parent[oidx] = (uint32_t)pidx; pslot[oidx] = (uint16_t)slot; }
     }
 }
 template <class S>
 __global__ void __launch_bounds__(256)
-k_init_materialise(typename S::Params prm, uint64_t *arena, uint64_t first, const uint64_t *__restrict__ newlist,
-                   uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr) {
+k_init_materialise(typename S::Params prm, uint64_t *arena, uint64_t first, const uint64_t *__restrict__ tmp,
+                   const uint64_t *__restrict__ newlist, uint64_t arena_cap, uint32_t *__restrict__ parent,
+                   uint16_t *__restrict__ pslot, DevCounters *ctr) {
     const uint64_t n = ctr->n_new, out0 = ctr->arena_next;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const int W = S::words(prm);
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const uint64_t k = first + (newlist[j] & ((1ull << 40) - 1ull));
+        const uint64_t col = newlist[j] & ((1ull << 40) - 1ull);
         const uint64_t oidx = out0 + j;
         if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); continue; }
-        S::init(prm, k, arena_ref(arena, oidx, S::WORDS));
-        if (parent) { parent[oidx] = 0xffffffffu; pslot[oidx] = (uint16_t)(k & 0xffffu); }
+        const WordRef o = arena_ref(arena, oidx, W);
+        for (int w = 0; w < W; w++) o.set(w, tmp[col * (uint64_t)W + w]);
+        if (parent) { parent[oidx] = 0xffffffffu; pslot[oidx] = (uint16_t)((first + col) & 0xffffu); }
     }
 }
 // arena (blocked, word-major) -> plain records, for read-back and for the exchange buffers
@@ -410,13 +428,15 @@ struct KTimer {
 template <class S>
 struct Engine : EngineBase {
     using Params = typename S::Params;
-    static constexpr int W = S::WORDS;
+    int W = 1;  // 64-bit words per packed state
+    unsigned max_slots = 1;
     Params prm;
     mc_spec_desc desc;
     mc_config cfg;
     hipStream_t stream = nullptr;
     uint64_t *d_arena = nullptr, *d_table = nullptr, *d_cand = nullptr, *d_newlist = nullptr;
     uint16_t *d_nsl = nullptr, *d_pslot = nullptr;
+    uint64_t *d_inittmp = nullptr;
     uint32_t *d_parent = nullptr;
     DevCounters *d_ctr = nullptr, *h_ctr = nullptr;
     uint64_t table_cap = 0, arena_cap = 0, chunk = 0, row_stride = 0;
@@ -428,6 +448,9 @@ struct Engine : EngineBase {
     std::vector<uint64_t> level_start;
 
     int alloc() {
+        W = S::words(prm);
+        max_slots = (unsigned)S::max_slots(prm);
+        use_matrix = (cfg.flags & MC_F_MATRIX) != 0;
         HIP_TRY(hipSetDevice(cfg.device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         table_cap = round_pow2(cfg.table_capacity ? cfg.table_capacity : (1ull << 24));
@@ -439,8 +462,12 @@ struct Engine : EngineBase {
         row_stride = chunk + 256;
         HIP_TRY(hipMalloc(&d_arena, arena_cap * W * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&d_table, table_cap * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&d_cand, (size_t)S::MAX_SLOTS * row_stride * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&d_newlist, (size_t)S::MAX_SLOTS * row_stride * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&d_cand, (size_t)(use_matrix ? max_slots : 1) * row_stride * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&d_newlist, (size_t)max_slots * row_stride * sizeof(uint64_t)));
+        {
+            const uint64_t ni = S::num_init(prm);
+            HIP_TRY(hipMalloc(&d_inittmp, (size_t)(ni < chunk ? ni : chunk) * W * sizeof(uint64_t)));
+        }
         HIP_TRY(hipMalloc(&d_nsl, row_stride * sizeof(uint16_t)));
         if (cfg.flags & MC_F_TRACE) {
             HIP_TRY(hipMalloc(&d_parent, arena_cap * sizeof(uint32_t)));
@@ -449,7 +476,6 @@ struct Engine : EngineBase {
         HIP_TRY(hipMalloc(&d_ctr, sizeof(DevCounters)));
         HIP_TRY(hipHostMalloc(&h_ctr, sizeof(DevCounters)));
         timer.enabled = (cfg.flags & MC_F_TIMING) != 0;
-        use_matrix = (cfg.flags & MC_F_MATRIX) != 0;
         return MC_OK;
     }
     ~Engine() override {
@@ -458,6 +484,7 @@ struct Engine : EngineBase {
         if (d_cand) hipFree(d_cand);
         if (d_newlist) hipFree(d_newlist);
         if (d_nsl) hipFree(d_nsl);
+        if (d_inittmp) hipFree(d_inittmp);
         if (d_parent) hipFree(d_parent);
         if (d_pslot) hipFree(d_pslot);
         if (d_ctr) hipFree(d_ctr);
@@ -511,7 +538,7 @@ struct Engine : EngineBase {
         timed(2, 0, [&] {
             if (INIT)
                 hipLaunchKernelGGL(k_init_materialise<S>, dim3(gm), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
-                                   d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
+                                   d_inittmp, d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
             else
                 hipLaunchKernelGGL(k_materialise<S>, dim3(gm), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
                                    d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
@@ -541,7 +568,7 @@ struct Engine : EngineBase {
             const uint64_t count = ninit - first < chunk ? ninit - first : chunk;
             const uint64_t ncols = (count + 63) & ~63ull;
             hipLaunchKernelGGL(k_init_cand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, first, count,
-                               d_cand, ncols, d_nsl, d_ctr);
+                               d_inittmp, d_cand, ncols, d_nsl, d_ctr);
             finish_chunk<true>(first, ncols, 1);
         }
         int rc = read_counters();
@@ -566,7 +593,7 @@ struct Engine : EngineBase {
                         hipLaunchKernelGGL(k_expand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena,
                                            c0, c1, d_cand, row_stride, ncols, d_nsl, d_ctr, cfg.flags);
                     });
-                    finish_chunk<false>(base, ncols, (unsigned)S::MAX_SLOTS);
+                    finish_chunk<false>(base, ncols, max_slots);
                 } else {
                     timed(0, c1 - c0, [&] {
                         hipLaunchKernelGGL(k_expand_insert<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm,
@@ -758,7 +785,7 @@ void mc_engine_destroy(mc_engine *e) {
 
 size_t mc_state_bytes(const mc_spec_desc *spec) {
     size_t n = 0;
-    dispatch_spec(spec, [&](auto s, const auto &) { n = sizeof(uint64_t) * decltype(s)::WORDS; return 0; });
+    dispatch_spec(spec, [&](auto s, const auto &prm) { n = sizeof(uint64_t) * decltype(s)::words(prm); return 0; });
     return n;
 }
 uint32_t mc_fp_owner(uint64_t fp, uint32_t shard_count) { return fp_owner(fp, shard_count); }
@@ -767,8 +794,8 @@ int mc_state_format(const mc_spec_desc *spec, const uint8_t *state, char *buf, s
     int n = MC_EBADCFG;
     int rc = dispatch_spec(spec, [&](auto s, const auto &prm) {
         using S = decltype(s);
-        uint64_t w[S::WORDS];
-        memcpy(w, state, sizeof w);
+        uint64_t w[S::MAX_WORDS];
+        memcpy(w, state, sizeof(uint64_t) * S::words(prm));
         n = S::format(prm, w, buf, cap);
         if ((size_t)n < cap) buf[n] = 0; else buf[cap - 1] = 0;
         return 0;

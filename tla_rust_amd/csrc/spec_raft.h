@@ -50,9 +50,40 @@ enum : int { RA_RESTART, RA_TIMEOUT, RA_REQUESTVOTE, RA_BECOMELEADER, RA_CLIENTR
 
 struct RaftParams {
     int n, max_client_requests, max_term, max_log_len, max_msgs, inv_mask;
+    int cm, ce, ca;  // capacities of the messages / elections / allLogs slot arrays (runtime: they size W)
 };
 
-template <int NS, int CM, int CE, int CA>
+// A small array that is guaranteed to live in registers: explicit scalar members and
+// compare-select access (no alloca, so nothing is ever indexed dynamically in scratch memory).
+// With a compile-time index the chains fold away.
+template <int N>
+struct RegArr {
+    static_assert(N >= 1 && N <= 8, "RegArr holds 1..8 words");
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    MC_HD uint64_t get(int i) const {
+        uint64_t r = a0;
+        if (N > 1) r = i == 1 ? a1 : r;
+        if (N > 2) r = i == 2 ? a2 : r;
+        if (N > 3) r = i == 3 ? a3 : r;
+        if (N > 4) r = i == 4 ? a4 : r;
+        if (N > 5) r = i == 5 ? a5 : r;
+        if (N > 6) r = i == 6 ? a6 : r;
+        if (N > 7) r = i == 7 ? a7 : r;
+        return r;
+    }
+    MC_HD void set(int i, uint64_t v) {
+        a0 = i == 0 ? v : a0;
+        if (N > 1) a1 = i == 1 ? v : a1;
+        if (N > 2) a2 = i == 2 ? v : a2;
+        if (N > 3) a3 = i == 3 ? v : a3;
+        if (N > 4) a4 = i == 4 ? v : a4;
+        if (N > 5) a5 = i == 5 ? v : a5;
+        if (N > 6) a6 = i == 6 ? v : a6;
+        if (N > 7) a7 = i == 7 ? v : a7;
+    }
+};
+
+template <int NS>
 struct SpecRaft {
     using Params = RaftParams;
     // ---------------------------------------------------------------- word layout
@@ -63,16 +94,18 @@ struct SpecRaft {
     MC_HD static constexpr int W_SRV(int i) { return 3 + i * SRV_WORDS; }      // scalars of server i
     MC_HD static constexpr int W_LOG(int i) { return W_SRV(i) + 1; }           // log[i]
     MC_HD static constexpr int W_VLOG(int i, int j) { return W_SRV(i) + 2 + j; }  // voterLog[i][j]
-    static constexpr int W_MSG0 = 3 + NS * SRV_WORDS;                         // messages[CM]
+    static constexpr int W_MSG0 = 3 + NS * SRV_WORDS;                         // messages[cm]
     static constexpr int EL_WORDS = 1 + NS;
-    static constexpr int W_EL0 = W_MSG0 + CM;                                 // elections[CE][1+NS]
-    static constexpr int W_ALL0 = W_EL0 + CE * EL_WORDS;                      // allLogs[CA]
-    static constexpr int WORDS = W_ALL0 + CA;
+    MC_HD static int W_EL0(const Params &p) { return W_MSG0 + p.cm; }                 // elections[ce][1+NS]
+    MC_HD static int W_ALL0(const Params &p) { return W_MSG0 + p.cm + p.ce * EL_WORDS; }  // allLogs[ca]
+    MC_HD static int words(const Params &p) { return W_MSG0 + p.cm + p.ce * EL_WORDS + p.ca; }
+    static constexpr int MAX_WORDS = W_MSG0 + 64 + 8 * EL_WORDS + 64;
     static constexpr int HDR_WORDS = W_MSG0;
     // slots: Restart NS | Timeout NS | RequestVote NS^2 | BecomeLeader NS | ClientRequest NS |
     //        AdvanceCommitIndex NS | AppendEntries NS^2 | per message k: Receive, Duplicate, Drop
     static constexpr int FIX = 5 * NS + 2 * NS * NS;
-    static constexpr int MAX_SLOTS = FIX + 3 * CM;
+    static constexpr int FIX_SLOTS = FIX;  // slots whose action and server indices are compile-time constants
+    MC_HD static int max_slots(const Params &p) { return FIX + 3 * p.cm; }
     static constexpr uint64_t SALT_M = 0x8f1bbcdc8f1bbcdcull, SALT_E = 0xca62c1d6ca62c1d6ull, SALT_A = 0x5a8279995a827999ull;
 
     // server scalar word: term[0,3) state[3,5) votedFor[5,8) votesGranted[8,13) commitIndex[13,16)
@@ -128,9 +161,10 @@ struct SpecRaft {
         return m_head(M_AERESP, term, src, dst) | ((uint64_t)success << 13) | ((uint64_t)midx << 14);
     }
     // election word 0: eterm[0,3) eleader[3,6) evotes[6,11) elog[11,44); words 1..NS: evoterLog[j]
-    MC_HD static uint64_t helec(const uint64_t *ew) {
-        uint64_t h = hmix(ew[0], SALT_E);
-        for (int q = 1; q <= NS; q++) h = hmix(ew[q] + h, SALT_E + (uint64_t)q);
+    MC_HD static uint64_t helec(const RegArr<1 + NS> &ew) {
+        uint64_t h = hmix(ew.get(0), SALT_E);
+#pragma unroll
+        for (int q = 1; q <= NS; q++) h = hmix(ew.get(q) + h, SALT_E + (uint64_t)q);
         return h;
     }
 
@@ -139,6 +173,10 @@ struct SpecRaft {
         o.n = (int)p[0]; o.max_client_requests = (int)p[1]; o.max_term = (int)p[2];
         o.max_log_len = (int)p[3]; o.max_msgs = (int)p[4];
         o.inv_mask = np > 5 ? (int)p[5] : 1;
+        o.cm = np > 6 && p[6] > 0 ? (int)p[6] : 40;
+        o.ce = np > 7 && p[7] > 0 ? (int)p[7] : 4;
+        o.ca = np > 8 && p[8] > 0 ? (int)p[8] : 16;
+        if (o.cm > 64 || o.ce > 8 || o.ca > 64) return -1;
         if (o.n != NS) return -1;
         if (o.max_client_requests < 1 || o.max_client_requests - 1 > rlog::LCAP || o.max_client_requests > 7) return -1;
         if (o.max_term < 1 || o.max_term > 6) return -1;  // term MaxTerm+1 must still fit 3 bits
@@ -148,8 +186,8 @@ struct SpecRaft {
 
     // ---------------------------------------------------------------- Init   raft.tla:156-179
     MC_HD static uint64_t num_init(const Params &) { return 1; }
-    MC_HD static void init(const Params &, uint64_t, WordRef out) {
-        for (int w = 0; w < WORDS; w++) out.set(w, 0);
+    MC_HD static void init(const Params &prm, uint64_t, WordRef out) {
+        for (int w = 0; w < words(prm); w++) out.set(w, 0);
         uint64_t sv = sv_reset_leader_vars(sv_set_term(0, 1), 1);  // currentTerm 1, Follower, Nil, {}, 0, next 1, match 0
         uint64_t fp = 0;
         for (int i = 0; i < NS; i++) out.set(W_SRV(i), sv);
@@ -161,17 +199,18 @@ struct SpecRaft {
     MC_HD static uint64_t fp_of(const Params &, Ref s) { return fp_nonzero(s.get(W_FP)); }
     // full recomputation of the fingerprint (tests: must equal the incrementally maintained one)
     template <class Ref>
-    MC_HD static uint64_t fp_recompute(Ref s) {
+    MC_HD static uint64_t fp_recompute(const Params &prm, Ref s) {
         uint64_t fp = 0;
         for (int w = 1; w < HDR_WORDS; w++) fp += hmix(s.get(w), salt_of((unsigned)w));
         const uint64_t g = s.get(W_GLOB);
         for (int k = 0; k < g_nm(g); k++) fp += hmix(s.get(W_MSG0 + k), SALT_M);
         for (int e = 0; e < g_ne(g); e++) {
-            uint64_t ew[EL_WORDS];
-            for (int q = 0; q < EL_WORDS; q++) ew[q] = s.get(W_EL0 + e * EL_WORDS + q);
+            RegArr<EL_WORDS> ew;
+#pragma unroll
+            for (int q = 0; q < EL_WORDS; q++) ew.set(q, s.get(W_EL0(prm) + e * EL_WORDS + q));
             fp += helec(ew);
         }
-        for (int a = 0; a < g_na(g); a++) fp += hmix(s.get(W_ALL0 + a), SALT_A);
+        for (int a = 0; a < g_na(g); a++) fp += hmix(s.get(W_ALL0(prm) + a), SALT_A);
         return fp;
     }
     template <class Ref>
@@ -180,37 +219,44 @@ struct SpecRaft {
     // ---------------------------------------------------------------- per-parent cache
     struct Local {
         uint64_t fp, glob, clog;
-        uint64_t sv[NS], log[NS];
+        RegArr<NS> sv, log;
         int nm, inflight;
-        int nadd;              // logs of {log[i]} not yet in allLogs (raft.tla:493), deduplicated
-        uint64_t addlog[NS];
+        unsigned addmask;      // servers whose log is not yet in allLogs (raft.tla:493), first occurrence only
+        int nadd;              // popcount(addmask)
         uint64_t add_fp;       // sum of their contributions
     };
     template <class Ref>
-    MC_HD static void load(const Params &, Ref s, Local &l) {
+    MC_HD static void load(const Params &prm, Ref s, Local &l) {
         l.fp = s.get(W_FP);
         l.glob = s.get(W_GLOB);
         l.clog = s.get(W_CLOG);
-        for (int i = 0; i < NS; i++) { l.sv[i] = s.get(W_SRV(i)); l.log[i] = s.get(W_LOG(i)); }
+        #pragma unroll
+        for (int i = 0; i < NS; i++) { l.sv.set(i, s.get(W_SRV(i))); l.log.set(i, s.get(W_LOG(i))); }
         l.nm = g_nm(l.glob);
         l.inflight = 0;
         for (int k = 0; k < l.nm; k++) l.inflight += m_count(s.get(W_MSG0 + k));
         // allLogs' = allLogs \cup {log[i] : i \in Server} — the same for every successor of this state
         unsigned present = 0;
         const int na = g_na(l.glob);
+        const int wall = W_ALL0(prm);
         for (int a = 0; a < na; a++) {
-            const uint64_t x = s.get(W_ALL0 + a);
-            for (int i = 0; i < NS; i++) if (x == l.log[i]) present |= 1u << i;
+            const uint64_t x = s.get(wall + a);
+#pragma unroll
+            for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
         }
+        l.addmask = 0;
         l.nadd = 0;
         l.add_fp = 0;
+#pragma unroll
         for (int i = 0; i < NS; i++) {
-            if (present >> i & 1) continue;
-            bool dup = false;
-            for (int q = 0; q < l.nadd; q++) dup |= l.addlog[q] == l.log[i];
-            if (dup) continue;
-            l.addlog[l.nadd++] = l.log[i];
-            l.add_fp += hmix(l.log[i], SALT_A);
+            bool skip = (present >> i & 1) != 0;
+#pragma unroll
+            for (int q = 0; q < i; q++) skip |= l.log.get(q) == l.log.get(i);  // an equal log of a lower server is added instead
+            if (!skip) {
+                l.addmask |= 1u << i;
+                l.nadd++;
+                l.add_fp += hmix(l.log.get(i), SALT_A);
+            }
         }
     }
     MC_HD static int nslots(const Params &, const Local &l) { return FIX + 3 * l.nm; }
@@ -219,121 +265,135 @@ struct SpecRaft {
     struct Delta {
         uint64_t glob, clog;
         int srv;                 // the one server whose words change (-1: none)
-        uint64_t sv, log;
+        uint64_t sv, log;        // its new scalars / log
+        uint64_t osv, olog;      // ... and the old ones
         int vmode;               // 0 voterLog[srv] unchanged, 1 cleared, 2 one entry set
         int vj; uint64_t vlog;
-        int nmop, midx[2];       // message slots rewritten (midx == nm: appended)
-        uint64_t mold[2], mnew[2];
+        int nmop;                // message slots rewritten: op A (send) and op B (discard / dup)
+        int midxA, midxB;        // midx == nm: appended
+        uint64_t moldA, mnewA, moldB, mnewB;
         bool eadd;
-        uint64_t ew[EL_WORDS];
+        RegArr<EL_WORDS> ew;
         int dinflight;
     };
 
     // Send(m) / WithMessage   raft.tla:117-121,138: increment (saturating at 2) or add with count 1
     template <class Ref>
-    MC_HD static unsigned send(const Local &l, Ref s, uint64_t key_word /*count bits zero*/, Delta &d) {
+    MC_HD static unsigned send(const Local &l, Ref s, int cm, uint64_t key_word /*count bits zero*/, Delta &d) {
         int idx = l.nm;
         uint64_t old = 0;
         for (int k = 0; k < l.nm; k++) {
             const uint64_t x = s.get(W_MSG0 + k);
             if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; }
         }
-        // a slot already rewritten by this delta (cannot happen: response key /= request key)
-        const int q = d.nmop++;
-        d.midx[q] = idx;
-        d.mold[q] = old;
+        // op A; the discard of a Reply is op B (response key /= request key, so the slots differ)
+        d.nmop |= 1;
+        d.midxA = idx;
+        d.moldA = old;
         if (idx < l.nm) {
             const int c = m_count(old);
-            d.mnew[q] = c < 2 ? old + 1 : old;
+            d.mnewA = c < 2 ? old + 1 : old;
             d.dinflight += c < 2 ? 1 : 0;
             return 0u;
         }
-        d.mnew[q] = key_word | 1;
+        d.mnewA = key_word | 1;
         d.dinflight += 1;
-        return idx >= CM ? (unsigned)ST_OVERFLOW : 0u;
+        return idx >= cm ? (unsigned)ST_OVERFLOW : 0u;
     }
     // Discard(m) / WithoutMessage on the slot the message was read from   raft.tla:125-129,142
     MC_HD static void discard(int k, uint64_t mword, Delta &d) {
-        const int q = d.nmop++;
-        d.midx[q] = k;
-        d.mold[q] = mword;
+        d.nmop |= 2;
+        d.midxB = k;
+        d.moldB = mword;
         const int c = m_count(mword);
-        d.mnew[q] = c > 0 ? mword - 1 : mword;
+        d.mnewB = c > 0 ? mword - 1 : mword;
         d.dinflight -= c > 0 ? 1 : 0;
     }
 
     MC_HD static bool in_quorum(unsigned set) { return 2 * __builtin_popcount(set) > NS; }  // raft.tla:110
 
-    // compute the successor of `slot`; returns status bits (0 = not enabled)
+    // compute the successor of `slot`; returns status bits (0 = not enabled).  When `slot` is a
+    // compile-time constant (the unrolled FIX_SLOTS part of the expand kernel) every server index
+    // below folds to a constant and the pick()s disappear.
     template <class Ref>
     MC_HD static unsigned compute(const Params &prm, const Local &l, Ref s, int slot, Delta &d, int &action) {
-        d.glob = l.glob; d.clog = l.clog; d.srv = -1; d.sv = 0; d.log = 0; d.vmode = 0; d.vj = 0; d.vlog = 0;
-        d.nmop = 0; d.eadd = false; d.dinflight = 0;
+        d.glob = l.glob; d.clog = l.clog; d.srv = -1; d.sv = d.osv = 0; d.log = d.olog = 0; d.vmode = 0; d.vj = 0; d.vlog = 0;
+        d.nmop = 0; d.midxA = d.midxB = -1; d.moldA = d.mnewA = d.moldB = d.mnewB = 0;
+        d.eadd = false; d.dinflight = 0;
+        d.ew = RegArr<EL_WORDS>();
         unsigned st = ST_ENABLED;
         if (slot < NS) {  // Restart(i)   raft.tla:186-194 (always enabled)
             const int i = slot;
             action = RA_RESTART;
-            d.srv = i; d.log = l.log[i];
-            d.sv = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(l.sv[i], R_FOLLOWER), 0), 0), 1);
+            d.srv = i; d.osv = l.sv.get(i); d.olog = d.log = l.log.get(i);
+            d.sv = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(d.osv, R_FOLLOWER), 0), 0), 1);
             d.vmode = 1;
         } else if (slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
             const int i = slot - NS;
             action = RA_TIMEOUT;
-            const int stt = sv_state(l.sv[i]);
+            const uint64_t svi = l.sv.get(i);
+            const int stt = sv_state(svi);
             if (!(stt == R_FOLLOWER || stt == R_CANDIDATE)) return 0;
-            const int nt = sv_term(l.sv[i]) + 1;
+            const int nt = sv_term(svi) + 1;
             if (nt > prm.max_term) st |= ST_OUT_OF_MODEL;
-            d.srv = i; d.log = l.log[i];
-            d.sv = sv_set_granted(sv_set_voted(sv_set_term(sv_set_state(l.sv[i], R_CANDIDATE), nt & 7), 0), 0);
+            d.srv = i; d.osv = svi; d.olog = d.log = l.log.get(i);
+            d.sv = sv_set_granted(sv_set_voted(sv_set_term(sv_set_state(svi, R_CANDIDATE), nt & 7), 0), 0);
             d.vmode = 1;
         } else if (slot < 2 * NS + NS * NS) {  // RequestVote(i, j)   raft.tla:209-217
             const int q = slot - 2 * NS, i = q / NS, j = q % NS;
             action = RA_REQUESTVOTE;
-            if (sv_state(l.sv[i]) != R_CANDIDATE) return 0;
-            st |= send(l, s, mk_rvreq(sv_term(l.sv[i]), rlog::last_term(l.log[i]), rlog::len(l.log[i]), i, j), d);
+            const uint64_t svi = l.sv.get(i), lgi = l.log.get(i);
+            if (sv_state(svi) != R_CANDIDATE) return 0;
+            st |= send(l, s, prm.cm, mk_rvreq(sv_term(svi), rlog::last_term(lgi), rlog::len(lgi), i, j), d);
         } else if (slot < 3 * NS + NS * NS) {  // BecomeLeader(i)   raft.tla:247-261
             const int i = slot - (2 * NS + NS * NS);
             action = RA_BECOMELEADER;
-            if (sv_state(l.sv[i]) != R_CANDIDATE || !in_quorum(sv_granted(l.sv[i]))) return 0;
-            d.srv = i; d.log = l.log[i];
-            d.sv = sv_reset_leader_vars(sv_set_state(l.sv[i], R_LEADER), rlog::len(l.log[i]) + 1);
-            d.ew[0] = (uint64_t)sv_term(l.sv[i]) | ((uint64_t)i << 3) | ((uint64_t)sv_granted(l.sv[i]) << 6) | (l.log[i] << 11);
-            for (int j = 0; j < NS; j++) d.ew[1 + j] = s.get(W_VLOG(i, j));
+            const uint64_t svi = l.sv.get(i), lgi = l.log.get(i);
+            if (sv_state(svi) != R_CANDIDATE || !in_quorum(sv_granted(svi))) return 0;
+            d.srv = i; d.osv = svi; d.olog = d.log = lgi;
+            d.sv = sv_reset_leader_vars(sv_set_state(svi, R_LEADER), rlog::len(lgi) + 1);
+            const uint64_t ew0 = (uint64_t)sv_term(svi) | ((uint64_t)i << 3) | ((uint64_t)sv_granted(svi) << 6) | (lgi << 11);
+            d.ew.set(0, ew0);
+#pragma unroll
+            for (int j = 0; j < NS; j++) d.ew.set(1 + j, s.get(W_VLOG(i, j)));
             // elections \cup {...}: a set — an identical record changes nothing
             bool present = false;
-            const int ne = g_ne(l.glob);
+            const int ne = g_ne(l.glob), wel = W_EL0(prm);
             for (int e = 0; e < ne; e++) {
                 bool eq = true;
-                for (int q = 0; q < EL_WORDS; q++) eq &= s.get(W_EL0 + e * EL_WORDS + q) == d.ew[q];
+#pragma unroll
+                for (int q = 0; q < EL_WORDS; q++) eq &= s.get(wel + e * EL_WORDS + q) == d.ew.get(q);
                 present |= eq;
             }
             if (!present) {
                 d.eadd = true;
-                if (ne >= CE) st |= ST_OVERFLOW;
+                if (ne >= prm.ce) st |= ST_OVERFLOW;
                 d.glob += 1ull << 16;
             }
         } else if (slot < 4 * NS + NS * NS) {  // ClientRequest(i)   raft.tla:264-274
             const int i = slot - (3 * NS + NS * NS);
             action = RA_CLIENTREQUEST;
             const int creq = g_creq(l.glob);
-            if (sv_state(l.sv[i]) != R_LEADER || !(creq < prm.max_client_requests)) return 0;
-            if (rlog::len(l.log[i]) >= rlog::LCAP) return ST_ENABLED | ST_OVERFLOW;
-            d.srv = i; d.sv = l.sv[i];
-            d.log = rlog::append(l.log[i], rlog::mk_entry(sv_term(l.sv[i]), creq));
+            const uint64_t svi = l.sv.get(i), lgi = l.log.get(i);
+            if (sv_state(svi) != R_LEADER || !(creq < prm.max_client_requests)) return 0;
+            if (rlog::len(lgi) >= rlog::LCAP) return ST_ENABLED | ST_OVERFLOW;
+            d.srv = i; d.osv = d.sv = svi; d.olog = lgi;
+            d.log = rlog::append(lgi, rlog::mk_entry(sv_term(svi), creq));
             d.glob += 1;  // clientRequests' = clientRequests + 1
             if (rlog::len(d.log) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
         } else if (slot < 5 * NS + NS * NS) {  // AdvanceCommitIndex(i)   raft.tla:280-305
             const int i = slot - (4 * NS + NS * NS);
             action = RA_ADVANCECOMMIT;
-            if (sv_state(l.sv[i]) != R_LEADER) return 0;
-            const uint64_t lg = l.log[i];
+            const uint64_t svi = l.sv.get(i), lg = l.log.get(i);
+            if (sv_state(svi) != R_LEADER) return 0;
             int maxAgree = 0;
             for (int index = 1; index <= rlog::len(lg); index++) {
                 unsigned agree = 1u << i;  // Agree(index) == {i} \cup {k : matchIndex[i][k] >= index}
-                for (int k = 0; k < NS; k++) if (sv_match(l.sv[i], k) >= index) agree |= 1u << k;
+#pragma unroll
+                for (int k = 0; k < NS; k++) if (sv_match(svi, k) >= index) agree |= 1u << k;
                 if (in_quorum(agree)) maxAgree = index;
             }
-            const int nci = (maxAgree > 0 && rlog::eterm(rlog::entry(lg, maxAgree)) == sv_term(l.sv[i])) ? maxAgree : sv_commit(l.sv[i]);
+            const int nci = (maxAgree > 0 && rlog::eterm(rlog::entry(lg, maxAgree)) == sv_term(svi)) ? maxAgree : sv_commit(svi);
             uint64_t ncl = 0;
             if (nci > 1) {
                 if (nci > rlog::len(lg)) return ST_ENABLED | ST_SPECERR;  // log[i][j] out of domain
@@ -342,15 +402,15 @@ struct SpecRaft {
             const int lc = rlog::len(l.clog);
             bool decr = nci < lc;  // lazy \/ : the \E is evaluated only when nci >= Len(committedLog)
             if (!decr && lc > 0) decr = (((l.clog ^ ncl) >> 3) & ((1ull << (6 * lc)) - 1ull)) != 0;
-            d.srv = i; d.log = lg; d.sv = sv_set_commit(l.sv[i], nci);
+            d.srv = i; d.osv = svi; d.olog = d.log = lg; d.sv = sv_set_commit(svi, nci);
             d.clog = ncl;
             d.glob = bits_set(d.glob, 3, 1, decr ? 1 : 0);
         } else if (slot < FIX) {  // AppendEntries(i, j)   raft.tla:222-244
             const int q = slot - (5 * NS + NS * NS), i = q / NS, j = q % NS;
             action = RA_APPENDENTRIES;
-            if (i == j || sv_state(l.sv[i]) != R_LEADER) return 0;
-            const uint64_t lg = l.log[i];
-            const int next = sv_next(l.sv[i], j), prevIdx = next - 1;
+            const uint64_t svi = l.sv.get(i), lg = l.log.get(i);
+            if (i == j || sv_state(svi) != R_LEADER) return 0;
+            const int next = sv_next(svi, j), prevIdx = next - 1;
             int prevTerm = 0;
             if (prevIdx > 0) {
                 if (prevIdx > rlog::len(lg)) return ST_ENABLED | ST_SPECERR;
@@ -359,8 +419,8 @@ struct SpecRaft {
             const int lastEntry = rlog::len(lg) < next ? rlog::len(lg) : next;  // Min({Len(log[i]), nextIndex[i][j]})
             const int nent = next <= lastEntry ? 1 : 0;                        // SubSeq(log[i], next, lastEntry)
             const unsigned ent = nent ? rlog::entry(lg, next) : 0u;
-            const int ci = sv_commit(l.sv[i]) < lastEntry ? sv_commit(l.sv[i]) : lastEntry;
-            st |= send(l, s, mk_aereq(sv_term(l.sv[i]), prevIdx, prevTerm, nent, ent, ci, lg, i, j), d);
+            const int ci = sv_commit(svi) < lastEntry ? sv_commit(svi) : lastEntry;
+            st |= send(l, s, prm.cm, mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j), d);
         } else {
             const int q = slot - FIX, k = q / 3, kind = q % 3;
             if (k >= l.nm) return 0;
@@ -369,7 +429,7 @@ struct SpecRaft {
             if (kind == 1) {  // DuplicateMessage(m), m \in SingleMessage(messages)   raft.tla:134-135,471-473
                 action = RA_DUPLICATE;
                 if (cnt != 1) return 0;
-                d.nmop = 1; d.midx[0] = k; d.mold[0] = m; d.mnew[0] = m + 1; d.dinflight = 1;
+                d.nmop = 2; d.midxB = k; d.moldB = m; d.mnewB = m + 1; d.dinflight = 1;
             } else if (kind == 2) {  // DropMessage(m), m \in ValidMessage(messages)   raft.tla:131-132,476-478
                 action = RA_DROP;
                 if (cnt == 0) return 0;
@@ -378,9 +438,11 @@ struct SpecRaft {
                 action = RA_RECEIVE;
                 if (cnt == 0) return 0;
                 const int i = m_dst(m), j = m_src(m), mterm = m_term(m), type = m_type(m);
-                const uint64_t svi = l.sv[i], lg = l.log[i];
+                // i differs per lane here: read the words from the (read-only) state instead of
+                // select-indexing the register copy
+                const uint64_t svi = s.get(W_SRV(i)), lg = s.get(W_LOG(i));
                 const int term = sv_term(svi);
-                d.srv = i; d.sv = svi; d.log = lg;
+                d.srv = i; d.osv = d.sv = svi; d.olog = d.log = lg;
                 if (mterm > term) {  // UpdateTerm   raft.tla:434-440 (message not consumed)
                     d.sv = sv_set_voted(sv_set_state(sv_set_term(svi, mterm), R_FOLLOWER), 0);
                     if (mterm > prm.max_term) st |= ST_OUT_OF_MODEL;
@@ -389,7 +451,7 @@ struct SpecRaft {
                     const bool logOk = llt > lt || (llt == lt && lli >= rlog::len(lg));
                     const bool grant = mterm == term && logOk && (sv_voted(svi) == 0 || sv_voted(svi) == j + 1);
                     if (grant) d.sv = sv_set_voted(svi, j + 1);
-                    st |= send(l, s, mk_rvresp(term, grant ? 1 : 0, lg, i, j), d);  // Reply(response, m)
+                    st |= send(l, s, prm.cm, mk_rvresp(term, grant ? 1 : 0, lg, i, j), d);  // Reply(response, m)
                     discard(k, m, d);
                 } else if (type == M_RVRESP) {
                     if (mterm == term) {  // HandleRequestVoteResponse   raft.tla:336-349
@@ -408,7 +470,7 @@ struct SpecRaft {
                     const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg);
                     const bool logOk = pidx == 0 || (pidx > 0 && pidx <= len && pterm == rlog::eterm(rlog::entry(lg, pidx)));
                     if (mterm < term || (mterm == term && stt == R_FOLLOWER && !logOk)) {  // reject   :361-373
-                        st |= send(l, s, mk_aeresp(term, 0, 0, i, j), d);
+                        st |= send(l, s, prm.cm, mk_aeresp(term, 0, 0, i, j), d);
                         discard(k, m, d);
                     } else if (stt == R_CANDIDATE) {  // return to follower state   :374-378 (mterm = term here)
                         d.sv = sv_set_state(svi, R_FOLLOWER);
@@ -417,7 +479,7 @@ struct SpecRaft {
                         if (nent == 0 || (len >= index && rlog::eterm(rlog::entry(lg, index)) == rlog::eterm(ent))) {
                             // already done with request   :384-402; commitIndex' assigned AND UNCHANGED
                             if (mci != sv_commit(svi)) return 0;
-                            st |= send(l, s, mk_aeresp(term, 1, pidx + nent, i, j), d);
+                            st |= send(l, s, prm.cm, mk_aeresp(term, 1, pidx + nent, i, j), d);
                             discard(k, m, d);
                         } else if (len >= index) {  // conflict: remove 1 entry   :403-410
                             d.log = rlog::drop_last(lg);
@@ -446,16 +508,17 @@ struct SpecRaft {
             }
         }
         // bookkeeping shared by every action: counts in the globals word
-        for (int q = 0; q < d.nmop; q++) if (d.midx[q] >= l.nm) d.glob += 1ull << 8;
+        if ((d.nmop & 1) && d.midxA >= l.nm) d.glob += 1ull << 8;
         if (l.nadd) {
-            if (g_na(l.glob) + l.nadd > CA) st |= ST_OVERFLOW;
+            if (g_na(l.glob) + l.nadd > prm.ca) st |= ST_OVERFLOW;
             d.glob += (uint64_t)l.nadd << 24;
         }
         if (l.inflight + d.dinflight > prm.max_msgs) st |= ST_OUT_OF_MODEL;
         // invariants on the successor (the parent satisfies them, so only the changed server matters)
         if ((prm.inv_mask & 1) && d.srv >= 0 && sv_state(d.sv) == R_LEADER) {  // NoTwoLeaders   raft.tla:500-507
+#pragma unroll
             for (int j = 0; j < NS; j++)
-                if (j != d.srv && sv_state(l.sv[j]) == R_LEADER && sv_term(l.sv[j]) == sv_term(d.sv)) st |= ST_INVARIANT;
+                if (j != d.srv && sv_state(l.sv.get(j)) == R_LEADER && sv_term(l.sv.get(j)) == sv_term(d.sv)) st |= ST_INVARIANT;
         }
         if ((prm.inv_mask & 2) && !(st & ST_INVARIANT) && g_decr(d.glob)) st |= ST_INVARIANT | (1u << 8);  // CommittedLogStable
         return st;
@@ -468,9 +531,11 @@ struct SpecRaft {
         if (d.clog != l.clog) fp += hmix(d.clog, salt_of(W_CLOG)) - hmix(l.clog, salt_of(W_CLOG));
         if (d.srv >= 0) {
             const int i = d.srv;
-            if (d.sv != l.sv[i]) fp += hmix(d.sv, salt_of((unsigned)W_SRV(i))) - hmix(l.sv[i], salt_of((unsigned)W_SRV(i)));
-            if (d.log != l.log[i]) fp += hmix(d.log, salt_of((unsigned)W_LOG(i))) - hmix(l.log[i], salt_of((unsigned)W_LOG(i)));
+            const uint64_t osv = d.osv, olog = d.olog;
+            if (d.sv != osv) fp += hmix(d.sv, salt_of((unsigned)W_SRV(i))) - hmix(osv, salt_of((unsigned)W_SRV(i)));
+            if (d.log != olog) fp += hmix(d.log, salt_of((unsigned)W_LOG(i))) - hmix(olog, salt_of((unsigned)W_LOG(i)));
             if (d.vmode == 1) {
+#pragma unroll
                 for (int j = 0; j < NS; j++) {
                     const uint64_t x = s.get(W_VLOG(i, j));
                     if (x) fp += hmix(0, salt_of((unsigned)W_VLOG(i, j))) - hmix(x, salt_of((unsigned)W_VLOG(i, j)));
@@ -479,10 +544,11 @@ struct SpecRaft {
                 fp += hmix(d.vlog, salt_of((unsigned)W_VLOG(i, d.vj))) - hmix(0, salt_of((unsigned)W_VLOG(i, d.vj)));
             }
         }
-        for (int q = 0; q < d.nmop; q++) {
-            if (d.midx[q] < l.nm) fp -= hmix(d.mold[q], SALT_M);
-            fp += hmix(d.mnew[q], SALT_M);
+        if (d.nmop & 1) {
+            if (d.midxA < l.nm) fp -= hmix(d.moldA, SALT_M);
+            fp += hmix(d.mnewA, SALT_M);
         }
+        if (d.nmop & 2) fp += hmix(d.mnewB, SALT_M) - hmix(d.moldB, SALT_M);
         if (d.eadd) fp += helec(d.ew);
         return fp;
     }
@@ -504,17 +570,20 @@ struct SpecRaft {
         Delta d;
         int action;
         const unsigned st = compute(prm, l, s, slot, d, action);
+        const int nw = words(prm);
         if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) {
-            for (int w = 0; w < WORDS; w++) out.set(w, s.get(w));
+            for (int w = 0; w < nw; w++) out.set(w, s.get(w));
             return st;
         }
         out.set(W_FP, delta_fp(l, s, d));
         out.set(W_GLOB, d.glob);
         out.set(W_CLOG, d.clog);
+#pragma unroll
         for (int i = 0; i < NS; i++) {
             const bool me = i == d.srv;
-            out.set(W_SRV(i), me ? d.sv : l.sv[i]);
-            out.set(W_LOG(i), me ? d.log : l.log[i]);
+            out.set(W_SRV(i), me ? d.sv : l.sv.get(i));
+            out.set(W_LOG(i), me ? d.log : l.log.get(i));
+#pragma unroll
             for (int j = 0; j < NS; j++) {
                 uint64_t x = s.get(W_VLOG(i, j));
                 if (me && d.vmode == 1) x = 0;
@@ -523,24 +592,26 @@ struct SpecRaft {
             }
         }
         const int nm2 = g_nm(d.glob);
-        for (int k = 0; k < CM; k++) {
+        for (int k = 0; k < prm.cm; k++) {
             uint64_t x = k < l.nm ? s.get(W_MSG0 + k) : 0;
-            for (int q = 0; q < d.nmop; q++) if (d.midx[q] == k) x = d.mnew[q];
+            if ((d.nmop & 1) && d.midxA == k) x = d.mnewA;
+            if ((d.nmop & 2) && d.midxB == k) x = d.mnewB;
             out.set(W_MSG0 + k, k < nm2 ? x : 0);
         }
-        const int ne = g_ne(l.glob);
-        for (int e = 0; e < CE; e++)
+        const int ne = g_ne(l.glob), wel = W_EL0(prm);
+        for (int e = 0; e < prm.ce; e++)
+#pragma unroll
             for (int q = 0; q < EL_WORDS; q++) {
-                uint64_t x = e < ne ? s.get(W_EL0 + e * EL_WORDS + q) : 0;
-                if (d.eadd && e == ne) x = d.ew[q];
-                out.set(W_EL0 + e * EL_WORDS + q, x);
+                uint64_t x = e < ne ? s.get(wel + e * EL_WORDS + q) : 0;
+                if (d.eadd && e == ne) x = d.ew.get(q);
+                out.set(wel + e * EL_WORDS + q, x);
             }
-        const int na = g_na(l.glob);
-        for (int a = 0; a < CA; a++) {
-            uint64_t x = a < na ? s.get(W_ALL0 + a) : 0;
-            if (a >= na && a - na < l.nadd) x = l.addlog[a - na];
-            out.set(W_ALL0 + a, x);
-        }
+        const int na = g_na(l.glob), wall = W_ALL0(prm);
+        for (int a = 0; a < prm.ca; a++) out.set(wall + a, a < na ? s.get(wall + a) : 0);
+        int pos = na;
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+            if (l.addmask >> i & 1) { if (pos < prm.ca) out.set(wall + pos, l.log.get(i)); pos++; }
         return st;
     }
 
@@ -623,12 +694,11 @@ struct SpecRaft {
         o.put("%s", close);
     }
     // canonical TLA+ text (same format as oracle/spec_raft.c:raft_print; sets sorted by text)
-    static int format(const Params &, const uint64_t *w, char *buf, size_t cap) {
+    static int format(const Params &prm, const uint64_t *w, char *buf, size_t cap) {
         static const char *stn[] = {"Follower", "Candidate", "Leader", "?"};
         Txt o{buf, cap, 0};
         char tmp[2048];
-        constexpr int MAXIT = CM > CA ? (CM > CE ? CM : CE) : (CA > CE ? CA : CE);
-        char *it[MAXIT];
+        char *it[64];
         const uint64_t g = w[W_GLOB];
         o.put("/\\ messages = ");
         for (int k = 0; k < g_nm(g); k++) { Txt e{tmp, sizeof tmp, 0}; t_msg(e, w[W_MSG0 + k]); e.put(" :> %d", m_count(w[W_MSG0 + k])); it[k] = strndup(tmp, e.k); }
@@ -636,7 +706,7 @@ struct SpecRaft {
         o.put("\n/\\ elections = ");
         for (int x = 0; x < g_ne(g); x++) {
             Txt e{tmp, sizeof tmp, 0};
-            const uint64_t *ew = w + W_EL0 + x * EL_WORDS;
+            const uint64_t *ew = w + W_EL0(prm) + x * EL_WORDS;
             const unsigned votes = (unsigned)(ew[0] >> 6 & 31);
             e.put("[eleader |-> s%d, elog |-> ", (int)(ew[0] >> 3 & 7) + 1); t_log(e, (ew[0] >> 11) & ((1ull << 33) - 1ull));
             e.put(", eterm |-> %d, evoterLog |-> ", (int)(ew[0] & 7)); t_vlog(e, votes, ew + 1);
@@ -645,7 +715,7 @@ struct SpecRaft {
         }
         t_sorted(o, it, g_ne(g), "{", ", ", "}", "{}");
         o.put("\n/\\ allLogs = ");
-        for (int a = 0; a < g_na(g); a++) { Txt e{tmp, sizeof tmp, 0}; t_log(e, w[W_ALL0 + a]); it[a] = strndup(tmp, e.k); }
+        for (int a = 0; a < g_na(g); a++) { Txt e{tmp, sizeof tmp, 0}; t_log(e, w[W_ALL0(prm) + a]); it[a] = strndup(tmp, e.k); }
         t_sorted(o, it, g_na(g), "{", ", ", "}", "{}");
 #define MC_PER_SERVER(title, expr)                                                             \
     o.put("\n/\\ " title " = (");                                                              \

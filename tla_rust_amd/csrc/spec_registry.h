@@ -10,9 +10,10 @@ namespace mc {
 
 // capacities of the unordered slot arrays (messages / elections / allLogs); exceeding one
 // raises MC_EOVERFLOW, never silently drops
-using SpecRaft2 = SpecRaft<2, 32, 4, 16>;
-using SpecRaft3 = SpecRaft<3, 40, 4, 16>;
-using SpecRaft5 = SpecRaft<5, 56, 6, 24>;
+// (defaults 40 / 4 / 16, overridable through params[6..8] of MC_SPEC_RAFT)
+using SpecRaft2 = SpecRaft<2>;
+using SpecRaft3 = SpecRaft<3>;
+using SpecRaft5 = SpecRaft<5>;
 
 template <class F>
 int dispatch_spec(const mc_spec_desc *d, F &&f) {
