@@ -42,14 +42,23 @@ static void set_error(const std::string &s) { g_last_error = s; }
         }                                                                                          \
     } while (0)
 
+// Device-resident counters.  One word saturates at ~88 returning atomics/us (MI355X_MICROARCH.md
+// "dequeue"), and atomics to the same cache line serialise, so everything the hot kernels bump
+// once per wavefront is sharded 8 ways (shard = blockIdx.x & 7, i.e. roughly per XCD) with each
+// shard on its own 128-byte line.
+constexpr int NSHARD = 8;
+struct alignas(128) PaddedCounter {
+    unsigned long long v;
+    unsigned long long pad[15];
+};
 struct DevCounters {
-    unsigned long long generated;
-    unsigned long long n_new;       // survivors of the current chunk
-    unsigned long long arena_next;  // next free arena index
-    unsigned long long viol_key;    // min over (idx << 24 | slot << 8 | kind); ~0 = none
-    unsigned long long cells;       // candidate cells probed
-    unsigned int max_slots;         // rows of the candidate matrix written by the current chunk
-    unsigned int error;             // DEV_E* bits
+    PaddedCounter n_new[NSHARD];      // survivors of the current chunk, per new-list segment
+    PaddedCounter generated[NSHARD];  // successors generated
+    PaddedCounter cells[NSHARD];      // seen-set probes issued
+    unsigned long long arena_next;    // next free arena index
+    unsigned long long viol_key;      // min over (idx << 24 | slot << 8 | kind); ~0 = none
+    unsigned int max_slots;           // rows of the candidate matrix written by the current chunk
+    unsigned int error;               // DEV_E* bits
 };
 enum : unsigned { DEV_ETABLE = 1u, DEV_EARENA = 2u, DEV_EOVERFLOW = 4u };
 enum : unsigned { VK_INVARIANT = 1, VK_ASSERT = 2, VK_DEADLOCK = 3, VK_SPECERR = 4 };
@@ -127,7 +136,7 @@ k_expand(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo
     const unsigned long long vmin = wave_min_u64(viol);
     const unsigned eor = wave_or_u32(err);
     if ((threadIdx.x & 63) == 0) {
-        if (gsum) atomicAdd(&ctr->generated, (unsigned long long)gsum);
+        if (gsum) atomicAdd(&ctr->generated[blockIdx.x & (NSHARD - 1)].v, (unsigned long long)gsum);
         if (wns) atomicMax(&ctr->max_slots, (unsigned)wns);
         if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
         if (eor) atomicOr(&ctr->error, eor);
@@ -159,7 +168,7 @@ k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__
     const unsigned gsum = wave_sum_u32(gen);
     const unsigned long long vmin = wave_min_u64(viol);
     if ((threadIdx.x & 63) == 0) {
-        if (gsum) atomicAdd(&ctr->generated, (unsigned long long)gsum);
+        if (gsum) atomicAdd(&ctr->generated[0].v, (unsigned long long)gsum);
         atomicMax(&ctr->max_slots, 1u);
         if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
     }
@@ -184,7 +193,7 @@ __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t mask, uint
 
 __global__ void __launch_bounds__(256)
 k_insert(const uint64_t *__restrict__ cand, uint64_t row_stride, uint64_t ncols, const uint16_t *__restrict__ nsl,
-         uint64_t *table, uint64_t mask, uint64_t *__restrict__ newlist, DevCounters *ctr) {
+         uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, DevCounters *ctr) {
     const unsigned slot = blockIdx.y;
     if (slot >= ctr->max_slots) return;
     const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,13 +212,13 @@ k_insert(const uint64_t *__restrict__ cand, uint64_t row_stride, uint64_t ncols,
     unsigned long long base = 0;
     const unsigned np = wave_sum_u32(probed);
     if (lane == 0) {
-        if (ballot) base = atomicAdd(&ctr->n_new, (unsigned long long)__popcll(ballot));
-        if (np) atomicAdd(&ctr->cells, (unsigned long long)np);
+        if (ballot) base = atomicAdd(&ctr->n_new[0].v, (unsigned long long)__popcll(ballot));
+        if (np) atomicAdd(&ctr->cells[0].v, (unsigned long long)np);
     }
     base = __shfl(base, 0);
     if (is_new) {
         const unsigned rank = (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
-        newlist[base + rank] = col | ((uint64_t)slot << 40);
+        newlist[base + rank] = (uint32_t)col | ((uint32_t)slot << 24);
     }
     if (wave_or_u32(err) && lane == 0) atomicOr(&ctr->error, DEV_ETABLE);
 }
@@ -233,7 +242,21 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 struct WaveQueues {
-    uint64_t q_fp[QCAP], q_src[QCAP], o_src[QCAP];
+    uint64_t q_fp[QCAP];
+    uint32_t q_src[QCAP], o_src[QCAP];  // (slot << 24) | column: chunks hold <= 2^24 states, specs <= 255 slots
+};
+constexpr int STAGE_MAX = 16;  // words of each parent state staged in LDS per lane (spec-chosen range)
+
+// View of a parent state whose words [lo, lo+n) have been staged in LDS by the owning lane
+// (lds points at this lane's column: word w of the range lives at lds[w * 64]).
+struct StagedRef {
+    const uint64_t *p;
+    size_t stride;
+    const uint64_t *lds;
+    int lo, hi;
+    __device__ __forceinline__ uint64_t get(int w) const {
+        return (w >= lo && w < hi) ? lds[(w - lo) * 64] : p[(size_t)w * stride];
+    }
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -244,8 +267,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <class S>
 __global__ void __launch_bounds__(256)
 k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
-                uint64_t *table, uint64_t mask, uint64_t *__restrict__ newlist, DevCounters *ctr, unsigned flags) {
+                uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags) {
     __shared__ WaveQueues wq[4];
+    __shared__ uint64_t stage[4][S::STAGE_WORDS > 0 ? S::STAGE_WORDS : 1][64];
     const unsigned lane = threadIdx.x & 63;
     WaveQueues &Q = wq[threadIdx.x >> 6];
     const uint64_t base = lo & ~63ull;
@@ -253,7 +277,26 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     if (col >= ncols) return;  // whole wavefronts leave together (ncols % 64 == 0)
     const uint64_t idx = base + col;
     const bool active = idx >= lo && idx < hi;
-    const CWordRef s = arena_cref(arena, idx, S::words(prm));
+    const CWordRef g = arena_cref(arena, idx, S::words(prm));
+    // Stage the spec-chosen word range of every parent (raft: the message slots, which each Send
+    // scans) in LDS: the loads are independent and coalesced, the later scans hit LDS.
+    using Ref = typename std::conditional<(S::STAGE_WORDS > 0), StagedRef, CWordRef>::type;
+    Ref s;
+    if constexpr (S::STAGE_WORDS > 0) {
+        int slo = 0, sn = 0;
+        if (active) S::stage_range(prm, g, slo, sn);
+        const int wn = min((int)wave_max_u32((unsigned)sn), (int)S::STAGE_WORDS);
+        slo = (int)wave_max_u32((unsigned)slo);
+        uint64_t *col_lds = &stage[threadIdx.x >> 6][0][lane];
+        uint64_t tmp[S::STAGE_WORDS];
+#pragma unroll
+        for (int w = 0; w < S::STAGE_WORDS; w++) tmp[w] = (active && w < wn) ? g.get(slo + w) : 0;
+#pragma unroll
+        for (int w = 0; w < S::STAGE_WORDS; w++) if (w < wn) col_lds[w * 64] = tmp[w];
+        s = StagedRef{g.p, g.stride, col_lds, slo, slo + wn};
+    } else {
+        s = g;
+    }
     typename S::Local loc;
     int ns = 0;
     if (active) {
@@ -264,18 +307,20 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     unsigned gen = 0, err = 0, probes = 0;
     unsigned long long viol = ~0ull;
     unsigned qhead = 0, qn = 0, ohead = 0, on = 0;  // wave-uniform ring state
+    const unsigned shard = blockIdx.x & (NSHARD - 1);
+    uint32_t *__restrict__ seg = newlist + (uint64_t)shard * seg_cap;  // this shard's new-list segment
 
     auto flush_out = [&](unsigned take) {  // append `take` survivors to the global new-list
         unsigned long long pos = 0;
-        if (lane == 0) pos = atomicAdd(&ctr->n_new, (unsigned long long)take);
+        if (lane == 0) pos = atomicAdd(&ctr->n_new[shard].v, (unsigned long long)take);
         pos = __shfl(pos, 0);
-        if (lane < take) newlist[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
+        if (lane < take) seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
         ohead = (ohead + take) & (QCAP - 1);
         on -= take;
     };
     auto flush_probe = [&](unsigned take) {  // probe `take` queued fingerprints, one per lane
         bool is_new = false;
-        uint64_t src = 0;
+        uint32_t src = 0;
         if (lane < take) {
             const unsigned k = (qhead + lane) & (QCAP - 1);
             src = Q.q_src[k];
@@ -312,7 +357,7 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             if (fp) {
                 const unsigned k = (qhead + qn + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
                 Q.q_fp[k] = fp;
-                Q.q_src[k] = col | ((uint64_t)slot << 40);
+                Q.q_src[k] = (uint32_t)col | ((uint32_t)slot << 24);
             }
             qn += (unsigned)__popcll(b);
             wave_lds_fence();
@@ -331,8 +376,8 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     const unsigned long long vmin = wave_min_u64(viol);
     const unsigned eor = wave_or_u32(err);
     if (lane == 0) {
-        if (gsum) atomicAdd(&ctr->generated, (unsigned long long)gsum);
-        if (probes) atomicAdd(&ctr->cells, (unsigned long long)probes);
+        if (gsum) atomicAdd(&ctr->generated[shard].v, (unsigned long long)gsum);
+        if (probes) atomicAdd(&ctr->cells[shard].v, (unsigned long long)probes);
         if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
         if (eor) atomicOr(&ctr->error, eor);
     }
@@ -341,14 +386,18 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
 // ------------------------------------------------------------------------------------- materialise
 template <class S>
 __global__ void __launch_bounds__(256)
-k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint64_t *__restrict__ newlist,
+k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint32_t *__restrict__ newlist, uint64_t seg_cap,
               uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr) {
-    const uint64_t n = ctr->n_new, out0 = ctr->arena_next;
+    const unsigned sh = blockIdx.y;  // new-list segment
+    const uint64_t n = ctr->n_new[sh].v;
+    uint64_t out0 = ctr->arena_next;
+    for (unsigned t = 0; t < sh; t++) out0 += ctr->n_new[t].v;
+    const uint32_t *__restrict__ seg = newlist + (uint64_t)sh * seg_cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const uint64_t src = newlist[j];
-        const uint64_t pidx = chunk_base + (src & ((1ull << 40) - 1ull));
-        const int slot = (int)(src >> 40);
+        const uint32_t src = seg[j];
+        const uint64_t pidx = chunk_base + (src & 0xffffffu);
+        const int slot = (int)(src >> 24);
         const uint64_t oidx = out0 + j;
         if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); continue; }
         S::apply(prm, arena_cref(arena, pidx, S::words(prm)), slot, arena_ref(arena, oidx, S::words(prm)));
@@ -358,13 +407,13 @@ k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, cons
 template <class S>
 __global__ void __launch_bounds__(256)
 k_init_materialise(typename S::Params prm, uint64_t *arena, uint64_t first, const uint64_t *__restrict__ tmp,
-                   const uint64_t *__restrict__ newlist, uint64_t arena_cap, uint32_t *__restrict__ parent,
+                   const uint32_t *__restrict__ newlist, uint64_t arena_cap, uint32_t *__restrict__ parent,
                    uint16_t *__restrict__ pslot, DevCounters *ctr) {
-    const uint64_t n = ctr->n_new, out0 = ctr->arena_next;
+    const uint64_t n = ctr->n_new[0].v, out0 = ctr->arena_next;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const int W = S::words(prm);
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const uint64_t col = newlist[j] & ((1ull << 40) - 1ull);
+        const uint64_t col = newlist[j] & 0xffffffu;
         const uint64_t oidx = out0 + j;
         if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); continue; }
         const WordRef o = arena_ref(arena, oidx, W);
@@ -381,8 +430,9 @@ k_gather_states(const uint64_t *__restrict__ arena, int words, uint64_t first, u
     out[t] = arena[((idx >> 6) * (uint64_t)words + w) * 64 + (idx & 63)];
 }
 __global__ void k_commit(DevCounters *ctr) {
-    ctr->arena_next += ctr->n_new;
-    ctr->n_new = 0;
+    unsigned long long n = 0;
+    for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; }
+    ctr->arena_next += n;
     ctr->max_slots = 0;
 }
 
@@ -434,12 +484,13 @@ struct Engine : EngineBase {
     mc_spec_desc desc;
     mc_config cfg;
     hipStream_t stream = nullptr;
-    uint64_t *d_arena = nullptr, *d_table = nullptr, *d_cand = nullptr, *d_newlist = nullptr;
+    uint64_t *d_arena = nullptr, *d_table = nullptr, *d_cand = nullptr;
+    uint32_t *d_newlist = nullptr;
     uint16_t *d_nsl = nullptr, *d_pslot = nullptr;
     uint64_t *d_inittmp = nullptr;
     uint32_t *d_parent = nullptr;
     DevCounters *d_ctr = nullptr, *h_ctr = nullptr;
-    uint64_t table_cap = 0, arena_cap = 0, chunk = 0, row_stride = 0;
+    uint64_t table_cap = 0, arena_cap = 0, chunk = 0, row_stride = 0, seg_cap = 0;
     KTimer timer;
     mc_kernel_stat kstat[3];
     // counterexample of the last run
@@ -459,11 +510,14 @@ struct Engine : EngineBase {
         if (arena_cap >= (1ull << 32) - 1) { set_error("arena_capacity must be < 2^32 states"); return MC_EBADCFG; }
         chunk = cfg.chunk_states ? cfg.chunk_states : (1ull << 18);
         chunk = (chunk + 255) & ~255ull;
+        if (chunk > (1ull << 23)) chunk = 1ull << 23;  // a column index must fit 24 bits
+        if (max_slots > 255) { set_error("spec has more than 255 action slots per state"); return MC_EBADCFG; }
         row_stride = chunk + 256;
         HIP_TRY(hipMalloc(&d_arena, arena_cap * W * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&d_table, table_cap * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&d_cand, (size_t)(use_matrix ? max_slots : 1) * row_stride * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&d_newlist, (size_t)max_slots * row_stride * sizeof(uint64_t)));
+        seg_cap = (row_stride / NSHARD + 256) * max_slots;
+        HIP_TRY(hipMalloc(&d_newlist, (size_t)NSHARD * seg_cap * sizeof(uint32_t)));
         {
             const uint64_t ni = S::num_init(prm);
             HIP_TRY(hipMalloc(&d_inittmp, (size_t)(ni < chunk ? ni : chunk) * W * sizeof(uint64_t)));
@@ -519,10 +573,10 @@ struct Engine : EngineBase {
     bool use_matrix = false;
     void finish_materialise(uint64_t chunk_base, uint64_t ncols) {
         const unsigned bx = (unsigned)((ncols + 255) / 256);
-        const unsigned gm = bx < 2048 ? bx : 2048;
+        const unsigned gm = bx < 8 * 256 ? (bx + 7) / 8 : 256;
         timed(2, 0, [&] {
-            hipLaunchKernelGGL(k_materialise<S>, dim3(gm), dim3(256), 0, stream, prm, d_arena, chunk_base, d_newlist, arena_cap,
-                               d_parent, d_pslot, d_ctr);
+            hipLaunchKernelGGL(k_materialise<S>, dim3(gm, NSHARD), dim3(256), 0, stream, prm, d_arena, chunk_base, d_newlist,
+                               seg_cap, arena_cap, d_parent, d_pslot, d_ctr);
         });
         hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
     }
@@ -540,8 +594,8 @@ struct Engine : EngineBase {
                 hipLaunchKernelGGL(k_init_materialise<S>, dim3(gm), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
                                    d_inittmp, d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
             else
-                hipLaunchKernelGGL(k_materialise<S>, dim3(gm), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
-                                   d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
+                hipLaunchKernelGGL(k_materialise<S>, dim3(gm, 1), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
+                                   d_newlist, seg_cap, arena_cap, d_parent, d_pslot, d_ctr);
         });
         hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
     }
@@ -597,7 +651,7 @@ struct Engine : EngineBase {
                 } else {
                     timed(0, c1 - c0, [&] {
                         hipLaunchKernelGGL(k_expand_insert<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm,
-                                           d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, d_ctr, cfg.flags);
+                                           d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags);
                     });
                     finish_materialise(base, ncols);
                 }
@@ -619,11 +673,12 @@ struct Engine : EngineBase {
         out->distinct = h_ctr->arena_next;
         last_distinct = h_ctr->arena_next;
         kstat[2].units = h_ctr->arena_next;
-        out->generated = h_ctr->generated;
+        out->generated = 0;
+        kstat_cells = 0;
+        for (int t = 0; t < NSHARD; t++) { out->generated += h_ctr->generated[t].v; kstat_cells += h_ctr->cells[t].v; }
         out->queue_left = hi - lo;
         out->depth = level;
         out->levels = level;
-        kstat_cells = h_ctr->cells;
         if (h_ctr->viol_key != ~0ull) {
             have_viol = true;
             last_viol = h_ctr->viol_key;

@@ -24,7 +24,7 @@ namespace mc {
 //   0 = Check, 1..N = Increment(self), N+1 = terminating stutter.
 struct SpecAtomicAdd {
     struct Params { int n; };
-    static constexpr int MAX_WORDS = 1, FIX_SLOTS = 0;
+    static constexpr int MAX_WORDS = 1, FIX_SLOTS = 0, STAGE_WORDS = 0;
     MC_HD static int words(const Params &) { return 1; }
     MC_HD static int max_slots(const Params &p) { return p.n + 2; }
     static constexpr uint64_t SALT = 0x5bd1e9955bd1e995ull;
@@ -97,7 +97,7 @@ struct SpecAtomicAdd {
 // Slots: self = TransProc(self) for self < P (at most one label is enabled), P = termination.
 struct SpecPcalIntro {
     struct Params { int variant, check_inv, max_money, nproc; };
-    static constexpr int MAX_WORDS = 1, FIX_SLOTS = 0;
+    static constexpr int MAX_WORDS = 1, FIX_SLOTS = 0, STAGE_WORDS = 0;
     MC_HD static int words(const Params &) { return 1; }
     MC_HD static int max_slots(const Params &p) { return p.nproc + 1; }
     static constexpr uint64_t SALT = 0x27d4eb2f165667c5ull;

@@ -105,6 +105,9 @@ struct SpecRaft {
     //        AdvanceCommitIndex NS | AppendEntries NS^2 | per message k: Receive, Duplicate, Drop
     static constexpr int FIX = 5 * NS + 2 * NS * NS;
     static constexpr int FIX_SLOTS = FIX;  // slots whose action and server indices are compile-time constants
+    static constexpr int STAGE_WORDS = 16; // message slots of each parent the expand kernel stages in LDS
+    template <class Ref>
+    MC_HD static void stage_range(const Params &, Ref s, int &lo, int &n) { lo = W_MSG0; n = g_nm(s.get(W_GLOB)); }
     MC_HD static int max_slots(const Params &p) { return FIX + 3 * p.cm; }
     static constexpr uint64_t SALT_M = 0x8f1bbcdc8f1bbcdcull, SALT_E = 0xca62c1d6ca62c1d6ull, SALT_A = 0x5a8279995a827999ull;
 
