@@ -64,23 +64,26 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run: sharded path, RCCL all-to-all
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    if world == 1:
+    if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << a.table_log2, matrix=a.matrix,
                          arena_capacity=30_000_000 if a.max_distinct <= 25_000_000 else 2 * a.max_distinct,
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run
     else:
         from tla_rust_amd.sharded import ShardedChecker
+        # weak scaling: the distinct-state budget grows with the number of GPUs
         chk = ShardedChecker(WORKLOAD["spec"], WORKLOAD["params"], device=local, max_distinct=a.max_distinct * world,
-                             chunk_states=a.chunk)
+                             chunk_states=min(a.chunk, 1 << 19), table_capacity=1 << 27, arena_capacity=48_000_000,
+                             fanout_cap=24, new_cap=6)
         run = chk.run
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -93,7 +96,7 @@ def main():
         res = run()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -107,7 +110,10 @@ def main():
         "config": {"workload": WORKLOAD["name"], "distinct": D, "generated": G, "depth": res.depth,
                    "verdict": res.verdict, "generated_per_s": G * a.steps / dt},
     }
-    if world == 1:
+    if use_dist:
+        line["config"]["parallelism"] = f"fingerprint-sharded seen-set x{world}, two-phase all-to-all over RCCL"
+        dist.destroy_process_group()
+    else:
         ks = eng.kernel_stats()
         W = ks["state_bytes"]
         # algorithmic bytes per launch: expand reads W per frontier state,

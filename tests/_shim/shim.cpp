@@ -135,3 +135,140 @@ extern "C" size_t shim_state_bytes(const mc_spec_desc *d) {
     dispatch_spec(d, [&](auto spec, const auto &prm) { n = sizeof(uint64_t) * decltype(spec)::words(prm); return 0; });
     return n;
 }
+
+// ------------------------------------------------------------------------------------------
+// Host emulation of the sharded step API (mc_shard_* of include/tlamc.h), same semantics, plain
+// host pointers.  Used only by the world_size-2 gloo tests of tla_rust_amd/sharded.py.
+struct ShimShardBase {
+    virtual ~ShimShardBase() {}
+    virtual int begin() = 0;
+    virtual uint64_t level_size() = 0;
+    virtual int expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
+    virtual int probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) = 0;
+    virtual int materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
+    virtual int ingest(const uint8_t *recv_states, uint64_t n) = 0;
+    virtual uint64_t end_level() = 0;
+    virtual void counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
+};
+
+template <class S>
+struct ShimShard : ShimShardBase {
+    typename S::Params prm;
+    uint32_t rank, nranks;
+    int W;
+    std::vector<uint64_t> arena;
+    std::unordered_set<uint64_t> seen;
+    uint64_t lo = 0, hi = 0, generated = 0;
+    int32_t verdict = MC_V_OK;
+    struct Pending { uint64_t parent; int slot; };
+    std::vector<Pending> pending;          // aligned with the compacted send_fp order
+    std::vector<uint64_t> pend_off;        // per-owner offsets into pending
+
+    uint64_t nstates() const { return arena.size() / (size_t)W; }
+    int begin() override {
+        W = S::words(prm);
+        arena.clear(); seen.clear(); generated = 0; verdict = MC_V_OK;
+        uint64_t tmp[S::MAX_WORDS];
+        for (uint64_t k = 0; k < S::num_init(prm); k++) {
+            S::init(prm, k, WordRef{tmp, 1});
+            const unsigned st = S::init_status(prm, CWordRef{tmp, 1});
+            const uint64_t fp = (st & ST_OUT_OF_MODEL) ? 0 : S::fp_of(prm, CWordRef{tmp, 1});
+            const bool mine = nranks <= 1 || (fp ? fp_owner(fp, nranks) == rank : rank == 0);
+            if (!mine) continue;
+            generated++;
+            if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
+            if (fp && seen.insert(fp).second) arena.insert(arena.end(), tmp, tmp + W);
+        }
+        lo = 0; hi = nstates();
+        return 0;
+    }
+    uint64_t level_size() override { return hi - lo; }
+    int expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) override {
+        std::vector<std::vector<uint64_t>> fps(nranks);
+        std::vector<std::vector<Pending>> src(nranks);
+        for (uint64_t i = lo + first; i < lo + first + count; i++) {
+            CWordRef s{&arena[i * W], 1};
+            typename S::Local loc;
+            S::load(prm, s, loc);
+            const int ns = S::nslots(prm, loc);
+            uint64_t nsucc = 0;
+            for (int slot = 0; slot < ns; slot++) {
+                uint64_t fp = 0;
+                const unsigned st = S::eval(prm, loc, s, slot, fp);
+                if (!(st & ST_ENABLED)) continue;
+                nsucc++; generated++;
+                if (st & ST_OVERFLOW) return MC_EOVERFLOW;
+                if (st & ST_ASSERT) { verdict = MC_V_ASSERT; continue; }
+                if (st & ST_SPECERR) { verdict = MC_V_SPECERR; continue; }
+                if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
+                if (st & ST_OUT_OF_MODEL) continue;
+                const uint32_t o = fp_owner(fp, nranks);
+                fps[o].push_back(fp);
+                src[o].push_back({i, slot});
+            }
+            if (!nsucc && verdict == MC_V_OK) verdict = MC_V_DEADLOCK;
+        }
+        pending.clear();
+        pend_off.assign(nranks + 1, 0);
+        uint64_t k = 0;
+        for (uint32_t o = 0; o < nranks; o++) {
+            pend_off[o] = k;
+            send_counts[o] = fps[o].size();
+            if (k + fps[o].size() > send_cap) return MC_EARENA;
+            for (size_t j = 0; j < fps[o].size(); j++) { send_fp[k++] = fps[o][j]; pending.push_back(src[o][j]); }
+        }
+        pend_off[nranks] = k;
+        return 0;
+    }
+    int probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) override {
+        for (uint64_t i = 0; i < n; i++) answers[i] = seen.insert(recv_fp[i]).second ? 1 : 0;
+        return 0;
+    }
+    int materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
+        uint64_t *out = (uint64_t *)send_states;
+        uint64_t k = 0;
+        for (uint32_t o = 0; o < nranks; o++) {
+            send_counts[o] = 0;
+            for (uint64_t i = pend_off[o]; i < pend_off[o + 1]; i++) {
+                if (!answers_back[i]) continue;
+                if (k >= send_cap) return MC_EARENA;
+                S::apply(prm, CWordRef{&arena[pending[i].parent * W], 1}, pending[i].slot, WordRef{out + k * W, 1});
+                k++; send_counts[o]++;
+            }
+        }
+        return 0;
+    }
+    int ingest(const uint8_t *recv_states, uint64_t n) override {
+        const uint64_t *in = (const uint64_t *)recv_states;
+        arena.insert(arena.end(), in, in + n * W);
+        return 0;
+    }
+    uint64_t end_level() override { lo = hi; hi = nstates(); return hi - lo; }
+    void counters(uint64_t *g, uint64_t *d, int32_t *v) override { *g = generated; *d = nstates(); *v = verdict; }
+};
+
+extern "C" {
+void *shim_shard_create(const mc_spec_desc *d, uint32_t rank, uint32_t nranks) {
+    ShimShardBase *e = nullptr;
+    dispatch_spec(d, [&](auto spec, const auto &prm) {
+        auto *x = new ShimShard<decltype(spec)>();
+        x->prm = prm; x->rank = rank; x->nranks = nranks ? nranks : 1; x->W = decltype(spec)::words(prm);
+        e = x;
+        return 0;
+    });
+    return e;
+}
+void shim_shard_destroy(void *e) { delete (ShimShardBase *)e; }
+int shim_shard_begin(void *e) { return ((ShimShardBase *)e)->begin(); }
+int shim_shard_level_size(void *e, uint64_t *n) { *n = ((ShimShardBase *)e)->level_size(); return 0; }
+int shim_shard_expand(void *e, uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t cap, uint64_t *counts) {
+    return ((ShimShardBase *)e)->expand(first, count, send_fp, cap, counts);
+}
+int shim_shard_probe(void *e, const uint64_t *fp, uint64_t n, uint8_t *ans) { return ((ShimShardBase *)e)->probe(fp, n, ans); }
+int shim_shard_materialise(void *e, const uint8_t *ans, uint8_t *states, uint64_t cap, uint64_t *counts) {
+    return ((ShimShardBase *)e)->materialise(ans, states, cap, counts);
+}
+int shim_shard_ingest(void *e, const uint8_t *states, uint64_t n) { return ((ShimShardBase *)e)->ingest(states, n); }
+int shim_shard_end_level(void *e, uint64_t *n) { *n = ((ShimShardBase *)e)->end_level(); return 0; }
+int shim_shard_counters(void *e, uint64_t *g, uint64_t *d, int32_t *v) { ((ShimShardBase *)e)->counters(g, d, v); return 0; }
+}

@@ -1,0 +1,42 @@
+"""Worker for the multi-process tests: python -m torch.distributed.run ... tests/dist_worker.py <mode> <spec> <json params> <out>
+mode = shim (CPU, gloo, host lowerings) | hip (one GPU shared by all ranks, exchange staged over gloo)."""
+import json
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import torch.distributed as dist  # noqa: E402
+
+from tla_rust_amd.sharded import ShardedChecker  # noqa: E402
+
+
+def main():
+    mode, spec, params, out = sys.argv[1], sys.argv[2], json.loads(sys.argv[3]), sys.argv[4]
+    opts = json.loads(sys.argv[5]) if len(sys.argv) > 5 else {}
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if mode == "shim":
+        from shim_step_engine import ShimStepEngine
+        eng = ShimStepEngine(spec, params, rank, world)
+        chk = ShardedChecker(spec, params, engine=eng, chunk_states=opts.get("chunk", 1000), max_distinct=opts.get("max_distinct", 0),
+                             fanout_cap=opts.get("fanout_cap", 64), new_cap=opts.get("new_cap", 64))
+    else:
+        chk = ShardedChecker(spec, params, device=0, chunk_states=opts.get("chunk", 1 << 14), max_distinct=opts.get("max_distinct", 0),
+                             table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
+                             fanout_cap=opts.get("fanout_cap", 32), new_cap=opts.get("new_cap", 16))
+    r = chk.run()
+    _, local, _ = chk.eng.counters()
+    shares = [None] * world
+    dist.all_gather_object(shares, local)
+    if rank == 0:
+        Path(out).write_text(json.dumps(dict(r, shares=shares)))
+    chk.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""CPU stand-in for tla_rust_amd.sharded.HipStepEngine, backed by tests/_shim (host build of the
+device lowerings).  TEST ONLY: lets the multi-rank exchange loop run under gloo without a GPU."""
+import ctypes as C
+
+import torch
+
+import helpers
+
+
+class ShimStepEngine:
+    def __init__(self, spec, params, rank, world):
+        self.lib = helpers.shim_lib()
+        L = self.lib
+        L.shim_shard_create.restype = C.c_void_p
+        L.shim_shard_create.argtypes = [C.POINTER(helpers.McSpecDesc), C.c_uint32, C.c_uint32]
+        for name in ("begin", "level_size", "expand", "probe", "materialise", "ingest", "end_level", "counters", "destroy"):
+            getattr(L, "shim_shard_" + name).restype = C.c_int if name != "destroy" else None
+        L.shim_shard_begin.argtypes = [C.c_void_p]
+        L.shim_shard_destroy.argtypes = [C.c_void_p]
+        L.shim_shard_level_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.shim_shard_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.shim_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.shim_shard_materialise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.shim_shard_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.shim_shard_end_level.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.shim_shard_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+        self.world = world
+        d = helpers.spec_desc(spec, params)
+        L.shim_state_bytes.restype = C.c_size_t
+        L.shim_state_bytes.argtypes = [C.POINTER(helpers.McSpecDesc)]
+        self.W = L.shim_state_bytes(C.byref(d))
+        self.h = L.shim_shard_create(C.byref(d), rank, world)
+        self.device = torch.device("cpu")
+
+    def _ck(self, rc, what):
+        if rc:
+            raise RuntimeError(f"{what} failed: {rc}")
+
+    def begin(self):
+        self._ck(self.lib.shim_shard_begin(self.h), "begin")
+
+    def level_size(self):
+        n = C.c_uint64()
+        self.lib.shim_shard_level_size(self.h, C.byref(n))
+        return n.value
+
+    def expand(self, first, count, send_fp):
+        counts = (C.c_uint64 * self.world)()
+        self._ck(self.lib.shim_shard_expand(self.h, first, count, send_fp.data_ptr(), send_fp.numel(), counts), "expand")
+        return list(counts)
+
+    def probe(self, recv_fp, n, answers):
+        self._ck(self.lib.shim_shard_probe(self.h, recv_fp.data_ptr(), n, answers.data_ptr()), "probe")
+
+    def materialise(self, answers_back, send_states):
+        counts = (C.c_uint64 * self.world)()
+        self._ck(self.lib.shim_shard_materialise(self.h, answers_back.data_ptr(), send_states.data_ptr(),
+                                                 send_states.numel() // self.W, counts), "materialise")
+        return list(counts)
+
+    def ingest(self, recv_states, n):
+        self._ck(self.lib.shim_shard_ingest(self.h, recv_states.data_ptr(), n), "ingest")
+
+    def end_level(self):
+        n = C.c_uint64()
+        self.lib.shim_shard_end_level(self.h, C.byref(n))
+        return n.value
+
+    def counters(self):
+        g, d, v = C.c_uint64(), C.c_uint64(), C.c_int32()
+        self.lib.shim_shard_counters(self.h, C.byref(g), C.byref(d), C.byref(v))
+        return g.value, d.value, v.value
+
+    def sync(self):
+        pass
+
+    def close(self):
+        self.lib.shim_shard_destroy(self.h)

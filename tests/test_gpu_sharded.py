@@ -1,0 +1,34 @@
+"""Sharded step kernels on the GPU: (a) one process, one shard (routing + compaction + probe +
+send-materialise + ingest with nranks = 1) against the fused single-GPU run; (b) two processes
+sharing GPU 0, buckets exchanged with gloo through the host, against the oracle."""
+import pytest
+
+from test_sharded_gloo import run_dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("spec,params,opts", [("atomic_add", [12], {}), ("pcal_intro", [0, 1, 20, 2], {}),
+                                               ("raft", [2, 2, 2, 9, 2, 1], {}), ("raft", [3, 4, 2, 3, 1, 1, 16, 2, 8], {"max_distinct": 1000000})])
+def test_single_shard_step_api_equals_fused_run(spec, params, opts):
+    import tla_rust_amd as amd
+    from tla_rust_amd.sharded import ShardedChecker
+    eng = amd.Engine(spec, params, table_capacity=1 << 23, arena_capacity=1 << 21, chunk_states=1 << 14, max_distinct=opts.get("max_distinct", 0))
+    a = eng.run()
+    eng.close()
+    chk = ShardedChecker(spec, params, device=0, chunk_states=1 << 14, max_distinct=opts.get("max_distinct", 0), table_capacity=1 << 23,
+                         arena_capacity=1 << 21, fanout_cap=40, new_cap=16)
+    b = chk.run()
+    chk.close()
+    assert (a.distinct, a.generated, a.depth, a.levels, a.verdict) == (b.distinct, b.generated, b.depth, b.levels, b.verdict)
+
+
+@pytest.mark.parametrize("spec,params,opts", [("raft", [2, 2, 2, 9, 2, 1], {"chunk": 1 << 12}),
+                                               ("raft", [3, 2, 2, 9, 1, 1], {"max_distinct": 300000, "chunk": 1 << 14, "table": 1 << 22, "arena": 1 << 20}),
+                                               ("pcal_intro", [1, 0, 20, 2], {"chunk": 512})])
+def test_two_ranks_on_one_gpu_equal_oracle(oracle, tmp_path, spec, params, opts):
+    o = oracle.oracle_run(spec, params, max_distinct=opts.get("max_distinct", 0))
+    r = run_dist("hip", 2, spec, params, tmp_path, opts)
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == \
+           (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"])
+    assert sum(r["shares"]) == o["distinct"]

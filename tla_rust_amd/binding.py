@@ -60,6 +60,13 @@ def lib():
     if not LIB_PATH.exists():
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m tla_rust_amd.build` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both open the
+    # GPU.  Loading torch first makes the dynamic linker resolve libtlamc.so's libamdhip64 (same SONAME)
+    # to the copy torch already mapped, so device memory, streams and RCCL share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(str(LIB_PATH))
     L.mc_engine_create.argtypes = [C.POINTER(SpecDesc), C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.mc_engine_run.argtypes = [C.c_void_p, C.POINTER(CResult)]
@@ -79,6 +86,15 @@ def lib():
     L.mc_strerror.restype = C.c_char_p
     L.mc_last_error.restype = C.c_char_p
     L.mc_device_count.restype = C.c_int
+    U64P = C.POINTER(C.c_uint64)
+    L.mc_shard_begin.argtypes = [C.c_void_p]
+    L.mc_shard_level_size.argtypes = [C.c_void_p, U64P]
+    L.mc_shard_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, U64P]
+    L.mc_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.mc_shard_materialise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, U64P]
+    L.mc_shard_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.mc_shard_end_level.argtypes = [C.c_void_p, U64P]
+    L.mc_shard_counters.argtypes = [C.c_void_p, U64P, U64P, C.POINTER(C.c_int32)]
     if hasattr(L, "mc_cfg_parse"):
         L.mc_cfg_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.mc_cfg_free.argtypes = [C.c_void_p]
@@ -176,6 +192,41 @@ class Engine:
         f = lambda s: dict(launches=s.launches, ms_total=s.ms_total, units=s.units)
         return dict(expand=f(ks.expand), insert=f(ks.insert), materialise=f(ks.materialise),
                     state_bytes=ks.state_bytes, cand_cells=ks.cand_cells)
+
+    # ---- sharded step API (mc_shard_*): raw device pointers in, counts out
+    def shard_begin(self):
+        _check(lib().mc_shard_begin(self._h), "mc_shard_begin")
+
+    def shard_level_size(self):
+        n = C.c_uint64()
+        _check(lib().mc_shard_level_size(self._h, C.byref(n)), "mc_shard_level_size")
+        return n.value
+
+    def shard_expand(self, first, count, send_fp_ptr, send_cap):
+        counts = (C.c_uint64 * max(1, self.cfg.shard_count))()
+        _check(lib().mc_shard_expand(self._h, first, count, send_fp_ptr, send_cap, counts), "mc_shard_expand")
+        return list(counts)
+
+    def shard_probe(self, recv_fp_ptr, n, answers_ptr):
+        _check(lib().mc_shard_probe(self._h, recv_fp_ptr, n, answers_ptr), "mc_shard_probe")
+
+    def shard_materialise(self, answers_back_ptr, send_states_ptr, send_cap):
+        counts = (C.c_uint64 * max(1, self.cfg.shard_count))()
+        _check(lib().mc_shard_materialise(self._h, answers_back_ptr, send_states_ptr, send_cap, counts), "mc_shard_materialise")
+        return list(counts)
+
+    def shard_ingest(self, recv_states_ptr, n):
+        _check(lib().mc_shard_ingest(self._h, recv_states_ptr, n), "mc_shard_ingest")
+
+    def shard_end_level(self):
+        n = C.c_uint64()
+        _check(lib().mc_shard_end_level(self._h, C.byref(n)), "mc_shard_end_level")
+        return n.value
+
+    def shard_counters(self):
+        g, d, v = C.c_uint64(), C.c_uint64(), C.c_int32()
+        _check(lib().mc_shard_counters(self._h, C.byref(g), C.byref(d), C.byref(v)), "mc_shard_counters")
+        return g.value, d.value, v.value
 
     def close(self):
         if self._h:

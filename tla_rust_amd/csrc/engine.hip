@@ -148,7 +148,7 @@ k_expand(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo
 template <class S>
 __global__ void __launch_bounds__(256)
 k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__restrict__ tmp, uint64_t *__restrict__ cand,
-            uint64_t ncols, uint16_t *__restrict__ nsl, DevCounters *ctr) {
+            uint64_t ncols, uint16_t *__restrict__ nsl, DevCounters *ctr, unsigned shard_rank, unsigned shard_count) {
     const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncols) return;
     uint64_t fp = 0;
@@ -162,6 +162,10 @@ k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__
         gen = 1;
         if (st & ST_INVARIANT) viol = viol_key(first + col, SLOT_NONE - 1, VK_INVARIANT, st >> 8);
         if (!(st & ST_OUT_OF_MODEL)) fp = S::fp_of(prm, st_ref);
+        if (shard_count > 1) {  // every rank enumerates Init; each keeps (and counts) only what it owns
+            const bool mine = fp ? fp_owner(fp, shard_count) == shard_rank : shard_rank == 0;
+            if (!mine) { fp = 0; gen = 0; viol = ~0ull; }
+        }
     }
     cand[col] = fp;
     nsl[col] = 1;
@@ -264,10 +268,23 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <class S>
+// Sharded (multi-GPU) mode: instead of probing, a flush ROUTES the queued fingerprints to the
+// rank that owns them (owner = fingerprint high bits): bucket [owner][shard] in HBM, one
+// atomicAdd per (flush, owner present).  k_compact_buckets then makes each owner's bucket
+// contiguous for the all-to-all.
+struct RouteArgs {
+    unsigned nranks;
+    PaddedCounter *cursors;   // [nranks * NSHARD]
+    uint64_t *rt_fp;          // [nranks * NSHARD][subcap]
+    uint32_t *rt_src;
+    uint64_t subcap;
+};
+
+template <class S, bool ROUTE>
 __global__ void __launch_bounds__(256)
 k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
-                uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags) {
+                uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
+                RouteArgs rt) {
     __shared__ WaveQueues wq[4];
     __shared__ uint64_t stage[4][S::STAGE_WORDS > 0 ? S::STAGE_WORDS : 1][64];
     const unsigned lane = threadIdx.x & 63;
@@ -318,22 +335,44 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         ohead = (ohead + take) & (QCAP - 1);
         on -= take;
     };
-    auto flush_probe = [&](unsigned take) {  // probe `take` queued fingerprints, one per lane
+    auto flush_probe = [&](unsigned take) {  // probe (or route) `take` queued fingerprints, one per lane
         bool is_new = false;
         uint32_t src = 0;
+        uint64_t qfp = 0;
         if (lane < take) {
             const unsigned k = (qhead + lane) & (QCAP - 1);
             src = Q.q_src[k];
-            is_new = seen_insert(table, mask, Q.q_fp[k], err);
+            qfp = Q.q_fp[k];
+            if constexpr (!ROUTE) is_new = seen_insert(table, mask, qfp, err);
         }
         qhead = (qhead + take) & (QCAP - 1);
         qn -= take;
         probes += take;
-        const unsigned long long b = __ballot(is_new);
-        if (is_new) Q.o_src[(ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1)] = src;
-        on += (unsigned)__popcll(b);
-        wave_lds_fence();
-        if (on >= 64) flush_out(64);
+        if constexpr (ROUTE) {
+            const unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
+            for (unsigned t = 0; t < rt.nranks; ++t) {
+                const unsigned long long b = __ballot(owner == t);
+                if (!b) continue;
+                const unsigned bucket = t * NSHARD + shard;
+                unsigned long long pos = 0;
+                if (lane == 0) pos = atomicAdd(&rt.cursors[bucket].v, (unsigned long long)__popcll(b));
+                pos = __shfl(pos, 0) + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+                if (owner == t) {
+                    if (pos < rt.subcap) {
+                        rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
+                        rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = src;
+                    } else {
+                        err |= DEV_EARENA;
+                    }
+                }
+            }
+        } else {
+            const unsigned long long b = __ballot(is_new);
+            if (is_new) Q.o_src[(ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1)] = src;
+            on += (unsigned)__popcll(b);
+            wave_lds_fence();
+            if (on >= 64) flush_out(64);
+        }
     };
 
     auto body = [&](int slot) __attribute__((always_inline)) {
@@ -429,6 +468,91 @@ k_gather_states(const uint64_t *__restrict__ arena, int words, uint64_t first, u
     const uint64_t j = t / (uint64_t)words, w = t % (uint64_t)words, idx = first + j;
     out[t] = arena[((idx >> 6) * (uint64_t)words + w) * 64 + (idx & 63)];
 }
+
+// ------------------------------------------------------------------------------------- sharded step kernels
+// sub-buckets [owner][shard] -> one contiguous range per owner (order inside an owner: by shard)
+__global__ void __launch_bounds__(256)
+k_compact_buckets(RouteArgs rt, uint64_t *__restrict__ send_fp, uint32_t *__restrict__ pend_src) {
+    const unsigned bucket = blockIdx.y;  // owner * NSHARD + shard
+    const uint64_t n = rt.cursors[bucket].v < rt.subcap ? rt.cursors[bucket].v : rt.subcap;
+    uint64_t off = 0;
+    for (unsigned b = 0; b < bucket; ++b) off += rt.cursors[b].v < rt.subcap ? rt.cursors[b].v : rt.subcap;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        send_fp[off + j] = rt.rt_fp[(uint64_t)bucket * rt.subcap + j];
+        pend_src[off + j] = rt.rt_src[(uint64_t)bucket * rt.subcap + j];
+    }
+}
+// owner side: insert received fingerprints, answer 1 = new
+__global__ void __launch_bounds__(256)
+k_probe(const uint64_t *__restrict__ fps, uint64_t n, uint64_t *table, uint64_t mask, uint8_t *__restrict__ answers, DevCounters *ctr) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned err = 0;
+    bool is_new = false;
+    if (i < n) {
+        is_new = seen_insert(table, mask, fps[i], err);
+        answers[i] = is_new ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(is_new);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&ctr->n_new[blockIdx.x & (NSHARD - 1)].v, (unsigned long long)__popcll(b));
+    if (wave_or_u32(err) && (threadIdx.x & 63) == 0) atomicOr(&ctr->error, DEV_ETABLE);
+}
+// sender side: per-owner count of positive answers (owner ranges given by off[0..nranks])
+struct OwnerOffsets { uint64_t off[9]; };
+__device__ __forceinline__ unsigned owner_of_index(const OwnerOffsets &o, unsigned nranks, uint64_t i) {
+    unsigned t = 0;
+    while (t + 1 < nranks && i >= o.off[t + 1]) ++t;
+    return t;
+}
+__global__ void __launch_bounds__(256)
+k_count_answers(const uint8_t *__restrict__ answers, uint64_t total, OwnerOffsets offs, unsigned nranks, PaddedCounter *counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool yes = i < total && answers[i] != 0;
+    const unsigned owner = yes ? owner_of_index(offs, nranks, i) : 0xffffffffu;
+    for (unsigned t = 0; t < nranks; ++t) {
+        const unsigned long long b = __ballot(owner == t);
+        if (b && (threadIdx.x & 63) == 0) atomicAdd(&counts[t].v, (unsigned long long)__popcll(b));
+    }
+}
+// sender side: build the full state of every candidate the owner reported as new, as a plain
+// record in the owner's range of the state send buffer
+template <class S>
+__global__ void __launch_bounds__(256)
+k_send_materialise(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t chunk_base, const uint32_t *__restrict__ pend_src,
+                   const uint8_t *__restrict__ answers, uint64_t total, OwnerOffsets offs, OwnerOffsets out_offs, unsigned nranks,
+                   PaddedCounter *cursors, uint64_t *__restrict__ send_states) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool yes = i < total && answers[i] != 0;
+    const unsigned owner = yes ? owner_of_index(offs, nranks, i) : 0xffffffffu;
+    const unsigned lane = threadIdx.x & 63;
+    uint64_t pos = 0;
+    for (unsigned t = 0; t < nranks; ++t) {
+        const unsigned long long b = __ballot(owner == t);
+        if (!b) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&cursors[t].v, (unsigned long long)__popcll(b));
+        base = __shfl(base, 0);
+        if (owner == t) pos = out_offs.off[t] + base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+    }
+    if (yes) {
+        const uint32_t src = pend_src[i];
+        const int W = S::words(prm);
+        S::apply(prm, arena_cref(arena, chunk_base + (src & 0xffffffu), W), (int)(src >> 24), WordRef{send_states + pos * (uint64_t)W, 1});
+    }
+}
+// owner side: append received plain records to the arena (next-level frontier)
+__global__ void __launch_bounds__(256)
+k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv, uint64_t n, uint64_t out0, uint64_t arena_cap,
+         uint32_t *__restrict__ parent, DevCounters *ctr) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t oidx = out0 + j;
+    if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); return; }
+    const WordRef o = arena_ref(arena, oidx, words);
+    for (int w = 0; w < words; w++) o.set(w, recv[j * (uint64_t)words + w]);
+    if (parent) parent[oidx] = 0xfffffffeu;  // produced on another rank: no local parent
+}
+__global__ void k_set_arena_next(DevCounters *ctr, unsigned long long v) { ctr->arena_next = v; }
 __global__ void k_commit(DevCounters *ctr) {
     unsigned long long n = 0;
     for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; }
@@ -443,6 +567,14 @@ struct EngineBase {
     virtual int trace(uint8_t *states_out, int32_t *actions_out, size_t *n_inout) = 0;
     virtual int kernel_stats(mc_kernel_stats *out) = 0;
     virtual int read_states(uint64_t first, uint64_t count, uint8_t *out) = 0;
+    virtual int shard_begin() = 0;
+    virtual int shard_level_size(uint64_t *n) = 0;
+    virtual int shard_expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
+    virtual int shard_probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) = 0;
+    virtual int shard_materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
+    virtual int shard_ingest(const uint8_t *recv_states, uint64_t n) = 0;
+    virtual int shard_end_level(uint64_t *new_local) = 0;
+    virtual int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
 };
 
 static uint64_t round_pow2(uint64_t v) {
@@ -539,6 +671,8 @@ struct Engine : EngineBase {
         if (d_newlist) hipFree(d_newlist);
         if (d_nsl) hipFree(d_nsl);
         if (d_inittmp) hipFree(d_inittmp);
+        if (d_rt_fp) { hipFree(d_rt_fp); hipFree(d_rt_src); hipFree(d_pend_src); }
+        if (d_rt_cur) hipFree(d_rt_cur);
         if (d_parent) hipFree(d_parent);
         if (d_pslot) hipFree(d_pslot);
         if (d_ctr) hipFree(d_ctr);
@@ -622,7 +756,7 @@ struct Engine : EngineBase {
             const uint64_t count = ninit - first < chunk ? ninit - first : chunk;
             const uint64_t ncols = (count + 63) & ~63ull;
             hipLaunchKernelGGL(k_init_cand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, first, count,
-                               d_inittmp, d_cand, ncols, d_nsl, d_ctr);
+                               d_inittmp, d_cand, ncols, d_nsl, d_ctr, cfg.shard_rank, cfg.shard_count);
             finish_chunk<true>(first, ncols, 1);
         }
         int rc = read_counters();
@@ -650,8 +784,9 @@ struct Engine : EngineBase {
                     finish_chunk<false>(base, ncols, max_slots);
                 } else {
                     timed(0, c1 - c0, [&] {
-                        hipLaunchKernelGGL(k_expand_insert<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm,
-                                           d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags);
+                        hipLaunchKernelGGL((k_expand_insert<S, false>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm,
+                                           d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags,
+                                           RouteArgs{});
                     });
                     finish_materialise(base, ncols);
                 }
@@ -779,6 +914,163 @@ struct Engine : EngineBase {
         return MC_OK;
     }
     uint64_t last_distinct = 0;
+    // ------------------------------------------------------------------ sharded step API
+    uint64_t sh_lo = 0, sh_hi = 0, sh_next = 0;  // local frontier [sh_lo, sh_hi), arena fill level
+    uint64_t *d_rt_fp = nullptr;
+    uint32_t *d_rt_src = nullptr, *d_pend_src = nullptr;
+    PaddedCounter *d_rt_cur = nullptr;  // [nranks*NSHARD] route cursors, then [nranks] answer counts, then [nranks] state cursors
+    uint64_t rt_subcap = 0, pend_cap = 0, pend_total = 0, sh_chunk_base = 0;
+    OwnerOffsets pend_off;
+    unsigned nranks() const { return cfg.shard_count > 1 ? cfg.shard_count : 1; }
+
+    int shard_alloc(uint64_t send_cap) {
+        if (send_cap <= pend_cap) return MC_OK;
+        if (d_rt_fp) { hipFree(d_rt_fp); hipFree(d_rt_src); hipFree(d_pend_src); }
+        const unsigned P = nranks();
+        rt_subcap = (send_cap / (P * NSHARD)) * 2 + 4096;
+        HIP_TRY(hipMalloc(&d_rt_fp, (size_t)P * NSHARD * rt_subcap * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&d_rt_src, (size_t)P * NSHARD * rt_subcap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&d_pend_src, send_cap * sizeof(uint32_t)));
+        if (!d_rt_cur) HIP_TRY(hipMalloc(&d_rt_cur, (size_t)(P * NSHARD + 2 * P) * sizeof(PaddedCounter)));
+        pend_cap = send_cap;
+        return MC_OK;
+    }
+    int shard_begin() override {
+        if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
+        HIP_TRY(hipSetDevice(cfg.device));
+        memset(kstat, 0, sizeof kstat);
+        HIP_TRY(hipMemsetAsync(d_table, 0, table_cap * sizeof(uint64_t), stream));
+        DevCounters init_c;
+        memset(&init_c, 0, sizeof init_c);
+        init_c.viol_key = ~0ull;
+        HIP_TRY(hipMemcpyAsync(d_ctr, &init_c, sizeof init_c, hipMemcpyHostToDevice, stream));
+        const uint64_t ninit = S::num_init(prm);
+        for (uint64_t first = 0; first < ninit; first += chunk) {
+            const uint64_t count = ninit - first < chunk ? ninit - first : chunk;
+            const uint64_t ncols = (count + 63) & ~63ull;
+            hipLaunchKernelGGL(k_init_cand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, first, count,
+                               d_inittmp, d_cand, ncols, d_nsl, d_ctr, cfg.shard_rank, cfg.shard_count);
+            finish_chunk<true>(first, ncols, 1);
+        }
+        int rc = read_counters();
+        if (rc) return rc;
+        if ((rc = check_dev_error())) return rc;
+        sh_lo = 0;
+        sh_hi = sh_next = h_ctr->arena_next;
+        last_distinct = sh_next;
+        return MC_OK;
+    }
+    int shard_level_size(uint64_t *n) override { *n = sh_hi - sh_lo; return MC_OK; }
+    int shard_expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        const unsigned P = nranks();
+        int rc = shard_alloc(send_cap);
+        if (rc) return rc;
+        for (unsigned t = 0; t < P; t++) send_counts[t] = 0;
+        pend_total = 0;
+        for (unsigned t = 0; t <= 8; t++) pend_off.off[t] = 0;
+        if (first + count > sh_hi - sh_lo) { set_error("shard_expand: chunk outside the local frontier"); return MC_EBADCFG; }
+        if (count > chunk) { set_error("shard_expand: chunk larger than chunk_states"); return MC_EBADCFG; }
+        if (!count) return MC_OK;
+        HIP_TRY(hipMemsetAsync(d_rt_cur, 0, (size_t)(P * NSHARD + 2 * P) * sizeof(PaddedCounter), stream));
+        const uint64_t c0 = sh_lo + first, c1 = c0 + count, base = c0 & ~63ull;
+        const uint64_t ncols = ((c1 - base) + 63) & ~63ull;
+        sh_chunk_base = base;
+        RouteArgs rt{P, d_rt_cur, d_rt_fp, d_rt_src, rt_subcap};
+        timed(0, count, [&] {
+            hipLaunchKernelGGL((k_expand_insert<S, true>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0,
+                               c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt);
+        });
+        std::vector<PaddedCounter> cur(P * NSHARD);
+        HIP_TRY(hipMemcpyAsync(cur.data(), d_rt_cur, cur.size() * sizeof(PaddedCounter), hipMemcpyDeviceToHost, stream));
+        if ((rc = read_counters())) return rc;
+        if ((rc = check_dev_error())) return rc;
+        uint64_t total = 0;
+        for (unsigned t = 0; t < P; t++) {
+            pend_off.off[t] = total;
+            for (unsigned x = 0; x < NSHARD; x++) {
+                if (cur[t * NSHARD + x].v > rt_subcap) { set_error("shard_expand: route bucket overflow (raise send_cap)"); return MC_EARENA; }
+                send_counts[t] += cur[t * NSHARD + x].v;
+            }
+            total += send_counts[t];
+        }
+        for (unsigned t = P; t <= 8; t++) pend_off.off[t] = total;
+        if (total > send_cap) { set_error("shard_expand: send buffer too small"); return MC_EARENA; }
+        pend_total = total;
+        if (total) {
+            hipLaunchKernelGGL(k_compact_buckets, dim3(64, P * NSHARD), dim3(256), 0, stream, rt, send_fp, d_pend_src);
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return MC_OK;
+    }
+    int shard_probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (!n) return MC_OK;
+        timed(1, n, [&] {
+            hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, recv_fp, n, d_table, table_cap - 1, answers, d_ctr);
+        });
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MC_OK;
+    }
+    int shard_materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        const unsigned P = nranks();
+        for (unsigned t = 0; t < P; t++) send_counts[t] = 0;
+        if (!pend_total) return MC_OK;
+        PaddedCounter *d_cnt = d_rt_cur + P * NSHARD, *d_cur2 = d_cnt + P;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 2 * P * sizeof(PaddedCounter), stream));
+        const unsigned bx = (unsigned)((pend_total + 255) / 256);
+        hipLaunchKernelGGL(k_count_answers, dim3(bx), dim3(256), 0, stream, answers_back, pend_total, pend_off, P, d_cnt);
+        std::vector<PaddedCounter> cnt(P);
+        HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, P * sizeof(PaddedCounter), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        OwnerOffsets out_off;
+        uint64_t total = 0;
+        for (unsigned t = 0; t < P; t++) { out_off.off[t] = total; send_counts[t] = cnt[t].v; total += cnt[t].v; }
+        for (unsigned t = P; t <= 8; t++) out_off.off[t] = total;
+        if (total > send_cap) { set_error("shard_materialise: state send buffer too small"); return MC_EARENA; }
+        if (total) {
+            timed(2, total, [&] {
+                hipLaunchKernelGGL(k_send_materialise<S>, dim3(bx), dim3(256), 0, stream, prm, d_arena, sh_chunk_base, d_pend_src,
+                                   answers_back, pend_total, pend_off, out_off, P, d_cur2, (uint64_t *)send_states);
+            });
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MC_OK;
+    }
+    int shard_ingest(const uint8_t *recv_states, uint64_t n) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (!n) return MC_OK;
+        if (sh_next + n > arena_cap) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }
+        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_arena, W, (const uint64_t *)recv_states, n,
+                           sh_next, arena_cap, d_parent, d_ctr);
+        sh_next += n;
+        hipLaunchKernelGGL(k_set_arena_next, dim3(1), dim3(1), 0, stream, d_ctr, (unsigned long long)sh_next);
+        HIP_TRY(hipStreamSynchronize(stream));
+        last_distinct = sh_next;
+        return MC_OK;
+    }
+    int shard_end_level(uint64_t *new_local) override {
+        sh_lo = sh_hi;
+        sh_hi = sh_next;
+        *new_local = sh_hi - sh_lo;
+        return MC_OK;
+    }
+    int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        int rc = read_counters();
+        if (rc) return rc;
+        if ((rc = check_dev_error())) return rc;
+        *generated = 0;
+        for (int t = 0; t < NSHARD; t++) *generated += h_ctr->generated[t].v;
+        *distinct_local = sh_next;
+        *verdict = MC_V_OK;
+        if (h_ctr->viol_key != ~0ull) {
+            const unsigned kind = (unsigned)(h_ctr->viol_key & 7u);
+            *verdict = kind == VK_INVARIANT ? MC_V_INVARIANT : kind == VK_ASSERT ? MC_V_ASSERT : kind == VK_DEADLOCK ? MC_V_DEADLOCK : MC_V_SPECERR;
+        }
+        return MC_OK;
+    }
     int kernel_stats(mc_kernel_stats *o) override {
         o->expand = kstat[0];
         o->insert = kstat[1];
@@ -881,14 +1173,22 @@ const char *mc_last_error(void) { return g_last_error.c_str(); }
 void mc_set_error_internal(const char *msg) { set_error(msg ? msg : ""); }
 
 
-// ---- sharded step API: implemented in the next section (see mc_shard_* in include/tlamc.h)
-int mc_shard_begin(mc_engine *) { set_error("sharded mode: not built yet"); return MC_ESTATE; }
-int mc_shard_level_size(mc_engine *, uint64_t *) { return MC_ESTATE; }
-int mc_shard_expand(mc_engine *, uint64_t, uint64_t, uint64_t *, uint64_t, uint64_t *) { return MC_ESTATE; }
-int mc_shard_probe(mc_engine *, const uint64_t *, uint64_t, uint8_t *) { return MC_ESTATE; }
-int mc_shard_materialise(mc_engine *, const uint8_t *, uint8_t *, uint64_t, uint64_t *) { return MC_ESTATE; }
-int mc_shard_ingest(mc_engine *, const uint8_t *, uint64_t) { return MC_ESTATE; }
-int mc_shard_end_level(mc_engine *, uint64_t *) { return MC_ESTATE; }
-int mc_shard_counters(mc_engine *, uint64_t *, uint64_t *, int32_t *) { return MC_ESTATE; }
+// ---- sharded (multi-GPU) step API
+int mc_shard_begin(mc_engine *e) { return e ? e->impl->shard_begin() : MC_EBADCFG; }
+int mc_shard_level_size(mc_engine *e, uint64_t *n) { return e && n ? e->impl->shard_level_size(n) : MC_EBADCFG; }
+int mc_shard_expand(mc_engine *e, uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) {
+    return e && send_counts ? e->impl->shard_expand(first, count, send_fp, send_cap, send_counts) : MC_EBADCFG;
+}
+int mc_shard_probe(mc_engine *e, const uint64_t *recv_fp, uint64_t n, uint8_t *answers) {
+    return e ? e->impl->shard_probe(recv_fp, n, answers) : MC_EBADCFG;
+}
+int mc_shard_materialise(mc_engine *e, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) {
+    return e && send_counts ? e->impl->shard_materialise(answers_back, send_states, send_cap, send_counts) : MC_EBADCFG;
+}
+int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n) { return e ? e->impl->shard_ingest(recv_states, n) : MC_EBADCFG; }
+int mc_shard_end_level(mc_engine *e, uint64_t *new_local) { return e && new_local ? e->impl->shard_end_level(new_local) : MC_EBADCFG; }
+int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) {
+    return e && generated && distinct_local && verdict ? e->impl->shard_counters(generated, distinct_local, verdict) : MC_EBADCFG;
+}
 
 }  // extern "C"
