@@ -129,7 +129,11 @@ void mc_engine_destroy(mc_engine *e);
  *   (all-to-all of answers, reversed)
  *   materialise: sender builds the full successor state of every "new" answer, bucketed by owner
  *   (all-to-all of states)
- *   ingest     : owner appends received states to its next-level frontier. */
+ *   ingest     : owner appends received states to its next-level frontier.
+ * Exchange format of full states: each owner's bucket is a whole number of 64-state BLOCKS
+ * (mc_state_bytes() * 64 bytes each), word-major inside a block like the HBM arena, so both ends
+ * move them with coalesced accesses; send_counts[] are STATES, a bucket occupies
+ * ceil(count / 64) blocks.  mc_shard_ingest takes ONE source's bucket per call. */
 int mc_shard_begin(mc_engine *e);                                  /* Init: keep the initial states this rank owns */
 int mc_shard_level_size(mc_engine *e, uint64_t *frontier_states);  /* local frontier of the current level          */
 int mc_shard_expand(mc_engine *e, uint64_t first, uint64_t count,  /* chunk of the local frontier                  */

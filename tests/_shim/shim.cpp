@@ -224,23 +224,28 @@ struct ShimShard : ShimShardBase {
         for (uint64_t i = 0; i < n; i++) answers[i] = seen.insert(recv_fp[i]).second ? 1 : 0;
         return 0;
     }
+    // exchange format: per owner a whole number of 64-state blocks, word-major inside a block
     int materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
         uint64_t *out = (uint64_t *)send_states;
-        uint64_t k = 0;
+        uint64_t blk0 = 0;
         for (uint32_t o = 0; o < nranks; o++) {
-            send_counts[o] = 0;
+            uint64_t k = 0;
             for (uint64_t i = pend_off[o]; i < pend_off[o + 1]; i++) {
                 if (!answers_back[i]) continue;
-                if (k >= send_cap) return MC_EARENA;
-                S::apply(prm, CWordRef{&arena[pending[i].parent * W], 1}, pending[i].slot, WordRef{out + k * W, 1});
-                k++; send_counts[o]++;
+                if ((blk0 + k / 64 + 1) * 64 > send_cap) return MC_EARENA;
+                S::apply(prm, CWordRef{&arena[pending[i].parent * W], 1}, pending[i].slot,
+                         WordRef{out + (blk0 + k / 64) * (uint64_t)W * 64 + k % 64, 64});
+                k++;
             }
+            send_counts[o] = k;
+            blk0 += (k + 63) / 64;
         }
         return 0;
     }
-    int ingest(const uint8_t *recv_states, uint64_t n) override {
+    int ingest(const uint8_t *recv_states, uint64_t n) override {  // one source's bucket
         const uint64_t *in = (const uint64_t *)recv_states;
-        arena.insert(arena.end(), in, in + n * W);
+        for (uint64_t j = 0; j < n; j++)
+            for (int w = 0; w < W; w++) arena.push_back(in[(j / 64) * (uint64_t)W * 64 + (uint64_t)w * 64 + j % 64]);
         return 0;
     }
     uint64_t end_level() override { lo = hi; hi = nstates(); return hi - lo; }

@@ -20,6 +20,7 @@
 // written once and read once, each generated successor touches one 8-byte seen-set word.
 // The candidate matrix adds 16 B per evaluated cell on top (written by expand, read by insert).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <chrono>
 #include <type_traits>
@@ -504,52 +505,60 @@ __device__ __forceinline__ unsigned owner_of_index(const OwnerOffsets &o, unsign
     while (t + 1 < nranks && i >= o.off[t + 1]) ++t;
     return t;
 }
+// sender side, step 1: compact the sources of the positively answered candidates per owner.
+// incl[] = inclusive prefix sum of the answers (hipcub::DeviceScan), so positions need no atomics;
+// start[t] = number of positive answers before owner t's range.
+struct AnswerCast {
+    __host__ __device__ uint32_t operator()(const uint8_t &a) const { return a ? 1u : 0u; }
+};
 __global__ void __launch_bounds__(256)
-k_count_answers(const uint8_t *__restrict__ answers, uint64_t total, OwnerOffsets offs, unsigned nranks, PaddedCounter *counts) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool yes = i < total && answers[i] != 0;
-    const unsigned owner = yes ? owner_of_index(offs, nranks, i) : 0xffffffffu;
-    for (unsigned t = 0; t < nranks; ++t) {
-        const unsigned long long b = __ballot(owner == t);
-        if (b && (threadIdx.x & 63) == 0) atomicAdd(&counts[t].v, (unsigned long long)__popcll(b));
-    }
+k_gather_range_ends(const uint32_t *__restrict__ incl, OwnerOffsets offs, unsigned nranks, unsigned long long *__restrict__ ends) {
+    const unsigned t = threadIdx.x;
+    if (t < nranks) ends[t] = offs.off[t + 1] ? incl[offs.off[t + 1] - 1] : 0;
 }
-// sender side: build the full state of every candidate the owner reported as new, as a plain
-// record in the owner's range of the state send buffer
+__global__ void __launch_bounds__(256)
+k_compact_new(const uint8_t *__restrict__ answers, const uint32_t *__restrict__ incl, const uint32_t *__restrict__ pend_src,
+              uint64_t total, OwnerOffsets offs, OwnerOffsets start, unsigned nranks, uint32_t *__restrict__ new_src) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || !answers[i]) return;
+    const unsigned t = owner_of_index(offs, nranks, i);
+    // new states of owner t are a subset of its pending range, so they fit at the range's start
+    new_src[offs.off[t] + (incl[i] - 1 - start.off[t])] = pend_src[i];
+}
+// Exchange format of full states: per owner a whole number of 64-state BLOCKS, word-major inside a
+// block exactly like the arena, so that both the sender's writes and the receiver's reads are
+// coalesced.  blk_off[t] = first block of owner t in the send buffer, cnt[t] = its states.
+struct BlockPlan { uint64_t blk_off[9]; uint64_t cnt[8]; };
 template <class S>
 __global__ void __launch_bounds__(256)
-k_send_materialise(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t chunk_base, const uint32_t *__restrict__ pend_src,
-                   const uint8_t *__restrict__ answers, uint64_t total, OwnerOffsets offs, OwnerOffsets out_offs, unsigned nranks,
-                   PaddedCounter *cursors, uint64_t *__restrict__ send_states) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool yes = i < total && answers[i] != 0;
-    const unsigned owner = yes ? owner_of_index(offs, nranks, i) : 0xffffffffu;
-    const unsigned lane = threadIdx.x & 63;
-    uint64_t pos = 0;
-    for (unsigned t = 0; t < nranks; ++t) {
-        const unsigned long long b = __ballot(owner == t);
-        if (!b) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&cursors[t].v, (unsigned long long)__popcll(b));
-        base = __shfl(base, 0);
-        if (owner == t) pos = out_offs.off[t] + base + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
-    }
-    if (yes) {
-        const uint32_t src = pend_src[i];
-        const int W = S::words(prm);
-        S::apply(prm, arena_cref(arena, chunk_base + (src & 0xffffffu), W), (int)(src >> 24), WordRef{send_states + pos * (uint64_t)W, 1});
+k_send_materialise(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t chunk_base, const uint32_t *__restrict__ new_src,
+                   OwnerOffsets offs, BlockPlan plan, unsigned nranks, uint64_t *__restrict__ send_states) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // global lane over all blocks
+    const uint64_t blk = g >> 6;
+    if (blk >= plan.blk_off[nranks]) return;
+    unsigned t = 0;
+    while (t + 1 < nranks && blk >= plan.blk_off[t + 1]) ++t;
+    const uint64_t j = ((blk - plan.blk_off[t]) << 6) + (g & 63);  // index inside owner t's bucket
+    const int W = S::words(prm);
+    const WordRef out{send_states + blk * (uint64_t)W * 64 + (g & 63), 64};
+    if (j < plan.cnt[t]) {
+        const uint32_t src = new_src[offs.off[t] + j];
+        S::apply(prm, arena_cref(arena, chunk_base + (src & 0xffffffu), W), (int)(src >> 24), out);
+    } else {
+        for (int w = 0; w < W; w++) out.set(w, 0);  // padding lanes of the owner's last block
     }
 }
-// owner side: append received plain records to the arena (next-level frontier)
+// owner side: append the `n` states of one received bucket (blocked layout) to the arena
 __global__ void __launch_bounds__(256)
-k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv, uint64_t n, uint64_t out0, uint64_t arena_cap,
+k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv_blocks, uint64_t n, uint64_t out0, uint64_t arena_cap,
          uint32_t *__restrict__ parent, DevCounters *ctr) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const uint64_t oidx = out0 + j;
     if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); return; }
     const WordRef o = arena_ref(arena, oidx, words);
-    for (int w = 0; w < words; w++) o.set(w, recv[j * (uint64_t)words + w]);
+    const uint64_t *src = recv_blocks + (j >> 6) * (uint64_t)words * 64 + (j & 63);
+    for (int w = 0; w < words; w++) o.set(w, src[(uint64_t)w * 64]);
     if (parent) parent[oidx] = 0xfffffffeu;  // produced on another rank: no local parent
 }
 __global__ void k_set_arena_next(DevCounters *ctr, unsigned long long v) { ctr->arena_next = v; }
@@ -671,8 +680,9 @@ struct Engine : EngineBase {
         if (d_newlist) hipFree(d_newlist);
         if (d_nsl) hipFree(d_nsl);
         if (d_inittmp) hipFree(d_inittmp);
-        if (d_rt_fp) { hipFree(d_rt_fp); hipFree(d_rt_src); hipFree(d_pend_src); }
+        if (d_rt_fp) { hipFree(d_rt_fp); hipFree(d_rt_src); hipFree(d_pend_src); hipFree(d_new_src); hipFree(d_incl); }
         if (d_rt_cur) hipFree(d_rt_cur);
+        if (d_scan_tmp) hipFree(d_scan_tmp);
         if (d_parent) hipFree(d_parent);
         if (d_pslot) hipFree(d_pslot);
         if (d_ctr) hipFree(d_ctr);
@@ -917,7 +927,9 @@ struct Engine : EngineBase {
     // ------------------------------------------------------------------ sharded step API
     uint64_t sh_lo = 0, sh_hi = 0, sh_next = 0;  // local frontier [sh_lo, sh_hi), arena fill level
     uint64_t *d_rt_fp = nullptr;
-    uint32_t *d_rt_src = nullptr, *d_pend_src = nullptr;
+    uint32_t *d_rt_src = nullptr, *d_pend_src = nullptr, *d_new_src = nullptr, *d_incl = nullptr;
+    void *d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
     PaddedCounter *d_rt_cur = nullptr;  // [nranks*NSHARD] route cursors, then [nranks] answer counts, then [nranks] state cursors
     uint64_t rt_subcap = 0, pend_cap = 0, pend_total = 0, sh_chunk_base = 0;
     OwnerOffsets pend_off;
@@ -925,12 +937,14 @@ struct Engine : EngineBase {
 
     int shard_alloc(uint64_t send_cap) {
         if (send_cap <= pend_cap) return MC_OK;
-        if (d_rt_fp) { hipFree(d_rt_fp); hipFree(d_rt_src); hipFree(d_pend_src); }
+        if (d_rt_fp) { hipFree(d_rt_fp); hipFree(d_rt_src); hipFree(d_pend_src); hipFree(d_new_src); hipFree(d_incl); }
         const unsigned P = nranks();
         rt_subcap = (send_cap / (P * NSHARD)) * 2 + 4096;
         HIP_TRY(hipMalloc(&d_rt_fp, (size_t)P * NSHARD * rt_subcap * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&d_rt_src, (size_t)P * NSHARD * rt_subcap * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&d_pend_src, send_cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&d_new_src, send_cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&d_incl, send_cap * sizeof(uint32_t)));
         if (!d_rt_cur) HIP_TRY(hipMalloc(&d_rt_cur, (size_t)(P * NSHARD + 2 * P) * sizeof(PaddedCounter)));
         pend_cap = send_cap;
         return MC_OK;
@@ -995,7 +1009,7 @@ struct Engine : EngineBase {
             total += send_counts[t];
         }
         for (unsigned t = P; t <= 8; t++) pend_off.off[t] = total;
-        if (total > send_cap) { set_error("shard_expand: send buffer too small"); return MC_EARENA; }
+        if (total > send_cap || total >= (1ull << 31)) { set_error("shard_expand: send buffer too small"); return MC_EARENA; }
         pend_total = total;
         if (total) {
             hipLaunchKernelGGL(k_compact_buckets, dim3(64, P * NSHARD), dim3(256), 0, stream, rt, send_fp, d_pend_src);
@@ -1017,27 +1031,51 @@ struct Engine : EngineBase {
         const unsigned P = nranks();
         for (unsigned t = 0; t < P; t++) send_counts[t] = 0;
         if (!pend_total) return MC_OK;
-        PaddedCounter *d_cnt = d_rt_cur + P * NSHARD, *d_cur2 = d_cnt + P;
-        HIP_TRY(hipMemsetAsync(d_cnt, 0, 2 * P * sizeof(PaddedCounter), stream));
         const unsigned bx = (unsigned)((pend_total + 255) / 256);
-        hipLaunchKernelGGL(k_count_answers, dim3(bx), dim3(256), 0, stream, answers_back, pend_total, pend_off, P, d_cnt);
-        std::vector<PaddedCounter> cnt(P);
-        HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, P * sizeof(PaddedCounter), hipMemcpyDeviceToHost, stream));
+        hipcub::TransformInputIterator<uint32_t, AnswerCast, const uint8_t *> in(answers_back, AnswerCast());
+        size_t need = 0;
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, need, in, d_incl, (int)pend_total, stream));
+        if (need > scan_tmp_bytes) {
+            if (d_scan_tmp) hipFree(d_scan_tmp);
+            HIP_TRY(hipMalloc(&d_scan_tmp, need));
+            scan_tmp_bytes = need;
+        }
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_scan_tmp, need, in, d_incl, (int)pend_total, stream));
+        unsigned long long *d_ends = (unsigned long long *)(d_rt_cur + P * NSHARD);
+        hipLaunchKernelGGL(k_gather_range_ends, dim3(1), dim3(64), 0, stream, d_incl, pend_off, P, d_ends);
+        unsigned long long ends[8];
+        HIP_TRY(hipMemcpyAsync(ends, d_ends, P * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        OwnerOffsets out_off;
-        uint64_t total = 0;
-        for (unsigned t = 0; t < P; t++) { out_off.off[t] = total; send_counts[t] = cnt[t].v; total += cnt[t].v; }
-        for (unsigned t = P; t <= 8; t++) out_off.off[t] = total;
-        if (total > send_cap) { set_error("shard_materialise: state send buffer too small"); return MC_EARENA; }
-        if (total) {
-            timed(2, total, [&] {
-                hipLaunchKernelGGL(k_send_materialise<S>, dim3(bx), dim3(256), 0, stream, prm, d_arena, sh_chunk_base, d_pend_src,
-                                   answers_back, pend_total, pend_off, out_off, P, d_cur2, (uint64_t *)send_states);
+        OwnerOffsets start;
+        std::vector<PaddedCounter> cnt(P);
+        for (unsigned t = 0; t <= 8; t++) start.off[t] = 0;
+        for (unsigned t = 0; t < P; t++) {
+            start.off[t] = t ? ends[t - 1] : 0;
+            cnt[t].v = ends[t] - start.off[t];
+        }
+        hipLaunchKernelGGL(k_compact_new, dim3(bx), dim3(256), 0, stream, answers_back, d_incl, d_pend_src, pend_total, pend_off, start, P,
+                           d_new_src);
+        BlockPlan plan;
+        uint64_t blocks = 0;
+        for (unsigned t = 0; t < 8; t++) {
+            plan.blk_off[t] = blocks;
+            plan.cnt[t] = t < P ? cnt[t].v : 0;
+            if (t < P) { send_counts[t] = cnt[t].v; blocks += (cnt[t].v + 63) / 64; }
+        }
+        plan.blk_off[8] = blocks;
+        for (unsigned t = P; t < 8; t++) plan.blk_off[t] = blocks;
+        if (blocks * 64 > send_cap) { set_error("shard_materialise: state send buffer too small"); return MC_EARENA; }
+        if (blocks) {
+            timed(2, blocks * 64, [&] {
+                hipLaunchKernelGGL(k_send_materialise<S>, dim3((unsigned)((blocks * 64 + 255) / 256)), dim3(256), 0, stream, prm, d_arena,
+                                   sh_chunk_base, d_new_src, pend_off, plan, P, (uint64_t *)send_states);
             });
         }
         HIP_TRY(hipStreamSynchronize(stream));
         return MC_OK;
     }
+    // recv_states: one bucket per source rank, back to back, each a whole number of 64-state blocks;
+    // n = valid states of ONE bucket starting at recv_states (call once per source)
     int shard_ingest(const uint8_t *recv_states, uint64_t n) override {
         HIP_TRY(hipSetDevice(cfg.device));
         if (!n) return MC_OK;

@@ -20,6 +20,8 @@ per level is the all-reduced maximum.
 This module only orchestrates; all compute is in libtlamc.so (HIP).  Tests drive the same loop
 on CPU with gloo and the host build of the lowerings (tests/_shim)."""
 import math
+import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -112,6 +114,14 @@ class ShardedChecker:
         dist.all_to_all_single(recv, src, [c * elem for c in recv_counts], [c * elem for c in send_counts], group=self.group)
         return recv.to(self.dev), recv_counts
 
+    def _exchange_counts(self, send_counts):
+        if not self.collective:
+            return list(send_counts)
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.comm_dev)
+        rc = torch.empty(self.world, dtype=torch.int64, device=self.comm_dev)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        return [int(x) for x in rc.tolist()]
+
     def _a2a_back(self, send, send_counts, recv_counts):
         """reverse direction with known sizes (answers travel back along the fingerprints' path)"""
         if not self.collective:
@@ -124,6 +134,7 @@ class ShardedChecker:
     # ---------------------------------------------------------------- BFS
     def run(self):
         e, SUM, MAX = self.eng, dist.ReduceOp.SUM, dist.ReduceOp.MAX
+        self.phase_s = {}   # wall seconds per phase of the last run (this rank)
         e.begin()
         frontier = self._allreduce(e.level_size(), SUM)
         levels, cum, level, budget = [frontier], frontier, 1, False
@@ -139,19 +150,38 @@ class ShardedChecker:
             for r in range(rounds):
                 first = min(r * self.chunk, local_n)
                 count = min(self.chunk, local_n - first)
+                t0 = time.perf_counter()
                 counts = e.expand(first, count, self.send_fp)
                 e.sync()
+                t1 = time.perf_counter()
                 recv_fp, rcounts = self._a2a(self.send_fp, counts, 1)
                 n = sum(rcounts)
                 answers = torch.empty(max(n, 1), dtype=torch.uint8, device=self.dev)
                 e.sync()
+                t2 = time.perf_counter()
                 e.probe(recv_fp, n, answers)
+                t3 = time.perf_counter()
                 back = self._a2a_back(answers, rcounts, counts)
                 e.sync()
+                t4 = time.perf_counter()
                 scounts = e.materialise(back, self.send_states)
-                recv_states, rsc = self._a2a(self.send_states, scounts, self.W)
+                t5 = time.perf_counter()
+                # full states travel as whole 64-state blocks per owner (coalesced at both ends)
+                blocks = [(c + 63) // 64 for c in scounts]
+                recv_states, rblocks = self._a2a(self.send_states, blocks, 64 * self.W)
+                rsc = self._exchange_counts(scounts)
                 e.sync()
-                e.ingest(recv_states, sum(rsc))
+                t6 = time.perf_counter()
+                off = 0
+                for src_rank in range(len(rsc)):            # one bucket per source rank
+                    if rsc[src_rank]:
+                        e.ingest(recv_states[off * 64 * self.W:], rsc[src_rank])
+                    off += rblocks[src_rank]
+                t7 = time.perf_counter()
+                for k, dt in zip(("expand", "a2a_fp", "probe", "a2a_ans", "materialise", "a2a_states", "ingest"),
+                                 (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6)):
+                    self.phase_s[k] = self.phase_s.get(k, 0.0) + dt
+                self.phase_s["rounds"] = self.phase_s.get("rounds", 0) + 1
             frontier = self._allreduce(e.end_level(), SUM)
             if frontier > 0:
                 level += 1
@@ -162,6 +192,8 @@ class ShardedChecker:
         verdict = self._allreduce(verdict, MAX)
         if verdict == 0 and budget:
             verdict = 5
+        if os.environ.get("TLAMC_PHASES") and self.rank == 0:
+            print("phases[s]:", {k: round(v, 4) for k, v in self.phase_s.items()}, flush=True)
         return Result(distinct=cum, generated=generated, queue_left=frontier, depth=level, verdict=VERDICTS[verdict],
                       violated_invariant=-1, trace_len=0, levels=levels, seconds=0.0)
 
