@@ -1,0 +1,123 @@
+"""Front-end of libtlamc.so: the .cfg parser (ConfigFileGrammar.tla:4-32) on every cfg file of the
+reference tree, spec resolution, and (GPU) the `tlc X.tla` end-to-end path with its report text."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import tla_rust_amd
+    return tla_rust_amd
+
+
+def test_parses_every_reference_cfg(amd):
+    """all 22 cfg files of the reference tree (needs /root/reference)."""
+    if not REF.exists():
+        pytest.skip("reference tree not present on this box")
+    files = sorted(REF.rglob("*.cfg")) + sorted(REF.rglob("*.cfg.alt"))
+    assert len(files) == 22
+    for f in files:
+        c = amd.cfg_parse(f.read_text())
+        assert isinstance(c["CONSTANTS"], list), f
+
+
+FEATURES = r'''
+(* boxed
+   multi-line comment *)
+  SPECIFICATION Spec  \* trailing comment
+CONSTANTS
+  a1=a1  a2=a2        \* several on one line, no spaces
+  Acceptor <- MCAcceptor
+  Ballot <-[Voting] MCBallot
+  Proc = {p1, p2}     Val = {"a", "b", "c"}   MaxQLen = 1   Neg = -3
+  Empty = {}
+INVARIANT Inv1 Inv2
+INVARIANTS Inv3
+PROPERTY Live
+CONSTRAINT Constraint
+ACTION-CONSTRAINT ActC
+SYMMETRY Perms
+VIEW V
+INIT Init
+NEXT Next
+'''
+
+
+def test_cfg_features(amd):
+    c = amd.cfg_parse(FEATURES)
+    assert c["SPECIFICATION"] == "Spec" and c["INIT"] == "Init" and c["NEXT"] == "Next"
+    assert c["INVARIANTS"] == ["Inv1", "Inv2", "Inv3"] and c["PROPERTIES"] == ["Live"]
+    assert c["CONSTRAINTS"] == ["Constraint"] and c["ACTION_CONSTRAINTS"] == ["ActC"]
+    assert c["SYMMETRY"] == "Perms" and c["VIEW"] == "V"
+    k = {x["name"]: x for x in c["CONSTANTS"]}
+    assert k["a1"]["value"] == {"model_value": "a1"} and k["a2"]["value"] == {"model_value": "a2"}
+    assert k["Acceptor"]["replace_by"] == "MCAcceptor" and "module" not in k["Acceptor"]
+    assert k["Ballot"]["replace_by"] == "MCBallot" and k["Ballot"]["module"] == "Voting"
+    assert k["Proc"]["value"] == {"set": [{"model_value": "p1"}, {"model_value": "p2"}]}
+    assert k["Val"]["value"] == {"set": ["a", "b", "c"]} and k["MaxQLen"]["value"] == 1 and k["Neg"]["value"] == -3
+    assert k["Empty"]["value"] == {"set": []}
+
+
+@pytest.mark.parametrize("bad", ["SPECIFICATION", "CONSTANTS x", "CONSTANT x = {a, }", "FOO Bar", "(* never closed", "CONSTANT x <- 3",
+                                 'CONSTANT s = "open'])
+def test_cfg_rejects_malformed(amd, bad):
+    with pytest.raises(amd.McError) as e:
+        amd.cfg_parse(bad)
+    assert e.value.code == -8
+
+
+def test_empty_cfg_is_valid(amd):
+    c = amd.cfg_parse("(* only a comment *)\n\\* and another\n")
+    assert c["SPECIFICATION"] == "" and c["CONSTANTS"] == []
+
+
+def test_cli_is_built():
+    import tla_rust_amd.build as b
+    b.build()
+    assert (ROOT / "tla_rust_amd" / "_build" / "mc").exists()
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_tlc_dropin_committed_pcal_intro(amd):
+    r, rep = amd.check_files(ROOT / "specs" / "pcal_intro.tla")
+    assert r.verdict == "ok" and (r.distinct, r.generated, r.depth) == (3800, 5850, 5)
+    assert "Finished computing initial states: 400 distinct states generated." in rep
+    assert "Model checking completed. No error has been found." in rep                       # testout2:260
+    assert "5850 states generated, 3800 distinct states found, 0 states left on queue." in rep   # README.md:319 format
+    assert "The depth of the complete state graph search is 5." in rep                        # README.md:320 format
+
+
+@pytest.mark.gpu
+def test_tlc_dropin_readme_variant_report(amd):
+    r, rep = amd.check_files(ROOT / "specs" / "readme_variant" / "pcal_intro.tla")
+    assert r.verdict == "assert" and r.trace_len == 6
+    lines = rep.splitlines()
+    assert lines[1] == "The first argument of Assert evaluated to FALSE; the second argument was:"   # README.md:268
+    assert lines[2] == '"Failure of assertion at line 16, column 4."'                                # README.md:269
+    assert lines[3] == "Error: The behavior up to this point is:"                                    # README.md:270
+    assert lines[4] == "State 1: <Initial predicate>"                                                # README.md:271
+    assert rep.count("\nState ") == 6 and "/\\ pc = <<\"C\", \"B\">>" in rep or "/\\ pc = <<\"B\", \"C\">>" in rep
+    assert "The depth of the complete state graph search is 7." in rep                               # README.md:320
+
+
+@pytest.mark.gpu
+def test_cli_exit_codes_and_raft(amd):
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "atomic_add.tla")], capture_output=True, text=True)
+    assert p.returncode == 0 and "7 states generated, 5 distinct states found, 0 states left on queue." in p.stdout
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "readme_variant" / "pcal_intro.tla")], capture_output=True, text=True)
+    assert p.returncode == 12
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCraft.tla"), "-config", str(ROOT / "specs" / "MCraft_small.cfg")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "104515 states generated, 13634 distinct states found, 0 states left on queue." in p.stdout
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "atomic_add_n.tla")], capture_output=True, text=True)
+    assert p.returncode == 0 and f"{2**20 + 1} distinct states found" in p.stdout
+    p = subprocess.run([str(mc), str(ROOT / "include" / "tlamc.h")], capture_output=True, text=True)
+    assert p.returncode == 1

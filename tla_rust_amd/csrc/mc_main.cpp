@@ -1,0 +1,54 @@
+// mc — command-line front door of libtlamc.so; the drop-in for `tlc X.tla` of the reference's
+// Makefile:6-7 / README.md:262 (same inputs: X.tla with X.cfg beside it; same report lines:
+// README.md:267-321).  All work happens behind the C ABI (include/tlamc.h).
+//
+//   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D]
+//            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
+//
+// -deadlock : as with TLC, do NOT check for deadlock.  -workers is accepted and ignored (the
+// GPU is the worker pool).  Exit status: 0 no error, 12 safety violation (invariant / assert),
+// 11 deadlock, 1 any other failure — TLC's convention.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/tlamc.h"
+
+int main(int argc, char **argv) {
+    const char *tla = nullptr, *cfgp = nullptr;
+    mc_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.flags = MC_F_DEADLOCK | MC_F_TRACE;
+    cfg.table_capacity = 1ull << 26;
+    cfg.arena_capacity = 1ull << 24;
+    for (int i = 1; i < argc; i++) {
+        auto arg = [&](const char *name) { return !strcmp(argv[i], name) && i + 1 < argc; };
+        if (arg("-config")) cfgp = argv[++i];
+        else if (!strcmp(argv[i], "-deadlock")) cfg.flags &= ~MC_F_DEADLOCK;
+        else if (arg("-workers")) ++i;
+        else if (arg("-device")) cfg.device = atoi(argv[++i]);
+        else if (arg("-maxdistinct")) cfg.max_distinct = strtoull(argv[++i], 0, 10);
+        else if (arg("-maxlevels")) cfg.max_levels = strtoull(argv[++i], 0, 10);
+        else if (arg("-tablelog2")) cfg.table_capacity = 1ull << atoi(argv[++i]);
+        else if (arg("-arena")) cfg.arena_capacity = strtoull(argv[++i], 0, 10);
+        else if (arg("-chunk")) cfg.chunk_states = strtoull(argv[++i], 0, 10);
+        else if (argv[i][0] != '-') tla = argv[i];
+        else { fprintf(stderr, "mc: unknown option %s\n", argv[i]); return 1; }
+    }
+    if (!tla) {
+        fprintf(stderr, "usage: mc X.tla [-config X.cfg] [-deadlock] [-device D] [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N]\n");
+        return 1;
+    }
+    std::vector<char> report(1 << 22);
+    static mc_result res;
+    const int rc = mc_check_files(tla, cfgp, &cfg, report.data(), report.size(), &res);
+    if (rc) {
+        fprintf(stderr, "mc: %s: %s\n", mc_strerror(rc), mc_last_error());
+        return 1;
+    }
+    fputs(report.data(), stdout);
+    if (res.verdict == MC_V_OK || res.verdict == MC_V_BUDGET) return 0;
+    return res.verdict == MC_V_DEADLOCK ? 11 : 12;
+}
