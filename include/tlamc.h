@@ -116,6 +116,8 @@ int mc_engine_kernel_stats(mc_engine *e, mc_kernel_stats *out);
 /* copy `count` resident states starting at arena index `first` (discovery order: level by level)
  * to the host, mc_state_bytes() bytes each — TLC's "states/" dump, for tests and tooling */
 int mc_engine_read_states(mc_engine *e, uint64_t first, uint64_t count, uint8_t *out);
+/* profiling aid: re-expand every resident state of the last run (all probes hit); extra_flags 16 = no probes */
+int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms);
 void mc_engine_destroy(mc_engine *e);
 
 /* ------------------------------------------------------------------ sharded (multi-GPU) step API

@@ -73,6 +73,7 @@ def lib():
     L.mc_engine_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
     L.mc_engine_kernel_stats.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
     L.mc_engine_read_states.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.mc_engine_debug_reexpand.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_double)]
     L.mc_engine_destroy.argtypes = [C.c_void_p]
     L.mc_engine_destroy.restype = None
     L.mc_state_bytes.argtypes = [C.POINTER(SpecDesc)]
@@ -148,11 +149,11 @@ class Engine:
     """One model-checking engine on one GPU (mc_engine_create / run / trace / destroy)."""
 
     def __init__(self, spec, params, device=0, table_capacity=0, arena_capacity=0, chunk_states=0, max_levels=0,
-                 max_distinct=0, deadlock=True, trace=True, timing=False, matrix=False, shard_rank=0, shard_count=1):
+                 max_distinct=0, deadlock=True, trace=True, timing=False, matrix=False, shard_rank=0, shard_count=1, debug_flags=0):
         self.spec, self.params = spec, list(params)
         self.desc = spec_desc(spec, params)
         flags = (MC_F_DEADLOCK if deadlock else 0) | (MC_F_TRACE if trace else 0) | (MC_F_TIMING if timing else 0) | \
-            (MC_F_MATRIX if matrix else 0)
+            (MC_F_MATRIX if matrix else 0) | debug_flags
         self.cfg = Config(device, flags, table_capacity, arena_capacity, chunk_states, max_levels, max_distinct,
                           shard_rank, shard_count)
         self._h = C.c_void_p()
@@ -185,6 +186,11 @@ class Engine:
 
     def state_texts(self, first, count):
         return [state_format(self.spec, self.params, s) for s in self.read_states(first, count)]
+
+    def debug_reexpand(self, extra_flags=0):
+        ms = C.c_double()
+        _check(lib().mc_engine_debug_reexpand(self._h, extra_flags, C.byref(ms)), "mc_engine_debug_reexpand")
+        return ms.value
 
     def kernel_stats(self):
         ks = KernelStats()

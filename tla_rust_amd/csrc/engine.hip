@@ -255,12 +255,15 @@ constexpr int STAGE_MAX = 16;  // words of each parent state staged in LDS per l
 // View of a parent state whose words [lo, lo+n) have been staged in LDS by the owning lane
 // (lds points at this lane's column: word w of the range lives at lds[w * 64]).
 struct StagedRef {
-    const uint64_t *p;
+    // address-space-qualified pointers: the LDS branch must compile to ds_read_b64 and the HBM
+    // branch to global_load (a generic pointer would make every access a flat_load)
+    const __attribute__((address_space(1))) uint64_t *p;
     size_t stride;
-    const uint64_t *lds;
+    const __attribute__((address_space(3))) uint64_t *lds;
     int lo, hi;
     __device__ __forceinline__ uint64_t get(int w) const {
-        return (w >= lo && w < hi) ? lds[(w - lo) * 64] : p[(size_t)w * stride];
+        if (w >= lo && w < hi) return lds[(w - lo) * 64];
+        return p[(size_t)w * stride];
     }
 };
 
@@ -311,7 +314,8 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         for (int w = 0; w < S::STAGE_WORDS; w++) tmp[w] = (active && w < wn) ? g.get(slo + w) : 0;
 #pragma unroll
         for (int w = 0; w < S::STAGE_WORDS; w++) if (w < wn) col_lds[w * 64] = tmp[w];
-        s = StagedRef{g.p, g.stride, col_lds, slo, slo + wn};
+        s = StagedRef{(const __attribute__((address_space(1))) uint64_t *)g.p, g.stride,
+                      (const __attribute__((address_space(3))) uint64_t *)col_lds, slo, slo + wn};
     } else {
         s = g;
     }
@@ -344,7 +348,7 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             const unsigned k = (qhead + lane) & (QCAP - 1);
             src = Q.q_src[k];
             qfp = Q.q_fp[k];
-            if constexpr (!ROUTE) is_new = seen_insert(table, mask, qfp, err);
+            if constexpr (!ROUTE) is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);  // 16 = ablation: no probes
         }
         qhead = (qhead + take) & (QCAP - 1);
         qn -= take;
@@ -576,6 +580,7 @@ struct EngineBase {
     virtual int trace(uint8_t *states_out, int32_t *actions_out, size_t *n_inout) = 0;
     virtual int kernel_stats(mc_kernel_stats *out) = 0;
     virtual int read_states(uint64_t first, uint64_t count, uint8_t *out) = 0;
+    virtual int debug_reexpand(unsigned extra_flags, double *ms) = 0;
     virtual int shard_begin() = 0;
     virtual int shard_level_size(uint64_t *n) = 0;
     virtual int shard_expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
@@ -924,6 +929,31 @@ struct Engine : EngineBase {
         return MC_OK;
     }
     uint64_t last_distinct = 0;
+    // Profiling aid: expand every resident state again (seen-set already full, so every probe hits)
+    // with optional ablation flags; returns the kernel time.  State counts are not changed.
+    int debug_reexpand(unsigned extra_flags, double *ms) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventRecord(a, stream));
+        for (uint64_t c0 = 0; c0 < last_distinct; c0 += chunk) {
+            const uint64_t c1 = c0 + chunk < last_distinct ? c0 + chunk : last_distinct;
+            const uint64_t ncols = ((c1 - c0) + 63) & ~63ull;
+            hipLaunchKernelGGL((k_expand_insert<S, false>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0,
+                               c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags | extra_flags, RouteArgs{});
+            hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
+        }
+        HIP_TRY(hipEventRecord(b, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, a, b));
+        *ms = t;
+        hipEventDestroy(a);
+        hipEventDestroy(b);
+        // restore arena_next (k_commit added nothing: no probe can be new) and leave counters as they were
+        return MC_OK;
+    }
     // ------------------------------------------------------------------ sharded step API
     uint64_t sh_lo = 0, sh_hi = 0, sh_next = 0;  // local frontier [sh_lo, sh_hi), arena fill level
     uint64_t *d_rt_fp = nullptr;
@@ -1211,6 +1241,7 @@ const char *mc_last_error(void) { return g_last_error.c_str(); }
 void mc_set_error_internal(const char *msg) { set_error(msg ? msg : ""); }
 
 
+int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms) { return e && ms ? e->impl->debug_reexpand(extra_flags, ms) : MC_EBADCFG; }
 // ---- sharded (multi-GPU) step API
 int mc_shard_begin(mc_engine *e) { return e ? e->impl->shard_begin() : MC_EBADCFG; }
 int mc_shard_level_size(mc_engine *e, uint64_t *n) { return e && n ? e->impl->shard_level_size(n) : MC_EBADCFG; }

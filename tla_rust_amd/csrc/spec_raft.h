@@ -227,6 +227,10 @@ struct SpecRaft {
         unsigned addmask;      // servers whose log is not yet in allLogs (raft.tla:493), first occurrence only
         int nadd;              // popcount(addmask)
         uint64_t add_fp;       // sum of their contributions
+        // (precomputing H(glob), H(sv[i]), ... once per parent was measured SLOWER — +10 % expand,
+        //  +40 % materialise: most successors touch few words, and the registers cost occupancy)
+        int cache_k;           // message slot whose H(word) is cached (Receive / Duplicate / Drop share it)
+        uint64_t cache_hm;
     };
     template <class Ref>
     MC_HD static void load(const Params &prm, Ref s, Local &l) {
@@ -247,6 +251,8 @@ struct SpecRaft {
 #pragma unroll
             for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
         }
+        l.cache_k = -1;
+        l.cache_hm = 0;
         l.addmask = 0;
         l.nadd = 0;
         l.add_fp = 0;
@@ -270,6 +276,7 @@ struct SpecRaft {
         int srv;                 // the one server whose words change (-1: none)
         uint64_t sv, log;        // its new scalars / log
         uint64_t osv, olog;      // ... and the old ones
+        bool pre;                // srv is a compile-time server: use the parent's precomputed hashes
         int vmode;               // 0 voterLog[srv] unchanged, 1 cleared, 2 one entry set
         int vj; uint64_t vlog;
         int nmop;                // message slots rewritten: op A (send) and op B (discard / dup)
@@ -318,9 +325,16 @@ struct SpecRaft {
     // compute the successor of `slot`; returns status bits (0 = not enabled).  When `slot` is a
     // compile-time constant (the unrolled FIX_SLOTS part of the expand kernel) every server index
     // below folds to a constant and the pick()s disappear.
-    template <class Ref>
+    // MEM = true (k_materialise: `slot` differs per lane): server words are read from the state
+    // itself instead of select-indexing the register copy, which would be demoted to scratch.
+    template <bool MEM, class Ref>
+    MC_HD static uint64_t srv_word(const Local &l, Ref s, int i) { if (MEM) return s.get(W_SRV(i)); return l.sv.get(i); }
+    template <bool MEM, class Ref>
+    MC_HD static uint64_t log_word(const Local &l, Ref s, int i) { if (MEM) return s.get(W_LOG(i)); return l.log.get(i); }
+
+    template <bool MEM = false, class Ref>
     MC_HD static unsigned compute(const Params &prm, const Local &l, Ref s, int slot, Delta &d, int &action) {
-        d.glob = l.glob; d.clog = l.clog; d.srv = -1; d.sv = d.osv = 0; d.log = d.olog = 0; d.vmode = 0; d.vj = 0; d.vlog = 0;
+        d.glob = l.glob; d.clog = l.clog; d.srv = -1; d.sv = d.osv = 0; d.log = d.olog = 0; d.pre = true; d.vmode = 0; d.vj = 0; d.vlog = 0;
         d.nmop = 0; d.midxA = d.midxB = -1; d.moldA = d.mnewA = d.moldB = d.mnewB = 0;
         d.eadd = false; d.dinflight = 0;
         d.ew = RegArr<EL_WORDS>();
@@ -328,30 +342,30 @@ struct SpecRaft {
         if (slot < NS) {  // Restart(i)   raft.tla:186-194 (always enabled)
             const int i = slot;
             action = RA_RESTART;
-            d.srv = i; d.osv = l.sv.get(i); d.olog = d.log = l.log.get(i);
+            d.srv = i; d.osv = srv_word<MEM>(l, s, i); d.olog = d.log = log_word<MEM>(l, s, i);
             d.sv = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(d.osv, R_FOLLOWER), 0), 0), 1);
             d.vmode = 1;
         } else if (slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
             const int i = slot - NS;
             action = RA_TIMEOUT;
-            const uint64_t svi = l.sv.get(i);
+            const uint64_t svi = srv_word<MEM>(l, s, i);
             const int stt = sv_state(svi);
             if (!(stt == R_FOLLOWER || stt == R_CANDIDATE)) return 0;
             const int nt = sv_term(svi) + 1;
             if (nt > prm.max_term) st |= ST_OUT_OF_MODEL;
-            d.srv = i; d.osv = svi; d.olog = d.log = l.log.get(i);
+            d.srv = i; d.osv = svi; d.olog = d.log = log_word<MEM>(l, s, i);
             d.sv = sv_set_granted(sv_set_voted(sv_set_term(sv_set_state(svi, R_CANDIDATE), nt & 7), 0), 0);
             d.vmode = 1;
         } else if (slot < 2 * NS + NS * NS) {  // RequestVote(i, j)   raft.tla:209-217
             const int q = slot - 2 * NS, i = q / NS, j = q % NS;
             action = RA_REQUESTVOTE;
-            const uint64_t svi = l.sv.get(i), lgi = l.log.get(i);
+            const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_CANDIDATE) return 0;
             st |= send(l, s, prm.cm, mk_rvreq(sv_term(svi), rlog::last_term(lgi), rlog::len(lgi), i, j), d);
         } else if (slot < 3 * NS + NS * NS) {  // BecomeLeader(i)   raft.tla:247-261
             const int i = slot - (2 * NS + NS * NS);
             action = RA_BECOMELEADER;
-            const uint64_t svi = l.sv.get(i), lgi = l.log.get(i);
+            const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_CANDIDATE || !in_quorum(sv_granted(svi))) return 0;
             d.srv = i; d.osv = svi; d.olog = d.log = lgi;
             d.sv = sv_reset_leader_vars(sv_set_state(svi, R_LEADER), rlog::len(lgi) + 1);
@@ -377,7 +391,7 @@ struct SpecRaft {
             const int i = slot - (3 * NS + NS * NS);
             action = RA_CLIENTREQUEST;
             const int creq = g_creq(l.glob);
-            const uint64_t svi = l.sv.get(i), lgi = l.log.get(i);
+            const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_LEADER || !(creq < prm.max_client_requests)) return 0;
             if (rlog::len(lgi) >= rlog::LCAP) return ST_ENABLED | ST_OVERFLOW;
             d.srv = i; d.osv = d.sv = svi; d.olog = lgi;
@@ -387,7 +401,7 @@ struct SpecRaft {
         } else if (slot < 5 * NS + NS * NS) {  // AdvanceCommitIndex(i)   raft.tla:280-305
             const int i = slot - (4 * NS + NS * NS);
             action = RA_ADVANCECOMMIT;
-            const uint64_t svi = l.sv.get(i), lg = l.log.get(i);
+            const uint64_t svi = srv_word<MEM>(l, s, i), lg = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_LEADER) return 0;
             int maxAgree = 0;
             for (int index = 1; index <= rlog::len(lg); index++) {
@@ -411,7 +425,7 @@ struct SpecRaft {
         } else if (slot < FIX) {  // AppendEntries(i, j)   raft.tla:222-244
             const int q = slot - (5 * NS + NS * NS), i = q / NS, j = q % NS;
             action = RA_APPENDENTRIES;
-            const uint64_t svi = l.sv.get(i), lg = l.log.get(i);
+            const uint64_t svi = srv_word<MEM>(l, s, i), lg = log_word<MEM>(l, s, i);
             if (i == j || sv_state(svi) != R_LEADER) return 0;
             const int next = sv_next(svi, j), prevIdx = next - 1;
             int prevTerm = 0;
@@ -445,7 +459,7 @@ struct SpecRaft {
                 // select-indexing the register copy
                 const uint64_t svi = s.get(W_SRV(i)), lg = s.get(W_LOG(i));
                 const int term = sv_term(svi);
-                d.srv = i; d.osv = d.sv = svi; d.olog = d.log = lg;
+                d.srv = i; d.osv = d.sv = svi; d.olog = d.log = lg; d.pre = false;
                 if (mterm > term) {  // UpdateTerm   raft.tla:434-440 (message not consumed)
                     d.sv = sv_set_voted(sv_set_state(sv_set_term(svi, mterm), R_FOLLOWER), 0);
                     if (mterm > prm.max_term) st |= ST_OUT_OF_MODEL;
@@ -528,15 +542,14 @@ struct SpecRaft {
     }
 
     template <class Ref>
-    MC_HD static uint64_t delta_fp(const Local &l, Ref s, const Delta &d) {
+    MC_HD static uint64_t delta_fp(Local &l, Ref s, const Delta &d) {
         uint64_t fp = l.fp + l.add_fp;
         if (d.glob != l.glob) fp += hmix(d.glob, salt_of(W_GLOB)) - hmix(l.glob, salt_of(W_GLOB));
         if (d.clog != l.clog) fp += hmix(d.clog, salt_of(W_CLOG)) - hmix(l.clog, salt_of(W_CLOG));
         if (d.srv >= 0) {
             const int i = d.srv;
-            const uint64_t osv = d.osv, olog = d.olog;
-            if (d.sv != osv) fp += hmix(d.sv, salt_of((unsigned)W_SRV(i))) - hmix(osv, salt_of((unsigned)W_SRV(i)));
-            if (d.log != olog) fp += hmix(d.log, salt_of((unsigned)W_LOG(i))) - hmix(olog, salt_of((unsigned)W_LOG(i)));
+            if (d.sv != d.osv) fp += hmix(d.sv, salt_of((unsigned)W_SRV(i))) - hmix(d.osv, salt_of((unsigned)W_SRV(i)));
+            if (d.log != d.olog) fp += hmix(d.log, salt_of((unsigned)W_LOG(i))) - hmix(d.olog, salt_of((unsigned)W_LOG(i)));
             if (d.vmode == 1) {
 #pragma unroll
                 for (int j = 0; j < NS; j++) {
@@ -551,17 +564,23 @@ struct SpecRaft {
             if (d.midxA < l.nm) fp -= hmix(d.moldA, SALT_M);
             fp += hmix(d.mnewA, SALT_M);
         }
-        if (d.nmop & 2) fp += hmix(d.mnewB, SALT_M) - hmix(d.moldB, SALT_M);
+        if (d.nmop & 2) {  // the message the slot was read from: Receive, Duplicate and Drop of one k share H(old)
+            if (l.cache_k != d.midxB) { l.cache_k = d.midxB; l.cache_hm = hmix(d.moldB, SALT_M); }
+            fp += hmix(d.mnewB, SALT_M) - l.cache_hm;
+        }
         if (d.eadd) fp += helec(d.ew);
         return fp;
     }
 
     template <class Ref>
-    MC_HD static unsigned eval(const Params &prm, const Local &l, Ref s, int slot, uint64_t &fp) {
+    MC_HD static unsigned eval(const Params &prm, Local &l, Ref s, int slot, uint64_t &fp) {
         Delta d;
         int action;
         const unsigned st = compute(prm, l, s, slot, d, action);
         if (!(st & ST_ENABLED)) return 0;
+        // a successor outside the CONSTRAINT is generated and invariant-checked (done in compute) but
+        // never stored, so its fingerprint is not needed
+        if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
         fp = fp_nonzero(delta_fp(l, s, d));
         return st;
     }
@@ -572,7 +591,7 @@ struct SpecRaft {
         load(prm, s, l);
         Delta d;
         int action;
-        const unsigned st = compute(prm, l, s, slot, d, action);
+        const unsigned st = compute<true>(prm, l, s, slot, d, action);
         const int nw = words(prm);
         if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) {
             for (int w = 0; w < nw; w++) out.set(w, s.get(w));
