@@ -309,6 +309,7 @@ int oracle_run(const char *spec, const int64_t *params, int nparams, const or_op
     if (!strcmp(spec, "atomic_add")) rc = or_spec_atomic_add(params, nparams, &sp);
     else if (!strcmp(spec, "pcal_intro")) rc = or_spec_pcal_intro(params, nparams, &sp);
     else if (!strcmp(spec, "raft")) rc = or_spec_raft(params, nparams, &sp);
+    else if (!strcmp(spec, "ssi")) rc = or_spec_ssi(params, nparams, &sp);
     else { or_set_error("unknown spec '%s'", spec); return -1; }
     if (rc) return rc;
     or_options o = {0, 0, 1, 1, NULL};
@@ -323,5 +324,6 @@ const char *oracle_action_name(const char *spec, int action) {
     if (!strcmp(spec, "atomic_add")) return or_atomic_add_action(action);
     if (!strcmp(spec, "pcal_intro")) return or_pcal_intro_action(action);
     if (!strcmp(spec, "raft")) return or_raft_action(action);
+    if (!strcmp(spec, "ssi")) return or_ssi_action(action);
     return "?";
 }

@@ -74,10 +74,11 @@ typedef struct {
     uint64_t arena_bytes;
 } or_result;
 
-/* spec = "atomic_add" | "pcal_intro" | "raft"; params = spec-specific int list:
+/* spec = "atomic_add" | "pcal_intro" | "raft" | "ssi"; params = spec-specific int list:
  *   atomic_add : {N adders}
  *   pcal_intro : {variant (0 = committed file, 1 = README variant with labels A/B),
  *                 check MoneyInvariant (0/1), MaxMoney (20), nproc (2)}
+ *   ssi        : {nTxn, nKey, invariant mask (127 = all), find}  — see spec_ssi.c
  *   raft       : {nServer, MaxClientRequests, MaxTerm, MaxLogLen, MaxMsgs, invariant mask
  *                 (bit0 NoTwoLeaders, bit1 CommittedLogStable), naive_commit (0; 1 = the
  *                 "obvious but wrong" lowering of raft.tla:392-402, a negative control)}
@@ -89,6 +90,8 @@ int oracle_run(const char *spec, const int64_t *params, int nparams,
 const char *oracle_trace_state(uint32_t k);
 const char *oracle_action_name(const char *spec, int action);
 const char *oracle_last_error(void);
+/* the in-spec unit tests of serializableSnapshotIsolation.tla:1068-1077,1184-1205; returns #failures */
+int oracle_ssi_unit_tests(void);
 
 #ifdef __cplusplus
 }

@@ -28,9 +28,11 @@ typedef struct or_spec {
 int or_spec_atomic_add(const int64_t *p, int np, or_spec *out);
 int or_spec_pcal_intro(const int64_t *p, int np, or_spec *out);
 int or_spec_raft(const int64_t *p, int np, or_spec *out);
+int or_spec_ssi(const int64_t *p, int np, or_spec *out);
 const char *or_atomic_add_action(int a);
 const char *or_pcal_intro_action(int a);
 const char *or_raft_action(int a);
+const char *or_ssi_action(int a);
 
 void or_set_error(const char *fmt, ...);
 
