@@ -93,6 +93,8 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
             typename S::Local loc;
             S::load(prm, s, loc);
             const int ns = S::nslots(prm, loc);
+            const unsigned ps = S::parent_status(prm, loc, s);
+            if (ps & ST_INVARIANT) violation(ps, level);
             uint64_t nsucc = 0;
             for (int slot = 0; slot < ns; slot++) {
                 uint64_t fp = 0;
@@ -191,6 +193,7 @@ struct ShimShard : ShimShardBase {
             typename S::Local loc;
             S::load(prm, s, loc);
             const int ns = S::nslots(prm, loc);
+            if (S::parent_status(prm, loc, s) & ST_INVARIANT) verdict = MC_V_INVARIANT;
             uint64_t nsucc = 0;
             for (int slot = 0; slot < ns; slot++) {
                 uint64_t fp = 0;

@@ -74,7 +74,7 @@ def oracle_run(spec, params, max_levels=0, max_distinct=0, check_deadlock=True, 
 
 # ---------------------------------------------------------------------------------- shim
 MC_MAX_LEVELS = 4096
-SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3}
+SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4}
 
 
 class McSpecDesc(C.Structure):

@@ -121,3 +121,12 @@ def test_cli_exit_codes_and_raft(amd):
     assert p.returncode == 0 and f"{2**20 + 1} distinct states found" in p.stdout
     p = subprocess.run([str(mc), str(ROOT / "include" / "tlamc.h")], capture_output=True, text=True)
     assert p.returncode == 1
+
+
+@pytest.mark.gpu
+def test_cli_ssi(amd):
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(ROOT / "specs" / "MCssi_2x2.cfg")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "50121 states generated, 29629 distinct states found, 0 states left on queue." in p.stdout
+    assert "The depth of the complete state graph search is 13." in p.stdout

@@ -15,6 +15,7 @@ SMALL = [
     ("atomic_add", [2]), ("atomic_add", [3]), ("atomic_add", [4]), ("atomic_add", [11]),
     ("pcal_intro", [0, 1, 20, 2]), ("pcal_intro", [1, 0, 20, 2]), ("pcal_intro", [1, 1, 20, 2]), ("pcal_intro", [0, 1, 7, 3]),
     ("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 3, 2, 9, 1, 3]),
+    ("ssi", [2, 1, 127, 0]), ("ssi", [2, 2, 127, 0]), ("ssi", [3, 1, 127, 0]),
 ]
 
 
@@ -162,4 +163,33 @@ def test_table_full_is_an_error(amd):
     with pytest.raises(amd.McError) as ei:
         eng.run()
     assert ei.value.code == -4
+    eng.close()
+
+
+@pytest.mark.parametrize("find", [1, 2, 3, 4, 5, 6, 7])
+def test_ssi_expected_violations_on_gpu(amd, oracle, find):
+    """serializableSnapshotIsolation.tla:81-96: each 'interesting history' is reachable; same shortest trace length as the oracle."""
+    o = oracle.oracle_run("ssi", [3, 2, 127, find])
+    eng = amd.Engine("ssi", [3, 2, 127, find], table_capacity=1 << 25, arena_capacity=1 << 24, chunk_states=1 << 18)
+    r = eng.run()
+    assert (r.verdict, r.violated_invariant, r.trace_len) == ("invariant", 7, len(o["trace"]))
+    tr = eng.trace()
+    assert len(tr) == r.trace_len and tr[0][0] == "Initial predicate" and tr[0][1] == o["trace"][0][1]
+    eng.close()
+
+
+def test_ssi_2x3_complete_graph_on_gpu(amd):
+    """SSI 2 txns x 3 keys = 7 910 565 distinct / 13 246 749 generated / 17 levels (oracle-verified), all invariants on."""
+    eng = amd.Engine("ssi", [2, 3, 127, 0], table_capacity=1 << 25, arena_capacity=9_000_000, chunk_states=1 << 19, trace=False)
+    r = eng.run()
+    assert (r.verdict, r.distinct, r.generated, r.depth) == ("ok", 7910565, 13246749, 17)
+    assert r.levels == [1, 2, 12, 60, 354, 1968, 9318, 35286, 102408, 222552, 381444, 641376, 1118376, 1616976, 1824552, 1405080, 550800]
+    eng.close()
+
+
+def test_ssi_4x3_prefix_on_gpu(amd):
+    """BASELINE config 5 (4 txns x 3 keys), levels 1-9."""
+    eng = amd.Engine("ssi", [4, 3, 127, 0], table_capacity=1 << 27, arena_capacity=24_000_000, chunk_states=1 << 19, max_levels=9, trace=False)
+    r = eng.run()
+    assert r.levels == [1, 4, 32, 264, 2532, 24576, 236844, 2189052, 18810792] and r.verdict == "budget"
     eng.close()

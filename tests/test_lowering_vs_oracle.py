@@ -9,6 +9,7 @@ CASES = [
     ("pcal_intro", [0, 1, 20, 2]), ("pcal_intro", [1, 0, 20, 2]), ("pcal_intro", [1, 1, 20, 2]),
     ("pcal_intro", [0, 1, 7, 3]),
     ("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 3, 2, 9, 1, 3]),
+    ("ssi", [2, 1, 127, 0]), ("ssi", [2, 2, 127, 0]), ("ssi", [3, 1, 127, 0]),
 ]
 
 
@@ -38,3 +39,17 @@ def test_raft_expected_violation_trace_length(oracle, shim):
     MaxClientRequests >= 3; the shortest counterexample has 31 states."""
     s = shim.shim_run("raft", [2, 3, 3, 9, 1, 2])
     assert s["verdict"] == "invariant" and s["violated_invariant"] == 1 and s["trace_len"] == 31
+
+
+@pytest.mark.parametrize("find", [1, 2, 3, 6, 7])   # 4 and 5 need 8.6 M states: GPU test only
+def test_ssi_expected_violation_same_trace_length(oracle, shim, find):
+    o = oracle.oracle_run("ssi", [3, 2, 127, find])
+    s = shim.shim_run("ssi", [3, 2, 127, find])
+    assert (s["verdict"], s["violated_invariant"], s["trace_len"]) == (o["verdict"], o["violated_invariant"], len(o["trace"]))
+
+
+def test_ssi_3x2_prefix(oracle, shim):
+    o = oracle.oracle_run("ssi", [3, 2, 127, 0], max_distinct=300000)
+    s = shim.shim_run("ssi", [3, 2, 127, 0], max_distinct=300000)
+    for k in ("distinct", "generated", "depth", "verdict", "levels"):
+        assert o[k] == s[k], k

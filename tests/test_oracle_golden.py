@@ -76,3 +76,35 @@ def test_raft_golden_levels(oracle):
         r = oracle.oracle_run("raft", case["params"], max_distinct=case.get("max_distinct", 0))
         assert r["levels"] == case["levels"], case["name"]
         assert r["generated"] == case["generated"]
+
+
+# ------------------------------------------------------------------ serializableSnapshotIsolation.tla
+SSI_ANCHORS = [  # BASELINE.md §2 / SURVEY.md §6 (survey-derived, independent implementation)
+    ([2, 1], 569, 945, 9), ([2, 2], 29629, 50121, 13), ([3, 1], 90430, 152554, 13),
+]
+
+
+@pytest.mark.parametrize("params,d,g,depth", SSI_ANCHORS)
+def test_ssi_anchors_all_invariants_hold(oracle, params, d, g, depth):
+    """serializableSnapshotIsolation.tla:61-79 'Should NEVER be violated' — all seven checked on every state."""
+    r = oracle.oracle_run("ssi", params + [127, 0])
+    assert r["verdict"] == "ok"
+    assert (r["distinct"], r["generated"], r["depth"]) == (d, g, depth)
+
+
+def test_ssi_4x3_prefix_levels(oracle):
+    """per-level distinct counts of the 4 txns x 3 keys model."""
+    r = oracle.oracle_run("ssi", [4, 3, 127, 0], max_levels=7)
+    assert r["levels"] == [1, 4, 32, 264, 2532, 24576, 236844]
+
+
+def test_ssi_in_spec_unit_tests(oracle):
+    """serializableSnapshotIsolation.tla:1068-1077 (9 cycle-finder cases) and :1184-1205 (10 well-formedness cases)."""
+    assert oracle.oracle_lib().oracle_ssi_unit_tests() == 0
+
+
+@pytest.mark.parametrize("find,trace_len", [(1, 3), (2, 6), (3, 7), (4, 12), (5, 12), (6, 9), (7, 7)])
+def test_ssi_expected_violations_are_reachable(oracle, find, trace_len):
+    """:81-96 'EXPECTED to be violated': every abort reason and two simultaneous lock waiters are reachable (3 txns x 2 keys)."""
+    r = oracle.oracle_run("ssi", [3, 2, 127, find])
+    assert r["verdict"] == "invariant" and r["violated_invariant"] == 7 and len(r["trace"]) == trace_len

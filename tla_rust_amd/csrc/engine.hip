@@ -63,7 +63,9 @@ struct DevCounters {
 };
 enum : unsigned { DEV_ETABLE = 1u, DEV_EARENA = 2u, DEV_EOVERFLOW = 4u };
 enum : unsigned { VK_INVARIANT = 1, VK_ASSERT = 2, VK_DEADLOCK = 3, VK_SPECERR = 4 };
-static constexpr unsigned SLOT_NONE = 0xffffu;
+static constexpr unsigned SLOT_NONE = 0xffffu;      // deadlock: no slot
+static constexpr unsigned SLOT_INIT = 0xfffeu;      // an initial state violates an invariant
+static constexpr unsigned SLOT_PARENT = 0xfffdu;    // the expanded state itself violates an invariant
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     for (int o = 32; o > 0; o >>= 1) { unsigned t = __shfl_xor(v, o); v = t > v ? t : v; }
@@ -161,7 +163,7 @@ k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__
         const CWordRef st_ref{tmp + col * (uint64_t)W, 1};
         const unsigned st = S::init_status(prm, st_ref);
         gen = 1;
-        if (st & ST_INVARIANT) viol = viol_key(first + col, SLOT_NONE - 1, VK_INVARIANT, st >> 8);
+        if (st & ST_INVARIANT) viol = viol_key(first + col, SLOT_INIT, VK_INVARIANT, st >> 8);
         if (!(st & ST_OUT_OF_MODEL)) fp = S::fp_of(prm, st_ref);
         if (shard_count > 1) {  // every rank enumerates Init; each keeps (and counts) only what it owns
             const bool mine = fp ? fp_owner(fp, shard_count) == shard_rank : shard_rank == 0;
@@ -321,13 +323,15 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     }
     typename S::Local loc;
     int ns = 0;
+    unsigned long long viol = ~0ull;
     if (active) {
         S::load(prm, s, loc);
         ns = S::nslots(prm, loc);
+        const unsigned ps = S::parent_status(prm, loc, s);  // specs that check invariants per expanded state
+        if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
     }
     const int wns = (int)wave_max_u32((unsigned)ns);
     unsigned gen = 0, err = 0, probes = 0;
-    unsigned long long viol = ~0ull;
     unsigned qhead = 0, qn = 0, ohead = 0, on = 0;  // wave-uniform ring state
     const unsigned shard = blockIdx.x & (NSHARD - 1);
     uint32_t *__restrict__ seg = newlist + (uint64_t)shard * seg_cap;  // this shard's new-list segment
@@ -839,7 +843,7 @@ struct Engine : EngineBase {
             std::vector<uint64_t> chain;
             if (build_chain(chain) == MC_OK) {
                 const unsigned slot = (unsigned)(last_viol >> 8 & 0xffffu);
-                const bool extra = kind == VK_INVARIANT && slot < SLOT_NONE - 1;  // violating successor itself
+                const bool extra = kind == VK_INVARIANT && slot < SLOT_PARENT;  // violating successor itself
                 out->trace_len = (uint32_t)chain.size() + (extra ? 1u : 0u);
             }
         } else {
@@ -859,7 +863,7 @@ struct Engine : EngineBase {
         chain.clear();
         if (!have_viol) return MC_ESTATE;
         const unsigned slot = (unsigned)(last_viol >> 8 & 0xffffu);
-        if (slot == SLOT_NONE - 1) return MC_OK;  // violated by an initial state: handled by the caller
+        if (slot == SLOT_INIT) return MC_OK;  // violated by an initial state: handled by the caller
         if (!d_parent) { set_error("engine created without MC_F_TRACE"); return MC_ESTATE; }
         uint64_t idx = last_viol >> 24;
         for (int guard = 0; guard < MC_MAX_LEVELS; ++guard) {
@@ -879,7 +883,7 @@ struct Engine : EngineBase {
         const unsigned kind = (unsigned)(last_viol & 7u), slot = (unsigned)(last_viol >> 8 & 0xffffu);
         std::vector<uint64_t> words;
         std::vector<int32_t> acts;
-        if (slot == SLOT_NONE - 1) {  // an initial state violates an invariant
+        if (slot == SLOT_INIT) {  // an initial state violates an invariant
             words.resize(W);
             S::init(prm, last_viol >> 24, WordRef{words.data(), 1});
             acts.push_back(-1);
@@ -897,7 +901,7 @@ struct Engine : EngineBase {
                     acts.push_back(S::action_of(prm, &words[(k - 1) * W], (int)ps));
                 }
             }
-            if (kind == VK_INVARIANT && slot < SLOT_NONE - 1) {  // append the violating successor
+            if (kind == VK_INVARIANT && slot < SLOT_PARENT) {  // append the violating successor
                 std::vector<uint64_t> last(words.end() - W, words.end());
                 words.resize(words.size() + W);
                 S::apply(prm, CWordRef{last.data(), 1}, (int)slot, WordRef{&words[words.size() - W], 1});

@@ -284,6 +284,7 @@ constexpr uint64_t H_PCAL_INTRO = 0x6da4921b5bd7b79aull;        // pcal_intro.tl
 constexpr uint64_t H_PCAL_INTRO_README = 0x446ad8dac291d64full; // README.md:224-240 (labels A:, B:)
 constexpr uint64_t H_ATOMIC_ADD = 0x6c3a51af80fccd40ull;        // atomic_add.tla:4-23
 constexpr uint64_t H_RAFT = 0x289fe41014391a24ull;              // examples/raft.tla:8-517 (EXTENDS .. before ====)
+constexpr uint64_t H_SSI = 0x85c02cbaf85b39ceull;              // examples/serializableSnapshotIsolation.tla:21-1579
 
 bool algorithm_text(const std::string &t, std::string &out) {
     const size_t i = t.find("--algorithm");
@@ -449,12 +450,49 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
         out->params[1] = mcr; out->params[2] = mt; out->params[3] = ml; out->params[4] = mm; out->params[5] = mask;
         return MC_OK;
     }
-    return fe_fail(MC_ENOSPEC, "module '%s' is not one of the lowered specs (atomic_add, atomic_add_n, pcal_intro, MCraft)", module);
+    if (m == "MCssi" || m == "serializableSnapshotIsolation") {  // serializableSnapshotIsolation.tla under specs/MCssi.tla
+        const CfgConst *tx = find_const(c, "TxnId"), *ky = find_const(c, "Key"), *nl = find_const(c, "NoLock");
+        if (!tx || tx->replacement || tx->value.kind != CfgValue::SET || tx->value.elems.empty() || tx->value.elems.size() > 4)
+            return fe_fail(MC_EBADCFG, "SSI needs CONSTANT TxnId = {T1, ...} with 1..4 model values");
+        if (!ky || ky->replacement || ky->value.kind != CfgValue::SET || ky->value.elems.empty() || ky->value.elems.size() > 3)
+            return fe_fail(MC_EBADCFG, "SSI needs CONSTANT Key = {K1, ...} with 1..3 model values");
+        if (!nl) return fe_fail(MC_EBADCFG, "NoLock is an unbounded CHOOSE (serializableSnapshotIsolation.tla:24): the cfg must give it a model value, NoLock = NoLock");
+        if (!c->constraints.empty()) return fe_fail(MC_ENOSPEC, "SSI defines no CONSTRAINT");
+        long long mask = 0, find = 0;
+        static const struct { const char *name; long long bit, find; } inv[] = {
+            {"TypeInv", 0, 0}, {"WellFormed", 1, 0}, {"CorrectnessOfHoldingXLocks", 2, 0}, {"CorrectnessOfWaitingForXLock", 4, 0},
+            {"CorrectReadView", 8, 0}, {"FirstCommitterWins", 16, 0}, {"SemanticsOfSnapshotIsolation", 24, 0}, {"CahillOK", 32, 0},
+            {"BernsteinOK", 64, 0}, {"NoVoluntaryAbort", 0, 1}, {"NoFCWAbort", 0, 2}, {"NoDeadlockAbort", 0, 3}, {"NoCommitAbort", 0, 4},
+            {"NoReadAbort", 0, 5}, {"NoWriteAbort", 0, 6}, {"NoTwoWaiters", 0, 7}};
+        for (const auto &i : c->invariants) {
+            bool ok = false;
+            for (const auto &e : inv)
+                if (i == e.name) {
+                    ok = true;
+                    mask |= e.bit;
+                    if (e.find) { if (find) return fe_fail(MC_ENOSPEC, "only one of the 'expected to be violated' predicates per run"); find = e.find; }
+                }
+            if (!ok) return fe_fail(MC_ENOSPEC, "MCssi defines no invariant named '%s'", i.c_str());
+        }
+        out->spec_id = MC_SPEC_SSI;
+        out->nparams = 4;
+        out->params[0] = (long long)tx->value.elems.size();
+        out->params[1] = (long long)ky->value.elems.size();
+        out->params[2] = mask;
+        out->params[3] = find;
+        return MC_OK;
+    }
+    return fe_fail(MC_ENOSPEC, "module '%s' is not one of the lowered specs (atomic_add, atomic_add_n, pcal_intro, MCraft, MCssi)", module);
 }
 
 static const char *invariant_name(const mc_spec_desc *d, int idx) {
     if (d->spec_id == MC_SPEC_PCAL_INTRO) return "MoneyInvariant";
     if (d->spec_id == MC_SPEC_RAFT) return idx == 1 ? "CommittedLogStable" : "NoTwoLeaders";
+    if (d->spec_id == MC_SPEC_SSI) {
+        static const char *nm[] = {"WellFormed", "CorrectnessOfHoldingXLocks", "CorrectnessOfWaitingForXLock", "CorrectReadView",
+                                   "FirstCommitterWins", "CahillOK", "BernsteinOK", "(expected-to-be-violated predicate)"};
+        return idx >= 0 && idx < 8 ? nm[idx] : "?";
+    }
     return "?";
 }
 
@@ -501,6 +539,18 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
             if (!module_body(raft, part)) return fe_fail(MC_ENOSPEC, "raft.tla: cannot find the module body");
             const uint64_t h = text_hash(part);
             if (h != H_RAFT) return fe_fail(MC_ENOSPEC, "raft.tla differs from the text the lowering was written against (hash %016llx)", (unsigned long long)h);
+        }
+    }
+    if (d.spec_id == MC_SPEC_SSI) {
+        std::string ssi;  // MCssi EXTENDS serializableSnapshotIsolation: verify it when it can be found
+        const char *env = getenv("TLA_PATH");
+        bool found = read_file(dir_of(tla_path) + "/serializableSnapshotIsolation.tla", ssi) ||
+                     (env && read_file(std::string(env) + "/serializableSnapshotIsolation.tla", ssi));
+        if (module == "serializableSnapshotIsolation") { ssi = tla; found = true; }
+        if (found) {
+            if (!module_body(ssi, part)) return fe_fail(MC_ENOSPEC, "serializableSnapshotIsolation.tla: cannot find the module body");
+            const uint64_t h = text_hash(part);
+            if (h != H_SSI) return fe_fail(MC_ENOSPEC, "serializableSnapshotIsolation.tla differs from the text the lowering was written against (hash %016llx)", (unsigned long long)h);
         }
     }
     mc_engine *e = nullptr;

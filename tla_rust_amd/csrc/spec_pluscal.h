@@ -42,6 +42,7 @@ struct SpecAtomicAdd {
     MC_HD static unsigned init_status(const Params &, CWordRef) { return ST_ENABLED; }
     MC_HD static void load(const Params &, CWordRef s, Local &l) { l.w = s.get(0); }
     MC_HD static int nslots(const Params &p, const Local &) { return p.n + 2; }
+    MC_HD static unsigned parent_status(const Params &, const Local &, CWordRef) { return 0; }
 
     MC_HD static bool step(const Params &p, uint64_t w, int slot, uint64_t &nw) {
         const int n = p.n;
@@ -143,6 +144,7 @@ struct SpecPcalIntro {
     }
     MC_HD static void load(const Params &, CWordRef s, Local &l) { l.w = s.get(0); }
     MC_HD static int nslots(const Params &p, const Local &) { return p.nproc + 1; }
+    MC_HD static unsigned parent_status(const Params &, const Local &, CWordRef) { return 0; }
 
     MC_HD static unsigned step(const Params &p, uint64_t w, int slot, uint64_t &nw) {
         if (slot == p.nproc) {  // termination disjunct (p-manual p.63)

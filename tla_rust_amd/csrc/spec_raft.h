@@ -269,6 +269,8 @@ struct SpecRaft {
         }
     }
     MC_HD static int nslots(const Params &, const Local &l) { return FIX + 3 * l.nm; }
+    template <class Ref>
+    MC_HD static unsigned parent_status(const Params &, const Local &, Ref) { return 0; }  // invariants are checked per successor
 
     // ---------------------------------------------------------------- successor delta
     struct Delta {

@@ -5,6 +5,7 @@
 #include "../../include/tlamc.h"
 #include "spec_pluscal.h"
 #include "spec_raft.h"
+#include "spec_ssi.h"
 
 namespace mc {
 
@@ -38,6 +39,11 @@ int dispatch_spec(const mc_spec_desc *d, F &&f) {
         case 5: if (SpecRaft5::make_params(d->params, d->nparams, p)) return MC_EBADCFG; return f(SpecRaft5{}, p);
         default: return MC_EBADCFG;
         }
+    }
+    case MC_SPEC_SSI: {
+        SsiParams p;
+        if (SpecSsi::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+        return f(SpecSsi{}, p);
     }
     default: return MC_EBADCFG;
     }

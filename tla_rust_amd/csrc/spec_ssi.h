@@ -1,0 +1,606 @@
+// spec_ssi.h — device lowering of examples/serializableSnapshotIsolation.tla (Cahill's serializable
+// snapshot isolation; reference lines cited per action) under specs/MCssi.tla / MCssi.cfg:
+// TxnId = {T1..Tn} (n <= 4), Key = {K1..Km} (m <= 3), NoLock a model value, INIT Init / NEXT Next.
+//
+// Packed state = 10 words (80 B):
+//   word 0      additive fingerprint (raw sum of H(word w, salt_w), w = 1..9)
+//   word 1      meta: Len(history)[0,6) | per txn t at bit 8+10t: holdingXLocks 3 | waitingForXLock 2
+//               (key, 3 = NoLock) | inConflict 1 | outConflict 1 | holdingSIREADlocks 3
+//   words 2..9  history, 4 events per word, 16 bits each: op 3 | txn 2 | key 2 | ver 2 | reason 3
+//               (history is append-only, at most |TxnId| * (2|Key| + 2) = 32 events)
+//
+// The spec's helper operators all scan `history`; here ONE unrolled pass per parent (load())
+// builds small index tables (begin / commit position per transaction, write / read position per
+// (key, transaction), read versions, key masks) and every action and invariant is a table lookup.
+// All 77 action slots have compile-time (transaction, key, choice) indices and are fully unrolled
+// by the expand kernel.  Every CHOOSE over transactions is resolved in ascending order T1 < T2 < ..
+// (Commit's AbortOpSeq :465-474); the other CHOOSEs are over singletons.
+//
+// Invariants (:59-79) are evaluated once per state when it is EXPANDED (parent_status), not per
+// generated successor: every stored state is expanded exactly once, so the verdict and the length
+// of the shortest counterexample are the same as TLC's check-on-generation.
+#pragma once
+#include "mc_common.h"
+#include <stdio.h>
+#include <string.h>
+
+namespace mc {
+
+struct SsiParams { int nt, nk, inv_mask, find; };
+
+struct SpecSsi {
+    using Params = SsiParams;
+    static constexpr int NT = 4, NK = 3, HWORDS = 8, HCAP = 32;
+    static constexpr int W_FP = 0, W_META = 1, W_H0 = 2;
+    static constexpr int MAX_WORDS = 10;
+    MC_HD static int words(const Params &) { return MAX_WORDS; }
+    // slots per txn t (base 19 t): 0 Begin, 1 Commit, 2 ChooseToAbort, 3 FinishBlockedWrite, 4+k Read(k),
+    // 7+4k+c StartWriteMayBlock(k) with c = index of the deadlock victim (c = 0 otherwise); slot 76 = termination
+    static constexpr int PER_TXN = 4 + NK + NK * NT, TOTAL_SLOTS = NT * PER_TXN + 1;
+    static constexpr int FIX_SLOTS = TOTAL_SLOTS;
+    static constexpr int STAGE_WORDS = 0;
+    MC_HD static int max_slots(const Params &) { return TOTAL_SLOTS; }
+    enum : int { OP_BEGIN = 0, OP_READ = 1, OP_WRITE = 2, OP_COMMIT = 3, OP_ABORT = 4 };
+    enum : int { R_VOLUNTARY = 0, R_FCW = 1, R_DEADLOCK = 2, R_COMMIT = 3, R_READ = 4, R_WRITE = 5 };
+    enum : int { SA_BEGIN, SA_COMMIT, SA_ABORT, SA_READ, SA_WRITE, SA_FINISH, SA_TERMINATED };
+    static constexpr unsigned NOLOCK = 3;
+
+    static int make_params(const int64_t *p, unsigned np, Params &o) {
+        if (np < 2) return -1;
+        o.nt = (int)p[0]; o.nk = (int)p[1];
+        o.inv_mask = np > 2 ? (int)p[2] : 127;
+        o.find = np > 3 ? (int)p[3] : 0;
+        if (o.nt < 1 || o.nt > NT || o.nk < 1 || o.nk > NK || o.find < 0 || o.find > 7) return -1;
+        return 0;
+    }
+
+    // ------------------------------------------------------------------ meta word accessors
+    MC_HD static int m_len(uint64_t m) { return (int)(m & 63); }
+    MC_HD static unsigned m_txn(uint64_t m, int t) { return (unsigned)(m >> (8 + 10 * t)) & 1023u; }
+    MC_HD static unsigned t_xl(unsigned f) { return f & 7u; }
+    MC_HD static unsigned t_wait(unsigned f) { return f >> 3 & 3u; }
+    MC_HD static unsigned t_in(unsigned f) { return f >> 5 & 1u; }
+    MC_HD static unsigned t_out(unsigned f) { return f >> 6 & 1u; }
+    MC_HD static unsigned t_sir(unsigned f) { return f >> 7 & 7u; }
+    MC_HD static unsigned mk_txn(unsigned xl, unsigned wait, unsigned in, unsigned out, unsigned sir) {
+        return xl | wait << 3 | in << 5 | out << 6 | sir << 7;
+    }
+    MC_HD static uint64_t m_set_txn(uint64_t m, int t, unsigned f) { return bits_set(m, 8 + 10 * t, 10, f); }
+    MC_HD static unsigned mk_event(int op, int txn, int key, int ver, int reason) {
+        return (unsigned)op | (unsigned)txn << 3 | (unsigned)key << 5 | (unsigned)ver << 7 | (unsigned)reason << 9;
+    }
+    MC_HD static unsigned idx6(uint32_t tab, int t) { return tab >> (6 * t) & 63u; }
+
+    // ------------------------------------------------------------------ Init :938-943
+    MC_HD static uint64_t num_init(const Params &) { return 1; }
+    MC_HD static uint64_t init_meta() {
+        uint64_t m = 0;
+        for (int t = 0; t < NT; t++) m = m_set_txn(m, t, mk_txn(0, NOLOCK, 0, 0, 0));
+        return m;
+    }
+    MC_HD static void init(const Params &, uint64_t, WordRef out) {
+        for (int w = 0; w < MAX_WORDS; w++) out.set(w, 0);
+        out.set(W_META, init_meta());
+        uint64_t fp = 0;
+        for (int w = 1; w < MAX_WORDS; w++) fp += hmix(out.get(w), salt_of((unsigned)w));
+        out.set(W_FP, fp);
+    }
+    template <class Ref>
+    MC_HD static uint64_t fp_of(const Params &, Ref s) { return fp_nonzero(s.get(W_FP)); }
+    template <class Ref>
+    MC_HD static uint64_t fp_recompute(const Params &, Ref s) {
+        uint64_t fp = 0;
+        for (int w = 1; w < MAX_WORDS; w++) fp += hmix(s.get(w), salt_of((unsigned)w));
+        return fp;
+    }
+    template <class Ref>
+    MC_HD static unsigned init_status(const Params &, Ref) { return ST_ENABLED; }
+
+    // ------------------------------------------------------------------ per-parent tables
+    struct Local {
+        uint64_t fp, meta;
+        int n;
+        unsigned started, committed, aborted;  // transaction masks
+        uint32_t bidx, cidx;                   // 6 bits per txn: position of begin / commit (0 = none)
+        uint32_t rkeys, wkeys;                 // 4 bits per txn: keys read / written
+        uint32_t widx0, widx1, widx2;          // per key: 6 bits per txn, position of its write
+        uint32_t ridx0, ridx1, ridx2;          // per key: position of its read
+        uint32_t rver0, rver1, rver2;          // per key: 2 bits per txn, version read
+        uint32_t abort_reasons;                // bit r: some transaction aborted with reason r
+        bool wellformed;
+    };
+    MC_HD static uint32_t pick3(uint32_t a, uint32_t b, uint32_t c, int k) { return k == 0 ? a : k == 1 ? b : c; }
+    MC_HD static uint32_t widx(const Local &l, int k) { return pick3(l.widx0, l.widx1, l.widx2, k); }
+    MC_HD static uint32_t ridx(const Local &l, int k) { return pick3(l.ridx0, l.ridx1, l.ridx2, k); }
+    MC_HD static uint32_t rver(const Local &l, int k) { return pick3(l.rver0, l.rver1, l.rver2, k); }
+
+    template <class Ref>
+    MC_HD static void load(const Params &, Ref s, Local &l) {
+        l.fp = s.get(W_FP);
+        l.meta = s.get(W_META);
+        l.n = m_len(l.meta);
+        l.started = l.committed = l.aborted = 0;
+        l.bidx = l.cidx = l.rkeys = l.wkeys = 0;
+        l.widx0 = l.widx1 = l.widx2 = l.ridx0 = l.ridx1 = l.ridx2 = l.rver0 = l.rver1 = l.rver2 = 0;
+        l.abort_reasons = 0;
+        l.wellformed = true;
+        // one pass over the history; WellFormedTransactionsInHistory (:1146-1179) is checked on the way
+#pragma unroll
+        for (int w = 0; w < HWORDS; w++) {
+            if (4 * w >= l.n) continue;
+            const uint64_t word = s.get(W_H0 + w);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 4 * w + q;
+                if (i >= l.n) continue;
+                const unsigned e = (unsigned)(word >> (16 * q)) & 0xffffu;
+                const int op = (int)(e & 7u), t = (int)(e >> 3 & 3u), k = (int)(e >> 5 & 3u);
+                const unsigned tb = 1u << t, pos = (unsigned)(i + 1);
+                const bool fin = ((l.committed | l.aborted) & tb) != 0, st = (l.started & tb) != 0;
+                if (fin) l.wellformed = false;  // nothing may follow commit / abort
+                if (op == OP_BEGIN) {
+                    if (st) l.wellformed = false;
+                    l.started |= tb;
+                    l.bidx |= pos << (6 * t);
+                } else {
+                    if (!st) l.wellformed = false;  // first operation must be begin
+                    if (op == OP_COMMIT) { l.committed |= tb; l.cidx |= pos << (6 * t); }
+                    else if (op == OP_ABORT) { l.aborted |= tb; l.abort_reasons |= 1u << (e >> 9 & 7u); }
+                    else if (op == OP_READ) {
+                        if (l.rkeys >> (4 * t + k) & 1u) l.wellformed = false;  // Bernstein's simplification
+                        l.rkeys |= 1u << (4 * t + k);
+                        const uint32_t a = pos << (6 * t), v = (e >> 7 & 3u) << (2 * t);
+                        l.ridx0 |= k == 0 ? a : 0; l.ridx1 |= k == 1 ? a : 0; l.ridx2 |= k == 2 ? a : 0;
+                        l.rver0 |= k == 0 ? v : 0; l.rver1 |= k == 1 ? v : 0; l.rver2 |= k == 2 ? v : 0;
+                    } else {
+                        if (l.wkeys >> (4 * t + k) & 1u) l.wellformed = false;
+                        l.wkeys |= 1u << (4 * t + k);
+                        const uint32_t a = pos << (6 * t);
+                        l.widx0 |= k == 0 ? a : 0; l.widx1 |= k == 1 ? a : 0; l.widx2 |= k == 2 ? a : 0;
+                    }
+                }
+            }
+        }
+    }
+    MC_HD static int nslots(const Params &, const Local &) { return TOTAL_SLOTS; }
+
+    MC_HD static bool is_active(const Local &l, int t) { return (l.started & ~(l.committed | l.aborted)) >> t & 1u; }  // :279
+    // StartedAndCanDoPublicOperation :328-336
+    MC_HD static bool can_do(const Local &l, int t) { return is_active(l, t) && t_wait(m_txn(l.meta, t)) == NOLOCK; }
+    // LatestCommittedVersionOfKeyWhenTxnBegan :351-361 (-1 = {})
+    MC_HD static int latest_version(const Params &p, const Local &l, int txn, int key) {
+        const unsigned st = idx6(l.bidx, txn);
+        int best = -1;
+        unsigned bw = 0;
+#pragma unroll
+        for (int w = 0; w < NT; w++) {
+            const unsigned wi = idx6(widx(l, key), w), ci = idx6(l.cidx, w);
+            if (w < p.nt && wi && wi <= st && ci && ci <= st && wi > bw) { bw = wi; best = w; }
+        }
+        return best;
+    }
+    // VersionThatWouldBeReadBy :366-378
+    MC_HD static int version_read_by(const Params &p, const Local &l, int txn, int key) {
+        if (t_xl(m_txn(l.meta, txn)) >> key & 1u) return txn;
+        return latest_version(p, l, txn, key);
+    }
+    // VersionIDsOfKeyNewerThanReadByTxn :384-399 (all later writes of key, whoever wrote them)
+    MC_HD static unsigned newer_versions(const Params &p, const Local &l, int key, int ver) {
+        const unsigned wv = idx6(widx(l, key), ver);
+        unsigned m = 0;
+#pragma unroll
+        for (int w = 0; w < NT; w++) if (w < p.nt && idx6(widx(l, key), w) > wv) m |= 1u << w;
+        return m;
+    }
+    // WritersCommittedToKeySinceTxnBegan :339-346
+    MC_HD static unsigned writers_since(const Params &p, const Local &l, int txn, int key) {
+        const unsigned st = idx6(l.bidx, txn);
+        unsigned m = 0;
+#pragma unroll
+        for (int w = 0; w < NT; w++) {
+            const unsigned ci = idx6(l.cidx, w);
+            if (w < p.nt && ci && ci >= st && (l.wkeys >> (4 * w + key) & 1u)) m |= 1u << w;
+        }
+        return m;
+    }
+    // findConcurrentSIREADlockOwners :657-685
+    MC_HD static unsigned siread_owners(const Params &p, const Local &l, int txn, int key) {
+        const unsigned bt = idx6(l.bidx, txn);
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const unsigned ci = idx6(l.cidx, t);
+            if (t < p.nt && t != txn && (t_sir(m_txn(l.meta, t)) >> key & 1u) && (ci == 0 || ci > bt)) m |= 1u << t;
+        }
+        return m;
+    }
+
+    // ------------------------------------------------------------------ successor = new meta + appended events
+    struct Delta {
+        uint64_t meta;
+        unsigned ev[4];
+        int nev;
+    };
+    MC_HD static void d_append(Delta &d, unsigned e) {
+        d.ev[0] = d.nev == 0 ? e : d.ev[0]; d.ev[1] = d.nev == 1 ? e : d.ev[1];
+        d.ev[2] = d.nev == 2 ? e : d.ev[2]; d.ev[3] = d.nev == 3 ? e : d.ev[3];
+        d.nev++;
+    }
+    // internalAbort(txn, reason) :406-416
+    MC_HD static void internal_abort(Delta &d, int txn, int reason) {
+        d_append(d, mk_event(OP_ABORT, txn, 0, 0, reason));
+        d.meta = m_set_txn(d.meta, txn, mk_txn(0, NOLOCK, 0, 0, 0));
+    }
+    // HelperWriteCanAcquireXLock :700-771
+    MC_HD static void write_can_acquire(const Params &p, const Local &l, int txn, int key, Delta &d) {
+        const unsigned owners = siread_owners(p, l, txn, key);
+        bool danger = false;
+#pragma unroll
+        for (int o = 0; o < NT; o++) if ((owners >> o & 1u) && ((l.committed >> o & 1u) || t_in(m_txn(l.meta, o)))) danger = true;  // :726-728
+        if (owners && danger) { internal_abort(d, txn, R_WRITE); return; }
+        // snapshotIsolationWriteAction :688-691
+        d_append(d, mk_event(OP_WRITE, txn, key, 0, 0));
+        unsigned f = m_txn(d.meta, txn);
+        f = mk_txn(t_xl(f) | 1u << key, NOLOCK, owners ? 1u : t_in(f), t_out(f), t_sir(f));
+        d.meta = m_set_txn(d.meta, txn, f);
+#pragma unroll
+        for (int o = 0; o < NT; o++) if (owners >> o & 1u) d.meta |= 1ull << (8 + 10 * o + 6);  // outConflict'[o] = TRUE
+    }
+
+    MC_HD static unsigned compute(const Params &p, const Local &l, int slot, Delta &d, int &action) {
+        d.meta = l.meta; d.nev = 0; d.ev[0] = d.ev[1] = d.ev[2] = d.ev[3] = 0;
+        if (slot == NT * PER_TXN) {  // LegitimateTermination /\ UNCHANGED allvars :963,996
+            action = SA_TERMINATED;
+            const unsigned all = (1u << p.nt) - 1u;
+            return ((l.committed | l.aborted) & all) == all ? (unsigned)ST_ENABLED : 0u;
+        }
+        const int txn = slot / PER_TXN, sub = slot % PER_TXN;
+        if (txn >= p.nt) return 0;
+        const unsigned me = m_txn(l.meta, txn);
+        if (sub == 0) {  // Begin(txn) :423-426
+            action = SA_BEGIN;
+            if (l.started >> txn & 1u) return 0;
+            d_append(d, mk_event(OP_BEGIN, txn, 0, 0, 0));
+        } else if (sub == 1) {  // Commit(txn) :429-491
+            action = SA_COMMIT;
+            if (!can_do(l, txn)) return 0;
+            if (t_in(me) && t_out(me)) internal_abort(d, txn, R_COMMIT);
+            else {
+                d_append(d, mk_event(OP_COMMIT, txn, 0, 0, 0));
+                d.meta = m_set_txn(d.meta, txn, mk_txn(0, t_wait(me), t_in(me), t_out(me), t_sir(me)));  // drop X locks only
+#pragma unroll
+                for (int b = 0; b < NT; b++) {  // LoserTxns :461-462, AbortOpSeq in ascending order :465-474
+                    const unsigned fb = m_txn(l.meta, b), wb = t_wait(fb);
+                    if (b < p.nt && wb != NOLOCK && (t_xl(me) >> wb & 1u)) {
+                        d_append(d, mk_event(OP_ABORT, b, 0, 0, R_FCW));
+                        d.meta = m_set_txn(d.meta, b, mk_txn(0, NOLOCK, 0, 0, 0));
+                    }
+                }
+            }
+        } else if (sub == 2) {  // ChooseToAbort(txn) :494-496
+            action = SA_ABORT;
+            if (!can_do(l, txn)) return 0;
+            internal_abort(d, txn, R_VOLUNTARY);
+        } else if (sub == 3) {  // FinishBlockedWrite(txn) :923-927
+            action = SA_FINISH;
+            const unsigned key = t_wait(me);
+            if (key == NOLOCK) return 0;
+            unsigned anylocked = 0;
+#pragma unroll
+            for (int t = 0; t < NT; t++) anylocked |= t_xl(m_txn(l.meta, t));
+            if (anylocked >> key & 1u) return 0;
+            write_can_acquire(p, l, txn, (int)key, d);
+        } else if (sub < 4 + NK) {  // Read(txn, key) :525-626
+            const int key = sub - 4;
+            action = SA_READ;
+            if (key >= p.nk || !can_do(l, txn) || (l.rkeys >> (4 * txn + key) & 1u)) return 0;
+            const int ver = version_read_by(p, l, txn, key);
+            if (ver < 0) return 0;
+            const unsigned newer = newer_versions(p, l, key, ver);
+            bool danger = false;
+#pragma unroll
+            for (int x = 0; x < NT; x++) if ((newer >> x & 1u) && (l.committed >> x & 1u) && t_out(m_txn(l.meta, x))) danger = true;
+            if (danger) internal_abort(d, txn, R_READ);
+            else {
+                d_append(d, mk_event(OP_READ, txn, key, ver, 0));
+                unsigned lockers = 0;
+#pragma unroll
+                for (int x = 0; x < NT; x++) if (x < p.nt && x != txn && (t_xl(m_txn(l.meta, x)) >> key & 1u)) lockers |= 1u << x;
+#pragma unroll
+                for (int x = 0; x < NT; x++) if ((newer | lockers) >> x & 1u) d.meta |= 1ull << (8 + 10 * x + 5);  // inConflict'[x] = TRUE
+                d.meta |= (uint64_t)(1u << key) << (8 + 10 * txn + 7);                                                // SIREAD lock
+                if (newer | lockers) d.meta |= 1ull << (8 + 10 * txn + 6);                                            // outConflict'[txn]
+            }
+        } else {  // StartWriteMayBlock(txn, key) :883-911, choice c of the deadlock victim
+            const int key = (sub - 4 - NK) / NT, c = (sub - 4 - NK) % NT;
+            action = SA_WRITE;
+            if (key >= p.nk || !can_do(l, txn) || (t_xl(me) >> key & 1u)) return 0;
+            unsigned anylocked = 0;
+#pragma unroll
+            for (int t = 0; t < NT; t++) anylocked |= t_xl(m_txn(l.meta, t));
+            if (writers_since(p, l, txn, key)) {  // lost First Committer Wins :897-905 (waitingForXLock unchanged = NoLock)
+                if (c) return 0;
+                d_append(d, mk_event(OP_ABORT, txn, 0, 0, R_FCW));
+                d.meta = m_set_txn(d.meta, txn, mk_txn(0, NOLOCK, 0, 0, 0));
+            } else if (anylocked >> key & 1u) {  // HelperWriteConflictsWithXLock :774-880
+                // follow "waits for the holder of" edges from txn (at most one per transaction)
+                unsigned path = 1u << txn;  // members of pathThatCyclesFromTxnToTxn, if it cycles
+                int from = txn;
+                unsigned want = (unsigned)key;
+                bool cycle = false;
+#pragma unroll
+                for (int step = 0; step < NT; step++) {
+                    int to = -1;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) if (to < 0 && is_active(l, t) && (t_xl(m_txn(l.meta, t)) >> want & 1u)) to = t;
+                    if (to < 0) break;                 // dead end: no cycle
+                    if (to == txn) { cycle = true; break; }
+                    path |= 1u << to;
+                    from = to;
+                    want = t_wait(m_txn(l.meta, from));
+                    if (want == NOLOCK) break;
+                }
+                (void)from;
+                if (!cycle) {
+                    if (c) return 0;
+                    d.meta = m_set_txn(d.meta, txn, mk_txn(t_xl(me), (unsigned)key, t_in(me), t_out(me), t_sir(me)));
+                } else {  // \E to_abort \in Range(path) :851: c-th member in ascending order
+                    int victim = -1, seen = 0;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) if (path >> t & 1u) { if (seen == c) victim = t; seen++; }
+                    if (victim < 0) return 0;
+                    d_append(d, mk_event(OP_ABORT, victim, 0, 0, R_DEADLOCK));
+                    if (victim == txn) d.meta = m_set_txn(d.meta, txn, mk_txn(0, t_wait(me), 0, 0, 0));
+                    else {
+                        d.meta = m_set_txn(d.meta, victim, mk_txn(0, NOLOCK, 0, 0, 0));
+                        d.meta = m_set_txn(d.meta, txn, mk_txn(t_xl(me), (unsigned)key, t_in(me), t_out(me), t_sir(me)));
+                    }
+                }
+            } else {
+                if (c) return 0;
+                write_can_acquire(p, l, txn, key, d);
+            }
+        }
+        if (l.n + d.nev > HCAP) return ST_ENABLED | ST_OVERFLOW;
+        d.meta = (d.meta & ~63ull) | (uint64_t)(l.n + d.nev);
+        return ST_ENABLED;
+    }
+
+    // the (at most two) history words the appended events land in
+    template <class Ref>
+    MC_HD static void touched(const Local &l, Ref s, const Delta &d, int &wa, uint64_t &olda, uint64_t &newa, uint64_t &newb) {
+        wa = l.n >> 2;
+        olda = (d.nev && wa < HWORDS) ? s.get(W_H0 + wa) : 0;
+        newa = olda;
+        newb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j >= d.nev) continue;
+            const int pos = l.n + j;
+            const uint64_t e = (uint64_t)d.ev[j] << (16 * (pos & 3));
+            if ((pos >> 2) == wa) newa |= e; else newb |= e;
+        }
+    }
+    template <class Ref>
+    MC_HD static unsigned eval(const Params &p, Local &l, Ref s, int slot, uint64_t &fp) {
+        Delta d;
+        int action;
+        const unsigned st = compute(p, l, slot, d, action);
+        if (!(st & ST_ENABLED)) return 0;
+        if (st & ST_OVERFLOW) { fp = 1; return st; }
+        int wa;
+        uint64_t olda, newa, newb;
+        touched(l, s, d, wa, olda, newa, newb);
+        uint64_t f = l.fp + hmix(d.meta, salt_of(W_META)) - hmix(l.meta, salt_of(W_META));
+        if (newa != olda) f += hmix(newa, salt_of((unsigned)(W_H0 + wa))) - hmix(olda, salt_of((unsigned)(W_H0 + wa)));
+        if (newb) f += hmix(newb, salt_of((unsigned)(W_H0 + wa + 1))) - hmix(0, salt_of((unsigned)(W_H0 + wa + 1)));
+        fp = fp_nonzero(f);
+        return st;
+    }
+    template <class Ref>
+    MC_HD static unsigned apply(const Params &p, Ref s, int slot, WordRef out) {
+        Local l;
+        load(p, s, l);
+        Delta d;
+        int action;
+        const unsigned st = compute(p, l, slot, d, action);
+        for (int w = 0; w < MAX_WORDS; w++) out.set(w, s.get(w));
+        if (!(st & ST_ENABLED) || (st & ST_OVERFLOW)) return st;
+        int wa;
+        uint64_t olda, newa, newb;
+        touched(l, s, d, wa, olda, newa, newb);
+        out.set(W_META, d.meta);
+        if (d.nev) out.set(W_H0 + wa, newa);
+        if (newb) out.set(W_H0 + wa + 1, newb);
+        uint64_t f = 0;
+        for (int w = 1; w < MAX_WORDS; w++) f += hmix(out.get(w), salt_of((unsigned)w));
+        out.set(W_FP, f);
+        return st;
+    }
+
+    // ------------------------------------------------------------------ invariants, per expanded state
+    MC_HD static bool has_cycle(const unsigned *adj_in) {  // FindAllNodesInAnyCycle(edges) /= {}  :1040-1060
+        unsigned r0 = adj_in[0], r1 = adj_in[1], r2 = adj_in[2], r3 = adj_in[3];
+        // Warshall over the 4 nodes: after step k, r_a holds everything reachable from a through nodes <= k
+        if (r1 & 1u) r1 |= r0;
+        if (r2 & 1u) r2 |= r0;
+        if (r3 & 1u) r3 |= r0;
+        if (r0 & 2u) r0 |= r1;
+        if (r2 & 2u) r2 |= r1;
+        if (r3 & 2u) r3 |= r1;
+        if (r0 & 4u) r0 |= r2;
+        if (r1 & 4u) r1 |= r2;
+        if (r3 & 4u) r3 |= r2;
+        if (r0 & 8u) r0 |= r3;
+        if (r1 & 8u) r1 |= r3;
+        if (r2 & 8u) r2 |= r3;
+        return (r0 & 1u) || (r1 & 2u) || (r2 & 4u) || (r3 & 8u);
+    }
+    // returns ST_INVARIANT | id << 8, or 0
+    template <class Ref>
+    MC_HD static unsigned parent_status(const Params &p, const Local &l, Ref) {
+        const unsigned all = (1u << p.nt) - 1u;
+        if ((p.inv_mask & 1) && !l.wellformed) return ST_INVARIANT | (0u << 8);
+        if (p.inv_mask & 2) {  // CorrectnessOfHoldingXLocks :1302-1321
+            bool ok = true;
+            unsigned seen = 0;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const unsigned xl = t_xl(m_txn(l.meta, t));
+                if (seen & xl) ok = false;
+                seen |= xl;
+                const unsigned wk = l.wkeys >> (4 * t) & 7u;
+                if (is_active(l, t) ? xl != wk : xl != 0) ok = false;
+            }
+            if (!ok) return ST_INVARIANT | (1u << 8);
+        }
+        if (p.inv_mask & 4) {  // CorrectnessOfWaitingForXLock :1324-1330
+#pragma unroll
+            for (int t = 0; t < NT; t++) if (t < p.nt && t_wait(m_txn(l.meta, t)) != NOLOCK && !is_active(l, t)) return ST_INVARIANT | (2u << 8);
+        }
+        if (p.inv_mask & 8) {  // CorrectReadView :1215-1268
+            bool ok = true;
+#pragma unroll
+            for (int txn = 0; txn < NT; txn++) {
+#pragma unroll
+                for (int key = 0; key < NK; key++) {
+                    if (!(l.rkeys >> (4 * txn + key) & 1u)) continue;
+                    const unsigned ir = idx6(ridx(l, key), txn), itxnb = idx6(l.bidx, txn);
+                    const int ver = (int)(rver(l, key) >> (2 * txn) & 3u);
+                    if (ver != txn) {  // only committed reads
+                        const unsigned irfc = idx6(l.cidx, ver);
+                        if (!irfc || !(irfc < itxnb)) ok = false;
+                    }
+                    const unsigned iwkv = idx6(widx(l, key), ver);
+#pragma unroll
+                    for (int w = 0; w < NT; w++) {  // only up-to-date reads
+                        const unsigned wi = idx6(widx(l, key), w), ci = idx6(l.cidx, w);
+                        if (wi > iwkv && wi <= itxnb && ci && ci <= itxnb) ok = false;
+                    }
+                    const unsigned iw = idx6(widx(l, key), txn);
+                    if (iw) {  // key both read and written by txn
+                        if (ir < iw) { if (ver != latest_version(p, l, txn, key)) ok = false; }
+                        else if (ver != txn) ok = false;
+                    }
+                }
+            }
+            if (!ok) return ST_INVARIANT | (3u << 8);
+        }
+        if (p.inv_mask & 16) {  // FirstCommitterWins :1271-1278 with AreConcurrent :1118-1133
+#pragma unroll
+            for (int a = 0; a < NT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++) {
+                    if (a == b || !(l.committed >> a & 1u) || !(l.committed >> b & 1u)) continue;
+                    const unsigned b1 = idx6(l.bidx, a), c1 = idx6(l.cidx, a), b2 = idx6(l.bidx, b), c2 = idx6(l.cidx, b);
+                    const bool conc = b1 < b2 ? c1 > b2 : c2 > b1;  // both committed, both started
+                    if (conc && ((l.wkeys >> (4 * a)) & (l.wkeys >> (4 * b)) & 7u)) return ST_INVARIANT | (4u << 8);
+                }
+        }
+        if (p.inv_mask & 32) {  // CahillSerializable :1379-1446
+            unsigned adj[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int a = 0; a < NT; a++)
+#pragma unroll
+                for (int b = 0; b < NT; b++) {
+                    if (a == b || !(l.committed >> a & 1u) || !(l.committed >> b & 1u)) continue;
+#pragma unroll
+                    for (int x = 0; x < NK; x++) {
+                        const unsigned aw = idx6(widx(l, x), a), bw = idx6(widx(l, x), b);
+                        const bool ww = aw && bw && aw < bw;
+                        const bool wr = aw && (l.rkeys >> (4 * b + x) & 1u) && idx6(l.cidx, a) < idx6(l.bidx, b);
+                        const bool rw = (l.rkeys >> (4 * a + x) & 1u) && bw && idx6(l.bidx, a) < idx6(l.cidx, b);
+                        if (ww || wr || rw) adj[a] |= 1u << b;
+                    }
+                }
+            if (has_cycle(adj)) return ST_INVARIANT | (5u << 8);
+        }
+        if (p.inv_mask & 64) {  // BernsteinSerializable :1505-1556
+            unsigned adj[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < NT; r++)
+#pragma unroll
+                for (int x = 0; x < NK; x++) {
+                    if (!(l.rkeys >> (4 * r + x) & 1u) || !(l.committed >> r & 1u)) continue;
+                    const int j = (int)(rver(l, x) >> (2 * r) & 3u);  // r read x from j: rk[xj] with k = r
+                    if (!(l.committed >> j & 1u)) continue;
+                    if (j != r) adj[j] |= 1u << r;  // BernsteinSG: writer -> reader
+#pragma unroll
+                    for (int i = 0; i < NT; i++) {  // version-order edges
+                        if (i == j || i == r || j == r || !(l.committed >> i & 1u)) continue;
+                        const unsigned xi = idx6(widx(l, x), i), xj = idx6(widx(l, x), j);
+                        if (!xi || !xj) continue;
+                        if (xi < xj) adj[i] |= 1u << j; else adj[r] |= 1u << i;
+                    }
+                }
+            if (has_cycle(adj)) return ST_INVARIANT | (6u << 8);
+        }
+        if (p.find >= 1 && p.find <= 6) {  // ~AtLeastNTxnsAbortedDueToReason(1, r) :1579-1582
+            if (l.abort_reasons >> (p.find - 1) & 1u) return ST_INVARIANT | (7u << 8);
+        } else if (p.find == 7) {  // ~AtLeastNTxnsAreWaitingForLocks(2) :1578
+            int n = 0;
+#pragma unroll
+            for (int t = 0; t < NT; t++) n += (t < p.nt && t_wait(m_txn(l.meta, t)) != NOLOCK) ? 1 : 0;
+            if (n >= 2) return ST_INVARIANT | (7u << 8);
+        }
+        (void)all;
+        return 0;
+    }
+
+    // ------------------------------------------------------------------ host side
+    static int action_of(const Params &p, const uint64_t *parent, int slot) {
+        Local l;
+        load(p, CWordRef{parent, 1}, l);
+        Delta d;
+        int action = -1;
+        compute(p, l, slot, d, action);
+        return action;
+    }
+    static const char *action_name(int a) {
+        static const char *nm[] = {"Begin", "Commit", "ChooseToAbort", "Read", "StartWriteMayBlock", "FinishBlockedWrite", "Terminated"};
+        return a >= 0 && a < 7 ? nm[a] : a < 0 ? "Initial predicate" : "?";
+    }
+    static int format(const Params &p, const uint64_t *w, char *buf, size_t cap) {
+        static const char *reason[] = {"voluntary", "forced by First Committer Wins", "forced by deadlock-prevention",
+                                       "in attempted commit, to preserve serializability",
+                                       "in attempted read, to preserve serializability",
+                                       "in attempted write, to preserve serializability", "?", "?"};
+        size_t k = 0;
+        auto put = [&](const char *fmt, auto... a) {
+            if (k < cap) { int n = snprintf(buf + k, cap - k, fmt, a..., 0); if (n > 0) k += (size_t)n; if (k > cap) k = cap; }
+        };
+        const uint64_t meta = w[W_META];
+        const int n = m_len(meta);
+        put("/\\ history = <<");
+        for (int i = 0; i < n; i++) {
+            const unsigned e = (unsigned)(w[W_H0 + (i >> 2)] >> (16 * (i & 3))) & 0xffffu;
+            const int op = (int)(e & 7u), t = (int)(e >> 3 & 3u) + 1, key = (int)(e >> 5 & 3u) + 1, ver = (int)(e >> 7 & 3u) + 1;
+            if (i) put(", ");
+            if (op == OP_BEGIN) put("[op |-> \"begin\", txnid |-> T%d]", t);
+            else if (op == OP_COMMIT) put("[op |-> \"commit\", txnid |-> T%d]", t);
+            else if (op == OP_ABORT) put("[op |-> \"abort\", reason |-> \"%s\", txnid |-> T%d]", reason[e >> 9 & 7u], t);
+            else if (op == OP_READ) put("[key |-> K%d, op |-> \"read\", txnid |-> T%d, ver |-> T%d]", key, t, ver);
+            else put("[key |-> K%d, op |-> \"write\", txnid |-> T%d]", key, t);
+        }
+        put(">>");
+        auto keyset = [&](unsigned m) {
+            put("{");
+            bool first = true;
+            for (int q = 0; q < p.nk; q++) if (m >> q & 1u) { put("%sK%d", first ? "" : ", ", q + 1); first = false; }
+            put("}");
+        };
+        auto per_txn = [&](const char *title, auto f) {
+            put("\n/\\ %s = (", title);
+            for (int t = 0; t < p.nt; t++) { put("%sT%d :> ", t ? " @@ " : "", t + 1); f(m_txn(meta, t)); }
+            put(")");
+        };
+        per_txn("holdingXLocks", [&](unsigned f) { keyset(t_xl(f)); });
+        per_txn("waitingForXLock", [&](unsigned f) { if (t_wait(f) == NOLOCK) put("NoLock"); else put("K%d", (int)t_wait(f) + 1); });
+        per_txn("inConflict", [&](unsigned f) { put("%s", t_in(f) ? "TRUE" : "FALSE"); });
+        per_txn("outConflict", [&](unsigned f) { put("%s", t_out(f) ? "TRUE" : "FALSE"); });
+        per_txn("holdingSIREADlocks", [&](unsigned f) { keyset(t_sir(f)); });
+        return (int)k;
+    }
+};
+
+}  // namespace mc
