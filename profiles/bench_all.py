@@ -1,0 +1,39 @@
+"""Throughput of every lowered spec on one MI355X (not the contract bench: see bench.py).
+Prints one JSON line per workload: distinct states/s, generated/s, kernel times, algorithmic GB/s."""
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import tla_rust_amd as amd
+
+WORKLOADS = [
+    ("atomic_add N=24 (config 2 series)", "atomic_add", [24], dict(table_capacity=1 << 26, arena_capacity=(1 << 24) + 4096)),
+    ("atomic_add N=28", "atomic_add", [28], dict(table_capacity=1 << 30, arena_capacity=(1 << 28) + 4096)),
+    ("pcal_intro committed (config 1)", "pcal_intro", [0, 1, 20, 2], dict(table_capacity=1 << 16, arena_capacity=1 << 14)),
+    ("raft 3 servers, 25M budget (config 3, bench.py)", "raft", [3, 4, 2, 3, 1, 1, 16, 2, 8],
+     dict(table_capacity=1 << 28, arena_capacity=30_000_000, max_distinct=25_000_000)),
+    ("raft 2 servers MaxTerm=3 complete (4.3M)", "raft", [2, 1, 3, 9, 1, 1], dict(table_capacity=1 << 25, arena_capacity=5_000_000)),
+    ("SSI 2x3 complete (7.9M), 7 invariants", "ssi", [2, 3, 127, 0], dict(table_capacity=1 << 26, arena_capacity=9_000_000)),
+    ("SSI 4x3 levels 1-10 (config 5 prefix), 7 invariants", "ssi", [4, 3, 127, 0],
+     dict(table_capacity=1 << 29, arena_capacity=200_000_000, max_levels=10)),
+]
+
+for name, spec, params, kw in WORKLOADS:
+    try:
+        eng = amd.Engine(spec, params, chunk_states=1 << 20, trace=False, timing=True, **kw)
+        eng.run()
+        t0 = time.perf_counter()
+        r = eng.run()
+        dt = time.perf_counter() - t0
+        ks = eng.kernel_stats()
+        W = ks["state_bytes"]
+        kms = {k: round(ks[k]["ms_total"], 3) for k in ("expand", "insert", "materialise")}
+        alg = 2 * W * r.distinct + 8 * r.generated
+        print(json.dumps(dict(workload=name, distinct=r.distinct, generated=r.generated, depth=r.depth, verdict=r.verdict,
+                              ms=round(dt * 1e3, 2), distinct_per_s=round(r.distinct / dt), generated_per_s=round(r.generated / dt),
+                              W=W, kernel_ms=kms, alg_GBs=round(alg / dt / 1e9, 1))), flush=True)
+        eng.close()
+    except Exception as e:  # noqa: BLE001
+        print(json.dumps(dict(workload=name, error=str(e))), flush=True)

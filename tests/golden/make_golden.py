@@ -23,6 +23,8 @@ CASES = [
     ("raft2_mcr3_t2_m1", [2, 3, 2, 9, 1, 3], 0),
     ("raft3_mcr2_t2_m1_prefix", [3, 2, 2, 9, 1, 1], 300000),
     ("raft3_mcr4_t2_m1_prefix_small", [3, 4, 2, 3, 1, 1], 1000000),
+    ("raft5_mcr6_t2_m1_prefix", [5, 6, 2, 5, 1, 1], 2000000),       # BASELINE config 4's model (5 servers, log <= 5), small prefix
+    ("raft3_mcr4_t3_m2_prefix", [3, 4, 3, 3, 2, 3], 2000000),       # more terms, two messages in flight, both invariants
 ]
 BIG = [
     ("raft2_mcr1_t3_m1", [2, 1, 3, 9, 1, 1], 0),

@@ -108,7 +108,7 @@ def _golden(name):
 
 
 @pytest.mark.parametrize("name", ["raft2_mcr2_t2_m2", "raft3_mcr2_t2_m1_prefix", "raft3_mcr4_t2_m1_prefix_small", "raft2_mcr1_t3_m1",
-                                  "raft3_mcr4_t2_m1_bench"])
+                                  "raft3_mcr4_t2_m1_bench", "raft5_mcr6_t2_m1_prefix", "raft3_mcr4_t3_m2_prefix"])
 def test_raft_golden_levels_on_gpu(amd, name):
     """Committed oracle fixtures (tests/golden/make_golden.py), incl. the bench workload's full size."""
     try:

@@ -25,7 +25,8 @@ def test_same_states_per_level(oracle, shim, tmp_path, spec, params):
     assert oracle.read_dump(od) == shim.read_dump(sd)
 
 
-@pytest.mark.parametrize("params,maxd", [([3, 2, 2, 9, 1, 1], 60000), ([3, 4, 3, 3, 2, 3], 40000), ([2, 3, 3, 9, 2, 3], 150000)])
+@pytest.mark.parametrize("params,maxd", [([3, 2, 2, 9, 1, 1], 60000), ([3, 4, 3, 3, 2, 3], 40000), ([2, 3, 3, 9, 2, 3], 150000),
+                                         ([5, 2, 2, 9, 1, 1], 100000), ([5, 6, 2, 5, 1, 1], 100000)])
 def test_raft_prefix_counts(oracle, shim, params, maxd):
     o = oracle.oracle_run("raft", params, max_distinct=maxd)
     s = shim.shim_run("raft", params, max_distinct=maxd)
