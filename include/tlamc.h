@@ -149,6 +149,10 @@ int mc_shard_probe(mc_engine *e, const uint64_t *recv_fp, uint64_t n, uint8_t *a
 int mc_shard_materialise(mc_engine *e, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap,
                          uint64_t *send_counts /* [shard_count] host, in states */);
 int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n);
+/* "stay" alternative to materialise + all-to-all + ingest: the positively answered candidates of the last
+ * mc_shard_expand are materialised into THIS rank's frontier (only fingerprints crossed xGMI).  The caller
+ * uses it once the frontier is large enough to stay balanced, and falls back to the moving form to rebalance. */
+int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new);
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local_states);  /* swap frontiers                                */
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict);
 

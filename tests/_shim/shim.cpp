@@ -149,6 +149,7 @@ struct ShimShardBase {
     virtual int probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) = 0;
     virtual int materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int ingest(const uint8_t *recv_states, uint64_t n) = 0;
+    virtual int keep(const uint8_t *answers_back, uint64_t *n_new) = 0;
     virtual uint64_t end_level() = 0;
     virtual void counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
 };
@@ -245,6 +246,17 @@ struct ShimShard : ShimShardBase {
         }
         return 0;
     }
+    int keep(const uint8_t *answers_back, uint64_t *n_new) override {
+        std::vector<uint64_t> tmp(W);
+        *n_new = 0;
+        for (size_t i = 0; i < pending.size(); i++) {
+            if (!answers_back[i]) continue;
+            S::apply(prm, CWordRef{&arena[pending[i].parent * W], 1}, pending[i].slot, WordRef{tmp.data(), 1});
+            arena.insert(arena.end(), tmp.begin(), tmp.end());
+            (*n_new)++;
+        }
+        return 0;
+    }
     int ingest(const uint8_t *recv_states, uint64_t n) override {  // one source's bucket
         const uint64_t *in = (const uint64_t *)recv_states;
         for (uint64_t j = 0; j < n; j++)
@@ -277,6 +289,7 @@ int shim_shard_materialise(void *e, const uint8_t *ans, uint8_t *states, uint64_
     return ((ShimShardBase *)e)->materialise(ans, states, cap, counts);
 }
 int shim_shard_ingest(void *e, const uint8_t *states, uint64_t n) { return ((ShimShardBase *)e)->ingest(states, n); }
+int shim_shard_keep(void *e, const uint8_t *ans, uint64_t *n) { return ((ShimShardBase *)e)->keep(ans, n); }
 int shim_shard_end_level(void *e, uint64_t *n) { *n = ((ShimShardBase *)e)->end_level(); return 0; }
 int shim_shard_counters(void *e, uint64_t *g, uint64_t *d, int32_t *v) { ((ShimShardBase *)e)->counters(g, d, v); return 0; }
 }

@@ -13,7 +13,7 @@ class ShimStepEngine:
         L = self.lib
         L.shim_shard_create.restype = C.c_void_p
         L.shim_shard_create.argtypes = [C.POINTER(helpers.McSpecDesc), C.c_uint32, C.c_uint32]
-        for name in ("begin", "level_size", "expand", "probe", "materialise", "ingest", "end_level", "counters", "destroy"):
+        for name in ("begin", "level_size", "expand", "probe", "materialise", "ingest", "keep", "end_level", "counters", "destroy"):
             getattr(L, "shim_shard_" + name).restype = C.c_int if name != "destroy" else None
         L.shim_shard_begin.argtypes = [C.c_void_p]
         L.shim_shard_destroy.argtypes = [C.c_void_p]
@@ -22,6 +22,7 @@ class ShimStepEngine:
         L.shim_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.shim_shard_materialise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.shim_shard_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.shim_shard_keep.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
         L.shim_shard_end_level.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.shim_shard_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
         self.world = world
@@ -60,6 +61,11 @@ class ShimStepEngine:
 
     def ingest(self, recv_states, n):
         self._ck(self.lib.shim_shard_ingest(self.h, recv_states.data_ptr(), n), "ingest")
+
+    def keep(self, answers_back):
+        n = C.c_uint64()
+        self._ck(self.lib.shim_shard_keep(self.h, answers_back.data_ptr(), C.byref(n)), "keep")
+        return n.value
 
     def end_level(self):
         n = C.c_uint64()

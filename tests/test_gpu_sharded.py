@@ -32,3 +32,12 @@ def test_two_ranks_on_one_gpu_equal_oracle(oracle, tmp_path, spec, params, opts)
     assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == \
            (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"])
     assert sum(r["shares"]) == o["distinct"]
+
+
+def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path):
+    params = [3, 2, 2, 9, 1, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=300000)
+    r = run_dist("hip", 2, "raft", params, tmp_path, {"max_distinct": 300000, "chunk": 1 << 14, "table": 1 << 22, "arena": 1 << 20,
+                                                       "stay_threshold": 200, "rebalance_ratio": 1.5})
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert r["phases"].get("stay_levels", 0) >= 3

@@ -47,3 +47,15 @@ def test_sharded_counts_equal_oracle(oracle, shim, tmp_path, world, spec, params
 def test_sharded_verdict_propagates(oracle, shim, tmp_path):
     r = run_dist("shim", 2, "pcal_intro", [1, 0, 20, 2], tmp_path, {"chunk": 500})
     assert r["verdict"] == "assert"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stay_mode_counts_equal_oracle(oracle, shim, tmp_path, world):
+    """States stay on the generating rank once the frontier is large (threshold lowered to 50 states per rank
+    here, loose rebalance ratio): only fingerprints and answers are exchanged; counts must not change."""
+    params = [2, 2, 2, 9, 2, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=60000)
+    r = run_dist("shim", world, "raft", params, tmp_path, {"max_distinct": 60000, "chunk": 2000, "stay_threshold": 50, "rebalance_ratio": 1.6})
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert r["phases"].get("stay_levels", 0) >= 5 and r["phases"].get("move_levels", 0) >= 3
+    assert sum(r["shares"]) == o["distinct"]

@@ -94,6 +94,7 @@ def lib():
     L.mc_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.mc_shard_materialise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, U64P]
     L.mc_shard_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.mc_shard_keep.argtypes = [C.c_void_p, C.c_void_p, U64P]
     L.mc_shard_end_level.argtypes = [C.c_void_p, U64P]
     L.mc_shard_counters.argtypes = [C.c_void_p, U64P, U64P, C.POINTER(C.c_int32)]
     if hasattr(L, "mc_cfg_parse"):
@@ -223,6 +224,11 @@ class Engine:
 
     def shard_ingest(self, recv_states_ptr, n):
         _check(lib().mc_shard_ingest(self._h, recv_states_ptr, n), "mc_shard_ingest")
+
+    def shard_keep(self, answers_back_ptr):
+        n = C.c_uint64()
+        _check(lib().mc_shard_keep(self._h, answers_back_ptr, C.byref(n)), "mc_shard_keep")
+        return n.value
 
     def shard_end_level(self):
         n = C.c_uint64()

@@ -556,6 +556,21 @@ k_send_materialise(typename S::Params prm, const uint64_t *__restrict__ arena, u
         for (int w = 0; w < W; w++) out.set(w, 0);  // padding lanes of the owner's last block
     }
 }
+// "stay" mode of the sharded engine: new states are materialised on the rank that generated them
+// (only fingerprints travelled); `list` holds the compacted sources of the positive answers
+template <class S>
+__global__ void __launch_bounds__(256)
+k_materialise_list(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint32_t *__restrict__ list, uint64_t n,
+                   uint64_t out0, uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t src = list[j];
+    const uint64_t pidx = chunk_base + (src & 0xffffffu), oidx = out0 + j;
+    if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); return; }
+    const int W = S::words(prm);
+    S::apply(prm, arena_cref(arena, pidx, W), (int)(src >> 24), arena_ref(arena, oidx, W));
+    if (parent) { parent[oidx] = (uint32_t)pidx; pslot[oidx] = (uint16_t)(src >> 24); }
+}
 // owner side: append the `n` states of one received bucket (blocked layout) to the arena
 __global__ void __launch_bounds__(256)
 k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv_blocks, uint64_t n, uint64_t out0, uint64_t arena_cap,
@@ -591,6 +606,7 @@ struct EngineBase {
     virtual int shard_probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) = 0;
     virtual int shard_materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int shard_ingest(const uint8_t *recv_states, uint64_t n) = 0;
+    virtual int shard_keep(const uint8_t *answers_back, uint64_t *n_new) = 0;
     virtual int shard_end_level(uint64_t *new_local) = 0;
     virtual int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
 };
@@ -1108,6 +1124,43 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamSynchronize(stream));
         return MC_OK;
     }
+    // "stay" mode: materialise the positively answered candidates of the last shard_expand into the LOCAL arena
+    int shard_keep(const uint8_t *answers_back, uint64_t *n_new) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        *n_new = 0;
+        if (!pend_total) return MC_OK;
+        const unsigned P = nranks();
+        const unsigned bx = (unsigned)((pend_total + 255) / 256);
+        hipcub::TransformInputIterator<uint32_t, AnswerCast, const uint8_t *> in(answers_back, AnswerCast());
+        size_t need = 0;
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, need, in, d_incl, (int)pend_total, stream));
+        if (need > scan_tmp_bytes) {
+            if (d_scan_tmp) hipFree(d_scan_tmp);
+            HIP_TRY(hipMalloc(&d_scan_tmp, need));
+            scan_tmp_bytes = need;
+        }
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_scan_tmp, need, in, d_incl, (int)pend_total, stream));
+        uint32_t total32 = 0;
+        HIP_TRY(hipMemcpyAsync(&total32, d_incl + (pend_total - 1), sizeof total32, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const uint64_t total = total32;
+        if (!total) return MC_OK;
+        if (sh_next + total > arena_cap) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }
+        OwnerOffsets one, zero;  // a single range covering every pending candidate
+        for (unsigned t = 0; t <= 8; t++) { one.off[t] = t ? pend_total : 0; zero.off[t] = 0; }
+        hipLaunchKernelGGL(k_compact_new, dim3(bx), dim3(256), 0, stream, answers_back, d_incl, d_pend_src, pend_total, one, zero, 1u, d_new_src);
+        timed(2, total, [&] {
+            hipLaunchKernelGGL(k_materialise_list<S>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, prm, d_arena, sh_chunk_base,
+                               d_new_src, total, sh_next, arena_cap, d_parent, d_pslot, d_ctr);
+        });
+        sh_next += total;
+        hipLaunchKernelGGL(k_set_arena_next, dim3(1), dim3(1), 0, stream, d_ctr, (unsigned long long)sh_next);
+        HIP_TRY(hipStreamSynchronize(stream));
+        last_distinct = sh_next;
+        *n_new = total;
+        (void)P;
+        return MC_OK;
+    }
     // recv_states: one bucket per source rank, back to back, each a whole number of 64-state blocks;
     // n = valid states of ONE bucket starting at recv_states (call once per source)
     int shard_ingest(const uint8_t *recv_states, uint64_t n) override {
@@ -1259,6 +1312,7 @@ int mc_shard_materialise(mc_engine *e, const uint8_t *answers_back, uint8_t *sen
     return e && send_counts ? e->impl->shard_materialise(answers_back, send_states, send_cap, send_counts) : MC_EBADCFG;
 }
 int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n) { return e ? e->impl->shard_ingest(recv_states, n) : MC_EBADCFG; }
+int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new) { return e && n_new ? e->impl->shard_keep(answers_back, n_new) : MC_EBADCFG; }
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local) { return e && new_local ? e->impl->shard_end_level(new_local) : MC_EBADCFG; }
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) {
     return e && generated && distinct_local && verdict ? e->impl->shard_counters(generated, distinct_local, verdict) : MC_EBADCFG;

@@ -56,6 +56,9 @@ class HipStepEngine:
     def ingest(self, recv_states, n):
         self.eng.shard_ingest(recv_states.data_ptr(), n)
 
+    def keep(self, answers_back):
+        return self.eng.shard_keep(answers_back.data_ptr())
+
     def end_level(self):
         return self.eng.shard_end_level()
 
@@ -71,7 +74,8 @@ class HipStepEngine:
 
 class ShardedChecker:
     def __init__(self, spec, params, device=0, chunk_states=1 << 19, max_distinct=0, max_levels=0, table_capacity=1 << 27,
-                 arena_capacity=1 << 25, fanout_cap=32, new_cap=8, engine=None, group=None):
+                 arena_capacity=1 << 25, fanout_cap=32, new_cap=8, engine=None, group=None, stay_threshold=1 << 16,
+                 rebalance_ratio=1.25):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -80,6 +84,10 @@ class ShardedChecker:
         self.collective = dist.is_initialized()
         self.chunk = chunk_states
         self.max_distinct, self.max_levels = max_distinct, max_levels
+        # States MOVE to the owner of their fingerprint while the frontier is small (that is what spreads the
+        # single initial state over the ranks) and whenever the ranks' frontiers drift apart; otherwise they
+        # STAY where they were generated and only fingerprints (8 B) and answers (1 B) cross xGMI.
+        self.stay_threshold, self.rebalance_ratio = stay_threshold, rebalance_ratio
         self.eng = engine if engine is not None else HipStepEngine(spec, params, device, self.rank, self.world, chunk_states,
                                                                     table_capacity, arena_capacity)
         self.dev = self.eng.device
@@ -147,6 +155,9 @@ class ShardedChecker:
                 break
             local_n = e.level_size()
             rounds = self._allreduce(math.ceil(local_n / self.chunk), MAX)
+            biggest = self._allreduce(local_n, MAX)
+            stay = frontier >= self.stay_threshold * self.world and biggest * self.world <= self.rebalance_ratio * frontier
+            self.phase_s["stay_levels" if stay else "move_levels"] = self.phase_s.get("stay_levels" if stay else "move_levels", 0) + 1
             for r in range(rounds):
                 first = min(r * self.chunk, local_n)
                 count = min(self.chunk, local_n - first)
@@ -164,6 +175,13 @@ class ShardedChecker:
                 back = self._a2a_back(answers, rcounts, counts)
                 e.sync()
                 t4 = time.perf_counter()
+                if stay:
+                    e.keep(back)
+                    self.phase_s["keep"] = self.phase_s.get("keep", 0.0) + time.perf_counter() - t4
+                    self.phase_s["rounds"] = self.phase_s.get("rounds", 0) + 1
+                    for k, dt in zip(("expand", "a2a_fp", "probe", "a2a_ans"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                        self.phase_s[k] = self.phase_s.get(k, 0.0) + dt
+                    continue
                 scounts = e.materialise(back, self.send_states)
                 t5 = time.perf_counter()
                 # full states travel as whole 64-state blocks per owner (coalesced at both ends)
