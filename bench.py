@@ -78,7 +78,9 @@ def main():
         from tla_rust_amd.sharded import ShardedChecker
         # weak scaling: the distinct-state budget grows with the number of GPUs
         chk = ShardedChecker(WORKLOAD["spec"], WORKLOAD["params"], device=local, max_distinct=a.max_distinct * world,
-                             chunk_states=min(a.chunk, 1 << 19), table_capacity=1 << 27, arena_capacity=48_000_000,
+                             chunk_states=min(a.chunk, 1 << 19), table_capacity=1 << 27,
+                             # the last level may overshoot the budget by the growth factor (~1.7x): size for it
+                             arena_capacity=64_000_000,
                              fanout_cap=24, new_cap=6)
         run = chk.run
 
@@ -122,8 +124,20 @@ def main():
         dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
         n_runs = a.steps  # stats are reset by every run(): they describe the last step
         ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
+        traffic, traffic_src = None, None
+        pmc = sorted((ROOT / "profiles").glob("r*_pmc.json"))
+        if pmc:  # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same command
+            try:
+                d = json.loads(pmc[-1].read_text())
+                kname = {"expand": "k_expand_insert", "insert": "k_insert", "materialise": "k_materialise"}[dom]
+                k = next(v for n, v in d.items() if n.startswith(kname + "<") and "Raft<3>" in n)
+                # FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts wide coalesced reads at 1/2 (MI355X_MICROARCH.md §HBM)
+                traffic = (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
+                traffic_src = f"profiles/{pmc[-1].name}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes"
+            except Exception:  # noqa: BLE001
+                traffic = None
         line["roofline"] = {"bound": "hbm", "kernel": f"k_{dom}", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                             "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
                             "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
                             "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},

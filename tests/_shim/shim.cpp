@@ -20,6 +20,34 @@
 
 using namespace mc;
 
+// open-addressing fingerprint set (the std::unordered_set it replaces spent minutes in malloc)
+struct FpSet {
+    std::vector<uint64_t> tab;
+    size_t n = 0;
+    FpSet() : tab(1 << 16, 0) {}
+    void clear() { tab.assign(1 << 16, 0); n = 0; }
+    void grow() {
+        std::vector<uint64_t> old;
+        old.swap(tab);
+        tab.assign(old.size() * 2, 0);
+        for (uint64_t v : old) if (v) put(v);
+    }
+    bool put(uint64_t fp) {
+        size_t h = fp & (tab.size() - 1);
+        while (tab[h]) { if (tab[h] == fp) return false; h = (h + 1) & (tab.size() - 1); }
+        tab[h] = fp;
+        return true;
+    }
+    // std::unordered_set-like insert: .second = newly inserted
+    struct R { int first; bool second; };
+    R insert(uint64_t fp) {
+        if ((n + 1) * 2 > tab.size()) grow();
+        const bool is_new = put(fp);
+        n += is_new;
+        return R{0, is_new};
+    }
+};
+
 struct ShimResult {
     uint64_t distinct, generated, queue_left;
     uint32_t depth;
@@ -47,14 +75,12 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
     const int W = S::words(prm);
     memset(r, 0, sizeof *r);
     r->violated_invariant = -1;
-    std::vector<uint64_t> arena;
-    std::vector<uint32_t> parent;
-    std::unordered_set<uint64_t> seen;
+    std::vector<uint64_t> cur, next;   // only two BFS levels are resident
+    FpSet seen;
     FILE *dump = dump_path ? fopen(dump_path, "w") : nullptr;
     std::vector<char> txt(1 << 16);
-    auto add_state = [&](const uint64_t *w, uint32_t par, uint32_t level) {
-        arena.insert(arena.end(), w, w + W);
-        parent.push_back(par);
+    auto add_state = [&](const uint64_t *w, uint32_t level) {
+        next.insert(next.end(), w, w + W);
         r->distinct++;
         r->level_distinct[level - 1]++;
         if (!FpCheck<S>::ok(prm, w)) r->fp_mismatch++;
@@ -78,18 +104,18 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
         const unsigned st = S::init_status(prm, CWordRef{tmp, 1});
         if (st & ST_INVARIANT) violation(st, 1);
         if (st & ST_OUT_OF_MODEL) continue;
-        if (seen.insert(stored_fp<S>(prm, tmp)).second) add_state(tmp, UINT32_MAX, 1);
+        if (seen.insert(stored_fp<S>(prm, tmp)).second) add_state(tmp, 1);
     }
-    uint64_t lo = 0, hi = r->distinct;
+    cur.swap(next);
     uint32_t level = 1;
     int budget = 0;
-    while (hi > lo) {
+    while (!cur.empty()) {
         if (r->verdict) break;
         if (max_levels && level >= max_levels) { budget = 1; break; }
         if (max_distinct && r->distinct >= max_distinct) { budget = 1; break; }
-        for (uint64_t i = lo; i < hi; i++) {
-            std::vector<uint64_t> cur(arena.begin() + i * W, arena.begin() + (i + 1) * W);  // arena may grow
-            CWordRef s{cur.data(), 1};
+        const uint64_t nstates = cur.size() / (size_t)W;
+        for (uint64_t i = 0; i < nstates; i++) {
+            CWordRef s{&cur[i * W], 1};
             typename S::Local loc;
             S::load(prm, s, loc);
             const int ns = S::nslots(prm, loc);
@@ -109,19 +135,19 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
                 if (seen.insert(fp).second) {
                     S::apply(prm, s, slot, WordRef{tmp, 1});
                     if (stored_fp<S>(prm, tmp) != fp) r->fp_mismatch++;
-                    add_state(tmp, (uint32_t)i, level + 1);
+                    add_state(tmp, level + 1);
                 }
             }
             if (nsucc == 0 && check_deadlock && !r->verdict) { r->verdict = MC_V_DEADLOCK; r->trace_len = level; }
         }
-        lo = hi;
-        hi = r->distinct;
-        if (hi > lo) level++;
+        cur.clear();
+        cur.swap(next);
+        if (!cur.empty()) level++;
         if (level >= MC_MAX_LEVELS) break;
     }
     r->depth = level;
     r->levels = level;
-    r->queue_left = hi - lo;
+    r->queue_left = cur.size() / (size_t)W;
     if (!r->verdict && budget) r->verdict = MC_V_BUDGET;
     if (dump) fclose(dump);
     return 0;
@@ -160,7 +186,7 @@ struct ShimShard : ShimShardBase {
     uint32_t rank, nranks;
     int W;
     std::vector<uint64_t> arena;
-    std::unordered_set<uint64_t> seen;
+    FpSet seen;
     uint64_t lo = 0, hi = 0, generated = 0;
     int32_t verdict = MC_V_OK;
     struct Pending { uint64_t parent; int slot; };

@@ -38,7 +38,7 @@ def test_raft_prefix_counts(oracle, shim, params, maxd):
 def test_raft_expected_violation_trace_length(oracle, shim):
     """SURVEY.md Appendix E caveat (ii): CommittedLogStable is violated once MaxTerm >= 3 and
     MaxClientRequests >= 3; the shortest counterexample has 31 states."""
-    s = shim.shim_run("raft", [2, 3, 3, 9, 1, 2])
+    s = shim.shim_run("raft", [2, 3, 3, 9, 1, 2, 24, 3, 8])     # tuned slot-array capacities: W = 416 B instead of 632 B
     assert s["verdict"] == "invariant" and s["violated_invariant"] == 1 and s["trace_len"] == 31
 
 
