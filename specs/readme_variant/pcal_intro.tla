@@ -1,10 +1,4 @@
 ------------------------------- MODULE pcal_intro -------------------------------
-(***************************************************************************)
-(* The variant of the money-transfer example printed in the tla-rust       *)
-(* README, with the labels A: and B: that split the transfer into three    *)
-(* atomic steps; TLC's failing run on it is the README's worked example.   *)
-(* Translation written by hand for this repository (p-manual.pdf App. B).  *)
-(***************************************************************************)
 EXTENDS Naturals, TLC
 
 (* --algorithm transfer
@@ -23,7 +17,6 @@ C: assert alice_account >= 0;
 end process
 
 end algorithm *)
-
 \* BEGIN TRANSLATION
 VARIABLES alice_account, bob_account, account_total, pc, money
 
@@ -31,9 +24,11 @@ vars == << alice_account, bob_account, account_total, pc, money >>
 
 ProcSet == (1..2)
 
-Init == /\ alice_account = 10
+Init == (* Global variables *)
+        /\ alice_account = 10
         /\ bob_account = 10
         /\ account_total = alice_account + bob_account
+        (* Process TransProc *)
         /\ money \in [1..2 -> 1..20]
         /\ pc = [self \in ProcSet |-> "Transfer"]
 
@@ -41,7 +36,8 @@ Transfer(self) == /\ pc[self] = "Transfer"
                   /\ IF alice_account >= money[self]
                         THEN /\ pc' = [pc EXCEPT ![self] = "A"]
                         ELSE /\ pc' = [pc EXCEPT ![self] = "C"]
-                  /\ UNCHANGED << alice_account, bob_account, account_total, money >>
+                  /\ UNCHANGED << alice_account, bob_account, account_total, 
+                                  money >>
 
 A(self) == /\ pc[self] = "A"
            /\ alice_account' = alice_account - money[self]
@@ -54,7 +50,7 @@ B(self) == /\ pc[self] = "B"
            /\ UNCHANGED << alice_account, account_total, money >>
 
 C(self) == /\ pc[self] = "C"
-           /\ Assert(alice_account >= 0,
+           /\ Assert(alice_account >= 0, 
                      "Failure of assertion at line 16, column 4.")
            /\ pc' = [pc EXCEPT ![self] = "Done"]
            /\ UNCHANGED << alice_account, bob_account, account_total, money >>
@@ -62,12 +58,17 @@ C(self) == /\ pc[self] = "C"
 TransProc(self) == Transfer(self) \/ A(self) \/ B(self) \/ C(self)
 
 Next == (\E self \in 1..2: TransProc(self))
-           \/ ((\A self \in ProcSet: pc[self] = "Done") /\ UNCHANGED vars)
+           \/ (* Disjunct to prevent deadlock on termination *)
+              ((\A self \in ProcSet: pc[self] = "Done") /\ UNCHANGED vars)
 
 Spec == Init /\ [][Next]_vars
 
 Termination == <>(\A self \in ProcSet: pc[self] = "Done")
+
 \* END TRANSLATION
 
+\* this is a TLA comment. pcal2tla will insert the transpiled TLA here
+
 MoneyInvariant == alice_account + bob_account = account_total
+
 =============================================================================

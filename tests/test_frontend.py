@@ -102,7 +102,19 @@ def test_tlc_dropin_readme_variant_report(amd):
     assert lines[2] == '"Failure of assertion at line 16, column 4."'                                # README.md:269
     assert lines[3] == "Error: The behavior up to this point is:"                                    # README.md:270
     assert lines[4] == "State 1: <Initial predicate>"                                                # README.md:271
-    assert rep.count("\nState ") == 6 and "/\\ pc = <<\"C\", \"B\">>" in rep or "/\\ pc = <<\"B\", \"C\">>" in rep
+    assert rep.count("\nState ") == 6
+    # action locations exactly as TLC printed them for this file layout (README.md:278,285,292,299,306)
+    hdr = [l for l in lines if l.startswith("State ") and "Initial" not in l]
+    allowed = {"Transfer": "<Action line 35, col 19 to line 40, col 42 of module pcal_intro>",
+               "A": "<Action line 42, col 12 to line 45, col 63 of module pcal_intro>",
+               "B": "<Action line 47, col 12 to line 50, col 65 of module pcal_intro>"}
+    assert len(hdr) == 5 and all(h.split(": ", 1)[1] in allowed.values() for h in hdr)
+    assert sorted(h.split(": ", 1)[1] for h in hdr) == sorted([allowed["Transfer"]] * 2 + [allowed["A"]] * 2 + [allowed["B"]])
+    # README.md:313-316
+    i = lines.index("Error: The error occurred when TLC was evaluating the nested")
+    assert lines[i + 1] == "expressions at the following positions:"
+    assert lines[i + 2] == "0. Line 52, column 15 to line 52, column 28 in pcal_intro"
+    assert lines[i + 3] == "1. Line 53, column 15 to line 54, column 66 in pcal_intro"
     assert "The depth of the complete state graph search is 7." in rep                               # README.md:320
 
 

@@ -333,6 +333,53 @@ std::string dir_of(const std::string &p) {
     return i == std::string::npos ? "." : p.substr(0, i);
 }
 
+// ---- source locations, as TLC prints them (README.md:278 "<Action line 35, col 19 to line 40, col 42 of module pcal_intro>")
+struct Span { int l1 = 0, c1 = 0, l2 = 0, c2 = 0; bool ok = false; };
+std::vector<std::string> split_lines(const std::string &t) {
+    std::vector<std::string> v;
+    size_t pos = 0;
+    while (pos <= t.size()) {
+        size_t eol = t.find('\n', pos);
+        if (eol == std::string::npos) eol = t.size();
+        std::string line = t.substr(pos, eol - pos);
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        v.push_back(line);
+        pos = eol + 1;
+    }
+    return v;
+}
+int last_nonspace(const std::string &l) {  // 1-based column of the last non-blank character, 0 if none
+    int c = (int)l.size();
+    while (c > 0 && (l[c - 1] == ' ' || l[c - 1] == '\t')) c--;
+    return c;
+}
+// body of the top-level definition `name(...) ==` / `name ==`: from the first token after "==" to the last
+// token before the next blank line or top-level definition
+Span definition_span(const std::vector<std::string> &L, const std::string &name, int *first_line = nullptr) {
+    Span sp;
+    for (size_t i = 0; i < L.size(); i++) {
+        const std::string &l = L[i];
+        if (l.compare(0, name.size(), name) != 0) continue;
+        const char nx = l.size() > name.size() ? l[name.size()] : 0;
+        if (nx != '(' && nx != ' ') continue;
+        const size_t eq = l.find("==");
+        if (eq == std::string::npos) continue;
+        size_t b = eq + 2;
+        while (b < l.size() && l[b] == ' ') b++;
+        if (b >= l.size()) continue;
+        sp.l1 = (int)i + 1;
+        sp.c1 = (int)b + 1;
+        size_t j = i;
+        while (j + 1 < L.size() && last_nonspace(L[j + 1]) > 0 && (L[j + 1][0] == ' ' || L[j + 1][0] == '\t')) j++;
+        sp.l2 = (int)j + 1;
+        sp.c2 = last_nonspace(L[j]);
+        sp.ok = true;
+        if (first_line) *first_line = (int)i;
+        return sp;
+    }
+    return sp;
+}
+
 struct Out {
     char *b; size_t cap, k;
     void put(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
@@ -519,7 +566,7 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
     mc_cfg_free(c);
     if (rc) return rc;
     // the lowering is valid only for the text it was written against
-    std::string part;
+    std::string part, def_text, def_module_name;  // text + name of the module that holds the action definitions
     if (d.spec_id == MC_SPEC_PCAL_INTRO) {
         if (!algorithm_text(tla, part)) return fe_fail(MC_ENOSPEC, "%s: no --algorithm block", tla_path);
         const uint64_t h = text_hash(part);
@@ -539,6 +586,7 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
             if (!module_body(raft, part)) return fe_fail(MC_ENOSPEC, "raft.tla: cannot find the module body");
             const uint64_t h = text_hash(part);
             if (h != H_RAFT) return fe_fail(MC_ENOSPEC, "raft.tla differs from the text the lowering was written against (hash %016llx)", (unsigned long long)h);
+            if (module != "raft") { def_text = raft; def_module_name = "raft"; }
         }
     }
     if (d.spec_id == MC_SPEC_SSI) {
@@ -551,6 +599,7 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
             if (!module_body(ssi, part)) return fe_fail(MC_ENOSPEC, "serializableSnapshotIsolation.tla: cannot find the module body");
             const uint64_t h = text_hash(part);
             if (h != H_SSI) return fe_fail(MC_ENOSPEC, "serializableSnapshotIsolation.tla differs from the text the lowering was written against (hash %016llx)", (unsigned long long)h);
+            if (module != "serializableSnapshotIsolation") { def_text = ssi; def_module_name = "serializableSnapshotIsolation"; }
         }
     }
     mc_engine *e = nullptr;
@@ -578,13 +627,50 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
         size_t n = res->trace_len ? res->trace_len : 1;
         std::vector<uint8_t> states(n * W);
         std::vector<int32_t> acts(n);
+        // action definitions live in the checked module, or in the module an MC wrapper EXTENDS
+        const std::vector<std::string> srcL = split_lines(def_text.empty() ? tla : def_text);
+        const std::string &def_module = def_text.empty() ? module : def_module_name;
         if (mc_engine_trace(e, states.data(), acts.data(), &n) == MC_OK && n) {
             o.put("Error: The behavior up to this point is:\n");
             std::vector<char> txt(1 << 16);
             for (size_t k = 0; k < n; k++) {
                 mc_state_format(&d, &states[k * W], txt.data(), txt.size());
-                if (acts[k] < 0) o.put("State %zu: <Initial predicate>\n%s\n\n", k + 1, txt.data());
-                else o.put("State %zu: <Action %s of module %s>\n%s\n\n", k + 1, mc_action_name(&d, acts[k]), module.c_str(), txt.data());
+                if (acts[k] < 0) { o.put("State %zu: <Initial predicate>\n%s\n\n", k + 1, txt.data()); continue; }
+                const char *an = mc_action_name(&d, acts[k]);
+                const Span sp = definition_span(srcL, an);
+                if (sp.ok)  // README.md:278
+                    o.put("State %zu: <Action line %d, col %d to line %d, col %d of module %s>\n%s\n\n", k + 1, sp.l1, sp.c1, sp.l2, sp.c2,
+                          def_module.c_str(), txt.data());
+                else
+                    o.put("State %zu: <Action %s of module %s>\n%s\n\n", k + 1, an, def_module.c_str(), txt.data());
+            }
+        }
+        if (res->verdict == MC_V_ASSERT) {  // README.md:313-316: the conjunct being evaluated and the Assert call itself
+            int first = 0;
+            const Span c = definition_span(srcL, "C", &first);
+            if (c.ok) {
+                Span a0, a1;
+                const std::string &l0 = srcL[first];
+                size_t b = (size_t)c.c1 - 1;
+                if (l0.compare(b, 2, "/\\") == 0) { b += 2; while (b < l0.size() && l0[b] == ' ') b++; }
+                a0.l1 = a0.l2 = c.l1; a0.c1 = (int)b + 1; a0.c2 = last_nonspace(l0);
+                for (int i = first; i < c.l2; i++) {
+                    const size_t at = srcL[i].find("Assert(");
+                    if (at == std::string::npos) continue;
+                    a1.l1 = i + 1; a1.c1 = (int)at + 1;
+                    int depth = 0;
+                    for (int j = i; j < c.l2 && !a1.ok; j++)
+                        for (size_t q = (j == i ? at : 0); q < srcL[j].size(); q++) {
+                            if (srcL[j][q] == '(') depth++;
+                            else if (srcL[j][q] == ')' && --depth == 0) { a1.l2 = j + 1; a1.c2 = (int)q + 1; a1.ok = true; break; }
+                        }
+                    break;
+                }
+                if (a1.ok) {
+                    o.put("Error: The error occurred when TLC was evaluating the nested\nexpressions at the following positions:\n");
+                    o.put("0. Line %d, column %d to line %d, column %d in %s\n", a0.l1, a0.c1, a0.l2, a0.c2, def_module.c_str());
+                    o.put("1. Line %d, column %d to line %d, column %d in %s\n\n\n", a1.l1, a1.c1, a1.l2, a1.c2, def_module.c_str());
+                }
             }
         }
     }
