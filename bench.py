@@ -77,11 +77,14 @@ def main():
     else:
         from tla_rust_amd.sharded import ShardedChecker
         # weak scaling: the distinct-state budget grows with the number of GPUs
-        chk = ShardedChecker(WORKLOAD["spec"], WORKLOAD["params"], device=local, max_distinct=a.max_distinct * world,
+        # deeper levels than the single-GPU prefix are reached: the message-slot maximum grows by about one per
+        # level (13 at level 23), so the sharded run gets 24 message slots (W = 464 B) instead of 16
+        sharded_params = WORKLOAD["params"][:6] + [24, 2, 8]
+        chk = ShardedChecker(WORKLOAD["spec"], sharded_params, device=local, max_distinct=a.max_distinct * world,
                              chunk_states=min(a.chunk, 1 << 19), table_capacity=1 << 27,
                              # the last level may overshoot the budget by the growth factor (~1.7x): size for it
                              arena_capacity=64_000_000,
-                             fanout_cap=24, new_cap=6)
+                             fanout_cap=48, new_cap=6)
         run = chk.run
 
     def barrier():
