@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--table-log2", type=int, default=28)
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
+    ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
     a = ap.parse_args()
 
     import torch
@@ -70,7 +71,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     if not use_dist:
-        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << a.table_log2, matrix=a.matrix,
+        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << a.table_log2, matrix=a.matrix, debug_flags=32 if a.no_family else 0,
                          arena_capacity=30_000_000 if a.max_distinct <= 25_000_000 else 2 * a.max_distinct,
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run

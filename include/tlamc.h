@@ -64,6 +64,8 @@ typedef struct {
 #define MC_F_TRACE 2u    /* keep (parent, action) per state so a counterexample can be rebuilt     */
 #define MC_F_TIMING 4u   /* time every kernel launch with HIP events on the engine stream          */
 #define MC_F_MATRIX 8u   /* A/B only: unfused expand -> candidate matrix -> insert kernels          */
+#define MC_F_NOPROBE 16u /* profiling only (mc_engine_debug_reexpand): skip the seen-set probes   */
+#define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
 
 typedef struct {
     int32_t device;          /* HIP device ordinal                                              */

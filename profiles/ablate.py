@@ -11,6 +11,7 @@ eng = amd.Engine("raft", P, table_capacity=1 << 28, arena_capacity=30_000_000, c
 r = eng.run()
 ks = eng.kernel_stats()
 print("run:", r.distinct, {k: round(ks[k]["ms_total"], 2) for k in ("expand", "materialise")}, "(expands", ks["expand"]["units"], "states)")
-for name, fl in (("probe(all hit)", 0), ("no probe", 16)):
+for name, fl in (("family kernel, probe(all hit)", 0), ("family kernel, no probe", 16), ("slot kernel, probe(all hit)", 32), ("slot kernel, no probe", 48),
+                 ("family kernel, load parents only", 64 + 16), ("slot kernel, load parents only", 64 + 48)):
     ts = [eng.debug_reexpand(fl) for _ in range(3)]
     print(f"re-expand {r.distinct} states, {name}: {min(ts):.2f} ms")

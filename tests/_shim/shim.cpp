@@ -60,6 +60,44 @@ struct ShimResult {
 template <class S>
 static uint64_t stored_fp(const typename S::Params &p, const uint64_t *w) { return S::fp_of(p, CWordRef{w, 1}); }
 
+// expand-by-family interface (specs with NFAM): for every (state, slot) the family-pruned evaluation through the
+// guard must reproduce exactly what the generic evaluation does
+template <class S, class = void>
+struct FamCheck {
+    template <class Ref>
+    static uint64_t mismatches(const typename S::Params &, typename S::Local &, Ref, int) { return 0; }
+};
+template <class S>
+struct FamCheck<S, decltype((void)S::NFAM)> {
+    template <int F, class Ref>
+    static unsigned run(int fam, const typename S::Params &p, const typename S::Summary &q, Ref s, int slot, uint64_t &fp) {
+        if constexpr (F < S::NFAM) {
+            if (fam == F) return S::template eval_pair<F>(p, q, s, slot, fp);
+            return run<F + 1>(fam, p, q, s, slot, fp);
+        } else {
+            return 0;
+        }
+    }
+    template <class Ref>
+    static uint64_t mismatches(const typename S::Params &p, typename S::Local &l, Ref s, int ns) {
+        typename S::Guards g;
+        S::guards(p, l, g);
+        typename S::Summary q;
+        S::summarize(l, q);
+        uint64_t bad = 0;
+        for (int slot = 0; slot < ns; slot++) {
+            uint64_t f0 = 0, f1 = 0;
+            const unsigned st0 = S::eval(p, l, s, slot, f0);
+            int fam = -1;
+            if (slot < S::FIX) { if (g.fixed >> slot & 1) fam = S::fixed_family(slot); }
+            else fam = S::guard_msg(g, s.get(S::W_MSG0 + (slot - S::FIX) / 3), (slot - S::FIX) % 3);
+            const unsigned st1 = fam >= 0 ? run<0>(fam, p, q, s, slot, f1) : 0u;
+            if (st0 != st1 || ((st0 & ST_ENABLED) && f0 != f1)) bad++;
+        }
+        return bad;
+    }
+};
+
 template <class S, class = void>
 struct FpCheck {
     static bool ok(const typename S::Params &, const uint64_t *) { return true; }
@@ -121,6 +159,7 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
             const int ns = S::nslots(prm, loc);
             const unsigned ps = S::parent_status(prm, loc, s);
             if (ps & ST_INVARIANT) violation(ps, level);
+            r->fp_mismatch += FamCheck<S>::mismatches(prm, loc, s, ns);
             uint64_t nsucc = 0;
             for (int slot = 0; slot < ns; slot++) {
                 uint64_t fp = 0;

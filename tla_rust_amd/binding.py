@@ -10,7 +10,7 @@ LIB_PATH = PKG / "_build" / "libtlamc.so"
 MC_MAX_LEVELS = 4096
 SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4}
 VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
-MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING, MC_F_MATRIX = 1, 2, 4, 8
+MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING, MC_F_MATRIX, MC_F_NOPROBE, MC_F_NOFAMILY = 1, 2, 4, 8, 16, 32
 
 
 class McError(RuntimeError):

@@ -31,8 +31,15 @@
 
 namespace mc {
 
-static thread_local std::string g_last_error;
-static void set_error(const std::string &s) { g_last_error = s; }
+// The library is built from this one source compiled several times (MC_TU = 0: C ABI + host helpers;
+// 1..5: the engine + kernels of one group of specs each), so the per-spec kernels compile in parallel.
+#ifndef MC_TU
+#define MC_TU -1  // single translation unit: everything
+#endif
+}  // namespace mc
+extern "C" void mc_set_error_internal(const char *msg);
+namespace mc {
+static void set_error(const std::string &s) { mc_set_error_internal(s.c_str()); }
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -198,7 +205,7 @@ __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t mask, uint
     return false;
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_insert(const uint64_t *__restrict__ cand, uint64_t row_stride, uint64_t ncols, const uint16_t *__restrict__ nsl,
          uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, DevCounters *ctr) {
     const unsigned slot = blockIdx.y;
@@ -330,7 +337,7 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         const unsigned ps = S::parent_status(prm, loc, s);  // specs that check invariants per expanded state
         if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
     }
-    const int wns = (int)wave_max_u32((unsigned)ns);
+    const int wns = (flags & 64u) ? 0 : (int)wave_max_u32((unsigned)ns);  // 64 = ablation: load the parents only
     unsigned gen = 0, err = 0, probes = 0;
     unsigned qhead = 0, qn = 0, ohead = 0, on = 0;  // wave-uniform ring state
     const unsigned shard = blockIdx.x & (NSHARD - 1);
@@ -431,6 +438,252 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     }
 }
 
+
+// ------------------------------------------------------------------------------------- expand BY ACTION FAMILY
+// For specs with many action kinds (raft: 13 families).  In k_expand_insert every slot body runs for the
+// whole wavefront as soon as ONE lane is enabled — about a quarter of the lanes do useful work, and the
+// Receive slot executes every message handler in turn.  Here the work is re-bucketed:
+//   phase A  lane = parent: cheap, exact guards only; each enabled (parent lane, slot) pair is appended to the
+//            LDS ring queue of its action family;
+//   phase B  as soon as a family has 64 pairs queued, the wavefront evaluates 64 pairs of THAT family — every
+//            lane busy, one code path — reading the pair's parent straight from the arena (the 64 parents of a
+//            wavefront are one arena block, so lanes reading word w of different parents hit one 512-byte row).
+// The fingerprints then go through the same probe / route queues as in k_expand_insert.
+constexpr int FQCAP = 128;
+
+template <class S>
+struct FamLds {
+    uint16_t fq[S::NFAM][FQCAP];  // (slot << 6) | parent lane
+    typename S::Summary sum[64];
+    unsigned succ[64];            // successors generated per parent (deadlock check)
+};
+
+template <class S, int F, class Fn>
+__device__ __forceinline__ void family_dispatch(int fam, Fn &&fn) {
+    if constexpr (F < S::NFAM) {
+        if (fam == F) fn(std::integral_constant<int, F>{});
+        else family_dispatch<S, F + 1>(fam, fn);
+    }
+}
+
+template <class S, bool ROUTE>
+__global__ void __launch_bounds__(256)
+k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
+                uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
+                RouteArgs rt) {
+    __shared__ WaveQueues wq[4];
+    __shared__ FamLds<S> fls[4];
+    const unsigned lane = threadIdx.x & 63;
+    WaveQueues &Q = wq[threadIdx.x >> 6];
+    FamLds<S> &FL = fls[threadIdx.x >> 6];
+    const uint64_t base = lo & ~63ull;
+    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    const uint64_t idx = base + col;
+    const uint64_t wave_idx0 = idx - lane, wave_col0 = col - lane;  // this wavefront's 64 parents = one arena block
+    const bool active = idx >= lo && idx < hi;
+    const int W = S::words(prm);
+    const CWordRef g = arena_cref(arena, idx, W);
+    typename S::Guards gd;
+    gd.fixed = 0;
+    gd.terms = 0;
+    int nm = 0;
+    unsigned long long viol = ~0ull;
+    if (active) {
+        typename S::Local loc;
+        S::load(prm, g, loc);
+        nm = loc.nm;
+        S::guards(prm, loc, gd);
+        typename S::Summary q;
+        S::summarize(loc, q);
+        FL.sum[lane] = q;
+        const unsigned ps = S::parent_status(prm, loc, g);
+        if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
+    }
+    FL.succ[lane] = 0;
+    wave_lds_fence();
+    const int wnm = (int)wave_max_u32((unsigned)nm);
+    unsigned gen = 0, err = 0, probes = 0;
+    unsigned qhead = 0, qn = 0, ohead = 0, on = 0;  // wave-uniform ring state of the probe / survivor queues
+    // ring state of the family queues, wave-uniform, packed 8 bits per family so that a run-time family index is a
+    // scalar shift (no LDS round trip): heads and counts of families 0..7 in *A, 8.. in *B
+    uint64_t fheadA = 0, fheadB = 0, fcntA = 0, fcntB = 0;
+    auto fget = [](uint64_t a, uint64_t b, int f) -> unsigned { return (unsigned)((f < 8 ? a >> (8 * f) : b >> (8 * (f - 8))) & 255u); };
+    auto fset = [](uint64_t &a, uint64_t &b, int f, unsigned v) {
+        if (f < 8) a = (a & ~(255ull << (8 * f))) | ((uint64_t)v << (8 * f));
+        else b = (b & ~(255ull << (8 * (f - 8)))) | ((uint64_t)v << (8 * (f - 8)));
+    };
+    const unsigned shard = blockIdx.x & (NSHARD - 1);
+    uint32_t *__restrict__ seg = newlist + (uint64_t)shard * seg_cap;
+
+    auto flush_out = [&](unsigned take) {
+        unsigned long long pos = 0;
+        if (lane == 0) pos = atomicAdd(&ctr->n_new[shard].v, (unsigned long long)take);
+        pos = __shfl(pos, 0);
+        if (lane < take) seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
+        ohead = (ohead + take) & (QCAP - 1);
+        on -= take;
+    };
+    auto flush_probe = [&](unsigned take) {
+        bool is_new = false;
+        uint32_t src = 0;
+        uint64_t qfp = 0;
+        if (lane < take) {
+            const unsigned k = (qhead + lane) & (QCAP - 1);
+            src = Q.q_src[k];
+            qfp = Q.q_fp[k];
+            if constexpr (!ROUTE) is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);
+        }
+        qhead = (qhead + take) & (QCAP - 1);
+        qn -= take;
+        probes += take;
+        if constexpr (ROUTE) {
+            const unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
+            for (unsigned t = 0; t < rt.nranks; ++t) {
+                const unsigned long long b = __ballot(owner == t);
+                if (!b) continue;
+                const unsigned bucket = t * NSHARD + shard;
+                unsigned long long pos = 0;
+                if (lane == 0) pos = atomicAdd(&rt.cursors[bucket].v, (unsigned long long)__popcll(b));
+                pos = __shfl(pos, 0) + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+                if (owner == t) {
+                    if (pos < rt.subcap) {
+                        rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
+                        rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = src;
+                    } else {
+                        err |= DEV_EARENA;
+                    }
+                }
+            }
+        } else {
+            const unsigned long long b = __ballot(is_new);
+            if (is_new) Q.o_src[(ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1)] = src;
+            on += (unsigned)__popcll(b);
+            wave_lds_fence();
+            if (on >= 64) flush_out(64);
+        }
+    };
+    // append the lanes of `b` (each with its slot) to family f's queue; returns true when it holds >= 64 pairs
+    auto fam_push = [&](int f, unsigned long long b, bool mine, int slot) -> bool {
+        const unsigned h = fget(fheadA, fheadB, f), c = fget(fcntA, fcntB, f);
+        if (mine) FL.fq[f][(h + c + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (FQCAP - 1)] = (uint16_t)(((unsigned)slot << 6) | lane);
+        const unsigned nc = c + (unsigned)__popcll(b);
+        fset(fcntA, fcntB, f, nc);
+        return nc >= 64;
+    };
+    // phase B: evaluate `take` queued pairs of family f (f is wave-uniform)
+    auto run_family = [&](int f, unsigned take) {
+        const unsigned h = fget(fheadA, fheadB, f);
+        wave_lds_fence();  // queue entries written by fam_push are visible
+        uint64_t fp = 0;
+        uint32_t src = 0;
+        if (lane < take) {
+            const unsigned e = FL.fq[f][(h + lane) & (FQCAP - 1)];
+            const unsigned p = e & 63u;
+            const int slot = (int)(e >> 6);
+            const uint64_t pidx = wave_idx0 + p;
+            const typename S::Summary q = FL.sum[p];
+            const CWordRef sp = arena_cref(arena, pidx, W);
+            unsigned st = 0;
+            uint64_t fv = 0;
+            family_dispatch<S, 0>(f, [&](auto fc) { st = S::template eval_pair<decltype(fc)::value>(prm, q, sp, slot, fv); });
+            if (st & ST_ENABLED) {
+                ++gen;
+                if (flags & MC_F_DEADLOCK) atomicAdd(&FL.succ[p], 1u);
+                if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
+                else if (st & ST_ASSERT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_ASSERT, 0));
+                else if (st & ST_SPECERR) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_SPECERR, 0));
+                else {
+                    if (st & ST_INVARIANT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_INVARIANT, st >> 8));
+                    if (!(st & ST_OUT_OF_MODEL)) { fp = fv; src = (uint32_t)(wave_col0 + p) | ((uint32_t)slot << 24); }
+                }
+            }
+        }
+        fset(fheadA, fheadB, f, (h + take) & (FQCAP - 1));
+        fset(fcntA, fcntB, f, fget(fcntA, fcntB, f) - take);
+        const unsigned long long b = __ballot(fp != 0);
+        if (b) {
+            if (fp) {
+                const unsigned k = (qhead + qn + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
+                Q.q_fp[k] = fp;
+                Q.q_src[k] = src;
+            }
+            qn += (unsigned)__popcll(b);
+            wave_lds_fence();
+            if (qn >= 64) flush_probe(64);
+        }
+        wave_lds_fence();
+    };
+
+    // one loop over "steps": fixed slots, then (message, kind) slots, then a final drain of every queue;
+    // the family dispatch below is the single place phase-B code is instantiated
+    const int nsteps = (flags & 64u) ? 1 : S::FIX + 3 * wnm + 1;  // 64 = ablation: load the parents only
+    for (int step = 0; step < nsteps; ++step) {
+        unsigned fullmask = 0;
+        bool drain = false;
+        if (step < S::FIX) {
+            const int f = S::fixed_family(step);
+            const bool en = (gd.fixed >> step) & 1ull;
+            const unsigned long long b = __ballot(en);
+            if (b && fam_push(f, b, en, step)) fullmask = 1u << f;
+        } else if (step < nsteps - 1) {
+            const int q = step - S::FIX, k = q / 3, kind = q % 3;
+            int fam = -1;
+            if (k < nm) fam = S::guard_msg(gd, g.get(S::W_MSG0 + k), kind);
+            if (kind == 0) {  // Receive: the family depends on the message (UpdateTerm or one of the four handlers)
+#pragma unroll
+                for (int f = S::F_UPDTERM; f <= S::F_AERESP; ++f) {
+                    const unsigned long long b = __ballot(fam == f);
+                    if (b && fam_push(f, b, fam == f, step)) fullmask |= 1u << f;
+                }
+            } else {
+                const unsigned long long b = __ballot(fam >= 0);
+                if (b && fam_push(S::F_DUPDROP, b, fam >= 0, step)) fullmask |= 1u << S::F_DUPDROP;
+            }
+        } else {
+            drain = true;
+#pragma unroll
+            for (int f = 0; f < S::NFAM; ++f) if (fget(fcntA, fcntB, f)) fullmask |= 1u << f;
+        }
+        while (fullmask) {
+            const int f = __ffs((int)fullmask) - 1;
+            const unsigned c = fget(fcntA, fcntB, f);
+            run_family(f, drain ? (c < 64 ? c : 64u) : 64u);
+            if (fget(fcntA, fcntB, f) < (drain ? 1u : 64u)) fullmask &= ~(1u << f);
+        }
+    }
+    if (qn) flush_probe(qn);
+    if (on) flush_out(on);
+
+    if (active && (flags & MC_F_DEADLOCK) && FL.succ[lane] == 0) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
+    const unsigned gsum = wave_sum_u32(gen);
+    const unsigned long long vmin = wave_min_u64(viol);
+    const unsigned eor = wave_or_u32(err);
+    if (lane == 0) {
+        if (gsum) atomicAdd(&ctr->generated[shard].v, (unsigned long long)gsum);
+        if (probes) atomicAdd(&ctr->cells[shard].v, (unsigned long long)probes);
+        if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
+        if (eor) atomicOr(&ctr->error, eor);
+    }
+}
+
+// specs that define action families (S::NFAM) are expanded by family, the others slot by slot
+template <class S, class = void>
+struct UsesFamilies : std::false_type {};
+template <class S>
+struct UsesFamilies<S, decltype((void)S::NFAM)> : std::true_type {};
+
+template <class S, bool ROUTE, class... A>
+static void launch_expand(bool by_family, dim3 grid, hipStream_t stream, A... args) {
+    if constexpr (UsesFamilies<S>::value) {
+        if (by_family) {
+            hipLaunchKernelGGL((k_expand_family<S, ROUTE>), grid, dim3(256), 0, stream, args...);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_expand_insert<S, ROUTE>), grid, dim3(256), 0, stream, args...);
+}
+
 // ------------------------------------------------------------------------------------- materialise
 template <class S>
 __global__ void __launch_bounds__(256)
@@ -470,7 +723,7 @@ k_init_materialise(typename S::Params prm, uint64_t *arena, uint64_t first, cons
     }
 }
 // arena (blocked, word-major) -> plain records, for read-back and for the exchange buffers
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_gather_states(const uint64_t *__restrict__ arena, int words, uint64_t first, uint64_t count, uint64_t *__restrict__ out) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count * (uint64_t)words) return;
@@ -480,7 +733,7 @@ k_gather_states(const uint64_t *__restrict__ arena, int words, uint64_t first, u
 
 // ------------------------------------------------------------------------------------- sharded step kernels
 // sub-buckets [owner][shard] -> one contiguous range per owner (order inside an owner: by shard)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_compact_buckets(RouteArgs rt, uint64_t *__restrict__ send_fp, uint32_t *__restrict__ pend_src) {
     const unsigned bucket = blockIdx.y;  // owner * NSHARD + shard
     const uint64_t n = rt.cursors[bucket].v < rt.subcap ? rt.cursors[bucket].v : rt.subcap;
@@ -493,7 +746,7 @@ k_compact_buckets(RouteArgs rt, uint64_t *__restrict__ send_fp, uint32_t *__rest
     }
 }
 // owner side: insert received fingerprints, answer 1 = new
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_probe(const uint64_t *__restrict__ fps, uint64_t n, uint64_t *table, uint64_t mask, uint8_t *__restrict__ answers, DevCounters *ctr) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned err = 0;
@@ -519,12 +772,12 @@ __device__ __forceinline__ unsigned owner_of_index(const OwnerOffsets &o, unsign
 struct AnswerCast {
     __host__ __device__ uint32_t operator()(const uint8_t &a) const { return a ? 1u : 0u; }
 };
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_gather_range_ends(const uint32_t *__restrict__ incl, OwnerOffsets offs, unsigned nranks, unsigned long long *__restrict__ ends) {
     const unsigned t = threadIdx.x;
     if (t < nranks) ends[t] = offs.off[t + 1] ? incl[offs.off[t + 1] - 1] : 0;
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_compact_new(const uint8_t *__restrict__ answers, const uint32_t *__restrict__ incl, const uint32_t *__restrict__ pend_src,
               uint64_t total, OwnerOffsets offs, OwnerOffsets start, unsigned nranks, uint32_t *__restrict__ new_src) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -572,7 +825,7 @@ k_materialise_list(typename S::Params prm, uint64_t *arena, uint64_t chunk_base,
     if (parent) { parent[oidx] = (uint32_t)pidx; pslot[oidx] = (uint16_t)(src >> 24); }
 }
 // owner side: append the `n` states of one received bucket (blocked layout) to the arena
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv_blocks, uint64_t n, uint64_t out0, uint64_t arena_cap,
          uint32_t *__restrict__ parent, DevCounters *ctr) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -584,8 +837,8 @@ k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv_blocks, u
     for (int w = 0; w < words; w++) o.set(w, src[(uint64_t)w * 64]);
     if (parent) parent[oidx] = 0xfffffffeu;  // produced on another rank: no local parent
 }
-__global__ void k_set_arena_next(DevCounters *ctr, unsigned long long v) { ctr->arena_next = v; }
-__global__ void k_commit(DevCounters *ctr) {
+static __global__ void k_set_arena_next(DevCounters *ctr, unsigned long long v) { ctr->arena_next = v; }
+static __global__ void k_commit(DevCounters *ctr) {
     unsigned long long n = 0;
     for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; }
     ctr->arena_next += n;
@@ -819,9 +1072,9 @@ struct Engine : EngineBase {
                     finish_chunk<false>(base, ncols, max_slots);
                 } else {
                     timed(0, c1 - c0, [&] {
-                        hipLaunchKernelGGL((k_expand_insert<S, false>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm,
-                                           d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags,
-                                           RouteArgs{});
+                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
+                                                (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
+                                                cfg.flags, RouteArgs{});
                     });
                     finish_materialise(base, ncols);
                 }
@@ -960,8 +1213,9 @@ struct Engine : EngineBase {
         for (uint64_t c0 = 0; c0 < last_distinct; c0 += chunk) {
             const uint64_t c1 = c0 + chunk < last_distinct ? c0 + chunk : last_distinct;
             const uint64_t ncols = ((c1 - c0) + 63) & ~63ull;
-            hipLaunchKernelGGL((k_expand_insert<S, false>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0,
-                               c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags | extra_flags, RouteArgs{});
+            launch_expand<S, false>(!((cfg.flags | extra_flags) & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
+                                    (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
+                                    cfg.flags | extra_flags, RouteArgs{});
             hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
         }
         HIP_TRY(hipEventRecord(b, stream));
@@ -1042,8 +1296,8 @@ struct Engine : EngineBase {
         sh_chunk_base = base;
         RouteArgs rt{P, d_rt_cur, d_rt_fp, d_rt_src, rt_subcap};
         timed(0, count, [&] {
-            hipLaunchKernelGGL((k_expand_insert<S, true>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0,
-                               c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt);
+            launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
+                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt);
         });
         std::vector<PaddedCounter> cur(P * NSHARD);
         HIP_TRY(hipMemcpyAsync(cur.data(), d_rt_cur, cur.size() * sizeof(PaddedCounter), hipMemcpyDeviceToHost, stream));
@@ -1208,6 +1462,74 @@ struct Engine : EngineBase {
 
 }  // namespace mc
 
+// --------------------------------------------------------------------------------------- engine factories
+// group 1: atomic_add + pcal_intro, 2: raft (2 servers), 3: raft (3), 4: raft (5), 5: serializableSnapshotIsolation
+namespace mc {
+static int spec_group(const mc_spec_desc *d) {
+    if (!d) return 0;
+    switch (d->spec_id) {
+    case MC_SPEC_ATOMIC_ADD: case MC_SPEC_PCAL_INTRO: return 1;
+    case MC_SPEC_RAFT: return d->nparams < 1 ? 0 : d->params[0] == 2 ? 2 : d->params[0] == 3 ? 3 : d->params[0] == 5 ? 4 : 0;
+    case MC_SPEC_SSI: return 5;
+    default: return 0;
+    }
+}
+template <class S>
+static int make_engine(const typename S::Params &prm, const mc_spec_desc *spec, const mc_config *cfg, EngineBase **out) {
+    auto *e = new Engine<S>();
+    e->prm = prm;
+    e->desc = *spec;
+    e->cfg = *cfg;
+    const int r = e->alloc();
+    if (r) { delete e; return r; }
+    *out = e;
+    return MC_OK;
+}
+}  // namespace mc
+extern "C" {
+int mc_make_engine_1(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
+int mc_make_engine_2(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
+int mc_make_engine_3(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
+int mc_make_engine_4(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
+int mc_make_engine_5(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
+#if MC_TU == 1 || MC_TU == -1
+int mc_make_engine_1(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {
+    if (d->spec_id == MC_SPEC_ATOMIC_ADD) {
+        mc::SpecAtomicAdd::Params p;
+        if (mc::SpecAtomicAdd::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+        return mc::make_engine<mc::SpecAtomicAdd>(p, d, c, out);
+    }
+    mc::SpecPcalIntro::Params p;
+    if (mc::SpecPcalIntro::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+    return mc::make_engine<mc::SpecPcalIntro>(p, d, c, out);
+}
+#endif
+#define MC_RAFT_FACTORY(K, SPEC)                                                                   \
+    int mc_make_engine_##K(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {      \
+        mc::RaftParams p;                                                                          \
+        if (mc::SPEC::make_params(d->params, d->nparams, p)) return MC_EBADCFG;                    \
+        return mc::make_engine<mc::SPEC>(p, d, c, out);                                            \
+    }
+#if MC_TU == 2 || MC_TU == -1
+MC_RAFT_FACTORY(2, SpecRaft2)
+#endif
+#if MC_TU == 3 || MC_TU == -1
+MC_RAFT_FACTORY(3, SpecRaft3)
+#endif
+#if MC_TU == 4 || MC_TU == -1
+MC_RAFT_FACTORY(4, SpecRaft5)
+#endif
+#if MC_TU == 5 || MC_TU == -1
+int mc_make_engine_5(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {
+    mc::SsiParams p;
+    if (mc::SpecSsi::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+    return mc::make_engine<mc::SpecSsi>(p, d, c, out);
+}
+#endif
+}  // extern "C"
+
+#if MC_TU == 0 || MC_TU == -1
+static thread_local std::string g_last_error;
 // --------------------------------------------------------------------------------------- C ABI
 using namespace mc;
 
@@ -1227,18 +1549,20 @@ int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine *
     if (!spec || !cfg || !out) return MC_EBADCFG;
     *out = nullptr;
     if (mc_device_count() <= 0) { set_error("no HIP device: libtlamc has no CPU fallback"); return MC_EHIP; }
-    int rc = dispatch_spec(spec, [&](auto s, const auto &prm) -> int {
-        using S = decltype(s);
-        auto *e = new Engine<S>();
-        e->prm = prm;
-        e->desc = *spec;
-        e->cfg = *cfg;
-        int r = e->alloc();
-        if (r) { delete e; return r; }
-        *out = new mc_engine{e};
-        return MC_OK;
-    });
-    if (rc == MC_EBADCFG && g_last_error.empty()) set_error("unknown spec id or constants out of range");
+    g_last_error.clear();
+    EngineBase *impl = nullptr;
+    const int group = spec_group(spec);
+    int rc = MC_EBADCFG;
+    switch (group) {
+    case 1: rc = mc_make_engine_1(spec, cfg, &impl); break;
+    case 2: rc = mc_make_engine_2(spec, cfg, &impl); break;
+    case 3: rc = mc_make_engine_3(spec, cfg, &impl); break;
+    case 4: rc = mc_make_engine_4(spec, cfg, &impl); break;
+    case 5: rc = mc_make_engine_5(spec, cfg, &impl); break;
+    default: break;
+    }
+    if (rc == MC_OK) *out = new mc_engine{impl};
+    else if (rc == MC_EBADCFG && g_last_error.empty()) set_error("unknown spec id or constants out of range");
     return rc;
 }
 int mc_engine_run(mc_engine *e, mc_result *out) { return e && out ? e->impl->run(out) : MC_EBADCFG; }
@@ -1295,7 +1619,7 @@ const char *mc_strerror(int code) {
     }
 }
 const char *mc_last_error(void) { return g_last_error.c_str(); }
-void mc_set_error_internal(const char *msg) { set_error(msg ? msg : ""); }
+void mc_set_error_internal(const char *msg) { g_last_error = msg ? msg : ""; }
 
 
 int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms) { return e && ms ? e->impl->debug_reexpand(extra_flags, ms) : MC_EBADCFG; }
@@ -1319,3 +1643,4 @@ int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_loca
 }
 
 }  // extern "C"
+#endif  // MC_TU == 0 || MC_TU == -1

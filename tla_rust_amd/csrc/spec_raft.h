@@ -219,11 +219,15 @@ struct SpecRaft {
     template <class Ref>
     MC_HD static unsigned init_status(const Params &, Ref) { return ST_ENABLED; }
 
+    // 6-bit bucket of a message key, for the per-parent presence filter that lets Send skip its scan
+    MC_HD static unsigned key_bucket(uint64_t word) { return (unsigned)(((word >> 2) * 0x9e3779b97f4a7c15ull) >> 58); }
+
     // ---------------------------------------------------------------- per-parent cache
     struct Local {
         uint64_t fp, glob, clog;
         RegArr<NS> sv, log;
         int nm, inflight;
+        uint64_t mfilter;      // bit key_bucket(m) set for every message key in the bag: a clear bit proves "not present"
         unsigned addmask;      // servers whose log is not yet in allLogs (raft.tla:493), first occurrence only
         int nadd;              // popcount(addmask)
         uint64_t add_fp;       // sum of their contributions
@@ -241,7 +245,12 @@ struct SpecRaft {
         for (int i = 0; i < NS; i++) { l.sv.set(i, s.get(W_SRV(i))); l.log.set(i, s.get(W_LOG(i))); }
         l.nm = g_nm(l.glob);
         l.inflight = 0;
-        for (int k = 0; k < l.nm; k++) l.inflight += m_count(s.get(W_MSG0 + k));
+        l.mfilter = 0;
+        for (int k = 0; k < l.nm; k++) {
+            const uint64_t x = s.get(W_MSG0 + k);
+            l.inflight += m_count(x);
+            l.mfilter |= 1ull << key_bucket(x);
+        }
         // allLogs' = allLogs \cup {log[i] : i \in Server} — the same for every successor of this state
         unsigned present = 0;
         const int na = g_na(l.glob);
@@ -294,9 +303,11 @@ struct SpecRaft {
     MC_HD static unsigned send(const Local &l, Ref s, int cm, uint64_t key_word /*count bits zero*/, Delta &d) {
         int idx = l.nm;
         uint64_t old = 0;
-        for (int k = 0; k < l.nm; k++) {
-            const uint64_t x = s.get(W_MSG0 + k);
-            if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; }
+        if (l.mfilter >> key_bucket(key_word) & 1ull) {  // possibly present: scan the bag
+            for (int k = 0; k < l.nm; k++) {
+                const uint64_t x = s.get(W_MSG0 + k);
+                if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; }
+            }
         }
         // op A; the discard of a Reply is op B (response key /= request key, so the slots differ)
         d.nmop |= 1;
@@ -334,20 +345,27 @@ struct SpecRaft {
     template <bool MEM, class Ref>
     MC_HD static uint64_t log_word(const Local &l, Ref s, int i) { if (MEM) return s.get(W_LOG(i)); return l.log.get(i); }
 
-    template <bool MEM = false, class Ref>
+    // Action FAMILIES: the expand-by-family kernel buckets enabled (state, slot) pairs per family in
+    // LDS and evaluates 64 pairs of ONE family at a time, so the successor construction below runs
+    // with every lane busy and without divergence between action types.  FAM < 0 = any family.
+    enum : int { F_RESTART, F_TIMEOUT, F_REQVOTE, F_BECOME, F_CLIENT, F_ADVANCE, F_APPEND,
+                 F_UPDTERM, F_RVREQ, F_RVRESP, F_AEREQ, F_AERESP, F_DUPDROP, NFAM };
+#define MC_FAM(f) (FAM < 0 || FAM == (f))
+
+    template <bool MEM = false, int FAM = -1, class Ref>
     MC_HD static unsigned compute(const Params &prm, const Local &l, Ref s, int slot, Delta &d, int &action) {
         d.glob = l.glob; d.clog = l.clog; d.srv = -1; d.sv = d.osv = 0; d.log = d.olog = 0; d.pre = true; d.vmode = 0; d.vj = 0; d.vlog = 0;
         d.nmop = 0; d.midxA = d.midxB = -1; d.moldA = d.mnewA = d.moldB = d.mnewB = 0;
         d.eadd = false; d.dinflight = 0;
         d.ew = RegArr<EL_WORDS>();
         unsigned st = ST_ENABLED;
-        if (slot < NS) {  // Restart(i)   raft.tla:186-194 (always enabled)
+        if (MC_FAM(F_RESTART) && slot < NS) {  // Restart(i)   raft.tla:186-194 (always enabled)
             const int i = slot;
             action = RA_RESTART;
             d.srv = i; d.osv = srv_word<MEM>(l, s, i); d.olog = d.log = log_word<MEM>(l, s, i);
             d.sv = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(d.osv, R_FOLLOWER), 0), 0), 1);
             d.vmode = 1;
-        } else if (slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
+        } else if (MC_FAM(F_TIMEOUT) && slot >= NS && slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
             const int i = slot - NS;
             action = RA_TIMEOUT;
             const uint64_t svi = srv_word<MEM>(l, s, i);
@@ -358,13 +376,13 @@ struct SpecRaft {
             d.srv = i; d.osv = svi; d.olog = d.log = log_word<MEM>(l, s, i);
             d.sv = sv_set_granted(sv_set_voted(sv_set_term(sv_set_state(svi, R_CANDIDATE), nt & 7), 0), 0);
             d.vmode = 1;
-        } else if (slot < 2 * NS + NS * NS) {  // RequestVote(i, j)   raft.tla:209-217
+        } else if (MC_FAM(F_REQVOTE) && slot >= 2 * NS && slot < 2 * NS + NS * NS) {  // RequestVote(i, j)   raft.tla:209-217
             const int q = slot - 2 * NS, i = q / NS, j = q % NS;
             action = RA_REQUESTVOTE;
             const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_CANDIDATE) return 0;
             st |= send(l, s, prm.cm, mk_rvreq(sv_term(svi), rlog::last_term(lgi), rlog::len(lgi), i, j), d);
-        } else if (slot < 3 * NS + NS * NS) {  // BecomeLeader(i)   raft.tla:247-261
+        } else if (MC_FAM(F_BECOME) && slot >= 2 * NS + NS * NS && slot < 3 * NS + NS * NS) {  // BecomeLeader(i)   raft.tla:247-261
             const int i = slot - (2 * NS + NS * NS);
             action = RA_BECOMELEADER;
             const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
@@ -389,7 +407,7 @@ struct SpecRaft {
                 if (ne >= prm.ce) st |= ST_OVERFLOW;
                 d.glob += 1ull << 16;
             }
-        } else if (slot < 4 * NS + NS * NS) {  // ClientRequest(i)   raft.tla:264-274
+        } else if (MC_FAM(F_CLIENT) && slot >= 3 * NS + NS * NS && slot < 4 * NS + NS * NS) {  // ClientRequest(i)   raft.tla:264-274
             const int i = slot - (3 * NS + NS * NS);
             action = RA_CLIENTREQUEST;
             const int creq = g_creq(l.glob);
@@ -400,7 +418,7 @@ struct SpecRaft {
             d.log = rlog::append(lgi, rlog::mk_entry(sv_term(svi), creq));
             d.glob += 1;  // clientRequests' = clientRequests + 1
             if (rlog::len(d.log) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
-        } else if (slot < 5 * NS + NS * NS) {  // AdvanceCommitIndex(i)   raft.tla:280-305
+        } else if (MC_FAM(F_ADVANCE) && slot >= 4 * NS + NS * NS && slot < 5 * NS + NS * NS) {  // AdvanceCommitIndex(i)   raft.tla:280-305
             const int i = slot - (4 * NS + NS * NS);
             action = RA_ADVANCECOMMIT;
             const uint64_t svi = srv_word<MEM>(l, s, i), lg = log_word<MEM>(l, s, i);
@@ -424,7 +442,7 @@ struct SpecRaft {
             d.srv = i; d.osv = svi; d.olog = d.log = lg; d.sv = sv_set_commit(svi, nci);
             d.clog = ncl;
             d.glob = bits_set(d.glob, 3, 1, decr ? 1 : 0);
-        } else if (slot < FIX) {  // AppendEntries(i, j)   raft.tla:222-244
+        } else if (MC_FAM(F_APPEND) && slot >= 5 * NS + NS * NS && slot < FIX) {  // AppendEntries(i, j)   raft.tla:222-244
             const int q = slot - (5 * NS + NS * NS), i = q / NS, j = q % NS;
             action = RA_APPENDENTRIES;
             const uint64_t svi = srv_word<MEM>(l, s, i), lg = log_word<MEM>(l, s, i);
@@ -440,20 +458,20 @@ struct SpecRaft {
             const unsigned ent = nent ? rlog::entry(lg, next) : 0u;
             const int ci = sv_commit(svi) < lastEntry ? sv_commit(svi) : lastEntry;
             st |= send(l, s, prm.cm, mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j), d);
-        } else {
+        } else if (slot >= FIX && (FAM < 0 || FAM >= F_UPDTERM)) {
             const int q = slot - FIX, k = q / 3, kind = q % 3;
             if (k >= l.nm) return 0;
             const uint64_t m = s.get(W_MSG0 + k);
             const int cnt = m_count(m);
-            if (kind == 1) {  // DuplicateMessage(m), m \in SingleMessage(messages)   raft.tla:134-135,471-473
+            if (MC_FAM(F_DUPDROP) && kind == 1) {  // DuplicateMessage(m), m \in SingleMessage(messages)   raft.tla:134-135,471-473
                 action = RA_DUPLICATE;
                 if (cnt != 1) return 0;
                 d.nmop = 2; d.midxB = k; d.moldB = m; d.mnewB = m + 1; d.dinflight = 1;
-            } else if (kind == 2) {  // DropMessage(m), m \in ValidMessage(messages)   raft.tla:131-132,476-478
+            } else if (MC_FAM(F_DUPDROP) && kind == 2) {  // DropMessage(m), m \in ValidMessage(messages)   raft.tla:131-132,476-478
                 action = RA_DROP;
                 if (cnt == 0) return 0;
                 discard(k, m, d);
-            } else {  // Receive(m), m \in ValidMessage(messages)   raft.tla:449-464
+            } else if (kind == 0 && (FAM < 0 || (FAM >= F_UPDTERM && FAM <= F_AERESP))) {  // Receive(m), m \in ValidMessage(messages)   raft.tla:449-464
                 action = RA_RECEIVE;
                 if (cnt == 0) return 0;
                 const int i = m_dst(m), j = m_src(m), mterm = m_term(m), type = m_type(m);
@@ -462,17 +480,17 @@ struct SpecRaft {
                 const uint64_t svi = s.get(W_SRV(i)), lg = s.get(W_LOG(i));
                 const int term = sv_term(svi);
                 d.srv = i; d.osv = d.sv = svi; d.olog = d.log = lg; d.pre = false;
-                if (mterm > term) {  // UpdateTerm   raft.tla:434-440 (message not consumed)
+                if (MC_FAM(F_UPDTERM) && mterm > term) {  // UpdateTerm   raft.tla:434-440 (message not consumed)
                     d.sv = sv_set_voted(sv_set_state(sv_set_term(svi, mterm), R_FOLLOWER), 0);
                     if (mterm > prm.max_term) st |= ST_OUT_OF_MODEL;
-                } else if (type == M_RVREQ) {  // HandleRequestVoteRequest   raft.tla:313-332
+                } else if (MC_FAM(F_RVREQ) && mterm <= term && type == M_RVREQ) {  // HandleRequestVoteRequest   raft.tla:313-332
                     const int llt = (int)(m >> 13 & 7), lli = (int)(m >> 16 & 7), lt = rlog::last_term(lg);
                     const bool logOk = llt > lt || (llt == lt && lli >= rlog::len(lg));
                     const bool grant = mterm == term && logOk && (sv_voted(svi) == 0 || sv_voted(svi) == j + 1);
                     if (grant) d.sv = sv_set_voted(svi, j + 1);
                     st |= send(l, s, prm.cm, mk_rvresp(term, grant ? 1 : 0, lg, i, j), d);  // Reply(response, m)
                     discard(k, m, d);
-                } else if (type == M_RVRESP) {
+                } else if (MC_FAM(F_RVRESP) && mterm <= term && type == M_RVRESP) {
                     if (mterm == term) {  // HandleRequestVoteResponse   raft.tla:336-349
                         if (m >> 13 & 1) {
                             const unsigned vg = sv_granted(svi);
@@ -483,7 +501,7 @@ struct SpecRaft {
                         }
                     }  // else DropStaleResponse   raft.tla:443-446
                     discard(k, m, d);
-                } else if (type == M_AEREQ) {  // HandleAppendEntriesRequest   raft.tla:355-417
+                } else if (MC_FAM(F_AEREQ) && mterm <= term && type == M_AEREQ) {  // HandleAppendEntriesRequest   raft.tla:355-417
                     const int pidx = (int)(m >> 13 & 7), pterm = (int)(m >> 16 & 7), nent = (int)(m >> 19 & 1);
                     const unsigned ent = (unsigned)(m >> 20 & 63);
                     const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg);
@@ -512,7 +530,7 @@ struct SpecRaft {
                     } else {
                         return 0;  // e.g. a Leader receiving AppendEntries of its own term
                     }
-                } else {  // AppendEntriesResponse
+                } else if (MC_FAM(F_AERESP) && mterm <= term && type == M_AERESP) {  // AppendEntriesResponse
                     if (mterm == term) {  // HandleAppendEntriesResponse   raft.tla:421-431
                         if (m >> 13 & 1) {
                             const int mi = (int)(m >> 14 & 7);
@@ -523,8 +541,14 @@ struct SpecRaft {
                         }
                     }  // else DropStaleResponse
                     discard(k, m, d);
+                } else {
+                    return 0;  // a pair queued for another family (cannot happen: guard_msg is exact)
                 }
+            } else {
+                return 0;
             }
+        } else {
+            return 0;
         }
         // bookkeeping shared by every action: counts in the globals word
         if ((d.nmop & 1) && d.midxA >= l.nm) d.glob += 1ull << 8;
@@ -537,9 +561,79 @@ struct SpecRaft {
         if ((prm.inv_mask & 1) && d.srv >= 0 && sv_state(d.sv) == R_LEADER) {  // NoTwoLeaders   raft.tla:500-507
 #pragma unroll
             for (int j = 0; j < NS; j++)
-                if (j != d.srv && sv_state(l.sv.get(j)) == R_LEADER && sv_term(l.sv.get(j)) == sv_term(d.sv)) st |= ST_INVARIANT;
+                if (j != d.srv && sv_state(srv_word<MEM>(l, s, j)) == R_LEADER && sv_term(srv_word<MEM>(l, s, j)) == sv_term(d.sv)) st |= ST_INVARIANT;
         }
         if ((prm.inv_mask & 2) && !(st & ST_INVARIANT) && g_decr(d.glob)) st |= ST_INVARIANT | (1u << 8);  // CommittedLogStable
+        return st;
+    }
+
+    // ---------------------------------------------------------------- expand-by-family interface
+    // guards: cheap and EXACT as to the family (compute<MEM, FAM> still decides whether the action is enabled)
+    struct Guards {
+        uint64_t fixed;   // bit s: fixed slot s (< FIX) may be enabled
+        uint32_t terms;   // 3 bits per server: currentTerm (for UpdateTerm vs handler dispatch)
+    };
+    MC_HD static int fixed_family(int slot) {
+        return slot < NS ? F_RESTART : slot < 2 * NS ? F_TIMEOUT : slot < 2 * NS + NS * NS ? F_REQVOTE
+             : slot < 3 * NS + NS * NS ? F_BECOME : slot < 4 * NS + NS * NS ? F_CLIENT : slot < 5 * NS + NS * NS ? F_ADVANCE : F_APPEND;
+    }
+    MC_HD static void guards(const Params &prm, const Local &l, Guards &g) {
+        g.fixed = 0;
+        g.terms = 0;
+        const int creq = g_creq(l.glob);
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const uint64_t sv = l.sv.get(i);
+            const int st = sv_state(sv);
+            g.terms |= (uint32_t)sv_term(sv) << (3 * i);
+            g.fixed |= 1ull << i;                                                               // Restart(i)
+            if (st == R_FOLLOWER || st == R_CANDIDATE) g.fixed |= 1ull << (NS + i);              // Timeout(i)
+            if (st == R_CANDIDATE) {
+#pragma unroll
+                for (int j = 0; j < NS; j++) g.fixed |= 1ull << (2 * NS + i * NS + j);           // RequestVote(i, j)
+                if (in_quorum(sv_granted(sv))) g.fixed |= 1ull << (2 * NS + NS * NS + i);        // BecomeLeader(i)
+            }
+            if (st == R_LEADER) {
+                if (creq < prm.max_client_requests) g.fixed |= 1ull << (3 * NS + NS * NS + i);   // ClientRequest(i)
+                g.fixed |= 1ull << (4 * NS + NS * NS + i);                                       // AdvanceCommitIndex(i)
+#pragma unroll
+                for (int j = 0; j < NS; j++) if (j != i) g.fixed |= 1ull << (5 * NS + NS * NS + i * NS + j);  // AppendEntries(i, j)
+            }
+        }
+    }
+    // family of message slot (k, kind) given the message word, or -1
+    MC_HD static int guard_msg(const Guards &g, uint64_t m, int kind) {
+        const int cnt = m_count(m);
+        if (kind == 1) return cnt == 1 ? (int)F_DUPDROP : -1;
+        if (kind == 2) return cnt > 0 ? (int)F_DUPDROP : -1;
+        if (cnt == 0) return -1;
+        const int term = (int)(g.terms >> (3 * m_dst(m)) & 7u);
+        if (m_term(m) > term) return F_UPDTERM;
+        return F_RVREQ + m_type(m);  // M_RVREQ..M_AERESP in the order of the enum
+    }
+    // what a lane evaluating a pair needs to know about the pair's parent (computed once by the parent's lane)
+    struct Summary {
+        uint64_t fp, glob, clog, add_fp, mfilter;
+        uint32_t packed;  // nm[0,8) inflight[8,16) nadd[16,20) addmask[20,28)
+    };
+    MC_HD static void summarize(const Local &l, Summary &q) {
+        q.fp = l.fp; q.glob = l.glob; q.clog = l.clog; q.add_fp = l.add_fp; q.mfilter = l.mfilter;
+        q.packed = (uint32_t)l.nm | (uint32_t)l.inflight << 8 | (uint32_t)l.nadd << 16 | l.addmask << 20;
+    }
+    // evaluate one (parent, slot) pair of family FAM; the parent's words are read through `s`
+    template <int FAM, class Ref>
+    MC_HD static unsigned eval_pair(const Params &prm, const Summary &q, Ref s, int slot, uint64_t &fp) {
+        Local l;
+        l.fp = q.fp; l.glob = q.glob; l.clog = q.clog; l.add_fp = q.add_fp; l.mfilter = q.mfilter;
+        l.nm = (int)(q.packed & 255u); l.inflight = (int)(q.packed >> 8 & 255u); l.nadd = (int)(q.packed >> 16 & 15u);
+        l.addmask = q.packed >> 20 & 255u;
+        l.cache_k = -1; l.cache_hm = 0;
+        Delta d;
+        int action;
+        const unsigned st = compute<true, FAM>(prm, l, s, slot, d, action);
+        if (!(st & ST_ENABLED)) return 0;
+        if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
+        fp = fp_nonzero(delta_fp(l, s, d));
         return st;
     }
 
