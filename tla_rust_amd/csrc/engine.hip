@@ -60,7 +60,8 @@ struct alignas(128) PaddedCounter {
     unsigned long long pad[15];
 };
 struct DevCounters {
-    PaddedCounter n_new[NSHARD];      // survivors of the current chunk, per new-list segment
+    PaddedCounter n_new[2 * NSHARD];  // survivors of the chunk in flight, per new-list segment; two parities so that
+                                      // materialise(chunk c) overlaps expand(chunk c+1) on a second stream
     PaddedCounter generated[NSHARD];  // successors generated
     PaddedCounter cells[NSHARD];      // seen-set probes issued
     unsigned long long arena_next;    // next free arena index
@@ -297,7 +298,7 @@ template <class S, bool ROUTE>
 __global__ void __launch_bounds__(256)
 k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
-                RouteArgs rt) {
+                RouteArgs rt, unsigned parity) {
     __shared__ WaveQueues wq[4];
     __shared__ uint64_t stage[4][S::STAGE_WORDS > 0 ? S::STAGE_WORDS : 1][64];
     const unsigned lane = threadIdx.x & 63;
@@ -340,12 +341,12 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     const int wns = (flags & 64u) ? 0 : (int)wave_max_u32((unsigned)ns);  // 64 = ablation: load the parents only
     unsigned gen = 0, err = 0, probes = 0;
     unsigned qhead = 0, qn = 0, ohead = 0, on = 0;  // wave-uniform ring state
-    const unsigned shard = blockIdx.x & (NSHARD - 1);
-    uint32_t *__restrict__ seg = newlist + (uint64_t)shard * seg_cap;  // this shard's new-list segment
+    const unsigned shard = blockIdx.x & (NSHARD - 1), pshard = parity * NSHARD + shard;
+    uint32_t *__restrict__ seg = newlist + (uint64_t)pshard * seg_cap;  // this shard's new-list segment
 
     auto flush_out = [&](unsigned take) {  // append `take` survivors to the global new-list
         unsigned long long pos = 0;
-        if (lane == 0) pos = atomicAdd(&ctr->n_new[shard].v, (unsigned long long)take);
+        if (lane == 0) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)take);
         pos = __shfl(pos, 0);
         if (lane < take) seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
         ohead = (ohead + take) & (QCAP - 1);
@@ -470,7 +471,7 @@ template <class S, bool ROUTE>
 __global__ void __launch_bounds__(256)
 k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
-                RouteArgs rt) {
+                RouteArgs rt, unsigned parity) {
     __shared__ WaveQueues wq[4];
     __shared__ FamLds<S> fls[4];
     const unsigned lane = threadIdx.x & 63;
@@ -513,12 +514,12 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         if (f < 8) a = (a & ~(255ull << (8 * f))) | ((uint64_t)v << (8 * f));
         else b = (b & ~(255ull << (8 * (f - 8)))) | ((uint64_t)v << (8 * (f - 8)));
     };
-    const unsigned shard = blockIdx.x & (NSHARD - 1);
-    uint32_t *__restrict__ seg = newlist + (uint64_t)shard * seg_cap;
+    const unsigned shard = blockIdx.x & (NSHARD - 1), pshard = parity * NSHARD + shard;
+    uint32_t *__restrict__ seg = newlist + (uint64_t)pshard * seg_cap;
 
     auto flush_out = [&](unsigned take) {
         unsigned long long pos = 0;
-        if (lane == 0) pos = atomicAdd(&ctr->n_new[shard].v, (unsigned long long)take);
+        if (lane == 0) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)take);
         pos = __shfl(pos, 0);
         if (lane < take) seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
         ohead = (ohead + take) & (QCAP - 1);
@@ -688,12 +689,12 @@ static void launch_expand(bool by_family, dim3 grid, hipStream_t stream, A... ar
 template <class S>
 __global__ void __launch_bounds__(256)
 k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint32_t *__restrict__ newlist, uint64_t seg_cap,
-              uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr) {
+              uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr, unsigned parity) {
     const unsigned sh = blockIdx.y;  // new-list segment
-    const uint64_t n = ctr->n_new[sh].v;
+    const uint64_t n = ctr->n_new[parity * NSHARD + sh].v;
     uint64_t out0 = ctr->arena_next;
-    for (unsigned t = 0; t < sh; t++) out0 += ctr->n_new[t].v;
-    const uint32_t *__restrict__ seg = newlist + (uint64_t)sh * seg_cap;
+    for (unsigned t = 0; t < sh; t++) out0 += ctr->n_new[parity * NSHARD + t].v;
+    const uint32_t *__restrict__ seg = newlist + (uint64_t)(parity * NSHARD + sh) * seg_cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t src = seg[j];
@@ -756,7 +757,7 @@ k_probe(const uint64_t *__restrict__ fps, uint64_t n, uint64_t *table, uint64_t 
         answers[i] = is_new ? 1 : 0;
     }
     const unsigned long long b = __ballot(is_new);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&ctr->n_new[blockIdx.x & (NSHARD - 1)].v, (unsigned long long)__popcll(b));
+    (void)b;
     if (wave_or_u32(err) && (threadIdx.x & 63) == 0) atomicOr(&ctr->error, DEV_ETABLE);
 }
 // sender side: per-owner count of positive answers (owner ranges given by off[0..nranks])
@@ -838,9 +839,9 @@ k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv_blocks, u
     if (parent) parent[oidx] = 0xfffffffeu;  // produced on another rank: no local parent
 }
 static __global__ void k_set_arena_next(DevCounters *ctr, unsigned long long v) { ctr->arena_next = v; }
-static __global__ void k_commit(DevCounters *ctr) {
+static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
     unsigned long long n = 0;
-    for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; }
+    for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[parity * NSHARD + t].v; ctr->n_new[parity * NSHARD + t].v = 0; }
     ctr->arena_next += n;
     ctr->max_slots = 0;
 }
@@ -902,7 +903,8 @@ struct Engine : EngineBase {
     Params prm;
     mc_spec_desc desc;
     mc_config cfg;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;  // expand+insert on `stream`, materialise on `stream2`
+    hipEvent_t ev_e[2] = {nullptr, nullptr}, ev_m[2] = {nullptr, nullptr};
     uint64_t *d_arena = nullptr, *d_table = nullptr, *d_cand = nullptr;
     uint32_t *d_newlist = nullptr;
     uint16_t *d_nsl = nullptr, *d_pslot = nullptr;
@@ -923,6 +925,8 @@ struct Engine : EngineBase {
         use_matrix = (cfg.flags & MC_F_MATRIX) != 0;
         HIP_TRY(hipSetDevice(cfg.device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&ev_e[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ev_m[i], hipEventDisableTiming)); }
         table_cap = round_pow2(cfg.table_capacity ? cfg.table_capacity : (1ull << 24));
         arena_cap = cfg.arena_capacity ? cfg.arena_capacity : (1ull << 22);
         arena_cap = (arena_cap + 63) & ~63ull;
@@ -936,7 +940,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipMalloc(&d_table, table_cap * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&d_cand, (size_t)(use_matrix ? max_slots : 1) * row_stride * sizeof(uint64_t)));
         seg_cap = (row_stride / NSHARD + 256) * max_slots;
-        HIP_TRY(hipMalloc(&d_newlist, (size_t)NSHARD * seg_cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&d_newlist, (size_t)2 * NSHARD * seg_cap * sizeof(uint32_t)));
         {
             const uint64_t ni = S::num_init(prm);
             HIP_TRY(hipMalloc(&d_inittmp, (size_t)(ni < chunk ? ni : chunk) * W * sizeof(uint64_t)));
@@ -965,21 +969,25 @@ struct Engine : EngineBase {
         if (d_pslot) hipFree(d_pslot);
         if (d_ctr) hipFree(d_ctr);
         if (h_ctr) hipHostFree(h_ctr);
+        for (int i = 0; i < 2; i++) { if (ev_e[i]) hipEventDestroy(ev_e[i]); if (ev_m[i]) hipEventDestroy(ev_m[i]); }
+        if (stream2) hipStreamDestroy(stream2);
         if (stream) hipStreamDestroy(stream);
     }
 
     template <class F>
-    void timed(int which, uint64_t units, F &&launch) {
+    void timed(int which, uint64_t units, F &&launch, hipStream_t on = nullptr) {
         if (!timer.enabled) { launch(); return; }
+        if (!on) on = stream;
         hipEvent_t a = timer.get(), b = timer.get();
         size_t ia = timer.used - 2, ib = timer.used - 1;
-        hipEventRecord(a, stream);
+        hipEventRecord(a, on);
         launch();
-        hipEventRecord(b, stream);
+        hipEventRecord(b, on);
         timer.pending.push_back({which, ia, ib, units});
     }
 
     int read_counters() {
+        HIP_TRY(hipStreamSynchronize(stream2));
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (timer.enabled) timer.resolve(kstat);
@@ -993,14 +1001,19 @@ struct Engine : EngineBase {
     }
 
     bool use_matrix = false;
-    void finish_materialise(uint64_t chunk_base, uint64_t ncols) {
+    // materialise + commit of the chunk whose survivors are in new-list `parity`, on the second stream: it overlaps
+    // the expansion of the next chunk (memory-bound next to latency-bound)
+    void finish_materialise(uint64_t chunk_base, uint64_t ncols, unsigned parity) {
         const unsigned bx = (unsigned)((ncols + 255) / 256);
         const unsigned gm = bx < 8 * 256 ? (bx + 7) / 8 : 256;
+        hipEventRecord(ev_e[parity], stream);
+        hipStreamWaitEvent(stream2, ev_e[parity], 0);
         timed(2, 0, [&] {
-            hipLaunchKernelGGL(k_materialise<S>, dim3(gm, NSHARD), dim3(256), 0, stream, prm, d_arena, chunk_base, d_newlist,
-                               seg_cap, arena_cap, d_parent, d_pslot, d_ctr);
-        });
-        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
+            hipLaunchKernelGGL(k_materialise<S>, dim3(gm, NSHARD), dim3(256), 0, stream2, prm, d_arena, chunk_base, d_newlist,
+                               seg_cap, arena_cap, d_parent, d_pslot, d_ctr, parity);
+        }, stream2);
+        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream2, d_ctr, parity);
+        hipEventRecord(ev_m[parity], stream2);
     }
     // insert + materialise + commit for the candidate matrix just written
     template <bool INIT>
@@ -1017,9 +1030,9 @@ struct Engine : EngineBase {
                                    d_inittmp, d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
             else
                 hipLaunchKernelGGL(k_materialise<S>, dim3(gm, 1), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
-                                   d_newlist, seg_cap, arena_cap, d_parent, d_pslot, d_ctr);
+                                   d_newlist, seg_cap, arena_cap, d_parent, d_pslot, d_ctr, 0u);
         });
-        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
+        hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr, 0u);
     }
 
     int run(mc_result *out) override {
@@ -1059,7 +1072,9 @@ struct Engine : EngineBase {
             if (h_ctr->viol_key != ~0ull) break;
             if (cfg.max_levels && level >= cfg.max_levels) { budget = 1; break; }
             if (cfg.max_distinct && hi >= cfg.max_distinct) { budget = 1; break; }
-            for (uint64_t c0 = lo; c0 < hi;) {
+            unsigned chunk_no = 0;
+            for (uint64_t c0 = lo; c0 < hi; ++chunk_no) {
+                const unsigned parity = chunk_no & 1u;
                 const uint64_t base = c0 & ~63ull;
                 uint64_t c1 = base + chunk;  // chunk boundaries stay 64-aligned
                 if (c1 > hi) c1 = hi;
@@ -1071,12 +1086,13 @@ struct Engine : EngineBase {
                     });
                     finish_chunk<false>(base, ncols, max_slots);
                 } else {
+                    if (chunk_no >= 2) hipStreamWaitEvent(stream, ev_m[parity], 0);  // new-list `parity` is free again
                     timed(0, c1 - c0, [&] {
                         launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
                                                 (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
-                                                cfg.flags, RouteArgs{});
+                                                cfg.flags, RouteArgs{}, parity);
                     });
-                    finish_materialise(base, ncols);
+                    finish_materialise(base, ncols, parity);
                 }
                 c0 = c1;
             }
@@ -1215,8 +1231,8 @@ struct Engine : EngineBase {
             const uint64_t ncols = ((c1 - c0) + 63) & ~63ull;
             launch_expand<S, false>(!((cfg.flags | extra_flags) & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
                                     (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
-                                    cfg.flags | extra_flags, RouteArgs{});
-            hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr);
+                                    cfg.flags | extra_flags, RouteArgs{}, 0u);
+            hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr, 0u);
         }
         HIP_TRY(hipEventRecord(b, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1297,7 +1313,7 @@ struct Engine : EngineBase {
         RouteArgs rt{P, d_rt_cur, d_rt_fp, d_rt_src, rt_subcap};
         timed(0, count, [&] {
             launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
-                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt);
+                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
         });
         std::vector<PaddedCounter> cur(P * NSHARD);
         HIP_TRY(hipMemcpyAsync(cur.data(), d_rt_cur, cur.size() * sizeof(PaddedCounter), hipMemcpyDeviceToHost, stream));
