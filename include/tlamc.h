@@ -52,7 +52,8 @@ extern "C" {
 #define MC_SPEC_SSI 4        /* reference examples/serializableSnapshotIsolation.tla:219-996 under specs/MCssi.tla;
                                 params {nTxn <= 4, nKey <= 3, invariantMask (1 WellFormed | 2 HoldingXLocks |
                                 4 WaitingForXLock | 8 CorrectReadView | 16 FirstCommitterWins | 32 Cahill |
-                                64 Bernstein), find (0; 1..6 abort reason, 7 two waiters: ":81-96 expected")}   */
+                                64 Bernstein), find (0; 1..6 abort reason, 7 two waiters: ":81-96 expected"),
+                                textbook (1 = examples/textbookSnapshotIsolation.tla: no Cahill variables)}  */
 
 typedef struct {
     uint32_t spec_id;

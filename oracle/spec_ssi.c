@@ -12,7 +12,10 @@
  * (T1 < T2 < ...): Commit's AbortOpSeq (:465-474).  The other CHOOSEs of the spec are over
  * singletons (:574 readVerSet, :790 holder, :851 path).
  *
- * params: {nTxn, nKey, invariant mask, find}
+ * params: {nTxn, nKey, invariant mask, find, textbook}
+ *   textbook = 1 selects examples/textbookSnapshotIsolation.tla: the same model WITHOUT Cahill's three variables
+ *     (its allvars :115): Commit never aborts the pivot (:325-355), Read (:365-378) and HelperWriteCanAcquireXLock
+ *     (:383-386) do no conflict bookkeeping.  Its serializability invariants are then EXPECTED to fail (write skew).
  *   invariant mask (serializableSnapshotIsolation.tla:59-79): 1 WellFormedTransactionsInHistory,
  *     2 CorrectnessOfHoldingXLocks, 4 CorrectnessOfWaitingForXLock, 8 CorrectReadView,
  *     16 FirstCommitterWins, 32 CahillSerializable, 64 BernsteinSerializable  (TypeInv holds by
@@ -49,7 +52,7 @@ typedef struct {
     uint8_t siread[ST];       /* holdingSIREADlocks[t]: bit k       */
 } SState;
 
-typedef struct { int nt, nk, inv_mask, find; } ssi_ctx;
+typedef struct { int nt, nk, inv_mask, find, textbook; } ssi_ctx;  /* textbook = 1: examples/textbookSnapshotIsolation.tla */
 
 static size_t s_ser(const ssi_ctx *c, const SState *s, uint8_t *out) {
     uint8_t *p = out;
@@ -163,7 +166,7 @@ static void si_write(SState *s, int txn, int key) {
 static void write_can_acquire(sgen *g, const SState *s, int txn, int key, int action) {
     const ssi_ctx *c = g->c;
     SState t = *s;
-    unsigned owners = concurrent_siread_owners(c, s, txn, key);
+    unsigned owners = c->textbook ? 0u : concurrent_siread_owners(c, s, txn, key);
     if (owners) {
         int danger = 0;
         for (int o = 0; o < c->nt; o++) if ((owners >> o & 1) && (committed(s, o) || s->inC[o])) danger = 1;   /* :726-728: \/ */
@@ -232,7 +235,7 @@ static void ssi_succ(void *ctx, const uint8_t *sb, size_t len, or_emit *em) {
         /* Commit(txn) :429-491 */
         if (can_do(&s, txn)) {
             SState t = s;
-            if (s.inC[txn] && s.outC[txn]) internal_abort(&t, txn, R_COMMIT);
+            if (!c->textbook && s.inC[txn] && s.outC[txn]) internal_abort(&t, txn, R_COMMIT);
             else {
                 append(&t, OP_COMMIT, txn, 0, 0, 0);
                 unsigned losers = 0;   /* LoserTxns :461-462 */
@@ -256,7 +259,8 @@ static void ssi_succ(void *ctx, const uint8_t *sb, size_t len, or_emit *em) {
                     int danger = 0;
                     for (int x = 0; x < c->nt; x++) if ((newer >> x & 1) && committed(&s, x) && s.outC[x]) danger = 1;
                     SState t = s;
-                    if (danger) internal_abort(&t, txn, R_READ);
+                    if (c->textbook) append(&t, OP_READ, txn, key, ver, 0);   /* textbookSnapshotIsolation.tla:365-378 */
+                    else if (danger) internal_abort(&t, txn, R_READ);
                     else {
                         append(&t, OP_READ, txn, key, ver, 0);
                         t.siread[txn] |= (uint8_t)(1u << key);
@@ -505,7 +509,7 @@ int oracle_ssi_unit_tests(void) {
         {3, {{OP_BEGIN, 0, 0, 0, 0}, {OP_ABORT, 0, 0, 0, R_VOLUNTARY}, {OP_WRITE, 0, 0, 0, 0}}, 0},
         {3, {{OP_BEGIN, 0, 0, 0, 0}, {OP_WRITE, 0, 0, 0, 0}, {OP_WRITE, 0, 0, 0, 0}}, 0},
         {3, {{OP_BEGIN, 0, 0, 0, 0}, {OP_READ, 0, 0, 1, 0}, {OP_READ, 0, 0, 1, 0}}, 0}};
-    ssi_ctx c = {2, 2, 127, 0};
+    ssi_ctx c = {2, 2, 127, 0, 0};
     for (int k = 0; k < 10; k++) {
         SState s;
         memset(&s, 0, sizeof s);
@@ -530,6 +534,7 @@ int or_spec_ssi(const int64_t *p, int np, or_spec *o) {
     c->nt = (int)p[0]; c->nk = (int)p[1];
     c->inv_mask = np > 2 ? (int)p[2] : 127;
     c->find = np > 3 ? (int)p[3] : 0;
+    c->textbook = np > 4 ? (int)p[4] : 0;
     o->name = "ssi"; o->ctx = c; o->max_state_bytes = 512;
     o->n_init = ssi_n_init; o->init = ssi_init; o->succ = ssi_succ; o->invariant = ssi_invariant; o->print = ssi_print;
     o->action_name = or_ssi_action; o->stats = ssi_stats;

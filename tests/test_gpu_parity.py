@@ -16,6 +16,7 @@ SMALL = [
     ("pcal_intro", [0, 1, 20, 2]), ("pcal_intro", [1, 0, 20, 2]), ("pcal_intro", [1, 1, 20, 2]), ("pcal_intro", [0, 1, 7, 3]),
     ("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 3, 2, 9, 1, 3]),
     ("ssi", [2, 1, 127, 0]), ("ssi", [2, 2, 127, 0]), ("ssi", [3, 1, 127, 0]),
+    ("ssi", [2, 2, 127, 0, 1]), ("ssi", [3, 1, 31, 0, 1]),       # textbookSnapshotIsolation.tla
 ]
 
 
@@ -192,4 +193,16 @@ def test_ssi_4x3_prefix_on_gpu(amd):
     eng = amd.Engine("ssi", [4, 3, 127, 0], table_capacity=1 << 27, arena_capacity=24_000_000, chunk_states=1 << 19, max_levels=9, trace=False)
     r = eng.run()
     assert r.levels == [1, 4, 32, 264, 2532, 24576, 236844, 2189052, 18810792] and r.verdict == "budget"
+    eng.close()
+
+
+@pytest.mark.parametrize("mask,inv", [(32, 5), (64, 6)])
+def test_textbook_si_write_skew_on_gpu(amd, mask, inv):
+    """textbookSnapshotIsolation.tla, 3 txns x 2 keys: serializability is violated by a 13-state history (oracle:
+    tests/test_oracle_golden.py), found by both Cahill's and Bernstein's formulation."""
+    eng = amd.Engine("ssi", [3, 2, mask, 0, 1], table_capacity=1 << 26, arena_capacity=40_000_000, chunk_states=1 << 19)
+    r = eng.run()
+    assert (r.verdict, r.violated_invariant, r.trace_len) == ("invariant", inv, 13)
+    tr = eng.trace()
+    assert len(tr) == 13 and tr[-1][1].count('"commit"') >= 2
     eng.close()

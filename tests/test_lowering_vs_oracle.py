@@ -10,6 +10,7 @@ CASES = [
     ("pcal_intro", [0, 1, 7, 3]),
     ("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 3, 2, 9, 1, 3]),
     ("ssi", [2, 1, 127, 0]), ("ssi", [2, 2, 127, 0]), ("ssi", [3, 1, 127, 0]),
+    ("ssi", [2, 2, 127, 0, 1]), ("ssi", [3, 1, 31, 0, 1]),       # textbookSnapshotIsolation.tla
 ]
 
 

@@ -108,3 +108,16 @@ def test_ssi_expected_violations_are_reachable(oracle, find, trace_len):
     """:81-96 'EXPECTED to be violated': every abort reason and two simultaneous lock waiters are reachable (3 txns x 2 keys)."""
     r = oracle.oracle_run("ssi", [3, 2, 127, find])
     assert r["verdict"] == "invariant" and r["violated_invariant"] == 7 and len(r["trace"]) == trace_len
+
+
+def test_textbook_si_is_not_serializable_and_both_formulations_agree(oracle):
+    """examples/textbookSnapshotIsolation.tla (SSI minus Cahill's variables): snapshot isolation admits write skew.
+    3 txns x 2 keys is the smallest model (a key must be committed before it can be read, :365-378); the reference
+    asks that Cahill's and Bernstein's formulations be equivalent (:84-89): same shortest counterexample length."""
+    a = oracle.oracle_run("ssi", [3, 2, 32, 0, 1])
+    b = oracle.oracle_run("ssi", [3, 2, 64, 0, 1])
+    assert (a["verdict"], a["violated_invariant"], len(a["trace"])) == ("invariant", 5, 13)
+    assert (b["verdict"], b["violated_invariant"], len(b["trace"])) == ("invariant", 6, 13)
+    assert a["distinct"] == b["distinct"] == 16559944
+    ok = oracle.oracle_run("ssi", [2, 2, 127, 0, 1])       # too small for write skew: everything holds
+    assert ok["verdict"] == "ok" and ok["distinct"] == 29629

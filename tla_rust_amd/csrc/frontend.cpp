@@ -284,6 +284,7 @@ constexpr uint64_t H_PCAL_INTRO = 0x6da4921b5bd7b79aull;        // pcal_intro.tl
 constexpr uint64_t H_PCAL_INTRO_README = 0x446ad8dac291d64full; // README.md:224-240 (labels A:, B:)
 constexpr uint64_t H_ATOMIC_ADD = 0x6c3a51af80fccd40ull;        // atomic_add.tla:4-23
 constexpr uint64_t H_RAFT = 0x289fe41014391a24ull;              // examples/raft.tla:8-517 (EXTENDS .. before ====)
+constexpr uint64_t H_TEXTBOOK_SI = 0x26b4e8333db4314cull;      // examples/textbookSnapshotIsolation.tla (EXTENDS .. before ====)
 constexpr uint64_t H_SSI = 0x85c02cbaf85b39ceull;              // examples/serializableSnapshotIsolation.tla:21-1579
 
 bool algorithm_text(const std::string &t, std::string &out) {
@@ -497,7 +498,8 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
         out->params[1] = mcr; out->params[2] = mt; out->params[3] = ml; out->params[4] = mm; out->params[5] = mask;
         return MC_OK;
     }
-    if (m == "MCssi" || m == "serializableSnapshotIsolation") {  // serializableSnapshotIsolation.tla under specs/MCssi.tla
+    const bool textbook = m == "MCtextbookSI" || m == "textbookSnapshotIsolation";  // examples/textbookSnapshotIsolation.tla
+    if (m == "MCssi" || m == "serializableSnapshotIsolation" || textbook) {  // serializableSnapshotIsolation.tla under specs/MCssi.tla
         const CfgConst *tx = find_const(c, "TxnId"), *ky = find_const(c, "Key"), *nl = find_const(c, "NoLock");
         if (!tx || tx->replacement || tx->value.kind != CfgValue::SET || tx->value.elems.empty() || tx->value.elems.size() > 4)
             return fe_fail(MC_EBADCFG, "SSI needs CONSTANT TxnId = {T1, ...} with 1..4 model values");
@@ -522,11 +524,12 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
             if (!ok) return fe_fail(MC_ENOSPEC, "MCssi defines no invariant named '%s'", i.c_str());
         }
         out->spec_id = MC_SPEC_SSI;
-        out->nparams = 4;
+        out->nparams = 5;
         out->params[0] = (long long)tx->value.elems.size();
         out->params[1] = (long long)ky->value.elems.size();
         out->params[2] = mask;
         out->params[3] = find;
+        out->params[4] = textbook ? 1 : 0;
         return MC_OK;
     }
     return fe_fail(MC_ENOSPEC, "module '%s' is not one of the lowered specs (atomic_add, atomic_add_n, pcal_intro, MCraft, MCssi)", module);
@@ -590,16 +593,18 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
         }
     }
     if (d.spec_id == MC_SPEC_SSI) {
-        std::string ssi;  // MCssi EXTENDS serializableSnapshotIsolation: verify it when it can be found
+        std::string ssi;  // the MC wrapper EXTENDS the spec: verify it when it can be found
+        const bool tb = d.params[4] != 0;
+        const std::string base = tb ? "textbookSnapshotIsolation" : "serializableSnapshotIsolation";
         const char *env = getenv("TLA_PATH");
-        bool found = read_file(dir_of(tla_path) + "/serializableSnapshotIsolation.tla", ssi) ||
-                     (env && read_file(std::string(env) + "/serializableSnapshotIsolation.tla", ssi));
-        if (module == "serializableSnapshotIsolation") { ssi = tla; found = true; }
+        bool found = read_file(dir_of(tla_path) + "/" + base + ".tla", ssi) || (env && read_file(std::string(env) + "/" + base + ".tla", ssi));
+        if (module == base) { ssi = tla; found = true; }
         if (found) {
-            if (!module_body(ssi, part)) return fe_fail(MC_ENOSPEC, "serializableSnapshotIsolation.tla: cannot find the module body");
+            if (!module_body(ssi, part)) return fe_fail(MC_ENOSPEC, "%s.tla: cannot find the module body", base.c_str());
             const uint64_t h = text_hash(part);
-            if (h != H_SSI) return fe_fail(MC_ENOSPEC, "serializableSnapshotIsolation.tla differs from the text the lowering was written against (hash %016llx)", (unsigned long long)h);
-            if (module != "serializableSnapshotIsolation") { def_text = ssi; def_module_name = "serializableSnapshotIsolation"; }
+            if (h != (tb ? H_TEXTBOOK_SI : H_SSI))
+                return fe_fail(MC_ENOSPEC, "%s.tla differs from the text the lowering was written against (hash %016llx)", base.c_str(), (unsigned long long)h);
+            if (module != base) { def_text = ssi; def_module_name = base; }
         }
     }
     mc_engine *e = nullptr;

@@ -26,7 +26,7 @@
 
 namespace mc {
 
-struct SsiParams { int nt, nk, inv_mask, find; };
+struct SsiParams { int nt, nk, inv_mask, find, textbook; };  // textbook = 1: examples/textbookSnapshotIsolation.tla
 
 struct SpecSsi {
     using Params = SsiParams;
@@ -50,6 +50,7 @@ struct SpecSsi {
         o.nt = (int)p[0]; o.nk = (int)p[1];
         o.inv_mask = np > 2 ? (int)p[2] : 127;
         o.find = np > 3 ? (int)p[3] : 0;
+        o.textbook = np > 4 ? (int)p[4] : 0;  // the same model without Cahill's variables (textbookSnapshotIsolation.tla:115)
         if (o.nt < 1 || o.nt > NT || o.nk < 1 || o.nk > NK || o.find < 0 || o.find > 7) return -1;
         return 0;
     }
@@ -233,7 +234,7 @@ struct SpecSsi {
     }
     // HelperWriteCanAcquireXLock :700-771
     MC_HD static void write_can_acquire(const Params &p, const Local &l, int txn, int key, Delta &d) {
-        const unsigned owners = siread_owners(p, l, txn, key);
+        const unsigned owners = p.textbook ? 0u : siread_owners(p, l, txn, key);  // textbook SI: HelperWriteCanAcquireXLock :383-386
         bool danger = false;
 #pragma unroll
         for (int o = 0; o < NT; o++) if ((owners >> o & 1u) && ((l.committed >> o & 1u) || t_in(m_txn(l.meta, o)))) danger = true;  // :726-728
@@ -264,7 +265,7 @@ struct SpecSsi {
         } else if (sub == 1) {  // Commit(txn) :429-491
             action = SA_COMMIT;
             if (!can_do(l, txn)) return 0;
-            if (t_in(me) && t_out(me)) internal_abort(d, txn, R_COMMIT);
+            if (!p.textbook && t_in(me) && t_out(me)) internal_abort(d, txn, R_COMMIT);
             else {
                 d_append(d, mk_event(OP_COMMIT, txn, 0, 0, 0));
                 d.meta = m_set_txn(d.meta, txn, mk_txn(0, t_wait(me), t_in(me), t_out(me), t_sir(me)));  // drop X locks only
@@ -300,7 +301,8 @@ struct SpecSsi {
             bool danger = false;
 #pragma unroll
             for (int x = 0; x < NT; x++) if ((newer >> x & 1u) && (l.committed >> x & 1u) && t_out(m_txn(l.meta, x))) danger = true;
-            if (danger) internal_abort(d, txn, R_READ);
+            if (p.textbook) d_append(d, mk_event(OP_READ, txn, key, ver, 0));  // textbookSnapshotIsolation.tla:365-378
+            else if (danger) internal_abort(d, txn, R_READ);
             else {
                 d_append(d, mk_event(OP_READ, txn, key, ver, 0));
                 unsigned lockers = 0;
