@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-distinct", type=int, default=WORKLOAD["max_distinct"])
     ap.add_argument("--chunk", type=int, default=1 << 20)
+    ap.add_argument("--shard-chunk", type=int, default=1 << 20, help="frontier states per round and rank in the sharded (torchrun) path")
     ap.add_argument("--table-log2", type=int, default=28)
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
@@ -82,7 +83,7 @@ def main():
         # level (13 at level 23), so the sharded run gets 24 message slots (W = 464 B) instead of 16
         sharded_params = WORKLOAD["params"][:6] + [24, 2, 8]
         chk = ShardedChecker(WORKLOAD["spec"], sharded_params, device=local, max_distinct=a.max_distinct * world,
-                             chunk_states=min(a.chunk, 1 << 19), table_capacity=1 << 27,
+                             chunk_states=a.shard_chunk, table_capacity=1 << 27,
                              # the last level may overshoot the budget by the growth factor (~1.7x): size for it
                              arena_capacity=64_000_000,
                              fanout_cap=48, new_cap=6)

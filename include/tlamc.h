@@ -144,18 +144,33 @@ void mc_engine_destroy(mc_engine *e);
  * (mc_state_bytes() * 64 bytes each), word-major inside a block like the HBM arena, so both ends
  * move them with coalesced accesses; send_counts[] are STATES, a bucket occupies
  * ceil(count / 64) blocks.  mc_shard_ingest takes ONE source's bucket per call. */
+/* Optional: hand the engine the HIP stream (hipStream_t) the caller issues its collectives on.  The engine then
+ * enqueues bucket compaction, probe, keep, materialise and ingest on THAT stream and returns without waiting
+ * (stream order ties them to the caller's all-to-alls); only calls that return counts to the host
+ * (expand_finish, materialise, end_level, counters) block.  enable = 0 restores the blocking default.
+ * With it mc_shard_keep* reports *n_new = 0: the count stays on the device until mc_shard_end_level. */
+int mc_shard_set_stream(mc_engine *e, void *hip_stream, int enable);
 int mc_shard_begin(mc_engine *e);                                  /* Init: keep the initial states this rank owns */
 int mc_shard_level_size(mc_engine *e, uint64_t *frontier_states);  /* local frontier of the current level          */
 int mc_shard_expand(mc_engine *e, uint64_t first, uint64_t count,  /* chunk of the local frontier                  */
                     uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts /* [shard_count] host */);
+/* The same step split in two so that rounds can be software-pipelined: _launch enqueues the expand of a chunk
+ * into `slot` (0 or 1) on the engine's main stream and returns at once; _finish waits for it and compacts the
+ * slot's buckets into send_fp.  Between them the caller may run probe / keep / materialise / ingest for the
+ * OTHER slot (they execute on the engine's side stream) and its collectives.  mc_shard_expand = both, slot 0. */
+int mc_shard_expand_launch(mc_engine *e, uint32_t slot, uint64_t first, uint64_t count, uint64_t send_cap);
+int mc_shard_expand_finish(mc_engine *e, uint32_t slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts);
 int mc_shard_probe(mc_engine *e, const uint64_t *recv_fp, uint64_t n, uint8_t *answers);
 int mc_shard_materialise(mc_engine *e, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap,
                          uint64_t *send_counts /* [shard_count] host, in states */);
+int mc_shard_materialise_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint8_t *send_states,
+                              uint64_t send_cap, uint64_t *send_counts);
 int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n);
 /* "stay" alternative to materialise + all-to-all + ingest: the positively answered candidates of the last
  * mc_shard_expand are materialised into THIS rank's frontier (only fingerprints crossed xGMI).  The caller
  * uses it once the frontier is large enough to stay balanced, and falls back to the moving form to rebalance. */
-int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new);
+int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new);              /* slot 0 */
+int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t *n_new);
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local_states);  /* swap frontiers                                */
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict);
 

@@ -210,11 +210,12 @@ struct ShimShardBase {
     virtual ~ShimShardBase() {}
     virtual int begin() = 0;
     virtual uint64_t level_size() = 0;
-    virtual int expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
+    virtual int expand_launch(unsigned slot, uint64_t first, uint64_t count) = 0;
+    virtual int expand_finish(unsigned slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) = 0;
-    virtual int materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
+    virtual int materialise(unsigned slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int ingest(const uint8_t *recv_states, uint64_t n) = 0;
-    virtual int keep(const uint8_t *answers_back, uint64_t *n_new) = 0;
+    virtual int keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) = 0;
     virtual uint64_t end_level() = 0;
     virtual void counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
 };
@@ -229,8 +230,13 @@ struct ShimShard : ShimShardBase {
     uint64_t lo = 0, hi = 0, generated = 0;
     int32_t verdict = MC_V_OK;
     struct Pending { uint64_t parent; int slot; };
-    std::vector<Pending> pending;          // aligned with the compacted send_fp order
-    std::vector<uint64_t> pend_off;        // per-owner offsets into pending
+    struct Slot {                              // two expand slots like the engine (tlamc.h: mc_shard_expand_launch)
+        std::vector<Pending> pending;          // aligned with the compacted send_fp order
+        std::vector<uint64_t> pend_off;        // per-owner offsets into pending
+        std::vector<std::vector<uint64_t>> fps;
+        std::vector<std::vector<Pending>> src;
+        bool launched = false;
+    } sl[2];
 
     uint64_t nstates() const { return arena.size() / (size_t)W; }
     int begin() override {
@@ -251,9 +257,14 @@ struct ShimShard : ShimShardBase {
         return 0;
     }
     uint64_t level_size() override { return hi - lo; }
-    int expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) override {
-        std::vector<std::vector<uint64_t>> fps(nranks);
-        std::vector<std::vector<Pending>> src(nranks);
+    int expand_launch(unsigned slot, uint64_t first, uint64_t count) override {
+        Slot &q = sl[slot & 1];
+        auto &fps = q.fps;
+        auto &src = q.src;
+        fps.assign(nranks, {});
+        src.assign(nranks, {});
+        q.launched = true;
+        if (first + count > hi - lo) return MC_EBADCFG;
         for (uint64_t i = lo + first; i < lo + first + count; i++) {
             CWordRef s{&arena[i * W], 1};
             typename S::Local loc;
@@ -277,6 +288,16 @@ struct ShimShard : ShimShardBase {
             }
             if (!nsucc && verdict == MC_V_OK) verdict = MC_V_DEADLOCK;
         }
+        return 0;
+    }
+    int expand_finish(unsigned slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) override {
+        Slot &q = sl[slot & 1];
+        if (!q.launched) return MC_EBADCFG;
+        q.launched = false;
+        auto &fps = q.fps;
+        auto &src = q.src;
+        auto &pending = q.pending;
+        auto &pend_off = q.pend_off;
         pending.clear();
         pend_off.assign(nranks + 1, 0);
         uint64_t k = 0;
@@ -294,7 +315,9 @@ struct ShimShard : ShimShardBase {
         return 0;
     }
     // exchange format: per owner a whole number of 64-state blocks, word-major inside a block
-    int materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
+    int materialise(unsigned slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
+        auto &pending = sl[slot & 1].pending;
+        auto &pend_off = sl[slot & 1].pend_off;
         uint64_t *out = (uint64_t *)send_states;
         uint64_t blk0 = 0;
         for (uint32_t o = 0; o < nranks; o++) {
@@ -311,7 +334,8 @@ struct ShimShard : ShimShardBase {
         }
         return 0;
     }
-    int keep(const uint8_t *answers_back, uint64_t *n_new) override {
+    int keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) override {
+        auto &pending = sl[slot & 1].pending;
         std::vector<uint64_t> tmp(W);
         *n_new = 0;
         for (size_t i = 0; i < pending.size(); i++) {
@@ -346,15 +370,18 @@ void *shim_shard_create(const mc_spec_desc *d, uint32_t rank, uint32_t nranks) {
 void shim_shard_destroy(void *e) { delete (ShimShardBase *)e; }
 int shim_shard_begin(void *e) { return ((ShimShardBase *)e)->begin(); }
 int shim_shard_level_size(void *e, uint64_t *n) { *n = ((ShimShardBase *)e)->level_size(); return 0; }
-int shim_shard_expand(void *e, uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t cap, uint64_t *counts) {
-    return ((ShimShardBase *)e)->expand(first, count, send_fp, cap, counts);
+int shim_shard_expand_launch(void *e, uint32_t slot, uint64_t first, uint64_t count) {
+    return ((ShimShardBase *)e)->expand_launch(slot, first, count);
+}
+int shim_shard_expand_finish(void *e, uint32_t slot, uint64_t *send_fp, uint64_t cap, uint64_t *counts) {
+    return ((ShimShardBase *)e)->expand_finish(slot, send_fp, cap, counts);
 }
 int shim_shard_probe(void *e, const uint64_t *fp, uint64_t n, uint8_t *ans) { return ((ShimShardBase *)e)->probe(fp, n, ans); }
-int shim_shard_materialise(void *e, const uint8_t *ans, uint8_t *states, uint64_t cap, uint64_t *counts) {
-    return ((ShimShardBase *)e)->materialise(ans, states, cap, counts);
+int shim_shard_materialise(void *e, uint32_t slot, const uint8_t *ans, uint8_t *states, uint64_t cap, uint64_t *counts) {
+    return ((ShimShardBase *)e)->materialise(slot, ans, states, cap, counts);
 }
 int shim_shard_ingest(void *e, const uint8_t *states, uint64_t n) { return ((ShimShardBase *)e)->ingest(states, n); }
-int shim_shard_keep(void *e, const uint8_t *ans, uint64_t *n) { return ((ShimShardBase *)e)->keep(ans, n); }
+int shim_shard_keep(void *e, uint32_t slot, const uint8_t *ans, uint64_t *n) { return ((ShimShardBase *)e)->keep(slot, ans, n); }
 int shim_shard_end_level(void *e, uint64_t *n) { *n = ((ShimShardBase *)e)->end_level(); return 0; }
 int shim_shard_counters(void *e, uint64_t *g, uint64_t *d, int32_t *v) { ((ShimShardBase *)e)->counters(g, d, v); return 0; }
 }

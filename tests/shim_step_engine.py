@@ -13,16 +13,17 @@ class ShimStepEngine:
         L = self.lib
         L.shim_shard_create.restype = C.c_void_p
         L.shim_shard_create.argtypes = [C.POINTER(helpers.McSpecDesc), C.c_uint32, C.c_uint32]
-        for name in ("begin", "level_size", "expand", "probe", "materialise", "ingest", "keep", "end_level", "counters", "destroy"):
+        for name in ("begin", "level_size", "expand_launch", "expand_finish", "probe", "materialise", "ingest", "keep", "end_level", "counters", "destroy"):
             getattr(L, "shim_shard_" + name).restype = C.c_int if name != "destroy" else None
         L.shim_shard_begin.argtypes = [C.c_void_p]
         L.shim_shard_destroy.argtypes = [C.c_void_p]
         L.shim_shard_level_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-        L.shim_shard_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.shim_shard_expand_launch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]
+        L.shim_shard_expand_finish.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.shim_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-        L.shim_shard_materialise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.shim_shard_materialise.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.shim_shard_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
-        L.shim_shard_keep.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.shim_shard_keep.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
         L.shim_shard_end_level.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.shim_shard_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
         self.world = world
@@ -45,26 +46,29 @@ class ShimStepEngine:
         self.lib.shim_shard_level_size(self.h, C.byref(n))
         return n.value
 
-    def expand(self, first, count, send_fp):
+    def expand_launch(self, slot, first, count, send_cap):
+        self._ck(self.lib.shim_shard_expand_launch(self.h, slot, first, count), "expand_launch")
+
+    def expand_finish(self, slot, send_fp):
         counts = (C.c_uint64 * self.world)()
-        self._ck(self.lib.shim_shard_expand(self.h, first, count, send_fp.data_ptr(), send_fp.numel(), counts), "expand")
+        self._ck(self.lib.shim_shard_expand_finish(self.h, slot, send_fp.data_ptr(), send_fp.numel(), counts), "expand_finish")
         return list(counts)
 
     def probe(self, recv_fp, n, answers):
         self._ck(self.lib.shim_shard_probe(self.h, recv_fp.data_ptr(), n, answers.data_ptr()), "probe")
 
-    def materialise(self, answers_back, send_states):
+    def materialise(self, slot, answers_back, send_states):
         counts = (C.c_uint64 * self.world)()
-        self._ck(self.lib.shim_shard_materialise(self.h, answers_back.data_ptr(), send_states.data_ptr(),
+        self._ck(self.lib.shim_shard_materialise(self.h, slot, answers_back.data_ptr(), send_states.data_ptr(),
                                                  send_states.numel() // self.W, counts), "materialise")
         return list(counts)
 
     def ingest(self, recv_states, n):
         self._ck(self.lib.shim_shard_ingest(self.h, recv_states.data_ptr(), n), "ingest")
 
-    def keep(self, answers_back):
+    def keep(self, slot, answers_back):
         n = C.c_uint64()
-        self._ck(self.lib.shim_shard_keep(self.h, answers_back.data_ptr(), C.byref(n)), "keep")
+        self._ck(self.lib.shim_shard_keep(self.h, slot, answers_back.data_ptr(), C.byref(n)), "keep")
         return n.value
 
     def end_level(self):
@@ -79,6 +83,10 @@ class ShimStepEngine:
 
     def sync(self):
         pass
+
+    def stream_ctx(self):
+        import contextlib
+        return contextlib.nullcontext()
 
     def close(self):
         self.lib.shim_shard_destroy(self.h)

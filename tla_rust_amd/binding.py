@@ -91,6 +91,11 @@ def lib():
     L.mc_shard_begin.argtypes = [C.c_void_p]
     L.mc_shard_level_size.argtypes = [C.c_void_p, U64P]
     L.mc_shard_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, U64P]
+    L.mc_shard_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.mc_shard_expand_launch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.mc_shard_expand_finish.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, U64P]
+    L.mc_shard_materialise_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, U64P]
+    L.mc_shard_keep_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, U64P]
     L.mc_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.mc_shard_materialise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, U64P]
     L.mc_shard_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -214,20 +219,31 @@ class Engine:
         _check(lib().mc_shard_expand(self._h, first, count, send_fp_ptr, send_cap, counts), "mc_shard_expand")
         return list(counts)
 
+    def shard_set_stream(self, hip_stream, enable=True):
+        _check(lib().mc_shard_set_stream(self._h, hip_stream, int(enable)), "mc_shard_set_stream")
+
+    def shard_expand_launch(self, slot, first, count, send_cap):
+        _check(lib().mc_shard_expand_launch(self._h, slot, first, count, send_cap), "mc_shard_expand_launch")
+
+    def shard_expand_finish(self, slot, send_fp_ptr, send_cap):
+        counts = (C.c_uint64 * max(1, self.cfg.shard_count))()
+        _check(lib().mc_shard_expand_finish(self._h, slot, send_fp_ptr, send_cap, counts), "mc_shard_expand_finish")
+        return list(counts)
+
     def shard_probe(self, recv_fp_ptr, n, answers_ptr):
         _check(lib().mc_shard_probe(self._h, recv_fp_ptr, n, answers_ptr), "mc_shard_probe")
 
-    def shard_materialise(self, answers_back_ptr, send_states_ptr, send_cap):
+    def shard_materialise(self, answers_back_ptr, send_states_ptr, send_cap, slot=0):
         counts = (C.c_uint64 * max(1, self.cfg.shard_count))()
-        _check(lib().mc_shard_materialise(self._h, answers_back_ptr, send_states_ptr, send_cap, counts), "mc_shard_materialise")
+        _check(lib().mc_shard_materialise_slot(self._h, slot, answers_back_ptr, send_states_ptr, send_cap, counts), "mc_shard_materialise")
         return list(counts)
 
     def shard_ingest(self, recv_states_ptr, n):
         _check(lib().mc_shard_ingest(self._h, recv_states_ptr, n), "mc_shard_ingest")
 
-    def shard_keep(self, answers_back_ptr):
+    def shard_keep(self, answers_back_ptr, slot=0):
         n = C.c_uint64()
-        _check(lib().mc_shard_keep(self._h, answers_back_ptr, C.byref(n)), "mc_shard_keep")
+        _check(lib().mc_shard_keep_slot(self._h, slot, answers_back_ptr, C.byref(n)), "mc_shard_keep")
         return n.value
 
     def shard_end_level(self):

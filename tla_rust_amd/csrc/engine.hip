@@ -814,9 +814,12 @@ k_send_materialise(typename S::Params prm, const uint64_t *__restrict__ arena, u
 // (only fingerprints travelled); `list` holds the compacted sources of the positive answers
 template <class S>
 __global__ void __launch_bounds__(256)
-k_materialise_list(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint32_t *__restrict__ list, uint64_t n,
-                   uint64_t out0, uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr) {
+k_materialise_list(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint32_t *__restrict__ list,
+                   const uint32_t *__restrict__ n_dev, uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot,
+                   DevCounters *ctr) {
+    // n (= last element of the inclusive scan) and the output base stay on the device: no host round trip per round
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = *n_dev, out0 = ctr->arena_next;
     if (j >= n) return;
     const uint32_t src = list[j];
     const uint64_t pidx = chunk_base + (src & 0xffffffu), oidx = out0 + j;
@@ -827,18 +830,23 @@ k_materialise_list(typename S::Params prm, uint64_t *arena, uint64_t chunk_base,
 }
 // owner side: append the `n` states of one received bucket (blocked layout) to the arena
 static __global__ void __launch_bounds__(256)
-k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv_blocks, uint64_t n, uint64_t out0, uint64_t arena_cap,
+k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv_blocks, uint64_t n, uint64_t arena_cap,
          uint32_t *__restrict__ parent, DevCounters *ctr) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const uint64_t oidx = out0 + j;
+    const uint64_t oidx = ctr->arena_next + j;
     if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); return; }
     const WordRef o = arena_ref(arena, oidx, words);
     const uint64_t *src = recv_blocks + (j >> 6) * (uint64_t)words * 64 + (j & 63);
     for (int w = 0; w < words; w++) o.set(w, src[(uint64_t)w * 64]);
     if (parent) parent[oidx] = 0xfffffffeu;  // produced on another rank: no local parent
 }
-static __global__ void k_set_arena_next(DevCounters *ctr, unsigned long long v) { ctr->arena_next = v; }
+// runs alone on its stream after the kernel that appended: arena_next += n (n on the device when n_dev != null)
+static __global__ void k_bump_arena_next(DevCounters *ctr, const uint32_t *n_dev, unsigned long long n, unsigned long long arena_cap) {
+    const unsigned long long v = ctr->arena_next + (n_dev ? (unsigned long long)*n_dev : n);
+    if (v > arena_cap) atomicOr(&ctr->error, DEV_EARENA);
+    else ctr->arena_next = v;
+}
 static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
     unsigned long long n = 0;
     for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[parity * NSHARD + t].v; ctr->n_new[parity * NSHARD + t].v = 0; }
@@ -856,11 +864,13 @@ struct EngineBase {
     virtual int debug_reexpand(unsigned extra_flags, double *ms) = 0;
     virtual int shard_begin() = 0;
     virtual int shard_level_size(uint64_t *n) = 0;
-    virtual int shard_expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
+    virtual int shard_set_stream(void *hip_stream, int enable) = 0;
+    virtual int shard_expand_launch(unsigned slot, uint64_t first, uint64_t count, uint64_t send_cap) = 0;
+    virtual int shard_expand_finish(unsigned slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int shard_probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) = 0;
-    virtual int shard_materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
+    virtual int shard_materialise(unsigned slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int shard_ingest(const uint8_t *recv_states, uint64_t n) = 0;
-    virtual int shard_keep(const uint8_t *answers_back, uint64_t *n_new) = 0;
+    virtual int shard_keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) = 0;
     virtual int shard_end_level(uint64_t *new_local) = 0;
     virtual int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
 };
@@ -962,8 +972,15 @@ struct Engine : EngineBase {
         if (d_newlist) hipFree(d_newlist);
         if (d_nsl) hipFree(d_nsl);
         if (d_inittmp) hipFree(d_inittmp);
-        if (d_rt_fp) { hipFree(d_rt_fp); hipFree(d_rt_src); hipFree(d_pend_src); hipFree(d_new_src); hipFree(d_incl); }
-        if (d_rt_cur) hipFree(d_rt_cur);
+        for (auto &q : sl) {
+            if (q.rt_fp) { hipFree(q.rt_fp); hipFree(q.rt_src); hipFree(q.pend_src); }
+            if (q.rt_cur) hipFree(q.rt_cur);
+        }
+        if (d_new_src) { hipFree(d_new_src); hipFree(d_incl); }
+        if (d_ends) { hipFree(d_ends); hipHostFree(h_ends); hipHostFree(h_cur); }
+        for (auto &ev : ev_slot) if (ev) hipEventDestroy(ev);
+        for (auto &ev : ev_keep) if (ev) hipEventDestroy(ev);
+        if (ev_ans) hipEventDestroy(ev_ans);
         if (d_scan_tmp) hipFree(d_scan_tmp);
         if (d_parent) hipFree(d_parent);
         if (d_pslot) hipFree(d_pslot);
@@ -1246,27 +1263,58 @@ struct Engine : EngineBase {
     }
     // ------------------------------------------------------------------ sharded step API
     uint64_t sh_lo = 0, sh_hi = 0, sh_next = 0;  // local frontier [sh_lo, sh_hi), arena fill level
-    uint64_t *d_rt_fp = nullptr;
-    uint32_t *d_rt_src = nullptr, *d_pend_src = nullptr, *d_new_src = nullptr, *d_incl = nullptr;
+    // Two expand slots: the route-mode expand of chunk r+1 (on `stream`) overlaps the exchange, probe and keep /
+    // materialise of chunk r (kernels on `stream2`, collectives on the caller's stream).
+    struct ShSlot {
+        uint64_t *rt_fp = nullptr;
+        uint32_t *rt_src = nullptr, *pend_src = nullptr;
+        PaddedCounter *rt_cur = nullptr;  // [nranks*NSHARD] route cursors
+        uint64_t rt_subcap = 0, pend_cap = 0, pend_total = 0, chunk_base = 0, count = 0;
+        OwnerOffsets pend_off;
+        bool launched = false, keep_pending = false;
+    } sl[2];
+    uint32_t *d_new_src = nullptr, *d_incl = nullptr;
+    uint64_t new_cap = 0;
+    unsigned long long *d_ends = nullptr, *h_ends = nullptr;
+    PaddedCounter *h_cur = nullptr;  // pinned copy of one slot's route cursors
     void *d_scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
-    PaddedCounter *d_rt_cur = nullptr;  // [nranks*NSHARD] route cursors, then [nranks] answer counts, then [nranks] state cursors
-    uint64_t rt_subcap = 0, pend_cap = 0, pend_total = 0, sh_chunk_base = 0;
-    OwnerOffsets pend_off;
     unsigned nranks() const { return cfg.shard_count > 1 ? cfg.shard_count : 1; }
 
-    int shard_alloc(uint64_t send_cap) {
-        if (send_cap <= pend_cap) return MC_OK;
-        if (d_rt_fp) { hipFree(d_rt_fp); hipFree(d_rt_src); hipFree(d_pend_src); hipFree(d_new_src); hipFree(d_incl); }
+    int shard_alloc(ShSlot &q, uint64_t send_cap) {
         const unsigned P = nranks();
-        rt_subcap = (send_cap / (P * NSHARD)) * 2 + 4096;
-        HIP_TRY(hipMalloc(&d_rt_fp, (size_t)P * NSHARD * rt_subcap * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&d_rt_src, (size_t)P * NSHARD * rt_subcap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&d_pend_src, send_cap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&d_new_src, send_cap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&d_incl, send_cap * sizeof(uint32_t)));
-        if (!d_rt_cur) HIP_TRY(hipMalloc(&d_rt_cur, (size_t)(P * NSHARD + 2 * P) * sizeof(PaddedCounter)));
-        pend_cap = send_cap;
+        if (send_cap > q.pend_cap) {
+            if (q.rt_fp) { hipFree(q.rt_fp); hipFree(q.rt_src); hipFree(q.pend_src); q.rt_fp = nullptr; }
+            q.rt_subcap = (send_cap / (P * NSHARD)) * 2 + 4096;
+            HIP_TRY(hipMalloc(&q.rt_fp, (size_t)P * NSHARD * q.rt_subcap * sizeof(uint64_t)));
+            HIP_TRY(hipMalloc(&q.rt_src, (size_t)P * NSHARD * q.rt_subcap * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&q.pend_src, send_cap * sizeof(uint32_t)));
+            q.pend_cap = send_cap;
+        }
+        if (!q.rt_cur) HIP_TRY(hipMalloc(&q.rt_cur, (size_t)(P * NSHARD) * sizeof(PaddedCounter)));
+        if (send_cap > new_cap) {
+            if (d_new_src) { hipFree(d_new_src); hipFree(d_incl); d_new_src = nullptr; }
+            HIP_TRY(hipMalloc(&d_new_src, send_cap * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&d_incl, send_cap * sizeof(uint32_t)));
+            new_cap = send_cap;
+        }
+        if (!d_ends) {
+            HIP_TRY(hipMalloc(&d_ends, 8 * sizeof(unsigned long long)));
+            HIP_TRY(hipHostMalloc(&h_ends, 8 * sizeof(unsigned long long)));
+            HIP_TRY(hipHostMalloc(&h_cur, (size_t)8 * NSHARD * sizeof(PaddedCounter)));
+        }
+        return MC_OK;
+    }
+    int scan_answers(const uint8_t *answers_back, uint64_t n, hipStream_t on) {
+        hipcub::TransformInputIterator<uint32_t, AnswerCast, const uint8_t *> in(answers_back, AnswerCast());
+        size_t need = 0;
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, need, in, d_incl, (int)n, on));
+        if (need > scan_tmp_bytes) {
+            if (d_scan_tmp) hipFree(d_scan_tmp);
+            HIP_TRY(hipMalloc(&d_scan_tmp, need));
+            scan_tmp_bytes = need;
+        }
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_scan_tmp, need, in, d_incl, (int)n, on));
         return MC_OK;
     }
     int shard_begin() override {
@@ -1295,77 +1343,113 @@ struct Engine : EngineBase {
         return MC_OK;
     }
     int shard_level_size(uint64_t *n) override { *n = sh_hi - sh_lo; return MC_OK; }
-    int shard_expand(uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) override {
+    // Side stream of the sharded path.  By default the engine's own second stream, and every step call returns
+    // with its work finished.  A caller that runs its collectives on a HIP stream hands that stream over with
+    // shard_set_stream: compaction / probe / keep / materialise / ingest are then enqueued on it WITHOUT host
+    // synchronisation (stream order ties them to the caller's all-to-alls), and only the calls that must return
+    // counts to the host wait.
+    hipStream_t ext_stream = nullptr;
+    bool ext_side = false;
+    hipEvent_t ev_slot[2] = {nullptr, nullptr}, ev_keep[2] = {nullptr, nullptr}, ev_ans = nullptr;
+    hipStream_t side() const { return ext_side ? ext_stream : stream2; }
+    int side_done() {
+        if (!ext_side) HIP_TRY(hipStreamSynchronize(stream2));
+        return MC_OK;
+    }
+    int shard_set_stream(void *hip_stream, int enable) override {
         HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipStreamSynchronize(side()));
+        ext_stream = (hipStream_t)hip_stream;
+        ext_side = enable != 0;
+        return MC_OK;
+    }
+    int shard_expand_launch(unsigned slot, uint64_t first, uint64_t count, uint64_t send_cap) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (slot > 1) { set_error("shard_expand: slot must be 0 or 1"); return MC_EBADCFG; }
+        ShSlot &q = sl[slot];
         const unsigned P = nranks();
-        int rc = shard_alloc(send_cap);
+        int rc = shard_alloc(q, send_cap);
         if (rc) return rc;
-        for (unsigned t = 0; t < P; t++) send_counts[t] = 0;
-        pend_total = 0;
-        for (unsigned t = 0; t <= 8; t++) pend_off.off[t] = 0;
+        q.pend_total = 0;
+        q.count = count;
+        q.launched = true;
+        for (unsigned t = 0; t <= 8; t++) q.pend_off.off[t] = 0;
         if (first + count > sh_hi - sh_lo) { set_error("shard_expand: chunk outside the local frontier"); return MC_EBADCFG; }
         if (count > chunk) { set_error("shard_expand: chunk larger than chunk_states"); return MC_EBADCFG; }
         if (!count) return MC_OK;
-        HIP_TRY(hipMemsetAsync(d_rt_cur, 0, (size_t)(P * NSHARD + 2 * P) * sizeof(PaddedCounter), stream));
+        if (!ev_slot[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_slot[slot], hipEventDisableTiming));
+        else HIP_TRY(hipStreamWaitEvent(stream, ev_slot[slot], 0));  // the slot's previous buckets have been compacted
+        HIP_TRY(hipMemsetAsync(q.rt_cur, 0, (size_t)(P * NSHARD) * sizeof(PaddedCounter), stream));
         const uint64_t c0 = sh_lo + first, c1 = c0 + count, base = c0 & ~63ull;
         const uint64_t ncols = ((c1 - base) + 63) & ~63ull;
-        sh_chunk_base = base;
-        RouteArgs rt{P, d_rt_cur, d_rt_fp, d_rt_src, rt_subcap};
+        q.chunk_base = base;
+        RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
         timed(0, count, [&] {
             launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
                                    (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
         });
-        std::vector<PaddedCounter> cur(P * NSHARD);
-        HIP_TRY(hipMemcpyAsync(cur.data(), d_rt_cur, cur.size() * sizeof(PaddedCounter), hipMemcpyDeviceToHost, stream));
-        if ((rc = read_counters())) return rc;
+        return MC_OK;
+    }
+    int shard_expand_finish(unsigned slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (slot > 1 || !sl[slot].launched) { set_error("shard_expand_finish: no expand in flight for this slot"); return MC_EBADCFG; }
+        ShSlot &q = sl[slot];
+        q.launched = false;
+        const unsigned P = nranks();
+        for (unsigned t = 0; t < P; t++) send_counts[t] = 0;
+        if (!q.count) return MC_OK;
+        // one wait on the expand stream only: the side stream may still be busy with the previous round
+        PaddedCounter *cur = h_cur;
+        HIP_TRY(hipMemcpyAsync(cur, q.rt_cur, (size_t)(P * NSHARD) * sizeof(PaddedCounter), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        int rc;
         if ((rc = check_dev_error())) return rc;
         uint64_t total = 0;
         for (unsigned t = 0; t < P; t++) {
-            pend_off.off[t] = total;
+            q.pend_off.off[t] = total;
             for (unsigned x = 0; x < NSHARD; x++) {
-                if (cur[t * NSHARD + x].v > rt_subcap) { set_error("shard_expand: route bucket overflow (raise send_cap)"); return MC_EARENA; }
+                if (cur[t * NSHARD + x].v > q.rt_subcap) { set_error("shard_expand: route bucket overflow (raise send_cap)"); return MC_EARENA; }
                 send_counts[t] += cur[t * NSHARD + x].v;
             }
             total += send_counts[t];
         }
-        for (unsigned t = P; t <= 8; t++) pend_off.off[t] = total;
-        if (total > send_cap || total >= (1ull << 31)) { set_error("shard_expand: send buffer too small"); return MC_EARENA; }
-        pend_total = total;
-        if (total) {
-            hipLaunchKernelGGL(k_compact_buckets, dim3(64, P * NSHARD), dim3(256), 0, stream, rt, send_fp, d_pend_src);
-            HIP_TRY(hipStreamSynchronize(stream));
+        for (unsigned t = P; t <= 8; t++) q.pend_off.off[t] = total;
+        if (total > send_cap || total > q.pend_cap || total >= (1ull << 31)) { set_error("shard_expand: send buffer too small"); return MC_EARENA; }
+        q.pend_total = total;
+        if (q.keep_pending) {  // the slot's previous keep still reads pend_src
+            HIP_TRY(hipStreamWaitEvent(side(), ev_keep[slot], 0));
+            q.keep_pending = false;
         }
-        return MC_OK;
+        if (total) {
+            RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
+            hipLaunchKernelGGL(k_compact_buckets, dim3(64, P * NSHARD), dim3(256), 0, side(), rt, send_fp, q.pend_src);
+        }
+        HIP_TRY(hipEventRecord(ev_slot[slot], side()));
+        return side_done();
     }
     int shard_probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) override {
         HIP_TRY(hipSetDevice(cfg.device));
         if (!n) return MC_OK;
         timed(1, n, [&] {
-            hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, recv_fp, n, d_table, table_cap - 1, answers, d_ctr);
-        });
-        HIP_TRY(hipStreamSynchronize(stream));
-        return MC_OK;
+            hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, side(), recv_fp, n, d_table, table_cap - 1, answers, d_ctr);
+        }, side());
+        return side_done();
     }
-    int shard_materialise(const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
+    int shard_materialise(unsigned slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
         HIP_TRY(hipSetDevice(cfg.device));
+        if (slot > 1) return MC_EBADCFG;
+        ShSlot &q = sl[slot];
         const unsigned P = nranks();
         for (unsigned t = 0; t < P; t++) send_counts[t] = 0;
-        if (!pend_total) return MC_OK;
-        const unsigned bx = (unsigned)((pend_total + 255) / 256);
-        hipcub::TransformInputIterator<uint32_t, AnswerCast, const uint8_t *> in(answers_back, AnswerCast());
-        size_t need = 0;
-        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, need, in, d_incl, (int)pend_total, stream));
-        if (need > scan_tmp_bytes) {
-            if (d_scan_tmp) hipFree(d_scan_tmp);
-            HIP_TRY(hipMalloc(&d_scan_tmp, need));
-            scan_tmp_bytes = need;
-        }
-        HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_scan_tmp, need, in, d_incl, (int)pend_total, stream));
-        unsigned long long *d_ends = (unsigned long long *)(d_rt_cur + P * NSHARD);
-        hipLaunchKernelGGL(k_gather_range_ends, dim3(1), dim3(64), 0, stream, d_incl, pend_off, P, d_ends);
-        unsigned long long ends[8];
-        HIP_TRY(hipMemcpyAsync(ends, d_ends, P * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        if (!q.pend_total) return MC_OK;
+        const unsigned bx = (unsigned)((q.pend_total + 255) / 256);
+        int rc = scan_answers(answers_back, q.pend_total, side());
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather_range_ends, dim3(1), dim3(64), 0, side(), d_incl, q.pend_off, P, d_ends);
+        unsigned long long *ends = h_ends;  // the per-owner counts go back to the host: the caller sizes its all-to-all with them
+        HIP_TRY(hipMemcpyAsync(ends, d_ends, P * sizeof(unsigned long long), hipMemcpyDeviceToHost, side()));
+        HIP_TRY(hipStreamSynchronize(side()));
         OwnerOffsets start;
         std::vector<PaddedCounter> cnt(P);
         for (unsigned t = 0; t <= 8; t++) start.off[t] = 0;
@@ -1373,7 +1457,7 @@ struct Engine : EngineBase {
             start.off[t] = t ? ends[t - 1] : 0;
             cnt[t].v = ends[t] - start.off[t];
         }
-        hipLaunchKernelGGL(k_compact_new, dim3(bx), dim3(256), 0, stream, answers_back, d_incl, d_pend_src, pend_total, pend_off, start, P,
+        hipLaunchKernelGGL(k_compact_new, dim3(bx), dim3(256), 0, side(), answers_back, d_incl, q.pend_src, q.pend_total, q.pend_off, start, P,
                            d_new_src);
         BlockPlan plan;
         uint64_t blocks = 0;
@@ -1387,48 +1471,50 @@ struct Engine : EngineBase {
         if (blocks * 64 > send_cap) { set_error("shard_materialise: state send buffer too small"); return MC_EARENA; }
         if (blocks) {
             timed(2, blocks * 64, [&] {
-                hipLaunchKernelGGL(k_send_materialise<S>, dim3((unsigned)((blocks * 64 + 255) / 256)), dim3(256), 0, stream, prm, d_arena,
-                                   sh_chunk_base, d_new_src, pend_off, plan, P, (uint64_t *)send_states);
-            });
+                hipLaunchKernelGGL(k_send_materialise<S>, dim3((unsigned)((blocks * 64 + 255) / 256)), dim3(256), 0, side(), prm, d_arena,
+                                   q.chunk_base, d_new_src, q.pend_off, plan, P, (uint64_t *)send_states);
+            }, side());
         }
-        HIP_TRY(hipStreamSynchronize(stream));
-        return MC_OK;
+        return side_done();
     }
-    // "stay" mode: materialise the positively answered candidates of the last shard_expand into the LOCAL arena
-    int shard_keep(const uint8_t *answers_back, uint64_t *n_new) override {
+    // "stay" mode: materialise the positively answered candidates of slot's expand into the LOCAL arena.
+    // The count of new states stays on the device (arena_next); the host learns it at shard_end_level.
+    int shard_keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) override {
         HIP_TRY(hipSetDevice(cfg.device));
-        *n_new = 0;
-        if (!pend_total) return MC_OK;
-        const unsigned P = nranks();
-        const unsigned bx = (unsigned)((pend_total + 255) / 256);
-        hipcub::TransformInputIterator<uint32_t, AnswerCast, const uint8_t *> in(answers_back, AnswerCast());
-        size_t need = 0;
-        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, need, in, d_incl, (int)pend_total, stream));
-        if (need > scan_tmp_bytes) {
-            if (d_scan_tmp) hipFree(d_scan_tmp);
-            HIP_TRY(hipMalloc(&d_scan_tmp, need));
-            scan_tmp_bytes = need;
+        if (n_new) *n_new = 0;
+        if (slot > 1) return MC_EBADCFG;
+        ShSlot &q = sl[slot];
+        if (!q.pend_total) return MC_OK;
+        const unsigned bx = (unsigned)((q.pend_total + 255) / 256);
+        // keep runs on the engine's own second stream, behind the caller's stream at this point (the answers
+        // are ready there), so the caller's next exchange does not queue behind the materialisation
+        hipStream_t ks = stream2;
+        if (ext_side) {
+            if (!ev_ans) HIP_TRY(hipEventCreateWithFlags(&ev_ans, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ev_ans, ext_stream));
+            HIP_TRY(hipStreamWaitEvent(ks, ev_ans, 0));
         }
-        HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_scan_tmp, need, in, d_incl, (int)pend_total, stream));
-        uint32_t total32 = 0;
-        HIP_TRY(hipMemcpyAsync(&total32, d_incl + (pend_total - 1), sizeof total32, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        const uint64_t total = total32;
-        if (!total) return MC_OK;
-        if (sh_next + total > arena_cap) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }
+        int rc = scan_answers(answers_back, q.pend_total, ks);
+        if (rc) return rc;
+        const uint32_t *d_total = d_incl + (q.pend_total - 1);
         OwnerOffsets one, zero;  // a single range covering every pending candidate
-        for (unsigned t = 0; t <= 8; t++) { one.off[t] = t ? pend_total : 0; zero.off[t] = 0; }
-        hipLaunchKernelGGL(k_compact_new, dim3(bx), dim3(256), 0, stream, answers_back, d_incl, d_pend_src, pend_total, one, zero, 1u, d_new_src);
-        timed(2, total, [&] {
-            hipLaunchKernelGGL(k_materialise_list<S>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, prm, d_arena, sh_chunk_base,
-                               d_new_src, total, sh_next, arena_cap, d_parent, d_pslot, d_ctr);
-        });
-        sh_next += total;
-        hipLaunchKernelGGL(k_set_arena_next, dim3(1), dim3(1), 0, stream, d_ctr, (unsigned long long)sh_next);
-        HIP_TRY(hipStreamSynchronize(stream));
-        last_distinct = sh_next;
-        *n_new = total;
-        (void)P;
+        for (unsigned t = 0; t <= 8; t++) { one.off[t] = t ? q.pend_total : 0; zero.off[t] = 0; }
+        hipLaunchKernelGGL(k_compact_new, dim3(bx), dim3(256), 0, ks, answers_back, d_incl, q.pend_src, q.pend_total, one, zero, 1u, d_new_src);
+        // grid sized for the upper bound (every candidate new); surplus threads leave at once
+        timed(2, 0, [&] {
+            hipLaunchKernelGGL(k_materialise_list<S>, dim3(bx), dim3(256), 0, ks, prm, d_arena, q.chunk_base, d_new_src, d_total, arena_cap,
+                               d_parent, d_pslot, d_ctr);
+        }, ks);
+        hipLaunchKernelGGL(k_bump_arena_next, dim3(1), dim3(1), 0, ks, d_ctr, d_total, 0ull, (unsigned long long)arena_cap);
+        if (!ev_keep[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_keep[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_keep[slot], ks));
+        q.keep_pending = true;
+        if (!ext_side) {
+            uint32_t total32 = 0;
+            HIP_TRY(hipMemcpyAsync(&total32, d_total, sizeof total32, hipMemcpyDeviceToHost, ks));
+            HIP_TRY(hipStreamSynchronize(ks));
+            if (n_new) *n_new = total32;
+        }
         return MC_OK;
     }
     // recv_states: one bucket per source rank, back to back, each a whole number of 64-state blocks;
@@ -1436,16 +1522,22 @@ struct Engine : EngineBase {
     int shard_ingest(const uint8_t *recv_states, uint64_t n) override {
         HIP_TRY(hipSetDevice(cfg.device));
         if (!n) return MC_OK;
-        if (sh_next + n > arena_cap) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }
-        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_arena, W, (const uint64_t *)recv_states, n,
-                           sh_next, arena_cap, d_parent, d_ctr);
-        sh_next += n;
-        hipLaunchKernelGGL(k_set_arena_next, dim3(1), dim3(1), 0, stream, d_ctr, (unsigned long long)sh_next);
-        HIP_TRY(hipStreamSynchronize(stream));
-        last_distinct = sh_next;
-        return MC_OK;
+        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, side(), d_arena, W, (const uint64_t *)recv_states, n,
+                           arena_cap, d_parent, d_ctr);
+        hipLaunchKernelGGL(k_bump_arena_next, dim3(1), dim3(1), 0, side(), d_ctr, (const uint32_t *)nullptr, (unsigned long long)n,
+                           (unsigned long long)arena_cap);
+        return side_done();
     }
     int shard_end_level(uint64_t *new_local) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (sl[0].launched || sl[1].launched) { set_error("shard_end_level: an expand is still in flight"); return MC_EBADCFG; }
+        HIP_TRY(hipStreamSynchronize(side()));
+        HIP_TRY(hipStreamSynchronize(stream2));
+        int rc = read_counters();
+        if (rc) return rc;
+        if ((rc = check_dev_error())) return rc;
+        sh_next = h_ctr->arena_next;
+        last_distinct = sh_next;
         sh_lo = sh_hi;
         sh_hi = sh_next;
         *new_local = sh_hi - sh_lo;
@@ -1453,12 +1545,13 @@ struct Engine : EngineBase {
     }
     int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) override {
         HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipStreamSynchronize(side()));
         int rc = read_counters();
         if (rc) return rc;
         if ((rc = check_dev_error())) return rc;
         *generated = 0;
         for (int t = 0; t < NSHARD; t++) *generated += h_ctr->generated[t].v;
-        *distinct_local = sh_next;
+        *distinct_local = h_ctr->arena_next;
         *verdict = MC_V_OK;
         if (h_ctr->viol_key != ~0ull) {
             const unsigned kind = (unsigned)(h_ctr->viol_key & 7u);
@@ -1643,16 +1736,32 @@ int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms) { r
 int mc_shard_begin(mc_engine *e) { return e ? e->impl->shard_begin() : MC_EBADCFG; }
 int mc_shard_level_size(mc_engine *e, uint64_t *n) { return e && n ? e->impl->shard_level_size(n) : MC_EBADCFG; }
 int mc_shard_expand(mc_engine *e, uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) {
-    return e && send_counts ? e->impl->shard_expand(first, count, send_fp, send_cap, send_counts) : MC_EBADCFG;
+    if (!e || !send_counts) return MC_EBADCFG;
+    const int rc = e->impl->shard_expand_launch(0, first, count, send_cap);
+    return rc ? rc : e->impl->shard_expand_finish(0, send_fp, send_cap, send_counts);
+}
+int mc_shard_set_stream(mc_engine *e, void *hip_stream, int enable) { return e ? e->impl->shard_set_stream(hip_stream, enable) : MC_EBADCFG; }
+int mc_shard_expand_launch(mc_engine *e, uint32_t slot, uint64_t first, uint64_t count, uint64_t send_cap) {
+    return e ? e->impl->shard_expand_launch(slot, first, count, send_cap) : MC_EBADCFG;
+}
+int mc_shard_expand_finish(mc_engine *e, uint32_t slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) {
+    return e && send_counts ? e->impl->shard_expand_finish(slot, send_fp, send_cap, send_counts) : MC_EBADCFG;
 }
 int mc_shard_probe(mc_engine *e, const uint64_t *recv_fp, uint64_t n, uint8_t *answers) {
     return e ? e->impl->shard_probe(recv_fp, n, answers) : MC_EBADCFG;
 }
 int mc_shard_materialise(mc_engine *e, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) {
-    return e && send_counts ? e->impl->shard_materialise(answers_back, send_states, send_cap, send_counts) : MC_EBADCFG;
+    return e && send_counts ? e->impl->shard_materialise(0, answers_back, send_states, send_cap, send_counts) : MC_EBADCFG;
+}
+int mc_shard_materialise_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap,
+                              uint64_t *send_counts) {
+    return e && send_counts ? e->impl->shard_materialise(slot, answers_back, send_states, send_cap, send_counts) : MC_EBADCFG;
 }
 int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n) { return e ? e->impl->shard_ingest(recv_states, n) : MC_EBADCFG; }
-int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new) { return e && n_new ? e->impl->shard_keep(answers_back, n_new) : MC_EBADCFG; }
+int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new) { return e && n_new ? e->impl->shard_keep(0, answers_back, n_new) : MC_EBADCFG; }
+int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t *n_new) {
+    return e ? e->impl->shard_keep(slot, answers_back, n_new) : MC_EBADCFG;
+}
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local) { return e && new_local ? e->impl->shard_end_level(new_local) : MC_EBADCFG; }
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) {
     return e && generated && distinct_local && verdict ? e->impl->shard_counters(generated, distinct_local, verdict) : MC_EBADCFG;

@@ -4,7 +4,7 @@ torch.distributed all-to-all (backend "nccl" = RCCL over xGMI).
 
 Per BFS level every rank walks its local frontier in rounds of `chunk_states`; a round is
 
-    expand       frontier chunk -> candidate FINGERPRINTS bucketed by owner        (mc_shard_expand)
+    expand       frontier chunk -> candidate FINGERPRINTS bucketed by owner        (mc_shard_expand_launch/_finish)
     all-to-all   8 bytes per generated, in-model successor
     probe        owner inserts them in its seen-set slice, answers 1 byte each      (mc_shard_probe)
     all-to-all   answers, reversed
@@ -14,6 +14,8 @@ Per BFS level every rank walks its local frontier in rounds of `chunk_states`; a
 
 so states live on the rank that owns their fingerprint (balanced), and xGMI carries
 8*(G/D) + 1*(G/D) + W bytes per distinct state instead of (W+8)*(G/D).
+Rounds are software-pipelined over two expand slots: while round r's buckets are exchanged, probed and
+materialised (engine side stream + the collective stream), round r+1's expand already runs.
 Ranks with a shorter frontier take part in every round with empty buckets: the number of rounds
 per level is the all-reduced maximum.
 
@@ -37,6 +39,12 @@ class HipStepEngine:
         self.W = state_bytes(spec, params)
         self.eng = Engine(spec, params, device=device, table_capacity=table_capacity, arena_capacity=arena_capacity,
                           chunk_states=chunk_states, trace=False, timing=False, shard_rank=rank, shard_count=world)
+        # the stream the collectives are issued on; the engine enqueues its side work on it without host syncs
+        self.stream = torch.cuda.Stream(self.device)
+        self.eng.shard_set_stream(self.stream.cuda_stream)
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
 
     def begin(self):
         self.eng.shard_begin()
@@ -44,20 +52,23 @@ class HipStepEngine:
     def level_size(self):
         return self.eng.shard_level_size()
 
-    def expand(self, first, count, send_fp):
-        return self.eng.shard_expand(first, count, send_fp.data_ptr(), send_fp.numel())
+    def expand_launch(self, slot, first, count, send_cap):
+        self.eng.shard_expand_launch(slot, first, count, send_cap)
+
+    def expand_finish(self, slot, send_fp):
+        return self.eng.shard_expand_finish(slot, send_fp.data_ptr(), send_fp.numel())
 
     def probe(self, recv_fp, n, answers):
         self.eng.shard_probe(recv_fp.data_ptr(), n, answers.data_ptr())
 
-    def materialise(self, answers_back, send_states):
-        return self.eng.shard_materialise(answers_back.data_ptr(), send_states.data_ptr(), send_states.numel() // self.W)
+    def materialise(self, slot, answers_back, send_states):
+        return self.eng.shard_materialise(answers_back.data_ptr(), send_states.data_ptr(), send_states.numel() // self.W, slot)
 
     def ingest(self, recv_states, n):
         self.eng.shard_ingest(recv_states.data_ptr(), n)
 
-    def keep(self, answers_back):
-        return self.eng.shard_keep(answers_back.data_ptr())
+    def keep(self, slot, answers_back):
+        return self.eng.shard_keep(answers_back.data_ptr(), slot)
 
     def end_level(self):
         return self.eng.shard_end_level()
@@ -66,7 +77,7 @@ class HipStepEngine:
         return self.eng.shard_counters()
 
     def sync(self):
-        torch.cuda.current_stream(self.device).synchronize()
+        self.stream.synchronize()
 
     def close(self):
         self.eng.close()
@@ -95,7 +106,8 @@ class ShardedChecker:
         backend = dist.get_backend(group) if dist.is_initialized() else None
         # gloo moves CPU tensors only: stage device buffers through the host for it
         self.comm_dev = torch.device("cpu") if backend == "gloo" else self.dev
-        self.send_fp = torch.empty(chunk_states * fanout_cap, dtype=torch.int64, device=self.dev)
+        # two expand slots: the expand of round r+1 runs while round r is exchanged, probed and kept
+        self.send_fp = [torch.empty(chunk_states * fanout_cap, dtype=torch.int64, device=self.dev) for _ in range(2)]
         self.send_states = torch.empty(chunk_states * new_cap * self.W, dtype=torch.uint8, device=self.dev)
 
     # ---------------------------------------------------------------- collectives
@@ -139,68 +151,94 @@ class ShardedChecker:
         dist.all_to_all_single(recv, src, list(recv_counts), list(send_counts), group=self.group)
         return recv.to(self.dev)
 
+    def _level_info(self, local_n, verdict):
+        """ONE collective per level: every rank learns every rank's frontier size and the worst verdict."""
+        if not self.collective:
+            return [int(local_n)], int(verdict)
+        t = torch.tensor([int(local_n), int(verdict)], dtype=torch.int64, device=self.comm_dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        rows = [o.tolist() for o in out]
+        return [int(r[0]) for r in rows], max(int(r[1]) for r in rows)
+
     # ---------------------------------------------------------------- BFS
     def run(self):
+        with self.eng.stream_ctx():
+            return self._run()
+
+    def _run(self):
         e, SUM, MAX = self.eng, dist.ReduceOp.SUM, dist.ReduceOp.MAX
-        self.phase_s = {}   # wall seconds per phase of the last run (this rank)
+        prof = bool(os.environ.get("TLAMC_PHASES"))     # per-phase wall clock: adds host syncs, off by default
+        self.phase_s = ph = {}
+
+        def tick(key, t_prev):
+            if not prof:
+                return t_prev
+            e.sync()
+            now = time.perf_counter()
+            ph[key] = ph.get(key, 0.0) + now - t_prev
+            return now
+
         e.begin()
-        frontier = self._allreduce(e.level_size(), SUM)
+        sizes, verdict = self._level_info(e.level_size(), e.counters()[2])
+        frontier = sum(sizes)
         levels, cum, level, budget = [frontier], frontier, 1, False
         while frontier > 0:
-            _, _, verdict = e.counters()
-            if self._allreduce(verdict, MAX) != 0:
+            if verdict != 0:
                 break
             if (self.max_levels and level >= self.max_levels) or (self.max_distinct and cum >= self.max_distinct):
                 budget = True
                 break
-            local_n = e.level_size()
-            rounds = self._allreduce(math.ceil(local_n / self.chunk), MAX)
-            biggest = self._allreduce(local_n, MAX)
-            stay = frontier >= self.stay_threshold * self.world and biggest * self.world <= self.rebalance_ratio * frontier
-            self.phase_s["stay_levels" if stay else "move_levels"] = self.phase_s.get("stay_levels" if stay else "move_levels", 0) + 1
-            for r in range(rounds):
+            local_n = sizes[self.rank] if self.collective else sizes[0]
+            rounds = max(math.ceil(n / self.chunk) for n in sizes)
+            stay = frontier >= self.stay_threshold * self.world and max(sizes) * self.world <= self.rebalance_ratio * frontier
+            ph["stay_levels" if stay else "move_levels"] = ph.get("stay_levels" if stay else "move_levels", 0) + 1
+            ph["rounds"] = ph.get("rounds", 0) + rounds
+
+            def launch(r):
                 first = min(r * self.chunk, local_n)
-                count = min(self.chunk, local_n - first)
-                t0 = time.perf_counter()
-                counts = e.expand(first, count, self.send_fp)
-                e.sync()
-                t1 = time.perf_counter()
-                recv_fp, rcounts = self._a2a(self.send_fp, counts, 1)
+                e.expand_launch(r & 1, first, min(self.chunk, local_n - first), self.send_fp[r & 1].numel())
+
+            hold = []
+            if rounds:
+                launch(0)
+            for r in range(rounds):
+                slot = r & 1
+                t = time.perf_counter()
+                counts = e.expand_finish(slot, self.send_fp[slot])     # waits for expand r only
+                if r + 1 < rounds:
+                    launch(r + 1)                                       # overlaps everything below
+                t = tick("expand_wait", t)
+                recv_fp, rcounts = self._a2a(self.send_fp[slot], counts, 1)
                 n = sum(rcounts)
                 answers = torch.empty(max(n, 1), dtype=torch.uint8, device=self.dev)
-                e.sync()
-                t2 = time.perf_counter()
+                t = tick("a2a_fp", t)
                 e.probe(recv_fp, n, answers)
-                t3 = time.perf_counter()
+                t = tick("probe", t)
                 back = self._a2a_back(answers, rcounts, counts)
-                e.sync()
-                t4 = time.perf_counter()
+                t = tick("a2a_ans", t)
                 if stay:
-                    e.keep(back)
-                    self.phase_s["keep"] = self.phase_s.get("keep", 0.0) + time.perf_counter() - t4
-                    self.phase_s["rounds"] = self.phase_s.get("rounds", 0) + 1
-                    for k, dt in zip(("expand", "a2a_fp", "probe", "a2a_ans"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
-                        self.phase_s[k] = self.phase_s.get(k, 0.0) + dt
+                    e.keep(slot, back)      # runs on the engine's own stream, behind this point of ours
+                    hold.append(back)       # ... so its input must outlive this round (freed after end_level)
+                    t = tick("keep", t)
                     continue
-                scounts = e.materialise(back, self.send_states)
-                t5 = time.perf_counter()
+                scounts = e.materialise(slot, back, self.send_states)
+                t = tick("materialise", t)
                 # full states travel as whole 64-state blocks per owner (coalesced at both ends)
                 blocks = [(c + 63) // 64 for c in scounts]
                 recv_states, rblocks = self._a2a(self.send_states, blocks, 64 * self.W)
                 rsc = self._exchange_counts(scounts)
-                e.sync()
-                t6 = time.perf_counter()
+                t = tick("a2a_states", t)
                 off = 0
                 for src_rank in range(len(rsc)):            # one bucket per source rank
                     if rsc[src_rank]:
                         e.ingest(recv_states[off * 64 * self.W:], rsc[src_rank])
                     off += rblocks[src_rank]
-                t7 = time.perf_counter()
-                for k, dt in zip(("expand", "a2a_fp", "probe", "a2a_ans", "materialise", "a2a_states", "ingest"),
-                                 (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6)):
-                    self.phase_s[k] = self.phase_s.get(k, 0.0) + dt
-                self.phase_s["rounds"] = self.phase_s.get("rounds", 0) + 1
-            frontier = self._allreduce(e.end_level(), SUM)
+                t = tick("ingest", t)
+            new_local = e.end_level()                       # waits for the engine's streams; arena fill level comes back
+            hold.clear()
+            sizes, verdict = self._level_info(new_local, e.counters()[2])
+            frontier = sum(sizes)
             if frontier > 0:
                 level += 1
                 levels.append(frontier)
@@ -210,8 +248,8 @@ class ShardedChecker:
         verdict = self._allreduce(verdict, MAX)
         if verdict == 0 and budget:
             verdict = 5
-        if os.environ.get("TLAMC_PHASES") and self.rank == 0:
-            print("phases[s]:", {k: round(v, 4) for k, v in self.phase_s.items()}, flush=True)
+        if prof and self.rank == 0:
+            print("phases[s]:", {k: round(v, 4) for k, v in ph.items()}, flush=True)
         return Result(distinct=cum, generated=generated, queue_left=frontier, depth=level, verdict=VERDICTS[verdict],
                       violated_invariant=-1, trace_len=0, levels=levels, seconds=0.0)
 
