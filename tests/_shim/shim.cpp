@@ -69,6 +69,33 @@ struct FamCheck {
 };
 template <class S>
 struct FamCheck<S, decltype((void)S::NFAM)> {
+    // analysis aid (SHIM_FAMSTATS=1): lane utilisation of the by-family expand for several tile sizes
+    struct Stats {
+        static constexpr int NT = 4;
+        uint64_t tile[NT][32] = {}, n_in_tile[NT] = {}, batches[NT] = {}, pairs = 0, fam_total[32] = {};
+        bool on = getenv("SHIM_FAMSTATS") != nullptr;
+        void state_done(const unsigned *c) {
+            for (int t = 0; t < NT; t++) {
+                for (int f = 0; f < S::NFAM; f++) tile[t][f] += c[f];
+                if (++n_in_tile[t] == (64u << t)) flush(t);
+            }
+            for (int f = 0; f < S::NFAM; f++) { pairs += c[f]; fam_total[f] += c[f]; }
+        }
+        void flush(int t) {
+            for (int f = 0; f < S::NFAM; f++) { batches[t] += (tile[t][f] + 63) / 64; tile[t][f] = 0; }
+            n_in_tile[t] = 0;
+        }
+        ~Stats() {
+            if (!on || !pairs) return;
+            for (int t = 0; t < NT; t++) {
+                flush(t);
+                fprintf(stderr, "famstats: tile %4u states: %llu batches, lane utilisation %.3f\n", 64u << t,
+                        (unsigned long long)batches[t], (double)pairs / (64.0 * (double)batches[t]));
+            }
+            for (int f = 0; f < S::NFAM; f++) fprintf(stderr, "famstats: family %2d: %.4f of pairs\n", f, (double)fam_total[f] / (double)pairs);
+        }
+    };
+    static Stats &stats() { static Stats st; return st; }
     template <int F, class Ref>
     static unsigned run(int fam, const typename S::Params &p, const typename S::Summary &q, Ref s, int slot, uint64_t &fp) {
         if constexpr (F < S::NFAM) {
@@ -85,6 +112,7 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
         typename S::Summary q;
         S::summarize(l, q);
         uint64_t bad = 0;
+        unsigned cnt[32] = {};
         for (int slot = 0; slot < ns; slot++) {
             uint64_t f0 = 0, f1 = 0;
             const unsigned st0 = S::eval(p, l, s, slot, f0);
@@ -93,7 +121,9 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
             else fam = S::guard_msg(g, s.get(S::W_MSG0 + (slot - S::FIX) / 3), (slot - S::FIX) % 3);
             const unsigned st1 = fam >= 0 ? run<0>(fam, p, q, s, slot, f1) : 0u;
             if (st0 != st1 || ((st0 & ST_ENABLED) && f0 != f1)) bad++;
+            if (fam >= 0) cnt[fam]++;
         }
+        if (stats().on) stats().state_done(cnt);
         return bad;
     }
 };
