@@ -55,6 +55,10 @@ extern "C" {
                                 64 Bernstein), find (0; 1..6 abort reason, 7 two waiters: ":81-96 expected"),
                                 textbook (1 = examples/textbookSnapshotIsolation.tla: no Cahill variables)}  */
 
+#define MC_SPEC_PCAL 5       /* a PlusCal algorithm compiled by mc_program_compile (any module of the supported subset,
+                                the reference's untranslated pcal_intro.tla:4-19 and atomic_add.tla:4-23 included);
+                                params {(int64) mc_program handle} — build the descriptor with mc_program_spec      */
+
 typedef struct {
     uint32_t spec_id;
     uint32_t nparams;
@@ -67,6 +71,8 @@ typedef struct {
 #define MC_F_MATRIX 8u   /* A/B only: unfused expand -> candidate matrix -> insert kernels          */
 #define MC_F_NOPROBE 16u /* profiling only (mc_engine_debug_reexpand): skip the seen-set probes   */
 #define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
+#define MC_F_GENERIC 128u /* mc_check_files: run a PlusCal module through the compiled program (MC_SPEC_PCAL) even
+                             when a hand lowering of its algorithm exists (A/B of the two paths)  */
 
 typedef struct {
     int32_t device;          /* HIP device ordinal                                              */
@@ -173,6 +179,23 @@ int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new);  
 int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t *n_new);
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local_states);  /* swap frontiers                                */
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict);
+
+/* ------------------------------------------------------------------ PlusCal front-end (host only)
+ * The reference's workflow is `pcal2tla *tla` then `tlc *tla` (Makefile:3-7).  mc_pcal_translate is the first
+ * half: it returns the module text with the TLA+ translation of its `--algorithm` inserted (p-manual.pdf App. B).
+ * mc_program_compile is what lets the checker run a PlusCal spec nobody hand-lowered: the algorithm (p-syntax;
+ * labels, := , if/elsif/else, while, either/or, with, await/when, assert, skip, goto; integers, booleans, strings,
+ * functions over constant sets) becomes a bytecode program every GPU lane interprets on its own packed state
+ * (tla_rust_amd/csrc/spec_vm.h).  cfg_text: CONSTANT(S) with integer / string / model-value / set values and
+ * INVARIANT(S) naming zero-argument definitions of the module; NULL = no constants, no invariants. */
+typedef struct mc_program mc_program;
+int mc_pcal_translate(const char *tla_text, char *out, size_t cap);   /* >= 0: bytes needed (NUL excluded); < 0: MC_E* */
+int mc_program_compile(const char *tla_text, const char *cfg_text, mc_program **out);
+int mc_program_spec(const mc_program *p, mc_spec_desc *out);          /* valid while p lives */
+const char *mc_program_translated(const mc_program *p);               /* the module text after translation */
+const char *mc_program_invariant(const mc_program *p, int index);     /* name of INVARIANT number index */
+int mc_program_assert_pos(const mc_program *p, int index, int *line, int *col);  /* source position of an assert */
+void mc_program_free(mc_program *p);
 
 /* ------------------------------------------------------------------ helpers (host only) */
 size_t mc_state_bytes(const mc_spec_desc *spec);                    /* W, 0 if the spec is invalid   */

@@ -34,7 +34,8 @@ vars == << global_counter, pc >>
 
 ProcSet == (1..2) \cup {3}
 
-Init == /\ global_counter = 0
+Init == (* Global variables *)
+        /\ global_counter = 0
         /\ pc = [self \in ProcSet |-> CASE self \in 1..2 -> "Increment"
                                         [] self = 3 -> "Check"]
 
@@ -59,5 +60,6 @@ Next == Checker
 Spec == Init /\ [][Next]_vars
 
 Termination == <>(\A self \in ProcSet: pc[self] = "Done")
+
 \* END TRANSLATION
 =============================================================================

@@ -31,7 +31,8 @@ vars == << global_counter, pc >>
 
 ProcSet == (1..N) \cup {N + 1}
 
-Init == /\ global_counter = 0
+Init == (* Global variables *)
+        /\ global_counter = 0
         /\ pc = [self \in ProcSet |-> CASE self \in 1..N -> "Increment"
                                         [] self = N + 1 -> "Check"]
 
@@ -50,8 +51,12 @@ Checker == Check
 
 Next == Checker
            \/ (\E self \in 1..N: AdderProc(self))
-           \/ ((\A self \in ProcSet: pc[self] = "Done") /\ UNCHANGED vars)
+           \/ (* Disjunct to prevent deadlock on termination *)
+              ((\A self \in ProcSet: pc[self] = "Done") /\ UNCHANGED vars)
 
 Spec == Init /\ [][Next]_vars
+
+Termination == <>(\A self \in ProcSet: pc[self] = "Done")
+
 \* END TRANSLATION
 =============================================================================

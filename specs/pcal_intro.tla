@@ -50,10 +50,11 @@ Transfer(self) == /\ pc[self] = "Transfer"
                   /\ UNCHANGED << account_total, money >>
 
 C(self) == /\ pc[self] = "C"
-           /\ Assert(alice_account >= 0,
-                     "Failure of assertion at line 16, column 4.")
+           /\ Assert(alice_account >= 0, 
+                     "Failure of assertion at line 23, column 4.")
            /\ pc' = [pc EXCEPT ![self] = "Done"]
-           /\ UNCHANGED << alice_account, bob_account, account_total, money >>
+           /\ UNCHANGED << alice_account, bob_account, account_total, 
+                           money >>
 
 TransProc(self) == Transfer(self) \/ C(self)
 
@@ -64,6 +65,7 @@ Next == (\E self \in 1..2: TransProc(self))
 Spec == Init /\ [][Next]_vars
 
 Termination == <>(\A self \in ProcSet: pc[self] = "Done")
+
 \* END TRANSLATION
 
 MoneyInvariant == alice_account + bob_account = account_total

@@ -53,7 +53,8 @@ C(self) == /\ pc[self] = "C"
            /\ Assert(alice_account >= 0, 
                      "Failure of assertion at line 16, column 4.")
            /\ pc' = [pc EXCEPT ![self] = "Done"]
-           /\ UNCHANGED << alice_account, bob_account, account_total, money >>
+           /\ UNCHANGED << alice_account, bob_account, account_total, 
+                           money >>
 
 TransProc(self) == Transfer(self) \/ A(self) \/ B(self) \/ C(self)
 

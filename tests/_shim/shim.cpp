@@ -11,6 +11,7 @@
 // multi-rank exchange logic of tla_rust_amd/sharded.py can be exercised with world_size-2
 // gloo tests on CPU.
 #include "../../tla_rust_amd/csrc/spec_registry.h"
+#include "../../tla_rust_amd/csrc/pcal.h"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -226,6 +227,54 @@ extern "C" int shim_run(const mc_spec_desc *d, uint64_t max_levels, uint64_t max
                         const char *dump_path, ShimResult *r) {
     return dispatch_spec(d, [&](auto spec, const auto &prm) { return run(spec, prm, max_levels, max_distinct, check_deadlock, dump_path, r); });
 }
+
+// ------------------------------------------------------------------------------------------
+// PlusCal front-end on the host (pcal.cpp / pcal_compile.cpp are linked into the shim): translate, compile,
+// and describe a program so that shim_run / the shard emulation execute it like any other lowering.
+static std::string g_pcal_error;
+extern "C" const char *shim_pcal_error() { return g_pcal_error.c_str(); }
+extern "C" int shim_pcal_translate(const char *tla_text, char *out, size_t cap) {
+    pcal::Module m;
+    const std::string text(tla_text);
+    g_pcal_error = pcal::parse_module(text, m);
+    if (!g_pcal_error.empty()) return -1;
+    const std::string tr = pcal::transpile_text(text, m);
+    if (tr.find("\\* TRANSLATION ERROR: ") != std::string::npos) { g_pcal_error = tr; return -1; }
+    if (out && cap) { const size_t n = tr.size() < cap ? tr.size() : cap - 1; memcpy(out, tr.data(), n); out[n] = 0; }
+    return (int)tr.size();
+}
+// invariants: comma separated names; constants: "N=3,M=2" (integers only)
+extern "C" void *shim_program_compile(const char *tla_text, const char *invariants, const char *constants) {
+    pcal::Config cf;
+    auto split = [](const char *s, char sep) {
+        std::vector<std::string> v;
+        std::string cur;
+        for (const char *p = s ? s : ""; ; p++) {
+            if (*p == sep || !*p) { if (!cur.empty()) v.push_back(cur); cur.clear(); if (!*p) break; }
+            else if (*p != ' ') cur += *p;
+        }
+        return v;
+    };
+    cf.invariants = split(invariants, ',');
+    for (const auto &kv : split(constants, ',')) {
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos) { g_pcal_error = "bad constant " + kv; return nullptr; }
+        pcal::ConstVal v;
+        v.k = pcal::ConstVal::INT;
+        v.i = atoll(kv.c_str() + eq + 1);
+        cf.constants.push_back({kv.substr(0, eq), v});
+    }
+    pcal::Module m;
+    const std::string text(tla_text);
+    g_pcal_error = pcal::parse_module(text, m);
+    if (!g_pcal_error.empty()) return nullptr;
+    auto *P = new pcal::Program();
+    g_pcal_error = pcal::compile(m, text, cf, *P);
+    if (!g_pcal_error.empty()) { delete P; return nullptr; }
+    return P;
+}
+extern "C" void shim_program_free(void *p) { delete (pcal::Program *)p; }
+extern "C" const char *shim_program_translated(void *p) { return ((pcal::Program *)p)->translated.c_str(); }
 
 extern "C" size_t shim_state_bytes(const mc_spec_desc *d) {
     size_t n = 0;

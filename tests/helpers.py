@@ -74,7 +74,7 @@ def oracle_run(spec, params, max_levels=0, max_distinct=0, check_deadlock=True, 
 
 # ---------------------------------------------------------------------------------- shim
 MC_MAX_LEVELS = 4096
-SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4}
+SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5}
 
 
 class McSpecDesc(C.Structure):
@@ -101,10 +101,13 @@ def build_shim():
     out = SHIM_DIR / "_build"
     out.mkdir(exist_ok=True)
     so = out / "libshim.so"
-    srcs = [SHIM_DIR / "shim.cpp"] + list((ROOT / "tla_rust_amd" / "csrc").glob("*.h")) + [ROOT / "include" / "tlamc.h"]
+    csrc = ROOT / "tla_rust_amd" / "csrc"
+    pcal = [csrc / "pcal.cpp", csrc / "pcal_compile.cpp"]  # the PlusCal front-end is host code: linked as is
+    srcs = [SHIM_DIR / "shim.cpp"] + pcal + list(csrc.glob("*.h")) + [ROOT / "include" / "tlamc.h"]
     if so.exists() and all(so.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return so
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(SHIM_DIR / "shim.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(SHIM_DIR / "shim.cpp")] + [str(x) for x in pcal],
+                   check=True)
     return so
 
 
@@ -131,6 +134,47 @@ def shim_run(spec, params, max_levels=0, max_distinct=0, check_deadlock=True, du
     return dict(distinct=res.distinct, generated=res.generated, queue_left=res.queue_left, depth=res.depth,
                 verdict=VERDICTS[res.verdict], violated_invariant=res.violated_invariant, trace_len=res.trace_len,
                 levels=[res.level_distinct[i] for i in range(res.levels)], fp_mismatch=res.fp_mismatch)
+
+
+class ShimProgram:
+    """A PlusCal module compiled by the host build of the front-end (tests only)."""
+
+    def __init__(self, tla_text, invariants=(), constants=None):
+        lib = shim_lib()
+        lib.shim_program_compile.restype = C.c_void_p
+        lib.shim_program_compile.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+        lib.shim_pcal_error.restype = C.c_char_p
+        lib.shim_program_free.argtypes = [C.c_void_p]
+        lib.shim_program_translated.restype = C.c_char_p
+        lib.shim_program_translated.argtypes = [C.c_void_p]
+        consts = ",".join(f"{k}={v}" for k, v in (constants or {}).items())
+        self.h = lib.shim_program_compile(tla_text.encode(), ",".join(invariants).encode(), consts.encode())
+        if not self.h:
+            raise RuntimeError(lib.shim_pcal_error().decode())
+        self.lib = lib
+
+    @property
+    def params(self):
+        return [self.h]
+
+    def translated(self):
+        return self.lib.shim_program_translated(self.h).decode()
+
+    def close(self):
+        if self.h:
+            self.lib.shim_program_free(self.h)
+            self.h = None
+
+
+def pcal_translate(tla_text):
+    lib = shim_lib()
+    lib.shim_pcal_translate.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.shim_pcal_error.restype = C.c_char_p
+    buf = C.create_string_buffer(1 << 20)
+    n = lib.shim_pcal_translate(tla_text.encode(), buf, len(buf))
+    if n < 0:
+        raise RuntimeError(lib.shim_pcal_error().decode())
+    return buf.value.decode()
 
 
 def read_dump(path):

@@ -1,0 +1,162 @@
+"""PlusCal front-end (tla_rust_amd/csrc/pcal.cpp, pcal_compile.cpp, spec_vm.h) on the CPU:
+
+* the translator (`mc --transpile` = the reference's `pcal2tla`, Makefile:3-4) is pinned by evaluating its
+  OUTPUT with oracle/tla_eval.py (a TLC-like evaluator of TLA+ text) against the TLC run the reference
+  publishes (README.md:267-321: 9097 / 6164 / 999, depth 7, the 6-state trace, the action positions);
+* the compiled program (the bytecode every GPU lane interprets) is run by the host build of the same
+  interpreter (tests/_shim) and compared with that evaluator: counters, per-level state SETS, verdicts;
+* and with the hand lowerings of the two root specs (spec_pluscal.h).
+The GPU leg of the same comparisons is tests/test_gpu_pcal.py."""
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import pytest
+
+import helpers
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+from tla_eval import Checker  # noqa: E402
+
+SPECS = ROOT / "specs"
+# (module file, invariants, integer constants)
+CASES = [
+    (SPECS / "pcal_intro.tla", ["MoneyInvariant"], {}),                      # reference pcal_intro.tla:4-23 + .cfg:3
+    (SPECS / "readme_variant" / "pcal_intro.tla", [], {}),                   # README.md:220-243 (labels A:, B:)
+    (SPECS / "readme_variant" / "pcal_intro.tla", ["MoneyInvariant"], {}),
+    (SPECS / "atomic_add.tla", [], {}),                                      # reference atomic_add.tla:4-23
+    (SPECS / "pluscal" / "peterson.tla", ["MutualExclusion", "TurnInRange"], {}),
+    (SPECS / "pluscal" / "cas_counter.tla", ["NeverTooMany", "SeenIsOld"], {"Workers": 2, "N": 2}),
+    (SPECS / "pluscal" / "cas_counter.tla", ["NeverTooMany"], {"Workers": 3, "N": 1}),
+    (SPECS / "pluscal" / "lost_update.tla", [], {}),
+    (SPECS / "pluscal" / "euclid.tla", ["Positive"], {"M": 12}),
+]
+
+
+def strip_translation(text):
+    """the module as its author wrote it: without the \\* BEGIN/END TRANSLATION block"""
+    a = text.find("\\* BEGIN TRANSLATION")
+    if a < 0:
+        return text
+    b = text.index("\\* END TRANSLATION", a)
+    b = text.index("\n", b) + 1
+    return text[:a] + text[b:]
+
+
+def test_translation_is_idempotent_and_matches_the_committed_specs():
+    """specs/*.tla carry the translator's own output: transpiling the stripped source gives the file back"""
+    for path in {c[0] for c in CASES} | {SPECS / "atomic_add_n.tla"}:
+        text = path.read_text()
+        if "BEGIN TRANSLATION" not in text:
+            continue
+        block = lambda t: t[t.index("\\* BEGIN TRANSLATION"):t.index("\\* END TRANSLATION")]  # noqa: E731
+        assert block(helpers.pcal_translate(strip_translation(text))) == block(text), path
+        assert helpers.pcal_translate(text) == text, path
+
+
+def test_readme_golden_through_the_translator():
+    """README.md:267-321: the TLC run of the README variant, reproduced by evaluating OUR translation"""
+    src = strip_translation((SPECS / "readme_variant" / "pcal_intro.tla").read_text())
+    tla = helpers.pcal_translate(src)
+    r = Checker(tla).run()
+    assert (r["generated"], r["distinct"], r["queue_left"], r["depth"]) == (9097, 6164, 999, 7)      # README.md:319-320
+    assert r["verdict"] == "assert" and r["message"] == "Failure of assertion at line 16, column 4."  # README.md:269
+    golden = json.loads((ROOT / "tests" / "golden" / "readme_pcal_intro_trace.json").read_text())
+    assert len(r["trace"]) == 6
+    got = [dict(l[3:].split(" = ", 1) for l in s.splitlines()) for s in r["trace"]]
+    assert got == golden["states"]                                                                    # README.md:272-311
+    # the action positions TLC printed for this layout (README.md:278,285,292,299): line of each definition
+    lines = tla.splitlines()
+    where = {name: next(i + 1 for i, l in enumerate(lines) if l.startswith(name + "(self) ==")) for name in ("Transfer", "A", "B", "C")}
+    assert where == {"Transfer": 35, "A": 42, "B": 47, "C": 52}
+    assert lines[39].rstrip() == " " * 34 + "money >>" and len(lines[39].rstrip()) == 42                # "line 40, col 42"
+    assert len(lines[44].rstrip()) == 63 and len(lines[49].rstrip()) == 65                            # A: 45:63, B: 50:65
+    assert lines[53].rstrip().endswith('"Failure of assertion at line 16, column 4.")') and len(lines[53].rstrip()) == 66
+
+
+def test_committed_specs_through_the_translator():
+    r = Checker(helpers.pcal_translate(Path("/root/reference/pcal_intro.tla").read_text() if Path("/root/reference").exists()
+                                       else strip_translation((SPECS / "pcal_intro.tla").read_text()))).run(invariants=["MoneyInvariant"])
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"]) == (3800, 5850, 5, "ok")
+    r = Checker(helpers.pcal_translate(strip_translation((SPECS / "atomic_add.tla").read_text()))).run()
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"]) == (5, 7, 4, "ok")                # 2^N + 1, N 2^(N-1) + 3
+
+
+def test_reference_files_translate_untouched():
+    """the reference commits its two root specs UNtranslated; they must go through as they are"""
+    ref = Path("/root/reference")
+    if not ref.exists():
+        pytest.skip("reference tree not present")
+    for name in ("pcal_intro.tla", "atomic_add.tla"):
+        out = helpers.pcal_translate((ref / name).read_text())
+        assert "\\* BEGIN TRANSLATION" in out and "\\* END TRANSLATION" in out
+        assert strip_translation(out) == (ref / name).read_text()
+
+
+@pytest.mark.parametrize("path,invs,consts", CASES, ids=lambda v: v.stem if isinstance(v, Path) else None)
+def test_compiled_program_vs_tla_evaluator(path, invs, consts):
+    text = path.read_text()
+    prog = helpers.ShimProgram(text, invs, consts)
+    try:
+        fd, dump = tempfile.mkstemp()
+        os.close(fd)
+        r = helpers.shim_run("pcal", prog.params, dump=dump)
+        o = Checker(prog.translated(), constants=consts).run_levels(invariants=invs)
+        for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len"):
+            assert r[k] == o[k], (k, r[k], o[k])
+        assert r["levels"] == o["levels"]
+        if r["verdict"] == "invariant":
+            assert invs[r["violated_invariant"]] == o["violated"]
+        states = helpers.read_dump(dump)
+        os.unlink(dump)
+        assert len(states) == len(o["states"])
+        for lvl, want in enumerate(o["states"], 1):      # bit-exact: the SET of states of every BFS level
+            assert states[lvl] == want, f"level {lvl}"
+    finally:
+        prog.close()
+
+
+def test_compiled_program_vs_hand_lowering():
+    """the two root specs have both a hand lowering (spec_pluscal.h) and a compiled program: same graph"""
+    for path, hand, invs in [(SPECS / "pcal_intro.tla", ("pcal_intro", [0, 1, 20, 2]), ["MoneyInvariant"]),
+                             (SPECS / "readme_variant" / "pcal_intro.tla", ("pcal_intro", [1, 0, 20, 2]), []),
+                             (SPECS / "atomic_add.tla", ("atomic_add", [2]), [])]:
+        prog = helpers.ShimProgram(path.read_text(), invs)
+        a = helpers.shim_run("pcal", prog.params)
+        b = helpers.shim_run(*hand)
+        for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+            assert a[k] == b[k], (path.name, k)
+        prog.close()
+
+
+MODULE = "---- MODULE t ----\nEXTENDS Naturals\n(* --algorithm t\n%s\nend algorithm *)\n====\n"
+
+
+@pytest.mark.parametrize("body,needle", [
+    ("variables x = 0;\nmacro m() begin skip; end macro;\nbegin\nA: skip;", "macros are not supported"),
+    ("variables x = 0;\nbegin\nskip;", "needs a label"),
+    ("variables x = 0;\nbegin\nA: x := 1; x := 2;", "second assignment to x"),
+    ("variables x = 0;\nbegin\nA: if x = 0 then B: x := 1; end if; x := 2;", "needs a label"),
+    ("variables x = 0;\nbegin\nA: y := 1;", "undeclared variable y"),
+    ("variables x;\nbegin\nA: skip;", "needs an initial value"),
+    ("variables x = 0;\nbegin\nA: while x < 2 do x := x + 1; end while; B: call f();", "not supported"),
+])
+def test_refusals_are_explained(body, needle):
+    with pytest.raises(RuntimeError) as e:
+        helpers.ShimProgram(MODULE % body)
+    assert needle in str(e.value)
+
+
+def test_either_with_while_goto_translation_shape():
+    """shape of the translation of the constructs the root specs do not use (p-manual App. B)"""
+    tla = helpers.pcal_translate(strip_translation((SPECS / "pluscal" / "lost_update.tla").read_text()))
+    assert "/\\ \\/ /\\ mode' = \"add\"" in tla and "\\E d \\in {2, 5}:" in tla
+    assert 'pc = [self \\in ProcSet |-> CASE self \\in 1..2 -> "Pick"' in tla and '[] self = 3 -> "Final"]' in tla
+    tla = helpers.pcal_translate(strip_translation((SPECS / "pluscal" / "cas_counter.tla").read_text()))
+    assert "ELSE /\\ pc' = [pc EXCEPT ![self] = \"Read\"]" in tla          # goto inside if
+    assert "/\\ IF done[self] < N" in tla                                     # while = IF on the loop label
+    tla = helpers.pcal_translate(strip_translation((SPECS / "pluscal" / "euclid.tla").read_text()))
+    assert "/\\ pc = \"Loop\"" in tla and "(pc = \"Done\" /\\ UNCHANGED vars)" in tla   # uniprocess

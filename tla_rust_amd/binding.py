@@ -8,7 +8,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "_build" / "libtlamc.so"
 
 MC_MAX_LEVELS = 4096
-SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4}
+SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5}
 VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
 MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING, MC_F_MATRIX, MC_F_NOPROBE, MC_F_NOFAMILY = 1, 2, 4, 8, 16, 32
 
@@ -109,6 +109,16 @@ def lib():
         L.mc_cfg_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.mc_spec_resolve.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(SpecDesc)]
         L.mc_check_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Config), C.c_char_p, C.c_size_t, C.POINTER(CResult)]
+    if hasattr(L, "mc_program_compile"):
+        L.mc_pcal_translate.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.mc_program_compile.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.mc_program_spec.argtypes = [C.c_void_p, C.POINTER(SpecDesc)]
+        L.mc_program_translated.argtypes = [C.c_void_p]
+        L.mc_program_translated.restype = C.c_char_p
+        L.mc_program_invariant.argtypes = [C.c_void_p, C.c_int]
+        L.mc_program_invariant.restype = C.c_char_p
+        L.mc_program_free.argtypes = [C.c_void_p]
+        L.mc_program_free.restype = None
     _lib = L
     return L
 
@@ -266,6 +276,39 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+def pcal_translate(tla_text: str) -> str:
+    """`pcal2tla`: the module text with the TLA+ translation of its PlusCal algorithm inserted (host only)."""
+    need = _check(lib().mc_pcal_translate(tla_text.encode(), None, 0), "mc_pcal_translate")
+    buf = C.create_string_buffer(need + 1)
+    _check(lib().mc_pcal_translate(tla_text.encode(), buf, len(buf)), "mc_pcal_translate")
+    return buf.value.decode()
+
+
+class Program:
+    """A PlusCal module compiled for the GPU interpreter (mc_program_* of include/tlamc.h).
+    Engine("pcal", program.params) checks it; the program must outlive its engines."""
+
+    def __init__(self, tla_text: str, cfg_text: str = None):
+        h = C.c_void_p()
+        _check(lib().mc_program_compile(tla_text.encode(), cfg_text.encode() if cfg_text is not None else None, C.byref(h)),
+               "mc_program_compile")
+        self._h = h
+        d = SpecDesc()
+        _check(lib().mc_program_spec(h, C.byref(d)), "mc_program_spec")
+        self.params = [int(d.params[0])]
+
+    def translated(self):
+        return lib().mc_program_translated(self._h).decode()
+
+    def invariant(self, index):
+        return lib().mc_program_invariant(self._h, index).decode()
+
+    def close(self):
+        if self._h:
+            lib().mc_program_free(self._h)
+            self._h = None
 
 
 def cfg_parse(text: str):

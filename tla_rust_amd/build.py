@@ -26,21 +26,32 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "tlamc.h"]
     srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
-    if force or _stale(LIB, [d for d in deps if d.name != "mc_main.cpp"]):
-        # engine.hip is compiled once per group of specs (MC_TU = 1..5) plus once for the C ABI (MC_TU = 0), in
-        # parallel: the unrolled per-spec kernels dominate compile time
-        common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
-                  "-I", str(PKG.parent / "include")]
-        jobs = []
-        for tu in range(6):
-            obj = OUT / f"engine_tu{tu}.o"
+    # engine.hip is compiled once per group of specs (MC_TU = 1..6) plus once for the C ABI (MC_TU = 0), in
+    # parallel: the unrolled per-spec kernels dominate compile time.  Each object is rebuilt only when one of the
+    # files it really depends on changed (a TU instantiates the kernels of its own spec header only).
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
+              "-I", str(PKG.parent / "include")]
+    base = [CSRC / "engine.hip", CSRC / "mc_common.h", CSRC / "spec_registry.h", PKG.parent / "include" / "tlamc.h"]
+    own = {0: ["spec_pluscal.h", "spec_raft.h", "spec_ssi.h", "spec_vm.h"], 1: ["spec_pluscal.h"], 2: ["spec_raft.h"],
+           3: ["spec_raft.h"], 4: ["spec_raft.h"], 5: ["spec_ssi.h"], 6: ["spec_vm.h"]}
+    jobs, objs = [], []
+    for tu in range(7):
+        obj = OUT / f"engine_tu{tu}.o"
+        objs.append(obj)
+        if force or _stale(obj, base + [CSRC / h for h in own[tu]]):
             jobs.append((obj, subprocess.Popen(common + ["-x", "hip", f"-DMC_TU={tu}", "-c", str(CSRC / "engine.hip"), "-o", str(obj)])))
-        fobj = OUT / "frontend.o"
-        jobs.append((fobj, subprocess.Popen(common + ["-x", "hip", "-c", str(CSRC / "frontend.cpp"), "-o", str(fobj)])))
-        for obj, pr in jobs:
-            if pr.wait() != 0:
-                raise RuntimeError(f"hipcc failed for {obj.name}")
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o, _ in jobs]
+    host_deps = {"frontend": ["frontend.cpp", "pcal.h", "spec_vm.h", "mc_common.h"], "pcal": ["pcal.cpp", "pcal.h"],
+                 "pcal_compile": ["pcal_compile.cpp", "pcal.h", "spec_vm.h", "mc_common.h"]}
+    for name, dd in host_deps.items():
+        obj = OUT / f"{name}.o"
+        objs.append(obj)
+        if force or _stale(obj, [CSRC / d for d in dd] + [PKG.parent / "include" / "tlamc.h"]):
+            jobs.append((obj, subprocess.Popen(common + ["-x", "hip", "-c", str(CSRC / f"{name}.cpp"), "-o", str(obj)])))
+    for obj, pr in jobs:
+        if pr.wait() != 0:
+            raise RuntimeError(f"hipcc failed for {obj.name}")
+    if force or jobs or not LIB.exists():
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -856,7 +856,8 @@ static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
 
 // ------------------------------------------------------------------------------------- host side
 struct EngineBase {
-    virtual ~EngineBase() {}
+    void *owned_device_blob = nullptr;  // program image of a compiled PlusCal spec (spec_vm.h)
+    virtual ~EngineBase() { if (owned_device_blob) hipFree(owned_device_blob); }
     virtual int run(mc_result *out) = 0;
     virtual int trace(uint8_t *states_out, int32_t *actions_out, size_t *n_inout) = 0;
     virtual int kernel_stats(mc_kernel_stats *out) = 0;
@@ -1580,6 +1581,7 @@ static int spec_group(const mc_spec_desc *d) {
     case MC_SPEC_ATOMIC_ADD: case MC_SPEC_PCAL_INTRO: return 1;
     case MC_SPEC_RAFT: return d->nparams < 1 ? 0 : d->params[0] == 2 ? 2 : d->params[0] == 3 ? 3 : d->params[0] == 5 ? 4 : 0;
     case MC_SPEC_SSI: return 5;
+    case MC_SPEC_PCAL: return 6;
     default: return 0;
     }
 }
@@ -1601,6 +1603,7 @@ int mc_make_engine_2(const mc_spec_desc *, const mc_config *, mc::EngineBase **)
 int mc_make_engine_3(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
 int mc_make_engine_4(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
 int mc_make_engine_5(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
+int mc_make_engine_6(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
 #if MC_TU == 1 || MC_TU == -1
 int mc_make_engine_1(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {
     if (d->spec_id == MC_SPEC_ATOMIC_ADD) {
@@ -1633,6 +1636,25 @@ int mc_make_engine_5(const mc_spec_desc *d, const mc_config *c, mc::EngineBase *
     mc::SsiParams p;
     if (mc::SpecSsi::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
     return mc::make_engine<mc::SpecSsi>(p, d, c, out);
+}
+#endif
+#if MC_TU == 6 || MC_TU == -1
+// compiled PlusCal (spec_vm.h): the program image is copied to the device, the kernels read it through prm.code
+int mc_make_engine_6(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {
+    mc::VmParams p;
+    if (mc::SpecVm::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+    if (hipSetDevice(c->device) != hipSuccess) { mc::set_error("hipSetDevice failed"); return MC_EHIP; }
+    int32_t *d_code = nullptr;
+    if (hipMalloc(&d_code, (size_t)p.code_len * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(d_code, p.code, (size_t)p.code_len * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        mc::set_error("cannot upload the PlusCal program image");
+        return MC_EHIP;
+    }
+    p.code = d_code;  // host-side helpers (format, action_of) use p.host only
+    const int rc = mc::make_engine<mc::SpecVm>(p, d, c, out);
+    if (rc) hipFree(d_code);
+    else (*out)->owned_device_blob = d_code;
+    return rc;
 }
 #endif
 }  // extern "C"
@@ -1668,6 +1690,7 @@ int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine *
     case 3: rc = mc_make_engine_3(spec, cfg, &impl); break;
     case 4: rc = mc_make_engine_4(spec, cfg, &impl); break;
     case 5: rc = mc_make_engine_5(spec, cfg, &impl); break;
+    case 6: rc = mc_make_engine_6(spec, cfg, &impl); break;
     default: break;
     }
     if (rc == MC_OK) *out = new mc_engine{impl};
@@ -1709,7 +1732,11 @@ int mc_state_format(const mc_spec_desc *spec, const uint8_t *state, char *buf, s
 }
 const char *mc_action_name(const mc_spec_desc *spec, int32_t action) {
     const char *nm = "?";
-    dispatch_spec(spec, [&](auto s, const auto &) { nm = decltype(s)::action_name(action); return 0; });
+    dispatch_spec(spec, [&](auto s, const auto &prm) {
+        if constexpr (std::is_same_v<decltype(s), SpecVm>) nm = vm_action_name(prm.host, action);  // label names live in the program
+        else nm = decltype(s)::action_name(action);
+        return 0;
+    });
     return nm;
 }
 const char *mc_strerror(int code) {

@@ -22,8 +22,14 @@
 #include <vector>
 
 #include "../../include/tlamc.h"
+#include "pcal.h"
+#include "spec_vm.h"
 
 extern "C" void mc_set_error_internal(const char *msg);  // engine.hip
+
+struct mc_program {
+    pcal::Program prog;
+};
 
 namespace {
 
@@ -535,7 +541,93 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
     return fe_fail(MC_ENOSPEC, "module '%s' is not one of the lowered specs (atomic_add, atomic_add_n, pcal_intro, MCraft, MCssi)", module);
 }
 
+// ---------------------------------------------------------------------------------- PlusCal programs
+static pcal::ConstVal to_const(const CfgValue &v) {
+    pcal::ConstVal c;
+    switch (v.kind) {
+    case CfgValue::NUMBER: c.k = pcal::ConstVal::INT; c.i = v.num; break;
+    case CfgValue::STRING: c.k = pcal::ConstVal::STR; c.s = v.text; break;
+    case CfgValue::IDENT:
+        if (v.text == "TRUE" || v.text == "FALSE") { c.k = pcal::ConstVal::INT; c.i = v.text == "TRUE"; }
+        else { c.k = pcal::ConstVal::STR; c.s = v.text; }  // a model value
+        break;
+    case CfgValue::SET:
+        c.k = pcal::ConstVal::SET;
+        for (const auto &e : v.elems) c.elems.push_back(to_const(e));
+        break;
+    }
+    return c;
+}
+
+int mc_pcal_translate(const char *tla_text, char *out, size_t cap) {
+    if (!tla_text) return MC_EBADCFG;
+    const std::string text(tla_text);
+    pcal::Module m;
+    const std::string err = pcal::parse_module(text, m);
+    if (!err.empty()) return fe_fail(MC_EPARSE, "PlusCal: %s", err.c_str());
+    const std::string tr = pcal::translate(m);
+    if (tr.rfind("\\* TRANSLATION ERROR: ", 0) == 0) return fe_fail(MC_EPARSE, "PlusCal: %s", tr.substr(22).c_str());
+    const std::string all = pcal::transpile_text(text, m);
+    if (out && cap) {
+        const size_t n = all.size() < cap ? all.size() : cap - 1;
+        memcpy(out, all.data(), n);
+        out[n] = 0;
+    }
+    return (int)all.size();
+}
+
+int mc_program_compile(const char *tla_text, const char *cfg_text, mc_program **out) {
+    if (!tla_text || !out) return MC_EBADCFG;
+    *out = nullptr;
+    pcal::Config cf;
+    if (cfg_text) {
+        mc_cfg *c = nullptr;
+        const int rc = mc_cfg_parse(cfg_text, strlen(cfg_text), &c);
+        if (rc) return rc;
+        cf.invariants = c->invariants;
+        for (const auto &k : c->constants) {
+            if (k.replacement) { mc_cfg_free(c); return fe_fail(MC_ENOSPEC, "CONSTANT %s <- ...: definition overrides are not supported for PlusCal programs", k.name.c_str()); }
+            cf.constants.push_back({k.name, to_const(k.value)});
+        }
+        const bool other = !c->constraints.empty() || !c->action_constraints.empty() || !c->symmetry.empty() || !c->view.empty();
+        mc_cfg_free(c);
+        if (other) return fe_fail(MC_ENOSPEC, "CONSTRAINT / ACTION-CONSTRAINT / SYMMETRY / VIEW are not supported for PlusCal programs");
+    }
+    const std::string text(tla_text);
+    pcal::Module m;
+    std::string err = pcal::parse_module(text, m);
+    if (!err.empty()) return fe_fail(MC_EPARSE, "PlusCal: %s", err.c_str());
+    auto *p = new mc_program();
+    err = pcal::compile(m, text, cf, p->prog);
+    if (!err.empty()) { delete p; return fe_fail(MC_ENOSPEC, "PlusCal: %s", err.c_str()); }
+    *out = p;
+    return MC_OK;
+}
+int mc_program_spec(const mc_program *p, mc_spec_desc *out) {
+    if (!p || !out) return MC_EBADCFG;
+    memset(out, 0, sizeof *out);
+    out->spec_id = MC_SPEC_PCAL;
+    out->nparams = 1;
+    out->params[0] = (int64_t)(intptr_t)&p->prog;
+    return MC_OK;
+}
+const char *mc_program_translated(const mc_program *p) { return p ? p->prog.translated.c_str() : ""; }
+const char *mc_program_invariant(const mc_program *p, int index) {
+    return p && index >= 0 && (size_t)index < p->prog.invariants.size() ? p->prog.invariants[(size_t)index].c_str() : "?";
+}
+int mc_program_assert_pos(const mc_program *p, int index, int *line, int *col) {
+    if (!p || index < 0 || (size_t)index >= p->prog.asserts.size()) return MC_EBADCFG;
+    if (line) *line = p->prog.asserts[(size_t)index].line;
+    if (col) *col = p->prog.asserts[(size_t)index].col;
+    return MC_OK;
+}
+void mc_program_free(mc_program *p) { delete p; }
+
 static const char *invariant_name(const mc_spec_desc *d, int idx) {
+    if (d->spec_id == MC_SPEC_PCAL) {
+        const pcal::Program *P = (const pcal::Program *)(intptr_t)d->params[0];
+        return idx >= 0 && (size_t)idx < P->invariants.size() ? P->invariants[(size_t)idx].c_str() : "?";
+    }
     if (d->spec_id == MC_SPEC_PCAL_INTRO) return "MoneyInvariant";
     if (d->spec_id == MC_SPEC_RAFT) return idx == 1 ? "CommittedLogStable" : "NoTwoLeaders";
     if (d->spec_id == MC_SPEC_SSI) {
@@ -560,26 +652,40 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
         const size_t dot = cpath.rfind(".tla");
         if (dot != std::string::npos) cpath.replace(dot, 4, ".cfg"); else cpath += ".cfg";
     }
-    if (!read_file(cpath, cfgtext)) return fe_fail(MC_EPARSE, "cannot read configuration file %s", cpath.c_str());
+    if (!read_file(cpath, cfgtext)) {
+        // a PlusCal module without a cfg is checked with no constants and no invariants (assert / deadlock only)
+        if (cfg_path || tla.find("--algorithm") == std::string::npos) return fe_fail(MC_EPARSE, "cannot read configuration file %s", cpath.c_str());
+        cfgtext.clear();
+    }
     mc_cfg *c = nullptr;
     int rc = mc_cfg_parse(cfgtext.c_str(), cfgtext.size(), &c);
     if (rc) return rc;
     mc_spec_desc d;
-    rc = mc_spec_resolve(module.c_str(), c, &d);
-    mc_cfg_free(c);
-    if (rc) return rc;
-    // the lowering is valid only for the text it was written against
+    memset(&d, 0, sizeof d);
+    // A PlusCal module goes through the hand lowering when its algorithm text is one the registry knows, and
+    // through the compiled program (spec_vm.h) otherwise — or always with MC_F_GENERIC (A/B of the two paths).
     std::string part, def_text, def_module_name;  // text + name of the module that holds the action definitions
-    if (d.spec_id == MC_SPEC_PCAL_INTRO) {
-        if (!algorithm_text(tla, part)) return fe_fail(MC_ENOSPEC, "%s: no --algorithm block", tla_path);
-        const uint64_t h = text_hash(part);
-        if (h == H_PCAL_INTRO) d.params[0] = 0;
-        else if (h == H_PCAL_INTRO_README) d.params[0] = 1;
-        else return fe_fail(MC_ENOSPEC, "pcal_intro: the algorithm text differs from both lowered variants (hash %016llx)", (unsigned long long)h);
+    const bool has_alg = algorithm_text(tla, part);
+    const uint64_t alg_hash = has_alg ? text_hash(part) : 0;
+    bool generic = has_alg && (cfg->flags & MC_F_GENERIC);
+    if (!generic) {
+        rc = mc_spec_resolve(module.c_str(), c, &d);
+        if (rc == MC_ENOSPEC && has_alg) generic = true;
+        else if (rc) { mc_cfg_free(c); return rc; }
+        if (!generic && d.spec_id == MC_SPEC_PCAL_INTRO && alg_hash != H_PCAL_INTRO && alg_hash != H_PCAL_INTRO_README) generic = true;
+        if (!generic && d.spec_id == MC_SPEC_ATOMIC_ADD && module == "atomic_add" && alg_hash != H_ATOMIC_ADD) generic = true;
+    }
+    mc_cfg_free(c);
+    mc_program *prog = nullptr;
+    struct ProgGuard { mc_program *&p; ~ProgGuard() { if (p) mc_program_free(p); } } prog_guard{prog};
+    if (generic) {
+        if ((rc = mc_program_compile(tla.c_str(), cfgtext.c_str(), &prog))) return rc;
+        mc_program_spec(prog, &d);
+        def_text = mc_program_translated(prog);  // action spans refer to the translation pcal2tla would insert
+        def_module_name = module;
+    } else if (d.spec_id == MC_SPEC_PCAL_INTRO) {
+        d.params[0] = alg_hash == H_PCAL_INTRO ? 0 : 1;
     } else if (d.spec_id == MC_SPEC_ATOMIC_ADD && module == "atomic_add") {
-        if (!algorithm_text(tla, part)) return fe_fail(MC_ENOSPEC, "%s: no --algorithm block", tla_path);
-        const uint64_t h = text_hash(part);
-        if (h != H_ATOMIC_ADD) return fe_fail(MC_ENOSPEC, "atomic_add: the algorithm text differs from the lowered one (hash %016llx)", (unsigned long long)h);
     } else if (d.spec_id == MC_SPEC_RAFT) {
         std::string raft;  // MCraft EXTENDS raft: verify raft.tla when it can be found beside the wrapper
         const char *env = getenv("TLA_PATH");
@@ -623,19 +729,38 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
         o.put("  Estimates of the probability that TLC did not check all reachable states\n"
               "  because two distinct states had the same fingerprint:\n  calculated (optimistic):  val = %.2g\n", opt);
     } else {
-        if (res->verdict == MC_V_ASSERT)
+        if (res->verdict == MC_V_ASSERT && !generic)
             o.put("The first argument of Assert evaluated to FALSE; the second argument was:\n\"Failure of assertion at line 16, column 4.\"\n");
+        else if (res->verdict == MC_V_ASSERT) { /* compiled program: the message names the failing assert, found below */ }
         else if (res->verdict == MC_V_INVARIANT) o.put("Error: Invariant %s is violated.\n", invariant_name(&d, res->violated_invariant));
         else if (res->verdict == MC_V_DEADLOCK) o.put("Error: Deadlock reached.\n");
         else o.put("Error: evaluation error (a function was applied outside its domain).\n");
         const size_t W = mc_state_bytes(&d);
+        std::string assert_def = "C";  // the action whose Assert failed
         size_t n = res->trace_len ? res->trace_len : 1;
         std::vector<uint8_t> states(n * W);
         std::vector<int32_t> acts(n);
         // action definitions live in the checked module, or in the module an MC wrapper EXTENDS
         const std::vector<std::string> srcL = split_lines(def_text.empty() ? tla : def_text);
         const std::string &def_module = def_text.empty() ? module : def_module_name;
-        if (mc_engine_trace(e, states.data(), acts.data(), &n) == MC_OK && n) {
+        const bool have_trace = mc_engine_trace(e, states.data(), acts.data(), &n) == MC_OK && n;
+        if (generic && res->verdict == MC_V_ASSERT) {  // which assert: re-evaluate the last state of the trace on the host
+            std::string msg = "Failure of assertion.";
+            if (have_trace) {
+                const pcal::Program &P = prog->prog;
+                std::vector<int32_t> vals((size_t)P.nv + 1);
+                const uint64_t *w = (const uint64_t *)&states[(n - 1) * W];
+                for (int i = 0; i < P.nv; i++) vals[(size_t)i] = (int32_t)(uint32_t)(w[i / 2] >> (32 * (i & 1)));
+                int label = -1;
+                const int id = mc::vm_failed_assert(&P, vals.data(), &label);
+                if (id >= 0) {
+                    msg = "Failure of assertion at line " + std::to_string(P.asserts[(size_t)id].line) + ", column " + std::to_string(P.asserts[(size_t)id].col) + ".";
+                    assert_def = P.strings[(size_t)label];
+                }
+            }
+            o.put("The first argument of Assert evaluated to FALSE; the second argument was:\n\"%s\"\n", msg.c_str());
+        }
+        if (have_trace) {
             o.put("Error: The behavior up to this point is:\n");
             std::vector<char> txt(1 << 16);
             for (size_t k = 0; k < n; k++) {
@@ -652,7 +777,7 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
         }
         if (res->verdict == MC_V_ASSERT) {  // README.md:313-316: the conjunct being evaluated and the Assert call itself
             int first = 0;
-            const Span c = definition_span(srcL, "C", &first);
+            const Span c = definition_span(srcL, assert_def.c_str(), &first);
             if (c.ok) {
                 Span a0, a1;
                 const std::string &l0 = srcL[first];

@@ -2,9 +2,13 @@
 // Makefile:6-7 / README.md:262 (same inputs: X.tla with X.cfg beside it; same report lines:
 // README.md:267-321).  All work happens behind the C ABI (include/tlamc.h).
 //
-//   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D]
+//   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
+//   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
+//                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
+//                                         the previous text is kept as X.old
 //
+// -generic  : check a PlusCal module through the compiled program even when a hand lowering exists.
 // -deadlock : as with TLC, do NOT check for deadlock.  -workers is accepted and ignored (the
 // GPU is the worker pool).  Exit status: 0 no error, 12 safety violation (invariant / assert),
 // 11 deadlock, 1 any other failure — TLC's convention.
@@ -12,11 +16,40 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "../../include/tlamc.h"
 
+static int transpile(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "mc: cannot read %s\n", path); return 1; }
+    std::string text;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    fclose(f);
+    const int need = mc_pcal_translate(text.c_str(), nullptr, 0);
+    if (need < 0) { fprintf(stderr, "mc: %s: %s\n", path, mc_last_error()); return 1; }
+    std::vector<char> out((size_t)need + 1);
+    mc_pcal_translate(text.c_str(), out.data(), out.size());
+    std::string old = path;
+    const size_t dot = old.rfind(".tla");
+    if (dot != std::string::npos) old.replace(dot, 4, ".old"); else old += ".old";
+    if ((f = fopen(old.c_str(), "wb"))) { fwrite(text.data(), 1, text.size(), f); fclose(f); }
+    if (!(f = fopen(path, "wb"))) { fprintf(stderr, "mc: cannot write %s\n", path); return 1; }
+    fwrite(out.data(), 1, (size_t)need, f);
+    fclose(f);
+    printf("pcal2tla-compatible translation written to %s (previous text in %s)\n", path, old.c_str());
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && (!strcmp(argv[1], "--transpile") || !strcmp(argv[1], "-transpile"))) {
+        int rc = argc > 2 ? 0 : 1;
+        for (int i = 2; i < argc; i++) rc |= transpile(argv[i]);
+        return rc;
+    }
     const char *tla = nullptr, *cfgp = nullptr;
     mc_config cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -28,6 +61,7 @@ int main(int argc, char **argv) {
         if (arg("-config")) cfgp = argv[++i];
         else if (!strcmp(argv[i], "-deadlock")) cfg.flags &= ~MC_F_DEADLOCK;
         else if (arg("-workers")) ++i;
+        else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
         else if (arg("-device")) cfg.device = atoi(argv[++i]);
         else if (arg("-maxdistinct")) cfg.max_distinct = strtoull(argv[++i], 0, 10);
         else if (arg("-maxlevels")) cfg.max_levels = strtoull(argv[++i], 0, 10);

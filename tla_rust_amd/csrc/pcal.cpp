@@ -1,0 +1,1002 @@
+// pcal.cpp — PlusCal (p-syntax) parser and pcal2tla-style translator.  See pcal.h.
+// Grammar: examples/p-manual.pdf App. A (p-syntax); translation: §3.8 pp.31-32 and App. B pp.60-64.
+// Supported: variables (= / \in), multiprocess and uniprocess algorithms, labels, assignment (x := e,
+// x[i] := e, a := e || b := e), if / elsif / else, while, either / or, with (\in / =), await / when, assert,
+// skip, goto, print.  Refused with a message: define, macro, procedure / call / return.
+#include "pcal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <set>
+
+namespace pcal {
+namespace {
+
+// ------------------------------------------------------------------------------------------ lexer
+struct Tok {
+    enum T { END, IDENT, NUM, STR, SYM, SEP } t = END;  // SEP: a ---- or ==== line
+    std::string s;
+    int line = 0, col = 0;
+};
+
+const char *kSyms[] = {"|->", ":=", "||", "==", "=>", "<=", ">=", "=<", "/=", "/\\", "\\/", "..", "->", "<<", ">>", "(", ")", "[",
+                       "]",   "{",  "}",  ",",  ";",  ":",  "+",  "-",  "*",  "%",   "=",   "<",  ">",  "#",  "~",  "'", "!", "@",
+                       ".",   "^"};
+
+struct LexError { std::string msg; };
+
+// Tokens of text[b, e) (comments skipped); lines and columns are 1-based positions in the whole file.
+std::vector<Tok> lex(const std::string &text, size_t b, size_t e) {
+    std::vector<Tok> out;
+    int line = 1, col = 1;
+    for (size_t i = 0; i < b; i++) { if (text[i] == '\n') { line++; col = 1; } else col++; }
+    size_t p = b;
+    auto adv = [&](size_t n) { for (size_t i = 0; i < n && p < e; i++, p++) { if (text[p] == '\n') { line++; col = 1; } else col++; } };
+    auto idch = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; };
+    while (p < e) {
+        const char c = text[p];
+        if (c == ' ' || c == '\t' || c == '\r' || c == '\n') { adv(1); continue; }
+        if (c == '\\' && p + 1 < e && text[p + 1] == '*') { while (p < e && text[p] != '\n') adv(1); continue; }
+        if (c == '(' && p + 1 < e && text[p + 1] == '*') {
+            int depth = 1;
+            adv(2);
+            while (p < e && depth) {
+                if (p + 1 < e && text[p] == '(' && text[p + 1] == '*') { depth++; adv(2); }
+                else if (p + 1 < e && text[p] == '*' && text[p + 1] == ')') { depth--; adv(2); }
+                else adv(1);
+            }
+            continue;
+        }
+        Tok t;
+        t.line = line;
+        t.col = col;
+        if ((c == '-' || c == '=') && p + 3 < e && text[p + 1] == c && text[p + 2] == c && text[p + 3] == c) {
+            size_t q = p;
+            while (q < e && text[q] == c) q++;
+            t.t = Tok::SEP;
+            t.s.assign(text, p, q - p);
+            adv(q - p);
+            out.push_back(t);
+            continue;
+        }
+        if (idch(c)) {
+            size_t q = p;
+            while (q < e && idch(text[q])) q++;
+            t.s.assign(text, p, q - p);
+            bool digits = true;
+            for (char ch : t.s) digits &= ch >= '0' && ch <= '9';
+            t.t = digits ? Tok::NUM : Tok::IDENT;
+            adv(q - p);
+            out.push_back(t);
+            continue;
+        }
+        if (c == '"') {
+            size_t q = p + 1;
+            while (q < e && text[q] != '"' && text[q] != '\n') q++;
+            if (q >= e || text[q] != '"') throw LexError{"unterminated string at line " + std::to_string(line)};
+            t.t = Tok::STR;
+            t.s.assign(text, p + 1, q - p - 1);
+            adv(q + 1 - p);
+            out.push_back(t);
+            continue;
+        }
+        if (c == '\\') {  // \in \notin \div \A \E \cup ...
+            size_t q = p + 1;
+            while (q < e && ((text[q] >= 'a' && text[q] <= 'z') || (text[q] >= 'A' && text[q] <= 'Z'))) q++;
+            if (q > p + 1) {
+                t.t = Tok::SYM;
+                t.s.assign(text, p, q - p);
+                adv(q - p);
+                out.push_back(t);
+                continue;
+            }
+        }
+        bool found = false;
+        for (const char *sy : kSyms) {
+            const size_t n = strlen(sy);
+            if (p + n <= e && text.compare(p, n, sy) == 0) {
+                t.t = Tok::SYM;
+                t.s = sy;
+                adv(n);
+                out.push_back(t);
+                found = true;
+                break;
+            }
+        }
+        if (!found) throw LexError{std::string("unexpected character '") + c + "' at line " + std::to_string(line) + ", column " + std::to_string(col)};
+    }
+    Tok end;
+    end.line = line;
+    end.col = col;
+    out.push_back(end);
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------ parser
+struct ParseError { std::string msg; };
+
+struct Parser {
+    std::vector<Tok> t;
+    size_t i = 0;
+    explicit Parser(std::vector<Tok> toks) : t(std::move(toks)) {}
+    const Tok &cur() const { return t[i]; }
+    const Tok &peek(size_t k = 1) const { return t[std::min(i + k, t.size() - 1)]; }
+    bool is_sym(const char *s) const { return cur().t == Tok::SYM && cur().s == s; }
+    bool is_id(const char *s) const { return cur().t == Tok::IDENT && cur().s == s; }
+    [[noreturn]] void fail(const std::string &what) const {
+        throw ParseError{what + " at line " + std::to_string(cur().line) + ", column " + std::to_string(cur().col) +
+                         (cur().t == Tok::END ? " (end of text)" : " (near `" + cur().s + "`)")};
+    }
+    void expect_sym(const char *s) { if (!is_sym(s)) fail(std::string("expected `") + s + "`"); i++; }
+    void expect_id(const char *s) { if (!is_id(s)) fail(std::string("expected `") + s + "`"); i++; }
+    std::string ident(const char *what) {
+        if (cur().t != Tok::IDENT) fail(std::string("expected ") + what);
+        return t[i++].s;
+    }
+
+    // ---- expressions (TLA+ operator precedences, Specifying Systems table 6)
+    static int infix_prec(const Tok &k, bool &right) {
+        right = false;
+        if (k.t != Tok::SYM) return -1;
+        const std::string &s = k.s;
+        if (s == "=>") return 1;
+        if (s == "\\/" || s == "\\lor") return 3;
+        if (s == "/\\" || s == "\\land") return 3;
+        if (s == "=" || s == "#" || s == "/=" || s == "<" || s == ">" || s == "<=" || s == "=<" || s == ">=" || s == "\\leq" || s == "\\geq" ||
+            s == "\\in" || s == "\\notin" || s == "\\subseteq")
+            return 5;
+        if (s == "\\cup" || s == "\\union" || s == "\\cap" || s == "\\intersect" || s == "\\") return 8;
+        if (s == "..") return 9;
+        if (s == "+" || s == "-") return 10;
+        if (s == "%") return 11;
+        if (s == "*" || s == "\\div") return 13;
+        return -1;
+    }
+    static EP mk(Expr::K k, const Tok &at) {
+        auto e = std::make_shared<Expr>();
+        e->k = k;
+        e->pos = {at.line, at.col};
+        return e;
+    }
+    EP primary() {
+        const Tok k = cur();
+        if (k.t == Tok::NUM) { i++; auto e = mk(Expr::NUM, k); e->num = atoll(k.s.c_str()); return e; }
+        if (k.t == Tok::STR) { i++; auto e = mk(Expr::STR, k); e->s = k.s; return e; }
+        if (k.t == Tok::IDENT) {
+            if (k.s == "TRUE" || k.s == "FALSE") { i++; auto e = mk(Expr::BOOL, k); e->num = k.s == "TRUE"; return e; }
+            if (k.s == "IF") {
+                i++;
+                auto e = mk(Expr::IF, k);
+                e->a.push_back(expr(0));
+                expect_id("THEN");
+                e->a.push_back(expr(0));
+                expect_id("ELSE");
+                e->a.push_back(expr(0));
+                return e;
+            }
+            i++;
+            auto e = mk(Expr::ID, k);
+            e->s = k.s;
+            return e;
+        }
+        if (k.t == Tok::SYM) {
+            if (k.s == "(") { i++; EP e = expr(0); expect_sym(")"); e->paren = true; return e; }
+            if (k.s == "{") {
+                i++;
+                auto e = mk(Expr::SETENUM, k);
+                if (!is_sym("}")) for (;;) { e->a.push_back(expr(0)); if (is_sym(",")) { i++; continue; } break; }
+                expect_sym("}");
+                return e;
+            }
+            if (k.s == "<<") {
+                i++;
+                auto e = mk(Expr::TUPLE, k);
+                if (!is_sym(">>")) for (;;) { e->a.push_back(expr(0)); if (is_sym(",")) { i++; continue; } break; }
+                expect_sym(">>");
+                return e;
+            }
+            if (k.s == "[") {  // [x \in S |-> e]
+                i++;
+                auto e = mk(Expr::FUNCDEF, k);
+                e->bound = ident("a bound variable after `[`");
+                expect_sym("\\in");
+                e->a.push_back(expr(6));
+                expect_sym("|->");
+                e->a.push_back(expr(0));
+                expect_sym("]");
+                return e;
+            }
+            if (k.s == "\\A" || k.s == "\\E") {
+                i++;
+                auto e = mk(Expr::QUANT, k);
+                e->s = k.s;
+                e->bound = ident("a bound variable");
+                expect_sym("\\in");
+                e->a.push_back(expr(6));
+                expect_sym(":");
+                e->a.push_back(expr(0));
+                return e;
+            }
+            if (k.s == "~" || k.s == "\\lnot" || k.s == "\\neg") { i++; auto e = mk(Expr::UNOP, k); e->s = "~"; e->a.push_back(expr(4)); return e; }
+            if (k.s == "-") { i++; auto e = mk(Expr::UNOP, k); e->s = "-"; e->a.push_back(expr(12)); return e; }
+            if (k.s == "/\\" || k.s == "\\/") {  // bulleted list: items separated by the same bullet
+                const std::string op = k.s;
+                i++;
+                EP acc = expr(4);
+                while (is_sym(op.c_str())) {
+                    const Tok at = cur();
+                    i++;
+                    auto b = mk(Expr::BINOP, at);
+                    b->s = op;
+                    b->a = {acc, expr(4)};
+                    acc = b;
+                }
+                acc->paren = true;
+                return acc;
+            }
+        }
+        fail("expected an expression");
+    }
+    EP postfix() {
+        EP e = primary();
+        for (;;) {
+            if (is_sym("[")) {
+                const Tok at = cur();
+                i++;
+                auto x = mk(Expr::INDEX, at);
+                x->a = {e, expr(0)};
+                expect_sym("]");
+                e = x;
+            } else if (is_sym("'")) {
+                const Tok at = cur();
+                i++;
+                auto x = mk(Expr::PRIME, at);
+                x->a = {e};
+                e = x;
+            } else {
+                return e;
+            }
+        }
+    }
+    EP expr(int minprec) {
+        EP lhs = postfix();
+        for (;;) {
+            bool right = false;
+            const int p = infix_prec(cur(), right);
+            if (p < 0 || p < minprec) return lhs;
+            const Tok op = cur();
+            i++;
+            EP rhs = expr(p + 1);
+            auto b = mk(Expr::BINOP, op);
+            b->s = op.s == "\\land" ? "/\\" : op.s == "\\lor" ? "\\/" : op.s == "=<" || op.s == "\\leq" ? "<=" : op.s == "\\geq" ? ">=" : op.s == "/=" ? "#" : op.s;
+            b->pos = lhs->pos;
+            b->a = {lhs, rhs};
+            lhs = b;
+        }
+    }
+
+    // ---- PlusCal
+    static bool decl_end_keyword(const std::string &s) {
+        return s == "begin" || s == "process" || s == "fair" || s == "define" || s == "macro" || s == "procedure";
+    }
+    std::vector<VarDecl> vardecls() {
+        std::vector<VarDecl> v;
+        while (cur().t == Tok::IDENT && !decl_end_keyword(cur().s)) {
+            VarDecl d;
+            d.pos = {cur().line, cur().col};
+            d.name = t[i++].s;
+            if (is_sym("=")) { i++; d.init = expr(0); }
+            else if (is_sym("\\in")) { i++; d.in_set = true; d.init = expr(0); }
+            else fail("variable `" + d.name + "` needs an initial value (`= e` or `\\in S`): defaultInitValue is not supported");
+            v.push_back(d);
+            if (is_sym(",") || is_sym(";")) i++;
+        }
+        return v;
+    }
+    bool at_block_end() const {
+        return cur().t == Tok::END || is_id("end") || is_id("else") || is_id("elsif") || is_id("or");
+    }
+    std::vector<SP> stmts() {
+        std::vector<SP> v;
+        while (!at_block_end()) {
+            v.push_back(stmt());
+            if (is_sym(";")) i++;
+            else if (!at_block_end()) fail("expected `;`");
+        }
+        return v;
+    }
+    // after `if` / `elsif`: condition, then-block and the else part (an elsif chain nests); `end if` is left to the caller
+    void if_tail(Stmt &s) {
+        s.e = expr(0);
+        expect_id("then");
+        s.blocks.push_back(stmts());
+        if (is_id("elsif")) {
+            auto inner = std::make_shared<Stmt>();
+            inner->k = Stmt::IF;
+            inner->pos = {cur().line, cur().col};
+            i++;
+            if_tail(*inner);
+            s.blocks.push_back({inner});
+        } else if (is_id("else")) {
+            i++;
+            s.blocks.push_back(stmts());
+        } else {
+            s.blocks.push_back({});
+        }
+    }
+    SP stmt() {
+        auto s = std::make_shared<Stmt>();
+        if (cur().t == Tok::IDENT && peek().t == Tok::SYM && peek().s == ":") {
+            s->label = t[i].s;
+            i += 2;
+            if (is_sym("+") || is_sym("-")) i++;  // fairness modifiers carry no meaning for safety checking
+        }
+        s->pos = {cur().line, cur().col};
+        if (cur().t != Tok::IDENT) fail("expected a statement");
+        const std::string kw = cur().s;
+        if (kw == "if") {
+            i++;
+            s->k = Stmt::IF;
+            if_tail(*s);
+            expect_id("end");
+            expect_id("if");
+            return s;
+        }
+        if (kw == "while") {
+            i++;
+            s->k = Stmt::WHILE;
+            s->e = expr(0);
+            expect_id("do");
+            s->blocks.push_back(stmts());
+            expect_id("end");
+            expect_id("while");
+            return s;
+        }
+        if (kw == "either") {
+            i++;
+            s->k = Stmt::EITHER;
+            s->blocks.push_back(stmts());
+            while (is_id("or")) { i++; s->blocks.push_back(stmts()); }
+            if (s->blocks.size() < 2) fail("`either` needs at least one `or`");
+            expect_id("end");
+            expect_id("either");
+            return s;
+        }
+        if (kw == "with") {
+            i++;
+            s->k = Stmt::WITH;
+            s->var = ident("a variable after `with`");
+            if (is_sym("=")) { i++; s->with_eq = true; }
+            else expect_sym("\\in");
+            s->e = expr(0);
+            if (is_sym(",") || is_sym(";")) fail("`with` over several variables is not supported: nest the statements");
+            expect_id("do");
+            s->blocks.push_back(stmts());
+            expect_id("end");
+            expect_id("with");
+            return s;
+        }
+        if (kw == "await" || kw == "when") { i++; s->k = Stmt::AWAIT; s->e = expr(0); return s; }
+        if (kw == "assert") { i++; s->k = Stmt::ASSERT; s->e = expr(0); return s; }
+        if (kw == "skip") { i++; s->k = Stmt::SKIP; return s; }
+        if (kw == "goto") { i++; s->k = Stmt::GOTO; s->var = ident("a label after `goto`"); return s; }
+        if (kw == "print") { i++; s->k = Stmt::PRINT; s->e = expr(0); return s; }
+        if (kw == "call" || kw == "return") fail("procedures (`call` / `return`) are not supported");
+        // assignment(s)
+        s->k = Stmt::ASSIGN;
+        s->var = t[i++].s;
+        if (is_sym("[")) { i++; s->idx = expr(0); expect_sym("]"); if (is_sym("[")) fail("only one index level is supported on the left of `:=`"); }
+        expect_sym(":=");
+        s->e = expr(0);
+        if (is_sym("||")) fail("multiple assignment `||` is not supported: use separate statements");
+        return s;
+    }
+    void algorithm(Module &m) {
+        // positioned after "--algorithm" / "--fair algorithm"
+        m.algorithm = ident("the algorithm name");
+        if (is_sym("{")) fail("c-syntax PlusCal is not supported (use the p-syntax: begin ... end algorithm)");
+        if (is_id("variables") || is_id("variable")) { i++; m.globals = vardecls(); }
+        if (is_id("define")) fail("`define` blocks are not supported");
+        if (is_id("macro")) fail("macros are not supported");
+        if (is_id("procedure")) fail("procedures are not supported");
+        if (is_id("begin")) {  // uniprocess
+            i++;
+            Proc p;
+            p.body = stmts();
+            m.procs.push_back(p);
+        } else {
+            while (is_id("process") || is_id("fair")) {
+                if (is_id("fair")) { i++; if (is_sym("+")) i++; }
+                expect_id("process");
+                Proc p;
+                p.name = ident("a process name");
+                if (is_sym("=")) { i++; }
+                else { expect_sym("\\in"); p.is_set = true; }
+                p.id = expr(0);
+                if (is_id("variables") || is_id("variable")) { i++; p.locals = vardecls(); }
+                expect_id("begin");
+                p.body = stmts();
+                expect_id("end");
+                expect_id("process");
+                if (is_sym(";")) i++;
+                m.procs.push_back(p);
+            }
+            if (m.procs.empty()) fail("expected `begin` or `process`");
+        }
+        expect_id("end");
+        expect_id("algorithm");
+    }
+};
+
+size_t find_line_start(const std::string &text, int line) {  // offset of 1-based line
+    size_t p = 0;
+    for (int l = 1; l < line && p != std::string::npos; l++) { p = text.find('\n', p); if (p != std::string::npos) p++; }
+    return p == std::string::npos ? text.size() : p;
+}
+int line_of(const std::string &text, size_t off) { return 1 + (int)std::count(text.begin(), text.begin() + (long)off, '\n'); }
+
+}  // namespace
+
+std::string parse_module(const std::string &text, Module &m) {
+    try {
+        size_t a = text.find("--algorithm");
+        const size_t fa = text.find("--fair algorithm");
+        size_t kw_len = strlen("--algorithm");
+        if (fa != std::string::npos && (a == std::string::npos || fa < a)) { a = fa; kw_len = strlen("--fair algorithm"); }
+        if (a == std::string::npos) return "no PlusCal algorithm (`--algorithm`) in the module";
+        const size_t cbeg = text.rfind("(*", a);
+        if (cbeg == std::string::npos) return "the PlusCal algorithm must be inside a (* ... *) comment";
+        size_t aend = text.find("end algorithm", a);
+        if (aend == std::string::npos) return "missing `end algorithm`";
+        aend += strlen("end algorithm");
+        size_t cend = text.find("*)", aend);
+        if (cend == std::string::npos) return "the algorithm comment is not closed";
+        cend += 2;
+        m.alg_first_line = line_of(text, cbeg);
+        m.alg_last_line = line_of(text, cend - 1);
+        // header: module name, constants
+        {
+            Parser h(lex(text, 0, cbeg));
+            for (; h.cur().t != Tok::END; h.i++) {
+                if (h.cur().t == Tok::IDENT && h.cur().s == "MODULE" && h.peek().t == Tok::IDENT) m.name = h.peek().s;
+                if (h.cur().t == Tok::IDENT && (h.cur().s == "CONSTANT" || h.cur().s == "CONSTANTS")) {
+                    h.i++;
+                    while (h.cur().t == Tok::IDENT) {
+                        m.constants.push_back(h.cur().s);
+                        h.i++;
+                        if (h.is_sym(",")) h.i++; else break;
+                    }
+                    h.i--;
+                }
+            }
+        }
+        {
+            Parser p(lex(text, a + kw_len, aend));
+            p.algorithm(m);
+        }
+        // the rest: an existing translation (skipped) and the definitions
+        size_t rest = cend;
+        const size_t tb = text.find("\\* BEGIN TRANSLATION", cend);
+        size_t te = std::string::npos;
+        if (tb != std::string::npos) {
+            te = text.find("\\* END TRANSLATION", tb);
+            if (te == std::string::npos) return "`\\* BEGIN TRANSLATION` without `\\* END TRANSLATION`";
+            m.has_translation = true;
+            m.tr_first_line = line_of(text, tb);
+            m.tr_last_line = line_of(text, te);
+        }
+        std::vector<Tok> toks;
+        if (m.has_translation) {
+            toks = lex(text, rest, tb);
+            toks.pop_back();
+            const size_t after = text.find('\n', te);
+            auto more = lex(text, after == std::string::npos ? text.size() : after, text.size());
+            toks.insert(toks.end(), more.begin(), more.end());
+        } else {
+            toks = lex(text, rest, text.size());
+        }
+        Parser d(toks);
+        while (d.cur().t != Tok::END) {
+            if (d.cur().t == Tok::IDENT && d.cur().col == 1 && d.peek().t == Tok::SYM && d.peek().s == "==") {
+                Definition def;
+                def.name = d.cur().s;
+                def.line = d.cur().line;
+                d.i += 2;
+                // the body ends at the next token in column 1 (next definition / separator / keyword)
+                size_t j = d.i;
+                while (d.t[j].t != Tok::END && d.t[j].col != 1) j++;
+                std::vector<Tok> body(d.t.begin() + (long)d.i, d.t.begin() + (long)j);
+                Tok end;
+                end.line = d.t[j].line;
+                end.col = d.t[j].col;
+                body.push_back(end);
+                Parser bp(body);
+                try {
+                    def.body = bp.expr(0);
+                    if (bp.cur().t == Tok::END) m.defs.push_back(def);  // otherwise: beyond the expression subset, ignored unless used
+                } catch (const ParseError &) {
+                }
+                d.i = j;
+            } else {
+                d.i++;
+            }
+        }
+        return "";
+    } catch (const LexError &e) {
+        return e.msg;
+    } catch (const ParseError &e) {
+        return e.msg;
+    }
+}
+
+// ============================================================================================ translator
+namespace {
+
+struct Ctx {
+    const Module *m = nullptr;
+    const Proc *proc = nullptr;
+    std::set<std::string> locals;   // names of this process's local variables
+    std::string self;               // "self" for a process set, the id text for a single process, "" for a uniprocess
+    bool multi = false;             // multiprocess algorithm: pc is a function
+};
+
+std::string pe(const EP &e, const Ctx &c, const std::set<std::string> &primed, const std::set<std::string> &shadow);
+
+std::string pe_inner(const EP &e, const Ctx &c, const std::set<std::string> &primed, const std::set<std::string> &shadow) {
+    switch (e->k) {
+    case Expr::NUM: return std::to_string(e->num);
+    case Expr::STR: return "\"" + e->s + "\"";
+    case Expr::BOOL: return e->num ? "TRUE" : "FALSE";
+    case Expr::ID: {
+        if (shadow.count(e->s)) return e->s;
+        if (e->s == "self" && c.proc && !c.proc->is_set && !c.self.empty()) return c.self;
+        std::string s = e->s;
+        if (primed.count(s)) s += "'";
+        if (c.locals.count(e->s) && c.proc && c.proc->is_set) s += "[self]";
+        return s;
+    }
+    case Expr::UNOP: return e->s + pe(e->a[0], c, primed, shadow);
+    case Expr::BINOP: {
+        const std::string l = pe(e->a[0], c, primed, shadow), r = pe(e->a[1], c, primed, shadow);
+        if (e->s == "..") return l + ".." + r;
+        return l + " " + e->s + " " + r;
+    }
+    case Expr::INDEX: return pe(e->a[0], c, primed, shadow) + "[" + pe(e->a[1], c, primed, shadow) + "]";
+    case Expr::PRIME: return pe(e->a[0], c, primed, shadow) + "'";
+    case Expr::IF:
+        return "IF " + pe(e->a[0], c, primed, shadow) + " THEN " + pe(e->a[1], c, primed, shadow) + " ELSE " + pe(e->a[2], c, primed, shadow);
+    case Expr::QUANT: {
+        std::set<std::string> sh = shadow;
+        const std::string dom = pe(e->a[0], c, primed, shadow);
+        sh.insert(e->bound);
+        return e->s + " " + e->bound + " \\in " + dom + " : " + pe(e->a[1], c, primed, sh);
+    }
+    case Expr::FUNCDEF: {
+        std::set<std::string> sh = shadow;
+        const std::string dom = pe(e->a[0], c, primed, shadow);
+        sh.insert(e->bound);
+        return "[" + e->bound + " \\in " + dom + " |-> " + pe(e->a[1], c, primed, sh) + "]";
+    }
+    case Expr::SETENUM:
+    case Expr::TUPLE: {
+        std::string s = e->k == Expr::SETENUM ? "{" : "<<";
+        for (size_t i = 0; i < e->a.size(); i++) s += (i ? ", " : "") + pe(e->a[i], c, primed, shadow);
+        return s + (e->k == Expr::SETENUM ? "}" : ">>");
+    }
+    }
+    return "?";
+}
+std::string pe(const EP &e, const Ctx &c, const std::set<std::string> &primed, const std::set<std::string> &shadow) {
+    const std::string s = pe_inner(e, c, primed, shadow);
+    return e->paren ? "(" + s + ")" : s;
+}
+
+// formula tree of one action, rendered with the translator's column conventions
+struct Node;
+using NP = std::shared_ptr<Node>;
+struct Node {
+    enum K { LINE, CONJ, DISJ, IF, EXISTS, ASSERT } k = LINE;
+    std::string text, text2;   // LINE; IF condition; EXISTS "x \in S"; ASSERT expression / message
+    std::vector<NP> kids;      // CONJ / DISJ items; IF: [then, else]; EXISTS: [body]
+};
+NP line(const std::string &s) { auto n = std::make_shared<Node>(); n->text = s; return n; }
+NP conj() { auto n = std::make_shared<Node>(); n->k = Node::CONJ; return n; }
+
+// renders `n` whose first character lands at column `col` (1-based) of the current line
+void render(const NP &n, int col, std::string &out) {
+    auto nl = [&](int c) { out += "\n"; out.append((size_t)(c - 1), ' '); };
+    switch (n->k) {
+    case Node::LINE: out += n->text; break;
+    case Node::ASSERT:
+        out += "Assert(" + n->text + ", ";
+        nl(col + 7);
+        out += "\"" + n->text2 + "\")";
+        break;
+    case Node::CONJ:
+    case Node::DISJ:
+        for (size_t i = 0; i < n->kids.size(); i++) {
+            if (i) nl(col);
+            out += n->k == Node::CONJ ? "/\\ " : "\\/ ";
+            render(n->kids[i], col + 3, out);
+        }
+        break;
+    case Node::IF:
+        out += "IF " + n->text;
+        nl(col + 3);
+        out += "THEN ";
+        render(n->kids[0], col + 8, out);
+        nl(col + 3);
+        out += "ELSE ";
+        render(n->kids[1], col + 8, out);
+        break;
+    case Node::EXISTS:
+        out += "\\E " + n->text + ":";
+        nl(col + 2);
+        render(n->kids[0], col + 2, out);
+        break;
+    }
+}
+
+bool contains_label(const std::vector<SP> &v);
+bool contains_label(const SP &s) {
+    for (const auto &b : s->blocks) if (contains_label(b)) return true;
+    return false;
+}
+bool contains_label(const std::vector<SP> &v) {  // a label or a goto: either one makes the enclosing statement set pc itself
+    for (const auto &s : v) if (!s->label.empty() || s->k == Stmt::GOTO || contains_label(s)) return true;
+    return false;
+}
+
+struct TranslateError { std::string msg; };
+
+struct ActionGen {
+    const Module &m;
+    Ctx c;
+    std::vector<std::string> var_order;  // globals then all locals (VARIABLES order without pc)
+    ActionGen(const Module &mod, const Ctx &ctx) : m(mod), c(ctx) {
+        for (const auto &g : m.globals) var_order.push_back(g.name);
+        for (const auto &p : m.procs) for (const auto &l : p.locals) var_order.push_back(l.name);
+    }
+    std::string pc_ref() const { return c.multi ? "pc[" + c.self + "]" : "pc"; }
+    std::string pc_set(const std::string &label) const {
+        return c.multi ? "pc' = [pc EXCEPT ![" + c.self + "] = \"" + label + "\"]" : "pc' = \"" + label + "\"";
+    }
+    std::string unchanged(const std::set<std::string> &vs, int col) const {
+        std::vector<std::string> names;
+        for (const auto &v : var_order) if (vs.count(v)) names.push_back(v);
+        if (names.size() == 1) return "UNCHANGED " + names[0];
+        // wrapped like the translator: a line is broken (after ", ") before it would pass column 78
+        std::string s = "UNCHANGED << ";
+        int cur = col + (int)s.size();
+        const int item_col = cur;
+        for (size_t i = 0; i < names.size(); i++) {
+            const bool last = i + 1 == names.size();
+            const int need = (int)names[i].size() + (last ? 3 : 1);
+            if (i && cur + need > 78) { s += "\n" + std::string((size_t)(item_col - 1), ' '); cur = item_col; }
+            s += names[i];
+            cur += (int)names[i].size();
+            if (!last) { s += ", "; cur += 2; }
+        }
+        return s + " >>";
+    }
+
+    struct Out {
+        std::vector<NP> items;
+        std::set<std::string> assigned;
+    };
+    // one statement without labels inside; `primed` = variables assigned so far on this path
+    void simple(const SP &s, Out &o, std::set<std::string> &primed, const std::set<std::string> &shadow, int col) {
+        switch (s->k) {
+        case Stmt::ASSIGN: {
+            if (s->var == "pc") throw TranslateError{"assignment to pc at line " + std::to_string(s->pos.line)};
+            if (shadow.count(s->var)) throw TranslateError{"assignment to the `with` variable " + s->var + " at line " + std::to_string(s->pos.line)};
+            bool known = false;
+            for (const auto &v : var_order) known |= v == s->var;
+            if (!known) throw TranslateError{"assignment to undeclared variable " + s->var + " at line " + std::to_string(s->pos.line)};
+            if (primed.count(s->var))
+                throw TranslateError{"second assignment to " + s->var + " in one step (line " + std::to_string(s->pos.line) + "): a label is needed between them"};
+            const std::string rhs = pe(s->e, c, primed, shadow);
+            const bool local_fn = c.locals.count(s->var) && c.proc && c.proc->is_set;
+            std::string t;
+            if (!s->idx && !local_fn) t = s->var + "' = " + rhs;
+            else {
+                std::string path;
+                if (local_fn) path += "[self]";
+                if (s->idx) path += "[" + pe(s->idx, c, primed, shadow) + "]";
+                t = s->var + "' = [" + s->var + " EXCEPT !" + path + " = " + rhs + "]";
+            }
+            o.items.push_back(line(t));
+            o.assigned.insert(s->var);
+            primed.insert(s->var);
+            break;
+        }
+        case Stmt::AWAIT: o.items.push_back(line(pe(s->e, c, primed, shadow))); break;
+        case Stmt::SKIP: o.items.push_back(line("TRUE")); break;
+        case Stmt::PRINT: o.items.push_back(line("PrintT(" + pe(s->e, c, primed, shadow) + ")")); break;
+        case Stmt::ASSERT: {
+            auto n = std::make_shared<Node>();
+            n->k = Node::ASSERT;
+            n->text = pe(s->e, c, primed, shadow);
+            n->text2 = "Failure of assertion at line " + std::to_string(s->pos.line) + ", column " + std::to_string(s->pos.col) + ".";
+            o.items.push_back(n);
+            break;
+        }
+        default: throw TranslateError{"internal: not a simple statement"};
+        }
+        (void)col;
+    }
+
+    // statements [i, n) of `v` inside the current action; `cont` = label control reaches when the sequence ends.
+    // `top` = the first statement is the action's own labeled statement.
+    void seq(const std::vector<SP> &v, size_t i, const std::string &cont, bool top, Out &o, std::set<std::string> primed,
+             const std::set<std::string> &shadow, int col) {
+        for (size_t j = i; j < v.size(); j++) {
+            const SP &s = v[j];
+            if (!s->label.empty() && !(top && j == i)) {  // control passes to another action
+                o.items.push_back(line(pc_set(s->label)));
+                return;
+            }
+            const std::string after = j + 1 < v.size() ? (v[j + 1]->label.empty() ? std::string() : v[j + 1]->label) : cont;
+            auto need_after = [&]() {
+                if (after.empty())
+                    throw TranslateError{"the statement after the " + std::string(s->k == Stmt::IF ? "if" : s->k == Stmt::EITHER ? "either" : "with") +
+                                         " at line " + std::to_string(s->pos.line) + " needs a label (a label occurs inside it)"};
+            };
+            switch (s->k) {
+            case Stmt::GOTO: o.items.push_back(line(pc_set(s->var))); return;
+            case Stmt::WHILE: {
+                if (!(top && j == i)) throw TranslateError{"the while at line " + std::to_string(s->pos.line) + " needs a label"};
+                auto n = std::make_shared<Node>();
+                n->k = Node::IF;
+                n->text = pe(s->e, c, primed, shadow);
+                Out a, b;
+                seq(s->blocks[0], 0, s->label, false, a, primed, shadow, col + 11);
+                seq(v, j + 1, cont, false, b, primed, shadow, col + 11);
+                branch_unchanged({&a, &b}, col + 11);
+                n->kids = {wrap(a), wrap(b)};
+                o.items.push_back(n);
+                o.assigned.insert(a.assigned.begin(), a.assigned.end());
+                o.assigned.insert(b.assigned.begin(), b.assigned.end());
+                return;
+            }
+            case Stmt::IF:
+            case Stmt::EITHER: {
+                const bool lab = contains_label(s);
+                if (lab) need_after();
+                std::vector<Out> outs(s->blocks.size());
+                std::vector<Out *> ptrs;
+                const int inner = s->k == Stmt::IF ? col + 11 : col + 6;
+                for (size_t b = 0; b < s->blocks.size(); b++) {
+                    if (lab) seq(s->blocks[b], 0, after, false, outs[b], primed, shadow, inner);
+                    else {
+                        std::set<std::string> pr = primed;
+                        for (const auto &st : s->blocks[b]) nested(st, outs[b], pr, shadow, inner);
+                        if (outs[b].items.empty()) outs[b].items.push_back(line("TRUE"));
+                    }
+                    ptrs.push_back(&outs[b]);
+                }
+                branch_unchanged(ptrs, inner);
+                auto n = std::make_shared<Node>();
+                if (s->k == Stmt::IF) {
+                    n->k = Node::IF;
+                    n->text = pe(s->e, c, primed, shadow);
+                } else {
+                    n->k = Node::DISJ;
+                }
+                for (auto &ob : outs) { n->kids.push_back(wrap(ob)); o.assigned.insert(ob.assigned.begin(), ob.assigned.end()); }
+                o.items.push_back(n);
+                if (lab) return;  // every branch set pc'
+                for (const auto &ob : outs) primed.insert(ob.assigned.begin(), ob.assigned.end());
+                break;
+            }
+            case Stmt::WITH: {
+                const bool lab = contains_label(s);
+                if (lab) throw TranslateError{"labels inside `with` (line " + std::to_string(s->pos.line) + ") are not allowed"};
+                std::set<std::string> sh = shadow;
+                sh.insert(s->var);
+                Out body;
+                std::set<std::string> pr = primed;
+                for (const auto &st : s->blocks[0]) nested(st, body, pr, sh, col + 5);
+                if (body.items.empty()) body.items.push_back(line("TRUE"));
+                auto n = std::make_shared<Node>();
+                if (s->with_eq) {
+                    n->k = Node::LINE;  // LET x == e IN /\ ...
+                    std::string txt = "LET " + s->var + " == " + pe(s->e, c, primed, shadow) + " IN";
+                    std::string bodytxt;
+                    render(wrap(body), col + 5, bodytxt);
+                    n->text = txt + "\n" + std::string((size_t)(col + 5 - 1), ' ') + bodytxt;
+                } else {
+                    n->k = Node::EXISTS;
+                    n->text = s->var + " \\in " + pe(s->e, c, primed, shadow);
+                    n->kids = {wrap(body)};
+                }
+                o.items.push_back(n);
+                o.assigned.insert(body.assigned.begin(), body.assigned.end());
+                primed.insert(body.assigned.begin(), body.assigned.end());
+                break;
+            }
+            default: simple(s, o, primed, shadow, col); break;
+            }
+        }
+        o.items.push_back(line(pc_set(cont)));
+    }
+    // a statement nested in a label-free compound statement
+    void nested(const SP &s, Out &o, std::set<std::string> &primed, const std::set<std::string> &shadow, int col) {
+        if (s->k == Stmt::GOTO || s->k == Stmt::WHILE)
+            throw TranslateError{std::string(s->k == Stmt::GOTO ? "goto" : "while") + " at line " + std::to_string(s->pos.line) +
+                                 " must be the last statement of its step (put a label after the enclosing statement)"};
+        if (s->k == Stmt::IF || s->k == Stmt::EITHER || s->k == Stmt::WITH) {
+            std::vector<SP> one{s};
+            Out tmp;
+            // reuse seq() on a one-statement sequence, then drop the trailing pc' it appends
+            seq(one, 0, "?", false, tmp, primed, shadow, col);
+            tmp.items.pop_back();
+            for (auto &it : tmp.items) o.items.push_back(it);
+            o.assigned.insert(tmp.assigned.begin(), tmp.assigned.end());
+            primed.insert(tmp.assigned.begin(), tmp.assigned.end());
+            return;
+        }
+        simple(s, o, primed, shadow, col);
+    }
+    void branch_unchanged(const std::vector<Out *> &bs, int col) {
+        std::set<std::string> all;
+        for (auto *b : bs) all.insert(b->assigned.begin(), b->assigned.end());
+        for (auto *b : bs) {
+            std::set<std::string> missing;
+            for (const auto &v : all) if (!b->assigned.count(v)) missing.insert(v);
+            if (missing.empty()) continue;
+            // goes before a trailing pc' conjunct? the translator appends it after the branch's statements
+            b->items.push_back(line(unchanged(missing, col + 3)));
+        }
+    }
+    static NP wrap(const Out &o) {
+        auto n = conj();
+        n->kids = o.items;
+        return n;
+    }
+};
+
+struct LabelSite { const std::vector<SP> *seq; size_t idx; std::string cont; };
+
+void collect_labels(const std::vector<SP> &v, const std::string &cont, std::vector<LabelSite> &out) {
+    for (size_t j = 0; j < v.size(); j++) {
+        const SP &s = v[j];
+        const std::string after = j + 1 < v.size() ? v[j + 1]->label : cont;
+        if (!s->label.empty()) out.push_back({&v, j, cont});
+        for (const auto &b : s->blocks) collect_labels(b, s->k == Stmt::WHILE ? s->label : after, out);
+    }
+}
+
+}  // namespace
+
+std::string translate(const Module &m) {
+    std::string o = "\\* BEGIN TRANSLATION\n";
+    const bool multi = !(m.procs.size() == 1 && m.procs[0].name.empty());
+    std::vector<std::string> vars;
+    for (const auto &g : m.globals) vars.push_back(g.name);
+    vars.push_back("pc");
+    for (const auto &p : m.procs) for (const auto &l : p.locals) vars.push_back(l.name);
+    auto join = [](const std::vector<std::string> &v, const char *sep) { std::string s; for (size_t i = 0; i < v.size(); i++) s += (i ? sep : "") + v[i]; return s; };
+    o += "VARIABLES " + join(vars, ", ") + "\n\n";
+    o += "vars == << " + join(vars, ", ") + " >>\n\n";
+    Ctx none;
+    none.m = &m;
+    const std::set<std::string> empty;
+    if (multi) {
+        std::vector<std::string> parts;
+        for (const auto &p : m.procs) parts.push_back(p.is_set ? "(" + pe(p.id, none, empty, empty) + ")" : "{" + pe(p.id, none, empty, empty) + "}");
+        o += "ProcSet == " + join(parts, " \\cup ") + "\n\n";
+    }
+    // ---- Init
+    {
+        std::string pad(8, ' ');
+        o += "Init == ";
+        bool first = true;
+        auto item = [&](const std::string &s) { o += (first ? "" : pad) + s + "\n"; first = false; };
+        if (!m.globals.empty()) {
+            item("(* Global variables *)");
+            for (const auto &g : m.globals) item("/\\ " + g.name + (g.in_set ? " \\in " : " = ") + pe(g.init, none, empty, empty));
+        }
+        for (const auto &p : m.procs) {
+            if (p.locals.empty()) continue;
+            if (multi) item("(* Process " + p.name + " *)");
+            Ctx c = none;
+            c.proc = &p;
+            const std::string ids = pe(p.id, none, empty, empty);
+            for (const auto &l : p.locals) {
+                const std::string e = pe(l.init, none, empty, empty);
+                if (!multi || !p.is_set) item("/\\ " + l.name + (l.in_set ? " \\in " : " = ") + e);
+                else if (l.in_set) item("/\\ " + l.name + " \\in [" + ids + " -> " + e + "]");
+                else item("/\\ " + l.name + " = [self \\in " + ids + " |-> " + e + "]");
+            }
+        }
+        auto first_label = [&](const Proc &p) -> std::string {
+            if (p.body.empty() || p.body[0]->label.empty()) throw TranslateError{"the first statement of " + (p.name.empty() ? std::string("the algorithm") : "process " + p.name) + " needs a label"};
+            return p.body[0]->label;
+        };
+        try {
+            if (!multi) item("/\\ pc = \"" + first_label(m.procs[0]) + "\"");
+            else if (m.procs.size() == 1) item("/\\ pc = [self \\in ProcSet |-> \"" + first_label(m.procs[0]) + "\"]");
+            else {
+                const std::string head = "/\\ pc = [self \\in ProcSet |-> CASE ";
+                std::string s = head;
+                for (size_t k = 0; k < m.procs.size(); k++) {
+                    const auto &p = m.procs[k];
+                    if (k) s += "\n" + pad + std::string(head.size() - 3, ' ') + "[] ";
+                    s += std::string("self ") + (p.is_set ? "\\in " : "= ") + pe(p.id, none, empty, empty) + " -> \"" + first_label(p) + "\"";
+                }
+                item(s + "]");
+            }
+        } catch (const TranslateError &e) {
+            return "\\* TRANSLATION ERROR: " + e.msg + "\n";
+        }
+        o += "\n";
+    }
+    // ---- actions
+    try {
+        for (const auto &p : m.procs) {
+            Ctx c = none;
+            c.proc = &p;
+            c.multi = multi;
+            for (const auto &l : p.locals) c.locals.insert(l.name);
+            c.self = !multi ? "" : p.is_set ? "self" : pe(p.id, none, empty, empty);
+            ActionGen g(m, c);
+            std::vector<LabelSite> sites;
+            collect_labels(p.body, "Done", sites);
+            std::vector<std::string> names;
+            for (const auto &site : sites) {
+                const SP &s = (*site.seq)[site.idx];
+                const std::string head = s->label + (multi && p.is_set ? "(self)" : "") + " == ";
+                const int col = (int)head.size() + 1;
+                ActionGen::Out out;
+                out.items.push_back(line(g.pc_ref() + " = \"" + s->label + "\""));
+                g.seq(*site.seq, site.idx, site.cont, true, out, {}, {}, col);
+                std::set<std::string> rest;
+                for (const auto &v : g.var_order) if (!out.assigned.count(v)) rest.insert(v);
+                if (!rest.empty()) out.items.push_back(line(g.unchanged(rest, col + 3)));
+                std::string body;
+                render(ActionGen::wrap(out), col, body);
+                o += head + body + "\n\n";
+                names.push_back(s->label + (multi && p.is_set ? "(self)" : ""));
+            }
+            if (multi) o += p.name + (p.is_set ? "(self)" : "") + " == " + join(names, " \\/ ") + "\n\n";
+            else {
+                o += "Next == " + join(names, " \\/ ") + "\n";
+                o += "           \\/ (* Disjunct to prevent deadlock on termination *)\n";
+                o += "              (pc = \"Done\" /\\ UNCHANGED vars)\n\n";
+            }
+        }
+    } catch (const TranslateError &e) {
+        return "\\* TRANSLATION ERROR: " + e.msg + "\n";
+    }
+    if (multi) {
+        std::vector<std::string> dis;
+        for (const auto &p : m.procs) if (!p.is_set) dis.push_back(p.name);
+        for (const auto &p : m.procs) if (p.is_set) dis.push_back("(\\E self \\in " + pe(p.id, none, empty, empty) + ": " + p.name + "(self))");
+        o += "Next == " + dis[0] + "\n";
+        for (size_t k = 1; k < dis.size(); k++) o += "           \\/ " + dis[k] + "\n";
+        o += "           \\/ (* Disjunct to prevent deadlock on termination *)\n";
+        o += "              ((\\A self \\in ProcSet: pc[self] = \"Done\") /\\ UNCHANGED vars)\n\n";
+    }
+    o += "Spec == Init /\\ [][Next]_vars\n\n";
+    o += multi ? "Termination == <>(\\A self \\in ProcSet: pc[self] = \"Done\")\n\n" : "Termination == <>(pc = \"Done\")\n\n";
+    o += "\\* END TRANSLATION\n";
+    return o;
+}
+
+std::string transpile_text(const std::string &text, const Module &m) {
+    const std::string tr = translate(m);
+    if (m.has_translation) {
+        const size_t b = find_line_start(text, m.tr_first_line);
+        size_t e = find_line_start(text, m.tr_last_line + 1);
+        return text.substr(0, b) + tr + text.substr(e);
+    }
+    const size_t after = find_line_start(text, m.alg_last_line + 1);
+    return text.substr(0, after) + tr + text.substr(after);
+}
+
+}  // namespace pcal

@@ -1,0 +1,119 @@
+// pcal.h — PlusCal front-end (p-syntax): parser, pcal2tla-style translator, compiler to the bytecode of
+// spec_vm.h.  Host only.
+//
+// The reference keeps its two root specs UNtranslated (pcal_intro.tla:4-19, atomic_add.tla:4-23) and its
+// Makefile runs `pcal2tla *tla` before `tlc *tla` (Makefile:3-7).  This is the `transpile` half: the
+// translation follows examples/p-manual.pdf §3.8 and App. B (one action per label guarded by pc[self],
+// `await` as an enabling conjunct, Assert(...) with the source position, the terminating disjunct), in the
+// layout of the translator whose output the README quotes (action spans README.md:278-318).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace pcal {
+
+struct Pos { int line = 0, col = 0; };
+
+struct Expr;
+using EP = std::shared_ptr<Expr>;
+struct Expr {
+    enum K { NUM, STR, BOOL, ID, UNOP, BINOP, INDEX, IF, QUANT, SETENUM, TUPLE, FUNCDEF, PRIME } k = NUM;
+    long long num = 0;      // NUM, BOOL
+    std::string s;          // ID name, STR text, operator text, QUANT "\\A" / "\\E"
+    std::string bound;      // QUANT / FUNCDEF bound variable
+    std::vector<EP> a;      // operands; INDEX: [fn, index]; IF: [c, t, e]; QUANT / FUNCDEF: [domain, body]
+    bool paren = false;     // written inside ( )
+    Pos pos;
+};
+
+struct Stmt;
+using SP = std::shared_ptr<Stmt>;
+struct Stmt {
+    enum K { ASSIGN, IF, WHILE, EITHER, WITH, AWAIT, ASSERT, SKIP, GOTO, PRINT } k = SKIP;
+    std::string label;                     // "" = unlabeled
+    Pos pos;                               // of the statement keyword / lhs (asserts print it)
+    std::string var;                       // ASSIGN lhs, WITH variable, GOTO target
+    EP idx;                                // ASSIGN lhs index (x[i] := e), may be null
+    EP e;                                  // ASSIGN rhs; condition of IF / WHILE / AWAIT / ASSERT; WITH set or value
+    bool with_eq = false;                  // with x = e
+    std::vector<std::vector<SP>> blocks;   // IF: then, else; EITHER: branches; WHILE / WITH: body
+};
+
+struct VarDecl {
+    std::string name;
+    bool in_set = false;   // `x \in S` instead of `x = e`
+    EP init;
+    Pos pos;
+};
+
+struct Proc {
+    std::string name;
+    bool is_set = false;   // process P \in S   vs   process P = e
+    EP id;
+    std::vector<VarDecl> locals;
+    std::vector<SP> body;
+};
+
+struct Definition { std::string name; EP body; int line = 0; };
+
+struct Module {
+    std::string name;
+    std::string algorithm;
+    std::vector<std::string> constants;     // CONSTANT(S) declared by the module
+    std::vector<VarDecl> globals;
+    std::vector<Proc> procs;                // a uniprocess algorithm is one Proc with an empty name
+    std::vector<Definition> defs;           // zero-argument definitions outside the algorithm (invariants)
+    int alg_first_line = 0, alg_last_line = 0;   // lines of "(* --algorithm" and "end algorithm *)"
+    bool has_translation = false;
+    int tr_first_line = 0, tr_last_line = 0;     // "\* BEGIN TRANSLATION" .. "\* END TRANSLATION"
+};
+
+// Parse the PlusCal algorithm (and the definitions around it) of a module text.  Returns "" or an error message.
+std::string parse_module(const std::string &text, Module &out);
+
+// The text `pcal2tla` inserts: from "\* BEGIN TRANSLATION" to "\* END TRANSLATION" inclusive, '\n' terminated.
+std::string translate(const Module &m);
+
+// The whole module with the translation inserted after the algorithm comment (replacing an existing one).
+std::string transpile_text(const std::string &text, const Module &m);
+
+// ------------------------------------------------------------------------------------------------
+// Compilation to the stack machine of spec_vm.h.
+struct ConstVal {
+    enum K { INT, STR, SET } k = INT;
+    long long i = 0;
+    std::string s;                 // STR: a string or a model value (both become interned strings)
+    std::vector<ConstVal> elems;   // SET
+};
+struct Config {
+    std::vector<std::string> invariants;                       // INVARIANT names, in cfg order
+    std::vector<std::pair<std::string, ConstVal>> constants;   // CONSTANT name = value
+};
+
+struct VarInfo {
+    std::string name;
+    bool array = false;       // a function over `ids` (flattened to consecutive variables)
+    int base = 0;             // index of the first 32-bit variable
+    std::vector<long long> ids;  // domain of the array (process ids for pc and process locals)
+    char type = 'i';          // 'i' integer, 'b' boolean, 's' interned string
+};
+
+struct Program {
+    int magic = 0x70634c31;
+    std::vector<int> image;               // what the device reads (header, tables, code)
+    std::vector<VarInfo> vars;            // VARIABLES order: globals, pc, process locals
+    std::vector<std::string> strings;     // interned strings; the first `nlabels` are the labels, "Done" included
+    int nlabels = 0, nv = 0, ninst = 0, maxch = 1, pc_base = 0;
+    bool multi = true;
+    unsigned long long num_init = 1;
+    std::vector<std::string> invariants;
+    struct AssertPos { int line, col; };
+    std::vector<AssertPos> asserts;
+    std::string module, translated;       // module name; the module text with the translation inserted
+};
+
+// Returns "" or an error message.
+std::string compile(const Module &m, const std::string &module_text, const Config &cfg, Program &out);
+
+}  // namespace pcal

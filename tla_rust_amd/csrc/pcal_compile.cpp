@@ -1,0 +1,811 @@
+// pcal_compile.cpp — compiles a parsed PlusCal algorithm (pcal.h) to the program image spec_vm.h executes.
+// Semantics follow the translation (examples/p-manual.pdf App. B): one atomic action per label; statements of a
+// step see the assignments made earlier in the same step; `either` / `with` alternatives are separate
+// successors; `await` disables; `assert` is an error raised while the successor is generated; the terminating
+// disjunct (p.63) is the engine's last slot.  INVARIANTs are the zero-argument definitions the cfg names.
+#include "pcal.h"
+#include "spec_vm.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <set>
+
+namespace pcal {
+namespace {
+
+struct CompileError { std::string msg; };
+[[noreturn]] void cfail(const std::string &msg, Pos p = {}) {
+    throw CompileError{p.line ? msg + " (line " + std::to_string(p.line) + ", column " + std::to_string(p.col) + ")" : msg};
+}
+
+bool has_label(const std::vector<SP> &v);
+bool has_label(const SP &s) {
+    for (const auto &b : s->blocks) if (has_label(b)) return true;
+    return false;
+}
+bool has_label(const std::vector<SP> &v) {  // a label or a goto: either one makes the enclosing statement set pc itself
+    for (const auto &s : v) if (!s->label.empty() || s->k == Stmt::GOTO || has_label(s)) return true;
+    return false;
+}
+void all_labels(const std::vector<SP> &v, std::vector<std::string> &out) {
+    for (const auto &s : v) {
+        if (!s->label.empty()) out.push_back(s->label);
+        for (const auto &b : s->blocks) all_labels(b, out);
+    }
+}
+
+struct Compiler {
+    const Module &m;
+    const Config &cfg;
+    Program &P;
+    std::vector<int> &c;  // the image being built
+    std::map<std::string, int> var_index, str_id;
+    std::map<std::string, ConstVal> consts;
+    struct Bind { std::string name; int temp; bool is_const; long long value; };
+    std::vector<Bind> binds;
+    int next_temp = 0;
+    const Proc *proc = nullptr;
+    std::set<std::string> proc_locals;
+    bool have_self_const = false;
+    long long self_const = 0;
+    std::vector<long long> procset;
+    int inline_depth = 0;
+
+    Compiler(const Module &mod, const Config &cf, Program &prog) : m(mod), cfg(cf), P(prog), c(prog.image) {}
+
+    int intern(const std::string &s) {
+        auto it = str_id.find(s);
+        if (it != str_id.end()) return it->second;
+        const int id = (int)P.strings.size();
+        P.strings.push_back(s);
+        str_id[s] = id;
+        return id;
+    }
+    void emit(int op) { c.push_back(op); }
+    void emit(int op, int a) { c.push_back(op); c.push_back(a); }
+    int emit_jump(int op) { c.push_back(op); c.push_back(-1); return (int)c.size() - 1; }
+    void patch(int at) { c[(size_t)at] = (int)c.size(); }
+    int new_temp(Pos p) {
+        if (next_temp >= mc::SpecVm::TEMPS) cfail("expression too deeply nested (temporaries exhausted)", p);
+        return next_temp++;
+    }
+
+    // ---- constants
+    bool const_scalar(const EP &e, long long &out) {
+        switch (e->k) {
+        case Expr::NUM: out = e->num; return true;
+        case Expr::BOOL: out = e->num; return true;
+        case Expr::STR: out = intern(e->s); return true;
+        case Expr::ID: {
+            for (size_t i = binds.size(); i-- > 0;) if (binds[i].name == e->s) { if (binds[i].is_const) { out = binds[i].value; return true; } return false; }
+            if (e->s == "self" && have_self_const) { out = self_const; return true; }
+            auto it = consts.find(e->s);
+            if (it == consts.end()) return false;
+            if (it->second.k == ConstVal::INT) { out = it->second.i; return true; }
+            if (it->second.k == ConstVal::STR) { out = intern(it->second.s); return true; }
+            return false;
+        }
+        case Expr::UNOP: { long long a; if (e->s == "-" && const_scalar(e->a[0], a)) { out = -a; return true; } return false; }
+        case Expr::BINOP: {
+            long long a, b;
+            if (!const_scalar(e->a[0], a) || !const_scalar(e->a[1], b)) return false;
+            if (e->s == "+") out = a + b; else if (e->s == "-") out = a - b; else if (e->s == "*") out = a * b;
+            else if (e->s == "\\div" && b > 0) out = a / b - ((a % b != 0 && a < 0) ? 1 : 0);
+            else if (e->s == "%" && b > 0) out = ((a % b) + b) % b;
+            else return false;
+            return true;
+        }
+        default: return false;
+        }
+    }
+    bool const_from(const ConstVal &v, std::vector<long long> &out) {
+        if (v.k != ConstVal::SET) return false;
+        for (const auto &x : v.elems) {
+            if (x.k == ConstVal::INT) out.push_back(x.i);
+            else if (x.k == ConstVal::STR) out.push_back(intern(x.s));
+            else return false;
+        }
+        return true;
+    }
+    bool const_set(const EP &e, std::vector<long long> &out) {
+        if (e->k == Expr::SETENUM) {
+            for (const auto &x : e->a) { long long v; if (!const_scalar(x, v)) return false; out.push_back(v); }
+            return true;
+        }
+        if (e->k == Expr::BINOP && e->s == "..") {
+            long long a, b;
+            if (!const_scalar(e->a[0], a) || !const_scalar(e->a[1], b)) return false;
+            if (b - a > 100000) return false;
+            for (long long x = a; x <= b; x++) out.push_back(x);
+            return true;
+        }
+        if (e->k == Expr::BINOP && (e->s == "\\cup" || e->s == "\\union")) {
+            std::vector<long long> a, b;
+            if (!const_set(e->a[0], a) || !const_set(e->a[1], b)) return false;
+            out = a;
+            for (long long x : b) if (std::find(out.begin(), out.end(), x) == out.end()) out.push_back(x);
+            return true;
+        }
+        if (e->k == Expr::ID) {
+            if (e->s == "BOOLEAN") { out = {0, 1}; return true; }
+            if (e->s == "ProcSet" && !procset.empty()) { out = procset; return true; }
+            auto it = consts.find(e->s);
+            if (it != consts.end()) return const_from(it->second, out);
+            for (const auto &d : m.defs) if (d.name == e->s && inline_depth < 8) { inline_depth++; const bool ok = const_set(d.body, out); inline_depth--; return ok; }
+        }
+        return false;
+    }
+    char type_of(const EP &e) {
+        switch (e->k) {
+        case Expr::STR: return 's';
+        case Expr::BOOL: case Expr::QUANT: return 'b';
+        case Expr::UNOP: return e->s == "~" ? 'b' : 'i';
+        case Expr::BINOP: {
+            static const char *boolops[] = {"/\\", "\\/", "=>", "=", "#", "<", ">", "<=", ">=", "\\in", "\\notin"};
+            for (const char *o : boolops) if (e->s == o) return 'b';
+            if (e->s == "..") return type_of(e->a[0]);
+            return 'i';
+        }
+        case Expr::IF: return type_of(e->a[1]);
+        case Expr::SETENUM: return e->a.empty() ? 'i' : type_of(e->a[0]);
+        case Expr::FUNCDEF: return type_of(e->a[1]);
+        case Expr::ID: {
+            if (e->s == "BOOLEAN") return 'b';
+            auto it = consts.find(e->s);
+            if (it != consts.end()) {
+                if (it->second.k == ConstVal::STR) return 's';
+                if (it->second.k == ConstVal::SET && !it->second.elems.empty() && it->second.elems[0].k == ConstVal::STR) return 's';
+                return 'i';
+            }
+            auto vi = var_index.find(e->s);
+            if (vi != var_index.end()) return P.vars[(size_t)vi->second].type;
+            return 'i';
+        }
+        case Expr::INDEX: return type_of(e->a[0]);
+        default: return 'i';
+        }
+    }
+
+    // ---- array access helpers
+    static bool contiguous(const std::vector<long long> &ids) {
+        for (size_t i = 1; i < ids.size(); i++) if (ids[i] != ids[0] + (long long)i) return false;
+        return !ids.empty();
+    }
+    void emit_indexed(int op, const VarInfo &vi, Pos p) {
+        if (!contiguous(vi.ids)) cfail("`" + vi.name + "` is indexed but its domain is not an integer interval", p);
+        c.push_back(op);
+        c.push_back(vi.base);
+        c.push_back((int)vi.ids[0]);
+        c.push_back((int)vi.ids.size());
+    }
+    void push_self(Pos p) {
+        if (have_self_const) emit(mc::VM_PUSH, (int)self_const);
+        else if (proc) emit(mc::VM_SELF);
+        else cfail("`self` outside a process", p);
+    }
+
+    // ---- expressions: leave one value on the stack
+    void ex(const EP &e) {
+        switch (e->k) {
+        case Expr::NUM: emit(mc::VM_PUSH, (int)e->num); return;
+        case Expr::BOOL: emit(mc::VM_PUSH, (int)e->num); return;
+        case Expr::STR: emit(mc::VM_PUSH, intern(e->s)); return;
+        case Expr::ID: {
+            for (size_t i = binds.size(); i-- > 0;)
+                if (binds[i].name == e->s) {
+                    if (binds[i].is_const) emit(mc::VM_PUSH, (int)binds[i].value);
+                    else emit(mc::VM_LOADT, binds[i].temp);
+                    return;
+                }
+            if (e->s == "self") { push_self(e->pos); return; }
+            auto vi = var_index.find(e->s);
+            if (vi != var_index.end()) {
+                const VarInfo &v = P.vars[(size_t)vi->second];
+                if (proc && proc_locals.count(e->s) && proc->is_set && P.multi) { push_self(e->pos); emit_indexed(mc::VM_LOADX, v, e->pos); return; }
+                if (v.array) cfail("the function `" + e->s + "` is used as a value; only `" + e->s + "[i]` is supported", e->pos);
+                emit(mc::VM_LOAD, v.base);
+                return;
+            }
+            long long cv;
+            if (const_scalar(e, cv)) { emit(mc::VM_PUSH, (int)cv); return; }
+            for (const auto &d : m.defs)
+                if (d.name == e->s) {
+                    if (++inline_depth > 16) cfail("definitions nest too deeply (recursion?)", e->pos);
+                    ex(d.body);
+                    inline_depth--;
+                    return;
+                }
+            cfail("unknown identifier `" + e->s + "`", e->pos);
+        }
+        case Expr::INDEX: {
+            if (e->a[0]->k != Expr::ID) cfail("only `name[index]` is supported", e->pos);
+            auto vi = var_index.find(e->a[0]->s);
+            if (vi == var_index.end() || !P.vars[(size_t)vi->second].array) cfail("`" + e->a[0]->s + "` is not a function variable", e->pos);
+            if (proc && proc_locals.count(e->a[0]->s) && proc->is_set && P.multi)
+                cfail("process-local function variables are not supported (`" + e->a[0]->s + "`)", e->pos);
+            ex(e->a[1]);
+            emit_indexed(mc::VM_LOADX, P.vars[(size_t)vi->second], e->pos);
+            return;
+        }
+        case Expr::UNOP: ex(e->a[0]); emit(e->s == "~" ? mc::VM_NOT : mc::VM_NEG); return;
+        case Expr::IF: {
+            ex(e->a[0]);
+            const int je = emit_jump(mc::VM_JZ);
+            ex(e->a[1]);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(je);
+            ex(e->a[2]);
+            patch(jend);
+            return;
+        }
+        case Expr::BINOP: binop(e); return;
+        case Expr::QUANT: quant(e); return;
+        default: cfail("this kind of expression is only supported as a constant set / initial value", e->pos);
+        }
+    }
+    void binop(const EP &e) {
+        const std::string &o = e->s;
+        if (o == "/\\" || o == "\\/" || o == "=>") {
+            ex(e->a[0]);
+            const int j1 = emit_jump(o == "\\/" ? mc::VM_JNZ : mc::VM_JZ);
+            ex(e->a[1]);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(j1);
+            emit(mc::VM_PUSH, o == "/\\" ? 0 : 1);
+            patch(jend);
+            return;
+        }
+        if (o == "\\in" || o == "\\notin") {
+            const int t = new_temp(e->pos);
+            ex(e->a[0]);
+            emit(mc::VM_STORET, t);
+            member(t, e->a[1]);
+            if (o == "\\notin") emit(mc::VM_NOT);
+            next_temp--;
+            return;
+        }
+        static const std::pair<const char *, int> ops[] = {{"=", mc::VM_EQ},  {"#", mc::VM_NE},  {"<", mc::VM_LT},    {">", mc::VM_GT},
+                                                          {"<=", mc::VM_LE}, {">=", mc::VM_GE}, {"+", mc::VM_ADD},   {"-", mc::VM_SUB},
+                                                          {"*", mc::VM_MUL}, {"%", mc::VM_MOD}, {"\\div", mc::VM_DIV}};
+        for (const auto &p : ops)
+            if (o == p.first) { ex(e->a[0]); ex(e->a[1]); emit(p.second); return; }
+        cfail("operator `" + o + "` is not supported here", e->pos);
+    }
+    // value in temp t is a member of the set expression s
+    void member(int t, const EP &s) {
+        if (s->k == Expr::BINOP && s->s == "..") {
+            emit(mc::VM_LOADT, t); ex(s->a[0]); emit(mc::VM_GE);
+            const int jf = emit_jump(mc::VM_JZ);
+            emit(mc::VM_LOADT, t); ex(s->a[1]); emit(mc::VM_LE);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(jf);
+            emit(mc::VM_PUSH, 0);
+            patch(jend);
+            return;
+        }
+        std::vector<long long> elems;
+        if (s->k == Expr::SETENUM) {  // elements may be state dependent
+            std::vector<int> hits;
+            for (const auto &x : s->a) { emit(mc::VM_LOADT, t); ex(x); emit(mc::VM_EQ); hits.push_back(emit_jump(mc::VM_JNZ)); }
+            emit(mc::VM_PUSH, 0);
+            const int jend = emit_jump(mc::VM_JMP);
+            for (int h : hits) patch(h);
+            emit(mc::VM_PUSH, 1);
+            patch(jend);
+            return;
+        }
+        if (!const_set(s, elems)) cfail("`\\in` needs an interval a..b, a set enumeration or a constant set", s->pos);
+        std::vector<int> hits;
+        for (long long x : elems) { emit(mc::VM_LOADT, t); emit(mc::VM_PUSH, (int)x); emit(mc::VM_EQ); hits.push_back(emit_jump(mc::VM_JNZ)); }
+        emit(mc::VM_PUSH, 0);
+        const int jend = emit_jump(mc::VM_JMP);
+        for (int h : hits) patch(h);
+        emit(mc::VM_PUSH, 1);
+        patch(jend);
+    }
+    void quant(const EP &e) {
+        const bool all = e->s == "\\A";
+        const EP &dom = e->a[0];
+        if (dom->k == Expr::BINOP && dom->s == "..") {
+            const int tx = new_temp(e->pos), th = new_temp(e->pos);
+            ex(dom->a[0]); emit(mc::VM_STORET, tx);
+            ex(dom->a[1]); emit(mc::VM_STORET, th);
+            const int loop = (int)c.size();
+            emit(mc::VM_LOADT, tx); emit(mc::VM_LOADT, th); emit(mc::VM_LE);
+            const int jdone = emit_jump(mc::VM_JZ);
+            binds.push_back({e->bound, tx, false, 0});
+            ex(e->a[1]);
+            binds.pop_back();
+            const int jhit = emit_jump(all ? mc::VM_JZ : mc::VM_JNZ);
+            emit(mc::VM_LOADT, tx); emit(mc::VM_PUSH, 1); emit(mc::VM_ADD); emit(mc::VM_STORET, tx);
+            emit(mc::VM_JMP, loop);
+            patch(jdone);
+            emit(mc::VM_PUSH, all ? 1 : 0);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(jhit);
+            emit(mc::VM_PUSH, all ? 0 : 1);
+            patch(jend);
+            next_temp -= 2;
+            return;
+        }
+        std::vector<long long> elems;
+        if (!const_set(dom, elems)) cfail("a quantifier needs an interval or a constant set as its domain", dom->pos);
+        std::vector<int> hits;
+        for (long long x : elems) {
+            binds.push_back({e->bound, 0, true, x});
+            ex(e->a[1]);
+            binds.pop_back();
+            hits.push_back(emit_jump(all ? mc::VM_JZ : mc::VM_JNZ));
+        }
+        emit(mc::VM_PUSH, all ? 1 : 0);
+        const int jend = emit_jump(mc::VM_JMP);
+        for (int h : hits) patch(h);
+        emit(mc::VM_PUSH, all ? 0 : 1);
+        patch(jend);
+    }
+
+    // CHOOSE over a constant set: leaves the chosen element on the stack; returns the number of alternatives
+    unsigned long long choose_from(const EP &set, Pos p) {
+        std::vector<long long> elems;
+        if (!const_set(set, elems)) cfail("the set must be an interval with constant bounds or a constant set", set->pos);
+        if (elems.empty()) cfail("empty set: the step would never be enabled", p);
+        emit(mc::VM_CHOOSE, (int)elems.size());
+        if (contiguous(elems)) { emit(mc::VM_PUSH, (int)elems[0]); emit(mc::VM_ADD); return elems.size(); }
+        const int t = new_temp(p);
+        emit(mc::VM_STORET, t);
+        std::vector<int> ends;
+        for (size_t k = 0; k < elems.size(); k++) {
+            emit(mc::VM_LOADT, t); emit(mc::VM_PUSH, (int)k); emit(mc::VM_EQ);
+            const int jn = emit_jump(mc::VM_JZ);
+            emit(mc::VM_PUSH, (int)elems[k]);
+            ends.push_back(emit_jump(mc::VM_JMP));
+            patch(jn);
+        }
+        emit(mc::VM_FAIL);
+        for (int x : ends) patch(x);
+        next_temp--;
+        return elems.size();
+    }
+
+    // ---- statements
+    void assign(const SP &s) {
+        auto vi = var_index.find(s->var);
+        if (vi == var_index.end() || s->var == "pc") cfail("assignment to `" + s->var + "`, which is not a variable of the algorithm", s->pos);
+        const VarInfo &v = P.vars[(size_t)vi->second];
+        const bool self_indexed = proc && proc_locals.count(s->var) && proc->is_set && P.multi;
+        bool global_or_own = self_indexed || !v.array || s->idx;
+        for (const auto &pr : m.procs) for (const auto &l : pr.locals) if (l.name == s->var && &pr != proc) global_or_own = false;
+        if (!global_or_own) cfail("`" + s->var + "` cannot be assigned here", s->pos);
+        if (self_indexed) {
+            if (s->idx) cfail("process-local function variables are not supported", s->pos);
+            push_self(s->pos);
+            ex(s->e);
+            emit_indexed(mc::VM_STOREX, v, s->pos);
+        } else if (s->idx) {
+            if (!v.array) cfail("`" + s->var + "` is not a function variable", s->pos);
+            ex(s->idx);
+            ex(s->e);
+            emit_indexed(mc::VM_STOREX, v, s->pos);
+        } else {
+            if (v.array) cfail("assigning a whole function (`" + s->var + " := ...`) is not supported: assign its elements", s->pos);
+            ex(s->e);
+            emit(mc::VM_STORE, v.base);
+        }
+    }
+    // a statement with no label inside; returns the number of alternatives it introduces
+    unsigned long long nolabel(const SP &s) {
+        switch (s->k) {
+        case Stmt::ASSIGN: assign(s); return 1;
+        case Stmt::AWAIT: ex(s->e); emit(mc::VM_AWAIT); return 1;
+        case Stmt::ASSERT:
+            ex(s->e);
+            emit(mc::VM_ASSERT, (int)P.asserts.size());
+            P.asserts.push_back({s->pos.line, s->pos.col});
+            return 1;
+        case Stmt::SKIP: case Stmt::PRINT: return 1;
+        case Stmt::IF: {
+            ex(s->e);
+            const int je = emit_jump(mc::VM_JZ);
+            const unsigned long long a = block(s->blocks[0]);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(je);
+            const unsigned long long b = block(s->blocks[1]);
+            patch(jend);
+            return std::max(a, b);
+        }
+        case Stmt::EITHER: {
+            const int t = new_temp(s->pos);
+            emit(mc::VM_CHOOSE, (int)s->blocks.size());
+            emit(mc::VM_STORET, t);
+            std::vector<int> ends;
+            unsigned long long mx = 1;
+            for (size_t b = 0; b < s->blocks.size(); b++) {
+                emit(mc::VM_LOADT, t); emit(mc::VM_PUSH, (int)b); emit(mc::VM_EQ);
+                const int jn = emit_jump(mc::VM_JZ);
+                mx = std::max(mx, block(s->blocks[b]));
+                ends.push_back(emit_jump(mc::VM_JMP));
+                patch(jn);
+            }
+            emit(mc::VM_FAIL);
+            for (int x : ends) patch(x);
+            next_temp--;
+            return mx * s->blocks.size();
+        }
+        case Stmt::WITH: {
+            const int t = new_temp(s->pos);
+            unsigned long long n = 1;
+            if (s->with_eq) ex(s->e);
+            else n = choose_from(s->e, s->pos);
+            emit(mc::VM_STORET, t);
+            binds.push_back({s->var, t, false, 0});
+            const unsigned long long b = block(s->blocks[0]);
+            binds.pop_back();
+            next_temp--;
+            return n * b;
+        }
+        case Stmt::GOTO: case Stmt::WHILE:
+            cfail(std::string(s->k == Stmt::GOTO ? "goto" : "while") + " must end its step: put a label after the enclosing statement", s->pos);
+        }
+        return 1;
+    }
+    unsigned long long block(const std::vector<SP> &v) {
+        unsigned long long ch = 1;
+        for (const auto &s : v) ch *= nolabel(s);
+        return ch;
+    }
+    void set_pc(const std::string &label, Pos p) {
+        auto it = str_id.find(label);
+        if (it == str_id.end() || it->second >= P.nlabels) cfail("unknown label `" + label + "`", p);
+        emit(mc::VM_SETPC, it->second);
+        emit(mc::VM_HALT);
+    }
+    // statements [i, n) of v inside one action; cont = label reached when the sequence ends
+    unsigned long long seq(const std::vector<SP> &v, size_t i, const std::string &cont, bool top) {
+        unsigned long long ch = 1;
+        for (size_t j = i; j < v.size(); j++) {
+            const SP &s = v[j];
+            if (!s->label.empty() && !(top && j == i)) { set_pc(s->label, s->pos); return ch; }
+            const std::string after = j + 1 < v.size() ? v[j + 1]->label : cont;
+            switch (s->k) {
+            case Stmt::GOTO: set_pc(s->var, s->pos); return ch;
+            case Stmt::WHILE: {
+                if (!(top && j == i)) cfail("a while needs a label", s->pos);
+                ex(s->e);
+                const int je = emit_jump(mc::VM_JZ);
+                const unsigned long long a = seq(s->blocks[0], 0, s->label, false);
+                patch(je);
+                const unsigned long long b = seq(v, j + 1, cont, false);
+                return ch * std::max(a, b);
+            }
+            case Stmt::IF:
+                if (has_label(s)) {
+                    if (after.empty()) cfail("the statement after this if needs a label (a label occurs inside it)", s->pos);
+                    ex(s->e);
+                    const int je = emit_jump(mc::VM_JZ);
+                    const unsigned long long a = seq(s->blocks[0], 0, after, false);
+                    patch(je);
+                    const unsigned long long b = seq(s->blocks[1], 0, after, false);
+                    return ch * std::max(a, b);
+                }
+                ch *= nolabel(s);
+                break;
+            case Stmt::EITHER:
+                if (has_label(s)) {
+                    if (after.empty()) cfail("the statement after this either needs a label (a label occurs inside it)", s->pos);
+                    const int t = new_temp(s->pos);
+                    emit(mc::VM_CHOOSE, (int)s->blocks.size());
+                    emit(mc::VM_STORET, t);
+                    next_temp--;  // consumed before any branch runs
+                    unsigned long long mx = 1;
+                    for (size_t b = 0; b < s->blocks.size(); b++) {
+                        emit(mc::VM_LOADT, t); emit(mc::VM_PUSH, (int)b); emit(mc::VM_EQ);
+                        const int jn = emit_jump(mc::VM_JZ);
+                        mx = std::max(mx, seq(s->blocks[b], 0, after, false));
+                        patch(jn);
+                    }
+                    emit(mc::VM_FAIL);
+                    return ch * mx * s->blocks.size();
+                }
+                ch *= nolabel(s);
+                break;
+            case Stmt::WITH:
+                if (has_label(s)) cfail("labels inside `with` are not allowed", s->pos);
+                ch *= nolabel(s);
+                break;
+            default: ch *= nolabel(s); break;
+            }
+        }
+        set_pc(cont, v.empty() ? Pos{} : v.back()->pos);
+        return ch;
+    }
+
+    struct Site { const std::vector<SP> *seq; size_t idx; std::string cont; };
+    void sites(const std::vector<SP> &v, const std::string &cont, std::vector<Site> &out) {
+        for (size_t j = 0; j < v.size(); j++) {
+            const SP &s = v[j];
+            const std::string after = j + 1 < v.size() ? v[j + 1]->label : cont;
+            if (!s->label.empty()) out.push_back({&v, j, cont});
+            for (const auto &b : s->blocks) sites(b, s->k == Stmt::WHILE ? s->label : after, out);
+        }
+    }
+
+    // ---- initial values
+    void init_scalar(const VarDecl &d, int slot, unsigned long long &ninit) {
+        if (d.in_set) ninit *= choose_from(d.init, d.pos);
+        else ex(d.init);
+        emit(mc::VM_STORE, slot);
+        if (ninit > (1ull << 40)) cfail("too many initial states", d.pos);
+    }
+
+    void run() {
+        P.module = m.name;
+        P.multi = !(m.procs.size() == 1 && m.procs[0].name.empty());
+        for (const auto &kv : cfg.constants) consts[kv.first] = kv.second;
+        for (const auto &cn : m.constants) if (!consts.count(cn)) cfail("CONSTANT " + cn + " has no value in the configuration");
+        // labels first: label id == string id
+        std::vector<std::string> labels;
+        for (const auto &p : m.procs) all_labels(p.body, labels);
+        for (const auto &l : labels) { if (str_id.count(l)) cfail("label `" + l + "` is used twice"); intern(l); }
+        if (str_id.count("Done")) cfail("`Done` cannot be used as a label");
+        const int done = intern("Done");
+        P.nlabels = (int)P.strings.size();
+        // process instances
+        struct Inst { const Proc *p; long long self; };
+        std::vector<Inst> insts;
+        std::map<const Proc *, std::vector<long long>> ids_of;
+        for (const auto &p : m.procs) {
+            std::vector<long long> ids;
+            if (!P.multi) ids.push_back(0);
+            else if (p.is_set) { if (!const_set(p.id, ids)) cfail("the identifier set of process " + p.name + " must be a constant set", p.id->pos); }
+            else { long long v; if (!const_scalar(p.id, v)) cfail("the identifier of process " + p.name + " must be a constant", p.id->pos); ids.push_back(v); }
+            if (ids.empty()) cfail("process " + p.name + " has no instance");
+            for (long long id : ids) {
+                for (const auto &x : insts) if (x.self == id) cfail("two processes share the identifier " + std::to_string(id));
+                insts.push_back({&p, id});
+                procset.push_back(id);
+            }
+            ids_of[&p] = ids;
+            if (p.body.empty() || p.body[0]->label.empty()) cfail("the first statement of " + (p.name.empty() ? std::string("the algorithm") : "process " + p.name) + " needs a label");
+        }
+        P.ninst = (int)insts.size();
+        // variables: globals, pc, process locals (the VARIABLES order of the translation)
+        int nv = 0;
+        auto add_var = [&](const std::string &name, bool array, const std::vector<long long> &ids, char type) {
+            if (var_index.count(name)) cfail("variable `" + name + "` is declared twice");
+            VarInfo v;
+            v.name = name;
+            v.array = array;
+            v.base = nv;
+            v.ids = ids;
+            v.type = type;
+            nv += array ? (int)ids.size() : 1;
+            var_index[name] = (int)P.vars.size();
+            P.vars.push_back(v);
+        };
+        auto decl_var = [&](const VarDecl &d, const Proc *owner) {
+            const bool per_inst = owner && owner->is_set && P.multi;
+            if (d.init->k == Expr::FUNCDEF && !d.in_set) {
+                if (per_inst) cfail("process-local function variables are not supported (`" + d.name + "`)", d.pos);
+                std::vector<long long> dom;
+                if (!const_set(d.init->a[0], dom)) cfail("the domain of `" + d.name + "` must be a constant set", d.pos);
+                add_var(d.name, true, dom, type_of(d.init->a[1]));
+            } else if (per_inst) {
+                add_var(d.name, true, ids_of[owner], type_of(d.init));
+            } else {
+                add_var(d.name, false, {}, type_of(d.init));
+            }
+        };
+        for (const auto &g : m.globals) decl_var(g, nullptr);
+        P.pc_base = nv;
+        add_var("pc", P.multi, P.multi ? procset : std::vector<long long>{}, 's');
+        for (const auto &p : m.procs) for (const auto &l : p.locals) decl_var(l, &p);
+        if (nv > mc::SpecVm::MAX_VARS) cfail("the state has " + std::to_string(nv) + " scalar variables; at most " + std::to_string(mc::SpecVm::MAX_VARS) + " are supported");
+        P.nv = nv;
+        // image: header, label table, self table, code
+        c.assign((size_t)mc::VMH_SIZE, 0);
+        const int label_tab = (int)c.size();
+        c.resize(c.size() + (size_t)P.nlabels, -1);
+        const int self_tab = (int)c.size();
+        for (const auto &x : insts) c.push_back((int)x.self);
+        // ---- Init
+        const int init_entry = (int)c.size();
+        unsigned long long ninit = 1;
+        auto init_decl = [&](const VarDecl &d, const Proc *owner) {
+            const VarInfo &v = P.vars[(size_t)var_index[d.name]];
+            const bool per_inst = owner && owner->is_set && P.multi;
+            if (per_inst) {
+                for (size_t k = 0; k < v.ids.size(); k++) {
+                    have_self_const = true;
+                    self_const = v.ids[k];
+                    init_scalar(d, v.base + (int)k, ninit);
+                    have_self_const = false;
+                }
+            } else if (v.array) {
+                for (size_t k = 0; k < v.ids.size(); k++) {
+                    binds.push_back({d.init->bound, 0, true, v.ids[k]});
+                    ex(d.init->a[1]);
+                    binds.pop_back();
+                    emit(mc::VM_STORE, v.base + (int)k);
+                }
+            } else {
+                if (owner && P.multi) { have_self_const = true; self_const = ids_of[owner][0]; }
+                init_scalar(d, v.base, ninit);
+                have_self_const = false;
+            }
+        };
+        for (const auto &g : m.globals) init_decl(g, nullptr);
+        for (const auto &p : m.procs) for (const auto &l : p.locals) init_decl(l, &p);
+        for (size_t k = 0; k < insts.size(); k++) { emit(mc::VM_PUSH, str_id[insts[k].p->body[0]->label]); emit(mc::VM_STORE, P.pc_base + (int)k); }
+        emit(mc::VM_HALT);
+        P.num_init = ninit;
+        // ---- actions
+        unsigned long long maxch = 1;
+        for (const auto &p : m.procs) {
+            proc = &p;
+            proc_locals.clear();
+            for (const auto &l : p.locals) proc_locals.insert(l.name);
+            if (P.multi && !p.is_set) { have_self_const = true; self_const = ids_of[&p][0]; }
+            std::vector<Site> ss;
+            sites(p.body, "Done", ss);
+            for (const auto &site : ss) {
+                const SP &s = (*site.seq)[site.idx];
+                c[(size_t)(label_tab + str_id[s->label])] = (int)c.size();
+                next_temp = 0;
+                maxch = std::max(maxch, seq(*site.seq, site.idx, site.cont, true));
+            }
+            have_self_const = false;
+            proc = nullptr;
+        }
+        proc_locals.clear();
+        if (maxch * (unsigned long long)P.ninst + 1 > 255)
+            cfail("too many alternatives per state (" + std::to_string(maxch) + " per process step x " + std::to_string(P.ninst) + " processes > 254)");
+        P.maxch = (int)maxch;
+        // ---- invariants
+        if (cfg.invariants.size() > 8) cfail("at most 8 invariants are supported");
+        std::vector<int> inv_entry;
+        for (const auto &name : cfg.invariants) {
+            const Definition *def = nullptr;
+            for (const auto &d : m.defs) if (d.name == name) def = &d;
+            if (!def) cfail("INVARIANT " + name + " is not a definition of the module this front-end can read");
+            inv_entry.push_back((int)c.size());
+            next_temp = 0;
+            ex(def->body);
+            emit(mc::VM_HALT);
+            P.invariants.push_back(name);
+        }
+        // ---- header
+        c[mc::VMH_MAGIC] = mc::VM_MAGIC;
+        c[mc::VMH_NV] = nv;
+        c[mc::VMH_NINST] = P.ninst;
+        c[mc::VMH_MAXCH] = P.maxch;
+        c[mc::VMH_PC_BASE] = P.pc_base;
+        c[mc::VMH_DONE] = done;
+        c[mc::VMH_INIT_ENTRY] = init_entry;
+        c[mc::VMH_NINV] = (int)inv_entry.size();
+        for (size_t k = 0; k < inv_entry.size(); k++) c[(size_t)mc::VMH_INV0 + k] = inv_entry[k];
+        c[mc::VMH_LABEL_TAB] = label_tab;
+        c[mc::VMH_SELF_TAB] = self_tab;
+        c[mc::VMH_NLABELS] = P.nlabels;
+        c[mc::VMH_NUM_INIT_LO] = (int)(uint32_t)ninit;
+        c[mc::VMH_NUM_INIT_HI] = (int)(uint32_t)(ninit >> 32);
+        c[mc::VMH_CODE_LEN] = (int)c.size();
+    }
+};
+
+std::string fmt_val(const Program &P, char type, int32_t v) {
+    if (type == 'b') return v ? "TRUE" : "FALSE";
+    if (type == 's') return v >= 0 && (size_t)v < P.strings.size() ? "\"" + P.strings[(size_t)v] + "\"" : "\"?\"";
+    return std::to_string(v);
+}
+
+}  // namespace
+
+std::string compile(const Module &m, const std::string &module_text, const Config &cfg, Program &out) {
+    out = Program();
+    const std::string tr = translate(m);
+    if (tr.rfind("\\* TRANSLATION ERROR: ", 0) == 0) return tr.substr(strlen("\\* TRANSLATION ERROR: "), tr.size() - strlen("\\* TRANSLATION ERROR: ") - 1);
+    out.translated = transpile_text(module_text, m);
+    try {
+        Compiler cc(m, cfg, out);
+        cc.run();
+    } catch (const CompileError &e) {
+        return e.msg;
+    }
+    return "";
+}
+
+}  // namespace pcal
+
+// ------------------------------------------------------------------------------------------------ spec_vm.h host side
+namespace mc {
+
+int SpecVm::make_params(const int64_t *p, unsigned np, Params &o) {
+    if (np < 1 || !p[0]) return -1;
+    const pcal::Program *P = (const pcal::Program *)(intptr_t)p[0];
+    if (P->magic != VM_MAGIC || P->image.size() < (size_t)VMH_SIZE || P->image[VMH_MAGIC] != VM_MAGIC) return -1;
+    const int32_t *c = P->image.data();
+    memset(&o, 0, sizeof o);
+    o.code = c;
+    o.host = P;
+    o.nv = c[VMH_NV];
+    o.words = (o.nv + 1) / 2;
+    o.ninst = c[VMH_NINST];
+    o.maxch = c[VMH_MAXCH];
+    o.pc_base = c[VMH_PC_BASE];
+    o.done = c[VMH_DONE];
+    o.init_entry = c[VMH_INIT_ENTRY];
+    o.ninv = c[VMH_NINV];
+    for (int k = 0; k < 8; k++) o.inv_entry[k] = c[VMH_INV0 + k];
+    o.label_tab = c[VMH_LABEL_TAB];
+    o.self_tab = c[VMH_SELF_TAB];
+    o.code_len = c[VMH_CODE_LEN];
+    o.num_init = (uint64_t)(uint32_t)c[VMH_NUM_INIT_LO] | (uint64_t)(uint32_t)c[VMH_NUM_INIT_HI] << 32;
+    return 0;
+}
+
+int vm_format(const void *host, const int32_t *vals, char *buf, size_t cap) {
+    const pcal::Program &P = *(const pcal::Program *)host;
+    std::string s;
+    for (const auto &v : P.vars) {
+        if (!s.empty()) s += "\n";
+        s += "/\\ " + v.name + " = ";
+        if (!v.array) { s += pcal::fmt_val(P, v.type, vals[v.base]); continue; }
+        // TLC prints a function whose domain is 1..n as a tuple, any other as (k :> v @@ ...) in ascending key order
+        std::vector<size_t> order(v.ids.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = k;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return v.ids[a] < v.ids[b]; });
+        bool seq = true;
+        for (size_t k = 0; k < order.size(); k++) seq &= v.ids[order[k]] == (long long)k + 1;
+        if (seq) {
+            s += "<<";
+            for (size_t k = 0; k < order.size(); k++) s += (k ? ", " : "") + pcal::fmt_val(P, v.type, vals[v.base + (int)order[k]]);
+            s += ">>";
+        } else {
+            s += "(";
+            for (size_t k = 0; k < order.size(); k++)
+                s += (k ? " @@ " : "") + std::to_string(v.ids[order[k]]) + " :> " + pcal::fmt_val(P, v.type, vals[v.base + (int)order[k]]);
+            s += ")";
+        }
+    }
+    const size_t n = s.size() < cap ? s.size() : (cap ? cap - 1 : 0);
+    if (cap) { memcpy(buf, s.data(), n); buf[n] = 0; }
+    return (int)n;
+}
+
+// action id = label id of the instance that moves; nlabels = the terminating disjunct
+int vm_action_of(const void *host, const int32_t *parent_vals, int slot) {
+    const pcal::Program &P = *(const pcal::Program *)host;
+    if (slot < 0) return -1;
+    if (slot >= P.ninst * P.maxch) return P.nlabels;
+    return parent_vals[P.pc_base + slot / P.maxch];
+}
+
+const char *vm_action_name(const void *host, int action) {
+    const pcal::Program &P = *(const pcal::Program *)host;
+    if (action < 0) return "Initial predicate";
+    if (action >= P.nlabels) return "Terminating";
+    return P.strings[(size_t)action].c_str();
+}
+
+// the assertion that fails when the state `vals` is expanded: its index (Program::asserts) or -1; *label = the label
+// (action) being evaluated
+int vm_failed_assert(const void *host, const int32_t *vals, int *label) {
+    const pcal::Program &P = *(const pcal::Program *)host;
+    VmParams prm;
+    const int64_t h = (int64_t)(intptr_t)host;
+    if (SpecVm::make_params(&h, 1, prm)) return -1;
+    for (int slot = 0; slot < P.ninst * P.maxch; slot++) {
+        const int inst = slot / P.maxch;
+        const int32_t lab = vals[P.pc_base + inst];
+        if (lab == prm.done) continue;
+        int32_t v[SpecVm::MAX_VARS], res;
+        for (int i = 0; i < P.nv; i++) v[i] = vals[i];
+        int aux = 0;
+        const int r = SpecVm::run(prm, prm.code[prm.label_tab + lab], prm.code[prm.self_tab + inst], inst, (uint64_t)(slot % P.maxch), v, res, aux);
+        if (r == SpecVm::R_ASSERT) { if (label) *label = lab; return aux; }
+    }
+    return -1;
+}
+
+}  // namespace mc

@@ -6,6 +6,7 @@
 #include "spec_pluscal.h"
 #include "spec_raft.h"
 #include "spec_ssi.h"
+#include "spec_vm.h"
 
 namespace mc {
 
@@ -44,6 +45,11 @@ int dispatch_spec(const mc_spec_desc *d, F &&f) {
         SsiParams p;
         if (SpecSsi::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
         return f(SpecSsi{}, p);
+    }
+    case MC_SPEC_PCAL: {  // compiled PlusCal: params[0] = the mc_program handle (pcal_compile.cpp)
+        VmParams p;
+        if (SpecVm::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+        return f(SpecVm{}, p);
     }
     default: return MC_EBADCFG;
     }
