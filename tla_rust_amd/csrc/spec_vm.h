@@ -2,7 +2,7 @@
 // every lane runs on its own state.  This is what lets `mc X.tla` check a PlusCal spec the hand-lowered
 // registry does not know (the reference's README.md:26-42 roadmap is new PlusCal specs of lock-free
 // algorithms); the two root specs of the reference (pcal_intro.tla, atomic_add.tla) compile through it too
-// and are parity-tested against their hand lowerings (spec_pluscal.h) and against oracle/tla_eval.py.
+// and are parity-tested against their hand lowerings (spec_pluscal.h) and against the TLA+ evaluator of the test suite.
 //
 // State: nv 32-bit variables (globals, pc per process instance, process locals per instance, arrays
 // flattened), two per 64-bit word.  Strings (labels, string constants) are interned integers.
