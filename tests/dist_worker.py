@@ -19,6 +19,17 @@ def main():
     opts = json.loads(sys.argv[5]) if len(sys.argv) > 5 else {}
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    keep = None
+    if spec == "pcal_file":  # a PlusCal module compiled in this process: params = {"path", "invariants", "constants"}
+        if mode == "shim":
+            import helpers
+            keep = helpers.ShimProgram(Path(params["path"]).read_text(), params.get("invariants", []), params.get("constants", {}))
+        else:
+            import tla_rust_amd as amd
+            cfg = "".join(f"CONSTANT {k} = {v}\n" for k, v in params.get("constants", {}).items())
+            cfg += "".join(f"INVARIANT {i}\n" for i in params.get("invariants", []))
+            keep = amd.Program(Path(params["path"]).read_text(), cfg)
+        spec, params = "pcal", keep.params
     if mode == "shim":
         from shim_step_engine import ShimStepEngine
         eng = ShimStepEngine(spec, params, rank, world)

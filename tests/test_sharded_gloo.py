@@ -59,3 +59,18 @@ def test_stay_mode_counts_equal_oracle(oracle, shim, tmp_path, world):
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["phases"].get("stay_levels", 0) >= 5 and r["phases"].get("move_levels", 0) >= 3
     assert sum(r["shares"]) == o["distinct"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_compiled_pluscal_program_sharded(shim, tmp_path, world):
+    """the compiled-program path (spec_vm.h) through the same sharded exchange: counts of the 1-rank run"""
+    import helpers
+    path = ROOT / "specs" / "pluscal" / "cas_counter.tla"
+    spec = {"path": str(path), "invariants": ["NeverTooMany", "SeenIsOld"], "constants": {"Workers": 3, "N": 2}}
+    prog = helpers.ShimProgram(path.read_text(), spec["invariants"], spec["constants"])
+    one = helpers.shim_run("pcal", prog.params)
+    prog.close()
+    r = run_dist("shim", world, "pcal_file", spec, tmp_path, {"chunk": 200, "stay_threshold": 40, "rebalance_ratio": 2.0})
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == \
+           (one["distinct"], one["generated"], one["depth"], one["levels"], one["verdict"])
+    assert sum(r["shares"]) == one["distinct"] and min(r["shares"]) > 0
