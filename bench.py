@@ -142,7 +142,9 @@ def main():
                 traffic_src = f"profiles/{pmc[-1].name}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes"
             except Exception:  # noqa: BLE001
                 traffic = None
-        line["roofline"] = {"bound": "hbm", "kernel": f"k_{dom}", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        kernel_name = {"expand": "k_expand_insert<SpecRaft<3>>" if (a.no_family or a.matrix) else "k_expand_family<SpecRaft<3>>",
+                       "insert": "k_insert", "materialise": "k_materialise<SpecRaft<3>>"}[dom]
+        line["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                             "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
                             "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
