@@ -33,6 +33,8 @@ CASES = [
     (SPECS / "pluscal" / "cas_counter.tla", ["NeverTooMany"], {"Workers": 3, "N": 1}),
     (SPECS / "pluscal" / "lost_update.tla", [], {}),
     (SPECS / "pluscal" / "euclid.tla", ["Positive"], {"M": 12}),
+    (SPECS / "pluscal" / "ticket_lock.tla", ["Mutex", "Fifo"], {"P": 3, "Rounds": 1}),      # define block + macro
+    (SPECS / "pluscal" / "ticket_lock.tla", ["Mutex", "Fifo"], {"P": 2, "Rounds": 2}),
 ]
 
 
@@ -136,7 +138,8 @@ MODULE = "---- MODULE t ----\nEXTENDS Naturals\n(* --algorithm t\n%s\nend algori
 
 
 @pytest.mark.parametrize("body,needle", [
-    ("variables x = 0;\nmacro m() begin skip; end macro;\nbegin\nA: skip;", "macros are not supported"),
+    ("variables x = 0;\nprocedure p() begin L: skip; end procedure;\nbegin\nA: skip;", "procedures are not supported"),
+    ("variables x = 0;\nmacro m(a) begin a := 1; end macro;\nbegin\nA: m(x + 1);", "must be instantiated with a variable"),
     ("variables x = 0;\nbegin\nskip;", "needs a label"),
     ("variables x = 0;\nbegin\nA: x := 1; x := 2;", "second assignment to x"),
     ("variables x = 0;\nbegin\nA: if x = 0 then B: x := 1; end if; x := 2;", "needs a label"),

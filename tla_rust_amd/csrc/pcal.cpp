@@ -2,7 +2,7 @@
 // Grammar: examples/p-manual.pdf App. A (p-syntax); translation: §3.8 pp.31-32 and App. B pp.60-64.
 // Supported: variables (= / \in), multiprocess and uniprocess algorithms, labels, assignment (x := e,
 // x[i] := e, a := e || b := e), if / elsif / else, while, either / or, with (\in / =), await / when, assert,
-// skip, goto, print.  Refused with a message: define, macro, procedure / call / return.
+// skip, goto, print, define blocks, macros.  Refused with a message: procedure / call / return, c-syntax.
 #include "pcal.h"
 
 #include <algorithm>
@@ -179,6 +179,14 @@ struct Parser {
                 return e;
             }
             i++;
+            if (is_sym("(") && cur().line == k.line && cur().col == k.col + (int)k.s.size()) {  // Op(args): no space before (
+                i++;
+                auto e = mk(Expr::CALL, k);
+                e->s = k.s;
+                if (!is_sym(")")) for (;;) { e->a.push_back(expr(0)); if (is_sym(",")) { i++; continue; } break; }
+                expect_sym(")");
+                return e;
+            }
             auto e = mk(Expr::ID, k);
             e->s = k.s;
             return e;
@@ -300,14 +308,75 @@ struct Parser {
     bool at_block_end() const {
         return cur().t == Tok::END || is_id("end") || is_id("else") || is_id("elsif") || is_id("or");
     }
+    std::vector<Macro> *macros = nullptr;
+    bool in_macro = false;
     std::vector<SP> stmts() {
         std::vector<SP> v;
         while (!at_block_end()) {
-            v.push_back(stmt());
+            if (!macro_call(v)) v.push_back(stmt());
             if (is_sym(";")) i++;
             else if (!at_block_end()) fail("expected `;`");
         }
         return v;
+    }
+    // ---- macros: expanded where they are called (p-manual §3.4); arguments are substituted as expressions
+    static EP subst(const EP &e, const std::map<std::string, EP> &m) {
+        if (!e) return e;
+        if (e->k == Expr::ID) {
+            auto it = m.find(e->s);
+            if (it == m.end()) return e;
+            auto c = std::make_shared<Expr>(*it->second);
+            if (c->k == Expr::BINOP || c->k == Expr::IF || c->k == Expr::QUANT) c->paren = true;
+            return c;
+        }
+        auto c = std::make_shared<Expr>(*e);
+        for (auto &x : c->a) x = subst(x, m);
+        return c;
+    }
+    SP subst(const SP &s, const std::map<std::string, EP> &m) {
+        auto c = std::make_shared<Stmt>(*s);
+        if (!c->label.empty()) fail("labels are not allowed inside a macro");
+        c->e = subst(s->e, m);
+        c->idx = subst(s->idx, m);
+        if (s->k == Stmt::ASSIGN) {
+            auto it = m.find(s->var);
+            if (it != m.end()) {
+                const EP &a = it->second;
+                if (a->k == Expr::ID) c->var = a->s;
+                else if (a->k == Expr::INDEX && a->a[0]->k == Expr::ID && !c->idx) { c->var = a->a[0]->s; c->idx = a->a[1]; }
+                else fail("a macro parameter that is assigned must be instantiated with a variable");
+            }
+        }
+        for (auto &b : c->blocks) for (auto &x : b) x = subst(x, m);
+        return c;
+    }
+    bool macro_call(std::vector<SP> &out) {
+        size_t j = i;
+        std::string label;
+        if (t[j].t == Tok::IDENT && t[j + 1].t == Tok::SYM && t[j + 1].s == ":" && j + 2 < t.size()) { label = t[j].s; j += 2; if (t[j].t == Tok::SYM && (t[j].s == "+" || t[j].s == "-")) j++; }
+        if (!macros || t[j].t != Tok::IDENT || !(t[j + 1].t == Tok::SYM && t[j + 1].s == "(")) return false;
+        const Macro *mac = nullptr;
+        for (const auto &m : *macros) if (m.name == t[j].s) mac = &m;
+        if (!mac) return false;
+        if (in_macro) fail("a macro cannot call a macro");
+        const Pos at{t[j].line, t[j].col};
+        i = j + 2;
+        std::vector<EP> args;
+        if (!is_sym(")")) for (;;) { args.push_back(expr(0)); if (is_sym(",")) { i++; continue; } break; }
+        expect_sym(")");
+        if (args.size() != mac->params.size()) fail("macro " + mac->name + " takes " + std::to_string(mac->params.size()) + " arguments");
+        std::map<std::string, EP> m;
+        for (size_t k = 0; k < args.size(); k++) m[mac->params[k]] = args[k];
+        bool first = true;
+        for (const auto &s : mac->body) {
+            SP c = subst(s, m);
+            c->pos = s->k == Stmt::ASSERT ? s->pos : at;
+            if (first) c->label = label;
+            first = false;
+            out.push_back(c);
+        }
+        if (mac->body.empty() && !label.empty()) fail("a labeled call of an empty macro");
+        return true;
     }
     // after `if` / `elsif`: condition, then-block and the else part (an elsif chain nests); `end if` is left to the caller
     void if_tail(Stmt &s) {
@@ -400,8 +469,43 @@ struct Parser {
         m.algorithm = ident("the algorithm name");
         if (is_sym("{")) fail("c-syntax PlusCal is not supported (use the p-syntax: begin ... end algorithm)");
         if (is_id("variables") || is_id("variable")) { i++; m.globals = vardecls(); }
-        if (is_id("define")) fail("`define` blocks are not supported");
-        if (is_id("macro")) fail("macros are not supported");
+        if (is_id("define")) {
+            i++;
+            while (!is_id("end")) {
+                Definition d;
+                d.in_define = true;
+                d.line = cur().line;
+                d.name = ident("a definition name");
+                if (is_sym("(")) {
+                    i++;
+                    for (;;) { d.params.push_back(ident("a parameter name")); if (is_sym(",")) { i++; continue; } break; }
+                    expect_sym(")");
+                }
+                expect_sym("==");
+                d.body = expr(0);
+                m.defs.push_back(d);
+            }
+            expect_id("end");
+            expect_id("define");
+            if (is_sym(";")) i++;
+        }
+        while (is_id("macro")) {
+            i++;
+            Macro mac;
+            mac.name = ident("a macro name");
+            expect_sym("(");
+            if (!is_sym(")")) for (;;) { mac.params.push_back(ident("a parameter name")); if (is_sym(",")) { i++; continue; } break; }
+            expect_sym(")");
+            expect_id("begin");
+            in_macro = true;
+            mac.body = stmts();
+            in_macro = false;
+            expect_id("end");
+            expect_id("macro");
+            if (is_sym(";")) i++;
+            m.macros.push_back(mac);
+        }
+        macros = &m.macros;
         if (is_id("procedure")) fail("procedures are not supported");
         if (is_id("begin")) {  // uniprocess
             i++;
@@ -501,11 +605,29 @@ std::string parse_module(const std::string &text, Module &m) {
         }
         Parser d(toks);
         while (d.cur().t != Tok::END) {
-            if (d.cur().t == Tok::IDENT && d.cur().col == 1 && d.peek().t == Tok::SYM && d.peek().s == "==") {
+            size_t hdr = 0;  // tokens of "Name ==" or "Name(p, q) =="
+            std::vector<std::string> params;
+            if (d.cur().t == Tok::IDENT && d.cur().col == 1) {
+                if (d.peek().t == Tok::SYM && d.peek().s == "==") hdr = 2;
+                else if (d.peek().t == Tok::SYM && d.peek().s == "(") {
+                    size_t j = d.i + 2;
+                    bool ok = true;
+                    while (ok) {
+                        if (d.t[j].t != Tok::IDENT) { ok = false; break; }
+                        params.push_back(d.t[j].s);
+                        j++;
+                        if (d.t[j].t == Tok::SYM && d.t[j].s == ",") { j++; continue; }
+                        break;
+                    }
+                    if (ok && d.t[j].t == Tok::SYM && d.t[j].s == ")" && d.t[j + 1].t == Tok::SYM && d.t[j + 1].s == "==") hdr = j + 2 - d.i;
+                }
+            }
+            if (hdr) {
                 Definition def;
                 def.name = d.cur().s;
                 def.line = d.cur().line;
-                d.i += 2;
+                def.params = params;
+                d.i += hdr;
                 // the body ends at the next token in column 1 (next definition / separator / keyword)
                 size_t j = d.i;
                 while (d.t[j].t != Tok::END && d.t[j].col != 1) j++;
@@ -567,6 +689,11 @@ std::string pe_inner(const EP &e, const Ctx &c, const std::set<std::string> &pri
     }
     case Expr::INDEX: return pe(e->a[0], c, primed, shadow) + "[" + pe(e->a[1], c, primed, shadow) + "]";
     case Expr::PRIME: return pe(e->a[0], c, primed, shadow) + "'";
+    case Expr::CALL: {
+        std::string r = e->s + "(";
+        for (size_t i = 0; i < e->a.size(); i++) r += (i ? ", " : "") + pe(e->a[i], c, primed, shadow);
+        return r + ")";
+    }
     case Expr::IF:
         return "IF " + pe(e->a[0], c, primed, shadow) + " THEN " + pe(e->a[1], c, primed, shadow) + " ELSE " + pe(e->a[2], c, primed, shadow);
     case Expr::QUANT: {
@@ -886,6 +1013,16 @@ std::string translate(const Module &m) {
     Ctx none;
     none.m = &m;
     const std::set<std::string> empty;
+    {
+        bool any = false;
+        for (const auto &d : m.defs) {
+            if (!d.in_define) continue;
+            if (!any) o += "(* define statement *)\n";
+            any = true;
+            std::set<std::string> sh(d.params.begin(), d.params.end());
+            o += d.name + (d.params.empty() ? "" : "(" + join(d.params, ", ") + ")") + " == " + pe(d.body, none, empty, sh) + "\n\n";
+        }
+    }
     if (multi) {
         std::vector<std::string> parts;
         for (const auto &p : m.procs) parts.push_back(p.is_set ? "(" + pe(p.id, none, empty, empty) + ")" : "{" + pe(p.id, none, empty, empty) + "}");

@@ -18,9 +18,9 @@ struct Pos { int line = 0, col = 0; };
 struct Expr;
 using EP = std::shared_ptr<Expr>;
 struct Expr {
-    enum K { NUM, STR, BOOL, ID, UNOP, BINOP, INDEX, IF, QUANT, SETENUM, TUPLE, FUNCDEF, PRIME } k = NUM;
+    enum K { NUM, STR, BOOL, ID, UNOP, BINOP, INDEX, IF, QUANT, SETENUM, TUPLE, FUNCDEF, PRIME, CALL } k = NUM;
     long long num = 0;      // NUM, BOOL
-    std::string s;          // ID name, STR text, operator text, QUANT "\\A" / "\\E"
+    std::string s;          // ID name, STR text, operator text, QUANT "\\A" / "\\E", CALL operator name
     std::string bound;      // QUANT / FUNCDEF bound variable
     std::vector<EP> a;      // operands; INDEX: [fn, index]; IF: [c, t, e]; QUANT / FUNCDEF: [domain, body]
     bool paren = false;     // written inside ( )
@@ -55,7 +55,18 @@ struct Proc {
     std::vector<SP> body;
 };
 
-struct Definition { std::string name; EP body; int line = 0; };
+struct Definition {
+    std::string name;
+    std::vector<std::string> params;
+    EP body;
+    int line = 0;
+    bool in_define = false;   // from the algorithm's `define` block (printed in the translation)
+};
+struct Macro {
+    std::string name;
+    std::vector<std::string> params;
+    std::vector<SP> body;
+};
 
 struct Module {
     std::string name;
@@ -63,7 +74,8 @@ struct Module {
     std::vector<std::string> constants;     // CONSTANT(S) declared by the module
     std::vector<VarDecl> globals;
     std::vector<Proc> procs;                // a uniprocess algorithm is one Proc with an empty name
-    std::vector<Definition> defs;           // zero-argument definitions outside the algorithm (invariants)
+    std::vector<Definition> defs;           // definitions of the `define` block and of the module around the algorithm
+    std::vector<Macro> macros;
     int alg_first_line = 0, alg_last_line = 0;   // lines of "(* --algorithm" and "end algorithm *)"
     bool has_translation = false;
     int tr_first_line = 0, tr_last_line = 0;     // "\* BEGIN TRANSLATION" .. "\* END TRANSLATION"

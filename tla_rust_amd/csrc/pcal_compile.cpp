@@ -132,7 +132,7 @@ struct Compiler {
             if (e->s == "ProcSet" && !procset.empty()) { out = procset; return true; }
             auto it = consts.find(e->s);
             if (it != consts.end()) return const_from(it->second, out);
-            for (const auto &d : m.defs) if (d.name == e->s && inline_depth < 8) { inline_depth++; const bool ok = const_set(d.body, out); inline_depth--; return ok; }
+            for (const auto &d : m.defs) if (d.name == e->s && d.params.empty() && inline_depth < 8) { inline_depth++; const bool ok = const_set(d.body, out); inline_depth--; return ok; }
         }
         return false;
     }
@@ -163,6 +163,9 @@ struct Compiler {
             return 'i';
         }
         case Expr::INDEX: return type_of(e->a[0]);
+        case Expr::CALL:
+            for (const auto &d : m.defs) if (d.name == e->s && d.params.size() == e->a.size()) return type_of(d.body);
+            return 'i';
         default: return 'i';
         }
     }
@@ -210,13 +213,45 @@ struct Compiler {
             long long cv;
             if (const_scalar(e, cv)) { emit(mc::VM_PUSH, (int)cv); return; }
             for (const auto &d : m.defs)
-                if (d.name == e->s) {
+                if (d.name == e->s && d.params.empty()) {
                     if (++inline_depth > 16) cfail("definitions nest too deeply (recursion?)", e->pos);
+                    const std::vector<Bind> saved = binds;  // a definition sees no local binding of its call site
+                    binds.clear();
+                    const Proc *sp = proc;
+                    proc = nullptr;
                     ex(d.body);
+                    proc = sp;
+                    binds = saved;
                     inline_depth--;
                     return;
                 }
             cfail("unknown identifier `" + e->s + "`", e->pos);
+        }
+        case Expr::CALL: {  // an operator of the define block / of the module, inlined: arguments evaluated once
+            const Definition *def = nullptr;
+            for (const auto &d : m.defs) if (d.name == e->s && d.params.size() == e->a.size()) def = &d;
+            if (!def) cfail("unknown operator `" + e->s + "` with " + std::to_string(e->a.size()) + " argument(s)", e->pos);
+            if (++inline_depth > 16) cfail("definitions nest too deeply (recursion?)", e->pos);
+            std::vector<Bind> inner;
+            const int temp0 = next_temp;
+            for (size_t k = 0; k < e->a.size(); k++) {
+                long long cv;
+                if (const_scalar(e->a[k], cv)) { inner.push_back({def->params[k], 0, true, cv}); continue; }
+                const int t = new_temp(e->pos);
+                ex(e->a[k]);
+                emit(mc::VM_STORET, t);
+                inner.push_back({def->params[k], t, false, 0});
+            }
+            const std::vector<Bind> saved = binds;
+            binds = inner;
+            const Proc *sp = proc;
+            proc = nullptr;
+            ex(def->body);
+            proc = sp;
+            binds = saved;
+            next_temp = temp0;
+            inline_depth--;
+            return;
         }
         case Expr::INDEX: {
             if (e->a[0]->k != Expr::ID) cfail("only `name[index]` is supported", e->pos);
@@ -666,7 +701,7 @@ struct Compiler {
         std::vector<int> inv_entry;
         for (const auto &name : cfg.invariants) {
             const Definition *def = nullptr;
-            for (const auto &d : m.defs) if (d.name == name) def = &d;
+            for (const auto &d : m.defs) if (d.name == name && d.params.empty()) def = &d;
             if (!def) cfail("INVARIANT " + name + " is not a definition of the module this front-end can read");
             inv_entry.push_back((int)c.size());
             next_temp = 0;
