@@ -10,6 +10,8 @@ pub const MC_SPEC_ATOMIC_ADD: u32 = 1;
 pub const MC_SPEC_PCAL_INTRO: u32 = 2;
 pub const MC_SPEC_RAFT: u32 = 3;
 pub const MC_SPEC_SSI: u32 = 4;
+pub const MC_SPEC_PCAL: u32 = 5; // a PlusCal algorithm compiled by mc_program_compile
+pub const MC_F_GENERIC: u32 = 128;
 pub const MC_F_DEADLOCK: u32 = 1;
 pub const MC_F_TRACE: u32 = 2;
 pub const MC_MAX_LEVELS: usize = 4096;
@@ -29,6 +31,8 @@ pub struct mc_result {
 }
 #[repr(C)]
 pub struct mc_engine { _private: [u8; 0] }
+#[repr(C)]
+pub struct mc_program { _private: [u8; 0] }
 
 extern "C" {
     pub fn mc_engine_create(spec: *const mc_spec_desc, cfg: *const mc_config, out: *mut *mut mc_engine) -> c_int;
@@ -38,6 +42,13 @@ extern "C" {
     pub fn mc_engine_destroy(e: *mut mc_engine);
     pub fn mc_check_files(tla: *const c_char, cfg_path: *const c_char, cfg: *const mc_config, report: *mut c_char,
                           cap: usize, out: *mut mc_result) -> c_int;
+    // PlusCal front-end: `pcal2tla` and the compiler to the GPU interpreter (include/tlamc.h)
+    pub fn mc_pcal_translate(tla_text: *const c_char, out: *mut c_char, cap: usize) -> c_int;
+    pub fn mc_program_compile(tla_text: *const c_char, cfg_text: *const c_char, out: *mut *mut mc_program) -> c_int;
+    pub fn mc_program_spec(p: *const mc_program, out: *mut mc_spec_desc) -> c_int;
+    pub fn mc_program_translated(p: *const mc_program) -> *const c_char;
+    pub fn mc_program_invariant(p: *const mc_program, index: c_int) -> *const c_char;
+    pub fn mc_program_free(p: *mut mc_program);
     pub fn mc_state_bytes(spec: *const mc_spec_desc) -> usize;
     pub fn mc_state_format(spec: *const mc_spec_desc, state: *const u8, buf: *mut c_char, cap: usize) -> c_int;
     pub fn mc_action_name(spec: *const mc_spec_desc, action: i32) -> *const c_char;

@@ -138,3 +138,25 @@ def test_bigger_program_throughput_smoke(amd):
     eng.close()
     eng2.close()
     prog.close()
+
+
+def test_reference_makefile_flow(tmp_path):
+    """the reference's Makefile:3-7 on its root directory: `pcal2tla *tla` then `tlc *tla`, with mc in both roles.
+    The root holds pcal_intro.tla + pcal_intro.cfg and atomic_add.tla (no cfg), both untranslated."""
+    for name in ("pcal_intro.tla", "atomic_add.tla"):
+        (tmp_path / name).write_text(strip_translation((ROOT / "specs" / name).read_text()))
+    shutil.copy(ROOT / "specs" / "pcal_intro.cfg", tmp_path / "pcal_intro.cfg")
+    # test: works on the untranslated files ...
+    for name, want in (("pcal_intro.tla", "5850 states generated, 3800 distinct states found"), ("atomic_add.tla", "7 states generated, 5 distinct states found")):
+        rc, out, err = run_mc(tmp_path / name)
+        assert rc == 0 and want in out, (name, out, err)
+    # ... transpile: inserts the translation in place, keeps X.old ...
+    p = subprocess.run([str(MC), "--transpile", str(tmp_path / "pcal_intro.tla"), str(tmp_path / "atomic_add.tla")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert (tmp_path / "pcal_intro.old").exists() and "\\* BEGIN TRANSLATION" in (tmp_path / "pcal_intro.tla").read_text()
+    block = lambda t: t[t.index("\\* BEGIN TRANSLATION"):t.index("\\* END TRANSLATION")]  # noqa: E731
+    assert block((tmp_path / "pcal_intro.tla").read_text()) == block((ROOT / "specs" / "pcal_intro.tla").read_text())
+    # ... and test again on the translated files: same answers
+    for name, want in (("pcal_intro.tla", "5850 states generated, 3800 distinct states found"), ("atomic_add.tla", "7 states generated, 5 distinct states found")):
+        rc, out, err = run_mc(tmp_path / name)
+        assert rc == 0 and want in out, (name, out, err)
