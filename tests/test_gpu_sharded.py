@@ -41,3 +41,16 @@ def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path):
                                                        "stay_threshold": 200, "rebalance_ratio": 1.5})
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["phases"].get("stay_levels", 0) >= 3
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_eight_engines_on_one_gpu(oracle, tmp_path, world):
+    """N = 4 and 8 HIP step engines (the widths of the driver's scaling run) sharing this one GPU, exchange staged
+    through gloo: exercises the 8-owner routing / compaction / block plans of the device code"""
+    params = [2, 2, 2, 9, 2, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=40000)
+    r = run_dist("hip", world, "raft", params, tmp_path, {"max_distinct": 40000, "chunk": 1 << 11, "table": 1 << 18, "arena": 1 << 17,
+                                                         "stay_threshold": 30, "rebalance_ratio": 2.5}, timeout=900)
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert len(r["shares"]) == world and sum(r["shares"]) == o["distinct"]
+    assert r["phases"].get("stay_levels", 0) >= 1 and r["phases"].get("move_levels", 0) >= 3

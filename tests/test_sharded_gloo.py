@@ -74,3 +74,14 @@ def test_compiled_pluscal_program_sharded(shim, tmp_path, world):
     assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == \
            (one["distinct"], one["generated"], one["depth"], one["levels"], one["verdict"])
     assert sum(r["shares"]) == one["distinct"] and min(r["shares"]) > 0
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_eight_way_sharding_counts_equal_oracle(oracle, shim, tmp_path, world):
+    """the widths the driver's scaling run uses (N = 4, 8): 8 owners, 8 x 8 count exchange, both exchange modes"""
+    params = [2, 2, 2, 9, 2, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=40000)
+    r = run_dist("shim", world, "raft", params, tmp_path, {"max_distinct": 40000, "chunk": 600, "stay_threshold": 30, "rebalance_ratio": 2.5})
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert len(r["shares"]) == world and sum(r["shares"]) == o["distinct"] and min(r["shares"]) > 0
+    assert r["phases"].get("stay_levels", 0) >= 1 and r["phases"].get("move_levels", 0) >= 3
