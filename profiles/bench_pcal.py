@@ -38,3 +38,11 @@ for w, n in ((3, 3), (4, 2), (4, 3)):
                           verdict=r.verdict, ms=round(t * 1e3, 2), Mstates_s=round(r.distinct / t / 1e6, 1),
                           state_bytes=amd.state_bytes("pcal", prog.params))), flush=True)
     prog.close()
+src = (ROOT / "specs" / "pluscal" / "treiber_stack.tla").read_text()
+for n in (3, 4):
+    prog = amd.Program(src, f"CONSTANT N = {n}\nINVARIANTS PoppedOnce TopIsNode Conservation\n")
+    t, r = timed(lambda: amd.Engine("pcal", prog.params, table_capacity=1 << 25, arena_capacity=1 << 23, chunk_states=1 << 17, trace=False))
+    print(json.dumps(dict(workload=f"treiber_stack N={n}", distinct=r.distinct, generated=r.generated, depth=r.depth,
+                          verdict=r.verdict, ms=round(t * 1e3, 2), Mstates_s=round(r.distinct / t / 1e6, 1),
+                          state_bytes=amd.state_bytes("pcal", prog.params))), flush=True)
+    prog.close()

@@ -35,6 +35,7 @@ CASES = [
     (SPECS / "pluscal" / "euclid.tla", ["Positive"], {"M": 12}),
     (SPECS / "pluscal" / "ticket_lock.tla", ["Mutex", "Fifo"], {"P": 3, "Rounds": 1}),      # define block + macro
     (SPECS / "pluscal" / "ticket_lock.tla", ["Mutex", "Fifo"], {"P": 2, "Rounds": 2}),
+    (SPECS / "pluscal" / "treiber_stack.tla", ["PoppedOnce", "TopIsNode", "Conservation"], {"N": 2}),   # CAS loops, pointers
 ]
 
 
