@@ -1642,7 +1642,7 @@ int mc_make_engine_5(const mc_spec_desc *d, const mc_config *c, mc::EngineBase *
 // compiled PlusCal (spec_vm.h): the program image is copied to the device, the kernels read it through prm.code
 int mc_make_engine_6(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {
     mc::VmParams p;
-    if (mc::SpecVm::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+    if (mc::vm_make_params(d->params, d->nparams, p)) return MC_EBADCFG;
     if (hipSetDevice(c->device) != hipSuccess) { mc::set_error("hipSetDevice failed"); return MC_EHIP; }
     int32_t *d_code = nullptr;
     if (hipMalloc(&d_code, (size_t)p.code_len * sizeof(int32_t)) != hipSuccess ||
@@ -1651,7 +1651,8 @@ int mc_make_engine_6(const mc_spec_desc *d, const mc_config *c, mc::EngineBase *
         return MC_EHIP;
     }
     p.code = d_code;  // host-side helpers (format, action_of) use p.host only
-    const int rc = mc::make_engine<mc::SpecVm>(p, d, c, out);
+    const int rc = p.nv <= 16 ? mc::make_engine<mc::SpecVm16>(p, d, c, out)
+                 : p.nv <= 32 ? mc::make_engine<mc::SpecVm32>(p, d, c, out) : mc::make_engine<mc::SpecVm>(p, d, c, out);
     if (rc) hipFree(d_code);
     else (*out)->owned_device_blob = d_code;
     return rc;
@@ -1733,7 +1734,7 @@ int mc_state_format(const mc_spec_desc *spec, const uint8_t *state, char *buf, s
 const char *mc_action_name(const mc_spec_desc *spec, int32_t action) {
     const char *nm = "?";
     dispatch_spec(spec, [&](auto s, const auto &prm) {
-        if constexpr (std::is_same_v<decltype(s), SpecVm>) nm = vm_action_name(prm.host, action);  // label names live in the program
+        if constexpr (std::is_same_v<std::decay_t<decltype(prm)>, VmParams>) nm = vm_action_name(prm.host, action);  // label names live in the program
         else nm = decltype(s)::action_name(action);
         return 0;
     });

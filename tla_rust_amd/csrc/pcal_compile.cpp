@@ -62,9 +62,24 @@ struct Compiler {
         str_id[s] = id;
         return id;
     }
-    void emit(int op) { c.push_back(op); }
-    void emit(int op, int a) { c.push_back(op); c.push_back(a); }
-    int emit_jump(int op) { c.push_back(op); c.push_back(-1); return (int)c.size() - 1; }
+    // conservative bound of the interpreter's stack depth (branches are tracked linearly: never an underestimate)
+    int depth = 0, max_depth = 0;
+    void track(int op) {
+        switch (op) {
+        case mc::VM_PUSH: case mc::VM_SELF: case mc::VM_LOAD: case mc::VM_LOADT: case mc::VM_CHOOSE: depth++; break;
+        case mc::VM_STORE: case mc::VM_STORET: case mc::VM_AWAIT: case mc::VM_ASSERT: case mc::VM_JZ: case mc::VM_JNZ: case mc::VM_POP:
+        case mc::VM_ADD: case mc::VM_SUB: case mc::VM_MUL: case mc::VM_DIV: case mc::VM_MOD: case mc::VM_EQ: case mc::VM_NE: case mc::VM_LT:
+        case mc::VM_LE: case mc::VM_GT: case mc::VM_GE: depth--; break;
+        case mc::VM_STOREX: depth -= 2; break;
+        case mc::VM_HALT: depth = 0; break;
+        default: break;
+        }
+        if (depth < 0) depth = 0;
+        if (depth > max_depth) max_depth = depth;
+    }
+    void emit(int op) { c.push_back(op); track(op); }
+    void emit(int op, int a) { c.push_back(op); c.push_back(a); track(op); }
+    int emit_jump(int op) { c.push_back(op); c.push_back(-1); track(op); return (int)c.size() - 1; }
     void patch(int at) { c[(size_t)at] = (int)c.size(); }
     int new_temp(Pos p) {
         if (next_temp >= mc::SpecVm::TEMPS) cfail("expression too deeply nested (temporaries exhausted)", p);
@@ -178,6 +193,7 @@ struct Compiler {
     void emit_indexed(int op, const VarInfo &vi, Pos p) {
         if (!contiguous(vi.ids)) cfail("`" + vi.name + "` is indexed but its domain is not an integer interval", p);
         c.push_back(op);
+        track(op);
         c.push_back(vi.base);
         c.push_back((int)vi.ids[0]);
         c.push_back((int)vi.ids.size());
@@ -696,6 +712,7 @@ struct Compiler {
         if (maxch * (unsigned long long)P.ninst + 1 > 255)
             cfail("too many alternatives per state (" + std::to_string(maxch) + " per process step x " + std::to_string(P.ninst) + " processes > 254)");
         P.maxch = (int)maxch;
+        if (max_depth > mc::SpecVm::STACK) cfail("an expression is too deeply nested for the interpreter's stack (" + std::to_string(max_depth) + " > " + std::to_string(mc::SpecVm::STACK) + ")");
         // ---- invariants
         if (cfg.invariants.size() > 8) cfail("at most 8 invariants are supported");
         std::vector<int> inv_entry;
@@ -755,7 +772,7 @@ std::string compile(const Module &m, const std::string &module_text, const Confi
 // ------------------------------------------------------------------------------------------------ spec_vm.h host side
 namespace mc {
 
-int SpecVm::make_params(const int64_t *p, unsigned np, Params &o) {
+int vm_make_params(const int64_t *p, unsigned np, VmParams &o) {
     if (np < 1 || !p[0]) return -1;
     const pcal::Program *P = (const pcal::Program *)(intptr_t)p[0];
     if (P->magic != VM_MAGIC || P->image.size() < (size_t)VMH_SIZE || P->image[VMH_MAGIC] != VM_MAGIC) return -1;
@@ -829,7 +846,7 @@ int vm_failed_assert(const void *host, const int32_t *vals, int *label) {
     const pcal::Program &P = *(const pcal::Program *)host;
     VmParams prm;
     const int64_t h = (int64_t)(intptr_t)host;
-    if (SpecVm::make_params(&h, 1, prm)) return -1;
+    if (vm_make_params(&h, 1, prm)) return -1;
     for (int slot = 0; slot < P.ninst * P.maxch; slot++) {
         const int inst = slot / P.maxch;
         const int32_t lab = vals[P.pc_base + inst];

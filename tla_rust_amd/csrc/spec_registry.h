@@ -48,7 +48,9 @@ int dispatch_spec(const mc_spec_desc *d, F &&f) {
     }
     case MC_SPEC_PCAL: {  // compiled PlusCal: params[0] = the mc_program handle (pcal_compile.cpp)
         VmParams p;
-        if (SpecVm::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+        if (vm_make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+        if (p.nv <= 16) return f(SpecVm16{}, p);
+        if (p.nv <= 32) return f(SpecVm32{}, p);
         return f(SpecVm{}, p);
     }
     default: return MC_EBADCFG;

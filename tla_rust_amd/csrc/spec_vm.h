@@ -44,15 +44,22 @@ struct VmParams {
     uint64_t num_init;
 };
 
-struct SpecVm {
+int vm_make_params(const int64_t *p, unsigned np, VmParams &o);  // pcal_compile.cpp (host)
+
+// MAXV = capacity of the per-lane variable arrays.  The interpreter indexes them dynamically, so they live in
+// scratch (private) memory; three instantiations (16 / 32 / 64 cells) keep small programs under the scratch size
+// above which the runtime allocates scratch per dispatch (528 B/lane at 64 cells made every launch ~150 us).
+template <int MAXV>
+struct SpecVmT {
     using Params = VmParams;
-    static constexpr int MAX_VARS = 64, MAX_WORDS = MAX_VARS / 2, FIX_SLOTS = 0, STAGE_WORDS = 0;
-    static constexpr int STACK = 16, TEMPS = 16;
+    static constexpr bool IS_VM = true;
+    static constexpr int MAX_VARS = MAXV, MAX_WORDS = MAX_VARS / 2, FIX_SLOTS = 0, STAGE_WORDS = 0;
+    static constexpr int STACK = 12, TEMPS = 8;  // pcal_compile.cpp checks both bounds when it emits code
     MC_HD static int words(const Params &p) { return p.words; }
     MC_HD static int max_slots(const Params &p) { return p.ninst * p.maxch + 1; }
     struct Local { int32_t v[MAX_VARS]; };
 
-    static int make_params(const int64_t *p, unsigned np, Params &o);  // pcal_compile.cpp (host)
+    static int make_params(const int64_t *p, unsigned np, Params &o) { return vm_make_params(p, np, o); }
 
     enum Run { R_DISABLED = 0, R_OK = 1, R_ASSERT = 2, R_ERROR = 3 };
 
@@ -254,5 +261,8 @@ struct SpecVm {
         return vm_format(p.host, v, buf, cap);
     }
 };
+using SpecVm = SpecVmT<64>;    // host-side helpers and the widest instantiation
+using SpecVm16 = SpecVmT<16>;
+using SpecVm32 = SpecVmT<32>;
 
 }  // namespace mc
