@@ -183,7 +183,7 @@ int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_loca
 /* ------------------------------------------------------------------ PlusCal front-end (host only)
  * The reference's workflow is `pcal2tla *tla` then `tlc *tla` (Makefile:3-7).  mc_pcal_translate is the first
  * half: it returns the module text with the TLA+ translation of its `--algorithm` inserted (p-manual.pdf App. B).
- * mc_program_compile is what lets the checker run a PlusCal spec nobody hand-lowered: the algorithm (p-syntax;
+ * mc_program_compile is what lets the checker run a PlusCal spec nobody hand-lowered: the algorithm (p- or c-syntax;
  * labels, := , if/elsif/else, while, either/or, with, await/when, assert, skip, goto, define, macros; integers, booleans, strings,
  * functions over constant sets) becomes a bytecode program every GPU lane interprets on its own packed state
  * (tla_rust_amd/csrc/spec_vm.h).  cfg_text: CONSTANT(S) with integer / string / model-value / set values and

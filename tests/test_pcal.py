@@ -36,6 +36,8 @@ CASES = [
     (SPECS / "pluscal" / "ticket_lock.tla", ["Mutex", "Fifo"], {"P": 3, "Rounds": 1}),      # define block + macro
     (SPECS / "pluscal" / "ticket_lock.tla", ["Mutex", "Fifo"], {"P": 2, "Rounds": 2}),
     (SPECS / "pluscal" / "treiber_stack.tla", ["PoppedOnce", "TopIsNode", "Conservation"], {"N": 2}),   # CAS loops, pointers
+    (SPECS / "pluscal" / "peterson_c.tla", ["MutualExclusion", "TurnInRange"], {}),                     # c-syntax
+    (SPECS / "pluscal" / "csyntax_mix.tla", ["Inv"], {"N": 2}),   # c-syntax: define, macro, else-if, goto in if, either, with
 ]
 
 
@@ -152,6 +154,13 @@ def test_refusals_are_explained(body, needle):
     with pytest.raises(RuntimeError) as e:
         helpers.ShimProgram(MODULE % body)
     assert needle in str(e.value)
+
+
+def test_c_syntax_translates_like_p_syntax():
+    block = lambda t: t[t.index("\\* BEGIN TRANSLATION"):t.index("\\* END TRANSLATION")]  # noqa: E731
+    a = helpers.pcal_translate(strip_translation((SPECS / "pluscal" / "peterson.tla").read_text()))
+    b = helpers.pcal_translate(strip_translation((SPECS / "pluscal" / "peterson_c.tla").read_text()))
+    assert block(a) == block(b)
 
 
 def test_either_with_while_goto_translation_shape():

@@ -297,9 +297,14 @@ bool algorithm_text(const std::string &t, std::string &out) {
     const size_t i = t.find("--algorithm");
     if (i == std::string::npos) return false;
     const size_t j = t.find("end algorithm", i);
-    if (j == std::string::npos) return false;
-    out = t.substr(i, j + strlen("end algorithm") - i);
-    return true;
+    if (j != std::string::npos) { out = t.substr(i, j + strlen("end algorithm") - i); return true; }
+    // c-syntax: the algorithm runs to the end of its (* ... *) comment
+    int depth = 1;
+    for (size_t k = i; k + 1 < t.size(); k++) {
+        if (t[k] == '(' && t[k + 1] == '*') { depth++; k++; }
+        else if (t[k] == '*' && t[k + 1] == ')') { if (--depth == 0) { out = t.substr(i, k - i); return true; } k++; }
+    }
+    return false;
 }
 bool module_body(const std::string &t, std::string &out) {
     const size_t i = t.find("EXTENDS");

@@ -2,7 +2,8 @@
 // Grammar: examples/p-manual.pdf App. A (p-syntax); translation: §3.8 pp.31-32 and App. B pp.60-64.
 // Supported: variables (= / \in), multiprocess and uniprocess algorithms, labels, assignment (x := e,
 // x[i] := e, a := e || b := e), if / elsif / else, while, either / or, with (\in / =), await / when, assert,
-// skip, goto, print, define blocks, macros.  Refused with a message: procedure / call / return, c-syntax.
+// skip, goto, print, define blocks, macros; both the p-syntax (begin ... end) and the c-syntax ({ ... }).
+// Refused with a message: procedure / call / return.
 #include "pcal.h"
 
 #include <algorithm>
@@ -293,7 +294,7 @@ struct Parser {
     }
     std::vector<VarDecl> vardecls() {
         std::vector<VarDecl> v;
-        while (cur().t == Tok::IDENT && !decl_end_keyword(cur().s)) {
+        while (cur().t == Tok::IDENT && !decl_end_keyword(cur().s)) {  // (a `{` is not an IDENT: it ends the list in c-syntax)
             VarDecl d;
             d.pos = {cur().line, cur().col};
             d.name = t[i++].s;
@@ -449,42 +450,191 @@ struct Parser {
             expect_id("with");
             return s;
         }
-        if (kw == "await" || kw == "when") { i++; s->k = Stmt::AWAIT; s->e = expr(0); return s; }
-        if (kw == "assert") { i++; s->k = Stmt::ASSERT; s->e = expr(0); return s; }
-        if (kw == "skip") { i++; s->k = Stmt::SKIP; return s; }
-        if (kw == "goto") { i++; s->k = Stmt::GOTO; s->var = ident("a label after `goto`"); return s; }
-        if (kw == "print") { i++; s->k = Stmt::PRINT; s->e = expr(0); return s; }
-        if (kw == "call" || kw == "return") fail("procedures (`call` / `return`) are not supported");
-        // assignment(s)
-        s->k = Stmt::ASSIGN;
-        s->var = t[i++].s;
-        if (is_sym("[")) { i++; s->idx = expr(0); expect_sym("]"); if (is_sym("[")) fail("only one index level is supported on the left of `:=`"); }
-        expect_sym(":=");
-        s->e = expr(0);
-        if (is_sym("||")) fail("multiple assignment `||` is not supported: use separate statements");
+        simple(*s);
         return s;
+    }
+    // await / assert / skip / goto / print / assignment: the same in both syntaxes
+    void simple(Stmt &s) {
+        const std::string kw = cur().s;
+        if (kw == "await" || kw == "when") { i++; s.k = Stmt::AWAIT; s.e = expr(0); return; }
+        if (kw == "assert") { i++; s.k = Stmt::ASSERT; s.e = expr(0); return; }
+        if (kw == "skip") { i++; s.k = Stmt::SKIP; return; }
+        if (kw == "goto") { i++; s.k = Stmt::GOTO; s.var = ident("a label after `goto`"); return; }
+        if (kw == "print") { i++; s.k = Stmt::PRINT; s.e = expr(0); return; }
+        if (kw == "call" || kw == "return") fail("procedures (`call` / `return`) are not supported");
+        s.k = Stmt::ASSIGN;
+        s.var = t[i++].s;
+        if (is_sym("[")) { i++; s.idx = expr(0); expect_sym("]"); if (is_sym("[")) fail("only one index level is supported on the left of `:=`"); }
+        expect_sym(":=");
+        s.e = expr(0);
+        if (is_sym("||")) fail("multiple assignment `||` is not supported: use separate statements");
+    }
+
+    // ---- c-syntax (p-manual App. A): braces instead of begin/end, tests in parentheses; same AST
+    std::vector<SP> c_block() {  // { stmt; stmt; ... }
+        expect_sym("{");
+        std::vector<SP> v;
+        while (!is_sym("}")) {
+            if (cur().t == Tok::END) fail("missing `}`");
+            c_stmt(v);
+        }
+        i++;
+        if (is_sym(";")) i++;
+        return v;
+    }
+    std::vector<SP> c_body() {  // a statement used as the body of if / while / either / with
+        if (is_sym("{")) return c_block();
+        std::vector<SP> v;
+        c_stmt(v);
+        return v;
+    }
+    void c_if_tail(Stmt &s) {
+        expect_sym("(");
+        s.e = expr(0);
+        expect_sym(")");
+        s.blocks.push_back(c_body());
+        if (is_id("else")) {
+            i++;
+            if (is_id("if")) {  // else if: nests like elsif
+                auto inner = std::make_shared<Stmt>();
+                inner->k = Stmt::IF;
+                inner->pos = {cur().line, cur().col};
+                i++;
+                c_if_tail(*inner);
+                s.blocks.push_back({inner});
+            } else {
+                s.blocks.push_back(c_body());
+            }
+        } else {
+            s.blocks.push_back({});
+        }
+    }
+    void c_stmt(std::vector<SP> &out) {
+        if (macro_call(out)) { if (is_sym(";")) i++; return; }
+        auto s = std::make_shared<Stmt>();
+        if (cur().t == Tok::IDENT && peek().t == Tok::SYM && peek().s == ":") {
+            s->label = t[i].s;
+            i += 2;
+            if (is_sym("+") || is_sym("-")) i++;
+        }
+        s->pos = {cur().line, cur().col};
+        if (is_sym("{")) {  // a compound statement in a sequence: its statements join the sequence
+            std::vector<SP> inner = c_block();
+            if (inner.empty()) fail("empty compound statement");
+            if (!s->label.empty()) { if (!inner[0]->label.empty()) fail("two labels on one statement"); inner[0]->label = s->label; }
+            for (auto &x : inner) out.push_back(x);
+            return;
+        }
+        if (cur().t != Tok::IDENT) fail("expected a statement");
+        const std::string kw = cur().s;
+        if (kw == "if") { i++; s->k = Stmt::IF; c_if_tail(*s); out.push_back(s); return; }
+        if (kw == "while") {
+            i++;
+            s->k = Stmt::WHILE;
+            expect_sym("(");
+            s->e = expr(0);
+            expect_sym(")");
+            s->blocks.push_back(c_body());
+            out.push_back(s);
+            return;
+        }
+        if (kw == "either") {
+            i++;
+            s->k = Stmt::EITHER;
+            s->blocks.push_back(c_body());
+            while (is_id("or")) { i++; s->blocks.push_back(c_body()); }
+            if (s->blocks.size() < 2) fail("`either` needs at least one `or`");
+            out.push_back(s);
+            return;
+        }
+        if (kw == "with") {
+            i++;
+            s->k = Stmt::WITH;
+            expect_sym("(");
+            s->var = ident("a variable after `with (`");
+            if (is_sym("=")) { i++; s->with_eq = true; }
+            else expect_sym("\\in");
+            s->e = expr(0);
+            if (is_sym(",") || is_sym(";")) fail("`with` over several variables is not supported: nest the statements");
+            expect_sym(")");
+            s->blocks.push_back(c_body());
+            out.push_back(s);
+            return;
+        }
+        simple(*s);
+        if (is_sym(";")) i++;
+        else if (!is_sym("}") && !is_id("else") && !is_id("or")) fail("expected `;`");
+        out.push_back(s);
+    }
+    void c_algorithm(Module &m) {  // positioned at the `{` after the algorithm name
+        expect_sym("{");
+        if (is_id("variables") || is_id("variable")) { i++; m.globals = vardecls(); }
+        if (is_id("define")) {
+            i++;
+            expect_sym("{");
+            while (!is_sym("}")) define_one(m);
+            i++;
+            if (is_sym(";")) i++;
+        }
+        while (is_id("macro")) {
+            i++;
+            Macro mac;
+            mac.name = ident("a macro name");
+            expect_sym("(");
+            if (!is_sym(")")) for (;;) { mac.params.push_back(ident("a parameter name")); if (is_sym(",")) { i++; continue; } break; }
+            expect_sym(")");
+            in_macro = true;
+            mac.body = c_block();
+            in_macro = false;
+            m.macros.push_back(mac);
+        }
+        macros = &m.macros;
+        if (is_id("procedure")) fail("procedures are not supported");
+        if (is_sym("{")) {  // uniprocess
+            Proc p;
+            p.body = c_block();
+            m.procs.push_back(p);
+        } else {
+            while (is_id("process") || is_id("fair")) {
+                if (is_id("fair")) { i++; if (is_sym("+")) i++; }
+                expect_id("process");
+                expect_sym("(");
+                Proc p;
+                p.name = ident("a process name");
+                if (is_sym("=")) { i++; }
+                else { expect_sym("\\in"); p.is_set = true; }
+                p.id = expr(0);
+                expect_sym(")");
+                if (is_id("variables") || is_id("variable")) { i++; p.locals = vardecls(); }
+                p.body = c_block();
+                m.procs.push_back(p);
+            }
+            if (m.procs.empty()) fail("expected `{` or `process`");
+        }
+        expect_sym("}");
+    }
+    void define_one(Module &m) {
+        Definition d;
+        d.in_define = true;
+        d.line = cur().line;
+        d.name = ident("a definition name");
+        if (is_sym("(")) {
+            i++;
+            for (;;) { d.params.push_back(ident("a parameter name")); if (is_sym(",")) { i++; continue; } break; }
+            expect_sym(")");
+        }
+        expect_sym("==");
+        d.body = expr(0);
+        m.defs.push_back(d);
     }
     void algorithm(Module &m) {
         // positioned after "--algorithm" / "--fair algorithm"
         m.algorithm = ident("the algorithm name");
-        if (is_sym("{")) fail("c-syntax PlusCal is not supported (use the p-syntax: begin ... end algorithm)");
+        if (is_sym("{")) { c_algorithm(m); return; }
         if (is_id("variables") || is_id("variable")) { i++; m.globals = vardecls(); }
         if (is_id("define")) {
             i++;
-            while (!is_id("end")) {
-                Definition d;
-                d.in_define = true;
-                d.line = cur().line;
-                d.name = ident("a definition name");
-                if (is_sym("(")) {
-                    i++;
-                    for (;;) { d.params.push_back(ident("a parameter name")); if (is_sym(",")) { i++; continue; } break; }
-                    expect_sym(")");
-                }
-                expect_sym("==");
-                d.body = expr(0);
-                m.defs.push_back(d);
-            }
+            while (!is_id("end")) define_one(m);
             expect_id("end");
             expect_id("define");
             if (is_sym(";")) i++;
@@ -554,12 +704,17 @@ std::string parse_module(const std::string &text, Module &m) {
         if (a == std::string::npos) return "no PlusCal algorithm (`--algorithm`) in the module";
         const size_t cbeg = text.rfind("(*", a);
         if (cbeg == std::string::npos) return "the PlusCal algorithm must be inside a (* ... *) comment";
-        size_t aend = text.find("end algorithm", a);
-        if (aend == std::string::npos) return "missing `end algorithm`";
-        aend += strlen("end algorithm");
-        size_t cend = text.find("*)", aend);
+        // end of the enclosing comment (comments nest); the p-syntax ends with `end algorithm`, the c-syntax with `}`
+        size_t cend = std::string::npos;
+        {
+            int depth = 1;
+            for (size_t k = cbeg + 2; k + 1 < text.size(); k++) {
+                if (text[k] == '(' && text[k + 1] == '*') { depth++; k++; }
+                else if (text[k] == '*' && text[k + 1] == ')') { if (--depth == 0) { cend = k + 2; break; } k++; }
+            }
+        }
         if (cend == std::string::npos) return "the algorithm comment is not closed";
-        cend += 2;
+        const size_t aend = cend - 2;
         m.alg_first_line = line_of(text, cbeg);
         m.alg_last_line = line_of(text, cend - 1);
         // header: module name, constants
