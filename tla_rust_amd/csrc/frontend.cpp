@@ -8,8 +8,10 @@
 //     both comment styles (pcal_intro.cfg:1 `\*`, AsynchInterface.cfg:1-5 `(* *)`);
 //   * choosing Init/Next/invariants/constraint from it (pcal_intro.cfg:2-3);
 //   * printing the report (README.md:267-321, testout2:260-266).
-// There is no general TLA+ evaluator: the module is matched by name to a
-// hand-lowered spec and its text is fingerprinted so a changed spec is refused, not mis-checked.
+// There is no general TLA+ evaluator: a TLA+-only module is matched by name to a
+// hand-lowered spec and its text is fingerprinted so a changed spec is refused, not mis-checked.  A module with a
+// PlusCal algorithm that has no hand lowering is compiled (pcal.cpp, pcal_compile.cpp) and runs through the
+// bytecode interpreter of spec_vm.h; `mc --transpile` is the reference's `pcal2tla` step (Makefile:3-4).
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
