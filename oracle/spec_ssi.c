@@ -517,6 +517,38 @@ int oracle_ssi_unit_tests(void) {
         for (int i = 0; i < s.n; i++) s.h[i] = wf[k].h[i];
         if (inv_wellformed(&c, &s) != wf[k].expect) fails++;
     }
+    /* examples/textbookSnapshotIsolation.tla:1231-1263 — UnitTests_ReadOnlyAnomaly: the history of Fekete's paper
+     *   R2(X0,0) R2(Y0,0) R1(Y0,0) W1(Y1,20) C1 R3(X0,0) R3(Y1,20) C3 W2(X2,-11) C2
+     * as the spec encodes it (T_0 = 0 creates the keys; K_X = 0, K_Y = 1; R1(Y0,0) is written as a "write" there,
+     * :1251).  ReadOnlyAnomaly(h) (:1216-1228): h is not serializable, and there is a transaction with reads and
+     * no writes whose removal makes it serializable (that transaction is T_3). */
+    {
+        static const Event fek[19] = {
+            {OP_BEGIN, 0, 0, 0, 0}, {OP_WRITE, 0, 0, 0, 0}, {OP_WRITE, 0, 1, 0, 0}, {OP_COMMIT, 0, 0, 0, 0},
+            {OP_BEGIN, 2, 0, 0, 0}, {OP_READ, 2, 0, 0, 0}, {OP_READ, 2, 1, 0, 0},
+            {OP_BEGIN, 1, 0, 0, 0}, {OP_WRITE, 1, 1, 0, 0}, {OP_WRITE, 1, 1, 0, 0}, {OP_COMMIT, 1, 0, 0, 0},
+            {OP_BEGIN, 3, 0, 0, 0}, {OP_READ, 3, 0, 0, 0}, {OP_READ, 3, 1, 1, 0}, {OP_COMMIT, 3, 0, 0, 0},
+            {OP_WRITE, 2, 0, 0, 0}, {OP_COMMIT, 2, 0, 0, 0}};
+        ssi_ctx c4 = {4, 2, 127, 0, 1};
+        SState s;
+        memset(&s, 0, sizeof s);
+        s.n = 17;
+        for (int i = 0; i < 17; i++) s.h[i] = fek[i];
+        if (inv_cahill(&c4, &s) != 0) fails++;     /* ~CahillSerializable(h) */
+        if (inv_bernstein(&c4, &s) != 0) fails++;  /* both formulations agree (:84-89) */
+        int found = 0;
+        for (int t = 0; t < 4; t++) {
+            int reads = 0, writes = 0;
+            for (int i = 0; i < 17; i++)
+                if (fek[i].txn == t) { reads += fek[i].op == OP_READ; writes += fek[i].op == OP_WRITE; }
+            if (!reads || writes) continue;
+            SState r;
+            memset(&r, 0, sizeof r);
+            for (int i = 0; i < 17; i++) if (fek[i].txn != t) r.h[r.n++] = fek[i];
+            if (inv_cahill(&c4, &r) && inv_bernstein(&c4, &r)) found = t + 1;   /* HistoryWithoutTxn(h, txn) is serializable */
+        }
+        if (found != 3 + 1) fails++;                /* the read-only transaction is T_3 */
+    }
     return fails;
 }
 

@@ -99,7 +99,8 @@ def test_ssi_4x3_prefix_levels(oracle):
 
 
 def test_ssi_in_spec_unit_tests(oracle):
-    """serializableSnapshotIsolation.tla:1068-1077 (9 cycle-finder cases) and :1184-1205 (10 well-formedness cases)."""
+    """serializableSnapshotIsolation.tla:1068-1077 (9 cycle-finder cases), :1184-1205 (10 well-formedness cases) and
+    textbookSnapshotIsolation.tla:1231-1263 (Fekete's read-only anomaly: ReadOnlyAnomaly(h) holds, the transaction is T_3)."""
     assert oracle.oracle_lib().oracle_ssi_unit_tests() == 0
 
 
