@@ -276,6 +276,22 @@ extern "C" void *shim_program_compile(const char *tla_text, const char *invarian
 extern "C" void shim_program_free(void *p) { delete (pcal::Program *)p; }
 extern "C" const char *shim_program_translated(void *p) { return ((pcal::Program *)p)->translated.c_str(); }
 
+// the DEVICE lowering's invariants on a hand-made history (known-answer tests of the reference's specs):
+// events = n x {op, txn, key, ver, reason}; returns the ST_* status of Spec::parent_status with `inv_mask`
+extern "C" unsigned shim_ssi_history_status(int nt, int nk, int inv_mask, int textbook, const int *events, int n) {
+    SsiParams p{nt, nk, inv_mask, 0, textbook};
+    uint64_t w[SpecSsi::MAX_WORDS] = {0};
+    w[SpecSsi::W_META] = (uint64_t)n;  // Len(history); no locks, no conflicts
+    for (int t = 0; t < SpecSsi::NT; t++) w[SpecSsi::W_META] = SpecSsi::m_set_txn(w[SpecSsi::W_META], t, SpecSsi::mk_txn(0, SpecSsi::NOLOCK, 0, 0, 0));
+    for (int i = 0; i < n; i++) {
+        const uint64_t e = SpecSsi::mk_event(events[5 * i], events[5 * i + 1], events[5 * i + 2], events[5 * i + 3], events[5 * i + 4]);
+        w[SpecSsi::W_H0 + i / 4] |= e << (16 * (i % 4));
+    }
+    SpecSsi::Local l;
+    SpecSsi::load(p, CWordRef{w, 1}, l);
+    return SpecSsi::parent_status(p, l, CWordRef{w, 1});
+}
+
 extern "C" size_t shim_state_bytes(const mc_spec_desc *d) {
     size_t n = 0;
     dispatch_spec(d, [&](auto spec, const auto &prm) { n = sizeof(uint64_t) * decltype(spec)::words(prm); return 0; });

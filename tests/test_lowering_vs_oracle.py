@@ -55,3 +55,30 @@ def test_ssi_3x2_prefix(oracle, shim):
     s = shim.shim_run("ssi", [3, 2, 127, 0], max_distinct=300000)
     for k in ("distinct", "generated", "depth", "verdict", "levels"):
         assert o[k] == s[k], k
+
+
+def test_device_ssi_invariants_on_fekete_read_only_anomaly(shim):
+    """examples/textbookSnapshotIsolation.tla:1231-1263 (UnitTests_ReadOnlyAnomaly) evaluated by the DEVICE lowering's
+    invariant code (spec_ssi.h parent_status): the history is not serializable by Cahill's (bit 32) nor Bernstein's
+    (bit 64) formulation, and is serializable by both once the read-only T_3 is removed."""
+    import ctypes as C
+    B, R, W, CM = 0, 1, 2, 3   # OP_BEGIN, OP_READ, OP_WRITE, OP_COMMIT (spec_ssi.h)
+    X, Y = 0, 1
+    h = [(B, 0, 0, 0, 0), (W, 0, X, 0, 0), (W, 0, Y, 0, 0), (CM, 0, 0, 0, 0),
+         (B, 2, 0, 0, 0), (R, 2, X, 0, 0), (R, 2, Y, 0, 0),
+         (B, 1, 0, 0, 0), (W, 1, Y, 0, 0), (W, 1, Y, 0, 0), (CM, 1, 0, 0, 0),
+         (B, 3, 0, 0, 0), (R, 3, X, 0, 0), (R, 3, Y, 1, 0), (CM, 3, 0, 0, 0),
+         (W, 2, X, 0, 0), (CM, 2, 0, 0, 0)]
+    lib = shim.shim_lib()
+    lib.shim_ssi_history_status.restype = C.c_uint
+    lib.shim_ssi_history_status.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+
+    def status(events, mask):
+        flat = [x for e in events for x in e]
+        return lib.shim_ssi_history_status(4, 2, mask, 1, (C.c_int * len(flat))(*flat), len(events))
+
+    ST_INVARIANT = 8
+    for mask, idx in ((32, 5), (64, 6)):
+        st = status(h, mask)
+        assert st & ST_INVARIANT and (st >> 8) & 255 == idx          # ~CahillSerializable(h) / ~BernsteinSerializable(h)
+        assert not status([e for e in h if e[1] != 3], mask) & ST_INVARIANT   # HistoryWithoutTxn(h, T_3) is serializable
