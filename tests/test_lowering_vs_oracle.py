@@ -82,3 +82,30 @@ def test_device_ssi_invariants_on_fekete_read_only_anomaly(shim):
         st = status(h, mask)
         assert st & ST_INVARIANT and (st >> 8) & 255 == idx          # ~CahillSerializable(h) / ~BernsteinSerializable(h)
         assert not status([e for e in h if e[1] != 3], mask) & ST_INVARIANT   # HistoryWithoutTxn(h, T_3) is serializable
+
+
+def test_device_ssi_wellformedness_unit_tests(shim):
+    """examples/serializableSnapshotIsolation.tla:1184-1205 (UnitTest_WellFormedTransactionsInHistory, 4 positive and
+    6 negative histories) through the DEVICE lowering's WellFormed invariant (bit 1)."""
+    import ctypes as C
+    B, R, W, CM, AB = 0, 1, 2, 3, 4
+    X, Y, T1, T2, VOL = 0, 1, 0, 1, 0
+    cases = [
+        ([(B, T1, 0, 0, 0)], True),
+        ([(B, T1, 0, 0, 0), (CM, T1, 0, 0, 0)], True),
+        ([(B, T1, 0, 0, 0), (R, T1, X, T2, 0), (W, T1, Y, 0, 0), (CM, T1, 0, 0, 0)], True),
+        ([(B, T1, 0, 0, 0), (R, T1, X, T2, 0), (W, T1, X, 0, 0), (AB, T1, 0, 0, VOL)], True),
+        ([(W, T1, X, 0, 0), (B, T1, 0, 0, 0)], False),
+        ([(B, T1, 0, 0, 0), (B, T1, 0, 0, 0), (W, T1, X, 0, 0)], False),
+        ([(B, T1, 0, 0, 0), (CM, T1, 0, 0, 0), (W, T1, X, 0, 0)], False),
+        ([(B, T1, 0, 0, 0), (AB, T1, 0, 0, VOL), (W, T1, X, 0, 0)], False),
+        ([(B, T1, 0, 0, 0), (W, T1, X, 0, 0), (W, T1, X, 0, 0)], False),
+        ([(B, T1, 0, 0, 0), (R, T1, X, T2, 0), (R, T1, X, T2, 0)], False),
+    ]
+    lib = shim.shim_lib()
+    lib.shim_ssi_history_status.restype = C.c_uint
+    lib.shim_ssi_history_status.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    for events, ok in cases:
+        flat = [x for e in events for x in e]
+        st = lib.shim_ssi_history_status(2, 2, 1, 0, (C.c_int * len(flat))(*flat), len(events))
+        assert bool(st & 8) == (not ok), events
