@@ -81,7 +81,7 @@ def main():
         # weak scaling: the distinct-state budget grows with the number of GPUs
         # deeper levels than the single-GPU prefix are reached: the message-slot maximum grows by about one per
         # level (13 at level 23), so the sharded run gets 24 message slots (W = 464 B) instead of 16
-        sharded_params = WORKLOAD["params"][:6] + [24, 2, 8]
+        sharded_params = WORKLOAD["params"][:6] + [int(os.environ.get("TLAMC_SHARD_CM", "24")), 2, 8]
         chk = ShardedChecker(WORKLOAD["spec"], sharded_params, device=local, max_distinct=a.max_distinct * world,
                              chunk_states=a.shard_chunk, table_capacity=1 << 27,
                              # the last level may overshoot the budget by the growth factor (~1.7x): size for it

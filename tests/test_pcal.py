@@ -38,6 +38,8 @@ CASES = [
     (SPECS / "pluscal" / "treiber_stack.tla", ["PoppedOnce", "TopIsNode", "Conservation"], {"N": 2}),   # CAS loops, pointers
     (SPECS / "pluscal" / "peterson_c.tla", ["MutualExclusion", "TurnInRange"], {}),                     # c-syntax
     (SPECS / "pluscal" / "csyntax_mix.tla", ["Inv"], {"N": 2}),   # c-syntax: define, macro, else-if, goto in if, either, with
+    (SPECS / "pluscal" / "bounded_queue.tla", ["Bounded", "Fifo"], {"Items": 4, "MaxQ": 2, "Consumers": 1}),   # sequences
+    (SPECS / "pluscal" / "bounded_queue.tla", ["Bounded", "Fifo"], {"Items": 3, "MaxQ": 2, "Consumers": 2}),   # ... assert fails
 ]
 
 
@@ -154,6 +156,15 @@ def test_refusals_are_explained(body, needle):
     with pytest.raises(RuntimeError) as e:
         helpers.ShimProgram(MODULE % body)
     assert needle in str(e.value)
+
+
+def test_sequence_longer_than_its_cells_is_an_error_not_a_truncation():
+    text = (SPECS / "pluscal" / "bounded_queue.tla").read_text()
+    prog = helpers.ShimProgram(text, ["Bounded"], {"Items": 9, "MaxQ": 9, "Consumers": 1})
+    with pytest.raises(RuntimeError) as e:
+        helpers.shim_run("pcal", prog.params)
+    assert "-3" in str(e.value)      # MC_EOVERFLOW
+    prog.close()
 
 
 def test_c_syntax_translates_like_p_syntax():

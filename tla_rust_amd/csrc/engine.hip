@@ -1012,7 +1012,7 @@ struct Engine : EngineBase {
         return MC_OK;
     }
     int check_dev_error() {
-        if (h_ctr->error & DEV_EOVERFLOW) { set_error("packed-state slot array overflow (messages/elections/allLogs capacity)"); return MC_EOVERFLOW; }
+        if (h_ctr->error & DEV_EOVERFLOW) { set_error("packed-state capacity exceeded (raft messages / elections / allLogs slots, or a PlusCal sequence longer than its cells)"); return MC_EOVERFLOW; }
         if (h_ctr->error & DEV_ETABLE) { set_error("seen-set full: raise table_capacity"); return MC_ETABLEFULL; }
         if (h_ctr->error & DEV_EARENA) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }
         return MC_OK;

@@ -154,7 +154,7 @@ struct Parser {
         if (s == "..") return 9;
         if (s == "+" || s == "-") return 10;
         if (s == "%") return 11;
-        if (s == "*" || s == "\\div") return 13;
+        if (s == "*" || s == "\\div" || s == "\\o" || s == "\\circ") return 13;
         return -1;
     }
     static EP mk(Expr::K k, const Tok &at) {

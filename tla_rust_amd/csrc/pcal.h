@@ -108,7 +108,9 @@ struct VarInfo {
     bool array = false;       // a function over `ids` (flattened to consecutive variables)
     int base = 0;             // index of the first 32-bit variable
     std::vector<long long> ids;  // domain of the array (process ids for pc and process locals)
-    char type = 'i';          // 'i' integer, 'b' boolean, 's' interned string
+    char type = 'i';          // 'i' integer, 'b' boolean, 's' interned string (of the elements for array / seq)
+    bool seq = false;         // a bounded sequence: cell `base` = Len, then `cap` element cells
+    int cap = 0;
 };
 
 struct Program {

@@ -163,7 +163,7 @@ struct Compiler {
             return 'i';
         }
         case Expr::IF: return type_of(e->a[1]);
-        case Expr::SETENUM: return e->a.empty() ? 'i' : type_of(e->a[0]);
+        case Expr::SETENUM: case Expr::TUPLE: return e->a.empty() ? 'i' : type_of(e->a[0]);
         case Expr::FUNCDEF: return type_of(e->a[1]);
         case Expr::ID: {
             if (e->s == "BOOLEAN") return 'b';
@@ -204,6 +204,70 @@ struct Compiler {
         else cfail("`self` outside a process", p);
     }
 
+    // ---- bounded sequences
+    static constexpr int SEQ_CAP = 8;  // element cells per sequence variable; a longer sequence is MC_EOVERFLOW, never truncated
+    const VarInfo *seq_var(const EP &e) {
+        if (e->k != Expr::ID) return nullptr;
+        for (size_t i = binds.size(); i-- > 0;) if (binds[i].name == e->s) return nullptr;
+        auto vi = var_index.find(e->s);
+        return vi != var_index.end() && P.vars[(size_t)vi->second].seq ? &P.vars[(size_t)vi->second] : nullptr;
+    }
+    void emit_seq(int op, const VarInfo &v) { c.push_back(op); track(op); c.push_back(v.base); c.push_back(v.cap); }
+    // q = <<a, b>>  (also #): Len(q) = n /\ q[1] = a /\ ...
+    void seq_equals(const VarInfo &q, const EP &tuple, bool negate) {
+        emit(mc::VM_LOAD, q.base); emit(mc::VM_PUSH, (int)tuple->a.size()); emit(mc::VM_EQ);
+        std::vector<int> fails;
+        fails.push_back(emit_jump(mc::VM_JZ));
+        for (size_t k = 0; k < tuple->a.size(); k++) {
+            emit(mc::VM_LOAD, q.base + 1 + (int)k); ex(tuple->a[k]); emit(mc::VM_EQ);
+            fails.push_back(emit_jump(mc::VM_JZ));
+        }
+        emit(mc::VM_PUSH, negate ? 0 : 1);
+        const int jend = emit_jump(mc::VM_JMP);
+        for (int f : fails) patch(f);
+        emit(mc::VM_PUSH, negate ? 1 : 0);
+        patch(jend);
+    }
+    // dst := <sequence expression>: <<..>>, q, Append(q, e), Tail(q), q \o <<..>>
+    void assign_seq(const VarInfo &dst, const EP &e) {
+        auto copy_from = [&](const EP &src) {
+            const VarInfo *sv = seq_var(src);
+            if (!sv) cfail("expected a sequence variable", src->pos);
+            if (sv != &dst) { c.push_back(mc::VM_SEQCOPY); c.push_back(dst.base); c.push_back(sv->base); c.push_back(dst.cap); }
+        };
+        if (e->k == Expr::TUPLE) {
+            // the elements may read dst (q := <<Head(q)>>): evaluate them first
+            if ((int)e->a.size() > dst.cap) cfail("sequence literal longer than the " + std::to_string(dst.cap) + " cells a sequence variable has", e->pos);
+            for (const auto &x : e->a) ex(x);
+            std::vector<int> tmp;
+            for (size_t k = 0; k < e->a.size(); k++) { tmp.push_back(new_temp(e->pos)); }
+            for (size_t k = e->a.size(); k-- > 0;) emit(mc::VM_STORET, tmp[k]);
+            emit_seq(mc::VM_SEQCLR, dst);
+            for (size_t k = 0; k < e->a.size(); k++) { emit(mc::VM_LOADT, tmp[k]); emit_seq(mc::VM_APPEND, dst); }
+            next_temp -= (int)tmp.size();
+            return;
+        }
+        if (e->k == Expr::ID) { copy_from(e); return; }
+        if (e->k == Expr::CALL && e->s == "Append" && e->a.size() == 2) {
+            ex(e->a[1]);  // evaluated on the old value of every variable
+            copy_from(e->a[0]);
+            emit_seq(mc::VM_APPEND, dst);
+            return;
+        }
+        if (e->k == Expr::CALL && e->s == "Tail" && e->a.size() == 1) { copy_from(e->a[0]); emit_seq(mc::VM_TAIL, dst); return; }
+        if (e->k == Expr::BINOP && (e->s == "\\o" || e->s == "\\circ") && e->a[1]->k == Expr::TUPLE) {
+            for (const auto &x : e->a[1]->a) ex(x);
+            std::vector<int> tmp;
+            for (size_t k = 0; k < e->a[1]->a.size(); k++) tmp.push_back(new_temp(e->pos));
+            for (size_t k = tmp.size(); k-- > 0;) emit(mc::VM_STORET, tmp[k]);
+            copy_from(e->a[0]);
+            for (int t : tmp) { emit(mc::VM_LOADT, t); emit_seq(mc::VM_APPEND, dst); }
+            next_temp -= (int)tmp.size();
+            return;
+        }
+        cfail("a sequence variable can be assigned <<...>>, another sequence, Append(q, e), Tail(q) or q \\o <<...>>", e->pos);
+    }
+
     // ---- expressions: leave one value on the stack
     void ex(const EP &e) {
         switch (e->k) {
@@ -222,6 +286,7 @@ struct Compiler {
             if (vi != var_index.end()) {
                 const VarInfo &v = P.vars[(size_t)vi->second];
                 if (proc && proc_locals.count(e->s) && proc->is_set && P.multi) { push_self(e->pos); emit_indexed(mc::VM_LOADX, v, e->pos); return; }
+                if (v.seq) cfail("the sequence `" + e->s + "` is used as a value here; supported: Len, Head, " + e->s + "[i], = / # <<...>>", e->pos);
                 if (v.array) cfail("the function `" + e->s + "` is used as a value; only `" + e->s + "[i]` is supported", e->pos);
                 emit(mc::VM_LOAD, v.base);
                 return;
@@ -244,6 +309,13 @@ struct Compiler {
             cfail("unknown identifier `" + e->s + "`", e->pos);
         }
         case Expr::CALL: {  // an operator of the define block / of the module, inlined: arguments evaluated once
+            if ((e->s == "Len" || e->s == "Head") && e->a.size() == 1) {
+                const VarInfo *q = seq_var(e->a[0]);
+                if (!q) cfail(e->s + " needs a sequence variable", e->pos);
+                if (e->s == "Len") emit(mc::VM_LOAD, q->base);
+                else { emit(mc::VM_PUSH, 1); emit_seq(mc::VM_LOADSEQ, *q); }
+                return;
+            }
             const Definition *def = nullptr;
             for (const auto &d : m.defs) if (d.name == e->s && d.params.size() == e->a.size()) def = &d;
             if (!def) cfail("unknown operator `" + e->s + "` with " + std::to_string(e->a.size()) + " argument(s)", e->pos);
@@ -271,6 +343,7 @@ struct Compiler {
         }
         case Expr::INDEX: {
             if (e->a[0]->k != Expr::ID) cfail("only `name[index]` is supported", e->pos);
+            if (const VarInfo *q = seq_var(e->a[0])) { ex(e->a[1]); emit_seq(mc::VM_LOADSEQ, *q); return; }
             auto vi = var_index.find(e->a[0]->s);
             if (vi == var_index.end() || !P.vars[(size_t)vi->second].array) cfail("`" + e->a[0]->s + "` is not a function variable", e->pos);
             if (proc && proc_locals.count(e->a[0]->s) && proc->is_set && P.multi)
@@ -315,6 +388,11 @@ struct Compiler {
             if (o == "\\notin") emit(mc::VM_NOT);
             next_temp--;
             return;
+        }
+        if (o == "=" || o == "#") {
+            for (int side = 0; side < 2; side++)
+                if (const VarInfo *q = seq_var(e->a[(size_t)side]))
+                    if (e->a[(size_t)(1 - side)]->k == Expr::TUPLE) { seq_equals(*q, e->a[(size_t)(1 - side)], o == "#"); return; }
         }
         static const std::pair<const char *, int> ops[] = {{"=", mc::VM_EQ},  {"#", mc::VM_NE},  {"<", mc::VM_LT},    {">", mc::VM_GT},
                                                           {"<=", mc::VM_LE}, {">=", mc::VM_GE}, {"+", mc::VM_ADD},   {"-", mc::VM_SUB},
@@ -424,6 +502,12 @@ struct Compiler {
         auto vi = var_index.find(s->var);
         if (vi == var_index.end() || s->var == "pc") cfail("assignment to `" + s->var + "`, which is not a variable of the algorithm", s->pos);
         const VarInfo &v = P.vars[(size_t)vi->second];
+        if (v.seq) {
+            for (const auto &pr : m.procs) for (const auto &l : pr.locals) if (l.name == s->var && &pr != proc) cfail("`" + s->var + "` cannot be assigned here", s->pos);
+            if (s->idx) { ex(s->idx); ex(s->e); emit_seq(mc::VM_STORESEQ, v); }
+            else assign_seq(v, s->e);
+            return;
+        }
         const bool self_indexed = proc && proc_locals.count(s->var) && proc->is_set && P.multi;
         bool global_or_own = self_indexed || !v.array || s->idx;
         for (const auto &pr : m.procs) for (const auto &l : pr.locals) if (l.name == s->var && &pr != proc) global_or_own = false;
@@ -636,7 +720,14 @@ struct Compiler {
         };
         auto decl_var = [&](const VarDecl &d, const Proc *owner) {
             const bool per_inst = owner && owner->is_set && P.multi;
-            if (d.init->k == Expr::FUNCDEF && !d.in_set) {
+            if (d.init->k == Expr::TUPLE && !d.in_set) {  // a sequence
+                if (per_inst) cfail("sequence variables local to a process SET are not supported (`" + d.name + "`)", d.pos);
+                add_var(d.name, false, {}, d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
+                VarInfo &v = P.vars.back();
+                v.seq = true;
+                v.cap = SEQ_CAP;
+                nv += SEQ_CAP;  // add_var counted the Len cell
+            } else if (d.init->k == Expr::FUNCDEF && !d.in_set) {
                 if (per_inst) cfail("process-local function variables are not supported (`" + d.name + "`)", d.pos);
                 std::vector<long long> dom;
                 if (!const_set(d.init->a[0], dom)) cfail("the domain of `" + d.name + "` must be a constant set", d.pos);
@@ -665,7 +756,11 @@ struct Compiler {
         auto init_decl = [&](const VarDecl &d, const Proc *owner) {
             const VarInfo &v = P.vars[(size_t)var_index[d.name]];
             const bool per_inst = owner && owner->is_set && P.multi;
-            if (per_inst) {
+            if (v.seq) {
+                if (owner && P.multi) { have_self_const = true; self_const = ids_of[owner][0]; }
+                assign_seq(v, d.init);
+                have_self_const = false;
+            } else if (per_inst) {
                 for (size_t k = 0; k < v.ids.size(); k++) {
                     have_self_const = true;
                     self_const = v.ids[k];
@@ -802,6 +897,12 @@ int vm_format(const void *host, const int32_t *vals, char *buf, size_t cap) {
     for (const auto &v : P.vars) {
         if (!s.empty()) s += "\n";
         s += "/\\ " + v.name + " = ";
+        if (v.seq) {
+            s += "<<";
+            for (int k = 0; k < vals[v.base] && k < v.cap; k++) s += (k ? ", " : "") + pcal::fmt_val(P, v.type, vals[v.base + 1 + k]);
+            s += ">>";
+            continue;
+        }
         if (!v.array) { s += pcal::fmt_val(P, v.type, vals[v.base]); continue; }
         // TLC prints a function whose domain is 1..n as a tuple, any other as (k :> v @@ ...) in ascending key order
         std::vector<size_t> order(v.ids.size());

@@ -20,7 +20,9 @@ namespace mc {
 enum VmOp : int32_t {
     VM_HALT = 0, VM_PUSH, VM_SELF, VM_LOAD, VM_LOADX, VM_STORE, VM_STOREX, VM_LOADT, VM_STORET,
     VM_ADD, VM_SUB, VM_MUL, VM_DIV, VM_MOD, VM_NEG, VM_EQ, VM_NE, VM_LT, VM_LE, VM_GT, VM_GE, VM_NOT,
-    VM_JMP, VM_JZ, VM_JNZ, VM_CHOOSE, VM_AWAIT, VM_ASSERT, VM_SETPC, VM_FAIL, VM_POP, VM_NOP
+    VM_JMP, VM_JZ, VM_JNZ, VM_CHOOSE, VM_AWAIT, VM_ASSERT, VM_SETPC, VM_FAIL, VM_POP, VM_NOP,
+    // bounded sequences: cell `base` holds Len, cells base+1 .. base+cap the elements (unused cells are 0)
+    VM_LOADSEQ, VM_STORESEQ, VM_APPEND, VM_TAIL, VM_SEQCLR, VM_SEQCOPY
 };
 
 // header words of the program image
@@ -61,7 +63,7 @@ struct SpecVmT {
 
     static int make_params(const int64_t *p, unsigned np, Params &o) { return vm_make_params(p, np, o); }
 
-    enum Run { R_DISABLED = 0, R_OK = 1, R_ASSERT = 2, R_ERROR = 3 };
+    enum Run { R_DISABLED = 0, R_OK = 1, R_ASSERT = 2, R_ERROR = 3, R_OVERFLOW = 4 };
 
     // run the code at `entry` on the variables v[]; `ch` = choice index consumed by VM_CHOOSE; top of stack at HALT
     // is returned through `result` (invariants); `aux` = assertion id on R_ASSERT
@@ -70,7 +72,7 @@ struct SpecVmT {
     MC_HD static int run(const Params &p, int entry, int32_t self, int inst, uint64_t ch, int32_t *v, int32_t &result, int &aux) {
         uint64_t rest = ch;
         const int r = run_raw(p, entry, self, inst, rest, v, result, aux);
-        return (r == R_ASSERT || r == R_ERROR) && rest != 0 ? (int)R_DISABLED : r;
+        return (r == R_ASSERT || r == R_ERROR || r == R_OVERFLOW) && rest != 0 ? (int)R_DISABLED : r;
     }
     MC_HD static int run_raw(const Params &p, int entry, int32_t self, int inst, uint64_t &ch, int32_t *v, int32_t &result, int &aux) {
         const int32_t *__restrict__ c = p.code;
@@ -149,6 +151,53 @@ struct SpecVmT {
             case VM_ASSERT: { const int32_t id = c[pc++]; if (!st[--sp]) { aux = id; return R_ASSERT; } break; }
             case VM_SETPC: v[p.pc_base + inst] = c[pc++]; break;
             case VM_POP: --sp; break;
+            case VM_LOADSEQ: {  // base, cap : 1-based index on the stack; Head(q) = q[1]
+                const int32_t base = c[pc], cap = c[pc + 1];
+                pc += 2;
+                const int32_t i = st[sp - 1];
+                if (i < 1 || i > v[base] || i > cap) return R_ERROR;  // TLC: index outside 1..Len(q), Head(<<>>)
+                st[sp - 1] = v[base + i];
+                break;
+            }
+            case VM_STORESEQ: {  // base, cap : value on top, index below
+                const int32_t base = c[pc], cap = c[pc + 1];
+                pc += 2;
+                const int32_t val = st[--sp], i = st[--sp];
+                if (i < 1 || i > v[base] || i > cap) return R_ERROR;
+                v[base + i] = val;
+                break;
+            }
+            case VM_APPEND: {  // base, cap : value on the stack
+                const int32_t base = c[pc], cap = c[pc + 1];
+                pc += 2;
+                const int32_t val = st[--sp], n = v[base];
+                if (n >= cap) return R_OVERFLOW;  // longer than the cells this program reserves: reported, never truncated
+                v[base + 1 + n] = val;
+                v[base] = n + 1;
+                break;
+            }
+            case VM_TAIL: {  // base, cap
+                const int32_t base = c[pc], cap = c[pc + 1];
+                pc += 2;
+                const int32_t n = v[base];
+                if (n < 1) return R_ERROR;  // Tail(<<>>)
+                for (int32_t k = 1; k < cap; ++k) v[base + k] = k < n ? v[base + k + 1] : 0;
+                v[base + cap] = 0;
+                v[base] = n - 1;
+                break;
+            }
+            case VM_SEQCLR: {
+                const int32_t base = c[pc], cap = c[pc + 1];
+                pc += 2;
+                for (int32_t k = 0; k <= cap; ++k) v[base + k] = 0;
+                break;
+            }
+            case VM_SEQCOPY: {  // dst, src, cap
+                const int32_t dst = c[pc], src = c[pc + 1], cap = c[pc + 2];
+                pc += 3;
+                for (int32_t k = 0; k <= cap; ++k) v[dst + k] = v[src + k];
+                break;
+            }
             case VM_NOP: break;
             case VM_FAIL:
             default: return R_ERROR;
@@ -231,6 +280,7 @@ struct SpecVmT {
         if (r == R_DISABLED) return 0;
         if (r == R_ASSERT) return ST_ENABLED | ST_ASSERT;
         if (r == R_ERROR) return ST_ENABLED | ST_SPECERR;
+        if (r == R_OVERFLOW) return ST_ENABLED | ST_OVERFLOW;
         return ST_ENABLED | inv_status(p, v);
     }
     template <class Ref>
