@@ -160,3 +160,21 @@ def test_reference_makefile_flow(tmp_path):
     for name, want in (("pcal_intro.tla", "5850 states generated, 3800 distinct states found"), ("atomic_add.tla", "7 states generated, 5 distinct states found")):
         rc, out, err = run_mc(tmp_path / name)
         assert rc == 0 and want in out, (name, out, err)
+
+
+def test_sequence_overflow_is_reported_on_gpu(amd):
+    text = (ROOT / "specs" / "pluscal" / "bounded_queue.tla").read_text()
+    prog = amd.Program(text, "CONSTANTS Items = 9 MaxQ = 9 Consumers = 1\n")
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 16, arena_capacity=1 << 14)
+    with pytest.raises(amd.McError) as e:
+        eng.run()
+    assert e.value.code == -3 and "sequence" in str(e.value)      # MC_EOVERFLOW
+    eng.close()
+    prog.close()
+
+
+def test_mc_bounded_queue_race():
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "bounded_queue.tla", "-config", ROOT / "specs" / "pluscal" / "bounded_queue_race.cfg")
+    assert rc == 12, err
+    assert '"Failure of assertion at line 37, column 9."' in out and out.count("\nState ") == 10
+    assert "/\\ queue = <<" in out
