@@ -221,6 +221,10 @@ int mc_spec_resolve(const char *module_name, const mc_cfg *c, mc_spec_desc *out)
 /* `tlc X.tla` end to end: read X.tla / X.cfg, run on `cfg->device`, write TLC's report text */
 int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report,
                    size_t report_cap, mc_result *out);
+/* the same, and every distinct state found is written to dump_path in TLC's `-dump` layout ("State k:" + the
+ * variables, blank line), in discovery order; dump_path NULL = mc_check_files */
+int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report,
+                        size_t report_cap, mc_result *out, const char *dump_path);
 
 #ifdef __cplusplus
 }

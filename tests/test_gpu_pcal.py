@@ -178,3 +178,16 @@ def test_mc_bounded_queue_race():
     assert rc == 12, err
     assert '"Failure of assertion at line 37, column 9."' in out and out.count("\nState ") == 10
     assert "/\\ queue = <<" in out
+
+
+def test_mc_dump_writes_every_state(tmp_path):
+    """`mc X.tla -dump FILE` = TLC's -dump: every distinct state, the same SET the TLA+ evaluator reaches"""
+    f = ROOT / "specs" / "pluscal" / "peterson.tla"
+    out_file = tmp_path / "states.dump"
+    rc, out, err = run_mc(f, "-dump", out_file)
+    assert rc == 0, err
+    blocks = [b for b in out_file.read_text().split("\n\n") if b.strip()]
+    assert len(blocks) == 58 and blocks[0].startswith("State 1:\n/\\ flag = ")
+    got = sorted(" ".join(b.splitlines()[1:]) for b in blocks)
+    o = Checker(f.read_text()).run_levels(invariants=["MutualExclusion", "TurnInRange"])
+    assert got == sorted(s for lvl in o["states"] for s in lvl)

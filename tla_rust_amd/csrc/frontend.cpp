@@ -647,6 +647,11 @@ static const char *invariant_name(const mc_spec_desc *d, int idx) {
 
 int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
                    mc_result *res) {
+    return mc_check_files_dump(tla_path, cfg_path, cfg, report, report_cap, res, nullptr);
+}
+
+int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
+                        mc_result *res, const char *dump_path) {
     if (!tla_path || !cfg || !report || !report_cap || !res) return MC_EBADCFG;
     report[0] = 0;
     std::string tla, cfgtext, module;
@@ -814,6 +819,23 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
     o.put("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)res->generated,
           (unsigned long long)res->distinct, (unsigned long long)res->queue_left);
     o.put("The depth of the complete state graph search is %u.\n", res->depth);
+    if (dump_path) {  // TLC -dump: every distinct state, in the order it was found
+        FILE *f = fopen(dump_path, "w");
+        if (!f) { mc_engine_destroy(e); return fe_fail(MC_EPARSE, "cannot write %s", dump_path); }
+        const size_t W = mc_state_bytes(&d);
+        const uint64_t batch = 1 << 14;
+        std::vector<uint8_t> buf(batch * W);
+        std::vector<char> txt(1 << 16);
+        for (uint64_t first = 0; first < res->distinct; first += batch) {
+            const uint64_t n = res->distinct - first < batch ? res->distinct - first : batch;
+            if ((rc = mc_engine_read_states(e, first, n, buf.data()))) { fclose(f); mc_engine_destroy(e); return rc; }
+            for (uint64_t k = 0; k < n; k++) {
+                mc_state_format(&d, &buf[k * W], txt.data(), txt.size());
+                fprintf(f, "State %llu:\n%s\n\n", (unsigned long long)(first + k + 1), txt.data());
+            }
+        }
+        fclose(f);
+    }
     mc_engine_destroy(e);
     return MC_OK;
 }

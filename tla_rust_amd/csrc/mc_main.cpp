@@ -2,13 +2,14 @@
 // Makefile:6-7 / README.md:262 (same inputs: X.tla with X.cfg beside it; same report lines:
 // README.md:267-321).  All work happens behind the C ABI (include/tlamc.h).
 //
-//   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic]
+//   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic] [-dump FILE]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
 //   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
 //                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
 //                                         the previous text is kept as X.old
 //
 // -generic  : check a PlusCal module through the compiled program even when a hand lowering exists.
+// -dump FILE: like TLC's -dump, write every distinct state found to FILE.
 // -deadlock : as with TLC, do NOT check for deadlock.  -workers is accepted and ignored (the
 // GPU is the worker pool).  Exit status: 0 no error, 12 safety violation (invariant / assert),
 // 11 deadlock, 1 any other failure — TLC's convention.
@@ -50,7 +51,7 @@ int main(int argc, char **argv) {
         for (int i = 2; i < argc; i++) rc |= transpile(argv[i]);
         return rc;
     }
-    const char *tla = nullptr, *cfgp = nullptr;
+    const char *tla = nullptr, *cfgp = nullptr, *dump = nullptr;
     mc_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.flags = MC_F_DEADLOCK | MC_F_TRACE;
@@ -60,6 +61,7 @@ int main(int argc, char **argv) {
         auto arg = [&](const char *name) { return !strcmp(argv[i], name) && i + 1 < argc; };
         if (arg("-config")) cfgp = argv[++i];
         else if (!strcmp(argv[i], "-deadlock")) cfg.flags &= ~MC_F_DEADLOCK;
+        else if (arg("-dump")) dump = argv[++i];
         else if (arg("-workers")) ++i;
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
         else if (arg("-device")) cfg.device = atoi(argv[++i]);
@@ -77,7 +79,7 @@ int main(int argc, char **argv) {
     }
     std::vector<char> report(1 << 22);
     static mc_result res;
-    const int rc = mc_check_files(tla, cfgp, &cfg, report.data(), report.size(), &res);
+    const int rc = mc_check_files_dump(tla, cfgp, &cfg, report.data(), report.size(), &res, dump);
     if (rc) {
         fprintf(stderr, "mc: %s: %s\n", mc_strerror(rc), mc_last_error());
         return 1;
