@@ -185,7 +185,7 @@ int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_loca
  * half: it returns the module text with the TLA+ translation of its `--algorithm` inserted (p-manual.pdf App. B).
  * mc_program_compile is what lets the checker run a PlusCal spec nobody hand-lowered: the algorithm (p- or c-syntax;
  * labels, := , if/elsif/else, while, either/or, with, await/when, assert, skip, goto, define, macros; integers, booleans, strings,
- * functions over constant sets, bounded sequences) becomes a bytecode program every GPU lane interprets on its own packed state
+ * functions over constant sets, bounded sequences, sets of small naturals) becomes a bytecode program every GPU lane interprets on its own packed state
  * (tla_rust_amd/csrc/spec_vm.h).  cfg_text: CONSTANT(S) with integer / string / model-value / set values and
  * INVARIANT(S) naming zero-argument definitions of the module; NULL = no constants, no invariants. */
 typedef struct mc_program mc_program;

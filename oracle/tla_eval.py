@@ -35,7 +35,7 @@ class Tok:
 
 
 SYMS = ["|->", "<>", "[]", ":=", "||", "==", "=>", "<=", ">=", "=<", "/=", "/\\", "\\/", "..", "->", "<<", ">>", ":>", "@@",
-        "(", ")", "[", "]", "{", "}", ",", ";", ":", "+", "-", "*", "%", "=", "<", ">", "#", "~", "'", "!", "@", ".", "^", "_"]
+        "(", ")", "[", "]", "{", "}", ",", ";", ":", "+", "-", "*", "%", "=", "<", ">", "#", "~", "'", "!", "@", ".", "^", "_", "\\"]
 
 
 def lex(text):

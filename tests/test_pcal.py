@@ -40,6 +40,7 @@ CASES = [
     (SPECS / "pluscal" / "csyntax_mix.tla", ["Inv"], {"N": 2}),   # c-syntax: define, macro, else-if, goto in if, either, with
     (SPECS / "pluscal" / "bounded_queue.tla", ["Bounded", "Fifo"], {"Items": 4, "MaxQ": 2, "Consumers": 1}),   # sequences
     (SPECS / "pluscal" / "bounded_queue.tla", ["Bounded", "Fifo"], {"Items": 3, "MaxQ": 2, "Consumers": 2}),   # ... assert fails
+    (SPECS / "pluscal" / "wait_set.tla", ["Disjoint", "HolderNotWaiting", "Counted"], {"N": 3}),               # set variables
 ]
 
 

@@ -26,7 +26,7 @@ struct Tok {
 
 const char *kSyms[] = {"|->", ":=", "||", "==", "=>", "<=", ">=", "=<", "/=", "/\\", "\\/", "..", "->", "<<", ">>", "(", ")", "[",
                        "]",   "{",  "}",  ",",  ";",  ":",  "+",  "-",  "*",  "%",   "=",   "<",  ">",  "#",  "~",  "'", "!", "@",
-                       ".",   "^"};
+                       ".",   "^",  "\\"};
 
 struct LexError { std::string msg; };
 

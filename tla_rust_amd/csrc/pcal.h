@@ -109,6 +109,7 @@ struct VarInfo {
     int base = 0;             // index of the first 32-bit variable
     std::vector<long long> ids;  // domain of the array (process ids for pc and process locals)
     char type = 'i';          // 'i' integer, 'b' boolean, 's' interned string (of the elements for array / seq)
+    bool set = false;         // a set of naturals 0..31 (or of interned strings), one cell holding the 32-bit mask
     bool seq = false;         // a bounded sequence: cell `base` = Len, then `cap` element cells
     int cap = 0;
 };

@@ -69,7 +69,7 @@ struct Compiler {
         case mc::VM_PUSH: case mc::VM_SELF: case mc::VM_LOAD: case mc::VM_LOADT: case mc::VM_CHOOSE: depth++; break;
         case mc::VM_STORE: case mc::VM_STORET: case mc::VM_AWAIT: case mc::VM_ASSERT: case mc::VM_JZ: case mc::VM_JNZ: case mc::VM_POP:
         case mc::VM_ADD: case mc::VM_SUB: case mc::VM_MUL: case mc::VM_DIV: case mc::VM_MOD: case mc::VM_EQ: case mc::VM_NE: case mc::VM_LT:
-        case mc::VM_LE: case mc::VM_GT: case mc::VM_GE: depth--; break;
+        case mc::VM_LE: case mc::VM_GT: case mc::VM_GE: case mc::VM_OR: case mc::VM_AND: case mc::VM_ANDN: depth--; break;
         case mc::VM_STOREX: depth -= 2; break;
         case mc::VM_HALT: depth = 0; break;
         default: break;
@@ -268,6 +268,49 @@ struct Compiler {
         cfail("a sequence variable can be assigned <<...>>, another sequence, Append(q, e), Tail(q) or q \\o <<...>>", e->pos);
     }
 
+    // ---- sets of small naturals as masks
+    const VarInfo *set_var(const EP &e) {
+        if (e->k != Expr::ID) return nullptr;
+        for (size_t i = binds.size(); i-- > 0;) if (binds[i].name == e->s) return nullptr;
+        auto vi = var_index.find(e->s);
+        return vi != var_index.end() && P.vars[(size_t)vi->second].set ? &P.vars[(size_t)vi->second] : nullptr;
+    }
+    // does the expression denote a set whose value depends on the state (a set variable somewhere inside)?
+    bool dynamic_set(const EP &e) {
+        if (set_var(e)) return true;
+        if (e->k == Expr::BINOP && (e->s == "\\cup" || e->s == "\\union" || e->s == "\\cap" || e->s == "\\intersect" || e->s == "\\"))
+            return dynamic_set(e->a[0]) || dynamic_set(e->a[1]);
+        if (e->k == Expr::SETENUM) { for (const auto &x : e->a) { long long v; if (!const_scalar(x, v)) return true; } }
+        return false;
+    }
+    // leave the 32-bit mask of a set expression on the stack
+    void ex_set(const EP &e) {
+        if (const VarInfo *v = set_var(e)) {
+            if (proc && proc_locals.count(e->s) && proc->is_set && P.multi) { push_self(e->pos); emit_indexed(mc::VM_LOADX, *v, e->pos); }
+            else emit(mc::VM_LOAD, v->base);
+            return;
+        }
+        if (e->k == Expr::BINOP && (e->s == "\\cup" || e->s == "\\union" || e->s == "\\cap" || e->s == "\\intersect" || e->s == "\\")) {
+            ex_set(e->a[0]);
+            ex_set(e->a[1]);
+            emit(e->s == "\\" ? mc::VM_ANDN : (e->s == "\\cap" || e->s == "\\intersect") ? mc::VM_AND : mc::VM_OR);
+            return;
+        }
+        if (e->k == Expr::SETENUM) {
+            emit(mc::VM_PUSH, 0);
+            for (const auto &x : e->a) { ex(x); emit(mc::VM_BIT); emit(mc::VM_OR); }
+            return;
+        }
+        std::vector<long long> elems;
+        if (const_set(e, elems)) {
+            unsigned mask = 0;
+            for (long long x : elems) { if (x < 0 || x > 31) cfail("only 0..31 can be members of a set value", e->pos); mask |= 1u << x; }
+            emit(mc::VM_PUSH, (int)mask);
+            return;
+        }
+        cfail("expected a set: a set variable, {...}, a constant set, or \\cup / \\cap / \\ of those", e->pos);
+    }
+
     // ---- expressions: leave one value on the stack
     void ex(const EP &e) {
         switch (e->k) {
@@ -286,6 +329,7 @@ struct Compiler {
             if (vi != var_index.end()) {
                 const VarInfo &v = P.vars[(size_t)vi->second];
                 if (proc && proc_locals.count(e->s) && proc->is_set && P.multi) { push_self(e->pos); emit_indexed(mc::VM_LOADX, v, e->pos); return; }
+                if (v.set) cfail("the set `" + e->s + "` is used as a number here; supported: \\in, \\cup, \\cap, \\, =, #, \\subseteq, Cardinality, with / quantifiers over it", e->pos);
                 if (v.seq) cfail("the sequence `" + e->s + "` is used as a value here; supported: Len, Head, " + e->s + "[i], = / # <<...>>", e->pos);
                 if (v.array) cfail("the function `" + e->s + "` is used as a value; only `" + e->s + "[i]` is supported", e->pos);
                 emit(mc::VM_LOAD, v.base);
@@ -309,6 +353,7 @@ struct Compiler {
             cfail("unknown identifier `" + e->s + "`", e->pos);
         }
         case Expr::CALL: {  // an operator of the define block / of the module, inlined: arguments evaluated once
+            if (e->s == "Cardinality" && e->a.size() == 1) { ex_set(e->a[0]); emit(mc::VM_POPCNT); return; }
             if ((e->s == "Len" || e->s == "Head") && e->a.size() == 1) {
                 const VarInfo *q = seq_var(e->a[0]);
                 if (!q) cfail(e->s + " needs a sequence variable", e->pos);
@@ -380,6 +425,10 @@ struct Compiler {
             patch(jend);
             return;
         }
+        if ((o == "\\in" || o == "\\notin") && dynamic_set(e->a[1])) {
+            ex(e->a[0]); emit(mc::VM_BIT); ex_set(e->a[1]); emit(mc::VM_AND); emit(mc::VM_PUSH, 0); emit(o == "\\in" ? mc::VM_NE : mc::VM_EQ);
+            return;
+        }
         if (o == "\\in" || o == "\\notin") {
             const int t = new_temp(e->pos);
             ex(e->a[0]);
@@ -389,6 +438,11 @@ struct Compiler {
             next_temp--;
             return;
         }
+        if ((o == "=" || o == "#") && (dynamic_set(e->a[0]) || dynamic_set(e->a[1]))) {
+            ex_set(e->a[0]); ex_set(e->a[1]); emit(o == "=" ? mc::VM_EQ : mc::VM_NE);
+            return;
+        }
+        if (o == "\\subseteq") { ex_set(e->a[0]); ex_set(e->a[1]); emit(mc::VM_ANDN); emit(mc::VM_PUSH, 0); emit(mc::VM_EQ); return; }
         if (o == "=" || o == "#") {
             for (int side = 0; side < 2; side++)
                 if (const VarInfo *q = seq_var(e->a[(size_t)side]))
@@ -458,8 +512,33 @@ struct Compiler {
             next_temp -= 2;
             return;
         }
+        if (dynamic_set(dom)) {  // x ranges over 0..31, the body counts only for members
+            const int tx = new_temp(e->pos), tm = new_temp(e->pos);
+            ex_set(dom); emit(mc::VM_STORET, tm);
+            emit(mc::VM_PUSH, 0); emit(mc::VM_STORET, tx);
+            const int loop = (int)c.size();
+            emit(mc::VM_LOADT, tx); emit(mc::VM_PUSH, 31); emit(mc::VM_LE);
+            const int jdone = emit_jump(mc::VM_JZ);
+            emit(mc::VM_LOADT, tx); emit(mc::VM_BIT); emit(mc::VM_LOADT, tm); emit(mc::VM_AND);
+            const int jskip = emit_jump(mc::VM_JZ);
+            binds.push_back({e->bound, tx, false, 0});
+            ex(e->a[1]);
+            binds.pop_back();
+            const int jhit = emit_jump(all ? mc::VM_JZ : mc::VM_JNZ);
+            patch(jskip);
+            emit(mc::VM_LOADT, tx); emit(mc::VM_PUSH, 1); emit(mc::VM_ADD); emit(mc::VM_STORET, tx);
+            emit(mc::VM_JMP, loop);
+            patch(jdone);
+            emit(mc::VM_PUSH, all ? 1 : 0);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(jhit);
+            emit(mc::VM_PUSH, all ? 0 : 1);
+            patch(jend);
+            next_temp -= 2;
+            return;
+        }
         std::vector<long long> elems;
-        if (!const_set(dom, elems)) cfail("a quantifier needs an interval or a constant set as its domain", dom->pos);
+        if (!const_set(dom, elems)) cfail("a quantifier needs an interval, a constant set or a set variable as its domain", dom->pos);
         std::vector<int> hits;
         for (long long x : elems) {
             binds.push_back({e->bound, 0, true, x});
@@ -502,6 +581,13 @@ struct Compiler {
         auto vi = var_index.find(s->var);
         if (vi == var_index.end() || s->var == "pc") cfail("assignment to `" + s->var + "`, which is not a variable of the algorithm", s->pos);
         const VarInfo &v = P.vars[(size_t)vi->second];
+        if (v.set) {
+            for (const auto &pr : m.procs) for (const auto &l : pr.locals) if (l.name == s->var && &pr != proc) cfail("`" + s->var + "` cannot be assigned here", s->pos);
+            if (s->idx) cfail("a set variable cannot be indexed", s->pos);
+            if (proc && proc_locals.count(s->var) && proc->is_set && P.multi) { push_self(s->pos); ex_set(s->e); emit_indexed(mc::VM_STOREX, v, s->pos); }
+            else { ex_set(s->e); emit(mc::VM_STORE, v.base); }
+            return;
+        }
         if (v.seq) {
             for (const auto &pr : m.procs) for (const auto &l : pr.locals) if (l.name == s->var && &pr != proc) cfail("`" + s->var + "` cannot be assigned here", s->pos);
             if (s->idx) { ex(s->idx); ex(s->e); emit_seq(mc::VM_STORESEQ, v); }
@@ -571,7 +657,13 @@ struct Compiler {
             const int t = new_temp(s->pos);
             unsigned long long n = 1;
             if (s->with_eq) ex(s->e);
-            else n = choose_from(s->e, s->pos);
+            else if (dynamic_set(s->e)) {  // any of 0..31, enabled only for the members
+                emit(mc::VM_CHOOSE, 32);
+                emit(mc::VM_STORET, t);
+                emit(mc::VM_LOADT, t); emit(mc::VM_BIT); ex_set(s->e); emit(mc::VM_AND); emit(mc::VM_AWAIT);
+                emit(mc::VM_LOADT, t);
+                n = 32;
+            } else n = choose_from(s->e, s->pos);
             emit(mc::VM_STORET, t);
             binds.push_back({s->var, t, false, 0});
             const unsigned long long b = block(s->blocks[0]);
@@ -703,6 +795,10 @@ struct Compiler {
             ids_of[&p] = ids;
             if (p.body.empty() || p.body[0]->label.empty()) cfail("the first statement of " + (p.name.empty() ? std::string("the algorithm") : "process " + p.name) + " needs a label");
         }
+        // instances in ascending identifier order: pc[i] can then be indexed whenever ProcSet is an integer interval
+        std::stable_sort(insts.begin(), insts.end(), [](const Inst &a, const Inst &b) { return a.self < b.self; });
+        procset.clear();
+        for (const auto &x : insts) procset.push_back(x.self);
         P.ninst = (int)insts.size();
         // variables: globals, pc, process locals (the VARIABLES order of the translation)
         int nv = 0;
@@ -720,7 +816,11 @@ struct Compiler {
         };
         auto decl_var = [&](const VarDecl &d, const Proc *owner) {
             const bool per_inst = owner && owner->is_set && P.multi;
-            if (d.init->k == Expr::TUPLE && !d.in_set) {  // a sequence
+            if (d.init->k == Expr::SETENUM && !d.in_set) {  // a set of small naturals / strings: one mask cell (per instance)
+                if (per_inst) add_var(d.name, true, ids_of[owner], d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
+                else add_var(d.name, false, {}, d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
+                P.vars.back().set = true;
+            } else if (d.init->k == Expr::TUPLE && !d.in_set) {  // a sequence
                 if (per_inst) cfail("sequence variables local to a process SET are not supported (`" + d.name + "`)", d.pos);
                 add_var(d.name, false, {}, d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
                 VarInfo &v = P.vars.back();
@@ -756,7 +856,14 @@ struct Compiler {
         auto init_decl = [&](const VarDecl &d, const Proc *owner) {
             const VarInfo &v = P.vars[(size_t)var_index[d.name]];
             const bool per_inst = owner && owner->is_set && P.multi;
-            if (v.seq) {
+            if (v.set) {
+                for (size_t k = 0; k < (v.array ? v.ids.size() : (size_t)1); k++) {
+                    if (owner && P.multi) { have_self_const = true; self_const = v.array ? v.ids[k] : ids_of[owner][0]; }
+                    ex_set(d.init);
+                    emit(mc::VM_STORE, v.base + (int)k);
+                    have_self_const = false;
+                }
+            } else if (v.seq) {
                 if (owner && P.multi) { have_self_const = true; self_const = ids_of[owner][0]; }
                 assign_seq(v, d.init);
                 have_self_const = false;
@@ -840,6 +947,15 @@ struct Compiler {
     }
 };
 
+std::string fmt_val(const Program &P, char type, int32_t v);
+std::string fmt_set(const Program &P, char type, int32_t mask) {  // elements in TLC's order: numbers ascending, strings sorted
+    std::vector<std::string> items;
+    for (int b = 0; b < 32; b++) if ((uint32_t)mask >> b & 1u) items.push_back(fmt_val(P, type, b));
+    if (type == 's') std::sort(items.begin(), items.end());
+    std::string s = "{";
+    for (size_t i = 0; i < items.size(); i++) s += (i ? ", " : "") + items[i];
+    return s + "}";
+}
 std::string fmt_val(const Program &P, char type, int32_t v) {
     if (type == 'b') return v ? "TRUE" : "FALSE";
     if (type == 's') return v >= 0 && (size_t)v < P.strings.size() ? "\"" + P.strings[(size_t)v] + "\"" : "\"?\"";
@@ -903,7 +1019,8 @@ int vm_format(const void *host, const int32_t *vals, char *buf, size_t cap) {
             s += ">>";
             continue;
         }
-        if (!v.array) { s += pcal::fmt_val(P, v.type, vals[v.base]); continue; }
+        auto one = [&](int32_t x) { return v.set ? pcal::fmt_set(P, v.type, x) : pcal::fmt_val(P, v.type, x); };
+        if (!v.array) { s += one(vals[v.base]); continue; }
         // TLC prints a function whose domain is 1..n as a tuple, any other as (k :> v @@ ...) in ascending key order
         std::vector<size_t> order(v.ids.size());
         for (size_t k = 0; k < order.size(); k++) order[k] = k;
@@ -912,12 +1029,12 @@ int vm_format(const void *host, const int32_t *vals, char *buf, size_t cap) {
         for (size_t k = 0; k < order.size(); k++) seq &= v.ids[order[k]] == (long long)k + 1;
         if (seq) {
             s += "<<";
-            for (size_t k = 0; k < order.size(); k++) s += (k ? ", " : "") + pcal::fmt_val(P, v.type, vals[v.base + (int)order[k]]);
+            for (size_t k = 0; k < order.size(); k++) s += (k ? ", " : "") + one(vals[v.base + (int)order[k]]);
             s += ">>";
         } else {
             s += "(";
             for (size_t k = 0; k < order.size(); k++)
-                s += (k ? " @@ " : "") + std::to_string(v.ids[order[k]]) + " :> " + pcal::fmt_val(P, v.type, vals[v.base + (int)order[k]]);
+                s += (k ? " @@ " : "") + std::to_string(v.ids[order[k]]) + " :> " + one(vals[v.base + (int)order[k]]);
             s += ")";
         }
     }

@@ -22,7 +22,9 @@ enum VmOp : int32_t {
     VM_ADD, VM_SUB, VM_MUL, VM_DIV, VM_MOD, VM_NEG, VM_EQ, VM_NE, VM_LT, VM_LE, VM_GT, VM_GE, VM_NOT,
     VM_JMP, VM_JZ, VM_JNZ, VM_CHOOSE, VM_AWAIT, VM_ASSERT, VM_SETPC, VM_FAIL, VM_POP, VM_NOP,
     // bounded sequences: cell `base` holds Len, cells base+1 .. base+cap the elements (unused cells are 0)
-    VM_LOADSEQ, VM_STORESEQ, VM_APPEND, VM_TAIL, VM_SEQCLR, VM_SEQCOPY
+    VM_LOADSEQ, VM_STORESEQ, VM_APPEND, VM_TAIL, VM_SEQCLR, VM_SEQCOPY,
+    // sets of small naturals (0..31) as 32-bit masks
+    VM_BIT, VM_OR, VM_AND, VM_ANDN, VM_POPCNT
 };
 
 // header words of the program image
@@ -190,6 +192,22 @@ struct SpecVmT {
                 const int32_t base = c[pc], cap = c[pc + 1];
                 pc += 2;
                 for (int32_t k = 0; k <= cap; ++k) v[base + k] = 0;
+                break;
+            }
+            case VM_BIT: {  // element -> singleton mask; only 0..31 can be a member of a set variable
+                const int32_t x = st[sp - 1];
+                if (x < 0 || x > 31) return R_OVERFLOW;
+                st[sp - 1] = (int32_t)(1u << x);
+                break;
+            }
+            case VM_OR: --sp; st[sp - 1] |= st[sp]; break;
+            case VM_AND: --sp; st[sp - 1] &= st[sp]; break;
+            case VM_ANDN: --sp; st[sp - 1] &= ~st[sp]; break;
+            case VM_POPCNT: {
+                uint32_t x = (uint32_t)st[sp - 1];
+                int32_t n = 0;
+                for (; x; x &= x - 1) ++n;
+                st[sp - 1] = n;
                 break;
             }
             case VM_SEQCOPY: {  // dst, src, cap
