@@ -41,6 +41,7 @@ CASES = [
     (SPECS / "pluscal" / "bounded_queue.tla", ["Bounded", "Fifo"], {"Items": 4, "MaxQ": 2, "Consumers": 1}),   # sequences
     (SPECS / "pluscal" / "bounded_queue.tla", ["Bounded", "Fifo"], {"Items": 3, "MaxQ": 2, "Consumers": 2}),   # ... assert fails
     (SPECS / "pluscal" / "wait_set.tla", ["Disjoint", "HolderNotWaiting", "Counted"], {"N": 3}),               # set variables
+    (SPECS / "pluscal" / "swap.tla", [], {}),                                                                  # a := e || b := f
 ]
 
 
@@ -148,6 +149,7 @@ MODULE = "---- MODULE t ----\nEXTENDS Naturals\n(* --algorithm t\n%s\nend algori
     ("variables x = 0;\nmacro m(a) begin a := 1; end macro;\nbegin\nA: m(x + 1);", "must be instantiated with a variable"),
     ("variables x = 0;\nbegin\nskip;", "needs a label"),
     ("variables x = 0;\nbegin\nA: x := 1; x := 2;", "second assignment to x"),
+    ("variables x = 0;\nbegin\nA: x := 1 || x := 2;", "two assignments to x"),
     ("variables x = 0;\nbegin\nA: if x = 0 then B: x := 1; end if; x := 2;", "needs a label"),
     ("variables x = 0;\nbegin\nA: y := 1;", "undeclared variable y"),
     ("variables x;\nbegin\nA: skip;", "needs an initial value"),

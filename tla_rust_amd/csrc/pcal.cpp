@@ -349,6 +349,7 @@ struct Parser {
             }
         }
         for (auto &b : c->blocks) for (auto &x : b) x = subst(x, m);
+        for (auto &x : c->more) x = subst(x, m);
         return c;
     }
     bool macro_call(std::vector<SP> &out) {
@@ -467,7 +468,19 @@ struct Parser {
         if (is_sym("[")) { i++; s.idx = expr(0); expect_sym("]"); if (is_sym("[")) fail("only one index level is supported on the left of `:=`"); }
         expect_sym(":=");
         s.e = expr(0);
-        if (is_sym("||")) fail("multiple assignment `||` is not supported: use separate statements");
+        while (is_sym("||")) {  // a := e || b := f: simultaneous
+            i++;
+            auto o = std::make_shared<Stmt>();
+            o->k = Stmt::ASSIGN;
+            o->pos = {cur().line, cur().col};
+            o->var = ident("a variable after `||`");
+            if (is_sym("[")) { i++; o->idx = expr(0); expect_sym("]"); }
+            expect_sym(":=");
+            o->e = expr(0);
+            if (o->var == s.var) fail("`||` with two assignments to " + s.var + " is not supported");
+            for (const auto &x : s.more) if (x->var == o->var) fail("`||` with two assignments to " + o->var + " is not supported");
+            s.more.push_back(o);
+        }
     }
 
     // ---- c-syntax (p-manual App. A): braces instead of begin/end, tests in parentheses; same AST
@@ -993,6 +1006,22 @@ struct ActionGen {
             }
             o.items.push_back(line(t));
             o.assigned.insert(s->var);
+            if (!s->more.empty()) {  // simultaneous: every right-hand side reads the values before the statement
+                std::set<std::string> before = primed;
+                std::set<std::string> after = primed;
+                after.insert(s->var);
+                for (const auto &x : s->more) {
+                    Out tmp;
+                    std::set<std::string> pr = before;
+                    if (after.count(x->var)) throw TranslateError{"second assignment to " + x->var + " in one step (line " + std::to_string(x->pos.line) + ")"};
+                    simple(x, tmp, pr, shadow, col);
+                    for (auto &it : tmp.items) o.items.push_back(it);
+                    o.assigned.insert(x->var);
+                    after.insert(x->var);
+                }
+                primed = after;
+                break;
+            }
             primed.insert(s->var);
             break;
         }

@@ -38,6 +38,8 @@ struct Stmt {
     EP e;                                  // ASSIGN rhs; condition of IF / WHILE / AWAIT / ASSERT; WITH set or value
     bool with_eq = false;                  // with x = e
     std::vector<std::vector<SP>> blocks;   // IF: then, else; EITHER: branches; WHILE / WITH: body
+    std::vector<SP> more;                  // ASSIGN: the other assignments of `a := e || b := f` (all right-hand sides
+                                           // see the values before the statement)
 };
 
 struct VarDecl {

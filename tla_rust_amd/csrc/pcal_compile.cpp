@@ -578,6 +578,45 @@ struct Compiler {
 
     // ---- statements
     void assign(const SP &s) {
+        if (!s->more.empty()) {  // a := e || b := f: evaluate every right-hand side (and index) first
+            std::vector<SP> all{s};
+            for (const auto &x : s->more) all.push_back(x);
+            struct Saved { int t_idx, t_val; };
+            std::vector<Saved> sv;
+            for (const auto &x : all) {
+                auto vi = var_index.find(x->var);
+                if (vi == var_index.end()) cfail("assignment to `" + x->var + "`, which is not a variable of the algorithm", x->pos);
+                if (P.vars[(size_t)vi->second].seq || P.vars[(size_t)vi->second].set) cfail("`||` with a sequence or set variable is not supported", x->pos);
+                Saved q{-1, new_temp(x->pos)};
+                if (x->idx) { q.t_idx = new_temp(x->pos); ex(x->idx); emit(mc::VM_STORET, q.t_idx); }
+                ex(x->e);
+                emit(mc::VM_STORET, q.t_val);
+                sv.push_back(q);
+            }
+            for (size_t k = 0; k < all.size(); k++) {  // then store, through single assignments of the saved values
+                auto one = std::make_shared<Stmt>(*all[k]);
+                one->more.clear();
+                const std::string vname = "\001v" + std::to_string(k), iname = "\001i" + std::to_string(k);
+                binds.push_back({vname, sv[k].t_val, false, 0});
+                auto ve = std::make_shared<Expr>();
+                ve->k = Expr::ID;
+                ve->s = vname;
+                ve->pos = one->pos;
+                one->e = ve;
+                if (one->idx) {
+                    binds.push_back({iname, sv[k].t_idx, false, 0});
+                    auto ie = std::make_shared<Expr>(*ve);
+                    ie->s = iname;
+                    one->idx = ie;
+                }
+                assign(one);
+                binds.pop_back();
+                if (all[k]->idx) binds.pop_back();
+            }
+            next_temp -= (int)sv.size();
+            for (const auto &q : sv) if (q.t_idx >= 0) next_temp--;
+            return;
+        }
         auto vi = var_index.find(s->var);
         if (vi == var_index.end() || s->var == "pc") cfail("assignment to `" + s->var + "`, which is not a variable of the algorithm", s->pos);
         const VarInfo &v = P.vars[(size_t)vi->second];
