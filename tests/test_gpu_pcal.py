@@ -191,3 +191,28 @@ def test_mc_dump_writes_every_state(tmp_path):
     got = sorted(" ".join(b.splitlines()[1:]) for b in blocks)
     o = Checker(f.read_text()).run_levels(invariants=["MutualExclusion", "TurnInRange"])
     assert got == sorted(s for lvl in o["states"] for s in lvl)
+
+
+def test_random_algorithms_on_gpu(amd):
+    """the seeded random algorithms of tests/test_pcal_random.py through the HIP engine"""
+    from test_pcal_random import Gen
+    checked = 0
+    for seed in range(1000, 1040):
+        text = Gen(seed).module(f"rnd{seed}")
+        try:
+            prog = amd.Program(text, "INVARIANT Small\n")
+        except amd.McError:
+            continue   # the generator broke a PlusCal rule; refusals are covered on the CPU
+        eng = amd.Engine("pcal", prog.params, table_capacity=1 << 18, arena_capacity=1 << 16, chunk_states=1 << 10, deadlock=False)
+        r = eng.run()
+        o = Checker(prog.translated()).run_levels(invariants=["Small"], check_deadlock=False)
+        for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+            assert getattr(r, k) == o[k], (seed, k, getattr(r, k), o[k])
+        first = 0
+        for lvl, n in enumerate(r.levels):
+            assert sorted(t.replace("\n", " ") for t in eng.state_texts(first, n)) == o["states"][lvl], (seed, lvl)
+            first += n
+        eng.close()
+        prog.close()
+        checked += 1
+    assert checked >= 25

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 
@@ -653,11 +654,69 @@ struct Compiler {
             emit(mc::VM_STORE, v.base);
         }
     }
+    // `await e` is the conjunct e of the action.  TLC evaluates an action formula disjunct by disjunct: for
+    // `A \\/ B` it continues once for every disjunct that holds (two successors — equal states — when both do), for a
+    // bounded `\\E x \\in S : p` once per witness, `/\\` and IF are walked in the same mode, and anything else is a
+    // boolean.  The alternatives become choice digits so that `states generated` counts what TLC counts.
+    unsigned long long await_action(const EP &e) {
+        if (e->k == Expr::BINOP && e->s == "\\/") {
+            std::vector<EP> ds;
+            std::function<void(const EP &)> flat = [&](const EP &x) {
+                if (x->k == Expr::BINOP && x->s == "\\/") { flat(x->a[0]); flat(x->a[1]); }
+                else ds.push_back(x);
+            };
+            flat(e);
+            const int t = new_temp(e->pos);
+            emit(mc::VM_CHOOSE, (int)ds.size());
+            emit(mc::VM_STORET, t);
+            std::vector<int> ends;
+            unsigned long long mx = 1;
+            for (size_t k = 0; k < ds.size(); k++) {
+                emit(mc::VM_LOADT, t); emit(mc::VM_PUSH, (int)k); emit(mc::VM_EQ);
+                const int jn = emit_jump(mc::VM_JZ);
+                mx = std::max(mx, await_action(ds[k]));
+                ends.push_back(emit_jump(mc::VM_JMP));
+                patch(jn);
+            }
+            emit(mc::VM_FAIL);
+            for (int x : ends) patch(x);
+            next_temp--;
+            return mx * ds.size();
+        }
+        if (e->k == Expr::BINOP && e->s == "/\\") return await_action(e->a[0]) * await_action(e->a[1]);
+        if (e->k == Expr::IF) {
+            ex(e->a[0]);
+            const int je = emit_jump(mc::VM_JZ);
+            const unsigned long long a = await_action(e->a[1]);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(je);
+            const unsigned long long b = await_action(e->a[2]);
+            patch(jend);
+            return std::max(a, b);
+        }
+        if (e->k == Expr::QUANT && e->s == "\\E") {
+            std::vector<long long> elems;
+            if (!dynamic_set(e->a[0]) && const_set(e->a[0], elems) && !elems.empty()) {  // one successor per witness
+                const int t = new_temp(e->pos);
+                const unsigned long long n = choose_from(e->a[0], e->pos);
+                emit(mc::VM_STORET, t);
+                binds.push_back({e->bound, t, false, 0});
+                const unsigned long long b = await_action(e->a[1]);
+                binds.pop_back();
+                next_temp--;
+                return n * b;
+            }
+        }
+        ex(e);
+        emit(mc::VM_AWAIT);
+        return 1;
+    }
+
     // a statement with no label inside; returns the number of alternatives it introduces
     unsigned long long nolabel(const SP &s) {
         switch (s->k) {
         case Stmt::ASSIGN: assign(s); return 1;
-        case Stmt::AWAIT: ex(s->e); emit(mc::VM_AWAIT); return 1;
+        case Stmt::AWAIT: return await_action(s->e);
         case Stmt::ASSERT:
             ex(s->e);
             emit(mc::VM_ASSERT, (int)P.asserts.size());
