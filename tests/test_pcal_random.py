@@ -31,7 +31,7 @@ class Gen:
 
     def expr(self, local):
         r = self.r
-        atoms = ["x", "y", "a[1]", "a[2]", "self", str(r.randrange(K))] + (["t"] if local else [])
+        atoms = ["x", "y", "a[1]", "a[2]", "self", str(r.randrange(K)), "Len(q)", "Cardinality(s)"] + (["t"] if local else [])
         e = r.choice(atoms)
         if r.random() < 0.5:
             e = f"({e} + {r.choice(atoms)}) % {K}"
@@ -40,6 +40,13 @@ class Gen:
     def cond(self, local):
         r = self.r
         c = f"{self.expr(local)} {r.choice(['=', '#', '<', '>='])} {self.expr(local)}"
+        k = r.random()
+        if k < 0.1:
+            c = f"{self.expr(local)} \\in s"
+        elif k < 0.15:
+            c = f"q # <<>>"
+        elif k < 0.2:
+            c = f"s \\subseteq {{0, 1}} \\/ {c}"
         if r.random() < 0.3:
             junct = r.choice(["/\\", "\\/"])
             c = f"{c} {junct} {self.expr(local)} # {r.randrange(K)}"
@@ -104,7 +111,22 @@ class Gen:
                 out.append(body.replace("self", "w", 1) if r.random() < 0.5 else body)
                 out.append(f"{ind}end with;")
                 free &= f1
-            elif k < 0.9:
+            elif k < 0.86 and "q" in free:
+                free.discard("q")
+                if r.random() < 0.5:
+                    out.append(f"{ind}if Len(q) < 2 then q := Append(q, {self.expr(local)}); end if;")
+                else:
+                    tgt = r.choice([v for v in ("x", "y") if v in free] or ["q"])
+                    if tgt == "q":
+                        out.append(f"{ind}if q # <<>> then q := Tail(q); end if;")
+                    else:
+                        free.discard(tgt)
+                        out.append(f"{ind}if q # <<>> then {tgt} := Head(q); q := Tail(q); end if;")
+            elif k < 0.9 and "s" in free:
+                free.discard("s")
+                op = r.choice(["\\cup", "\\"])
+                out.append(f"{ind}s := s {op} {{{self.expr(local)}}};")
+            elif k < 0.93:
                 out.append(f"{ind}await {self.cond(local)};")
             elif k < 0.95:
                 out.append(f"{ind}assert {self.expr(local)} < {K};")
@@ -117,13 +139,13 @@ class Gen:
         labels = [self.label() for _ in range(r.randint(2, 4))]
         out = []
         for i, lab in enumerate(labels):
-            free = {"x", "y", "a1", "a2", "as", "t"}
+            free = {"x", "y", "a1", "a2", "as", "t", "q", "s"}
             k = r.random()
             if k < 0.2 and i + 1 < len(labels):    # a while loop on a bounded counter (t), body with its own label
                 inner = self.label()
                 out.append(f"  {lab}: while {'t' if local else 'x'} < {K - 1} do")
                 out.append(f"    {inner}: {'t := t + 1' if local else 'x := x + 1'};")
-                f2 = {"y", "a1", "a2", "as"}
+                f2 = {"y", "a1", "a2", "as", "q", "s"}
                 out.append(self.simple_block(f2, local, "      "))
                 out.append("  end while;")
             elif k < 0.4 and i + 1 < len(labels):  # an if with a label / goto inside: the next statement is labeled
@@ -152,9 +174,9 @@ class Gen:
         if r.random() < 0.5:
             body = self.process_body(False).replace("self", "0")
             procs.append("process Q = 0\nbegin\n" + body + "\nend process")
-        alg = (f"variables x = 0, y \\in 0..1, a = [i \\in 0..2 |-> i % {K}];\n\n" + "\n\n".join(procs))
-        return (f"---- MODULE {name} ----\nEXTENDS Naturals, TLC\n\n(* --algorithm {name}\n{alg}\n\nend algorithm *)\n\n"
-                f"Small == x < {K} /\\ y < {K} /\\ \\A i \\in 0..2 : a[i] < {K}\n====\n")
+        alg = (f"variables x = 0, y \\in 0..1, a = [i \\in 0..2 |-> i % {K}], q = <<>>, s = {{}};\n\n" + "\n\n".join(procs))
+        return (f"---- MODULE {name} ----\nEXTENDS Naturals, Sequences, FiniteSets, TLC\n\n(* --algorithm {name}\n{alg}\n\nend algorithm *)\n\n"
+                f"Small == x < {K} /\\ y < {K} /\\ (\\A i \\in 0..2 : a[i] < {K}) /\\ Len(q) <= 2 /\\ (\\A e \\in s : e < {K})\n====\n")
 
 
 @pytest.mark.parametrize("block", range(8))
@@ -167,7 +189,7 @@ def test_random_algorithms_compiled_vs_evaluated(block):
         except RuntimeError as e:   # the generator may break a PlusCal rule (e.g. a needed label): both routes refuse
             with pytest.raises(RuntimeError):
                 helpers.pcal_translate(text)
-            assert "label" in str(e) or "assignment" in str(e), (seed, str(e))
+            assert "label" in str(e) or "assignment" in str(e), (seed, str(e), text)
             continue
         fd, dump = tempfile.mkstemp()
         os.close(fd)
