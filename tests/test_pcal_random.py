@@ -47,6 +47,10 @@ class Gen:
             c = f"q # <<>>"
         elif k < 0.2:
             c = f"s \\subseteq {{0, 1}} \\/ {c}"
+        elif k < 0.25:
+            c = f"\\E e \\in s : e # {r.randrange(K)}"
+        elif k < 0.3:
+            c = f"\\E e \\in 0..1 : e = x \\/ e = y"
         if r.random() < 0.3:
             junct = r.choice(["/\\", "\\/"])
             c = f"{c} {junct} {self.expr(local)} # {r.randrange(K)}"

@@ -696,7 +696,20 @@ struct Compiler {
         }
         if (e->k == Expr::QUANT && e->s == "\\E") {
             std::vector<long long> elems;
-            if (!dynamic_set(e->a[0]) && const_set(e->a[0], elems) && !elems.empty()) {  // one successor per witness
+            if (dynamic_set(e->a[0])) {  // a set variable: any of 0..31 that is a member
+                const int t = new_temp(e->pos);
+                emit(mc::VM_CHOOSE, 32);
+                emit(mc::VM_STORET, t);
+                emit(mc::VM_LOADT, t); emit(mc::VM_BIT); ex_set(e->a[0]); emit(mc::VM_AND); emit(mc::VM_AWAIT);
+                binds.push_back({e->bound, t, false, 0});
+                const unsigned long long b = await_action(e->a[1]);
+                binds.pop_back();
+                next_temp--;
+                return 32 * b;
+            }
+            // (a state-dependent interval such as 1..Len(q) has no static bound: evaluated as a boolean below, i.e.
+            // ONE successor where TLC would generate one per witness — same states, smaller `generated`)
+            if (const_set(e->a[0], elems) && !elems.empty()) {  // one successor per witness
                 const int t = new_temp(e->pos);
                 const unsigned long long n = choose_from(e->a[0], e->pos);
                 emit(mc::VM_STORET, t);
