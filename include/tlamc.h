@@ -71,6 +71,7 @@ typedef struct {
 #define MC_F_MATRIX 8u   /* A/B only: unfused expand -> candidate matrix -> insert kernels          */
 #define MC_F_NOPROBE 16u /* profiling only (mc_engine_debug_reexpand): skip the seen-set probes   */
 #define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
+#define MC_F_NOBATCH 256u /* A/B only: one host round trip per BFS level even while the frontier is small         */
 #define MC_F_GENERIC 128u /* mc_check_files: run a PlusCal module through the compiled program (MC_SPEC_PCAL) even
                              when a hand lowering of its algorithm exists (A/B of the two paths)  */
 

@@ -286,12 +286,26 @@ __device__ __forceinline__ void wave_lds_fence() {
 // rank that owns them (owner = fingerprint high bits): bucket [owner][shard] in HBM, one
 // atomicAdd per (flush, owner present).  k_compact_buckets then makes each owner's bucket
 // contiguous for the all-to-all.
+// Device-driven levels: while the frontier is small, the host enqueues a batch of levels back to back and the
+// kernels read the level's range from this block (no host round trip per level; see Engine::run).
+constexpr int BLIND_BATCH = 8;
+struct LevelCtl {
+    unsigned long long lo, hi;        // frontier of the level about to be expanded
+    unsigned long long max_states;    // a batched level handles at most this many states
+    unsigned long long max_distinct;  // budget (0 = none)
+    unsigned int stop;                // 0 run; 1 finished (empty frontier / violation / error / budget); 2 next level too large
+    unsigned int nlev;                // levels completed since the host last looked
+    unsigned int levels_left;         // max_levels budget: expansions still allowed (0 = unlimited)
+    unsigned int pad;
+    unsigned long long level_hi[BLIND_BATCH];  // arena fill level after each completed level
+};
 struct RouteArgs {
     unsigned nranks;
     PaddedCounter *cursors;   // [nranks * NSHARD]
     uint64_t *rt_fp;          // [nranks * NSHARD][subcap]
     uint32_t *rt_src;
     uint64_t subcap;
+    const LevelCtl *lc = nullptr;  // non-null: [lo, hi) come from the device (batched small levels)
 };
 
 template <class S, bool ROUTE>
@@ -301,6 +315,12 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 RouteArgs rt, unsigned parity) {
     __shared__ WaveQueues wq[4];
     __shared__ uint64_t stage[4][S::STAGE_WORDS > 0 ? S::STAGE_WORDS : 1][64];
+    if (rt.lc) {
+        if (rt.lc->stop) return;
+        lo = rt.lc->lo;
+        hi = rt.lc->hi;
+        ncols = ((hi - (lo & ~63ull)) + 63) & ~63ull;
+    }
     const unsigned lane = threadIdx.x & 63;
     WaveQueues &Q = wq[threadIdx.x >> 6];
     const uint64_t base = lo & ~63ull;
@@ -474,6 +494,12 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 RouteArgs rt, unsigned parity) {
     __shared__ WaveQueues wq[4];
     __shared__ FamLds<S> fls[4];
+    if (rt.lc) {
+        if (rt.lc->stop) return;
+        lo = rt.lc->lo;
+        hi = rt.lc->hi;
+        ncols = ((hi - (lo & ~63ull)) + 63) & ~63ull;
+    }
     const unsigned lane = threadIdx.x & 63;
     WaveQueues &Q = wq[threadIdx.x >> 6];
     FamLds<S> &FL = fls[threadIdx.x >> 6];
@@ -689,7 +715,12 @@ static void launch_expand(bool by_family, dim3 grid, hipStream_t stream, A... ar
 template <class S>
 __global__ void __launch_bounds__(256)
 k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint32_t *__restrict__ newlist, uint64_t seg_cap,
-              uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr, unsigned parity) {
+              uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr, unsigned parity,
+              const LevelCtl *lc) {
+    if (lc) {
+        if (lc->stop) return;
+        chunk_base = lc->lo & ~63ull;
+    }
     const unsigned sh = blockIdx.y;  // new-list segment
     const uint64_t n = ctr->n_new[parity * NSHARD + sh].v;
     uint64_t out0 = ctr->arena_next;
@@ -854,6 +885,25 @@ static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
     ctr->max_slots = 0;
 }
 
+// closes a batched level on the device: advances [lo, hi), records the fill level, decides whether the next one may run
+static __global__ void k_end_level(DevCounters *ctr, LevelCtl *lc) {
+    if (lc->stop) return;
+    {  // k_commit of new-list parity 0, folded in (one launch less per level)
+        unsigned long long n = 0;
+        for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; }
+        ctr->arena_next += n;
+        ctr->max_slots = 0;
+    }
+    const unsigned long long hi_new = ctr->arena_next;
+    lc->level_hi[lc->nlev++] = hi_new;
+    lc->lo = lc->hi;
+    lc->hi = hi_new;
+    if (hi_new == lc->lo || ctr->viol_key != ~0ull || ctr->error) lc->stop = 1;
+    else if (lc->max_distinct && hi_new >= lc->max_distinct) lc->stop = 1;
+    else if (lc->levels_left && --lc->levels_left == 0) lc->stop = 1;
+    else if (hi_new - lc->lo > lc->max_states) lc->stop = 2;
+}
+
 // ------------------------------------------------------------------------------------- host side
 struct EngineBase {
     void *owned_device_blob = nullptr;  // program image of a compiled PlusCal spec (spec_vm.h)
@@ -922,6 +972,7 @@ struct Engine : EngineBase {
     uint64_t *d_inittmp = nullptr;
     uint32_t *d_parent = nullptr;
     DevCounters *d_ctr = nullptr, *h_ctr = nullptr;
+    LevelCtl *d_lc = nullptr, *h_lc = nullptr;
     uint64_t table_cap = 0, arena_cap = 0, chunk = 0, row_stride = 0, seg_cap = 0;
     KTimer timer;
     mc_kernel_stat kstat[3];
@@ -963,6 +1014,8 @@ struct Engine : EngineBase {
         }
         HIP_TRY(hipMalloc(&d_ctr, sizeof(DevCounters)));
         HIP_TRY(hipHostMalloc(&h_ctr, sizeof(DevCounters)));
+        HIP_TRY(hipMalloc(&d_lc, sizeof(LevelCtl)));
+        HIP_TRY(hipHostMalloc(&h_lc, sizeof(LevelCtl)));
         timer.enabled = (cfg.flags & MC_F_TIMING) != 0;
         return MC_OK;
     }
@@ -987,6 +1040,8 @@ struct Engine : EngineBase {
         if (d_pslot) hipFree(d_pslot);
         if (d_ctr) hipFree(d_ctr);
         if (h_ctr) hipHostFree(h_ctr);
+        if (d_lc) hipFree(d_lc);
+        if (h_lc) hipHostFree(h_lc);
         for (int i = 0; i < 2; i++) { if (ev_e[i]) hipEventDestroy(ev_e[i]); if (ev_m[i]) hipEventDestroy(ev_m[i]); }
         if (stream2) hipStreamDestroy(stream2);
         if (stream) hipStreamDestroy(stream);
@@ -1028,11 +1083,29 @@ struct Engine : EngineBase {
         hipStreamWaitEvent(stream2, ev_e[parity], 0);
         timed(2, 0, [&] {
             hipLaunchKernelGGL(k_materialise<S>, dim3(gm, NSHARD), dim3(256), 0, stream2, prm, d_arena, chunk_base, d_newlist,
-                               seg_cap, arena_cap, d_parent, d_pslot, d_ctr, parity);
+                               seg_cap, arena_cap, d_parent, d_pslot, d_ctr, parity, (const LevelCtl *)nullptr);
         }, stream2);
         hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream2, d_ctr, parity);
         hipEventRecord(ev_m[parity], stream2);
     }
+    // one batched level (LevelCtl): the same pair of kernels, ranges read on the device, then the level is closed there
+    void enqueue_blind_level(uint64_t max_states) {
+        // all four kernels on ONE stream: for a frontier this small the two-stream overlap buys nothing and the
+        // cross-stream events would cost more than the kernels
+        const uint64_t ncols = max_states + 64;
+        RouteArgs rt{};
+        rt.lc = d_lc;
+        timed(0, 0, [&] {
+            launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm, (const uint64_t *)d_arena,
+                                    (uint64_t)0, (uint64_t)0, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
+        });
+        timed(2, 0, [&] {
+            hipLaunchKernelGGL(k_materialise<S>, dim3(32, NSHARD), dim3(256), 0, stream, prm, d_arena, (uint64_t)0, d_newlist, seg_cap,
+                               arena_cap, d_parent, d_pslot, d_ctr, 0u, (const LevelCtl *)d_lc);
+        });
+        hipLaunchKernelGGL(k_end_level, dim3(1), dim3(1), 0, stream, d_ctr, d_lc);
+    }
+
     // insert + materialise + commit for the candidate matrix just written
     template <bool INIT>
     void finish_chunk(uint64_t chunk_base_or_first, uint64_t ncols, unsigned rows) {
@@ -1048,7 +1121,7 @@ struct Engine : EngineBase {
                                    d_inittmp, d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
             else
                 hipLaunchKernelGGL(k_materialise<S>, dim3(gm, 1), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
-                                   d_newlist, seg_cap, arena_cap, d_parent, d_pslot, d_ctr, 0u);
+                                   d_newlist, seg_cap, arena_cap, d_parent, d_pslot, d_ctr, 0u, (const LevelCtl *)nullptr);
         });
         hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr, 0u);
     }
@@ -1086,10 +1159,40 @@ struct Engine : EngineBase {
         out->level_distinct[0] = hi;
         level_start.push_back(0);
         int budget = 0;
+        const uint64_t blind_max = chunk < (1ull << 16) ? chunk : (1ull << 16);
         while (hi > lo) {
             if (h_ctr->viol_key != ~0ull) break;
             if (cfg.max_levels && level >= cfg.max_levels) { budget = 1; break; }
             if (cfg.max_distinct && hi >= cfg.max_distinct) { budget = 1; break; }
+            if (!use_matrix && !(cfg.flags & MC_F_NOBATCH) && hi - lo <= blind_max) {
+                // Small frontier: BLIND_BATCH levels are enqueued back to back; the kernels take each level's range from
+                // LevelCtl and k_end_level applies the same stopping rules as this loop, so one host round trip covers
+                // up to BLIND_BATCH levels instead of one (a level of a few thousand states is pure launch latency).
+                memset(h_lc, 0, sizeof *h_lc);
+                h_lc->lo = lo;
+                h_lc->hi = hi;
+                h_lc->max_states = blind_max;
+                h_lc->max_distinct = cfg.max_distinct;
+                h_lc->levels_left = cfg.max_levels ? (unsigned)(cfg.max_levels - level) : 0u;
+                HIP_TRY(hipMemcpyAsync(d_lc, h_lc, sizeof *h_lc, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipStreamSynchronize(stream2));  // (nothing of an earlier level is still being materialised)
+                for (int k = 0; k < BLIND_BATCH; k++) enqueue_blind_level(blind_max);
+                HIP_TRY(hipMemcpyAsync(h_lc, d_lc, sizeof *h_lc, hipMemcpyDeviceToHost, stream));
+                if ((rc = read_counters())) return rc;
+                if ((rc = check_dev_error())) return rc;
+                for (unsigned k = 0; k < h_lc->nlev; k++) {
+                    kstat[0].units += hi - lo;  // states expanded by this level (the launches were timed with 0 units)
+                    lo = hi;
+                    hi = h_lc->level_hi[k];
+                    if (hi > lo) {
+                        level_start.push_back(lo);
+                        if (level < MC_MAX_LEVELS) out->level_distinct[level] = hi - lo;
+                        level++;
+                    }
+                    if (level >= MC_MAX_LEVELS) { set_error("too many BFS levels"); return MC_EBADCFG; }
+                }
+                continue;  // the loop head re-checks violation / budgets / frontier with the host's copies
+            }
             unsigned chunk_no = 0;
             for (uint64_t c0 = lo; c0 < hi; ++chunk_no) {
                 const unsigned parity = chunk_no & 1u;
