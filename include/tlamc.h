@@ -158,6 +158,14 @@ void mc_engine_destroy(mc_engine *e);
  * With it mc_shard_keep* reports *n_new = 0: the count stays on the device until mc_shard_end_level. */
 int mc_shard_set_stream(mc_engine *e, void *hip_stream, int enable);
 int mc_shard_begin(mc_engine *e);                                  /* Init: keep the initial states this rank owns */
+/* Alternative start: every rank runs the same single-GPU BFS until a level has at least min_frontier states (the
+ * small first levels are not worth a collective each), keeps the states of that level whose fingerprint it owns as its
+ * local frontier and holds all prefix fingerprints in its seen-set.  levels_out[0 .. *nlevels) = states per level of the
+ * prefix, the last one being the level the sharded rounds continue with (*nlevels in: capacity, out: count).  Only
+ * rank 0 reports the prefix's `generated`; distinct_local excludes what another rank already counts.  max_distinct /
+ * max_levels (0 = none) are the budgets of the WHOLE job: the prefix stops where a single-GPU run would. */
+int mc_shard_begin_replicated(mc_engine *e, uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels,
+                              uint64_t *levels_out, uint32_t *nlevels);
 int mc_shard_level_size(mc_engine *e, uint64_t *frontier_states);  /* local frontier of the current level          */
 int mc_shard_expand(mc_engine *e, uint64_t first, uint64_t count,  /* chunk of the local frontier                  */
                     uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts /* [shard_count] host */);

@@ -304,6 +304,7 @@ extern "C" size_t shim_state_bytes(const mc_spec_desc *d) {
 struct ShimShardBase {
     virtual ~ShimShardBase() {}
     virtual int begin() = 0;
+    virtual int begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) = 0;
     virtual uint64_t level_size() = 0;
     virtual int expand_launch(unsigned slot, uint64_t first, uint64_t count) = 0;
     virtual int expand_finish(unsigned slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
@@ -336,6 +337,7 @@ struct ShimShard : ShimShardBase {
     uint64_t nstates() const { return arena.size() / (size_t)W; }
     int begin() override {
         W = S::words(prm);
+        dup = 0;
         arena.clear(); seen.clear(); generated = 0; verdict = MC_V_OK;
         uint64_t tmp[S::MAX_WORDS];
         for (uint64_t k = 0; k < S::num_init(prm); k++) {
@@ -349,6 +351,71 @@ struct ShimShard : ShimShardBase {
             if (fp && seen.insert(fp).second) arena.insert(arena.end(), tmp, tmp + W);
         }
         lo = 0; hi = nstates();
+        return 0;
+    }
+    // mc_shard_begin_replicated: the same BFS on every rank until a level has >= min_frontier states, then a slice
+    uint64_t dup = 0;
+    int begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) override {
+        W = S::words(prm);
+        arena.clear(); seen.clear(); generated = 0; verdict = MC_V_OK;
+        uint64_t tmp[S::MAX_WORDS];
+        for (uint64_t k = 0; k < S::num_init(prm); k++) {
+            S::init(prm, k, WordRef{tmp, 1});
+            const unsigned st = S::init_status(prm, CWordRef{tmp, 1});
+            generated++;
+            if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
+            if (st & ST_OUT_OF_MODEL) continue;
+            if (seen.insert(S::fp_of(prm, CWordRef{tmp, 1})).second) arena.insert(arena.end(), tmp, tmp + W);
+        }
+        uint64_t l = 0, h = nstates();
+        uint32_t nl = 0;
+        const uint32_t cap = *nlevels;
+        auto push = [&](uint64_t n) { if (nl < cap) levels_out[nl] = n; nl++; };
+        push(h);
+        while (h > l && verdict == MC_V_OK && h - l < (min_frontier ? min_frontier : 1) && !(max_distinct && h >= max_distinct) &&
+               !(max_levels && nl >= max_levels)) {
+            for (uint64_t i = l; i < h; i++) {
+                std::vector<uint64_t> cur(arena.begin() + (long)(i * W), arena.begin() + (long)((i + 1) * W));
+                CWordRef s{cur.data(), 1};
+                typename S::Local loc;
+                S::load(prm, s, loc);
+                const int ns = S::nslots(prm, loc);
+                if (S::parent_status(prm, loc, s) & ST_INVARIANT) verdict = MC_V_INVARIANT;
+                uint64_t nsucc = 0;
+                for (int slot = 0; slot < ns; slot++) {
+                    uint64_t fp = 0;
+                    const unsigned st = S::eval(prm, loc, s, slot, fp);
+                    if (!(st & ST_ENABLED)) continue;
+                    nsucc++; generated++;
+                    if (st & ST_OVERFLOW) return MC_EOVERFLOW;
+                    if (st & ST_ASSERT) { verdict = MC_V_ASSERT; continue; }
+                    if (st & ST_SPECERR) { verdict = MC_V_SPECERR; continue; }
+                    if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
+                    if (st & ST_OUT_OF_MODEL) continue;
+                    if (seen.insert(fp).second) {
+                        S::apply(prm, s, slot, WordRef{tmp, 1});
+                        arena.insert(arena.end(), tmp, tmp + W);
+                    }
+                }
+                if (!nsucc && verdict == MC_V_OK) verdict = MC_V_DEADLOCK;
+            }
+            l = h;
+            h = nstates();
+            if (h > l) push(h - l);
+        }
+        if (nl > cap) return MC_EBADCFG;
+        *nlevels = nl;
+        const uint64_t base = h;
+        if (verdict == MC_V_OK)
+            for (uint64_t i = l; i < h; i++) {  // the states of the level whose fingerprint this rank owns
+                std::vector<uint64_t> cur(arena.begin() + (long)(i * W), arena.begin() + (long)((i + 1) * W));
+                if (nranks > 1 && fp_owner(S::fp_of(prm, CWordRef{cur.data(), 1}), nranks) != rank) continue;
+                arena.insert(arena.end(), cur.begin(), cur.end());
+            }
+        lo = base;
+        hi = nstates();
+        dup = rank == 0 ? hi - base : hi;
+        if (rank != 0) generated = 0;
         return 0;
     }
     uint64_t level_size() override { return hi - lo; }
@@ -448,7 +515,7 @@ struct ShimShard : ShimShardBase {
         return 0;
     }
     uint64_t end_level() override { lo = hi; hi = nstates(); return hi - lo; }
-    void counters(uint64_t *g, uint64_t *d, int32_t *v) override { *g = generated; *d = nstates(); *v = verdict; }
+    void counters(uint64_t *g, uint64_t *d, int32_t *v) override { *g = generated; *d = nstates() - dup; *v = verdict; }
 };
 
 extern "C" {
@@ -464,6 +531,10 @@ void *shim_shard_create(const mc_spec_desc *d, uint32_t rank, uint32_t nranks) {
 }
 void shim_shard_destroy(void *e) { delete (ShimShardBase *)e; }
 int shim_shard_begin(void *e) { return ((ShimShardBase *)e)->begin(); }
+int shim_shard_begin_replicated(void *e, uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out,
+                                uint32_t *nlevels) {
+    return ((ShimShardBase *)e)->begin_replicated(min_frontier, max_distinct, max_levels, levels_out, nlevels);
+}
 int shim_shard_level_size(void *e, uint64_t *n) { *n = ((ShimShardBase *)e)->level_size(); return 0; }
 int shim_shard_expand_launch(void *e, uint32_t slot, uint64_t first, uint64_t count) {
     return ((ShimShardBase *)e)->expand_launch(slot, first, count);

@@ -16,6 +16,8 @@ class ShimStepEngine:
         for name in ("begin", "level_size", "expand_launch", "expand_finish", "probe", "materialise", "ingest", "keep", "end_level", "counters", "destroy"):
             getattr(L, "shim_shard_" + name).restype = C.c_int if name != "destroy" else None
         L.shim_shard_begin.argtypes = [C.c_void_p]
+        L.shim_shard_begin_replicated.restype = C.c_int
+        L.shim_shard_begin_replicated.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.shim_shard_destroy.argtypes = [C.c_void_p]
         L.shim_shard_level_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.shim_shard_expand_launch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]
@@ -40,6 +42,12 @@ class ShimStepEngine:
 
     def begin(self):
         self._ck(self.lib.shim_shard_begin(self.h), "begin")
+
+    def begin_replicated(self, min_frontier, max_distinct=0, max_levels=0):
+        cap = C.c_uint32(4096)
+        levels = (C.c_uint64 * 4096)()
+        self._ck(self.lib.shim_shard_begin_replicated(self.h, min_frontier, max_distinct, max_levels, levels, C.byref(cap)), "begin_replicated")
+        return [int(levels[i]) for i in range(cap.value)]
 
     def level_size(self):
         n = C.c_uint64()

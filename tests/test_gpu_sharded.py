@@ -54,3 +54,14 @@ def test_eight_engines_on_one_gpu(oracle, tmp_path, world):
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert len(r["shares"]) == world and sum(r["shares"]) == o["distinct"]
     assert r["phases"].get("stay_levels", 0) >= 1 and r["phases"].get("move_levels", 0) >= 3
+
+
+@pytest.mark.parametrize("world,until", [(1, 300), (2, 300), (4, 50)])
+def test_replicated_prefix_on_gpu(oracle, tmp_path, world, until):
+    """mc_shard_begin_replicated: the fused single-GPU BFS on every rank for the small levels, then slices"""
+    params = [2, 2, 2, 9, 2, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=40000)
+    r = run_dist("hip", world, "raft", params, tmp_path, {"max_distinct": 40000, "chunk": 1 << 11, "table": 1 << 18, "arena": 1 << 17,
+                                                         "stay_threshold": 60, "rebalance_ratio": 2.0, "replicate_until": until}, timeout=900)
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert sum(r["shares"]) == o["distinct"]

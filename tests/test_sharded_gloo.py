@@ -85,3 +85,24 @@ def test_eight_way_sharding_counts_equal_oracle(oracle, shim, tmp_path, world):
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert len(r["shares"]) == world and sum(r["shares"]) == o["distinct"] and min(r["shares"]) > 0
     assert r["phases"].get("stay_levels", 0) >= 1 and r["phases"].get("move_levels", 0) >= 3
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("until", [5, 200])
+def test_replicated_prefix_then_sharded(oracle, shim, tmp_path, world, until):
+    """every rank runs the small first levels itself, then takes its slice of the first large level"""
+    params = [2, 2, 2, 9, 2, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=40000)
+    r = run_dist("shim", world, "raft", params, tmp_path, {"max_distinct": 40000, "chunk": 700, "stay_threshold": 60, "rebalance_ratio": 2.0,
+                                                           "replicate_until": until})
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert sum(r["shares"]) == o["distinct"] and min(r["shares"]) > 0
+
+
+def test_replicated_prefix_covers_a_whole_small_graph_and_a_violation(oracle, shim, tmp_path):
+    o = oracle.oracle_run("atomic_add", [6])
+    r = run_dist("shim", 2, "atomic_add", [6], tmp_path, {"replicate_until": 1 << 20})
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == (o["distinct"], o["generated"], o["depth"], o["levels"], "ok")
+    r = run_dist("shim", 2, "pcal_intro", [1, 0, 20, 2], tmp_path, {"replicate_until": 1 << 20})
+    o = oracle.oracle_run("pcal_intro", [1, 0, 20, 2])
+    assert r["verdict"] == "assert" and (r["distinct"], r["generated"], r["levels"]) == (o["distinct"], o["generated"], o["levels"])

@@ -89,6 +89,7 @@ def lib():
     L.mc_device_count.restype = C.c_int
     U64P = C.POINTER(C.c_uint64)
     L.mc_shard_begin.argtypes = [C.c_void_p]
+    L.mc_shard_begin_replicated.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, U64P, C.POINTER(C.c_uint32)]
     L.mc_shard_level_size.argtypes = [C.c_void_p, U64P]
     L.mc_shard_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, U64P]
     L.mc_shard_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -218,6 +219,12 @@ class Engine:
     # ---- sharded step API (mc_shard_*): raw device pointers in, counts out
     def shard_begin(self):
         _check(lib().mc_shard_begin(self._h), "mc_shard_begin")
+
+    def shard_begin_replicated(self, min_frontier, max_distinct=0, max_levels=0):
+        cap = C.c_uint32(4096)
+        levels = (C.c_uint64 * 4096)()
+        _check(lib().mc_shard_begin_replicated(self._h, min_frontier, max_distinct, max_levels, levels, C.byref(cap)), "mc_shard_begin_replicated")
+        return [int(levels[i]) for i in range(cap.value)]
 
     def shard_level_size(self):
         n = C.c_uint64()

@@ -885,6 +885,29 @@ static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
     ctr->max_slots = 0;
 }
 
+// replicated prefix -> sharded continuation: rank r keeps the states of the last replicated level whose fingerprint it
+// owns.  (Not "every nranks-th state": the ORDER of a level in the arena differs from rank to rank, its SET does not.)
+template <class S>
+__global__ void __launch_bounds__(256)
+k_take_owned(typename S::Params prm, uint64_t *arena, uint64_t lo, uint64_t hi, unsigned rank, unsigned nranks, uint64_t dst0,
+             uint64_t arena_cap, uint32_t *__restrict__ parent, DevCounters *ctr) {
+    const uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const int W = S::words(prm);
+    const CWordRef in = arena_cref(arena, i, W);
+    if (fp_owner(S::fp_of(prm, in), nranks) != rank) return;
+    const uint64_t dst = dst0 + atomicAdd(&ctr->n_new[0].v, 1ull);
+    if (dst >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); return; }
+    const WordRef out = arena_ref(arena, dst, W);
+    for (int w = 0; w < W; w++) out.set(w, in.get(w));
+    if (parent) parent[dst] = (uint32_t)i;
+}
+static __global__ void k_after_prefix(DevCounters *ctr, unsigned long long dst0, int zero_counts) {
+    ctr->arena_next = dst0 + ctr->n_new[0].v;
+    ctr->n_new[0].v = 0;
+    if (zero_counts) for (int t = 0; t < NSHARD; t++) { ctr->generated[t].v = 0; ctr->cells[t].v = 0; }
+}
+
 // closes a batched level on the device: advances [lo, hi), records the fill level, decides whether the next one may run
 static __global__ void k_end_level(DevCounters *ctr, LevelCtl *lc) {
     if (lc->stop) return;
@@ -914,6 +937,7 @@ struct EngineBase {
     virtual int read_states(uint64_t first, uint64_t count, uint8_t *out) = 0;
     virtual int debug_reexpand(unsigned extra_flags, double *ms) = 0;
     virtual int shard_begin() = 0;
+    virtual int shard_begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) = 0;
     virtual int shard_level_size(uint64_t *n) = 0;
     virtual int shard_set_stream(void *hip_stream, int enable) = 0;
     virtual int shard_expand_launch(unsigned slot, uint64_t first, uint64_t count, uint64_t send_cap) = 0;
@@ -1148,7 +1172,7 @@ struct Engine : EngineBase {
             const uint64_t count = ninit - first < chunk ? ninit - first : chunk;
             const uint64_t ncols = (count + 63) & ~63ull;
             hipLaunchKernelGGL(k_init_cand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, first, count,
-                               d_inittmp, d_cand, ncols, d_nsl, d_ctr, cfg.shard_rank, cfg.shard_count);
+                               d_inittmp, d_cand, ncols, d_nsl, d_ctr, 0u, 1u);  // run() is never owner-filtered
             finish_chunk<true>(first, ncols, 1);
         }
         int rc = read_counters();
@@ -1162,6 +1186,7 @@ struct Engine : EngineBase {
         const uint64_t blind_max = chunk < (1ull << 16) ? chunk : (1ull << 16);
         while (hi > lo) {
             if (h_ctr->viol_key != ~0ull) break;
+            if (stop_frontier && hi - lo >= stop_frontier) break;  // the caller continues this level sharded
             if (cfg.max_levels && level >= cfg.max_levels) { budget = 1; break; }
             if (cfg.max_distinct && hi >= cfg.max_distinct) { budget = 1; break; }
             if (!use_matrix && !(cfg.flags & MC_F_NOBATCH) && hi - lo <= blind_max) {
@@ -1239,6 +1264,8 @@ struct Engine : EngineBase {
         out->queue_left = hi - lo;
         out->depth = level;
         out->levels = level;
+        run_lo = lo;
+        run_hi = hi;
         if (h_ctr->viol_key != ~0ull) {
             have_viol = true;
             last_viol = h_ctr->viol_key;
@@ -1258,6 +1285,7 @@ struct Engine : EngineBase {
         return MC_OK;
     }
     uint64_t kstat_cells = 0;
+    uint64_t stop_frontier = 0, run_lo = 0, run_hi = 0;  // run() stops before a level of >= stop_frontier states (0 = never)
 
     int fetch_state(uint64_t idx, uint64_t *words) {
         const uint64_t *src = d_arena + ((idx >> 6) * (uint64_t)W) * 64 + (idx & 63);
@@ -1423,6 +1451,7 @@ struct Engine : EngineBase {
     }
     int shard_begin() override {
         if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
+        sh_dup = 0;
         HIP_TRY(hipSetDevice(cfg.device));
         memset(kstat, 0, sizeof kstat);
         HIP_TRY(hipMemsetAsync(d_table, 0, table_cap * sizeof(uint64_t), stream));
@@ -1443,6 +1472,44 @@ struct Engine : EngineBase {
         if ((rc = check_dev_error())) return rc;
         sh_lo = 0;
         sh_hi = sh_next = h_ctr->arena_next;
+        last_distinct = sh_next;
+        return MC_OK;
+    }
+    // The first levels of a run are tiny: sharding them costs several collectives per level and balances nothing.
+    // Every rank therefore runs the SAME fused BFS (run()) until a level has at least min_frontier states, keeps every
+    // nranks-th state of that level as its local frontier, and the sharded rounds start there.  The seen-set of each
+    // rank then holds ALL prefix fingerprints (a superset of the ones it owns: harmless); rank 0 alone reports the
+    // prefix's `generated`, and distinct_local excludes what other ranks already count.
+    uint64_t sh_dup = 0;
+    int shard_begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) override {
+        if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
+        static mc_result res;  // large (level table): not on the stack
+        const uint64_t saved_md = cfg.max_distinct, saved_ml = cfg.max_levels;
+        cfg.max_distinct = max_distinct;  // the whole job's budgets: the prefix stops where the single-GPU run would
+        cfg.max_levels = max_levels;
+        stop_frontier = min_frontier ? min_frontier : 1;
+        const int rc = run(&res);
+        stop_frontier = 0;
+        cfg.max_distinct = saved_md;
+        cfg.max_levels = saved_ml;
+        if (rc) return rc;
+        const uint32_t cap = *nlevels;
+        *nlevels = res.levels;
+        for (uint32_t k = 0; k < res.levels && k < cap; k++) levels_out[k] = res.level_distinct[k];
+        if (res.levels > cap) { set_error("shard_begin_replicated: level buffer too small"); return MC_EBADCFG; }
+        const unsigned P = nranks(), r = cfg.shard_rank;
+        const uint64_t lo = run_lo, hi = run_hi;
+        const bool go_on = h_ctr->viol_key == ~0ull && hi > lo;  // otherwise finished or failed inside the prefix
+        if (go_on)
+            hipLaunchKernelGGL(k_take_owned<S>, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, stream, prm, d_arena, lo, hi, r, P, hi,
+                               arena_cap, d_parent, d_ctr);
+        hipLaunchKernelGGL(k_after_prefix, dim3(1), dim3(1), 0, stream, d_ctr, (unsigned long long)hi, r != 0 ? 1 : 0);
+        int rc2 = read_counters();
+        if (rc2) return rc2;
+        if ((rc2 = check_dev_error())) return rc2;
+        sh_lo = hi;
+        sh_hi = sh_next = h_ctr->arena_next;
+        sh_dup = r == 0 ? sh_hi - hi : sh_hi;
         last_distinct = sh_next;
         return MC_OK;
     }
@@ -1655,7 +1722,7 @@ struct Engine : EngineBase {
         if ((rc = check_dev_error())) return rc;
         *generated = 0;
         for (int t = 0; t < NSHARD; t++) *generated += h_ctr->generated[t].v;
-        *distinct_local = h_ctr->arena_next;
+        *distinct_local = h_ctr->arena_next - sh_dup;
         *verdict = MC_V_OK;
         if (h_ctr->viol_key != ~0ull) {
             const unsigned kind = (unsigned)(h_ctr->viol_key & 7u);
@@ -1865,6 +1932,10 @@ void mc_set_error_internal(const char *msg) { g_last_error = msg ? msg : ""; }
 int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms) { return e && ms ? e->impl->debug_reexpand(extra_flags, ms) : MC_EBADCFG; }
 // ---- sharded (multi-GPU) step API
 int mc_shard_begin(mc_engine *e) { return e ? e->impl->shard_begin() : MC_EBADCFG; }
+int mc_shard_begin_replicated(mc_engine *e, uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out,
+                              uint32_t *nlevels) {
+    return e && levels_out && nlevels ? e->impl->shard_begin_replicated(min_frontier, max_distinct, max_levels, levels_out, nlevels) : MC_EBADCFG;
+}
 int mc_shard_level_size(mc_engine *e, uint64_t *n) { return e && n ? e->impl->shard_level_size(n) : MC_EBADCFG; }
 int mc_shard_expand(mc_engine *e, uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) {
     if (!e || !send_counts) return MC_EBADCFG;

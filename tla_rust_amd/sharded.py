@@ -49,6 +49,9 @@ class HipStepEngine:
     def begin(self):
         self.eng.shard_begin()
 
+    def begin_replicated(self, min_frontier, max_distinct=0, max_levels=0):
+        return self.eng.shard_begin_replicated(min_frontier, max_distinct, max_levels)
+
     def level_size(self):
         return self.eng.shard_level_size()
 
@@ -86,7 +89,7 @@ class HipStepEngine:
 class ShardedChecker:
     def __init__(self, spec, params, device=0, chunk_states=1 << 19, max_distinct=0, max_levels=0, table_capacity=1 << 27,
                  arena_capacity=1 << 25, fanout_cap=32, new_cap=8, engine=None, group=None, stay_threshold=1 << 16,
-                 rebalance_ratio=1.25):
+                 rebalance_ratio=1.25, replicate_until=1 << 15):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -99,6 +102,10 @@ class ShardedChecker:
         # single initial state over the ranks) and whenever the ranks' frontiers drift apart; otherwise they
         # STAY where they were generated and only fingerprints (8 B) and answers (1 B) cross xGMI.
         self.stay_threshold, self.rebalance_ratio = stay_threshold, rebalance_ratio
+        # The first levels are tiny: every rank runs them itself (same fused BFS everywhere, no collective) until a
+        # level has replicate_until states per rank, then keeps the states of it whose fingerprint it owns; 0 = shard
+        # from Init on.
+        self.replicate_until = replicate_until
         self.eng = engine if engine is not None else HipStepEngine(spec, params, device, self.rank, self.world, chunk_states,
                                                                     table_capacity, arena_capacity)
         self.dev = self.eng.device
@@ -179,10 +186,17 @@ class ShardedChecker:
             ph[key] = ph.get(key, 0.0) + now - t_prev
             return now
 
-        e.begin()
-        sizes, verdict = self._level_info(e.level_size(), e.counters()[2])
-        frontier = sum(sizes)
-        levels, cum, level, budget = [frontier], frontier, 1, False
+        if self.replicate_until:
+            levels = e.begin_replicated(self.replicate_until * self.world, self.max_distinct, self.max_levels)
+            sizes, verdict = self._level_info(e.level_size(), e.counters()[2])
+            frontier = sum(sizes) if verdict == 0 else levels[-1]
+            cum, level, budget = sum(levels), len(levels), False
+            ph["replicated_levels"] = len(levels)
+        else:
+            e.begin()
+            sizes, verdict = self._level_info(e.level_size(), e.counters()[2])
+            frontier = sum(sizes)
+            levels, cum, level, budget = [frontier], frontier, 1, False
         while frontier > 0:
             if verdict != 0:
                 break
