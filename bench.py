@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-distinct", type=int, default=WORKLOAD["max_distinct"])
     ap.add_argument("--chunk", type=int, default=1 << 22)
-    ap.add_argument("--shard-chunk", type=int, default=1 << 20, help="frontier states per round and rank in the sharded (torchrun) path")
+    ap.add_argument("--shard-chunk", type=int, default=1 << 21, help="frontier states per round and rank in the sharded (torchrun) path")
     ap.add_argument("--table-log2", type=int, default=28)
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
