@@ -118,7 +118,8 @@ def main():
                    "verdict": res.verdict, "generated_per_s": G * a.steps / dt},
     }
     if use_dist:
-        line["config"]["parallelism"] = f"fingerprint-sharded seen-set x{world}, two-phase all-to-all over RCCL"
+        line["config"]["parallelism"] = (f"fingerprint-sharded seen-set x{world}, replicated prefix for the small levels, "
+                                         f"pipelined two-phase all-to-all over RCCL")
         dist.destroy_process_group()
     else:
         ks = eng.kernel_stats()
