@@ -386,21 +386,26 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         qn -= take;
         probes += take;
         if constexpr (ROUTE) {
+            // one round trip for all owners: lane t reserves the bucket space of owner t (the P atomics issue together
+            // instead of one after the other), then every candidate takes its owner's base from that lane
             const unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
+            unsigned my_rank = 0, my_cnt = 0;
             for (unsigned t = 0; t < rt.nranks; ++t) {
                 const unsigned long long b = __ballot(owner == t);
-                if (!b) continue;
-                const unsigned bucket = t * NSHARD + shard;
-                unsigned long long pos = 0;
-                if (lane == 0) pos = atomicAdd(&rt.cursors[bucket].v, (unsigned long long)__popcll(b));
-                pos = __shfl(pos, 0) + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
-                if (owner == t) {
-                    if (pos < rt.subcap) {
-                        rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
-                        rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = src;
-                    } else {
-                        err |= DEV_EARENA;
-                    }
+                if (owner == t) my_rank = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+                if (lane == t) my_cnt = (unsigned)__popcll(b);
+            }
+            unsigned long long base = 0;
+            if (lane < rt.nranks && my_cnt) base = atomicAdd(&rt.cursors[lane * NSHARD + shard].v, (unsigned long long)my_cnt);
+            base = __shfl(base, (int)(owner < rt.nranks ? owner : 0u));
+            if (owner < rt.nranks) {
+                const unsigned bucket = owner * NSHARD + shard;
+                const unsigned long long pos = base + my_rank;
+                if (pos < rt.subcap) {
+                    rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
+                    rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = src;
+                } else {
+                    err |= DEV_EARENA;
                 }
             }
         } else {
@@ -565,21 +570,26 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         qn -= take;
         probes += take;
         if constexpr (ROUTE) {
+            // one round trip for all owners: lane t reserves the bucket space of owner t (the P atomics issue together
+            // instead of one after the other), then every candidate takes its owner's base from that lane
             const unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
+            unsigned my_rank = 0, my_cnt = 0;
             for (unsigned t = 0; t < rt.nranks; ++t) {
                 const unsigned long long b = __ballot(owner == t);
-                if (!b) continue;
-                const unsigned bucket = t * NSHARD + shard;
-                unsigned long long pos = 0;
-                if (lane == 0) pos = atomicAdd(&rt.cursors[bucket].v, (unsigned long long)__popcll(b));
-                pos = __shfl(pos, 0) + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
-                if (owner == t) {
-                    if (pos < rt.subcap) {
-                        rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
-                        rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = src;
-                    } else {
-                        err |= DEV_EARENA;
-                    }
+                if (owner == t) my_rank = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+                if (lane == t) my_cnt = (unsigned)__popcll(b);
+            }
+            unsigned long long base = 0;
+            if (lane < rt.nranks && my_cnt) base = atomicAdd(&rt.cursors[lane * NSHARD + shard].v, (unsigned long long)my_cnt);
+            base = __shfl(base, (int)(owner < rt.nranks ? owner : 0u));
+            if (owner < rt.nranks) {
+                const unsigned bucket = owner * NSHARD + shard;
+                const unsigned long long pos = base + my_rank;
+                if (pos < rt.subcap) {
+                    rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
+                    rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = src;
+                } else {
+                    err |= DEV_EARENA;
                 }
             }
         } else {
