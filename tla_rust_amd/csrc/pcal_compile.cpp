@@ -577,6 +577,30 @@ struct Compiler {
         return elems.size();
     }
 
+    // `x \\in a..b` with state-dependent bounds: any of a .. a+31 that is <= b (a longer interval is reported as an
+    // overflow, never cut short).  Leaves the chosen value on the stack; 32 alternatives.
+    bool dynamic_interval(const EP &e) {
+        if (!(e->k == Expr::BINOP && e->s == "..")) return false;
+        long long a, b;
+        return !(const_scalar(e->a[0], a) && const_scalar(e->a[1], b));
+    }
+    unsigned long long choose_interval(const EP &e, Pos p) {
+        const int tl = new_temp(p), th = new_temp(p), tx = new_temp(p);
+        ex(e->a[0]); emit(mc::VM_STORET, tl);
+        ex(e->a[1]); emit(mc::VM_STORET, th);
+        // more than 32 values: refuse (VM_BIT on the width - 1 overflows exactly then; an empty interval passes)
+        emit(mc::VM_LOADT, th); emit(mc::VM_LOADT, tl); emit(mc::VM_GE);
+        const int jempty = emit_jump(mc::VM_JZ);
+        emit(mc::VM_LOADT, th); emit(mc::VM_LOADT, tl); emit(mc::VM_SUB); emit(mc::VM_BIT); emit(mc::VM_POP);
+        patch(jempty);
+        emit(mc::VM_CHOOSE, 32);
+        emit(mc::VM_LOADT, tl); emit(mc::VM_ADD); emit(mc::VM_STORET, tx);
+        emit(mc::VM_LOADT, tx); emit(mc::VM_LOADT, th); emit(mc::VM_LE); emit(mc::VM_AWAIT);
+        emit(mc::VM_LOADT, tx);
+        next_temp -= 3;
+        return 32;
+    }
+
     // ---- statements
     void assign(const SP &s) {
         if (!s->more.empty()) {  // a := e || b := f: evaluate every right-hand side (and index) first
@@ -707,8 +731,16 @@ struct Compiler {
                 next_temp--;
                 return 32 * b;
             }
-            // (a state-dependent interval such as 1..Len(q) has no static bound: evaluated as a boolean below, i.e.
-            // ONE successor where TLC would generate one per witness — same states, smaller `generated`)
+            if (dynamic_interval(e->a[0])) {  // e.g. 1..Len(q): one successor per witness among the first 32 values
+                const int t = new_temp(e->pos);
+                const unsigned long long n = choose_interval(e->a[0], e->pos);
+                emit(mc::VM_STORET, t);
+                binds.push_back({e->bound, t, false, 0});
+                const unsigned long long b = await_action(e->a[1]);
+                binds.pop_back();
+                next_temp--;
+                return n * b;
+            }
             if (const_set(e->a[0], elems) && !elems.empty()) {  // one successor per witness
                 const int t = new_temp(e->pos);
                 const unsigned long long n = choose_from(e->a[0], e->pos);
@@ -774,7 +806,8 @@ struct Compiler {
                 emit(mc::VM_LOADT, t); emit(mc::VM_BIT); ex_set(s->e); emit(mc::VM_AND); emit(mc::VM_AWAIT);
                 emit(mc::VM_LOADT, t);
                 n = 32;
-            } else n = choose_from(s->e, s->pos);
+            } else if (dynamic_interval(s->e)) n = choose_interval(s->e, s->pos);
+            else n = choose_from(s->e, s->pos);
             emit(mc::VM_STORET, t);
             binds.push_back({s->var, t, false, 0});
             const unsigned long long b = block(s->blocks[0]);
