@@ -216,3 +216,15 @@ def test_random_algorithms_on_gpu(amd):
         prog.close()
         checked += 1
     assert checked >= 25
+
+
+def test_wide_state_on_gpu(amd):
+    """72 scalar cells (the 128-cell interpreter instantiation): 70 adders, level-budgeted, against the closed form"""
+    from math import comb
+    prog = amd.Program((ROOT / "specs" / "atomic_add_n.tla").read_text(), "CONSTANT N = 70\n")
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 22, arena_capacity=1_100_000, chunk_states=1 << 16, max_distinct=100_000, trace=False)
+    r = eng.run()
+    assert r.levels == [comb(70, k) for k in range(5)] and r.verdict == "budget"
+    assert r.generated == 1 + sum(comb(70, k) * (70 - k) for k in range(4))
+    eng.close()
+    prog.close()

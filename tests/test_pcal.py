@@ -187,3 +187,19 @@ def test_either_with_while_goto_translation_shape():
     assert "/\\ IF done[self] < N" in tla                                     # while = IF on the loop label
     tla = helpers.pcal_translate(strip_translation((SPECS / "pluscal" / "euclid.tla").read_text()))
     assert "/\\ pc = \"Loop\"" in tla and "(pc = \"Done\" /\\ UNCHANGED vars)" in tla   # uniprocess
+
+
+def test_wide_state_128_cells():
+    """more than 64 scalar cells: atomic_add_n with 70 adders (72 cells) — the 128-cell instantiation of the interpreter"""
+    text = (SPECS / "atomic_add_n.tla").read_text()
+    prog = helpers.ShimProgram(text, [], {"N": 70})
+    fd, dump = tempfile.mkstemp()
+    os.close(fd)
+    r = helpers.shim_run("pcal", prog.params, max_distinct=2000, dump=dump)
+    o = Checker(prog.translated(), constants={"N": 70}).run_levels(max_distinct=2000)
+    assert r["levels"] == o["levels"] == [1, 70, 2415]
+    assert (r["distinct"], r["generated"]) == (o["distinct"], o["generated"])
+    states = helpers.read_dump(dump)
+    os.unlink(dump)
+    assert [states[l + 1] for l in range(3)] == o["states"]
+    prog.close()

@@ -1832,7 +1832,8 @@ int mc_make_engine_6(const mc_spec_desc *d, const mc_config *c, mc::EngineBase *
     }
     p.code = d_code;  // host-side helpers (format, action_of) use p.host only
     const int rc = p.nv <= 16 ? mc::make_engine<mc::SpecVm16>(p, d, c, out)
-                 : p.nv <= 32 ? mc::make_engine<mc::SpecVm32>(p, d, c, out) : mc::make_engine<mc::SpecVm>(p, d, c, out);
+                 : p.nv <= 32 ? mc::make_engine<mc::SpecVm32>(p, d, c, out)
+                 : p.nv <= 64 ? mc::make_engine<mc::SpecVm64>(p, d, c, out) : mc::make_engine<mc::SpecVm>(p, d, c, out);
     if (rc) hipFree(d_code);
     else (*out)->owned_device_blob = d_code;
     return rc;

@@ -51,6 +51,7 @@ int dispatch_spec(const mc_spec_desc *d, F &&f) {
         if (vm_make_params(d->params, d->nparams, p)) return MC_EBADCFG;
         if (p.nv <= 16) return f(SpecVm16{}, p);
         if (p.nv <= 32) return f(SpecVm32{}, p);
+        if (p.nv <= 64) return f(SpecVm64{}, p);
         return f(SpecVm{}, p);
     }
     default: return MC_EBADCFG;

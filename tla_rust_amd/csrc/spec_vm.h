@@ -51,7 +51,7 @@ struct VmParams {
 int vm_make_params(const int64_t *p, unsigned np, VmParams &o);  // pcal_compile.cpp (host)
 
 // MAXV = capacity of the per-lane variable arrays.  The interpreter indexes them dynamically, so they live in
-// scratch (private) memory; three instantiations (16 / 32 / 64 cells) keep small programs under the scratch size
+// scratch (private) memory; four instantiations (16 / 32 / 64 / 128 cells) keep small programs under the scratch size
 // above which the runtime allocates scratch per dispatch (528 B/lane at 64 cells made every launch ~150 us).
 template <int MAXV>
 struct SpecVmT {
@@ -329,8 +329,9 @@ struct SpecVmT {
         return vm_format(p.host, v, buf, cap);
     }
 };
-using SpecVm = SpecVmT<64>;    // host-side helpers and the widest instantiation
+using SpecVm = SpecVmT<128>;   // host-side helpers and the widest instantiation
 using SpecVm16 = SpecVmT<16>;
 using SpecVm32 = SpecVmT<32>;
+using SpecVm64 = SpecVmT<64>;
 
 }  // namespace mc
