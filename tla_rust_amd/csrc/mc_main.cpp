@@ -70,11 +70,16 @@ int main(int argc, char **argv) {
         else if (arg("-tablelog2")) cfg.table_capacity = 1ull << atoi(argv[++i]);
         else if (arg("-arena")) cfg.arena_capacity = strtoull(argv[++i], 0, 10);
         else if (arg("-chunk")) cfg.chunk_states = strtoull(argv[++i], 0, 10);
+        else if (!strcmp(argv[i], "-help") || !strcmp(argv[i], "--help") || !strcmp(argv[i], "-h")) { tla = nullptr; break; }
         else if (argv[i][0] != '-') tla = argv[i];
         else { fprintf(stderr, "mc: unknown option %s\n", argv[i]); return 1; }
     }
     if (!tla) {
-        fprintf(stderr, "usage: mc X.tla [-config X.cfg] [-deadlock] [-device D] [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N]\n");
+        fprintf(stderr,
+                "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-device D]\n"
+                "                [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]     check X.tla like `tlc X.tla`\n"
+                "       mc --transpile X.tla [Y.tla ...]                                                  translate like `pcal2tla`\n"
+                "exit status: 0 no error, 12 invariant / assertion violated, 11 deadlock, 1 anything else\n");
         return 1;
     }
     std::vector<char> report(1 << 22);
