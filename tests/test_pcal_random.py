@@ -31,7 +31,8 @@ class Gen:
 
     def expr(self, local):
         r = self.r
-        atoms = ["x", "y", "a[1]", "a[2]", "self", str(r.randrange(K)), "Len(q)", "Cardinality(s)"] + (["t"] if local else [])
+        atoms = ["x", "y", "a[1]", "a[2]", "self", str(r.randrange(K)), "Len(q)", "Cardinality(s)", "Sum", "Bump(x)",
+                 "Mix(y, a[1])"] + (["t"] if local else [])
         e = r.choice(atoms)
         if r.random() < 0.5:
             e = f"({e} + {r.choice(atoms)}) % {K}"
@@ -71,6 +72,8 @@ class Gen:
             idx = {"a1": "1", "a2": "2", "as": "self"}[v]
             return f"{ind}a[{idx}] := {self.expr(local)};"
         free.discard(v)
+        if v in ("x", "y") and r.random() < 0.15:
+            return f"{ind}bump({v});"                     # macro call: v := Bump(v)
         if v in ("x", "y") and r.random() < 0.2:
             other = "y" if v == "x" else "x"
             if other in free:
@@ -180,7 +183,9 @@ class Gen:
         if r.random() < 0.5:
             body = self.process_body(False).replace("self", "0")
             procs.append("process Q = 0\nbegin\n" + body + "\nend process")
-        alg = (f"variables x = 0, y \\in 0..1, a = [i \\in 0..2 |-> i % {K}], q = <<>>, s = {{}};\n\n" + "\n\n".join(procs))
+        alg = (f"variables x = 0, y \\in 0..1, a = [i \\in 0..2 |-> i % {K}], q = <<>>, s = {{}};\n"
+               f"define\n  Sum == (x + y) % {K}\n  Bump(v) == (v + 1) % {K}\n  Mix(u, v) == IF u < v THEN Bump(u) ELSE v\nend define;\n"
+               f"macro bump(v) begin v := Bump(v); end macro;\n\n" + "\n\n".join(procs))
         return (f"---- MODULE {name} ----\nEXTENDS Naturals, Sequences, FiniteSets, TLC\n\n(* --algorithm {name}\n{alg}\n\nend algorithm *)\n\n"
                 f"Small == x < {K} /\\ y < {K} /\\ (\\A i \\in 0..2 : a[i] < {K}) /\\ Len(q) <= 2 /\\ (\\A e \\in s : e < {K})\n====\n")
 

@@ -65,7 +65,10 @@ struct Compiler {
     }
     // conservative bound of the interpreter's stack depth (branches are tracked linearly: never an underestimate)
     int depth = 0, max_depth = 0;
+    bool fallthrough = true;          // false right after JMP / HALT / FAIL: the next code is reached through a jump only
+    std::map<int, int> jump_depth;    // operand slot of a jump -> stack depth at its target
     void track(int op) {
+        fallthrough = !(op == mc::VM_JMP || op == mc::VM_HALT || op == mc::VM_FAIL);
         switch (op) {
         case mc::VM_PUSH: case mc::VM_SELF: case mc::VM_LOAD: case mc::VM_LOADT: case mc::VM_CHOOSE: depth++; break;
         case mc::VM_STORE: case mc::VM_STORET: case mc::VM_AWAIT: case mc::VM_ASSERT: case mc::VM_JZ: case mc::VM_JNZ: case mc::VM_POP:
@@ -80,8 +83,20 @@ struct Compiler {
     }
     void emit(int op) { c.push_back(op); track(op); }
     void emit(int op, int a) { c.push_back(op); c.push_back(a); track(op); }
-    int emit_jump(int op) { c.push_back(op); c.push_back(-1); track(op); return (int)c.size() - 1; }
-    void patch(int at) { c[(size_t)at] = (int)c.size(); }
+    int emit_jump(int op) {
+        c.push_back(op);
+        c.push_back(-1);
+        track(op);
+        jump_depth[(int)c.size() - 1] = depth;
+        return (int)c.size() - 1;
+    }
+    void patch(int at) {  // the code that follows is a jump target: its depth is the jump's (and the fall-through's, if any)
+        c[(size_t)at] = (int)c.size();
+        const int d = jump_depth.count(at) ? jump_depth[at] : depth;
+        depth = fallthrough ? std::max(depth, d) : d;
+        fallthrough = true;
+        if (depth > max_depth) max_depth = depth;
+    }
     int new_temp(Pos p) {
         if (next_temp >= mc::SpecVm::TEMPS) cfail("expression too deeply nested (temporaries exhausted)", p);
         return next_temp++;
@@ -345,7 +360,9 @@ struct Compiler {
                     binds.clear();
                     const Proc *sp = proc;
                     proc = nullptr;
+                    emit(mc::VM_OLD_ON);   // a defined operator speaks about the unprimed variables
                     ex(d.body);
+                    emit(mc::VM_OLD_OFF);
                     proc = sp;
                     binds = saved;
                     inline_depth--;
@@ -380,7 +397,9 @@ struct Compiler {
             binds = inner;
             const Proc *sp = proc;
             proc = nullptr;
+            emit(mc::VM_OLD_ON);   // the arguments were evaluated in the caller's context; the body reads unprimed variables
             ex(def->body);
+            emit(mc::VM_OLD_OFF);
             proc = sp;
             binds = saved;
             next_temp = temp0;
@@ -1216,7 +1235,7 @@ int vm_failed_assert(const void *host, const int32_t *vals, int *label) {
         int32_t v[SpecVm::MAX_VARS], res;
         for (int i = 0; i < P.nv; i++) v[i] = vals[i];
         int aux = 0;
-        const int r = SpecVm::run(prm, prm.code[prm.label_tab + lab], prm.code[prm.self_tab + inst], inst, (uint64_t)(slot % P.maxch), v, res, aux);
+        const int r = SpecVm::run(prm, prm.code[prm.label_tab + lab], prm.code[prm.self_tab + inst], inst, (uint64_t)(slot % P.maxch), v, res, aux, vals);
         if (r == SpecVm::R_ASSERT) { if (label) *label = lab; return aux; }
     }
     return -1;

@@ -24,7 +24,9 @@ enum VmOp : int32_t {
     // bounded sequences: cell `base` holds Len, cells base+1 .. base+cap the elements (unused cells are 0)
     VM_LOADSEQ, VM_STORESEQ, VM_APPEND, VM_TAIL, VM_SEQCLR, VM_SEQCOPY,
     // sets of small naturals (0..31) as 32-bit masks
-    VM_BIT, VM_OR, VM_AND, VM_ANDN, VM_POPCNT
+    VM_BIT, VM_OR, VM_AND, VM_ANDN, VM_POPCNT,
+    // inside a defined operator the variables are the UNPRIMED ones: reads come from the state before the step
+    VM_OLD_ON, VM_OLD_OFF
 };
 
 // header words of the program image
@@ -58,7 +60,7 @@ struct SpecVmT {
     using Params = VmParams;
     static constexpr bool IS_VM = true;
     static constexpr int MAX_VARS = MAXV, MAX_WORDS = MAX_VARS / 2, FIX_SLOTS = 0, STAGE_WORDS = 0;
-    static constexpr int STACK = 12, TEMPS = 8;  // pcal_compile.cpp checks both bounds when it emits code
+    static constexpr int STACK = 16, TEMPS = 8;  // pcal_compile.cpp checks both bounds when it emits code
     MC_HD static int words(const Params &p) { return p.words; }
     MC_HD static int max_slots(const Params &p) { return p.ninst * p.maxch + 1; }
     struct Local { int32_t v[MAX_VARS]; };
@@ -71,15 +73,18 @@ struct SpecVmT {
     // is returned through `result` (invariants); `aux` = assertion id on R_ASSERT
     // A path that ends early (failed assert, evaluation error) has not consumed all of its choice index: only the
     // index whose unconsumed remainder is 0 reports it, the others would enumerate the same path again.
-    MC_HD static int run(const Params &p, int entry, int32_t self, int inst, uint64_t ch, int32_t *v, int32_t &result, int &aux) {
+    MC_HD static int run(const Params &p, int entry, int32_t self, int inst, uint64_t ch, int32_t *v, int32_t &result, int &aux,
+                         const int32_t *old = nullptr) {
         uint64_t rest = ch;
-        const int r = run_raw(p, entry, self, inst, rest, v, result, aux);
+        const int r = run_raw(p, entry, self, inst, rest, v, result, aux, old ? old : v);
         return (r == R_ASSERT || r == R_ERROR || r == R_OVERFLOW) && rest != 0 ? (int)R_DISABLED : r;
     }
-    MC_HD static int run_raw(const Params &p, int entry, int32_t self, int inst, uint64_t &ch, int32_t *v, int32_t &result, int &aux) {
+    MC_HD static int run_raw(const Params &p, int entry, int32_t self, int inst, uint64_t &ch, int32_t *v, int32_t &result, int &aux,
+                             const int32_t *old) {
         const int32_t *__restrict__ c = p.code;
         int32_t st[STACK], t[TEMPS];
-        int sp = 0, pc = entry;
+        int sp = 0, pc = entry, old_depth = 0;
+        const int32_t *rd = v;  // where variable READS come from: v, or `old` inside a defined operator
         result = 0;
         aux = 0;
         for (int steps = 0; steps < 100000; ++steps) {
@@ -90,13 +95,15 @@ struct SpecVmT {
                 return ch == 0 ? R_OK : R_DISABLED;  // an unconsumed choice index would enumerate a path twice
             case VM_PUSH: if (sp >= STACK) return R_ERROR; st[sp++] = c[pc++]; break;
             case VM_SELF: if (sp >= STACK) return R_ERROR; st[sp++] = self; break;
-            case VM_LOAD: if (sp >= STACK) return R_ERROR; st[sp++] = v[c[pc++]]; break;
+            case VM_LOAD: if (sp >= STACK) return R_ERROR; st[sp++] = rd[c[pc++]]; break;
+            case VM_OLD_ON: if (++old_depth == 1) rd = old; break;
+            case VM_OLD_OFF: if (--old_depth == 0) rd = v; break;
             case VM_LOADX: {  // base, lo, n : index on the stack
                 const int32_t base = c[pc], lo = c[pc + 1], n = c[pc + 2];
                 pc += 3;
                 const int32_t i = st[sp - 1] - lo;
                 if (i < 0 || i >= n) return R_ERROR;  // TLC: function applied outside its domain
-                st[sp - 1] = v[base + i];
+                st[sp - 1] = rd[base + i];
                 break;
             }
             case VM_STORE: v[c[pc++]] = st[--sp]; break;
@@ -157,8 +164,8 @@ struct SpecVmT {
                 const int32_t base = c[pc], cap = c[pc + 1];
                 pc += 2;
                 const int32_t i = st[sp - 1];
-                if (i < 1 || i > v[base] || i > cap) return R_ERROR;  // TLC: index outside 1..Len(q), Head(<<>>)
-                st[sp - 1] = v[base + i];
+                if (i < 1 || i > rd[base] || i > cap) return R_ERROR;  // TLC: index outside 1..Len(q), Head(<<>>)
+                st[sp - 1] = rd[base + i];
                 break;
             }
             case VM_STORESEQ: {  // base, cap : value on top, index below
@@ -294,7 +301,7 @@ struct SpecVmT {
         if (label == p.done) return 0;
         int32_t res;
         int aux;
-        const int r = run(p, p.code[p.label_tab + label], p.code[p.self_tab + inst], inst, ch, v, res, aux);
+        const int r = run(p, p.code[p.label_tab + label], p.code[p.self_tab + inst], inst, ch, v, res, aux, cur);
         if (r == R_DISABLED) return 0;
         if (r == R_ASSERT) return ST_ENABLED | ST_ASSERT;
         if (r == R_ERROR) return ST_ENABLED | ST_SPECERR;
