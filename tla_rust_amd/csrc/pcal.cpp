@@ -890,6 +890,19 @@ std::string pe(const EP &e, const Ctx &c, const std::set<std::string> &primed, c
     return e->paren ? "(" + s + ")" : s;
 }
 
+// the right-hand side of `v' = e` (or of an EXCEPT `= e`): an operator that binds no tighter than `=` needs parentheses,
+// or `f' = a \\/ b` would read as `(f' = a) \\/ b`
+std::string pe_rhs(const EP &e, const Ctx &c, const std::set<std::string> &primed, const std::set<std::string> &shadow) {
+    const std::string s = pe(e, c, primed, shadow);
+    if (e->paren) return s;
+    bool loose = e->k == Expr::QUANT;
+    if (e->k == Expr::BINOP) {
+        static const char *ops[] = {"=>", "\\/", "/\\", "=", "#", "<", ">", "<=", ">=", "\\in", "\\notin", "\\subseteq"};
+        for (const char *o : ops) loose |= e->s == o;
+    }
+    return loose ? "(" + s + ")" : s;
+}
+
 // formula tree of one action, rendered with the translator's column conventions
 struct Node;
 using NP = std::shared_ptr<Node>;
@@ -994,7 +1007,7 @@ struct ActionGen {
             if (!known) throw TranslateError{"assignment to undeclared variable " + s->var + " at line " + std::to_string(s->pos.line)};
             if (primed.count(s->var))
                 throw TranslateError{"second assignment to " + s->var + " in one step (line " + std::to_string(s->pos.line) + "): a label is needed between them"};
-            const std::string rhs = pe(s->e, c, primed, shadow);
+            const std::string rhs = pe_rhs(s->e, c, primed, shadow);
             const bool local_fn = c.locals.count(s->var) && c.proc && c.proc->is_set;
             std::string t;
             if (!s->idx && !local_fn) t = s->var + "' = " + rhs;
