@@ -12,7 +12,9 @@
  * (T1 < T2 < ...): Commit's AbortOpSeq (:465-474).  The other CHOOSEs of the spec are over
  * singletons (:574 readVerSet, :790 holder, :851 path).
  *
- * params: {nTxn, nKey, invariant mask, find, textbook}
+ * params: {nTxn, nKey, invariant mask, find, textbook, sym}
+ *   sym (cfg SYMMETRY; :38-44 make Key and TxnId symmetry sets): bit 0 = Permutations(TxnId), bit 1 = Permutations(Key);
+ *     brute-force canonicalisation, see s_canonical
  *   textbook = 1 selects examples/textbookSnapshotIsolation.tla: the same model WITHOUT Cahill's three variables
  *     (its allvars :115): Commit never aborts the pivot (:325-355), Read (:365-378) and HelperWriteCanAcquireXLock
  *     (:383-386) do no conflict bookkeeping.  Its serializability invariants are then EXPECTED to fail (write skew).
@@ -52,7 +54,7 @@ typedef struct {
     uint8_t siread[ST];       /* holdingSIREADlocks[t]: bit k       */
 } SState;
 
-typedef struct { int nt, nk, inv_mask, find, textbook; } ssi_ctx;  /* textbook = 1: examples/textbookSnapshotIsolation.tla */
+typedef struct { int nt, nk, inv_mask, find, textbook, sym; } ssi_ctx;  /* textbook = 1: examples/textbookSnapshotIsolation.tla */
 
 static size_t s_ser(const ssi_ctx *c, const SState *s, uint8_t *out) {
     uint8_t *p = out;
@@ -139,9 +141,63 @@ static void internal_abort(SState *s, int txn, int reason) {
     s->xlocks[txn] = 0; s->waiting[txn] = NOLOCK; s->inC[txn] = 0; s->outC[txn] = 0; s->siread[txn] = 0;
 }
 
+/* SYMMETRY.  The spec's run-book declares Key and TxnId "symmetry sets" (serializableSnapshotIsolation.tla:38-44,
+ * p-manual section 4.7.3 p.41): states that differ by a permutation of the model values are one state.  The oracle does
+ * it by BRUTE FORCE: apply every permutation of TxnId (sym & 1) x every permutation of Key (sym & 2) to the
+ * successor, serialise each image, keep the lexicographically smallest byte string; that representative is what
+ * is stored and later expanded (so the CHOOSE order of Commit's AbortOpSeq :465-474 is the ascending order of the
+ * representative's labels). */
+static void s_permute(const ssi_ctx *c, const SState *s, const int *pt, const int *pk, SState *o) {
+    memset(o, 0, sizeof *o);
+    o->n = s->n;
+    for (int i = 0; i < s->n; i++) {
+        Event e = s->h[i];
+        e.txn = (uint8_t)pt[e.txn];
+        if (e.op == OP_READ || e.op == OP_WRITE) e.key = (uint8_t)pk[e.key];
+        if (e.op == OP_READ) e.ver = (uint8_t)pt[e.ver];
+        o->h[i] = e;
+    }
+    for (int t = 0; t < c->nt; t++) {
+        unsigned xl = 0, sr = 0;
+        for (int k = 0; k < c->nk; k++) {
+            if (s->xlocks[t] >> k & 1) xl |= 1u << pk[k];
+            if (s->siread[t] >> k & 1) sr |= 1u << pk[k];
+        }
+        const int u = pt[t];
+        o->xlocks[u] = (uint8_t)xl; o->siread[u] = (uint8_t)sr;
+        o->waiting[u] = s->waiting[t] == NOLOCK ? NOLOCK : (uint8_t)pk[s->waiting[t]];
+        o->inC[u] = s->inC[t]; o->outC[u] = s->outC[t];
+    }
+}
+static int next_perm(int *a, int n) {   /* lexicographic successor; 0 when a was the last one */
+    int i = n - 2;
+    while (i >= 0 && a[i] > a[i + 1]) i--;
+    if (i < 0) return 0;
+    int j = n - 1;
+    while (a[j] < a[i]) j--;
+    int x = a[i]; a[i] = a[j]; a[j] = x;
+    for (int l = i + 1, r = n - 1; l < r; l++, r--) { x = a[l]; a[l] = a[r]; a[r] = x; }
+    return 1;
+}
+static size_t s_canonical(const ssi_ctx *c, const SState *t, uint8_t *best) {
+    uint8_t cand[512];
+    size_t blen = s_ser(c, t, best);   /* the identity image */
+    int pt[ST] = {0, 1, 2, 3};
+    do {
+        int pk[SK] = {0, 1, 2};
+        do {
+            SState img;
+            s_permute(c, t, pt, pk, &img);
+            size_t len = s_ser(c, &img, cand);
+            if (memcmp(cand, best, len < blen ? len : blen) < 0) { memcpy(best, cand, len); blen = len; }  /* equal lengths: same n, nt */
+        } while ((c->sym & 2) && next_perm(pk, c->nk));
+    } while ((c->sym & 1) && next_perm(pt, c->nt));
+    return blen;
+}
+
 typedef struct { const ssi_ctx *c; or_emit *em; uint8_t buf[512]; } sgen;
 static void s_emit(sgen *g, const SState *t, int action) {
-    size_t len = s_ser(g->c, t, g->buf);
+    size_t len = g->c->sym ? s_canonical(g->c, t, g->buf) : s_ser(g->c, t, g->buf);
     g->em->emit(g->em, g->buf, len, action, 0);
 }
 
@@ -509,7 +565,7 @@ int oracle_ssi_unit_tests(void) {
         {3, {{OP_BEGIN, 0, 0, 0, 0}, {OP_ABORT, 0, 0, 0, R_VOLUNTARY}, {OP_WRITE, 0, 0, 0, 0}}, 0},
         {3, {{OP_BEGIN, 0, 0, 0, 0}, {OP_WRITE, 0, 0, 0, 0}, {OP_WRITE, 0, 0, 0, 0}}, 0},
         {3, {{OP_BEGIN, 0, 0, 0, 0}, {OP_READ, 0, 0, 1, 0}, {OP_READ, 0, 0, 1, 0}}, 0}};
-    ssi_ctx c = {2, 2, 127, 0, 0};
+    ssi_ctx c = {2, 2, 127, 0, 0, 0};
     for (int k = 0; k < 10; k++) {
         SState s;
         memset(&s, 0, sizeof s);
@@ -529,7 +585,7 @@ int oracle_ssi_unit_tests(void) {
             {OP_BEGIN, 1, 0, 0, 0}, {OP_WRITE, 1, 1, 0, 0}, {OP_WRITE, 1, 1, 0, 0}, {OP_COMMIT, 1, 0, 0, 0},
             {OP_BEGIN, 3, 0, 0, 0}, {OP_READ, 3, 0, 0, 0}, {OP_READ, 3, 1, 1, 0}, {OP_COMMIT, 3, 0, 0, 0},
             {OP_WRITE, 2, 0, 0, 0}, {OP_COMMIT, 2, 0, 0, 0}};
-        ssi_ctx c4 = {4, 2, 127, 0, 1};
+        ssi_ctx c4 = {4, 2, 127, 0, 1, 0};
         SState s;
         memset(&s, 0, sizeof s);
         s.n = 17;
@@ -567,6 +623,7 @@ int or_spec_ssi(const int64_t *p, int np, or_spec *o) {
     c->inv_mask = np > 2 ? (int)p[2] : 127;
     c->find = np > 3 ? (int)p[3] : 0;
     c->textbook = np > 4 ? (int)p[4] : 0;
+    c->sym = np > 5 ? (int)p[5] & 3 : 0;
     o->name = "ssi"; o->ctx = c; o->max_state_bytes = 512;
     o->n_init = ssi_n_init; o->init = ssi_init; o->succ = ssi_succ; o->invariant = ssi_invariant; o->print = ssi_print;
     o->action_name = or_ssi_action; o->stats = ssi_stats;

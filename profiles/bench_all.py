@@ -18,7 +18,14 @@ WORKLOADS = [
     ("SSI 2x3 complete (7.9M), 7 invariants", "ssi", [2, 3, 127, 0], dict(table_capacity=1 << 26, arena_capacity=9_000_000)),
     ("SSI 4x3 levels 1-10 (config 5 prefix), 7 invariants", "ssi", [4, 3, 127, 0],
      dict(table_capacity=1 << 29, arena_capacity=200_000_000, max_levels=10)),
+    # cfg SYMMETRY Perms (Key and TxnId symmetry sets, serializableSnapshotIsolation.tla:38-44): orbits instead of states
+    ("SSI 3x2 complete under SYMMETRY (6.7M orbits of 80.8M states), 7 invariants", "ssi", [3, 2, 127, 0, 0, 3],
+     dict(table_capacity=1 << 25, arena_capacity=8_000_000)),
+    ("SSI 4x3 under SYMMETRY (config 5 as the run-book sets it up), 60M budget, 7 invariants", "ssi", [4, 3, 127, 0, 0, 3],
+     dict(table_capacity=1 << 30, arena_capacity=400_000_000, max_distinct=60_000_000)),
 ]
+if len(sys.argv) > 1:   # substring filter
+    WORKLOADS = [w for w in WORKLOADS if sys.argv[1] in w[0]]
 
 for name, spec, params, kw in WORKLOADS:
     try:
@@ -31,7 +38,7 @@ for name, spec, params, kw in WORKLOADS:
         W = ks["state_bytes"]
         kms = {k: round(ks[k]["ms_total"], 3) for k in ("expand", "insert", "materialise")}
         alg = 2 * W * r.distinct + 8 * r.generated
-        print(json.dumps(dict(workload=name, distinct=r.distinct, generated=r.generated, depth=r.depth, verdict=r.verdict,
+        print(json.dumps(dict(workload=name, distinct=r.distinct, generated=r.generated, depth=r.depth, verdict=r.verdict, levels=r.levels[-4:],
                               ms=round(dt * 1e3, 2), distinct_per_s=round(r.distinct / dt), generated_per_s=round(r.generated / dt),
                               W=W, kernel_ms=kms, alg_GBs=round(alg / dt / 1e9, 1))), flush=True)
         eng.close()

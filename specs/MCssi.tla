@@ -19,4 +19,8 @@ NoDeadlockAbort     == ~ AtLeastNTxnsAbortedDueToReason(1, "forced by deadlock-p
 NoCommitAbort       == ~ AtLeastNTxnsAbortedDueToReason(1, "in attempted commit, to preserve serializability")
 NoReadAbort         == ~ AtLeastNTxnsAbortedDueToReason(1, "in attempted read, to preserve serializability")
 NoWriteAbort        == ~ AtLeastNTxnsAbortedDueToReason(1, "in attempted write, to preserve serializability")
+\* Key and TxnId are "symmetry sets" in the spec's run-book (serializableSnapshotIsolation.tla:38-44); cfg: SYMMETRY Perms
+TxnPerms == Permutations(TxnId)
+KeyPerms == Permutations(Key)
+Perms    == Permutations(TxnId) \cup Permutations(Key)
 =============================================================================

@@ -12,4 +12,8 @@ EXTENDS textbookSnapshotIsolation
 WellFormed  == WellFormedTransactionsInHistory(history)
 CahillOK    == CahillSerializable(history)
 BernsteinOK == BernsteinSerializable(history)
+\* Key and TxnId are "symmetry sets" in the spec's run-book (serializableSnapshotIsolation.tla:38-44); cfg: SYMMETRY Perms
+TxnPerms == Permutations(TxnId)
+KeyPerms == Permutations(Key)
+Perms    == Permutations(TxnId) \cup Permutations(Key)
 =============================================================================

@@ -76,6 +76,20 @@ def test_empty_cfg_is_valid(amd):
     assert c["SPECIFICATION"] == "" and c["CONSTANTS"] == []
 
 
+def test_symmetry_resolution(amd):
+    """SYMMETRY is accepted for the snapshot-isolation models (the spec's run-book makes Key and TxnId symmetry sets,
+    serializableSnapshotIsolation.tla:38-44) and refused — never ignored — for every other lowering."""
+    cfg = (ROOT / "specs" / "MCssi_2x2_sym.cfg").read_text()
+    sid, params = amd.spec_resolve("MCssi", cfg)
+    assert sid == amd.SPEC_IDS["ssi"] and params[:2] == [2, 2] and params[5] == 3
+    sid, params = amd.spec_resolve("MCssi", (ROOT / "specs" / "MCssi_2x2.cfg").read_text())
+    assert params[5] == 0
+    with pytest.raises(amd.McError):
+        amd.spec_resolve("MCraft", (ROOT / "specs" / "MCraft_small.cfg").read_text() + "\nSYMMETRY Perms\n")
+    with pytest.raises(amd.McError):
+        amd.spec_resolve("pcal_intro", (ROOT / "specs" / "pcal_intro.cfg").read_text() + "\nSYMMETRY Perms\n")
+
+
 def test_cli_is_built():
     import tla_rust_amd.build as b
     b.build()
@@ -133,6 +147,25 @@ def test_cli_exit_codes_and_raft(amd):
     assert p.returncode == 0 and f"{2**20 + 1} distinct states found" in p.stdout
     p = subprocess.run([str(mc), str(ROOT / "include" / "tlamc.h")], capture_output=True, text=True)
     assert p.returncode == 1
+
+
+@pytest.mark.gpu
+def test_cli_ssi_symmetry(amd, tmp_path):
+    """`SYMMETRY Perms` end to end: which sets Perms permutes is read from the model module."""
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(ROOT / "specs" / "MCssi_2x2_sym.cfg")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "12558 states generated, 7419 distinct states found, 0 states left on queue." in p.stdout
+    assert "The depth of the complete state graph search is 13." in p.stdout
+    for name, want in (("TxnPerms", "25062 states generated, 14815 distinct"), ("KeyPerms", "25113 states generated, 14837 distinct")):
+        cfg = tmp_path / f"{name}.cfg"
+        cfg.write_text((ROOT / "specs" / "MCssi_2x2_sym.cfg").read_text().replace("SYMMETRY Perms", f"SYMMETRY {name}"))
+        p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(cfg)], capture_output=True, text=True)
+        assert p.returncode == 0 and want in p.stdout, p.stdout + p.stderr
+    cfg = tmp_path / "bad.cfg"
+    cfg.write_text((ROOT / "specs" / "MCssi_2x2_sym.cfg").read_text().replace("SYMMETRY Perms", "SYMMETRY WellFormed"))
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(cfg)], capture_output=True, text=True)
+    assert p.returncode != 0 and "Permutations" in (p.stdout + p.stderr)
 
 
 @pytest.mark.gpu

@@ -17,6 +17,10 @@ SMALL = [
     ("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 3, 2, 9, 1, 3]),
     ("ssi", [2, 1, 127, 0]), ("ssi", [2, 2, 127, 0]), ("ssi", [3, 1, 127, 0]),
     ("ssi", [2, 2, 127, 0, 1]), ("ssi", [3, 1, 31, 0, 1]),       # textbookSnapshotIsolation.tla
+    # cfg SYMMETRY (serializableSnapshotIsolation.tla:38-44; bit 0 TxnId, bit 1 Key): same orbit representatives as the
+    # oracle's brute-force search over all permutations, level by level
+    ("ssi", [2, 2, 127, 0, 0, 1]), ("ssi", [2, 2, 127, 0, 0, 2]), ("ssi", [2, 2, 127, 0, 0, 3]), ("ssi", [3, 1, 127, 0, 0, 3]),
+    ("ssi", [2, 2, 127, 0, 1, 3]),
 ]
 
 
@@ -193,6 +197,31 @@ def test_ssi_4x3_prefix_on_gpu(amd):
     eng = amd.Engine("ssi", [4, 3, 127, 0], table_capacity=1 << 27, arena_capacity=24_000_000, chunk_states=1 << 19, max_levels=9, trace=False)
     r = eng.run()
     assert r.levels == [1, 4, 32, 264, 2532, 24576, 236844, 2189052, 18810792] and r.verdict == "budget"
+    eng.close()
+
+
+@pytest.mark.parametrize("case", ["2x3", "3x2", "4x3_prefix"])
+def test_ssi_symmetry_golden_on_gpu(amd, case):
+    """cfg SYMMETRY on the SSI model, Key and TxnId symmetry sets as the spec's run-book prescribes (:38-44): per-level orbit
+    counts of tests/golden/ssi_symmetry.json (oracle, brute force over |TxnId|! x |Key|! permutations per successor;
+    tests/golden/make_ssi_symmetry_golden.py).  3 x 2: 80 807 116 states -> 6 734 049 orbits."""
+    g = json.loads((GOLDEN / "ssi_symmetry.json").read_text())[case]
+    eng = amd.Engine("ssi", g["params"], table_capacity=1 << 25, arena_capacity=8_000_000, chunk_states=1 << 19,
+                     max_distinct=g["max_distinct"], trace=False)
+    r = eng.run()
+    assert (r.verdict, r.distinct, r.generated, r.depth) == (g["verdict"], g["distinct"], g["generated"], g["depth"])
+    assert r.levels == g["levels"]
+    eng.close()
+
+
+def test_textbook_si_write_skew_under_symmetry_on_gpu(amd):
+    """Symmetry reduction keeps the verdict and the length of the shortest counterexample (13-state write skew)."""
+    g = json.loads((GOLDEN / "ssi_symmetry.json").read_text())["textbook_3x2_cahill"]
+    eng = amd.Engine("ssi", g["params"], table_capacity=1 << 24, arena_capacity=4_000_000, chunk_states=1 << 19)
+    r = eng.run()
+    assert (r.verdict, r.violated_invariant, r.trace_len) == ("invariant", 5, g["trace_len"])
+    tr = eng.trace()
+    assert len(tr) == 13 and tr[-1][1].count('"commit"') >= 2
     eng.close()
 
 

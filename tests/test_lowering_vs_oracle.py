@@ -11,6 +11,10 @@ CASES = [
     ("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 3, 2, 9, 1, 3]),
     ("ssi", [2, 1, 127, 0]), ("ssi", [2, 2, 127, 0]), ("ssi", [3, 1, 127, 0]),
     ("ssi", [2, 2, 127, 0, 1]), ("ssi", [3, 1, 31, 0, 1]),       # textbookSnapshotIsolation.tla
+    # cfg SYMMETRY (serializableSnapshotIsolation.tla:38-44): oracle = brute force over all permutations,
+    # lowering = begin-order / first-touch relabelling; bit 0 TxnId, bit 1 Key
+    ("ssi", [2, 2, 127, 0, 0, 1]), ("ssi", [2, 2, 127, 0, 0, 2]), ("ssi", [2, 2, 127, 0, 0, 3]),
+    ("ssi", [3, 1, 127, 0, 0, 3]), ("ssi", [2, 3, 127, 0, 0, 3]), ("ssi", [2, 2, 127, 0, 1, 3]),
 ]
 
 
@@ -55,6 +59,42 @@ def test_ssi_3x2_prefix(oracle, shim):
     s = shim.shim_run("ssi", [3, 2, 127, 0], max_distinct=300000)
     for k in ("distinct", "generated", "depth", "verdict", "levels"):
         assert o[k] == s[k], k
+
+
+def test_ssi_symmetry_orbit_counts(oracle):
+    """Under SYMMETRY the distinct states are orbits: between D / (|TxnId|! |Key|!) and D, and the search depth,
+    the verdict and every invariant are those of the unreduced graph (2 x 2: 29 629 -> 7 419)."""
+    full = oracle.oracle_run("ssi", [2, 2, 127, 0, 0, 0])
+    both = oracle.oracle_run("ssi", [2, 2, 127, 0, 0, 3])
+    assert (full["distinct"], both["distinct"], both["generated"]) == (29629, 7419, 12558)
+    assert both["depth"] == full["depth"] and both["verdict"] == full["verdict"] == "ok"
+    assert full["distinct"] / 4 <= both["distinct"] <= full["distinct"]
+    for sym, group in ((1, 2), (2, 2)):
+        part = oracle.oracle_run("ssi", [2, 2, 127, 0, 0, sym])
+        assert full["distinct"] / group <= part["distinct"] <= full["distinct"]
+        assert both["distinct"] <= part["distinct"]
+
+
+@pytest.mark.parametrize("params,maxd", [([3, 2, 127, 0, 0, 3], 200000), ([4, 3, 127, 0, 0, 3], 60000), ([4, 2, 127, 0, 0, 1], 60000),
+                                         ([3, 3, 127, 0, 1, 3], 100000)])
+def test_ssi_symmetry_prefix(oracle, shim, params, maxd):
+    """3 and 4 transactions: Commit's AbortOpSeq (CHOOSE order, :465-474) can abort two losers, so the count depends on
+    which representative of an orbit is expanded — both sides expand the begin-ordered one."""
+    o = oracle.oracle_run("ssi", params, max_distinct=maxd)
+    s = shim.shim_run("ssi", params, max_distinct=maxd)
+    for k in ("distinct", "generated", "depth", "verdict", "levels"):
+        assert o[k] == s[k], k
+    assert s["fp_mismatch"] == 0
+
+
+@pytest.mark.parametrize("find", [2, 3, 7])
+def test_ssi_symmetry_expected_violation_same_trace_length(oracle, shim, find):
+    """Symmetry reduction keeps the length of the shortest counterexample."""
+    plain = oracle.oracle_run("ssi", [3, 2, 127, find])
+    o = oracle.oracle_run("ssi", [3, 2, 127, find, 0, 3])
+    s = shim.shim_run("ssi", [3, 2, 127, find, 0, 3])
+    assert (s["verdict"], s["violated_invariant"], s["trace_len"]) == (o["verdict"], o["violated_invariant"], len(o["trace"]))
+    assert len(o["trace"]) == len(plain["trace"])
 
 
 def test_device_ssi_invariants_on_fekete_read_only_anomaly(shim):

@@ -6,4 +6,4 @@ front-end and the symbol table can be tested without a GPU), but every compute e
 raises if the shared library is missing or no HIP device is present.
 """
 from .binding import (Engine, McError, Program, Result, SPEC_IDS, VERDICTS, cfg_parse, check_files, device_count, lib,  # noqa: F401
-                      pcal_translate, spec_desc, state_bytes, state_format)
+                      pcal_translate, spec_desc, spec_resolve, state_bytes, state_format)

@@ -331,6 +331,19 @@ def cfg_parse(text: str):
         lib().mc_cfg_free(h)
 
 
+def spec_resolve(module: str, cfg_text: str):
+    """mc_spec_resolve: (module name, cfg text) -> (spec id, parameter list) of the lowering the registry picks."""
+    h = C.c_void_p()
+    b = cfg_text.encode()
+    _check(lib().mc_cfg_parse(b, len(b), C.byref(h)), "mc_cfg_parse")
+    try:
+        d = SpecDesc()
+        _check(lib().mc_spec_resolve(module.encode(), h, C.byref(d)), "mc_spec_resolve")
+        return int(d.spec_id), [int(d.params[i]) for i in range(d.nparams)]
+    finally:
+        lib().mc_cfg_free(h)
+
+
 def check_files(tla_path, cfg_path=None, device=0, **kw):
     """`tlc X.tla` end to end (reference Makefile:6-7): returns (Result, report text)."""
     cfg = Config(device, MC_F_DEADLOCK | MC_F_TRACE, kw.get("table_capacity", 0), kw.get("arena_capacity", 0),

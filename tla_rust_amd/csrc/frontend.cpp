@@ -460,7 +460,10 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
     memset(out, 0, sizeof *out);
     const std::string m = module;
     if (!c->properties.empty()) return fe_fail(MC_ENOSPEC, "PROPERTY (temporal) checking is not supported; only INVARIANT safety checking");
-    if (!c->symmetry.empty() || !c->view.empty()) return fe_fail(MC_ENOSPEC, "SYMMETRY / VIEW are not supported yet");
+    if (!c->view.empty()) return fe_fail(MC_ENOSPEC, "VIEW is not supported");
+    const bool is_ssi = m == "MCssi" || m == "serializableSnapshotIsolation" || m == "MCtextbookSI" || m == "textbookSnapshotIsolation";
+    if (!c->symmetry.empty() && !is_ssi)
+        return fe_fail(MC_ENOSPEC, "SYMMETRY is supported for the snapshot-isolation models only (their run-book makes Key and TxnId symmetry sets)");
     if (m == "atomic_add" || m == "atomic_add_n") {  // atomic_add.tla:4-23; atomic_add_n: N adders (specs/atomic_add_n.tla)
         long long n = 2;
         if (m == "atomic_add_n" && !const_int(c, "N", n)) return fe_fail(MC_EBADCFG, "atomic_add_n needs CONSTANT N = <number>");
@@ -537,7 +540,10 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
             if (!ok) return fe_fail(MC_ENOSPEC, "MCssi defines no invariant named '%s'", i.c_str());
         }
         out->spec_id = MC_SPEC_SSI;
-        out->nparams = 5;
+        out->nparams = 6;
+        // SYMMETRY <name>: which of Permutations(TxnId) / Permutations(Key) the set <name> holds is read from the module
+        // text by mc_check_files (symmetry_sets); through this entry point both are assumed, as :38-44 prescribe.
+        out->params[5] = c->symmetry.empty() ? 0 : 3;
         out->params[0] = (long long)tx->value.elems.size();
         out->params[1] = (long long)ky->value.elems.size();
         out->params[2] = mask;
@@ -645,6 +651,45 @@ static const char *invariant_name(const mc_spec_desc *d, int idx) {
     return "?";
 }
 
+// `SYMMETRY Perms` names a definition of the model module, e.g. (examples/Paxos/MCPaxos.tla:14-style)
+//   Perms == Permutations(TxnId) \cup Permutations(Key)
+// Returns bit 0 for Permutations(TxnId), bit 1 for Permutations(Key), 0 if the definition is missing or names anything else.
+static int symmetry_sets(const std::string &tla, const std::string &name) {
+    size_t at = 0;
+    for (;;) {
+        at = tla.find(name, at);
+        if (at == std::string::npos) return 0;
+        const bool starts = at == 0 || tla[at - 1] == '\n';
+        size_t q = at + name.size();
+        while (q < tla.size() && (tla[q] == ' ' || tla[q] == '\t')) q++;
+        if (starts && tla.compare(q, 2, "==") == 0) { at = q + 2; break; }
+        at += name.size();
+    }
+    size_t end = tla.find("\n\n", at);   // a definition ends at the next blank line / the next definition / the module end
+    for (const char *stop : {"==", "\n----", "\n===="}) {
+        const size_t e = tla.find(stop, at);
+        if (e != std::string::npos && (end == std::string::npos || e < end)) end = e;
+    }
+    std::string body = tla.substr(at, end == std::string::npos ? std::string::npos : end - at);
+    if (body.find("==") == std::string::npos && end != std::string::npos && tla.compare(end, 2, "==") == 0) {
+        const size_t nl = body.rfind('\n');   // the "==" belongs to the NEXT definition: drop its name line
+        if (nl != std::string::npos) body.resize(nl);
+    }
+    int sets = 0;
+    size_t k = 0;
+    while ((k = body.find("Permutations", k)) != std::string::npos) {
+        size_t a = body.find('(', k), b = body.find(')', k);
+        if (a == std::string::npos || b == std::string::npos || b < a) return 0;
+        std::string arg = body.substr(a + 1, b - a - 1);
+        arg.erase(std::remove_if(arg.begin(), arg.end(), [](char ch) { return ch == ' ' || ch == '\t' || ch == '\n'; }), arg.end());
+        if (arg == "TxnId") sets |= 1;
+        else if (arg == "Key") sets |= 2;
+        else return 0;
+        k = b;
+    }
+    return sets;
+}
+
 int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
                    mc_result *res) {
     return mc_check_files_dump(tla_path, cfg_path, cfg, report, report_cap, res, nullptr);
@@ -687,6 +732,7 @@ int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_con
         if (!generic && d.spec_id == MC_SPEC_PCAL_INTRO && alg_hash != H_PCAL_INTRO && alg_hash != H_PCAL_INTRO_README) generic = true;
         if (!generic && d.spec_id == MC_SPEC_ATOMIC_ADD && module == "atomic_add" && alg_hash != H_ATOMIC_ADD) generic = true;
     }
+    const std::string symmetry_name = c->symmetry;
     mc_cfg_free(c);
     mc_program *prog = nullptr;
     struct ProgGuard { mc_program *&p; ~ProgGuard() { if (p) mc_program_free(p); } } prog_guard{prog};
@@ -709,6 +755,11 @@ int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_con
             if (h != H_RAFT) return fe_fail(MC_ENOSPEC, "raft.tla differs from the text the lowering was written against (hash %016llx)", (unsigned long long)h);
             if (module != "raft") { def_text = raft; def_module_name = "raft"; }
         }
+    }
+    if (d.spec_id == MC_SPEC_SSI && d.params[5]) {
+        const int sets = symmetry_sets(tla, symmetry_name);
+        if (sets <= 0) return fe_fail(MC_ENOSPEC, "SYMMETRY %s: the module must define it from Permutations(TxnId) and / or Permutations(Key)", symmetry_name.c_str());
+        d.params[5] = sets;
     }
     if (d.spec_id == MC_SPEC_SSI) {
         std::string ssi;  // the MC wrapper EXTENDS the spec: verify it when it can be found

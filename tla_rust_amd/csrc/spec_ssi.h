@@ -16,6 +16,18 @@
 // by the expand kernel.  Every CHOOSE over transactions is resolved in ascending order T1 < T2 < ..
 // (Commit's AbortOpSeq :465-474); the other CHOOSEs are over singletons.
 //
+// SYMMETRY (the run-book makes Key and TxnId symmetry sets, :38-44).  TLC canonicalises a successor by trying
+// every permutation; here the orbit representative is chosen so that NO search is needed: transactions are
+// numbered in the order of their `begin` events and keys in the order of their first read / write event.  Every
+// other label of a state is at its initial value (an unstarted transaction, an untouched key), so two states
+// are in one orbit iff these relabelled forms are equal.  A parent stored in that form has started = {T1..Tj}
+// and touched keys {K1..Ki}; an action introduces at most one new label, so its successor's representative is
+// the same action taken with the lowest unused label: Begin(t), t unstarted, appends `begin T(j+1)`;
+// StartWriteMayBlock(txn, k), k untouched, writes K(i+1).  The aliased slots still count as generated
+// successors (TLC generates each and finds the duplicates through the fingerprints), the seen-set does the
+// rest, and the fingerprint stays incremental.  (tests/ compare this, level by level, with a brute-force search
+// over all |TxnId|! * |Key|! permutations.)
+//
 // Invariants (:59-79) are evaluated once per state when it is EXPANDED (parent_status), not per
 // generated successor: every stored state is expanded exactly once, so the verdict and the length
 // of the shortest counterexample are the same as TLC's check-on-generation.
@@ -26,7 +38,7 @@
 
 namespace mc {
 
-struct SsiParams { int nt, nk, inv_mask, find, textbook; };  // textbook = 1: examples/textbookSnapshotIsolation.tla
+struct SsiParams { int nt, nk, inv_mask, find, textbook, sym; };  // textbook = 1: examples/textbookSnapshotIsolation.tla; sym: cfg SYMMETRY
 
 struct SpecSsi {
     using Params = SsiParams;
@@ -51,6 +63,7 @@ struct SpecSsi {
         o.inv_mask = np > 2 ? (int)p[2] : 127;
         o.find = np > 3 ? (int)p[3] : 0;
         o.textbook = np > 4 ? (int)p[4] : 0;  // the same model without Cahill's variables (textbookSnapshotIsolation.tla:115)
+        o.sym = np > 5 ? (int)p[5] & 3 : 0;   // cfg SYMMETRY: bit 0 Permutations(TxnId), bit 1 Permutations(Key) (:38-44)
         if (o.nt < 1 || o.nt > NT || o.nk < 1 || o.nk > NK || o.find < 0 || o.find > 7) return -1;
         return 0;
     }
@@ -261,7 +274,8 @@ struct SpecSsi {
         if (sub == 0) {  // Begin(txn) :423-426
             action = SA_BEGIN;
             if (l.started >> txn & 1u) return 0;
-            d_append(d, mk_event(OP_BEGIN, txn, 0, 0, 0));
+            // SYMMETRY over TxnId: the representative of the successor's orbit begins the lowest unstarted transaction
+            d_append(d, mk_event(OP_BEGIN, (p.sym & 1) ? (int)__builtin_popcount(l.started) : txn, 0, 0, 0));
         } else if (sub == 1) {  // Commit(txn) :429-491
             action = SA_COMMIT;
             if (!can_do(l, txn)) return 0;
@@ -296,7 +310,7 @@ struct SpecSsi {
             action = SA_READ;
             if (key >= p.nk || !can_do(l, txn) || (l.rkeys >> (4 * txn + key) & 1u)) return 0;
             const int ver = version_read_by(p, l, txn, key);
-            if (ver < 0) return 0;
+            if (ver < 0) return 0;  // no version yet: in particular an untouched key is never read, so Read needs no SYMMETRY alias
             const unsigned newer = newer_versions(p, l, key, ver);
             bool danger = false;
 #pragma unroll
@@ -317,6 +331,17 @@ struct SpecSsi {
             const int key = (sub - 4 - NK) / NT, c = (sub - 4 - NK) % NT;
             action = SA_WRITE;
             if (key >= p.nk || !can_do(l, txn) || (t_xl(me) >> key & 1u)) return 0;
+            if (p.sym & 2) {  // SYMMETRY over Key: writing an untouched key = writing the lowest untouched key
+                unsigned ks = l.rkeys | l.wkeys;
+                ks = (ks | ks >> 4 | ks >> 8 | ks >> 12) & 7u;
+                if (!(ks >> key & 1u)) {  // untouched: nobody wrote, locked or SIREAD-locked it, so :897-911 reduces to the plain write
+                    if (c) return 0;
+                    write_can_acquire(p, l, txn, (int)__builtin_popcount(ks), d);
+                    if (l.n + d.nev > HCAP) return ST_ENABLED | ST_OVERFLOW;
+                    d.meta = (d.meta & ~63ull) | (uint64_t)(l.n + d.nev);
+                    return ST_ENABLED;
+                }
+            }
             unsigned anylocked = 0;
 #pragma unroll
             for (int t = 0; t < NT; t++) anylocked |= t_xl(m_txn(l.meta, t));
