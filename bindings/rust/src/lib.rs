@@ -39,6 +39,9 @@ extern "C" {
     pub fn mc_engine_run(e: *mut mc_engine, out: *mut mc_result) -> c_int;
     pub fn mc_engine_trace(e: *mut mc_engine, states: *mut u8, actions: *mut i32, n_inout: *mut usize) -> c_int;
     pub fn mc_engine_read_states(e: *mut mc_engine, first: u64, count: u64, out: *mut u8) -> c_int;
+    // TLC's checkpoint / -recover (testout1:10): write / reload the states found so far; the next run continues
+    pub fn mc_engine_checkpoint(e: *mut mc_engine, path: *const c_char) -> c_int;
+    pub fn mc_engine_restore(e: *mut mc_engine, path: *const c_char) -> c_int;
     pub fn mc_engine_destroy(e: *mut mc_engine);
     pub fn mc_check_files(tla: *const c_char, cfg_path: *const c_char, cfg: *const mc_config, report: *mut c_char,
                           cap: usize, out: *mut mc_result) -> c_int;

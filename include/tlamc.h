@@ -131,6 +131,17 @@ int mc_engine_kernel_stats(mc_engine *e, mc_kernel_stats *out);
 /* copy `count` resident states starting at arena index `first` (discovery order: level by level)
  * to the host, mc_state_bytes() bytes each — TLC's "states/" dump, for tests and tooling */
 int mc_engine_read_states(mc_engine *e, uint64_t first, uint64_t count, uint8_t *out);
+/* Checkpoint / recover — TLC checkpoints a run into its states/ directory ("-- Checkpointing of run states/01-08-03-18-14-01
+ * completed.", reference examples/SpecifyingSystems/AdvancedExamples/testout1:10; .gitignore:2) and continues it with -recover.
+ * mc_engine_checkpoint: after an mc_engine_run that ended without a violation (normally MC_V_BUDGET), write every distinct
+ *   state found (the arena's blocks as they lie in HBM), the level boundaries, the counters and — with MC_F_TRACE — the
+ *   parent pointers to `path`.  The seen-set is not written.
+ * mc_engine_restore: load such a file into an engine created for the SAME spec descriptor (MC_EBADCFG otherwise); the next
+ *   mc_engine_run rebuilds the seen-set from the states' fingerprints and continues with the checkpoint's last level as
+ *   the frontier: counters, depth, per-level counts and counterexamples are those of an uninterrupted run.  max_levels /
+ *   max_distinct of the new engine are absolute (they count the checkpointed part).  Single-GPU engines only. */
+int mc_engine_checkpoint(mc_engine *e, const char *path);
+int mc_engine_restore(mc_engine *e, const char *path);
 /* profiling aid: re-expand every resident state of the last run (all probes hit); extra_flags 16 = no probes */
 int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms);
 void mc_engine_destroy(mc_engine *e);
@@ -234,6 +245,11 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
  * variables, blank line), in discovery order; dump_path NULL = mc_check_files */
 int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report,
                         size_t report_cap, mc_result *out, const char *dump_path);
+/* the same with TLC's -recover / checkpointing: recover_path (or NULL) is restored before the run, checkpoint_path (or
+ * NULL) is written after a run that ended without an error; the report then carries TLC's line
+ * "-- Checkpointing of run <path> completed." (testout1:10) */
+int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
+                        mc_result *out, const char *dump_path, const char *recover_path, const char *checkpoint_path);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,143 @@
+"""Checkpoint / recover on the GPU (TLC: "-- Checkpointing of run states/... completed.", testout1:10, and -recover):
+a search stopped on a budget, written to a file, reloaded into a NEW engine and continued must report exactly what the
+uninterrupted search reports — counters, depth, per-level counts, verdict, counterexample."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+KEYS = ("distinct", "generated", "depth", "verdict", "levels", "queue_left")
+KW = dict(table_capacity=1 << 22, arena_capacity=1 << 20, chunk_states=1 << 12)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import tla_rust_amd
+    assert tla_rust_amd.device_count() >= 1, "no HIP device visible"
+    return tla_rust_amd
+
+
+@pytest.mark.parametrize("spec,params,cut", [
+    ("atomic_add", [11], 5), ("pcal_intro", [0, 1, 20, 2], 3), ("raft", [2, 2, 2, 9, 1, 1], 9), ("raft", [2, 2, 2, 9, 1, 1], 1),
+    ("ssi", [2, 2, 127, 0], 7), ("ssi", [3, 1, 127, 0, 0, 3], 6), ("ssi", [2, 2, 127, 0, 1], 12)])
+@pytest.mark.parametrize("trace", [True, False])
+def test_recovered_run_equals_uninterrupted_run(amd, oracle, tmp_path, spec, params, cut, trace):
+    o = oracle.oracle_run(spec, params)
+    a = amd.Engine(spec, params, max_levels=cut, trace=trace, **KW)
+    ra = a.run()
+    assert ra.verdict == "budget" and ra.depth == cut and ra.levels == o["levels"][:cut]
+    ck = tmp_path / "run.ckpt"
+    a.checkpoint(ck)
+    states_a = a.read_states(0, ra.distinct)
+    a.close()
+    b = amd.Engine(spec, params, trace=trace, **KW)
+    b.restore(ck)
+    rb = b.run()
+    for k in KEYS:
+        assert rb[k] == o[k], k
+    # the checkpointed levels are the states the first engine found, in its order
+    assert b.read_states(0, ra.distinct) == states_a
+    # a second run() of the same engine starts from Init again
+    rc = b.run()
+    for k in KEYS:
+        assert rc[k] == o[k], k
+    b.close()
+
+
+def test_checkpoint_of_a_checkpoint(amd, oracle, tmp_path):
+    params = [2, 2, 127, 0]
+    o = oracle.oracle_run("ssi", params)
+    ck = tmp_path / "c"
+    e = amd.Engine("ssi", params, max_levels=4, **KW)
+    e.run(); e.checkpoint(ck); e.close()
+    e = amd.Engine("ssi", params, max_levels=9, **KW)        # budgets are absolute: 5 more levels
+    e.restore(ck)
+    r = e.run()
+    assert r.verdict == "budget" and r.levels == o["levels"][:9]
+    e.checkpoint(ck); e.close()
+    e = amd.Engine("ssi", params, **KW)
+    e.restore(ck)
+    r = e.run()
+    for k in KEYS:
+        assert r[k] == o[k], k
+    e.close()
+
+
+def test_counterexample_found_after_recovery(amd, oracle, tmp_path):
+    """the parent pointers travel with the checkpoint: the shortest counterexample is rebuilt through the checkpointed levels"""
+    params = [3, 2, 127, 3]     # ~AtLeastNTxnsAbortedDueToReason(1, deadlock prevention): serializableSnapshotIsolation.tla:81-96
+    o = oracle.oracle_run("ssi", params)
+    kw = dict(table_capacity=1 << 24, arena_capacity=1 << 22, chunk_states=1 << 16)
+    a = amd.Engine("ssi", params, max_levels=len(o["trace"]) - 3, **kw)
+    assert a.run().verdict == "budget"
+    a.checkpoint(tmp_path / "c"); a.close()
+    b = amd.Engine("ssi", params, **kw)
+    b.restore(tmp_path / "c")
+    r = b.run()
+    assert (r.verdict, r.violated_invariant, r.trace_len) == ("invariant", 7, len(o["trace"]))
+    tr = b.trace()
+    assert len(tr) == r.trace_len and tr[0][0] == "Initial predicate" and tr[0][1] == o["trace"][0][1]
+    assert "forced by deadlock-prevention" in tr[-1][1]
+    b.close()
+
+
+def test_checkpoint_misuse_is_refused(amd, tmp_path):
+    e = amd.Engine("ssi", [2, 2, 127, 0], max_levels=5, **KW)
+    with pytest.raises(amd.McError):
+        e.checkpoint(tmp_path / "early")          # nothing has run yet
+    e.run()
+    e.checkpoint(tmp_path / "ok")
+    e.close()
+    for spec, params in (("ssi", [2, 2, 127, 0, 0, 3]), ("ssi", [3, 2, 127, 0]), ("atomic_add", [5])):
+        other = amd.Engine(spec, params, **KW)
+        with pytest.raises(amd.McError):
+            other.restore(tmp_path / "ok")          # another model: other constants / SYMMETRY / spec
+        other.close()
+    small = amd.Engine("ssi", [2, 2, 127, 0], table_capacity=1 << 22, arena_capacity=64)
+    with pytest.raises(amd.McError):
+        small.restore(tmp_path / "ok")
+    small.close()
+    data = (tmp_path / "ok").read_bytes()
+    (tmp_path / "cut").write_bytes(data[: len(data) // 2])
+    (tmp_path / "junk").write_bytes(b"not a checkpoint" * 100)
+    e = amd.Engine("ssi", [2, 2, 127, 0], **KW)
+    for bad in ("cut", "junk", "missing"):
+        with pytest.raises(amd.McError):
+            e.restore(tmp_path / bad)
+    viol = amd.Engine("pcal_intro", [1, 0, 20, 2], **KW)    # README variant: the assertion fails
+    assert viol.run().verdict == "assert"
+    with pytest.raises(amd.McError):
+        viol.checkpoint(tmp_path / "v")              # a run that ended in an error is not continued
+    viol.close()
+    e.close()
+
+
+def test_cli_checkpoint_and_recover(amd, tmp_path):
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    tla, cfg, ck = str(ROOT / "specs" / "MCssi.tla"), str(ROOT / "specs" / "MCssi_2x2.cfg"), str(tmp_path / "ssi.ckpt")
+    p = subprocess.run([str(mc), tla, "-config", cfg, "-maxlevels", "6", "-checkpoint", ck], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert f"-- Checkpointing of run {ck} completed." in p.stdout                  # testout1:10
+    p = subprocess.run([str(mc), tla, "-config", cfg, "-recover", ck], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "50121 states generated, 29629 distinct states found, 0 states left on queue." in p.stdout
+    assert "The depth of the complete state graph search is 13." in p.stdout
+    p = subprocess.run([str(mc), tla, "-config", str(ROOT / "specs" / "MCssi_2x2_sym.cfg"), "-recover", ck], capture_output=True, text=True)
+    assert p.returncode == 1 and "other constants" in p.stderr
+
+
+def test_large_checkpoint_round_trip(amd, tmp_path):
+    """SSI 2 x 3 (7 910 565 states): stop after level 13 (2.5 M states, 200 MB), recover, finish."""
+    kw = dict(table_capacity=1 << 25, arena_capacity=9_000_000, chunk_states=1 << 19, trace=False)
+    a = amd.Engine("ssi", [2, 3, 127, 0], max_levels=13, **kw)
+    ra = a.run()
+    assert ra.verdict == "budget" and ra.distinct == sum([1, 2, 12, 60, 354, 1968, 9318, 35286, 102408, 222552, 381444, 641376, 1118376])
+    a.checkpoint(tmp_path / "big"); a.close()
+    assert (tmp_path / "big").stat().st_size >= ra.distinct * 80
+    b = amd.Engine("ssi", [2, 3, 127, 0], **kw)
+    b.restore(tmp_path / "big")
+    r = b.run()
+    assert (r.verdict, r.distinct, r.generated, r.depth) == ("ok", 7910565, 13246749, 17)
+    b.close()

@@ -97,6 +97,8 @@ def lib():
     L.mc_shard_expand_finish.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, U64P]
     L.mc_shard_materialise_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, U64P]
     L.mc_shard_keep_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, U64P]
+    L.mc_engine_checkpoint.argtypes = [C.c_void_p, C.c_char_p]
+    L.mc_engine_restore.argtypes = [C.c_void_p, C.c_char_p]
     L.mc_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.mc_shard_materialise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, U64P]
     L.mc_shard_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -193,6 +195,14 @@ class Engine:
             name = lib().mc_action_name(C.byref(self.desc), acts[k]).decode()
             out.append((name, state_format(self.spec, self.params, states.raw[k * W:(k + 1) * W])))
         return out
+
+    def checkpoint(self, path):
+        """TLC's checkpoint (testout1:10): states found so far + level boundaries + counters (+ parent pointers) -> file."""
+        _check(lib().mc_engine_checkpoint(self._h, str(path).encode()), "mc_engine_checkpoint")
+
+    def restore(self, path):
+        """TLC's -recover: the next run() continues the checkpointed search."""
+        _check(lib().mc_engine_restore(self._h, str(path).encode()), "mc_engine_restore")
 
     def read_states(self, first, count):
         """Packed records of `count` states in discovery order starting at `first`."""

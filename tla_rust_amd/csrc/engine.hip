@@ -206,6 +206,17 @@ __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t mask, uint
     return false;
 }
 
+// checkpoint recovery: the seen-set is not part of a checkpoint — it is rebuilt from word 0 (the fingerprint) of the
+// arena's states, one coalesced pass
+template <class S>
+__global__ void __launch_bounds__(256)
+k_reseed_table(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t n, uint64_t *table, uint64_t mask, DevCounters *ctr) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned err = 0;
+    if (i < n) seen_insert(table, mask, S::fp_of(prm, arena_cref(arena, i, S::words(prm))), err);
+    if (wave_or_u32(err) && (threadIdx.x & 63) == 0) atomicOr(&ctr->error, DEV_ETABLE);
+}
+
 static __global__ void __launch_bounds__(256)
 k_insert(const uint64_t *__restrict__ cand, uint64_t row_stride, uint64_t ncols, const uint16_t *__restrict__ nsl,
          uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, DevCounters *ctr) {
@@ -946,6 +957,8 @@ struct EngineBase {
     virtual int kernel_stats(mc_kernel_stats *out) = 0;
     virtual int read_states(uint64_t first, uint64_t count, uint8_t *out) = 0;
     virtual int debug_reexpand(unsigned extra_flags, double *ms) = 0;
+    virtual int checkpoint(const char *path) = 0;
+    virtual int restore(const char *path) = 0;
     virtual int shard_begin() = 0;
     virtual int shard_begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) = 0;
     virtual int shard_level_size(uint64_t *n) = 0;
@@ -1172,12 +1185,22 @@ struct Engine : EngineBase {
         DevCounters init_c;
         memset(&init_c, 0, sizeof init_c);
         init_c.viol_key = ~0ull;
+        const bool resuming = ck_pending;
+        ck_pending = false;
+        if (resuming) {  // counters of the checkpointed run; its states are already in the arena (restore())
+            init_c.arena_next = ck_distinct;
+            init_c.generated[0].v = ck_generated;
+            init_c.cells[0].v = ck_cells;
+        }
         HIP_TRY(hipMemcpyAsync(d_ctr, &init_c, sizeof init_c, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         const auto t0 = std::chrono::steady_clock::now();
 
         // level 1: Init
-        const uint64_t ninit = S::num_init(prm);
+        const uint64_t ninit = resuming ? 0 : S::num_init(prm);
+        if (resuming && ck_distinct)
+            hipLaunchKernelGGL(k_reseed_table<S>, dim3((unsigned)((ck_distinct + 255) / 256)), dim3(256), 0, stream, prm,
+                               (const uint64_t *)d_arena, ck_distinct, d_table, table_cap - 1, d_ctr);
         for (uint64_t first = 0; first < ninit; first += chunk) {
             const uint64_t count = ninit - first < chunk ? ninit - first : chunk;
             const uint64_t ncols = (count + 63) & ~63ull;
@@ -1192,6 +1215,13 @@ struct Engine : EngineBase {
         uint32_t level = 1;
         out->level_distinct[0] = hi;
         level_start.push_back(0);
+        if (resuming) {  // continue with the frontier [lo, hi) = the last, unexpanded level of the checkpointed run
+            level_start = ck_level_start;
+            level = (uint32_t)level_start.size();
+            lo = ck_lo;
+            for (uint32_t k = 0; k < level && k < MC_MAX_LEVELS; k++)
+                out->level_distinct[k] = (k + 1 < level ? level_start[k + 1] : hi) - level_start[k];
+        }
         int budget = 0;
         const uint64_t blind_max = chunk < (1ull << 16) ? chunk : (1ull << 16);
         while (hi > lo) {
@@ -1271,6 +1301,8 @@ struct Engine : EngineBase {
         out->generated = 0;
         kstat_cells = 0;
         for (int t = 0; t < NSHARD; t++) { out->generated += h_ctr->generated[t].v; kstat_cells += h_ctr->cells[t].v; }
+        last_generated = out->generated;
+        have_run = true;
         out->queue_left = hi - lo;
         out->depth = level;
         out->levels = level;
@@ -1296,6 +1328,101 @@ struct Engine : EngineBase {
     }
     uint64_t kstat_cells = 0;
     uint64_t stop_frontier = 0, run_lo = 0, run_hi = 0;  // run() stops before a level of >= stop_frontier states (0 = never)
+
+    // ------------------------------------------------------------------------------- checkpoint / recover
+    // TLC checkpoints a run into its states/ directory and continues it with -recover (testout1:10: "-- Checkpointing of
+    // run states/01-08-03-18-14-01 completed."; .gitignore:2).  Here the resident arena already IS the state store: a
+    // checkpoint is the arena's used blocks as they lie in HBM, the level boundaries, the counters and (with MC_F_TRACE)
+    // the parent pointers.  The seen-set is not written: recovery re-inserts word 0 of every state (k_reseed_table).
+    struct CkHeader {
+        char magic[8];
+        uint32_t spec_id, nparams;
+        int64_t params[16];
+        uint32_t words, has_trace;
+        uint64_t distinct, generated, cells, lo, hi, nlevels;
+    };
+    bool have_run = false, ck_pending = false;
+    uint64_t last_generated = 0, ck_distinct = 0, ck_generated = 0, ck_cells = 0, ck_lo = 0;
+    std::vector<uint64_t> ck_level_start;
+    bool ck_params_comparable() const { return desc.spec_id != MC_SPEC_PCAL; }  // a compiled program's parameter is a host pointer
+    int dev_to_file(const void *dev, size_t bytes, FILE *f) {
+        std::vector<char> buf(bytes < (64u << 20) ? bytes : (64u << 20));
+        for (size_t off = 0; off < bytes; off += buf.size()) {
+            const size_t n = bytes - off < buf.size() ? bytes - off : buf.size();
+            HIP_TRY(hipMemcpy(buf.data(), (const char *)dev + off, n, hipMemcpyDeviceToHost));
+            if (fwrite(buf.data(), 1, n, f) != n) { set_error("checkpoint: short write"); return MC_EBADCFG; }
+        }
+        return MC_OK;
+    }
+    int file_to_dev(void *dev, size_t bytes, FILE *f) {
+        std::vector<char> buf(bytes < (64u << 20) ? bytes : (64u << 20));
+        for (size_t off = 0; off < bytes; off += buf.size()) {
+            const size_t n = bytes - off < buf.size() ? bytes - off : buf.size();
+            if (fread(buf.data(), 1, n, f) != n) { set_error("restore: the checkpoint file is truncated"); return MC_EPARSE; }
+            HIP_TRY(hipMemcpy((char *)dev + off, buf.data(), n, hipMemcpyHostToDevice));
+        }
+        return MC_OK;
+    }
+    int checkpoint(const char *path) override {
+        if (cfg.shard_count > 1) { set_error("checkpoint: not available for a sharded engine"); return MC_EBADCFG; }
+        if (!have_run || have_viol) { set_error("checkpoint: needs a completed mc_engine_run that stopped on a budget (or finished) without a violation"); return MC_EBADCFG; }
+        HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipDeviceSynchronize());
+        FILE *f = fopen(path, "wb");
+        if (!f) { set_error(std::string("checkpoint: cannot write ") + path); return MC_EBADCFG; }
+        CkHeader h;
+        memset(&h, 0, sizeof h);
+        memcpy(h.magic, "TLAMCCK1", 8);
+        h.spec_id = desc.spec_id;
+        h.nparams = ck_params_comparable() ? desc.nparams : 0;
+        for (uint32_t i = 0; i < h.nparams && i < 16; i++) h.params[i] = desc.params[i];
+        h.words = (uint32_t)W;
+        h.has_trace = d_parent ? 1u : 0u;
+        h.distinct = last_distinct; h.generated = last_generated; h.cells = kstat_cells;
+        h.lo = run_lo; h.hi = run_hi; h.nlevels = level_start.size();
+        int rc = MC_OK;
+        if (fwrite(&h, sizeof h, 1, f) != 1 || fwrite(level_start.data(), sizeof(uint64_t), level_start.size(), f) != level_start.size()) {
+            set_error("checkpoint: short write");
+            rc = MC_EBADCFG;
+        }
+        const size_t blocks = (size_t)((last_distinct + 63) >> 6);
+        if (!rc) rc = dev_to_file(d_arena, blocks * (size_t)W * 64 * sizeof(uint64_t), f);
+        if (!rc && d_parent) rc = dev_to_file(d_parent, (size_t)last_distinct * sizeof(uint32_t), f);
+        if (!rc && d_parent) rc = dev_to_file(d_pslot, (size_t)last_distinct * sizeof(uint16_t), f);
+        if (fclose(f) != 0 && !rc) { set_error("checkpoint: close failed"); rc = MC_EBADCFG; }
+        return rc;
+    }
+    int restore(const char *path) override {
+        if (cfg.shard_count > 1) { set_error("restore: not available for a sharded engine"); return MC_EBADCFG; }
+        FILE *f = fopen(path, "rb");
+        if (!f) { set_error(std::string("restore: cannot read ") + path); return MC_EPARSE; }
+        CkHeader h;
+        int rc = MC_OK;
+        auto fail = [&](int code, const char *msg) { set_error(msg); rc = code; };
+        if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "TLAMCCK1", 8) != 0) fail(MC_EPARSE, "restore: not a checkpoint file");
+        else if (h.spec_id != desc.spec_id || h.words != (uint32_t)W) fail(MC_EBADCFG, "restore: the checkpoint belongs to another spec");
+        else if (ck_params_comparable() && (h.nparams != desc.nparams || memcmp(h.params, desc.params, sizeof(int64_t) * (h.nparams < 16 ? h.nparams : 16)) != 0))
+            fail(MC_EBADCFG, "restore: the checkpoint was written with other constants / invariants");
+        else if (h.distinct > arena_cap) fail(MC_EARENA, "restore: arena_capacity is smaller than the checkpoint");
+        else if (h.hi != h.distinct || h.lo > h.hi || h.nlevels == 0 || h.nlevels >= MC_MAX_LEVELS) fail(MC_EPARSE, "restore: inconsistent header");
+        else if (d_parent && !h.has_trace) fail(MC_EBADCFG, "restore: the checkpoint holds no parent pointers (written without MC_F_TRACE); run without MC_F_TRACE");
+        if (!rc) {
+            ck_level_start.assign((size_t)h.nlevels, 0);
+            if (fread(ck_level_start.data(), sizeof(uint64_t), ck_level_start.size(), f) != ck_level_start.size()) fail(MC_EPARSE, "restore: the checkpoint file is truncated");
+        }
+        if (!rc) {
+            HIP_TRY(hipSetDevice(cfg.device));
+            const size_t blocks = (size_t)((h.distinct + 63) >> 6);
+            rc = file_to_dev(d_arena, blocks * (size_t)W * 64 * sizeof(uint64_t), f);
+            if (!rc && d_parent && h.has_trace) rc = file_to_dev(d_parent, (size_t)h.distinct * sizeof(uint32_t), f);
+            if (!rc && d_parent && h.has_trace) rc = file_to_dev(d_pslot, (size_t)h.distinct * sizeof(uint16_t), f);
+        }
+        fclose(f);
+        if (rc) return rc;
+        ck_distinct = h.distinct; ck_generated = h.generated; ck_cells = h.cells; ck_lo = h.lo;
+        ck_pending = true;  // the next run() continues from here
+        return MC_OK;
+    }
 
     int fetch_state(uint64_t idx, uint64_t *words) {
         const uint64_t *src = d_arena + ((idx >> 6) * (uint64_t)W) * 64 + (idx & 63);
@@ -1887,6 +2014,8 @@ int mc_engine_kernel_stats(mc_engine *e, mc_kernel_stats *out) { return e && out
 int mc_engine_read_states(mc_engine *e, uint64_t first, uint64_t count, uint8_t *out) {
     return e && (out || !count) ? e->impl->read_states(first, count, out) : MC_EBADCFG;
 }
+int mc_engine_checkpoint(mc_engine *e, const char *path) { return e && path ? e->impl->checkpoint(path) : MC_EBADCFG; }
+int mc_engine_restore(mc_engine *e, const char *path) { return e && path ? e->impl->restore(path) : MC_EBADCFG; }
 void mc_engine_destroy(mc_engine *e) {
     if (!e) return;
     delete e->impl;

@@ -697,6 +697,11 @@ int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *
 
 int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
                         mc_result *res, const char *dump_path) {
+    return mc_check_files_ckpt(tla_path, cfg_path, cfg, report, report_cap, res, dump_path, nullptr, nullptr);
+}
+
+int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
+                        mc_result *res, const char *dump_path, const char *recover_path, const char *checkpoint_path) {
     if (!tla_path || !cfg || !report || !report_cap || !res) return MC_EBADCFG;
     report[0] = 0;
     std::string tla, cfgtext, module;
@@ -778,8 +783,11 @@ int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_con
     }
     mc_engine *e = nullptr;
     if ((rc = mc_engine_create(&d, cfg, &e))) return rc;
+    if (recover_path && (rc = mc_engine_restore(e, recover_path))) { mc_engine_destroy(e); return rc; }  // TLC -recover
     rc = mc_engine_run(e, res);
     if (rc) { mc_engine_destroy(e); return rc; }
+    const bool clean = res->verdict == MC_V_OK || res->verdict == MC_V_BUDGET;
+    if (checkpoint_path && clean && (rc = mc_engine_checkpoint(e, checkpoint_path))) { mc_engine_destroy(e); return rc; }
 
     Out o{report, report_cap, 0};
     o.put("Finished computing initial states: %llu distinct state%s generated.\n", (unsigned long long)res->level_distinct[0],
@@ -787,6 +795,7 @@ int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_con
     if (res->verdict == MC_V_OK || res->verdict == MC_V_BUDGET) {
         if (res->verdict == MC_V_OK) o.put("Model checking completed. No error has been found.\n");
         else o.put("Search stopped by the level/state budget; no error has been found so far.\n");
+        if (checkpoint_path) o.put("-- Checkpointing of run %s completed.\n", checkpoint_path);  // testout1:10
         // testout2:261-264: optimistic estimate = (generated - distinct) * distinct / 2^64
         const double opt = (double)(res->generated - res->distinct) * (double)res->distinct / 18446744073709551616.0;
         o.put("  Estimates of the probability that TLC did not check all reachable states\n"

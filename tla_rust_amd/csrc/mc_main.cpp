@@ -4,12 +4,16 @@
 //
 //   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic] [-dump FILE]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
+//            [-checkpoint FILE] [-recover FILE]
 //   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
 //                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
 //                                         the previous text is kept as X.old
 //
 // -generic  : check a PlusCal module through the compiled program even when a hand lowering exists.
 // -dump FILE: like TLC's -dump, write every distinct state found to FILE.
+// -checkpoint FILE / -recover FILE: TLC's checkpointing (testout1:10) and -recover: write the run (all states found, level
+//             boundaries, counters, parent pointers) after a search that stopped on -maxlevels / -maxdistinct without an
+//             error; continue such a run later, with the same X.tla / X.cfg.
 // -deadlock : as with TLC, do NOT check for deadlock.  -workers is accepted and ignored (the
 // GPU is the worker pool).  Exit status: 0 no error, 12 safety violation (invariant / assert),
 // 11 deadlock, 1 any other failure — TLC's convention.
@@ -51,7 +55,7 @@ int main(int argc, char **argv) {
         for (int i = 2; i < argc; i++) rc |= transpile(argv[i]);
         return rc;
     }
-    const char *tla = nullptr, *cfgp = nullptr, *dump = nullptr;
+    const char *tla = nullptr, *cfgp = nullptr, *dump = nullptr, *recover = nullptr, *ckpt = nullptr;
     mc_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.flags = MC_F_DEADLOCK | MC_F_TRACE;
@@ -62,6 +66,8 @@ int main(int argc, char **argv) {
         if (arg("-config")) cfgp = argv[++i];
         else if (!strcmp(argv[i], "-deadlock")) cfg.flags &= ~MC_F_DEADLOCK;
         else if (arg("-dump")) dump = argv[++i];
+        else if (arg("-checkpoint")) ckpt = argv[++i];
+        else if (arg("-recover")) recover = argv[++i];
         else if (arg("-workers")) ++i;
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
         else if (arg("-device")) cfg.device = atoi(argv[++i]);
@@ -77,14 +83,15 @@ int main(int argc, char **argv) {
     if (!tla) {
         fprintf(stderr,
                 "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-device D]\n"
-                "                [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]     check X.tla like `tlc X.tla`\n"
+                "                [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]\n"
+                "                [-checkpoint FILE] [-recover FILE]                                       check X.tla like `tlc X.tla`\n"
                 "       mc --transpile X.tla [Y.tla ...]                                                  translate like `pcal2tla`\n"
                 "exit status: 0 no error, 12 invariant / assertion violated, 11 deadlock, 1 anything else\n");
         return 1;
     }
     std::vector<char> report(1 << 22);
     static mc_result res;
-    const int rc = mc_check_files_dump(tla, cfgp, &cfg, report.data(), report.size(), &res, dump);
+    const int rc = mc_check_files_ckpt(tla, cfgp, &cfg, report.data(), report.size(), &res, dump, recover, ckpt);
     if (rc) {
         fprintf(stderr, "mc: %s: %s\n", mc_strerror(rc), mc_last_error());
         return 1;
