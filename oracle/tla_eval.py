@@ -710,7 +710,12 @@ class Checker:
     def fmt_state(self, s):
         return "\n".join(f"/\\ {v} = {fmt(s[v])}" for v in self.vars)
 
-    def run_levels(self, invariants=(), check_deadlock=True, max_distinct=0, init="Init", nxt="Next"):
+    def in_model(self, s, constraints):
+        """cfg CONSTRAINT (FIFO/MCInnerFIFO.cfg:23-26, p-manual section 4.3 p.36): a state that does not satisfy it is generated
+        and checked, but neither stored nor expanded."""
+        return all(self.ev(self.defs[name][1], s, None, {}) for name in constraints)
+
+    def run_levels(self, invariants=(), check_deadlock=True, max_distinct=0, init="Init", nxt="Next", constraints=()):
         """The engine's convention (include/tlamc.h): a violation does not cut the level short — every state of the
         level is expanded, every enabled successor counted (a failing Assert is one generated successor that is
         not stored), and the search stops at the end of that level.  Also returns the state texts per level."""
@@ -722,13 +727,15 @@ class Checker:
             res["generated"] += 1
             k = self.key(s)
             if k not in seen:
-                seen[k] = 1
-                cur.append(s)
                 if res["verdict"] == "ok":
                     for name in invariants:
                         if not self.ev(self.defs[name][1], s, None, {}):
                             res.update(verdict="invariant", violated=name, trace_len=1)
                             break
+                if not self.in_model(s, constraints):
+                    continue
+                seen[k] = 1
+                cur.append(s)
         level = 1
         while cur:
             res["levels"].append(len(cur))
@@ -748,13 +755,15 @@ class Checker:
                     k = self.key(n)
                     if k in seen:
                         continue
-                    seen[k] = 1
-                    nxt_level.append(n)
                     if res["verdict"] == "ok":
                         for name in invariants:
                             if not self.ev(self.defs[name][1], n, None, {}):
                                 res.update(verdict="invariant", violated=name, trace_len=level + 1)
                                 break
+                    if not self.in_model(n, constraints):
+                        continue
+                    seen[k] = 1
+                    nxt_level.append(n)
                 if nsucc == 0 and check_deadlock and res["verdict"] == "ok":
                     res.update(verdict="deadlock", trace_len=level)
             cur = nxt_level
@@ -767,7 +776,7 @@ class Checker:
         self.engine_mode = False
         return res
 
-    def run(self, invariants=(), check_deadlock=True, max_distinct=0, init="Init", nxt="Next"):
+    def run(self, invariants=(), check_deadlock=True, max_distinct=0, init="Init", nxt="Next", constraints=()):
         """TLC-like BFS.  Returns dict(distinct, generated, queue_left, depth, verdict, violated, trace, levels)."""
         seen, order, parent = {}, [], []
         res = dict(distinct=0, generated=0, queue_left=0, depth=0, verdict="ok", violated=None, trace=[], levels=[], message=None)
@@ -783,6 +792,8 @@ class Checker:
             k = self.key(s)
             if k in seen:
                 return None
+            if not self.in_model(s, constraints):   # generated and checked, not stored (returns -1: check it, do not keep it)
+                return -1
             seen[k] = len(order)
             order.append(s)
             parent.append(par)
@@ -800,7 +811,8 @@ class Checker:
             if i is not None:
                 b = bad_inv(s)
                 if b:
-                    res.update(verdict="invariant", violated=b, trace=trace_to(i), distinct=len(order), depth=1, queue_left=len(order) - 1)
+                    res.update(verdict="invariant", violated=b, trace=trace_to(i) if i >= 0 else [self.fmt_state(s)], distinct=len(order), depth=1,
+                               queue_left=max(0, len(order) - 1))
                     return res
         lo, hi, level = 0, len(order), 1
         res["levels"].append(hi)
@@ -820,7 +832,7 @@ class Checker:
                         if j is not None:
                             b = bad_inv(n)
                             if b:
-                                stop = ("invariant", b, trace_to(j), None)
+                                stop = ("invariant", b, trace_to(j) if j >= 0 else trace_to(i) + [self.fmt_state(n)], None)
                                 break
                 except AssertViolation as a:
                     stop = ("assert", None, trace_to(i), str(a))

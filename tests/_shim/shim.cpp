@@ -244,7 +244,11 @@ extern "C" int shim_pcal_translate(const char *tla_text, char *out, size_t cap) 
     return (int)tr.size();
 }
 // invariants: comma separated names; constants: "N=3,M=2" (integers only)
+extern "C" void *shim_program_compile2(const char *tla_text, const char *invariants, const char *constants, const char *constraints);
 extern "C" void *shim_program_compile(const char *tla_text, const char *invariants, const char *constants) {
+    return shim_program_compile2(tla_text, invariants, constants, "");
+}
+extern "C" void *shim_program_compile2(const char *tla_text, const char *invariants, const char *constants, const char *constraints) {
     pcal::Config cf;
     auto split = [](const char *s, char sep) {
         std::vector<std::string> v;
@@ -256,6 +260,7 @@ extern "C" void *shim_program_compile(const char *tla_text, const char *invarian
         return v;
     };
     cf.invariants = split(invariants, ',');
+    cf.constraints = split(constraints, ',');
     for (const auto &kv : split(constants, ',')) {
         const size_t eq = kv.find('=');
         if (eq == std::string::npos) { g_pcal_error = "bad constant " + kv; return nullptr; }

@@ -139,16 +139,16 @@ def shim_run(spec, params, max_levels=0, max_distinct=0, check_deadlock=True, du
 class ShimProgram:
     """A PlusCal module compiled by the host build of the front-end (tests only)."""
 
-    def __init__(self, tla_text, invariants=(), constants=None):
+    def __init__(self, tla_text, invariants=(), constants=None, constraints=()):
         lib = shim_lib()
-        lib.shim_program_compile.restype = C.c_void_p
-        lib.shim_program_compile.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+        lib.shim_program_compile2.restype = C.c_void_p
+        lib.shim_program_compile2.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
         lib.shim_pcal_error.restype = C.c_char_p
         lib.shim_program_free.argtypes = [C.c_void_p]
         lib.shim_program_translated.restype = C.c_char_p
         lib.shim_program_translated.argtypes = [C.c_void_p]
         consts = ",".join(f"{k}={v}" for k, v in (constants or {}).items())
-        self.h = lib.shim_program_compile(tla_text.encode(), ",".join(invariants).encode(), consts.encode())
+        self.h = lib.shim_program_compile2(tla_text.encode(), ",".join(invariants).encode(), consts.encode(), ",".join(constraints).encode())
         if not self.h:
             raise RuntimeError(lib.shim_pcal_error().decode())
         self.lib = lib

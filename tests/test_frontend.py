@@ -90,6 +90,18 @@ def test_symmetry_resolution(amd):
         amd.spec_resolve("pcal_intro", (ROOT / "specs" / "pcal_intro.cfg").read_text() + "\nSYMMETRY Perms\n")
 
 
+def test_constraint_is_never_silently_ignored(amd):
+    """a CONSTRAINT in the cfg of a hand-lowered PlusCal module is not dropped: the registry declines (the CLI then compiles
+    the module); MCraft accepts exactly its own StateConstraint; the SI models define none"""
+    for module, cfg in (("pcal_intro", "pcal_intro.cfg"), ("atomic_add", "atomic_add.cfg")):
+        with pytest.raises(amd.McError):
+            amd.spec_resolve(module, (ROOT / "specs" / cfg).read_text() + "\nCONSTRAINT Small\n")
+    with pytest.raises(amd.McError):
+        amd.spec_resolve("MCraft", (ROOT / "specs" / "MCraft_small.cfg").read_text() + "\nCONSTRAINT Other\n")
+    with pytest.raises(amd.McError):
+        amd.spec_resolve("MCssi", (ROOT / "specs" / "MCssi_2x2.cfg").read_text() + "\nCONSTRAINT Small\n")
+
+
 def test_cli_is_built():
     import tla_rust_amd.build as b
     b.build()

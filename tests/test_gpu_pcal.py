@@ -58,6 +58,39 @@ def test_compiled_program_on_gpu_vs_tla_evaluator(amd, path, invs, consts):
     prog.close()
 
 
+@pytest.mark.parametrize("bound,invs,verdict", [(6, ["NeverAhead"], "ok"), (40, [], "ok"), (4, ["NeverAhead", "Small"], "invariant")])
+def test_constraint_bounds_an_infinite_algorithm_on_gpu(amd, bound, invs, verdict):
+    """cfg CONSTRAINT for compiled programs: growing_counters has an infinite state space; states outside the constraint are
+    generated and checked, not stored (FIFO/MCInnerFIFO.cfg:23-26).  Same graph as the TLA+ evaluator, level by level."""
+    text = (ROOT / "specs" / "pluscal" / "growing_counters.tla").read_text()
+    prog = amd.Program(text, cfg_text(invs, {"Bound": bound}) + "CONSTRAINT Small\n")
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
+    r = eng.run()
+    o = Checker(prog.translated(), constants={"Bound": bound}).run_levels(invariants=invs, constraints=["Small"])
+    for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+        assert getattr(r, k) == o[k], (k, getattr(r, k), o[k])
+    assert r.verdict == verdict
+    first = 0
+    for lvl, n in enumerate(r.levels):
+        assert sorted(t.replace("\n", " ") for t in eng.state_texts(first, n)) == o["states"][lvl], f"level {lvl + 1}"
+        first += n
+    if verdict == "invariant":
+        tr = eng.trace()
+        assert prog.invariant(r.violated_invariant) == "Small" and len(tr) == bound + 2 and f"produced = {bound + 1}" in tr[-1][1]
+    eng.close()
+    prog.close()
+
+
+def test_mc_reads_constraint_from_the_cfg_beside_the_module():
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "pluscal" / "growing_counters.tla")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    text = (ROOT / "specs" / "pluscal" / "growing_counters.tla").read_text()
+    o = Checker(text, constants={"Bound": 6}).run(invariants=["NeverAhead"], constraints=["Small"])
+    assert "Model checking completed. No error has been found." in p.stdout
+    assert f"{o['generated']} states generated, {o['distinct']} distinct states found, 0 states left on queue." in p.stdout
+
+
 def test_chunking_and_small_tables_do_not_change_the_graph(amd):
     path, invs, consts = CASES[-1]
     prog = amd.Program(path.read_text(), cfg_text(invs, consts))

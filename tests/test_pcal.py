@@ -128,6 +128,42 @@ def test_compiled_program_vs_tla_evaluator(path, invs, consts):
         prog.close()
 
 
+@pytest.mark.parametrize("bound,invs,verdict", [(3, ["NeverAhead"], "ok"), (6, ["NeverAhead"], "ok"), (4, ["NeverAhead", "Small"], "invariant")])
+def test_constraint_bounds_an_infinite_algorithm(bound, invs, verdict):
+    """cfg CONSTRAINT for compiled programs (FIFO/MCInnerFIFO.cfg:23-26, p-manual section 4.3 p.36): growing_counters has an infinite state
+    space; under CONSTRAINT Small the states outside are generated and invariant-checked but neither stored nor expanded.  An
+    INVARIANT that only fails outside the constraint IS reported (TLC checks a successor before it filters it)."""
+    text = (SPECS / "pluscal" / "growing_counters.tla").read_text()
+    consts = {"Bound": bound}
+    prog = helpers.ShimProgram(text, invs, consts, constraints=["Small"])
+    try:
+        fd, dump = tempfile.mkstemp()
+        os.close(fd)
+        r = helpers.shim_run("pcal", prog.params, dump=dump)
+        o = Checker(prog.translated(), constants=consts).run_levels(invariants=invs, constraints=["Small"])
+        for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+            assert r[k] == o[k], (k, r[k], o[k])
+        assert r["verdict"] == verdict
+        if verdict == "invariant":
+            assert invs[r["violated_invariant"]] == o["violated"] == "Small" and r["trace_len"] == bound + 2
+        else:
+            assert r["generated"] > r["distinct"] > 2 * bound
+        states = helpers.read_dump(dump)
+        os.unlink(dump)
+        for lvl, want in enumerate(o["states"], 1):
+            assert states[lvl] == want, f"level {lvl}"
+        assert all("produced = %d" % (bound + 1) not in t for lvl in states.values() for t in lvl) or verdict == "invariant"
+    finally:
+        prog.close()
+
+
+def test_constraint_must_be_a_definition():
+    text = (SPECS / "pluscal" / "growing_counters.tla").read_text()
+    with pytest.raises(RuntimeError) as e:
+        helpers.ShimProgram(text, [], {"Bound": 2}, constraints=["Tiny"])
+    assert "CONSTRAINT Tiny" in str(e.value)
+
+
 def test_compiled_program_vs_hand_lowering():
     """the two root specs have both a hand lowering (spec_pluscal.h) and a compiled program: same graph"""
     for path, hand, invs in [(SPECS / "pcal_intro.tla", ("pcal_intro", [0, 1, 20, 2]), ["MoneyInvariant"]),

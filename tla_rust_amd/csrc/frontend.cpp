@@ -464,6 +464,10 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
     const bool is_ssi = m == "MCssi" || m == "serializableSnapshotIsolation" || m == "MCtextbookSI" || m == "textbookSnapshotIsolation";
     if (!c->symmetry.empty() && !is_ssi)
         return fe_fail(MC_ENOSPEC, "SYMMETRY is supported for the snapshot-isolation models only (their run-book makes Key and TxnId symmetry sets)");
+    // the hand lowerings of the PlusCal root specs know no CONSTRAINT: MC_ENOSPEC sends the module through the compiled-program
+    // path, which evaluates the constraint (or refuses an ACTION-CONSTRAINT) instead of silently ignoring it
+    if ((m == "atomic_add" || m == "atomic_add_n" || m == "pcal_intro") && (!c->constraints.empty() || !c->action_constraints.empty()))
+        return fe_fail(MC_ENOSPEC, "the hand lowering of %s takes no CONSTRAINT / ACTION-CONSTRAINT", module);
     if (m == "atomic_add" || m == "atomic_add_n") {  // atomic_add.tla:4-23; atomic_add_n: N adders (specs/atomic_add_n.tla)
         long long n = 2;
         if (m == "atomic_add_n" && !const_int(c, "N", n)) return fe_fail(MC_EBADCFG, "atomic_add_n needs CONSTANT N = <number>");
@@ -598,13 +602,14 @@ int mc_program_compile(const char *tla_text, const char *cfg_text, mc_program **
         const int rc = mc_cfg_parse(cfg_text, strlen(cfg_text), &c);
         if (rc) return rc;
         cf.invariants = c->invariants;
+        cf.constraints = c->constraints;
         for (const auto &k : c->constants) {
             if (k.replacement) { mc_cfg_free(c); return fe_fail(MC_ENOSPEC, "CONSTANT %s <- ...: definition overrides are not supported for PlusCal programs", k.name.c_str()); }
             cf.constants.push_back({k.name, to_const(k.value)});
         }
-        const bool other = !c->constraints.empty() || !c->action_constraints.empty() || !c->symmetry.empty() || !c->view.empty();
+        const bool other = !c->action_constraints.empty() || !c->symmetry.empty() || !c->view.empty();
         mc_cfg_free(c);
-        if (other) return fe_fail(MC_ENOSPEC, "CONSTRAINT / ACTION-CONSTRAINT / SYMMETRY / VIEW are not supported for PlusCal programs");
+        if (other) return fe_fail(MC_ENOSPEC, "ACTION-CONSTRAINT / SYMMETRY / VIEW are not supported for PlusCal programs");
     }
     const std::string text(tla_text);
     pcal::Module m;

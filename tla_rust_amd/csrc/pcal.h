@@ -102,6 +102,7 @@ struct ConstVal {
 };
 struct Config {
     std::vector<std::string> invariants;                       // INVARIANT names, in cfg order
+    std::vector<std::string> constraints;                      // CONSTRAINT names
     std::vector<std::pair<std::string, ConstVal>> constants;   // CONSTANT name = value
 };
 

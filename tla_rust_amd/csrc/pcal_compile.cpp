@@ -1079,18 +1079,19 @@ struct Compiler {
         P.maxch = (int)maxch;
         if (max_depth > mc::SpecVm::STACK) cfail("an expression is too deeply nested for the interpreter's stack (" + std::to_string(max_depth) + " > " + std::to_string(mc::SpecVm::STACK) + ")");
         // ---- invariants
-        if (cfg.invariants.size() > 8) cfail("at most 8 invariants are supported");
+        if (cfg.invariants.size() + cfg.constraints.size() > 8) cfail("at most 8 invariants + constraints are supported");
         std::vector<int> inv_entry;
-        for (const auto &name : cfg.invariants) {
-            const Definition *def = nullptr;
-            for (const auto &d : m.defs) if (d.name == name && d.params.empty()) def = &d;
-            if (!def) cfail("INVARIANT " + name + " is not a definition of the module this front-end can read");
-            inv_entry.push_back((int)c.size());
-            next_temp = 0;
-            ex(def->body);
-            emit(mc::VM_HALT);
-            P.invariants.push_back(name);
-        }
+        for (int pass = 0; pass < 2; pass++)  // INVARIANTs, then CONSTRAINTs: both are state predicates named by the cfg
+            for (const auto &name : pass == 0 ? cfg.invariants : cfg.constraints) {
+                const Definition *def = nullptr;
+                for (const auto &d : m.defs) if (d.name == name && d.params.empty()) def = &d;
+                if (!def) cfail(std::string(pass == 0 ? "INVARIANT " : "CONSTRAINT ") + name + " is not a definition of the module this front-end can read");
+                inv_entry.push_back((int)c.size());
+                next_temp = 0;
+                ex(def->body);
+                emit(mc::VM_HALT);
+                if (pass == 0) P.invariants.push_back(name);
+            }
         // ---- header
         c[mc::VMH_MAGIC] = mc::VM_MAGIC;
         c[mc::VMH_NV] = nv;
@@ -1099,7 +1100,8 @@ struct Compiler {
         c[mc::VMH_PC_BASE] = P.pc_base;
         c[mc::VMH_DONE] = done;
         c[mc::VMH_INIT_ENTRY] = init_entry;
-        c[mc::VMH_NINV] = (int)inv_entry.size();
+        c[mc::VMH_NINV] = (int)cfg.invariants.size();
+        c[mc::VMH_NCON] = (int)cfg.constraints.size();
         for (size_t k = 0; k < inv_entry.size(); k++) c[(size_t)mc::VMH_INV0 + k] = inv_entry[k];
         c[mc::VMH_LABEL_TAB] = label_tab;
         c[mc::VMH_SELF_TAB] = self_tab;
@@ -1162,6 +1164,7 @@ int vm_make_params(const int64_t *p, unsigned np, VmParams &o) {
     o.done = c[VMH_DONE];
     o.init_entry = c[VMH_INIT_ENTRY];
     o.ninv = c[VMH_NINV];
+    o.ncon = c[VMH_NCON];
     for (int k = 0; k < 8; k++) o.inv_entry[k] = c[VMH_INV0 + k];
     o.label_tab = c[VMH_LABEL_TAB];
     o.self_tab = c[VMH_SELF_TAB];

@@ -32,7 +32,8 @@ enum VmOp : int32_t {
 // header words of the program image
 enum VmHdr : int32_t {
     VMH_MAGIC = 0, VMH_NV, VMH_NINST, VMH_MAXCH, VMH_PC_BASE, VMH_DONE, VMH_INIT_ENTRY, VMH_NINV, VMH_INV0 /* .. +8 */,
-    VMH_LABEL_TAB = VMH_INV0 + 8, VMH_SELF_TAB, VMH_NLABELS, VMH_NUM_INIT_LO, VMH_NUM_INIT_HI, VMH_CODE_LEN, VMH_SIZE
+    VMH_LABEL_TAB = VMH_INV0 + 8, VMH_SELF_TAB, VMH_NLABELS, VMH_NUM_INIT_LO, VMH_NUM_INIT_HI, VMH_CODE_LEN,
+    VMH_NCON /* CONSTRAINTs: entries VMH_INV0 + ninv .. of the same table */, VMH_SIZE
 };
 constexpr int32_t VM_MAGIC = 0x70634c31;  // "pcL1"
 
@@ -45,8 +46,8 @@ int vm_failed_assert(const void *host, const int32_t *vals, int *label);
 struct VmParams {
     const int32_t *code;   // program image: host memory in host builds, device memory inside Engine<SpecVm>
     const void *host;      // pcal::Program (host only)
-    int nv, words, ninst, maxch, pc_base, done, init_entry, ninv, label_tab, self_tab, code_len;
-    int inv_entry[8];
+    int nv, words, ninst, maxch, pc_base, done, init_entry, ninv, ncon, label_tab, self_tab, code_len;
+    int inv_entry[8];      // ninv INVARIANTs, then ncon CONSTRAINTs
     uint64_t num_init;
 };
 
@@ -251,14 +252,24 @@ struct SpecVmT {
     }
     // first violated invariant of the state v[] (or -1); R_ERROR inside an invariant counts as a spec error
     MC_HD static unsigned inv_status(const Params &p, int32_t *v) {
-        for (int k = 0; k < p.ninv; ++k) {
+        unsigned st = 0;
+        for (int k = 0; k < p.ninv && !st; ++k) {
             int32_t res;
             int aux;
             const int r = run(p, p.inv_entry[k], 0, 0, 0, v, res, aux);
             if (r != R_OK) return ST_SPECERR;
-            if (!res) return ST_INVARIANT | (unsigned)k << 8;
+            if (!res) st = ST_INVARIANT | (unsigned)k << 8;
         }
-        return 0;
+        // cfg CONSTRAINT (FIFO/MCInnerFIFO.cfg:23-26, p-manual section 4.3 p.36): a state outside the constraint is generated and
+        // invariant-checked like any other (a violation is reported), but neither stored nor expanded
+        for (int k = p.ninv; k < p.ninv + p.ncon; ++k) {
+            int32_t res;
+            int aux;
+            const int r = run(p, p.inv_entry[k], 0, 0, 0, v, res, aux);
+            if (r != R_OK) return ST_SPECERR;
+            if (!res) return st | ST_OUT_OF_MODEL;
+        }
+        return st;
     }
 
     MC_HD static uint64_t num_init(const Params &p) { return p.num_init; }
