@@ -236,3 +236,26 @@ def test_random_algorithms_compiled_vs_evaluated(block):
             os.unlink(dump)
             prog.close()
     assert checked >= 10
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_algorithms_under_a_constraint(block):
+    """the same two routes under cfg CONSTRAINT Tight (states outside are generated and invariant-checked, not stored)"""
+    checked = pruned = 0
+    for seed in range(300 + block * 20, 300 + block * 20 + 20):
+        text = Gen(seed).module(f"rnd{seed}").replace("\n====\n", f"\nTight == x + y < {K} - 1 /\\ Len(q) <= 1 /\\ Cardinality(s) <= 1\n====\n")
+        try:
+            prog = helpers.ShimProgram(text, ["Small"], {}, constraints=["Tight"])
+        except RuntimeError:
+            continue            # refusals are the subject of the test above
+        try:
+            r = helpers.shim_run("pcal", prog.params, check_deadlock=False)
+            o = Checker(prog.translated()).run_levels(invariants=["Small"], check_deadlock=False, constraints=["Tight"])
+            free = Checker(prog.translated()).run_levels(invariants=["Small"], check_deadlock=False)
+            for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+                assert r[k] == o[k], (seed, k, r[k], o[k], text)
+            checked += 1
+            pruned += o["distinct"] < free["distinct"]
+        finally:
+            prog.close()
+    assert checked >= 10 and pruned >= 5
