@@ -43,6 +43,9 @@ extern "C" {
     pub fn mc_engine_checkpoint(e: *mut mc_engine, path: *const c_char) -> c_int;
     pub fn mc_engine_restore(e: *mut mc_engine, path: *const c_char) -> c_int;
     pub fn mc_engine_destroy(e: *mut mc_engine);
+    // X.tla + X.cfg -> the descriptor mc_engine_create takes (one engine per rank in sharded mode)
+    pub fn mc_resolve_files(tla: *const c_char, cfg_path: *const c_char, flags: u32, out: *mut mc_spec_desc,
+                            prog_out: *mut *mut mc_program) -> c_int;
     pub fn mc_check_files(tla: *const c_char, cfg_path: *const c_char, cfg: *const mc_config, report: *mut c_char,
                           cap: usize, out: *mut mc_result) -> c_int;
     // PlusCal front-end: `pcal2tla` and the compiler to the GPU interpreter (include/tlamc.h)

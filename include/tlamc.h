@@ -238,6 +238,12 @@ void mc_cfg_free(mc_cfg *c);
 int mc_cfg_json(const mc_cfg *c, char *buf, size_t cap);
 /* resolve module + cfg to a lowering; fails with MC_ENOSPEC for modules that are not lowered */
 int mc_spec_resolve(const char *module_name, const mc_cfg *c, mc_spec_desc *out);
+/* the front half of `tlc X.tla` (reference Makefile:6-7, README.md:262,356): read X.tla and the X.cfg beside it (or cfg_path),
+ * pick the lowering (verified against the module text) or compile the PlusCal algorithm, and return the descriptor
+ * mc_engine_create takes — what a multi-GPU host needs to create one engine per rank (mc_shard_*).  flags: MC_F_GENERIC.
+ * *prog_out = the compiled program when the module went through the PlusCal compiler (the descriptor points into it: free
+ * it with mc_program_free after the engines are destroyed), NULL otherwise. */
+int mc_resolve_files(const char *tla_path, const char *cfg_path, unsigned flags, mc_spec_desc *out, mc_program **prog_out);
 /* `tlc X.tla` end to end: read X.tla / X.cfg, run on `cfg->device`, write TLC's report text */
 int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report,
                    size_t report_cap, mc_result *out);

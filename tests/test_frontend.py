@@ -102,6 +102,46 @@ def test_constraint_is_never_silently_ignored(amd):
         amd.spec_resolve("MCssi", (ROOT / "specs" / "MCssi_2x2.cfg").read_text() + "\nCONSTRAINT Small\n")
 
 
+def test_resolve_files_for_a_multi_gpu_host(amd):
+    """mc_resolve_files = the front half of `tlc X.tla` (no GPU needed): the descriptor every rank of a sharded run creates
+    its engine from — same registry, same text checks, same PlusCal compiler as the one-GPU CLI."""
+    S = ROOT / "specs"
+    r = amd.ResolvedSpec(S / "MCssi.tla", S / "MCssi_2x2_sym.cfg")
+    assert (r.spec, r.params[:2], r.params[5]) == ("ssi", [2, 2], 3)
+    r = amd.ResolvedSpec(S / "pcal_intro.tla")                       # X.cfg beside X.tla (README.md:356)
+    assert (r.spec, r.params) == ("pcal_intro", [0, 1, 20, 2])
+    r = amd.ResolvedSpec(S / "readme_variant" / "pcal_intro.tla")    # README.md:220-243: labels A / B
+    assert (r.spec, r.params[0]) == ("pcal_intro", 1)
+    r = amd.ResolvedSpec(S / "MCraft.tla", S / "MCraft_small.cfg")
+    assert r.spec == "raft" and r.params[0] == 2
+    for f in ("peterson.tla", "growing_counters.tla"):               # no hand lowering: compiled (the handle keeps the program)
+        r = amd.ResolvedSpec(S / "pluscal" / f)
+        assert r.spec == "pcal" and r.params[0] != 0
+        r.close()
+    r = amd.ResolvedSpec(S / "pcal_intro.tla", generic=True)
+    assert r.spec == "pcal"
+    r.close()
+    with pytest.raises(amd.McError):
+        amd.ResolvedSpec(ROOT / "include" / "tlamc.h")
+    with pytest.raises(amd.McError):
+        amd.ResolvedSpec(S / "MCssi.tla", S / "MCraft.cfg")
+
+
+def test_multi_gpu_front_door_report_and_options():
+    from tla_rust_amd import mc_multi
+    from tla_rust_amd.binding import Result
+    o = mc_multi.parse(["X.tla", "-config", "Y.cfg", "-maxlevels", "7", "-workers", "8", "-backend", "gloo", "-device", "0"])
+    assert (o["tla"], o["config"], o["maxlevels"], o["backend"], o["device"]) == ("X.tla", "Y.cfg", 7, "gloo", 0)
+    with pytest.raises(SystemExit):
+        mc_multi.parse(["-nonsense"])
+    rep = mc_multi.report(Result(distinct=3800, generated=5850, queue_left=0, depth=5, verdict="ok", levels=[400, 1250, 900, 800, 450]), 8, 0.5)
+    assert "Finished computing initial states: 400 distinct states generated." in rep
+    assert "5850 states generated, 3800 distinct states found, 0 states left on queue." in rep         # README.md:319 format
+    assert "The depth of the complete state graph search is 5." in rep                                 # README.md:320 format
+    rep = mc_multi.report(Result(distinct=10, generated=20, queue_left=3, depth=4, verdict="assert", levels=[1, 2, 3, 4]), 2, 0.1)
+    assert "Assert evaluated to FALSE" in rep and "one GPU" in rep
+
+
 def test_cli_is_built():
     import tla_rust_amd.build as b
     b.build()

@@ -65,3 +65,41 @@ def test_replicated_prefix_on_gpu(oracle, tmp_path, world, until):
                                                          "stay_threshold": 60, "rebalance_ratio": 2.0, "replicate_until": until}, timeout=900)
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert sum(r["shares"]) == o["distinct"]
+
+
+def _mc_multi(world, *args, timeout=300):
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable]
+    if world > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += ["-m", "tla_rust_amd.mc_multi"] + [str(a) for a in args]
+    if world > 1:
+        cmd += ["-backend", "gloo", "-device", "0"]      # one GPU box: the ranks share GPU 0, buckets staged over gloo
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_multi_gpu_front_door(world):
+    """`python -m tla_rust_amd.mc_multi X.tla` = `tlc X.tla` across ranks: TLC's counter / depth lines, TLC's exit codes,
+    the numbers of the one-GPU `mc` (tests/test_frontend.py)."""
+    from pathlib import Path
+    S = Path(__file__).resolve().parent.parent / "specs"
+    small = ["-chunk", 4096, "-tablelog2", 22, "-arena", 1 << 20]
+    p = _mc_multi(world, S / "MCssi.tla", "-config", S / "MCssi_2x2_sym.cfg", *small)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "12558 states generated, 7419 distinct states found, 0 states left on queue." in p.stdout      # SYMMETRY Perms
+    assert "The depth of the complete state graph search is 13." in p.stdout
+    p = _mc_multi(world, S / "MCraft.tla", "-config", S / "MCraft_small.cfg", *small)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "104515 states generated, 13634 distinct states found, 0 states left on queue." in p.stdout
+    p = _mc_multi(world, S / "pluscal" / "peterson.tla", *small)                                         # compiled PlusCal program
+    assert p.returncode == 0 and "58 distinct states found" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    p = _mc_multi(world, S / "readme_variant" / "pcal_intro.tla", *small)                                # README.md:267-321: the assertion fails
+    assert p.returncode == 12 and "Assert evaluated to FALSE" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

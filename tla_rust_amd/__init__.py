@@ -5,5 +5,5 @@ HIP kernels for gfx950).  There is no CPU fallback: importing works anywhere (so
 front-end and the symbol table can be tested without a GPU), but every compute entry point
 raises if the shared library is missing or no HIP device is present.
 """
-from .binding import (Engine, McError, Program, Result, SPEC_IDS, VERDICTS, cfg_parse, check_files, device_count, lib,  # noqa: F401
+from .binding import (Engine, McError, Program, ResolvedSpec, Result, SPEC_IDS, VERDICTS, cfg_parse, check_files, device_count, lib,  # noqa: F401
                       pcal_translate, spec_desc, spec_resolve, state_bytes, state_format)

@@ -111,6 +111,8 @@ def lib():
         L.mc_cfg_free.restype = None
         L.mc_cfg_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.mc_spec_resolve.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(SpecDesc)]
+        if hasattr(L, "mc_resolve_files"):
+            L.mc_resolve_files.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(SpecDesc), C.POINTER(C.c_void_p)]
         L.mc_check_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Config), C.c_char_p, C.c_size_t, C.POINTER(CResult)]
     if hasattr(L, "mc_program_compile"):
         L.mc_pcal_translate.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
@@ -352,6 +354,25 @@ def spec_resolve(module: str, cfg_text: str):
         return int(d.spec_id), [int(d.params[i]) for i in range(d.nparams)]
     finally:
         lib().mc_cfg_free(h)
+
+
+class ResolvedSpec:
+    """mc_resolve_files: X.tla + X.cfg -> (spec name, params) for Engine / sharded.ShardedChecker.  Keeps the compiled
+    PlusCal program (if any) alive; close() after the engines."""
+
+    def __init__(self, tla_path, cfg_path=None, generic=False):
+        d, prog = SpecDesc(), C.c_void_p()
+        _check(lib().mc_resolve_files(str(tla_path).encode(), str(cfg_path).encode() if cfg_path else None,
+                                      128 if generic else 0, C.byref(d), C.byref(prog)), "mc_resolve_files")
+        names = {v: k for k, v in SPEC_IDS.items()}
+        self.spec = names[int(d.spec_id)]
+        self.params = [int(d.params[i]) for i in range(d.nparams)]
+        self._prog = prog
+
+    def close(self):
+        if self._prog:
+            lib().mc_program_free(self._prog)
+            self._prog = C.c_void_p()
 
 
 def check_files(tla_path, cfg_path=None, device=0, **kw):

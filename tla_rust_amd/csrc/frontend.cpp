@@ -705,11 +705,21 @@ int mc_check_files_dump(const char *tla_path, const char *cfg_path, const mc_con
     return mc_check_files_ckpt(tla_path, cfg_path, cfg, report, report_cap, res, dump_path, nullptr, nullptr);
 }
 
-int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
-                        mc_result *res, const char *dump_path, const char *recover_path, const char *checkpoint_path) {
-    if (!tla_path || !cfg || !report || !report_cap || !res) return MC_EBADCFG;
-    report[0] = 0;
-    std::string tla, cfgtext, module;
+// The front half of `tlc X.tla`: X.tla + X.cfg -> the lowering's descriptor (verified against the module text), or a compiled
+// PlusCal program.  Shared by mc_check_files (one GPU) and mc_resolve_files (one engine per rank in sharded mode).
+namespace {
+struct Resolved {
+    mc_spec_desc d;
+    mc_program *prog = nullptr;
+    std::string tla, module, def_text, def_module_name;  // def_*: text + name of the module that holds the action definitions
+    ~Resolved() { if (prog) mc_program_free(prog); }
+};
+}  // namespace
+static int resolve_files(const char *tla_path, const char *cfg_path, unsigned flags, Resolved &R) {
+    std::string &tla = R.tla, &module = R.module, &def_text = R.def_text, &def_module_name = R.def_module_name;
+    mc_spec_desc &d = R.d;
+    mc_program *&prog = R.prog;
+    std::string cfgtext;
     if (!read_file(tla_path, tla)) return fe_fail(MC_EPARSE, "cannot read %s", tla_path);
     if (!module_name(tla, module)) return fe_fail(MC_EPARSE, "%s: no MODULE header", tla_path);
     std::string cpath;
@@ -727,14 +737,13 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     mc_cfg *c = nullptr;
     int rc = mc_cfg_parse(cfgtext.c_str(), cfgtext.size(), &c);
     if (rc) return rc;
-    mc_spec_desc d;
     memset(&d, 0, sizeof d);
     // A PlusCal module goes through the hand lowering when its algorithm text is one the registry knows, and
     // through the compiled program (spec_vm.h) otherwise — or always with MC_F_GENERIC (A/B of the two paths).
-    std::string part, def_text, def_module_name;  // text + name of the module that holds the action definitions
+    std::string part;
     const bool has_alg = algorithm_text(tla, part);
     const uint64_t alg_hash = has_alg ? text_hash(part) : 0;
-    bool generic = has_alg && (cfg->flags & MC_F_GENERIC);
+    bool generic = has_alg && (flags & MC_F_GENERIC);
     if (!generic) {
         rc = mc_spec_resolve(module.c_str(), c, &d);
         if (rc == MC_ENOSPEC && has_alg) generic = true;
@@ -744,8 +753,6 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     }
     const std::string symmetry_name = c->symmetry;
     mc_cfg_free(c);
-    mc_program *prog = nullptr;
-    struct ProgGuard { mc_program *&p; ~ProgGuard() { if (p) mc_program_free(p); } } prog_guard{prog};
     if (generic) {
         if ((rc = mc_program_compile(tla.c_str(), cfgtext.c_str(), &prog))) return rc;
         mc_program_spec(prog, &d);
@@ -786,6 +793,32 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
             if (module != base) { def_text = ssi; def_module_name = base; }
         }
     }
+    return MC_OK;
+}
+
+int mc_resolve_files(const char *tla_path, const char *cfg_path, unsigned flags, mc_spec_desc *out, mc_program **prog_out) {
+    if (!tla_path || !out || !prog_out) return MC_EBADCFG;
+    *prog_out = nullptr;
+    Resolved R;
+    const int rc = resolve_files(tla_path, cfg_path, flags, R);
+    if (rc) return rc;
+    *out = R.d;
+    *prog_out = R.prog;  // the descriptor of a compiled program points into it: the caller frees it after its engines
+    R.prog = nullptr;
+    return MC_OK;
+}
+
+int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
+                        mc_result *res, const char *dump_path, const char *recover_path, const char *checkpoint_path) {
+    if (!tla_path || !cfg || !report || !report_cap || !res) return MC_EBADCFG;
+    report[0] = 0;
+    Resolved R;
+    int rc = resolve_files(tla_path, cfg_path, cfg->flags, R);
+    if (rc) return rc;
+    const mc_spec_desc &d = R.d;
+    const std::string &tla = R.tla, &module = R.module, &def_text = R.def_text, &def_module_name = R.def_module_name;
+    mc_program *const prog = R.prog;
+    const bool generic = prog != nullptr;  // the module went through the PlusCal compiler
     mc_engine *e = nullptr;
     if ((rc = mc_engine_create(&d, cfg, &e))) return rc;
     if (recover_path && (rc = mc_engine_restore(e, recover_path))) { mc_engine_destroy(e); return rc; }  // TLC -recover
