@@ -8,7 +8,8 @@ through the C ABI exactly like the one-GPU `mc` (mc_resolve_files: same lowering
 PlusCal compiler), creates its engine and runs tla_rust_amd.sharded.ShardedChecker; rank 0 prints TLC's report lines
 (reference README.md:319-320, testout2:260-266).  Counters, depth and verdict are those of the one-GPU run; a
 counterexample is not rebuilt across ranks — on an error the report says so and `mc X.tla` on one GPU prints the trace.
-Without a launcher (no WORLD_SIZE) it runs one rank.  `-backend gloo -device 0` puts several ranks on ONE GPU (tests)."""
+Exit status of every rank: TLC's (0 / 12 safety violation / 11 deadlock); torch.distributed.run itself returns 1 when its
+ranks exit non-zero.  Without a launcher (no WORLD_SIZE) it runs one rank.  `-backend gloo -device 0` puts several ranks on ONE GPU (tests)."""
 import os
 import sys
 import time
