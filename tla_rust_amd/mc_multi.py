@@ -78,6 +78,9 @@ def main(argv=None):
     rs = ResolvedSpec(o["tla"], o["config"], generic=o["generic"])
     chk = ShardedChecker(rs.spec, rs.params, device=device, chunk_states=o["chunk"], max_distinct=o["maxdistinct"], max_levels=o["maxlevels"],
                          table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"])
+    if launched:  # communicator set-up (RCCL builds its rings on the first collective) stays out of the reported time
+        dist.all_reduce(torch.zeros(1, device="cpu" if o["backend"] == "gloo" else f"cuda:{device}"))
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     r = chk.run()
     torch.cuda.synchronize()
