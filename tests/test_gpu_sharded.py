@@ -103,6 +103,9 @@ def test_multi_gpu_front_door(world):
     assert p.returncode == 0 and "58 distinct states found" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
     p = _mc_multi(world, S / "readme_variant" / "pcal_intro.tla", *small)                                # README.md:267-321: the assertion fails
     assert "Assert evaluated to FALSE" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    # the counterexample comes from a one-GPU re-run bounded to the error's depth: the README's 6-state behavior
+    assert '"Failure of assertion at line 16, column 4."' in p.stdout and p.stdout.count("\nState ") == 6       # README.md:269-311
+    assert "counterexample rebuilt by a one-GPU run" in p.stdout
     if world == 1:
         assert p.returncode == 12                     # TLC's exit code for a safety violation
     else:                                             # every rank exits 12; the launcher itself reports 1

@@ -1341,6 +1341,10 @@ struct Engine : EngineBase {
         uint32_t words, has_trace;
         uint64_t distinct, generated, cells, lo, hi, nlevels;
     };
+    struct FileCloser {
+        FILE *f;
+        ~FileCloser() { if (f) fclose(f); }
+    };
     bool have_run = false, ck_pending = false;
     uint64_t last_generated = 0, ck_distinct = 0, ck_generated = 0, ck_cells = 0, ck_lo = 0;
     std::vector<uint64_t> ck_level_start;
@@ -1370,6 +1374,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipDeviceSynchronize());
         FILE *f = fopen(path, "wb");
         if (!f) { set_error(std::string("checkpoint: cannot write ") + path); return MC_EBADCFG; }
+        FileCloser closer{f};  // early returns (HIP errors) must not leak the handle
         CkHeader h;
         memset(&h, 0, sizeof h);
         memcpy(h.magic, "TLAMCCK1", 8);
@@ -1389,6 +1394,7 @@ struct Engine : EngineBase {
         if (!rc) rc = dev_to_file(d_arena, blocks * (size_t)W * 64 * sizeof(uint64_t), f);
         if (!rc && d_parent) rc = dev_to_file(d_parent, (size_t)last_distinct * sizeof(uint32_t), f);
         if (!rc && d_parent) rc = dev_to_file(d_pslot, (size_t)last_distinct * sizeof(uint16_t), f);
+        closer.f = nullptr;
         if (fclose(f) != 0 && !rc) { set_error("checkpoint: close failed"); rc = MC_EBADCFG; }
         return rc;
     }
@@ -1396,6 +1402,7 @@ struct Engine : EngineBase {
         if (cfg.shard_count > 1) { set_error("restore: not available for a sharded engine"); return MC_EBADCFG; }
         FILE *f = fopen(path, "rb");
         if (!f) { set_error(std::string("restore: cannot read ") + path); return MC_EPARSE; }
+        FileCloser closer{f};
         CkHeader h;
         int rc = MC_OK;
         auto fail = [&](int code, const char *msg) { set_error(msg); rc = code; };
@@ -1417,7 +1424,6 @@ struct Engine : EngineBase {
             if (!rc && d_parent && h.has_trace) rc = file_to_dev(d_parent, (size_t)h.distinct * sizeof(uint32_t), f);
             if (!rc && d_parent && h.has_trace) rc = file_to_dev(d_pslot, (size_t)h.distinct * sizeof(uint16_t), f);
         }
-        fclose(f);
         if (rc) return rc;
         ck_distinct = h.distinct; ck_generated = h.generated; ck_cells = h.cells; ck_lo = h.lo;
         ck_pending = true;  // the next run() continues from here

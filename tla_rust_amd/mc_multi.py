@@ -7,7 +7,10 @@ One process per GPU (LOCAL_RANK), `torch.distributed` backend "nccl" (= RCCL ove
 through the C ABI exactly like the one-GPU `mc` (mc_resolve_files: same lowering registry, same text verification, same
 PlusCal compiler), creates its engine and runs tla_rust_amd.sharded.ShardedChecker; rank 0 prints TLC's report lines
 (reference README.md:319-320, testout2:260-266).  Counters, depth and verdict are those of the one-GPU run; a
-counterexample is not rebuilt across ranks — on an error the report says so and `mc X.tla` on one GPU prints the trace.
+counterexample is not rebuilt across ranks (a state's parent may live on another GPU): on an error rank 0 re-runs the search
+on its own GPU bounded to the depth at which the sharded search found the error — a breadth-first search finds a shortest
+counterexample, so the bounded one-GPU run finds one of the same length — and prints that run's TLC report (error, behavior,
+counters); if those levels do not fit one GPU the report says so.
 Exit status of every rank: TLC's (0 / 12 safety violation / 11 deadlock); torch.distributed.run itself returns 1 when its
 ranks exit non-zero.  Without a launcher (no WORLD_SIZE) it runs one rank.  `-backend gloo -device 0` puts several ranks on ONE GPU (tests)."""
 import os
@@ -85,13 +88,24 @@ def main(argv=None):
     r = chk.run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if rank == 0:
-        sys.stdout.write(report(r, world, dt))
-        sys.stdout.flush()
     chk.close()
     rs.close()
     if launched:
-        dist.destroy_process_group()
+        dist.destroy_process_group()  # before rank 0's (possibly long) one-GPU re-run: the other ranks are done
+    if rank == 0:
+        text = report(r, world, dt)
+        if r.verdict not in ("ok", "budget") and not o["generic"]:
+            try:  # the counterexample: one GPU, the same search bounded to the error's depth
+                from . import check_files
+                one, rep = check_files(o["tla"], o["config"], device=device, max_levels=r.depth + 1, chunk_states=o["chunk"],
+                                       table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"])
+                if one.verdict == r.verdict:
+                    text = rep + f"(counterexample rebuilt by a one-GPU run bounded to depth {r.depth + 1}; the sharded search on {world} GPU" \
+                                 f"{'s' if world != 1 else ''} had generated {r.generated} states, {r.distinct} distinct)\n"
+            except Exception as e:  # noqa: BLE001 — e.g. the levels do not fit one GPU's arena: keep the sharded report
+                text += f"(one-GPU re-run for the counterexample failed: {e})\n"
+        sys.stdout.write(text)
+        sys.stdout.flush()
     return 0 if r.verdict in ("ok", "budget") else 11 if r.verdict == "deadlock" else 12     # TLC's exit codes, like `mc`
 
 
