@@ -1034,7 +1034,14 @@ struct Engine : EngineBase {
         use_matrix = (cfg.flags & MC_F_MATRIX) != 0;
         HIP_TRY(hipSetDevice(cfg.device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        {   // A/B knob (measured in DESIGN.md section 4): TLAMC_PRIO=1 gives the materialise stream the highest priority, =2 the lowest
+            const char *pe = getenv("TLAMC_PRIO");
+            int lo_p = 0, hi_p = 0;
+            hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);  // lo_p = least, hi_p = greatest priority (numerically smaller)
+            if (pe && *pe == '1') HIP_TRY(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, hi_p));
+            else if (pe && *pe == '2') HIP_TRY(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, lo_p));
+            else HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        }
         for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&ev_e[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ev_m[i], hipEventDisableTiming)); }
         table_cap = round_pow2(cfg.table_capacity ? cfg.table_capacity : (1ull << 24));
         arena_cap = cfg.arena_capacity ? cfg.arena_capacity : (1ull << 22);
