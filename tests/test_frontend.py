@@ -142,6 +142,24 @@ def test_multi_gpu_front_door_report_and_options():
     assert "Assert evaluated to FALSE" in rep and "one GPU" in rep      # replaced by the bounded one-GPU re-run's report when that fits
 
 
+def test_mc_gpus_hands_over_to_the_multi_process_front_door(tmp_path):
+    """`mc X.tla -gpus P` replaces itself by torch.distributed.run -m tla_rust_amd.mc_multi (found through the binary's own
+    location, whatever the working directory).  Without a GPU the ranks refuse loudly — there is no CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_sharded.py")
+    import tla_rust_amd.build as b
+    b.build()
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(ROOT / "specs" / "MCssi_2x2_sym.cfg"), "-gpus", "1"],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert p.returncode != 0 and "no HIP device visible" in p.stderr + p.stdout
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "2", "-dump", "x"], capture_output=True, text=True)
+    assert p.returncode == 1 and "not available with -gpus" in p.stderr
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "0"], capture_output=True, text=True)
+    assert p.returncode == 1
+
+
 def test_cli_is_built():
     import tla_rust_amd.build as b
     b.build()

@@ -110,3 +110,15 @@ def test_multi_gpu_front_door(world):
         assert p.returncode == 12                     # TLC's exit code for a safety violation
     else:                                             # every rank exits 12; the launcher itself reports 1
         assert p.returncode != 0 and "exitcode  : 12" in p.stderr
+
+
+def test_mc_gpus_option():
+    """`mc X.tla -gpus 1`: the C++ CLI hands over to the multi-process front door (RCCL, world 1 on this box)"""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([str(root / "tla_rust_amd" / "_build" / "mc"), str(root / "specs" / "MCssi.tla"), "-config",
+                        str(root / "specs" / "MCssi_2x2_sym.cfg"), "-gpus", "1", "-tablelog2", "22", "-arena", "1048576", "-chunk", "4096"],
+                       capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "12558 states generated, 7419 distinct states found, 0 states left on queue." in p.stdout

@@ -4,7 +4,7 @@
 //
 //   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic] [-dump FILE]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
-//            [-checkpoint FILE] [-recover FILE]
+//            [-checkpoint FILE] [-recover FILE] [-gpus P]
 //   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
 //                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
 //                                         the previous text is kept as X.old
@@ -14,12 +14,17 @@
 // -checkpoint FILE / -recover FILE: TLC's checkpointing (testout1:10) and -recover: write the run (all states found, level
 //             boundaries, counters, parent pointers) after a search that stopped on -maxlevels / -maxdistinct without an
 //             error; continue such a run later, with the same X.tla / X.cfg.
+// -gpus P   : the search sharded over P GPUs of this node (one process per GPU, RCCL): mc replaces itself by
+//             `python3 -m torch.distributed.run --nproc-per-node P -m tla_rust_amd.mc_multi X.tla <the other options>`
+//             (tla_rust_amd/mc_multi.py; same report lines and exit codes).
 // -deadlock : as with TLC, do NOT check for deadlock.  -workers is accepted and ignored (the
 // GPU is the worker pool).  Exit status: 0 no error, 12 safety violation (invariant / assert),
 // 11 deadlock, 1 any other failure — TLC's convention.
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <string>
 #include <vector>
@@ -49,7 +54,43 @@ static int transpile(const char *path) {
     return 0;
 }
 
+// mc X.tla -gpus P ...: hand over to the multi-process front door.  The package root is two directories above this
+// binary (tla_rust_amd/_build/mc).
+static int exec_multi(int gpus, int argc, char **argv) {
+    char exe[PATH_MAX];
+    const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+    if (n <= 0) { fprintf(stderr, "mc: cannot locate the package root for -gpus\n"); return 1; }
+    exe[n] = 0;
+    std::string root(exe);
+    for (int up = 0; up < 3; up++) { const size_t s = root.rfind('/'); if (s == std::string::npos) break; root.resize(s); }
+    const char *pp = getenv("PYTHONPATH");
+    setenv("PYTHONPATH", pp && *pp ? (root + ":" + pp).c_str() : root.c_str(), 1);
+    const char *port = getenv("MASTER_PORT");
+    std::vector<std::string> a = {"python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=" + std::to_string(gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", port && *port ? port : "29517", "-m", "tla_rust_amd.mc_multi"};
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "-gpus")) { ++i; continue; }
+        if (!strcmp(argv[i], "-deadlock") || !strcmp(argv[i], "-dump") || !strcmp(argv[i], "-checkpoint") || !strcmp(argv[i], "-recover")) {
+            fprintf(stderr, "mc: %s is not available with -gpus\n", argv[i]);
+            return 1;
+        }
+        a.push_back(argv[i]);
+    }
+    std::vector<char *> v;
+    for (auto &x : a) v.push_back(&x[0]);
+    v.push_back(nullptr);
+    execvp(v[0], v.data());
+    perror("mc: cannot start python3");
+    return 1;
+}
+
 int main(int argc, char **argv) {
+    for (int i = 1; i + 1 < argc; i++)
+        if (!strcmp(argv[i], "-gpus")) {
+            const int g = atoi(argv[i + 1]);
+            if (g < 1 || g > 64) { fprintf(stderr, "mc: -gpus needs a number of GPUs\n"); return 1; }
+            return exec_multi(g, argc, argv);
+        }
     if (argc >= 2 && (!strcmp(argv[1], "--transpile") || !strcmp(argv[1], "-transpile"))) {
         int rc = argc > 2 ? 0 : 1;
         for (int i = 2; i < argc; i++) rc |= transpile(argv[i]);
@@ -84,7 +125,7 @@ int main(int argc, char **argv) {
         fprintf(stderr,
                 "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-device D]\n"
                 "                [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]\n"
-                "                [-checkpoint FILE] [-recover FILE]                                       check X.tla like `tlc X.tla`\n"
+                "                [-checkpoint FILE] [-recover FILE] [-gpus P]                             check X.tla like `tlc X.tla`\n"
                 "       mc --transpile X.tla [Y.tla ...]                                                  translate like `pcal2tla`\n"
                 "exit status: 0 no error, 12 invariant / assertion violated, 11 deadlock, 1 anything else\n");
         return 1;

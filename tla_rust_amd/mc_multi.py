@@ -73,6 +73,8 @@ def main(argv=None):
     launched = "WORLD_SIZE" in os.environ
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = o["device"] if o["device"] is not None else local
+    if not torch.cuda.is_available():
+        raise SystemExit("mc_multi: no HIP device visible — the checker has no CPU fallback")
     torch.cuda.set_device(device)
     if launched:
         dist.init_process_group(o["backend"])
