@@ -75,6 +75,21 @@ def test_ssi_symmetry_orbit_counts(oracle):
         assert both["distinct"] <= part["distinct"]
 
 
+@pytest.mark.parametrize("params", [[2, 2, 127, 0], [3, 1, 127, 0], [2, 2, 127, 0, 1]])
+def test_ssi_symmetry_representatives_are_reachable_states(oracle, shim, tmp_path, params):
+    """The orbit representative the device lowering stores is itself a reachable state of the UNREDUCED graph, on the same
+    BFS level (so a counterexample under SYMMETRY is a behaviour of the spec, not a relabelled one)."""
+    base = params + [0] * (5 - len(params))
+    fd, sd = str(tmp_path / "full.txt"), str(tmp_path / "sym.txt")
+    oracle.oracle_run("ssi", base + [0], dump=fd)
+    shim.shim_run("ssi", base + [3], dump=sd)
+    full, sym = oracle.read_dump(fd), shim.read_dump(sd)
+    assert len(full) == len(sym)
+    for lvl in sym:
+        assert set(sym[lvl]) <= set(full[lvl]), lvl
+        assert len(sym[lvl]) <= len(full[lvl])
+
+
 @pytest.mark.parametrize("params,maxd", [([3, 2, 127, 0, 0, 3], 200000), ([4, 3, 127, 0, 0, 3], 60000), ([4, 2, 127, 0, 0, 1], 60000),
                                          ([3, 3, 127, 0, 1, 3], 100000)])
 def test_ssi_symmetry_prefix(oracle, shim, params, maxd):
