@@ -406,6 +406,17 @@ class Fn:
         return [a for a, _ in self.items] == list(range(1, len(self.items) + 1))
 
 
+class MV(str):
+    """a model value (cfg `c = c`): equal only to itself, printed bare"""
+    def __eq__(self, o):
+        return isinstance(o, MV) and str.__eq__(self, o)
+
+    def __ne__(self, o):
+        return not self.__eq__(o)
+
+    __hash__ = str.__hash__
+
+
 def sort_key(v):
     if isinstance(v, bool):
         return (0, int(v))
@@ -419,6 +430,8 @@ def sort_key(v):
 
 
 def fmt(v):
+    if isinstance(v, MV):
+        return str(v)
     if isinstance(v, bool):
         return "TRUE" if v else "FALSE"
     if isinstance(v, int):
@@ -448,6 +461,8 @@ class Checker:
         self.vars = self.m.variables
         self.defs = self.m.defs
         self.consts = dict(constants or {})
+        if "defaultInitValue" in self.m.constants and "defaultInitValue" not in self.consts:
+            self.consts["defaultInitValue"] = MV("defaultInitValue")   # the cfg line TLC needs: defaultInitValue = defaultInitValue
 
     # ---- value expressions.  env = (state dict, next dict or None, bound dict)
     def ev(self, e, st, nx, bd):

@@ -42,6 +42,8 @@ CASES = [
     (SPECS / "pluscal" / "bounded_queue.tla", ["Bounded", "Fifo"], {"Items": 3, "MaxQ": 2, "Consumers": 2}),   # ... assert fails
     (SPECS / "pluscal" / "wait_set.tla", ["Disjoint", "HolderNotWaiting", "Counted"], {"N": 3}),               # set variables
     (SPECS / "pluscal" / "swap.tla", [], {}),                                                                  # a := e || b := f
+    (SPECS / "pluscal" / "scratch_locals.tla", ["AtMostN"], {"N": 2}),      # `variable tmp;`: defaultInitValue
+    (SPECS / "pluscal" / "scratch_locals.tla", ["AtMostN"], {"N": 3}),
 ]
 
 
@@ -188,13 +190,43 @@ MODULE = "---- MODULE t ----\nEXTENDS Naturals\n(* --algorithm t\n%s\nend algori
     ("variables x = 0;\nbegin\nA: x := 1 || x := 2;", "two assignments to x"),
     ("variables x = 0;\nbegin\nA: if x = 0 then B: x := 1; end if; x := 2;", "needs a label"),
     ("variables x = 0;\nbegin\nA: y := 1;", "undeclared variable y"),
-    ("variables x;\nbegin\nA: skip;", "needs an initial value"),
     ("variables x = 0;\nbegin\nA: while x < 2 do x := x + 1; end while; B: call f();", "not supported"),
 ])
 def test_refusals_are_explained(body, needle):
     with pytest.raises(RuntimeError) as e:
         helpers.ShimProgram(MODULE % body)
     assert needle in str(e.value)
+
+
+def test_uninitialised_variables_translate_to_defaultInitValue():
+    """`variable x;` (p-manual section 3.3): CONSTANT defaultInitValue + `x = defaultInitValue` in Init; the compiled program
+    prints the model value bare like TLC, and READING a variable that still holds it is an evaluation error, not garbage."""
+    text = (SPECS / "pluscal" / "scratch_locals.tla").read_text()
+    tr = helpers.pcal_translate(strip_translation(text))
+    assert "\\* BEGIN TRANSLATION\nCONSTANT defaultInitValue\nVARIABLES cell, winner, spare, pc, tmp, seen" in tr
+    assert "/\\ winner = defaultInitValue" in tr and "/\\ tmp = [self \\in 1..N |-> defaultInitValue]" in tr
+    prog = helpers.ShimProgram(text, ["AtMostN"], {"N": 2})
+    fd, dump = tempfile.mkstemp()
+    os.close(fd)
+    r = helpers.shim_run("pcal", prog.params, dump=dump)
+    states = helpers.read_dump(dump)
+    os.unlink(dump)
+    prog.close()
+    assert r["verdict"] == "ok"
+    assert states[1] == ['/\\ cell = 0 /\\ winner = defaultInitValue /\\ spare = defaultInitValue /\\ pc = <<"R", "R">> '
+                         '/\\ tmp = <<defaultInitValue, defaultInitValue>> /\\ seen = <<defaultInitValue, defaultInitValue>>']
+    assert all("spare = defaultInitValue" in t for lvl in states.values() for t in lvl)          # never assigned
+    assert any("seen = <<FALSE, TRUE>>" in t or "seen = <<TRUE, FALSE>>" in t for lvl in states.values() for t in lvl)   # typed by its first assignment
+    early = MODULE % "variables x, y = 0;\nbegin\nA: y := x + 1;"
+    prog = helpers.ShimProgram(early)
+    assert helpers.shim_run("pcal", prog.params)["verdict"] == "spec-error"
+    prog.close()
+    with pytest.raises(RuntimeError) as e:
+        helpers.ShimProgram(MODULE % "variables x;\nbegin\nA: if x = defaultInitValue then x := 1; end if;")
+    assert "defaultInitValue can only be" in str(e.value)
+    with pytest.raises(RuntimeError) as e:
+        helpers.ShimProgram(MODULE % "variables x;\nbegin\nA: x := <<1>>;")
+    assert "without an initial value" in str(e.value)
 
 
 def test_sequence_longer_than_its_cells_is_an_error_not_a_truncation():

@@ -300,7 +300,14 @@ struct Parser {
             d.name = t[i++].s;
             if (is_sym("=")) { i++; d.init = expr(0); }
             else if (is_sym("\\in")) { i++; d.in_set = true; d.init = expr(0); }
-            else fail("variable `" + d.name + "` needs an initial value (`= e` or `\\in S`): defaultInitValue is not supported");
+            else {  // `variable x;` — pcal2tla initialises it to the model value defaultInitValue (p-manual section 3.3)
+                d.no_init = true;
+                auto e = std::make_shared<Expr>();
+                e->k = Expr::ID;
+                e->s = "defaultInitValue";
+                e->pos = d.pos;
+                d.init = e;
+            }
             v.push_back(d);
             if (is_sym(",") || is_sym(";")) i++;
         }
@@ -1205,6 +1212,10 @@ std::string translate(const Module &m) {
     vars.push_back("pc");
     for (const auto &p : m.procs) for (const auto &l : p.locals) vars.push_back(l.name);
     auto join = [](const std::vector<std::string> &v, const char *sep) { std::string s; for (size_t i = 0; i < v.size(); i++) s += (i ? sep : "") + v[i]; return s; };
+    bool any_default = false;
+    for (const auto &g : m.globals) any_default |= g.no_init;
+    for (const auto &p : m.procs) for (const auto &l : p.locals) any_default |= l.no_init;
+    if (any_default) o += "CONSTANT defaultInitValue\n";
     o += "VARIABLES " + join(vars, ", ") + "\n\n";
     o += "vars == << " + join(vars, ", ") + " >>\n\n";
     Ctx none;

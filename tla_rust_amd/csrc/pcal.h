@@ -45,6 +45,7 @@ struct Stmt {
 struct VarDecl {
     std::string name;
     bool in_set = false;   // `x \in S` instead of `x = e`
+    bool no_init = false;  // `variable x;`: the translation initialises it to the model value defaultInitValue
     EP init;
     Pos pos;
 };
@@ -114,6 +115,7 @@ struct VarInfo {
     char type = 'i';          // 'i' integer, 'b' boolean, 's' interned string (of the elements for array / seq)
     bool set = false;         // a set of naturals 0..31 (or of interned strings), one cell holding the 32-bit mask
     bool seq = false;         // a bounded sequence: cell `base` = Len, then `cap` element cells
+    bool defval = false;      // declared without an initial value: a cell holding VM_DEFAULT_INIT prints as defaultInitValue
     int cap = 0;
 };
 

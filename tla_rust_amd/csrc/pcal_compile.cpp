@@ -36,6 +36,18 @@ void all_labels(const std::vector<SP> &v, std::vector<std::string> &out) {
     }
 }
 
+// the right-hand side of the first `name := e` (whole variable or name[self]) in a statement list, or null
+const Expr *first_assignment(const std::vector<SP> &v, const std::string &name) {
+    for (const auto &s : v) {
+        if (s->k == Stmt::ASSIGN) {
+            if (s->var == name) return s->e.get();
+            for (const auto &o : s->more) if (o->var == name) return o->e.get();
+        }
+        for (const auto &b : s->blocks) if (const Expr *e = first_assignment(b, name)) return e;
+    }
+    return nullptr;
+}
+
 struct Compiler {
     const Module &m;
     const Config &cfg;
@@ -341,10 +353,20 @@ struct Compiler {
                     return;
                 }
             if (e->s == "self") { push_self(e->pos); return; }
+            if (e->s == "defaultInitValue") cfail("defaultInitValue can only be the (implicit) initial value of a variable, not part of an expression", e->pos);
             auto vi = var_index.find(e->s);
             if (vi != var_index.end()) {
                 const VarInfo &v = P.vars[(size_t)vi->second];
-                if (proc && proc_locals.count(e->s) && proc->is_set && P.multi) { push_self(e->pos); emit_indexed(mc::VM_LOADX, v, e->pos); return; }
+                const bool per_self = proc && proc_locals.count(e->s) && proc->is_set && P.multi;
+                if (v.defval && !v.array == !per_self) {  // reading a variable that still is defaultInitValue is an evaluation error, as in TLC
+                    if (per_self) { push_self(e->pos); emit_indexed(mc::VM_LOADX, v, e->pos); } else emit(mc::VM_LOAD, v.base);
+                    emit(mc::VM_PUSH, mc::VM_DEFAULT_INIT);
+                    emit(mc::VM_NE);
+                    const int ok = emit_jump(mc::VM_JNZ);
+                    emit(mc::VM_FAIL);
+                    patch(ok);
+                }
+                if (per_self) { push_self(e->pos); emit_indexed(mc::VM_LOADX, v, e->pos); return; }
                 if (v.set) cfail("the set `" + e->s + "` is used as a number here; supported: \\in, \\cup, \\cap, \\, =, #, \\subseteq, Cardinality, with / quantifiers over it", e->pos);
                 if (v.seq) cfail("the sequence `" + e->s + "` is used as a value here; supported: Len, Head, " + e->s + "[i], = / # <<...>>", e->pos);
                 if (v.array) cfail("the function `" + e->s + "` is used as a value; only `" + e->s + "[i]` is supported", e->pos);
@@ -922,7 +944,8 @@ struct Compiler {
 
     // ---- initial values
     void init_scalar(const VarDecl &d, int slot, unsigned long long &ninit) {
-        if (d.in_set) ninit *= choose_from(d.init, d.pos);
+        if (d.no_init) emit(mc::VM_PUSH, mc::VM_DEFAULT_INIT);
+        else if (d.in_set) ninit *= choose_from(d.init, d.pos);
         else ex(d.init);
         emit(mc::VM_STORE, slot);
         if (ninit > (1ull << 40)) cfail("too many initial states", d.pos);
@@ -932,6 +955,12 @@ struct Compiler {
         P.module = m.name;
         P.multi = !(m.procs.size() == 1 && m.procs[0].name.empty());
         for (const auto &kv : cfg.constants) consts[kv.first] = kv.second;
+        if (!consts.count("defaultInitValue")) {  // TLC needs `defaultInitValue = defaultInitValue` in the cfg; here it is implied
+            ConstVal dv;
+            dv.k = ConstVal::STR;
+            dv.s = "defaultInitValue";
+            consts["defaultInitValue"] = dv;
+        }
         for (const auto &cn : m.constants) if (!consts.count(cn)) cfail("CONSTANT " + cn + " has no value in the configuration");
         // labels first: label id == string id
         std::vector<std::string> labels;
@@ -979,7 +1008,11 @@ struct Compiler {
         };
         auto decl_var = [&](const VarDecl &d, const Proc *owner) {
             const bool per_inst = owner && owner->is_set && P.multi;
-            if (d.init->k == Expr::SETENUM && !d.in_set) {  // a set of small naturals / strings: one mask cell (per instance)
+            if (d.no_init) {  // a scalar whose type is that of its first assignment (fixed below, once every variable is known)
+                if (per_inst) add_var(d.name, true, ids_of[owner], 'i');
+                else add_var(d.name, false, {}, 'i');
+                P.vars.back().defval = true;
+            } else if (d.init->k == Expr::SETENUM && !d.in_set) {  // a set of small naturals / strings: one mask cell (per instance)
                 if (per_inst) add_var(d.name, true, ids_of[owner], d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
                 else add_var(d.name, false, {}, d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
                 P.vars.back().set = true;
@@ -1005,6 +1038,16 @@ struct Compiler {
         P.pc_base = nv;
         add_var("pc", P.multi, P.multi ? procset : std::vector<long long>{}, 's');
         for (const auto &p : m.procs) for (const auto &l : p.locals) decl_var(l, &p);
+        for (auto &v : P.vars) {
+            if (!v.defval) continue;
+            const Expr *rhs = nullptr;
+            for (const auto &p : m.procs) if (!rhs) rhs = first_assignment(p.body, v.name);
+            if (!rhs) continue;  // never assigned: it stays defaultInitValue
+            if (rhs->k == Expr::SETENUM || rhs->k == Expr::TUPLE || rhs->k == Expr::FUNCDEF)
+                cfail("`" + v.name + "` is declared without an initial value and later holds a set / sequence / function: give it an initial value of that kind");
+            auto probe = std::make_shared<Expr>(*rhs);
+            v.type = type_of(probe);
+        }
         if (nv > mc::SpecVm::MAX_VARS) cfail("the state has " + std::to_string(nv) + " scalar variables; at most " + std::to_string(mc::SpecVm::MAX_VARS) + " are supported");
         P.nv = nv;
         // image: header, label table, self table, code
@@ -1122,6 +1165,7 @@ std::string fmt_set(const Program &P, char type, int32_t mask) {  // elements in
     return s + "}";
 }
 std::string fmt_val(const Program &P, char type, int32_t v) {
+    if (v == mc::VM_DEFAULT_INIT) return "defaultInitValue";  // a model value: TLC prints it bare
     if (type == 'b') return v ? "TRUE" : "FALSE";
     if (type == 's') return v >= 0 && (size_t)v < P.strings.size() ? "\"" + P.strings[(size_t)v] + "\"" : "\"?\"";
     return std::to_string(v);

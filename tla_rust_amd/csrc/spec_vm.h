@@ -36,6 +36,7 @@ enum VmHdr : int32_t {
     VMH_NCON /* CONSTRAINTs: entries VMH_INV0 + ninv .. of the same table */, VMH_SIZE
 };
 constexpr int32_t VM_MAGIC = 0x70634c31;  // "pcL1"
+constexpr int32_t VM_DEFAULT_INIT = -2147483641;  // the cell of a variable declared without an initial value (defaultInitValue)
 
 // what the host keeps about a compiled program (names, types, source positions); defined in pcal_compile.cpp
 int vm_format(const void *host, const int32_t *vals, char *buf, size_t cap);
