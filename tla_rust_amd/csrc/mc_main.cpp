@@ -16,7 +16,8 @@
 //             error; continue such a run later, with the same X.tla / X.cfg.
 // -gpus P   : the search sharded over P GPUs of this node (one process per GPU, RCCL): mc replaces itself by
 //             `python3 -m torch.distributed.run --nproc-per-node P -m tla_rust_amd.mc_multi X.tla <the other options>`
-//             (tla_rust_amd/mc_multi.py; same report lines and exit codes).
+//             (tla_rust_amd/mc_multi.py; same report lines and exit codes; $PYTHON names another interpreter, $MASTER_PORT the
+//             rendezvous port).
 // -deadlock : as with TLC, do NOT check for deadlock.  -workers is accepted and ignored (the
 // GPU is the worker pool).  Exit status: 0 no error, 12 safety violation (invariant / assert),
 // 11 deadlock, 1 any other failure — TLC's convention.
@@ -66,7 +67,8 @@ static int exec_multi(int gpus, int argc, char **argv) {
     const char *pp = getenv("PYTHONPATH");
     setenv("PYTHONPATH", pp && *pp ? (root + ":" + pp).c_str() : root.c_str(), 1);
     const char *port = getenv("MASTER_PORT");
-    std::vector<std::string> a = {"python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=" + std::to_string(gpus),
+    const char *py = getenv("PYTHON");  // the interpreter that has torch; default: python3 on PATH
+    std::vector<std::string> a = {py && *py ? py : "python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=" + std::to_string(gpus),
                                   "--master-addr", "127.0.0.1", "--master-port", port && *port ? port : "29517", "-m", "tla_rust_amd.mc_multi"};
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "-gpus")) { ++i; continue; }
