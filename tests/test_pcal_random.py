@@ -259,3 +259,32 @@ def test_random_algorithms_under_a_constraint(block):
         finally:
             prog.close()
     assert checked >= 10 and pruned >= 5
+
+
+def test_random_algorithms_with_an_uninitialised_variable():
+    """`variables u, ...` (defaultInitValue) threaded through random algorithms: an extra process assigns u, then reads it"""
+    checked = 0
+    for seed in range(400, 420):
+        text = Gen(seed).module(f"rnd{seed}")
+        text = text.replace("variables x = 0,", "variables u, x = 0,", 1)
+        text = text.replace("\n\nend algorithm *)", f"\n\nprocess R = 7\nbegin\n  R0: u := x;\n  R1: u := (u + 1) % {K};\nend process\n\nend algorithm *)", 1)
+        assert "process R = 7" in text and "variables u, x" in text
+        try:
+            prog = helpers.ShimProgram(text, ["Small"], {})
+        except RuntimeError:
+            continue
+        fd, dump = tempfile.mkstemp()
+        os.close(fd)
+        try:
+            r = helpers.shim_run("pcal", prog.params, dump=dump, check_deadlock=False)
+            o = Checker(prog.translated()).run_levels(invariants=["Small"], check_deadlock=False)
+            for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+                assert r[k] == o[k], (seed, k, r[k], o[k], text)
+            states = helpers.read_dump(dump)
+            assert [states[l + 1] for l in range(len(states))] == o["states"], (seed, text)
+            assert "u = defaultInitValue" in states[1][0]
+            checked += 1
+        finally:
+            os.unlink(dump)
+            prog.close()
+    assert checked >= 8
