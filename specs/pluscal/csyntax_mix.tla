@@ -15,14 +15,16 @@ CONSTANT N
   }
 } *)
 \* BEGIN TRANSLATION
-VARIABLES x, lock, a, pc, t, k
-
-vars == << x, lock, a, pc, t, k >>
+VARIABLES x, lock, a, pc
 
 (* define statement *)
 Sum == a[1] + a[2]
 
 Twice(v) == v + v
+
+VARIABLES t, k
+
+vars == << x, lock, a, pc, t, k >>
 
 ProcSet == (1..N)
 

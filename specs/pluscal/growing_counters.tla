@@ -33,14 +33,16 @@ C: while TRUE do
 end process;
 end algorithm *)
 \* BEGIN TRANSLATION
-VARIABLES produced, consumed, pc, mine
-
-vars == << produced, consumed, pc, mine >>
+VARIABLES produced, consumed, pc
 
 (* define statement *)
 NeverAhead == consumed <= produced
 
 Small == produced <= Bound
+
+VARIABLES mine
+
+vars == << produced, consumed, pc, mine >>
 
 ProcSet == {1} \cup (2..3)
 
@@ -53,23 +55,17 @@ Init == (* Global variables *)
                                         [] self \in 2..3 -> "C"]
 
 P == /\ pc[1] = "P"
-     /\ IF TRUE
-           THEN /\ produced' = produced + 1
-                /\ pc' = [pc EXCEPT ![1] = "P"]
-           ELSE /\ pc' = [pc EXCEPT ![1] = "Done"]
-                /\ UNCHANGED produced
+     /\ produced' = produced + 1
+     /\ pc' = [pc EXCEPT ![1] = "P"]
      /\ UNCHANGED << consumed, mine >>
 
 producer == P
 
 C(self) == /\ pc[self] = "C"
-           /\ IF TRUE
-                 THEN /\ consumed < produced
-                      /\ consumed' = consumed + 1
-                      /\ mine' = [mine EXCEPT ![self] = mine[self] + 1]
-                      /\ pc' = [pc EXCEPT ![self] = "C"]
-                 ELSE /\ pc' = [pc EXCEPT ![self] = "Done"]
-                      /\ UNCHANGED << consumed, mine >>
+           /\ consumed < produced
+           /\ consumed' = consumed + 1
+           /\ mine' = [mine EXCEPT ![self] = mine[self] + 1]
+           /\ pc' = [pc EXCEPT ![self] = "C"]
            /\ UNCHANGED produced
 
 consumer(self) == C(self)

@@ -38,9 +38,7 @@ Init == (* Global variables *)
         /\ pc = [self \in ProcSet |-> "Loop"]
 
 Loop(self) == /\ pc[self] = "Loop"
-              /\ IF TRUE
-                    THEN /\ pc' = [pc EXCEPT ![self] = "Want"]
-                    ELSE /\ pc' = [pc EXCEPT ![self] = "Done"]
+              /\ pc' = [pc EXCEPT ![self] = "Want"]
               /\ UNCHANGED << flag, turn, in_cs >>
 
 Want(self) == /\ pc[self] = "Want"

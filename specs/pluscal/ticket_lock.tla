@@ -40,9 +40,7 @@ end process
 
 end algorithm *)
 \* BEGIN TRANSLATION
-VARIABLES next_ticket, now_serving, holding, pc, my, laps
-
-vars == << next_ticket, now_serving, holding, pc, my, laps >>
+VARIABLES next_ticket, now_serving, holding, pc
 
 (* define statement *)
 Waiting == next_ticket - now_serving
@@ -50,6 +48,10 @@ Waiting == next_ticket - now_serving
 InCS(i) == holding[i]
 
 NobodyElse(i) == \A j \in 1..P : j = i \/ ~InCS(j)
+
+VARIABLES my, laps
+
+vars == << next_ticket, now_serving, holding, pc, my, laps >>
 
 ProcSet == (1..P)
 

@@ -1081,6 +1081,12 @@ struct ActionGen {
             case Stmt::GOTO: o.items.push_back(line(pc_set(s->var))); return;
             case Stmt::WHILE: {
                 if (!(top && j == i)) throw TranslateError{"the while at line " + std::to_string(s->pos.line) + " needs a label"};
+                if (s->e->k == Expr::BOOL && s->e->num == 1) {
+                    // p-manual App. B p.61 (action ncs of FastMutex): "The evaluation of the while test does not appear
+                    // explicitly in the action because it equals TRUE" — the body is the action, control returns to the label
+                    seq(s->blocks[0], 0, s->label, false, o, primed, shadow, col);
+                    return;
+                }
                 auto n = std::make_shared<Node>();
                 n->k = Node::IF;
                 n->text = pe(s->e, c, primed, shadow);
@@ -1215,22 +1221,30 @@ std::string translate(const Module &m) {
     bool any_default = false;
     for (const auto &g : m.globals) any_default |= g.no_init;
     for (const auto &p : m.procs) for (const auto &l : p.locals) any_default |= l.no_init;
-    if (any_default) o += "CONSTANT defaultInitValue\n";
-    o += "VARIABLES " + join(vars, ", ") + "\n\n";
-    o += "vars == << " + join(vars, ", ") + " >>\n\n";
+    if (any_default) o += "CONSTANT defaultInitValue\n";  // p-manual App. B p.60: omitted if every variable is initialised
     Ctx none;
     none.m = &m;
     const std::set<std::string> empty;
-    {
-        bool any = false;
+    bool has_define = false;
+    for (const auto &d : m.defs) has_define |= d.in_define;
+    if (!has_define) {
+        o += "VARIABLES " + join(vars, ", ") + "\n\n";
+    } else {
+        // p-manual App. B p.60: with a define statement there are two VARIABLES statements — the global variables and pc
+        // first, then the definitions (which may mention those), then the remaining (process-local) variables
+        std::vector<std::string> first, rest;
+        for (const auto &g : m.globals) first.push_back(g.name);
+        first.push_back("pc");
+        for (const auto &p : m.procs) for (const auto &l : p.locals) rest.push_back(l.name);
+        o += "VARIABLES " + join(first, ", ") + "\n\n(* define statement *)\n";
         for (const auto &d : m.defs) {
             if (!d.in_define) continue;
-            if (!any) o += "(* define statement *)\n";
-            any = true;
             std::set<std::string> sh(d.params.begin(), d.params.end());
             o += d.name + (d.params.empty() ? "" : "(" + join(d.params, ", ") + ")") + " == " + pe(d.body, none, empty, sh) + "\n\n";
         }
+        if (!rest.empty()) o += "VARIABLES " + join(rest, ", ") + "\n\n";
     }
+    o += "vars == << " + join(vars, ", ") + " >>\n\n";
     if (multi) {
         std::vector<std::string> parts;
         for (const auto &p : m.procs) parts.push_back(p.is_set ? "(" + pe(p.id, none, empty, empty) + ")" : "{" + pe(p.id, none, empty, empty) + "}");
