@@ -44,6 +44,9 @@ CASES = [
     (SPECS / "pluscal" / "swap.tla", [], {}),                                                                  # a := e || b := f
     (SPECS / "pluscal" / "scratch_locals.tla", ["AtMostN"], {"N": 2}),      # `variable tmp;`: defaultInitValue
     (SPECS / "pluscal" / "scratch_locals.tla", ["AtMostN"], {"N": 3}),
+    # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
+    (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
+    (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
 ]
 
 
@@ -196,6 +199,30 @@ def test_refusals_are_explained(body, needle):
     with pytest.raises(RuntimeError) as e:
         helpers.ShimProgram(MODULE % body)
     assert needle in str(e.value)
+
+
+def test_fast_mutex_translation_follows_the_manual_appendix_b():
+    """examples/p-manual.pdf App. B pp.60-62 walks through the translation of FastMutex (Figure 2 p.13): the declarations, Init and
+    the actions it prints (ncs, start, l1, l2, l4, l7, l8) come out of the translator conjunct by conjunct (the manual's rendering
+    drops the `/\\ TRUE` of a skip and line breaks)."""
+    text = (SPECS / "pluscal" / "fast_mutex.tla").read_text()
+    tr = " ".join(helpers.pcal_translate(strip_translation(text)).split())
+    for piece in [
+        "\\* BEGIN TRANSLATION CONSTANT defaultInitValue VARIABLES x, y, b, pc, j vars == << x, y, b, pc, j >> ProcSet == (1..N)",
+        "/\\ x = defaultInitValue /\\ y = 0 /\\ b = [i \\in 1..N |-> FALSE]",
+        '/\\ j = [self \\in 1..N |-> defaultInitValue] /\\ pc = [self \\in ProcSet |-> "ncs"]',
+        'ncs(self) == /\\ pc[self] = "ncs" /\\ TRUE /\\ pc\' = [pc EXCEPT ![self] = "start"] /\\ UNCHANGED << x, y, b, j >>',
+        'start(self) == /\\ pc[self] = "start" /\\ b\' = [b EXCEPT ![self] = TRUE] /\\ pc\' = [pc EXCEPT ![self] = "l1"] /\\ UNCHANGED << x, y, j >>',
+        'l1(self) == /\\ pc[self] = "l1" /\\ x\' = self /\\ pc\' = [pc EXCEPT ![self] = "l2"] /\\ UNCHANGED << y, b, j >>',
+        'l2(self) == /\\ pc[self] = "l2" /\\ IF y # 0 THEN /\\ pc\' = [pc EXCEPT ![self] = "l3"] ELSE /\\ pc\' = [pc EXCEPT ![self] = "l5"] '
+        '/\\ UNCHANGED << x, y, b, j >>',
+        'l4(self) == /\\ pc[self] = "l4" /\\ y = 0 /\\ pc\' = [pc EXCEPT ![self] = "start"] /\\ UNCHANGED << x, y, b, j >>',
+        'l7(self) == /\\ pc[self] = "l7" /\\ b\' = [b EXCEPT ![self] = FALSE] /\\ j\' = [j EXCEPT ![self] = 1] /\\ pc\' = [pc EXCEPT ![self] = "l8"] '
+        '/\\ UNCHANGED << x, y >>',
+        'l8(self) == /\\ pc[self] = "l8" /\\ IF j[self] <= N THEN /\\ ~b[j[self]] /\\ j\' = [j EXCEPT ![self] = j[self] + 1] '
+        '/\\ pc\' = [pc EXCEPT ![self] = "l8"] ELSE /\\ pc\' = [pc EXCEPT ![self] = "l9"]',
+    ]:
+        assert piece in tr, piece
 
 
 def test_uninitialised_variables_translate_to_defaultInitValue():
