@@ -47,6 +47,9 @@ CASES = [
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
+    # the manual's first example: Euclid's algorithm WITHOUT labels (p-manual sections 2.1-2.3): labels Lbl_1, Lbl_2 are added
+    (SPECS / "pluscal" / "euclid_manual.tla", ["ResultIsGcd"], {"N": 4}),
+    (SPECS / "pluscal" / "euclid_manual.tla", ["ResultIsGcd"], {"N": 30}),
 ]
 
 
@@ -188,7 +191,6 @@ MODULE = "---- MODULE t ----\nEXTENDS Naturals\n(* --algorithm t\n%s\nend algori
 @pytest.mark.parametrize("body,needle", [
     ("variables x = 0;\nprocedure p() begin L: skip; end procedure;\nbegin\nA: skip;", "procedures are not supported"),
     ("variables x = 0;\nmacro m(a) begin a := 1; end macro;\nbegin\nA: m(x + 1);", "must be instantiated with a variable"),
-    ("variables x = 0;\nbegin\nskip;", "needs a label"),
     ("variables x = 0;\nbegin\nA: x := 1; x := 2;", "second assignment to x"),
     ("variables x = 0;\nbegin\nA: x := 1 || x := 2;", "two assignments to x"),
     ("variables x = 0;\nbegin\nA: if x = 0 then B: x := 1; end if; x := 2;", "needs a label"),
@@ -223,6 +225,25 @@ def test_fast_mutex_translation_follows_the_manual_appendix_b():
         '/\\ pc\' = [pc EXCEPT ![self] = "l8"] ELSE /\\ pc\' = [pc EXCEPT ![self] = "l9"]',
     ]:
         assert piece in tr, piece
+
+
+def test_euclid_of_the_manual_known_answer():
+    """examples/p-manual.pdf p.10: model checking EuclidAlg with N = 4 prints <<24, 4, "have gcd", 4>>, <<24, 3, "have gcd", 3>>,
+    <<24, 2, "have gcd", 2>>, <<24, 1, "have gcd", 1>>.  The algorithm has no labels: the front-end adds Lbl_1 (the while) and
+    Lbl_2 (the second assignment to u), as the manual says its translator does (p.9)."""
+    text = (SPECS / "pluscal" / "euclid_manual.tla").read_text()
+    tr = helpers.pcal_translate(strip_translation(text))
+    assert 'pc = "Lbl_1"' in tr and "Lbl_2 == /\\ pc = \"Lbl_2\"\n         /\\ u' = u - v" in tr and "Lbl_3" not in tr
+    prog = helpers.ShimProgram(text, ["ResultIsGcd"], {"N": 4})
+    fd, dump = tempfile.mkstemp()
+    os.close(fd)
+    r = helpers.shim_run("pcal", prog.params, dump=dump)
+    states = helpers.read_dump(dump)
+    os.unlink(dump)
+    prog.close()
+    assert r["verdict"] == "ok" and r["levels"][0] == 4            # four initial states: v \in 1..4
+    done = sorted(t for lvl in states.values() for t in lvl if 'pc = "Done"' in t)
+    assert done == ['/\\ u = 0 /\\ v = %d /\\ v_ini = %d /\\ pc = "Done"' % (k, k) for k in (1, 2, 3, 4)]   # gcd(24, k) = k
 
 
 def test_uninitialised_variables_translate_to_defaultInitValue():

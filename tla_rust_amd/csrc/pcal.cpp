@@ -715,6 +715,74 @@ int line_of(const std::string &text, size_t off) { return 1 + (int)std::count(te
 
 }  // namespace
 
+// An algorithm written without any label gets the labels it needs, named Lbl_1, Lbl_2, ... like pcal2tla's (p-manual section 2.3
+// p.9: "Because this is a uniprocess algorithm that contains no labels, the translator will automatically add the necessary
+// labels"): on the first statement of a body, on every while, on a statement that assigns a variable already assigned in the
+// step, and on the statement after an if / either that received a label inside.
+namespace {
+struct AutoLabel {
+    int next = 1;
+    static bool any_label(const std::vector<SP> &v) {
+        for (const auto &s : v) {
+            if (!s->label.empty()) return true;
+            for (const auto &b : s->blocks) if (any_label(b)) return true;
+        }
+        return false;
+    }
+    static void assigned_in(const SP &s, std::set<std::string> &out) {
+        if (s->k == Stmt::ASSIGN) {
+            out.insert(s->var);
+            for (const auto &o : s->more) out.insert(o->var);
+        }
+        for (const auto &b : s->blocks) for (const auto &x : b) assigned_in(x, out);
+    }
+    // returns true when a label was placed somewhere inside v (not counting v's own first statement)
+    bool seq(std::vector<SP> &v, std::set<std::string> &assigned, bool first_needs_label) {
+        bool need = first_needs_label, placed = false;
+        for (size_t i = 0; i < v.size(); i++) {
+            SP &s = v[i];
+            std::set<std::string> mine;
+            assigned_in(s, mine);
+            bool clash = false;
+            for (const auto &x : mine) clash |= assigned.count(x) != 0;
+            if (need || clash || s->k == Stmt::WHILE) {
+                s->label = "Lbl_" + std::to_string(next++);
+                assigned.clear();
+                if (i) placed = true;
+            }
+            need = false;
+            if (s->k == Stmt::WHILE) {
+                std::set<std::string> in_body;
+                seq(s->blocks[0], in_body, false);
+                assigned.clear();  // the exit path of the test assigns nothing
+            } else if (s->k == Stmt::IF || s->k == Stmt::EITHER) {
+                std::set<std::string> uni;
+                bool inner = false;
+                for (auto &b : s->blocks) {
+                    std::set<std::string> a = assigned;
+                    inner |= seq(b, a, false);
+                    uni.insert(a.begin(), a.end());
+                }
+                if (inner) { need = true; placed = true; assigned.clear(); }
+                else assigned = uni;
+            } else {
+                assigned.insert(mine.begin(), mine.end());  // ASSIGN, WITH (no label may go inside a with)
+                if (s->k == Stmt::GOTO) need = true;
+            }
+        }
+        return placed;
+    }
+};
+void add_missing_labels(Module &m) {
+    for (const auto &p : m.procs) if (AutoLabel::any_label(p.body)) return;
+    AutoLabel al;
+    for (auto &p : m.procs) {
+        std::set<std::string> assigned;
+        al.seq(p.body, assigned, true);
+    }
+}
+}  // namespace
+
 std::string parse_module(const std::string &text, Module &m) {
     try {
         size_t a = text.find("--algorithm");
@@ -757,6 +825,7 @@ std::string parse_module(const std::string &text, Module &m) {
             Parser p(lex(text, a + kw_len, aend));
             p.algorithm(m);
         }
+        add_missing_labels(m);
         // the rest: an existing translation (skipped) and the definitions
         size_t rest = cend;
         const size_t tb = text.find("\\* BEGIN TRANSLATION", cend);
