@@ -187,6 +187,13 @@ class Parser:
                 self.i += 1
                 return ("temporal", self.expr(4))
         if c.k == "id":
+            if c.s == "CHOOSE":
+                self.i += 1
+                var = self.ident()
+                self.expect("\\in")
+                dom = self.expr(6)
+                self.expect(":")
+                return ("quant", "C", var, dom, self.expr(0))
             if c.s == "IF":
                 self.i += 1
                 cond = self.expr(0)
@@ -561,6 +568,11 @@ class Checker:
             return f.get(self.ev(e[2], st, nx, bd))
         if k == "quant":
             dom = sorted(self.ev(e[3], st, nx, bd), key=sort_key)
+            if e[1] == "C":   # CHOOSE: TLC takes the first element of its (sorted) enumeration that satisfies the body
+                for v in dom:
+                    if self.ev(e[4], st, nx, {**bd, e[2]: v}):
+                        return v
+                raise EvalError("CHOOSE: no element of the set satisfies the predicate")
             gen = (self.ev(e[4], st, nx, {**bd, e[2]: v}) for v in dom)
             return all(gen) if e[1] == "A" else any(gen)
         if k == "setenum":

@@ -50,6 +50,9 @@ CASES = [
     # the manual's first example: Euclid's algorithm WITHOUT labels (p-manual sections 2.1-2.3): labels Lbl_1, Lbl_2 are added
     (SPECS / "pluscal" / "euclid_manual.tla", ["ResultIsGcd"], {"N": 4}),
     (SPECS / "pluscal" / "euclid_manual.tla", ["ResultIsGcd"], {"N": 30}),
+    # p-manual section 2.4: `assert v = gcd(24, v_ini)` with the manual's CHOOSE definition of gcd before the translation
+    (SPECS / "pluscal" / "euclid_assert.tla", [], {"N": 4}),
+    (SPECS / "pluscal" / "euclid_assert.tla", [], {"N": 40}),
 ]
 
 
@@ -244,6 +247,28 @@ def test_euclid_of_the_manual_known_answer():
     assert r["verdict"] == "ok" and r["levels"][0] == 4            # four initial states: v \in 1..4
     done = sorted(t for lvl in states.values() for t in lvl if 'pc = "Done"' in t)
     assert done == ['/\\ u = 0 /\\ v = %d /\\ v_ini = %d /\\ pc = "Done"' % (k, k) for k in (1, 2, 3, 4)]   # gcd(24, k) = k
+
+
+def test_manual_gcd_assertion_and_bounded_choose():
+    """examples/p-manual.pdf section 2.4 pp.10-11: the assertion `v = gcd(24, v_ini)` holds with the manual's definition of gcd (a
+    bounded CHOOSE, evaluated like TLC: first satisfying element in ascending order); a wrong definition trips it, and a CHOOSE
+    that no element satisfies is an evaluation error, not a silent value."""
+    text = (SPECS / "pluscal" / "euclid_assert.tla").read_text()
+    assert text.index("gcd(x, y) ==") < text.index("\\* BEGIN TRANSLATION")          # "before the BEGIN TRANSLATION line" (p.10)
+    prog = helpers.ShimProgram(text, [], {"N": 24})
+    assert helpers.shim_run("pcal", prog.params)["verdict"] == "ok"
+    prog.close()
+    prog = helpers.ShimProgram(text.replace("=> i >= j", "=> i <= j"), [], {"N": 4})     # the SMALLEST common divisor: wrong
+    r = helpers.shim_run("pcal", prog.params)
+    o = Checker(prog.translated(), constants={"N": 4}).run_levels()
+    assert (r["verdict"], r["trace_len"]) == ("assert", o["trace_len"]) and o["verdict"] == "assert"
+    prog.close()
+    prog = helpers.ShimProgram(text.replace("=> i >= j", "=> i > j"), [], {"N": 4})      # nothing is greater than itself: no witness
+    assert helpers.shim_run("pcal", prog.params)["verdict"] == "spec-error"
+    prog.close()
+    with pytest.raises(RuntimeError) as e:
+        helpers.ShimProgram(MODULE % "variables s = {1, 2}, x = 0;\nbegin\nA: x := CHOOSE i \\in s : i > 1;")
+    assert "CHOOSE is supported over an integer interval" in str(e.value)
 
 
 def test_uninitialised_variables_translate_to_defaultInitValue():

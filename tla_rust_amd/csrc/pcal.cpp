@@ -179,6 +179,17 @@ struct Parser {
                 e->a.push_back(expr(0));
                 return e;
             }
+            if (k.s == "CHOOSE") {  // bounded CHOOSE x \in S : P (examples/p-manual.pdf section 2.4: the definition of gcd)
+                i++;
+                auto e = mk(Expr::QUANT, k);
+                e->s = "CHOOSE";
+                e->bound = ident("a bound variable");
+                expect_sym("\\in");
+                e->a.push_back(expr(6));
+                expect_sym(":");
+                e->a.push_back(expr(0));
+                return e;
+            }
             i++;
             if (is_sym("(") && cur().line == k.line && cur().col == k.col + (int)k.s.size()) {  // Op(args): no space before (
                 i++;

@@ -182,7 +182,8 @@ struct Compiler {
     char type_of(const EP &e) {
         switch (e->k) {
         case Expr::STR: return 's';
-        case Expr::BOOL: case Expr::QUANT: return 'b';
+        case Expr::BOOL: return 'b';
+        case Expr::QUANT: return e->s == "CHOOSE" ? type_of(e->a[0]) : 'b';
         case Expr::UNOP: return e->s == "~" ? 'b' : 'i';
         case Expr::BINOP: {
             static const char *boolops[] = {"/\\", "\\/", "=>", "=", "#", "<", ">", "<=", ">=", "\\in", "\\notin"};
@@ -532,6 +533,28 @@ struct Compiler {
     void quant(const EP &e) {
         const bool all = e->s == "\\A";
         const EP &dom = e->a[0];
+        if (e->s == "CHOOSE") {
+            // CHOOSE x \in a..b : P — TLC takes the first element (ascending) that satisfies P and raises an error when none does
+            if (!(dom->k == Expr::BINOP && dom->s == "..")) cfail("CHOOSE is supported over an integer interval a..b only", e->pos);
+            const int tx = new_temp(e->pos), th = new_temp(e->pos);
+            ex(dom->a[0]); emit(mc::VM_STORET, tx);
+            ex(dom->a[1]); emit(mc::VM_STORET, th);
+            const int loop = (int)c.size();
+            emit(mc::VM_LOADT, tx); emit(mc::VM_LOADT, th); emit(mc::VM_LE);
+            const int jnone = emit_jump(mc::VM_JZ);
+            binds.push_back({e->bound, tx, false, 0});
+            ex(e->a[1]);
+            binds.pop_back();
+            const int jhit = emit_jump(mc::VM_JNZ);
+            emit(mc::VM_LOADT, tx); emit(mc::VM_PUSH, 1); emit(mc::VM_ADD); emit(mc::VM_STORET, tx);
+            emit(mc::VM_JMP, loop);
+            patch(jnone);
+            emit(mc::VM_FAIL);  // "Attempted to compute the value of CHOOSE x \in S: P, but no element of S satisfied P"
+            patch(jhit);
+            emit(mc::VM_LOADT, tx);
+            next_temp -= 2;
+            return;
+        }
         if (dom->k == Expr::BINOP && dom->s == "..") {
             const int tx = new_temp(e->pos), th = new_temp(e->pos);
             ex(dom->a[0]); emit(mc::VM_STORET, tx);
