@@ -1,0 +1,58 @@
+"""The C oracle (oracle/spec_raft.c) pinned to the REFERENCE'S OWN TEXT: oracle/tlaplus.py evaluates
+/root/reference/examples/raft.tla:110-507 under specs/MCraft.tla the way TLC does, and the hand restatement must give the
+same state graph — per-level SETS of states as canonical TLA+ text, counters, depth — on the 2-server anchors of
+BASELINE.md section 2 (6 128 and 13 634 distinct), including the negative control of SURVEY.md App. B item 0: evaluating
+raft.tla:392-393 as an unconditional assignment ("naive") yields 15 794.
+
+/root/reference exists only in the build container: there the test runs the evaluator on the reference file itself and
+checks the committed fixture (tests/golden/raft_reference_text.json, made by tests/golden/make_reference_text_golden.py) is
+what it produces; on the GPU box (no /root/reference) the fixture alone is compared with the oracle.
+"""
+import hashlib
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+import helpers
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+REF = Path("/root/reference/examples")
+GOLD = json.loads((ROOT / "tests" / "golden" / "raft_reference_text.json").read_text())
+
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+from make_reference_text_golden import RAFT_MODELS, raft_cfg, run_raft_text  # noqa: E402
+
+
+def level_digests(by_level):
+    return [hashlib.sha256("\n".join(sorted(by_level[k])).encode()).hexdigest()[:16] for k in sorted(by_level)]
+
+
+@pytest.mark.parametrize("name", sorted(RAFT_MODELS))
+def test_c_oracle_equals_reference_text_fixture(name, tmp_path):
+    """C oracle vs the fixture produced from the reference's text: counters, per-level counts, per-level state-set digests"""
+    g = GOLD[name]
+    dump = tmp_path / "dump.txt"
+    o = helpers.oracle_run("raft", RAFT_MODELS[name]["params"], dump=str(dump))
+    if RAFT_MODELS[name]["clash"] == "ignore":
+        # the negative control: the oracle (TLC semantics) must NOT reproduce the naive count
+        assert o["distinct"] != g["distinct"] and g["distinct"] == 15794
+        return
+    assert (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"]) == \
+           (g["distinct"], g["generated"], g["depth"], g["levels"], g["verdict"])
+    assert level_digests(helpers.read_dump(str(dump))) == g["level_digests"]
+
+
+@pytest.mark.skipif(not REF.exists(), reason="/root/reference is only present in the build container")
+@pytest.mark.parametrize("name", ["raft_2s_mcr1"])
+def test_fixture_is_what_the_reference_text_gives(name):
+    r = run_raft_text(name)
+    g = GOLD[name]
+    assert {k: r[k] for k in g} == g
+
+
+def test_models_use_the_committed_wrapper():
+    assert "EXTENDS raft" in (ROOT / "specs" / "MCraft.tla").read_text()
+    assert "MaxTerm = 2" in raft_cfg(2, 1, 2, 9, 1)
