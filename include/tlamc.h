@@ -47,7 +47,10 @@ extern "C" {
 #define MC_SPEC_PCAL_INTRO 2 /* reference pcal_intro.tla:4-23; params {variant, checkInv, MaxMoney, P}  */
 #define MC_SPEC_RAFT 3       /* reference examples/raft.tla:110-507 under specs/MCraft.tla;
                                 params {nServer, MaxClientRequests, MaxTerm, MaxLogLen, MaxMsgs,
-                                        invariantMask (1 NoTwoLeaders | 2 CommittedLogStable)}    */
+                                        invariantMask (1 NoTwoLeaders | 2 CommittedLogStable),
+                                        [6..8] capacities of the messages / elections / allLogs slot arrays of the
+                                        packed state (0 = default 40 / 4 / 16; exceeding one is MC_EOVERFLOW),
+                                        [9] MaxMsgKeys (0 = unbounded)}                             */
 
 #define MC_SPEC_SSI 4        /* reference examples/serializableSnapshotIsolation.tla:219-996 under specs/MCssi.tla;
                                 params {nTxn <= 4, nKey <= 3, invariantMask (1 WellFormed | 2 HoldingXLocks |
@@ -72,6 +75,9 @@ typedef struct {
 #define MC_F_NOPROBE 16u /* profiling only (mc_engine_debug_reexpand): skip the seen-set probes   */
 #define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
 #define MC_F_NOBATCH 256u /* A/B only: one host round trip per BFS level even while the frontier is small         */
+#define MC_F_UNVERIFIED 512u /* mc_check_files / mc_resolve_files: when the module an MC wrapper EXTENDS (raft.tla, the snapshot-isolation
+                             specs) is found neither beside it nor under $TLA_PATH, use the built-in lowering anyway (the report
+                             carries a warning) instead of failing with MC_ENOSPEC                                          */
 #define MC_F_GENERIC 128u /* mc_check_files: run a PlusCal module through the compiled program (MC_SPEC_PCAL) even
                              when a hand lowering of its algorithm exists (A/B of the two paths)  */
 

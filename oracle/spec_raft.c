@@ -80,7 +80,7 @@ typedef struct {
 } State;
 
 typedef struct {
-    int n, max_client_requests, max_term, max_log_len, max_msgs, inv_mask, naive_commit;
+    int n, max_client_requests, max_term, max_log_len, max_msgs, inv_mask, naive_commit, max_keys;
 } raft_ctx;
 
 /* ---------------------------------------------------------------- (de)serialisation */
@@ -541,6 +541,7 @@ static int raft_constraint(void *ctx, const uint8_t *sb, size_t len) {
     }
     int inflight = 0;
     for (int k = 0; k < s.nm; k++) inflight += s.cnt[k];
+    if (c->max_keys && s.nm > c->max_keys) return 0;  /* Cardinality(DOMAIN messages) <= MaxMsgKeys */
     return inflight <= c->max_msgs;
 }
 /* NoTwoLeaders == ~MoreThanOneLeader (raft.tla:500-507); CommittedLogStable == ~committedLogDecrease */
@@ -705,6 +706,7 @@ int or_spec_raft(const int64_t *p, int np, or_spec *o) {
     c->max_log_len = (int)p[3]; c->max_msgs = (int)p[4];
     c->inv_mask = np > 5 ? (int)p[5] : 1;
     c->naive_commit = np > 6 ? (int)p[6] : 0;
+    c->max_keys = np > 7 ? (int)p[7] : 0;  /* MaxMsgKeys of specs/MCraft.tla, 0 = unbounded */
     if (c->n < 1 || c->n > RN || c->max_client_requests < 1 || c->max_client_requests - 1 > RL || c->max_term < 1 || c->max_term > 250) {
         or_set_error("raft: parameters out of range"); free(c); return -1;
     }

@@ -7,7 +7,7 @@
 (* Pattern: SpecifyingSystems/TLC/MCAlternatingBit.tla + .cfg.             *)
 (***************************************************************************)
 EXTENDS raft
-CONSTANTS MaxTerm, MaxLogLen, MaxMsgs        \* used only by the constraint
+CONSTANTS MaxTerm, MaxLogLen, MaxMsgs, MaxMsgKeys   \* used only by the constraint
 
 InFlight ==                                   \* copies of messages currently deliverable
   LET RECURSIVE Sum(_)
@@ -18,6 +18,8 @@ InFlight ==                                   \* copies of messages currently de
 StateConstraint == /\ \A i \in Server : currentTerm[i] <= MaxTerm
                    /\ \A i \in Server : Len(log[i]) <= MaxLogLen
                    /\ InFlight <= MaxMsgs
+                   \* the bag's key set only grows (raft.tla:117-129 keep a zero-count key): bound it too
+                   /\ Cardinality(DOMAIN messages) <= MaxMsgKeys
 
 NoTwoLeaders       == ~MoreThanOneLeader
 CommittedLogStable == ~committedLogDecrease

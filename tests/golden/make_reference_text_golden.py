@@ -18,10 +18,24 @@ RAFT_MODELS = {
     "raft_2s_mcr1": dict(params=[2, 1, 2, 9, 1, 1], clash="test"),        # 6 128 distinct
     "raft_2s_mcr2": dict(params=[2, 2, 2, 9, 1, 1], clash="test"),        # 13 634 distinct
     "raft_2s_mcr2_naive": dict(params=[2, 2, 2, 9, 1, 1], clash="ignore"),  # negative control: 15 794
+    "raft_2s_mcr2_keys8": dict(params=[2, 2, 2, 9, 1, 1], clash="test", mk=8),  # the MaxMsgKeys conjunct of StateConstraint
+    "raft_2s_mm2_keys6": dict(params=[2, 1, 2, 9, 2, 1], clash="test", mk=6),   # two copies in flight: DuplicateMessage
 }
 
 
-def raft_cfg(n, mcr, mt, mll, mm, inv=1):
+def oracle_params(name):
+    """the C oracle's parameter vector of a model (its p[6] = naive flag, p[7] = MaxMsgKeys)"""
+    m = RAFT_MODELS[name]
+    return m["params"] + [0, m["mk"]] if m.get("mk") else m["params"]
+
+
+def device_params(name):
+    """the lowering's parameter vector (p[6..8] = capacities, 0 = default; p[9] = MaxMsgKeys)"""
+    m = RAFT_MODELS[name]
+    return m["params"] + [0, 0, 0, m["mk"]] if m.get("mk") else m["params"]
+
+
+def raft_cfg(n, mcr, mt, mll, mm, inv=1, mk=64):
     servers = ", ".join(f"s{i + 1}" for i in range(n))
     invs = " ".join(nm for bit, nm in ((1, "NoTwoLeaders"), (2, "CommittedLogStable")) if inv & bit)
     return f"""SPECIFICATION Spec
@@ -31,7 +45,7 @@ CONSTANTS
   RequestVoteRequest = RequestVoteRequest       RequestVoteResponse = RequestVoteResponse
   AppendEntriesRequest = AppendEntriesRequest   AppendEntriesResponse = AppendEntriesResponse
   MaxClientRequests = {mcr}
-  MaxTerm = {mt}   MaxLogLen = {mll}   MaxMsgs = {mm}
+  MaxTerm = {mt}   MaxLogLen = {mll}   MaxMsgs = {mm}   MaxMsgKeys = {mk}
 CONSTRAINT StateConstraint
 {"INVARIANT " + invs if invs else ""}
 """
@@ -40,7 +54,7 @@ CONSTRAINT StateConstraint
 def run_raft_text(name):
     import tlaplus as T
     m = RAFT_MODELS[name]
-    c = T.Checker(ROOT / "specs" / "MCraft.tla", cfg_text=raft_cfg(*m["params"][:5], m["params"][5]), search=[REF], clash=m["clash"])
+    c = T.Checker(ROOT / "specs" / "MCraft.tla", cfg_text=raft_cfg(*m["params"][:5], m["params"][5], m.get("mk", 64)), search=[REF], clash=m["clash"])
     r = c.run_levels()
     digests = [hashlib.sha256("\n".join(sorted(c.spec.state_text(s, RAFT_ORDER) for s in lvl)).encode()).hexdigest()[:16]
                for lvl in r["level_states"]]

@@ -72,6 +72,13 @@ def oracle_run(spec, params, max_levels=0, max_distinct=0, check_deadlock=True, 
                 max_stat=list(res.max_stat))
 
 
+def raft_oracle_params(dev):
+    """lowering's raft parameter vector {n, MCR, MaxTerm, MaxLogLen, MaxMsgs, invMask, cm, ce, ca, MaxMsgKeys} -> the
+    oracle's {n, MCR, MaxTerm, MaxLogLen, MaxMsgs, invMask, naive, MaxMsgKeys} (the oracle has no slot capacities)"""
+    dev = list(dev)
+    return dev[:6] + ([0, dev[9]] if len(dev) > 9 and dev[9] else [])
+
+
 # ---------------------------------------------------------------------------------- shim
 MC_MAX_LEVELS = 4096
 SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5}

@@ -245,3 +245,65 @@ def test_cli_ssi(amd):
     assert p.returncode == 0, p.stderr
     assert "50121 states generated, 29629 distinct states found, 0 states left on queue." in p.stdout
     assert "The depth of the complete state graph search is 13." in p.stdout
+
+
+def test_wrapper_and_extended_module_are_verified_or_refused(amd, tmp_path, monkeypatch):
+    """`mc specs/MCraft.tla` must not hand a changed StateConstraint / raft.tla to the hard-wired lowering.
+    The wrapper body is hashed; the EXTENDed module must be found and match, or the run is refused unless the caller
+    explicitly accepts the built-in lowering (MC_F_UNVERIFIED / -unverified / TLAMC_UNVERIFIED=1)."""
+    import shutil
+    S = ROOT / "specs"
+    cfg = S / "MCraft_small.cfg"
+    monkeypatch.delenv("TLA_PATH", raising=False)
+    monkeypatch.delenv("TLAMC_UNVERIFIED", raising=False)
+    # 1. EXTENDed module not found: refused, accepted only when asked for
+    with pytest.raises(amd.McError) as e:
+        amd.ResolvedSpec(S / "MCraft.tla", cfg)
+    assert e.value.code == -9 and "raft" in str(e.value)
+    with pytest.raises(amd.McError):
+        amd.ResolvedSpec(S / "MCssi.tla", S / "MCssi_2x2.cfg")
+    r = amd.ResolvedSpec(S / "MCraft.tla", cfg, unverified=True)
+    assert r.spec == "raft" and r.params[9] == 64
+    monkeypatch.setenv("TLAMC_UNVERIFIED", "1")
+    assert amd.ResolvedSpec(S / "MCssi.tla", S / "MCssi_2x2.cfg").spec == "ssi"
+    # 2. a one-character change of the wrapper is refused even then
+    for name, old, new in (("MCraft", "currentTerm[i] <= MaxTerm", "currentTerm[i] < MaxTerm"), ("MCssi", "CahillSerializable(history)", "CahillSerializable(history) ")):
+        d = tmp_path / name
+        d.mkdir()
+        text = (S / f"{name}.tla").read_text()
+        assert old in text
+        (d / f"{name}.tla").write_text(text.replace(old, new))
+        c2 = cfg if name == "MCraft" else S / "MCssi_2x2.cfg"
+        if old.strip() == new.strip():   # whitespace only: still the same wrapper
+            assert amd.ResolvedSpec(d / f"{name}.tla", c2).spec == "ssi"
+        else:
+            with pytest.raises(amd.McError) as e:
+                amd.ResolvedSpec(d / f"{name}.tla", c2)
+            assert e.value.code == -9 and "wrapper" in str(e.value)
+    # 3. a changed raft.tla beside the wrapper is refused (build container only: needs the reference's file)
+    ref = Path("/root/reference/examples/raft.tla")
+    if ref.exists():
+        d = tmp_path / "with_raft"
+        d.mkdir()
+        shutil.copy(S / "MCraft.tla", d / "MCraft.tla")
+        (d / "raft.tla").write_text(ref.read_text().replace("clientRequests < MaxClientRequests", "clientRequests <= MaxClientRequests"))
+        with pytest.raises(amd.McError) as e:
+            amd.ResolvedSpec(d / "MCraft.tla", cfg)
+        assert e.value.code == -9 and "differs" in str(e.value)
+        (d / "raft.tla").write_text(ref.read_text())
+        assert amd.ResolvedSpec(d / "MCraft.tla", cfg).spec == "raft"
+
+
+def test_edited_atomic_add_n_takes_the_compiled_path(amd, tmp_path):
+    """a module NAMED atomic_add_n whose algorithm differs from specs/atomic_add_n.tla is not the N-adder
+    hand lowering: it is compiled like any other PlusCal module"""
+    S = ROOT / "specs"
+    r = amd.ResolvedSpec(S / "atomic_add_n.tla")
+    assert r.spec == "atomic_add"
+    text = (S / "atomic_add_n.tla").read_text()
+    assert "await global_counter = N" in text
+    (tmp_path / "atomic_add_n.tla").write_text(text.replace("await global_counter = N", "await global_counter >= N - 1"))
+    (tmp_path / "atomic_add_n.cfg").write_text((S / "atomic_add_n.cfg").read_text())
+    r = amd.ResolvedSpec(tmp_path / "atomic_add_n.tla")
+    assert r.spec == "pcal"
+    r.close()

@@ -40,6 +40,21 @@ def test_raft_prefix_counts(oracle, shim, params, maxd):
     assert s["fp_mismatch"] == 0
 
 
+@pytest.mark.parametrize("dev", [[2, 2, 2, 9, 1, 1, 0, 0, 0, 8], [2, 1, 2, 9, 2, 1, 0, 0, 0, 6],
+                                 [2, 2, 2, 9, 1, 1, 8, 0, 0, 8],   # cm == MaxMsgKeys: the 9th key leaves the model, it is not an overflow
+                                 [2, 3, 2, 9, 1, 3, 0, 0, 0, 10]])
+def test_raft_max_msg_keys_same_states_per_level(oracle, shim, tmp_path, dev):
+    """StateConstraint's fourth conjunct, Cardinality(DOMAIN messages) <= MaxMsgKeys (specs/MCraft.tla)"""
+    od, sd = str(tmp_path / "o.txt"), str(tmp_path / "s.txt")
+    o = oracle.oracle_run("raft", oracle.raft_oracle_params(dev), dump=od)
+    s = shim.shim_run("raft", dev, dump=sd)
+    for k in ("distinct", "generated", "depth", "verdict", "levels", "queue_left"):
+        assert o[k] == s[k], k
+    assert s["fp_mismatch"] == 0
+    assert oracle.read_dump(od) == shim.read_dump(sd)
+    assert o["distinct"] < oracle.oracle_run("raft", dev[:6])["distinct"]   # the bound really cuts
+
+
 def test_raft_expected_violation_trace_length(oracle, shim):
     """SURVEY.md Appendix E caveat (ii): CommittedLogStable is violated once MaxTerm >= 3 and
     MaxClientRequests >= 3; the shortest counterexample has 31 states."""

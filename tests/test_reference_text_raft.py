@@ -23,7 +23,7 @@ REF = Path("/root/reference/examples")
 GOLD = json.loads((ROOT / "tests" / "golden" / "raft_reference_text.json").read_text())
 
 sys.path.insert(0, str(ROOT / "tests" / "golden"))
-from make_reference_text_golden import RAFT_MODELS, raft_cfg, run_raft_text  # noqa: E402
+from make_reference_text_golden import RAFT_MODELS, oracle_params, raft_cfg, run_raft_text  # noqa: E402
 
 
 def level_digests(by_level):
@@ -35,7 +35,7 @@ def test_c_oracle_equals_reference_text_fixture(name, tmp_path):
     """C oracle vs the fixture produced from the reference's text: counters, per-level counts, per-level state-set digests"""
     g = GOLD[name]
     dump = tmp_path / "dump.txt"
-    o = helpers.oracle_run("raft", RAFT_MODELS[name]["params"], dump=str(dump))
+    o = helpers.oracle_run("raft", oracle_params(name), dump=str(dump))
     if RAFT_MODELS[name]["clash"] == "ignore":
         # the negative control: the oracle (TLC semantics) must NOT reproduce the naive count
         assert o["distinct"] != g["distinct"] and g["distinct"] == 15794
@@ -46,7 +46,7 @@ def test_c_oracle_equals_reference_text_fixture(name, tmp_path):
 
 
 @pytest.mark.skipif(not REF.exists(), reason="/root/reference is only present in the build container")
-@pytest.mark.parametrize("name", ["raft_2s_mcr1"])
+@pytest.mark.parametrize("name", ["raft_2s_mcr1", "raft_2s_mm2_keys6"])
 def test_fixture_is_what_the_reference_text_gives(name):
     r = run_raft_text(name)
     g = GOLD[name]

@@ -11,6 +11,7 @@ MC_MAX_LEVELS = 4096
 SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5}
 VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
 MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING, MC_F_MATRIX, MC_F_NOPROBE, MC_F_NOFAMILY = 1, 2, 4, 8, 16, 32
+MC_F_UNVERIFIED = 512  # use the built-in lowering even when the module a wrapper EXTENDS cannot be found (include/tlamc.h)
 
 
 class McError(RuntimeError):
@@ -360,10 +361,10 @@ class ResolvedSpec:
     """mc_resolve_files: X.tla + X.cfg -> (spec name, params) for Engine / sharded.ShardedChecker.  Keeps the compiled
     PlusCal program (if any) alive; close() after the engines."""
 
-    def __init__(self, tla_path, cfg_path=None, generic=False):
+    def __init__(self, tla_path, cfg_path=None, generic=False, unverified=False):
         d, prog = SpecDesc(), C.c_void_p()
         _check(lib().mc_resolve_files(str(tla_path).encode(), str(cfg_path).encode() if cfg_path else None,
-                                      128 if generic else 0, C.byref(d), C.byref(prog)), "mc_resolve_files")
+                                      (128 if generic else 0) | (MC_F_UNVERIFIED if unverified else 0), C.byref(d), C.byref(prog)), "mc_resolve_files")
         names = {v: k for k, v in SPEC_IDS.items()}
         self.spec = names[int(d.spec_id)]
         self.params = [int(d.params[i]) for i in range(d.nparams)]
@@ -377,7 +378,7 @@ class ResolvedSpec:
 
 def check_files(tla_path, cfg_path=None, device=0, **kw):
     """`tlc X.tla` end to end (reference Makefile:6-7): returns (Result, report text)."""
-    cfg = Config(device, MC_F_DEADLOCK | MC_F_TRACE, kw.get("table_capacity", 0), kw.get("arena_capacity", 0),
+    cfg = Config(device, MC_F_DEADLOCK | MC_F_TRACE | (MC_F_UNVERIFIED if kw.get("unverified") else 0), kw.get("table_capacity", 0), kw.get("arena_capacity", 0),
                  kw.get("chunk_states", 0), kw.get("max_levels", 0), kw.get("max_distinct", 0), 0, 1)
     r = CResult()
     buf = C.create_string_buffer(1 << 20)

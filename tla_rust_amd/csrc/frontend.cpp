@@ -294,6 +294,11 @@ constexpr uint64_t H_ATOMIC_ADD = 0x6c3a51af80fccd40ull;        // atomic_add.tl
 constexpr uint64_t H_RAFT = 0x289fe41014391a24ull;              // examples/raft.tla:8-517 (EXTENDS .. before ====)
 constexpr uint64_t H_TEXTBOOK_SI = 0x26b4e8333db4314cull;      // examples/textbookSnapshotIsolation.tla (EXTENDS .. before ====)
 constexpr uint64_t H_SSI = 0x85c02cbaf85b39ceull;              // examples/serializableSnapshotIsolation.tla:21-1579
+constexpr uint64_t H_ATOMIC_ADD_N = 0x586f8fd08bcb696bull;      // specs/atomic_add_n.tla (--algorithm .. end algorithm)
+// the model wrappers of this repo (EXTENDS .. before ====): StateConstraint, the invariant definitions, Perms
+constexpr uint64_t H_MCRAFT = 0xa9171a6df0ae47d0ull;            // specs/MCraft.tla
+constexpr uint64_t H_MCSSI = 0xefcc77c2546e41bfull;             // specs/MCssi.tla
+constexpr uint64_t H_MCTEXTBOOK_SI = 0xe66bad24776b2048ull;     // specs/MCtextbookSI.tla
 
 bool algorithm_text(const std::string &t, std::string &out) {
     const size_t i = t.find("--algorithm");
@@ -495,7 +500,7 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
         const CfgConst *srv = find_const(c, "Server");
         if (!srv || srv->replacement || srv->value.kind != CfgValue::SET || srv->value.elems.empty())
             return fe_fail(MC_EBADCFG, "raft needs CONSTANT Server = {s1, ..., sn}");
-        long long mcr = 0, mt = 0, ml = 0, mm = 0;
+        long long mcr = 0, mt = 0, ml = 0, mm = 0, mk = 0;
         if (!const_int(c, "MaxClientRequests", mcr)) return fe_fail(MC_EBADCFG, "raft needs CONSTANT MaxClientRequests = <number> (raft.tla:23-24)");
         bool has_constraint = false;
         for (const auto &k : c->constraints) {
@@ -504,8 +509,9 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
         }
         if (!has_constraint)
             return fe_fail(MC_EBADCFG, "raft.tla has an unbounded term counter (raft.tla:199): the cfg must name CONSTRAINT StateConstraint");
-        if (!const_int(c, "MaxTerm", mt) || !const_int(c, "MaxLogLen", ml) || !const_int(c, "MaxMsgs", mm))
-            return fe_fail(MC_EBADCFG, "StateConstraint needs CONSTANTS MaxTerm, MaxLogLen, MaxMsgs");
+        if (!const_int(c, "MaxTerm", mt) || !const_int(c, "MaxLogLen", ml) || !const_int(c, "MaxMsgs", mm) || !const_int(c, "MaxMsgKeys", mk))
+            return fe_fail(MC_EBADCFG, "StateConstraint needs CONSTANTS MaxTerm, MaxLogLen, MaxMsgs, MaxMsgKeys");
+        if (mk < 1 || mk > 64) return fe_fail(MC_EBADCFG, "MaxMsgKeys must be 1..64 (the packed state holds at most 64 message keys)");
         long long mask = 0;
         for (const auto &i : c->invariants) {
             if (i == "NoTwoLeaders") mask |= 1;
@@ -513,9 +519,10 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
             else return fe_fail(MC_ENOSPEC, "MCraft defines no invariant named '%s'", i.c_str());
         }
         out->spec_id = MC_SPEC_RAFT;
-        out->nparams = 6;
+        out->nparams = 10;  // [6..8] = slot-array capacities (0 = defaults), [9] = MaxMsgKeys
         out->params[0] = (long long)srv->value.elems.size();
         out->params[1] = mcr; out->params[2] = mt; out->params[3] = ml; out->params[4] = mm; out->params[5] = mask;
+        out->params[6] = mk > 40 ? mk : 0; out->params[7] = 0; out->params[8] = 0; out->params[9] = mk;
         return MC_OK;
     }
     const bool textbook = m == "MCtextbookSI" || m == "textbookSnapshotIsolation";  // examples/textbookSnapshotIsolation.tla
@@ -712,10 +719,15 @@ struct Resolved {
     mc_spec_desc d;
     mc_program *prog = nullptr;
     std::string tla, module, def_text, def_module_name;  // def_*: text + name of the module that holds the action definitions
+    std::string warning;  // printed at the top of the report (MC_F_UNVERIFIED)
     ~Resolved() { if (prog) mc_program_free(prog); }
 };
 }  // namespace
 static int resolve_files(const char *tla_path, const char *cfg_path, unsigned flags, Resolved &R) {
+    {   // MC_F_UNVERIFIED can also be given through the environment (callers that only have the `mc` command line of a script)
+        const char *uv = getenv("TLAMC_UNVERIFIED");
+        if (uv && uv[0] == '1') flags |= MC_F_UNVERIFIED;
+    }
     std::string &tla = R.tla, &module = R.module, &def_text = R.def_text, &def_module_name = R.def_module_name;
     mc_spec_desc &d = R.d;
     mc_program *&prog = R.prog;
@@ -750,6 +762,8 @@ static int resolve_files(const char *tla_path, const char *cfg_path, unsigned fl
         else if (rc) { mc_cfg_free(c); return rc; }
         if (!generic && d.spec_id == MC_SPEC_PCAL_INTRO && alg_hash != H_PCAL_INTRO && alg_hash != H_PCAL_INTRO_README) generic = true;
         if (!generic && d.spec_id == MC_SPEC_ATOMIC_ADD && module == "atomic_add" && alg_hash != H_ATOMIC_ADD) generic = true;
+        // an edited atomic_add_n.tla (another await, an extra label) is not the N-adder hand lowering: compile it instead
+        if (!generic && d.spec_id == MC_SPEC_ATOMIC_ADD && module == "atomic_add_n" && alg_hash != H_ATOMIC_ADD_N) generic = true;
     }
     const std::string symmetry_name = c->symmetry;
     mc_cfg_free(c);
@@ -762,15 +776,30 @@ static int resolve_files(const char *tla_path, const char *cfg_path, unsigned fl
         d.params[0] = alg_hash == H_PCAL_INTRO ? 0 : 1;
     } else if (d.spec_id == MC_SPEC_ATOMIC_ADD && module == "atomic_add") {
     } else if (d.spec_id == MC_SPEC_RAFT) {
-        std::string raft;  // MCraft EXTENDS raft: verify raft.tla when it can be found beside the wrapper
+        // The lowering is written against two texts: examples/raft.tla and the wrapper specs/MCraft.tla (StateConstraint,
+        // the invariant definitions).  Both are verified; a module that cannot be found is refused (never mis-checked)
+        // unless the caller asks for the built-in lowering unverified (MC_F_UNVERIFIED, `mc -unverified`).
+        std::string raft;
         const char *env = getenv("TLA_PATH");
         bool found = read_file(dir_of(tla_path) + "/raft.tla", raft) || (env && read_file(std::string(env) + "/raft.tla", raft));
         if (module == "raft") { raft = tla; found = true; }
+        else {
+            if (!module_body(tla, part)) return fe_fail(MC_ENOSPEC, "%s: cannot find the module body", tla_path);
+            const uint64_t hw = text_hash(part);
+            if (hw != H_MCRAFT)
+                return fe_fail(MC_ENOSPEC, "module %s differs from the wrapper the raft lowering was written against (specs/MCraft.tla; hash %016llx): "
+                               "its StateConstraint / invariant definitions are hard-wired", module.c_str(), (unsigned long long)hw);
+        }
         if (found) {
             if (!module_body(raft, part)) return fe_fail(MC_ENOSPEC, "raft.tla: cannot find the module body");
             const uint64_t h = text_hash(part);
             if (h != H_RAFT) return fe_fail(MC_ENOSPEC, "raft.tla differs from the text the lowering was written against (hash %016llx)", (unsigned long long)h);
             if (module != "raft") { def_text = raft; def_module_name = "raft"; }
+        } else if (flags & MC_F_UNVERIFIED) {
+            R.warning = "Warning: raft.tla was found neither beside the module nor under $TLA_PATH; the built-in lowering of examples/raft.tla was used without checking the module text.\n";
+        } else {
+            return fe_fail(MC_ENOSPEC, "module raft (EXTENDed by %s) was found neither beside it nor under $TLA_PATH: the lowering cannot be checked against its text "
+                           "(put raft.tla there, or pass -unverified to use the built-in lowering of examples/raft.tla as is)", module.c_str());
         }
     }
     if (d.spec_id == MC_SPEC_SSI && d.params[5]) {
@@ -785,12 +814,24 @@ static int resolve_files(const char *tla_path, const char *cfg_path, unsigned fl
         const char *env = getenv("TLA_PATH");
         bool found = read_file(dir_of(tla_path) + "/" + base + ".tla", ssi) || (env && read_file(std::string(env) + "/" + base + ".tla", ssi));
         if (module == base) { ssi = tla; found = true; }
+        else {
+            if (!module_body(tla, part)) return fe_fail(MC_ENOSPEC, "%s: cannot find the module body", tla_path);
+            const uint64_t hw = text_hash(part);
+            if (hw != (tb ? H_MCTEXTBOOK_SI : H_MCSSI))
+                return fe_fail(MC_ENOSPEC, "module %s differs from the wrapper the lowering was written against (specs/%s.tla; hash %016llx): "
+                               "its invariant and Perms definitions are hard-wired", module.c_str(), tb ? "MCtextbookSI" : "MCssi", (unsigned long long)hw);
+        }
         if (found) {
             if (!module_body(ssi, part)) return fe_fail(MC_ENOSPEC, "%s.tla: cannot find the module body", base.c_str());
             const uint64_t h = text_hash(part);
             if (h != (tb ? H_TEXTBOOK_SI : H_SSI))
                 return fe_fail(MC_ENOSPEC, "%s.tla differs from the text the lowering was written against (hash %016llx)", base.c_str(), (unsigned long long)h);
             if (module != base) { def_text = ssi; def_module_name = base; }
+        } else if (flags & MC_F_UNVERIFIED) {
+            R.warning = "Warning: " + base + ".tla was found neither beside the module nor under $TLA_PATH; the built-in lowering was used without checking the module text.\n";
+        } else {
+            return fe_fail(MC_ENOSPEC, "module %s (EXTENDed by %s) was found neither beside it nor under $TLA_PATH: the lowering cannot be checked against its text "
+                           "(put %s.tla there, or pass -unverified to use the built-in lowering as is)", base.c_str(), module.c_str(), base.c_str());
         }
     }
     return MC_OK;
@@ -828,6 +869,7 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     if (checkpoint_path && clean && (rc = mc_engine_checkpoint(e, checkpoint_path))) { mc_engine_destroy(e); return rc; }
 
     Out o{report, report_cap, 0};
+    if (!R.warning.empty()) o.put("%s", R.warning.c_str());
     o.put("Finished computing initial states: %llu distinct state%s generated.\n", (unsigned long long)res->level_distinct[0],
           res->level_distinct[0] == 1 ? "" : "s");
     if (res->verdict == MC_V_OK || res->verdict == MC_V_BUDGET) {
@@ -839,8 +881,18 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
         o.put("  Estimates of the probability that TLC did not check all reachable states\n"
               "  because two distinct states had the same fingerprint:\n  calculated (optimistic):  val = %.2g\n", opt);
     } else {
-        if (res->verdict == MC_V_ASSERT && !generic)
-            o.put("The first argument of Assert evaluated to FALSE; the second argument was:\n\"Failure of assertion at line 16, column 4.\"\n");
+        if (res->verdict == MC_V_ASSERT && !generic) {
+            // the message pcal2tla puts into the translation names the position of the `assert` statement in THIS module's
+            // text (pcal_intro.tla:16 col 4 in the reference's layout; the hash that selected the lowering ignores layout)
+            int al = 16, ac = 4;
+            const size_t a0 = tla.find("--algorithm");
+            size_t at = a0 == std::string::npos ? a0 : tla.find("assert", a0);
+            if (at != std::string::npos) {
+                al = 1; ac = 1;
+                for (size_t k = 0; k < at; k++) { if (tla[k] == '\n') { al++; ac = 1; } else ac++; }
+            }
+            o.put("The first argument of Assert evaluated to FALSE; the second argument was:\n\"Failure of assertion at line %d, column %d.\"\n", al, ac);
+        }
         else if (res->verdict == MC_V_ASSERT) { /* compiled program: the message names the failing assert, found below */ }
         else if (res->verdict == MC_V_INVARIANT) o.put("Error: Invariant %s is violated.\n", invariant_name(&d, res->violated_invariant));
         else if (res->verdict == MC_V_DEADLOCK) o.put("Error: Deadlock reached.\n");

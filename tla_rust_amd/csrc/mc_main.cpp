@@ -10,6 +10,9 @@
 //                                         the previous text is kept as X.old
 //
 // -generic  : check a PlusCal module through the compiled program even when a hand lowering exists.
+// -unverified: an MC wrapper (specs/MCraft.tla ...) EXTENDS a module of the reference (raft.tla); when that module is found
+//             neither beside the wrapper nor under $TLA_PATH the run is refused, unless this option accepts the built-in
+//             lowering unchecked (the report then starts with a warning).
 // -dump FILE: like TLC's -dump, write every distinct state found to FILE.
 // -checkpoint FILE / -recover FILE: TLC's checkpointing (testout1:10) and -recover: write the run (all states found, level
 //             boundaries, counters, parent pointers) after a search that stopped on -maxlevels / -maxdistinct without an
@@ -113,6 +116,7 @@ int main(int argc, char **argv) {
         else if (arg("-recover")) recover = argv[++i];
         else if (arg("-workers")) ++i;
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
+        else if (!strcmp(argv[i], "-unverified")) cfg.flags |= MC_F_UNVERIFIED;
         else if (arg("-device")) cfg.device = atoi(argv[++i]);
         else if (arg("-maxdistinct")) cfg.max_distinct = strtoull(argv[++i], 0, 10);
         else if (arg("-maxlevels")) cfg.max_levels = strtoull(argv[++i], 0, 10);
@@ -125,7 +129,7 @@ int main(int argc, char **argv) {
     }
     if (!tla) {
         fprintf(stderr,
-                "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-device D]\n"
+                "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-unverified] [-device D]\n"
                 "                [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]\n"
                 "                [-checkpoint FILE] [-recover FILE] [-gpus P]                             check X.tla like `tlc X.tla`\n"
                 "       mc --transpile X.tla [Y.tla ...]                                                  translate like `pcal2tla`\n"

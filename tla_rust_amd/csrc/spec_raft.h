@@ -51,6 +51,7 @@ enum : int { RA_RESTART, RA_TIMEOUT, RA_REQUESTVOTE, RA_BECOMELEADER, RA_CLIENTR
 struct RaftParams {
     int n, max_client_requests, max_term, max_log_len, max_msgs, inv_mask;
     int cm, ce, ca;  // capacities of the messages / elections / allLogs slot arrays (runtime: they size W)
+    int max_keys;    // MaxMsgKeys of specs/MCraft.tla: Cardinality(DOMAIN messages) <= max_keys (0 = unbounded)
 };
 
 // A small array that is guaranteed to live in registers: explicit scalar members and
@@ -179,7 +180,8 @@ struct SpecRaft {
         o.cm = np > 6 && p[6] > 0 ? (int)p[6] : 40;
         o.ce = np > 7 && p[7] > 0 ? (int)p[7] : 4;
         o.ca = np > 8 && p[8] > 0 ? (int)p[8] : 16;
-        if (o.cm > 64 || o.ce > 8 || o.ca > 64) return -1;
+        o.max_keys = np > 9 && p[9] > 0 ? (int)p[9] : 0;
+        if (o.cm > 64 || o.ce > 8 || o.ca > 64 || o.max_keys > 255) return -1;
         if (o.n != NS) return -1;
         if (o.max_client_requests < 1 || o.max_client_requests - 1 > rlog::LCAP || o.max_client_requests > 7) return -1;
         if (o.max_term < 1 || o.max_term > 6) return -1;  // term MaxTerm+1 must still fit 3 bits
@@ -300,7 +302,7 @@ struct SpecRaft {
 
     // Send(m) / WithMessage   raft.tla:117-121,138: increment (saturating at 2) or add with count 1
     template <class Ref>
-    MC_HD static unsigned send(const Local &l, Ref s, int cm, uint64_t key_word /*count bits zero*/, Delta &d) {
+    MC_HD static unsigned send(const Local &l, Ref s, const Params &prm, uint64_t key_word /*count bits zero*/, Delta &d) {
         int idx = l.nm;
         uint64_t old = 0;
         if (l.mfilter >> key_bucket(key_word) & 1ull) {  // possibly present: scan the bag
@@ -321,7 +323,9 @@ struct SpecRaft {
         }
         d.mnewA = key_word | 1;
         d.dinflight += 1;
-        return idx >= cm ? (unsigned)ST_OVERFLOW : 0u;
+        // a new key beyond MaxMsgKeys leaves the model (checked by the caller's bookkeeping): not a capacity overflow
+        if (prm.max_keys && idx >= prm.max_keys) return 0u;
+        return idx >= prm.cm ? (unsigned)ST_OVERFLOW : 0u;
     }
     // Discard(m) / WithoutMessage on the slot the message was read from   raft.tla:125-129,142
     MC_HD static void discard(int k, uint64_t mword, Delta &d) {
@@ -381,7 +385,7 @@ struct SpecRaft {
             action = RA_REQUESTVOTE;
             const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_CANDIDATE) return 0;
-            st |= send(l, s, prm.cm, mk_rvreq(sv_term(svi), rlog::last_term(lgi), rlog::len(lgi), i, j), d);
+            st |= send(l, s, prm, mk_rvreq(sv_term(svi), rlog::last_term(lgi), rlog::len(lgi), i, j), d);
         } else if (MC_FAM(F_BECOME) && slot >= 2 * NS + NS * NS && slot < 3 * NS + NS * NS) {  // BecomeLeader(i)   raft.tla:247-261
             const int i = slot - (2 * NS + NS * NS);
             action = RA_BECOMELEADER;
@@ -457,7 +461,7 @@ struct SpecRaft {
             const int nent = next <= lastEntry ? 1 : 0;                        // SubSeq(log[i], next, lastEntry)
             const unsigned ent = nent ? rlog::entry(lg, next) : 0u;
             const int ci = sv_commit(svi) < lastEntry ? sv_commit(svi) : lastEntry;
-            st |= send(l, s, prm.cm, mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j), d);
+            st |= send(l, s, prm, mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j), d);
         } else if (slot >= FIX && (FAM < 0 || FAM >= F_UPDTERM)) {
             const int q = slot - FIX, k = q / 3, kind = q % 3;
             if (k >= l.nm) return 0;
@@ -488,7 +492,7 @@ struct SpecRaft {
                     const bool logOk = llt > lt || (llt == lt && lli >= rlog::len(lg));
                     const bool grant = mterm == term && logOk && (sv_voted(svi) == 0 || sv_voted(svi) == j + 1);
                     if (grant) d.sv = sv_set_voted(svi, j + 1);
-                    st |= send(l, s, prm.cm, mk_rvresp(term, grant ? 1 : 0, lg, i, j), d);  // Reply(response, m)
+                    st |= send(l, s, prm, mk_rvresp(term, grant ? 1 : 0, lg, i, j), d);  // Reply(response, m)
                     discard(k, m, d);
                 } else if (MC_FAM(F_RVRESP) && mterm <= term && type == M_RVRESP) {
                     if (mterm == term) {  // HandleRequestVoteResponse   raft.tla:336-349
@@ -507,7 +511,7 @@ struct SpecRaft {
                     const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg);
                     const bool logOk = pidx == 0 || (pidx > 0 && pidx <= len && pterm == rlog::eterm(rlog::entry(lg, pidx)));
                     if (mterm < term || (mterm == term && stt == R_FOLLOWER && !logOk)) {  // reject   :361-373
-                        st |= send(l, s, prm.cm, mk_aeresp(term, 0, 0, i, j), d);
+                        st |= send(l, s, prm, mk_aeresp(term, 0, 0, i, j), d);
                         discard(k, m, d);
                     } else if (stt == R_CANDIDATE) {  // return to follower state   :374-378 (mterm = term here)
                         d.sv = sv_set_state(svi, R_FOLLOWER);
@@ -516,7 +520,7 @@ struct SpecRaft {
                         if (nent == 0 || (len >= index && rlog::eterm(rlog::entry(lg, index)) == rlog::eterm(ent))) {
                             // already done with request   :384-402; commitIndex' assigned AND UNCHANGED
                             if (mci != sv_commit(svi)) return 0;
-                            st |= send(l, s, prm.cm, mk_aeresp(term, 1, pidx + nent, i, j), d);
+                            st |= send(l, s, prm, mk_aeresp(term, 1, pidx + nent, i, j), d);
                             discard(k, m, d);
                         } else if (len >= index) {  // conflict: remove 1 entry   :403-410
                             d.log = rlog::drop_last(lg);
@@ -551,7 +555,10 @@ struct SpecRaft {
             return 0;
         }
         // bookkeeping shared by every action: counts in the globals word
-        if ((d.nmop & 1) && d.midxA >= l.nm) d.glob += 1ull << 8;
+        if ((d.nmop & 1) && d.midxA >= l.nm) {
+            d.glob += 1ull << 8;
+            if (prm.max_keys && l.nm + 1 > prm.max_keys) st |= ST_OUT_OF_MODEL;  // StateConstraint: Cardinality(DOMAIN messages) <= MaxMsgKeys
+        }
         if (l.nadd) {
             if (g_na(l.glob) + l.nadd > prm.ca) st |= ST_OVERFLOW;
             d.glob += (uint64_t)l.nadd << 24;

@@ -20,7 +20,7 @@ import time
 
 def parse(argv):
     o = dict(tla=None, config=None, maxdistinct=0, maxlevels=0, chunk=1 << 19, tablelog2=27, arena=1 << 25, backend="nccl", device=None,
-             generic=False)
+             generic=False, unverified=False)
     i = 0
     while i < len(argv):
         a = argv[i]
@@ -33,6 +33,9 @@ def parse(argv):
             i += 2
         elif a == "-generic":
             o["generic"] = True
+            i += 1
+        elif a == "-unverified":
+            o["unverified"] = True
             i += 1
         elif not a.startswith("-"):
             o["tla"] = a
@@ -80,7 +83,7 @@ def main(argv=None):
         dist.init_process_group(o["backend"])
     rank = dist.get_rank() if launched else 0
     world = dist.get_world_size() if launched else 1
-    rs = ResolvedSpec(o["tla"], o["config"], generic=o["generic"])
+    rs = ResolvedSpec(o["tla"], o["config"], generic=o["generic"], unverified=o["unverified"])
     chk = ShardedChecker(rs.spec, rs.params, device=device, chunk_states=o["chunk"], max_distinct=o["maxdistinct"], max_levels=o["maxlevels"],
                          table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"])
     if launched:  # communicator set-up (RCCL builds its rings on the first collective) stays out of the reported time
@@ -99,7 +102,7 @@ def main(argv=None):
         if r.verdict not in ("ok", "budget") and not o["generic"]:
             try:  # the counterexample: one GPU, the same search bounded to the error's depth
                 from . import check_files
-                one, rep = check_files(o["tla"], o["config"], device=device, max_levels=r.depth + 1, chunk_states=o["chunk"],
+                one, rep = check_files(o["tla"], o["config"], device=device, max_levels=r.depth + 1, chunk_states=o["chunk"], unverified=o["unverified"],
                                        table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"])
                 if one.verdict == r.verdict:
                     text = rep + f"(counterexample rebuilt by a one-GPU run bounded to depth {r.depth + 1}; the sharded search on {world} GPU" \
