@@ -301,7 +301,7 @@ done:
     return 0;
 }
 
-int oracle_run(const char *spec, const int64_t *params, int nparams, const or_options *opt, or_result *res) {
+static int run_any(const char *spec, const int64_t *params, int nparams, const or_options *opt, int threads, double max_seconds, or_result *res) {
     or_spec sp;
     memset(&sp, 0, sizeof sp);
     int rc;
@@ -314,9 +314,15 @@ int oracle_run(const char *spec, const int64_t *params, int nparams, const or_op
     if (rc) return rc;
     or_options o = {0, 0, 1, 1, NULL};
     if (opt) o = *opt;
-    rc = run_bfs(&sp, &o, res);
+    rc = threads > 0 ? or_run_bfs_mt(&sp, &o, threads, max_seconds, res) : run_bfs(&sp, &o, res);
     free(sp.ctx);
     return rc;
+}
+int oracle_run(const char *spec, const int64_t *params, int nparams, const or_options *opt, or_result *res) {
+    return run_any(spec, params, nparams, opt, 0, 0.0, res);
+}
+int oracle_run_mt(const char *spec, const int64_t *params, int nparams, const or_options *opt, int threads, double max_seconds, or_result *res) {
+    return run_any(spec, params, nparams, opt, threads < 1 ? 1 : threads, max_seconds, res);
 }
 
 const char *oracle_action_name(const char *spec, int action) {

@@ -86,6 +86,14 @@ typedef struct {
 int oracle_run(const char *spec, const int64_t *params, int nparams,
                const or_options *opt, or_result *res);
 
+/* Multi-threaded variant (oracle/bfs_mt.c): same specs, same counting conventions, exact dedup over a
+ * hash-sharded seen-set, `threads` worker threads per BFS level.  Counts, depth, per-level counts and the
+ * verdict only (no counterexample trace).  max_seconds > 0: stop (verdict budget) after the first level
+ * that ends later than that.  This is also the "in-house CPU BFS, all host cores - not TLC" baseline that
+ * bench.py reports beside the GPU number. */
+int oracle_run_mt(const char *spec, const int64_t *params, int nparams,
+                  const or_options *opt, int threads, double max_seconds, or_result *res);
+
 /* text of the k-th state of the last counterexample trace (valid until next oracle_run) */
 const char *oracle_trace_state(uint32_t k);
 const char *oracle_action_name(const char *spec, int action);

@@ -35,5 +35,7 @@ const char *or_raft_action(int a);
 const char *or_ssi_action(int a);
 
 void or_set_error(const char *fmt, ...);
+/* bfs_mt.c: the multi-threaded BFS (counts and verdict only; max_seconds > 0 stops after the level that exceeds it) */
+int or_run_bfs_mt(const or_spec *sp, const or_options *opt, int nthreads, double max_seconds, or_result *r);
 
 #endif

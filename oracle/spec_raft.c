@@ -493,7 +493,7 @@ static void receive(gen_t *g, int k) {
 static void raft_succ(void *ctx, const uint8_t *sb, size_t len, or_emit *em) {
     const raft_ctx *c = ctx;
     (void)len;
-    static State s; /* single-threaded oracle */
+    static _Thread_local State s; /* single-threaded oracle */
     deser(c, sb, &s);
     gen_t g;
     g.c = c; g.em = em; g.parent = &s;
@@ -521,7 +521,7 @@ static void raft_succ(void *ctx, const uint8_t *sb, size_t len, or_emit *em) {
 static int raft_n_init(void *ctx) { (void)ctx; return 1; }
 static size_t raft_init(void *ctx, int k, uint8_t *out) {
     const raft_ctx *c = ctx; (void)k;
-    static State s;
+    static _Thread_local State s;
     memset(&s, 0, sizeof s);
     for (int i = 0; i < c->n; i++) {
         s.currentTerm[i] = 1; s.state[i] = FOLLOWER; s.votedFor[i] = 0;
@@ -533,7 +533,7 @@ static size_t raft_init(void *ctx, int k, uint8_t *out) {
 /* StateConstraint of specs/MCraft.tla */
 static int raft_constraint(void *ctx, const uint8_t *sb, size_t len) {
     const raft_ctx *c = ctx; (void)len;
-    static State s;
+    static _Thread_local State s;
     deser(c, sb, &s);
     for (int i = 0; i < c->n; i++) {
         if (s.currentTerm[i] > c->max_term) return 0;
@@ -547,7 +547,7 @@ static int raft_constraint(void *ctx, const uint8_t *sb, size_t len) {
 /* NoTwoLeaders == ~MoreThanOneLeader (raft.tla:500-507); CommittedLogStable == ~committedLogDecrease */
 static int raft_invariant(void *ctx, const uint8_t *sb, size_t len) {
     const raft_ctx *c = ctx; (void)len;
-    static State s;
+    static _Thread_local State s;
     deser(c, sb, &s);
     if (c->inv_mask & 1)
         for (int i = 0; i < c->n; i++) for (int j = 0; j < c->n; j++)
@@ -557,7 +557,7 @@ static int raft_invariant(void *ctx, const uint8_t *sb, size_t len) {
 }
 static void raft_stats(void *ctx, const uint8_t *sb, size_t len, uint64_t *mx) {
     const raft_ctx *c = ctx; (void)len;
-    static State s;
+    static _Thread_local State s;
     deser(c, sb, &s);
     uint64_t inflight = 0;
     for (int k = 0; k < s.nm; k++) inflight += s.cnt[k];
@@ -642,7 +642,7 @@ static void p_sorted(sb_t *o, char **items, int n, const char *open, const char 
 static const char *st_name[] = {"Follower", "Candidate", "Leader"};
 static size_t raft_print(void *ctx, const uint8_t *sbytes, size_t len, char *buf, size_t cap) {
     const raft_ctx *c = ctx; (void)len;
-    static State s;
+    static _Thread_local State s;
     deser(c, sbytes, &s);
     int n = c->n;
     sb_t o = {buf, cap, 0};

@@ -47,6 +47,8 @@ def oracle_lib():
         lib = C.CDLL(str(so))
         lib.oracle_run.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(OrOptions), C.POINTER(OrResult)]
         lib.oracle_run.restype = C.c_int
+        lib.oracle_run_mt.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(OrOptions), C.c_int, C.c_double, C.POINTER(OrResult)]
+        lib.oracle_run_mt.restype = C.c_int
         lib.oracle_trace_state.argtypes = [C.c_uint32]
         lib.oracle_trace_state.restype = C.c_char_p
         lib.oracle_action_name.argtypes = [C.c_char_p, C.c_int]
@@ -70,6 +72,20 @@ def oracle_run(spec, params, max_levels=0, max_distinct=0, check_deadlock=True, 
                 verdict=VERDICTS[res.verdict], violated_invariant=res.violated_invariant,
                 levels=[res.level_distinct[i] for i in range(res.depth)], trace=trace, seconds=res.seconds,
                 max_stat=list(res.max_stat))
+
+
+def oracle_run_mt(spec, params, threads, max_levels=0, max_distinct=0, check_deadlock=True, max_seconds=0.0):
+    """The multi-threaded oracle (oracle/bfs_mt.c): counts, depth, per-level counts and verdict; no trace."""
+    lib = oracle_lib()
+    p = (C.c_int64 * len(params))(*params)
+    opt = OrOptions(max_levels, max_distinct, int(check_deadlock), 1, None)
+    res = OrResult()
+    rc = lib.oracle_run_mt(spec.encode(), p, len(params), C.byref(opt), threads, max_seconds, C.byref(res))
+    if rc:
+        raise RuntimeError(lib.oracle_last_error().decode())
+    return dict(distinct=res.distinct, generated=res.generated, queue_left=res.queue_left, depth=res.depth,
+                verdict=VERDICTS[res.verdict], violated_invariant=res.violated_invariant,
+                levels=[res.level_distinct[i] for i in range(res.depth)], seconds=res.seconds, max_stat=list(res.max_stat))
 
 
 def raft_oracle_params(dev):
