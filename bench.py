@@ -6,11 +6,12 @@ from rank 0.  A "step" is one complete pass of the hot path over the workload: a
 frozen model configuration from Init to the budget level (every level: expand -> seen-set insert
 -> materialise), starting from a cleared seen-set.  Nothing is cached between steps.
 
-Workload (BASELINE.json configs[2]): examples/raft.tla under
+Workload (BASELINE.json configs[2] "single-GPU full BFS"): examples/raft.tla under
 specs/MCraft.cfg — Server = {s1,s2,s3}, MaxClientRequests = 4 (=> MaxLogLen 3), MaxTerm = 2,
-MaxMsgs = 1, INVARIANT NoTwoLeaders, level-budgeted at the first level whose cumulative distinct
-count reaches 25,000,000 (25,752,293 distinct / 23 levels; golden per-level counts from the CPU
-oracle in tests/golden/raft_levels.json).
+MaxMsgs = 1, MaxMsgKeys = 10, INVARIANT NoTwoLeaders — the COMPLETE state graph: 102,586,254 distinct /
+1,217,433,925 generated / depth 33, verdict "ok" with nothing left on the queue (golden per-level counts
+from the exact-dedup CPU oracle in tests/golden/raft_levels.json; the line is refused unless the run
+reproduces them).
 """
 import argparse
 import json
@@ -23,25 +24,35 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-# params[6..8] = capacities of the messages / elections / allLogs slot arrays of the packed state:
-# the oracle's maxima over this prefix are 14 / 1 / 4 (tests/golden/raft_levels.json max_stat);
-# an overflow would raise MC_EOVERFLOW, never drop a state.  W = 18 + 16 + 2*4 + 8 = 50 words.
-WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 16, 2, 8], max_distinct=25_000_000,
-                name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1, budget 25M distinct")
+# params[6..8] = capacities of the messages / elections / allLogs slot arrays of the packed state = the
+# oracle's maxima over the complete graph, 10 / 1 / 4 (tests/golden/raft_levels.json max_stat); an overflow
+# would raise MC_EOVERFLOW, never drop a state.  params[9] = MaxMsgKeys.  W = 18 + 10 + 1*4 + 4 = 36 words = 288 B.
+WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 10, 1, 4, 10], golden="raft3_mcr4_t2_m1_k10_complete",
+                name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=10 "
+                     "(specs/MCraft.cfg), complete state graph")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(sample_distinct=1_500_000):
-    """The oracle ("port") timed on the host cores: same workload, bounded prefix."""
+def golden():
+    g = json.loads((ROOT / "tests" / "golden" / "raft_levels.json").read_text())
+    return next(c for c in g["cases"] if c["name"] == WORKLOAD["golden"])
+
+
+def cpu_baseline(max_seconds=15.0):
+    """The exact-dedup CPU oracle ("port"; in-house CPU BFS, NOT TLC: the box has no JVM) on ALL host cores
+    (TLC's run-book: "Number of worker threads: Use the number of cpu cores",
+    examples/serializableSnapshotIsolation.tla:52-53): same model, BFS levels until `max_seconds` have passed."""
     exe = ROOT / "oracle" / "_build" / "oracle_mc"
     if not exe.exists():
         subprocess.run(["make", "-s", "-C", str(ROOT / "oracle")], check=True)
-    p = [str(x) for x in WORKLOAD["params"][:6]]
-    out = subprocess.run([str(exe), "raft", *p, "--distinct", str(sample_distinct)], capture_output=True, text=True, check=True).stdout
+    cores = os.cpu_count() or 1
+    p = [str(x) for x in WORKLOAD["params"][:6]] + ["0", str(WORKLOAD["params"][9])]
+    out = subprocess.run([str(exe), "raft", *p, "--threads", str(cores), "--max-seconds", str(max_seconds), "--distinct", "60000000"],
+                         capture_output=True, text=True, check=True).stdout
     r = json.loads(out.splitlines()[0])
-    return dict(value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=1, kind="port",
-                sample=f"same cfg, BFS prefix to {r['distinct']} distinct / {r['generated']} generated states "
-                       f"({r['seconds']:.1f} s, single-thread exact-dedup C oracle, in-house CPU BFS — not TLC)")
+    return dict(value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=cores, kind="port",
+                sample=f"not TLC (no JVM on the box): in-house exact-dedup multi-threaded C BFS, {cores} threads, same cfg, "
+                       f"levels 1-{r['depth']} = {r['distinct']} distinct / {r['generated']} generated states in {r['seconds']:.1f} s")
 
 
 def main():
@@ -50,12 +61,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--max-distinct", type=int, default=WORKLOAD["max_distinct"])
+    ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
     ap.add_argument("--chunk", type=int, default=1 << 22)
     ap.add_argument("--shard-chunk", type=int, default=1 << 21, help="frontier states per round and rank in the sharded (torchrun) path")
-    ap.add_argument("--table-log2", type=int, default=28)
+    ap.add_argument("--table-log2", type=int, default=27, help="seen-set slots: 2^27 = load 0.76 at the end of the run")
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
+    ap.add_argument("--direct", action="store_true", help="A/B: one kernel per chunk (k_expand_direct: expand + insert + copy-and-patch write)")
+    ap.add_argument("--fam-blocks", type=int, default=4, choices=[1, 2, 4], help="A/B: arena blocks per wavefront of the by-family expand kernel")
+    ap.add_argument("--occ3", action="store_true", help="A/B: k_expand_direct compiled for 3 waves per SIMD (no register spills)")
     a = ap.parse_args()
 
     import torch
@@ -71,21 +85,20 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    G0 = golden()
     if not use_dist:
-        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << a.table_log2, matrix=a.matrix, debug_flags=32 if a.no_family else 0,
-                         arena_capacity=30_000_000 if a.max_distinct <= 25_000_000 else 2 * a.max_distinct,
+        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << a.table_log2, matrix=a.matrix,
+                         debug_flags=(32 if a.no_family else 0) | (1024 if a.direct else 0) | (2048 if a.occ3 else 0) | {1: 4096, 2: 8192, 4: 0}[a.fam_blocks],
+                         arena_capacity=G0["distinct"] + (1 << 20),
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run
     else:
         from tla_rust_amd.sharded import ShardedChecker
-        # weak scaling: the distinct-state budget grows with the number of GPUs
-        # deeper levels than the single-GPU prefix are reached: the message-slot maximum grows by about one per
-        # level (13 at level 23), so the sharded run gets 24 message slots (W = 464 B) instead of 16
-        sharded_params = WORKLOAD["params"][:6] + [int(os.environ.get("TLAMC_SHARD_CM", "24")), 2, 8]
-        chk = ShardedChecker(WORKLOAD["spec"], sharded_params, device=local, max_distinct=a.max_distinct * world,
-                             chunk_states=a.shard_chunk, table_capacity=1 << 27,
-                             # the last level may overshoot the budget by the growth factor (~1.7x): size for it
-                             arena_capacity=64_000_000,
+        # strong scaling: the same complete graph, its seen-set and frontier sharded over the ranks by fingerprint
+        chk = ShardedChecker(WORKLOAD["spec"], WORKLOAD["params"], device=local, max_distinct=a.max_distinct,
+                             chunk_states=a.shard_chunk, table_capacity=(1 << 28) // world,
+                             # a rank's share of the states (+25 % imbalance allowance) + the replicated prefix
+                             arena_capacity=int(G0["distinct"] / world * 1.25) + (1 << 22),
                              fanout_cap=48, new_cap=6)
         run = chk.run
 
@@ -110,12 +123,22 @@ def main():
     if rank != 0:
         return
     D, G = res.distinct, res.generated
+    if not a.max_distinct:
+        # parity gate: the measured run must BE the golden graph (exact counts, per-level where the engine reports them)
+        got = (D, G, res.depth, res.verdict)
+        want = (G0["distinct"], G0["generated"], G0["depth"], "ok")
+        if got != want or ("levels" in res and list(res["levels"]) != G0["levels"]):
+            print(f"bench.py: run does not reproduce the golden state graph: got {got}, want {want}", file=sys.stderr)
+            sys.exit(1)
     line = {
         "metric": "distinct states/sec, raft.tla (3 servers)", "value": D * a.steps / dt, "unit": "distinct states/s",
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if a.gpus > 1 else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": WORKLOAD["name"], "distinct": D, "generated": G, "depth": res.depth,
-                   "verdict": res.verdict, "generated_per_s": G * a.steps / dt},
+                   "verdict": res.verdict, "queue_left": res.queue_left, "generated_per_s": G * a.steps / dt,
+                   "seen_set_load": D / float(1 << a.table_log2) if not use_dist else None,
+                   "golden": f"tests/golden/raft_levels.json:{WORKLOAD['golden']} (exact-dedup CPU oracle): counts and per-level counts equal"
+                             if not a.max_distinct else "A/B run with a budget: NOT the benchmark"},
     }
     if use_dist:
         line["config"]["parallelism"] = (f"fingerprint-sharded seen-set x{world}, replicated prefix for the small levels, "
@@ -126,7 +149,10 @@ def main():
         W = ks["state_bytes"]
         # algorithmic bytes per launch: expand reads W per frontier state,
         # insert touches one 8-byte seen-set word per generated candidate, materialise writes W per new state
+        direct = a.direct and not (a.matrix or a.no_family)   # k_expand_direct: expand + insert + write in one kernel
         alg = {"expand": W * ks["expand"]["units"], "insert": 8 * ks["cand_cells"], "materialise": W * ks["materialise"]["units"]}
+        if direct:  # reads W per expanded state, touches 8 B of the seen-set per in-model successor, writes W per new state
+            alg["expand"] = W * ks["expand"]["units"] + 8 * ks["cand_cells"] + W * D
         dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
         n_runs = a.steps  # stats are reset by every run(): they describe the last step
         ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
@@ -135,7 +161,7 @@ def main():
         if pmc:  # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same command
             try:
                 d = json.loads(pmc[-1].read_text())
-                knames = {"expand": ("k_expand_insert",) if a.no_family else ("k_expand_family", "k_expand_insert"),
+                knames = {"expand": ("k_expand_direct",) if direct else ("k_expand_insert",) if a.no_family else ("k_expand_family", "k_expand_insert"),
                           "insert": ("k_insert",), "materialise": ("k_materialise",)}[dom]
                 k = next(v for kn in knames for n, v in d.items() if n.startswith(kn + "<") and "Raft<3>" in n)
                 # FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts wide coalesced reads at 1/2 (MI355X_MICROARCH.md §HBM)
@@ -143,7 +169,7 @@ def main():
                 traffic_src = f"profiles/{pmc[-1].name}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes"
             except Exception:  # noqa: BLE001
                 traffic = None
-        kernel_name = {"expand": "k_expand_insert<SpecRaft<3>>" if (a.no_family or a.matrix) else "k_expand_family<SpecRaft<3>>",
+        kernel_name = {"expand": "k_expand_direct<SpecRaft<3>>" if direct else "k_expand_insert<SpecRaft<3>>" if (a.no_family or a.matrix) else "k_expand_family<SpecRaft<3>>",
                        "insert": "k_insert", "materialise": "k_materialise<SpecRaft<3>>"}[dom]
         line["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -74,6 +74,10 @@ typedef struct {
 #define MC_F_MATRIX 8u   /* A/B only: unfused expand -> candidate matrix -> insert kernels          */
 #define MC_F_NOPROBE 16u /* profiling only (mc_engine_debug_reexpand): skip the seen-set probes   */
 #define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
+#define MC_F_DIRECT 1024u /* A/B only: one kernel per chunk (expand + insert + copy-and-patch write, k_expand_direct) instead of
+                          * expand and materialise on two streams; measured slower, kept for the comparison */
+#define MC_F_FAMBLOCKS1 4096u /* A/B only: the by-family expand kernel works through 1 (default 4) arena blocks per wavefront */
+#define MC_F_FAMBLOCKS2 8192u /* A/B only: ... 2 blocks per wavefront                                                   */
 #define MC_F_NOBATCH 256u /* A/B only: one host round trip per BFS level even while the frontier is small         */
 #define MC_F_UNVERIFIED 512u /* mc_check_files / mc_resolve_files: when the module an MC wrapper EXTENDS (raft.tla, the snapshot-isolation
                              specs) is found neither beside it nor under $TLA_PATH, use the built-in lowering anyway (the report
@@ -205,6 +209,11 @@ int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new);  
 int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t *n_new);
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local_states);  /* swap frontiers                                */
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict);
+/* Before a sharded run that stops on a budget reports: evaluate the invariants of this rank's unexpanded frontier for the
+ * specs that check invariants when a state is expanded (the snapshot-isolation models); TLC checks a state when it is
+ * generated, so no counted state may stay unchecked.  A violation shows up in mc_shard_counters' verdict.  No-op for the
+ * other specs. */
+int mc_shard_check_frontier(mc_engine *e);
 
 /* ------------------------------------------------------------------ PlusCal front-end (host only)
  * The reference's workflow is `pcal2tla *tla` then `tlc *tla` (Makefile:3-7).  mc_pcal_translate is the first

@@ -106,6 +106,16 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
             return 0;
         }
     }
+    // the copy + patch writer of k_expand_direct (eval_pair_delta + write_patched) must produce exactly apply()'s successor
+    template <int F, class Ref>
+    static unsigned run_delta(int fam, const typename S::Params &p, const typename S::Summary &q, Ref s, int slot, uint64_t &fp, uint64_t *pd) {
+        if constexpr (F < S::NFAM) {
+            if (fam == F) return S::template eval_pair_delta<F>(p, q, s, slot, fp, pd);
+            return run_delta<F + 1>(fam, p, q, s, slot, fp, pd);
+        } else {
+            return 0;
+        }
+    }
     template <class Ref>
     static uint64_t mismatches(const typename S::Params &p, typename S::Local &l, Ref s, int ns) {
         typename S::Guards g;
@@ -122,6 +132,19 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
             else fam = S::guard_msg(g, s.get(S::W_MSG0 + (slot - S::FIX) / 3), (slot - S::FIX) % 3);
             const unsigned st1 = fam >= 0 ? run<0>(fam, p, q, s, slot, f1) : 0u;
             if (st0 != st1 || ((st0 & ST_ENABLED) && f0 != f1)) bad++;
+            if (st0 & ST_SELFLOOP) {  // claimed stuttering step: apply() must reproduce the parent word for word
+                uint64_t a[S::MAX_WORDS];
+                S::apply(p, s, slot, WordRef{a, 1});
+                for (int w = 0; w < S::words(p); w++) if (a[w] != s.get(w)) { bad++; break; }
+            }
+            if ((st1 & ST_ENABLED) && !(st1 & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR | ST_ASSERT | ST_SELFLOOP))) {
+                uint64_t pd[S::PATCH_WORDS] = {}, f2 = 0, a[S::MAX_WORDS], b[S::MAX_WORDS];
+                const unsigned st2 = run_delta<0>(fam, p, q, s, slot, f2, pd);
+                pd[0] |= 0xdeadbeefull;  // the caller's source tag must not disturb the patch
+                S::apply(p, s, slot, WordRef{a, 1});
+                S::write_patched(p, s, pd, q, WordRef{b, 1});
+                if (st2 != st1 || f2 != f1 || memcmp(a, b, sizeof(uint64_t) * (size_t)S::words(p)) != 0) bad++;
+            }
             if (fam >= 0) cnt[fam]++;
         }
         if (stats().on) stats().state_done(cnt);
@@ -214,6 +237,16 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
         cur.swap(next);
         if (!cur.empty()) level++;
         if (level >= MC_MAX_LEVELS) break;
+    }
+    if (!r->verdict && !cur.empty()) {  // engine.hip k_check_frontier: check-on-expand invariants of the level the run stops on
+        const uint64_t nstates = cur.size() / (size_t)W;
+        for (uint64_t i = 0; i < nstates && !r->verdict; i++) {
+            CWordRef s{&cur[i * W], 1};
+            typename S::Local loc;
+            S::load(prm, s, loc);
+            const unsigned ps = S::parent_status(prm, loc, s);
+            if (ps & ST_INVARIANT) violation(ps, level);
+        }
     }
     r->depth = level;
     r->levels = level;
@@ -319,6 +352,7 @@ struct ShimShardBase {
     virtual int keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) = 0;
     virtual uint64_t end_level() = 0;
     virtual void counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
+    virtual void check_frontier() = 0;
 };
 
 template <class S>
@@ -521,6 +555,14 @@ struct ShimShard : ShimShardBase {
     }
     uint64_t end_level() override { lo = hi; hi = nstates(); return hi - lo; }
     void counters(uint64_t *g, uint64_t *d, int32_t *v) override { *g = generated; *d = nstates() - dup; *v = verdict; }
+    void check_frontier() override {  // mc_shard_check_frontier: check-on-expand invariants of the unexpanded local frontier
+        for (uint64_t i = lo; i < hi && verdict == MC_V_OK; i++) {
+            CWordRef s{&arena[i * W], 1};
+            typename S::Local loc;
+            S::load(prm, s, loc);
+            if (S::parent_status(prm, loc, s) & ST_INVARIANT) verdict = MC_V_INVARIANT;
+        }
+    }
 };
 
 extern "C" {
@@ -555,4 +597,5 @@ int shim_shard_ingest(void *e, const uint8_t *states, uint64_t n) { return ((Shi
 int shim_shard_keep(void *e, uint32_t slot, const uint8_t *ans, uint64_t *n) { return ((ShimShardBase *)e)->keep(slot, ans, n); }
 int shim_shard_end_level(void *e, uint64_t *n) { *n = ((ShimShardBase *)e)->end_level(); return 0; }
 int shim_shard_counters(void *e, uint64_t *g, uint64_t *d, int32_t *v) { ((ShimShardBase *)e)->counters(g, d, v); return 0; }
+int shim_shard_check_frontier(void *e) { ((ShimShardBase *)e)->check_frontier(); return 0; }
 }

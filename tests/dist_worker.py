@@ -34,12 +34,12 @@ def main():
         from shim_step_engine import ShimStepEngine
         eng = ShimStepEngine(spec, params, rank, world)
         chk = ShardedChecker(spec, params, engine=eng, chunk_states=opts.get("chunk", 1000), max_distinct=opts.get("max_distinct", 0),
-                             fanout_cap=opts.get("fanout_cap", 64), new_cap=opts.get("new_cap", 64),
+                             max_levels=opts.get("max_levels", 0), fanout_cap=opts.get("fanout_cap", 64), new_cap=opts.get("new_cap", 64),
                              stay_threshold=opts.get("stay_threshold", 1 << 16), rebalance_ratio=opts.get("rebalance_ratio", 1.25),
                              replicate_until=opts.get("replicate_until", 0))
     else:
         chk = ShardedChecker(spec, params, device=0, chunk_states=opts.get("chunk", 1 << 14), max_distinct=opts.get("max_distinct", 0),
-                             table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
+                             max_levels=opts.get("max_levels", 0), table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
                              fanout_cap=opts.get("fanout_cap", 32), new_cap=opts.get("new_cap", 16),
                              stay_threshold=opts.get("stay_threshold", 1 << 16), rebalance_ratio=opts.get("rebalance_ratio", 1.25),
                              replicate_until=opts.get("replicate_until", 0))

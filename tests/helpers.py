@@ -95,6 +95,16 @@ def raft_oracle_params(dev):
     return dev[:6] + ([0, dev[9]] if len(dev) > 9 and dev[9] else [])
 
 
+def raft_device_params(orc, cm=0, ce=0, ca=0):
+    """inverse of raft_oracle_params: the oracle's vector -> the lowering's, with slot-array capacities (0 = defaults; with a
+    MaxMsgKeys bound the message array needs exactly that many slots)"""
+    orc = list(orc)
+    keys = orc[7] if len(orc) > 7 else 0
+    if not (cm or ce or ca or keys):
+        return orc[:6]
+    return orc[:6] + [cm or keys, ce, ca] + ([keys] if keys else [])
+
+
 # ---------------------------------------------------------------------------------- shim
 MC_MAX_LEVELS = 4096
 SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5}

@@ -28,6 +28,7 @@ class ShimStepEngine:
         L.shim_shard_keep.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
         L.shim_shard_end_level.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.shim_shard_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+        L.shim_shard_check_frontier.argtypes = [C.c_void_p]
         self.world = world
         d = helpers.spec_desc(spec, params)
         L.shim_state_bytes.restype = C.c_size_t
@@ -83,6 +84,9 @@ class ShimStepEngine:
         n = C.c_uint64()
         self.lib.shim_shard_end_level(self.h, C.byref(n))
         return n.value
+
+    def check_frontier(self):
+        self.lib.shim_shard_check_frontier(self.h)
 
     def counters(self):
         g, d, v = C.c_uint64(), C.c_uint64(), C.c_int32()

@@ -141,3 +141,73 @@ def test_large_checkpoint_round_trip(amd, tmp_path):
     r = b.run()
     assert (r.verdict, r.distinct, r.generated, r.depth) == ("ok", 7910565, 13246749, 17)
     b.close()
+
+
+def test_checkpoint_of_a_compiled_program_is_bound_to_that_program(amd, tmp_path):
+    """a checkpoint of a compiled PlusCal program must be refused by ANY other program (other algorithm, other
+    constants, other invariants), not only by one with another state width: the header carries a hash of the program image."""
+    S = ROOT / "specs" / "pluscal"
+    text = (S / "cas_counter.tla").read_text()
+    cfg = (S / "cas_counter.cfg").read_text()
+    kw = dict(table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
+    prog = amd.Program(text, cfg)
+    full = amd.Engine("pcal", prog.params, **kw)
+    want = full.run()
+    full.close()
+    a = amd.Engine("pcal", prog.params, max_levels=6, **kw)
+    assert a.run().verdict == "budget"
+    ck = tmp_path / "cas.ckpt"
+    a.checkpoint(ck)
+    a.close()
+    b = amd.Engine("pcal", prog.params, **kw)      # the same program: accepted, and the continued run equals the uninterrupted one
+    b.restore(ck)
+    rb = b.run()
+    assert (rb.distinct, rb.generated, rb.depth, rb.verdict, rb.levels) == (want.distinct, want.generated, want.depth, want.verdict, want.levels)
+    b.close()
+    # the same algorithm with another constant (same variables, same state width) and with one invariant less: both refused
+    import re
+    other_n = amd.Program(text, re.sub(r"N\s*=\s*\d+", "N = 3", cfg))
+    assert " SeenIsOld" in cfg
+    fewer_inv = amd.Program(text, cfg.replace(" SeenIsOld", ""))
+    for other in (other_n, fewer_inv):
+        assert amd.state_bytes("pcal", other.params) == amd.state_bytes("pcal", prog.params)
+        e = amd.Engine("pcal", other.params, **kw)
+        with pytest.raises(amd.McError) as ei:
+            e.restore(ck)
+        assert "another compiled program" in str(ei.value)
+        e.close()
+        other.close()
+    prog.close()
+
+
+def test_corrupt_level_table_is_refused(amd, tmp_path):
+    """restore() validates the level table (starts at 0, strictly increasing, consistent with the frontier)"""
+    import struct
+    e = amd.Engine("ssi", [2, 2, 127, 0], max_levels=6, **KW)
+    r = e.run()
+    e.checkpoint(tmp_path / "ok")
+    e.close()
+    data = bytearray((tmp_path / "ok").read_bytes())
+    # header: magic[8] spec_id nparams params[16] words has_trace distinct generated cells lo hi nlevels, then the level table
+    hdr = 8 + 4 + 4 + 16 * 8 + 4 + 4 + 6 * 8
+    nlevels = struct.unpack_from("<Q", data, hdr - 8)[0]
+    assert nlevels == r.depth
+    for mutate in (lambda t: [t[0] + 1] + t[1:], lambda t: t[:2] + [t[1]] + t[3:], lambda t: t[:-1] + [t[-1] + 1]):
+        bad = bytearray(data)
+        table = list(struct.unpack_from(f"<{nlevels}Q", bad, hdr))
+        struct.pack_into(f"<{nlevels}Q", bad, hdr, *mutate(table))
+        (tmp_path / "bad").write_bytes(bad)
+        e = amd.Engine("ssi", [2, 2, 127, 0], **KW)
+        with pytest.raises(amd.McError) as ei:
+            e.restore(tmp_path / "bad")
+        assert ei.value.code == -8
+        e.close()
+    e = amd.Engine("ssi", [2, 2, 127, 0], max_levels=10, **KW)
+    assert e.run().distinct * 2 > 1 << 10
+    e.checkpoint(tmp_path / "ten")
+    e.close()
+    small_table = amd.Engine("ssi", [2, 2, 127, 0], table_capacity=1 << 10, arena_capacity=1 << 20, chunk_states=1 << 12)
+    with pytest.raises(amd.McError) as ei:      # the states of ten levels do not fit a 1024-slot seen-set at load 1/2
+        small_table.restore(tmp_path / "ten")
+    assert ei.value.code == -4
+    small_table.close()

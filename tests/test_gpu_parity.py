@@ -129,6 +129,34 @@ def test_raft_golden_levels_on_gpu(amd, name):
     eng.close()
 
 
+@pytest.mark.parametrize("name,caps", [("raft3_mcr4_t2_m1_k5_complete", (0, 0, 0)), ("raft3_mcr4_t2_m1_k7_complete", (7, 1, 4)),
+                                       ("raft3_mcr4_t3_m2_k5_complete", (0, 0, 0))])
+def test_raft_complete_graphs_on_gpu(amd, oracle, name, caps):
+    """COMPLETE 3-server graphs (verdict ok, nothing left on the queue): StateConstraint's MaxMsgKeys conjunct makes the graph
+    finite; per-level counts of the oracle's exact-dedup run (tests/golden/raft_levels.json)."""
+    c = _golden(name)
+    params = oracle.raft_device_params(c["params"], *caps)
+    eng = amd.Engine("raft", params, table_capacity=2 * c["distinct"], arena_capacity=c["distinct"] + (1 << 16), chunk_states=1 << 19, trace=False)
+    r = eng.run()
+    assert r.levels == c["levels"]
+    assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (c["distinct"], c["generated"], c["depth"], "ok", 0)
+    eng.close()
+
+
+def test_bench_workload_complete_on_gpu(amd, oracle):
+    """bench.py's workload = BASELINE config 3 = specs/MCraft.cfg: the COMPLETE graph of raft.tla with 3 servers, 102 586 254 states,
+    with the slot capacities bench.py uses (10 / 1 / 4 = the oracle's maxima, W = 288 B) and its seen-set load (0.76)."""
+    c = _golden("raft3_mcr4_t2_m1_k10_complete")
+    params = oracle.raft_device_params(c["params"], 10, 1, 4)
+    assert params == [3, 4, 2, 3, 1, 1, 10, 1, 4, 10] and amd.state_bytes("raft", params) == 288
+    assert c["max_stat"][:3] == [10, 1, 4]
+    eng = amd.Engine("raft", params, table_capacity=1 << 27, arena_capacity=c["distinct"] + (1 << 16), chunk_states=1 << 22, trace=False)
+    r = eng.run()
+    assert r.levels == c["levels"]
+    assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (102586254, 1217433925, 33, "ok", 0)
+    eng.close()
+
+
 def test_bench_workload_with_tuned_capacities(amd):
     """bench.py runs the same model with slot-array capacities sized from the oracle's maxima
     (16 / 2 / 8 instead of the defaults 40 / 4 / 16): W changes, the state graph must not."""
@@ -180,6 +208,31 @@ def test_ssi_expected_violations_on_gpu(amd, oracle, find):
     assert (r.verdict, r.violated_invariant, r.trace_len) == ("invariant", 7, len(o["trace"]))
     tr = eng.trace()
     assert len(tr) == r.trace_len and tr[0][0] == "Initial predicate" and tr[0][1] == o["trace"][0][1]
+    eng.close()
+
+
+@pytest.mark.parametrize("params", [[2, 2, 127, 2], [2, 2, 127, 3], [3, 2, 127, 6]])
+def test_ssi_invariants_checked_on_the_level_a_budget_stops_at_on_gpu(amd, oracle, params):
+    """invariants of the SI models are evaluated at expansion; a run cut by max_levels exactly at the depth
+    of a violation must report it (k_check_frontier over the unexpanded last level), as TLC's check-on-generation does."""
+    L = len(oracle.oracle_run("ssi", params)["trace"])
+    o = oracle.oracle_run("ssi", params, max_levels=L)
+    eng = amd.Engine("ssi", params, table_capacity=1 << 24, arena_capacity=1 << 23, chunk_states=1 << 16, max_levels=L)
+    r = eng.run()
+    assert o["verdict"] == "invariant"
+    assert (r.verdict, r.violated_invariant, r.trace_len, r.levels) == ("invariant", o["violated_invariant"], L, o["levels"])
+    assert len(eng.trace()) == L
+    eng.close()
+    eng = amd.Engine("ssi", params, table_capacity=1 << 24, arena_capacity=1 << 23, chunk_states=1 << 16, max_levels=L - 1)
+    assert eng.run().verdict == "budget"
+    eng.close()
+
+
+def test_textbook_si_write_skew_found_when_cut_at_its_depth_on_gpu(amd):
+    """textbook SI write skew is a 13-state history: max_levels = 13 stops before level 13 is expanded and must still find it"""
+    eng = amd.Engine("ssi", [3, 2, 32, 0, 1], table_capacity=1 << 26, arena_capacity=40_000_000, chunk_states=1 << 19, max_levels=13)
+    r = eng.run()
+    assert (r.verdict, r.violated_invariant, r.trace_len, r.depth) == ("invariant", 5, 13, 13)
     eng.close()
 
 

@@ -55,6 +55,23 @@ def test_raft_max_msg_keys_same_states_per_level(oracle, shim, tmp_path, dev):
     assert o["distinct"] < oracle.oracle_run("raft", dev[:6])["distinct"]   # the bound really cuts
 
 
+@pytest.mark.parametrize("params", [[2, 2, 127, 2], [2, 2, 127, 3], [3, 1, 127, 1]])
+def test_ssi_invariants_are_checked_on_the_level_a_budget_stops_at(oracle, shim, params):
+    """the SI lowering evaluates its invariants when a state is EXPANDED; TLC (and the oracle) when it is
+    generated.  A run cut by max_levels exactly at the depth of a violation must still report it: the unexpanded last level
+    is checked before the run reports (engine.hip k_check_frontier, mirrored by the host build)."""
+    full = oracle.oracle_run("ssi", params)
+    L = len(full["trace"])
+    assert full["verdict"] == "invariant" and L >= 3
+    o = oracle.oracle_run("ssi", params, max_levels=L)
+    s = shim.shim_run("ssi", params, max_levels=L)
+    assert (s["verdict"], s["violated_invariant"], s["trace_len"]) == ("invariant", o["violated_invariant"], L) and o["verdict"] == "invariant"
+    assert (s["distinct"], s["generated"], s["levels"]) == (o["distinct"], o["generated"], o["levels"])
+    o1 = oracle.oracle_run("ssi", params, max_levels=L - 1)
+    s1 = shim.shim_run("ssi", params, max_levels=L - 1)
+    assert s1["verdict"] == o1["verdict"] == "budget" and s1["levels"] == o1["levels"]
+
+
 def test_raft_expected_violation_trace_length(oracle, shim):
     """SURVEY.md Appendix E caveat (ii): CommittedLogStable is violated once MaxTerm >= 3 and
     MaxClientRequests >= 3; the shortest counterexample has 31 states."""

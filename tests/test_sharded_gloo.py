@@ -51,6 +51,18 @@ def test_sharded_verdict_propagates(oracle, shim, tmp_path):
     assert r["verdict"] == "assert"
 
 
+@pytest.mark.parametrize("replicate_until", [0, 50])
+def test_sharded_budget_stop_checks_the_last_level(oracle, shim, tmp_path, replicate_until):
+    """the SI models check invariants on expansion: a sharded run cut by max_levels at the depth of a violation reports it
+    (mc_shard_check_frontier on every rank's unexpanded frontier), one level earlier it reports the budget"""
+    params = [2, 2, 127, 3]
+    L = len(oracle.oracle_run("ssi", params)["trace"])
+    r = run_dist("shim", 2, "ssi", params, tmp_path, {"chunk": 400, "max_levels": L, "replicate_until": replicate_until})
+    assert r["verdict"] == "invariant" and r["depth"] == L
+    r = run_dist("shim", 2, "ssi", params, tmp_path, {"chunk": 400, "max_levels": L - 1, "replicate_until": replicate_until})
+    assert r["verdict"] == "budget" and r["depth"] == L - 1
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_stay_mode_counts_equal_oracle(oracle, shim, tmp_path, world):
     """States stay on the generating rank once the frontier is large (threshold lowered to 50 states per rank

@@ -106,6 +106,7 @@ def lib():
     L.mc_shard_keep.argtypes = [C.c_void_p, C.c_void_p, U64P]
     L.mc_shard_end_level.argtypes = [C.c_void_p, U64P]
     L.mc_shard_counters.argtypes = [C.c_void_p, U64P, U64P, C.POINTER(C.c_int32)]
+    L.mc_shard_check_frontier.argtypes = [C.c_void_p]
     if hasattr(L, "mc_cfg_parse"):
         L.mc_cfg_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.mc_cfg_free.argtypes = [C.c_void_p]
@@ -280,6 +281,9 @@ class Engine:
         n = C.c_uint64()
         _check(lib().mc_shard_end_level(self._h, C.byref(n)), "mc_shard_end_level")
         return n.value
+
+    def shard_check_frontier(self):
+        _check(lib().mc_shard_check_frontier(self._h), "mc_shard_check_frontier")
 
     def shard_counters(self):
         g, d, v = C.c_uint64(), C.c_uint64(), C.c_int32()

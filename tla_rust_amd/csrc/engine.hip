@@ -23,6 +23,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <chrono>
+#include <memory>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -135,7 +136,7 @@ k_expand(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo
                 else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, (unsigned)slot, VK_SPECERR, 0));
                 else {
                     if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_INVARIANT, st >> 8));
-                    if (!(st & ST_OUT_OF_MODEL)) fp = f;
+                    if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = f;
                 }
             }
         }
@@ -440,7 +441,7 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, (unsigned)slot, VK_SPECERR, 0));
                 else {
                     if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_INVARIANT, st >> 8));
-                    if (!(st & ST_OUT_OF_MODEL)) fp = f;
+                    if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = f;
                 }
             }
         }
@@ -488,11 +489,11 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
 // The fingerprints then go through the same probe / route queues as in k_expand_insert.
 constexpr int FQCAP = 128;
 
-template <class S>
+template <class S, int NB>
 struct FamLds {
-    uint16_t fq[S::NFAM][FQCAP];  // (slot << 6) | parent lane
-    typename S::Summary sum[64];
-    unsigned succ[64];            // successors generated per parent (deadlock check)
+    uint16_t fq[S::NFAM][FQCAP];   // (slot << 8) | (block << 6) | parent lane
+    typename S::Summary sum[NB * 64];
+    unsigned has_succ[NB * 2];     // bit per parent: some successor was generated (deadlock check)
 };
 
 template <class S, int F, class Fn>
@@ -503,13 +504,17 @@ __device__ __forceinline__ void family_dispatch(int fam, Fn &&fn) {
     }
 }
 
-template <class S, bool ROUTE>
-__global__ void __launch_bounds__(256)
+// NB = arena blocks (of 64 parents) one wavefront works through.  The family queues live across the blocks and are
+// drained once at the end, so the partially filled batches of the drain (up to one per family) are paid once per
+// NB * 64 parents instead of once per 64: phase B's lane utilisation goes from ~80 % (NB = 1) towards 95 % (NB = 4).
+template <class S, bool ROUTE, int NB>
+__global__ void __launch_bounds__(256, 4)  // 4 wavefronts per SIMD: at most 128 VGPRs
 k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
                 RouteArgs rt, unsigned parity) {
+    static_assert(NB >= 1 && NB <= 4, "the queue entry has two bits for the block");
     __shared__ WaveQueues wq[4];
-    __shared__ FamLds<S> fls[4];
+    __shared__ FamLds<S, NB> fls[4];
     if (rt.lc) {
         if (rt.lc->stop) return;
         lo = rt.lc->lo;
@@ -518,34 +523,14 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     }
     const unsigned lane = threadIdx.x & 63;
     WaveQueues &Q = wq[threadIdx.x >> 6];
-    FamLds<S> &FL = fls[threadIdx.x >> 6];
+    FamLds<S, NB> &FL = fls[threadIdx.x >> 6];
     const uint64_t base = lo & ~63ull;
-    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
-    const uint64_t idx = base + col;
-    const uint64_t wave_idx0 = idx - lane, wave_col0 = col - lane;  // this wavefront's 64 parents = one arena block
-    const bool active = idx >= lo && idx < hi;
+    // this wavefront's first column: NB consecutive arena blocks
+    const uint64_t wave_col0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64ull * NB);
+    if (wave_col0 >= ncols) return;
+    const uint64_t wave_idx0 = base + wave_col0;
     const int W = S::words(prm);
-    const CWordRef g = arena_cref(arena, idx, W);
-    typename S::Guards gd;
-    gd.fixed = 0;
-    gd.terms = 0;
-    int nm = 0;
     unsigned long long viol = ~0ull;
-    if (active) {
-        typename S::Local loc;
-        S::load(prm, g, loc);
-        nm = loc.nm;
-        S::guards(prm, loc, gd);
-        typename S::Summary q;
-        S::summarize(loc, q);
-        FL.sum[lane] = q;
-        const unsigned ps = S::parent_status(prm, loc, g);
-        if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
-    }
-    FL.succ[lane] = 0;
-    wave_lds_fence();
-    const int wnm = (int)wave_max_u32((unsigned)nm);
     unsigned gen = 0, err = 0, probes = 0;
     unsigned qhead = 0, qn = 0, ohead = 0, on = 0;  // wave-uniform ring state of the probe / survivor queues
     // ring state of the family queues, wave-uniform, packed 8 bits per family so that a run-time family index is a
@@ -612,9 +597,9 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         }
     };
     // append the lanes of `b` (each with its slot) to family f's queue; returns true when it holds >= 64 pairs
-    auto fam_push = [&](int f, unsigned long long b, bool mine, int slot) -> bool {
+    auto fam_push = [&](int f, unsigned long long b, bool mine, unsigned entry) -> bool {
         const unsigned h = fget(fheadA, fheadB, f), c = fget(fcntA, fcntB, f);
-        if (mine) FL.fq[f][(h + c + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (FQCAP - 1)] = (uint16_t)(((unsigned)slot << 6) | lane);
+        if (mine) FL.fq[f][(h + c + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (FQCAP - 1)] = (uint16_t)entry;
         const unsigned nc = c + (unsigned)__popcll(b);
         fset(fcntA, fcntB, f, nc);
         return nc >= 64;
@@ -627,8 +612,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         uint32_t src = 0;
         if (lane < take) {
             const unsigned e = FL.fq[f][(h + lane) & (FQCAP - 1)];
-            const unsigned p = e & 63u;
-            const int slot = (int)(e >> 6);
+            const unsigned p = e & 255u;  // (block << 6) | lane of the parent
+            const int slot = (int)(e >> 8);
             const uint64_t pidx = wave_idx0 + p;
             const typename S::Summary q = FL.sum[p];
             const CWordRef sp = arena_cref(arena, pidx, W);
@@ -637,13 +622,13 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             family_dispatch<S, 0>(f, [&](auto fc) { st = S::template eval_pair<decltype(fc)::value>(prm, q, sp, slot, fv); });
             if (st & ST_ENABLED) {
                 ++gen;
-                if (flags & MC_F_DEADLOCK) atomicAdd(&FL.succ[p], 1u);
+                if (flags & MC_F_DEADLOCK) atomicOr(&FL.has_succ[p >> 5], 1u << (p & 31u));
                 if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
                 else if (st & ST_ASSERT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_ASSERT, 0));
                 else if (st & ST_SPECERR) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_SPECERR, 0));
                 else {
                     if (st & ST_INVARIANT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_INVARIANT, st >> 8));
-                    if (!(st & ST_OUT_OF_MODEL)) { fp = fv; src = (uint32_t)(wave_col0 + p) | ((uint32_t)slot << 24); }
+                    if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) { fp = fv; src = (uint32_t)(wave_col0 + p) | ((uint32_t)slot << 24); }
                 }
             }
         }
@@ -662,9 +647,240 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         }
         wave_lds_fence();
     };
+    auto run_full = [&](unsigned fullmask, bool drain) {
+        while (fullmask) {
+            const int f = __ffs((int)fullmask) - 1;
+            const unsigned c = fget(fcntA, fcntB, f);
+            run_family(f, drain ? (c < 64 ? c : 64u) : 64u);
+            if (fget(fcntA, fcntB, f) < (drain ? 1u : 64u)) fullmask &= ~(1u << f);
+        }
+    };
 
-    // one loop over "steps": fixed slots, then (message, kind) slots, then a final drain of every queue;
-    // the family dispatch below is the single place phase-B code is instantiated
+    for (int blk = 0; blk < NB; ++blk) {
+        const uint64_t idx = wave_idx0 + (uint64_t)blk * 64 + lane;
+        if (wave_col0 + (uint64_t)blk * 64 >= ncols) break;  // wave-uniform
+        const bool active = idx >= lo && idx < hi;
+        const unsigned pl = (unsigned)blk * 64 + lane;       // this lane's parent inside the wavefront's NB blocks
+        const CWordRef g = arena_cref(arena, idx, W);
+        typename S::Guards gd;
+        gd.fixed = 0;
+        gd.terms = 0;
+        int nm = 0;
+        if (active) {
+            typename S::Local loc;
+            S::load(prm, g, loc);
+            nm = loc.nm;
+            S::guards(prm, loc, gd);
+            typename S::Summary q;
+            S::summarize(loc, q);
+            FL.sum[pl] = q;
+            const unsigned ps = S::parent_status(prm, loc, g);
+            if (ps & ST_INVARIANT) viol = min(viol, viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8));
+        }
+        if (lane < 2) FL.has_succ[blk * 2 + lane] = 0;
+        wave_lds_fence();
+        const int wnm = (int)wave_max_u32((unsigned)nm);
+        // one loop over "steps": fixed slots, then (message, kind) slots; the drain of every queue follows the last block
+        const int nsteps = (flags & 64u) ? 0 : S::FIX + 3 * wnm;  // 64 = ablation: load the parents only
+        for (int step = 0; step < nsteps; ++step) {
+            unsigned fullmask = 0;
+            const unsigned entry = ((unsigned)step << 8) | pl;
+            if (step < S::FIX) {
+                const int f = S::fixed_family(step);
+                const bool en = (gd.fixed >> step) & 1ull;
+                const unsigned long long b = __ballot(en);
+                if (b && fam_push(f, b, en, entry)) fullmask = 1u << f;
+            } else {
+                const int q = step - S::FIX, k = q / 3, kind = q % 3;
+                int fam = -1;
+                if (k < nm) fam = S::guard_msg(gd, g.get(S::W_MSG0 + k), kind);
+                if (kind == 0) {  // Receive: the family depends on the message (UpdateTerm or one of the four handlers)
+#pragma unroll
+                    for (int f = S::F_UPDTERM; f <= S::F_AERESP; ++f) {
+                        const unsigned long long b = __ballot(fam == f);
+                        if (b && fam_push(f, b, fam == f, entry)) fullmask |= 1u << f;
+                    }
+                } else {
+                    const unsigned long long b = __ballot(fam >= 0);
+                    if (b && fam_push(S::F_DUPDROP, b, fam >= 0, entry)) fullmask |= 1u << S::F_DUPDROP;
+                }
+            }
+            run_full(fullmask, false);
+        }
+    }
+    {
+        unsigned fullmask = 0;
+#pragma unroll
+        for (int f = 0; f < S::NFAM; ++f) if (fget(fcntA, fcntB, f)) fullmask |= 1u << f;
+        run_full(fullmask, true);
+    }
+    if (qn) flush_probe(qn);
+    if (on) flush_out(on);
+
+    if (flags & MC_F_DEADLOCK) {
+        wave_lds_fence();
+        for (int blk = 0; blk < NB; ++blk) {
+            const uint64_t idx = wave_idx0 + (uint64_t)blk * 64 + lane;
+            if (wave_col0 + (uint64_t)blk * 64 >= ncols) break;
+            if (idx >= lo && idx < hi && !(FL.has_succ[blk * 2 + (lane >> 5)] >> (lane & 31u) & 1u)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
+        }
+    }
+    const unsigned gsum = wave_sum_u32(gen);
+    const unsigned long long vmin = wave_min_u64(viol);
+    const unsigned eor = wave_or_u32(err);
+    if (lane == 0) {
+        if (gsum) atomicAdd(&ctr->generated[shard].v, (unsigned long long)gsum);
+        if (probes) atomicAdd(&ctr->cells[shard].v, (unsigned long long)probes);
+        if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
+        if (eor) atomicOr(&ctr->error, eor);
+    }
+}
+
+// ------------------------------------------------------------------------------------- expand + insert + WRITE, one kernel
+// k_expand_family's phase A / phase B, but a pair's lane probes the seen-set itself as soon as the pair is evaluated
+// (by-family batches keep ~80 % of the lanes busy, so the probe ring of the slot-by-slot kernel is not needed) and —
+// while it still holds the successor's delta in registers — parks the delta of every NEW state in an LDS buffer.
+// When 64 survivors are together the wavefront reserves 64 consecutive arena indices with one atomicAdd and writes the
+// 64 successors as "parent (the arena block this wavefront owns: L1 / L2 resident) + patch", lane = new state, i.e. a
+// 512-byte row per word.  No new-list, no k_materialise, no second stream: each state is read once and written once.
+template <class S>
+struct DirectLds {
+    uint16_t fq[S::NFAM][FQCAP];          // (slot << 6) | parent lane
+    typename S::Summary sum[64];
+    unsigned succ[64];                    // successors generated per parent (deadlock check)
+    uint64_t sv[S::PATCH_WORDS][64];      // packed deltas of the survivors, word-major (conflict-free per lane)
+};
+
+// MINW = waves per SIMD the register allocation must leave room for (A/B: 4 = 128 VGPRs with a few spills, 3 = none)
+template <class S, int MINW>
+__global__ void __launch_bounds__(256, MINW)
+k_expand_direct(typename S::Params prm, uint64_t *arena, uint64_t lo, uint64_t hi, uint64_t ncols,
+                uint64_t *table, uint64_t mask, uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot,
+                DevCounters *ctr, unsigned flags, const LevelCtl *lc) {
+    __shared__ DirectLds<S> dls[4];
+    if (lc) {
+        if (lc->stop) return;
+        lo = lc->lo;
+        hi = lc->hi;
+        ncols = ((hi - (lo & ~63ull)) + 63) & ~63ull;
+    }
+    const unsigned lane = threadIdx.x & 63;
+    DirectLds<S> &FL = dls[threadIdx.x >> 6];
+    const uint64_t base = lo & ~63ull;
+    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    const uint64_t idx = base + col;
+    const uint64_t wave_idx0 = idx - lane;  // this wavefront's 64 parents = one arena block
+    const bool active = idx >= lo && idx < hi;
+    const int W = S::words(prm);
+    const CWordRef g = arena_cref(arena, idx, W);
+    typename S::Guards gd;
+    gd.fixed = 0;
+    gd.terms = 0;
+    int nm = 0;
+    unsigned long long viol = ~0ull;
+    if (active) {
+        typename S::Local loc;
+        S::load(prm, g, loc);
+        nm = loc.nm;
+        S::guards(prm, loc, gd);
+        typename S::Summary q;
+        S::summarize(loc, q);
+        FL.sum[lane] = q;
+        const unsigned ps = S::parent_status(prm, loc, g);
+        if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
+    }
+    FL.succ[lane] = 0;
+    wave_lds_fence();
+    const int wnm = (int)wave_max_u32((unsigned)nm);
+    unsigned gen = 0, err = 0, probes = 0;
+    unsigned on = 0;  // survivors parked in FL.sv (wave-uniform)
+    uint64_t fheadA = 0, fheadB = 0, fcntA = 0, fcntB = 0;
+    auto fget = [](uint64_t a, uint64_t b, int f) -> unsigned { return (unsigned)((f < 8 ? a >> (8 * f) : b >> (8 * (f - 8))) & 255u); };
+    auto fset = [](uint64_t &a, uint64_t &b, int f, unsigned v) {
+        if (f < 8) a = (a & ~(255ull << (8 * f))) | ((uint64_t)v << (8 * f));
+        else b = (b & ~(255ull << (8 * (f - 8)))) | ((uint64_t)v << (8 * (f - 8)));
+    };
+    const unsigned shard = blockIdx.x & (NSHARD - 1);
+
+    // write the `take` parked survivors: lane j builds new state (first free index + j)
+    auto flush_out = [&](unsigned take) {
+        unsigned long long pos = 0;
+        if (lane == 0) pos = atomicAdd(&ctr->arena_next, (unsigned long long)take);
+        pos = __shfl(pos, 0);
+        if (lane < take) {
+            uint64_t pd[S::PATCH_WORDS];
+#pragma unroll
+            for (int w = 0; w < S::PATCH_WORDS; w++) pd[w] = FL.sv[w][lane];
+            const unsigned p = (unsigned)pd[0] & 63u, slot = (unsigned)pd[0] >> 6 & 0xffffu;
+            const uint64_t oidx = pos + lane;
+            if (oidx >= arena_cap) {
+                err |= DEV_EARENA;
+            } else {
+                S::write_patched(prm, arena_cref(arena, wave_idx0 + p, W), pd, FL.sum[p], arena_ref(arena, oidx, W));
+                if (parent) { parent[oidx] = (uint32_t)(wave_idx0 + p); pslot[oidx] = (uint16_t)slot; }
+            }
+        }
+        on = 0;
+        wave_lds_fence();
+    };
+    auto fam_push = [&](int f, unsigned long long b, bool mine, int slot) -> bool {
+        const unsigned h = fget(fheadA, fheadB, f), c = fget(fcntA, fcntB, f);
+        if (mine) FL.fq[f][(h + c + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (FQCAP - 1)] = (uint16_t)(((unsigned)slot << 6) | lane);
+        const unsigned nc = c + (unsigned)__popcll(b);
+        fset(fcntA, fcntB, f, nc);
+        return nc >= 64;
+    };
+    // phase B: evaluate `take` queued pairs of family f (f is wave-uniform), probe, park the survivors' deltas
+    auto run_family = [&](int f, unsigned take) {
+        const unsigned h = fget(fheadA, fheadB, f);
+        wave_lds_fence();  // queue entries written by fam_push are visible
+        bool is_new = false;
+        uint64_t pd[S::PATCH_WORDS];
+        if (lane < take) {
+            const unsigned e = FL.fq[f][(h + lane) & (FQCAP - 1)];
+            const unsigned p = e & 63u;
+            const int slot = (int)(e >> 6);
+            const uint64_t pidx = wave_idx0 + p;
+            const typename S::Summary q = FL.sum[p];
+            const CWordRef sp = arena_cref(arena, pidx, W);
+            unsigned st = 0;
+            uint64_t fv = 0;
+            family_dispatch<S, 0>(f, [&](auto fc) { st = S::template eval_pair_delta<decltype(fc)::value>(prm, q, sp, slot, fv, pd); });
+            if (st & ST_ENABLED) {
+                ++gen;
+                if (flags & MC_F_DEADLOCK) atomicAdd(&FL.succ[p], 1u);
+                if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
+                else if (st & ST_ASSERT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_ASSERT, 0));
+                else if (st & ST_SPECERR) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_SPECERR, 0));
+                else {
+                    if (st & ST_INVARIANT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_INVARIANT, st >> 8));
+                    if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) {
+                        ++probes;
+                        is_new = (flags & 16u) ? false : seen_insert(table, mask, fv, err);  // 16 = ablation: no probes
+                        pd[0] |= (uint64_t)(p | ((unsigned)slot << 6));
+                    }
+                }
+            }
+        }
+        fset(fheadA, fheadB, f, (h + take) & (FQCAP - 1));
+        fset(fcntA, fcntB, f, fget(fcntA, fcntB, f) - take);
+        const unsigned long long b = __ballot(is_new);
+        if (b) {
+            const unsigned cnt = (unsigned)__popcll(b);
+            if (on + cnt > 64) flush_out(on);
+            if (is_new) {
+                const unsigned k = on + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int w = 0; w < S::PATCH_WORDS; w++) FL.sv[w][k] = pd[w];
+            }
+            on += cnt;
+            wave_lds_fence();
+            if (on == 64) flush_out(64);
+        }
+        wave_lds_fence();
+    };
+
     const int nsteps = (flags & 64u) ? 1 : S::FIX + 3 * wnm + 1;  // 64 = ablation: load the parents only
     for (int step = 0; step < nsteps; ++step) {
         unsigned fullmask = 0;
@@ -700,20 +916,26 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             if (fget(fcntA, fcntB, f) < (drain ? 1u : 64u)) fullmask &= ~(1u << f);
         }
     }
-    if (qn) flush_probe(qn);
     if (on) flush_out(on);
 
     if (active && (flags & MC_F_DEADLOCK) && FL.succ[lane] == 0) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
     const unsigned gsum = wave_sum_u32(gen);
+    const unsigned psum = wave_sum_u32(probes);
     const unsigned long long vmin = wave_min_u64(viol);
     const unsigned eor = wave_or_u32(err);
     if (lane == 0) {
         if (gsum) atomicAdd(&ctr->generated[shard].v, (unsigned long long)gsum);
-        if (probes) atomicAdd(&ctr->cells[shard].v, (unsigned long long)probes);
+        if (psum) atomicAdd(&ctr->cells[shard].v, (unsigned long long)psum);
         if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
         if (eor) atomicOr(&ctr->error, eor);
     }
 }
+
+// specs with a copy + patch writer (S::PATCH_WORDS, eval_pair_delta, write_patched) run the one-kernel form
+template <class S, class = void>
+struct HasPatch : std::false_type {};
+template <class S>
+struct HasPatch<S, decltype((void)S::PATCH_WORDS)> : std::true_type {};
 
 // specs that define action families (S::NFAM) are expanded by family, the others slot by slot
 template <class S, class = void>
@@ -721,15 +943,24 @@ struct UsesFamilies : std::false_type {};
 template <class S>
 struct UsesFamilies<S, decltype((void)S::NFAM)> : std::true_type {};
 
+// blocks per wavefront of the by-family kernel (see k_expand_family): run-time choice among the compiled instances
+static int family_blocks(unsigned flags) { return (flags & 4096u) ? 1 : (flags & 8192u) ? 2 : 4; }
+
 template <class S, bool ROUTE, class... A>
-static void launch_expand(bool by_family, dim3 grid, hipStream_t stream, A... args) {
+static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStream_t stream, A... args) {
     if constexpr (UsesFamilies<S>::value) {
         if (by_family) {
-            hipLaunchKernelGGL((k_expand_family<S, ROUTE>), grid, dim3(256), 0, stream, args...);
+            const int nb = ROUTE ? 1 : family_blocks(flags);
+            const dim3 grid((unsigned)((ncols + 256ull * nb - 1) / (256ull * nb)));
+            if constexpr (!ROUTE) {
+                if (nb == 4) { hipLaunchKernelGGL((k_expand_family<S, ROUTE, 4>), grid, dim3(256), 0, stream, args...); return; }
+                if (nb == 2) { hipLaunchKernelGGL((k_expand_family<S, ROUTE, 2>), grid, dim3(256), 0, stream, args...); return; }
+            }
+            hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1>), grid, dim3(256), 0, stream, args...);
             return;
         }
     }
-    hipLaunchKernelGGL((k_expand_insert<S, ROUTE>), grid, dim3(256), 0, stream, args...);
+    hipLaunchKernelGGL((k_expand_insert<S, ROUTE>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, args...);
 }
 
 // ------------------------------------------------------------------------------------- materialise
@@ -929,6 +1160,29 @@ static __global__ void k_after_prefix(DevCounters *ctr, unsigned long long dst0,
     if (zero_counts) for (int t = 0; t < NSHARD; t++) { ctr->generated[t].v = 0; ctr->cells[t].v = 0; }
 }
 
+// Specs that check their invariants when a state is EXPANDED (S::CHECK_ON_EXPAND: the SI models — one evaluation per stored
+// state instead of one per generated successor) have not yet looked at the level a run stops on.  TLC checks a state when it
+// is generated, so before a run that leaves an unexpanded frontier reports "budget", that frontier is checked here.
+template <class S>
+__global__ void __launch_bounds__(256)
+k_check_frontier(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, DevCounters *ctr) {
+    const uint64_t idx = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long viol = ~0ull;
+    if (idx < hi) {
+        const CWordRef g = arena_cref(arena, idx, S::words(prm));
+        typename S::Local loc;
+        S::load(prm, g, loc);
+        const unsigned ps = S::parent_status(prm, loc, g);
+        if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
+    }
+    const unsigned long long vmin = wave_min_u64(viol);
+    if ((threadIdx.x & 63) == 0 && vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
+}
+template <class S, class = void>
+struct ChecksOnExpand : std::false_type {};
+template <class S>
+struct ChecksOnExpand<S, decltype((void)S::CHECK_ON_EXPAND)> : std::true_type {};
+
 // closes a batched level on the device: advances [lo, hi), records the fill level, decides whether the next one may run
 static __global__ void k_end_level(DevCounters *ctr, LevelCtl *lc) {
     if (lc->stop) return;
@@ -951,6 +1205,7 @@ static __global__ void k_end_level(DevCounters *ctr, LevelCtl *lc) {
 // ------------------------------------------------------------------------------------- host side
 struct EngineBase {
     void *owned_device_blob = nullptr;  // program image of a compiled PlusCal spec (spec_vm.h)
+    uint64_t program_hash = 0;          // ... and a hash of that image + its entry points: what a checkpoint of it is matched by
     virtual ~EngineBase() { if (owned_device_blob) hipFree(owned_device_blob); }
     virtual int run(mc_result *out) = 0;
     virtual int trace(uint8_t *states_out, int32_t *actions_out, size_t *n_inout) = 0;
@@ -971,6 +1226,7 @@ struct EngineBase {
     virtual int shard_keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) = 0;
     virtual int shard_end_level(uint64_t *new_local) = 0;
     virtual int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
+    virtual int shard_check_frontier() = 0;
 };
 
 static uint64_t round_pow2(uint64_t v) {
@@ -1032,6 +1288,7 @@ struct Engine : EngineBase {
         W = S::words(prm);
         max_slots = (unsigned)S::max_slots(prm);
         use_matrix = (cfg.flags & MC_F_MATRIX) != 0;
+        use_direct = HasPatch<S>::value && (cfg.flags & MC_F_DIRECT) && !(cfg.flags & (MC_F_MATRIX | MC_F_NOFAMILY));
         HIP_TRY(hipSetDevice(cfg.device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         {   // A/B knob (measured in DESIGN.md section 4): TLAMC_PRIO=1 gives the materialise stream the highest priority, =2 the lowest
@@ -1127,7 +1384,7 @@ struct Engine : EngineBase {
         return MC_OK;
     }
 
-    bool use_matrix = false;
+    bool use_matrix = false, use_direct = false;
     // materialise + commit of the chunk whose survivors are in new-list `parity`, on the second stream: it overlaps
     // the expansion of the next chunk (memory-bound next to latency-bound)
     void finish_materialise(uint64_t chunk_base, uint64_t ncols, unsigned parity) {
@@ -1142,15 +1399,31 @@ struct Engine : EngineBase {
         hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream2, d_ctr, parity);
         hipEventRecord(ev_m[parity], stream2);
     }
+    // one-kernel form (k_expand_direct): expand + seen-set insert + copy-and-patch write of the new states
+    void launch_direct(uint64_t c0, uint64_t c1, uint64_t ncols, const LevelCtl *lc) {
+        if constexpr (HasPatch<S>::value) {
+            if (cfg.flags & 2048u)  // A/B: register allocation for 3 waves per SIMD (no spills)
+                hipLaunchKernelGGL((k_expand_direct<S, 3>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0, c1, ncols,
+                                   d_table, table_cap - 1, arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
+            else
+                hipLaunchKernelGGL((k_expand_direct<S, 4>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0, c1, ncols,
+                                   d_table, table_cap - 1, arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
+        }
+    }
     // one batched level (LevelCtl): the same pair of kernels, ranges read on the device, then the level is closed there
     void enqueue_blind_level(uint64_t max_states) {
         // all four kernels on ONE stream: for a frontier this small the two-stream overlap buys nothing and the
         // cross-stream events would cost more than the kernels
         const uint64_t ncols = max_states + 64;
+        if (use_direct) {
+            timed(0, 0, [&] { launch_direct(0, 0, ncols, d_lc); });
+            hipLaunchKernelGGL(k_end_level, dim3(1), dim3(1), 0, stream, d_ctr, d_lc);
+            return;
+        }
         RouteArgs rt{};
         rt.lc = d_lc;
         timed(0, 0, [&] {
-            launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm, (const uint64_t *)d_arena,
+            launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm, (const uint64_t *)d_arena,
                                     (uint64_t)0, (uint64_t)0, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
         });
         timed(2, 0, [&] {
@@ -1272,7 +1545,9 @@ struct Engine : EngineBase {
                 uint64_t c1 = base + chunk;  // chunk boundaries stay 64-aligned
                 if (c1 > hi) c1 = hi;
                 const uint64_t ncols = ((c1 - base) + 63) & ~63ull;
-                if (use_matrix) {  // two-kernel form: sparse candidate matrix + k_insert (kept for A/B measurements)
+                if (use_direct) {  // one kernel per chunk, one stream: the new states are written where they are found
+                    timed(0, c1 - c0, [&] { launch_direct(c0, c1, ncols, nullptr); });
+                } else if (use_matrix) {  // two-kernel form: sparse candidate matrix + k_insert (kept for A/B measurements)
                     timed(0, c1 - c0, [&] {
                         hipLaunchKernelGGL(k_expand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena,
                                            c0, c1, d_cand, row_stride, ncols, d_nsl, d_ctr, cfg.flags);
@@ -1281,7 +1556,7 @@ struct Engine : EngineBase {
                 } else {
                     if (chunk_no >= 2) hipStreamWaitEvent(stream, ev_m[parity], 0);  // new-list `parity` is free again
                     timed(0, c1 - c0, [&] {
-                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
+                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
                                                 (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
                                                 cfg.flags, RouteArgs{}, parity);
                     });
@@ -1300,6 +1575,8 @@ struct Engine : EngineBase {
             }
             if (level >= MC_MAX_LEVELS) { set_error("too many BFS levels"); return MC_EBADCFG; }
         }
+        // a run that stops with an unexpanded frontier (budget) has not evaluated that level's check-on-expand invariants yet
+        if (hi > lo && h_ctr->viol_key == ~0ull && !stop_frontier && (rc = check_frontier(lo, hi))) return rc;
         const auto t1 = std::chrono::steady_clock::now();
         out->seconds = std::chrono::duration<double>(t1 - t0).count();
         out->distinct = h_ctr->arena_next;
@@ -1386,8 +1663,9 @@ struct Engine : EngineBase {
         memset(&h, 0, sizeof h);
         memcpy(h.magic, "TLAMCCK1", 8);
         h.spec_id = desc.spec_id;
-        h.nparams = ck_params_comparable() ? desc.nparams : 0;
+        h.nparams = ck_params_comparable() ? desc.nparams : 1;
         for (uint32_t i = 0; i < h.nparams && i < 16; i++) h.params[i] = desc.params[i];
+        if (!ck_params_comparable()) h.params[0] = (int64_t)program_hash;  // a compiled program is identified by its image
         h.words = (uint32_t)W;
         h.has_trace = d_parent ? 1u : 0u;
         h.distinct = last_distinct; h.generated = last_generated; h.cells = kstat_cells;
@@ -1417,12 +1695,20 @@ struct Engine : EngineBase {
         else if (h.spec_id != desc.spec_id || h.words != (uint32_t)W) fail(MC_EBADCFG, "restore: the checkpoint belongs to another spec");
         else if (ck_params_comparable() && (h.nparams != desc.nparams || memcmp(h.params, desc.params, sizeof(int64_t) * (h.nparams < 16 ? h.nparams : 16)) != 0))
             fail(MC_EBADCFG, "restore: the checkpoint was written with other constants / invariants");
+        else if (!ck_params_comparable() && (h.nparams != 1 || (uint64_t)h.params[0] != program_hash))
+            fail(MC_EBADCFG, "restore: the checkpoint was written by another compiled program (algorithm, constants, invariants or constraints differ)");
+        else if (h.distinct * 2 > table_cap) fail(MC_ETABLEFULL, "restore: table_capacity cannot hold the checkpoint's states at load 1/2");
         else if (h.distinct > arena_cap) fail(MC_EARENA, "restore: arena_capacity is smaller than the checkpoint");
         else if (h.hi != h.distinct || h.lo > h.hi || h.nlevels == 0 || h.nlevels >= MC_MAX_LEVELS) fail(MC_EPARSE, "restore: inconsistent header");
         else if (d_parent && !h.has_trace) fail(MC_EBADCFG, "restore: the checkpoint holds no parent pointers (written without MC_F_TRACE); run without MC_F_TRACE");
         if (!rc) {
             ck_level_start.assign((size_t)h.nlevels, 0);
             if (fread(ck_level_start.data(), sizeof(uint64_t), ck_level_start.size(), f) != ck_level_start.size()) fail(MC_EPARSE, "restore: the checkpoint file is truncated");
+            else {  // level table: starts at 0, strictly increasing, below the fill level; an unexpanded frontier IS the last level
+                bool ok = ck_level_start[0] == 0 && ck_level_start.back() < h.hi && (h.lo == h.hi || ck_level_start.back() == h.lo);
+                for (size_t k = 1; k < ck_level_start.size() && ok; k++) ok = ck_level_start[k] > ck_level_start[k - 1];
+                if (!ok) fail(MC_EPARSE, "restore: inconsistent level table");
+            }
         }
         if (!rc) {
             HIP_TRY(hipSetDevice(cfg.device));
@@ -1528,7 +1814,7 @@ struct Engine : EngineBase {
         for (uint64_t c0 = 0; c0 < last_distinct; c0 += chunk) {
             const uint64_t c1 = c0 + chunk < last_distinct ? c0 + chunk : last_distinct;
             const uint64_t ncols = ((c1 - c0) + 63) & ~63ull;
-            launch_expand<S, false>(!((cfg.flags | extra_flags) & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
+            launch_expand<S, false>(!((cfg.flags | extra_flags) & MC_F_NOFAMILY), cfg.flags | extra_flags, ncols, stream, prm,
                                     (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
                                     cfg.flags | extra_flags, RouteArgs{}, 0u);
             hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr, 0u);
@@ -1631,9 +1917,10 @@ struct Engine : EngineBase {
     // rank then holds ALL prefix fingerprints (a superset of the ones it owns: harmless); rank 0 alone reports the
     // prefix's `generated`, and distinct_local excludes what other ranks already count.
     uint64_t sh_dup = 0;
+    std::unique_ptr<mc_result> prefix_res{new mc_result()};
     int shard_begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) override {
         if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
-        static mc_result res;  // large (level table): not on the stack
+        mc_result &res = *prefix_res;  // large (level table): not on the stack, and not shared between engines / threads
         const uint64_t saved_md = cfg.max_distinct, saved_ml = cfg.max_levels;
         cfg.max_distinct = max_distinct;  // the whole job's budgets: the prefix stops where the single-GPU run would
         cfg.max_levels = max_levels;
@@ -1706,7 +1993,7 @@ struct Engine : EngineBase {
         q.chunk_base = base;
         RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
         timed(0, count, [&] {
-            launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), dim3((unsigned)((ncols + 255) / 256)), stream, prm,
+            launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
                                    (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
         });
         return MC_OK;
@@ -1864,6 +2151,23 @@ struct Engine : EngineBase {
         *new_local = sh_hi - sh_lo;
         return MC_OK;
     }
+    // invariants of the unexpanded frontier [lo, hi) for specs that check on expansion (see k_check_frontier); no-op otherwise
+    int check_frontier(uint64_t lo, uint64_t hi) {
+        if constexpr (ChecksOnExpand<S>::value) {
+            if (hi > lo) {
+                hipLaunchKernelGGL(k_check_frontier<S>, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, stream, prm,
+                                   (const uint64_t *)d_arena, lo, hi, d_ctr);
+                return read_counters();
+            }
+        }
+        return MC_OK;
+    }
+    int shard_check_frontier() override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipStreamSynchronize(side()));
+        HIP_TRY(hipStreamSynchronize(stream2));
+        return check_frontier(sh_lo, sh_hi);
+    }
     int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) override {
         HIP_TRY(hipSetDevice(cfg.device));
         HIP_TRY(hipStreamSynchronize(side()));
@@ -1970,12 +2274,19 @@ int mc_make_engine_6(const mc_spec_desc *d, const mc_config *c, mc::EngineBase *
         mc::set_error("cannot upload the PlusCal program image");
         return MC_EHIP;
     }
+    // identity of the compiled program for checkpoints: the whole image (header, tables, code) and the scalars derived from it
+    uint64_t ph = 0xcbf29ce484222325ull;
+    auto mixin = [&](uint64_t v) { ph = (ph ^ v) * 0x100000001b3ull; ph ^= ph >> 29; };
+    for (int i = 0; i < p.code_len; i++) mixin((uint32_t)p.code[i]);
+    for (int v : {p.nv, p.words, p.ninst, p.maxch, p.pc_base, p.done, p.init_entry, p.ninv, p.ncon, p.label_tab, p.self_tab, p.code_len}) mixin((uint32_t)v);
+    for (int i = 0; i < 8; i++) mixin((uint32_t)p.inv_entry[i]);
+    mixin(p.num_init);
     p.code = d_code;  // host-side helpers (format, action_of) use p.host only
     const int rc = p.nv <= 16 ? mc::make_engine<mc::SpecVm16>(p, d, c, out)
                  : p.nv <= 32 ? mc::make_engine<mc::SpecVm32>(p, d, c, out)
                  : p.nv <= 64 ? mc::make_engine<mc::SpecVm64>(p, d, c, out) : mc::make_engine<mc::SpecVm>(p, d, c, out);
     if (rc) hipFree(d_code);
-    else (*out)->owned_device_blob = d_code;
+    else { (*out)->owned_device_blob = d_code; (*out)->program_hash = ph ? ph : 1; }
     return rc;
 }
 #endif
@@ -2121,6 +2432,7 @@ int mc_shard_end_level(mc_engine *e, uint64_t *new_local) { return e && new_loca
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) {
     return e && generated && distinct_local && verdict ? e->impl->shard_counters(generated, distinct_local, verdict) : MC_EBADCFG;
 }
+int mc_shard_check_frontier(mc_engine *e) { return e ? e->impl->shard_check_frontier() : MC_EBADCFG; }
 
 }  // extern "C"
 #endif  // MC_TU == 0 || MC_TU == -1

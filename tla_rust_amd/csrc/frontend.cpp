@@ -522,7 +522,8 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
         out->nparams = 10;  // [6..8] = slot-array capacities (0 = defaults), [9] = MaxMsgKeys
         out->params[0] = (long long)srv->value.elems.size();
         out->params[1] = mcr; out->params[2] = mt; out->params[3] = ml; out->params[4] = mm; out->params[5] = mask;
-        out->params[6] = mk > 40 ? mk : 0; out->params[7] = 0; out->params[8] = 0; out->params[9] = mk;
+        out->params[6] = mk; out->params[7] = 0;  // a stored state holds at most MaxMsgKeys message keys: exactly that many slots
+        out->params[8] = 0; out->params[9] = mk;
         return MC_OK;
     }
     const bool textbook = m == "MCtextbookSI" || m == "textbookSnapshotIsolation";  // examples/textbookSnapshotIsolation.tla

@@ -24,7 +24,9 @@ enum : unsigned {
     ST_ASSERT = 4u,        // Assert(...) evaluated to FALSE while generating it
     ST_INVARIANT = 8u,     // successor violates an INVARIANT (index in bits 8..15)
     ST_SPECERR = 16u,      // TLC would raise an evaluation error
-    ST_OVERFLOW = 32u      // a fixed-capacity slot array of the packed state is full
+    ST_OVERFLOW = 32u,     // a fixed-capacity slot array of the packed state is full
+    ST_SELFLOOP = 64u      // the successor IS the expanded state (a stuttering step of the action): generated and counted, but
+                           // already in the seen-set by construction, so it needs neither a fingerprint nor a probe
 };
 
 // Strided view of one packed state.  In the HBM arena states are stored in blocks of 64,

@@ -221,15 +221,15 @@ struct SpecRaft {
     template <class Ref>
     MC_HD static unsigned init_status(const Params &, Ref) { return ST_ENABLED; }
 
-    // 6-bit bucket of a message key, for the per-parent presence filter that lets Send skip its scan
-    MC_HD static unsigned key_bucket(uint64_t word) { return (unsigned)(((word >> 2) * 0x9e3779b97f4a7c15ull) >> 58); }
+    // 5-bit bucket of a message key, for the per-parent presence filter that lets Send skip its scan
+    MC_HD static unsigned key_bucket(uint64_t word) { return (unsigned)(((word >> 2) * 0x9e3779b97f4a7c15ull) >> 59); }
 
     // ---------------------------------------------------------------- per-parent cache
     struct Local {
         uint64_t fp, glob, clog;
         RegArr<NS> sv, log;
         int nm, inflight;
-        uint64_t mfilter;      // bit key_bucket(m) set for every message key in the bag: a clear bit proves "not present"
+        uint32_t mfilter;      // bit key_bucket(m) set for every message key in the bag: a clear bit proves "not present"
         unsigned addmask;      // servers whose log is not yet in allLogs (raft.tla:493), first occurrence only
         int nadd;              // popcount(addmask)
         uint64_t add_fp;       // sum of their contributions
@@ -251,7 +251,7 @@ struct SpecRaft {
         for (int k = 0; k < l.nm; k++) {
             const uint64_t x = s.get(W_MSG0 + k);
             l.inflight += m_count(x);
-            l.mfilter |= 1ull << key_bucket(x);
+            l.mfilter |= 1u << key_bucket(x);
         }
         // allLogs' = allLogs \cup {log[i] : i \in Server} — the same for every successor of this state
         unsigned present = 0;
@@ -305,7 +305,7 @@ struct SpecRaft {
     MC_HD static unsigned send(const Local &l, Ref s, const Params &prm, uint64_t key_word /*count bits zero*/, Delta &d) {
         int idx = l.nm;
         uint64_t old = 0;
-        if (l.mfilter >> key_bucket(key_word) & 1ull) {  // possibly present: scan the bag
+        if (l.mfilter >> key_bucket(key_word) & 1u) {  // possibly present: scan the bag
             for (int k = 0; k < l.nm; k++) {
                 const uint64_t x = s.get(W_MSG0 + k);
                 if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; }
@@ -618,30 +618,122 @@ struct SpecRaft {
         if (m_term(m) > term) return F_UPDTERM;
         return F_RVREQ + m_type(m);  // M_RVREQ..M_AERESP in the order of the enum
     }
-    // what a lane evaluating a pair needs to know about the pair's parent (computed once by the parent's lane)
+    // what a lane evaluating a pair needs to know about the pair's parent beyond the parent's own words (computed once by
+    // the parent's lane, kept in LDS: 16 B per parent; fp / globals / committedLog are re-read from the arena block the
+    // wavefront owns, where they are L1-resident)
     struct Summary {
-        uint64_t fp, glob, clog, add_fp, mfilter;
+        uint64_t add_fp;
+        uint32_t mfilter;
         uint32_t packed;  // nm[0,8) inflight[8,16) nadd[16,20) addmask[20,28)
     };
     MC_HD static void summarize(const Local &l, Summary &q) {
-        q.fp = l.fp; q.glob = l.glob; q.clog = l.clog; q.add_fp = l.add_fp; q.mfilter = l.mfilter;
+        q.add_fp = l.add_fp; q.mfilter = l.mfilter;
         q.packed = (uint32_t)l.nm | (uint32_t)l.inflight << 8 | (uint32_t)l.nadd << 16 | l.addmask << 20;
+    }
+    template <class Ref>
+    MC_HD static void local_of_summary(const Summary &q, Ref s, Local &l) {
+        l.fp = s.get(W_FP); l.glob = s.get(W_GLOB); l.clog = s.get(W_CLOG); l.add_fp = q.add_fp; l.mfilter = q.mfilter;
+        l.nm = (int)(q.packed & 255u); l.inflight = (int)(q.packed >> 8 & 255u); l.nadd = (int)(q.packed >> 16 & 15u);
+        l.addmask = q.packed >> 20 & 255u;
+        l.cache_k = -1; l.cache_hm = 0;
     }
     // evaluate one (parent, slot) pair of family FAM; the parent's words are read through `s`
     template <int FAM, class Ref>
     MC_HD static unsigned eval_pair(const Params &prm, const Summary &q, Ref s, int slot, uint64_t &fp) {
         Local l;
-        l.fp = q.fp; l.glob = q.glob; l.clog = q.clog; l.add_fp = q.add_fp; l.mfilter = q.mfilter;
-        l.nm = (int)(q.packed & 255u); l.inflight = (int)(q.packed >> 8 & 255u); l.nadd = (int)(q.packed >> 16 & 15u);
-        l.addmask = q.packed >> 20 & 255u;
-        l.cache_k = -1; l.cache_hm = 0;
+        local_of_summary(q, s, l);
         Delta d;
         int action;
         const unsigned st = compute<true, FAM>(prm, l, s, slot, d, action);
         if (!(st & ST_ENABLED)) return 0;
         if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
+        if (is_self_loop(l, s, d)) { fp = fp_nonzero(l.fp); return st | ST_SELFLOOP; }
         fp = fp_nonzero(delta_fp(l, s, d));
         return st;
+    }
+
+    // ---------------------------------------------------------------- copy + patch (k_expand_direct)
+    // The lane that evaluated a pair still holds the successor's Delta when the seen-set says "new": instead of
+    // re-evaluating (parent, slot) in a second kernel, the delta is packed into PATCH_WORDS words, parked in LDS until
+    // 64 survivors are together, and the successor is written as "copy of the parent, patched".
+    //   pd[0]: caller's source tag [0,32) | srv+1 [32,35) | vmode [35,37) | vj [37,40) | midxA+1 [40,47) | midxB+1 [47,54) | eadd [54]
+    //   pd[1..8]: raw fingerprint, globals, committedLog, scalars and log of server srv, voterLog entry, message words A and B
+    static constexpr int PATCH_WORDS = 9;
+    template <int FAM, class Ref>
+    MC_HD static unsigned eval_pair_delta(const Params &prm, const Summary &q, Ref s, int slot, uint64_t &fp, uint64_t *pd) {
+        Local l;
+        local_of_summary(q, s, l);
+        Delta d;
+        int action;
+        const unsigned st = compute<true, FAM>(prm, l, s, slot, d, action);
+        if (!(st & ST_ENABLED)) return 0;
+        if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
+        if (is_self_loop(l, s, d)) { fp = fp_nonzero(l.fp); return st | ST_SELFLOOP; }
+        const uint64_t raw = delta_fp(l, s, d);
+        fp = fp_nonzero(raw);
+        pd[0] = ((uint64_t)(d.srv + 1) << 32) | ((uint64_t)d.vmode << 35) | ((uint64_t)d.vj << 37) |
+                ((uint64_t)((d.nmop & 1) ? d.midxA + 1 : 0) << 40) | ((uint64_t)((d.nmop & 2) ? d.midxB + 1 : 0) << 47) |
+                ((uint64_t)(d.eadd ? 1 : 0) << 54);
+        pd[1] = raw; pd[2] = d.glob; pd[3] = d.clog; pd[4] = d.sv; pd[5] = d.log; pd[6] = d.vlog; pd[7] = d.mnewA; pd[8] = d.mnewB;
+        return st;
+    }
+    // successor = parent `s` with the packed delta applied, written to `out`; q = the parent's summary (allLogs' additions)
+    template <class Ref>
+    MC_HD static void write_patched(const Params &prm, Ref s, const uint64_t *pd, const Summary &q, WordRef out) {
+        const uint64_t meta = pd[0];
+        const int srv = (int)(meta >> 32 & 7) - 1, vmode = (int)(meta >> 35 & 3), vj = (int)(meta >> 37 & 7);
+        const int ia = (int)(meta >> 40 & 127) - 1, ib = (int)(meta >> 47 & 127) - 1;
+        const bool eadd = (meta >> 54 & 1) != 0;
+        const uint64_t oglob = s.get(W_GLOB);
+        out.set(W_FP, pd[1]);
+        out.set(W_GLOB, pd[2]);
+        out.set(W_CLOG, pd[3]);
+        RegArr<NS> logs;
+        uint64_t osv = 0, olog = 0;
+        uint64_t ovl[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) ovl[j] = 0;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const bool me = i == srv;
+            const uint64_t svi = s.get(W_SRV(i)), lgi = s.get(W_LOG(i));
+            logs.set(i, lgi);
+            if (me) { osv = svi; olog = lgi; }
+            out.set(W_SRV(i), me ? pd[4] : svi);
+            out.set(W_LOG(i), me ? pd[5] : lgi);
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                uint64_t x = s.get(W_VLOG(i, j));
+                if (me) ovl[j] = x;
+                if (me && vmode == 1) x = 0;
+                if (me && vmode == 2 && j == vj) x = pd[6];
+                out.set(W_VLOG(i, j), x);
+            }
+        }
+        const int nm = g_nm(oglob), nm2 = g_nm(pd[2]);
+        for (int k = 0; k < prm.cm; k++) {
+            uint64_t x = k < nm ? s.get(W_MSG0 + k) : 0;
+            if (ia == k) x = pd[7];
+            if (ib == k) x = pd[8];
+            out.set(W_MSG0 + k, k < nm2 ? x : 0);
+        }
+        const int ne = g_ne(oglob), wel = W_EL0(prm);
+        for (int e = 0; e < prm.ce; e++) {
+#pragma unroll
+            for (int w = 0; w < EL_WORDS; w++) {
+                uint64_t x = e < ne ? s.get(wel + e * EL_WORDS + w) : 0;
+                if (eadd && e == ne)  // BecomeLeader(srv): the record built from the PARENT's words   raft.tla:253-258
+                    x = w == 0 ? ((uint64_t)sv_term(osv) | ((uint64_t)srv << 3) | ((uint64_t)sv_granted(osv) << 6) | (olog << 11)) : ovl[w > 0 ? w - 1 : 0];
+                out.set(wel + e * EL_WORDS + w, x);
+            }
+        }
+        const int na = g_na(oglob), wall = W_ALL0(prm);
+        const unsigned addmask = q.packed >> 20 & 255u;
+        for (int a = 0; a < prm.ca; a++) out.set(wall + a, a < na ? s.get(wall + a) : 0);
+        int pos = na;
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+            if (addmask >> i & 1) { if (pos < prm.ca) out.set(wall + pos, logs.get(i)); pos++; }
     }
 
     template <class Ref>
@@ -675,6 +767,23 @@ struct SpecRaft {
         return fp;
     }
 
+    // the successor equals its parent (Restart of a freshly restarted server, AdvanceCommitIndex without progress, ...: about
+    // one generated successor in nine): no fingerprint, no probe — the parent is in the seen-set
+    template <class Ref>
+    MC_HD static bool is_self_loop(const Local &l, Ref s, const Delta &d) {
+        if (l.nadd || d.nmop || d.eadd || d.glob != l.glob || d.clog != l.clog) return false;
+        if (d.srv < 0) return true;
+        if (d.sv != d.osv || d.log != d.olog) return false;
+        if (d.vmode == 2) return d.vlog == 0;
+        if (d.vmode == 1) {
+            uint64_t any = 0;
+#pragma unroll
+            for (int j = 0; j < NS; j++) any |= s.get(W_VLOG(d.srv, j));
+            return any == 0;
+        }
+        return true;
+    }
+
     template <class Ref>
     MC_HD static unsigned eval(const Params &prm, Local &l, Ref s, int slot, uint64_t &fp) {
         Delta d;
@@ -684,6 +793,7 @@ struct SpecRaft {
         // a successor outside the CONSTRAINT is generated and invariant-checked (done in compute) but
         // never stored, so its fingerprint is not needed
         if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
+        if (is_self_loop(l, s, d)) { fp = fp_nonzero(l.fp); return st | ST_SELFLOOP; }
         fp = fp_nonzero(delta_fp(l, s, d));
         return st;
     }

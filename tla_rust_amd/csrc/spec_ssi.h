@@ -30,7 +30,9 @@
 //
 // Invariants (:59-79) are evaluated once per state when it is EXPANDED (parent_status), not per
 // generated successor: every stored state is expanded exactly once, so the verdict and the length
-// of the shortest counterexample are the same as TLC's check-on-generation.
+// of the shortest counterexample are the same as TLC's check-on-generation.  A run that stops on a
+// budget leaves its last level unexpanded: the engine evaluates parent_status on that frontier before
+// it reports (CHECK_ON_EXPAND, k_check_frontier), so no counted state is ever left unchecked.
 #pragma once
 #include "mc_common.h"
 #include <stdio.h>
@@ -43,6 +45,7 @@ struct SsiParams { int nt, nk, inv_mask, find, textbook, sym; };  // textbook = 
 struct SpecSsi {
     using Params = SsiParams;
     static constexpr int NT = 4, NK = 3, HWORDS = 8, HCAP = 32;
+    static constexpr bool CHECK_ON_EXPAND = true;  // invariants live in parent_status: the engine checks a run's last, unexpanded level too
     static constexpr int W_FP = 0, W_META = 1, W_H0 = 2;
     static constexpr int MAX_WORDS = 10;
     MC_HD static int words(const Params &) { return MAX_WORDS; }

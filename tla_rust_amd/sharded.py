@@ -79,6 +79,9 @@ class HipStepEngine:
     def counters(self):
         return self.eng.shard_counters()
 
+    def check_frontier(self):
+        self.eng.shard_check_frontier()
+
     def sync(self):
         self.stream.synchronize()
 
@@ -257,6 +260,8 @@ class ShardedChecker:
                 level += 1
                 levels.append(frontier)
                 cum += frontier
+        if frontier > 0 and verdict == 0:
+            e.check_frontier()  # a budget stop leaves a level unexpanded: its check-on-expand invariants (SI models) are due
         generated, _, verdict = e.counters()
         generated = self._allreduce(generated, SUM)
         verdict = self._allreduce(verdict, MAX)
