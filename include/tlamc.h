@@ -76,8 +76,10 @@ typedef struct {
 #define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
 #define MC_F_DIRECT 1024u /* A/B only: one kernel per chunk (expand + insert + copy-and-patch write, k_expand_direct) instead of
                           * expand and materialise on two streams; measured slower, kept for the comparison */
-#define MC_F_FAMBLOCKS1 4096u /* A/B only: the by-family expand kernel works through 1 (default 4) arena blocks per wavefront */
+#define MC_F_FAMBLOCKS4 4096u /* A/B only: the by-family expand kernel works through 4 (default 1) arena blocks per wavefront */
 #define MC_F_FAMBLOCKS2 8192u /* A/B only: ... 2 blocks per wavefront                                                   */
+#define MC_F_PROGRESS 16384u /* mc_check_files: print TLC's "Progress(d): ..." lines (testout2:4-259) to stdout while the search runs,
+                              * at most one per second */
 #define MC_F_NOBATCH 256u /* A/B only: one host round trip per BFS level even while the frontier is small         */
 #define MC_F_UNVERIFIED 512u /* mc_check_files / mc_resolve_files: when the module an MC wrapper EXTENDS (raft.tla, the snapshot-isolation
                              specs) is found neither beside it nor under $TLA_PATH, use the built-in lowering anyway (the report
@@ -133,6 +135,11 @@ typedef struct mc_engine mc_engine;
  * checks, counters, depth and counterexample (README.md:267-321, testout2:1-266). */
 int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine **out);
 int mc_engine_run(mc_engine *e, mc_result *out);
+/* Progress reports while mc_engine_run searches (TLC's "Progress(5): 6117 states generated, 195 distinct states found, 1 states
+ * left on queue.", testout2:4-259): `fn` is called from the calling thread between two BFS levels, at most once per
+ * `min_interval_seconds`, with the number of levels found so far and the three counters.  fn = NULL switches it off. */
+typedef void (*mc_progress_fn)(void *user, uint32_t levels, uint64_t generated, uint64_t distinct, uint64_t queue);
+int mc_engine_set_progress(mc_engine *e, mc_progress_fn fn, void *user, double min_interval_seconds);
 /* counterexample of the last run: states_out receives trace_len records of mc_state_bytes()
  * bytes each (plain word order), actions_out the action id that produced each state (-1 for
  * the initial state).  *n_inout: capacity in, count out. */

@@ -144,6 +144,9 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
                 S::apply(p, s, slot, WordRef{a, 1});
                 S::write_patched(p, s, pd, q, WordRef{b, 1});
                 if (st2 != st1 || f2 != f1 || memcmp(a, b, sizeof(uint64_t) * (size_t)S::words(p)) != 0) bad++;
+                uint64_t c[S::MAX_WORDS];  // k_materialise with the fingerprint handed over by the expand kernel
+                S::apply_known_fp(p, s, slot, f1, WordRef{c, 1});
+                if (memcmp(a, c, sizeof(uint64_t) * (size_t)S::words(p)) != 0) bad++;
             }
             if (fam >= 0) cnt[fam]++;
         }
@@ -334,6 +337,21 @@ extern "C" size_t shim_state_bytes(const mc_spec_desc *d) {
     size_t n = 0;
     dispatch_spec(d, [&](auto spec, const auto &prm) { n = sizeof(uint64_t) * decltype(spec)::words(prm); return 0; });
     return n;
+}
+
+// one (state, slot) pair of the device lowering on hand-made words (negative controls of invariants no reachable state violates)
+extern "C" int shim_init_state(const mc_spec_desc *d, uint64_t k, uint64_t *words_out) {
+    return dispatch_spec(d, [&](auto spec, const auto &prm) { decltype(spec)::init(prm, k, WordRef{words_out, 1}); return 0; });
+}
+extern "C" int shim_eval_slot(const mc_spec_desc *d, const uint64_t *words, int slot, unsigned *status, uint64_t *fp) {
+    return dispatch_spec(d, [&](auto spec, const auto &prm) {
+        using S = decltype(spec);
+        CWordRef s{words, 1};
+        typename S::Local loc;
+        S::load(prm, s, loc);
+        *status = slot < S::nslots(prm, loc) ? S::eval(prm, loc, s, slot, *fp) : 0u;
+        return 0;
+    });
 }
 
 // ------------------------------------------------------------------------------------------

@@ -247,6 +247,31 @@ def test_cli_ssi(amd):
     assert "The depth of the complete state graph search is 13." in p.stdout
 
 
+@pytest.mark.gpu
+def test_progress_lines_like_tlc(amd):
+    """testout2:4-259: "Progress(5): 6117 states generated, 195 distinct states found, 1 states left on queue." while the search
+    runs (mc prints them by default, at most one per second; TLAMC_PROGRESS_INTERVAL=0 reports after every host-visible level)"""
+    import os
+    import re
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    env = dict(os.environ, TLAMC_PROGRESS_INTERVAL="0")
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(ROOT / "specs" / "MCssi_2x2.cfg")], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr
+    rows = [tuple(map(int, m.groups())) for m in re.finditer(r"^Progress\((\d+)\): (\d+) states generated, (\d+) distinct states found, (\d+) states left on queue\.$", p.stdout, re.M)]
+    assert len(rows) >= 2 and rows == sorted(rows)                      # every counter only grows
+    assert rows[-1][0] == 13 and rows[-1][1:] == (50121, 29629, 0)      # the last report is the final state of the search
+    assert p.stdout.index("Progress(") < p.stdout.index("Model checking completed")
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(ROOT / "specs" / "MCssi_2x2.cfg"), "-noprogress"], capture_output=True, text=True, env=env)
+    assert p.returncode == 0 and "Progress(" not in p.stdout
+    # the same through the C ABI
+    seen = []
+    eng = amd.Engine("ssi", [2, 2, 127, 0], table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
+    eng.set_progress(lambda lv, g, d, q: seen.append((lv, g, d, q)), 0.0)
+    r = eng.run()
+    assert seen and seen[-1] == (r.depth, r.generated, r.distinct, 0) and seen == sorted(seen)
+    eng.close()
+
+
 def test_wrapper_and_extended_module_are_verified_or_refused(amd, tmp_path, monkeypatch):
     """`mc specs/MCraft.tla` must not hand a changed StateConstraint / raft.tla to the hard-wired lowering.
     The wrapper body is hashed; the EXTENDed module must be found and match, or the run is refused unless the caller

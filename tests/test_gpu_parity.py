@@ -177,18 +177,55 @@ def test_capacity_too_small_overflows(amd):
     eng.close()
 
 
-def test_overflow_is_reported_not_dropped(amd):
-    """overflow of a slot array must raise MC_EOVERFLOW, never silently drop.
-    raft2 has room for 32 distinct messages; MaxMsgs = 6 with 3 terms exceeds it."""
-    eng = amd.Engine("raft", [2, 3, 4, 9, 6, 0], table_capacity=1 << 24, arena_capacity=1 << 22, chunk_states=1 << 16, max_distinct=3_000_000)
-    try:
+def test_overflow_is_reported_not_dropped(amd, oracle):
+    """overflow of a slot array must raise MC_EOVERFLOW, never silently drop a state.  Three servers with
+    8 message slots and no MaxMsgKeys bound: the ninth key appears on level 16, deep inside the run (692 605 states are stored by
+    then); a run that stops before that level is unaffected."""
+    params = [3, 4, 2, 3, 1, 1, 8, 2, 8]
+    eng = amd.Engine("raft", params, table_capacity=1 << 24, arena_capacity=1 << 23, chunk_states=1 << 16, max_distinct=3_000_000, trace=False)
+    with pytest.raises(amd.McError) as ei:
         eng.run()
-    except amd.McError as e:
-        assert e.code == -3
-    else:
-        pytest.skip("configuration did not overflow within the budget")
-    finally:
-        eng.close()
+    assert ei.value.code == -3
+    eng.close()
+    o = oracle.oracle_run("raft", params[:6], max_levels=12)
+    eng = amd.Engine("raft", params, table_capacity=1 << 24, arena_capacity=1 << 23, chunk_states=1 << 16, max_levels=12, trace=False)
+    r = eng.run()
+    assert (r.verdict, r.levels, r.generated) == ("budget", o["levels"], o["generated"]) and o["max_stat"][0] <= 8
+    eng.close()
+
+
+def test_no_two_leaders_negative_control_on_gpu(amd, tmp_path):
+    """NoTwoLeaders (raft.tla:500-507) holds in every reachable state, so no graph test ever sees the kernels raise it.  Negative
+    control through the checkpoint door: the one-state checkpoint of Init is edited by hand into "s1 Leader of term 2, s2
+    Candidate of term 2 holding the votes {s2, s3}" and recovered; BecomeLeader(s2) must be reported as a violation of
+    invariant 0 with a 2-state counterexample; with s2 in term 3 the same run finds nothing."""
+    import struct
+    params = [3, 4, 3, 3, 1, 1]
+    kw = dict(table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
+    e = amd.Engine("raft", params, max_levels=1, **kw)
+    assert e.run().distinct == 1
+    e.checkpoint(tmp_path / "init")
+    e.close()
+    data = (tmp_path / "init").read_bytes()
+    hdr = 8 + 4 + 4 + 16 * 8 + 4 + 4 + 6 * 8      # CkHeader (engine.hip), then the level table (1 entry), then the arena's blocks
+    arena = hdr + 8
+    word = lambda buf, w: struct.unpack_from("<Q", buf, arena + w * 64 * 8)[0]   # state 0 of block 0: word w at (w * 64 + 0)
+    for same_term in (True, False):
+        buf = bytearray(data)
+        sv0, sv1 = word(buf, 3), word(buf, 8)
+        struct.pack_into("<Q", buf, arena + 3 * 64 * 8, (sv0 & ~0x1f) | 2 | (2 << 3))
+        struct.pack_into("<Q", buf, arena + 8 * 64 * 8, (sv1 & ~(0x1f | (0x1f << 8))) | (2 if same_term else 3) | (1 << 3) | (0b110 << 8))
+        (tmp_path / "edited").write_bytes(buf)
+        e = amd.Engine("raft", params, max_levels=2, **kw)
+        e.restore(tmp_path / "edited")
+        r = e.run()
+        if same_term:
+            assert (r.verdict, r.violated_invariant, r.trace_len) == ("invariant", 0, 2)
+            tr = e.trace()
+            assert tr[-1][0] == "BecomeLeader" and tr[-1][1].count("Leader") >= 2
+        else:
+            assert r.verdict == "budget"
+        e.close()
 
 
 def test_table_full_is_an_error(amd):

@@ -72,6 +72,35 @@ def test_ssi_invariants_are_checked_on_the_level_a_budget_stops_at(oracle, shim,
     assert s1["verdict"] == o1["verdict"] == "budget" and s1["levels"] == o1["levels"]
 
 
+def _two_leader_parent(shim, same_term):
+    """Init of a 3-server model with, by hand, s1 = Leader of term 2 and s2 = Candidate of term 2 (or 3) holding the votes
+    {s2, s3}: not a reachable state (votedFor would forbid it) — the parent of the only kind of step that breaks NoTwoLeaders"""
+    import ctypes as C
+    lib = shim.shim_lib()
+    d = shim.spec_desc("raft", [3, 4, 3, 3, 1, 1])
+    w = (C.c_uint64 * 64)()
+    assert lib.shim_init_state(C.byref(d), C.c_uint64(0), w) == 0
+    W_SRV = lambda i: 3 + i * 5                    # spec_raft.h: W_SRV(i) = 3 + i * (2 + NS); term[0,3) state[3,5) votesGranted[8,13)
+    w[W_SRV(0)] = (w[W_SRV(0)] & ~0x1f) | 2 | (2 << 3)
+    w[W_SRV(1)] = (w[W_SRV(1)] & ~(0x1f | (0x1f << 8))) | (2 if same_term else 3) | (1 << 3) | (0b110 << 8)
+    return lib, d, w
+
+
+def test_no_two_leaders_negative_control(shim):
+    """NoTwoLeaders (raft.tla:500-507) is never violated by a reachable state, so a lowering that never raised
+    it would pass every graph test.  BecomeLeader(s2) on a hand-made parent with another Leader of the same term must raise
+    invariant 0; with the other Leader in a different term it must not."""
+    import ctypes as C
+    ST_ENABLED, ST_INVARIANT = 1, 8
+    slot = 2 * 3 + 3 * 3 + 1                       # BecomeLeader(s2): after Restart, Timeout (NS each) and RequestVote (NS * NS)
+    for same_term, expect in ((True, True), (False, False)):
+        lib, d, w = _two_leader_parent(shim, same_term)
+        st, fp = C.c_uint(0), C.c_uint64(0)
+        assert lib.shim_eval_slot(C.byref(d), w, slot, C.byref(st), C.byref(fp)) == 0
+        assert st.value & ST_ENABLED
+        assert bool(st.value & ST_INVARIANT) == expect and (not expect or st.value >> 8 == 0)
+
+
 def test_raft_expected_violation_trace_length(oracle, shim):
     """SURVEY.md Appendix E caveat (ii): CommittedLogStable is violated once MaxTerm >= 3 and
     MaxClientRequests >= 3; the shortest counterexample has 31 states."""

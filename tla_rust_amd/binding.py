@@ -46,6 +46,9 @@ class KernelStats(C.Structure):
                 ("state_bytes", C.c_uint64), ("cand_cells", C.c_uint64)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64)
+
+
 class Result(dict):
     __getattr__ = dict.__getitem__
 
@@ -71,6 +74,7 @@ def lib():
     L = C.CDLL(str(LIB_PATH))
     L.mc_engine_create.argtypes = [C.POINTER(SpecDesc), C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.mc_engine_run.argtypes = [C.c_void_p, C.POINTER(CResult)]
+    L.mc_engine_set_progress.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p, C.c_double]
     L.mc_engine_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
     L.mc_engine_kernel_stats.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
     L.mc_engine_read_states.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
@@ -281,6 +285,11 @@ class Engine:
         n = C.c_uint64()
         _check(lib().mc_shard_end_level(self._h, C.byref(n)), "mc_shard_end_level")
         return n.value
+
+    def set_progress(self, fn, min_interval_seconds=1.0):
+        """fn(levels, generated, distinct, queue) between BFS levels of run(), at most once per interval (mc_engine_set_progress)"""
+        self._progress = PROGRESS_FN(lambda _u, lv, g, d, q: fn(lv, g, d, q)) if fn else PROGRESS_FN()
+        _check(lib().mc_engine_set_progress(self._h, self._progress, None, min_interval_seconds), "mc_engine_set_progress")
 
     def shard_check_frontier(self):
         _check(lib().mc_shard_check_frontier(self._h), "mc_shard_check_frontier")

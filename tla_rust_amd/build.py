@@ -62,6 +62,11 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+    # profiling aid, not part of the product: known-byte access patterns to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (profiles/calib)
+    calib_src = PKG.parent / "profiles" / "calib" / "calib_fetch.hip"
+    calib = OUT / "calib_fetch"
+    if calib_src.exists() and (force or _stale(calib, [calib_src])):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-Wno-unused-result", "-o", str(calib), str(calib_src)], check=True)
     return LIB
 
 

@@ -191,17 +191,26 @@ k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__
 }
 
 // ------------------------------------------------------------------------------------- seen-set
-// Open addressing, linear probing, 64-bit fingerprints, EMPTY = 0.  Entries are write-once, so a
-// relaxed agent-scope load that returns a non-zero word is final; only an observed-empty slot
-// needs the CAS (per-XCD L2s are not coherent: every access to the table is agent scope).
+// Open addressing over BUCKETS of 8 slots (one 64-byte line), 64-bit fingerprints, EMPTY = 0.  A probe reads the whole
+// bucket with four independent 16-byte loads — one memory round trip for 8 slots instead of one dependent 8-byte load
+// per slot: at the load factors a complete graph needs (0.5 .. 0.8) linear probing slot by slot walks 3 to 9 slots per
+// unsuccessful lookup, each a serialised trip to L2 / HBM.  Entries are write-once, so a non-zero word that was read is
+// final whatever cache it came from; an EMPTY word may be stale (the per-XCD L2s are not coherent), so it is only ever
+// taken by an agent-scope atomicCAS, whose return value is the truth.
 __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t mask, uint64_t fp, unsigned &err) {
-    uint64_t h = fp & mask;
-    for (int probe = 0; probe < 8192; ++probe) {
-        unsigned long long cur = __hip_atomic_load((unsigned long long *)&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == 0) cur = atomicCAS((unsigned long long *)&table[h], 0ull, (unsigned long long)fp);
-        if (cur == 0) return true;
-        if (cur == fp) return false;
-        h = (h + 1) & mask;
+    uint64_t b = (fp & mask) & ~7ull;
+    for (int probe = 0; probe < 2048; ++probe) {
+        const ulonglong2 *line = reinterpret_cast<const ulonglong2 *>(table + b);
+        const ulonglong2 v0 = line[0], v1 = line[1], v2 = line[2], v3 = line[3];
+        const unsigned long long slot[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned long long cur = slot[i];
+            if (cur == 0) cur = atomicCAS((unsigned long long *)&table[b + i], 0ull, (unsigned long long)fp);
+            if (cur == 0) return true;
+            if (cur == fp) return false;
+        }
+        b = (b + 8) & mask;
     }
     err |= DEV_ETABLE;
     return false;
@@ -271,6 +280,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 struct WaveQueues {
     uint64_t q_fp[QCAP];
     uint32_t q_src[QCAP], o_src[QCAP];  // (slot << 24) | column: chunks hold <= 2^24 states, specs <= 255 slots
+    uint64_t o_fp[QCAP];                // the survivors' fingerprints: k_materialise need not recompute them
 };
 constexpr int STAGE_MAX = 16;  // words of each parent state staged in LDS per lane (spec-chosen range)
 
@@ -318,6 +328,7 @@ struct RouteArgs {
     uint32_t *rt_src;
     uint64_t subcap;
     const LevelCtl *lc = nullptr;  // non-null: [lo, hi) come from the device (batched small levels)
+    uint64_t *new_fp = nullptr;    // non-null: fingerprints of the new-list entries (same segments, same positions)
 };
 
 template <class S, bool ROUTE>
@@ -380,7 +391,10 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         unsigned long long pos = 0;
         if (lane == 0) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)take);
         pos = __shfl(pos, 0);
-        if (lane < take) seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
+        if (lane < take) {
+            seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
+            if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos + lane] = Q.o_fp[(ohead + lane) & (QCAP - 1)];
+        }
         ohead = (ohead + take) & (QCAP - 1);
         on -= take;
     };
@@ -422,7 +436,11 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             }
         } else {
             const unsigned long long b = __ballot(is_new);
-            if (is_new) Q.o_src[(ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1)] = src;
+            if (is_new) {
+                const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
+                Q.o_src[k] = src;
+                Q.o_fp[k] = qfp;
+            }
             on += (unsigned)__popcll(b);
             wave_lds_fence();
             if (on >= 64) flush_out(64);
@@ -548,7 +566,10 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         unsigned long long pos = 0;
         if (lane == 0) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)take);
         pos = __shfl(pos, 0);
-        if (lane < take) seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
+        if (lane < take) {
+            seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
+            if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos + lane] = Q.o_fp[(ohead + lane) & (QCAP - 1)];
+        }
         ohead = (ohead + take) & (QCAP - 1);
         on -= take;
     };
@@ -590,7 +611,11 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             }
         } else {
             const unsigned long long b = __ballot(is_new);
-            if (is_new) Q.o_src[(ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1)] = src;
+            if (is_new) {
+                const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
+                Q.o_src[k] = src;
+                Q.o_fp[k] = qfp;
+            }
             on += (unsigned)__popcll(b);
             wave_lds_fence();
             if (on >= 64) flush_out(64);
@@ -944,7 +969,7 @@ template <class S>
 struct UsesFamilies<S, decltype((void)S::NFAM)> : std::true_type {};
 
 // blocks per wavefront of the by-family kernel (see k_expand_family): run-time choice among the compiled instances
-static int family_blocks(unsigned flags) { return (flags & 4096u) ? 1 : (flags & 8192u) ? 2 : 4; }
+static int family_blocks(unsigned flags) { return (flags & 4096u) ? 4 : (flags & 8192u) ? 2 : 1; }
 
 template <class S, bool ROUTE, class... A>
 static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStream_t stream, A... args) {
@@ -964,11 +989,15 @@ static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStr
 }
 
 // ------------------------------------------------------------------------------------- materialise
+template <class S, class = void>
+struct HasKnownFp : std::false_type {};
+template <class S>
+struct HasKnownFp<S, decltype((void)S::KNOWN_FP)> : std::true_type {};
 template <class S>
 __global__ void __launch_bounds__(256)
 k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint32_t *__restrict__ newlist, uint64_t seg_cap,
               uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr, unsigned parity,
-              const LevelCtl *lc) {
+              const LevelCtl *lc, const uint64_t *__restrict__ newfp) {
     if (lc) {
         if (lc->stop) return;
         chunk_base = lc->lo & ~63ull;
@@ -985,7 +1014,12 @@ k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, cons
         const int slot = (int)(src >> 24);
         const uint64_t oidx = out0 + j;
         if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); continue; }
-        S::apply(prm, arena_cref(arena, pidx, S::words(prm)), slot, arena_ref(arena, oidx, S::words(prm)));
+        if constexpr (HasKnownFp<S>::value) {  // the expand kernel hands the successor's fingerprint over: no second delta_fp
+            if (newfp) S::apply_known_fp(prm, arena_cref(arena, pidx, S::words(prm)), slot, newfp[(uint64_t)(parity * NSHARD + sh) * seg_cap + j], arena_ref(arena, oidx, S::words(prm)));
+            else S::apply(prm, arena_cref(arena, pidx, S::words(prm)), slot, arena_ref(arena, oidx, S::words(prm)));
+        } else {
+            S::apply(prm, arena_cref(arena, pidx, S::words(prm)), slot, arena_ref(arena, oidx, S::words(prm)));
+        }
         if (parent) { parent[oidx] = (uint32_t)pidx; pslot[oidx] = (uint16_t)slot; }
     }
 }
@@ -1206,6 +1240,17 @@ static __global__ void k_end_level(DevCounters *ctr, LevelCtl *lc) {
 struct EngineBase {
     void *owned_device_blob = nullptr;  // program image of a compiled PlusCal spec (spec_vm.h)
     uint64_t program_hash = 0;          // ... and a hash of that image + its entry points: what a checkpoint of it is matched by
+    mc_progress_fn progress_fn = nullptr;  // mc_engine_set_progress
+    void *progress_user = nullptr;
+    double progress_interval = 1.0;
+    std::chrono::steady_clock::time_point progress_last;
+    void report_progress(uint32_t levels, uint64_t generated, uint64_t distinct, uint64_t queue) {
+        if (!progress_fn) return;
+        const auto now = std::chrono::steady_clock::now();
+        if (std::chrono::duration<double>(now - progress_last).count() < progress_interval) return;
+        progress_last = now;
+        progress_fn(progress_user, levels, generated, distinct, queue);
+    }
     virtual ~EngineBase() { if (owned_device_blob) hipFree(owned_device_blob); }
     virtual int run(mc_result *out) = 0;
     virtual int trace(uint8_t *states_out, int32_t *actions_out, size_t *n_inout) = 0;
@@ -1271,6 +1316,7 @@ struct Engine : EngineBase {
     hipEvent_t ev_e[2] = {nullptr, nullptr}, ev_m[2] = {nullptr, nullptr};
     uint64_t *d_arena = nullptr, *d_table = nullptr, *d_cand = nullptr;
     uint32_t *d_newlist = nullptr;
+    uint64_t *d_newfp = nullptr;  // fingerprints of the new-list entries (specs with apply_known_fp)
     uint16_t *d_nsl = nullptr, *d_pslot = nullptr;
     uint64_t *d_inittmp = nullptr;
     uint32_t *d_parent = nullptr;
@@ -1301,6 +1347,7 @@ struct Engine : EngineBase {
         }
         for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&ev_e[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ev_m[i], hipEventDisableTiming)); }
         table_cap = round_pow2(cfg.table_capacity ? cfg.table_capacity : (1ull << 24));
+        if (table_cap < 64) table_cap = 64;  // whole 8-slot buckets
         arena_cap = cfg.arena_capacity ? cfg.arena_capacity : (1ull << 22);
         arena_cap = (arena_cap + 63) & ~63ull;
         if (arena_cap >= (1ull << 32) - 1) { set_error("arena_capacity must be < 2^32 states"); return MC_EBADCFG; }
@@ -1314,6 +1361,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipMalloc(&d_cand, (size_t)(use_matrix ? max_slots : 1) * row_stride * sizeof(uint64_t)));
         seg_cap = (row_stride / NSHARD + 256) * max_slots;
         HIP_TRY(hipMalloc(&d_newlist, (size_t)2 * NSHARD * seg_cap * sizeof(uint32_t)));
+        if (HasKnownFp<S>::value && !use_matrix) HIP_TRY(hipMalloc(&d_newfp, (size_t)2 * NSHARD * seg_cap * sizeof(uint64_t)));
         {
             const uint64_t ni = S::num_init(prm);
             HIP_TRY(hipMalloc(&d_inittmp, (size_t)(ni < chunk ? ni : chunk) * W * sizeof(uint64_t)));
@@ -1335,6 +1383,7 @@ struct Engine : EngineBase {
         if (d_table) hipFree(d_table);
         if (d_cand) hipFree(d_cand);
         if (d_newlist) hipFree(d_newlist);
+        if (d_newfp) hipFree(d_newfp);
         if (d_nsl) hipFree(d_nsl);
         if (d_inittmp) hipFree(d_inittmp);
         for (auto &q : sl) {
@@ -1394,7 +1443,7 @@ struct Engine : EngineBase {
         hipStreamWaitEvent(stream2, ev_e[parity], 0);
         timed(2, 0, [&] {
             hipLaunchKernelGGL(k_materialise<S>, dim3(gm, NSHARD), dim3(256), 0, stream2, prm, d_arena, chunk_base, d_newlist,
-                               seg_cap, arena_cap, d_parent, d_pslot, d_ctr, parity, (const LevelCtl *)nullptr);
+                               seg_cap, arena_cap, d_parent, d_pslot, d_ctr, parity, (const LevelCtl *)nullptr, (const uint64_t *)d_newfp);
         }, stream2);
         hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream2, d_ctr, parity);
         hipEventRecord(ev_m[parity], stream2);
@@ -1422,13 +1471,14 @@ struct Engine : EngineBase {
         }
         RouteArgs rt{};
         rt.lc = d_lc;
+        rt.new_fp = d_newfp;
         timed(0, 0, [&] {
             launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm, (const uint64_t *)d_arena,
                                     (uint64_t)0, (uint64_t)0, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
         });
         timed(2, 0, [&] {
             hipLaunchKernelGGL(k_materialise<S>, dim3(32, NSHARD), dim3(256), 0, stream, prm, d_arena, (uint64_t)0, d_newlist, seg_cap,
-                               arena_cap, d_parent, d_pslot, d_ctr, 0u, (const LevelCtl *)d_lc);
+                               arena_cap, d_parent, d_pslot, d_ctr, 0u, (const LevelCtl *)d_lc, (const uint64_t *)d_newfp);
         });
         hipLaunchKernelGGL(k_end_level, dim3(1), dim3(1), 0, stream, d_ctr, d_lc);
     }
@@ -1448,7 +1498,7 @@ struct Engine : EngineBase {
                                    d_inittmp, d_newlist, arena_cap, d_parent, d_pslot, d_ctr);
             else
                 hipLaunchKernelGGL(k_materialise<S>, dim3(gm, 1), dim3(256), 0, stream, prm, d_arena, chunk_base_or_first,
-                                   d_newlist, seg_cap, arena_cap, d_parent, d_pslot, d_ctr, 0u, (const LevelCtl *)nullptr);
+                                   d_newlist, seg_cap, arena_cap, d_parent, d_pslot, d_ctr, 0u, (const LevelCtl *)nullptr, (const uint64_t *)nullptr);
         });
         hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr, 0u);
     }
@@ -1475,6 +1525,13 @@ struct Engine : EngineBase {
         HIP_TRY(hipMemcpyAsync(d_ctr, &init_c, sizeof init_c, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         const auto t0 = std::chrono::steady_clock::now();
+        progress_last = t0;
+        auto progress = [&](uint32_t lv, uint64_t lo_, uint64_t hi_) {
+            if (!progress_fn) return;
+            uint64_t g = 0;
+            for (int t = 0; t < NSHARD; t++) g += h_ctr->generated[t].v;
+            report_progress(lv, g, hi_, hi_ - lo_);
+        };
 
         // level 1: Init
         const uint64_t ninit = resuming ? 0 : S::num_init(prm);
@@ -1536,6 +1593,7 @@ struct Engine : EngineBase {
                     }
                     if (level >= MC_MAX_LEVELS) { set_error("too many BFS levels"); return MC_EBADCFG; }
                 }
+                progress(level, lo, hi);
                 continue;  // the loop head re-checks violation / budgets / frontier with the host's copies
             }
             unsigned chunk_no = 0;
@@ -1555,10 +1613,12 @@ struct Engine : EngineBase {
                     finish_chunk<false>(base, ncols, max_slots);
                 } else {
                     if (chunk_no >= 2) hipStreamWaitEvent(stream, ev_m[parity], 0);  // new-list `parity` is free again
+                    RouteArgs rt_new{};
+                    rt_new.new_fp = d_newfp;
                     timed(0, c1 - c0, [&] {
                         launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
                                                 (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
-                                                cfg.flags, RouteArgs{}, parity);
+                                                cfg.flags, rt_new, parity);
                     });
                     finish_materialise(base, ncols, parity);
                 }
@@ -1574,6 +1634,7 @@ struct Engine : EngineBase {
                 level++;
             }
             if (level >= MC_MAX_LEVELS) { set_error("too many BFS levels"); return MC_EBADCFG; }
+            progress(level, lo, hi);
         }
         // a run that stops with an unexpanded frontier (budget) has not evaluated that level's check-on-expand invariants yet
         if (hi > lo && h_ctr->viol_key == ~0ull && !stop_frontier && (rc = check_frontier(lo, hi))) return rc;
@@ -2331,6 +2392,13 @@ int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine *
     return rc;
 }
 int mc_engine_run(mc_engine *e, mc_result *out) { return e && out ? e->impl->run(out) : MC_EBADCFG; }
+int mc_engine_set_progress(mc_engine *e, mc_progress_fn fn, void *user, double min_interval_seconds) {
+    if (!e) return MC_EBADCFG;
+    e->impl->progress_fn = fn;
+    e->impl->progress_user = user;
+    e->impl->progress_interval = min_interval_seconds > 0 ? min_interval_seconds : 0.0;
+    return MC_OK;
+}
 int mc_engine_trace(mc_engine *e, uint8_t *states_out, int32_t *actions_out, size_t *n_inout) {
     return e && n_inout ? e->impl->trace(states_out, actions_out, n_inout) : MC_EBADCFG;
 }

@@ -14,6 +14,7 @@
 // bytecode interpreter of spec_vm.h; `mc --transpile` is the reference's `pcal2tla` step (Makefile:3-4).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -864,6 +865,14 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     mc_engine *e = nullptr;
     if ((rc = mc_engine_create(&d, cfg, &e))) return rc;
     if (recover_path && (rc = mc_engine_restore(e, recover_path))) { mc_engine_destroy(e); return rc; }  // TLC -recover
+    if (cfg->flags & MC_F_PROGRESS) {  // testout2:4-259: one line per report, straight to stdout while the search runs
+        const char *iv = getenv("TLAMC_PROGRESS_INTERVAL");
+        mc_engine_set_progress(e, [](void *, uint32_t levels, uint64_t g, uint64_t dst, uint64_t q) {
+            printf("Progress(%u): %llu states generated, %llu distinct states found, %llu states left on queue.\n", levels,
+                   (unsigned long long)g, (unsigned long long)dst, (unsigned long long)q);
+            fflush(stdout);
+        }, nullptr, iv ? atof(iv) : 1.0);
+    }
     rc = mc_engine_run(e, res);
     if (rc) { mc_engine_destroy(e); return rc; }
     const bool clean = res->verdict == MC_V_OK || res->verdict == MC_V_BUDGET;

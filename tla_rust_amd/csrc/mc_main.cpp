@@ -4,7 +4,7 @@
 //
 //   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic] [-dump FILE]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
-//            [-checkpoint FILE] [-recover FILE] [-gpus P]
+//            [-checkpoint FILE] [-recover FILE] [-gpus P] [-noprogress]
 //   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
 //                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
 //                                         the previous text is kept as X.old
@@ -104,7 +104,7 @@ int main(int argc, char **argv) {
     const char *tla = nullptr, *cfgp = nullptr, *dump = nullptr, *recover = nullptr, *ckpt = nullptr;
     mc_config cfg;
     memset(&cfg, 0, sizeof cfg);
-    cfg.flags = MC_F_DEADLOCK | MC_F_TRACE;
+    cfg.flags = MC_F_DEADLOCK | MC_F_TRACE | MC_F_PROGRESS;  // TLC reports its progress while it runs (testout2:4-259); -noprogress
     cfg.table_capacity = 1ull << 26;
     cfg.arena_capacity = 1ull << 24;
     for (int i = 1; i < argc; i++) {
@@ -117,6 +117,7 @@ int main(int argc, char **argv) {
         else if (arg("-workers")) ++i;
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
         else if (!strcmp(argv[i], "-unverified")) cfg.flags |= MC_F_UNVERIFIED;
+        else if (!strcmp(argv[i], "-noprogress")) cfg.flags &= ~MC_F_PROGRESS;
         else if (arg("-device")) cfg.device = atoi(argv[++i]);
         else if (arg("-maxdistinct")) cfg.max_distinct = strtoull(argv[++i], 0, 10);
         else if (arg("-maxlevels")) cfg.max_levels = strtoull(argv[++i], 0, 10);

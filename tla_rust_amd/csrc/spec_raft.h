@@ -238,7 +238,8 @@ struct SpecRaft {
         int cache_k;           // message slot whose H(word) is cached (Receive / Duplicate / Drop share it)
         uint64_t cache_hm;
     };
-    template <class Ref>
+    // WANT_FP = false: the caller never computes a fingerprint from this cache (k_materialise with a known one)
+    template <bool WANT_FP = true, class Ref>
     MC_HD static void load(const Params &prm, Ref s, Local &l) {
         l.fp = s.get(W_FP);
         l.glob = s.get(W_GLOB);
@@ -275,7 +276,7 @@ struct SpecRaft {
             if (!skip) {
                 l.addmask |= 1u << i;
                 l.nadd++;
-                l.add_fp += hmix(l.log.get(i), SALT_A);
+                if (WANT_FP) l.add_fp += hmix(l.log.get(i), SALT_A);
             }
         }
     }
@@ -799,9 +800,19 @@ struct SpecRaft {
     }
     // re-evaluate `slot` on parent `s` and write the whole successor to `out`
     template <class Ref>
-    MC_HD static unsigned apply(const Params &prm, Ref s, int slot, WordRef out) {
+    MC_HD static unsigned apply(const Params &prm, Ref s, int slot, WordRef out) { return apply_impl<false>(prm, s, slot, 0, out); }
+    // ... when the expand kernel hands the successor's fingerprint over (fp_nonzero of the raw sum): the dozen hash terms of
+    // delta_fp are not computed a second time.  The one ambiguous value (raw sum 0 or the substitute itself) is recomputed.
+    static constexpr bool KNOWN_FP = true;
+    template <class Ref>
+    MC_HD static unsigned apply_known_fp(const Params &prm, Ref s, int slot, uint64_t fp_nz, WordRef out) {
+        if (fp_nz == fp_nonzero(0)) return apply_impl<false>(prm, s, slot, 0, out);
+        return apply_impl<true>(prm, s, slot, fp_nz, out);
+    }
+    template <bool KNOWN, class Ref>
+    MC_HD static unsigned apply_impl(const Params &prm, Ref s, int slot, uint64_t fp_known, WordRef out) {
         Local l;
-        load(prm, s, l);
+        load<!KNOWN>(prm, s, l);
         Delta d;
         int action;
         const unsigned st = compute<true>(prm, l, s, slot, d, action);
@@ -810,7 +821,7 @@ struct SpecRaft {
             for (int w = 0; w < nw; w++) out.set(w, s.get(w));
             return st;
         }
-        out.set(W_FP, delta_fp(l, s, d));
+        out.set(W_FP, KNOWN ? fp_known : delta_fp(l, s, d));
         out.set(W_GLOB, d.glob);
         out.set(W_CLOG, d.clog);
 #pragma unroll
