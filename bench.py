@@ -156,23 +156,29 @@ def main():
         dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
         n_runs = a.steps  # stats are reset by every run(): they describe the last step
         ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
-        traffic, traffic_src = None, None
-        pmc = sorted((ROOT / "profiles").glob("r*_pmc.json"))
+        traffic, traffic_src, traffic_lower, l2_hit = None, None, None, None
+        pmc = sorted(p for p in (ROOT / "profiles").glob("r*_pmc.json"))
         if pmc:  # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same command
             try:
                 d = json.loads(pmc[-1].read_text())
                 knames = {"expand": ("k_expand_direct",) if direct else ("k_expand_insert",) if a.no_family else ("k_expand_family", "k_expand_insert"),
                           "insert": ("k_insert",), "materialise": ("k_materialise",)}[dom]
                 k = next(v for kn in knames for n, v in d.items() if n.startswith(kn + "<") and "Raft<3>" in n)
-                # FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts wide coalesced reads at 1/2 (MI355X_MICROARCH.md §HBM)
+                # FETCH_SIZE / WRITE_SIZE are in KB.  Calibration on this box (profiles/r02e_calib_*.json*, profiles/calib/calib_fetch.hip):
+                # FETCH_SIZE = read requests x 64 B; the arena's 8 B/lane row reads and 16 B/lane streaming reads are 128-B
+                # requests (FETCH_SIZE = exactly 1/2 of the known bytes, as MI355X_MICROARCH.md says), a random 64-byte seen-set
+                # bucket probe is ONE request (request size not observable); WRITE_SIZE equals the known bytes.  `traffic`
+                # applies the guide's x2 to every read request (upper bound), `traffic_lower` counts a probe's request as 64 B.
                 traffic = (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
-                traffic_src = f"profiles/{pmc[-1].name}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes"
+                traffic_lower = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
+                l2_hit = k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) if "TCC_HIT_sum" in k else None
+                traffic_src = f"profiles/{pmc[-1].name}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes of this command"
             except Exception:  # noqa: BLE001
                 traffic = None
         kernel_name = {"expand": "k_expand_direct<SpecRaft<3>>" if direct else "k_expand_insert<SpecRaft<3>>" if (a.no_family or a.matrix) else "k_expand_family<SpecRaft<3>>",
                        "insert": "k_insert", "materialise": "k_materialise<SpecRaft<3>>"}[dom]
         line["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_lower": traffic_lower, "l2_hit_rate": l2_hit, "traffic_source": traffic_src,
                             "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
                             "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
                             "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},

@@ -339,6 +339,12 @@ class Parser:
         if c.k == "id":
             if c.s == "CHOOSE":
                 self.i += 1
+                if self.cur().k == "id" and self.t[self.i + 1].s == ":":
+                    # unbounded CHOOSE x : P (serializableSnapshotIsolation.tla:24 NoLock): TLC cannot evaluate it either — the cfg
+                    # replaces the definition by a model value (CachingMemory/MCInternalMemory.cfg:24-27); parsed, never evaluated
+                    name = self.ident()
+                    self.expect(":")
+                    return ("choose_unbounded", name, self.expr(0))
                 bs = self.bounds()
                 self.expect(":")
                 return ("choose", bs, self.expr(0))
@@ -911,7 +917,7 @@ class Spec:
                 raise TLAError(f"CONSTANT {k} has no value in the configuration")
 
     def _load(self, path):
-        m = Module(path.read_text())
+        m = Module(path.read_text(errors="replace"))  # the reference's SSI spec has cp1252 quotes inside comments
         for e in m.extends:
             if e in self.BUILTIN_MODULES or any(x.name == e for x in self.modules):
                 continue
@@ -1163,7 +1169,7 @@ class Spec:
             args = [self._arg(a, scope) for a in argnodes]
             return lambda env, st, nx: op.cv({p: a(env, st, nx) for p, a in zip(op.params, args)}, st, nx)
         bi = BUILTIN_OPS.get(name)
-        if bi is not None:
+        if name in BUILTIN_OPS:
             if name == "SelectSeq":
                 seq = self.cv(argnodes[0], scope)
                 test = self._arg(argnodes[1], scope, 1)
@@ -1351,6 +1357,11 @@ class Spec:
                         raise TLAError(f"\\A body is the non-boolean {fmt(v)}")
                 return True
         return g
+
+    def v_choose_unbounded(self, node, scope):
+        def f(env, st, nx):
+            raise TLAError(f"TLC cannot evaluate the unbounded CHOOSE {node[1]} : ... (give the defined symbol a model value in the cfg)")
+        return f
 
     def v_choose(self, node, scope):
         bs, body = node[1], node[2]
@@ -1820,7 +1831,7 @@ class Spec:
         return sep.join(f"/\\ {v} = {fmt(st[self.varidx[v]])}" for v in names)
 
 
-NODE_KINDS = {"num", "str", "bool", "id", "call", "paren", "at", "conj", "disj", "op", "not", "neg", "quant", "choose", "if", "case",
+NODE_KINDS = {"num", "str", "bool", "id", "call", "paren", "at", "conj", "disj", "op", "not", "neg", "quant", "choose", "choose_unbounded", "if", "case",
               "let", "lambda", "unchanged", "enabled", "pre", "setenum", "setfilter", "setmap", "tuple", "record", "recordset",
               "fndef", "fnset", "except", "idx", "prime", "temporal", "instance"}
 

@@ -502,13 +502,24 @@ struct ShimShard : ShimShardBase {
                 if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
                 if (st & ST_OUT_OF_MODEL) continue;
                 const uint32_t o = fp_owner(fp, nranks);
+                if (o == rank) {  // engine.hip, local-owner shortcut: probed at once, a new state joins this rank's own frontier
+                    if (seen.insert(fp).second) {
+                        uint64_t tmp[S::MAX_WORDS];
+                        S::apply(prm, s, slot, WordRef{tmp, 1});
+                        local_new.insert(local_new.end(), tmp, tmp + W);
+                    }
+                    continue;
+                }
                 fps[o].push_back(fp);
                 src[o].push_back({i, slot});
             }
             if (!nsucc && verdict == MC_V_OK) verdict = MC_V_DEADLOCK;
         }
+        arena.insert(arena.end(), local_new.begin(), local_new.end());  // (after the loop: `s` points into the arena)
+        local_new.clear();
         return 0;
     }
+    std::vector<uint64_t> local_new;
     int expand_finish(unsigned slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) override {
         Slot &q = sl[slot & 1];
         if (!q.launched) return MC_EBADCFG;

@@ -1,6 +1,7 @@
-"""Makes tests/golden/raft_reference_text.json: the reference's OWN spec text (/root/reference/examples/raft.tla, read where
-it lies) evaluated by oracle/tlaplus.py under specs/MCraft.tla.  Run in the build container (the GPU box has no
-/root/reference):  python tests/golden/make_reference_text_golden.py
+"""Makes tests/golden/raft_reference_text.json and tests/golden/ssi_reference_text.json: the reference's OWN spec texts
+(/root/reference/examples/raft.tla, serializableSnapshotIsolation.tla, textbookSnapshotIsolation.tla, read where they lie)
+evaluated by oracle/tlaplus.py under the model wrappers of specs/.  Run in the build container (the GPU box has no
+/root/reference):  python tests/golden/make_reference_text_golden.py [raft] [ssi]
 """
 import hashlib
 import json
@@ -62,9 +63,53 @@ def run_raft_text(name):
                 level_digests=digests)
 
 
+# ---------------------------------------------------------------------------------------------- snapshot isolation
+SSI_ORDER = ["history", "holdingXLocks", "waitingForXLock", "inConflict", "outConflict", "holdingSIREADlocks"]
+TEXTBOOK_ORDER = ["history", "holdingXLocks", "waitingForXLock"]
+SSI_INVARIANTS = ["TypeInv", "WellFormed", "CorrectnessOfHoldingXLocks", "CorrectnessOfWaitingForXLock", "CorrectReadView",
+                  "FirstCommitterWins", "CahillOK", "BernsteinOK"]
+# params = the C oracle's / the lowering's {nTxn, nKey, invariant mask, find, textbook}
+SSI_MODELS = {
+    "ssi_2x1": dict(params=[2, 1, 127, 0], module="MCssi"),                 # 569 distinct
+    "ssi_2x2": dict(params=[2, 2, 127, 0], module="MCssi"),                 # 29 629 distinct / 50 121 generated / depth 13
+    "ssi_3x1": dict(params=[3, 1, 127, 0], module="MCssi"),                 # 90 430 distinct
+    "textbook_2x2": dict(params=[2, 2, 31, 0, 1], module="MCtextbookSI"),   # textbookSnapshotIsolation.tla, the SI-level invariants
+}
+
+
+def ssi_cfg(nt, nk, invariants):
+    return (f"INIT Init\nNEXT Next\nCONSTANTS\n  TxnId = {{{', '.join(f'T{i + 1}' for i in range(nt))}}}\n"
+            f"  Key = {{{', '.join(f'K{i + 1}' for i in range(nk))}}}\n  NoLock = NoLock\nINVARIANTS {' '.join(invariants)}\n")
+
+
+def run_ssi_text(name):
+    import tlaplus as T
+    m = SSI_MODELS[name]
+    textbook = len(m["params"]) > 4 and m["params"][4]
+    invs = [i for i in SSI_INVARIANTS if not (textbook and i in ("CahillOK", "BernsteinOK"))]  # textbook SI is not serializable
+    c = T.Checker(ROOT / "specs" / f"{m['module']}.tla", cfg_text=ssi_cfg(m["params"][0], m["params"][1], invs), search=[REF])
+    r = c.run_levels()
+    order = TEXTBOOK_ORDER if textbook else SSI_ORDER
+    digests = [hashlib.sha256("\n".join(sorted(c.spec.state_text(s, order) for s in lvl)).encode()).hexdigest()[:16]
+               for lvl in r["level_states"]]
+    return dict(distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"], verdict=r["verdict"],
+                level_digests=digests)
+
+
 if __name__ == "__main__":
-    out = {}
-    for name in RAFT_MODELS:
-        out[name] = run_raft_text(name)
-        print(name, {k: v for k, v in out[name].items() if k != "level_digests"}, flush=True)
-    (ROOT / "tests" / "golden" / "raft_reference_text.json").write_text(json.dumps(out, indent=1) + "\n")
+    which = sys.argv[1:] or ["raft", "ssi"]
+    if "raft" in which:
+        out = {}
+        for name in RAFT_MODELS:
+            out[name] = run_raft_text(name)
+            print(name, {k: v for k, v in out[name].items() if k != "level_digests"}, flush=True)
+        (ROOT / "tests" / "golden" / "raft_reference_text.json").write_text(json.dumps(out, indent=1) + "\n")
+    if "ssi" in which:
+        path = ROOT / "tests" / "golden" / "ssi_reference_text.json"
+        out = json.loads(path.read_text()) if path.exists() else {}
+        for name in SSI_MODELS:
+            if len(which) > 1 and which[0] == "ssi" and name not in which[1:]:
+                continue
+            out[name] = run_ssi_text(name)
+            print(name, {k: v for k, v in out[name].items() if k != "level_digests"}, flush=True)
+            path.write_text(json.dumps(out, indent=1) + "\n")

@@ -329,6 +329,7 @@ struct RouteArgs {
     uint64_t subcap;
     const LevelCtl *lc = nullptr;  // non-null: [lo, hi) come from the device (batched small levels)
     uint64_t *new_fp = nullptr;    // non-null: fingerprints of the new-list entries (same segments, same positions)
+    unsigned my_rank = 0;          // route mode: this rank (candidates it owns are probed locally)
 };
 
 template <class S, bool ROUTE>
@@ -412,9 +413,27 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         qn -= take;
         probes += take;
         if constexpr (ROUTE) {
-            // one round trip for all owners: lane t reserves the bucket space of owner t (the P atomics issue together
+            // LOCAL-OWNER SHORTCUT: a candidate this rank owns is probed right here, like on one GPU, and a new one goes to the
+            // rank's own new-list (materialised locally, it never travels); only candidates of OTHER owners are routed.  On P
+            // ranks 1/P of the candidates skip the exchange; on one rank the sharded engine does exactly the fused engine's work.
+            unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
+            if (owner == rt.my_rank) {
+                is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);
+                owner = 0xffffffffu;
+            }
+            {
+                const unsigned long long b = __ballot(is_new);
+                if (is_new) {
+                    const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
+                    Q.o_src[k] = src;
+                    Q.o_fp[k] = qfp;
+                }
+                on += (unsigned)__popcll(b);
+                wave_lds_fence();
+                if (on >= 64) flush_out(64);
+            }
+            // one round trip for all remote owners: lane t reserves the bucket space of owner t (the P atomics issue together
             // instead of one after the other), then every candidate takes its owner's base from that lane
-            const unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
             unsigned my_rank = 0, my_cnt = 0;
             for (unsigned t = 0; t < rt.nranks; ++t) {
                 const unsigned long long b = __ballot(owner == t);
@@ -587,9 +606,27 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         qn -= take;
         probes += take;
         if constexpr (ROUTE) {
-            // one round trip for all owners: lane t reserves the bucket space of owner t (the P atomics issue together
+            // LOCAL-OWNER SHORTCUT: a candidate this rank owns is probed right here, like on one GPU, and a new one goes to the
+            // rank's own new-list (materialised locally, it never travels); only candidates of OTHER owners are routed.  On P
+            // ranks 1/P of the candidates skip the exchange; on one rank the sharded engine does exactly the fused engine's work.
+            unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
+            if (owner == rt.my_rank) {
+                is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);
+                owner = 0xffffffffu;
+            }
+            {
+                const unsigned long long b = __ballot(is_new);
+                if (is_new) {
+                    const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
+                    Q.o_src[k] = src;
+                    Q.o_fp[k] = qfp;
+                }
+                on += (unsigned)__popcll(b);
+                wave_lds_fence();
+                if (on >= 64) flush_out(64);
+            }
+            // one round trip for all remote owners: lane t reserves the bucket space of owner t (the P atomics issue together
             // instead of one after the other), then every candidate takes its owner's base from that lane
-            const unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
             unsigned my_rank = 0, my_cnt = 0;
             for (unsigned t = 0; t < rt.nranks; ++t) {
                 const unsigned long long b = __ballot(owner == t);
@@ -1395,6 +1432,7 @@ struct Engine : EngineBase {
         for (auto &ev : ev_slot) if (ev) hipEventDestroy(ev);
         for (auto &ev : ev_keep) if (ev) hipEventDestroy(ev);
         if (ev_ans) hipEventDestroy(ev_ans);
+        if (ev_append) hipEventDestroy(ev_append);
         if (d_scan_tmp) hipFree(d_scan_tmp);
         if (d_parent) hipFree(d_parent);
         if (d_pslot) hipFree(d_pslot);
@@ -1898,7 +1936,7 @@ struct Engine : EngineBase {
         uint64_t *rt_fp = nullptr;
         uint32_t *rt_src = nullptr, *pend_src = nullptr;
         PaddedCounter *rt_cur = nullptr;  // [nranks*NSHARD] route cursors
-        uint64_t rt_subcap = 0, pend_cap = 0, pend_total = 0, chunk_base = 0, count = 0;
+        uint64_t rt_subcap = 0, pend_cap = 0, pend_total = 0, chunk_base = 0, count = 0, ncols = 0;
         OwnerOffsets pend_off;
         bool launched = false, keep_pending = false;
     } sl[2];
@@ -2021,6 +2059,14 @@ struct Engine : EngineBase {
     bool ext_side = false;
     hipEvent_t ev_slot[2] = {nullptr, nullptr}, ev_keep[2] = {nullptr, nullptr}, ev_ans = nullptr;
     hipStream_t side() const { return ext_side ? ext_stream : stream2; }
+    // Three kinds of kernels append states at arena_next (the chunk's locally owned new states, keep, ingest) and they run on
+    // different streams: one event chains them, each appender waits for the previous one and records when it is enqueued.
+    hipEvent_t ev_append = nullptr;
+    void append_begin(hipStream_t s) { if (ev_append) hipStreamWaitEvent(s, ev_append, 0); }
+    void append_end(hipStream_t s) {
+        if (!ev_append) hipEventCreateWithFlags(&ev_append, hipEventDisableTiming);
+        hipEventRecord(ev_append, s);
+    }
     int side_done() {
         if (!ext_side) HIP_TRY(hipStreamSynchronize(stream2));
         return MC_OK;
@@ -2053,9 +2099,12 @@ struct Engine : EngineBase {
         const uint64_t ncols = ((c1 - base) + 63) & ~63ull;
         q.chunk_base = base;
         RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
-        timed(0, count, [&] {
+        rt.my_rank = cfg.shard_rank;
+        rt.new_fp = d_newfp;
+        q.ncols = ncols;
+        timed(0, count, [&] {  // new-list parity = slot: the locally owned new states of this chunk (local-owner shortcut)
             launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
-                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
+                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, slot);
         });
         return MC_OK;
     }
@@ -2089,6 +2138,18 @@ struct Engine : EngineBase {
         if (q.keep_pending) {  // the slot's previous keep still reads pend_src
             HIP_TRY(hipStreamWaitEvent(side(), ev_keep[slot], 0));
             q.keep_pending = false;
+        }
+        {   // the chunk's locally owned new states (local-owner shortcut): materialised on the side stream, in order with the
+            // other kernels that append at arena_next (keep, ingest); the expand kernel has finished (stream was synchronised)
+            const unsigned bx = (unsigned)((q.ncols + 255) / 256);
+            const unsigned gm = bx < 8 * 256 ? (bx + 7) / 8 : 256;
+            append_begin(stream2);
+            timed(2, 0, [&] {
+                hipLaunchKernelGGL(k_materialise<S>, dim3(gm ? gm : 1, NSHARD), dim3(256), 0, stream2, prm, d_arena, q.chunk_base, d_newlist, seg_cap,
+                                   arena_cap, d_parent, d_pslot, d_ctr, slot, (const LevelCtl *)nullptr, (const uint64_t *)d_newfp);
+            }, stream2);
+            hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream2, d_ctr, slot);
+            append_end(stream2);
         }
         if (total) {
             RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
@@ -2165,6 +2226,7 @@ struct Engine : EngineBase {
         }
         int rc = scan_answers(answers_back, q.pend_total, ks);
         if (rc) return rc;
+        append_begin(ks);
         const uint32_t *d_total = d_incl + (q.pend_total - 1);
         OwnerOffsets one, zero;  // a single range covering every pending candidate
         for (unsigned t = 0; t <= 8; t++) { one.off[t] = t ? q.pend_total : 0; zero.off[t] = 0; }
@@ -2175,6 +2237,7 @@ struct Engine : EngineBase {
                                d_parent, d_pslot, d_ctr);
         }, ks);
         hipLaunchKernelGGL(k_bump_arena_next, dim3(1), dim3(1), 0, ks, d_ctr, d_total, 0ull, (unsigned long long)arena_cap);
+        append_end(ks);
         if (!ev_keep[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_keep[slot], hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev_keep[slot], ks));
         q.keep_pending = true;
@@ -2191,10 +2254,12 @@ struct Engine : EngineBase {
     int shard_ingest(const uint8_t *recv_states, uint64_t n) override {
         HIP_TRY(hipSetDevice(cfg.device));
         if (!n) return MC_OK;
+        append_begin(side());
         hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, side(), d_arena, W, (const uint64_t *)recv_states, n,
                            arena_cap, d_parent, d_ctr);
         hipLaunchKernelGGL(k_bump_arena_next, dim3(1), dim3(1), 0, side(), d_ctr, (const uint32_t *)nullptr, (unsigned long long)n,
                            (unsigned long long)arena_cap);
+        append_end(side());
         return side_done();
     }
     int shard_end_level(uint64_t *new_local) override {
