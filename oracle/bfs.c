@@ -35,6 +35,10 @@ typedef struct {
     uint32_t *parent;  /* parent index, UINT32_MAX for initial states */
     int16_t *act;
     uint64_t n, ncap;
+    /* optional key arena (spec->canon): what the seen-set compares; entry i belongs to state i */
+    uint8_t *karena, *kbuf;
+    uint64_t karena_len, karena_cap;
+    uint64_t *koff;
     /* exact seen-set: open addressing over state indices */
     uint32_t *tab;
     uint64_t tab_cap; /* power of two */
@@ -75,7 +79,8 @@ static void tab_grow(bfs_t *b) {
     uint32_t *nt = calloc(ncap, sizeof *nt);
     if (!nt) { fprintf(stderr, "oracle: out of memory (table)\n"); abort(); }
     for (uint64_t i = 0; i < b->n; i++) {
-        uint64_t h = hash_bytes(b->arena + b->off[i], b->off[i + 1] - b->off[i]) & (ncap - 1);
+        uint64_t h = (b->koff ? hash_bytes(b->karena + b->koff[i], b->koff[i + 1] - b->koff[i])
+                              : hash_bytes(b->arena + b->off[i], b->off[i + 1] - b->off[i])) & (ncap - 1);
         while (nt[h]) h = (h + 1) & (ncap - 1);
         nt[h] = (uint32_t)(i + 1);
     }
@@ -88,15 +93,29 @@ static void tab_grow(bfs_t *b) {
 static int store_insert(bfs_t *b, const uint8_t *s, size_t len, uint32_t parent, int action) {
     if ((b->n + 1) * 2 > b->tab_cap) tab_grow(b);
     uint64_t mask = b->tab_cap - 1;
-    uint64_t h = hash_bytes(s, len) & mask;
+    const uint8_t *key = s;
+    size_t klen = len;
+    if (b->spec->canon) {  /* dedup on the orbit's canonical form, store the state as it was generated */
+        if (!b->kbuf) b->kbuf = malloc(b->spec->max_state_bytes);
+        klen = b->spec->canon(b->spec->ctx, s, len, b->kbuf);
+        key = b->kbuf;
+    }
+    uint64_t h = hash_bytes(key, klen) & mask;
     while (b->tab[h]) {
         uint64_t i = b->tab[h] - 1;
-        if (b->off[i + 1] - b->off[i] == len && memcmp(b->arena + b->off[i], s, len) == 0) return 0;
+        if (b->spec->canon) {
+            if (b->koff[i + 1] - b->koff[i] == klen && memcmp(b->karena + b->koff[i], key, klen) == 0) return 0;
+        } else if (b->off[i + 1] - b->off[i] == len && memcmp(b->arena + b->off[i], s, len) == 0) return 0;
         h = (h + 1) & mask;
     }
     if (b->n + 2 > b->ncap) {
         b->ncap = b->ncap ? b->ncap * 2 : 1024;
         b->off = realloc(b->off, (b->ncap + 1) * sizeof *b->off);
+        if (b->spec->canon) {
+            b->koff = realloc(b->koff, (b->ncap + 1) * sizeof *b->koff);
+            if (!b->koff) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
+            if (b->n == 0) b->koff[0] = 0;
+        }
         b->parent = realloc(b->parent, b->ncap * sizeof *b->parent);
         b->act = realloc(b->act, b->ncap * sizeof *b->act);
         if (!b->off || !b->parent || !b->act) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
@@ -110,6 +129,16 @@ static int store_insert(bfs_t *b, const uint8_t *s, size_t len, uint32_t parent,
     memcpy(b->arena + b->arena_len, s, len);
     b->arena_len += len;
     b->off[b->n + 1] = b->arena_len;
+    if (b->spec->canon) {
+        if (b->karena_len + klen > b->karena_cap) {
+            while (b->karena_len + klen > b->karena_cap) b->karena_cap = b->karena_cap ? b->karena_cap * 2 : (1u << 20);
+            b->karena = realloc(b->karena, b->karena_cap);
+            if (!b->karena) { fprintf(stderr, "oracle: out of memory (key arena)\n"); abort(); }
+        }
+        memcpy(b->karena + b->karena_len, key, klen);
+        b->karena_len += klen;
+        b->koff[b->n + 1] = b->karena_len;
+    }
     b->parent[b->n] = parent;
     b->act[b->n] = (int16_t)action;
     b->tab[h] = (uint32_t)(b->n + 1);
@@ -298,6 +327,9 @@ done:
     free(b.act);
     free(b.tab);
     free(b.viol_state);
+    free(b.karena);
+    free(b.koff);
+    free(b.kbuf);
     return 0;
 }
 

@@ -191,6 +191,7 @@ static double mt_now(void) {
 
 int or_run_bfs_mt(const or_spec *sp, const or_options *opt, int nthreads, double max_seconds, or_result *r) {
     if (nthreads < 1) nthreads = 1;
+    if (sp->canon) { or_set_error("the multi-threaded oracle does not implement first-met SYMMETRY representatives"); return -1; }
     if (opt->stop_on_violation == 2 || opt->dump_path) { or_set_error("the multi-threaded oracle has no stop-at-once mode and no dump"); return -1; }
     mt_bfs b;
     memset(&b, 0, sizeof b);

@@ -23,6 +23,9 @@ typedef struct or_spec {
     size_t (*print)(void *ctx, const uint8_t *s, size_t len, char *buf, size_t cap);
     const char *(*action_name)(int action);
     void (*stats)(void *ctx, const uint8_t *s, size_t len, uint64_t *max_stat); /* optional */
+    /* optional: the seen-set compares canon(s) instead of s (SYMMETRY with TLC's first-met representative: the state that is
+     * stored and later expanded is the one that was generated, the ORBIT decides whether it is new) */
+    size_t (*canon)(void *ctx, const uint8_t *s, size_t len, uint8_t *out);
 } or_spec;
 
 int or_spec_atomic_add(const int64_t *p, int np, or_spec *out);

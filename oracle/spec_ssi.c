@@ -14,6 +14,8 @@
  *
  * params: {nTxn, nKey, invariant mask, find, textbook, sym}
  *   sym (cfg SYMMETRY; :38-44 make Key and TxnId symmetry sets): bit 0 = Permutations(TxnId), bit 1 = Permutations(Key);
+ *     bit 2 = TLC's representative (the orbit member that was generated first is stored and expanded) instead of the
+ *     canonical one — to measure whether the orbit COUNT depends on the representative (Commit's CHOOSE, :465-474);
  *     brute-force canonicalisation, see s_canonical
  *   textbook = 1 selects examples/textbookSnapshotIsolation.tla: the same model WITHOUT Cahill's three variables
  *     (its allvars :115): Commit never aborts the pivot (:325-355), Read (:365-378) and HelperWriteCanAcquireXLock
@@ -197,7 +199,9 @@ static size_t s_canonical(const ssi_ctx *c, const SState *t, uint8_t *best) {
 
 typedef struct { const ssi_ctx *c; or_emit *em; uint8_t buf[512]; } sgen;
 static void s_emit(sgen *g, const SState *t, int action) {
-    size_t len = g->c->sym ? s_canonical(g->c, t, g->buf) : s_ser(g->c, t, g->buf);
+    /* sym & 4 = TLC's own scheme: the state is stored and expanded AS GENERATED (first member of its orbit that was met);
+     * only the seen-set looks at the canonical form (ssi_canon below) */
+    size_t len = (g->c->sym & 3) && !(g->c->sym & 4) ? s_canonical(g->c, t, g->buf) : s_ser(g->c, t, g->buf);
     g->em->emit(g->em, g->buf, len, action, 0);
 }
 
@@ -616,6 +620,13 @@ static void ssi_stats(void *ctx, const uint8_t *sb, size_t len, uint64_t *mx) {
     (void)ctx; (void)len;
     if (sb[0] > mx[0]) mx[0] = sb[0];   /* longest history */
 }
+/* first-met mode (sym & 4): the seen-set's key of a state = its orbit's canonical form */
+static size_t ssi_canon(void *ctx, const uint8_t *sb, size_t len, uint8_t *out) {
+    const ssi_ctx *c = ctx; (void)len;
+    SState s;
+    s_deser(c, sb, &s);
+    return s_canonical(c, &s, out);
+}
 int or_spec_ssi(const int64_t *p, int np, or_spec *o) {
     if (np < 2 || p[0] < 1 || p[0] > ST || p[1] < 1 || p[1] > SK) { or_set_error("ssi: need {nTxn <= 4, nKey <= 3[, invmask, find]}"); return -1; }
     ssi_ctx *c = calloc(1, sizeof *c);
@@ -623,9 +634,11 @@ int or_spec_ssi(const int64_t *p, int np, or_spec *o) {
     c->inv_mask = np > 2 ? (int)p[2] : 127;
     c->find = np > 3 ? (int)p[3] : 0;
     c->textbook = np > 4 ? (int)p[4] : 0;
-    c->sym = np > 5 ? (int)p[5] & 3 : 0;
+    c->sym = np > 5 ? (int)p[5] & 7 : 0;
+    if (!(c->sym & 3)) c->sym = 0;
     o->name = "ssi"; o->ctx = c; o->max_state_bytes = 512;
     o->n_init = ssi_n_init; o->init = ssi_init; o->succ = ssi_succ; o->invariant = ssi_invariant; o->print = ssi_print;
     o->action_name = or_ssi_action; o->stats = ssi_stats;
+    if (c->sym & 4) o->canon = ssi_canon;
     return 0;
 }

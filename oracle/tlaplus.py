@@ -337,6 +337,13 @@ class Parser:
                 self.i += 1
                 return ("temporal", c.s, self.expr(4))
         if c.k == "id":
+            if c.s in ("WF_", "SF_") and self.t[self.i + 1].s == "<<":  # WF_<<v1, v2>>(A): fairness, parsed and never evaluated
+                self.i += 1
+                sub = self.expr(16)
+                self.expect("(")
+                act = self.expr(0)
+                self.expect(")")
+                return ("temporal", c.s, ("tuple", [sub, act]))
             if c.s == "CHOOSE":
                 self.i += 1
                 if self.cur().k == "id" and self.t[self.i + 1].s == ":":
@@ -466,7 +473,10 @@ class Parser:
             if c.s == "<<":
                 items = self.exprlist(">>")
                 if self.cur().k == "id" and self.cur().s.startswith("_") and not self.ended():  # <<A>>_v
+                    bare = self.cur().s == "_"
                     self.i += 1
+                    if bare:
+                        self.expr(16)   # <<A>>_<<v1, v2>>: the subscript is a tuple
                     return ("temporal", "<<>>_", ("tuple", items))
                 return ("tuple", items)
             if c.s == "[":
@@ -529,7 +539,10 @@ class Parser:
                     return ("fnset", first, rng)
                 self.expect("]")
                 if self.cur().k == "id" and self.cur().s.startswith("_"):  # [A]_v
+                    bare = self.cur().s == "_"
                     self.i += 1
+                    if bare:
+                        self.expr(16)   # [A]_<<v1, v2>>: the subscript is a tuple
                     return ("temporal", "[]_", first)
                 self.fail("unsupported bracket expression")
         self.i -= 1

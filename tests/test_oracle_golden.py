@@ -122,3 +122,18 @@ def test_textbook_si_is_not_serializable_and_both_formulations_agree(oracle):
     assert a["distinct"] == b["distinct"] == 16559944
     ok = oracle.oracle_run("ssi", [2, 2, 127, 0, 1])       # too small for write skew: everything holds
     assert ok["verdict"] == "ok" and ok["distinct"] == 29629
+
+
+@pytest.mark.parametrize("params", [[2, 2, 127, 0, 0], [3, 1, 127, 0, 0], [2, 3, 127, 0, 0], [3, 1, 31, 0, 1]])
+@pytest.mark.parametrize("sym", [1, 2, 3])
+def test_symmetry_orbit_counts_do_not_depend_on_the_representative(oracle, params, sym):
+    """TLC stores and expands the orbit member it met FIRST, the oracle (and the device lowering) the
+    canonical one; Commit's AbortOpSeq (serializableSnapshotIsolation.tla:465-474) CHOOSEs an order, so the two could in
+    principle count different numbers of orbits.  They do not: with sym bit 2 the oracle runs TLC's scheme (seen-set keyed
+    by the canonical form, the generated state stored) — same orbits, same generated count, same depth, level by level.
+    (3 x 2 under both symmetry sets: 6 734 049 orbits / 11 514 563 generated / 19 levels either way)"""
+    a = oracle.oracle_run("ssi", params + [sym])
+    b = oracle.oracle_run("ssi", params + [sym | 4])
+    assert (a["distinct"], a["generated"], a["depth"], a["levels"], a["verdict"]) == \
+           (b["distinct"], b["generated"], b["depth"], b["levels"], b["verdict"])
+    assert a["distinct"] <= oracle.oracle_run("ssi", params)["distinct"]   # (Key symmetry cannot reduce a one-key model)
