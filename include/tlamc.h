@@ -77,6 +77,9 @@ typedef struct {
 #define MC_F_DIRECT 1024u /* A/B only: one kernel per chunk (expand + insert + copy-and-patch write, k_expand_direct) instead of
                           * expand and materialise on two streams; measured slower, kept for the comparison */
 #define MC_F_FAMBLOCKS4 4096u /* A/B only: the by-family expand kernel works through 4 (default 1) arena blocks per wavefront */
+#define MC_F_NODENSE 32768u  /* A/B only: Restart / Timeout slots of raft through the family queues instead of inline, lane = parent */
+#define MC_F_OCC5 2048u      /* A/B only: by-family expand kernel compiled for 5 wavefronts per SIMD (96 VGPRs, some spilled); with
+                              * MC_F_DIRECT: k_expand_direct compiled for 3 */
 #define MC_F_FAMBLOCKS2 8192u /* A/B only: ... 2 blocks per wavefront                                                   */
 #define MC_F_PROGRESS 16384u /* mc_check_files: print TLC's "Progress(d): ..." lines (testout2:4-259) to stdout while the search runs,
                               * at most one per second */
@@ -221,6 +224,20 @@ int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_loca
  * generated, so no counted state may stay unchecked.  A violation shows up in mc_shard_counters' verdict.  No-op for the
  * other specs. */
 int mc_shard_check_frontier(mc_engine *e);
+/* Counterexamples of a sharded run (engines created with MC_F_TRACE): every state records the rank and arena index of its
+ * parent.  A state that stays on the rank that generated it (stay mode, local-owner shortcut, replicated prefix) has a local
+ * parent; a state that MOVES to its owner takes its parent with it: after mc_shard_materialise_slot the sender fills
+ * `send_parents` (one word per moved state, same owner order, (index << 16) | slot), the caller exchanges it like the states,
+ * and the owner calls mc_shard_ingest_parents right after the mc_shard_ingest of the same bucket.
+ * mc_shard_violation: this rank's first violation (arena index, slot code as in the single-GPU engine: 0xffff deadlock,
+ * 0xfffd the state itself violates an invariant, otherwise the slot whose successor does).
+ * mc_shard_fetch: one step of the walk — the packed state at `idx` of this rank, the rank / index of its parent
+ * (0xffffffff: an initial state) and the slot that produced it (0xfffc: this entry is a COPY of state parent_idx made by the
+ * replicated prefix, not a step). */
+int mc_shard_materialise_parents(mc_engine *e, uint32_t slot, uint64_t *send_parents);
+int mc_shard_ingest_parents(mc_engine *e, const uint64_t *recv_parents, uint64_t n, uint32_t src_rank);
+int mc_shard_violation(mc_engine *e, int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant);
+int mc_shard_fetch(mc_engine *e, uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot);
 
 /* ------------------------------------------------------------------ PlusCal front-end (host only)
  * The reference's workflow is `pcal2tla *tla` then `tlc *tla` (Makefile:3-7).  mc_pcal_translate is the first
@@ -245,6 +262,10 @@ uint32_t mc_fp_owner(uint64_t fp, uint32_t shard_count);
 /* canonical TLA+ text of one packed state ("/\ var = value" lines, README.md:272-276) */
 int mc_state_format(const mc_spec_desc *spec, const uint8_t *state, char *buf, size_t cap);
 const char *mc_action_name(const mc_spec_desc *spec, int32_t action);
+/* host evaluation of one (packed state, slot) pair: the action id of the slot (for mc_action_name; negative MC_E* on error)
+ * and the successor it produces — what a host needs to print a counterexample it assembled itself (sharded runs) */
+int mc_state_action(const mc_spec_desc *spec, const uint8_t *state, int32_t slot);
+int mc_state_apply(const mc_spec_desc *spec, const uint8_t *state, int32_t slot, uint8_t *successor_out);
 const char *mc_strerror(int code);
 const char *mc_last_error(void);                                    /* detail of the last failure    */
 int mc_device_count(void);

@@ -75,6 +75,7 @@ enum : unsigned { VK_INVARIANT = 1, VK_ASSERT = 2, VK_DEADLOCK = 3, VK_SPECERR =
 static constexpr unsigned SLOT_NONE = 0xffffu;      // deadlock: no slot
 static constexpr unsigned SLOT_INIT = 0xfffeu;      // an initial state violates an invariant
 static constexpr unsigned SLOT_PARENT = 0xfffdu;    // the expanded state itself violates an invariant
+static constexpr unsigned SLOT_COPY = 0xfffcu;      // sharded runs: this entry is a copy of state parent[i] (replicated prefix -> owned slice)
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     for (int o = 32; o > 0; o >>= 1) { unsigned t = __shfl_xor(v, o); v = t > v ? t : v; }
@@ -526,6 +527,12 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
 // The fingerprints then go through the same probe / route queues as in k_expand_insert.
 constexpr int FQCAP = 128;
 
+// number of leading fixed slots a by-family spec wants evaluated inline, lane = parent (S::DENSE_SLOTS; 0 if absent)
+template <class S, class = void>
+struct DenseSlots : std::integral_constant<int, 0> {};
+template <class S>
+struct DenseSlots<S, decltype((void)S::DENSE_SLOTS)> : std::integral_constant<int, S::DENSE_SLOTS> {};
+
 template <class S, int NB>
 struct FamLds {
     uint16_t fq[S::NFAM][FQCAP];   // (slot << 8) | (block << 6) | parent lane
@@ -544,8 +551,10 @@ __device__ __forceinline__ void family_dispatch(int fam, Fn &&fn) {
 // NB = arena blocks (of 64 parents) one wavefront works through.  The family queues live across the blocks and are
 // drained once at the end, so the partially filled batches of the drain (up to one per family) are paid once per
 // NB * 64 parents instead of once per 64: phase B's lane utilisation goes from ~80 % (NB = 1) towards 95 % (NB = 4).
-template <class S, bool ROUTE, int NB>
-__global__ void __launch_bounds__(256, 4)  // 4 wavefronts per SIMD: at most 128 VGPRs
+// MINW = wavefronts per SIMD the register allocation leaves room for: 4 = at most 128 VGPRs (no spills), 5 = at most 96
+// (a few dozen spilled VGPRs, one more wavefront per SIMD to hide the probe / gather latency behind)
+template <class S, bool ROUTE, int NB, int MINW = 4>
+__global__ void __launch_bounds__(256, MINW)
 k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
                 RouteArgs rt, unsigned parity) {
@@ -666,6 +675,20 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         fset(fcntA, fcntB, f, nc);
         return nc >= 64;
     };
+    // a lane's candidate (fp != 0) joins the probe ring; 64 queued candidates are probed (or routed) at once
+    auto enqueue = [&](uint64_t fp, uint32_t src) {
+        const unsigned long long b = __ballot(fp != 0);
+        if (b) {
+            if (fp) {
+                const unsigned k = (qhead + qn + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
+                Q.q_fp[k] = fp;
+                Q.q_src[k] = src;
+            }
+            qn += (unsigned)__popcll(b);
+            wave_lds_fence();
+            if (qn >= 64) flush_probe(64);
+        }
+    };
     // phase B: evaluate `take` queued pairs of family f (f is wave-uniform)
     auto run_family = [&](int f, unsigned take) {
         const unsigned h = fget(fheadA, fheadB, f);
@@ -696,17 +719,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         }
         fset(fheadA, fheadB, f, (h + take) & (FQCAP - 1));
         fset(fcntA, fcntB, f, fget(fcntA, fcntB, f) - take);
-        const unsigned long long b = __ballot(fp != 0);
-        if (b) {
-            if (fp) {
-                const unsigned k = (qhead + qn + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
-                Q.q_fp[k] = fp;
-                Q.q_src[k] = src;
-            }
-            qn += (unsigned)__popcll(b);
-            wave_lds_fence();
-            if (qn >= 64) flush_probe(64);
-        }
+        enqueue(fp, src);
         wave_lds_fence();
     };
     auto run_full = [&](unsigned fullmask, bool drain) {
@@ -728,8 +741,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         gd.fixed = 0;
         gd.terms = 0;
         int nm = 0;
+        typename S::Local loc;
         if (active) {
-            typename S::Local loc;
             S::load(prm, g, loc);
             nm = loc.nm;
             S::guards(prm, loc, gd);
@@ -742,6 +755,34 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         if (lane < 2) FL.has_succ[blk * 2 + lane] = 0;
         wave_lds_fence();
         const int wnm = (int)wave_max_u32((unsigned)nm);
+        // DENSE slots (raft: Restart(i), Timeout(i) — enabled for nearly every parent, half of all successors): evaluated right
+        // here, lane = parent, the parent's words in this lane's registers and the server index a compile-time constant; no
+        // family queue, no gather.  Only the sparse slots below go through the by-family queues.
+        if constexpr (DenseSlots<S>::value > 0) {
+            if (!(flags & (64u | 32768u))) {  // 32768 = A/B: dense slots through the family queues like the others
+                static_for<0, DenseSlots<S>::value>([&](auto c) __attribute__((always_inline)) {
+                    constexpr int slot = decltype(c)::value;
+                    uint64_t fp = 0;
+                    if (active && ((gd.fixed >> slot) & 1ull)) {
+                        uint64_t f = 0;
+                        const unsigned st = S::eval(prm, loc, g, slot, f);
+                        if (st & ST_ENABLED) {
+                            ++gen;
+                            if (flags & MC_F_DEADLOCK) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
+                            if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
+                            else if (st & ST_ASSERT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_ASSERT, 0));
+                            else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, (unsigned)slot, VK_SPECERR, 0));
+                            else {
+                                if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_INVARIANT, st >> 8));
+                                if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = f;
+                            }
+                        }
+                    }
+                    enqueue(fp, (uint32_t)(wave_col0 + pl) | ((uint32_t)slot << 24));
+                });
+                gd.fixed &= ~((1ull << DenseSlots<S>::value) - 1ull);
+            }
+        }
         // one loop over "steps": fixed slots, then (message, kind) slots; the drain of every queue follows the last block
         const int nsteps = (flags & 64u) ? 0 : S::FIX + 3 * wnm;  // 64 = ablation: load the parents only
         for (int step = 0; step < nsteps; ++step) {
@@ -1015,6 +1056,7 @@ static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStr
             const int nb = ROUTE ? 1 : family_blocks(flags);
             const dim3 grid((unsigned)((ncols + 256ull * nb - 1) / (256ull * nb)));
             if constexpr (!ROUTE) {
+                if (nb == 1 && (flags & 2048u)) { hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1, 5>), grid, dim3(256), 0, stream, args...); return; }
                 if (nb == 4) { hipLaunchKernelGGL((k_expand_family<S, ROUTE, 4>), grid, dim3(256), 0, stream, args...); return; }
                 if (nb == 2) { hipLaunchKernelGGL((k_expand_family<S, ROUTE, 2>), grid, dim3(256), 0, stream, args...); return; }
             }
@@ -1195,6 +1237,33 @@ k_ingest(uint64_t *arena, int words, const uint64_t *__restrict__ recv_blocks, u
     for (int w = 0; w < words; w++) o.set(w, src[(uint64_t)w * 64]);
     if (parent) parent[oidx] = 0xfffffffeu;  // produced on another rank: no local parent
 }
+// Counterexamples across ranks: a state that MOVES to its owner takes (index of its parent on the sending rank, slot) with it.
+// sender side: per moved state, in the order of the state blocks (owner by owner), parent = chunk_base + column
+static __global__ void __launch_bounds__(256)
+k_send_parents(const uint32_t *__restrict__ new_src, uint64_t chunk_base, OwnerOffsets offs, BlockPlan plan, unsigned nranks,
+               uint64_t *__restrict__ send_parents) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t before = 0;
+    for (unsigned t = 0; t < nranks; ++t) {
+        if (g < before + plan.cnt[t]) {
+            const uint32_t src = new_src[offs.off[t] + (g - before)];
+            send_parents[g] = ((chunk_base + (src & 0xffffffu)) << 16) | (uint64_t)(src >> 24);
+            return;
+        }
+        before += plan.cnt[t];
+    }
+}
+// owner side: the n states ingested last (arena_next - n ...) get their remote parent
+static __global__ void __launch_bounds__(256)
+k_ingest_parents(const uint64_t *__restrict__ recv_parents, uint64_t n, unsigned src_rank, uint32_t *__restrict__ parent,
+                 uint16_t *__restrict__ pslot, uint8_t *__restrict__ prank, const DevCounters *ctr) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t oidx = ctr->arena_next - n + j;
+    parent[oidx] = (uint32_t)(recv_parents[j] >> 16);
+    pslot[oidx] = (uint16_t)(recv_parents[j] & 0xffffu);
+    prank[oidx] = (uint8_t)src_rank;
+}
 // runs alone on its stream after the kernel that appended: arena_next += n (n on the device when n_dev != null)
 static __global__ void k_bump_arena_next(DevCounters *ctr, const uint32_t *n_dev, unsigned long long n, unsigned long long arena_cap) {
     const unsigned long long v = ctr->arena_next + (n_dev ? (unsigned long long)*n_dev : n);
@@ -1213,7 +1282,7 @@ static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
 template <class S>
 __global__ void __launch_bounds__(256)
 k_take_owned(typename S::Params prm, uint64_t *arena, uint64_t lo, uint64_t hi, unsigned rank, unsigned nranks, uint64_t dst0,
-             uint64_t arena_cap, uint32_t *__restrict__ parent, DevCounters *ctr) {
+             uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot, DevCounters *ctr) {
     const uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
     const int W = S::words(prm);
@@ -1223,7 +1292,7 @@ k_take_owned(typename S::Params prm, uint64_t *arena, uint64_t lo, uint64_t hi, 
     if (dst >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); return; }
     const WordRef out = arena_ref(arena, dst, W);
     for (int w = 0; w < W; w++) out.set(w, in.get(w));
-    if (parent) parent[dst] = (uint32_t)i;
+    if (parent) { parent[dst] = (uint32_t)i; pslot[dst] = (uint16_t)SLOT_COPY; }
 }
 static __global__ void k_after_prefix(DevCounters *ctr, unsigned long long dst0, int zero_counts) {
     ctr->arena_next = dst0 + ctr->n_new[0].v;
@@ -1309,6 +1378,10 @@ struct EngineBase {
     virtual int shard_end_level(uint64_t *new_local) = 0;
     virtual int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
     virtual int shard_check_frontier() = 0;
+    virtual int shard_materialise_parents(unsigned slot, uint64_t *send_parents) = 0;
+    virtual int shard_ingest_parents(const uint64_t *recv_parents, uint64_t n, unsigned src_rank) = 0;
+    virtual int shard_violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant) = 0;
+    virtual int shard_fetch(uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) = 0;
 };
 
 static uint64_t round_pow2(uint64_t v) {
@@ -1357,6 +1430,7 @@ struct Engine : EngineBase {
     uint16_t *d_nsl = nullptr, *d_pslot = nullptr;
     uint64_t *d_inittmp = nullptr;
     uint32_t *d_parent = nullptr;
+    uint8_t *d_prank = nullptr;  // sharded runs with MC_F_TRACE: rank a state's parent lives on (0xff = this rank)
     DevCounters *d_ctr = nullptr, *h_ctr = nullptr;
     LevelCtl *d_lc = nullptr, *h_lc = nullptr;
     uint64_t table_cap = 0, arena_cap = 0, chunk = 0, row_stride = 0, seg_cap = 0;
@@ -1407,6 +1481,10 @@ struct Engine : EngineBase {
         if (cfg.flags & MC_F_TRACE) {
             HIP_TRY(hipMalloc(&d_parent, arena_cap * sizeof(uint32_t)));
             HIP_TRY(hipMalloc(&d_pslot, arena_cap * sizeof(uint16_t)));
+            if (cfg.shard_count > 1) {
+                HIP_TRY(hipMalloc(&d_prank, arena_cap));
+                HIP_TRY(hipMemset(d_prank, 0xff, arena_cap));
+            }
         }
         HIP_TRY(hipMalloc(&d_ctr, sizeof(DevCounters)));
         HIP_TRY(hipHostMalloc(&h_ctr, sizeof(DevCounters)));
@@ -1436,6 +1514,7 @@ struct Engine : EngineBase {
         if (d_scan_tmp) hipFree(d_scan_tmp);
         if (d_parent) hipFree(d_parent);
         if (d_pslot) hipFree(d_pslot);
+        if (d_prank) hipFree(d_prank);
         if (d_ctr) hipFree(d_ctr);
         if (h_ctr) hipHostFree(h_ctr);
         if (d_lc) hipFree(d_lc);
@@ -1937,6 +2016,8 @@ struct Engine : EngineBase {
         uint32_t *rt_src = nullptr, *pend_src = nullptr;
         PaddedCounter *rt_cur = nullptr;  // [nranks*NSHARD] route cursors
         uint64_t rt_subcap = 0, pend_cap = 0, pend_total = 0, chunk_base = 0, count = 0, ncols = 0;
+        BlockPlan plan;          // of the slot's last shard_materialise (for shard_materialise_parents)
+        uint64_t moved = 0;
         OwnerOffsets pend_off;
         bool launched = false, keep_pending = false;
     } sl[2];
@@ -2038,7 +2119,7 @@ struct Engine : EngineBase {
         const bool go_on = h_ctr->viol_key == ~0ull && hi > lo;  // otherwise finished or failed inside the prefix
         if (go_on)
             hipLaunchKernelGGL(k_take_owned<S>, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, stream, prm, d_arena, lo, hi, r, P, hi,
-                               arena_cap, d_parent, d_ctr);
+                               arena_cap, d_parent, d_pslot, d_ctr);
         hipLaunchKernelGGL(k_after_prefix, dim3(1), dim3(1), 0, stream, d_ctr, (unsigned long long)hi, r != 0 ? 1 : 0);
         int rc2 = read_counters();
         if (rc2) return rc2;
@@ -2172,6 +2253,7 @@ struct Engine : EngineBase {
         ShSlot &q = sl[slot];
         const unsigned P = nranks();
         for (unsigned t = 0; t < P; t++) send_counts[t] = 0;
+        q.moved = 0;
         if (!q.pend_total) return MC_OK;
         const unsigned bx = (unsigned)((q.pend_total + 255) / 256);
         int rc = scan_answers(answers_back, q.pend_total, side());
@@ -2198,6 +2280,9 @@ struct Engine : EngineBase {
         }
         plan.blk_off[8] = blocks;
         for (unsigned t = P; t < 8; t++) plan.blk_off[t] = blocks;
+        q.plan = plan;
+        q.moved = 0;
+        for (unsigned t = 0; t < P; t++) q.moved += plan.cnt[t];
         if (blocks * 64 > send_cap) { set_error("shard_materialise: state send buffer too small"); return MC_EARENA; }
         if (blocks) {
             timed(2, blocks * 64, [&] {
@@ -2261,6 +2346,63 @@ struct Engine : EngineBase {
                            (unsigned long long)arena_cap);
         append_end(side());
         return side_done();
+    }
+    // (parent index on this rank << 16 | slot) of the states the slot's last shard_materialise put into its send buffer, same
+    // order (owner by owner, without the block padding); call it before the next shard_materialise / shard_keep of any slot
+    int shard_materialise_parents(unsigned slot, uint64_t *send_parents) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (slot > 1) return MC_EBADCFG;
+        ShSlot &q = sl[slot];
+        if (!q.moved) return MC_OK;
+        hipLaunchKernelGGL(k_send_parents, dim3((unsigned)((q.moved + 255) / 256)), dim3(256), 0, side(), (const uint32_t *)d_new_src, q.chunk_base,
+                           q.pend_off, q.plan, nranks(), send_parents);
+        return side_done();
+    }
+    // right after the shard_ingest of the same bucket: the n states just appended came from `src_rank`
+    int shard_ingest_parents(const uint64_t *recv_parents, uint64_t n, unsigned src_rank) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (!n || !d_prank) return MC_OK;  // without MC_F_TRACE nothing is recorded
+        hipLaunchKernelGGL(k_ingest_parents, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, side(), recv_parents, n, src_rank, d_parent, d_pslot,
+                           d_prank, (const DevCounters *)d_ctr);
+        return side_done();
+    }
+    int shard_violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipStreamSynchronize(side()));
+        int rc = read_counters();
+        if (rc) return rc;
+        *found = h_ctr->viol_key != ~0ull;
+        *idx = 0; *slot = 0; *verdict = MC_V_OK; *invariant = -1;
+        if (*found) {
+            const unsigned long long k = h_ctr->viol_key;
+            const unsigned kind = (unsigned)(k & 7u);
+            *idx = k >> 24;
+            *slot = (uint32_t)(k >> 8 & 0xffffu);
+            *verdict = kind == VK_INVARIANT ? MC_V_INVARIANT : kind == VK_ASSERT ? MC_V_ASSERT : kind == VK_DEADLOCK ? MC_V_DEADLOCK : MC_V_SPECERR;
+            if (kind == VK_INVARIANT) *invariant = (int32_t)(k >> 3 & 31u);
+        }
+        return MC_OK;
+    }
+    // one step of a counterexample walk: the state at arena index idx of THIS rank and where its parent lives
+    // (parent_rank == shard_rank: here; parent_idx == 0xffffffff: an initial state; parent_slot 0xfffc: the entry is a copy
+    // of state parent_idx made by the replicated prefix, not a step)
+    int shard_fetch(uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (!d_parent) { set_error("engine created without MC_F_TRACE"); return MC_ESTATE; }
+        if (idx >= arena_cap) return MC_EBADCFG;
+        HIP_TRY(hipDeviceSynchronize());
+        int rc = fetch_state(idx, (uint64_t *)state_out);
+        if (rc) return rc;
+        uint32_t p = 0;
+        uint16_t ps = 0;
+        uint8_t pr = 0xff;
+        HIP_TRY(hipMemcpy(&p, d_parent + idx, sizeof p, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&ps, d_pslot + idx, sizeof ps, hipMemcpyDeviceToHost));
+        if (d_prank) HIP_TRY(hipMemcpy(&pr, d_prank + idx, sizeof pr, hipMemcpyDeviceToHost));
+        *parent_rank = pr == 0xff ? cfg.shard_rank : pr;
+        *parent_idx = p;
+        *parent_slot = ps;
+        return MC_OK;
     }
     int shard_end_level(uint64_t *new_local) override {
         HIP_TRY(hipSetDevice(cfg.device));
@@ -2498,6 +2640,30 @@ int mc_state_format(const mc_spec_desc *spec, const uint8_t *state, char *buf, s
     });
     return rc ? rc : n;
 }
+// host-side evaluation of one (state, slot) pair: the action it is (mc_action_name's argument) and its successor
+int mc_state_action(const mc_spec_desc *spec, const uint8_t *state, int32_t slot) {
+    if (!state) return MC_EBADCFG;
+    int a = -1;
+    int rc = dispatch_spec(spec, [&](auto s, const auto &prm) {
+        using S = decltype(s);
+        uint64_t w[S::MAX_WORDS];
+        memcpy(w, state, sizeof(uint64_t) * S::words(prm));
+        a = S::action_of(prm, w, (int)slot);
+        return 0;
+    });
+    return rc ? rc : a;
+}
+int mc_state_apply(const mc_spec_desc *spec, const uint8_t *state, int32_t slot, uint8_t *successor_out) {
+    if (!state || !successor_out) return MC_EBADCFG;
+    return dispatch_spec(spec, [&](auto s, const auto &prm) {
+        using S = decltype(s);
+        uint64_t w[S::MAX_WORDS], o[S::MAX_WORDS];
+        memcpy(w, state, sizeof(uint64_t) * S::words(prm));
+        S::apply(prm, CWordRef{w, 1}, (int)slot, WordRef{o, 1});
+        memcpy(successor_out, o, sizeof(uint64_t) * S::words(prm));
+        return 0;
+    });
+}
 const char *mc_action_name(const mc_spec_desc *spec, int32_t action) {
     const char *nm = "?";
     dispatch_spec(spec, [&](auto s, const auto &prm) {
@@ -2566,6 +2732,16 @@ int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_loca
     return e && generated && distinct_local && verdict ? e->impl->shard_counters(generated, distinct_local, verdict) : MC_EBADCFG;
 }
 int mc_shard_check_frontier(mc_engine *e) { return e ? e->impl->shard_check_frontier() : MC_EBADCFG; }
+int mc_shard_materialise_parents(mc_engine *e, uint32_t slot, uint64_t *send_parents) { return e ? e->impl->shard_materialise_parents(slot, send_parents) : MC_EBADCFG; }
+int mc_shard_ingest_parents(mc_engine *e, const uint64_t *recv_parents, uint64_t n, uint32_t src_rank) {
+    return e ? e->impl->shard_ingest_parents(recv_parents, n, src_rank) : MC_EBADCFG;
+}
+int mc_shard_violation(mc_engine *e, int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant) {
+    return e && found && idx && slot && verdict && invariant ? e->impl->shard_violation(found, idx, slot, verdict, invariant) : MC_EBADCFG;
+}
+int mc_shard_fetch(mc_engine *e, uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) {
+    return e && state_out && parent_rank && parent_idx && parent_slot ? e->impl->shard_fetch(idx, state_out, parent_rank, parent_idx, parent_slot) : MC_EBADCFG;
+}
 
 }  // extern "C"
 #endif  // MC_TU == 0 || MC_TU == -1

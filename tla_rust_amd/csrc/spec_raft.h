@@ -106,6 +106,8 @@ struct SpecRaft {
     //        AdvanceCommitIndex NS | AppendEntries NS^2 | per message k: Receive, Duplicate, Drop
     static constexpr int FIX = 5 * NS + 2 * NS * NS;
     static constexpr int FIX_SLOTS = FIX;  // slots whose action and server indices are compile-time constants
+    static constexpr int DENSE_SLOTS = 2 * NS;  // Restart(i), Timeout(i): enabled for (nearly) every state — the by-family kernel
+                                                // evaluates them inline, lane = parent (engine.hip k_expand_family)
     static constexpr int STAGE_WORDS = 16; // message slots of each parent the expand kernel stages in LDS
     template <class Ref>
     MC_HD static void stage_range(const Params &, Ref s, int &lo, int &n) { lo = W_MSG0; n = g_nm(s.get(W_GLOB)); }
