@@ -155,6 +155,32 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
     }
 };
 
+// dense slot pairs (S::eval_dense: two slots of one server evaluated together with shared hash terms) must give
+// exactly what the generic evaluation of the two slots gives
+template <class S, class = void>
+struct DenseCheck {
+    template <class Ref>
+    static uint64_t mismatches(const typename S::Params &, typename S::Local &, Ref) { return 0; }
+};
+template <class S>
+struct DenseCheck<S, decltype((void)S::DENSE_PAIRS)> {
+    template <class Ref>
+    static uint64_t mismatches(const typename S::Params &p, typename S::Local &l, Ref s) {
+        uint64_t bad = 0;
+        for (int i = 0; i < S::DENSE_PAIRS; i++) {
+            unsigned st[2] = {0, 0};
+            uint64_t fp[2] = {0, 0};
+            S::eval_dense(p, l, s, i, st[0], fp[0], st[1], fp[1]);
+            for (int h = 0; h < 2; h++) {
+                uint64_t f0 = 0;
+                const unsigned st0 = S::eval(p, l, s, S::dense_slot(i, h), f0);
+                if (st0 != st[h] || ((st0 & ST_ENABLED) && f0 != fp[h])) bad++;
+            }
+        }
+        return bad;
+    }
+};
+
 template <class S, class = void>
 struct FpCheck {
     static bool ok(const typename S::Params &, const uint64_t *) { return true; }
@@ -217,6 +243,7 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
             const unsigned ps = S::parent_status(prm, loc, s);
             if (ps & ST_INVARIANT) violation(ps, level);
             r->fp_mismatch += FamCheck<S>::mismatches(prm, loc, s, ns);
+            r->fp_mismatch += DenseCheck<S>::mismatches(prm, loc, s);
             uint64_t nsucc = 0;
             for (int slot = 0; slot < ns; slot++) {
                 uint64_t fp = 0;
@@ -268,6 +295,10 @@ extern "C" int shim_run(const mc_spec_desc *d, uint64_t max_levels, uint64_t max
 // PlusCal front-end on the host (pcal.cpp / pcal_compile.cpp are linked into the shim): translate, compile,
 // and describe a program so that shim_run / the shard emulation execute it like any other lowering.
 static std::string g_pcal_error;
+// the per-element hash of the additive fingerprints (mc_common.h), for tests/test_hash_quality.py
+extern "C" void shim_hmum(const uint64_t *x, uint64_t n, uint64_t salt, uint64_t *out) {
+    for (uint64_t i = 0; i < n; i++) out[i] = hmum(x[i], salt);
+}
 extern "C" const char *shim_pcal_error() { return g_pcal_error.c_str(); }
 extern "C" int shim_pcal_translate(const char *tla_text, char *out, size_t cap) {
     pcal::Module m;

@@ -137,10 +137,20 @@ def build_shim():
     csrc = ROOT / "tla_rust_amd" / "csrc"
     pcal = [csrc / "pcal.cpp", csrc / "pcal_compile.cpp"]  # the PlusCal front-end is host code: linked as is
     srcs = [SHIM_DIR / "shim.cpp"] + pcal + list(csrc.glob("*.h")) + [ROOT / "include" / "tlamc.h"]
-    if so.exists() and all(so.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+    def fresh():
+        return so.exists() and all(so.stat().st_mtime >= s.stat().st_mtime for s in srcs)
+    if fresh():
         return so
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(SHIM_DIR / "shim.cpp")] + [str(x) for x in pcal],
-                   check=True)
+    # several ranks of a multi-process test may arrive here together: one builds (into a temporary name, renamed when
+    # complete), the others wait for the lock and find the library fresh
+    import fcntl
+    with open(out / ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not fresh():
+            tmp = out / f"libshim.{os.getpid()}.so"
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(tmp), str(SHIM_DIR / "shim.cpp")] + [str(x) for x in pcal],
+                           check=True)
+            os.replace(tmp, so)
     return so
 
 

@@ -760,43 +760,50 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         // family queue, no gather.  Only the sparse slots below go through the by-family queues.
         if constexpr (DenseSlots<S>::value > 0) {
             if (!(flags & (64u | 32768u))) {  // 32768 = A/B: dense slots through the family queues like the others
-                static_for<0, DenseSlots<S>::value>([&](auto c) __attribute__((always_inline)) {
-                    constexpr int slot = decltype(c)::value;
-                    uint64_t fp = 0;
-                    if (active && ((gd.fixed >> slot) & 1ull)) {
-                        uint64_t f = 0;
-                        const unsigned st = S::eval(prm, loc, g, slot, f);
+                // S::eval_dense(i): the two dense slots of server i together (shared hash terms).  The loops are NOT unrolled: the
+                // server index is wave-uniform (scalar registers), and the probe / flush code below exists twice, not 2 * NS times.
+#pragma clang loop unroll(disable)
+                for (int i = 0; i < S::DENSE_PAIRS; ++i) {
+                    unsigned st2[2] = {0u, 0u};
+                    uint64_t f2[2] = {0ull, 0ull};
+                    if (active) S::eval_dense(prm, loc, g, i, st2[0], f2[0], st2[1], f2[1]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned st = st2[h];
+                        const unsigned slot = (unsigned)S::dense_slot(i, h);
+                        uint64_t fp = 0;
                         if (st & ST_ENABLED) {
                             ++gen;
                             if (flags & MC_F_DEADLOCK) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
                             if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
-                            else if (st & ST_ASSERT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_ASSERT, 0));
-                            else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, (unsigned)slot, VK_SPECERR, 0));
+                            else if (st & ST_ASSERT) viol = min(viol, viol_key(idx, slot, VK_ASSERT, 0));
+                            else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, slot, VK_SPECERR, 0));
                             else {
-                                if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_INVARIANT, st >> 8));
-                                if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = f;
+                                if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, slot, VK_INVARIANT, st >> 8));
+                                if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = f2[h];
                             }
                         }
+                        enqueue(fp, (uint32_t)(wave_col0 + pl) | (slot << 24));
                     }
-                    enqueue(fp, (uint32_t)(wave_col0 + pl) | ((uint32_t)slot << 24));
-                });
+                }
                 gd.fixed &= ~((1ull << DenseSlots<S>::value) - 1ull);
             }
         }
-        // one loop over "steps": fixed slots, then (message, kind) slots; the drain of every queue follows the last block
-        const int nsteps = (flags & 64u) ? 0 : S::FIX + 3 * wnm;  // 64 = ablation: load the parents only
-        for (int step = 0; step < nsteps; ++step) {
-            unsigned fullmask = 0;
-            const unsigned entry = ((unsigned)step << 8) | pl;
-            if (step < S::FIX) {
-                const int f = S::fixed_family(step);
-                const bool en = (gd.fixed >> step) & 1ull;
-                const unsigned long long b = __ballot(en);
-                if (b && fam_push(f, b, en, entry)) fullmask = 1u << f;
-            } else {
-                const int q = step - S::FIX, k = q / 3, kind = q % 3;
-                int fam = -1;
-                if (k < nm) fam = S::guard_msg(gd, g.get(S::W_MSG0 + k), kind);
+        // the fixed slots, then per message slot the three kinds (Receive, Duplicate, Drop) on ONE load of the message word;
+        // the drain of every queue follows the last block.  (flag 64 = ablation: load the parents only)
+        for (int step = 0; step < ((flags & 64u) ? 0 : S::FIX); ++step) {
+            const int f = S::fixed_family(step);
+            const bool en = (gd.fixed >> step) & 1ull;
+            const unsigned long long b = __ballot(en);
+            if (b && fam_push(f, b, en, ((unsigned)step << 8) | pl)) run_full(1u << f, false);
+        }
+        for (int k = 0; k < ((flags & 64u) ? 0 : wnm); ++k) {
+            const uint64_t mword = k < nm ? g.get(S::W_MSG0 + k) : 0;
+#pragma clang loop unroll(disable)
+            for (int kind = 0; kind < 3; ++kind) {
+                unsigned fullmask = 0;
+                const unsigned entry = ((unsigned)(S::FIX + 3 * k + kind) << 8) | pl;
+                const int fam = k < nm ? S::guard_msg(gd, mword, kind) : -1;
                 if (kind == 0) {  // Receive: the family depends on the message (UpdateTerm or one of the four handlers)
 #pragma unroll
                     for (int f = S::F_UPDTERM; f <= S::F_AERESP; ++f) {
@@ -807,8 +814,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                     const unsigned long long b = __ballot(fam >= 0);
                     if (b && fam_push(S::F_DUPDROP, b, fam >= 0, entry)) fullmask |= 1u << S::F_DUPDROP;
                 }
+                run_full(fullmask, false);
             }
-            run_full(fullmask, false);
         }
     }
     {
@@ -1046,21 +1053,14 @@ struct UsesFamilies : std::false_type {};
 template <class S>
 struct UsesFamilies<S, decltype((void)S::NFAM)> : std::true_type {};
 
-// blocks per wavefront of the by-family kernel (see k_expand_family): run-time choice among the compiled instances
-static int family_blocks(unsigned flags) { return (flags & 4096u) ? 4 : (flags & 8192u) ? 2 : 1; }
-
+// (several arena blocks per wavefront, NB = 2 / 4, and a 5-waves-per-SIMD register budget were measured slower in round 2 —
+// DESIGN.md §5 — and are no longer compiled)
 template <class S, bool ROUTE, class... A>
 static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStream_t stream, A... args) {
+    (void)flags;
     if constexpr (UsesFamilies<S>::value) {
         if (by_family) {
-            const int nb = ROUTE ? 1 : family_blocks(flags);
-            const dim3 grid((unsigned)((ncols + 256ull * nb - 1) / (256ull * nb)));
-            if constexpr (!ROUTE) {
-                if (nb == 1 && (flags & 2048u)) { hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1, 5>), grid, dim3(256), 0, stream, args...); return; }
-                if (nb == 4) { hipLaunchKernelGGL((k_expand_family<S, ROUTE, 4>), grid, dim3(256), 0, stream, args...); return; }
-                if (nb == 2) { hipLaunchKernelGGL((k_expand_family<S, ROUTE, 2>), grid, dim3(256), 0, stream, args...); return; }
-            }
-            hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1>), grid, dim3(256), 0, stream, args...);
+            hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, args...);
             return;
         }
     }

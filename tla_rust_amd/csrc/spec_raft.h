@@ -4,10 +4,16 @@
 // Packed state = WORDS 64-bit words (layout below).  The three set-valued history variables
 // (messages with its monotone key set, elections, allLogs) are kept as UNORDERED slot arrays:
 // equality of TLA+ values is decided by an additive (multiset) fingerprint
-//     fp = sum_w H(header word w, salt_w) + sum_m H(msg word, SALT_M) + sum_e He(e) + sum_l H(log, SALT_A)
+//     fp = sum_w Hw(header word w) + sum_m (count(m) + 1) * H(key(m), SALT_M) + sum_e He(e) + sum_l H(log, SALT_A)
 // which does not depend on slot order, so a successor is "parent with <= 2 message slots
 // changed, <= 1 election appended, <= NS logs appended, one server's words and the globals
 // rewritten" and its fingerprint is the parent's plus the differences — O(delta), not O(W).
+// Chosen so that the common deltas cost ONE hash each (H = hmum, mc_common.h):
+//   * the bag is a multiset: a message contributes (count + 1) * H(key) — the "+ 1" because a key whose count fell to 0
+//     stays in the bag (note 1 below) — so Send / Discard / Duplicate / Drop change the sum by +-H(key) (a new key: 2 H(key));
+//   * of the globals word only clientRequests and committedLogDecrease are hashed: the slot counts nMsgs / nElec / nAll are
+//     functions of the three sets, which are hashed element by element;
+//   * an empty voterLog entry contributes 0 (Restart / Timeout clear them, a vote sets one).
 //
 // Semantic notes that change counts — all kept:
 //  0. raft.tla:392-393 vs :402/:75: the "already done" branch is enabled only when
@@ -168,11 +174,24 @@ struct SpecRaft {
     }
     // election word 0: eterm[0,3) eleader[3,6) evotes[6,11) elog[11,44); words 1..NS: evoterLog[j]
     MC_HD static uint64_t helec(const RegArr<1 + NS> &ew) {
-        uint64_t h = hmix(ew.get(0), SALT_E);
+        uint64_t h = hmum(ew.get(0), SALT_E);
 #pragma unroll
-        for (int q = 1; q <= NS; q++) h = hmix(ew.get(q) + h, SALT_E + (uint64_t)q);
+        for (int q = 1; q <= NS; q++) h = hmum(ew.get(q) + h, SALT_E + (uint64_t)q);
         return h;
     }
+
+    // contribution of header word w holding x
+    static constexpr uint64_t GLOB_HASHED = 0xffull;  // clientRequests[0,3) decrease[3]
+    MC_HD static constexpr bool is_vlog_word(int w) { return w >= W_SRV(0) && w < W_MSG0 && (w - W_SRV(0)) % SRV_WORDS >= 2; }
+    MC_HD static uint64_t hvlog(uint64_t x, int i, int j) { return x ? hmum(x, salt_of((unsigned)W_VLOG(i, j))) : 0ull; }
+    MC_HD static uint64_t hword(int w, uint64_t x) {
+        if (w == W_GLOB) x &= GLOB_HASHED;
+        if (is_vlog_word(w) && x == 0) return 0;
+        return hmum(x, salt_of((unsigned)w));
+    }
+    // contribution of one message slot: (count + 1) * H(key)
+    MC_HD static uint64_t hkey(uint64_t mword) { return hmum(mword >> 2, SALT_M); }
+    MC_HD static uint64_t hmsg(uint64_t mword) { return hkey(mword) * (uint64_t)(m_count(mword) + 1); }
 
     static int make_params(const int64_t *p, unsigned np, Params &o) {
         if (np < 5) return -1;
@@ -199,7 +218,7 @@ struct SpecRaft {
         uint64_t fp = 0;
         for (int i = 0; i < NS; i++) out.set(W_SRV(i), sv);
         out.set(W_GLOB, 1);  // clientRequests = 1
-        for (int w = 1; w < HDR_WORDS; w++) fp += hmix(out.get(w), salt_of((unsigned)w));
+        for (int w = 1; w < HDR_WORDS; w++) fp += hword(w, out.get(w));
         out.set(W_FP, fp);
     }
     template <class Ref>
@@ -208,30 +227,53 @@ struct SpecRaft {
     template <class Ref>
     MC_HD static uint64_t fp_recompute(const Params &prm, Ref s) {
         uint64_t fp = 0;
-        for (int w = 1; w < HDR_WORDS; w++) fp += hmix(s.get(w), salt_of((unsigned)w));
+        for (int w = 1; w < HDR_WORDS; w++) fp += hword(w, s.get(w));
         const uint64_t g = s.get(W_GLOB);
-        for (int k = 0; k < g_nm(g); k++) fp += hmix(s.get(W_MSG0 + k), SALT_M);
+        for (int k = 0; k < g_nm(g); k++) fp += hmsg(s.get(W_MSG0 + k));
         for (int e = 0; e < g_ne(g); e++) {
             RegArr<EL_WORDS> ew;
 #pragma unroll
             for (int q = 0; q < EL_WORDS; q++) ew.set(q, s.get(W_EL0(prm) + e * EL_WORDS + q));
             fp += helec(ew);
         }
-        for (int a = 0; a < g_na(g); a++) fp += hmix(s.get(W_ALL0(prm) + a), SALT_A);
+        for (int a = 0; a < g_na(g); a++) fp += hmum(s.get(W_ALL0(prm) + a), SALT_A);
         return fp;
     }
     template <class Ref>
     MC_HD static unsigned init_status(const Params &, Ref) { return ST_ENABLED; }
 
-    // 5-bit bucket of a message key, for the per-parent presence filter that lets Send skip its scan
-    MC_HD static unsigned key_bucket(uint64_t word) { return (unsigned)(((word >> 2) * 0x9e3779b97f4a7c15ull) >> 59); }
+    // Per-parent SIGNATURES of the message keys: one byte per message slot k < SIG_SLOTS (7 bits folded from the key; 0x80 =
+    // no message in the slot), slot k in byte k & 3 of word k >> 2.  Send(m) must find m's slot in the bag: comparing the 16
+    // bytes at once (SWAR) names the candidate slot, and ONE load verifies it — instead of a scan of the whole bag, whose
+    // loads the evaluating lane had to take one after the other from L2 (up to MaxMsgKeys round trips per batch of pairs).
+    static constexpr int SIG_SLOTS = 16;
+    static constexpr uint32_t SIG_EMPTY = 0x80808080u;
+    struct Sigs { uint32_t w0, w1, w2, w3; };  // plain data: it lives in LDS (Summary)
+    MC_HD static Sigs sigs_empty() { return Sigs{SIG_EMPTY, SIG_EMPTY, SIG_EMPTY, SIG_EMPTY}; }
+    MC_HD static uint32_t key_sig(uint64_t word) {
+        uint32_t h = (uint32_t)(word >> 2) ^ (uint32_t)(word >> 34);
+        h ^= h >> 16;
+        return (h ^ (h >> 7) ^ (h >> 14)) & 0x7fu;
+    }
+    // bit 8 * j + h set: byte j of word h equals sg, i.e. slot 4 * h + j is a candidate
+    MC_HD static uint32_t sig_match(const Sigs &g, uint32_t sg) {
+        uint32_t v = sg | (sg << 8);
+        v |= v << 16;
+        uint32_t m = 0, t, y;
+        t = g.w0 ^ v; y = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t; m |= (~y & 0x80808080u) >> 7;
+        t = g.w1 ^ v; y = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t; m |= (~y & 0x80808080u) >> 6;
+        t = g.w2 ^ v; y = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t; m |= (~y & 0x80808080u) >> 5;
+        t = g.w3 ^ v; y = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t; m |= (~y & 0x80808080u) >> 4;
+        return m;
+    }
+    MC_HD static int sig_slot_of_bit(int b) { return ((b & 7) << 2) | (b >> 3); }
 
     // ---------------------------------------------------------------- per-parent cache
     struct Local {
         uint64_t fp, glob, clog;
         RegArr<NS> sv, log;
         int nm, inflight;
-        uint32_t mfilter;      // bit key_bucket(m) set for every message key in the bag: a clear bit proves "not present"
+        Sigs sig;              // signatures of the message keys (slots < SIG_SLOTS)
         unsigned addmask;      // servers whose log is not yet in allLogs (raft.tla:493), first occurrence only
         int nadd;              // popcount(addmask)
         uint64_t add_fp;       // sum of their contributions
@@ -250,20 +292,35 @@ struct SpecRaft {
         for (int i = 0; i < NS; i++) { l.sv.set(i, s.get(W_SRV(i))); l.log.set(i, s.get(W_LOG(i))); }
         l.nm = g_nm(l.glob);
         l.inflight = 0;
-        l.mfilter = 0;
-        for (int k = 0; k < l.nm; k++) {
-            const uint64_t x = s.get(W_MSG0 + k);
-            l.inflight += m_count(x);
-            l.mfilter |= 1u << key_bucket(x);
+        l.sig = sigs_empty();
+        // four slots per round: the four loads are in flight together (a slot index is clamped into the bag, never past it)
+        for (int k0 = 0; k0 < l.nm; k0 += 4) {
+            const bool v1 = k0 + 1 < l.nm, v2 = k0 + 2 < l.nm, v3 = k0 + 3 < l.nm;
+            const uint64_t x0 = s.get(W_MSG0 + k0), x1 = s.get(W_MSG0 + (v1 ? k0 + 1 : k0)), x2 = s.get(W_MSG0 + (v2 ? k0 + 2 : k0)),
+                           x3 = s.get(W_MSG0 + (v3 ? k0 + 3 : k0));
+            l.inflight += m_count(x0) + (v1 ? m_count(x1) : 0) + (v2 ? m_count(x2) : 0) + (v3 ? m_count(x3) : 0);
+            uint32_t w = key_sig(x0) | 0x80808000u;
+            if (k0 + 1 < l.nm) w = (w & ~0x0000ff00u) | (key_sig(x1) << 8);
+            if (k0 + 2 < l.nm) w = (w & ~0x00ff0000u) | (key_sig(x2) << 16);
+            if (k0 + 3 < l.nm) w = (w & ~0xff000000u) | (key_sig(x3) << 24);
+            if (k0 == 0) l.sig.w0 = w;
+            if (k0 == 4) l.sig.w1 = w;
+            if (k0 == 8) l.sig.w2 = w;
+            if (k0 == 12) l.sig.w3 = w;
         }
         // allLogs' = allLogs \cup {log[i] : i \in Server} — the same for every successor of this state
         unsigned present = 0;
         const int na = g_na(l.glob);
         const int wall = W_ALL0(prm);
-        for (int a = 0; a < na; a++) {
-            const uint64_t x = s.get(wall + a);
+        for (int a0 = 0; a0 < na; a0 += 4) {
+            // (an index past the set is clamped to a0: the comparison sees y0 twice, which changes nothing)
+            const uint64_t y0 = s.get(wall + a0), y1 = s.get(wall + (a0 + 1 < na ? a0 + 1 : a0)),
+                           y2 = s.get(wall + (a0 + 2 < na ? a0 + 2 : a0)), y3 = s.get(wall + (a0 + 3 < na ? a0 + 3 : a0));
 #pragma unroll
-            for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
+            for (int i = 0; i < NS; i++) {
+                const uint64_t lg = l.log.get(i);
+                if (y0 == lg || y1 == lg || y2 == lg || y3 == lg) present |= 1u << i;
+            }
         }
         l.cache_k = -1;
         l.cache_hm = 0;
@@ -278,7 +335,7 @@ struct SpecRaft {
             if (!skip) {
                 l.addmask |= 1u << i;
                 l.nadd++;
-                if (WANT_FP) l.add_fp += hmix(l.log.get(i), SALT_A);
+                if (WANT_FP) l.add_fp += hmum(l.log.get(i), SALT_A);
             }
         }
     }
@@ -308,11 +365,16 @@ struct SpecRaft {
     MC_HD static unsigned send(const Local &l, Ref s, const Params &prm, uint64_t key_word /*count bits zero*/, Delta &d) {
         int idx = l.nm;
         uint64_t old = 0;
-        if (l.mfilter >> key_bucket(key_word) & 1u) {  // possibly present: scan the bag
-            for (int k = 0; k < l.nm; k++) {
-                const uint64_t x = s.get(W_MSG0 + k);
-                if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; }
-            }
+        uint32_t cand = sig_match(l.sig, key_sig(key_word));  // slots whose signature equals the key's: almost always 0 or 1
+        while (cand) {
+            const int k = sig_slot_of_bit(__builtin_ctz(cand));
+            cand &= cand - 1;
+            const uint64_t x = s.get(W_MSG0 + k);
+            if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; cand = 0; }
+        }
+        for (int k = SIG_SLOTS; k < l.nm; k++) {  // bags beyond the signature words: scanned
+            const uint64_t x = s.get(W_MSG0 + k);
+            if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; }
         }
         // op A; the discard of a Reply is op B (response key /= request key, so the slots differ)
         d.nmop |= 1;
@@ -622,20 +684,21 @@ struct SpecRaft {
         return F_RVREQ + m_type(m);  // M_RVREQ..M_AERESP in the order of the enum
     }
     // what a lane evaluating a pair needs to know about the pair's parent beyond the parent's own words (computed once by
-    // the parent's lane, kept in LDS: 16 B per parent; fp / globals / committedLog are re-read from the arena block the
+    // the parent's lane, kept in LDS: 32 B per parent; fp / globals / committedLog are re-read from the arena block the
     // wavefront owns, where they are L1-resident)
     struct Summary {
         uint64_t add_fp;
-        uint32_t mfilter;
+        Sigs sig;
         uint32_t packed;  // nm[0,8) inflight[8,16) nadd[16,20) addmask[20,28)
+        uint32_t pad;
     };
     MC_HD static void summarize(const Local &l, Summary &q) {
-        q.add_fp = l.add_fp; q.mfilter = l.mfilter;
+        q.add_fp = l.add_fp; q.sig = l.sig; q.pad = 0;
         q.packed = (uint32_t)l.nm | (uint32_t)l.inflight << 8 | (uint32_t)l.nadd << 16 | l.addmask << 20;
     }
     template <class Ref>
     MC_HD static void local_of_summary(const Summary &q, Ref s, Local &l) {
-        l.fp = s.get(W_FP); l.glob = s.get(W_GLOB); l.clog = s.get(W_CLOG); l.add_fp = q.add_fp; l.mfilter = q.mfilter;
+        l.fp = s.get(W_FP); l.glob = s.get(W_GLOB); l.clog = s.get(W_CLOG); l.add_fp = q.add_fp; l.sig = q.sig;
         l.nm = (int)(q.packed & 255u); l.inflight = (int)(q.packed >> 8 & 255u); l.nadd = (int)(q.packed >> 16 & 15u);
         l.addmask = q.packed >> 20 & 255u;
         l.cache_k = -1; l.cache_hm = 0;
@@ -742,29 +805,26 @@ struct SpecRaft {
     template <class Ref>
     MC_HD static uint64_t delta_fp(Local &l, Ref s, const Delta &d) {
         uint64_t fp = l.fp + l.add_fp;
-        if (d.glob != l.glob) fp += hmix(d.glob, salt_of(W_GLOB)) - hmix(l.glob, salt_of(W_GLOB));
-        if (d.clog != l.clog) fp += hmix(d.clog, salt_of(W_CLOG)) - hmix(l.clog, salt_of(W_CLOG));
+        if ((d.glob ^ l.glob) & GLOB_HASHED) fp += hmum(d.glob & GLOB_HASHED, salt_of(W_GLOB)) - hmum(l.glob & GLOB_HASHED, salt_of(W_GLOB));
+        if (d.clog != l.clog) fp += hmum(d.clog, salt_of(W_CLOG)) - hmum(l.clog, salt_of(W_CLOG));
         if (d.srv >= 0) {
             const int i = d.srv;
-            if (d.sv != d.osv) fp += hmix(d.sv, salt_of((unsigned)W_SRV(i))) - hmix(d.osv, salt_of((unsigned)W_SRV(i)));
-            if (d.log != d.olog) fp += hmix(d.log, salt_of((unsigned)W_LOG(i))) - hmix(d.olog, salt_of((unsigned)W_LOG(i)));
+            if (d.sv != d.osv) fp += hmum(d.sv, salt_of((unsigned)W_SRV(i))) - hmum(d.osv, salt_of((unsigned)W_SRV(i)));
+            if (d.log != d.olog) fp += hmum(d.log, salt_of((unsigned)W_LOG(i))) - hmum(d.olog, salt_of((unsigned)W_LOG(i)));
             if (d.vmode == 1) {
 #pragma unroll
-                for (int j = 0; j < NS; j++) {
-                    const uint64_t x = s.get(W_VLOG(i, j));
-                    if (x) fp += hmix(0, salt_of((unsigned)W_VLOG(i, j))) - hmix(x, salt_of((unsigned)W_VLOG(i, j)));
-                }
-            } else if (d.vmode == 2 && d.vlog != 0) {
-                fp += hmix(d.vlog, salt_of((unsigned)W_VLOG(i, d.vj))) - hmix(0, salt_of((unsigned)W_VLOG(i, d.vj)));
+                for (int j = 0; j < NS; j++) fp -= hvlog(s.get(W_VLOG(i, j)), i, j);
+            } else if (d.vmode == 2) {
+                fp += hvlog(d.vlog, i, d.vj);  // the entry was empty (compute: "existing entry wins")
             }
         }
-        if (d.nmop & 1) {
-            if (d.midxA < l.nm) fp -= hmix(d.moldA, SALT_M);
-            fp += hmix(d.mnewA, SALT_M);
+        if (d.nmop & 1) {  // Send: a new key enters with count 1 (multiplicity 2), a known one gains a copy unless saturated
+            if (d.midxA >= l.nm) fp += 2 * hkey(d.mnewA);
+            else if (d.mnewA != d.moldA) fp += hkey(d.mnewA);
         }
-        if (d.nmop & 2) {  // the message the slot was read from: Receive, Duplicate and Drop of one k share H(old)
-            if (l.cache_k != d.midxB) { l.cache_k = d.midxB; l.cache_hm = hmix(d.moldB, SALT_M); }
-            fp += hmix(d.mnewB, SALT_M) - l.cache_hm;
+        if ((d.nmop & 2) && d.mnewB != d.moldB) {  // the message the slot was read from: one copy less (Discard / Drop) or more (Duplicate)
+            if (l.cache_k != d.midxB) { l.cache_k = d.midxB; l.cache_hm = hkey(d.moldB); }
+            fp += d.mnewB > d.moldB ? l.cache_hm : 0ull - l.cache_hm;
         }
         if (d.eadd) fp += helec(d.ew);
         return fp;
@@ -800,6 +860,63 @@ struct SpecRaft {
         fp = fp_nonzero(delta_fp(l, s, d));
         return st;
     }
+    // Restart(i) and Timeout(i) of ONE server, evaluated together by the parent's own lane (the dense slots of k_expand_family:
+    // half of all successors).  Both rewrite the scalars of server i and clear voterLog[i], so H(old scalars) and the voterLog
+    // terms are computed once for the two, and nothing else of the state changes (raft.tla:186-194, 197-206).  The results are
+    // exactly eval(slot = i) and eval(slot = NS + i) — tests/_shim compares them on every state of every lowering test.
+    static constexpr int DENSE_PAIRS = NS;
+    MC_HD static int dense_slot(int i, int second) { return second ? NS + i : i; }
+    // (the server index is a template parameter: a run-time index into the register copy `l.sv` would be turned into an indexed
+    //  load of a stack array by the compiler — scratch memory — however uniform it is)
+    template <class Ref>
+    MC_HD static void eval_dense(const Params &prm, const Local &l, Ref s, int i, unsigned &stR, uint64_t &fpR, unsigned &stT, uint64_t &fpT) {
+        if (i == 0) eval_dense_i<0>(prm, l, s, stR, fpR, stT, fpT);
+        if (NS > 1 && i == 1) eval_dense_i<1 % NS>(prm, l, s, stR, fpR, stT, fpT);
+        if (NS > 2 && i == 2) eval_dense_i<2 % NS>(prm, l, s, stR, fpR, stT, fpT);
+        if (NS > 3 && i == 3) eval_dense_i<3 % NS>(prm, l, s, stR, fpR, stT, fpT);
+        if (NS > 4 && i == 4) eval_dense_i<4 % NS>(prm, l, s, stR, fpR, stT, fpT);
+        static_assert(NS <= 5, "eval_dense dispatches over at most 5 servers");
+    }
+    template <int i, class Ref>
+    MC_HD static void eval_dense_i(const Params &prm, const Local &l, Ref s, unsigned &stR, uint64_t &fpR, unsigned &stT, uint64_t &fpT) {
+        const uint64_t osv = l.sv.get(i);
+        // bookkeeping shared by every action (compute): allLogs' additions, the in-flight bound, CommittedLogStable
+        unsigned stc = ST_ENABLED;
+        uint64_t glob = l.glob;
+        if (l.nadd) {
+            if (g_na(l.glob) + l.nadd > prm.ca) stc |= ST_OVERFLOW;
+            glob += (uint64_t)l.nadd << 24;
+        }
+        if (l.inflight > prm.max_msgs) stc |= ST_OUT_OF_MODEL;
+        if ((prm.inv_mask & 2) && g_decr(glob)) stc |= ST_INVARIANT | (1u << 8);
+        uint64_t any = 0, vl = 0;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const uint64_t x = s.get(W_VLOG(i, j));
+            any |= x;
+            vl += hvlog(x, i, j);
+        }
+        const uint64_t salt = salt_of((unsigned)W_SRV(i));
+        const uint64_t base = l.fp + l.add_fp - vl - hmum(osv, salt);
+        const bool still = !l.nadd && any == 0;  // nothing but the scalars can differ from the parent
+        // Restart(i): always enabled
+        const uint64_t svR = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(osv, R_FOLLOWER), 0), 0), 1);
+        stR = stc;
+        if (stc & (ST_OUT_OF_MODEL | ST_OVERFLOW)) fpR = 1;
+        else if (still && svR == osv) { fpR = fp_nonzero(l.fp); stR |= ST_SELFLOOP; }
+        else fpR = fp_nonzero(base + hmum(svR, salt));
+        // Timeout(i): a follower or a candidate
+        const int stt = sv_state(osv), nt = sv_term(osv) + 1;
+        stT = 0;
+        fpT = 0;
+        if (stt == R_FOLLOWER || stt == R_CANDIDATE) {
+            const uint64_t svT = sv_set_granted(sv_set_voted(sv_set_term(sv_set_state(osv, R_CANDIDATE), nt & 7), 0), 0);
+            stT = stc | (nt > prm.max_term ? (unsigned)ST_OUT_OF_MODEL : 0u);
+            if (stT & (ST_OUT_OF_MODEL | ST_OVERFLOW)) fpT = 1;
+            else fpT = fp_nonzero(base + hmum(svT, salt));  // never the parent: the term grows
+        }
+    }
+
     // re-evaluate `slot` on parent `s` and write the whole successor to `out`
     template <class Ref>
     MC_HD static unsigned apply(const Params &prm, Ref s, int slot, WordRef out) { return apply_impl<false>(prm, s, slot, 0, out); }
