@@ -97,6 +97,20 @@ __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
 MC_HD CWordRef arena_cref(const uint64_t *arena, uint64_t idx, int words) {
     return CWordRef{arena + ((idx >> 6) * (uint64_t)words) * 64 + (idx & 63), 64};
 }
+// View of one state of the arena block a WAVEFRONT works on: the block's base address is wave-uniform (scalar registers), the
+// state is a 32-bit lane offset, so every access is "global_load v, v_offset, s[base]" — no 64-bit per-lane pointer to keep
+// (or spill), no 64-bit address arithmetic per access.  Block-relative word offsets fit 32 bits (a block is words * 512 bytes).
+using GlobalWords = const __attribute__((address_space(1))) uint64_t *;  // (a generic pointer would make every access a flat_load)
+struct BlockRef {
+    GlobalWords base;  // arena + block * words * 64: uniform
+    unsigned lane;     // the state inside the block
+    __device__ __forceinline__ uint64_t get(int w) const { return base[(unsigned)w * 64u + lane]; }
+};
+__device__ __forceinline__ GlobalWords uniform_ptr(const uint64_t *p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (GlobalWords)(((uint64_t)hi << 32) | lo);
+}
 MC_HD WordRef arena_ref(uint64_t *arena, uint64_t idx, int words) {
     return WordRef{arena + ((idx >> 6) * (uint64_t)words) * 64 + (idx & 63), 64};
 }
@@ -576,6 +590,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     if (wave_col0 >= ncols) return;
     const uint64_t wave_idx0 = base + wave_col0;
     const int W = S::words(prm);
+    static_assert(NB == 1, "BlockRef addresses ONE arena block per wavefront");
+    const GlobalWords blk_base = uniform_ptr(arena + (wave_idx0 >> 6) * (uint64_t)W * 64);
     unsigned long long viol = ~0ull;
     unsigned gen = 0, err = 0, probes = 0;
     unsigned qhead = 0, qn = 0, ohead = 0, on = 0;  // wave-uniform ring state of the probe / survivor queues
@@ -701,7 +717,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             const int slot = (int)(e >> 8);
             const uint64_t pidx = wave_idx0 + p;
             const typename S::Summary q = FL.sum[p];
-            const CWordRef sp = arena_cref(arena, pidx, W);
+            const BlockRef sp{blk_base, p & 63u};  // NB == 1: the pair's parent is in this wavefront's block
             unsigned st = 0;
             uint64_t fv = 0;
             family_dispatch<S, 0>(f, [&](auto fc) { st = S::template eval_pair<decltype(fc)::value>(prm, q, sp, slot, fv); });
@@ -736,16 +752,16 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         if (wave_col0 + (uint64_t)blk * 64 >= ncols) break;  // wave-uniform
         const bool active = idx >= lo && idx < hi;
         const unsigned pl = (unsigned)blk * 64 + lane;       // this lane's parent inside the wavefront's NB blocks
-        const CWordRef g = arena_cref(arena, idx, W);
+        const BlockRef g{blk_base, lane};
         typename S::Guards gd;
         gd.fixed = 0;
         gd.terms = 0;
+        gd.mc0 = gd.mc1 = 0;
         int nm = 0;
         typename S::Local loc;
         if (active) {
-            S::load(prm, g, loc);
+            S::load_expand(prm, g, loc, gd);  // the whole row in one round trip; guards and per-message codes included
             nm = loc.nm;
-            S::guards(prm, loc, gd);
             typename S::Summary q;
             S::summarize(loc, q);
             FL.sum[pl] = q;
@@ -798,15 +814,17 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             if (b && fam_push(f, b, en, ((unsigned)step << 8) | pl)) run_full(1u << f, false);
         }
         for (int k = 0; k < ((flags & 64u) ? 0 : wnm); ++k) {
-            const uint64_t mword = k < nm ? g.get(S::W_MSG0 + k) : 0;
+            // (the first GUARD_SLOTS message slots were classified by load_expand: no memory access here)
+            const uint64_t mword = (k >= S::GUARD_SLOTS && k < nm) ? g.get(S::W_MSG0 + k) : 0;
 #pragma clang loop unroll(disable)
             for (int kind = 0; kind < 3; ++kind) {
                 unsigned fullmask = 0;
                 const unsigned entry = ((unsigned)(S::FIX + 3 * k + kind) << 8) | pl;
-                const int fam = k < nm ? S::guard_msg(gd, mword, kind) : -1;
+                const int fam = k >= nm ? -1 : k < S::GUARD_SLOTS ? S::guard_code(gd, k, kind) : S::guard_msg(gd, mword, kind);
                 if (kind == 0) {  // Receive: the family depends on the message (UpdateTerm or one of the four handlers)
 #pragma unroll
-                    for (int f = S::F_UPDTERM; f <= S::F_AERESP; ++f) {
+                    for (int f = 0; f < S::NFAM; ++f) {
+                        if (!(S::RECV_FAMS >> f & 1u)) continue;
                         const unsigned long long b = __ballot(fam == f);
                         if (b && fam_push(f, b, fam == f, entry)) fullmask |= 1u << f;
                     }
@@ -1006,7 +1024,8 @@ k_expand_direct(typename S::Params prm, uint64_t *arena, uint64_t lo, uint64_t h
             if (k < nm) fam = S::guard_msg(gd, g.get(S::W_MSG0 + k), kind);
             if (kind == 0) {  // Receive: the family depends on the message (UpdateTerm or one of the four handlers)
 #pragma unroll
-                for (int f = S::F_UPDTERM; f <= S::F_AERESP; ++f) {
+                for (int f = 0; f < S::NFAM; ++f) {
+                    if (!(S::RECV_FAMS >> f & 1u)) continue;
                     const unsigned long long b = __ballot(fam == f);
                     if (b && fam_push(f, b, fam == f, step)) fullmask |= 1u << f;
                 }

@@ -281,6 +281,8 @@ struct SpecRaft {
         //  +40 % materialise: most successors touch few words, and the registers cost occupancy)
         int cache_k;           // message slot whose H(word) is cached (Receive / Duplicate / Drop share it)
         uint64_t cache_hm;
+        RegArr<NS> vlh;        // sum_j H(voterLog[i][j]) per server and ...
+        unsigned vany;         // ... bit i: voterLog[i] has an entry (dense Restart / Timeout pairs; filled when WANT_FP)
     };
     // WANT_FP = false: the caller never computes a fingerprint from this cache (k_materialise with a known one)
     template <bool WANT_FP = true, class Ref>
@@ -322,6 +324,24 @@ struct SpecRaft {
                 if (y0 == lg || y1 == lg || y2 == lg || y3 == lg) present |= 1u << i;
             }
         }
+        l.vany = 0;
+        if (WANT_FP) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                uint64_t h = 0;
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    const uint64_t x = s.get(W_VLOG(i, j));
+                    if (x) l.vany |= 1u << i;
+                    h += hvlog(x, i, j);
+                }
+                l.vlh.set(i, h);
+            }
+        }
+        finish_local<WANT_FP>(l, present);
+    }
+    template <bool WANT_FP>
+    MC_HD static void finish_local(Local &l, unsigned present) {
         l.cache_k = -1;
         l.cache_hm = 0;
         l.addmask = 0;
@@ -340,6 +360,7 @@ struct SpecRaft {
         }
     }
     MC_HD static int nslots(const Params &, const Local &l) { return FIX + 3 * l.nm; }
+
     template <class Ref>
     MC_HD static unsigned parent_status(const Params &, const Local &, Ref) { return 0; }  // invariants are checked per successor
 
@@ -414,13 +435,21 @@ struct SpecRaft {
     template <bool MEM, class Ref>
     MC_HD static uint64_t log_word(const Local &l, Ref s, int i) { if (MEM) return s.get(W_LOG(i)); return l.log.get(i); }
 
-    // Action FAMILIES: the expand-by-family kernel buckets enabled (state, slot) pairs per family in
-    // LDS and evaluates 64 pairs of ONE family at a time, so the successor construction below runs
-    // with every lane busy and without divergence between action types.  FAM < 0 = any family.
-    enum : int { F_RESTART, F_TIMEOUT, F_REQVOTE, F_BECOME, F_CLIENT, F_ADVANCE, F_APPEND,
-                 F_UPDTERM, F_RVREQ, F_RVRESP, F_AEREQ, F_AERESP, F_DUPDROP, NFAM };
-#define MC_FAM(f) (FAM < 0 || FAM == (f))
+    // Action FAMILIES: the expand-by-family kernel buckets enabled (state, slot) pairs per family in LDS and evaluates 64 pairs
+    // of ONE family at a time, so the successor construction below runs with every lane busy and without divergence between
+    // action types.  The first NFAM ids are the QUEUES; the rare kinds (together 7 % of the pairs of the bench model, none of
+    // them over 3 %) share the queue F_MISC — one batch with divergent arithmetic instead of seven nearly empty ones, each of
+    // which would pay its own chain of memory round trips.  FAM < 0 = any kind.
+    enum : int { F_RESTART, F_TIMEOUT, F_REQVOTE, F_APPEND, F_RVREQ, F_DUPDROP, F_MISC, NFAM,
+                 F_BECOME = NFAM, F_CLIENT, F_ADVANCE, F_UPDTERM, F_RVRESP, F_AEREQ, F_AERESP };
+    static constexpr unsigned RECV_FAMS = (1u << F_RVREQ) | (1u << F_MISC);  // queues a Receive pair can go to
+#define MC_FAM(f) (FAM < 0 || FAM == (f) || (FAM == F_MISC && (f) >= NFAM))
 
+    // The function is staged so that the memory round trips of a pair do not depend on its kind: (1) the message word of a
+    // message slot, (2) the scalars and the log of the ONE server the action is about, (3) arithmetic only — a branch per kind,
+    // which records the message it wants to send instead of sending it — (4) one Send: signature match + one verifying load.
+    // A wavefront evaluating pairs of several kinds (F_MISC, k_materialise) walks the branches of (3) one after the other, but
+    // its loads are issued once, before and after them.
     template <bool MEM = false, int FAM = -1, class Ref>
     MC_HD static unsigned compute(const Params &prm, const Local &l, Ref s, int slot, Delta &d, int &action) {
         d.glob = l.glob; d.clog = l.clog; d.srv = -1; d.sv = d.osv = 0; d.log = d.olog = 0; d.pre = true; d.vmode = 0; d.vj = 0; d.vlog = 0;
@@ -428,40 +457,61 @@ struct SpecRaft {
         d.eadd = false; d.dinflight = 0;
         d.ew = RegArr<EL_WORDS>();
         unsigned st = ST_ENABLED;
+        // ---- (1), (2): operands
+        constexpr bool MSG_KINDS = FAM < 0 || FAM == F_RVREQ || FAM == F_DUPDROP || FAM == F_MISC;
+        int i = 0, j = 0, k = -1, kind = -1;
+        uint64_t m = 0;
+        if (slot >= FIX) {
+            if (!MSG_KINDS) return 0;
+            const int q = slot - FIX;
+            k = q / 3; kind = q % 3;
+            if (k >= l.nm) return 0;
+            m = s.get(W_MSG0 + k);
+            i = m_dst(m); j = m_src(m);
+        } else if (slot < 2 * NS) {
+            i = slot < NS ? slot : slot - NS;
+        } else if (slot < 2 * NS + NS * NS) {
+            const int q = slot - 2 * NS; i = q / NS; j = q % NS;
+        } else if (slot < 5 * NS + NS * NS) {
+            i = (slot - (2 * NS + NS * NS)) % NS;
+        } else {
+            const int q = slot - (5 * NS + NS * NS); i = q / NS; j = q % NS;
+        }
+        // (slot >= FIX: i differs per lane, the words are read from the read-only state, never select-indexed from the register copy)
+        // Duplicate / Drop are about the message alone
+        const uint64_t svi = slot >= FIX ? (kind == 0 ? s.get(W_SRV(i)) : 0ull) : srv_word<MEM>(l, s, i);
+        const uint64_t lgi = slot >= FIX ? (kind == 0 ? s.get(W_LOG(i)) : 0ull) : log_word<MEM>(l, s, i);
+        bool want_send = false;
+        uint64_t skey = 0;
+        // ---- (3): the action
         if (MC_FAM(F_RESTART) && slot < NS) {  // Restart(i)   raft.tla:186-194 (always enabled)
-            const int i = slot;
             action = RA_RESTART;
-            d.srv = i; d.osv = srv_word<MEM>(l, s, i); d.olog = d.log = log_word<MEM>(l, s, i);
+            d.srv = i; d.osv = svi; d.olog = d.log = lgi;
             d.sv = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(d.osv, R_FOLLOWER), 0), 0), 1);
             d.vmode = 1;
         } else if (MC_FAM(F_TIMEOUT) && slot >= NS && slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
-            const int i = slot - NS;
             action = RA_TIMEOUT;
-            const uint64_t svi = srv_word<MEM>(l, s, i);
             const int stt = sv_state(svi);
             if (!(stt == R_FOLLOWER || stt == R_CANDIDATE)) return 0;
             const int nt = sv_term(svi) + 1;
             if (nt > prm.max_term) st |= ST_OUT_OF_MODEL;
-            d.srv = i; d.osv = svi; d.olog = d.log = log_word<MEM>(l, s, i);
+            d.srv = i; d.osv = svi; d.olog = d.log = lgi;
             d.sv = sv_set_granted(sv_set_voted(sv_set_term(sv_set_state(svi, R_CANDIDATE), nt & 7), 0), 0);
             d.vmode = 1;
         } else if (MC_FAM(F_REQVOTE) && slot >= 2 * NS && slot < 2 * NS + NS * NS) {  // RequestVote(i, j)   raft.tla:209-217
-            const int q = slot - 2 * NS, i = q / NS, j = q % NS;
             action = RA_REQUESTVOTE;
-            const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_CANDIDATE) return 0;
-            st |= send(l, s, prm, mk_rvreq(sv_term(svi), rlog::last_term(lgi), rlog::len(lgi), i, j), d);
+            want_send = true;
+            skey = mk_rvreq(sv_term(svi), rlog::last_term(lgi), rlog::len(lgi), i, j);
         } else if (MC_FAM(F_BECOME) && slot >= 2 * NS + NS * NS && slot < 3 * NS + NS * NS) {  // BecomeLeader(i)   raft.tla:247-261
-            const int i = slot - (2 * NS + NS * NS);
             action = RA_BECOMELEADER;
-            const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_CANDIDATE || !in_quorum(sv_granted(svi))) return 0;
             d.srv = i; d.osv = svi; d.olog = d.log = lgi;
             d.sv = sv_reset_leader_vars(sv_set_state(svi, R_LEADER), rlog::len(lgi) + 1);
             const uint64_t ew0 = (uint64_t)sv_term(svi) | ((uint64_t)i << 3) | ((uint64_t)sv_granted(svi) << 6) | (lgi << 11);
             d.ew.set(0, ew0);
 #pragma unroll
-            for (int j = 0; j < NS; j++) d.ew.set(1 + j, s.get(W_VLOG(i, j)));
+            for (int jj = 0; jj < NS; jj++) d.ew.set(1 + jj, s.get(W_VLOG(i, jj)));
             // elections \cup {...}: a set — an identical record changes nothing
             bool present = false;
             const int ne = g_ne(l.glob), wel = W_EL0(prm);
@@ -477,10 +527,8 @@ struct SpecRaft {
                 d.glob += 1ull << 16;
             }
         } else if (MC_FAM(F_CLIENT) && slot >= 3 * NS + NS * NS && slot < 4 * NS + NS * NS) {  // ClientRequest(i)   raft.tla:264-274
-            const int i = slot - (3 * NS + NS * NS);
             action = RA_CLIENTREQUEST;
             const int creq = g_creq(l.glob);
-            const uint64_t svi = srv_word<MEM>(l, s, i), lgi = log_word<MEM>(l, s, i);
             if (sv_state(svi) != R_LEADER || !(creq < prm.max_client_requests)) return 0;
             if (rlog::len(lgi) >= rlog::LCAP) return ST_ENABLED | ST_OVERFLOW;
             d.srv = i; d.osv = d.sv = svi; d.olog = lgi;
@@ -488,15 +536,14 @@ struct SpecRaft {
             d.glob += 1;  // clientRequests' = clientRequests + 1
             if (rlog::len(d.log) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
         } else if (MC_FAM(F_ADVANCE) && slot >= 4 * NS + NS * NS && slot < 5 * NS + NS * NS) {  // AdvanceCommitIndex(i)   raft.tla:280-305
-            const int i = slot - (4 * NS + NS * NS);
             action = RA_ADVANCECOMMIT;
-            const uint64_t svi = srv_word<MEM>(l, s, i), lg = log_word<MEM>(l, s, i);
+            const uint64_t lg = lgi;
             if (sv_state(svi) != R_LEADER) return 0;
             int maxAgree = 0;
             for (int index = 1; index <= rlog::len(lg); index++) {
                 unsigned agree = 1u << i;  // Agree(index) == {i} \cup {k : matchIndex[i][k] >= index}
 #pragma unroll
-                for (int k = 0; k < NS; k++) if (sv_match(svi, k) >= index) agree |= 1u << k;
+                for (int kk = 0; kk < NS; kk++) if (sv_match(svi, kk) >= index) agree |= 1u << kk;
                 if (in_quorum(agree)) maxAgree = index;
             }
             const int nci = (maxAgree > 0 && rlog::eterm(rlog::entry(lg, maxAgree)) == sv_term(svi)) ? maxAgree : sv_commit(svi);
@@ -512,9 +559,8 @@ struct SpecRaft {
             d.clog = ncl;
             d.glob = bits_set(d.glob, 3, 1, decr ? 1 : 0);
         } else if (MC_FAM(F_APPEND) && slot >= 5 * NS + NS * NS && slot < FIX) {  // AppendEntries(i, j)   raft.tla:222-244
-            const int q = slot - (5 * NS + NS * NS), i = q / NS, j = q % NS;
             action = RA_APPENDENTRIES;
-            const uint64_t svi = srv_word<MEM>(l, s, i), lg = log_word<MEM>(l, s, i);
+            const uint64_t lg = lgi;
             if (i == j || sv_state(svi) != R_LEADER) return 0;
             const int next = sv_next(svi, j), prevIdx = next - 1;
             int prevTerm = 0;
@@ -526,11 +572,9 @@ struct SpecRaft {
             const int nent = next <= lastEntry ? 1 : 0;                        // SubSeq(log[i], next, lastEntry)
             const unsigned ent = nent ? rlog::entry(lg, next) : 0u;
             const int ci = sv_commit(svi) < lastEntry ? sv_commit(svi) : lastEntry;
-            st |= send(l, s, prm, mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j), d);
-        } else if (slot >= FIX && (FAM < 0 || FAM >= F_UPDTERM)) {
-            const int q = slot - FIX, k = q / 3, kind = q % 3;
-            if (k >= l.nm) return 0;
-            const uint64_t m = s.get(W_MSG0 + k);
+            want_send = true;
+            skey = mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j);
+        } else if (MSG_KINDS && slot >= FIX) {
             const int cnt = m_count(m);
             if (MC_FAM(F_DUPDROP) && kind == 1) {  // DuplicateMessage(m), m \in SingleMessage(messages)   raft.tla:134-135,471-473
                 action = RA_DUPLICATE;
@@ -540,13 +584,11 @@ struct SpecRaft {
                 action = RA_DROP;
                 if (cnt == 0) return 0;
                 discard(k, m, d);
-            } else if (kind == 0 && (FAM < 0 || (FAM >= F_UPDTERM && FAM <= F_AERESP))) {  // Receive(m), m \in ValidMessage(messages)   raft.tla:449-464
+            } else if (kind == 0 && (FAM < 0 || FAM == F_RVREQ || FAM == F_MISC)) {  // Receive(m), m \in ValidMessage(messages)   raft.tla:449-464
                 action = RA_RECEIVE;
                 if (cnt == 0) return 0;
-                const int i = m_dst(m), j = m_src(m), mterm = m_term(m), type = m_type(m);
-                // i differs per lane here: read the words from the (read-only) state instead of
-                // select-indexing the register copy
-                const uint64_t svi = s.get(W_SRV(i)), lg = s.get(W_LOG(i));
+                const int mterm = m_term(m), type = m_type(m);
+                const uint64_t lg = lgi;
                 const int term = sv_term(svi);
                 d.srv = i; d.osv = d.sv = svi; d.olog = d.log = lg; d.pre = false;
                 if (MC_FAM(F_UPDTERM) && mterm > term) {  // UpdateTerm   raft.tla:434-440 (message not consumed)
@@ -557,7 +599,8 @@ struct SpecRaft {
                     const bool logOk = llt > lt || (llt == lt && lli >= rlog::len(lg));
                     const bool grant = mterm == term && logOk && (sv_voted(svi) == 0 || sv_voted(svi) == j + 1);
                     if (grant) d.sv = sv_set_voted(svi, j + 1);
-                    st |= send(l, s, prm, mk_rvresp(term, grant ? 1 : 0, lg, i, j), d);  // Reply(response, m)
+                    want_send = true;  // Reply(response, m)
+                    skey = mk_rvresp(term, grant ? 1 : 0, lg, i, j);
                     discard(k, m, d);
                 } else if (MC_FAM(F_RVRESP) && mterm <= term && type == M_RVRESP) {
                     if (mterm == term) {  // HandleRequestVoteResponse   raft.tla:336-349
@@ -576,7 +619,8 @@ struct SpecRaft {
                     const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg);
                     const bool logOk = pidx == 0 || (pidx > 0 && pidx <= len && pterm == rlog::eterm(rlog::entry(lg, pidx)));
                     if (mterm < term || (mterm == term && stt == R_FOLLOWER && !logOk)) {  // reject   :361-373
-                        st |= send(l, s, prm, mk_aeresp(term, 0, 0, i, j), d);
+                        want_send = true;
+                        skey = mk_aeresp(term, 0, 0, i, j);
                         discard(k, m, d);
                     } else if (stt == R_CANDIDATE) {  // return to follower state   :374-378 (mterm = term here)
                         d.sv = sv_set_state(svi, R_FOLLOWER);
@@ -585,7 +629,8 @@ struct SpecRaft {
                         if (nent == 0 || (len >= index && rlog::eterm(rlog::entry(lg, index)) == rlog::eterm(ent))) {
                             // already done with request   :384-402; commitIndex' assigned AND UNCHANGED
                             if (mci != sv_commit(svi)) return 0;
-                            st |= send(l, s, prm, mk_aeresp(term, 1, pidx + nent, i, j), d);
+                            want_send = true;
+                            skey = mk_aeresp(term, 1, pidx + nent, i, j);
                             discard(k, m, d);
                         } else if (len >= index) {  // conflict: remove 1 entry   :403-410
                             d.log = rlog::drop_last(lg);
@@ -619,6 +664,8 @@ struct SpecRaft {
         } else {
             return 0;
         }
+        // ---- (4): Send(m) / Reply(response, m): one place, whatever the kind
+        if (want_send) st |= send(l, s, prm, skey, d);
         // bookkeeping shared by every action: counts in the globals word
         if ((d.nmop & 1) && d.midxA >= l.nm) {
             d.glob += 1ull << 8;
@@ -632,8 +679,8 @@ struct SpecRaft {
         // invariants on the successor (the parent satisfies them, so only the changed server matters)
         if ((prm.inv_mask & 1) && d.srv >= 0 && sv_state(d.sv) == R_LEADER) {  // NoTwoLeaders   raft.tla:500-507
 #pragma unroll
-            for (int j = 0; j < NS; j++)
-                if (j != d.srv && sv_state(srv_word<MEM>(l, s, j)) == R_LEADER && sv_term(srv_word<MEM>(l, s, j)) == sv_term(d.sv)) st |= ST_INVARIANT;
+            for (int jj = 0; jj < NS; jj++)
+                if (jj != d.srv && sv_state(srv_word<MEM>(l, s, jj)) == R_LEADER && sv_term(srv_word<MEM>(l, s, jj)) == sv_term(d.sv)) st |= ST_INVARIANT;
         }
         if ((prm.inv_mask & 2) && !(st & ST_INVARIANT) && g_decr(d.glob)) st |= ST_INVARIANT | (1u << 8);  // CommittedLogStable
         return st;
@@ -644,14 +691,28 @@ struct SpecRaft {
     struct Guards {
         uint64_t fixed;   // bit s: fixed slot s (< FIX) may be enabled
         uint32_t terms;   // 3 bits per server: currentTerm (for UpdateTerm vs handler dispatch)
+        uint64_t mc0, mc1;  // load_expand: one byte per message slot k < GUARD_SLOTS — queue of Receive(k) [0,4) (15 = none),
+                            // bit 4 Duplicate(k) enabled, bit 5 Drop(k) enabled: the push loop of the kernel reads no memory
     };
+    static constexpr int GUARD_SLOTS = 16;
+    MC_HD static unsigned msg_code(const Guards &g, uint64_t m) {
+        const int r = guard_msg(g, m, 0);
+        return (unsigned)(r < 0 ? 15 : r) | (m_count(m) == 1 ? 16u : 0u) | (m_count(m) > 0 ? 32u : 0u);
+    }
+    // family of message slot (k < GUARD_SLOTS, kind) from the codes, or -1
+    MC_HD static int guard_code(const Guards &g, int k, int kind) {
+        const unsigned c = (unsigned)((k < 8 ? g.mc0 >> (8 * k) : g.mc1 >> (8 * (k - 8))) & 255u);
+        if (kind == 0) return (c & 15u) == 15u ? -1 : (int)(c & 15u);
+        return (c >> (3 + kind) & 1u) ? (int)F_DUPDROP : -1;
+    }
     MC_HD static int fixed_family(int slot) {
         return slot < NS ? F_RESTART : slot < 2 * NS ? F_TIMEOUT : slot < 2 * NS + NS * NS ? F_REQVOTE
-             : slot < 3 * NS + NS * NS ? F_BECOME : slot < 4 * NS + NS * NS ? F_CLIENT : slot < 5 * NS + NS * NS ? F_ADVANCE : F_APPEND;
+             : slot < 5 * NS + NS * NS ? F_MISC /* BecomeLeader, ClientRequest, AdvanceCommitIndex */ : F_APPEND;
     }
     MC_HD static void guards(const Params &prm, const Local &l, Guards &g) {
         g.fixed = 0;
         g.terms = 0;
+        g.mc0 = g.mc1 = 0;
         const int creq = g_creq(l.glob);
 #pragma unroll
         for (int i = 0; i < NS; i++) {
@@ -680,25 +741,111 @@ struct SpecRaft {
         if (kind == 2) return cnt > 0 ? (int)F_DUPDROP : -1;
         if (cnt == 0) return -1;
         const int term = (int)(g.terms >> (3 * m_dst(m)) & 7u);
-        if (m_term(m) > term) return F_UPDTERM;
-        return F_RVREQ + m_type(m);  // M_RVREQ..M_AERESP in the order of the enum
+        if (m_term(m) > term) return F_MISC;  // UpdateTerm
+        return m_type(m) == M_RVREQ ? (int)F_RVREQ : (int)F_MISC;
     }
-    // what a lane evaluating a pair needs to know about the pair's parent beyond the parent's own words (computed once by
-    // the parent's lane, kept in LDS: 32 B per parent; fp / globals / committedLog are re-read from the arena block the
-    // wavefront owns, where they are L1-resident)
+    // Phase A of the by-family expand kernel (lane = parent, rows of the arena block coalesced): load() and guards() in one, with
+    // the loads of the parent's row issued in TWO groups — header + voterLogs, then up to 12 message slots + 4 allLogs entries:
+    // two trips to HBM instead of eight dependent ones (header; messages by fours; allLogs; voterLogs per dense pair) —
+    // and with what the kernel's push loop needs of each message (queue of its Receive, Duplicate / Drop enabled) kept as a
+    // byte code, so that the loop does not read the message words again.  Same Local / Guards as load() + guards().
+    template <class Ref>
+    MC_HD static void load_expand(const Params &prm, Ref s, Local &l, Guards &g) {
+        // ---- trip 1: header and voterLogs (18 loads in flight)
+        l.fp = s.get(W_FP);
+        l.glob = s.get(W_GLOB);
+        l.clog = s.get(W_CLOG);
+        uint64_t vl[NS * NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            l.sv.set(i, s.get(W_SRV(i)));
+            l.log.set(i, s.get(W_LOG(i)));
+#pragma unroll
+            for (int j = 0; j < NS; j++) vl[i * NS + j] = s.get(W_VLOG(i, j));
+        }
+        l.vany = 0;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            uint64_t h = 0;
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                if (vl[i * NS + j]) l.vany |= 1u << i;
+                h += hvlog(vl[i * NS + j], i, j);
+            }
+            l.vlh.set(i, h);
+        }
+        l.nm = g_nm(l.glob);
+        guards(prm, l, g);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);  // the loads of trip 2 stay below: all 34 in flight at once spill registers
+#endif
+        // ---- trip 2: up to PRE message slots and 4 allLogs entries (slots up to the capacity are part of the row whatever
+        //      nMsgs says; an index is clamped into the capacity, wave-uniformly)
+        constexpr int PRE = 12;
+        uint64_t mw[PRE], al[4];
+#pragma unroll
+        for (int k = 0; k < PRE; k++) mw[k] = 0;
+#pragma unroll
+        for (int g4 = 0; g4 < PRE / 4; g4++)
+            if (prm.cm > 4 * g4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int k = 4 * g4 + u; mw[k] = s.get(W_MSG0 + (k < prm.cm ? k : prm.cm - 1)); }
+            }
+        const int wall = W_ALL0(prm);
+#pragma unroll
+        for (int a = 0; a < 4; a++) al[a] = s.get(wall + (a < prm.ca ? a : prm.ca - 1));
+        // ---- arithmetic (bags beyond PRE keys / sets beyond 4 logs: the tail loads)
+        l.inflight = 0;
+        uint32_t sw[4] = {SIG_EMPTY, SIG_EMPTY, SIG_EMPTY, SIG_EMPTY};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < l.nm) {
+                const uint64_t x = k < PRE ? mw[k < PRE ? k : 0] : s.get(W_MSG0 + k);
+                l.inflight += m_count(x);
+                sw[k >> 2] = (sw[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (key_sig(x) << (8 * (k & 3)));
+                const uint64_t c = (uint64_t)msg_code(g, x) << (8 * (k & 7));
+                if (k < 8) g.mc0 |= c; else g.mc1 |= c;
+            } else {
+                const uint64_t c = 15ull << (8 * (k & 7));
+                if (k < 8) g.mc0 |= c; else g.mc1 |= c;
+            }
+        }
+        l.sig = Sigs{sw[0], sw[1], sw[2], sw[3]};
+        for (int k = 16; k < l.nm; k++) l.inflight += m_count(s.get(W_MSG0 + k));
+        unsigned present = 0;
+        const int na = g_na(l.glob);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            if (a < na) {
+#pragma unroll
+                for (int i = 0; i < NS; i++) if (al[a] == l.log.get(i)) present |= 1u << i;
+            }
+        for (int a = 4; a < na; a++) {
+            const uint64_t x = s.get(wall + a);
+#pragma unroll
+            for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
+        }
+        finish_local<true>(l, present);
+    }
+    // what a lane evaluating a pair needs to know about the pair's parent beyond the words it reads itself (computed once by the
+    // parent's lane, kept in LDS: 32 B per parent): the fingerprint every successor starts from, the globals (all of its fields
+    // lie in the low 32 bits), the key signatures and the allLogs' bookkeeping.  committedLog is read from the arena by the one
+    // kind that needs it (AdvanceCommitIndex).
     struct Summary {
-        uint64_t add_fp;
+        uint64_t base_fp;  // fp + add_fp
         Sigs sig;
-        uint32_t packed;  // nm[0,8) inflight[8,16) nadd[16,20) addmask[20,28)
-        uint32_t pad;
+        uint32_t packed;   // nm[0,8) inflight[8,16) nadd[16,20) addmask[20,28)
+        uint32_t glob;
     };
     MC_HD static void summarize(const Local &l, Summary &q) {
-        q.add_fp = l.add_fp; q.sig = l.sig; q.pad = 0;
+        q.base_fp = l.fp + l.add_fp; q.sig = l.sig; q.glob = (uint32_t)l.glob;
         q.packed = (uint32_t)l.nm | (uint32_t)l.inflight << 8 | (uint32_t)l.nadd << 16 | l.addmask << 20;
     }
-    template <class Ref>
+    // FAM = the queue the pair was taken from: only kinds that read or write committedLog load it
+    template <int FAM, class Ref>
     MC_HD static void local_of_summary(const Summary &q, Ref s, Local &l) {
-        l.fp = s.get(W_FP); l.glob = s.get(W_GLOB); l.clog = s.get(W_CLOG); l.add_fp = q.add_fp; l.sig = q.sig;
+        l.fp = q.base_fp; l.add_fp = 0; l.glob = q.glob; l.sig = q.sig;
+        l.clog = (FAM < 0 || FAM == F_MISC) ? s.get(W_CLOG) : 0ull;  // other kinds copy it: d.clog = l.clog, never hashed
         l.nm = (int)(q.packed & 255u); l.inflight = (int)(q.packed >> 8 & 255u); l.nadd = (int)(q.packed >> 16 & 15u);
         l.addmask = q.packed >> 20 & 255u;
         l.cache_k = -1; l.cache_hm = 0;
@@ -707,13 +854,13 @@ struct SpecRaft {
     template <int FAM, class Ref>
     MC_HD static unsigned eval_pair(const Params &prm, const Summary &q, Ref s, int slot, uint64_t &fp) {
         Local l;
-        local_of_summary(q, s, l);
+        local_of_summary<FAM>(q, s, l);
         Delta d;
         int action;
         const unsigned st = compute<true, FAM>(prm, l, s, slot, d, action);
         if (!(st & ST_ENABLED)) return 0;
         if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
-        if (is_self_loop(l, s, d)) { fp = fp_nonzero(l.fp); return st | ST_SELFLOOP; }
+        if (is_self_loop(l, s, d)) { fp = 1; return st | ST_SELFLOOP; }  // (the successor is the parent: no fingerprint needed)
         fp = fp_nonzero(delta_fp(l, s, d));
         return st;
     }
@@ -722,24 +869,24 @@ struct SpecRaft {
     // The lane that evaluated a pair still holds the successor's Delta when the seen-set says "new": instead of
     // re-evaluating (parent, slot) in a second kernel, the delta is packed into PATCH_WORDS words, parked in LDS until
     // 64 survivors are together, and the successor is written as "copy of the parent, patched".
-    //   pd[0]: caller's source tag [0,32) | srv+1 [32,35) | vmode [35,37) | vj [37,40) | midxA+1 [40,47) | midxB+1 [47,54) | eadd [54]
+    //   pd[0]: caller's source tag [0,32) | srv+1 [32,35) | vmode [35,37) | vj [37,40) | midxA+1 [40,47) | midxB+1 [47,54) | eadd [54] | clog [55]
     //   pd[1..8]: raw fingerprint, globals, committedLog, scalars and log of server srv, voterLog entry, message words A and B
     static constexpr int PATCH_WORDS = 9;
     template <int FAM, class Ref>
     MC_HD static unsigned eval_pair_delta(const Params &prm, const Summary &q, Ref s, int slot, uint64_t &fp, uint64_t *pd) {
         Local l;
-        local_of_summary(q, s, l);
+        local_of_summary<FAM>(q, s, l);
         Delta d;
         int action;
         const unsigned st = compute<true, FAM>(prm, l, s, slot, d, action);
         if (!(st & ST_ENABLED)) return 0;
         if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
-        if (is_self_loop(l, s, d)) { fp = fp_nonzero(l.fp); return st | ST_SELFLOOP; }
+        if (is_self_loop(l, s, d)) { fp = 1; return st | ST_SELFLOOP; }  // (the successor is the parent: no fingerprint needed)
         const uint64_t raw = delta_fp(l, s, d);
         fp = fp_nonzero(raw);
         pd[0] = ((uint64_t)(d.srv + 1) << 32) | ((uint64_t)d.vmode << 35) | ((uint64_t)d.vj << 37) |
                 ((uint64_t)((d.nmop & 1) ? d.midxA + 1 : 0) << 40) | ((uint64_t)((d.nmop & 2) ? d.midxB + 1 : 0) << 47) |
-                ((uint64_t)(d.eadd ? 1 : 0) << 54);
+                ((uint64_t)(d.eadd ? 1 : 0) << 54) | ((uint64_t)((FAM < 0 || FAM == F_MISC) ? 1 : 0) << 55);  // 55: pd[3] holds committedLog
         pd[1] = raw; pd[2] = d.glob; pd[3] = d.clog; pd[4] = d.sv; pd[5] = d.log; pd[6] = d.vlog; pd[7] = d.mnewA; pd[8] = d.mnewB;
         return st;
     }
@@ -753,7 +900,7 @@ struct SpecRaft {
         const uint64_t oglob = s.get(W_GLOB);
         out.set(W_FP, pd[1]);
         out.set(W_GLOB, pd[2]);
-        out.set(W_CLOG, pd[3]);
+        out.set(W_CLOG, (meta >> 55 & 1) ? pd[3] : s.get(W_CLOG));  // kinds outside F_MISC never loaded it: unchanged
         RegArr<NS> logs;
         uint64_t osv = 0, olog = 0;
         uint64_t ovl[NS];
@@ -856,7 +1003,7 @@ struct SpecRaft {
         // a successor outside the CONSTRAINT is generated and invariant-checked (done in compute) but
         // never stored, so its fingerprint is not needed
         if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
-        if (is_self_loop(l, s, d)) { fp = fp_nonzero(l.fp); return st | ST_SELFLOOP; }
+        if (is_self_loop(l, s, d)) { fp = fp_nonzero(l.fp); return st | ST_SELFLOOP; }  // the parent's own fingerprint
         fp = fp_nonzero(delta_fp(l, s, d));
         return st;
     }
@@ -889,16 +1036,10 @@ struct SpecRaft {
         }
         if (l.inflight > prm.max_msgs) stc |= ST_OUT_OF_MODEL;
         if ((prm.inv_mask & 2) && g_decr(glob)) stc |= ST_INVARIANT | (1u << 8);
-        uint64_t any = 0, vl = 0;
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            const uint64_t x = s.get(W_VLOG(i, j));
-            any |= x;
-            vl += hvlog(x, i, j);
-        }
+        (void)s;
         const uint64_t salt = salt_of((unsigned)W_SRV(i));
-        const uint64_t base = l.fp + l.add_fp - vl - hmum(osv, salt);
-        const bool still = !l.nadd && any == 0;  // nothing but the scalars can differ from the parent
+        const uint64_t base = l.fp + l.add_fp - l.vlh.get(i) - hmum(osv, salt);
+        const bool still = !l.nadd && !(l.vany >> i & 1u);  // nothing but the scalars can differ from the parent
         // Restart(i): always enabled
         const uint64_t svR = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(osv, R_FOLLOWER), 0), 0), 1);
         stR = stc;
@@ -940,7 +1081,16 @@ struct SpecRaft {
             for (int w = 0; w < nw; w++) out.set(w, s.get(w));
             return st;
         }
-        out.set(W_FP, KNOWN ? fp_known : delta_fp(l, s, d));
+        // The arena is both source and destination, so the compiler keeps every load behind every earlier store: a loop of
+        // "read a parent word, write it" is one memory round trip per word (36 in a row: k_materialise spent 90 % of its time
+        // waiting).  The parent's words are therefore read in GROUPS, each group before its own stores.
+        const uint64_t fp_out = KNOWN ? fp_known : delta_fp(l, s, d);
+        uint64_t vl[NS * NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) vl[i * NS + j] = s.get(W_VLOG(i, j));
+        out.set(W_FP, fp_out);
         out.set(W_GLOB, d.glob);
         out.set(W_CLOG, d.clog);
 #pragma unroll
@@ -950,33 +1100,68 @@ struct SpecRaft {
             out.set(W_LOG(i), me ? d.log : l.log.get(i));
 #pragma unroll
             for (int j = 0; j < NS; j++) {
-                uint64_t x = s.get(W_VLOG(i, j));
+                uint64_t x = vl[i * NS + j];
                 if (me && d.vmode == 1) x = 0;
                 if (me && d.vmode == 2 && j == d.vj) x = d.vlog;
                 out.set(W_VLOG(i, j), x);
             }
         }
         const int nm2 = g_nm(d.glob);
-        for (int k = 0; k < prm.cm; k++) {
-            uint64_t x = k < l.nm ? s.get(W_MSG0 + k) : 0;
-            if ((d.nmop & 1) && d.midxA == k) x = d.mnewA;
-            if ((d.nmop & 2) && d.midxB == k) x = d.mnewB;
-            out.set(W_MSG0 + k, k < nm2 ? x : 0);
+        for (int k0 = 0; k0 < prm.cm; k0 += 4) {
+            uint64_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) x[u] = s.get(W_MSG0 + (k0 + u < l.nm ? k0 + u : 0));  // slot 0 exists whatever nMsgs is
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = k0 + u;
+                if (k < prm.cm) {
+                    uint64_t v = k < l.nm ? x[u] : 0;
+                    if ((d.nmop & 1) && d.midxA == k) v = d.mnewA;
+                    if ((d.nmop & 2) && d.midxB == k) v = d.mnewB;
+                    out.set(W_MSG0 + k, k < nm2 ? v : 0);
+                }
+            }
         }
         const int ne = g_ne(l.glob), wel = W_EL0(prm);
-        for (int e = 0; e < prm.ce; e++)
+        for (int e = 0; e < prm.ce; e++) {
+            uint64_t x[EL_WORDS];
+#pragma unroll
+            for (int q = 0; q < EL_WORDS; q++) x[q] = s.get(wel + (e < ne ? e : 0) * EL_WORDS + q);
 #pragma unroll
             for (int q = 0; q < EL_WORDS; q++) {
-                uint64_t x = e < ne ? s.get(wel + e * EL_WORDS + q) : 0;
-                if (d.eadd && e == ne) x = d.ew.get(q);
-                out.set(wel + e * EL_WORDS + q, x);
+                uint64_t v = e < ne ? x[q] : 0;
+                if (d.eadd && e == ne) v = d.ew.get(q);
+                out.set(wel + e * EL_WORDS + q, v);
             }
+        }
         const int na = g_na(l.glob), wall = W_ALL0(prm);
-        for (int a = 0; a < prm.ca; a++) out.set(wall + a, a < na ? s.get(wall + a) : 0);
-        int pos = na;
+        // allLogs' = allLogs with the logs of `addmask` appended (raft.tla:493)
+        uint64_t add[NS];
+        int nadd = 0;
+#pragma unroll
+        for (int i = 0; i < NS; i++) add[i] = 0;
 #pragma unroll
         for (int i = 0; i < NS; i++)
-            if (l.addmask >> i & 1) { if (pos < prm.ca) out.set(wall + pos, l.log.get(i)); pos++; }
+            if (l.addmask >> i & 1) {
+#pragma unroll
+                for (int q = 0; q < NS; q++) if (q == nadd) add[q] = l.log.get(i);
+                nadd++;
+            }
+        for (int a0 = 0; a0 < prm.ca; a0 += 4) {
+            uint64_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) x[u] = s.get(wall + (a0 + u < na ? a0 + u : 0));
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int a = a0 + u;
+                if (a < prm.ca) {
+                    uint64_t v = a < na ? x[u] : 0;
+#pragma unroll
+                    for (int q = 0; q < NS; q++) if (a == na + q && q < nadd) v = add[q];
+                    out.set(wall + a, v);
+                }
+            }
+        }
         return st;
     }
 
