@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
     ap.add_argument("--direct", action="store_true", help="A/B: one kernel per chunk (k_expand_direct: expand + insert + copy-and-patch write)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: Restart / Timeout through the family queues instead of inline")
+    ap.add_argument("--no-filter", action="store_true", help="A/B: without the per-wavefront duplicate filter in front of the seen-set")
     ap.add_argument("--occ3", action="store_true", help="A/B: k_expand_direct compiled for 3 waves per SIMD (no register spills)")
     a = ap.parse_args()
 
@@ -88,7 +89,7 @@ def main():
     G0 = golden()
     if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << a.table_log2, matrix=a.matrix,
-                         debug_flags=(32 if a.no_family else 0) | (1024 if a.direct else 0) | (2048 if a.occ3 else 0) | (32768 if a.no_dense else 0),
+                         debug_flags=(32 if a.no_family else 0) | (1024 if a.direct else 0) | (2048 if a.occ3 else 0) | (32768 if a.no_dense else 0) | (8192 if a.no_filter else 0),
                          arena_capacity=G0["distinct"] + (1 << 20),
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run

@@ -129,7 +129,7 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
             typename S::Guards g2;
             S::load_expand(p, s, l2, g2);
             bool same = l2.fp == l.fp && l2.glob == l.glob && l2.clog == l.clog && l2.nm == l.nm && l2.inflight == l.inflight &&
-                        l2.addmask == l.addmask && l2.nadd == l.nadd && l2.add_fp == l.add_fp && l2.vany == l.vany &&
+                        l2.addmask == l.addmask && l2.nadd == l.nadd && l2.add_fp == l.add_fp && l2.vany == l.vany && l2.dig == l.dig &&
                         l2.sig.w0 == l.sig.w0 && l2.sig.w1 == l.sig.w1 && l2.sig.w2 == l.sig.w2 && l2.sig.w3 == l.sig.w3 &&
                         g2.fixed == g.fixed && g2.terms == g.terms;
             for (int i = 0; i < p.n; i++) same = same && l2.sv.get(i) == l.sv.get(i) && l2.log.get(i) == l.log.get(i) && l2.vlh.get(i) == l.vlh.get(i);

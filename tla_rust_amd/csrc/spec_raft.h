@@ -283,7 +283,12 @@ struct SpecRaft {
         uint64_t cache_hm;
         RegArr<NS> vlh;        // sum_j H(voterLog[i][j]) per server and ...
         unsigned vany;         // ... bit i: voterLog[i] has an entry (dense Restart / Timeout pairs; filled when WANT_FP)
+        uint64_t dig;          // 11 bits per server: state[0,2) currentTerm[2,5) LastTerm(log)[5,8) Len(log)[8,11) — all that
+                               // RequestVote(i, j) reads of server i (raft.tla:209-217): a quarter of all pairs needs no arena word
     };
+    MC_HD static uint64_t digest_of(uint64_t sv, uint64_t lg) {
+        return (uint64_t)sv_state(sv) | (uint64_t)sv_term(sv) << 2 | (uint64_t)rlog::last_term(lg) << 5 | (uint64_t)rlog::len(lg) << 8;
+    }
     // WANT_FP = false: the caller never computes a fingerprint from this cache (k_materialise with a known one)
     template <bool WANT_FP = true, class Ref>
     MC_HD static void load(const Params &prm, Ref s, Local &l) {
@@ -347,6 +352,9 @@ struct SpecRaft {
         l.addmask = 0;
         l.nadd = 0;
         l.add_fp = 0;
+        l.dig = 0;
+#pragma unroll
+        for (int i = 0; i < NS; i++) l.dig |= digest_of(l.sv.get(i), l.log.get(i)) << (11 * i);
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             bool skip = (present >> i & 1) != 0;
@@ -478,9 +486,10 @@ struct SpecRaft {
             const int q = slot - (5 * NS + NS * NS); i = q / NS; j = q % NS;
         }
         // (slot >= FIX: i differs per lane, the words are read from the read-only state, never select-indexed from the register copy)
-        // Duplicate / Drop are about the message alone
-        const uint64_t svi = slot >= FIX ? (kind == 0 ? s.get(W_SRV(i)) : 0ull) : srv_word<MEM>(l, s, i);
-        const uint64_t lgi = slot >= FIX ? (kind == 0 ? s.get(W_LOG(i)) : 0ull) : log_word<MEM>(l, s, i);
+        // Duplicate / Drop are about the message alone; a RequestVote pair evaluated by another lane (MEM) reads the digest
+        constexpr bool BY_DIGEST = MEM && FAM == F_REQVOTE;
+        const uint64_t svi = slot >= FIX ? (kind == 0 ? s.get(W_SRV(i)) : 0ull) : BY_DIGEST ? 0ull : srv_word<MEM>(l, s, i);
+        const uint64_t lgi = slot >= FIX ? (kind == 0 ? s.get(W_LOG(i)) : 0ull) : BY_DIGEST ? 0ull : log_word<MEM>(l, s, i);
         bool want_send = false;
         uint64_t skey = 0;
         // ---- (3): the action
@@ -500,9 +509,10 @@ struct SpecRaft {
             d.vmode = 1;
         } else if (MC_FAM(F_REQVOTE) && slot >= 2 * NS && slot < 2 * NS + NS * NS) {  // RequestVote(i, j)   raft.tla:209-217
             action = RA_REQUESTVOTE;
-            if (sv_state(svi) != R_CANDIDATE) return 0;
+            const unsigned dg = BY_DIGEST ? (unsigned)(l.dig >> (11 * i)) & 2047u : (unsigned)digest_of(svi, lgi);
+            if ((int)(dg & 3u) != R_CANDIDATE) return 0;
             want_send = true;
-            skey = mk_rvreq(sv_term(svi), rlog::last_term(lgi), rlog::len(lgi), i, j);
+            skey = mk_rvreq((int)(dg >> 2 & 7u), (int)(dg >> 5 & 7u), (int)(dg >> 8 & 7u), i, j);
         } else if (MC_FAM(F_BECOME) && slot >= 2 * NS + NS * NS && slot < 3 * NS + NS * NS) {  // BecomeLeader(i)   raft.tla:247-261
             action = RA_BECOMELEADER;
             if (sv_state(svi) != R_CANDIDATE || !in_quorum(sv_granted(svi))) return 0;
@@ -828,7 +838,7 @@ struct SpecRaft {
         finish_local<true>(l, present);
     }
     // what a lane evaluating a pair needs to know about the pair's parent beyond the words it reads itself (computed once by the
-    // parent's lane, kept in LDS: 32 B per parent): the fingerprint every successor starts from, the globals (all of its fields
+    // parent's lane, kept in LDS: 40 B per parent): the fingerprint every successor starts from, the globals (all of its fields
     // lie in the low 32 bits), the key signatures and the allLogs' bookkeeping.  committedLog is read from the arena by the one
     // kind that needs it (AdvanceCommitIndex).
     struct Summary {
@@ -836,15 +846,16 @@ struct SpecRaft {
         Sigs sig;
         uint32_t packed;   // nm[0,8) inflight[8,16) nadd[16,20) addmask[20,28)
         uint32_t glob;
+        uint64_t dig;      // Local::dig
     };
     MC_HD static void summarize(const Local &l, Summary &q) {
-        q.base_fp = l.fp + l.add_fp; q.sig = l.sig; q.glob = (uint32_t)l.glob;
+        q.base_fp = l.fp + l.add_fp; q.sig = l.sig; q.glob = (uint32_t)l.glob; q.dig = l.dig;
         q.packed = (uint32_t)l.nm | (uint32_t)l.inflight << 8 | (uint32_t)l.nadd << 16 | l.addmask << 20;
     }
     // FAM = the queue the pair was taken from: only kinds that read or write committedLog load it
     template <int FAM, class Ref>
     MC_HD static void local_of_summary(const Summary &q, Ref s, Local &l) {
-        l.fp = q.base_fp; l.add_fp = 0; l.glob = q.glob; l.sig = q.sig;
+        l.fp = q.base_fp; l.add_fp = 0; l.glob = q.glob; l.sig = q.sig; l.dig = q.dig;
         l.clog = (FAM < 0 || FAM == F_MISC) ? s.get(W_CLOG) : 0ull;  // other kinds copy it: d.clog = l.clog, never hashed
         l.nm = (int)(q.packed & 255u); l.inflight = (int)(q.packed >> 8 & 255u); l.nadd = (int)(q.packed >> 16 & 15u);
         l.addmask = q.packed >> 20 & 255u;
@@ -1066,8 +1077,122 @@ struct SpecRaft {
     static constexpr bool KNOWN_FP = true;
     template <class Ref>
     MC_HD static unsigned apply_known_fp(const Params &prm, Ref s, int slot, uint64_t fp_nz, WordRef out) {
-        if (fp_nz == fp_nonzero(0)) return apply_impl<false>(prm, s, slot, 0, out);
-        return apply_impl<true>(prm, s, slot, fp_nz, out);
+        if (fp_nz == fp_nonzero(0)) return apply_copy_patch<false>(prm, s, slot, 0, out);
+        return apply_copy_patch<true>(prm, s, slot, fp_nz, out);
+    }
+    // k_materialise's writer: COPY the parent row while reading it once — every group of loads is followed by the stores of the
+    // same words, and the per-parent cache (in-flight count, key signatures, allLogs' additions) is computed from the registers
+    // the copy passes through — then evaluate the action and PATCH the handful of words it changes.  Eight memory round trips
+    // per new state instead of sixteen (apply_impl reads the row for the cache, then again word by word for the output).
+    // Same result as apply_impl (tests/_shim compares the two on every successor of every lowering test).
+    template <bool KNOWN, class Ref>
+    MC_HD static unsigned apply_copy_patch(const Params &prm, Ref s, int slot, uint64_t fp_known, WordRef out) {
+        Local l;
+        l.fp = KNOWN ? 0ull : s.get(W_FP);
+        l.glob = s.get(W_GLOB);
+        l.clog = s.get(W_CLOG);
+        uint64_t vl[NS * NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            l.sv.set(i, s.get(W_SRV(i)));
+            l.log.set(i, s.get(W_LOG(i)));
+#pragma unroll
+            for (int j = 0; j < NS; j++) vl[i * NS + j] = s.get(W_VLOG(i, j));
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) out.set(W_VLOG(i, j), vl[i * NS + j]);
+        l.nm = g_nm(l.glob);
+        l.inflight = 0;
+        uint32_t sw[4] = {SIG_EMPTY, SIG_EMPTY, SIG_EMPTY, SIG_EMPTY};
+        for (int k0 = 0; k0 < prm.cm; k0 += 8) {
+            uint64_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = s.get(W_MSG0 + (k0 + u < l.nm ? k0 + u : 0));  // slot 0 exists whatever nMsgs is
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + u;
+                if (k < l.nm) {
+                    l.inflight += m_count(x[u]);
+                    if (k0 < SIG_SLOTS) {
+                        const uint32_t sg = key_sig(x[u]) << (8 * (u & 3)), mk = ~(0xffu << (8 * (u & 3)));
+                        const int wi = (k0 >> 2) + (u >> 2);  // k0 is 0 or 8 here
+                        if (wi == 0) sw[0] = (sw[0] & mk) | sg;
+                        if (wi == 1) sw[1] = (sw[1] & mk) | sg;
+                        if (wi == 2) sw[2] = (sw[2] & mk) | sg;
+                        if (wi == 3) sw[3] = (sw[3] & mk) | sg;
+                    }
+                }
+                if (k < prm.cm) out.set(W_MSG0 + k, k < l.nm ? x[u] : 0ull);
+            }
+        }
+        l.sig = Sigs{sw[0], sw[1], sw[2], sw[3]};
+        const int ne = g_ne(l.glob), wel = W_EL0(prm);
+        for (int e = 0; e < prm.ce; e++) {
+            uint64_t x[EL_WORDS];
+#pragma unroll
+            for (int q = 0; q < EL_WORDS; q++) x[q] = s.get(wel + (e < ne ? e : 0) * EL_WORDS + q);
+#pragma unroll
+            for (int q = 0; q < EL_WORDS; q++) out.set(wel + e * EL_WORDS + q, e < ne ? x[q] : 0ull);
+        }
+        unsigned present = 0;
+        const int na = g_na(l.glob), wall = W_ALL0(prm);
+        for (int a0 = 0; a0 < prm.ca; a0 += 4) {
+            uint64_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) x[u] = s.get(wall + (a0 + u < na ? a0 + u : 0));
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int a = a0 + u;
+                if (a < na) {
+#pragma unroll
+                    for (int i = 0; i < NS; i++) if (x[u] == l.log.get(i)) present |= 1u << i;
+                }
+                if (a < prm.ca) out.set(wall + a, a < na ? x[u] : 0ull);
+            }
+        }
+        l.vany = 0;
+        finish_local<!KNOWN>(l, present);
+        // ---- the action
+        Delta d;
+        int action;
+        const unsigned st = compute<true>(prm, l, s, slot, d, action);
+        if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) {  // not a successor: the parent itself (never the case in k_materialise)
+            out.set(W_FP, s.get(W_FP));
+            out.set(W_GLOB, l.glob);
+            out.set(W_CLOG, l.clog);
+#pragma unroll
+            for (int i = 0; i < NS; i++) { out.set(W_SRV(i), l.sv.get(i)); out.set(W_LOG(i), l.log.get(i)); }
+            return st;
+        }
+        // ---- patch
+        out.set(W_FP, KNOWN ? fp_known : delta_fp(l, s, d));
+        out.set(W_GLOB, d.glob);
+        out.set(W_CLOG, d.clog);
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const bool me = i == d.srv;
+            out.set(W_SRV(i), me ? d.sv : l.sv.get(i));
+            out.set(W_LOG(i), me ? d.log : l.log.get(i));
+        }
+        if (d.srv >= 0 && d.vmode == 1) {
+#pragma unroll
+            for (int j = 0; j < NS; j++) out.set(W_VLOG(d.srv, j), 0);
+        } else if (d.srv >= 0 && d.vmode == 2) {
+            out.set(W_VLOG(d.srv, d.vj), d.vlog);
+        }
+        if (d.nmop & 1) out.set(W_MSG0 + d.midxA, d.mnewA);
+        if (d.nmop & 2) out.set(W_MSG0 + d.midxB, d.mnewB);
+        if (d.eadd) {
+#pragma unroll
+            for (int q = 0; q < EL_WORDS; q++) out.set(wel + ne * EL_WORDS + q, d.ew.get(q));
+        }
+        int pos = na;
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+            if (l.addmask >> i & 1) { if (pos < prm.ca) out.set(wall + pos, l.log.get(i)); pos++; }
+        return st;
     }
     template <bool KNOWN, class Ref>
     MC_HD static unsigned apply_impl(const Params &prm, Ref s, int slot, uint64_t fp_known, WordRef out) {
