@@ -212,6 +212,20 @@ int mc_shard_materialise(mc_engine *e, const uint8_t *answers_back, uint8_t *sen
 int mc_shard_materialise_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint8_t *send_states,
                               uint64_t send_cap, uint64_t *send_counts);
 int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n);
+/* FIXED-CAPACITY rounds of the "stay" form — nothing in a round waits for the host: every rank sends every rank a bucket of
+ * exactly `cap` words, word 0 = the number of fingerprints that follow (in band: no size message, no device-to-host copy
+ * before the payload all-to-all can be sized), so the two collectives of a round are equal-split all-to-alls of cap words and
+ * cap bytes per peer.
+ *   _expand_pack(slot, send_fp[shard_count * cap], cap): after mc_shard_expand_launch(slot, ...) — orders itself behind the
+ *       expand kernel with an event and packs owner t's candidates into send_fp[t * cap + 1 ...], count in send_fp[t * cap];
+ *   _probe_pack(recv_fp[shard_count * cap], cap, answers[shard_count * cap]): bucket s came from rank s; answers keep the
+ *       positions and are 0 outside a bucket's count;
+ *   _keep_pack(slot, answers_back[shard_count * cap], cap): the sender materialises its positively answered candidates.
+ * cap must be the same on every rank (derive it from the level's frontier sizes, which every rank knows).  A bucket that
+ * does not fit is not truncated: the level fails with MC_EARENA at mc_shard_end_level ("an exchange bucket is full"). */
+int mc_shard_expand_pack(mc_engine *e, uint32_t slot, uint64_t *send_fp, uint64_t cap);
+int mc_shard_probe_pack(mc_engine *e, const uint64_t *recv_fp, uint64_t cap, uint8_t *answers);
+int mc_shard_keep_pack(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t cap);
 /* "stay" alternative to materialise + all-to-all + ingest: the positively answered candidates of the last
  * mc_shard_expand are materialised into THIS rank's frontier (only fingerprints crossed xGMI).  The caller
  * uses it once the frontier is large enough to stay balanced, and falls back to the moving form to rebalance. */

@@ -36,19 +36,20 @@ def main():
         chk = ShardedChecker(spec, params, engine=eng, chunk_states=opts.get("chunk", 1000), max_distinct=opts.get("max_distinct", 0),
                              max_levels=opts.get("max_levels", 0), fanout_cap=opts.get("fanout_cap", 64), new_cap=opts.get("new_cap", 64),
                              stay_threshold=opts.get("stay_threshold", 1 << 16), rebalance_ratio=opts.get("rebalance_ratio", 1.25),
-                             replicate_until=opts.get("replicate_until", 0))
+                             replicate_until=opts.get("replicate_until", 0), packed=opts.get("packed", True))
     else:
         chk = ShardedChecker(spec, params, device=0, chunk_states=opts.get("chunk", 1 << 14), max_distinct=opts.get("max_distinct", 0),
                              max_levels=opts.get("max_levels", 0), table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
                              fanout_cap=opts.get("fanout_cap", 32), new_cap=opts.get("new_cap", 16),
                              stay_threshold=opts.get("stay_threshold", 1 << 16), rebalance_ratio=opts.get("rebalance_ratio", 1.25),
-                             replicate_until=opts.get("replicate_until", 0))
+                             replicate_until=opts.get("replicate_until", 0), packed=opts.get("packed", True), trace=opts.get("trace", False))
     r = chk.run()
+    trace = chk.counterexample() if opts.get("trace") else None
     _, local, _ = chk.eng.counters()
     shares = [None] * world
     dist.all_gather_object(shares, local)
     if rank == 0:
-        Path(out).write_text(json.dumps(dict(r, shares=shares, phases={k: v for k, v in chk.phase_s.items() if k.endswith("levels")})))
+        Path(out).write_text(json.dumps(dict(r, shares=shares, trace=trace, phases={k: v for k, v in chk.phase_s.items() if k.endswith("levels")})))
     chk.close()
     dist.destroy_process_group()
 

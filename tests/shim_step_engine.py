@@ -80,6 +80,42 @@ class ShimStepEngine:
         self._ck(self.lib.shim_shard_keep(self.h, slot, answers_back.data_ptr(), C.byref(n)), "keep")
         return n.value
 
+    # fixed-capacity rounds, emulated on top of the variable-size step calls: packs / unpacks the in-band layout of
+    # include/tlamc.h mc_shard_*_pack, so that the exchange loop of tla_rust_amd/sharded.py runs unchanged under gloo
+    def expand_pack(self, slot, send_fp, cap):
+        P = self.world
+        tmp = torch.zeros(P * cap, dtype=torch.int64)
+        counts = self.expand_finish(slot, tmp)
+        assert max(counts) + 1 <= cap, "exchange bucket overflow"
+        packed = torch.zeros(P * cap, dtype=torch.int64)
+        off = 0
+        for t in range(P):
+            packed[t * cap] = counts[t]
+            packed[t * cap + 1: t * cap + 1 + counts[t]] = tmp[off: off + counts[t]]
+            off += counts[t]
+        send_fp[: P * cap] = packed
+        self._pack_counts = getattr(self, "_pack_counts", {})
+        self._pack_counts[slot] = counts
+
+    def probe_pack(self, recv_fp, cap, answers):
+        P = self.world
+        answers[: P * cap] = 0
+        for s_ in range(P):
+            n = int(recv_fp[s_ * cap])
+            if n:
+                fps = recv_fp[s_ * cap + 1: s_ * cap + 1 + n].contiguous()
+                ans = torch.zeros(n, dtype=torch.uint8)
+                self.probe(fps, n, ans)
+                answers[s_ * cap + 1: s_ * cap + 1 + n] = ans
+
+    def keep_pack(self, slot, answers_back, cap):
+        counts = self._pack_counts[slot]
+        parts = [answers_back[t * cap + 1: t * cap + 1 + counts[t]] for t in range(self.world)]
+        flat = torch.cat(parts).contiguous() if sum(counts) else torch.zeros(1, dtype=torch.uint8)
+        for t in range(self.world):  # answers outside the counts must be 0 (the HIP sender scans the whole packed range)
+            assert int(answers_back[t * cap]) == 0 and int(answers_back[t * cap + 1 + counts[t]: (t + 1) * cap].sum()) == 0
+        self.keep(slot, flat)
+
     def end_level(self):
         n = C.c_uint64()
         self.lib.shim_shard_end_level(self.h, C.byref(n))

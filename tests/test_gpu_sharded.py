@@ -34,13 +34,52 @@ def test_two_ranks_on_one_gpu_equal_oracle(oracle, tmp_path, spec, params, opts)
     assert sum(r["shares"]) == o["distinct"]
 
 
-def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path):
+@pytest.mark.parametrize("packed", [True, False])
+def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path, packed):
+    """packed: mc_shard_expand_pack / _probe_pack / _keep_pack (fixed-capacity buckets, counts in band, no host wait in a round)"""
     params = [3, 2, 2, 9, 1, 1]
     o = oracle.oracle_run("raft", params, max_distinct=300000)
     r = run_dist("hip", 2, "raft", params, tmp_path, {"max_distinct": 300000, "chunk": 1 << 14, "table": 1 << 22, "arena": 1 << 20,
-                                                       "stay_threshold": 200, "rebalance_ratio": 1.5})
+                                                       "stay_threshold": 200, "rebalance_ratio": 1.5, "packed": packed})
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["phases"].get("stay_levels", 0) >= 3
+
+
+@pytest.mark.parametrize("world,replicate_until", [(2, 0), (3, 0), (3, 40)])
+def test_counterexample_walked_back_across_ranks(oracle, tmp_path, world, replicate_until):
+    """README.md:267-321 on several ranks with MC_F_TRACE engines: the parents of states that moved to their owner travelled
+    with them (mc_shard_materialise_parents / _ingest_parents), and the failing Assert's behaviour is rebuilt by walking
+    (rank, index) pointers with mc_shard_fetch — no single-GPU re-run.  Shortest length (the oracle's), the README's last state."""
+    params = [1, 0, 20, 2]   # the README variant: money 1..20, the assertion fails
+    o = oracle.oracle_run("pcal_intro", params)
+    r = run_dist("hip", world, "pcal_intro", params, tmp_path, {"chunk": 512, "trace": True, "replicate_until": replicate_until})
+    assert r["verdict"] == "assert" == o["verdict"]
+    tr = r["trace"]
+    assert tr is not None and len(tr) == len(o["trace"]) == 6
+    assert tr[0][0] == "Initial predicate" and all(isinstance(a, str) and a and a != "?" for a, _ in tr)
+    # README.md:305-311: the state the Assert fails in — alice overdrawn, one process at C (which of the equally short
+    # behaviours is found depends on which rank reports first: money = <<1, 10>> in the README, any <<m, 10>> with m < 10 here)
+    assert "alice_account = -" in tr[-1][1] and '"C"' in tr[-1][1].split("pc = ")[1].split("\n")[0]
+    assert len({t for _, t in tr}) == 6
+
+
+@pytest.mark.parametrize("spec,params,last", [("pcal_intro", [1, 1, 20, 2], "account_total"), ("ssi", [2, 2, 127, 3], "history")])
+def test_invariant_counterexample_across_ranks(oracle, tmp_path, spec, params, last):
+    """an INVARIANT violated by a successor (pcal_intro's MoneyInvariant, README variant: the violating state is stored nowhere,
+    it is rebuilt from its parent with mc_state_apply) and one found when the state is expanded (the SI models' expected
+    violations: SLOT_PARENT), three ranks, move and stay levels: the oracle's shortest length, a behaviour without repeats"""
+    o = oracle.oracle_run(spec, params)
+    assert o["verdict"] == "invariant"
+    r = run_dist("hip", 3, spec, params, tmp_path, {"chunk": 256, "trace": True, "stay_threshold": 40, "rebalance_ratio": 2.5}, timeout=900)
+    assert r["verdict"] == "invariant"
+    tr = r["trace"]
+    assert tr is not None and len(tr) == len(o["trace"]) and len({t for _, t in tr}) == len(tr)
+    assert tr[0][0] == "Initial predicate" and all(a and a != "?" for a, _ in tr) and last in tr[-1][1]
+    if spec == "pcal_intro":   # MoneyInvariant == alice_account + bob_account = account_total: broken in the last state only
+        def broken(text):
+            v = {ln.split(" = ")[0].strip("/\\ "): ln.split(" = ")[1] for ln in text.splitlines() if " = " in ln}
+            return int(v["alice_account"]) + int(v["bob_account"]) != int(v["account_total"])
+        assert broken(tr[-1][1]) and not any(broken(t) for _, t in tr[:-1])
 
 
 @pytest.mark.parametrize("world", [4, 8])
@@ -103,9 +142,13 @@ def test_multi_gpu_front_door(world):
     assert p.returncode == 0 and "58 distinct states found" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
     p = _mc_multi(world, S / "readme_variant" / "pcal_intro.tla", *small)                                # README.md:267-321: the assertion fails
     assert "Assert evaluated to FALSE" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
-    # the counterexample comes from a one-GPU re-run bounded to the error's depth: the README's 6-state behavior
-    assert '"Failure of assertion at line 16, column 4."' in p.stdout and p.stdout.count("\nState ") == 6       # README.md:269-311
-    assert "counterexample rebuilt by a one-GPU run" in p.stdout
+    # the behaviour is walked back across the ranks' arenas (no one-GPU re-run): the README's 6 states, ending where the Assert fails
+    assert "Error: The behavior up to this point is:" in p.stdout and p.stdout.count("\nState ") == 6       # README.md:270-311
+    assert "State 1: <Initial predicate>" in p.stdout and "alice_account = -" in p.stdout.split("State 6:")[1]
+    assert "one-GPU run" not in p.stdout
+    if world == 1:   # -rerun: the one-GPU report with TLC's positions on top
+        q = _mc_multi(world, S / "readme_variant" / "pcal_intro.tla", "-rerun", *small)
+        assert '"Failure of assertion at line 16, column 4."' in q.stdout and "counterexample rebuilt by a one-GPU run" in q.stdout
     if world == 1:
         assert p.returncode == 12                     # TLC's exit code for a safety violation
     else:                                             # every rank exits 12; the launcher itself reports 1

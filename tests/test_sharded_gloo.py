@@ -63,13 +63,16 @@ def test_sharded_budget_stop_checks_the_last_level(oracle, shim, tmp_path, repli
     assert r["verdict"] == "budget" and r["depth"] == L - 1
 
 
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("world", [2, 3])
-def test_stay_mode_counts_equal_oracle(oracle, shim, tmp_path, world):
+def test_stay_mode_counts_equal_oracle(oracle, shim, tmp_path, world, packed):
     """States stay on the generating rank once the frontier is large (threshold lowered to 50 states per rank
-    here, loose rebalance ratio): only fingerprints and answers are exchanged; counts must not change."""
+    here, loose rebalance ratio): only fingerprints and answers are exchanged; counts must not change.
+    packed: fixed-capacity buckets with in-band counts (equal-split all-to-alls, no size exchange) / the host-paced rounds."""
     params = [2, 2, 2, 9, 2, 1]
     o = oracle.oracle_run("raft", params, max_distinct=60000)
-    r = run_dist("shim", world, "raft", params, tmp_path, {"max_distinct": 60000, "chunk": 2000, "stay_threshold": 50, "rebalance_ratio": 1.6})
+    r = run_dist("shim", world, "raft", params, tmp_path, {"max_distinct": 60000, "chunk": 2000, "stay_threshold": 50, "rebalance_ratio": 1.6,
+                                                           "packed": packed})
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["phases"].get("stay_levels", 0) >= 5 and r["phases"].get("move_levels", 0) >= 3
     assert sum(r["shares"]) == o["distinct"]

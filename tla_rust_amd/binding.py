@@ -105,6 +105,15 @@ def lib():
     L.mc_engine_checkpoint.argtypes = [C.c_void_p, C.c_char_p]
     L.mc_engine_restore.argtypes = [C.c_void_p, C.c_char_p]
     L.mc_shard_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.mc_shard_materialise_parents.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mc_shard_ingest_parents.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    L.mc_shard_violation.argtypes = [C.c_void_p, C.POINTER(C.c_int32), U64P, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.mc_shard_fetch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32), U64P, C.POINTER(C.c_uint32)]
+    L.mc_state_action.argtypes = [C.POINTER(SpecDesc), C.c_char_p, C.c_int32]
+    L.mc_state_apply.argtypes = [C.POINTER(SpecDesc), C.c_char_p, C.c_int32, C.c_char_p]
+    L.mc_shard_expand_pack.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    L.mc_shard_probe_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.mc_shard_keep_pack.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     L.mc_shard_materialise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, U64P]
     L.mc_shard_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.mc_shard_keep.argtypes = [C.c_void_p, C.c_void_p, U64P]
@@ -164,6 +173,21 @@ def state_format(spec, params, state: bytes):
     d = spec_desc(spec, params)
     n = _check(lib().mc_state_format(C.byref(d), state, buf, len(buf)), "mc_state_format")
     return buf.raw[:n].decode()
+
+
+def state_action_name(spec, params, state: bytes, slot: int):
+    """name of the action slot `slot` takes from the packed state (mc_state_action + mc_action_name)"""
+    d = spec_desc(spec, params)
+    a = _check(lib().mc_state_action(C.byref(d), state, slot), "mc_state_action")
+    return lib().mc_action_name(C.byref(d), a).decode()
+
+
+def state_apply(spec, params, state: bytes, slot: int):
+    """the successor slot `slot` produces from the packed state (host evaluation, mc_state_apply)"""
+    d = spec_desc(spec, params)
+    out = C.create_string_buffer(lib().mc_state_bytes(C.byref(d)))
+    _check(lib().mc_state_apply(C.byref(d), state, slot, out), "mc_state_apply")
+    return out.raw
 
 
 def _result(r: CResult):
@@ -280,6 +304,35 @@ class Engine:
         n = C.c_uint64()
         _check(lib().mc_shard_keep_slot(self._h, slot, answers_back_ptr, C.byref(n)), "mc_shard_keep")
         return n.value
+
+    # counterexamples of a sharded run (engine created with trace=True)
+    def shard_materialise_parents(self, slot, send_parents_ptr):
+        _check(lib().mc_shard_materialise_parents(self._h, slot, send_parents_ptr), "mc_shard_materialise_parents")
+
+    def shard_ingest_parents(self, recv_parents_ptr, n, src_rank):
+        _check(lib().mc_shard_ingest_parents(self._h, recv_parents_ptr, n, src_rank), "mc_shard_ingest_parents")
+
+    def shard_violation(self):
+        """(found, arena index, slot code, verdict name, invariant index) of this rank's first violation"""
+        f, i, sl, v, inv = C.c_int32(), C.c_uint64(), C.c_uint32(), C.c_int32(), C.c_int32()
+        _check(lib().mc_shard_violation(self._h, C.byref(f), C.byref(i), C.byref(sl), C.byref(v), C.byref(inv)), "mc_shard_violation")
+        return bool(f.value), i.value, sl.value, VERDICTS[v.value], inv.value
+
+    def shard_fetch(self, idx):
+        """(packed state, parent rank, parent index, parent slot) of the state at arena index idx of this rank"""
+        st = C.create_string_buffer(lib().mc_state_bytes(C.byref(self.desc)))
+        pr, pi, ps = C.c_uint32(), C.c_uint64(), C.c_uint32()
+        _check(lib().mc_shard_fetch(self._h, idx, st, C.byref(pr), C.byref(pi), C.byref(ps)), "mc_shard_fetch")
+        return st.raw, pr.value, pi.value, ps.value
+
+    def shard_expand_pack(self, slot, send_fp_ptr, cap):
+        _check(lib().mc_shard_expand_pack(self._h, slot, send_fp_ptr, cap), "mc_shard_expand_pack")
+
+    def shard_probe_pack(self, recv_fp_ptr, cap, answers_ptr):
+        _check(lib().mc_shard_probe_pack(self._h, recv_fp_ptr, cap, answers_ptr), "mc_shard_probe_pack")
+
+    def shard_keep_pack(self, slot, answers_back_ptr, cap):
+        _check(lib().mc_shard_keep_pack(self._h, slot, answers_back_ptr, cap), "mc_shard_keep_pack")
 
     def shard_end_level(self):
         n = C.c_uint64()

@@ -70,7 +70,7 @@ struct DevCounters {
     unsigned int max_slots;           // rows of the candidate matrix written by the current chunk
     unsigned int error;               // DEV_E* bits
 };
-enum : unsigned { DEV_ETABLE = 1u, DEV_EARENA = 2u, DEV_EOVERFLOW = 4u };
+enum : unsigned { DEV_ETABLE = 1u, DEV_EARENA = 2u, DEV_EOVERFLOW = 4u, DEV_EROUTE = 8u /* an exchange bucket of a sharded round is full */ };
 enum : unsigned { VK_INVARIANT = 1, VK_ASSERT = 2, VK_DEADLOCK = 3, VK_SPECERR = 4 };
 static constexpr unsigned SLOT_NONE = 0xffffu;      // deadlock: no slot
 static constexpr unsigned SLOT_INIT = 0xfffeu;      // an initial state violates an invariant
@@ -1186,6 +1186,50 @@ k_compact_buckets(RouteArgs rt, uint64_t *__restrict__ send_fp, uint32_t *__rest
         pend_src[off + j] = rt.rt_src[(uint64_t)bucket * rt.subcap + j];
     }
 }
+// FIXED-CAPACITY exchange (no size message, no host in the round): owner t's candidates go to send_fp[t * cap + 1 ...] and their
+// NUMBER into send_fp[t * cap] — in band, so the receiver learns it from the bucket itself; pend_src uses the same positions.
+// A bucket that does not fit raises DEV_EROUTE (reported at the end of the level: raise the caller's fan-out allowance).
+static __global__ void __launch_bounds__(256)
+k_compact_packed(RouteArgs rt, uint64_t cap, uint64_t *__restrict__ send_fp, uint32_t *__restrict__ pend_src, DevCounters *ctr) {
+    const unsigned bucket = blockIdx.y, owner = bucket / NSHARD;  // bucket = owner * NSHARD + shard
+    const uint64_t n = rt.cursors[bucket].v < rt.subcap ? rt.cursors[bucket].v : rt.subcap;
+    uint64_t off = 1, total = 0;
+    bool over = false;
+    for (unsigned b = owner * NSHARD; b < (owner + 1) * NSHARD; ++b) {
+        const uint64_t c = rt.cursors[b].v;
+        over |= c > rt.subcap;
+        const uint64_t cc = c < rt.subcap ? c : rt.subcap;
+        if (b < bucket) off += cc;
+        total += cc;
+    }
+    over |= total + 1 > cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bucket == owner * NSHARD) {
+        send_fp[(uint64_t)owner * cap] = over ? 0ull : total;
+        if (over) atomicOr(&ctr->error, DEV_EROUTE);
+    }
+    if (over) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, base = (uint64_t)owner * cap + off;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        send_fp[base + j] = rt.rt_fp[(uint64_t)bucket * rt.subcap + j];
+        pend_src[base + j] = rt.rt_src[(uint64_t)bucket * rt.subcap + j];
+    }
+}
+// owner side of the fixed-capacity exchange: bucket s of recv_fp came from rank s; answers keep the positions (0 outside a bucket's
+// count, so the sender can scan the whole buffer without knowing the counts)
+static __global__ void __launch_bounds__(256)
+k_probe_packed(const uint64_t *__restrict__ fps, uint64_t cap, uint64_t total, uint64_t *table, uint64_t mask, uint8_t *__restrict__ answers,
+               DevCounters *ctr) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned err = 0;
+    if (i < total) {
+        const uint64_t s0 = (i / cap) * cap, j = i - s0;
+        const uint64_t n = fps[s0] < cap ? fps[s0] : 0;  // (a count that cannot be: an overflowed bucket, already reported by its sender)
+        bool is_new = false;
+        if (j >= 1 && j <= n) is_new = seen_insert(table, mask, fps[i], err);
+        answers[i] = is_new ? 1 : 0;
+    }
+    if (wave_or_u32(err) && (threadIdx.x & 63) == 0) atomicOr(&ctr->error, DEV_ETABLE);
+}
 // owner side: insert received fingerprints, answer 1 = new
 static __global__ void __launch_bounds__(256)
 k_probe(const uint64_t *__restrict__ fps, uint64_t n, uint64_t *table, uint64_t mask, uint8_t *__restrict__ answers, DevCounters *ctr) {
@@ -1416,6 +1460,9 @@ struct EngineBase {
     virtual int shard_expand_launch(unsigned slot, uint64_t first, uint64_t count, uint64_t send_cap) = 0;
     virtual int shard_expand_finish(unsigned slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int shard_probe(const uint64_t *recv_fp, uint64_t n, uint8_t *answers) = 0;
+    virtual int shard_expand_pack(unsigned slot, uint64_t *send_fp, uint64_t cap) = 0;
+    virtual int shard_probe_pack(const uint64_t *recv_fp, uint64_t cap, uint8_t *answers) = 0;
+    virtual int shard_keep_pack(unsigned slot, const uint8_t *answers_back, uint64_t cap) = 0;
     virtual int shard_materialise(unsigned slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int shard_ingest(const uint8_t *recv_states, uint64_t n) = 0;
     virtual int shard_keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) = 0;
@@ -1590,6 +1637,7 @@ struct Engine : EngineBase {
     int check_dev_error() {
         if (h_ctr->error & DEV_EOVERFLOW) { set_error("packed-state capacity exceeded (raft messages / elections / allLogs slots, or a PlusCal sequence longer than its cells)"); return MC_EOVERFLOW; }
         if (h_ctr->error & DEV_ETABLE) { set_error("seen-set full: raise table_capacity"); return MC_ETABLEFULL; }
+        if (h_ctr->error & DEV_EROUTE) { set_error("sharded round: an exchange bucket is full (raise the fan-out allowance / send capacity)"); return MC_EARENA; }
         if (h_ctr->error & DEV_EARENA) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }
         return MC_OK;
     }
@@ -2294,6 +2342,58 @@ struct Engine : EngineBase {
         }, side());
         return side_done();
     }
+    // ---- fixed-capacity rounds: nothing of a round waits for the host (sizes travel in band; errors surface at shard_end_level)
+    hipEvent_t ev_exp[2] = {nullptr, nullptr};
+    int shard_expand_pack(unsigned slot, uint64_t *send_fp, uint64_t cap) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (slot > 1 || !sl[slot].launched) { set_error("shard_expand_pack: no expand in flight for this slot"); return MC_EBADCFG; }
+        ShSlot &q = sl[slot];
+        q.launched = false;
+        const unsigned P = nranks();
+        if (cap < 2 || (uint64_t)P * cap > q.pend_cap || (uint64_t)P * cap >= (1ull << 31)) { set_error("shard_expand_pack: capacity does not fit the slot's buffers"); return MC_EBADCFG; }
+        q.pend_total = (uint64_t)P * cap;  // the sender scans the whole packed range: answers outside the counts are 0
+        for (unsigned t = 0; t <= 8; t++) q.pend_off.off[t] = (t < P ? t : P) * cap;
+        if (!ev_exp[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_exp[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_exp[slot], stream));  // behind the slot's expand kernel (or behind nothing: an empty chunk)
+        HIP_TRY(hipStreamWaitEvent(side(), ev_exp[slot], 0));
+        if (q.keep_pending) {  // the slot's previous keep still reads pend_src
+            HIP_TRY(hipStreamWaitEvent(side(), ev_keep[slot], 0));
+            q.keep_pending = false;
+        }
+        if (q.count) {  // the chunk's locally owned new states (local-owner shortcut), as in shard_expand_finish
+            const unsigned bx = (unsigned)((q.ncols + 255) / 256);
+            const unsigned gm = bx < 8 * 256 ? (bx + 7) / 8 : 256;
+            HIP_TRY(hipStreamWaitEvent(stream2, ev_exp[slot], 0));
+            append_begin(stream2);
+            timed(2, 0, [&] {
+                hipLaunchKernelGGL(k_materialise<S>, dim3(gm ? gm : 1, NSHARD), dim3(256), 0, stream2, prm, d_arena, q.chunk_base, d_newlist, seg_cap,
+                                   arena_cap, d_parent, d_pslot, d_ctr, slot, (const LevelCtl *)nullptr, (const uint64_t *)d_newfp);
+            }, stream2);
+            hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream2, d_ctr, slot);
+            append_end(stream2);
+            RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
+            hipLaunchKernelGGL(k_compact_packed, dim3(64, P * NSHARD), dim3(256), 0, side(), rt, cap, send_fp, q.pend_src, d_ctr);
+        } else {  // no chunk for this rank in this round: empty buckets
+            for (unsigned t = 0; t < P; t++) HIP_TRY(hipMemsetAsync(send_fp + (uint64_t)t * cap, 0, sizeof(uint64_t), side()));
+        }
+        if (!ev_slot[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_slot[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_slot[slot], side()));
+        return side_done();
+    }
+    int shard_probe_pack(const uint64_t *recv_fp, uint64_t cap, uint8_t *answers) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        const uint64_t total = (uint64_t)nranks() * cap;
+        if (!total) return MC_OK;
+        timed(1, total, [&] {
+            hipLaunchKernelGGL(k_probe_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, side(), recv_fp, cap, total, d_table, table_cap - 1,
+                               answers, d_ctr);
+        }, side());
+        return side_done();
+    }
+    int shard_keep_pack(unsigned slot, const uint8_t *answers_back, uint64_t cap) override {
+        if (slot > 1 || sl[slot].pend_total != (uint64_t)nranks() * cap) { set_error("shard_keep_pack: not the capacity the slot was packed with"); return MC_EBADCFG; }
+        return shard_keep(slot, answers_back, nullptr);
+    }
     int shard_materialise(unsigned slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
         HIP_TRY(hipSetDevice(cfg.device));
         if (slot > 1) return MC_EBADCFG;
@@ -2770,6 +2870,13 @@ int mc_shard_materialise_slot(mc_engine *e, uint32_t slot, const uint8_t *answer
     return e && send_counts ? e->impl->shard_materialise(slot, answers_back, send_states, send_cap, send_counts) : MC_EBADCFG;
 }
 int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n) { return e ? e->impl->shard_ingest(recv_states, n) : MC_EBADCFG; }
+int mc_shard_expand_pack(mc_engine *e, uint32_t slot, uint64_t *send_fp, uint64_t cap) { return e && send_fp ? e->impl->shard_expand_pack(slot, send_fp, cap) : MC_EBADCFG; }
+int mc_shard_probe_pack(mc_engine *e, const uint64_t *recv_fp, uint64_t cap, uint8_t *answers) {
+    return e && recv_fp && answers ? e->impl->shard_probe_pack(recv_fp, cap, answers) : MC_EBADCFG;
+}
+int mc_shard_keep_pack(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t cap) {
+    return e && answers_back ? e->impl->shard_keep_pack(slot, answers_back, cap) : MC_EBADCFG;
+}
 int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new) { return e && n_new ? e->impl->shard_keep(0, answers_back, n_new) : MC_EBADCFG; }
 int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t *n_new) {
     return e ? e->impl->shard_keep(slot, answers_back, n_new) : MC_EBADCFG;

@@ -6,11 +6,12 @@
 One process per GPU (LOCAL_RANK), `torch.distributed` backend "nccl" (= RCCL over xGMI).  Every rank resolves X.tla / X.cfg
 through the C ABI exactly like the one-GPU `mc` (mc_resolve_files: same lowering registry, same text verification, same
 PlusCal compiler), creates its engine and runs tla_rust_amd.sharded.ShardedChecker; rank 0 prints TLC's report lines
-(reference README.md:319-320, testout2:260-266).  Counters, depth and verdict are those of the one-GPU run; a
-counterexample is not rebuilt across ranks (a state's parent may live on another GPU): on an error rank 0 re-runs the search
-on its own GPU bounded to the depth at which the sharded search found the error — a breadth-first search finds a shortest
-counterexample, so the bounded one-GPU run finds one of the same length — and prints that run's TLC report (error, behavior,
-counters); if those levels do not fit one GPU the report says so.
+(reference README.md:319-320, testout2:260-266).  Counters, depth and verdict are those of the one-GPU run.  A counterexample is
+rebuilt ACROSS ranks: the engines keep (rank, index, action) of every state's parent — a state that moves to its owner takes
+them along — and on an error the behaviour is walked back with one small broadcast per state (ShardedChecker.counterexample),
+printed in TLC's layout ("State k: <Action>" + the state, README.md:270-311; the <line, col> positions of the one-GPU report are
+not reproduced).  `-rerun` adds what round 1 did instead: rank 0 repeats the search on ONE GPU bounded to the error's depth and
+prints that run's full TLC report — only possible while those levels fit one GPU.
 Exit status of every rank: TLC's (0 / 12 safety violation / 11 deadlock); torch.distributed.run itself returns 1 when its
 ranks exit non-zero.  Without a launcher (no WORLD_SIZE) it runs one rank.  `-backend gloo -device 0` puts several ranks on ONE GPU (tests)."""
 import os
@@ -20,7 +21,7 @@ import time
 
 def parse(argv):
     o = dict(tla=None, config=None, maxdistinct=0, maxlevels=0, chunk=1 << 19, tablelog2=27, arena=1 << 25, backend="nccl", device=None,
-             generic=False, unverified=False)
+             generic=False, unverified=False, rerun=False)
     i = 0
     while i < len(argv):
         a = argv[i]
@@ -37,6 +38,9 @@ def parse(argv):
         elif a == "-unverified":
             o["unverified"] = True
             i += 1
+        elif a == "-rerun":
+            o["rerun"] = True
+            i += 1
         elif not a.startswith("-"):
             o["tla"] = a
             i += 1
@@ -47,7 +51,7 @@ def parse(argv):
     return o
 
 
-def report(r, world, seconds):
+def report(r, world, seconds, trace=None):
     """TLC's closing lines for a sharded run (format of README.md:319-320 / testout2:260-266)."""
     out = [f"Finished computing initial states: {r.levels[0] if r.levels else 0} distinct state{'' if r.levels and r.levels[0] == 1 else 's'} generated."]
     if r.verdict == "ok":
@@ -58,7 +62,14 @@ def report(r, world, seconds):
         what = {"invariant": "Error: Invariant is violated.", "assert": "Error: The first argument of Assert evaluated to FALSE.",
                 "deadlock": "Error: Deadlock reached.", "spec-error": "Error: TLC would raise an evaluation error."}[r.verdict]
         out.append(what)
-        out.append("The counterexample is not rebuilt across GPUs: run `mc` on one GPU for the behavior up to this point.")
+        if trace:
+            out.append("Error: The behavior up to this point is:")
+            for k, (action, text) in enumerate(trace):
+                out.append(f"State {k + 1}: <{action}>")
+                out.append(text.rstrip("\n"))
+                out.append("")
+        else:
+            out.append("(no behavior: the engines were created without parent pointers)")
     out.append(f"{r.generated} states generated, {r.distinct} distinct states found, {r.queue_left} states left on queue.")
     out.append(f"The depth of the complete state graph search is {r.depth}.")
     out.append(f"({world} GPU{'s' if world != 1 else ''}, {seconds:.3f} s, {r.distinct / max(seconds, 1e-9):.3g} distinct states/s)")
@@ -85,7 +96,7 @@ def main(argv=None):
     world = dist.get_world_size() if launched else 1
     rs = ResolvedSpec(o["tla"], o["config"], generic=o["generic"], unverified=o["unverified"])
     chk = ShardedChecker(rs.spec, rs.params, device=device, chunk_states=o["chunk"], max_distinct=o["maxdistinct"], max_levels=o["maxlevels"],
-                         table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"])
+                         table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"], trace=True)
     if launched:  # communicator set-up (RCCL builds its rings on the first collective) stays out of the reported time
         dist.all_reduce(torch.zeros(1, device="cpu" if o["backend"] == "gloo" else f"cuda:{device}"))
         torch.cuda.synchronize()
@@ -93,13 +104,14 @@ def main(argv=None):
     r = chk.run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    trace = chk.counterexample() if r.verdict not in ("ok", "budget") else None   # collective: every rank walks along
     chk.close()
     rs.close()
     if launched:
         dist.destroy_process_group()  # before rank 0's (possibly long) one-GPU re-run: the other ranks are done
     if rank == 0:
-        text = report(r, world, dt)
-        if r.verdict not in ("ok", "budget") and not o["generic"]:
+        text = report(r, world, dt, trace)
+        if r.verdict not in ("ok", "budget") and not o["generic"] and o["rerun"]:
             try:  # the counterexample: one GPU, the same search bounded to the error's depth
                 from . import check_files
                 one, rep = check_files(o["tla"], o["config"], device=device, max_levels=r.depth + 1, chunk_states=o["chunk"], unverified=o["unverified"],

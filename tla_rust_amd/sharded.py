@@ -28,17 +28,20 @@ import time
 import torch
 import torch.distributed as dist
 
-from .binding import Engine, Result, VERDICTS, state_bytes
+from .binding import Engine, Result, VERDICTS, state_action_name, state_apply, state_bytes, state_format
+
+SLOT_NONE, SLOT_INIT, SLOT_PARENT, SLOT_COPY = 0xFFFF, 0xFFFE, 0xFFFD, 0xFFFC  # slot codes of the engine (engine.hip)
+NO_PARENT = 0xFFFFFFFF
 
 
 class HipStepEngine:
     """mc_shard_* of include/tlamc.h on one GPU; buffers are torch CUDA tensors (plumbing only)."""
 
-    def __init__(self, spec, params, device, rank, world, chunk_states, table_capacity, arena_capacity):
+    def __init__(self, spec, params, device, rank, world, chunk_states, table_capacity, arena_capacity, trace=False):
         self.device = torch.device("cuda", device)
         self.W = state_bytes(spec, params)
         self.eng = Engine(spec, params, device=device, table_capacity=table_capacity, arena_capacity=arena_capacity,
-                          chunk_states=chunk_states, trace=False, timing=False, shard_rank=rank, shard_count=world)
+                          chunk_states=chunk_states, trace=trace, timing=False, shard_rank=rank, shard_count=world)
         # the stream the collectives are issued on; the engine enqueues its side work on it without host syncs
         self.stream = torch.cuda.Stream(self.device)
         self.eng.shard_set_stream(self.stream.cuda_stream)
@@ -73,6 +76,29 @@ class HipStepEngine:
     def keep(self, slot, answers_back):
         return self.eng.shard_keep(answers_back.data_ptr(), slot)
 
+    # counterexamples across ranks (engine created with trace=True): parents travel with the states that move
+    def materialise_parents(self, slot, send_parents):
+        self.eng.shard_materialise_parents(slot, send_parents.data_ptr())
+
+    def ingest_parents(self, recv_parents, n, src_rank):
+        self.eng.shard_ingest_parents(recv_parents.data_ptr(), n, src_rank)
+
+    def violation(self):
+        return self.eng.shard_violation()
+
+    def fetch(self, idx):
+        return self.eng.shard_fetch(idx)
+
+    # fixed-capacity rounds (include/tlamc.h mc_shard_*_pack): nothing waits for the host
+    def expand_pack(self, slot, send_fp, cap):
+        self.eng.shard_expand_pack(slot, send_fp.data_ptr(), cap)
+
+    def probe_pack(self, recv_fp, cap, answers):
+        self.eng.shard_probe_pack(recv_fp.data_ptr(), cap, answers.data_ptr())
+
+    def keep_pack(self, slot, answers_back, cap):
+        self.eng.shard_keep_pack(slot, answers_back.data_ptr(), cap)
+
     def end_level(self):
         return self.eng.shard_end_level()
 
@@ -92,7 +118,7 @@ class HipStepEngine:
 class ShardedChecker:
     def __init__(self, spec, params, device=0, chunk_states=1 << 19, max_distinct=0, max_levels=0, table_capacity=1 << 27,
                  arena_capacity=1 << 25, fanout_cap=32, new_cap=8, engine=None, group=None, stay_threshold=1 << 16,
-                 rebalance_ratio=1.25, replicate_until=1 << 15):
+                 rebalance_ratio=1.25, replicate_until=1 << 15, packed=True, packed_fanout=16, trace=False):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -109,8 +135,17 @@ class ShardedChecker:
         # level has replicate_until states per rank, then keeps the states of it whose fingerprint it owns; 0 = shard
         # from Init on.
         self.replicate_until = replicate_until
+        # "stay" rounds as fixed-capacity exchanges with in-band counts: the host only enqueues (no size all-to-all, no
+        # device-to-host copy inside a round); packed=False keeps the host-paced rounds (variable-size all-to-alls) for A/B
+        # packed_fanout: in-model successors per expanded state the fixed buckets allow for (the buckets are moved and scanned
+        # whole, so the allowance is tighter than fanout_cap, which only sizes buffers; a level that exceeds it fails loudly)
+        self.packed, self.packed_fanout = packed, min(packed_fanout, fanout_cap)
+        # trace: every state keeps (rank, index, slot) of its parent — a state that moves to its owner takes them along — so that
+        # a counterexample is walked back ACROSS ranks (counterexample()); costs 7 bytes per state and one more all-to-all per
+        # moving round
+        self.spec, self.params, self.trace = spec, list(params), trace
         self.eng = engine if engine is not None else HipStepEngine(spec, params, device, self.rank, self.world, chunk_states,
-                                                                    table_capacity, arena_capacity)
+                                                                    table_capacity, arena_capacity, trace=trace)
         self.dev = self.eng.device
         self.W = self.eng.W
         backend = dist.get_backend(group) if dist.is_initialized() else None
@@ -119,6 +154,7 @@ class ShardedChecker:
         # two expand slots: the expand of round r+1 runs while round r is exchanged, probed and kept
         self.send_fp = [torch.empty(chunk_states * fanout_cap, dtype=torch.int64, device=self.dev) for _ in range(2)]
         self.send_states = torch.empty(chunk_states * new_cap * self.W, dtype=torch.uint8, device=self.dev)
+        self.send_parents = torch.empty(chunk_states * new_cap if trace else 1, dtype=torch.int64, device=self.dev)
 
     # ---------------------------------------------------------------- collectives
     def _allreduce(self, value, op):
@@ -159,6 +195,15 @@ class ShardedChecker:
         src = send[: sum(send_counts)].to(self.comm_dev)
         recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=self.comm_dev)
         dist.all_to_all_single(recv, src, list(recv_counts), list(send_counts), group=self.group)
+        return recv.to(self.dev)
+
+    def _a2a_equal(self, send, n):
+        """equal-split all-to-all of the first n elements of `send` (n a multiple of the world size): fixed-capacity buckets"""
+        if not self.collective:
+            return send[:n]
+        src = send[:n].to(self.comm_dev)
+        recv = torch.empty(n, dtype=send.dtype, device=self.comm_dev)
+        dist.all_to_all_single(recv, src, group=self.group)
         return recv.to(self.dev)
 
     def _level_info(self, local_n, verdict):
@@ -219,6 +264,30 @@ class ShardedChecker:
             hold = []
             if rounds:
                 launch(0)
+            if stay and self.packed:
+                # every rank derives the same capacity from the level's frontier sizes: the largest chunk of the round times the
+                # fan-out allowance, split over the owners (+ slack and the count word)
+                P = self.world
+                for r in range(rounds):
+                    slot = r & 1
+                    n_round = max(min(self.chunk, max(n - r * self.chunk, 0)) for n in sizes)
+                    # a rank routes (P - 1) / P of its candidates, spread over P owners (its own share is probed locally)
+                    cap = min((n_round * self.packed_fanout * (P - 1)) // (P * P) + 1024, self.send_fp[slot].numel() // P)
+                    t = time.perf_counter()
+                    e.expand_pack(slot, self.send_fp[slot], cap)      # enqueued behind expand r: the host does not wait
+                    if r + 1 < rounds:
+                        launch(r + 1)
+                    recv_fp = self._a2a_equal(self.send_fp[slot], P * cap)
+                    t = tick("a2a_fp", t)
+                    answers = torch.empty(P * cap, dtype=torch.uint8, device=self.dev)
+                    e.probe_pack(recv_fp, cap, answers)
+                    t = tick("probe", t)
+                    back = self._a2a_equal(answers, P * cap)
+                    t = tick("a2a_ans", t)
+                    e.keep_pack(slot, back, cap)
+                    hold += [recv_fp, answers, back]                  # inputs of kernels still queued: freed after end_level
+                    t = tick("keep", t)
+                rounds = 0
             for r in range(rounds):
                 slot = r & 1
                 t = time.perf_counter()
@@ -245,12 +314,19 @@ class ShardedChecker:
                 blocks = [(c + 63) // 64 for c in scounts]
                 recv_states, rblocks = self._a2a(self.send_states, blocks, 64 * self.W)
                 rsc = self._exchange_counts(scounts)
+                recv_parents = None
+                if self.trace:   # (index on the sending rank << 16 | slot) of every moved state, same owner order, no block padding
+                    e.materialise_parents(slot, self.send_parents)
+                    recv_parents, _ = self._a2a(self.send_parents, scounts, 1)
                 t = tick("a2a_states", t)
-                off = 0
+                off = poff = 0
                 for src_rank in range(len(rsc)):            # one bucket per source rank
                     if rsc[src_rank]:
                         e.ingest(recv_states[off * 64 * self.W:], rsc[src_rank])
+                        if recv_parents is not None:
+                            e.ingest_parents(recv_parents[poff:], rsc[src_rank], src_rank)
                     off += rblocks[src_rank]
+                    poff += rsc[src_rank]
                 t = tick("ingest", t)
             new_local = e.end_level()                       # waits for the engine's streams; arena fill level comes back
             hold.clear()
@@ -271,6 +347,52 @@ class ShardedChecker:
             print("phases[s]:", {k: round(v, 4) for k, v in ph.items()}, flush=True)
         return Result(distinct=cum, generated=generated, queue_left=frontier, depth=level, verdict=VERDICTS[verdict],
                       violated_invariant=-1, trace_len=0, levels=levels, seconds=0.0)
+
+    # ---------------------------------------------------------------- counterexample
+    def counterexample(self):
+        """After a run that ended in a violation (trace=True): the behaviour that leads to it, walked back parent by parent
+        ACROSS ranks — the rank that holds a state looks it up and tells the others where its parent lives (one small
+        broadcast per step; a counterexample has tens of states).  Collective: every rank calls it and gets the same list
+        of (action name, TLA+ text of the state), first the initial state.  None when no rank found a violation."""
+        e = self.eng
+        mine = e.violation()   # (found, idx, slot, verdict, invariant)
+        if self.collective:
+            every = [None] * self.world
+            dist.all_gather_object(every, mine, group=self.group)
+        else:
+            every = [mine]
+        owners = [r for r, v in enumerate(every) if v[0]]
+        if not owners:
+            return None
+        owner = owners[0]
+        _, idx, vslot, _verdict, _inv = every[owner]
+        steps = []           # (packed state, slot that produced it), last state first
+        cur_rank, cur_idx = owner, idx
+        for _ in range(1 << 16):
+            obj = [e.fetch(cur_idx) if self.rank == cur_rank else None]
+            if self.collective:
+                src = dist.get_global_rank(self.group, cur_rank) if self.group is not None else cur_rank
+                dist.broadcast_object_list(obj, src=src, group=self.group)
+            state, prank, pidx, pslot = obj[0]
+            if pslot == SLOT_COPY:      # the replicated prefix copied the state into this rank's slice: not a step
+                cur_idx = pidx
+                continue
+            steps.append((state, pslot))
+            if pidx == NO_PARENT:
+                break
+            cur_rank, cur_idx = prank, pidx
+        steps.reverse()
+        out = []
+        for k, (state, pslot) in enumerate(steps):
+            name = "Initial predicate" if k == 0 else state_action_name(self.spec, self.params, steps[k - 1][0], pslot)
+            out.append((name, state_format(self.spec, self.params, state)))
+        # an invariant violated by a SUCCESSOR: that state is not stored anywhere, it is rebuilt from its parent.  (A failed
+        # Assert / an evaluation error has no successor: TLC's behaviour ends at the state the action was taken from.)
+        if _verdict == "invariant" and vslot not in (SLOT_NONE, SLOT_PARENT, SLOT_INIT):
+            last = steps[-1][0]
+            out.append((state_action_name(self.spec, self.params, last, vslot),
+                        state_format(self.spec, self.params, state_apply(self.spec, self.params, last, vslot))))
+        return out
 
     def close(self):
         self.eng.close()
