@@ -76,11 +76,9 @@ typedef struct {
 #define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
 #define MC_F_DIRECT 1024u /* A/B only: one kernel per chunk (expand + insert + copy-and-patch write, k_expand_direct) instead of
                           * expand and materialise on two streams; measured slower, kept for the comparison */
-#define MC_F_FAMBLOCKS4 4096u /* A/B only: the by-family expand kernel works through 4 (default 1) arena blocks per wavefront */
 #define MC_F_NODENSE 32768u  /* A/B only: Restart / Timeout slots of raft through the family queues instead of inline, lane = parent */
-#define MC_F_OCC5 2048u      /* A/B only: by-family expand kernel compiled for 5 wavefronts per SIMD (96 VGPRs, some spilled); with
-                              * MC_F_DIRECT: k_expand_direct compiled for 3 */
-#define MC_F_FAMBLOCKS2 8192u /* A/B only: ... 2 blocks per wavefront                                                   */
+#define MC_F_OCC3 2048u      /* A/B only, with MC_F_DIRECT: k_expand_direct compiled for 3 wavefronts per SIMD */
+#define MC_F_NOFILTER 8192u  /* A/B only: by-family expand kernel without the per-wavefront duplicate filter in front of the seen-set */
 #define MC_F_PROGRESS 16384u /* mc_check_files: print TLC's "Progress(d): ..." lines (testout2:4-259) to stdout while the search runs,
                               * at most one per second */
 #define MC_F_NOBATCH 256u /* A/B only: one host round trip per BFS level even while the frontier is small         */
@@ -226,6 +224,9 @@ int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n);
 int mc_shard_expand_pack(mc_engine *e, uint32_t slot, uint64_t *send_fp, uint64_t cap);
 int mc_shard_probe_pack(mc_engine *e, const uint64_t *recv_fp, uint64_t cap, uint8_t *answers);
 int mc_shard_keep_pack(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t cap);
+/* device-side wait of the caller's stream for the slot's last keep: call it before a collective overwrites the answers
+ * buffer that keep was given (a caller with one buffer per slot; callers that allocate per round need not) */
+int mc_shard_wait_keep(mc_engine *e, uint32_t slot);
 /* "stay" alternative to materialise + all-to-all + ingest: the positively answered candidates of the last
  * mc_shard_expand are materialised into THIS rank's frontier (only fingerprints crossed xGMI).  The caller
  * uses it once the frontier is large enough to stay balanced, and falls back to the moving form to rebalance. */
@@ -252,6 +253,32 @@ int mc_shard_materialise_parents(mc_engine *e, uint32_t slot, uint64_t *send_par
 int mc_shard_ingest_parents(mc_engine *e, const uint64_t *recv_parents, uint64_t n, uint32_t src_rank);
 int mc_shard_violation(mc_engine *e, int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant);
 int mc_shard_fetch(mc_engine *e, uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot);
+
+/* ------------------------------------------------------------------ hip-rccl back-end (tla_rust_amd/csrc/shard_rccl.cpp)
+ * The level loop of the sharded search behind the C ABI, collectives over RCCL (xGMI): one process per GPU, no Python.
+ *   rank 0:      mc_comm_unique_id(id)            -- ncclGetUniqueId; ship the MC_COMM_ID_BYTES to the other ranks (file, socket, env ...)
+ *   every rank:  mc_comm_create(id, rank, world, device, &c)          -- ncclCommInitRank + the stream the collectives run on
+ *                mc_engine_create(spec, cfg with shard_rank / shard_count, &e)
+ *                mc_shard_run(e, c, &opts, &result)                    -- the whole search; every rank gets the global counters
+ * replaces: TLC's worker pool ("Number of worker threads", examples/serializableSnapshotIsolation.tla:52-53) scaled past one
+ * device.  Per level one host synchronisation (frontier sizes + verdicts, ncclAllGather); the rounds inside a level are the
+ * fixed-capacity exchanges above (mc_shard_*_pack) as ncclSend / ncclRecv groups.  Any RCCL failure returns MC_ERCCL
+ * (mc_last_error() carries ncclGetErrorString).  `mc X.tla -gpus P` is this API with forked ranks. */
+#define MC_COMM_ID_BYTES 128
+typedef struct mc_comm mc_comm;
+typedef struct {
+    uint64_t chunk_states;    /* frontier states per round and rank (0 = 2^19); at most the engine's chunk_states            */
+    uint64_t max_distinct;    /* budgets of the whole job (0 = none)                                                        */
+    uint64_t max_levels;
+    uint64_t replicate_until; /* states per rank a level must have before the search is sharded (0 = 2^15); below it every
+                               * rank runs the same fused BFS (mc_shard_begin_replicated)                                    */
+    uint64_t packed_fanout;   /* in-model successors per expanded state the fixed-capacity buckets allow for (0 = 16); a
+                               * level that exceeds it fails with MC_EARENA, it is never truncated                          */
+} mc_shard_opts;
+int mc_comm_unique_id(uint8_t id_out[MC_COMM_ID_BYTES]);
+int mc_comm_create(const uint8_t id[MC_COMM_ID_BYTES], uint32_t rank, uint32_t world, int32_t device, mc_comm **out);
+void mc_comm_destroy(mc_comm *c);
+int mc_shard_run(mc_engine *e, mc_comm *c, const mc_shard_opts *opts, mc_result *out);
 
 /* ------------------------------------------------------------------ PlusCal front-end (host only)
  * The reference's workflow is `pcal2tla *tla` then `tlc *tla` (Makefile:3-7).  mc_pcal_translate is the first

@@ -139,22 +139,28 @@ def test_multi_gpu_front_door_report_and_options():
     assert "5850 states generated, 3800 distinct states found, 0 states left on queue." in rep         # README.md:319 format
     assert "The depth of the complete state graph search is 5." in rep                                 # README.md:320 format
     rep = mc_multi.report(Result(distinct=10, generated=20, queue_left=3, depth=4, verdict="assert", levels=[1, 2, 3, 4]), 2, 0.1)
-    assert "Assert evaluated to FALSE" in rep and "one GPU" in rep      # replaced by the bounded one-GPU re-run's report when that fits
+    assert "Assert evaluated to FALSE" in rep and "no behavior" in rep  # engines without parent pointers
+    rep = mc_multi.report(Result(distinct=10, generated=20, queue_left=3, depth=4, verdict="assert", levels=[1, 2, 3, 4]), 2, 0.1,
+                          [("Initial predicate", "/\\ x = 0"), ("Step", "/\\ x = 1")])
+    assert "Error: The behavior up to this point is:" in rep and "State 1: <Initial predicate>" in rep and "State 2: <Step>" in rep  # README.md:270-311
 
 
-def test_mc_gpus_hands_over_to_the_multi_process_front_door(tmp_path):
-    """`mc X.tla -gpus P` replaces itself by torch.distributed.run -m tla_rust_amd.mc_multi (found through the binary's own
-    location, whatever the working directory).  Without a GPU the ranks refuse loudly — there is no CPU fallback."""
+def test_mc_gpus_without_a_gpu_refuses_loudly(tmp_path):
+    """`mc X.tla -gpus P` starts P ranks of itself over the hip-rccl back-end of the C ABI; `-gpus P -torch` replaces itself by
+    torch.distributed.run -m tla_rust_amd.mc_multi (found through the binary's own location, whatever the working directory).
+    Without a GPU both refuse loudly — there is no CPU fallback."""
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by tests/test_gpu_sharded.py")
     import tla_rust_amd.build as b
     b.build()
     mc = ROOT / "tla_rust_amd" / "_build" / "mc"
-    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(ROOT / "specs" / "MCssi_2x2_sym.cfg"), "-gpus", "1"],
-                       capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    args = [str(mc), str(ROOT / "specs" / "MCssi.tla"), "-config", str(ROOT / "specs" / "MCssi_2x2_sym.cfg"), "-gpus", "1"]
+    p = subprocess.run(args, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert p.returncode == 1 and "mc[0]:" in p.stderr and "states generated" not in p.stdout
+    p = subprocess.run(args + ["-torch"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
     assert p.returncode != 0 and "no HIP device visible" in p.stderr + p.stdout
-    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "2", "-dump", "x"], capture_output=True, text=True)
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "2", "-dump", "x"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 1 and "not available with -gpus" in p.stderr
     p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "0"], capture_output=True, text=True)
     assert p.returncode == 1

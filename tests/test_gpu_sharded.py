@@ -155,13 +155,31 @@ def test_multi_gpu_front_door(world):
         assert p.returncode != 0 and "exitcode  : 12" in p.stderr
 
 
-def test_mc_gpus_option():
-    """`mc X.tla -gpus 1`: the C++ CLI hands over to the multi-process front door (RCCL, world 1 on this box)"""
+@pytest.mark.parametrize("door", ["rccl", "torch"])
+def test_mc_gpus_option(door):
+    """`mc X.tla -gpus 1`: the C++ CLI forks its ranks and runs the search over the hip-rccl back-end of the C ABI (mc_comm_* /
+    mc_shard_run: RCCL, world 1 on this box, no Python in the process); `-torch` hands over to the torch.distributed front door"""
     import subprocess
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    p = subprocess.run([str(root / "tla_rust_amd" / "_build" / "mc"), str(root / "specs" / "MCssi.tla"), "-config",
-                        str(root / "specs" / "MCssi_2x2_sym.cfg"), "-gpus", "1", "-tablelog2", "22", "-arena", "1048576", "-chunk", "4096"],
-                       capture_output=True, text=True, timeout=300, cwd="/tmp")
+    mc = str(root / "tla_rust_amd" / "_build" / "mc")
+    extra = ["-torch"] if door == "torch" else []
+    p = subprocess.run([mc, str(root / "specs" / "MCssi.tla"), "-config", str(root / "specs" / "MCssi_2x2_sym.cfg"), "-gpus", "1", *extra,
+                        "-tablelog2", "22", "-arena", "1048576", "-chunk", "4096"], capture_output=True, text=True, timeout=300, cwd="/tmp")
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert "12558 states generated, 7419 distinct states found, 0 states left on queue." in p.stdout
+    assert "The depth of the complete state graph search is 13." in p.stdout
+    if door == "rccl":
+        assert "over RCCL" in p.stdout
+        # a model large enough to leave the replicated prefix: sharded rounds (fixed-capacity exchange over RCCL), the 1-GPU counts
+        p = subprocess.run([mc, str(root / "specs" / "MCraft.tla"), "-config", str(root / "specs" / "MCraft.cfg"), "-gpus", "1", "-maxdistinct", "3000000",
+                            "-tablelog2", "24", "-arena", "6000000", "-chunk", "262144"], capture_output=True, text=True, timeout=300, cwd="/tmp")
+        q = subprocess.run([mc, str(root / "specs" / "MCraft.tla"), "-config", str(root / "specs" / "MCraft.cfg"), "-maxdistinct", "3000000", "-noprogress",
+                            "-tablelog2", "24", "-arena", "6000000", "-chunk", "262144"], capture_output=True, text=True, timeout=300, cwd="/tmp")
+        assert p.returncode == 0 and q.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:] + q.stdout[-1500:] + q.stderr[-1500:]
+        line = next(ln for ln in q.stdout.splitlines() if "distinct states found" in ln)
+        assert line in p.stdout, (line, p.stdout[-800:])
+        # a violation: TLC's exit code from every rank, the verdict line from rank 0
+        p = subprocess.run([mc, str(root / "specs" / "readme_variant" / "pcal_intro.tla"), "-gpus", "1", "-tablelog2", "20", "-arena", "100000"],
+                           capture_output=True, text=True, timeout=300, cwd="/tmp")
+        assert p.returncode == 12 and "Assert evaluated to FALSE" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]

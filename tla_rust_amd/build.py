@@ -47,11 +47,16 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _stale(obj, [CSRC / d for d in dd] + [PKG.parent / "include" / "tlamc.h"]):
             jobs.append((obj, subprocess.Popen(common + ["-x", "hip", "-c", str(CSRC / f"{name}.cpp"), "-o", str(obj)])))
+    # the hip-rccl back-end: host code over the public C ABI, HIP runtime and RCCL
+    obj = OUT / "shard_rccl.o"
+    objs.append(obj)
+    if force or _stale(obj, [CSRC / "shard_rccl.cpp", PKG.parent / "include" / "tlamc.h"]):
+        jobs.append((obj, subprocess.Popen(common + ["-x", "hip", "-c", str(CSRC / "shard_rccl.cpp"), "-o", str(obj)])))
     for obj, pr in jobs:
         if pr.wait() != 0:
             raise RuntimeError(f"hipcc failed for {obj.name}")
     if force or jobs or not LIB.exists():
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs] + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -1463,6 +1463,7 @@ struct EngineBase {
     virtual int shard_expand_pack(unsigned slot, uint64_t *send_fp, uint64_t cap) = 0;
     virtual int shard_probe_pack(const uint64_t *recv_fp, uint64_t cap, uint8_t *answers) = 0;
     virtual int shard_keep_pack(unsigned slot, const uint8_t *answers_back, uint64_t cap) = 0;
+    virtual int shard_wait_keep(unsigned slot) = 0;
     virtual int shard_materialise(unsigned slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) = 0;
     virtual int shard_ingest(const uint8_t *recv_states, uint64_t n) = 0;
     virtual int shard_keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) = 0;
@@ -2270,6 +2271,7 @@ struct Engine : EngineBase {
         if (!count) return MC_OK;
         if (!ev_slot[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_slot[slot], hipEventDisableTiming));
         else HIP_TRY(hipStreamWaitEvent(stream, ev_slot[slot], 0));  // the slot's previous buckets have been compacted
+        if (ev_mat[slot]) HIP_TRY(hipStreamWaitEvent(stream, ev_mat[slot], 0));  // ... and its locally owned new states written
         HIP_TRY(hipMemsetAsync(q.rt_cur, 0, (size_t)(P * NSHARD) * sizeof(PaddedCounter), stream));
         const uint64_t c0 = sh_lo + first, c1 = c0 + count, base = c0 & ~63ull;
         const uint64_t ncols = ((c1 - base) + 63) & ~63ull;
@@ -2326,6 +2328,8 @@ struct Engine : EngineBase {
             }, stream2);
             hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream2, d_ctr, slot);
             append_end(stream2);
+            if (!ev_mat[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_mat[slot], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ev_mat[slot], stream2));
         }
         if (total) {
             RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
@@ -2344,6 +2348,9 @@ struct Engine : EngineBase {
     }
     // ---- fixed-capacity rounds: nothing of a round waits for the host (sizes travel in band; errors surface at shard_end_level)
     hipEvent_t ev_exp[2] = {nullptr, nullptr};
+    // the slot's new-list segment and its counters (parity = slot) are read by the local materialise + commit on the second
+    // stream: the NEXT expand into the same slot waits for them (a host that never blocks enqueues expands back to back)
+    hipEvent_t ev_mat[2] = {nullptr, nullptr};
     int shard_expand_pack(unsigned slot, uint64_t *send_fp, uint64_t cap) override {
         HIP_TRY(hipSetDevice(cfg.device));
         if (slot > 1 || !sl[slot].launched) { set_error("shard_expand_pack: no expand in flight for this slot"); return MC_EBADCFG; }
@@ -2371,6 +2378,8 @@ struct Engine : EngineBase {
             }, stream2);
             hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream2, d_ctr, slot);
             append_end(stream2);
+            if (!ev_mat[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_mat[slot], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ev_mat[slot], stream2));
             RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
             hipLaunchKernelGGL(k_compact_packed, dim3(64, P * NSHARD), dim3(256), 0, side(), rt, cap, send_fp, q.pend_src, d_ctr);
         } else {  // no chunk for this rank in this round: empty buckets
@@ -2393,6 +2402,14 @@ struct Engine : EngineBase {
     int shard_keep_pack(unsigned slot, const uint8_t *answers_back, uint64_t cap) override {
         if (slot > 1 || sl[slot].pend_total != (uint64_t)nranks() * cap) { set_error("shard_keep_pack: not the capacity the slot was packed with"); return MC_EBADCFG; }
         return shard_keep(slot, answers_back, nullptr);
+    }
+    // the caller's stream waits (on the device) until the slot's last keep has consumed its answers buffer: a caller that
+    // reuses ONE answers buffer per slot calls this before the collective that overwrites it
+    int shard_wait_keep(unsigned slot) override {
+        if (slot > 1) return MC_EBADCFG;
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (sl[slot].keep_pending && ev_keep[slot]) HIP_TRY(hipStreamWaitEvent(side(), ev_keep[slot], 0));
+        return MC_OK;
     }
     int shard_materialise(unsigned slot, const uint8_t *answers_back, uint8_t *send_states, uint64_t send_cap, uint64_t *send_counts) override {
         HIP_TRY(hipSetDevice(cfg.device));
@@ -2877,6 +2894,7 @@ int mc_shard_probe_pack(mc_engine *e, const uint64_t *recv_fp, uint64_t cap, uin
 int mc_shard_keep_pack(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t cap) {
     return e && answers_back ? e->impl->shard_keep_pack(slot, answers_back, cap) : MC_EBADCFG;
 }
+int mc_shard_wait_keep(mc_engine *e, uint32_t slot) { return e ? e->impl->shard_wait_keep(slot) : MC_EBADCFG; }
 int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new) { return e && n_new ? e->impl->shard_keep(0, answers_back, n_new) : MC_EBADCFG; }
 int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t *n_new) {
     return e ? e->impl->shard_keep(slot, answers_back, n_new) : MC_EBADCFG;

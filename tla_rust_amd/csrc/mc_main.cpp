@@ -17,10 +17,13 @@
 // -checkpoint FILE / -recover FILE: TLC's checkpointing (testout1:10) and -recover: write the run (all states found, level
 //             boundaries, counters, parent pointers) after a search that stopped on -maxlevels / -maxdistinct without an
 //             error; continue such a run later, with the same X.tla / X.cfg.
-// -gpus P   : the search sharded over P GPUs of this node (one process per GPU, RCCL): mc replaces itself by
-//             `python3 -m torch.distributed.run --nproc-per-node P -m tla_rust_amd.mc_multi X.tla <the other options>`
-//             (tla_rust_amd/mc_multi.py; same report lines and exit codes; $PYTHON names another interpreter, $MASTER_PORT the
-//             rendezvous port).
+// -gpus P   : the search sharded over P GPUs of this node, one process per GPU, collectives over RCCL (include/tlamc.h
+//             mc_comm_* / mc_shard_run): mc starts P copies of itself (rank r on device r; rank 0 writes the communicator id to
+//             a temporary file the others read) and rank 0 prints TLC's counter / depth lines; exit status as below.
+// -gpus P -torch: the same search driven by tla_rust_amd/mc_multi.py over torch.distributed instead — mc replaces itself by
+//             `python3 -m torch.distributed.run --nproc-per-node P -m tla_rust_amd.mc_multi X.tla <the other options>`; that front
+//             door also rebalances drifting ranks by moving states and prints a counterexample walked back across the ranks
+//             ($PYTHON names another interpreter, $MASTER_PORT the rendezvous port).
 // -deadlock : as with TLC, do NOT check for deadlock.  -workers is accepted and ignored (the
 // GPU is the worker pool).  Exit status: 0 no error, 12 safety violation (invariant / assert),
 // 11 deadlock, 1 any other failure — TLC's convention.
@@ -28,6 +31,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <string>
@@ -75,6 +80,7 @@ static int exec_multi(int gpus, int argc, char **argv) {
                                   "--master-addr", "127.0.0.1", "--master-port", port && *port ? port : "29517", "-m", "tla_rust_amd.mc_multi"};
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "-gpus")) { ++i; continue; }
+        if (!strcmp(argv[i], "-torch")) continue;
         if (!strcmp(argv[i], "-deadlock") || !strcmp(argv[i], "-dump") || !strcmp(argv[i], "-checkpoint") || !strcmp(argv[i], "-recover")) {
             fprintf(stderr, "mc: %s is not available with -gpus\n", argv[i]);
             return 1;
@@ -89,13 +95,123 @@ static int exec_multi(int gpus, int argc, char **argv) {
     return 1;
 }
 
-int main(int argc, char **argv) {
-    for (int i = 1; i + 1 < argc; i++)
-        if (!strcmp(argv[i], "-gpus")) {
-            const int g = atoi(argv[i + 1]);
-            if (g < 1 || g > 64) { fprintf(stderr, "mc: -gpus needs a number of GPUs\n"); return 1; }
-            return exec_multi(g, argc, argv);
+// ---- mc X.tla -gpus P, native: P copies of this binary, one per GPU, over the hip-rccl back-end of the C ABI
+static double now_s() {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+static int spawn_ranks(int gpus, char **argv) {
+    char idfile[] = "/tmp/mc_comm_id_XXXXXX";
+    const int fd = mkstemp(idfile);
+    if (fd < 0) { perror("mc: mkstemp"); return 1; }
+    close(fd);  // empty: rank 0 fills it (through a rename), the other ranks wait for MC_COMM_ID_BYTES bytes
+    setenv("MC_WORLD", std::to_string(gpus).c_str(), 1);
+    setenv("MC_IDFILE", idfile, 1);
+    std::vector<pid_t> pids;
+    for (int r = 0; r < gpus; r++) {
+        const pid_t p = fork();
+        if (p < 0) { perror("mc: fork"); return 1; }
+        if (p == 0) {
+            setenv("MC_RANK", std::to_string(r).c_str(), 1);
+            execv("/proc/self/exe", argv);
+            perror("mc: exec");
+            _exit(1);
         }
+        pids.push_back(p);
+    }
+    int worst = 0;
+    for (pid_t p : pids) {
+        int st = 0;
+        waitpid(p, &st, 0);
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+        if (code == 1 || (code > worst && worst != 1)) worst = code;  // 1 (a failure) dominates 11 / 12 (TLC's verdict codes)
+    }
+    unlink(idfile);
+    return worst;
+}
+static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, int world, const char *idfile) {
+    mc_spec_desc desc;
+    mc_program *prog = nullptr;
+    int rc = mc_resolve_files(tla, cfgp, cfg.flags & (MC_F_GENERIC | MC_F_UNVERIFIED), &desc, &prog);
+    if (rc) { fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error()); return 1; }
+    uint8_t id[MC_COMM_ID_BYTES];
+    if (rank == 0) {
+        if ((rc = mc_comm_unique_id(id))) { fprintf(stderr, "mc[0]: %s: %s\n", mc_strerror(rc), mc_last_error()); return 1; }
+        const std::string tmp = std::string(idfile) + ".w";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { perror("mc: communicator id file"); return 1; }
+        fclose(f);
+        if (rename(tmp.c_str(), idfile)) { perror("mc: rename"); return 1; }
+    } else {
+        const double t0 = now_s();
+        for (;;) {
+            FILE *f = fopen(idfile, "rb");
+            const size_t n = f ? fread(id, 1, sizeof id, f) : 0;
+            if (f) fclose(f);
+            if (n == sizeof id) break;
+            if (now_s() - t0 > 120) { fprintf(stderr, "mc[%d]: no communicator id from rank 0\n", rank); return 1; }
+            usleep(20000);
+        }
+    }
+    cfg.device += rank;  // rank r on device (-device D) + r
+    cfg.shard_rank = (uint32_t)rank;
+    cfg.shard_count = (uint32_t)world;
+    cfg.flags &= ~(MC_F_TRACE | MC_F_PROGRESS);
+    mc_comm *comm = nullptr;
+    if ((rc = mc_comm_create(id, (uint32_t)rank, (uint32_t)world, cfg.device, &comm))) { fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error()); return 1; }
+    mc_engine *eng = nullptr;
+    if ((rc = mc_engine_create(&desc, &cfg, &eng))) { fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error()); return 1; }
+    mc_shard_opts so;
+    memset(&so, 0, sizeof so);
+    so.chunk_states = cfg.chunk_states;
+    so.max_distinct = cfg.max_distinct;
+    so.max_levels = cfg.max_levels;
+    static mc_result res;
+    const double t0 = now_s();
+    rc = mc_shard_run(eng, comm, &so, &res);
+    const double dt = now_s() - t0;
+    if (rc) fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error());
+    if (!rc && rank == 0) {  // TLC's closing lines (README.md:319-320, testout2:260-266), as tla_rust_amd/mc_multi.py prints them
+        const unsigned long long n0 = res.levels ? (unsigned long long)res.level_distinct[0] : 0ull;
+        printf("Finished computing initial states: %llu distinct state%s generated.\n", n0, n0 == 1 ? "" : "s");
+        if (res.verdict == MC_V_OK) printf("Model checking completed. No error has been found.\n");
+        else if (res.verdict == MC_V_BUDGET) printf("Search stopped by the level/state budget; no error has been found so far.\n");
+        else {
+            printf("%s\n", res.verdict == MC_V_INVARIANT ? "Error: Invariant is violated." : res.verdict == MC_V_ASSERT ? "Error: The first argument of Assert evaluated to FALSE."
+                          : res.verdict == MC_V_DEADLOCK ? "Error: Deadlock reached." : "Error: TLC would raise an evaluation error.");
+            printf("(the behavior up to this point: `mc X.tla -gpus P -torch` walks it back across the GPUs, `mc X.tla` rebuilds it on one)\n");
+        }
+        printf("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)res.generated,
+               (unsigned long long)res.distinct, (unsigned long long)res.queue_left);
+        printf("The depth of the complete state graph search is %u.\n", res.depth);
+        printf("(%d GPU%s over RCCL, %.3f s, %.3g distinct states/s)\n", world, world == 1 ? "" : "s", dt, (double)res.distinct / (dt > 1e-9 ? dt : 1e-9));
+        fflush(stdout);
+    }
+    mc_engine_destroy(eng);
+    mc_comm_destroy(comm);
+    if (prog) mc_program_free(prog);
+    if (rc) return 1;
+    if (res.verdict == MC_V_OK || res.verdict == MC_V_BUDGET) return 0;
+    return res.verdict == MC_V_DEADLOCK ? 11 : 12;
+}
+
+int main(int argc, char **argv) {
+    int gpus = 0;
+    bool torch_door = false;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "-gpus") && i + 1 < argc) {
+            gpus = atoi(argv[i + 1]);
+            if (gpus < 1 || gpus > 64) { fprintf(stderr, "mc: -gpus needs a number of GPUs\n"); return 1; }
+        }
+        if (!strcmp(argv[i], "-torch")) torch_door = true;
+    }
+    if (gpus && torch_door) return exec_multi(gpus, argc, argv);
+    const char *env_rank = getenv("MC_RANK");
+    if (gpus && !env_rank) {
+        if (gpus > 8) { fprintf(stderr, "mc: -gpus: at most 8 ranks (one node)\n"); return 1; }
+        return spawn_ranks(gpus, argv);
+    }
     if (argc >= 2 && (!strcmp(argv[1], "--transpile") || !strcmp(argv[1], "-transpile"))) {
         int rc = argc > 2 ? 0 : 1;
         for (int i = 2; i < argc; i++) rc |= transpile(argv[i]);
@@ -115,6 +231,8 @@ int main(int argc, char **argv) {
         else if (arg("-checkpoint")) ckpt = argv[++i];
         else if (arg("-recover")) recover = argv[++i];
         else if (arg("-workers")) ++i;
+        else if (arg("-gpus")) ++i;
+        else if (!strcmp(argv[i], "-torch")) {}
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
         else if (!strcmp(argv[i], "-unverified")) cfg.flags |= MC_F_UNVERIFIED;
         else if (!strcmp(argv[i], "-noprogress")) cfg.flags &= ~MC_F_PROGRESS;
@@ -132,10 +250,14 @@ int main(int argc, char **argv) {
         fprintf(stderr,
                 "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-unverified] [-device D]\n"
                 "                [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]\n"
-                "                [-checkpoint FILE] [-recover FILE] [-gpus P]                             check X.tla like `tlc X.tla`\n"
+                "                [-checkpoint FILE] [-recover FILE] [-gpus P [-torch]]                    check X.tla like `tlc X.tla`\n"
                 "       mc --transpile X.tla [Y.tla ...]                                                  translate like `pcal2tla`\n"
                 "exit status: 0 no error, 12 invariant / assertion violated, 11 deadlock, 1 anything else\n");
         return 1;
+    }
+    if (gpus) {  // one rank of `mc X.tla -gpus P`
+        if (dump || recover || ckpt) { fprintf(stderr, "mc: -dump / -checkpoint / -recover are not available with -gpus\n"); return 1; }
+        return run_rank(tla, cfgp, cfg, atoi(env_rank), gpus, getenv("MC_IDFILE"));
     }
     std::vector<char> report(1 << 22);
     static mc_result res;
