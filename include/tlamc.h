@@ -62,6 +62,15 @@ extern "C" {
                                 the reference's untranslated pcal_intro.tla:4-19 and atomic_add.tla:4-23 included);
                                 params {(int64) mc_program handle} — build the descriptor with mc_program_spec      */
 
+#define MC_SPEC_PAXOS 6      /* reference examples/Paxos/Voting.tla:133-160 and Paxos.tla:93-208 under MCVoting.tla / MCPaxos.tla
+                                (+ .cfg: INVARIANT, PROPERTY C!Spec / V!Spec as a per-transition refinement check, SYMMETRY);
+                                params {kind (0 Paxos, 1 Voting), nAcceptor <= 4, nValue <= 3, nBallot = MaxBallot + 1 <= 4,
+                                invariantMask (Paxos: bit k = Inv!(k+1), MCPaxos.tla:65-68; Voting: 1 = Inv),
+                                symmetry (1 Permutations(Acceptor) | 2 Permutations(Value)),
+                                property (1 = check the cfg's PROPERTY; a violation is reported as invariant index 4 (Paxos) /
+                                1 (Voting); 2 = negative control: Phase2a without its quorum conjunct),
+                                nQuorum (0 = all majorities of minimal size), quorum acceptor bit masks ...}            */
+
 typedef struct {
     uint32_t spec_id;
     uint32_t nparams;

@@ -186,6 +186,7 @@ static void on_emit(or_emit *em, const uint8_t *s, size_t len, int action, unsig
         note_violation(b, OR_ASSERT, -1, b->cur, NULL, 0, action, 1);
         return;
     }
+    if (flags & OR_FLAG_PROPERTY) note_violation(b, OR_INVARIANT, (int)(flags >> 8), b->cur, s, len, action, 0);
     int inmodel = sp->constraint ? sp->constraint(sp->ctx, s, len) : 1;
     int is_new = 0;
     if (inmodel) {
@@ -342,6 +343,7 @@ static int run_any(const char *spec, const int64_t *params, int nparams, const o
     else if (!strcmp(spec, "pcal_intro")) rc = or_spec_pcal_intro(params, nparams, &sp);
     else if (!strcmp(spec, "raft")) rc = or_spec_raft(params, nparams, &sp);
     else if (!strcmp(spec, "ssi")) rc = or_spec_ssi(params, nparams, &sp);
+    else if (!strcmp(spec, "paxos")) rc = or_spec_paxos(params, nparams, &sp);
     else { or_set_error("unknown spec '%s'", spec); return -1; }
     if (rc) return rc;
     or_options o = {0, 0, 1, 1, NULL};
@@ -363,5 +365,6 @@ const char *oracle_action_name(const char *spec, int action) {
     if (!strcmp(spec, "pcal_intro")) return or_pcal_intro_action(action);
     if (!strcmp(spec, "raft")) return or_raft_action(action);
     if (!strcmp(spec, "ssi")) return or_ssi_action(action);
+    if (!strcmp(spec, "paxos")) return or_paxos_action(action);
     return "?";
 }

@@ -139,6 +139,7 @@ static void mt_emit(or_emit *em, const uint8_t *s, size_t len, int action, unsig
     w->generated++;
     if (flags & OR_FLAG_SPECERR) { mt_note(w, OR_SPEC_ERROR, -1); return; }
     if (flags & OR_FLAG_ASSERT) { mt_note(w, OR_ASSERT, -1); return; }
+    if (flags & OR_FLAG_PROPERTY) mt_note(w, OR_INVARIANT, (int)(flags >> 8));
     int inmodel = sp->constraint ? sp->constraint(sp->ctx, s, len) : 1;
     int is_new = 0;
     if (inmodel) {

@@ -5,6 +5,7 @@
 
 #define OR_FLAG_ASSERT 1u      /* Assert(...) failed while generating this successor */
 #define OR_FLAG_SPECERR 2u     /* TLC would have raised an evaluation error           */
+#define OR_FLAG_PROPERTY 4u    /* this TRANSITION violates the safety part of a PROPERTY; bits 8.. = the index reported */
 
 typedef struct or_emit {
     void *bfs;                 /* opaque */
@@ -32,10 +33,12 @@ int or_spec_atomic_add(const int64_t *p, int np, or_spec *out);
 int or_spec_pcal_intro(const int64_t *p, int np, or_spec *out);
 int or_spec_raft(const int64_t *p, int np, or_spec *out);
 int or_spec_ssi(const int64_t *p, int np, or_spec *out);
+int or_spec_paxos(const int64_t *p, int np, or_spec *out);
 const char *or_atomic_add_action(int a);
 const char *or_pcal_intro_action(int a);
 const char *or_raft_action(int a);
 const char *or_ssi_action(int a);
+const char *or_paxos_action(int a);
 
 void or_set_error(const char *fmt, ...);
 /* bfs_mt.c: the multi-threaded BFS (counts and verdict only; max_seconds > 0 stops after the level that exceeds it) */

@@ -23,6 +23,7 @@ Pure Python with the expression tree compiled to closures: meant for models of 1
 Only tests/, tests/golden/*.py, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
 """
 import itertools
+import re
 import sys
 from pathlib import Path
 
@@ -430,6 +431,14 @@ class Parser:
             while self.is_sym("!") and self.peek().k == "id":  # Inst!Op
                 self.i += 1
                 name = name + "!" + self.ident()
+            if self.is_sym("!") and self.peek().k == "sym" and self.peek().s == ":":  # Thm!: = the statement of Thm
+                self.i += 2
+                return ("id", name)
+            if self.is_sym("!") and self.peek().k == "num":  # Def!k = the k-th conjunct of Def's body (MCPaxos.tla:44-46)
+                self.i += 1
+                k = int(self.cur().s)
+                self.i += 1
+                return ("nth", name, k)
             if self.is_sym("(") and not self.ended():
                 self.i += 1
                 return ("call", name, self.exprlist(")"))
@@ -540,10 +549,11 @@ class Parser:
                 self.expect("]")
                 if self.cur().k == "id" and self.cur().s.startswith("_"):  # [A]_v
                     bare = self.cur().s == "_"
+                    sub = ("id", self.cur().s[1:])
                     self.i += 1
                     if bare:
-                        self.expr(16)   # [A]_<<v1, v2>>: the subscript is a tuple
-                    return ("temporal", "[]_", first)
+                        sub = self.expr(16)   # [A]_<<v1, v2>>: the subscript is a tuple
+                    return ("temporal", "[]_", first, sub)
                 self.fail("unsupported bracket expression")
         self.i -= 1
         self.fail("expected an expression")
@@ -568,8 +578,11 @@ class Parser:
 class Module:
     """parsed MODULE text: name, extends, constants (name -> arity), variables (ordered), definitions"""
 
+    PROOF_LINE = re.compile(r"^\s*(<\d+>\w*\.?|BY\b|QED\b|OBVIOUS\b|OMITTED\b|PROOF\b).*$", re.M)
+
     def __init__(self, text):
-        toks = lex(text)
+        # structured proofs (examples/Paxos/Voting.tla:187-196, Consensus.tla:40-47) are not evaluated: their lines are blanked
+        toks = lex(self.PROOF_LINE.sub("", text))
         p = Parser(toks)
         # skip to  ---- MODULE name ----
         while not (p.cur().k == "id" and p.cur().s == "MODULE"):
@@ -626,14 +639,25 @@ class Module:
                     self.variables.append(p.ident())
             elif c.s in ("ASSUME", "ASSUMPTION", "AXIOM"):
                 p.i += 1
+                nm = None
                 if p.cur().k == "id" and p.peek().k == "sym" and p.peek().s == "==":
+                    nm = p.cur().s
                     p.i += 2
-                self.assumes.append(p.expr(0))
+                e = p.expr(0)
+                self.assumes.append(e)
+                if nm:  # a named assumption is a definition (Name!: is its body, MCVoting.tla:32)
+                    self.defs[nm] = (nm, [], e, c.line)
+                    self.def_order.append(nm)
             elif c.s in ("THEOREM", "LEMMA", "PROPOSITION", "COROLLARY"):
                 p.i += 1
+                nm = None
                 if p.cur().k == "id" and p.peek().k == "sym" and p.peek().s == "==":
+                    nm = p.cur().s
                     p.i += 2
-                p.expr(0)  # parsed, never evaluated
+                e = p.expr(0)  # never evaluated unless a model refers to it as Name!: (MCVoting.tla:42-46)
+                if nm:
+                    self.defs[nm] = (nm, [], e, c.line)
+                    self.def_order.append(nm)
                 while p.cur().k == "id" and p.cur().s in ("PROOF", "BY", "OBVIOUS", "OMITTED", "QED"):
                     p.i += 1
             elif c.s == "INSTANCE":
@@ -916,8 +940,10 @@ class Spec:
 
     BUILTIN_MODULES = {"Naturals", "Integers", "Reals", "FiniteSets", "Sequences", "TLC", "Bags", "RealTime", "TLAPS"}
 
-    def __init__(self, path, search=(), constants=None, overrides=None, clash="test"):
+    def __init__(self, path, search=(), constants=None, overrides=None, clash="test", scoped=None):
         self.search = [Path(path).parent] + [Path(s) for s in search]
+        self.scoped = dict(scoped or {})  # (module, name) -> name: the cfg's `Id <-[Module] Id` (examples/Paxos/MCPaxos.cfg:9)
+        self.scoped_overrides = {}
         self.clash = clash  # "test": TLC (a second x' = e is an equality test); "ignore": naive (first assignment wins, later ones TRUE)
         self.modules = []
         self.variables, self.constants, self.defs = [], {}, {}
@@ -925,6 +951,7 @@ class Spec:
         self.varidx = {v: i for i, v in enumerate(self.variables)}
         self.const_vals = dict(constants or {})
         self.overrides = dict(overrides or {})  # name <- name (cfg substitution)
+        self.overrides.update(self.scoped_overrides)
         for k in self.constants:
             if k not in self.const_vals and k not in self.overrides:
                 raise TLAError(f"CONSTANT {k} has no value in the configuration")
@@ -946,7 +973,56 @@ class Spec:
             if v not in self.variables:
                 self.variables.append(v)
         for name, (nm, params, body, line) in m.defs.items():
-            self.defs[name] = GDef(nm, params, body, m.name, line)
+            if body[0] == "instance":
+                self._import_instance(name + "!", body[1], body[2])
+            else:
+                self.defs[name] = GDef(nm, params, body, m.name, line)
+
+    def _find_module(self, name):
+        for d in self.search:
+            if (d / f"{name}.tla").exists():
+                return d / f"{name}.tla"
+        raise TLAError(f"module {name} not found (search path: {[str(s) for s in self.search]})")
+
+    def _import_instance(self, prefix, modname, subst):
+        """I == INSTANCE M WITH c <- e, ...: every definition d of M (and of what M EXTENDS) becomes the global definition
+        I!d, in which M's own definition names are prefixed and the substituted constants / variables are replaced by their
+        expressions; a constant or variable of M without a WITH clause stands for the instantiating module's identifier of the
+        same name (Voting.tla:185 `C == INSTANCE Consensus`: Consensus's variable `chosen` IS Voting's state function
+        `chosen`).  Priming such an identifier is priming a state function (v_prime)."""
+        mods = []
+
+        def gather(nm):
+            m = Module(self._find_module(nm).read_text(errors="replace"))
+            for e in m.extends:
+                if e not in self.BUILTIN_MODULES:
+                    gather(e)
+            mods.append(m)
+        gather(modname)
+        names = set()
+        for m in mods:
+            names.update(m.defs)
+        sub = dict(subst)
+
+        def rn(x):
+            if isinstance(x, tuple):
+                if x and isinstance(x[0], str) and x[0] in ("id", "call", "nth") and len(x) > 1 and isinstance(x[1], str):
+                    if x[0] == "id" and x[1] in sub:
+                        return sub[x[1]]
+                    if x[1].split("!")[0] in names:
+                        return (x[0], prefix + x[1]) + tuple(rn(y) for y in x[2:])
+                return tuple(rn(y) for y in x)
+            if isinstance(x, list):
+                return [rn(y) for y in x]
+            return x
+        for m in mods:
+            for name, (nm, params, body, line) in m.defs.items():
+                if body[0] == "instance":
+                    self._import_instance(prefix + name + "!", body[1], [(a, rn(e)) for a, e in body[2]])
+                    continue
+                self.defs[prefix + name] = GDef(prefix + nm, params, rn(body), m.name, line)
+                if (m.name, name) in self.scoped:
+                    self.scoped_overrides[prefix + name] = self.scoped[(m.name, name)]
 
     # ------------------------------------------------------------------ static analysis
     def primed(self, node, scope):
@@ -956,6 +1032,8 @@ class Spec:
             return True
         if k in ("num", "str", "bool", "at"):
             return False
+        if k == "nth":
+            return self.primed(self._nth_node(node), {})
         if k == "id" or k == "call":
             name = node[1]
             r = False
@@ -1043,6 +1121,20 @@ class Spec:
     def v_at(self, node, scope):
         return lambda env, st, nx: env["@"]
 
+    def _nth_node(self, node):
+        name = self.overrides.get(node[1], node[1])
+        if name not in self.defs:
+            raise TLAError(f"{node[1]}!{node[2]}: {node[1]} is not a definition")
+        body = self.defs[name].body
+        while body[0] == "paren":
+            body = body[1]
+        if body[0] not in ("conj", "disj") or not 1 <= node[2] <= len(body[1]):
+            raise TLAError(f"{node[1]}!{node[2]}: the definition has no such conjunct")
+        return body[1][node[2] - 1]
+
+    def v_nth(self, node, scope):
+        return self.cv(self._nth_node(node), {})
+
     def v_temporal(self, node, scope):
         def f(env, st, nx):
             raise TLAError("temporal formula evaluated")
@@ -1113,6 +1205,8 @@ class Spec:
     def _mentions_state(self, node, seen):
         """does the expression (transitively) mention a VARIABLE?"""
         if isinstance(node, tuple) and node and isinstance(node[0], str) and node[0] in NODE_KINDS:
+            if node[0] == "nth":
+                return self._mentions_state(self._nth_node(node), seen)
             if node[0] in ("id", "call"):
                 nm = self.overrides.get(node[1], node[1])
                 if nm in self.varidx:
@@ -1553,7 +1647,10 @@ class Spec:
         raise TLAError("LAMBDA outside an argument position")
 
     def v_unchanged(self, node, scope):
-        idxs = self._unchanged_vars(node[1], scope)
+        try:
+            idxs = self._unchanged_vars(node[1], scope)
+        except TLAError:  # UNCHANGED e for a state function e (an instantiated module's variable, Paxos.tla:201): e' = e
+            return self.cv(("op", "=", ("prime", node[1]), node[1]), scope)
 
         def g(env, st, nx):
             if nx is None:
@@ -1695,7 +1792,10 @@ class Spec:
         return lambda env, st, nx: body(binder(env, st, nx), st, nx)
 
     def a_unchanged(self, node, scope):
-        idxs = self._unchanged_vars(node[1], scope)
+        try:
+            idxs = self._unchanged_vars(node[1], scope)
+        except TLAError:
+            return self._a_test(node, scope)
         clash_test = self.clash == "test"
 
         def g(env, st, nx):
@@ -1846,7 +1946,7 @@ class Spec:
 
 NODE_KINDS = {"num", "str", "bool", "id", "call", "paren", "at", "conj", "disj", "op", "not", "neg", "quant", "choose", "choose_unbounded", "if", "case",
               "let", "lambda", "unchanged", "enabled", "pre", "setenum", "setfilter", "setmap", "tuple", "record", "recordset",
-              "fndef", "fnset", "except", "idx", "prime", "temporal", "instance"}
+              "fndef", "fnset", "except", "idx", "prime", "temporal", "instance", "nth"}
 
 
 # ---- built-in operators
@@ -1966,12 +2066,25 @@ BUILTIN_CONSTS = {"Nat": NatSet(0), "Int": NatSet(None), "BOOLEAN": frozenset([T
 
 
 # =============================================================================================== cfg
+def permute(v, g):
+    """the value with every model value m replaced by g[m] (TLC's symmetry reduction applies a permutation to a whole state)"""
+    if isinstance(v, MV):
+        return g.get(v, v)
+    if isinstance(v, tuple):
+        return tuple(permute(x, g) for x in v)
+    if isinstance(v, frozenset):
+        return frozenset(permute(x, g) for x in v)
+    if isinstance(v, Fn):
+        return mk_fn({permute(k, g): permute(x, g) for k, x in v.d.items()})
+    return v
+
+
 def parse_cfg(text):
     """TLC configuration file (grammar: examples/SpecifyingSystems/TLC/ConfigFileGrammar.tla:4-32) ->
     dict(spec, init, next, invariants, constraints, constants {name: value}, overrides {name: name}, symmetry)"""
     toks = [t for t in lex(text) if t.k != "end"]
     out = dict(spec=None, init=None, next=None, invariants=[], constraints=[], constants={}, overrides={}, symmetry=None,
-               properties=[])
+               properties=[], scoped={})
     KW = {"SPECIFICATION", "INIT", "NEXT", "INVARIANT", "INVARIANTS", "CONSTRAINT", "CONSTRAINTS", "CONSTANT", "CONSTANTS", "SYMMETRY",
           "PROPERTY", "PROPERTIES", "ACTION_CONSTRAINT", "ACTION_CONSTRAINTS", "VIEW"}
     i = 0
@@ -2024,8 +2137,10 @@ def parse_cfg(text):
                     out["constants"][name] = v
                 elif toks[i].k == "sym" and toks[i].s == "<-":
                     i += 1
-                    if toks[i].k == "sym" and toks[i].s == "[":  # <-[Module] Id
-                        i += 3
+                    if toks[i].k == "sym" and toks[i].s == "[":  # <-[Module] Id: only inside that module (MCPaxos.cfg:9)
+                        out["scoped"][(toks[i + 1].s, name)] = toks[i + 3].s
+                        i += 4
+                        continue
                     out["overrides"][name] = toks[i].s
                     i += 1
                 else:
@@ -2037,13 +2152,14 @@ def parse_cfg(text):
 class Checker:
     """TLC's breadth-first search over a Spec"""
 
-    def __init__(self, tla_path, cfg_text=None, cfg_path=None, search=(), clash="test", constants=None):
+    def __init__(self, tla_path, cfg_text=None, cfg_path=None, search=(), clash="test", constants=None, symmetry=True):
         if cfg_text is None:
             cfg_text = Path(cfg_path or str(tla_path)[:-4] + ".cfg").read_text()
         self.cfg = parse_cfg(cfg_text)
         consts = dict(self.cfg["constants"])
         consts.update(constants or {})
-        self.spec = Spec(tla_path, search=search, constants=consts, overrides=self.cfg["overrides"], clash=clash)
+        self.spec = Spec(tla_path, search=search, constants=consts, overrides=self.cfg["overrides"], clash=clash,
+                         scoped=self.cfg["scoped"])
         init, nxt = self.cfg["init"], self.cfg["next"]
         if self.cfg["spec"]:
             init, nxt = self._split_spec(self.cfg["spec"])
@@ -2051,6 +2167,90 @@ class Checker:
         self.nextf = self.spec.compile_action(nxt)
         self.invs = [(n, self.spec.compile_value(n)) for n in self.cfg["invariants"]]
         self.cons = [(n, self.spec.compile_value(n)) for n in self.cfg["constraints"]]
+        self.props = [self._compile_property(n) for n in self.cfg["properties"]]
+        self.group = self._symmetry_group(self.cfg["symmetry"]) if self.cfg["symmetry"] and symmetry else None
+
+    # ------------------------------------------------------------------ PROPERTY (safety part) and SYMMETRY
+    def _compile_property(self, name):
+        """PROPERTY P with P == I /\\ [][A]_v (/\\ fairness): what TLC checks of it without liveness — I on the initial states,
+        A \\/ v' = v on every transition it generates (MCVoting.cfg:9 ConsensusSpecBar == C!Spec, MCPaxos.cfg:12)"""
+        sp = self.spec
+        flat = []
+
+        def walk(n):
+            if n[0] == "conj":
+                for x in n[1]:
+                    walk(x)
+            elif n[0] == "paren":
+                walk(n[1])
+            elif n[0] == "id" and n[1] not in sp.varidx and sp.overrides.get(n[1], n[1]) in sp.defs and \
+                    not sp.defs[sp.overrides.get(n[1], n[1])].params and self._is_temporal(sp.defs[sp.overrides.get(n[1], n[1])].body):
+                walk(sp.defs[sp.overrides.get(n[1], n[1])].body)
+            else:
+                flat.append(n)
+        walk(("id", name))
+        inits, steps = [], []
+        for n in flat:
+            if n[0] == "temporal" and n[1] == "[]" and n[2][0] == "temporal" and n[2][1] == "[]_":
+                steps.append((sp.ca(n[2][2], {}), sp.cv(n[2][3], {})))
+            elif n[0] == "temporal" or (n[0] == "call" and n[1][:3] in ("WF_", "SF_")):
+                continue  # liveness: not checked
+            else:
+                inits.append(sp.cv(n, {}))
+        return name, inits, steps
+
+    def _is_temporal(self, n, seen=None):
+        seen = seen if seen is not None else set()
+        if isinstance(n, tuple) and n and n[0] == "temporal":
+            return True
+        if isinstance(n, tuple) and n and n[0] == "id":
+            nm = self.spec.overrides.get(n[1], n[1])
+            if nm in self.spec.defs and nm not in seen:
+                seen.add(nm)
+                return self._is_temporal(self.spec.defs[nm].body, seen)
+            return False
+        if isinstance(n, (tuple, list)):
+            return any(self._is_temporal(x, seen) for x in n)
+        return False
+
+    def property_violated_init(self, st):
+        for k, (_, inits, _) in enumerate(self.props):
+            if any(f({}, st, None) is not True for f in inits):
+                return k
+        return -1
+
+    def property_violated_step(self, st, s2):
+        nx = dict(enumerate(s2))
+        for k, (_, _, steps) in enumerate(self.props):
+            for act, sub in steps:
+                if sub({}, st, None) == sub({}, s2, None):
+                    continue
+                if not any(True for _ in act({}, st, nx)):
+                    return k
+        return -1
+
+    def _symmetry_group(self, name):
+        """the group generated by the cfg's SYMMETRY set of permutations (functions on model values), each as a dict"""
+        gens = [dict(fn_items(f)) for f in iter_set(self.spec.compile_value(name)({}, None, None))]
+        dom = sorted({k for g in gens for k in g}, key=vkey)
+        ident = tuple(dom)
+        gens = [tuple(g.get(k, k) for k in dom) for g in gens]
+        pos = {k: i for i, k in enumerate(dom)}
+        group, todo = {ident}, [ident]
+        while todo:
+            a = todo.pop()
+            for g in gens:
+                c = tuple(g[pos[x]] for x in a)
+                if c not in group:
+                    group.add(c)
+                    todo.append(c)
+        return [dict(zip(dom, g)) for g in sorted(group, key=lambda g: [vkey(x) for x in g])]
+
+    def canon(self, st):
+        """the orbit's key: the least image of the state under the group (any fixed choice gives the same orbit counts)"""
+        if not self.group:
+            return st
+        return min((permute(st, g) for g in self.group), key=vkey)
 
     def _split_spec(self, name):
         """Spec == Init /\\ [][Next]_vars (/\\ fairness): the first non-temporal conjunct is Init, [][N]_v gives Next"""
@@ -2103,15 +2303,24 @@ class Checker:
             nonlocal verdict, viol_inv, trace_len
             if verdict == "ok":
                 verdict, viol_inv, trace_len = kind, inv, depth_len
+        keys = set() if self.group else None  # SYMMETRY: the orbit decides whether a state is new; the state met first is kept
         for st in sp.init_states(self.init_name):
             generated += 1
-            if st in seen:
+            if keys is not None:
+                key = self.canon(st)
+                if key in keys:
+                    continue
+            elif st in seen:
                 continue
             k = self.violated(st)
             if k >= 0:
                 note("invariant", k, 1)
+            if self.props and self.property_violated_init(st) >= 0:
+                note("property", self.property_violated_init(st), 1)
             if not self.in_model(st):
                 continue
+            if keys is not None:
+                keys.add(key)
             seen[st] = None
             frontier.append(st)
         levels.append(len(frontier))
@@ -2133,13 +2342,23 @@ class Checker:
                     for s2 in sp.successors(st, self.nextf):
                         nsucc += 1
                         generated += 1
-                        if s2 in seen:
+                        if self.props:
+                            k = self.property_violated_step(st, s2)
+                            if k >= 0:
+                                note("property", k, depth + 1)
+                        if keys is not None:
+                            key = self.canon(s2)
+                            if key in keys:
+                                continue
+                        elif s2 in seen:
                             continue
                         inm = self.in_model(s2)
                         k = self.violated(s2)
                         if k >= 0:
                             note("invariant", k, depth + 1)
                         if inm:
+                            if keys is not None:
+                                keys.add(key)
                             seen[s2] = st
                             new.append(s2)
                 except AssertFail as e:
@@ -2179,11 +2398,13 @@ if __name__ == "__main__":
     ap.add_argument("-config")
     ap.add_argument("-I", action="append", default=[])
     ap.add_argument("-levels", type=int, default=0)
+    ap.add_argument("-deadlock", action="store_true", help="do not report deadlock (TLC's -deadlock)")
+    ap.add_argument("-nosymmetry", action="store_true", help="ignore the cfg's SYMMETRY")
     ap.add_argument("-naive", action="store_true", help="negative control: a second x' = e is ignored instead of tested")
     a = ap.parse_args()
     t0 = time.time()
-    c = Checker(a.tla, cfg_path=a.config, search=a.I, clash="ignore" if a.naive else "test")
-    r = c.run_levels(max_levels=a.levels, keep_states=False, progress=lambda d, n, g: print(f"  level {d}: {n} distinct, {g} generated", file=sys.stderr))
+    c = Checker(a.tla, cfg_path=a.config, search=a.I, clash="ignore" if a.naive else "test", symmetry=not a.nosymmetry)
+    r = c.run_levels(max_levels=a.levels, keep_states=False, check_deadlock=not a.deadlock, progress=lambda d, n, g: print(f"  level {d}: {n} distinct, {g} generated", file=sys.stderr))
     r.pop("level_states")
     r.pop("parents")
     r["seconds"] = time.time() - t0

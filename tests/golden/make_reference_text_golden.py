@@ -96,8 +96,75 @@ def run_ssi_text(name):
                 level_digests=digests)
 
 
+# ---------------------------------------------------------------------------------------------- Paxos family
+PAXOS_REF = REF / "Paxos"
+VOTING_ORDER = ["votes", "maxBal"]
+PAXOS_ORDER = ["maxBal", "maxVBal", "maxVal", "msgs"]
+# params = the C oracle's / the lowering's {kind (0 Paxos, 1 Voting), nAcceptor, nValue, nBallot, invariant mask, symmetry, property}
+# tla: the reference's own model module (read where it lies) or a wrapper of specs/paxos/ with the sizes MCPaxos.tla:7-9 names
+PAXOS_MODELS = {
+    "voting_mc": dict(params=[1, 3, 2, 2, 1, 3, 1], tla=PAXOS_REF / "MCVoting.tla", sym=True),          # MCVoting.cfg as committed
+    "voting_mc_nosym": dict(params=[1, 3, 2, 2, 1, 0, 1], tla=PAXOS_REF / "MCVoting.tla", sym=False),
+    "paxos_mc": dict(params=[0, 1, 1, 2, 15, 3, 1], tla=PAXOS_REF / "MCPaxos.tla", sym=True),          # MCPaxos.cfg as committed (1 x 1)
+    "paxos_3x2": dict(params=[0, 3, 2, 2, 15, 3, 1], tla=ROOT / "specs" / "paxos" / "MCPaxos3.tla", sym=True),
+    "paxos_3x2_nosym": dict(params=[0, 3, 2, 2, 15, 0, 1], tla=ROOT / "specs" / "paxos" / "MCPaxos3.tla", sym=False),
+    "paxos_3x2_b3": dict(params=[0, 3, 2, 3, 15, 3, 1], tla=ROOT / "specs" / "paxos" / "MCPaxos3.tla", sym=True, max_ballot=2, slow=True),
+}
+
+
+# negative controls: wrappers of specs/paxos/ in which something the cfg checks must FAIL; params as above ([7..] = quorum masks)
+PAXOS_NEGATIVE = {
+    "voting_badquorum": dict(params=[1, 3, 2, 2, 1, 0, 1, 3, 1, 2, 4], tla=ROOT / "specs" / "paxos" / "MCVotingBadQuorum.tla"),
+    "paxos_bad_phase2a": dict(params=[0, 3, 2, 2, 15, 0, 3], tla=ROOT / "specs" / "paxos" / "MCPaxosBad.tla"),
+}
+
+
+def run_paxos_negative(name):
+    """verdict of the evaluator on the wrapper's own cfg: what is violated (an INVARIANT by its cfg position, or the PROPERTY,
+    reported as index = number of invariants + its position, the convention of the oracle and the lowering) and the length of
+    the shortest counterexample"""
+    import tlaplus as T
+    c = T.Checker(PAXOS_NEGATIVE[name]["tla"], search=[PAXOS_REF])
+    r = c.run_levels(check_deadlock=False)
+    idx = r["violated_invariant"] + (len(c.invs) if r["verdict"] == "property" else 0)
+    return dict(verdict=r["verdict"], index=idx, trace_len=r["trace_len"],
+                name=(c.cfg["properties"] if r["verdict"] == "property" else c.cfg["invariants"])[r["violated_invariant"]])
+
+
+def run_paxos_text(name):
+    """deadlock checking off: Voting with a finite Ballot set ends in states without successors (every acceptor at the last
+    ballot); the reference's cfg files say nothing about it and TLC would need -deadlock to finish the run"""
+    import tlaplus as T
+    m = PAXOS_MODELS[name]
+    tla = Path(m["tla"])
+    if m.get("max_ballot"):  # same wrapper, MCMaxBallot edited: evaluated from a scratch copy beside nothing, found through `search`
+        import tempfile
+        d = Path(tempfile.mkdtemp())
+        text = tla.read_text().replace("MCMaxBallot == 1", f"MCMaxBallot == {m['max_ballot']}")
+        (d / tla.name).write_text(text)
+        (d / (tla.stem + ".cfg")).write_text(tla.with_suffix(".cfg").read_text())
+        tla = d / tla.name
+    c = T.Checker(tla, search=[PAXOS_REF], symmetry=m["sym"])
+    r = c.run_levels(check_deadlock=False)
+    out = dict(distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"], verdict=r["verdict"])
+    if not m["sym"]:  # under SYMMETRY the kept representative is whichever state of the orbit is met first: counts only
+        order = VOTING_ORDER if m["params"][0] == 1 else PAXOS_ORDER
+        out["level_digests"] = [hashlib.sha256("\n".join(sorted(c.spec.state_text(s, order) for s in lvl)).encode()).hexdigest()[:16]
+                                for lvl in r["level_states"]]
+    return out
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["raft", "ssi"]
+    which = sys.argv[1:] or ["raft", "ssi", "paxos"]
+    if "paxos" in which:
+        out = {}
+        for name in PAXOS_MODELS:
+            out[name] = run_paxos_text(name)
+            print(name, {k: v for k, v in out[name].items() if k != "level_digests"}, flush=True)
+        for name in PAXOS_NEGATIVE:
+            out[name] = run_paxos_negative(name)
+            print(name, out[name], flush=True)
+        (ROOT / "tests" / "golden" / "paxos_reference_text.json").write_text(json.dumps(out, indent=1) + "\n")
     if "raft" in which:
         out = {}
         for name in RAFT_MODELS:

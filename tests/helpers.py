@@ -107,7 +107,7 @@ def raft_device_params(orc, cm=0, ce=0, ca=0):
 
 # ---------------------------------------------------------------------------------- shim
 MC_MAX_LEVELS = 4096
-SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5}
+SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5, "paxos": 6}
 
 
 class McSpecDesc(C.Structure):

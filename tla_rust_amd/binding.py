@@ -8,7 +8,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "_build" / "libtlamc.so"
 
 MC_MAX_LEVELS = 4096
-SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5}
+SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5, "paxos": 6}
 VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
 MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING, MC_F_MATRIX, MC_F_NOPROBE, MC_F_NOFAMILY = 1, 2, 4, 8, 16, 32
 MC_F_UNVERIFIED = 512  # use the built-in lowering even when the module a wrapper EXTENDS cannot be found (include/tlamc.h)

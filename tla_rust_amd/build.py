@@ -26,16 +26,16 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "tlamc.h"]
     srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
-    # engine.hip is compiled once per group of specs (MC_TU = 1..6) plus once for the C ABI (MC_TU = 0), in
+    # engine.hip is compiled once per group of specs (MC_TU = 1..7) plus once for the C ABI (MC_TU = 0), in
     # parallel: the unrolled per-spec kernels dominate compile time.  Each object is rebuilt only when one of the
     # files it really depends on changed (a TU instantiates the kernels of its own spec header only).
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
               "-I", str(PKG.parent / "include")]
     base = [CSRC / "engine.hip", CSRC / "mc_common.h", CSRC / "spec_registry.h", PKG.parent / "include" / "tlamc.h"]
-    own = {0: ["spec_pluscal.h", "spec_raft.h", "spec_ssi.h", "spec_vm.h"], 1: ["spec_pluscal.h"], 2: ["spec_raft.h"],
+    own = {0: ["spec_pluscal.h", "spec_raft.h", "spec_ssi.h", "spec_vm.h", "spec_paxos.h"], 7: ["spec_paxos.h"], 1: ["spec_pluscal.h"], 2: ["spec_raft.h"],
            3: ["spec_raft.h"], 4: ["spec_raft.h"], 5: ["spec_ssi.h"], 6: ["spec_vm.h"]}
     jobs, objs = [], []
-    for tu in range(7):
+    for tu in range(8):
         obj = OUT / f"engine_tu{tu}.o"
         objs.append(obj)
         if force or _stale(obj, base + [CSRC / h for h in own[tu]]):

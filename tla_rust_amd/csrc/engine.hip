@@ -2629,7 +2629,8 @@ struct Engine : EngineBase {
 }  // namespace mc
 
 // --------------------------------------------------------------------------------------- engine factories
-// group 1: atomic_add + pcal_intro, 2: raft (2 servers), 3: raft (3), 4: raft (5), 5: serializableSnapshotIsolation
+// group 1: atomic_add + pcal_intro, 2: raft (2 servers), 3: raft (3), 4: raft (5), 5: serializableSnapshotIsolation,
+// 6: compiled PlusCal, 7: Voting / Paxos
 namespace mc {
 static int spec_group(const mc_spec_desc *d) {
     if (!d) return 0;
@@ -2638,6 +2639,7 @@ static int spec_group(const mc_spec_desc *d) {
     case MC_SPEC_RAFT: return d->nparams < 1 ? 0 : d->params[0] == 2 ? 2 : d->params[0] == 3 ? 3 : d->params[0] == 5 ? 4 : 0;
     case MC_SPEC_SSI: return 5;
     case MC_SPEC_PCAL: return 6;
+    case MC_SPEC_PAXOS: return 7;
     default: return 0;
     }
 }
@@ -2660,6 +2662,7 @@ int mc_make_engine_3(const mc_spec_desc *, const mc_config *, mc::EngineBase **)
 int mc_make_engine_4(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
 int mc_make_engine_5(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
 int mc_make_engine_6(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
+int mc_make_engine_7(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
 #if MC_TU == 1 || MC_TU == -1
 int mc_make_engine_1(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {
     if (d->spec_id == MC_SPEC_ATOMIC_ADD) {
@@ -2692,6 +2695,14 @@ int mc_make_engine_5(const mc_spec_desc *d, const mc_config *c, mc::EngineBase *
     mc::SsiParams p;
     if (mc::SpecSsi::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
     return mc::make_engine<mc::SpecSsi>(p, d, c, out);
+}
+#endif
+#if MC_TU == 7 || MC_TU == -1
+// Voting / Paxos (spec_paxos.h)
+int mc_make_engine_7(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {
+    mc::PaxosParams p;
+    if (mc::SpecPaxos::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+    return mc::make_engine<mc::SpecPaxos>(p, d, c, out);
 }
 #endif
 #if MC_TU == 6 || MC_TU == -1
@@ -2756,6 +2767,7 @@ int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine *
     case 4: rc = mc_make_engine_4(spec, cfg, &impl); break;
     case 5: rc = mc_make_engine_5(spec, cfg, &impl); break;
     case 6: rc = mc_make_engine_6(spec, cfg, &impl); break;
+    case 7: rc = mc_make_engine_7(spec, cfg, &impl); break;
     default: break;
     }
     if (rc == MC_OK) *out = new mc_engine{impl};

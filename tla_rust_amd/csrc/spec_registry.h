@@ -3,6 +3,7 @@
 // no general TLA+ evaluator in v1, each in-scope spec is hand-lowered.)
 #pragma once
 #include "../../include/tlamc.h"
+#include "spec_paxos.h"
 #include "spec_pluscal.h"
 #include "spec_raft.h"
 #include "spec_ssi.h"
@@ -45,6 +46,11 @@ int dispatch_spec(const mc_spec_desc *d, F &&f) {
         SsiParams p;
         if (SpecSsi::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
         return f(SpecSsi{}, p);
+    }
+    case MC_SPEC_PAXOS: {
+        PaxosParams p;
+        if (SpecPaxos::make_params(d->params, d->nparams, p)) return MC_EBADCFG;
+        return f(SpecPaxos{}, p);
     }
     case MC_SPEC_PCAL: {  // compiled PlusCal: params[0] = the mc_program handle (pcal_compile.cpp)
         VmParams p;
