@@ -338,3 +338,54 @@ def test_edited_atomic_add_n_takes_the_compiled_path(amd, tmp_path):
     r = amd.ResolvedSpec(tmp_path / "atomic_add_n.tla")
     assert r.spec == "pcal"
     r.close()
+
+
+def test_paxos_models_are_resolved_from_the_module_text(amd, tmp_path, monkeypatch):
+    """examples/Paxos/MCVoting.cfg:3-6, MCPaxos.cfg:4-9: the cfg replaces Acceptor / Value / Quorum / Ballot by DEFINITIONS of
+    the model module, so the sizes come from the text (MCAcceptor == {a1, a2, a3}; MCPaxos.tla:7-9 as committed: one
+    acceptor, one value).  Voting.tla / Paxos.tla / Consensus.tla are verified by hash where they are found."""
+    import shutil
+    P = ROOT / "specs" / "paxos"
+    monkeypatch.delenv("TLA_PATH", raising=False)
+    monkeypatch.delenv("TLAMC_UNVERIFIED", raising=False)
+    with pytest.raises(amd.McError) as e:                      # Paxos.tla not found: refused
+        amd.ResolvedSpec(P / "MCPaxos3.tla")
+    assert e.value.code == -9 and "Paxos" in str(e.value)
+    r = amd.ResolvedSpec(P / "MCPaxos3.tla", unverified=True)
+    assert (r.spec, r.params) == ("paxos", [0, 3, 2, 2, 15, 3, 1, 3, 3, 5, 6])
+    r = amd.ResolvedSpec(P / "MCVoting3.tla", unverified=True)
+    assert (r.spec, r.params) == ("paxos", [1, 3, 2, 3, 1, 3, 1, 3, 3, 5, 6])
+    with pytest.raises(amd.McError) as e:                      # quorums that do not intersect: TLC evaluates the ASSUME first
+        amd.ResolvedSpec(P / "MCVotingBadQuorum.tla", unverified=True)
+    assert "QuorumAssumption" in str(e.value)
+    with pytest.raises(amd.McError) as e:                      # another next-state relation than Paxos.tla's own
+        amd.ResolvedSpec(P / "MCPaxosBad.tla", unverified=True)
+    assert e.value.code == -9
+    # an invariant / property the lowering does not implement is refused, never ignored
+    d = tmp_path / "m"
+    d.mkdir()
+    shutil.copy(P / "MCPaxos3.tla", d / "MCPaxos3.tla")
+    (d / "MCPaxos3.cfg").write_text((P / "MCPaxos3.cfg").read_text().replace("Inv4", "Inv4 MCLiveness"))
+    with pytest.raises(amd.McError):
+        amd.ResolvedSpec(d / "MCPaxos3.tla", unverified=True)
+    (d / "MCPaxos3.cfg").write_text((P / "MCPaxos3.cfg").read_text().replace("Ballot <-[Voting] MCBallot", ""))
+    with pytest.raises(amd.McError) as e:
+        amd.ResolvedSpec(d / "MCPaxos3.tla", unverified=True)
+    assert "<-[Voting]" in str(e.value)
+    ref = REF / "examples" / "Paxos"
+    if ref.exists():   # build container: the reference's own model files, and an edited Voting.tla
+        r = amd.ResolvedSpec(ref / "MCVoting.tla")
+        assert (r.spec, r.params) == ("paxos", [1, 3, 2, 2, 1, 3, 1, 3, 3, 5, 6])
+        r = amd.ResolvedSpec(ref / "MCPaxos.tla")             # MCPaxos.tla:7-9 as committed
+        assert (r.spec, r.params) == ("paxos", [0, 1, 1, 2, 15, 3, 1, 1, 1])
+        monkeypatch.setenv("TLA_PATH", str(ref))
+        assert amd.ResolvedSpec(P / "MCPaxos3.tla").spec == "paxos"
+        monkeypatch.delenv("TLA_PATH")
+        for f in ("Paxos.tla", "Voting.tla"):
+            shutil.copy(ref / f, d / f)
+        (d / "MCPaxos3.cfg").write_text((P / "MCPaxos3.cfg").read_text())
+        assert amd.ResolvedSpec(d / "MCPaxos3.tla").spec == "paxos"
+        (d / "Voting.tla").write_text((ref / "Voting.tla").read_text().replace("maxBal[a] \\leq b", "maxBal[a] < b"))
+        with pytest.raises(amd.McError) as e:
+            amd.ResolvedSpec(d / "MCPaxos3.tla")
+        assert e.value.code == -9 and "Voting.tla differs" in str(e.value)

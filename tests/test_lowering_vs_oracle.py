@@ -18,6 +18,52 @@ CASES = [
 ]
 
 
+# the Paxos family (examples/Paxos/Voting.tla, Paxos.tla): {kind, nAcceptor, nValue, nBallot, invariants, symmetry, property};
+# deadlock checking off (Voting over a finite Ballot set ends without successors)
+PAXOS_CASES = [[1, 3, 2, 2, 1, 0, 1], [1, 2, 3, 3, 1, 0, 1], [0, 1, 1, 2, 15, 0, 1], [0, 3, 2, 2, 15, 0, 1], [0, 2, 3, 2, 15, 0, 1], [0, 2, 2, 3, 15, 0, 1]]
+PAXOS_SYM = [[1, 3, 2, 2, 1, 3, 1], [1, 4, 3, 3, 1, 3, 1], [1, 4, 2, 4, 1, 1, 1], [0, 3, 2, 2, 15, 3, 1], [0, 3, 2, 2, 15, 1, 1], [0, 3, 2, 2, 15, 2, 1],
+             [0, 3, 2, 3, 15, 3, 1], [0, 3, 3, 3, 15, 3, 1], [0, 4, 2, 2, 15, 3, 1]]
+
+
+@pytest.mark.parametrize("params", PAXOS_CASES)
+def test_paxos_same_states_per_level(oracle, shim, tmp_path, params):
+    od, sd = str(tmp_path / "o.txt"), str(tmp_path / "s.txt")
+    o = oracle.oracle_run("paxos", params, check_deadlock=False, dump=od)
+    s = shim.shim_run("paxos", params, check_deadlock=False, dump=sd)
+    for k in ("distinct", "generated", "depth", "verdict", "levels", "queue_left"):
+        assert o[k] == s[k], k
+    assert s["fp_mismatch"] == 0
+    assert oracle.read_dump(od) == shim.read_dump(sd)
+
+
+@pytest.mark.parametrize("params", PAXOS_SYM)
+def test_paxos_symmetry_counts(oracle, shim, tmp_path, params):
+    """SYMMETRY (MCVoting.tla:10, MCPaxos.tla:12): the lowering's least image (sorted acceptor blocks x value shuffles) against
+    the oracle's brute force over all na!·nv! images with the first-met representative: same orbit / generated / depth numbers,
+    and every representative the lowering stores is a state of the unreduced graph on the same level"""
+    o = oracle.oracle_run("paxos", params, check_deadlock=False)
+    sd, fd = str(tmp_path / "s.txt"), str(tmp_path / "f.txt")
+    s = shim.shim_run("paxos", params, check_deadlock=False, dump=sd)
+    for k in ("distinct", "generated", "depth", "verdict", "levels", "queue_left"):
+        assert o[k] == s[k], k
+    assert s["fp_mismatch"] == 0
+    full = params[:5] + [0] + params[6:]
+    f = shim.shim_run("paxos", full, check_deadlock=False, dump=fd)
+    assert f["depth"] == s["depth"] and f["distinct"] >= s["distinct"]
+    red, unred = shim.read_dump(sd), shim.read_dump(fd)
+    assert all(set(red[lvl]) <= set(unred[lvl]) for lvl in red)
+
+
+def test_paxos_rejects_what_it_cannot_pack(shim):
+    import ctypes as C
+    lib = shim.shim_lib()
+    for bad in ([0, 5, 2, 2], [0, 3, 4, 2], [0, 3, 2, 5], [0, 3, 2, 4, 15, 0, 1],          # 4 ballots of a 3 x 2 Paxos need a 76-bit block
+                [0, 3, 2, 2, 15, 1, 1, 2, 3, 4]):                                            # Permutations(Acceptor) does not preserve {{a1,a2},{a3}}
+        d = shim.spec_desc("paxos", bad)
+        r = shim.ShimResult()
+        assert lib.shim_run(C.byref(d), 0, 0, 0, None, C.byref(r)) != 0, bad
+
+
 @pytest.mark.parametrize("spec,params", CASES)
 def test_same_states_per_level(oracle, shim, tmp_path, spec, params):
     od, sd = str(tmp_path / "o.txt"), str(tmp_path / "s.txt")

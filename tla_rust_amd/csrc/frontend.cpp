@@ -300,6 +300,9 @@ constexpr uint64_t H_ATOMIC_ADD_N = 0x586f8fd08bcb696bull;      // specs/atomic_
 constexpr uint64_t H_MCRAFT = 0xa9171a6df0ae47d0ull;            // specs/MCraft.tla
 constexpr uint64_t H_MCSSI = 0xefcc77c2546e41bfull;             // specs/MCssi.tla
 constexpr uint64_t H_MCTEXTBOOK_SI = 0xe66bad24776b2048ull;     // specs/MCtextbookSI.tla
+constexpr uint64_t H_VOTING = 0xa61c2608a8ec9233ull;            // examples/Paxos/Voting.tla:6-199 (EXTENDS .. before ====)
+constexpr uint64_t H_PAXOS = 0x979510bc1153e9fbull;             // examples/Paxos/Paxos.tla
+constexpr uint64_t H_CONSENSUS = 0x96d890afa5b1ac82ull;         // examples/Paxos/Consensus.tla
 
 bool algorithm_text(const std::string &t, std::string &out) {
     const size_t i = t.find("--algorithm");
@@ -564,7 +567,8 @@ int mc_spec_resolve(const char *module, const mc_cfg *c, mc_spec_desc *out) {
         out->params[4] = textbook ? 1 : 0;
         return MC_OK;
     }
-    return fe_fail(MC_ENOSPEC, "module '%s' is not one of the lowered specs (atomic_add, atomic_add_n, pcal_intro, MCraft, MCssi)", module);
+    return fe_fail(MC_ENOSPEC, "module '%s' is not one of the lowered specs (atomic_add, atomic_add_n, pcal_intro, MCraft, MCssi; "
+                   "models of examples/Paxos are resolved from the module text: mc_resolve_files / mc_check_files)", module);
 }
 
 // ---------------------------------------------------------------------------------- PlusCal programs
@@ -657,6 +661,11 @@ static const char *invariant_name(const mc_spec_desc *d, int idx) {
     }
     if (d->spec_id == MC_SPEC_PCAL_INTRO) return "MoneyInvariant";
     if (d->spec_id == MC_SPEC_RAFT) return idx == 1 ? "CommittedLogStable" : "NoTwoLeaders";
+    if (d->spec_id == MC_SPEC_PAXOS) {
+        static const char *px[] = {"Inv1", "Inv2", "Inv3", "Inv4", "VotingSpecBar"}, *vt[] = {"Inv", "ConsensusSpecBar"};
+        if (d->params[0] == 1) return idx >= 0 && idx < 2 ? vt[idx] : "?";
+        return idx >= 0 && idx < 5 ? px[idx] : "?";
+    }
     if (d->spec_id == MC_SPEC_SSI) {
         static const char *nm[] = {"WellFormed", "CorrectnessOfHoldingXLocks", "CorrectnessOfWaitingForXLock", "CorrectReadView",
                                    "FirstCommitterWins", "CahillOK", "BernsteinOK", "(expected-to-be-violated predicate)"};
@@ -702,6 +711,201 @@ static int symmetry_sets(const std::string &tla, const std::string &name) {
         k = b;
     }
     return sets;
+}
+
+
+// ---------------------------------------------------------------------------------- the Paxos family (spec_paxos.h)
+// examples/Paxos/MCVoting.tla + .cfg and MCPaxos.tla + .cfg: the cfg replaces Acceptor / Value / Quorum / Ballot by
+// DEFINITIONS of the model module (`Acceptor <- MCAcceptor`, MCVoting.cfg:3-6), so the sizes of the model are read from the
+// module text: `MCAcceptor == {a1, a2, a3}`, `MCQuorum == {{a1, a2}, ...}`, `MCBallot == 0..1` / `0..MCMaxBallot`.
+namespace {
+std::string strip_comments(const std::string &t) {
+    std::string o;
+    int depth = 0;
+    for (size_t i = 0; i < t.size(); i++) {
+        if (t.compare(i, 2, "(*") == 0) { depth++; i++; continue; }
+        if (depth && t.compare(i, 2, "*)") == 0) { depth--; i++; continue; }
+        if (depth) { if (t[i] == '\n') o += '\n'; continue; }
+        if (t.compare(i, 2, "\\*") == 0) { while (i < t.size() && t[i] != '\n') i++; o += '\n'; continue; }
+        o += t[i];
+    }
+    return o;
+}
+// body of the zero-argument definition `name == ...` (text up to the next line that starts in column 1), blanks removed
+bool def_body(const std::string &t, const std::string &name, std::string &out) {
+    size_t at = 0;
+    for (;;) {
+        at = t.find(name, at);
+        if (at == std::string::npos) return false;
+        size_t q = at + name.size();
+        while (q < t.size() && (t[q] == ' ' || t[q] == '\t')) q++;
+        if ((at == 0 || t[at - 1] == '\n') && t.compare(q, 2, "==") == 0) { at = q + 2; break; }
+        at += name.size();
+    }
+    size_t end = at;
+    while (end < t.size()) {
+        const size_t eol = t.find('\n', end);
+        if (eol == std::string::npos) { end = t.size(); break; }
+        end = eol + 1;
+        if (end < t.size() && t[end] != ' ' && t[end] != '\t' && t[end] != '\n' && t[end] != '\r') break;
+    }
+    out.clear();
+    for (size_t i = at; i < end; i++)
+        if (t[i] != ' ' && t[i] != '\t' && t[i] != '\n' && t[i] != '\r') out += t[i];
+    return true;
+}
+// "{a1,a2,a3}" -> names
+bool parse_id_set(const std::string &b, size_t &i, std::vector<std::string> &out) {
+    if (i >= b.size() || b[i] != '{') return false;
+    i++;
+    out.clear();
+    while (i < b.size() && b[i] != '}') {
+        size_t j = i;
+        while (j < b.size() && Lexer::idch(b[j])) j++;
+        if (j == i) return false;
+        out.push_back(b.substr(i, j - i));
+        i = j;
+        if (i < b.size() && b[i] == ',') i++;
+    }
+    if (i >= b.size()) return false;
+    i++;
+    return true;
+}
+}  // namespace
+
+// 1 = not a Paxos-family model (the other resolvers go on); MC_OK = R.d is filled in; < 0 = an error
+static int resolve_paxos(const char *tla_path, const std::string &tla, const std::string &module, const mc_cfg *c, unsigned flags,
+                         mc_spec_desc &d, std::string &def_text, std::string &def_module_name, std::string &warning) {
+    const std::string t = strip_comments(tla);
+    const size_t ex = t.find("EXTENDS");
+    if (ex == std::string::npos) return 1;
+    const std::string exline = t.substr(ex, t.find('\n', ex) - ex);
+    auto extends = [&](const char *m) {
+        size_t k = exline.find(m);
+        while (k != std::string::npos) {
+            const bool l = k == 0 || !Lexer::idch(exline[k - 1]), r = k + strlen(m) >= exline.size() || !Lexer::idch(exline[k + strlen(m)]);
+            if (l && r) return true;
+            k = exline.find(m, k + 1);
+        }
+        return false;
+    };
+    const int kind = extends("Voting") ? 1 : extends("Paxos") ? 0 : -1;
+    if (kind < 0) return 1;
+    const char *base = kind ? "Voting" : "Paxos";
+    auto target = [&](const char *name, std::string &out) {
+        for (const auto &k : c->constants)
+            if (k.name == name && k.replacement && k.module.empty()) { out = k.target; return true; }
+        return false;
+    };
+    std::string tA, tV, tQ, tB, body;
+    if (!target("Acceptor", tA) || !target("Value", tV) || !target("Quorum", tQ) || !target("Ballot", tB))
+        return fe_fail(MC_EBADCFG, "%s: the cfg must replace Acceptor, Value, Quorum and Ballot by definitions of the model module "
+                       "(Acceptor <- MCAcceptor ..., examples/Paxos/MCVoting.cfg:3-6)", module.c_str());
+    if (kind == 0) {
+        bool scoped = false;  // Voting's own Ballot == Nat must be replaced too (MCPaxos.cfg:9)
+        for (const auto &k : c->constants) scoped |= k.name == "Ballot" && k.replacement && k.module == "Voting" && k.target == tB;
+        if (!scoped) return fe_fail(MC_EBADCFG, "%s: Paxos instantiates Voting, whose Ballot == Nat needs `Ballot <-[Voting] %s` (MCPaxos.cfg:9)", module.c_str(), tB.c_str());
+        if (!find_const(c, "None")) return fe_fail(MC_EBADCFG, "None is an unbounded CHOOSE (Paxos.tla:55): the cfg must give it a model value, None = None");
+    }
+    std::vector<std::string> acc, val, qs;
+    size_t i = 0;
+    if (!def_body(t, tA, body) || !parse_id_set(body, i = 0, acc) || i != body.size() || acc.empty() || acc.size() > 4)
+        return fe_fail(MC_ENOSPEC, "%s: %s must be a set of 1..4 model values, {a1, ...}", module.c_str(), tA.c_str());
+    if (!def_body(t, tV, body) || !parse_id_set(body, i = 0, val) || i != body.size() || val.empty() || val.size() > 3)
+        return fe_fail(MC_ENOSPEC, "%s: %s must be a set of 1..3 model values, {v1, ...}", module.c_str(), tV.c_str());
+    for (const auto &set : {acc, val})
+        for (const auto &nm : set) {
+            const CfgConst *k = find_const(c, nm.c_str());
+            if (!k || k->replacement || k->value.kind != CfgValue::IDENT) return fe_fail(MC_EBADCFG, "%s must be a model value of the cfg (%s = %s)", nm.c_str(), nm.c_str(), nm.c_str());
+        }
+    std::vector<long long> masks;
+    if (!def_body(t, tQ, body) || body.size() < 2 || body[0] != '{') return fe_fail(MC_ENOSPEC, "%s: %s must be a set of sets of acceptors", module.c_str(), tQ.c_str());
+    for (i = 1; i < body.size() && body[i] != '}';) {
+        if (!parse_id_set(body, i, qs) || qs.empty()) return fe_fail(MC_ENOSPEC, "%s: cannot read %s", module.c_str(), tQ.c_str());
+        long long m = 0;
+        for (const auto &nm : qs) {
+            const auto it = std::find(acc.begin(), acc.end(), nm);
+            if (it == acc.end()) return fe_fail(MC_ENOSPEC, "%s: %s is not an element of %s", tQ.c_str(), nm.c_str(), tA.c_str());
+            m |= 1ll << (it - acc.begin());
+        }
+        masks.push_back(m);
+        if (i < body.size() && body[i] == ',') i++;
+    }
+    if (masks.empty() || masks.size() > 8 || i + 1 != body.size()) return fe_fail(MC_ENOSPEC, "%s: %s must hold 1..8 quorums", module.c_str(), tQ.c_str());
+    for (size_t a = 0; a < masks.size(); a++)  // QuorumAssumption (Voting.tla:16-17, Paxos.tla:12-13): TLC checks the ASSUME first
+        for (size_t b = 0; b < masks.size(); b++)
+            if (!(masks[a] & masks[b])) return fe_fail(MC_EBADCFG, "Assumption QuorumAssumption is false: two quorums of %s do not intersect", tQ.c_str());
+    long long nb = -1;
+    if (!def_body(t, tB, body) || body.compare(0, 3, "0..") != 0) return fe_fail(MC_ENOSPEC, "%s: %s must be 0..N", module.c_str(), tB.c_str());
+    {
+        std::string hi = body.substr(3), hb;
+        if (!hi.empty() && !isdigit((unsigned char)hi[0]) && def_body(t, hi, hb)) hi = hb;
+        char *endp = nullptr;
+        nb = strtoll(hi.c_str(), &endp, 10) + 1;
+        if (hi.empty() || *endp || nb < 1 || nb > 4) return fe_fail(MC_ENOSPEC, "%s: %s must be 0..N with N <= 3", module.c_str(), tB.c_str());
+    }
+    if (c->specification != "Spec" || !c->init.empty() || !c->next.empty())
+        return fe_fail(MC_ENOSPEC, "%s: only SPECIFICATION Spec (%s.tla's own Init and Next) is lowered", module.c_str(), base);
+    if (!c->constraints.empty() || !c->action_constraints.empty() || !c->view.empty()) return fe_fail(MC_ENOSPEC, "%s: CONSTRAINT / VIEW are not part of the lowering", module.c_str());
+    long long inv = 0;
+    for (const auto &nm : c->invariants) {
+        std::string b;
+        if (kind == 1) {
+            if (nm == "Inv") inv |= 1;
+            else if (nm == "TypeOK") {}  // holds by construction of the packed state
+            else return fe_fail(MC_ENOSPEC, "the Voting lowering checks INVARIANT Inv (Voting.tla:160); '%s' is not lowered", nm.c_str());
+        } else if (nm == "Inv") inv |= 15;
+        else if (nm == "TypeOK") inv |= 1;
+        else if (def_body(t, nm, b) && b.size() == 5 && b.compare(0, 4, "Inv!") == 0 && b[4] >= '1' && b[4] <= '4') inv |= 1ll << (b[4] - '1');  // Inv3 == Inv!3 (MCPaxos.tla:65-68)
+        else return fe_fail(MC_ENOSPEC, "the Paxos lowering checks Inv (Paxos.tla:192-208) and its conjuncts Inv!1..Inv!4; '%s' is not one of them", nm.c_str());
+    }
+    long long prop = 0;
+    for (const auto &nm : c->properties) {
+        std::string b;
+        if (def_body(t, nm, b) && b == (kind ? "C!Spec" : "V!Spec")) prop = 1;  // ConsensusSpecBar == C!Spec (MCVoting.tla:26)
+        else return fe_fail(MC_ENOSPEC, "PROPERTY %s: only the refinement %s (its safety part, checked on every transition) is lowered", nm.c_str(), kind ? "C!Spec" : "V!Spec");
+    }
+    long long sym = 0;
+    if (!c->symmetry.empty()) {
+        std::string b;
+        if (!def_body(t, c->symmetry, b)) return fe_fail(MC_ENOSPEC, "SYMMETRY %s: no such definition in %s", c->symmetry.c_str(), module.c_str());
+        size_t k = 0;
+        while (k < b.size()) {
+            if (b.compare(k, 13, "Permutations(") != 0) return fe_fail(MC_ENOSPEC, "SYMMETRY %s must be a union of Permutations(%s) and Permutations(%s)", c->symmetry.c_str(), tA.c_str(), tV.c_str());
+            const size_t e = b.find(')', k);
+            const std::string arg = b.substr(k + 13, e - k - 13);
+            if (arg == tA) sym |= 1; else if (arg == tV) sym |= 2;
+            else return fe_fail(MC_ENOSPEC, "SYMMETRY %s: Permutations(%s) is neither the acceptors nor the values", c->symmetry.c_str(), arg.c_str());
+            k = e + 1;
+            if (b.compare(k, 4, "\\cup") == 0) k += 4; else if (b.compare(k, 6, "\\union") == 0) k += 6;
+        }
+    }
+    // the lowering is written against Voting.tla, Paxos.tla and Consensus.tla: verified where they are found (beside the
+    // model or under $TLA_PATH), refused otherwise unless -unverified
+    const char *env = getenv("TLA_PATH");
+    const std::vector<std::pair<const char *, uint64_t>> need = kind ? std::vector<std::pair<const char *, uint64_t>>{{"Voting", H_VOTING}, {"Consensus", H_CONSENSUS}}
+                                                                      : std::vector<std::pair<const char *, uint64_t>>{{"Paxos", H_PAXOS}, {"Voting", H_VOTING}};
+    for (const auto &nh : need) {
+        std::string text, part;
+        const bool found = read_file(dir_of(tla_path) + "/" + nh.first + ".tla", text) || (env && read_file(std::string(env) + "/" + nh.first + ".tla", text));
+        if (found) {
+            if (!module_body(text, part) || text_hash(part) != nh.second)
+                return fe_fail(MC_ENOSPEC, "%s.tla differs from the text the lowering was written against (examples/Paxos/%s.tla)", nh.first, nh.first);
+            if (!strcmp(nh.first, base)) { def_text = text; def_module_name = base; }
+        } else if (flags & MC_F_UNVERIFIED) {
+            warning = std::string("Warning: ") + nh.first + ".tla was found neither beside the module nor under $TLA_PATH; the built-in lowering was used without checking the module text.\n";
+        } else {
+            return fe_fail(MC_ENOSPEC, "module %s (needed by %s) was found neither beside it nor under $TLA_PATH: the lowering cannot be checked against its text "
+                           "(put %s.tla there, or pass -unverified)", nh.first, module.c_str(), nh.first);
+        }
+    }
+    memset(&d, 0, sizeof d);
+    d.spec_id = MC_SPEC_PAXOS;
+    d.params[0] = kind; d.params[1] = (long long)acc.size(); d.params[2] = (long long)val.size(); d.params[3] = nb;
+    d.params[4] = inv; d.params[5] = sym; d.params[6] = prop; d.params[7] = (long long)masks.size();
+    for (size_t q = 0; q < masks.size(); q++) d.params[8 + q] = masks[q];
+    d.nparams = 8 + (uint32_t)masks.size();
+    return MC_OK;
 }
 
 int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
@@ -758,6 +962,10 @@ static int resolve_files(const char *tla_path, const char *cfg_path, unsigned fl
     const bool has_alg = algorithm_text(tla, part);
     const uint64_t alg_hash = has_alg ? text_hash(part) : 0;
     bool generic = has_alg && (flags & MC_F_GENERIC);
+    if (!has_alg) {  // the Paxos family is recognised by what the model EXTENDS and by the cfg's replacements
+        rc = resolve_paxos(tla_path, tla, module, c, flags, d, def_text, def_module_name, R.warning);
+        if (rc <= 0) { mc_cfg_free(c); return rc; }
+    }
     if (!generic) {
         rc = mc_spec_resolve(module.c_str(), c, &d);
         if (rc == MC_ENOSPEC && has_alg) generic = true;
@@ -904,6 +1112,8 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
             o.put("The first argument of Assert evaluated to FALSE; the second argument was:\n\"Failure of assertion at line %d, column %d.\"\n", al, ac);
         }
         else if (res->verdict == MC_V_ASSERT) { /* compiled program: the message names the failing assert, found below */ }
+        else if (res->verdict == MC_V_INVARIANT && d.spec_id == MC_SPEC_PAXOS && res->violated_invariant == (d.params[0] == 1 ? 1 : 4))
+            o.put("Error: Action property %s is violated.\n", invariant_name(&d, res->violated_invariant));  // the step breaks [Next]_v of the PROPERTY
         else if (res->verdict == MC_V_INVARIANT) o.put("Error: Invariant %s is violated.\n", invariant_name(&d, res->violated_invariant));
         else if (res->verdict == MC_V_DEADLOCK) o.put("Error: Deadlock reached.\n");
         else o.put("Error: evaluation error (a function was applied outside its domain).\n");
