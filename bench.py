@@ -64,7 +64,8 @@ def main():
     ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
     ap.add_argument("--chunk", type=int, default=1 << 22)
     ap.add_argument("--shard-chunk", type=int, default=1 << 21, help="frontier states per round and rank in the sharded (torchrun) path")
-    ap.add_argument("--table-log2", type=int, default=27, help="seen-set slots: 2^27 = load 0.76 at the end of the run")
+    ap.add_argument("--table-slots", type=int, default=3 << 26, help="seen-set slots (any multiple of 64): 1.5 * 2^27 = 1.6 GB, load 0.51 at the end of the run")
+    ap.add_argument("--table-log2", type=int, default=0, help="A/B: a power-of-two seen-set (27: load 0.76, 28: load 0.38)")
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
     ap.add_argument("--direct", action="store_true", help="A/B: one kernel per chunk (k_expand_direct: expand + insert + copy-and-patch write)")
@@ -87,8 +88,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     G0 = golden()
+    slots = (1 << a.table_log2) if a.table_log2 else a.table_slots
     if not use_dist:
-        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=1 << a.table_log2, matrix=a.matrix,
+        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=slots, matrix=a.matrix,
                          debug_flags=(32 if a.no_family else 0) | (1024 if a.direct else 0) | (2048 if a.occ3 else 0) | (32768 if a.no_dense else 0) | (8192 if a.no_filter else 0),
                          arena_capacity=G0["distinct"] + (1 << 20),
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
@@ -97,7 +99,7 @@ def main():
         from tla_rust_amd.sharded import ShardedChecker
         # strong scaling: the same complete graph, its seen-set and frontier sharded over the ranks by fingerprint
         chk = ShardedChecker(WORKLOAD["spec"], WORKLOAD["params"], device=local, max_distinct=a.max_distinct,
-                             chunk_states=a.shard_chunk, table_capacity=(1 << 28) // world,
+                             chunk_states=a.shard_chunk, table_capacity=(slots * 4 // 3) // world // 64 * 64,
                              # a rank's share of the states (+25 % imbalance allowance) + the replicated prefix
                              arena_capacity=int(G0["distinct"] / world * 1.25) + (1 << 22),
                              fanout_cap=48, new_cap=6)
@@ -137,7 +139,7 @@ def main():
         "higher_is_better": True, "scaling": "strong" if a.gpus > 1 else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": WORKLOAD["name"], "distinct": D, "generated": G, "depth": res.depth,
                    "verdict": res.verdict, "queue_left": res.queue_left, "generated_per_s": G * a.steps / dt,
-                   "seen_set_load": D / float(1 << a.table_log2) if not use_dist else None,
+                   "seen_set_load": D / float(slots) if not use_dist else None,
                    "golden": f"tests/golden/raft_levels.json:{WORKLOAD['golden']} (exact-dedup CPU oracle): counts and per-level counts equal"
                              if not a.max_distinct else "A/B run with a budget: NOT the benchmark"},
     }

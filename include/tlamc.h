@@ -100,7 +100,8 @@ typedef struct {
 typedef struct {
     int32_t device;          /* HIP device ordinal                                              */
     uint32_t flags;          /* MC_F_*                                                          */
-    uint64_t table_capacity; /* seen-set slots, rounded up to a power of two (0 = default)      */
+    uint64_t table_capacity; /* seen-set slots, ANY number (rounded up to whole 64-slot groups; 0 = default 2^24):
+                                size it to the HBM that is left, not to a power of two             */
     uint64_t arena_capacity; /* states kept resident in HBM (0 = default)                       */
     uint64_t chunk_states;   /* frontier states expanded per launch (0 = default)               */
     uint64_t max_levels;     /* 0 = unlimited                                                   */

@@ -688,6 +688,9 @@ class MV:
     def __repr__(self):
         return self.name
 
+    def __reduce__(self):  # a model value crosses a process boundary by name (tests/golden/make_tlc_log_golden.py)
+        return (MV, (self.name,))
+
 
 class Fn:
     """a function whose domain is NOT 1..n (those are Python tuples; the empty function is ())"""
@@ -710,6 +713,9 @@ class Fn:
 
     def __repr__(self):
         return fmt(self)
+
+    def __reduce__(self):
+        return (Fn, (self.d,))
 
 
 def mk_fn(d):
@@ -2193,15 +2199,15 @@ class Checker:
         for n in flat:
             if n[0] == "temporal" and n[1] == "[]" and n[2][0] == "temporal" and n[2][1] == "[]_":
                 steps.append((sp.ca(n[2][2], {}), sp.cv(n[2][3], {})))
-            elif n[0] == "temporal" or (n[0] == "call" and n[1][:3] in ("WF_", "SF_")):
-                continue  # liveness: not checked
+            elif self._is_temporal(n) or (n[0] == "call" and n[1][:3] in ("WF_", "SF_")):
+                continue  # liveness (<>, ~>, fairness): not checked
             else:
                 inits.append(sp.cv(n, {}))
         return name, inits, steps
 
     def _is_temporal(self, n, seen=None):
         seen = seen if seen is not None else set()
-        if isinstance(n, tuple) and n and n[0] == "temporal":
+        if isinstance(n, tuple) and n and (n[0] == "temporal" or (n[0] == "op" and n[1] == "~>")):
             return True
         if isinstance(n, tuple) and n and n[0] == "id":
             nm = self.spec.overrides.get(n[1], n[1])

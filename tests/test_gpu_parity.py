@@ -325,3 +325,19 @@ def test_textbook_si_write_skew_on_gpu(amd, mask, inv):
     tr = eng.trace()
     assert len(tr) == 13 and tr[-1][1].count('"commit"') >= 2
     eng.close()
+
+
+@pytest.mark.parametrize("slots", [3 << 12, 40000, 1 << 16, 100032])
+def test_seen_set_of_any_size(amd, oracle, slots):
+    """the seen-set is sized in slots, not in powers of two (home bucket = multiply-shift of the fingerprint's low 32 bits):
+    same counts for every table size that holds the states, MC_ETABLEFULL for one that does not"""
+    o = oracle.oracle_run("raft", [2, 2, 2, 9, 1, 1])          # 13 634 distinct
+    eng = amd.Engine("raft", [2, 2, 2, 9, 1, 1], table_capacity=slots, arena_capacity=1 << 16, chunk_states=1 << 10)
+    if slots < o["distinct"]:
+        with pytest.raises(amd.McError) as e:
+            eng.run()
+        assert e.value.code == -4
+    else:
+        r = eng.run()
+        assert (r.distinct, r.generated, r.depth, r.levels) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    eng.close()

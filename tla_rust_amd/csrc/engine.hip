@@ -212,9 +212,14 @@ k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__
 // unsuccessful lookup, each a serialised trip to L2 / HBM.  Entries are write-once, so a non-zero word that was read is
 // final whatever cache it came from; an EMPTY word may be stale (the per-XCD L2s are not coherent), so it is only ever
 // taken by an agent-scope atomicCAS, whose return value is the truth.
-__device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t mask, uint64_t fp, unsigned &err) {
-    uint64_t b = (fp & mask) & ~7ull;
+// The table holds `nbuckets` buckets, ANY number of them (not a power of two: a seen-set is sized to the HBM that is left, and
+// between 128 GiB and 256 GiB there is a lot of a 288 GB device): the home bucket is the multiply-shift of the fingerprint's low
+// 32 bits (one v_mad_u64_u32; the owner rank of a sharded run comes from the high bits, fp_owner), the probe sequence is linear.
+// (The parameter is still called `mask` at the call sites' kernels: it carries nbuckets.)
+__device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
+    uint64_t bk = ((fp & 0xffffffffull) * nbuckets) >> 32;
     for (int probe = 0; probe < 2048; ++probe) {
+        const uint64_t b = bk * 8;
         const ulonglong2 *line = reinterpret_cast<const ulonglong2 *>(table + b);
         const ulonglong2 v0 = line[0], v1 = line[1], v2 = line[2], v3 = line[3];
         const unsigned long long slot[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
@@ -225,7 +230,7 @@ __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t mask, uint
             if (cur == 0) return true;
             if (cur == fp) return false;
         }
-        b = (b + 8) & mask;
+        bk = bk + 1 == nbuckets ? 0 : bk + 1;
     }
     err |= DEV_ETABLE;
     return false;
@@ -1549,8 +1554,9 @@ struct Engine : EngineBase {
             else HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         }
         for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&ev_e[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ev_m[i], hipEventDisableTiming)); }
-        table_cap = round_pow2(cfg.table_capacity ? cfg.table_capacity : (1ull << 24));
-        if (table_cap < 64) table_cap = 64;  // whole 8-slot buckets
+        table_cap = cfg.table_capacity ? cfg.table_capacity : (1ull << 24);
+        table_cap = (table_cap + 63) / 64 * 64;  // whole 8-slot buckets; any size (seen_insert), at most 2^32 buckets
+        if (table_cap / 8 > 0xffffffffull) { set_error("table_capacity: at most 2^35 - 8 slots per device"); return MC_EBADCFG; }
         arena_cap = cfg.arena_capacity ? cfg.arena_capacity : (1ull << 22);
         arena_cap = (arena_cap + 63) & ~63ull;
         if (arena_cap >= (1ull << 32) - 1) { set_error("arena_capacity must be < 2^32 states"); return MC_EBADCFG; }
@@ -1666,10 +1672,10 @@ struct Engine : EngineBase {
         if constexpr (HasPatch<S>::value) {
             if (cfg.flags & 2048u)  // A/B: register allocation for 3 waves per SIMD (no spills)
                 hipLaunchKernelGGL((k_expand_direct<S, 3>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0, c1, ncols,
-                                   d_table, table_cap - 1, arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
+                                   d_table, table_cap / 8, arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
             else
                 hipLaunchKernelGGL((k_expand_direct<S, 4>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0, c1, ncols,
-                                   d_table, table_cap - 1, arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
+                                   d_table, table_cap / 8, arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
         }
     }
     // one batched level (LevelCtl): the same pair of kernels, ranges read on the device, then the level is closed there
@@ -1687,7 +1693,7 @@ struct Engine : EngineBase {
         rt.new_fp = d_newfp;
         timed(0, 0, [&] {
             launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm, (const uint64_t *)d_arena,
-                                    (uint64_t)0, (uint64_t)0, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
+                                    (uint64_t)0, (uint64_t)0, ncols, d_table, table_cap / 8, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
         });
         timed(2, 0, [&] {
             hipLaunchKernelGGL(k_materialise<S>, dim3(32, NSHARD), dim3(256), 0, stream, prm, d_arena, (uint64_t)0, d_newlist, seg_cap,
@@ -1702,7 +1708,7 @@ struct Engine : EngineBase {
         const unsigned bx = (unsigned)((ncols + 255) / 256);
         timed(1, ncols * rows, [&] {
             hipLaunchKernelGGL(k_insert, dim3(bx, rows), dim3(256), 0, stream, d_cand, row_stride, ncols, d_nsl, d_table,
-                               table_cap - 1, d_newlist, d_ctr);
+                               table_cap / 8, d_newlist, d_ctr);
         });
         const unsigned gm = bx < 2048 ? bx : 2048;
         timed(2, 0, [&] {
@@ -1750,7 +1756,7 @@ struct Engine : EngineBase {
         const uint64_t ninit = resuming ? 0 : S::num_init(prm);
         if (resuming && ck_distinct)
             hipLaunchKernelGGL(k_reseed_table<S>, dim3((unsigned)((ck_distinct + 255) / 256)), dim3(256), 0, stream, prm,
-                               (const uint64_t *)d_arena, ck_distinct, d_table, table_cap - 1, d_ctr);
+                               (const uint64_t *)d_arena, ck_distinct, d_table, table_cap / 8, d_ctr);
         for (uint64_t first = 0; first < ninit; first += chunk) {
             const uint64_t count = ninit - first < chunk ? ninit - first : chunk;
             const uint64_t ncols = (count + 63) & ~63ull;
@@ -1830,7 +1836,7 @@ struct Engine : EngineBase {
                     rt_new.new_fp = d_newfp;
                     timed(0, c1 - c0, [&] {
                         launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
-                                                (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
+                                                (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap / 8, d_newlist, seg_cap, d_ctr,
                                                 cfg.flags, rt_new, parity);
                     });
                     finish_materialise(base, ncols, parity);
@@ -2089,7 +2095,7 @@ struct Engine : EngineBase {
             const uint64_t c1 = c0 + chunk < last_distinct ? c0 + chunk : last_distinct;
             const uint64_t ncols = ((c1 - c0) + 63) & ~63ull;
             launch_expand<S, false>(!((cfg.flags | extra_flags) & MC_F_NOFAMILY), cfg.flags | extra_flags, ncols, stream, prm,
-                                    (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr,
+                                    (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap / 8, d_newlist, seg_cap, d_ctr,
                                     cfg.flags | extra_flags, RouteArgs{}, 0u);
             hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr, 0u);
         }
@@ -2282,7 +2288,7 @@ struct Engine : EngineBase {
         q.ncols = ncols;
         timed(0, count, [&] {  // new-list parity = slot: the locally owned new states of this chunk (local-owner shortcut)
             launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
-                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap - 1, d_newlist, seg_cap, d_ctr, cfg.flags, rt, slot);
+                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap / 8, d_newlist, seg_cap, d_ctr, cfg.flags, rt, slot);
         });
         return MC_OK;
     }
@@ -2342,7 +2348,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipSetDevice(cfg.device));
         if (!n) return MC_OK;
         timed(1, n, [&] {
-            hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, side(), recv_fp, n, d_table, table_cap - 1, answers, d_ctr);
+            hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, side(), recv_fp, n, d_table, table_cap / 8, answers, d_ctr);
         }, side());
         return side_done();
     }
@@ -2394,7 +2400,7 @@ struct Engine : EngineBase {
         const uint64_t total = (uint64_t)nranks() * cap;
         if (!total) return MC_OK;
         timed(1, total, [&] {
-            hipLaunchKernelGGL(k_probe_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, side(), recv_fp, cap, total, d_table, table_cap - 1,
+            hipLaunchKernelGGL(k_probe_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, side(), recv_fp, cap, total, d_table, table_cap / 8,
                                answers, d_ctr);
         }, side());
         return side_done();

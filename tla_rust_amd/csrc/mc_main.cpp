@@ -240,6 +240,7 @@ int main(int argc, char **argv) {
         else if (arg("-maxdistinct")) cfg.max_distinct = strtoull(argv[++i], 0, 10);
         else if (arg("-maxlevels")) cfg.max_levels = strtoull(argv[++i], 0, 10);
         else if (arg("-tablelog2")) cfg.table_capacity = 1ull << atoi(argv[++i]);
+        else if (arg("-table")) cfg.table_capacity = strtoull(argv[++i], 0, 10);  // seen-set slots, any number
         else if (arg("-arena")) cfg.arena_capacity = strtoull(argv[++i], 0, 10);
         else if (arg("-chunk")) cfg.chunk_states = strtoull(argv[++i], 0, 10);
         else if (!strcmp(argv[i], "-help") || !strcmp(argv[i], "--help") || !strcmp(argv[i], "-h")) { tla = nullptr; break; }
