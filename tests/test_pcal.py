@@ -344,3 +344,23 @@ def test_wide_state_128_cells():
     os.unlink(dump)
     assert [states[l + 1] for l in range(3)] == o["states"]
     prog.close()
+
+
+def test_integer_overflow_and_division_like_tlc():
+    """TLC's integers are 32-bit and an overflow is an error, not a wrap; `\\div` rounds towards minus infinity
+    for a divisor of either sign; division by zero is an error"""
+    prog = helpers.ShimProgram(MODULE % "variables x = 2147483000, y = 0;\nbegin\nA: x := x + 1000;\nB: y := 1;")
+    assert helpers.shim_run("pcal", prog.params)["verdict"] == "spec-error"                 # 2^31 - 648 + 1000 overflows
+    prog.close()
+    prog = helpers.ShimProgram(MODULE % "variables x = 65536, y = 0;\nbegin\nA: y := x * x;")
+    assert helpers.shim_run("pcal", prog.params)["verdict"] == "spec-error"
+    prog.close()
+    text = MODULE % "variables a = 7, b = 0 - 2, q = 0, r = 0;\nbegin\nA: q := a \\div b;\nB: r := (0 - 7) \\div 2;\nC: assert q = 0 - 4 /\\ r = 0 - 4;"
+    prog = helpers.ShimProgram(text)
+    r = helpers.shim_run("pcal", prog.params)
+    o = Checker(prog.translated()).run_levels()
+    assert r["verdict"] == o["verdict"] == "ok" and r["distinct"] == o["distinct"]
+    prog.close()
+    prog = helpers.ShimProgram(MODULE % "variables a = 7, b = 0, q = 0;\nbegin\nA: q := a \\div b;")
+    assert helpers.shim_run("pcal", prog.params)["verdict"] == "spec-error"
+    prog.close()

@@ -119,15 +119,16 @@ struct SpecVmT {
             }
             case VM_LOADT: if (sp >= STACK) return R_ERROR; st[sp++] = t[c[pc++]]; break;
             case VM_STORET: t[c[pc++]] = st[--sp]; break;
-            case VM_ADD: --sp; st[sp - 1] = (int32_t)((uint32_t)st[sp - 1] + (uint32_t)st[sp]); break;
-            case VM_SUB: --sp; st[sp - 1] = (int32_t)((uint32_t)st[sp - 1] - (uint32_t)st[sp]); break;
-            case VM_MUL: --sp; st[sp - 1] = (int32_t)((uint32_t)st[sp - 1] * (uint32_t)st[sp]); break;
-            case VM_DIV: {  // TLA+ \div rounds towards minus infinity
+            // TLC's integers are 32-bit and it reports an overflow instead of wrapping: so does the program (R_ERROR)
+            case VM_ADD: { --sp; int32_t r; if (__builtin_add_overflow(st[sp - 1], st[sp], &r)) return R_ERROR; st[sp - 1] = r; break; }
+            case VM_SUB: { --sp; int32_t r; if (__builtin_sub_overflow(st[sp - 1], st[sp], &r)) return R_ERROR; st[sp - 1] = r; break; }
+            case VM_MUL: { --sp; int32_t r; if (__builtin_mul_overflow(st[sp - 1], st[sp], &r)) return R_ERROR; st[sp - 1] = r; break; }
+            case VM_DIV: {  // TLA+ \div rounds towards minus infinity, for a divisor of either sign; a \div 0 is an error
                 --sp;
                 const int32_t a = st[sp - 1], b = st[sp];
-                if (b <= 0) return R_ERROR;
+                if (b == 0 || (a == INT32_MIN && b == -1)) return R_ERROR;
                 int32_t q = a / b;
-                if ((a % b != 0) && (a < 0)) --q;
+                if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
                 st[sp - 1] = q;
                 break;
             }
@@ -140,7 +141,7 @@ struct SpecVmT {
                 st[sp - 1] = r;
                 break;
             }
-            case VM_NEG: st[sp - 1] = -st[sp - 1]; break;
+            case VM_NEG: if (st[sp - 1] == INT32_MIN) return R_ERROR; st[sp - 1] = -st[sp - 1]; break;
             case VM_EQ: --sp; st[sp - 1] = st[sp - 1] == st[sp]; break;
             case VM_NE: --sp; st[sp - 1] = st[sp - 1] != st[sp]; break;
             case VM_LT: --sp; st[sp - 1] = st[sp - 1] < st[sp]; break;
