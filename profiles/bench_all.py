@@ -12,8 +12,9 @@ WORKLOADS = [
     ("atomic_add N=24 (config 2 series)", "atomic_add", [24], dict(table_capacity=1 << 26, arena_capacity=(1 << 24) + 4096)),
     ("atomic_add N=28", "atomic_add", [28], dict(table_capacity=1 << 30, arena_capacity=(1 << 28) + 4096)),
     ("pcal_intro committed (config 1)", "pcal_intro", [0, 1, 20, 2], dict(table_capacity=1 << 16, arena_capacity=1 << 14)),
-    ("raft 3 servers, 25M budget (config 3, bench.py)", "raft", [3, 4, 2, 3, 1, 1, 16, 2, 8],
+    ("raft 3 servers, 25M budget (round 1's bench prefix)", "raft", [3, 4, 2, 3, 1, 1, 16, 2, 8],
      dict(table_capacity=1 << 28, arena_capacity=30_000_000, max_distinct=25_000_000)),
+    ("raft 3 servers complete, MaxMsgKeys=9 (29.7M)", "raft", [3, 4, 2, 3, 1, 1, 9, 0, 0, 9], dict(table_capacity=3 << 24, arena_capacity=31_000_000)),
     ("raft 2 servers MaxTerm=3 complete (4.3M)", "raft", [2, 1, 3, 9, 1, 1], dict(table_capacity=1 << 25, arena_capacity=5_000_000)),
     ("SSI 2x3 complete (7.9M), 7 invariants", "ssi", [2, 3, 127, 0], dict(table_capacity=1 << 26, arena_capacity=9_000_000)),
     ("SSI 4x3 levels 1-10 (config 5 prefix), 7 invariants", "ssi", [4, 3, 127, 0],
@@ -23,6 +24,12 @@ WORKLOADS = [
      dict(table_capacity=1 << 25, arena_capacity=8_000_000)),
     ("SSI 4x3 under SYMMETRY (config 5 as the run-book sets it up), 60M budget, 7 invariants", "ssi", [4, 3, 127, 0, 0, 3],
      dict(table_capacity=1 << 30, arena_capacity=400_000_000, max_distinct=60_000_000)),
+]
+WORKLOADS += [
+    # the Paxos family (examples/Paxos): small graphs, launch-bound — listed for completeness, not as a throughput claim
+    ("Paxos 3 acceptors x 2 values x ballots 0..2 (185 369 states), Inv1-4 + V!Spec", "paxos", [0, 3, 2, 3, 15, 0, 1],
+     dict(table_capacity=1 << 20, arena_capacity=1 << 18, deadlock=False)),
+    ("Paxos 3 x 2 x 0..2 under SYMMETRY (17 153 orbits)", "paxos", [0, 3, 2, 3, 15, 3, 1], dict(table_capacity=1 << 18, arena_capacity=1 << 16, deadlock=False)),
 ]
 if len(sys.argv) > 1:   # substring filter
     WORKLOADS = [w for w in WORKLOADS if sys.argv[1] in w[0]]

@@ -39,3 +39,18 @@ def test_first_progress_line_of_the_reference_tlc_log():
     assert r["levels"] == [4, 16, 60, 80]
     assert (r["generated"], r["distinct"]) == (772, 160)                                 # testout1:4
     assert r["queue_left"] == 80                                                         # TLC had dequeued one of them: 79
+
+
+def test_complete_run_of_the_reference_tlc_log():
+    """testout2:260-266, the end of the one complete TLC run the reference holds a log of: "Model checking completed. No error
+    has been found." / "6181 states generated, 195 distinct states found, 0 states left on queue." / "The state graph has
+    diameter 5."  The evaluator's complete run (about an hour on 8 cores: tests/golden/make_tlc_log_golden.py expands every
+    level's frontier with forked workers) is committed as tests/golden/tlc_log_mcinnerserial.json; the fixture must say what
+    TLC's log says, and the four levels this suite can afford to re-evaluate must be its first four."""
+    import json
+    g = json.loads((ROOT / "tests" / "golden" / "tlc_log_mcinnerserial.json").read_text())
+    assert (g["generated"], g["distinct"], g["depth"], g["verdict"]) == (6181, 195, 5, "ok")       # testout2:265-266, :260
+    assert g["levels"][:4] == [4, 16, 60, 80] and sum(g["levels"]) == 195
+    assert any(p["levels"] == 4 and (p["generated"], p["distinct"]) == (772, 160) for p in g["progress"])   # testout1:4 on the way
+    r = _checker().run_levels(max_levels=4)
+    assert r["levels"] == g["levels"][:4]

@@ -15,8 +15,8 @@
 // A permutation of Acceptor permutes the blocks, so the least image over Permutations(Acceptor) is the blocks SORTED; a
 // permutation of Value is a fixed bit shuffle inside every word.  The representative of an orbit is the lexicographically
 // least (word 0, sorted blocks) over the value permutations: nv! shuffles and one small sort instead of na!·nv! images.
-// (TLC keeps the first state of an orbit it meets; the counts do not depend on the choice: tests compare with the oracle's
-// brute force over all na!·nv! images and with oracle/tlaplus.py's first-met representatives.)
+// (TLC keeps the first state of an orbit it meets; the counts do not depend on the choice: the parity tests compare with a brute
+// force over all na!·nv! images and with first-met representatives.)
 //
 // Slots = TLC's enumeration of the action's witnesses (every witness of a bounded \E inside an action is one generated
 // successor, also when the quantified formula has no primed variable):
