@@ -16,7 +16,7 @@ WORKLOADS = [
      dict(table_capacity=1 << 28, arena_capacity=30_000_000, max_distinct=25_000_000)),
     ("raft 3 servers complete, MaxMsgKeys=9 (29.7M)", "raft", [3, 4, 2, 3, 1, 1, 9, 0, 0, 9], dict(table_capacity=3 << 24, arena_capacity=31_000_000)),
     ("raft 5 servers, log <= 5, 20M budget (config 4's model on one GPU)", "raft", [5, 6, 2, 5, 1, 1],
-     dict(table_capacity=3 << 26, arena_capacity=24_000_000, max_distinct=20_000_000)),
+     dict(table_capacity=3 << 26, arena_capacity=70_000_000, max_distinct=20_000_000)),
     ("raft 2 servers MaxTerm=3 complete (4.3M)", "raft", [2, 1, 3, 9, 1, 1], dict(table_capacity=1 << 25, arena_capacity=5_000_000)),
     ("SSI 2x3 complete (7.9M), 7 invariants", "ssi", [2, 3, 127, 0], dict(table_capacity=1 << 26, arena_capacity=9_000_000)),
     ("SSI 4x3 levels 1-10 (config 5 prefix), 7 invariants", "ssi", [4, 3, 127, 0],

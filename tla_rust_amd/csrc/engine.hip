@@ -215,16 +215,22 @@ k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__
 // The table holds `nbuckets` buckets, ANY number of them (not a power of two: a seen-set is sized to the HBM that is left, and
 // between 128 GiB and 256 GiB there is a lot of a 288 GB device): the home bucket is the multiply-shift of the fingerprint's low
 // 32 bits (one v_mad_u64_u32; the owner rank of a sharded run comes from the high bits, fp_owner), the probe sequence is linear.
-// (The parameter is still called `mask` at the call sites' kernels: it carries nbuckets.)
-__device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
+// SLOTS = 8: one 64-byte line per probe, for tables that fill up (the raft graphs: load 0.5 .. 0.8).  SLOTS = 4: 32 bytes per
+// probe, for a SPARSE table (capacity >= 3 x the states it can ever hold): random HBM reads cost by the byte — 1.2-1.3 TB/s on
+// this device whether they are 32- or 64-byte requests (atomic_add N = 28, 3.76 G probes into an 8 GB table: 94 ms with 32-byte,
+// 197 ms with 64-byte probes) — and at load <= 1/3 a 4-slot bucket almost always decides in one request.  The engine picks
+// the mode when it allocates the table (seen_arg()); bit 63 of the bucket count the kernels receive says which.
+template <int SLOTS>
+__device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
     uint64_t bk = ((fp & 0xffffffffull) * nbuckets) >> 32;
     for (int probe = 0; probe < 2048; ++probe) {
-        const uint64_t b = bk * 8;
+        const uint64_t b = bk * SLOTS;
         const ulonglong2 *line = reinterpret_cast<const ulonglong2 *>(table + b);
-        const ulonglong2 v0 = line[0], v1 = line[1], v2 = line[2], v3 = line[3];
-        const unsigned long long slot[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+        unsigned long long slot[SLOTS];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < SLOTS / 2; ++i) { const ulonglong2 v = line[i]; slot[2 * i] = v.x; slot[2 * i + 1] = v.y; }
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
             unsigned long long cur = slot[i];
             if (cur == 0) cur = atomicCAS((unsigned long long *)&table[b + i], 0ull, (unsigned long long)fp);
             if (cur == 0) return true;
@@ -234,6 +240,12 @@ __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t nbuckets, 
     }
     err |= DEV_ETABLE;
     return false;
+}
+constexpr uint64_t SEEN_SPARSE = 1ull << 63;
+// (the parameter is still called `mask` in the kernels' signatures: it carries the bucket count and the mode bit)
+__device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
+    if (nbuckets & SEEN_SPARSE) return seen_insert_t<4>(table, nbuckets & ~SEEN_SPARSE, fp, err);
+    return seen_insert_t<8>(table, nbuckets, fp, err);
 }
 
 // checkpoint recovery: the seen-set is not part of a checkpoint — it is rebuilt from word 0 (the fingerprint) of the
@@ -640,7 +652,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             const unsigned k = (qhead + lane) & (QCAP - 1);
             src = Q.q_src[k];
             qfp = Q.q_fp[k];
-            if constexpr (!ROUTE) is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);
+            if constexpr (!ROUTE) is_new = (flags & 16u) ? false : seen_insert_t<8>(table, mask, qfp, err);
         }
         qhead = (qhead + take) & (QCAP - 1);
         qn -= take;
@@ -651,7 +663,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             // ranks 1/P of the candidates skip the exchange; on one rank the sharded engine does exactly the fused engine's work.
             unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
             if (owner == rt.my_rank) {
-                is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);
+                is_new = (flags & 16u) ? false : seen_insert_t<8>(table, mask, qfp, err);
                 owner = 0xffffffffu;
             }
             {
@@ -1015,7 +1027,7 @@ k_expand_direct(typename S::Params prm, uint64_t *arena, uint64_t lo, uint64_t h
                     if (st & ST_INVARIANT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_INVARIANT, st >> 8));
                     if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) {
                         ++probes;
-                        is_new = (flags & 16u) ? false : seen_insert(table, mask, fv, err);  // 16 = ablation: no probes
+                        is_new = (flags & 16u) ? false : seen_insert_t<8>(table, mask, fv, err);  // 16 = ablation: no probes
                         pd[0] |= (uint64_t)(p | ((unsigned)slot << 6));
                     }
                 }
@@ -1531,6 +1543,8 @@ struct Engine : EngineBase {
     DevCounters *d_ctr = nullptr, *h_ctr = nullptr;
     LevelCtl *d_lc = nullptr, *h_lc = nullptr;
     uint64_t table_cap = 0, arena_cap = 0, chunk = 0, row_stride = 0, seg_cap = 0;
+    bool seen_sparse = false;
+    uint64_t seen_arg() const { return seen_sparse ? ((table_cap / 4) | SEEN_SPARSE) : table_cap / 8; }
     KTimer timer;
     mc_kernel_stat kstat[3];
     // counterexample of the last run
@@ -1560,6 +1574,9 @@ struct Engine : EngineBase {
         arena_cap = cfg.arena_capacity ? cfg.arena_capacity : (1ull << 22);
         arena_cap = (arena_cap + 63) & ~63ull;
         if (arena_cap >= (1ull << 32) - 1) { set_error("arena_capacity must be < 2^32 states"); return MC_EBADCFG; }
+        // a table that can never be more than a third full is probed 32 bytes at a time (seen_insert); the by-family kernels of
+        // the raft lowering are compiled for the 64-byte form only (their graphs fill the table)
+        seen_sparse = !UsesFamilies<S>::value && table_cap >= 3 * arena_cap && table_cap / 4 <= 0xffffffffull && !getenv("TLAMC_DENSE_TABLE");
         chunk = cfg.chunk_states ? cfg.chunk_states : (1ull << 18);
         chunk = (chunk + 255) & ~255ull;
         if (chunk > (1ull << 23)) chunk = 1ull << 23;  // a column index must fit 24 bits
@@ -1672,10 +1689,10 @@ struct Engine : EngineBase {
         if constexpr (HasPatch<S>::value) {
             if (cfg.flags & 2048u)  // A/B: register allocation for 3 waves per SIMD (no spills)
                 hipLaunchKernelGGL((k_expand_direct<S, 3>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0, c1, ncols,
-                                   d_table, table_cap / 8, arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
+                                   d_table, seen_arg(), arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
             else
                 hipLaunchKernelGGL((k_expand_direct<S, 4>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0, c1, ncols,
-                                   d_table, table_cap / 8, arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
+                                   d_table, seen_arg(), arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
         }
     }
     // one batched level (LevelCtl): the same pair of kernels, ranges read on the device, then the level is closed there
@@ -1693,7 +1710,7 @@ struct Engine : EngineBase {
         rt.new_fp = d_newfp;
         timed(0, 0, [&] {
             launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm, (const uint64_t *)d_arena,
-                                    (uint64_t)0, (uint64_t)0, ncols, d_table, table_cap / 8, d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
+                                    (uint64_t)0, (uint64_t)0, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
         });
         timed(2, 0, [&] {
             hipLaunchKernelGGL(k_materialise<S>, dim3(32, NSHARD), dim3(256), 0, stream, prm, d_arena, (uint64_t)0, d_newlist, seg_cap,
@@ -1708,7 +1725,7 @@ struct Engine : EngineBase {
         const unsigned bx = (unsigned)((ncols + 255) / 256);
         timed(1, ncols * rows, [&] {
             hipLaunchKernelGGL(k_insert, dim3(bx, rows), dim3(256), 0, stream, d_cand, row_stride, ncols, d_nsl, d_table,
-                               table_cap / 8, d_newlist, d_ctr);
+                               seen_arg(), d_newlist, d_ctr);
         });
         const unsigned gm = bx < 2048 ? bx : 2048;
         timed(2, 0, [&] {
@@ -1756,7 +1773,7 @@ struct Engine : EngineBase {
         const uint64_t ninit = resuming ? 0 : S::num_init(prm);
         if (resuming && ck_distinct)
             hipLaunchKernelGGL(k_reseed_table<S>, dim3((unsigned)((ck_distinct + 255) / 256)), dim3(256), 0, stream, prm,
-                               (const uint64_t *)d_arena, ck_distinct, d_table, table_cap / 8, d_ctr);
+                               (const uint64_t *)d_arena, ck_distinct, d_table, seen_arg(), d_ctr);
         for (uint64_t first = 0; first < ninit; first += chunk) {
             const uint64_t count = ninit - first < chunk ? ninit - first : chunk;
             const uint64_t ncols = (count + 63) & ~63ull;
@@ -1836,7 +1853,7 @@ struct Engine : EngineBase {
                     rt_new.new_fp = d_newfp;
                     timed(0, c1 - c0, [&] {
                         launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
-                                                (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap / 8, d_newlist, seg_cap, d_ctr,
+                                                (const uint64_t *)d_arena, c0, c1, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr,
                                                 cfg.flags, rt_new, parity);
                     });
                     finish_materialise(base, ncols, parity);
@@ -2095,7 +2112,7 @@ struct Engine : EngineBase {
             const uint64_t c1 = c0 + chunk < last_distinct ? c0 + chunk : last_distinct;
             const uint64_t ncols = ((c1 - c0) + 63) & ~63ull;
             launch_expand<S, false>(!((cfg.flags | extra_flags) & MC_F_NOFAMILY), cfg.flags | extra_flags, ncols, stream, prm,
-                                    (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap / 8, d_newlist, seg_cap, d_ctr,
+                                    (const uint64_t *)d_arena, c0, c1, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr,
                                     cfg.flags | extra_flags, RouteArgs{}, 0u);
             hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr, 0u);
         }
@@ -2288,7 +2305,7 @@ struct Engine : EngineBase {
         q.ncols = ncols;
         timed(0, count, [&] {  // new-list parity = slot: the locally owned new states of this chunk (local-owner shortcut)
             launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
-                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, table_cap / 8, d_newlist, seg_cap, d_ctr, cfg.flags, rt, slot);
+                                   (const uint64_t *)d_arena, c0, c1, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr, cfg.flags, rt, slot);
         });
         return MC_OK;
     }
@@ -2348,7 +2365,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipSetDevice(cfg.device));
         if (!n) return MC_OK;
         timed(1, n, [&] {
-            hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, side(), recv_fp, n, d_table, table_cap / 8, answers, d_ctr);
+            hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, side(), recv_fp, n, d_table, seen_arg(), answers, d_ctr);
         }, side());
         return side_done();
     }
@@ -2400,7 +2417,7 @@ struct Engine : EngineBase {
         const uint64_t total = (uint64_t)nranks() * cap;
         if (!total) return MC_OK;
         timed(1, total, [&] {
-            hipLaunchKernelGGL(k_probe_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, side(), recv_fp, cap, total, d_table, table_cap / 8,
+            hipLaunchKernelGGL(k_probe_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, side(), recv_fp, cap, total, d_table, seen_arg(),
                                answers, d_ctr);
         }, side());
         return side_done();
