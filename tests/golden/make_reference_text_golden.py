@@ -108,7 +108,7 @@ PAXOS_MODELS = {
     "paxos_mc": dict(params=[0, 1, 1, 2, 15, 3, 1], tla=PAXOS_REF / "MCPaxos.tla", sym=True),          # MCPaxos.cfg as committed (1 x 1)
     "voting_3x2_b3": dict(params=[1, 3, 2, 3, 1, 3, 1], tla=ROOT / "specs" / "paxos" / "MCVoting3.tla", sym=True),    # ballots 0..2
     "paxos_3x2": dict(params=[0, 3, 2, 2, 15, 3, 1], tla=ROOT / "specs" / "paxos" / "MCPaxos3.tla", sym=True),
-    "paxos_3x2_nosym": dict(params=[0, 3, 2, 2, 15, 0, 1], tla=ROOT / "specs" / "paxos" / "MCPaxos3.tla", sym=False),
+    "paxos_3x2_nosym": dict(params=[0, 3, 2, 2, 15, 0, 1], tla=ROOT / "specs" / "paxos" / "MCPaxos3.tla", sym=False, slow=True),  # 30 s
     "paxos_3x2_b3": dict(params=[0, 3, 2, 3, 15, 3, 1], tla=ROOT / "specs" / "paxos" / "MCPaxos3.tla", sym=True, max_ballot=2, slow=True),
 }
 

@@ -21,7 +21,7 @@ CASES = [
 # the Paxos family (examples/Paxos/Voting.tla, Paxos.tla): {kind, nAcceptor, nValue, nBallot, invariants, symmetry, property};
 # deadlock checking off (Voting over a finite Ballot set ends without successors)
 PAXOS_CASES = [[1, 3, 2, 2, 1, 0, 1], [1, 2, 3, 3, 1, 0, 1], [0, 1, 1, 2, 15, 0, 1], [0, 3, 2, 2, 15, 0, 1], [0, 2, 3, 2, 15, 0, 1], [0, 2, 2, 3, 15, 0, 1]]
-PAXOS_SYM = [[1, 3, 2, 2, 1, 3, 1], [1, 4, 3, 3, 1, 3, 1], [1, 4, 2, 4, 1, 1, 1], [0, 3, 2, 2, 15, 3, 1], [0, 3, 2, 2, 15, 1, 1], [0, 3, 2, 2, 15, 2, 1],
+PAXOS_SYM = [[1, 3, 2, 2, 1, 3, 1], [1, 4, 3, 3, 1, 3, 1], [1, 4, 2, 3, 1, 1, 1], [0, 3, 2, 2, 15, 3, 1], [0, 3, 2, 2, 15, 1, 1], [0, 3, 2, 2, 15, 2, 1],
              [0, 3, 2, 3, 15, 3, 1], [0, 3, 3, 3, 15, 3, 1], [0, 4, 2, 2, 15, 3, 1]]
 
 

@@ -114,9 +114,15 @@ __device__ __forceinline__ GlobalWords uniform_ptr(const uint64_t *p) {
 MC_HD WordRef arena_ref(uint64_t *arena, uint64_t idx, int words) {
     return WordRef{arena + ((idx >> 6) * (uint64_t)words) * 64 + (idx & 63), 64};
 }
+// Order of the keys = order in which TLC would have met the errors of one level: a state that ITSELF violates an invariant
+// (SLOT_PARENT: specs that check per stored state) was generated on the previous level, before anything of this level was
+// expanded — bit 62 is clear for it and set for everything found while generating successors; then by arena index, then by slot.
+static constexpr unsigned long long VIOL_LATER = 1ull << 62;
 MC_HD unsigned long long viol_key(uint64_t idx, unsigned slot, unsigned kind, unsigned inv) {
-    return ((unsigned long long)idx << 24) | ((unsigned long long)(slot & 0xffffu) << 8) | ((inv & 31u) << 3) | kind;
+    return ((slot & 0xffffu) == 0xfffdu ? 0ull : VIOL_LATER) | ((unsigned long long)idx << 24) | ((unsigned long long)(slot & 0xffffu) << 8) |
+           ((inv & 31u) << 3) | kind;
 }
+MC_HD uint64_t viol_idx(unsigned long long key) { return (uint64_t)((key & ~VIOL_LATER) >> 24); }
 
 // ------------------------------------------------------------------------------------- expand
 template <class S>
@@ -2032,7 +2038,7 @@ struct Engine : EngineBase {
         const unsigned slot = (unsigned)(last_viol >> 8 & 0xffffu);
         if (slot == SLOT_INIT) return MC_OK;  // violated by an initial state: handled by the caller
         if (!d_parent) { set_error("engine created without MC_F_TRACE"); return MC_ESTATE; }
-        uint64_t idx = last_viol >> 24;
+        uint64_t idx = viol_idx(last_viol);
         for (int guard = 0; guard < MC_MAX_LEVELS; ++guard) {
             chain.push_back(idx);
             uint32_t p;
@@ -2052,7 +2058,7 @@ struct Engine : EngineBase {
         std::vector<int32_t> acts;
         if (slot == SLOT_INIT) {  // an initial state violates an invariant
             words.resize(W);
-            S::init(prm, last_viol >> 24, WordRef{words.data(), 1});
+            S::init(prm, viol_idx(last_viol), WordRef{words.data(), 1});
             acts.push_back(-1);
         } else {
             std::vector<uint64_t> chain;
@@ -2563,7 +2569,7 @@ struct Engine : EngineBase {
         if (*found) {
             const unsigned long long k = h_ctr->viol_key;
             const unsigned kind = (unsigned)(k & 7u);
-            *idx = k >> 24;
+            *idx = viol_idx(k);
             *slot = (uint32_t)(k >> 8 & 0xffffu);
             *verdict = kind == VK_INVARIANT ? MC_V_INVARIANT : kind == VK_ASSERT ? MC_V_ASSERT : kind == VK_DEADLOCK ? MC_V_DEADLOCK : MC_V_SPECERR;
             if (kind == VK_INVARIANT) *invariant = (int32_t)(k >> 3 & 31u);

@@ -41,6 +41,10 @@ struct SpecPaxos {
     using Params = PaxosParams;
     static constexpr int XA = 4, XV = 3, XB = 4;
     static constexpr int MAX_WORDS = 1 + XA, FIX_SLOTS = 0, STAGE_WORDS = 0;
+    // the INVARIANTs are evaluated once per STORED state, when it is expanded (parent_status), like TLC evaluates them once per
+    // new state — not once per generated successor (7 x as many here); the engine checks a run's last, unexpanded level too.
+    // The PROPERTY is a predicate of a TRANSITION and stays with the successor (eval).
+    static constexpr bool CHECK_ON_EXPAND = true;
     struct Local { uint64_t w[MAX_WORDS]; };
     struct View { unsigned votes[XA]; int maxBal[XA]; };  // what Voting's operators read: votes[a] as bits b*nv + v
 
@@ -279,7 +283,7 @@ struct SpecPaxos {
         for (int i = 0; i < MAX_WORDS; i++) l.w[i] = i <= p.na ? s.get(i) : 0;
     }
     MC_HD static int nslots(const Params &p, const Local &) { return max_slots(p); }
-    MC_HD static unsigned parent_status(const Params &, const Local &, CWordRef) { return 0; }
+    MC_HD static unsigned parent_status(const Params &p, const Local &l, CWordRef) { return check_invariants(p, l.w); }
 
     // invariants of the cfg on a (not yet canonicalised) state; returns the status bits
     MC_HD static unsigned check_invariants(const Params &p, const uint64_t *w) {
@@ -411,7 +415,6 @@ struct SpecPaxos {
         bool same = true;
         for (int i = 0; i <= p.na; i++) same &= t[i] == w[i];
         if (same) return st | ST_SELFLOOP;  // e.g. Phase1a(b) of a ballot whose 1a message is already in msgs
-        if (!(st & ST_INVARIANT)) st |= check_invariants(p, t);
         canonicalise(p, t);
         return st;
     }
