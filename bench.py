@@ -50,7 +50,12 @@ def cpu_baseline(max_seconds=15.0):
     out = subprocess.run([str(exe), "raft", *p, "--threads", str(cores), "--max-seconds", str(max_seconds), "--distinct", "60000000"],
                          capture_output=True, text=True, check=True).stdout
     r = json.loads(out.splitlines()[0])
-    return dict(value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=cores, kind="port",
+    # stock TLC on the same box would be the preferred baseline — probe for it every time and say what was found
+    import shutil
+    java = shutil.which("java")
+    jar = next((str(q) for d in ("/usr/share/java", "/opt", str(Path.home())) if Path(d).is_dir() for q in Path(d).glob("**/tla2tools.jar")), None) if java else None
+    tlc = f"java at {java}, tla2tools.jar {'at ' + jar if jar else 'not found'}" if java else "no java on PATH"
+    return dict(tlc_probe=tlc, value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=cores, kind="port",
                 sample=f"not TLC (no JVM on the box): in-house exact-dedup multi-threaded C BFS, {cores} threads, same cfg, "
                        f"levels 1-{r['depth']} = {r['distinct']} distinct / {r['generated']} generated states in {r['seconds']:.1f} s")
 

@@ -146,6 +146,11 @@ typedef struct mc_engine mc_engine;
  * checks, counters, depth and counterexample (README.md:267-321, testout2:1-266). */
 int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine **out);
 int mc_engine_run(mc_engine *e, mc_result *out);
+/* Incremental search: `levels` more BFS levels.  The first call starts from Init (like mc_engine_run with max_levels = levels);
+ * a call after a step that stopped at its budget (MC_V_BUDGET) continues where it stopped — arena, seen-set and parent pointers
+ * stay resident in HBM, nothing is recomputed; `out` holds the counters of the whole search so far.  After a step that ended
+ * the search (MC_V_OK) or found an error, the next call starts over.  cfg.max_distinct still applies. */
+int mc_engine_step(mc_engine *e, uint32_t levels, mc_result *out);
 /* Progress reports while mc_engine_run searches (TLC's "Progress(5): 6117 states generated, 195 distinct states found, 1 states
  * left on queue.", testout2:4-259): `fn` is called from the calling thread between two BFS levels, at most once per
  * `min_interval_seconds`, with the number of levels found so far and the three counters.  fn = NULL switches it off. */

@@ -211,3 +211,44 @@ def test_corrupt_level_table_is_refused(amd, tmp_path):
         small_table.restore(tmp_path / "ten")
     assert ei.value.code == -4
     small_table.close()
+
+
+@pytest.mark.parametrize("spec,params,stride", [("ssi", [2, 2, 127, 0], 3), ("raft", [2, 2, 2, 9, 1, 1], 5), ("paxos", [0, 3, 2, 2, 15, 3, 1], 4),
+                                                  ("atomic_add", [11], 1)])
+def test_incremental_steps_equal_one_run(amd, oracle, spec, params, stride):
+    """mc_engine_step (the optional incremental entry point): the search advanced `stride` levels at a time, in
+    place — arena, seen-set and parent pointers stay in HBM between the calls — ends with the counters, the per-level counts
+    and the state sets of one uninterrupted run; every intermediate result is a prefix of it"""
+    o = oracle.oracle_run(spec, params, check_deadlock=(spec != "paxos"))
+    kw = dict(table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 10, deadlock=(spec != "paxos"))
+    e = amd.Engine(spec, params, **kw)
+    seen_levels, r = 0, None
+    for _ in range(100):
+        r = e.step(stride)
+        assert r.levels == o["levels"][:len(r.levels)] and len(r.levels) >= min(len(o["levels"]), seen_levels + 1)
+        seen_levels = len(r.levels)
+        if r.verdict != "budget":
+            break
+    assert (r.verdict, r.distinct, r.generated, r.depth, r.levels, r.queue_left) == \
+           (o["verdict"], o["distinct"], o["generated"], o["depth"], o["levels"], o["queue_left"])
+    full = amd.Engine(spec, params, **kw)
+    rf = full.run()
+    assert sorted(e.state_texts(0, r.distinct)) == sorted(full.state_texts(0, rf.distinct))
+    r2 = e.step(2)                     # after the end: starts over
+    assert r2.levels == o["levels"][:2] and r2.verdict == "budget"
+    e.close(); full.close()
+
+
+def test_counterexample_found_by_a_later_step(amd, oracle):
+    params = [3, 2, 127, 3]
+    o = oracle.oracle_run("ssi", params)
+    e = amd.Engine("ssi", params, table_capacity=1 << 24, arena_capacity=1 << 22, chunk_states=1 << 16)
+    r = e.step(len(o["trace"]) - 3)
+    assert r.verdict == "budget"
+    r = e.step(2)
+    assert r.verdict == "budget"
+    r = e.step(5)
+    assert (r.verdict, r.violated_invariant, r.trace_len) == ("invariant", 7, len(o["trace"]))
+    tr = e.trace()
+    assert len(tr) == r.trace_len and tr[0][0] == "Initial predicate" and "forced by deadlock-prevention" in tr[-1][1]
+    e.close()

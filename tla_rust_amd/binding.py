@@ -74,6 +74,7 @@ def lib():
     L = C.CDLL(str(LIB_PATH))
     L.mc_engine_create.argtypes = [C.POINTER(SpecDesc), C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.mc_engine_run.argtypes = [C.c_void_p, C.POINTER(CResult)]
+    L.mc_engine_step.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(CResult)]
     L.mc_engine_set_progress.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p, C.c_double]
     L.mc_engine_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
     L.mc_engine_kernel_stats.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
@@ -213,6 +214,12 @@ class Engine:
     def run(self):
         r = CResult()
         _check(lib().mc_engine_run(self._h, C.byref(r)), "mc_engine_run")
+        return _result(r)
+
+    def step(self, levels):
+        """mc_engine_step: `levels` more BFS levels; continues in place after a budget stop, starts over after an end."""
+        r = CResult()
+        _check(lib().mc_engine_step(self._h, levels, C.byref(r)), "mc_engine_step")
         return _result(r)
 
     def trace(self):

@@ -1470,6 +1470,7 @@ struct EngineBase {
     }
     virtual ~EngineBase() { if (owned_device_blob) hipFree(owned_device_blob); }
     virtual int run(mc_result *out) = 0;
+    virtual int step(uint32_t levels, mc_result *out) = 0;
     virtual int trace(uint8_t *states_out, int32_t *actions_out, size_t *n_inout) = 0;
     virtual int kernel_stats(mc_kernel_stats *out) = 0;
     virtual int read_states(uint64_t first, uint64_t count, uint8_t *out) = 0;
@@ -1752,7 +1753,9 @@ struct Engine : EngineBase {
         have_viol = false;
         level_start.clear();
         HIP_TRY(hipSetDevice(cfg.device));
-        HIP_TRY(hipMemsetAsync(d_table, 0, table_cap * sizeof(uint64_t), stream));
+        const bool in_place = ck_pending && ck_in_place;  // mc_engine_step: the seen-set of the stopped run is still valid
+        ck_in_place = false;
+        if (!in_place) HIP_TRY(hipMemsetAsync(d_table, 0, table_cap * sizeof(uint64_t), stream));
         HIP_TRY(hipMemsetAsync(d_ctr, 0, sizeof(DevCounters), stream));
         DevCounters init_c;
         memset(&init_c, 0, sizeof init_c);
@@ -1777,7 +1780,7 @@ struct Engine : EngineBase {
 
         // level 1: Init
         const uint64_t ninit = resuming ? 0 : S::num_init(prm);
-        if (resuming && ck_distinct)
+        if (resuming && ck_distinct && !in_place)
             hipLaunchKernelGGL(k_reseed_table<S>, dim3((unsigned)((ck_distinct + 255) / 256)), dim3(256), 0, stream, prm,
                                (const uint64_t *)d_arena, ck_distinct, d_table, seen_arg(), d_ctr);
         for (uint64_t first = 0; first < ninit; first += chunk) {
@@ -1932,7 +1935,27 @@ struct Engine : EngineBase {
         FILE *f;
         ~FileCloser() { if (f) fclose(f); }
     };
-    bool have_run = false, ck_pending = false;
+    bool have_run = false, ck_pending = false, ck_in_place = false;
+    // mc_engine_step: `levels` more BFS levels.  The first call (or a call after a run that ended: complete, or with an error)
+    // starts from Init; a call after a budget stop continues IN PLACE — arena, seen-set and parent pointers stay where they
+    // are in HBM, only the counters and the level table are handed over (the same hand-over as restore(), without the file
+    // and without rebuilding the seen-set).
+    int step(uint32_t levels, mc_result *out) override {
+        if (!levels) return MC_EBADCFG;
+        const uint64_t saved = cfg.max_levels;
+        const bool cont = have_run && !have_viol && run_hi > run_lo && !ck_pending;
+        if (cont) {
+            ck_distinct = last_distinct; ck_generated = last_generated; ck_cells = kstat_cells; ck_lo = run_lo;
+            ck_level_start = level_start;
+            ck_pending = ck_in_place = true;
+            cfg.max_levels = (uint64_t)level_start.size() + levels;
+        } else {
+            cfg.max_levels = levels;
+        }
+        const int rc = run(out);
+        cfg.max_levels = saved;
+        return rc;
+    }
     uint64_t last_generated = 0, ck_distinct = 0, ck_generated = 0, ck_cells = 0, ck_lo = 0;
     std::vector<uint64_t> ck_level_start;
     bool ck_params_comparable() const { return desc.spec_id != MC_SPEC_PCAL; }  // a compiled program's parameter is a host pointer
@@ -2804,6 +2827,7 @@ int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine *
     return rc;
 }
 int mc_engine_run(mc_engine *e, mc_result *out) { return e && out ? e->impl->run(out) : MC_EBADCFG; }
+int mc_engine_step(mc_engine *e, uint32_t levels, mc_result *out) { return e && out ? e->impl->step(levels, out) : MC_EBADCFG; }
 int mc_engine_set_progress(mc_engine *e, mc_progress_fn fn, void *user, double min_interval_seconds) {
     if (!e) return MC_EBADCFG;
     e->impl->progress_fn = fn;
