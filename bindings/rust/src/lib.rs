@@ -11,6 +11,7 @@ pub const MC_SPEC_PCAL_INTRO: u32 = 2;
 pub const MC_SPEC_RAFT: u32 = 3;
 pub const MC_SPEC_SSI: u32 = 4;
 pub const MC_SPEC_PCAL: u32 = 5; // a PlusCal algorithm compiled by mc_program_compile
+pub const MC_SPEC_PAXOS: u32 = 6; // examples/Paxos/Voting.tla, Paxos.tla under MCVoting / MCPaxos (+ .cfg)
 pub const MC_F_GENERIC: u32 = 128;
 pub const MC_F_DEADLOCK: u32 = 1;
 pub const MC_F_TRACE: u32 = 2;
