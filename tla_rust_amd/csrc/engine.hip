@@ -368,6 +368,7 @@ struct RouteArgs {
     const LevelCtl *lc = nullptr;  // non-null: [lo, hi) come from the device (batched small levels)
     uint64_t *new_fp = nullptr;    // non-null: fingerprints of the new-list entries (same segments, same positions)
     unsigned my_rank = 0;          // route mode: this rank (candidates it owns are probed locally)
+    uint16_t *succ = nullptr;      // slot-sliced launch (gridDim.y > 1) with deadlock checking: one "has a successor" flag per column
 };
 
 template <class S, bool ROUTE>
@@ -414,11 +415,18 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     typename S::Local loc;
     int ns = 0;
     unsigned long long viol = ~0ull;
+    // SLOT SLICES (gridDim.y = SG > 1; specs without unrolled slots only): slice sy evaluates the slots FIX_SLOTS + sy,
+    // + SG, ... of the same parents.  A small frontier of a spec with many slots per state (the witness enumeration of the
+    // Paxos family: 210; compiled PlusCal programs) is otherwise a handful of wavefronts each walking its slots one after the
+    // other — a level costs slots x eval latency while the device idles.  Slice 0 alone evaluates the parent's own status.
+    const unsigned sy = blockIdx.y, SG = gridDim.y;
     if (active) {
         S::load(prm, s, loc);
         ns = S::nslots(prm, loc);
-        const unsigned ps = S::parent_status(prm, loc, s);  // specs that check invariants per expanded state
-        if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
+        if (sy == 0) {
+            const unsigned ps = S::parent_status(prm, loc, s);  // specs that check invariants per expanded state
+            if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
+        }
     }
     const int wns = (flags & 64u) ? 0 : (int)wave_max_u32((unsigned)ns);  // 64 = ablation: load the parents only
     unsigned gen = 0, err = 0, probes = 0;
@@ -535,11 +543,15 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     // slots whose action / server indices are compile-time constants: fully unrolled, so the
     // spec's dispatch and register-array indexing fold away; the rest (per-message slots) loops
     if (wns > 0) static_for<0, S::FIX_SLOTS>([&](auto c) __attribute__((always_inline)) { body(decltype(c)::value); });
-    for (int slot = S::FIX_SLOTS; slot < wns; ++slot) body(slot);
+    for (int slot = S::FIX_SLOTS + (int)sy; slot < wns; slot += (int)SG) body(slot);
     if (qn) flush_probe(qn);
     if (on) flush_out(on);
 
-    if (active && gen == 0 && (flags & MC_F_DEADLOCK)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
+    if (SG == 1) {
+        if (active && gen == 0 && (flags & MC_F_DEADLOCK)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
+    } else if (rt.succ && active && gen) {
+        rt.succ[col] = 1;  // a deadlock is the absence of a successor in EVERY slice: k_deadlock_slices looks at the flags
+    }
     const unsigned gsum = wave_sum_u32(gen);
     const unsigned long long vmin = wave_min_u64(viol);
     const unsigned eor = wave_or_u32(err);
@@ -1116,14 +1128,35 @@ struct HasPatch<S, decltype((void)S::PATCH_WORDS)> : std::true_type {};
 
 // specs that define action families (S::NFAM) are expanded by family, the others slot by slot
 template <class S, class = void>
+struct WantsSlices : std::false_type {};
+template <class S>
+struct WantsSlices<S, decltype((void)S::SLICE_SLOTS)> : std::true_type {};
+template <class S, class = void>
 struct UsesFamilies : std::false_type {};
 template <class S>
 struct UsesFamilies<S, decltype((void)S::NFAM)> : std::true_type {};
 
 // (several arena blocks per wavefront, NB = 2 / 4, and a 5-waves-per-SIMD register budget were measured slower in round 2 —
 // DESIGN.md §5 — and are no longer compiled)
+// after a slot-sliced expand: the parents none of whose slices produced a successor
+static __global__ void __launch_bounds__(256)
+k_deadlock_slices(const uint16_t *__restrict__ succ, uint64_t lo, uint64_t hi, uint64_t ncols, const LevelCtl *lc, DevCounters *ctr) {
+    if (lc) {
+        if (lc->stop) return;
+        lo = lc->lo;
+        hi = lc->hi;
+        ncols = ((hi - (lo & ~63ull)) + 63) & ~63ull;
+    }
+    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    const uint64_t idx = (lo & ~63ull) + col;
+    unsigned long long viol = ~0ull;
+    if (idx >= lo && idx < hi && !succ[col]) viol = viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0);
+    const unsigned long long vmin = wave_min_u64(viol);
+    if ((threadIdx.x & 63) == 0 && vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
+}
 template <class S, bool ROUTE, class... A>
-static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStream_t stream, A... args) {
+static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStream_t stream, unsigned slices, A... args) {
     (void)flags;
     if constexpr (UsesFamilies<S>::value) {
         if (by_family) {
@@ -1131,7 +1164,7 @@ static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStr
             return;
         }
     }
-    hipLaunchKernelGGL((k_expand_insert<S, ROUTE>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, args...);
+    hipLaunchKernelGGL((k_expand_insert<S, ROUTE>), dim3((unsigned)((ncols + 255) / 256), slices ? slices : 1u), dim3(256), 0, stream, args...);
 }
 
 // ------------------------------------------------------------------------------------- materialise
@@ -1551,6 +1584,19 @@ struct Engine : EngineBase {
     LevelCtl *d_lc = nullptr, *h_lc = nullptr;
     uint64_t table_cap = 0, arena_cap = 0, chunk = 0, row_stride = 0, seg_cap = 0;
     bool seen_sparse = false;
+    // slot slices of a generic-kernel launch (k_expand_insert): as many as it takes to give the device a few thousand wavefronts,
+    // for specs whose slots all go through the loop (no unrolled prefix) and that have enough of them; TLAMC_NOSLICE=1 = A/B
+    unsigned slices_for(uint64_t ncols, bool blind) const {
+        // (a lowering asks for it with SLICE_SLOTS: worth it when one slot evaluation is expensive — the Paxos family's witness
+        // enumeration, the bytecode interpreter; for atomic_add's two-instruction slots the slices only repeat the parent loads)
+        if (!WantsSlices<S>::value || S::FIX_SLOTS != 0 || UsesFamilies<S>::value || use_matrix || max_slots < 16 || no_slices) return 1;
+        const uint64_t waves = (ncols + 63) / 64;
+        uint64_t sg = blind ? 32 : (16384 + waves - 1) / waves;  // a blind level launches its CAPACITY: the frontier itself is smaller
+        if (sg > 32) sg = 32;
+        if (sg > max_slots / 4) sg = max_slots / 4;
+        return sg < 1 ? 1u : (unsigned)sg;
+    }
+    bool no_slices = getenv("TLAMC_NOSLICE") != nullptr;
     uint64_t seen_arg() const { return seen_sparse ? ((table_cap / 4) | SEEN_SPARSE) : table_cap / 8; }
     KTimer timer;
     mc_kernel_stat kstat[3];
@@ -1715,9 +1761,14 @@ struct Engine : EngineBase {
         RouteArgs rt{};
         rt.lc = d_lc;
         rt.new_fp = d_newfp;
+        const unsigned sg = slices_for(ncols, true);
+        const bool dl = sg > 1 && (cfg.flags & MC_F_DEADLOCK);
+        if (dl) { rt.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), stream); }
         timed(0, 0, [&] {
-            launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm, (const uint64_t *)d_arena,
+            launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, sg, prm, (const uint64_t *)d_arena,
                                     (uint64_t)0, (uint64_t)0, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
+            if (dl) hipLaunchKernelGGL(k_deadlock_slices, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)d_nsl,
+                                       (uint64_t)0, (uint64_t)0, ncols, (const LevelCtl *)d_lc, d_ctr);
         });
         timed(2, 0, [&] {
             hipLaunchKernelGGL(k_materialise<S>, dim3(32, NSHARD), dim3(256), 0, stream, prm, d_arena, (uint64_t)0, d_newlist, seg_cap,
@@ -1860,10 +1911,15 @@ struct Engine : EngineBase {
                     if (chunk_no >= 2) hipStreamWaitEvent(stream, ev_m[parity], 0);  // new-list `parity` is free again
                     RouteArgs rt_new{};
                     rt_new.new_fp = d_newfp;
+                    const unsigned sg = slices_for(ncols, false);
+                    const bool dl = sg > 1 && (cfg.flags & MC_F_DEADLOCK);
+                    if (dl) { rt_new.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), stream); }
                     timed(0, c1 - c0, [&] {
-                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
+                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, sg, prm,
                                                 (const uint64_t *)d_arena, c0, c1, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr,
                                                 cfg.flags, rt_new, parity);
+                        if (dl) hipLaunchKernelGGL(k_deadlock_slices, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream,
+                                                   (const uint16_t *)d_nsl, c0, c1, ncols, (const LevelCtl *)nullptr, d_ctr);
                     });
                     finish_materialise(base, ncols, parity);
                 }
@@ -2140,7 +2196,7 @@ struct Engine : EngineBase {
         for (uint64_t c0 = 0; c0 < last_distinct; c0 += chunk) {
             const uint64_t c1 = c0 + chunk < last_distinct ? c0 + chunk : last_distinct;
             const uint64_t ncols = ((c1 - c0) + 63) & ~63ull;
-            launch_expand<S, false>(!((cfg.flags | extra_flags) & MC_F_NOFAMILY), cfg.flags | extra_flags, ncols, stream, prm,
+            launch_expand<S, false>(!((cfg.flags | extra_flags) & MC_F_NOFAMILY), cfg.flags | extra_flags, ncols, stream, 0u, prm,
                                     (const uint64_t *)d_arena, c0, c1, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr,
                                     cfg.flags | extra_flags, RouteArgs{}, 0u);
             hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, stream, d_ctr, 0u);
@@ -2333,7 +2389,7 @@ struct Engine : EngineBase {
         rt.new_fp = d_newfp;
         q.ncols = ncols;
         timed(0, count, [&] {  // new-list parity = slot: the locally owned new states of this chunk (local-owner shortcut)
-            launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, prm,
+            launch_expand<S, true>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, 0u, prm,
                                    (const uint64_t *)d_arena, c0, c1, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr, cfg.flags, rt, slot);
         });
         return MC_OK;

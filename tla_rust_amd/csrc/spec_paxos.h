@@ -45,6 +45,7 @@ struct SpecPaxos {
     // new state — not once per generated successor (7 x as many here); the engine checks a run's last, unexpanded level too.
     // The PROPERTY is a predicate of a TRANSITION and stays with the successor (eval).
     static constexpr bool CHECK_ON_EXPAND = true;
+    static constexpr bool SLICE_SLOTS = true;  // up to 255 witness slots per state, each a few hundred instructions: slice small frontiers
     struct Local { uint64_t w[MAX_WORDS]; };
     struct View { unsigned votes[XA]; int maxBal[XA]; };  // what Voting's operators read: votes[a] as bits b*nv + v
 

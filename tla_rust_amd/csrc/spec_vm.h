@@ -62,6 +62,7 @@ struct SpecVmT {
     using Params = VmParams;
     static constexpr bool IS_VM = true;
     static constexpr int MAX_VARS = MAXV, MAX_WORDS = MAX_VARS / 2, FIX_SLOTS = 0, STAGE_WORDS = 0;
+    static constexpr bool SLICE_SLOTS = true;  // a slot = one interpreted action instance: small frontiers are sliced by slot (engine.hip)
     static constexpr int STACK = 16, TEMPS = 8;  // pcal_compile.cpp checks both bounds when it emits code
     MC_HD static int words(const Params &p) { return p.words; }
     MC_HD static int max_slots(const Params &p) { return p.ninst * p.maxch + 1; }
