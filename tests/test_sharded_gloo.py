@@ -31,7 +31,9 @@ def run_dist(mode, world, spec, params, tmp_path, opts=None, timeout=600):
 CASES = [("atomic_add", [9], {}), ("pcal_intro", [0, 1, 20, 2], {"chunk": 300}), ("raft", [2, 2, 2, 9, 1, 1], {"chunk": 700}),
          ("raft", [3, 2, 2, 9, 1, 1], {"max_distinct": 60000, "chunk": 5000}),
          ("ssi", [2, 2, 127, 0], {"chunk": 900}),
-         ("ssi", [3, 2, 127, 0, 0, 3], {"max_distinct": 50000, "chunk": 3000})]   # cfg SYMMETRY: orbit representatives are sharded like states
+         ("ssi", [3, 2, 127, 0, 0, 3], {"max_distinct": 50000, "chunk": 3000}),   # cfg SYMMETRY: orbit representatives are sharded like states
+         # examples/Paxos/Paxos.tla, 3 acceptors x 2 values (Inv1-4 per stored state, V!Spec per transition), with and without SYMMETRY
+         ("paxos", [0, 3, 2, 2, 15, 0, 1], {"chunk": 500}), ("paxos", [0, 3, 2, 2, 15, 3, 1], {"chunk": 100})]
 
 
 @pytest.mark.parametrize("world", [2, 3])
