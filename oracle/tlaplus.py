@@ -1161,7 +1161,15 @@ class Spec:
             return self.v_id(("id", self.overrides[name]), scope)
         if name in self.varidx:
             i = self.varidx[name]
-            return lambda env, st, nx: st[i]
+
+            def fvar(env, st, nx):
+                v = st[i]
+                if v is UNASSIGNED and nx:  # inside Init a later conjunct reads what an earlier one assigned (MCConsensus.tla:19-20)
+                    v = nx.get(i, UNASSIGNED)
+                    if v is UNASSIGNED:
+                        raise TLAError(f"{name} is read before the initial predicate gives it a value")
+                return v
+            return fvar
         if name in self.const_vals:
             v = self.const_vals[name]
             return lambda env, st, nx: v

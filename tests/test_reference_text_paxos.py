@@ -101,3 +101,15 @@ def test_theorems_of_mcvoting_hold():
     r = c.run_levels(check_deadlock=False)
     assert r["distinct"] == 599
     assert all(mcinv({}, st, None) is True for lvl in r["level_states"] for st in lvl)
+
+
+@pytest.mark.skipif(not REF.exists(), reason="/root/reference is only present in the build container")
+def test_mcconsensus_inductive_invariant_model():
+    """examples/Paxos/MCConsensus.tla + .cfg as committed: `SPECIFICATION ISpec` with ISpec == IInv /\\ [][Next]_chosen checks that
+    Inv is inductive — the initial predicate is the invariant itself (every subset of Value = {"a", "b", "c"} with at most one
+    element: 4 initial states; its second conjunct READS what the first one assigned), from {} each value can be chosen"""
+    import tlaplus as T
+    c = T.Checker(REF / "MCConsensus.tla", search=[REF])
+    r = c.run_levels(check_deadlock=False)
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"]) == (4, 7, 1, "ok")
+    assert sorted(c.spec.state_text(s) for s in r["level_states"][0]) == ['/\\ chosen = {"a"}', '/\\ chosen = {"b"}', '/\\ chosen = {"c"}', '/\\ chosen = {}']
