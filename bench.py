@@ -63,8 +63,8 @@ def cpu_baseline(max_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)   # 40 complete BFS runs of 50 ms: two seconds of GPU work in the timed region
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
     ap.add_argument("--chunk", type=int, default=1 << 22)
