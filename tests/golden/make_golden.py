@@ -38,6 +38,9 @@ BIG = [
     # 17 GB; run with the multi-threaded oracle, whose counts equal the single-threaded one's: tests/test_oracle_mt.py)
     ("raft3_mcr4_t2_m1_k10_complete", [3, 4, 2, 3, 1, 1, 0, 10], 0),
 ]
+# raft3_mcr4_t2_m1_k11_complete (MaxMsgKeys = 11: 336 581 097 states, a 55.5 GB oracle arena) is NOT regenerated here: it was
+# made by the same oracle binary on the GPU box's host — `oracle_mc raft 3 4 2 3 1 1 0 11 --threads 192 --levels-out`, 248 s,
+# profiles/r02zf_cmd.sh / profiles/r02zf_oracle_k11.txt — and its entry (with a `source` field) is kept as it is.
 
 if __name__ == "__main__":
     cases = CASES + (BIG if "--big" in sys.argv else [])

@@ -157,6 +157,19 @@ def test_bench_workload_complete_on_gpu(amd, oracle):
     eng.close()
 
 
+def test_next_complete_graph_on_gpu(amd):
+    """MaxMsgKeys = 11: 336 581 097 states / 3 913 649 887 generated / depth 35, the largest complete graph the exact-dedup oracle
+    has verified (on the GPU box's host: the build container cannot hold it; tests/golden/raft_levels.json `source`).  116 GB arena."""
+    c = _golden("raft3_mcr4_t2_m1_k11_complete")
+    assert c["max_stat"][:3] == [11, 1, 4]
+    params = [3, 4, 2, 3, 1, 1, 11, 1, 4, 11]
+    eng = amd.Engine("raft", params, table_capacity=5 << 27, arena_capacity=c["distinct"] + (1 << 16), chunk_states=1 << 22, trace=False)
+    r = eng.run()
+    assert r.levels == c["levels"]
+    assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (336581097, 3913649887, 35, "ok", 0)
+    eng.close()
+
+
 def test_bench_workload_with_tuned_capacities(amd):
     """bench.py runs the same model with slot-array capacities sized from the oracle's maxima
     (16 / 2 / 8 instead of the defaults 40 / 4 / 16): W changes, the state graph must not."""
