@@ -389,3 +389,36 @@ def test_paxos_models_are_resolved_from_the_module_text(amd, tmp_path, monkeypat
         with pytest.raises(amd.McError) as e:
             amd.ResolvedSpec(d / "MCPaxos3.tla")
         assert e.value.code == -9 and "Voting.tla differs" in str(e.value)
+
+
+def test_mutated_paxos_models_are_refused_or_resolved_never_crash(amd, tmp_path):
+    """the sizes of a Paxos model are parsed out of module text by hand-written C++: 300 randomly damaged copies of the model and
+    its cfg must come back as an error code or a descriptor within the lowering's limits"""
+    import random
+    P = ROOT / "specs" / "paxos"
+    tla, cfg = (P / "MCPaxos3.tla").read_text(), (P / "MCPaxos3.cfg").read_text()
+    rnd = random.Random(7)
+    outcomes = {"resolved": 0, "refused": 0}
+    for _ in range(300):
+        t, c = tla, cfg
+        for _ in range(rnd.randint(1, 3)):
+            in_tla = rnd.random() < 0.6
+            src = t if in_tla else c
+            a = rnd.randrange(len(src))
+            b = min(len(src), a + rnd.randint(1, 12))
+            how = rnd.choice(["del", "dup", "chr"])
+            src = src[:a] + src[b:] if how == "del" else src[:a] + src[a:b] * 2 + src[b:] if how == "dup" else \
+                src[:a] + rnd.choice("{}(),=<>\\!|.x1 ") + src[a + 1:]
+            if in_tla:
+                t = src
+            else:
+                c = src
+        (tmp_path / "MCPaxos3.tla").write_text(t)
+        (tmp_path / "MCPaxos3.cfg").write_text(c)
+        try:
+            r = amd.ResolvedSpec(tmp_path / "MCPaxos3.tla", unverified=True)
+            assert r.spec == "paxos" and 1 <= r.params[1] <= 4 and 1 <= r.params[2] <= 3 and 1 <= r.params[3] <= 4
+            outcomes["resolved"] += 1
+        except amd.McError:
+            outcomes["refused"] += 1
+    assert outcomes["refused"] > 100 and outcomes["resolved"] > 20

@@ -779,7 +779,8 @@ static int resolve_paxos(const char *tla_path, const std::string &tla, const std
     const std::string t = strip_comments(tla);
     const size_t ex = t.find("EXTENDS");
     if (ex == std::string::npos) return 1;
-    const std::string exline = t.substr(ex, t.find('\n', ex) - ex);
+    const size_t exend = t.find('\n', ex);
+    const std::string exline = t.substr(ex, exend == std::string::npos ? std::string::npos : exend - ex);
     auto extends = [&](const char *m) {
         size_t k = exline.find(m);
         while (k != std::string::npos) {
@@ -873,6 +874,7 @@ static int resolve_paxos(const char *tla_path, const std::string &tla, const std
         while (k < b.size()) {
             if (b.compare(k, 13, "Permutations(") != 0) return fe_fail(MC_ENOSPEC, "SYMMETRY %s must be a union of Permutations(%s) and Permutations(%s)", c->symmetry.c_str(), tA.c_str(), tV.c_str());
             const size_t e = b.find(')', k);
+            if (e == std::string::npos) return fe_fail(MC_ENOSPEC, "SYMMETRY %s: cannot read the definition", c->symmetry.c_str());
             const std::string arg = b.substr(k + 13, e - k - 13);
             if (arg == tA) sym |= 1; else if (arg == tV) sym |= 2;
             else return fe_fail(MC_ENOSPEC, "SYMMETRY %s: Permutations(%s) is neither the acceptors nor the values", c->symmetry.c_str(), arg.c_str());
