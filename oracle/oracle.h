@@ -98,6 +98,9 @@ int oracle_run_mt(const char *spec, const int64_t *params, int nparams,
 const char *oracle_trace_state(uint32_t k);
 const char *oracle_action_name(const char *spec, int action);
 const char *oracle_last_error(void);
+/* Voting census (examples/Paxos/MCVoting.cfg:7-8's alternative configurations): out = {type-correct states, states satisfying Inv,
+ * successors generated from those, successors violating Inv}; params as for spec "paxos" with kind = 1 */
+int oracle_voting_census(const int64_t *params, int nparams, uint64_t out[4]);
 /* the in-spec unit tests of serializableSnapshotIsolation.tla:1068-1077,1184-1205; returns #failures */
 int oracle_ssi_unit_tests(void);
 

@@ -468,6 +468,60 @@ static size_t px_canon(void *c, const uint8_t *sb, size_t len, uint8_t *out) {
     return len;
 }
 
+
+/* ------------------------------------------------------------------------------------------ census (Voting)
+ * The two alternative configurations of examples/Paxos/MCVoting.cfg:7-8 (MCVoting.tla:36-55), restated: over EVERY type-correct
+ * state (TypeOK, Voting.tla:46-47) — out[0] = how many there are, out[1] = how many satisfy Inv (:160), out[2] = successors
+ * generated from those by Next (TLC's witness multiplicities), out[3] = how many of these successors violate Inv (0 = Inv is
+ * inductive on this model).  Pinned to oracle/tlaplus.py's evaluation of MCSpecI (tests/test_reference_text_paxos.py). */
+typedef struct { or_emit em; const px_ctx *x; uint64_t n, bad; } census_emit;
+static void census_on_emit(or_emit *em, const uint8_t *sb, size_t len, int action, unsigned flags) {
+    census_emit *c = (census_emit *)em;
+    vt_state t;
+    (void)len; (void)action; (void)flags;
+    memcpy(&t, sb, sizeof t);
+    c->n++;
+    if (!vt_Inv(c->x, &t)) c->bad++;
+}
+int oracle_voting_census(const int64_t *p, int np, uint64_t out[4]) {
+    or_spec sp;
+    if (or_spec_paxos(p, np, &sp)) return -1;
+    px_ctx *x = sp.ctx;
+    if (x->kind != 1) { or_set_error("census: Voting models only"); free(x); return -1; }
+    const int vbits = x->nb * x->nv;
+    const uint64_t per = ((uint64_t)1 << vbits) * (uint64_t)(x->nb + 1);
+    uint64_t total = 1;
+    for (int a = 0; a < x->na; a++) total *= per;
+    census_emit ce;
+    memset(&ce, 0, sizeof ce);
+    ce.em.emit = census_on_emit;
+    ce.x = x;
+    x->prop = 0;
+    memset(out, 0, 4 * sizeof out[0]);
+    for (uint64_t k = 0; k < total; k++) {
+        vt_state s;
+        memset(&s, 0, sizeof s);
+        for (int a = 0; a < XA; a++) s.maxBal[a] = -1;
+        uint64_t r = k;
+        for (int a = 0; a < x->na; a++) {
+            const uint64_t d = r % per;
+            r /= per;
+            s.maxBal[a] = (int8_t)((int)(d % (uint64_t)(x->nb + 1)) - 1);
+            const uint64_t m = d / (uint64_t)(x->nb + 1);
+            for (int b = 0; b < x->nb; b++)
+                for (int v = 0; v < x->nv; v++) s.votes[a][b][v] = (uint8_t)(m >> (b * x->nv + v) & 1);
+        }
+        out[0]++;
+        if (!vt_Inv(x, &s)) continue;
+        out[1]++;
+        vt_succ(x, (const uint8_t *)&s, sizeof s, &ce.em);
+    }
+    out[2] = ce.n;
+    out[3] = ce.bad;
+    free(x);
+    return 0;
+}
+
 static const char *VT_ACT[] = {"IncreaseMaxBal", "VoteFor"};
 static const char *PX_ACT[] = {"Phase1a", "Phase2a", "Phase1b", "Phase2b"};
 static int g_px_kind;

@@ -378,6 +378,40 @@ extern "C" unsigned shim_ssi_history_status(int nt, int nk, int inv_mask, int te
     return SpecSsi::parent_status(p, l, CWordRef{w, 1});
 }
 
+// Voting census through the DEVICE lowering (spec_paxos.h): every type-correct packed state — out = {how many, how many satisfy Inv
+// (parent_status), successors generated from those (enabled slots), successors violating Inv}; the oracle's oracle_voting_census
+// and oracle/tlaplus.py on MCVoting's MCSpecI configuration give the same four numbers
+extern "C" int shim_voting_census(const mc_spec_desc *d, uint64_t out[4]) {
+    PaxosParams p;
+    if (d->spec_id != MC_SPEC_PAXOS || SpecPaxos::make_params(d->params, d->nparams, p) || p.kind != 1 || p.sym) return -1;
+    const int vbits = p.nb * p.nv;
+    const uint64_t per = ((uint64_t)1 << vbits) * (uint64_t)(p.nb + 1);
+    uint64_t total = 1;
+    for (int a = 0; a < p.na; a++) total *= per;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (uint64_t k = 0; k < total; k++) {
+        uint64_t w[SpecPaxos::MAX_WORDS] = {0}, t[SpecPaxos::MAX_WORDS];
+        uint64_t r = k;
+        for (int a = 0; a < p.na; a++) {
+            const uint64_t dgt = r % per;
+            r /= per;
+            w[1 + a] = (dgt % (uint64_t)(p.nb + 1)) | (dgt / (uint64_t)(p.nb + 1)) << p.o_2b;  // maxBal + 1 | votes
+        }
+        out[0]++;
+        SpecPaxos::Local l;
+        SpecPaxos::load(p, CWordRef{w, 1}, l);
+        if (SpecPaxos::parent_status(p, l, CWordRef{w, 1}) & ST_INVARIANT) continue;
+        out[1]++;
+        for (int slot = 0; slot < SpecPaxos::max_slots(p); slot++) {
+            const unsigned st = SpecPaxos::successor(p, w, slot, t);
+            if (!(st & ST_ENABLED)) continue;
+            out[2]++;
+            if (SpecPaxos::check_invariants(p, t) & ST_INVARIANT) out[3]++;
+        }
+    }
+    return 0;
+}
+
 extern "C" size_t shim_state_bytes(const mc_spec_desc *d) {
     size_t n = 0;
     dispatch_spec(d, [&](auto spec, const auto &prm) { n = sizeof(uint64_t) * decltype(spec)::words(prm); return 0; });

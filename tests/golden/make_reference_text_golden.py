@@ -21,6 +21,12 @@ RAFT_MODELS = {
     "raft_2s_mcr2_naive": dict(params=[2, 2, 2, 9, 1, 1], clash="ignore"),  # negative control: 15 794
     "raft_2s_mcr2_keys8": dict(params=[2, 2, 2, 9, 1, 1], clash="test", mk=8),  # the MaxMsgKeys conjunct of StateConstraint
     "raft_2s_mm2_keys6": dict(params=[2, 1, 2, 9, 2, 1], clash="test", mk=6),   # two copies in flight: DuplicateMessage
+    # THREE servers (majority quorums are no longer "everybody"; the bench model's MCraft.cfg with a smaller bag bound): 4 message
+    # keys are what one election needs, the 5th and 6th are the first AppendEntries request / response.  58 s / 4 min / 15 min of
+    # evaluation: fixtures only, not re-evaluated by the suite
+    "raft_3s_keys4": dict(params=[3, 4, 2, 3, 1, 3], clash="test", mk=4, slow=True),
+    "raft_3s_keys5": dict(params=[3, 4, 2, 3, 1, 3], clash="test", mk=5, slow=True),
+    "raft_3s_keys6": dict(params=[3, 4, 2, 3, 1, 3], clash="test", mk=6, slow=True),
 }
 
 
@@ -132,6 +138,25 @@ def run_paxos_negative(name):
                 name=(c.cfg["properties"] if r["verdict"] == "property" else c.cfg["invariants"])[r["violated_invariant"]])
 
 
+# the two alternative configurations examples/Paxos/MCVoting.cfg:7-8 names in its comments (SPECIFICATION Spec \* MCSpec,
+# INVARIANT Inv \* MCInv) and MCVoting.tla:36-55 explains: MCSpec == TypeOK /\ [][FALSE]_vars with MCInv = the statements of five
+# THEOREMs of Voting.tla on EVERY type-correct state; MCSpecI == Inv /\ [][Next]_vars with Inv = "Inv is inductive"
+VOTING_ALTERNATIVES = {
+    "voting_theorems_on_all_type_correct_states": dict(spec="MCSpec", inv="MCInv", slow=True),   # 110 592 states, 66 s
+    "voting_inv_is_inductive": dict(spec="MCSpecI", inv="Inv"),                                  # 2 771 states satisfy Inv, 20 s
+}
+
+
+def run_voting_alternative(name):
+    import tlaplus as T
+    a = VOTING_ALTERNATIVES[name]
+    cfg = (PAXOS_REF / "MCVoting.cfg").read_text()
+    head = cfg[:cfg.index("SPECIFICATION")]     # the CONSTANTS block as committed
+    c = T.Checker(PAXOS_REF / "MCVoting.tla", cfg_text=head + f"SPECIFICATION {a['spec']}\nINVARIANT {a['inv']}\n", search=[PAXOS_REF])
+    r = c.run_levels(check_deadlock=False)
+    return dict(distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"], verdict=r["verdict"])
+
+
 def run_paxos_text(name):
     """deadlock checking off: Voting with a finite Ballot set ends in states without successors (every acceptor at the last
     ballot); the reference's cfg files say nothing about it and TLC would need -deadlock to finish the run"""
@@ -158,17 +183,31 @@ def run_paxos_text(name):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["raft", "ssi", "paxos"]
     if "paxos" in which:
-        out = {}
+        ppath = ROOT / "tests" / "golden" / "paxos_reference_text.json"
+        out = json.loads(ppath.read_text()) if ppath.exists() else {}
+        only = which[1:] if which[0] == "paxos" and len(which) > 1 else None      # ... paxos name name: only the named entries
         for name in PAXOS_MODELS:
+            if only and name not in only:
+                continue
             out[name] = run_paxos_text(name)
             print(name, {k: v for k, v in out[name].items() if k != "level_digests"}, flush=True)
         for name in PAXOS_NEGATIVE:
+            if only and name not in only:
+                continue
             out[name] = run_paxos_negative(name)
+            print(name, out[name], flush=True)
+        for name in VOTING_ALTERNATIVES:
+            if only and name not in only:
+                continue
+            out[name] = run_voting_alternative(name)
             print(name, out[name], flush=True)
         (ROOT / "tests" / "golden" / "paxos_reference_text.json").write_text(json.dumps(out, indent=1) + "\n")
     if "raft" in which:
-        out = {}
+        path = ROOT / "tests" / "golden" / "raft_reference_text.json"
+        out = json.loads(path.read_text()) if path.exists() else {}
         for name in RAFT_MODELS:
+            if len(which) > 1 and which[0] == "raft" and name not in which[1:]:
+                continue      # python make_reference_text_golden.py raft raft_3s_keys5 ...: only the named models
             out[name] = run_raft_text(name)
             print(name, {k: v for k, v in out[name].items() if k != "level_digests"}, flush=True)
         (ROOT / "tests" / "golden" / "raft_reference_text.json").write_text(json.dumps(out, indent=1) + "\n")

@@ -26,7 +26,8 @@ sys.path.insert(0, str(ROOT / "tests" / "golden"))
 REF = Path("/root/reference/examples/Paxos")
 GOLD = json.loads((ROOT / "tests" / "golden" / "paxos_reference_text.json").read_text())
 
-from make_reference_text_golden import PAXOS_MODELS, PAXOS_NEGATIVE, run_paxos_negative, run_paxos_text  # noqa: E402
+from make_reference_text_golden import (PAXOS_MODELS, PAXOS_NEGATIVE, VOTING_ALTERNATIVES, run_paxos_negative, run_paxos_text,  # noqa: E402
+                                        run_voting_alternative)
 
 
 def level_digests(by_level):
@@ -113,3 +114,36 @@ def test_mcconsensus_inductive_invariant_model():
     r = c.run_levels(check_deadlock=False)
     assert (r["distinct"], r["generated"], r["depth"], r["verdict"]) == (4, 7, 1, "ok")
     assert sorted(c.spec.state_text(s) for s in r["level_states"][0]) == ['/\\ chosen = {"a"}', '/\\ chosen = {"b"}', '/\\ chosen = {"c"}', '/\\ chosen = {}']
+
+
+def test_alternative_configurations_of_mcvoting():
+    """MCVoting.cfg:7-8 names two more configurations in its comments (MCVoting.tla:36-55 explains them): the statements of five
+    THEOREMs of Voting.tla hold on EVERY type-correct state (110 592 of them, no transitions: [][FALSE]_vars), and Inv is inductive
+    (2 771 type-correct states satisfy it; all 11 745 steps from them end in one of the 2 771)"""
+    t, i = GOLD["voting_theorems_on_all_type_correct_states"], GOLD["voting_inv_is_inductive"]
+    assert (t["distinct"], t["generated"], t["depth"], t["verdict"]) == (110592, 110592, 1, "ok")      # (2^4)^3 vote sets x 3^3 maxBal
+    assert (i["distinct"], i["generated"], i["depth"], i["verdict"]) == (2771, 2771 + 11745, 1, "ok")
+    if REF.exists():
+        assert run_voting_alternative("voting_inv_is_inductive") == i
+
+
+def test_census_of_all_type_correct_voting_states():
+    """the same two configurations restated: the C oracle (oracle_voting_census) and the device lowering (host build,
+    shim_voting_census) enumerate all 110 592 type-correct states of the MCVoting model — 2 771 satisfy Inv, Next generates 11 745
+    successors from those (TLC's witness multiplicities), none of them violates Inv: the numbers of the evaluator's MCSpecI run.
+    This exercises the invariant code on states no reachable-state test ever sees."""
+    import ctypes as C
+    g = GOLD["voting_inv_is_inductive"]
+    params = [1, 3, 2, 2, 1, 0, 0]
+    out = (C.c_uint64 * 4)()
+    lib = helpers.oracle_lib()
+    lib.oracle_voting_census.argtypes = [C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_uint64)]
+    assert lib.oracle_voting_census((C.c_int64 * len(params))(*params), len(params), out) == 0
+    assert list(out) == [GOLD["voting_theorems_on_all_type_correct_states"]["distinct"], g["distinct"], g["generated"] - g["distinct"], 0]
+    assert list(out) == [110592, 2771, 11745, 0]
+    sh = helpers.shim_lib()
+    d = helpers.spec_desc("paxos", params)
+    out2 = (C.c_uint64 * 4)()
+    sh.shim_voting_census.argtypes = [C.POINTER(helpers.McSpecDesc), C.POINTER(C.c_uint64)]
+    assert sh.shim_voting_census(C.byref(d), out2) == 0
+    assert list(out2) == list(out)

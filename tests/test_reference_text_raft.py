@@ -1,7 +1,8 @@
 """The C oracle (oracle/spec_raft.c) pinned to the REFERENCE'S OWN TEXT: oracle/tlaplus.py evaluates
 /root/reference/examples/raft.tla:110-507 under specs/MCraft.tla the way TLC does, and the hand restatement must give the
 same state graph — per-level SETS of states as canonical TLA+ text, counters, depth — on the 2-server anchors of
-BASELINE.md section 2 (6 128 and 13 634 distinct), including the negative control of SURVEY.md App. B item 0: evaluating
+BASELINE.md section 2 (6 128 and 13 634 distinct) and on THREE-server models (the bench model's cfg with 4 / 5 / 6 message keys:
+48 274 / 178 654 / 641 869 states — one election, then the first AppendEntries round trip), including the negative control of SURVEY.md App. B item 0: evaluating
 raft.tla:392-393 as an unconditional assignment ("naive") yields 15 794.
 
 /root/reference exists only in the build container: there the test runs the evaluator on the reference file itself and
@@ -51,6 +52,20 @@ def test_fixture_is_what_the_reference_text_gives(name):
     r = run_raft_text(name)
     g = GOLD[name]
     assert {k: r[k] for k in g} == g
+
+
+@pytest.mark.parametrize("name", ["raft_2s_mcr2_keys8", "raft_3s_keys4", "raft_3s_keys5"])
+def test_lowering_equals_reference_text_fixture(name, tmp_path):
+    """the DEVICE lowering (tla_rust_amd/csrc/spec_raft.h, host build) against the fixture made from the reference's text — three
+    servers included, where a quorum is a real majority: counters, per-level counts, per-level state-set digests"""
+    from make_reference_text_golden import device_params
+    g = GOLD[name]
+    dump = tmp_path / "dump.txt"
+    s = helpers.shim_run("raft", device_params(name), dump=str(dump))
+    assert (s["distinct"], s["generated"], s["depth"], s["levels"], s["verdict"]) == \
+           (g["distinct"], g["generated"], g["depth"], g["levels"], g["verdict"])
+    assert s["fp_mismatch"] == 0
+    assert level_digests(helpers.read_dump(str(dump))) == g["level_digests"]
 
 
 def test_models_use_the_committed_wrapper():
