@@ -47,7 +47,7 @@ def test_c_oracle_equals_reference_text_fixture(name, tmp_path):
 
 
 @pytest.mark.skipif(not REF.exists(), reason="/root/reference is only present in the build container")
-@pytest.mark.parametrize("name", ["raft_2s_mcr1", "raft_2s_mm2_keys6"])
+@pytest.mark.parametrize("name", ["raft_2s_mcr1"])   # the others: python tests/golden/make_reference_text_golden.py raft <name> (1 - 15 min each)
 def test_fixture_is_what_the_reference_text_gives(name):
     r = run_raft_text(name)
     g = GOLD[name]
