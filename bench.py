@@ -30,6 +30,11 @@ sys.path.insert(0, str(ROOT))
 WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 10, 1, 4, 10], golden="raft3_mcr4_t2_m1_k10_complete",
                 name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=10 "
                      "(specs/MCraft.cfg), complete state graph")
+# --msg-keys 11: the next complete graph of the same model (336 581 097 states, 165 ms per step; golden made by the same oracle on
+# the GPU box's host, tests/golden/raft_levels.json `source`): an optional longer step, NOT the default workload of the contract line
+WORKLOAD_K11 = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 11, 1, 4, 11], golden="raft3_mcr4_t2_m1_k11_complete",
+                    name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=11 "
+                         "(specs/MCraft.cfg with MaxMsgKeys = 11), complete state graph")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -71,6 +76,7 @@ def main():
     ap.add_argument("--shard-chunk", type=int, default=1 << 21, help="frontier states per round and rank in the sharded (torchrun) path")
     ap.add_argument("--table-slots", type=int, default=3 << 26, help="seen-set slots (any multiple of 64): 1.5 * 2^27 = 1.6 GB, load 0.51 at the end of the run")
     ap.add_argument("--table-log2", type=int, default=0, help="A/B: a power-of-two seen-set (27: load 0.76, 28: load 0.38)")
+    ap.add_argument("--msg-keys", type=int, default=10, choices=[10, 11], help="11: the 3.4e8-state graph (165 ms/step) instead of the contract workload")
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
     ap.add_argument("--direct", action="store_true", help="A/B: one kernel per chunk (k_expand_direct: expand + insert + copy-and-patch write)")
@@ -78,6 +84,11 @@ def main():
     ap.add_argument("--no-filter", action="store_true", help="A/B: without the per-wavefront duplicate filter in front of the seen-set")
     ap.add_argument("--occ3", action="store_true", help="A/B: k_expand_direct compiled for 3 waves per SIMD (no register spills)")
     a = ap.parse_args()
+    if a.msg_keys == 11:
+        global WORKLOAD
+        WORKLOAD = WORKLOAD_K11
+        if a.table_slots == 3 << 26:
+            a.table_slots = 5 << 27   # load 0.50
 
     import torch
     import tla_rust_amd as amd
