@@ -1,6 +1,7 @@
 """ctypes binding of include/tlamc.h.  Mirrors the C ABI one to one (same names, same argument
 meaning, negative MC_E* codes raised as McError)."""
 import ctypes as C
+import os
 import json
 from pathlib import Path
 
@@ -67,10 +68,11 @@ def lib():
     # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both open the
     # GPU.  Loading torch first makes the dynamic linker resolve libtlamc.so's libamdhip64 (same SONAME)
     # to the copy torch already mapped, so device memory, streams and RCCL share one runtime.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    if os.path.exists("/dev/kfd"):  # (a box without a GPU never opens one: nothing to share, no reason to load torch's runtime)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(str(LIB_PATH))
     L.mc_engine_create.argtypes = [C.POINTER(SpecDesc), C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.mc_engine_run.argtypes = [C.c_void_p, C.POINTER(CResult)]
