@@ -300,6 +300,41 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
     return 0;
 }
 
+// TEST DIAGNOSTIC: a native fault inside the host build prints its own backtrace before Python's faulthandler runs
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+struct sigaction g_prev_segv;
+char g_altstack[1 << 16];
+void shim_segv(int sig, siginfo_t *info, void *ctx) {
+    static const char msg[] = "\n[shim] SIGSEGV backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    void *bt[64];
+    const int n = backtrace(bt, 64);
+    backtrace_symbols_fd(bt, n, 2);
+    char line[128];
+    const int k = snprintf(line, sizeof line, "[shim] fault address %p\n", info ? info->si_addr : nullptr);
+    (void)!write(2, line, (size_t)k);
+    if (g_prev_segv.sa_flags & SA_SIGINFO) { if (g_prev_segv.sa_sigaction) g_prev_segv.sa_sigaction(sig, info, ctx); }
+    else if (g_prev_segv.sa_handler && g_prev_segv.sa_handler != SIG_DFL && g_prev_segv.sa_handler != SIG_IGN) g_prev_segv.sa_handler(sig);
+    signal(SIGSEGV, SIG_DFL);
+    raise(SIGSEGV);
+}
+struct InstallSegv {
+    InstallSegv() {
+        if (!getenv("TLAMC_SHIM_BACKTRACE")) return;
+        stack_t ss{};
+        ss.ss_sp = g_altstack; ss.ss_size = sizeof g_altstack;
+        sigaltstack(&ss, nullptr);
+        struct sigaction sa{};
+        sa.sa_sigaction = shim_segv;
+        sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, &g_prev_segv);
+    }
+} g_install_segv;
+}  // namespace
+
 extern "C" int shim_run(const mc_spec_desc *d, uint64_t max_levels, uint64_t max_distinct, int check_deadlock,
                         const char *dump_path, ShimResult *r) {
     return dispatch_spec(d, [&](auto spec, const auto &prm) { return run(spec, prm, max_levels, max_distinct, check_deadlock, dump_path, r); });
