@@ -278,22 +278,88 @@ int mc_shard_fetch(mc_engine *e, uint64_t idx, uint8_t *state_out, uint32_t *par
  * replaces: TLC's worker pool ("Number of worker threads", examples/serializableSnapshotIsolation.tla:52-53) scaled past one
  * device.  Per level one host synchronisation (frontier sizes + verdicts, ncclAllGather); the rounds inside a level are the
  * fixed-capacity exchanges above (mc_shard_*_pack) as ncclSend / ncclRecv groups.  Any RCCL failure returns MC_ERCCL
- * (mc_last_error() carries ncclGetErrorString).  `mc X.tla -gpus P` is this API with forked ranks. */
+ * (mc_last_error() carries ncclGetErrorString).  A rank-local failure (a full exchange bucket, MC_ETABLEFULL, MC_EOVERFLOW,
+ * an allocation) does not leave the others waiting in a collective: every rank's status travels with the per-level
+ * all-gather and all ranks leave the loop together with the first failing rank's code.  Levels whose new states STAY where they
+ * were generated exchange 9 bytes per candidate (fixed-capacity rounds, pipelined: the fingerprint exchange of round r+1
+ * overlaps the probes of round r, the expand of round r+1 overlaps both); small or unbalanced levels MOVE the new states to
+ * their owners (mc_shard_materialise_slot / mc_shard_ingest).  `mc X.tla -gpus P` is this API with forked ranks. */
 #define MC_COMM_ID_BYTES 128
 typedef struct mc_comm mc_comm;
+#define MC_SHARD_NO_PREFIX 1u /* mc_shard_opts.flags: shard from Init on (mc_shard_begin) instead of the replicated prefix */
+/* what one rank's level loop did (diagnostics; filled when mc_shard_opts.stats != NULL) */
 typedef struct {
-    uint64_t chunk_states;    /* frontier states per round and rank (0 = 2^19); at most the engine's chunk_states            */
+    uint64_t replicated_levels; /* levels every rank ran itself (mc_shard_begin_replicated)                                  */
+    uint64_t stay_levels;       /* levels whose new states stayed on the generating rank (9 B per candidate cross xGMI)      */
+    uint64_t move_levels;       /* levels whose new states moved to their owner (small frontiers, rebalancing)               */
+    uint64_t rounds;            /* exchange rounds (one chunk per rank each)                                                 */
+    uint64_t sent_bytes;        /* bytes THIS rank handed to the all-to-alls for other ranks (fingerprints, answers, states) */
+    uint64_t distinct_local;    /* states resident on this rank at the end (its share)                                       */
+    uint64_t max_frontier;      /* over the sharded levels: largest max-over-ranks frontier ...                              */
+    uint64_t mean_frontier;     /* ... and the mean frontier of that same level (imbalance = max / mean)                     */
+} mc_shard_stats;
+typedef struct {
+    uint64_t chunk_states;    /* frontier states per round and rank (0 = 2^19); clamped to the engine's chunk_states         */
     uint64_t max_distinct;    /* budgets of the whole job (0 = none)                                                        */
     uint64_t max_levels;
     uint64_t replicate_until; /* states per rank a level must have before the search is sharded (0 = 2^15); below it every
                                * rank runs the same fused BFS (mc_shard_begin_replicated)                                    */
     uint64_t packed_fanout;   /* in-model successors per expanded state the fixed-capacity buckets allow for (0 = 16); a
                                * level that exceeds it fails with MC_EARENA, it is never truncated                          */
+    uint64_t stay_threshold;  /* states per rank a level needs before its new states STAY where they were generated
+                               * (0 = 2^16); smaller levels MOVE every new state to its owner, which is what spreads a
+                               * small frontier over the ranks                                                              */
+    double rebalance_ratio;   /* a level whose largest per-rank frontier exceeds ratio x the mean is a MOVE level again:
+                               * a drifting rank cannot stall the level loop (0 = 1.25)                                     */
+    uint64_t move_fanout;     /* in-model successors per expanded state the buffers of a move round allow for (0 = 32)      */
+    uint32_t flags;           /* MC_SHARD_*                                                                                 */
+    uint32_t reserved;
+    mc_shard_stats *stats;    /* NULL or where to put this rank's loop statistics                                            */
 } mc_shard_opts;
 int mc_comm_unique_id(uint8_t id_out[MC_COMM_ID_BYTES]);
 int mc_comm_create(const uint8_t id[MC_COMM_ID_BYTES], uint32_t rank, uint32_t world, int32_t device, mc_comm **out);
 void mc_comm_destroy(mc_comm *c);
+/* host-side all-gather of `bytes` bytes per rank over the communicator (rank r's block at all_out + r * bytes): a barrier,
+ * a max-over-ranks of wall times, the shares of a run — what a multi-process host needs besides the search itself */
+int mc_comm_all_gather(mc_comm *c, const void *mine, void *all_out, uint64_t bytes);
 int mc_shard_run(mc_engine *e, mc_comm *c, const mc_shard_opts *opts, mc_result *out);
+/* Counterexample of a sharded run that ended in a violation (engines created with MC_F_TRACE): the behaviour is walked back
+ * parent by parent ACROSS the ranks' arenas (mc_shard_violation / mc_shard_fetch on the rank that holds the state, one small
+ * all-gather per step).  Collective: every rank calls it and receives the same trace.  states_out: *n_inout records of
+ * mc_state_bytes() bytes (capacity in, count out), first the initial state; slots_out[k] = the action slot that led from state
+ * k-1 to state k (-1 for k = 0): mc_state_action(spec, state k-1, slot) names it.  *final_slot >= 0: the violation is an
+ * INVARIANT broken by a successor that is stored nowhere — the caller appends mc_state_apply(spec, last state, *final_slot);
+ * -1 otherwise (Assert / evaluation error / deadlock / the last state itself violates).  *n_inout = 0: no rank found one. */
+int mc_shard_trace(mc_engine *e, mc_comm *c, uint8_t *states_out, int32_t *slots_out, size_t *n_inout, int32_t *final_slot);
+
+/* ---- bring your own collectives.  mc_shard_run / mc_shard_trace are written against this table; mc_comm fills it with RCCL
+ * (ncclSend / ncclRecv groups, ncclAllGather).  A host that already owns a communicator — torch.distributed's process group
+ * (tla_rust_amd/sharded.py: backend "nccl" = RCCL, or gloo staged through the host in the CPU tests), MPI — hands its own
+ * functions over and gets the SAME level loop.  All buffers the loop passes to all_to_all / all_to_all_v come from alloc()
+ * (device memory for a HIP engine) and are passed by their base address; every collective is ordered on `hip_stream` like a
+ * kernel launch (the loop makes that stream wait for its producers with events and lets its consumers wait for it), may
+ * return before it has completed, and must be called by every rank in the same order.  Return 0 or a negative MC_E* code. */
+typedef struct mc_transport {
+    void *user;
+    uint32_t rank, world;
+    void *hip_stream;  /* hipStream_t the collectives are ordered on; NULL: the collectives are synchronous host calls */
+    void *(*alloc)(void *user, size_t bytes);
+    void (*release)(void *user, void *p);
+    /* equal split: bytes_per_peer bytes at send + p * bytes_per_peer go to rank p, rank p's block lands at recv + p * bytes_per_peer */
+    int (*all_to_all)(void *user, const void *send, void *recv, uint64_t bytes_per_peer);
+    /* variable split: send_bytes[p] bytes at send + send_off[p] go to rank p; recv_bytes[p] bytes from rank p land at recv + recv_off[p] */
+    int (*all_to_all_v)(void *user, const void *send, const uint64_t *send_off, const uint64_t *send_bytes, void *recv,
+                        const uint64_t *recv_off, const uint64_t *recv_bytes);
+    /* HOST buffers, blocking: rank r's `bytes` bytes appear at all_out + r * bytes on every rank */
+    int (*all_gather)(void *user, const void *mine, void *all_out, uint64_t bytes);
+} mc_transport;
+int mc_comm_transport(mc_comm *c, mc_transport *out);  /* the RCCL functions of a communicator; valid while c lives */
+int mc_shard_run_transport(mc_engine *e, const mc_transport *t, const mc_shard_opts *opts, mc_result *out);
+int mc_shard_trace_transport(mc_engine *e, const mc_transport *t, uint8_t *states_out, int32_t *slots_out, size_t *n_inout,
+                             int32_t *final_slot);
+/* what the level loop needs to know about an engine: its expand stream (the loop orders bucket compaction / its collectives
+ * against it with events), the largest chunk one launch takes, whether parent pointers are kept (MC_F_TRACE) */
+int mc_shard_info(mc_engine *e, void **main_stream_out, uint64_t *chunk_states_out, int32_t *traced_out);
 
 /* ------------------------------------------------------------------ PlusCal front-end (host only)
  * The reference's workflow is `pcal2tla *tla` then `tlc *tla` (Makefile:3-7).  mc_pcal_translate is the first

@@ -485,6 +485,12 @@ struct ShimShardBase {
     virtual uint64_t end_level() = 0;
     virtual void counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
     virtual void check_frontier() = 0;
+    // counterexamples across ranks (always recorded here; the engine needs MC_F_TRACE)
+    virtual int materialise_parents(unsigned slot, uint64_t *send_parents) = 0;
+    virtual int ingest_parents(const uint64_t *recv_parents, uint64_t n, unsigned src_rank) = 0;
+    virtual int violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant) = 0;
+    virtual int fetch(uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) = 0;
+    virtual size_t state_bytes() = 0;
 };
 
 template <class S>
@@ -506,10 +512,44 @@ struct ShimShard : ShimShardBase {
     } sl[2];
 
     uint64_t nstates() const { return arena.size() / (size_t)W; }
+    // (rank, index, slot) of every state's parent, like the engine's d_prank / d_parent / d_pslot with MC_F_TRACE
+    struct Par { uint32_t rank; uint64_t idx; uint32_t slot; };
+    std::vector<Par> par;
+    std::vector<uint64_t> moved_par[2];  // (parent index << 16 | slot) of the states the slot's last materialise sent, owner order
+    bool v_found = false;
+    uint64_t v_idx = 0;
+    uint32_t v_slot = 0;
+    void viol(int32_t kind, uint64_t idx, uint32_t slot) {
+        if (verdict == MC_V_OK) verdict = kind;
+        if (!v_found) { v_found = true; v_idx = idx; v_slot = slot; }
+    }
+    void push_state(const uint64_t *w, uint32_t prank, uint64_t pidx, uint32_t pslot) {
+        arena.insert(arena.end(), w, w + W);
+        par.push_back(Par{prank, pidx, pslot});
+    }
+    size_t state_bytes() override { return (size_t)W * 8; }
+    int materialise_parents(unsigned slot, uint64_t *out) override {
+        for (size_t k = 0; k < moved_par[slot & 1].size(); k++) out[k] = moved_par[slot & 1][k];
+        return 0;
+    }
+    int ingest_parents(const uint64_t *pp, uint64_t n, unsigned src) override {
+        for (uint64_t j = 0; j < n; j++) par[par.size() - n + j] = Par{src, pp[j] >> 16, (uint32_t)(pp[j] & 0xffffu)};
+        return 0;
+    }
+    int violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *v, int32_t *inv) override {
+        *found = v_found; *idx = v_idx; *slot = v_slot; *v = v_found ? verdict : MC_V_OK; *inv = v_found && verdict == MC_V_INVARIANT ? 0 : -1;
+        return 0;
+    }
+    int fetch(uint64_t idx, uint8_t *out, uint32_t *prank, uint64_t *pidx, uint32_t *pslot) override {
+        if (idx >= nstates()) return MC_EBADCFG;
+        memcpy(out, &arena[idx * W], (size_t)W * 8);
+        *prank = par[idx].rank; *pidx = par[idx].idx; *pslot = par[idx].slot;
+        return 0;
+    }
     int begin() override {
         W = S::words(prm);
         dup = 0;
-        arena.clear(); seen.clear(); generated = 0; verdict = MC_V_OK;
+        arena.clear(); par.clear(); seen.clear(); generated = 0; verdict = MC_V_OK; v_found = false;
         uint64_t tmp[S::MAX_WORDS];
         for (uint64_t k = 0; k < S::num_init(prm); k++) {
             S::init(prm, k, WordRef{tmp, 1});
@@ -518,8 +558,8 @@ struct ShimShard : ShimShardBase {
             const bool mine = nranks <= 1 || (fp ? fp_owner(fp, nranks) == rank : rank == 0);
             if (!mine) continue;
             generated++;
-            if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
-            if (fp && seen.insert(fp).second) arena.insert(arena.end(), tmp, tmp + W);
+            if (st & ST_INVARIANT) viol(MC_V_INVARIANT, nstates(), 0xfffeu);
+            if (fp && seen.insert(fp).second) push_state(tmp, rank, 0xffffffffull, 0xfffeu);
         }
         lo = 0; hi = nstates();
         return 0;
@@ -528,15 +568,15 @@ struct ShimShard : ShimShardBase {
     uint64_t dup = 0;
     int begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) override {
         W = S::words(prm);
-        arena.clear(); seen.clear(); generated = 0; verdict = MC_V_OK;
+        arena.clear(); par.clear(); seen.clear(); generated = 0; verdict = MC_V_OK; v_found = false;
         uint64_t tmp[S::MAX_WORDS];
         for (uint64_t k = 0; k < S::num_init(prm); k++) {
             S::init(prm, k, WordRef{tmp, 1});
             const unsigned st = S::init_status(prm, CWordRef{tmp, 1});
             generated++;
-            if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
+            if (st & ST_INVARIANT) viol(MC_V_INVARIANT, nstates(), 0xfffeu);
             if (st & ST_OUT_OF_MODEL) continue;
-            if (seen.insert(S::fp_of(prm, CWordRef{tmp, 1})).second) arena.insert(arena.end(), tmp, tmp + W);
+            if (seen.insert(S::fp_of(prm, CWordRef{tmp, 1})).second) push_state(tmp, rank, 0xffffffffull, 0xfffeu);
         }
         uint64_t l = 0, h = nstates();
         uint32_t nl = 0;
@@ -551,7 +591,7 @@ struct ShimShard : ShimShardBase {
                 typename S::Local loc;
                 S::load(prm, s, loc);
                 const int ns = S::nslots(prm, loc);
-                if (S::parent_status(prm, loc, s) & ST_INVARIANT) verdict = MC_V_INVARIANT;
+                if (S::parent_status(prm, loc, s) & ST_INVARIANT) viol(MC_V_INVARIANT, i, 0xfffdu);
                 uint64_t nsucc = 0;
                 for (int slot = 0; slot < ns; slot++) {
                     uint64_t fp = 0;
@@ -559,16 +599,16 @@ struct ShimShard : ShimShardBase {
                     if (!(st & ST_ENABLED)) continue;
                     nsucc++; generated++;
                     if (st & ST_OVERFLOW) return MC_EOVERFLOW;
-                    if (st & ST_ASSERT) { verdict = MC_V_ASSERT; continue; }
-                    if (st & ST_SPECERR) { verdict = MC_V_SPECERR; continue; }
-                    if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
+                    if (st & ST_ASSERT) { viol(MC_V_ASSERT, i, (uint32_t)slot); continue; }
+                    if (st & ST_SPECERR) { viol(MC_V_SPECERR, i, (uint32_t)slot); continue; }
+                    if (st & ST_INVARIANT) viol(MC_V_INVARIANT, i, (uint32_t)slot);
                     if (st & ST_OUT_OF_MODEL) continue;
                     if (seen.insert(fp).second) {
                         S::apply(prm, s, slot, WordRef{tmp, 1});
-                        arena.insert(arena.end(), tmp, tmp + W);
+                        push_state(tmp, rank, i, (uint32_t)slot);
                     }
                 }
-                if (!nsucc && verdict == MC_V_OK) verdict = MC_V_DEADLOCK;
+                if (!nsucc && verdict == MC_V_OK) viol(MC_V_DEADLOCK, i, 0xffffu);
             }
             l = h;
             h = nstates();
@@ -581,7 +621,7 @@ struct ShimShard : ShimShardBase {
             for (uint64_t i = l; i < h; i++) {  // the states of the level whose fingerprint this rank owns
                 std::vector<uint64_t> cur(arena.begin() + (long)(i * W), arena.begin() + (long)((i + 1) * W));
                 if (nranks > 1 && fp_owner(S::fp_of(prm, CWordRef{cur.data(), 1}), nranks) != rank) continue;
-                arena.insert(arena.end(), cur.begin(), cur.end());
+                push_state(cur.data(), rank, i, 0xfffcu);  // SLOT_COPY: not a step
             }
         lo = base;
         hi = nstates();
@@ -603,7 +643,7 @@ struct ShimShard : ShimShardBase {
             typename S::Local loc;
             S::load(prm, s, loc);
             const int ns = S::nslots(prm, loc);
-            if (S::parent_status(prm, loc, s) & ST_INVARIANT) verdict = MC_V_INVARIANT;
+            if (S::parent_status(prm, loc, s) & ST_INVARIANT) viol(MC_V_INVARIANT, i, 0xfffdu);
             uint64_t nsucc = 0;
             for (int slot = 0; slot < ns; slot++) {
                 uint64_t fp = 0;
@@ -611,9 +651,9 @@ struct ShimShard : ShimShardBase {
                 if (!(st & ST_ENABLED)) continue;
                 nsucc++; generated++;
                 if (st & ST_OVERFLOW) return MC_EOVERFLOW;
-                if (st & ST_ASSERT) { verdict = MC_V_ASSERT; continue; }
-                if (st & ST_SPECERR) { verdict = MC_V_SPECERR; continue; }
-                if (st & ST_INVARIANT) verdict = MC_V_INVARIANT;
+                if (st & ST_ASSERT) { viol(MC_V_ASSERT, i, (uint32_t)slot); continue; }
+                if (st & ST_SPECERR) { viol(MC_V_SPECERR, i, (uint32_t)slot); continue; }
+                if (st & ST_INVARIANT) viol(MC_V_INVARIANT, i, (uint32_t)slot);
                 if (st & ST_OUT_OF_MODEL) continue;
                 const uint32_t o = fp_owner(fp, nranks);
                 if (o == rank) {  // engine.hip, local-owner shortcut: probed at once, a new state joins this rank's own frontier
@@ -621,19 +661,23 @@ struct ShimShard : ShimShardBase {
                         uint64_t tmp[S::MAX_WORDS];
                         S::apply(prm, s, slot, WordRef{tmp, 1});
                         local_new.insert(local_new.end(), tmp, tmp + W);
+                        local_par.push_back(Par{rank, i, (uint32_t)slot});
                     }
                     continue;
                 }
                 fps[o].push_back(fp);
                 src[o].push_back({i, slot});
             }
-            if (!nsucc && verdict == MC_V_OK) verdict = MC_V_DEADLOCK;
+            if (!nsucc && verdict == MC_V_OK) viol(MC_V_DEADLOCK, i, 0xffffu);
         }
         arena.insert(arena.end(), local_new.begin(), local_new.end());  // (after the loop: `s` points into the arena)
+        par.insert(par.end(), local_par.begin(), local_par.end());
         local_new.clear();
+        local_par.clear();
         return 0;
     }
     std::vector<uint64_t> local_new;
+    std::vector<Par> local_par;
     int expand_finish(unsigned slot, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) override {
         Slot &q = sl[slot & 1];
         if (!q.launched) return MC_EBADCFG;
@@ -664,11 +708,14 @@ struct ShimShard : ShimShardBase {
         auto &pend_off = sl[slot & 1].pend_off;
         uint64_t *out = (uint64_t *)send_states;
         uint64_t blk0 = 0;
+        auto &mp = moved_par[slot & 1];
+        mp.clear();
         for (uint32_t o = 0; o < nranks; o++) {
             uint64_t k = 0;
             for (uint64_t i = pend_off[o]; i < pend_off[o + 1]; i++) {
                 if (!answers_back[i]) continue;
                 if ((blk0 + k / 64 + 1) * 64 > send_cap) return MC_EARENA;
+                mp.push_back((pending[i].parent << 16) | (uint64_t)(unsigned)pending[i].slot);
                 S::apply(prm, CWordRef{&arena[pending[i].parent * W], 1}, pending[i].slot,
                          WordRef{out + (blk0 + k / 64) * (uint64_t)W * 64 + k % 64, 64});
                 k++;
@@ -685,15 +732,17 @@ struct ShimShard : ShimShardBase {
         for (size_t i = 0; i < pending.size(); i++) {
             if (!answers_back[i]) continue;
             S::apply(prm, CWordRef{&arena[pending[i].parent * W], 1}, pending[i].slot, WordRef{tmp.data(), 1});
-            arena.insert(arena.end(), tmp.begin(), tmp.end());
+            push_state(tmp.data(), rank, pending[i].parent, (uint32_t)pending[i].slot);
             (*n_new)++;
         }
         return 0;
     }
     int ingest(const uint8_t *recv_states, uint64_t n) override {  // one source's bucket
         const uint64_t *in = (const uint64_t *)recv_states;
-        for (uint64_t j = 0; j < n; j++)
+        for (uint64_t j = 0; j < n; j++) {
             for (int w = 0; w < W; w++) arena.push_back(in[(j / 64) * (uint64_t)W * 64 + (uint64_t)w * 64 + j % 64]);
+            par.push_back(Par{rank, 0xfffffffeull, 0});  // produced on another rank: ingest_parents fills it in
+        }
         return 0;
     }
     uint64_t end_level() override { lo = hi; hi = nstates(); return hi - lo; }
@@ -703,7 +752,7 @@ struct ShimShard : ShimShardBase {
             CWordRef s{&arena[i * W], 1};
             typename S::Local loc;
             S::load(prm, s, loc);
-            if (S::parent_status(prm, loc, s) & ST_INVARIANT) verdict = MC_V_INVARIANT;
+            if (S::parent_status(prm, loc, s) & ST_INVARIANT) viol(MC_V_INVARIANT, i, 0xfffdu);
         }
     }
 };
@@ -741,4 +790,124 @@ int shim_shard_keep(void *e, uint32_t slot, const uint8_t *ans, uint64_t *n) { r
 int shim_shard_end_level(void *e, uint64_t *n) { *n = ((ShimShardBase *)e)->end_level(); return 0; }
 int shim_shard_counters(void *e, uint64_t *g, uint64_t *d, int32_t *v) { ((ShimShardBase *)e)->counters(g, d, v); return 0; }
 int shim_shard_check_frontier(void *e) { ((ShimShardBase *)e)->check_frontier(); return 0; }
+}
+
+// ------------------------------------------------------------------------------------------
+// The product's level loop (tla_rust_amd/csrc/shard_loop.h — the same source libtlamc.so compiles) over the host emulation
+// above: what the multi-rank CPU tests run, with a transport the test supplies (torch.distributed gloo through callbacks).
+#include "../../tla_rust_amd/csrc/shard_loop.h"
+
+static thread_local std::string g_shim_error;
+extern "C" void mc_set_error_internal(const char *msg) { g_shim_error = msg ? msg : ""; }
+extern "C" const char *shim_last_error() { return g_shim_error.c_str(); }
+extern "C" const char *mc_strerror(int code) {
+    switch (code) {
+        case MC_OK: return "ok";
+        case MC_EBADCFG: return "bad configuration";
+        case MC_EHIP: return "HIP error";
+        case MC_EOVERFLOW: return "packed-state slot overflow";
+        case MC_ETABLEFULL: return "seen-set full";
+        case MC_EARENA: return "arena / exchange buffer exhausted";
+        case MC_ERCCL: return "exchange failure";
+        case MC_ESTATE: return "call sequence error";
+        default: return "error";
+    }
+}
+
+struct ShimOps {
+    ShimShardBase *s;
+    uint32_t P;
+    std::vector<uint64_t> pack_counts[2];
+    uint64_t chunk_limit() const { return 0; }
+    size_t state_bytes() const { return s->state_bytes(); }
+    bool traced() const { return true; }
+    void record(int, int) {}
+    void wait(int, int) {}
+    void clear_counts(uint64_t *buf, uint32_t n, uint64_t cap) { for (uint32_t t = 0; t < n; t++) buf[(uint64_t)t * cap] = 0; }
+    void clear_bytes(void *p, size_t n, int) { memset(p, 0, n); }
+    int begin() { return s->begin(); }
+    int begin_replicated(uint64_t mf, uint64_t md, uint64_t ml, uint64_t *lv, uint32_t *n) { return s->begin_replicated(mf, md, ml, lv, n); }
+    int level_size(uint64_t *n) { *n = s->level_size(); return 0; }
+    int expand_launch(uint32_t slot, uint64_t first, uint64_t count, uint64_t) { return s->expand_launch(slot, first, count); }
+    int expand_finish(uint32_t slot, uint64_t *fp, uint64_t cap, uint64_t *counts) { return s->expand_finish(slot, fp, cap, counts); }
+    // fixed-capacity rounds emulated on the variable-size step calls: the in-band layout of include/tlamc.h mc_shard_*_pack
+    int expand_pack(uint32_t slot, uint64_t *send_fp, uint64_t cap) {
+        std::vector<uint64_t> tmp((size_t)P * cap), counts(P);
+        int rc = s->expand_finish(slot, tmp.data(), tmp.size(), counts.data());
+        if (rc) return rc;
+        memset(send_fp, 0, (size_t)P * cap * 8);
+        uint64_t off = 0;
+        for (uint32_t t = 0; t < P; t++) {
+            if (counts[t] + 1 > cap) { mc_set_error_internal("an exchange bucket is full"); return MC_EARENA; }
+            send_fp[(uint64_t)t * cap] = counts[t];
+            memcpy(send_fp + (uint64_t)t * cap + 1, tmp.data() + off, counts[t] * 8);
+            off += counts[t];
+        }
+        pack_counts[slot & 1] = counts;
+        return 0;
+    }
+    int probe(const uint64_t *fp, uint64_t n, uint8_t *ans) { return s->probe(fp, n, ans); }
+    int probe_pack(const uint64_t *recv, uint64_t cap, uint8_t *ans) {
+        memset(ans, 0, (size_t)P * cap);
+        for (uint32_t q = 0; q < P; q++) {
+            const uint64_t n = recv[(uint64_t)q * cap] < cap ? recv[(uint64_t)q * cap] : 0;
+            if (n) s->probe(recv + (uint64_t)q * cap + 1, n, ans + (uint64_t)q * cap + 1);
+        }
+        return 0;
+    }
+    int keep_pack(uint32_t slot, const uint8_t *back, uint64_t cap) {
+        const auto &counts = pack_counts[slot & 1];
+        if (counts.size() != P) return MC_ESTATE;
+        std::vector<uint8_t> flat;
+        for (uint32_t t = 0; t < P; t++) {
+            // answers outside the counts must be 0 (the HIP sender scans the whole packed range)
+            if (back[(uint64_t)t * cap]) return MC_ESTATE;
+            for (uint64_t j = 1 + counts[t]; j < cap; j++) if (back[(uint64_t)t * cap + j]) return MC_ESTATE;
+            flat.insert(flat.end(), back + (uint64_t)t * cap + 1, back + (uint64_t)t * cap + 1 + counts[t]);
+        }
+        uint64_t n = 0;
+        if (flat.empty()) flat.push_back(0);
+        return s->keep(slot, flat.data(), &n);
+    }
+    int wait_keep(uint32_t) { return 0; }
+    int materialise_slot(uint32_t slot, const uint8_t *back, uint8_t *st, uint64_t cap, uint64_t *counts) { return s->materialise(slot, back, st, cap, counts); }
+    int materialise_parents(uint32_t slot, uint64_t *out) { return s->materialise_parents(slot, out); }
+    int ingest(const uint8_t *st, uint64_t n) { return s->ingest(st, n); }
+    int ingest_parents(const uint64_t *pp, uint64_t n, uint32_t src) { return s->ingest_parents(pp, n, src); }
+    int end_level(uint64_t *n) { *n = s->end_level(); return 0; }
+    int counters(uint64_t *g, uint64_t *d, int32_t *v) { s->counters(g, d, v); return 0; }
+    int check_frontier() { s->check_frontier(); return 0; }
+    int violation(int32_t *f, uint64_t *i, uint32_t *sl, int32_t *v, int32_t *inv) { return s->violation(f, i, sl, v, inv); }
+    int fetch(uint64_t idx, uint8_t *st, uint32_t *pr, uint64_t *pi, uint32_t *ps) { return s->fetch(idx, st, pr, pi, ps); }
+};
+
+extern "C" int shim_shard_run_transport(void *e, const mc_transport *t, const mc_shard_opts *o, mc_result *out) {
+    ShimOps ops{(ShimShardBase *)e, t->world, {}};
+    mc_shard::Loop<ShimOps> loop(ops, *t);
+    return loop.run(*o, out);
+}
+extern "C" int shim_shard_trace_transport(void *e, const mc_transport *t, uint8_t *states_out, int32_t *slots_out, size_t *n_inout, int32_t *final_slot) {
+    ShimOps ops{(ShimShardBase *)e, t->world, {}};
+    mc_shard::Loop<ShimOps> loop(ops, *t);
+    return loop.trace(states_out, slots_out, n_inout, final_slot);
+}
+// host evaluation of one (state, slot) pair for the tests' counterexample printing: the successor and the action id
+extern "C" int shim_state_apply(const mc_spec_desc *d, const uint64_t *words, int slot, uint64_t *out) {
+    return dispatch_spec(d, [&](auto spec, const auto &prm) {
+        using S = decltype(spec);
+        S::apply(prm, CWordRef{words, 1}, slot, WordRef{out, 1});
+        return 0;
+    });
+}
+extern "C" int shim_state_format(const mc_spec_desc *d, const uint64_t *words, char *buf, size_t cap) {
+    return dispatch_spec(d, [&](auto spec, const auto &prm) { return decltype(spec)::format(prm, words, buf, cap); });
+}
+extern "C" const char *shim_state_action_name(const mc_spec_desc *d, const uint64_t *words, int slot) {
+    const char *name = "?";
+    dispatch_spec(d, [&](auto spec, const auto &prm) {
+        using S = decltype(spec);
+        name = S::action_name(S::action_of(prm, words, slot));
+        return 0;
+    });
+    return name;
 }

@@ -1,7 +1,7 @@
 """Worker for the multi-process tests: python -m torch.distributed.run ... tests/dist_worker.py <mode> <spec> <json params> <out>
-mode = shim (CPU, gloo, host lowerings) | hip (one GPU shared by all ranks, exchange staged over gloo)."""
+mode = shim (CPU, gloo, host lowerings) | hip (one GPU shared by all ranks, exchange staged over gloo).  Either way the level
+loop that runs is the library's (tla_rust_amd/csrc/shard_loop.h) with torch.distributed's collectives handed in as callbacks."""
 import json
-import os
 import sys
 from pathlib import Path
 
@@ -30,26 +30,23 @@ def main():
             cfg += "".join(f"INVARIANT {i}\n" for i in params.get("invariants", []))
             keep = amd.Program(Path(params["path"]).read_text(), cfg)
         spec, params = "pcal", keep.params
+    common = dict(chunk_states=opts.get("chunk", 1000 if mode == "shim" else 1 << 14), max_distinct=opts.get("max_distinct", 0),
+                  max_levels=opts.get("max_levels", 0), stay_threshold=opts.get("stay_threshold", 1 << 16),
+                  rebalance_ratio=opts.get("rebalance_ratio", 1.25), replicate_until=opts.get("replicate_until", 0),
+                  packed_fanout=opts.get("packed_fanout", 16), move_fanout=opts.get("move_fanout", 64 if mode == "shim" else 32))
     if mode == "shim":
-        from shim_step_engine import ShimStepEngine
-        eng = ShimStepEngine(spec, params, rank, world)
-        chk = ShardedChecker(spec, params, engine=eng, chunk_states=opts.get("chunk", 1000), max_distinct=opts.get("max_distinct", 0),
-                             max_levels=opts.get("max_levels", 0), fanout_cap=opts.get("fanout_cap", 64), new_cap=opts.get("new_cap", 64),
-                             stay_threshold=opts.get("stay_threshold", 1 << 16), rebalance_ratio=opts.get("rebalance_ratio", 1.25),
-                             replicate_until=opts.get("replicate_until", 0), packed=opts.get("packed", True))
+        from shim_step_engine import ShimShard
+        chk = ShardedChecker(spec, params, engine=ShimShard(spec, params, rank, world), **common)
     else:
-        chk = ShardedChecker(spec, params, device=0, chunk_states=opts.get("chunk", 1 << 14), max_distinct=opts.get("max_distinct", 0),
-                             max_levels=opts.get("max_levels", 0), table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
-                             fanout_cap=opts.get("fanout_cap", 32), new_cap=opts.get("new_cap", 16),
-                             stay_threshold=opts.get("stay_threshold", 1 << 16), rebalance_ratio=opts.get("rebalance_ratio", 1.25),
-                             replicate_until=opts.get("replicate_until", 0), packed=opts.get("packed", True), trace=opts.get("trace", False))
+        chk = ShardedChecker(spec, params, device=0, table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
+                             trace=opts.get("trace", False), **common)
     r = chk.run()
     trace = chk.counterexample() if opts.get("trace") else None
-    _, local, _ = chk.eng.counters()
     shares = [None] * world
-    dist.all_gather_object(shares, local)
+    dist.all_gather_object(shares, chk.local_distinct)
     if rank == 0:
-        Path(out).write_text(json.dumps(dict(r, shares=shares, trace=trace, phases={k: v for k, v in chk.phase_s.items() if k.endswith("levels")})))
+        Path(out).write_text(json.dumps(dict(r, shares=shares, trace=trace, phases={k: v for k, v in chk.stats.items() if k.endswith("levels")},
+                                             stats=chk.stats)))
     chk.close()
     dist.destroy_process_group()
 

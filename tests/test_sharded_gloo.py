@@ -1,6 +1,7 @@
-"""The N>1 path on CPU: world_size-2 (and 3) gloo runs of tla_rust_amd.sharded.ShardedChecker with the
-host build of the lowerings standing in for the HIP step kernels.  Counts must equal the oracle's
-(= the 1-GPU engine's), whatever the number of ranks or the chunk size."""
+"""The N>1 path on CPU: world_size-2 (3, 4, 8) gloo runs of the library's level loop (tla_rust_amd/csrc/shard_loop.h, the one
+`mc -gpus P` and `bench.py --gpus N` run over RCCL) with the host build of the lowerings standing in for the HIP step kernels
+and torch.distributed's gloo collectives handed to the loop as its transport.  Counts must equal the oracle's (= the 1-GPU
+engine's), whatever the number of ranks or the chunk size."""
 import json
 import socket
 import subprocess
@@ -65,16 +66,14 @@ def test_sharded_budget_stop_checks_the_last_level(oracle, shim, tmp_path, repli
     assert r["verdict"] == "budget" and r["depth"] == L - 1
 
 
-@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("world", [2, 3])
-def test_stay_mode_counts_equal_oracle(oracle, shim, tmp_path, world, packed):
+def test_stay_mode_counts_equal_oracle(oracle, shim, tmp_path, world):
     """States stay on the generating rank once the frontier is large (threshold lowered to 50 states per rank
-    here, loose rebalance ratio): only fingerprints and answers are exchanged; counts must not change.
-    packed: fixed-capacity buckets with in-band counts (equal-split all-to-alls, no size exchange) / the host-paced rounds."""
+    here, loose rebalance ratio): only fingerprints and answers are exchanged — fixed-capacity buckets with in-band counts,
+    equal-split all-to-alls, no size exchange; counts must not change."""
     params = [2, 2, 2, 9, 2, 1]
     o = oracle.oracle_run("raft", params, max_distinct=60000)
-    r = run_dist("shim", world, "raft", params, tmp_path, {"max_distinct": 60000, "chunk": 2000, "stay_threshold": 50, "rebalance_ratio": 1.6,
-                                                           "packed": packed})
+    r = run_dist("shim", world, "raft", params, tmp_path, {"max_distinct": 60000, "chunk": 2000, "stay_threshold": 50, "rebalance_ratio": 1.6})
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["phases"].get("stay_levels", 0) >= 5 and r["phases"].get("move_levels", 0) >= 3
     assert sum(r["shares"]) == o["distinct"]
@@ -125,3 +124,42 @@ def test_replicated_prefix_covers_a_whole_small_graph_and_a_violation(oracle, sh
     r = run_dist("shim", 2, "pcal_intro", [1, 0, 20, 2], tmp_path, {"replicate_until": 1 << 20})
     o = oracle.oracle_run("pcal_intro", [1, 0, 20, 2])
     assert r["verdict"] == "assert" and (r["distinct"], r["generated"], r["levels"]) == (o["distinct"], o["generated"], o["levels"])
+
+
+def test_a_drifted_level_is_rebalanced(oracle, shim, tmp_path):
+    """rebalance_ratio 1.0 (+ nothing ever balanced exactly): every large level is a MOVE level, the new states travel to their
+    owners and the shares stay even; ratio 100: the same graph with stay levels only after the first large level — same counts"""
+    params = [2, 2, 2, 9, 2, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=40000)
+    for ratio, want_stay in ((1.0, False), (100.0, True)):
+        r = run_dist("shim", 3, "raft", params, tmp_path, {"max_distinct": 40000, "chunk": 900, "stay_threshold": 40, "rebalance_ratio": ratio,
+                                                           "replicate_until": 30})
+        assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+        assert (r["phases"]["stay_levels"] > 0) == want_stay and sum(r["shares"]) == o["distinct"]
+        if not want_stay:
+            assert max(r["shares"]) < 1.15 * o["distinct"] / 3
+
+
+@pytest.mark.parametrize("world,replicate_until", [(2, 0), (3, 0), (3, 40)])
+def test_counterexample_walked_back_across_ranks_on_cpu(oracle, shim, tmp_path, world, replicate_until):
+    """README.md:267-321 on several ranks: the behaviour that ends in the failing Assert is rebuilt by the loop's collective walk
+    (mc_shard_trace_transport: parents of states that moved travelled with them) — the oracle's shortest length"""
+    params = [1, 0, 20, 2]
+    o = oracle.oracle_run("pcal_intro", params)
+    r = run_dist("shim", world, "pcal_intro", params, tmp_path, {"chunk": 512, "trace": True, "replicate_until": replicate_until})
+    assert r["verdict"] == "assert" == o["verdict"]
+    tr = r["trace"]
+    assert tr is not None and len(tr) == len(o["trace"]) == 6 and tr[0][0] == "Initial predicate"
+    assert "alice_account = -" in tr[-1][1] and len({t for _, t in tr}) == 6
+
+
+def test_invariant_counterexample_across_ranks_on_cpu(oracle, shim, tmp_path):
+    """an INVARIANT violated by a successor that is stored nowhere (rebuilt from its parent) and one found when the state is
+    expanded (SI models), three ranks, move and stay levels: the oracle's shortest length, a behaviour without repeats"""
+    for spec, params, last in (("pcal_intro", [1, 1, 20, 2], "account_total"), ("ssi", [2, 2, 127, 3], "history")):
+        o = oracle.oracle_run(spec, params)
+        assert o["verdict"] == "invariant"
+        r = run_dist("shim", 3, spec, params, tmp_path, {"chunk": 256, "trace": True, "stay_threshold": 40, "rebalance_ratio": 2.5})
+        tr = r["trace"]
+        assert r["verdict"] == "invariant" and tr is not None and len(tr) == len(o["trace"]) and len({t for _, t in tr}) == len(tr)
+        assert tr[0][0] == "Initial predicate" and all(a and a != "?" for a, _ in tr) and last in tr[-1][1]

@@ -49,6 +49,36 @@ class KernelStats(C.Structure):
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64)
 
+MC_COMM_ID_BYTES = 128
+MC_SHARD_NO_PREFIX = 1
+
+
+class ShardStats(C.Structure):
+    """mc_shard_stats: what one rank's level loop did"""
+    _fields_ = [("replicated_levels", C.c_uint64), ("stay_levels", C.c_uint64), ("move_levels", C.c_uint64), ("rounds", C.c_uint64),
+                ("sent_bytes", C.c_uint64), ("distinct_local", C.c_uint64), ("max_frontier", C.c_uint64), ("mean_frontier", C.c_uint64)]
+
+
+class ShardOpts(C.Structure):
+    """mc_shard_opts"""
+    _fields_ = [("chunk_states", C.c_uint64), ("max_distinct", C.c_uint64), ("max_levels", C.c_uint64), ("replicate_until", C.c_uint64),
+                ("packed_fanout", C.c_uint64), ("stay_threshold", C.c_uint64), ("rebalance_ratio", C.c_double), ("move_fanout", C.c_uint64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32), ("stats", C.POINTER(ShardStats))]
+
+
+T_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+T_RELEASE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+T_A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+T_A2AV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                     C.POINTER(C.c_uint64))
+T_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+
+
+class Transport(C.Structure):
+    """mc_transport: the collectives the level loop runs on (RCCL from mc_comm_transport, or a host's own)"""
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("hip_stream", C.c_void_p), ("alloc", T_ALLOC),
+                ("release", T_RELEASE), ("all_to_all", T_A2A), ("all_to_all_v", T_A2AV), ("all_gather", T_GATHER)]
+
 
 class Result(dict):
     __getattr__ = dict.__getitem__
@@ -123,6 +153,18 @@ def lib():
     L.mc_shard_end_level.argtypes = [C.c_void_p, U64P]
     L.mc_shard_counters.argtypes = [C.c_void_p, U64P, U64P, C.POINTER(C.c_int32)]
     L.mc_shard_check_frontier.argtypes = [C.c_void_p]
+    L.mc_comm_unique_id.argtypes = [C.c_char_p]
+    L.mc_comm_create.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.mc_comm_destroy.argtypes = [C.c_void_p]
+    L.mc_comm_destroy.restype = None
+    L.mc_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.mc_comm_transport.argtypes = [C.c_void_p, C.POINTER(Transport)]
+    L.mc_shard_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ShardOpts), C.POINTER(CResult)]
+    L.mc_shard_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    L.mc_shard_run_transport.argtypes = [C.c_void_p, C.POINTER(Transport), C.POINTER(ShardOpts), C.POINTER(CResult)]
+    L.mc_shard_trace_transport.argtypes = [C.c_void_p, C.POINTER(Transport), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t),
+                                           C.POINTER(C.c_int32)]
+    L.mc_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), U64P, C.POINTER(C.c_int32)]
     if hasattr(L, "mc_cfg_parse"):
         L.mc_cfg_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.mc_cfg_free.argtypes = [C.c_void_p]
@@ -371,6 +413,87 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """mc_comm_*: one rank's RCCL communicator (hip-rccl back-end of the C ABI).  Rank 0 makes the id (Comm.unique_id()) and the
+    host ships its 128 bytes to the other ranks however it likes (a file, a TCP store, the environment)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(MC_COMM_ID_BYTES)
+        _check(lib().mc_comm_unique_id(buf), "mc_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int):
+        self._h = C.c_void_p()
+        self.rank, self.world, self.device = rank, world, device
+        _check(lib().mc_comm_create(uid, rank, world, device, C.byref(self._h)), "mc_comm_create")
+
+    def all_gather_u64(self, value: int):
+        """every rank's value (a barrier when the values are ignored)"""
+        mine = C.c_uint64(int(value))
+        out = (C.c_uint64 * self.world)()
+        _check(lib().mc_comm_all_gather(self._h, C.byref(mine), out, 8), "mc_comm_all_gather")
+        return [int(x) for x in out]
+
+    def all_gather_f64(self, value: float):
+        mine = C.c_double(float(value))
+        out = (C.c_double * self.world)()
+        _check(lib().mc_comm_all_gather(self._h, C.byref(mine), out, 8), "mc_comm_all_gather")
+        return [float(x) for x in out]
+
+    def shard_run(self, engine, **opts):
+        """mc_shard_run: the whole sharded search over this communicator; returns (Result, stats dict)"""
+        st = ShardStats()
+        o = shard_opts(stats=st, **opts)
+        r = CResult()
+        _check(lib().mc_shard_run(engine._h, self._h, C.byref(o), C.byref(r)), "mc_shard_run")
+        return _result(r), {k: int(getattr(st, k)) for k, _ in ShardStats._fields_}
+
+    def shard_trace(self, engine):
+        """mc_shard_trace (collective): [(action name, state text)] of the counterexample, or None"""
+        sp, pr = engine.spec, engine.params
+        return _trace_from(lambda st, sl, n, fs: lib().mc_shard_trace(engine._h, self._h, st, sl, n, fs), "mc_shard_trace", state_bytes(sp, pr),
+                           lambda st: state_format(sp, pr, st), lambda st, slot: state_action_name(sp, pr, st, slot),
+                           lambda st, slot: state_apply(sp, pr, st, slot))
+
+    def close(self):
+        if self._h:
+            lib().mc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def shard_opts(stats=None, chunk_states=0, max_distinct=0, max_levels=0, replicate_until=None, packed_fanout=0, stay_threshold=0,
+               rebalance_ratio=0.0, move_fanout=0):
+    """mc_shard_opts; replicate_until = 0 shards from Init on (MC_SHARD_NO_PREFIX), None = the default prefix"""
+    o = ShardOpts()
+    o.chunk_states, o.max_distinct, o.max_levels = chunk_states, max_distinct, max_levels
+    o.replicate_until = replicate_until or 0
+    o.flags = MC_SHARD_NO_PREFIX if replicate_until == 0 else 0
+    o.packed_fanout, o.stay_threshold, o.rebalance_ratio, o.move_fanout = packed_fanout, stay_threshold, rebalance_ratio, move_fanout
+    if stats is not None:
+        o.stats = C.pointer(stats)
+    return o
+
+
+def _trace_from(call, what, W, fmt, action, apply):
+    """shared by Comm.shard_trace and sharded.ShardedChecker.counterexample: run the collective walk (call fills packed states
+    and the slot that led to each), name the actions and print the states: [(action name, TLA+ text)], or None"""
+    cap = C.c_size_t(4096)
+    states = C.create_string_buffer(W * cap.value)
+    slots = (C.c_int32 * cap.value)()
+    final = C.c_int32(-1)
+    _check(call(states, slots, C.byref(cap), C.byref(final)), what)
+    if cap.value == 0:
+        return None
+    sts = [states.raw[k * W:(k + 1) * W] for k in range(cap.value)]
+    out = [("Initial predicate", fmt(sts[0]))]
+    for k in range(1, len(sts)):
+        out.append((action(sts[k - 1], slots[k]), fmt(sts[k])))
+    if final.value >= 0:  # an invariant broken by a successor that is stored nowhere: rebuilt from its parent
+        out.append((action(sts[-1], final.value), fmt(apply(sts[-1], final.value))))
+    return out
 
 
 def pcal_translate(tla_text: str) -> str:

@@ -1531,6 +1531,8 @@ struct EngineBase {
     virtual int shard_ingest_parents(const uint64_t *recv_parents, uint64_t n, unsigned src_rank) = 0;
     virtual int shard_violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant) = 0;
     virtual int shard_fetch(uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) = 0;
+    virtual int shard_info(void **main_stream, uint64_t *chunk_states, int32_t *traced) = 0;
+    virtual size_t state_bytes() const = 0;
 };
 
 static uint64_t round_pow2(uint64_t v) {
@@ -1802,6 +1804,8 @@ struct Engine : EngineBase {
         out->violated_invariant = -1;
         memset(kstat, 0, sizeof kstat);
         have_viol = false;
+        have_run = false;  // set again on the success path only: a run that fails half-way (MC_EARENA, MC_ETABLEFULL, MC_EOVERFLOW)
+                           // leaves fingerprints of an unfinished level in the seen-set — the next step / checkpoint must not continue it
         level_start.clear();
         HIP_TRY(hipSetDevice(cfg.device));
         const bool in_place = ck_pending && ck_in_place;  // mc_engine_step: the seen-set of the stopped run is still valid
@@ -2005,11 +2009,14 @@ struct Engine : EngineBase {
             ck_level_start = level_start;
             ck_pending = ck_in_place = true;
             cfg.max_levels = (uint64_t)level_start.size() + levels;
+        } else if (ck_pending) {  // restore() handed a checkpoint over: `levels` more levels beyond the checkpointed ones
+            cfg.max_levels = (uint64_t)ck_level_start.size() + levels;
         } else {
             cfg.max_levels = levels;
         }
         const int rc = run(out);
         cfg.max_levels = saved;
+        if (rc) ck_pending = ck_in_place = false;  // after a failure the next step starts over
         return rc;
     }
     uint64_t last_generated = 0, ck_distinct = 0, ck_generated = 0, ck_cells = 0, ck_lo = 0;
@@ -2079,7 +2086,9 @@ struct Engine : EngineBase {
             fail(MC_EBADCFG, "restore: the checkpoint was written with other constants / invariants");
         else if (!ck_params_comparable() && (h.nparams != 1 || (uint64_t)h.params[0] != program_hash))
             fail(MC_EBADCFG, "restore: the checkpoint was written by another compiled program (algorithm, constants, invariants or constraints differ)");
-        else if (h.distinct * 2 > table_cap) fail(MC_ETABLEFULL, "restore: table_capacity cannot hold the checkpoint's states at load 1/2");
+        // a run may legitimately stop on a budget at a seen-set load of 0.5 - 0.8 (the bench model at 2^27 slots ends at 0.76): its
+        // checkpoint must restore into the same configuration; beyond 0.9 the reseeding itself could not finish (DEV_ETABLE)
+        else if (h.distinct * 10 > table_cap * 9) fail(MC_ETABLEFULL, "restore: table_capacity cannot hold the checkpoint's states (load > 0.9)");
         else if (h.distinct > arena_cap) fail(MC_EARENA, "restore: arena_capacity is smaller than the checkpoint");
         else if (h.hi != h.distinct || h.lo > h.hi || h.nlevels == 0 || h.nlevels >= MC_MAX_LEVELS) fail(MC_EPARSE, "restore: inconsistent header");
         else if (d_parent && !h.has_trace) fail(MC_EBADCFG, "restore: the checkpoint holds no parent pointers (written without MC_F_TRACE); run without MC_F_TRACE");
@@ -2335,6 +2344,14 @@ struct Engine : EngineBase {
         return MC_OK;
     }
     int shard_level_size(uint64_t *n) override { *n = sh_hi - sh_lo; return MC_OK; }
+    int shard_info(void **main_stream, uint64_t *chunk_states, int32_t *traced) override {
+        HIP_TRY(hipSetDevice(cfg.device));
+        if (main_stream) *main_stream = (void *)stream;
+        if (chunk_states) *chunk_states = chunk;
+        if (traced) *traced = d_parent != nullptr;
+        return MC_OK;
+    }
+    size_t state_bytes() const override { return (size_t)W * 8; }
     // Side stream of the sharded path.  By default the engine's own second stream, and every step call returns
     // with its work finished.  A caller that runs its collectives on a HIP stream hands that stream over with
     // shard_set_stream: compaction / probe / keep / materialise / ingest are then enqueued on it WITHOUT host
@@ -2470,9 +2487,12 @@ struct Engine : EngineBase {
         for (unsigned t = 0; t <= 8; t++) q.pend_off.off[t] = (t < P ? t : P) * cap;
         if (!ev_exp[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_exp[slot], hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ev_exp[slot], stream));  // behind the slot's expand kernel (or behind nothing: an empty chunk)
-        HIP_TRY(hipStreamWaitEvent(side(), ev_exp[slot], 0));
+        // The buckets are compacted on the EXPAND stream, right behind the kernel that filled them: on the side stream the
+        // compaction of round r+1 would queue behind the probes of round r (or those behind it), and the fingerprint exchange of
+        // round r+1 could never overlap them.  The caller orders its collective behind this call with an event on that stream
+        // (mc_shard_info hands it out).
         if (q.keep_pending) {  // the slot's previous keep still reads pend_src
-            HIP_TRY(hipStreamWaitEvent(side(), ev_keep[slot], 0));
+            HIP_TRY(hipStreamWaitEvent(stream, ev_keep[slot], 0));
             q.keep_pending = false;
         }
         if (q.count) {  // the chunk's locally owned new states (local-owner shortcut), as in shard_expand_finish
@@ -2489,12 +2509,13 @@ struct Engine : EngineBase {
             if (!ev_mat[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_mat[slot], hipEventDisableTiming));
             HIP_TRY(hipEventRecord(ev_mat[slot], stream2));
             RouteArgs rt{P, q.rt_cur, q.rt_fp, q.rt_src, q.rt_subcap};
-            hipLaunchKernelGGL(k_compact_packed, dim3(64, P * NSHARD), dim3(256), 0, side(), rt, cap, send_fp, q.pend_src, d_ctr);
+            hipLaunchKernelGGL(k_compact_packed, dim3(64, P * NSHARD), dim3(256), 0, stream, rt, cap, send_fp, q.pend_src, d_ctr);
         } else {  // no chunk for this rank in this round: empty buckets
-            for (unsigned t = 0; t < P; t++) HIP_TRY(hipMemsetAsync(send_fp + (uint64_t)t * cap, 0, sizeof(uint64_t), side()));
+            for (unsigned t = 0; t < P; t++) HIP_TRY(hipMemsetAsync(send_fp + (uint64_t)t * cap, 0, sizeof(uint64_t), stream));
         }
         if (!ev_slot[slot]) HIP_TRY(hipEventCreateWithFlags(&ev_slot[slot], hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ev_slot[slot], side()));
+        HIP_TRY(hipEventRecord(ev_slot[slot], stream));
+        if (!ext_side) HIP_TRY(hipStreamSynchronize(stream));
         return side_done();
     }
     int shard_probe_pack(const uint64_t *recv_fp, uint64_t cap, uint8_t *answers) override {
@@ -2985,6 +3006,10 @@ int mc_shard_begin_replicated(mc_engine *e, uint64_t min_frontier, uint64_t max_
     return e && levels_out && nlevels ? e->impl->shard_begin_replicated(min_frontier, max_distinct, max_levels, levels_out, nlevels) : MC_EBADCFG;
 }
 int mc_shard_level_size(mc_engine *e, uint64_t *n) { return e && n ? e->impl->shard_level_size(n) : MC_EBADCFG; }
+int mc_shard_info(mc_engine *e, void **main_stream_out, uint64_t *chunk_states_out, int32_t *traced_out) {
+    return e ? e->impl->shard_info(main_stream_out, chunk_states_out, traced_out) : MC_EBADCFG;
+}
+size_t mc_engine_state_bytes_internal(mc_engine *e) { return e ? e->impl->state_bytes() : 0; }
 int mc_shard_expand(mc_engine *e, uint64_t first, uint64_t count, uint64_t *send_fp, uint64_t send_cap, uint64_t *send_counts) {
     if (!e || !send_counts) return MC_EBADCFG;
     const int rc = e->impl->shard_expand_launch(0, first, count, send_cap);

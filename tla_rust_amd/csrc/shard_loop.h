@@ -1,0 +1,459 @@
+// shard_loop.h — THE level loop of the fingerprint-sharded search, written once against two small interfaces:
+//
+//   * `mc_transport` (include/tlamc.h): the collectives — RCCL in the product (shard_rccl.cpp), torch.distributed through
+//     callbacks (tla_rust_amd/sharded.py: backend "nccl", or gloo staged through the host in the CPU tests);
+//   * `Ops`: the step calls of ONE rank's engine — mc_shard_* of the C ABI in the product (shard_rccl.cpp `AbiOps`), the host
+//     build of the lowerings in the CPU tests (tests/_shim/shim.cpp `ShimOps`).
+//
+// Round 2 had two loops (this one's ancestor in C++ over RCCL, which only knew the "stay" form, and a Python one over
+// torch.distributed that the tests drove); they are one now: every multi-rank test, `mc X.tla -gpus P`, `bench.py --gpus N`
+// and the torch front door run the code below.
+//
+// Per level ONE host synchronisation: the all-gather of {frontier size, verdict, status} of every rank.  A rank-local failure
+// is sticky and collective: the failing rank keeps taking part in the level's collectives with empty buckets, its status travels
+// with the all-gather, and all ranks leave together (nobody is left waiting in a collective).
+//
+//   STAY level (large, balanced frontier): fixed-capacity rounds, nothing waits for the host.  Streams: MAIN (the engine's expand
+//     stream: expand r, bucket compaction r), COMM (the transport's: the all-to-alls), WORK (probes), the engine's second
+//     stream (materialisation of the kept states).  Issue order on COMM is fp(0) fp(1) ans(0) fp(2) ans(1) ...: the fingerprint
+//     exchange of round r+1 overlaps the probes of round r, the expand of round r+1 overlaps both.  9 bytes per routed
+//     candidate cross xGMI; new states stay on the rank that generated them.
+//   MOVE level (small frontier, or the largest rank holds more than rebalance_ratio x the mean): host-paced rounds with
+//     exact sizes; the new states travel to their owners as whole 64-state blocks (+ their parent pointers with MC_F_TRACE),
+//     which is what spreads a small frontier — and a drifted one — evenly again.
+#ifndef MC_SHARD_LOOP_H
+#define MC_SHARD_LOOP_H
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/tlamc.h"
+
+extern "C" void mc_set_error_internal(const char *msg);
+
+namespace mc_shard {
+
+enum Stream { S_COMM = 0, S_WORK = 1, S_MAIN = 2 };
+// event ids of a stay level (two slots each) and of the serialised move rounds
+enum Event { EV_PACKED = 0, EV_FP = 2, EV_PROBED = 4, EV_ANS = 6, EV_TMP = 8, EV_COUNT = 10 };
+
+constexpr uint32_t SLOT_NONE = 0xffffu, SLOT_INIT = 0xfffeu, SLOT_PARENT = 0xfffdu, SLOT_COPY = 0xfffcu;
+constexpr uint64_t NO_PARENT = 0xffffffffull;
+
+// exchange buffer from the transport's allocator; grows on demand (only ever between levels or in host-paced rounds)
+struct NetBuf {
+    const mc_transport *t = nullptr;
+    void *p = nullptr;
+    size_t bytes = 0;
+    int need(size_t n) {
+        if (n <= bytes && p) return MC_OK;
+        if (p) t->release(t->user, p);
+        p = nullptr;
+        bytes = 0;
+        n = (n + 4095) & ~(size_t)4095;
+        p = t->alloc(t->user, n);
+        if (!p) { mc_set_error_internal("sharded search: cannot allocate an exchange buffer"); return MC_EHIP; }
+        bytes = n;
+        return MC_OK;
+    }
+    ~NetBuf() { if (p && t) t->release(t->user, p); }
+};
+
+struct LevelInfo { uint64_t n, verdict, status, pad; };
+
+template <class Ops>
+struct Loop {
+    Ops &e;
+    const mc_transport &net;
+    const uint32_t P, me;
+    std::vector<LevelInfo> all;
+    std::vector<uint64_t> sizes;
+    int lrc = MC_OK;  // this rank's sticky status: once non-zero, no engine call is made any more, the collectives still are
+    mc_shard_stats st;
+
+    Loop(Ops &ops, const mc_transport &t) : e(ops), net(t), P(t.world), me(t.rank), all(t.world), sizes(t.world) { memset(&st, 0, sizeof st); }
+
+    // engine step: skipped once this rank has failed
+    template <class F>
+    void step(F &&f) { if (!lrc) lrc = f(); }
+
+    // ONE collective per level: every rank's frontier size, verdict and status.  Returns the transport's error only.
+    int level_info(uint64_t local_n, int32_t verdict, uint64_t &frontier, int32_t &worst, int &failed) {
+        LevelInfo mine{local_n, (uint64_t)verdict, (uint64_t)(int64_t)lrc, 0};
+        int trc = net.all_gather(net.user, &mine, all.data(), sizeof mine);
+        if (trc) return trc;
+        frontier = 0;
+        worst = 0;
+        failed = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            sizes[p] = all[p].n;
+            frontier += sizes[p];
+            worst = std::max(worst, (int32_t)all[p].verdict);
+            if (!failed && (int64_t)all[p].status != 0) {
+                failed = (int)(int64_t)all[p].status;
+                if (p != me) mc_set_error_internal(("sharded search: rank " + std::to_string(p) + " failed: " + mc_strerror(failed)).c_str());
+            }
+        }
+        return MC_OK;
+    }
+
+    int run(const mc_shard_opts &o, mc_result *out) {
+        if (!out || !P || me >= P || P > 8) { mc_set_error_internal("sharded search: bad transport (1..8 ranks)"); return MC_EBADCFG; }
+        memset(out, 0, sizeof *out);
+        out->violated_invariant = -1;
+        uint64_t chunk = o.chunk_states ? o.chunk_states : (1ull << 19);
+        if (e.chunk_limit() && chunk > e.chunk_limit()) chunk = e.chunk_limit();  // never more than one launch of the engine takes
+        const uint64_t fan = o.packed_fanout ? o.packed_fanout : 16, mfan = o.move_fanout ? o.move_fanout : 32;
+        const uint64_t stay_threshold = o.stay_threshold ? o.stay_threshold : (1ull << 16);
+        const double ratio = o.rebalance_ratio > 0 ? o.rebalance_ratio : 1.25;
+        const size_t W = e.state_bytes();
+        const bool traced = e.traced();
+        int trc;
+
+        // ---- the small levels: the same fused BFS on every rank, then each rank keeps the states it owns
+        std::vector<uint64_t> levels;
+        if (o.flags & MC_SHARD_NO_PREFIX) {
+            step([&] { return e.begin(); });
+        } else {
+            levels.resize(MC_MAX_LEVELS);
+            uint32_t nlev = MC_MAX_LEVELS;
+            const uint64_t until = (o.replicate_until ? o.replicate_until : (1ull << 15)) * P;
+            step([&] { return e.begin_replicated(until, o.max_distinct, o.max_levels, levels.data(), &nlev); });
+            levels.resize(lrc ? 0 : nlev);
+            st.replicated_levels = levels.size();
+        }
+        uint64_t local_n = 0, gen = 0, dl = 0, frontier = 0;
+        int32_t verdict = 0, worst = 0;
+        int failed = 0;
+        step([&] { return e.level_size(&local_n); });
+        step([&] { return e.counters(&gen, &dl, &verdict); });
+        if ((trc = level_info(local_n, verdict, frontier, worst, failed))) return trc;
+        if (failed) return lrc ? lrc : failed;
+        uint64_t cum = 0;
+        if (o.flags & MC_SHARD_NO_PREFIX) {
+            if (frontier) levels.push_back(frontier);
+        } else if (worst != 0) {
+            frontier = levels.empty() ? 0 : levels.back();
+        }
+        for (uint64_t v : levels) cum += v;
+        bool budget = false;
+
+        NetBuf send[2], recv[2], ans[2], back[2], states, rstates, parents, rparents;
+        for (NetBuf *b : {&send[0], &send[1], &recv[0], &recv[1], &ans[0], &ans[1], &back[0], &back[1], &states, &rstates, &parents, &rparents}) b->t = &net;
+
+        while (frontier > 0 && worst == 0) {
+            if ((o.max_levels && levels.size() >= o.max_levels) || (o.max_distinct && cum >= o.max_distinct)) { budget = true; break; }
+            uint64_t max_n = 0;
+            for (uint32_t p = 0; p < P; ++p) max_n = std::max(max_n, sizes[p]);
+            // imbalance of the worst large level (max over ranks against the mean), before this level's stay / move decision
+            if (frontier >= stay_threshold * P && (double)max_n * st.mean_frontier * P >= (double)st.max_frontier * frontier) {
+                st.max_frontier = max_n;
+                st.mean_frontier = std::max<uint64_t>(frontier / P, 1);
+            }
+            const uint64_t mine = sizes[me];
+            const bool stay = frontier >= stay_threshold * P && (double)max_n * P <= ratio * (double)frontier;
+            // a move level ships whole states: smaller rounds keep its buffers modest
+            const uint64_t ch = stay ? chunk : std::min<uint64_t>(chunk, 1ull << 17);
+            const uint64_t rounds = (max_n + ch - 1) / ch;
+            (stay ? st.stay_levels : st.move_levels)++;
+            st.rounds += rounds;
+            const uint64_t f = stay ? fan : mfan;
+            const uint64_t send_cap = (uint64_t)P * (std::min(ch, max_n) * f / P + 4096);  // candidates of one round, all owners
+            auto launch = [&](uint64_t r) {
+                const uint64_t first = std::min(r * ch, mine), n = std::min(ch, mine - first);
+                step([&] { return e.expand_launch((uint32_t)(r & 1), first, n, send_cap); });
+            };
+            if (stay) {
+                if ((trc = stay_level(rounds, ch, fan, max_n, launch, send, recv, ans, back))) return trc;
+            } else {
+                if ((trc = move_level(rounds, send_cap, W, traced, launch, send, recv, ans, back, states, rstates, parents, rparents))) return trc;
+            }
+            uint64_t new_local = 0;
+            step([&] { return e.end_level(&new_local); });  // waits for the engine's streams; device errors surface here
+            step([&] { return e.counters(&gen, &dl, &verdict); });
+            if ((trc = level_info(new_local, verdict, frontier, worst, failed))) return trc;
+            if (failed) return lrc ? lrc : failed;
+            if (frontier > 0) {
+                if (levels.size() >= MC_MAX_LEVELS) { mc_set_error_internal("more BFS levels than MC_MAX_LEVELS"); return MC_EBADCFG; }
+                levels.push_back(frontier);
+                cum += frontier;
+            }
+        }
+        if (frontier > 0 && worst == 0) step([&] { return e.check_frontier(); });  // a budget stop leaves a level unexpanded
+        step([&] { return e.counters(&gen, &dl, &verdict); });
+        {   // global counters: sum of generated, worst verdict (the unexpanded frontier's check included), status once more
+            LevelInfo mine2{gen, (uint64_t)verdict, (uint64_t)(int64_t)lrc, 0};
+            if ((trc = net.all_gather(net.user, &mine2, all.data(), sizeof mine2))) return trc;
+            gen = 0;
+            worst = 0;
+            for (uint32_t p = 0; p < P; ++p) {
+                gen += all[p].n;
+                worst = std::max(worst, (int32_t)all[p].verdict);
+                if ((int64_t)all[p].status != 0) return lrc ? lrc : (int)(int64_t)all[p].status;
+            }
+        }
+        st.distinct_local = dl;
+        if (o.stats) *o.stats = st;
+        out->distinct = cum;
+        out->generated = gen;
+        out->queue_left = frontier;
+        out->depth = (uint32_t)levels.size();
+        out->levels = (uint32_t)levels.size();
+        for (size_t k = 0; k < levels.size(); ++k) out->level_distinct[k] = levels[k];
+        out->verdict = worst != 0 ? worst : budget ? MC_V_BUDGET : MC_V_OK;
+        return MC_OK;
+    }
+
+    // ------------------------------------------------------------------ STAY: fixed-capacity rounds, counts in band, no host wait
+    size_t stay_bytes = 0;
+    template <class L>
+    int stay_level(uint64_t rounds, uint64_t ch, uint64_t fan, uint64_t max_n, L &&launch, NetBuf *send, NetBuf *recv, NetBuf *ans, NetBuf *back) {
+        int trc;
+        // every rank derives the same capacities from the level's frontier sizes (which all ranks know): the exchanges are
+        // equal-split.  A rank routes (P - 1) / P of its candidates over P owners (its own share is probed locally).
+        const uint64_t cap_max = std::min(ch, max_n) * fan / P + 4096;
+        auto cap_of = [&](uint64_t r) {
+            uint64_t n_round = 0;
+            for (uint32_t p = 0; p < P; ++p) n_round = std::max(n_round, std::min(ch, sizes[p] > r * ch ? sizes[p] - r * ch : 0));
+            return std::min(n_round * fan * (P - 1) / ((uint64_t)P * P) + 1024, cap_max);
+        };
+        const size_t total_max = (size_t)P * (ch * fan / P + 4096);  // the largest a level of this run can ask for
+        if (stay_bytes < total_max) {
+            // Allocated once, before the first round that needs them, and agreed on: an allocation failure on one rank must not
+            // leave a peer waiting inside the rounds (nothing else in a stay round can fail on one rank alone).
+            for (int s = 0; s < 2; ++s) {
+                step([&] { return send[s].need(total_max * 8); });
+                step([&] { return recv[s].need(total_max * 8); });
+                step([&] { return ans[s].need(total_max); });
+                step([&] { return back[s].need(total_max); });
+            }
+            uint64_t mine = (uint64_t)(int64_t)lrc;
+            std::vector<uint64_t> every(P);
+            if ((trc = net.all_gather(net.user, &mine, every.data(), sizeof mine))) return trc;
+            for (uint32_t p = 0; p < P; ++p)
+                if ((int64_t)every[p] != 0) return MC_OK;  // the level ends here; run() reports it through level_info
+            stay_bytes = total_max;
+        }
+        auto answers = [&](uint64_t q) -> int {  // second half of round q: answers travel back, the sender keeps its new states
+            const uint32_t t = (uint32_t)(q & 1);
+            const uint64_t cap = cap_of(q);
+            e.wait(S_COMM, EV_PROBED + t);
+            step([&] { return e.wait_keep(t); });  // (on WORK) the slot's previous keep has read back[t] ...
+            e.record(EV_TMP, S_WORK);
+            e.wait(S_COMM, EV_TMP);                // ... before this exchange overwrites it
+            int rc = net.all_to_all(net.user, ans[t].p, back[t].p, cap);
+            if (rc) return rc;
+            st.sent_bytes += cap * (P - 1);
+            e.record(EV_ANS + t, S_COMM);
+            e.wait(S_WORK, EV_ANS + t);
+            step([&] { return e.keep_pack(t, (const uint8_t *)back[t].p, cap); });  // on the engine's second stream, behind WORK here
+            return MC_OK;
+        };
+        if (rounds) launch(0);
+        for (uint64_t r = 0; r < rounds; ++r) {
+            const uint32_t s = (uint32_t)(r & 1);
+            const uint64_t cap = cap_of(r);
+            if (r >= 2) e.wait(S_MAIN, EV_FP + s);  // the exchange of round r-2 has read send[s]
+            step([&] { return e.expand_pack(s, (uint64_t *)send[s].p, cap); });  // on MAIN, behind expand r: no host wait
+            if (lrc) e.clear_counts((uint64_t *)send[s].p, P, cap);  // a failed rank sends empty buckets
+            e.record(EV_PACKED + s, S_MAIN);
+            if (r + 1 < rounds) launch(r + 1);  // overlaps everything below
+            e.wait(S_COMM, EV_PACKED + s);
+            if (r >= 2) e.wait(S_COMM, EV_PROBED + s);  // the probes of round r-2 have read recv[s]
+            if ((trc = net.all_to_all(net.user, send[s].p, recv[s].p, cap * 8))) return trc;
+            st.sent_bytes += cap * 8 * (P - 1);
+            e.record(EV_FP + s, S_COMM);
+            if (r >= 1 && (trc = answers(r - 1))) return trc;  // issued AFTER fp(r): probes of r-1 ran while fp(r) travelled
+            e.wait(S_WORK, EV_FP + s);
+            if (r >= 2) e.wait(S_WORK, EV_ANS + s);  // the answers exchange of round r-2 has read ans[s]
+            step([&] { return e.probe_pack((const uint64_t *)recv[s].p, cap, (uint8_t *)ans[s].p); });
+            if (lrc) e.clear_bytes(ans[s].p, (size_t)P * cap, S_WORK);
+            e.record(EV_PROBED + s, S_WORK);
+        }
+        if (rounds && (trc = answers(rounds - 1))) return trc;
+        return MC_OK;
+    }
+
+    // ------------------------------------------------------------------ MOVE: host-paced rounds, new states travel to their owners
+    int exchange_counts(const uint64_t *mine, std::vector<uint64_t> &from_peers) {
+        std::vector<uint64_t> m(P * (size_t)P);
+        int rc = net.all_gather(net.user, mine, m.data(), P * sizeof(uint64_t));
+        if (rc) return rc;
+        from_peers.resize(P);
+        for (uint32_t p = 0; p < P; ++p) from_peers[p] = m[(size_t)p * P + me];
+        return MC_OK;
+    }
+    void comm_after_work() { e.record(EV_TMP, S_WORK); e.wait(S_COMM, EV_TMP); }
+    void work_after_comm() { e.record(EV_TMP + 1, S_COMM); e.wait(S_WORK, EV_TMP + 1); }
+    int a2a_v(const void *s, const std::vector<uint64_t> &sc, void *r, const std::vector<uint64_t> &rc_, uint64_t elem) {
+        std::vector<uint64_t> so(P), sb(P), ro(P), rb(P);
+        uint64_t a = 0, b = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            so[p] = a; sb[p] = sc[p] * elem; a += sb[p];
+            ro[p] = b; rb[p] = rc_[p] * elem; b += rb[p];
+            if (p != me) st.sent_bytes += sb[p];
+        }
+        comm_after_work();
+        int rc = net.all_to_all_v(net.user, s, so.data(), sb.data(), r, ro.data(), rb.data());
+        work_after_comm();
+        return rc;
+    }
+    template <class L>
+    int move_level(uint64_t rounds, uint64_t send_cap, size_t W, bool traced, L &&launch, NetBuf *send, NetBuf *recv, NetBuf *ans, NetBuf *back,
+                   NetBuf &states, NetBuf &rstates, NetBuf &parents, NetBuf &rparents) {
+        int trc;
+        std::vector<uint64_t> counts(P), rcounts, scounts(P), rsc, blocks(P), rblocks(P);
+        if (rounds) launch(0);
+        for (uint64_t r = 0; r < rounds; ++r) {
+            const uint32_t s = (uint32_t)(r & 1);
+            std::fill(counts.begin(), counts.end(), 0);
+            step([&] { return send[s].need(send_cap * 8); });
+            step([&] { return e.expand_finish(s, (uint64_t *)send[s].p, send_cap, counts.data()); });  // waits for expand r only
+            if (lrc) std::fill(counts.begin(), counts.end(), 0);
+            if (r + 1 < rounds) launch(r + 1);  // overlaps everything below
+            if ((trc = exchange_counts(counts.data(), rcounts))) return trc;
+            uint64_t n = 0, total = 0;
+            for (uint32_t p = 0; p < P; ++p) { n += rcounts[p]; total += counts[p]; }
+            step([&] { return recv[0].need(std::max<uint64_t>(n, 1) * 8); });
+            step([&] { return ans[0].need(std::max<uint64_t>(n, 1)); });
+            step([&] { return back[0].need(std::max<uint64_t>(total, 1)); });
+            if ((trc = a2a_v_safe(send[s], counts, recv[0], rcounts, 8))) return trc;
+            step([&] { return e.probe((const uint64_t *)recv[0].p, n, (uint8_t *)ans[0].p); });
+            if ((trc = a2a_v_safe(ans[0], rcounts, back[0], counts, 1))) return trc;
+            // the sender materialises its positively answered candidates, bucketed by owner, as whole 64-state blocks
+            std::fill(scounts.begin(), scounts.end(), 0);
+            const uint64_t guess = std::min<uint64_t>(total, total / 4 + 4096) + 64ull * P;
+            step([&] { return states.need(guess * W); });
+            if (!lrc) {
+                int rc = e.materialise_slot(s, (const uint8_t *)back[0].p, (uint8_t *)states.p, states.bytes / W, scounts.data());
+                if (rc == MC_EARENA) {  // more new states than guessed: size the buffer for the upper bound (every candidate new) and repeat
+                    lrc = states.need((total + 64ull * P) * W);
+                    if (!lrc) rc = e.materialise_slot(s, (const uint8_t *)back[0].p, (uint8_t *)states.p, states.bytes / W, scounts.data());
+                }
+                if (!lrc) lrc = rc;
+            }
+            if (lrc) std::fill(scounts.begin(), scounts.end(), 0);
+            if ((trc = exchange_counts(scounts.data(), rsc))) return trc;
+            uint64_t rb = 0, moved = 0, rmoved = 0;
+            for (uint32_t p = 0; p < P; ++p) {
+                blocks[p] = (scounts[p] + 63) / 64;
+                rblocks[p] = (rsc[p] + 63) / 64;
+                rb += rblocks[p];
+                moved += scounts[p];
+                rmoved += rsc[p];
+            }
+            step([&] { return rstates.need(std::max<uint64_t>(rb, 1) * 64 * W); });
+            if ((trc = a2a_v_safe(states, blocks, rstates, rblocks, 64 * W))) return trc;
+            if (traced) {  // (index on the sending rank << 16 | slot) of every moved state, same owner order, no block padding
+                step([&] { return parents.need(std::max<uint64_t>(moved, 1) * 8); });
+                step([&] { return rparents.need(std::max<uint64_t>(rmoved, 1) * 8); });
+                step([&] { return e.materialise_parents(s, (uint64_t *)parents.p); });
+                if ((trc = a2a_v_safe(parents, scounts, rparents, rsc, 8))) return trc;
+            }
+            uint64_t off = 0, poff = 0;
+            for (uint32_t src = 0; src < P; ++src) {  // one bucket per source rank
+                if (rsc[src]) {
+                    step([&] { return e.ingest((const uint8_t *)rstates.p + off * 64 * W, rsc[src]); });
+                    if (traced) step([&] { return e.ingest_parents((const uint64_t *)rparents.p + poff, rsc[src], src); });
+                }
+                off += rblocks[src];
+                poff += rsc[src];
+            }
+        }
+        return MC_OK;
+    }
+    // What a rank ANNOUNCED it sends; a rank that failed after announcing (an allocation, an engine call) still moves those
+    // sizes — out of / into scratch memory when its own buffers are missing: the peers abort at the end of the level, until
+    // then nobody may be left waiting in a collective.
+    NetBuf scratch_s, scratch_r;
+    int a2a_v_safe(NetBuf &s, const std::vector<uint64_t> &sc, NetBuf &r, const std::vector<uint64_t> &rc_, uint64_t elem) {
+        uint64_t need_s = 0, need_r = 0;
+        for (uint32_t p = 0; p < P; ++p) { need_s += sc[p] * elem; need_r += rc_[p] * elem; }
+        void *sp = s.p, *rp = r.p;
+        if (!sp || s.bytes < need_s) {
+            scratch_s.t = &net;
+            if (scratch_s.need(std::max<uint64_t>(need_s, 8))) return MC_EHIP;
+            sp = scratch_s.p;
+        }
+        if (!rp || r.bytes < need_r) {
+            scratch_r.t = &net;
+            if (scratch_r.need(std::max<uint64_t>(need_r, 8))) return MC_EHIP;
+            rp = scratch_r.p;
+        }
+        return a2a_v(sp, sc, rp, rc_, elem);
+    }
+
+    // ------------------------------------------------------------------ counterexample across ranks
+    int trace(uint8_t *states_out, int32_t *slots_out, size_t *n_inout, int32_t *final_slot) {
+        const size_t W = e.state_bytes(), cap = *n_inout;
+        *n_inout = 0;
+        if (final_slot) *final_slot = -1;
+        struct Viol { int64_t found, idx, slot, verdict, invariant, status; } mine{0, 0, 0, 0, -1, 0};
+        {
+            int32_t found = 0, v = 0, inv = -1;
+            uint64_t idx = 0;
+            uint32_t slot = 0;
+            int rc = e.violation(&found, &idx, &slot, &v, &inv);
+            mine = Viol{found, (int64_t)idx, (int64_t)slot, v, inv, rc};
+        }
+        std::vector<Viol> every(P);
+        int trc = net.all_gather(net.user, &mine, every.data(), sizeof mine);
+        if (trc) return trc;
+        int owner = -1;
+        for (uint32_t p = 0; p < P; ++p) {
+            if (every[p].status) return (int)every[p].status;
+            if (owner < 0 && every[p].found) owner = (int)p;
+        }
+        if (owner < 0) return MC_OK;
+        const Viol v = every[owner];
+        // one record per step, gathered from every rank; only the rank that holds the state fills it
+        const size_t rec = 32 + W;
+        std::vector<uint8_t> mine_rec(rec), all_rec(rec * P);
+        std::vector<std::vector<uint8_t>> st_rev;
+        std::vector<int32_t> slot_rev;
+        uint32_t cur_rank = (uint32_t)owner;
+        uint64_t cur_idx = (uint64_t)v.idx;
+        for (int guard = 0; guard < (1 << 16); ++guard) {
+            memset(mine_rec.data(), 0, rec);
+            if (cur_rank == me) {
+                uint32_t prank = 0, pslot = 0;
+                uint64_t pidx = 0;
+                int64_t rc = e.fetch(cur_idx, mine_rec.data() + 32, &prank, &pidx, &pslot);
+                int64_t hdr[4] = {rc, (int64_t)prank, (int64_t)pidx, (int64_t)pslot};
+                memcpy(mine_rec.data(), hdr, sizeof hdr);
+            }
+            if ((trc = net.all_gather(net.user, mine_rec.data(), all_rec.data(), rec))) return trc;
+            int64_t hdr[4];
+            memcpy(hdr, all_rec.data() + (size_t)cur_rank * rec, sizeof hdr);
+            if (hdr[0]) return (int)hdr[0];
+            const uint32_t pslot = (uint32_t)hdr[3];
+            if (pslot == SLOT_COPY) {  // the replicated prefix copied the state into this rank's slice: not a step
+                cur_idx = (uint64_t)hdr[2];
+                continue;
+            }
+            st_rev.emplace_back(all_rec.begin() + (long)((size_t)cur_rank * rec + 32), all_rec.begin() + (long)((size_t)cur_rank * rec + 32 + W));
+            slot_rev.push_back((int32_t)pslot);
+            if ((uint64_t)hdr[2] == NO_PARENT) break;
+            cur_rank = (uint32_t)hdr[1];
+            cur_idx = (uint64_t)hdr[2];
+        }
+        const size_t n = st_rev.size();
+        if (n > cap) { mc_set_error_internal("mc_shard_trace: trace buffer too small"); return MC_EBADCFG; }
+        for (size_t k = 0; k < n; ++k) {
+            memcpy(states_out + k * W, st_rev[n - 1 - k].data(), W);
+            slots_out[k] = k == 0 ? -1 : slot_rev[n - 1 - k];   // slot_rev[j] produced st_rev[j] from st_rev[j + 1]
+        }
+        *n_inout = n;
+        // an invariant violated by a SUCCESSOR: that state is stored nowhere, the caller rebuilds it from its parent.  (A failed
+        // Assert / an evaluation error has no successor: TLC's behaviour ends at the state the action was taken from.)
+        if (final_slot && v.verdict == MC_V_INVARIANT && (uint32_t)v.slot != SLOT_NONE && (uint32_t)v.slot != SLOT_PARENT && (uint32_t)v.slot != SLOT_INIT)
+            *final_slot = (int32_t)v.slot;
+        return MC_OK;
+    }
+};
+
+}  // namespace mc_shard
+#endif

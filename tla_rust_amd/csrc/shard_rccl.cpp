@@ -1,15 +1,10 @@
-// shard_rccl.cpp — the hip-rccl back-end behind the C ABI: the level loop of the fingerprint-sharded
-// search in C++, its collectives issued with RCCL (ncclSend / ncclRecv groups = all-to-all, ncclAllGather, ncclAllReduce over
-// xGMI) on one HIP stream per rank — the stream the engine's step kernels are ordered on (mc_shard_set_stream).  One process
-// per GPU; a host in any language creates the communicator from 128 bytes it ships between its ranks itself
-// (mc_comm_unique_id on rank 0, mc_comm_create everywhere) and calls mc_shard_run; `mc X.tla -gpus P` does exactly that with
-// forked ranks and a file (mc_main.cpp).  tla_rust_amd/sharded.py is the same loop over torch.distributed, which the CPU
-// tests drive with gloo; this file has no Python in it.
-//
-// Per level (after the replicated prefix, mc_shard_begin_replicated): ONE host synchronisation — the all-gather of the ranks'
-// frontier sizes and verdicts — then rounds of  expand -> pack -> all-to-all (fingerprints, fixed capacity, counts in band) ->
-// probe -> all-to-all (answers) -> keep,  all enqueued without waiting (include/tlamc.h mc_shard_*_pack).  States stay on the
-// rank that generated them ("stay" form); the prefix hands every rank the states of its last level it OWNS, a uniform sample.
+// shard_rccl.cpp — the hip-rccl back-end behind the C ABI: the collectives of the fingerprint-sharded
+// search issued with RCCL (ncclSend / ncclRecv groups = all-to-all, ncclAllGather over xGMI) on one HIP stream per rank, and
+// the binding of the ONE level loop (shard_loop.h) to the engine's step calls (mc_shard_* of include/tlamc.h).  One process per
+// GPU; a host in any language creates the communicator from 128 bytes it ships between its ranks itself (mc_comm_unique_id on
+// rank 0, mc_comm_create everywhere) and calls mc_shard_run; `mc X.tla -gpus P` does exactly that with forked ranks and a file
+// (mc_main.cpp), `bench.py --gpus N` with spawned ranks.  A host that owns its own collectives (torch.distributed: tla_rust_amd/
+// sharded.py) hands them over as an mc_transport and runs the same loop (mc_shard_run_transport).  No Python in this file.
 #include "tlamc.h"
 
 #include <dlfcn.h>
@@ -23,13 +18,15 @@
 #include <string>
 #include <vector>
 
-extern "C" void mc_set_error_internal(const char *msg);
+#include "shard_loop.h"
 
 struct mc_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     uint32_t rank = 0, world = 1;
     int device = 0;
+    void *d_scratch = nullptr;  // staging of the host all-gather
+    size_t scratch_bytes = 0;
 };
 
 namespace {
@@ -70,29 +67,123 @@ int fail_nccl(ncclResult_t r, const char *what) {
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_hip(e_, #x); } while (0)
 #define NCCLCK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail_nccl(r_, #x); } while (0)
 
-// equal-split all-to-all of `count` elements per peer
-int all_to_all(mc_comm *c, const void *send, void *recv, size_t count, ncclDataType_t t, size_t elem) {
+// ---- the RCCL transport (mc_transport of include/tlamc.h over one communicator)
+void *rccl_alloc(void *user, size_t bytes) {
+    mc_comm *c = (mc_comm *)user;
+    void *p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+void rccl_release(void *user, void *p) {
+    (void)user;
+    if (p) hipFree(p);  // (synchronises with the device: no kernel or collective still uses the buffer afterwards)
+}
+int rccl_all_to_all(void *user, const void *send, void *recv, uint64_t bytes) {
+    mc_comm *c = (mc_comm *)user;
     NCCLCK(R.GroupStart());
     for (uint32_t p = 0; p < c->world; ++p) {
-        NCCLCK(R.Send((const char *)send + (size_t)p * count * elem, count, t, (int)p, c->comm, c->stream));
-        NCCLCK(R.Recv((char *)recv + (size_t)p * count * elem, count, t, (int)p, c->comm, c->stream));
+        NCCLCK(R.Send((const char *)send + (size_t)p * bytes, bytes, ncclUint8, (int)p, c->comm, c->stream));
+        NCCLCK(R.Recv((char *)recv + (size_t)p * bytes, bytes, ncclUint8, (int)p, c->comm, c->stream));
     }
     NCCLCK(R.GroupEnd());
     return MC_OK;
 }
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    int need(size_t n) {
-        if (n <= bytes) return MC_OK;
-        if (p) hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        HIPCK(hipMalloc(&p, n));
-        bytes = n;
-        return MC_OK;
+int rccl_all_to_all_v(void *user, const void *send, const uint64_t *so, const uint64_t *sb, void *recv, const uint64_t *ro, const uint64_t *rb) {
+    mc_comm *c = (mc_comm *)user;
+    NCCLCK(R.GroupStart());
+    for (uint32_t p = 0; p < c->world; ++p) {  // both ends know a pair's size: an empty pair is skipped on both
+        if (sb[p]) NCCLCK(R.Send((const char *)send + so[p], sb[p], ncclUint8, (int)p, c->comm, c->stream));
+        if (rb[p]) NCCLCK(R.Recv((char *)recv + ro[p], rb[p], ncclUint8, (int)p, c->comm, c->stream));
     }
-    ~DevBuf() { if (p) hipFree(p); }
+    NCCLCK(R.GroupEnd());
+    return MC_OK;
+}
+int rccl_all_gather(void *user, const void *mine, void *all_out, uint64_t bytes) {
+    mc_comm *c = (mc_comm *)user;
+    HIPCK(hipSetDevice(c->device));
+    const size_t need = (size_t)bytes * (c->world + 1);
+    if (need > c->scratch_bytes) {
+        if (c->d_scratch) hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->scratch_bytes = 0;
+        HIPCK(hipMalloc(&c->d_scratch, need + 4096));
+        c->scratch_bytes = need + 4096;
+    }
+    char *d_mine = (char *)c->d_scratch, *d_all = d_mine + bytes;
+    HIPCK(hipMemcpyAsync(d_mine, mine, bytes, hipMemcpyHostToDevice, c->stream));
+    NCCLCK(R.AllGather(d_mine, d_all, bytes, ncclUint8, c->comm, c->stream));
+    HIPCK(hipMemcpyAsync(all_out, d_all, (size_t)bytes * c->world, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return MC_OK;
+}
+
+// ---- the engine's step calls as the loop sees them, and the three streams of a stay level
+struct AbiOps {
+    mc_engine *eng;
+    int device = 0;
+    hipStream_t comm = nullptr, work = nullptr, main_s = nullptr;
+    bool sync_comm = false;  // transport without a stream: its collectives are synchronous host calls
+    hipEvent_t ev[mc_shard::EV_COUNT] = {};
+    bool on_host[mc_shard::EV_COUNT] = {};  // recorded "on" a synchronous transport: complete when record() returns
+    uint64_t chunk = 0;
+    int32_t is_traced = 0;
+    mc_spec_desc desc;
+    size_t W = 0;
+    int init(mc_engine *e, const mc_transport *t) {
+        eng = e;
+        void *ms = nullptr;
+        int rc = mc_shard_info(e, &ms, &chunk, &is_traced);
+        if (rc) return rc;
+        main_s = (hipStream_t)ms;
+        comm = (hipStream_t)t->hip_stream;
+        sync_comm = t->hip_stream == nullptr;
+        HIPCK(hipStreamCreateWithFlags(&work, hipStreamNonBlocking));
+        for (auto &x : ev) HIPCK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        return mc_shard_set_stream(e, (void *)work, 1);
+    }
+    ~AbiOps() {
+        if (eng) mc_shard_set_stream(eng, nullptr, 0);
+        for (auto &x : ev) if (x) hipEventDestroy(x);
+        if (work) { hipStreamSynchronize(work); hipStreamDestroy(work); }
+    }
+    hipStream_t stream(int s) const { return s == mc_shard::S_COMM ? comm : s == mc_shard::S_WORK ? work : main_s; }
+    void record(int e, int s) {
+        on_host[e] = s == mc_shard::S_COMM && sync_comm;
+        if (!on_host[e]) hipEventRecord(ev[e], stream(s));
+    }
+    void wait(int s, int e) {
+        if (on_host[e]) return;
+        if (s == mc_shard::S_COMM && sync_comm) hipEventSynchronize(ev[e]);  // the host issues the collective: the host waits
+        else hipStreamWaitEvent(stream(s), ev[e], 0);
+    }
+    void clear_counts(uint64_t *buf, uint32_t P, uint64_t cap) {
+        for (uint32_t t = 0; t < P; ++t) hipMemsetAsync(buf + (uint64_t)t * cap, 0, sizeof(uint64_t), main_s);
+    }
+    void clear_bytes(void *p, size_t n, int s) { hipMemsetAsync(p, 0, n, stream(s)); }
+    uint64_t chunk_limit() const { return chunk; }
+    size_t state_bytes() const { return W; }
+    bool traced() const { return is_traced != 0; }
+    int begin() { return mc_shard_begin(eng); }
+    int begin_replicated(uint64_t mf, uint64_t md, uint64_t ml, uint64_t *lv, uint32_t *n) { return mc_shard_begin_replicated(eng, mf, md, ml, lv, n); }
+    int level_size(uint64_t *n) { return mc_shard_level_size(eng, n); }
+    int expand_launch(uint32_t slot, uint64_t first, uint64_t count, uint64_t cap) { return mc_shard_expand_launch(eng, slot, first, count, cap); }
+    int expand_finish(uint32_t slot, uint64_t *fp, uint64_t cap, uint64_t *counts) { return mc_shard_expand_finish(eng, slot, fp, cap, counts); }
+    int expand_pack(uint32_t slot, uint64_t *fp, uint64_t cap) { return mc_shard_expand_pack(eng, slot, fp, cap); }
+    int probe(const uint64_t *fp, uint64_t n, uint8_t *ans) { return mc_shard_probe(eng, fp, n, ans); }
+    int probe_pack(const uint64_t *fp, uint64_t cap, uint8_t *ans) { return mc_shard_probe_pack(eng, fp, cap, ans); }
+    int keep_pack(uint32_t slot, const uint8_t *back, uint64_t cap) { return mc_shard_keep_pack(eng, slot, back, cap); }
+    int wait_keep(uint32_t slot) { return mc_shard_wait_keep(eng, slot); }
+    int materialise_slot(uint32_t slot, const uint8_t *back, uint8_t *st, uint64_t cap, uint64_t *counts) {
+        return mc_shard_materialise_slot(eng, slot, back, st, cap, counts);
+    }
+    int materialise_parents(uint32_t slot, uint64_t *out) { return mc_shard_materialise_parents(eng, slot, out); }
+    int ingest(const uint8_t *st, uint64_t n) { return mc_shard_ingest(eng, st, n); }
+    int ingest_parents(const uint64_t *pp, uint64_t n, uint32_t src) { return mc_shard_ingest_parents(eng, pp, n, src); }
+    int end_level(uint64_t *n) { return mc_shard_end_level(eng, n); }
+    int counters(uint64_t *g, uint64_t *d, int32_t *v) { return mc_shard_counters(eng, g, d, v); }
+    int check_frontier() { return mc_shard_check_frontier(eng); }
+    int violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *v, int32_t *inv) { return mc_shard_violation(eng, found, idx, slot, v, inv); }
+    int fetch(uint64_t idx, uint8_t *st, uint32_t *pr, uint64_t *pi, uint32_t *ps) { return mc_shard_fetch(eng, idx, st, pr, pi, ps); }
 };
 }  // namespace
 
@@ -131,117 +222,69 @@ void mc_comm_destroy(mc_comm *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    if (c->d_scratch) hipFree(c->d_scratch);
     if (c->comm && R.h) R.CommDestroy(c->comm);
     delete c;
 }
 
-int mc_shard_run(mc_engine *e, mc_comm *c, const mc_shard_opts *o, mc_result *out) {
-    if (!e || !c || !o || !out) return MC_EBADCFG;
-    const uint32_t P = c->world;
-    const uint64_t chunk = o->chunk_states ? o->chunk_states : (1ull << 19);
-    const uint64_t fan = o->packed_fanout ? o->packed_fanout : 16;
-    HIPCK(hipSetDevice(c->device));
+int mc_comm_transport(mc_comm *c, mc_transport *out) {
+    if (!c || !out) return MC_EBADCFG;
     memset(out, 0, sizeof *out);
-    out->violated_invariant = -1;
-    int rc;
-    if ((rc = mc_shard_set_stream(e, (void *)c->stream, 1))) return rc;
-    struct Restore { mc_engine *e; ~Restore() { mc_shard_set_stream(e, nullptr, 0); } } restore{e};
-
-    // ---- the small levels: the same fused BFS on every rank, then each rank keeps the states it owns
-    std::vector<uint64_t> levels(MC_MAX_LEVELS);
-    uint32_t nlev = MC_MAX_LEVELS;
-    const uint64_t until = (o->replicate_until ? o->replicate_until : (1ull << 15)) * P;
-    if ((rc = mc_shard_begin_replicated(e, until, o->max_distinct, o->max_levels, levels.data(), &nlev))) return rc;
-    levels.resize(nlev);
-
-    DevBuf d_info, d_all, d_send[2], d_recv[2], d_ans[2], d_back[2];
-    if ((rc = d_info.need(2 * sizeof(uint64_t))) || (rc = d_all.need((size_t)P * 2 * sizeof(uint64_t)))) return rc;
-    std::vector<uint64_t> all(2 * (size_t)P), sizes(P);
-    // ONE collective and one host wait per level: every rank learns every rank's frontier size and verdict
-    auto level_info = [&](uint64_t local_n, int32_t verdict, uint64_t &frontier, int32_t &worst) -> int {
-        const uint64_t mine[2] = {local_n, (uint64_t)verdict};
-        HIPCK(hipMemcpyAsync(d_info.p, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-        NCCLCK(R.AllGather(d_info.p, d_all.p, 2, ncclUint64, c->comm, c->stream));
-        HIPCK(hipMemcpyAsync(all.data(), d_all.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCK(hipStreamSynchronize(c->stream));
-        frontier = 0;
-        worst = 0;
-        for (uint32_t p = 0; p < P; ++p) {
-            sizes[p] = all[2 * p];
-            frontier += sizes[p];
-            worst = std::max(worst, (int32_t)all[2 * p + 1]);
-        }
-        return MC_OK;
-    };
-    uint64_t local_n = 0, gen = 0, dl = 0, frontier = 0;
-    int32_t verdict = 0, worst = 0;
-    if ((rc = mc_shard_level_size(e, &local_n)) || (rc = mc_shard_counters(e, &gen, &dl, &verdict))) return rc;
-    if ((rc = level_info(local_n, verdict, frontier, worst))) return rc;
-    uint64_t cum = 0;
-    for (uint64_t v : levels) cum += v;
-    if (worst != 0) frontier = levels.empty() ? 0 : levels.back();
-    bool budget = false;
-
-    while (frontier > 0 && worst == 0) {
-        if ((o->max_levels && levels.size() >= o->max_levels) || (o->max_distinct && cum >= o->max_distinct)) { budget = true; break; }
-        uint64_t max_n = 0;
-        for (uint32_t p = 0; p < P; ++p) max_n = std::max(max_n, sizes[p]);
-        const uint64_t rounds = (max_n + chunk - 1) / chunk;
-        const uint64_t mine = sizes[c->rank];
-        auto launch = [&](uint64_t r) -> int {
-            const uint64_t first = std::min(r * chunk, mine), n = std::min(chunk, mine - first);
-            // a rank routes (P - 1) / P of its candidates over P owners; the capacity every rank derives is that of the level's
-            // largest chunk (the same number everywhere: the exchanges are equal-split)
-            return mc_shard_expand_launch(e, (uint32_t)(r & 1), first, n, P * (std::min(chunk, max_n) * fan / P + 4096));
-        };
-        if (rounds && (rc = launch(0))) return rc;
-        for (uint64_t r = 0; r < rounds; ++r) {
-            const uint32_t slot = (uint32_t)(r & 1);
-            uint64_t n_round = 0;
-            for (uint32_t p = 0; p < P; ++p) n_round = std::max(n_round, std::min(chunk, sizes[p] > r * chunk ? sizes[p] - r * chunk : 0));
-            const uint64_t cap = std::min(n_round * fan * (P - 1) / ((uint64_t)P * P) + 1024, std::min(chunk, max_n) * fan / P + 4096);
-            const size_t total = (size_t)P * cap;
-            if ((rc = d_send[slot].need(total * 8)) || (rc = d_recv[slot].need(total * 8)) || (rc = d_ans[slot].need(total)) ||
-                (rc = d_back[slot].need(total)))
-                return rc;
-            if ((rc = mc_shard_expand_pack(e, slot, (uint64_t *)d_send[slot].p, cap))) return rc;  // behind expand r, no host wait
-            if (r + 1 < rounds && (rc = launch(r + 1))) return rc;                                   // overlaps the exchange below
-            if ((rc = all_to_all(c, d_send[slot].p, d_recv[slot].p, cap, ncclUint64, 8))) return rc;
-            if ((rc = mc_shard_probe_pack(e, (const uint64_t *)d_recv[slot].p, cap, (uint8_t *)d_ans[slot].p))) return rc;
-            if ((rc = mc_shard_wait_keep(e, slot))) return rc;  // the slot's previous keep has read d_back[slot]
-            if ((rc = all_to_all(c, d_ans[slot].p, d_back[slot].p, cap, ncclUint8, 1))) return rc;
-            if ((rc = mc_shard_keep_pack(e, slot, (const uint8_t *)d_back[slot].p, cap))) return rc;
-        }
-        uint64_t new_local = 0;
-        if ((rc = mc_shard_end_level(e, &new_local))) return rc;  // waits for the engine's streams; device errors surface here
-        if ((rc = mc_shard_counters(e, &gen, &dl, &verdict))) return rc;
-        if ((rc = level_info(new_local, verdict, frontier, worst))) return rc;
-        if (frontier > 0) {
-            if (levels.size() >= MC_MAX_LEVELS) { mc_set_error_internal("more BFS levels than MC_MAX_LEVELS"); return MC_EBADCFG; }
-            levels.push_back(frontier);
-            cum += frontier;
-        }
-    }
-    if (frontier > 0 && worst == 0 && (rc = mc_shard_check_frontier(e))) return rc;  // a budget stop leaves a level unexpanded
-    if ((rc = mc_shard_counters(e, &gen, &dl, &verdict))) return rc;
-    {   // global counters: sum of generated, worst verdict
-        const uint64_t mine2[2] = {gen, (uint64_t)verdict};
-        HIPCK(hipMemcpyAsync(d_info.p, mine2, sizeof mine2, hipMemcpyHostToDevice, c->stream));
-        NCCLCK(R.AllGather(d_info.p, d_all.p, 2, ncclUint64, c->comm, c->stream));
-        HIPCK(hipMemcpyAsync(all.data(), d_all.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCK(hipStreamSynchronize(c->stream));
-        gen = 0;
-        worst = 0;
-        for (uint32_t p = 0; p < P; ++p) { gen += all[2 * p]; worst = std::max(worst, (int32_t)all[2 * p + 1]); }
-    }
-    out->distinct = cum;
-    out->generated = gen;
-    out->queue_left = frontier;
-    out->depth = (uint32_t)levels.size();
-    out->levels = (uint32_t)levels.size();
-    for (size_t k = 0; k < levels.size(); ++k) out->level_distinct[k] = levels[k];
-    out->verdict = worst != 0 ? worst : budget ? MC_V_BUDGET : MC_V_OK;
+    out->user = c;
+    out->rank = c->rank;
+    out->world = c->world;
+    out->hip_stream = (void *)c->stream;
+    out->alloc = rccl_alloc;
+    out->release = rccl_release;
+    out->all_to_all = rccl_all_to_all;
+    out->all_to_all_v = rccl_all_to_all_v;
+    out->all_gather = rccl_all_gather;
     return MC_OK;
+}
+
+int mc_comm_all_gather(mc_comm *c, const void *mine, void *all_out, uint64_t bytes) {
+    if (!c || !mine || !all_out || !bytes) return MC_EBADCFG;
+    return rccl_all_gather(c, mine, all_out, bytes);
+}
+
+extern "C" size_t mc_engine_state_bytes_internal(mc_engine *e);
+
+int mc_shard_run_transport(mc_engine *e, const mc_transport *t, const mc_shard_opts *o, mc_result *out) {
+    if (!e || !t || !o || !out || !t->all_to_all || !t->all_to_all_v || !t->all_gather || !t->alloc || !t->release) return MC_EBADCFG;
+    AbiOps ops;
+    ops.eng = nullptr;
+    int rc = ops.init(e, t);
+    if (rc) return rc;
+    ops.W = mc_engine_state_bytes_internal(e);
+    mc_shard::Loop<AbiOps> loop(ops, *t);
+    return loop.run(*o, out);
+}
+
+int mc_shard_trace_transport(mc_engine *e, const mc_transport *t, uint8_t *states_out, int32_t *slots_out, size_t *n_inout, int32_t *final_slot) {
+    if (!e || !t || !states_out || !slots_out || !n_inout || !t->all_gather) return MC_EBADCFG;
+    AbiOps ops;
+    ops.eng = nullptr;
+    int rc = ops.init(e, t);
+    if (rc) return rc;
+    ops.W = mc_engine_state_bytes_internal(e);
+    mc_shard::Loop<AbiOps> loop(ops, *t);
+    return loop.trace(states_out, slots_out, n_inout, final_slot);
+}
+
+int mc_shard_run(mc_engine *e, mc_comm *c, const mc_shard_opts *o, mc_result *out) {
+    mc_transport t;
+    int rc = mc_comm_transport(c, &t);
+    if (rc) return rc;
+    HIPCK(hipSetDevice(c->device));
+    return mc_shard_run_transport(e, &t, o, out);
+}
+
+int mc_shard_trace(mc_engine *e, mc_comm *c, uint8_t *states_out, int32_t *slots_out, size_t *n_inout, int32_t *final_slot) {
+    mc_transport t;
+    int rc = mc_comm_transport(c, &t);
+    if (rc) return rc;
+    HIPCK(hipSetDevice(c->device));
+    return mc_shard_trace_transport(e, &t, states_out, slots_out, n_inout, final_slot);
 }
 
 }  // extern "C"
