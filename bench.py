@@ -36,6 +36,53 @@ WORKLOAD_K11 = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 11, 1, 4, 11], golden
                     name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=11 "
                          "(specs/MCraft.cfg with MaxMsgKeys = 11), complete state graph")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+XGMI_PEAK_GBS = 7 * 153.0  # MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the environment
+    torch.distributed.run would give them), wait, and take the first failing rank's siblings down with it."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    worst = 0
+    left = set(range(a.gpus))
+    while left:
+        for r in list(left):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            left.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for q in left:   # nobody is left waiting in a collective for a rank that died
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return worst
+
+
+def comm_id(rank, world):
+    """The 128 bytes of the RCCL communicator id travel from rank 0 to the others through the launcher's TCP store
+    (torch.distributed.run hosts one at MASTER_ADDR:MASTER_PORT; for ranks spawned by bench.py itself rank 0 hosts it)."""
+    import datetime
+    import torch.distributed as dist
+    from tla_rust_amd.binding import Comm
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world_size=None if agent else world,
+                          is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    key = "tlamc/bench/comm_id"
+    if rank == 0:
+        uid = Comm.unique_id()
+        store.set(key, uid)
+    else:
+        uid = store.get(key)
+    return bytes(uid), store
 
 
 def golden():
@@ -73,7 +120,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
     ap.add_argument("--chunk", type=int, default=1 << 22)
-    ap.add_argument("--shard-chunk", type=int, default=1 << 21, help="frontier states per round and rank in the sharded (torchrun) path")
+    ap.add_argument("--shard-chunk", type=int, default=1 << 21, help="frontier states per round and rank in the sharded (--gpus N) path")
+    ap.add_argument("--packed-fanout", type=int, default=16, help="in-model successors per state the fixed-capacity exchange buckets allow for")
+    ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank on GPU 0 (needs a librccl stand-in in $TLAMC_RCCL; RCCL refuses it)")
     ap.add_argument("--table-slots", type=int, default=3 << 26, help="seen-set slots (any multiple of 64): 1.5 * 2^27 = 1.6 GB, load 0.51 at the end of the run")
     ap.add_argument("--table-log2", type=int, default=0, help="A/B: a power-of-two seen-set (27: load 0.76, 28: load 0.38)")
     ap.add_argument("--msg-keys", type=int, default=10, choices=[10, 11], help="11: the 3.4e8-state graph (165 ms/step) instead of the contract workload")
@@ -90,40 +139,50 @@ def main():
         if a.table_slots == 3 << 26:
             a.table_slots = 5 << 27   # load 0.50
 
+    launched = "RANK" in os.environ
+    if a.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(a))
+
     import torch
     import tla_rust_amd as amd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
-    import torch.distributed as dist
-    use_dist = "RANK" in os.environ  # launched by torch.distributed.run: sharded path, RCCL all-to-all
-    if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    use_dist = launched  # one rank of N (N = 1 included: the sharded engine over RCCL at world size 1)
 
     G0 = golden()
     slots = (1 << a.table_log2) if a.table_log2 else a.table_slots
+    comm = store = None
     if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=slots, matrix=a.matrix,
                          debug_flags=(32 if a.no_family else 0) | (1024 if a.direct else 0) | (2048 if a.occ3 else 0) | (32768 if a.no_dense else 0) | (8192 if a.no_filter else 0),
                          arena_capacity=G0["distinct"] + (1 << 20),
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run
+        stats = {}
     else:
-        from tla_rust_amd.sharded import ShardedChecker
-        # strong scaling: the same complete graph, its seen-set and frontier sharded over the ranks by fingerprint
-        chk = ShardedChecker(WORKLOAD["spec"], WORKLOAD["params"], device=local, max_distinct=a.max_distinct,
-                             chunk_states=a.shard_chunk, table_capacity=(slots * 4 // 3) // world // 64 * 64,
-                             # a rank's share of the states (+25 % imbalance allowance) + the replicated prefix
-                             arena_capacity=int(G0["distinct"] / world * 1.25) + (1 << 22),
-                             fanout_cap=48, new_cap=6)
-        run = chk.run
+        # strong scaling: the same complete graph, its seen-set and frontier sharded over the ranks by fingerprint; the level loop
+        # is the library's (mc_shard_run: C++, collectives issued with RCCL directly — no Python inside a step)
+        from tla_rust_amd.binding import Comm
+        uid, store = comm_id(rank, world)
+        comm = Comm(uid, rank, world, local)
+        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, shard_rank=rank, shard_count=world, trace=False,
+                         chunk_states=a.shard_chunk, max_distinct=a.max_distinct, table_capacity=(slots * 4 // 3) // world // 64 * 64,
+                         # a rank's share of the states (+25 % imbalance allowance) + the replicated prefix
+                         arena_capacity=int(G0["distinct"] / world * 1.25) + (1 << 22))
+        stats = {}
+
+        def run():
+            r, st = comm.shard_run(eng, chunk_states=a.shard_chunk, max_distinct=a.max_distinct, packed_fanout=a.packed_fanout)
+            stats.update(st)
+            return r
 
     def barrier():
         if use_dist:
-            dist.barrier()
+            comm.all_gather_u64(0)
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -136,10 +195,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max(comm.all_gather_f64(dt))                                   # MAX over ranks
+        shares = comm.all_gather_u64(stats.get("distinct_local", 0))
+        sent = comm.all_gather_u64(stats.get("sent_bytes", 0))
     if rank != 0:
+        eng.close()
+        comm.close()
         return
     D, G = res.distinct, res.generated
     if not a.max_distinct:
@@ -160,9 +221,23 @@ def main():
                              if not a.max_distinct else "A/B run with a budget: NOT the benchmark"},
     }
     if use_dist:
-        line["config"]["parallelism"] = (f"fingerprint-sharded seen-set x{world}, replicated prefix for the small levels, "
-                                         f"pipelined two-phase all-to-all over RCCL")
-        dist.destroy_process_group()
+        step_s = dt / a.steps
+        line["config"]["parallelism"] = (f"fingerprint-sharded seen-set x{world} (owner = fingerprint high bits), replicated prefix for the small "
+                                         f"levels, two-phase fingerprint-first all-to-all over RCCL (mc_shard_run: level loop in C++, exchange of "
+                                         f"round r+1 overlapped with the probes of round r and the next expand)")
+        line["config"]["shares"] = shares
+        line["config"]["levels"] = {k: stats.get(k) for k in ("replicated_levels", "stay_levels", "move_levels", "rounds")}
+        line["config"]["frontier_imbalance"] = stats.get("max_frontier", 0) / max(1, stats.get("mean_frontier", 1))
+        # xGMI roofline: bytes a rank hands to the all-to-alls for OTHER ranks per step, against 7 links x 153 GB/s
+        per_rank = max(sent) if sent else 0
+        line["xgmi"] = {"bound": "xgmi", "sent_bytes_per_step_per_gpu": per_rank, "achieved": per_rank / step_s / 1e9, "peak": XGMI_PEAK_GBS,
+                        "unit": "GB/s", "frac": per_rank / step_s / 1e9 / XGMI_PEAK_GBS,
+                        "model_bytes_per_step": G * (world - 1) / world * 9,
+                        "note": "fixed-capacity buckets are moved whole: sent bytes include the unused tail of every bucket"}
+        if a.share_gpu:
+            line["config"]["NOT_A_MEASUREMENT"] = "all ranks share ONE GPU through a librccl stand-in ($TLAMC_RCCL): a functional run of the N-rank path, not a scaling number"
+        eng.close()
+        comm.close()
     else:
         ks = eng.kernel_stats()
         W = ks["state_bytes"]

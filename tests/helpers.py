@@ -154,6 +154,21 @@ def build_shim():
     return so
 
 
+def build_fakerccl():
+    """tests/_fakerccl: the librccl stand-in that lets P ranks of the hip-rccl back-end share ONE GPU ($TLAMC_RCCL)"""
+    d = ROOT / "tests" / "_fakerccl"
+    out = d / "_build"
+    out.mkdir(exist_ok=True)
+    so = out / "libfakerccl.so"
+    src = d / "fakerccl.cpp"
+    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        tmp = out / f"libfakerccl.{os.getpid()}.so"
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(tmp), str(src),
+                        "-lpthread", "-lrt"], check=True)
+        os.replace(tmp, so)
+    return so
+
+
 _shim = None
 
 

@@ -1,6 +1,8 @@
-"""Sharded step kernels on the GPU: (a) one process, one shard (routing + compaction + probe +
-send-materialise + ingest with nranks = 1) against the fused single-GPU run; (b) two processes
-sharing GPU 0, buckets exchanged with gloo through the host, against the oracle."""
+"""The sharded path on the GPU — always the library's ONE level loop (tla_rust_amd/csrc/shard_loop.h): (a) one process, one
+shard (routing + compaction + probe + send-materialise + ingest with nranks = 1) against the fused single-GPU run; (b) 2 / 3 /
+4 / 8 processes sharing GPU 0 with torch.distributed's gloo collectives as the loop's transport, against the oracle; (c) the
+hip-rccl back-end itself (mc_comm_* / mc_shard_run / mc_shard_trace: `mc X.tla -gpus P`, `bench.py --gpus N`) with P = 2 / 4 /
+8 ranks on this one GPU through the librccl stand-in of tests/_fakerccl ($TLAMC_RCCL) — RCCL refuses two ranks on one device."""
 import pytest
 
 from test_sharded_gloo import run_dist
@@ -17,7 +19,7 @@ def test_single_shard_step_api_equals_fused_run(spec, params, opts):
     a = eng.run()
     eng.close()
     chk = ShardedChecker(spec, params, device=0, chunk_states=1 << 14, max_distinct=opts.get("max_distinct", 0), table_capacity=1 << 23,
-                         arena_capacity=1 << 21, fanout_cap=40, new_cap=16)
+                         arena_capacity=1 << 21, move_fanout=40)
     b = chk.run()
     chk.close()
     assert (a.distinct, a.generated, a.depth, a.levels, a.verdict) == (b.distinct, b.generated, b.depth, b.levels, b.verdict)
@@ -34,13 +36,13 @@ def test_two_ranks_on_one_gpu_equal_oracle(oracle, tmp_path, spec, params, opts)
     assert sum(r["shares"]) == o["distinct"]
 
 
-@pytest.mark.parametrize("packed", [True, False])
-def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path, packed):
-    """packed: mc_shard_expand_pack / _probe_pack / _keep_pack (fixed-capacity buckets, counts in band, no host wait in a round)"""
+def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path):
+    """mc_shard_expand_pack / _probe_pack / _keep_pack (fixed-capacity buckets, counts in band, no host wait in a round), three
+    streams and their events; several rounds per level (chunk 2^14)"""
     params = [3, 2, 2, 9, 1, 1]
     o = oracle.oracle_run("raft", params, max_distinct=300000)
     r = run_dist("hip", 2, "raft", params, tmp_path, {"max_distinct": 300000, "chunk": 1 << 14, "table": 1 << 22, "arena": 1 << 20,
-                                                       "stay_threshold": 200, "rebalance_ratio": 1.5, "packed": packed})
+                                                       "stay_threshold": 200, "rebalance_ratio": 1.5})
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["phases"].get("stay_levels", 0) >= 3
 
@@ -183,3 +185,97 @@ def test_mc_gpus_option(door):
         p = subprocess.run([mc, str(root / "specs" / "readme_variant" / "pcal_intro.tla"), "-gpus", "1", "-tablelog2", "20", "-arena", "100000"],
                            capture_output=True, text=True, timeout=300, cwd="/tmp")
         assert p.returncode == 12 and "Assert evaluated to FALSE" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+# ------------------------------------------------------------------------------------------ the hip-rccl back-end with P > 1
+def _fake_env():
+    import os
+    import helpers
+    return dict(os.environ, TLAMC_RCCL=str(helpers.build_fakerccl()))
+
+
+def _mc(*args, env=None, timeout=600):
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    return subprocess.run([str(root / "tla_rust_amd" / "_build" / "mc")] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout,
+                          cwd="/tmp", env=env)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_native_rccl_loop_with_several_ranks(world):
+    """`mc X.tla -gpus P -samedevice`: P forked ranks, mc_comm_create / mc_shard_run over the nccl* entry points (stand-in), the
+    C++ level loop with replicated prefix, move and stay levels: the one-GPU `mc`'s counter line — raft (3 servers, 3 M states:
+    several rounds per level), the SI model under SYMMETRY, the compiled PlusCal path, Paxos under SYMMETRY with its PROPERTY"""
+    from pathlib import Path
+    S = Path(__file__).resolve().parent.parent / "specs"
+    env = _fake_env()
+    cases = [([S / "MCraft.tla", "-config", S / "MCraft.cfg", "-maxdistinct", 3000000, "-tablelog2", 24, "-arena", 6000000, "-chunk", 65536], None),
+             ([S / "MCssi.tla", "-config", S / "MCssi_2x2_sym.cfg", "-tablelog2", 22, "-arena", 1 << 20, "-chunk", 4096],
+              "12558 states generated, 7419 distinct states found, 0 states left on queue."),
+             ([S / "pluscal" / "peterson.tla", "-tablelog2", 20, "-arena", 1 << 18], "58 distinct states found"),
+             ([S / "paxos" / "MCPaxos3.tla", "-tablelog2", 22, "-arena", 1 << 20, "-deadlock"], None)]
+    for args, want in cases:
+        q = _mc(*args, "-noprogress")
+        line = next((ln for ln in q.stdout.splitlines() if "distinct states found" in ln), None)
+        p = _mc(*args, "-gpus", world, "-samedevice", env=env)
+        assert p.returncode == q.returncode, (args, p.stdout[-1500:], p.stderr[-1500:], q.stdout[-500:], q.stderr[-500:])
+        assert line and line in p.stdout, (line, p.stdout[-800:], p.stderr[-800:])
+        assert want is None or want in p.stdout
+        assert f"({world} GPUs over RCCL" in p.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_counterexample_across_ranks(world):
+    """README.md:267-321 through `mc -gpus P`: every rank exits 12, rank 0 prints the 6-state behaviour walked back across the
+    ranks by mc_shard_trace (no Python, no one-GPU re-run); an INVARIANT broken by a successor is rebuilt from its parent"""
+    from pathlib import Path
+    S = Path(__file__).resolve().parent.parent / "specs"
+    p = _mc(S / "readme_variant" / "pcal_intro.tla", "-gpus", world, "-samedevice", "-tablelog2", 20, "-arena", 100000, env=_fake_env())
+    assert p.returncode == 12, p.stdout[-1500:] + p.stderr[-1500:]
+    assert "Assert evaluated to FALSE" in p.stdout and "Error: The behavior up to this point is:" in p.stdout
+    assert p.stdout.count("\nState ") == 6 and "State 1: <Initial predicate>" in p.stdout and "alice_account = -" in p.stdout.split("State 6:")[1]
+
+
+def test_native_loop_survives_a_failing_rank():
+    """a rank-local failure (here: an arena too small for the rank's share, MC_EARENA at the end of a level) must
+    not leave the other ranks waiting in a collective — every rank's status travels with the per-level all-gather, all leave
+    together, `mc -gpus P` exits 1 (and would SIGTERM the siblings of a rank that died)"""
+    from pathlib import Path
+    S = Path(__file__).resolve().parent.parent / "specs"
+    p = _mc(S / "MCraft.tla", "-config", S / "MCraft.cfg", "-gpus", 2, "-samedevice", "-maxdistinct", 3000000, "-tablelog2", 24, "-arena", 700000,
+            "-chunk", 65536, env=_fake_env(), timeout=300)
+    assert p.returncode == 1 and ("arena" in p.stderr.lower() or "failed" in p.stderr.lower()), p.stdout[-800:] + p.stderr[-1500:]
+
+
+def test_native_default_chunk_beyond_one_launch():
+    """`mc X.tla -gpus P` WITHOUT -chunk on a model whose per-rank frontier exceeds the engine's default chunk
+    (2^18 states): the loop clamps its rounds to what one launch of the engine takes"""
+    from pathlib import Path
+    S = Path(__file__).resolve().parent.parent / "specs"
+    args = [S / "MCraft.tla", "-config", S / "MCraft.cfg", "-maxdistinct", 12000000, "-tablelog2", 26, "-arena", 30000000]
+    q = _mc(*args, "-noprogress")
+    p = _mc(*args, "-gpus", 2, "-samedevice", env=_fake_env())
+    line = next(ln for ln in q.stdout.splitlines() if "distinct states found" in ln)
+    assert p.returncode == 0 and line in p.stdout, (line, p.stdout[-800:], p.stderr[-1500:])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_contract_invocation_with_several_ranks(world):
+    """`python bench.py --gpus N` — the contract invocation, no launcher: bench.py spawns its N ranks, the ranks build the RCCL
+    communicator (id through a TCP store), run mc_shard_run on the COMPLETE bench graph and rank 0 prints the line.  Here the
+    ranks share this one GPU (--share-gpu + stand-in): a functional run, the line says so.  P = 8: the frontier stays balanced."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--share-gpu"],
+                       capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=str(root))
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    line = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
+    c = line["config"]
+    assert line["n_gpus"] == world and (c["distinct"], c["generated"], c["depth"], c["verdict"]) == (102586254, 1217433925, 33, "ok")
+    assert len(c["shares"]) == world and sum(c["shares"]) == 102586254 and c["levels"]["stay_levels"] >= 10
+    assert c["frontier_imbalance"] <= 1.25 and max(c["shares"]) <= 1.25 * 102586254 / world
+    assert "xgmi" in line and line["xgmi"]["sent_bytes_per_step_per_gpu"] > 0

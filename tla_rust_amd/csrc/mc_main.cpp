@@ -4,7 +4,7 @@
 //
 //   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic] [-dump FILE]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
-//            [-checkpoint FILE] [-recover FILE] [-gpus P] [-noprogress]
+//            [-checkpoint FILE] [-recover FILE] [-gpus P [-samedevice | -torch]] [-noprogress]
 //   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
 //                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
 //                                         the previous text is kept as X.old
@@ -19,7 +19,10 @@
 //             error; continue such a run later, with the same X.tla / X.cfg.
 // -gpus P   : the search sharded over P GPUs of this node, one process per GPU, collectives over RCCL (include/tlamc.h
 //             mc_comm_* / mc_shard_run): mc starts P copies of itself (rank r on device r; rank 0 writes the communicator id to
-//             a temporary file the others read) and rank 0 prints TLC's counter / depth lines; exit status as below.
+//             a temporary file the others read) and rank 0 prints TLC's counter / depth lines and, on an error, the behaviour that
+//             leads to it — walked back across the ranks' arenas (mc_shard_trace); exit status as below.  A rank that fails takes
+//             the others down with it (no rank is left waiting in a collective).  -samedevice: every rank on device D (a one-GPU
+//             box: only with a librccl stand-in named by $TLAMC_RCCL — RCCL itself refuses two ranks on one device).
 // -gpus P -torch: the same search driven by tla_rust_amd/mc_multi.py over torch.distributed instead — mc replaces itself by
 //             `python3 -m torch.distributed.run --nproc-per-node P -m tla_rust_amd.mc_multi X.tla <the other options>`; that front
 //             door also rebalances drifting ranks by moving states and prints a counterexample walked back across the ranks
@@ -28,6 +31,7 @@
 // GPU is the worker pool).  Exit status: 0 no error, 12 safety violation (invariant / assert),
 // 11 deadlock, 1 any other failure — TLC's convention.
 #include <limits.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -80,7 +84,7 @@ static int exec_multi(int gpus, int argc, char **argv) {
                                   "--master-addr", "127.0.0.1", "--master-port", port && *port ? port : "29517", "-m", "tla_rust_amd.mc_multi"};
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "-gpus")) { ++i; continue; }
-        if (!strcmp(argv[i], "-torch")) continue;
+        if (!strcmp(argv[i], "-torch") || !strcmp(argv[i], "-samedevice")) continue;
         if (!strcmp(argv[i], "-deadlock") || !strcmp(argv[i], "-dump") || !strcmp(argv[i], "-checkpoint") || !strcmp(argv[i], "-recover")) {
             fprintf(stderr, "mc: %s is not available with -gpus\n", argv[i]);
             return 1;
@@ -121,11 +125,19 @@ static int spawn_ranks(int gpus, char **argv) {
         pids.push_back(p);
     }
     int worst = 0;
-    for (pid_t p : pids) {
+    size_t left = pids.size();
+    while (left) {
         int st = 0;
-        waitpid(p, &st, 0);
+        const pid_t p = waitpid(-1, &st, 0);
+        if (p < 0) break;
+        bool ours = false;
+        for (pid_t &q : pids) if (q == p) { q = -1; ours = true; }
+        if (!ours) continue;
+        --left;
         const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
         if (code == 1 || (code > worst && worst != 1)) worst = code;  // 1 (a failure) dominates 11 / 12 (TLC's verdict codes)
+        if (code != 0 && code != 11 && code != 12)  // a rank FAILED (a verdict is no failure): the others may be waiting for it in a
+            for (pid_t q : pids) if (q > 0) kill(q, SIGTERM);  // collective that will never complete
     }
     unlink(idfile);
     return worst;
@@ -154,10 +166,10 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
             usleep(20000);
         }
     }
-    cfg.device += rank;  // rank r on device (-device D) + r
+    if (!getenv("MC_SAMEDEVICE")) cfg.device += rank;  // rank r on device (-device D) + r
     cfg.shard_rank = (uint32_t)rank;
     cfg.shard_count = (uint32_t)world;
-    cfg.flags &= ~(MC_F_TRACE | MC_F_PROGRESS);
+    cfg.flags &= ~MC_F_PROGRESS;  // (MC_F_TRACE stays: a counterexample is walked back across the ranks)
     mc_comm *comm = nullptr;
     if ((rc = mc_comm_create(id, (uint32_t)rank, (uint32_t)world, cfg.device, &comm))) { fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error()); return 1; }
     mc_engine *eng = nullptr;
@@ -172,6 +184,19 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
     rc = mc_shard_run(eng, comm, &so, &res);
     const double dt = now_s() - t0;
     if (rc) fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error());
+    // the behaviour that leads to an error: walked back parent by parent across the ranks (collective: every rank takes part)
+    const size_t W = mc_state_bytes(&desc);
+    std::vector<uint8_t> tr_states;
+    std::vector<int32_t> tr_slots;
+    size_t tr_n = 0;
+    int32_t tr_final = -1;
+    if (!rc && res.verdict != MC_V_OK && res.verdict != MC_V_BUDGET && (cfg.flags & MC_F_TRACE)) {
+        tr_n = 4096;
+        tr_states.resize(tr_n * W);
+        tr_slots.resize(tr_n);
+        const int trc = mc_shard_trace(eng, comm, tr_states.data(), tr_slots.data(), &tr_n, &tr_final);
+        if (trc) { fprintf(stderr, "mc[%d]: counterexample: %s: %s\n", rank, mc_strerror(trc), mc_last_error()); tr_n = 0; }
+    }
     if (!rc && rank == 0) {  // TLC's closing lines (README.md:319-320, testout2:260-266), as tla_rust_amd/mc_multi.py prints them
         const unsigned long long n0 = res.levels ? (unsigned long long)res.level_distinct[0] : 0ull;
         printf("Finished computing initial states: %llu distinct state%s generated.\n", n0, n0 == 1 ? "" : "s");
@@ -180,7 +205,22 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
         else {
             printf("%s\n", res.verdict == MC_V_INVARIANT ? "Error: Invariant is violated." : res.verdict == MC_V_ASSERT ? "Error: The first argument of Assert evaluated to FALSE."
                           : res.verdict == MC_V_DEADLOCK ? "Error: Deadlock reached." : "Error: TLC would raise an evaluation error.");
-            printf("(the behavior up to this point: `mc X.tla -gpus P -torch` walks it back across the GPUs, `mc X.tla` rebuilds it on one)\n");
+            if (tr_n) {  // README.md:270-311: "State k: <Action>" + the variables
+                printf("Error: The behavior up to this point is:\n");
+                std::vector<char> text(1 << 16);
+                std::vector<uint8_t> succ(W);
+                auto print_state = [&](size_t k, const uint8_t *prev, int32_t slot, const uint8_t *st) {
+                    const char *name = "Initial predicate";
+                    if (prev) { const int a = mc_state_action(&desc, prev, slot); name = a >= 0 ? mc_action_name(&desc, a) : "?"; }
+                    const int n = mc_state_format(&desc, st, text.data(), text.size());
+                    printf("State %zu: <%s>\n%.*s\n", k + 1, name, n > 0 ? n : 0, text.data());
+                };
+                for (size_t k = 0; k < tr_n; k++) print_state(k, k ? &tr_states[(k - 1) * W] : nullptr, tr_slots[k], &tr_states[k * W]);
+                if (tr_final >= 0 && mc_state_apply(&desc, &tr_states[(tr_n - 1) * W], tr_final, succ.data()) == 0)
+                    print_state(tr_n, &tr_states[(tr_n - 1) * W], tr_final, succ.data());
+            } else {
+                printf("(no behavior: the engines keep no parent pointers)\n");
+            }
         }
         printf("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)res.generated,
                (unsigned long long)res.distinct, (unsigned long long)res.queue_left);
@@ -205,6 +245,7 @@ int main(int argc, char **argv) {
             if (gpus < 1 || gpus > 64) { fprintf(stderr, "mc: -gpus needs a number of GPUs\n"); return 1; }
         }
         if (!strcmp(argv[i], "-torch")) torch_door = true;
+        if (!strcmp(argv[i], "-samedevice")) setenv("MC_SAMEDEVICE", "1", 1);
     }
     if (gpus && torch_door) return exec_multi(gpus, argc, argv);
     const char *env_rank = getenv("MC_RANK");
@@ -232,7 +273,7 @@ int main(int argc, char **argv) {
         else if (arg("-recover")) recover = argv[++i];
         else if (arg("-workers")) ++i;
         else if (arg("-gpus")) ++i;
-        else if (!strcmp(argv[i], "-torch")) {}
+        else if (!strcmp(argv[i], "-torch") || !strcmp(argv[i], "-samedevice")) {}
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
         else if (!strcmp(argv[i], "-unverified")) cfg.flags |= MC_F_UNVERIFIED;
         else if (!strcmp(argv[i], "-noprogress")) cfg.flags &= ~MC_F_PROGRESS;
