@@ -90,26 +90,35 @@ def golden():
     return next(c for c in g["cases"] if c["name"] == WORKLOAD["golden"])
 
 
-def cpu_baseline(max_seconds=15.0):
+def cpu_baseline(max_seconds=10.0):
     """The exact-dedup CPU oracle ("port"; in-house CPU BFS, NOT TLC: the box has no JVM) on ALL host cores
     (TLC's run-book: "Number of worker threads: Use the number of cpu cores",
-    examples/serializableSnapshotIsolation.tla:52-53): same model, BFS levels until `max_seconds` have passed."""
+    examples/serializableSnapshotIsolation.tla:52-53): same model, BFS levels until `max_seconds` have passed; plus short
+    samples at 1 / 8 / 64 threads, so that the line shows how the baseline itself scales (oracle/bfs_mt.c: per-thread arenas,
+    one lock-free CAS table, exact comparison of the state bytes)."""
     exe = ROOT / "oracle" / "_build" / "oracle_mc"
     if not exe.exists():
         subprocess.run(["make", "-s", "-C", str(ROOT / "oracle")], check=True)
     cores = os.cpu_count() or 1
     p = [str(x) for x in WORKLOAD["params"][:6]] + ["0", str(WORKLOAD["params"][9])]
-    out = subprocess.run([str(exe), "raft", *p, "--threads", str(cores), "--max-seconds", str(max_seconds), "--distinct", "60000000"],
-                         capture_output=True, text=True, check=True).stdout
-    r = json.loads(out.splitlines()[0])
+
+    def sample(threads, seconds):
+        out = subprocess.run([str(exe), "raft", *p, "--threads", str(threads), "--max-seconds", str(seconds), "--distinct", "200000000"],
+                             capture_output=True, text=True, check=True).stdout
+        return json.loads(out.splitlines()[0])
+
+    r = sample(cores, max_seconds)
+    table = [dict(threads=t, value=(q := sample(t, 3.0))["distinct"] / q["seconds"], levels=q["depth"]) for t in (1, 8, 64) if t < cores]
+    table.append(dict(threads=cores, value=r["distinct"] / r["seconds"], levels=r["depth"]))
     # SURVEY.md 8d: stock TLC on the same box would be the preferred baseline — probe for it every time and say what was found
     import shutil
     java = shutil.which("java")
     jar = next((str(q) for d in ("/usr/share/java", "/opt", str(Path.home())) if Path(d).is_dir() for q in Path(d).glob("**/tla2tools.jar")), None) if java else None
     tlc = f"java at {java}, tla2tools.jar {'at ' + jar if jar else 'not found'}" if java else "no java on PATH"
-    return dict(tlc_probe=tlc, value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=cores, kind="port",
+    return dict(tlc_probe=tlc, value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=cores, kind="port", scaling=table,
                 sample=f"not TLC (no JVM on the box): in-house exact-dedup multi-threaded C BFS, {cores} threads, same cfg, "
-                       f"levels 1-{r['depth']} = {r['distinct']} distinct / {r['generated']} generated states in {r['seconds']:.1f} s")
+                       f"levels 1-{r['depth']} = {r['distinct']} distinct / {r['generated']} generated states in {r['seconds']:.1f} s "
+                       f"(a sample stops after the level that exceeds its time; deeper levels have more duplicates per distinct state)")
 
 
 def main():

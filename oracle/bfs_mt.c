@@ -5,8 +5,8 @@
  * Same observable contract as oracle/bfs.c (which restates TLC's BFS: README.md:267-321,
  * testout2:1-266, p-manual §4): level-synchronous breadth-first search, CONSTRAINT filter, invariant /
  * Assert / deadlock checks, the three counters, the depth, per-level distinct counts.  Dedup is EXACT:
- * the seen-set stores whole canonical state byte strings, sharded by hash over NSHARD independently
- * locked stores; a count produced here cannot be off by a hash collision.  The reference prescribes
+ * the seen-set refers to whole canonical state byte strings and compares them (the 64-bit table entries carry a 19-bit
+ * tag only to skip most comparisons); a count produced here cannot be off by a hash collision.  The reference prescribes
  * TLC with "Number of worker threads: Use the number of cpu cores"
  * (examples/serializableSnapshotIsolation.tla:52-53); this is the stand-in where no JVM exists.
  *
@@ -22,39 +22,61 @@
 #include <string.h>
 #include <time.h>
 
-#define MT_SHARD_BITS 12
-#define MT_NSHARD (1u << MT_SHARD_BITS)
+/*
+ * Data structures (round 3: the round-2 form — 4096 hash shards, one mutex per shard taken on EVERY insert, arenas grown by
+ * realloc, i.e. mremap under the process-wide mmap lock — scaled 4.3x on 256 threads; it measured its locks, not the search):
+ *
+ *   - one append-only ARENA per worker thread, a fixed virtual reservation (MAP_NORESERVE) that never moves: a state is
+ *     written once by its discoverer (2-byte length + bytes), first touched by that thread (NUMA-local), and read by anyone
+ *     afterwards without a lock — the frontier of a level IS the tail ranges of the arenas;
+ *   - ONE lock-free open-addressing table of 64-bit entries  tag[19] | thread[9] | offset[36]  claimed with a CAS; a probe
+ *     compares the tag and only then the bytes (exact dedup: a count produced here cannot be off by a hash collision).  An
+ *     inserter appends its candidate to its own arena first and publishes it with the CAS; if it loses the slot to an equal
+ *     state it takes the append back (nobody has seen it);
+ *   - the table is resized only BETWEEN levels (every thread rehashes a slice), so that no reader ever meets a moving table;
+ *   - work of a level: the arenas' frontier ranges cut into blocks of MT_BLOCK states, handed out by one atomic counter.
+ */
+#include <sys/mman.h>
 
-typedef struct {
-    pthread_mutex_t mu;
-    uint8_t *arena;
-    uint64_t arena_len, arena_cap;
-    uint64_t *off;        /* n+1 offsets */
-    uint32_t n, ncap;
-    uint32_t *tab;        /* open addressing over state indices + 1 */
-    uint32_t tab_cap;     /* power of two */
-    uint32_t lvl_lo, lvl_hi; /* frontier of the level being expanded */
-} shard_t;
+#define MT_MAX_THREADS 512
+#define MT_BLOCK 64u
+#define MT_OFF_BITS 36
+#define MT_TID_BITS 9
+#define MT_TAG_SHIFT (MT_OFF_BITS + MT_TID_BITS)
+#define MT_ARENA_BYTES (1ull << MT_OFF_BITS)  /* virtual reservation per thread (64 GiB); touched pages only cost memory */
 
 typedef struct mt_bfs mt_bfs;
 typedef struct {
     mt_bfs *b;
+    int tid;
+    uint8_t *arena;           /* MT_ARENA_BYTES reserved */
+    uint64_t len;             /* bytes used (starts at 8: offset 0 is "no entry") */
+    uint64_t lvl_lo, lvl_hi;  /* byte range of the states this thread found on the level being expanded */
+    uint64_t *blk;            /* offsets of every MT_BLOCK-th state found on the level being filled (frontier blocks of the next) */
+    uint64_t nblk, blk_cap, nnew;
+    uint64_t *fblk;           /* ... of the level being expanded */
+    uint64_t nfblk, fblk_cap;
     uint64_t generated, distinct, nsucc;
     uint64_t max_stat[8];
-    int verdict, inv;     /* first violation seen by this thread on the current level (verdict 0 = none) */
-    uint8_t *copy;        /* private copy of one shard's frontier slice */
-    uint64_t copy_cap;
-    uint64_t *copy_off;
-    uint32_t copy_off_cap;
+    int verdict, inv;         /* first violation seen by this thread on the current level (verdict 0 = none) */
 } worker_t;
 
 struct mt_bfs {
     const or_spec *spec;
     const or_options *opt;
-    shard_t *sh;
-    atomic_uint next_shard;
+    _Atomic uint64_t *tab;
+    uint64_t tab_cap;         /* power of two */
+    _Atomic uint64_t used;    /* entries (approximate while a level runs: per-thread counts are folded in at level ends) */
+    atomic_uint_fast64_t next_block;
+    uint64_t nblocks;
+    uint64_t *blk_base;       /* prefix sums of the threads' frontier block counts */
     int nthreads;
     worker_t *w;
+    /* rehash */
+    _Atomic uint64_t *old_tab;
+    uint64_t old_cap;
+    atomic_uint_fast64_t rehash_next;
+    atomic_int table_full;
 };
 
 static uint64_t mt_hash(const uint8_t *p, size_t n) {
@@ -75,55 +97,61 @@ static uint64_t mt_hash(const uint8_t *p, size_t n) {
 
 static void oom(const char *what) { fprintf(stderr, "oracle(mt): out of memory (%s)\n", what); abort(); }
 
-/* caller holds the shard's lock */
-static void shard_grow_table(shard_t *s) {
-    uint32_t ncap = s->tab_cap ? s->tab_cap * 2 : 64;
-    uint32_t *nt = calloc(ncap, sizeof *nt);
-    if (!nt) oom("table");
-    for (uint32_t i = 0; i < s->n; i++) {
-        /* the low bits of the hash index the table, the high bits chose the shard */
-        uint64_t h = mt_hash(s->arena + s->off[i], s->off[i + 1] - s->off[i]) & (ncap - 1);
-        while (nt[h]) h = (h + 1) & (ncap - 1);
-        nt[h] = i + 1;
-    }
-    free(s->tab);
-    s->tab = nt;
-    s->tab_cap = ncap;
+static void *mt_reserve(uint64_t bytes, int populate_hint) {
+    void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) return NULL;
+    if (populate_hint) madvise(p, bytes, MADV_HUGEPAGE);
+    return p;
 }
 
-/* 1 = new (appended), 0 = already present */
-static int shard_insert(shard_t *s, uint64_t hash, const uint8_t *st, size_t len) {
-    int is_new = 0;
-    pthread_mutex_lock(&s->mu);
-    if ((uint64_t)(s->n + 1) * 2 > s->tab_cap) shard_grow_table(s);
-    uint64_t mask = s->tab_cap - 1, h = hash & mask;
-    for (;;) {
-        uint32_t e = s->tab[h];
-        if (!e) break;
-        uint64_t o = s->off[e - 1];
-        if (s->off[e] - o == len && memcmp(s->arena + o, st, len) == 0) goto out;
+static inline const uint8_t *mt_state_at(const mt_bfs *b, uint64_t entry, size_t *len) {
+    const worker_t *o = &b->w[(entry >> MT_OFF_BITS) & ((1u << MT_TID_BITS) - 1)];
+    const uint8_t *p = o->arena + (entry & ((1ull << MT_OFF_BITS) - 1));
+    uint16_t l;
+    memcpy(&l, p, 2);
+    *len = l;
+    return p + 2;
+}
+
+/* 1 = new (this thread's arena now holds it), 0 = already present */
+static int mt_insert(worker_t *w, uint64_t hash, const uint8_t *st, size_t len) {
+    mt_bfs *b = w->b;
+    const uint64_t mask = b->tab_cap - 1, tag = (hash >> (64 - 19)) << MT_TAG_SHIFT;
+    uint64_t h = hash & mask, mine = 0;
+    for (uint64_t probes = 0;; probes++) {
+        uint64_t e = atomic_load_explicit(&b->tab[h], memory_order_acquire);
+        if (e == 0) {
+            if (!mine) {  /* append the candidate to this thread's arena (not yet visible to anyone) */
+                if (w->len + 2 + len > MT_ARENA_BYTES) oom("a thread's arena reservation");
+                uint16_t l16 = (uint16_t)len;
+                memcpy(w->arena + w->len, &l16, 2);
+                memcpy(w->arena + w->len + 2, st, len);
+                mine = tag | ((uint64_t)w->tid << MT_OFF_BITS) | w->len;
+            }
+            uint64_t expect = 0;
+            if (atomic_compare_exchange_strong_explicit(&b->tab[h], &expect, mine, memory_order_acq_rel, memory_order_acquire)) {
+                if ((w->nnew % MT_BLOCK) == 0) {
+                    if (w->nblk == w->blk_cap) {
+                        w->blk_cap = w->blk_cap ? w->blk_cap * 2 : 1024;
+                        w->blk = realloc(w->blk, w->blk_cap * sizeof *w->blk);
+                        if (!w->blk) oom("block index");
+                    }
+                    w->blk[w->nblk++] = w->len;
+                }
+                w->nnew++;
+                w->len += 2 + len;
+                return 1;
+            }
+            e = expect;  /* somebody took the slot: is it the same state? */
+        }
+        if ((e >> MT_TAG_SHIFT) == (tag >> MT_TAG_SHIFT)) {
+            size_t ol;
+            const uint8_t *os = mt_state_at(b, e, &ol);
+            if (ol == len && memcmp(os, st, len) == 0) return 0;  /* (a tentative append is simply overwritten by the next one) */
+        }
         h = (h + 1) & mask;
+        if (probes > mask) { atomic_store(&b->table_full, 1); return 0; }
     }
-    if (s->n + 2 > s->ncap) {
-        s->ncap = s->ncap ? s->ncap * 2 : 32;
-        s->off = realloc(s->off, ((size_t)s->ncap + 1) * sizeof *s->off);
-        if (!s->off) oom("offsets");
-        if (s->n == 0) s->off[0] = 0;
-    }
-    if (s->arena_len + len > s->arena_cap) {
-        while (s->arena_len + len > s->arena_cap) s->arena_cap = s->arena_cap ? s->arena_cap + s->arena_cap / 2 : 4096;
-        s->arena = realloc(s->arena, s->arena_cap);
-        if (!s->arena) oom("arena");
-    }
-    memcpy(s->arena + s->arena_len, st, len);
-    s->arena_len += len;
-    s->off[s->n + 1] = s->arena_len;
-    s->tab[h] = s->n + 1;
-    s->n++;
-    is_new = 1;
-out:
-    pthread_mutex_unlock(&s->mu);
-    return is_new;
 }
 
 static void mt_note(worker_t *w, int verdict, int inv) {
@@ -143,8 +171,7 @@ static void mt_emit(or_emit *em, const uint8_t *s, size_t len, int action, unsig
     int inmodel = sp->constraint ? sp->constraint(sp->ctx, s, len) : 1;
     int is_new = 0;
     if (inmodel) {
-        uint64_t h = mt_hash(s, len);
-        is_new = shard_insert(&w->b->sh[h >> (64 - MT_SHARD_BITS)], h, s, len);
+        is_new = mt_insert(w, mt_hash(s, len), s, len);
         if (is_new) {
             w->distinct++;
             if (sp->stats) sp->stats(sp->ctx, s, len, w->max_stat);
@@ -156,29 +183,53 @@ static void mt_emit(or_emit *em, const uint8_t *s, size_t len, int action, unsig
     }
 }
 
+/* one level: blocks of MT_BLOCK frontier states, whoever found them */
 static void *mt_level_worker(void *arg) {
     worker_t *w = arg;
     mt_bfs *b = w->b;
     const or_spec *sp = b->spec;
     or_emit em = {w, mt_emit};
     for (;;) {
-        unsigned si = atomic_fetch_add(&b->next_shard, 1u);
-        if (si >= MT_NSHARD) break;
-        shard_t *s = &b->sh[si];
-        if (s->lvl_hi == s->lvl_lo) continue;
-        /* private copy of the shard's frontier slice: other threads append to (and may reallocate) the shard meanwhile */
-        pthread_mutex_lock(&s->mu);
-        uint32_t cnt = s->lvl_hi - s->lvl_lo;
-        uint64_t o0 = s->off[s->lvl_lo], bytes = s->off[s->lvl_hi] - o0;
-        if (bytes > w->copy_cap) { w->copy_cap = bytes * 2; free(w->copy); w->copy = malloc(w->copy_cap); if (!w->copy) oom("copy"); }
-        if (cnt + 1 > w->copy_off_cap) { w->copy_off_cap = (cnt + 1) * 2; free(w->copy_off); w->copy_off = malloc(w->copy_off_cap * sizeof *w->copy_off); if (!w->copy_off) oom("copy"); }
-        memcpy(w->copy, s->arena + o0, bytes);
-        for (uint32_t k = 0; k <= cnt; k++) w->copy_off[k] = s->off[s->lvl_lo + k] - o0;
-        pthread_mutex_unlock(&s->mu);
-        for (uint32_t k = 0; k < cnt; k++) {
+        const uint64_t g = atomic_fetch_add(&b->next_block, 1);
+        if (g >= b->nblocks || atomic_load(&b->table_full)) break;
+        int t = 0;
+        while (g >= b->blk_base[t + 1]) t++;  /* owner of block g */
+        const worker_t *o = &b->w[t];
+        const uint64_t k = g - b->blk_base[t];
+        uint64_t off = o->fblk[k];
+        const uint64_t end = k + 1 < o->nfblk ? o->fblk[k + 1] : o->lvl_hi;
+        while (off < end) {
+            uint16_t l;
+            memcpy(&l, o->arena + off, 2);
             w->nsucc = 0;
-            sp->succ(sp->ctx, w->copy + w->copy_off[k], w->copy_off[k + 1] - w->copy_off[k], &em);
+            sp->succ(sp->ctx, o->arena + off + 2, l, &em);
             if (w->nsucc == 0 && b->opt->check_deadlock) mt_note(w, OR_DEADLOCK, -1);
+            off += 2 + (uint64_t)l;
+        }
+    }
+    return NULL;
+}
+
+/* between levels: every thread moves a slice of the old table into the new one */
+static void *mt_rehash_worker(void *arg) {
+    worker_t *w = arg;
+    mt_bfs *b = w->b;
+    const uint64_t slice = 1u << 16, mask = b->tab_cap - 1;
+    for (;;) {
+        const uint64_t lo = atomic_fetch_add(&b->rehash_next, slice);
+        if (lo >= b->old_cap) break;
+        const uint64_t hi = lo + slice < b->old_cap ? lo + slice : b->old_cap;
+        for (uint64_t i = lo; i < hi; i++) {
+            const uint64_t e = atomic_load_explicit(&b->old_tab[i], memory_order_relaxed);
+            if (!e) continue;
+            size_t len;
+            const uint8_t *st = mt_state_at(b, e, &len);
+            uint64_t h = mt_hash(st, len) & mask;
+            for (;;) {
+                uint64_t expect = 0;
+                if (atomic_compare_exchange_strong_explicit(&b->tab[h], &expect, e, memory_order_acq_rel, memory_order_relaxed)) break;
+                h = (h + 1) & mask;
+            }
         }
     }
     return NULL;
@@ -190,10 +241,17 @@ static double mt_now(void) {
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+static void mt_run_threads(mt_bfs *b, pthread_t *th, void *(*fn)(void *)) {
+    for (int t = 0; t < b->nthreads; t++) pthread_create(&th[t], NULL, fn, &b->w[t]);
+    for (int t = 0; t < b->nthreads; t++) pthread_join(th[t], NULL);
+}
+
 int or_run_bfs_mt(const or_spec *sp, const or_options *opt, int nthreads, double max_seconds, or_result *r) {
     if (nthreads < 1) nthreads = 1;
+    if (nthreads > MT_MAX_THREADS) nthreads = MT_MAX_THREADS;
     if (sp->canon) { or_set_error("the multi-threaded oracle does not implement first-met SYMMETRY representatives"); return -1; }
     if (opt->stop_on_violation == 2 || opt->dump_path) { or_set_error("the multi-threaded oracle has no stop-at-once mode and no dump"); return -1; }
+    if (sp->max_state_bytes > 65535) { or_set_error("the multi-threaded oracle stores state lengths in 16 bits"); return -1; }
     mt_bfs b;
     memset(&b, 0, sizeof b);
     memset(r, 0, sizeof *r);
@@ -201,11 +259,19 @@ int or_run_bfs_mt(const or_spec *sp, const or_options *opt, int nthreads, double
     b.spec = sp;
     b.opt = opt;
     b.nthreads = nthreads;
-    b.sh = calloc(MT_NSHARD, sizeof *b.sh);
     b.w = calloc((size_t)nthreads, sizeof *b.w);
-    if (!b.sh || !b.w) oom("setup");
-    for (unsigned i = 0; i < MT_NSHARD; i++) pthread_mutex_init(&b.sh[i].mu, NULL);
-    for (int t = 0; t < nthreads; t++) b.w[t].b = &b;
+    b.blk_base = calloc((size_t)nthreads + 1, sizeof *b.blk_base);
+    if (!b.w || !b.blk_base) oom("setup");
+    for (int t = 0; t < nthreads; t++) {
+        b.w[t].b = &b;
+        b.w[t].tid = t;
+        b.w[t].arena = mt_reserve(MT_ARENA_BYTES, 1);
+        if (!b.w[t].arena) { or_set_error("cannot reserve %d thread arenas of %llu GiB of address space", nthreads, (unsigned long long)(MT_ARENA_BYTES >> 30)); return -1; }
+        b.w[t].len = b.w[t].lvl_lo = b.w[t].lvl_hi = 8;
+    }
+    b.tab_cap = 1ull << 22;
+    b.tab = mt_reserve(b.tab_cap * sizeof(uint64_t), 1);
+    if (!b.tab) oom("table");
     pthread_t *th = calloc((size_t)nthreads, sizeof *th);
     double t0 = mt_now();
 
@@ -219,10 +285,10 @@ int or_run_bfs_mt(const or_spec *sp, const or_options *opt, int nthreads, double
     }
     free(tmp);
     uint32_t level = 1;
-    int budget = 0, have_violation = 0;
-    uint64_t frontier = 0;
+    int budget = 0, have_violation = 0, rc = 0;
+    uint64_t frontier = 0, grow = 4;
     for (;;) {
-        /* close the level: gather the workers' counters, advance every shard's frontier */
+        /* close the level: gather the workers' counters, turn what every thread found into its frontier */
         uint64_t newd = 0;
         for (int t = 0; t < nthreads; t++) {
             worker_t *w = &b.w[t];
@@ -236,14 +302,20 @@ int or_run_bfs_mt(const or_spec *sp, const or_options *opt, int nthreads, double
                 r->verdict = w->verdict;
                 r->violated_invariant = w->inv;
             }
+            w->lvl_lo = w->lvl_hi;
+            w->lvl_hi = w->len;
+            uint64_t *sw = w->fblk; w->fblk = w->blk; w->blk = sw;
+            uint64_t sc = w->fblk_cap; w->fblk_cap = w->blk_cap; w->blk_cap = sc;
+            w->nfblk = w->nblk;
+            w->nblk = 0;
+            w->nnew = 0;
+            b.blk_base[t + 1] = b.blk_base[t] + w->nfblk;
         }
-        frontier = 0;
-        for (unsigned i = 0; i < MT_NSHARD; i++) {
-            b.sh[i].lvl_lo = b.sh[i].lvl_hi;
-            b.sh[i].lvl_hi = b.sh[i].n;
-            frontier += b.sh[i].lvl_hi - b.sh[i].lvl_lo;
-        }
+        if (atomic_load(&b.table_full)) { or_set_error("the multi-threaded oracle's table filled up inside a level"); rc = -1; break; }
+        b.nblocks = b.blk_base[nthreads];
+        frontier = newd;
         r->distinct += newd;
+        if (frontier > 0 && r->distinct > frontier) { const uint64_t g = r->distinct / (r->distinct - frontier) + 2; if (g > grow) grow = g < 16 ? g : 16; }
         if (newd) {
             if (level - 1 < OR_MAX_LEVELS) r->level_distinct[level - 1] = newd;
         } else {
@@ -255,25 +327,35 @@ int or_run_bfs_mt(const or_spec *sp, const or_options *opt, int nthreads, double
         if (opt->max_distinct && r->distinct >= opt->max_distinct) { budget = 1; break; }
         if (max_seconds > 0 && mt_now() - t0 >= max_seconds) { budget = 1; break; }
         if (level + 1 >= OR_MAX_LEVELS) { or_set_error("too many levels"); break; }
+        /* room for the next level at a load below 1/2: what is there + the frontier times the largest growth seen so far */
+        uint64_t need = 2 * (r->distinct + frontier * grow);
+        if (need > b.tab_cap) {
+            b.old_tab = b.tab;
+            b.old_cap = b.tab_cap;
+            while (b.tab_cap < need) b.tab_cap *= 2;
+            b.tab = mt_reserve(b.tab_cap * sizeof(uint64_t), 1);
+            if (!b.tab) oom("table");
+            atomic_store(&b.rehash_next, 0);
+            mt_run_threads(&b, th, mt_rehash_worker);
+            munmap((void *)b.old_tab, b.old_cap * sizeof(uint64_t));
+        }
         level++;
-        atomic_store(&b.next_shard, 0u);
-        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, mt_level_worker, &b.w[t]);
-        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        atomic_store(&b.next_block, 0);
+        mt_run_threads(&b, th, mt_level_worker);
     }
     r->seconds = mt_now() - t0;
     r->depth = level;
     r->queue_left = frontier;
     if (!have_violation) r->verdict = budget ? OR_BUDGET : OR_OK;
-    for (unsigned i = 0; i < MT_NSHARD; i++) {
-        r->arena_bytes += b.sh[i].arena_len;
-        free(b.sh[i].arena);
-        free(b.sh[i].off);
-        free(b.sh[i].tab);
-        pthread_mutex_destroy(&b.sh[i].mu);
+    for (int t = 0; t < nthreads; t++) {
+        r->arena_bytes += b.w[t].len - 8;
+        munmap(b.w[t].arena, MT_ARENA_BYTES);
+        free(b.w[t].blk);
+        free(b.w[t].fblk);
     }
-    for (int t = 0; t < nthreads; t++) { free(b.w[t].copy); free(b.w[t].copy_off); }
-    free(b.sh);
+    munmap((void *)b.tab, b.tab_cap * sizeof(uint64_t));
+    free(b.blk_base);
     free(b.w);
     free(th);
-    return 0;
+    return rc;
 }

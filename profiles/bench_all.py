@@ -11,6 +11,9 @@ import tla_rust_amd as amd
 WORKLOADS = [
     ("atomic_add N=24 (config 2 series)", "atomic_add", [24], dict(table_capacity=1 << 26, arena_capacity=(1 << 24) + 4096)),
     ("atomic_add N=28", "atomic_add", [28], dict(table_capacity=1 << 30, arena_capacity=(1 << 28) + 4096)),
+    # SURVEY 8d config 2's series is N in {20, 24, 28, 30}: 2^30 + 1 states, an 8.6 GB arena, a 16 GB seen-set at load 0.5
+    ("atomic_add N=20", "atomic_add", [20], dict(table_capacity=1 << 22, arena_capacity=(1 << 20) + 4096)),
+    ("atomic_add N=30", "atomic_add", [30], dict(table_capacity=1 << 31, arena_capacity=(1 << 30) + 4096)),
     ("pcal_intro committed (config 1)", "pcal_intro", [0, 1, 20, 2], dict(table_capacity=1 << 16, arena_capacity=1 << 14)),
     ("raft 3 servers, 25M budget (round 1's bench prefix)", "raft", [3, 4, 2, 3, 1, 1, 16, 2, 8],
      dict(table_capacity=1 << 28, arena_capacity=30_000_000, max_distinct=25_000_000)),

@@ -828,7 +828,9 @@ struct ShimOps {
     int begin() { return s->begin(); }
     int begin_replicated(uint64_t mf, uint64_t md, uint64_t ml, uint64_t *lv, uint32_t *n) { return s->begin_replicated(mf, md, ml, lv, n); }
     int level_size(uint64_t *n) { *n = s->level_size(); return 0; }
-    int expand_launch(uint32_t slot, uint64_t first, uint64_t count, uint64_t) { return s->expand_launch(slot, first, count); }
+    // like the engine, a launch into a slot invalidates what the slot's previous round left pending: a loop that launches round
+    // r+1 before it has issued the keep of round r-1 (same slot) fails here as it does on the GPU
+    int expand_launch(uint32_t slot, uint64_t first, uint64_t count, uint64_t) { pack_counts[slot & 1].clear(); return s->expand_launch(slot, first, count); }
     int expand_finish(uint32_t slot, uint64_t *fp, uint64_t cap, uint64_t *counts) { return s->expand_finish(slot, fp, cap, counts); }
     // fixed-capacity rounds emulated on the variable-size step calls: the in-band layout of include/tlamc.h mc_shard_*_pack
     int expand_pack(uint32_t slot, uint64_t *send_fp, uint64_t cap) {

@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
     # the hip-rccl back-end: host code over the public C ABI, HIP runtime and RCCL
     obj = OUT / "shard_rccl.o"
     objs.append(obj)
-    if force or _stale(obj, [CSRC / "shard_rccl.cpp", PKG.parent / "include" / "tlamc.h"]):
+    if force or _stale(obj, [CSRC / "shard_rccl.cpp", CSRC / "shard_loop.h", PKG.parent / "include" / "tlamc.h"]):
         jobs.append((obj, subprocess.Popen(common + ["-x", "hip", "-c", str(CSRC / "shard_rccl.cpp"), "-o", str(obj)])))
     for obj, pr in jobs:
         if pr.wait() != 0:

@@ -1273,12 +1273,18 @@ k_compact_packed(RouteArgs rt, uint64_t cap, uint64_t *__restrict__ send_fp, uin
 // owner side of the fixed-capacity exchange: bucket s of recv_fp came from rank s; answers keep the positions (0 outside a bucket's
 // count, so the sender can scan the whole buffer without knowing the counts)
 static __global__ void __launch_bounds__(256)
-k_probe_packed(const uint64_t *__restrict__ fps, uint64_t cap, uint64_t total, uint64_t *table, uint64_t mask, uint8_t *__restrict__ answers,
+k_probe_packed(const uint64_t *__restrict__ fps, uint64_t cap, unsigned nranks, uint64_t *table, uint64_t mask, uint8_t *__restrict__ answers,
                DevCounters *ctr) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroup b probes 256 consecutive entries of the bucket of source rank b % nranks: the sources are walked INTERLEAVED.
+    // A fingerprint that several ranks generated in the same round is "new" for whichever candidate reaches the table first,
+    // and its state then lives on that rank: with the buckets walked one after the other (source 0 first) the lower ranks won
+    // those ties systematically and their frontiers grew level after level (8 ranks, 10^8 states: 17.2 M on rank 0 against
+    // 11.1 M on rank 5; measured, profiles/r03a) — every other level became a rebalancing level.
+    const unsigned s = blockIdx.x % nranks;
+    const uint64_t j = (uint64_t)(blockIdx.x / nranks) * blockDim.x + threadIdx.x;
     unsigned err = 0;
-    if (i < total) {
-        const uint64_t s0 = (i / cap) * cap, j = i - s0;
+    if (j < cap) {
+        const uint64_t s0 = (uint64_t)s * cap, i = s0 + j;
         const uint64_t n = fps[s0] < cap ? fps[s0] : 0;  // (a count that cannot be: an overflowed bucket, already reported by its sender)
         bool is_new = false;
         if (j >= 1 && j <= n) is_new = seen_insert(table, mask, fps[i], err);
@@ -2523,8 +2529,8 @@ struct Engine : EngineBase {
         const uint64_t total = (uint64_t)nranks() * cap;
         if (!total) return MC_OK;
         timed(1, total, [&] {
-            hipLaunchKernelGGL(k_probe_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, side(), recv_fp, cap, total, d_table, seen_arg(),
-                               answers, d_ctr);
+            hipLaunchKernelGGL(k_probe_packed, dim3((unsigned)(nranks() * ((cap + 255) / 256))), dim3(256), 0, side(), recv_fp, cap, nranks(), d_table,
+                               seen_arg(), answers, d_ctr);
         }, side());
         return side_done();
     }

@@ -260,13 +260,14 @@ struct Loop {
             step([&] { return e.expand_pack(s, (uint64_t *)send[s].p, cap); });  // on MAIN, behind expand r: no host wait
             if (lrc) e.clear_counts((uint64_t *)send[s].p, P, cap);  // a failed rank sends empty buckets
             e.record(EV_PACKED + s, S_MAIN);
-            if (r + 1 < rounds) launch(r + 1);  // overlaps everything below
             e.wait(S_COMM, EV_PACKED + s);
             if (r >= 2) e.wait(S_COMM, EV_PROBED + s);  // the probes of round r-2 have read recv[s]
             if ((trc = net.all_to_all(net.user, send[s].p, recv[s].p, cap * 8))) return trc;
             st.sent_bytes += cap * 8 * (P - 1);
             e.record(EV_FP + s, S_COMM);
             if (r >= 1 && (trc = answers(r - 1))) return trc;  // issued AFTER fp(r): probes of r-1 ran while fp(r) travelled
+            // (only now: round r+1 reuses the engine slot of round r-1, whose keep has just been issued)
+            if (r + 1 < rounds) launch(r + 1);  // overlaps the exchanges and probes of rounds r and r+1
             e.wait(S_WORK, EV_FP + s);
             if (r >= 2) e.wait(S_WORK, EV_ANS + s);  // the answers exchange of round r-2 has read ans[s]
             step([&] { return e.probe_pack((const uint64_t *)recv[s].p, cap, (uint8_t *)ans[s].p); });
