@@ -26,7 +26,8 @@ sys.path.insert(0, str(ROOT))
 
 # params[6..8] = capacities of the messages / elections / allLogs slot arrays of the packed state = the
 # oracle's maxima over the complete graph, 10 / 1 / 4 (tests/golden/raft_levels.json max_stat); an overflow
-# would raise MC_EOVERFLOW, never drop a state.  params[9] = MaxMsgKeys.  W = 18 + 10 + 1*4 + 4 = 36 words = 288 B.
+# would raise MC_EOVERFLOW, never drop a state.  params[9] = MaxMsgKeys.  W = 2 + 2*3 + 10 + 1*2 + 1 = 21 words = 168 B
+# (round 3 layout: logs as 2 bits per client-request value; 288 B in rounds 1-2).
 WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 10, 1, 4, 10], golden="raft3_mcr4_t2_m1_k10_complete",
                 name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=10 "
                      "(specs/MCraft.cfg), complete state graph")
@@ -137,10 +138,8 @@ def main():
     ap.add_argument("--msg-keys", type=int, default=10, choices=[10, 11], help="11: the 3.4e8-state graph (165 ms/step) instead of the contract workload")
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
-    ap.add_argument("--direct", action="store_true", help="A/B: one kernel per chunk (k_expand_direct: expand + insert + copy-and-patch write)")
     ap.add_argument("--no-dense", action="store_true", help="A/B: Restart / Timeout through the family queues instead of inline")
     ap.add_argument("--no-filter", action="store_true", help="A/B: without the per-wavefront duplicate filter in front of the seen-set")
-    ap.add_argument("--occ3", action="store_true", help="A/B: k_expand_direct compiled for 3 waves per SIMD (no register spills)")
     a = ap.parse_args()
     if a.msg_keys == 11:
         global WORKLOAD
@@ -167,7 +166,7 @@ def main():
     comm = store = None
     if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=slots, matrix=a.matrix,
-                         debug_flags=(32 if a.no_family else 0) | (1024 if a.direct else 0) | (2048 if a.occ3 else 0) | (32768 if a.no_dense else 0) | (8192 if a.no_filter else 0),
+                         debug_flags=(32 if a.no_family else 0) | (32768 if a.no_dense else 0) | (8192 if a.no_filter else 0),
                          arena_capacity=G0["distinct"] + (1 << 20),
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run
@@ -252,7 +251,7 @@ def main():
         W = ks["state_bytes"]
         # algorithmic bytes per launch: expand reads W per frontier state,
         # insert touches one 8-byte seen-set word per generated candidate, materialise writes W per new state
-        direct = a.direct and not (a.matrix or a.no_family)   # k_expand_direct: expand + insert + write in one kernel
+        direct = False
         alg = {"expand": W * ks["expand"]["units"], "insert": 8 * ks["cand_cells"], "materialise": W * ks["materialise"]["units"]}
         if direct:  # reads W per expanded state, touches 8 B of the seen-set per in-model successor, writes W per new state
             alg["expand"] = W * ks["expand"]["units"] + 8 * ks["cand_cells"] + W * D

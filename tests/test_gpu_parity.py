@@ -225,9 +225,9 @@ def test_no_two_leaders_negative_control_on_gpu(amd, tmp_path):
     word = lambda buf, w: struct.unpack_from("<Q", buf, arena + w * 64 * 8)[0]   # state 0 of block 0: word w at (w * 64 + 0)
     for same_term in (True, False):
         buf = bytearray(data)
-        sv0, sv1 = word(buf, 3), word(buf, 8)
-        struct.pack_into("<Q", buf, arena + 3 * 64 * 8, (sv0 & ~0x1f) | 2 | (2 << 3))
-        struct.pack_into("<Q", buf, arena + 8 * 64 * 8, (sv1 & ~(0x1f | (0x1f << 8))) | (2 if same_term else 3) | (1 << 3) | (0b110 << 8))
+        sv0, sv1 = word(buf, 2), word(buf, 4)       # spec_raft.h: W_SRV(i) = 2 + 2 i; term[0,3) state[3,5) votesGranted[8,13)
+        struct.pack_into("<Q", buf, arena + 2 * 64 * 8, (sv0 & ~0x1f) | 2 | (2 << 3))
+        struct.pack_into("<Q", buf, arena + 4 * 64 * 8, (sv1 & ~(0x1f | (0x1f << 8))) | (2 if same_term else 3) | (1 << 3) | (0b110 << 8))
         (tmp_path / "edited").write_bytes(buf)
         e = amd.Engine("raft", params, max_levels=2, **kw)
         e.restore(tmp_path / "edited")

@@ -126,7 +126,7 @@ def _two_leader_parent(shim, same_term):
     d = shim.spec_desc("raft", [3, 4, 3, 3, 1, 1])
     w = (C.c_uint64 * 64)()
     assert lib.shim_init_state(C.byref(d), C.c_uint64(0), w) == 0
-    W_SRV = lambda i: 3 + i * 5                    # spec_raft.h: W_SRV(i) = 3 + i * (2 + NS); term[0,3) state[3,5) votesGranted[8,13)
+    W_SRV = lambda i: 2 + 2 * i                    # spec_raft.h: W_SRV(i) = 2 + 2 i (scalars + log of server i); term[0,3) state[3,5) votesGranted[8,13)
     w[W_SRV(0)] = (w[W_SRV(0)] & ~0x1f) | 2 | (2 << 3)
     w[W_SRV(1)] = (w[W_SRV(1)] & ~(0x1f | (0x1f << 8))) | (2 if same_term else 3) | (1 << 3) | (0b110 << 8)
     return lib, d, w

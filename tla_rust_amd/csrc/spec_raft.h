@@ -1,17 +1,24 @@
 // spec_raft.h — device lowering of examples/raft.tla (reference examples/raft.tla:110-507) under
 // the model wrapper specs/MCraft.tla (+ specs/MCraft.cfg) of this repo.
 //
-// Packed state = WORDS 64-bit words (layout below).  The three set-valued history variables
-// (messages with its monotone key set, elections, allLogs) are kept as UNORDERED slot arrays:
-// equality of TLA+ values is decided by an additive (multiset) fingerprint
-//     fp = sum_w Hw(header word w) + sum_m (count(m) + 1) * H(key(m), SALT_M) + sum_e He(e) + sum_l H(log, SALT_A)
+// Packed state = WORDS 64-bit words (layout below).  Round 3 layout (W 288 -> 168 bytes for the bench model, 944 -> 264 for
+// five servers): a LOG is 2 or 3 bits per client-request VALUE (the term of the entry with that value, 0 = no such entry) instead
+// of a length and a list of entries — 6 bits instead of 33 for three values — so that the scalars AND the log of a server share
+// one word, voterLog[i] is one word, committedLog rides in the globals word, an election record takes two words instead of 1 + n
+// and allLogs four logs per word (SURVEY.md Appendix B's budget).  Every byte of W is paid three times per distinct state
+// (expand reads it, materialise reads and writes it).
+//
+// The three set-valued history variables (messages with its monotone key set, elections, allLogs) are kept as UNORDERED slot
+// arrays: equality of TLA+ values is decided by an additive (multiset) fingerprint
+//     fp = sum_w Hw(logical field w) + sum_m (count(m) + 1) * H(key(m), SALT_M) + sum_e He(e) + sum_l H(log, SALT_A)
 // which does not depend on slot order, so a successor is "parent with <= 2 message slots
 // changed, <= 1 election appended, <= NS logs appended, one server's words and the globals
 // rewritten" and its fingerprint is the parent's plus the differences — O(delta), not O(W).
-// Chosen so that the common deltas cost ONE hash each (H = hmum, mc_common.h):
+// The hashed FIELDS are logical (globals, committedLog, scalars of server i, log[i], voterLog[i][j]: one salt each), whatever
+// physical word they share.  Chosen so that the common deltas cost ONE hash each (H = hmum, mc_common.h):
 //   * the bag is a multiset: a message contributes (count + 1) * H(key) — the "+ 1" because a key whose count fell to 0
 //     stays in the bag (note 1 below) — so Send / Discard / Duplicate / Drop change the sum by +-H(key) (a new key: 2 H(key));
-//   * of the globals word only clientRequests and committedLogDecrease are hashed: the slot counts nMsgs / nElec / nAll are
+//   * of the globals only clientRequests and committedLogDecrease are hashed: the slot counts nMsgs / nElec / nAll are
 //     functions of the three sets, which are hashed element by element;
 //   * an empty voterLog entry contributes 0 (Restart / Timeout clear them, a vote sets one).
 //
@@ -35,18 +42,53 @@
 namespace mc {
 
 // -------------------------------------------------------------------------- log encoding
-// log word: bits 0..2 = Len, entry k (1-based) at bits 3+6(k-1).. : term (3 bits) | value << 3.
+// An entry is [term, value] with value = clientRequests when ClientRequest appended it (raft.tla:264-274): the counter only
+// grows, so every value is created exactly once, every log is a sequence of entries with strictly increasing values, and a log
+// is the map value -> term of its entry (0: none).  Log word: digit v (1-based value) at bits tb * (v - 1), tb bits each (tb = 2
+// while MaxTerm <= 3, else 3); Len = number of non-zero digits; the k-th entry is the k-th non-zero digit.  An append that
+// would break the order (a digit at or above the new value is set) cannot happen in raft.tla; it is reported (ST_OVERFLOW ->
+// MC_EOVERFLOW), never stored wrongly.  Entries INSIDE messages keep the 6-bit form term | value << 3.
 namespace rlog {
-constexpr int LCAP = 5;
-MC_HD int len(uint64_t l) { return (int)(l & 7); }
-MC_HD unsigned entry(uint64_t l, int k) { return (unsigned)(l >> (3 + 6 * (k - 1))) & 63u; }
+constexpr int LCAP = 5;   // values 1..5 at most (MaxClientRequests <= 6)
+constexpr int LB_MAX = 15;
+MC_HD unsigned digit(uint64_t l, int v, int tb) { return (unsigned)(l >> (tb * (v - 1))) & ((1u << tb) - 1u); }
+MC_HD int len(uint64_t l, int tb) {
+    int n = 0;
+#pragma unroll
+    for (int v = 1; v <= LCAP; v++) n += digit(l, v, tb) != 0;
+    return n;
+}
 MC_HD int eterm(unsigned e) { return (int)(e & 7u); }
 MC_HD int evalue(unsigned e) { return (int)(e >> 3); }
 MC_HD unsigned mk_entry(int term, int value) { return (unsigned)term | ((unsigned)value << 3); }
-MC_HD int last_term(uint64_t l) { return len(l) ? eterm(entry(l, len(l))) : 0; }                    // raft.tla:113
-MC_HD uint64_t append(uint64_t l, unsigned e) { return (l + 1) | ((uint64_t)e << (3 + 6 * len(l))); }  // Append
-MC_HD uint64_t prefix(uint64_t l, int k) { return k == 0 ? 0 : ((l & ((1ull << (3 + 6 * k)) - 1ull)) & ~7ull) | (uint64_t)k; }
-MC_HD uint64_t drop_last(uint64_t l) { return prefix(l, len(l) - 1); }
+// k-th entry (1-based, k <= Len) as term | value << 3
+MC_HD unsigned entry(uint64_t l, int k, int tb) {
+    unsigned e = 0;
+#pragma unroll
+    for (int v = 1; v <= LCAP; v++) {
+        const unsigned d = digit(l, v, tb);
+        if (d && --k == 0) e = mk_entry((int)d, v);
+    }
+    return e;
+}
+MC_HD int last_term(uint64_t l, int tb) {                                                            // raft.tla:113
+    int t = 0;
+#pragma unroll
+    for (int v = 1; v <= LCAP; v++) { const unsigned d = digit(l, v, tb); t = d ? (int)d : t; }
+    return t;
+}
+MC_HD bool can_append(uint64_t l, unsigned e, int tb) { return evalue(e) >= 1 && evalue(e) <= LCAP && (l >> (tb * (evalue(e) - 1))) == 0; }
+MC_HD uint64_t append(uint64_t l, unsigned e, int tb) { return l | ((uint64_t)eterm(e) << (tb * (evalue(e) - 1))); }  // Append
+MC_HD uint64_t prefix(uint64_t l, int k, int tb) {  // SubSeq(l, 1, k)
+    uint64_t out = 0;
+#pragma unroll
+    for (int v = 1; v <= LCAP; v++) {
+        const unsigned d = digit(l, v, tb);
+        if (d && k > 0) { out |= (uint64_t)d << (tb * (v - 1)); --k; }
+    }
+    return out;
+}
+MC_HD uint64_t drop_last(uint64_t l, int tb) { return prefix(l, len(l, tb) - 1, tb); }
 }  // namespace rlog
 
 enum : int { R_FOLLOWER = 0, R_CANDIDATE = 1, R_LEADER = 2 };
@@ -58,6 +100,7 @@ struct RaftParams {
     int n, max_client_requests, max_term, max_log_len, max_msgs, inv_mask;
     int cm, ce, ca;  // capacities of the messages / elections / allLogs slot arrays (runtime: they size W)
     int max_keys;    // MaxMsgKeys of specs/MCraft.tla: Cardinality(DOMAIN messages) <= max_keys (0 = unbounded)
+    int tb, lb;      // bits per log digit (2: MaxTerm <= 3, else 3) and per log (tb * (MaxClientRequests - 1) <= 15)
 };
 
 // A small array that is guaranteed to live in registers: explicit scalar members and
@@ -93,21 +136,26 @@ struct RegArr {
 template <int NS>
 struct SpecRaft {
     using Params = RaftParams;
-    // ---------------------------------------------------------------- word layout
+    // ---------------------------------------------------------------- word layout (physical)
     static constexpr int W_FP = 0;     // additive fingerprint of this state (raw sum)
-    static constexpr int W_GLOB = 1;   // clientRequests[0,3) decrease[3] nMsgs[8,16) nElec[16,20) nAll[24,32)
-    static constexpr int W_CLOG = 2;   // committedLog
-    static constexpr int SRV_WORDS = 2 + NS;
-    MC_HD static constexpr int W_SRV(int i) { return 3 + i * SRV_WORDS; }      // scalars of server i
-    MC_HD static constexpr int W_LOG(int i) { return W_SRV(i) + 1; }           // log[i]
-    MC_HD static constexpr int W_VLOG(int i, int j) { return W_SRV(i) + 2 + j; }  // voterLog[i][j]
-    static constexpr int W_MSG0 = 3 + NS * SRV_WORDS;                         // messages[cm]
-    static constexpr int EL_WORDS = 1 + NS;
-    MC_HD static int W_EL0(const Params &p) { return W_MSG0 + p.cm; }                 // elections[ce][1+NS]
-    MC_HD static int W_ALL0(const Params &p) { return W_MSG0 + p.cm + p.ce * EL_WORDS; }  // allLogs[ca]
-    MC_HD static int words(const Params &p) { return W_MSG0 + p.cm + p.ce * EL_WORDS + p.ca; }
-    static constexpr int MAX_WORDS = W_MSG0 + 64 + 8 * EL_WORDS + 64;
-    static constexpr int HDR_WORDS = W_MSG0;
+    static constexpr int W_GLOB = 1;   // clientRequests[0,3) decrease[3] nMsgs[8,16) nElec[16,20) nAll[24,32) | committedLog[32,47)
+    MC_HD static constexpr int W_SRV(int i) { return 2 + 2 * i; }   // scalars of server i [0, LOGSH) | log[i] [LOGSH, LOGSH + 15)
+    MC_HD static constexpr int W_VL(int i) { return 3 + 2 * i; }    // voterLog[i][j] at bits [lb * j, lb * (j + 1))
+    static constexpr int W_MSG0 = 2 + 2 * NS;                       // messages[cm], one word each
+    static constexpr int EL_WORDS = 2;                              // election: record word | evoterLog (packed like W_VL)
+    MC_HD static int W_EL0(const Params &p) { return W_MSG0 + p.cm; }                 // elections[ce][2]
+    MC_HD static int W_ALL0(const Params &p) { return W_MSG0 + p.cm + p.ce * EL_WORDS; }  // allLogs[ca]: four 16-bit slots per word
+    MC_HD static int all_words(const Params &p) { return (p.ca + 3) >> 2; }
+    MC_HD static int words(const Params &p) { return W_MSG0 + p.cm + p.ce * EL_WORDS + all_words(p); }
+    static constexpr int MAX_WORDS = W_MSG0 + 64 + 8 * EL_WORDS + 16;
+    static constexpr int LOGSH = 16 + 6 * NS;  // 34 (3 servers) / 46 (5 servers): the scalars end here
+    static constexpr uint64_t SVMASK = (1ull << LOGSH) - 1ull;
+    static_assert(LOGSH + rlog::LB_MAX <= 64, "scalars + log of a server share one word");
+    // LOGICAL fields: what the fingerprint hashes, one salt each (the numbering of the one-field-per-word layout of rounds 1-2)
+    static constexpr int F_GLOB = 1, F_CLOG = 2;
+    MC_HD static constexpr int F_SV(int i) { return 3 + i * (2 + NS); }
+    MC_HD static constexpr int F_LOG(int i) { return F_SV(i) + 1; }
+    MC_HD static constexpr int F_VLOG(int i, int j) { return F_SV(i) + 2 + j; }
     // slots: Restart NS | Timeout NS | RequestVote NS^2 | BecomeLeader NS | ClientRequest NS |
     //        AdvanceCommitIndex NS | AppendEntries NS^2 | per message k: Receive, Duplicate, Drop
     static constexpr int FIX = 5 * NS + 2 * NS * NS;
@@ -120,22 +168,33 @@ struct SpecRaft {
     MC_HD static int max_slots(const Params &p) { return FIX + 3 * p.cm; }
     static constexpr uint64_t SALT_M = 0x8f1bbcdc8f1bbcdcull, SALT_E = 0xca62c1d6ca62c1d6ull, SALT_A = 0x5a8279995a827999ull;
 
-    // server scalar word: term[0,3) state[3,5) votedFor[5,8) votesGranted[8,13) commitIndex[13,16)
-    //                     nextIndex[j] 4 bits at 16+4j, matchIndex[j] 3 bits at 36+3j
+    // ---- field access through a state reference (Ref::get = physical word)
+    template <class Ref> MC_HD static uint64_t rd_glob(Ref s) { return s.get(W_GLOB) & 0xffffffffull; }
+    template <class Ref> MC_HD static uint64_t rd_clog(Ref s) { return s.get(W_GLOB) >> 32; }
+    template <class Ref> MC_HD static uint64_t rd_sv(Ref s, int i) { return s.get(W_SRV(i)) & SVMASK; }
+    template <class Ref> MC_HD static uint64_t rd_log(Ref s, int i) { return s.get(W_SRV(i)) >> LOGSH; }
+    MC_HD static uint64_t pack_srv(uint64_t sv, uint64_t log) { return sv | (log << LOGSH); }
+    MC_HD static uint64_t pack_glob(uint64_t glob, uint64_t clog) { return (glob & 0xffffffffull) | (clog << 32); }
+    MC_HD static uint64_t vl_get(uint64_t word, int j, const Params &p) { return (word >> (p.lb * j)) & ((1ull << p.lb) - 1ull); }
+    MC_HD static uint64_t vl_set(uint64_t word, int j, uint64_t log, const Params &p) { return word | (log << (p.lb * j)); }  // (the entry was empty)
+    template <class Ref> MC_HD static uint64_t rd_all(const Params &p, Ref s, int a) { return (s.get(W_ALL0(p) + (a >> 2)) >> (16 * (a & 3))) & 0xffffull; }
+
+    // server scalars: term[0,3) state[3,5) votedFor[5,8) votesGranted[8,13) commitIndex[13,16)
+    //                 nextIndex[j] 3 bits at 16+3j (1 .. Len + 1 <= 6), matchIndex[j] 3 bits at 16+3NS+3j
     MC_HD static int sv_term(uint64_t v) { return (int)(v & 7); }
     MC_HD static int sv_state(uint64_t v) { return (int)(v >> 3 & 3); }
     MC_HD static int sv_voted(uint64_t v) { return (int)(v >> 5 & 7); }       // 0 = Nil, j+1
     MC_HD static unsigned sv_granted(uint64_t v) { return (unsigned)(v >> 8 & 31); }
     MC_HD static int sv_commit(uint64_t v) { return (int)(v >> 13 & 7); }
-    MC_HD static int sv_next(uint64_t v, int j) { return (int)(v >> (16 + 4 * j) & 15); }
-    MC_HD static int sv_match(uint64_t v, int j) { return (int)(v >> (36 + 3 * j) & 7); }
+    MC_HD static int sv_next(uint64_t v, int j) { return (int)(v >> (16 + 3 * j) & 7); }
+    MC_HD static int sv_match(uint64_t v, int j) { return (int)(v >> (16 + 3 * NS + 3 * j) & 7); }
     MC_HD static uint64_t sv_set_term(uint64_t v, int x) { return bits_set(v, 0, 3, (uint64_t)x); }
     MC_HD static uint64_t sv_set_state(uint64_t v, int x) { return bits_set(v, 3, 2, (uint64_t)x); }
     MC_HD static uint64_t sv_set_voted(uint64_t v, int x) { return bits_set(v, 5, 3, (uint64_t)x); }
     MC_HD static uint64_t sv_set_granted(uint64_t v, unsigned x) { return bits_set(v, 8, 5, x); }
     MC_HD static uint64_t sv_set_commit(uint64_t v, int x) { return bits_set(v, 13, 3, (uint64_t)x); }
-    MC_HD static uint64_t sv_set_next(uint64_t v, int j, int x) { return bits_set(v, 16 + 4 * j, 4, (uint64_t)x); }
-    MC_HD static uint64_t sv_set_match(uint64_t v, int j, int x) { return bits_set(v, 36 + 3 * j, 3, (uint64_t)x); }
+    MC_HD static uint64_t sv_set_next(uint64_t v, int j, int x) { return bits_set(v, 16 + 3 * j, 3, (uint64_t)x); }
+    MC_HD static uint64_t sv_set_match(uint64_t v, int j, int x) { return bits_set(v, 16 + 3 * NS + 3 * j, 3, (uint64_t)x); }
     MC_HD static uint64_t sv_reset_leader_vars(uint64_t v, int next) {        // nextIndex = next, matchIndex = 0 for all j
         for (int j = 0; j < NS; j++) v = sv_set_match(sv_set_next(v, j, next), j, 0);
         return v;
@@ -156,8 +215,8 @@ struct SpecRaft {
         return ((uint64_t)type << 2) | ((uint64_t)term << 4) | ((uint64_t)src << 7) | ((uint64_t)dst << 10);
     }
     // RVReq : lastLogTerm[13,16) lastLogIndex[16,19)
-    // RVResp: granted[13] mlog[14,47)
-    // AEReq : prevIdx[13,16) prevTerm[16,19) nentries[19] entry[20,26) commitIdx[26,29) mlog[29,62)
+    // RVResp: granted[13] mlog[14,29)
+    // AEReq : prevIdx[13,16) prevTerm[16,19) nentries[19] entry[20,26) commitIdx[26,29) mlog[29,44)
     // AEResp: success[13] matchIndex[14,17)
     MC_HD static uint64_t mk_rvreq(int term, int llt, int lli, int src, int dst) {
         return m_head(M_RVREQ, term, src, dst) | ((uint64_t)llt << 13) | ((uint64_t)lli << 16);
@@ -172,22 +231,23 @@ struct SpecRaft {
     MC_HD static uint64_t mk_aeresp(int term, int success, int midx, int src, int dst) {
         return m_head(M_AERESP, term, src, dst) | ((uint64_t)success << 13) | ((uint64_t)midx << 14);
     }
-    // election word 0: eterm[0,3) eleader[3,6) evotes[6,11) elog[11,44); words 1..NS: evoterLog[j]
-    MC_HD static uint64_t helec(const RegArr<1 + NS> &ew) {
-        uint64_t h = hmum(ew.get(0), SALT_E);
-#pragma unroll
-        for (int q = 1; q <= NS; q++) h = hmum(ew.get(q) + h, SALT_E + (uint64_t)q);
-        return h;
-    }
+    // election word 0: eterm[0,3) eleader[3,6) evotes[6,11) elog[11,26); word 1: evoterLog, packed like voterLog[i]
+    MC_HD static uint64_t helec(const RegArr<EL_WORDS> &ew) { return hmum(ew.get(1) + hmum(ew.get(0), SALT_E), SALT_E + 1ull); }
 
-    // contribution of header word w holding x
+    // contribution of logical field f holding x
     static constexpr uint64_t GLOB_HASHED = 0xffull;  // clientRequests[0,3) decrease[3]
-    MC_HD static constexpr bool is_vlog_word(int w) { return w >= W_SRV(0) && w < W_MSG0 && (w - W_SRV(0)) % SRV_WORDS >= 2; }
-    MC_HD static uint64_t hvlog(uint64_t x, int i, int j) { return x ? hmum(x, salt_of((unsigned)W_VLOG(i, j))) : 0ull; }
-    MC_HD static uint64_t hword(int w, uint64_t x) {
-        if (w == W_GLOB) x &= GLOB_HASHED;
-        if (is_vlog_word(w) && x == 0) return 0;
-        return hmum(x, salt_of((unsigned)w));
+    MC_HD static uint64_t hvlog(uint64_t x, int i, int j) { return x ? hmum(x, salt_of((unsigned)F_VLOG(i, j))) : 0ull; }
+    MC_HD static uint64_t hfield(int f, uint64_t x) { return hmum(x, salt_of((unsigned)f)); }
+    // sum over the fields of the header (everything but the three slot arrays)
+    template <class Ref>
+    MC_HD static uint64_t hheader(const Params &prm, Ref s) {
+        uint64_t fp = hfield(F_GLOB, rd_glob(s) & GLOB_HASHED) + hfield(F_CLOG, rd_clog(s));
+        for (int i = 0; i < NS; i++) {
+            fp += hfield(F_SV(i), rd_sv(s, i)) + hfield(F_LOG(i), rd_log(s, i));
+            const uint64_t vw = s.get(W_VL(i));
+            for (int j = 0; j < NS; j++) fp += hvlog(vl_get(vw, j, prm), i, j);
+        }
+        return fp;
     }
     // contribution of one message slot: (count + 1) * H(key)
     MC_HD static uint64_t hkey(uint64_t mword) { return hmum(mword >> 2, SALT_M); }
@@ -207,6 +267,10 @@ struct SpecRaft {
         if (o.max_client_requests < 1 || o.max_client_requests - 1 > rlog::LCAP || o.max_client_requests > 7) return -1;
         if (o.max_term < 1 || o.max_term > 6) return -1;  // term MaxTerm+1 must still fit 3 bits
         if (o.max_log_len < 0 || o.max_msgs < 0) return -1;
+        o.tb = o.max_term <= 3 ? 2 : 3;                       // an entry's term is a leader's currentTerm <= MaxTerm
+        o.lb = o.tb * (o.max_client_requests - 1);           // values 1 .. MaxClientRequests - 1
+        if (o.lb < o.tb) o.lb = o.tb;
+        if (o.lb > rlog::LB_MAX || NS * o.lb > 64) return -1;  // voterLog[i] is one word
         return 0;
     }
 
@@ -215,20 +279,17 @@ struct SpecRaft {
     MC_HD static void init(const Params &prm, uint64_t, WordRef out) {
         for (int w = 0; w < words(prm); w++) out.set(w, 0);
         uint64_t sv = sv_reset_leader_vars(sv_set_term(0, 1), 1);  // currentTerm 1, Follower, Nil, {}, 0, next 1, match 0
-        uint64_t fp = 0;
-        for (int i = 0; i < NS; i++) out.set(W_SRV(i), sv);
-        out.set(W_GLOB, 1);  // clientRequests = 1
-        for (int w = 1; w < HDR_WORDS; w++) fp += hword(w, out.get(w));
-        out.set(W_FP, fp);
+        for (int i = 0; i < NS; i++) out.set(W_SRV(i), pack_srv(sv, 0));
+        out.set(W_GLOB, pack_glob(1, 0));  // clientRequests = 1, committedLog = <<>>
+        out.set(W_FP, hheader(prm, out));
     }
     template <class Ref>
     MC_HD static uint64_t fp_of(const Params &, Ref s) { return fp_nonzero(s.get(W_FP)); }
     // full recomputation of the fingerprint (tests: must equal the incrementally maintained one)
     template <class Ref>
     MC_HD static uint64_t fp_recompute(const Params &prm, Ref s) {
-        uint64_t fp = 0;
-        for (int w = 1; w < HDR_WORDS; w++) fp += hword(w, s.get(w));
-        const uint64_t g = s.get(W_GLOB);
+        uint64_t fp = hheader(prm, s);
+        const uint64_t g = rd_glob(s);
         for (int k = 0; k < g_nm(g); k++) fp += hmsg(s.get(W_MSG0 + k));
         for (int e = 0; e < g_ne(g); e++) {
             RegArr<EL_WORDS> ew;
@@ -236,7 +297,7 @@ struct SpecRaft {
             for (int q = 0; q < EL_WORDS; q++) ew.set(q, s.get(W_EL0(prm) + e * EL_WORDS + q));
             fp += helec(ew);
         }
-        for (int a = 0; a < g_na(g); a++) fp += hmum(s.get(W_ALL0(prm) + a), SALT_A);
+        for (int a = 0; a < g_na(g); a++) fp += hmum(rd_all(prm, s, a), SALT_A);
         return fp;
     }
     template <class Ref>
@@ -286,17 +347,18 @@ struct SpecRaft {
         uint64_t dig;          // 11 bits per server: state[0,2) currentTerm[2,5) LastTerm(log)[5,8) Len(log)[8,11) — all that
                                // RequestVote(i, j) reads of server i (raft.tla:209-217): a quarter of all pairs needs no arena word
     };
-    MC_HD static uint64_t digest_of(uint64_t sv, uint64_t lg) {
-        return (uint64_t)sv_state(sv) | (uint64_t)sv_term(sv) << 2 | (uint64_t)rlog::last_term(lg) << 5 | (uint64_t)rlog::len(lg) << 8;
+    MC_HD static uint64_t digest_of(uint64_t sv, uint64_t lg, int tb) {
+        return (uint64_t)sv_state(sv) | (uint64_t)sv_term(sv) << 2 | (uint64_t)rlog::last_term(lg, tb) << 5 | (uint64_t)rlog::len(lg, tb) << 8;
     }
     // WANT_FP = false: the caller never computes a fingerprint from this cache (k_materialise with a known one)
     template <bool WANT_FP = true, class Ref>
     MC_HD static void load(const Params &prm, Ref s, Local &l) {
         l.fp = s.get(W_FP);
-        l.glob = s.get(W_GLOB);
-        l.clog = s.get(W_CLOG);
+        const uint64_t gw = s.get(W_GLOB);
+        l.glob = gw & 0xffffffffull;
+        l.clog = gw >> 32;
         #pragma unroll
-        for (int i = 0; i < NS; i++) { l.sv.set(i, s.get(W_SRV(i))); l.log.set(i, s.get(W_LOG(i))); }
+        for (int i = 0; i < NS; i++) { const uint64_t x = s.get(W_SRV(i)); l.sv.set(i, x & SVMASK); l.log.set(i, x >> LOGSH); }
         l.nm = g_nm(l.glob);
         l.inflight = 0;
         l.sig = sigs_empty();
@@ -316,37 +378,40 @@ struct SpecRaft {
             if (k0 == 12) l.sig.w3 = w;
         }
         // allLogs' = allLogs \cup {log[i] : i \in Server} — the same for every successor of this state
-        unsigned present = 0;
-        const int na = g_na(l.glob);
-        const int wall = W_ALL0(prm);
-        for (int a0 = 0; a0 < na; a0 += 4) {
-            // (an index past the set is clamped to a0: the comparison sees y0 twice, which changes nothing)
-            const uint64_t y0 = s.get(wall + a0), y1 = s.get(wall + (a0 + 1 < na ? a0 + 1 : a0)),
-                           y2 = s.get(wall + (a0 + 2 < na ? a0 + 2 : a0)), y3 = s.get(wall + (a0 + 3 < na ? a0 + 3 : a0));
-#pragma unroll
-            for (int i = 0; i < NS; i++) {
-                const uint64_t lg = l.log.get(i);
-                if (y0 == lg || y1 == lg || y2 == lg || y3 == lg) present |= 1u << i;
-            }
-        }
+        const unsigned present = all_present(prm, s, l, g_na(l.glob));
         l.vany = 0;
         if (WANT_FP) {
 #pragma unroll
             for (int i = 0; i < NS; i++) {
+                const uint64_t vw = s.get(W_VL(i));
+                if (vw) l.vany |= 1u << i;
                 uint64_t h = 0;
 #pragma unroll
-                for (int j = 0; j < NS; j++) {
-                    const uint64_t x = s.get(W_VLOG(i, j));
-                    if (x) l.vany |= 1u << i;
-                    h += hvlog(x, i, j);
-                }
+                for (int j = 0; j < NS; j++) h += hvlog(vl_get(vw, j, prm), i, j);
                 l.vlh.set(i, h);
             }
         }
-        finish_local<WANT_FP>(l, present);
+        finish_local<WANT_FP>(prm, l, present);
+    }
+    // bit i: log[i] is an element of allLogs (four 16-bit slots per word)
+    template <class Ref>
+    MC_HD static unsigned all_present(const Params &prm, Ref s, const Local &l, int na) {
+        unsigned present = 0;
+        const int wall = W_ALL0(prm);
+        for (int a0 = 0; a0 < na; a0 += 4) {
+            const uint64_t y = s.get(wall + (a0 >> 2));
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (a0 + u < na) {
+                    const uint64_t x = (y >> (16 * u)) & 0xffffull;
+#pragma unroll
+                    for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
+                }
+        }
+        return present;
     }
     template <bool WANT_FP>
-    MC_HD static void finish_local(Local &l, unsigned present) {
+    MC_HD static void finish_local(const Params &prm, Local &l, unsigned present) {
         l.cache_k = -1;
         l.cache_hm = 0;
         l.addmask = 0;
@@ -354,7 +419,7 @@ struct SpecRaft {
         l.add_fp = 0;
         l.dig = 0;
 #pragma unroll
-        for (int i = 0; i < NS; i++) l.dig |= digest_of(l.sv.get(i), l.log.get(i)) << (11 * i);
+        for (int i = 0; i < NS; i++) l.dig |= digest_of(l.sv.get(i), l.log.get(i), prm.tb) << (11 * i);
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             bool skip = (present >> i & 1) != 0;
@@ -386,6 +451,7 @@ struct SpecRaft {
         uint64_t moldA, mnewA, moldB, mnewB;
         bool eadd;
         RegArr<EL_WORDS> ew;
+        uint64_t ovl;            // the packed voterLog word of server srv (read when vmode != 0)
         int dinflight;
     };
 
@@ -439,9 +505,9 @@ struct SpecRaft {
     // MEM = true (k_materialise: `slot` differs per lane): server words are read from the state
     // itself instead of select-indexing the register copy, which would be demoted to scratch.
     template <bool MEM, class Ref>
-    MC_HD static uint64_t srv_word(const Local &l, Ref s, int i) { if (MEM) return s.get(W_SRV(i)); return l.sv.get(i); }
+    MC_HD static uint64_t srv_word(const Local &l, Ref s, int i) { if (MEM) return rd_sv(s, i); return l.sv.get(i); }
     template <bool MEM, class Ref>
-    MC_HD static uint64_t log_word(const Local &l, Ref s, int i) { if (MEM) return s.get(W_LOG(i)); return l.log.get(i); }
+    MC_HD static uint64_t log_word(const Local &l, Ref s, int i) { if (MEM) return rd_log(s, i); return l.log.get(i); }
 
     // Action FAMILIES: the expand-by-family kernel buckets enabled (state, slot) pairs per family in LDS and evaluates 64 pairs
     // of ONE family at a time, so the successor construction below runs with every lane busy and without divergence between
@@ -462,9 +528,10 @@ struct SpecRaft {
     MC_HD static unsigned compute(const Params &prm, const Local &l, Ref s, int slot, Delta &d, int &action) {
         d.glob = l.glob; d.clog = l.clog; d.srv = -1; d.sv = d.osv = 0; d.log = d.olog = 0; d.pre = true; d.vmode = 0; d.vj = 0; d.vlog = 0;
         d.nmop = 0; d.midxA = d.midxB = -1; d.moldA = d.mnewA = d.moldB = d.mnewB = 0;
-        d.eadd = false; d.dinflight = 0;
+        d.eadd = false; d.dinflight = 0; d.ovl = 0;
         d.ew = RegArr<EL_WORDS>();
         unsigned st = ST_ENABLED;
+        const int tb = prm.tb;
         // ---- (1), (2): operands
         constexpr bool MSG_KINDS = FAM < 0 || FAM == F_RVREQ || FAM == F_DUPDROP || FAM == F_MISC;
         int i = 0, j = 0, k = -1, kind = -1;
@@ -488,8 +555,10 @@ struct SpecRaft {
         // (slot >= FIX: i differs per lane, the words are read from the read-only state, never select-indexed from the register copy)
         // Duplicate / Drop are about the message alone; a RequestVote pair evaluated by another lane (MEM) reads the digest
         constexpr bool BY_DIGEST = MEM && FAM == F_REQVOTE;
-        const uint64_t svi = slot >= FIX ? (kind == 0 ? s.get(W_SRV(i)) : 0ull) : BY_DIGEST ? 0ull : srv_word<MEM>(l, s, i);
-        const uint64_t lgi = slot >= FIX ? (kind == 0 ? s.get(W_LOG(i)) : 0ull) : BY_DIGEST ? 0ull : log_word<MEM>(l, s, i);
+        // (scalars and log of a server are ONE physical word: one load)
+        const uint64_t svw = slot >= FIX ? (kind == 0 ? s.get(W_SRV(i)) : 0ull) : (BY_DIGEST || !MEM) ? 0ull : s.get(W_SRV(i));
+        const uint64_t svi = (slot >= FIX || MEM) ? svw & SVMASK : l.sv.get(i);
+        const uint64_t lgi = (slot >= FIX || MEM) ? svw >> LOGSH : l.log.get(i);
         bool want_send = false;
         uint64_t skey = 0;
         // ---- (3): the action
@@ -497,7 +566,7 @@ struct SpecRaft {
             action = RA_RESTART;
             d.srv = i; d.osv = svi; d.olog = d.log = lgi;
             d.sv = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(d.osv, R_FOLLOWER), 0), 0), 1);
-            d.vmode = 1;
+            d.vmode = 1; d.ovl = s.get(W_VL(i));
         } else if (MC_FAM(F_TIMEOUT) && slot >= NS && slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
             action = RA_TIMEOUT;
             const int stt = sv_state(svi);
@@ -506,10 +575,10 @@ struct SpecRaft {
             if (nt > prm.max_term) st |= ST_OUT_OF_MODEL;
             d.srv = i; d.osv = svi; d.olog = d.log = lgi;
             d.sv = sv_set_granted(sv_set_voted(sv_set_term(sv_set_state(svi, R_CANDIDATE), nt & 7), 0), 0);
-            d.vmode = 1;
+            d.vmode = 1; d.ovl = s.get(W_VL(i));
         } else if (MC_FAM(F_REQVOTE) && slot >= 2 * NS && slot < 2 * NS + NS * NS) {  // RequestVote(i, j)   raft.tla:209-217
             action = RA_REQUESTVOTE;
-            const unsigned dg = BY_DIGEST ? (unsigned)(l.dig >> (11 * i)) & 2047u : (unsigned)digest_of(svi, lgi);
+            const unsigned dg = BY_DIGEST ? (unsigned)(l.dig >> (11 * i)) & 2047u : (unsigned)digest_of(svi, lgi, tb);
             if ((int)(dg & 3u) != R_CANDIDATE) return 0;
             want_send = true;
             skey = mk_rvreq((int)(dg >> 2 & 7u), (int)(dg >> 5 & 7u), (int)(dg >> 8 & 7u), i, j);
@@ -517,11 +586,10 @@ struct SpecRaft {
             action = RA_BECOMELEADER;
             if (sv_state(svi) != R_CANDIDATE || !in_quorum(sv_granted(svi))) return 0;
             d.srv = i; d.osv = svi; d.olog = d.log = lgi;
-            d.sv = sv_reset_leader_vars(sv_set_state(svi, R_LEADER), rlog::len(lgi) + 1);
+            d.sv = sv_reset_leader_vars(sv_set_state(svi, R_LEADER), rlog::len(lgi, tb) + 1);
             const uint64_t ew0 = (uint64_t)sv_term(svi) | ((uint64_t)i << 3) | ((uint64_t)sv_granted(svi) << 6) | (lgi << 11);
             d.ew.set(0, ew0);
-#pragma unroll
-            for (int jj = 0; jj < NS; jj++) d.ew.set(1 + jj, s.get(W_VLOG(i, jj)));
+            d.ew.set(1, s.get(W_VL(i)));
             // elections \cup {...}: a set — an identical record changes nothing
             bool present = false;
             const int ne = g_ne(l.glob), wel = W_EL0(prm);
@@ -540,31 +608,33 @@ struct SpecRaft {
             action = RA_CLIENTREQUEST;
             const int creq = g_creq(l.glob);
             if (sv_state(svi) != R_LEADER || !(creq < prm.max_client_requests)) return 0;
-            if (rlog::len(lgi) >= rlog::LCAP) return ST_ENABLED | ST_OVERFLOW;
+            if (!rlog::can_append(lgi, rlog::mk_entry(sv_term(svi), creq), tb)) return ST_ENABLED | ST_OVERFLOW;
             d.srv = i; d.osv = d.sv = svi; d.olog = lgi;
-            d.log = rlog::append(lgi, rlog::mk_entry(sv_term(svi), creq));
+            d.log = rlog::append(lgi, rlog::mk_entry(sv_term(svi), creq), tb);
             d.glob += 1;  // clientRequests' = clientRequests + 1
-            if (rlog::len(d.log) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
+            if (rlog::len(d.log, tb) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
         } else if (MC_FAM(F_ADVANCE) && slot >= 4 * NS + NS * NS && slot < 5 * NS + NS * NS) {  // AdvanceCommitIndex(i)   raft.tla:280-305
             action = RA_ADVANCECOMMIT;
             const uint64_t lg = lgi;
             if (sv_state(svi) != R_LEADER) return 0;
             int maxAgree = 0;
-            for (int index = 1; index <= rlog::len(lg); index++) {
+            const int lglen = rlog::len(lg, tb);
+            for (int index = 1; index <= lglen; index++) {
                 unsigned agree = 1u << i;  // Agree(index) == {i} \cup {k : matchIndex[i][k] >= index}
 #pragma unroll
                 for (int kk = 0; kk < NS; kk++) if (sv_match(svi, kk) >= index) agree |= 1u << kk;
                 if (in_quorum(agree)) maxAgree = index;
             }
-            const int nci = (maxAgree > 0 && rlog::eterm(rlog::entry(lg, maxAgree)) == sv_term(svi)) ? maxAgree : sv_commit(svi);
+            const int nci = (maxAgree > 0 && rlog::eterm(rlog::entry(lg, maxAgree, tb)) == sv_term(svi)) ? maxAgree : sv_commit(svi);
             uint64_t ncl = 0;
             if (nci > 1) {
-                if (nci > rlog::len(lg)) return ST_ENABLED | ST_SPECERR;  // log[i][j] out of domain
-                ncl = rlog::prefix(lg, nci);
+                if (nci > lglen) return ST_ENABLED | ST_SPECERR;  // log[i][j] out of domain
+                ncl = rlog::prefix(lg, nci, tb);
             }
-            const int lc = rlog::len(l.clog);
+            const int lc = rlog::len(l.clog, tb);
             bool decr = nci < lc;  // lazy \/ : the \E is evaluated only when nci >= Len(committedLog)
-            if (!decr && lc > 0) decr = (((l.clog ^ ncl) >> 3) & ((1ull << (6 * lc)) - 1ull)) != 0;
+            // \E index \in 1..Len(committedLog) : committedLog[index] /= newCommittedLog[index] — here Len(newCommittedLog) >= lc
+            if (!decr && lc > 0) decr = rlog::prefix(ncl, lc, tb) != l.clog;
             d.srv = i; d.osv = svi; d.olog = d.log = lg; d.sv = sv_set_commit(svi, nci);
             d.clog = ncl;
             d.glob = bits_set(d.glob, 3, 1, decr ? 1 : 0);
@@ -574,13 +644,14 @@ struct SpecRaft {
             if (i == j || sv_state(svi) != R_LEADER) return 0;
             const int next = sv_next(svi, j), prevIdx = next - 1;
             int prevTerm = 0;
+            const int lglen = rlog::len(lg, tb);
             if (prevIdx > 0) {
-                if (prevIdx > rlog::len(lg)) return ST_ENABLED | ST_SPECERR;
-                prevTerm = rlog::eterm(rlog::entry(lg, prevIdx));
+                if (prevIdx > lglen) return ST_ENABLED | ST_SPECERR;
+                prevTerm = rlog::eterm(rlog::entry(lg, prevIdx, tb));
             }
-            const int lastEntry = rlog::len(lg) < next ? rlog::len(lg) : next;  // Min({Len(log[i]), nextIndex[i][j]})
-            const int nent = next <= lastEntry ? 1 : 0;                        // SubSeq(log[i], next, lastEntry)
-            const unsigned ent = nent ? rlog::entry(lg, next) : 0u;
+            const int lastEntry = lglen < next ? lglen : next;  // Min({Len(log[i]), nextIndex[i][j]})
+            const int nent = next <= lastEntry ? 1 : 0;          // SubSeq(log[i], next, lastEntry)
+            const unsigned ent = nent ? rlog::entry(lg, next, tb) : 0u;
             const int ci = sv_commit(svi) < lastEntry ? sv_commit(svi) : lastEntry;
             want_send = true;
             skey = mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j);
@@ -605,8 +676,8 @@ struct SpecRaft {
                     d.sv = sv_set_voted(sv_set_state(sv_set_term(svi, mterm), R_FOLLOWER), 0);
                     if (mterm > prm.max_term) st |= ST_OUT_OF_MODEL;
                 } else if (MC_FAM(F_RVREQ) && mterm <= term && type == M_RVREQ) {  // HandleRequestVoteRequest   raft.tla:313-332
-                    const int llt = (int)(m >> 13 & 7), lli = (int)(m >> 16 & 7), lt = rlog::last_term(lg);
-                    const bool logOk = llt > lt || (llt == lt && lli >= rlog::len(lg));
+                    const int llt = (int)(m >> 13 & 7), lli = (int)(m >> 16 & 7), lt = rlog::last_term(lg, tb);
+                    const bool logOk = llt > lt || (llt == lt && lli >= rlog::len(lg, tb));
                     const bool grant = mterm == term && logOk && (sv_voted(svi) == 0 || sv_voted(svi) == j + 1);
                     if (grant) d.sv = sv_set_voted(svi, j + 1);
                     want_send = true;  // Reply(response, m)
@@ -618,7 +689,7 @@ struct SpecRaft {
                             const unsigned vg = sv_granted(svi);
                             d.sv = sv_set_granted(svi, vg | (1u << j));
                             if (!(vg >> j & 1)) {  // voterLog[i] @@ (j :> m.mlog): existing entry wins
-                                d.vmode = 2; d.vj = j; d.vlog = (m >> 14) & ((1ull << 33) - 1ull);
+                                d.vmode = 2; d.vj = j; d.vlog = (m >> 14) & 0x7fffull; d.ovl = s.get(W_VL(i));
                             }
                         }
                     }  // else DropStaleResponse   raft.tla:443-446
@@ -626,8 +697,8 @@ struct SpecRaft {
                 } else if (MC_FAM(F_AEREQ) && mterm <= term && type == M_AEREQ) {  // HandleAppendEntriesRequest   raft.tla:355-417
                     const int pidx = (int)(m >> 13 & 7), pterm = (int)(m >> 16 & 7), nent = (int)(m >> 19 & 1);
                     const unsigned ent = (unsigned)(m >> 20 & 63);
-                    const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg);
-                    const bool logOk = pidx == 0 || (pidx > 0 && pidx <= len && pterm == rlog::eterm(rlog::entry(lg, pidx)));
+                    const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg, tb);
+                    const bool logOk = pidx == 0 || (pidx > 0 && pidx <= len && pterm == rlog::eterm(rlog::entry(lg, pidx, tb)));
                     if (mterm < term || (mterm == term && stt == R_FOLLOWER && !logOk)) {  // reject   :361-373
                         want_send = true;
                         skey = mk_aeresp(term, 0, 0, i, j);
@@ -636,18 +707,18 @@ struct SpecRaft {
                         d.sv = sv_set_state(svi, R_FOLLOWER);
                     } else if (stt == R_FOLLOWER && logOk) {  // accept request   :379-416
                         const int index = pidx + 1;
-                        if (nent == 0 || (len >= index && rlog::eterm(rlog::entry(lg, index)) == rlog::eterm(ent))) {
+                        if (nent == 0 || (len >= index && rlog::eterm(rlog::entry(lg, index, tb)) == rlog::eterm(ent))) {
                             // already done with request   :384-402; commitIndex' assigned AND UNCHANGED
                             if (mci != sv_commit(svi)) return 0;
                             want_send = true;
                             skey = mk_aeresp(term, 1, pidx + nent, i, j);
                             discard(k, m, d);
                         } else if (len >= index) {  // conflict: remove 1 entry   :403-410
-                            d.log = rlog::drop_last(lg);
+                            d.log = rlog::drop_last(lg, tb);
                         } else if (len == pidx) {  // no conflict: append entry   :411-416
-                            if (len >= rlog::LCAP) return ST_ENABLED | ST_OVERFLOW;
-                            d.log = rlog::append(lg, ent);
-                            if (rlog::len(d.log) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
+                            if (!rlog::can_append(lg, ent, tb)) return ST_ENABLED | ST_OVERFLOW;
+                            d.log = rlog::append(lg, ent, tb);
+                            if (rlog::len(d.log, tb) > prm.max_log_len) st |= ST_OUT_OF_MODEL;
                         } else {
                             return 0;
                         }
@@ -755,44 +826,43 @@ struct SpecRaft {
         return m_type(m) == M_RVREQ ? (int)F_RVREQ : (int)F_MISC;
     }
     // Phase A of the by-family expand kernel (lane = parent, rows of the arena block coalesced): load() and guards() in one, with
-    // the loads of the parent's row issued in TWO groups — header + voterLogs, then up to 12 message slots + 4 allLogs entries:
-    // two trips to HBM instead of eight dependent ones (header; messages by fours; allLogs; voterLogs per dense pair) —
-    // and with what the kernel's push loop needs of each message (queue of its Receive, Duplicate / Drop enabled) kept as a
-    // byte code, so that the loop does not read the message words again.  Same Local / Guards as load() + guards().
+    // the loads of the parent's row issued in TWO groups — header (fingerprint, globals, two words per server), then up to 12
+    // message slots + the allLogs words: two trips to HBM instead of eight dependent ones — and with what the kernel's push loop
+    // needs of each message (queue of its Receive, Duplicate / Drop enabled) kept as a byte code, so that the loop does not read
+    // the message words again.  Same Local / Guards as load() + guards().
     template <class Ref>
     MC_HD static void load_expand(const Params &prm, Ref s, Local &l, Guards &g) {
-        // ---- trip 1: header and voterLogs (18 loads in flight)
+        // ---- trip 1: header (2 + 2 NS loads in flight)
         l.fp = s.get(W_FP);
-        l.glob = s.get(W_GLOB);
-        l.clog = s.get(W_CLOG);
-        uint64_t vl[NS * NS];
+        const uint64_t gw = s.get(W_GLOB);
+        l.glob = gw & 0xffffffffull;
+        l.clog = gw >> 32;
+        uint64_t vw[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) {
-            l.sv.set(i, s.get(W_SRV(i)));
-            l.log.set(i, s.get(W_LOG(i)));
-#pragma unroll
-            for (int j = 0; j < NS; j++) vl[i * NS + j] = s.get(W_VLOG(i, j));
+            const uint64_t x = s.get(W_SRV(i));
+            l.sv.set(i, x & SVMASK);
+            l.log.set(i, x >> LOGSH);
+            vw[i] = s.get(W_VL(i));
         }
         l.vany = 0;
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             uint64_t h = 0;
+            if (vw[i]) l.vany |= 1u << i;
 #pragma unroll
-            for (int j = 0; j < NS; j++) {
-                if (vl[i * NS + j]) l.vany |= 1u << i;
-                h += hvlog(vl[i * NS + j], i, j);
-            }
+            for (int j = 0; j < NS; j++) h += hvlog(vl_get(vw[i], j, prm), i, j);
             l.vlh.set(i, h);
         }
         l.nm = g_nm(l.glob);
         guards(prm, l, g);
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_sched_barrier(0);  // the loads of trip 2 stay below: all 34 in flight at once spill registers
+        __builtin_amdgcn_sched_barrier(0);  // the loads of trip 2 stay below
 #endif
-        // ---- trip 2: up to PRE message slots and 4 allLogs entries (slots up to the capacity are part of the row whatever
+        // ---- trip 2: up to PRE message slots and the first allLogs word (slots up to the capacity are part of the row whatever
         //      nMsgs says; an index is clamped into the capacity, wave-uniformly)
         constexpr int PRE = 12;
-        uint64_t mw[PRE], al[4];
+        uint64_t mw[PRE];
 #pragma unroll
         for (int k = 0; k < PRE; k++) mw[k] = 0;
 #pragma unroll
@@ -802,8 +872,7 @@ struct SpecRaft {
                 for (int u = 0; u < 4; u++) { const int k = 4 * g4 + u; mw[k] = s.get(W_MSG0 + (k < prm.cm ? k : prm.cm - 1)); }
             }
         const int wall = W_ALL0(prm);
-#pragma unroll
-        for (int a = 0; a < 4; a++) al[a] = s.get(wall + (a < prm.ca ? a : prm.ca - 1));
+        const uint64_t al0 = s.get(wall);
         // ---- arithmetic (bags beyond PRE keys / sets beyond 4 logs: the tail loads)
         l.inflight = 0;
         uint32_t sw[4] = {SIG_EMPTY, SIG_EMPTY, SIG_EMPTY, SIG_EMPTY};
@@ -827,20 +896,21 @@ struct SpecRaft {
 #pragma unroll
         for (int a = 0; a < 4; a++)
             if (a < na) {
+                const uint64_t x = (al0 >> (16 * a)) & 0xffffull;
 #pragma unroll
-                for (int i = 0; i < NS; i++) if (al[a] == l.log.get(i)) present |= 1u << i;
+                for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
             }
         for (int a = 4; a < na; a++) {
-            const uint64_t x = s.get(wall + a);
+            const uint64_t x = rd_all(prm, s, a);
 #pragma unroll
             for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
         }
-        finish_local<true>(l, present);
+        finish_local<true>(prm, l, present);
     }
     // what a lane evaluating a pair needs to know about the pair's parent beyond the words it reads itself (computed once by the
-    // parent's lane, kept in LDS: 40 B per parent): the fingerprint every successor starts from, the globals (all of its fields
-    // lie in the low 32 bits), the key signatures and the allLogs' bookkeeping.  committedLog is read from the arena by the one
-    // kind that needs it (AdvanceCommitIndex).
+    // parent's lane, kept in LDS: 40 B per parent): the fingerprint every successor starts from, the globals (the low 32 bits of
+    // their word), the key signatures and the allLogs' bookkeeping.  committedLog (the high half of that word) is read from the
+    // arena by the one kind that needs it (AdvanceCommitIndex).
     struct Summary {
         uint64_t base_fp;  // fp + add_fp
         Sigs sig;
@@ -856,7 +926,7 @@ struct SpecRaft {
     template <int FAM, class Ref>
     MC_HD static void local_of_summary(const Summary &q, Ref s, Local &l) {
         l.fp = q.base_fp; l.add_fp = 0; l.glob = q.glob; l.sig = q.sig; l.dig = q.dig;
-        l.clog = (FAM < 0 || FAM == F_MISC) ? s.get(W_CLOG) : 0ull;  // other kinds copy it: d.clog = l.clog, never hashed
+        l.clog = (FAM < 0 || FAM == F_MISC) ? rd_clog(s) : 0ull;  // other kinds copy it: d.clog = l.clog, never hashed
         l.nm = (int)(q.packed & 255u); l.inflight = (int)(q.packed >> 8 & 255u); l.nadd = (int)(q.packed >> 16 & 15u);
         l.addmask = q.packed >> 20 & 255u;
         l.cache_k = -1; l.cache_hm = 0;
@@ -872,106 +942,26 @@ struct SpecRaft {
         if (!(st & ST_ENABLED)) return 0;
         if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
         if (is_self_loop(l, s, d)) { fp = 1; return st | ST_SELFLOOP; }  // (the successor is the parent: no fingerprint needed)
-        fp = fp_nonzero(delta_fp(l, s, d));
+        fp = fp_nonzero(delta_fp(prm, l, s, d));
         return st;
     }
 
-    // ---------------------------------------------------------------- copy + patch (k_expand_direct)
-    // The lane that evaluated a pair still holds the successor's Delta when the seen-set says "new": instead of
-    // re-evaluating (parent, slot) in a second kernel, the delta is packed into PATCH_WORDS words, parked in LDS until
-    // 64 survivors are together, and the successor is written as "copy of the parent, patched".
-    //   pd[0]: caller's source tag [0,32) | srv+1 [32,35) | vmode [35,37) | vj [37,40) | midxA+1 [40,47) | midxB+1 [47,54) | eadd [54] | clog [55]
-    //   pd[1..8]: raw fingerprint, globals, committedLog, scalars and log of server srv, voterLog entry, message words A and B
-    static constexpr int PATCH_WORDS = 9;
-    template <int FAM, class Ref>
-    MC_HD static unsigned eval_pair_delta(const Params &prm, const Summary &q, Ref s, int slot, uint64_t &fp, uint64_t *pd) {
-        Local l;
-        local_of_summary<FAM>(q, s, l);
-        Delta d;
-        int action;
-        const unsigned st = compute<true, FAM>(prm, l, s, slot, d, action);
-        if (!(st & ST_ENABLED)) return 0;
-        if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
-        if (is_self_loop(l, s, d)) { fp = 1; return st | ST_SELFLOOP; }  // (the successor is the parent: no fingerprint needed)
-        const uint64_t raw = delta_fp(l, s, d);
-        fp = fp_nonzero(raw);
-        pd[0] = ((uint64_t)(d.srv + 1) << 32) | ((uint64_t)d.vmode << 35) | ((uint64_t)d.vj << 37) |
-                ((uint64_t)((d.nmop & 1) ? d.midxA + 1 : 0) << 40) | ((uint64_t)((d.nmop & 2) ? d.midxB + 1 : 0) << 47) |
-                ((uint64_t)(d.eadd ? 1 : 0) << 54) | ((uint64_t)((FAM < 0 || FAM == F_MISC) ? 1 : 0) << 55);  // 55: pd[3] holds committedLog
-        pd[1] = raw; pd[2] = d.glob; pd[3] = d.clog; pd[4] = d.sv; pd[5] = d.log; pd[6] = d.vlog; pd[7] = d.mnewA; pd[8] = d.mnewB;
-        return st;
-    }
-    // successor = parent `s` with the packed delta applied, written to `out`; q = the parent's summary (allLogs' additions)
     template <class Ref>
-    MC_HD static void write_patched(const Params &prm, Ref s, const uint64_t *pd, const Summary &q, WordRef out) {
-        const uint64_t meta = pd[0];
-        const int srv = (int)(meta >> 32 & 7) - 1, vmode = (int)(meta >> 35 & 3), vj = (int)(meta >> 37 & 7);
-        const int ia = (int)(meta >> 40 & 127) - 1, ib = (int)(meta >> 47 & 127) - 1;
-        const bool eadd = (meta >> 54 & 1) != 0;
-        const uint64_t oglob = s.get(W_GLOB);
-        out.set(W_FP, pd[1]);
-        out.set(W_GLOB, pd[2]);
-        out.set(W_CLOG, (meta >> 55 & 1) ? pd[3] : s.get(W_CLOG));  // kinds outside F_MISC never loaded it: unchanged
-        RegArr<NS> logs;
-        uint64_t osv = 0, olog = 0;
-        uint64_t ovl[NS];
-#pragma unroll
-        for (int j = 0; j < NS; j++) ovl[j] = 0;
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            const bool me = i == srv;
-            const uint64_t svi = s.get(W_SRV(i)), lgi = s.get(W_LOG(i));
-            logs.set(i, lgi);
-            if (me) { osv = svi; olog = lgi; }
-            out.set(W_SRV(i), me ? pd[4] : svi);
-            out.set(W_LOG(i), me ? pd[5] : lgi);
-#pragma unroll
-            for (int j = 0; j < NS; j++) {
-                uint64_t x = s.get(W_VLOG(i, j));
-                if (me) ovl[j] = x;
-                if (me && vmode == 1) x = 0;
-                if (me && vmode == 2 && j == vj) x = pd[6];
-                out.set(W_VLOG(i, j), x);
-            }
-        }
-        const int nm = g_nm(oglob), nm2 = g_nm(pd[2]);
-        for (int k = 0; k < prm.cm; k++) {
-            uint64_t x = k < nm ? s.get(W_MSG0 + k) : 0;
-            if (ia == k) x = pd[7];
-            if (ib == k) x = pd[8];
-            out.set(W_MSG0 + k, k < nm2 ? x : 0);
-        }
-        const int ne = g_ne(oglob), wel = W_EL0(prm);
-        for (int e = 0; e < prm.ce; e++) {
-#pragma unroll
-            for (int w = 0; w < EL_WORDS; w++) {
-                uint64_t x = e < ne ? s.get(wel + e * EL_WORDS + w) : 0;
-                if (eadd && e == ne)  // BecomeLeader(srv): the record built from the PARENT's words   raft.tla:253-258
-                    x = w == 0 ? ((uint64_t)sv_term(osv) | ((uint64_t)srv << 3) | ((uint64_t)sv_granted(osv) << 6) | (olog << 11)) : ovl[w > 0 ? w - 1 : 0];
-                out.set(wel + e * EL_WORDS + w, x);
-            }
-        }
-        const int na = g_na(oglob), wall = W_ALL0(prm);
-        const unsigned addmask = q.packed >> 20 & 255u;
-        for (int a = 0; a < prm.ca; a++) out.set(wall + a, a < na ? s.get(wall + a) : 0);
-        int pos = na;
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-            if (addmask >> i & 1) { if (pos < prm.ca) out.set(wall + pos, logs.get(i)); pos++; }
-    }
-
-    template <class Ref>
-    MC_HD static uint64_t delta_fp(Local &l, Ref s, const Delta &d) {
+    MC_HD static uint64_t delta_fp(const Params &prm, Local &l, Ref s, const Delta &d) {
+        (void)s;
+        const int lbits = prm.lb;
         uint64_t fp = l.fp + l.add_fp;
-        if ((d.glob ^ l.glob) & GLOB_HASHED) fp += hmum(d.glob & GLOB_HASHED, salt_of(W_GLOB)) - hmum(l.glob & GLOB_HASHED, salt_of(W_GLOB));
-        if (d.clog != l.clog) fp += hmum(d.clog, salt_of(W_CLOG)) - hmum(l.clog, salt_of(W_CLOG));
+        if ((d.glob ^ l.glob) & GLOB_HASHED) fp += hfield(F_GLOB, d.glob & GLOB_HASHED) - hfield(F_GLOB, l.glob & GLOB_HASHED);
+        if (d.clog != l.clog) fp += hfield(F_CLOG, d.clog) - hfield(F_CLOG, l.clog);
         if (d.srv >= 0) {
             const int i = d.srv;
-            if (d.sv != d.osv) fp += hmum(d.sv, salt_of((unsigned)W_SRV(i))) - hmum(d.osv, salt_of((unsigned)W_SRV(i)));
-            if (d.log != d.olog) fp += hmum(d.log, salt_of((unsigned)W_LOG(i))) - hmum(d.olog, salt_of((unsigned)W_LOG(i)));
+            if (d.sv != d.osv) fp += hfield(F_SV(i), d.sv) - hfield(F_SV(i), d.osv);
+            if (d.log != d.olog) fp += hfield(F_LOG(i), d.log) - hfield(F_LOG(i), d.olog);
             if (d.vmode == 1) {
+                if (d.ovl) {
 #pragma unroll
-                for (int j = 0; j < NS; j++) fp -= hvlog(s.get(W_VLOG(i, j)), i, j);
+                    for (int j = 0; j < NS; j++) fp -= hvlog((d.ovl >> (lbits * j)) & ((1ull << lbits) - 1ull), i, j);
+                }
             } else if (d.vmode == 2) {
                 fp += hvlog(d.vlog, i, d.vj);  // the entry was empty (compute: "existing entry wins")
             }
@@ -996,12 +986,7 @@ struct SpecRaft {
         if (d.srv < 0) return true;
         if (d.sv != d.osv || d.log != d.olog) return false;
         if (d.vmode == 2) return d.vlog == 0;
-        if (d.vmode == 1) {
-            uint64_t any = 0;
-#pragma unroll
-            for (int j = 0; j < NS; j++) any |= s.get(W_VLOG(d.srv, j));
-            return any == 0;
-        }
+        if (d.vmode == 1) return d.ovl == 0;
         return true;
     }
 
@@ -1015,7 +1000,7 @@ struct SpecRaft {
         // never stored, so its fingerprint is not needed
         if (st & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR)) { fp = 1; return st; }
         if (is_self_loop(l, s, d)) { fp = fp_nonzero(l.fp); return st | ST_SELFLOOP; }  // the parent's own fingerprint
-        fp = fp_nonzero(delta_fp(l, s, d));
+        fp = fp_nonzero(delta_fp(prm, l, s, d));
         return st;
     }
     // Restart(i) and Timeout(i) of ONE server, evaluated together by the parent's own lane (the dense slots of k_expand_family:
@@ -1048,7 +1033,7 @@ struct SpecRaft {
         if (l.inflight > prm.max_msgs) stc |= ST_OUT_OF_MODEL;
         if ((prm.inv_mask & 2) && g_decr(glob)) stc |= ST_INVARIANT | (1u << 8);
         (void)s;
-        const uint64_t salt = salt_of((unsigned)W_SRV(i));
+        const uint64_t salt = salt_of((unsigned)F_SV(i));
         const uint64_t base = l.fp + l.add_fp - l.vlh.get(i) - hmum(osv, salt);
         const bool still = !l.nadd && !(l.vany >> i & 1u);  // nothing but the scalars can differ from the parent
         // Restart(i): always enabled
@@ -1071,7 +1056,7 @@ struct SpecRaft {
 
     // re-evaluate `slot` on parent `s` and write the whole successor to `out`
     template <class Ref>
-    MC_HD static unsigned apply(const Params &prm, Ref s, int slot, WordRef out) { return apply_impl<false>(prm, s, slot, 0, out); }
+    MC_HD static unsigned apply(const Params &prm, Ref s, int slot, WordRef out) { return apply_copy_patch<false>(prm, s, slot, 0, out); }
     // ... when the expand kernel hands the successor's fingerprint over (fp_nonzero of the raw sum): the dozen hash terms of
     // delta_fp are not computed a second time.  The one ambiguous value (raw sum 0 or the substitute itself) is recomputed.
     static constexpr bool KNOWN_FP = true;
@@ -1081,28 +1066,25 @@ struct SpecRaft {
         return apply_copy_patch<true>(prm, s, slot, fp_nz, out);
     }
     // k_materialise's writer: COPY the parent row while reading it once — every group of loads is followed by the stores of the
-    // same words, and the per-parent cache (in-flight count, key signatures, allLogs' additions) is computed from the registers
-    // the copy passes through — then evaluate the action and PATCH the handful of words it changes.  Eight memory round trips
-    // per new state instead of sixteen (apply_impl reads the row for the cache, then again word by word for the output).
-    // Same result as apply_impl (tests/_shim compares the two on every successor of every lowering test).
+    // same words (the arena is both source and destination, so the compiler keeps every load behind every earlier store: a loop
+    // of "read a word, write it" would be one memory round trip per word), and the per-parent cache (in-flight count, key
+    // signatures, allLogs' additions) is computed from the registers the copy passes through — then evaluate the action and
+    // PATCH the handful of words it changes.
     template <bool KNOWN, class Ref>
     MC_HD static unsigned apply_copy_patch(const Params &prm, Ref s, int slot, uint64_t fp_known, WordRef out) {
         Local l;
         l.fp = KNOWN ? 0ull : s.get(W_FP);
-        l.glob = s.get(W_GLOB);
-        l.clog = s.get(W_CLOG);
-        uint64_t vl[NS * NS];
+        const uint64_t gw = s.get(W_GLOB);
+        l.glob = gw & 0xffffffffull;
+        l.clog = gw >> 32;
+        uint64_t vw[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) {
-            l.sv.set(i, s.get(W_SRV(i)));
-            l.log.set(i, s.get(W_LOG(i)));
-#pragma unroll
-            for (int j = 0; j < NS; j++) vl[i * NS + j] = s.get(W_VLOG(i, j));
+            const uint64_t x = s.get(W_SRV(i));
+            l.sv.set(i, x & SVMASK);
+            l.log.set(i, x >> LOGSH);
+            vw[i] = s.get(W_VL(i));
         }
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = 0; j < NS; j++) out.set(W_VLOG(i, j), vl[i * NS + j]);
         l.nm = g_nm(l.glob);
         l.inflight = 0;
         uint32_t sw[4] = {SIG_EMPTY, SIG_EMPTY, SIG_EMPTY, SIG_EMPTY};
@@ -1136,51 +1118,47 @@ struct SpecRaft {
 #pragma unroll
             for (int q = 0; q < EL_WORDS; q++) out.set(wel + e * EL_WORDS + q, e < ne ? x[q] : 0ull);
         }
+        // allLogs: four 16-bit slots per word; the successor's additions (the same for every successor of this parent,
+        // raft.tla:493) go to slots na, na + 1, ... — the words are assembled in registers and written once
         unsigned present = 0;
-        const int na = g_na(l.glob), wall = W_ALL0(prm);
-        for (int a0 = 0; a0 < prm.ca; a0 += 4) {
-            uint64_t x[4];
+        const int na = g_na(l.glob), wall = W_ALL0(prm), naw = all_words(prm);
+        uint64_t aw[16];
 #pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = s.get(wall + (a0 + u < na ? a0 + u : 0));
+        for (int q = 0; q < 16; q++) aw[q] = 0;
+        for (int q0 = 0; q0 < naw; q0 += 4) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int a = a0 + u;
-                if (a < na) {
+            for (int u = 0; u < 4; u++) if (q0 + u < naw) aw[q0 + u] = (q0 + u) * 4 < na ? s.get(wall + q0 + u) : 0ull;
+        }
+        for (int a = 0; a < na; a++) {
+            const uint64_t x = (aw[a >> 2] >> (16 * (a & 3))) & 0xffffull;
 #pragma unroll
-                    for (int i = 0; i < NS; i++) if (x[u] == l.log.get(i)) present |= 1u << i;
-                }
-                if (a < prm.ca) out.set(wall + a, a < na ? x[u] : 0ull);
-            }
+            for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
         }
         l.vany = 0;
-        finish_local<!KNOWN>(l, present);
+        finish_local<!KNOWN>(prm, l, present);
         // ---- the action
         Delta d;
         int action;
         const unsigned st = compute<true>(prm, l, s, slot, d, action);
         if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) {  // not a successor: the parent itself (never the case in k_materialise)
             out.set(W_FP, s.get(W_FP));
-            out.set(W_GLOB, l.glob);
-            out.set(W_CLOG, l.clog);
+            out.set(W_GLOB, gw);
 #pragma unroll
-            for (int i = 0; i < NS; i++) { out.set(W_SRV(i), l.sv.get(i)); out.set(W_LOG(i), l.log.get(i)); }
+            for (int i = 0; i < NS; i++) { out.set(W_SRV(i), pack_srv(l.sv.get(i), l.log.get(i))); out.set(W_VL(i), vw[i]); }
+            for (int q = 0; q < naw; q++) out.set(wall + q, aw[q]);
             return st;
         }
         // ---- patch
-        out.set(W_FP, KNOWN ? fp_known : delta_fp(l, s, d));
-        out.set(W_GLOB, d.glob);
-        out.set(W_CLOG, d.clog);
+        out.set(W_FP, KNOWN ? fp_known : delta_fp(prm, l, s, d));
+        out.set(W_GLOB, pack_glob(d.glob, d.clog));
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             const bool me = i == d.srv;
-            out.set(W_SRV(i), me ? d.sv : l.sv.get(i));
-            out.set(W_LOG(i), me ? d.log : l.log.get(i));
-        }
-        if (d.srv >= 0 && d.vmode == 1) {
-#pragma unroll
-            for (int j = 0; j < NS; j++) out.set(W_VLOG(d.srv, j), 0);
-        } else if (d.srv >= 0 && d.vmode == 2) {
-            out.set(W_VLOG(d.srv, d.vj), d.vlog);
+            out.set(W_SRV(i), pack_srv(me ? d.sv : l.sv.get(i), me ? d.log : l.log.get(i)));
+            uint64_t v = vw[i];
+            if (me && d.vmode == 1) v = 0;
+            if (me && d.vmode == 2) v = vl_set(v, d.vj, d.vlog, prm);
+            out.set(W_VL(i), v);
         }
         if (d.nmop & 1) out.set(W_MSG0 + d.midxA, d.mnewA);
         if (d.nmop & 2) out.set(W_MSG0 + d.midxB, d.mnewB);
@@ -1191,102 +1169,14 @@ struct SpecRaft {
         int pos = na;
 #pragma unroll
         for (int i = 0; i < NS; i++)
-            if (l.addmask >> i & 1) { if (pos < prm.ca) out.set(wall + pos, l.log.get(i)); pos++; }
-        return st;
-    }
-    template <bool KNOWN, class Ref>
-    MC_HD static unsigned apply_impl(const Params &prm, Ref s, int slot, uint64_t fp_known, WordRef out) {
-        Local l;
-        load<!KNOWN>(prm, s, l);
-        Delta d;
-        int action;
-        const unsigned st = compute<true>(prm, l, s, slot, d, action);
-        const int nw = words(prm);
-        if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) {
-            for (int w = 0; w < nw; w++) out.set(w, s.get(w));
-            return st;
-        }
-        // The arena is both source and destination, so the compiler keeps every load behind every earlier store: a loop of
-        // "read a parent word, write it" is one memory round trip per word (36 in a row: k_materialise spent 90 % of its time
-        // waiting).  The parent's words are therefore read in GROUPS, each group before its own stores.
-        const uint64_t fp_out = KNOWN ? fp_known : delta_fp(l, s, d);
-        uint64_t vl[NS * NS];
-#pragma unroll
-        for (int i = 0; i < NS; i++)
-#pragma unroll
-            for (int j = 0; j < NS; j++) vl[i * NS + j] = s.get(W_VLOG(i, j));
-        out.set(W_FP, fp_out);
-        out.set(W_GLOB, d.glob);
-        out.set(W_CLOG, d.clog);
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            const bool me = i == d.srv;
-            out.set(W_SRV(i), me ? d.sv : l.sv.get(i));
-            out.set(W_LOG(i), me ? d.log : l.log.get(i));
-#pragma unroll
-            for (int j = 0; j < NS; j++) {
-                uint64_t x = vl[i * NS + j];
-                if (me && d.vmode == 1) x = 0;
-                if (me && d.vmode == 2 && j == d.vj) x = d.vlog;
-                out.set(W_VLOG(i, j), x);
-            }
-        }
-        const int nm2 = g_nm(d.glob);
-        for (int k0 = 0; k0 < prm.cm; k0 += 4) {
-            uint64_t x[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = s.get(W_MSG0 + (k0 + u < l.nm ? k0 + u : 0));  // slot 0 exists whatever nMsgs is
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int k = k0 + u;
-                if (k < prm.cm) {
-                    uint64_t v = k < l.nm ? x[u] : 0;
-                    if ((d.nmop & 1) && d.midxA == k) v = d.mnewA;
-                    if ((d.nmop & 2) && d.midxB == k) v = d.mnewB;
-                    out.set(W_MSG0 + k, k < nm2 ? v : 0);
-                }
-            }
-        }
-        const int ne = g_ne(l.glob), wel = W_EL0(prm);
-        for (int e = 0; e < prm.ce; e++) {
-            uint64_t x[EL_WORDS];
-#pragma unroll
-            for (int q = 0; q < EL_WORDS; q++) x[q] = s.get(wel + (e < ne ? e : 0) * EL_WORDS + q);
-#pragma unroll
-            for (int q = 0; q < EL_WORDS; q++) {
-                uint64_t v = e < ne ? x[q] : 0;
-                if (d.eadd && e == ne) v = d.ew.get(q);
-                out.set(wel + e * EL_WORDS + q, v);
-            }
-        }
-        const int na = g_na(l.glob), wall = W_ALL0(prm);
-        // allLogs' = allLogs with the logs of `addmask` appended (raft.tla:493)
-        uint64_t add[NS];
-        int nadd = 0;
-#pragma unroll
-        for (int i = 0; i < NS; i++) add[i] = 0;
-#pragma unroll
-        for (int i = 0; i < NS; i++)
             if (l.addmask >> i & 1) {
+                if (pos < prm.ca) {
 #pragma unroll
-                for (int q = 0; q < NS; q++) if (q == nadd) add[q] = l.log.get(i);
-                nadd++;
-            }
-        for (int a0 = 0; a0 < prm.ca; a0 += 4) {
-            uint64_t x[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = s.get(wall + (a0 + u < na ? a0 + u : 0));
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int a = a0 + u;
-                if (a < prm.ca) {
-                    uint64_t v = a < na ? x[u] : 0;
-#pragma unroll
-                    for (int q = 0; q < NS; q++) if (a == na + q && q < nadd) v = add[q];
-                    out.set(wall + a, v);
+                    for (int q = 0; q < 16; q++) if (q == (pos >> 2)) aw[q] |= l.log.get(i) << (16 * (pos & 3));
                 }
+                pos++;
             }
-        }
+        for (int q = 0; q < naw; q++) out.set(wall + q, aw[q]);
         return st;
     }
 
@@ -1315,11 +1205,11 @@ struct SpecRaft {
             va_end(ap);
         }
     };
-    static void t_log(Txt &o, uint64_t lg) {
-        const int n = rlog::len(lg);
+    static void t_log(Txt &o, uint64_t lg, int tb) {
+        const int n = rlog::len(lg, tb);
         if (!n) { o.put("<<>>"); return; }
         o.put("<<");
-        for (int k = 1; k <= n; k++) { const unsigned e = rlog::entry(lg, k); o.put("%s[term |-> %d, value |-> %d]", k > 1 ? ", " : "", rlog::eterm(e), rlog::evalue(e)); }
+        for (int k = 1; k <= n; k++) { const unsigned e = rlog::entry(lg, k, tb); o.put("%s[term |-> %d, value |-> %d]", k > 1 ? ", " : "", rlog::eterm(e), rlog::evalue(e)); }
         o.put(">>");
     }
     static void t_servers(Txt &o, unsigned mask) {
@@ -1328,14 +1218,14 @@ struct SpecRaft {
         for (int j = 0; j < NS; j++) if (mask >> j & 1) { o.put("%ss%d", first ? "" : ", ", j + 1); first = false; }
         o.put("}");
     }
-    static void t_vlog(Txt &o, unsigned dom, const uint64_t *v) {
+    static void t_vlog(Txt &o, unsigned dom, uint64_t packed, const Params &prm) {
         if (!dom) { o.put("<<>>"); return; }
         o.put("(");
         bool first = true;
-        for (int j = 0; j < NS; j++) if (dom >> j & 1) { o.put("%ss%d :> ", first ? "" : " @@ ", j + 1); t_log(o, v[j]); first = false; }
+        for (int j = 0; j < NS; j++) if (dom >> j & 1) { o.put("%ss%d :> ", first ? "" : " @@ ", j + 1); t_log(o, vl_get(packed, j, prm), prm.tb); first = false; }
         o.put(")");
     }
-    static void t_msg(Txt &o, uint64_t m) {
+    static void t_msg(Txt &o, uint64_t m, int tb) {
         const int d = m_dst(m) + 1, sr = m_src(m) + 1, t = m_term(m);
         switch (m_type(m)) {
         case M_RVREQ:
@@ -1343,14 +1233,14 @@ struct SpecRaft {
                   d, (int)(m >> 16 & 7), (int)(m >> 13 & 7), sr, t);
             break;
         case M_RVRESP:
-            o.put("[mdest |-> s%d, mlog |-> ", d); t_log(o, (m >> 14) & ((1ull << 33) - 1ull));
+            o.put("[mdest |-> s%d, mlog |-> ", d); t_log(o, (m >> 14) & 0x7fffull, tb);
             o.put(", msource |-> s%d, mterm |-> %d, mtype |-> RequestVoteResponse, mvoteGranted |-> %s]", sr, t, (m >> 13 & 1) ? "TRUE" : "FALSE");
             break;
         case M_AEREQ: {
             o.put("[mcommitIndex |-> %d, mdest |-> s%d, mentries |-> ", (int)(m >> 26 & 7), d);
             const unsigned e = (unsigned)(m >> 20 & 63);
             if (m >> 19 & 1) o.put("<<[term |-> %d, value |-> %d]>>", rlog::eterm(e), rlog::evalue(e)); else o.put("<<>>");
-            o.put(", mlog |-> "); t_log(o, (m >> 29) & ((1ull << 33) - 1ull));
+            o.put(", mlog |-> "); t_log(o, (m >> 29) & 0x7fffull, tb);
             o.put(", mprevLogIndex |-> %d, mprevLogTerm |-> %d, msource |-> s%d, mterm |-> %d, mtype |-> AppendEntriesRequest]",
                   (int)(m >> 13 & 7), (int)(m >> 16 & 7), sr, t);
             break;
@@ -1374,39 +1264,40 @@ struct SpecRaft {
         Txt o{buf, cap, 0};
         char tmp[2048];
         char *it[64];
-        const uint64_t g = w[W_GLOB];
+        const uint64_t g = w[W_GLOB] & 0xffffffffull;
+        const int tb = prm.tb;
         o.put("/\\ messages = ");
-        for (int k = 0; k < g_nm(g); k++) { Txt e{tmp, sizeof tmp, 0}; t_msg(e, w[W_MSG0 + k]); e.put(" :> %d", m_count(w[W_MSG0 + k])); it[k] = strndup(tmp, e.k); }
+        for (int k = 0; k < g_nm(g); k++) { Txt e{tmp, sizeof tmp, 0}; t_msg(e, w[W_MSG0 + k], tb); e.put(" :> %d", m_count(w[W_MSG0 + k])); it[k] = strndup(tmp, e.k); }
         t_sorted(o, it, g_nm(g), "(", " @@ ", ")", "<<>>");
         o.put("\n/\\ elections = ");
         for (int x = 0; x < g_ne(g); x++) {
             Txt e{tmp, sizeof tmp, 0};
             const uint64_t *ew = w + W_EL0(prm) + x * EL_WORDS;
             const unsigned votes = (unsigned)(ew[0] >> 6 & 31);
-            e.put("[eleader |-> s%d, elog |-> ", (int)(ew[0] >> 3 & 7) + 1); t_log(e, (ew[0] >> 11) & ((1ull << 33) - 1ull));
-            e.put(", eterm |-> %d, evoterLog |-> ", (int)(ew[0] & 7)); t_vlog(e, votes, ew + 1);
+            e.put("[eleader |-> s%d, elog |-> ", (int)(ew[0] >> 3 & 7) + 1); t_log(e, (ew[0] >> 11) & 0x7fffull, tb);
+            e.put(", eterm |-> %d, evoterLog |-> ", (int)(ew[0] & 7)); t_vlog(e, votes, ew[1], prm);
             e.put(", evotes |-> "); t_servers(e, votes); e.put("]");
             it[x] = strndup(tmp, e.k);
         }
         t_sorted(o, it, g_ne(g), "{", ", ", "}", "{}");
         o.put("\n/\\ allLogs = ");
-        for (int a = 0; a < g_na(g); a++) { Txt e{tmp, sizeof tmp, 0}; t_log(e, w[W_ALL0(prm) + a]); it[a] = strndup(tmp, e.k); }
+        for (int a = 0; a < g_na(g); a++) { Txt e{tmp, sizeof tmp, 0}; t_log(e, rd_all(prm, CWordRef{w, 1}, a), tb); it[a] = strndup(tmp, e.k); }
         t_sorted(o, it, g_na(g), "{", ", ", "}", "{}");
 #define MC_PER_SERVER(title, expr)                                                             \
     o.put("\n/\\ " title " = (");                                                              \
-    for (int i = 0; i < NS; i++) { const uint64_t sv = w[W_SRV(i)]; (void)sv; o.put("%ss%d :> ", i ? " @@ " : "", i + 1); expr; } \
+    for (int i = 0; i < NS; i++) { const uint64_t sv = w[W_SRV(i)] & SVMASK; (void)sv; o.put("%ss%d :> ", i ? " @@ " : "", i + 1); expr; } \
     o.put(")");
         MC_PER_SERVER("currentTerm", o.put("%d", sv_term(sv)));
         MC_PER_SERVER("state", o.put("%s", stn[sv_state(sv)]));
         MC_PER_SERVER("votedFor", if (sv_voted(sv)) o.put("s%d", sv_voted(sv)); else o.put("Nil"));
         o.put("\n/\\ clientRequests = %d", g_creq(g));
-        MC_PER_SERVER("log", t_log(o, w[W_LOG(i)]));
+        MC_PER_SERVER("log", t_log(o, w[W_SRV(i)] >> LOGSH, tb));
         MC_PER_SERVER("commitIndex", o.put("%d", sv_commit(sv)));
-        o.put("\n/\\ committedLog = "); t_log(o, w[W_CLOG]);
+        o.put("\n/\\ committedLog = "); t_log(o, w[W_GLOB] >> 32, tb);
         o.put("\n/\\ committedLogDecrease = %s", g_decr(g) ? "TRUE" : "FALSE");
         MC_PER_SERVER("votesSent", o.put("FALSE"));
         MC_PER_SERVER("votesGranted", t_servers(o, sv_granted(sv)));
-        MC_PER_SERVER("voterLog", t_vlog(o, sv_granted(sv), w + W_VLOG(i, 0)));
+        MC_PER_SERVER("voterLog", t_vlog(o, sv_granted(sv), w[W_VL(i)], prm));
         MC_PER_SERVER("nextIndex", { o.put("("); for (int j = 0; j < NS; j++) o.put("%ss%d :> %d", j ? " @@ " : "", j + 1, sv_next(sv, j)); o.put(")"); });
         MC_PER_SERVER("matchIndex", { o.put("("); for (int j = 0; j < NS; j++) o.put("%ss%d :> %d", j ? " @@ " : "", j + 1, sv_match(sv, j)); o.put(")"); });
 #undef MC_PER_SERVER
