@@ -7,11 +7,14 @@ frozen model configuration from Init to the budget level (every level: expand ->
 -> materialise), starting from a cleared seen-set.  Nothing is cached between steps.
 
 Workload (BASELINE.json configs[2] "single-GPU full BFS"): examples/raft.tla under
-specs/MCraft.cfg — Server = {s1,s2,s3}, MaxClientRequests = 4 (=> MaxLogLen 3), MaxTerm = 2,
-MaxMsgs = 1, MaxMsgKeys = 10, INVARIANT NoTwoLeaders — the COMPLETE state graph: 102,586,254 distinct /
-1,217,433,925 generated / depth 33, verdict "ok" with nothing left on the queue (golden per-level counts
+specs/MCraft_t3.cfg — Server = {s1,s2,s3}, MaxClientRequests = 4 (=> MaxLogLen 3), MaxTerm = 3,
+MaxMsgs = 1, MaxMsgKeys = 8, INVARIANT NoTwoLeaders — the COMPLETE state graph: 525,782,408 distinct /
+6,708,500,293 generated / depth 33, verdict "ok" with nothing left on the queue (golden per-level counts
 from the exact-dedup CPU oracle in tests/golden/raft_levels.json; the line is refused unless the run
-reproduces them).
+reproduces them).  `--workload k10` is rounds 1-2's line (MaxTerm = 2, MaxMsgKeys = 10: 102,586,254 states).
+
+`python bench.py --gpus N` (N > 1) starts its own N ranks, one per GPU; each builds the RCCL communicator (mc_comm_*) and
+runs the library's sharded level loop (mc_shard_run) on the SAME complete graph ("scaling": "strong").
 """
 import argparse
 import json
@@ -36,6 +39,16 @@ WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 10, 1, 4, 10], golden="ra
 WORKLOAD_K11 = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 11, 1, 4, 11], golden="raft3_mcr4_t2_m1_k11_complete",
                     name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=11 "
                          "(specs/MCraft.cfg with MaxMsgKeys = 11), complete state graph")
+# DEFAULT since round 3: the complete graph of the same model with MaxTerm = 3 — two elections, leader
+# changes, the conflict-truncate branch of HandleAppendEntriesRequest reachable (with MaxTerm = 2 exactly one term of elections is
+# explored and NoTwoLeaders is trivially true) — bounded by MaxMsgKeys = 8: 525 782 408 distinct / 6 708 500 293 generated / depth
+# 33, verified by the exact-dedup oracle on the GPU box's host (tests/golden/raft_levels.json `source`); one step = 0.24 s of GPU time.
+# Slot capacities 8 / 2 / 4 = the oracle's maxima (two election records now).  W = 2 + 2*3 + 8 + 2*2 + 1 = 21 words = 168 B.
+WORKLOAD_T3 = dict(spec="raft", params=[3, 4, 3, 3, 1, 1, 8, 2, 4, 8], golden="raft3_mcr4_t3_m1_k8_complete",
+                   name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=3 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=8 "
+                        "(specs/MCraft_t3.cfg), complete state graph")
+WORKLOADS = {"t3": WORKLOAD_T3, "k10": WORKLOAD, "k11": WORKLOAD_K11}
+TABLE_SLOTS = {"t3": 17 << 26, "k10": 3 << 26, "k11": 5 << 27}   # seen-set load ~0.46 / 0.51 / 0.50 at the end of the run
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 XGMI_PEAK_GBS = 7 * 153.0  # MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point
 
@@ -86,9 +99,42 @@ def comm_id(rank, world):
     return bytes(uid), store
 
 
+def kernel_source_hash():
+    """the stamp profiles/summarize_pmc.py puts into a PMC summary: the kernel sources the counters were collected on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tla_rust_amd/csrc/engine.hip", "tla_rust_amd/csrc/spec_raft.h", "tla_rust_amd/csrc/mc_common.h"):
+        h.update((ROOT / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def golden():
     g = json.loads((ROOT / "tests" / "golden" / "raft_levels.json").read_text())
     return next(c for c in g["cases"] if c["name"] == WORKLOAD["golden"])
+
+
+def usable_cores():
+    """cores this process may really use: the affinity mask and the cgroup CPU quota, not just the box's core count (round 3: the
+    256-core GPU box gives its container ~16 cores' worth of CPU time — user time of a 192-thread run / its wall time = 15.9)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return n, quota
 
 
 def cpu_baseline(max_seconds=10.0):
@@ -100,24 +146,36 @@ def cpu_baseline(max_seconds=10.0):
     exe = ROOT / "oracle" / "_build" / "oracle_mc"
     if not exe.exists():
         subprocess.run(["make", "-s", "-C", str(ROOT / "oracle")], check=True)
-    cores = os.cpu_count() or 1
+    host_cores, quota = usable_cores()
+    # threads: every core the process may use; under a CPU quota four threads per core's worth of quota (measured on the GPU
+    # box, quota 16 of 256 cores: 64 threads 4.8 M states/s, 256 threads 2.8 M — throttled threads holding blocks of work)
+    cores = host_cores if not quota else max(1, min(host_cores, int(4 * quota + 0.5)))
     p = [str(x) for x in WORKLOAD["params"][:6]] + ["0", str(WORKLOAD["params"][9])]
 
     def sample(threads, seconds):
+        t0 = time.perf_counter()
+        c0 = os.times()
         out = subprocess.run([str(exe), "raft", *p, "--threads", str(threads), "--max-seconds", str(seconds), "--distinct", "200000000"],
                              capture_output=True, text=True, check=True).stdout
-        return json.loads(out.splitlines()[0])
+        c1 = os.times()
+        r = json.loads(out.splitlines()[0])
+        # CPU time the sample really got / its wall time = the cores it ran on (a container may be throttled far below nproc)
+        r["cores_used"] = (c1.children_user + c1.children_system - c0.children_user - c0.children_system) / max(1e-9, time.perf_counter() - t0)
+        return r
 
     r = sample(cores, max_seconds)
-    table = [dict(threads=t, value=(q := sample(t, 3.0))["distinct"] / q["seconds"], levels=q["depth"]) for t in (1, 8, 64) if t < cores]
-    table.append(dict(threads=cores, value=r["distinct"] / r["seconds"], levels=r["depth"]))
+    table = [dict(threads=t, value=(q := sample(t, 3.0))["distinct"] / q["seconds"], levels=q["depth"], cores_used=round(q["cores_used"], 1))
+             for t in (1, 8, 64) if t < cores]
+    table.append(dict(threads=cores, value=r["distinct"] / r["seconds"], levels=r["depth"], cores_used=round(r["cores_used"], 1)))
     # stock TLC on the same box would be the preferred baseline — probe for it every time and say what was found
     import shutil
     java = shutil.which("java")
     jar = next((str(q) for d in ("/usr/share/java", "/opt", str(Path.home())) if Path(d).is_dir() for q in Path(d).glob("**/tla2tools.jar")), None) if java else None
     tlc = f"java at {java}, tla2tools.jar {'at ' + jar if jar else 'not found'}" if java else "no java on PATH"
     return dict(tlc_probe=tlc, value=r["distinct"] / r["seconds"], unit="distinct states/s", cores=cores, kind="port", scaling=table,
-                sample=f"not TLC (no JVM on the box): in-house exact-dedup multi-threaded C BFS, {cores} threads, same cfg, "
+                cores_used=round(r["cores_used"], 1), cgroup_cpu_quota=quota,
+                sample=f"not TLC (no JVM on the box): in-house exact-dedup multi-threaded C BFS, {cores} threads on "
+                       f"{r['cores_used']:.1f} cores' worth of CPU time (nproc {host_cores}, cgroup quota {quota}), same cfg, "
                        f"levels 1-{r['depth']} = {r['distinct']} distinct / {r['generated']} generated states in {r['seconds']:.1f} s "
                        f"(a sample stops after the level that exceeds its time; deeper levels have more duplicates per distinct state)")
 
@@ -133,19 +191,22 @@ def main():
     ap.add_argument("--shard-chunk", type=int, default=1 << 21, help="frontier states per round and rank in the sharded (--gpus N) path")
     ap.add_argument("--packed-fanout", type=int, default=16, help="in-model successors per state the fixed-capacity exchange buckets allow for")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank on GPU 0 (needs a librccl stand-in in $TLAMC_RCCL; RCCL refuses it)")
-    ap.add_argument("--table-slots", type=int, default=3 << 26, help="seen-set slots (any multiple of 64): 1.5 * 2^27 = 1.6 GB, load 0.51 at the end of the run")
+    ap.add_argument("--workload", choices=["t3", "k10", "k11"], default="t3", help="t3: MaxTerm 3, MaxMsgKeys 8 (525.8 M states, the contract line); "
+                    "k10 / k11: MaxTerm 2 with 10 / 11 message keys (102.6 M / 336.6 M states; rounds 1-2's line was k10)")
+    ap.add_argument("--table-slots", type=int, default=0, help="seen-set slots (any multiple of 64; 0 = the workload's default, load ~0.5 at the end)")
     ap.add_argument("--table-log2", type=int, default=0, help="A/B: a power-of-two seen-set (27: load 0.76, 28: load 0.38)")
-    ap.add_argument("--msg-keys", type=int, default=10, choices=[10, 11], help="11: the 3.4e8-state graph (165 ms/step) instead of the contract workload")
+    ap.add_argument("--msg-keys", type=int, default=0, choices=[0, 10, 11], help="(rounds 1-2) same as --workload k10 / k11")
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
-    ap.add_argument("--no-dense", action="store_true", help="A/B: Restart / Timeout through the family queues instead of inline")
+    ap.add_argument("--occ3", action="store_true", help="A/B: by-family expand kernel compiled for 3 waves per SIMD (no register spills)")
     ap.add_argument("--no-filter", action="store_true", help="A/B: without the per-wavefront duplicate filter in front of the seen-set")
     a = ap.parse_args()
-    if a.msg_keys == 11:
-        global WORKLOAD
-        WORKLOAD = WORKLOAD_K11
-        if a.table_slots == 3 << 26:
-            a.table_slots = 5 << 27   # load 0.50
+    global WORKLOAD
+    if a.msg_keys:
+        a.workload = "k%d" % a.msg_keys
+    WORKLOAD = WORKLOADS[a.workload]
+    if not a.table_slots:
+        a.table_slots = TABLE_SLOTS[a.workload]
 
     launched = "RANK" in os.environ
     if a.gpus > 1 and not launched:
@@ -166,7 +227,7 @@ def main():
     comm = store = None
     if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=slots, matrix=a.matrix,
-                         debug_flags=(32 if a.no_family else 0) | (32768 if a.no_dense else 0) | (8192 if a.no_filter else 0),
+                         debug_flags=(32 if a.no_family else 0) | (2048 if a.occ3 else 0) | (8192 if a.no_filter else 0),
                          arena_capacity=G0["distinct"] + (1 << 20),
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run
@@ -263,6 +324,9 @@ def main():
         if pmc:  # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same command
             try:
                 d = json.loads(pmc[-1].read_text())
+                stamp = d.get("__source__", {}).get("hash")
+                if stamp != kernel_source_hash():   # counters of other kernels say nothing about the ones timed here
+                    raise ValueError(f"{pmc[-1].name} was collected on kernel sources {stamp}, the timed ones are {kernel_source_hash()}")
                 knames = {"expand": ("k_expand_direct",) if direct else ("k_expand_insert",) if a.no_family else ("k_expand_family", "k_expand_insert"),
                           "insert": ("k_insert",), "materialise": ("k_materialise",)}[dom]
                 k = next(v for kn in knames for n, v in d.items() if n.startswith(kn + "<") and "Raft<3>" in n)
@@ -275,8 +339,9 @@ def main():
                 traffic_lower = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
                 l2_hit = k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) if "TCC_HIT_sum" in k else None
                 traffic_src = f"profiles/{pmc[-1].name}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes of this command"
-            except Exception:  # noqa: BLE001
-                traffic = None
+            except Exception as e:  # noqa: BLE001
+                traffic, traffic_lower, l2_hit = None, None, None
+                traffic_src = f"none: {e}"
         kernel_name = {"expand": "k_expand_direct<SpecRaft<3>>" if direct else "k_expand_insert<SpecRaft<3>>" if (a.no_family or a.matrix) else "k_expand_family<SpecRaft<3>>",
                        "insert": "k_insert", "materialise": "k_materialise<SpecRaft<3>>"}[dom]
         line["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -284,7 +349,10 @@ def main():
                             "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
                             "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
                             "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
-                            "pipeline_GBs": (2 * W * D + 8 * G) / (1e-3 * sum(ks[k]["ms_total"] for k in ("expand", "insert", "materialise"))) / 1e9}
+                            # (2 W + 8 G/D) bytes per distinct state over the WALL time of a step
+                            "pipeline_GBs": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9,
+                            "pipeline_frac": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                            "state_bytes": W}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     print(json.dumps(line), flush=True)

@@ -83,10 +83,7 @@ typedef struct {
 #define MC_F_MATRIX 8u   /* A/B only: unfused expand -> candidate matrix -> insert kernels          */
 #define MC_F_NOPROBE 16u /* profiling only (mc_engine_debug_reexpand): skip the seen-set probes   */
 #define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
-#define MC_F_DIRECT 1024u /* A/B only: one kernel per chunk (expand + insert + copy-and-patch write, k_expand_direct) instead of
-                          * expand and materialise on two streams; measured slower, kept for the comparison */
-#define MC_F_NODENSE 32768u  /* A/B only: Restart / Timeout slots of raft through the family queues instead of inline, lane = parent */
-#define MC_F_OCC3 2048u      /* A/B only, with MC_F_DIRECT: k_expand_direct compiled for 3 wavefronts per SIMD */
+#define MC_F_OCC3 2048u      /* A/B only: the by-family expand kernel compiled for 3 wavefronts per SIMD (146 VGPRs, no spills) instead of 4 */
 #define MC_F_NOFILTER 8192u  /* A/B only: by-family expand kernel without the per-wavefront duplicate filter in front of the seen-set */
 #define MC_F_PROGRESS 16384u /* mc_check_files: print TLC's "Progress(d): ..." lines (testout2:4-259) to stdout while the search runs,
                               * at most one per second */
@@ -177,6 +174,9 @@ int mc_engine_checkpoint(mc_engine *e, const char *path);
 int mc_engine_restore(mc_engine *e, const char *path);
 /* profiling aid: re-expand every resident state of the last run (all probes hit); extra_flags 16 = no probes */
 int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms);
+/* profiling builds only (libtlamc.so compiled with -DMC_PHASE_PROF, profiles/phase_prof.sh): shader-clock cycles per phase of the
+ * by-family expand kernel summed over all wavefronts since the last reset (48 words: layout in engine.hip); MC_ESTATE otherwise */
+int mc_engine_debug_phases(mc_engine *e, uint64_t *out48, int reset);
 void mc_engine_destroy(mc_engine *e);
 
 /* ------------------------------------------------------------------ sharded (multi-GPU) step API
@@ -307,7 +307,7 @@ typedef struct {
     uint64_t packed_fanout;   /* in-model successors per expanded state the fixed-capacity buckets allow for (0 = 16); a
                                * level that exceeds it fails with MC_EARENA, it is never truncated                          */
     uint64_t stay_threshold;  /* states per rank a level needs before its new states STAY where they were generated
-                               * (0 = 2^16); smaller levels MOVE every new state to its owner, which is what spreads a
+                               * (0 = 2^15); smaller levels MOVE every new state to its owner, which is what spreads a
                                * small frontier over the ranks                                                              */
     double rebalance_ratio;   /* a level whose largest per-rank frontier exceeds ratio x the mean is a MOVE level again:
                                * a drifting rank cannot stall the level loop (0 = 1.25)                                     */

@@ -2,8 +2,22 @@
 Usage: python profiles/summarize_pmc.py out.json file.csv [file.csv ...]"""
 import collections
 import csv
+import hashlib
 import json
 import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+KERNEL_SOURCES = ["tla_rust_amd/csrc/engine.hip", "tla_rust_amd/csrc/spec_raft.h", "tla_rust_amd/csrc/mc_common.h"]
+
+
+def kernel_source_hash():
+    """identifies the kernels a counter pass was taken on: bench.py refuses traffic numbers whose stamp is not the timed library's"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update((ROOT / f).read_bytes())
+    return h.hexdigest()[:16]
+
 
 out = collections.defaultdict(dict)
 for path in sys.argv[2:]:
@@ -16,6 +30,7 @@ for path in sys.argv[2:]:
     for k, d in agg.items():
         out[k].update(d)
         out[k]["launches"] = len(launches[k])
+out["__source__"] = {"hash": kernel_source_hash(), "files": KERNEL_SOURCES}
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 for k, d in out.items():
     if "k_" in k:

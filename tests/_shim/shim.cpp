@@ -114,34 +114,38 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
         S::summarize(l, q);
         uint64_t bad = 0;
         unsigned cnt[32] = {};
-        {   // load_expand (the kernel's phase A: the whole row at once, per-message guard codes) == load + guards + guard_msg
+        typename S::Guards g2c;
+        {   // load_expand (the kernel's phase A: the whole row at once, in-flight mask) == load + guards
             typename S::Local l2;
             typename S::Guards g2;
             S::load_expand(p, s, l2, g2);
+            g2c = g2;
             bool same = l2.fp == l.fp && l2.glob == l.glob && l2.clog == l.clog && l2.nm == l.nm && l2.inflight == l.inflight &&
                         l2.addmask == l.addmask && l2.nadd == l.nadd && l2.add_fp == l.add_fp && l2.vany == l.vany && l2.dig == l.dig &&
                         l2.sig.w0 == l.sig.w0 && l2.sig.w1 == l.sig.w1 && l2.sig.w2 == l.sig.w2 && l2.sig.w3 == l.sig.w3 &&
-                        g2.fixed == g.fixed && g2.terms == g.terms;
+                        g2.fixed == g.fixed;
             for (int i = 0; i < p.n; i++) same = same && l2.sv.get(i) == l.sv.get(i) && l2.log.get(i) == l.log.get(i) && l2.vlh.get(i) == l.vlh.get(i);
-            for (int k = 0; k < l.nm && k < S::GUARD_SLOTS; k++)
-                for (int kind = 0; kind < 3; kind++) same = same && S::guard_code(g2, k, kind) == S::guard_msg(g, s.get(S::W_MSG0 + k), kind);
+            for (int k = 0; k < l.nm && k < S::GUARD_SLOTS; k++)   // the in-flight mask names exactly the messages with count > 0
+                same = same && ((S::inflight_slots(g2) >> k & 1u) != 0) == (S::m_count(s.get(S::W_MSG0 + k)) > 0);
             if (!same) bad++;
         }
         for (int slot = 0; slot < ns; slot++) {
             uint64_t f0 = 0, f1 = 0;
             const unsigned st0 = S::eval(p, l, s, slot, f0);
             int fam = -1;
-            if (slot < S::FIX) { if (g.fixed >> slot & 1) fam = S::fixed_family(slot); }
-            else fam = S::guard_msg(g, s.get(S::W_MSG0 + (slot - S::FIX) / 3), (slot - S::FIX) % 3);
+            // queued: the sparse fixed slots (the dense pairs, slots < DENSE_SLOTS, and the message slots are evaluated by eval itself)
+            const bool queued = slot >= S::DENSE_SLOTS && slot < S::FIX;
+            if (queued && (g.fixed >> slot & 1)) fam = S::fixed_family(slot);
             const unsigned st1 = fam >= 0 ? run<0>(fam, p, q, s, slot, f1) : 0u;
             // (a stuttering step carries no fingerprint through the by-family path: the flag alone drops it)
-            if (st0 != st1 || ((st0 & ST_ENABLED) && !(st0 & ST_SELFLOOP) && f0 != f1)) bad++;
+            if (queued && (st0 != st1 || ((st0 & ST_ENABLED) && !(st0 & ST_SELFLOOP) && f0 != f1))) bad++;
+            if (!queued && slot >= S::FIX && (st0 & ST_ENABLED) && !(S::inflight_slots(g2c) >> ((slot - S::FIX) / 3) & 1u) && (slot - S::FIX) / 3 < S::GUARD_SLOTS) bad++;  // enabled but not in flight
             if (st0 & ST_SELFLOOP) {  // claimed stuttering step: apply() must reproduce the parent word for word
                 uint64_t a[S::MAX_WORDS];
                 S::apply(p, s, slot, WordRef{a, 1});
                 for (int w = 0; w < S::words(p); w++) if (a[w] != s.get(w)) { bad++; break; }
             }
-            if ((st1 & ST_ENABLED) && !(st1 & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR | ST_ASSERT | ST_SELFLOOP))) {
+            if (queued && (st1 & ST_ENABLED) && !(st1 & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR | ST_ASSERT | ST_SELFLOOP))) {
                 uint64_t a[S::MAX_WORDS];
                 S::apply(p, s, slot, WordRef{a, 1});
                 if (S::fp_of(p, CWordRef{a, 1}) != f1) bad++;  // the successor carries the fingerprint the by-family evaluation announced

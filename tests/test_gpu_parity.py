@@ -144,16 +144,31 @@ def test_raft_complete_graphs_on_gpu(amd, oracle, name, caps):
 
 
 def test_bench_workload_complete_on_gpu(amd, oracle):
-    """bench.py's workload = BASELINE config 3 = specs/MCraft.cfg: the COMPLETE graph of raft.tla with 3 servers, 102 586 254 states,
-    with the slot capacities bench.py uses (10 / 1 / 4 = the oracle's maxima, W = 288 B) and its seen-set load (0.76)."""
+    """rounds 1-2's bench workload (`bench.py --workload k10`) = specs/MCraft.cfg: the COMPLETE graph of raft.tla with 3 servers and
+    MaxTerm = 2, 102 586 254 states, with the slot capacities bench.py uses (10 / 1 / 4 = the oracle's maxima; W = 168 B since the
+    compact layout of round 3, 288 B before) and a seen-set load of 0.76."""
     c = _golden("raft3_mcr4_t2_m1_k10_complete")
     params = oracle.raft_device_params(c["params"], 10, 1, 4)
-    assert params == [3, 4, 2, 3, 1, 1, 10, 1, 4, 10] and amd.state_bytes("raft", params) == 288
+    assert params == [3, 4, 2, 3, 1, 1, 10, 1, 4, 10] and amd.state_bytes("raft", params) == 168
     assert c["max_stat"][:3] == [10, 1, 4]
     eng = amd.Engine("raft", params, table_capacity=1 << 27, arena_capacity=c["distinct"] + (1 << 16), chunk_states=1 << 22, trace=False)
     r = eng.run()
     assert r.levels == c["levels"]
     assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (102586254, 1217433925, 33, "ok", 0)
+    eng.close()
+
+
+def test_contract_bench_workload_complete_on_gpu(amd, oracle):
+    """bench.py's DEFAULT workload since round 3 = specs/MCraft_t3.cfg: MaxTerm = 3 (two elections, leader changes, conflict-truncate
+    reachable), MaxMsgKeys = 8: the COMPLETE graph, 525 782 408 states / 6 708 500 293 generated / depth 33, every one of the 33
+    per-level counts equal to the exact-dedup oracle's (run on the GPU box's host: tests/golden/raft_levels.json `source`)."""
+    c = _golden("raft3_mcr4_t3_m1_k8_complete")
+    params = oracle.raft_device_params(c["params"], 8, 2, 4)
+    assert params == [3, 4, 3, 3, 1, 1, 8, 2, 4, 8] and amd.state_bytes("raft", params) == 168 and c["max_stat"][:3] == [8, 2, 4]
+    eng = amd.Engine("raft", params, table_capacity=17 << 26, arena_capacity=c["distinct"] + (1 << 16), chunk_states=1 << 22, trace=False)
+    r = eng.run()
+    assert r.levels == c["levels"]
+    assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (525782408, 6708500293, 33, "ok", 0)
     eng.close()
 
 
@@ -176,7 +191,7 @@ def test_bench_workload_with_tuned_capacities(amd):
     c = _golden("raft3_mcr4_t2_m1_bench")
     eng = amd.Engine("raft", c["params"] + [16, 2, 8], table_capacity=1 << 27, arena_capacity=30_000_000, chunk_states=1 << 19,
                      max_distinct=c["max_distinct"], trace=False)
-    assert amd.state_bytes("raft", c["params"] + [16, 2, 8]) == 400
+    assert amd.state_bytes("raft", c["params"] + [16, 2, 8]) == 240
     r = eng.run()
     assert r.levels == c["levels"] and (r.distinct, r.generated) == (c["distinct"], c["generated"])
     eng.close()

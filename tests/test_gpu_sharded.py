@@ -270,7 +270,7 @@ def test_bench_contract_invocation_with_several_ranks(world):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--share-gpu"],
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--share-gpu", "--workload", "k10"],
                        capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=str(root))
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     line = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))

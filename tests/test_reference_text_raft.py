@@ -54,7 +54,7 @@ def test_fixture_is_what_the_reference_text_gives(name):
     assert {k: r[k] for k in g} == g
 
 
-@pytest.mark.parametrize("name", ["raft_2s_mcr2_keys8", "raft_3s_keys4", "raft_3s_keys5"])
+@pytest.mark.parametrize("name", ["raft_2s_mcr2_keys8", "raft_3s_keys4", "raft_3s_keys5", "raft_3s_keys6"])
 def test_lowering_equals_reference_text_fixture(name, tmp_path):
     """the DEVICE lowering (tla_rust_amd/csrc/spec_raft.h, host build) against the fixture made from the reference's text — three
     servers included, where a quorum is a real majority: counters, per-level counts, per-level state-set digests"""

@@ -31,6 +31,10 @@ def build(force=False, verbose=False):
     # files it really depends on changed (a TU instantiates the kernels of its own spec header only).
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result",
               "-I", str(PKG.parent / "include")]
+    if os.environ.get("TLAMC_LINE_TABLES"):  # source lines for rocprofv3's PC sampling (profiles/pcsample.sh); code generation unchanged
+        common.append("-gline-tables-only")
+    if os.environ.get("TLAMC_PHASE_PROF"):   # per-phase cycle counters inside k_expand_family (profiles/phase_prof.py): a profiling build
+        common.append("-DMC_PHASE_PROF")
     base = [CSRC / "engine.hip", CSRC / "mc_common.h", CSRC / "spec_registry.h", PKG.parent / "include" / "tlamc.h"]
     own = {0: ["spec_pluscal.h", "spec_raft.h", "spec_ssi.h", "spec_vm.h", "spec_paxos.h"], 7: ["spec_paxos.h"], 1: ["spec_pluscal.h"], 2: ["spec_raft.h"],
            3: ["spec_raft.h"], 4: ["spec_raft.h"], 5: ["spec_ssi.h"], 6: ["spec_vm.h"]}

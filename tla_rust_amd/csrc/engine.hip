@@ -565,16 +565,39 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
 
 
 // ------------------------------------------------------------------------------------- expand BY ACTION FAMILY
-// For specs with many action kinds (raft: 13 families).  In k_expand_insert every slot body runs for the
+// For specs with many action kinds (raft).  In k_expand_insert every slot body runs for the
 // whole wavefront as soon as ONE lane is enabled — about a quarter of the lanes do useful work, and the
-// Receive slot executes every message handler in turn.  Here the work is re-bucketed:
-//   phase A  lane = parent: cheap, exact guards only; each enabled (parent lane, slot) pair is appended to the
-//            LDS ring queue of its action family;
+// Receive slot executes every message handler in turn.  Here the work is split three ways:
+//   dense    lane = parent: the slots nearly every state enables (raft: Restart / Timeout), evaluated in pairs;
+//   inline   lane = parent: the actions on a parent's IN-FLIGHT messages (raft: Receive / Duplicate / Drop of at most MaxMsgs
+//            messages, whatever the size of the bag), the message word and its hash shared by the three;
+//   phase A  lane = parent: cheap, exact guards of the sparse fixed slots; each enabled (parent lane, slot) pair is appended
+//            to the LDS ring queue of its action family;
 //   phase B  as soon as a family has 64 pairs queued, the wavefront evaluates 64 pairs of THAT family — every
 //            lane busy, one code path — reading the pair's parent straight from the arena (the 64 parents of a
 //            wavefront are one arena block, so lanes reading word w of different parents hit one 512-byte row).
 // The fingerprints then go through the same probe / route queues as in k_expand_insert.
 constexpr int FQCAP = 128;
+
+// Phase profile of k_expand_family (build with -DMC_PHASE_PROF: profiles/phase_prof.sh — rocprofv3's PC sampling is not
+// available for gfx950 in this image).  Every wavefront accumulates shader-clock cycles per phase — nested phases are exclusive:
+// switching to a phase charges the time since the last switch to the phase that was current — and adds them to g_phase at exit.
+//   0 load_expand + summarize | 1 dense pairs (Restart / Timeout) | 2 enqueue (filter, probe ring) | 3 flush_probe (seen-set)
+//   4 flush_out (new-list) | 5 push loop of the fixed slots | 6 push loop of the message slots | 7 epilogue
+//   8 + f: phase B of family f (eval_pair) | 24 + f: pairs evaluated of family f | 40: wavefronts
+#ifdef MC_PHASE_PROF
+__device__ unsigned long long g_phase[48];
+#define MC_PROF_DECL unsigned long long pf_t = wall_clock64(), pf_acc[24] = {}; int pf_cur = 0; unsigned long long pf_pairs[16] = {};
+#define MC_PROF(ph) do { const unsigned long long pf_n = wall_clock64(); pf_acc[pf_cur] += pf_n - pf_t; pf_t = pf_n; pf_cur = (ph); } while (0)
+#define MC_PROF_PAIRS(f, n) do { pf_pairs[(f)] += (n); } while (0)
+#define MC_PROF_END do { MC_PROF(7); if (lane == 0) { for (int q_ = 0; q_ < 24; ++q_) if (pf_acc[q_]) atomicAdd(&g_phase[q_], pf_acc[q_]); \
+    for (int q_ = 0; q_ < 16; ++q_) if (pf_pairs[q_]) atomicAdd(&g_phase[24 + q_], pf_pairs[q_]); atomicAdd(&g_phase[40], 1ull); } } while (0)
+#else
+#define MC_PROF_DECL
+#define MC_PROF(ph) do { } while (0)
+#define MC_PROF_PAIRS(f, n) do { } while (0)
+#define MC_PROF_END do { } while (0)
+#endif
 
 // number of leading fixed slots a by-family spec wants evaluated inline, lane = parent (S::DENSE_SLOTS; 0 if absent)
 template <class S, class = void>
@@ -588,6 +611,12 @@ struct DenseSlots<S, decltype((void)S::DENSE_SLOTS)> : std::integral_constant<in
 // inserted — by this very wavefront, so it is dropped before it costs a random 64-byte read of HBM.  Sound: an entry is only
 // ever a fingerprint this wavefront handed to the seen-set.
 constexpr int WFILT = 256;
+// specs whose message actions are evaluated inline, lane = parent (S::inflight_slots; see k_expand_family)
+template <class S, class = void>
+struct InlineMsgs : std::false_type {};
+template <class S>
+struct InlineMsgs<S, decltype((void)&S::inflight_slots)> : std::true_type {};
+
 template <class S, int NB>
 struct FamLds {
     uint16_t fq[S::NFAM][FQCAP];   // (slot << 8) | (block << 6) | parent lane
@@ -609,7 +638,10 @@ __device__ __forceinline__ void family_dispatch(int fam, Fn &&fn) {
 // NB * 64 parents instead of once per 64: phase B's lane utilisation goes from ~80 % (NB = 1) towards 95 % (NB = 4).
 // MINW = wavefronts per SIMD the register allocation leaves room for: 4 = at most 128 VGPRs (no spills), 5 = at most 96
 // (a few dozen spilled VGPRs, one more wavefront per SIMD to hide the probe / gather latency behind)
-template <class S, bool ROUTE, int NB, int MINW = 4>
+#ifndef MC_EXPAND_MINW
+#define MC_EXPAND_MINW 4
+#endif
+template <class S, bool ROUTE, int NB, int MINW = MC_EXPAND_MINW>
 __global__ void __launch_bounds__(256, MINW)
 k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
@@ -650,8 +682,10 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     };
     const unsigned shard = blockIdx.x & (NSHARD - 1), pshard = parity * NSHARD + shard;
     uint32_t *__restrict__ seg = newlist + (uint64_t)pshard * seg_cap;
+    MC_PROF_DECL
 
     auto flush_out = [&](unsigned take) {
+        MC_PROF(4);
         unsigned long long pos = 0;
         if (lane == 0) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)take);
         pos = __shfl(pos, 0);
@@ -661,8 +695,10 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         }
         ohead = (ohead + take) & (QCAP - 1);
         on -= take;
+        MC_PROF(3);
     };
     auto flush_probe = [&](unsigned take) {
+        MC_PROF(3);
         bool is_new = false;
         uint32_t src = 0;
         uint64_t qfp = 0;
@@ -727,6 +763,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             wave_lds_fence();
             if (on >= 64) flush_out(64);
         }
+        MC_PROF(2);
     };
     // append the lanes of `b` (each with its slot) to family f's queue; returns true when it holds >= 64 pairs
     auto fam_push = [&](int f, unsigned long long b, bool mine, unsigned entry) -> bool {
@@ -737,7 +774,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         return nc >= 64;
     };
     // a lane's candidate (fp != 0) joins the probe ring; 64 queued candidates are probed (or routed) at once
-    auto enqueue = [&](uint64_t fp, uint32_t src) {
+    auto enqueue = [&](uint64_t fp, uint32_t src, int back_to) {
+        MC_PROF(2);
         const unsigned long long b0 = __ballot(fp != 0);
         if (b0) {
             cands += (unsigned)__popcll(b0);
@@ -746,6 +784,9 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 if (FL.filt[h] == fp) fp = 0;  // this wavefront has queued it before
                 else FL.filt[h] = fp;
             }
+            // (measured and NOT adopted, round 3: touching the candidate's home bucket here, so that the probe a few microseconds
+            //  later hits L2 — 40.9 ms per step against 38.5 without, profiles/r03g: the extra request per candidate costs more
+            //  than the latency it hides)
             const unsigned long long b = __ballot(fp != 0);
             if (fp) {
                 const unsigned k = (qhead + qn + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
@@ -756,9 +797,13 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             wave_lds_fence();
             if (qn >= 64) flush_probe(64);
         }
+        MC_PROF(back_to);
+        (void)back_to;
     };
     // phase B: evaluate `take` queued pairs of family f (f is wave-uniform)
-    auto run_family = [&](int f, unsigned take) {
+    auto run_family = [&](int f, unsigned take, int back_to) {
+        MC_PROF(8 + f);
+        MC_PROF_PAIRS(f, take);
         const unsigned h = fget(fheadA, fheadB, f);
         wave_lds_fence();  // queue entries written by fam_push are visible
         uint64_t fp = 0;
@@ -787,14 +832,14 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         }
         fset(fheadA, fheadB, f, (h + take) & (FQCAP - 1));
         fset(fcntA, fcntB, f, fget(fcntA, fcntB, f) - take);
-        enqueue(fp, src);
+        enqueue(fp, src, back_to);
         wave_lds_fence();
     };
-    auto run_full = [&](unsigned fullmask, bool drain) {
+    auto run_full = [&](unsigned fullmask, bool drain, int back_to) {
         while (fullmask) {
             const int f = __ffs((int)fullmask) - 1;
             const unsigned c = fget(fcntA, fcntB, f);
-            run_family(f, drain ? (c < 64 ? c : 64u) : 64u);
+            run_family(f, drain ? (c < 64 ? c : 64u) : 64u, back_to);
             if (fget(fcntA, fcntB, f) < (drain ? 1u : 64u)) fullmask &= ~(1u << f);
         }
     };
@@ -807,10 +852,10 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         const BlockRef g{blk_base, lane};
         typename S::Guards gd;
         gd.fixed = 0;
-        gd.terms = 0;
-        gd.mc0 = gd.mc1 = 0;
+        gd.infl = 0;
         int nm = 0;
         typename S::Local loc;
+        MC_PROF(0);
         if (active) {
             S::load_expand(prm, g, loc, gd);  // the whole row in one round trip; guards and per-message codes included
             nm = loc.nm;
@@ -827,10 +872,11 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         // here, lane = parent, the parent's words in this lane's registers and the server index a compile-time constant; no
         // family queue, no gather.  Only the sparse slots below go through the by-family queues.
         if constexpr (DenseSlots<S>::value > 0) {
-            if (!(flags & (64u | 32768u))) {  // 32768 = A/B: dense slots through the family queues like the others
+            if (!(flags & 64u)) {
                 // S::eval_dense(i): the two dense slots of server i together (shared hash terms).  The loops are NOT unrolled: the
                 // server index is wave-uniform (scalar registers), and the probe / flush code below exists twice, not 2 * NS times.
                 bool mysucc = false;
+                MC_PROF(1);
 #pragma clang loop unroll(disable)
                 for (int i = 0; i < S::DENSE_PAIRS; ++i) {
                     unsigned st2[2] = {0u, 0u};
@@ -852,7 +898,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                                 if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = f2[h];
                             }
                         }
-                        enqueue(fp, (uint32_t)(wave_col0 + pl) | (slot << 24));
+                        enqueue(fp, (uint32_t)(wave_col0 + pl) | (slot << 24), 1);
                     }
                 }
                 gd.fixed &= ~((1ull << DenseSlots<S>::value) - 1ull);
@@ -864,45 +910,70 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 }
             }
         }
-        // the fixed slots, then per message slot the three kinds (Receive, Duplicate, Drop) on ONE load of the message word;
-        // the drain of every queue follows the last block.  (flag 64 = ablation: load the parents only)
+        // (flag 64 = ablation: load the parents only)
+        // IN-FLIGHT MESSAGES, inline, lane = parent (round 3): Receive(m), DuplicateMessage(m), DropMessage(m) need count(m) > 0, and the model
+        // bounds the copies in flight (MaxMsgs = 1 in the bench models): a parent has at most MaxMsgs such messages whatever the
+        // size of its bag.  Lane = parent evaluates the three actions of ITS j-th in-flight message together — the message word
+        // and H(key) shared by the three (Local::cache_hm) — instead of pushing three pairs per bag slot through the family
+        // queues: no queue traffic, no gather of the pair's parent, no partially filled batches at the drain; 73 % of the lanes
+        // are busy on the bench model (measured share of the wave time before: push loop 10 % + phase B of the message families
+        // 15 %, profiles/r03e_phase_profile; step 48.2 -> 41.1 ms on the 102.6 M-state graph, profiles/r03f).  S::eval is the
+        // slot-by-slot evaluation the oracle comparisons of tests/_shim run on.
+        static_assert(InlineMsgs<S>::value, "a by-family spec evaluates its message actions inline (S::inflight_slots)");
+        {
+            if (!(flags & 64u)) {
+                MC_PROF(6);
+                unsigned infl = active ? S::inflight_slots(gd) : 0u;  // bit k: count(message k) > 0, k < GUARD_SLOTS
+                auto eval_three = [&](bool on, int k) {
+#pragma clang loop unroll(disable)
+                    for (int kind = 0; kind < 3; ++kind) {
+                        const unsigned slot = (unsigned)(S::FIX + 3 * k + kind);
+                        uint64_t fv = 0, fp = 0;
+                        const unsigned st = on ? S::eval(prm, loc, g, (int)slot, fv) : 0u;
+                        if (st & ST_ENABLED) {
+                            ++gen;
+                            if (track_succ) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
+                            if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
+                            else if (st & ST_ASSERT) viol = min(viol, viol_key(idx, slot, VK_ASSERT, 0));
+                            else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, slot, VK_SPECERR, 0));
+                            else {
+                                if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, slot, VK_INVARIANT, st >> 8));
+                                if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = fv;
+                            }
+                        }
+                        enqueue(fp, (uint32_t)(wave_col0 + pl) | (slot << 24), 6);
+                    }
+                };
+                while (__ballot(infl != 0)) {
+                    const bool on = infl != 0;
+                    const int k = on ? __ffs((int)infl) - 1 : 0;
+                    infl &= infl - 1;
+                    eval_three(on, k);
+                }
+                for (int k = S::GUARD_SLOTS; k < wnm; ++k) {  // bags beyond the classified slots: the count is read from the row
+                    const bool on = k < nm && S::m_count(g.get(S::W_MSG0 + k)) > 0;
+                    if (__ballot(on)) eval_three(on, k);
+                }
+            }
+        }
+        MC_PROF(5);
         for (int step = 0; step < ((flags & 64u) ? 0 : S::FIX); ++step) {
             const int f = S::fixed_family(step);
             const bool en = (gd.fixed >> step) & 1ull;
             const unsigned long long b = __ballot(en);
-            if (b && fam_push(f, b, en, ((unsigned)step << 8) | pl)) run_full(1u << f, false);
-        }
-        for (int k = 0; k < ((flags & 64u) ? 0 : wnm); ++k) {
-            // (the first GUARD_SLOTS message slots were classified by load_expand: no memory access here)
-            const uint64_t mword = (k >= S::GUARD_SLOTS && k < nm) ? g.get(S::W_MSG0 + k) : 0;
-#pragma clang loop unroll(disable)
-            for (int kind = 0; kind < 3; ++kind) {
-                unsigned fullmask = 0;
-                const unsigned entry = ((unsigned)(S::FIX + 3 * k + kind) << 8) | pl;
-                const int fam = k >= nm ? -1 : k < S::GUARD_SLOTS ? S::guard_code(gd, k, kind) : S::guard_msg(gd, mword, kind);
-                if (kind == 0) {  // Receive: the family depends on the message (UpdateTerm or one of the four handlers)
-#pragma unroll
-                    for (int f = 0; f < S::NFAM; ++f) {
-                        if (!(S::RECV_FAMS >> f & 1u)) continue;
-                        const unsigned long long b = __ballot(fam == f);
-                        if (b && fam_push(f, b, fam == f, entry)) fullmask |= 1u << f;
-                    }
-                } else {
-                    const unsigned long long b = __ballot(fam >= 0);
-                    if (b && fam_push(S::F_DUPDROP, b, fam >= 0, entry)) fullmask |= 1u << S::F_DUPDROP;
-                }
-                run_full(fullmask, false);
-            }
+            if (b && fam_push(f, b, en, ((unsigned)step << 8) | pl)) run_full(1u << f, false, 5);
         }
     }
+    MC_PROF(7);
     {
         unsigned fullmask = 0;
 #pragma unroll
         for (int f = 0; f < S::NFAM; ++f) if (fget(fcntA, fcntB, f)) fullmask |= 1u << f;
-        run_full(fullmask, true);
+        run_full(fullmask, true, 7);
     }
     if (qn) flush_probe(qn);
     if (on) flush_out(on);
+    MC_PROF(7);
 
     if (flags & MC_F_DEADLOCK) {
         wave_lds_fence();
@@ -922,209 +993,10 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
         if (eor) atomicOr(&ctr->error, eor);
     }
-}
-
-// ------------------------------------------------------------------------------------- expand + insert + WRITE, one kernel
-// k_expand_family's phase A / phase B, but a pair's lane probes the seen-set itself as soon as the pair is evaluated
-// (by-family batches keep ~80 % of the lanes busy, so the probe ring of the slot-by-slot kernel is not needed) and —
-// while it still holds the successor's delta in registers — parks the delta of every NEW state in an LDS buffer.
-// When 64 survivors are together the wavefront reserves 64 consecutive arena indices with one atomicAdd and writes the
-// 64 successors as "parent (the arena block this wavefront owns: L1 / L2 resident) + patch", lane = new state, i.e. a
-// 512-byte row per word.  No new-list, no k_materialise, no second stream: each state is read once and written once.
-template <class S>
-struct DirectLds {
-    uint16_t fq[S::NFAM][FQCAP];          // (slot << 6) | parent lane
-    typename S::Summary sum[64];
-    unsigned succ[64];                    // successors generated per parent (deadlock check)
-    uint64_t sv[S::PATCH_WORDS][64];      // packed deltas of the survivors, word-major (conflict-free per lane)
-};
-
-// MINW = waves per SIMD the register allocation must leave room for (A/B: 4 = 128 VGPRs with a few spills, 3 = none)
-template <class S, int MINW>
-__global__ void __launch_bounds__(256, MINW)
-k_expand_direct(typename S::Params prm, uint64_t *arena, uint64_t lo, uint64_t hi, uint64_t ncols,
-                uint64_t *table, uint64_t mask, uint64_t arena_cap, uint32_t *__restrict__ parent, uint16_t *__restrict__ pslot,
-                DevCounters *ctr, unsigned flags, const LevelCtl *lc) {
-    __shared__ DirectLds<S> dls[4];
-    if (lc) {
-        if (lc->stop) return;
-        lo = lc->lo;
-        hi = lc->hi;
-        ncols = ((hi - (lo & ~63ull)) + 63) & ~63ull;
-    }
-    const unsigned lane = threadIdx.x & 63;
-    DirectLds<S> &FL = dls[threadIdx.x >> 6];
-    const uint64_t base = lo & ~63ull;
-    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
-    const uint64_t idx = base + col;
-    const uint64_t wave_idx0 = idx - lane;  // this wavefront's 64 parents = one arena block
-    const bool active = idx >= lo && idx < hi;
-    const int W = S::words(prm);
-    const CWordRef g = arena_cref(arena, idx, W);
-    typename S::Guards gd;
-    gd.fixed = 0;
-    gd.terms = 0;
-    int nm = 0;
-    unsigned long long viol = ~0ull;
-    if (active) {
-        typename S::Local loc;
-        S::load(prm, g, loc);
-        nm = loc.nm;
-        S::guards(prm, loc, gd);
-        typename S::Summary q;
-        S::summarize(loc, q);
-        FL.sum[lane] = q;
-        const unsigned ps = S::parent_status(prm, loc, g);
-        if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
-    }
-    FL.succ[lane] = 0;
-    wave_lds_fence();
-    const int wnm = (int)wave_max_u32((unsigned)nm);
-    unsigned gen = 0, err = 0, probes = 0;
-    unsigned on = 0;  // survivors parked in FL.sv (wave-uniform)
-    uint64_t fheadA = 0, fheadB = 0, fcntA = 0, fcntB = 0;
-    auto fget = [](uint64_t a, uint64_t b, int f) -> unsigned { return (unsigned)((f < 8 ? a >> (8 * f) : b >> (8 * (f - 8))) & 255u); };
-    auto fset = [](uint64_t &a, uint64_t &b, int f, unsigned v) {
-        if (f < 8) a = (a & ~(255ull << (8 * f))) | ((uint64_t)v << (8 * f));
-        else b = (b & ~(255ull << (8 * (f - 8)))) | ((uint64_t)v << (8 * (f - 8)));
-    };
-    const unsigned shard = blockIdx.x & (NSHARD - 1);
-
-    // write the `take` parked survivors: lane j builds new state (first free index + j)
-    auto flush_out = [&](unsigned take) {
-        unsigned long long pos = 0;
-        if (lane == 0) pos = atomicAdd(&ctr->arena_next, (unsigned long long)take);
-        pos = __shfl(pos, 0);
-        if (lane < take) {
-            uint64_t pd[S::PATCH_WORDS];
-#pragma unroll
-            for (int w = 0; w < S::PATCH_WORDS; w++) pd[w] = FL.sv[w][lane];
-            const unsigned p = (unsigned)pd[0] & 63u, slot = (unsigned)pd[0] >> 6 & 0xffffu;
-            const uint64_t oidx = pos + lane;
-            if (oidx >= arena_cap) {
-                err |= DEV_EARENA;
-            } else {
-                S::write_patched(prm, arena_cref(arena, wave_idx0 + p, W), pd, FL.sum[p], arena_ref(arena, oidx, W));
-                if (parent) { parent[oidx] = (uint32_t)(wave_idx0 + p); pslot[oidx] = (uint16_t)slot; }
-            }
-        }
-        on = 0;
-        wave_lds_fence();
-    };
-    auto fam_push = [&](int f, unsigned long long b, bool mine, int slot) -> bool {
-        const unsigned h = fget(fheadA, fheadB, f), c = fget(fcntA, fcntB, f);
-        if (mine) FL.fq[f][(h + c + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (FQCAP - 1)] = (uint16_t)(((unsigned)slot << 6) | lane);
-        const unsigned nc = c + (unsigned)__popcll(b);
-        fset(fcntA, fcntB, f, nc);
-        return nc >= 64;
-    };
-    // phase B: evaluate `take` queued pairs of family f (f is wave-uniform), probe, park the survivors' deltas
-    auto run_family = [&](int f, unsigned take) {
-        const unsigned h = fget(fheadA, fheadB, f);
-        wave_lds_fence();  // queue entries written by fam_push are visible
-        bool is_new = false;
-        uint64_t pd[S::PATCH_WORDS];
-        if (lane < take) {
-            const unsigned e = FL.fq[f][(h + lane) & (FQCAP - 1)];
-            const unsigned p = e & 63u;
-            const int slot = (int)(e >> 6);
-            const uint64_t pidx = wave_idx0 + p;
-            const typename S::Summary q = FL.sum[p];
-            const CWordRef sp = arena_cref(arena, pidx, W);
-            unsigned st = 0;
-            uint64_t fv = 0;
-            family_dispatch<S, 0>(f, [&](auto fc) { st = S::template eval_pair_delta<decltype(fc)::value>(prm, q, sp, slot, fv, pd); });
-            if (st & ST_ENABLED) {
-                ++gen;
-                if (flags & MC_F_DEADLOCK) atomicAdd(&FL.succ[p], 1u);
-                if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
-                else if (st & ST_ASSERT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_ASSERT, 0));
-                else if (st & ST_SPECERR) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_SPECERR, 0));
-                else {
-                    if (st & ST_INVARIANT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_INVARIANT, st >> 8));
-                    if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) {
-                        ++probes;
-                        is_new = (flags & 16u) ? false : seen_insert_t<8>(table, mask, fv, err);  // 16 = ablation: no probes
-                        pd[0] |= (uint64_t)(p | ((unsigned)slot << 6));
-                    }
-                }
-            }
-        }
-        fset(fheadA, fheadB, f, (h + take) & (FQCAP - 1));
-        fset(fcntA, fcntB, f, fget(fcntA, fcntB, f) - take);
-        const unsigned long long b = __ballot(is_new);
-        if (b) {
-            const unsigned cnt = (unsigned)__popcll(b);
-            if (on + cnt > 64) flush_out(on);
-            if (is_new) {
-                const unsigned k = on + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
-#pragma unroll
-                for (int w = 0; w < S::PATCH_WORDS; w++) FL.sv[w][k] = pd[w];
-            }
-            on += cnt;
-            wave_lds_fence();
-            if (on == 64) flush_out(64);
-        }
-        wave_lds_fence();
-    };
-
-    const int nsteps = (flags & 64u) ? 1 : S::FIX + 3 * wnm + 1;  // 64 = ablation: load the parents only
-    for (int step = 0; step < nsteps; ++step) {
-        unsigned fullmask = 0;
-        bool drain = false;
-        if (step < S::FIX) {
-            const int f = S::fixed_family(step);
-            const bool en = (gd.fixed >> step) & 1ull;
-            const unsigned long long b = __ballot(en);
-            if (b && fam_push(f, b, en, step)) fullmask = 1u << f;
-        } else if (step < nsteps - 1) {
-            const int q = step - S::FIX, k = q / 3, kind = q % 3;
-            int fam = -1;
-            if (k < nm) fam = S::guard_msg(gd, g.get(S::W_MSG0 + k), kind);
-            if (kind == 0) {  // Receive: the family depends on the message (UpdateTerm or one of the four handlers)
-#pragma unroll
-                for (int f = 0; f < S::NFAM; ++f) {
-                    if (!(S::RECV_FAMS >> f & 1u)) continue;
-                    const unsigned long long b = __ballot(fam == f);
-                    if (b && fam_push(f, b, fam == f, step)) fullmask |= 1u << f;
-                }
-            } else {
-                const unsigned long long b = __ballot(fam >= 0);
-                if (b && fam_push(S::F_DUPDROP, b, fam >= 0, step)) fullmask |= 1u << S::F_DUPDROP;
-            }
-        } else {
-            drain = true;
-#pragma unroll
-            for (int f = 0; f < S::NFAM; ++f) if (fget(fcntA, fcntB, f)) fullmask |= 1u << f;
-        }
-        while (fullmask) {
-            const int f = __ffs((int)fullmask) - 1;
-            const unsigned c = fget(fcntA, fcntB, f);
-            run_family(f, drain ? (c < 64 ? c : 64u) : 64u);
-            if (fget(fcntA, fcntB, f) < (drain ? 1u : 64u)) fullmask &= ~(1u << f);
-        }
-    }
-    if (on) flush_out(on);
-
-    if (active && (flags & MC_F_DEADLOCK) && FL.succ[lane] == 0) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
-    const unsigned gsum = wave_sum_u32(gen);
-    const unsigned psum = wave_sum_u32(probes);
-    const unsigned long long vmin = wave_min_u64(viol);
-    const unsigned eor = wave_or_u32(err);
-    if (lane == 0) {
-        if (gsum) atomicAdd(&ctr->generated[shard].v, (unsigned long long)gsum);
-        if (psum) atomicAdd(&ctr->cells[shard].v, (unsigned long long)psum);
-        if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
-        if (eor) atomicOr(&ctr->error, eor);
-    }
+    MC_PROF_END;
 }
 
 // specs with a copy + patch writer (S::PATCH_WORDS, eval_pair_delta, write_patched) run the one-kernel form
-template <class S, class = void>
-struct HasPatch : std::false_type {};
-template <class S>
-struct HasPatch<S, decltype((void)S::PATCH_WORDS)> : std::true_type {};
 
 // specs that define action families (S::NFAM) are expanded by family, the others slot by slot
 template <class S, class = void>
@@ -1157,10 +1029,13 @@ k_deadlock_slices(const uint16_t *__restrict__ succ, uint64_t lo, uint64_t hi, u
 }
 template <class S, bool ROUTE, class... A>
 static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStream_t stream, unsigned slices, A... args) {
-    (void)flags;
     if constexpr (UsesFamilies<S>::value) {
         if (by_family) {
-            hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, args...);
+            // MC_F_OCC3 (A/B): the register budget of 3 wavefronts per SIMD (no spills) instead of 4 (a dozen spilled VGPRs)
+            if (flags & MC_F_OCC3)
+                hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1, 3>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, args...);
+            else
+                hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, args...);
             return;
         }
     }
@@ -1514,6 +1389,7 @@ struct EngineBase {
     virtual int kernel_stats(mc_kernel_stats *out) = 0;
     virtual int read_states(uint64_t first, uint64_t count, uint8_t *out) = 0;
     virtual int debug_reexpand(unsigned extra_flags, double *ms) = 0;
+    virtual int debug_phases(uint64_t *out48, int reset) = 0;
     virtual int checkpoint(const char *path) = 0;
     virtual int restore(const char *path) = 0;
     virtual int shard_begin() = 0;
@@ -1617,7 +1493,6 @@ struct Engine : EngineBase {
         W = S::words(prm);
         max_slots = (unsigned)S::max_slots(prm);
         use_matrix = (cfg.flags & MC_F_MATRIX) != 0;
-        use_direct = HasPatch<S>::value && (cfg.flags & MC_F_DIRECT) && !(cfg.flags & (MC_F_MATRIX | MC_F_NOFAMILY));
         HIP_TRY(hipSetDevice(cfg.device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         {   // A/B knob (measured in DESIGN.md section 4): TLAMC_PRIO=1 gives the materialise stream the highest priority, =2 the lowest
@@ -1727,7 +1602,7 @@ struct Engine : EngineBase {
         return MC_OK;
     }
 
-    bool use_matrix = false, use_direct = false;
+    bool use_matrix = false;
     // materialise + commit of the chunk whose survivors are in new-list `parity`, on the second stream: it overlaps
     // the expansion of the next chunk (memory-bound next to latency-bound)
     void finish_materialise(uint64_t chunk_base, uint64_t ncols, unsigned parity) {
@@ -1745,27 +1620,11 @@ struct Engine : EngineBase {
         static const bool serial = getenv("TLAMC_SERIAL") != nullptr;
         if (serial) hipStreamSynchronize(stream2);
     }
-    // one-kernel form (k_expand_direct): expand + seen-set insert + copy-and-patch write of the new states
-    void launch_direct(uint64_t c0, uint64_t c1, uint64_t ncols, const LevelCtl *lc) {
-        if constexpr (HasPatch<S>::value) {
-            if (cfg.flags & 2048u)  // A/B: register allocation for 3 waves per SIMD (no spills)
-                hipLaunchKernelGGL((k_expand_direct<S, 3>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0, c1, ncols,
-                                   d_table, seen_arg(), arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
-            else
-                hipLaunchKernelGGL((k_expand_direct<S, 4>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena, c0, c1, ncols,
-                                   d_table, seen_arg(), arena_cap, d_parent, d_pslot, d_ctr, cfg.flags, lc);
-        }
-    }
     // one batched level (LevelCtl): the same pair of kernels, ranges read on the device, then the level is closed there
     void enqueue_blind_level(uint64_t max_states) {
         // all four kernels on ONE stream: for a frontier this small the two-stream overlap buys nothing and the
         // cross-stream events would cost more than the kernels
         const uint64_t ncols = max_states + 64;
-        if (use_direct) {
-            timed(0, 0, [&] { launch_direct(0, 0, ncols, d_lc); });
-            hipLaunchKernelGGL(k_end_level, dim3(1), dim3(1), 0, stream, d_ctr, d_lc);
-            return;
-        }
         RouteArgs rt{};
         rt.lc = d_lc;
         rt.new_fp = d_newfp;
@@ -1909,9 +1768,7 @@ struct Engine : EngineBase {
                 uint64_t c1 = base + chunk;  // chunk boundaries stay 64-aligned
                 if (c1 > hi) c1 = hi;
                 const uint64_t ncols = ((c1 - base) + 63) & ~63ull;
-                if (use_direct) {  // one kernel per chunk, one stream: the new states are written where they are found
-                    timed(0, c1 - c0, [&] { launch_direct(c0, c1, ncols, nullptr); });
-                } else if (use_matrix) {  // two-kernel form: sparse candidate matrix + k_insert (kept for A/B measurements)
+                if (use_matrix) {  // two-kernel form: sparse candidate matrix + k_insert (kept for A/B measurements)
                     timed(0, c1 - c0, [&] {
                         hipLaunchKernelGGL(k_expand<S>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, prm, d_arena,
                                            c0, c1, d_cand, row_stride, ncols, d_nsl, d_ctr, cfg.flags);
@@ -2202,6 +2059,19 @@ struct Engine : EngineBase {
     uint64_t last_distinct = 0;
     // Profiling aid: expand every resident state again (seen-set already full, so every probe hits)
     // with optional ablation flags; returns the kernel time.  State counts are not changed.
+    int debug_phases(uint64_t *out48, int reset) override {
+#ifdef MC_PHASE_PROF
+        HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_phase), 48 * sizeof(uint64_t)));
+        if (reset) { static const unsigned long long zero[48] = {}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof zero)); }
+        return MC_OK;
+#else
+        (void)out48; (void)reset;
+        set_error("the library was built without MC_PHASE_PROF");
+        return MC_ESTATE;
+#endif
+    }
     int debug_reexpand(unsigned extra_flags, double *ms) override {
         HIP_TRY(hipSetDevice(cfg.device));
         hipEvent_t a, b;
@@ -3005,6 +2875,8 @@ void mc_set_error_internal(const char *msg) { g_last_error = msg ? msg : ""; }
 
 
 int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms) { return e && ms ? e->impl->debug_reexpand(extra_flags, ms) : MC_EBADCFG; }
+// profiling builds only (-DMC_PHASE_PROF): cycles per phase of k_expand_family summed over all wavefronts since the last reset
+int mc_engine_debug_phases(mc_engine *e, uint64_t *out48, int reset) { return e && out48 ? e->impl->debug_phases(out48, reset) : MC_EBADCFG; }
 // ---- sharded (multi-GPU) step API
 int mc_shard_begin(mc_engine *e) { return e ? e->impl->shard_begin() : MC_EBADCFG; }
 int mc_shard_begin_replicated(mc_engine *e, uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out,

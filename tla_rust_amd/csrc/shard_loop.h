@@ -107,7 +107,9 @@ struct Loop {
         uint64_t chunk = o.chunk_states ? o.chunk_states : (1ull << 19);
         if (e.chunk_limit() && chunk > e.chunk_limit()) chunk = e.chunk_limit();  // never more than one launch of the engine takes
         const uint64_t fan = o.packed_fanout ? o.packed_fanout : 16, mfan = o.move_fanout ? o.move_fanout : 32;
-        const uint64_t stay_threshold = o.stay_threshold ? o.stay_threshold : (1ull << 16);
+        // (default = the replicated prefix's own threshold: the prefix hands every rank an even share of a level that size, so the
+        //  first sharded level can already keep its new states where they are generated)
+        const uint64_t stay_threshold = o.stay_threshold ? o.stay_threshold : (1ull << 15);
         const double ratio = o.rebalance_ratio > 0 ? o.rebalance_ratio : 1.25;
         const size_t W = e.state_bytes();
         const bool traced = e.traced();

@@ -51,8 +51,9 @@ namespace mc {
 namespace rlog {
 constexpr int LCAP = 5;   // values 1..5 at most (MaxClientRequests <= 6)
 constexpr int LB_MAX = 15;
-MC_HD unsigned digit(uint64_t l, int v, int tb) { return (unsigned)(l >> (tb * (v - 1))) & ((1u << tb) - 1u); }
-MC_HD int len(uint64_t l, int tb) {
+// (a log fits 15 bits: 32-bit arithmetic throughout — half the instructions and registers of the 64-bit words it is stored in)
+MC_HD unsigned digit(uint32_t l, int v, int tb) { return (l >> (tb * (v - 1))) & ((1u << tb) - 1u); }
+MC_HD int len(uint32_t l, int tb) {
     int n = 0;
 #pragma unroll
     for (int v = 1; v <= LCAP; v++) n += digit(l, v, tb) != 0;
@@ -62,7 +63,7 @@ MC_HD int eterm(unsigned e) { return (int)(e & 7u); }
 MC_HD int evalue(unsigned e) { return (int)(e >> 3); }
 MC_HD unsigned mk_entry(int term, int value) { return (unsigned)term | ((unsigned)value << 3); }
 // k-th entry (1-based, k <= Len) as term | value << 3
-MC_HD unsigned entry(uint64_t l, int k, int tb) {
+MC_HD unsigned entry(uint32_t l, int k, int tb) {
     unsigned e = 0;
 #pragma unroll
     for (int v = 1; v <= LCAP; v++) {
@@ -71,24 +72,24 @@ MC_HD unsigned entry(uint64_t l, int k, int tb) {
     }
     return e;
 }
-MC_HD int last_term(uint64_t l, int tb) {                                                            // raft.tla:113
+MC_HD int last_term(uint32_t l, int tb) {                                                            // raft.tla:113
     int t = 0;
 #pragma unroll
     for (int v = 1; v <= LCAP; v++) { const unsigned d = digit(l, v, tb); t = d ? (int)d : t; }
     return t;
 }
-MC_HD bool can_append(uint64_t l, unsigned e, int tb) { return evalue(e) >= 1 && evalue(e) <= LCAP && (l >> (tb * (evalue(e) - 1))) == 0; }
-MC_HD uint64_t append(uint64_t l, unsigned e, int tb) { return l | ((uint64_t)eterm(e) << (tb * (evalue(e) - 1))); }  // Append
-MC_HD uint64_t prefix(uint64_t l, int k, int tb) {  // SubSeq(l, 1, k)
-    uint64_t out = 0;
+MC_HD bool can_append(uint32_t l, unsigned e, int tb) { return evalue(e) >= 1 && evalue(e) <= LCAP && (l >> (tb * (evalue(e) - 1))) == 0; }
+MC_HD uint32_t append(uint32_t l, unsigned e, int tb) { return l | ((uint32_t)eterm(e) << (tb * (evalue(e) - 1))); }  // Append
+MC_HD uint32_t prefix(uint32_t l, int k, int tb) {  // SubSeq(l, 1, k)
+    uint32_t out = 0;
 #pragma unroll
     for (int v = 1; v <= LCAP; v++) {
         const unsigned d = digit(l, v, tb);
-        if (d && k > 0) { out |= (uint64_t)d << (tb * (v - 1)); --k; }
+        if (d && k > 0) { out |= d << (tb * (v - 1)); --k; }
     }
     return out;
 }
-MC_HD uint64_t drop_last(uint64_t l, int tb) { return prefix(l, len(l, tb) - 1, tb); }
+MC_HD uint32_t drop_last(uint32_t l, int tb) { return prefix(l, len(l, tb) - 1, tb); }
 }  // namespace rlog
 
 enum : int { R_FOLLOWER = 0, R_CANDIDATE = 1, R_LEADER = 2 };
@@ -106,12 +107,12 @@ struct RaftParams {
 // A small array that is guaranteed to live in registers: explicit scalar members and
 // compare-select access (no alloca, so nothing is ever indexed dynamically in scratch memory).
 // With a compile-time index the chains fold away.
-template <int N>
+template <int N, class T = uint64_t>
 struct RegArr {
     static_assert(N >= 1 && N <= 8, "RegArr holds 1..8 words");
-    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
-    MC_HD uint64_t get(int i) const {
-        uint64_t r = a0;
+    T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    MC_HD T get(int i) const {
+        T r = a0;
         if (N > 1) r = i == 1 ? a1 : r;
         if (N > 2) r = i == 2 ? a2 : r;
         if (N > 3) r = i == 3 ? a3 : r;
@@ -121,7 +122,7 @@ struct RegArr {
         if (N > 7) r = i == 7 ? a7 : r;
         return r;
     }
-    MC_HD void set(int i, uint64_t v) {
+    MC_HD void set(int i, T v) {
         a0 = i == 0 ? v : a0;
         if (N > 1) a1 = i == 1 ? v : a1;
         if (N > 2) a2 = i == 2 ? v : a2;
@@ -332,7 +333,8 @@ struct SpecRaft {
     // ---------------------------------------------------------------- per-parent cache
     struct Local {
         uint64_t fp, glob, clog;
-        RegArr<NS> sv, log;
+        RegArr<NS> sv;
+        RegArr<NS, uint32_t> log;   // (15 bits each)
         int nm, inflight;
         Sigs sig;              // signatures of the message keys (slots < SIG_SLOTS)
         unsigned addmask;      // servers whose log is not yet in allLogs (raft.tla:493), first occurrence only
@@ -347,8 +349,8 @@ struct SpecRaft {
         uint64_t dig;          // 11 bits per server: state[0,2) currentTerm[2,5) LastTerm(log)[5,8) Len(log)[8,11) — all that
                                // RequestVote(i, j) reads of server i (raft.tla:209-217): a quarter of all pairs needs no arena word
     };
-    MC_HD static uint64_t digest_of(uint64_t sv, uint64_t lg, int tb) {
-        return (uint64_t)sv_state(sv) | (uint64_t)sv_term(sv) << 2 | (uint64_t)rlog::last_term(lg, tb) << 5 | (uint64_t)rlog::len(lg, tb) << 8;
+    MC_HD static uint32_t digest_of(uint64_t sv, uint32_t lg, int tb) {
+        return (uint32_t)sv_state(sv) | (uint32_t)sv_term(sv) << 2 | (uint32_t)rlog::last_term(lg, tb) << 5 | (uint32_t)rlog::len(lg, tb) << 8;
     }
     // WANT_FP = false: the caller never computes a fingerprint from this cache (k_materialise with a known one)
     template <bool WANT_FP = true, class Ref>
@@ -358,7 +360,7 @@ struct SpecRaft {
         l.glob = gw & 0xffffffffull;
         l.clog = gw >> 32;
         #pragma unroll
-        for (int i = 0; i < NS; i++) { const uint64_t x = s.get(W_SRV(i)); l.sv.set(i, x & SVMASK); l.log.set(i, x >> LOGSH); }
+        for (int i = 0; i < NS; i++) { const uint64_t x = s.get(W_SRV(i)); l.sv.set(i, x & SVMASK); l.log.set(i, (uint32_t)(x >> LOGSH)); }
         l.nm = g_nm(l.glob);
         l.inflight = 0;
         l.sig = sigs_empty();
@@ -419,7 +421,7 @@ struct SpecRaft {
         l.add_fp = 0;
         l.dig = 0;
 #pragma unroll
-        for (int i = 0; i < NS; i++) l.dig |= digest_of(l.sv.get(i), l.log.get(i), prm.tb) << (11 * i);
+        for (int i = 0; i < NS; i++) l.dig |= (uint64_t)digest_of(l.sv.get(i), l.log.get(i), prm.tb) << (11 * i);
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             bool skip = (present >> i & 1) != 0;
@@ -509,14 +511,14 @@ struct SpecRaft {
     template <bool MEM, class Ref>
     MC_HD static uint64_t log_word(const Local &l, Ref s, int i) { if (MEM) return rd_log(s, i); return l.log.get(i); }
 
-    // Action FAMILIES: the expand-by-family kernel buckets enabled (state, slot) pairs per family in LDS and evaluates 64 pairs
-    // of ONE family at a time, so the successor construction below runs with every lane busy and without divergence between
-    // action types.  The first NFAM ids are the QUEUES; the rare kinds (together 7 % of the pairs of the bench model, none of
-    // them over 3 %) share the queue F_MISC — one batch with divergent arithmetic instead of seven nearly empty ones, each of
-    // which would pay its own chain of memory round trips.  FAM < 0 = any kind.
-    enum : int { F_RESTART, F_TIMEOUT, F_REQVOTE, F_APPEND, F_RVREQ, F_DUPDROP, F_MISC, NFAM,
-                 F_BECOME = NFAM, F_CLIENT, F_ADVANCE, F_UPDTERM, F_RVRESP, F_AEREQ, F_AERESP };
-    static constexpr unsigned RECV_FAMS = (1u << F_RVREQ) | (1u << F_MISC);  // queues a Receive pair can go to
+    // Action FAMILIES: the expand-by-family kernel buckets enabled (state, slot) pairs of the SPARSE fixed slots per family in LDS
+    // and evaluates 64 pairs of ONE family at a time, so the successor construction below runs with every lane busy and without
+    // divergence between action types.  The first NFAM ids are the QUEUES: RequestVote(i, j), AppendEntries(i, j), and F_MISC for
+    // the three rare kinds BecomeLeader / ClientRequest / AdvanceCommitIndex (one batch with divergent arithmetic instead of three
+    // nearly empty ones).  Not queued: Restart(i) / Timeout(i) — enabled for nearly every state, evaluated by the parent's lane
+    // (eval_dense) — and Receive / Duplicate / Drop, evaluated by the parent's lane per IN-FLIGHT message (eval, slot >= FIX: at
+    // most MaxMsgs messages of a bag have a copy in flight).  FAM < 0 = any kind (eval, apply).
+    enum : int { F_REQVOTE, F_APPEND, F_MISC, NFAM, F_BECOME = NFAM, F_CLIENT, F_ADVANCE };
 #define MC_FAM(f) (FAM < 0 || FAM == (f) || (FAM == F_MISC && (f) >= NFAM))
 
     // The function is staged so that the memory round trips of a pair do not depend on its kind: (1) the message word of a
@@ -533,7 +535,7 @@ struct SpecRaft {
         unsigned st = ST_ENABLED;
         const int tb = prm.tb;
         // ---- (1), (2): operands
-        constexpr bool MSG_KINDS = FAM < 0 || FAM == F_RVREQ || FAM == F_DUPDROP || FAM == F_MISC;
+        constexpr bool MSG_KINDS = FAM < 0;  // the message kinds are never queued
         int i = 0, j = 0, k = -1, kind = -1;
         uint64_t m = 0;
         if (slot >= FIX) {
@@ -562,12 +564,12 @@ struct SpecRaft {
         bool want_send = false;
         uint64_t skey = 0;
         // ---- (3): the action
-        if (MC_FAM(F_RESTART) && slot < NS) {  // Restart(i)   raft.tla:186-194 (always enabled)
+        if (FAM < 0 && slot < NS) {  // Restart(i)   raft.tla:186-194 (always enabled)
             action = RA_RESTART;
             d.srv = i; d.osv = svi; d.olog = d.log = lgi;
             d.sv = sv_reset_leader_vars(sv_set_commit(sv_set_granted(sv_set_state(d.osv, R_FOLLOWER), 0), 0), 1);
             d.vmode = 1; d.ovl = s.get(W_VL(i));
-        } else if (MC_FAM(F_TIMEOUT) && slot >= NS && slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
+        } else if (FAM < 0 && slot >= NS && slot < 2 * NS) {  // Timeout(i)   raft.tla:197-206
             action = RA_TIMEOUT;
             const int stt = sv_state(svi);
             if (!(stt == R_FOLLOWER || stt == R_CANDIDATE)) return 0;
@@ -657,25 +659,25 @@ struct SpecRaft {
             skey = mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j);
         } else if (MSG_KINDS && slot >= FIX) {
             const int cnt = m_count(m);
-            if (MC_FAM(F_DUPDROP) && kind == 1) {  // DuplicateMessage(m), m \in SingleMessage(messages)   raft.tla:134-135,471-473
+            if (kind == 1) {  // DuplicateMessage(m), m \in SingleMessage(messages)   raft.tla:134-135,471-473
                 action = RA_DUPLICATE;
                 if (cnt != 1) return 0;
                 d.nmop = 2; d.midxB = k; d.moldB = m; d.mnewB = m + 1; d.dinflight = 1;
-            } else if (MC_FAM(F_DUPDROP) && kind == 2) {  // DropMessage(m), m \in ValidMessage(messages)   raft.tla:131-132,476-478
+            } else if (kind == 2) {  // DropMessage(m), m \in ValidMessage(messages)   raft.tla:131-132,476-478
                 action = RA_DROP;
                 if (cnt == 0) return 0;
                 discard(k, m, d);
-            } else if (kind == 0 && (FAM < 0 || FAM == F_RVREQ || FAM == F_MISC)) {  // Receive(m), m \in ValidMessage(messages)   raft.tla:449-464
+            } else if (kind == 0) {  // Receive(m), m \in ValidMessage(messages)   raft.tla:449-464
                 action = RA_RECEIVE;
                 if (cnt == 0) return 0;
                 const int mterm = m_term(m), type = m_type(m);
                 const uint64_t lg = lgi;
                 const int term = sv_term(svi);
                 d.srv = i; d.osv = d.sv = svi; d.olog = d.log = lg; d.pre = false;
-                if (MC_FAM(F_UPDTERM) && mterm > term) {  // UpdateTerm   raft.tla:434-440 (message not consumed)
+                if (mterm > term) {  // UpdateTerm   raft.tla:434-440 (message not consumed)
                     d.sv = sv_set_voted(sv_set_state(sv_set_term(svi, mterm), R_FOLLOWER), 0);
                     if (mterm > prm.max_term) st |= ST_OUT_OF_MODEL;
-                } else if (MC_FAM(F_RVREQ) && mterm <= term && type == M_RVREQ) {  // HandleRequestVoteRequest   raft.tla:313-332
+                } else if (type == M_RVREQ) {  // HandleRequestVoteRequest   raft.tla:313-332
                     const int llt = (int)(m >> 13 & 7), lli = (int)(m >> 16 & 7), lt = rlog::last_term(lg, tb);
                     const bool logOk = llt > lt || (llt == lt && lli >= rlog::len(lg, tb));
                     const bool grant = mterm == term && logOk && (sv_voted(svi) == 0 || sv_voted(svi) == j + 1);
@@ -683,7 +685,7 @@ struct SpecRaft {
                     want_send = true;  // Reply(response, m)
                     skey = mk_rvresp(term, grant ? 1 : 0, lg, i, j);
                     discard(k, m, d);
-                } else if (MC_FAM(F_RVRESP) && mterm <= term && type == M_RVRESP) {
+                } else if (type == M_RVRESP) {
                     if (mterm == term) {  // HandleRequestVoteResponse   raft.tla:336-349
                         if (m >> 13 & 1) {
                             const unsigned vg = sv_granted(svi);
@@ -694,7 +696,7 @@ struct SpecRaft {
                         }
                     }  // else DropStaleResponse   raft.tla:443-446
                     discard(k, m, d);
-                } else if (MC_FAM(F_AEREQ) && mterm <= term && type == M_AEREQ) {  // HandleAppendEntriesRequest   raft.tla:355-417
+                } else if (type == M_AEREQ) {  // HandleAppendEntriesRequest   raft.tla:355-417
                     const int pidx = (int)(m >> 13 & 7), pterm = (int)(m >> 16 & 7), nent = (int)(m >> 19 & 1);
                     const unsigned ent = (unsigned)(m >> 20 & 63);
                     const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg, tb);
@@ -725,7 +727,7 @@ struct SpecRaft {
                     } else {
                         return 0;  // e.g. a Leader receiving AppendEntries of its own term
                     }
-                } else if (MC_FAM(F_AERESP) && mterm <= term && type == M_AERESP) {  // AppendEntriesResponse
+                } else {  // AppendEntriesResponse
                     if (mterm == term) {  // HandleAppendEntriesResponse   raft.tla:421-431
                         if (m >> 13 & 1) {
                             const int mi = (int)(m >> 14 & 7);
@@ -736,8 +738,6 @@ struct SpecRaft {
                         }
                     }  // else DropStaleResponse
                     discard(k, m, d);
-                } else {
-                    return 0;  // a pair queued for another family (cannot happen: guard_msg is exact)
                 }
             } else {
                 return 0;
@@ -771,35 +771,22 @@ struct SpecRaft {
     // guards: cheap and EXACT as to the family (compute<MEM, FAM> still decides whether the action is enabled)
     struct Guards {
         uint64_t fixed;   // bit s: fixed slot s (< FIX) may be enabled
-        uint32_t terms;   // 3 bits per server: currentTerm (for UpdateTerm vs handler dispatch)
-        uint64_t mc0, mc1;  // load_expand: one byte per message slot k < GUARD_SLOTS — queue of Receive(k) [0,4) (15 = none),
-                            // bit 4 Duplicate(k) enabled, bit 5 Drop(k) enabled: the push loop of the kernel reads no memory
+        uint32_t infl;    // load_expand: bit k — message slot k < GUARD_SLOTS holds a message with a copy in flight (count > 0)
     };
     static constexpr int GUARD_SLOTS = 16;
-    MC_HD static unsigned msg_code(const Guards &g, uint64_t m) {
-        const int r = guard_msg(g, m, 0);
-        return (unsigned)(r < 0 ? 15 : r) | (m_count(m) == 1 ? 16u : 0u) | (m_count(m) > 0 ? 32u : 0u);
-    }
-    // family of message slot (k < GUARD_SLOTS, kind) from the codes, or -1
-    MC_HD static int guard_code(const Guards &g, int k, int kind) {
-        const unsigned c = (unsigned)((k < 8 ? g.mc0 >> (8 * k) : g.mc1 >> (8 * (k - 8))) & 255u);
-        if (kind == 0) return (c & 15u) == 15u ? -1 : (int)(c & 15u);
-        return (c >> (3 + kind) & 1u) ? (int)F_DUPDROP : -1;
-    }
+    MC_HD static unsigned inflight_slots(const Guards &g) { return g.infl; }
     MC_HD static int fixed_family(int slot) {
-        return slot < NS ? F_RESTART : slot < 2 * NS ? F_TIMEOUT : slot < 2 * NS + NS * NS ? F_REQVOTE
-             : slot < 5 * NS + NS * NS ? F_MISC /* BecomeLeader, ClientRequest, AdvanceCommitIndex */ : F_APPEND;
+        // (slots < 2 NS are the dense pairs: never asked)
+        return slot < 2 * NS + NS * NS ? F_REQVOTE : slot < 5 * NS + NS * NS ? F_MISC /* BecomeLeader, ClientRequest, AdvanceCommitIndex */ : F_APPEND;
     }
     MC_HD static void guards(const Params &prm, const Local &l, Guards &g) {
         g.fixed = 0;
-        g.terms = 0;
-        g.mc0 = g.mc1 = 0;
+        g.infl = 0;
         const int creq = g_creq(l.glob);
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             const uint64_t sv = l.sv.get(i);
             const int st = sv_state(sv);
-            g.terms |= (uint32_t)sv_term(sv) << (3 * i);
             g.fixed |= 1ull << i;                                                               // Restart(i)
             if (st == R_FOLLOWER || st == R_CANDIDATE) g.fixed |= 1ull << (NS + i);              // Timeout(i)
             if (st == R_CANDIDATE) {
@@ -815,21 +802,11 @@ struct SpecRaft {
             }
         }
     }
-    // family of message slot (k, kind) given the message word, or -1
-    MC_HD static int guard_msg(const Guards &g, uint64_t m, int kind) {
-        const int cnt = m_count(m);
-        if (kind == 1) return cnt == 1 ? (int)F_DUPDROP : -1;
-        if (kind == 2) return cnt > 0 ? (int)F_DUPDROP : -1;
-        if (cnt == 0) return -1;
-        const int term = (int)(g.terms >> (3 * m_dst(m)) & 7u);
-        if (m_term(m) > term) return F_MISC;  // UpdateTerm
-        return m_type(m) == M_RVREQ ? (int)F_RVREQ : (int)F_MISC;
-    }
     // Phase A of the by-family expand kernel (lane = parent, rows of the arena block coalesced): load() and guards() in one, with
     // the loads of the parent's row issued in TWO groups — header (fingerprint, globals, two words per server), then up to 12
     // message slots + the allLogs words: two trips to HBM instead of eight dependent ones — and with what the kernel's push loop
-    // needs of each message (queue of its Receive, Duplicate / Drop enabled) kept as a byte code, so that the loop does not read
-    // the message words again.  Same Local / Guards as load() + guards().
+    // needs of the bag — which messages have a copy in flight: their Receive / Duplicate / Drop are evaluated inline — kept as
+    // one bit per slot.  Same Local / Guards as load() + guards().
     template <class Ref>
     MC_HD static void load_expand(const Params &prm, Ref s, Local &l, Guards &g) {
         // ---- trip 1: header (2 + 2 NS loads in flight)
@@ -842,7 +819,7 @@ struct SpecRaft {
         for (int i = 0; i < NS; i++) {
             const uint64_t x = s.get(W_SRV(i));
             l.sv.set(i, x & SVMASK);
-            l.log.set(i, x >> LOGSH);
+            l.log.set(i, (uint32_t)(x >> LOGSH));
             vw[i] = s.get(W_VL(i));
         }
         l.vany = 0;
@@ -882,11 +859,7 @@ struct SpecRaft {
                 const uint64_t x = k < PRE ? mw[k < PRE ? k : 0] : s.get(W_MSG0 + k);
                 l.inflight += m_count(x);
                 sw[k >> 2] = (sw[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (key_sig(x) << (8 * (k & 3)));
-                const uint64_t c = (uint64_t)msg_code(g, x) << (8 * (k & 7));
-                if (k < 8) g.mc0 |= c; else g.mc1 |= c;
-            } else {
-                const uint64_t c = 15ull << (8 * (k & 7));
-                if (k < 8) g.mc0 |= c; else g.mc1 |= c;
+                if (m_count(x) > 0) g.infl |= 1u << k;
             }
         }
         l.sig = Sigs{sw[0], sw[1], sw[2], sw[3]};
@@ -1082,7 +1055,7 @@ struct SpecRaft {
         for (int i = 0; i < NS; i++) {
             const uint64_t x = s.get(W_SRV(i));
             l.sv.set(i, x & SVMASK);
-            l.log.set(i, x >> LOGSH);
+            l.log.set(i, (uint32_t)(x >> LOGSH));
             vw[i] = s.get(W_VL(i));
         }
         l.nm = g_nm(l.glob);
@@ -1172,7 +1145,7 @@ struct SpecRaft {
             if (l.addmask >> i & 1) {
                 if (pos < prm.ca) {
 #pragma unroll
-                    for (int q = 0; q < 16; q++) if (q == (pos >> 2)) aw[q] |= l.log.get(i) << (16 * (pos & 3));
+                    for (int q = 0; q < 16; q++) if (q == (pos >> 2)) aw[q] |= (uint64_t)l.log.get(i) << (16 * (pos & 3));
                 }
                 pos++;
             }
