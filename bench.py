@@ -29,8 +29,8 @@ sys.path.insert(0, str(ROOT))
 
 # params[6..8] = capacities of the messages / elections / allLogs slot arrays of the packed state = the
 # oracle's maxima over the complete graph, 10 / 1 / 4 (tests/golden/raft_levels.json max_stat); an overflow
-# would raise MC_EOVERFLOW, never drop a state.  params[9] = MaxMsgKeys.  W = 2 + 2*3 + 10 + 1*2 + 1 = 21 words = 168 B
-# (round 3 layout: logs as 2 bits per client-request value; 288 B in rounds 1-2).
+# would raise MC_EOVERFLOW, never drop a state.  params[9] = MaxMsgKeys.  W = 2 + 2*3 + 10/2 + 1*2 + 1 = 16 words = 128 B
+# (round 3 layout: logs as 2 bits per client-request value, 32-bit messages two per word; 288 B in rounds 1-2).
 WORKLOAD = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 10, 1, 4, 10], golden="raft3_mcr4_t2_m1_k10_complete",
                 name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=2 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=10 "
                      "(specs/MCraft.cfg), complete state graph")
@@ -43,7 +43,7 @@ WORKLOAD_K11 = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 11, 1, 4, 11], golden
 # changes, the conflict-truncate branch of HandleAppendEntriesRequest reachable (with MaxTerm = 2 exactly one term of elections is
 # explored and NoTwoLeaders is trivially true) — bounded by MaxMsgKeys = 8: 525 782 408 distinct / 6 708 500 293 generated / depth
 # 33, verified by the exact-dedup oracle on the GPU box's host (tests/golden/raft_levels.json `source`); one step = 0.24 s of GPU time.
-# Slot capacities 8 / 2 / 4 = the oracle's maxima (two election records now).  W = 2 + 2*3 + 8 + 2*2 + 1 = 21 words = 168 B.
+# Slot capacities 8 / 2 / 4 = the oracle's maxima (two election records now).  W = 2 + 2*3 + 8/2 + 2*2 + 1 = 17 words = 136 B.
 WORKLOAD_T3 = dict(spec="raft", params=[3, 4, 3, 3, 1, 1, 8, 2, 4, 8], golden="raft3_mcr4_t3_m1_k8_complete",
                    name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=3 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=8 "
                         "(specs/MCraft_t3.cfg), complete state graph")

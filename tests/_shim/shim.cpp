@@ -123,10 +123,10 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
             bool same = l2.fp == l.fp && l2.glob == l.glob && l2.clog == l.clog && l2.nm == l.nm && l2.inflight == l.inflight &&
                         l2.addmask == l.addmask && l2.nadd == l.nadd && l2.add_fp == l.add_fp && l2.vany == l.vany && l2.dig == l.dig &&
                         l2.sig.w0 == l.sig.w0 && l2.sig.w1 == l.sig.w1 && l2.sig.w2 == l.sig.w2 && l2.sig.w3 == l.sig.w3 &&
-                        g2.fixed == g.fixed;
+                        g2.fixed == g.fixed && g2.fixed_hi == g.fixed_hi;
             for (int i = 0; i < p.n; i++) same = same && l2.sv.get(i) == l.sv.get(i) && l2.log.get(i) == l.log.get(i) && l2.vlh.get(i) == l.vlh.get(i);
             for (int k = 0; k < l.nm && k < S::GUARD_SLOTS; k++)   // the in-flight mask names exactly the messages with count > 0
-                same = same && ((S::inflight_slots(g2) >> k & 1u) != 0) == (S::m_count(s.get(S::W_MSG0 + k)) > 0);
+                same = same && ((S::inflight_slots(g2) >> k & 1u) != 0) == (S::m_count(S::rd_msg(s, k)) > 0);
             if (!same) bad++;
         }
         for (int slot = 0; slot < ns; slot++) {
@@ -135,7 +135,7 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
             int fam = -1;
             // queued: the sparse fixed slots (the dense pairs, slots < DENSE_SLOTS, and the message slots are evaluated by eval itself)
             const bool queued = slot >= S::DENSE_SLOTS && slot < S::FIX;
-            if (queued && (g.fixed >> slot & 1)) fam = S::fixed_family(slot);
+            if (queued && S::fixed_bit(g, slot)) fam = S::fixed_family(slot);
             const unsigned st1 = fam >= 0 ? run<0>(fam, p, q, s, slot, f1) : 0u;
             // (a stuttering step carries no fingerprint through the by-family path: the flag alone drops it)
             if (queued && (st0 != st1 || ((st0 & ST_ENABLED) && !(st0 & ST_SELFLOOP) && f0 != f1))) bad++;
@@ -891,6 +891,74 @@ extern "C" int shim_state_apply(const mc_spec_desc *d, const uint64_t *words, in
         S::apply(prm, CWordRef{words, 1}, slot, WordRef{out, 1});
         return 0;
     });
+}
+// ANALYSIS AID (profiles/probe_cache_sim.py): what fraction of the seen-set probes would a direct-mapped cache of recently probed
+// fingerprints answer?  BFS in arena order; per 64-parent block the wavefront's own 256-entry filter (engine.hip WFILT) first,
+// then a global direct-mapped cache of 2^cache_log2 fingerprints, then the exact set.  out: candidates, wave-filter hits, cache
+// hits, duplicates that reached the table, new states.
+extern "C" int shim_probe_cache_sim(const mc_spec_desc *d, uint64_t max_levels, int cache_log2, uint64_t *out) {
+    return dispatch_spec(d, [&](auto spec, const auto &prm) {
+        using S = decltype(spec);
+        const int W = S::words(prm);
+        std::vector<uint64_t> cur, next, cache((size_t)1 << cache_log2, 0);
+        const uint64_t cmask = ((uint64_t)1 << cache_log2) - 1;
+        FpSet seen;
+        uint64_t tmp[S::MAX_WORDS], filt[256];
+        for (int q = 0; q < 5; q++) out[q] = 0;
+        for (uint64_t k = 0; k < S::num_init(prm); k++) {
+            S::init(prm, k, WordRef{tmp, 1});
+            if (S::init_status(prm, CWordRef{tmp, 1}) & ST_OUT_OF_MODEL) continue;
+            if (seen.insert(stored_fp<S>(prm, tmp)).second) next.insert(next.end(), tmp, tmp + W);
+        }
+        cur.swap(next);
+        for (uint64_t level = 1; !cur.empty() && (!max_levels || level < max_levels); level++) {
+            const uint64_t nstates = cur.size() / (size_t)W;
+            for (uint64_t i = 0; i < nstates; i++) {
+                if ((i & 63) == 0) memset(filt, 0, sizeof filt);
+                CWordRef s{&cur[i * W], 1};
+                typename S::Local loc;
+                S::load(prm, s, loc);
+                const int ns = S::nslots(prm, loc);
+                for (int slot = 0; slot < ns; slot++) {
+                    uint64_t fp = 0;
+                    const unsigned st = S::eval(prm, loc, s, slot, fp);
+                    if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_ASSERT | ST_SPECERR | ST_OUT_OF_MODEL | ST_SELFLOOP))) continue;
+                    out[0]++;
+                    const unsigned h = (unsigned)(fp >> 20) & 255u;
+                    if (filt[h] == fp) { out[1]++; continue; }
+                    filt[h] = fp;
+                    const uint64_t ch = (fp >> 24) & cmask;
+                    if (cache[ch] == fp) { out[2]++; continue; }
+                    cache[ch] = fp;
+                    if (seen.insert(fp).second) {
+                        out[4]++;
+                        S::apply(prm, s, slot, WordRef{tmp, 1});
+                        next.insert(next.end(), tmp, tmp + W);
+                    } else {
+                        out[3]++;
+                    }
+                }
+            }
+            cur.clear();
+            cur.swap(next);
+        }
+        return 0;
+    });
+}
+// the consistency checks shim_run applies to every reachable state (by-family evaluation == slot-by-slot evaluation, dense pairs,
+// load_expand == load + guards), on ONE hand-made state: states no small model reaches (a Leader s5 of the 5-server model)
+extern "C" long shim_state_mismatches(const mc_spec_desc *d, const uint64_t *words) {
+    long bad = -1;
+    dispatch_spec(d, [&](auto spec, const auto &prm) {
+        using S = decltype(spec);
+        CWordRef s{words, 1};
+        typename S::Local loc;
+        S::load(prm, s, loc);
+        const int ns = S::nslots(prm, loc);
+        bad = (long)(FamCheck<S>::mismatches(prm, loc, s, ns) + DenseCheck<S>::mismatches(prm, loc, s));
+        return 0;
+    });
+    return bad;
 }
 extern "C" int shim_state_format(const mc_spec_desc *d, const uint64_t *words, char *buf, size_t cap) {
     return dispatch_spec(d, [&](auto spec, const auto &prm) { return decltype(spec)::format(prm, words, buf, cap); });

@@ -145,11 +145,11 @@ def test_raft_complete_graphs_on_gpu(amd, oracle, name, caps):
 
 def test_bench_workload_complete_on_gpu(amd, oracle):
     """rounds 1-2's bench workload (`bench.py --workload k10`) = specs/MCraft.cfg: the COMPLETE graph of raft.tla with 3 servers and
-    MaxTerm = 2, 102 586 254 states, with the slot capacities bench.py uses (10 / 1 / 4 = the oracle's maxima; W = 168 B since the
+    MaxTerm = 2, 102 586 254 states, with the slot capacities bench.py uses (10 / 1 / 4 = the oracle's maxima; W = 128 B since the
     compact layout of round 3, 288 B before) and a seen-set load of 0.76."""
     c = _golden("raft3_mcr4_t2_m1_k10_complete")
     params = oracle.raft_device_params(c["params"], 10, 1, 4)
-    assert params == [3, 4, 2, 3, 1, 1, 10, 1, 4, 10] and amd.state_bytes("raft", params) == 168
+    assert params == [3, 4, 2, 3, 1, 1, 10, 1, 4, 10] and amd.state_bytes("raft", params) == 128
     assert c["max_stat"][:3] == [10, 1, 4]
     eng = amd.Engine("raft", params, table_capacity=1 << 27, arena_capacity=c["distinct"] + (1 << 16), chunk_states=1 << 22, trace=False)
     r = eng.run()
@@ -164,12 +164,36 @@ def test_contract_bench_workload_complete_on_gpu(amd, oracle):
     per-level counts equal to the exact-dedup oracle's (run on the GPU box's host: tests/golden/raft_levels.json `source`)."""
     c = _golden("raft3_mcr4_t3_m1_k8_complete")
     params = oracle.raft_device_params(c["params"], 8, 2, 4)
-    assert params == [3, 4, 3, 3, 1, 1, 8, 2, 4, 8] and amd.state_bytes("raft", params) == 168 and c["max_stat"][:3] == [8, 2, 4]
+    assert params == [3, 4, 3, 3, 1, 1, 8, 2, 4, 8] and amd.state_bytes("raft", params) == 136 and c["max_stat"][:3] == [8, 2, 4]
     eng = amd.Engine("raft", params, table_capacity=17 << 26, arena_capacity=c["distinct"] + (1 << 16), chunk_states=1 << 22, trace=False)
     r = eng.run()
     assert r.levels == c["levels"]
     assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (525782408, 6708500293, 33, "ok", 0)
     eng.close()
+
+
+def test_config4_model_one_billion_states_on_one_gpu(amd):
+    """BASELINE config 4's model (examples/raft.tla, Server = {s1..s5}, MaxClientRequests = 6 => log <= 5; raft.tla:11-24) at the
+    size its 8-GPU run is budgeted for, on ONE GPU: 18 BFS levels = 924 041 864 states resident in HBM (W = 192 B with the compact
+    layout of round 3: 177 GB; the 944 B of round 2 would have needed 872 GB).  Level 19 alone has 1.26e9 states: 18 levels is what
+    288 GB can hold whatever the arena policy.  Levels 1-15 (63 297 104 states) equal the exact-dedup oracle's — level 15 is where
+    round 2's 64-bit guard mask lost 216 states (AppendEntries of a leader s4 / s5); beyond them the fused engine and the sharded
+    engine (mc_shard_run over RCCL at world size 1: route-mode expand, packed exchange with itself, keep) must agree level by level."""
+    c = _golden("raft5_mcr6_t2_m1_levels15")
+    params = [5, 6, 2, 5, 1, 1, 18, 1, 4]
+    assert amd.state_bytes("raft", params) == 192
+    eng = amd.Engine("raft", params, table_capacity=3 << 29, arena_capacity=1_300_000_000, chunk_states=1 << 22, max_levels=18, trace=False)
+    r = eng.run()
+    eng.close()
+    assert r.levels[:15] == c["levels"] and r.verdict == "budget" and r.depth == 18
+    assert r.levels[15:] == [94825875, 228419035, 537499850] and r.distinct == 924041864
+    from tla_rust_amd.binding import Comm
+    comm = Comm(Comm.unique_id(), 0, 1, 0)
+    eng = amd.Engine("raft", params, table_capacity=3 << 29, arena_capacity=1_300_000_000, chunk_states=1 << 21, trace=False, shard_rank=0, shard_count=1)
+    s, st = comm.shard_run(eng, chunk_states=1 << 21, max_levels=18)
+    eng.close()
+    comm.close()
+    assert (s.levels, s.distinct, s.generated, s.verdict) == (r.levels, r.distinct, r.generated, "budget") and st["stay_levels"] >= 3
 
 
 def test_next_complete_graph_on_gpu(amd):
@@ -191,7 +215,7 @@ def test_bench_workload_with_tuned_capacities(amd):
     c = _golden("raft3_mcr4_t2_m1_bench")
     eng = amd.Engine("raft", c["params"] + [16, 2, 8], table_capacity=1 << 27, arena_capacity=30_000_000, chunk_states=1 << 19,
                      max_distinct=c["max_distinct"], trace=False)
-    assert amd.state_bytes("raft", c["params"] + [16, 2, 8]) == 240
+    assert amd.state_bytes("raft", c["params"] + [16, 2, 8]) == 176
     r = eng.run()
     assert r.levels == c["levels"] and (r.distinct, r.generated) == (c["distinct"], c["generated"])
     eng.close()

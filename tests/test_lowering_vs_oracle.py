@@ -132,6 +132,30 @@ def _two_leader_parent(shim, same_term):
     return lib, d, w
 
 
+def test_every_fixed_slot_of_five_servers_reaches_its_queue(shim):
+    """Round 3 found that the guard mask of the by-family expand kernel had 64 bits for the 75 fixed slots of the 5-server model:
+    AppendEntries(i, j) of a leader s4 / s5 (slots 65 .. 74) was never queued — invisible to every golden of rounds 1-2 (their
+    12-level prefix has no leader yet), found by the 15-level golden (216 states missing on level 15).  A hand-made state with
+    EVERY server a Leader enables every AppendEntries slot: the by-family evaluation must agree with the slot-by-slot one."""
+    import ctypes as C
+    lib = shim.shim_lib()
+    lib.shim_state_mismatches.restype = C.c_long
+    for n, params in ((5, [5, 6, 2, 5, 1, 1]), (3, [3, 4, 3, 3, 1, 1])):
+        d = shim.spec_desc("raft", params)
+        w = (C.c_uint64 * 64)()
+        assert lib.shim_init_state(C.byref(d), C.c_uint64(0), w) == 0
+        assert lib.shim_state_mismatches(C.byref(d), w) == 0
+        for i in range(n):                                   # W_SRV(i) = 2 + 2 i: state[3,5) = Leader (2), term[0,3) = 2
+            w[2 + 2 * i] = (w[2 + 2 * i] & ~0x1f) | 2 | (2 << 3)
+        assert lib.shim_state_mismatches(C.byref(d), w) == 0
+        enabled = 0
+        for slot in range(5 * n + n * n, 5 * n + 2 * n * n):   # the AppendEntries slots: all but i = j are enabled
+            st, fp = C.c_uint(0), C.c_uint64(0)
+            assert lib.shim_eval_slot(C.byref(d), w, slot, C.byref(st), C.byref(fp)) == 0
+            enabled += st.value & 1
+        assert enabled == n * (n - 1)
+
+
 def test_no_two_leaders_negative_control(shim):
     """NoTwoLeaders (raft.tla:500-507) is never violated by a reachable state, so a lowering that never raised
     it would pass every graph test.  BecomeLeader(s2) on a hand-made parent with another Leader of the same term must raise

@@ -851,7 +851,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         const unsigned pl = (unsigned)blk * 64 + lane;       // this lane's parent inside the wavefront's NB blocks
         const BlockRef g{blk_base, lane};
         typename S::Guards gd;
-        gd.fixed = 0;
+        gd.fixed = gd.fixed_hi = 0;
         gd.infl = 0;
         int nm = 0;
         typename S::Local loc;
@@ -901,7 +901,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                         enqueue(fp, (uint32_t)(wave_col0 + pl) | (slot << 24), 1);
                     }
                 }
-                gd.fixed &= ~((1ull << DenseSlots<S>::value) - 1ull);
+                S::fixed_clear_dense(gd);
                 if (track_succ) {  // deadlock check: one bit per parent; when every parent already has a successor, nothing more to track
                     const unsigned long long sb = __ballot(mysucc);
                     if (lane == 0) { FL.has_succ[blk * 2] = (unsigned)sb; FL.has_succ[blk * 2 + 1] = (unsigned)(sb >> 32); }
@@ -951,7 +951,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                     eval_three(on, k);
                 }
                 for (int k = S::GUARD_SLOTS; k < wnm; ++k) {  // bags beyond the classified slots: the count is read from the row
-                    const bool on = k < nm && S::m_count(g.get(S::W_MSG0 + k)) > 0;
+                    const bool on = k < nm && S::m_count(S::rd_msg(g, k)) > 0;
                     if (__ballot(on)) eval_three(on, k);
                 }
             }
@@ -959,7 +959,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         MC_PROF(5);
         for (int step = 0; step < ((flags & 64u) ? 0 : S::FIX); ++step) {
             const int f = S::fixed_family(step);
-            const bool en = (gd.fixed >> step) & 1ull;
+            const bool en = S::fixed_bit(gd, step);
             const unsigned long long b = __ballot(en);
             if (b && fam_push(f, b, en, ((unsigned)step << 8) | pl)) run_full(1u << f, false, 5);
         }

@@ -142,13 +142,14 @@ struct SpecRaft {
     static constexpr int W_GLOB = 1;   // clientRequests[0,3) decrease[3] nMsgs[8,16) nElec[16,20) nAll[24,32) | committedLog[32,47)
     MC_HD static constexpr int W_SRV(int i) { return 2 + 2 * i; }   // scalars of server i [0, LOGSH) | log[i] [LOGSH, LOGSH + 15)
     MC_HD static constexpr int W_VL(int i) { return 3 + 2 * i; }    // voterLog[i][j] at bits [lb * j, lb * (j + 1))
-    static constexpr int W_MSG0 = 2 + 2 * NS;                       // messages[cm], one word each
+    static constexpr int W_MSG0 = 2 + 2 * NS;                       // messages[cm]: 32 bits each, two per word (slot k in half k & 1 of word k >> 1)
     static constexpr int EL_WORDS = 2;                              // election: record word | evoterLog (packed like W_VL)
-    MC_HD static int W_EL0(const Params &p) { return W_MSG0 + p.cm; }                 // elections[ce][2]
-    MC_HD static int W_ALL0(const Params &p) { return W_MSG0 + p.cm + p.ce * EL_WORDS; }  // allLogs[ca]: four 16-bit slots per word
+    MC_HD static int msg_words(const Params &p) { return (p.cm + 1) >> 1; }
+    MC_HD static int W_EL0(const Params &p) { return W_MSG0 + msg_words(p); }                 // elections[ce][2]
+    MC_HD static int W_ALL0(const Params &p) { return W_MSG0 + msg_words(p) + p.ce * EL_WORDS; }  // allLogs[ca]: four 16-bit slots per word
     MC_HD static int all_words(const Params &p) { return (p.ca + 3) >> 2; }
-    MC_HD static int words(const Params &p) { return W_MSG0 + p.cm + p.ce * EL_WORDS + all_words(p); }
-    static constexpr int MAX_WORDS = W_MSG0 + 64 + 8 * EL_WORDS + 16;
+    MC_HD static int words(const Params &p) { return W_MSG0 + msg_words(p) + p.ce * EL_WORDS + all_words(p); }
+    static constexpr int MAX_WORDS = W_MSG0 + 32 + 8 * EL_WORDS + 16;
     static constexpr int LOGSH = 16 + 6 * NS;  // 34 (3 servers) / 46 (5 servers): the scalars end here
     static constexpr uint64_t SVMASK = (1ull << LOGSH) - 1ull;
     static_assert(LOGSH + rlog::LB_MAX <= 64, "scalars + log of a server share one word");
@@ -165,7 +166,7 @@ struct SpecRaft {
                                                 // evaluates them inline, lane = parent (engine.hip k_expand_family)
     static constexpr int STAGE_WORDS = 16; // message slots of each parent the expand kernel stages in LDS
     template <class Ref>
-    MC_HD static void stage_range(const Params &, Ref s, int &lo, int &n) { lo = W_MSG0; n = g_nm(s.get(W_GLOB)); }
+    MC_HD static void stage_range(const Params &, Ref s, int &lo, int &n) { lo = W_MSG0; n = (g_nm(s.get(W_GLOB)) + 1) >> 1; }
     MC_HD static int max_slots(const Params &p) { return FIX + 3 * p.cm; }
     static constexpr uint64_t SALT_M = 0x8f1bbcdc8f1bbcdcull, SALT_E = 0xca62c1d6ca62c1d6ull, SALT_A = 0x5a8279995a827999ull;
 
@@ -178,6 +179,9 @@ struct SpecRaft {
     MC_HD static uint64_t pack_glob(uint64_t glob, uint64_t clog) { return (glob & 0xffffffffull) | (clog << 32); }
     MC_HD static uint64_t vl_get(uint64_t word, int j, const Params &p) { return (word >> (p.lb * j)) & ((1ull << p.lb) - 1ull); }
     MC_HD static uint64_t vl_set(uint64_t word, int j, uint64_t log, const Params &p) { return word | (log << (p.lb * j)); }  // (the entry was empty)
+    template <class Ref> MC_HD static uint64_t rd_msg(Ref s, int k) { return (s.get(W_MSG0 + (k >> 1)) >> (32 * (k & 1))) & 0xffffffffull; }
+    MC_HD static uint64_t half_of(uint64_t word, int k) { return (word >> (32 * (k & 1))) & 0xffffffffull; }
+    MC_HD static uint64_t set_half(uint64_t word, int k, uint64_t m) { return (k & 1) ? (word & 0xffffffffull) | (m << 32) : (word & ~0xffffffffull) | m; }
     template <class Ref> MC_HD static uint64_t rd_all(const Params &p, Ref s, int a) { return (s.get(W_ALL0(p) + (a >> 2)) >> (16 * (a & 3))) & 0xffffull; }
 
     // server scalars: term[0,3) state[3,5) votedFor[5,8) votesGranted[8,13) commitIndex[13,16)
@@ -216,8 +220,10 @@ struct SpecRaft {
         return ((uint64_t)type << 2) | ((uint64_t)term << 4) | ((uint64_t)src << 7) | ((uint64_t)dst << 10);
     }
     // RVReq : lastLogTerm[13,16) lastLogIndex[16,19)
-    // RVResp: granted[13] mlog[14,29)
-    // AEReq : prevIdx[13,16) prevTerm[16,19) nentries[19] entry[20,26) commitIdx[26,29) mlog[29,44)
+    // RVResp: granted[13] mlog[14,27)
+    // AEReq : prevIdx[13,16) commitIdx[16,19) mlog[19,32) — mprevLogTerm and mentries are FUNCTIONS of (mlog, mprevLogIndex)
+    //         (raft.tla:225-244: prevLogTerm = log[i][prevLogIndex].term, entries = SubSeq(log[i], nextIndex, lastEntry), mlog =
+    //         log[i]), so the record is determined by the fields kept: 32 bits per message, two per word
     // AEResp: success[13] matchIndex[14,17)
     MC_HD static uint64_t mk_rvreq(int term, int llt, int lli, int src, int dst) {
         return m_head(M_RVREQ, term, src, dst) | ((uint64_t)llt << 13) | ((uint64_t)lli << 16);
@@ -225,10 +231,17 @@ struct SpecRaft {
     MC_HD static uint64_t mk_rvresp(int term, int granted, uint64_t mlog, int src, int dst) {
         return m_head(M_RVRESP, term, src, dst) | ((uint64_t)granted << 13) | (mlog << 14);
     }
-    MC_HD static uint64_t mk_aereq(int term, int pidx, int pterm, int nent, unsigned ent, int cidx, uint64_t mlog, int src, int dst) {
-        return m_head(M_AEREQ, term, src, dst) | ((uint64_t)pidx << 13) | ((uint64_t)pterm << 16) | ((uint64_t)nent << 19) |
-               ((uint64_t)ent << 20) | ((uint64_t)cidx << 26) | (mlog << 29);
+    MC_HD static uint64_t mk_aereq(int term, int pidx, int cidx, uint64_t mlog, int src, int dst) {
+        return m_head(M_AEREQ, term, src, dst) | ((uint64_t)pidx << 13) | ((uint64_t)cidx << 16) | (mlog << 19);
     }
+    // the derived fields of an AppendEntriesRequest
+    MC_HD static int ae_pidx(uint64_t m) { return (int)(m >> 13 & 7); }
+    MC_HD static int ae_cidx(uint64_t m) { return (int)(m >> 16 & 7); }
+    MC_HD static uint32_t ae_mlog(uint64_t m) { return (uint32_t)(m >> 19) & 0x1fffu; }
+    MC_HD static int ae_pterm(uint64_t m, int tb) { const int p = ae_pidx(m); return p > 0 ? rlog::eterm(rlog::entry(ae_mlog(m), p, tb)) : 0; }
+    MC_HD static int ae_nent(uint64_t m, int tb) { return ae_pidx(m) + 1 <= rlog::len(ae_mlog(m), tb) ? 1 : 0; }
+    MC_HD static unsigned ae_ent(uint64_t m, int tb) { return ae_nent(m, tb) ? rlog::entry(ae_mlog(m), ae_pidx(m) + 1, tb) : 0u; }
+    MC_HD static uint32_t rv_mlog(uint64_t m) { return (uint32_t)(m >> 14) & 0x1fffu; }
     MC_HD static uint64_t mk_aeresp(int term, int success, int midx, int src, int dst) {
         return m_head(M_AERESP, term, src, dst) | ((uint64_t)success << 13) | ((uint64_t)midx << 14);
     }
@@ -271,7 +284,7 @@ struct SpecRaft {
         o.tb = o.max_term <= 3 ? 2 : 3;                       // an entry's term is a leader's currentTerm <= MaxTerm
         o.lb = o.tb * (o.max_client_requests - 1);           // values 1 .. MaxClientRequests - 1
         if (o.lb < o.tb) o.lb = o.tb;
-        if (o.lb > rlog::LB_MAX || NS * o.lb > 64) return -1;  // voterLog[i] is one word
+        if (o.lb > 13 || NS * o.lb > 64) return -1;  // a message is 32 bits (AppendEntriesRequest: 19 + lb); voterLog[i] is one word
         return 0;
     }
 
@@ -291,7 +304,7 @@ struct SpecRaft {
     MC_HD static uint64_t fp_recompute(const Params &prm, Ref s) {
         uint64_t fp = hheader(prm, s);
         const uint64_t g = rd_glob(s);
-        for (int k = 0; k < g_nm(g); k++) fp += hmsg(s.get(W_MSG0 + k));
+        for (int k = 0; k < g_nm(g); k++) fp += hmsg(rd_msg(s, k));
         for (int e = 0; e < g_ne(g); e++) {
             RegArr<EL_WORDS> ew;
 #pragma unroll
@@ -367,8 +380,8 @@ struct SpecRaft {
         // four slots per round: the four loads are in flight together (a slot index is clamped into the bag, never past it)
         for (int k0 = 0; k0 < l.nm; k0 += 4) {
             const bool v1 = k0 + 1 < l.nm, v2 = k0 + 2 < l.nm, v3 = k0 + 3 < l.nm;
-            const uint64_t x0 = s.get(W_MSG0 + k0), x1 = s.get(W_MSG0 + (v1 ? k0 + 1 : k0)), x2 = s.get(W_MSG0 + (v2 ? k0 + 2 : k0)),
-                           x3 = s.get(W_MSG0 + (v3 ? k0 + 3 : k0));
+            const uint64_t p0 = s.get(W_MSG0 + (k0 >> 1)), p1 = s.get(W_MSG0 + (v2 ? (k0 >> 1) + 1 : (k0 >> 1)));  // (k0 is a multiple of 4)
+            const uint64_t x0 = p0 & 0xffffffffull, x1 = p0 >> 32, x2 = p1 & 0xffffffffull, x3 = p1 >> 32;
             l.inflight += m_count(x0) + (v1 ? m_count(x1) : 0) + (v2 ? m_count(x2) : 0) + (v3 ? m_count(x3) : 0);
             uint32_t w = key_sig(x0) | 0x80808000u;
             if (k0 + 1 < l.nm) w = (w & ~0x0000ff00u) | (key_sig(x1) << 8);
@@ -466,11 +479,11 @@ struct SpecRaft {
         while (cand) {
             const int k = sig_slot_of_bit(__builtin_ctz(cand));
             cand &= cand - 1;
-            const uint64_t x = s.get(W_MSG0 + k);
+            const uint64_t x = rd_msg(s, k);
             if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; cand = 0; }
         }
         for (int k = SIG_SLOTS; k < l.nm; k++) {  // bags beyond the signature words: scanned
-            const uint64_t x = s.get(W_MSG0 + k);
+            const uint64_t x = rd_msg(s, k);
             if ((x >> 2) == (key_word >> 2)) { idx = k; old = x; }
         }
         // op A; the discard of a Reply is op B (response key /= request key, so the slots differ)
@@ -543,7 +556,7 @@ struct SpecRaft {
             const int q = slot - FIX;
             k = q / 3; kind = q % 3;
             if (k >= l.nm) return 0;
-            m = s.get(W_MSG0 + k);
+            m = rd_msg(s, k);
             i = m_dst(m); j = m_src(m);
         } else if (slot < 2 * NS) {
             i = slot < NS ? slot : slot - NS;
@@ -647,16 +660,12 @@ struct SpecRaft {
             const int next = sv_next(svi, j), prevIdx = next - 1;
             int prevTerm = 0;
             const int lglen = rlog::len(lg, tb);
-            if (prevIdx > 0) {
-                if (prevIdx > lglen) return ST_ENABLED | ST_SPECERR;
-                prevTerm = rlog::eterm(rlog::entry(lg, prevIdx, tb));
-            }
+            if (prevIdx > 0 && prevIdx > lglen) return ST_ENABLED | ST_SPECERR;  // log[i][prevLogIndex] out of domain
+            (void)prevTerm;  // (prevLogTerm and the entries are functions of (log[i], prevLogIndex): not stored in the message word)
             const int lastEntry = lglen < next ? lglen : next;  // Min({Len(log[i]), nextIndex[i][j]})
-            const int nent = next <= lastEntry ? 1 : 0;          // SubSeq(log[i], next, lastEntry)
-            const unsigned ent = nent ? rlog::entry(lg, next, tb) : 0u;
             const int ci = sv_commit(svi) < lastEntry ? sv_commit(svi) : lastEntry;
             want_send = true;
-            skey = mk_aereq(sv_term(svi), prevIdx, prevTerm, nent, ent, ci, lg, i, j);
+            skey = mk_aereq(sv_term(svi), prevIdx, ci, lg, i, j);
         } else if (MSG_KINDS && slot >= FIX) {
             const int cnt = m_count(m);
             if (kind == 1) {  // DuplicateMessage(m), m \in SingleMessage(messages)   raft.tla:134-135,471-473
@@ -691,15 +700,15 @@ struct SpecRaft {
                             const unsigned vg = sv_granted(svi);
                             d.sv = sv_set_granted(svi, vg | (1u << j));
                             if (!(vg >> j & 1)) {  // voterLog[i] @@ (j :> m.mlog): existing entry wins
-                                d.vmode = 2; d.vj = j; d.vlog = (m >> 14) & 0x7fffull; d.ovl = s.get(W_VL(i));
+                                d.vmode = 2; d.vj = j; d.vlog = rv_mlog(m); d.ovl = s.get(W_VL(i));
                             }
                         }
                     }  // else DropStaleResponse   raft.tla:443-446
                     discard(k, m, d);
                 } else if (type == M_AEREQ) {  // HandleAppendEntriesRequest   raft.tla:355-417
-                    const int pidx = (int)(m >> 13 & 7), pterm = (int)(m >> 16 & 7), nent = (int)(m >> 19 & 1);
-                    const unsigned ent = (unsigned)(m >> 20 & 63);
-                    const int mci = (int)(m >> 26 & 7), stt = sv_state(svi), len = rlog::len(lg, tb);
+                    const int pidx = ae_pidx(m), pterm = ae_pterm(m, tb), nent = ae_nent(m, tb);
+                    const unsigned ent = ae_ent(m, tb);
+                    const int mci = ae_cidx(m), stt = sv_state(svi), len = rlog::len(lg, tb);
                     const bool logOk = pidx == 0 || (pidx > 0 && pidx <= len && pterm == rlog::eterm(rlog::entry(lg, pidx, tb)));
                     if (mterm < term || (mterm == term && stt == R_FOLLOWER && !logOk)) {  // reject   :361-373
                         want_send = true;
@@ -770,35 +779,41 @@ struct SpecRaft {
     // ---------------------------------------------------------------- expand-by-family interface
     // guards: cheap and EXACT as to the family (compute<MEM, FAM> still decides whether the action is enabled)
     struct Guards {
-        uint64_t fixed;   // bit s: fixed slot s (< FIX) may be enabled
+        uint64_t fixed, fixed_hi;  // bit s: fixed slot s (< FIX) may be enabled.  FIX = 5 n + 2 n^2 is 33 for three servers and 75 for
+                                   // five: two words (round 2 kept one — AppendEntries(i, j) of a leader s4 / s5, slots 65 .. 74, was
+                                   // never queued by the by-family kernel; found by the 15-level golden of the 5-server model)
         uint32_t infl;    // load_expand: bit k — message slot k < GUARD_SLOTS holds a message with a copy in flight (count > 0)
     };
     static constexpr int GUARD_SLOTS = 16;
     MC_HD static unsigned inflight_slots(const Guards &g) { return g.infl; }
+    MC_HD static void fixed_set(Guards &g, int slot) { if (slot < 64) g.fixed |= 1ull << slot; else g.fixed_hi |= 1ull << (slot - 64); }
+    MC_HD static bool fixed_bit(const Guards &g, int slot) { return ((slot < 64 ? g.fixed >> slot : g.fixed_hi >> (slot - 64)) & 1ull) != 0; }
+    MC_HD static void fixed_clear_dense(Guards &g) { g.fixed &= ~((1ull << DENSE_SLOTS) - 1ull); }
+    static_assert(FIX <= 128 && DENSE_SLOTS < 64, "Guards holds 128 fixed slots");
     MC_HD static int fixed_family(int slot) {
         // (slots < 2 NS are the dense pairs: never asked)
         return slot < 2 * NS + NS * NS ? F_REQVOTE : slot < 5 * NS + NS * NS ? F_MISC /* BecomeLeader, ClientRequest, AdvanceCommitIndex */ : F_APPEND;
     }
     MC_HD static void guards(const Params &prm, const Local &l, Guards &g) {
-        g.fixed = 0;
+        g.fixed = g.fixed_hi = 0;
         g.infl = 0;
         const int creq = g_creq(l.glob);
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             const uint64_t sv = l.sv.get(i);
             const int st = sv_state(sv);
-            g.fixed |= 1ull << i;                                                               // Restart(i)
-            if (st == R_FOLLOWER || st == R_CANDIDATE) g.fixed |= 1ull << (NS + i);              // Timeout(i)
+            fixed_set(g, i);                                                               // Restart(i)
+            if (st == R_FOLLOWER || st == R_CANDIDATE) fixed_set(g, NS + i);              // Timeout(i)
             if (st == R_CANDIDATE) {
 #pragma unroll
-                for (int j = 0; j < NS; j++) g.fixed |= 1ull << (2 * NS + i * NS + j);           // RequestVote(i, j)
-                if (in_quorum(sv_granted(sv))) g.fixed |= 1ull << (2 * NS + NS * NS + i);        // BecomeLeader(i)
+                for (int j = 0; j < NS; j++) fixed_set(g, 2 * NS + i * NS + j);           // RequestVote(i, j)
+                if (in_quorum(sv_granted(sv))) fixed_set(g, 2 * NS + NS * NS + i);        // BecomeLeader(i)
             }
             if (st == R_LEADER) {
-                if (creq < prm.max_client_requests) g.fixed |= 1ull << (3 * NS + NS * NS + i);   // ClientRequest(i)
-                g.fixed |= 1ull << (4 * NS + NS * NS + i);                                       // AdvanceCommitIndex(i)
+                if (creq < prm.max_client_requests) fixed_set(g, 3 * NS + NS * NS + i);   // ClientRequest(i)
+                fixed_set(g, 4 * NS + NS * NS + i);                                       // AdvanceCommitIndex(i)
 #pragma unroll
-                for (int j = 0; j < NS; j++) if (j != i) g.fixed |= 1ull << (5 * NS + NS * NS + i * NS + j);  // AppendEntries(i, j)
+                for (int j = 0; j < NS; j++) if (j != i) fixed_set(g, 5 * NS + NS * NS + i * NS + j);  // AppendEntries(i, j)
             }
         }
     }
@@ -840,14 +855,15 @@ struct SpecRaft {
         //      nMsgs says; an index is clamped into the capacity, wave-uniformly)
         constexpr int PRE = 12;
         uint64_t mw[PRE];
+        {
+            const int mwords = msg_words(prm);
 #pragma unroll
-        for (int k = 0; k < PRE; k++) mw[k] = 0;
-#pragma unroll
-        for (int g4 = 0; g4 < PRE / 4; g4++)
-            if (prm.cm > 4 * g4) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const int k = 4 * g4 + u; mw[k] = s.get(W_MSG0 + (k < prm.cm ? k : prm.cm - 1)); }
+            for (int q = 0; q < PRE / 2; q++) {  // (an index past the capacity is clamped into it, wave-uniformly)
+                const uint64_t x = s.get(W_MSG0 + (q < mwords ? q : mwords - 1));
+                mw[2 * q] = x & 0xffffffffull;
+                mw[2 * q + 1] = x >> 32;
             }
+        }
         const int wall = W_ALL0(prm);
         const uint64_t al0 = s.get(wall);
         // ---- arithmetic (bags beyond PRE keys / sets beyond 4 logs: the tail loads)
@@ -856,14 +872,14 @@ struct SpecRaft {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             if (k < l.nm) {
-                const uint64_t x = k < PRE ? mw[k < PRE ? k : 0] : s.get(W_MSG0 + k);
+                const uint64_t x = k < PRE ? mw[k < PRE ? k : 0] : rd_msg(s, k);
                 l.inflight += m_count(x);
                 sw[k >> 2] = (sw[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (key_sig(x) << (8 * (k & 3)));
                 if (m_count(x) > 0) g.infl |= 1u << k;
             }
         }
         l.sig = Sigs{sw[0], sw[1], sw[2], sw[3]};
-        for (int k = 16; k < l.nm; k++) l.inflight += m_count(s.get(W_MSG0 + k));
+        for (int k = 16; k < l.nm; k++) l.inflight += m_count(rd_msg(s, k));
         unsigned present = 0;
         const int na = g_na(l.glob);
 #pragma unroll
@@ -1061,10 +1077,13 @@ struct SpecRaft {
         l.nm = g_nm(l.glob);
         l.inflight = 0;
         uint32_t sw[4] = {SIG_EMPTY, SIG_EMPTY, SIG_EMPTY, SIG_EMPTY};
+        const int mwords = msg_words(prm);
         for (int k0 = 0; k0 < prm.cm; k0 += 8) {
-            uint64_t x[8];
+            uint64_t pw[4], x[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) x[u] = s.get(W_MSG0 + (k0 + u < l.nm ? k0 + u : 0));  // slot 0 exists whatever nMsgs is
+            for (int q = 0; q < 4; q++) pw[q] = s.get(W_MSG0 + (k0 + 2 * q < l.nm ? (k0 >> 1) + q : 0));  // word 0 exists whatever nMsgs is
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = half_of(pw[u >> 1], u);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int k = k0 + u;
@@ -1079,8 +1098,10 @@ struct SpecRaft {
                         if (wi == 3) sw[3] = (sw[3] & mk) | sg;
                     }
                 }
-                if (k < prm.cm) out.set(W_MSG0 + k, k < l.nm ? x[u] : 0ull);
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++)   // (slots >= nMsgs of a used word are zero in the parent already)
+                if ((k0 >> 1) + q < mwords) out.set(W_MSG0 + (k0 >> 1) + q, k0 + 2 * q < l.nm ? pw[q] : 0ull);
         }
         l.sig = Sigs{sw[0], sw[1], sw[2], sw[3]};
         const int ne = g_ne(l.glob), wel = W_EL0(prm);
@@ -1133,8 +1154,16 @@ struct SpecRaft {
             if (me && d.vmode == 2) v = vl_set(v, d.vj, d.vlog, prm);
             out.set(W_VL(i), v);
         }
-        if (d.nmop & 1) out.set(W_MSG0 + d.midxA, d.mnewA);
-        if (d.nmop & 2) out.set(W_MSG0 + d.midxB, d.mnewB);
+        {   // the one or two message slots the action rewrites: read-modify-write of their (parent) words; both may share a word
+            const int wa = d.midxA >> 1, wb = d.midxB >> 1;
+            if (d.nmop & 1) {
+                uint64_t x = 2 * wa < l.nm ? s.get(W_MSG0 + wa) : 0ull;
+                x = set_half(x, d.midxA, d.mnewA);
+                if ((d.nmop & 2) && wb == wa) x = set_half(x, d.midxB, d.mnewB);
+                out.set(W_MSG0 + wa, x);
+            }
+            if ((d.nmop & 2) && !((d.nmop & 1) && wb == wa)) out.set(W_MSG0 + wb, set_half(s.get(W_MSG0 + wb), d.midxB, d.mnewB));
+        }
         if (d.eadd) {
 #pragma unroll
             for (int q = 0; q < EL_WORDS; q++) out.set(wel + ne * EL_WORDS + q, d.ew.get(q));
@@ -1206,16 +1235,16 @@ struct SpecRaft {
                   d, (int)(m >> 16 & 7), (int)(m >> 13 & 7), sr, t);
             break;
         case M_RVRESP:
-            o.put("[mdest |-> s%d, mlog |-> ", d); t_log(o, (m >> 14) & 0x7fffull, tb);
+            o.put("[mdest |-> s%d, mlog |-> ", d); t_log(o, rv_mlog(m), tb);
             o.put(", msource |-> s%d, mterm |-> %d, mtype |-> RequestVoteResponse, mvoteGranted |-> %s]", sr, t, (m >> 13 & 1) ? "TRUE" : "FALSE");
             break;
         case M_AEREQ: {
-            o.put("[mcommitIndex |-> %d, mdest |-> s%d, mentries |-> ", (int)(m >> 26 & 7), d);
-            const unsigned e = (unsigned)(m >> 20 & 63);
-            if (m >> 19 & 1) o.put("<<[term |-> %d, value |-> %d]>>", rlog::eterm(e), rlog::evalue(e)); else o.put("<<>>");
-            o.put(", mlog |-> "); t_log(o, (m >> 29) & 0x7fffull, tb);
+            o.put("[mcommitIndex |-> %d, mdest |-> s%d, mentries |-> ", ae_cidx(m), d);
+            const unsigned e = ae_ent(m, tb);
+            if (ae_nent(m, tb)) o.put("<<[term |-> %d, value |-> %d]>>", rlog::eterm(e), rlog::evalue(e)); else o.put("<<>>");
+            o.put(", mlog |-> "); t_log(o, ae_mlog(m), tb);
             o.put(", mprevLogIndex |-> %d, mprevLogTerm |-> %d, msource |-> s%d, mterm |-> %d, mtype |-> AppendEntriesRequest]",
-                  (int)(m >> 13 & 7), (int)(m >> 16 & 7), sr, t);
+                  ae_pidx(m), ae_pterm(m, tb), sr, t);
             break;
         }
         default:
@@ -1240,7 +1269,7 @@ struct SpecRaft {
         const uint64_t g = w[W_GLOB] & 0xffffffffull;
         const int tb = prm.tb;
         o.put("/\\ messages = ");
-        for (int k = 0; k < g_nm(g); k++) { Txt e{tmp, sizeof tmp, 0}; t_msg(e, w[W_MSG0 + k], tb); e.put(" :> %d", m_count(w[W_MSG0 + k])); it[k] = strndup(tmp, e.k); }
+        for (int k = 0; k < g_nm(g); k++) { const uint64_t mk_ = rd_msg(CWordRef{w, 1}, k); Txt e{tmp, sizeof tmp, 0}; t_msg(e, mk_, tb); e.put(" :> %d", m_count(mk_)); it[k] = strndup(tmp, e.k); }
         t_sorted(o, it, g_nm(g), "(", " @@ ", ")", "<<>>");
         o.put("\n/\\ elections = ");
         for (int x = 0; x < g_ne(g); x++) {
