@@ -1,0 +1,40 @@
+// tlaeval.h — general TLA+ evaluator on the HOST: what `mc X.tla` falls back to for a TLA+ module that
+// has neither a hand lowering nor a PlusCal algorithm the compiler takes (the *Specifying Systems* examples of the reference,
+// e.g. examples/SpecifyingSystems/AdvancedExamples/MCInnerSerial.tla, whose TLC log testout2:260-266 is the end-to-end golden).
+// It evaluates module TEXT the way TLC does — actions left to right, `x' = e` assigns or tests, `x' \in S` / \E / \/ branch,
+// lazily evaluated operator arguments, bounded CHOOSE in a fixed value order, EXTENDS chains and named INSTANCEs, cfg CONSTANTS /
+// `<-` overrides / CONSTRAINT / INVARIANT / the safety part of a PROPERTY — and runs TLC's breadth-first search with exact
+// de-duplication on whole states.  It is NOT a GPU path and never stands in for one: the lowered specs (atomic_add, pcal_intro,
+// MCraft, the snapshot-isolation and Paxos models, compiled PlusCal programs) are refused here, and the report says which
+// engine produced it.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace tlaeval {
+
+struct Options {
+    uint64_t max_levels = 0, max_distinct = 0;
+    bool check_deadlock = true;
+    double progress_seconds = 0;  // > 0: print TLC's "Progress(d): ..." lines to stdout at this interval
+    std::vector<std::string> search;  // directories searched for EXTENDed / INSTANCEd modules (after the root module's own)
+};
+
+struct Result {
+    uint64_t distinct = 0, generated = 0, queue_left = 0, init_states = 0;
+    uint32_t depth = 0;
+    int verdict = 0;             // MC_V_* of include/tlamc.h
+    int violated_invariant = -1; // index into the cfg's INVARIANT list
+    std::string violated_name, error_message;
+    std::vector<uint64_t> levels;                                 // new distinct states per BFS level
+    std::vector<std::pair<std::string, std::string>> trace;       // (action label, state text) of a counterexample
+    double seconds = 0;
+};
+
+// `tlc X.tla` on the host.  Returns 0 or a negative MC_E* code with `error` set (parse errors: MC_EPARSE; a module the
+// evaluator cannot handle: MC_ENOSPEC).
+int check_files(const std::string &tla_path, const std::string &cfg_path, const Options &opt, Result &out, std::string &error);
+
+}  // namespace tlaeval
