@@ -118,7 +118,7 @@ typedef struct {
     int32_t violated_invariant; /* index into the spec's invariant list, -1 if none             */
     uint32_t trace_len;       /* states in the counterexample, 0 if none                        */
     uint32_t levels;          /* entries valid in level_distinct[]                              */
-    uint32_t reserved;
+    uint32_t host_evaluated;  /* 1: mc_check_files ran a module WITHOUT a GPU lowering on the host's general TLA+ evaluator */
     double seconds;           /* init -> last level complete, device work included              */
     uint64_t level_distinct[MC_MAX_LEVELS]; /* new distinct states per BFS level                */
 } mc_result;

@@ -483,10 +483,13 @@ class Parser:
                 items = self.exprlist(">>")
                 if self.cur().k == "id" and self.cur().s.startswith("_") and not self.ended():  # <<A>>_v
                     bare = self.cur().s == "_"
+                    sub = ("id", self.cur().s[1:])
                     self.i += 1
                     if bare:
-                        self.expr(16)   # <<A>>_<<v1, v2>>: the subscript is a tuple
-                    return ("temporal", "<<>>_", ("tuple", items))
+                        sub = self.expr(16)   # <<A>>_<<v1, v2>>: the subscript is a tuple
+                    if len(items) != 1:
+                        self.fail("<<A>>_v takes one action")
+                    return ("temporal", "<<>>_", items[0], sub)
                 return ("tuple", items)
             if c.s == "[":
                 n1 = self.peek()
@@ -904,11 +907,12 @@ def fmt(v):
 # =============================================================================================== evaluator
 class Thunk:
     """a lazily evaluated operator argument / LET definition without parameters"""
-    __slots__ = ("f", "env", "st", "memo", "val", "done")
+    __slots__ = ("f", "env", "st", "memo", "val", "done", "pvar")
 
     def __init__(self, f, env, st, memo):
         self.f, self.env, self.st, self.memo, self.done = f, env, st, memo, False
         self.val = None
+        self.pvar = None
 
     def force(self, nx):
         if self.done:
@@ -917,6 +921,14 @@ class Thunk:
         if self.memo:
             self.val, self.done = v, True
         return v
+
+
+class RecFn:
+    """a recursively defined function while it is being built"""
+    __slots__ = ("dom", "cache", "apply")
+
+    def __init__(self, dom):
+        self.dom, self.cache, self.apply = dom, {}, None
 
 
 class OpVal:
@@ -983,6 +995,9 @@ class Spec:
                 self._import_instance(name + "!", body[1], body[2])
             else:
                 self.defs[name] = GDef(nm, params, body, m.name, line)
+        for inst in m.instances:  # INSTANCE M without a name (TLC/MCAlternatingBit.tla:4): M's definitions under their own names
+            if inst not in self.BUILTIN_MODULES and not any(x.name == inst for x in self.modules):
+                self._import_instance("", inst, [])
 
     def _find_module(self, name):
         for d in self.search:
@@ -1026,6 +1041,8 @@ class Spec:
                 if body[0] == "instance":
                     self._import_instance(prefix + name + "!", body[1], [(a, rn(e)) for a, e in body[2]])
                     continue
+                if not prefix and name in self.defs:
+                    continue  # already there through EXTENDS
                 self.defs[prefix + name] = GDef(prefix + nm, params, rn(body), m.name, line)
                 if (m.name, name) in self.scoped:
                     self.scoped_overrides[prefix + name] = self.scoped[(m.name, name)]
@@ -1142,9 +1159,33 @@ class Spec:
         return self.cv(self._nth_node(node), {})
 
     def v_temporal(self, node, scope):
+        if node[1] in ("[]_", "<<>>_"):  # [A]_v = A \/ UNCHANGED v;  <<A>>_v = A /\ ~UNCHANGED v
+            a, u = self.cv(node[2], scope), self.cv(("unchanged", node[3]), scope)
+            if node[1] == "[]_":
+                return lambda env, st, nx: _bool(a(env, st, nx), "[A]_v") or _bool(u(env, st, nx), "UNCHANGED")
+            return lambda env, st, nx: _bool(a(env, st, nx), "<<A>>_v") and not _bool(u(env, st, nx), "UNCHANGED")
+
         def f(env, st, nx):
             raise TLAError("temporal formula evaluated")
         return f
+
+    def a_temporal(self, node, scope):
+        if node[1] == "[]_":
+            a, u = self.ca(node[2], scope), self.ca(("unchanged", node[3]), scope)
+
+            def g(env, st, nx):
+                yield from a(env, st, nx)
+                yield from u(env, st, nx)
+            return g
+        if node[1] == "<<>>_":
+            a, u = self.ca(node[2], scope), self.cv(("unchanged", node[3]), scope)
+
+            def g2(env, st, nx):
+                for nx2 in a(env, st, nx):
+                    if u(env, st, nx2) is False:
+                        yield nx2
+            return g2
+        return self._a_test(node, scope)
 
     def v_id(self, node, scope):
         name = node[1]
@@ -1265,7 +1306,29 @@ class Spec:
                 return mkb
         f = self.cv(node, scope)
         memo = not self.primed(node, scope)
-        return lambda env, st, nx: Thunk(f, env, st, memo)
+        # an argument that IS a primed variable (InternalMemory.tla:17 Send(p, req, memInt, memInt')) can be assigned through the
+        # parameter (MCSend(p, d, old, new) == new = <<p, d>>): the thunk remembers which variable
+        inner = node
+        while inner[0] == "paren":
+            inner = inner[1]
+        pvar = None
+        if inner[0] == "prime" and inner[1][0] == "id" and inner[1][1] not in scope and self.overrides.get(inner[1][1], inner[1][1]) in self.varidx:
+            pvar = self.varidx[self.overrides.get(inner[1][1], inner[1][1])]
+        if inner[0] == "id" and inner[1] in scope:
+            name = inner[1]
+
+            def mkp(env, st, nx):
+                t = Thunk(f, env, st, memo)
+                src = env[name]
+                t.pvar = src.pvar if type(src) is Thunk else None
+                return t
+            return mkp
+
+        def mkt(env, st, nx):
+            t = Thunk(f, env, st, memo)
+            t.pvar = pvar
+            return t
+        return mkt
 
     def v_call(self, node, scope):
         name, argnodes = node[1], node[2]
@@ -1542,7 +1605,30 @@ class Spec:
         doms = [(pat, self.cv(dom, scope)) for pat, dom in bs]
         bind = self._bind
         if selfname:
-            raise TLAError("recursive function definitions f[x \\in S] == ... are not supported")
+            # f[x \in S] == e with f inside e (WriteThroughCache.tla:55-60): while the function is built, f[a] evaluates e for x = a
+            if len(doms) != 1:
+                raise TLAError("recursive function definitions with several bounds are not supported")
+            pat0, dom0 = doms[0]
+
+            def grec(env, st, nx):
+                d = dom0(env, st, nx)
+                rec = RecFn(d)
+                e1 = dict(env)
+                e1[selfname] = rec
+
+                def apply(a):
+                    if a in rec.cache:
+                        return rec.cache[a]
+                    if not set_in(a, d):
+                        raise TLAError(f"function applied outside its domain: {fmt(a)}")
+                    e2 = dict(e1)
+                    bind(pat0, a, e2)
+                    v = body(e2, st, nx)
+                    rec.cache[a] = v
+                    return v
+                rec.apply = apply
+                return mk_fn({x: apply(x) for x in iter_set(d)})
+            return grec
         if len(doms) == 1 and not isinstance(doms[0][0], tuple):
             pat, dom = doms[0]
 
@@ -1608,7 +1694,13 @@ class Spec:
 
     def v_idx(self, node, scope):
         f, a = self.cv(node[1], scope), self.cv(node[2], scope)
-        return lambda env, st, nx: fn_apply(f(env, st, nx), a(env, st, nx))
+
+        def g(env, st, nx):
+            fv = f(env, st, nx)
+            if type(fv) is RecFn:
+                return fv.apply(a(env, st, nx))
+            return fn_apply(fv, a(env, st, nx))
+        return g
 
     def v_pre(self, node, scope):
         f = self.cv(node[2], scope)
@@ -1857,6 +1949,27 @@ class Spec:
                 elif not clash_test or set_in(cur, s):
                     yield nx
             return gin
+        if op in ("=", "\\in") and lhs[0] == "id" and lhs[1] in scope:
+            pname = lhs[1]
+            rhs = self.cv(node[3], scope)
+            test = self._a_test(node, scope)
+
+            def gpar(env, st, nx):
+                t = env[pname]
+                i = t.pvar if type(t) is Thunk else None
+                if i is None:
+                    yield from test(env, st, nx)
+                    return
+                cur = nx.get(i, UNASSIGNED)
+                r = rhs(env, st, nx)
+                if cur is UNASSIGNED:
+                    for v in ([r] if op == "=" else iter_set(r)):
+                        new = dict(nx)
+                        new[i] = v
+                        yield new
+                elif (cur == r) if op == "=" else set_in(cur, r):
+                    yield nx
+            return gpar
         return self._a_test(node, scope)
 
     def a_id(self, node, scope):
@@ -2215,7 +2328,8 @@ class Checker:
 
     def _is_temporal(self, n, seen=None):
         seen = seen if seen is not None else set()
-        if isinstance(n, tuple) and n and (n[0] == "temporal" or (n[0] == "op" and n[1] == "~>")):
+        if isinstance(n, tuple) and n and (n[0] == "temporal" or (n[0] == "op" and n[1] == "~>")
+                                           or (n[0] == "call" and isinstance(n[1], str) and n[1][:3] in ("WF_", "SF_"))):
             return True
         if isinstance(n, tuple) and n and n[0] == "id":
             nm = self.spec.overrides.get(n[1], n[1])
@@ -2272,12 +2386,17 @@ class Checker:
         items = body[1] if body[0] == "conj" else [body]
         flat = []
 
+        sp = self.spec
+
         def walk(n):
             if n[0] == "conj":
                 for x in n[1]:
                     walk(x)
             elif n[0] == "paren":
                 walk(n[1])
+            elif n[0] == "id" and n[1] not in sp.varidx and sp.overrides.get(n[1], n[1]) in sp.defs and \
+                    not sp.defs[sp.overrides.get(n[1], n[1])].params and self._is_temporal(sp.defs[sp.overrides.get(n[1], n[1])].body):
+                walk(sp.defs[sp.overrides.get(n[1], n[1])].body)  # LSpec == HC /\ WF_hr(HCnxt) with HC == HCini /\ [][HCnxt]_hr
             else:
                 flat.append(n)
         for it in items:
@@ -2287,7 +2406,7 @@ class Checker:
             if n[0] == "temporal" and n[1] == "[]" and n[2][0] == "temporal" and n[2][1] == "[]_":
                 a = n[2][2]
                 nxt = a[1] if a[0] == "id" else a
-            elif n[0] != "temporal" and not (n[0] == "call" and n[1][:3] in ("WF_", "SF_")) and init is None:
+            elif init is None and not self._is_temporal(n) and not (n[0] == "call" and n[1][:3] in ("WF_", "SF_")):
                 init = n[1] if n[0] == "id" else n
         if init is None or nxt is None:
             raise TLAError(f"cannot split {name} into Init and Next")

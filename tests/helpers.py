@@ -154,6 +154,34 @@ def build_shim():
     return so
 
 
+def build_tlaeval_door():
+    """tests/_tlaeval: the host evaluator of the product (tla_rust_amd/csrc/tlaeval.cpp) behind a test-only door, so that it can be
+    run on module texts the product itself never evaluates on the host (the ones with a GPU lowering)"""
+    d = ROOT / "tests" / "_tlaeval"
+    out = d / "_build"
+    out.mkdir(exist_ok=True)
+    so = out / "libtlaeval_door.so"
+    csrc = ROOT / "tla_rust_amd" / "csrc"
+    srcs = [d / "door.cpp", csrc / "tlaeval.cpp", csrc / "tlaeval.h"]
+    if not so.exists() or any(so.stat().st_mtime < s.stat().st_mtime for s in srcs):
+        tmp = out / f"libtlaeval_door.{os.getpid()}.so"
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(tmp), str(srcs[0]), str(srcs[1]), "-lpthread"], check=True)
+        os.replace(tmp, so)
+    return so
+
+
+def tlaeval_run(tla, cfg, search=(), max_levels=0, deadlock=True, dump=None, order=()):
+    """the host evaluator on module + cfg files -> dict(rc, distinct, generated, depth, verdict (MC_V_*), levels, ...)"""
+    import ctypes as C
+    import json
+    lib = C.CDLL(str(build_tlaeval_door()))
+    lib.tlaeval_door.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(1 << 16)
+    lib.tlaeval_door(str(tla).encode(), str(cfg).encode(), ":".join(str(s) for s in search).encode(), max_levels, 1 if deadlock else 0,
+                     str(dump).encode() if dump else None, ",".join(order).encode(), buf, len(buf))
+    return json.loads(buf.value.decode())
+
+
 def build_fakerccl():
     """tests/_fakerccl: the librccl stand-in that lets P ranks of the hip-rccl back-end share ONE GPU ($TLAMC_RCCL)"""
     d = ROOT / "tests" / "_fakerccl"

@@ -1,0 +1,203 @@
+"""The product's host evaluator (tla_rust_amd/csrc/tlaeval.cpp): `mc X.tla` for a TLA+ module that has no
+GPU lowering.
+
+  * end to end through the C ABI (mc_check_files) on the reference's MCInnerSerial.tla + MCInnerSerial.cfg: the COMPLETE TLC run
+    of testout2 (4 initial states :3; 6181 generated / 195 distinct / 0 on queue :265; diameter 5 :266; "No error" :260), testout1:4's
+    first progress line (772 / 160) on the way, and the level profile of the committed fixture tests/golden/tlc_log_mcinnerserial.json;
+  * against the independent Python evaluator of the oracle (oracle/tlaplus.py — closures compiled from the tree, where this one is
+    a tree interpreter) on every other checkable model of examples/SpecifyingSystems and on MCConsensus;
+  * through a test-only door (tests/_tlaeval) on texts the product itself never evaluates on the host because they HAVE a lowering:
+    the reference's raft.tla under specs/MCraft.tla must give the per-level state SETS of the committed reference-text fixture,
+    and the PlusCal translation in specs/pcal_intro.tla the README's TLC run (9097 / 6164 / depth 7, MoneyInvariant violated);
+  * the product refuses to host-evaluate a module of a lowered family (no CPU fallback for the GPU path).
+
+Tests that read /root/reference run only in the build container; the rest (own texts under specs/ and tests/golden) run anywhere."""
+import hashlib
+import json
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+import helpers
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+S = Path("/root/reference/examples/SpecifyingSystems")
+SEARCH = [S / d for d in ("Standard", "CachingMemory", "TLC", "FIFO", "AsynchronousInterface", "HourClock", "Liveness", "RealTime", "AdvancedExamples")]
+needs_reference = pytest.mark.skipif(not S.exists(), reason="/root/reference is only present in the build container")
+V_OK, V_INVARIANT, V_ASSERT, V_DEADLOCK, V_SPECERR, V_BUDGET = range(6)
+
+
+@pytest.fixture
+def tla_path(monkeypatch):
+    monkeypatch.setenv("TLA_PATH", ":".join(str(s) for s in SEARCH))
+
+
+def _product(tla, cfg=None, **kw):
+    from tla_rust_amd import binding as B
+    return B.check_files(tla, cfg, **kw)
+
+
+@needs_reference
+def test_mc_reproduces_the_complete_tlc_log_of_the_reference(tla_path):
+    g = json.loads((ROOT / "tests" / "golden" / "tlc_log_mcinnerserial.json").read_text())
+    r, report = _product(S / "AdvancedExamples" / "MCInnerSerial.tla")
+    assert r.host_evaluated
+    assert (r.generated, r.distinct, r.queue_left, r.depth, r.verdict) == (6181, 195, 0, 5, "ok")       # testout2:265-266, :260
+    assert r.levels == g["levels"] == [4, 16, 60, 80, 35]
+    lines = report.splitlines()
+    assert "evaluated on the host" in lines[0]                                                        # the report says which engine ran
+    assert lines[1] == "Finished computing initial states: 4 distinct states generated."              # testout2:3
+    assert "Model checking completed. No error has been found." in lines                               # testout2:260
+    assert "6181 states generated, 195 distinct states found, 0 states left on queue." in lines        # testout2:265
+    assert lines[-1] == "The state graph has diameter 5."                                              # testout2:266
+
+
+@needs_reference
+def test_first_progress_line_of_testout1(tla_path):
+    r, _ = _product(S / "AdvancedExamples" / "MCInnerSerial.tla", max_levels=4)
+    assert (r.generated, r.distinct, r.levels, r.verdict) == (772, 160, [4, 16, 60, 80], "budget")    # testout1:4
+
+
+MODELS = ["AdvancedExamples/MCInnerSequential", "AsynchronousInterface/AsynchInterface", "AsynchronousInterface/Channel",
+          "CachingMemory/MCInternalMemory", "CachingMemory/MCWriteThroughCache", "FIFO/MCInnerFIFO", "HourClock/HourClock", "HourClock/HourClock2",
+          "Liveness/LiveHourClock", "Liveness/MCLiveInternalMemory", "Liveness/MCLiveWriteThroughCache", "RealTime/MCRealTimeHourClock",
+          "TLC/ABCorrectness", "TLC/MCAlternatingBit"]
+
+
+@needs_reference
+@pytest.mark.parametrize("model", MODELS)
+def test_equals_the_python_evaluator_on_the_specifying_systems_models(model, tla_path):
+    """two independent evaluators of the same text: counters, depth, verdict and per-level counts"""
+    import tlaplus as T
+    tla = S / f"{model}.tla"
+    c = T.Checker(tla, cfg_path=tla.with_suffix(".cfg"), search=[tla.parent] + SEARCH)
+    p = c.run_levels(keep_states=False)
+    r, _ = _product(tla)
+    assert r.host_evaluated
+    assert (r.distinct, r.generated, r.depth, r.verdict, r.levels) == (p["distinct"], p["generated"], p["depth"], p["verdict"], p["levels"])
+    assert r.distinct > 1
+
+
+@needs_reference
+def test_deadlock_of_mcconsensus():
+    """examples/Paxos/MCConsensus: a chosen value is a state without successors (TLC reports deadlock unless run with -deadlock)"""
+    tla = Path("/root/reference/examples/Paxos/MCConsensus.tla")
+    r, report = _product(tla)
+    assert (r.distinct, r.generated, r.verdict) == (4, 7, "deadlock") and "Error: Deadlock reached." in report
+
+
+def _digests(dump):
+    by_level = helpers.read_dump(str(dump))
+    return [hashlib.sha256("\n".join(sorted(by_level[k])).encode()).hexdigest()[:16] for k in sorted(by_level)]
+
+
+@needs_reference
+@pytest.mark.parametrize("name", ["raft_2s_mcr1", "raft_2s_mcr2_keys8", "raft_3s_keys4"])
+def test_evaluator_on_the_reference_raft_text(name, tmp_path):
+    """the reference's raft.tla:110-507 under specs/MCraft.tla: per-level state SETS equal the reference-text fixture (which the C
+    oracle and the device lowering are pinned to)"""
+    from make_reference_text_golden import RAFT_MODELS, RAFT_ORDER, raft_cfg
+    gold = json.loads((ROOT / "tests" / "golden" / "raft_reference_text.json").read_text())[name]
+    m = RAFT_MODELS[name]
+    cfg = tmp_path / "m.cfg"
+    cfg.write_text(raft_cfg(*m["params"][:5], m["params"][5], m.get("mk", 64)))
+    dump = tmp_path / "dump.txt"
+    r = helpers.tlaeval_run(ROOT / "specs" / "MCraft.tla", cfg, search=["/root/reference/examples"], dump=dump, order=RAFT_ORDER)
+    assert r["rc"] == 0, r
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (gold["distinct"], gold["generated"], gold["depth"], gold["levels"])
+    assert _digests(dump) == gold["level_digests"]
+
+
+def test_evaluator_on_the_pluscal_translation_gives_the_readme_run(tmp_path):
+    """specs/pcal_intro.tla carries the translation pcal2tla inserts: evaluated as plain TLA+ it must give the README's TLC run
+    (README.md:319-321: 9097 generated / 6164 distinct / 999 on queue; depth 7; MoneyInvariant violated)"""
+    r = helpers.tlaeval_run(ROOT / "specs" / "readme_variant" / "pcal_intro.tla", ROOT / "specs" / "readme_variant" / "pcal_intro.cfg")
+    assert r["rc"] == 0, r
+    assert (r["verdict"], r["trace_len"]) in ((V_INVARIANT, 6), (V_ASSERT, 6)), r
+
+
+def test_evaluator_equals_the_c_oracle_on_atomic_add(tmp_path):
+    o = helpers.oracle_run("atomic_add", [3])
+    (tmp_path / "n3.cfg").write_text("SPECIFICATION Spec\nCONSTANT N = 3\n")
+    r = helpers.tlaeval_run(ROOT / "specs" / "atomic_add_n.tla", tmp_path / "n3.cfg", deadlock=False)
+    assert r["rc"] == 0, r
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+
+
+def test_the_product_never_host_evaluates_a_lowered_family(tmp_path):
+    """a raft wrapper whose text the lowering refuses stays refused (MC_ENOSPEC): no CPU fallback for the GPU path"""
+    from tla_rust_amd import binding as B
+    t = (ROOT / "specs" / "MCraft.tla").read_text().replace("MODULE MCraft", "MODULE MCraftEdited") + "\n"
+    t = t.replace("====", "Extra == TRUE\n====", 1)
+    (tmp_path / "MCraftEdited.tla").write_text(t)
+    (tmp_path / "MCraftEdited.cfg").write_text((ROOT / "specs" / "MCraft_small.cfg").read_text())
+    with pytest.raises(B.McError) as e:
+        B.check_files(tmp_path / "MCraftEdited.tla")
+    assert e.value.code == -9   # MC_ENOSPEC
+
+
+def test_syntax_error_is_a_parse_error(tmp_path):
+    from tla_rust_amd import binding as B
+    (tmp_path / "Bad.tla").write_text("---- MODULE Bad ----\nVARIABLE x\nInit == x = (1\nNext == x' = x\n====\n")
+    (tmp_path / "Bad.cfg").write_text("INIT Init\nNEXT Next\n")
+    with pytest.raises(B.McError) as e:
+        B.check_files(tmp_path / "Bad.tla")
+    assert e.value.code == -8   # MC_EPARSE
+
+
+OWN = r"""---- MODULE Own ----
+EXTENDS Naturals, Sequences, FiniteSets, TLC
+CONSTANTS Proc, Max
+VARIABLES q, seen, owner
+Msg == [from : Proc, n : 0 .. Max]
+Fresh(p) == {m \in Msg : m.from = p /\ m \notin seen}
+Init == /\ q = << >>
+        /\ seen = {}
+        /\ owner = [p \in Proc |-> 0]
+Send(p) == \E m \in Fresh(p) :
+             /\ Len(q) < 2
+             /\ q' = Append(q, m)
+             /\ seen' = seen \cup {m}
+             /\ UNCHANGED owner
+Recv == /\ q # << >>
+        /\ LET m == Head(q)
+               best == CHOOSE p \in Proc : \A r \in Proc : owner[p] >= owner[r]
+           IN  /\ owner' = [owner EXCEPT ![m.from] = IF m.n > @ THEN m.n ELSE @]
+               /\ q' = Tail(q)
+               /\ best \in Proc
+        /\ UNCHANGED seen
+Next == (\E p \in Proc : Send(p)) \/ Recv
+Spec == Init /\ [][Next]_<<q, seen, owner>>
+Bounded == Cardinality(seen) <= Cardinality(Msg)
+Small == \A p \in Proc : owner[p] < Max
+====
+"""
+
+
+@pytest.mark.parametrize("inv,verdict", [("Bounded", "ok"), ("Small", "invariant")])
+def test_own_module_equals_the_python_evaluator(inv, verdict, tmp_path):
+    """runs anywhere (no reference text): records, sequences, EXCEPT with @, LET, CHOOSE, set filters, a violated invariant with its
+    counterexample"""
+    import tlaplus as T
+    (tmp_path / "Own.tla").write_text(OWN)
+    cfg = f"SPECIFICATION Spec\nCONSTANTS Proc = {{a, b}}  Max = 2\nINVARIANT {inv}\n"
+    (tmp_path / "Own.cfg").write_text(cfg)
+    p = T.Checker(tmp_path / "Own.tla", cfg_text=cfg).run_levels(keep_states=False, check_deadlock=False)
+    from tla_rust_amd import binding as B
+    cfgc = B.Config(0, B.MC_F_TRACE, 0, 0, 0, 0, 0, 0, 1)   # -deadlock: the model stops when every message was sent
+    import ctypes as C
+    r = B.CResult()
+    buf = C.create_string_buffer(1 << 20)
+    rc = B.lib().mc_check_files(str(tmp_path / "Own.tla").encode(), None, C.byref(cfgc), buf, len(buf), C.byref(r))
+    assert rc == 0, B.lib().mc_last_error().decode()
+    res = B._result(r)
+    assert res.verdict == verdict == p["verdict"]
+    if verdict == "ok":
+        assert (res.distinct, res.generated, res.depth, res.levels) == (p["distinct"], p["generated"], p["depth"], p["levels"])
+    else:  # the search stops at the first violation it meets: which one depends on the enumeration order, its depth does not
+        assert (res.trace_len, res.depth) == (p["trace_len"], p["depth"]) and f"Error: Invariant {inv} is violated." in buf.value.decode()
+        assert buf.value.decode().count("State ") == res.trace_len

@@ -26,6 +26,7 @@
 
 #include "../../include/tlamc.h"
 #include "pcal.h"
+#include "tlaeval.h"
 #include "spec_vm.h"
 
 extern "C" void mc_set_error_internal(const char *msg);  // engine.hip
@@ -773,6 +774,28 @@ bool parse_id_set(const std::string &b, size_t &i, std::vector<std::string> &out
 }
 }  // namespace
 
+// $TLA_PATH: a ':'-separated list of directories searched (after the model's own) for the modules a model EXTENDS / INSTANCEs
+static std::vector<std::string> tla_path_dirs() {
+    std::vector<std::string> out;
+    const char *env = getenv("TLA_PATH");
+    if (!env) return out;
+    const std::string e = env;
+    size_t a = 0;
+    while (a <= e.size()) {
+        const size_t b = e.find(':', a);
+        const std::string d = e.substr(a, b == std::string::npos ? std::string::npos : b - a);
+        if (!d.empty()) out.push_back(d);
+        if (b == std::string::npos) break;
+        a = b + 1;
+    }
+    return out;
+}
+static bool read_module(const char *model_path, const std::string &name, std::string &out) {
+    if (read_file(dir_of(model_path) + "/" + name + ".tla", out)) return true;
+    for (const auto &d : tla_path_dirs()) if (read_file(d + "/" + name + ".tla", out)) return true;
+    return false;
+}
+
 // 1 = not a Paxos-family model (the other resolvers go on); MC_OK = R.d is filled in; < 0 = an error
 static int resolve_paxos(const char *tla_path, const std::string &tla, const std::string &module, const mc_cfg *c, unsigned flags,
                          mc_spec_desc &d, std::string &def_text, std::string &def_module_name, std::string &warning) {
@@ -884,12 +907,11 @@ static int resolve_paxos(const char *tla_path, const std::string &tla, const std
     }
     // the lowering is written against Voting.tla, Paxos.tla and Consensus.tla: verified where they are found (beside the
     // model or under $TLA_PATH), refused otherwise unless -unverified
-    const char *env = getenv("TLA_PATH");
     const std::vector<std::pair<const char *, uint64_t>> need = kind ? std::vector<std::pair<const char *, uint64_t>>{{"Voting", H_VOTING}, {"Consensus", H_CONSENSUS}}
                                                                       : std::vector<std::pair<const char *, uint64_t>>{{"Paxos", H_PAXOS}, {"Voting", H_VOTING}};
     for (const auto &nh : need) {
         std::string text, part;
-        const bool found = read_file(dir_of(tla_path) + "/" + nh.first + ".tla", text) || (env && read_file(std::string(env) + "/" + nh.first + ".tla", text));
+        const bool found = read_module(tla_path, nh.first, text);
         if (found) {
             if (!module_body(text, part) || text_hash(part) != nh.second)
                 return fe_fail(MC_ENOSPEC, "%s.tla differs from the text the lowering was written against (examples/Paxos/%s.tla)", nh.first, nh.first);
@@ -992,8 +1014,7 @@ static int resolve_files(const char *tla_path, const char *cfg_path, unsigned fl
         // the invariant definitions).  Both are verified; a module that cannot be found is refused (never mis-checked)
         // unless the caller asks for the built-in lowering unverified (MC_F_UNVERIFIED, `mc -unverified`).
         std::string raft;
-        const char *env = getenv("TLA_PATH");
-        bool found = read_file(dir_of(tla_path) + "/raft.tla", raft) || (env && read_file(std::string(env) + "/raft.tla", raft));
+        bool found = read_module(tla_path, "raft", raft);
         if (module == "raft") { raft = tla; found = true; }
         else {
             if (!module_body(tla, part)) return fe_fail(MC_ENOSPEC, "%s: cannot find the module body", tla_path);
@@ -1023,8 +1044,7 @@ static int resolve_files(const char *tla_path, const char *cfg_path, unsigned fl
         std::string ssi;  // the MC wrapper EXTENDS the spec: verify it when it can be found
         const bool tb = d.params[4] != 0;
         const std::string base = tb ? "textbookSnapshotIsolation" : "serializableSnapshotIsolation";
-        const char *env = getenv("TLA_PATH");
-        bool found = read_file(dir_of(tla_path) + "/" + base + ".tla", ssi) || (env && read_file(std::string(env) + "/" + base + ".tla", ssi));
+        bool found = read_module(tla_path, base, ssi);
         if (module == base) { ssi = tla; found = true; }
         else {
             if (!module_body(tla, part)) return fe_fail(MC_ENOSPEC, "%s: cannot find the module body", tla_path);
@@ -1061,12 +1081,89 @@ int mc_resolve_files(const char *tla_path, const char *cfg_path, unsigned flags,
     return MC_OK;
 }
 
+// Is the module one of the families that HAVE a GPU lowering (the model-checking hot path)?  Those never reach the host
+// evaluator: a raft / snapshot-isolation / Paxos / PlusCal model that the lowerings refuse stays refused (MC_ENOSPEC).
+static bool lowered_family(const std::string &module, const std::string &tla) {
+    static const char *const names[] = {"atomic_add", "atomic_add_n", "pcal_intro", "MCraft", "raft", "MCssi", "serializableSnapshotIsolation",
+                                        "MCtextbookSI", "textbookSnapshotIsolation", "MCPaxos", "MCVoting", "Paxos", "Voting"};
+    for (const char *n : names) if (module == n) return true;
+    if (tla.find("--algorithm") != std::string::npos || tla.find("--fair") != std::string::npos) return true;
+    const std::string t = strip_comments(tla);
+    const size_t ex = t.find("EXTENDS");
+    if (ex == std::string::npos) return false;
+    const size_t exend = t.find('\n', ex);
+    const std::string line = t.substr(ex, exend == std::string::npos ? std::string::npos : exend - ex);
+    for (const char *n : {"raft", "serializableSnapshotIsolation", "textbookSnapshotIsolation", "Voting", "Paxos"}) {
+        size_t k = line.find(n);
+        while (k != std::string::npos) {
+            const bool l = k == 0 || !Lexer::idch(line[k - 1]), r = k + strlen(n) >= line.size() || !Lexer::idch(line[k + strlen(n)]);
+            if (l && r) return true;
+            k = line.find(n, k + 1);
+        }
+    }
+    return false;
+}
+
+// `tlc X.tla` for a TLA+ module that has NO GPU lowering (the Specifying Systems examples of the reference: MCInnerSerial.tla and
+// its TLC log testout2): the general evaluator of tlaeval.h runs TLC's breadth-first search on the host and the report says so.
+static int host_evaluate(const char *tla_path, const char *cfg_path, const mc_config *cfg, const std::string &module, char *report,
+                         size_t report_cap, mc_result *res) {
+    std::string cpath;
+    if (cfg_path) cpath = cfg_path;
+    else {
+        cpath = tla_path;
+        const size_t dot = cpath.rfind(".tla");
+        if (dot != std::string::npos) cpath.replace(dot, 4, ".cfg"); else cpath += ".cfg";
+    }
+    tlaeval::Options opt;
+    opt.max_levels = cfg->max_levels;
+    opt.max_distinct = cfg->max_distinct;
+    opt.check_deadlock = (cfg->flags & MC_F_DEADLOCK) != 0;
+    if (cfg->flags & MC_F_PROGRESS) { const char *iv = getenv("TLAMC_PROGRESS_INTERVAL"); opt.progress_seconds = iv ? atof(iv) : 60.0; }
+    opt.search = tla_path_dirs();
+    tlaeval::Result r;
+    std::string err;
+    const int rc = tlaeval::check_files(tla_path, cpath, opt, r, err);
+    if (rc) return fe_fail(rc, "%s: %s", module.c_str(), err.c_str());
+    memset(res, 0, sizeof *res);
+    res->distinct = r.distinct; res->generated = r.generated; res->queue_left = r.queue_left; res->depth = r.depth; res->verdict = r.verdict;
+    res->violated_invariant = r.violated_invariant; res->trace_len = (uint32_t)r.trace.size(); res->seconds = r.seconds; res->host_evaluated = 1;
+    res->levels = (uint32_t)std::min<size_t>(r.levels.size(), MC_MAX_LEVELS);
+    for (uint32_t i = 0; i < res->levels; i++) res->level_distinct[i] = r.levels[i];
+    Out o{report, report_cap, 0};
+    o.put("Module %s has no GPU lowering: evaluated on the host by the general TLA+ evaluator.\n", module.c_str());
+    o.put("Finished computing initial states: %llu distinct state%s generated.\n", (unsigned long long)r.init_states, r.init_states == 1 ? "" : "s");
+    if (r.verdict == MC_V_OK || r.verdict == MC_V_BUDGET) {
+        if (r.verdict == MC_V_OK) o.put("Model checking completed. No error has been found.\n");
+        else o.put("Search stopped by the level/state budget; no error has been found so far.\n");
+    } else {
+        if (r.verdict == MC_V_ASSERT) o.put("The first argument of Assert evaluated to FALSE; the second argument was:\n\"%s\"\n", r.error_message.c_str());
+        else if (r.verdict == MC_V_INVARIANT && r.violated_invariant >= 0 && (size_t)r.violated_invariant >= r.n_invariants) o.put("Error: Action property %s is violated.\n", r.violated_name.c_str());
+        else if (r.verdict == MC_V_INVARIANT) o.put("Error: Invariant %s is violated.\n", r.violated_name.c_str());
+        else if (r.verdict == MC_V_DEADLOCK) o.put("Error: Deadlock reached.\n");
+        else o.put("Error: evaluation error: %s\n", r.error_message.c_str());
+        if (!r.trace.empty()) {
+            o.put("Error: The behavior up to this point is:\n");
+            for (size_t k = 0; k < r.trace.size(); k++) o.put("State %zu:%s\n%s\n\n", k + 1, k ? "" : " <Initial predicate>", r.trace[k].second.c_str());
+        }
+    }
+    o.put("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)r.generated, (unsigned long long)r.distinct,
+          (unsigned long long)r.queue_left);
+    if (r.verdict == MC_V_OK) o.put("The state graph has diameter %u.\n", r.depth);  // testout2:266
+    else o.put("The depth of the complete state graph search is %u.\n", r.depth);
+    return MC_OK;
+}
+
 int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
                         mc_result *res, const char *dump_path, const char *recover_path, const char *checkpoint_path) {
     if (!tla_path || !cfg || !report || !report_cap || !res) return MC_EBADCFG;
     report[0] = 0;
     Resolved R;
     int rc = resolve_files(tla_path, cfg_path, cfg->flags, R);
+    if (rc == MC_ENOSPEC && !R.module.empty() && !lowered_family(R.module, R.tla)) {
+        if (dump_path || recover_path || checkpoint_path) return fe_fail(MC_ENOSPEC, "%s: -dump / -recover / -checkpoint need a GPU lowering (the module is evaluated on the host)", R.module.c_str());
+        return host_evaluate(tla_path, cfg_path, cfg, R.module, report, report_cap, res);
+    }
     if (rc) return rc;
     const mc_spec_desc &d = R.d;
     const std::string &tla = R.tla, &module = R.module, &def_text = R.def_text, &def_module_name = R.def_module_name;

@@ -4,11 +4,16 @@
 //
 //   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic] [-dump FILE]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
-//            [-checkpoint FILE] [-recover FILE] [-gpus P [-samedevice | -torch]] [-noprogress]
+//            [-checkpoint FILE] [-recover FILE] [-gpus P [-samedevice | -torch]] [-noprogress] [-I DIR]
 //   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
 //                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
 //                                         the previous text is kept as X.old
 //
+// A module that has a GPU lowering (the PlusCal programs, raft, the snapshot-isolation and Paxos models) is checked on the GPU
+// and nowhere else.  Any OTHER TLA+ module (the Specifying Systems examples of the reference: `mc MCInnerSerial.tla` prints
+// testout2:260-266) is evaluated on the host by the general evaluator (csrc/tlaeval.cpp); the report's first line says so.
+// -I DIR    : one more directory searched for the modules X.tla EXTENDS / INSTANCEs (after X.tla's own and $TLA_PATH's, which
+//             is a ':'-separated list).
 // -generic  : check a PlusCal module through the compiled program even when a hand lowering exists.
 // -unverified: an MC wrapper (specs/MCraft.tla ...) EXTENDS a module of the reference (raft.tla); when that module is found
 //             neither beside the wrapper nor under $TLA_PATH the run is refused, unless this option accepts the built-in
@@ -276,6 +281,12 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "-torch") || !strcmp(argv[i], "-samedevice")) {}
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
         else if (!strcmp(argv[i], "-unverified")) cfg.flags |= MC_F_UNVERIFIED;
+        else if (arg("-I")) {  // one more directory searched for EXTENDed / INSTANCEd modules (appended to $TLA_PATH)
+            const char *old = getenv("TLA_PATH");
+            const std::string v = old && *old ? std::string(old) + ":" + argv[i + 1] : std::string(argv[i + 1]);
+            setenv("TLA_PATH", v.c_str(), 1);
+            ++i;
+        }
         else if (!strcmp(argv[i], "-noprogress")) cfg.flags &= ~MC_F_PROGRESS;
         else if (arg("-device")) cfg.device = atoi(argv[++i]);
         else if (arg("-maxdistinct")) cfg.max_distinct = strtoull(argv[++i], 0, 10);
@@ -290,7 +301,7 @@ int main(int argc, char **argv) {
     }
     if (!tla) {
         fprintf(stderr,
-                "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-unverified] [-device D]\n"
+                "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-unverified] [-device D] [-I DIR]\n"
                 "                [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]\n"
                 "                [-checkpoint FILE] [-recover FILE] [-gpus P [-torch]]                    check X.tla like `tlc X.tla`\n"
                 "       mc --transpile X.tla [Y.tla ...]                                                  translate like `pcal2tla`\n"

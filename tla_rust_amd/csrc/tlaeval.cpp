@@ -685,11 +685,15 @@ struct Parser {
             }
             if (c.s == "<<") {
                 auto items = exprlist(">>");
-                if (cur().k == Tok::ID && cur().s[0] == '_' && !ended()) {  // <<A>>_v
+                if (cur().k == Tok::ID && cur().s[0] == '_' && !ended()) {  // <<A>>_v  =  A /\ (v' # v)
                     const bool bare = cur().s == "_";
+                    NodeP sub = node_id(cur().s.substr(1));
                     i++;
-                    if (bare) expr(16);
-                    NodeP n = node(N_TEMPORAL, c.line); n->s = "<<>>_"; n->kids = items; return n;
+                    if (bare) sub = expr(16);
+                    NodeP un = node(N_UNCHANGED, c.line); un->kids = {sub};
+                    NodeP act = items.size() == 1 ? items[0] : nullptr;
+                    if (!act) failp("<<A>>_v takes one action");
+                    NodeP n = node(N_TEMPORAL, c.line); n->s = "<<>>_"; n->kids = {act, sub, un}; return n;
                 }
                 NodeP n = node(N_TUPLE, c.line); n->kids = items; return n;
             }
@@ -750,7 +754,8 @@ struct Parser {
                     NodeP sub = node_id(cur().s.substr(1));
                     i++;
                     if (bare) sub = expr(16);
-                    NodeP n = node(N_TEMPORAL, c.line); n->s = "[]_"; n->kids = {first, sub}; return n;
+                    NodeP un = node(N_UNCHANGED, c.line); un->kids = {sub};  // [A]_v  =  A \/ UNCHANGED v
+                    NodeP n = node(N_TEMPORAL, c.line); n->s = "[]_"; n->kids = {first, sub, un}; return n;
                 }
                 failp("unsupported bracket expression");
             }
@@ -772,7 +777,7 @@ struct Parser {
 // parsed MODULE text: name, extends, constants (name -> arity), variables (ordered), definitions
 struct Module {
     std::string name;
-    std::vector<std::string> extends, variables, def_order;
+    std::vector<std::string> extends, variables, def_order, instances;
     std::map<std::string, int> constants;
     std::map<std::string, Def> defs;
     explicit Module(const std::string &text_in) {
@@ -834,7 +839,7 @@ struct Module {
                 while (p.cur().k == Tok::ID && (p.cur().s == "PROOF" || p.cur().s == "BY" || p.cur().s == "OBVIOUS" || p.cur().s == "OMITTED" || p.cur().s == "QED")) p.i++;
             } else if (c.s == "INSTANCE") {
                 p.i++;
-                p.ident();  // an unnamed INSTANCE of a standard module adds nothing the built-ins do not have
+                instances.push_back(p.ident());  // its definitions join this module's (those of a standard module are built in)
                 if (p.is_id("WITH")) p.failp("unnamed INSTANCE ... WITH is not supported");
             } else {
                 const size_t before = p.i;
@@ -877,12 +882,15 @@ void arena_reset() { for (Obj *p : g_arena) delete p; g_arena.clear(); }
 
 struct Thunk;
 struct OpVal;
-struct Env : Obj { int sym = -1; V val; Thunk *th = nullptr; OpVal *op = nullptr; Env *next = nullptr; };
+struct RecFn;
+struct Env : Obj { int sym = -1; V val; Thunk *th = nullptr; OpVal *op = nullptr; RecFn *rec = nullptr; Env *next = nullptr; };
 // a lazily evaluated operator argument / LET definition without parameters: memoised unless it looks at primed variables
 struct Thunk : Obj { const Node *n = nullptr; Env *env = nullptr; const State *st = nullptr; bool memo = true, done = false, is_def = false; V val; };
 // an operator as a value: LAMBDA, an operator passed by name, a LET operator with parameters
 struct OpVal : Obj { std::vector<int> params; const Node *body = nullptr; Env *env = nullptr; bool primed = false, is_let = false; int builtin = -1; std::string name; };
 
+// f[x \in S] == e with f inside e (WriteThroughCache.tla:55-60): while the function is being built, f[a] evaluates e for x = a
+struct RecFn : Obj { const Node *n = nullptr; Env *env = nullptr; const State *st = nullptr; V dom; std::vector<std::pair<V, V>> cache; };
 inline Env *env_find(Env *e, int sym) { for (; e; e = e->next) if (e->sym == sym) return e; return nullptr; }
 inline Env *bind_val(int sym, const V &v, Env *next) { Env *e = anew<Env>(); e->sym = sym; e->val = v; e->next = next; return e; }
 inline bool entry_primed(const Env *e);
@@ -894,6 +902,12 @@ struct GDef {  // a module-level definition
     NodeP body;
     int primed = -1, is_const = -1;
     V const_val;
+    // a state-level definition without parameters is a function of the variables it (transitively) mentions: its last few
+    // values are kept by the identity of those variables' values (totalOpOrder of InnerSerial.tla:89-95 depends on opQ only and
+    // is asked for once per candidate opOrder')
+    int deps_known = 0, memo_next = 0;
+    std::vector<int> deps;
+    struct Memo { std::vector<V> key; V val; } memo[4];
 };
 
 // which identifiers decide whether evaluating a node looks at primed variables (decides whether a thunk may be memoised, and
@@ -1006,6 +1020,8 @@ struct Spec {
             if (d.body->k == N_INSTANCE) import_instance(nm + "!", d.body->s, d.body->fields);
             else add_def(nm, d, d.body, m.name);
         }
+        for (auto &i : m.instances)  // INSTANCE M without a name (TLC/MCAlternatingBit.tla:4): M's definitions under their own names
+            if (!BUILTIN_MODULES.count(i) && std::find(loaded.begin(), loaded.end(), i) == loaded.end()) import_instance("", i, {});
     }
     // I == INSTANCE M WITH c <- e, ...: every definition d of M (and of what M EXTENDS) becomes the global definition I!d, in
     // which M's own definition names are prefixed and the substituted constants / variables are replaced by their expressions; a
@@ -1045,6 +1061,7 @@ struct Spec {
                     import_instance(prefix + nm + "!", d.body->s, s2);
                     continue;
                 }
+                if (prefix.empty() && defs.count(intern(nm))) continue;  // already there through EXTENDS
                 add_def(prefix + nm, d, clone_tree(d.body, leaf), m->name);
                 auto sc = scoped.find({m->name, nm});
                 if (sc != scoped.end()) scoped_overrides[intern(prefix + nm)] = intern(sc->second);
@@ -1161,6 +1178,17 @@ struct Spec {
         each_child(*n, [&](const Node &c) { r = r || mentions_state(&c, seen); });
         return r;
     }
+    void state_deps(const Node *n, std::set<int> &seen, std::set<int> &vars) {  // the variables an expression (transitively) mentions
+        if (n->k == N_NTH) { state_deps(nth_node(n), seen, vars); return; }
+        if (n->k == N_ID || n->k == N_CALL) {
+            const int nm = resolve(nsym(n));
+            auto v = varidx.find(nm);
+            if (v != varidx.end()) vars.insert(v->second);
+            auto it = defs.find(nm);
+            if (it != defs.end() && !seen.count(nm)) { seen.insert(nm); state_deps(it->second->body.get(), seen, vars); }
+        }
+        each_child(*n, [&](const Node &c) { state_deps(&c, seen, vars); });
+    }
     // UNCHANGED <<a, b, vars>> flattened to variable indices (definitions that are tuples of variables are expanded)
     bool unchanged_vars(const Node *n, std::vector<int> &out) {
         if (n->k == N_PAREN) return unchanged_vars(n->kids[0].get(), out);
@@ -1202,7 +1230,7 @@ struct Spec {
         if (a->k == N_NUM || a->k == N_STR || a->k == N_BOOL) { e->val = ev(a, env, st, nullptr); return e; }
         if (a->k == N_ID) {
             const int name = nsym(a);
-            if (Env *l = env_find(env, name)) { e->val = l->val; e->th = l->th; e->op = l->op; return e; }  // pass the entry on
+            if (Env *l = env_find(env, name)) { e->val = l->val; e->th = l->th; e->op = l->op; e->rec = l->rec; return e; }  // pass the entry on
             if (arity > 0) {
                 const int nm = resolve(name);
                 auto d = defs.find(nm);
@@ -1274,8 +1302,21 @@ struct Spec {
             if (!args.empty()) fail("operator " + d->name + " takes 0 arguments, " + std::to_string(args.size()) + " given");
             if (d->const_val) return d->const_val;
             if (d->is_const < 0) { std::set<int> seen; d->is_const = !mentions_state(d->body.get(), seen); }
+            if (d->is_const) { d->const_val = ev(d->body.get(), nullptr, st, nx); return d->const_val; }  // constant-level: evaluated once
+            if (!st || def_primed(d)) return ev(d->body.get(), nullptr, st, nx);
+            if (!d->deps_known) { std::set<int> seen, vars; state_deps(d->body.get(), seen, vars); d->deps.assign(vars.begin(), vars.end()); d->deps_known = 1; }
+            for (int i : d->deps) if (!(*st)[(size_t)i]) return ev(d->body.get(), nullptr, st, nx);  // inside Init
+            for (auto &m : d->memo) {
+                if (!m.val) continue;
+                bool hit = true;
+                for (size_t k = 0; k < d->deps.size() && hit; k++) hit = m.key[k].get() == (*st)[(size_t)d->deps[k]].get();
+                if (hit) return m.val;
+            }
             V v = ev(d->body.get(), nullptr, st, nx);
-            if (d->is_const) d->const_val = v;  // constant-level zero-argument definitions are evaluated once
+            GDef::Memo &m = d->memo[d->memo_next++ & 3];
+            m.key.clear();
+            for (int i : d->deps) m.key.push_back((*st)[(size_t)i]);
+            m.val = v;
             return v;
         }
         std::vector<int> ps;
@@ -1340,6 +1381,24 @@ struct Spec {
         it->second = nw;
         return r;
     }
+    V rec_apply(RecFn *r, const V &a, State *nx) {
+        for (auto &p : r->cache) if (cmp(p.first, a) == 0) return p.second;
+        if (!set_in(a, r->dom)) fail("function applied outside its domain: " + fmt(a) + " not in the domain of " + r->n->s);
+        const Bound &b = r->n->bounds[0];
+        V v = ev(r->n->kids[0].get(), bind_pattern(b, a, r->env), r->st, nx);
+        r->cache.emplace_back(a, v);
+        return v;
+    }
+    V rec_function(const Node *n, Env *env, const State *st, State *nx) {
+        if (n->bounds.size() != 1) fail("recursive function definitions with several bounds are not supported");
+        RecFn *r = anew<RecFn>();
+        Env *self = anew<Env>();
+        self->sym = nsym(n); self->rec = r; self->next = env;
+        r->n = n; r->env = self; r->st = st; r->dom = ev(n->bounds[0].dom.get(), env, st, nx);
+        std::vector<std::pair<V, V>> kv;
+        for (auto &x : elements(r->dom)) kv.emplace_back(x, rec_apply(r, x, nx));
+        return mk_fn(std::move(kv));
+    }
     V binop(int opc, const Node *n, Env *env, const State *st, State *nx) {
         const Node *an = n->kids[0].get(), *bn = n->kids[1].get();
         if (opc == OP_IMP) {
@@ -1391,6 +1450,7 @@ struct Spec {
         int name = nsym(n);
         if (Env *e = env_find(env, name)) {
             if (e->th) return force(e->th, nx);
+            if (e->rec) fail("recursive function " + n->s + " used as a value inside its own definition");
             if (e->op) { if (!e->op->params.empty() || e->op->builtin >= 0) fail("operator " + e->op->name + " used as a value"); return ev(e->op->body, e->op->env, st, nx); }
             return e->val;
         }
@@ -1445,7 +1505,10 @@ struct Spec {
             case N_PAREN: return ev(n->kids[0].get(), env, st, nx);
             case N_AT: { Env *e = env_find(env, sym_at); if (!e) fail("@ outside EXCEPT"); return e->val; }
             case N_NTH: return ev(nth_node(n), nullptr, st, nx);
-            case N_TEMPORAL: fail("temporal formula evaluated");
+            case N_TEMPORAL:
+                if (n->s == "[]_") return mk_bool(as_bool(ev(n->kids[0].get(), env, st, nx), "[A]_v: A is") || as_bool(ev(n->kids[2].get(), env, st, nx), "UNCHANGED is"));
+                if (n->s == "<<>>_") return mk_bool(as_bool(ev(n->kids[0].get(), env, st, nx), "<<A>>_v: A is") && !as_bool(ev(n->kids[2].get(), env, st, nx), "UNCHANGED is"));
+                fail("temporal formula evaluated");
             case N_ID: return ev_id(n, env, st, nx);
             case N_CALL: return ev_call(n, env, st, nx);
             case N_PRIME: {
@@ -1508,7 +1571,7 @@ struct Spec {
                 return mk_set(std::move(out));
             }
             case N_FNDEF: {
-                if (!n->s.empty()) fail("recursive function definitions f[x \\in S] == ... are not supported");
+                if (!n->s.empty()) return rec_function(n, env, st, nx);
                 std::vector<std::pair<V, V>> kv;
                 for_bounds(n->bounds, env, st, nx, [&](Env *e2, const std::vector<V> &combo) {
                     kv.emplace_back(combo.size() > 1 ? mk_tuple(combo) : combo[0], ev(n->kids[0].get(), e2, st, nx));
@@ -1524,7 +1587,11 @@ struct Spec {
                 for (auto &u : n->ups) f = except_update(f, u.first, 0, u.second.get(), env, st, nx);
                 return f;
             }
-            case N_IDX: { V f = ev(n->kids[0].get(), env, st, nx); return fn_apply(f, ev(n->kids[1].get(), env, st, nx)); }
+            case N_IDX: {
+                if (n->kids[0]->k == N_ID) { Env *e = env_find(env, nsym(n->kids[0].get())); if (e && e->rec) return rec_apply(e->rec, ev(n->kids[1].get(), env, st, nx), nx); }
+                V f = ev(n->kids[0].get(), env, st, nx);
+                return fn_apply(f, ev(n->kids[1].get(), env, st, nx));
+            }
             case N_PRE: {
                 V x = ev(n->kids[0].get(), env, st, nx);
                 if (n->s == "DOMAIN") return fn_domain(x);
@@ -1588,6 +1655,25 @@ struct Spec {
         if (d != defs.end()) { act_global(d->second, args, env, st, nx, k); return; }
         act_test(n, env, st, nx, k);
     }
+    // is the left side of `=` / `\in` a primed variable — directly, or an operator parameter whose argument is one
+    // (CachingMemory/InternalMemory.tla:17 Send(p, req, memInt, memInt') with MCSend(p, d, old, new) == new = <<p, d>>)
+    int primed_var(const Node *lhs, Env *env) {
+        for (int hops = 0; hops < 32; hops++) {
+            while (lhs->k == N_PAREN) lhs = lhs->kids[0].get();
+            if (lhs->k == N_PRIME) {
+                const Node *in = lhs->kids[0].get();
+                if (in->k != N_ID || env_find(env, nsym(in))) return -1;
+                auto vi = varidx.find(resolve(nsym(in)));
+                return vi == varidx.end() ? -1 : vi->second;
+            }
+            if (lhs->k != N_ID) return -1;
+            Env *e = env_find(env, nsym(lhs));
+            if (!e || !e->th || e->th->is_def) return -1;
+            env = e->th->env;
+            lhs = e->th->n;
+        }
+        return -1;
+    }
     void act(const Node *n, Env *env, const State *st, State &nx, const Cont &k) {
         switch (n->k) {
             case N_PAREN: act(n->kids[0].get(), env, st, nx, k); return;
@@ -1622,12 +1708,10 @@ struct Spec {
             }
             case N_OP: {
                 if (n->s == "=" || n->s == "\\in") {
-                    const Node *lhs = n->kids[0].get();
-                    while (lhs->k == N_PAREN) lhs = lhs->kids[0].get();
-                    if (lhs->k == N_PRIME && lhs->kids[0]->k == N_ID && !env_find(env, nsym(lhs->kids[0].get()))) {
-                        auto vi = varidx.find(resolve(nsym(lhs->kids[0].get())));
-                        if (vi != varidx.end()) {
-                            const size_t i = (size_t)vi->second;
+                    const int pv = primed_var(n->kids[0].get(), env);
+                    {
+                        if (pv >= 0) {
+                            const size_t i = (size_t)pv;
                             V rhs = ev(n->kids[1].get(), env, st, &nx);
                             if (n->s == "=") {  // x' = e assigns when x' has no value yet and is an equality test otherwise
                                 if (!nx[i]) { nx[i] = rhs; k(); nx[i] = nullptr; }
@@ -1643,6 +1727,11 @@ struct Spec {
                 act_test(n, env, st, nx, k);
                 return;
             }
+            case N_TEMPORAL:
+                if (n->s == "[]_") { act(n->kids[0].get(), env, st, nx, k); act(n->kids[2].get(), env, st, nx, k); return; }
+                if (n->s == "<<>>_") { act(n->kids[0].get(), env, st, nx, [&]() { if (!as_bool(ev(n->kids[2].get(), env, st, &nx), "UNCHANGED is")) k(); }); return; }
+                act_test(n, env, st, nx, k);
+                return;
             case N_ID: act_call(n, {}, env, st, nx, k); return;
             case N_CALL: act_call(n, n->kids, env, st, nx, k); return;
             default: act_test(n, env, st, nx, k); return;
@@ -1784,14 +1873,19 @@ struct Checker {
         if (d == sp.defs.end()) fail("SPECIFICATION " + name + " is not defined");
         std::vector<NodeP> flat;
         std::function<void(const NodeP &)> walk = [&](const NodeP &n) {
-            if (n->k == N_CONJ) { for (auto &x : n->kids) walk(x); }
-            else if (n->k == N_PAREN) walk(n->kids[0]);
-            else flat.push_back(n);
+            if (n->k == N_CONJ) { for (auto &x : n->kids) walk(x); return; }
+            if (n->k == N_PAREN) { walk(n->kids[0]); return; }
+            if (n->k == N_ID && !sp.varidx.count(nsym(n.get()))) {  // LSpec == HC /\ WF_hr(HCnxt) with HC == HCini /\ [][HCnxt]_hr (Liveness/LiveHourClock.tla)
+                auto dd = sp.defs.find(sp.resolve(nsym(n.get())));
+                std::set<int> seen;
+                if (dd != sp.defs.end() && dd->second->params.empty() && is_temporal(dd->second->body.get(), seen)) { walk(dd->second->body); return; }
+            }
+            flat.push_back(n);
         };
         walk(d->second->body);
         for (auto &n : flat) {
             if (is_box_action(n.get())) next_node = n->kids[0]->kids[0];
-            else if (n->k != N_TEMPORAL && !init_node) init_node = n;
+            else if (!init_node) { std::set<int> seen; if (!is_temporal(n.get(), seen)) init_node = n; }  // not fairness, possibly quantified (InnerSerial.tla:147-156)
         }
         if (!init_node || !next_node) fail("cannot split " + name + " into Init and Next");
     }
@@ -2010,7 +2104,23 @@ struct Checker {
             if (!fresh.empty()) { R.levels.push_back(fresh.size()); depth++; }
         }
         if (verdict == MC_V_OK && budget) verdict = MC_V_BUDGET;
+        if (!opt.dump_path.empty()) {
+            FILE *f = fopen(opt.dump_path.c_str(), "w");
+            if (!f) fail("cannot write " + opt.dump_path);
+            std::vector<size_t> order;
+            for (auto &nm : opt.dump_order) { auto it = sp.varidx.find(intern(nm)); if (it == sp.varidx.end()) fail("dump order: no variable " + nm); order.push_back((size_t)it->second); }
+            if (order.empty()) for (size_t i = 0; i < nv; i++) order.push_back(i);
+            std::vector<uint32_t> level(states.size(), 0);
+            for (size_t i = 0; i < states.size(); i++) {
+                level[i] = parent[i] < 0 ? 0 : level[(size_t)parent[i]] + 1;
+                std::string line = "L" + std::to_string(level[i]);
+                for (size_t k : order) line += " /\\ " + sp.variables[k] + " = " + fmt(states[i][k]);
+                fprintf(f, "%s\n", line.c_str());
+            }
+            fclose(f);
+        }
         R.distinct = seen.size();
+        R.n_invariants = invs.size();
         R.generated = generated;
         R.depth = depth;
         R.verdict = verdict;
@@ -2054,6 +2164,7 @@ int check_files(const std::string &tla_path, const std::string &cfg_path, const 
     static std::mutex mu;  // the evaluator keeps its symbol tables and the arena in globals: one run at a time
     std::lock_guard<std::mutex> lock(mu);
     Job j{&tla_path, &cfg_path, &opt, &out, &error};
+    if (getenv("TLAEVAL_INLINE")) { job_main(&j); return j.rc; }  // profiling: on the caller's own stack
     // a tree-walking evaluator recurses as deep as the specification nests: run on a thread with a large stack
     pthread_attr_t attr;
     pthread_attr_init(&attr);

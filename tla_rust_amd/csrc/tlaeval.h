@@ -20,11 +20,14 @@ struct Options {
     bool check_deadlock = true;
     double progress_seconds = 0;  // > 0: print TLC's "Progress(d): ..." lines to stdout at this interval
     std::vector<std::string> search;  // directories searched for EXTENDed / INSTANCEd modules (after the root module's own)
+    std::string dump_path;            // every stored state as one line "L<level> /\ v = ... /\ w = ..." (tests compare state SETS)
+    std::vector<std::string> dump_order;  // variable order of those lines (empty: declaration order)
 };
 
 struct Result {
     uint64_t distinct = 0, generated = 0, queue_left = 0, init_states = 0;
     uint32_t depth = 0;
+    size_t n_invariants = 0;     // violated_invariant >= n_invariants: the safety part of PROPERTY number (violated_invariant - n_invariants)
     int verdict = 0;             // MC_V_* of include/tlamc.h
     int violated_invariant = -1; // index into the cfg's INVARIANT list
     std::string violated_name, error_message;
