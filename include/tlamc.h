@@ -268,6 +268,21 @@ int mc_shard_materialise_parents(mc_engine *e, uint32_t slot, uint64_t *send_par
 int mc_shard_ingest_parents(mc_engine *e, const uint64_t *recv_parents, uint64_t n, uint32_t src_rank);
 int mc_shard_violation(mc_engine *e, int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant);
 int mc_shard_fetch(mc_engine *e, uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot);
+/* One checkpoint file per rank (TLC checkpoints a run and continues it with -recover: testout1:10 "-- Checkpointing of run
+ * states/... completed."; mc_engine_checkpoint is the single-GPU form).  After an mc_shard_run* that ended without an error —
+ * normally MC_V_BUDGET — every rank writes ITS share with mc_shard_checkpoint (a different path per rank): arena, parent
+ * pointers (index, slot, rank), its seen-set slice as it lies in HBM (the states a rank holds are the ones it generated or
+ * was sent, the fingerprints it stores are the ones it OWNS: the slice cannot be rebuilt from the arena), its counters and the
+ * job's level table.  mc_shard_restore loads such a file into an engine created for the same spec, rank, world size,
+ * table_capacity and MC_F_TRACE (MC_EBADCFG otherwise; arena_capacity may differ); the next mc_shard_run* of those engines
+ * continues with the unexpanded frontier instead of starting at Init — every rank must have restored a file of the SAME run
+ * (checked: MC_EBADCFG on all ranks otherwise).
+ * mc_shard_note_levels / mc_shard_resume are the level loop's side of it (shard_loop.h): the loop leaves the job's level table
+ * with the engine when a run ends, and asks a restored engine for it when the next one begins (*nlevels = 0: nothing restored). */
+int mc_shard_checkpoint(mc_engine *e, const char *path);
+int mc_shard_restore(mc_engine *e, const char *path);
+int mc_shard_note_levels(mc_engine *e, const uint64_t *levels, uint32_t n, int32_t verdict);
+int mc_shard_resume(mc_engine *e, uint64_t *levels_out, uint32_t *nlevels);
 
 /* ------------------------------------------------------------------ hip-rccl back-end (tla_rust_amd/csrc/shard_rccl.cpp)
  * The level loop of the sharded search behind the C ABI, collectives over RCCL (xGMI): one process per GPU, no Python.

@@ -462,6 +462,7 @@ extern "C" int shim_eval_slot(const mc_spec_desc *d, const uint64_t *words, int 
 // ------------------------------------------------------------------------------------------
 // Host emulation of the sharded step API (mc_shard_* of include/tlamc.h), same semantics, plain
 // host pointers.  Used only by the world_size-2 gloo tests of tla_rust_amd/sharded.py.
+extern "C" void mc_set_error_internal(const char *msg);
 struct ShimShardBase {
     virtual ~ShimShardBase() {}
     virtual int begin() = 0;
@@ -482,6 +483,11 @@ struct ShimShardBase {
     virtual int violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant) = 0;
     virtual int fetch(uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) = 0;
     virtual size_t state_bytes() = 0;
+    // per-rank checkpoints (include/tlamc.h mc_shard_checkpoint / mc_shard_restore), in the host build's own format
+    virtual int checkpoint(const char *path) = 0;
+    virtual int restore(const char *path) = 0;
+    std::vector<uint64_t> ck_levels;
+    bool ck_ok = false, ck_resume = false;
 };
 
 template <class S>
@@ -537,9 +543,51 @@ struct ShimShard : ShimShardBase {
         *prank = par[idx].rank; *pidx = par[idx].idx; *pslot = par[idx].slot;
         return 0;
     }
+    int checkpoint(const char *path) override {
+        if (!ck_ok || ck_levels.empty()) { mc_set_error_internal("shim checkpoint: needs a run that ended without an error"); return MC_EBADCFG; }
+        FILE *f = fopen(path, "wb");
+        if (!f) return MC_EBADCFG;
+        const uint64_t hdr[10] = {0x314b434d494853ull, (uint64_t)W, rank, nranks, lo, hi, generated, dup, nstates(), ck_levels.size()};
+        std::vector<uint64_t> fps;
+        for (uint64_t v : seen.tab) if (v) fps.push_back(v);
+        const uint64_t nf = fps.size();
+        bool ok = fwrite(hdr, sizeof hdr, 1, f) == 1 && fwrite(ck_levels.data(), 8, ck_levels.size(), f) == ck_levels.size() &&
+                  fwrite(arena.data(), 8, arena.size(), f) == arena.size() && fwrite(par.data(), sizeof(Par), par.size(), f) == par.size() &&
+                  fwrite(&nf, 8, 1, f) == 1 && fwrite(fps.data(), 8, fps.size(), f) == fps.size();
+        fclose(f);
+        return ok ? 0 : MC_EBADCFG;
+    }
+    int restore(const char *path) override {
+        FILE *f = fopen(path, "rb");
+        if (!f) return MC_EPARSE;
+        uint64_t hdr[10];
+        W = S::words(prm);
+        bool ok = fread(hdr, sizeof hdr, 1, f) == 1 && hdr[0] == 0x314b434d494853ull;
+        if (ok && (hdr[1] != (uint64_t)W || hdr[2] != rank || hdr[3] != nranks)) { fclose(f); mc_set_error_internal("shim restore: another rank's file, or another spec / world size"); return MC_EBADCFG; }
+        uint64_t nf = 0;
+        std::vector<uint64_t> fps;
+        if (ok) {
+            ck_levels.assign(hdr[9], 0);
+            arena.assign(hdr[8] * (uint64_t)W, 0);
+            par.assign(hdr[8], Par{0, 0, 0});
+            ok = fread(ck_levels.data(), 8, ck_levels.size(), f) == ck_levels.size() && fread(arena.data(), 8, arena.size(), f) == arena.size() &&
+                 fread(par.data(), sizeof(Par), par.size(), f) == par.size() && fread(&nf, 8, 1, f) == 1;
+            if (ok) { fps.assign(nf, 0); ok = fread(fps.data(), 8, nf, f) == nf; }
+        }
+        fclose(f);
+        if (!ok) return MC_EPARSE;
+        seen.clear();
+        for (uint64_t v : fps) seen.insert(v);
+        lo = hdr[4]; hi = hdr[5]; generated = hdr[6]; dup = hdr[7];
+        verdict = MC_V_OK; v_found = false;
+        sl[0].launched = sl[1].launched = false;
+        ck_resume = true; ck_ok = false;
+        return 0;
+    }
     int begin() override {
         W = S::words(prm);
         dup = 0;
+        ck_resume = ck_ok = false;
         arena.clear(); par.clear(); seen.clear(); generated = 0; verdict = MC_V_OK; v_found = false;
         uint64_t tmp[S::MAX_WORDS];
         for (uint64_t k = 0; k < S::num_init(prm); k++) {
@@ -761,6 +809,8 @@ void *shim_shard_create(const mc_spec_desc *d, uint32_t rank, uint32_t nranks) {
 }
 void shim_shard_destroy(void *e) { delete (ShimShardBase *)e; }
 int shim_shard_begin(void *e) { return ((ShimShardBase *)e)->begin(); }
+int shim_shard_checkpoint(void *e, const char *path) { return ((ShimShardBase *)e)->checkpoint(path); }
+int shim_shard_restore(void *e, const char *path) { return ((ShimShardBase *)e)->restore(path); }
 int shim_shard_begin_replicated(void *e, uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out,
                                 uint32_t *nlevels) {
     return ((ShimShardBase *)e)->begin_replicated(min_frontier, max_distinct, max_levels, levels_out, nlevels);
@@ -816,8 +866,19 @@ struct ShimOps {
     void wait(int, int) {}
     void clear_counts(uint64_t *buf, uint32_t n, uint64_t cap) { for (uint32_t t = 0; t < n; t++) buf[(uint64_t)t * cap] = 0; }
     void clear_bytes(void *p, size_t n, int) { memset(p, 0, n); }
+    int resume(uint64_t *lv, uint32_t *n) {
+        const uint32_t cap = *n;
+        *n = 0;
+        if (!s->ck_resume) return 0;
+        if (s->ck_levels.size() > cap) return MC_EBADCFG;
+        for (size_t k = 0; k < s->ck_levels.size(); k++) lv[k] = s->ck_levels[k];
+        *n = (uint32_t)s->ck_levels.size();
+        s->ck_resume = false;
+        return 0;
+    }
+    int note_levels(const uint64_t *lv, uint32_t n, int32_t verdict) { s->ck_levels.assign(lv, lv + n); s->ck_ok = verdict == MC_V_OK || verdict == MC_V_BUDGET; return 0; }
     int begin() { return s->begin(); }
-    int begin_replicated(uint64_t mf, uint64_t md, uint64_t ml, uint64_t *lv, uint32_t *n) { return s->begin_replicated(mf, md, ml, lv, n); }
+    int begin_replicated(uint64_t mf, uint64_t md, uint64_t ml, uint64_t *lv, uint32_t *n) { s->ck_resume = s->ck_ok = false; return s->begin_replicated(mf, md, ml, lv, n); }
     int level_size(uint64_t *n) { *n = s->level_size(); return 0; }
     // like the engine, a launch into a slot invalidates what the slot's previous round left pending: a loop that launches round
     // r+1 before it has issued the keep of round r-1 (same slot) fails here as it does on the GPU

@@ -35,17 +35,57 @@ def main():
                   rebalance_ratio=opts.get("rebalance_ratio", 1.25), replicate_until=opts.get("replicate_until", 0),
                   packed_fanout=opts.get("packed_fanout", 16), move_fanout=opts.get("move_fanout", 64 if mode == "shim" else 32))
     if mode == "shim":
-        from shim_step_engine import ShimShard
+        from shim_step_engine import ShimShard  # noqa: F401
         chk = ShardedChecker(spec, params, engine=ShimShard(spec, params, rank, world), **common)
     else:
         chk = ShardedChecker(spec, params, device=0, table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
                              trace=opts.get("trace", False), **common)
+    def make():
+        if mode == "shim":
+            return ShardedChecker(spec, params, engine=ShimShard(spec, params, rank, world), **common)
+        return ShardedChecker(spec, params, device=0, table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
+                              trace=opts.get("trace", False), **common)
     r = chk.run()
+    first = None
+    if opts.get("checkpoint"):  # stop on the budget, write one file per rank, continue in FRESH engines (TLC -recover)
+        first = dict(r)
+        stem = opts["checkpoint"]
+        chk.checkpoint(f"{stem}.rank{rank}")
+        chk.close()
+        chk = make()
+        wrong = opts.get("restore_wrong_rank") and world > 1
+        try:
+            chk.restore(f"{stem}.rank{(rank + 1) % world if wrong else rank}", max_distinct=0, max_levels=opts.get("resume_max_levels", 0))
+            restore_error = None
+        except Exception as e:  # noqa: BLE001
+            restore_error = str(e)
+        if opts.get("restore_only_rank0") and rank != 0:
+            chk.close()
+            chk = make()
+            chk.opts["max_distinct"], chk.opts["max_levels"] = 0, 0
+        if restore_error is not None:
+            errs = [None] * world
+            dist.all_gather_object(errs, restore_error)
+            if rank == 0:
+                Path(out).write_text(json.dumps(dict(restore_errors=errs)))
+            chk.close()
+            dist.destroy_process_group()
+            return
+        try:
+            r = chk.run()
+        except Exception as e:  # noqa: BLE001
+            errs = [None] * world
+            dist.all_gather_object(errs, str(e))
+            if rank == 0:
+                Path(out).write_text(json.dumps(dict(run_errors=errs, first=first)))
+            chk.close()
+            dist.destroy_process_group()
+            return
     trace = chk.counterexample() if opts.get("trace") else None
     shares = [None] * world
     dist.all_gather_object(shares, chk.local_distinct)
     if rank == 0:
-        Path(out).write_text(json.dumps(dict(r, shares=shares, trace=trace, phases={k: v for k, v in chk.stats.items() if k.endswith("levels")},
+        Path(out).write_text(json.dumps(dict(r, first=first, shares=shares, trace=trace, phases={k: v for k, v in chk.stats.items() if k.endswith("levels")},
                                              stats=chk.stats)))
     chk.close()
     dist.destroy_process_group()

@@ -36,6 +36,14 @@ class ShimShard:
     def trace_transport(self, t, states, slots, n, final):
         return self.lib.shim_shard_trace_transport(self.h, C.byref(t), states, slots, n, final)
 
+    def checkpoint(self, path):
+        self.lib.shim_shard_checkpoint.argtypes = [C.c_void_p, C.c_char_p]
+        return self.lib.shim_shard_checkpoint(self.h, str(path).encode())
+
+    def restore(self, path):
+        self.lib.shim_shard_restore.argtypes = [C.c_void_p, C.c_char_p]
+        return self.lib.shim_shard_restore(self.h, str(path).encode())
+
     def check(self, rc, what):
         if rc:
             raise RuntimeError(f"{what} failed: {rc} {self.lib.shim_last_error().decode()}")

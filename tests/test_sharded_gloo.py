@@ -163,3 +163,41 @@ def test_invariant_counterexample_across_ranks_on_cpu(oracle, shim, tmp_path):
         tr = r["trace"]
         assert r["verdict"] == "invariant" and tr is not None and len(tr) == len(o["trace"]) and len({t for _, t in tr}) == len(tr)
         assert tr[0][0] == "Initial predicate" and all(a and a != "?" for a, _ in tr) and last in tr[-1][1]
+
+
+# ---------------------------------------------------------------------------------------------- one checkpoint file per rank
+@pytest.mark.parametrize("world,opts", [(2, {"max_levels": 9, "chunk": 700}),                                            # stopped in a move level
+                                        (3, {"max_levels": 14, "chunk": 900, "stay_threshold": 50, "rebalance_ratio": 1.6}),   # ... in a stay level
+                                        (2, {"max_levels": 3, "chunk": 700, "replicate_until": 100000})])                 # ... inside the replicated prefix
+def test_checkpoint_per_rank_then_continue_in_fresh_engines(oracle, shim, tmp_path, world, opts):
+    """TLC's checkpoint / -recover for the sharded engine (testout1:10): a run stopped on its budget writes ONE FILE PER RANK
+    (arena, parents, the rank's seen-set slice, counters, the job's level table); fresh engines restore their files and the level
+    loop continues with the unexpanded frontier — the completed run must equal the uninterrupted one (= the oracle's)"""
+    params = [2, 2, 2, 9, 2, 1]
+    o = oracle.oracle_run("raft", params)
+    cut = oracle.oracle_run("raft", params, max_levels=opts["max_levels"])
+    r = run_dist("shim", world, "raft", params, tmp_path, dict(opts, checkpoint=str(tmp_path / "ck")))
+    assert (r["first"]["verdict"], r["first"]["distinct"], r["first"]["levels"]) == ("budget", cut["distinct"], cut["levels"])
+    assert all((tmp_path / f"ck.rank{k}").stat().st_size > 0 for k in range(world))
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"])
+    assert sum(r["shares"]) == o["distinct"]
+
+
+def test_counterexample_after_a_restore_walks_into_the_checkpointed_part(oracle, shim, tmp_path):
+    """the parent pointers travel with the checkpoint: a violation found after the restore is traced back to Init across ranks"""
+    params = [1, 0, 20, 2]   # pcal_intro, the README's failing Assert (depth 7)
+    o = oracle.oracle_run("pcal_intro", params)
+    r = run_dist("shim", 2, "pcal_intro", params, tmp_path, {"chunk": 300, "max_levels": 4, "checkpoint": str(tmp_path / "ck"), "trace": True})
+    assert r["first"]["verdict"] == "budget" and r["verdict"] == "assert"
+    assert len(r["trace"]) == len(o["trace"]) and r["trace"][0][0] == "Initial predicate"
+
+
+def test_restore_refuses_another_ranks_file(oracle, shim, tmp_path):
+    r = run_dist("shim", 2, "raft", [2, 2, 2, 9, 2, 1], tmp_path, {"max_levels": 6, "chunk": 700, "checkpoint": str(tmp_path / "ck"), "restore_wrong_rank": True})
+    assert all("another rank" in e for e in r["restore_errors"])
+
+
+def test_ranks_that_did_not_restore_the_same_run_stop_together(oracle, shim, tmp_path):
+    """rank 0 restored, rank 1 starts from Init: the level tables travel with the first all-gather and every rank refuses"""
+    r = run_dist("shim", 2, "raft", [2, 2, 2, 9, 2, 1], tmp_path, {"max_levels": 6, "chunk": 700, "checkpoint": str(tmp_path / "ck"), "restore_only_rank0": True})
+    assert len(r["run_errors"]) == 2 and all("same run" in e for e in r["run_errors"])

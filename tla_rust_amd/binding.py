@@ -162,6 +162,10 @@ def lib():
     L.mc_shard_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ShardOpts), C.POINTER(CResult)]
     L.mc_shard_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     L.mc_shard_run_transport.argtypes = [C.c_void_p, C.POINTER(Transport), C.POINTER(ShardOpts), C.POINTER(CResult)]
+    L.mc_shard_checkpoint.argtypes = [C.c_void_p, C.c_char_p]
+    L.mc_shard_restore.argtypes = [C.c_void_p, C.c_char_p]
+    L.mc_shard_note_levels.argtypes = [C.c_void_p, U64P, C.c_uint32, C.c_int32]
+    L.mc_shard_resume.argtypes = [C.c_void_p, U64P, C.POINTER(C.c_uint32)]
     L.mc_shard_trace_transport.argtypes = [C.c_void_p, C.POINTER(Transport), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t),
                                            C.POINTER(C.c_int32)]
     L.mc_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), U64P, C.POINTER(C.c_int32)]
@@ -286,6 +290,14 @@ class Engine:
     def restore(self, path):
         """TLC's -recover: the next run() continues the checkpointed search."""
         _check(lib().mc_engine_restore(self._h, str(path).encode()), "mc_engine_restore")
+
+    def shard_checkpoint(self, path):
+        """this rank's file of a sharded run that ended without an error (one file per rank: mc_shard_checkpoint)"""
+        _check(lib().mc_shard_checkpoint(self._h, str(path).encode()), "mc_shard_checkpoint")
+
+    def shard_restore(self, path):
+        """load this rank's file; the next Comm.shard_run / mc_shard_run_transport of the engines continues that run"""
+        _check(lib().mc_shard_restore(self._h, str(path).encode()), "mc_shard_restore")
 
     def read_states(self, first, count):
         """Packed records of `count` states in discovery order starting at `first`."""

@@ -1414,6 +1414,10 @@ struct EngineBase {
     virtual int shard_violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant) = 0;
     virtual int shard_fetch(uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) = 0;
     virtual int shard_info(void **main_stream, uint64_t *chunk_states, int32_t *traced) = 0;
+    virtual int shard_note_levels(const uint64_t *levels, uint32_t n, int32_t verdict) = 0;
+    virtual int shard_resume(uint64_t *levels_out, uint32_t *nlevels) = 0;
+    virtual int shard_checkpoint(const char *path) = 0;
+    virtual int shard_restore(const char *path) = 0;
     virtual size_t state_bytes() const = 0;
 };
 
@@ -2157,6 +2161,7 @@ struct Engine : EngineBase {
     int shard_begin() override {
         if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
         sh_dup = 0;
+        sh_resume = sh_ck_ok = false;
         HIP_TRY(hipSetDevice(cfg.device));
         memset(kstat, 0, sizeof kstat);
         HIP_TRY(hipMemsetAsync(d_table, 0, table_cap * sizeof(uint64_t), stream));
@@ -2190,6 +2195,7 @@ struct Engine : EngineBase {
     int shard_begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) override {
         if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
         mc_result &res = *prefix_res;  // large (level table): not on the stack, and not shared between engines / threads
+        sh_resume = sh_ck_ok = false;
         const uint64_t saved_md = cfg.max_distinct, saved_ml = cfg.max_levels;
         cfg.max_distinct = max_distinct;  // the whole job's budgets: the prefix stops where the single-GPU run would
         cfg.max_levels = max_levels;
@@ -2220,6 +2226,117 @@ struct Engine : EngineBase {
         return MC_OK;
     }
     int shard_level_size(uint64_t *n) override { *n = sh_hi - sh_lo; return MC_OK; }
+    // ------------------------------------------------------------------ one checkpoint file per rank (testout1:10)
+    // A rank's share of a sharded run cannot be rebuilt from its arena alone: the states a rank HOLDS are the ones it generated
+    // (stay levels) or was sent (move levels), the fingerprints its seen-set slice holds are the ones it OWNS.  So a rank's file is
+    // its arena, its parent pointers (index, slot, rank), its seen-set slice as it lies in HBM, its counters, and the level table of
+    // the whole job (the same on every rank; the level loop hands it over when a run ends: shard_note_levels).  Restoring needs
+    // the same world size, rank, table_capacity and spec; the next mc_shard_run* then continues with the unexpanded frontier.
+    struct ShCkHeader {
+        char magic[8];
+        uint32_t spec_id, nparams;
+        int64_t params[16];
+        uint32_t words, has_trace, rank, world;
+        uint64_t table_cap, lo, hi, next, dup, nlevels;
+    };
+    std::vector<uint64_t> sh_levels;
+    bool sh_ck_ok = false, sh_resume = false;
+    int shard_note_levels(const uint64_t *levels, uint32_t n, int32_t verdict) override {
+        sh_levels.assign(levels, levels + n);
+        sh_ck_ok = verdict == MC_V_OK || verdict == MC_V_BUDGET;
+        return MC_OK;
+    }
+    int shard_resume(uint64_t *levels_out, uint32_t *nlevels) override {
+        const uint32_t cap = *nlevels;
+        *nlevels = 0;
+        if (!sh_resume) return MC_OK;
+        if (sh_levels.size() > cap) { set_error("shard_resume: level buffer too small"); return MC_EBADCFG; }
+        for (size_t k = 0; k < sh_levels.size(); k++) levels_out[k] = sh_levels[k];
+        *nlevels = (uint32_t)sh_levels.size();
+        sh_resume = false;
+        return MC_OK;
+    }
+    int shard_checkpoint(const char *path) override {
+        if (!sh_ck_ok || sh_levels.empty()) { set_error("mc_shard_checkpoint: needs a sharded run that ended (finished, or stopped on a budget) without an error"); return MC_EBADCFG; }
+        HIP_TRY(hipSetDevice(cfg.device));
+        HIP_TRY(hipDeviceSynchronize());
+        FILE *f = fopen(path, "wb");
+        if (!f) { set_error(std::string("mc_shard_checkpoint: cannot write ") + path); return MC_EBADCFG; }
+        FileCloser closer{f};
+        ShCkHeader h;
+        memset(&h, 0, sizeof h);
+        memcpy(h.magic, "TLAMCSK1", 8);
+        h.spec_id = desc.spec_id;
+        h.nparams = ck_params_comparable() ? desc.nparams : 1;
+        for (uint32_t i = 0; i < h.nparams && i < 16; i++) h.params[i] = desc.params[i];
+        if (!ck_params_comparable()) h.params[0] = (int64_t)program_hash;
+        h.words = (uint32_t)W; h.has_trace = d_parent ? 1u : 0u; h.rank = cfg.shard_rank; h.world = nranks();
+        h.table_cap = table_cap; h.lo = sh_lo; h.hi = sh_hi; h.next = sh_next; h.dup = sh_dup; h.nlevels = sh_levels.size();
+        int rc = MC_OK;
+        DevCounters c;
+        HIP_TRY(hipMemcpy(&c, d_ctr, sizeof c, hipMemcpyDeviceToHost));
+        if (fwrite(&h, sizeof h, 1, f) != 1 || fwrite(sh_levels.data(), sizeof(uint64_t), sh_levels.size(), f) != sh_levels.size() || fwrite(&c, sizeof c, 1, f) != 1) {
+            set_error("mc_shard_checkpoint: short write");
+            rc = MC_EBADCFG;
+        }
+        const size_t blocks = (size_t)((sh_next + 63) >> 6);
+        if (!rc) rc = dev_to_file(d_arena, blocks * (size_t)W * 64 * sizeof(uint64_t), f);
+        if (!rc && d_parent) rc = dev_to_file(d_parent, (size_t)sh_next * sizeof(uint32_t), f);
+        if (!rc && d_parent) rc = dev_to_file(d_pslot, (size_t)sh_next * sizeof(uint16_t), f);
+        if (!rc && d_prank) rc = dev_to_file(d_prank, (size_t)sh_next, f);
+        if (!rc) rc = dev_to_file(d_table, (size_t)table_cap * sizeof(uint64_t), f);
+        closer.f = nullptr;
+        if (fclose(f) != 0 && !rc) { set_error("mc_shard_checkpoint: close failed"); rc = MC_EBADCFG; }
+        return rc;
+    }
+    int shard_restore(const char *path) override {
+        FILE *f = fopen(path, "rb");
+        if (!f) { set_error(std::string("mc_shard_restore: cannot read ") + path); return MC_EPARSE; }
+        FileCloser closer{f};
+        ShCkHeader h;
+        int rc = MC_OK;
+        auto fail = [&](int code, const char *msg) { set_error(msg); rc = code; };
+        if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "TLAMCSK1", 8) != 0) fail(MC_EPARSE, "mc_shard_restore: not a per-rank checkpoint file");
+        else if (h.spec_id != desc.spec_id || h.words != (uint32_t)W) fail(MC_EBADCFG, "mc_shard_restore: the checkpoint belongs to another spec");
+        else if (ck_params_comparable() && (h.nparams != desc.nparams || memcmp(h.params, desc.params, sizeof(int64_t) * (h.nparams < 16 ? h.nparams : 16)) != 0))
+            fail(MC_EBADCFG, "mc_shard_restore: the checkpoint was written with other constants / invariants");
+        else if (!ck_params_comparable() && (h.nparams != 1 || (uint64_t)h.params[0] != program_hash))
+            fail(MC_EBADCFG, "mc_shard_restore: the checkpoint was written by another compiled program");
+        else if (h.rank != cfg.shard_rank || h.world != nranks()) fail(MC_EBADCFG, "mc_shard_restore: the file is another rank's, or of a run with another number of ranks");
+        else if (h.table_cap != table_cap) fail(MC_EBADCFG, "mc_shard_restore: table_capacity differs from the checkpointed run's (the seen-set slice is stored as it lay in HBM)");
+        else if (h.next > arena_cap) fail(MC_EARENA, "mc_shard_restore: arena_capacity is smaller than the checkpoint");
+        else if (h.lo > h.hi || h.hi != h.next || h.dup > h.next || h.nlevels == 0 || h.nlevels >= MC_MAX_LEVELS) fail(MC_EPARSE, "mc_shard_restore: inconsistent header");
+        else if ((d_parent != nullptr) != (h.has_trace != 0)) fail(MC_EBADCFG, "mc_shard_restore: MC_F_TRACE differs from the checkpointed run's");
+        DevCounters c;
+        if (!rc) {
+            sh_levels.assign((size_t)h.nlevels, 0);
+            if (fread(sh_levels.data(), sizeof(uint64_t), sh_levels.size(), f) != sh_levels.size() || fread(&c, sizeof c, 1, f) != 1) fail(MC_EPARSE, "mc_shard_restore: the checkpoint file is truncated");
+            else if (c.arena_next != h.next || c.viol_key != ~0ull || c.error) fail(MC_EPARSE, "mc_shard_restore: inconsistent counters");
+        }
+        if (!rc) {
+            HIP_TRY(hipSetDevice(cfg.device));
+            HIP_TRY(hipDeviceSynchronize());
+            const size_t blocks = (size_t)((h.next + 63) >> 6);
+            rc = file_to_dev(d_arena, blocks * (size_t)W * 64 * sizeof(uint64_t), f);
+            if (!rc && d_parent) rc = file_to_dev(d_parent, (size_t)h.next * sizeof(uint32_t), f);
+            if (!rc && d_parent) rc = file_to_dev(d_pslot, (size_t)h.next * sizeof(uint16_t), f);
+            if (!rc && d_prank) rc = file_to_dev(d_prank, (size_t)h.next, f);
+            if (!rc) rc = file_to_dev(d_table, (size_t)table_cap * sizeof(uint64_t), f);
+            if (!rc && fgetc(f) != EOF) fail(MC_EPARSE, "mc_shard_restore: trailing bytes (not the file this engine's configuration wrote)");
+        }
+        if (rc) { sh_levels.clear(); return rc; }
+        for (auto &n : c.n_new) n.v = 0;
+        c.max_slots = 0;
+        HIP_TRY(hipMemcpy(d_ctr, &c, sizeof c, hipMemcpyHostToDevice));
+        memset(kstat, 0, sizeof kstat);
+        sh_lo = h.lo; sh_hi = h.hi; sh_next = h.next; sh_dup = h.dup;
+        last_distinct = sh_next;
+        have_viol = false;
+        sl[0].launched = sl[1].launched = false;
+        sh_resume = true;
+        sh_ck_ok = false;
+        return MC_OK;
+    }
     int shard_info(void **main_stream, uint64_t *chunk_states, int32_t *traced) override {
         HIP_TRY(hipSetDevice(cfg.device));
         if (main_stream) *main_stream = (void *)stream;
@@ -2935,6 +3052,10 @@ int mc_shard_ingest_parents(mc_engine *e, const uint64_t *recv_parents, uint64_t
 int mc_shard_violation(mc_engine *e, int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant) {
     return e && found && idx && slot && verdict && invariant ? e->impl->shard_violation(found, idx, slot, verdict, invariant) : MC_EBADCFG;
 }
+int mc_shard_note_levels(mc_engine *e, const uint64_t *levels, uint32_t n, int32_t verdict) { return e && (levels || !n) ? e->impl->shard_note_levels(levels, n, verdict) : MC_EBADCFG; }
+int mc_shard_resume(mc_engine *e, uint64_t *levels_out, uint32_t *nlevels) { return e && levels_out && nlevels ? e->impl->shard_resume(levels_out, nlevels) : MC_EBADCFG; }
+int mc_shard_checkpoint(mc_engine *e, const char *path) { return e && path ? e->impl->shard_checkpoint(path) : MC_EBADCFG; }
+int mc_shard_restore(mc_engine *e, const char *path) { return e && path ? e->impl->shard_restore(path) : MC_EBADCFG; }
 int mc_shard_fetch(mc_engine *e, uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) {
     return e && state_out && parent_rank && parent_idx && parent_slot ? e->impl->shard_fetch(idx, state_out, parent_rank, parent_idx, parent_slot) : MC_EBADCFG;
 }

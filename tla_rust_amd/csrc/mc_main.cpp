@@ -21,7 +21,8 @@
 // -dump FILE: like TLC's -dump, write every distinct state found to FILE.
 // -checkpoint FILE / -recover FILE: TLC's checkpointing (testout1:10) and -recover: write the run (all states found, level
 //             boundaries, counters, parent pointers) after a search that stopped on -maxlevels / -maxdistinct without an
-//             error; continue such a run later, with the same X.tla / X.cfg.
+//             error; continue such a run later, with the same X.tla / X.cfg.  With -gpus P: one file per rank,
+//             FILE.rank<r>of<P> (the rank's arena, parent pointers and seen-set slice); -recover needs the same P.
 // -gpus P   : the search sharded over P GPUs of this node, one process per GPU, collectives over RCCL (include/tlamc.h
 //             mc_comm_* / mc_shard_run): mc starts P copies of itself (rank r on device r; rank 0 writes the communicator id to
 //             a temporary file the others read) and rank 0 prints TLC's counter / depth lines and, on an error, the behaviour that
@@ -147,7 +148,7 @@ static int spawn_ranks(int gpus, char **argv) {
     unlink(idfile);
     return worst;
 }
-static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, int world, const char *idfile) {
+static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, int world, const char *idfile, const char *ckpt, const char *recover) {
     mc_spec_desc desc;
     mc_program *prog = nullptr;
     int rc = mc_resolve_files(tla, cfgp, cfg.flags & (MC_F_GENERIC | MC_F_UNVERIFIED), &desc, &prog);
@@ -185,10 +186,22 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
     so.max_distinct = cfg.max_distinct;
     so.max_levels = cfg.max_levels;
     static mc_result res;
+    // -recover FILE / -checkpoint FILE with -gpus P: one file per rank, FILE.rank<r>of<P> (mc_shard_restore / mc_shard_checkpoint)
+    auto rank_file = [&](const char *stem) { return std::string(stem) + ".rank" + std::to_string(rank) + "of" + std::to_string(world); };
+    if (recover && (rc = mc_shard_restore(eng, rank_file(recover).c_str()))) { fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error()); return 1; }
     const double t0 = now_s();
     rc = mc_shard_run(eng, comm, &so, &res);
     const double dt = now_s() - t0;
     if (rc) fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error());
+    bool ckpt_done = false;
+    if (!rc && ckpt && (res.verdict == MC_V_OK || res.verdict == MC_V_BUDGET)) {
+        if ((rc = mc_shard_checkpoint(eng, rank_file(ckpt).c_str()))) fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error());
+        int64_t mine = rc, every[8] = {0};
+        const int grc = mc_comm_all_gather(comm, &mine, every, sizeof mine);  // "completed" only when every rank's file is written
+        ckpt_done = !grc;
+        for (int p = 0; p < world && ckpt_done; p++) ckpt_done = every[p] == 0;
+        if (!ckpt_done && !rc) rc = MC_EBADCFG;
+    }
     // the behaviour that leads to an error: walked back parent by parent across the ranks (collective: every rank takes part)
     const size_t W = mc_state_bytes(&desc);
     std::vector<uint8_t> tr_states;
@@ -207,7 +220,8 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
         printf("Finished computing initial states: %llu distinct state%s generated.\n", n0, n0 == 1 ? "" : "s");
         if (res.verdict == MC_V_OK) printf("Model checking completed. No error has been found.\n");
         else if (res.verdict == MC_V_BUDGET) printf("Search stopped by the level/state budget; no error has been found so far.\n");
-        else {
+        if (ckpt_done) printf("-- Checkpointing of run %s completed.\n", ckpt);  // testout1:10 (one file per rank: %s.rank<r>of<P>)
+        if (res.verdict != MC_V_OK && res.verdict != MC_V_BUDGET) {
             printf("%s\n", res.verdict == MC_V_INVARIANT ? "Error: Invariant is violated." : res.verdict == MC_V_ASSERT ? "Error: The first argument of Assert evaluated to FALSE."
                           : res.verdict == MC_V_DEADLOCK ? "Error: Deadlock reached." : "Error: TLC would raise an evaluation error.");
             if (tr_n) {  // README.md:270-311: "State k: <Action>" + the variables
@@ -309,8 +323,8 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (gpus) {  // one rank of `mc X.tla -gpus P`
-        if (dump || recover || ckpt) { fprintf(stderr, "mc: -dump / -checkpoint / -recover are not available with -gpus\n"); return 1; }
-        return run_rank(tla, cfgp, cfg, atoi(env_rank), gpus, getenv("MC_IDFILE"));
+        if (dump) { fprintf(stderr, "mc: -dump is not available with -gpus\n"); return 1; }
+        return run_rank(tla, cfgp, cfg, atoi(env_rank), gpus, getenv("MC_IDFILE"), ckpt, recover);
     }
     std::vector<char> report(1 << 22);
     static mc_result res;

@@ -81,8 +81,8 @@ struct Loop {
     void step(F &&f) { if (!lrc) lrc = f(); }
 
     // ONE collective per level: every rank's frontier size, verdict and status.  Returns the transport's error only.
-    int level_info(uint64_t local_n, int32_t verdict, uint64_t &frontier, int32_t &worst, int &failed) {
-        LevelInfo mine{local_n, (uint64_t)verdict, (uint64_t)(int64_t)lrc, 0};
+    int level_info(uint64_t local_n, int32_t verdict, uint64_t &frontier, int32_t &worst, int &failed, uint64_t sig = 0) {
+        LevelInfo mine{local_n, (uint64_t)verdict, (uint64_t)(int64_t)lrc, sig};
         int trc = net.all_gather(net.user, &mine, all.data(), sizeof mine);
         if (trc) return trc;
         frontier = 0;
@@ -115,9 +115,19 @@ struct Loop {
         const bool traced = e.traced();
         int trc;
 
+        // ---- a run restored from per-rank checkpoints continues with its unexpanded frontier (mc_shard_restore)
+        std::vector<uint64_t> levels(MC_MAX_LEVELS);
+        {
+            uint32_t rn = MC_MAX_LEVELS;
+            step([&] { return e.resume(levels.data(), &rn); });
+            levels.resize(lrc ? 0 : rn);
+        }
+        const bool resumed = !levels.empty();
+        uint64_t resume_sig = 0;  // every rank must continue the SAME run: the level tables travel with the first all-gather
+        for (uint64_t v : levels) resume_sig = resume_sig * 0x9e3779b97f4a7c15ull + v + 1;
         // ---- the small levels: the same fused BFS on every rank, then each rank keeps the states it owns
-        std::vector<uint64_t> levels;
-        if (o.flags & MC_SHARD_NO_PREFIX) {
+        if (resumed) {
+        } else if (o.flags & MC_SHARD_NO_PREFIX) {
             step([&] { return e.begin(); });
         } else {
             levels.resize(MC_MAX_LEVELS);
@@ -132,10 +142,14 @@ struct Loop {
         int failed = 0;
         step([&] { return e.level_size(&local_n); });
         step([&] { return e.counters(&gen, &dl, &verdict); });
-        if ((trc = level_info(local_n, verdict, frontier, worst, failed))) return trc;
+        if ((trc = level_info(local_n, verdict, frontier, worst, failed, resume_sig))) return trc;
         if (failed) return lrc ? lrc : failed;
+        for (uint32_t p = 0; p < P; ++p)
+            if (all[p].pad != resume_sig) { mc_set_error_internal("sharded search: the ranks did not restore checkpoints of the same run (mc_shard_restore on every rank, or on none)"); return MC_EBADCFG; }
         uint64_t cum = 0;
-        if (o.flags & MC_SHARD_NO_PREFIX) {
+        if (resumed) {
+            if (frontier != levels.back()) { mc_set_error_internal("sharded search: the restored frontiers do not add up to the checkpointed level"); return MC_EBADCFG; }
+        } else if (o.flags & MC_SHARD_NO_PREFIX) {
             if (frontier) levels.push_back(frontier);
         } else if (worst != 0) {
             frontier = levels.empty() ? 0 : levels.back();
@@ -206,7 +220,8 @@ struct Loop {
         out->levels = (uint32_t)levels.size();
         for (size_t k = 0; k < levels.size(); ++k) out->level_distinct[k] = levels[k];
         out->verdict = worst != 0 ? worst : budget ? MC_V_BUDGET : MC_V_OK;
-        return MC_OK;
+        step([&] { return e.note_levels(levels.data(), (uint32_t)levels.size(), out->verdict); });  // what mc_shard_checkpoint writes
+        return lrc;
     }
 
     // ------------------------------------------------------------------ STAY: fixed-capacity rounds, counts in band, no host wait

@@ -163,6 +163,8 @@ struct AbiOps {
     uint64_t chunk_limit() const { return chunk; }
     size_t state_bytes() const { return W; }
     bool traced() const { return is_traced != 0; }
+    int resume(uint64_t *lv, uint32_t *n) { return mc_shard_resume(eng, lv, n); }
+    int note_levels(const uint64_t *lv, uint32_t n, int32_t verdict) { return mc_shard_note_levels(eng, lv, n, verdict); }
     int begin() { return mc_shard_begin(eng); }
     int begin_replicated(uint64_t mf, uint64_t md, uint64_t ml, uint64_t *lv, uint32_t *n) { return mc_shard_begin_replicated(eng, mf, md, ml, lv, n); }
     int level_size(uint64_t *n) { return mc_shard_level_size(eng, n); }

@@ -154,6 +154,12 @@ class HipShard:
     def trace_transport(self, t, states, slots, n, final):
         return B.lib().mc_shard_trace_transport(self.eng._h, C.byref(t), states, slots, n, final)
 
+    def checkpoint(self, path):
+        return B.lib().mc_shard_checkpoint(self.eng._h, str(path).encode())
+
+    def restore(self, path):
+        return B.lib().mc_shard_restore(self.eng._h, str(path).encode())
+
     def check(self, rc, what):
         B._check(rc, what)
 
@@ -202,6 +208,18 @@ class ShardedChecker:
         self.eng.check(rc, "mc_shard_run_transport")
         self.stats = {k: int(getattr(st, k)) for k, _ in B.ShardStats._fields_}
         return B._result(r)
+
+    def checkpoint(self, path):
+        """this rank's share of a run that ended without an error (normally on a budget): one file per rank (mc_shard_checkpoint)"""
+        self.eng.check(self.eng.checkpoint(path), "mc_shard_checkpoint")
+
+    def restore(self, path, max_distinct=None, max_levels=None):
+        """load this rank's file of a checkpointed run; the next run() continues it (every rank must restore the same run)"""
+        self.eng.check(self.eng.restore(path), "mc_shard_restore")
+        if max_distinct is not None:
+            self.opts["max_distinct"] = max_distinct
+        if max_levels is not None:
+            self.opts["max_levels"] = max_levels
 
     @property
     def local_distinct(self):
