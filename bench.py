@@ -48,7 +48,9 @@ WORKLOAD_T3 = dict(spec="raft", params=[3, 4, 3, 3, 1, 1, 8, 2, 4, 8], golden="r
                    name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=3 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=8 "
                         "(specs/MCraft_t3.cfg), complete state graph")
 WORKLOADS = {"t3": WORKLOAD_T3, "k10": WORKLOAD, "k11": WORKLOAD_K11}
-TABLE_SLOTS = {"t3": 17 << 26, "k10": 3 << 26, "k11": 5 << 27}   # seen-set load ~0.46 / 0.51 / 0.50 at the end of the run
+# seen-set slots: >= 3 x the arena, so that the table can never be more than a third full and is probed 32 bytes at a time
+# (engine.hip seen_insert: random HBM reads cost by the byte); load 0.2 at the end of the run: 21.5 / 4.3 / 14 GB of the 288
+TABLE_SLOTS = {"t3": 40 << 26, "k10": 8 << 26, "k11": 26 << 26}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 XGMI_PEAK_GBS = 7 * 153.0  # MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point
 
@@ -198,6 +200,7 @@ def main():
     ap.add_argument("--msg-keys", type=int, default=0, choices=[0, 10, 11], help="(rounds 1-2) same as --workload k10 / k11")
     ap.add_argument("--matrix", action="store_true", help="A/B: unfused candidate-matrix kernels")
     ap.add_argument("--no-family", action="store_true", help="A/B: expand slot by slot instead of by action family")
+    ap.add_argument("--dense-table", action="store_true", help="A/B: 64-byte (8-slot) seen-set buckets even when the table is sparse enough for 32-byte probes")
     ap.add_argument("--occ3", action="store_true", help="A/B: by-family expand kernel compiled for 3 waves per SIMD (no register spills)")
     ap.add_argument("--no-filter", action="store_true", help="A/B: without the per-wavefront duplicate filter in front of the seen-set")
     a = ap.parse_args()
@@ -208,6 +211,8 @@ def main():
     if not a.table_slots:
         a.table_slots = TABLE_SLOTS[a.workload]
 
+    if a.dense_table:
+        os.environ["TLAMC_DENSE_TABLE"] = "1"
     launched = "RANK" in os.environ
     if a.gpus > 1 and not launched:
         sys.exit(spawn_ranks(a))
@@ -316,6 +321,9 @@ def main():
         alg = {"expand": W * ks["expand"]["units"], "insert": 8 * ks["cand_cells"], "materialise": W * ks["materialise"]["units"]}
         if direct:  # reads W per expanded state, touches 8 B of the seen-set per in-model successor, writes W per new state
             alg["expand"] = W * ks["expand"]["units"] + 8 * ks["cand_cells"] + W * D
+        state_only = alg["expand"]
+        if not a.matrix:  # the seen-set insert is FUSED into the expand kernel: its 8 bytes per probed candidate (SURVEY 8d's G x 8 term,
+            alg["expand"] += 8 * ks["cand_cells"]   # counted on the probes really issued) are that kernel's algorithmic bytes
         dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
         n_runs = a.steps  # stats are reset by every run(): they describe the last step
         ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
@@ -348,6 +356,11 @@ def main():
                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_lower": traffic_lower, "l2_hit_rate": l2_hit, "traffic_source": traffic_src,
                             "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
                             "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
+                            "alg_bytes": ("W x states expanded + 8 x seen-set probes issued (the insert is fused into this kernel)" if dom == "expand" and not a.matrix
+                                          else "W x units"),
+                            "frac_state_bytes_only": (state_only / (ks[dom]["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == "expand" and ks[dom]["ms_total"] else None,
+                            # the practical ceiling SURVEY 8d asks for: a probe moves a whole bucket (32 bytes in a sparse table, 64 in a full one)
+                            "probe_bytes": 32 if slots >= 3 * (G0["distinct"] + (1 << 20)) and not a.dense_table else 64,
                             "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
                             # (2 W + 8 G/D) bytes per distinct state over the WALL time of a step
                             "pipeline_GBs": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9,

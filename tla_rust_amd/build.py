@@ -33,6 +33,8 @@ def build(force=False, verbose=False):
               "-I", str(PKG.parent / "include")]
     if os.environ.get("TLAMC_LINE_TABLES"):  # source lines for rocprofv3's PC sampling (profiles/pcsample.sh); code generation unchanged
         common.append("-gline-tables-only")
+    if os.environ.get("TLAMC_EXTRA_DEFS"):   # A/B builds: extra -D flags (e.g. -DMC_NT_PARENT), space-separated
+        common += os.environ["TLAMC_EXTRA_DEFS"].split()
     if os.environ.get("TLAMC_PHASE_PROF"):   # per-phase cycle counters inside k_expand_family (profiles/phase_prof.py): a profiling build
         common.append("-DMC_PHASE_PROF")
     base = [CSRC / "engine.hip", CSRC / "mc_common.h", CSRC / "spec_registry.h", PKG.parent / "include" / "tlamc.h"]

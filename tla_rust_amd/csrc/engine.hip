@@ -104,6 +104,7 @@ using GlobalWords = const __attribute__((address_space(1))) uint64_t *;  // (a g
 struct BlockRef {
     GlobalWords base;  // arena + block * words * 64: uniform
     unsigned lane;     // the state inside the block
+    // (loading the rows non-temporally — they are read once — was measured: 170.7 against 165.4 ms per step on the t3 graph)
     __device__ __forceinline__ uint64_t get(int w) const { return base[(unsigned)w * 64u + lane]; }
 };
 __device__ __forceinline__ GlobalWords uniform_ptr(const uint64_t *p) {
@@ -248,9 +249,12 @@ __device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets
     return false;
 }
 constexpr uint64_t SEEN_SPARSE = 1ull << 63;
+#ifndef MC_SPARSE_SLOTS
+#define MC_SPARSE_SLOTS 4
+#endif
 // (the parameter is still called `mask` in the kernels' signatures: it carries the bucket count and the mode bit)
 __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
-    if (nbuckets & SEEN_SPARSE) return seen_insert_t<4>(table, nbuckets & ~SEEN_SPARSE, fp, err);
+    if (nbuckets & SEEN_SPARSE) return seen_insert_t<MC_SPARSE_SLOTS>(table, nbuckets & ~SEEN_SPARSE, fp, err);
     return seen_insert_t<8>(table, nbuckets, fp, err);
 }
 
@@ -706,7 +710,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             const unsigned k = (qhead + lane) & (QCAP - 1);
             src = Q.q_src[k];
             qfp = Q.q_fp[k];
-            if constexpr (!ROUTE) is_new = (flags & 16u) ? false : seen_insert_t<8>(table, mask, qfp, err);
+            if constexpr (!ROUTE) is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);
         }
         qhead = (qhead + take) & (QCAP - 1);
         qn -= take;
@@ -717,7 +721,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             // ranks 1/P of the candidates skip the exchange; on one rank the sharded engine does exactly the fused engine's work.
             unsigned owner = lane < take ? fp_owner(qfp, rt.nranks) : 0xffffffffu;
             if (owner == rt.my_rank) {
-                is_new = (flags & 16u) ? false : seen_insert_t<8>(table, mask, qfp, err);
+                is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);
                 owner = 0xffffffffu;
             }
             {
@@ -1485,7 +1489,7 @@ struct Engine : EngineBase {
         return sg < 1 ? 1u : (unsigned)sg;
     }
     bool no_slices = getenv("TLAMC_NOSLICE") != nullptr;
-    uint64_t seen_arg() const { return seen_sparse ? ((table_cap / 4) | SEEN_SPARSE) : table_cap / 8; }
+    uint64_t seen_arg() const { return seen_sparse ? ((table_cap / MC_SPARSE_SLOTS) | SEEN_SPARSE) : table_cap / 8; }
     KTimer timer;
     mc_kernel_stat kstat[3];
     // counterexample of the last run
@@ -1514,9 +1518,8 @@ struct Engine : EngineBase {
         arena_cap = cfg.arena_capacity ? cfg.arena_capacity : (1ull << 22);
         arena_cap = (arena_cap + 63) & ~63ull;
         if (arena_cap >= (1ull << 32) - 1) { set_error("arena_capacity must be < 2^32 states"); return MC_EBADCFG; }
-        // a table that can never be more than a third full is probed 32 bytes at a time (seen_insert); the by-family kernels of
-        // the raft lowering are compiled for the 64-byte form only (their graphs fill the table)
-        seen_sparse = !UsesFamilies<S>::value && table_cap >= 3 * arena_cap && table_cap / 4 <= 0xffffffffull && !getenv("TLAMC_DENSE_TABLE");
+        // a table that can never be more than a third full is probed 32 bytes at a time (seen_insert)
+        seen_sparse = table_cap >= 3 * arena_cap && table_cap / MC_SPARSE_SLOTS <= 0xffffffffull && !getenv("TLAMC_DENSE_TABLE");
         chunk = cfg.chunk_states ? cfg.chunk_states : (1ull << 18);
         chunk = (chunk + 255) & ~255ull;
         if (chunk > (1ull << 23)) chunk = 1ull << 23;  // a column index must fit 24 bits
@@ -2271,7 +2274,7 @@ struct Engine : EngineBase {
         for (uint32_t i = 0; i < h.nparams && i < 16; i++) h.params[i] = desc.params[i];
         if (!ck_params_comparable()) h.params[0] = (int64_t)program_hash;
         h.words = (uint32_t)W; h.has_trace = d_parent ? 1u : 0u; h.rank = cfg.shard_rank; h.world = nranks();
-        h.table_cap = table_cap; h.lo = sh_lo; h.hi = sh_hi; h.next = sh_next; h.dup = sh_dup; h.nlevels = sh_levels.size();
+        h.table_cap = table_cap | (seen_sparse ? SEEN_SPARSE : 0); h.lo = sh_lo; h.hi = sh_hi; h.next = sh_next; h.dup = sh_dup; h.nlevels = sh_levels.size();
         int rc = MC_OK;
         DevCounters c;
         HIP_TRY(hipMemcpy(&c, d_ctr, sizeof c, hipMemcpyDeviceToHost));
@@ -2303,7 +2306,8 @@ struct Engine : EngineBase {
         else if (!ck_params_comparable() && (h.nparams != 1 || (uint64_t)h.params[0] != program_hash))
             fail(MC_EBADCFG, "mc_shard_restore: the checkpoint was written by another compiled program");
         else if (h.rank != cfg.shard_rank || h.world != nranks()) fail(MC_EBADCFG, "mc_shard_restore: the file is another rank's, or of a run with another number of ranks");
-        else if (h.table_cap != table_cap) fail(MC_EBADCFG, "mc_shard_restore: table_capacity differs from the checkpointed run's (the seen-set slice is stored as it lay in HBM)");
+        else if (h.table_cap != (table_cap | (seen_sparse ? SEEN_SPARSE : 0)))
+            fail(MC_EBADCFG, "mc_shard_restore: table_capacity differs from the checkpointed run's, or the bucket form it implies (4 slots when the table is >= 3 x the arena): the seen-set slice is stored as it lay in HBM");
         else if (h.next > arena_cap) fail(MC_EARENA, "mc_shard_restore: arena_capacity is smaller than the checkpoint");
         else if (h.lo > h.hi || h.hi != h.next || h.dup > h.next || h.nlevels == 0 || h.nlevels >= MC_MAX_LEVELS) fail(MC_EPARSE, "mc_shard_restore: inconsistent header");
         else if ((d_parent != nullptr) != (h.has_trace != 0)) fail(MC_EBADCFG, "mc_shard_restore: MC_F_TRACE differs from the checkpointed run's");
