@@ -12,7 +12,7 @@ from tla_rust_amd import binding as B
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 params = [3, 4, 2, 3, 1, 1, K, 1, 4, K]
-eng = amd.Engine("raft", params, table_capacity=3 << 26, arena_capacity=103_000_000 if K == 10 else 340_000_000, chunk_states=1 << 22, trace=False, timing=True)
+eng = amd.Engine("raft", params, table_capacity=(8 << 26) if K == 10 else (26 << 26), arena_capacity=103_000_000 if K == 10 else 340_000_000, chunk_states=1 << 22, trace=False, timing=True)
 L = B.lib()
 L.mc_engine_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
 out = (C.c_uint64 * 48)()
