@@ -424,7 +424,12 @@ int mc_spec_resolve(const char *module_name, const mc_cfg *c, mc_spec_desc *out)
  * *prog_out = the compiled program when the module went through the PlusCal compiler (the descriptor points into it: free
  * it with mc_program_free after the engines are destroyed), NULL otherwise. */
 int mc_resolve_files(const char *tla_path, const char *cfg_path, unsigned flags, mc_spec_desc *out, mc_program **prog_out);
-/* `tlc X.tla` end to end: read X.tla / X.cfg, run on `cfg->device`, write TLC's report text */
+/* `tlc X.tla` end to end: read X.tla / X.cfg, run on `cfg->device`, write TLC's report text.
+ * A TLA+ module that belongs to none of the lowered families (no PlusCal algorithm, not raft / the snapshot-isolation specs /
+ * Voting / Paxos or a wrapper of them) is evaluated on the HOST by the general evaluator (csrc/tlaeval.cpp: the Specifying Systems
+ * examples of the reference; `MCInnerSerial.tla` gives testout2:260-266): out->host_evaluated = 1, the report's first line says
+ * so, cfg->max_levels / max_distinct / MC_F_DEADLOCK / MC_F_PROGRESS apply, $TLA_PATH (a ':'-separated list) names more module
+ * directories.  A module of a lowered family is never evaluated on the host: what its lowering refuses stays MC_ENOSPEC. */
 int mc_check_files(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report,
                    size_t report_cap, mc_result *out);
 /* the same, and every distinct state found is written to dump_path in TLC's `-dump` layout ("State k:" + the
