@@ -9,12 +9,13 @@
 
 #include "../../tla_rust_amd/csrc/tlaeval.h"
 
-extern "C" int tlaeval_door(const char *tla, const char *cfg, const char *search, uint64_t max_levels, int check_deadlock, const char *dump,
+extern "C" int tlaeval_door(const char *tla, const char *cfg, const char *search, uint64_t max_levels, int check_deadlock, int symmetry, const char *dump,
                             const char *order, char *out, size_t cap) {
     tlaeval::Options o;
     tlaeval::Result r;
     o.max_levels = max_levels;
     o.check_deadlock = check_deadlock != 0;
+    o.symmetry = symmetry != 0;
     auto split = [](const char *s, char sep, std::vector<std::string> &dst) {
         if (!s) return;
         std::string t = s;

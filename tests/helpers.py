@@ -170,14 +170,14 @@ def build_tlaeval_door():
     return so
 
 
-def tlaeval_run(tla, cfg, search=(), max_levels=0, deadlock=True, dump=None, order=()):
+def tlaeval_run(tla, cfg, search=(), max_levels=0, deadlock=True, dump=None, order=(), symmetry=True):
     """the host evaluator on module + cfg files -> dict(rc, distinct, generated, depth, verdict (MC_V_*), levels, ...)"""
     import ctypes as C
     import json
     lib = C.CDLL(str(build_tlaeval_door()))
-    lib.tlaeval_door.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.tlaeval_door.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
     buf = C.create_string_buffer(1 << 16)
-    lib.tlaeval_door(str(tla).encode(), str(cfg).encode(), ":".join(str(s) for s in search).encode(), max_levels, 1 if deadlock else 0,
+    lib.tlaeval_door(str(tla).encode(), str(cfg).encode(), ":".join(str(s) for s in search).encode(), max_levels, 1 if deadlock else 0, 1 if symmetry else 0,
                      str(dump).encode() if dump else None, ",".join(order).encode(), buf, len(buf))
     return json.loads(buf.value.decode())
 

@@ -112,6 +112,53 @@ def test_evaluator_on_the_reference_raft_text(name, tmp_path):
     assert _digests(dump) == gold["level_digests"]
 
 
+@needs_reference
+@pytest.mark.parametrize("name", ["ssi_2x1", "ssi_2x2", "textbook_2x2"])
+def test_evaluator_on_the_reference_snapshot_isolation_text(name, tmp_path):
+    """serializableSnapshotIsolation.tla:219-996 / textbookSnapshotIsolation.tla under specs/MCssi.tla / MCtextbookSI.tla: recursive
+    operators, CHOOSE, SelectSeq with LAMBDA, sets of records; all eight invariants on every state; per-level state SETS equal the
+    reference-text fixture"""
+    from make_reference_text_golden import SSI_INVARIANTS, SSI_MODELS, SSI_ORDER, TEXTBOOK_ORDER, ssi_cfg
+    gold = json.loads((ROOT / "tests" / "golden" / "ssi_reference_text.json").read_text())[name]
+    m = SSI_MODELS[name]
+    textbook = len(m["params"]) > 4 and m["params"][4]
+    cfg = tmp_path / "m.cfg"
+    cfg.write_text(ssi_cfg(m["params"][0], m["params"][1], [i for i in SSI_INVARIANTS if not (textbook and i in ("CahillOK", "BernsteinOK"))]))
+    dump = tmp_path / "dump.txt"
+    r = helpers.tlaeval_run(ROOT / "specs" / f"{m['module']}.tla", cfg, search=["/root/reference/examples"], dump=dump,
+                            order=TEXTBOOK_ORDER if textbook else SSI_ORDER)
+    assert r["rc"] == 0, r
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == (gold["distinct"], gold["generated"], gold["depth"], gold["levels"], V_OK)
+    assert _digests(dump) == gold["level_digests"]
+
+
+@needs_reference
+@pytest.mark.parametrize("name", ["voting_mc", "voting_mc_nosym", "paxos_mc", "voting_3x2_b3", "paxos_3x2", "paxos_3x2_nosym"])
+def test_evaluator_on_the_paxos_family(name):
+    """examples/Paxos/MCVoting.tla, MCPaxos.tla + cfg AS COMMITTED (named INSTANCE with substitution, `<-` overrides, SYMMETRY by least
+    image over the generated group, the safety part of PROPERTY C!Spec / V!Spec on every transition) and the 3 x 2 wrappers of
+    specs/paxos: the counts of tests/golden/paxos_reference_text.json"""
+    from make_reference_text_golden import PAXOS_MODELS
+    gold = json.loads((ROOT / "tests" / "golden" / "paxos_reference_text.json").read_text())[name]
+    m = PAXOS_MODELS[name]
+    tla = Path(m["tla"])
+    r = helpers.tlaeval_run(tla, tla.with_suffix(".cfg"), search=["/root/reference/examples/Paxos"], deadlock=False, symmetry=m["sym"])
+    assert r["rc"] == 0, r
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == (gold["distinct"], gold["generated"], gold["depth"], gold["levels"], V_OK)
+
+
+@needs_reference
+@pytest.mark.parametrize("name,index,trace_len", [("voting_badquorum", 1, 4), ("paxos_bad_phase2a", 2, 2)])
+def test_evaluator_finds_the_paxos_negative_controls(name, index, trace_len):
+    """a wrapper with a non-intersecting quorum system breaks the refinement PROPERTY (reported after the invariants), a Phase2a
+    without its quorum conjunct breaks Inv3 one step after Init: same index and counterexample length as the fixture"""
+    from make_reference_text_golden import PAXOS_NEGATIVE
+    gold = json.loads((ROOT / "tests" / "golden" / "paxos_reference_text.json").read_text())[name]
+    tla = Path(PAXOS_NEGATIVE[name]["tla"])
+    r = helpers.tlaeval_run(tla, tla.with_suffix(".cfg"), search=["/root/reference/examples/Paxos"], deadlock=False)
+    assert (r["verdict"], r["violated_invariant"], r["trace_len"]) == (V_INVARIANT, index, trace_len) == (V_INVARIANT, gold["index"], gold["trace_len"])
+
+
 def test_evaluator_on_the_pluscal_translation_gives_the_readme_run(tmp_path):
     """specs/pcal_intro.tla carries the translation pcal2tla inserts: evaluated as plain TLA+ it must give the README's TLC run
     (README.md:319-321: 9097 generated / 6164 distinct / 999 on queue; depth 7; MoneyInvariant violated)"""

@@ -1914,8 +1914,9 @@ struct Checker {
         }
         return p;
     }
-    void setup(const std::string &tla_path, const std::string &cfg_text, const std::vector<std::string> &search) {
+    void setup(const std::string &tla_path, const std::string &cfg_text, const std::vector<std::string> &search, bool symmetry) {
         cfg = parse_cfg(cfg_text);
+        if (!symmetry) cfg.symmetry.clear();
         const size_t slash = tla_path.rfind('/');
         sp.search.push_back(slash == std::string::npos ? "." : tla_path.substr(0, slash));
         for (auto &s : search) sp.search.push_back(s);
@@ -2149,7 +2150,7 @@ void *job_main(void *p) {
         std::string cfg_text;
         if (!read_text(*j.cfg, cfg_text)) { *j.error = "cannot read configuration file " + *j.cfg; j.rc = MC_EPARSE; return nullptr; }
         Checker c;
-        c.setup(*j.tla, cfg_text, j.opt->search);
+        c.setup(*j.tla, cfg_text, j.opt->search, j.opt->symmetry);
         c.run(*j.opt, *j.out);
     } catch (SyntaxErr &e) { *j.error = e.msg; j.rc = MC_EPARSE; }
     catch (TlaError &e) { *j.error = e.msg; j.rc = MC_ENOSPEC; }

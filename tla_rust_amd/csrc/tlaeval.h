@@ -18,6 +18,7 @@ namespace tlaeval {
 struct Options {
     uint64_t max_levels = 0, max_distinct = 0;
     bool check_deadlock = true;
+    bool symmetry = true;             // false: ignore the cfg's SYMMETRY (TLC run on a copy of the cfg without that line)
     double progress_seconds = 0;  // > 0: print TLC's "Progress(d): ..." lines to stdout at this interval
     std::vector<std::string> search;  // directories searched for EXTENDed / INSTANCEd modules (after the root module's own)
     std::string dump_path;            // every stored state as one line "L<level> /\ v = ... /\ w = ..." (tests compare state SETS)
