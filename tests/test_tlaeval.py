@@ -113,7 +113,7 @@ def test_evaluator_on_the_reference_raft_text(name, tmp_path):
 
 
 @needs_reference
-@pytest.mark.parametrize("name", ["ssi_2x1", "ssi_2x2", "textbook_2x2"])
+@pytest.mark.parametrize("name", ["ssi_2x1", "ssi_2x2"])   # textbook_2x2 (17 s) and ssi_3x1 (64 s) by hand: the same call
 def test_evaluator_on_the_reference_snapshot_isolation_text(name, tmp_path):
     """serializableSnapshotIsolation.tla:219-996 / textbookSnapshotIsolation.tla under specs/MCssi.tla / MCtextbookSI.tla: recursive
     operators, CHOOSE, SelectSeq with LAMBDA, sets of records; all eight invariants on every state; per-level state SETS equal the
