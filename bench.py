@@ -322,8 +322,8 @@ def main():
         if direct:  # reads W per expanded state, touches 8 B of the seen-set per in-model successor, writes W per new state
             alg["expand"] = W * ks["expand"]["units"] + 8 * ks["cand_cells"] + W * D
         state_only = alg["expand"]
-        if not a.matrix:  # the seen-set insert is FUSED into the expand kernel: its 8 bytes per probed candidate (SURVEY 8d's G x 8 term,
-            alg["expand"] += 8 * ks["cand_cells"]   # counted on the probes really issued) are that kernel's algorithmic bytes
+        if not a.matrix:  # the seen-set insert is FUSED into the expand kernel: its 8 bytes per look-up (SURVEY 8d's G x 8 term, counted
+            alg["expand"] += 8 * ks["cand_cells"]   # on the in-model, state-changing successors: the ones that ARE looked up) are that kernel's
         dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
         n_runs = a.steps  # stats are reset by every run(): they describe the last step
         ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
@@ -356,7 +356,8 @@ def main():
                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_lower": traffic_lower, "l2_hit_rate": l2_hit, "traffic_source": traffic_src,
                             "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
                             "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
-                            "alg_bytes": ("W x states expanded + 8 x seen-set probes issued (the insert is fused into this kernel)" if dom == "expand" and not a.matrix
+                            "seen_set_lookups": ks["cand_cells"],
+                            "alg_bytes": ("W x states expanded + 8 x seen-set look-ups (in-model, state-changing successors; the insert is fused into this kernel)" if dom == "expand" and not a.matrix
                                           else "W x units"),
                             "frac_state_bytes_only": (state_only / (ks[dom]["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == "expand" and ks[dom]["ms_total"] else None,
                             # the practical ceiling SURVEY 8d asks for: a probe moves a whole bucket (32 bytes in a sparse table, 64 in a full one)
