@@ -1,15 +1,11 @@
-# A/B on the t3 and K = 10 workloads: pipelined seen-set probes in the by-family kernel (second library built with -DMC_PROBE_PIPELINE=0)
-set -x
-for w in t3 k10; do python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/ab_${w}_pipe.json 2> gpurun_out/ab.err; done
-cp tla_rust_amd/_build/libtlamc.so /tmp/keep.so
-cp tla_rust_amd/_build/libtlamc_np.so tla_rust_amd/_build/libtlamc.so
-for w in t3 k10; do python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/ab_${w}_nopipe.json 2>> gpurun_out/ab.err; done
-cp /tmp/keep.so tla_rust_amd/_build/libtlamc.so
-tail -n 3 gpurun_out/ab.err
-python - <<'PY'
-import json
-for f in ['ab_t3_pipe','ab_t3_nopipe','ab_k10_pipe','ab_k10_nopipe']:
-    for l in open('gpurun_out/'+f+'.json'):
-        if l.startswith('{'):
-            d=json.loads(l); print(f, d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['config'].get('verdict'))
-PY
+# round 3, the A/B runs behind DESIGN.md section 5's "measured and NOT adopted" list (each was one gpurun call with this file holding
+# the commands of that experiment; the last one is kept): seen-set bucket width and sparsity, non-temporal parent loads, XCD-aware
+# tile order, frontier states per launch, pipelined probes, level-boundary overlap, stream priorities, and the kernel timeline of a
+# step (profiles/r03l_gaps.py -> profiles/r03l_gaps.txt)
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/ktrace -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/ktrace.log 2>&1
+f=$(ls $R/gpurun_out/ktrace/*/*_kernel_trace.csv | head -1)
+python $R/profiles/r03l_gaps.py $f | tee $R/gpurun_out/r03l_gaps.txt
+rm -rf $R/gpurun_out/ktrace
+for p in 0 1 2; do TLAMC_PRIO=$p python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/ab_prio$p.json 2> $R/gpurun_out/ab.err; done
