@@ -248,3 +248,115 @@ def test_own_module_equals_the_python_evaluator(inv, verdict, tmp_path):
     else:  # the search stops at the first violation it meets: which one depends on the enumeration order, its depth does not
         assert (res.trace_len, res.depth) == (p["trace_len"], p["depth"]) and f"Error: Invariant {inv} is violated." in buf.value.decode()
         assert buf.value.decode().count("State ") == res.trace_len
+
+
+# ---------------------------------------------------------------------------------------------- language features, one small module each
+FEATURES = {
+    # named INSTANCE with substitution, an EXTENDS chain, operators with operator arguments, LAMBDA, SelectSeq, CASE / OTHER
+    "Inst": ("""---- MODULE Inst ----
+EXTENDS Naturals, Sequences, Base
+VARIABLES hist, n
+C == INSTANCE Counter WITH val <- n, Max <- Limit
+Apply(Op(_, _), a, b) == Op(a, b)
+Evens(s) == SelectSeq(s, LAMBDA x : x % 2 = 0)
+Init == hist = << >> /\\ C!CInit
+Next == /\\ C!CNext
+        /\\ hist' = IF Len(hist) < 3 THEN Append(hist, Apply(LAMBDA a, b : a + b, n, n')) ELSE Evens(hist)
+        /\\ CASE n = 0 -> TRUE [] n > 0 /\\ n < Limit -> n' # n [] OTHER -> TRUE
+Inv == C!Bounded /\\ \\A i \\in 1 .. Len(hist) : hist[i] <= 2 * Limit
+====
+""", {"Base": "---- MODULE Base ----\nEXTENDS Naturals\nCONSTANT Limit\nDouble(x) == 2 * x\n====\n",
+      "Counter": "---- MODULE Counter ----\nEXTENDS Naturals\nCONSTANT Max\nVARIABLE val\nCInit == val = 0\nCNext == val' \\in {v \\in 0 .. Max : v = val + 1 \\/ v = 0}\nBounded == val <= Max\n====\n"},
+             "INIT Init\nNEXT Next\nCONSTANT Limit = 3\nINVARIANT Inv\n", False),
+    # functions: [x \in S |-> e], EXCEPT with @ and nested paths, DOMAIN, :> and @@, function sets, SUBSET, UNION, \X, tuples as bounds
+    "Fns": ("""---- MODULE Fns ----
+EXTENDS Naturals, FiniteSets, TLC
+CONSTANT K
+VARIABLES f, g
+Keys == 1 .. K
+Init == /\\ f \\in [Keys -> {0, 1}]
+        /\\ g = [k \\in Keys |-> [lo |-> 0, hi |-> k]]
+Bump(k) == /\\ f' = [f EXCEPT ![k] = (@ + 1) % 3]
+           /\\ g' = [g EXCEPT ![k].lo = @ + 1, ![k].hi = g[k].lo]
+Merge == /\\ \\E <<a, b>> \\in Keys \\X Keys : a < b /\\ f' = (a :> f[b]) @@ (b :> f[a]) @@ f
+         /\\ UNCHANGED g
+Next == (\\E k \\in Keys : g[k].lo < 2 /\\ Bump(k)) \\/ Merge
+Inv == /\\ DOMAIN f = Keys
+       /\\ Cardinality(UNION {{f[k]} : k \\in Keys}) <= 3
+       /\\ {k \\in Keys : f[k] = 0} \\in SUBSET Keys
+====
+""", {}, "INIT Init\nNEXT Next\nCONSTANT K = 2\nINVARIANT Inv\n", False),
+    # model values, SYMMETRY by Permutations, CHOOSE, a CONSTRAINT (out-of-model successors are generated and not stored), deadlock off
+    "Sym": ("""---- MODULE Sym ----
+EXTENDS Naturals, FiniteSets, TLC
+CONSTANTS Node, None
+VARIABLES owner, waiting
+Perms == Permutations(Node)
+Init == owner = None /\\ waiting = {}
+Ask(n) == n \\notin waiting /\\ owner # n /\\ waiting' = waiting \\cup {n} /\\ UNCHANGED owner
+Grant == /\\ owner = None /\\ waiting # {}
+         /\\ \\E n \\in waiting : owner' = n /\\ waiting' = waiting \\ {n}
+Release == owner # None /\\ owner' = None /\\ UNCHANGED waiting
+Next == (\\E n \\in Node : Ask(n)) \\/ Grant \\/ Release
+Small == Cardinality(waiting) <= 2
+Inv == owner = None \\/ owner \\in Node
+Oldest == IF waiting = {} THEN None ELSE CHOOSE n \\in waiting : TRUE
+====
+""", {}, "INIT Init\nNEXT Next\nCONSTANTS Node = {a, b, c}  None = None\nSYMMETRY Perms\nCONSTRAINT Small\nINVARIANT Inv\n", False),
+    # recursive function in LET, [A]_v and <<A>>_v as actions, assignment through an operator parameter, `<-` override of an operator
+    "Recs": ("""---- MODULE Recs ----
+EXTENDS Naturals, Sequences
+CONSTANT Put(_, _, _)
+VARIABLES q, total
+Sum(s) == LET F[i \\in 0 .. Len(s)] == IF i = 0 THEN 0 ELSE F[i - 1] + s[i] IN F[Len(s)]
+MCPut(v, old, new) == new = Append(old, v)
+Init == q = << >> /\\ total = 0
+Enq == \\E v \\in 1 .. 2 : Len(q) < 3 /\\ Put(v, q, q') /\\ total' = Sum(q')
+Deq == q # << >> /\\ q' = Tail(q) /\\ total' = total - Head(q)
+Next == [Enq]_<<q, total>> /\\ (<<Deq>>_q \\/ Enq \\/ UNCHANGED <<q, total>>)
+Inv == total = Sum(q)
+====
+""", {}, "INIT Init\nNEXT Next\nCONSTANT Put <- MCPut\nINVARIANT Inv\n", True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FEATURES))
+def test_language_features_equal_the_python_evaluator(name, tmp_path):
+    """runs anywhere: the product through the C ABI against oracle/tlaplus.py — counters, depth, verdict, per-level counts"""
+    import tlaplus as T
+    text, extra, cfg, deadlock = FEATURES[name]
+    (tmp_path / f"{name}.tla").write_text(text)
+    for m, t in extra.items():
+        (tmp_path / f"{m}.tla").write_text(t)
+    (tmp_path / f"{name}.cfg").write_text(cfg)
+    p = T.Checker(tmp_path / f"{name}.tla", cfg_text=cfg).run_levels(keep_states=False, check_deadlock=deadlock)
+    from tla_rust_amd import binding as B
+    import ctypes as C
+    cfgc = B.Config(0, B.MC_F_TRACE | (B.MC_F_DEADLOCK if deadlock else 0), 0, 0, 0, 0, 0, 0, 1)
+    r = B.CResult()
+    buf = C.create_string_buffer(1 << 20)
+    rc = B.lib().mc_check_files(str(tmp_path / f"{name}.tla").encode(), None, C.byref(cfgc), buf, len(buf), C.byref(r))
+    assert rc == 0, B.lib().mc_last_error().decode()
+    res = B._result(r)
+    assert p["verdict"] == "ok" and p["distinct"] > 5, p
+    assert (res.verdict, res.distinct, res.generated, res.depth, res.levels) == (p["verdict"], p["distinct"], p["generated"], p["depth"], p["levels"])
+
+
+def test_mc_exit_codes_and_traces_for_host_evaluated_modules(tmp_path):
+    """`mc X.tla` keeps TLC's exit codes for a module without a lowering: 12 for a violated invariant (with the behaviour), 11 for a
+    deadlock, 12 for a failed Assert, 0 otherwise"""
+    import subprocess
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    mod = ("---- MODULE Tiny ----\nEXTENDS Naturals, TLC\nVARIABLE x\nInit == x = 0\nNext == x < 3 /\\ x' = x + 1 /\\ %s\n"
+           "Low == x < 2\n====\n")
+    cases = [("TRUE", "INVARIANT Low\n", [], 12, ["Error: Invariant Low is violated.", "State 3:", "/\\ x = 2"]),
+             ("TRUE", "", [], 11, ["Error: Deadlock reached.", "State 4:"]),
+             ("TRUE", "", ["-deadlock"], 0, ["Model checking completed. No error has been found.", "4 distinct states found"]),
+             ('Assert(x < 1, "too far")', "", ["-deadlock"], 12, ["The first argument of Assert evaluated to FALSE", "too far"])]
+    for body, cfg, opts, code, lines in cases:
+        (tmp_path / "Tiny.tla").write_text(mod % body)
+        (tmp_path / "Tiny.cfg").write_text("INIT Init\nNEXT Next\n" + cfg)
+        p = subprocess.run([str(mc), str(tmp_path / "Tiny.tla"), "-noprogress"] + opts, capture_output=True, text=True, timeout=120)
+        assert p.returncode == code, (body, cfg, p.stdout, p.stderr)
+        assert all(ln in p.stdout for ln in lines), (lines, p.stdout)
+        assert "evaluated on the host" in p.stdout.splitlines()[0]
