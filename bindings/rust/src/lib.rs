@@ -27,7 +27,7 @@ pub struct mc_config {
 #[repr(C)]
 pub struct mc_result {
     pub distinct: u64, pub generated: u64, pub queue_left: u64, pub depth: u32, pub verdict: i32,
-    pub violated_invariant: i32, pub trace_len: u32, pub levels: u32, pub reserved: u32, pub seconds: f64,
+    pub violated_invariant: i32, pub trace_len: u32, pub levels: u32, pub host_evaluated: u32, pub seconds: f64,
     pub level_distinct: [u64; MC_MAX_LEVELS],
 }
 #[repr(C)]
@@ -45,6 +45,9 @@ extern "C" {
     pub fn mc_engine_checkpoint(e: *mut mc_engine, path: *const c_char) -> c_int;
     pub fn mc_engine_restore(e: *mut mc_engine, path: *const c_char) -> c_int;
     pub fn mc_engine_destroy(e: *mut mc_engine);
+    // one checkpoint file per rank of a sharded run (include/tlamc.h: mc_shard_checkpoint / mc_shard_restore)
+    pub fn mc_shard_checkpoint(e: *mut mc_engine, path: *const c_char) -> c_int;
+    pub fn mc_shard_restore(e: *mut mc_engine, path: *const c_char) -> c_int;
     // X.tla + X.cfg -> the descriptor mc_engine_create takes (one engine per rank in sharded mode)
     pub fn mc_resolve_files(tla: *const c_char, cfg_path: *const c_char, flags: u32, out: *mut mc_spec_desc,
                             prog_out: *mut *mut mc_program) -> c_int;
@@ -66,7 +69,7 @@ extern "C" {
 }
 
 #[derive(Debug)]
-pub struct Outcome { pub distinct: u64, pub generated: u64, pub depth: u32, pub verdict: i32, pub report: String }
+pub struct Outcome { pub distinct: u64, pub generated: u64, pub depth: u32, pub verdict: i32, pub host_evaluated: bool, pub report: String }
 
 /// `tlc X.tla` (reference Makefile:6-7) from Rust.
 pub fn check(tla: &std::path::Path, device: i32) -> Result<Outcome, String> {
@@ -80,7 +83,7 @@ pub fn check(tla: &std::path::Path, device: i32) -> Result<Outcome, String> {
         return Err(unsafe { CStr::from_ptr(mc_last_error()) }.to_string_lossy().into_owned());
     }
     let end = buf.iter().position(|&b| b == 0).unwrap_or(0);
-    Ok(Outcome { distinct: res.distinct, generated: res.generated, depth: res.depth, verdict: res.verdict,
+    Ok(Outcome { distinct: res.distinct, generated: res.generated, depth: res.depth, verdict: res.verdict, host_evaluated: res.host_evaluated != 0,
                  report: String::from_utf8_lossy(&buf[..end]).into_owned() })
 }
 
