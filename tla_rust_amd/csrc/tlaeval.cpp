@@ -1817,11 +1817,19 @@ Cfg parse_cfg(const std::string &text) {
             while (toks[i].k != Tok::END && !is_kw(i)) dst.push_back(toks[i++].s);
         } else {
             while (toks[i].k != Tok::END && !is_kw(i)) {
+                if (toks[i].k != Tok::ID) throw SyntaxErr{"cfg: expected a constant name at line " + std::to_string(toks[i].line) + ", found '" + toks[i].s + "'"};
                 const std::string name = toks[i++].s;
                 if (toks[i].k == Tok::SYM && toks[i].s == "=") { i++; out.constants.emplace_back(name, value(i)); }
                 else if (toks[i].k == Tok::SYM && toks[i].s == "<-") {
                     i++;
-                    if (toks[i].k == Tok::SYM && toks[i].s == "[") { out.scoped[{toks[i + 1].s, name}] = toks[i + 3].s; i += 4; continue; }  // <-[Module] Id (MCPaxos.cfg:9)
+                    if (toks[i].k == Tok::SYM && toks[i].s == "[") {  // <-[Module] Id (MCPaxos.cfg:9)
+                        if (i + 3 >= toks.size() || toks[i + 1].k != Tok::ID || toks[i + 2].s != "]" || toks[i + 3].k != Tok::ID)
+                            throw SyntaxErr{"cfg: expected <-[Module] Id at line " + std::to_string(toks[i].line)};
+                        out.scoped[{toks[i + 1].s, name}] = toks[i + 3].s;
+                        i += 4;
+                        continue;
+                    }
+                    if (toks[i].k != Tok::ID) throw SyntaxErr{"cfg: expected a definition name after <- at line " + std::to_string(toks[i].line)};
                     out.overrides.emplace_back(name, toks[i++].s);
                 } else throw SyntaxErr{"cfg: expected = or <- after " + name + " at line " + std::to_string(toks[i].line)};
             }
