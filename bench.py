@@ -190,7 +190,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
     ap.add_argument("--chunk", type=int, default=1 << 23)   # frontier states per launch (the engine's maximum: 160.5 ms per step against 163.6 at 2^22, 169.4 at 2^21)
-    ap.add_argument("--shard-chunk", type=int, default=1 << 21, help="frontier states per round and rank in the sharded (--gpus N) path")
+    ap.add_argument("--shard-chunk", type=int, default=0, help="frontier states per round and rank in the sharded (--gpus N) path; 0 = 2^23 at world "
+                    "size 1 (one engine launch per round: 168.9 ms per step against 184.1 at 2^21), 2^21 otherwise (several rounds per level, so that "
+                    "the exchange of round r+1 overlaps the probes of round r)")
     ap.add_argument("--packed-fanout", type=int, default=16, help="in-model successors per state the fixed-capacity exchange buckets allow for")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank on GPU 0 (needs a librccl stand-in in $TLAMC_RCCL; RCCL refuses it)")
     ap.add_argument("--workload", choices=["t3", "k10", "k11"], default="t3", help="t3: MaxTerm 3, MaxMsgKeys 8 (525.8 M states, the contract line); "
@@ -226,6 +228,8 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     use_dist = launched  # one rank of N (N = 1 included: the sharded engine over RCCL at world size 1)
+    if not a.shard_chunk:
+        a.shard_chunk = (1 << 23) if world == 1 else (1 << 21)
 
     G0 = golden()
     slots = (1 << a.table_log2) if a.table_log2 else a.table_slots
