@@ -245,8 +245,9 @@ def test_own_module_equals_the_python_evaluator(inv, verdict, tmp_path):
     assert res.verdict == verdict == p["verdict"]
     if verdict == "ok":
         assert (res.distinct, res.generated, res.depth, res.levels) == (p["distinct"], p["generated"], p["depth"], p["levels"])
-    else:  # the search stops at the first violation it meets: which one depends on the enumeration order, its depth does not
-        assert (res.trace_len, res.depth) == (p["trace_len"], p["depth"]) and f"Error: Invariant {inv} is violated." in buf.value.decode()
+    else:  # the product finishes the level the violation was found on (like the GPU engine), the oracle's evaluator stops at once:
+        #      the counterexample has the same length, the product's depth counts the level that was being generated
+        assert (res.trace_len, res.depth) == (p["trace_len"], p["depth"] + 1) and f"Error: Invariant {inv} is violated." in buf.value.decode()
         assert buf.value.decode().count("State ") == res.trace_len
 
 
@@ -360,3 +361,43 @@ def test_mc_exit_codes_and_traces_for_host_evaluated_modules(tmp_path):
         assert p.returncode == code, (body, cfg, p.stdout, p.stderr)
         assert all(ln in p.stdout for ln in lines), (lines, p.stdout)
         assert "evaluated on the host" in p.stdout.splitlines()[0]
+
+
+# ---------------------------------------------------------------------------------------------- PlusCal programs: a third opinion
+def _pcal_cases():
+    import test_pcal
+    return test_pcal.CASES
+
+
+@pytest.mark.parametrize("path,invs,consts", _pcal_cases(), ids=lambda v: v.stem if isinstance(v, Path) else None)
+def test_pluscal_translation_evaluated_vs_compiled_program(path, invs, consts, tmp_path):
+    """the product's translator writes the TLA+ translation of a PlusCal algorithm, the product's PlusCal compiler turns the same
+    algorithm into a bytecode program (the GPU path; here its host build): evaluating the TRANSLATION with the general evaluator
+    (through the test door — a module with an algorithm is never host-evaluated by the product) must give the compiled program's
+    state graph: counters, depth, per-level counts, the violated invariant and the counterexample's length.  (tests/test_pcal.py
+    makes the same comparison with the Python evaluator of the oracle, state sets included.)"""
+    text = path.read_text()
+    prog = helpers.ShimProgram(text, invs, consts)
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+        (tmp_path / f"{path.stem}.tla").write_text(prog.translated())
+
+        def lit(v):
+            if isinstance(v, (list, tuple, set, frozenset)):
+                return "{" + ", ".join(lit(x) for x in v) + "}"
+            return f'"{v}"' if isinstance(v, str) and not v.isidentifier() else str(v)
+        cfg = "SPECIFICATION Spec\n" + "".join(f"CONSTANT {k} = {lit(v)}\n" for k, v in consts.items()) + "".join(f"INVARIANT {i}\n" for i in invs)
+        if "CONSTANT defaultInitValue" in prog.translated():   # `variable tmp;` (p-manual section 3.1): a model value
+            cfg += "CONSTANT defaultInitValue = defaultInitValue\n"
+        (tmp_path / "m.cfg").write_text(cfg)
+        e = helpers.tlaeval_run(tmp_path / f"{path.stem}.tla", tmp_path / "m.cfg")
+        assert e["rc"] == 0, e
+        verdicts = {"ok": V_OK, "invariant": V_INVARIANT, "assert": V_ASSERT, "deadlock": V_DEADLOCK, "spec-error": V_SPECERR}
+        assert e["verdict"] == verdicts[r["verdict"]], (e, r["verdict"])
+        # an error ends the search when the level it was found on has been expanded, in both engines: every counter is comparable
+        assert (e["distinct"], e["generated"], e["depth"], e["levels"], e["queue_left"]) == (r["distinct"], r["generated"], r["depth"], r["levels"], r["queue_left"])
+        assert e["trace_len"] == r["trace_len"]
+        if r["verdict"] == "invariant":
+            assert e["violated_invariant"] == r["violated_invariant"]
+    finally:
+        prog.close()

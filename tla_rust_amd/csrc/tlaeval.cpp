@@ -1674,11 +1674,27 @@ struct Spec {
         }
         return -1;
     }
+    // One branch of a disjunction / of \E: while the successors of a state are generated (branch_errors), an evaluation error or a
+    // failed Assert inside one branch — one action instance — does not lose the successors of the other branches: the first error
+    // is kept and reported for the state (the GPU engine evaluates a state's action slots independently in the same way).
+    bool branch_errors = false;
+    uint64_t failed_branches = 0;
+    std::unique_ptr<TlaError> first_error;
+    void act_branch(const Node *n, Env *env, const State *st, State &nx, const Cont &k) {
+        if (!branch_errors) { act(n, env, st, nx, k); return; }
+        const State saved = nx;
+        try { act(n, env, st, nx, k); }
+        catch (TlaError &e) {
+            nx = saved;  // (assignments of the abandoned branch)
+            failed_branches++;  // an enabled action instance whose evaluation failed: counted as generated, like the engine does
+            if (!first_error) first_error.reset(new TlaError(e));
+        }
+    }
     void act(const Node *n, Env *env, const State *st, State &nx, const Cont &k) {
         switch (n->k) {
             case N_PAREN: act(n->kids[0].get(), env, st, nx, k); return;
             case N_CONJ: act_conj(n, 0, env, st, nx, k); return;
-            case N_DISJ: for (auto &x : n->kids) act(x.get(), env, st, nx, k); return;
+            case N_DISJ: for (auto &x : n->kids) act_branch(x.get(), env, st, nx, k); return;
             case N_IF: act(n->kids[as_bool(ev(n->kids[0].get(), env, st, &nx), "IF condition is") ? 1 : 2].get(), env, st, nx, k); return;
             case N_CASE: {
                 const size_t arms = (n->kids.size() - (size_t)n->num) / 2;
@@ -1689,7 +1705,7 @@ struct Spec {
             }
             case N_QUANT:
                 if (n->s != "E") { act_test(n, env, st, nx, k); return; }
-                for_bounds(n->bounds, env, st, &nx, [&](Env *e2, const std::vector<V> &) { act(n->kids[0].get(), e2, st, nx, k); return true; });
+                for_bounds(n->bounds, env, st, &nx, [&](Env *e2, const std::vector<V> &) { act_branch(n->kids[0].get(), e2, st, nx, k); return true; });
                 return;
             case N_LET: act(n->kids[0].get(), bind_let(n, env, st), st, nx, k); return;
             case N_UNCHANGED: {
@@ -2067,12 +2083,23 @@ struct Checker {
                 try {
                     std::vector<State> succ;
                     State nx(nv);
-                    sp.act(next_node.get(), nullptr, &st, nx, [&]() {
-                        const std::string m = missing(nx);
-                        if (!m.empty()) fail("a successor leaves " + m + " unassigned");
-                        succ.push_back(nx);
-                    });
+                    sp.branch_errors = true;
+                    sp.first_error.reset();
+                    sp.failed_branches = 0;
+                    try {
+                        sp.act(next_node.get(), nullptr, &st, nx, [&]() {
+                            const std::string m = missing(nx);
+                            if (!m.empty()) fail("a successor leaves " + m + " unassigned");
+                            succ.push_back(nx);
+                        });
+                    } catch (TlaError &e) { if (!sp.first_error) sp.first_error.reset(new TlaError(e)); }
+                    sp.branch_errors = false;
                     arena_reset();
+                    generated += sp.failed_branches;
+                    if (sp.first_error) {
+                        note(sp.first_error->is_assert ? MC_V_ASSERT : MC_V_SPECERR, -1, "", si, nullptr);
+                        if (err_msg.empty()) err_msg = sp.first_error->msg;
+                    }
                     for (auto &s2 : succ) {
                         nsucc++;
                         generated++;
@@ -2090,14 +2117,17 @@ struct Checker {
                         }
                         arena_reset();
                     }
-                } catch (TlaError &e) {
+                } catch (TlaError &e) {  // (an error while a successor is checked: invariants, constraints, properties)
+                    sp.branch_errors = false;
                     arena_reset();
                     note(e.is_assert ? MC_V_ASSERT : MC_V_SPECERR, -1, "", si, nullptr);
-                    err_msg = e.msg;
+                    if (err_msg.empty()) err_msg = e.msg;
                 }
-                if (!nsucc && opt.check_deadlock && verdict == MC_V_OK) note(MC_V_DEADLOCK, -1, "", si, nullptr);
+                if (!nsucc && opt.check_deadlock && !sp.first_error) note(MC_V_DEADLOCK, -1, "", si, nullptr);
                 done++;
-                if (verdict != MC_V_OK) break;
+                // (an error does not stop the level: like the GPU engine — and like the TLC run of README.md:319-321 — the search ends
+                //  when the level the first error was found on has been expanded: counters, queue and depth do not depend on the order
+                //  the states of a level are expanded in)
                 if (opt.progress_seconds > 0) {
                     const auto now = std::chrono::steady_clock::now();
                     if (std::chrono::duration<double>(now - last_report).count() >= opt.progress_seconds) {
@@ -2108,7 +2138,6 @@ struct Checker {
                     }
                 }
             }
-            if (verdict != MC_V_OK) { frontier = fresh; break; }
             frontier = fresh;
             if (!fresh.empty()) { R.levels.push_back(fresh.size()); depth++; }
         }
