@@ -105,7 +105,11 @@ struct VLess { bool operator()(const V &a, const V &b) const { return cmp(a, b) 
 
 V g_true, g_false, g_empty_tuple, g_empty_set;
 V mk_bool(bool b) { return b ? g_true : g_false; }
-V mk_int(long i) { auto v = std::make_shared<Val>(); v->k = K_INT; v->i = i; return v; }
+V g_small_ints[1 + 16 + 1024];  // -16 .. 1023: most integers a specification computes are counters and indices
+V mk_int(long i) {
+    if (i >= -16 && i < 1024 && g_small_ints[i + 16]) return g_small_ints[i + 16];
+    auto v = std::make_shared<Val>(); v->k = K_INT; v->i = i; return v;
+}
 V mk_str(const std::string &s) { auto v = std::make_shared<Val>(); v->k = K_STR; v->s = s; return v; }
 V mk_tuple(std::vector<V> items) { if (items.empty()) return g_empty_tuple; auto v = std::make_shared<Val>(); v->k = K_TUPLE; v->items = std::move(items); return v; }
 V normal_set(const V &s);
@@ -378,6 +382,7 @@ struct Node {
     mutable int sym = -1, opc = -1, uv_state = 0;
     mutable V lit;
     mutable std::vector<int> uvars, psyms;
+    mutable std::vector<V> keys;   // N_RECORD: the field names as values
     mutable std::shared_ptr<PInfo> pinfo;
 };
 NodeP node(NK k, int line = 0) { auto n = std::make_shared<Node>(); n->k = k; n->line = line; return n; }
@@ -875,22 +880,37 @@ typedef std::vector<V> State;  // one value per VARIABLE, in declaration order; 
 
 // Environment entries, thunks and operator values live until the current source state has been expanded (they refer to each
 // other cyclically: a LET definition sees itself and its siblings); values (V) are the only things that outlive the arena.
-struct Obj { virtual ~Obj() {} };
-std::vector<Obj *> g_arena;
-template <class T> T *anew() { T *p = new T(); g_arena.push_back(p); return p; }
-void arena_reset() { for (Obj *p : g_arena) delete p; g_arena.clear(); }
-
+// (pooled: an expansion creates tens of millions of environment entries; they are constructed in place in blocks that are
+//  reused from one source state to the next)
+template <class T>
+struct Pool {
+    static constexpr size_t B = 4096;
+    std::vector<T *> blocks;
+    size_t used = 0;
+    T *get() {
+        if (used == blocks.size() * B) blocks.push_back(static_cast<T *>(malloc(sizeof(T) * B)));
+        T *p = &blocks[used / B][used % B];
+        used++;
+        return new (p) T();
+    }
+    void reset() { for (size_t i = 0; i < used; i++) blocks[i / B][i % B].~T(); used = 0; }
+    ~Pool() { reset(); for (T *b : blocks) free(b); }
+};
+template <class T> Pool<T> &pool() { static Pool<T> p; return p; }
+template <class T> T *anew() { return pool<T>().get(); }
+void arena_reset();
 struct Thunk;
 struct OpVal;
 struct RecFn;
-struct Env : Obj { int sym = -1; V val; Thunk *th = nullptr; OpVal *op = nullptr; RecFn *rec = nullptr; Env *next = nullptr; };
+struct Env { int sym = -1; V val; Thunk *th = nullptr; OpVal *op = nullptr; RecFn *rec = nullptr; Env *next = nullptr; };
 // a lazily evaluated operator argument / LET definition without parameters: memoised unless it looks at primed variables
-struct Thunk : Obj { const Node *n = nullptr; Env *env = nullptr; const State *st = nullptr; bool memo = true, done = false, is_def = false; V val; };
+struct Thunk { const Node *n = nullptr; Env *env = nullptr; const State *st = nullptr; bool memo = true, done = false, is_def = false; V val; };
 // an operator as a value: LAMBDA, an operator passed by name, a LET operator with parameters
-struct OpVal : Obj { std::vector<int> params; const Node *body = nullptr; Env *env = nullptr; bool primed = false, is_let = false; int builtin = -1; std::string name; };
+struct OpVal { std::vector<int> params; const Node *body = nullptr; Env *env = nullptr; bool primed = false, is_let = false; int builtin = -1; std::string name; };
 
 // f[x \in S] == e with f inside e (WriteThroughCache.tla:55-60): while the function is being built, f[a] evaluates e for x = a
-struct RecFn : Obj { const Node *n = nullptr; Env *env = nullptr; const State *st = nullptr; V dom; std::vector<std::pair<V, V>> cache; };
+struct RecFn { const Node *n = nullptr; Env *env = nullptr; const State *st = nullptr; V dom; std::vector<std::pair<V, V>> cache; };
+void arena_reset() { pool<Env>().reset(); pool<Thunk>().reset(); pool<OpVal>().reset(); pool<RecFn>().reset(); }
 inline Env *env_find(Env *e, int sym) { for (; e; e = e->next) if (e->sym == sym) return e; return nullptr; }
 inline Env *bind_val(int sym, const V &v, Env *next) { Env *e = anew<Env>(); e->sym = sym; e->val = v; e->next = next; return e; }
 inline bool entry_primed(const Env *e);
@@ -1579,7 +1599,12 @@ struct Spec {
                 });
                 return mk_fn(std::move(kv));
             }
-            case N_RECORD: { std::vector<std::pair<V, V>> kv; for (auto &f : n->fields) kv.emplace_back(mk_str(f.first), ev(f.second.get(), env, st, nx)); auto r = mk_fn(kv); return r; }
+            case N_RECORD: {
+                if (n->keys.size() != n->fields.size()) { n->keys.clear(); for (auto &f : n->fields) n->keys.push_back(mk_str(f.first)); }
+                std::vector<std::pair<V, V>> kv;
+                for (size_t i = 0; i < n->fields.size(); i++) kv.emplace_back(n->keys[i], ev(n->fields[i].second.get(), env, st, nx));
+                return mk_fn(std::move(kv));
+            }
             case N_RECORDSET: { auto r = std::make_shared<Val>(); r->k = K_LAZY; r->i = L_RECSET; for (auto &f : n->fields) r->fields.emplace_back(f.first, ev(f.second.get(), env, st, nx)); return r; }
             case N_FNSET: { V a = ev(n->kids[0].get(), env, st, nx), b = ev(n->kids[1].get(), env, st, nx); return mk_lazy(L_FNSET, a, b); }
             case N_EXCEPT: {
@@ -2177,6 +2202,7 @@ void init_globals() {
     auto e = std::make_shared<Val>(); e->k = K_TUPLE; g_empty_tuple = e;
     auto s = std::make_shared<Val>(); s->k = K_SET; g_empty_set = s;
     g_mvs.clear();
+    for (long i = -16; i < 1024; i++) { auto v = std::make_shared<Val>(); v->k = K_INT; v->i = i; g_small_ints[i + 16] = v; }
 }
 
 struct Job { const std::string *tla, *cfg; const Options *opt; Result *out; std::string *error; int rc = 0; };
