@@ -401,3 +401,28 @@ def test_pluscal_translation_evaluated_vs_compiled_program(path, invs, consts, t
             assert e["violated_invariant"] == r["violated_invariant"]
     finally:
         prog.close()
+
+
+def test_view_and_action_constraint(tmp_path):
+    """the rest of the cfg grammar (TLC/ConfigFileGrammar.tla:4-32): VIEW — two states with the same value of the view are the same
+    state; ACTION_CONSTRAINT — a transition that violates it is generated but its successor is not stored.  Hand-counted on a
+    counter with a phase bit: x in 0..3 wraps around, b flips on every step"""
+    mod = ("---- MODULE Vw ----\nEXTENDS Naturals\nVARIABLES x, b\nInit == x = 0 /\\ b = FALSE\n"
+           "Next == x' = (x + 1) % 4 /\\ b' = ~b\nOnlyX == x\nUp == x' > x\n====\n")
+    (tmp_path / "Vw.tla").write_text(mod)
+    cases = [("INIT Init\nNEXT Next\n", (4, 5, 4)),                          # (0,F) (1,T) (2,F) (3,T), then back to (0,F)
+             ("INIT Init\nNEXT Next\nVIEW OnlyX\n", (4, 5, 4)),              # the same four values of x
+             ("INIT Init\nNEXT Next\nACTION_CONSTRAINT Up\n", (4, 5, 4))]    # 3 -> 0 is generated and dropped (it was seen anyway)
+    for cfg, want in cases:
+        (tmp_path / "Vw.cfg").write_text(cfg)
+        r = helpers.tlaeval_run(tmp_path / "Vw.tla", tmp_path / "Vw.cfg", deadlock=False)
+        assert (r["rc"], r["distinct"], r["generated"], r["depth"]) == (0,) + want, (cfg, r)
+    # a model where the two matter: b flips only when x = 0, so x alone does not determine the state ...
+    mod2 = mod.replace("b' = ~b", "b' = IF x = 0 THEN ~b ELSE b").replace("MODULE Vw", "MODULE Vw2")
+    (tmp_path / "Vw2.tla").write_text(mod2)
+    for cfg, want in [("INIT Init\nNEXT Next\n", (8, 9, 8)),                 # period 8: two rounds of x, one with each b
+                      ("INIT Init\nNEXT Next\nVIEW OnlyX\n", (4, 5, 4)),     # ... under the view the second round is old
+                      ("INIT Init\nNEXT Next\nACTION_CONSTRAINT Up\n", (4, 5, 4))]:  # the wrap-around (3,T) -> (0,T) is generated, never stored
+        (tmp_path / "Vw2.cfg").write_text(cfg)
+        r = helpers.tlaeval_run(tmp_path / "Vw2.tla", tmp_path / "Vw2.cfg", deadlock=False)
+        assert (r["rc"], r["distinct"], r["generated"], r["depth"]) == (0,) + want, (cfg, r)

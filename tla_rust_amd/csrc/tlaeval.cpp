@@ -1816,7 +1816,7 @@ struct Spec {
 // TLC configuration file (grammar: examples/SpecifyingSystems/TLC/ConfigFileGrammar.tla:4-32)
 struct Cfg {
     std::string spec, init, next, symmetry, view;
-    std::vector<std::string> invariants, constraints, properties;
+    std::vector<std::string> invariants, constraints, properties, action_constraints;
     std::vector<std::pair<std::string, V>> constants;
     std::vector<std::pair<std::string, std::string>> overrides;
     std::map<std::pair<std::string, std::string>, std::string> scoped;
@@ -1854,7 +1854,8 @@ Cfg parse_cfg(const std::string &text) {
             if (toks[i].k != Tok::ID) throw SyntaxErr{"cfg: " + kw + " needs a name at line " + std::to_string(toks[i].line)};
             (kw == "SPECIFICATION" ? out.spec : kw == "INIT" ? out.init : kw == "NEXT" ? out.next : kw == "SYMMETRY" ? out.symmetry : out.view) = toks[i++].s;
         } else if (kw.compare(0, 3, "INV") == 0 || kw.compare(0, 10, "CONSTRAINT") == 0 || kw.compare(0, 4, "PROP") == 0 || kw.compare(0, 6, "ACTION") == 0) {
-            auto &dst = kw.compare(0, 3, "INV") == 0 ? out.invariants : kw.compare(0, 10, "CONSTRAINT") == 0 ? out.constraints : out.properties;
+            auto &dst = kw.compare(0, 3, "INV") == 0 ? out.invariants : kw.compare(0, 10, "CONSTRAINT") == 0 ? out.constraints
+                      : kw.compare(0, 6, "ACTION") == 0 ? out.action_constraints : out.properties;
             while (toks[i].k != Tok::END && !is_kw(i)) dst.push_back(toks[i++].s);
         } else {
             while (toks[i].k != Tok::END && !is_kw(i)) {
@@ -1896,7 +1897,8 @@ struct Checker {
     Spec sp;
     Cfg cfg;
     NodeP init_node, next_node, init_act;
-    std::vector<std::pair<std::string, NodeP>> invs, cons;
+    std::vector<std::pair<std::string, NodeP>> invs, cons, acons;
+    NodeP view;  // VIEW: two states with the same value of this expression are the same state (p-manual section 4.5 / TLC's -view)
     struct Prop { std::string name; std::vector<NodeP> inits; std::vector<std::pair<NodeP, NodeP>> steps; };
     std::vector<Prop> props;
     std::vector<std::map<const Val *, V>> group;
@@ -1983,6 +1985,8 @@ struct Checker {
         init_act = sp.init_tree(init_node);
         for (auto &n : cfg.invariants) invs.emplace_back(n, node_id(n));
         for (auto &n : cfg.constraints) cons.emplace_back(n, node_id(n));
+        for (auto &n : cfg.action_constraints) acons.emplace_back(n, node_id(n));
+        if (!cfg.view.empty()) view = node_id(cfg.view);
         for (auto &n : cfg.properties) props.push_back(compile_property(n));
         if (!cfg.symmetry.empty()) symmetry_group(cfg.symmetry);
     }
@@ -2011,6 +2015,7 @@ struct Checker {
     }
     std::string key_of(const State &st) {  // SYMMETRY: the orbit's key is the least image of the state under the group
         std::string best;
+        if (view) { ser(sp.ev(view.get(), nullptr, &st, nullptr), best); return best; }
         if (!has_group) { for (auto &v : st) ser(v, best); return best; }
         V bestv;
         for (auto &g : group) {
@@ -2023,6 +2028,15 @@ struct Checker {
         return best;
     }
     bool in_model(const State &st) { for (auto &c : cons) { V v = sp.ev(c.second.get(), nullptr, &st, nullptr); if (!(v->k == K_BOOL && v->i)) return false; } return true; }
+    // ACTION_CONSTRAINT: a transition that does not satisfy it is generated, and its successor checked, but the successor is not stored
+    bool in_actions(const State &st, const State &s2) {
+        for (auto &c : acons) {
+            State nx = s2;
+            V v = sp.ev(c.second.get(), nullptr, &st, &nx);
+            if (!(v->k == K_BOOL && v->i)) return false;
+        }
+        return true;
+    }
     int violated(const State &st) { for (size_t k = 0; k < invs.size(); k++) { V v = sp.ev(invs[k].second.get(), nullptr, &st, nullptr); if (!(v->k == K_BOOL && v->i)) return (int)k; } return -1; }
     int property_violated_init(const State &st) {
         for (size_t k = 0; k < props.size(); k++)
@@ -2131,7 +2145,7 @@ struct Checker {
                         if (!props.empty()) { const int k = property_violated_step(st, s2); if (k >= 0) note(MC_V_INVARIANT, (int)invs.size() + k, props[(size_t)k].name, si, &s2); }
                         const std::string key = key_of(s2);
                         if (seen.count(key)) { arena_reset(); continue; }
-                        const bool inm = in_model(s2);
+                        const bool inm = in_model(s2) && in_actions(st, s2);
                         const int k = violated(s2);
                         if (k >= 0) note(MC_V_INVARIANT, k, invs[(size_t)k].first, si, &s2);
                         if (inm) {
