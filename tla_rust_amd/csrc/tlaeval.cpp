@@ -2244,13 +2244,18 @@ int check_files(const std::string &tla_path, const std::string &cfg_path, const 
     Job j{&tla_path, &cfg_path, &opt, &out, &error};
     if (getenv("TLAEVAL_INLINE")) { job_main(&j); return j.rc; }  // profiling: on the caller's own stack
     // a tree-walking evaluator recurses as deep as the specification nests: run on a thread with a large stack
-    pthread_attr_t attr;
-    pthread_attr_init(&attr);
-    pthread_attr_setstacksize(&attr, (size_t)1 << 30);
-    pthread_t th;
-    if (pthread_create(&th, &attr, job_main, &j)) { pthread_attr_destroy(&attr); error = "cannot start the evaluator thread"; return MC_EBADCFG; }
-    pthread_join(th, nullptr);
-    pthread_attr_destroy(&attr);
+    for (int shift = 30; shift >= 24; shift -= 2) {  // 1 GB of address space, less where the process may not reserve that much
+        pthread_attr_t attr;
+        pthread_attr_init(&attr);
+        pthread_attr_setstacksize(&attr, (size_t)1 << shift);
+        pthread_t th;
+        const int rc = pthread_create(&th, &attr, job_main, &j);
+        pthread_attr_destroy(&attr);
+        if (rc) continue;
+        pthread_join(th, nullptr);
+        return j.rc;
+    }
+    job_main(&j);  // no thread to be had: on the caller's stack
     return j.rc;
 }
 
