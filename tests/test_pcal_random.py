@@ -2,7 +2,8 @@
 variables / process locals, if / elsif / else with and without labels inside, either, with, while, await, goto,
 assert, skip, ||) are compiled to the bytecode program and run by the host build of the interpreter, and the
 TRANSLATION of the same algorithm is evaluated by oracle/tla_eval.py: counters, verdict and the per-level sets of
-states must be identical.  Two independent routes from one source text (compile vs translate + evaluate)."""
+states must be identical.  Two independent routes from one source text (compile vs translate + evaluate) — and a third: the
+translation evaluated by the product's own host evaluator (C++, tests/_tlaeval door), counters and verdict."""
 import os
 import random
 import sys
@@ -231,6 +232,15 @@ def test_random_algorithms_compiled_vs_evaluated(block):
                 assert r[k] == o[k], (seed, k, r[k], o[k], text)
             states = helpers.read_dump(dump)
             assert [states[l + 1] for l in range(len(states))] == o["states"], (seed, text)
+            # third route: the product's host evaluator (tla_rust_amd/csrc/tlaeval.cpp, through the test door) on the translation
+            with tempfile.TemporaryDirectory() as d:
+                (Path(d) / f"rnd{seed}.tla").write_text(prog.translated())
+                (Path(d) / "m.cfg").write_text("SPECIFICATION Spec\nINVARIANT Small\n")
+                e = helpers.tlaeval_run(Path(d) / f"rnd{seed}.tla", Path(d) / "m.cfg", deadlock=False)
+            assert e["rc"] == 0, (seed, e)
+            for k in ("distinct", "generated", "queue_left", "depth", "trace_len"):
+                assert r[k] == e[k], (seed, k, r[k], e[k], text)
+            assert e["verdict"] == {"ok": 0, "invariant": 1, "assert": 2, "deadlock": 3, "spec-error": 4}[r["verdict"]], (seed, e, r["verdict"])
             checked += 1
         finally:
             os.unlink(dump)
