@@ -34,6 +34,8 @@ extern "C" int tlaeval_door(const char *tla, const char *cfg, const char *search
             ", \"verdict\": " + std::to_string(r.verdict) + ", \"violated_invariant\": " + std::to_string(r.violated_invariant) + ", \"trace_len\": " + std::to_string(r.trace.size()) +
             ", \"queue_left\": " + std::to_string(r.queue_left) + ", \"seconds\": " + std::to_string(r.seconds) + ", \"levels\": [";
         for (size_t i = 0; i < r.levels.size(); i++) j += (i ? ", " : "") + std::to_string(r.levels[i]);
+        j += "], \"trace_labels\": [";
+        for (size_t i = 0; i < r.trace.size(); i++) j += std::string(i ? ", " : "") + "\"" + r.trace[i].first + "\"";
         j += "]}";
     }
     if (j.size() + 1 > cap) return -1;

@@ -167,6 +167,19 @@ def test_evaluator_on_the_pluscal_translation_gives_the_readme_run(tmp_path):
     assert (r["verdict"], r["trace_len"]) in ((V_INVARIANT, 6), (V_ASSERT, 6)), r
 
 
+def test_action_locations_of_the_readme_counterexample():
+    """README.md:271-306: TLC names the action of every step by the location of its formula; the evaluator takes Next apart the
+    same way (disjunctions, \\E and the definitions that are nothing else are looked through) and reports the span of the first
+    definition body that is something else"""
+    r = helpers.tlaeval_run(ROOT / "specs" / "readme_variant" / "pcal_intro.tla", ROOT / "specs" / "readme_variant" / "pcal_intro.cfg")
+    assert r["trace_labels"] == ["Initial predicate",
+                                 "Action line 35, col 19 to line 40, col 42 of module pcal_intro",    # README.md:278
+                                 "Action line 35, col 19 to line 40, col 42 of module pcal_intro",    # :285
+                                 "Action line 42, col 12 to line 45, col 63 of module pcal_intro",    # :292
+                                 "Action line 47, col 12 to line 50, col 65 of module pcal_intro",    # :299
+                                 "Action line 42, col 12 to line 45, col 63 of module pcal_intro"]    # :306
+
+
 def test_evaluator_equals_the_c_oracle_on_atomic_add(tmp_path):
     o = helpers.oracle_run("atomic_add", [3])
     (tmp_path / "n3.cfg").write_text("SPECIFICATION Spec\nCONSTANT N = 3\n")
@@ -350,7 +363,8 @@ def test_mc_exit_codes_and_traces_for_host_evaluated_modules(tmp_path):
     mc = ROOT / "tla_rust_amd" / "_build" / "mc"
     mod = ("---- MODULE Tiny ----\nEXTENDS Naturals, TLC\nVARIABLE x\nInit == x = 0\nNext == x < 3 /\\ x' = x + 1 /\\ %s\n"
            "Low == x < 2\n====\n")
-    cases = [("TRUE", "INVARIANT Low\n", [], 12, ["Error: Invariant Low is violated.", "State 3:", "/\\ x = 2"]),
+    cases = [("TRUE", "INVARIANT Low\n", [], 12, ["Error: Invariant Low is violated.", "State 1: <Initial predicate>",
+                                                  "State 3: <Action line 5, col 9 to line 5, col 35 of module Tiny>", "/\\ x = 2"]),
              ("TRUE", "", [], 11, ["Error: Deadlock reached.", "State 4:"]),
              ("TRUE", "", ["-deadlock"], 0, ["Model checking completed. No error has been found.", "4 distinct states found"]),
              ('Assert(x < 1, "too far")', "", ["-deadlock"], 12, ["The first argument of Assert evaluated to FALSE", "too far"])]

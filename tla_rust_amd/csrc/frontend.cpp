@@ -1144,7 +1144,10 @@ static int host_evaluate(const char *tla_path, const char *cfg_path, const mc_co
         else o.put("Error: evaluation error: %s\n", r.error_message.c_str());
         if (!r.trace.empty()) {
             o.put("Error: The behavior up to this point is:\n");
-            for (size_t k = 0; k < r.trace.size(); k++) o.put("State %zu:%s\n%s\n\n", k + 1, k ? "" : " <Initial predicate>", r.trace[k].second.c_str());
+            for (size_t k = 0; k < r.trace.size(); k++) {  // README.md:270-311
+                if (r.trace[k].first.empty()) o.put("State %zu:\n%s\n\n", k + 1, r.trace[k].second.c_str());
+                else o.put("State %zu: <%s>\n%s\n\n", k + 1, r.trace[k].first.c_str(), r.trace[k].second.c_str());
+            }
         }
     }
     o.put("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)r.generated, (unsigned long long)r.distinct,

@@ -366,7 +366,8 @@ struct Node;
 using NodeP = std::shared_ptr<Node>;
 struct PInfo;
 struct Bound { std::vector<std::string> names; bool is_tuple = false; NodeP dom; mutable std::vector<int> syms; };
-struct Def { std::string name; std::vector<std::pair<std::string, int>> params; NodeP body; int line = 0; mutable std::vector<int> psyms; mutable int sym = -1; };
+struct Def { std::string name; std::vector<std::pair<std::string, int>> params; NodeP body; int line = 0; mutable std::vector<int> psyms; mutable int sym = -1;
+             int l1 = 0, c1 = 0, l2 = 0, c2 = 0; };  // the body's first and last character (what TLC prints as the location of an action)
 struct Node {
     NK k;
     std::string s;            // identifier / operator / keyword
@@ -505,7 +506,7 @@ struct Parser {
             }
             expect(")");
             expect("==");
-            d.body = expr(0);
+            body_with_span(d);
         } else if (is_sym("[")) {  // f[x \in S] == e  is  f == [x \in S |-> e]
             i++;
             NodeP n = node(N_FNDEF, d.line);
@@ -532,9 +533,15 @@ struct Parser {
                     }
                 }
                 d.body = n;
-            } else d.body = expr(0);
+            } else body_with_span(d);
         }
         return d;
+    }
+    void body_with_span(Def &d) {
+        const size_t first = i;
+        d.body = expr(0);
+        const Tok &a = t[first], &z = t[i - 1];
+        d.l1 = a.line; d.c1 = a.col; d.l2 = z.line; d.c2 = z.col + (int)z.s.size() - 1 + (z.k == Tok::STR ? 2 : 0);
     }
     NodeP prefix() {
         const Tok c = cur();
@@ -917,7 +924,7 @@ inline bool entry_primed(const Env *e);
 
 struct GDef {  // a module-level definition
     std::string name, module;
-    int sym = -1, line = 0;
+    int sym = -1, line = 0, l1 = 0, c1 = 0, l2 = 0, c2 = 0;
     std::vector<std::pair<int, int>> params;  // (symbol, arity)
     NodeP body;
     int primed = -1, is_const = -1;
@@ -1018,6 +1025,7 @@ struct Spec {
     GDef *add_def(const std::string &name, const Def &d, const NodeP &body, const std::string &module) {
         auto g = std::make_unique<GDef>();
         g->name = name; g->module = module; g->sym = intern(name); g->line = d.line; g->body = body;
+        g->l1 = d.l1; g->c1 = d.c1; g->l2 = d.l2; g->c2 = d.c2;
         for (auto &p : d.params) g->params.emplace_back(intern(p.first), p.second);
         GDef *r = g.get();
         def_store.push_back(std::move(g));
@@ -1662,10 +1670,21 @@ struct Spec {
         if (i + 1 == n->kids.size()) { act(n->kids[i].get(), env, st, nx, k); return; }
         act(n->kids[i].get(), env, st, nx, [&]() { act_conj(n, i + 1, env, st, nx, k); });
     }
+    // Which ACTION produced a successor, the way TLC names it in a counterexample (README.md:278 "<Action line 35, col 19 to line
+    // 40, col 42 of module pcal_intro>"): Next is taken apart through disjunctions, \E and the definitions that are nothing but
+    // those; the first definition whose body is something else is the action, and its body's span is its location.
+    const GDef *cur_action = nullptr;
     void act_global(GDef *d, const std::vector<NodeP> &args, Env *env, const State *st, State &nx, const Cont &k) {
         std::vector<int> ps;
         for (auto &p : d->params) ps.push_back(p.first);
-        act(d->body.get(), bind_args(ps, args, &d->params, env, st, nullptr, d->name), st, nx, k);
+        const Node *b = d->body.get();
+        while (b->k == N_PAREN) b = b->kids[0].get();
+        const bool transparent = b->k == N_DISJ || (b->k == N_QUANT && b->s == "E") || ((b->k == N_ID || b->k == N_CALL) && defs.count(resolve(nsym(b))));
+        const GDef *saved = cur_action;
+        if (!cur_action && !transparent) cur_action = d;
+        try { act(d->body.get(), bind_args(ps, args, &d->params, env, st, nullptr, d->name), st, nx, k); }
+        catch (...) { cur_action = saved; throw; }
+        cur_action = saved;
     }
     void act_call(const Node *n, const std::vector<NodeP> &args, Env *env, const State *st, State &nx, const Cont &k) {
         int name = nsym(n);
@@ -2061,16 +2080,21 @@ struct Checker {
         std::unordered_map<std::string, int64_t> seen;
         std::vector<State> states;      // every stored state, in discovery order
         std::vector<int64_t> parent;
+        std::vector<const GDef *> via;  // the action that produced it (null: an initial state)
         std::vector<int64_t> frontier;
         uint64_t generated = 0;
         int verdict = MC_V_OK, viol = -1;
         std::string viol_name, err_msg;
         std::vector<State> trace;
+        std::vector<const GDef *> trace_via;
+        const GDef *last_via = nullptr;  // the action that produced the successor being checked
         auto chain = [&](int64_t from, const State *last) {
             std::vector<State> t;
-            for (int64_t i = from; i >= 0; i = parent[(size_t)i]) t.push_back(states[(size_t)i]);
+            trace_via.clear();
+            for (int64_t i = from; i >= 0; i = parent[(size_t)i]) { t.push_back(states[(size_t)i]); trace_via.push_back(via[(size_t)i]); }
             std::reverse(t.begin(), t.end());
-            if (last) t.push_back(*last);
+            std::reverse(trace_via.begin(), trace_via.end());
+            if (last) { t.push_back(*last); trace_via.push_back(last_via); }
             return t;
         };
         auto note = [&](int kind, int inv, const std::string &name, int64_t from, const State *last) {
@@ -2103,6 +2127,7 @@ struct Checker {
                 frontier.push_back((int64_t)states.size());
                 states.push_back(st);
                 parent.push_back(-1);
+                via.push_back(nullptr);
                 arena_reset();
             }
         }
@@ -2121,8 +2146,10 @@ struct Checker {
                 uint64_t nsucc = 0;
                 try {
                     std::vector<State> succ;
+                    std::vector<const GDef *> succ_via;
                     State nx(nv);
                     sp.branch_errors = true;
+                    sp.cur_action = nullptr;
                     sp.first_error.reset();
                     sp.failed_branches = 0;
                     try {
@@ -2130,8 +2157,10 @@ struct Checker {
                             const std::string m = missing(nx);
                             if (!m.empty()) fail("a successor leaves " + m + " unassigned");
                             succ.push_back(nx);
+                            succ_via.push_back(sp.cur_action);
                         });
                     } catch (TlaError &e) { if (!sp.first_error) sp.first_error.reset(new TlaError(e)); }
+                    sp.cur_action = nullptr;
                     sp.branch_errors = false;
                     arena_reset();
                     generated += sp.failed_branches;
@@ -2139,7 +2168,9 @@ struct Checker {
                         note(sp.first_error->is_assert ? MC_V_ASSERT : MC_V_SPECERR, -1, "", si, nullptr);
                         if (err_msg.empty()) err_msg = sp.first_error->msg;
                     }
-                    for (auto &s2 : succ) {
+                    for (size_t q = 0; q < succ.size(); q++) {
+                        const State &s2 = succ[q];
+                        last_via = succ_via[q];
                         nsucc++;
                         generated++;
                         if (!props.empty()) { const int k = property_violated_step(st, s2); if (k >= 0) note(MC_V_INVARIANT, (int)invs.size() + k, props[(size_t)k].name, si, &s2); }
@@ -2153,6 +2184,7 @@ struct Checker {
                             fresh.push_back((int64_t)states.size());
                             states.push_back(s2);
                             parent.push_back(si);
+                            via.push_back(last_via);
                         }
                         arena_reset();
                     }
@@ -2205,7 +2237,14 @@ struct Checker {
         R.violated_name = viol_name;
         R.error_message = err_msg;
         R.queue_left = verdict != MC_V_OK ? frontier.size() : 0;
-        for (size_t i = 0; i < trace.size(); i++) R.trace.emplace_back(i ? "" : "Initial predicate", sp.state_text(trace[i]));
+        for (size_t i = 0; i < trace.size(); i++) {
+            const GDef *a = i < trace_via.size() ? trace_via[i] : nullptr;
+            std::string label = i ? "" : "Initial predicate";
+            if (a && a->l1) label = "Action line " + std::to_string(a->l1) + ", col " + std::to_string(a->c1) + " to line " + std::to_string(a->l2) + ", col " +
+                                    std::to_string(a->c2) + " of module " + a->module;
+            else if (a) label = "Action " + a->name + " of module " + a->module;
+            R.trace.emplace_back(label, sp.state_text(trace[i]));
+        }
         R.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 };
