@@ -57,41 +57,80 @@ XGMI_PEAK_GBS = 7 * 153.0  # MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per G
 
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the environment
-    torch.distributed.run would give them), wait, and take the first failing rank's siblings down with it."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    torch.distributed.run would give them), wait, and take the first failing rank's siblings down with it.
+    No rendezvous port: the 128 bytes of the RCCL communicator id travel through a file in a directory only this job knows
+    ($TLAMC_BENCH_IDDIR, as `mc -gpus` does, mc_main.cpp) — round 3 picked a "free" port by bind(0) + close and rank 0 bound it
+    seconds later, after `import torch`: anything could take it in between (EADDRINUSE on the driver's box)."""
+    import shutil
+    import tempfile
+    iddir = tempfile.mkdtemp(prefix="tlamc_bench_")
     procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
-    worst = 0
-    left = set(range(a.gpus))
-    while left:
-        for r in list(left):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            left.discard(r)
-            if rc != 0:
-                worst = worst or rc
-                for q in left:   # nobody is left waiting in a collective for a rank that died
-                    procs[q].terminate()
-        time.sleep(0.05)
-    return worst
+    try:
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), TLAMC_BENCH_IDDIR=iddir,
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            env.pop("MASTER_PORT", None)   # (nothing listens anywhere)
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+        worst = 0
+        left = set(range(a.gpus))
+        while left:
+            for r in list(left):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                left.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in left:   # nobody is left waiting in a collective for a rank that died
+                        procs[q].terminate()
+            time.sleep(0.05)
+        return worst
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(iddir, ignore_errors=True)
 
 
 def comm_id(rank, world):
-    """The 128 bytes of the RCCL communicator id travel from rank 0 to the others through the launcher's TCP store
-    (torch.distributed.run hosts one at MASTER_ADDR:MASTER_PORT; for ranks spawned by bench.py itself rank 0 hosts it)."""
+    """The 128 bytes of the RCCL communicator id travel from rank 0 to the others
+    * through a file when bench.py spawned the ranks itself ($TLAMC_BENCH_IDDIR: written under a temporary name and renamed,
+      so a reader sees all of it or nothing; no socket, nothing to collide with);
+    * through the launcher's TCP store under torch.distributed.run (the agent hosts it at MASTER_ADDR:MASTER_PORT and is
+      listening before any rank starts);
+    * ranks started by hand (RANK / WORLD_SIZE / MASTER_PORT set, no agent): rank 0 hosts the store and retries while the
+      port is still held by something else."""
+    from tla_rust_amd.binding import Comm
+    iddir = os.environ.get("TLAMC_BENCH_IDDIR")
+    if iddir:
+        f = Path(iddir) / "comm_id"
+        if rank == 0:
+            uid = bytes(Comm.unique_id())
+            tmp = Path(iddir) / "comm_id.tmp"
+            tmp.write_bytes(uid)
+            os.replace(tmp, f)
+            return uid, None
+        deadline = time.monotonic() + 300
+        while not f.exists():
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rank {rank}: no communicator id in {f} after 300 s (did rank 0 start?)")
+            time.sleep(0.02)
+        return f.read_bytes(), None
     import datetime
     import torch.distributed as dist
-    from tla_rust_amd.binding import Comm
     agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
-    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world_size=None if agent else world,
-                          is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+    store, err = None, None
+    for attempt in range(60):
+        try:
+            store = dist.TCPStore(addr, port, world_size=None if agent else world, is_master=(rank == 0 and not agent),
+                                  timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+            break
+        except (RuntimeError, OSError) as e:   # DistNetworkError (EADDRINUSE on the master, refused on a client): try again
+            err = e
+            time.sleep(0.5)
+    if store is None:
+        raise err
     key = "tlamc/bench/comm_id"
     if rank == 0:
         uid = Comm.unique_id()
@@ -205,6 +244,8 @@ def main():
     ap.add_argument("--dense-table", action="store_true", help="A/B: 64-byte (8-slot) seen-set buckets even when the table is sparse enough for 32-byte probes")
     ap.add_argument("--occ3", action="store_true", help="A/B: by-family expand kernel compiled for 3 waves per SIMD (no register spills)")
     ap.add_argument("--no-filter", action="store_true", help="A/B: without the per-wavefront duplicate filter in front of the seen-set")
+    ap.add_argument("--no-inwave", action="store_true", help="A/B: every new state through the new-list and k_materialise (rounds 1-3) instead of "
+                    "being written by the expand wavefront that found it")
     a = ap.parse_args()
     global WORKLOAD
     if a.msg_keys:
@@ -236,7 +277,7 @@ def main():
     comm = store = None
     if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=slots, matrix=a.matrix,
-                         debug_flags=(32 if a.no_family else 0) | (2048 if a.occ3 else 0) | (8192 if a.no_filter else 0),
+                         debug_flags=(32 if a.no_family else 0) | (2048 if a.occ3 else 0) | (8192 if a.no_filter else 0) | (65536 if a.no_inwave else 0),
                          arena_capacity=G0["distinct"] + (1 << 20),
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run
@@ -321,10 +362,8 @@ def main():
         W = ks["state_bytes"]
         # algorithmic bytes per launch: expand reads W per frontier state,
         # insert touches one 8-byte seen-set word per generated candidate, materialise writes W per new state
-        direct = False
-        alg = {"expand": W * ks["expand"]["units"], "insert": 8 * ks["cand_cells"], "materialise": W * ks["materialise"]["units"]}
-        if direct:  # reads W per expanded state, touches 8 B of the seen-set per in-model successor, writes W per new state
-            alg["expand"] = W * ks["expand"]["units"] + 8 * ks["cand_cells"] + W * D
+        inwave = ks.get("inwave_states", 0)   # states the expand wavefronts wrote themselves (round 4): their W bytes are that kernel's
+        alg = {"expand": W * ks["expand"]["units"] + W * inwave, "insert": 8 * ks["cand_cells"], "materialise": W * (ks["materialise"]["units"] - inwave)}
         state_only = alg["expand"]
         if not a.matrix:  # the seen-set insert is FUSED into the expand kernel: its 8 bytes per look-up (SURVEY 8d's G x 8 term, counted
             alg["expand"] += 8 * ks["cand_cells"]   # on the in-model, state-changing successors: the ones that ARE looked up) are that kernel's
@@ -339,7 +378,7 @@ def main():
                 stamp = d.get("__source__", {}).get("hash")
                 if stamp != kernel_source_hash():   # counters of other kernels say nothing about the ones timed here
                     raise ValueError(f"{pmc[-1].name} was collected on kernel sources {stamp}, the timed ones are {kernel_source_hash()}")
-                knames = {"expand": ("k_expand_direct",) if direct else ("k_expand_insert",) if a.no_family else ("k_expand_family", "k_expand_insert"),
+                knames = {"expand": ("k_expand_insert",) if a.no_family else ("k_expand_family", "k_expand_insert"),
                           "insert": ("k_insert",), "materialise": ("k_materialise",)}[dom]
                 k = next(v for kn in knames for n, v in d.items() if n.startswith(kn + "<") and "Raft<3>" in n)
                 # FETCH_SIZE / WRITE_SIZE are in KB.  Calibration on this box (profiles/r02e_calib_*.json*, profiles/calib/calib_fetch.hip):
@@ -354,14 +393,15 @@ def main():
             except Exception as e:  # noqa: BLE001
                 traffic, traffic_lower, l2_hit = None, None, None
                 traffic_src = f"none: {e}"
-        kernel_name = {"expand": "k_expand_direct<SpecRaft<3>>" if direct else "k_expand_insert<SpecRaft<3>>" if (a.no_family or a.matrix) else "k_expand_family<SpecRaft<3>>",
+        kernel_name = {"expand": "k_expand_insert<SpecRaft<3>>" if (a.no_family or a.matrix) else "k_expand_family<SpecRaft<3>>",
                        "insert": "k_insert", "materialise": "k_materialise<SpecRaft<3>>"}[dom]
         line["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_lower": traffic_lower, "l2_hit_rate": l2_hit, "traffic_source": traffic_src,
                             "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
                             "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
                             "seen_set_lookups": ks["cand_cells"],
-                            "alg_bytes": ("W x states expanded + 8 x seen-set look-ups (in-model, state-changing successors; the insert is fused into this kernel)" if dom == "expand" and not a.matrix
+                            "inwave_states": inwave,
+                            "alg_bytes": ("W x states expanded + W x states written in-wave + 8 x seen-set look-ups (in-model, state-changing successors; insert and write are fused into this kernel)" if dom == "expand" and not a.matrix
                                           else "W x units"),
                             "frac_state_bytes_only": (state_only / (ks[dom]["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == "expand" and ks[dom]["ms_total"] else None,
                             # the practical ceiling SURVEY 8d asks for: a probe moves a whole bucket (32 bytes in a sparse table, 64 in a full one)

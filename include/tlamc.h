@@ -84,6 +84,8 @@ typedef struct {
 #define MC_F_NOPROBE 16u /* profiling only (mc_engine_debug_reexpand): skip the seen-set probes   */
 #define MC_F_NOFAMILY 32u /* A/B only: expand raft slot by slot instead of by action family        */
 #define MC_F_OCC3 2048u      /* A/B only: the by-family expand kernel compiled for 3 wavefronts per SIMD (146 VGPRs, no spills) instead of 4 */
+#define MC_F_NOINWAVE 65536u /* A/B only: every new state through the new-list and k_materialise (rounds 1-3) instead of being written by
+                                the expand wavefront that found it (round 4; by-family kernels of a fused run) */
 #define MC_F_NOFILTER 8192u  /* A/B only: by-family expand kernel without the per-wavefront duplicate filter in front of the seen-set */
 #define MC_F_PROGRESS 16384u /* mc_check_files: print TLC's "Progress(d): ..." lines (testout2:4-259) to stdout while the search runs,
                               * at most one per second */
@@ -133,6 +135,7 @@ typedef struct {
     mc_kernel_stat expand, insert, materialise;
     uint64_t state_bytes;     /* W: packed bytes per state in HBM                               */
     uint64_t cand_cells;      /* candidate-matrix cells probed                                  */
+    uint64_t inwave_states;   /* states the expand wavefronts wrote themselves (the others went through k_materialise) */
 } mc_kernel_stats;
 
 typedef struct mc_engine mc_engine;

@@ -44,7 +44,7 @@ class KernelStat(C.Structure):
 
 class KernelStats(C.Structure):
     _fields_ = [("expand", KernelStat), ("insert", KernelStat), ("materialise", KernelStat),
-                ("state_bytes", C.c_uint64), ("cand_cells", C.c_uint64)]
+                ("state_bytes", C.c_uint64), ("cand_cells", C.c_uint64), ("inwave_states", C.c_uint64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64)
@@ -319,7 +319,7 @@ class Engine:
         _check(lib().mc_engine_kernel_stats(self._h, C.byref(ks)), "mc_engine_kernel_stats")
         f = lambda s: dict(launches=s.launches, ms_total=s.ms_total, units=s.units)
         return dict(expand=f(ks.expand), insert=f(ks.insert), materialise=f(ks.materialise),
-                    state_bytes=ks.state_bytes, cand_cells=ks.cand_cells)
+                    state_bytes=ks.state_bytes, cand_cells=ks.cand_cells, inwave_states=ks.inwave_states)
 
     # ---- sharded step API (mc_shard_*): raw device pointers in, counts out
     def shard_begin(self):

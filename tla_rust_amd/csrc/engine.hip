@@ -65,10 +65,18 @@ struct DevCounters {
                                       // materialise(chunk c) overlaps expand(chunk c+1) on a second stream
     PaddedCounter generated[NSHARD];  // successors generated
     PaddedCounter cells[NSHARD];      // seen-set probes issued
-    unsigned long long arena_next;    // next free arena index
+    // next free arena index, on a line of its own.  Round 4: in a fused run (atomic_alloc != 0) it is bumped by the writers
+    // themselves — the expand wavefront that appends its own survivors (one atomicAdd per wavefront, at its tail) and the
+    // wavefronts of k_materialise (the overflow path) — so a new state's final index is known the moment it is written.
+    // The sharded step calls keep the serialised form (atomic_alloc == 0: an appender reads arena_next, k_commit /
+    // k_bump_arena_next add its count behind it; the appenders are chained by events, see append_begin).
+    alignas(128) unsigned long long arena_next;
+    unsigned long long pad_an[15];
     unsigned long long viol_key;      // min over (idx << 24 | slot << 8 | kind); ~0 = none
+    unsigned long long via_list;      // fused runs: states that went through the new-list + k_materialise (the rest were written in-wave)
     unsigned int max_slots;           // rows of the candidate matrix written by the current chunk
     unsigned int error;               // DEV_E* bits
+    unsigned int atomic_alloc;        // see arena_next
 };
 enum : unsigned { DEV_ETABLE = 1u, DEV_EARENA = 2u, DEV_EOVERFLOW = 4u, DEV_EROUTE = 8u /* an exchange bucket of a sharded round is full */ };
 enum : unsigned { VK_INVARIANT = 1, VK_ASSERT = 2, VK_DEADLOCK = 3, VK_SPECERR = 4 };
@@ -373,6 +381,12 @@ struct RouteArgs {
     uint64_t *new_fp = nullptr;    // non-null: fingerprints of the new-list entries (same segments, same positions)
     unsigned my_rank = 0;          // route mode: this rank (candidates it owns are probed locally)
     uint16_t *succ = nullptr;      // slot-sliced launch (gridDim.y > 1) with deadlock checking: one "has a successor" flag per column
+    // IN-WAVE WRITES (round 4, fused runs of the by-family kernel): non-null = the expand wavefront appends its own survivors to
+    // the arena at its tail (it still has the parent block in its caches; k_materialise's second read of every parent row is gone)
+    uint64_t *arena_w = nullptr;
+    uint64_t arena_cap = 0;
+    uint32_t *parent = nullptr;    // MC_F_TRACE: parent pointers of the states written in-wave
+    uint16_t *pslot = nullptr;
 };
 
 template <class S, bool ROUTE>
@@ -621,6 +635,50 @@ struct InlineMsgs : std::false_type {};
 template <class S>
 struct InlineMsgs<S, decltype((void)&S::inflight_slots)> : std::true_type {};
 
+// specs whose expand kernel hands the successor's fingerprint to the writer (S::apply_known_fp)
+template <class S, class = void>
+struct HasKnownFp : std::false_type {};
+template <class S>
+struct HasKnownFp<S, decltype((void)S::KNOWN_FP)> : std::true_type {};
+// The writer of the in-wave tail, a REAL function (not inlined): the copy-and-patch writer wants 160+ VGPRs on its own, and
+// inlined into k_expand_family it drags the register allocation of the whole kernel down with it (101 spilled VGPRs against 1).
+// Behind a call it is allocated by itself, and at the call site — the wavefront's tail — nothing is live that would have to be
+// saved.  Arguments of a device function travel in vector registers, so the wave-uniform ones are made scalar again here.
+template <class T>
+__device__ __forceinline__ T wave_uniform_copy(const T &v) {
+    static_assert(sizeof(T) % 4 == 0, "copied in 32-bit words");
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+}
+template <class S>
+__device__ __noinline__ void wave_write_survivors(typename S::Params prm_v, const uint64_t *blk_v, bool mine, unsigned e, uint64_t fp,
+                                                  uint64_t *arena_w_v, uint64_t oidx) {
+    const typename S::Params prm = wave_uniform_copy(prm_v);
+    const GlobalWords blk = uniform_ptr(blk_v);
+    uint64_t *arena_w = (uint64_t *)uniform_ptr(arena_w_v);
+    if (!mine) return;
+    const BlockRef sp{blk, e & 63u};
+    const int W = S::words(prm);
+    if constexpr (HasKnownFp<S>::value) S::apply_known_fp(prm, sp, (int)(e >> 6), fp, arena_ref(arena_w, oidx, W));
+    else S::apply(prm, sp, (int)(e >> 6), arena_ref(arena_w, oidx, W));
+}
+
+// Probe ring and survivor list of a by-family wavefront.  An entry names its (parent, slot) pair inside the wavefront's own
+// arena block: (slot << 6) | parent lane, 16 bits.  The survivor list holds up to OCAP entries: with in-wave writes the
+// survivors wait here until the wavefront's tail (one per parent on average; 64 are moved to the global new-list — the
+// overflow path, k_materialise — only when the list is about to fill up).
+constexpr int OCAP = 256;
+struct FamQueues {
+    uint64_t q_fp[QCAP];
+    uint64_t o_fp[OCAP];
+    uint16_t q_ent[QCAP], o_ent[OCAP];
+};
+
 template <class S, int NB>
 struct FamLds {
     uint16_t fq[S::NFAM][FQCAP];   // (slot << 8) | (block << 6) | parent lane
@@ -651,7 +709,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
                 RouteArgs rt, unsigned parity) {
     static_assert(NB >= 1 && NB <= 4, "the queue entry has two bits for the block");
-    __shared__ WaveQueues wq[4];
+    __shared__ FamQueues wq[4];
     __shared__ FamLds<S, NB> fls[4];
     if (rt.lc) {
         if (rt.lc->stop) return;
@@ -660,7 +718,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         ncols = ((hi - (lo & ~63ull)) + 63) & ~63ull;
     }
     const unsigned lane = threadIdx.x & 63;
-    WaveQueues &Q = wq[threadIdx.x >> 6];
+    FamQueues &Q = wq[threadIdx.x >> 6];
     FamLds<S, NB> &FL = fls[threadIdx.x >> 6];
     const uint64_t base = lo & ~63ull;
     // (An XCD-aware tile order — XCD k = workgroup id % 8 walks the k-th eighth of the chunk's tiles, so that neighbouring arena
@@ -690,6 +748,10 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     };
     const unsigned shard = blockIdx.x & (NSHARD - 1), pshard = parity * NSHARD + shard;
     uint32_t *__restrict__ seg = newlist + (uint64_t)pshard * seg_cap;
+    const bool inwave = !ROUTE && rt.arena_w != nullptr;  // wave-uniform (a kernel argument)
+    // survivors kept in LDS before a batch of 64 goes to the global new-list: all the list holds minus one probe batch (in-wave
+    // writes: the global list is the overflow path), or one batch (everything goes through the new-list)
+    const unsigned okeep = inwave ? (unsigned)(OCAP - 64) : 63u;
     MC_PROF_DECL
 
     auto flush_out = [&](unsigned take) {
@@ -698,21 +760,22 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         if (lane == 0) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)take);
         pos = __shfl(pos, 0);
         if (lane < take) {
-            seg[pos + lane] = Q.o_src[(ohead + lane) & (QCAP - 1)];
-            if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos + lane] = Q.o_fp[(ohead + lane) & (QCAP - 1)];
+            const unsigned e = Q.o_ent[(ohead + lane) & (OCAP - 1)];
+            seg[pos + lane] = (uint32_t)(wave_col0 + (e & 63u)) | ((uint32_t)(e >> 6) << 24);
+            if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos + lane] = Q.o_fp[(ohead + lane) & (OCAP - 1)];
         }
-        ohead = (ohead + take) & (QCAP - 1);
+        ohead = (ohead + take) & (OCAP - 1);
         on -= take;
         MC_PROF(3);
     };
     auto flush_probe = [&](unsigned take) {
         MC_PROF(3);
         bool is_new = false;
-        uint32_t src = 0;
+        unsigned src = 0;  // (slot << 6) | parent lane
         uint64_t qfp = 0;
         if (lane < take) {
             const unsigned k = (qhead + lane) & (QCAP - 1);
-            src = Q.q_src[k];
+            src = Q.q_ent[k];
             qfp = Q.q_fp[k];
             if constexpr (!ROUTE) is_new = (flags & 16u) ? false : seen_insert(table, mask, qfp, err);
         }
@@ -731,13 +794,13 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             {
                 const unsigned long long b = __ballot(is_new);
                 if (is_new) {
-                    const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
-                    Q.o_src[k] = src;
+                    const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                    Q.o_ent[k] = (uint16_t)src;
                     Q.o_fp[k] = qfp;
                 }
                 on += (unsigned)__popcll(b);
                 wave_lds_fence();
-                if (on >= 64) flush_out(64);
+                if (on > okeep) flush_out(64);
             }
             // one round trip for all remote owners: lane t reserves the bucket space of owner t (the P atomics issue together
             // instead of one after the other), then every candidate takes its owner's base from that lane
@@ -755,7 +818,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 const unsigned long long pos = base + my_rank;
                 if (pos < rt.subcap) {
                     rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
-                    rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = src;
+                    rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = (uint32_t)(wave_col0 + (src & 63u)) | ((uint32_t)(src >> 6) << 24);
                 } else {
                     err |= DEV_EARENA;
                 }
@@ -763,13 +826,13 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         } else {
             const unsigned long long b = __ballot(is_new);
             if (is_new) {
-                const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
-                Q.o_src[k] = src;
+                const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                Q.o_ent[k] = (uint16_t)src;
                 Q.o_fp[k] = qfp;
             }
             on += (unsigned)__popcll(b);
             wave_lds_fence();
-            if (on >= 64) flush_out(64);
+            if (on > okeep) flush_out(64);
         }
         MC_PROF(2);
     };
@@ -782,7 +845,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         return nc >= 64;
     };
     // a lane's candidate (fp != 0) joins the probe ring; 64 queued candidates are probed (or routed) at once
-    auto enqueue = [&](uint64_t fp, uint32_t src, int back_to) {
+    auto enqueue = [&](uint64_t fp, unsigned src /* (slot << 6) | parent lane */, int back_to) {
         MC_PROF(2);
         const unsigned long long b0 = __ballot(fp != 0);
         if (b0) {
@@ -799,7 +862,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             if (fp) {
                 const unsigned k = (qhead + qn + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
                 Q.q_fp[k] = fp;
-                Q.q_src[k] = src;
+                Q.q_ent[k] = (uint16_t)src;
             }
             qn += (unsigned)__popcll(b);
             wave_lds_fence();
@@ -815,7 +878,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         const unsigned h = fget(fheadA, fheadB, f);
         wave_lds_fence();  // queue entries written by fam_push are visible
         uint64_t fp = 0;
-        uint32_t src = 0;
+        unsigned src = 0;
         if (lane < take) {
             const unsigned e = FL.fq[f][(h + lane) & (FQCAP - 1)];
             const unsigned p = e & 255u;  // (block << 6) | lane of the parent
@@ -834,7 +897,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 else if (st & ST_SPECERR) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_SPECERR, 0));
                 else {
                     if (st & ST_INVARIANT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_INVARIANT, st >> 8));
-                    if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) { fp = fv; src = (uint32_t)(wave_col0 + p) | ((uint32_t)slot << 24); }
+                    if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) { fp = fv; src = ((unsigned)slot << 6) | (p & 63u); }
                 }
             }
         }
@@ -906,7 +969,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                                 if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = f2[h];
                             }
                         }
-                        enqueue(fp, (uint32_t)(wave_col0 + pl) | (slot << 24), 1);
+                        enqueue(fp, (slot << 6) | pl, 1);
                     }
                 }
                 S::fixed_clear_dense(gd);
@@ -949,7 +1012,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                                 if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = fv;
                             }
                         }
-                        enqueue(fp, (uint32_t)(wave_col0 + pl) | (slot << 24), 6);
+                        enqueue(fp, (slot << 6) | pl, 6);
                     }
                 };
                 while (__ballot(infl != 0)) {
@@ -980,7 +1043,33 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         run_full(fullmask, true, 7);
     }
     if (qn) flush_probe(qn);
-    if (on) flush_out(on);
+    if (inwave) {
+        // THE TAIL: this wavefront writes its own survivors.  Their final arena indices come from ONE atomicAdd; the parent of
+        // every survivor is in this wavefront's block (read a few microseconds ago: L2 / Infinity Cache, not HBM); lanes write
+        // consecutive arena indices, i.e. whole rows of the word-major blocks.  Nothing of the generation phase is live here,
+        // so the copy-and-patch writer has the whole register budget.
+        MC_PROF(4);
+        if (on) {
+            unsigned long long out0 = 0;
+            if (lane == 0) out0 = atomicAdd(&ctr->arena_next, (unsigned long long)on);
+            out0 = __shfl(out0, 0);
+            if (out0 + on > rt.arena_cap) {
+                err |= DEV_EARENA;
+            } else {
+                for (unsigned t = 0; t < on; t += 64) {
+                    const bool mine = t + lane < on;
+                    const unsigned k = (ohead + t + lane) & (OCAP - 1);
+                    const unsigned e = mine ? Q.o_ent[k] : 0u;
+                    const uint64_t sfp = mine ? Q.o_fp[k] : 0ull;
+                    const uint64_t oidx = out0 + t + lane;
+                    wave_write_survivors<S>(prm, (const uint64_t *)blk_base, mine, e, sfp, rt.arena_w, oidx);
+                    if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)(wave_idx0 + (e & 63u)); rt.pslot[oidx] = (uint16_t)(e >> 6); }
+                }
+            }
+        }
+    } else if (on) {
+        flush_out(on);
+    }
     MC_PROF(7);
 
     if (flags & MC_F_DEADLOCK) {
@@ -1051,10 +1140,6 @@ static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStr
 }
 
 // ------------------------------------------------------------------------------------- materialise
-template <class S, class = void>
-struct HasKnownFp : std::false_type {};
-template <class S>
-struct HasKnownFp<S, decltype((void)S::KNOWN_FP)> : std::true_type {};
 template <class S>
 __global__ void __launch_bounds__(256)
 k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, const uint32_t *__restrict__ newlist, uint64_t seg_cap,
@@ -1066,15 +1151,25 @@ k_materialise(typename S::Params prm, uint64_t *arena, uint64_t chunk_base, cons
     }
     const unsigned sh = blockIdx.y;  // new-list segment
     const uint64_t n = ctr->n_new[parity * NSHARD + sh].v;
-    uint64_t out0 = ctr->arena_next;
-    for (unsigned t = 0; t < sh; t++) out0 += ctr->n_new[parity * NSHARD + t].v;
+    const bool atomic_alloc = ctr->atomic_alloc != 0;  // fused runs: every writer takes its indices from arena_next itself
+    uint64_t out0 = 0;
+    if (!atomic_alloc) {
+        out0 = ctr->arena_next;
+        for (unsigned t = 0; t < sh; t++) out0 += ctr->n_new[parity * NSHARD + t].v;
+    }
     const uint32_t *__restrict__ seg = newlist + (uint64_t)(parity * NSHARD + sh) * seg_cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         const uint32_t src = seg[j];
         const uint64_t pidx = chunk_base + (src & 0xffffffu);
         const int slot = (int)(src >> 24);
-        const uint64_t oidx = out0 + j;
+        uint64_t oidx = out0 + j;
+        if (atomic_alloc) {  // (the lanes of a wavefront hold consecutive j: the active ones are a prefix)
+            const unsigned long long act = __ballot(true);
+            unsigned long long w0 = 0;
+            if ((threadIdx.x & 63u) == 0) w0 = atomicAdd(&ctr->arena_next, (unsigned long long)__popcll(act));
+            oidx = __shfl(w0, 0) + (threadIdx.x & 63u);
+        }
         if (oidx >= arena_cap) { atomicOr(&ctr->error, DEV_EARENA); continue; }
         if constexpr (HasKnownFp<S>::value) {  // the expand kernel hands the successor's fingerprint over: no second delta_fp
             if (newfp) S::apply_known_fp(prm, arena_cref(arena, pidx, S::words(prm)), slot, newfp[(uint64_t)(parity * NSHARD + sh) * seg_cap + j], arena_ref(arena, oidx, S::words(prm)));
@@ -1306,7 +1401,8 @@ static __global__ void k_bump_arena_next(DevCounters *ctr, const uint32_t *n_dev
 static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
     unsigned long long n = 0;
     for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[parity * NSHARD + t].v; ctr->n_new[parity * NSHARD + t].v = 0; }
-    ctr->arena_next += n;
+    if (ctr->atomic_alloc) ctr->via_list += n;  // (k_materialise took the indices itself)
+    else ctr->arena_next += n;
     ctr->max_slots = 0;
 }
 
@@ -1327,7 +1423,9 @@ k_take_owned(typename S::Params prm, uint64_t *arena, uint64_t lo, uint64_t hi, 
     for (int w = 0; w < W; w++) out.set(w, in.get(w));
     if (parent) { parent[dst] = (uint32_t)i; pslot[dst] = (uint16_t)SLOT_COPY; }
 }
+static __global__ void k_set_alloc_mode(DevCounters *ctr, unsigned atomic_alloc) { ctr->atomic_alloc = atomic_alloc; }
 static __global__ void k_after_prefix(DevCounters *ctr, unsigned long long dst0, int zero_counts) {
+    ctr->atomic_alloc = 0;  // the sharded rounds append in stream order (k_commit / k_bump_arena_next)
     ctr->arena_next = dst0 + ctr->n_new[0].v;
     ctr->n_new[0].v = 0;
     if (zero_counts) for (int t = 0; t < NSHARD; t++) { ctr->generated[t].v = 0; ctr->cells[t].v = 0; }
@@ -1362,7 +1460,8 @@ static __global__ void k_end_level(DevCounters *ctr, LevelCtl *lc) {
     {  // k_commit of new-list parity 0, folded in (one launch less per level)
         unsigned long long n = 0;
         for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; }
-        ctr->arena_next += n;
+        if (ctr->atomic_alloc) ctr->via_list += n;
+        else ctr->arena_next += n;
         ctr->max_slots = 0;
     }
     const unsigned long long hi_new = ctr->arena_next;
@@ -1614,6 +1713,16 @@ struct Engine : EngineBase {
     }
 
     bool use_matrix = false;
+    // fused runs of a by-family spec: the expand wavefronts write their own survivors (MC_F_NOINWAVE = A/B: everything through the
+    // new-list and k_materialise, as in rounds 1-3)
+    bool inwave_ok() const { return UsesFamilies<S>::value && !use_matrix && !(cfg.flags & (MC_F_NOFAMILY | MC_F_NOINWAVE)); }
+    void set_inwave(RouteArgs &rt) const {
+        if (!inwave_ok()) return;
+        rt.arena_w = d_arena;
+        rt.arena_cap = arena_cap;
+        rt.parent = d_parent;
+        rt.pslot = d_pslot;
+    }
     // materialise + commit of the chunk whose survivors are in new-list `parity`, on the second stream: it overlaps
     // the expansion of the next chunk (memory-bound next to latency-bound)
     void finish_materialise(uint64_t chunk_base, uint64_t ncols, unsigned parity) {
@@ -1639,6 +1748,7 @@ struct Engine : EngineBase {
         RouteArgs rt{};
         rt.lc = d_lc;
         rt.new_fp = d_newfp;
+        set_inwave(rt);
         const unsigned sg = slices_for(ncols, true);
         const bool dl = sg > 1 && (cfg.flags & MC_F_DEADLOCK);
         if (dl) { rt.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), stream); }
@@ -1721,6 +1831,9 @@ struct Engine : EngineBase {
                                d_inittmp, d_cand, ncols, d_nsl, d_ctr, 0u, 1u);  // run() is never owner-filtered
             finish_chunk<true>(first, ncols, 1);
         }
+        // from here on every writer takes its arena indices from arena_next itself (DevCounters::atomic_alloc); Init above and
+        // the candidate-matrix form append in stream order
+        if (!use_matrix) hipLaunchKernelGGL(k_set_alloc_mode, dim3(1), dim3(1), 0, stream, d_ctr, 1u);
         int rc = read_counters();
         if (rc) return rc;
         if ((rc = check_dev_error())) return rc;
@@ -1789,6 +1902,7 @@ struct Engine : EngineBase {
                     if (chunk_no >= 2) hipStreamWaitEvent(stream, ev_m[parity], 0);  // new-list `parity` is free again
                     RouteArgs rt_new{};
                     rt_new.new_fp = d_newfp;
+                    set_inwave(rt_new);
                     const unsigned sg = slices_for(ncols, false);
                     const bool dl = sg > 1 && (cfg.flags & MC_F_DEADLOCK);
                     if (dl) { rt_new.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), stream); }
@@ -1826,6 +1940,9 @@ struct Engine : EngineBase {
         kstat_cells = 0;
         for (int t = 0; t < NSHARD; t++) { out->generated += h_ctr->generated[t].v; kstat_cells += h_ctr->cells[t].v; }
         last_generated = out->generated;
+        // (a resumed run counts from the checkpoint on: via_list starts at 0 there)
+        kstat_inwave = inwave_ok() && h_ctr->arena_next >= h_ctr->via_list + (resuming ? ck_distinct : out->level_distinct[0])
+                           ? h_ctr->arena_next - h_ctr->via_list - (resuming ? ck_distinct : out->level_distinct[0]) : 0;
         have_run = true;
         out->queue_left = hi - lo;
         out->depth = level;
@@ -1850,7 +1967,7 @@ struct Engine : EngineBase {
         }
         return MC_OK;
     }
-    uint64_t kstat_cells = 0;
+    uint64_t kstat_cells = 0, kstat_inwave = 0;
     uint64_t stop_frontier = 0, run_lo = 0, run_hi = 0;  // run() stops before a level of >= stop_frontier states (0 = never)
 
     // ------------------------------------------------------------------------------- checkpoint / recover
@@ -2335,6 +2452,7 @@ struct Engine : EngineBase {
         if (rc) { sh_levels.clear(); return rc; }
         for (auto &n : c.n_new) n.v = 0;
         c.max_slots = 0;
+        c.atomic_alloc = 0;
         HIP_TRY(hipMemcpy(d_ctr, &c, sizeof c, hipMemcpyHostToDevice));
         memset(kstat, 0, sizeof kstat);
         sh_lo = h.lo; sh_hi = h.hi; sh_next = h.next; sh_dup = h.dup;
@@ -2752,6 +2870,7 @@ struct Engine : EngineBase {
         o->materialise = kstat[2];
         o->state_bytes = (uint64_t)W * 8;
         o->cand_cells = kstat_cells;
+        o->inwave_states = kstat_inwave;
         return MC_OK;
     }
 };
