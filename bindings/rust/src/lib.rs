@@ -27,7 +27,7 @@ pub struct mc_config {
 #[repr(C)]
 pub struct mc_result {
     pub distinct: u64, pub generated: u64, pub queue_left: u64, pub depth: u32, pub verdict: i32,
-    pub violated_invariant: i32, pub trace_len: u32, pub levels: u32, pub host_evaluated: u32, pub seconds: f64,
+    pub violated_invariant: i32, pub trace_len: u32, pub levels: u32, pub host_evaluated: u32, pub unchecked_properties: u32, pub seconds: f64,
     pub level_distinct: [u64; MC_MAX_LEVELS],
 }
 #[repr(C)]

@@ -121,6 +121,9 @@ typedef struct {
     uint32_t trace_len;       /* states in the counterexample, 0 if none                        */
     uint32_t levels;          /* entries valid in level_distinct[]                              */
     uint32_t host_evaluated;  /* 1: mc_check_files ran a module WITHOUT a GPU lowering on the host's general TLA+ evaluator */
+    uint32_t unchecked_properties; /* cfg PROPERTIES with a liveness part (<>, ~>, WF_ / SF_) that were NOT checked: only their safety
+                                 parts ([]P, [][A]_v, initial predicates) are; the report names them in a "Warning:" line.  A caller
+                                 that needs TLC's verdict on them must not read "No error has been found" as that verdict. */
     double seconds;           /* init -> last level complete, device work included              */
     uint64_t level_distinct[MC_MAX_LEVELS]; /* new distinct states per BFS level                */
 } mc_result;
@@ -266,7 +269,8 @@ int mc_shard_check_frontier(mc_engine *e);
  * 0xfffd the state itself violates an invariant, otherwise the slot whose successor does).
  * mc_shard_fetch: one step of the walk — the packed state at `idx` of this rank, the rank / index of its parent
  * (0xffffffff: an initial state) and the slot that produced it (0xfffc: this entry is a COPY of state parent_idx made by the
- * replicated prefix, not a step). */
+ * replicated prefix, not a step).  With bit 63 of `idx` set the low bits are an ORDINAL of Init's enumeration: the state is
+ * rebuilt from it (an invariant violated by an initial state reports that ordinal, slot 0xfffe, not an arena index). */
 int mc_shard_materialise_parents(mc_engine *e, uint32_t slot, uint64_t *send_parents);
 int mc_shard_ingest_parents(mc_engine *e, const uint64_t *recv_parents, uint64_t n, uint32_t src_rank);
 int mc_shard_violation(mc_engine *e, int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *verdict, int32_t *invariant);

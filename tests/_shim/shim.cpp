@@ -538,6 +538,13 @@ struct ShimShard : ShimShardBase {
         return 0;
     }
     int fetch(uint64_t idx, uint8_t *out, uint32_t *prank, uint64_t *pidx, uint32_t *pslot) override {
+        if (idx & (1ull << 63)) {  // (shard_loop.h FETCH_INIT) a violating initial state: rebuilt from its ordinal
+            const uint64_t ord = idx & ~(1ull << 63);
+            if (ord >= S::num_init(prm)) return MC_EBADCFG;
+            S::init(prm, ord, WordRef{(uint64_t *)out, 1});
+            *prank = rank; *pidx = 0xffffffffull; *pslot = 0xfffeu;
+            return 0;
+        }
         if (idx >= nstates()) return MC_EBADCFG;
         memcpy(out, &arena[idx * W], (size_t)W * 8);
         *prank = par[idx].rank; *pidx = par[idx].idx; *pslot = par[idx].slot;
@@ -597,7 +604,7 @@ struct ShimShard : ShimShardBase {
             const bool mine = nranks <= 1 || (fp ? fp_owner(fp, nranks) == rank : rank == 0);
             if (!mine) continue;
             generated++;
-            if (st & ST_INVARIANT) viol(MC_V_INVARIANT, nstates(), 0xfffeu);
+            if (st & ST_INVARIANT) viol(MC_V_INVARIANT, k, 0xfffeu);  // (the ORDINAL of the initial state, as the engine reports it)
             if (fp && seen.insert(fp).second) push_state(tmp, rank, 0xffffffffull, 0xfffeu);
         }
         lo = 0; hi = nstates();
@@ -613,7 +620,7 @@ struct ShimShard : ShimShardBase {
             S::init(prm, k, WordRef{tmp, 1});
             const unsigned st = S::init_status(prm, CWordRef{tmp, 1});
             generated++;
-            if (st & ST_INVARIANT) viol(MC_V_INVARIANT, nstates(), 0xfffeu);
+            if (st & ST_INVARIANT) viol(MC_V_INVARIANT, k, 0xfffeu);
             if (st & ST_OUT_OF_MODEL) continue;
             if (seen.insert(S::fp_of(prm, CWordRef{tmp, 1})).second) push_state(tmp, rank, 0xffffffffull, 0xfffeu);
         }

@@ -165,6 +165,33 @@ def test_invariant_counterexample_across_ranks_on_cpu(oracle, shim, tmp_path):
         assert tr[0][0] == "Initial predicate" and all(a and a != "?" for a, _ in tr) and last in tr[-1][1]
 
 
+INIT_VIOL = """---- MODULE init_viol ----
+EXTENDS Naturals
+(* --algorithm init_viol
+variables v \\in 1..8, w = 0;
+begin
+  A: w := v;
+end algorithm *)
+Small == v < 6
+====
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_invariant_violated_by_an_initial_state_sharded(shim, tmp_path, world):
+    """with Init owner-filtered over the ranks, the violation's index is the ORDINAL of the initial state, not an
+    arena index of the rank that found it: the counterexample is that one state, rebuilt from the ordinal (v = 6, the first of
+    1..8 that is not < 6), not whatever state sits at arena[ordinal] on that rank."""
+    path = tmp_path / "init_viol.tla"
+    path.write_text(INIT_VIOL)
+    spec = {"path": str(path), "invariants": ["Small"], "constants": {}}
+    r = run_dist("shim", world, "pcal_file", spec, tmp_path, {"chunk": 100, "trace": True})
+    assert r["verdict"] == "invariant"
+    assert len(r["trace"]) == 1 and r["trace"][0][0] == "Initial predicate"
+    assert "v = 6" in r["trace"][0][1] or "v = 7" in r["trace"][0][1] or "v = 8" in r["trace"][0][1]
+    assert "w = 0" in r["trace"][0][1]
+
+
 # ---------------------------------------------------------------------------------------------- one checkpoint file per rank
 @pytest.mark.parametrize("world,opts", [(2, {"max_levels": 9, "chunk": 700}),                                            # stopped in a move level
                                         (3, {"max_levels": 14, "chunk": 900, "stay_threshold": 50, "rebalance_ratio": 1.6}),   # ... in a stay level
@@ -180,6 +207,19 @@ def test_checkpoint_per_rank_then_continue_in_fresh_engines(oracle, shim, tmp_pa
     assert (r["first"]["verdict"], r["first"]["distinct"], r["first"]["levels"]) == ("budget", cut["distinct"], cut["levels"])
     assert all((tmp_path / f"ck.rank{k}").stat().st_size > 0 for k in range(world))
     assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"])
+    assert sum(r["shares"]) == o["distinct"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_checkpoint_of_a_finished_run_recovers_as_finished(oracle, shim, tmp_path, world):
+    """mc_shard_checkpoint accepts a run that FINISHED (`mc -gpus P -checkpoint` writes it and prints TLC's
+    "Checkpointing ... completed"); recovering it must report the finished result again — no frontier is left, the level loop does
+    not run — instead of refusing it as "frontiers do not add up"."""
+    params = [2, 1, 2, 9, 1, 1]
+    o = oracle.oracle_run("raft", params)
+    r = run_dist("shim", world, "raft", params, tmp_path, {"chunk": 700, "checkpoint": str(tmp_path / "ck")})
+    assert (r["first"]["verdict"], r["first"]["distinct"], r["first"]["levels"]) == ("ok", o["distinct"], o["levels"])
+    assert (r["distinct"], r["depth"], r["levels"], r["verdict"], r["queue_left"]) == (o["distinct"], o["depth"], o["levels"], "ok", 0)
     assert sum(r["shares"]) == o["distinct"]
 
 

@@ -34,7 +34,7 @@ class Config(C.Structure):
 class CResult(C.Structure):
     _fields_ = [("distinct", C.c_uint64), ("generated", C.c_uint64), ("queue_left", C.c_uint64),
                 ("depth", C.c_uint32), ("verdict", C.c_int32), ("violated_invariant", C.c_int32),
-                ("trace_len", C.c_uint32), ("levels", C.c_uint32), ("host_evaluated", C.c_uint32), ("seconds", C.c_double),
+                ("trace_len", C.c_uint32), ("levels", C.c_uint32), ("host_evaluated", C.c_uint32), ("unchecked_properties", C.c_uint32), ("seconds", C.c_double),
                 ("level_distinct", C.c_uint64 * MC_MAX_LEVELS)]
 
 
@@ -242,7 +242,8 @@ def state_apply(spec, params, state: bytes, slot: int):
 def _result(r: CResult):
     return Result(distinct=r.distinct, generated=r.generated, queue_left=r.queue_left, depth=r.depth,
                   verdict=VERDICTS[r.verdict], violated_invariant=r.violated_invariant, trace_len=r.trace_len,
-                  levels=[r.level_distinct[i] for i in range(r.levels)], seconds=r.seconds, host_evaluated=bool(r.host_evaluated))
+                  levels=[r.level_distinct[i] for i in range(r.levels)], seconds=r.seconds, host_evaluated=bool(r.host_evaluated),
+                  unchecked_properties=int(r.unchecked_properties))
 
 
 class Engine:

@@ -656,17 +656,27 @@ __device__ __forceinline__ T wave_uniform_copy(const T &v) {
     return r;
 }
 template <class S>
-__device__ __noinline__ void wave_write_survivors(typename S::Params prm_v, const uint64_t *blk_v, bool mine, unsigned e, uint64_t fp,
+__device__ __noinline__ void wave_write_survivors(typename S::Params prm_v, const uint64_t *arena_v, uint64_t pidx, bool mine, unsigned slot, uint64_t fp,
                                                   uint64_t *arena_w_v, uint64_t oidx) {
     const typename S::Params prm = wave_uniform_copy(prm_v);
-    const GlobalWords blk = uniform_ptr(blk_v);
+    const uint64_t *arena = (const uint64_t *)uniform_ptr(arena_v);
     uint64_t *arena_w = (uint64_t *)uniform_ptr(arena_w_v);
     if (!mine) return;
-    const BlockRef sp{blk, e & 63u};
     const int W = S::words(prm);
-    if constexpr (HasKnownFp<S>::value) S::apply_known_fp(prm, sp, (int)(e >> 6), fp, arena_ref(arena_w, oidx, W));
-    else S::apply(prm, sp, (int)(e >> 6), arena_ref(arena_w, oidx, W));
+    const CWordRef sp = arena_cref(arena, pidx, W);
+    if constexpr (HasKnownFp<S>::value) S::apply_known_fp(prm, sp, (int)slot, fp, arena_ref(arena_w, oidx, W));
+    else S::apply(prm, sp, (int)slot, arena_ref(arena_w, oidx, W));
 }
+// classes of action slots whose successor construction shares a code path (S::NCLS, S::slot_class): the workgroup's tail sorts
+// its survivors by class, so that the 64 lanes of a batch walk one or two branches of the writer instead of all of them
+template <class S, class = void>
+struct SlotClasses : std::integral_constant<int, 1> {
+    __device__ static int of(int) { return 0; }
+};
+template <class S>
+struct SlotClasses<S, decltype((void)S::NCLS)> : std::integral_constant<int, S::NCLS> {
+    __device__ static int of(int slot) { return S::slot_class(slot); }
+};
 
 // Probe ring and survivor list of a by-family wavefront.  An entry names its (parent, slot) pair inside the wavefront's own
 // arena block: (slot << 6) | parent lane, 16 bits.  The survivor list holds up to OCAP entries: with in-wave writes the
@@ -727,7 +737,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     //  neighbourhood are already caught by the wavefront's own filter, the rest miss every L2.)
     // this wavefront's first column: NB consecutive arena blocks
     const uint64_t wave_col0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64ull * NB);
-    if (wave_col0 >= ncols) return;
+    const bool inwave = !ROUTE && rt.arena_w != nullptr;  // wave-uniform (a kernel argument)
+    if (wave_col0 >= ncols && !inwave) return;  // (in-wave writes: the workgroup's tail has barriers — a wavefront without parents walks through the empty loops below)
     const uint64_t wave_idx0 = base + wave_col0;
     const int W = S::words(prm);
     static_assert(NB == 1, "BlockRef addresses ONE arena block per wavefront");
@@ -748,7 +759,6 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     };
     const unsigned shard = blockIdx.x & (NSHARD - 1), pshard = parity * NSHARD + shard;
     uint32_t *__restrict__ seg = newlist + (uint64_t)pshard * seg_cap;
-    const bool inwave = !ROUTE && rt.arena_w != nullptr;  // wave-uniform (a kernel argument)
     // survivors kept in LDS before a batch of 64 goes to the global new-list: all the list holds minus one probe batch (in-wave
     // writes: the global list is the overflow path), or one batch (everything goes through the new-list)
     const unsigned okeep = inwave ? (unsigned)(OCAP - 64) : 63u;
@@ -1044,27 +1054,67 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     }
     if (qn) flush_probe(qn);
     if (inwave) {
-        // THE TAIL: this wavefront writes its own survivors.  Their final arena indices come from ONE atomicAdd; the parent of
-        // every survivor is in this wavefront's block (read a few microseconds ago: L2 / Infinity Cache, not HBM); lanes write
-        // consecutive arena indices, i.e. whole rows of the word-major blocks.  Nothing of the generation phase is live here,
-        // so the copy-and-patch writer has the whole register budget.
+        // THE TAIL, by WORKGROUP: the four wavefronts pool their survivors (one per parent on average: 250-400 per workgroup),
+        // sort them by action class, take their arena indices with ONE atomicAdd and write them — parent row (this workgroup's
+        // own four arena blocks: read a few microseconds ago, L2 / Infinity Cache, not HBM) + patch, lanes = consecutive arena
+        // indices, i.e. whole rows of the word-major blocks.  Why sorted: the writer re-evaluates (parent, slot), and with 64
+        // survivors in discovery order a wavefront walks EVERY branch of the next-state relation for every batch (~2600
+        // instructions per 64 states: k_materialise is bound by instruction issue, 44 ms of the 159 of round 3); sorted, a batch
+        // holds one or two classes.  The sort is a counting sort over S::NCLS classes in LDS that is dead by now (the duplicate
+        // filters of the wavefronts): no LDS beyond the generation phase's.
         MC_PROF(4);
-        if (on) {
-            unsigned long long out0 = 0;
-            if (lane == 0) out0 = atomicAdd(&ctr->arena_next, (unsigned long long)on);
-            out0 = __shfl(out0, 0);
-            if (out0 + on > rt.arena_cap) {
-                err |= DEV_EARENA;
-            } else {
-                for (unsigned t = 0; t < on; t += 64) {
-                    const bool mine = t + lane < on;
-                    const unsigned k = (ohead + t + lane) & (OCAP - 1);
-                    const unsigned e = mine ? Q.o_ent[k] : 0u;
-                    const uint64_t sfp = mine ? Q.o_fp[k] : 0ull;
-                    const uint64_t oidx = out0 + t + lane;
-                    wave_write_survivors<S>(prm, (const uint64_t *)blk_base, mine, e, sfp, rt.arena_w, oidx);
-                    if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)(wave_idx0 + (e & 63u)); rt.pslot[oidx] = (uint16_t)(e >> 6); }
-                }
+        constexpr int NCLS = SlotClasses<S>::value;
+        static_assert(NCLS * 4 <= 64, "one lane per (class, wavefront) in the prefix sum");
+        static_assert(4 * OCAP * sizeof(uint16_t) <= sizeof(fls[0].filt) && OCAP <= 256, "the sorted order aliases one duplicate filter");
+        uint16_t *order = reinterpret_cast<uint16_t *>(fls[0].filt);        // [4 * OCAP]: (wavefront << 8) | position in its list
+        unsigned *hist = reinterpret_cast<unsigned *>(fls[1].filt);         // [NCLS][4]
+        unsigned long long *wg_out0 = reinterpret_cast<unsigned long long *>(fls[2].filt);
+        const unsigned w = threadIdx.x >> 6;
+        __syncthreads();  // (1) no wavefront of the workgroup generates any more: the filters are free, the lists final
+        unsigned ccnt[NCLS];
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
+        for (unsigned t = 0; t < on; t += 64) {
+            const bool valid = t + lane < on;
+            const int cls = valid ? SlotClasses<S>::of((int)(Q.o_ent[(ohead + t + lane) & (OCAP - 1)] >> 6)) : -1;
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) ccnt[c] += (unsigned)__popcll(__ballot(cls == c));
+        }
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) if (lane == 0) hist[c * 4 + w] = ccnt[c];
+        __syncthreads();  // (2)
+        const unsigned h = lane < (unsigned)(NCLS * 4) ? hist[lane] : 0u;
+        unsigned incl = h;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
+        const unsigned excl = incl - h, total = __shfl(incl, 63);
+        if (w == 0 && lane == 0) *wg_out0 = total ? atomicAdd(&ctr->arena_next, (unsigned long long)total) : 0ull;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) ccnt[c] = __shfl(excl, c * 4 + (int)w);  // where this wavefront's class-c survivors go
+        for (unsigned t = 0; t < on; t += 64) {
+            const bool valid = t + lane < on;
+            const unsigned k = (ohead + t + lane) & (OCAP - 1);
+            const int cls = valid ? SlotClasses<S>::of((int)(Q.o_ent[k] >> 6)) : -1;
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+                const unsigned long long b = __ballot(cls == c);
+                if (cls == c) order[ccnt[c] + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((w << 8) | k);
+                ccnt[c] += (unsigned)__popcll(b);
+            }
+        }
+        __syncthreads();  // (3) the order and the workgroup's first arena index are visible
+        const unsigned long long out0 = *wg_out0;
+        if (total && out0 + total > rt.arena_cap) {
+            err |= DEV_EARENA;
+        } else {
+            const uint64_t wg_idx0 = base + (uint64_t)blockIdx.x * 256u;
+            for (unsigned bt = w * 64u; bt < total; bt += 256u) {  // batch of 64 sorted survivors; the wavefronts take turns
+                const bool mine = bt + lane < total;
+                const unsigned ref = mine ? order[bt + lane] : 0u;
+                const unsigned e = mine ? wq[ref >> 8].o_ent[ref & 255u] : 0u;
+                const uint64_t sfp = mine ? wq[ref >> 8].o_fp[ref & 255u] : 0ull;
+                const uint64_t pidx = wg_idx0 + (ref >> 8) * 64u + (e & 63u), oidx = out0 + bt + lane;
+                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx);
+                if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
             }
         }
     } else if (on) {
@@ -2800,6 +2850,15 @@ struct Engine : EngineBase {
     // of state parent_idx made by the replicated prefix, not a step)
     int shard_fetch(uint64_t idx, uint8_t *state_out, uint32_t *parent_rank, uint64_t *parent_idx, uint32_t *parent_slot) override {
         HIP_TRY(hipSetDevice(cfg.device));
+        if (idx & (1ull << 63)) {  // an initial state, rebuilt from its ordinal in Init's enumeration (a violating initial state is not looked up in the arena)
+            const uint64_t ord = idx & ~(1ull << 63);
+            if (ord >= S::num_init(prm)) return MC_EBADCFG;
+            S::init(prm, ord, WordRef{(uint64_t *)state_out, 1});
+            *parent_rank = cfg.shard_rank;
+            *parent_idx = 0xffffffffull;
+            *parent_slot = SLOT_INIT;
+            return MC_OK;
+        }
         if (!d_parent) { set_error("engine created without MC_F_TRACE"); return MC_ESTATE; }
         if (idx >= arena_cap) return MC_EBADCFG;
         HIP_TRY(hipDeviceSynchronize());

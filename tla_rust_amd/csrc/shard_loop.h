@@ -42,6 +42,7 @@ enum Event { EV_PACKED = 0, EV_FP = 2, EV_PROBED = 4, EV_ANS = 6, EV_TMP = 8, EV
 
 constexpr uint32_t SLOT_NONE = 0xffffu, SLOT_INIT = 0xfffeu, SLOT_PARENT = 0xfffdu, SLOT_COPY = 0xfffcu;
 constexpr uint64_t NO_PARENT = 0xffffffffull;
+constexpr uint64_t FETCH_INIT = 1ull << 63;  // Ops::fetch / mc_shard_fetch: the low bits are an ordinal of Init's enumeration, not an arena index
 
 // exchange buffer from the transport's allocator; grows on demand (only ever between levels or in host-paced rounds)
 struct NetBuf {
@@ -148,7 +149,20 @@ struct Loop {
             if (all[p].pad != resume_sig) { mc_set_error_internal("sharded search: the ranks did not restore checkpoints of the same run (mc_shard_restore on every rank, or on none)"); return MC_EBADCFG; }
         uint64_t cum = 0;
         if (resumed) {
-            if (frontier != levels.back()) { mc_set_error_internal("sharded search: the restored frontiers do not add up to the checkpointed level"); return MC_EBADCFG; }
+            // A checkpoint of a run that STOPPED ON A BUDGET leaves its last level unexpanded: the ranks' frontiers add up to it.  A
+            // checkpoint of a FINISHED run (mc_shard_checkpoint accepts MC_V_OK, `mc -gpus P -checkpoint` writes it) has no frontier
+            // left: the loop below does not run and the finished result is reported again.  Either way the states the ranks hold
+            // must add up to the level table.
+            uint64_t total = 0, held = 0;
+            for (uint64_t v : levels) total += v;
+            std::vector<uint64_t> every(P);
+            uint64_t mine_dl = lrc ? 0 : dl;
+            if ((trc = net.all_gather(net.user, &mine_dl, every.data(), sizeof mine_dl))) return trc;
+            for (uint32_t p = 0; p < P; ++p) held += every[p];
+            if ((frontier != 0 && frontier != levels.back()) || held != total) {
+                mc_set_error_internal("sharded search: the restored frontiers / states do not add up to the checkpointed level table");
+                return MC_EBADCFG;
+            }
         } else if (o.flags & MC_SHARD_NO_PREFIX) {
             if (frontier) levels.push_back(frontier);
         } else if (worst != 0) {
@@ -383,24 +397,33 @@ struct Loop {
         }
         return MC_OK;
     }
-    // What a rank ANNOUNCED it sends; a rank that failed after announcing (an allocation, an engine call) still moves those
-    // sizes — out of / into scratch memory when its own buffers are missing: the peers abort at the end of the level, until
-    // then nobody may be left waiting in a collective.
+    // What a rank ANNOUNCED it sends it must still move — or every rank must know that it cannot.  A rank whose own buffers are
+    // missing (it failed after announcing: an allocation, an engine call) moves the sizes out of / into scratch memory; if even
+    // the scratch cannot be had, nobody enters the collective: the ranks agree on that with one small all-gather first (a rank
+    // that returned alone would leave its peers waiting in the all-to-all forever — an out-of-memory rank is the likeliest case).
+    // The level then runs on with stale buffers and ends at its level_info, where the failed rank's status stops every rank.
     NetBuf scratch_s, scratch_r;
     int a2a_v_safe(NetBuf &s, const std::vector<uint64_t> &sc, NetBuf &r, const std::vector<uint64_t> &rc_, uint64_t elem) {
         uint64_t need_s = 0, need_r = 0;
         for (uint32_t p = 0; p < P; ++p) { need_s += sc[p] * elem; need_r += rc_[p] * elem; }
         void *sp = s.p, *rp = r.p;
+        uint64_t cannot = 0;
         if (!sp || s.bytes < need_s) {
             scratch_s.t = &net;
-            if (scratch_s.need(std::max<uint64_t>(need_s, 8))) return MC_EHIP;
+            if (scratch_s.need(std::max<uint64_t>(need_s, 8))) cannot = 1;
             sp = scratch_s.p;
         }
         if (!rp || r.bytes < need_r) {
             scratch_r.t = &net;
-            if (scratch_r.need(std::max<uint64_t>(need_r, 8))) return MC_EHIP;
+            if (scratch_r.need(std::max<uint64_t>(need_r, 8))) cannot = 1;
             rp = scratch_r.p;
         }
+        if (cannot && !lrc) lrc = MC_EHIP;
+        std::vector<uint64_t> every(P);
+        int trc = net.all_gather(net.user, &cannot, every.data(), sizeof cannot);
+        if (trc) return trc;
+        for (uint32_t p = 0; p < P; ++p)
+            if (every[p]) return MC_OK;  // nobody moves anything; the failed rank's status travels with the level's all-gather
         return a2a_v(sp, sc, rp, rc_, elem);
     }
 
@@ -433,7 +456,10 @@ struct Loop {
         std::vector<std::vector<uint8_t>> st_rev;
         std::vector<int32_t> slot_rev;
         uint32_t cur_rank = (uint32_t)owner;
-        uint64_t cur_idx = (uint64_t)v.idx;
+        // An invariant violated by an INITIAL state: the violation's index is the ordinal of that state in Init's enumeration, not an
+        // arena index (an owner-filtered or deduplicated Init stores it elsewhere, or nowhere on this rank) — the owner rebuilds the
+        // state from the ordinal (fetch with FETCH_INIT set) and the behaviour is that one state.
+        uint64_t cur_idx = (uint32_t)v.slot == SLOT_INIT ? (FETCH_INIT | (uint64_t)v.idx) : (uint64_t)v.idx;
         for (int guard = 0; guard < (1 << 16); ++guard) {
             memset(mine_rec.data(), 0, rec);
             if (cur_rank == me) {

@@ -161,6 +161,16 @@ struct SpecRaft {
     // slots: Restart NS | Timeout NS | RequestVote NS^2 | BecomeLeader NS | ClientRequest NS |
     //        AdvanceCommitIndex NS | AppendEntries NS^2 | per message k: Receive, Duplicate, Drop
     static constexpr int FIX = 5 * NS + 2 * NS * NS;
+    // classes of slots whose successors are built by the same branch of compute(): the in-wave tail of the expand kernel sorts a
+    // workgroup's new states by class before it writes them (engine.hip SlotClasses)
+    static constexpr int NCLS = 10;
+    MC_HD static int slot_class(int slot) {
+        if (slot >= FIX) return 7 + (slot - FIX) % 3;  // Receive / Duplicate / Drop
+        if (slot < 2 * NS) return slot < NS ? 0 : 1;   // Restart, Timeout
+        if (slot < 2 * NS + NS * NS) return 2;         // RequestVote
+        if (slot < 5 * NS + NS * NS) return 3 + (slot - (2 * NS + NS * NS)) / NS;  // BecomeLeader, ClientRequest, AdvanceCommitIndex
+        return 6;                                      // AppendEntries
+    }
     static constexpr int FIX_SLOTS = FIX;  // slots whose action and server indices are compile-time constants
     static constexpr int DENSE_SLOTS = 2 * NS;  // Restart(i), Timeout(i): enabled for (nearly) every state — the by-family kernel
                                                 // evaluates them inline, lane = parent (engine.hip k_expand_family)

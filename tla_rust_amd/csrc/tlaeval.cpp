@@ -1920,6 +1920,9 @@ struct Checker {
     NodeP view;  // VIEW: two states with the same value of this expression are the same state (p-manual section 4.5 / TLC's -view)
     struct Prop { std::string name; std::vector<NodeP> inits; std::vector<std::pair<NodeP, NodeP>> steps; };
     std::vector<Prop> props;
+    size_t n_cfg_invariants = 0;
+    std::vector<std::pair<std::string, NodeP>> always;  // []P conjuncts of the PROPERTIES: checked like invariants, under the property's name
+    std::vector<std::string> unchecked;                 // PROPERTIES with a liveness part (never checked here; the report names them)
     std::vector<std::map<const Val *, V>> group;
     bool has_group = false;
 
@@ -1976,12 +1979,18 @@ struct Checker {
             flat.push_back(n);
         };
         walk(node_id(name));
+        bool live = false;
         for (auto &n : flat) {
-            std::set<int> seen;
+            std::set<int> seen, seen2;
             if (is_box_action(n.get())) p.steps.emplace_back(n->kids[0]->kids[0], n->kids[0]->kids[1]);
-            else if (is_temporal(n.get(), seen) || is_fairness(n.get())) continue;  // liveness (<>, ~>, fairness): not checked
+            else if (n->k == N_TEMPORAL && n->s == "[]" && !is_temporal(n->kids[0].get(), seen2)) {
+                // []P with a state predicate P is an invariance property: TLC checks it as an invariant (Liveness/LiveHourClock.cfg:10
+                // TypeInvariance == []HCini, LiveHourClock.tla:23)
+                always.emplace_back(name, n->kids[0]);
+            } else if (is_temporal(n.get(), seen) || is_fairness(n.get())) live = true;  // liveness (<>, ~>, WF_ / SF_): NOT checked — and said so
             else p.inits.push_back(n);
         }
+        if (live) unchecked.push_back(name);
         return p;
     }
     void setup(const std::string &tla_path, const std::string &cfg_text, const std::vector<std::string> &search, bool symmetry) {
@@ -2007,6 +2016,8 @@ struct Checker {
         for (auto &n : cfg.action_constraints) acons.emplace_back(n, node_id(n));
         if (!cfg.view.empty()) view = node_id(cfg.view);
         for (auto &n : cfg.properties) props.push_back(compile_property(n));
+        n_cfg_invariants = invs.size();
+        for (auto &a : always) invs.push_back(a);  // (after the cfg's INVARIANTs: the indices of those stay what they were)
         if (!cfg.symmetry.empty()) symmetry_group(cfg.symmetry);
     }
     // the group generated by the cfg's SYMMETRY set of permutations (functions on model values)
@@ -2230,6 +2241,7 @@ struct Checker {
         }
         R.distinct = seen.size();
         R.n_invariants = invs.size();
+        R.unchecked_properties = unchecked;
         R.generated = generated;
         R.depth = depth;
         R.verdict = verdict;

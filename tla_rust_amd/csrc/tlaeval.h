@@ -32,6 +32,7 @@ struct Result {
     int verdict = 0;             // MC_V_* of include/tlamc.h
     int violated_invariant = -1; // index into the cfg's INVARIANT list
     std::string violated_name, error_message;
+    std::vector<std::string> unchecked_properties;                // cfg PROPERTIES with a liveness part (<>, ~>, WF_ / SF_): NOT checked; the caller must say so
     std::vector<uint64_t> levels;                                 // new distinct states per BFS level
     std::vector<std::pair<std::string, std::string>> trace;       // (action label, state text) of a counterexample
     double seconds = 0;

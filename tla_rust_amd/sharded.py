@@ -82,6 +82,8 @@ class TorchTransport:
     def _exchange(self, out, inp, osplit=None, isplit=None):
         if not self.on:
             out.copy_(inp)
+            if self.cuda:   # no hip_stream was handed to the loop: it takes the exchange as COMPLETE when this returns, and its
+                torch.cuda.synchronize(self.device)   # consumers run on other (non-blocking) streams — the copy must have landed
         elif self.staged:   # the loop made the host wait for the producers (no hip_stream): plain blocking copies
             src = inp.cpu()
             dst = torch.empty(out.numel(), dtype=torch.uint8)
