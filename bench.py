@@ -47,10 +47,23 @@ WORKLOAD_K11 = dict(spec="raft", params=[3, 4, 2, 3, 1, 1, 11, 1, 4, 11], golden
 WORKLOAD_T3 = dict(spec="raft", params=[3, 4, 3, 3, 1, 1, 8, 2, 4, 8], golden="raft3_mcr4_t3_m1_k8_complete",
                    name="examples/raft.tla Server=3 MaxClientRequests=4 MaxTerm=3 MaxLogLen=3 MaxMsgs=1 MaxMsgKeys=8 "
                         "(specs/MCraft_t3.cfg), complete state graph")
-WORKLOADS = {"t3": WORKLOAD_T3, "k10": WORKLOAD, "k11": WORKLOAD_K11}
+# BASELINE config 4's model (north_star's target sentence: raft.tla, 5 servers, bounded log, fingerprint-sharded over the GPUs of a node):
+# Server = {s1..s5}, MaxClientRequests = 6 (log <= 5), MaxTerm = 2, MaxMsgs = 1, slot capacities 18 / 1 / 4 (W = 192 B), LEVEL-BUDGETED as
+# SURVEY.md 8d prescribes: 18 BFS levels = 924 041 864 states / 177 GB of states — what ONE 288 GB device holds (level 19 alone has
+# 1.26e9), so that N = 1, 2, 4, 8 run the same search ("scaling": "strong").  Gate: all 18 per-level counts equal the exact-dedup
+# oracle's (tests/golden/raft_levels.json raft5_mcr6_t2_m1_levels18).
+WORKLOAD_RAFT5 = dict(spec="raft", params=[5, 6, 2, 5, 1, 1, 18, 1, 4], golden="raft5_mcr6_t2_m1_levels18", max_levels=18, verdict="budget",
+                      metric="distinct states/sec, raft.tla (5 servers, 18 BFS levels)",
+                      name="examples/raft.tla Server=5 MaxClientRequests=6 MaxTerm=2 MaxLogLen=5 MaxMsgs=1 (BASELINE config 4), levels 1-18")
+# BASELINE config 5: serializableSnapshotIsolation.tla, TxnId = {T1..T4}, Key = {K1,K2,K3}, every invariant of :59-79 on, no SYMMETRY,
+# level-budgeted: 10 BFS levels = 168 M states (W = 80 B).  Gate: the oracle's per-level counts (tests/golden/ssi_levels.json).
+WORKLOAD_SSI = dict(spec="ssi", params=[4, 3, 127, 0], golden="ssi_4x3_levels10", golden_file="ssi_levels.json", max_levels=10, verdict="budget",
+                    metric="distinct states/sec, serializableSnapshotIsolation.tla (4 txns x 3 keys, 10 BFS levels)",
+                    name="examples/serializableSnapshotIsolation.tla TxnId=4 Key=3 all invariants (BASELINE config 5), levels 1-10")
+WORKLOADS = {"t3": WORKLOAD_T3, "k10": WORKLOAD, "k11": WORKLOAD_K11, "raft5": WORKLOAD_RAFT5, "ssi4x3": WORKLOAD_SSI}
 # seen-set slots: >= 3 x the arena, so that the table can never be more than a third full and is probed 32 bytes at a time
 # (engine.hip seen_insert: random HBM reads cost by the byte); load 0.2 at the end of the run: 21.5 / 4.3 / 14 GB of the 288
-TABLE_SLOTS = {"t3": 40 << 26, "k10": 8 << 26, "k11": 26 << 26}
+TABLE_SLOTS = {"t3": 40 << 26, "k10": 8 << 26, "k11": 26 << 26, "raft5": 3 << 30, "ssi4x3": 9 << 26}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 XGMI_PEAK_GBS = 7 * 153.0  # MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point
 
@@ -150,7 +163,7 @@ def kernel_source_hash():
 
 
 def golden():
-    g = json.loads((ROOT / "tests" / "golden" / "raft_levels.json").read_text())
+    g = json.loads((ROOT / "tests" / "golden" / WORKLOAD.get("golden_file", "raft_levels.json")).read_text())
     return next(c for c in g["cases"] if c["name"] == WORKLOAD["golden"])
 
 
@@ -191,12 +204,15 @@ def cpu_baseline(max_seconds=10.0):
     # threads: every core the process may use; under a CPU quota four threads per core's worth of quota (measured on the GPU
     # box, quota 16 of 256 cores: 64 threads 4.8 M states/s, 256 threads 2.8 M — throttled threads holding blocks of work)
     cores = host_cores if not quota else max(1, min(host_cores, int(4 * quota + 0.5)))
-    p = [str(x) for x in WORKLOAD["params"][:6]] + ["0", str(WORKLOAD["params"][9])]
+    wp = WORKLOAD["params"]
+    spec = WORKLOAD["spec"]
+    # the oracle's constants of the same model (its slot arrays are unbounded: no capacities; MaxMsgKeys is its 8th raft argument)
+    p = [str(x) for x in (wp[:6] + ([0, wp[9]] if len(wp) > 9 else []) if spec == "raft" else wp)]
 
     def sample(threads, seconds):
         t0 = time.perf_counter()
         c0 = os.times()
-        out = subprocess.run([str(exe), "raft", *p, "--threads", str(threads), "--max-seconds", str(seconds), "--distinct", "200000000"],
+        out = subprocess.run([str(exe), spec, *p, "--threads", str(threads), "--max-seconds", str(seconds), "--distinct", "200000000"],
                              capture_output=True, text=True, check=True).stdout
         c1 = os.times()
         r = json.loads(out.splitlines()[0])
@@ -234,8 +250,9 @@ def main():
                     "the exchange of round r+1 overlaps the probes of round r)")
     ap.add_argument("--packed-fanout", type=int, default=16, help="in-model successors per state the fixed-capacity exchange buckets allow for")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank on GPU 0 (needs a librccl stand-in in $TLAMC_RCCL; RCCL refuses it)")
-    ap.add_argument("--workload", choices=["t3", "k10", "k11"], default="t3", help="t3: MaxTerm 3, MaxMsgKeys 8 (525.8 M states, the contract line); "
-                    "k10 / k11: MaxTerm 2 with 10 / 11 message keys (102.6 M / 336.6 M states; rounds 1-2's line was k10)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="t3", help="t3: MaxTerm 3, MaxMsgKeys 8 (525.8 M states, the contract line); "
+                    "k10 / k11: MaxTerm 2 with 10 / 11 message keys (102.6 M / 336.6 M states; rounds 1-2's line was k10); raft5: BASELINE config 4 "
+                    "(5 servers, 18 levels = 924 M states); ssi4x3: BASELINE config 5 (10 levels = 168 M states)")
     ap.add_argument("--table-slots", type=int, default=0, help="seen-set slots (any multiple of 64; 0 = the workload's default, load ~0.5 at the end)")
     ap.add_argument("--table-log2", type=int, default=0, help="A/B: a power-of-two seen-set (27: load 0.76, 28: load 0.38)")
     ap.add_argument("--msg-keys", type=int, default=0, choices=[0, 10, 11], help="(rounds 1-2) same as --workload k10 / k11")
@@ -273,12 +290,13 @@ def main():
         a.shard_chunk = (1 << 23) if world == 1 else (1 << 21)
 
     G0 = golden()
+    ML = WORKLOAD.get("max_levels", 0)   # level-budgeted workloads (BASELINE configs 4, 5: SURVEY.md 8d); 0 = the complete graph
     slots = (1 << a.table_log2) if a.table_log2 else a.table_slots
     comm = store = None
     if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=slots, matrix=a.matrix,
                          debug_flags=(32 if a.no_family else 0) | (2048 if a.occ3 else 0) | (8192 if a.no_filter else 0) | (65536 if a.no_inwave else 0),
-                         arena_capacity=G0["distinct"] + (1 << 20),
+                         arena_capacity=G0["distinct"] + (1 << 20), max_levels=ML,
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run
         stats = {}
@@ -295,7 +313,7 @@ def main():
         stats = {}
 
         def run():
-            r, st = comm.shard_run(eng, chunk_states=a.shard_chunk, max_distinct=a.max_distinct, packed_fanout=a.packed_fanout)
+            r, st = comm.shard_run(eng, chunk_states=a.shard_chunk, max_distinct=a.max_distinct, max_levels=ML, packed_fanout=a.packed_fanout)
             stats.update(st)
             return r
 
@@ -325,18 +343,18 @@ def main():
     if not a.max_distinct:
         # parity gate: the measured run must BE the golden graph (exact counts, per-level where the engine reports them)
         got = (D, G, res.depth, res.verdict)
-        want = (G0["distinct"], G0["generated"], G0["depth"], "ok")
+        want = (G0["distinct"], G0["generated"], G0["depth"], WORKLOAD.get("verdict", "ok"))
         if got != want or ("levels" in res and list(res["levels"]) != G0["levels"]):
             print(f"bench.py: run does not reproduce the golden state graph: got {got}, want {want}", file=sys.stderr)
             sys.exit(1)
     line = {
-        "metric": "distinct states/sec, raft.tla (3 servers)", "value": D * a.steps / dt, "unit": "distinct states/s",
+        "metric": WORKLOAD.get("metric", "distinct states/sec, raft.tla (3 servers)"), "value": D * a.steps / dt, "unit": "distinct states/s",
         "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "strong" if a.gpus > 1 else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": WORKLOAD["name"], "distinct": D, "generated": G, "depth": res.depth,
                    "verdict": res.verdict, "queue_left": res.queue_left, "generated_per_s": G * a.steps / dt,
                    "seen_set_load": D / float(slots) if not use_dist else None,
-                   "golden": f"tests/golden/raft_levels.json:{WORKLOAD['golden']} (exact-dedup CPU oracle): counts and per-level counts equal"
+                   "golden": f"tests/golden/{WORKLOAD.get('golden_file', 'raft_levels.json')}:{WORKLOAD['golden']} (exact-dedup CPU oracle): counts and per-level counts equal"
                              if not a.max_distinct else "A/B run with a budget: NOT the benchmark"},
     }
     if use_dist:
@@ -360,6 +378,7 @@ def main():
     else:
         ks = eng.kernel_stats()
         W = ks["state_bytes"]
+        STAG = "SpecSsi" if WORKLOAD["spec"] == "ssi" else "SpecRaft<%d>" % WORKLOAD["params"][0]   # the kernels' template argument
         # algorithmic bytes per launch: expand reads W per frontier state,
         # insert touches one 8-byte seen-set word per generated candidate, materialise writes W per new state
         inwave = ks.get("inwave_states", 0)   # states the expand wavefronts wrote themselves (round 4): their W bytes are that kernel's
@@ -380,7 +399,7 @@ def main():
                     raise ValueError(f"{pmc[-1].name} was collected on kernel sources {stamp}, the timed ones are {kernel_source_hash()}")
                 knames = {"expand": ("k_expand_insert",) if a.no_family else ("k_expand_family", "k_expand_insert"),
                           "insert": ("k_insert",), "materialise": ("k_materialise",)}[dom]
-                k = next(v for kn in knames for n, v in d.items() if n.startswith(kn + "<") and "Raft<3>" in n)
+                k = next(v for kn in knames for n, v in d.items() if n.startswith(kn + "<") and STAG in n)
                 # FETCH_SIZE / WRITE_SIZE are in KB.  Calibration on this box (profiles/r02e_calib_*.json*, profiles/calib/calib_fetch.hip):
                 # FETCH_SIZE = read requests x 64 B; the arena's 8 B/lane row reads and 16 B/lane streaming reads are 128-B
                 # requests (FETCH_SIZE = exactly 1/2 of the known bytes, as MI355X_MICROARCH.md says), a random 64-byte seen-set
@@ -393,8 +412,8 @@ def main():
             except Exception as e:  # noqa: BLE001
                 traffic, traffic_lower, l2_hit = None, None, None
                 traffic_src = f"none: {e}"
-        kernel_name = {"expand": "k_expand_insert<SpecRaft<3>>" if (a.no_family or a.matrix) else "k_expand_family<SpecRaft<3>>",
-                       "insert": "k_insert", "materialise": "k_materialise<SpecRaft<3>>"}[dom]
+        kernel_name = {"expand": f"k_expand_insert<{STAG}>" if (a.no_family or a.matrix or WORKLOAD["spec"] != "raft") else f"k_expand_family<{STAG}>",
+                       "insert": "k_insert", "materialise": f"k_materialise<{STAG}>"}[dom]
         line["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_lower": traffic_lower, "l2_hit_rate": l2_hit, "traffic_source": traffic_src,
                             "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),

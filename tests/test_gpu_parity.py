@@ -179,14 +179,15 @@ def test_config4_model_one_billion_states_on_one_gpu(amd):
     288 GB can hold whatever the arena policy.  Levels 1-15 (63 297 104 states) equal the exact-dedup oracle's — level 15 is where
     round 2's 64-bit guard mask lost 216 states (AppendEntries of a leader s4 / s5); beyond them the fused engine and the sharded
     engine (mc_shard_run over RCCL at world size 1: route-mode expand, packed exchange with itself, keep) must agree level by level."""
-    c = _golden("raft5_mcr6_t2_m1_levels15")
+    c = _golden("raft5_mcr6_t2_m1_levels18")   # round 4: ALL 18 levels from the exact-dedup oracle (GPU box's host, 274 s) — no count here comes from the GPU
+    assert c["levels"][:15] == _golden("raft5_mcr6_t2_m1_levels15")["levels"] and "oracle_mc" in c["source"]
     params = [5, 6, 2, 5, 1, 1, 18, 1, 4]
-    assert amd.state_bytes("raft", params) == 192
+    assert amd.state_bytes("raft", params) == 192 and c["max_stat"][:3] <= [18, 1, 4]
     eng = amd.Engine("raft", params, table_capacity=3 << 29, arena_capacity=1_300_000_000, chunk_states=1 << 22, max_levels=18, trace=False)
     r = eng.run()
     eng.close()
-    assert r.levels[:15] == c["levels"] and r.verdict == "budget" and r.depth == 18
-    assert r.levels[15:] == [94825875, 228419035, 537499850] and r.distinct == 924041864
+    assert r.levels == c["levels"] and r.verdict == "budget" and r.depth == 18
+    assert (r.distinct, r.generated) == (c["distinct"], c["generated"]) == (924041864, 10345499171)
     from tla_rust_amd.binding import Comm
     comm = Comm(Comm.unique_id(), 0, 1, 0)
     eng = amd.Engine("raft", params, table_capacity=3 << 29, arena_capacity=1_300_000_000, chunk_states=1 << 21, trace=False, shard_rank=0, shard_count=1)
@@ -340,6 +341,17 @@ def test_ssi_4x3_prefix_on_gpu(amd):
     r = eng.run()
     assert r.levels == [1, 4, 32, 264, 2532, 24576, 236844, 2189052, 18810792] and r.verdict == "budget"
     eng.close()
+
+
+def test_ssi_4x3_ten_levels_on_gpu(amd):
+    """BASELINE config 5 to the depth the bench (`--workload ssi4x3`) and profiles/ quote: 10 levels = 168 052 153 states, every
+    per-level count and `generated` from the exact-dedup oracle on the GPU box's host (tests/golden/ssi_levels.json `source`)."""
+    c = json.loads((GOLDEN / "ssi_levels.json").read_text())["cases"][0]
+    assert c["name"] == "ssi_4x3_levels10" and "oracle_mc" in c["source"]
+    eng = amd.Engine("ssi", c["params"], table_capacity=9 << 26, arena_capacity=c["distinct"] + (1 << 20), chunk_states=1 << 21, max_levels=10, trace=False)
+    r = eng.run()
+    eng.close()
+    assert r.levels == c["levels"] and (r.distinct, r.generated, r.verdict) == (c["distinct"], c["generated"], "budget")
 
 
 @pytest.mark.parametrize("case", ["2x3", "3x2", "4x3_prefix"])

@@ -1133,6 +1133,7 @@ static int host_evaluate(const char *tla_path, const char *cfg_path, const mc_co
     res->unchecked_properties = (uint32_t)r.unchecked_properties.size();
     Out o{report, report_cap, 0};
     o.put("Module %s has no GPU lowering: evaluated on the host by the general TLA+ evaluator.\n", module.c_str());
+    o.put("Finished computing initial states: %llu distinct state%s generated.\n", (unsigned long long)r.init_states, r.init_states == 1 ? "" : "s");
     if (!r.unchecked_properties.empty()) {
         // Liveness is out of scope — saying nothing about it is not (Liveness/LiveHourClock.cfg:10 PROPERTIES AlwaysTick AllTimes
         // TypeInvariance: TLC checks all three; here only []HCini is).  The line comes BEFORE the verdict it qualifies.
@@ -1141,7 +1142,6 @@ static int host_evaluate(const char *tla_path, const char *cfg_path, const mc_co
         o.put("Warning: temporal propert%s %s NOT checked: liveness (<>, ~>, WF_ / SF_ fairness) is not supported; only the safety parts of the "
               "PROPERTIES ([]P, [][A]_v, initial predicates) are checked.\n", r.unchecked_properties.size() == 1 ? "y" : "ies", names.c_str());
     }
-    o.put("Finished computing initial states: %llu distinct state%s generated.\n", (unsigned long long)r.init_states, r.init_states == 1 ? "" : "s");
     if (r.verdict == MC_V_OK || r.verdict == MC_V_BUDGET) {
         if (r.verdict == MC_V_OK) o.put("Model checking completed. No error has been found.\n");
         else o.put("Search stopped by the level/state budget; no error has been found so far.\n");
