@@ -58,6 +58,7 @@ WORKLOAD_RAFT5 = dict(spec="raft", params=[5, 6, 2, 5, 1, 1, 18, 1, 4], golden="
 # BASELINE config 5: serializableSnapshotIsolation.tla, TxnId = {T1..T4}, Key = {K1,K2,K3}, every invariant of :59-79 on, no SYMMETRY,
 # level-budgeted: 10 BFS levels = 168 M states (W = 80 B).  Gate: the oracle's per-level counts (tests/golden/ssi_levels.json).
 WORKLOAD_SSI = dict(spec="ssi", params=[4, 3, 127, 0], golden="ssi_4x3_levels10", golden_file="ssi_levels.json", max_levels=10, verdict="budget",
+                    packed_fanout=40, imbalance=1.8,   # (the last level is 87 % of the states and stays where it was generated)
                     metric="distinct states/sec, serializableSnapshotIsolation.tla (4 txns x 3 keys, 10 BFS levels)",
                     name="examples/serializableSnapshotIsolation.tla TxnId=4 Key=3 all invariants (BASELINE config 5), levels 1-10")
 WORKLOADS = {"t3": WORKLOAD_T3, "k10": WORKLOAD, "k11": WORKLOAD_K11, "raft5": WORKLOAD_RAFT5, "ssi4x3": WORKLOAD_SSI}
@@ -248,7 +249,8 @@ def main():
     ap.add_argument("--shard-chunk", type=int, default=0, help="frontier states per round and rank in the sharded (--gpus N) path; 0 = 2^23 at world "
                     "size 1 (one engine launch per round: 168.9 ms per step against 184.1 at 2^21), 2^21 otherwise (several rounds per level, so that "
                     "the exchange of round r+1 overlaps the probes of round r)")
-    ap.add_argument("--packed-fanout", type=int, default=16, help="in-model successors per state the fixed-capacity exchange buckets allow for")
+    ap.add_argument("--packed-fanout", type=int, default=0, help="in-model successors per state the fixed-capacity exchange buckets allow for "
+                    "(0 = the workload's: 16 for the raft models, 40 for the SI model, whose frontier grows 8 x per level)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank on GPU 0 (needs a librccl stand-in in $TLAMC_RCCL; RCCL refuses it)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="t3", help="t3: MaxTerm 3, MaxMsgKeys 8 (525.8 M states, the contract line); "
                     "k10 / k11: MaxTerm 2 with 10 / 11 message keys (102.6 M / 336.6 M states; rounds 1-2's line was k10); raft5: BASELINE config 4 "
@@ -270,6 +272,8 @@ def main():
     WORKLOAD = WORKLOADS[a.workload]
     if not a.table_slots:
         a.table_slots = TABLE_SLOTS[a.workload]
+    if not a.packed_fanout:
+        a.packed_fanout = WORKLOAD.get("packed_fanout", 16)
 
     if a.dense_table:
         os.environ["TLAMC_DENSE_TABLE"] = "1"
@@ -309,7 +313,7 @@ def main():
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, shard_rank=rank, shard_count=world, trace=False,
                          chunk_states=a.shard_chunk, max_distinct=a.max_distinct, table_capacity=(slots * 4 // 3) // world // 64 * 64,
                          # a rank's share of the states (+25 % imbalance allowance) + the replicated prefix
-                         arena_capacity=int(G0["distinct"] / world * 1.25) + (1 << 22))
+                         arena_capacity=int(G0["distinct"] / world * (WORKLOAD.get("imbalance", 1.25) if world > 1 else 1.0)) + (1 << 22))
         stats = {}
 
         def run():

@@ -6,7 +6,7 @@ import json
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "_build" / "libtlamc.so"
+LIB_PATH = Path(os.environ["TLAMC_LIB"]) if os.environ.get("TLAMC_LIB") else PKG / "_build" / "libtlamc.so"   # (TLAMC_LIB: profiling builds, profiles/build_phase_prof.sh)
 
 MC_MAX_LEVELS = 4096
 SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5, "paxos": 6}

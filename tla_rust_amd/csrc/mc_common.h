@@ -45,6 +45,31 @@ struct CWordRef {
     MC_HD uint64_t get(int w) const { return p[(size_t)w * stride]; }
 };
 
+// Writers that re-read a parent row from the arena (Spec::apply*): ask for ALL its words at once, before the first use.  The
+// copy-and-patch code below it reads the row group by group with stores in between (source and destination are the same arena,
+// so the compiler keeps every load behind every earlier store): five or six dependent round trips to L2 / the Infinity Cache
+// per batch of 64 new states, and a wavefront that writes states does little else — the writer was bound by that latency, not
+// by its instructions (round 4: 41 of 152 ms of the expand kernel).  After this pass the groups hit the CU's L1.
+template <class Ref>
+MC_HD void prefetch_row(Ref s, int words) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t acc = 0;
+#pragma unroll
+    for (int w0 = 0; w0 < 64; w0 += 16) {
+        if (w0 < words) {
+            uint64_t t[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) t[u] = s.get(w0 + u < words ? w0 + u : words - 1);
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc ^= t[u];
+        }
+    }
+    asm volatile("" ::"v"((uint32_t)acc), "v"((uint32_t)(acc >> 32)));  // the loads are kept although nothing uses their values
+#else
+    (void)s; (void)words;
+#endif
+}
+
 MC_HD uint64_t fmix64(uint64_t h) {
     h ^= h >> 33;
     h *= 0xff51afd7ed558ccdull;

@@ -1071,6 +1071,7 @@ struct SpecRaft {
     // PATCH the handful of words it changes.
     template <bool KNOWN, class Ref>
     MC_HD static unsigned apply_copy_patch(const Params &prm, Ref s, int slot, uint64_t fp_known, WordRef out) {
+        prefetch_row(s, words(prm));
         Local l;
         l.fp = KNOWN ? 0ull : s.get(W_FP);
         const uint64_t gw = s.get(W_GLOB);
