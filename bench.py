@@ -238,12 +238,40 @@ def cpu_baseline(max_seconds=10.0):
                        f"(a sample stops after the level that exceeds its time; deeper levels have more duplicates per distinct state)")
 
 
+def atomic_add_series(amd, device, n=28, steps=3):
+    """north_star's second workload, in the same line: the synthetic N-process atomic-counter spec (atomic_add.tla:9-21 with N adders +
+    the checker; SURVEY.md 8d config 2's throughput series).  One 64-bit word per state: the 32-byte random seen-set probe IS the
+    workload.  Gate: the closed form D = 2^N + 1, G = N 2^(N-1) + 3, depth N + 2 (counts are not measured, they are checked)."""
+    eng = amd.Engine("atomic_add", [n], device=device, table_capacity=1 << (n + 2), arena_capacity=(1 << n) + 4096, chunk_states=1 << 23,
+                     trace=False, timing=True)
+    eng.run()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = eng.run()
+    dt = (time.perf_counter() - t0) / steps
+    ks = eng.kernel_stats()
+    eng.close()
+    D, G = (1 << n) + 1, n * (1 << (n - 1)) + 3
+    if (r.distinct, r.generated, r.depth, r.verdict) != (D, G, n + 2, "ok"):
+        print(f"bench.py: atomic_add N={n}: got {(r.distinct, r.generated, r.depth, r.verdict)}, the closed form is {(D, G, n + 2, 'ok')}", file=sys.stderr)
+        sys.exit(1)
+    alg = 2 * 8 * D + 8 * G   # SURVEY.md 8d: (2 W + 8 G/D) bytes per distinct state, W = 8
+    return {"workload": f"atomic_add.tla, {n} adders + checker (synthetic throughput series), complete graph", "value": D / dt, "unit": "distinct states/s",
+            "ms_per_step": 1e3 * dt, "steps": steps, "distinct": D, "generated": G, "depth": n + 2, "generated_per_s": G / dt,
+            "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dt / 1e9 / HBM_PEAK_GBS,
+                         "alg_bytes": "(2 x 8 + 8 x G/D) bytes per distinct state over the wall time of a step",
+                         "probe_GBs_at_32B": 32 * G / dt / 1e9,   # what the probes really move: a 32-byte bucket each
+                         "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")}},
+            "golden": "closed form 2^N + 1 / N 2^(N-1) + 3 / depth N + 2 (tests/test_oracle_golden.py: equal to the oracle for N <= 16)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)   # 40 complete BFS runs of 50 ms: two seconds of GPU work in the timed region
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-atomic-add", action="store_true", help="skip the synthetic N-process atomic-counter object of the line")
     ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
     ap.add_argument("--chunk", type=int, default=1 << 23)   # frontier states per launch (the engine's maximum: 160.5 ms per step against 163.6 at 2^22, 169.4 at 2^21)
     ap.add_argument("--shard-chunk", type=int, default=0, help="frontier states per round and rank in the sharded (--gpus N) path; 0 = 2^23 at world "
@@ -263,6 +291,7 @@ def main():
     ap.add_argument("--dense-table", action="store_true", help="A/B: 64-byte (8-slot) seen-set buckets even when the table is sparse enough for 32-byte probes")
     ap.add_argument("--occ3", action="store_true", help="A/B: by-family expand kernel compiled for 3 waves per SIMD (no register spills)")
     ap.add_argument("--no-filter", action="store_true", help="A/B: without the per-wavefront duplicate filter in front of the seen-set")
+    ap.add_argument("--wave-tail", action="store_true", help="A/B: in-wave writes by wavefront (no workgroup barrier) instead of by workgroup")
     ap.add_argument("--no-inwave", action="store_true", help="A/B: every new state through the new-list and k_materialise (rounds 1-3) instead of "
                     "being written by the expand wavefront that found it")
     a = ap.parse_args()
@@ -299,7 +328,7 @@ def main():
     comm = store = None
     if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=slots, matrix=a.matrix,
-                         debug_flags=(32 if a.no_family else 0) | (2048 if a.occ3 else 0) | (8192 if a.no_filter else 0) | (65536 if a.no_inwave else 0),
+                         debug_flags=(32 if a.no_family else 0) | (2048 if a.occ3 else 0) | (8192 if a.no_filter else 0) | (65536 if a.no_inwave else 0) | (131072 if a.wave_tail else 0),
                          arena_capacity=G0["distinct"] + (1 << 20), max_levels=ML,
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run
@@ -434,6 +463,9 @@ def main():
                             "pipeline_GBs": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9,
                             "pipeline_frac": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
                             "state_bytes": W}
+        if not a.no_atomic_add and not a.max_distinct and a.workload == "t3":   # (the contract line carries both of north_star's workloads)
+            eng.close()
+            line["atomic_add"] = atomic_add_series(amd, local)
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     print(json.dumps(line), flush=True)

@@ -86,6 +86,7 @@ typedef struct {
 #define MC_F_OCC3 2048u      /* A/B only: the by-family expand kernel compiled for 3 wavefronts per SIMD (146 VGPRs, no spills) instead of 4 */
 #define MC_F_NOINWAVE 65536u /* A/B only: every new state through the new-list and k_materialise (rounds 1-3) instead of being written by
                                 the expand wavefront that found it (round 4; by-family kernels of a fused run) */
+#define MC_F_WAVETAIL 131072u /* A/B only: in-wave writes by wavefront (no workgroup barrier) instead of by workgroup */
 #define MC_F_NOFILTER 8192u  /* A/B only: by-family expand kernel without the per-wavefront duplicate filter in front of the seen-set */
 #define MC_F_PROGRESS 16384u /* mc_check_files: print TLC's "Progress(d): ..." lines (testout2:4-259) to stdout while the search runs,
                               * at most one per second */

@@ -1064,6 +1064,58 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         // filters of the wavefronts): no LDS beyond the generation phase's.
         MC_PROF(4);
         constexpr int NCLS = SlotClasses<S>::value;
+        if (flags & MC_F_WAVETAIL) {
+            // A/B: the tail by WAVEFRONT — no barrier (nobody waits for the slowest wavefront of the workgroup), one atomicAdd per
+            // wavefront, the wavefront's own 64-100 survivors sorted by class (a batch still holds about half of the classes)
+            MC_PROF(16);
+            uint16_t *order = reinterpret_cast<uint16_t *>(FL.filt);  // this wavefront's own filter: dead, its generation is over
+            unsigned ccnt[NCLS];
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
+            for (unsigned t = 0; t < on; t += 64) {
+                const bool valid = t + lane < on;
+                const int cls = valid ? SlotClasses<S>::of((int)(Q.o_ent[(ohead + t + lane) & (OCAP - 1)] >> 6)) : -1;
+#pragma unroll
+                for (int c = 0; c < NCLS; ++c) ccnt[c] += (unsigned)__popcll(__ballot(cls == c));
+            }
+            {
+                unsigned run = 0;
+#pragma unroll
+                for (int c = 0; c < NCLS; ++c) { const unsigned n = ccnt[c]; ccnt[c] = run; run += n; }
+            }
+            wave_lds_fence();
+            for (unsigned t = 0; t < on; t += 64) {
+                const bool valid = t + lane < on;
+                const unsigned k = (ohead + t + lane) & (OCAP - 1);
+                const int cls = valid ? SlotClasses<S>::of((int)(Q.o_ent[k] >> 6)) : -1;
+#pragma unroll
+                for (int c = 0; c < NCLS; ++c) {
+                    const unsigned long long b = __ballot(cls == c);
+                    if (cls == c) order[ccnt[c] + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)k;
+                    ccnt[c] += (unsigned)__popcll(b);
+                }
+            }
+            wave_lds_fence();
+            MC_PROF(17);
+            if (on) {
+                unsigned long long out0 = 0;
+                if (lane == 0) out0 = atomicAdd(&ctr->arena_next, (unsigned long long)on);
+                out0 = __shfl(out0, 0);
+                if (out0 + on > rt.arena_cap) {
+                    err |= DEV_EARENA;
+                } else {
+                    for (unsigned t = 0; t < on; t += 64) {
+                        const bool mine = t + lane < on;
+                        const unsigned k = mine ? order[t + lane] : 0u;
+                        const unsigned e = mine ? Q.o_ent[k] : 0u;
+                        const uint64_t sfp = mine ? Q.o_fp[k] : 0ull;
+                        const uint64_t pidx = wave_idx0 + (e & 63u), oidx = out0 + t + lane;
+                        wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx);
+                        if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
+                    }
+                }
+            }
+        } else {
         static_assert(NCLS * 4 <= 64, "one lane per (class, wavefront) in the prefix sum");
         static_assert(4 * OCAP * sizeof(uint16_t) <= sizeof(fls[0].filt) && OCAP <= 256, "the sorted order aliases one duplicate filter");
         uint16_t *order = reinterpret_cast<uint16_t *>(fls[0].filt);        // [4 * OCAP]: (wavefront << 8) | position in its list
@@ -1071,6 +1123,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         unsigned long long *wg_out0 = reinterpret_cast<unsigned long long *>(fls[2].filt);
         const unsigned w = threadIdx.x >> 6;
         __syncthreads();  // (1) no wavefront of the workgroup generates any more: the filters are free, the lists final
+        MC_PROF(16);      // (profiling builds: 4 = waiting at barrier (1), 16 = the counting sort, 17 = the writes)
         unsigned ccnt[NCLS];
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
@@ -1102,6 +1155,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             }
         }
         __syncthreads();  // (3) the order and the workgroup's first arena index are visible
+        MC_PROF(17);
         const unsigned long long out0 = *wg_out0;
         if (total && out0 + total > rt.arena_cap) {
             err |= DEV_EARENA;
@@ -1117,6 +1171,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
             }
         }
+        }  // (workgroup tail)
     } else if (on) {
         flush_out(on);
     }
