@@ -1077,13 +1077,11 @@ struct SpecRaft {
         const uint64_t gw = s.get(W_GLOB);
         l.glob = gw & 0xffffffffull;
         l.clog = gw >> 32;
-        uint64_t vw[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) {
             const uint64_t x = s.get(W_SRV(i));
             l.sv.set(i, x & SVMASK);
             l.log.set(i, (uint32_t)(x >> LOGSH));
-            vw[i] = s.get(W_VL(i));
         }
         l.nm = g_nm(l.glob);
         l.inflight = 0;
@@ -1124,21 +1122,11 @@ struct SpecRaft {
             for (int q = 0; q < EL_WORDS; q++) out.set(wel + e * EL_WORDS + q, e < ne ? x[q] : 0ull);
         }
         // allLogs: four 16-bit slots per word; the successor's additions (the same for every successor of this parent,
-        // raft.tla:493) go to slots na, na + 1, ... — the words are assembled in registers and written once
-        unsigned present = 0;
+        // raft.tla:493) go to slots na, na + 1, ...  The words are NOT kept in registers across the action (16 words = 32
+        // VGPRs of a writer that already wants more than the 128 it gets inside the expand kernel: round 4): read here for
+        // the membership test, read again (the CU's L1) when they are written at the end.
         const int na = g_na(l.glob), wall = W_ALL0(prm), naw = all_words(prm);
-        uint64_t aw[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) aw[q] = 0;
-        for (int q0 = 0; q0 < naw; q0 += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) if (q0 + u < naw) aw[q0 + u] = (q0 + u) * 4 < na ? s.get(wall + q0 + u) : 0ull;
-        }
-        for (int a = 0; a < na; a++) {
-            const uint64_t x = (aw[a >> 2] >> (16 * (a & 3))) & 0xffffull;
-#pragma unroll
-            for (int i = 0; i < NS; i++) if (x == l.log.get(i)) present |= 1u << i;
-        }
+        const unsigned present = all_present(prm, s, l, na);
         l.vany = 0;
         finish_local<!KNOWN>(prm, l, present);
         // ---- the action
@@ -1149,21 +1137,27 @@ struct SpecRaft {
             out.set(W_FP, s.get(W_FP));
             out.set(W_GLOB, gw);
 #pragma unroll
-            for (int i = 0; i < NS; i++) { out.set(W_SRV(i), pack_srv(l.sv.get(i), l.log.get(i))); out.set(W_VL(i), vw[i]); }
-            for (int q = 0; q < naw; q++) out.set(wall + q, aw[q]);
+            for (int i = 0; i < NS; i++) { out.set(W_SRV(i), s.get(W_SRV(i))); out.set(W_VL(i), s.get(W_VL(i))); }
+            for (int q = 0; q < naw; q++) out.set(wall + q, q * 4 < na ? s.get(wall + q) : 0ull);
             return st;
         }
         // ---- patch
         out.set(W_FP, KNOWN ? fp_known : delta_fp(prm, l, s, d));
         out.set(W_GLOB, pack_glob(d.glob, d.clog));
+        {   // the servers' words: re-read from the parent row (the CU's L1: the row was asked for at the top) instead of being kept
+            // in registers across the action — the writer has 120 VGPRs inside the expand kernel
+            uint64_t sw2[NS], vw2[NS];
 #pragma unroll
-        for (int i = 0; i < NS; i++) {
-            const bool me = i == d.srv;
-            out.set(W_SRV(i), pack_srv(me ? d.sv : l.sv.get(i), me ? d.log : l.log.get(i)));
-            uint64_t v = vw[i];
-            if (me && d.vmode == 1) v = 0;
-            if (me && d.vmode == 2) v = vl_set(v, d.vj, d.vlog, prm);
-            out.set(W_VL(i), v);
+            for (int i = 0; i < NS; i++) { sw2[i] = s.get(W_SRV(i)); vw2[i] = s.get(W_VL(i)); }
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const bool me = i == d.srv;
+                out.set(W_SRV(i), me ? pack_srv(d.sv, d.log) : sw2[i]);
+                uint64_t v = vw2[i];
+                if (me && d.vmode == 1) v = 0;
+                if (me && d.vmode == 2) v = vl_set(v, d.vj, d.vlog, prm);
+                out.set(W_VL(i), v);
+            }
         }
         {   // the one or two message slots the action rewrites: read-modify-write of their (parent) words; both may share a word
             const int wa = d.midxA >> 1, wb = d.midxB >> 1;
@@ -1179,17 +1173,17 @@ struct SpecRaft {
 #pragma unroll
             for (int q = 0; q < EL_WORDS; q++) out.set(wel + ne * EL_WORDS + q, d.ew.get(q));
         }
-        int pos = na;
+        for (int q = 0; q < naw; q++) {  // one word at a time: the parent's slots of the word + the additions that fall into it
+            uint64_t x = q * 4 < na ? s.get(wall + q) : 0ull;
+            int pos = na;
 #pragma unroll
-        for (int i = 0; i < NS; i++)
-            if (l.addmask >> i & 1) {
-                if (pos < prm.ca) {
-#pragma unroll
-                    for (int q = 0; q < 16; q++) if (q == (pos >> 2)) aw[q] |= (uint64_t)l.log.get(i) << (16 * (pos & 3));
+            for (int i = 0; i < NS; i++)
+                if (l.addmask >> i & 1) {
+                    if (pos < prm.ca && (pos >> 2) == q) x |= (uint64_t)l.log.get(i) << (16 * (pos & 3));
+                    pos++;
                 }
-                pos++;
-            }
-        for (int q = 0; q < naw; q++) out.set(wall + q, aw[q]);
+            out.set(wall + q, x);
+        }
         return st;
     }
 
