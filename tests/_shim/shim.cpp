@@ -153,6 +153,15 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
                 S::apply_known_fp(p, s, slot, f1, WordRef{c, 1});
                 if (memcmp(a, c, sizeof(uint64_t) * (size_t)S::words(p)) != 0) bad++;
             }
+            if ((st0 & ST_ENABLED) && !(st0 & (ST_OUT_OF_MODEL | ST_OVERFLOW | ST_SPECERR | ST_ASSERT | ST_SELFLOOP))) {
+                // the in-wave writer of the expand kernel (round 4): row copy + action + patch, starting from the parent's Summary
+                // — EVERY kind of slot, word for word what apply() writes
+                uint64_t a[S::MAX_WORDS], c[S::MAX_WORDS];
+                S::apply(p, s, slot, WordRef{a, 1});
+                for (int w = 0; w < S::MAX_WORDS; w++) c[w] = 0xdeadbeefdeadbeefull;
+                S::apply_summary_patch(p, q, s, slot, f0, WordRef{c, 1});
+                if (memcmp(a, c, sizeof(uint64_t) * (size_t)S::words(p)) != 0) bad++;
+            }
             if (fam >= 0) cnt[fam]++;
         }
         if (stats().on) stats().state_done(cnt);

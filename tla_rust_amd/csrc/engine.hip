@@ -655,27 +655,33 @@ __device__ __forceinline__ T wave_uniform_copy(const T &v) {
     __builtin_memcpy(&r, w, sizeof(T));
     return r;
 }
+// specs whose writer starts from what the parent's lane derived (S::Summary in LDS) instead of walking the row again
+template <class S, class = void>
+struct HasSummaryWriter : std::false_type {};
+template <class S>
+struct HasSummaryWriter<S, decltype((void)S::SUMMARY_WRITER)> : std::true_type {};
 template <class S>
 __device__ __noinline__ void wave_write_survivors(typename S::Params prm_v, const uint64_t *arena_v, uint64_t pidx, bool mine, unsigned slot, uint64_t fp,
-                                                  uint64_t *arena_w_v, uint64_t oidx) {
+                                                  uint64_t *arena_w_v, uint64_t oidx, typename S::Summary q) {
     const typename S::Params prm = wave_uniform_copy(prm_v);
     const uint64_t *arena = (const uint64_t *)uniform_ptr(arena_v);
     uint64_t *arena_w = (uint64_t *)uniform_ptr(arena_w_v);
     if (!mine) return;
     const int W = S::words(prm);
     const CWordRef sp = arena_cref(arena, pidx, W);
-    if constexpr (HasKnownFp<S>::value) S::apply_known_fp(prm, sp, (int)slot, fp, arena_ref(arena_w, oidx, W));
+    if constexpr (HasSummaryWriter<S>::value) S::apply_summary_patch(prm, q, sp, (int)slot, fp, arena_ref(arena_w, oidx, W));
+    else if constexpr (HasKnownFp<S>::value) S::apply_known_fp(prm, sp, (int)slot, fp, arena_ref(arena_w, oidx, W));
     else S::apply(prm, sp, (int)slot, arena_ref(arena_w, oidx, W));
 }
 // classes of action slots whose successor construction shares a code path (S::NCLS, S::slot_class): the workgroup's tail sorts
 // its survivors by class, so that the 64 lanes of a batch walk one or two branches of the writer instead of all of them
 template <class S, class = void>
 struct SlotClasses : std::integral_constant<int, 1> {
-    __device__ static int of(int) { return 0; }
+    __device__ __forceinline__ static int of(int) { return 0; }
 };
 template <class S>
 struct SlotClasses<S, decltype((void)S::NCLS)> : std::integral_constant<int, S::NCLS> {
-    __device__ static int of(int slot) { return S::slot_class(slot); }
+    __device__ __forceinline__ static int of(int slot) { return S::slot_class(slot); }
 };
 
 // Probe ring and survivor list of a by-family wavefront.  An entry names its (parent, slot) pair inside the wavefront's own
@@ -1110,7 +1116,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                         const unsigned e = mine ? Q.o_ent[k] : 0u;
                         const uint64_t sfp = mine ? Q.o_fp[k] : 0ull;
                         const uint64_t pidx = wave_idx0 + (e & 63u), oidx = out0 + t + lane;
-                        wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx);
+                        wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx, FL.sum[e & 63u]);
                         if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
                     }
                 }
@@ -1167,7 +1173,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 const unsigned e = mine ? wq[ref >> 8].o_ent[ref & 255u] : 0u;
                 const uint64_t sfp = mine ? wq[ref >> 8].o_fp[ref & 255u] : 0ull;
                 const uint64_t pidx = wg_idx0 + (ref >> 8) * 64u + (e & 63u), oidx = out0 + bt + lane;
-                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx);
+                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx, fls[ref >> 8].sum[e & 63u]);
                 if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
             }
         }

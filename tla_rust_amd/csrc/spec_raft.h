@@ -1187,6 +1187,75 @@ struct SpecRaft {
         return st;
     }
 
+    // The in-wave writer (round 4: the expand wavefront that found a new state writes it; engine.hip wave_write_survivors).  The
+    // parent was expanded by this very workgroup: what its lane derived from the row — in-flight count, key signatures, allLogs'
+    // additions — still lies in LDS (Summary), so the writer does NOT walk the message bag and allLogs a second time as
+    // apply_copy_patch does for k_materialise.  It (1) copies the row verbatim, all words asked for before the first is used
+    // (one round trip to L2 / the Infinity Cache), (2) evaluates the action, (3) overwrites the handful of words it changes;
+    // stores of one wavefront to one address stay in order.  About half the instructions of apply_copy_patch.
+    static constexpr bool SUMMARY_WRITER = true;
+    template <class Ref>
+    MC_HD static unsigned apply_summary_patch(const Params &prm, const Summary &q, Ref s, int slot, uint64_t fp_nz, WordRef out) {
+        const int W = words(prm);
+        {
+            uint64_t t[16];
+#pragma unroll
+            for (int w0 = 0; w0 < MAX_WORDS; w0 += 16) {
+                if (w0 < W) {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) t[u] = s.get(w0 + u < W ? w0 + u : W - 1);
+#pragma unroll
+                    for (int u = 0; u < 16; u++) if (w0 + u < W) out.set(w0 + u, t[u]);
+                }
+            }
+        }
+        Local l;
+        local_of_summary<-1>(q, s, l);
+        Delta d;
+        int action;
+        const unsigned st = compute<true>(prm, l, s, slot, d, action);
+        if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) return st;  // not a successor: the parent itself (never the case for a survivor)
+        // the fingerprint arrives with the survivor; the one ambiguous value (raw sum 0 or the substitute itself) is recomputed
+        out.set(W_FP, fp_nz != fp_nonzero(0) ? fp_nz : delta_fp(prm, l, s, d));
+        out.set(W_GLOB, pack_glob(d.glob, d.clog));
+        if (d.srv >= 0) {
+            out.set(W_SRV(d.srv), pack_srv(d.sv, d.log));
+            if (d.vmode == 1) out.set(W_VL(d.srv), 0ull);
+            else if (d.vmode == 2) out.set(W_VL(d.srv), vl_set(s.get(W_VL(d.srv)), d.vj, d.vlog, prm));
+        }
+        {   // the one or two message slots the action rewrites (both may share a word)
+            const int wa = d.midxA >> 1, wb = d.midxB >> 1;
+            if (d.nmop & 1) {
+                uint64_t x = 2 * wa < l.nm ? s.get(W_MSG0 + wa) : 0ull;
+                x = set_half(x, d.midxA, d.mnewA);
+                if ((d.nmop & 2) && wb == wa) x = set_half(x, d.midxB, d.mnewB);
+                out.set(W_MSG0 + wa, x);
+            }
+            if ((d.nmop & 2) && !((d.nmop & 1) && wb == wa)) out.set(W_MSG0 + wb, set_half(s.get(W_MSG0 + wb), d.midxB, d.mnewB));
+        }
+        if (d.eadd) {
+            const int ne = g_ne(l.glob), wel = W_EL0(prm);
+#pragma unroll
+            for (int e = 0; e < EL_WORDS; e++) out.set(wel + ne * EL_WORDS + e, d.ew.get(e));
+        }
+        if (l.nadd) {  // allLogs' additions (the same for every successor of this parent) land in slots na, na + 1, ...
+            const int na = g_na(l.glob), wall = W_ALL0(prm);
+            const int qlo = na >> 2, qhi = (na + l.nadd - 1) >> 2;
+            for (int qq = qlo; qq <= qhi && qq < all_words(prm); qq++) {
+                uint64_t x = qq * 4 < na ? s.get(wall + qq) : 0ull;
+                int pos = na;
+#pragma unroll
+                for (int i = 0; i < NS; i++)
+                    if (l.addmask >> i & 1) {
+                        if (pos < prm.ca && (pos >> 2) == qq) x |= (uint64_t)rd_log(s, i) << (16 * (pos & 3));
+                        pos++;
+                    }
+                out.set(wall + qq, x);
+            }
+        }
+        return st;
+    }
+
     // ---------------------------------------------------------------- host side: names and text
     static int action_of(const Params &prm, const uint64_t *parent, int slot) {
         Local l;
