@@ -389,6 +389,13 @@ struct RouteArgs {
     uint16_t *pslot = nullptr;
 };
 
+// specs that ask for a per-wavefront duplicate filter in front of the seen-set in the slot-by-slot kernel (S::WAVE_FILTER
+// entries, a power of two; see k_expand_family's filter): a candidate found there was queued — hence probed — by this wavefront
+template <class S, class = void>
+struct WaveFilter : std::integral_constant<int, 0> {};
+template <class S>
+struct WaveFilter<S, decltype((void)S::WAVE_FILTER)> : std::integral_constant<int, S::WAVE_FILTER> {};
+
 template <class S, bool ROUTE>
 __global__ void __launch_bounds__(256)
 k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
@@ -396,6 +403,8 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 RouteArgs rt, unsigned parity) {
     __shared__ WaveQueues wq[4];
     __shared__ uint64_t stage[4][S::STAGE_WORDS > 0 ? S::STAGE_WORDS : 1][64];
+    constexpr int WF = WaveFilter<S>::value;
+    __shared__ uint64_t wfilt[4][WF > 0 ? WF : 1];
     if (rt.lc) {
         if (rt.lc->stop) return;
         lo = rt.lc->lo;
@@ -404,9 +413,15 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     }
     const unsigned lane = threadIdx.x & 63;
     WaveQueues &Q = wq[threadIdx.x >> 6];
+    uint64_t *const filt = wfilt[threadIdx.x >> 6];
     const uint64_t base = lo & ~63ull;
     const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncols) return;  // whole wavefronts leave together (ncols % 64 == 0)
+    if constexpr (WF > 0) {
+#pragma unroll
+        for (int t = 0; t < WF / 64; ++t) filt[t * 64 + lane] = 0;  // fingerprint 0 is never a candidate
+        wave_lds_fence();
+    }
     const uint64_t idx = base + col;
     const bool active = idx >= lo && idx < hi;
     const CWordRef g = arena_cref(arena, idx, S::words(prm));
@@ -544,6 +559,13 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                     if (st & ST_INVARIANT) viol = min(viol, viol_key(idx, (unsigned)slot, VK_INVARIANT, st >> 8));
                     if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) fp = f;
                 }
+            }
+        }
+        if constexpr (WF > 0) {
+            if (fp && !(flags & 8192u)) {  // 8192 = A/B: no duplicate filter
+                const unsigned h = (unsigned)(fp >> 20) & (unsigned)(WF - 1);
+                if (filt[h] == fp) fp = 0;  // this wavefront has queued it before
+                else filt[h] = fp;
             }
         }
         const unsigned long long b = __ballot(fp != 0);
