@@ -339,6 +339,11 @@ typedef struct {
     uint32_t reserved;
     mc_shard_stats *stats;    /* NULL or where to put this rank's loop statistics                                            */
 } mc_shard_opts;
+/* TEST-ONLY hooks of this part of the library (a one-GPU lab has no second device): the environment variable TLAMC_RCCL names the
+ * file dlopen()ed instead of /opt/rocm/lib/librccl.so (tests/_fakerccl: the nine nccl* entry points over POSIX shared memory, so
+ * that P ranks can share ONE device — RCCL itself refuses two ranks on a device); `mc X.tla -gpus P -samedevice` and
+ * `bench.py --gpus N --share-gpu` put every rank on device 0 for it.  None of them belongs in a deployment: without TLAMC_RCCL
+ * the real RCCL is loaded, and a run through the stand-in says so in its report / bench line ("NOT_A_MEASUREMENT"). */
 int mc_comm_unique_id(uint8_t id_out[MC_COMM_ID_BYTES]);
 int mc_comm_create(const uint8_t id[MC_COMM_ID_BYTES], uint32_t rank, uint32_t world, int32_t device, mc_comm **out);
 void mc_comm_destroy(mc_comm *c);
