@@ -1964,9 +1964,11 @@ struct Engine : EngineBase {
                                d_inittmp, d_cand, ncols, d_nsl, d_ctr, 0u, 1u);  // run() is never owner-filtered
             finish_chunk<true>(first, ncols, 1);
         }
-        // from here on every writer takes its arena indices from arena_next itself (DevCounters::atomic_alloc); Init above and
-        // the candidate-matrix form append in stream order
-        if (!use_matrix) hipLaunchKernelGGL(k_set_alloc_mode, dim3(1), dim3(1), 0, stream, d_ctr, 1u);
+        // with in-wave writes every writer takes its arena indices from arena_next itself from here on (DevCounters::atomic_alloc).
+        // Init above, the candidate-matrix form and every spec whose states all go through k_materialise keep appending in stream
+        // order: one returning atomicAdd per wavefront of k_materialise on ONE word is pure cost there (atomic_add N = 28: 145
+        // against 108 ms per run, profiles/r04h / r04i; raft through k_materialise only: 203 against 159 ms)
+        if (inwave_ok()) hipLaunchKernelGGL(k_set_alloc_mode, dim3(1), dim3(1), 0, stream, d_ctr, 1u);
         int rc = read_counters();
         if (rc) return rc;
         if ((rc = check_dev_error())) return rc;
@@ -2415,10 +2417,18 @@ struct Engine : EngineBase {
         HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_scan_tmp, need, in, d_incl, (int)n, on));
         return MC_OK;
     }
+    // a sharded run that failed mid-level (a full route bucket, MC_ETABLEFULL ...) leaves its slots as they were: the remedy the
+    // error message names — run the same engine again with a larger allowance — must not trip over an expand "still in flight"
+    void shard_reset_slots() {
+        hipSetDevice(cfg.device);
+        hipDeviceSynchronize();  // (whatever the failed run left on the streams has drained; its events are complete)
+        for (auto &q : sl) { q.launched = false; q.keep_pending = false; q.pend_total = 0; q.moved = 0; q.count = 0; }
+    }
     int shard_begin() override {
         if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
         sh_dup = 0;
         sh_resume = sh_ck_ok = false;
+        shard_reset_slots();
         HIP_TRY(hipSetDevice(cfg.device));
         memset(kstat, 0, sizeof kstat);
         HIP_TRY(hipMemsetAsync(d_table, 0, table_cap * sizeof(uint64_t), stream));
@@ -2453,6 +2463,7 @@ struct Engine : EngineBase {
         if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
         mc_result &res = *prefix_res;  // large (level table): not on the stack, and not shared between engines / threads
         sh_resume = sh_ck_ok = false;
+        shard_reset_slots();
         const uint64_t saved_md = cfg.max_distinct, saved_ml = cfg.max_levels;
         cfg.max_distinct = max_distinct;  // the whole job's budgets: the prefix stops where the single-GPU run would
         cfg.max_levels = max_levels;
