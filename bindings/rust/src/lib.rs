@@ -69,7 +69,9 @@ extern "C" {
 }
 
 #[derive(Debug)]
-pub struct Outcome { pub distinct: u64, pub generated: u64, pub depth: u32, pub verdict: i32, pub host_evaluated: bool, pub report: String }
+pub struct Outcome { pub distinct: u64, pub generated: u64, pub depth: u32, pub verdict: i32, pub host_evaluated: bool,
+                     /// cfg PROPERTIES with a liveness part that were NOT checked (named in the report's "Warning:" line)
+                     pub unchecked_properties: u32, pub report: String }
 
 /// `tlc X.tla` (reference Makefile:6-7) from Rust.
 pub fn check(tla: &std::path::Path, device: i32) -> Result<Outcome, String> {
@@ -83,7 +85,7 @@ pub fn check(tla: &std::path::Path, device: i32) -> Result<Outcome, String> {
         return Err(unsafe { CStr::from_ptr(mc_last_error()) }.to_string_lossy().into_owned());
     }
     let end = buf.iter().position(|&b| b == 0).unwrap_or(0);
-    Ok(Outcome { distinct: res.distinct, generated: res.generated, depth: res.depth, verdict: res.verdict, host_evaluated: res.host_evaluated != 0,
+    Ok(Outcome { distinct: res.distinct, generated: res.generated, depth: res.depth, verdict: res.verdict, host_evaluated: res.host_evaluated != 0, unchecked_properties: res.unchecked_properties,
                  report: String::from_utf8_lossy(&buf[..end]).into_owned() })
 }
 

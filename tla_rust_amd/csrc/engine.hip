@@ -1534,8 +1534,8 @@ static __global__ void k_bump_arena_next(DevCounters *ctr, const uint32_t *n_dev
 static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
     unsigned long long n = 0;
     for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[parity * NSHARD + t].v; ctr->n_new[parity * NSHARD + t].v = 0; }
-    if (ctr->atomic_alloc) ctr->via_list += n;  // (k_materialise took the indices itself)
-    else ctr->arena_next += n;
+    ctr->via_list += n;
+    if (!ctr->atomic_alloc) ctr->arena_next += n;  // (atomic_alloc: k_materialise took the indices itself)
     ctr->max_slots = 0;
 }
 
@@ -1593,8 +1593,8 @@ static __global__ void k_end_level(DevCounters *ctr, LevelCtl *lc) {
     {  // k_commit of new-list parity 0, folded in (one launch less per level)
         unsigned long long n = 0;
         for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; }
-        if (ctr->atomic_alloc) ctr->via_list += n;
-        else ctr->arena_next += n;
+        ctr->via_list += n;
+        if (!ctr->atomic_alloc) ctr->arena_next += n;
         ctr->max_slots = 0;
     }
     const unsigned long long hi_new = ctr->arena_next;
@@ -1848,6 +1848,7 @@ struct Engine : EngineBase {
     bool use_matrix = false;
     // fused runs of a by-family spec: the expand wavefronts write their own survivors (MC_F_NOINWAVE = A/B: everything through the
     // new-list and k_materialise, as in rounds 1-3)
+    double inwave_growth_limit = getenv("TLAMC_INWAVE_GROWTH") ? atof(getenv("TLAMC_INWAVE_GROWTH")) : 1.7;  // (A/B knob)
     bool inwave_ok() const { return UsesFamilies<S>::value && !use_matrix && !(cfg.flags & (MC_F_NOFAMILY | MC_F_NOINWAVE)); }
     void set_inwave(RouteArgs &rt) const {
         if (!inwave_ok()) return;
@@ -1969,6 +1970,8 @@ struct Engine : EngineBase {
         // order: one returning atomicAdd per wavefront of k_materialise on ONE word is pure cost there (atomic_add N = 28: 145
         // against 108 ms per run, profiles/r04h / r04i; raft through k_materialise only: 203 against 159 ms)
         if (inwave_ok()) hipLaunchKernelGGL(k_set_alloc_mode, dim3(1), dim3(1), 0, stream, d_ctr, 1u);
+        bool alloc_atomic = inwave_ok();
+        uint64_t prev_frontier = ~0ull >> 12;  // (the first level is never "fast growing")
         int rc = read_counters();
         if (rc) return rc;
         if ((rc = check_dev_error())) return rc;
@@ -2002,6 +2005,10 @@ struct Engine : EngineBase {
                 h_lc->levels_left = cfg.max_levels ? (unsigned)(cfg.max_levels - level) : 0u;
                 HIP_TRY(hipMemcpyAsync(d_lc, h_lc, sizeof *h_lc, hipMemcpyHostToDevice, stream));
                 HIP_TRY(hipStreamSynchronize(stream2));  // (nothing of an earlier level is still being materialised)
+                if (inwave_ok() && !alloc_atomic) {  // the batched small levels always write in-wave
+                    hipLaunchKernelGGL(k_set_alloc_mode, dim3(1), dim3(1), 0, stream, d_ctr, 1u);
+                    alloc_atomic = true;
+                }
                 for (int k = 0; k < BLIND_BATCH; k++) enqueue_blind_level(blind_max);
                 HIP_TRY(hipMemcpyAsync(h_lc, d_lc, sizeof *h_lc, hipMemcpyDeviceToHost, stream));
                 if ((rc = read_counters())) return rc;
@@ -2018,8 +2025,20 @@ struct Engine : EngineBase {
                     if (level >= MC_MAX_LEVELS) { set_error("too many BFS levels"); return MC_EBADCFG; }
                 }
                 progress(level, lo, hi);
+                prev_frontier = hi > lo ? hi - lo : 1;
                 continue;  // the loop head re-checks violation / budgets / frontier with the host's copies
             }
+            // IN-WAVE WRITES, level by level: they pay where a wavefront has about one survivor per parent (its list holds them
+            // all, one workgroup tail per 256 parents); in a level that grows fast (config 4's model: x 2.4 on every one of its 18
+            // levels) most survivors overflow into the new-list anyway and k_materialise alone is the better writer (924 M states:
+            // 234.7 against 239.0 ms, profiles/r04k).  The level before this one says which kind it is; the allocation mode
+            // (DevCounters::atomic_alloc) follows — nothing is in flight between two levels.
+            const bool lvl_inwave = inwave_ok() && (double)(hi - lo) <= inwave_growth_limit * (double)prev_frontier;
+            if (inwave_ok() && lvl_inwave != alloc_atomic) {
+                hipLaunchKernelGGL(k_set_alloc_mode, dim3(1), dim3(1), 0, stream, d_ctr, lvl_inwave ? 1u : 0u);
+                alloc_atomic = lvl_inwave;
+            }
+            prev_frontier = hi - lo;
             unsigned chunk_no = 0;
             for (uint64_t c0 = lo; c0 < hi; ++chunk_no) {
                 const unsigned parity = chunk_no & 1u;
@@ -2037,7 +2056,7 @@ struct Engine : EngineBase {
                     if (chunk_no >= 2) hipStreamWaitEvent(stream, ev_m[parity], 0);  // new-list `parity` is free again
                     RouteArgs rt_new{};
                     rt_new.new_fp = d_newfp;
-                    set_inwave(rt_new);
+                    if (lvl_inwave) set_inwave(rt_new);
                     const unsigned sg = slices_for(ncols, false);
                     const bool dl = sg > 1 && (cfg.flags & MC_F_DEADLOCK);
                     if (dl) { rt_new.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), stream); }
@@ -2076,8 +2095,8 @@ struct Engine : EngineBase {
         for (int t = 0; t < NSHARD; t++) { out->generated += h_ctr->generated[t].v; kstat_cells += h_ctr->cells[t].v; }
         last_generated = out->generated;
         // (a resumed run counts from the checkpoint on: via_list starts at 0 there)
-        kstat_inwave = inwave_ok() && h_ctr->arena_next >= h_ctr->via_list + (resuming ? ck_distinct : out->level_distinct[0])
-                           ? h_ctr->arena_next - h_ctr->via_list - (resuming ? ck_distinct : out->level_distinct[0]) : 0;
+        kstat_inwave = inwave_ok() && h_ctr->arena_next >= h_ctr->via_list + (resuming ? ck_distinct : 0)
+                           ? h_ctr->arena_next - h_ctr->via_list - (resuming ? ck_distinct : 0) : 0;  // (Init's states went through the list too)
         have_run = true;
         out->queue_left = hi - lo;
         out->depth = level;
