@@ -132,6 +132,10 @@ struct FamCheck<S, decltype((void)S::NFAM)> {
         for (int slot = 0; slot < ns; slot++) {
             uint64_t f0 = 0, f1 = 0;
             const unsigned st0 = S::eval(p, l, s, slot, f0);
+            {   // generated-only shortcuts of the expand kernel: a slot they name must be enabled, never storable, and raise nothing
+                const bool go = slot < S::FIX ? (S::fixed_bit(g, slot) && S::fixed_generated_only(p, l.inflight, slot)) : S::message_generated_only(p, l, s, slot);
+                if (go && (!(st0 & ST_ENABLED) || !(st0 & (ST_OUT_OF_MODEL | ST_SELFLOOP)) || (st0 & (ST_ASSERT | ST_SPECERR | ST_INVARIANT | ST_OVERFLOW)))) bad++;
+            }
             int fam = -1;
             // queued: the sparse fixed slots (the dense pairs, slots < DENSE_SLOTS, and the message slots are evaluated by eval itself)
             const bool queued = slot >= S::DENSE_SLOTS && slot < S::FIX;

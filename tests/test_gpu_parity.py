@@ -346,9 +346,36 @@ def test_ssi_4x3_prefix_on_gpu(amd):
 def test_ssi_4x3_ten_levels_on_gpu(amd):
     """BASELINE config 5 to the depth the bench (`--workload ssi4x3`) and profiles/ quote: 10 levels = 168 052 153 states, every
     per-level count and `generated` from the exact-dedup oracle on the GPU box's host (tests/golden/ssi_levels.json `source`)."""
-    c = json.loads((GOLDEN / "ssi_levels.json").read_text())["cases"][0]
-    assert c["name"] == "ssi_4x3_levels10" and "oracle_mc" in c["source"]
+    c = next(x for x in json.loads((GOLDEN / "ssi_levels.json").read_text())["cases"] if x["name"] == "ssi_4x3_levels10")
+    assert "oracle_mc" in c["source"]
     eng = amd.Engine("ssi", c["params"], table_capacity=9 << 26, arena_capacity=c["distinct"] + (1 << 20), chunk_states=1 << 21, max_levels=10, trace=False)
+    r = eng.run()
+    eng.close()
+    assert r.levels == c["levels"] and (r.distinct, r.generated, r.verdict) == (c["distinct"], c["generated"], "budget")
+
+
+def _ssi_case(name):
+    c = next(x for x in json.loads((GOLDEN / "ssi_levels.json").read_text())["cases"] if x["name"] == name)
+    assert "oracle_mc" in c["source"]
+    return c
+
+
+def test_ssi_4x3_eleven_levels_on_gpu(amd):
+    """config 5 one level deeper than the bench runs it: 11 levels = 1 184 049 193 states (95 GB of states resident), per-level counts and
+    `generated` from the oracle on the GPU box's host (75 s there, 0.3 s here)"""
+    c = _ssi_case("ssi_4x3_levels11")
+    eng = amd.Engine("ssi", c["params"], table_capacity=57 << 26, arena_capacity=c["distinct"] + (1 << 20), chunk_states=1 << 23, max_levels=11, trace=False)
+    r = eng.run()
+    eng.close()
+    assert r.levels == c["levels"] and (r.distinct, r.generated, r.verdict) == (c["distinct"], c["generated"], "budget")
+
+
+def test_ssi_4x3_symmetry_thirteen_levels_on_gpu(amd):
+    """config 5 as the spec's run-book sets it up (SYMMETRY over TxnId and Key, :38-44), 13 levels = 267 790 850 orbits: the number
+    profiles/ has quoted since round 1 is now the oracle's (brute-force least image over 144 permutations per successor, 154 s on the GPU
+    box's host), level by level"""
+    c = _ssi_case("ssi_4x3_sym_levels13")
+    eng = amd.Engine("ssi", c["params"], table_capacity=13 << 26, arena_capacity=c["distinct"] + (1 << 20), chunk_states=1 << 22, max_levels=13, trace=False)
     r = eng.run()
     eng.close()
     assert r.levels == c["levels"] and (r.distinct, r.generated, r.verdict) == (c["distinct"], c["generated"], "budget")

@@ -677,6 +677,11 @@ __device__ __forceinline__ T wave_uniform_copy(const T &v) {
     __builtin_memcpy(&r, w, sizeof(T));
     return r;
 }
+// specs that name successors which are generated (counted) but provably never stored, so that the kernel need not evaluate them
+template <class S, class = void>
+struct HasGeneratedOnly : std::false_type {};
+template <class S>
+struct HasGeneratedOnly<S, decltype((void)S::GENERATED_ONLY)> : std::true_type {};
 // specs whose writer starts from what the parent's lane derived (S::Summary in LDS) instead of walking the row again
 template <class S, class = void>
 struct HasSummaryWriter : std::false_type {};
@@ -1038,7 +1043,15 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                     for (int kind = 0; kind < 3; ++kind) {
                         const unsigned slot = (unsigned)(S::FIX + 3 * k + kind);
                         uint64_t fv = 0, fp = 0;
-                        const unsigned st = on ? S::eval(prm, loc, g, (int)slot, fv) : 0u;
+                        bool ev = on;
+                        if constexpr (HasGeneratedOnly<S>::value) {
+                            if (on && S::message_generated_only(prm, loc, g, (int)slot)) {  // (DuplicateMessage of a full bag: counted, not evaluated)
+                                ++gen;
+                                if (track_succ) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
+                                ev = false;
+                            }
+                        }
+                        const unsigned st = ev ? S::eval(prm, loc, g, (int)slot, fv) : 0u;
                         if (st & ST_ENABLED) {
                             ++gen;
                             if (track_succ) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
@@ -1066,9 +1079,19 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             }
         }
         MC_PROF(5);
+        const int lane_inflight = active ? loc.inflight : 0;
         for (int step = 0; step < ((flags & 64u) ? 0 : S::FIX); ++step) {
             const int f = S::fixed_family(step);
-            const bool en = S::fixed_bit(gd, step);
+            bool en = S::fixed_bit(gd, step);
+            if constexpr (HasGeneratedOnly<S>::value) {
+                // enabled but never storable, known from the guard and the parent's in-flight count (S::fixed_generated_only):
+                // counted as generated — TLC counts it — and neither queued nor evaluated
+                if (en && S::fixed_generated_only(prm, lane_inflight, step)) {
+                    ++gen;
+                    if (track_succ) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
+                    en = false;
+                }
+            }
             const unsigned long long b = __ballot(en);
             if (b && fam_push(f, b, en, ((unsigned)step << 8) | pl)) run_full(1u << f, false, 5);
         }

@@ -786,6 +786,26 @@ struct SpecRaft {
         return st;
     }
 
+    // GENERATED-ONLY successors (round 4): enabled, so TLC counts them, but never stored — decided from the parent's in-flight
+    // count alone, without evaluating the action.  StateConstraint bounds the copies in flight by MaxMsgs (specs/MCraft.tla), every
+    // stored parent satisfies it, and an action that only ADDS a copy to a parent that already holds MaxMsgs leaves the model:
+    //   DuplicateMessage(m) of a message in flight once (raft.tla:471-473): always one copy more;
+    //   RequestVote(i, j) of a candidate (raft.tla:209-217): Send adds a copy of its request — unless the key is saturated at two
+    //   copies (raft.tla:117-121), which a stored parent can only hold when MaxMsgs >= 2: the shortcut is taken for MaxMsgs = 1.
+    // Neither changes a server or a global, so no invariant can fire on the discarded successor.  73 % of the bench model's parents
+    // hold a message in flight: three quarters of the RequestVote pairs and every DuplicateMessage were evaluated for nothing
+    // (profiles/r04m_phase_profile_t3.json: RequestVote batches 12 %, inline message actions 8 % of a wavefront's time).
+    // tests/_shim checks on every (state, slot) of the CPU lowering tests that a slot named here IS enabled and NOT storable.
+    static constexpr bool GENERATED_ONLY = true;
+    MC_HD static bool fixed_generated_only(const Params &prm, int inflight, int slot) {  // for a slot whose guard bit is set
+        return prm.max_msgs == 1 && inflight >= 1 && slot >= 2 * NS && slot < 2 * NS + NS * NS;
+    }
+    template <class Ref>
+    MC_HD static bool message_generated_only(const Params &prm, const Local &l, Ref s, int slot) {  // slot >= FIX
+        const int q = slot - FIX, k = q / 3;
+        return q % 3 == 1 && l.inflight >= prm.max_msgs && k < l.nm && m_count(rd_msg(s, k)) == 1;
+    }
+
     // ---------------------------------------------------------------- expand-by-family interface
     // guards: cheap and EXACT as to the family (compute<MEM, FAM> still decides whether the action is enabled)
     struct Guards {
