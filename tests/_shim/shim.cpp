@@ -39,6 +39,11 @@ struct FpSet {
         tab[h] = fp;
         return true;
     }
+    bool contains(uint64_t fp) const {
+        size_t h = fp & (tab.size() - 1);
+        while (tab[h]) { if (tab[h] == fp) return true; h = (h + 1) & (tab.size() - 1); }
+        return false;
+    }
     // std::unordered_set-like insert: .second = newly inserted
     struct R { int first; bool second; };
     R insert(uint64_t fp) {
@@ -248,6 +253,18 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
     cur.swap(next);
     uint32_t level = 1;
     int budget = 0;
+    const bool kindstats = getenv("SHIM_KINDSTATS") != nullptr;
+    uint64_t kind_cnt[16][4] = {};
+    struct KindReport {
+        const bool &on; uint64_t (&c)[16][4];
+        ~KindReport() {
+            if (!on) return;
+            for (int a = 0; a < 16; a++)
+                if (c[a][0]) fprintf(stderr, "kindstats: action %2d %-20s generated %12llu  stutter %12llu  out-of-model %12llu  already seen %12llu  new %12llu\n", a,
+                                     S::action_name(a), (unsigned long long)c[a][0], (unsigned long long)c[a][1], (unsigned long long)c[a][2],
+                                     (unsigned long long)c[a][3], (unsigned long long)(c[a][0] - c[a][1] - c[a][2] - c[a][3]));
+        }
+    } kind_report{kindstats, kind_cnt};
     while (!cur.empty()) {
         if (r->verdict) break;
         if (max_levels && level >= max_levels) { budget = 1; break; }
@@ -269,6 +286,14 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
                 if (!(st & ST_ENABLED)) continue;
                 nsucc++;
                 r->generated++;
+                if (kindstats) {  // analysis aid (SHIM_KINDSTATS=1): what becomes of the successors of each action kind
+                    const int a = S::action_of(prm, &cur[i * W], slot);
+                    uint64_t *k = kind_cnt[a >= 0 && a < 15 ? a : 15];
+                    k[0]++;
+                    if (st & ST_SELFLOOP) k[1]++;
+                    else if (st & ST_OUT_OF_MODEL) k[2]++;
+                    else if (seen.contains(fp)) k[3]++;
+                }
                 if (st & ST_OVERFLOW) { if (dump) fclose(dump); return MC_EOVERFLOW; }
                 if (st & (ST_ASSERT | ST_SPECERR)) { violation(st, level); continue; }
                 if (st & ST_INVARIANT) violation(st, level + 1);

@@ -1170,11 +1170,13 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         static_assert(NCLS * 4 <= 64, "one lane per (class, wavefront) in the prefix sum");
         static_assert(4 * OCAP * sizeof(uint16_t) <= sizeof(fls[0].filt) && OCAP <= 256, "the sorted order aliases one duplicate filter");
         uint16_t *order = reinterpret_cast<uint16_t *>(fls[0].filt);        // [4 * OCAP]: (wavefront << 8) | position in its list
-        unsigned *hist = reinterpret_cast<unsigned *>(fls[1].filt);         // [NCLS][4]
-        unsigned long long *wg_out0 = reinterpret_cast<unsigned long long *>(fls[2].filt);
+        __shared__ unsigned wg_hist[NCLS * 4];                              // [NCLS][4] (its own LDS: filled BEFORE the barrier)
+        __shared__ unsigned long long wg_out0_s;
+        unsigned *hist = wg_hist;
+        unsigned long long *wg_out0 = &wg_out0_s;
         const unsigned w = threadIdx.x >> 6;
-        __syncthreads();  // (1) no wavefront of the workgroup generates any more: the filters are free, the lists final
-        MC_PROF(16);      // (profiling builds: 4 = waiting at barrier (1), 16 = the counting sort, 17 = the writes)
+        // a wavefront counts its own survivors per class as soon as IT has finished — in the shadow of the wait for its siblings
+        MC_PROF(16);      // (profiling builds: 16 = the counting sort, 4 = waiting at barrier (1), 17 = the writes)
         unsigned ccnt[NCLS];
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
@@ -1186,7 +1188,9 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         }
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) if (lane == 0) hist[c * 4 + w] = ccnt[c];
-        __syncthreads();  // (2)
+        MC_PROF(4);
+        __syncthreads();  // (1) no wavefront of the workgroup generates any more: the filters are free, the lists final, the counts there
+        MC_PROF(16);
         const unsigned h = lane < (unsigned)(NCLS * 4) ? hist[lane] : 0u;
         unsigned incl = h;
         for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
@@ -1205,7 +1209,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 ccnt[c] += (unsigned)__popcll(b);
             }
         }
-        __syncthreads();  // (3) the order and the workgroup's first arena index are visible
+        __syncthreads();  // (2) the order and the workgroup's first arena index are visible
         MC_PROF(17);
         const unsigned long long out0 = *wg_out0;
         if (total && out0 + total > rt.arena_cap) {
