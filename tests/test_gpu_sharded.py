@@ -263,7 +263,8 @@ def test_native_default_chunk_beyond_one_launch():
 @pytest.mark.parametrize("world", [2, 8])
 def test_bench_contract_invocation_with_several_ranks(world):
     """`python bench.py --gpus N` — the contract invocation, no launcher: bench.py spawns its N ranks, the ranks build the RCCL
-    communicator (id through a TCP store), run mc_shard_run on the COMPLETE bench graph and rank 0 prints the line.  Here the
+    communicator (id through a file in a directory of the job's own: no port to lose, round 3's GPUTEST failure), run mc_shard_run on
+    the COMPLETE bench graph and rank 0 prints the line.  Here the
     ranks share this one GPU (--share-gpu + stand-in): a functional run, the line says so.  P = 8: the frontier stays balanced."""
     import json
     import subprocess
@@ -279,6 +280,29 @@ def test_bench_contract_invocation_with_several_ranks(world):
     assert len(c["shares"]) == world and sum(c["shares"]) == 102586254 and c["levels"]["stay_levels"] >= 10
     assert c["frontier_imbalance"] <= 1.25 and max(c["shares"]) <= 1.25 * 102586254 / world
     assert "xgmi" in line and line["xgmi"]["sent_bytes_per_step_per_gpu"] > 0
+
+
+def test_bench_under_the_drivers_launcher():
+    """the driver's N > 1 command line, word for word: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` — the communicator id travels through the launcher's own TCP store
+    (the agent listens before any rank starts); here with the two ranks on this one GPU (--share-gpu + stand-in)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--share-gpu", "--workload", "k10"],
+                       capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=str(root))
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    line = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
+    c = line["config"]
+    assert (line["n_gpus"], line["steps"], line["warmup"], line["scaling"]) == (2, 2, 1, "strong")
+    assert (c["distinct"], c["generated"], c["depth"], c["verdict"]) == (102586254, 1217433925, 33, "ok") and sum(c["shares"]) == 102586254
 
 
 # ------------------------------------------------------------------------------------------ one checkpoint file per rank
