@@ -158,6 +158,17 @@ def test_mc_new_pluscal_specs():
     assert rc == 0 and "1768 states generated, 1624 distinct states found" in out, err
 
 
+def test_mc_on_a_module_with_procedures():
+    """`mc treiber_procs.tla` = tlc on a PlusCal module that uses PROCEDURES (round 4): the counts of pcal2tla's stack translation
+    (tests/golden/pcal_procedures/TreiberStack.tla, evaluated in tests/test_pcal.py) on the GPU"""
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "treiber_procs.tla")
+    assert rc == 0, err
+    assert "574 states generated, 330 distinct states found, 0 states left on queue." in out
+    assert "The depth of the complete state graph search is 22." in out
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "proc_nested.tla")
+    assert rc == 0 and "12735 distinct states found" in out, err
+
+
 def test_bigger_program_throughput_smoke(amd):
     """cas_counter with 3 workers x 3 increments: a graph large enough to run many chunks"""
     path = ROOT / "specs" / "pluscal" / "cas_counter.tla"

@@ -44,6 +44,11 @@ CASES = [
     (SPECS / "pluscal" / "swap.tla", [], {}),                                                                  # a := e || b := f
     (SPECS / "pluscal" / "scratch_locals.tla", ["AtMostN"], {"N": 2}),      # `variable tmp;`: defaultInitValue
     (SPECS / "pluscal" / "scratch_locals.tla", ["AtMostN"], {"N": 3}),
+    # PROCEDURES (round 4; expanded into the calling processes, tla_rust_amd/csrc/pcal.h): call / return, parameters, procedure variables
+    (SPECS / "pluscal" / "proc_demo.tla", [], {}),
+    (SPECS / "pluscal" / "treiber_procs.tla", ["PopsDistinct"], {"N": 2}),      # the lock-free stack of the reference's roadmap, with procedures
+    (SPECS / "pluscal" / "treiber_procs.tla", ["PopsDistinct"], {"N": 3}),
+    (SPECS / "pluscal" / "proc_nested.tla", ["XBound", "Final"], {}),           # c-syntax; a procedure calling another; two kinds of processes
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -192,13 +197,13 @@ MODULE = "---- MODULE t ----\nEXTENDS Naturals\n(* --algorithm t\n%s\nend algori
 
 
 @pytest.mark.parametrize("body,needle", [
-    ("variables x = 0;\nprocedure p() begin L: skip; end procedure;\nbegin\nA: skip;", "procedures are not supported"),
+    ("variables x = 0;\nprocedure p() begin L: skip; end procedure;\nbegin\nA: skip;", "run off the end of procedure p"),
     ("variables x = 0;\nmacro m(a) begin a := 1; end macro;\nbegin\nA: m(x + 1);", "must be instantiated with a variable"),
     ("variables x = 0;\nbegin\nA: x := 1; x := 2;", "second assignment to x"),
     ("variables x = 0;\nbegin\nA: x := 1 || x := 2;", "two assignments to x"),
     ("variables x = 0;\nbegin\nA: if x = 0 then B: x := 1; end if; x := 2;", "needs a label"),
     ("variables x = 0;\nbegin\nA: y := 1;", "undeclared variable y"),
-    ("variables x = 0;\nbegin\nA: while x < 2 do x := x + 1; end while; B: call f();", "not supported"),
+    ("variables x = 0;\nbegin\nA: while x < 2 do x := x + 1; end while; B: call f();", "no such procedure"),
 ])
 def test_refusals_are_explained(body, needle):
     with pytest.raises(RuntimeError) as e:
@@ -364,3 +369,48 @@ def test_integer_overflow_and_division_like_tlc():
     prog = helpers.ShimProgram(MODULE % "variables a = 7, b = 0, q = 0;\nbegin\nA: q := a \\div b;")
     assert helpers.shim_run("pcal", prog.params)["verdict"] == "spec-error"
     prog.close()
+
+
+# ---------------------------------------------------------------------------------------------- procedures (round 4)
+PROC_FIXTURES = ROOT / "tests" / "golden" / "pcal_procedures"
+
+
+@pytest.mark.parametrize("spec,fixture,consts,invs", [("proc_demo", "ProcDemoStack", {}, []), ("treiber_procs", "TreiberStack", {"N": 2}, ["PopsDistinct"])])
+def test_procedure_expansion_equals_the_stack_translation(spec, fixture, consts, invs):
+    """PlusCal procedures are EXPANDED into the calling processes (tla_rust_amd/csrc/pcal.h) instead of being translated with a `stack`
+    variable as pcal2tla does (p-manual section 3.5).  For non-recursive procedures the two are the same state graph: the hand-written
+    stack translation of each spec (tests/golden/pcal_procedures/*.tla: frames, Head / Tail, restore on return), evaluated by the general
+    TLA+ evaluator, against the expansion — evaluated as text AND compiled — counters, depth, verdict, per-level counts."""
+    import tlaplus as T
+    c = T.Checker(PROC_FIXTURES / f"{fixture}.tla", cfg_path=PROC_FIXTURES / f"{fixture}.cfg", search=[])
+    p = c.run_levels(keep_states=False)
+    text = (SPECS / "pluscal" / f"{spec}.tla").read_text()
+    o = Checker(helpers.pcal_translate(text), constants=consts).run_levels(invariants=invs)
+    prog = helpers.ShimProgram(text, invs, consts)
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (p["distinct"], p["generated"], p["depth"], p["verdict"], p["levels"]) == (o["distinct"], o["generated"], o["depth"], o["verdict"], o["levels"])
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (p["distinct"], p["generated"], p["depth"], p["verdict"], p["levels"])
+    assert p["distinct"] > 100
+
+
+PROC_HEAD = "---- MODULE M ----\nEXTENDS Naturals\n(* --algorithm M\nvariables x = 0;\n"
+PROC_ERRORS = [
+    ("procedure f(a) begin F1: x := a; call f(a); F2: return; end procedure; begin M1: call f(1); M2: skip; end algorithm *)\n====\n", "recursive call of procedure f"),
+    ("procedure f(a) begin F1: x := a; return; end procedure; begin M1: call f(1); x := 2; end algorithm *)\n====\n", "after a `call` must have a label"),
+    ("procedure f(a) begin F1: x := a; return; end procedure; begin M1: call f(1, 2); M2: skip; end algorithm *)\n====\n", "takes 1 arguments"),
+    ("procedure f(a) begin x := a; return; end procedure; begin M1: call f(1); M2: skip; end algorithm *)\n====\n", "first statement of procedure f must have a label"),
+    ("procedure f(a) begin F1: x := a; end procedure; begin M1: call f(1); M2: skip; end algorithm *)\n====\n", "run off the end of procedure f"),
+    ("procedure f(a) begin F1: x := a; return; end procedure; procedure g() begin G1: call f(1); return; end procedure; begin M1: call g(); M2: skip; end algorithm *)\n====\n", "tail call"),
+    ("begin M1: x := 1; return; end algorithm *)\n====\n", "`return` outside a procedure"),
+    ("begin M1: call nope(1); M2: skip; end algorithm *)\n====\n", "no such procedure"),
+]
+
+
+@pytest.mark.parametrize("body,msg", PROC_ERRORS, ids=[m[:18] for _, m in PROC_ERRORS])
+def test_procedure_errors_are_refused_with_a_message(body, msg):
+    with pytest.raises(RuntimeError) as e:
+        helpers.pcal_translate(PROC_HEAD + body)
+    assert msg in str(e.value), str(e.value)

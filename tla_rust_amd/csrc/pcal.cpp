@@ -3,7 +3,8 @@
 // Supported: variables (= / \in), multiprocess and uniprocess algorithms, labels, assignment (x := e,
 // x[i] := e, a := e || b := e), if / elsif / else, while, either / or, with (\in / =), await / when, assert,
 // skip, goto, print, define blocks, macros; both the p-syntax (begin ... end) and the c-syntax ({ ... }).
-// Refused with a message: procedure / call / return.
+// procedure / call / return: parsed here and expanded into the calling processes (expand_procedures below; pcal.h says what
+// that keeps of pcal2tla's translation and what not).
 #include "pcal.h"
 
 #include <algorithm>
@@ -480,7 +481,22 @@ struct Parser {
         if (kw == "skip") { i++; s.k = Stmt::SKIP; return; }
         if (kw == "goto") { i++; s.k = Stmt::GOTO; s.var = ident("a label after `goto`"); return; }
         if (kw == "print") { i++; s.k = Stmt::PRINT; s.e = expr(0); return; }
-        if (kw == "call" || kw == "return") fail("procedures (`call` / `return`) are not supported");
+        if (kw == "call") {  // call P(e1, ..., en)   (p-manual section 3.5)
+            if (in_macro) fail("a macro cannot contain a `call`");
+            i++;
+            s.k = Stmt::CALL;
+            s.var = ident("a procedure name after `call`");
+            expect_sym("(");
+            if (!is_sym(")")) for (;;) { s.args.push_back(expr(0)); if (is_sym(",")) { i++; continue; } break; }
+            expect_sym(")");
+            return;
+        }
+        if (kw == "return") {
+            if (in_macro) fail("a macro cannot contain a `return`");
+            i++;
+            s.k = Stmt::RETURN;
+            return;
+        }
         s.k = Stmt::ASSIGN;
         s.var = t[i++].s;
         if (is_sym("[")) { i++; s.idx = expr(0); expect_sym("]"); if (is_sym("[")) fail("only one index level is supported on the left of `:=`"); }
@@ -620,7 +636,7 @@ struct Parser {
             m.macros.push_back(mac);
         }
         macros = &m.macros;
-        if (is_id("procedure")) fail("procedures are not supported");
+        procedures(m, true);
         if (is_sym("{")) {  // uniprocess
             Proc p;
             p.body = c_block();
@@ -643,6 +659,50 @@ struct Parser {
             if (m.procs.empty()) fail("expected `{` or `process`");
         }
         expect_sym("}");
+    }
+    // procedure P(a, b = e) [variables x = e, y;] begin ... end procedure [;]      /      ... { ... }   in the c-syntax
+    void procedures(Module &m, bool c_syntax) {
+        while (is_id("procedure")) {
+            Procedure pr;
+            pr.pos = {cur().line, cur().col};
+            i++;
+            pr.name = ident("a procedure name");
+            expect_sym("(");
+            while (!is_sym(")")) {
+                VarDecl d;
+                d.pos = {cur().line, cur().col};
+                d.name = ident("a parameter name");
+                if (is_sym("=")) { i++; d.init = expr(0); }
+                else {
+                    d.no_init = true;
+                    auto e = std::make_shared<Expr>();
+                    e->k = Expr::ID;
+                    e->s = "defaultInitValue";
+                    e->pos = d.pos;
+                    d.init = e;
+                }
+                pr.params.push_back(d);
+                if (is_sym(",")) i++;
+                else if (!is_sym(")")) fail("expected `,` or `)` in the parameter list");
+            }
+            i++;
+            if (is_id("variables") || is_id("variable")) {
+                i++;
+                pr.locals = vardecls();
+                for (const auto &d : pr.locals) if (d.in_set) fail("a procedure variable is initialised with `=`, not `\\in` (p-manual section 3.5)");
+            }
+            if (c_syntax) {
+                pr.body = c_block();
+            } else {
+                expect_id("begin");
+                pr.body = stmts();
+                expect_id("end");
+                expect_id("procedure");
+                if (is_sym(";")) i++;
+            }
+            for (const auto &q : m.procedures) if (q.name == pr.name) fail("procedure " + pr.name + " is declared twice");
+            m.procedures.push_back(pr);
+        }
     }
     void define_one(Module &m) {
         Definition d;
@@ -687,7 +747,7 @@ struct Parser {
             m.macros.push_back(mac);
         }
         macros = &m.macros;
-        if (is_id("procedure")) fail("procedures are not supported");
+        procedures(m, false);
         if (is_id("begin")) {  // uniprocess
             i++;
             Proc p;
@@ -794,6 +854,216 @@ void add_missing_labels(Module &m) {
 }
 }  // namespace
 
+// ---- procedures: expanded into the processes that call them (pcal.h says what this preserves of pcal2tla's translation)
+namespace {
+struct ExpandError { std::string msg; };
+struct ProcExpander {
+    Module &m;
+    int copies = 0;
+    [[noreturn]] static void fail(const Pos &at, const std::string &what) {
+        throw ExpandError{"line " + std::to_string(at.line) + ", col " + std::to_string(at.col) + ": " + what};
+    }
+    const Procedure &find(const SP &call) const {
+        for (const auto &p : m.procedures) if (p.name == call->var) return p;
+        fail(call->pos, "`call " + call->var + "`: no such procedure");
+    }
+    static EP rename(const EP &e, const std::map<std::string, std::string> &r) {
+        if (!e) return e;
+        auto c = std::make_shared<Expr>(*e);
+        if (c->k == Expr::ID) { auto it = r.find(c->s); if (it != r.end()) c->s = it->second; return c; }
+        // (a bound variable of a quantifier / function constructor that shadows a procedure variable: PlusCal forbids the clash)
+        for (auto &x : c->a) x = rename(x, r);
+        return c;
+    }
+    // one process being expanded
+    struct Job {
+        Proc *proc;
+        std::string suffix;                         // appended to the procedure variables' names when several processes call procedures
+        std::vector<std::string> active;            // procedures on the current call chain (recursion check)
+        std::set<std::string> declared;             // procedure variables this process already has
+        std::vector<SP> copies;                     // the expanded bodies, appended behind the process's own
+    };
+    // statements of `v` with the procedures' variables renamed, labels given the copy's suffix, calls / returns expanded.
+    // `cont` = the label control reaches after the last statement of v ("" = unknown: a call may not be last then);
+    // `ret` = the label a `return` goes to ("" = not inside a procedure); `reset` = what a return assigns
+    std::vector<SP> expand(const std::vector<SP> &v, Job &job, const std::map<std::string, std::string> &ren, const std::string &lsuf,
+                           const std::string &cont, const std::string &ret, const std::vector<SP> &reset) {
+        std::vector<SP> out;
+        for (size_t i = 0; i < v.size(); i++) {
+            const SP &s = v[i];
+            const std::string next = i + 1 < v.size() ? (v[i + 1]->label.empty() ? std::string() : v[i + 1]->label + lsuf) : cont;
+            auto c = std::make_shared<Stmt>(*s);
+            if (!c->label.empty()) c->label += lsuf;
+            c->e = rename(s->e, ren);
+            c->idx = rename(s->idx, ren);
+            if (s->k == Stmt::ASSIGN || s->k == Stmt::WITH) { auto it = ren.find(s->var); if (it != ren.end()) c->var = it->second; }
+            if (s->k == Stmt::GOTO && s->var != "Done") c->var = s->var + lsuf;
+            c->more.clear();
+            for (const auto &o : s->more) {
+                auto oc = std::make_shared<Stmt>(*o);
+                oc->e = rename(o->e, ren);
+                oc->idx = rename(o->idx, ren);
+                auto it = ren.find(o->var);
+                if (it != ren.end()) oc->var = it->second;
+                c->more.push_back(oc);
+            }
+            if (s->k == Stmt::CALL) {
+                if (i + 1 < v.size() && v[i + 1]->k == Stmt::RETURN && v[i + 1]->label.empty())
+                    fail(s->pos, "`call` directly followed by `return` (pcal2tla's tail call: the frame is replaced, not pushed) is not supported: put a label on the return");
+                if (next.empty()) fail(s->pos, "the statement after a `call` must have a label (p-manual section 3.5)");
+                std::vector<SP> stmts = call(s, c->label, job, ren, next);
+                out.insert(out.end(), stmts.begin(), stmts.end());
+                continue;
+            }
+            if (s->k == Stmt::RETURN) {
+                if (ret.empty()) fail(s->pos, "`return` outside a procedure");
+                bool first = true;
+                for (const auto &r : reset) {
+                    auto rc = std::make_shared<Stmt>(*r);
+                    rc->pos = s->pos;
+                    if (first) rc->label = c->label;
+                    first = false;
+                    out.push_back(rc);
+                }
+                auto g = std::make_shared<Stmt>();
+                g->k = Stmt::GOTO;
+                g->pos = s->pos;
+                g->var = ret;
+                if (first) g->label = c->label;
+                out.push_back(g);
+                continue;
+            }
+            c->blocks.clear();
+            for (size_t b = 0; b < s->blocks.size(); b++) {
+                // what follows a branch of an if / either is what follows the statement; the body of a while goes back to its test
+                const std::string bcont = s->k == Stmt::WHILE ? c->label : next;
+                if (s->k == Stmt::WITH) for (const auto &x : s->blocks[b]) if (x->k == Stmt::CALL || x->k == Stmt::RETURN) { /* allowed: no label inside a with, the goto is fine */ }
+                c->blocks.push_back(expand(s->blocks[b], job, ren, lsuf, bcont, ret, reset));
+            }
+            out.push_back(c);
+        }
+        return out;
+    }
+    // every path through v ends in a return / goto (the copies of procedure bodies lie one behind the other: none may run into the next)
+    static bool ends_in_jump(const std::vector<SP> &v) {
+        if (v.empty()) return false;
+        const SP &l = v.back();
+        if (l->k == Stmt::RETURN || l->k == Stmt::GOTO) return true;
+        if (l->k == Stmt::IF || l->k == Stmt::EITHER) {
+            for (const auto &b : l->blocks) if (!ends_in_jump(b)) return false;
+            return l->k == Stmt::EITHER || l->blocks.size() == 2;
+        }
+        if (l->k == Stmt::WITH) return ends_in_jump(l->blocks[0]);
+        return false;
+    }
+    static SP assign(const std::string &var, const EP &e, const Pos &at) {
+        auto a = std::make_shared<Stmt>();
+        a->k = Stmt::ASSIGN;
+        a->pos = at;
+        a->var = var;
+        a->e = e;
+        return a;
+    }
+    // the statements that replace `call P(args)` in its step; P's body is copied behind the process's own
+    std::vector<SP> call(const SP &s, const std::string &label, Job &job, const std::map<std::string, std::string> &outer, const std::string &after) {
+        const Procedure &pr = find(s);
+        if (s->args.size() != pr.params.size())
+            fail(s->pos, "procedure " + pr.name + " takes " + std::to_string(pr.params.size()) + " arguments");
+        for (const auto &a : job.active) if (a == pr.name) fail(s->pos, "recursive call of procedure " + pr.name + " (recursion is not supported: procedures are expanded where they are called)");
+        if (pr.body.empty()) fail(pr.pos, "procedure " + pr.name + " has an empty body");
+        if (pr.body[0]->label.empty()) fail(pr.body[0]->pos, "the first statement of procedure " + pr.name + " must have a label (p-manual section 3.5)");
+        if (!ends_in_jump(pr.body)) fail(pr.body.back()->pos, "control can run off the end of procedure " + pr.name + ": it must end with `return` (or a `goto`) on every path");
+        // the procedure's variables as locals of this process (once per process)
+        std::map<std::string, std::string> ren;
+        std::vector<const VarDecl *> pv;
+        for (const auto &d : pr.params) pv.push_back(&d);
+        for (const auto &d : pr.locals) pv.push_back(&d);
+        for (const VarDecl *d : pv) {
+            const std::string nm = d->name + job.suffix;
+            ren[d->name] = nm;
+            if (job.declared.insert(nm).second) {
+                VarDecl l = *d;
+                l.name = nm;
+                job.proc->locals.push_back(l);
+            }
+        }
+        const int k = ++copies;
+        const std::string lsuf = "_p" + std::to_string(k);
+        // in the caller's step: parameters := arguments (all at once: an argument may mention a parameter of an enclosing call),
+        // locals := their initial values, goto the copy's first label
+        std::vector<SP> out;
+        SP first;
+        for (size_t a = 0; a < pr.params.size(); a++) {
+            SP x = assign(ren[pr.params[a].name], rename(s->args[a], outer), s->pos);
+            if (!first) first = x; else first->more.push_back(x);
+        }
+        for (const auto &d : pr.locals) {
+            SP x = assign(ren[d.name], d.init, s->pos);
+            if (!first) first = x; else first->more.push_back(x);
+        }
+        if (first) { first->label = label; out.push_back(first); }
+        auto g = std::make_shared<Stmt>();
+        g->k = Stmt::GOTO;
+        g->pos = s->pos;
+        g->var = pr.body[0]->label + lsuf;
+        if (!first) g->label = label;
+        out.push_back(g);
+        // what `return` assigns: every variable of the procedure back to its initial value (what pcal2tla's frame had saved)
+        std::vector<SP> reset;
+        {
+            SP r0;
+            for (const VarDecl *d : pv) {
+                SP x = assign(ren[d->name], d->init, s->pos);
+                if (!r0) r0 = x; else r0->more.push_back(x);
+            }
+            if (r0) reset.push_back(r0);
+        }
+        job.active.push_back(pr.name);
+        std::map<std::string, std::string> inner = ren;  // (a procedure sees globals and its own variables; an enclosing procedure's are not in scope)
+        std::vector<SP> body = expand(pr.body, job, inner, lsuf, std::string(), after, reset);
+        job.active.pop_back();
+        job.copies.insert(job.copies.end(), body.begin(), body.end());
+        return out;
+    }
+    static bool uses_procedures(const std::vector<SP> &v) {
+        for (const auto &s : v) {
+            if (s->k == Stmt::CALL) return true;
+            for (const auto &b : s->blocks) if (uses_procedures(b)) return true;
+        }
+        return false;
+    }
+    void run() {
+        for (const auto &pr : m.procedures) {  // every declared procedure is checked, called or not
+            if (pr.body.empty()) fail(pr.pos, "procedure " + pr.name + " has an empty body");
+            if (pr.body[0]->label.empty()) fail(pr.body[0]->pos, "the first statement of procedure " + pr.name + " must have a label (p-manual section 3.5)");
+            if (!ends_in_jump(pr.body)) fail(pr.body.back()->pos, "control can run off the end of procedure " + pr.name + ": it must end with `return` (or a `goto`) on every path");
+        }
+        int callers = 0;
+        for (auto &p : m.procs) callers += uses_procedures(p.body) ? 1 : 0;
+        for (auto &p : m.procs) {
+            for (const auto &s : p.body) if (s->k == Stmt::RETURN) fail(s->pos, "`return` outside a procedure");
+            if (!uses_procedures(p.body)) continue;
+            Job job;
+            job.proc = &p;
+            job.suffix = callers > 1 ? "_" + (p.name.empty() ? std::string("main") : p.name) : std::string();
+            std::vector<SP> body = expand(p.body, job, {}, "", "Done", "", {});
+            if (!job.copies.empty()) {  // the process's own body must not run into the copies
+                if (body.empty() || body.back()->k != Stmt::GOTO) {
+                    auto g = std::make_shared<Stmt>();
+                    g->k = Stmt::GOTO;
+                    g->var = "Done";
+                    g->pos = body.empty() ? Pos{} : body.back()->pos;
+                    body.push_back(g);
+                }
+                body.insert(body.end(), job.copies.begin(), job.copies.end());
+            }
+            p.body = body;
+        }
+        m.had_procedures = !m.procedures.empty();
+    }
+};
+}  // namespace
+
 std::string parse_module(const std::string &text, Module &m) {
     try {
         size_t a = text.find("--algorithm");
@@ -835,6 +1105,13 @@ std::string parse_module(const std::string &text, Module &m) {
         {
             Parser p(lex(text, a + kw_len, aend));
             p.algorithm(m);
+        }
+        {   // (always: a `call` / `return` in an algorithm without procedures is refused there)
+            try {
+                ProcExpander{m}.run();
+            } catch (const ExpandError &e) {
+                return e.msg;
+            }
         }
         add_missing_labels(m);
         // the rest: an existing translation (skipped) and the definitions

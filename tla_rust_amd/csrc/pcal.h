@@ -30,7 +30,7 @@ struct Expr {
 struct Stmt;
 using SP = std::shared_ptr<Stmt>;
 struct Stmt {
-    enum K { ASSIGN, IF, WHILE, EITHER, WITH, AWAIT, ASSERT, SKIP, GOTO, PRINT } k = SKIP;
+    enum K { ASSIGN, IF, WHILE, EITHER, WITH, AWAIT, ASSERT, SKIP, GOTO, PRINT, CALL, RETURN } k = SKIP;
     std::string label;                     // "" = unlabeled
     Pos pos;                               // of the statement keyword / lhs (asserts print it)
     std::string var;                       // ASSIGN lhs, WITH variable, GOTO target
@@ -40,6 +40,7 @@ struct Stmt {
     std::vector<std::vector<SP>> blocks;   // IF: then, else; EITHER: branches; WHILE / WITH: body
     std::vector<SP> more;                  // ASSIGN: the other assignments of `a := e || b := f` (all right-hand sides
                                            // see the values before the statement)
+    std::vector<EP> args;                  // CALL: the arguments (`var` = the procedure's name); gone after expand_procedures
 };
 
 struct VarDecl {
@@ -56,6 +57,15 @@ struct Proc {
     EP id;
     std::vector<VarDecl> locals;
     std::vector<SP> body;
+};
+
+// procedure P(a, b = e) variables x = e; begin ... return; end procedure   (p-manual section 3.5)
+struct Procedure {
+    std::string name;
+    std::vector<VarDecl> params;   // `a` (initially defaultInitValue) or `a = e`
+    std::vector<VarDecl> locals;   // (re)initialised on every call
+    std::vector<SP> body;
+    Pos pos;
 };
 
 struct Definition {
@@ -79,12 +89,22 @@ struct Module {
     std::vector<Proc> procs;                // a uniprocess algorithm is one Proc with an empty name
     std::vector<Definition> defs;           // definitions of the `define` block and of the module around the algorithm
     std::vector<Macro> macros;
+    std::vector<Procedure> procedures;      // as written; expand_procedures() has inlined them into the processes' bodies
+    bool had_procedures = false;
     int alg_first_line = 0, alg_last_line = 0;   // lines of "(* --algorithm" and "end algorithm *)"
     bool has_translation = false;
     int tr_first_line = 0, tr_last_line = 0;     // "\* BEGIN TRANSLATION" .. "\* END TRANSLATION"
 };
 
 // Parse the PlusCal algorithm (and the definitions around it) of a module text.  Returns "" or an error message.
+// PROCEDURES (round 4): parsed and then EXPANDED into the calling processes — every call site gets its own copy of the procedure's
+// body (labels `Label_pK`, K = the number of the copy), `call` becomes "parameters := arguments || locals := their initial values;
+// goto the copy's first label" and `return` "parameters, locals := their initial values; goto the label after the call", all in
+// the step the statement was in.  For NON-RECURSIVE procedures this is a bijection on states with the translation pcal2tla gives
+// (pc + the contents of `stack` <-> the copy's pc; a frame's saved values are the initial values, which `return` restores), so
+// distinct / generated / depth and every verdict agree (tests/test_pcal.py checks it against hand-written stack translations);
+// what differs is the TEXT of the translation and of a printed state: no `stack` variable, the copies' label names.  Recursive
+// procedures and `call P(..); return` (pcal2tla's tail call) are refused with a message.
 std::string parse_module(const std::string &text, Module &out);
 
 // The text `pcal2tla` inserts: from "\* BEGIN TRANSLATION" to "\* END TRANSLATION" inclusive, '\n' terminated.

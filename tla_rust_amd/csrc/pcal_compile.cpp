@@ -38,10 +38,12 @@ void all_labels(const std::vector<SP> &v, std::vector<std::string> &out) {
 
 // the right-hand side of the first `name := e` (whole variable or name[self]) in a statement list, or null
 const Expr *first_assignment(const std::vector<SP> &v, const std::string &name) {
+    // (`x := defaultInitValue` — the expansion of a procedure's `return` — says nothing about what x holds otherwise)
+    auto tells = [](const SP &a) { return !(a->e && a->e->k == Expr::ID && a->e->s == "defaultInitValue"); };
     for (const auto &s : v) {
         if (s->k == Stmt::ASSIGN) {
-            if (s->var == name) return s->e.get();
-            for (const auto &o : s->more) if (o->var == name) return o->e.get();
+            if (s->var == name && tells(s)) return s->e.get();
+            for (const auto &o : s->more) if (o->var == name && tells(o)) return o->e.get();
         }
         for (const auto &b : s->blocks) if (const Expr *e = first_assignment(b, name)) return e;
     }
@@ -666,6 +668,16 @@ struct Compiler {
     }
 
     // ---- statements
+    // the right-hand side of an assignment; `x := defaultInitValue` (what the expansion of a procedure's `return` assigns to a
+    // parameter declared without a default: back to the model value it held before the call) is the one place where the name is a value
+    void ex_rhs(const EP &e) {
+        if (e->k == Expr::ID && e->s == "defaultInitValue") {
+            bool bound = false;
+            for (const auto &b : binds) bound |= b.name == e->s;
+            if (!bound) { emit(mc::VM_PUSH, mc::VM_DEFAULT_INIT); return; }
+        }
+        ex(e);
+    }
     void assign(const SP &s) {
         if (!s->more.empty()) {  // a := e || b := f: evaluate every right-hand side (and index) first
             std::vector<SP> all{s};
@@ -678,7 +690,7 @@ struct Compiler {
                 if (P.vars[(size_t)vi->second].seq || P.vars[(size_t)vi->second].set) cfail("`||` with a sequence or set variable is not supported", x->pos);
                 Saved q{-1, new_temp(x->pos)};
                 if (x->idx) { q.t_idx = new_temp(x->pos); ex(x->idx); emit(mc::VM_STORET, q.t_idx); }
-                ex(x->e);
+                ex_rhs(x->e);
                 emit(mc::VM_STORET, q.t_val);
                 sv.push_back(q);
             }
@@ -729,7 +741,7 @@ struct Compiler {
         if (self_indexed) {
             if (s->idx) cfail("process-local function variables are not supported", s->pos);
             push_self(s->pos);
-            ex(s->e);
+            ex_rhs(s->e);
             emit_indexed(mc::VM_STOREX, v, s->pos);
         } else if (s->idx) {
             if (!v.array) cfail("`" + s->var + "` is not a function variable", s->pos);
@@ -738,7 +750,7 @@ struct Compiler {
             emit_indexed(mc::VM_STOREX, v, s->pos);
         } else {
             if (v.array) cfail("assigning a whole function (`" + s->var + " := ...`) is not supported: assign its elements", s->pos);
-            ex(s->e);
+            ex_rhs(s->e);
             emit(mc::VM_STORE, v.base);
         }
     }
