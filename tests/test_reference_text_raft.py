@@ -46,6 +46,28 @@ def test_c_oracle_equals_reference_text_fixture(name, tmp_path):
     assert level_digests(helpers.read_dump(str(dump))) == g["level_digests"]
 
 
+def test_c_oracle_and_lowering_equal_the_deep_reference_text_fixture(tmp_path):
+    """raft.tla at 3 servers / 7 message keys — 2 303 950 states, 27 levels — evaluated from the reference's TEXT by
+    the product's C++ evaluator (tlaeval.cpp, 9.5 min) and equal, level by level as state SETS, to the C oracle: an independent pair (the
+    C++ evaluator is a port of oracle/tlaplus.py, not of the oracle).  The suite re-runs the oracle AND the host build of the device
+    lowering against the fixture's counters; with TLAMC_SLOW=1 also against the per-level digests (a 4 GB dump each); re-evaluating the
+    text is `python tests/golden/make_deep_text_pin.py raft_3s_keys7`."""
+    import os
+    g = GOLD["raft_3s_keys7"]
+    assert "make_deep_text_pin" in g["source"] and g["distinct"] == 2303950
+    slow = os.environ.get("TLAMC_SLOW") == "1"
+    dump = tmp_path / "dump.txt"
+    o = helpers.oracle_run("raft", [3, 4, 2, 3, 1, 3, 0, 7], dump=str(dump) if slow else None)
+    assert (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"]) == (g["distinct"], g["generated"], g["depth"], g["levels"], g["verdict"])
+    if slow:
+        from make_deep_text_pin import digests
+        assert digests(dump) == g["level_digests"]
+    s = helpers.shim_run("raft", [3, 4, 2, 3, 1, 3, 0, 0, 0, 7], dump=str(dump) if slow else None)
+    assert (s["distinct"], s["generated"], s["depth"], s["levels"], s["verdict"], s["fp_mismatch"]) == (g["distinct"], g["generated"], g["depth"], g["levels"], g["verdict"], 0)
+    if slow:
+        assert digests(dump) == g["level_digests"]
+
+
 @pytest.mark.skipif(not REF.exists(), reason="/root/reference is only present in the build container")
 @pytest.mark.parametrize("name", ["raft_2s_mcr1"])   # the others: python tests/golden/make_reference_text_golden.py raft <name> (1 - 15 min each)
 def test_fixture_is_what_the_reference_text_gives(name):
