@@ -380,6 +380,11 @@ typedef struct mc_transport {
                         const uint64_t *recv_off, const uint64_t *recv_bytes);
     /* HOST buffers, blocking: rank r's `bytes` bytes appear at all_out + r * bytes on every rank */
     int (*all_gather)(void *user, const void *mine, void *all_out, uint64_t bytes);
+    /* OPTIONAL (may be NULL: a transport zero-initialises the struct and fills what it has): all_to_all without the rank's own
+     * block — recv + rank * bytes_per_peer is left untouched.  The fingerprint exchange of a stay round uses it when present: a
+     * rank's own bucket is empty by construction (candidates it owns are probed where they are generated), so moving it is a
+     * device copy of the whole bucket for its count word; the loop zeroes that word itself. */
+    int (*all_to_all_others)(void *user, const void *send, void *recv, uint64_t bytes_per_peer);
 } mc_transport;
 int mc_comm_transport(mc_comm *c, mc_transport *out);  /* the RCCL functions of a communicator; valid while c lives */
 int mc_shard_run_transport(mc_engine *e, const mc_transport *t, const mc_shard_opts *opts, mc_result *out);

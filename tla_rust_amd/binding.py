@@ -77,7 +77,8 @@ T_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 class Transport(C.Structure):
     """mc_transport: the collectives the level loop runs on (RCCL from mc_comm_transport, or a host's own)"""
     _fields_ = [("user", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("hip_stream", C.c_void_p), ("alloc", T_ALLOC),
-                ("release", T_RELEASE), ("all_to_all", T_A2A), ("all_to_all_v", T_A2AV), ("all_gather", T_GATHER)]
+                ("release", T_RELEASE), ("all_to_all", T_A2A), ("all_to_all_v", T_A2AV), ("all_gather", T_GATHER),
+                ("all_to_all_others", T_A2A)]   # optional: NULL (a positional constructor leaves it so) = use all_to_all
 
 
 class Result(dict):

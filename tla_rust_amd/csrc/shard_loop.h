@@ -293,7 +293,12 @@ struct Loop {
             e.record(EV_PACKED + s, S_MAIN);
             e.wait(S_COMM, EV_PACKED + s);
             if (r >= 2) e.wait(S_COMM, EV_PROBED + s);  // the probes of round r-2 have read recv[s]
-            if ((trc = net.all_to_all(net.user, send[s].p, recv[s].p, cap * 8))) return trc;
+            if (net.all_to_all_others) {  // the rank's own bucket is empty by construction: only its count word matters, and the loop writes that
+                e.clear_bytes((uint64_t *)recv[s].p + (uint64_t)me * cap, sizeof(uint64_t), S_COMM);
+                if ((trc = net.all_to_all_others(net.user, send[s].p, recv[s].p, cap * 8))) return trc;
+            } else if ((trc = net.all_to_all(net.user, send[s].p, recv[s].p, cap * 8))) {
+                return trc;
+            }
             st.sent_bytes += cap * 8 * (P - 1);
             e.record(EV_FP + s, S_COMM);
             if (r >= 1 && (trc = answers(r - 1))) return trc;  // issued AFTER fp(r): probes of r-1 ran while fp(r) travelled

@@ -88,6 +88,17 @@ int rccl_all_to_all(void *user, const void *send, void *recv, uint64_t bytes) {
     NCCLCK(R.GroupEnd());
     return MC_OK;
 }
+int rccl_all_to_all_others(void *user, const void *send, void *recv, uint64_t bytes) {  // every block but the rank's own
+    mc_comm *c = (mc_comm *)user;
+    NCCLCK(R.GroupStart());
+    for (uint32_t p = 0; p < c->world; ++p) {
+        if (p == c->rank) continue;
+        NCCLCK(R.Send((const char *)send + (size_t)p * bytes, bytes, ncclUint8, (int)p, c->comm, c->stream));
+        NCCLCK(R.Recv((char *)recv + (size_t)p * bytes, bytes, ncclUint8, (int)p, c->comm, c->stream));
+    }
+    NCCLCK(R.GroupEnd());
+    return MC_OK;
+}
 int rccl_all_to_all_v(void *user, const void *send, const uint64_t *so, const uint64_t *sb, void *recv, const uint64_t *ro, const uint64_t *rb) {
     mc_comm *c = (mc_comm *)user;
     NCCLCK(R.GroupStart());
@@ -241,6 +252,7 @@ int mc_comm_transport(mc_comm *c, mc_transport *out) {
     out->all_to_all = rccl_all_to_all;
     out->all_to_all_v = rccl_all_to_all_v;
     out->all_gather = rccl_all_gather;
+    out->all_to_all_others = rccl_all_to_all_others;
     return MC_OK;
 }
 
