@@ -1,24 +1,29 @@
 // engine.hip — the MI355X (gfx950) BFS engine behind include/tlamc.h.
 //
-// Per BFS level the frontier (a contiguous index range of the state arena in HBM) is processed
-// in chunks of `chunk_states` by three kernels, with no host synchronisation inside a level:
+// Per BFS level the frontier (a contiguous index range of the state arena in HBM) is processed in chunks of `chunk_states`
+// (bench.py: 2^23) with no host synchronisation inside a level; the host reads one small counter block per level, and while
+// levels are small it enqueues eight of them blind (LevelCtl).  The kernels, in the order they matter:
 //
-//   k_expand<Spec>      lane = frontier state, loop = action slot.  Evaluates every (state, slot)
-//                       pair of Next, computes the successor's 64-bit fingerprint (incrementally
-//                       for raft) and writes it to a SLOT-MAJOR candidate matrix
-//                       cand[slot][column] (0 = not enabled / not storable).  All arena reads and
-//                       all candidate writes are 512-byte coalesced per wavefront because the
-//                       arena is word-major inside blocks of 64 states (mc_common.h WordRef).
-//   k_insert            one thread per candidate cell: open-addressed seen-set in HBM, linear
-//                       probing, agent-scope atomicCAS on 64-bit fingerprints; survivors are
-//                       compacted with a wavefront ballot + one atomicAdd per wave into `newlist`.
-//   k_materialise<Spec> one lane per NEW state: re-evaluates its (parent, slot) and writes the
-//                       full successor into the arena (coalesced: consecutive lanes own
-//                       consecutive arena indices), plus (parent, slot) for counterexamples.
+//   k_expand_family<Spec, ROUTE>   (specs with action families: raft)  one wavefront = one arena block of 64 parents, one
+//                       workgroup = four.  Guards -> enabled (parent, slot) pairs, dense slots and the actions of in-flight
+//                       messages evaluated by the parent's lane, the sparse fixed slots bucketed per family in LDS and evaluated
+//                       64 pairs of ONE family at a time; successors that can never be stored are counted, not evaluated
+//                       (S::GENERATED_ONLY); a candidate's fingerprint is the parent's plus O(delta) terms; a per-wavefront
+//                       filter drops repeats; 64 candidates at a time probe the seen-set (open addressing over 32- or 64-byte
+//                       buckets in HBM, agent-scope atomicCAS on write-once slots).  ROUTE = false (fused runs): the
+//                       survivors wait in LDS and the WORKGROUP writes them at its end — pooled, counting-sorted by action
+//                       class, one atomicAdd on the arena's fill level, row copy + patch from the parent's Summary (the
+//                       in-wave tail; wave_write_survivors).  ROUTE = true (sharded runs): candidates of other owners go to
+//                       exchange buckets, the rank's own are probed here and go through the new-list.
+//   k_expand_insert<Spec, ROUTE>   the slot-by-slot form of the same (lane = parent, loop = action slot; every other spec).
+//   k_materialise<Spec> one lane per entry of the new-list (the survivors a wavefront had no list space for, every survivor of
+//                       a spec without in-wave writes, of a fast-growing level, or of a sharded run): re-evaluates its
+//                       (parent, slot) and writes the full successor (coalesced: consecutive lanes own consecutive arena
+//                       indices), plus (parent, slot) for counterexamples.  Runs on a second stream beside the next expand.
+//   k_expand + k_insert the round-1 form — a slot-major candidate matrix between two kernels — kept behind MC_F_MATRIX for A/B.
 //
-// Algorithmic HBM bytes per distinct state = 2*W + 8*(G/D)  (SURVEY.md §8d): each state is
-// written once and read once, each generated successor touches one 8-byte seen-set word.
-// The candidate matrix adds 16 B per evaluated cell on top (written by expand, read by insert).
+// Algorithmic HBM bytes per distinct state = 2*W + 8*(G/D)  (SURVEY.md §8d): each state is written once and read once, each
+// in-model successor touches one seen-set word; DESIGN.md §5 has what the kernels really move and what bounds them.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
