@@ -391,7 +391,7 @@ def main():
         "config": {"workload": WORKLOAD["name"], "distinct": D, "generated": G, "depth": res.depth,
                    "verdict": res.verdict, "queue_left": res.queue_left, "generated_per_s": G * a.steps / dt,
                    "seen_set_load": D / float(slots) if not use_dist else None,
-                   "golden": f"tests/golden/{WORKLOAD.get('golden_file', 'raft_levels.json')}:{WORKLOAD['golden']} (exact-dedup CPU oracle): counts and per-level counts equal"
+                   "golden": f"tests/golden/{WORKLOAD.get('golden_file', 'raft_levels.json')}:{WORKLOAD['golden']} (exact-dedup CPU oracle, its multi-threaded BFS on the GPU box's host): counts and per-level counts equal"
                              if not a.max_distinct else "A/B run with a budget: NOT the benchmark"},
     }
     if use_dist:
