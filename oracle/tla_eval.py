@@ -289,6 +289,20 @@ class Parser:
                     body = self.expr(0)
                     self.expect("]")
                     return ("funcdef", var, dom, body)
+                if self.cur().k == "id" and self.t[self.i + 1].k == "sym" and self.t[self.i + 1].s == "|->":
+                    # [f |-> e, g |-> h]: a record = a function on the field names (the translator's view of a record variable
+                    # it keeps field by field, tla_rust_amd/csrc/pcal.h RECORDS)
+                    fields = []
+                    while True:
+                        name = self.ident()
+                        self.expect("|->")
+                        fields.append((name, self.expr(0)))
+                        if self.is_sym(","):
+                            self.i += 1
+                            continue
+                        break
+                    self.expect("]")
+                    return ("record", fields)
                 first = self.expr(0)
                 if self.is_id("EXCEPT"):
                     self.i += 1
@@ -328,6 +342,9 @@ class Parser:
                 idx = self.expr(0)
                 self.expect("]")
                 e = ("idx", e, idx)
+            elif self.is_sym(".") and self.t[self.i + 1].k == "id":
+                self.i += 1
+                e = ("idx", e, ("str", self.ident()))
             elif self.is_sym("'"):
                 self.i += 1
                 e = ("prime", e)
@@ -579,6 +596,8 @@ class Checker:
             return frozenset(self.ev(x, st, nx, bd) for x in e[1])
         if k == "tuple":
             return Fn({i + 1: self.ev(x, st, nx, bd) for i, x in enumerate(e[1])})
+        if k == "record":
+            return Fn({name: self.ev(x, st, nx, bd) for name, x in e[1]})
         if k == "funcdef":
             return Fn({v: self.ev(e[3], st, nx, {**bd, e[1]: v}) for v in self.ev(e[2], st, nx, bd)})
         if k == "funcset":

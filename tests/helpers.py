@@ -233,7 +233,7 @@ class ShimProgram:
         lib.shim_program_free.argtypes = [C.c_void_p]
         lib.shim_program_translated.restype = C.c_char_p
         lib.shim_program_translated.argtypes = [C.c_void_p]
-        consts = ",".join(f"{k}={v}" for k, v in (constants or {}).items())
+        consts = ",".join(f"{k}={int(v)}" for k, v in (constants or {}).items())   # (TRUE / FALSE: 1 / 0, like frontend.cpp to_const)
         self.h = lib.shim_program_compile2(tla_text.encode(), ",".join(invariants).encode(), consts.encode(), ",".join(constraints).encode())
         if not self.h:
             raise RuntimeError(lib.shim_pcal_error().decode())

@@ -30,7 +30,7 @@ def amd():
 def cfg_text(invs, consts):
     s = "SPECIFICATION Spec\n"
     if consts:
-        s += "CONSTANTS " + " ".join(f"{k} = {v}" for k, v in consts.items()) + "\n"
+        s += "CONSTANTS " + " ".join(f"{k} = {str(v).upper() if isinstance(v, bool) else v}" for k, v in consts.items()) + "\n"
     if invs:
         s += "INVARIANTS " + " ".join(invs) + "\n"
     return s
@@ -167,6 +167,21 @@ def test_mc_on_a_module_with_procedures():
     assert "The depth of the complete state graph search is 22." in out
     rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "proc_nested.tla")
     assert rc == 0 and "12735 distinct states found" in out, err
+
+
+def test_mc_on_a_module_with_records():
+    """`mc treiber_records.tla` / `mc ring_buffer.tla` = tlc on PlusCal modules whose variables are RECORDS (round 4; kept field by
+    field, tla_rust_amd/csrc/pcal.h): the counts of the record-valued translations pcal2tla would write
+    (tests/golden/pcal_records/*.tla, evaluated in tests/test_pcal.py) on the GPU; the torn ring buffer's assertion is found"""
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "treiber_records.tla")
+    assert rc == 0, err
+    assert "19363 states generated, 9052 distinct states found, 0 states left on queue." in out
+    assert "The depth of the complete state graph search is 24." in out
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "ring_buffer.tla")
+    assert rc == 0 and "88 states generated, 55 distinct states found" in out, err
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "ring_buffer.tla", "-config", ROOT / "specs" / "pluscal" / "ring_buffer_torn.cfg")
+    assert rc == 12, err
+    assert '"Failure of assertion at line 36, column 9."' in out and "/\\ buf_full = " in out
 
 
 def test_bigger_program_throughput_smoke(amd):

@@ -436,6 +436,8 @@ def test_pluscal_translation_evaluated_vs_compiled_program(path, invs, consts, t
         def lit(v):
             if isinstance(v, (list, tuple, set, frozenset)):
                 return "{" + ", ".join(lit(x) for x in v) + "}"
+            if isinstance(v, bool):
+                return "TRUE" if v else "FALSE"
             return f'"{v}"' if isinstance(v, str) and not v.isidentifier() else str(v)
         cfg = "SPECIFICATION Spec\n" + "".join(f"CONSTANT {k} = {lit(v)}\n" for k, v in consts.items()) + "".join(f"INVARIANT {i}\n" for i in invs)
         if "CONSTANT defaultInitValue" in prog.translated():   # `variable tmp;` (p-manual section 3.1): a model value

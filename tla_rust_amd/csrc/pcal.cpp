@@ -220,6 +220,21 @@ struct Parser {
                 expect_sym(">>");
                 return e;
             }
+            if (k.s == "[" && peek().t == Tok::IDENT && i + 2 < t.size() && t[i + 2].t == Tok::SYM && t[i + 2].s == "|->") {  // [f |-> e, g |-> h]
+                i++;
+                auto e = mk(Expr::RECORD, k);
+                for (;;) {
+                    const std::string f = ident("a field name");
+                    for (const auto &n : e->names) if (n == f) fail("field " + f + " appears twice in the record");
+                    e->names.push_back(f);
+                    expect_sym("|->");
+                    e->a.push_back(expr(0));
+                    if (is_sym(",")) { i++; continue; }
+                    break;
+                }
+                expect_sym("]");
+                return e;
+            }
             if (k.s == "[") {  // [x \in S |-> e]
                 i++;
                 auto e = mk(Expr::FUNCDEF, k);
@@ -271,6 +286,13 @@ struct Parser {
                 auto x = mk(Expr::INDEX, at);
                 x->a = {e, expr(0)};
                 expect_sym("]");
+                e = x;
+            } else if (is_sym(".") && peek().t == Tok::IDENT) {  // r.f
+                const Tok at = cur();
+                i++;
+                auto x = mk(Expr::DOT, at);
+                x->s = t[i++].s;
+                x->a = {e};
                 e = x;
             } else if (is_sym("'")) {
                 const Tok at = cur();
@@ -500,6 +522,7 @@ struct Parser {
         s.k = Stmt::ASSIGN;
         s.var = t[i++].s;
         if (is_sym("[")) { i++; s.idx = expr(0); expect_sym("]"); if (is_sym("[")) fail("only one index level is supported on the left of `:=`"); }
+        if (is_sym(".")) { i++; s.field = ident("a field name after `.`"); if (is_sym("[") || is_sym(".")) fail("only `r.f` and `r[i].f` are supported on the left of `:=`"); }
         expect_sym(":=");
         s.e = expr(0);
         while (is_sym("||")) {  // a := e || b := f: simultaneous
@@ -509,10 +532,13 @@ struct Parser {
             o->pos = {cur().line, cur().col};
             o->var = ident("a variable after `||`");
             if (is_sym("[")) { i++; o->idx = expr(0); expect_sym("]"); }
+            if (is_sym(".")) { i++; o->field = ident("a field name after `.`"); }
             expect_sym(":=");
             o->e = expr(0);
-            if (o->var == s.var) fail("`||` with two assignments to " + s.var + " is not supported");
-            for (const auto &x : s.more) if (x->var == o->var) fail("`||` with two assignments to " + o->var + " is not supported");
+            // (two FIELDS of one record, `r.f := a || r.g := b`, are two variables here: pcal.h, RECORDS)
+            auto same = [&](const Stmt &x) { return x.var == o->var && (x.field.empty() || o->field.empty() || x.field == o->field); };
+            if (same(s)) fail("`||` with two assignments to " + s.var + " is not supported");
+            for (const auto &x : s.more) if (same(*x)) fail("`||` with two assignments to " + o->var + " is not supported");
             s.more.push_back(o);
         }
     }
@@ -1064,6 +1090,203 @@ struct ProcExpander {
 };
 }  // namespace
 
+// ---- records: kept field by field (pcal.h, RECORDS)
+namespace {
+struct FlattenError { std::string msg; };
+struct RecordFlattener {
+    Module &m;
+    std::map<std::string, const RecordVar *> recs;
+    [[noreturn]] static void fail(const Pos &at, const std::string &msg) { throw FlattenError{"line " + std::to_string(at.line) + ", column " + std::to_string(at.col) + ": " + msg}; }
+    static EP node(Expr::K k, const Pos &at) { auto e = std::make_shared<Expr>(); e->k = k; e->pos = at; return e; }
+    static EP id(const std::string &name, const Pos &at) { auto e = node(Expr::ID, at); e->s = name; return e; }
+    const RecordVar *rec_of(const EP &e) const {  // r or r[i] of a record variable r
+        const EP &b = e->k == Expr::INDEX ? e->a[0] : e;
+        if (b->k != Expr::ID) return nullptr;
+        auto it = recs.find(b->s);
+        return it == recs.end() ? nullptr : it->second;
+    }
+    bool record_valued(const EP &e) const { return e->k == Expr::RECORD || ((e->k == Expr::ID || e->k == Expr::INDEX) && rec_of(e)); }
+    std::vector<std::string> fields_of(const EP &e) const { return e->k == Expr::RECORD ? e->names : rec_of(e)->fields; }
+    static void check_field(const RecordVar &r, const std::string &f, const Pos &at) {
+        for (const auto &x : r.fields) if (x == f) return;
+        fail(at, "record " + r.name + " has no field " + f);
+    }
+    // field f of a record-valued expression
+    EP field_of(const EP &e, const std::string &f) const {
+        if (e->k == Expr::RECORD) {
+            for (size_t i = 0; i < e->names.size(); i++) if (e->names[i] == f) return rw(e->a[i]);
+            fail(e->pos, "the record has no field " + f);
+        }
+        const RecordVar &r = *rec_of(e);
+        check_field(r, f, e->pos);
+        if (e->k == Expr::ID) return id(r.name + "_" + f, e->pos);
+        auto x = node(Expr::INDEX, e->pos);
+        x->a = {id(r.name + "_" + f, e->a[0]->pos), rw(e->a[1])};
+        return x;
+    }
+    static bool same_fields(std::vector<std::string> a, std::vector<std::string> b) {
+        std::sort(a.begin(), a.end());
+        std::sort(b.begin(), b.end());
+        return a == b;
+    }
+    EP rw(const EP &e) const {
+        if (!e) return e;
+        switch (e->k) {
+        case Expr::DOT: {
+            const EP &b = e->a[0];
+            if (b->k == Expr::RECORD || ((b->k == Expr::ID || b->k == Expr::INDEX) && rec_of(b))) return field_of(b, e->s);
+            fail(e->pos, "`." + e->s + "`: field access is supported on record variables (r." + e->s + ", r[i]." + e->s + ") only");
+        }
+        case Expr::BINOP:
+            if ((e->s == "=" || e->s == "#") && (record_valued(e->a[0]) || record_valued(e->a[1]))) {
+                if (!record_valued(e->a[0]) || !record_valued(e->a[1])) fail(e->pos, "a record can only be compared with a record variable, an element of a record array or a record constructor");
+                const auto fs = fields_of(e->a[0]);
+                if (!same_fields(fs, fields_of(e->a[1]))) fail(e->pos, "comparison of records with different fields");
+                EP acc;
+                for (const auto &f : fs) {
+                    auto eq = node(Expr::BINOP, e->pos);
+                    eq->s = "=";
+                    eq->a = {field_of(e->a[0], f), field_of(e->a[1], f)};
+                    if (!acc) { acc = eq; continue; }
+                    auto both = node(Expr::BINOP, e->pos);
+                    both->s = "/\\";
+                    both->a = {acc, eq};
+                    acc = both;
+                }
+                acc->paren = true;
+                if (e->s == "=") return acc;
+                auto no = node(Expr::UNOP, e->pos);
+                no->s = "~";
+                no->a = {acc};
+                no->paren = true;
+                return no;
+            }
+            break;
+        case Expr::ID:
+            if (recs.count(e->s)) fail(e->pos, "record variable " + e->s + " is used as a whole value here (supported: " + e->s + ".f, " + e->s + " := ..., " + e->s + " = ...)");
+            return e;
+        case Expr::RECORD:
+            fail(e->pos, "a record constructor is supported as the initial value of a variable, on the right of `:=` to a record variable and in `=` / `#` only");
+        default: break;
+        }
+        auto c = std::make_shared<Expr>(*e);
+        for (auto &x : c->a) x = rw(x);
+        return c;
+    }
+    // one assignment `var[idx].field := e` -> the assignments to the fields' variables
+    void assignment(const Stmt &a, std::vector<SP> &out) const {
+        auto mk = [&](const std::string &var, const EP &idx, const EP &e, const std::string &whole) {
+            auto o = std::make_shared<Stmt>();
+            o->k = Stmt::ASSIGN;
+            o->pos = a.pos;
+            o->var = var;
+            o->idx = idx;
+            o->e = e;
+            o->whole = whole;
+            for (const auto &x : out) if (x->var == var) fail(a.pos, "two assignments to " + var + " in one statement");
+            out.push_back(o);
+        };
+        auto it = recs.find(a.var);
+        if (it == recs.end()) {
+            if (!a.field.empty()) fail(a.pos, a.var + " is not a record variable (its initial value is not a record constructor)");
+            if (record_valued(a.e)) fail(a.e->pos, "a record is assigned to " + a.var + ", which is not a record variable (its initial value is not a record constructor)");
+            mk(a.var, rw(a.idx), rw(a.e), "");
+            return;
+        }
+        const RecordVar &r = *it->second;
+        if (r.array != (a.idx != nullptr)) fail(a.pos, r.array ? "assignment to the whole record array " + r.name + " (supported: " + r.name + "[i] := ..., " + r.name + "[i].f := ...)" : r.name + " is a record, not an array of records");
+        if (!a.field.empty()) {
+            check_field(r, a.field, a.pos);
+            mk(r.name + "_" + a.field, rw(a.idx), rw(a.e), r.name);
+            return;
+        }
+        if (!record_valued(a.e)) fail(a.e->pos, "the value assigned to record variable " + r.name + " must be a record constructor, a record variable or an element of a record array");
+        if (!same_fields(r.fields, fields_of(a.e))) fail(a.e->pos, "the value assigned to " + r.name + " does not have its fields");
+        for (const auto &f : r.fields) mk(r.name + "_" + f, rw(a.idx), field_of(a.e, f), r.name);
+    }
+    void stmts(std::vector<SP> &v) const {
+        for (auto &s : v) {
+            if (s->k == Stmt::ASSIGN) {
+                std::vector<SP> flat;
+                assignment(*s, flat);
+                for (const auto &o : s->more) assignment(*o, flat);
+                auto c = std::make_shared<Stmt>(*flat[0]);
+                c->label = s->label;
+                c->more.assign(flat.begin() + 1, flat.end());
+                s = c;
+                continue;
+            }
+            if (s->k == Stmt::WITH && s->e && record_valued(s->e)) fail(s->e->pos, "`with` over a record value is not supported");
+            auto c = std::make_shared<Stmt>(*s);
+            c->e = rw(s->e);
+            c->idx = rw(s->idx);
+            for (auto &b : c->blocks) stmts(b);
+            s = c;
+        }
+    }
+    // declarations: a record variable becomes one variable per field
+    void decls(std::vector<VarDecl> &v, int proc, const std::set<std::string> &taken) {
+        std::vector<VarDecl> out;
+        for (const auto &d : v) {
+            const EP &e = d.init;
+            const bool scalar = e && !d.in_set && e->k == Expr::RECORD;
+            const bool array = e && !d.in_set && e->k == Expr::FUNCDEF && e->a[1]->k == Expr::RECORD;
+            if (!scalar && !array) { out.push_back(d); continue; }
+            const EP &rc = scalar ? e : e->a[1];
+            RecordVar r;
+            r.name = d.name;
+            r.fields = rc->names;
+            r.array = array;
+            r.proc = proc;
+            if (array) { r.bound = e->bound; r.domain = e->a[0]; }
+            for (size_t i = 0; i < rc->names.size(); i++) {
+                if (rc->a[i]->k == Expr::RECORD) fail(rc->a[i]->pos, "nested records are not supported");
+                VarDecl f = d;
+                f.name = d.name + "_" + rc->names[i];
+                if (taken.count(f.name)) fail(d.pos, "field " + rc->names[i] + " of record variable " + d.name + " is kept as a variable " + f.name + ", and that name is taken");
+                if (scalar) f.init = rc->a[i];
+                else { auto fn = std::make_shared<Expr>(*e); fn->a[1] = rc->a[i]; f.init = fn; }
+                out.push_back(f);
+            }
+            m.records.push_back(r);
+        }
+        v = out;
+    }
+    void run() {
+        std::set<std::string> taken(m.constants.begin(), m.constants.end());
+        for (const auto &g : m.globals) taken.insert(g.name);
+        for (const auto &p : m.procs) for (const auto &l : p.locals) taken.insert(l.name);
+        for (const auto &d : m.defs) taken.insert(d.name);
+        size_t locals = 0;
+        for (const auto &p : m.procs) locals += p.locals.size();
+        m.records.reserve(m.globals.size() + locals);  // (recs points into it)
+        decls(m.globals, -1, taken);
+        for (size_t k = 0; k < m.procs.size(); k++) decls(m.procs[k].locals, (int)k, taken);
+        for (const auto &r : m.records) {
+            if (recs.count(r.name)) fail(Pos{m.alg_first_line, 1}, "two record variables named " + r.name);
+            recs[r.name] = &r;
+        }
+        // (without a record variable too: a `.f` or a record constructor anywhere is refused by rw(), with its position)
+        for (auto &g : m.globals) g.init = rw(g.init);
+        for (auto &p : m.procs) {
+            for (auto &l : p.locals) l.init = rw(l.init);
+            stmts(p.body);
+        }
+        for (auto &d : m.defs) {
+            try {
+                d.body = rw(d.body);
+            } catch (const FlattenError &) {
+                if (d.in_define) throw;
+                d.body = nullptr;  // a definition of the module text beyond the subset: unusable as an invariant, like an unparsed one
+            }
+        }
+        std::vector<Definition> kept;
+        for (auto &d : m.defs) if (d.body) kept.push_back(d);
+        m.defs = kept;
+    }
+};
+}  // namespace
+
 std::string parse_module(const std::string &text, Module &m) {
     try {
         size_t a = text.find("--algorithm");
@@ -1179,6 +1402,11 @@ std::string parse_module(const std::string &text, Module &m) {
                 d.i++;
             }
         }
+        try {
+            RecordFlattener{m, {}}.run();
+        } catch (const FlattenError &e) {
+            return e.msg;
+        }
         return "";
     } catch (const LexError &e) {
         return e.msg;
@@ -1239,6 +1467,12 @@ std::string pe_inner(const EP &e, const Ctx &c, const std::set<std::string> &pri
         const std::string dom = pe(e->a[0], c, primed, shadow);
         sh.insert(e->bound);
         return "[" + e->bound + " \\in " + dom + " |-> " + pe(e->a[1], c, primed, sh) + "]";
+    }
+    case Expr::DOT: return pe(e->a[0], c, primed, shadow) + "." + e->s;
+    case Expr::RECORD: {
+        std::string s = "[";
+        for (size_t i = 0; i < e->a.size(); i++) s += (i ? ", " : "") + e->names[i] + " |-> " + pe(e->a[i], c, primed, shadow);
+        return s + "]";
     }
     case Expr::SETENUM:
     case Expr::TUPLE: {
@@ -1371,6 +1605,10 @@ struct ActionGen {
             if (!known) throw TranslateError{"assignment to undeclared variable " + s->var + " at line " + std::to_string(s->pos.line)};
             if (primed.count(s->var))
                 throw TranslateError{"second assignment to " + s->var + " in one step (line " + std::to_string(s->pos.line) + "): a label is needed between them"};
+            // a field's variable: pcal2tla sees ONE variable, the record (only `||` may assign two of its fields in a step)
+            const std::string rec_mark = s->whole.empty() ? std::string() : s->whole + ".";
+            if (!rec_mark.empty() && primed.count(rec_mark))
+                throw TranslateError{"second assignment to " + s->whole + " in one step (line " + std::to_string(s->pos.line) + "): a label is needed between them"};
             const std::string rhs = pe_rhs(s->e, c, primed, shadow);
             const bool local_fn = c.locals.count(s->var) && c.proc && c.proc->is_set;
             std::string t;
@@ -1395,11 +1633,14 @@ struct ActionGen {
                     for (auto &it : tmp.items) o.items.push_back(it);
                     o.assigned.insert(x->var);
                     after.insert(x->var);
+                    if (!x->whole.empty()) after.insert(x->whole + ".");
                 }
+                if (!rec_mark.empty()) after.insert(rec_mark);
                 primed = after;
                 break;
             }
             primed.insert(s->var);
+            if (!rec_mark.empty()) primed.insert(rec_mark);
             break;
         }
         case Stmt::AWAIT: o.items.push_back(line(pe(s->e, c, primed, shadow))); break;
@@ -1602,6 +1843,20 @@ std::string translate(const Module &m) {
         if (!rest.empty()) o += "VARIABLES " + join(rest, ", ") + "\n\n";
     }
     o += "vars == << " + join(vars, ", ") + " >>\n\n";
+    if (!m.records.empty()) {  // pcal.h, RECORDS: the record as the text around the algorithm knows it
+        o += "(* record variables are kept field by field: r.f is r_f *)\n";
+        for (const auto &r : m.records) {
+            const bool per_process = r.proc >= 0 && multi && m.procs[(size_t)r.proc].is_set;
+            const std::string at = r.array ? "[" + r.bound + "]" : "";
+            std::string rec = "[";
+            for (size_t i = 0; i < r.fields.size(); i++) rec += (i ? ", " : "") + r.fields[i] + " |-> " + r.name + "_" + r.fields[i] + (per_process ? "[self]" : "") + at;
+            rec += "]";
+            if (r.array) { std::set<std::string> sh{r.bound}; rec = "[" + r.bound + " \\in " + pe(r.domain, none, empty, sh) + " |-> " + rec + "]"; }
+            if (per_process) rec = "[self \\in " + pe(m.procs[(size_t)r.proc].id, none, empty, empty) + " |-> " + rec + "]";
+            o += r.name + " == " + rec + "\n";
+        }
+        o += "\n";
+    }
     if (multi) {
         std::vector<std::string> parts;
         for (const auto &p : m.procs) parts.push_back(p.is_set ? "(" + pe(p.id, none, empty, empty) + ")" : "{" + pe(p.id, none, empty, empty) + "}");

@@ -18,11 +18,12 @@ struct Pos { int line = 0, col = 0; };
 struct Expr;
 using EP = std::shared_ptr<Expr>;
 struct Expr {
-    enum K { NUM, STR, BOOL, ID, UNOP, BINOP, INDEX, IF, QUANT, SETENUM, TUPLE, FUNCDEF, PRIME, CALL } k = NUM;
+    enum K { NUM, STR, BOOL, ID, UNOP, BINOP, INDEX, IF, QUANT, SETENUM, TUPLE, FUNCDEF, PRIME, CALL, RECORD, DOT } k = NUM;
     long long num = 0;      // NUM, BOOL
-    std::string s;          // ID name, STR text, operator text, QUANT "\\A" / "\\E", CALL operator name
+    std::string s;          // ID name, STR text, operator text, QUANT "\\A" / "\\E", CALL operator name, DOT field name
     std::string bound;      // QUANT / FUNCDEF bound variable
-    std::vector<EP> a;      // operands; INDEX: [fn, index]; IF: [c, t, e]; QUANT / FUNCDEF: [domain, body]
+    std::vector<EP> a;      // operands; INDEX: [fn, index]; IF: [c, t, e]; QUANT / FUNCDEF: [domain, body]; DOT: [record]; RECORD: the values
+    std::vector<std::string> names;  // RECORD [f |-> e, g |-> h]: the field names, in the order written
     bool paren = false;     // written inside ( )
     Pos pos;
 };
@@ -35,6 +36,8 @@ struct Stmt {
     Pos pos;                               // of the statement keyword / lhs (asserts print it)
     std::string var;                       // ASSIGN lhs, WITH variable, GOTO target
     EP idx;                                // ASSIGN lhs index (x[i] := e), may be null
+    std::string field;                     // ASSIGN lhs field (r.f := e, r[i].f := e); gone after flatten_records
+    std::string whole;                     // ASSIGN to a variable that flatten_records made from the record variable `whole`
     EP e;                                  // ASSIGN rhs; condition of IF / WHILE / AWAIT / ASSERT; WITH set or value
     bool with_eq = false;                  // with x = e
     std::vector<std::vector<SP>> blocks;   // IF: then, else; EITHER: branches; WHILE / WITH: body
@@ -68,6 +71,16 @@ struct Procedure {
     Pos pos;
 };
 
+// A variable whose initial value is a record constructor (or a function to records): kept FIELD BY FIELD (flatten_records, pcal.cpp).
+struct RecordVar {
+    std::string name;                  // r: the variables of the translation are r_f, one per field
+    std::vector<std::string> fields;
+    bool array = false;                // r = [x \in S |-> [f |-> e, ...]]
+    std::string bound;                 // array: x
+    EP domain;                         // array: S
+    int proc = -1;                     // index into Module::procs of the process it is local to, -1 = global
+};
+
 struct Definition {
     std::string name;
     std::vector<std::string> params;
@@ -91,6 +104,7 @@ struct Module {
     std::vector<Macro> macros;
     std::vector<Procedure> procedures;      // as written; expand_procedures() has inlined them into the processes' bodies
     bool had_procedures = false;
+    std::vector<RecordVar> records;         // record variables, replaced by their fields' variables in globals / locals
     int alg_first_line = 0, alg_last_line = 0;   // lines of "(* --algorithm" and "end algorithm *)"
     bool has_translation = false;
     int tr_first_line = 0, tr_last_line = 0;     // "\* BEGIN TRANSLATION" .. "\* END TRANSLATION"
@@ -105,6 +119,14 @@ struct Module {
 // distinct / generated / depth and every verdict agree (tests/test_pcal.py checks it against hand-written stack translations);
 // what differs is the TEXT of the translation and of a printed state: no `stack` variable, the copies' label names.  Recursive
 // procedures and `call P(..); return` (pcal2tla's tail call) are refused with a message.
+// RECORDS (round 4): a variable initialised with `[f |-> e, g |-> h]` (or `[x \in S |-> [f |-> e, ...]]`) is kept field by field —
+// variables r_f, r_g; `r.f` / `r[i].f` read them, `r.f := e` / `r[i].f := e` assign one, `r := [f |-> a, g |-> b]`, `r := s`
+// (s another record variable or an element of a record array) assign all fields at once (`||`), `r = s` / `r # s` compare
+// fieldwise.  A record value <-> the tuple of its fields is a bijection on states, so counts, depth and verdicts equal those of
+// pcal2tla's translation (which keeps r one record-valued variable: tests/test_pcal.py checks it against hand-written record
+// translations); the translation's TEXT differs: it declares r_f, r_g and defines `r == [f |-> r_f, g |-> r_g]` after them, so
+// that the text around the algorithm (invariants written with r.f) keeps its meaning.  Refused with a message: nested records,
+// a record as a whole value anywhere else (`with`, procedure arguments, set members), sets of records as initial values.
 std::string parse_module(const std::string &text, Module &out);
 
 // The text `pcal2tla` inserts: from "\* BEGIN TRANSLATION" to "\* END TRANSLATION" inclusive, '\n' terminated.

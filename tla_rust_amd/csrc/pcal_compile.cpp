@@ -893,6 +893,8 @@ struct Compiler {
         }
         case Stmt::GOTO: case Stmt::WHILE:
             cfail(std::string(s->k == Stmt::GOTO ? "goto" : "while") + " must end its step: put a label after the enclosing statement", s->pos);
+        case Stmt::CALL: case Stmt::RETURN:
+            cfail("internal: a `call` / `return` survived the expansion of procedures", s->pos);
         }
         return 1;
     }
