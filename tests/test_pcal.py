@@ -474,6 +474,47 @@ def test_records_translate_like_their_fields():
         assert line in tr, (line, tr)
 
 
+PROC_WITH_RECORDS = r"""---- MODULE M ----
+EXTENDS Naturals
+CONSTANT N
+(* --algorithm M
+variables top = [ptr |-> 0, ver |-> 0], mem = [a \in 1..N |-> [val |-> 0, next |-> 0]], sum = 0;
+procedure push(node)
+variables old = [ptr |-> 0, ver |-> 0];
+begin
+  R: old := top;
+  L: mem[node].next := old.ptr;
+  C: if top = old then top := [ptr |-> node, ver |-> old.ver + 1]; else goto R; end if;
+  X: return;
+end procedure
+process w \in 1..N
+begin
+  A: mem[self].val := self;
+  B: call push(self);
+  D: sum := sum + mem[top.ptr].val;
+end process
+end algorithm *)
+Inv == top.ver <= N /\ (top.ptr # 0 => mem[top.ptr].val = top.ptr) /\ \A p \in 1..N : old[p].ver <= N
+====
+"""
+
+
+@pytest.mark.parametrize("n,distinct", [(2, 91), (3, 1688)])
+def test_a_procedure_with_a_record_variable(n, distinct):
+    """procedures are expanded first, records flattened after: a procedure's own record variable becomes the calling processes'
+    `old_ptr`, `old_ver`, is reset field by field on `return`, and the invariant reads it as `old[p].ver` through the derived definition"""
+    tr = helpers.pcal_translate(PROC_WITH_RECORDS)
+    assert "old == [self \\in 1..N |-> [ptr |-> old_ptr[self], ver |-> old_ver[self]]]" in tr
+    o = Checker(tr, constants={"N": n}).run_levels(invariants=["Inv"])
+    prog = helpers.ShimProgram(PROC_WITH_RECORDS, ["Inv"], {"N": n})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["verdict"], o["levels"])
+    assert o["verdict"] == "ok" and o["distinct"] == distinct
+
+
 PROC_HEAD = "---- MODULE M ----\nEXTENDS Naturals\n(* --algorithm M\nvariables x = 0;\n"
 PROC_ERRORS = [
     ("procedure f(a) begin F1: x := a; call f(a); F2: return; end procedure; begin M1: call f(1); M2: skip; end algorithm *)\n====\n", "recursive call of procedure f"),
