@@ -3,7 +3,8 @@ fields, a set and a sequence variable, `||`, if / either / with / await / assert
 product's back-ends and must describe the same state graph:
 
   * the translator's TLA+ text (tla_rust_amd/csrc/pcal.cpp: translate), evaluated by the oracle's evaluator (oracle/tla_eval.py), and
-  * the compiled bytecode program (tla_rust_amd/csrc/pcal_compile.cpp), run by the host build of the engine's interpreter (tests/_shim).
+  * the compiled bytecode program (tla_rust_amd/csrc/pcal_compile.cpp), run by the host build of the engine's interpreter (tests/_shim),
+  * and the same translation evaluated by the product's host evaluator (tla_rust_amd/csrc/tlaeval.cpp), counters only.
 
 Counters, depth, verdict (ok / invariant / assert / deadlock), trace length, per-level counts and the SET of states of every level.
 The hand-written specs of specs/pluscal/ cover the constructs one by one; this covers their combinations (the shapes p-manual
@@ -17,6 +18,7 @@ import pytest
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 import helpers  # noqa: E402
 import test_pcal  # noqa: E402
+import test_tlaeval  # noqa: E402
 
 MAX_STATES = 3000
 
@@ -237,6 +239,8 @@ def test_random_algorithm_translated_vs_compiled(seed, tmp_path):
     path.write_text(text)
     try:
         test_pcal.test_compiled_program_vs_tla_evaluator(path, invs, {})
+        # ... and a third opinion: the product's host evaluator (tla_rust_amd/csrc/tlaeval.cpp) on the translation
+        test_tlaeval.test_pluscal_translation_evaluated_vs_compiled_program(path, invs, {}, tmp_path)
     except AssertionError:
         print(text)
         raise
