@@ -432,3 +432,30 @@ def test_seen_set_of_any_size(amd, oracle, slots):
         r = eng.run()
         assert (r.distinct, r.generated, r.depth, r.levels) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- random configurations (round 4)
+@pytest.mark.parametrize("seed", range(20))
+def test_raft_random_configuration_prefix_on_gpu(amd, oracle, seed):
+    """the seeded random raft configurations of tests/test_lowering_sweep.py (server counts, term / log / message bounds, MaxMsgKeys,
+    invariant masks) through the HIP engine against the C oracle run beside it: counters, verdict, depth, every per-level count"""
+    from test_lowering_sweep import raft_config
+    dev = raft_config(seed)
+    o = oracle.oracle_run("raft", oracle.raft_oracle_params(dev), max_distinct=60000)
+    eng = amd.Engine("raft", dev, table_capacity=1 << 21, arena_capacity=1 << 20, chunk_states=1 << 13, max_distinct=60000, trace=False)
+    r = eng.run()
+    for k in ("distinct", "generated", "depth", "verdict", "levels"):
+        assert o[k] == r[k], (k, dev)
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_ssi_random_configuration_prefix_on_gpu(amd, oracle, seed):
+    from test_lowering_sweep import ssi_config
+    params = ssi_config(seed)
+    o = oracle.oracle_run("ssi", params, max_distinct=40000)
+    eng = amd.Engine("ssi", params, table_capacity=1 << 21, arena_capacity=1 << 20, chunk_states=1 << 13, max_distinct=40000, trace=False)
+    r = eng.run()
+    for k in ("distinct", "generated", "depth", "verdict", "levels"):
+        assert o[k] == r[k], (k, params)
+    eng.close()
