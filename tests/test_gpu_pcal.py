@@ -287,3 +287,27 @@ def test_wide_state_on_gpu(amd):
     assert r.generated == 1 + sum(comb(70, k) * (70 - k) for k in range(4))
     eng.close()
     prog.close()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_algorithm_on_gpu_vs_tla_evaluator(amd, seed, tmp_path):
+    """the seeded random algorithms of tests/test_pcal_fuzz.py (records, set / sequence variables, macros, procedures, every kind of
+    statement) compiled and run by the HIP engine, against the oracle's evaluator on the translation: counters, verdict, trace
+    length, per-level counts and the set of states of every level"""
+    import helpers
+    from test_pcal_fuzz import Gen, MAX_STATES
+    text, invs = Gen(seed).program()
+    try:
+        helpers.pcal_translate(text)
+    except RuntimeError as e:
+        pytest.skip(f"refused: {e}")
+    prog = helpers.ShimProgram(text, invs, {})
+    try:
+        n = helpers.shim_run("pcal", prog.params)["distinct"]
+    finally:
+        prog.close()
+    if n > MAX_STATES:
+        pytest.skip(f"{n} states: too many for the Python evaluator in a unit test")
+    path = tmp_path / "Fz.tla"
+    path.write_text(text)
+    test_compiled_program_on_gpu_vs_tla_evaluator(amd, path, invs, {})
