@@ -525,6 +525,9 @@ PROC_ERRORS = [
     ("procedure f(a) begin F1: x := a; return; end procedure; procedure g() begin G1: call f(1); return; end procedure; begin M1: call g(); M2: skip; end algorithm *)\n====\n", "tail call"),
     ("begin M1: x := 1; return; end algorithm *)\n====\n", "`return` outside a procedure"),
     ("begin M1: call nope(1); M2: skip; end algorithm *)\n====\n", "no such procedure"),
+    # (one name, one variable: pcal2tla would rename the second `t`; here both back-ends refuse, the translator included)
+    ("process a = 1 variables t = 0; begin A1: t := 1; end process; process b = 2 variables t = 0; begin B1: t := 2; end process; end algorithm *)\n====\n", "variable `t` is declared twice"),
+    ("process a = 1 variables x = 0; begin A1: x := 1; end process; end algorithm *)\n====\n", "variable `x` is declared twice"),
 ]
 
 

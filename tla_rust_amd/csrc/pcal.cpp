@@ -1337,6 +1337,12 @@ std::string parse_module(const std::string &text, Module &m) {
             }
         }
         add_missing_labels(m);
+        {   // one name, one variable (pcal2tla renames a second `t` to `t_`; here the author does: both back-ends refuse alike)
+            std::set<std::string> names{"pc"};
+            auto declare = [&](const VarDecl &d) { return names.insert(d.name).second; };
+            for (const auto &g : m.globals) if (!declare(g)) return "variable `" + g.name + "` is declared twice";
+            for (const auto &p : m.procs) for (const auto &l : p.locals) if (!declare(l)) return "variable `" + l.name + "` is declared twice (a variable of one process may not have the name of a global variable or of another process's variable)";
+        }
         // the rest: an existing translation (skipped) and the definitions
         size_t rest = cend;
         const size_t tb = text.find("\\* BEGIN TRANSLATION", cend);
