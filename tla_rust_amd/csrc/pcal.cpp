@@ -1095,7 +1095,7 @@ namespace {
 struct FlattenError { std::string msg; };
 struct RecordFlattener {
     Module &m;
-    std::map<std::string, const RecordVar *> recs;
+    std::map<std::string, RecordVar> recs;   // by name (copies: m.records grows while they are collected)
     [[noreturn]] static void fail(const Pos &at, const std::string &msg) { throw FlattenError{"line " + std::to_string(at.line) + ", column " + std::to_string(at.col) + ": " + msg}; }
     static EP node(Expr::K k, const Pos &at) { auto e = std::make_shared<Expr>(); e->k = k; e->pos = at; return e; }
     static EP id(const std::string &name, const Pos &at) { auto e = node(Expr::ID, at); e->s = name; return e; }
@@ -1103,7 +1103,7 @@ struct RecordFlattener {
         const EP &b = e->k == Expr::INDEX ? e->a[0] : e;
         if (b->k != Expr::ID) return nullptr;
         auto it = recs.find(b->s);
-        return it == recs.end() ? nullptr : it->second;
+        return it == recs.end() ? nullptr : &it->second;
     }
     bool record_valued(const EP &e) const { return e->k == Expr::RECORD || ((e->k == Expr::ID || e->k == Expr::INDEX) && rec_of(e)); }
     std::vector<std::string> fields_of(const EP &e) const { return e->k == Expr::RECORD ? e->names : rec_of(e)->fields; }
@@ -1193,7 +1193,7 @@ struct RecordFlattener {
             mk(a.var, rw(a.idx), rw(a.e), "");
             return;
         }
-        const RecordVar &r = *it->second;
+        const RecordVar &r = it->second;
         if (r.array != (a.idx != nullptr)) fail(a.pos, r.array ? "assignment to the whole record array " + r.name + " (supported: " + r.name + "[i] := ..., " + r.name + "[i].f := ...)" : r.name + " is a record, not an array of records");
         if (!a.field.empty()) {
             check_field(r, a.field, a.pos);
@@ -1257,14 +1257,11 @@ struct RecordFlattener {
         for (const auto &g : m.globals) taken.insert(g.name);
         for (const auto &p : m.procs) for (const auto &l : p.locals) taken.insert(l.name);
         for (const auto &d : m.defs) taken.insert(d.name);
-        size_t locals = 0;
-        for (const auto &p : m.procs) locals += p.locals.size();
-        m.records.reserve(m.globals.size() + locals);  // (recs points into it)
         decls(m.globals, -1, taken);
         for (size_t k = 0; k < m.procs.size(); k++) decls(m.procs[k].locals, (int)k, taken);
         for (const auto &r : m.records) {
             if (recs.count(r.name)) fail(Pos{m.alg_first_line, 1}, "two record variables named " + r.name);
-            recs[r.name] = &r;
+            recs[r.name] = r;
         }
         // (without a record variable too: a `.f` or a record constructor anywhere is refused by rw(), with its position)
         for (auto &g : m.globals) g.init = rw(g.init);
