@@ -93,3 +93,35 @@ def test_lowering_equals_reference_text_fixture(name, tmp_path):
 def test_models_use_the_committed_wrapper():
     assert "EXTENDS raft" in (ROOT / "specs" / "MCraft.tla").read_text()
     assert "MaxTerm = 2" in raft_cfg(2, 1, 2, 9, 1)
+
+
+def _sweep_config(seed):
+    import random
+    r = random.Random(500 + seed)
+    n = r.choice([2, 2, 2, 3])
+    mcr, mt, mll, mm = r.randrange(1, 4), r.choice([2, 3]), r.choice([2, 3, 9]), r.choice([1, 1, 2])
+    mk = r.choice([4, 5, 6, 8]) if n == 2 else r.choice([3, 4])
+    inv = r.choice([1, 3])
+    return [n, mcr, mt, mll, mm, inv], mk
+
+
+@pytest.mark.skipif(not REF.exists(), reason="/root/reference is only present in the build container")
+@pytest.mark.parametrize("seed", range(16))
+def test_c_oracle_equals_the_reference_text_on_random_configurations(seed, tmp_path):
+    """the reference's raft.tla, evaluated from its TEXT by the product's C++ evaluator (tlaeval.cpp) under seeded random constants
+    (server count, MaxClientRequests, MaxTerm, MaxLogLen, MaxMsgs, MaxMsgKeys, invariants), against the C oracle's hand restatement:
+    counters, per-level counts and the per-level SETS of states (canonical TLA+ text) over the first 11 levels (9 with three servers) — the fixed models
+    above pin the configurations the goldens use, this walks the parameter space between them.  (To 13 levels — up to 330 s a case —
+    the first ten seeds were equal too when the test was written.)"""
+    params, mk = _sweep_config(seed)
+    cfg = tmp_path / "m.cfg"
+    cfg.write_text(raft_cfg(*params[:5], params[5], mk))
+    from make_reference_text_golden import RAFT_ORDER
+    ed, od = tmp_path / "e.txt", tmp_path / "o.txt"
+    depth = 9 if params[0] == 3 else 11          # (what keeps a case under ~20 s of evaluation)
+    e = helpers.tlaeval_run(ROOT / "specs" / "MCraft.tla", cfg, search=[str(REF)], dump=ed, order=RAFT_ORDER, max_levels=depth)
+    assert e["rc"] == 0, e
+    o = helpers.oracle_run("raft", params + [0, mk], dump=str(od), max_levels=depth)
+    assert (o["distinct"], o["generated"], o["depth"], o["levels"]) == (e["distinct"], e["generated"], e["depth"], e["levels"]), (params, mk)
+    assert level_digests(helpers.read_dump(str(od))) == level_digests(helpers.read_dump(str(ed))), (params, mk)
+    assert o["distinct"] > 300
