@@ -33,6 +33,9 @@ extern "C" {
 #define MC_ESTATE (-7)     /* call sequence error                                            */
 #define MC_EPARSE (-8)     /* .cfg / .tla front-end error                                    */
 #define MC_ENOSPEC (-9)    /* module is not one of the lowered specs (or its text changed)   */
+#define MC_EROUTE (-10)    /* sharded mode: an exchange bucket of a round was too small for the candidates it had to hold
+                            * (mc_shard_opts.packed_fanout / move_fanout); nothing was truncated.  mc_shard_run* does not hand
+                            * this to its caller until it has restarted the search with twice the allowance (mc_shard_stats.restarts) */
 
 /* ------------------------------------------------------------------ verdicts (TLC's outcomes) */
 #define MC_V_OK 0          /* "Model checking completed. No error has been found." (testout2:260) */
@@ -320,6 +323,7 @@ typedef struct {
     uint64_t distinct_local;    /* states resident on this rank at the end (its share)                                       */
     uint64_t max_frontier;      /* over the sharded levels: largest max-over-ranks frontier ...                              */
     uint64_t mean_frontier;     /* ... and the mean frontier of that same level (imbalance = max / mean)                     */
+    uint64_t restarts;          /* times the search was started over from Init with twice the fan-out allowance (MC_EROUTE)  */
 } mc_shard_stats;
 typedef struct {
     uint64_t chunk_states;    /* frontier states per round and rank (0 = 2^19); clamped to the engine's chunk_states         */
@@ -328,7 +332,8 @@ typedef struct {
     uint64_t replicate_until; /* states per rank a level must have before the search is sharded (0 = 2^15); below it every
                                * rank runs the same fused BFS (mc_shard_begin_replicated)                                    */
     uint64_t packed_fanout;   /* in-model successors per expanded state the fixed-capacity buckets allow for (0 = 16); a
-                               * level that exceeds it fails with MC_EARENA, it is never truncated                          */
+                               * round that exceeds it is never truncated: the level fails on every rank (MC_EROUTE) and
+                               * mc_shard_run* starts the search over with twice the allowance (at most 5 times)            */
     uint64_t stay_threshold;  /* states per rank a level needs before its new states STAY where they were generated
                                * (0 = 2^15); smaller levels MOVE every new state to its owner, which is what spreads a
                                * small frontier over the ranks                                                              */

@@ -776,7 +776,7 @@ struct ShimShard : ShimShardBase {
         for (uint32_t o = 0; o < nranks; o++) {
             pend_off[o] = k;
             send_counts[o] = fps[o].size();
-            if (k + fps[o].size() > send_cap) return MC_EARENA;
+            if (k + fps[o].size() > send_cap) { mc_set_error_internal("shim expand: send buffer too small"); return MC_EROUTE; }
             for (size_t j = 0; j < fps[o].size(); j++) { send_fp[k++] = fps[o][j]; pending.push_back(src[o][j]); }
         }
         pend_off[nranks] = k;
@@ -798,7 +798,7 @@ struct ShimShard : ShimShardBase {
             uint64_t k = 0;
             for (uint64_t i = pend_off[o]; i < pend_off[o + 1]; i++) {
                 if (!answers_back[i]) continue;
-                if ((blk0 + k / 64 + 1) * 64 > send_cap) return MC_EARENA;
+                if ((blk0 + k / 64 + 1) * 64 > send_cap) return MC_EARENA;  // (the loop sizes the buffer for the upper bound and repeats)
                 mp.push_back((pending[i].parent << 16) | (uint64_t)(unsigned)pending[i].slot);
                 S::apply(prm, CWordRef{&arena[pending[i].parent * W], 1}, pending[i].slot,
                          WordRef{out + (blk0 + k / 64) * (uint64_t)W * 64 + k % 64, 64});
@@ -893,7 +893,8 @@ extern "C" const char *mc_strerror(int code) {
         case MC_EHIP: return "HIP error";
         case MC_EOVERFLOW: return "packed-state slot overflow";
         case MC_ETABLEFULL: return "seen-set full";
-        case MC_EARENA: return "arena / exchange buffer exhausted";
+        case MC_EARENA: return "arena exhausted";
+        case MC_EROUTE: return "exchange bucket full";
         case MC_ERCCL: return "exchange failure";
         case MC_ESTATE: return "call sequence error";
         default: return "error";
@@ -937,7 +938,7 @@ struct ShimOps {
         memset(send_fp, 0, (size_t)P * cap * 8);
         uint64_t off = 0;
         for (uint32_t t = 0; t < P; t++) {
-            if (counts[t] + 1 > cap) { mc_set_error_internal("an exchange bucket is full"); return MC_EARENA; }
+            if (counts[t] + 1 > cap) { mc_set_error_internal("an exchange bucket is full"); return MC_EROUTE; }
             send_fp[(uint64_t)t * cap] = counts[t];
             memcpy(send_fp + (uint64_t)t * cap + 1, tmp.data() + off, counts[t] * 8);
             off += counts[t];
@@ -982,8 +983,7 @@ struct ShimOps {
 
 extern "C" int shim_shard_run_transport(void *e, const mc_transport *t, const mc_shard_opts *o, mc_result *out) {
     ShimOps ops{(ShimShardBase *)e, t->world, {}};
-    mc_shard::Loop<ShimOps> loop(ops, *t);
-    return loop.run(*o, out);
+    return mc_shard::run_restarting(ops, *t, *o, out);
 }
 extern "C" int shim_shard_trace_transport(void *e, const mc_transport *t, uint8_t *states_out, int32_t *slots_out, size_t *n_inout, int32_t *final_slot) {
     ShimOps ops{(ShimShardBase *)e, t->world, {}};

@@ -47,6 +47,18 @@ def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path):
     assert r["phases"].get("stay_levels", 0) >= 3
 
 
+def test_a_full_exchange_bucket_restarts_the_search_on_gpu(oracle, tmp_path):
+    """round 4: an allowance of ONE in-model successor per state (packed_fanout = move_fanout = 1) overflows the route buckets of the
+    HIP engines (DEV_EROUTE / "send buffer too small" -> MC_EROUTE on every rank, nothing truncated); mc_shard_run_transport starts
+    the search over with twice the allowance until it fits: the oracle's counters, and mc_shard_stats.restarts says how often"""
+    params = [3, 2, 2, 9, 1, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=100000)
+    r = run_dist("hip", 2, "raft", params, tmp_path, {"max_distinct": 100000, "chunk": 1 << 13, "table": 1 << 22, "arena": 1 << 20,
+                                                       "stay_threshold": 200, "rebalance_ratio": 1.5, "packed_fanout": 1, "move_fanout": 1})
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert r["stats"]["restarts"] >= 2
+
+
 @pytest.mark.parametrize("world,replicate_until", [(2, 0), (3, 0), (3, 40)])
 def test_counterexample_walked_back_across_ranks(oracle, tmp_path, world, replicate_until):
     """README.md:267-321 on several ranks with MC_F_TRACE engines: the parents of states that moved to their owner travelled

@@ -241,3 +241,44 @@ def test_ranks_that_did_not_restore_the_same_run_stop_together(oracle, shim, tmp
     """rank 0 restored, rank 1 starts from Init: the level tables travel with the first all-gather and every rank refuses"""
     r = run_dist("shim", 2, "raft", [2, 2, 2, 9, 2, 1], tmp_path, {"max_levels": 6, "chunk": 700, "checkpoint": str(tmp_path / "ck"), "restore_only_rank0": True})
     assert len(r["run_errors"]) == 2 and all("same run" in e for e in r["run_errors"])
+
+
+def _random_sharding(seed):
+    import random
+    from test_lowering_sweep import raft_config, ssi_config
+    r = random.Random(3000 + seed)
+    spec = r.choice(["raft", "raft", "ssi"])
+    params = raft_config(r.randrange(40)) if spec == "raft" else ssi_config(r.randrange(24))
+    world = r.choice([2, 3, 4, 5])
+    opts = {"max_distinct": 30000, "chunk": r.choice([150, 400, 1000, 4000]), "stay_threshold": r.choice([20, 60, 400, 1 << 15]),
+            "rebalance_ratio": r.choice([1.2, 1.6, 2.5]), "replicate_until": r.choice([0, 0, 30, 300])}
+    return spec, params, world, opts
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TLAMC_SWEEP", "10"))))
+def test_random_model_world_and_exchange_settings(oracle, shim, tmp_path, seed):
+    """seeded random combinations of a model (the raft / SI configurations of tests/test_lowering_sweep.py), a world size (2-5), the
+    chunk size, the frontier size from which states stay on their rank, the rebalancing ratio and the length of the replicated prefix:
+    whatever mix of replicated, move and stay levels that gives, the counters and every per-level count are the oracle's"""
+    spec, params, world, opts = _random_sharding(seed)
+    oparams = oracle.raft_oracle_params(params) if spec == "raft" else params
+    o = oracle.oracle_run(spec, oparams, max_distinct=opts["max_distinct"])
+    r = run_dist("shim", world, spec, params, tmp_path, opts)
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == \
+           (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"]), (spec, params, world, opts)
+    assert sum(r["shares"]) == o["distinct"] and len(r["shares"]) == world
+
+
+def test_a_full_exchange_bucket_restarts_the_search(oracle, shim, tmp_path):
+    """more in-model successors per state than `packed_fanout` allows for (found by the sweep above: seed 38 of 70) is MC_EROUTE on
+    every rank — nothing truncated, nobody left in a collective — and mc_shard_run* starts over with twice the allowance: the run
+    ends with the oracle's counters and says how often it restarted; with an allowance of 1 it needs several doublings"""
+    params = [3, 4, 3, 3, 2, 3, 5, 0, 0, 5]
+    opts = {"max_distinct": 30000, "chunk": 1000, "stay_threshold": 60, "rebalance_ratio": 1.6, "replicate_until": 30}
+    o = oracle.oracle_run("raft", oracle.raft_oracle_params(params), max_distinct=30000)
+    r = run_dist("shim", 2, "raft", params, tmp_path, opts)
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert r["stats"]["restarts"] >= 1
+    r = run_dist("shim", 3, "raft", params, tmp_path, dict(opts, packed_fanout=1, move_fanout=1))
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert r["stats"]["restarts"] >= 3

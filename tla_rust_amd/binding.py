@@ -56,7 +56,8 @@ MC_SHARD_NO_PREFIX = 1
 class ShardStats(C.Structure):
     """mc_shard_stats: what one rank's level loop did"""
     _fields_ = [("replicated_levels", C.c_uint64), ("stay_levels", C.c_uint64), ("move_levels", C.c_uint64), ("rounds", C.c_uint64),
-                ("sent_bytes", C.c_uint64), ("distinct_local", C.c_uint64), ("max_frontier", C.c_uint64), ("mean_frontier", C.c_uint64)]
+                ("sent_bytes", C.c_uint64), ("distinct_local", C.c_uint64), ("max_frontier", C.c_uint64), ("mean_frontier", C.c_uint64),
+                ("restarts", C.c_uint64)]
 
 
 class ShardOpts(C.Structure):

@@ -1872,7 +1872,7 @@ struct Engine : EngineBase {
     int check_dev_error() {
         if (h_ctr->error & DEV_EOVERFLOW) { set_error("packed-state capacity exceeded (raft messages / elections / allLogs slots, or a PlusCal sequence longer than its cells)"); return MC_EOVERFLOW; }
         if (h_ctr->error & DEV_ETABLE) { set_error("seen-set full: raise table_capacity"); return MC_ETABLEFULL; }
-        if (h_ctr->error & DEV_EROUTE) { set_error("sharded round: an exchange bucket is full (raise the fan-out allowance / send capacity)"); return MC_EARENA; }
+        if (h_ctr->error & DEV_EROUTE) { set_error("sharded round: an exchange bucket is full (raise the fan-out allowance / send capacity)"); return MC_EROUTE; }
         if (h_ctr->error & DEV_EARENA) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }
         return MC_OK;
     }
@@ -2746,13 +2746,14 @@ struct Engine : EngineBase {
         for (unsigned t = 0; t < P; t++) {
             q.pend_off.off[t] = total;
             for (unsigned x = 0; x < NSHARD; x++) {
-                if (cur[t * NSHARD + x].v > q.rt_subcap) { set_error("shard_expand: route bucket overflow (raise send_cap)"); return MC_EARENA; }
+                if (cur[t * NSHARD + x].v > q.rt_subcap) { set_error("shard_expand: route bucket overflow (raise send_cap)"); return MC_EROUTE; }
                 send_counts[t] += cur[t * NSHARD + x].v;
             }
             total += send_counts[t];
         }
         for (unsigned t = P; t <= 8; t++) q.pend_off.off[t] = total;
-        if (total > send_cap || total > q.pend_cap || total >= (1ull << 31)) { set_error("shard_expand: send buffer too small"); return MC_EARENA; }
+        if (total > q.pend_cap || total >= (1ull << 31)) { set_error("shard_expand: more candidates in one round than the engine's pending list holds (lower chunk_states)"); return MC_EARENA; }
+        if (total > send_cap) { set_error("shard_expand: send buffer too small (raise the fan-out allowance)"); return MC_EROUTE; }
         q.pend_total = total;
         if (q.keep_pending) {  // the slot's previous keep still reads pend_src
             HIP_TRY(hipStreamWaitEvent(side(), ev_keep[slot], 0));
@@ -2892,7 +2893,7 @@ struct Engine : EngineBase {
         q.plan = plan;
         q.moved = 0;
         for (unsigned t = 0; t < P; t++) q.moved += plan.cnt[t];
-        if (blocks * 64 > send_cap) { set_error("shard_materialise: state send buffer too small"); return MC_EARENA; }
+        if (blocks * 64 > send_cap) { set_error("shard_materialise: state send buffer too small"); return MC_EARENA; }  // (the loop sizes it for the upper bound and repeats)
         if (blocks) {
             timed(2, blocks * 64, [&] {
                 hipLaunchKernelGGL(k_send_materialise<S>, dim3((unsigned)((blocks * 64 + 255) / 256)), dim3(256), 0, side(), prm, d_arena,
@@ -3317,6 +3318,7 @@ const char *mc_strerror(int code) {
     case MC_ESTATE: return "call sequence error";
     case MC_EPARSE: return "parse error";
     case MC_ENOSPEC: return "module is not a lowered spec";
+    case MC_EROUTE: return "exchange bucket full";
     default: return "unknown error";
     }
 }

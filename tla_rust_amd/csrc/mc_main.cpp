@@ -185,6 +185,8 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
     so.chunk_states = cfg.chunk_states;
     so.max_distinct = cfg.max_distinct;
     so.max_levels = cfg.max_levels;
+    static mc_shard_stats sstats;
+    so.stats = &sstats;
     static mc_result res;
     // -recover FILE / -checkpoint FILE with -gpus P: one file per rank, FILE.rank<r>of<P> (mc_shard_restore / mc_shard_checkpoint)
     auto rank_file = [&](const char *stem) { return std::string(stem) + ".rank" + std::to_string(rank) + "of" + std::to_string(world); };
@@ -193,6 +195,9 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
     rc = mc_shard_run(eng, comm, &so, &res);
     const double dt = now_s() - t0;
     if (rc) fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error());
+    if (sstats.restarts && rank == 0)
+        fprintf(stderr, "mc: a level had more successors per state than the exchange buckets allow for; the search was started over %llu time(s), "
+                        "each with twice the allowance\n", (unsigned long long)sstats.restarts);
     bool ckpt_done = false;
     if (!rc && ckpt && (res.verdict == MC_V_OK || res.verdict == MC_V_BUDGET)) {
         if ((rc = mc_shard_checkpoint(eng, rank_file(ckpt).c_str()))) fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error());

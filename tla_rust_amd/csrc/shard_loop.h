@@ -504,5 +504,28 @@ struct Loop {
     }
 };
 
+// The whole search.  A round whose exchange bucket was too small for its candidates (more in-model successors per state than
+// packed_fanout / move_fanout allow for) fails the level on EVERY rank with MC_EROUTE — the statuses travel with the level's
+// all-gather, nothing was truncated and nobody is left inside a collective — and the search is started over from Init with twice
+// the allowance: the engine's begin / begin_replicated clear the seen-set and the arena as they do for every run, the exchange
+// buffers belong to the Loop.  (A run restored from checkpoints starts over from Init too: correct, only slower.)  Every rank takes
+// the same decision from the same status, so the restarts need no further agreement.
+template <class Ops>
+int run_restarting(Ops &ops, const mc_transport &t, const mc_shard_opts &o, mc_result *out) {
+    mc_shard_opts cur = o;
+    uint64_t restarts = 0;
+    for (;;) {
+        Loop<Ops> loop(ops, t);
+        const int rc = loop.run(cur, out);
+        if (rc != MC_EROUTE || restarts == 5) {
+            if (o.stats) o.stats->restarts = restarts;
+            return rc;
+        }
+        cur.packed_fanout = 2 * (cur.packed_fanout ? cur.packed_fanout : 16);
+        cur.move_fanout = 2 * (cur.move_fanout ? cur.move_fanout : 32);
+        ++restarts;
+    }
+}
+
 }  // namespace mc_shard
 #endif

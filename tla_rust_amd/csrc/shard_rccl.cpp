@@ -270,8 +270,7 @@ int mc_shard_run_transport(mc_engine *e, const mc_transport *t, const mc_shard_o
     int rc = ops.init(e, t);
     if (rc) return rc;
     ops.W = mc_engine_state_bytes_internal(e);
-    mc_shard::Loop<AbiOps> loop(ops, *t);
-    return loop.run(*o, out);
+    return mc_shard::run_restarting(ops, *t, *o, out);
 }
 
 int mc_shard_trace_transport(mc_engine *e, const mc_transport *t, uint8_t *states_out, int32_t *slots_out, size_t *n_inout, int32_t *final_slot) {
