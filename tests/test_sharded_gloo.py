@@ -282,3 +282,29 @@ def test_a_full_exchange_bucket_restarts_the_search(oracle, shim, tmp_path):
     r = run_dist("shim", 3, "raft", params, tmp_path, dict(opts, packed_fanout=1, move_fanout=1))
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["stats"]["restarts"] >= 3
+
+
+SMALL_COMPLETE = [("raft", [2, 1, 2, 9, 1, 1]), ("raft", [2, 2, 2, 9, 1, 1]), ("raft", [2, 1, 2, 9, 2, 1, 6, 0, 0, 6]), ("ssi", [2, 2, 127, 0]), ("ssi", [3, 1, 127, 0, 1]),
+                  ("pcal_intro", [0, 1, 20, 2]), ("atomic_add", [9]), ("paxos", [0, 3, 2, 2, 15, 0, 1]), ("paxos", [0, 3, 2, 2, 15, 3, 1])]
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TLAMC_SWEEP", "8"))))
+def test_checkpoint_at_a_random_level_of_a_random_run(oracle, shim, tmp_path, seed):
+    """seeded random: a complete model, a world size (2-4), exchange settings, and the BFS level the run is stopped at; one checkpoint
+    file per rank, fresh engines, restore, continue — the completed run is the uninterrupted one (= the oracle's), wherever the cut
+    falls (replicated prefix, move level, stay level) and whatever the ranks held at that moment"""
+    import random
+    r = random.Random(4000 + seed)
+    spec, params = r.choice(SMALL_COMPLETE)
+    world = r.choice([2, 3, 4])
+    kw = {"check_deadlock": False} if spec == "paxos" else {}
+    oparams = oracle.raft_oracle_params(params) if spec == "raft" else params
+    o = oracle.oracle_run(spec, oparams, **kw)
+    cut_level = r.randrange(2, max(3, o["depth"] - 1))
+    cut = oracle.oracle_run(spec, oparams, max_levels=cut_level, **kw)
+    opts = {"max_levels": cut_level, "chunk": r.choice([100, 300, 900]), "stay_threshold": r.choice([10, 40, 1 << 15]), "rebalance_ratio": r.choice([1.3, 2.0]),
+            "replicate_until": r.choice([0, 0, 20, 500]), "checkpoint": str(tmp_path / "ck")}
+    got = run_dist("shim", world, spec, params, tmp_path, opts)
+    assert (got["first"]["verdict"], got["first"]["distinct"], got["first"]["levels"]) == ("budget", cut["distinct"], cut["levels"]), (spec, params, world, opts)
+    assert (got["distinct"], got["generated"], got["depth"], got["levels"], got["verdict"]) == (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"]), (spec, params, world, opts)
+    assert sum(got["shares"]) == o["distinct"]
