@@ -459,3 +459,49 @@ def test_ssi_random_configuration_prefix_on_gpu(amd, oracle, seed):
     for k in ("distinct", "generated", "depth", "verdict", "levels"):
         assert o[k] == r[k], (k, params)
     eng.close()
+
+
+def _random_engine_case(seed):
+    import random
+    from test_lowering_sweep import raft_config, ssi_config
+    r = random.Random(6000 + seed)
+    kind = r.choice(["raft", "raft", "raft", "ssi", "atomic_add", "pcal_intro"])
+    if kind == "raft":
+        params = raft_config(r.randrange(40))
+    elif kind == "ssi":
+        params = ssi_config(r.randrange(24))
+    elif kind == "atomic_add":
+        params = [r.randrange(3, 13)]
+    else:
+        params = r.choice([[0, 1, 20, 2], [1, 1, 20, 2], [0, 1, 7, 3]])
+    flags = 0
+    for bit, p in ((256, 0.3), (65536, 0.3), (131072, 0.25), (8192, 0.25), (32, 0.15)):   # NOBATCH, NOINWAVE, WAVETAIL, NOFILTER, NOFAMILY
+        if r.random() < p:
+            flags |= bit
+    cfg = dict(chunk_states=r.choice([64, 200, 1024, 5000, 1 << 15]), table_capacity=r.choice([1 << 20, 1 << 21, 1 << 23]), arena_capacity=r.choice([1 << 19, 1 << 21]),
+               trace=r.random() < 0.5, timing=r.random() < 0.3, debug_flags=flags)
+    return kind, params, cfg, r.choice([0, 0, 1, 3])
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_model_and_engine_settings_on_gpu(amd, oracle, seed):
+    """seeded random combinations of a model (raft / SI configurations of tests/test_lowering_sweep.py, the PlusCal root specs) with the
+    engine's settings — states per launch from 64 to 2^15, seen-set sizes on both sides of the bucket / single-slot switch, parent
+    tracking on and off, kernel timing, and the A/B flags (one round trip per level, every state through the new-list, the
+    wavefront tail, no duplicate filter, slot-by-slot expansion) — and with the search taken in steps of 1 or 3 levels
+    (mc_engine_step) instead of one run: counters, verdict, depth and every per-level count are the oracle's in all of them"""
+    kind, params, cfg, step = _random_engine_case(seed)
+    oparams = oracle.raft_oracle_params(params) if kind == "raft" else params
+    o = oracle.oracle_run(kind, oparams, max_distinct=40000)
+    eng = amd.Engine(kind, params, max_distinct=40000, **cfg)
+    if step:
+        r = eng.step(step)
+        for _ in range(4096):
+            if not (r.verdict == "budget" and r.distinct < 40000 and r.queue_left):
+                break
+            r = eng.step(step)
+    else:
+        r = eng.run()
+    for k in ("distinct", "generated", "depth", "verdict", "levels"):
+        assert o[k] == r[k], (k, kind, params, cfg, step)
+    eng.close()
