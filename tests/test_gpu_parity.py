@@ -483,7 +483,7 @@ def _random_engine_case(seed):
     return kind, params, cfg, r.choice([0, 0, 1, 3])
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TLAMC_SWEEP", "48"))))
 def test_random_model_and_engine_settings_on_gpu(amd, oracle, seed):
     """seeded random combinations of a model (raft / SI configurations of tests/test_lowering_sweep.py, the PlusCal root specs) with the
     engine's settings — states per launch from 64 to 2^15, seen-set sizes on both sides of the bucket / single-slot switch, parent
