@@ -3,7 +3,6 @@
 and torch.distributed's gloo collectives handed to the loop as its transport.  Counts must equal the oracle's (= the 1-GPU
 engine's), whatever the number of ranks or the chunk size."""
 import json
-import socket
 import subprocess
 import sys
 from pathlib import Path
@@ -13,17 +12,12 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def run_dist(mode, world, spec, params, tmp_path, opts=None, timeout=600):
     out = tmp_path / "out.json"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(ROOT / "tests" / "dist_worker.py"), mode, spec, json.dumps(params), str(out),
-           json.dumps(opts or {})]
+    # --standalone: the launcher binds its rendezvous store to a port the kernel picks (no "find a free port, close it, hope"): several
+    # of these run side by side when the CPU suite is spread over the cores (tests/conftest.py)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={world}",
+           str(ROOT / "tests" / "dist_worker.py"), mode, spec, json.dumps(params), str(out), json.dumps(opts or {})]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     return json.loads(out.read_text())
