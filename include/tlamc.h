@@ -259,6 +259,11 @@ int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new);  
 int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t *n_new);
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local_states);  /* swap frontiers                                */
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict);
+/* After mc_shard_end_level: *max_bucket = the entries the fullest exchange bucket of that level's mc_shard_expand_pack rounds was
+ * asked to hold (0: the level had no packed round), *routed_total = the entries of all packed buckets of the run so far.  The level
+ * loop sizes the NEXT level's fixed-capacity buckets from the first (mc_shard_opts.cap_safety_pct) and reports 9 bytes x the
+ * second as the exchange volume the candidates needed (mc_shard_stats.routed_candidates). */
+int mc_shard_route_fill(mc_engine *e, uint64_t *max_bucket, uint64_t *routed_total);
 /* Before a sharded run that stops on a budget reports: evaluate the invariants of this rank's unexpanded frontier for the
  * specs that check invariants when a state is expanded (the snapshot-isolation models); TLC checks a state when it is
  * generated, so no counted state may stay unchecked.  A violation shows up in mc_shard_counters' verdict.  No-op for the
@@ -313,6 +318,13 @@ int mc_shard_resume(mc_engine *e, uint64_t *levels_out, uint32_t *nlevels);
 #define MC_COMM_ID_BYTES 128
 typedef struct mc_comm mc_comm;
 #define MC_SHARD_NO_PREFIX 1u /* mc_shard_opts.flags: shard from Init on (mc_shard_begin) instead of the replicated prefix */
+#define MC_SHARD_EXACT_STAY 4u /* mc_shard_opts.flags: stay levels run as HOST-PACED rounds with exact sizes (the ranks exchange their P bucket
+                                * counts, then all_to_all_v moves exactly 8 bytes per routed candidate out and 1 byte back): the least the
+                                * exchange can move and nothing that could overflow, for one host wait + one small all-gather per round
+                                * (the next round's expand is launched before them and overlaps them).  Default: the fixed-capacity
+                                * pipelined rounds (no host wait inside a level), whose buckets are moved whole */
+#define MC_SHARD_FIXED_CAPS 2u /* mc_shard_opts.flags: every stay round's buckets sized from packed_fanout alone (round 3's form)
+                                * instead of from the previous level's measured fill; a search restarted after MC_EROUTE runs so */
 /* what one rank's level loop did (diagnostics; filled when mc_shard_opts.stats != NULL) */
 typedef struct {
     uint64_t replicated_levels; /* levels every rank ran itself (mc_shard_begin_replicated)                                  */
@@ -324,6 +336,10 @@ typedef struct {
     uint64_t max_frontier;      /* over the sharded levels: largest max-over-ranks frontier ...                              */
     uint64_t mean_frontier;     /* ... and the mean frontier of that same level (imbalance = max / mean)                     */
     uint64_t restarts;          /* times the search was started over from Init with twice the fan-out allowance (MC_EROUTE)  */
+    uint64_t routed_candidates; /* candidates THIS rank sent to other ranks' seen-set slices (stay rounds: the in-band counts; move
+                                 * rounds: the exact sizes): 9 bytes each (fingerprint out, answer back) is what the exchange needs */
+    uint64_t fp_answer_bytes;   /* the part of sent_bytes that carried fingerprints and answers (the rest: moved states, parents)  */
+    uint64_t measured_levels;   /* stay levels whose buckets were sized from the previous level's measured fill                   */
 } mc_shard_stats;
 typedef struct {
     uint64_t chunk_states;    /* frontier states per round and rank (0 = 2^19); clamped to the engine's chunk_states         */
@@ -341,7 +357,10 @@ typedef struct {
                                * a drifting rank cannot stall the level loop (0 = 1.25)                                     */
     uint64_t move_fanout;     /* in-model successors per expanded state the buffers of a move round allow for (0 = 32)      */
     uint32_t flags;           /* MC_SHARD_*                                                                                 */
-    uint32_t reserved;
+    uint32_t cap_safety_pct;  /* a stay level's buckets hold this many percent of what the previous level's fullest bucket held
+                               * per expanded state (0 = 140; never more than packed_fanout allows; the first stay level and a level
+                               * after one without packed rounds use packed_fanout).  Only the capacity — i.e. the bytes moved over
+                               * xGMI — depends on it, never a count: a bucket that does not fit still fails the level (MC_EROUTE)   */
     mc_shard_stats *stats;    /* NULL or where to put this rank's loop statistics                                            */
 } mc_shard_opts;
 /* TEST-ONLY hooks of this part of the library (a one-GPU lab has no second device): the environment variable TLAMC_RCCL names the

@@ -905,6 +905,7 @@ struct ShimOps {
     ShimShardBase *s;
     uint32_t P;
     std::vector<uint64_t> pack_counts[2];
+    uint64_t route_max = 0, route_lvl = 0, route_sum = 0;  // mc_shard_route_fill of the HIP engine
     uint64_t chunk_limit() const { return 0; }
     size_t state_bytes() const { return s->state_bytes(); }
     bool traced() const { return true; }
@@ -938,6 +939,11 @@ struct ShimOps {
         memset(send_fp, 0, (size_t)P * cap * 8);
         uint64_t off = 0;
         for (uint32_t t = 0; t < P; t++) {
+            route_max = std::max(route_max, counts[t]);
+            route_sum += counts[t];
+            if (getenv("TLAMC_SHARD_DEBUG_ROUNDS") && counts[t]) fprintf(stderr, "[shard]   pack slot %u owner %u: %llu entries, cap %llu\n", slot, t, (unsigned long long)counts[t], (unsigned long long)cap);
+        }
+        for (uint32_t t = 0; t < P; t++) {
             if (counts[t] + 1 > cap) { mc_set_error_internal("an exchange bucket is full"); return MC_EROUTE; }
             send_fp[(uint64_t)t * cap] = counts[t];
             memcpy(send_fp + (uint64_t)t * cap + 1, tmp.data() + off, counts[t] * 8);
@@ -970,11 +976,13 @@ struct ShimOps {
         return s->keep(slot, flat.data(), &n);
     }
     int wait_keep(uint32_t) { return 0; }
+    int keep(uint32_t slot, const uint8_t *back) { uint64_t n = 0; return s->keep(slot, back, &n); }
     int materialise_slot(uint32_t slot, const uint8_t *back, uint8_t *st, uint64_t cap, uint64_t *counts) { return s->materialise(slot, back, st, cap, counts); }
     int materialise_parents(uint32_t slot, uint64_t *out) { return s->materialise_parents(slot, out); }
     int ingest(const uint8_t *st, uint64_t n) { return s->ingest(st, n); }
     int ingest_parents(const uint64_t *pp, uint64_t n, uint32_t src) { return s->ingest_parents(pp, n, src); }
-    int end_level(uint64_t *n) { *n = s->end_level(); return 0; }
+    int end_level(uint64_t *n) { *n = s->end_level(); route_lvl = route_max; route_max = 0; return 0; }
+    int route_fill(uint64_t *mx, uint64_t *sum) { *mx = route_lvl; *sum = route_sum; return 0; }
     int counters(uint64_t *g, uint64_t *d, int32_t *v) { s->counters(g, d, v); return 0; }
     int check_frontier() { s->check_frontier(); return 0; }
     int violation(int32_t *f, uint64_t *i, uint32_t *sl, int32_t *v, int32_t *inv) { return s->violation(f, i, sl, v, inv); }

@@ -33,7 +33,9 @@ def main():
     common = dict(chunk_states=opts.get("chunk", 1000 if mode == "shim" else 1 << 14), max_distinct=opts.get("max_distinct", 0),
                   max_levels=opts.get("max_levels", 0), stay_threshold=opts.get("stay_threshold", 1 << 16),
                   rebalance_ratio=opts.get("rebalance_ratio", 1.25), replicate_until=opts.get("replicate_until", 0),
-                  packed_fanout=opts.get("packed_fanout", 16), move_fanout=opts.get("move_fanout", 64 if mode == "shim" else 32))
+                  packed_fanout=opts.get("packed_fanout", 16), move_fanout=opts.get("move_fanout", 64 if mode == "shim" else 32),
+                  fixed_caps=opts.get("fixed_caps", False), cap_safety_pct=opts.get("cap_safety_pct", 0),
+                  exact_stay=opts.get("exact_stay", False))
     if mode == "shim":
         from shim_step_engine import ShimShard  # noqa: F401
         chk = ShardedChecker(spec, params, engine=ShimShard(spec, params, rank, world), **common)

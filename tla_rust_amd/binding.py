@@ -51,20 +51,22 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, 
 
 MC_COMM_ID_BYTES = 128
 MC_SHARD_NO_PREFIX = 1
+MC_SHARD_FIXED_CAPS = 2
+MC_SHARD_EXACT_STAY = 4
 
 
 class ShardStats(C.Structure):
     """mc_shard_stats: what one rank's level loop did"""
     _fields_ = [("replicated_levels", C.c_uint64), ("stay_levels", C.c_uint64), ("move_levels", C.c_uint64), ("rounds", C.c_uint64),
                 ("sent_bytes", C.c_uint64), ("distinct_local", C.c_uint64), ("max_frontier", C.c_uint64), ("mean_frontier", C.c_uint64),
-                ("restarts", C.c_uint64)]
+                ("restarts", C.c_uint64), ("routed_candidates", C.c_uint64), ("fp_answer_bytes", C.c_uint64), ("measured_levels", C.c_uint64)]
 
 
 class ShardOpts(C.Structure):
     """mc_shard_opts"""
     _fields_ = [("chunk_states", C.c_uint64), ("max_distinct", C.c_uint64), ("max_levels", C.c_uint64), ("replicate_until", C.c_uint64),
                 ("packed_fanout", C.c_uint64), ("stay_threshold", C.c_uint64), ("rebalance_ratio", C.c_double), ("move_fanout", C.c_uint64),
-                ("flags", C.c_uint32), ("reserved", C.c_uint32), ("stats", C.POINTER(ShardStats))]
+                ("flags", C.c_uint32), ("cap_safety_pct", C.c_uint32), ("stats", C.POINTER(ShardStats))]
 
 
 T_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
@@ -480,12 +482,15 @@ class Comm:
 
 
 def shard_opts(stats=None, chunk_states=0, max_distinct=0, max_levels=0, replicate_until=None, packed_fanout=0, stay_threshold=0,
-               rebalance_ratio=0.0, move_fanout=0):
-    """mc_shard_opts; replicate_until = 0 shards from Init on (MC_SHARD_NO_PREFIX), None = the default prefix"""
+               rebalance_ratio=0.0, move_fanout=0, fixed_caps=False, cap_safety_pct=0, exact_stay=False):
+    """mc_shard_opts; replicate_until = 0 shards from Init on (MC_SHARD_NO_PREFIX), None = the default prefix; fixed_caps: the
+    stay rounds' buckets sized from packed_fanout alone (MC_SHARD_FIXED_CAPS) instead of from the previous level's measured fill;
+    exact_stay: stay levels as host-paced rounds with exact sizes (MC_SHARD_EXACT_STAY)"""
     o = ShardOpts()
     o.chunk_states, o.max_distinct, o.max_levels = chunk_states, max_distinct, max_levels
     o.replicate_until = replicate_until or 0
-    o.flags = MC_SHARD_NO_PREFIX if replicate_until == 0 else 0
+    o.flags = (MC_SHARD_NO_PREFIX if replicate_until == 0 else 0) | (MC_SHARD_FIXED_CAPS if fixed_caps else 0) | (MC_SHARD_EXACT_STAY if exact_stay else 0)
+    o.cap_safety_pct = cap_safety_pct
     o.packed_fanout, o.stay_threshold, o.rebalance_ratio, o.move_fanout = packed_fanout, stay_threshold, rebalance_ratio, move_fanout
     if stats is not None:
         o.stats = C.pointer(stats)

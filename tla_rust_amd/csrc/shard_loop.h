@@ -24,6 +24,8 @@
 #ifndef MC_SHARD_LOOP_H
 #define MC_SHARD_LOOP_H
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -74,6 +76,20 @@ struct Loop {
     std::vector<uint64_t> sizes;
     int lrc = MC_OK;  // this rank's sticky status: once non-zero, no engine call is made any more, the collectives still are
     mc_shard_stats st;
+    // Bucket capacities from MEASURED fill.  A stay round moves its buckets whole, so their capacity is the
+    // exchange volume.  packed_fanout allows for 16 in-model successors per expanded state; the models send 3 - 6, and a level sends
+    // about what the level before it sent.  Every rank therefore reports, with the level's all-gather, the fullest bucket its
+    // rounds filled per expanded state (`fill`, in 2^-20 entries per state; the engine counts it on the device, a move level knows its
+    // exact sizes), every rank takes the maximum, and the next stay level's buckets hold cap_safety_pct of that (+ 1024 entries for
+    // the small-number noise), never more than packed_fanout allows.  Counts never depend on it: a bucket that does not fit fails the
+    // level as before (MC_EROUTE), and the search restarted for it keeps to packed_fanout (MC_SHARD_FIXED_CAPS).
+    static constexpr uint64_t FILL_ONE = 1ull << 20, FILL_MIN_STATES = 1024;
+    uint64_t fill_prev = 0;        // max over ranks, previous level; 0 = not known
+    uint64_t fill_mine = 0;        // this rank, current level
+    bool level_measured = false;   // the current (or failing) level's buckets were sized from fill_prev
+    void note_fill(uint64_t bucket_entries, uint64_t states) {
+        if (states >= FILL_MIN_STATES) fill_mine = std::max(fill_mine, (bucket_entries * FILL_ONE + states - 1) / states);
+    }
 
     Loop(Ops &ops, const mc_transport &t) : e(ops), net(t), P(t.world), me(t.rank), all(t.world), sizes(t.world) { memset(&st, 0, sizeof st); }
 
@@ -112,6 +128,7 @@ struct Loop {
         //  first sharded level can already keep its new states where they are generated)
         const uint64_t stay_threshold = o.stay_threshold ? o.stay_threshold : (1ull << 15);
         const double ratio = o.rebalance_ratio > 0 ? o.rebalance_ratio : 1.25;
+        const uint64_t safety = (o.flags & MC_SHARD_FIXED_CAPS) ? 0 : o.cap_safety_pct ? o.cap_safety_pct : 140;
         const size_t W = e.state_bytes();
         const bool traced = e.traced();
         int trc;
@@ -143,6 +160,9 @@ struct Loop {
         int failed = 0;
         step([&] { return e.level_size(&local_n); });
         step([&] { return e.counters(&gen, &dl, &verdict); });
+        uint64_t routed_base = 0, routed_now = 0, bucket_max = 0;
+        step([&] { return e.route_fill(&bucket_max, &routed_base); });
+        routed_now = routed_base;
         if ((trc = level_info(local_n, verdict, frontier, worst, failed, resume_sig))) return trc;
         if (failed) return lrc ? lrc : failed;
         for (uint32_t p = 0; p < P; ++p)
@@ -186,26 +206,41 @@ struct Loop {
             const uint64_t mine = sizes[me];
             const bool stay = frontier >= stay_threshold * P && (double)max_n * P <= ratio * (double)frontier;
             // a move level ships whole states: smaller rounds keep its buffers modest
+            const bool exact = stay && (o.flags & MC_SHARD_EXACT_STAY);  // the stay level as host-paced rounds with exact sizes
             const uint64_t ch = stay ? chunk : std::min<uint64_t>(chunk, 1ull << 17);
             const uint64_t rounds = (max_n + ch - 1) / ch;
             (stay ? st.stay_levels : st.move_levels)++;
             st.rounds += rounds;
             const uint64_t f = stay ? fan : mfan;
             const uint64_t send_cap = (uint64_t)P * (std::min(ch, max_n) * f / P + 4096);  // candidates of one round, all owners
+            fill_mine = 0;
+            level_measured = stay && !exact && safety && fill_prev;
+            if (level_measured) st.measured_levels++;
             auto launch = [&](uint64_t r) {
                 const uint64_t first = std::min(r * ch, mine), n = std::min(ch, mine - first);
                 step([&] { return e.expand_launch((uint32_t)(r & 1), first, n, send_cap); });
             };
-            if (stay) {
-                if ((trc = stay_level(rounds, ch, fan, max_n, launch, send, recv, ans, back))) return trc;
+            if (stay && !exact) {
+                if ((trc = stay_level(rounds, ch, fan, max_n, level_measured ? safety : 0, launch, send, recv, ans, back))) return trc;
             } else {
-                if ((trc = move_level(rounds, send_cap, W, traced, launch, send, recv, ans, back, states, rstates, parents, rparents))) return trc;
+                if ((trc = move_level(rounds, ch, send_cap, W, traced, exact, launch, send, recv, ans, back, states, rstates, parents, rparents))) return trc;
             }
             uint64_t new_local = 0;
             step([&] { return e.end_level(&new_local); });  // waits for the engine's streams; device errors surface here
             step([&] { return e.counters(&gen, &dl, &verdict); });
-            if ((trc = level_info(new_local, verdict, frontier, worst, failed))) return trc;
+            if (stay && !exact) {  // (host-paced rounds noted their exact sizes round by round)
+                bucket_max = 0;
+                step([&] { return e.route_fill(&bucket_max, &routed_now); });
+                if (!lrc) note_fill(bucket_max, std::min(ch, mine));
+            }
+            if ((trc = level_info(new_local, verdict, frontier, worst, failed, lrc ? 0 : fill_mine))) return trc;
             if (failed) return lrc ? lrc : failed;
+            fill_prev = 0;
+            for (uint32_t p = 0; p < P; ++p) fill_prev = std::max(fill_prev, all[p].pad);
+            if (me == 0 && getenv("TLAMC_SHARD_DEBUG"))
+                fprintf(stderr, "[shard] level %zu %s%s: %llu states, %llu rounds, fullest bucket %.3f entries per expanded state -> %llu new\n", levels.size(),
+                        stay ? "stay" : "move", level_measured ? " (measured caps)" : "", (unsigned long long)(cum ? levels.back() : 0),
+                        (unsigned long long)rounds, (double)fill_prev / (double)FILL_ONE, (unsigned long long)frontier);
             if (frontier > 0) {
                 if (levels.size() >= MC_MAX_LEVELS) { mc_set_error_internal("more BFS levels than MC_MAX_LEVELS"); return MC_EBADCFG; }
                 levels.push_back(frontier);
@@ -226,6 +261,7 @@ struct Loop {
             }
         }
         st.distinct_local = dl;
+        st.routed_candidates += routed_now - routed_base;
         if (o.stats) *o.stats = st;
         out->distinct = cum;
         out->generated = gen;
@@ -241,15 +277,20 @@ struct Loop {
     // ------------------------------------------------------------------ STAY: fixed-capacity rounds, counts in band, no host wait
     size_t stay_bytes = 0;
     template <class L>
-    int stay_level(uint64_t rounds, uint64_t ch, uint64_t fan, uint64_t max_n, L &&launch, NetBuf *send, NetBuf *recv, NetBuf *ans, NetBuf *back) {
+    int stay_level(uint64_t rounds, uint64_t ch, uint64_t fan, uint64_t max_n, uint64_t safety, L &&launch, NetBuf *send, NetBuf *recv, NetBuf *ans,
+                   NetBuf *back) {
         int trc;
         // every rank derives the same capacities from the level's frontier sizes (which all ranks know): the exchanges are
-        // equal-split.  A rank routes (P - 1) / P of its candidates over P owners (its own share is probed locally).
+        // equal-split.  A rank's candidates spread evenly over the P owners (its own share is probed locally, its own bucket stays empty).
         const uint64_t cap_max = std::min(ch, max_n) * fan / P + 4096;
         auto cap_of = [&](uint64_t r) {
             uint64_t n_round = 0;
             for (uint32_t p = 0; p < P; ++p) n_round = std::max(n_round, std::min(ch, sizes[p] > r * ch ? sizes[p] - r * ch : 0));
-            return std::min(n_round * fan * (P - 1) / ((uint64_t)P * P) + 1024, cap_max);
+            // measured form: what the fullest bucket of the previous level held per state, with the safety margin (it may also be MORE
+            // than packed_fanout's share, up to what the buffers were allocated for); otherwise packed_fanout candidates per state,
+            // spread over the P owners
+            if (safety) return std::min((uint64_t)((unsigned __int128)n_round * fill_prev * safety / (100 * FILL_ONE)) + 1024, cap_max);
+            return std::min(n_round * fan / P + 1024, cap_max);
         };
         const size_t total_max = (size_t)P * (ch * fan / P + 4096);  // the largest a level of this run can ask for
         if (stay_bytes < total_max) {
@@ -278,6 +319,7 @@ struct Loop {
             int rc = net.all_to_all(net.user, ans[t].p, back[t].p, cap);
             if (rc) return rc;
             st.sent_bytes += cap * (P - 1);
+            st.fp_answer_bytes += cap * (P - 1);
             e.record(EV_ANS + t, S_COMM);
             e.wait(S_WORK, EV_ANS + t);
             step([&] { return e.keep_pack(t, (const uint8_t *)back[t].p, cap); });  // on the engine's second stream, behind WORK here
@@ -300,6 +342,7 @@ struct Loop {
                 return trc;
             }
             st.sent_bytes += cap * 8 * (P - 1);
+            st.fp_answer_bytes += cap * 8 * (P - 1);
             e.record(EV_FP + s, S_COMM);
             if (r >= 1 && (trc = answers(r - 1))) return trc;  // issued AFTER fp(r): probes of r-1 ran while fp(r) travelled
             // (only now: round r+1 reuses the engine slot of round r-1, whose keep has just been issued)
@@ -339,7 +382,7 @@ struct Loop {
         return rc;
     }
     template <class L>
-    int move_level(uint64_t rounds, uint64_t send_cap, size_t W, bool traced, L &&launch, NetBuf *send, NetBuf *recv, NetBuf *ans, NetBuf *back,
+    int move_level(uint64_t rounds, uint64_t move_ch, uint64_t send_cap, size_t W, bool traced, bool keep_local, L &&launch, NetBuf *send, NetBuf *recv, NetBuf *ans, NetBuf *back,
                    NetBuf &states, NetBuf &rstates, NetBuf &parents, NetBuf &rparents) {
         int trc;
         std::vector<uint64_t> counts(P), rcounts, scounts(P), rsc, blocks(P), rblocks(P);
@@ -352,14 +395,29 @@ struct Loop {
             if (lrc) std::fill(counts.begin(), counts.end(), 0);
             if (r + 1 < rounds) launch(r + 1);  // overlaps everything below
             if ((trc = exchange_counts(counts.data(), rcounts))) return trc;
-            uint64_t n = 0, total = 0;
-            for (uint32_t p = 0; p < P; ++p) { n += rcounts[p]; total += counts[p]; }
+            uint64_t n = 0, total = 0, fullest = 0;
+            for (uint32_t p = 0; p < P; ++p) {
+                n += rcounts[p];
+                total += counts[p];
+                if (p != me) { fullest = std::max(fullest, counts[p]); st.routed_candidates += counts[p]; st.fp_answer_bytes += 9 * counts[p]; }
+            }
+            note_fill(fullest, std::min(move_ch, sizes[me] > r * move_ch ? sizes[me] - r * move_ch : 0));
+            // (the answers come back into the slot's own buffer when the states stay: the keep of round r reads it on the engine's
+            //  second stream while round r+1 is already being exchanged)
+            NetBuf &bk = keep_local ? back[s] : back[0];
             step([&] { return recv[0].need(std::max<uint64_t>(n, 1) * 8); });
             step([&] { return ans[0].need(std::max<uint64_t>(n, 1)); });
-            step([&] { return back[0].need(std::max<uint64_t>(total, 1)); });
+            if (keep_local) step([&] { return e.wait_keep(s); });  // (on WORK) the slot's previous keep has read back[s] — also before it may be re-allocated
+            step([&] { return bk.need(std::max<uint64_t>(total, 1)); });
             if ((trc = a2a_v_safe(send[s], counts, recv[0], rcounts, 8))) return trc;
             step([&] { return e.probe((const uint64_t *)recv[0].p, n, (uint8_t *)ans[0].p); });
-            if ((trc = a2a_v_safe(ans[0], rcounts, back[0], counts, 1))) return trc;
+            if ((trc = a2a_v_safe(ans[0], rcounts, bk, counts, 1))) return trc;
+            if (keep_local) {
+                // STAY with exact sizes (MC_SHARD_EXACT_STAY): the positively answered candidates become states of THIS rank; what crossed
+                // xGMI is 9 bytes per routed candidate and the P counts, nothing else — no capacity to guess, no bucket to overflow
+                step([&] { return e.keep(s, (const uint8_t *)bk.p); });
+                continue;
+            }
             // the sender materialises its positively answered candidates, bucketed by owner, as whole 64-state blocks
             std::fill(scounts.begin(), scounts.end(), 0);
             const uint64_t guess = std::min<uint64_t>(total, total / 4 + 4096) + 64ull * P;
@@ -521,6 +579,11 @@ int run_restarting(Ops &ops, const mc_transport &t, const mc_shard_opts &o, mc_r
             if (o.stats) o.stats->restarts = restarts;
             return rc;
         }
+        // Was it a level whose buckets were sized from the previous level's measured fill (it grew faster than cap_safety_pct allows)?
+        // Every rank left the loop at the same level with the same sizing decision (it depends on all-gathered values only), so
+        // every rank takes the same branch here.
+        const bool any = loop.level_measured;
+        if (any) cur.flags |= MC_SHARD_FIXED_CAPS;  // (a measured bucket does not grow with the allowance)
         cur.packed_fanout = 2 * (cur.packed_fanout ? cur.packed_fanout : 16);
         cur.move_fanout = 2 * (cur.move_fanout ? cur.move_fanout : 32);
         ++restarts;

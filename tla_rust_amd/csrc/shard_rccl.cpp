@@ -186,6 +186,7 @@ struct AbiOps {
     int probe_pack(const uint64_t *fp, uint64_t cap, uint8_t *ans) { return mc_shard_probe_pack(eng, fp, cap, ans); }
     int keep_pack(uint32_t slot, const uint8_t *back, uint64_t cap) { return mc_shard_keep_pack(eng, slot, back, cap); }
     int wait_keep(uint32_t slot) { return mc_shard_wait_keep(eng, slot); }
+    int keep(uint32_t slot, const uint8_t *back) { return mc_shard_keep_slot(eng, slot, back, nullptr); }
     int materialise_slot(uint32_t slot, const uint8_t *back, uint8_t *st, uint64_t cap, uint64_t *counts) {
         return mc_shard_materialise_slot(eng, slot, back, st, cap, counts);
     }
@@ -193,6 +194,7 @@ struct AbiOps {
     int ingest(const uint8_t *st, uint64_t n) { return mc_shard_ingest(eng, st, n); }
     int ingest_parents(const uint64_t *pp, uint64_t n, uint32_t src) { return mc_shard_ingest_parents(eng, pp, n, src); }
     int end_level(uint64_t *n) { return mc_shard_end_level(eng, n); }
+    int route_fill(uint64_t *mx, uint64_t *sum) { return mc_shard_route_fill(eng, mx, sum); }
     int counters(uint64_t *g, uint64_t *d, int32_t *v) { return mc_shard_counters(eng, g, d, v); }
     int check_frontier() { return mc_shard_check_frontier(eng); }
     int violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *v, int32_t *inv) { return mc_shard_violation(eng, found, idx, slot, v, inv); }
