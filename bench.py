@@ -283,6 +283,9 @@ def main():
                     "the exchange of round r+1 overlaps the probes of round r)")
     ap.add_argument("--packed-fanout", type=int, default=0, help="in-model successors per state the fixed-capacity exchange buckets allow for "
                     "(0 = the workload's: 16 for the raft models, 40 for the SI model, whose frontier grows 8 x per level)")
+    ap.add_argument("--exchange", choices=["exact", "measured", "packed"], default="exact",
+                    help="--gpus N: how a stay level exchanges its candidates (include/tlamc.h MC_SHARD_*): host-paced rounds with exact sizes, "
+                         "pipelined fixed-capacity buckets sized from the previous level's measured fill, or the same buckets from --packed-fanout")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank on GPU 0 (needs a librccl stand-in in $TLAMC_RCCL; RCCL refuses it)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="t3", help="t3: MaxTerm 3, MaxMsgKeys 8 (525.8 M states, the contract line); "
                     "k10 / k11: MaxTerm 2 with 10 / 11 message keys (102.6 M / 336.6 M states; rounds 1-2's line was k10); raft5: BASELINE config 4 "
@@ -350,7 +353,8 @@ def main():
         stats = {}
 
         def run():
-            r, st = comm.shard_run(eng, chunk_states=a.shard_chunk, max_distinct=a.max_distinct, max_levels=ML, packed_fanout=a.packed_fanout)
+            r, st = comm.shard_run(eng, chunk_states=a.shard_chunk, max_distinct=a.max_distinct, max_levels=ML, packed_fanout=a.packed_fanout,
+                                    exchange=a.exchange)
             stats.update(st)
             return r
 
@@ -372,6 +376,8 @@ def main():
         dt = max(comm.all_gather_f64(dt))                                   # MAX over ranks
         shares = comm.all_gather_u64(stats.get("distinct_local", 0))
         sent = comm.all_gather_u64(stats.get("sent_bytes", 0))
+        routed = comm.all_gather_u64(stats.get("routed_candidates", 0))
+        fpans = comm.all_gather_u64(stats.get("fp_answer_bytes", 0))
     if rank != 0:
         eng.close()
         comm.close()
@@ -406,8 +412,13 @@ def main():
         per_rank = max(sent) if sent else 0
         line["xgmi"] = {"bound": "xgmi", "sent_bytes_per_step_per_gpu": per_rank, "achieved": per_rank / step_s / 1e9, "peak": XGMI_PEAK_GBS,
                         "unit": "GB/s", "frac": per_rank / step_s / 1e9 / XGMI_PEAK_GBS,
-                        "model_bytes_per_step": G * (world - 1) / world * 9,
-                        "note": "fixed-capacity buckets are moved whole: sent bytes include the unused tail of every bucket"}
+                        # what the exchange NEEDS: 9 bytes (fingerprint out, answer back) per candidate a rank sent to another rank's seen-set
+                        # slice — counted by the loop (mc_shard_stats.routed_candidates), not estimated — against what it MOVED for them
+                        "exchange": a.exchange, "routed_candidates_per_step": sum(routed), "model_bytes_per_step": 9 * sum(routed),
+                        "fp_answer_bytes_per_step": sum(fpans), "sent_over_model": sum(fpans) / max(1, 9 * sum(routed)),
+                        "restarts": stats.get("restarts", 0), "measured_levels": stats.get("measured_levels", 0),
+                        "note": "packed / measured: the buckets of a stay round are moved whole (sent bytes include their unused tails); "
+                                "exact: all_to_all_v moves what the counts say"}
         if a.share_gpu:
             line["config"]["NOT_A_MEASUREMENT"] = "all ranks share ONE GPU through a librccl stand-in ($TLAMC_RCCL): a functional run of the N-rank path, not a scaling number"
         eng.close()

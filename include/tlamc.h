@@ -318,13 +318,18 @@ int mc_shard_resume(mc_engine *e, uint64_t *levels_out, uint32_t *nlevels);
 #define MC_COMM_ID_BYTES 128
 typedef struct mc_comm mc_comm;
 #define MC_SHARD_NO_PREFIX 1u /* mc_shard_opts.flags: shard from Init on (mc_shard_begin) instead of the replicated prefix */
-#define MC_SHARD_EXACT_STAY 4u /* mc_shard_opts.flags: stay levels run as HOST-PACED rounds with exact sizes (the ranks exchange their P bucket
-                                * counts, then all_to_all_v moves exactly 8 bytes per routed candidate out and 1 byte back): the least the
-                                * exchange can move and nothing that could overflow, for one host wait + one small all-gather per round
-                                * (the next round's expand is launched before them and overlaps them).  Default: the fixed-capacity
-                                * pipelined rounds (no host wait inside a level), whose buckets are moved whole */
-#define MC_SHARD_FIXED_CAPS 2u /* mc_shard_opts.flags: every stay round's buckets sized from packed_fanout alone (round 3's form)
-                                * instead of from the previous level's measured fill; a search restarted after MC_EROUTE runs so */
+/* How a STAY level exchanges its candidates (mc_shard_opts.flags; `mc -gpus P -exchange exact | measured | packed`):
+ *   default (neither flag): HOST-PACED rounds with exact sizes — the ranks exchange their P bucket counts (one small all-gather),
+ *     then all_to_all_v moves exactly 8 bytes per routed candidate out and 1 byte back: the least the exchange can move, no
+ *     capacity to guess and no bucket that could overflow, for one host wait + that all-gather per round (the next round's expand is
+ *     launched before them and overlaps the exchange, the probes and the materialisation of this one);
+ *   MC_SHARD_PACKED: pipelined FIXED-CAPACITY rounds, counts in band, no host wait inside a level (mc_shard_*_pack); the buckets are
+ *     moved whole, so their capacity is the exchange volume: it is sized from the previous level's MEASURED fill
+ *     (mc_shard_route_fill, cap_safety_pct) ...
+ *   MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS: ... or from packed_fanout alone (rounds 2-3).  A search restarted after MC_EROUTE in a
+ *     measured level runs so. */
+#define MC_SHARD_FIXED_CAPS 2u
+#define MC_SHARD_PACKED 4u
 /* what one rank's level loop did (diagnostics; filled when mc_shard_opts.stats != NULL) */
 typedef struct {
     uint64_t replicated_levels; /* levels every rank ran itself (mc_shard_begin_replicated)                                  */

@@ -34,8 +34,7 @@ def main():
                   max_levels=opts.get("max_levels", 0), stay_threshold=opts.get("stay_threshold", 1 << 16),
                   rebalance_ratio=opts.get("rebalance_ratio", 1.25), replicate_until=opts.get("replicate_until", 0),
                   packed_fanout=opts.get("packed_fanout", 16), move_fanout=opts.get("move_fanout", 64 if mode == "shim" else 32),
-                  fixed_caps=opts.get("fixed_caps", False), cap_safety_pct=opts.get("cap_safety_pct", 0),
-                  exact_stay=opts.get("exact_stay", False))
+                  exchange=opts.get("exchange", "exact"), cap_safety_pct=opts.get("cap_safety_pct", 0))
     if mode == "shim":
         from shim_step_engine import ShimShard  # noqa: F401
         chk = ShardedChecker(spec, params, engine=ShimShard(spec, params, rank, world), **common)
@@ -53,6 +52,7 @@ def main():
         first = dict(r)
         stem = opts["checkpoint"]
         chk.checkpoint(f"{stem}.rank{rank}")
+        dist.barrier()   # every rank's file is complete before anybody reads one (restore_wrong_rank reads a neighbour's)
         chk.close()
         chk = make()
         wrong = opts.get("restore_wrong_rank") and world > 1

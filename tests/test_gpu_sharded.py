@@ -37,14 +37,53 @@ def test_two_ranks_on_one_gpu_equal_oracle(oracle, tmp_path, spec, params, opts)
 
 
 def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path):
-    """mc_shard_expand_pack / _probe_pack / _keep_pack (fixed-capacity buckets, counts in band, no host wait in a round), three
-    streams and their events; several rounds per level (chunk 2^14)"""
+    """stay levels of two engines on one GPU, several rounds per level (chunk 2^14): the default form (host-paced rounds with exact sizes,
+    mc_shard_expand_finish / _probe / _keep_slot, the next round's expand in flight meanwhile); the fixed-capacity forms
+    (mc_shard_expand_pack / _probe_pack / _keep_pack, counts in band, three streams and their events) are test_the_three_forms_... below"""
     params = [3, 2, 2, 9, 1, 1]
     o = oracle.oracle_run("raft", params, max_distinct=300000)
     r = run_dist("hip", 2, "raft", params, tmp_path, {"max_distinct": 300000, "chunk": 1 << 14, "table": 1 << 22, "arena": 1 << 20,
                                                        "stay_threshold": 200, "rebalance_ratio": 1.5})
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["phases"].get("stay_levels", 0) >= 3
+
+
+@pytest.mark.parametrize("form,extra", [("fixed", {"exchange": "packed"}), ("measured", {"exchange": "measured", "cap_safety_pct": 140}), ("exact", {"exchange": "exact"})])
+def test_the_three_forms_of_a_stay_level_on_gpu(oracle, tmp_path, form, extra):
+    """the stay levels of two HIP engines in their three forms (include/tlamc.h: MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS, MC_SHARD_PACKED + cap_safety_pct, the default):
+    buckets from packed_fanout, buckets from the fill the device measured on the previous level (mc_shard_route_fill), host-paced rounds
+    with exact sizes (mc_shard_expand_finish + mc_shard_probe + mc_shard_keep_slot) — the oracle's counters and per-level counts each
+    time; 9 bytes per routed candidate in the exact form"""
+    params = [3, 2, 2, 9, 1, 1]
+    o = oracle.oracle_run("raft", params, max_distinct=300000)
+    r = run_dist("hip", 2, "raft", params, tmp_path, dict({"max_distinct": 300000, "chunk": 1 << 14, "table": 1 << 22, "arena": 1 << 20,
+                                                           "stay_threshold": 200, "rebalance_ratio": 1.5}, **extra))
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    st = r["stats"]
+    assert st["stay_levels"] >= 3 and st["restarts"] == 0 and st["routed_candidates"] > 100000, st
+    if form == "exact":
+        assert st["fp_answer_bytes"] == 9 * st["routed_candidates"] and st["measured_levels"] == 0, st
+    elif form == "measured":
+        assert st["measured_levels"] >= 2 and st["fp_answer_bytes"] < 2.5 * 9 * st["routed_candidates"], st
+    else:
+        assert st["measured_levels"] == 0 and st["fp_answer_bytes"] > 9 * st["routed_candidates"], st
+
+
+@pytest.mark.parametrize("exchange", ["packed", "measured", "exact"])
+def test_native_rccl_loop_exchange_forms(exchange):
+    """`mc X.tla -gpus 4 -samedevice -exchange packed | measured | exact` (exact is the default the other tests run): the native loop over
+    the nccl* entry points with each form of the stay levels — the one-GPU run's counter line, and the report's exchange line"""
+    from pathlib import Path
+    S = Path(__file__).resolve().parent.parent / "specs"
+    args = [S / "MCraft.tla", "-config", S / "MCraft.cfg", "-maxdistinct", 3000000, "-tablelog2", 24, "-arena", 6000000, "-chunk", 65536]
+    q = _mc(*args, "-noprogress")
+    line = next((ln for ln in q.stdout.splitlines() if "distinct states found" in ln), None)
+    p = _mc(*args, "-gpus", 4, "-samedevice", "-exchange", exchange, env=_fake_env())
+    assert p.returncode == q.returncode, (p.stdout[-1500:], p.stderr[-1500:])
+    assert line and line in p.stdout, (line, p.stdout[-800:], p.stderr[-800:])
+    x = next(ln for ln in p.stdout.splitlines() if ln.startswith("(exchange"))
+    ratio = float(x.split("candidates = ")[1].split(" x")[0])
+    assert ratio == 1.0 if exchange == "exact" else ratio > 1.0, x
 
 
 def test_a_full_exchange_bucket_restarts_the_search_on_gpu(oracle, tmp_path):

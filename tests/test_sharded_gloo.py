@@ -228,7 +228,7 @@ def test_counterexample_after_a_restore_walks_into_the_checkpointed_part(oracle,
 
 def test_restore_refuses_another_ranks_file(oracle, shim, tmp_path):
     r = run_dist("shim", 2, "raft", [2, 2, 2, 9, 2, 1], tmp_path, {"max_levels": 6, "chunk": 700, "checkpoint": str(tmp_path / "ck"), "restore_wrong_rank": True})
-    assert all("another rank" in e for e in r["restore_errors"])
+    assert all("another rank" in e for e in r["restore_errors"]), r["restore_errors"]
 
 
 def test_ranks_that_did_not_restore_the_same_run_stop_together(oracle, shim, tmp_path):
@@ -247,7 +247,7 @@ def _random_sharding(seed):
     opts = {"max_distinct": 30000, "chunk": r.choice([150, 400, 1000, 4000]), "stay_threshold": r.choice([20, 60, 400, 1 << 15]),
             "rebalance_ratio": r.choice([1.2, 1.6, 2.5]), "replicate_until": r.choice([0, 0, 30, 300])}
     # (drawn last: the seeds keep the models and settings they had before the stay levels had three forms)
-    opts.update(r.choice([{}, {"exact_stay": True}, {"fixed_caps": True}, {"cap_safety_pct": 110}, {"cap_safety_pct": 250}]))
+    opts.update(r.choice([{}, {"exchange": "exact"}, {"exchange": "packed"}, {"exchange": "measured", "cap_safety_pct": 110}, {"exchange": "measured", "cap_safety_pct": 250}]))
     return spec, params, world, opts
 
 
@@ -272,10 +272,10 @@ def test_a_full_exchange_bucket_restarts_the_search(oracle, shim, tmp_path):
     params = [3, 4, 3, 3, 2, 3, 5, 0, 0, 5]
     opts = {"max_distinct": 30000, "chunk": 1000, "stay_threshold": 60, "rebalance_ratio": 1.6, "replicate_until": 30}
     o = oracle.oracle_run("raft", oracle.raft_oracle_params(params), max_distinct=30000)
-    r = run_dist("shim", 2, "raft", params, tmp_path, dict(opts, packed_fanout=8))   # (these states have up to ~11 in-model successors)
+    r = run_dist("shim", 2, "raft", params, tmp_path, dict(opts, packed_fanout=8, exchange="packed"))   # (these states have up to ~11 in-model successors)
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["stats"]["restarts"] >= 1
-    r = run_dist("shim", 3, "raft", params, tmp_path, dict(opts, packed_fanout=1, move_fanout=1))
+    r = run_dist("shim", 3, "raft", params, tmp_path, dict(opts, packed_fanout=1, move_fanout=1, exchange="packed"))
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
     assert r["stats"]["restarts"] >= 3
 
@@ -285,14 +285,14 @@ K5 = [3, 4, 2, 3, 1, 1, 0, 0, 0, 5]   # examples/raft.tla, 3 servers, MaxMsgKeys
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_the_three_forms_of_a_stay_level(oracle, shim, tmp_path, world):
-    """A stay level's exchange in its three forms — fixed-capacity buckets sized from packed_fanout (MC_SHARD_FIXED_CAPS), the same
-    buckets sized from the previous level's measured fill (cap_safety_pct), host-paced rounds with exact sizes (MC_SHARD_EXACT_STAY):
+    """A stay level's exchange in its three forms — fixed-capacity buckets sized from packed_fanout (MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS), the same
+    buckets sized from the previous level's measured fill (MC_SHARD_PACKED, cap_safety_pct), host-paced rounds with exact sizes (the default):
     the same counters and per-level counts (the oracle's), and the bytes that crossed between ranks for fingerprints and answers are
     9 per routed candidate in the exact form, less in the measured than in the fixed form"""
     o = oracle.oracle_run("raft", oracle.raft_oracle_params(K5))
     base = {"chunk": 4096, "stay_threshold": 1024}
     got = {}
-    for form, extra in (("fixed", {"fixed_caps": True}), ("measured", {"cap_safety_pct": 140}), ("exact", {"exact_stay": True})):
+    for form, extra in (("fixed", {"exchange": "packed"}), ("measured", {"exchange": "measured", "cap_safety_pct": 140}), ("exact", {"exchange": "exact"})):
         r = run_dist("shim", world, "raft", K5, tmp_path, dict(base, **extra))
         assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"]), form
         assert r["stats"]["restarts"] == 0 and r["stats"]["stay_levels"] >= 8, (form, r["stats"])
@@ -307,7 +307,7 @@ def test_a_measured_bucket_that_is_too_small_restarts_with_fixed_capacities(orac
     """buckets sized at HALF of what the previous level's fullest bucket held per state cannot hold the next level's: MC_EROUTE on every
     rank, and the search that is started over sizes its buckets from (twice) packed_fanout alone — the oracle's counters, one restart"""
     o = oracle.oracle_run("raft", oracle.raft_oracle_params(K5))
-    r = run_dist("shim", 2, "raft", K5, tmp_path, {"chunk": 65536, "stay_threshold": 1024, "cap_safety_pct": 50})
+    r = run_dist("shim", 2, "raft", K5, tmp_path, {"chunk": 65536, "stay_threshold": 1024, "exchange": "measured", "cap_safety_pct": 50})
     assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"])
     assert r["stats"]["restarts"] == 1 and r["stats"]["measured_levels"] == 0, r["stats"]
 

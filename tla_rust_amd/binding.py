@@ -52,7 +52,8 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, 
 MC_COMM_ID_BYTES = 128
 MC_SHARD_NO_PREFIX = 1
 MC_SHARD_FIXED_CAPS = 2
-MC_SHARD_EXACT_STAY = 4
+MC_SHARD_PACKED = 4
+EXCHANGE_FLAGS = {"exact": 0, "measured": MC_SHARD_PACKED, "packed": MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS}
 
 
 class ShardStats(C.Structure):
@@ -482,14 +483,14 @@ class Comm:
 
 
 def shard_opts(stats=None, chunk_states=0, max_distinct=0, max_levels=0, replicate_until=None, packed_fanout=0, stay_threshold=0,
-               rebalance_ratio=0.0, move_fanout=0, fixed_caps=False, cap_safety_pct=0, exact_stay=False):
-    """mc_shard_opts; replicate_until = 0 shards from Init on (MC_SHARD_NO_PREFIX), None = the default prefix; fixed_caps: the
-    stay rounds' buckets sized from packed_fanout alone (MC_SHARD_FIXED_CAPS) instead of from the previous level's measured fill;
-    exact_stay: stay levels as host-paced rounds with exact sizes (MC_SHARD_EXACT_STAY)"""
+               rebalance_ratio=0.0, move_fanout=0, exchange="exact", cap_safety_pct=0):
+    """mc_shard_opts; replicate_until = 0 shards from Init on (MC_SHARD_NO_PREFIX), None = the default prefix; exchange: how a stay
+    level moves its candidates — "exact" (host-paced rounds, exact sizes: the default), "measured" (pipelined fixed-capacity rounds, buckets
+    sized from the previous level's measured fill: MC_SHARD_PACKED) or "packed" (the same from packed_fanout alone: + MC_SHARD_FIXED_CAPS)"""
     o = ShardOpts()
     o.chunk_states, o.max_distinct, o.max_levels = chunk_states, max_distinct, max_levels
     o.replicate_until = replicate_until or 0
-    o.flags = (MC_SHARD_NO_PREFIX if replicate_until == 0 else 0) | (MC_SHARD_FIXED_CAPS if fixed_caps else 0) | (MC_SHARD_EXACT_STAY if exact_stay else 0)
+    o.flags = (MC_SHARD_NO_PREFIX if replicate_until == 0 else 0) | EXCHANGE_FLAGS[exchange]
     o.cap_safety_pct = cap_safety_pct
     o.packed_fanout, o.stay_threshold, o.rebalance_ratio, o.move_fanout = packed_fanout, stay_threshold, rebalance_ratio, move_fanout
     if stats is not None:

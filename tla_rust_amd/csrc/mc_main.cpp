@@ -4,7 +4,7 @@
 //
 //   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic] [-dump FILE]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
-//            [-checkpoint FILE] [-recover FILE] [-gpus P [-samedevice | -torch]] [-noprogress] [-I DIR]
+//            [-checkpoint FILE] [-recover FILE] [-gpus P [-samedevice | -torch] [-exchange exact|measured|packed]] [-noprogress] [-I DIR]
 //   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
 //                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
 //                                         the previous text is kept as X.old
@@ -148,6 +148,7 @@ static int spawn_ranks(int gpus, char **argv) {
     unlink(idfile);
     return worst;
 }
+static uint32_t g_shard_flags = 0;  // -exchange exact (default) | measured | packed (mc_shard_opts.flags, include/tlamc.h)
 static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, int world, const char *idfile, const char *ckpt, const char *recover) {
     mc_spec_desc desc;
     mc_program *prog = nullptr;
@@ -182,6 +183,7 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
     if ((rc = mc_engine_create(&desc, &cfg, &eng))) { fprintf(stderr, "mc[%d]: %s: %s\n", rank, mc_strerror(rc), mc_last_error()); return 1; }
     mc_shard_opts so;
     memset(&so, 0, sizeof so);
+    so.flags = g_shard_flags;  // -exchange
     so.chunk_states = cfg.chunk_states;
     so.max_distinct = cfg.max_distinct;
     so.max_levels = cfg.max_levels;
@@ -250,6 +252,11 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
                (unsigned long long)res.distinct, (unsigned long long)res.queue_left);
         printf("The depth of the complete state graph search is %u.\n", res.depth);
         printf("(%d GPU%s over RCCL, %.3f s, %.3g distinct states/s)\n", world, world == 1 ? "" : "s", dt, (double)res.distinct / (dt > 1e-9 ? dt : 1e-9));
+        if (world > 1 && sstats.routed_candidates)  // rank 0's share of the exchange: what it handed over against 9 bytes per routed candidate
+            printf("(exchange, this rank: %.1f MB of fingerprints and answers for %llu candidates = %.2f x the 9 bytes each needs; %llu stay / %llu move levels)\n",
+                   (double)sstats.fp_answer_bytes / 1e6, (unsigned long long)sstats.routed_candidates,
+                   (double)sstats.fp_answer_bytes / (9.0 * (double)sstats.routed_candidates), (unsigned long long)sstats.stay_levels,
+                   (unsigned long long)sstats.move_levels);
         fflush(stdout);
     }
     mc_engine_destroy(eng);
@@ -297,6 +304,13 @@ int main(int argc, char **argv) {
         else if (arg("-recover")) recover = argv[++i];
         else if (arg("-workers")) ++i;
         else if (arg("-gpus")) ++i;
+        else if (arg("-exchange")) {  // how the stay levels of a -gpus run exchange their candidates (MC_SHARD_*)
+            const char *v = argv[++i];
+            if (!strcmp(v, "packed")) g_shard_flags = MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS;
+            else if (!strcmp(v, "measured")) g_shard_flags = MC_SHARD_PACKED;
+            else if (!strcmp(v, "exact")) g_shard_flags = 0;
+            else { fprintf(stderr, "mc: -exchange exact | measured | packed\n"); return 1; }
+        }
         else if (!strcmp(argv[i], "-torch") || !strcmp(argv[i], "-samedevice")) {}
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
         else if (!strcmp(argv[i], "-unverified")) cfg.flags |= MC_F_UNVERIFIED;

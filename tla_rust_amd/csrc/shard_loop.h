@@ -13,7 +13,10 @@
 // is sticky and collective: the failing rank keeps taking part in the level's collectives with empty buckets, its status travels
 // with the all-gather, and all ranks leave together (nobody is left waiting in a collective).
 //
-//   STAY level (large, balanced frontier): fixed-capacity rounds, nothing waits for the host.  Streams: MAIN (the engine's expand
+//   STAY level (large, balanced frontier): the new states stay on the rank that generated them; 9 bytes per routed candidate are
+//     what the exchange needs.  Default form: host-paced rounds with EXACT sizes (the first half of a move round + mc_shard_keep_slot:
+//     one host wait for the round's expand and one small all-gather of the bucket counts per round, both behind the launch of the
+//     next round's expand).  MC_SHARD_PACKED: fixed-capacity rounds, nothing waits for the host.  Streams: MAIN (the engine's expand
 //     stream: expand r, bucket compaction r), COMM (the transport's: the all-to-alls), WORK (probes), the engine's second
 //     stream (materialisation of the kept states).  Issue order on COMM is fp(0) fp(1) ans(0) fp(2) ans(1) ...: the fingerprint
 //     exchange of round r+1 overlaps the probes of round r, the expand of round r+1 overlaps both.  9 bytes per routed
@@ -206,7 +209,7 @@ struct Loop {
             const uint64_t mine = sizes[me];
             const bool stay = frontier >= stay_threshold * P && (double)max_n * P <= ratio * (double)frontier;
             // a move level ships whole states: smaller rounds keep its buffers modest
-            const bool exact = stay && (o.flags & MC_SHARD_EXACT_STAY);  // the stay level as host-paced rounds with exact sizes
+            const bool exact = stay && !(o.flags & (MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS));  // the stay level as host-paced rounds with exact sizes
             const uint64_t ch = stay ? chunk : std::min<uint64_t>(chunk, 1ull << 17);
             const uint64_t rounds = (max_n + ch - 1) / ch;
             (stay ? st.stay_levels : st.move_levels)++;
@@ -413,7 +416,7 @@ struct Loop {
             step([&] { return e.probe((const uint64_t *)recv[0].p, n, (uint8_t *)ans[0].p); });
             if ((trc = a2a_v_safe(ans[0], rcounts, bk, counts, 1))) return trc;
             if (keep_local) {
-                // STAY with exact sizes (MC_SHARD_EXACT_STAY): the positively answered candidates become states of THIS rank; what crossed
+                // STAY with exact sizes (the default form, include/tlamc.h): the positively answered candidates become states of THIS rank; what crossed
                 // xGMI is 9 bytes per routed candidate and the P counts, nothing else — no capacity to guess, no bucket to overflow
                 step([&] { return e.keep(s, (const uint8_t *)bk.p); });
                 continue;
@@ -583,7 +586,7 @@ int run_restarting(Ops &ops, const mc_transport &t, const mc_shard_opts &o, mc_r
         // Every rank left the loop at the same level with the same sizing decision (it depends on all-gathered values only), so
         // every rank takes the same branch here.
         const bool any = loop.level_measured;
-        if (any) cur.flags |= MC_SHARD_FIXED_CAPS;  // (a measured bucket does not grow with the allowance)
+        if (any) cur.flags |= MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS;  // (a measured bucket does not grow with the allowance)
         cur.packed_fanout = 2 * (cur.packed_fanout ? cur.packed_fanout : 16);
         cur.move_fanout = 2 * (cur.move_fanout ? cur.move_fanout : 32);
         ++restarts;

@@ -32,6 +32,11 @@ def parse(argv):
             if a != "-workers":      # accepted and ignored like the one-GPU CLI: the GPUs are the worker pool
                 o[a[1:]] = int(argv[i + 1])
             i += 2
+        elif a == "-exchange" and i + 1 < len(argv):
+            if argv[i + 1] not in ("packed", "measured", "exact"):
+                raise SystemExit("mc_multi: -exchange packed | measured | exact")
+            o["exchange"] = argv[i + 1]
+            i += 2
         elif a == "-generic":
             o["generic"] = True
             i += 1
@@ -96,7 +101,8 @@ def main(argv=None):
     world = dist.get_world_size() if launched else 1
     rs = ResolvedSpec(o["tla"], o["config"], generic=o["generic"], unverified=o["unverified"])
     chk = ShardedChecker(rs.spec, rs.params, device=device, chunk_states=o["chunk"], max_distinct=o["maxdistinct"], max_levels=o["maxlevels"],
-                         table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"], trace=True)
+                         table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"], trace=True,
+                         exchange=o.get("exchange", "exact"))
     if launched:  # communicator set-up (RCCL builds its rings on the first collective) stays out of the reported time
         dist.all_reduce(torch.zeros(1, device="cpu" if o["backend"] == "gloo" else f"cuda:{device}"))
         torch.cuda.synchronize()

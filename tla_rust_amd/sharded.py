@@ -183,7 +183,7 @@ class ShardedChecker:
 
     def __init__(self, spec, params, device=0, chunk_states=1 << 19, max_distinct=0, max_levels=0, table_capacity=1 << 27,
                  arena_capacity=1 << 25, engine=None, group=None, stay_threshold=1 << 16, rebalance_ratio=1.25, replicate_until=1 << 15,
-                 packed_fanout=16, move_fanout=32, trace=False, fixed_caps=False, cap_safety_pct=0, exact_stay=False):
+                 packed_fanout=16, move_fanout=32, trace=False, exchange="exact", cap_safety_pct=0):
         self.spec, self.params = spec, list(params)
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -193,7 +193,7 @@ class ShardedChecker:
         # search is sharded at all (below it every rank runs the same fused BFS); 0 = shard from Init on.
         self.opts = dict(chunk_states=chunk_states, max_distinct=max_distinct, max_levels=max_levels, replicate_until=replicate_until,
                          packed_fanout=packed_fanout, stay_threshold=stay_threshold, rebalance_ratio=rebalance_ratio, move_fanout=move_fanout,
-                         fixed_caps=fixed_caps, cap_safety_pct=cap_safety_pct, exact_stay=exact_stay)
+                         exchange=exchange, cap_safety_pct=cap_safety_pct)
         self.eng = engine if engine is not None else HipShard(spec, params, device, rank, world, chunk_states, table_capacity,
                                                               arena_capacity, trace=trace)
         self.net = TorchTransport(self.eng.device, group)
