@@ -259,11 +259,6 @@ int mc_shard_keep(mc_engine *e, const uint8_t *answers_back, uint64_t *n_new);  
 int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t *n_new);
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local_states);  /* swap frontiers                                */
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict);
-/* After mc_shard_end_level: *max_bucket = the entries the fullest exchange bucket of that level's mc_shard_expand_pack rounds was
- * asked to hold (0: the level had no packed round), *routed_total = the entries of all packed buckets of the run so far.  The level
- * loop sizes the NEXT level's fixed-capacity buckets from the first (mc_shard_opts.cap_safety_pct) and reports 9 bytes x the
- * second as the exchange volume the candidates needed (mc_shard_stats.routed_candidates). */
-int mc_shard_route_fill(mc_engine *e, uint64_t *max_bucket, uint64_t *routed_total);
 /* Before a sharded run that stops on a budget reports: evaluate the invariants of this rank's unexpanded frontier for the
  * specs that check invariants when a state is expanded (the snapshot-isolation models); TLC checks a state when it is
  * generated, so no counted state may stay unchecked.  A violation shows up in mc_shard_counters' verdict.  No-op for the
@@ -325,7 +320,7 @@ typedef struct mc_comm mc_comm;
  *     launched before them and overlaps the exchange, the probes and the materialisation of this one);
  *   MC_SHARD_PACKED: pipelined FIXED-CAPACITY rounds, counts in band, no host wait inside a level (mc_shard_*_pack); the buckets are
  *     moved whole, so their capacity is the exchange volume: it is sized from the previous level's MEASURED fill
- *     (mc_shard_route_fill, cap_safety_pct) ...
+ *     (the loop reads the in-band counts of every round back, asynchronously; cap_safety_pct) ...
  *   MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS: ... or from packed_fanout alone (rounds 2-3).  A search restarted after MC_EROUTE in a
  *     measured level runs so. */
 #define MC_SHARD_FIXED_CAPS 2u

@@ -905,7 +905,7 @@ struct ShimOps {
     ShimShardBase *s;
     uint32_t P;
     std::vector<uint64_t> pack_counts[2];
-    uint64_t route_max = 0, route_lvl = 0, route_sum = 0;  // mc_shard_route_fill of the HIP engine
+    uint64_t route_max = 0, route_lvl = 0, route_sum = 0;  // what AbiOps reads back from the in-band counts of the HIP engine
     uint64_t chunk_limit() const { return 0; }
     size_t state_bytes() const { return s->state_bytes(); }
     bool traced() const { return true; }

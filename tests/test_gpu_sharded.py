@@ -51,7 +51,7 @@ def test_two_ranks_stay_mode_on_gpu(oracle, tmp_path):
 @pytest.mark.parametrize("form,extra", [("fixed", {"exchange": "packed"}), ("measured", {"exchange": "measured", "cap_safety_pct": 140}), ("exact", {"exchange": "exact"})])
 def test_the_three_forms_of_a_stay_level_on_gpu(oracle, tmp_path, form, extra):
     """the stay levels of two HIP engines in their three forms (include/tlamc.h: MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS, MC_SHARD_PACKED + cap_safety_pct, the default):
-    buckets from packed_fanout, buckets from the fill the device measured on the previous level (mc_shard_route_fill), host-paced rounds
+    buckets from packed_fanout, buckets from the fill of the previous level (the in-band counts read back by the loop), host-paced rounds
     with exact sizes (mc_shard_expand_finish + mc_shard_probe + mc_shard_keep_slot) — the oracle's counters and per-level counts each
     time; 9 bytes per routed candidate in the exact form"""
     params = [3, 2, 2, 9, 1, 1]

@@ -79,8 +79,6 @@ struct DevCounters {
     unsigned long long pad_an[15];
     unsigned long long viol_key;      // min over (idx << 24 | slot << 8 | kind); ~0 = none
     unsigned long long via_list;      // fused runs: states that went through the new-list + k_materialise (the rest were written in-wave)
-    unsigned long long route_max;     // sharded stay rounds: the fullest exchange bucket of the current level (entries; reset at shard_end_level) ...
-    unsigned long long route_sum;     // ... and the entries of all buckets of the run: what the level loop sizes the next level's buckets from
     unsigned int max_slots;           // rows of the candidate matrix written by the current chunk
     unsigned int error;               // DEV_E* bits
     unsigned int atomic_alloc;        // see arena_next
@@ -1394,7 +1392,7 @@ static __global__ void __launch_bounds__(256)
 k_compact_packed(RouteArgs rt, uint64_t cap, uint64_t *__restrict__ send_fp, uint32_t *__restrict__ pend_src, DevCounters *ctr) {
     const unsigned bucket = blockIdx.y, owner = bucket / NSHARD;  // bucket = owner * NSHARD + shard
     const uint64_t n = rt.cursors[bucket].v < rt.subcap ? rt.cursors[bucket].v : rt.subcap;
-    uint64_t off = 1, total = 0, asked = 0;
+    uint64_t off = 1, total = 0;
     bool over = false;
     for (unsigned b = owner * NSHARD; b < (owner + 1) * NSHARD; ++b) {
         const uint64_t c = rt.cursors[b].v;
@@ -1402,14 +1400,11 @@ k_compact_packed(RouteArgs rt, uint64_t cap, uint64_t *__restrict__ send_fp, uin
         const uint64_t cc = c < rt.subcap ? c : rt.subcap;
         if (b < bucket) off += cc;
         total += cc;
-        asked += c;
     }
     over |= total + 1 > cap;
     if (blockIdx.x == 0 && threadIdx.x == 0 && bucket == owner * NSHARD) {
         send_fp[(uint64_t)owner * cap] = over ? 0ull : total;
         if (over) atomicOr(&ctr->error, DEV_EROUTE);
-        // what the buckets were ASKED to hold (an overflowing one included): mc_shard_route_fill
-        if (asked) { atomicMax(&ctr->route_max, (unsigned long long)asked); atomicAdd(&ctr->route_sum, (unsigned long long)asked); }
     }
     if (over) return;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, base = (uint64_t)owner * cap + off;
@@ -1684,7 +1679,6 @@ struct EngineBase {
     virtual int shard_ingest(const uint8_t *recv_states, uint64_t n) = 0;
     virtual int shard_keep(unsigned slot, const uint8_t *answers_back, uint64_t *n_new) = 0;
     virtual int shard_end_level(uint64_t *new_local) = 0;
-    virtual int shard_route_fill(uint64_t *max_bucket, uint64_t *routed_total) = 0;
     virtual int shard_counters(uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) = 0;
     virtual int shard_check_frontier() = 0;
     virtual int shard_materialise_parents(unsigned slot, uint64_t *send_parents) = 0;
@@ -3042,17 +3036,6 @@ struct Engine : EngineBase {
         sh_lo = sh_hi;
         sh_hi = sh_next;
         *new_local = sh_hi - sh_lo;
-        // the fullest packed bucket is a per-level figure: cleared behind the copy above, in front of the next level's compactions
-        // (all on the expand stream)
-        lvl_route_max = h_ctr->route_max;
-        run_route_sum = h_ctr->route_sum;
-        if (lvl_route_max) HIP_TRY(hipMemsetAsync(&d_ctr->route_max, 0, sizeof(unsigned long long), stream));
-        return MC_OK;
-    }
-    uint64_t lvl_route_max = 0, run_route_sum = 0;
-    int shard_route_fill(uint64_t *max_bucket, uint64_t *routed_total) override {
-        *max_bucket = lvl_route_max;
-        *routed_total = run_route_sum;
         return MC_OK;
     }
     // invariants of the unexpanded frontier [lo, hi) for specs that check on expansion (see k_check_frontier); no-op otherwise
@@ -3393,9 +3376,6 @@ int mc_shard_keep_slot(mc_engine *e, uint32_t slot, const uint8_t *answers_back,
     return e ? e->impl->shard_keep(slot, answers_back, n_new) : MC_EBADCFG;
 }
 int mc_shard_end_level(mc_engine *e, uint64_t *new_local) { return e && new_local ? e->impl->shard_end_level(new_local) : MC_EBADCFG; }
-int mc_shard_route_fill(mc_engine *e, uint64_t *max_bucket, uint64_t *routed_total) {
-    return e && max_bucket && routed_total ? e->impl->shard_route_fill(max_bucket, routed_total) : MC_EBADCFG;
-}
 int mc_shard_counters(mc_engine *e, uint64_t *generated, uint64_t *distinct_local, int32_t *verdict) {
     return e && generated && distinct_local && verdict ? e->impl->shard_counters(generated, distinct_local, verdict) : MC_EBADCFG;
 }

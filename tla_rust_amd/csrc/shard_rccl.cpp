@@ -147,6 +147,7 @@ struct AbiOps {
         if (rc) return rc;
         main_s = (hipStream_t)ms;
         comm = (hipStream_t)t->hip_stream;
+        h_world = t->world;
         sync_comm = t->hip_stream == nullptr;
         HIPCK(hipStreamCreateWithFlags(&work, hipStreamNonBlocking));
         for (auto &x : ev) HIPCK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
@@ -155,6 +156,7 @@ struct AbiOps {
     ~AbiOps() {
         if (eng) mc_shard_set_stream(eng, nullptr, 0);
         for (auto &x : ev) if (x) hipEventDestroy(x);
+        if (h_counts) { if (main_s) hipStreamSynchronize(main_s); hipHostFree(h_counts); }
         if (work) { hipStreamSynchronize(work); hipStreamDestroy(work); }
     }
     hipStream_t stream(int s) const { return s == mc_shard::S_COMM ? comm : s == mc_shard::S_WORK ? work : main_s; }
@@ -181,7 +183,34 @@ struct AbiOps {
     int level_size(uint64_t *n) { return mc_shard_level_size(eng, n); }
     int expand_launch(uint32_t slot, uint64_t first, uint64_t count, uint64_t cap) { return mc_shard_expand_launch(eng, slot, first, count, cap); }
     int expand_finish(uint32_t slot, uint64_t *fp, uint64_t cap, uint64_t *counts) { return mc_shard_expand_finish(eng, slot, fp, cap, counts); }
-    int expand_pack(uint32_t slot, uint64_t *fp, uint64_t cap) { return mc_shard_expand_pack(eng, slot, fp, cap); }
+    // Fixed-capacity rounds: the count word of every bucket is read back behind the compaction — asynchronously, on the expand stream,
+    // into pinned memory — and folded when the level ends: the fullest bucket of the level and the entries of all buckets of the run
+    // are what the loop sizes the next level's buckets from and reports as the volume the candidates needed (shard_loop.h `fill`).
+    static constexpr size_t FILL_ROUNDS = 1024;
+    uint64_t *h_counts = nullptr;
+    size_t h_rounds = 0;
+    uint32_t h_world = 0;
+    uint64_t fill_max = 0, fill_lvl = 0, fill_sum = 0;
+    void fold_counts() {
+        for (size_t i = 0; i < h_rounds * h_world; ++i) {
+            fill_max = std::max(fill_max, h_counts[i]);
+            fill_sum += h_counts[i];
+        }
+        h_rounds = 0;
+    }
+    int expand_pack(uint32_t slot, uint64_t *fp, uint64_t cap) {
+        int rc = mc_shard_expand_pack(eng, slot, fp, cap);
+        if (rc) return rc;
+        if (!h_counts) HIPCK(hipHostMalloc((void **)&h_counts, FILL_ROUNDS * 8 * sizeof(uint64_t)));
+        if (h_rounds == FILL_ROUNDS) {  // (a level of more than a thousand rounds: fold what has arrived)
+            HIPCK(hipStreamSynchronize(main_s));
+            fold_counts();
+        }
+        for (uint32_t t = 0; t < h_world; ++t)
+            HIPCK(hipMemcpyAsync(h_counts + h_rounds * h_world + t, fp + (uint64_t)t * cap, sizeof(uint64_t), hipMemcpyDeviceToHost, main_s));
+        ++h_rounds;
+        return MC_OK;
+    }
     int probe(const uint64_t *fp, uint64_t n, uint8_t *ans) { return mc_shard_probe(eng, fp, n, ans); }
     int probe_pack(const uint64_t *fp, uint64_t cap, uint8_t *ans) { return mc_shard_probe_pack(eng, fp, cap, ans); }
     int keep_pack(uint32_t slot, const uint8_t *back, uint64_t cap) { return mc_shard_keep_pack(eng, slot, back, cap); }
@@ -193,8 +222,17 @@ struct AbiOps {
     int materialise_parents(uint32_t slot, uint64_t *out) { return mc_shard_materialise_parents(eng, slot, out); }
     int ingest(const uint8_t *st, uint64_t n) { return mc_shard_ingest(eng, st, n); }
     int ingest_parents(const uint64_t *pp, uint64_t n, uint32_t src) { return mc_shard_ingest_parents(eng, pp, n, src); }
-    int end_level(uint64_t *n) { return mc_shard_end_level(eng, n); }
-    int route_fill(uint64_t *mx, uint64_t *sum) { return mc_shard_route_fill(eng, mx, sum); }
+    int end_level(uint64_t *n) {
+        int rc = mc_shard_end_level(eng, n);  // waits for the engine's streams: the count words of the level's rounds have landed
+        if (h_rounds) {
+            if (rc) HIPCK(hipStreamSynchronize(main_s));  // (a failed level may have returned before its wait)
+            fold_counts();
+        }
+        fill_lvl = fill_max;
+        fill_max = 0;
+        return rc;
+    }
+    int route_fill(uint64_t *mx, uint64_t *sum) { *mx = fill_lvl; *sum = fill_sum; return MC_OK; }
     int counters(uint64_t *g, uint64_t *d, int32_t *v) { return mc_shard_counters(eng, g, d, v); }
     int check_frontier() { return mc_shard_check_frontier(eng); }
     int violation(int32_t *found, uint64_t *idx, uint32_t *slot, int32_t *v, int32_t *inv) { return mc_shard_violation(eng, found, idx, slot, v, inv); }
