@@ -95,7 +95,7 @@ def test_a_full_exchange_bucket_restarts_the_search_on_gpu(oracle, tmp_path):
     r = run_dist("hip", 2, "raft", params, tmp_path, {"max_distinct": 100000, "chunk": 1 << 13, "table": 1 << 22, "arena": 1 << 20,
                                                        "stay_threshold": 200, "rebalance_ratio": 1.5, "packed_fanout": 1, "move_fanout": 1})
     assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
-    assert r["stats"]["restarts"] >= 2
+    assert r["stats"]["restarts"] >= 1
 
 
 @pytest.mark.parametrize("world,replicate_until", [(2, 0), (3, 0), (3, 40)])
