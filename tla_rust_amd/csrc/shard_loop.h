@@ -94,7 +94,7 @@ struct Loop {
         if (states >= FILL_MIN_STATES) fill_mine = std::max(fill_mine, (bucket_entries * FILL_ONE + states - 1) / states);
     }
 
-    Loop(Ops &ops, const mc_transport &t) : e(ops), net(t), P(t.world), me(t.rank), all(t.world), sizes(t.world) { memset(&st, 0, sizeof st); }
+    Loop(Ops &ops, const mc_transport &t) : e(ops), net(t), P(t.world), me(t.rank), all(t.world), sizes(t.world) { memset(&st, 0, sizeof st); probe_rot = t.rank; }
 
     // engine step: skipped once this rank has failed
     template <class F>
@@ -369,6 +369,8 @@ struct Loop {
         for (uint32_t p = 0; p < P; ++p) from_peers[p] = m[(size_t)p * P + me];
         return MC_OK;
     }
+    static constexpr uint32_t PROBE_SEGS = 4;
+    uint64_t probe_rot = 0;  // which source goes first, round by round (starts at this rank's number: the owners differ too)
     void comm_after_work() { e.record(EV_TMP, S_WORK); e.wait(S_COMM, EV_TMP); }
     void work_after_comm() { e.record(EV_TMP + 1, S_COMM); e.wait(S_WORK, EV_TMP + 1); }
     int a2a_v(const void *s, const std::vector<uint64_t> &sc, void *r, const std::vector<uint64_t> &rc_, uint64_t elem) {
@@ -413,7 +415,26 @@ struct Loop {
             if (keep_local) step([&] { return e.wait_keep(s); });  // (on WORK) the slot's previous keep has read back[s] — also before it may be re-allocated
             step([&] { return bk.need(std::max<uint64_t>(total, 1)); });
             if ((trc = a2a_v_safe(send[s], counts, recv[0], rcounts, 8))) return trc;
-            step([&] { return e.probe((const uint64_t *)recv[0].p, n, (uint8_t *)ans[0].p); });
+            if (keep_local && P > 1) {
+                // WHO KEEPS A STATE that several ranks generated in the same round is decided by whose candidate reaches the table first.
+                // Probed as they lie (source 0's bucket first), the lower ranks win those ties systematically and their frontiers grow
+                // level after level (8 ranks on the 10^8-state bench graph: 17.3 M states on rank 0 against 11.1 M on rank 5, every other
+                // level a rebalancing one — profiles/r04zc; the fixed-capacity form walks the sources interleaved inside its kernel for
+                // the same reason).  Here: each source's bucket in PROBE_SEGS segments, the segments in rotating source order, one launch
+                // per segment on the same stream — a tie between two sources falls either way equally often.
+                const uint32_t K = n >= (1u << 16) ? PROBE_SEGS : 1;
+                std::vector<uint64_t> off(P + 1, 0);
+                for (uint32_t p = 0; p < P; ++p) off[p + 1] = off[p] + rcounts[p];
+                for (uint32_t k = 0; k < K; ++k)
+                    for (uint32_t j = 0; j < P; ++j) {
+                        const uint32_t p = (uint32_t)((j + k + probe_rot) % P);
+                        const uint64_t a = rcounts[p] * k / K, b = rcounts[p] * (k + 1) / K;
+                        if (b > a) step([&] { return e.probe((const uint64_t *)recv[0].p + off[p] + a, b - a, (uint8_t *)ans[0].p + off[p] + a); });
+                    }
+                ++probe_rot;
+            } else {
+                step([&] { return e.probe((const uint64_t *)recv[0].p, n, (uint8_t *)ans[0].p); });
+            }
             if ((trc = a2a_v_safe(ans[0], rcounts, bk, counts, 1))) return trc;
             if (keep_local) {
                 // STAY with exact sizes (the default form, include/tlamc.h): the positively answered candidates become states of THIS rank; what crossed
