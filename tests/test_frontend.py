@@ -164,6 +164,9 @@ def test_mc_gpus_without_a_gpu_refuses_loudly(tmp_path):
     assert p.returncode == 1 and "not available with -gpus" in p.stderr
     p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "0"], capture_output=True, text=True)
     assert p.returncode == 1
+    # -exchange names one of the three forms of a stay level's exchange (include/tlamc.h); anything else is refused by every rank
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "2", "-exchange", "sideways"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1 and "-exchange exact | measured | packed" in p.stderr
 
 
 def test_cli_is_built():

@@ -58,6 +58,8 @@ struct NetBuf {
         if (n <= bytes && p) return MC_OK;
         if (p) t->release(t->user, p);
         p = nullptr;
+        // (geometric: the exact sizes of host-paced rounds grow level by level, and a release waits for the device)
+        if (bytes) n = std::max(n, bytes + bytes / 2);
         bytes = 0;
         n = (n + 4095) & ~(size_t)4095;
         p = t->alloc(t->user, n);
