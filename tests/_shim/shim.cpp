@@ -955,10 +955,15 @@ struct ShimOps {
     int probe(const uint64_t *fp, uint64_t n, uint8_t *ans) { return s->probe(fp, n, ans); }
     int probe_pack(const uint64_t *recv, uint64_t cap, uint8_t *ans) {
         memset(ans, 0, (size_t)P * cap);
-        for (uint32_t q = 0; q < P; q++) {
-            const uint64_t n = recv[(uint64_t)q * cap] < cap ? recv[(uint64_t)q * cap] : 0;
-            if (n) s->probe(recv + (uint64_t)q * cap + 1, n, ans + (uint64_t)q * cap + 1);
-        }
+        // like k_probe_packed: the sources are walked INTERLEAVED, 256 entries at a time (walked one after the other, the lower
+        // ranks would win every same-round tie and keep the state)
+        uint64_t most = 0;
+        for (uint32_t q = 0; q < P; q++) most = std::max(most, recv[(uint64_t)q * cap] < cap ? recv[(uint64_t)q * cap] : 0);
+        for (uint64_t b = 0; b < most; b += 256)
+            for (uint32_t q = 0; q < P; q++) {
+                const uint64_t n = recv[(uint64_t)q * cap] < cap ? recv[(uint64_t)q * cap] : 0;
+                if (b < n) s->probe(recv + (uint64_t)q * cap + 1 + b, std::min<uint64_t>(256, n - b), ans + (uint64_t)q * cap + 1 + b);
+            }
         return 0;
     }
     int keep_pack(uint32_t slot, const uint8_t *back, uint64_t cap) {

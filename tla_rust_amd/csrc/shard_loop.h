@@ -81,13 +81,16 @@ struct Loop {
     std::vector<uint64_t> sizes;
     int lrc = MC_OK;  // this rank's sticky status: once non-zero, no engine call is made any more, the collectives still are
     mc_shard_stats st;
-    // Bucket capacities from MEASURED fill.  A stay round moves its buckets whole, so their capacity is the
-    // exchange volume.  packed_fanout allows for 16 in-model successors per expanded state; the models send 3 - 6, and a level sends
-    // about what the level before it sent.  Every rank therefore reports, with the level's all-gather, the fullest bucket its
-    // rounds filled per expanded state (`fill`, in 2^-20 entries per state; the engine counts it on the device, a move level knows its
-    // exact sizes), every rank takes the maximum, and the next stay level's buckets hold cap_safety_pct of that (+ 1024 entries for
-    // the small-number noise), never more than packed_fanout allows.  Counts never depend on it: a bucket that does not fit fails the
-    // level as before (MC_EROUTE), and the search restarted for it keeps to packed_fanout (MC_SHARD_FIXED_CAPS).
+    // Bucket capacities from MEASURED fill (the `measured` form of a stay level, MC_SHARD_PACKED without MC_SHARD_FIXED_CAPS).  A
+    // fixed-capacity round moves its buckets whole, so their capacity IS the exchange volume.  packed_fanout allows for 16 in-model
+    // successors per expanded state; the models route 3 - 6 per state to each owner's share, and a level sends about what the level
+    // before it sent.  Every rank therefore reports, with the level's all-gather, the fullest bucket its rounds filled per expanded
+    // state (`fill`, in 2^-20 entries per state: Ops::route_fill — the HIP ops read every bucket's count word back behind its
+    // compaction; a host-paced round knows its exact sizes), every rank takes the maximum, and the next stay level's buckets hold
+    // cap_safety_pct of that (+ 1024 entries for the small-number noise), never more than the buffers were allocated for.  Counts never
+    // depend on it: a bucket that does not fit fails the level as before (MC_EROUTE), and the search restarted for it sizes its buckets
+    // from twice packed_fanout (MC_SHARD_FIXED_CAPS).  The bet can be lost — inside a level the candidates per state rise in BFS order
+    //  — which is why the exact form is the default.
     static constexpr uint64_t FILL_ONE = 1ull << 20, FILL_MIN_STATES = 1024;
     uint64_t fill_prev = 0;        // max over ranks, previous level; 0 = not known
     uint64_t fill_mine = 0;        // this rank, current level
