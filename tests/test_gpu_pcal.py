@@ -184,6 +184,19 @@ def test_mc_on_a_module_with_records():
     assert '"Failure of assertion at line 36, column 9."' in out and "/\\ buf_full = " in out
 
 
+def test_mc_on_the_michael_scott_queue():
+    """`mc ms_queue.tla` = tlc on the lock-free linked-list queue (the "lists" of the reference's roadmap, README.md:26-42): three threads,
+    the counts the TLA+ evaluator gives for the translation (tests/test_pcal.py); with the linking CAS replaced by a plain store
+    (ms_queue_racy.cfg) the Fifo invariant breaks (an 18-state behaviour: tests/test_pcal.py compares its length on the host)"""
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "ms_queue.tla")
+    assert rc == 0, err
+    assert "228229 states generated, 91727 distinct states found, 0 states left on queue." in out
+    assert "The depth of the complete state graph search is 40." in out
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "ms_queue.tla", "-config", ROOT / "specs" / "pluscal" / "ms_queue_racy.cfg")
+    assert rc == 12, err
+    assert "Error: Invariant Fifo is violated." in out and "State 1: <Initial predicate>" in out
+
+
 def test_bigger_program_throughput_smoke(amd):
     """cas_counter with 3 workers x 3 increments: a graph large enough to run many chunks"""
     path = ROOT / "specs" / "pluscal" / "cas_counter.tla"
