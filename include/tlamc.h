@@ -245,7 +245,7 @@ int mc_shard_ingest(mc_engine *e, const uint8_t *recv_states, uint64_t n);
  *       positions and are 0 outside a bucket's count;
  *   _keep_pack(slot, answers_back[shard_count * cap], cap): the sender materialises its positively answered candidates.
  * cap must be the same on every rank (derive it from the level's frontier sizes, which every rank knows).  A bucket that
- * does not fit is not truncated: the level fails with MC_EARENA at mc_shard_end_level ("an exchange bucket is full"). */
+ * does not fit is not truncated: the level fails with MC_EROUTE at mc_shard_end_level ("an exchange bucket is full"). */
 int mc_shard_expand_pack(mc_engine *e, uint32_t slot, uint64_t *send_fp, uint64_t cap);
 int mc_shard_probe_pack(mc_engine *e, const uint64_t *recv_fp, uint64_t cap, uint8_t *answers);
 int mc_shard_keep_pack(mc_engine *e, uint32_t slot, const uint8_t *answers_back, uint64_t cap);
@@ -302,13 +302,15 @@ int mc_shard_resume(mc_engine *e, uint64_t *levels_out, uint32_t *nlevels);
  *                mc_engine_create(spec, cfg with shard_rank / shard_count, &e)
  *                mc_shard_run(e, c, &opts, &result)                    -- the whole search; every rank gets the global counters
  * replaces: TLC's worker pool ("Number of worker threads", examples/serializableSnapshotIsolation.tla:52-53) scaled past one
- * device.  Per level one host synchronisation (frontier sizes + verdicts, ncclAllGather); the rounds inside a level are the
- * fixed-capacity exchanges above (mc_shard_*_pack) as ncclSend / ncclRecv groups.  Any RCCL failure returns MC_ERCCL
+ * device.  Per level one collective for frontier sizes + verdicts + statuses (ncclAllGather); the rounds inside a level are
+ * ncclSend / ncclRecv groups — of exact sizes after a small all-gather of the bucket counts (the default), or the fixed-capacity
+ * exchanges above (mc_shard_*_pack, no host wait inside a level): MC_SHARD_* below.  Any RCCL failure returns MC_ERCCL
  * (mc_last_error() carries ncclGetErrorString).  A rank-local failure (a full exchange bucket, MC_ETABLEFULL, MC_EOVERFLOW,
  * an allocation) does not leave the others waiting in a collective: every rank's status travels with the per-level
  * all-gather and all ranks leave the loop together with the first failing rank's code.  Levels whose new states STAY where they
- * were generated exchange 9 bytes per candidate (fixed-capacity rounds, pipelined: the fingerprint exchange of round r+1
- * overlaps the probes of round r, the expand of round r+1 overlaps both); small or unbalanced levels MOVE the new states to
+ * were generated need 9 bytes per routed candidate (the expand of round r+1 overlaps the exchange, the probes and the
+ * materialisation of round r; the fixed-capacity forms also overlap the exchange of round r+1 with the probes of round r and move
+ * their buckets whole); small or unbalanced levels MOVE the new states to
  * their owners (mc_shard_materialise_slot / mc_shard_ingest).  `mc X.tla -gpus P` is this API with forked ranks. */
 #define MC_COMM_ID_BYTES 128
 typedef struct mc_comm mc_comm;

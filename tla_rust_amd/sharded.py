@@ -2,7 +2,7 @@
 seen-set partitioned by fingerprint high bits.
 
 The level loop itself is NOT here any more: it is the C++ loop of the library (tla_rust_amd/csrc/shard_loop.h — replicated
-prefix, pipelined fixed-capacity "stay" rounds, "move" rounds that rebalance, collective error status, counterexamples walked
+prefix, "stay" rounds in three forms (exact sizes by default; `exchange=`), "move" rounds that rebalance, collective error status, counterexamples walked
 back across ranks), the same one `mc X.tla -gpus P` and `bench.py --gpus N` run over RCCL directly (mc_comm_* / mc_shard_run).
 This module is the "bring your own collectives" door of that loop (include/tlamc.h `mc_transport`): `TorchTransport` hands
 torch.distributed's collectives to it as callbacks —
