@@ -79,6 +79,11 @@ def build(force=False, verbose=False):
     calib = OUT / "calib_fetch"
     if calib_src.exists() and (force or _stale(calib, [calib_src])):
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-Wno-unused-result", "-o", str(calib), str(calib_src)], check=True)
+    # ... and the random-probe rate against the working set / the cost of partitioning candidates by table region (profiles/calib/probe_locality.hip)
+    loc_src = PKG.parent / "profiles" / "calib" / "probe_locality.hip"
+    loc = OUT / "probe_locality"
+    if loc_src.exists() and (force or _stale(loc, [loc_src])):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-Wno-unused-result", "-o", str(loc), str(loc_src)], check=True)
     return LIB
 
 
