@@ -14,6 +14,7 @@
 //      HBM, and beyond the reach of the address translation caches.  The reads are the engine's (seen_insert: 16-byte loads of one
 //      bucket), the addresses a multiply-shift of a mixed counter like its home-bucket function.
 //   2. k_insert32: the same with the compare-and-swap of a first-time insert into an empty region (the write side of a new state).
+//   2b. k_probe_ilp<1 | 2 | 4>: probes in flight per lane against the wavefronts per SIMD (capped through the workgroup's LDS).
 //   3. partition: the candidates of one round (fp 8 B + src 4 B) counting-sorted by table region — k_hist (read 8 B) + k_scatter
 //      (read 12 B, write 12 B) — and then probed region by region (k_probe_part): the end-to-end rate of the partitioned scheme
 //      against measurement 1 at S = the whole table, for region sizes 4 MiB ... 256 MiB.
@@ -65,6 +66,31 @@ __global__ void __launch_bounds__(256) k_insert32(uint64_t *__restrict__ table, 
                 acc += done;
             }
         }
+    }
+    if (acc == 0x1234567ull) *sink = acc;
+}
+
+// ---- probes in flight: ILP independent 32-byte probes issued before the first is consumed, at an occupancy capped through the
+// workgroup's dynamic LDS (160 KB per CU: lds_bytes = 160 KB / workgroups per CU; a 256-thread workgroup is one wavefront per SIMD) —
+// what the by-family expand kernel of the raft model has (4 wavefronts per SIMD, one probe batch in flight) against what a fifth
+// wavefront or a second probe batch would buy
+template <int ILP>
+__global__ void __launch_bounds__(256) k_probe_ilp(const uint64_t *__restrict__ table, uint64_t buckets, uint64_t nprobes, uint64_t salt,
+                                                   unsigned long long *sink) {
+    extern __shared__ unsigned char occupancy_pad[];
+    unsigned long long acc = 0;
+    if (salt == ~0ull) acc = occupancy_pad[threadIdx.x];  // (keeps the allocation alive)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + (ILP - 1) * stride < nprobes; i += ILP * stride) {
+        ulonglong2 a[ILP], b[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {
+            const ulonglong2 *line = reinterpret_cast<const ulonglong2 *>(table + home(mix((i + k * stride) ^ salt), buckets) * 4);
+            a[k] = line[0];
+            b[k] = line[1];
+        }
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) acc += a[k].x ^ a[k].y ^ b[k].x ^ b[k].y;
     }
     if (acc == 0x1234567ull) *sink = acc;
 }
@@ -173,6 +199,19 @@ int main(int argc, char **argv) {
         const uint64_t n = s == tbytes ? nprobes : (s / 32);
         printf("{\"what\": \"first-time inserts (32-byte read + CAS)\", \"region_MiB\": %.0f, \"inserts\": %llu, \"ms\": %.3f, \"Ginserts_s\": %.2f}\n",
                (double)s / (1 << 20), (unsigned long long)n, ms, n / ms / 1e6);
+    }
+    // 2b. probes in flight against occupancy (whole table)
+    for (int wg_per_cu : {3, 4, 5, 6, 8}) {
+        const size_t lds = (size_t)(160 * 1024) / wg_per_cu - 512;
+        const dim3 g(256 * wg_per_cu);  // one resident set: every workgroup runs from start to end
+        auto run = [&](auto kern) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            return timed([&] { hipLaunchKernelGGL(kern, g, block, lds, 0, table, tbytes / 32, nprobes, 17ull, sink); });
+        };
+        const double m1 = run(k_probe_ilp<1>), m2 = run(k_probe_ilp<2>), m4 = run(k_probe_ilp<4>);
+        printf("{\"what\": \"probes in flight\", \"wavefronts_per_SIMD\": %d, \"Gprobes_s_ilp1\": %.2f, \"Gprobes_s_ilp2\": %.2f, \"Gprobes_s_ilp4\": %.2f}\n", wg_per_cu,
+               nprobes / m1 / 1e6, nprobes / m2 / 1e6, nprobes / m4 / 1e6);
+        fflush(stdout);
     }
     CK(hipMemset(table, 0, tbytes));
     // 3. partition the candidates of a round by table region, then probe region by region
