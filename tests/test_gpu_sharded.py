@@ -331,6 +331,9 @@ def test_bench_contract_invocation_with_several_ranks(world):
     assert len(c["shares"]) == world and sum(c["shares"]) == 102586254 and c["levels"]["stay_levels"] >= 10
     assert c["frontier_imbalance"] <= 1.25 and max(c["shares"]) <= 1.25 * 102586254 / world
     assert "xgmi" in line and line["xgmi"]["sent_bytes_per_step_per_gpu"] > 0
+    # the default (exact) form of the stay levels moves 9 bytes per routed candidate and nothing else
+    x = line["xgmi"]
+    assert x["exchange"] == "exact" and x["routed_candidates_per_step"] > 10 ** 8 and x["fp_answer_bytes_per_step"] == x["model_bytes_per_step"] and x["sent_over_model"] == 1.0
 
 
 def test_bench_under_the_drivers_launcher():
