@@ -214,7 +214,8 @@ struct Loop {
             const uint64_t mine = sizes[me];
             const bool stay = frontier >= stay_threshold * P && (double)max_n * P <= ratio * (double)frontier;
             // a move level ships whole states: smaller rounds keep its buffers modest
-            const bool exact = stay && !(o.flags & (MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS));  // the stay level as host-paced rounds with exact sizes
+            // the stay level as host-paced rounds with exact sizes (a single rank exchanges nothing: it keeps the rounds that never wait)
+            const bool exact = stay && P > 1 && !(o.flags & (MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS));
             const uint64_t ch = stay ? chunk : std::min<uint64_t>(chunk, 1ull << 17);
             const uint64_t rounds = (max_n + ch - 1) / ch;
             (stay ? st.stay_levels : st.move_levels)++;
@@ -298,7 +299,7 @@ struct Loop {
             // than packed_fanout's share, up to what the buffers were allocated for); otherwise packed_fanout candidates per state,
             // spread over the P owners
             if (safety) return std::min((uint64_t)((unsigned __int128)n_round * fill_prev * safety / (100 * FILL_ONE)) + 1024, cap_max);
-            return std::min(n_round * fan / P + 1024, cap_max);
+            return std::min((P > 1 ? n_round * fan / P : 0) + 1024, cap_max);  // (one rank: its only bucket is its own, always empty)
         };
         const size_t total_max = (size_t)P * (ch * fan / P + 4096);  // the largest a level of this run can ask for
         if (stay_bytes < total_max) {
