@@ -327,7 +327,8 @@ typedef struct mc_comm mc_comm;
  *     measured level runs so. */
 #define MC_SHARD_FIXED_CAPS 2u
 #define MC_SHARD_PACKED 4u
-/* what one rank's level loop did (diagnostics; filled when mc_shard_opts.stats != NULL) */
+/* what one rank's level loop did (diagnostics; filled when mc_shard_opts.stats != NULL).  With TLAMC_SHARD_DEBUG set in the
+ * environment rank 0 also prints one line per level to stderr: its kind, states, rounds, the fullest bucket per expanded state. */
 typedef struct {
     uint64_t replicated_levels; /* levels every rank ran itself (mc_shard_begin_replicated)                                  */
     uint64_t stay_levels;       /* levels whose new states stayed on the generating rank (9 B per candidate cross xGMI)      */
