@@ -134,6 +134,9 @@ def test_multi_gpu_front_door_report_and_options():
     assert (o["tla"], o["config"], o["maxlevels"], o["backend"], o["device"]) == ("X.tla", "Y.cfg", 7, "gloo", 0)
     with pytest.raises(SystemExit):
         mc_multi.parse(["-nonsense"])
+    assert mc_multi.parse(["X.tla", "-exchange", "measured"])["exchange"] == "measured" and "exchange" not in mc_multi.parse(["X.tla"])
+    with pytest.raises(SystemExit):
+        mc_multi.parse(["X.tla", "-exchange", "sideways"])
     rep = mc_multi.report(Result(distinct=3800, generated=5850, queue_left=0, depth=5, verdict="ok", levels=[400, 1250, 900, 800, 450]), 8, 0.5)
     assert "Finished computing initial states: 400 distinct states generated." in rep
     assert "5850 states generated, 3800 distinct states found, 0 states left on queue." in rep         # README.md:319 format
