@@ -43,3 +43,14 @@ def test_product_does_not_reference_the_oracle():
     for p in list((ROOT / "tla_rust_amd").rglob("*.py")) + list((ROOT / "tla_rust_amd" / "csrc").glob("*")):
         if p.is_file() and p.suffix in (".py", ".h", ".hip", ".cpp"):
             assert "oracle/" not in p.read_text().replace("oracle/spec_raft.c:raft_print", ""), p
+
+
+def test_the_pending_list_condition_keeps_its_wording():
+    """tla_rust_amd/csrc/shard_rccl.cpp (AbiOps::expand_finish) recognises the engine's "a round with more candidates than the slot's pending
+    list holds" by its message and hands it to the level loop as MC_EROUTE (restart with twice the fan-out allowance) instead of
+    MC_EARENA: the two places must keep saying the same words"""
+    root = Path(__file__).resolve().parent.parent / "tla_rust_amd" / "csrc"
+    engine, ops = (root / "engine.hip").read_text(), (root / "shard_rccl.cpp").read_text()
+    assert engine.count("pending list holds") == 1 and 'strstr(mc_last_error(), "pending list")' in ops
+    msg = engine[engine.index("pending list holds") - 120:engine.index("pending list holds") + 80]
+    assert "return MC_EARENA" in msg and "shard_expand" in msg
