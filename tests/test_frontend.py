@@ -135,6 +135,7 @@ def test_multi_gpu_front_door_report_and_options():
     with pytest.raises(SystemExit):
         mc_multi.parse(["-nonsense"])
     assert mc_multi.parse(["X.tla", "-exchange", "measured"])["exchange"] == "measured" and "exchange" not in mc_multi.parse(["X.tla"])
+    assert mc_multi.parse(["X.tla", "-fanout", "40"])["fanout"] == 40
     with pytest.raises(SystemExit):
         mc_multi.parse(["X.tla", "-exchange", "sideways"])
     rep = mc_multi.report(Result(distinct=3800, generated=5850, queue_left=0, depth=5, verdict="ok", levels=[400, 1250, 900, 800, 450]), 8, 0.5)
@@ -170,6 +171,8 @@ def test_mc_gpus_without_a_gpu_refuses_loudly(tmp_path):
     # -exchange names one of the three forms of a stay level's exchange (include/tlamc.h); anything else is refused by every rank
     p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "2", "-exchange", "sideways"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 1 and "-exchange exact | measured | packed" in p.stderr
+    p = subprocess.run([str(mc), str(ROOT / "specs" / "MCssi.tla"), "-gpus", "2", "-fanout", "0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1 and "-fanout needs a number" in p.stderr
 
 
 def test_cli_is_built():

@@ -4,7 +4,7 @@
 //
 //   mc X.tla [-config X.cfg] [-deadlock] [-workers N] [-device D] [-generic] [-dump FILE]
 //            [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]
-//            [-checkpoint FILE] [-recover FILE] [-gpus P [-samedevice | -torch] [-exchange exact|measured|packed]] [-noprogress] [-I DIR]
+//            [-checkpoint FILE] [-recover FILE] [-gpus P [-samedevice | -torch] [-exchange exact|measured|packed] [-fanout N]] [-noprogress] [-I DIR]
 //   mc --transpile X.tla [Y.tla ...]      the `pcal2tla *tla` of the reference's Makefile:3-4: inserts (or
 //                                         replaces) the TLA+ translation of the PlusCal algorithm in place,
 //                                         the previous text is kept as X.old
@@ -148,6 +148,7 @@ static int spawn_ranks(int gpus, char **argv) {
     unlink(idfile);
     return worst;
 }
+static uint64_t g_fanout = 0;        // -fanout N: in-model successors per state the buffers of a sharded round allow for (0 = the defaults)
 static uint32_t g_shard_flags = 0;  // -exchange exact (default) | measured | packed (mc_shard_opts.flags, include/tlamc.h)
 static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, int world, const char *idfile, const char *ckpt, const char *recover) {
     mc_spec_desc desc;
@@ -184,6 +185,8 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
     mc_shard_opts so;
     memset(&so, 0, sizeof so);
     so.flags = g_shard_flags;  // -exchange
+    so.packed_fanout = g_fanout;
+    so.move_fanout = g_fanout ? 2 * g_fanout : 0;  // (the default pair is 16 / 32)
     so.chunk_states = cfg.chunk_states;
     so.max_distinct = cfg.max_distinct;
     so.max_levels = cfg.max_levels;
@@ -304,6 +307,10 @@ int main(int argc, char **argv) {
         else if (arg("-recover")) recover = argv[++i];
         else if (arg("-workers")) ++i;
         else if (arg("-gpus")) ++i;
+        else if (arg("-fanout")) {  // a dense model (the SI specs: up to ~40 in-model successors per state) without the restarts that find the allowance by doubling
+            g_fanout = strtoull(argv[++i], nullptr, 10);
+            if (g_fanout < 1 || g_fanout > 4096) { fprintf(stderr, "mc: -fanout needs a number of successors per state (1..4096)\n"); return 1; }
+        }
         else if (arg("-exchange")) {  // how the stay levels of a -gpus run exchange their candidates (MC_SHARD_*)
             const char *v = argv[++i];
             if (!strcmp(v, "packed")) g_shard_flags = MC_SHARD_PACKED | MC_SHARD_FIXED_CAPS;

@@ -1,7 +1,7 @@
 """`tlc X.tla` on the GPUs of one node — the multi-GPU front door (SURVEY.md §8b `mc X.tla -gpus P`, §8e):
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node P --master-addr 127.0.0.1 --master-port 29512 \\
-        -m tla_rust_amd.mc_multi X.tla [-config X.cfg] [-maxdistinct N] [-maxlevels N] [-chunk N] [-tablelog2 T] [-arena N]
+        -m tla_rust_amd.mc_multi X.tla [-config X.cfg] [-maxdistinct N] [-maxlevels N] [-chunk N] [-tablelog2 T] [-arena N] [-exchange F] [-fanout N]
 
 One process per GPU (LOCAL_RANK), `torch.distributed` backend "nccl" (= RCCL over xGMI).  Every rank resolves X.tla / X.cfg
 through the C ABI exactly like the one-GPU `mc` (mc_resolve_files: same lowering registry, same text verification, same
@@ -28,7 +28,7 @@ def parse(argv):
         if a in ("-config", "-backend") and i + 1 < len(argv):
             o[a[1:]] = argv[i + 1]
             i += 2
-        elif a in ("-maxdistinct", "-maxlevels", "-chunk", "-tablelog2", "-arena", "-device", "-workers") and i + 1 < len(argv):
+        elif a in ("-maxdistinct", "-maxlevels", "-chunk", "-tablelog2", "-arena", "-device", "-workers", "-fanout") and i + 1 < len(argv):
             if a != "-workers":      # accepted and ignored like the one-GPU CLI: the GPUs are the worker pool
                 o[a[1:]] = int(argv[i + 1])
             i += 2
@@ -102,7 +102,8 @@ def main(argv=None):
     rs = ResolvedSpec(o["tla"], o["config"], generic=o["generic"], unverified=o["unverified"])
     chk = ShardedChecker(rs.spec, rs.params, device=device, chunk_states=o["chunk"], max_distinct=o["maxdistinct"], max_levels=o["maxlevels"],
                          table_capacity=1 << o["tablelog2"], arena_capacity=o["arena"], trace=True,
-                         exchange=o.get("exchange", "exact"))
+                         exchange=o.get("exchange", "exact"),
+                         **({"packed_fanout": o["fanout"], "move_fanout": 2 * o["fanout"]} if o.get("fanout") else {}))
     if launched:  # communicator set-up (RCCL builds its rings on the first collective) stays out of the reported time
         dist.all_reduce(torch.zeros(1, device="cpu" if o["backend"] == "gloo" else f"cuda:{device}"))
         torch.cuda.synchronize()
