@@ -163,6 +163,16 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def dist_roofline(state_bytes, distinct, generated, world, step_s):
+    """the N-rank line's HBM figure: SURVEY.md 8d's (2 W + 8 G/D) bytes per distinct state, a rank's share of them over the WALL time
+    of a step — the pipeline-level number of the one-GPU line (`pipeline_frac`), not a kernel's (the kernels of a sharded step are
+    timed by nobody: route-mode expand, probes, keep on three streams)"""
+    alg = (2 * state_bytes * distinct + 8 * generated) / max(1, world)
+    return {"bound": "hbm", "kernel": None, "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "alg_bytes_per_step_per_gpu": alg, "state_bytes": state_bytes,
+            "note": "per GPU, whole step: (2 W D + 8 G) / N bytes over the step's wall time; no kernel-level figure and no counters for the sharded step"}
+
+
 def golden():
     g = json.loads((ROOT / "tests" / "golden" / WORKLOAD.get("golden_file", "raft_levels.json")).read_text())
     return next(c for c in g["cases"] if c["name"] == WORKLOAD["golden"])
@@ -419,6 +429,12 @@ def main():
                         "restarts": stats.get("restarts", 0), "measured_levels": stats.get("measured_levels", 0),
                         "note": "packed / measured: the buckets of a stay round are moved whole (sent bytes include their unused tails); "
                                 "exact: all_to_all_v moves what the counts say"}
+        try:   # (never worth the line: a failure here leaves the object out)
+            line["roofline"] = dist_roofline(amd.state_bytes(WORKLOAD["spec"], WORKLOAD["params"]), D, G, world, step_s)
+        except Exception as e:  # noqa: BLE001
+            line["roofline"] = None
+            line["config"]["roofline_error"] = str(e)
+        line["cpu_baseline"] = None   # (timed beside the one-GPU line only: rank 0 at N = 1)
         if a.share_gpu:
             line["config"]["NOT_A_MEASUREMENT"] = "all ranks share ONE GPU through a librccl stand-in ($TLAMC_RCCL): a functional run of the N-rank path, not a scaling number"
         eng.close()
