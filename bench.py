@@ -412,9 +412,11 @@ def main():
     }
     if use_dist:
         step_s = dt / a.steps
+        how = {"exact": "host-paced rounds with exact sizes: all_to_all_v of 8 bytes per routed candidate out and 1 byte back, the next round's expand in flight meanwhile",
+               "measured": "pipelined fixed-capacity rounds, buckets sized from the previous level's measured fill: the exchange of round r+1 overlaps the probes of round r and the next expand",
+               "packed": "pipelined fixed-capacity rounds, buckets sized from the fan-out allowance: the exchange of round r+1 overlaps the probes of round r and the next expand"}[a.exchange]
         line["config"]["parallelism"] = (f"fingerprint-sharded seen-set x{world} (owner = fingerprint high bits), replicated prefix for the small "
-                                         f"levels, two-phase fingerprint-first all-to-all over RCCL (mc_shard_run: level loop in C++, exchange of "
-                                         f"round r+1 overlapped with the probes of round r and the next expand)")
+                                         f"levels, two-phase fingerprint-first exchange over RCCL (mc_shard_run: level loop in C++; large levels: {how})")
         line["config"]["shares"] = shares
         line["config"]["levels"] = {k: stats.get(k) for k in ("replicated_levels", "stay_levels", "move_levels", "rounds")}
         line["config"]["frontier_imbalance"] = stats.get("max_frontier", 0) / max(1, stats.get("mean_frontier", 1))
