@@ -265,6 +265,36 @@ def test_random_model_world_and_exchange_settings(oracle, shim, tmp_path, seed):
     assert sum(r["shares"]) == o["distinct"] and len(r["shares"]) == world
 
 
+def _random_large_rounds(seed):
+    import random
+    from test_lowering_sweep import raft_config, ssi_config
+    r = random.Random(9000 + seed)
+    spec = r.choice(["raft", "raft", "ssi"])
+    params = raft_config(r.randrange(40)) if spec == "raft" else ssi_config(r.randrange(24))
+    world = r.choice([2, 3, 4, 5])
+    opts = {"max_distinct": 150000, "chunk": r.choice([2000, 5000, 20000]), "stay_threshold": r.choice([1024, 1500, 4000]), "rebalance_ratio": r.choice([1.3, 2.0]),
+            "replicate_until": r.choice([0, 300]), "exchange": r.choice(["measured", "measured", "packed", "exact"]), "cap_safety_pct": r.choice([60, 100, 140, 200]),
+            "packed_fanout": r.choice([4, 16, 16])}
+    return spec, params, world, opts
+
+
+# (seeds 4, 5, 14, 16, 26 of the first 36 restart: a measured bucket too small at 60 / 100 / 140 %, an allowance of 4 successors per state)
+@pytest.mark.parametrize("seed", [4, 5, 14, 16, 23, 26] + list(range(36, 36 + int(__import__("os").environ.get("TLAMC_SWEEP", "0")))))
+def test_random_models_with_rounds_large_enough_to_measure(oracle, shim, tmp_path, seed):
+    """like the sweep above with rounds of 2 000 - 20 000 states (the fill of a bucket is only measured on rounds of >= 1 024), 150 000
+    states, the three forms of the stay levels, safety margins from 60 % (the measured buckets overflow: restart) to 200 %, fan-out
+    allowances of 4 and 16: whatever restarts that takes, the oracle's counters and per-level counts"""
+    spec, params, world, opts = _random_large_rounds(seed)
+    oparams = oracle.raft_oracle_params(params) if spec == "raft" else params
+    o = oracle.oracle_run(spec, oparams, max_distinct=opts["max_distinct"])
+    r = run_dist("shim", world, spec, params, tmp_path, opts, timeout=1200)
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == \
+           (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"]), (spec, params, world, opts)
+    assert sum(r["shares"]) == o["distinct"] and len(r["shares"]) == world
+    if seed in (4, 5, 14, 16, 26):
+        assert r["stats"]["restarts"] >= 1, r["stats"]
+
+
 def test_a_full_exchange_bucket_restarts_the_search(oracle, shim, tmp_path):
     """more in-model successors per state than `packed_fanout` allows for (found by the sweep above: seed 38 of 70) is MC_EROUTE on
     every rank — nothing truncated, nobody left in a collective — and mc_shard_run* starts over with twice the allowance: the run
