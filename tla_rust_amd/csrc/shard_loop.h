@@ -9,7 +9,8 @@
 // torch.distributed that the tests drove); they are one now: every multi-rank test, `mc X.tla -gpus P`, `bench.py --gpus N`
 // and the torch front door run the code below.
 //
-// Per level ONE host synchronisation: the all-gather of {frontier size, verdict, status} of every rank.  A rank-local failure
+// Per level ONE collective for the job's state: the all-gather of {frontier size, verdict, status} of every rank (host-paced rounds
+// add two host waits each: the round's route cursors and the all-gather of its bucket counts).  A rank-local failure
 // is sticky and collective: the failing rank keeps taking part in the level's collectives with empty buckets, its status travels
 // with the all-gather, and all ranks leave together (nobody is left waiting in a collective).
 //
