@@ -91,6 +91,8 @@ typedef struct {
                                 the expand wavefront that found it (round 4; by-family kernels of a fused run) */
 #define MC_F_WAVETAIL 131072u /* A/B only: in-wave writes by wavefront (no workgroup barrier) instead of by workgroup */
 #define MC_F_NOFILTER 8192u  /* A/B only: by-family expand kernel without the per-wavefront duplicate filter in front of the seen-set */
+#define MC_F_SYNCPROBE 4096u /* A/B only: the by-family expand kernel waits for every seen-set probe where it issues it (rounds 1-4) instead of
+                              * resolving a batch of probes one batch later (round 5: split-phase probes, engine.hip MC_ASYNC_PROBE) */
 #define MC_F_PROGRESS 16384u /* mc_check_files: print TLC's "Progress(d): ..." lines (testout2:4-259) to stdout while the search runs,
                               * at most one per second */
 #define MC_F_NOBATCH 256u /* A/B only: one host round trip per BFS level even while the frontier is small         */
@@ -370,7 +372,10 @@ typedef struct {
  * file dlopen()ed instead of /opt/rocm/lib/librccl.so (tests/_fakerccl: the nine nccl* entry points over POSIX shared memory, so
  * that P ranks can share ONE device — RCCL itself refuses two ranks on a device); `mc X.tla -gpus P -samedevice` and
  * `bench.py --gpus N --share-gpu` put every rank on device 0 for it.  None of them belongs in a deployment: without TLAMC_RCCL
- * the real RCCL is loaded, and a run through the stand-in says so in its report / bench line ("NOT_A_MEASUREMENT"). */
+ * the real RCCL is loaded, and a run through the stand-in says so in its report / bench line ("NOT_A_MEASUREMENT").
+ * TLAMC_TEST_FAIL_AT = "rank:level:code[,rank:level:code...]" makes that rank of mc_shard_run* fail that BFS level with that status,
+ * once per process (tests/test_sharded_gloo.py: two DIFFERENT failures in one level must end every rank with ONE agreed code —
+ * MC_EROUTE, i.e. a restart, only if every failing rank reports MC_EROUTE). */
 int mc_comm_unique_id(uint8_t id_out[MC_COMM_ID_BYTES]);
 int mc_comm_create(const uint8_t id[MC_COMM_ID_BYTES], uint32_t rank, uint32_t world, int32_t device, mc_comm **out);
 void mc_comm_destroy(mc_comm *c);

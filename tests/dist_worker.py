@@ -46,6 +46,20 @@ def main():
             return ShardedChecker(spec, params, engine=ShimShard(spec, params, rank, world), **common)
         return ShardedChecker(spec, params, device=0, table_capacity=opts.get("table", 1 << 22), arena_capacity=opts.get("arena", 1 << 20),
                               trace=opts.get("trace", False), **common)
+    if opts.get("expect_error"):   # every rank writes what ITS call returned: the ranks must agree (tests of the failure paths)
+        import tla_rust_amd as amd
+        try:
+            r = chk.run()
+            res = {"code": 0, "restarts": chk.stats.get("restarts", 0),
+                   "distinct": r.distinct, "generated": r.generated, "levels": list(r.levels)}
+        except (amd.McError, RuntimeError) as e:   # (the host build's engine raises a plain RuntimeError: "... failed: <rc> <text>")
+            import re
+            m = re.search(r"failed: (-?\d+)", str(e))
+            res = {"code": getattr(e, "code", None) if getattr(e, "code", None) is not None else int(m.group(1)), "msg": str(e)}
+        Path(f"{out}.rank{rank}").write_text(json.dumps(res))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     r = chk.run()
     first = None
     if opts.get("checkpoint"):  # stop on the budget, write one file per rank, continue in FRESH engines (TLC -recover)

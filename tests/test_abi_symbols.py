@@ -45,12 +45,12 @@ def test_product_does_not_reference_the_oracle():
             assert "oracle/" not in p.read_text().replace("oracle/spec_raft.c:raft_print", ""), p
 
 
-def test_the_pending_list_condition_keeps_its_wording():
-    """tla_rust_amd/csrc/shard_rccl.cpp (AbiOps::expand_finish) recognises the engine's "a round with more candidates than the slot's pending
-    list holds" by its message and hands it to the level loop as MC_EROUTE (restart with twice the fan-out allowance) instead of
-    MC_EARENA: the two places must keep saying the same words"""
+def test_route_overflows_are_error_codes_not_words():
+    """A round with more candidates than a route bucket / the slot's pending list holds is MC_EROUTE from the engine itself (the level
+    loop restarts with twice the allowance); nothing above the C ABI looks at the words of an error message"""
     root = Path(__file__).resolve().parent.parent / "tla_rust_amd" / "csrc"
-    engine, ops = (root / "engine.hip").read_text(), (root / "shard_rccl.cpp").read_text()
-    assert engine.count("pending list holds") == 1 and 'strstr(mc_last_error(), "pending list")' in ops
-    msg = engine[engine.index("pending list holds") - 120:engine.index("pending list holds") + 80]
-    assert "return MC_EARENA" in msg and "shard_expand" in msg
+    engine, ops, loop = ((root / f).read_text() for f in ("engine.hip", "shard_rccl.cpp", "shard_loop.h"))
+    assert "strstr(" not in ops and "strstr(" not in loop and "mc_last_error()" not in loop
+    at = engine.index("slot's pending list holds")
+    assert "return MC_EROUTE" in engine[at:at + 120]
+    assert engine.count("err |= DEV_EROUTE;") == 2   # the route sub-buckets of both expand kernels

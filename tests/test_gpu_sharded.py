@@ -98,6 +98,21 @@ def test_a_full_exchange_bucket_restarts_the_search_on_gpu(oracle, tmp_path):
     assert r["stats"]["restarts"] >= 1
 
 
+@pytest.mark.parametrize("exchange", ["packed", "exact"])
+def test_a_full_route_sub_bucket_restarts_the_search_at_a_production_chunk_size(oracle, tmp_path, exchange):
+    """with rounds of 2^17 states the +4096 slack of a route sub-bucket no longer hides an allowance that is too
+    small — the expand kernel itself finds its sub-bucket full (DEV_EROUTE, not DEV_EARENA: `check_dev_error` runs before the host's own
+    count test) and every rank restarts with twice the allowance instead of reporting a full arena.  Levels of > 100 000 states of the
+    3-server model, one in-model successor per state allowed where four are generated."""
+    params = [3, 4, 2, 3, 1, 1, 16, 2, 8]
+    o = oracle.oracle_run("raft", params, max_distinct=1500000)
+    r = run_dist("hip", 2, "raft", params, tmp_path, {"max_distinct": 1500000, "chunk": 1 << 17, "table": 1 << 24, "arena": 1 << 22,
+                                                       "stay_threshold": 200, "rebalance_ratio": 1.5, "packed_fanout": 1, "move_fanout": 1,
+                                                       "exchange": exchange})
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert r["stats"]["restarts"] >= 1
+
+
 @pytest.mark.parametrize("world,replicate_until", [(2, 0), (3, 0), (3, 40)])
 def test_counterexample_walked_back_across_ranks(oracle, tmp_path, world, replicate_until):
     """README.md:267-321 on several ranks with MC_F_TRACE engines: the parents of states that moved to their owner travelled

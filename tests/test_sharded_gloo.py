@@ -400,3 +400,34 @@ def test_checkpoint_at_a_random_level_of_a_random_run(oracle, shim, tmp_path, se
     assert (got["first"]["verdict"], got["first"]["distinct"], got["first"]["levels"]) == ("budget", cut["distinct"], cut["levels"]), (spec, params, world, opts)
     assert (got["distinct"], got["generated"], got["depth"], got["levels"], got["verdict"]) == (o["distinct"], o["generated"], o["depth"], o["levels"], o["verdict"]), (spec, params, world, opts)
     assert sum(got["shares"]) == o["distinct"]
+
+
+def _run_expect(world, spec, params, tmp_path, opts, fail_at):
+    """every rank's own return code of mc_shard_run_transport with $TLAMC_TEST_FAIL_AT set (include/tlamc.h, test-only hooks)"""
+    import os
+    out = tmp_path / "out.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={world}",
+           str(ROOT / "tests" / "dist_worker.py"), "shim", spec, json.dumps(params), str(out), json.dumps(dict(opts, expect_error=True))]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, TLAMC_TEST_FAIL_AT=fail_at))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]   # (a hang in a collective would be the timeout above)
+    return [json.loads((tmp_path / f"out.json.rank{r}").read_text()) for r in range(world)]
+
+
+def test_ranks_failing_differently_in_one_level_agree_on_one_code(oracle, shim, tmp_path):
+    """rank 0 fails level 4 with MC_EROUTE (-10: restart with twice the allowance), rank 1 fails the SAME level
+    with MC_EARENA (-5).  Every rank must leave the loop with the same code — the one that is not a restart — instead of one rank
+    restarting into collectives the other never enters (a hang).  Three ranks: the third did not fail at all and still agrees."""
+    for world, fail_at in ((2, "0:4:-10,1:4:-5"), (3, "2:4:-10,1:4:-4")):
+        res = _run_expect(world, "raft", [2, 2, 2, 9, 1, 1], tmp_path, {"chunk": 700, "stay_threshold": 50}, fail_at)
+        want = -5 if world == 2 else -4
+        assert [r["code"] for r in res] == [want] * world, res
+
+
+def test_a_route_failure_on_one_rank_restarts_every_rank(oracle, shim, tmp_path):
+    """... and when the only failure of the level is MC_EROUTE — on ONE rank — every rank starts over (restarts = 1 on each) and the
+    search ends with the oracle's counters"""
+    params = [2, 2, 2, 9, 1, 1]
+    o = oracle.oracle_run("raft", params)
+    res = _run_expect(2, "raft", params, tmp_path, {"chunk": 700, "stay_threshold": 50}, "1:4:-10")
+    assert [r["code"] for r in res] == [0, 0] and [r["restarts"] for r in res] == [1, 1], res
+    assert all((r["distinct"], r["generated"], r["levels"]) == (o["distinct"], o["generated"], o["levels"]) for r in res), res

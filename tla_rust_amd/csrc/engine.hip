@@ -240,15 +240,27 @@ k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__
 // this device whether they are 32- or 64-byte requests (atomic_add N = 28, 3.76 G probes into an 8 GB table: 94 ms with 32-byte,
 // 197 ms with 64-byte probes) — and at load <= 1/3 a 4-slot bucket almost always decides in one request.  The engine picks
 // the mode when it allocates the table (seen_arg()); bit 63 of the bucket count the kernels receive says which.
+// MC_NT_PROBE (A/B): a probe reads its bucket past the L2 (`nt`: a random line of a 20 GB table is never read twice while cached,
+// but it evicts a line of the parent rows the in-wave writer comes back for).  Bit 0: the synchronous prober, bit 1: the LDS-DMA.
+#ifndef MC_NT_PROBE
+#define MC_NT_PROBE 0
+#endif
+typedef unsigned long long mc_ull2 __attribute__((ext_vector_type(2)));
 template <int SLOTS>
 __device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
     uint64_t bk = ((fp & 0xffffffffull) * nbuckets) >> 32;
     for (int probe = 0; probe < 2048; ++probe) {
         const uint64_t b = bk * SLOTS;
-        const ulonglong2 *line = reinterpret_cast<const ulonglong2 *>(table + b);
         unsigned long long slot[SLOTS];
+#if MC_NT_PROBE & 1
+        const mc_ull2 *line = reinterpret_cast<const mc_ull2 *>(table + b);
+#pragma unroll
+        for (int i = 0; i < SLOTS / 2; ++i) { const mc_ull2 v = __builtin_nontemporal_load(line + i); slot[2 * i] = v.x; slot[2 * i + 1] = v.y; }
+#else
+        const ulonglong2 *line = reinterpret_cast<const ulonglong2 *>(table + b);
 #pragma unroll
         for (int i = 0; i < SLOTS / 2; ++i) { const ulonglong2 v = line[i]; slot[2 * i] = v.x; slot[2 * i + 1] = v.y; }
+#endif
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             unsigned long long cur = slot[i];
@@ -269,6 +281,15 @@ constexpr uint64_t SEEN_SPARSE = 1ull << 63;
 __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
     if (nbuckets & SEEN_SPARSE) return seen_insert_t<MC_SPARSE_SLOTS>(table, nbuckets & ~SEEN_SPARSE, fp, err);
     return seen_insert_t<8>(table, nbuckets, fp, err);
+}
+
+// The synchronous prober as a REAL function: the rare ways out of the split-phase probes of k_expand_family (a candidate whose
+// home bucket is full, a compare-and-swap lost to another fingerprint) call it instead of carrying inlined copies of the loop.
+// bit 0: the fingerprint is new (inserted here); bit 1: the table is full
+__device__ __noinline__ unsigned seen_insert_slow(uint64_t *table, uint64_t nbuckets, uint64_t fp) {
+    unsigned e = 0;
+    const bool nw = seen_insert(table, nbuckets, fp, e);
+    return (nw ? 1u : 0u) | (e ? 2u : 0u);
 }
 
 // checkpoint recovery: the seen-set is not part of a checkpoint — it is rebuilt from word 0 (the fingerprint) of the
@@ -534,7 +555,7 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                     rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
                     rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = src;
                 } else {
-                    err |= DEV_EARENA;
+                    err |= DEV_EROUTE;  // a full route sub-bucket is "more candidates than the allowance" (restart), not a full arena
                 }
             }
         } else {
@@ -721,6 +742,28 @@ struct SlotClasses<S, decltype((void)S::NCLS)> : std::integral_constant<int, S::
 // survivors wait here until the wavefront's tail (one per parent on average; 64 are moved to the global new-list — the
 // overflow path, k_materialise — only when the list is about to fill up).
 constexpr int OCAP = 256;
+// SPLIT-PHASE PROBES (round 5; MC_ASYNC_PROBE: 0 = off, 1 = loads, 2 = loads + compare-and-swaps).  A seen-set probe is two dependent
+// trips to HBM — read the bucket, then compare-and-swap the fingerprint into its first empty slot — and until round 4 a wavefront
+// sat through both with nothing else to do (flush_probe: 6 of the ~10 HBM-class waits of a wavefront's life).  Now the 64 queued
+// candidates of a batch ISSUE their read as an LDS-DMA (global_load_lds_dwordx4: 16 bytes = the first two slots of the 32-byte
+// bucket per lane, no VGPRs held while it flies) and the wavefront goes on generating; when the next 64 candidates are queued the
+// batch is RESOLVED from LDS — match: dropped; an empty slot: compare-and-swap; both slots taken by others: the candidate stays at
+// the head of the ring with its displacement bumped and reads the next 16 bytes with the next batch (the probe sequence and the
+// "first empty slot" rule are the synchronous prober's: the table format does not change).  With MC_ASYNC_PROBE = 2 the
+// compare-and-swap is not waited for either: the candidate goes to the survivor list as TENTATIVE, the returned word stays in two
+// VGPRs, and the next resolve step confirms it (0: new; its own fingerprint: somebody else inserted it first — the entry becomes a
+// tombstone, O_DEAD; anything else: the synchronous prober decides).  Only sparse tables (32-byte buckets) of fused runs.
+#ifndef MC_ASYNC_PROBE
+#define MC_ASYNC_PROBE 0
+#endif
+#ifndef MC_FOLD_MSG
+#define MC_FOLD_MSG 0   // (one loop over the message slots instead of two: 14 KB less code, but 14 spilled VGPRs)
+#endif
+#ifndef MC_FOLD_FIX
+#define MC_FOLD_FIX 0   // (the drain of the family queues as the last step of the fixed-slot loop: 14 KB less code, no spills — and
+#endif                  //  147.3 -> 153.6 ms per step on the t3 graph, profiles/r05b_ab.jsonl: not adopted)
+constexpr unsigned O_DEAD = 0xffffu;    // survivor-list tombstone: a tentative survivor that turned out to be known
+constexpr unsigned Q_DSP_SHIFT = 14;    // probe-ring entries: bits [14, 16) = 16-byte steps already taken past the home bucket's first half
 struct FamQueues {
     uint64_t q_fp[QCAP];
     uint64_t o_fp[OCAP];
@@ -732,7 +775,8 @@ struct FamLds {
     uint16_t fq[S::NFAM][FQCAP];   // (slot << 8) | (block << 6) | parent lane
     typename S::Summary sum[NB * 64];
     uint64_t filt[WFILT];
-    unsigned has_succ[NB * 2];     // bit per parent: some successor was generated (deadlock check)
+    // (deadlock check: "this parent has a successor" is a register of the parent's own lane for everything that lane evaluates,
+    //  and bit 31 of a word of its Summary — S::succ_word — for the pairs another lane evaluates in a family batch)
 };
 
 template <class S, int F, class Fn>
@@ -751,14 +795,21 @@ __device__ __forceinline__ void family_dispatch(int fam, Fn &&fn) {
 #ifndef MC_EXPAND_MINW
 #define MC_EXPAND_MINW 4
 #endif
-template <class S, bool ROUTE, int NB, int MINW = MC_EXPAND_MINW>
-__global__ void __launch_bounds__(256, MINW)
+// WAVES = wavefronts per workgroup.  The workgroup only matters to the in-wave tail (its wavefronts pool their survivors behind a
+// barrier): 4 = the widest pool (a batch of 64 sorted survivors holds one or two action classes) but four wavefronts wait for the
+// slowest; 2 = a tail per PAIR of wavefronts.
+#ifndef MC_EXPAND_WAVES
+#define MC_EXPAND_WAVES 4
+#endif
+template <class S, bool ROUTE, int NB, int MINW = MC_EXPAND_MINW, int WAVES = MC_EXPAND_WAVES>
+__global__ void __launch_bounds__(64 * WAVES, MINW)
 k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
                 RouteArgs rt, unsigned parity) {
     static_assert(NB >= 1 && NB <= 4, "the queue entry has two bits for the block");
-    __shared__ FamQueues wq[4];
-    __shared__ FamLds<S, NB> fls[4];
+    static_assert(WAVES == 1 || WAVES == 2 || WAVES == 4, "wavefronts per workgroup");
+    __shared__ FamQueues wq[WAVES];
+    __shared__ FamLds<S, NB> fls[WAVES];
     if (rt.lc) {
         if (rt.lc->stop) return;
         lo = rt.lc->lo;
@@ -774,7 +825,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     //  graphs: 168.8 against 166.4 ms and 35.0 against 34.6 ms per step, i.e. nothing: the probes that repeat within a
     //  neighbourhood are already caught by the wavefront's own filter, the rest miss every L2.)
     // this wavefront's first column: NB consecutive arena blocks
-    const uint64_t wave_col0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64ull * NB);
+    const uint64_t wave_col0 = ((uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * (64ull * NB);
     const bool inwave = !ROUTE && rt.arena_w != nullptr;  // wave-uniform (a kernel argument)
     if (wave_col0 >= ncols && !inwave) return;  // (in-wave writes: the workgroup's tail has barriers — a wavefront without parents walks through the empty loops below)
     const uint64_t wave_idx0 = base + wave_col0;
@@ -787,6 +838,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
 #pragma unroll
     for (int t = 0; t < WFILT / 64; ++t) FL.filt[t * 64 + lane] = 0;  // fingerprint 0 is never a candidate
     bool track_succ = (flags & MC_F_DEADLOCK) != 0;  // cleared once the dense slots gave every parent of the block a successor
+    bool lane_succ = false;                          // this lane's parent has a successor (NB == 1: one parent per lane)
     // ring state of the family queues, wave-uniform, packed 8 bits per family so that a run-time family index is a
     // scalar shift (no LDS round trip): heads and counts of families 0..7 in *A, 8.. in *B
     uint64_t fheadA = 0, fheadB = 0, fcntA = 0, fcntB = 0;
@@ -800,23 +852,40 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     // survivors kept in LDS before a batch of 64 goes to the global new-list: all the list holds minus one probe batch (in-wave
     // writes: the global list is the overflow path), or one batch (everything goes through the new-list)
     const unsigned okeep = inwave ? (unsigned)(OCAP - 64) : 63u;
+    // split-phase probes (MC_ASYNC_PROBE above): wave-uniform state
+    constexpr bool ASYNC_BUILD = !ROUTE && MC_ASYNC_PROBE > 0 && MC_SPARSE_SLOTS == 4;
+    constexpr bool ASYNC_CAS = ASYNC_BUILD && MC_ASYNC_PROBE > 1;
+    __shared__ __attribute__((aligned(16))) uint64_t probe_land[WAVES][ASYNC_BUILD ? 128 : 2];  // 16 bytes per lane: where the DMA lands
+    constexpr bool async_probe = ASYNC_BUILD;
+    const bool async_cas = ASYNC_CAS && inwave;  // (a tentative survivor must not reach the global new-list)
+    const unsigned hshift = (mask & SEEN_SPARSE) ? 1u : 2u;        // 16-byte halves per bucket: 2 (32-byte buckets) or 4 (64-byte)
+    const uint64_t nhalves = (mask & ~SEEN_SPARSE) << hshift;
+    const bool probe_at_once = (flags & MC_F_SYNCPROBE) != 0;      // A/B: resolve a batch at the next candidate instead of a batch later
+    unsigned pend = 0;               // the first `pend` entries of the probe ring have their 16 bytes on the way to LDS
+    unsigned long long casmask = 0;  // lanes whose compare-and-swap is in flight; lane's tentative survivor: list position cas_obase + rank
+    unsigned cas_obase = 0;
+    unsigned long long casret = 0;   // what that compare-and-swap returns (per lane; waited for at its first use, one resolve step later)
+    uint64_t *const land = probe_land[threadIdx.x >> 6];
     MC_PROF_DECL
 
-    auto flush_out = [&](unsigned take) {
+    auto flush_out = [&](unsigned take) __attribute__((always_inline)) {
         MC_PROF(4);
+        // (the `take` oldest entries: all confirmed — tentative ones are the newest — but some may be tombstones)
+        const unsigned e = lane < take ? Q.o_ent[(ohead + lane) & (OCAP - 1)] : O_DEAD;
+        const unsigned long long bl = __ballot(e != O_DEAD);
         unsigned long long pos = 0;
-        if (lane == 0) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)take);
-        pos = __shfl(pos, 0);
-        if (lane < take) {
-            const unsigned e = Q.o_ent[(ohead + lane) & (OCAP - 1)];
-            seg[pos + lane] = (uint32_t)(wave_col0 + (e & 63u)) | ((uint32_t)(e >> 6) << 24);
-            if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos + lane] = Q.o_fp[(ohead + lane) & (OCAP - 1)];
+        if (lane == 0 && bl) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)__popcll(bl));
+        pos = __shfl(pos, 0) + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
+        if (e != O_DEAD) {
+            seg[pos] = (uint32_t)(wave_col0 + (e & 63u)) | ((uint32_t)(e >> 6) << 24);
+            if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos] = Q.o_fp[(ohead + lane) & (OCAP - 1)];
         }
         ohead = (ohead + take) & (OCAP - 1);
         on -= take;
         MC_PROF(3);
     };
-    auto flush_probe = [&](unsigned take) {
+    auto flush_probe = [&](unsigned take) __attribute__((always_inline)) {
+      if constexpr (!ASYNC_BUILD) {
         MC_PROF(3);
         bool is_new = false;
         unsigned src = 0;  // (slot << 6) | parent lane
@@ -868,7 +937,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                     rt.rt_fp[(uint64_t)bucket * rt.subcap + pos] = qfp;
                     rt.rt_src[(uint64_t)bucket * rt.subcap + pos] = (uint32_t)(wave_col0 + (src & 63u)) | ((uint32_t)(src >> 6) << 24);
                 } else {
-                    err |= DEV_EARENA;
+                    err |= DEV_EROUTE;  // a full route sub-bucket is "more candidates than the allowance" (restart), not a full arena
                 }
             }
         } else {
@@ -883,9 +952,129 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             if (on > okeep) flush_out(64);
         }
         MC_PROF(2);
+      }
+    };
+    // ---- split-phase probes: issue / resolve (MC_ASYNC_PROBE above)
+    auto half_of_entry = [&](uint64_t fp, unsigned ent) __attribute__((always_inline)) -> uint64_t {  // the 16-byte half this ring entry looks at next
+        uint64_t h = ((((fp & 0xffffffffull) * (mask & ~SEEN_SPARSE)) >> 32) << hshift) + (ent >> Q_DSP_SHIFT);
+        if (h >= nhalves) h -= nhalves;
+        return h;
+    };
+    auto slow_insert = [&](uint64_t fp) __attribute__((always_inline)) -> bool {
+        const unsigned r = seen_insert_slow(table, mask, fp);
+        if (r & 2u) err |= DEV_ETABLE;
+        return (r & 1u) != 0;
+    };
+    auto probe_issue = [&](unsigned take) __attribute__((always_inline)) {
+        if constexpr (ASYNC_BUILD) {
+            MC_PROF(3);
+            if (lane < take) {
+                const unsigned k = (qhead + lane) & (QCAP - 1);
+                const uint64_t h = half_of_entry(Q.q_fp[k], Q.q_ent[k]);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(table + h * 2),
+                                                 (__attribute__((address_space(3))) void *)land, 16, 0, (MC_NT_PROBE & 2) ? 2 : 0);
+            }
+            pend = take;
+            MC_PROF(2);
+        }
+    };
+    // resolve the batch whose reads were issued a flush ago; at most `room` candidates that must look at the next 16 bytes stay in
+    // the ring (at its head, in front of the fresh ones), the others fall back to the synchronous prober.  First, the tentative
+    // survivors of the PREVIOUS resolve step are confirmed: 0 came back = new; the fingerprint itself = somebody else inserted it
+    // in between (tombstone); another fingerprint took the slot = the synchronous prober decides.
+    auto probe_resolve = [&](unsigned room) __attribute__((always_inline)) {
+        if constexpr (ASYNC_BUILD) {
+            MC_PROF(3);
+            if constexpr (ASYNC_CAS) {
+                if (casmask) {
+                    if ((casmask >> lane & 1ull) && casret != 0ull) {
+                        const unsigned pos = (cas_obase + (unsigned)__popcll(casmask & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                        const uint64_t f = Q.o_fp[pos];
+                        bool nw = false;
+                        if (casret != f) nw = slow_insert(f);
+                        if (!nw) Q.o_ent[pos] = (uint16_t)O_DEAD;
+                    }
+                    casmask = 0;
+                    wave_lds_fence();
+                }
+            }
+            bool is_new = false, again = false, cas = false, slow = false;
+            uint64_t fp = 0, half = 0;
+            unsigned ent = 0, which = 0;
+            // the DMA is NOT tracked by the compiler's wait-count insertion (the landing area is read by ordinary LDS loads): wait
+            // for it here — and keep memory accesses from moving across the wait
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane < pend) {
+                const unsigned k = (qhead + lane) & (QCAP - 1);
+                ent = Q.q_ent[k];
+                fp = Q.q_fp[k];
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(land + lane * 2);
+                if (v.x != fp && v.y != fp && !(flags & 16u)) {  // (16 = ablation: no probes)
+                    if (v.x == 0ull || v.y == 0ull) { cas = true; which = v.x != 0ull ? 1u : 0u; half = half_of_entry(fp, ent); }
+                    else if ((ent >> Q_DSP_SHIFT) < 3u) again = true;
+                    else slow = true;
+                }
+            }
+            const unsigned long long ba = __ballot(again);
+            unsigned r = (unsigned)__popcll(ba);
+            const unsigned arank = (unsigned)__popcll(ba & ((1ull << lane) - 1ull));
+            if (r > room) {  // (rare: the ring has no room for all of them)
+                if (again && arank >= room) { again = false; slow = true; }
+                r = room;
+            }
+            if (again) {
+                const unsigned k2 = (qhead + pend - r + arank) & (QCAP - 1);
+                Q.q_fp[k2] = fp;
+                Q.q_ent[k2] = (uint16_t)(ent + (1u << Q_DSP_SHIFT));
+            }
+            qhead = (qhead + pend - r) & (QCAP - 1);
+            qn -= pend - r;
+            probes += pend;
+            pend = 0;
+            unsigned long long cur = 0;
+            if (cas) cur = atomicCAS((unsigned long long *)(table + half * 2 + which), 0ull, (unsigned long long)fp);
+            if (!async_cas) {
+                // (the empty asm keeps the compiler from evaluating `cur` speculatively outside this branch — it did, as a select —
+                //  which would wait for the compare-and-swap right where it was issued)
+                asm volatile("" : "+v"(cur));
+                if (cas) {
+                    if (cur == 0ull) is_new = true;
+                    else if (cur != fp) slow = true;
+                }
+            }
+            if (slow) is_new = slow_insert(fp);
+            {
+                const unsigned long long bn = __ballot(is_new);
+                if (bn) {
+                    if (is_new) {
+                        const unsigned k = (ohead + on + (unsigned)__popcll(bn & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                        Q.o_ent[k] = (uint16_t)(ent & ((1u << Q_DSP_SHIFT) - 1u));
+                        Q.o_fp[k] = fp;
+                    }
+                    on += (unsigned)__popcll(bn);
+                }
+            }
+            if constexpr (ASYNC_CAS) {
+                if (async_cas) {  // tentative survivors: the newest entries of the list, confirmed by the next resolve step
+                    const unsigned long long bc = __ballot(cas);
+                    if (cas) {
+                        const unsigned k = (ohead + on + (unsigned)__popcll(bc & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                        Q.o_ent[k] = (uint16_t)(ent & ((1u << Q_DSP_SHIFT) - 1u));
+                        Q.o_fp[k] = fp;
+                        casret = cur;
+                    }
+                    casmask = bc;
+                    cas_obase = (ohead + on) & (OCAP - 1);
+                    on += (unsigned)__popcll(bc);
+                }
+            }
+            wave_lds_fence();
+            if (on > okeep) flush_out(64);
+            MC_PROF(2);
+        }
     };
     // append the lanes of `b` (each with its slot) to family f's queue; returns true when it holds >= 64 pairs
-    auto fam_push = [&](int f, unsigned long long b, bool mine, unsigned entry) -> bool {
+    auto fam_push = [&](int f, unsigned long long b, bool mine, unsigned entry) __attribute__((always_inline)) -> bool {
         const unsigned h = fget(fheadA, fheadB, f), c = fget(fcntA, fcntB, f);
         if (mine) FL.fq[f][(h + c + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (FQCAP - 1)] = (uint16_t)entry;
         const unsigned nc = c + (unsigned)__popcll(b);
@@ -893,7 +1082,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         return nc >= 64;
     };
     // a lane's candidate (fp != 0) joins the probe ring; 64 queued candidates are probed (or routed) at once
-    auto enqueue = [&](uint64_t fp, unsigned src /* (slot << 6) | parent lane */, int back_to) {
+    auto enqueue = [&](uint64_t fp, unsigned src /* (slot << 6) | parent lane */, int back_to) __attribute__((always_inline)) {
         MC_PROF(2);
         const unsigned long long b0 = __ballot(fp != 0);
         if (b0) {
@@ -907,20 +1096,26 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             //  later hits L2 — 40.9 ms per step against 38.5 without, profiles/r03g: the extra request per candidate costs more
             //  than the latency it hides)
             const unsigned long long b = __ballot(fp != 0);
+            const unsigned nb = (unsigned)__popcll(b);
+            // split-phase: the ring holds the batch in flight (`pend` entries) and the fresh candidates behind it; as soon as the
+            // fresh ones make a batch, the batch in flight is resolved (its reads were issued ~64 candidates ago) and the next one issued
+            if (async_probe && pend && (qn - pend + nb >= 64 || probe_at_once)) probe_resolve((unsigned)QCAP - (qn - pend) - nb);
             if (fp) {
                 const unsigned k = (qhead + qn + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (QCAP - 1);
                 Q.q_fp[k] = fp;
                 Q.q_ent[k] = (uint16_t)src;
             }
-            qn += (unsigned)__popcll(b);
+            qn += nb;
             wave_lds_fence();
-            if (qn >= 64) flush_probe(64);
+            if (async_probe) {
+                if (!pend && qn >= 64) probe_issue(64);
+            } else if (qn >= 64) flush_probe(64);
         }
         MC_PROF(back_to);
         (void)back_to;
     };
     // phase B: evaluate `take` queued pairs of family f (f is wave-uniform)
-    auto run_family = [&](int f, unsigned take, int back_to) {
+    auto run_family = [&](int f, unsigned take, int back_to) __attribute__((always_inline)) {
         MC_PROF(8 + f);
         MC_PROF_PAIRS(f, take);
         const unsigned h = fget(fheadA, fheadB, f);
@@ -939,7 +1134,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             family_dispatch<S, 0>(f, [&](auto fc) { st = S::template eval_pair<decltype(fc)::value>(prm, q, sp, slot, fv); });
             if (st & ST_ENABLED) {
                 ++gen;
-                if (track_succ) atomicOr(&FL.has_succ[p >> 5], 1u << (p & 31u));
+                if (track_succ) atomicOr(S::succ_word(FL.sum[p]), 0x80000000u);
                 if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
                 else if (st & ST_ASSERT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_ASSERT, 0));
                 else if (st & ST_SPECERR) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_SPECERR, 0));
@@ -954,7 +1149,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         enqueue(fp, src, back_to);
         wave_lds_fence();
     };
-    auto run_full = [&](unsigned fullmask, bool drain, int back_to) {
+    auto run_full = [&](unsigned fullmask, bool drain, int back_to) __attribute__((always_inline)) {
         while (fullmask) {
             const int f = __ffs((int)fullmask) - 1;
             const unsigned c = fget(fcntA, fcntB, f);
@@ -984,7 +1179,6 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             const unsigned ps = S::parent_status(prm, loc, g);
             if (ps & ST_INVARIANT) viol = min(viol, viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8));
         }
-        if (lane < 2) FL.has_succ[blk * 2 + lane] = 0;
         wave_lds_fence();
         const int wnm = (int)wave_max_u32((unsigned)nm);
         // DENSE slots (raft: Restart(i), Timeout(i) — enabled for nearly every parent, half of all successors): evaluated right
@@ -1022,10 +1216,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 }
                 S::fixed_clear_dense(gd);
                 if (track_succ) {  // deadlock check: one bit per parent; when every parent already has a successor, nothing more to track
-                    const unsigned long long sb = __ballot(mysucc);
-                    if (lane == 0) { FL.has_succ[blk * 2] = (unsigned)sb; FL.has_succ[blk * 2 + 1] = (unsigned)(sb >> 32); }
+                    lane_succ = mysucc;
                     if (!__ballot(active && !mysucc)) track_succ = false;
-                    wave_lds_fence();
                 }
             }
         }
@@ -1043,7 +1235,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             if (!(flags & 64u)) {
                 MC_PROF(6);
                 unsigned infl = active ? S::inflight_slots(gd) : 0u;  // bit k: count(message k) > 0, k < GUARD_SLOTS
-                auto eval_three = [&](bool on, int k) {
+                auto eval_three = [&](bool on, int k) __attribute__((always_inline)) {
 #pragma clang loop unroll(disable)
                     for (int kind = 0; kind < 3; ++kind) {
                         const unsigned slot = (unsigned)(S::FIX + 3 * k + kind);
@@ -1052,14 +1244,14 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                         if constexpr (HasGeneratedOnly<S>::value) {
                             if (on && S::message_generated_only(prm, loc, g, (int)slot)) {  // (DuplicateMessage of a full bag: counted, not evaluated)
                                 ++gen;
-                                if (track_succ) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
+                                lane_succ = true;
                                 ev = false;
                             }
                         }
                         const unsigned st = ev ? S::eval(prm, loc, g, (int)slot, fv) : 0u;
                         if (st & ST_ENABLED) {
                             ++gen;
-                            if (track_succ) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
+                            lane_succ = true;
                             if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
                             else if (st & ST_ASSERT) viol = min(viol, viol_key(idx, slot, VK_ASSERT, 0));
                             else if (st & ST_SPECERR) viol = min(viol, viol_key(idx, slot, VK_SPECERR, 0));
@@ -1071,6 +1263,24 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                         enqueue(fp, (slot << 6) | pl, 6);
                     }
                 };
+                // ONE loop, one inlined copy of eval_three (and of the probe code behind enqueue): first every lane's classified
+                // in-flight messages (its own k), then the bags beyond the classified slots (the count is read from the row)
+#if MC_FOLD_MSG
+                for (int kx = S::GUARD_SLOTS;;) {
+                    bool on;
+                    int k;
+                    if (__ballot(infl != 0)) {
+                        on = infl != 0;
+                        k = on ? __ffs((int)infl) - 1 : 0;
+                        infl &= infl - 1;
+                    } else if (kx < wnm) {
+                        k = kx++;
+                        on = k < nm && S::m_count(S::rd_msg(g, k)) > 0;
+                        if (!__ballot(on)) continue;
+                    } else break;
+                    eval_three(on, k);
+                }
+#else
                 while (__ballot(infl != 0)) {
                     const bool on = infl != 0;
                     const int k = on ? __ffs((int)infl) - 1 : 0;
@@ -1081,19 +1291,21 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                     const bool on = k < nm && S::m_count(S::rd_msg(g, k)) > 0;
                     if (__ballot(on)) eval_three(on, k);
                 }
+#endif
             }
         }
         MC_PROF(5);
         const int lane_inflight = active ? loc.inflight : 0;
+        // the fixed slots, and — as the last step of the wavefront's last block — the drain of the family queues (their partially
+        // filled batches): ONE loop, so that run_full (family batches, the probe code behind enqueue) is inlined once
+#if !MC_FOLD_FIX
         for (int step = 0; step < ((flags & 64u) ? 0 : S::FIX); ++step) {
             const int f = S::fixed_family(step);
             bool en = S::fixed_bit(gd, step);
             if constexpr (HasGeneratedOnly<S>::value) {
-                // enabled but never storable, known from the guard and the parent's in-flight count (S::fixed_generated_only):
-                // counted as generated — TLC counts it — and neither queued nor evaluated
                 if (en && S::fixed_generated_only(prm, lane_inflight, step)) {
                     ++gen;
-                    if (track_succ) atomicOr(&FL.has_succ[pl >> 5], 1u << (pl & 31u));
+                    lane_succ = true;
                     en = false;
                 }
             }
@@ -1108,7 +1320,47 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         for (int f = 0; f < S::NFAM; ++f) if (fget(fcntA, fcntB, f)) fullmask |= 1u << f;
         run_full(fullmask, true, 7);
     }
-    if (qn) flush_probe(qn);
+    if (false) { int blk = 0; typename S::Guards gd; unsigned pl = 0; int lane_inflight = 0;
+#endif
+        const int nfix = (flags & 64u) ? 0 : S::FIX;
+        for (int step = 0; step <= nfix; ++step) {
+            unsigned fullmask = 0;
+            const bool drain = step == nfix;
+            if (!drain) {
+                const int f = S::fixed_family(step);
+                bool en = S::fixed_bit(gd, step);
+                if constexpr (HasGeneratedOnly<S>::value) {
+                    // enabled but never storable, known from the guard and the parent's in-flight count (S::fixed_generated_only):
+                    // counted as generated — TLC counts it — and neither queued nor evaluated
+                    if (en && S::fixed_generated_only(prm, lane_inflight, step)) {
+                        ++gen;
+                        lane_succ = true;
+                        en = false;
+                    }
+                }
+                const unsigned long long b = __ballot(en);
+                if (!(b && fam_push(f, b, en, ((unsigned)step << 8) | pl))) continue;
+                fullmask = 1u << f;
+            } else {
+                if (blk != NB - 1) break;
+                MC_PROF(7);
+#pragma unroll
+                for (int f = 0; f < S::NFAM; ++f) if (fget(fcntA, fcntB, f)) fullmask |= 1u << f;
+            }
+            run_full(fullmask, drain, drain ? 7 : 5);
+        }
+    }
+    MC_PROF(7);
+    if (async_probe) {
+        // (nothing left to overlap with: what must look further does so synchronously; the last pass confirms the last
+        //  tentative survivors)
+        bool first = true;
+        while (pend || qn || casmask) {
+            if (!pend && qn) probe_issue(qn < 64 ? qn : 64u);
+            probe_resolve(first ? (unsigned)QCAP - (qn - pend) : 0u);
+            first = false;
+        }
+    } else if (qn) flush_probe(qn);
     if (inwave) {
         // THE TAIL, by WORKGROUP: the four wavefronts pool their survivors (one per parent on average: 250-400 per workgroup),
         // sort them by action class, take their arena indices with ONE atomicAdd and write them — parent row (this workgroup's
@@ -1130,20 +1382,22 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
             for (unsigned t = 0; t < on; t += 64) {
                 const bool valid = t + lane < on;
-                const int cls = valid ? SlotClasses<S>::of((int)(Q.o_ent[(ohead + t + lane) & (OCAP - 1)] >> 6)) : -1;
+                const unsigned e_ = valid ? Q.o_ent[(ohead + t + lane) & (OCAP - 1)] : O_DEAD;
+                const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
 #pragma unroll
                 for (int c = 0; c < NCLS; ++c) ccnt[c] += (unsigned)__popcll(__ballot(cls == c));
             }
+            unsigned nlive = 0;  // (tombstones of the split-phase probes are not survivors)
             {
-                unsigned run = 0;
 #pragma unroll
-                for (int c = 0; c < NCLS; ++c) { const unsigned n = ccnt[c]; ccnt[c] = run; run += n; }
+                for (int c = 0; c < NCLS; ++c) { const unsigned n = ccnt[c]; ccnt[c] = nlive; nlive += n; }
             }
             wave_lds_fence();
             for (unsigned t = 0; t < on; t += 64) {
                 const bool valid = t + lane < on;
                 const unsigned k = (ohead + t + lane) & (OCAP - 1);
-                const int cls = valid ? SlotClasses<S>::of((int)(Q.o_ent[k] >> 6)) : -1;
+                const unsigned e_ = valid ? Q.o_ent[k] : O_DEAD;
+                const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
 #pragma unroll
                 for (int c = 0; c < NCLS; ++c) {
                     const unsigned long long b = __ballot(cls == c);
@@ -1153,15 +1407,15 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             }
             wave_lds_fence();
             MC_PROF(17);
-            if (on) {
+            if (nlive) {
                 unsigned long long out0 = 0;
-                if (lane == 0) out0 = atomicAdd(&ctr->arena_next, (unsigned long long)on);
+                if (lane == 0) out0 = atomicAdd(&ctr->arena_next, (unsigned long long)nlive);
                 out0 = __shfl(out0, 0);
-                if (out0 + on > rt.arena_cap) {
+                if (out0 + nlive > rt.arena_cap) {
                     err |= DEV_EARENA;
                 } else {
-                    for (unsigned t = 0; t < on; t += 64) {
-                        const bool mine = t + lane < on;
+                    for (unsigned t = 0; t < nlive; t += 64) {
+                        const bool mine = t + lane < nlive;
                         const unsigned k = mine ? order[t + lane] : 0u;
                         const unsigned e = mine ? Q.o_ent[k] : 0u;
                         const uint64_t sfp = mine ? Q.o_fp[k] : 0ull;
@@ -1172,13 +1426,28 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 }
             }
         } else {
-        static_assert(NCLS * 4 <= 64, "one lane per (class, wavefront) in the prefix sum");
-        static_assert(4 * OCAP * sizeof(uint16_t) <= sizeof(fls[0].filt) && OCAP <= 256, "the sorted order aliases one duplicate filter");
-        uint16_t *order = reinterpret_cast<uint16_t *>(fls[0].filt);        // [4 * OCAP]: (wavefront << 8) | position in its list
-        __shared__ unsigned wg_hist[NCLS * 4];                              // [NCLS][4] (its own LDS: filled BEFORE the barrier)
-        __shared__ unsigned long long wg_out0_s;
-        unsigned *hist = wg_hist;
-        unsigned long long *wg_out0 = &wg_out0_s;
+        static_assert(NCLS * WAVES <= 64, "one lane per (class, wavefront) in the prefix sum");
+        static_assert(WAVES * OCAP * sizeof(uint16_t) <= sizeof(fls[0].filt) && OCAP <= 256, "the sorted order aliases one duplicate filter");
+        uint16_t *order = reinterpret_cast<uint16_t *>(fls[0].filt);        // [WAVES * OCAP]: (wavefront << 8) | position in its list
+        // [NCLS][WAVES] class counts + the workgroup's first arena index.  Written BEFORE barrier (1), while sibling wavefronts still
+        // generate: in LDS of its own, or — split-phase builds — in the writing wavefront's own probe landing area, dead by then
+        // (its last probe is resolved); every wavefront's slice lies in ITS landing area: hist of wave w' = probe_land[w'][...]
+        static_assert(NCLS * sizeof(unsigned) <= 512, "class counts + first index fit a landing area");
+        unsigned *hist_base;             // class c of wavefront ww: hist_base[ww * hist_stride + c]
+        unsigned hist_stride;
+        unsigned long long *wg_out0;
+        if constexpr (ASYNC_BUILD) {
+            hist_base = reinterpret_cast<unsigned *>(&probe_land[0][0]);
+            hist_stride = (unsigned)((ASYNC_BUILD ? 128 : 2) * 2);  // (32-bit words of one wavefront's landing area)
+            wg_out0 = reinterpret_cast<unsigned long long *>(&probe_land[0][64]);
+        } else {
+            __shared__ unsigned wg_hist_s[WAVES * NCLS];
+            __shared__ unsigned long long wg_out0_s;
+            hist_base = wg_hist_s;
+            hist_stride = NCLS;
+            wg_out0 = &wg_out0_s;
+        }
+        auto hist_at = [&](unsigned c, unsigned ww) -> unsigned & { return hist_base[ww * hist_stride + c]; };
         const unsigned w = threadIdx.x >> 6;
         // a wavefront counts its own survivors per class as soon as IT has finished — in the shadow of the wait for its siblings
         MC_PROF(16);      // (profiling builds: 16 = the counting sort, 4 = waiting at barrier (1), 17 = the writes)
@@ -1187,26 +1456,28 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
         for (unsigned t = 0; t < on; t += 64) {
             const bool valid = t + lane < on;
-            const int cls = valid ? SlotClasses<S>::of((int)(Q.o_ent[(ohead + t + lane) & (OCAP - 1)] >> 6)) : -1;
+            const unsigned e_ = valid ? Q.o_ent[(ohead + t + lane) & (OCAP - 1)] : O_DEAD;
+            const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) ccnt[c] += (unsigned)__popcll(__ballot(cls == c));
         }
 #pragma unroll
-        for (int c = 0; c < NCLS; ++c) if (lane == 0) hist[c * 4 + w] = ccnt[c];
+        for (int c = 0; c < NCLS; ++c) if (lane == 0) hist_at((unsigned)c, w) = ccnt[c];
         MC_PROF(4);
         __syncthreads();  // (1) no wavefront of the workgroup generates any more: the filters are free, the lists final, the counts there
         MC_PROF(16);
-        const unsigned h = lane < (unsigned)(NCLS * 4) ? hist[lane] : 0u;
+        const unsigned h = lane < (unsigned)(NCLS * WAVES) ? hist_at(lane / WAVES, lane % WAVES) : 0u;
         unsigned incl = h;
         for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
         const unsigned excl = incl - h, total = __shfl(incl, 63);
         if (w == 0 && lane == 0) *wg_out0 = total ? atomicAdd(&ctr->arena_next, (unsigned long long)total) : 0ull;
 #pragma unroll
-        for (int c = 0; c < NCLS; ++c) ccnt[c] = __shfl(excl, c * 4 + (int)w);  // where this wavefront's class-c survivors go
+        for (int c = 0; c < NCLS; ++c) ccnt[c] = __shfl(excl, c * WAVES + (int)w);  // where this wavefront's class-c survivors go
         for (unsigned t = 0; t < on; t += 64) {
             const bool valid = t + lane < on;
             const unsigned k = (ohead + t + lane) & (OCAP - 1);
-            const int cls = valid ? SlotClasses<S>::of((int)(Q.o_ent[k] >> 6)) : -1;
+            const unsigned e_ = valid ? Q.o_ent[k] : O_DEAD;
+            const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) {
                 const unsigned long long b = __ballot(cls == c);
@@ -1220,8 +1491,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         if (total && out0 + total > rt.arena_cap) {
             err |= DEV_EARENA;
         } else {
-            const uint64_t wg_idx0 = base + (uint64_t)blockIdx.x * 256u;
-            for (unsigned bt = w * 64u; bt < total; bt += 256u) {  // batch of 64 sorted survivors; the wavefronts take turns
+            const uint64_t wg_idx0 = base + (uint64_t)blockIdx.x * (64u * WAVES);
+            for (unsigned bt = w * 64u; bt < total; bt += 64u * WAVES) {  // batch of 64 sorted survivors; the wavefronts take turns
                 const bool mine = bt + lane < total;
                 const unsigned ref = mine ? order[bt + lane] : 0u;
                 const unsigned e = mine ? wq[ref >> 8].o_ent[ref & 255u] : 0u;
@@ -1242,7 +1513,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         for (int blk = 0; blk < NB; ++blk) {
             const uint64_t idx = wave_idx0 + (uint64_t)blk * 64 + lane;
             if (wave_col0 + (uint64_t)blk * 64 >= ncols) break;
-            if (idx >= lo && idx < hi && !(FL.has_succ[blk * 2 + (lane >> 5)] >> (lane & 31u) & 1u)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
+            if (idx >= lo && idx < hi && !lane_succ && !(*S::succ_word(FL.sum[blk * 64 + lane]) >> 31)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
         }
     }
     const unsigned gsum = wave_sum_u32(gen);
@@ -1294,10 +1565,11 @@ static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStr
     if constexpr (UsesFamilies<S>::value) {
         if (by_family) {
             // MC_F_OCC3 (A/B): the register budget of 3 wavefronts per SIMD (no spills) instead of 4 (a dozen spilled VGPRs)
+            constexpr unsigned WG = 64u * MC_EXPAND_WAVES;   // columns (parents) per workgroup
             if (flags & MC_F_OCC3)
-                hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1, 3>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, args...);
+                hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1, 3>), dim3((unsigned)((ncols + WG - 1) / WG)), dim3(WG), 0, stream, args...);
             else
-                hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1>), dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, args...);
+                hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1>), dim3((unsigned)((ncols + WG - 1) / WG)), dim3(WG), 0, stream, args...);
             return;
         }
     }
@@ -2752,7 +3024,10 @@ struct Engine : EngineBase {
             total += send_counts[t];
         }
         for (unsigned t = P; t <= 8; t++) q.pend_off.off[t] = total;
-        if (total > q.pend_cap || total >= (1ull << 31)) { set_error("shard_expand: more candidates in one round than the engine's pending list holds (lower chunk_states)"); return MC_EARENA; }
+        // (the pending list is as long as the largest send capacity asked for so far: more candidates than it holds is "more successors
+        //  per state than the fan-out allowance" — MC_EROUTE, the level loop starts over with twice the allowance — not a full arena)
+        if (total >= (1ull << 31)) { set_error("shard_expand: more than 2^31 candidates in one round (lower chunk_states)"); return MC_EARENA; }
+        if (total > q.pend_cap) { set_error("shard_expand: more candidates in one round than the slot's pending list holds (raise the fan-out allowance)"); return MC_EROUTE; }
         if (total > send_cap) { set_error("shard_expand: send buffer too small (raise the fan-out allowance)"); return MC_EROUTE; }
         q.pend_total = total;
         if (q.keep_pending) {  // the slot's previous keep still reads pend_src

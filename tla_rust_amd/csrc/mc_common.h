@@ -37,7 +37,15 @@ struct WordRef {
     uint64_t *p;
     size_t stride;
     MC_HD uint64_t get(int w) const { return p[(size_t)w * stride]; }
-    MC_HD void set(int w, uint64_t v) const { p[(size_t)w * stride] = v; }
+    // MC_NT_ROWSTORE (A/B, device code): state rows are written once and read a BFS level later — stream them past the L2 (`nt`), so
+    // that they do not push out the parent rows the in-wave writer re-reads
+    MC_HD void set(int w, uint64_t v) const {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MC_NT_ROWSTORE) && MC_NT_ROWSTORE
+        __builtin_nontemporal_store(v, p + (size_t)w * stride);
+#else
+        p[(size_t)w * stride] = v;
+#endif
+    }
 };
 struct CWordRef {
     const uint64_t *p;

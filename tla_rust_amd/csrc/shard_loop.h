@@ -106,6 +106,45 @@ struct Loop {
     template <class F>
     void step(F &&f) { if (!lrc) lrc = f(); }
 
+    // TEST-ONLY (include/tlamc.h): $TLAMC_TEST_FAIL_AT = "rank:level:code[,rank:level:code...]" makes that rank fail the level with
+    // that status, ONCE per process (a restarted search is not failed again) — how the tests put two different failures into one
+    // level without building a model that produces them.
+    int test_fault(size_t level) {
+        static bool spent = false;
+        const char *env = getenv("TLAMC_TEST_FAIL_AT");
+        if (!env || spent) return MC_OK;
+        for (const char *q = env; *q;) {
+            unsigned r = 0, lv = 0;
+            int code = 0, used = 0;
+            if (sscanf(q, "%u:%u:%d%n", &r, &lv, &code, &used) < 3) break;
+            if (r == me && lv == level) {
+                spent = true;
+                mc_set_error_internal("TLAMC_TEST_FAIL_AT: injected failure");
+                return code;
+            }
+            q += used;
+            if (*q == ',') ++q;
+        }
+        return MC_OK;
+    }
+    // What the ranks AGREE the failure is, from the all-gathered statuses (the same value on every rank): a rank must never act on
+    // its own status alone — run_restarting starts over on MC_EROUTE, and a rank that restarted while another returned would wait
+    // in the next collective for ever.  MC_EROUTE (restart with twice the allowance) only if EVERY failing rank reports it; else the
+    // first failing rank's status that is not MC_EROUTE.  A rank's own error text stays where its own failure put it.
+    int agreed_failure() {
+        int first = 0, first_other = 0;
+        uint32_t who = 0, who_other = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            const int stt = (int)(int64_t)all[p].status;
+            if (!stt) continue;
+            if (!first) { first = stt; who = p; }
+            if (!first_other && stt != MC_EROUTE) { first_other = stt; who_other = p; }
+        }
+        const int code = first_other ? first_other : first;
+        const uint32_t p = first_other ? who_other : who;
+        if (code && p != me && !lrc) mc_set_error_internal(("sharded search: rank " + std::to_string(p) + " failed: " + mc_strerror(code)).c_str());
+        return code;
+    }
     // ONE collective per level: every rank's frontier size, verdict and status.  Returns the transport's error only.
     int level_info(uint64_t local_n, int32_t verdict, uint64_t &frontier, int32_t &worst, int &failed, uint64_t sig = 0) {
         LevelInfo mine{local_n, (uint64_t)verdict, (uint64_t)(int64_t)lrc, sig};
@@ -118,11 +157,8 @@ struct Loop {
             sizes[p] = all[p].n;
             frontier += sizes[p];
             worst = std::max(worst, (int32_t)all[p].verdict);
-            if (!failed && (int64_t)all[p].status != 0) {
-                failed = (int)(int64_t)all[p].status;
-                if (p != me) mc_set_error_internal(("sharded search: rank " + std::to_string(p) + " failed: " + mc_strerror(failed)).c_str());
-            }
         }
+        failed = agreed_failure();
         return MC_OK;
     }
 
@@ -173,7 +209,7 @@ struct Loop {
         step([&] { return e.route_fill(&bucket_max, &routed_base); });
         routed_now = routed_base;
         if ((trc = level_info(local_n, verdict, frontier, worst, failed, resume_sig))) return trc;
-        if (failed) return lrc ? lrc : failed;
+        if (failed) return failed;   // (the agreed code, the same on every rank: agreed_failure)
         for (uint32_t p = 0; p < P; ++p)
             if (all[p].pad != resume_sig) { mc_set_error_internal("sharded search: the ranks did not restore checkpoints of the same run (mc_shard_restore on every rank, or on none)"); return MC_EBADCFG; }
         uint64_t cum = 0;
@@ -237,6 +273,7 @@ struct Loop {
             }
             uint64_t new_local = 0;
             step([&] { return e.end_level(&new_local); });  // waits for the engine's streams; device errors surface here
+            step([&] { return test_fault(levels.size()); });
             step([&] { return e.counters(&gen, &dl, &verdict); });
             if (stay && !exact) {  // (host-paced rounds noted their exact sizes round by round)
                 bucket_max = 0;
@@ -244,7 +281,7 @@ struct Loop {
                 if (!lrc) note_fill(bucket_max, std::min(ch, mine));
             }
             if ((trc = level_info(new_local, verdict, frontier, worst, failed, lrc ? 0 : fill_mine))) return trc;
-            if (failed) return lrc ? lrc : failed;
+            if (failed) return failed;   // (the agreed code, the same on every rank: agreed_failure)
             fill_prev = 0;
             for (uint32_t p = 0; p < P; ++p) fill_prev = std::max(fill_prev, all[p].pad);
             if (me == 0 && getenv("TLAMC_SHARD_DEBUG"))
@@ -267,8 +304,8 @@ struct Loop {
             for (uint32_t p = 0; p < P; ++p) {
                 gen += all[p].n;
                 worst = std::max(worst, (int32_t)all[p].verdict);
-                if ((int64_t)all[p].status != 0) return lrc ? lrc : (int)(int64_t)all[p].status;
             }
+            if (const int f = agreed_failure()) return f;
         }
         st.distinct_local = dl;
         st.routed_candidates += routed_now - routed_base;

@@ -183,12 +183,7 @@ struct AbiOps {
     int level_size(uint64_t *n) { return mc_shard_level_size(eng, n); }
     int expand_launch(uint32_t slot, uint64_t first, uint64_t count, uint64_t cap) { return mc_shard_expand_launch(eng, slot, first, count, cap); }
     int expand_finish(uint32_t slot, uint64_t *fp, uint64_t cap, uint64_t *counts) {
-        int rc = mc_shard_expand_finish(eng, slot, fp, cap, counts);
-        // A round with more candidates than the slot's pending list holds: the list is as long as the largest send capacity asked for so
-        // far, so this is "more successors per state than the fan-out allowance" — the condition the loop answers by starting over with
-        // twice the allowance (MC_EROUTE), not a full arena.  (The engine tests the list before the send capacity and words it as
-        // MC_EARENA; with large exact-size stay rounds that test comes first.)
-        if (rc == MC_EARENA && strstr(mc_last_error(), "pending list")) rc = MC_EROUTE;
+        const int rc = mc_shard_expand_finish(eng, slot, fp, cap, counts);  // (MC_EROUTE itself when the slot's pending list is what overflowed)
         return rc;
     }
     // Fixed-capacity rounds: the count word of every bucket is read back behind the compaction — asynchronously, on the expand stream,

@@ -937,6 +937,8 @@ struct SpecRaft {
         uint32_t glob;
         uint64_t dig;      // Local::dig
     };
+    // bit 31 of `packed` is free: the by-family kernel marks there a parent that got a successor from another lane's family batch
+    MC_HD static uint32_t *succ_word(Summary &q) { return &q.packed; }
     MC_HD static void summarize(const Local &l, Summary &q) {
         q.base_fp = l.fp + l.add_fp; q.sig = l.sig; q.glob = (uint32_t)l.glob; q.dig = l.dig;
         q.packed = (uint32_t)l.nm | (uint32_t)l.inflight << 8 | (uint32_t)l.nadd << 16 | l.addmask << 20;
