@@ -67,6 +67,13 @@ WORKLOADS = {"t3": WORKLOAD_T3, "k10": WORKLOAD, "k11": WORKLOAD_K11, "raft5": W
 TABLE_SLOTS = {"t3": 40 << 26, "k10": 8 << 26, "k11": 26 << 26, "raft5": 3 << 30, "ssi4x3": 9 << 26}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 XGMI_PEAK_GBS = 7 * 153.0  # MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, point to point
+# MEASURED on this device (profiles/calib/probe_locality.hip, round 5: profiles/r05a_probe_locality_8GiB.jsonl / _24GiB.jsonl): what the
+# memory system serves when every request is a random 32-byte seen-set bucket — 41.2 G requests/s (1.32 TB/s) into an 8 GiB table, 38.7 G
+# into 24 GiB, whatever the occupancy (3 .. 8 wavefronts per SIMD) or the probes in flight per lane (1, 2, 4); 55 - 58 G/s when the
+# region fits the 256 MiB Infinity Cache, 235 G/s when it fits an XCD's 4 MiB L2; first-time inserts (read + compare-and-swap) 20 G/s.
+# Partitioning the candidates by table region first (histogram + scatter + probe) ran at 0.52 - 0.79 x the unpartitioned rate.
+RANDOM_REQ_CEILING = 41.2e9   # random 32-byte requests per second, whole-table
+RANDOM_INSERT_CEILING = 20.0e9
 
 
 def spawn_ranks(a):
@@ -158,7 +165,7 @@ def kernel_source_hash():
     """the stamp profiles/summarize_pmc.py puts into a PMC summary: the kernel sources the counters were collected on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tla_rust_amd/csrc/engine.hip", "tla_rust_amd/csrc/spec_raft.h", "tla_rust_amd/csrc/mc_common.h"):
+    for f in ("tla_rust_amd/csrc/engine_kernels.h", "tla_rust_amd/csrc/spec_raft.h", "tla_rust_amd/csrc/mc_common.h"):
         h.update((ROOT / f).read_bytes())
     return h.hexdigest()[:16]
 
@@ -275,6 +282,10 @@ def atomic_add_series(amd, device, n=28, steps=3):
             "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dt / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes": "(2 x 8 + 8 x G/D) bytes per distinct state over the wall time of a step",
                          "probe_GBs_at_32B": 32 * G / dt / 1e9,   # what the probes really move: a 32-byte bucket each
+                         # the ceiling that binds this workload: the device's MEASURED random 32-byte request rate (see RANDOM_REQ_CEILING)
+                         "random_access_ceiling_GBs": 32 * RANDOM_REQ_CEILING / 1e9, "random_access_ceiling_Gprobes_s": RANDOM_REQ_CEILING / 1e9,
+                         "probes_Gs": G / dt / 1e9, "frac_of_random_access_ceiling": G / dt / RANDOM_REQ_CEILING,
+                         "ceiling_source": "profiles/r05a_probe_locality_8GiB.jsonl (k_probe<4>, whole table); region-partitioned probing measured at 0.52-0.79 x",
                          "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")}},
             "golden": "closed form 2^N + 1 / N 2^(N-1) + 3 / depth N + 2 (tests/test_oracle_golden.py: equal to the oracle for N <= 16)"}
 
@@ -293,9 +304,14 @@ def main():
                     "the exchange of round r+1 overlaps the probes of round r)")
     ap.add_argument("--packed-fanout", type=int, default=0, help="in-model successors per state the fixed-capacity exchange buckets allow for "
                     "(0 = the workload's: 16 for the raft models, 40 for the SI model, whose frontier grows 8 x per level)")
-    ap.add_argument("--exchange", choices=["exact", "measured", "packed"], default="exact",
+    ap.add_argument("--exchange", choices=["auto", "exact", "measured", "packed"], default="auto",
                     help="--gpus N: how a stay level exchanges its candidates (include/tlamc.h MC_SHARD_*): host-paced rounds with exact sizes, "
-                         "pipelined fixed-capacity buckets sized from the previous level's measured fill, or the same buckets from --packed-fanout")
+                         "pipelined fixed-capacity buckets sized from the previous level's measured fill, or the same buckets from --packed-fanout; "
+                         "auto (default) = one untimed trial step in the exact and in the measured form, the faster one (max over ranks) is timed: "
+                         "which of the two wins depends on what a host wait + two small all-gathers per round cost over xGMI, and no 8-GPU box "
+                         "has told yet")
+    ap.add_argument("--force-shard", action="store_true", help="--gpus 1 under a launcher: run the N-rank engine at world size 1 (RCCL, route-mode "
+                    "kernels) instead of the fused engine — the sharded path's own overhead (+9 % on t3, profiles/r04q_bench_world1_rccl.json)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank on GPU 0 (needs a librccl stand-in in $TLAMC_RCCL; RCCL refuses it)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="t3", help="t3: MaxTerm 3, MaxMsgKeys 8 (525.8 M states, the contract line); "
                     "k10 / k11: MaxTerm 2 with 10 / 11 message keys (102.6 M / 336.6 M states; rounds 1-2's line was k10); raft5: BASELINE config 4 "
@@ -336,7 +352,11 @@ def main():
     local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
-    use_dist = launched  # one rank of N (N = 1 included: the sharded engine over RCCL at world size 1)
+    # one rank of N.  At world size 1 — the N = 1 point of a launched scaling run — the fused engine runs, as without a launcher: the
+    # N-rank engine at world size 1 is the same search with the exchange machinery idling beside it (route-mode kernels, three streams)
+    # and cost 9 % in round 4; a SCALE curve's first point should be the one-GPU line.  --force-shard keeps
+    # that path measurable.
+    use_dist = launched and (world > 1 or a.force_shard)
     if not a.shard_chunk:
         a.shard_chunk = (1 << 23) if world == 1 else (1 << 21)
 
@@ -357,7 +377,7 @@ def main():
         from tla_rust_amd.binding import Comm
         uid, store = comm_id(rank, world)
         comm = Comm(uid, rank, world, local)
-        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, shard_rank=rank, shard_count=world, trace=False,
+        eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, shard_rank=rank, shard_count=world, trace=False, timing=True,
                          chunk_states=a.shard_chunk, max_distinct=a.max_distinct, table_capacity=(slots * 4 // 3) // world // 64 * 64,
                          # a rank's share of the states (+25 % imbalance allowance) + the replicated prefix
                          arena_capacity=int(G0["distinct"] / world * (WORKLOAD.get("imbalance", 1.25) if world > 1 else 1.0)) + (1 << 22))
@@ -368,6 +388,21 @@ def main():
                                     exchange=a.exchange)
             stats.update(st)
             return r
+
+        trial = None
+        if a.exchange == "auto" and world == 1:
+            a.exchange = "exact"   # (a single rank exchanges nothing)
+        if a.exchange == "auto":   # one untimed step in each form; every rank sees the same maxima, so every rank picks the same form
+            trial = {}
+            for form in ("exact", "measured"):
+                a.exchange = form
+                comm.all_gather_u64(0)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run()
+                torch.cuda.synchronize()
+                trial[form] = max(comm.all_gather_f64(time.perf_counter() - t1))
+            a.exchange = min(trial, key=trial.get)
 
     def barrier():
         if use_dist:
@@ -389,6 +424,14 @@ def main():
         sent = comm.all_gather_u64(stats.get("sent_bytes", 0))
         routed = comm.all_gather_u64(stats.get("routed_candidates", 0))
         fpans = comm.all_gather_u64(stats.get("fp_answer_bytes", 0))
+        # per rank, last step: the GPU time of its three kinds of kernels (HIP events on the engine's own streams) and the host time of
+        # its level loop inside engine calls (launches + the waits for its own streams) and inside collectives (the exchange + waiting for
+        # the slowest peer) — what a step's wall time is made of, rank by rank
+        ksd = eng.kernel_stats()
+        per_rank = {k: comm.all_gather_f64(ksd[n]["ms_total"]) for k, n in (("expand_ms", "expand"), ("probe_ms", "insert"), ("keep_ms", "materialise"))}
+        per_rank["engine_host_ms"] = [x / 1e6 for x in comm.all_gather_u64(stats.get("engine_ns", 0))]
+        per_rank["collective_host_ms"] = [x / 1e6 for x in comm.all_gather_u64(stats.get("collective_ns", 0))]
+        per_rank["collectives"] = comm.all_gather_u64(stats.get("collectives", 0))
     if rank != 0:
         eng.close()
         comm.close()
@@ -419,6 +462,13 @@ def main():
         line["config"]["parallelism"] = (f"fingerprint-sharded seen-set x{world} (owner = fingerprint high bits), replicated prefix for the small "
                                          f"levels, two-phase fingerprint-first exchange over RCCL (mc_shard_run: level loop in C++; large levels: {how})")
         line["config"]["shares"] = shares
+        line["config"]["exchange"] = a.exchange
+        if trial is not None:
+            line["config"]["exchange_trial_ms"] = {k: 1e3 * v for k, v in trial.items()}   # (--exchange auto: one untimed step in each form)
+        line["per_rank"] = dict(per_rank, rounds=stats.get("rounds"), host_ms_per_round=[(e + c) / max(1, stats.get("rounds", 0))
+                                for e, c in zip(per_rank["engine_host_ms"], per_rank["collective_host_ms"])],
+                                note="last step; *_ms of kernels = summed HIP-event times on the engine's streams (they overlap each other); "
+                                     "engine_host / collective_host = wall time of this rank's level loop inside engine calls / inside collectives")
         line["config"]["levels"] = {k: stats.get(k) for k in ("replicated_levels", "stay_levels", "move_levels", "rounds")}
         line["config"]["frontier_imbalance"] = stats.get("max_frontier", 0) / max(1, stats.get("mean_frontier", 1))
         # xGMI roofline: bytes a rank hands to the all-to-alls for OTHER ranks per step, against 7 links x 153 GB/s
@@ -456,7 +506,7 @@ def main():
         dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
         n_runs = a.steps  # stats are reset by every run(): they describe the last step
         ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
-        traffic, traffic_src, traffic_lower, l2_hit = None, None, None, None
+        traffic, traffic_src, traffic_lower, l2_hit, l2_miss_rate = None, None, None, None, None
         pmc = sorted(p for p in (ROOT / "profiles").glob("r*_pmc.json"))
         if pmc:  # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same command
             try:
@@ -475,9 +525,11 @@ def main():
                 traffic = (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
                 traffic_lower = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
                 l2_hit = k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) if "TCC_HIT_sum" in k else None
+                if "TCC_MISS_sum" in k and ks[dom]["ms_total"]:   # (counters of ONE step against the timed step's kernel time: the same 102 launches)
+                    l2_miss_rate = k["TCC_MISS_sum"] / k["launches"] * ks[dom]["launches"] / (ks[dom]["ms_total"] * 1e-3) / 1e9
                 traffic_src = f"profiles/{pmc[-1].name}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes of this command"
             except Exception as e:  # noqa: BLE001
-                traffic, traffic_lower, l2_hit = None, None, None
+                traffic, traffic_lower, l2_hit, l2_miss_rate = None, None, None, None
                 traffic_src = f"none: {e}"
         kernel_name = {"expand": f"k_expand_insert<{STAG}>" if (a.no_family or a.matrix or WORKLOAD["spec"] != "raft") else f"k_expand_family<{STAG}>",
                        "insert": "k_insert", "materialise": f"k_materialise<{STAG}>"}[dom]
@@ -496,7 +548,12 @@ def main():
                             # (2 W + 8 G/D) bytes per distinct state over the WALL time of a step
                             "pipeline_GBs": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9,
                             "pipeline_frac": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
-                            "state_bytes": W}
+                            "state_bytes": W,
+                            # the MEASURED random-access ceiling of the device (RANDOM_REQ_CEILING above) and what this kernel asks of the memory
+                            # system: L2 misses (probes, rows, parent rows the writer comes back for) + memory-side atomics per second of kernel time
+                            "random_access_ceiling_GBs": 32 * RANDOM_REQ_CEILING / 1e9, "random_access_ceiling_Greq_s": RANDOM_REQ_CEILING / 1e9,
+                            "l2_miss_Greq_s": l2_miss_rate, "frac_of_request_ceiling": (l2_miss_rate / (RANDOM_REQ_CEILING / 1e9)) if l2_miss_rate else None,
+                            "lookups_Gs": ks["cand_cells"] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if dom == "expand" and ks[dom]["ms_total"] else None}
         if not a.no_atomic_add and not a.max_distinct and a.workload == "t3":   # (the contract line carries both of north_star's workloads)
             eng.close()
             line["atomic_add"] = atomic_add_series(amd, local)

@@ -44,6 +44,8 @@ extern "C" {
 #define MC_V_DEADLOCK 3    /* p-manual §4.7.1 p.41                                            */
 #define MC_V_SPECERR 4     /* TLC would raise an evaluation error (index out of domain)       */
 #define MC_V_BUDGET 5      /* stopped by max_levels / max_distinct                            */
+#define MC_V_ASSUME 6      /* an ASSUME of the module is false (TLC's "No Behavior Spec" mode: a cfg that names neither SPECIFICATION
+                            * nor INIT / NEXT — SpecifyingSystems/SimpleMath/SimpleMath.cfg — makes mc_check_files evaluate the ASSUMEs) */
 
 /* ------------------------------------------------------------------ lowered specs */
 #define MC_SPEC_ATOMIC_ADD 1 /* reference atomic_add.tla:4-23, N adders + checker; params {N}          */
@@ -320,7 +322,9 @@ typedef struct mc_comm mc_comm;
 /* How a STAY level exchanges its candidates (mc_shard_opts.flags; `mc -gpus P -exchange exact | measured | packed`):
  *   default (neither flag): HOST-PACED rounds with exact sizes — the ranks exchange their P bucket counts (one small all-gather),
  *     then all_to_all_v moves exactly 8 bytes per routed candidate out and 1 byte back: the least the exchange can move, no
- *     capacity to guess and no bucket that could overflow, for one host wait + that all-gather per round (the next round's expand is
+ *     capacity to guess and no bucket that could overflow, for one host wait + two small all-gathers per round (the counts, and "every
+ *     rank has the buffers its announced sizes need": a rank that could not allocate must not leave its peers inside the all-to-all;
+ *     one agreement covers both all-to-alls of the round) (the next round's expand is
  *     launched before them and overlaps the exchange, the probes and the materialisation of this one);
  *   MC_SHARD_PACKED: pipelined FIXED-CAPACITY rounds, counts in band, no host wait inside a level (mc_shard_*_pack); the buckets are
  *     moved whole, so their capacity is the exchange volume: it is sized from the previous level's MEASURED fill
@@ -345,6 +349,9 @@ typedef struct {
                                  * rounds: the exact sizes): 9 bytes each (fingerprint out, answer back) is what the exchange needs */
     uint64_t fp_answer_bytes;   /* the part of sent_bytes that carried fingerprints and answers (the rest: moved states, parents)  */
     uint64_t measured_levels;   /* stay levels whose buckets were sized from the previous level's measured fill                   */
+    uint64_t engine_ns;         /* host time this rank spent inside engine calls (mc_shard_*: launches AND the waits for its own streams) */
+    uint64_t collective_ns;     /* host time inside the transport's collectives (the exchange itself + waiting for the slowest peer)  */
+    uint64_t collectives;       /* how many collectives that was                                                                  */
 } mc_shard_stats;
 typedef struct {
     uint64_t chunk_states;    /* frontier states per round and rank (0 = 2^19); clamped to the engine's chunk_states         */

@@ -8,7 +8,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-KERNEL_SOURCES = ["tla_rust_amd/csrc/engine.hip", "tla_rust_amd/csrc/spec_raft.h", "tla_rust_amd/csrc/mc_common.h"]
+KERNEL_SOURCES = ["tla_rust_amd/csrc/engine_kernels.h", "tla_rust_amd/csrc/spec_raft.h", "tla_rust_amd/csrc/mc_common.h"]
 
 
 def kernel_source_hash():

@@ -14,7 +14,7 @@ SHIM_DIR = ROOT / "tests" / "_shim"
 
 OR_MAX_LEVELS = 4096
 OR_MAX_TRACE = 4096
-VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
+VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget", "assume"]
 
 
 class OrOptions(C.Structure):

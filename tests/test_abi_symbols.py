@@ -49,8 +49,24 @@ def test_route_overflows_are_error_codes_not_words():
     """A round with more candidates than a route bucket / the slot's pending list holds is MC_EROUTE from the engine itself (the level
     loop restarts with twice the allowance); nothing above the C ABI looks at the words of an error message"""
     root = Path(__file__).resolve().parent.parent / "tla_rust_amd" / "csrc"
-    engine, ops, loop = ((root / f).read_text() for f in ("engine.hip", "shard_rccl.cpp", "shard_loop.h"))
+    engine, kernels, ops, loop = ((root / f).read_text() for f in ("engine.hip", "engine_kernels.h", "shard_rccl.cpp", "shard_loop.h"))
     assert "strstr(" not in ops and "strstr(" not in loop and "mc_last_error()" not in loop
     at = engine.index("slot's pending list holds")
     assert "return MC_EROUTE" in engine[at:at + 120]
-    assert engine.count("err |= DEV_EROUTE;") == 2   # the route sub-buckets of both expand kernels
+    assert kernels.count("err |= DEV_EROUTE;") == 2   # the route sub-buckets of both expand kernels
+
+
+def test_the_counter_stamp_covers_device_code_only():
+    """the kernels live in engine_kernels.h, the host half (Engine, C ABI, checkpoints) in engine.hip; the stamp
+    of a counter collection hashes the former (+ the spec lowering and mc_common.h), so a host-side fix does not invalidate counters"""
+    import importlib.util
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_module2", root / "bench.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    src = (root / "bench.py").read_text()
+    assert "engine_kernels.h" in src[src.index("def kernel_source_hash"):src.index("def dist_roofline")]
+    assert "engine_kernels.h" in (root / "profiles" / "summarize_pmc.py").read_text()
+    host, dev = (root / "tla_rust_amd" / "csrc" / "engine.hip").read_text(), (root / "tla_rust_amd" / "csrc" / "engine_kernels.h").read_text()
+    assert "__global__" not in host, "a kernel in the host half"
+    assert "hipMalloc" not in dev and "struct Engine" not in dev and len(b.kernel_source_hash()) == 16

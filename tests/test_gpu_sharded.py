@@ -104,12 +104,16 @@ def test_a_full_route_sub_bucket_restarts_the_search_at_a_production_chunk_size(
     small — the expand kernel itself finds its sub-bucket full (DEV_EROUTE, not DEV_EARENA: `check_dev_error` runs before the host's own
     count test) and every rank restarts with twice the allowance instead of reporting a full arena.  Levels of > 100 000 states of the
     3-server model, one in-model successor per state allowed where four are generated."""
-    params = [3, 4, 2, 3, 1, 1, 16, 2, 8]
-    o = oracle.oracle_run("raft", params, max_distinct=1500000)
+    import tla_rust_amd as amd
+    params = [3, 4, 2, 3, 1, 1, 16, 2, 8]   # (with slot capacities: the reference run is the fused one-GPU engine, itself pinned to the oracle)
+    eng = amd.Engine("raft", params, table_capacity=1 << 24, arena_capacity=1 << 22, chunk_states=1 << 17, max_distinct=1500000)
+    o = eng.run()
+    eng.close()
     r = run_dist("hip", 2, "raft", params, tmp_path, {"max_distinct": 1500000, "chunk": 1 << 17, "table": 1 << 24, "arena": 1 << 22,
                                                        "stay_threshold": 200, "rebalance_ratio": 1.5, "packed_fanout": 1, "move_fanout": 1,
                                                        "exchange": exchange})
-    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
+    assert (r["distinct"], r["generated"], r["depth"], r["levels"]) == (o.distinct, o.generated, o.depth, list(o.levels))
+    assert o.distinct > 1500000 and max(o.levels) > 100000
     assert r["stats"]["restarts"] >= 1
 
 
@@ -337,8 +341,8 @@ def test_bench_contract_invocation_with_several_ranks(world):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--share-gpu", "--workload", "k10"],
-                       capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=str(root))
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--share-gpu", "--workload", "k10",
+                        "--exchange", "exact"], capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=str(root))
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     line = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
     c = line["config"]
@@ -372,6 +376,42 @@ def test_bench_under_the_drivers_launcher():
     c = line["config"]
     assert (line["n_gpus"], line["steps"], line["warmup"], line["scaling"]) == (2, 2, 1, "strong")
     assert (c["distinct"], c["generated"], c["depth"], c["verdict"]) == (102586254, 1217433925, 33, "ok") and sum(c["shares"]) == 102586254
+    # round 5: the N-rank line describes itself — the default `--exchange auto` ran one untimed step in the exact
+    # and in the measured form and timed the faster one; per rank: the GPU time of its three kinds of kernels and the host time of its
+    # level loop inside engine calls and inside collectives
+    assert c["exchange"] in ("exact", "measured") and set(c["exchange_trial_ms"]) == {"exact", "measured"}
+    assert c["exchange"] == min(c["exchange_trial_ms"], key=c["exchange_trial_ms"].get) == line["xgmi"]["exchange"]
+    pr = line["per_rank"]
+    for k in ("expand_ms", "probe_ms", "keep_ms", "engine_host_ms", "collective_host_ms", "collectives", "host_ms_per_round"):
+        assert len(pr[k]) == 2 and all(v > 0 for v in pr[k]), (k, pr)
+    assert pr["rounds"] > 0 and max(pr["expand_ms"]) < 1e3 * 60
+
+
+def test_bench_under_a_launcher_at_world_size_1_is_the_fused_line():
+    """`python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`: the N = 1 point of a launched scaling run is the
+    one-GPU line itself (fused engine: a roofline object with its dominant kernel, no exchange), not the N-rank engine at world size 1
+    (+9 % in round 4); --force-shard still runs that one (RCCL at world size 1: the real librccl accepts one rank per device)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    lines = []
+    for extra in ([], ["--force-shard"]):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            str(root / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "k10", "--no-cpu-baseline"] + extra,
+                           capture_output=True, text=True, timeout=900, cwd=str(root))
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        lines.append(json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{"))))
+    fused, shard = lines
+    assert fused["n_gpus"] == 1 and fused["roofline"]["kernel"].startswith("k_expand_family<SpecRaft<3>") and "xgmi" not in fused
+    assert fused["config"]["distinct"] == shard["config"]["distinct"] == 102586254
+    assert "xgmi" in shard and shard["config"]["exchange"] == "exact" and len(shard["per_rank"]["expand_ms"]) == 1
+    assert fused["ms_per_step"] < 1.05 * shard["ms_per_step"]   # (the fused engine is never the slower one)
 
 
 # ------------------------------------------------------------------------------------------ one checkpoint file per rank

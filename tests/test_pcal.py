@@ -540,6 +540,8 @@ PROC_ERRORS = [
     ("procedure f(a) begin F1: x := a; end procedure; begin M1: call f(1); M2: skip; end algorithm *)\n====\n", "run off the end of procedure f"),
     ("procedure f(a) begin F1: x := a; return; end procedure; procedure g() begin G1: call f(1); return; end procedure; begin M1: call g(); M2: skip; end algorithm *)\n====\n", "tail call"),
     ("begin M1: x := 1; return; end algorithm *)\n====\n", "`return` outside a procedure"),
+    # (pcal2tla evaluates it once when the frame is pushed; the expansion would re-evaluate it at every return)
+    ("procedure f(a) variables y = a + 1; begin F1: x := y; return; end procedure; begin M1: call f(1); M2: skip; end algorithm *)\n====\n", "mentions another variable of the procedure"),
     ("begin M1: call nope(1); M2: skip; end algorithm *)\n====\n", "no such procedure"),
     # (one name, one variable: pcal2tla would rename the second `t`; here both back-ends refuse, the translator included)
     ("process a = 1 variables t = 0; begin A1: t := 1; end process; process b = 2 variables t = 0; begin B1: t := 2; end process; end algorithm *)\n====\n", "variable `t` is declared twice"),

@@ -10,7 +10,7 @@ LIB_PATH = Path(os.environ["TLAMC_LIB"]) if os.environ.get("TLAMC_LIB") else PKG
 
 MC_MAX_LEVELS = 4096
 SPEC_IDS = {"atomic_add": 1, "pcal_intro": 2, "raft": 3, "ssi": 4, "pcal": 5, "paxos": 6}
-VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget"]
+VERDICTS = ["ok", "invariant", "assert", "deadlock", "spec-error", "budget", "assume"]
 MC_F_DEADLOCK, MC_F_TRACE, MC_F_TIMING, MC_F_MATRIX, MC_F_NOPROBE, MC_F_NOFAMILY = 1, 2, 4, 8, 16, 32
 MC_F_UNVERIFIED = 512  # use the built-in lowering even when the module a wrapper EXTENDS cannot be found (include/tlamc.h)
 
@@ -60,7 +60,8 @@ class ShardStats(C.Structure):
     """mc_shard_stats: what one rank's level loop did"""
     _fields_ = [("replicated_levels", C.c_uint64), ("stay_levels", C.c_uint64), ("move_levels", C.c_uint64), ("rounds", C.c_uint64),
                 ("sent_bytes", C.c_uint64), ("distinct_local", C.c_uint64), ("max_frontier", C.c_uint64), ("mean_frontier", C.c_uint64),
-                ("restarts", C.c_uint64), ("routed_candidates", C.c_uint64), ("fp_answer_bytes", C.c_uint64), ("measured_levels", C.c_uint64)]
+                ("restarts", C.c_uint64), ("routed_candidates", C.c_uint64), ("fp_answer_bytes", C.c_uint64), ("measured_levels", C.c_uint64),
+                ("engine_ns", C.c_uint64), ("collective_ns", C.c_uint64), ("collectives", C.c_uint64)]
 
 
 class ShardOpts(C.Structure):

@@ -37,7 +37,7 @@ def build(force=False, verbose=False):
         common += os.environ["TLAMC_EXTRA_DEFS"].split()
     if os.environ.get("TLAMC_PHASE_PROF"):   # per-phase cycle counters inside k_expand_family (profiles/phase_prof.py): a profiling build
         common.append("-DMC_PHASE_PROF")
-    base = [CSRC / "engine.hip", CSRC / "mc_common.h", CSRC / "spec_registry.h", PKG.parent / "include" / "tlamc.h"]
+    base = [CSRC / "engine.hip", CSRC / "engine_kernels.h", CSRC / "mc_common.h", CSRC / "spec_registry.h", PKG.parent / "include" / "tlamc.h"]
     own = {0: ["spec_pluscal.h", "spec_raft.h", "spec_ssi.h", "spec_vm.h", "spec_paxos.h"], 7: ["spec_paxos.h"], 1: ["spec_pluscal.h"], 2: ["spec_raft.h"],
            3: ["spec_raft.h"], 4: ["spec_raft.h"], 5: ["spec_ssi.h"], 6: ["spec_vm.h"]}
     jobs, objs = [], []

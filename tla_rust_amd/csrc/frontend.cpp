@@ -1104,6 +1104,24 @@ static bool lowered_family(const std::string &module, const std::string &tla) {
     return false;
 }
 
+// does X.cfg (read beside X.tla when not given) name neither SPECIFICATION nor INIT / NEXT?  (false when it cannot be read / parsed:
+// the ordinary path then reports that)
+static bool no_behavior_cfg(const char *tla_path, const char *cfg_path) {
+    std::string cpath, text;
+    if (cfg_path) cpath = cfg_path;
+    else {
+        cpath = tla_path;
+        const size_t dot = cpath.rfind(".tla");
+        if (dot != std::string::npos) cpath.replace(dot, 4, ".cfg"); else cpath += ".cfg";
+    }
+    if (!read_file(cpath, text)) return false;
+    mc_cfg *c = nullptr;
+    if (mc_cfg_parse(text.c_str(), text.size(), &c)) return false;
+    const bool none = c->specification.empty() && c->init.empty() && c->next.empty();
+    mc_cfg_free(c);
+    return none;
+}
+
 // `tlc X.tla` for a TLA+ module that has NO GPU lowering (the Specifying Systems examples of the reference: MCInnerSerial.tla and
 // its TLC log testout2): the general evaluator of tlaeval.h runs TLC's breadth-first search on the host and the report says so.
 static int host_evaluate(const char *tla_path, const char *cfg_path, const mc_config *cfg, const std::string &module, char *report,
@@ -1132,6 +1150,16 @@ static int host_evaluate(const char *tla_path, const char *cfg_path, const mc_co
     for (uint32_t i = 0; i < res->levels; i++) res->level_distinct[i] = r.levels[i];
     res->unchecked_properties = (uint32_t)r.unchecked_properties.size();
     Out o{report, report_cap, 0};
+    if (r.no_behavior) {
+        // TLC's "No Behavior Spec" mode: what Print / PrintT printed while the ASSUMEs were evaluated, then TLC's closing lines
+        o.put("Module %s, no behavior spec: the assumptions are evaluated on the host by the general TLA+ evaluator.\n", module.c_str());
+        for (auto &ln : r.printed) o.put("%s\n", ln.c_str());
+        if (r.verdict == MC_V_OK) o.put("Model checking completed. No error has been found.\n");
+        else if (r.verdict == MC_V_ASSERT) o.put("The first argument of Assert evaluated to FALSE; the second argument was:\n\"%s\"\n", r.error_message.c_str());
+        else o.put("Error: %s\n", r.error_message.c_str());
+        o.put("0 states generated, 0 distinct states found, 0 states left on queue.\n");
+        return MC_OK;
+    }
     o.put("Module %s has no GPU lowering: evaluated on the host by the general TLA+ evaluator.\n", module.c_str());
     o.put("Finished computing initial states: %llu distinct state%s generated.\n", (unsigned long long)r.init_states, r.init_states == 1 ? "" : "s");
     if (!r.unchecked_properties.empty()) {
@@ -1170,6 +1198,18 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
                         mc_result *res, const char *dump_path, const char *recover_path, const char *checkpoint_path) {
     if (!tla_path || !cfg || !report || !report_cap || !res) return MC_EBADCFG;
     report[0] = 0;
+    // A cfg that names no behaviour (neither SPECIFICATION nor INIT / NEXT) asks for the module's ASSUMEs to be evaluated — TLC's "No
+    // Behavior Spec" mode — whatever the module EXTENDS: the in-spec unit tests of the snapshot-isolation models are run that way
+    // (serializableSnapshotIsolation.tla:1062-1066).  No state is generated, so no lowering is stood in for.
+    if (no_behavior_cfg(tla_path, cfg_path)) {
+        std::string tla, module;
+        if (!read_file(tla_path, tla)) return fe_fail(MC_EPARSE, "cannot read %s", tla_path);
+        if (!module_name(tla, module)) return fe_fail(MC_EPARSE, "%s: no MODULE header", tla_path);
+        if (tla.find("--algorithm") == std::string::npos && tla.find("--fair") == std::string::npos) {
+            if (dump_path || recover_path || checkpoint_path) return fe_fail(MC_ENOSPEC, "%s: -dump / -recover / -checkpoint need a behaviour spec", module.c_str());
+            return host_evaluate(tla_path, cfg_path, cfg, module, report, report_cap, res);
+        }
+    }
     Resolved R;
     int rc = resolve_files(tla_path, cfg_path, cfg->flags, R);
     if (rc == MC_ENOSPEC && !R.module.empty() && !lowered_family(R.module, R.tla)) {

@@ -901,6 +901,12 @@ struct ProcExpander {
         for (auto &x : c->a) x = rename(x, r);
         return c;
     }
+    static bool mentions(const EP &e, const std::set<std::string> &names) {
+        if (!e) return false;
+        if (e->k == Expr::ID && names.count(e->s)) return true;
+        for (const auto &x : e->a) if (mentions(x, names)) return true;
+        return false;
+    }
     // one process being expanded
     struct Job {
         Proc *proc;
@@ -1004,6 +1010,18 @@ struct ProcExpander {
         std::vector<const VarDecl *> pv;
         for (const auto &d : pr.params) pv.push_back(&d);
         for (const auto &d : pr.locals) pv.push_back(&d);
+        // An initial value that mentions another variable of the procedure (`variables x = a + 1`) is refused: pcal2tla evaluates it
+        // ONCE, when the frame is pushed, and a `return` pops the saved values — the expansion re-evaluates the expression at every
+        // call and at every return, with whatever the mentioned variable holds then, and (with several calling processes) under
+        // names the expression was never renamed to.  Constants, globals and `self` are fine.  
+        {
+            std::set<std::string> own;
+            for (const VarDecl *d : pv) own.insert(d->name);
+            for (const VarDecl *d : pv)
+                if (d->init && mentions(d->init, own))
+                    fail(d->pos, "the initial value of procedure variable " + d->name + " of " + pr.name +
+                                 " mentions another variable of the procedure: not supported (assign it in the body's first step instead)");
+        }
         for (const VarDecl *d : pv) {
             const std::string nm = d->name + job.suffix;
             ren[d->name] = nm;

@@ -16,7 +16,7 @@
 //
 //   STAY level (large, balanced frontier): the new states stay on the rank that generated them; 9 bytes per routed candidate are
 //     what the exchange needs.  Default form: host-paced rounds with EXACT sizes (the first half of a move round + mc_shard_keep_slot:
-//     one host wait for the round's expand and one small all-gather of the bucket counts per round, both behind the launch of the
+//     one host wait for the round's expand and two small all-gathers per round (the bucket counts; "every rank has its buffers"), both behind the launch of the
 //     next round's expand).  MC_SHARD_PACKED: fixed-capacity rounds, nothing waits for the host.  Streams: MAIN (the engine's expand
 //     stream: expand r, bucket compaction r), COMM (the transport's: the all-to-alls), WORK (probes), the engine's second
 //     stream (materialisation of the kept states).  Issue order on COMM is fp(0) fp(1) ans(0) fp(2) ans(1) ...: the fingerprint
@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -102,9 +103,26 @@ struct Loop {
 
     Loop(Ops &ops, const mc_transport &t) : e(ops), net(t), P(t.world), me(t.rank), all(t.world), sizes(t.world) { memset(&st, 0, sizeof st); probe_rot = t.rank; }
 
-    // engine step: skipped once this rank has failed
+    // engine step: skipped once this rank has failed.  The host time inside engine calls (their stream waits included) and inside
+    // the transport's collectives is what mc_shard_stats.engine_ns / collective_ns report: with the GPU kernels' own times
+    // (mc_engine_kernel_stats) they say where a sharded step's wall time goes — a rank waiting for its own streams, for its
+    // slowest peer inside a collective, or for neither.
+    static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     template <class F>
-    void step(F &&f) { if (!lrc) lrc = f(); }
+    void step(F &&f) {
+        if (lrc) return;
+        const uint64_t t0 = now_ns();
+        lrc = f();
+        st.engine_ns += now_ns() - t0;
+    }
+    template <class Fn, class... A>
+    int timed_net(Fn fn, A... a) {
+        const uint64_t t0 = now_ns();
+        const int rc = fn(net.user, a...);
+        st.collective_ns += now_ns() - t0;
+        ++st.collectives;
+        return rc;
+    }
 
     // TEST-ONLY (include/tlamc.h): $TLAMC_TEST_FAIL_AT = "rank:level:code[,rank:level:code...]" makes that rank fail the level with
     // that status, ONCE per process (a restarted search is not failed again) — how the tests put two different failures into one
@@ -148,7 +166,7 @@ struct Loop {
     // ONE collective per level: every rank's frontier size, verdict and status.  Returns the transport's error only.
     int level_info(uint64_t local_n, int32_t verdict, uint64_t &frontier, int32_t &worst, int &failed, uint64_t sig = 0) {
         LevelInfo mine{local_n, (uint64_t)verdict, (uint64_t)(int64_t)lrc, sig};
-        int trc = net.all_gather(net.user, &mine, all.data(), sizeof mine);
+        int trc = timed_net(net.all_gather, &mine, all.data(), sizeof mine);
         if (trc) return trc;
         frontier = 0;
         worst = 0;
@@ -222,7 +240,7 @@ struct Loop {
             for (uint64_t v : levels) total += v;
             std::vector<uint64_t> every(P);
             uint64_t mine_dl = lrc ? 0 : dl;
-            if ((trc = net.all_gather(net.user, &mine_dl, every.data(), sizeof mine_dl))) return trc;
+            if ((trc = timed_net(net.all_gather, &mine_dl, every.data(), sizeof mine_dl))) return trc;
             for (uint32_t p = 0; p < P; ++p) held += every[p];
             if ((frontier != 0 && frontier != levels.back()) || held != total) {
                 mc_set_error_internal("sharded search: the restored frontiers / states do not add up to the checkpointed level table");
@@ -298,7 +316,7 @@ struct Loop {
         step([&] { return e.counters(&gen, &dl, &verdict); });
         {   // global counters: sum of generated, worst verdict (the unexpanded frontier's check included), status once more
             LevelInfo mine2{gen, (uint64_t)verdict, (uint64_t)(int64_t)lrc, 0};
-            if ((trc = net.all_gather(net.user, &mine2, all.data(), sizeof mine2))) return trc;
+            if ((trc = timed_net(net.all_gather, &mine2, all.data(), sizeof mine2))) return trc;
             gen = 0;
             worst = 0;
             for (uint32_t p = 0; p < P; ++p) {
@@ -351,7 +369,7 @@ struct Loop {
             }
             uint64_t mine = (uint64_t)(int64_t)lrc;
             std::vector<uint64_t> every(P);
-            if ((trc = net.all_gather(net.user, &mine, every.data(), sizeof mine))) return trc;
+            if ((trc = timed_net(net.all_gather, &mine, every.data(), sizeof mine))) return trc;
             for (uint32_t p = 0; p < P; ++p)
                 if ((int64_t)every[p] != 0) return MC_OK;  // the level ends here; run() reports it through level_info
             stay_bytes = total_max;
@@ -363,7 +381,7 @@ struct Loop {
             step([&] { return e.wait_keep(t); });  // (on WORK) the slot's previous keep has read back[t] ...
             e.record(EV_TMP, S_WORK);
             e.wait(S_COMM, EV_TMP);                // ... before this exchange overwrites it
-            int rc = net.all_to_all(net.user, ans[t].p, back[t].p, cap);
+            int rc = timed_net(net.all_to_all, ans[t].p, back[t].p, cap);
             if (rc) return rc;
             st.sent_bytes += cap * (P - 1);
             st.fp_answer_bytes += cap * (P - 1);
@@ -384,8 +402,8 @@ struct Loop {
             if (r >= 2) e.wait(S_COMM, EV_PROBED + s);  // the probes of round r-2 have read recv[s]
             if (net.all_to_all_others) {  // the rank's own bucket is empty by construction: only its count word matters, and the loop writes that
                 e.clear_bytes((uint64_t *)recv[s].p + (uint64_t)me * cap, sizeof(uint64_t), S_COMM);
-                if ((trc = net.all_to_all_others(net.user, send[s].p, recv[s].p, cap * 8))) return trc;
-            } else if ((trc = net.all_to_all(net.user, send[s].p, recv[s].p, cap * 8))) {
+                if ((trc = timed_net(net.all_to_all_others, send[s].p, recv[s].p, cap * 8))) return trc;
+            } else if ((trc = timed_net(net.all_to_all, send[s].p, recv[s].p, cap * 8))) {
                 return trc;
             }
             st.sent_bytes += cap * 8 * (P - 1);
@@ -407,7 +425,7 @@ struct Loop {
     // ------------------------------------------------------------------ MOVE: host-paced rounds, new states travel to their owners
     int exchange_counts(const uint64_t *mine, std::vector<uint64_t> &from_peers) {
         std::vector<uint64_t> m(P * (size_t)P);
-        int rc = net.all_gather(net.user, mine, m.data(), P * sizeof(uint64_t));
+        int rc = timed_net(net.all_gather, mine, m.data(), P * sizeof(uint64_t));
         if (rc) return rc;
         from_peers.resize(P);
         for (uint32_t p = 0; p < P; ++p) from_peers[p] = m[(size_t)p * P + me];
@@ -426,7 +444,7 @@ struct Loop {
             if (p != me) st.sent_bytes += sb[p];
         }
         comm_after_work();
-        int rc = net.all_to_all_v(net.user, s, so.data(), sb.data(), r, ro.data(), rb.data());
+        int rc = timed_net(net.all_to_all_v, s, so.data(), sb.data(), r, ro.data(), rb.data());
         work_after_comm();
         return rc;
     }
@@ -458,7 +476,11 @@ struct Loop {
             step([&] { return ans[0].need(std::max<uint64_t>(n, 1)); });
             if (keep_local) step([&] { return e.wait_keep(s); });  // (on WORK) the slot's previous keep has read back[s] — also before it may be re-allocated
             step([&] { return bk.need(std::max<uint64_t>(total, 1)); });
-            if ((trc = a2a_v_safe(send[s], counts, recv[0], rcounts, 8))) return trc;
+            // (one agreement for the round's two all-to-alls: all four buffers were asked for above)
+            Move mv[2] = {{&send[s], &counts, &recv[0], &rcounts, 8, nullptr, nullptr}, {&ans[0], &rcounts, &bk, &counts, 1, nullptr, nullptr}};
+            const int go = agree_moves(mv, 2);
+            if (go < 0) return go;
+            if (!go && (trc = a2a_v(mv[0].sp, counts, mv[0].rp, rcounts, 8))) return trc;
             if (keep_local && P > 1) {
                 // WHO KEEPS A STATE that several ranks generated in the same round is decided by whose candidate reaches the table first.
                 // Probed as they lie (source 0's bucket first), the lower ranks win those ties systematically and their frontiers grow
@@ -479,7 +501,7 @@ struct Loop {
             } else {
                 step([&] { return e.probe((const uint64_t *)recv[0].p, n, (uint8_t *)ans[0].p); });
             }
-            if ((trc = a2a_v_safe(ans[0], rcounts, bk, counts, 1))) return trc;
+            if (!go && (trc = a2a_v(mv[1].sp, rcounts, mv[1].rp, counts, 1))) return trc;
             if (keep_local) {
                 // STAY with exact sizes (the default form, include/tlamc.h): the positively answered candidates become states of THIS rank; what crossed
                 // xGMI is 9 bytes per routed candidate and the P counts, nothing else — no capacity to guess, no bucket to overflow
@@ -533,29 +555,44 @@ struct Loop {
     // the scratch cannot be had, nobody enters the collective: the ranks agree on that with one small all-gather first (a rank
     // that returned alone would leave its peers waiting in the all-to-all forever — an out-of-memory rank is the likeliest case).
     // The level then runs on with stale buffers and ends at its level_info, where the failed rank's status stops every rank.
-    NetBuf scratch_s, scratch_r;
-    int a2a_v_safe(NetBuf &s, const std::vector<uint64_t> &sc, NetBuf &r, const std::vector<uint64_t> &rc_, uint64_t elem) {
-        uint64_t need_s = 0, need_r = 0;
-        for (uint32_t p = 0; p < P; ++p) { need_s += sc[p] * elem; need_r += rc_[p] * elem; }
-        void *sp = s.p, *rp = r.p;
+    // ONE agreement covers all the all-to-alls whose sizes are known when it is made: the two of an exchange round (fingerprints
+    // out, answers back) share it, so a round costs the all-gather of the counts + this one, not three.
+    struct Move { NetBuf *s; const std::vector<uint64_t> *sc; NetBuf *r; const std::vector<uint64_t> *rc; uint64_t elem; void *sp, *rp; };
+    NetBuf scratch[4];
+    // 0: every rank has its buffers (m[i].sp / rp say which); 1: some rank has not — nobody moves anything; < 0: the transport failed
+    int agree_moves(Move *m, size_t nm) {
         uint64_t cannot = 0;
-        if (!sp || s.bytes < need_s) {
-            scratch_s.t = &net;
-            if (scratch_s.need(std::max<uint64_t>(need_s, 8))) cannot = 1;
-            sp = scratch_s.p;
-        }
-        if (!rp || r.bytes < need_r) {
-            scratch_r.t = &net;
-            if (scratch_r.need(std::max<uint64_t>(need_r, 8))) cannot = 1;
-            rp = scratch_r.p;
+        for (size_t i = 0; i < nm && i < 2; ++i) {
+            uint64_t need_s = 0, need_r = 0;
+            for (uint32_t p = 0; p < P; ++p) { need_s += (*m[i].sc)[p] * m[i].elem; need_r += (*m[i].rc)[p] * m[i].elem; }
+            m[i].sp = m[i].s->p;
+            m[i].rp = m[i].r->p;
+            if (!m[i].sp || m[i].s->bytes < need_s) {
+                NetBuf &x = scratch[2 * i];
+                x.t = &net;
+                if (x.need(std::max<uint64_t>(need_s, 8))) cannot = 1;
+                m[i].sp = x.p;
+            }
+            if (!m[i].rp || m[i].r->bytes < need_r) {
+                NetBuf &x = scratch[2 * i + 1];
+                x.t = &net;
+                if (x.need(std::max<uint64_t>(need_r, 8))) cannot = 1;
+                m[i].rp = x.p;
+            }
         }
         if (cannot && !lrc) lrc = MC_EHIP;
         std::vector<uint64_t> every(P);
-        int trc = net.all_gather(net.user, &cannot, every.data(), sizeof cannot);
-        if (trc) return trc;
+        const int trc = timed_net(net.all_gather, &cannot, every.data(), sizeof cannot);
+        if (trc) return trc < 0 ? trc : -trc;
         for (uint32_t p = 0; p < P; ++p)
-            if (every[p]) return MC_OK;  // nobody moves anything; the failed rank's status travels with the level's all-gather
-        return a2a_v(sp, sc, rp, rc_, elem);
+            if (every[p]) return 1;  // nobody moves anything; the failed rank's status travels with the level's all-gather
+        return 0;
+    }
+    int a2a_v_safe(NetBuf &s, const std::vector<uint64_t> &sc, NetBuf &r, const std::vector<uint64_t> &rc_, uint64_t elem) {
+        Move m{&s, &sc, &r, &rc_, elem, nullptr, nullptr};
+        const int go = agree_moves(&m, 1);
+        if (go) return go < 0 ? go : MC_OK;
+        return a2a_v(m.sp, sc, m.rp, rc_, elem);
     }
 
     // ------------------------------------------------------------------ counterexample across ranks
@@ -572,7 +609,7 @@ struct Loop {
             mine = Viol{found, (int64_t)idx, (int64_t)slot, v, inv, rc};
         }
         std::vector<Viol> every(P);
-        int trc = net.all_gather(net.user, &mine, every.data(), sizeof mine);
+        int trc = timed_net(net.all_gather, &mine, every.data(), sizeof mine);
         if (trc) return trc;
         int owner = -1;
         for (uint32_t p = 0; p < P; ++p) {
@@ -600,7 +637,7 @@ struct Loop {
                 int64_t hdr[4] = {rc, (int64_t)prank, (int64_t)pidx, (int64_t)pslot};
                 memcpy(mine_rec.data(), hdr, sizeof hdr);
             }
-            if ((trc = net.all_gather(net.user, mine_rec.data(), all_rec.data(), rec))) return trc;
+            if ((trc = timed_net(net.all_gather, mine_rec.data(), all_rec.data(), rec))) return trc;
             int64_t hdr[4];
             memcpy(hdr, all_rec.data() + (size_t)cur_rank * rec, sizeof hdr);
             if (hdr[0]) return (int)hdr[0];

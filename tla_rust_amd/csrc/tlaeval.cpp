@@ -790,6 +790,7 @@ struct Parser {
 struct Module {
     std::string name;
     std::vector<std::string> extends, variables, def_order, instances;
+    std::vector<std::pair<std::string, int>> assumes;  // (definition name, line) of every ASSUME / ASSUMPTION / AXIOM, in order
     std::map<std::string, int> constants;
     std::map<std::string, Def> defs;
     explicit Module(const std::string &text_in) {
@@ -843,11 +844,15 @@ struct Module {
                 variables.push_back(p.ident());
                 while (p.is_sym(",")) { p.i++; variables.push_back(p.ident()); }
             } else if (c.s == "ASSUME" || c.s == "ASSUMPTION" || c.s == "AXIOM" || c.s == "THEOREM" || c.s == "LEMMA" || c.s == "PROPOSITION" || c.s == "COROLLARY") {
+                const bool assumption = c.s == "ASSUME" || c.s == "ASSUMPTION" || c.s == "AXIOM";
                 p.i++;
                 std::string nm;
                 if (p.cur().k == Tok::ID && p.peek().k == Tok::SYM && p.peek().s == "==") { nm = p.cur().s; p.i += 2; }
-                NodeP e = p.expr(0);  // never evaluated unless a model refers to it as Name!:
+                NodeP e = p.expr(0);  // evaluated in TLC's "No Behavior Spec" mode only (Checker::run), or when a model refers to it as Name
+                // (an unnamed assumption gets a name nobody can type, so that it is loaded like every other definition)
+                if (nm.empty() && assumption) nm = "ASSUME@line" + std::to_string(c.line);
                 if (!nm.empty()) { Def d; d.name = nm; d.body = e; d.line = c.line; defs[nm] = d; def_order.push_back(nm); }
+                if (assumption) assumes.emplace_back(nm, c.line);
                 while (p.cur().k == Tok::ID && (p.cur().s == "PROOF" || p.cur().s == "BY" || p.cur().s == "OBVIOUS" || p.cur().s == "OMITTED" || p.cur().s == "QED")) p.i++;
             } else if (c.s == "INSTANCE") {
                 p.i++;
@@ -948,6 +953,7 @@ const std::map<std::string, int> OPCODES = {{"=", OP_EQ}, {"#", OP_NE}, {"\\in",
     {"+", OP_ADD}, {"-", OP_SUB}, {"*", OP_MUL}, {"\\div", OP_DIV}, {"%", OP_MOD}, {"^", OP_POW}, {"<", OP_LT}, {">", OP_GT}, {"<=", OP_LE}, {">=", OP_GE},
     {"..", OP_RANGE}, {"\\cup", OP_CUP}, {"\\cap", OP_CAP}, {"\\", OP_SETMINUS}, {"\\subseteq", OP_SUBSETEQ}, {"\\o", OP_CONCAT}, {":>", OP_MAPSTO},
     {"@@", OP_ATAT}, {"\\X", OP_TIMES}, {"\\subset", OP_PSUBSET}};
+std::vector<std::string> *g_print_sink = nullptr;
 enum { B_CARD, B_ISFINITE, B_LEN, B_APPEND, B_HEAD, B_TAIL, B_SUBSEQ, B_SEQ, B_SELECTSEQ, B_ASSERT, B_PERMUTATIONS, B_PRINT, B_PRINTT, B_TOSTRING };
 const std::map<std::string, std::pair<int, int>> BUILTIN_OPS = {{"Cardinality", {B_CARD, 1}}, {"IsFiniteSet", {B_ISFINITE, 1}}, {"Len", {B_LEN, 1}},
     {"Append", {B_APPEND, 2}}, {"Head", {B_HEAD, 1}}, {"Tail", {B_TAIL, 1}}, {"SubSeq", {B_SUBSEQ, 3}}, {"Seq", {B_SEQ, 1}}, {"SelectSeq", {B_SELECTSEQ, 2}},
@@ -1032,6 +1038,8 @@ struct Spec {
         defs[r->sym] = r;
         return r;
     }
+    struct Assume { std::string def; int line; std::string module; };
+    std::vector<Assume> assumes;  // of the root module and of what it EXTENDS, in load order (TLC checks them all)
     void load(const std::string &path) {
         std::string text;
         if (!read_text(path, text)) fail("cannot read " + path);
@@ -1041,6 +1049,7 @@ struct Spec {
             load(find_module(e));
         }
         loaded.push_back(m.name);
+        for (auto &a : m.assumes) assumes.push_back({a.first, a.second, m.name});
         for (auto &c : m.constants) constants[c.first] = c.second;
         for (auto &v : m.variables) if (std::find(variables.begin(), variables.end(), v) == variables.end()) variables.push_back(v);
         for (auto &nm : m.def_order) {
@@ -1305,8 +1314,10 @@ struct Spec {
                 } while (std::next_permutation(p.begin(), p.end()));
                 return mk_set(out);
             }
-            case B_PRINT: return a[1];
-            case B_PRINTT: return g_true;
+            // TLC prints when it EVALUATES Print / PrintT; here only where the caller asked for it (the ASSUMEs of a model without a
+            // behaviour spec: AsynchronousInterface/PrintValues.tla) — not once per state of a search
+            case B_PRINT: if (g_print_sink) g_print_sink->push_back(fmt(a[0]) + "  " + fmt(a[1])); return a[1];
+            case B_PRINTT: if (g_print_sink) g_print_sink->push_back(fmt(a[0])); return g_true;
             case B_TOSTRING: return mk_str(fmt(a[0]));
             default: fail("built-in operator used in an unsupported position");
         }
@@ -1925,6 +1936,7 @@ struct Checker {
     std::vector<std::string> unchecked;                 // PROPERTIES with a liveness part (never checked here; the report names them)
     std::vector<std::map<const Val *, V>> group;
     bool has_group = false;
+    bool no_behavior = false;   // the cfg names neither SPECIFICATION nor INIT / NEXT: evaluate the ASSUMEs (setup)
 
     bool is_temporal(const Node *n, std::set<int> &seen) {
         if (n->k == N_TEMPORAL || (n->k == N_OP && n->s == "~>")) return true;
@@ -2005,7 +2017,12 @@ struct Checker {
         sp.load(tla_path);
         sp.finish_load();
         if (!cfg.spec.empty()) split_spec(cfg.spec);
-        else {
+        else if (cfg.init.empty() && cfg.next.empty()) {
+            // TLC's "No Behavior Spec" mode (SpecifyingSystems/SimpleMath/SimpleMath.cfg, AsynchronousInterface/PrintValues.cfg; the
+            // run-book of serializableSnapshotIsolation.tla:1062-1066 for the in-spec unit tests): no states, the ASSUMEs are evaluated
+            no_behavior = true;
+            return;
+        } else {
             if (cfg.init.empty() || cfg.next.empty()) fail("the configuration names neither a SPECIFICATION nor INIT and NEXT");
             init_node = node_id(cfg.init);
             next_node = node_id(cfg.next);
@@ -2085,7 +2102,30 @@ struct Checker {
         return -1;
     }
 
+    void run_assumes(Result &R) {
+        const auto t0 = std::chrono::steady_clock::now();
+        R.no_behavior = true;
+        R.verdict = MC_V_OK;
+        g_print_sink = &R.printed;
+        struct Unsink { ~Unsink() { g_print_sink = nullptr; } } unsink;
+        for (auto &a : sp.assumes) {
+            bool ok = false;
+            try {
+                V v = sp.ev(node_id(a.def).get(), nullptr, nullptr, nullptr);
+                ok = v->k == K_BOOL && v->i;
+                if (!ok && v->k != K_BOOL) { R.verdict = MC_V_SPECERR; R.error_message = "Assumption line " + std::to_string(a.line) + " of module " + a.module + " is not a Boolean: " + fmt(v); break; }
+            } catch (TlaError &e) {
+                R.verdict = e.is_assert ? MC_V_ASSERT : MC_V_SPECERR;
+                R.error_message = e.is_assert ? e.msg : "evaluating the assumption of line " + std::to_string(a.line) + " of module " + a.module + ": " + e.msg;
+                break;
+            }
+            if (!ok) { R.verdict = MC_V_ASSUME; R.error_message = "Assumption line " + std::to_string(a.line) + " of module " + a.module + " is false."; break; }
+            R.assumes_checked++;
+        }
+        R.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
     void run(const Options &opt, Result &R) {
+        if (no_behavior) { run_assumes(R); return; }
         const auto t0 = std::chrono::steady_clock::now();
         const size_t nv = sp.variables.size();
         std::unordered_map<std::string, int64_t> seen;

@@ -36,6 +36,12 @@ struct Result {
     std::vector<uint64_t> levels;                                 // new distinct states per BFS level
     std::vector<std::pair<std::string, std::string>> trace;       // (action label, state text) of a counterexample
     double seconds = 0;
+    // TLC's "No Behavior Spec" mode (a cfg with neither SPECIFICATION nor INIT / NEXT): no states; the ASSUMEs of the module and of what
+    // it EXTENDS were evaluated (verdict MC_V_OK, or MC_V_ASSUME with error_message "Assumption line L of module M is false."), and
+    // what Print / PrintT printed while they were, one line each, in evaluation order
+    bool no_behavior = false;
+    uint64_t assumes_checked = 0;
+    std::vector<std::string> printed;
 };
 
 // `tlc X.tla` on the host.  Returns 0 or a negative MC_E* code with `error` set (parse errors: MC_EPARSE; a module the
