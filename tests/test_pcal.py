@@ -49,6 +49,10 @@ CASES = [
     (SPECS / "pluscal" / "treiber_procs.tla", ["PopsDistinct"], {"N": 2}),      # the lock-free stack of the reference's roadmap, with procedures
     (SPECS / "pluscal" / "treiber_procs.tla", ["PopsDistinct"], {"N": 3}),
     (SPECS / "pluscal" / "proc_nested.tla", ["XBound", "Final"], {}),           # c-syntax; a procedure calling another; two kinds of processes
+    # RECURSION (round 5; one copy of the body per process + a bounded call stack per procedure kept as plain variables, pcal.cpp call_recursive)
+    (SPECS / "pluscal" / "recursive_sum.tla", ["Bounded"], {"N": 3}),           # four frames deep in two interleaving processes
+    (SPECS / "pluscal" / "recursive_sum.tla", ["Bounded"], {"N": 4}),           # ... a fifth frame: the assertion at the call fails
+    (SPECS / "pluscal" / "even_odd.tla", ["Answered"], {"N": 4}),               # mutual recursion: two stacks, return sites in each other's body
     # RECORDS (round 4; kept field by field, tla_rust_amd/csrc/pcal.h): r.f, r[i].f, r := [f |-> ..], r = s, r[i] := [..], records as process locals
     (SPECS / "pluscal" / "treiber_records.tla", ["PoppedOnce", "TopIsNode", "NextIsNode", "OldIsNode"], {"N": 2}),   # versioned head, nodes as records
     (SPECS / "pluscal" / "treiber_records.tla", ["PoppedOnce", "TopIsNode", "NextIsNode", "OldIsNode"], {"N": 3}),
@@ -417,6 +421,61 @@ def test_procedure_expansion_equals_the_stack_translation(spec, fixture, consts,
     assert p["distinct"] > 100
 
 
+def test_recursive_procedure_equals_the_stack_translation():
+    """round 5 (missing 4): a RECURSIVE procedure is compiled with one copy of its body per process and a bounded call
+    stack kept as plain variables (depth counter, return-site codes, one slot per variable and level; $TLAMC_PCAL_STACK levels, default
+    4).  Same state graph as pcal2tla's `stack` of frames: the hand-written stack translation of specs/pluscal/recursive_sum.tla
+    (tests/golden/pcal_recursion/RecursiveSumStack.tla, N = 3: four frames deep), evaluated by the general TLA+ evaluator, against the
+    product's translation — evaluated as text AND compiled — counters, depth, verdict, per-level counts."""
+    import tlaplus as T
+    fx = ROOT / "tests" / "golden" / "pcal_recursion"
+    p = T.Checker(fx / "RecursiveSumStack.tla", cfg_path=fx / "RecursiveSumStack.cfg", search=[]).run_levels(keep_states=False)
+    text = (SPECS / "pluscal" / "recursive_sum.tla").read_text()
+    o = Checker(helpers.pcal_translate(text), constants={"N": 3}).run_levels(invariants=["Bounded"])
+    prog = helpers.ShimProgram(text, ["Bounded"], {"N": 3})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (p["distinct"], p["generated"], p["depth"], p["verdict"], p["levels"]) == (o["distinct"], o["generated"], o["depth"], o["verdict"], o["levels"])
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (p["distinct"], p["generated"], p["depth"], p["verdict"], p["levels"])
+    assert p["verdict"] == "ok" and p["distinct"] > 200
+
+
+def test_recursion_deeper_than_the_stack_fails_at_the_call_and_mutual_recursion():
+    """N = 4 needs a fifth frame: the run is not cut short silently — the assertion in front of the push fails (verdict assert, both
+    back-ends, at the depth where pcal2tla's unbounded stack would have had five frames); with TLAMC_PCAL_STACK = 5 in the translator's
+    environment it passes.  Mutual recursion (even / odd): evaluated translation == compiled program, and the answers are right."""
+    import os
+    text = (SPECS / "pluscal" / "recursive_sum.tla").read_text()
+    o = Checker(helpers.pcal_translate(text), constants={"N": 4}).run_levels(invariants=["Bounded"])
+    prog = helpers.ShimProgram(text, ["Bounded"], {"N": 4})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert o["verdict"] == "assert" == r["verdict"] and (r["distinct"], r["depth"]) == (o["distinct"], o["depth"])
+    os.environ["TLAMC_PCAL_STACK"] = "5"
+    try:
+        o5 = Checker(helpers.pcal_translate(text), constants={"N": 4}).run_levels(invariants=["Bounded"])
+    finally:
+        del os.environ["TLAMC_PCAL_STACK"]
+    assert o5["verdict"] == "ok" and o5["distinct"] > o["distinct"]
+    text = (SPECS / "pluscal" / "even_odd.tla").read_text()
+    os.environ["TLAMC_PCAL_STACK"] = "3"   # (even and odd each hold at most three frames for N + 1 = 5)
+    try:
+        o = Checker(helpers.pcal_translate(text), constants={"N": 4}).run_levels(invariants=["Answered"])
+        prog = helpers.ShimProgram(text, ["Answered"], {"N": 4})
+        try:
+            r = helpers.shim_run("pcal", prog.params)
+        finally:
+            prog.close()
+    finally:
+        del os.environ["TLAMC_PCAL_STACK"]
+    assert o["verdict"] == "ok" and (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["verdict"], o["levels"])
+    assert o["distinct"] > 100
+
+
 RECORD_FIXTURES = ROOT / "tests" / "golden" / "pcal_records"
 
 
@@ -533,7 +592,6 @@ def test_a_procedure_with_a_record_variable(n, distinct):
 
 PROC_HEAD = "---- MODULE M ----\nEXTENDS Naturals\n(* --algorithm M\nvariables x = 0;\n"
 PROC_ERRORS = [
-    ("procedure f(a) begin F1: x := a; call f(a); F2: return; end procedure; begin M1: call f(1); M2: skip; end algorithm *)\n====\n", "recursive call of procedure f"),
     ("procedure f(a) begin F1: x := a; return; end procedure; begin M1: call f(1); x := 2; end algorithm *)\n====\n", "after a `call` must have a label"),
     ("procedure f(a) begin F1: x := a; return; end procedure; begin M1: call f(1, 2); M2: skip; end algorithm *)\n====\n", "takes 1 arguments"),
     ("procedure f(a) begin x := a; return; end procedure; begin M1: call f(1); M2: skip; end algorithm *)\n====\n", "first statement of procedure f must have a label"),

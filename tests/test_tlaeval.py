@@ -414,6 +414,47 @@ def test_mc_exit_codes_and_traces_for_host_evaluated_modules(tmp_path):
         assert "evaluated on the host" in p.stdout.splitlines()[0]
 
 
+def test_mc_no_behavior_spec_mode(tmp_path):
+    """TLC's "No Behavior Spec" mode (missing 5): a cfg that names neither SPECIFICATION nor INIT / NEXT makes `mc X.tla`
+    evaluate the module's ASSUMEs and print what Print / PrintT print — the reference's SimpleMath.cfg and PrintValues.cfg, and the
+    run-book of serializableSnapshotIsolation.tla:1062-1066 for its in-spec unit tests (a wrapper that EXTENDS the spec: no state is
+    generated, so the GPU lowering of that spec is not stood in for).  A false assumption: TLC's sentence, exit code 12."""
+    import os
+    import subprocess
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    ref = Path("/root/reference/examples")
+    if not ref.is_dir():
+        pytest.skip("the reference tree is not on this box")
+    env = dict(os.environ, TLA_PATH=str(ref))
+    p = subprocess.run([str(mc), str(ref / "SpecifyingSystems" / "SimpleMath" / "SimpleMath.tla")], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0 and "Model checking completed. No error has been found." in p.stdout and "0 states generated" in p.stdout, (p.stdout, p.stderr)
+    p = subprocess.run([str(mc), str(ref / "SpecifyingSystems" / "AsynchronousInterface" / "PrintValues.tla")], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0, (p.stdout, p.stderr)
+    out = p.stdout.splitlines()
+    assert '<<"Three more cats: ", 4>>  TRUE' in out, p.stdout
+    assert '<<"Here\'s a record: ", [game |-> "baseball", homers |-> 70, player |-> "McGuire"]>>  TRUE' in out, p.stdout
+    # the in-spec unit tests of the SI model, the way its comments prescribe (Toolbox: "Evaluate Constant Expression")
+    (tmp_path / "SsiUnitTests.tla").write_text("---- MODULE SsiUnitTests ----\nEXTENDS serializableSnapshotIsolation\n"
+                                               "ASSUME PrintT(<<\"UnitTests_FindAllNodesInAnyCycle\", UnitTests_FindAllNodesInAnyCycle>>)\n"
+                                               "ASSUME UnitTests_FindAllNodesInAnyCycle\n====\n")
+    (tmp_path / "SsiUnitTests.cfg").write_text("CONSTANTS TxnId = {T1, T2}\n Key = {K1}\n")
+    p = subprocess.run([str(mc), str(tmp_path / "SsiUnitTests.tla")], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and '<<"UnitTests_FindAllNodesInAnyCycle", TRUE>>' in p.stdout.splitlines(), (p.stdout, p.stderr)
+    # a false assumption (line 4 of the module), and one that fails an Assert
+    (tmp_path / "Wrong.tla").write_text("---- MODULE Wrong ----\nEXTENDS Naturals, TLC\nASSUME 1 + 1 = 2\nASSUME \\A x \\in 1..3 : x * x < 9\n====\n")
+    (tmp_path / "Wrong.cfg").write_text("")
+    p = subprocess.run([str(mc), str(tmp_path / "Wrong.tla")], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 12 and "Error: Assumption line 4 of module Wrong is false." in p.stdout, (p.stdout, p.stderr)
+    # through the C ABI: verdict MC_V_ASSUME ("assume")
+    from tla_rust_amd import binding as B
+    import ctypes as C
+    cfgc = B.Config(0, B.MC_F_TRACE, 0, 0, 0, 0, 0, 0, 1)
+    r = B.CResult()
+    buf = C.create_string_buffer(1 << 16)
+    assert B.lib().mc_check_files(str(tmp_path / "Wrong.tla").encode(), None, C.byref(cfgc), buf, len(buf), C.byref(r)) == 0
+    assert B._result(r).verdict == "assume" and B._result(r).distinct == 0
+
+
 # ---------------------------------------------------------------------------------------------- PlusCal programs: a third opinion
 def _pcal_cases():
     import test_pcal

@@ -154,6 +154,12 @@ struct Engine : EngineBase {
     mc_spec_desc desc;
     mc_config cfg;
     hipStream_t stream = nullptr, stream2 = nullptr;  // expand+insert on `stream`, materialise on `stream2`
+    // The chunks of ONE level are independent of each other (they read the frontier, probe / insert with atomics, take arena indices
+    // with atomics): the odd ones go to a stream of their own, so that the first workgroups of chunk c+1 fill the CUs the last
+    // workgroups of chunk c leave idle (a launch of 2^23 parents is 32 rounds of the 2048 resident workgroups: the last one is half
+    // empty) instead of waiting for the stream order.  $TLAMC_EXPAND_STREAMS = 2 switches it on (A/B; off by default until measured).
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_level = nullptr;
     hipEvent_t ev_e[2] = {nullptr, nullptr}, ev_m[2] = {nullptr, nullptr};
     uint64_t *d_arena = nullptr, *d_table = nullptr, *d_cand = nullptr;
     uint32_t *d_newlist = nullptr;
@@ -202,6 +208,13 @@ struct Engine : EngineBase {
             else HIP_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         }
         for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&ev_e[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ev_m[i], hipEventDisableTiming)); }
+        {
+            const char *es = getenv("TLAMC_EXPAND_STREAMS");
+            if (es && *es == '2') {
+                HIP_TRY(hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&ev_level, hipEventDisableTiming));
+            }
+        }
         table_cap = cfg.table_capacity ? cfg.table_capacity : (1ull << 24);
         table_cap = (table_cap + 63) / 64 * 64;  // whole 8-slot buckets; any size (seen_insert), at most 2^32 buckets
         if (table_cap / 8 > 0xffffffffull) { set_error("table_capacity: at most 2^35 - 8 slots per device"); return MC_EBADCFG; }
@@ -269,6 +282,8 @@ struct Engine : EngineBase {
         if (h_lc) hipHostFree(h_lc);
         for (int i = 0; i < 2; i++) { if (ev_e[i]) hipEventDestroy(ev_e[i]); if (ev_m[i]) hipEventDestroy(ev_m[i]); }
         if (stream2) hipStreamDestroy(stream2);
+        if (stream_b) hipStreamDestroy(stream_b);
+        if (ev_level) hipEventDestroy(ev_level);
         if (stream) hipStreamDestroy(stream);
     }
 
@@ -285,6 +300,7 @@ struct Engine : EngineBase {
     }
 
     int read_counters() {
+        if (stream_b) HIP_TRY(hipStreamSynchronize(stream_b));
         HIP_TRY(hipStreamSynchronize(stream2));
         HIP_TRY(hipMemcpyAsync(h_ctr, d_ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -315,10 +331,10 @@ struct Engine : EngineBase {
     }
     // materialise + commit of the chunk whose survivors are in new-list `parity`, on the second stream: it overlaps
     // the expansion of the next chunk (memory-bound next to latency-bound)
-    void finish_materialise(uint64_t chunk_base, uint64_t ncols, unsigned parity) {
+    void finish_materialise(uint64_t chunk_base, uint64_t ncols, unsigned parity, hipStream_t expanded_on = nullptr) {
         const unsigned bx = (unsigned)((ncols + 255) / 256);
         const unsigned gm = bx < 8 * 256 ? (bx + 7) / 8 : 256;
-        hipEventRecord(ev_e[parity], stream);
+        hipEventRecord(ev_e[parity], expanded_on ? expanded_on : stream);
         hipStreamWaitEvent(stream2, ev_e[parity], 0);
         timed(2, 0, [&] {
             hipLaunchKernelGGL(k_materialise<S>, dim3(gm, NSHARD), dim3(256), 0, stream2, prm, d_arena, chunk_base, d_newlist,
@@ -496,6 +512,12 @@ struct Engine : EngineBase {
             }
             prev_frontier = hi - lo;
             unsigned chunk_no = 0;
+            // (odd chunks on their own stream — see stream_b; not with the slot-sliced launches' shared flag array, not for the matrix form)
+            const bool two_streams = stream_b && !use_matrix && hi - lo > chunk && !(slices_for(chunk, false) > 1 && (cfg.flags & MC_F_DEADLOCK));
+            if (two_streams) {  // what the level's first kernels on `stream` were ordered behind, stream_b's are too
+                hipEventRecord(ev_level, stream);
+                hipStreamWaitEvent(stream_b, ev_level, 0);
+            }
             for (uint64_t c0 = lo; c0 < hi; ++chunk_no) {
                 const unsigned parity = chunk_no & 1u;
                 const uint64_t base = c0 & ~63ull;
@@ -509,21 +531,22 @@ struct Engine : EngineBase {
                     });
                     finish_chunk<false>(base, ncols, max_slots);
                 } else {
-                    if (chunk_no >= 2) hipStreamWaitEvent(stream, ev_m[parity], 0);  // new-list `parity` is free again
+                    hipStream_t es = two_streams && parity ? stream_b : stream;
+                    if (chunk_no >= 2) hipStreamWaitEvent(es, ev_m[parity], 0);  // new-list `parity` is free again
                     RouteArgs rt_new{};
                     rt_new.new_fp = d_newfp;
                     if (lvl_inwave) set_inwave(rt_new);
                     const unsigned sg = slices_for(ncols, false);
                     const bool dl = sg > 1 && (cfg.flags & MC_F_DEADLOCK);
-                    if (dl) { rt_new.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), stream); }
+                    if (dl) { rt_new.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), es); }
                     timed(0, c1 - c0, [&] {
-                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, sg, prm,
+                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, es, sg, prm,
                                                 (const uint64_t *)d_arena, c0, c1, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr,
                                                 cfg.flags, rt_new, parity);
-                        if (dl) hipLaunchKernelGGL(k_deadlock_slices, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream,
+                        if (dl) hipLaunchKernelGGL(k_deadlock_slices, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, es,
                                                    (const uint16_t *)d_nsl, c0, c1, ncols, (const LevelCtl *)nullptr, d_ctr);
-                    });
-                    finish_materialise(base, ncols, parity);
+                    }, es);
+                    finish_materialise(base, ncols, parity, es);
                 }
                 c0 = c1;
             }

@@ -914,7 +914,194 @@ struct ProcExpander {
         std::vector<std::string> active;            // procedures on the current call chain (recursion check)
         std::set<std::string> declared;             // procedure variables this process already has
         std::vector<SP> copies;                     // the expanded bodies, appended behind the process's own
+        // RECURSIVE procedures (round 5): ONE copy of the body per process and a bounded call stack per procedure, kept as plain
+        // variables — depth counter P_sp, and for every level K = 1 .. D a return-site code P_retK and one slot vK per variable v of
+        // the procedure (what pcal2tla's frame [pc |-> ..., v |-> ...] holds: the value v had BEFORE the call).
+        struct Rec {
+            std::string entry, sp;                          // the copy's first label; the depth counter
+            std::vector<std::string> ret;                   // P_ret1 .. P_retD
+            std::vector<const VarDecl *> pv;                // parameters, then locals
+            std::map<std::string, std::string> ren;         // v -> the process's variable
+            std::map<std::string, std::vector<std::string>> slot;  // v -> its D slots
+            std::vector<std::string> sites;                 // label a call returns to; its code is index + 1
+            std::vector<std::pair<SP, Pos>> returns;        // the IF statements standing for `return`, filled in by finish_returns
+        };
+        std::map<std::string, Rec> rec;
     };
+    std::set<std::string> recursive;   // procedures that can reach themselves through `call`
+    static int stack_depth() {
+        const char *e = getenv("TLAMC_PCAL_STACK");
+        const int d = e ? atoi(e) : 4;
+        return d < 1 ? 1 : d > 16 ? 16 : d;
+    }
+    static EP mk(Expr::K k, const Pos &at) { auto e = std::make_shared<Expr>(); e->k = k; e->pos = at; return e; }
+    static EP num(long long v, const Pos &at) { auto e = mk(Expr::NUM, at); e->num = v; return e; }
+    static EP ident(const std::string &n, const Pos &at) { auto e = mk(Expr::ID, at); e->s = n; return e; }
+    static EP bin(const std::string &op, const EP &a, const EP &b, const Pos &at) { auto e = mk(Expr::BINOP, at); e->s = op; e->a = {a, b}; return e; }
+    static EP ife(const EP &c, const EP &t, const EP &f, const Pos &at) { auto e = mk(Expr::IF, at); e->a = {c, t, f}; e->paren = true; return e; }
+    // the slot the depth counter points at: IF sp = 1 THEN s1 ELSE IF sp = 2 THEN s2 ... ELSE sD
+    static EP select(const std::vector<std::string> &slots, const std::string &sp, const Pos &at) {
+        EP acc = ident(slots.back(), at);
+        for (size_t k = slots.size() - 1; k-- > 0;) acc = ife(bin("=", ident(sp, at), num((long long)k + 1, at), at), ident(slots[k], at), acc, at);
+        return acc;
+    }
+    static void collect_calls(const std::vector<SP> &v, std::set<std::string> &out) {
+        for (const auto &s : v) {
+            if (s->k == Stmt::CALL) out.insert(s->var);
+            for (const auto &b : s->blocks) collect_calls(b, out);
+        }
+    }
+    void find_recursive() {
+        std::map<std::string, std::set<std::string>> g;
+        for (const auto &pr : m.procedures) collect_calls(pr.body, g[pr.name]);
+        for (const auto &pr : m.procedures) {
+            std::set<std::string> seen;
+            std::vector<std::string> todo(g[pr.name].begin(), g[pr.name].end());
+            while (!todo.empty()) {
+                const std::string x = todo.back();
+                todo.pop_back();
+                if (!seen.insert(x).second) continue;
+                for (const auto &y : g[x]) todo.push_back(y);
+            }
+            if (seen.count(pr.name)) recursive.insert(pr.name);
+        }
+    }
+    // `call P(args)` of a recursive procedure, in the caller's step: the stack must have room (an assertion: a run that needs more than
+    // $TLAMC_PCAL_STACK levels — default 4 — fails HERE, at the call, instead of being cut short silently); push the procedure's
+    // variables and the return site; parameters := arguments, locals := their initial values; goto the body's first label
+    std::vector<SP> call_recursive(const SP &s, const Procedure &pr, const std::string &label, Job &job, const std::map<std::string, std::string> &outer,
+                                   const std::string &after) {
+        const int D = stack_depth();
+        const bool first_call = !job.rec.count(pr.name);
+        Job::Rec &rc = job.rec[pr.name];
+        if (first_call) {
+            for (const auto &d : pr.params) rc.pv.push_back(&d);
+            for (const auto &d : pr.locals) rc.pv.push_back(&d);
+            {
+                std::set<std::string> own;
+                for (const VarDecl *d : rc.pv) own.insert(d->name);
+                for (const VarDecl *d : rc.pv)
+                    if (d->init && mentions(d->init, own))
+                        fail(d->pos, "the initial value of procedure variable " + d->name + " of " + pr.name +
+                                     " mentions another variable of the procedure: not supported (assign it in the body's first step instead)");
+            }
+            auto declare = [&](const std::string &nm, const VarDecl *like, const EP &init) {
+                if (!job.declared.insert(nm).second) return;
+                VarDecl l;
+                if (like) l = *like;
+                l.name = nm;
+                if (init) { l.init = init; l.no_init = false; l.in_set = false; }
+                job.proc->locals.push_back(l);
+            };
+            rc.sp = pr.name + "_sp" + job.suffix;
+            declare(rc.sp, nullptr, num(0, pr.pos));
+            for (int k = 1; k <= D; k++) {
+                rc.ret.push_back(pr.name + "_ret" + std::to_string(k) + job.suffix);
+                declare(rc.ret.back(), nullptr, num(0, pr.pos));
+            }
+            for (const VarDecl *d : rc.pv) {
+                if (d->in_set) fail(d->pos, "procedure variable " + d->name + ": `\\in` initial values are not supported in a recursive procedure");
+                const std::string nm = d->name + job.suffix;
+                rc.ren[d->name] = nm;
+                declare(nm, d, nullptr);
+                for (int k = 1; k <= D; k++) {
+                    rc.slot[d->name].push_back(d->name + "_stk" + std::to_string(k) + job.suffix);
+                    declare(rc.slot[d->name].back(), d, nullptr);
+                }
+            }
+            rc.entry = pr.body[0]->label + "_p" + std::to_string(++copies);
+        }
+        const Pos at = s->pos;
+        rc.sites.push_back(after);
+        const long long code = (long long)rc.sites.size();
+        std::vector<SP> out;
+        auto chk = std::make_shared<Stmt>();
+        chk->k = Stmt::ASSERT;
+        chk->pos = at;
+        chk->label = label;
+        chk->e = bin("<", ident(rc.sp, at), num(D, at), at);   // call stack of procedure P deeper than D: raise TLAMC_PCAL_STACK
+        out.push_back(chk);
+        // One step, its statements in an order in which none reads what an earlier one wrote — so they need not be ONE multiple
+        // assignment (whose right-hand sides the compiled program would all have to hold in temporaries): first the frame (reads the
+        // depth counter and the variables' values before the call), then parameters := arguments || locals := initial values (an
+        // argument may mention any of the procedure's own variables: `call down(n - 1)`), the depth counter last.
+        for (int k = 1; k <= D; k++) {
+            const EP here = bin("=", ident(rc.sp, at), num(k - 1, at), at);
+            out.push_back(assign(rc.ret[k - 1], ife(here, num(code, at), ident(rc.ret[k - 1], at), at), at));
+            for (const VarDecl *d : rc.pv) out.push_back(assign(rc.slot[d->name][k - 1], ife(here, ident(rc.ren[d->name], at), ident(rc.slot[d->name][k - 1], at), at), at));
+        }
+        SP first;
+        auto add = [&](const std::string &var, const EP &e) {
+            SP x = assign(var, e, at);
+            if (!first) first = x; else first->more.push_back(x);
+        };
+        for (size_t a = 0; a < pr.params.size(); a++) add(rc.ren[pr.params[a].name], rename(s->args[a], outer));
+        for (const auto &d : pr.locals) add(rc.ren[d.name], d.init);
+        if (first) out.push_back(first);
+        out.push_back(assign(rc.sp, bin("+", ident(rc.sp, at), num(1, at), at), at));
+        auto g = std::make_shared<Stmt>();
+        g->k = Stmt::GOTO;
+        g->pos = at;
+        g->var = rc.entry;
+        out.push_back(g);
+        if (first_call) {   // the ONE copy of the body in this process; its `return`s are IF statements filled in by finish_returns
+            const std::string lsuf = rc.entry.substr(pr.body[0]->label.size());
+            const std::map<std::string, std::string> inner = rc.ren;
+            std::vector<SP> body = expand(pr.body, job, inner, lsuf, std::string(), "@" + pr.name, {});
+            job.copies.insert(job.copies.end(), body.begin(), body.end());
+        }
+        return out;
+    }
+    // `return` of a recursive procedure: restore the variables from the top frame, clear the frame (a popped slot goes back to its
+    // initial value: two states must not differ in what lies ABOVE the stack), pop, and go where the frame says
+    void finish_returns(Job &job) {
+        const int D = stack_depth();
+        for (auto &kv : job.rec) {
+            Job::Rec &rc = kv.second;
+            for (auto &ph : rc.returns) {
+                const Pos at = ph.second;
+                // (again single assignments in an order in which none reads what an earlier one wrote: the variables from the top
+                //  frame, the frame back to its initial values, the depth counter last)
+                auto restore = [&]() {
+                    std::vector<SP> v;
+                    for (const VarDecl *d : rc.pv) v.push_back(assign(rc.ren[d->name], select(rc.slot[d->name], rc.sp, at), at));
+                    for (int k = 1; k <= D; k++) {
+                        const EP here = bin("=", ident(rc.sp, at), num(k, at), at);
+                        v.push_back(assign(rc.ret[k - 1], ife(here, num(0, at), ident(rc.ret[k - 1], at), at), at));
+                        for (const VarDecl *d : rc.pv) v.push_back(assign(rc.slot[d->name][k - 1], ife(here, d->init, ident(rc.slot[d->name][k - 1], at), at), at));
+                    }
+                    v.push_back(assign(rc.sp, bin("-", ident(rc.sp, at), num(1, at), at), at));
+                    return v;
+                };
+                auto jump = [&](const std::string &to) { auto g = std::make_shared<Stmt>(); g->k = Stmt::GOTO; g->pos = at; g->var = to; return g; };
+                // IF code = 1 THEN restore; goto site1 ELSE IF code = 2 ... ELSE (no such site: unreachable) assert FALSE; goto Done
+                std::vector<SP> tail;
+                {
+                    auto bad = std::make_shared<Stmt>();
+                    bad->k = Stmt::ASSERT;
+                    bad->pos = at;
+                    bad->e = mk(Expr::BOOL, at);   // FALSE
+                    tail = {bad, jump("Done")};
+                }
+                for (size_t i = rc.sites.size(); i-- > 0;) {
+                    const EP cond = bin("=", select(rc.ret, rc.sp, at), num((long long)i + 1, at), at);
+                    std::vector<SP> then = restore();
+                    then.push_back(jump(rc.sites[i]));
+                    if (i == 0) {
+                        ph.first->e = cond;
+                        ph.first->blocks = {then, tail};
+                    } else {
+                        auto nested = std::make_shared<Stmt>();
+                        nested->k = Stmt::IF;
+                        nested->pos = at;
+                        nested->e = cond;
+                        nested->blocks = {then, tail};
+                        tail = {nested};
+                    }
+                }
+            }
+        }
+    }
     // statements of `v` with the procedures' variables renamed, labels given the copy's suffix, calls / returns expanded.
     // `cont` = the label control reaches after the last statement of v ("" = unknown: a call may not be last then);
     // `ret` = the label a `return` goes to ("" = not inside a procedure); `reset` = what a return assigns
@@ -949,6 +1136,15 @@ struct ProcExpander {
             }
             if (s->k == Stmt::RETURN) {
                 if (ret.empty()) fail(s->pos, "`return` outside a procedure");
+                if (ret[0] == '@') {  // of a recursive procedure: where to is in the frame (finish_returns)
+                    auto ph = std::make_shared<Stmt>();
+                    ph->k = Stmt::IF;
+                    ph->pos = s->pos;
+                    ph->label = c->label;
+                    out.push_back(ph);
+                    job.rec[ret.substr(1)].returns.emplace_back(ph, s->pos);
+                    continue;
+                }
                 bool first = true;
                 for (const auto &r : reset) {
                     auto rc = std::make_shared<Stmt>(*r);
@@ -1001,10 +1197,11 @@ struct ProcExpander {
         const Procedure &pr = find(s);
         if (s->args.size() != pr.params.size())
             fail(s->pos, "procedure " + pr.name + " takes " + std::to_string(pr.params.size()) + " arguments");
-        for (const auto &a : job.active) if (a == pr.name) fail(s->pos, "recursive call of procedure " + pr.name + " (recursion is not supported: procedures are expanded where they are called)");
         if (pr.body.empty()) fail(pr.pos, "procedure " + pr.name + " has an empty body");
         if (pr.body[0]->label.empty()) fail(pr.body[0]->pos, "the first statement of procedure " + pr.name + " must have a label (p-manual section 3.5)");
         if (!ends_in_jump(pr.body)) fail(pr.body.back()->pos, "control can run off the end of procedure " + pr.name + ": it must end with `return` (or a `goto`) on every path");
+        if (recursive.count(pr.name)) return call_recursive(s, pr, label, job, outer, after);
+        for (const auto &a : job.active) if (a == pr.name) fail(s->pos, "recursive call of procedure " + pr.name + " (internal error: not recognised as recursive)");
         // the procedure's variables as locals of this process (once per process)
         std::map<std::string, std::string> ren;
         std::vector<const VarDecl *> pv;
@@ -1082,6 +1279,7 @@ struct ProcExpander {
             if (pr.body[0]->label.empty()) fail(pr.body[0]->pos, "the first statement of procedure " + pr.name + " must have a label (p-manual section 3.5)");
             if (!ends_in_jump(pr.body)) fail(pr.body.back()->pos, "control can run off the end of procedure " + pr.name + ": it must end with `return` (or a `goto`) on every path");
         }
+        find_recursive();
         int callers = 0;
         for (auto &p : m.procs) callers += uses_procedures(p.body) ? 1 : 0;
         for (auto &p : m.procs) {
@@ -1091,6 +1289,7 @@ struct ProcExpander {
             job.proc = &p;
             job.suffix = callers > 1 ? "_" + (p.name.empty() ? std::string("main") : p.name) : std::string();
             std::vector<SP> body = expand(p.body, job, {}, "", "Done", "", {});
+            finish_returns(job);
             if (!job.copies.empty()) {  // the process's own body must not run into the copies
                 if (body.empty() || body.back()->k != Stmt::GOTO) {
                     auto g = std::make_shared<Stmt>();

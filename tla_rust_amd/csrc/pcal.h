@@ -117,8 +117,18 @@ struct Module {
 // the step the statement was in.  For NON-RECURSIVE procedures this is a bijection on states with the translation pcal2tla gives
 // (pc + the contents of `stack` <-> the copy's pc; a frame's saved values are the initial values, which `return` restores), so
 // distinct / generated / depth and every verdict agree (tests/test_pcal.py checks it against hand-written stack translations);
-// what differs is the TEXT of the translation and of a printed state: no `stack` variable, the copies' label names.  Recursive
-// procedures and `call P(..); return` (pcal2tla's tail call) are refused with a message.
+// what differs is the TEXT of the translation and of a printed state: no `stack` variable, the copies' label names.
+// `call P(..); return` (pcal2tla's tail call) is refused with a message.
+// RECURSIVE procedures (round 5; a procedure that can reach itself through `call`, mutual recursion included) get ONE copy of the body per
+// calling process and a BOUNDED call stack per procedure, kept as plain variables: the depth counter P_sp, and for every level
+// K = 1 .. D (D = $TLAMC_PCAL_STACK, default 4) the return-site code P_retK and one slot vK per parameter / procedure variable v — what a
+// frame of pcal2tla's `stack` holds (the return pc and the values the procedure's variables had BEFORE the call).  `call`: assert
+// P_sp < D (a run that needs a deeper stack fails THERE, with the call's position, instead of being cut short silently), fill level
+// P_sp + 1, parameters := arguments, locals := initial values, goto the body's first label; `return`: branch on the top frame's
+// return-site code, restore the variables from it, put the frame back to its initial values (two states must not differ in what lies
+// above the stack), pop, goto the site.  pc + `stack` <-> pc + (P_sp, frames) is again a bijection on states — the return sites tell
+// how the per-procedure stacks interleave — so counts, depth and verdicts equal those of pcal2tla's translation for every run that
+// stays within D frames (tests/test_pcal.py: the hand-written stack translation tests/golden/pcal_recursion/RecursiveSumStack.tla).
 // RECORDS (round 4): a variable initialised with `[f |-> e, g |-> h]` (or `[x \in S |-> [f |-> e, ...]]`) is kept field by field —
 // variables r_f, r_g; `r.f` / `r[i].f` read them, `r.f := e` / `r[i].f := e` assign one, `r := [f |-> a, g |-> b]`, `r := s`
 // (s another record variable or an element of a record array) assign all fields at once (`||`), `r = s` / `r # s` compare

@@ -39,7 +39,9 @@ void all_labels(const std::vector<SP> &v, std::vector<std::string> &out) {
 // the right-hand side of the first `name := e` (whole variable or name[self]) in a statement list, or null
 const Expr *first_assignment(const std::vector<SP> &v, const std::string &name) {
     // (`x := defaultInitValue` — the expansion of a procedure's `return` — says nothing about what x holds otherwise)
-    auto tells = [](const SP &a) { return !(a->e && a->e->k == Expr::ID && a->e->s == "defaultInitValue"); };
+    // (... and neither does `x := IF c THEN defaultInitValue ELSE x`: a frame slot of a recursive procedure being cleared by a `return`)
+    auto is_default = [](const EP &e) { return e && e->k == Expr::ID && e->s == "defaultInitValue"; };
+    auto tells = [&](const SP &a) { return !(is_default(a->e) || (a->e && a->e->k == Expr::IF && is_default(a->e->a[1]))); };
     for (const auto &s : v) {
         if (s->k == Stmt::ASSIGN) {
             if (s->var == name && tells(s)) return s->e.get();
@@ -111,6 +113,7 @@ struct Compiler {
         fallthrough = true;
         if (depth > max_depth) max_depth = depth;
     }
+    bool copy_read = false;   // ex_rhs: the variable being compiled is only copied
     int new_temp(Pos p) {
         if (next_temp >= mc::SpecVm::TEMPS) cfail("expression too deeply nested (temporaries exhausted)", p);
         return next_temp++;
@@ -361,7 +364,7 @@ struct Compiler {
             if (vi != var_index.end()) {
                 const VarInfo &v = P.vars[(size_t)vi->second];
                 const bool per_self = proc && proc_locals.count(e->s) && proc->is_set && P.multi;
-                if (v.defval && !v.array == !per_self) {  // reading a variable that still is defaultInitValue is an evaluation error, as in TLC
+                if (v.defval && !v.array == !per_self && !copy_read) {  // reading a variable that still is defaultInitValue is an evaluation error, as in TLC
                     if (per_self) { push_self(e->pos); emit_indexed(mc::VM_LOADX, v, e->pos); } else emit(mc::VM_LOAD, v.base);
                     emit(mc::VM_PUSH, mc::VM_DEFAULT_INIT);
                     emit(mc::VM_NE);
@@ -675,6 +678,22 @@ struct Compiler {
             bool bound = false;
             for (const auto &b : binds) bound |= b.name == e->s;
             if (!bound) { emit(mc::VM_PUSH, mc::VM_DEFAULT_INIT); return; }
+        }
+        if (e->k == Expr::ID && var_index.count(e->s)) {  // `x := y`: COPYING a variable that still holds defaultInitValue is not an error (a frame
+            copy_read = true;                             //  of a recursive procedure saves its parameters as they are; TLC copies a model value too)
+            ex(e);
+            copy_read = false;
+            return;
+        }
+        if (e->k == Expr::IF) {  // ... and the branches of a conditional right-hand side (the frame slots of a recursive procedure's
+            ex(e->a[0]);         //     `return`: IF sp = K THEN defaultInitValue ELSE slot)
+            const int je = emit_jump(mc::VM_JZ);
+            ex_rhs(e->a[1]);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(je);
+            ex_rhs(e->a[2]);
+            patch(jend);
+            return;
         }
         ex(e);
     }
