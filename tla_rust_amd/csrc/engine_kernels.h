@@ -665,6 +665,34 @@ template <class S, class = void>
 struct HasSummaryWriter : std::false_type {};
 template <class S>
 struct HasSummaryWriter<S, decltype((void)S::SUMMARY_WRITER)> : std::true_type {};
+// The parent's Summary travels in REGISTERS, word by word: an aggregate passed by value goes through the stack, i.e. through scratch
+// memory — 48 bytes stored and loaded again per lane and call, 27 GB per step of the contract workload that the L2 had to hold beside
+// the seen-set lines and the parent rows (round 5; the kernel has no private segment left but the callee's one saved register).
+template <class S, size_t... I>
+__device__ __noinline__ void wave_write_survivors_r(typename S::Params prm_v, const uint64_t *arena_v, uint64_t pidx, bool mine, unsigned slot, uint64_t fp,
+                                                    uint64_t *arena_w_v, uint64_t oidx, std::index_sequence<I...>, decltype((void)I, uint64_t{})... qw) {
+    const typename S::Params prm = wave_uniform_copy(prm_v);
+    const uint64_t *arena = (const uint64_t *)uniform_ptr(arena_v);
+    uint64_t *arena_w = (uint64_t *)uniform_ptr(arena_w_v);
+    if (!mine) return;
+    const uint64_t words[] = {qw...};
+    typename S::Summary q;
+    static_assert(sizeof(q) == sizeof(words), "the Summary is passed as whole 64-bit words");
+    __builtin_memcpy(&q, words, sizeof q);
+    const int W = S::words(prm);
+    const CWordRef sp = arena_cref(arena, pidx, W);
+    if constexpr (HasSummaryWriter<S>::value) S::apply_summary_patch(prm, q, sp, (int)slot, fp, arena_ref(arena_w, oidx, W));
+    else if constexpr (HasKnownFp<S>::value) S::apply_known_fp(prm, sp, (int)slot, fp, arena_ref(arena_w, oidx, W));
+    else S::apply(prm, sp, (int)slot, arena_ref(arena_w, oidx, W));
+}
+template <class S, size_t... I>
+__device__ __forceinline__ void wave_write_survivors_split(typename S::Params prm, const uint64_t *arena, uint64_t pidx, bool mine, unsigned slot, uint64_t fp,
+                                                          uint64_t *arena_w, uint64_t oidx, const typename S::Summary &q, std::index_sequence<I...> seq) {
+    uint64_t words[sizeof...(I)];
+    __builtin_memcpy(words, &q, sizeof words);
+    wave_write_survivors_r<S>(prm, arena, pidx, mine, slot, fp, arena_w, oidx, seq, words[I]...);
+}
+#if defined(MC_SUMMARY_BY_STACK) && MC_SUMMARY_BY_STACK   // A/B: rounds 1-4's form, the Summary by value (= through scratch memory)
 template <class S>
 __device__ __noinline__ void wave_write_survivors(typename S::Params prm_v, const uint64_t *arena_v, uint64_t pidx, bool mine, unsigned slot, uint64_t fp,
                                                   uint64_t *arena_w_v, uint64_t oidx, typename S::Summary q) {
@@ -678,6 +706,14 @@ __device__ __noinline__ void wave_write_survivors(typename S::Params prm_v, cons
     else if constexpr (HasKnownFp<S>::value) S::apply_known_fp(prm, sp, (int)slot, fp, arena_ref(arena_w, oidx, W));
     else S::apply(prm, sp, (int)slot, arena_ref(arena_w, oidx, W));
 }
+#else
+template <class S>
+__device__ __forceinline__ void wave_write_survivors(typename S::Params prm, const uint64_t *arena, uint64_t pidx, bool mine, unsigned slot, uint64_t fp,
+                                                    uint64_t *arena_w, uint64_t oidx, const typename S::Summary &q) {
+    static_assert(sizeof(typename S::Summary) % 8 == 0, "the Summary is passed as whole 64-bit words");
+    wave_write_survivors_split<S>(prm, arena, pidx, mine, slot, fp, arena_w, oidx, q, std::make_index_sequence<sizeof(typename S::Summary) / 8>{});
+}
+#endif
 // classes of action slots whose successor construction shares a code path (S::NCLS, S::slot_class): the workgroup's tail sorts
 // its survivors by class, so that the 64 lanes of a batch walk one or two branches of the writer instead of all of them
 template <class S, class = void>

@@ -1216,9 +1216,11 @@ struct SpecRaft {
     // (one round trip to L2 / the Infinity Cache), (2) evaluates the action, (3) overwrites the handful of words it changes;
     // stores of one wavefront to one address stay in order.  About half the instructions of apply_copy_patch.
     static constexpr bool SUMMARY_WRITER = true;
+#if defined(MC_WRITER_TWICE) && MC_WRITER_TWICE   // A/B: round 4's form — copy the row, then overwrite the changed words
     template <class Ref>
     MC_HD static unsigned apply_summary_patch(const Params &prm, const Summary &q, Ref s, int slot, uint64_t fp_nz, WordRef out) {
         const int W = words(prm);
+        static_assert(W_FP == 0 && W_GLOB == 1, "the two words every successor rewrites are the row's first two");
         {
             uint64_t t[16];
 #pragma unroll
@@ -1226,8 +1228,9 @@ struct SpecRaft {
                 if (w0 < W) {
 #pragma unroll
                     for (int u = 0; u < 16; u++) t[u] = s.get(w0 + u < W ? w0 + u : W - 1);
+                    // (words 0 and 1 — fingerprint and globals — are rewritten by EVERY successor: not copied first, 2 of 17 stores less)
 #pragma unroll
-                    for (int u = 0; u < 16; u++) if (w0 + u < W) out.set(w0 + u, t[u]);
+                    for (int u = 0; u < 16; u++) if (w0 + u < W && w0 + u > W_GLOB) out.set(w0 + u, t[u]);
                 }
             }
         }
@@ -1236,7 +1239,11 @@ struct SpecRaft {
         Delta d;
         int action;
         const unsigned st = compute<true>(prm, l, s, slot, d, action);
-        if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) return st;  // not a successor: the parent itself (never the case for a survivor)
+        if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_SPECERR))) {  // not a successor: the parent itself (never the case for a survivor)
+            out.set(W_FP, s.get(W_FP));
+            out.set(W_GLOB, s.get(W_GLOB));
+            return st;
+        }
         // the fingerprint arrives with the survivor; the one ambiguous value (raw sum 0 or the substitute itself) is recomputed
         out.set(W_FP, fp_nz != fp_nonzero(0) ? fp_nz : delta_fp(prm, l, s, d));
         out.set(W_GLOB, pack_glob(d.glob, d.clog));
@@ -1277,6 +1284,111 @@ struct SpecRaft {
         }
         return st;
     }
+
+#else
+    // Round 5: EVERY WORD IS STORED ONCE.  Round 4's writer copied the row and then overwrote the words the action changes — stores whose
+    // word index differs from lane to lane (which server, which message slot), i.e. 8 bytes here and 8 bytes there into lines the copy had
+    // just written whole: the L2 handed 2.05 G write requests per step of the contract workload to the memory for 1.05 G sectors of rows
+    // (profiles/r05g_request_mix.json).  Now the action is evaluated first, its handful of (word, value) changes stay in registers, and
+    // the row is copied THROUGH them: a word is loaded, replaced if the successor changes it — the compare knows its class from the
+    // (compile-time) word index: fingerprint, globals, server i, message word, election word, allLogs word — and stored, 64 lanes =
+    // 512 contiguous bytes, once.
+    template <class Ref>
+    MC_HD static unsigned apply_summary_patch(const Params &prm, const Summary &q, Ref s, int slot, uint64_t fp_nz, WordRef out) {
+        const int W = words(prm);
+        static_assert(W_FP == 0 && W_GLOB == 1 && W_MSG0 == 2 + 2 * NS, "word classes by index: fingerprint, globals, NS x (server, voterLog), messages, elections, allLogs");
+        Local l;
+        local_of_summary<-1>(q, s, l);
+        Delta d;
+        int action;
+        const unsigned st = compute<true>(prm, l, s, slot, d, action);
+        const bool ok = (st & ST_ENABLED) && !(st & (ST_OVERFLOW | ST_SPECERR));  // (false: the parent itself is written — never the case for a survivor)
+        // the fingerprint arrives with the survivor; the one ambiguous value (raw sum 0 or the substitute itself) is recomputed
+        const uint64_t nfp = !ok ? 0ull : fp_nz != fp_nonzero(0) ? fp_nz : delta_fp(prm, l, s, d);
+        const uint64_t nglob = ok ? pack_glob(d.glob, d.clog) : 0ull;
+        const int srv = ok ? d.srv : -1;
+        const uint64_t nsrv = srv >= 0 ? pack_srv(d.sv, d.log) : 0ull;
+        const bool vch = srv >= 0 && d.vmode != 0;
+        const uint64_t nvl = !vch || d.vmode == 1 ? 0ull : vl_set(s.get(W_VL(srv)), d.vj, d.vlog, prm);
+        // the one or two message slots the action rewrites (both may share a word)
+        const int wa = d.midxA >> 1, wb = d.midxB >> 1;
+        bool hasA = false, hasB = false;
+        uint64_t xa = 0, xb = 0;
+        if (ok && (d.nmop & 1)) {
+            xa = 2 * wa < l.nm ? s.get(W_MSG0 + wa) : 0ull;
+            xa = set_half(xa, d.midxA, d.mnewA);
+            if ((d.nmop & 2) && wb == wa) xa = set_half(xa, d.midxB, d.mnewB);
+            hasA = true;
+        }
+        if (ok && (d.nmop & 2) && !((d.nmop & 1) && wb == wa)) { xb = set_half(s.get(W_MSG0 + wb), d.midxB, d.mnewB); hasB = true; }
+        const int nmw = msg_words(prm), wel = W_MSG0 + nmw, wall = wel + prm.ce * EL_WORDS;
+        const int e0 = ok && d.eadd ? g_ne(l.glob) * EL_WORDS : -1;   // election words e0, e0 + 1 (relative to wel)
+        // allLogs' additions (the same for every successor of this parent) land in slots na, na + 1, ...: at most NS of them, 4 per word
+        constexpr int ALLW = (NS + 3) / 4 + 1;
+        int qlo = 0, qhi = -1;
+        uint64_t xall[ALLW];
+#pragma unroll
+        for (int j = 0; j < ALLW; j++) xall[j] = 0;
+        if (ok && l.nadd) {
+            const int na = g_na(l.glob);
+            qlo = na >> 2;
+            qhi = (na + l.nadd - 1) >> 2;
+            if (qhi >= all_words(prm)) qhi = all_words(prm) - 1;
+#pragma unroll
+            for (int j = 0; j < ALLW; j++) {
+                const int qq = qlo + j;
+                if (qq <= qhi) {
+                    uint64_t x = qq * 4 < na ? s.get(wall + qq) : 0ull;
+                    int pos = na;
+#pragma unroll
+                    for (int i = 0; i < NS; i++)
+                        if (l.addmask >> i & 1) {
+                            if (pos < prm.ca && (pos >> 2) == qq) x |= (uint64_t)rd_log(s, i) << (16 * (pos & 3));
+                            pos++;
+                        }
+                    xall[j] = x;
+                }
+            }
+        }
+        uint64_t t[16];
+#pragma unroll
+        for (int w0 = 0; w0 < MAX_WORDS; w0 += 16) {
+            if (w0 < W) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) t[u] = s.get(w0 + u < W ? w0 + u : W - 1);
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int w = w0 + u;   // (a compile-time constant after unrolling)
+                    if (w >= W) continue;
+                    uint64_t v = t[u];
+                    if (w == W_FP) { if (ok) v = nfp; }
+                    else if (w == W_GLOB) { if (ok) v = nglob; }
+                    else if (w < W_MSG0) {
+                        const int i = (w - 2) >> 1;
+                        if (((w - 2) & 1) == 0) { if (srv == i) v = nsrv; }
+                        else if (vch && srv == i) v = nvl;
+                    } else {
+                        const int mw = w - W_MSG0;
+                        if (mw < nmw) {
+                            if (hasA && wa == mw) v = xa;
+                            if (hasB && wb == mw) v = xb;
+                        } else if (w < wall) {
+                            const int e = w - wel;
+#pragma unroll
+                            for (int k = 0; k < EL_WORDS; k++) if (e == e0 + k && e0 >= 0) v = d.ew.get(k);
+                        } else {
+                            const int qq = w - wall;
+#pragma unroll
+                            for (int j = 0; j < ALLW; j++) if (qq == qlo + j && qq <= qhi) v = xall[j];
+                        }
+                    }
+                    out.set(w, v);
+                }
+            }
+        }
+        return st;
+    }
+#endif
 
     // ---------------------------------------------------------------- host side: names and text
     static int action_of(const Params &prm, const uint64_t *parent, int slot) {
