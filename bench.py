@@ -399,10 +399,19 @@ def main():
                 comm.all_gather_u64(0)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                run()
+                try:
+                    run()
+                    mine = time.perf_counter() - t1
+                except amd.McError as e:   # (every rank leaves mc_shard_run with the same agreed code: every rank lands here, or none)
+                    print(f"bench.py: rank {rank}: the trial step in the {form} form failed ({e}); not chosen", file=sys.stderr)
+                    mine = float("inf")
                 torch.cuda.synchronize()
-                trial[form] = max(comm.all_gather_f64(time.perf_counter() - t1))
+                trial[form] = max(comm.all_gather_f64(mine))
             a.exchange = min(trial, key=trial.get)
+            if trial[a.exchange] == float("inf"):
+                print("bench.py: both trial steps failed", file=sys.stderr)
+                sys.exit(1)
+            trial = {k: (v if v != float("inf") else None) for k, v in trial.items()}
 
     def barrier():
         if use_dist:
@@ -464,7 +473,7 @@ def main():
         line["config"]["shares"] = shares
         line["config"]["exchange"] = a.exchange
         if trial is not None:
-            line["config"]["exchange_trial_ms"] = {k: 1e3 * v for k, v in trial.items()}   # (--exchange auto: one untimed step in each form)
+            line["config"]["exchange_trial_ms"] = {k: (1e3 * v if v is not None else None) for k, v in trial.items()}   # (--exchange auto: one untimed step in each form; null = it failed)
         line["per_rank"] = dict(per_rank, rounds=stats.get("rounds"), host_ms_per_round=[(e + c) / max(1, stats.get("rounds", 0))
                                 for e, c in zip(per_rank["engine_host_ms"], per_rank["collective_host_ms"])],
                                 note="last step; *_ms of kernels = summed HIP-event times on the engine's streams (they overlap each other); "

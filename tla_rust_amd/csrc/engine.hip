@@ -318,9 +318,10 @@ struct Engine : EngineBase {
     bool use_matrix = false;
     // fused runs of a by-family spec: the expand wavefronts write their own survivors (MC_F_NOINWAVE = A/B: everything through the
     // new-list and k_materialise, as in rounds 1-3)
-    double inwave_growth_limit = getenv("TLAMC_INWAVE_GROWTH") ? atof(getenv("TLAMC_INWAVE_GROWTH")) : 2.3;  // (A/B knob; profiles/r04l: t3 — levels
-    // grow by at most 2.2 x — is best with every level in-wave, 159.6 against 161.8 ms at 1.7; the 5-server model — 2.4 x and more on all
-    // 18 levels — with none, 230.6 against 239.0 ms)
+    double inwave_growth_limit = getenv("TLAMC_INWAVE_GROWTH") ? atof(getenv("TLAMC_INWAVE_GROWTH")) : 10.0;  // (A/B knob.  Round 4, profiles/r04l:
+    // t3 — levels grow by at most 2.2 x — was best with every level in-wave, the 5-server model — 2.4 x and more on all 18 levels — with
+    // none, 230.6 against 239.0 ms: the limit was 2.3.  Round 5: with the writer's scratch traffic gone the in-wave tail wins there too,
+    // 191.9 / 192.1 against 205.0 / 203.0 ms at 2.3 (profiles/r05i_raft5_inwave_growth.jsonl); 10 = in effect every level)
     bool inwave_ok() const { return UsesFamilies<S>::value && !use_matrix && !(cfg.flags & (MC_F_NOFAMILY | MC_F_NOINWAVE)); }
     void set_inwave(RouteArgs &rt) const {
         if (!inwave_ok()) return;
@@ -500,10 +501,8 @@ struct Engine : EngineBase {
                 prev_frontier = hi > lo ? hi - lo : 1;
                 continue;  // the loop head re-checks violation / budgets / frontier with the host's copies
             }
-            // IN-WAVE WRITES, level by level: they pay where a wavefront has about one survivor per parent (its list holds them
-            // all, one workgroup tail per 256 parents); in a level that grows fast (config 4's model: x 2.4 on every one of its 18
-            // levels) most survivors overflow into the new-list anyway and k_materialise alone is the better writer (924 M states:
-            // 234.7 against 239.0 ms, profiles/r04k).  The level before this one says which kind it is; the allocation mode
+            // IN-WAVE WRITES, level by level (inwave_growth_limit above: a level that grows faster than the limit goes through the
+            // new-list and k_materialise alone).  The level before this one says which kind it is; the allocation mode
             // (DevCounters::atomic_alloc) follows — nothing is in flight between two levels.
             const bool lvl_inwave = inwave_ok() && (double)(hi - lo) <= inwave_growth_limit * (double)prev_frontier;
             if (inwave_ok() && lvl_inwave != alloc_atomic) {
