@@ -62,6 +62,10 @@ CASES = [
     # forward, ghost tickets at the linearisation points; with a plain store instead of the linking CAS a node is lost and Fifo breaks (18-state trace)
     (SPECS / "pluscal" / "ms_queue.tla", ["PointersAreNodes", "TailLagsByOne", "NeverEmpty", "DequeuedOnce", "Fifo", "Conservation"], {"N": 2, "Racy": False}),
     (SPECS / "pluscal" / "ms_queue.tla", ["PointersAreNodes", "TailLagsByOne", "NeverEmpty", "DequeuedOnce", "Fifo", "Conservation"], {"N": 2, "Racy": True}),
+    # NESTED records (round 5; one level per pass, pcal.cpp RecordFlattener): the Michael-Scott queue as published — every pointer a (ptr, count)
+    # record inside the queue / node records, nodes freed and reused; Counted = FALSE compares the ptr halves only: ABA, Head swings to a freed node
+    (SPECS / "pluscal" / "ms_queue_counted.tla", ["HeadLive", "TailLive", "PointersAreNodes", "TailAtMostOneBehind", "CountsGrow"], {"N": 2, "K": 3, "Counted": True}),
+    (SPECS / "pluscal" / "ms_queue_counted.tla", ["HeadLive", "TailLive", "PointersAreNodes", "TailAtMostOneBehind", "CountsGrow"], {"N": 2, "K": 3, "Counted": False}),
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -483,6 +487,9 @@ RECORD_FIXTURES = ROOT / "tests" / "golden" / "pcal_records"
     ("treiber_records", "TreiberRecords", "TreiberRecords", {"N": 2}, ["PoppedOnce", "TopIsNode", "NextIsNode", "OldIsNode"]),
     ("ring_buffer", "RingBuffer", "RingBuffer", {"K": 3, "Items": 5, "Torn": False}, ["Fifo", "FullHasItem", "EmptyIsClean"]),
     ("ring_buffer", "RingBuffer", "RingBufferTorn", {"K": 3, "Items": 5, "Torn": True}, ["Fifo"]),
+    # nested records: Q.Head.ptr, mem[i].next.count — pcal2tla's EXCEPT !.Head, ![i].next.ptr against three passes of flattening
+    ("ms_queue_counted", "MsQueueCounted", "MsQueueCounted", {"N": 2, "K": 3, "Counted": True}, ["HeadLive", "TailLive", "PointersAreNodes", "TailAtMostOneBehind", "CountsGrow"]),
+    ("ms_queue_counted", "MsQueueCounted", "MsQueueUncounted", {"N": 2, "K": 3, "Counted": False}, ["HeadLive", "TailLive", "PointersAreNodes", "TailAtMostOneBehind", "CountsGrow"]),
 ])
 def test_records_field_by_field_equal_the_record_valued_translation(spec, fixture, cfg, consts, invs):
     """PlusCal record variables are kept FIELD BY FIELD (tla_rust_amd/csrc/pcal.h, RECORDS) instead of as one record-valued variable
@@ -531,6 +538,79 @@ def test_record_errors_are_refused_with_a_message(body, msg):
     with pytest.raises(RuntimeError) as e:
         helpers.pcal_translate(REC_HEAD + body)
     assert msg in str(e.value), str(e.value)
+
+
+NEST_HEAD = "---- MODULE M ----\nEXTENDS Naturals\n(* --algorithm M\nvariables r = [a |-> 0, b |-> FALSE], x = 0, n = [k |-> 0, inner |-> [p |-> 0, q |-> 0]];\n"
+NEST_ERRORS = [
+    # nested records (round 5)
+    ("begin L: r.a.z := 1; end algorithm *)\n====\n", "r.a is not a record"),
+    ("begin L: n.inner.c := 1; end algorithm *)\n====\n", "record n_inner has no field c"),
+    ("begin L: x := n.inner.c; end algorithm *)\n====\n", "the record has no field c"),
+    ("begin L: n.inner := 3; end algorithm *)\n====\n", "the value assigned to n.inner must be a record constructor"),
+    ("begin L: n.inner := r; end algorithm *)\n====\n", "the value assigned to n.inner does not have its fields"),
+    ("begin L: n.k := n.inner; end algorithm *)\n====\n", "a record is assigned to n.k"),
+    ("begin L: x := n.inner; end algorithm *)\n====\n", "a record is assigned to x"),
+    ("begin L: n.inner.p := 1 || n.inner := [p |-> 1, q |-> 2]; end algorithm *)\n====\n", "two assignments to n"),
+    ("begin L: n.inner.p := 1; n.k := 2; end algorithm *)\n====\n", "second assignment to n in one step"),
+    ("begin L: if n.inner = 3 then skip; end if; end algorithm *)\n====\n", "a record can only be compared with"),
+    ("begin Next: x := 1; end algorithm *)\n====\n", "the label `Next` has the name of a definition of the translation"),
+]
+
+
+@pytest.mark.parametrize("body,msg", NEST_ERRORS, ids=[m[:28] for _, m in NEST_ERRORS])
+def test_nested_record_errors_are_refused_with_a_message(body, msg):
+    with pytest.raises(RuntimeError) as e:
+        helpers.pcal_translate(NEST_HEAD + body)
+    assert msg in str(e.value), str(e.value)
+
+
+NESTED = r"""---- MODULE M ----
+EXTENDS Naturals
+(* --algorithm M
+variables r = [a |-> 0, f |-> [g |-> 1, h |-> [k |-> 2, l |-> FALSE]]],
+          s = [g |-> 5, h |-> [k |-> 7, l |-> TRUE]],
+          mem = [i \in 1..2 |-> [val |-> 0, next |-> [ptr |-> 0, ver |-> 0]]],
+          x = 0;
+begin
+ L1: r.f := s;
+ L2: r.f.h.k := r.f.g + 1 || r.a := 3;
+ L3: if r.f = s then x := 1; end if;
+ L4: mem[1].next := [ptr |-> 2, ver |-> mem[1].next.ver + 1];
+ L5: mem[2].next.ptr := mem[1].next.ptr || mem[2].val := 9;
+ L6: if mem[1].next # mem[2].next then x := r.f.h.k; end if;
+ L7: r := [a |-> 1, f |-> [g |-> 2, h |-> s.h]];
+ L8: mem[2] := mem[1];
+end algorithm *)
+Inv == r.f.h.k <= 10 /\ mem[1].next.ver <= 1 /\ (pc = "Done" => mem[2] = mem[1] /\ r.f.h = s.h /\ x = 6)
+====
+"""
+
+
+def test_nested_records_translate_level_by_level():
+    """NESTED records are flattened one level per pass (pcal.cpp RecordFlattener): r.f.h.k is the variable r_f_h_k; assigning or comparing
+    an inner record is the assignment / comparison of its leaves; the translation DEFINES every level (inner before outer) so that
+    the text around the algorithm keeps saying r.f.h.k; both routes run the straight-line program to the same single behaviour"""
+    tr = helpers.pcal_translate(NESTED)
+    for line in ["VARIABLES r_a, r_f_g, r_f_h_k, r_f_h_l, s_g, s_h_k, s_h_l, mem_val, mem_next_ptr, mem_next_ver, x, pc",
+                 "r_f_h == [k |-> r_f_h_k, l |-> r_f_h_l]\nr_f == [g |-> r_f_g, h |-> r_f_h]",
+                 "mem_next == [i \\in 1..2 |-> [ptr |-> mem_next_ptr[i], ver |-> mem_next_ver[i]]]",
+                 "mem == [i \\in 1..2 |-> [val |-> mem_val[i], next |-> mem_next[i]]]",
+                 "/\\ r_f_g' = s_g\n      /\\ r_f_h_k' = s_h_k\n      /\\ r_f_h_l' = s_h_l",
+                 "/\\ r_f_h_k' = r_f_g + 1\n      /\\ r_a' = 3",
+                 "IF (r_f_g = s_g /\\ (r_f_h_k = s_h_k /\\ r_f_h_l = s_h_l))",
+                 "/\\ mem_next_ptr' = [mem_next_ptr EXCEPT ![1] = 2]\n      /\\ mem_next_ver' = [mem_next_ver EXCEPT ![1] = mem_next_ver[1] + 1]",
+                 "/\\ mem_next_ptr' = [mem_next_ptr EXCEPT ![2] = mem_next_ptr[1]]\n      /\\ mem_val' = [mem_val EXCEPT ![2] = 9]",
+                 "/\\ r_a' = 1\n      /\\ r_f_g' = 2\n      /\\ r_f_h_k' = s_h_k\n      /\\ r_f_h_l' = s_h_l"]:
+        assert line in tr, (line, tr)
+    assert tr.index("r_f_h ==") < tr.index("r_f ==") < tr.index("\nr ==")
+    o = Checker(tr).run_levels(invariants=["Inv"])
+    prog = helpers.ShimProgram(NESTED, ["Inv"], {})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (o["distinct"], o["generated"], o["depth"], o["verdict"], o["levels"])
+    assert o["verdict"] == "ok" and o["distinct"] == 9
 
 
 def test_records_translate_like_their_fields():

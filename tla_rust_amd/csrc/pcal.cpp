@@ -118,6 +118,13 @@ std::vector<Tok> lex(const std::string &text, size_t b, size_t e) {
     return out;
 }
 
+// two field paths of one record variable ("" = the whole record, "f", "f.g") name overlapping parts when one is a prefix of the other
+static bool paths_overlap(const std::string &a, const std::string &b) {
+    if (a.empty() || b.empty() || a == b) return true;
+    const std::string &sh = a.size() < b.size() ? a : b, &lg = a.size() < b.size() ? b : a;
+    return lg.compare(0, sh.size(), sh) == 0 && lg[sh.size()] == '.';
+}
+
 // ------------------------------------------------------------------------------------------ parser
 struct ParseError { std::string msg; };
 
@@ -522,7 +529,7 @@ struct Parser {
         s.k = Stmt::ASSIGN;
         s.var = t[i++].s;
         if (is_sym("[")) { i++; s.idx = expr(0); expect_sym("]"); if (is_sym("[")) fail("only one index level is supported on the left of `:=`"); }
-        if (is_sym(".")) { i++; s.field = ident("a field name after `.`"); if (is_sym("[") || is_sym(".")) fail("only `r.f` and `r[i].f` are supported on the left of `:=`"); }
+        s.field = field_path();
         expect_sym(":=");
         s.e = expr(0);
         while (is_sym("||")) {  // a := e || b := f: simultaneous
@@ -532,17 +539,28 @@ struct Parser {
             o->pos = {cur().line, cur().col};
             o->var = ident("a variable after `||`");
             if (is_sym("[")) { i++; o->idx = expr(0); expect_sym("]"); }
-            if (is_sym(".")) { i++; o->field = ident("a field name after `.`"); }
+            o->field = field_path();
             expect_sym(":=");
             o->e = expr(0);
-            // (two FIELDS of one record, `r.f := a || r.g := b`, are two variables here: pcal.h, RECORDS)
-            auto same = [&](const Stmt &x) { return x.var == o->var && (x.field.empty() || o->field.empty() || x.field == o->field); };
+            // (two FIELDS of one record, `r.f := a || r.g := b`, are two variables here: pcal.h, RECORDS; with nested records two
+            //  paths collide when one is a prefix of the other: `r.f := .. || r.f.g := ..`)
+            auto same = [&](const Stmt &x) { return x.var == o->var && paths_overlap(x.field, o->field); };
             if (same(s)) fail("`||` with two assignments to " + s.var + " is not supported");
             for (const auto &x : s.more) if (same(*x)) fail("`||` with two assignments to " + o->var + " is not supported");
             s.more.push_back(o);
         }
     }
 
+    // the field path on the left of `:=`: "" | "f" | "f.g" ... (r.f.g := e, r[i].f.g := e — nested records, pcal.h RECORDS)
+    std::string field_path() {
+        std::string path;
+        while (is_sym(".")) {
+            i++;
+            path += (path.empty() ? "" : ".") + ident("a field name after `.`");
+            if (is_sym("[")) fail("only `r.f...` and `r[i].f...` are supported on the left of `:=`");
+        }
+        return path;
+    }
     // ---- c-syntax (p-manual App. A): braces instead of begin/end, tests in parentheses; same AST
     std::vector<SP> c_block() {  // { stmt; stmt; ... }
         expect_sym("{");
@@ -1310,36 +1328,108 @@ struct ProcExpander {
 // ---- records: kept field by field (pcal.h, RECORDS)
 namespace {
 struct FlattenError { std::string msg; };
+// NESTED records (round 5): one LEVEL per pass.  Pass k replaces every variable whose value is a record constructor by one variable per
+// field; a field whose own value is a constructor becomes a variable with a record value (`pending`), which pass k + 1 replaces in turn:
+// r = [a |-> 0, f |-> [g |-> 1, h |-> 2]]  ->  r_a, r_f = [g |-> 1, h |-> 2]  ->  r_a, r_f_g, r_f_h.  Expressions follow: `r.f.g` is
+// `r_f.g` after pass k and `r_f_g` after pass k + 1; a record value that has to survive a pass (the right-hand side of `r.f := ...`,
+// an operand of `=`) is handed on as a constructor over the fields' variables (as_value).
 struct RecordFlattener {
     Module &m;
-    std::map<std::string, RecordVar> recs;   // by name (copies: m.records grows while they are collected)
+    std::map<std::string, RecordVar> recs;   // the record variables THIS pass replaces, by name
+    std::map<std::string, EP> shapes;        // their constructors, and those of the variables this pass declares with a record value
+    std::set<std::string> pending;           // ... the latter: the next pass's record variables
+    int depth = 0;
     [[noreturn]] static void fail(const Pos &at, const std::string &msg) { throw FlattenError{"line " + std::to_string(at.line) + ", column " + std::to_string(at.col) + ": " + msg}; }
     static EP node(Expr::K k, const Pos &at) { auto e = std::make_shared<Expr>(); e->k = k; e->pos = at; return e; }
     static EP id(const std::string &name, const Pos &at) { auto e = node(Expr::ID, at); e->s = name; return e; }
-    const RecordVar *rec_of(const EP &e) const {  // r or r[i] of a record variable r
+    static const std::string &base_name(const EP &e) {  // of r or r[i]
+        static const std::string none;
         const EP &b = e->k == Expr::INDEX ? e->a[0] : e;
-        if (b->k != Expr::ID) return nullptr;
-        auto it = recs.find(b->s);
+        return b->k == Expr::ID ? b->s : none;
+    }
+    const RecordVar *rec_of(const EP &e) const {  // r or r[i] of a record variable r of this pass
+        auto it = recs.find(base_name(e));
         return it == recs.end() ? nullptr : &it->second;
     }
-    bool record_valued(const EP &e) const { return e->k == Expr::RECORD || ((e->k == Expr::ID || e->k == Expr::INDEX) && rec_of(e)); }
-    std::vector<std::string> fields_of(const EP &e) const { return e->k == Expr::RECORD ? e->names : rec_of(e)->fields; }
+    bool pending_ref(const EP &e) const { return (e->k == Expr::ID || e->k == Expr::INDEX) && pending.count(base_name(e)) != 0; }
+    static int field_index(const EP &rec, const std::string &f) {
+        for (size_t i = 0; i < rec->names.size(); i++) if (rec->names[i] == f) return (int)i;
+        return -1;
+    }
+    // the constructor that says which fields a record-valued expression has (null: not a record value)
+    EP shape(const EP &e) const {
+        if (!e) return nullptr;
+        if (e->k == Expr::RECORD) return e;
+        if (e->k == Expr::ID || e->k == Expr::INDEX) {
+            const std::string &n = base_name(e);
+            if (!n.empty()) {
+                auto it = shapes.find(n);
+                return it == shapes.end() ? nullptr : it->second;
+            }
+            if (e->k == Expr::INDEX && e->a[0]->k == Expr::DOT) {  // r.f[i]: an element of a field that is a function to records
+                const EP sb = shape(e->a[0]->a[0]);
+                const int k = sb ? field_index(sb, e->a[0]->s) : -1;
+                if (k >= 0 && sb->a[(size_t)k]->k == Expr::FUNCDEF && sb->a[(size_t)k]->a[1]->k == Expr::RECORD) return sb->a[(size_t)k]->a[1];
+            }
+            return nullptr;
+        }
+        if (e->k == Expr::DOT) {
+            const EP sb = shape(e->a[0]);
+            const int k = sb ? field_index(sb, e->s) : -1;
+            return k >= 0 && sb->a[(size_t)k]->k == Expr::RECORD ? sb->a[(size_t)k] : nullptr;
+        }
+        return nullptr;
+    }
+    bool record_valued(const EP &e) const { return shape(e) != nullptr; }
+    std::vector<std::string> fields_of(const EP &e) const { return shape(e)->names; }
     static void check_field(const RecordVar &r, const std::string &f, const Pos &at) {
         for (const auto &x : r.fields) if (x == f) return;
         fail(at, "record " + r.name + " has no field " + f);
     }
+    EP with_index(const EP &e) const {  // r or r[i] of a variable that stays for the next pass: the index is rewritten now
+        if (e->k != Expr::INDEX) return e;
+        auto c = std::make_shared<Expr>(*e);
+        c->a[1] = rw(e->a[1]);
+        return c;
+    }
+    // a record value as the NEXT pass reads it: a constructor over the fields' variables, or a variable the next pass replaces
+    EP as_value(const EP &e) const {
+        if (e->k == Expr::RECORD) {
+            auto c = std::make_shared<Expr>(*e);
+            for (auto &x : c->a) x = record_valued(x) ? as_value(x) : rw(x);
+            return c;
+        }
+        if (const RecordVar *r = rec_of(e)) {
+            auto c = node(Expr::RECORD, e->pos);
+            c->names = r->fields;
+            for (const auto &f : r->fields) c->a.push_back(field_of(e, f));
+            return c;
+        }
+        if (pending_ref(e)) return with_index(e);
+        return rw(e);  // a path `x.f` to a record-valued field
+    }
     // field f of a record-valued expression
     EP field_of(const EP &e, const std::string &f) const {
         if (e->k == Expr::RECORD) {
-            for (size_t i = 0; i < e->names.size(); i++) if (e->names[i] == f) return rw(e->a[i]);
-            fail(e->pos, "the record has no field " + f);
+            const int k = field_index(e, f);
+            if (k < 0) fail(e->pos, "the record has no field " + f);
+            const EP &v = e->a[(size_t)k];
+            return record_valued(v) ? as_value(v) : rw(v);
         }
-        const RecordVar &r = *rec_of(e);
-        check_field(r, f, e->pos);
-        if (e->k == Expr::ID) return id(r.name + "_" + f, e->pos);
-        auto x = node(Expr::INDEX, e->pos);
-        x->a = {id(r.name + "_" + f, e->a[0]->pos), rw(e->a[1])};
-        return x;
+        if (const RecordVar *r = rec_of(e)) {
+            check_field(*r, f, e->pos);
+            if (e->k == Expr::ID) return id(r->name + "_" + f, e->pos);
+            auto x = node(Expr::INDEX, e->pos);
+            x->a = {id(r->name + "_" + f, e->a[0]->pos), rw(e->a[1])};
+            return x;
+        }
+        // a deeper level: the path is resolved as far as this pass can, the rest is the next pass's
+        const EP sb = shape(e);
+        if (!sb || field_index(sb, f) < 0) fail(e->pos, "the record has no field " + f);
+        auto d = node(Expr::DOT, e->pos);
+        d->s = f;
+        d->a = {as_value(e)};
+        return d;
     }
     static bool same_fields(std::vector<std::string> a, std::vector<std::string> b) {
         std::sort(a.begin(), a.end());
@@ -1350,8 +1440,23 @@ struct RecordFlattener {
         if (!e) return e;
         switch (e->k) {
         case Expr::DOT: {
-            const EP &b = e->a[0];
-            if (b->k == Expr::RECORD || ((b->k == Expr::ID || b->k == Expr::INDEX) && rec_of(b))) return field_of(b, e->s);
+            EP b = e->a[0];
+            if (b->k == Expr::DOT) b = rw(b);  // the inner path first: r.f.g
+            else if (b->k == Expr::INDEX && b->a[0]->k == Expr::DOT) {  // r.f[i].g
+                auto c = std::make_shared<Expr>(*b);
+                c->a[0] = rw(b->a[0]);
+                c->a[1] = rw(b->a[1]);
+                b = c;
+            }
+            if (b->k == Expr::RECORD || rec_of(b)) return field_of(b, e->s);
+            if (pending_ref(b) || b->k == Expr::DOT) {  // a field of a record this pass has only just made a variable of (or a path into it): the next pass's
+                const EP sb = shape(b);
+                if (!sb) fail(e->pos, "`." + e->s + "`: not a field of a record");
+                if (field_index(sb, e->s) < 0) fail(e->pos, "the record has no field " + e->s);
+                auto c = std::make_shared<Expr>(*e);
+                c->a = {b->k == Expr::DOT ? b : with_index(b)};
+                return c;
+            }
             fail(e->pos, "`." + e->s + "`: field access is supported on record variables (r." + e->s + ", r[i]." + e->s + ") only");
         }
         case Expr::BINOP:
@@ -1363,7 +1468,7 @@ struct RecordFlattener {
                 for (const auto &f : fs) {
                     auto eq = node(Expr::BINOP, e->pos);
                     eq->s = "=";
-                    eq->a = {field_of(e->a[0], f), field_of(e->a[1], f)};
+                    eq->a = {field_of(e->a[0], f), field_of(e->a[1], f)};   // (record-valued fields: a comparison of records for the next pass)
                     if (!acc) { acc = eq; continue; }
                     auto both = node(Expr::BINOP, e->pos);
                     both->s = "/\\";
@@ -1390,9 +1495,9 @@ struct RecordFlattener {
         for (auto &x : c->a) x = rw(x);
         return c;
     }
-    // one assignment `var[idx].field := e` -> the assignments to the fields' variables
+    // one assignment `var[idx].path := e` -> the assignments to the fields' variables
     void assignment(const Stmt &a, std::vector<SP> &out) const {
-        auto mk = [&](const std::string &var, const EP &idx, const EP &e, const std::string &whole) {
+        auto mk = [&](const std::string &var, const EP &idx, const EP &e, const std::string &whole, const std::string &path) {
             auto o = std::make_shared<Stmt>();
             o->k = Stmt::ASSIGN;
             o->pos = a.pos;
@@ -1400,26 +1505,44 @@ struct RecordFlattener {
             o->idx = idx;
             o->e = e;
             o->whole = whole;
-            for (const auto &x : out) if (x->var == var) fail(a.pos, "two assignments to " + var + " in one statement");
+            o->field = path;
+            for (const auto &x : out) if (x->var == var && paths_overlap(x->field, path)) fail(a.pos, "two assignments to " + var + " in one statement");
             out.push_back(o);
         };
         auto it = recs.find(a.var);
         if (it == recs.end()) {
             if (!a.field.empty()) fail(a.pos, a.var + " is not a record variable (its initial value is not a record constructor)");
             if (record_valued(a.e)) fail(a.e->pos, "a record is assigned to " + a.var + ", which is not a record variable (its initial value is not a record constructor)");
-            mk(a.var, rw(a.idx), rw(a.e), "");
+            mk(a.var, rw(a.idx), rw(a.e), a.whole, "");
             return;
         }
         const RecordVar &r = it->second;
+        const std::string root = a.whole.empty() ? r.name : a.whole;   // the one variable pcal2tla sees (one assignment per step)
         if (r.array != (a.idx != nullptr)) fail(a.pos, r.array ? "assignment to the whole record array " + r.name + " (supported: " + r.name + "[i] := ..., " + r.name + "[i].f := ...)" : r.name + " is a record, not an array of records");
         if (!a.field.empty()) {
-            check_field(r, a.field, a.pos);
-            mk(r.name + "_" + a.field, rw(a.idx), rw(a.e), r.name);
+            const size_t dot = a.field.find('.');
+            const std::string first = a.field.substr(0, dot), rest = dot == std::string::npos ? std::string() : a.field.substr(dot + 1);
+            check_field(r, first, a.pos);
+            const bool sub = std::find(r.sub.begin(), r.sub.end(), first) != r.sub.end();
+            if (!rest.empty()) {
+                if (!sub) fail(a.pos, r.name + "." + first + " is not a record");
+                mk(r.name + "_" + first, rw(a.idx), record_valued(a.e) ? as_value(a.e) : rw(a.e), root, rest);
+                return;
+            }
+            if (sub) {
+                const EP want = shapes.at(r.name)->a[(size_t)field_index(shapes.at(r.name), first)];
+                if (!record_valued(a.e)) fail(a.e->pos, "the value assigned to " + r.name + "." + first + " must be a record constructor, a record variable or an element of a record array");
+                if (!same_fields(want->names, fields_of(a.e))) fail(a.e->pos, "the value assigned to " + r.name + "." + first + " does not have its fields");
+                mk(r.name + "_" + first, rw(a.idx), as_value(a.e), root, "");
+                return;
+            }
+            if (record_valued(a.e)) fail(a.e->pos, "a record is assigned to " + r.name + "." + first + ", which is not a record (its initial value is not a record constructor)");
+            mk(r.name + "_" + first, rw(a.idx), rw(a.e), root, "");
             return;
         }
         if (!record_valued(a.e)) fail(a.e->pos, "the value assigned to record variable " + r.name + " must be a record constructor, a record variable or an element of a record array");
         if (!same_fields(r.fields, fields_of(a.e))) fail(a.e->pos, "the value assigned to " + r.name + " does not have its fields");
-        for (const auto &f : r.fields) mk(r.name + "_" + f, rw(a.idx), field_of(a.e, f), r.name);
+        for (const auto &f : r.fields) mk(r.name + "_" + f, rw(a.idx), field_of(a.e, f), root, "");
     }
     void stmts(std::vector<SP> &v) const {
         for (auto &s : v) {
@@ -1455,48 +1578,70 @@ struct RecordFlattener {
             r.fields = rc->names;
             r.array = array;
             r.proc = proc;
+            r.depth = depth;
             if (array) { r.bound = e->bound; r.domain = e->a[0]; }
             for (size_t i = 0; i < rc->names.size(); i++) {
-                if (rc->a[i]->k == Expr::RECORD) fail(rc->a[i]->pos, "nested records are not supported");
                 VarDecl f = d;
                 f.name = d.name + "_" + rc->names[i];
                 if (taken.count(f.name)) fail(d.pos, "field " + rc->names[i] + " of record variable " + d.name + " is kept as a variable " + f.name + ", and that name is taken");
                 if (scalar) f.init = rc->a[i];
                 else { auto fn = std::make_shared<Expr>(*e); fn->a[1] = rc->a[i]; f.init = fn; }
+                if (rc->a[i]->k == Expr::RECORD) {  // a nested record: the next pass's record variable
+                    if (depth >= 6) fail(rc->a[i]->pos, "records nest too deeply");
+                    r.sub.push_back(rc->names[i]);
+                    pending.insert(f.name);
+                    shapes[f.name] = rc->a[i];
+                } else if (scalar && rc->a[i]->k == Expr::FUNCDEF && rc->a[i]->a[1]->k == Expr::RECORD) {  // a function to records: the next pass's record ARRAY
+                    if (depth >= 6) fail(rc->a[i]->pos, "records nest too deeply");
+                    pending.insert(f.name);
+                    shapes[f.name] = rc->a[i]->a[1];
+                } else if (array && rc->a[i]->k == Expr::FUNCDEF) {
+                    fail(rc->a[i]->pos, "a function as a field of an ELEMENT of a record array is not supported (" + d.name + "[i]." + rc->names[i] + "[j])");
+                }
                 out.push_back(f);
             }
+            shapes[r.name] = rc;
             m.records.push_back(r);
+            recs[r.name] = r;
         }
         v = out;
     }
     void run() {
-        std::set<std::string> taken(m.constants.begin(), m.constants.end());
-        for (const auto &g : m.globals) taken.insert(g.name);
-        for (const auto &p : m.procs) for (const auto &l : p.locals) taken.insert(l.name);
-        for (const auto &d : m.defs) taken.insert(d.name);
-        decls(m.globals, -1, taken);
-        for (size_t k = 0; k < m.procs.size(); k++) decls(m.procs[k].locals, (int)k, taken);
-        for (const auto &r : m.records) {
-            if (recs.count(r.name)) fail(Pos{m.alg_first_line, 1}, "two record variables named " + r.name);
-            recs[r.name] = r;
-        }
-        // (without a record variable too: a `.f` or a record constructor anywhere is refused by rw(), with its position)
-        for (auto &g : m.globals) g.init = rw(g.init);
-        for (auto &p : m.procs) {
-            for (auto &l : p.locals) l.init = rw(l.init);
-            stmts(p.body);
-        }
-        for (auto &d : m.defs) {
-            try {
-                d.body = rw(d.body);
-            } catch (const FlattenError &) {
-                if (d.in_define) throw;
-                d.body = nullptr;  // a definition of the module text beyond the subset: unusable as an invariant, like an unparsed one
+        for (depth = 0;; depth++) {
+            std::set<std::string> taken(m.constants.begin(), m.constants.end());
+            for (const auto &g : m.globals) taken.insert(g.name);
+            for (const auto &p : m.procs) for (const auto &l : p.locals) taken.insert(l.name);
+            for (const auto &d : m.defs) taken.insert(d.name);
+            for (const auto &r : m.records) taken.insert(r.name);   // (a replaced record's name stays a DEFINITION of the translation)
+            recs.clear();
+            shapes.clear();
+            pending.clear();
+            const size_t before = m.records.size();
+            decls(m.globals, -1, taken);
+            for (size_t k = 0; k < m.procs.size(); k++) decls(m.procs[k].locals, (int)k, taken);
+            if (depth > 0 && m.records.size() == before) break;  // nothing left to replace
+            // (pass 0 without a record variable too: a `.f` or a record constructor anywhere is refused by rw(), with its position)
+            for (auto &g : m.globals) g.init = pending.count(g.name) ? g.init : rw(g.init);
+            for (auto &p : m.procs) {
+                for (auto &l : p.locals) l.init = pending.count(l.name) ? l.init : rw(l.init);
+                stmts(p.body);
             }
+            for (auto &d : m.defs) {
+                try {
+                    d.body = rw(d.body);
+                } catch (const FlattenError &) {
+                    if (d.in_define) throw;
+                    d.body = nullptr;  // a definition of the module text beyond the subset: unusable as an invariant, like an unparsed one
+                }
+            }
+            std::vector<Definition> kept;
+            for (auto &d : m.defs) if (d.body) kept.push_back(d);
+            m.defs = kept;
+            if (pending.empty()) break;
         }
-        std::vector<Definition> kept;
-        for (auto &d : m.defs) if (d.body) kept.push_back(d);
-        m.defs = kept;
+        // the translation DEFINES every replaced record from its fields' variables (`r == [f |-> r_f, ...]`): an inner record before
+        // the record that holds it
+        std::stable_sort(m.records.begin(), m.records.end(), [](const RecordVar &a, const RecordVar &b) { return a.depth > b.depth; });
     }
 };
 }  // namespace
@@ -1556,6 +1701,20 @@ std::string parse_module(const std::string &text, Module &m) {
             auto declare = [&](const VarDecl &d) { return names.insert(d.name).second; };
             for (const auto &g : m.globals) if (!declare(g)) return "variable `" + g.name + "` is declared twice";
             for (const auto &p : m.procs) for (const auto &l : p.locals) if (!declare(l)) return "variable `" + l.name + "` is declared twice (a variable of one process may not have the name of a global variable or of another process's variable)";
+        }
+        {   // a label becomes a DEFINITION of the translation (one action per label): it may not take the name of one the translation
+            // writes itself (pcal2tla renames such a label; here the author does) — `Next: ...` would make `Next` call itself
+            std::set<std::string> own{"Init", "Next", "Spec", "Termination", "vars", "ProcSet"};
+            for (const auto &p : m.procs) if (!p.name.empty()) own.insert(p.name);
+            std::function<std::string(const std::vector<SP> &)> clash = [&](const std::vector<SP> &v) -> std::string {
+                for (const auto &st : v) {
+                    if (!st->label.empty() && own.count(st->label))
+                        return "line " + std::to_string(st->pos.line) + ": the label `" + st->label + "` has the name of a definition of the translation (Init, Next, Spec, Termination, vars, ProcSet, a process): rename it";
+                    for (const auto &b : st->blocks) { const std::string r = clash(b); if (!r.empty()) return r; }
+                }
+                return "";
+            };
+            for (const auto &p : m.procs) { const std::string r = clash(p.body); if (!r.empty()) return r; }
         }
         // the rest: an existing translation (skipped) and the definitions
         size_t rest = cend;
@@ -1623,7 +1782,7 @@ std::string parse_module(const std::string &text, Module &m) {
             }
         }
         try {
-            RecordFlattener{m, {}}.run();
+            RecordFlattener{m}.run();
         } catch (const FlattenError &e) {
             return e.msg;
         }

@@ -79,6 +79,8 @@ struct RecordVar {
     std::string bound;                 // array: x
     EP domain;                         // array: S
     int proc = -1;                     // index into Module::procs of the process it is local to, -1 = global
+    std::vector<std::string> sub;      // the fields that are records themselves (nested records): r_f is a RecordVar of depth + 1
+    int depth = 0;                     // 0 = a variable of the algorithm, k = a field of a record of depth k - 1
 };
 
 struct Definition {

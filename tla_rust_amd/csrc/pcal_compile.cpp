@@ -1068,9 +1068,11 @@ struct Compiler {
                 if (per_inst) add_var(d.name, true, ids_of[owner], 'i');
                 else add_var(d.name, false, {}, 'i');
                 P.vars.back().defval = true;
-            } else if (d.init->k == Expr::SETENUM && !d.in_set) {  // a set of small naturals / strings: one mask cell (per instance)
-                if (per_inst) add_var(d.name, true, ids_of[owner], d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
-                else add_var(d.name, false, {}, d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
+            } else if ((d.init->k == Expr::SETENUM || (d.init->k == Expr::BINOP && d.init->s == "..")) && !d.in_set) {
+                // a set of small naturals / strings — {...}, or an interval a..b of constants as its initial value (`free = 3..K`): one mask cell (per instance)
+                const char et = d.init->k == Expr::BINOP || d.init->a.empty() ? 'i' : type_of(d.init->a[0]);
+                if (per_inst) add_var(d.name, true, ids_of[owner], et);
+                else add_var(d.name, false, {}, et);
                 P.vars.back().set = true;
             } else if (d.init->k == Expr::TUPLE && !d.in_set) {  // a sequence
                 if (per_inst) cfail("sequence variables local to a process SET are not supported (`" + d.name + "`)", d.pos);
