@@ -298,7 +298,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-atomic-add", action="store_true", help="skip the synthetic N-process atomic-counter object of the line")
     ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
-    ap.add_argument("--chunk", type=int, default=1 << 23)   # frontier states per launch (the engine's maximum: 160.5 ms per step against 163.6 at 2^22, 169.4 at 2^21)
+    ap.add_argument("--chunk", type=int, default=(1 << 24) - 256)   # frontier states per launch: the engine's maximum (a column index has 24 bits).  Round 3: 169.4 / 163.6 / 160.5 ms
+    # per step at 2^21 / 2^22 / 2^23; round 5 (profiles/r05k_ab.jsonl): 2^24 - 256 against 2^23 = 135.3 against 135.5 - 136.3 ms on t3 (70 launches instead of 102),
+    # 91.4 against 92.7 on k11, 181 - 184 against 192 - 197 on raft5
     ap.add_argument("--shard-chunk", type=int, default=0, help="frontier states per round and rank in the sharded (--gpus N) path; 0 = 2^23 at world "
                     "size 1 (one engine launch per round: 168.9 ms per step against 184.1 at 2^21), 2^21 otherwise (several rounds per level, so that "
                     "the exchange of round r+1 overlaps the probes of round r)")

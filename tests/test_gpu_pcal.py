@@ -38,7 +38,7 @@ def cfg_text(invs, consts):
 
 # (the Michael-Scott queue was added after the round's last GPU minute: its GPU cases live in tests/test_gpu_zz_ms_queue.py, which sorts
 #  behind every other GPU file — under the driver's `pytest -x` a surprise there cannot keep the rest of the suite from running)
-GPU_CASES = [c for c in CASES if c[0].stem != "ms_queue"]
+GPU_CASES = [c for c in CASES if not c[0].stem.startswith("ms_queue")]
 
 
 @pytest.mark.parametrize("path,invs,consts", GPU_CASES, ids=lambda v: v.stem if isinstance(v, Path) else None)

@@ -225,7 +225,7 @@ struct Engine : EngineBase {
         seen_sparse = table_cap >= 3 * arena_cap && table_cap / MC_SPARSE_SLOTS <= 0xffffffffull && !getenv("TLAMC_DENSE_TABLE");
         chunk = cfg.chunk_states ? cfg.chunk_states : (1ull << 18);
         chunk = (chunk + 255) & ~255ull;
-        if (chunk > (1ull << 23)) chunk = 1ull << 23;  // a column index must fit 24 bits
+        if (chunk > (1ull << 24) - 256) chunk = (1ull << 24) - 256;  // a column index must fit 24 bits (new-list entries: (slot << 24) | column)
         if (max_slots > 255) { set_error("spec has more than 255 action slots per state"); return MC_EBADCFG; }
         row_stride = chunk + 256;
         HIP_TRY(hipMalloc(&d_arena, arena_cap * W * sizeof(uint64_t)));

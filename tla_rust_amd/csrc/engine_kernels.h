@@ -628,7 +628,11 @@ struct DenseSlots<S, decltype((void)S::DENSE_SLOTS)> : std::integral_constant<in
 // 30 % of the candidates of a wavefront, measured on the bench model in BFS order); a candidate found here was probed — found or
 // inserted — by this very wavefront, so it is dropped before it costs a random 64-byte read of HBM.  Sound: an entry is only
 // ever a fingerprint this wavefront handed to the seen-set.
-constexpr int WFILT = 256;
+#ifndef MC_WFILT
+#define MC_WFILT 128   // (round 5: 256 -> 128 entries; the kilobyte went to the survivor list, MC_OCAP below)
+#endif
+constexpr int WFILT = MC_WFILT;
+static_assert(WFILT >= 64 && (WFILT & (WFILT - 1)) == 0, "the filter is direct-mapped by fingerprint bits and cleared 64 entries at a time");
 // specs whose message actions are evaluated inline, lane = parent (S::inflight_slots; see k_expand_family)
 template <class S, class = void>
 struct InlineMsgs : std::false_type {};
@@ -729,7 +733,20 @@ struct SlotClasses<S, decltype((void)S::NCLS)> : std::integral_constant<int, S::
 // arena block: (slot << 6) | parent lane, 16 bits.  The survivor list holds up to OCAP entries: with in-wave writes the
 // survivors wait here until the wavefront's tail (one per parent on average; 64 are moved to the global new-list — the
 // overflow path, k_materialise — only when the list is about to fill up).
-constexpr int OCAP = 256;
+// Round 5: 384 entries (a ring that need not be a power of two).  With 256 a wavefront with more than 192 survivors — three per parent:
+// every level that grows by 2 x and more has many — pushed 64 at a time through the global new-list, and the level could not end before
+// a k_materialise had written them, alone on the device (16 level ends x 230 us on the contract workload, profiles/r05l_levels_*.txt,
+// and 27 M of its 526 M states re-read from HBM by that kernel); with 384 (320 before the first batch leaves) the list is the rare exception.
+#ifndef MC_OCAP
+#define MC_OCAP 384
+#endif
+constexpr int OCAP = MC_OCAP;
+static_assert(OCAP >= 128 && OCAP % 64 == 0 && OCAP <= 512, "survivor list: whole batches; positions have 9 bits in the tail's sort order");
+// position in the survivor ring: x < 2 * OCAP
+__device__ __forceinline__ unsigned owrap(unsigned x) {
+    if constexpr ((OCAP & (OCAP - 1)) == 0) return x & (unsigned)(OCAP - 1);
+    else return x >= (unsigned)OCAP ? x - (unsigned)OCAP : x;
+}
 // SPLIT-PHASE PROBES (round 5; MC_ASYNC_PROBE: 0 = off, 1 = loads, 2 = loads + compare-and-swaps).  A seen-set probe is two dependent
 // trips to HBM — read the bucket, then compare-and-swap the fingerprint into its first empty slot — and until round 4 a wavefront
 // sat through both with nothing else to do (flush_probe: 6 of the ~10 HBM-class waits of a wavefront's life).  Now the 64 queued
@@ -755,8 +772,8 @@ struct FamQueues {
 template <class S, int NB>
 struct FamLds {
     uint16_t fq[S::NFAM][FQCAP];   // (slot << 8) | (block << 6) | parent lane
+    uint64_t filt[WFILT];          // (directly behind fq: both are dead when the tail begins, its sort order lies over the two)
     typename S::Summary sum[NB * 64];
-    uint64_t filt[WFILT];
     // (deadlock check: "this parent has a successor" is a register of the parent's own lane for everything that lane evaluates,
     //  and bit 31 of a word of its Summary — S::succ_word — for the pairs another lane evaluates in a family batch)
 };
@@ -790,8 +807,9 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 RouteArgs rt, unsigned parity) {
     static_assert(NB >= 1 && NB <= 4, "the queue entry has two bits for the block");
     static_assert(WAVES == 1 || WAVES == 2 || WAVES == 4, "wavefronts per workgroup");
+    using FamLdsT = FamLds<S, NB>;
     __shared__ FamQueues wq[WAVES];
-    __shared__ FamLds<S, NB> fls[WAVES];
+    __shared__ FamLdsT fls[WAVES];
     if (rt.lc) {
         if (rt.lc->stop) return;
         lo = rt.lc->lo;
@@ -800,7 +818,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     }
     const unsigned lane = threadIdx.x & 63;
     FamQueues &Q = wq[threadIdx.x >> 6];
-    FamLds<S, NB> &FL = fls[threadIdx.x >> 6];
+    FamLdsT &FL = fls[threadIdx.x >> 6];
     const uint64_t base = lo & ~63ull;
     // (An XCD-aware tile order — XCD k = workgroup id % 8 walks the k-th eighth of the chunk's tiles, so that neighbouring arena
     //  blocks, which generate many of the same successors, probe the seen-set through ONE L2 — was measured on the t3 and K = 10
@@ -853,16 +871,16 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     auto flush_out = [&](unsigned take) __attribute__((always_inline)) {
         MC_PROF(4);
         // (the `take` oldest entries: all confirmed — tentative ones are the newest — but some may be tombstones)
-        const unsigned e = lane < take ? Q.o_ent[(ohead + lane) & (OCAP - 1)] : O_DEAD;
+        const unsigned e = lane < take ? Q.o_ent[owrap(ohead + lane)] : O_DEAD;
         const unsigned long long bl = __ballot(e != O_DEAD);
         unsigned long long pos = 0;
         if (lane == 0 && bl) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)__popcll(bl));
         pos = __shfl(pos, 0) + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
         if (e != O_DEAD) {
             seg[pos] = (uint32_t)(wave_col0 + (e & 63u)) | ((uint32_t)(e >> 6) << 24);
-            if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos] = Q.o_fp[(ohead + lane) & (OCAP - 1)];
+            if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos] = Q.o_fp[owrap(ohead + lane)];
         }
-        ohead = (ohead + take) & (OCAP - 1);
+        ohead = owrap(ohead + take);
         on -= take;
         MC_PROF(3);
     };
@@ -893,7 +911,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             {
                 const unsigned long long b = __ballot(is_new);
                 if (is_new) {
-                    const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                    const unsigned k = owrap(ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull)));
                     Q.o_ent[k] = (uint16_t)src;
                     Q.o_fp[k] = qfp;
                 }
@@ -925,7 +943,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         } else {
             const unsigned long long b = __ballot(is_new);
             if (is_new) {
-                const unsigned k = (ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                const unsigned k = owrap(ohead + on + (unsigned)__popcll(b & ((1ull << lane) - 1ull)));
                 Q.o_ent[k] = (uint16_t)src;
                 Q.o_fp[k] = qfp;
             }
@@ -970,7 +988,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             if constexpr (ASYNC_CAS) {
                 if (casmask) {
                     if ((casmask >> lane & 1ull) && casret != 0ull) {
-                        const unsigned pos = (cas_obase + (unsigned)__popcll(casmask & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                        const unsigned pos = owrap(cas_obase + (unsigned)__popcll(casmask & ((1ull << lane) - 1ull)));
                         const uint64_t f = Q.o_fp[pos];
                         bool nw = false;
                         if (casret != f) nw = slow_insert(f);
@@ -1029,7 +1047,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 const unsigned long long bn = __ballot(is_new);
                 if (bn) {
                     if (is_new) {
-                        const unsigned k = (ohead + on + (unsigned)__popcll(bn & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                        const unsigned k = owrap(ohead + on + (unsigned)__popcll(bn & ((1ull << lane) - 1ull)));
                         Q.o_ent[k] = (uint16_t)(ent & ((1u << Q_DSP_SHIFT) - 1u));
                         Q.o_fp[k] = fp;
                     }
@@ -1040,13 +1058,13 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 if (async_cas) {  // tentative survivors: the newest entries of the list, confirmed by the next resolve step
                     const unsigned long long bc = __ballot(cas);
                     if (cas) {
-                        const unsigned k = (ohead + on + (unsigned)__popcll(bc & ((1ull << lane) - 1ull))) & (OCAP - 1);
+                        const unsigned k = owrap(ohead + on + (unsigned)__popcll(bc & ((1ull << lane) - 1ull)));
                         Q.o_ent[k] = (uint16_t)(ent & ((1u << Q_DSP_SHIFT) - 1u));
                         Q.o_fp[k] = fp;
                         casret = cur;
                     }
                     casmask = bc;
-                    cas_obase = (ohead + on) & (OCAP - 1);
+                    cas_obase = owrap(ohead + on);
                     on += (unsigned)__popcll(bc);
                 }
             }
@@ -1313,13 +1331,14 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             // A/B: the tail by WAVEFRONT — no barrier (nobody waits for the slowest wavefront of the workgroup), one atomicAdd per
             // wavefront, the wavefront's own 64-100 survivors sorted by class (a batch still holds about half of the classes)
             MC_PROF(16);
-            uint16_t *order = reinterpret_cast<uint16_t *>(FL.filt);  // this wavefront's own filter: dead, its generation is over
+            static_assert(OCAP * sizeof(uint16_t) <= sizeof(FL.fq) + sizeof(FL.filt), "a wavefront's sorted order fits its own dead queues + filter");
+            uint16_t *order = reinterpret_cast<uint16_t *>(&FL.fq[0][0]);  // this wavefront's own family queues + filter: dead, its generation is over
             unsigned ccnt[NCLS];
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
             for (unsigned t = 0; t < on; t += 64) {
                 const bool valid = t + lane < on;
-                const unsigned e_ = valid ? Q.o_ent[(ohead + t + lane) & (OCAP - 1)] : O_DEAD;
+                const unsigned e_ = valid ? Q.o_ent[owrap(ohead + t + lane)] : O_DEAD;
                 const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
 #pragma unroll
                 for (int c = 0; c < NCLS; ++c) ccnt[c] += (unsigned)__popcll(__ballot(cls == c));
@@ -1332,7 +1351,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             wave_lds_fence();
             for (unsigned t = 0; t < on; t += 64) {
                 const bool valid = t + lane < on;
-                const unsigned k = (ohead + t + lane) & (OCAP - 1);
+                const unsigned k = owrap(ohead + t + lane);
                 const unsigned e_ = valid ? Q.o_ent[k] : O_DEAD;
                 const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
 #pragma unroll
@@ -1364,8 +1383,9 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             }
         } else {
         static_assert(NCLS * WAVES <= 64, "one lane per (class, wavefront) in the prefix sum");
-        static_assert(WAVES * OCAP * sizeof(uint16_t) <= sizeof(fls[0].filt) && OCAP <= 256, "the sorted order aliases one duplicate filter");
-        uint16_t *order = reinterpret_cast<uint16_t *>(fls[0].filt);        // [WAVES * OCAP]: (wavefront << 8) | position in its list
+        static_assert(sizeof(fls[0].fq) % 8 == 0 && offsetof(FamLdsT, filt) == sizeof(fls[0].fq), "the filter lies directly behind the family queues");
+        static_assert(WAVES * OCAP * sizeof(uint16_t) <= sizeof(fls[0].fq) + sizeof(fls[0].filt), "the sorted order aliases the family queues + the duplicate filter of the first wavefront");
+        uint16_t *order = reinterpret_cast<uint16_t *>(&fls[0].fq[0][0]);   // [WAVES * OCAP]: (wavefront << 9) | position in its list
         // [NCLS][WAVES] class counts + the workgroup's first arena index.  Written BEFORE barrier (1), while sibling wavefronts still
         // generate: in LDS of its own, or — split-phase builds — in the writing wavefront's own probe landing area, dead by then
         // (its last probe is resolved); every wavefront's slice lies in ITS landing area: hist of wave w' = probe_land[w'][...]
@@ -1393,7 +1413,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
         for (unsigned t = 0; t < on; t += 64) {
             const bool valid = t + lane < on;
-            const unsigned e_ = valid ? Q.o_ent[(ohead + t + lane) & (OCAP - 1)] : O_DEAD;
+            const unsigned e_ = valid ? Q.o_ent[owrap(ohead + t + lane)] : O_DEAD;
             const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) ccnt[c] += (unsigned)__popcll(__ballot(cls == c));
@@ -1412,13 +1432,13 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         for (int c = 0; c < NCLS; ++c) ccnt[c] = __shfl(excl, c * WAVES + (int)w);  // where this wavefront's class-c survivors go
         for (unsigned t = 0; t < on; t += 64) {
             const bool valid = t + lane < on;
-            const unsigned k = (ohead + t + lane) & (OCAP - 1);
+            const unsigned k = owrap(ohead + t + lane);
             const unsigned e_ = valid ? Q.o_ent[k] : O_DEAD;
             const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) {
                 const unsigned long long b = __ballot(cls == c);
-                if (cls == c) order[ccnt[c] + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((w << 8) | k);
+                if (cls == c) order[ccnt[c] + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((w << 9) | k);
                 ccnt[c] += (unsigned)__popcll(b);
             }
         }
@@ -1432,10 +1452,10 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             for (unsigned bt = w * 64u; bt < total; bt += 64u * WAVES) {  // batch of 64 sorted survivors; the wavefronts take turns
                 const bool mine = bt + lane < total;
                 const unsigned ref = mine ? order[bt + lane] : 0u;
-                const unsigned e = mine ? wq[ref >> 8].o_ent[ref & 255u] : 0u;
-                const uint64_t sfp = mine ? wq[ref >> 8].o_fp[ref & 255u] : 0ull;
-                const uint64_t pidx = wg_idx0 + (ref >> 8) * 64u + (e & 63u), oidx = out0 + bt + lane;
-                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx, fls[ref >> 8].sum[e & 63u]);
+                const unsigned e = mine ? wq[ref >> 9].o_ent[ref & 511u] : 0u;
+                const uint64_t sfp = mine ? wq[ref >> 9].o_fp[ref & 511u] : 0ull;
+                const uint64_t pidx = wg_idx0 + (ref >> 9) * 64u + (e & 63u), oidx = out0 + bt + lane;
+                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx, fls[ref >> 9].sum[e & 63u]);
                 if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
             }
         }
