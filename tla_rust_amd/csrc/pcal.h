@@ -36,7 +36,7 @@ struct Stmt {
     Pos pos;                               // of the statement keyword / lhs (asserts print it)
     std::string var;                       // ASSIGN lhs, WITH variable, GOTO target
     EP idx;                                // ASSIGN lhs index (x[i] := e), may be null
-    std::string field;                     // ASSIGN lhs field (r.f := e, r[i].f := e); gone after flatten_records
+    std::string field;                     // ASSIGN lhs field path (r.f := e, r[i].f := e, r.f.g := e: "f.g"); gone after flatten_records
     std::string whole;                     // ASSIGN to a variable that flatten_records made from the record variable `whole`
     EP e;                                  // ASSIGN rhs; condition of IF / WHILE / AWAIT / ASSERT; WITH set or value
     bool with_eq = false;                  // with x = e
@@ -137,8 +137,10 @@ struct Module {
 // fieldwise.  A record value <-> the tuple of its fields is a bijection on states, so counts, depth and verdicts equal those of
 // pcal2tla's translation (which keeps r one record-valued variable: tests/test_pcal.py checks it against hand-written record
 // translations); the translation's TEXT differs: it declares r_f, r_g and defines `r == [f |-> r_f, g |-> r_g]` after them, so
-// that the text around the algorithm (invariants written with r.f) keeps its meaning.  Refused with a message: nested records,
-// a record as a whole value anywhere else (`with`, procedure arguments, set members), sets of records as initial values.
+// that the text around the algorithm (invariants written with r.f) keeps its meaning.  NESTED records (round 5): a field may itself
+// be a record; the flattener works one level per pass (r -> r_f -> r_f_g), `r.f.g := e` carries its path in Stmt::field ("f.g"), an
+// inner record is assigned / compared leaf by leaf, the translation defines every level, inner before outer.  Refused with a message:
+// a record as a whole value anywhere else (`with`, procedure arguments, set members), sets / sequences of records as initial values.
 std::string parse_module(const std::string &text, Module &out);
 
 // The text `pcal2tla` inserts: from "\* BEGIN TRANSLATION" to "\* END TRANSLATION" inclusive, '\n' terminated.
