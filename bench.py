@@ -290,6 +290,39 @@ def atomic_add_series(amd, device, n=28, steps=3):
             "golden": "closed form 2^N + 1 / N 2^(N-1) + 3 / depth N + 2 (tests/test_oracle_golden.py: equal to the oracle for N <= 16)"}
 
 
+def other_config(amd, device, key, steps=3):
+    """BASELINE.json's configs 4 and 5 name models that are meant for eight GPUs; their graphs up to a level budget fit ONE MI355X, and the
+    driver's line carries them as objects of their own (round 5: until then only builder-run `--workload raft5 / ssi4x3` lines existed,
+    which nobody else measured).  Same engine, same gate as the main line: the run must reproduce the oracle's golden — counts and every
+    per-level count — or nothing is printed.  One untimed run, `steps` timed ones."""
+    w = WORKLOADS[key]
+    g = json.loads((ROOT / "tests" / "golden" / w.get("golden_file", "raft_levels.json")).read_text())
+    G0 = next(c for c in g["cases"] if c["name"] == w["golden"])
+    slots = TABLE_SLOTS[key]
+    ML = w.get("max_levels", 0)
+    eng = amd.Engine(w["spec"], w["params"], device=device, table_capacity=slots, arena_capacity=G0["distinct"] + (1 << 20), max_levels=ML,
+                     chunk_states=(1 << 24) - 256, trace=False, timing=True)
+    eng.run()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = eng.run()
+    dt = (time.perf_counter() - t0) / steps
+    ks = eng.kernel_stats()
+    eng.close()
+    got, want = (r.distinct, r.generated, r.depth, r.verdict), (G0["distinct"], G0["generated"], G0["depth"], w.get("verdict", "ok"))
+    if got != want or list(r["levels"]) != G0["levels"]:
+        print(f"bench.py: {key}: run does not reproduce the golden state graph: got {got}, want {want}", file=sys.stderr)
+        sys.exit(1)
+    W, D, G = ks["state_bytes"], r.distinct, r.generated
+    return {"workload": w["name"] + " — ONE GPU, fused engine (the 8-GPU form of this configuration is `bench.py --gpus 8 --workload " + key + "`)",
+            "value": D / dt, "unit": "distinct states/s", "ms_per_step": 1e3 * dt, "steps": steps, "distinct": D, "generated": G, "depth": r.depth,
+            "verdict": r.verdict, "state_bytes": W, "seen_set_load": D / float(slots), "inwave_states": ks.get("inwave_states", 0),
+            "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
+            "pipeline_GBs": (2 * W * D + 8 * G) / dt / 1e9, "pipeline_frac": (2 * W * D + 8 * G) / dt / 1e9 / HBM_PEAK_GBS,
+            "alg_bytes": "SURVEY.md 8d: (2 W + 8 G/D) bytes per distinct state over the wall time of a step, against 8 TB/s",
+            "golden": f"tests/golden/{w.get('golden_file', 'raft_levels.json')}:{w['golden']} (exact-dedup CPU oracle): counts and per-level counts equal"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +330,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-atomic-add", action="store_true", help="skip the synthetic N-process atomic-counter object of the line")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the one-GPU objects of BASELINE configs 4 and 5 (raft with 5 servers, SSI 4 x 3)")
     ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
     ap.add_argument("--chunk", type=int, default=(1 << 24) - 256)   # frontier states per launch: the engine's maximum (a column index has 24 bits).  Round 3: 169.4 / 163.6 / 160.5 ms
     # per step at 2^21 / 2^22 / 2^23; round 5 (profiles/r05k_ab.jsonl): 2^24 - 256 against 2^23 = 135.3 against 135.5 - 136.3 ms on t3 (70 launches instead of 102),
@@ -568,6 +602,11 @@ def main():
         if not a.no_atomic_add and not a.max_distinct and a.workload == "t3":   # (the contract line carries both of north_star's workloads)
             eng.close()
             line["atomic_add"] = atomic_add_series(amd, local)
+        if not a.no_other_configs and not a.max_distinct and a.workload == "t3" and not a.matrix and not a.no_family:
+            # ... and BASELINE configs 4 and 5 as far as one GPU holds them (a few seconds: two engines of 200 GB and 30 GB come and go)
+            eng.close()
+            line["config4_model_one_gpu"] = other_config(amd, local, "raft5")
+            line["config5_model_one_gpu"] = other_config(amd, local, "ssi4x3")
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     print(json.dumps(line), flush=True)
