@@ -733,12 +733,15 @@ struct SlotClasses<S, decltype((void)S::NCLS)> : std::integral_constant<int, S::
 // arena block: (slot << 6) | parent lane, 16 bits.  The survivor list holds up to OCAP entries: with in-wave writes the
 // survivors wait here until the wavefront's tail (one per parent on average; 64 are moved to the global new-list — the
 // overflow path, k_materialise — only when the list is about to fill up).
-// Round 5: 384 entries (a ring that need not be a power of two).  With 256 a wavefront with more than 192 survivors — three per parent:
+// Round 5: 448 entries (a ring that need not be a power of two).  With 256 a wavefront with more than 192 survivors — three per parent:
 // every level that grows by 2 x and more has many — pushed 64 at a time through the global new-list, and the level could not end before
 // a k_materialise had written them, alone on the device (16 level ends x 230 us on the contract workload, profiles/r05l_levels_*.txt,
-// and 27 M of its 526 M states re-read from HBM by that kernel); with 384 (320 before the first batch leaves) the list is the rare exception.
+// and 27 M of its 526 M states re-read from HBM by that kernel); with 384 (320 before the first batch leaves) the list is the rare
+// exception (t3 138.3 -> 132.0 ms, profiles/r05m), with 448 rarer still (-1.2 %; the 5-server model 171.5 -> 169.0, profiles/r05t): 448
+// is what fits — the tail's sort order (2 x 448 x 2 bytes) fills the dead family queues + filter exactly, and eight workgroups of
+// 20.3 KB fill the CU's 160 KB of LDS.
 #ifndef MC_OCAP
-#define MC_OCAP 384
+#define MC_OCAP 448
 #endif
 constexpr int OCAP = MC_OCAP;
 static_assert(OCAP >= 128 && OCAP % 64 == 0 && OCAP <= 512, "survivor list: whole batches; positions have 9 bits in the tail's sort order");
