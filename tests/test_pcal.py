@@ -66,6 +66,13 @@ CASES = [
     # record inside the queue / node records, nodes freed and reused; Counted = FALSE compares the ptr halves only: ABA, Head swings to a freed node
     (SPECS / "pluscal" / "ms_queue_counted.tla", ["HeadLive", "TailLive", "PointersAreNodes", "TailAtMostOneBehind", "CountsGrow"], {"N": 2, "K": 3, "Counted": True}),
     (SPECS / "pluscal" / "ms_queue_counted.tla", ["HeadLive", "TailLive", "PointersAreNodes", "TailAtMostOneBehind", "CountsGrow"], {"N": 2, "K": 3, "Counted": False}),
+    # CHANNELS (round 5, last part): ARRAYS of sequences (spec_vm.h VM_SEQSEL) and SEQUENCES of RECORDS (one sequence per field, pcal.cpp RecordFlattener):
+    # two-phase commit over FIFO channels of [type, from] messages; Eager = TRUE commits on the first yes vote: Consistent breaks
+    (SPECS / "pluscal" / "two_phase_channels.tla", ["Consistent", "CommitNeedsAllVotes", "InboxHoldsVotes", "FromTheCoordinator", "AtMostTwoWaiting"], {"RM": 2, "Eager": False}),
+    (SPECS / "pluscal" / "two_phase_channels.tla", ["Consistent", "CommitNeedsAllVotes", "InboxHoldsVotes", "FromTheCoordinator", "AtMostTwoWaiting"], {"RM": 3, "Eager": False}),
+    (SPECS / "pluscal" / "two_phase_channels.tla", ["Consistent", "InboxHoldsVotes", "FromTheCoordinator"], {"RM": 3, "Eager": True}),
+    # ... q \o <<r>>, q[k] := r, an initial element, `||` over two sequences, an array of sequences of numbers beside the record channels
+    (SPECS / "pluscal" / "mailboxes.tla", ["LogOk", "Pongs", "HeardTheLeft"], {"N": 2}),
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -490,6 +497,11 @@ RECORD_FIXTURES = ROOT / "tests" / "golden" / "pcal_records"
     # nested records: Q.Head.ptr, mem[i].next.count — pcal2tla's EXCEPT !.Head, ![i].next.ptr against three passes of flattening
     ("ms_queue_counted", "MsQueueCounted", "MsQueueCounted", {"N": 2, "K": 3, "Counted": True}, ["HeadLive", "TailLive", "PointersAreNodes", "TailAtMostOneBehind", "CountsGrow"]),
     ("ms_queue_counted", "MsQueueCounted", "MsQueueUncounted", {"N": 2, "K": 3, "Counted": False}, ["HeadLive", "TailLive", "PointersAreNodes", "TailAtMostOneBehind", "CountsGrow"]),
+    # sequences of records: pcal2tla's `chan' = [chan EXCEPT ![p] = Append(chan[p], [type |-> ..])]`, `msg' = Head(chan[0])` against one sequence per field
+    ("two_phase_channels", "TwoPhaseChannels", "TwoPhaseChannels", {"RM": 3, "Eager": False}, ["Consistent", "CommitNeedsAllVotes", "InboxHoldsVotes", "FromTheCoordinator", "AtMostTwoWaiting"]),
+    ("two_phase_channels", "TwoPhaseChannels", "TwoPhaseChannelsEager", {"RM": 3, "Eager": True}, ["Consistent", "InboxHoldsVotes", "FromTheCoordinator"]),
+    ("mailboxes", "Mailboxes", "Mailboxes", {"N": 2}, ["LogOk", "Pongs", "HeardTheLeft"]),
+    ("mailboxes", "Mailboxes", "Mailboxes3", {"N": 3}, ["LogOk", "Pongs", "HeardTheLeft"]),      # (deadlock: a node that has its pong leaves without answering)
 ])
 def test_records_field_by_field_equal_the_record_valued_translation(spec, fixture, cfg, consts, invs):
     """PlusCal record variables are kept FIELD BY FIELD (tla_rust_amd/csrc/pcal.h, RECORDS) instead of as one record-valued variable
@@ -502,7 +514,12 @@ def test_records_field_by_field_equal_the_record_valued_translation(spec, fixtur
     p = c.run_levels(keep_states=False)
     text = (SPECS / "pluscal" / f"{spec}.tla").read_text()
     o = Checker(helpers.pcal_translate(text), constants=consts).run_levels(invariants=invs)
-    prog = helpers.ShimProgram(text, invs, consts)
+    if cfg == "Mailboxes3":   # three mailboxes of three-field records + two more sequence variables: 4 cells per sequence instead of 8 fit the 128 cells of a state
+        os.environ["TLAMC_PCAL_SEQ"] = "4"
+    try:
+        prog = helpers.ShimProgram(text, invs, consts)
+    finally:
+        os.environ.pop("TLAMC_PCAL_SEQ", None)
     try:
         r = helpers.shim_run("pcal", prog.params)
     finally:
@@ -511,7 +528,7 @@ def test_records_field_by_field_equal_the_record_valued_translation(spec, fixtur
     assert p["verdict"] == o["verdict"]
     if p["verdict"] == "ok":   # (an error stops the general evaluator at the state, the other two at the end of the level)
         assert (p["distinct"], p["generated"], p["depth"], p["levels"]) == (o["distinct"], o["generated"], o["depth"], o["levels"])
-        assert p["distinct"] > 80
+        assert p["distinct"] > 50
 
 
 REC_HEAD = "---- MODULE M ----\nEXTENDS Naturals\n(* --algorithm M\nvariables r = [a |-> 0, b |-> FALSE], q = [a |-> 1, b |-> TRUE], arr = [i \\in 1..2 |-> [a |-> 0, b |-> FALSE]], x = 0;\n"
@@ -692,3 +709,108 @@ def test_procedure_errors_are_refused_with_a_message(body, msg):
     with pytest.raises(RuntimeError) as e:
         helpers.pcal_translate(PROC_HEAD + body)
     assert msg in str(e.value), str(e.value)
+
+
+def _vm_equals_evaluator(text, invs=(), consts=None):
+    """the compiled program on the host VM against oracle/tla_eval.py on the translation: counters, verdict, the SET of states of every level"""
+    consts = consts or {}
+    prog = helpers.ShimProgram(text, list(invs), consts)
+    try:
+        fd, dump = tempfile.mkstemp()
+        os.close(fd)
+        r = helpers.shim_run("pcal", prog.params, dump=dump)
+        o = Checker(prog.translated(), constants=consts).run_levels(invariants=list(invs))
+        for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+            assert r[k] == o[k], (k, r[k], o[k])
+        states = helpers.read_dump(dump)
+        os.unlink(dump)
+        for lvl, want in enumerate(o["states"], 1):
+            assert states[lvl] == want, f"level {lvl}"
+        return r
+    finally:
+        prog.close()
+
+
+def test_multiple_assignment_with_sequences_reads_the_values_before_the_statement():
+    """`a := Tail(a) || x := Head(a) || b := Append(b, Head(a))`: every right-hand side (the scalar operands of the sequence expressions
+    included, and the indices of an array of sequences) is evaluated before anything is stored (pcal_compile.cpp seq_operands_to_temps)"""
+    text = """---- MODULE par ----
+EXTENDS Naturals, Sequences
+(* --algorithm par
+variables a = <<1, 2, 3>>, b = <<10, 20>>, x = 0, arr = [i \\in 1..2 |-> <<5, 6>>], y = 0;
+begin
+  L1: a := Tail(a) || x := Head(a) || b := Append(b, Head(a));
+  L2: a := <<Head(b), a[1]>> || b := b \\o <<Head(a), x>>;
+  L3: arr[1] := Tail(arr[1]) || y := Head(arr[1]);
+  L4: arr[y - 3] := Append(arr[y - 3], Len(arr[1]) + Len(arr[2]) * 10) || a[1] := a[2];
+  L5: either arr[1] := <<>>; or arr[2] := <<arr[1][1], arr[2][1]>>; end either;
+end algorithm *)
+====
+""".replace("\\\\", "\\")
+    r = _vm_equals_evaluator(text)
+    assert (r["distinct"], r["verdict"]) == (7, "ok")
+    prog = helpers.ShimProgram(text)
+    try:
+        fd, dump = tempfile.mkstemp()
+        os.close(fd)
+        helpers.shim_run("pcal", prog.params, dump=dump)
+        states = helpers.read_dump(dump)
+        os.unlink(dump)
+    finally:
+        prog.close()
+    assert any("a = <<2, 3>>" in s and "x = 1" in s and "b = <<10, 20, 1>>" in s for s in states[2])          # after L1: all three read the OLD a
+    assert any("a = <<10, 2>>" in s and "b = <<10, 20, 1, 2, 1>>" in s for s in states[3])                     # after L2
+    assert any("arr = <<<<6>>, <<5, 6, 21>>>>" in s and "a = <<2, 2>>" in s for s in states[5])               # after L4: arr[y - 3] = arr[2]
+
+
+def test_sequence_cells_come_from_the_environment():
+    """$TLAMC_PCAL_SEQ cells per sequence (default 8): a longer sequence is MC_EOVERFLOW, never a truncated run"""
+    text = """---- MODULE grow ----
+EXTENDS Naturals, Sequences
+(* --algorithm grow
+variables box = [p \\in 1..2 |-> <<>>], n = 0;
+begin
+  L: while n < 6 do box[1 + (n % 2)] := Append(box[1 + (n % 2)], n); n := n + 1; end while;
+end algorithm *)
+====
+""".replace("\\\\", "\\")
+    assert _vm_equals_evaluator(text)["verdict"] == "ok"
+    os.environ["TLAMC_PCAL_SEQ"] = "2"
+    try:
+        prog = helpers.ShimProgram(text)
+    finally:
+        del os.environ["TLAMC_PCAL_SEQ"]
+    try:
+        with pytest.raises(RuntimeError) as e:
+            helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert "-3" in str(e.value)      # MC_EOVERFLOW
+
+
+SEQ_HEAD = ("---- MODULE M ----\nEXTENDS Naturals, Sequences\n(* --algorithm M\nvariables q = <<>>, box = [p \\in 1..2 |-> <<>>], ints = [p \\in 1..2 |-> <<>>], "
+            "r = [a |-> 0, b |-> FALSE], s = <<>>, x = 0;\n")
+SEQ_ERRORS = [
+    ("begin L: q := Append(q, [a |-> 1, b |-> TRUE]); x := q; end algorithm *)\n====\n", "the sequence of records q is used as a whole value"),
+    ("begin L: q := Append(q, [a |-> 1, b |-> TRUE]); x := Head(q); end algorithm *)\n====\n", "a record is assigned to x"),
+    ("begin L: q := Append(q, [a |-> 1]); M: q := Append(q, r); end algorithm *)\n====\n", "the record put into q does not have its fields"),
+    ("begin L: q := Append(q, r); q.a := 1; end algorithm *)\n====\n", "q is a sequence of records: assign an element"),
+    ("begin L: q := Append(q, r); M: if q = <<r>> then skip; end if; end algorithm *)\n====\n", "can only be compared with <<>>"),
+    ("begin L: box[1] := Append(box[1], r); M: box := box; end algorithm *)\n====\n", "assignment to the whole array of sequences box"),
+    ("begin L: box[1] := Append(box[1], r); M: box[2] := box[1]; end algorithm *)\n====\n", "can only start from the same element"),
+    ("begin L: q := Append(q, [a |-> 1, b |-> [c |-> 1]]); end algorithm *)\n====\n", "can only have plain fields"),
+    ("begin L: q := Append(q, r); M: q := Append(q, 3); end algorithm *)\n====\n", "must be a record constructor, a record variable or an element of a sequence / array of records"),
+    ("begin L: q := Append(q, r); M: x := q[1].c; end algorithm *)\n====\n", "record q has no field c"),
+    ("begin L: ints[1] := Append(ints[1], 3); M: ints[2] := ints[1]; end algorithm *)\n====\n", "can only start from the same element ints[i]"),
+    ("begin L: ints[1] := Append(ints[2], 3); end algorithm *)\n====\n", "can only start from the same element ints[i]"),
+    ("begin L: ints[1] := Append(ints[1], 3); M: ints := ints; end algorithm *)\n====\n", "assigning the whole array of sequences `ints` is not supported"),
+    ("begin L: ints[1] := Append(ints[1], 3); M: x := ints[1]; end algorithm *)\n====\n", "the sequence `ints[..]` is used as a value here"),
+    ("begin L: ints[1] := Append(ints[1], 3); M: s := ints[1]; end algorithm *)\n====\n", "copying a sequence into / out of the array `ints` is not supported"),
+]
+
+
+@pytest.mark.parametrize("body,msg", SEQ_ERRORS, ids=[m[:28] for _, m in SEQ_ERRORS])
+def test_channel_errors_are_refused_with_a_message(body, msg):
+    with pytest.raises(RuntimeError) as e:
+        helpers.ShimProgram(SEQ_HEAD.replace("\\\\", "\\") + body)
+    assert msg in str(e.value)

@@ -1349,7 +1349,54 @@ struct RecordFlattener {
     }
     const RecordVar *rec_of(const EP &e) const {  // r or r[i] of a record variable r of this pass
         auto it = recs.find(base_name(e));
-        return it == recs.end() ? nullptr : &it->second;
+        if (it == recs.end() || it->second.seq) return nullptr;
+        return &it->second;
+    }
+    // ---- sequences of records (pcal.h, RecordVar::seq): q / box[i] is kept as one sequence per field
+    const RecordVar *recseq(const EP &e) const {  // e = q, or box[i] of an array of record sequences
+        if (e->k == Expr::ID) {
+            auto it = recs.find(e->s);
+            return it != recs.end() && it->second.seq && !it->second.array ? &it->second : nullptr;
+        }
+        if (e->k == Expr::INDEX && e->a[0]->k == Expr::ID) {
+            auto it = recs.find(e->a[0]->s);
+            return it != recs.end() && it->second.seq && it->second.array ? &it->second : nullptr;
+        }
+        return nullptr;
+    }
+    const RecordVar *recseq_elem(const EP &e) const {  // e = Head(Q) or Q[k]: an ELEMENT of a record sequence Q
+        if (e->k == Expr::CALL && e->s == "Head" && e->a.size() == 1) return recseq(e->a[0]);
+        if (e->k == Expr::INDEX) return recseq(e->a[0]);
+        return nullptr;
+    }
+    EP proj_seq(const EP &q, const std::string &f) const {  // the sequence of the f fields of Q
+        const RecordVar *r = recseq(q);
+        if (!r) fail(q->pos, "expected a sequence of records (a variable, or an element of an array of them)");
+        check_field(*r, f, q->pos);
+        if (q->k == Expr::ID) return id(r->name + "_" + f, q->pos);
+        auto x = node(Expr::INDEX, q->pos);
+        x->a = {id(r->name + "_" + f, q->a[0]->pos), rw(q->a[1])};
+        return x;
+    }
+    // field f of a record-SEQUENCE-valued expression: <<R, ..>>, Q, Append(Q, R), Tail(Q), Q \o <<R, ..>>
+    EP proj_seq_expr(const EP &e, const std::string &f, const RecordVar &dst) const {
+        auto elem = [&](const EP &x) {
+            if (!record_valued(x)) fail(x->pos, "an element of the sequence of records " + dst.name + " must be a record constructor, a record variable or an element of a sequence / array of records");
+            if (!same_fields(dst.fields, fields_of(x))) fail(x->pos, "the record put into " + dst.name + " does not have its fields");
+            return field_of(x, f);
+        };
+        auto c = std::make_shared<Expr>(*e);
+        if (e->k == Expr::TUPLE) { for (auto &x : c->a) x = elem(x); return c; }
+        if (recseq(e)) return proj_seq(e, f);
+        if (e->k == Expr::CALL && e->s == "Append" && e->a.size() == 2) { c->a = {proj_seq(e->a[0], f), elem(e->a[1])}; return c; }
+        if (e->k == Expr::CALL && e->s == "Tail" && e->a.size() == 1) { c->a = {proj_seq(e->a[0], f)}; return c; }
+        if (e->k == Expr::BINOP && (e->s == "\\o" || e->s == "\\circ") && e->a[1]->k == Expr::TUPLE) {
+            auto t = std::make_shared<Expr>(*e->a[1]);
+            for (auto &x : t->a) x = elem(x);
+            c->a = {proj_seq(e->a[0], f), t};
+            return c;
+        }
+        fail(e->pos, "a sequence of records can be assigned <<...>>, itself, Append(q, r), Tail(q) or q \\o <<...>>");
     }
     bool pending_ref(const EP &e) const { return (e->k == Expr::ID || e->k == Expr::INDEX) && pending.count(base_name(e)) != 0; }
     static int field_index(const EP &rec, const std::string &f) {
@@ -1360,8 +1407,11 @@ struct RecordFlattener {
     EP shape(const EP &e) const {
         if (!e) return nullptr;
         if (e->k == Expr::RECORD) return e;
+        if (const RecordVar *r = recseq_elem(e)) return shapes.at(r->name);
+        if (recseq(e)) return nullptr;
         if (e->k == Expr::ID || e->k == Expr::INDEX) {
             const std::string &n = base_name(e);
+            if (!n.empty() && recs.count(n) && recs.at(n).seq) return nullptr;
             if (!n.empty()) {
                 auto it = shapes.find(n);
                 return it == shapes.end() ? nullptr : it->second;
@@ -1399,7 +1449,7 @@ struct RecordFlattener {
             for (auto &x : c->a) x = record_valued(x) ? as_value(x) : rw(x);
             return c;
         }
-        if (const RecordVar *r = rec_of(e)) {
+        if (const RecordVar *r = rec_of(e) ? rec_of(e) : recseq_elem(e)) {
             auto c = node(Expr::RECORD, e->pos);
             c->names = r->fields;
             for (const auto &f : r->fields) c->a.push_back(field_of(e, f));
@@ -1415,6 +1465,13 @@ struct RecordFlattener {
             if (k < 0) fail(e->pos, "the record has no field " + f);
             const EP &v = e->a[(size_t)k];
             return record_valued(v) ? as_value(v) : rw(v);
+        }
+        if (const RecordVar *r = recseq_elem(e)) {  // Head(Q).f = Head(Q_f), Q[k].f = Q_f[k]
+            check_field(*r, f, e->pos);
+            auto c = std::make_shared<Expr>(*e);
+            c->a[0] = proj_seq(e->a[0], f);
+            if (e->k == Expr::INDEX) c->a[1] = rw(e->a[1]);
+            return c;
         }
         if (const RecordVar *r = rec_of(e)) {
             check_field(*r, f, e->pos);
@@ -1448,7 +1505,7 @@ struct RecordFlattener {
                 c->a[1] = rw(b->a[1]);
                 b = c;
             }
-            if (b->k == Expr::RECORD || rec_of(b)) return field_of(b, e->s);
+            if (b->k == Expr::RECORD || rec_of(b) || recseq_elem(b)) return field_of(b, e->s);
             if (pending_ref(b) || b->k == Expr::DOT) {  // a field of a record this pass has only just made a variable of (or a path into it): the next pass's
                 const EP sb = shape(b);
                 if (!sb) fail(e->pos, "`." + e->s + "`: not a field of a record");
@@ -1459,7 +1516,27 @@ struct RecordFlattener {
             }
             fail(e->pos, "`." + e->s + "`: field access is supported on record variables (r." + e->s + ", r[i]." + e->s + ") only");
         }
+        case Expr::CALL:
+            if (e->s == "Len" && e->a.size() == 1) if (const RecordVar *r = recseq(e->a[0])) {
+                auto c = std::make_shared<Expr>(*e);
+                c->a = {proj_seq(e->a[0], r->fields[0])};
+                return c;
+            }
+            if (recseq_elem(e)) fail(e->pos, "an element of a sequence of records is used as a whole value here (supported: Head(q).f, r := Head(q), Head(q) = ...)");
+            break;
+        case Expr::INDEX:
+            if (recseq_elem(e)) fail(e->pos, "an element of a sequence of records is used as a whole value here (supported: q[k].f, r := q[k], q[k] = ...)");
+            if (recseq(e)) fail(e->pos, "a sequence of records is used as a whole value here (supported: Len, Head, [k], = / # <<>>, :=)");
+            break;
         case Expr::BINOP:
+            if ((e->s == "=" || e->s == "#") && (recseq(e->a[0]) || recseq(e->a[1]))) {
+                const int side = recseq(e->a[0]) ? 0 : 1;
+                const EP &other = e->a[(size_t)(1 - side)];
+                if (other->k != Expr::TUPLE || !other->a.empty()) fail(e->pos, "a sequence of records can only be compared with <<>>");
+                auto c = std::make_shared<Expr>(*e);
+                c->a[(size_t)side] = proj_seq(e->a[(size_t)side], recseq(e->a[(size_t)side])->fields[0]);
+                return c;
+            }
             if ((e->s == "=" || e->s == "#") && (record_valued(e->a[0]) || record_valued(e->a[1]))) {
                 if (!record_valued(e->a[0]) || !record_valued(e->a[1])) fail(e->pos, "a record can only be compared with a record variable, an element of a record array or a record constructor");
                 const auto fs = fields_of(e->a[0]);
@@ -1485,6 +1562,7 @@ struct RecordFlattener {
             }
             break;
         case Expr::ID:
+            if (recs.count(e->s) && recs.at(e->s).seq) fail(e->pos, "the sequence of records " + e->s + " is used as a whole value here (supported: Len, Head, [k], = / # <<>>, :=)");
             if (recs.count(e->s)) fail(e->pos, "record variable " + e->s + " is used as a whole value here (supported: " + e->s + ".f, " + e->s + " := ..., " + e->s + " = ...)");
             return e;
         case Expr::RECORD:
@@ -1518,6 +1596,17 @@ struct RecordFlattener {
         }
         const RecordVar &r = it->second;
         const std::string root = a.whole.empty() ? r.name : a.whole;   // the one variable pcal2tla sees (one assignment per step)
+        if (r.seq) {
+            if (!a.field.empty()) fail(a.pos, r.name + " is a sequence of records: assign an element (" + r.name + "[k] := r) or the sequence (Append, Tail, <<...>>)");
+            if (r.array && !a.idx) fail(a.pos, "assignment to the whole array of sequences " + r.name + " (supported: " + r.name + "[i] := Append(" + r.name + "[i], r), ...)");
+            if (!r.array && a.idx) {   // q[k] := R: one element
+                if (!record_valued(a.e) || !same_fields(r.fields, fields_of(a.e))) fail(a.e->pos, "the value assigned to an element of " + r.name + " must be a record with its fields");
+                for (const auto &f : r.fields) mk(r.name + "_" + f, rw(a.idx), field_of(a.e, f), root, "");
+                return;
+            }
+            for (const auto &f : r.fields) mk(r.name + "_" + f, rw(a.idx), proj_seq_expr(a.e, f, r), root, "");
+            return;
+        }
         if (r.array != (a.idx != nullptr)) fail(a.pos, r.array ? "assignment to the whole record array " + r.name + " (supported: " + r.name + "[i] := ..., " + r.name + "[i].f := ...)" : r.name + " is a record, not an array of records");
         if (!a.field.empty()) {
             const size_t dot = a.field.find('.');
@@ -1564,6 +1653,51 @@ struct RecordFlattener {
             s = c;
         }
     }
+    // the constructor that says which fields the ELEMENTS of the sequence variable `name` have: the first record constructor (or record
+    // variable, by its declaration) among its initial elements and among what the algorithm puts into it — null: not a sequence of records
+    EP decl_shape(const std::string &name) const {
+        auto look = [&](const std::vector<VarDecl> &v) -> EP {
+            for (const auto &d : v)
+                if (d.name == name && d.init && !d.in_set) {
+                    if (d.init->k == Expr::RECORD) return d.init;
+                    if (d.init->k == Expr::FUNCDEF && d.init->a[1]->k == Expr::RECORD) return d.init->a[1];
+                }
+            return nullptr;
+        };
+        if (EP r = look(m.globals)) return r;
+        for (const auto &p : m.procs) if (EP r = look(p.locals)) return r;
+        return nullptr;
+    }
+    EP seq_elem_shape(const std::string &name, const EP &init_tuple) const {
+        auto of_value = [&](const EP &x) -> EP {
+            if (!x) return nullptr;
+            if (x->k == Expr::RECORD) return x;
+            if (x->k == Expr::ID) return decl_shape(x->s);
+            if (x->k == Expr::INDEX && x->a[0]->k == Expr::ID) return decl_shape(x->a[0]->s);
+            return nullptr;
+        };
+        for (const auto &x : init_tuple->a) if (EP r = of_value(x)) return r;
+        EP found;
+        std::function<void(const std::vector<SP> &)> walk = [&](const std::vector<SP> &v) {
+            for (const auto &st : v) {
+                if (found) return;
+                if (st->k == Stmt::ASSIGN) {
+                    std::vector<const Stmt *> all{st.get()};
+                    for (const auto &o : st->more) all.push_back(o.get());
+                    for (const Stmt *a : all) {
+                        if (a->var != name || !a->e || !a->field.empty() || found) continue;
+                        const EP &e = a->e;
+                        if (e->k == Expr::TUPLE) { for (const auto &x : e->a) if (!found) found = of_value(x); }
+                        else if (e->k == Expr::CALL && e->s == "Append" && e->a.size() == 2) found = of_value(e->a[1]);
+                        else if (e->k == Expr::BINOP && (e->s == "\\o" || e->s == "\\circ") && e->a[1]->k == Expr::TUPLE) { for (const auto &x : e->a[1]->a) if (!found) found = of_value(x); }
+                    }
+                }
+                for (const auto &b : st->blocks) walk(b);
+            }
+        };
+        for (const auto &p : m.procs) walk(p.body);
+        return found;
+    }
     // declarations: a record variable becomes one variable per field
     void decls(std::vector<VarDecl> &v, int proc, const std::set<std::string> &taken) {
         std::vector<VarDecl> out;
@@ -1571,7 +1705,40 @@ struct RecordFlattener {
             const EP &e = d.init;
             const bool scalar = e && !d.in_set && e->k == Expr::RECORD;
             const bool array = e && !d.in_set && e->k == Expr::FUNCDEF && e->a[1]->k == Expr::RECORD;
-            if (!scalar && !array) { out.push_back(d); continue; }
+            if (!scalar && !array) {
+                // a SEQUENCE of records (or an array of them): `q = <<>>` / `box = [p \in S |-> <<>>]` into which records are put
+                const bool sq = e && !d.in_set && e->k == Expr::TUPLE, sqa = e && !d.in_set && e->k == Expr::FUNCDEF && e->a[1]->k == Expr::TUPLE;
+                const EP es = sq || sqa ? seq_elem_shape(d.name, sq ? e : e->a[1]) : nullptr;
+                if (!es) { out.push_back(d); continue; }
+                const EP &tup = sq ? e : e->a[1];
+                RecordVar r;
+                r.name = d.name;
+                r.fields = es->names;
+                r.array = sqa;
+                r.seq = true;
+                r.proc = proc;
+                r.depth = depth;
+                if (sqa) { r.bound = e->bound; r.domain = e->a[0]; }
+                for (size_t i = 0; i < es->names.size(); i++) {
+                    if (es->a[i]->k == Expr::RECORD || es->a[i]->k == Expr::FUNCDEF || es->a[i]->k == Expr::TUPLE)
+                        fail(es->a[i]->pos, "an element of the sequence of records " + d.name + " can only have plain fields (field " + es->names[i] + " is a record, a function or a sequence)");
+                    VarDecl f = d;
+                    f.name = d.name + "_" + es->names[i];
+                    if (taken.count(f.name)) fail(d.pos, "field " + es->names[i] + " of the sequence of records " + d.name + " is kept as a variable " + f.name + ", and that name is taken");
+                    auto ft = std::make_shared<Expr>(*tup);   // the initial elements, field by field
+                    for (auto &x : ft->a) {
+                        if (x->k != Expr::RECORD || !same_fields(x->names, es->names)) fail(x->pos, "the initial elements of " + d.name + " must be record constructors with the same fields");
+                        x = x->a[(size_t)field_index(x, es->names[i])];
+                    }
+                    if (sq) f.init = ft;
+                    else { auto fn = std::make_shared<Expr>(*e); fn->a[1] = ft; f.init = fn; }
+                    out.push_back(f);
+                }
+                shapes[r.name] = es;
+                m.records.push_back(r);
+                recs[r.name] = r;
+                continue;
+            }
             const EP &rc = scalar ? e : e->a[1];
             RecordVar r;
             r.name = d.name;
@@ -2226,6 +2393,16 @@ std::string translate(const Module &m) {
         o += "(* record variables are kept field by field: r.f is r_f *)\n";
         for (const auto &r : m.records) {
             const bool per_process = r.proc >= 0 && multi && m.procs[(size_t)r.proc].is_set;
+            if (r.seq) {   // q == [n_ \in 1..Len(q_f) |-> [f |-> q_f[n_], ...]]: a function on 1..n IS a sequence
+                const std::string at = std::string(per_process ? "[self]" : "") + (r.array ? "[" + r.bound + "]" : "");
+                std::string rec = "[n_ \\in 1..Len(" + r.name + "_" + r.fields[0] + at + ") |-> [";
+                for (size_t i = 0; i < r.fields.size(); i++) rec += (i ? ", " : "") + r.fields[i] + " |-> " + r.name + "_" + r.fields[i] + at + "[n_]";
+                rec += "]]";
+                if (r.array) { std::set<std::string> sh{r.bound}; rec = "[" + r.bound + " \\in " + pe(r.domain, none, empty, sh) + " |-> " + rec + "]"; }
+                if (per_process) rec = "[self \\in " + pe(m.procs[(size_t)r.proc].id, none, empty, empty) + " |-> " + rec + "]";
+                o += r.name + " == " + rec + "\n";
+                continue;
+            }
             const std::string at = r.array ? "[" + r.bound + "]" : "";
             std::string rec = "[";
             for (size_t i = 0; i < r.fields.size(); i++) rec += (i ? ", " : "") + r.fields[i] + " |-> " + r.name + "_" + r.fields[i] + (per_process ? "[self]" : "") + at;

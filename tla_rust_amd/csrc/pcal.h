@@ -76,6 +76,8 @@ struct RecordVar {
     std::string name;                  // r: the variables of the translation are r_f, one per field
     std::vector<std::string> fields;
     bool array = false;                // r = [x \in S |-> [f |-> e, ...]]
+    bool seq = false;                  // a SEQUENCE of records (q = <<>> ... Append(q, [f |-> e, ...]); with `array`: [x \in S |-> <<>>], the
+                                       // channels of a message-passing algorithm): one sequence per field, all of the same length
     std::string bound;                 // array: x
     EP domain;                         // array: S
     int proc = -1;                     // index into Module::procs of the process it is local to, -1 = global

@@ -7,6 +7,7 @@
 #include "spec_vm.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -89,8 +90,9 @@ struct Compiler {
         case mc::VM_PUSH: case mc::VM_SELF: case mc::VM_LOAD: case mc::VM_LOADT: case mc::VM_CHOOSE: depth++; break;
         case mc::VM_STORE: case mc::VM_STORET: case mc::VM_AWAIT: case mc::VM_ASSERT: case mc::VM_JZ: case mc::VM_JNZ: case mc::VM_POP:
         case mc::VM_ADD: case mc::VM_SUB: case mc::VM_MUL: case mc::VM_DIV: case mc::VM_MOD: case mc::VM_EQ: case mc::VM_NE: case mc::VM_LT:
-        case mc::VM_LE: case mc::VM_GT: case mc::VM_GE: case mc::VM_OR: case mc::VM_AND: case mc::VM_ANDN: depth--; break;
-        case mc::VM_STOREX: depth -= 2; break;
+        case mc::VM_LE: case mc::VM_GT: case mc::VM_GE: case mc::VM_OR: case mc::VM_AND: case mc::VM_ANDN: case mc::VM_APPEND: case mc::VM_SEQSEL: depth--; break;
+        case mc::VM_SEQLEN: depth++; break;
+        case mc::VM_STOREX: case mc::VM_STORESEQ: depth -= 2; break;
         case mc::VM_HALT: depth = 0; break;
         default: break;
         }
@@ -239,21 +241,93 @@ struct Compiler {
     }
 
     // ---- bounded sequences
-    static constexpr int SEQ_CAP = 8;  // element cells per sequence variable; a longer sequence is MC_EOVERFLOW, never truncated
+    // element cells per sequence; a longer sequence is MC_EOVERFLOW, never truncated.  $TLAMC_PCAL_SEQ (1 .. 16) changes it: an ARRAY of
+    // sequences (the channels of a message-passing algorithm) costs |domain| x (cells + 1) of the 128 cells a state has
+    static int seq_cap() {
+        const char *e = getenv("TLAMC_PCAL_SEQ");
+        const int n = e ? atoi(e) : 8;
+        return n < 1 ? 1 : n > 16 ? 16 : n;
+    }
     const VarInfo *seq_var(const EP &e) {
         if (e->k != Expr::ID) return nullptr;
         for (size_t i = binds.size(); i-- > 0;) if (binds[i].name == e->s) return nullptr;
         auto vi = var_index.find(e->s);
         return vi != var_index.end() && P.vars[(size_t)vi->second].seq ? &P.vars[(size_t)vi->second] : nullptr;
     }
-    void emit_seq(int op, const VarInfo &v) { c.push_back(op); track(op); c.push_back(v.base); c.push_back(v.cap); }
+    // a sequence: a sequence variable q, or the element box[i] of an ARRAY of sequences (`box = [p \in S |-> <<>>]`)
+    struct SeqRef {
+        const VarInfo *v = nullptr;
+        EP idx;    // array: the index as it is evaluated (possibly a temporary that holds it)
+        EP same;   // array: the index as it was written (what `box[i] := Append(box[i], e)` compares)
+        explicit operator bool() const { return v != nullptr; }
+    };
+    std::map<std::string, EP> bound_orig;   // a temporary that holds an index -> the expression it was evaluated from
+    SeqRef seq_ref(const EP &e) {
+        if (e->k == Expr::ID) {
+            const VarInfo *v = seq_var(e);
+            return v && !v->array ? SeqRef{v, nullptr, nullptr} : SeqRef{};
+        }
+        if (e->k == Expr::INDEX && e->a[0]->k == Expr::ID) {
+            const VarInfo *v = seq_var(e->a[0]);
+            if (v && v->array) return SeqRef{v, e->a[1], e->a[1]};
+        }
+        return SeqRef{};
+    }
+    static bool same_expr(const EP &a, const EP &b) {
+        if (!a || !b) return !a && !b;
+        if (a->k != b->k || a->num != b->num || a->s != b->s || a->bound != b->bound || a->names != b->names || a->a.size() != b->a.size()) return false;
+        for (size_t k = 0; k < a->a.size(); k++) if (!same_expr(a->a[k], b->a[k])) return false;
+        return true;
+    }
+    void emit_sel(const SeqRef &r) {  // selects the element of the array the next sequence instruction works on
+        if (!r.idx) return;
+        if (!contiguous(r.v->ids)) cfail("`" + r.v->name + "` is indexed but its domain is not an integer interval", r.idx->pos);
+        ex(r.idx);
+        c.push_back(mc::VM_SEQSEL);
+        track(mc::VM_SEQSEL);
+        c.push_back((int)r.v->ids[0]);
+        c.push_back((int)r.v->ids.size());
+        c.push_back(r.v->cap + 1);
+    }
+    void emit_seq(int op, const SeqRef &r) { emit_sel(r); c.push_back(op); track(op); c.push_back(r.v->base); c.push_back(r.v->cap); }
+    void emit_len(const SeqRef &r) {
+        if (!r.idx) { emit(mc::VM_LOAD, r.v->base); return; }
+        emit_seq(mc::VM_SEQLEN, r);
+    }
+    // an array index that is neither a constant nor `self` is evaluated ONCE, into a temporary the reference then reads
+    // (returns the number of temporaries taken: the caller gives them back)
+    int pin_index(SeqRef &r) {
+        long long cv;
+        if (!r.idx || const_scalar(r.idx, cv) || (r.idx->k == Expr::ID && r.idx->s == "self")) return 0;
+        if (r.idx->k == Expr::ID && bound_orig.count(r.idx->s)) return 0;
+        const int t = new_temp(r.idx->pos);
+        ex(r.idx);
+        emit(mc::VM_STORET, t);
+        const std::string name = "\001s" + std::to_string(t);
+        binds.push_back({name, t, false, 0});
+        bound_orig[name] = r.same;
+        auto id = std::make_shared<Expr>();
+        id->k = Expr::ID;
+        id->s = name;
+        id->pos = r.idx->pos;
+        r.idx = id;
+        return 1;
+    }
+    void unpin_index(int n) {
+        if (!n) return;
+        bound_orig.erase(binds.back().name);
+        binds.pop_back();
+        next_temp--;
+    }
     // q = <<a, b>>  (also #): Len(q) = n /\ q[1] = a /\ ...
-    void seq_equals(const VarInfo &q, const EP &tuple, bool negate) {
-        emit(mc::VM_LOAD, q.base); emit(mc::VM_PUSH, (int)tuple->a.size()); emit(mc::VM_EQ);
+    void seq_equals(SeqRef q, const EP &tuple, bool negate) {
+        const int pinned = pin_index(q);
+        emit_len(q); emit(mc::VM_PUSH, (int)tuple->a.size()); emit(mc::VM_EQ);
         std::vector<int> fails;
         fails.push_back(emit_jump(mc::VM_JZ));
         for (size_t k = 0; k < tuple->a.size(); k++) {
-            emit(mc::VM_LOAD, q.base + 1 + (int)k); ex(tuple->a[k]); emit(mc::VM_EQ);
+            if (q.idx) { emit(mc::VM_PUSH, 1 + (int)k); emit_seq(mc::VM_LOADSEQ, q); } else emit(mc::VM_LOAD, q.v->base + 1 + (int)k);
+            ex(tuple->a[k]); emit(mc::VM_EQ);
             fails.push_back(emit_jump(mc::VM_JZ));
         }
         emit(mc::VM_PUSH, negate ? 0 : 1);
@@ -261,45 +335,105 @@ struct Compiler {
         for (int f : fails) patch(f);
         emit(mc::VM_PUSH, negate ? 1 : 0);
         patch(jend);
+        unpin_index(pinned);
     }
     // dst := <sequence expression>: <<..>>, q, Append(q, e), Tail(q), q \o <<..>>
-    void assign_seq(const VarInfo &dst, const EP &e) {
+    void assign_seq(SeqRef dst, const EP &e) {
+        const int pinned = pin_index(dst);
         auto copy_from = [&](const EP &src) {
-            const VarInfo *sv = seq_var(src);
+            const SeqRef sv = seq_ref(src);
             if (!sv) cfail("expected a sequence variable", src->pos);
-            if (sv != &dst) { c.push_back(mc::VM_SEQCOPY); c.push_back(dst.base); c.push_back(sv->base); c.push_back(dst.cap); }
+            if (sv.v == dst.v) {
+                const EP want = dst.same && dst.same->k == Expr::ID && bound_orig.count(dst.same->s) ? bound_orig[dst.same->s] : dst.same;
+                if (dst.v->array && !same_expr(sv.same, want))
+                    cfail("`" + dst.v->name + "[i] := ...` can only start from the same element " + dst.v->name + "[i] (copying one sequence of the array to another is not supported)", src->pos);
+                return;
+            }
+            if (sv.v->array || dst.v->array) cfail("copying a sequence into / out of the array `" + (dst.v->array ? dst.v->name : sv.v->name) + "` is not supported", src->pos);
+            c.push_back(mc::VM_SEQCOPY); c.push_back(dst.v->base); c.push_back(sv.v->base); c.push_back(dst.v->cap);
+        };
+        auto elems_to_temps = [&](const std::vector<EP> &xs, std::vector<int> &tmp) {
+            for (const auto &x : xs) ex(x);
+            for (size_t k = 0; k < xs.size(); k++) tmp.push_back(new_temp(e->pos));
+            for (size_t k = xs.size(); k-- > 0;) emit(mc::VM_STORET, tmp[k]);
         };
         if (e->k == Expr::TUPLE) {
             // the elements may read dst (q := <<Head(q)>>): evaluate them first
-            if ((int)e->a.size() > dst.cap) cfail("sequence literal longer than the " + std::to_string(dst.cap) + " cells a sequence variable has", e->pos);
-            for (const auto &x : e->a) ex(x);
+            if ((int)e->a.size() > dst.v->cap) cfail("sequence literal longer than the " + std::to_string(dst.v->cap) + " cells a sequence variable has", e->pos);
             std::vector<int> tmp;
-            for (size_t k = 0; k < e->a.size(); k++) { tmp.push_back(new_temp(e->pos)); }
-            for (size_t k = e->a.size(); k-- > 0;) emit(mc::VM_STORET, tmp[k]);
+            elems_to_temps(e->a, tmp);
             emit_seq(mc::VM_SEQCLR, dst);
-            for (size_t k = 0; k < e->a.size(); k++) { emit(mc::VM_LOADT, tmp[k]); emit_seq(mc::VM_APPEND, dst); }
+            for (int t : tmp) { emit(mc::VM_LOADT, t); emit_seq(mc::VM_APPEND, dst); }
             next_temp -= (int)tmp.size();
-            return;
-        }
-        if (e->k == Expr::ID) { copy_from(e); return; }
-        if (e->k == Expr::CALL && e->s == "Append" && e->a.size() == 2) {
+        } else if (e->k == Expr::ID || (e->k == Expr::INDEX && seq_ref(e))) {
+            copy_from(e);
+        } else if (e->k == Expr::CALL && e->s == "Append" && e->a.size() == 2) {
             ex(e->a[1]);  // evaluated on the old value of every variable
             copy_from(e->a[0]);
             emit_seq(mc::VM_APPEND, dst);
-            return;
-        }
-        if (e->k == Expr::CALL && e->s == "Tail" && e->a.size() == 1) { copy_from(e->a[0]); emit_seq(mc::VM_TAIL, dst); return; }
-        if (e->k == Expr::BINOP && (e->s == "\\o" || e->s == "\\circ") && e->a[1]->k == Expr::TUPLE) {
-            for (const auto &x : e->a[1]->a) ex(x);
+        } else if (e->k == Expr::CALL && e->s == "Tail" && e->a.size() == 1) {
+            copy_from(e->a[0]);
+            emit_seq(mc::VM_TAIL, dst);
+        } else if (e->k == Expr::BINOP && (e->s == "\\o" || e->s == "\\circ") && e->a[1]->k == Expr::TUPLE) {
             std::vector<int> tmp;
-            for (size_t k = 0; k < e->a[1]->a.size(); k++) tmp.push_back(new_temp(e->pos));
-            for (size_t k = tmp.size(); k-- > 0;) emit(mc::VM_STORET, tmp[k]);
+            elems_to_temps(e->a[1]->a, tmp);
             copy_from(e->a[0]);
             for (int t : tmp) { emit(mc::VM_LOADT, t); emit_seq(mc::VM_APPEND, dst); }
             next_temp -= (int)tmp.size();
-            return;
+        } else {
+            cfail("a sequence variable can be assigned <<...>>, another sequence, Append(q, e), Tail(q) or q \\o <<...>>", e->pos);
         }
-        cfail("a sequence variable can be assigned <<...>>, another sequence, Append(q, e), Tail(q) or q \\o <<...>>", e->pos);
+        unpin_index(pinned);
+    }
+    // the element type of a sequence that starts empty: that of the first value an assignment puts into it
+    char seq_elem_type(const std::string &name) {
+        char found = 0;
+        std::function<void(const std::vector<SP> &)> walk = [&](const std::vector<SP> &v) {
+            for (const auto &s : v) {
+                if (found) return;
+                if (s->k == Stmt::ASSIGN) {
+                    std::vector<const Stmt *> all{s.get()};
+                    for (const auto &o : s->more) all.push_back(o.get());
+                    for (const Stmt *a : all) {
+                        if (a->var != name || !a->e || found) continue;
+                        const EP &e = a->e;
+                        if (e->k == Expr::TUPLE && !e->a.empty()) found = type_of(e->a[0]);
+                        else if (e->k == Expr::CALL && e->s == "Append" && e->a.size() == 2) found = type_of(e->a[1]);
+                        else if (e->k == Expr::BINOP && (e->s == "\\o" || e->s == "\\circ") && e->a[1]->k == Expr::TUPLE && !e->a[1]->a.empty()) found = type_of(e->a[1]->a[0]);
+                    }
+                }
+                for (const auto &b : s->blocks) walk(b);
+            }
+        };
+        for (const auto &p : m.procs) walk(p.body);
+        return found ? found : 'i';
+    }
+    // the scalar operands of a sequence expression (the elements of <<..>>, Append's value, the elements behind \o): `||` evaluates
+    // them before anything is stored, and hands assign_seq the expression with temporaries in their places
+    EP seq_operands_to_temps(const EP &e, int &taken) {
+        auto hold = [&](const EP &x) {
+            const int t = new_temp(x->pos);
+            ex(x);
+            emit(mc::VM_STORET, t);
+            const std::string name = "\001o" + std::to_string(t);
+            binds.push_back({name, t, false, 0});
+            taken++;
+            auto id = std::make_shared<Expr>();
+            id->k = Expr::ID;
+            id->s = name;
+            id->pos = x->pos;
+            return EP(id);
+        };
+        auto c2 = std::make_shared<Expr>(*e);
+        if (e->k == Expr::TUPLE) { for (auto &x : c2->a) x = hold(x); return c2; }
+        if (e->k == Expr::CALL && e->s == "Append" && e->a.size() == 2) { c2->a[1] = hold(e->a[1]); return c2; }
+        if (e->k == Expr::BINOP && (e->s == "\\o" || e->s == "\\circ") && e->a[1]->k == Expr::TUPLE) {
+            auto t2 = std::make_shared<Expr>(*e->a[1]);
+            for (auto &x : t2->a) x = hold(x);
+            c2->a[1] = t2;
+            return c2;
+        }
+        return c2;  // Tail(q), q: nothing to evaluate
     }
 
     // ---- sets of small naturals as masks
@@ -401,10 +535,10 @@ struct Compiler {
         case Expr::CALL: {  // an operator of the define block / of the module, inlined: arguments evaluated once
             if (e->s == "Cardinality" && e->a.size() == 1) { ex_set(e->a[0]); emit(mc::VM_POPCNT); return; }
             if ((e->s == "Len" || e->s == "Head") && e->a.size() == 1) {
-                const VarInfo *q = seq_var(e->a[0]);
-                if (!q) cfail(e->s + " needs a sequence variable", e->pos);
-                if (e->s == "Len") emit(mc::VM_LOAD, q->base);
-                else { emit(mc::VM_PUSH, 1); emit_seq(mc::VM_LOADSEQ, *q); }
+                const SeqRef q = seq_ref(e->a[0]);
+                if (!q) cfail(e->s + " needs a sequence variable (or an element of an array of sequences)", e->pos);
+                if (e->s == "Len") emit_len(q);
+                else { emit(mc::VM_PUSH, 1); emit_seq(mc::VM_LOADSEQ, q); }
                 return;
             }
             const Definition *def = nullptr;
@@ -435,8 +569,9 @@ struct Compiler {
             return;
         }
         case Expr::INDEX: {
+            if (const SeqRef q = seq_ref(e->a[0])) { ex(e->a[1]); emit_seq(mc::VM_LOADSEQ, q); return; }   // q[k], box[i][k]
             if (e->a[0]->k != Expr::ID) cfail("only `name[index]` is supported", e->pos);
-            if (const VarInfo *q = seq_var(e->a[0])) { ex(e->a[1]); emit_seq(mc::VM_LOADSEQ, *q); return; }
+            if (seq_var(e->a[0])) cfail("the sequence `" + e->a[0]->s + "[..]` is used as a value here; supported: Len, Head, " + e->a[0]->s + "[i][k], = / # <<...>>", e->pos);
             auto vi = var_index.find(e->a[0]->s);
             if (vi == var_index.end() || !P.vars[(size_t)vi->second].array) cfail("`" + e->a[0]->s + "` is not a function variable", e->pos);
             if (proc && proc_locals.count(e->a[0]->s) && proc->is_set && P.multi)
@@ -493,8 +628,8 @@ struct Compiler {
         if (o == "\\subseteq") { ex_set(e->a[0]); ex_set(e->a[1]); emit(mc::VM_ANDN); emit(mc::VM_PUSH, 0); emit(mc::VM_EQ); return; }
         if (o == "=" || o == "#") {
             for (int side = 0; side < 2; side++)
-                if (const VarInfo *q = seq_var(e->a[(size_t)side]))
-                    if (e->a[(size_t)(1 - side)]->k == Expr::TUPLE) { seq_equals(*q, e->a[(size_t)(1 - side)], o == "#"); return; }
+                if (const SeqRef q = seq_ref(e->a[(size_t)side]))
+                    if (e->a[(size_t)(1 - side)]->k == Expr::TUPLE) { seq_equals(q, e->a[(size_t)(1 - side)], o == "#"); return; }
         }
         static const std::pair<const char *, int> ops[] = {{"=", mc::VM_EQ},  {"#", mc::VM_NE},  {"<", mc::VM_LT},    {">", mc::VM_GT},
                                                           {"<=", mc::VM_LE}, {">=", mc::VM_GE}, {"+", mc::VM_ADD},   {"-", mc::VM_SUB},
@@ -703,10 +838,23 @@ struct Compiler {
             for (const auto &x : s->more) all.push_back(x);
             struct Saved { int t_idx, t_val; };
             std::vector<Saved> sv;
+            std::vector<EP> seq_rhs;   // per assignment: the right-hand side of a whole-sequence assignment with its operands in temporaries (else null)
+            int seq_taken = 0;
             for (const auto &x : all) {
                 auto vi = var_index.find(x->var);
                 if (vi == var_index.end()) cfail("assignment to `" + x->var + "`, which is not a variable of the algorithm", x->pos);
-                if (P.vars[(size_t)vi->second].seq || P.vars[(size_t)vi->second].set) cfail("`||` with a sequence or set variable is not supported", x->pos);
+                const VarInfo &xv = P.vars[(size_t)vi->second];
+                if (xv.set) cfail("`||` with a set variable is not supported", x->pos);
+                if (xv.seq && (xv.array || !x->idx)) {
+                    // a whole sequence (q, box[i]): its scalar operands are evaluated now, the sequence it starts from must be itself — and then
+                    // nothing another assignment of the statement stores can be read by this one
+                    Saved q{-1, -1};
+                    if (x->idx) { q.t_idx = new_temp(x->pos); ex(x->idx); emit(mc::VM_STORET, q.t_idx); }
+                    seq_rhs.push_back(seq_operands_to_temps(x->e, seq_taken));
+                    sv.push_back(q);
+                    continue;
+                }
+                seq_rhs.push_back(nullptr);
                 Saved q{-1, new_temp(x->pos)};
                 if (x->idx) { q.t_idx = new_temp(x->pos); ex(x->idx); emit(mc::VM_STORET, q.t_idx); }
                 ex_rhs(x->e);
@@ -722,19 +870,21 @@ struct Compiler {
                 ve->k = Expr::ID;
                 ve->s = vname;
                 ve->pos = one->pos;
-                one->e = ve;
+                one->e = seq_rhs[k] ? seq_rhs[k] : ve;
                 if (one->idx) {
                     binds.push_back({iname, sv[k].t_idx, false, 0});
                     auto ie = std::make_shared<Expr>(*ve);
                     ie->s = iname;
+                    bound_orig[iname] = all[k]->idx;
                     one->idx = ie;
                 }
                 assign(one);
                 binds.pop_back();
-                if (all[k]->idx) binds.pop_back();
+                if (all[k]->idx) { binds.pop_back(); bound_orig.erase(iname); }
             }
-            next_temp -= (int)sv.size();
-            for (const auto &q : sv) if (q.t_idx >= 0) next_temp--;
+            for (int k = 0; k < seq_taken; k++) binds.pop_back();   // (pushed before the \001v / \001i names, which are gone by now)
+            next_temp -= seq_taken;
+            for (const auto &q : sv) { if (q.t_val >= 0) next_temp--; if (q.t_idx >= 0) next_temp--; }
             return;
         }
         auto vi = var_index.find(s->var);
@@ -749,8 +899,11 @@ struct Compiler {
         }
         if (v.seq) {
             for (const auto &pr : m.procs) for (const auto &l : pr.locals) if (l.name == s->var && &pr != proc) cfail("`" + s->var + "` cannot be assigned here", s->pos);
-            if (s->idx) { ex(s->idx); ex(s->e); emit_seq(mc::VM_STORESEQ, v); }
-            else assign_seq(v, s->e);
+            if (v.array) {   // box[i] := <sequence expression>
+                if (!s->idx) cfail("assigning the whole array of sequences `" + s->var + "` is not supported: assign its elements (" + s->var + "[i] := Append(" + s->var + "[i], e), ...)", s->pos);
+                assign_seq(SeqRef{&v, s->idx, s->idx}, s->e);
+            } else if (s->idx) { ex(s->idx); ex(s->e); emit_seq(mc::VM_STORESEQ, SeqRef{&v, nullptr, nullptr}); }
+            else assign_seq(SeqRef{&v, nullptr, nullptr}, s->e);
             return;
         }
         const bool self_indexed = proc && proc_locals.count(s->var) && proc->is_set && P.multi;
@@ -1062,6 +1215,7 @@ struct Compiler {
             var_index[name] = (int)P.vars.size();
             P.vars.push_back(v);
         };
+        std::vector<std::string> untyped_seqs;   // sequences that start empty: typed by what is put into them, once every variable is known
         auto decl_var = [&](const VarDecl &d, const Proc *owner) {
             const bool per_inst = owner && owner->is_set && P.multi;
             if (d.no_init) {  // a scalar whose type is that of its first assignment (fixed below, once every variable is known)
@@ -1079,8 +1233,20 @@ struct Compiler {
                 add_var(d.name, false, {}, d.init->a.empty() ? 'i' : type_of(d.init->a[0]));
                 VarInfo &v = P.vars.back();
                 v.seq = true;
-                v.cap = SEQ_CAP;
-                nv += SEQ_CAP;  // add_var counted the Len cell
+                v.cap = seq_cap();
+                nv += v.cap;  // add_var counted the Len cell
+                if (d.init->a.empty()) untyped_seqs.push_back(d.name);
+            } else if (d.init->k == Expr::FUNCDEF && !d.in_set && d.init->a[1]->k == Expr::TUPLE) {   // an ARRAY of sequences: the channels of a message-passing algorithm
+                if (per_inst) cfail("process-local function variables are not supported (`" + d.name + "`)", d.pos);
+                std::vector<long long> dom;
+                if (!const_set(d.init->a[0], dom)) cfail("the domain of `" + d.name + "` must be a constant set", d.pos);
+                if (!contiguous(dom)) cfail("the domain of the array of sequences `" + d.name + "` must be an integer interval", d.pos);
+                add_var(d.name, true, dom, d.init->a[1]->a.empty() ? 'i' : type_of(d.init->a[1]->a[0]));
+                if (d.init->a[1]->a.empty()) untyped_seqs.push_back(d.name);
+                VarInfo &v = P.vars.back();
+                v.seq = true;
+                v.cap = seq_cap();
+                nv += v.cap * (int)dom.size();  // add_var counted one (Len) cell per element
             } else if (d.init->k == Expr::FUNCDEF && !d.in_set) {
                 if (per_inst) cfail("process-local function variables are not supported (`" + d.name + "`)", d.pos);
                 std::vector<long long> dom;
@@ -1096,6 +1262,7 @@ struct Compiler {
         P.pc_base = nv;
         add_var("pc", P.multi, P.multi ? procset : std::vector<long long>{}, 's');
         for (const auto &p : m.procs) for (const auto &l : p.locals) decl_var(l, &p);
+        for (const auto &name : untyped_seqs) P.vars[(size_t)var_index[name]].type = seq_elem_type(name);
         for (auto &v : P.vars) {
             if (!v.defval) continue;
             const Expr *rhs = nullptr;
@@ -1127,9 +1294,19 @@ struct Compiler {
                     emit(mc::VM_STORE, v.base + (int)k);
                     have_self_const = false;
                 }
+            } else if (v.seq && v.array) {
+                for (size_t k = 0; k < v.ids.size(); k++) {
+                    binds.push_back({d.init->bound, 0, true, v.ids[k]});
+                    auto at = std::make_shared<Expr>();
+                    at->k = Expr::NUM;
+                    at->num = v.ids[k];
+                    at->pos = d.pos;
+                    assign_seq(SeqRef{&v, at, at}, d.init->a[1]);
+                    binds.pop_back();
+                }
             } else if (v.seq) {
                 if (owner && P.multi) { have_self_const = true; self_const = ids_of[owner][0]; }
-                assign_seq(v, d.init);
+                assign_seq(SeqRef{&v, nullptr, nullptr}, d.init);
                 have_self_const = false;
             } else if (per_inst) {
                 for (size_t k = 0; k < v.ids.size(); k++) {
@@ -1281,14 +1458,18 @@ int vm_format(const void *host, const int32_t *vals, char *buf, size_t cap) {
     for (const auto &v : P.vars) {
         if (!s.empty()) s += "\n";
         s += "/\\ " + v.name + " = ";
-        if (v.seq) {
-            s += "<<";
-            for (int k = 0; k < vals[v.base] && k < v.cap; k++) s += (k ? ", " : "") + pcal::fmt_val(P, v.type, vals[v.base + 1 + k]);
-            s += ">>";
-            continue;
-        }
-        auto one = [&](int32_t x) { return v.set ? pcal::fmt_set(P, v.type, x) : pcal::fmt_val(P, v.type, x); };
-        if (!v.array) { s += one(vals[v.base]); continue; }
+        auto seq_at = [&](int base) {
+            std::string t = "<<";
+            for (int k = 0; k < vals[base] && k < v.cap; k++) t += (k ? ", " : "") + pcal::fmt_val(P, v.type, vals[base + 1 + k]);
+            return t + ">>";
+        };
+        if (v.seq && !v.array) { s += seq_at(v.base); continue; }
+        auto one = [&](int k) {   // element k of the array (or the variable itself)
+            if (v.seq) return seq_at(v.base + k * (v.cap + 1));
+            const int32_t x = vals[v.base + k];
+            return v.set ? pcal::fmt_set(P, v.type, x) : pcal::fmt_val(P, v.type, x);
+        };
+        if (!v.array) { s += one(0); continue; }
         // TLC prints a function whose domain is 1..n as a tuple, any other as (k :> v @@ ...) in ascending key order
         std::vector<size_t> order(v.ids.size());
         for (size_t k = 0; k < order.size(); k++) order[k] = k;
@@ -1297,12 +1478,12 @@ int vm_format(const void *host, const int32_t *vals, char *buf, size_t cap) {
         for (size_t k = 0; k < order.size(); k++) seq &= v.ids[order[k]] == (long long)k + 1;
         if (seq) {
             s += "<<";
-            for (size_t k = 0; k < order.size(); k++) s += (k ? ", " : "") + one(vals[v.base + (int)order[k]]);
+            for (size_t k = 0; k < order.size(); k++) s += (k ? ", " : "") + one((int)order[k]);
             s += ">>";
         } else {
             s += "(";
             for (size_t k = 0; k < order.size(); k++)
-                s += (k ? " @@ " : "") + std::to_string(v.ids[order[k]]) + " :> " + one(vals[v.base + (int)order[k]]);
+                s += (k ? " @@ " : "") + std::to_string(v.ids[order[k]]) + " :> " + one((int)order[k]);
             s += ")";
         }
     }

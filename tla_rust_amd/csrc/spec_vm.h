@@ -26,7 +26,10 @@ enum VmOp : int32_t {
     // sets of small naturals (0..31) as 32-bit masks
     VM_BIT, VM_OR, VM_AND, VM_ANDN, VM_POPCNT,
     // inside a defined operator the variables are the UNPRIMED ones: reads come from the state before the step
-    VM_OLD_ON, VM_OLD_OFF
+    VM_OLD_ON, VM_OLD_OFF,
+    // ARRAYS of bounded sequences (`box = [p \in 1..N |-> <<>>]`: the channels of a message-passing algorithm): element k of the array is
+    // the sequence at base + k * (cap + 1).  VM_SEQSEL pops the array index and selects the element the NEXT sequence instruction works on
+    VM_SEQSEL, VM_SEQLEN
 };
 
 // header words of the program image
@@ -87,6 +90,7 @@ struct SpecVmT {
         const int32_t *__restrict__ c = p.code;
         int32_t st[STACK], t[TEMPS];
         int sp = 0, pc = entry, old_depth = 0;
+        int32_t sb = 0;         // offset of the selected element of an array of sequences (VM_SEQSEL), consumed by the next sequence instruction
         const int32_t *rd = v;  // where variable READS come from: v, or `old` inside a defined operator
         result = 0;
         aux = 0;
@@ -164,8 +168,25 @@ struct SpecVmT {
             case VM_ASSERT: { const int32_t id = c[pc++]; if (!st[--sp]) { aux = id; return R_ASSERT; } break; }
             case VM_SETPC: v[p.pc_base + inst] = c[pc++]; break;
             case VM_POP: --sp; break;
+            case VM_SEQSEL: {  // lo, n, stride : index on the stack
+                const int32_t lo = c[pc], n = c[pc + 1], stride = c[pc + 2];
+                pc += 3;
+                const int32_t i = st[--sp] - lo;
+                if (i < 0 || i >= n) return R_ERROR;  // TLC: function applied outside its domain
+                sb = i * stride;
+                break;
+            }
+            case VM_SEQLEN: {  // base, cap : Len of the selected sequence
+                const int32_t base = c[pc] + sb;
+                sb = 0;
+                pc += 2;
+                if (sp >= STACK) return R_ERROR;
+                st[sp++] = rd[base];
+                break;
+            }
             case VM_LOADSEQ: {  // base, cap : 1-based index on the stack; Head(q) = q[1]
-                const int32_t base = c[pc], cap = c[pc + 1];
+                const int32_t base = c[pc] + sb, cap = c[pc + 1];
+                sb = 0;
                 pc += 2;
                 const int32_t i = st[sp - 1];
                 if (i < 1 || i > rd[base] || i > cap) return R_ERROR;  // TLC: index outside 1..Len(q), Head(<<>>)
@@ -173,7 +194,8 @@ struct SpecVmT {
                 break;
             }
             case VM_STORESEQ: {  // base, cap : value on top, index below
-                const int32_t base = c[pc], cap = c[pc + 1];
+                const int32_t base = c[pc] + sb, cap = c[pc + 1];
+                sb = 0;
                 pc += 2;
                 const int32_t val = st[--sp], i = st[--sp];
                 if (i < 1 || i > v[base] || i > cap) return R_ERROR;
@@ -181,7 +203,8 @@ struct SpecVmT {
                 break;
             }
             case VM_APPEND: {  // base, cap : value on the stack
-                const int32_t base = c[pc], cap = c[pc + 1];
+                const int32_t base = c[pc] + sb, cap = c[pc + 1];
+                sb = 0;
                 pc += 2;
                 const int32_t val = st[--sp], n = v[base];
                 if (n >= cap) return R_OVERFLOW;  // longer than the cells this program reserves: reported, never truncated
@@ -190,7 +213,8 @@ struct SpecVmT {
                 break;
             }
             case VM_TAIL: {  // base, cap
-                const int32_t base = c[pc], cap = c[pc + 1];
+                const int32_t base = c[pc] + sb, cap = c[pc + 1];
+                sb = 0;
                 pc += 2;
                 const int32_t n = v[base];
                 if (n < 1) return R_ERROR;  // Tail(<<>>)
@@ -200,7 +224,8 @@ struct SpecVmT {
                 break;
             }
             case VM_SEQCLR: {
-                const int32_t base = c[pc], cap = c[pc + 1];
+                const int32_t base = c[pc] + sb, cap = c[pc + 1];
+                sb = 0;
                 pc += 2;
                 for (int32_t k = 0; k <= cap; ++k) v[base + k] = 0;
                 break;
