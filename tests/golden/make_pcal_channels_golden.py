@@ -1,0 +1,27 @@
+"""tests/golden/pcal_channels.json: two-phase commit over channels with 4 and 5 resource managers — per-level counts of the HAND-WRITTEN
+pcal2tla-style translation tests/golden/pcal_records/TwoPhaseChannels.tla (chan one function to sequences of records), evaluated by the
+product's host evaluator tla_rust_amd/csrc/tlaeval.cpp (through its test door).  The compiled program (one sequence per field, host VM
+and GPU) must reproduce them: another text, another engine.  RM = 5 takes the evaluator a few minutes.
+
+    python tests/golden/make_pcal_channels_golden.py"""
+import json
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+import helpers  # noqa: E402
+
+F = ROOT / "tests" / "golden" / "pcal_records"
+out = {}
+for rm, cells in ((4, 8), (5, 5)):
+    with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
+        f.write(f"SPECIFICATION Spec\nCONSTANT RM = {rm}\nCONSTANT Eager = FALSE\n"
+                "INVARIANT Consistent CommitNeedsAllVotes InboxHoldsVotes FromTheCoordinator AtMostTwoWaiting\n")
+    r = helpers.tlaeval_run(F / "TwoPhaseChannels.tla", f.name, search=[])
+    assert r["rc"] == 0 and r["verdict"] == 0, r
+    out[f"two_phase_channels_rm{rm}"] = dict(RM=rm, seq_cells=cells, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
+                                             source="tlaeval.cpp on tests/golden/pcal_records/TwoPhaseChannels.tla (hand-written record-valued translation)")
+    print(rm, r["distinct"], r["generated"], r["depth"], r["seconds"])
+(ROOT / "tests" / "golden" / "pcal_channels.json").write_text(json.dumps(out, indent=1) + "\n")

@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "oracle"))
 sys.path.insert(0, str(ROOT / "tests"))
 from tla_eval import Checker  # noqa: E402
-from test_pcal import CASES, strip_translation  # noqa: E402
+from test_pcal import CASES, CHANNEL_STEMS, strip_translation  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 MC = ROOT / "tla_rust_amd" / "_build" / "mc"
@@ -38,7 +38,8 @@ def cfg_text(invs, consts):
 
 # (the Michael-Scott queue was added after the round's last GPU minute: its GPU cases live in tests/test_gpu_zz_ms_queue.py, which sorts
 #  behind every other GPU file — under the driver's `pytest -x` a surprise there cannot keep the rest of the suite from running)
-GPU_CASES = [c for c in CASES if not c[0].stem.startswith("ms_queue")]
+# (... and so do the channel specs of the round's last part: tests/test_gpu_zz_channels.py)
+GPU_CASES = [c for c in CASES if not c[0].stem.startswith("ms_queue") and c[0].stem not in CHANNEL_STEMS]
 
 
 @pytest.mark.parametrize("path,invs,consts", GPU_CASES, ids=lambda v: v.stem if isinstance(v, Path) else None)

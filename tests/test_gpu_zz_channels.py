@@ -1,0 +1,58 @@
+"""GPU tests of the PlusCal CHANNELS (arrays of sequences, sequences of records: specs/pluscal/two_phase_channels.tla, mailboxes.tla;
+spec_vm.h VM_SEQSEL / VM_SEQLEN, pcal.cpp RecordFlattener).  Added late in round 5; like tests/test_gpu_zz_ms_queue.py the file sorts
+behind every other GPU file so that under `pytest -x` a surprise here cannot keep the rest of the suite from running."""
+import json
+import os
+from pathlib import Path
+
+import pytest
+
+from test_gpu_pcal import ROOT, amd, cfg_text, check_compiled_program_on_gpu, run_mc  # noqa: F401  (amd: the fixture)
+from test_pcal import CASES, CHANNEL_STEMS
+
+pytestmark = pytest.mark.gpu
+CH = [c for c in CASES if c[0].stem in CHANNEL_STEMS]
+GOLDEN = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())
+INVS = ["Consistent", "CommitNeedsAllVotes", "InboxHoldsVotes", "FromTheCoordinator", "AtMostTwoWaiting"]
+
+
+@pytest.mark.parametrize("path,invs,consts", CH, ids=lambda v: v.stem if isinstance(v, Path) else None)
+def test_channels_compiled_program_on_gpu_vs_tla_evaluator(amd, path, invs, consts):  # noqa: F811
+    """counters, verdict, trace length and the SET of states of every BFS level equal those of oracle/tla_eval.py on the translation"""
+    check_compiled_program_on_gpu(amd, path, invs, consts)
+
+
+def test_three_mailboxes_with_four_cells_per_sequence(amd, monkeypatch):  # noqa: F811
+    """$TLAMC_PCAL_SEQ = 4: three mailboxes of three-field records + two more sequence variables fit the 128 cells of a state (deadlock:
+    a node that has its pong leaves without answering its left neighbour's ping)"""
+    monkeypatch.setenv("TLAMC_PCAL_SEQ", "4")
+    check_compiled_program_on_gpu(amd, ROOT / "specs" / "pluscal" / "mailboxes.tla", ["LogOk", "Pongs", "HeardTheLeft"], {"N": 3})
+
+
+@pytest.mark.parametrize("case", ["two_phase_channels_rm4", "two_phase_channels_rm5"])
+def test_two_phase_commit_larger_models_equal_the_record_valued_translation(amd, monkeypatch, case):  # noqa: F811
+    """4 / 5 resource managers (98 945 / 2 848 539 states): per-level counts of the HAND-WRITTEN pcal2tla-style translation
+    (tests/golden/pcal_records/TwoPhaseChannels.tla: chan one function to sequences of records) evaluated by the product's host
+    evaluator tlaeval.cpp — another text, another engine — tests/golden/pcal_channels.json"""
+    g = GOLDEN[case]
+    monkeypatch.setenv("TLAMC_PCAL_SEQ", str(g["seq_cells"]))
+    prog = amd.Program((ROOT / "specs" / "pluscal" / "two_phase_channels.tla").read_text(), cfg_text(INVS, {"RM": g["RM"], "Eager": False}))
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 24, arena_capacity=1 << 22, chunk_states=1 << 16)
+    r = eng.run()
+    assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (g["distinct"], g["generated"], g["depth"], "ok", 0)
+    assert list(r.levels) == g["levels"]
+    eng.close()
+    prog.close()
+
+
+def test_mc_on_two_phase_commit_over_channels():
+    """`mc two_phase_channels.tla` = tlc on the message-passing protocol; the eager coordinator (two_phase_channels_eager.cfg) commits on the
+    first yes vote: Consistent is violated, with a trace"""
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "two_phase_channels.tla")
+    assert rc == 0, err
+    assert "11905 states generated, 4523 distinct states found, 0 states left on queue." in out
+    assert "The depth of the complete state graph search is 28." in out
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "two_phase_channels.tla", "-config", ROOT / "specs" / "pluscal" / "two_phase_channels_eager.cfg")
+    assert rc == 12, err
+    assert "Error: Invariant Consistent is violated." in out and "State 1: <Initial predicate>" in out
+    assert 'chan_type = (0 :> <<' in out and '"commit"' in out     # the channels print as TLC prints a function on 0..RM of sequences

@@ -85,6 +85,9 @@ CASES = [
 ]
 
 
+CHANNEL_STEMS = {"two_phase_channels", "mailboxes"}   # their GPU cases: tests/test_gpu_zz_channels.py
+
+
 def strip_translation(text):
     """the module as its author wrote it: without the \\* BEGIN/END TRANSLATION block"""
     a = text.find("\\* BEGIN TRANSLATION")
@@ -814,3 +817,25 @@ def test_channel_errors_are_refused_with_a_message(body, msg):
     with pytest.raises(RuntimeError) as e:
         helpers.ShimProgram(SEQ_HEAD.replace("\\\\", "\\") + body)
     assert msg in str(e.value)
+
+
+@pytest.mark.parametrize("case", ["two_phase_channels_rm4", "two_phase_channels_rm5"])
+def test_two_phase_commit_larger_models_equal_the_record_valued_translation(case):
+    """4 / 5 resource managers: the compiled program (chan one sequence per FIELD, host VM) against tests/golden/pcal_channels.json — the
+    hand-written record-valued translation evaluated by the product's host evaluator tlaeval.cpp (tests/golden/make_pcal_channels_golden.py):
+    another text, another engine.  RM = 5 (2 848 539 states, 40 s here) runs under $TLAMC_SLOW; its GPU leg always does (tests/test_gpu_zz_channels.py)"""
+    g = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())[case]
+    if g["RM"] > 4 and not os.environ.get("TLAMC_SLOW"):
+        pytest.skip("40 s of host VM: $TLAMC_SLOW")
+    invs = ["Consistent", "CommitNeedsAllVotes", "InboxHoldsVotes", "FromTheCoordinator", "AtMostTwoWaiting"]
+    os.environ["TLAMC_PCAL_SEQ"] = str(g["seq_cells"])
+    try:
+        prog = helpers.ShimProgram((SPECS / "pluscal" / "two_phase_channels.tla").read_text(), invs, {"RM": g["RM"], "Eager": False})
+    finally:
+        del os.environ["TLAMC_PCAL_SEQ"]
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["queue_left"]) == (g["distinct"], g["generated"], g["depth"], "ok", 0)
+    assert r["levels"] == g["levels"]

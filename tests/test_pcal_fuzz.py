@@ -244,3 +244,82 @@ def test_random_algorithm_translated_vs_compiled(seed, tmp_path):
     except AssertionError:
         print(text)
         raise
+
+
+class ChanGen(Gen):
+    """... plus the CHANNEL shapes of round 5's last part: `box`, an ARRAY of sequences of numbers, and `m`, a SEQUENCE of RECORDS (kept as
+    one sequence per field), read and assigned inside the same random steps (a subclass: the 300 programs above stay what they were)"""
+
+    def __init__(self, seed):
+        super().__init__(seed + 100000)
+        self.single = False          # (box is a function on the process SET)
+        self.chan = True
+
+    def atom(self, env):
+        if getattr(self, "chan", False) and self.r.random() < 0.3:
+            i = self.r.choice(["self", "3 - self"])
+            return self.r.choice([f"Len(box[{i}])", f"(IF box[{i}] # <<>> THEN Head(box[{i}]) ELSE 0)", f"(IF Len(box[{i}]) = 2 THEN box[{i}][2] ELSE 1)",
+                                  "Len(m)", "(IF m # <<>> THEN Head(m).a ELSE 0)", "(IF Len(m) = 2 THEN m[2].a ELSE 1)"])
+        return super().atom(env)
+
+    def cond(self, env, depth=0):
+        if getattr(self, "chan", False) and self.r.random() < 0.15:
+            return self.r.choice(["box[3 - self] = <<>>", "box[self] # <<>>", "m # <<>>", "(m # <<>> /\\ Head(m).b)", "(Len(m) = 2 /\\ ~m[2].b)", "Len(box[self]) < 2"])
+        return super().cond(env, depth)
+
+    def assign(self, env, done):
+        if getattr(self, "chan", False) and self.r.random() < 0.35:
+            c = []
+            if "box" not in done:
+                i = self.r.choice(["self", "3 - self"])
+                c += [("box", f"if Len(box[{i}]) < 2 then box[{i}] := Append(box[{i}], {self.iexpr(env)}); end if"),
+                      ("box", "if box[self] # <<>> then box[self] := Tail(box[self]); end if"),
+                      ("box", f"box[{i}] := <<>>"),
+                      ("box", f"box[self] := <<{self.iexpr(env)}, {self.iexpr(env)}>>"),
+                      ("box", f"if Len(box[{i}]) < 2 then box[{i}] := box[{i}] \\o <<{self.iexpr(env)}>>; end if")]
+            if "m" not in done:
+                rec = f"[a |-> {self.iexpr(env)}, b |-> {self.cond(env)}]"
+                c += [("m", f"if Len(m) < 2 then m := Append(m, {rec}); end if"), ("m", "if m # <<>> then m := Tail(m); end if"), ("m", "m := <<>>"),
+                      ("m", f"if m # <<>> then m[1] := {rec}; end if"), ("m", f"m := <<{rec}>>")]
+                if self.use_rec:
+                    c += [("m", "if Len(m) < 2 then m := Append(m, r); end if"), ("m", "if Len(m) = 2 then m[2] := r; end if")]
+                    if "r" not in done:
+                        c += [("r", "if m # <<>> then r := Head(m); end if"), ("mr", "if m # <<>> then r := Head(m) || m := Tail(m); end if")]
+                if "box" not in done:
+                    c += [("mbox", f"if Len(m) < 2 /\\ box[self] # <<>> then m := Append(m, [a |-> Head(box[self]), b |-> TRUE]) || box[self] := Tail(box[self]); end if")]
+            if c:
+                what, stmt = self.r.choice(c)
+                done |= {"mr": {"m", "r"}, "mbox": {"m", "box"}}.get(what, {what})
+                return stmt
+        return super().assign(env, done)
+
+    def program(self):
+        text, invs = super().program()
+        text = text.replace("variables x = 0, y = 1", "variables x = 0, y = 1, box = [i \\in 1..2 |-> <<>>], m = << [a |-> 1, b |-> FALSE] >>", 1)
+        text = text.replace("====\n", "ChanOk == (\\A i \\in 1..2 : Len(box[i]) <= 2) /\\ (\\A k \\in 1..Len(m) : m[k].a \\in 0..2 /\\ (m[k].b \\/ ~m[k].b))\n====\n")
+        return text, invs + ["ChanOk"]
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_algorithm_with_channels_translated_vs_compiled(seed, tmp_path):
+    text, invs = ChanGen(seed).program()
+    try:
+        helpers.pcal_translate(text)
+    except RuntimeError as e:
+        assert str(e).strip(), text
+        pytest.skip(f"refused: {e}")
+    prog = helpers.ShimProgram(text, invs, {})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    if r["distinct"] > MAX_STATES:
+        pytest.skip(f"{r['distinct']} states: too many for the Python evaluator in a unit test")
+    path = tmp_path / "Fz.tla"
+    path.write_text(text)
+    try:
+        test_pcal.test_compiled_program_vs_tla_evaluator(path, invs, {})
+        test_tlaeval.test_pluscal_translation_evaluated_vs_compiled_program(path, invs, {}, tmp_path)
+    except AssertionError:
+        print(text)
+        raise

@@ -90,7 +90,7 @@ struct Compiler {
         case mc::VM_PUSH: case mc::VM_SELF: case mc::VM_LOAD: case mc::VM_LOADT: case mc::VM_CHOOSE: depth++; break;
         case mc::VM_STORE: case mc::VM_STORET: case mc::VM_AWAIT: case mc::VM_ASSERT: case mc::VM_JZ: case mc::VM_JNZ: case mc::VM_POP:
         case mc::VM_ADD: case mc::VM_SUB: case mc::VM_MUL: case mc::VM_DIV: case mc::VM_MOD: case mc::VM_EQ: case mc::VM_NE: case mc::VM_LT:
-        case mc::VM_LE: case mc::VM_GT: case mc::VM_GE: case mc::VM_OR: case mc::VM_AND: case mc::VM_ANDN: case mc::VM_APPEND: case mc::VM_SEQSEL: depth--; break;
+        case mc::VM_LE: case mc::VM_GT: case mc::VM_GE: case mc::VM_OR: case mc::VM_AND: case mc::VM_ANDN: case mc::VM_APPEND: depth--; break;
         case mc::VM_SEQLEN: depth++; break;
         case mc::VM_STOREX: case mc::VM_STORESEQ: depth -= 2; break;
         case mc::VM_HALT: depth = 0; break;
@@ -289,7 +289,15 @@ struct Compiler {
         c.push_back((int)r.v->ids.size());
         c.push_back(r.v->cap + 1);
     }
-    void emit_seq(int op, const SeqRef &r) { emit_sel(r); c.push_back(op); track(op); c.push_back(r.v->base); c.push_back(r.v->cap); }
+    void emit_seq(int op, const SeqRef &r) {
+        emit_sel(r);
+        c.push_back(op);
+        track(op);
+        c.push_back(r.v->base);
+        c.push_back(r.v->cap);
+        c.push_back(r.idx ? 1 : 0);   // 1: the offset VM_SEQSEL left on the stack is added to base
+        if (r.idx && depth > 0) depth--;
+    }
     void emit_len(const SeqRef &r) {
         if (!r.idx) { emit(mc::VM_LOAD, r.v->base); return; }
         emit_seq(mc::VM_SEQLEN, r);

@@ -21,14 +21,15 @@ enum VmOp : int32_t {
     VM_HALT = 0, VM_PUSH, VM_SELF, VM_LOAD, VM_LOADX, VM_STORE, VM_STOREX, VM_LOADT, VM_STORET,
     VM_ADD, VM_SUB, VM_MUL, VM_DIV, VM_MOD, VM_NEG, VM_EQ, VM_NE, VM_LT, VM_LE, VM_GT, VM_GE, VM_NOT,
     VM_JMP, VM_JZ, VM_JNZ, VM_CHOOSE, VM_AWAIT, VM_ASSERT, VM_SETPC, VM_FAIL, VM_POP, VM_NOP,
-    // bounded sequences: cell `base` holds Len, cells base+1 .. base+cap the elements (unused cells are 0)
+    // bounded sequences: cell `base` holds Len, cells base+1 .. base+cap the elements (unused cells are 0); operands: base, cap, indexed
     VM_LOADSEQ, VM_STORESEQ, VM_APPEND, VM_TAIL, VM_SEQCLR, VM_SEQCOPY,
     // sets of small naturals (0..31) as 32-bit masks
     VM_BIT, VM_OR, VM_AND, VM_ANDN, VM_POPCNT,
     // inside a defined operator the variables are the UNPRIMED ones: reads come from the state before the step
     VM_OLD_ON, VM_OLD_OFF,
     // ARRAYS of bounded sequences (`box = [p \in 1..N |-> <<>>]`: the channels of a message-passing algorithm): element k of the array is
-    // the sequence at base + k * (cap + 1).  VM_SEQSEL pops the array index and selects the element the NEXT sequence instruction works on
+    // the sequence at base + k * (cap + 1).  VM_SEQSEL replaces the array index on the stack by that offset; the sequence instruction that
+    // follows pops it when its third operand is 1 (every sequence instruction has the operands base, cap, indexed)
     VM_SEQSEL, VM_SEQLEN
 };
 
@@ -90,7 +91,6 @@ struct SpecVmT {
         const int32_t *__restrict__ c = p.code;
         int32_t st[STACK], t[TEMPS];
         int sp = 0, pc = entry, old_depth = 0;
-        int32_t sb = 0;         // offset of the selected element of an array of sequences (VM_SEQSEL), consumed by the next sequence instruction
         const int32_t *rd = v;  // where variable READS come from: v, or `old` inside a defined operator
         result = 0;
         aux = 0;
@@ -173,39 +173,35 @@ struct SpecVmT {
                 pc += 3;
                 const int32_t i = st[--sp] - lo;
                 if (i < 0 || i >= n) return R_ERROR;  // TLC: function applied outside its domain
-                sb = i * stride;
+                st[sp++] = i * stride;   // ... consumed by the sequence instruction that follows (its third operand says so)
                 break;
             }
             case VM_SEQLEN: {  // base, cap : Len of the selected sequence
-                const int32_t base = c[pc] + sb;
-                sb = 0;
-                pc += 2;
+                const int32_t base = c[pc] + (c[pc + 2] ? st[--sp] : 0);
+                pc += 3;
                 if (sp >= STACK) return R_ERROR;
                 st[sp++] = rd[base];
                 break;
             }
             case VM_LOADSEQ: {  // base, cap : 1-based index on the stack; Head(q) = q[1]
-                const int32_t base = c[pc] + sb, cap = c[pc + 1];
-                sb = 0;
-                pc += 2;
+                const int32_t base = c[pc] + (c[pc + 2] ? st[--sp] : 0), cap = c[pc + 1];
+                pc += 3;
                 const int32_t i = st[sp - 1];
                 if (i < 1 || i > rd[base] || i > cap) return R_ERROR;  // TLC: index outside 1..Len(q), Head(<<>>)
                 st[sp - 1] = rd[base + i];
                 break;
             }
             case VM_STORESEQ: {  // base, cap : value on top, index below
-                const int32_t base = c[pc] + sb, cap = c[pc + 1];
-                sb = 0;
-                pc += 2;
+                const int32_t base = c[pc] + (c[pc + 2] ? st[--sp] : 0), cap = c[pc + 1];
+                pc += 3;
                 const int32_t val = st[--sp], i = st[--sp];
                 if (i < 1 || i > v[base] || i > cap) return R_ERROR;
                 v[base + i] = val;
                 break;
             }
             case VM_APPEND: {  // base, cap : value on the stack
-                const int32_t base = c[pc] + sb, cap = c[pc + 1];
-                sb = 0;
-                pc += 2;
+                const int32_t base = c[pc] + (c[pc + 2] ? st[--sp] : 0), cap = c[pc + 1];
+                pc += 3;
                 const int32_t val = st[--sp], n = v[base];
                 if (n >= cap) return R_OVERFLOW;  // longer than the cells this program reserves: reported, never truncated
                 v[base + 1 + n] = val;
@@ -213,9 +209,8 @@ struct SpecVmT {
                 break;
             }
             case VM_TAIL: {  // base, cap
-                const int32_t base = c[pc] + sb, cap = c[pc + 1];
-                sb = 0;
-                pc += 2;
+                const int32_t base = c[pc] + (c[pc + 2] ? st[--sp] : 0), cap = c[pc + 1];
+                pc += 3;
                 const int32_t n = v[base];
                 if (n < 1) return R_ERROR;  // Tail(<<>>)
                 for (int32_t k = 1; k < cap; ++k) v[base + k] = k < n ? v[base + k + 1] : 0;
@@ -224,9 +219,8 @@ struct SpecVmT {
                 break;
             }
             case VM_SEQCLR: {
-                const int32_t base = c[pc] + sb, cap = c[pc + 1];
-                sb = 0;
-                pc += 2;
+                const int32_t base = c[pc] + (c[pc + 2] ? st[--sp] : 0), cap = c[pc + 1];
+                pc += 3;
                 for (int32_t k = 0; k <= cap; ++k) v[base + k] = 0;
                 break;
             }
