@@ -768,16 +768,25 @@ class Checker:
         self.engine_mode = True
         seen, levels_states = {}, []
         res = dict(distinct=0, generated=0, queue_left=0, depth=0, verdict="ok", violated=None, trace_len=0, levels=[], states=levels_states)
+        # `errors`: EVERY (verdict, violated invariant, trace length) the failing pass holds.  verdict / violated / trace_len are the first
+        # one in this evaluator's order; an engine that expands a level in parallel may report any of them (as TLC does with several workers)
+        errors = set()
+
+        def first_violated(st):
+            for name in invariants:
+                if not self.ev(self.defs[name][1], st, None, {}):
+                    return name
+            return None
         cur = []
         for s in self.initial_states(init):
             res["generated"] += 1
             k = self.key(s)
             if k not in seen:
-                if res["verdict"] == "ok":
-                    for name in invariants:
-                        if not self.ev(self.defs[name][1], s, None, {}):
-                            res.update(verdict="invariant", violated=name, trace_len=1)
-                            break
+                bad = first_violated(s)
+                if bad:
+                    errors.add(("invariant", bad, 1))
+                    if res["verdict"] == "ok":
+                        res.update(verdict="invariant", violated=bad, trace_len=1)
                 if not self.in_model(s, constraints):
                     continue
                 seen[k] = 1
@@ -795,29 +804,33 @@ class Checker:
                     nsucc += 1
                     res["generated"] += 1
                     if "__assert__" in n:
+                        errors.add(("assert", None, level))
                         if res["verdict"] == "ok":
                             res.update(verdict="assert", trace_len=level, message=n["__assert__"])
                         continue
                     k = self.key(n)
                     if k in seen:
                         continue
-                    if res["verdict"] == "ok":
-                        for name in invariants:
-                            if not self.ev(self.defs[name][1], n, None, {}):
-                                res.update(verdict="invariant", violated=name, trace_len=level + 1)
-                                break
+                    bad = first_violated(n)
+                    if bad:
+                        errors.add(("invariant", bad, level + 1))
+                        if res["verdict"] == "ok":
+                            res.update(verdict="invariant", violated=bad, trace_len=level + 1)
                     if not self.in_model(n, constraints):
                         continue
                     seen[k] = 1
                     nxt_level.append(n)
-                if nsucc == 0 and check_deadlock and res["verdict"] == "ok":
-                    res.update(verdict="deadlock", trace_len=level)
+                if nsucc == 0 and check_deadlock:
+                    errors.add(("deadlock", None, level))
+                    if res["verdict"] == "ok":
+                        res.update(verdict="deadlock", trace_len=level)
             cur = nxt_level
             if cur:
                 level += 1
         if res["verdict"] != "ok" and cur and len(res["levels"]) < level:
             res["levels"].append(len(cur))
             levels_states.append(sorted(self.fmt_state(s).replace("\n", " ") for s in cur))
+        res["errors"] = sorted(errors, key=lambda e: (e[2], e[0], e[1] or ""))
         res.update(distinct=len(seen), depth=level, queue_left=len(cur) if res["verdict"] != "ok" else 0)
         self.engine_mode = False
         return res

@@ -47,15 +47,27 @@ def test_compiled_program_on_gpu_vs_tla_evaluator(amd, path, invs, consts):
     check_compiled_program_on_gpu(amd, path, invs, consts)
 
 
+def same_outcome(r, o, prog):
+    """the engine's verdict against the evaluator's.  A BFS pass that holds SEVERAL errors (an Assert failing in one state of the level, an
+    invariant broken by a successor of another) has no first one on a GPU: the engine reports the error with the smallest (arena index,
+    slot), and the order of a level's states in the arena depends on which workgroup got there first — as TLC's report does with several
+    workers.  Counters, depth and per-level state sets do not depend on it (the whole level is expanded); the reported error must be ONE OF
+    those the evaluator finds in that pass (oracle/tla_eval.py run_levels: `errors`)."""
+    if o["verdict"] == "ok":
+        assert r.verdict == "ok" and r.trace_len == o["trace_len"]
+        return
+    got = (r.verdict, prog.invariant(r.violated_invariant) if r.verdict == "invariant" else None, r.trace_len)
+    assert got in [tuple(e) for e in o["errors"]], (got, o["errors"])
+
+
 def check_compiled_program_on_gpu(amd, path, invs, consts):
     prog = amd.Program(path.read_text(), cfg_text(invs, consts))
     eng = amd.Engine("pcal", prog.params, table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
     r = eng.run()
     o = Checker(prog.translated(), constants=consts).run_levels(invariants=invs)
-    for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+    for k in ("distinct", "generated", "queue_left", "depth", "levels"):
         assert getattr(r, k) == o[k], (k, getattr(r, k), o[k])
-    if r.verdict == "invariant":
-        assert prog.invariant(r.violated_invariant) == o["violated"]
+    same_outcome(r, o, prog)
     first = 0
     for lvl, n in enumerate(r.levels):
         got = sorted(t.replace("\n", " ") for t in eng.state_texts(first, n))
@@ -275,8 +287,9 @@ def test_random_algorithms_on_gpu(amd):
         eng = amd.Engine("pcal", prog.params, table_capacity=1 << 18, arena_capacity=1 << 16, chunk_states=1 << 10, deadlock=False)
         r = eng.run()
         o = Checker(prog.translated()).run_levels(invariants=["Small"], check_deadlock=False)
-        for k in ("distinct", "generated", "queue_left", "depth", "verdict", "trace_len", "levels"):
+        for k in ("distinct", "generated", "queue_left", "depth", "levels"):
             assert getattr(r, k) == o[k], (seed, k, getattr(r, k), o[k])
+        same_outcome(r, o, prog)
         first = 0
         for lvl, n in enumerate(r.levels):
             assert sorted(t.replace("\n", " ") for t in eng.state_texts(first, n)) == o["states"][lvl], (seed, lvl)

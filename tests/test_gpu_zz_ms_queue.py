@@ -42,7 +42,9 @@ def test_mc_on_the_counted_pointer_queue():
     assert "The depth of the complete state graph search is 69." in out
     rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "ms_queue_counted.tla", "-config", ROOT / "specs" / "pluscal" / "ms_queue_uncounted.cfg")
     assert rc == 12, err
-    assert "Error: Invariant HeadLive is violated." in out and "/\\ Q_Head_ptr = " in out
+    # (the failing pass holds two errors — HeadLive broken by a successor of one state, an assert failing in another: a parallel search may
+    #  report either, test_gpu_pcal.same_outcome)
+    assert ("Error: Invariant HeadLive is violated." in out or "The first argument of Assert evaluated to FALSE" in out) and "/\\ Q_Head_ptr = " in out
 
 
 def test_counted_pointer_queue_three_threads_on_gpu(amd):  # noqa: F811
