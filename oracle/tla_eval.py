@@ -465,6 +465,8 @@ def fmt(v):
     if isinstance(v, Fn):
         if v.is_seq():
             return "<<" + ", ".join(fmt(b) for _, b in v.items) + ">>"
+        if v.items and all(isinstance(a, str) and not isinstance(a, MV) for a, _ in v.items):   # a record (fields in name order)
+            return "[" + ", ".join(f"{a} |-> {fmt(b)}" for a, b in v.items) + "]"
         return "(" + " @@ ".join(f"{fmt(a)} :> {fmt(b)}" for a, b in v.items) + ")"
     return "{" + ", ".join(fmt(x) for x in sorted(v, key=sort_key)) + "}"
 

@@ -24,4 +24,14 @@ for rm, cells in ((4, 8), (5, 5)):
     out[f"two_phase_channels_rm{rm}"] = dict(RM=rm, seq_cells=cells, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
                                              source="tlaeval.cpp on tests/golden/pcal_records/TwoPhaseChannels.tla (hand-written record-valued translation)")
     print(rm, r["distinct"], r["generated"], r["depth"], r["seconds"])
+# the message SOUP (a set of records, specs/pluscal/two_phase_soup.tla): the translation keeps msgs the set pcal2tla keeps, so the text evaluated
+# here is the spec file itself; RM = 3 is also walked by oracle/tlaplus.py and oracle/tla_eval.py in tests/test_pcal.py
+for rm in (6, 7):
+    with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
+        f.write(f"SPECIFICATION Spec\nCONSTANT RM = {rm}\nCONSTANT Hasty = FALSE\nINVARIANT Consistent OneDecision PreparedWereSent KnownMessages SoupIsSmall\n")
+    r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "two_phase_soup.tla", f.name, search=[])
+    assert r["rc"] == 0 and r["verdict"] == 0, r
+    out[f"two_phase_soup_rm{rm}"] = dict(RM=rm, seq_cells=rm + 1, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
+                                         source="tlaeval.cpp on specs/pluscal/two_phase_soup.tla (msgs one set-valued variable, as pcal2tla keeps it)")
+    print("soup", rm, r["distinct"], r["generated"], r["depth"], r["seconds"])
 (ROOT / "tests" / "golden" / "pcal_channels.json").write_text(json.dumps(out, indent=1) + "\n")

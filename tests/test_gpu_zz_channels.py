@@ -1,5 +1,5 @@
 """GPU tests of the PlusCal CHANNELS (arrays of sequences, sequences of records: specs/pluscal/two_phase_channels.tla, mailboxes.tla;
-spec_vm.h VM_SEQSEL / VM_SEQLEN, pcal.cpp RecordFlattener).  Added late in round 5; like tests/test_gpu_zz_ms_queue.py the file sorts
+spec_vm.h VM_SEQSEL / VM_SEQLEN, pcal.cpp RecordFlattener) and of the message SOUP (a set of records: two_phase_soup.tla; VM_RSADD / VM_RSDEL / VM_RSHAS).  Added late in round 5; like tests/test_gpu_zz_ms_queue.py the file sorts
 behind every other GPU file so that under `pytest -x` a surprise here cannot keep the rest of the suite from running."""
 import json
 import os
@@ -59,3 +59,60 @@ def test_mc_on_two_phase_commit_over_channels():
     assert ("Error: Invariant Consistent is violated." in out or "The first argument of Assert evaluated to FALSE" in out) and "State 1: <Initial predicate>" in out
     assert "1051 distinct states found" in out
     assert 'chan_type = (0 :> <<' in out and '"commit"' in out     # the channels print as TLC prints a function on 0..RM of sequences
+
+
+SOUP_INVS = ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages", "SoupIsSmall"]
+
+
+@pytest.mark.parametrize("case", ["two_phase_soup_rm6", "two_phase_soup_rm7"])
+def test_message_soup_larger_models_equal_the_host_evaluator(amd, monkeypatch, case):  # noqa: F811
+    """two-phase commit with a message soup, 6 / 7 resource managers (251 051 / 1 725 467 states): per-level counts of the module's text — msgs
+    one set-valued variable, as pcal2tla keeps it — under the product's host evaluator tlaeval.cpp (tests/golden/pcal_channels.json); the
+    compiled program keeps the set as sorted cells"""
+    g = GOLDEN[case]
+    monkeypatch.setenv("TLAMC_PCAL_SEQ", str(g["seq_cells"]))
+    prog = amd.Program((ROOT / "specs" / "pluscal" / "two_phase_soup.tla").read_text(), cfg_text(SOUP_INVS, {"RM": g["RM"], "Hasty": False}))
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 24, arena_capacity=1 << 22, chunk_states=1 << 16)
+    r = eng.run()
+    assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (g["distinct"], g["generated"], g["depth"], "ok", 0)
+    assert list(r.levels) == g["levels"]
+    eng.close()
+    prog.close()
+
+
+def test_mc_on_the_message_soup():
+    """`mc two_phase_soup.tla` = tlc on Lamport-style two-phase commit; a hasty transaction manager (two_phase_soup_hasty.cfg) breaks Consistent"""
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "two_phase_soup.tla")
+    assert rc == 0, err
+    assert "2300 states generated, 827 distinct states found, 0 states left on queue." in out
+    assert "The depth of the complete state graph search is 12." in out
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "two_phase_soup.tla", "-config", ROOT / "specs" / "pluscal" / "two_phase_soup_hasty.cfg")
+    assert rc == 12, err
+    assert "Error: Invariant Consistent is violated." in out and "State 1: <Initial predicate>" in out
+    assert '/\\ msgs = {[rm |-> 0, type |-> "commit"], [rm |-> ' in out      # a set of records, fields in name order
+
+
+def test_random_algorithms_with_channels_on_gpu(amd, tmp_path):  # noqa: F811
+    """40 of the seeded random algorithms of tests/test_pcal_fuzz.py ChanGen (an array of sequences, a sequence of records and a set of records
+    inside random steps) through the HIP engine against the evaluator on the translation"""
+    import helpers
+    from test_pcal_fuzz import ChanGen, MAX_STATES
+    checked = 0
+    for seed in range(40):
+        text, invs = ChanGen(seed).program()
+        try:
+            helpers.pcal_translate(text)
+            prog = helpers.ShimProgram(text, invs, {})
+        except RuntimeError:
+            continue
+        try:
+            n = helpers.shim_run("pcal", prog.params)["distinct"]
+        finally:
+            prog.close()
+        if n > MAX_STATES:
+            continue
+        path = tmp_path / f"Fz{seed}.tla"
+        path.write_text(text.replace("MODULE Fz ", f"MODULE Fz{seed} "))
+        check_compiled_program_on_gpu(amd, path, invs, {})
+        checked += 1
+    assert checked >= 30

@@ -73,6 +73,11 @@ CASES = [
     (SPECS / "pluscal" / "two_phase_channels.tla", ["Consistent", "InboxHoldsVotes", "FromTheCoordinator"], {"RM": 3, "Eager": True}),
     # ... q \o <<r>>, q[k] := r, an initial element, `||` over two sequences, an array of sequences of numbers beside the record channels
     (SPECS / "pluscal" / "mailboxes.tla", ["LogOk", "Pongs", "HeardTheLeft"], {"N": 2}),
+    # SETS of RECORDS (a message soup: msgs := msgs \cup {[type |-> "prepared", rm |-> self]}, with m \in msgs, r \in msgs; spec_vm.h VM_RSADD): two-phase
+    # commit after Lamport's TwoPhase; Hasty = TRUE commits on the first "prepared": Consistent breaks
+    (SPECS / "pluscal" / "two_phase_soup.tla", ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages", "SoupIsSmall"], {"RM": 2, "Hasty": False}),
+    (SPECS / "pluscal" / "two_phase_soup.tla", ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages", "SoupIsSmall"], {"RM": 3, "Hasty": False}),
+    (SPECS / "pluscal" / "two_phase_soup.tla", ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages"], {"RM": 3, "Hasty": True}),
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -85,7 +90,7 @@ CASES = [
 ]
 
 
-CHANNEL_STEMS = {"two_phase_channels", "mailboxes"}   # their GPU cases: tests/test_gpu_zz_channels.py
+CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup"}   # their GPU cases: tests/test_gpu_zz_channels.py
 
 
 def strip_translation(text):
@@ -839,3 +844,108 @@ def test_two_phase_commit_larger_models_equal_the_record_valued_translation(case
         prog.close()
     assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["queue_left"]) == (g["distinct"], g["generated"], g["depth"], "ok", 0)
     assert r["levels"] == g["levels"]
+
+
+def test_with_over_a_set_of_records_binds_the_element_by_value():
+    """`with m \\in msgs do msgs := (msgs \\ {m}) \\cup {...}; r := m; x := m.a ...`: m is the element as it was when the step chose it (its fields are
+    copied: removing it moves the others), a chain of set operations reads the set as it was before the statement, `{... Cardinality(msgs) ...}`
+    is evaluated before the set is cleared"""
+    text = """---- MODULE byval ----
+EXTENDS Naturals, FiniteSets
+(* --algorithm byval
+variables msgs = {[a |-> 2, b |-> TRUE], [a |-> 0, b |-> FALSE], [a |-> 1, b |-> TRUE]}, other = {[a |-> 1, b |-> TRUE]}, r = [a |-> 0, b |-> FALSE], x = 0, y = 0;
+begin
+  M: with m \\in msgs do
+       msgs := (msgs \\ {m}) \\cup {[a |-> m.a + 3, b |-> ~m.b]};
+       r := m;
+       x := m.a + 10 * Cardinality(msgs);
+     end with;
+  N: if r \\in msgs \\/ [a |-> x % 10, b |-> r.b] \\notin other then y := 5; end if;
+  O: msgs := {[a |-> Cardinality(msgs), b |-> \\E m \\in msgs : m.a > 3 /\\ m.b]};
+end algorithm *)
+====
+""".replace("\\\\", "\\")
+    r = _vm_equals_evaluator(text)
+    assert (r["distinct"], r["generated"], r["verdict"]) == (10, 13, "ok")
+
+
+def test_message_soup_equals_the_general_evaluators():
+    """specs/pluscal/two_phase_soup.tla: its translation keeps msgs ONE set-valued variable, as pcal2tla does — the module file is the text
+    oracle/tlaplus.py (the general evaluator that reads the reference's own specs) and the product's host evaluator tlaeval.cpp walk; the
+    compiled program keeps the set as sorted cells (spec_vm.h VM_RSADD).  Counters, depth, per-level counts; RM = 6 / 7 (251 051 / 1 725 467
+    states) against tests/golden/pcal_channels.json (tlaeval.cpp; 7 under $TLAMC_SLOW: 53 s of host VM)"""
+    import tlaplus as T
+    spec, invs = SPECS / "pluscal" / "two_phase_soup.tla", ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages", "SoupIsSmall"]
+    p = T.Checker(spec, cfg_path=SPECS / "pluscal" / "two_phase_soup.cfg", search=[]).run_levels(keep_states=False)
+    e = helpers.tlaeval_run(spec, SPECS / "pluscal" / "two_phase_soup.cfg", search=[])
+    prog = helpers.ShimProgram(spec.read_text(), invs, {"RM": 3, "Hasty": False})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (p["distinct"], p["generated"], p["depth"], p["verdict"], p["levels"]) == (r["distinct"], r["generated"], r["depth"], "ok", r["levels"]) and r["distinct"] == 827
+    assert (e["distinct"], e["generated"], e["depth"], e["verdict"], e["levels"]) == (r["distinct"], r["generated"], r["depth"], 0, r["levels"])
+    golden = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())
+    for case in ("two_phase_soup_rm6", "two_phase_soup_rm7"):
+        g = golden[case]
+        if g["RM"] > 6 and not os.environ.get("TLAMC_SLOW"):
+            continue
+        os.environ["TLAMC_PCAL_SEQ"] = str(g["seq_cells"])
+        try:
+            prog = helpers.ShimProgram(spec.read_text(), invs, {"RM": g["RM"], "Hasty": False})
+        finally:
+            del os.environ["TLAMC_PCAL_SEQ"]
+        try:
+            r = helpers.shim_run("pcal", prog.params)
+        finally:
+            prog.close()
+        assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
+
+
+def test_a_set_of_records_that_outgrows_its_cells_overflows():
+    text = """---- MODULE grow ----
+EXTENDS Naturals
+(* --algorithm grow
+variables msgs = {}, n = 0;
+begin
+  L: while n < 4 do msgs := msgs \\cup {[k |-> n, twice |-> 2 * n]}; n := n + 1; end while;
+end algorithm *)
+====
+""".replace("\\\\", "\\")
+    assert _vm_equals_evaluator(text)["verdict"] == "ok"
+    os.environ["TLAMC_PCAL_SEQ"] = "3"
+    try:
+        prog = helpers.ShimProgram(text)
+    finally:
+        del os.environ["TLAMC_PCAL_SEQ"]
+    try:
+        with pytest.raises(RuntimeError) as e:
+            helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert "-3" in str(e.value)      # MC_EOVERFLOW
+
+
+RSET_HEAD = ("---- MODULE M ----\nEXTENDS Naturals, FiniteSets\n(* --algorithm M\nvariables msgs = {}, other = {[a |-> 1, b |-> TRUE]}, r = [a |-> 0, b |-> FALSE], "
+             "s = {}, x = 0;\n")
+RSET_ERRORS = [
+    ("begin L: msgs := msgs \\cup {[a |-> 1, b |-> TRUE]}; x := msgs; end algorithm *)\n====\n", "the set of records `msgs` is used as a value here"),
+    ("begin L: msgs := msgs \\cup {[a |-> 1]}; M: msgs := msgs \\cup {r}; end algorithm *)\n====\n", "does not have the fields of the elements of msgs"),
+    ("begin L: msgs := msgs \\cup {r}; M: msgs := msgs \\cup {3}; end algorithm *)\n====\n", "an element of the set of records msgs must be a record constructor"),
+    ("begin L: msgs := msgs \\cup {r}; M: msgs := msgs \\cup other; end algorithm *)\n====\n", "a set of records can be assigned {r, ...}"),
+    ("begin L: msgs := msgs \\cup {r}; M: if msgs = other then skip; end if; end algorithm *)\n====\n", "comparing two sets of records is not supported"),
+    ("begin L: msgs := msgs \\cup {r}; M: if msgs = {r} then skip; end if; end algorithm *)\n====\n", "can only be compared with {}"),
+    ("begin L: msgs := msgs \\cup {r}; M: with m \\in msgs do x := m; end with; end algorithm *)\n====\n", "a record is assigned to x"),
+    ("begin L: msgs := msgs \\cup {r}; M: with m \\in msgs do x := m.c; end with; end algorithm *)\n====\n", "the record has no field c"),
+    ("begin L: msgs := msgs \\cup {[a |-> 1, b |-> [c |-> 1]]}; end algorithm *)\n====\n", "can only have plain fields"),
+    ("begin L: msgs := msgs \\cup {r}; M: msgs.a := 1; end algorithm *)\n====\n", "msgs is a set of records: assign the set"),
+    ("begin L: msgs := msgs \\cup {r}; M: msgs := other \\cup {r}; end algorithm *)\n====\n", "a set of records can be assigned {r, ...}"),
+    ("begin L: msgs := msgs \\cup {r} || x := 1; end algorithm *)\n====\n", "`||` with a set variable is not supported"),
+]
+
+
+@pytest.mark.parametrize("body,msg", RSET_ERRORS, ids=[m[:28] for _, m in RSET_ERRORS])
+def test_set_of_records_errors_are_refused_with_a_message(body, msg):
+    with pytest.raises(RuntimeError) as e:
+        helpers.ShimProgram(RSET_HEAD.replace("\\\\", "\\") + body.replace("\\\\", "\\"))
+    assert msg in str(e.value)

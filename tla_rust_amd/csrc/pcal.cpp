@@ -1338,6 +1338,8 @@ struct RecordFlattener {
     std::map<std::string, RecordVar> recs;   // the record variables THIS pass replaces, by name
     std::map<std::string, EP> shapes;        // their constructors, and those of the variables this pass declares with a record value
     std::set<std::string> pending;           // ... the latter: the next pass's record variables
+    std::map<std::string, EP> rsets;         // SETS of records (RecordVar::set): they stay variables; name -> the elements' constructor
+    mutable std::vector<std::pair<std::string, EP>> bound;   // `with m \in msgs` / `\E m \in msgs`: m is a record value with msgs' fields
     int depth = 0;
     [[noreturn]] static void fail(const Pos &at, const std::string &msg) { throw FlattenError{"line " + std::to_string(at.line) + ", column " + std::to_string(at.col) + ": " + msg}; }
     static EP node(Expr::K k, const Pos &at) { auto e = std::make_shared<Expr>(); e->k = k; e->pos = at; return e; }
@@ -1407,6 +1409,7 @@ struct RecordFlattener {
     EP shape(const EP &e) const {
         if (!e) return nullptr;
         if (e->k == Expr::RECORD) return e;
+        if (e->k == Expr::ID) for (size_t i = bound.size(); i-- > 0;) if (bound[i].first == e->s) return bound[i].second;
         if (const RecordVar *r = recseq_elem(e)) return shapes.at(r->name);
         if (recseq(e)) return nullptr;
         if (e->k == Expr::ID || e->k == Expr::INDEX) {
@@ -1456,7 +1459,17 @@ struct RecordFlattener {
             return c;
         }
         if (pending_ref(e)) return with_index(e);
+        if (const EP bs = bound_shape(e)) {   // an element of a set of records, named by `with` / a quantifier: [f |-> m.f, ...]
+            auto c = node(Expr::RECORD, e->pos);
+            c->names = bs->names;
+            for (const auto &f : bs->names) c->a.push_back(field_of(e, f));
+            return c;
+        }
         return rw(e);  // a path `x.f` to a record-valued field
+    }
+    EP bound_shape(const EP &e) const {
+        if (e->k == Expr::ID) for (size_t i = bound.size(); i-- > 0;) if (bound[i].first == e->s) return bound[i].second;
+        return nullptr;
     }
     // field f of a record-valued expression
     EP field_of(const EP &e, const std::string &f) const {
@@ -1465,6 +1478,13 @@ struct RecordFlattener {
             if (k < 0) fail(e->pos, "the record has no field " + f);
             const EP &v = e->a[(size_t)k];
             return record_valued(v) ? as_value(v) : rw(v);
+        }
+        if (const EP bs = bound_shape(e)) {  // m.f of an element of a set of records: the compiled program reads the field's cell
+            if (field_index(bs, f) < 0) fail(e->pos, "the record has no field " + f);
+            auto d = node(Expr::DOT, e->pos);
+            d->s = f;
+            d->a = {e};
+            return d;
         }
         if (const RecordVar *r = recseq_elem(e)) {  // Head(Q).f = Head(Q_f), Q[k].f = Q_f[k]
             check_field(*r, f, e->pos);
@@ -1493,6 +1513,62 @@ struct RecordFlattener {
         std::sort(b.begin(), b.end());
         return a == b;
     }
+    // ---- sets of records (pcal.h, RecordVar::set): the variable stays; record values around it become constructors over plain values
+    // which operand of `S \cup {..}`, `S \ {..}`, `r \in S`, `S = {}` is a set-of-records variable (-1: none)
+    int rset_side(const EP &e) const {
+        static const char *ops[] = {"\\cup", "\\union", "\\", "\\in", "\\notin", "=", "#", "\\subseteq"};
+        bool is = false;
+        for (const char *o : ops) is |= e->s == o;
+        if (!is || e->a.size() != 2) return -1;
+        for (int side = 1; side >= 0; side--) if (e->a[(size_t)side]->k == Expr::ID && rsets.count(e->a[(size_t)side]->s) && !bound_shape(e->a[(size_t)side])) return side;
+        return -1;
+    }
+    EP rset_elem(const EP &x, const EP &want, const std::string &name) const {  // a record value as an element of the set `name`
+        if (!record_valued(x)) fail(x->pos, "an element of the set of records " + name + " must be a record constructor, a record variable or an element of a set / sequence / array of records");
+        if (!same_fields(want->names, fields_of(x))) fail(x->pos, "the record does not have the fields of the elements of " + name);
+        auto c = node(Expr::RECORD, x->pos);   // in the set's own field order
+        c->names = want->names;
+        for (const auto &f : want->names) c->a.push_back(field_of(x, f));
+        return c;
+    }
+    // S | chain \cup {r, ...} | chain \ {r, ...}: what a set of records can be assigned
+    bool rset_chain(const EP &e, const std::string &name) const {
+        if (e->k == Expr::ID) return e->s == name && !bound_shape(e);
+        return e->k == Expr::BINOP && (e->s == "\\cup" || e->s == "\\union" || e->s == "\\") && e->a[1]->k == Expr::SETENUM && rset_chain(e->a[0], name);
+    }
+    EP rw_rset_chain(const EP &e, const std::string &name) const {
+        if (e->k == Expr::ID) return e;
+        auto c = std::make_shared<Expr>(*e);
+        c->a[0] = rw_rset_chain(e->a[0], name);
+        auto t = std::make_shared<Expr>(*e->a[1]);
+        for (auto &x : t->a) x = rset_elem(x, rsets.at(name), name);
+        c->a[1] = t;
+        return c;
+    }
+    EP rw_rset(const EP &e) const {
+        const int side = rset_side(e);
+        const std::string &name = e->a[(size_t)side]->s;
+        const EP &want = rsets.at(name);
+        const EP &other = e->a[(size_t)(1 - side)];
+        auto c = std::make_shared<Expr>(*e);
+        if (e->s == "\\in" || e->s == "\\notin") {
+            if (side != 1) fail(e->pos, "a set of records cannot be a member of something");
+            c->a[0] = rset_elem(other, want, name);
+            return c;
+        }
+        if (other->k == Expr::ID && rsets.count(other->s)) {
+            if (e->s == "=" || e->s == "#" || e->s == "\\subseteq") fail(e->pos, "comparing two sets of records is not supported (supported: = {}, # {}, \\in, Cardinality)");
+            fail(e->pos, "a set of records can be united with / reduced by {r, ...} only");
+        }
+        if (other->k != Expr::SETENUM) fail(other->pos, "a set of records works with {r, ...} ({} included) only: " + name + " \\cup {r}, " + name + " \\ {r}, r \\in " + name + ", " + name + " = {}");
+        if ((e->s == "=" || e->s == "#") && !other->a.empty()) fail(e->pos, "a set of records can only be compared with {}");
+        if (e->s == "\\subseteq") fail(e->pos, "\\subseteq on a set of records is not supported");
+        if (e->s == "\\" && side != 0) fail(e->pos, "only " + name + " \\ {r, ...} is supported");
+        auto t = std::make_shared<Expr>(*other);
+        for (auto &x : t->a) x = rset_elem(x, want, name);
+        c->a[(size_t)(1 - side)] = t;
+        return c;
+    }
     EP rw(const EP &e) const {
         if (!e) return e;
         switch (e->k) {
@@ -1505,7 +1581,7 @@ struct RecordFlattener {
                 c->a[1] = rw(b->a[1]);
                 b = c;
             }
-            if (b->k == Expr::RECORD || rec_of(b) || recseq_elem(b)) return field_of(b, e->s);
+            if (b->k == Expr::RECORD || rec_of(b) || recseq_elem(b) || bound_shape(b)) return field_of(b, e->s);
             if (pending_ref(b) || b->k == Expr::DOT) {  // a field of a record this pass has only just made a variable of (or a path into it): the next pass's
                 const EP sb = shape(b);
                 if (!sb) fail(e->pos, "`." + e->s + "`: not a field of a record");
@@ -1528,7 +1604,17 @@ struct RecordFlattener {
             if (recseq_elem(e)) fail(e->pos, "an element of a sequence of records is used as a whole value here (supported: q[k].f, r := q[k], q[k] = ...)");
             if (recseq(e)) fail(e->pos, "a sequence of records is used as a whole value here (supported: Len, Head, [k], = / # <<>>, :=)");
             break;
+        case Expr::QUANT:
+            if (e->a[0]->k == Expr::ID && rsets.count(e->a[0]->s) && e->s != "CHOOSE") {   // \E m \in msgs : P(m.f)
+                auto c = std::make_shared<Expr>(*e);
+                bound.push_back({e->bound, rsets.at(e->a[0]->s)});
+                try { c->a[1] = rw(e->a[1]); } catch (...) { bound.pop_back(); throw; }
+                bound.pop_back();
+                return c;
+            }
+            break;
         case Expr::BINOP:
+            if (rset_side(e) >= 0) return rw_rset(e);
             if ((e->s == "=" || e->s == "#") && (recseq(e->a[0]) || recseq(e->a[1]))) {
                 const int side = recseq(e->a[0]) ? 0 : 1;
                 const EP &other = e->a[(size_t)(1 - side)];
@@ -1562,6 +1648,7 @@ struct RecordFlattener {
             }
             break;
         case Expr::ID:
+            if (bound_shape(e)) fail(e->pos, "the record " + e->s + " (an element of a set of records) is used as a whole value here (supported: " + e->s + ".f, r := " + e->s + ", " + e->s + " = ..., {" + e->s + "})");
             if (recs.count(e->s) && recs.at(e->s).seq) fail(e->pos, "the sequence of records " + e->s + " is used as a whole value here (supported: Len, Head, [k], = / # <<>>, :=)");
             if (recs.count(e->s)) fail(e->pos, "record variable " + e->s + " is used as a whole value here (supported: " + e->s + ".f, " + e->s + " := ..., " + e->s + " = ...)");
             return e;
@@ -1587,6 +1674,22 @@ struct RecordFlattener {
             for (const auto &x : out) if (x->var == var && paths_overlap(x->field, path)) fail(a.pos, "two assignments to " + var + " in one statement");
             out.push_back(o);
         };
+        if (rsets.count(a.var)) {   // msgs := msgs \cup {r} | msgs \ {r} | {r, ...} | {}
+            if (!a.field.empty() || a.idx) fail(a.pos, a.var + " is a set of records: assign the set (" + a.var + " := " + a.var + " \\cup {r}, ...)");
+            const EP &want = rsets.at(a.var);
+            EP v;
+            if (a.e->k == Expr::SETENUM) {
+                auto t = std::make_shared<Expr>(*a.e);
+                for (auto &x : t->a) x = rset_elem(x, want, a.var);
+                v = t;
+            } else if (rset_chain(a.e, a.var)) {   // msgs, msgs \cup {r}, (msgs \ {m}) \cup {r}, ...
+                v = rw_rset_chain(a.e, a.var);
+            } else {
+                fail(a.e->pos, "a set of records can be assigned {r, ...}, " + a.var + " \\cup {r, ...} or " + a.var + " \\ {r, ...}");
+            }
+            mk(a.var, nullptr, v, a.whole, "");
+            return;
+        }
         auto it = recs.find(a.var);
         if (it == recs.end()) {
             if (!a.field.empty()) fail(a.pos, a.var + " is not a record variable (its initial value is not a record constructor)");
@@ -1647,6 +1750,13 @@ struct RecordFlattener {
             }
             if (s->k == Stmt::WITH && s->e && record_valued(s->e)) fail(s->e->pos, "`with` over a record value is not supported");
             auto c = std::make_shared<Stmt>(*s);
+            if (s->k == Stmt::WITH && !s->with_eq && s->e && s->e->k == Expr::ID && rsets.count(s->e->s)) {   // with m \in msgs do ... m.f ... end with
+                bound.push_back({s->var, rsets.at(s->e->s)});
+                try { for (auto &b : c->blocks) stmts(b); } catch (...) { bound.pop_back(); throw; }
+                bound.pop_back();
+                s = c;
+                continue;
+            }
             c->e = rw(s->e);
             c->idx = rw(s->idx);
             for (auto &b : c->blocks) stmts(b);
@@ -1698,6 +1808,59 @@ struct RecordFlattener {
         for (const auto &p : m.procs) walk(p.body);
         return found;
     }
+    // the elements' constructor of the SET variable `name` (initial elements, `name \cup {r}`, `{r}` somewhere in the algorithm) — null: not a set of records
+    EP set_elem_shape(const std::string &name, const EP &init_set) const {
+        auto of_value = [&](const EP &x) -> EP {
+            if (!x) return nullptr;
+            if (x->k == Expr::RECORD) return x;
+            if (x->k == Expr::ID) return decl_shape(x->s);
+            if (x->k == Expr::INDEX && x->a[0]->k == Expr::ID) return decl_shape(x->a[0]->s);
+            return nullptr;
+        };
+        for (const auto &x : init_set->a) if (EP r = of_value(x)) return r;
+        EP found;
+        std::function<void(const std::vector<SP> &)> walk = [&](const std::vector<SP> &v) {
+            for (const auto &st : v) {
+                if (found) return;
+                if (st->k == Stmt::ASSIGN) {
+                    std::vector<const Stmt *> all{st.get()};
+                    for (const auto &o : st->more) all.push_back(o.get());
+                    for (const Stmt *a : all) {
+                        if (a->var != name || !a->e || !a->field.empty() || a->idx || found) continue;
+                        const EP &e = a->e;
+                        const EP lit = e->k == Expr::SETENUM ? e : e->k == Expr::BINOP && (e->s == "\\cup" || e->s == "\\union") && e->a[1]->k == Expr::SETENUM ? e->a[1] : nullptr;
+                        if (lit) for (const auto &x : lit->a) if (!found) found = of_value(x);
+                    }
+                }
+                for (const auto &b : st->blocks) walk(b);
+            }
+        };
+        for (const auto &p : m.procs) walk(p.body);
+        return found;
+    }
+    void find_rsets() {
+        auto scan = [&](std::vector<VarDecl> &v, int proc) {
+            for (auto &d : v) {
+                if (!d.init || d.in_set || d.init->k != Expr::SETENUM) continue;
+                const EP es = set_elem_shape(d.name, d.init);
+                if (!es) continue;
+                for (size_t i = 0; i < es->names.size(); i++)
+                    if (es->a[i]->k == Expr::RECORD || es->a[i]->k == Expr::FUNCDEF || es->a[i]->k == Expr::TUPLE || es->a[i]->k == Expr::SETENUM)
+                        fail(es->a[i]->pos, "an element of the set of records " + d.name + " can only have plain fields (field " + es->names[i] + " is a record, a function, a sequence or a set)");
+                if (proc >= 0 && m.procs[(size_t)proc].is_set) fail(d.pos, "a set of records local to a process SET is not supported (`" + d.name + "`)");
+                rsets[d.name] = es;
+                RecordVar r;
+                r.name = d.name;
+                r.fields = es->names;
+                r.set = true;
+                r.shape = es;
+                r.proc = proc;
+                m.records.push_back(r);
+            }
+        };
+        scan(m.globals, -1);
+        for (size_t k = 0; k < m.procs.size(); k++) scan(m.procs[k].locals, (int)k);
+    }
     // declarations: a record variable becomes one variable per field
     void decls(std::vector<VarDecl> &v, int proc, const std::set<std::string> &taken) {
         std::vector<VarDecl> out;
@@ -1716,6 +1879,7 @@ struct RecordFlattener {
                 r.fields = es->names;
                 r.array = sqa;
                 r.seq = true;
+                r.shape = es;
                 r.proc = proc;
                 r.depth = depth;
                 if (sqa) { r.bound = e->bound; r.domain = e->a[0]; }
@@ -1774,6 +1938,7 @@ struct RecordFlattener {
         v = out;
     }
     void run() {
+        find_rsets();
         for (depth = 0;; depth++) {
             std::set<std::string> taken(m.constants.begin(), m.constants.end());
             for (const auto &g : m.globals) taken.insert(g.name);
@@ -1788,9 +1953,18 @@ struct RecordFlattener {
             for (size_t k = 0; k < m.procs.size(); k++) decls(m.procs[k].locals, (int)k, taken);
             if (depth > 0 && m.records.size() == before) break;  // nothing left to replace
             // (pass 0 without a record variable too: a `.f` or a record constructor anywhere is refused by rw(), with its position)
-            for (auto &g : m.globals) g.init = pending.count(g.name) ? g.init : rw(g.init);
+            auto init_of = [&](const VarDecl &d) -> EP {
+                if (pending.count(d.name)) return d.init;
+                if (rsets.count(d.name)) {   // the initial elements of a set of records, in the set's field order
+                    auto t = std::make_shared<Expr>(*d.init);
+                    for (auto &x : t->a) x = rset_elem(x, rsets.at(d.name), d.name);
+                    return t;
+                }
+                return rw(d.init);
+            };
+            for (auto &g : m.globals) g.init = init_of(g);
             for (auto &p : m.procs) {
-                for (auto &l : p.locals) l.init = pending.count(l.name) ? l.init : rw(l.init);
+                for (auto &l : p.locals) l.init = init_of(l);
                 stmts(p.body);
             }
             for (auto &d : m.defs) {
@@ -2389,9 +2563,10 @@ std::string translate(const Module &m) {
         if (!rest.empty()) o += "VARIABLES " + join(rest, ", ") + "\n\n";
     }
     o += "vars == << " + join(vars, ", ") + " >>\n\n";
-    if (!m.records.empty()) {  // pcal.h, RECORDS: the record as the text around the algorithm knows it
+    if (std::any_of(m.records.begin(), m.records.end(), [](const RecordVar &r) { return !r.set; })) {  // pcal.h, RECORDS: the record as the text around the algorithm knows it
         o += "(* record variables are kept field by field: r.f is r_f *)\n";
         for (const auto &r : m.records) {
+            if (r.set) continue;   // a set of records stays the variable it is
             const bool per_process = r.proc >= 0 && multi && m.procs[(size_t)r.proc].is_set;
             if (r.seq) {   // q == [n_ \in 1..Len(q_f) |-> [f |-> q_f[n_], ...]]: a function on 1..n IS a sequence
                 const std::string at = std::string(per_process ? "[self]" : "") + (r.array ? "[" + r.bound + "]" : "");

@@ -80,6 +80,9 @@ struct RecordVar {
                                        // channels of a message-passing algorithm): one sequence per field, all of the same length
     std::string bound;                 // array: x
     EP domain;                         // array: S
+    bool set = false;                  // a SET of records (msgs = {} ... msgs := msgs \cup {[type |-> "1a", bal |-> b]}): stays ONE set-valued variable of the
+                                       // translation (as pcal2tla keeps it); the compiled program keeps its elements sorted, field by field
+    EP shape;                          // seq / set: the constructor that says which fields (and of which types) an element has
     int proc = -1;                     // index into Module::procs of the process it is local to, -1 = global
     std::vector<std::string> sub;      // the fields that are records themselves (nested records): r_f is a RecordVar of depth + 1
     int depth = 0;                     // 0 = a variable of the algorithm, k = a field of a record of depth k - 1
@@ -142,7 +145,9 @@ struct Module {
 // that the text around the algorithm (invariants written with r.f) keeps its meaning.  NESTED records (round 5): a field may itself
 // be a record; the flattener works one level per pass (r -> r_f -> r_f_g), `r.f.g := e` carries its path in Stmt::field ("f.g"), an
 // inner record is assigned / compared leaf by leaf, the translation defines every level, inner before outer.  Refused with a message:
-// a record as a whole value anywhere else (`with`, procedure arguments, set members), sets / sequences of records as initial values.
+// a record as a whole value anywhere else (`with` over a record, procedure arguments).  SEQUENCES of records (and arrays of them: channels)
+// are kept as one sequence per field; a SET of records (a message soup) stays one set-valued variable of the translation and is kept as
+// sorted cells by the compiled program (RecordVar::seq / ::set below).
 std::string parse_module(const std::string &text, Module &out);
 
 // The text `pcal2tla` inserts: from "\* BEGIN TRANSLATION" to "\* END TRANSLATION" inclusive, '\n' terminated.
@@ -175,6 +180,9 @@ struct VarInfo {
     bool seq = false;         // a bounded sequence: cell `base` = Len, then `cap` element cells
     bool defval = false;      // declared without an initial value: a cell holding VM_DEFAULT_INIT prints as defaultInitValue
     int cap = 0;
+    bool rset = false;        // a SET of records: cell `base` = the number of elements, field f of element i at base + 1 + f * cap + i (sorted, spec_vm.h VM_RSADD)
+    std::vector<std::string> fields;   // rset: the field names, in the order of the cells
+    std::string ftypes;                // rset: their types ('i' / 'b' / 's')
 };
 
 struct Program {

@@ -60,7 +60,11 @@ struct Compiler {
     std::vector<int> &c;  // the image being built
     std::map<std::string, int> var_index, str_id;
     std::map<std::string, ConstVal> consts;
-    struct Bind { std::string name; int temp; bool is_const; long long value; };
+    struct Bind {
+        std::string name; int temp; bool is_const; long long value;
+        const VarInfo *rs = nullptr;   // an ELEMENT of a set of records: `temp` holds its index (quantifiers) ...
+        std::vector<int> ftemps;       // ... or these temporaries hold its fields (`with`: the body may change the set)
+    };
     std::vector<Bind> binds;
     int next_temp = 0;
     const Proc *proc = nullptr;
@@ -92,6 +96,7 @@ struct Compiler {
         case mc::VM_ADD: case mc::VM_SUB: case mc::VM_MUL: case mc::VM_DIV: case mc::VM_MOD: case mc::VM_EQ: case mc::VM_NE: case mc::VM_LT:
         case mc::VM_LE: case mc::VM_GT: case mc::VM_GE: case mc::VM_OR: case mc::VM_AND: case mc::VM_ANDN: case mc::VM_APPEND: depth--; break;
         case mc::VM_SEQLEN: depth++; break;
+        // (VM_RSADD / VM_RSDEL / VM_RSHAS pop their k fields: emit_rs adjusts the depth)
         case mc::VM_STOREX: case mc::VM_STORESEQ: depth -= 2; break;
         case mc::VM_HALT: depth = 0; break;
         default: break;
@@ -214,6 +219,10 @@ struct Compiler {
             return 'i';
         }
         case Expr::INDEX: return type_of(e->a[0]);
+        case Expr::DOT:
+            if (const Bind *b = rs_bind(e->a[0]))
+                for (size_t k = 0; k < b->rs->fields.size(); k++) if (b->rs->fields[k] == e->s) return b->rs->ftypes[k];
+            return 'i';
         case Expr::CALL:
             for (const auto &d : m.defs) if (d.name == e->s && d.params.size() == e->a.size()) return type_of(d.body);
             return 'i';
@@ -444,6 +453,76 @@ struct Compiler {
         return c2;  // Tail(q), q: nothing to evaluate
     }
 
+    // ---- sets of records (pcal.h VarInfo::rset; spec_vm.h VM_RSADD)
+    const RecordVar *rset_record(const std::string &name) const {
+        for (const auto &r : m.records) if (r.set && r.name == name) return &r;
+        return nullptr;
+    }
+    const VarInfo *rset_var(const EP &e) {
+        if (e->k != Expr::ID) return nullptr;
+        for (size_t i = binds.size(); i-- > 0;) if (binds[i].name == e->s) return nullptr;
+        auto vi = var_index.find(e->s);
+        return vi != var_index.end() && P.vars[(size_t)vi->second].rset ? &P.vars[(size_t)vi->second] : nullptr;
+    }
+    void push_record(const VarInfo &v, const EP &r) {  // the fields of a constructor, in the order of the set's cells
+        if (r->k != Expr::RECORD) cfail("expected a record constructor as an element of the set of records `" + v.name + "`", r->pos);
+        for (const auto &f : v.fields) {
+            size_t k = 0;
+            while (k < r->names.size() && r->names[k] != f) k++;
+            if (k == r->names.size()) cfail("the record has no field " + f, r->pos);
+            ex(r->a[k]);
+        }
+    }
+    void emit_rs(int op, const VarInfo &v) {
+        c.push_back(op); track(op);
+        c.push_back(v.base); c.push_back(v.cap); c.push_back((int)v.fields.size());
+        depth -= (int)v.fields.size() - (op == mc::VM_RSHAS ? 1 : 0);
+        if (depth < 0) depth = 0;
+    }
+    const Bind *rs_bind(const EP &e) {  // the binding of a name that stands for an element of a set of records
+        if (e->k != Expr::ID) return nullptr;
+        for (size_t i = binds.size(); i-- > 0;) if (binds[i].name == e->s) return binds[i].rs ? &binds[i] : nullptr;
+        return nullptr;
+    }
+    void load_field(const Bind &b, const std::string &f, Pos p) {
+        const VarInfo &v = *b.rs;
+        size_t k = 0;
+        while (k < v.fields.size() && v.fields[k] != f) k++;
+        if (k == v.fields.size()) cfail("the record has no field " + f, p);
+        if (!b.ftemps.empty()) { emit(mc::VM_LOADT, b.ftemps[k]); return; }
+        emit(mc::VM_LOADT, b.temp);
+        c.push_back(mc::VM_LOADX); track(mc::VM_LOADX);
+        c.push_back(v.base + 1 + (int)k * v.cap); c.push_back(0); c.push_back(v.cap);
+    }
+    // msgs := {r, ...} | msgs \cup {r, ...} | msgs \ {r, ...} | msgs
+    void assign_rset(const VarInfo &v, const EP &e) {
+        auto each = [&](const EP &lit, int op) { for (const auto &r : lit->a) { push_record(v, r); emit_rs(op, v); } };
+        if (e->k == Expr::SETENUM) {
+            // the elements may read the set (`msgs := {[n |-> Cardinality(msgs)]}`): every field of every element first, then the clear
+            for (const auto &r : e->a) push_record(v, r);
+            c.push_back(mc::VM_SEQCLR); track(mc::VM_SEQCLR); c.push_back(v.base); c.push_back((int)v.fields.size() * v.cap); c.push_back(0);
+            for (size_t k = 0; k < e->a.size(); k++) emit_rs(mc::VM_RSADD, v);
+            return;
+        }
+        // msgs | chain \cup {r, ...} | chain \ {r, ...}: every field of every record is evaluated first (on the set as it was), pushed so
+        // that the first operation's record is on top; then the operations run in the order written
+        std::vector<std::pair<int, EP>> ops;
+        std::function<bool(const EP &)> chain = [&](const EP &x) -> bool {
+            if (x->k == Expr::ID) return rset_var(x) == &v;
+            if (x->k != Expr::BINOP || x->a[1]->k != Expr::SETENUM || !chain(x->a[0])) return false;
+            const int op = (x->s == "\\cup" || x->s == "\\union") ? (int)mc::VM_RSADD : x->s == "\\" ? (int)mc::VM_RSDEL : -1;
+            if (op < 0) return false;
+            for (const auto &r : x->a[1]->a) ops.push_back({op, r});
+            return true;
+        };
+        if (chain(e)) {
+            for (size_t k = ops.size(); k-- > 0;) push_record(v, ops[k].second);
+            for (const auto &o : ops) emit_rs(o.first, v);
+            return;
+        }
+        cfail("a set of records can be assigned {r, ...}, " + v.name + " \\cup {r, ...} or " + v.name + " \\ {r, ...}", e->pos);
+    }
+
     // ---- sets of small naturals as masks
     const VarInfo *set_var(const EP &e) {
         if (e->k != Expr::ID) return nullptr;
@@ -515,6 +594,7 @@ struct Compiler {
                     patch(ok);
                 }
                 if (per_self) { push_self(e->pos); emit_indexed(mc::VM_LOADX, v, e->pos); return; }
+                if (v.rset) cfail("the set of records `" + e->s + "` is used as a value here; supported: \\cup {r}, \\ {r}, r \\in, = {}, Cardinality, with / quantifiers over it", e->pos);
                 if (v.set) cfail("the set `" + e->s + "` is used as a number here; supported: \\in, \\cup, \\cap, \\, =, #, \\subseteq, Cardinality, with / quantifiers over it", e->pos);
                 if (v.seq) cfail("the sequence `" + e->s + "` is used as a value here; supported: Len, Head, " + e->s + "[i], = / # <<...>>", e->pos);
                 if (v.array) cfail("the function `" + e->s + "` is used as a value; only `" + e->s + "[i]` is supported", e->pos);
@@ -541,7 +621,10 @@ struct Compiler {
             cfail("unknown identifier `" + e->s + "`", e->pos);
         }
         case Expr::CALL: {  // an operator of the define block / of the module, inlined: arguments evaluated once
-            if (e->s == "Cardinality" && e->a.size() == 1) { ex_set(e->a[0]); emit(mc::VM_POPCNT); return; }
+            if (e->s == "Cardinality" && e->a.size() == 1) {
+                if (const VarInfo *rs = rset_var(e->a[0])) { emit(mc::VM_LOAD, rs->base); return; }
+                ex_set(e->a[0]); emit(mc::VM_POPCNT); return;
+            }
             if ((e->s == "Len" || e->s == "Head") && e->a.size() == 1) {
                 const SeqRef q = seq_ref(e->a[0]);
                 if (!q) cfail(e->s + " needs a sequence variable (or an element of an array of sequences)", e->pos);
@@ -588,6 +671,12 @@ struct Compiler {
             emit_indexed(mc::VM_LOADX, P.vars[(size_t)vi->second], e->pos);
             return;
         }
+        case Expr::DOT: {   // m.f of an element of a set of records (`with m \in msgs`, `\E m \in msgs`)
+            const Bind *b = rs_bind(e->a[0]);
+            if (!b) cfail("`." + e->s + "`: field access is compiled for the elements of a set of records only", e->pos);
+            load_field(*b, e->s, e->pos);
+            return;
+        }
         case Expr::UNOP: ex(e->a[0]); emit(e->s == "~" ? mc::VM_NOT : mc::VM_NEG); return;
         case Expr::IF: {
             ex(e->a[0]);
@@ -606,6 +695,21 @@ struct Compiler {
     }
     void binop(const EP &e) {
         const std::string &o = e->s;
+        if ((o == "\\in" || o == "\\notin") && rset_var(e->a[1])) {   // [type |-> "ack", from |-> self] \in msgs
+            const VarInfo &v = *rset_var(e->a[1]);
+            push_record(v, e->a[0]);
+            emit_rs(mc::VM_RSHAS, v);
+            if (o == "\\notin") emit(mc::VM_NOT);
+            return;
+        }
+        if (o == "=" || o == "#")
+            for (int side = 0; side < 2; side++)
+                if (const VarInfo *v = rset_var(e->a[(size_t)side])) {
+                    const EP &other = e->a[(size_t)(1 - side)];
+                    if (other->k != Expr::SETENUM || !other->a.empty()) cfail("a set of records can only be compared with {}", e->pos);
+                    emit(mc::VM_LOAD, v->base); emit(mc::VM_PUSH, 0); emit(o == "=" ? mc::VM_EQ : mc::VM_NE);
+                    return;
+                }
         if (o == "/\\" || o == "\\/" || o == "=>") {
             ex(e->a[0]);
             const int j1 = emit_jump(o == "\\/" ? mc::VM_JNZ : mc::VM_JZ);
@@ -723,6 +827,29 @@ struct Compiler {
             emit(mc::VM_PUSH, all ? 0 : 1);
             patch(jend);
             next_temp -= 2;
+            return;
+        }
+        if (const VarInfo *rs = rset_var(dom)) {  // the elements of a set of records, by index (an expression changes nothing)
+            const int tx = new_temp(e->pos);
+            emit(mc::VM_PUSH, 0); emit(mc::VM_STORET, tx);
+            const int loop = (int)c.size();
+            emit(mc::VM_LOADT, tx); emit(mc::VM_LOAD, rs->base); emit(mc::VM_LT);
+            const int jdone = emit_jump(mc::VM_JZ);
+            Bind b{e->bound, tx, false, 0};
+            b.rs = rs;
+            binds.push_back(b);
+            ex(e->a[1]);
+            binds.pop_back();
+            const int jhit = emit_jump(all ? mc::VM_JZ : mc::VM_JNZ);
+            emit(mc::VM_LOADT, tx); emit(mc::VM_PUSH, 1); emit(mc::VM_ADD); emit(mc::VM_STORET, tx);
+            emit(mc::VM_JMP, loop);
+            patch(jdone);
+            emit(mc::VM_PUSH, all ? 1 : 0);
+            const int jend = emit_jump(mc::VM_JMP);
+            patch(jhit);
+            emit(mc::VM_PUSH, all ? 0 : 1);
+            patch(jend);
+            next_temp -= 1;
             return;
         }
         if (dynamic_set(dom)) {  // x ranges over 0..31, the body counts only for members
@@ -852,7 +979,7 @@ struct Compiler {
                 auto vi = var_index.find(x->var);
                 if (vi == var_index.end()) cfail("assignment to `" + x->var + "`, which is not a variable of the algorithm", x->pos);
                 const VarInfo &xv = P.vars[(size_t)vi->second];
-                if (xv.set) cfail("`||` with a set variable is not supported", x->pos);
+                if (xv.set || xv.rset) cfail("`||` with a set variable is not supported", x->pos);
                 if (xv.seq && (xv.array || !x->idx)) {
                     // a whole sequence (q, box[i]): its scalar operands are evaluated now, the sequence it starts from must be itself — and then
                     // nothing another assignment of the statement stores can be read by this one
@@ -898,6 +1025,12 @@ struct Compiler {
         auto vi = var_index.find(s->var);
         if (vi == var_index.end() || s->var == "pc") cfail("assignment to `" + s->var + "`, which is not a variable of the algorithm", s->pos);
         const VarInfo &v = P.vars[(size_t)vi->second];
+        if (v.rset) {
+            for (const auto &pr : m.procs) for (const auto &l : pr.locals) if (l.name == s->var && &pr != proc) cfail("`" + s->var + "` cannot be assigned here", s->pos);
+            if (s->idx) cfail("a set variable cannot be indexed", s->pos);
+            assign_rset(v, s->e);
+            return;
+        }
         if (v.set) {
             for (const auto &pr : m.procs) for (const auto &l : pr.locals) if (l.name == s->var && &pr != proc) cfail("`" + s->var + "` cannot be assigned here", s->pos);
             if (s->idx) cfail("a set variable cannot be indexed", s->pos);
@@ -1055,6 +1188,26 @@ struct Compiler {
         case Stmt::WITH: {
             const int t = new_temp(s->pos);
             unsigned long long n = 1;
+            if (!s->with_eq && rset_var(s->e)) {   // any element of a set of records: its fields are COPIED (the body may change the set)
+                const VarInfo &v = *rset_var(s->e);
+                emit(mc::VM_CHOOSE, v.cap);
+                emit(mc::VM_STORET, t);
+                emit(mc::VM_LOADT, t); emit(mc::VM_LOAD, v.base); emit(mc::VM_LT); emit(mc::VM_AWAIT);
+                Bind b{s->var, t, false, 0};
+                b.rs = &v;
+                Bind byidx = b;
+                for (size_t k = 0; k < v.fields.size(); k++) {
+                    const int tf = new_temp(s->pos);
+                    load_field(byidx, v.fields[k], s->pos);
+                    emit(mc::VM_STORET, tf);
+                    b.ftemps.push_back(tf);
+                }
+                binds.push_back(b);
+                const unsigned long long nb = block(s->blocks[0]);
+                binds.pop_back();
+                next_temp -= 1 + (int)v.fields.size();
+                return (unsigned long long)v.cap * nb;
+            }
             if (s->with_eq) ex(s->e);
             else if (dynamic_set(s->e)) {  // any of 0..31, enabled only for the members
                 emit(mc::VM_CHOOSE, 32);
@@ -1230,6 +1383,16 @@ struct Compiler {
                 if (per_inst) add_var(d.name, true, ids_of[owner], 'i');
                 else add_var(d.name, false, {}, 'i');
                 P.vars.back().defval = true;
+            } else if (d.init->k == Expr::SETENUM && !d.in_set && rset_record(d.name)) {   // a SET of records: a count cell + fields x cells
+                const RecordVar &rv = *rset_record(d.name);
+                if (per_inst) cfail("a set of records local to a process SET is not supported (`" + d.name + "`)", d.pos);
+                add_var(d.name, false, {}, 'i');
+                VarInfo &v = P.vars.back();
+                v.rset = true;
+                v.fields = rv.fields;
+                for (const auto &x : rv.shape->a) v.ftypes += type_of(x);
+                v.cap = seq_cap();
+                nv += v.cap * (int)v.fields.size();
             } else if ((d.init->k == Expr::SETENUM || (d.init->k == Expr::BINOP && d.init->s == "..")) && !d.in_set) {
                 // a set of small naturals / strings — {...}, or an interval a..b of constants as its initial value (`free = 3..K`): one mask cell (per instance)
                 const char et = d.init->k == Expr::BINOP || d.init->a.empty() ? 'i' : type_of(d.init->a[0]);
@@ -1295,7 +1458,11 @@ struct Compiler {
         auto init_decl = [&](const VarDecl &d, const Proc *owner) {
             const VarInfo &v = P.vars[(size_t)var_index[d.name]];
             const bool per_inst = owner && owner->is_set && P.multi;
-            if (v.set) {
+            if (v.rset) {
+                if (owner && P.multi) { have_self_const = true; self_const = ids_of[owner][0]; }
+                assign_rset(v, d.init);
+                have_self_const = false;
+            } else if (v.set) {
                 for (size_t k = 0; k < (v.array ? v.ids.size() : (size_t)1); k++) {
                     if (owner && P.multi) { have_self_const = true; self_const = v.array ? v.ids[k] : ids_of[owner][0]; }
                     ex_set(d.init);
@@ -1471,6 +1638,36 @@ int vm_format(const void *host, const int32_t *vals, char *buf, size_t cap) {
             for (int k = 0; k < vals[base] && k < v.cap; k++) t += (k ? ", " : "") + pcal::fmt_val(P, v.type, vals[base + 1 + k]);
             return t + ">>";
         };
+        if (v.rset) {
+            // a set of records as the evaluator of the test suite prints it: fields in name order, elements ascending by their fields in that
+            // order (numbers by value, strings by text).  TLC's own order of a record's fields is not pinned by anything in the reference
+            std::vector<size_t> fo(v.fields.size());
+            for (size_t k = 0; k < fo.size(); k++) fo[k] = k;
+            std::sort(fo.begin(), fo.end(), [&](size_t a, size_t b) { return v.fields[a] < v.fields[b]; });
+            std::vector<int> el((size_t)std::max(0, std::min(vals[v.base], v.cap)));
+            for (size_t i = 0; i < el.size(); i++) el[i] = (int)i;
+            auto cell = [&](int i, size_t f) { return vals[v.base + 1 + (int)f * v.cap + i]; };
+            std::sort(el.begin(), el.end(), [&](int a, int b) {
+                for (size_t f : fo) {
+                    const int32_t x = cell(a, f), y = cell(b, f);
+                    if (x == y) continue;
+                    if (v.ftypes[f] == 's') {
+                        const std::string sx = x >= 0 && (size_t)x < P.strings.size() ? P.strings[(size_t)x] : "", sy = y >= 0 && (size_t)y < P.strings.size() ? P.strings[(size_t)y] : "";
+                        return sx < sy;
+                    }
+                    return x < y;
+                }
+                return false;
+            });
+            s += "{";
+            for (size_t i = 0; i < el.size(); i++) {
+                s += i ? ", [" : "[";
+                for (size_t k = 0; k < fo.size(); k++) s += (k ? ", " : "") + v.fields[fo[k]] + " |-> " + pcal::fmt_val(P, v.ftypes[fo[k]], cell(el[i], fo[k]));
+                s += "]";
+            }
+            s += "}";
+            continue;
+        }
         if (v.seq && !v.array) { s += seq_at(v.base); continue; }
         auto one = [&](int k) {   // element k of the array (or the variable itself)
             if (v.seq) return seq_at(v.base + k * (v.cap + 1));

@@ -30,7 +30,11 @@ enum VmOp : int32_t {
     // ARRAYS of bounded sequences (`box = [p \in 1..N |-> <<>>]`: the channels of a message-passing algorithm): element k of the array is
     // the sequence at base + k * (cap + 1).  VM_SEQSEL replaces the array index on the stack by that offset; the sequence instruction that
     // follows pops it when its third operand is 1 (every sequence instruction has the operands base, cap, indexed)
-    VM_SEQSEL, VM_SEQLEN
+    VM_SEQSEL, VM_SEQLEN,
+    // SETS of RECORDS (a message soup: `msgs := msgs \cup {[type |-> "1a", bal |-> b]}`): cell `base` holds the number of elements, field f of
+    // element i is cell base + 1 + f * cap + i; the elements are kept in ascending lexicographic order of their cells, without duplicates, so
+    // that one set has one representation.  Operands: base, cap, k (fields); the k field values are on the stack, the last field on top
+    VM_RSADD, VM_RSDEL, VM_RSHAS
 };
 
 // header words of the program image
@@ -244,6 +248,41 @@ struct SpecVmT {
                 const int32_t dst = c[pc], src = c[pc + 1], cap = c[pc + 2];
                 pc += 3;
                 for (int32_t k = 0; k <= cap; ++k) v[dst + k] = v[src + k];
+                break;
+            }
+            case VM_RSADD: case VM_RSDEL: case VM_RSHAS: {
+                const int32_t base = c[pc], cap = c[pc + 1], k = c[pc + 2];
+                pc += 3;
+                sp -= k;   // the element: st[sp .. sp + k)
+                if (sp < 0) return R_ERROR;
+                const int32_t *src = op == VM_RSHAS ? rd : v;
+                const int32_t n = src[base];
+                int32_t pos = 0, cmp = 1;   // first element that is not smaller; cmp == 0: it is equal
+                for (; pos < n; ++pos) {
+                    cmp = 0;
+                    for (int32_t f = 0; f < k && cmp == 0; ++f) {
+                        const int32_t a = src[base + 1 + f * cap + pos], b = st[sp + f];
+                        cmp = a < b ? -1 : a > b ? 1 : 0;
+                    }
+                    if (cmp >= 0) break;
+                }
+                const bool found = pos < n && cmp == 0;
+                if (op == VM_RSHAS) { st[sp++] = found; break; }
+                if (op == VM_RSADD) {
+                    if (found) break;
+                    if (n >= cap) return R_OVERFLOW;  // more elements than the cells this program reserves: reported, never dropped
+                    for (int32_t f = 0; f < k; ++f) {
+                        for (int32_t i = n; i > pos; --i) v[base + 1 + f * cap + i] = v[base + 1 + f * cap + i - 1];
+                        v[base + 1 + f * cap + pos] = st[sp + f];
+                    }
+                    v[base] = n + 1;
+                } else if (found) {
+                    for (int32_t f = 0; f < k; ++f) {
+                        for (int32_t i = pos; i + 1 < n; ++i) v[base + 1 + f * cap + i] = v[base + 1 + f * cap + i + 1];
+                        v[base + 1 + f * cap + n - 1] = 0;   // unused cells are 0: one set, one representation
+                    }
+                    v[base] = n - 1;
+                }
                 break;
             }
             case VM_NOP: break;
