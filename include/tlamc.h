@@ -438,8 +438,11 @@ int mc_shard_info(mc_engine *e, void **main_stream_out, uint64_t *chunk_states_o
  * half: it returns the module text with the TLA+ translation of its `--algorithm` inserted (p-manual.pdf App. B).
  * mc_program_compile is what lets the checker run a PlusCal spec nobody hand-lowered: the algorithm (p- or c-syntax;
  * labels, := , if/elsif/else, while, either/or, with, await/when, assert, skip, goto, define, macros; integers, booleans, strings,
- * functions over constant sets, bounded sequences, sets of small naturals) becomes a bytecode program every GPU lane interprets on its own packed state
- * (tla_rust_amd/csrc/spec_vm.h).  cfg_text: CONSTANT(S) with integer / string / model-value / set values and
+ * functions over constant sets, bounded sequences and arrays of them, sets of small naturals; procedures incl. recursion, records incl. nested
+ * ones, sequences and sets of records: DESIGN.md section 9) becomes a bytecode program every GPU lane interprets on its own packed state
+ * (tla_rust_amd/csrc/spec_vm.h).  Two bounds come from the environment at compile time: $TLAMC_PCAL_SEQ, the element cells per sequence /
+ * set of records (1 .. 16, default 8; a longer one is MC_EOVERFLOW, never truncated), and $TLAMC_PCAL_STACK, the frames per recursive
+ * procedure (default 4; a deeper call fails an assertion at the call).  cfg_text: CONSTANT(S) with integer / string / model-value / set values and
  * INVARIANT(S) naming zero-argument definitions of the module; NULL = no constants, no invariants. */
 typedef struct mc_program mc_program;
 int mc_pcal_translate(const char *tla_text, char *out, size_t cap);   /* >= 0: bytes needed (NUL excluded); < 0: MC_E* */

@@ -78,6 +78,9 @@ CASES = [
     (SPECS / "pluscal" / "two_phase_soup.tla", ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages", "SoupIsSmall"], {"RM": 2, "Hasty": False}),
     (SPECS / "pluscal" / "two_phase_soup.tla", ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages", "SoupIsSmall"], {"RM": 3, "Hasty": False}),
     (SPECS / "pluscal" / "two_phase_soup.tla", ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages"], {"RM": 3, "Hasty": True}),
+    # a procedure with a RECORD PARAMETER (call deposit(mine), call deposit([who |-> self, amount |-> 2])) and `with old = biggest` (a record bound field by field)
+    (SPECS / "pluscal" / "record_args.tla", ["Sane"], {"N": 2}),
+    (SPECS / "pluscal" / "record_args.tla", ["Sane"], {"N": 3}),
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -90,7 +93,7 @@ CASES = [
 ]
 
 
-CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup"}   # their GPU cases: tests/test_gpu_zz_channels.py
+CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args"}   # their GPU cases: tests/test_gpu_zz_channels.py
 
 
 def strip_translation(text):
@@ -419,7 +422,9 @@ def test_integer_overflow_and_division_like_tlc():
 PROC_FIXTURES = ROOT / "tests" / "golden" / "pcal_procedures"
 
 
-@pytest.mark.parametrize("spec,fixture,consts,invs", [("proc_demo", "ProcDemoStack", {}, []), ("treiber_procs", "TreiberStack", {"N": 2}, ["PopsDistinct"])])
+@pytest.mark.parametrize("spec,fixture,consts,invs", [("proc_demo", "ProcDemoStack", {}, []), ("treiber_procs", "TreiberStack", {"N": 2}, ["PopsDistinct"]),
+                                                      # a RECORD parameter: pcal2tla's record-valued `req` (defaultInitValue, restored from the frame) against fields req_who, req_amount
+                                                      ("record_args", "RecordArgsStack", {"N": 2}, ["Sane"])])
 def test_procedure_expansion_equals_the_stack_translation(spec, fixture, consts, invs):
     """PlusCal procedures are EXPANDED into the calling processes (tla_rust_amd/csrc/pcal.h) instead of being translated with a `stack`
     variable as pcal2tla does (p-manual section 3.5).  For non-recursive procedures the two are the same state graph: the hand-written
@@ -552,7 +557,6 @@ REC_ERRORS = [
     ("begin L: r[1] := q; end algorithm *)\n====\n", "r is a record, not an array of records"),
     ("begin L: x := x.a; end algorithm *)\n====\n", "field access is supported on record variables"),
     ("begin L: if r = 3 then skip; end if; end algorithm *)\n====\n", "a record can only be compared with"),
-    ("begin L: with v = r do x := v.a; end with; end algorithm *)\n====\n", "`with` over a record value is not supported"),
     ("begin L: r.a := 1; r.b := TRUE; end algorithm *)\n====\n", "second assignment to r in one step"),
     ("begin L: r.a := 1 || r.a := 2; end algorithm *)\n====\n", "two assignments to r"),
 ]
@@ -949,3 +953,28 @@ def test_set_of_records_errors_are_refused_with_a_message(body, msg):
     with pytest.raises(RuntimeError) as e:
         helpers.ShimProgram(RSET_HEAD.replace("\\\\", "\\") + body.replace("\\\\", "\\"))
     assert msg in str(e.value)
+
+
+def test_uniprocess_algorithm_with_procedure_variables_translates():
+    """a uniprocess algorithm has no process identifier: its procedures' parameters / variables are plain variables of the translation
+    (the translator dereferenced the missing identifier: a crash until round 5's last part)"""
+    text = MODULE % "variables x = 0, r = [a |-> 0, b |-> FALSE];\nprocedure p(q) variables k = 1; begin P1: q.a := q.a + k; P2: x := q.a; return; end procedure;\nbegin\nL: call p(r);\nM: call p([a |-> 7, b |-> TRUE]);\nN: assert x = 8;"
+    tr = helpers.pcal_translate(text)
+    assert "/\\ q_a = defaultInitValue" in tr and "/\\ k = 1" in tr and "CONSTANT defaultInitValue" in tr
+    r = _vm_equals_evaluator(text)
+    assert (r["verdict"], r["distinct"]) == ("ok", 8)
+
+
+@pytest.mark.parametrize("body,needle", [
+    ("variables r = [a |-> 0, b |-> FALSE], x = 0;\nprocedure p(q) begin P1: x := q.a; P2: if x < 2 then call p(q); end if; P3: return; end procedure;\nbegin\nL: call p(r);\nM: skip;",
+     "parameter q of the RECURSIVE procedure p is passed a record"),
+    ("variables r = [a |-> 0, b |-> FALSE], x = 0;\nprocedure p(q = 3) begin P1: x := q; return; end procedure;\nbegin\nL: call p(r);\nM: skip;", "has a default value and is passed a record"),
+    ("variables r = [a |-> 0, b |-> FALSE], x = 0;\nprocedure p(q) begin P1: x := q.c; return; end procedure;\nbegin\nL: call p(r);\nM: skip;", "record q has no field c"),
+    ("variables r = [a |-> 0, b |-> FALSE], x = 0;\nprocedure p(q) begin P1: x := q.a; return; end procedure;\nbegin\nL: call p(r);\nM: call p(5);\nN: skip;",
+     "the value assigned to record variable q must be a record"),
+    ("variables r = [a |-> 0, b |-> FALSE], x = 0;\nbegin\nL: with v \\in {r} do x := v.a; end with;", "record variable r is used as a whole value"),
+])
+def test_record_argument_errors_are_refused_with_a_message(body, needle):
+    with pytest.raises(RuntimeError) as e:
+        helpers.ShimProgram(MODULE % body)
+    assert needle in str(e.value)

@@ -901,6 +901,68 @@ void add_missing_labels(Module &m) {
 // ---- procedures: expanded into the processes that call them (pcal.h says what this preserves of pcal2tla's translation)
 namespace {
 struct ExpandError { std::string msg; };
+// RECORD PARAMETERS (round 5, last part): a procedure parameter that some call passes a record (a record variable, an element of a record
+// array, a constructor) becomes a record variable itself — its initial value the constructor [f |-> defaultInitValue, ...], which is what
+// pcal2tla's `param = defaultInitValue` is, field by field — so that the `param := argument` of the expanded call and the reset of the
+// `return` are record assignments the flattener knows.  Not for recursive procedures (their frames are plain cells).
+void record_parameters(Module &m) {
+    auto decl_shape = [&](const std::string &name) -> EP {
+        auto look = [&](const std::vector<VarDecl> &v) -> EP {
+            for (const auto &d : v)
+                if (d.name == name && d.init && !d.in_set) {
+                    if (d.init->k == Expr::RECORD) return d.init;
+                    if (d.init->k == Expr::FUNCDEF && d.init->a[1]->k == Expr::RECORD) return d.init->a[1];
+                }
+            return nullptr;
+        };
+        if (EP r = look(m.globals)) return r;
+        for (const auto &p : m.procs) if (EP r = look(p.locals)) return r;
+        for (const auto &p : m.procedures) { if (EP r = look(p.params)) return r; if (EP r = look(p.locals)) return r; }
+        return nullptr;
+    };
+    auto shape_of = [&](const EP &x) -> EP {
+        if (!x) return nullptr;
+        if (x->k == Expr::RECORD) return x;
+        if (x->k == Expr::ID) return decl_shape(x->s);
+        if (x->k == Expr::INDEX && x->a[0]->k == Expr::ID) return decl_shape(x->a[0]->s);
+        return nullptr;
+    };
+    for (bool changed = true; changed;) {   // (a record handed on by a procedure to the next one: until nothing changes)
+        changed = false;
+        std::function<void(const std::vector<SP> &)> walk = [&](const std::vector<SP> &v) {
+            for (const auto &s : v) {
+                if (s->k == Stmt::CALL)
+                    for (auto &pr : m.procedures)
+                        if (pr.name == s->var)
+                            for (size_t k = 0; k < pr.params.size() && k < s->args.size(); k++) {
+                                VarDecl &pd = pr.params[k];
+                                const EP sh = shape_of(s->args[k]);
+                                if (!sh || (pd.init && pd.init->k == Expr::RECORD)) continue;
+                                if (!pd.no_init) throw ExpandError{"line " + std::to_string(s->pos.line) + ", col " + std::to_string(s->pos.col) + ": parameter " + pd.name + " of " + pr.name + " has a default value and is passed a record: not supported"};
+                                auto rc = std::make_shared<Expr>();
+                                rc->k = Expr::RECORD;
+                                rc->pos = pd.pos;
+                                rc->names = sh->names;
+                                for (size_t f = 0; f < sh->names.size(); f++) {
+                                    if (sh->a[f]->k == Expr::RECORD || sh->a[f]->k == Expr::FUNCDEF) throw ExpandError{"line " + std::to_string(s->pos.line) + ", col " + std::to_string(s->pos.col) + ": a record with record / function fields as a procedure argument is not supported"};
+                                    auto dv = std::make_shared<Expr>();
+                                    dv->k = Expr::ID;
+                                    dv->s = "defaultInitValue";
+                                    dv->pos = pd.pos;
+                                    rc->a.push_back(dv);
+                                }
+                                pd.init = rc;
+                                pd.no_init = false;
+                                changed = true;
+                            }
+                for (const auto &b : s->blocks) walk(b);
+            }
+        };
+        for (const auto &p : m.procs) walk(p.body);
+        for (const auto &pr : m.procedures) walk(pr.body);
+    }
+}
+
 struct ProcExpander {
     Module &m;
     int copies = 0;
@@ -1298,6 +1360,10 @@ struct ProcExpander {
             if (!ends_in_jump(pr.body)) fail(pr.body.back()->pos, "control can run off the end of procedure " + pr.name + ": it must end with `return` (or a `goto`) on every path");
         }
         find_recursive();
+        for (const auto &pr : m.procedures)
+            if (recursive.count(pr.name))
+                for (const auto &d : pr.params)
+                    if (d.init && d.init->k == Expr::RECORD) fail(d.pos, "parameter " + d.name + " of the RECURSIVE procedure " + pr.name + " is passed a record: not supported (its frames are plain cells)");
         int callers = 0;
         for (auto &p : m.procs) callers += uses_procedures(p.body) ? 1 : 0;
         for (auto &p : m.procs) {
@@ -1340,6 +1406,7 @@ struct RecordFlattener {
     std::set<std::string> pending;           // ... the latter: the next pass's record variables
     std::map<std::string, EP> rsets;         // SETS of records (RecordVar::set): they stay variables; name -> the elements' constructor
     mutable std::vector<std::pair<std::string, EP>> bound;   // `with m \in msgs` / `\E m \in msgs`: m is a record value with msgs' fields
+    mutable std::vector<std::pair<std::string, EP>> split;   // `with v = r`: v is a record value bound FIELD BY FIELD (v.f is the bound name v_f)
     int depth = 0;
     [[noreturn]] static void fail(const Pos &at, const std::string &msg) { throw FlattenError{"line " + std::to_string(at.line) + ", column " + std::to_string(at.col) + ": " + msg}; }
     static EP node(Expr::K k, const Pos &at) { auto e = std::make_shared<Expr>(); e->k = k; e->pos = at; return e; }
@@ -1409,7 +1476,7 @@ struct RecordFlattener {
     EP shape(const EP &e) const {
         if (!e) return nullptr;
         if (e->k == Expr::RECORD) return e;
-        if (e->k == Expr::ID) for (size_t i = bound.size(); i-- > 0;) if (bound[i].first == e->s) return bound[i].second;
+        if (const EP bs = bound_shape(e)) return bs;
         if (const RecordVar *r = recseq_elem(e)) return shapes.at(r->name);
         if (recseq(e)) return nullptr;
         if (e->k == Expr::ID || e->k == Expr::INDEX) {
@@ -1468,8 +1535,13 @@ struct RecordFlattener {
         return rw(e);  // a path `x.f` to a record-valued field
     }
     EP bound_shape(const EP &e) const {
+        if (e->k == Expr::ID) for (size_t i = split.size(); i-- > 0;) if (split[i].first == e->s) return split[i].second;
         if (e->k == Expr::ID) for (size_t i = bound.size(); i-- > 0;) if (bound[i].first == e->s) return bound[i].second;
         return nullptr;
+    }
+    bool is_split(const EP &e) const {
+        if (e->k == Expr::ID) for (const auto &x : split) if (x.first == e->s) return true;
+        return false;
     }
     // field f of a record-valued expression
     EP field_of(const EP &e, const std::string &f) const {
@@ -1481,6 +1553,7 @@ struct RecordFlattener {
         }
         if (const EP bs = bound_shape(e)) {  // m.f of an element of a set of records: the compiled program reads the field's cell
             if (field_index(bs, f) < 0) fail(e->pos, "the record has no field " + f);
+            if (is_split(e)) return id(e->s + "_" + f, e->pos);   // with v = r: v.f is the bound name v_f
             auto d = node(Expr::DOT, e->pos);
             d->s = f;
             d->a = {e};
@@ -1748,7 +1821,29 @@ struct RecordFlattener {
                 s = c;
                 continue;
             }
-            if (s->k == Stmt::WITH && s->e && record_valued(s->e)) fail(s->e->pos, "`with` over a record value is not supported");
+            if (s->k == Stmt::WITH && s->e && s->with_eq && record_valued(s->e)) {
+                // with v = r do ... v.f ... : one `with v_f = r.f` per field, the body inside the innermost
+                const EP sh = shape(s->e);
+                for (const auto &x : sh->a) if (x->k == Expr::RECORD) fail(s->e->pos, "`with " + s->var + " = ...` over a record with record fields is not supported");
+                std::vector<EP> vals;
+                for (const auto &f : sh->names) vals.push_back(field_of(s->e, f));
+                auto body = s->blocks;
+                split.push_back({s->var, sh});
+                try { for (auto &b : body) stmts(b); } catch (...) { split.pop_back(); throw; }
+                split.pop_back();
+                SP inner;
+                for (size_t k = sh->names.size(); k-- > 0;) {
+                    auto w = std::make_shared<Stmt>(*s);
+                    w->var = s->var + "_" + sh->names[k];
+                    w->e = vals[k];
+                    w->label = k == 0 ? s->label : "";
+                    w->blocks = inner ? std::vector<std::vector<SP>>{{inner}} : body;
+                    inner = w;
+                }
+                s = inner;
+                continue;
+            }
+            if (s->k == Stmt::WITH && s->e && record_valued(s->e)) fail(s->e->pos, "`with` over a record value is supported as `with v = r` only");
             auto c = std::make_shared<Stmt>(*s);
             if (s->k == Stmt::WITH && !s->with_eq && s->e && s->e->k == Expr::ID && rsets.count(s->e->s)) {   // with m \in msgs do ... m.f ... end with
                 bound.push_back({s->var, rsets.at(s->e->s)});
@@ -1915,8 +2010,10 @@ struct RecordFlattener {
                 VarDecl f = d;
                 f.name = d.name + "_" + rc->names[i];
                 if (taken.count(f.name)) fail(d.pos, "field " + rc->names[i] + " of record variable " + d.name + " is kept as a variable " + f.name + ", and that name is taken");
-                if (scalar) f.init = rc->a[i];
-                else { auto fn = std::make_shared<Expr>(*e); fn->a[1] = rc->a[i]; f.init = fn; }
+                if (scalar) {
+                    f.init = rc->a[i];
+                    f.no_init = f.init->k == Expr::ID && f.init->s == "defaultInitValue";   // (a record PARAMETER: pcal2tla's `param = defaultInitValue`, field by field)
+                } else { auto fn = std::make_shared<Expr>(*e); fn->a[1] = rc->a[i]; f.init = fn; }
                 if (rc->a[i]->k == Expr::RECORD) {  // a nested record: the next pass's record variable
                     if (depth >= 6) fail(rc->a[i]->pos, "records nest too deeply");
                     r.sub.push_back(rc->names[i]);
@@ -2031,6 +2128,7 @@ std::string parse_module(const std::string &text, Module &m) {
         }
         {   // (always: a `call` / `return` in an algorithm without procedures is refused there)
             try {
+                record_parameters(m);
                 ProcExpander{m}.run();
             } catch (const ExpandError &e) {
                 return e.msg;
@@ -2608,7 +2706,7 @@ std::string translate(const Module &m) {
             if (multi) item("(* Process " + p.name + " *)");
             Ctx c = none;
             c.proc = &p;
-            const std::string ids = pe(p.id, none, empty, empty);
+            const std::string ids = p.id ? pe(p.id, none, empty, empty) : std::string();   // (a uniprocess algorithm has no identifier: its procedures' variables are plain variables)
             for (const auto &l : p.locals) {
                 const std::string e = pe(l.init, none, empty, empty);
                 if (!multi || !p.is_set) item("/\\ " + l.name + (l.in_set ? " \\in " : " = ") + e);
