@@ -978,3 +978,12 @@ def test_record_argument_errors_are_refused_with_a_message(body, needle):
     with pytest.raises(RuntimeError) as e:
         helpers.ShimProgram(MODULE % body)
     assert needle in str(e.value)
+
+
+def test_a_set_of_records_filled_through_a_record_parameter_is_typed_by_the_arguments():
+    """`procedure send(m) ... msgs := msgs \\cup {m}`: the fields of the parameter start as defaultInitValue and say nothing about the types of
+    the set's fields; they come from the first real values (`call send([t |-> "a", n |-> 1])`): a number prints as a number"""
+    text = (MODULE % "variables msgs = {}, log = <<>>, x = 0;\nprocedure send(m) begin P1: msgs := msgs \\cup {m}; log := Append(log, m); return; end procedure;\nbegin\n"
+            "L: call send([t |-> \"a\", n |-> 1]);\nM: call send([t |-> \"b\", n |-> 2]);\nN: with m \\in msgs do x := m.n; end with;").replace("EXTENDS Naturals", "EXTENDS Naturals, Sequences")
+    r = _vm_equals_evaluator(text)     # (state TEXTS are compared: `[n |-> 1, t |-> "a"]`, not `[n |-> "M", ...]`)
+    assert (r["verdict"], r["distinct"]) == ("ok", 7)

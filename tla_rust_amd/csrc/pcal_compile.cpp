@@ -224,6 +224,7 @@ struct Compiler {
                 for (size_t k = 0; k < b->rs->fields.size(); k++) if (b->rs->fields[k] == e->s) return b->rs->ftypes[k];
             return 'i';
         case Expr::CALL:
+            if (e->s == "Head" && e->a.size() == 1) return type_of(e->a[0]);
             for (const auto &d : m.defs) if (d.name == e->s && d.params.size() == e->a.size()) return type_of(d.body);
             return 'i';
         default: return 'i';
@@ -424,6 +425,39 @@ struct Compiler {
         };
         for (const auto &p : m.procs) walk(p.body);
         return found ? found : 'i';
+    }
+    // the types of the fields of a set of records: per field, the first value put into it (initial elements, then `\\cup {r}` / `{r}` in the
+    // algorithm) that is not the defaultInitValue of a record parameter
+    std::string rset_field_types(const VarInfo &v) {
+        std::string types(v.fields.size(), 0);
+        auto see = [&](const EP &lit) {
+            if (!lit || lit->k != Expr::SETENUM) return;
+            for (const auto &r : lit->a) {
+                if (r->k != Expr::RECORD) continue;
+                for (size_t f = 0; f < v.fields.size(); f++) {
+                    if (types[f]) continue;
+                    for (size_t k = 0; k < r->names.size(); k++)
+                        if (r->names[k] == v.fields[f] && !(r->a[k]->k == Expr::ID && r->a[k]->s == "defaultInitValue")) types[f] = type_of(r->a[k]);
+                }
+            }
+        };
+        auto decl = [&](const std::vector<VarDecl> &ds) { for (const auto &d : ds) if (d.name == v.name) see(d.init); };
+        decl(m.globals);
+        for (const auto &p : m.procs) decl(p.locals);
+        std::function<void(const EP &)> chain = [&](const EP &e) {
+            if (!e) return;
+            if (e->k == Expr::SETENUM) { see(e); return; }
+            if (e->k == Expr::BINOP) { chain(e->a[0]); chain(e->a[1]); }
+        };
+        std::function<void(const std::vector<SP> &)> walk = [&](const std::vector<SP> &b) {
+            for (const auto &s : b) {
+                if (s->k == Stmt::ASSIGN && s->var == v.name) chain(s->e);
+                for (const auto &x : s->blocks) walk(x);
+            }
+        };
+        for (const auto &p : m.procs) walk(p.body);
+        for (auto &t : types) if (!t) t = 'i';
+        return types;
     }
     // the scalar operands of a sequence expression (the elements of <<..>>, Append's value, the elements behind \o): `||` evaluates
     // them before anything is stored, and hands assign_seq the expression with temporaries in their places
@@ -1390,7 +1424,7 @@ struct Compiler {
                 VarInfo &v = P.vars.back();
                 v.rset = true;
                 v.fields = rv.fields;
-                for (const auto &x : rv.shape->a) v.ftypes += type_of(x);
+                v.ftypes = std::string(rv.fields.size(), 'i');   // (fixed below, once every variable is known)
                 v.cap = seq_cap();
                 nv += v.cap * (int)v.fields.size();
             } else if ((d.init->k == Expr::SETENUM || (d.init->k == Expr::BINOP && d.init->s == "..")) && !d.in_set) {
@@ -1433,7 +1467,10 @@ struct Compiler {
         P.pc_base = nv;
         add_var("pc", P.multi, P.multi ? procset : std::vector<long long>{}, 's');
         for (const auto &p : m.procs) for (const auto &l : p.locals) decl_var(l, &p);
-        for (const auto &name : untyped_seqs) P.vars[(size_t)var_index[name]].type = seq_elem_type(name);
+        // types that come from what the algorithm assigns: sequences that start empty, variables without an initial value (a procedure's
+        // parameters), the fields of a set of records — each may be typed by another, so: sequences, then variables, sequences again, sets
+        auto type_seqs = [&]() { for (const auto &name : untyped_seqs) P.vars[(size_t)var_index[name]].type = seq_elem_type(name); };
+        type_seqs();
         for (auto &v : P.vars) {
             if (!v.defval) continue;
             const Expr *rhs = nullptr;
@@ -1444,6 +1481,8 @@ struct Compiler {
             auto probe = std::make_shared<Expr>(*rhs);
             v.type = type_of(probe);
         }
+        type_seqs();
+        for (auto &v : P.vars) if (v.rset) v.ftypes = rset_field_types(v);
         if (nv > mc::SpecVm::MAX_VARS) cfail("the state has " + std::to_string(nv) + " scalar variables; at most " + std::to_string(mc::SpecVm::MAX_VARS) + " are supported");
         P.nv = nv;
         // image: header, label table, self table, code
