@@ -343,3 +343,36 @@ def test_random_algorithm_with_channels_translated_vs_compiled(seed, tmp_path):
     except AssertionError:
         print(text)
         raise
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_uniprocess_algorithm_translated_vs_compiled(seed, tmp_path):
+    """the same random steps as ONE process without a name (a uniprocess algorithm: `pc` a plain variable, no `self`, the procedure's
+    parameter and variable plain variables of the translation) — the shape on which the translator crashed until round 5's last part"""
+    import re
+    g = ChanGen(seed) if seed % 2 else Gen(seed)
+    g.single = False
+    text, invs = g.program()
+    text = text.replace("process p \\in 1..2\nvariables t = 0;\nbegin\n", "begin\n").replace("end process;\n", "")
+    text = text.replace("variables x = 0, y = 1", "variables t = 0, x = 0, y = 1", 1)
+    text = re.sub(r"\bself\b", "1", text)
+    try:
+        helpers.pcal_translate(text)
+        prog = helpers.ShimProgram(text, invs, {})
+    except RuntimeError as e:
+        assert str(e).strip(), text
+        pytest.skip(f"refused: {e}")
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    if r["distinct"] > MAX_STATES:
+        pytest.skip(f"{r['distinct']} states: too many for the Python evaluator in a unit test")
+    path = tmp_path / "Fz.tla"
+    path.write_text(text)
+    try:
+        test_pcal.test_compiled_program_vs_tla_evaluator(path, invs, {})
+        test_tlaeval.test_pluscal_translation_evaluated_vs_compiled_program(path, invs, {}, tmp_path)
+    except AssertionError:
+        print(text)
+        raise
