@@ -2213,7 +2213,7 @@ def parse_cfg(text):
     out = dict(spec=None, init=None, next=None, invariants=[], constraints=[], constants={}, overrides={}, symmetry=None,
                properties=[], scoped={})
     KW = {"SPECIFICATION", "INIT", "NEXT", "INVARIANT", "INVARIANTS", "CONSTRAINT", "CONSTRAINTS", "CONSTANT", "CONSTANTS", "SYMMETRY",
-          "PROPERTY", "PROPERTIES", "ACTION_CONSTRAINT", "ACTION_CONSTRAINTS", "VIEW"}
+          "PROPERTY", "PROPERTIES", "ACTION_CONSTRAINT", "ACTION_CONSTRAINTS", "VIEW", "CHECK_DEADLOCK"}
     i = 0
 
     def value(j):
@@ -2246,7 +2246,10 @@ def parse_cfg(text):
             raise SyntaxError(f"cfg: expected a statement keyword at line {t.line}, found {t.s!r}")
         kw = t.s
         i += 1
-        if kw in ("SPECIFICATION", "INIT", "NEXT", "SYMMETRY", "VIEW"):
+        if kw == "CHECK_DEADLOCK":   # TLC2's statement (not in the 2001 grammar): TRUE | FALSE
+            out["check_deadlock"] = toks[i].s == "TRUE"
+            i += 1
+        elif kw in ("SPECIFICATION", "INIT", "NEXT", "SYMMETRY", "VIEW"):
             key = {"SPECIFICATION": "spec", "INIT": "init", "NEXT": "next", "SYMMETRY": "symmetry", "VIEW": "view"}[kw]
             out[key] = toks[i].s
             i += 1
@@ -2500,7 +2503,7 @@ class Checker:
                 except TLAError as e:
                     note("spec-error", -1, depth)
                     err_msg = str(e)
-                if nsucc == 0 and check_deadlock:
+                if nsucc == 0 and check_deadlock and self.cfg.get("check_deadlock", True):
                     note("deadlock", -1, depth)
                 if verdict != "ok" and stop_on_violation:
                     break

@@ -71,6 +71,17 @@ def test_cfg_rejects_malformed(amd, bad):
     assert e.value.code == -8
 
 
+def test_cfg_check_deadlock_statement(amd):
+    """TLC2's `CHECK_DEADLOCK FALSE` (= the command line's -deadlock; not in the 2001 grammar of TLC/ConfigFileGrammar.tla:4-32):
+    specs/pluscal/paxos_soup.cfg uses it — its acceptors never stop"""
+    assert amd.cfg_parse("SPECIFICATION Spec\nCHECK_DEADLOCK FALSE\nINVARIANT I\n")["CHECK_DEADLOCK"] is False
+    assert amd.cfg_parse("CHECK_DEADLOCK TRUE\n")["CHECK_DEADLOCK"] is True
+    assert "CHECK_DEADLOCK" not in amd.cfg_parse("SPECIFICATION Spec\n")
+    with pytest.raises(amd.McError) as e:
+        amd.cfg_parse("CHECK_DEADLOCK maybe\n")
+    assert e.value.code == -8
+
+
 def test_empty_cfg_is_valid(amd):
     c = amd.cfg_parse("(* only a comment *)\n\\* and another\n")
     assert c["SPECIFICATION"] == "" and c["CONSTANTS"] == []

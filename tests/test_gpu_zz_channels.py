@@ -116,3 +116,30 @@ def test_random_algorithms_with_channels_on_gpu(amd, tmp_path):  # noqa: F811
         check_compiled_program_on_gpu(amd, path, invs, {})
         checked += 1
     assert checked >= 30
+
+
+def test_paxos_in_pluscal_on_gpu(amd, monkeypatch):  # noqa: F811
+    """specs/pluscal/paxos_soup.tla (single-decree Paxos over a set of five-field records, 16 cells): 15 993 states / 58 405 generated / depth 25 —
+    what oracle/tla_eval.py (7 569-state variant, state sets) and tlaeval.cpp give on the host (tests/test_pcal.py); the forgetful proposer
+    breaks Agreement at depth 21; `mc` reads CHECK_DEADLOCK FALSE from the cfg (the acceptors never stop)"""
+    monkeypatch.setenv("TLAMC_PCAL_SEQ", "16")
+    spec = ROOT / "specs" / "pluscal" / "paxos_soup.tla"
+    invs = ["Agreement", "VotesAreProposed", "OneValuePerBallot", "PromisesAreHonest"]
+    prog = amd.Program(spec.read_text(), cfg_text(invs, {"NA": 3, "NB": 2, "NV": 2, "Forgetful": False}))
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12, deadlock=False)
+    r = eng.run()
+    assert (r.distinct, r.generated, r.depth, r.verdict, r.queue_left) == (15993, 58405, 25, "ok", 0)
+    eng.close()
+    prog.close()
+    prog = amd.Program(spec.read_text(), cfg_text(["Agreement", "VotesAreProposed", "PromisesAreHonest"], {"NA": 3, "NB": 2, "NV": 2, "Forgetful": True}))
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12, deadlock=False)
+    r = eng.run()
+    assert (r.verdict, r.trace_len, r.distinct) == ("invariant", 21, 16533) and prog.invariant(r.violated_invariant) == "Agreement"
+    assert len(eng.trace()) == 21
+    eng.close()
+    prog.close()
+    rc, out, err = run_mc(spec)
+    assert rc == 0, err
+    assert "58405 states generated, 15993 distinct states found, 0 states left on queue." in out
+    rc, out, err = run_mc(spec, "-config", ROOT / "specs" / "pluscal" / "paxos_soup_forgetful.cfg")
+    assert rc == 12 and "Error: Invariant Agreement is violated." in out, err

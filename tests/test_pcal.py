@@ -987,3 +987,43 @@ def test_a_set_of_records_filled_through_a_record_parameter_is_typed_by_the_argu
             "L: call send([t |-> \"a\", n |-> 1]);\nM: call send([t |-> \"b\", n |-> 2]);\nN: with m \\in msgs do x := m.n; end with;").replace("EXTENDS Naturals", "EXTENDS Naturals, Sequences")
     r = _vm_equals_evaluator(text)     # (state TEXTS are compared: `[n |-> 1, t |-> "a"]`, not `[n |-> "M", ...]`)
     assert (r["verdict"], r["distinct"]) == ("ok", 7)
+
+
+def test_paxos_in_pluscal_over_a_message_soup():
+    """specs/pluscal/paxos_soup.tla: single-decree Paxos, one proposer process per ballot, three acceptors, the network a SET of RECORDS with
+    five fields; the acceptors never stop (CHECK_DEADLOCK FALSE in the cfg).  The compiled program on the host VM against oracle/tla_eval.py
+    on the translation (one value: 7 569 states, state sets included) and against the product's host evaluator tlaeval.cpp reading the
+    module + cfg files (two values: 15 993 states / 58 405 generated / depth 25); a proposer that forgets what it was promised (Forgetful)
+    lets two values be chosen: Agreement fails at depth 21 on every route"""
+    spec = SPECS / "pluscal" / "paxos_soup.tla"
+    invs = ["Agreement", "VotesAreProposed", "OneValuePerBallot", "PromisesAreHonest"]
+    os.environ["TLAMC_PCAL_SEQ"] = "16"
+    try:
+        small = helpers.ShimProgram(spec.read_text(), invs, {"NA": 3, "NB": 2, "NV": 1, "Forgetful": False})
+        full = helpers.ShimProgram(spec.read_text(), invs, {"NA": 3, "NB": 2, "NV": 2, "Forgetful": False})
+        bad = helpers.ShimProgram(spec.read_text(), ["Agreement", "VotesAreProposed", "PromisesAreHonest"], {"NA": 3, "NB": 2, "NV": 2, "Forgetful": True})
+    finally:
+        del os.environ["TLAMC_PCAL_SEQ"]
+    try:
+        fd, dump = tempfile.mkstemp()
+        os.close(fd)
+        r = helpers.shim_run("pcal", small.params, check_deadlock=False, dump=dump)
+        o = Checker(small.translated(), constants={"NA": 3, "NB": 2, "NV": 1, "Forgetful": False}).run_levels(invariants=invs, check_deadlock=False)
+        for k in ("distinct", "generated", "depth", "verdict", "levels"):
+            assert r[k] == o[k], (k, r[k], o[k])
+        assert r["distinct"] == 7569
+        states = helpers.read_dump(dump)
+        os.unlink(dump)
+        for lvl, want in enumerate(o["states"], 1):
+            assert states[lvl] == want, f"level {lvl}"
+        r = helpers.shim_run("pcal", full.params, check_deadlock=False)
+        e = helpers.tlaeval_run(spec, SPECS / "pluscal" / "paxos_soup.cfg", search=[])
+        assert (r["distinct"], r["generated"], r["depth"], r["verdict"]) == (15993, 58405, 25, "ok")
+        assert (e["distinct"], e["generated"], e["depth"], e["verdict"], e["levels"]) == (r["distinct"], r["generated"], r["depth"], 0, r["levels"])
+        r = helpers.shim_run("pcal", bad.params, check_deadlock=False)
+        e = helpers.tlaeval_run(spec, SPECS / "pluscal" / "paxos_soup_forgetful.cfg", search=[])
+        assert (r["verdict"], r["trace_len"], r["distinct"]) == ("invariant", 21, 16533) and (e["verdict"], e["distinct"], e["levels"]) == (1, 16533, r["levels"])
+    finally:
+        small.close()
+        full.close()
+        bad.close()

@@ -58,6 +58,7 @@ struct mc_cfg {
     std::string specification, init, next, view, symmetry;
     std::vector<std::string> invariants, properties, constraints, action_constraints;
     std::vector<CfgConst> constants;
+    int check_deadlock = -1;   // TLC's `CHECK_DEADLOCK TRUE | FALSE` statement (-1: not given; the command line's -deadlock decides)
 };
 
 namespace {
@@ -156,7 +157,7 @@ bool is_plural(const std::string &s) {
     return s == "CONSTRAINT" || s == "CONSTRAINTS" || s == "ACTION-CONSTRAINT" || s == "ACTION-CONSTRAINTS" || s == "INVARIANT" ||
            s == "INVARIANTS" || s == "PROPERTY" || s == "PROPERTIES";
 }
-bool is_keyword(const std::string &s) { return is_singular(s) || is_plural(s) || s == "CONSTANT" || s == "CONSTANTS"; }
+bool is_keyword(const std::string &s) { return is_singular(s) || is_plural(s) || s == "CONSTANT" || s == "CONSTANTS" || s == "CHECK_DEADLOCK"; }
 
 struct Parser {
     Lexer lx;
@@ -193,7 +194,11 @@ struct Parser {
             if (cur.t != Tok::IDENT || !is_keyword(cur.s)) return fail("expected a configuration keyword, got '" + cur.s + "'");
             const std::string kw = cur.s;
             if (!adv()) return false;
-            if (is_singular(kw)) {
+            if (kw == "CHECK_DEADLOCK") {   // TLC2's cfg statement (not in the 2001 grammar of TLC/ConfigFileGrammar.tla:4-32): same as -deadlock
+                if (cur.t != Tok::IDENT || (cur.s != "TRUE" && cur.s != "FALSE")) return fail("CHECK_DEADLOCK must be followed by TRUE or FALSE");
+                c.check_deadlock = cur.s == "TRUE";
+                if (!adv()) return false;
+            } else if (is_singular(kw)) {
                 if (cur.t != Tok::IDENT || is_keyword(cur.s)) return fail(kw + " must be followed by an identifier");
                 std::string &dst = kw == "SPECIFICATION" ? c.specification : kw == "INIT" ? c.init : kw == "NEXT" ? c.next
                                    : kw == "VIEW" ? c.view : c.symmetry;
@@ -441,6 +446,7 @@ int mc_cfg_json(const mc_cfg *c, char *buf, size_t cap) {
     o += ", \"NEXT\": "; json_str(o, c->next);
     o += ", \"VIEW\": "; json_str(o, c->view);
     o += ", \"SYMMETRY\": "; json_str(o, c->symmetry);
+    if (c->check_deadlock >= 0) o += std::string(", \"CHECK_DEADLOCK\": ") + (c->check_deadlock ? "true" : "false");
     o += ", \"INVARIANTS\": "; json_list(o, c->invariants);
     o += ", \"PROPERTIES\": "; json_list(o, c->properties);
     o += ", \"CONSTRAINTS\": "; json_list(o, c->constraints);
@@ -950,6 +956,7 @@ struct Resolved {
     mc_program *prog = nullptr;
     std::string tla, module, def_text, def_module_name;  // def_*: text + name of the module that holds the action definitions
     std::string warning;  // printed at the top of the report (MC_F_UNVERIFIED)
+    int check_deadlock = -1;   // the cfg's CHECK_DEADLOCK statement (-1: none)
     ~Resolved() { if (prog) mc_program_free(prog); }
 };
 }  // namespace
@@ -979,6 +986,7 @@ static int resolve_files(const char *tla_path, const char *cfg_path, unsigned fl
     mc_cfg *c = nullptr;
     int rc = mc_cfg_parse(cfgtext.c_str(), cfgtext.size(), &c);
     if (rc) return rc;
+    R.check_deadlock = c->check_deadlock;
     memset(&d, 0, sizeof d);
     // A PlusCal module goes through the hand lowering when its algorithm text is one the registry knows, and
     // through the compiled program (spec_vm.h) otherwise — or always with MC_F_GENERIC (A/B of the two paths).
@@ -1222,6 +1230,12 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     mc_program *const prog = R.prog;
     const bool generic = prog != nullptr;  // the module went through the PlusCal compiler
     mc_engine *e = nullptr;
+    mc_config with_cfg_statements;
+    if (R.check_deadlock >= 0) {   // the cfg's CHECK_DEADLOCK statement decides over the default (the command line's -deadlock still turns it off)
+        with_cfg_statements = *cfg;
+        if (!R.check_deadlock) with_cfg_statements.flags &= ~MC_F_DEADLOCK;
+        cfg = &with_cfg_statements;
+    }
     if ((rc = mc_engine_create(&d, cfg, &e))) return rc;
     if (recover_path && (rc = mc_engine_restore(e, recover_path))) { mc_engine_destroy(e); return rc; }  // TLC -recover
     if (cfg->flags & MC_F_PROGRESS) {  // testout2:4-259: one line per report, straight to stdout while the search runs

@@ -841,7 +841,12 @@ struct Compiler {
             next_temp -= 2;
             return;
         }
-        if (dom->k == Expr::BINOP && dom->s == "..") {
+        // (an interval with constant bounds and at most four elements is unrolled like a constant set, further down: its bound variable is
+        //  then a constant — no temporaries, and operators called with it take it as a constant too; nested quantifiers over small
+        //  intervals, `\A b1 \in 1..NB : \A b2 \in 1..NB : \A v1 \in 1..NV : ...`, would otherwise exhaust the interpreter's eight)
+        long long clo = 0, chi = -1;
+        const bool small_const_interval = dom->k == Expr::BINOP && dom->s == ".." && const_scalar(dom->a[0], clo) && const_scalar(dom->a[1], chi) && chi - clo < 4;
+        if (dom->k == Expr::BINOP && dom->s == ".." && !small_const_interval) {
             const int tx = new_temp(e->pos), th = new_temp(e->pos);
             ex(dom->a[0]); emit(mc::VM_STORET, tx);
             ex(dom->a[1]); emit(mc::VM_STORET, th);

@@ -1850,10 +1850,11 @@ struct Cfg {
     std::vector<std::pair<std::string, V>> constants;
     std::vector<std::pair<std::string, std::string>> overrides;
     std::map<std::pair<std::string, std::string>, std::string> scoped;
+    int check_deadlock = -1;   // CHECK_DEADLOCK TRUE | FALSE (-1: not given)
 };
 Cfg parse_cfg(const std::string &text) {
     static const std::set<std::string> KW = {"SPECIFICATION", "INIT", "NEXT", "INVARIANT", "INVARIANTS", "CONSTRAINT", "CONSTRAINTS", "CONSTANT", "CONSTANTS",
-        "SYMMETRY", "PROPERTY", "PROPERTIES", "ACTION_CONSTRAINT", "ACTION_CONSTRAINTS", "VIEW"};
+        "SYMMETRY", "PROPERTY", "PROPERTIES", "ACTION_CONSTRAINT", "ACTION_CONSTRAINTS", "VIEW", "CHECK_DEADLOCK"};
     std::vector<Tok> toks = lex(text);
     Cfg out;
     size_t i = 0;
@@ -1880,7 +1881,10 @@ Cfg parse_cfg(const std::string &text) {
     while (toks[i].k != Tok::END) {
         if (!is_kw(i)) throw SyntaxErr{"cfg: expected a statement keyword at line " + std::to_string(toks[i].line) + ", found '" + toks[i].s + "'"};
         const std::string kw = toks[i++].s;
-        if (kw == "SPECIFICATION" || kw == "INIT" || kw == "NEXT" || kw == "SYMMETRY" || kw == "VIEW") {
+        if (kw == "CHECK_DEADLOCK") {   // TLC2's statement: TRUE | FALSE
+            if (toks[i].k != Tok::ID || (toks[i].s != "TRUE" && toks[i].s != "FALSE")) throw SyntaxErr{"cfg: CHECK_DEADLOCK needs TRUE or FALSE at line " + std::to_string(toks[i].line)};
+            out.check_deadlock = toks[i++].s == "TRUE";
+        } else if (kw == "SPECIFICATION" || kw == "INIT" || kw == "NEXT" || kw == "SYMMETRY" || kw == "VIEW") {
             if (toks[i].k != Tok::ID) throw SyntaxErr{"cfg: " + kw + " needs a name at line " + std::to_string(toks[i].line)};
             (kw == "SPECIFICATION" ? out.spec : kw == "INIT" ? out.init : kw == "NEXT" ? out.next : kw == "SYMMETRY" ? out.symmetry : out.view) = toks[i++].s;
         } else if (kw.compare(0, 3, "INV") == 0 || kw.compare(0, 10, "CONSTRAINT") == 0 || kw.compare(0, 4, "PROP") == 0 || kw.compare(0, 6, "ACTION") == 0) {
@@ -2245,7 +2249,7 @@ struct Checker {
                     note(e.is_assert ? MC_V_ASSERT : MC_V_SPECERR, -1, "", si, nullptr);
                     if (err_msg.empty()) err_msg = e.msg;
                 }
-                if (!nsucc && opt.check_deadlock && !sp.first_error) note(MC_V_DEADLOCK, -1, "", si, nullptr);
+                if (!nsucc && opt.check_deadlock && cfg.check_deadlock != 0 && !sp.first_error) note(MC_V_DEADLOCK, -1, "", si, nullptr);
                 done++;
                 // (an error does not stop the level: like the GPU engine — and like the TLC run of README.md:319-321 — the search ends
                 //  when the level the first error was found on has been expanded: counters, queue and depth do not depend on the order
