@@ -88,6 +88,24 @@ def test_compiled_pluscal_program_sharded(shim, tmp_path, world):
     assert sum(r["shares"]) == one["distinct"] and min(r["shares"]) > 0
 
 
+def test_compiled_program_with_a_set_of_records_sharded(shim, tmp_path):
+    """the message soup (a set of records as sorted cells, `with m \\in msgs` by value; spec_vm.h VM_RSADD) and the channels (an array of
+    sequences of records; VM_SEQSEL) through the sharded exchange at world size 2: counts of the 1-rank run, which equal the evaluators'
+    (tests/test_pcal.py)"""
+    import helpers
+    for name, invs, consts in (("two_phase_soup", ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages", "SoupIsSmall"], {"RM": 4, "Hasty": False}),
+                               ("two_phase_channels", ["Consistent", "CommitNeedsAllVotes", "InboxHoldsVotes", "FromTheCoordinator"], {"RM": 3, "Eager": False})):
+        path = ROOT / "specs" / "pluscal" / f"{name}.tla"
+        spec = {"path": str(path), "invariants": invs, "constants": consts}
+        prog = helpers.ShimProgram(path.read_text(), invs, consts)
+        one = helpers.shim_run("pcal", prog.params)
+        prog.close()
+        r = run_dist("shim", 2, "pcal_file", spec, tmp_path, {"chunk": 300, "stay_threshold": 40, "rebalance_ratio": 2.0})
+        assert (r["distinct"], r["generated"], r["depth"], r["levels"], r["verdict"]) == \
+               (one["distinct"], one["generated"], one["depth"], one["levels"], one["verdict"]), name
+        assert sum(r["shares"]) == one["distinct"] and min(r["shares"]) > 0 and one["distinct"] > 4000
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_eight_way_sharding_counts_equal_oracle(oracle, shim, tmp_path, world):
     """the widths the driver's scaling run uses (N = 4, 8): 8 owners, 8 x 8 count exchange, both exchange modes"""
