@@ -523,7 +523,11 @@ struct Compiler {
         size_t k = 0;
         while (k < v.fields.size() && v.fields[k] != f) k++;
         if (k == v.fields.size()) cfail("the record has no field " + f, p);
-        if (!b.ftemps.empty()) { emit(mc::VM_LOADT, b.ftemps[k]); return; }
+        if (!b.ftemps.empty()) {
+            if (b.ftemps[k] < 0) cfail("internal: field " + f + " of a `with` element was not copied", p);
+            emit(mc::VM_LOADT, b.ftemps[k]);
+            return;
+        }
         emit(mc::VM_LOADT, b.temp);
         c.push_back(mc::VM_LOADX); track(mc::VM_LOADX);
         c.push_back(v.base + 1 + (int)k * v.cap); c.push_back(0); c.push_back(v.cap);
@@ -1235,8 +1239,27 @@ struct Compiler {
                 Bind b{s->var, t, false, 0};
                 b.rs = &v;
                 Bind byidx = b;
+                // (only the fields the body reads are copied: a message of five fields of which a step looks at two costs two temporaries)
+                std::set<std::string> used;
+                std::function<void(const EP &)> in_expr = [&](const EP &e) {
+                    if (!e) return;
+                    if (e->k == Expr::DOT && e->a[0]->k == Expr::ID && e->a[0]->s == s->var) used.insert(e->s);
+                    for (const auto &x : e->a) in_expr(x);
+                };
+                std::function<void(const std::vector<SP> &)> in_stmts = [&](const std::vector<SP> &v2) {
+                    for (const auto &x : v2) {
+                        in_expr(x->e);
+                        in_expr(x->idx);
+                        for (const auto &o : x->more) { in_expr(o->e); in_expr(o->idx); }
+                        for (const auto &bl : x->blocks) in_stmts(bl);
+                    }
+                };
+                in_stmts(s->blocks[0]);
+                int taken = 0;
                 for (size_t k = 0; k < v.fields.size(); k++) {
+                    if (!used.count(v.fields[k])) { b.ftemps.push_back(-1); continue; }
                     const int tf = new_temp(s->pos);
+                    taken++;
                     load_field(byidx, v.fields[k], s->pos);
                     emit(mc::VM_STORET, tf);
                     b.ftemps.push_back(tf);
@@ -1244,7 +1267,7 @@ struct Compiler {
                 binds.push_back(b);
                 const unsigned long long nb = block(s->blocks[0]);
                 binds.pop_back();
-                next_temp -= 1 + (int)v.fields.size();
+                next_temp -= 1 + taken;
                 return (unsigned long long)v.cap * nb;
             }
             if (s->with_eq) ex(s->e);
