@@ -34,4 +34,9 @@ for rm in (6, 7):
     out[f"two_phase_soup_rm{rm}"] = dict(RM=rm, seq_cells=rm + 1, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
                                          source="tlaeval.cpp on specs/pluscal/two_phase_soup.tla (msgs one set-valued variable, as pcal2tla keeps it)")
     print("soup", rm, r["distinct"], r["generated"], r["depth"], r["seconds"])
+# epoch-based reclamation with three threads (specs/pluscal/epoch_gc.tla + .cfg): 33 s
+r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "epoch_gc.tla", ROOT / "specs" / "pluscal" / "epoch_gc.cfg", search=[])
+assert r["rc"] == 0 and r["verdict"] == 0, r
+out["epoch_gc_n3"] = dict(N=3, Grace=2, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
+                          source="tlaeval.cpp on specs/pluscal/epoch_gc.tla + epoch_gc.cfg")
 (ROOT / "tests" / "golden" / "pcal_channels.json").write_text(json.dumps(out, indent=1) + "\n")

@@ -143,3 +143,18 @@ def test_paxos_in_pluscal_on_gpu(amd, monkeypatch):  # noqa: F811
     assert "58405 states generated, 15993 distinct states found, 0 states left on queue." in out
     rc, out, err = run_mc(spec, "-config", ROOT / "specs" / "pluscal" / "paxos_soup_forgetful.cfg")
     assert rc == 12 and "Error: Invariant Agreement is violated." in out, err
+
+
+def test_epoch_based_reclamation_on_gpu(amd):  # noqa: F811
+    """specs/pluscal/epoch_gc.tla, three threads: 1 380 120 states = tlaeval.cpp on module + cfg (tests/golden/pcal_channels.json); `mc` with one
+    epoch of grace: NoDanglingReader is violated (a 14-state behaviour)"""
+    g = GOLDEN["epoch_gc_n3"]
+    invs = ["HeadIsLive", "NoDanglingReader", "EpochInRange"]
+    prog = amd.Program((ROOT / "specs" / "pluscal" / "epoch_gc.tla").read_text(), cfg_text(invs, {"N": 3, "Grace": 2}))
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 24, arena_capacity=1 << 21, chunk_states=1 << 16)
+    r = eng.run()
+    assert (r.distinct, r.generated, r.depth, r.verdict, list(r.levels)) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
+    eng.close()
+    prog.close()
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "epoch_gc.tla", "-config", ROOT / "specs" / "pluscal" / "epoch_gc_one_grace.cfg")
+    assert rc == 12 and "Error: Invariant NoDanglingReader is violated." in out and "State 14:" in out, err

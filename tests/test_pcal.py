@@ -81,6 +81,10 @@ CASES = [
     # a procedure with a RECORD PARAMETER (call deposit(mine), call deposit([who |-> self, amount |-> 2])) and `with old = biggest` (a record bound field by field)
     (SPECS / "pluscal" / "record_args.tla", ["Sane"], {"N": 2}),
     (SPECS / "pluscal" / "record_args.tla", ["Sane"], {"N": 3}),
+    # epoch-based reclamation (the lock-free epoch-based GC of the roadmap): pin / read / exchange / retire / advance / free; one epoch of grace instead
+    # of two frees a node a pinned reader still holds
+    (SPECS / "pluscal" / "epoch_gc.tla", ["HeadIsLive", "NoDanglingReader", "EpochInRange"], {"N": 2, "Grace": 2}),
+    (SPECS / "pluscal" / "epoch_gc.tla", ["HeadIsLive", "NoDanglingReader", "EpochInRange"], {"N": 2, "Grace": 1}),
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -93,7 +97,7 @@ CASES = [
 ]
 
 
-CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args"}   # their GPU cases: tests/test_gpu_zz_channels.py
+CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args", "epoch_gc"}   # their GPU cases: tests/test_gpu_zz_channels.py
 
 
 def strip_translation(text):
@@ -1027,3 +1031,25 @@ def test_paxos_in_pluscal_over_a_message_soup():
         small.close()
         full.close()
         bad.close()
+
+
+def test_epoch_based_reclamation_three_threads():
+    """specs/pluscal/epoch_gc.tla with three threads: 1 380 120 states / 3 557 242 generated / depth 46, no reader ever holds a freed node — the
+    compiled program on the host VM against the product's host evaluator tlaeval.cpp on module + cfg (tests/golden/pcal_channels.json; the
+    two-thread model is compared with oracle/tla_eval.py state by state above); with one epoch of grace NoDanglingReader fails at depth 14"""
+    g = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())["epoch_gc_n3"]
+    invs = ["HeadIsLive", "NoDanglingReader", "EpochInRange"]
+    text = (SPECS / "pluscal" / "epoch_gc.tla").read_text()
+    prog = helpers.ShimProgram(text, invs, {"N": 3, "Grace": 2})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
+    assert r["distinct"] == 1380120
+    prog = helpers.ShimProgram(text, invs, {"N": 3, "Grace": 1})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["verdict"], invs[r["violated_invariant"]], r["trace_len"]) == ("invariant", "NoDanglingReader", 14)
