@@ -39,4 +39,9 @@ r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "epoch_gc.tla", ROOT / "spe
 assert r["rc"] == 0 and r["verdict"] == 0, r
 out["epoch_gc_n3"] = dict(N=3, Grace=2, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
                           source="tlaeval.cpp on specs/pluscal/epoch_gc.tla + epoch_gc.cfg")
+# the lock-free IO buffer with four writers (specs/pluscal/io_buffer.tla + .cfg): 12 s
+r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "io_buffer.tla", ROOT / "specs" / "pluscal" / "io_buffer.cfg", search=[])
+assert r["rc"] == 0 and r["verdict"] == 0, r
+out["io_buffer_n4"] = dict(N=4, Cap=2, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
+                           source="tlaeval.cpp on specs/pluscal/io_buffer.tla + io_buffer.cfg")
 (ROOT / "tests" / "golden" / "pcal_channels.json").write_text(json.dumps(out, indent=1) + "\n")

@@ -158,3 +158,18 @@ def test_epoch_based_reclamation_on_gpu(amd):  # noqa: F811
     prog.close()
     rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "epoch_gc.tla", "-config", ROOT / "specs" / "pluscal" / "epoch_gc_one_grace.cfg")
     assert rc == 12 and "Error: Invariant NoDanglingReader is violated." in out and "State 14:" in out, err
+
+
+def test_io_buffer_on_gpu(amd):  # noqa: F811
+    """specs/pluscal/io_buffer.tla, four writers, two slots: 539 320 states = tlaeval.cpp on module + cfg; `mc` on the hasty flusher: the assert
+    in Copy fails"""
+    g = GOLDEN["io_buffer_n4"]
+    invs = ["HeaderInRange", "SealedIsFull", "FlushedFull"]
+    prog = amd.Program((ROOT / "specs" / "pluscal" / "io_buffer.tla").read_text(), cfg_text(invs, {"N": 4, "Cap": 2, "Patient": True}))
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 23, arena_capacity=1 << 20, chunk_states=1 << 15)
+    r = eng.run()
+    assert (r.distinct, r.generated, r.depth, r.verdict, list(r.levels)) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
+    eng.close()
+    prog.close()
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "io_buffer.tla", "-config", ROOT / "specs" / "pluscal" / "io_buffer_hasty.cfg")
+    assert rc == 12 and "The first argument of Assert evaluated to FALSE" in out, err

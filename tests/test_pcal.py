@@ -85,6 +85,11 @@ CASES = [
     # of two frees a node a pinned reader still holds
     (SPECS / "pluscal" / "epoch_gc.tla", ["HeadIsLive", "NoDanglingReader", "EpochInRange"], {"N": 2, "Grace": 2}),
     (SPECS / "pluscal" / "epoch_gc.tla", ["HeadIsLive", "NoDanglingReader", "EpochInRange"], {"N": 2, "Grace": 1}),
+    # the roadmap's lock-free IO buffer: reserve / seal with one CAS on a header RECORD, release, the last writer out flushes; flushing a sealed buffer
+    # while a writer still copies (Patient = FALSE) lets its bytes land after the flush (assert)
+    (SPECS / "pluscal" / "io_buffer.tla", ["HeaderInRange", "SealedIsFull", "FlushedFull"], {"N": 2, "Cap": 1, "Patient": True}),
+    (SPECS / "pluscal" / "io_buffer.tla", ["HeaderInRange", "SealedIsFull", "FlushedFull"], {"N": 3, "Cap": 2, "Patient": True}),
+    (SPECS / "pluscal" / "io_buffer.tla", ["HeaderInRange", "SealedIsFull", "FlushedFull"], {"N": 3, "Cap": 2, "Patient": False}),
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -97,7 +102,7 @@ CASES = [
 ]
 
 
-CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args", "epoch_gc"}   # their GPU cases: tests/test_gpu_zz_channels.py
+CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args", "epoch_gc", "io_buffer"}   # their GPU cases: tests/test_gpu_zz_channels.py
 
 
 def strip_translation(text):
@@ -1053,3 +1058,16 @@ def test_epoch_based_reclamation_three_threads():
     finally:
         prog.close()
     assert (r["verdict"], invs[r["violated_invariant"]], r["trace_len"]) == ("invariant", "NoDanglingReader", 14)
+
+
+def test_io_buffer_four_writers():
+    """specs/pluscal/io_buffer.tla with four writers and two slots: 539 320 states / 1 776 249 generated / depth 32 — the compiled program on the
+    host VM against tlaeval.cpp on module + cfg (tests/golden/pcal_channels.json); the smaller models are compared with oracle/tla_eval.py
+    state by state above"""
+    g = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())["io_buffer_n4"]
+    prog = helpers.ShimProgram((SPECS / "pluscal" / "io_buffer.tla").read_text(), ["HeaderInRange", "SealedIsFull", "FlushedFull"], {"N": 4, "Cap": 2, "Patient": True})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"]) and r["distinct"] == 539320
