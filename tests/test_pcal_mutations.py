@@ -58,3 +58,53 @@ def test_damaged_algorithms_are_refused_not_crashed_on(seed):
     assert p.returncode == 0 and last.startswith("done"), f"seed {seed}: the front-end died on mutation {last} (rc {p.returncode}): {p.stderr[-400:]}"
     ok, refused = map(int, last.split()[1:])
     assert refused > 40 and ok + refused == 120
+
+
+CFG_CHILD = r'''
+import glob, random, re, sys
+sys.path.insert(0, sys.argv[1])
+import tla_rust_amd as amd
+cfgs = sorted(glob.glob(sys.argv[1] + "/specs/**/*.cfg", recursive=True)) + sorted(glob.glob("/root/reference/examples/**/*.cfg", recursive=True))
+r = random.Random(int(sys.argv[2]))
+ok = refused = 0
+for it in range(int(sys.argv[3])):
+    path = r.choice(cfgs)
+    toks = re.findall(r"\s+|\w+|[^\w\s]", open(path).read())
+    for _ in range(r.randrange(1, 4)):
+        i = r.randrange(len(toks))
+        k = r.randrange(4)
+        if k == 0:
+            del toks[i]
+        elif k == 1:
+            toks.insert(i, r.choice(toks))
+        elif k == 2:
+            toks[i] = r.choice(["=", "{", "}", "<-", "[", "]", "CONSTANT", "INVARIANT", "SPECIFICATION", "CHECK_DEADLOCK", "x", "3", ",", '"', "(*", "\\*", "-"])
+        else:
+            j = r.randrange(len(toks))
+            toks[i], toks[j] = toks[j], toks[i]
+    text = "".join(toks)
+    print(it, flush=True)
+    try:
+        amd.cfg_parse(text)
+        ok += 1
+        for module in ("raft", "MCraft", "pcal_intro", "atomic_add", "MCssi", "MCPaxos"):
+            try:
+                amd.spec_resolve(module, text)
+            except amd.McError as ex:
+                assert str(ex).strip()
+    except amd.McError as ex:
+        assert str(ex).strip()
+        refused += 1
+print("done", ok, refused)
+'''
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_damaged_configuration_files_are_refused_not_crashed_on(seed):
+    """the cfg parser and the spec registry (frontend.cpp: mc_cfg_parse, mc_spec_resolve) on token-level mutations of every cfg of specs/ and
+    of the reference tree: a message or a result, never a crash"""
+    p = subprocess.run([sys.executable, "-c", CFG_CHILD, str(ROOT), str(seed), "300"], capture_output=True, text=True, timeout=600)
+    last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
+    assert p.returncode == 0 and last.startswith("done"), f"seed {seed}: the cfg front-end died on mutation {last} (rc {p.returncode}): {p.stderr[-400:]}"
+    ok, refused = map(int, last.split()[1:])
+    assert refused > 30 and ok > 30
