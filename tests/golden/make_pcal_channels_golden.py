@@ -44,4 +44,11 @@ r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "io_buffer.tla", ROOT / "sp
 assert r["rc"] == 0 and r["verdict"] == 0, r
 out["io_buffer_n4"] = dict(N=4, Cap=2, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
                            source="tlaeval.cpp on specs/pluscal/io_buffer.tla + io_buffer.cfg")
+# the radix tree with four inserters (specs/pluscal/radix_tree.tla, N = 4): about 100 s
+with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
+    f.write("SPECIFICATION Spec\nCONSTANT N = 4\nCONSTANT Plain = FALSE\nINVARIANT InsertedKeysAreFound NoLeak ChildrenAreNodes\n")
+r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "radix_tree.tla", f.name, search=[])
+assert r["rc"] == 0 and r["verdict"] == 0, r
+out["radix_tree_n4"] = dict(N=4, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
+                            source="tlaeval.cpp on specs/pluscal/radix_tree.tla, N = 4, Plain = FALSE")
 (ROOT / "tests" / "golden" / "pcal_channels.json").write_text(json.dumps(out, indent=1) + "\n")

@@ -173,3 +173,18 @@ def test_io_buffer_on_gpu(amd):  # noqa: F811
     prog.close()
     rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "io_buffer.tla", "-config", ROOT / "specs" / "pluscal" / "io_buffer_hasty.cfg")
     assert rc == 12 and "The first argument of Assert evaluated to FALSE" in out, err
+
+
+def test_radix_tree_on_gpu(amd):  # noqa: F811
+    """specs/pluscal/radix_tree.tla, four inserters: 3 411 041 states = tlaeval.cpp (tests/golden/pcal_channels.json); `mc` on the plain-store
+    variant: an inserted key is not found"""
+    g = GOLDEN["radix_tree_n4"]
+    invs = ["InsertedKeysAreFound", "NoLeak", "ChildrenAreNodes"]
+    prog = amd.Program((ROOT / "specs" / "pluscal" / "radix_tree.tla").read_text(), cfg_text(invs, {"N": 4, "Plain": False}))
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 25, arena_capacity=1 << 22, chunk_states=1 << 17)
+    r = eng.run()
+    assert (r.distinct, r.generated, r.depth, r.verdict, list(r.levels)) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
+    eng.close()
+    prog.close()
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "radix_tree.tla", "-config", ROOT / "specs" / "pluscal" / "radix_tree_plain.cfg")
+    assert rc == 12 and "Error: Invariant InsertedKeysAreFound is violated." in out, err

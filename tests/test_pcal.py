@@ -90,6 +90,9 @@ CASES = [
     (SPECS / "pluscal" / "io_buffer.tla", ["HeaderInRange", "SealedIsFull", "FlushedFull"], {"N": 2, "Cap": 1, "Patient": True}),
     (SPECS / "pluscal" / "io_buffer.tla", ["HeaderInRange", "SealedIsFull", "FlushedFull"], {"N": 3, "Cap": 2, "Patient": True}),
     (SPECS / "pluscal" / "io_buffer.tla", ["HeaderInRange", "SealedIsFull", "FlushedFull"], {"N": 3, "Cap": 2, "Patient": False}),
+    # the roadmap's lock-free radix tree: a missing child is installed by CAS, the loser frees its node; with a plain store a subtree is unlinked
+    (SPECS / "pluscal" / "radix_tree.tla", ["InsertedKeysAreFound", "NoLeak", "ChildrenAreNodes"], {"N": 2, "Plain": False}),
+    (SPECS / "pluscal" / "radix_tree.tla", ["InsertedKeysAreFound", "ChildrenAreNodes"], {"N": 2, "Plain": True}),
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -102,7 +105,7 @@ CASES = [
 ]
 
 
-CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args", "epoch_gc", "io_buffer"}   # their GPU cases: tests/test_gpu_zz_channels.py
+CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args", "epoch_gc", "io_buffer", "radix_tree"}   # their GPU cases: tests/test_gpu_zz_channels.py
 
 
 def strip_translation(text):
@@ -1071,3 +1074,33 @@ def test_io_buffer_four_writers():
     finally:
         prog.close()
     assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"]) and r["distinct"] == 539320
+
+
+def test_radix_tree_three_and_four_inserters():
+    """specs/pluscal/radix_tree.tla: three inserters 50 361 states, four 3 411 041 states / 12 822 241 generated / depth 17 (the compiled program on
+    the host VM against tlaeval.cpp, tests/golden/pcal_channels.json; four under $TLAMC_SLOW: 8 s of host VM after 100 s of evaluator when the
+    golden was made); with a plain store instead of the CAS an inserted key is not found (a 14-state behaviour with three inserters)"""
+    invs = ["InsertedKeysAreFound", "NoLeak", "ChildrenAreNodes"]
+    text = (SPECS / "pluscal" / "radix_tree.tla").read_text()
+    e = helpers.tlaeval_run(SPECS / "pluscal" / "radix_tree.tla", SPECS / "pluscal" / "radix_tree.cfg", search=[])
+    prog = helpers.ShimProgram(text, invs, {"N": 3, "Plain": False})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["distinct"], r["generated"], r["depth"], r["verdict"]) == (50361, 139105, 14, "ok")
+    assert (e["distinct"], e["generated"], e["depth"], e["verdict"], e["levels"]) == (r["distinct"], r["generated"], r["depth"], 0, r["levels"])
+    prog = helpers.ShimProgram(text, ["InsertedKeysAreFound", "ChildrenAreNodes"], {"N": 3, "Plain": True})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["verdict"], r["violated_invariant"], r["trace_len"]) == ("invariant", 0, 14)
+    if os.environ.get("TLAMC_SLOW"):
+        g = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())["radix_tree_n4"]
+        prog = helpers.ShimProgram(text, invs, {"N": 4, "Plain": False})
+        try:
+            r = helpers.shim_run("pcal", prog.params)
+        finally:
+            prog.close()
+        assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
