@@ -51,4 +51,9 @@ r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "radix_tree.tla", f.name, s
 assert r["rc"] == 0 and r["verdict"] == 0, r
 out["radix_tree_n4"] = dict(N=4, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
                             source="tlaeval.cpp on specs/pluscal/radix_tree.tla, N = 4, Plain = FALSE")
+# the pagecache entry with three threads (specs/pluscal/pagecache.tla + .cfg): 20 M states, several minutes and a few GB
+r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "pagecache.tla", ROOT / "specs" / "pluscal" / "pagecache.cfg", search=[])
+assert r["rc"] == 0 and r["verdict"] == 0, r
+out["pagecache_n3"] = dict(N=3, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
+                           source="tlaeval.cpp on specs/pluscal/pagecache.tla + pagecache.cfg")
 (ROOT / "tests" / "golden" / "pcal_channels.json").write_text(json.dumps(out, indent=1) + "\n")

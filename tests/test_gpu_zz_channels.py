@@ -188,3 +188,18 @@ def test_radix_tree_on_gpu(amd):  # noqa: F811
     prog.close()
     rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "radix_tree.tla", "-config", ROOT / "specs" / "pluscal" / "radix_tree_plain.cfg")
     assert rc == 12 and "Error: Invariant InsertedKeysAreFound is violated." in out, err
+
+
+def test_pagecache_on_gpu(amd):  # noqa: F811
+    """specs/pluscal/pagecache.tla, three threads: 20 254 597 states / 47 629 297 generated / depth 37 (tests/golden/pcal_channels.json); `mc` on
+    the blind consolidation: Conservation is violated after 14 states"""
+    g = GOLDEN["pagecache_n3"]
+    invs = ["Conservation", "HeadIsAllocated"]
+    prog = amd.Program((ROOT / "specs" / "pluscal" / "pagecache.tla").read_text(), cfg_text(invs, {"N": 3, "Blind": False}))
+    eng = amd.Engine("pcal", prog.params, table_capacity=1 << 27, arena_capacity=22 << 20, chunk_states=1 << 20, trace=False)
+    r = eng.run()
+    assert (r.distinct, r.generated, r.depth, r.verdict, list(r.levels)) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
+    eng.close()
+    prog.close()
+    rc, out, err = run_mc(ROOT / "specs" / "pluscal" / "pagecache.tla", "-config", ROOT / "specs" / "pluscal" / "pagecache_blind.cfg")
+    assert rc == 12 and "Error: Invariant Conservation is violated." in out and "State 14:" in out, err

@@ -93,6 +93,10 @@ CASES = [
     # the roadmap's lock-free radix tree: a missing child is installed by CAS, the loser frees its node; with a plain store a subtree is unlinked
     (SPECS / "pluscal" / "radix_tree.tla", ["InsertedKeysAreFound", "NoLeak", "ChildrenAreNodes"], {"N": 2, "Plain": False}),
     (SPECS / "pluscal" / "radix_tree.tla", ["InsertedKeysAreFound", "ChildrenAreNodes"], {"N": 2, "Plain": True}),
+    # the roadmap's lock-free pagecache: deltas linked onto a page's chain by CAS, a consolidation installed by CAS from the head it read; installed
+    # blindly it loses the deltas linked meanwhile
+    (SPECS / "pluscal" / "pagecache.tla", ["Conservation", "HeadIsAllocated"], {"N": 2, "Blind": False}),
+    (SPECS / "pluscal" / "pagecache.tla", ["Conservation", "HeadIsAllocated"], {"N": 2, "Blind": True}),
     # the reference's own PlusCal example: FastMutex, examples/p-manual.pdf Figure 2 p.13 (translation walked through in App. B)
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 2}),
     (SPECS / "pluscal" / "fast_mutex.tla", ["MutualExclusion"], {"N": 3}),
@@ -105,7 +109,7 @@ CASES = [
 ]
 
 
-CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args", "epoch_gc", "io_buffer", "radix_tree"}   # their GPU cases: tests/test_gpu_zz_channels.py
+CHANNEL_STEMS = {"two_phase_channels", "mailboxes", "two_phase_soup", "record_args", "epoch_gc", "io_buffer", "radix_tree", "pagecache"}   # their GPU cases: tests/test_gpu_zz_channels.py
 
 
 def strip_translation(text):
@@ -1099,6 +1103,28 @@ def test_radix_tree_three_and_four_inserters():
     if os.environ.get("TLAMC_SLOW"):
         g = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())["radix_tree_n4"]
         prog = helpers.ShimProgram(text, invs, {"N": 4, "Plain": False})
+        try:
+            r = helpers.shim_run("pcal", prog.params)
+        finally:
+            prog.close()
+        assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
+
+
+def test_pagecache_three_threads():
+    """specs/pluscal/pagecache.tla with three threads: the blind consolidation loses a delta after 14 states (342 457 states explored); the correct
+    one has 20 254 597 states / 47 629 297 generated / depth 37 (tests/golden/pcal_channels.json: tlaeval.cpp on module + cfg) — 47 s of host
+    VM, under $TLAMC_SLOW here, always on the GPU (tests/test_gpu_zz_channels.py)"""
+    invs = ["Conservation", "HeadIsAllocated"]
+    text = (SPECS / "pluscal" / "pagecache.tla").read_text()
+    prog = helpers.ShimProgram(text, invs, {"N": 3, "Blind": True})
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    assert (r["verdict"], invs[r["violated_invariant"]], r["trace_len"], r["distinct"]) == ("invariant", "Conservation", 14, 342457)
+    if os.environ.get("TLAMC_SLOW"):
+        g = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())["pagecache_n3"]
+        prog = helpers.ShimProgram(text, invs, {"N": 3, "Blind": False})
         try:
             r = helpers.shim_run("pcal", prog.params)
         finally:
