@@ -1,7 +1,9 @@
 """tests/golden/pcal_channels.json: two-phase commit over channels with 4 and 5 resource managers — per-level counts of the HAND-WRITTEN
 pcal2tla-style translation tests/golden/pcal_records/TwoPhaseChannels.tla (chan one function to sequences of records), evaluated by the
 product's host evaluator tla_rust_amd/csrc/tlaeval.cpp (through its test door).  The compiled program (one sequence per field, host VM
-and GPU) must reproduce them: another text, another engine.  RM = 5 takes the evaluator a few minutes.
+and GPU) must reproduce them: another text, another engine.  RM = 5 takes the evaluator a few minutes.  Further down: the message soup (RM = 6, 7),
+epoch-based reclamation (N = 3), the IO buffer (N = 4), the radix tree (N = 4) and the pagecache entry (N = 3: 20 M states, 10 minutes, ~25 GB) —
+for those the evaluator reads the module file of specs/pluscal/ with its cfg.
 
     python tests/golden/make_pcal_channels_golden.py"""
 import json
