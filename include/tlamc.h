@@ -437,7 +437,7 @@ int mc_shard_info(mc_engine *e, void **main_stream_out, uint64_t *chunk_states_o
  * The reference's workflow is `pcal2tla *tla` then `tlc *tla` (Makefile:3-7).  mc_pcal_translate is the first
  * half: it returns the module text with the TLA+ translation of its `--algorithm` inserted (p-manual.pdf App. B).
  * mc_program_compile is what lets the checker run a PlusCal spec nobody hand-lowered: the algorithm (p- or c-syntax;
- * labels, := , if/elsif/else, while, either/or, with, await/when, assert, skip, goto, define, macros; integers, booleans, strings,
+ * labels, := , if/elsif/else, while, either/or, with, await/when, assert, skip, goto, define, macros, LET; integers, booleans, strings,
  * functions over constant sets, bounded sequences and arrays of them, sets of small naturals; procedures incl. recursion, records incl. nested
  * ones, sequences and sets of records: DESIGN.md section 9) becomes a bytecode program every GPU lane interprets on its own packed state
  * (tla_rust_amd/csrc/spec_vm.h).  Two bounds come from the environment at compile time: $TLAMC_PCAL_SEQ, the element cells per sequence /

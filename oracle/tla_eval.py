@@ -218,17 +218,65 @@ class Parser:
                         continue
                     break
                 return ("case", arms, other)
-            if c.s == "LET":
+            if c.s == "LET":   # LET a == e  f(x, y) == g  ... IN body
                 self.i += 1
-                name = self.ident()
-                self.expect("==")
-                val = self.expr(0)
+                defs = []
+                while True:
+                    name = self.ident()
+                    params = []
+                    if self.is_sym("("):
+                        self.i += 1
+                        while True:
+                            params.append(self.ident())
+                            if self.is_sym(","):
+                                self.i += 1
+                                continue
+                            break
+                        self.expect(")")
+                    self.expect("==")
+                    defs.append((name, params, self.expr(0)))
+                    if self.cur().k == "id" and self.cur().s == "IN":
+                        break
                 self.expect("IN")
-                return ("let", name, val, self.expr(0))
+                body = self.expr(0)
+                # a definition without parameters is a binding evaluated where the LET stands; one with parameters is substituted into
+                # the definitions after it and into the body, at parse time (its body sees the earlier bindings of this LET)
+                for k in range(len(defs) - 1, -1, -1):
+                    name, params, val = defs[k]
+                    if params:
+                        rest = [(n, ps, self._subst_call(v, name, params, val)) for n, ps, v in defs[k + 1:]]
+                        defs[k + 1:] = rest
+                        body = self._subst_call(body, name, params, val)
+                for name, params, val in reversed(defs):
+                    if not params:
+                        body = ("let", name, val, body)
+                return body
             if c.s == "UNCHANGED":
                 self.i += 1
                 return ("unchanged", self.expr(14))
         return self.postfix(self.atom())
+
+    @classmethod
+    def _subst_ids(cls, e, m):
+        if isinstance(e, tuple):
+            if len(e) == 2 and e[0] == "id" and e[1] in m:
+                return m[e[1]]
+            return tuple(cls._subst_ids(x, m) for x in e)
+        if isinstance(e, list):
+            return [cls._subst_ids(x, m) for x in e]
+        return e
+
+    @classmethod
+    def _subst_call(cls, e, name, params, body):
+        """every call name(args) inside e replaced by body with params := args"""
+        if isinstance(e, tuple):
+            if len(e) == 3 and e[0] == "call" and e[1] == name and len(e[2]) == len(params):
+                args = [cls._subst_call(a, name, params, body) for a in e[2]]
+                return cls._subst_ids(body, dict(zip(params, args)))
+            return tuple(cls._subst_call(x, name, params, body) for x in e)
+        if isinstance(e, list):
+            return [cls._subst_call(x, name, params, body) for x in e]
+        return e
 
     def ident(self):
         c = self.cur()

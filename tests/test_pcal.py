@@ -1130,3 +1130,37 @@ def test_pagecache_three_threads():
         finally:
             prog.close()
         assert (r["distinct"], r["generated"], r["depth"], r["verdict"], r["levels"]) == (g["distinct"], g["generated"], g["depth"], "ok", g["levels"])
+
+
+def test_let_in_expressions_and_definitions(tmp_path):
+    """`LET a == e  f(x) == g ... IN body` in the algorithm's expressions and in the definitions around it: the front-end substitutes it
+    where it is parsed (a definition sees the earlier ones; an unused or guarded one is never evaluated: Head(q) under `IF q = <<>>`); the
+    evaluators read the LET as written — same graph, state by state, and a third opinion from tlaeval.cpp"""
+    text = """---- MODULE lett ----
+EXTENDS Naturals, Sequences
+CONSTANTS N
+(* --algorithm lett
+variables q = <<>>, x = 0, hi = 0;
+process P \\in 1..N
+begin
+  A: x := LET d == x + self
+              twice(n) == n + n
+              t == twice(d)
+          IN  IF t > 6 THEN d ELSE t;
+  B: q := Append(q, LET m == x % 3 IN m + 1);
+  C: hi := LET best == IF q = <<>> THEN 0 ELSE Head(q) IN IF best > hi THEN best ELSE hi;
+end process
+end algorithm *)
+Bounded == LET top == 3
+               sm(k) == IF k <= Len(q) THEN q[k] ELSE 0
+           IN  hi <= top /\\ sm(1) <= top /\\ sm(2) <= top /\\ (\\A k \\in 1..Len(q) : LET v == q[k] IN v >= 1)
+====
+""".replace("\\\\", "\\")
+    r = _vm_equals_evaluator(text, ["Bounded"], {"N": 2})
+    assert (r["distinct"], r["generated"], r["verdict"]) == (37, 55, "ok")
+    tr = helpers.pcal_translate(text)
+    assert "x' = (IF ((x + self) + (x + self)) > 6 THEN (x + self) ELSE ((x + self) + (x + self)))" in tr
+    (tmp_path / "lett.tla").write_text(tr)
+    (tmp_path / "lett.cfg").write_text("SPECIFICATION Spec\nCONSTANT N = 2\nINVARIANT Bounded\n")
+    e = helpers.tlaeval_run(tmp_path / "lett.tla", tmp_path / "lett.cfg", search=[])
+    assert (e["distinct"], e["generated"], e["verdict"], e["levels"]) == (r["distinct"], r["generated"], 0, r["levels"])

@@ -171,6 +171,36 @@ struct Parser {
         e->pos = {at.line, at.col};
         return e;
     }
+    struct LetDef { std::string name; std::vector<std::string> params; EP body; };
+    // e with the LET definitions substituted: a name without parameters by its body, f(args) by f's body with the parameters replaced;
+    // `hidden` = names re-bound by a quantifier / function constructor on the way down
+    static EP let_subst(const EP &e, const std::vector<LetDef> &defs, std::set<std::string> hidden) {
+        if (!e) return e;
+        if (e->k == Expr::ID && !hidden.count(e->s))
+            for (size_t k = defs.size(); k-- > 0;)
+                if (defs[k].name == e->s && defs[k].params.empty()) return defs[k].body;
+        if (e->k == Expr::CALL && !hidden.count(e->s))
+            for (size_t k = defs.size(); k-- > 0;)
+                if (defs[k].name == e->s && defs[k].params.size() == e->a.size() && !defs[k].params.empty()) {
+                    std::vector<LetDef> args;
+                    for (size_t j = 0; j < e->a.size(); j++) {
+                        EP a = let_subst(e->a[j], defs, hidden);
+                        a = std::make_shared<Expr>(*a);
+                        a->paren = true;
+                        args.push_back({defs[k].params[j], {}, a});
+                    }
+                    return let_subst(defs[k].body, args, {});
+                }
+        auto c = std::make_shared<Expr>(*e);
+        if ((e->k == Expr::QUANT || e->k == Expr::FUNCDEF) && !e->bound.empty()) {
+            if (!c->a.empty()) c->a[0] = let_subst(e->a[0], defs, hidden);   // the domain is outside the binding
+            hidden.insert(e->bound);
+            for (size_t j = 1; j < c->a.size(); j++) c->a[j] = let_subst(e->a[j], defs, hidden);
+            return c;
+        }
+        for (auto &x : c->a) x = let_subst(x, defs, hidden);
+        return c;
+    }
     EP primary() {
         const Tok k = cur();
         if (k.t == Tok::NUM) { i++; auto e = mk(Expr::NUM, k); e->num = atoll(k.s.c_str()); return e; }
@@ -186,6 +216,35 @@ struct Parser {
                 expect_id("ELSE");
                 e->a.push_back(expr(0));
                 return e;
+            }
+            if (k.s == "LET") {   // LET a == e  f(x, y) == g ... IN body: substituted where it is parsed (a definition sees the earlier ones;
+                i++;              //  like TLC's, an unused or guarded definition is never evaluated); the translation prints the result
+                std::vector<LetDef> defs;
+                for (;;) {
+                    LetDef d;
+                    d.name = ident("a name after LET");
+                    if (is_sym("(")) {
+                        i++;
+                        for (;;) {
+                            d.params.push_back(ident("a parameter name"));
+                            if (is_sym(",")) { i++; continue; }
+                            break;
+                        }
+                        expect_sym(")");
+                    }
+                    expect_sym("==");
+                    d.body = let_subst(expr(0), defs, {});
+                    d.body = std::make_shared<Expr>(*d.body);
+                    d.body->paren = true;
+                    defs.push_back(d);
+                    if (cur().t == Tok::IDENT && cur().s == "IN") break;
+                    if (cur().t != Tok::IDENT) fail("expected another definition or IN");
+                }
+                expect_id("IN");
+                EP body = let_subst(expr(0), defs, {});
+                body = std::make_shared<Expr>(*body);
+                body->paren = true;
+                return body;
             }
             if (k.s == "CHOOSE") {  // bounded CHOOSE x \in S : P (examples/p-manual.pdf section 2.4: the definition of gcd)
                 i++;
