@@ -34,7 +34,7 @@ class Tok:
         return f"{self.k}:{self.s}@{self.line}:{self.col}"
 
 
-SYMS = ["|->", "<>", "[]", ":=", "||", "==", "=>", "<=", ">=", "=<", "/=", "/\\", "\\/", "..", "->", "<<", ">>", ":>", "@@",
+SYMS = ["|->", "<=>", "<>", "[]", ":=", "||", "==", "=>", "<=", ">=", "=<", "/=", "/\\", "\\/", "..", "->", "<<", ">>", ":>", "@@",
         "(", ")", "[", "]", "{", "}", ",", ";", ":", "+", "-", "*", "%", "=", "<", ">", "#", "~", "'", "!", "@", ".", "^", "_", "\\"]
 
 
@@ -105,10 +105,10 @@ def lex(text):
 
 
 # ------------------------------------------------------------------------------------------------ parser
-PREC = {"=>": 1, "\\/": 3, "/\\": 3, "=": 5, "#": 5, "/=": 5, "<": 5, ">": 5, "<=": 5, "=<": 5, ">=": 5, "\\leq": 5, "\\geq": 5,
+PREC = {"=>": 1, "<=>": 1, "\\equiv": 1, "\\/": 3, "/\\": 3, "=": 5, "#": 5, "/=": 5, "<": 5, ">": 5, "<=": 5, "=<": 5, ">=": 5, "\\leq": 5, "\\geq": 5,
         "\\in": 5, "\\notin": 5, "\\subseteq": 5, "\\cup": 8, "\\union": 8, "\\cap": 8, "\\intersect": 8, "\\": 8, "..": 9,
         "+": 10, "-": 10, "%": 11, "*": 13, "\\div": 13, "\\o": 13, ":>": 7, "@@": 6}
-CANON = {"=<": "<=", "\\leq": "<=", "\\geq": ">=", "/=": "#", "\\union": "\\cup", "\\intersect": "\\cap"}
+CANON = {"\\equiv": "<=>", "=<": "<=", "\\leq": "<=", "\\geq": ">=", "/=": "#", "\\union": "\\cup", "\\intersect": "\\cap"}
 
 
 class Parser:
@@ -187,6 +187,9 @@ class Parser:
                 self.i += 1
                 return ("temporal", self.expr(4))
         if c.k == "id":
+            if c.s == "DOMAIN":
+                self.i += 1
+                return ("domain", self.postfix(self.atom()))
             if c.s == "CHOOSE":
                 self.i += 1
                 var = self.ident()
@@ -313,6 +316,18 @@ class Parser:
                 items = []
                 if not self.is_sym("}"):
                     items.append(self.expr(0))
+                    if self.is_sym(":"):   # {x \\in S : P}   {e : x \\in S}
+                        self.i += 1
+                        first = items[0]
+                        if first[0] == "op" and first[1] == "\\in" and first[2][0] == "id":
+                            pred = self.expr(0)
+                            self.expect("}")
+                            return ("setfilter", first[2][1], first[3], pred)
+                        var = self.ident()
+                        self.expect("\\in")
+                        dom = self.expr(6)
+                        self.expect("}")
+                        return ("setmap", var, dom, first)
                     while self.is_sym(","):
                         self.i += 1
                         items.append(self.expr(0))
@@ -566,7 +581,13 @@ class Checker:
                 return self.ev(e[2], st, nx, bd) or self.ev(e[3], st, nx, bd)
             if o == "=>":
                 return (not self.ev(e[2], st, nx, bd)) or self.ev(e[3], st, nx, bd)
+            if o in ("\\in", "\\notin") and e[3] in (("id", "Nat"), ("id", "Int")):    # TypeOK conjuncts: x \\in Nat
+                a = self.ev(e[2], st, nx, bd)
+                yes = isinstance(a, int) and not isinstance(a, bool) and (a >= 0 or e[3][1] == "Int")
+                return yes if o == "\\in" else not yes
             a, b = self.ev(e[2], st, nx, bd), self.ev(e[3], st, nx, bd)
+            if o == "<=>":
+                return bool(a) == bool(b)
             if o == "=":
                 return a == b
             if o == "#":
@@ -644,6 +665,13 @@ class Checker:
             return all(gen) if e[1] == "A" else any(gen)
         if k == "setenum":
             return frozenset(self.ev(x, st, nx, bd) for x in e[1])
+        if k == "setfilter":
+            return frozenset(v for v in self.ev(e[2], st, nx, bd) if self.ev(e[3], st, nx, {**bd, e[1]: v}))
+        if k == "setmap":
+            return frozenset(self.ev(e[3], st, nx, {**bd, e[1]: v}) for v in self.ev(e[2], st, nx, bd))
+        if k == "domain":
+            f = self.ev(e[1], st, nx, bd)
+            return f.domain()
         if k == "tuple":
             return Fn({i + 1: self.ev(x, st, nx, bd) for i, x in enumerate(e[1])})
         if k == "record":

@@ -25,7 +25,7 @@ struct Tok {
     int line = 0, col = 0;
 };
 
-const char *kSyms[] = {"|->", ":=", "||", "==", "=>", "<=", ">=", "=<", "/=", "/\\", "\\/", "..", "->", "<<", ">>", "(", ")", "[",
+const char *kSyms[] = {"|->", ":=", "||", "==", "<=>", "=>", "<=", ">=", "=<", "/=", "/\\", "\\/", "..", "->", "<<", ">>", "(", ")", "[",
                        "]",   "{",  "}",  ",",  ";",  ":",  "+",  "-",  "*",  "%",   "=",   "<",  ">",  "#",  "~",  "'", "!", "@",
                        ".",   "^",  "\\"};
 
@@ -152,7 +152,7 @@ struct Parser {
         right = false;
         if (k.t != Tok::SYM) return -1;
         const std::string &s = k.s;
-        if (s == "=>") return 1;
+        if (s == "=>" || s == "<=>" || s == "\\equiv") return 1;
         if (s == "\\/" || s == "\\lor") return 3;
         if (s == "/\\" || s == "\\land") return 3;
         if (s == "=" || s == "#" || s == "/=" || s == "<" || s == ">" || s == "<=" || s == "=<" || s == ">=" || s == "\\leq" || s == "\\geq" ||
@@ -192,7 +192,7 @@ struct Parser {
                     return let_subst(defs[k].body, args, {});
                 }
         auto c = std::make_shared<Expr>(*e);
-        if ((e->k == Expr::QUANT || e->k == Expr::FUNCDEF) && !e->bound.empty()) {
+        if ((e->k == Expr::QUANT || e->k == Expr::FUNCDEF || e->k == Expr::SETOF) && !e->bound.empty()) {
             if (!c->a.empty()) c->a[0] = let_subst(e->a[0], defs, hidden);   // the domain is outside the binding
             hidden.insert(e->bound);
             for (size_t j = 1; j < c->a.size(); j++) c->a[j] = let_subst(e->a[j], defs, hidden);
@@ -217,6 +217,42 @@ struct Parser {
                 e->a.push_back(expr(0));
                 return e;
             }
+            if (k.s == "CASE") {   // CASE p1 -> e1 [] p2 -> e2 [] OTHER -> e: the first arm whose guard holds; without OTHER, no arm is an evaluation error
+                i++;
+                std::vector<std::pair<EP, EP>> arms;
+                EP other;
+                for (;;) {
+                    if (is_id("OTHER")) { i++; expect_sym("->"); other = expr(2); break; }
+                    EP g = expr(2);
+                    expect_sym("->");
+                    arms.push_back({g, expr(2)});
+                    if (is_sym("[") && peek().t == Tok::SYM && peek().s == "]") { i += 2; continue; }
+                    break;
+                }
+                if (!other) {   // (what TLC raises an error for: CHOOSE from the empty set does the same, in every back-end)
+                    other = mk(Expr::QUANT, k);
+                    other->s = "CHOOSE";
+                    other->bound = "none_";
+                    auto dom = mk(Expr::BINOP, k);
+                    dom->s = "..";
+                    auto one = mk(Expr::NUM, k), zero = mk(Expr::NUM, k);
+                    one->num = 1;
+                    dom->a = {one, zero};
+                    auto yes = mk(Expr::BOOL, k);
+                    yes->num = 1;
+                    other->a = {dom, yes};
+                    other->paren = true;
+                }
+                EP acc = other;
+                for (size_t a = arms.size(); a-- > 0;) {
+                    auto e = mk(Expr::IF, k);
+                    e->a = {arms[a].first, arms[a].second, acc};
+                    e->paren = true;
+                    acc = e;
+                }
+                return acc;
+            }
+            if (k.s == "DOMAIN") { i++; auto e = mk(Expr::UNOP, k); e->s = "DOMAIN"; e->a.push_back(postfix()); return e; }
             if (k.s == "LET") {   // LET a == e  f(x, y) == g ... IN body: substituted where it is parsed (a definition sees the earlier ones;
                 i++;              //  like TLC's, an unused or guarded definition is never evaluated); the translation prints the result
                 std::vector<LetDef> defs;
@@ -275,7 +311,27 @@ struct Parser {
             if (k.s == "{") {
                 i++;
                 auto e = mk(Expr::SETENUM, k);
-                if (!is_sym("}")) for (;;) { e->a.push_back(expr(0)); if (is_sym(",")) { i++; continue; } break; }
+                if (!is_sym("}")) {
+                    EP first = expr(0);
+                    if (is_sym(":")) {   // {x \\in S : P} or {e : x \\in S}
+                        i++;
+                        auto so = mk(Expr::SETOF, k);
+                        if (first->k == Expr::BINOP && first->s == "\\in" && first->a[0]->k == Expr::ID && !first->paren) {
+                            so->s = "filter";
+                            so->bound = first->a[0]->s;
+                            so->a = {first->a[1], expr(0)};
+                        } else {
+                            so->s = "map";
+                            so->bound = ident("a bound variable");
+                            expect_sym("\\in");
+                            so->a = {expr(6), first};
+                        }
+                        expect_sym("}");
+                        return so;
+                    }
+                    e->a.push_back(first);
+                    while (is_sym(",")) { i++; e->a.push_back(expr(0)); }
+                }
                 expect_sym("}");
                 return e;
             }
@@ -346,7 +402,7 @@ struct Parser {
     EP postfix() {
         EP e = primary();
         for (;;) {
-            if (is_sym("[")) {
+            if (is_sym("[") && !(peek().t == Tok::SYM && peek().s == "]")) {   // (`[]` separates the arms of a CASE)
                 const Tok at = cur();
                 i++;
                 auto x = mk(Expr::INDEX, at);
@@ -381,7 +437,7 @@ struct Parser {
             i++;
             EP rhs = expr(p + 1);
             auto b = mk(Expr::BINOP, op);
-            b->s = op.s == "\\land" ? "/\\" : op.s == "\\lor" ? "\\/" : op.s == "=<" || op.s == "\\leq" ? "<=" : op.s == "\\geq" ? ">=" : op.s == "/=" ? "#" : op.s;
+            b->s = op.s == "\\land" ? "/\\" : op.s == "\\lor" ? "\\/" : op.s == "=<" || op.s == "\\leq" ? "<=" : op.s == "\\geq" ? ">=" : op.s == "/=" ? "#" : op.s == "\\equiv" ? "<=>" : op.s;
             b->pos = lhs->pos;
             b->a = {lhs, rhs};
             lhs = b;
@@ -2318,7 +2374,7 @@ std::string pe_inner(const EP &e, const Ctx &c, const std::set<std::string> &pri
         if (c.locals.count(e->s) && c.proc && c.proc->is_set) s += "[self]";
         return s;
     }
-    case Expr::UNOP: return e->s + pe(e->a[0], c, primed, shadow);
+    case Expr::UNOP: return e->s + (e->s == "DOMAIN" ? " " : "") + pe(e->a[0], c, primed, shadow);
     case Expr::BINOP: {
         const std::string l = pe(e->a[0], c, primed, shadow), r = pe(e->a[1], c, primed, shadow);
         if (e->s == "..") return l + ".." + r;
@@ -2338,6 +2394,13 @@ std::string pe_inner(const EP &e, const Ctx &c, const std::set<std::string> &pri
         const std::string dom = pe(e->a[0], c, primed, shadow);
         sh.insert(e->bound);
         return e->s + " " + e->bound + " \\in " + dom + " : " + pe(e->a[1], c, primed, sh);
+    }
+    case Expr::SETOF: {
+        std::set<std::string> sh = shadow;
+        const std::string dom = pe(e->a[0], c, primed, shadow);
+        sh.insert(e->bound);
+        if (e->s == "filter") return "{" + e->bound + " \\in " + dom + " : " + pe(e->a[1], c, primed, sh) + "}";
+        return "{" + pe(e->a[1], c, primed, sh) + " : " + e->bound + " \\in " + dom + "}";
     }
     case Expr::FUNCDEF: {
         std::set<std::string> sh = shadow;
@@ -2372,7 +2435,7 @@ std::string pe_rhs(const EP &e, const Ctx &c, const std::set<std::string> &prime
     if (e->paren) return s;
     bool loose = e->k == Expr::QUANT;
     if (e->k == Expr::BINOP) {
-        static const char *ops[] = {"=>", "\\/", "/\\", "=", "#", "<", ">", "<=", ">=", "\\in", "\\notin", "\\subseteq"};
+        static const char *ops[] = {"=>", "<=>", "\\/", "/\\", "=", "#", "<", ">", "<=", ">=", "\\in", "\\notin", "\\subseteq"};
         for (const char *o : ops) loose |= e->s == o;
     }
     return loose ? "(" + s + ")" : s;

@@ -18,10 +18,10 @@ struct Pos { int line = 0, col = 0; };
 struct Expr;
 using EP = std::shared_ptr<Expr>;
 struct Expr {
-    enum K { NUM, STR, BOOL, ID, UNOP, BINOP, INDEX, IF, QUANT, SETENUM, TUPLE, FUNCDEF, PRIME, CALL, RECORD, DOT } k = NUM;
+    enum K { NUM, STR, BOOL, ID, UNOP, BINOP, INDEX, IF, QUANT, SETENUM, TUPLE, FUNCDEF, PRIME, CALL, RECORD, DOT, SETOF } k = NUM;
     long long num = 0;      // NUM, BOOL
     std::string s;          // ID name, STR text, operator text, QUANT "\\A" / "\\E", CALL operator name, DOT field name
-    std::string bound;      // QUANT / FUNCDEF bound variable
+    std::string bound;      // QUANT / FUNCDEF / SETOF bound variable (SETOF: s = "filter" {x \in S : P} or "map" {e : x \in S}; a = [domain, P or e])
     std::vector<EP> a;      // operands; INDEX: [fn, index]; IF: [c, t, e]; QUANT / FUNCDEF: [domain, body]; DOT: [record]; RECORD: the values
     std::vector<std::string> names;  // RECORD [f |-> e, g |-> h]: the field names, in the order written
     bool paren = false;     // written inside ( )

@@ -163,7 +163,8 @@ struct Compiler {
         }
         return true;
     }
-    bool const_set(const EP &e, std::vector<long long> &out) {
+    bool const_set(const EP &e0, std::vector<long long> &out) {
+        const EP e = e0->k == Expr::UNOP && e0->s == "DOMAIN" && !seq_ref(e0->a[0]) ? resolve_domain(e0) : e0;
         if (e->k == Expr::SETENUM) {
             for (const auto &x : e->a) { long long v; if (!const_scalar(x, v)) return false; out.push_back(v); }
             return true;
@@ -198,13 +199,14 @@ struct Compiler {
         case Expr::QUANT: return e->s == "CHOOSE" ? type_of(e->a[0]) : 'b';
         case Expr::UNOP: return e->s == "~" ? 'b' : 'i';
         case Expr::BINOP: {
-            static const char *boolops[] = {"/\\", "\\/", "=>", "=", "#", "<", ">", "<=", ">=", "\\in", "\\notin"};
+            static const char *boolops[] = {"/\\", "\\/", "=>", "<=>", "=", "#", "<", ">", "<=", ">=", "\\in", "\\notin", "\\subseteq"};
             for (const char *o : boolops) if (e->s == o) return 'b';
             if (e->s == "..") return type_of(e->a[0]);
             return 'i';
         }
         case Expr::IF: return type_of(e->a[1]);
         case Expr::SETENUM: case Expr::TUPLE: return e->a.empty() ? 'i' : type_of(e->a[0]);
+        case Expr::SETOF: return e->s == "map" ? type_of(e->a[1]) : type_of(e->a[0]);
         case Expr::FUNCDEF: return type_of(e->a[1]);
         case Expr::ID: {
             if (e->s == "BOOLEAN") return 'b';
@@ -568,8 +570,40 @@ struct Compiler {
         auto vi = var_index.find(e->s);
         return vi != var_index.end() && P.vars[(size_t)vi->second].set ? &P.vars[(size_t)vi->second] : nullptr;
     }
+    // DOMAIN f of a function variable is its (constant) index set, DOMAIN q of a sequence the interval 1..Len(q)
+    EP resolve_domain(const EP &e) {
+        if (!e || e->k != Expr::UNOP || e->s != "DOMAIN") return e;
+        const EP &x = e->a[0];
+        if (seq_ref(x)) {
+            auto len = std::make_shared<Expr>();
+            len->k = Expr::CALL; len->s = "Len"; len->a = {x}; len->pos = e->pos;
+            auto one = std::make_shared<Expr>();
+            one->k = Expr::NUM; one->num = 1; one->pos = e->pos;
+            auto iv = std::make_shared<Expr>();
+            iv->k = Expr::BINOP; iv->s = ".."; iv->a = {one, len}; iv->pos = e->pos;
+            return iv;
+        }
+        if (x->k == Expr::ID) {
+            bool shadowed = false;
+            for (const auto &b : binds) shadowed |= b.name == x->s;
+            auto vi = var_index.find(x->s);
+            if (!shadowed && vi != var_index.end() && P.vars[(size_t)vi->second].array && !P.vars[(size_t)vi->second].seq) {
+                auto lit = std::make_shared<Expr>();
+                lit->k = Expr::SETENUM; lit->pos = e->pos;
+                for (long long id : P.vars[(size_t)vi->second].ids) {
+                    auto n = std::make_shared<Expr>();
+                    n->k = Expr::NUM; n->num = id; n->pos = e->pos;
+                    lit->a.push_back(n);
+                }
+                return lit;
+            }
+        }
+        cfail("DOMAIN is supported on a function variable and on a sequence", e->pos);
+    }
     // does the expression denote a set whose value depends on the state (a set variable somewhere inside)?
-    bool dynamic_set(const EP &e) {
+    bool dynamic_set(const EP &e0) {
+        const EP e = resolve_domain(e0);
+        if (e->k == Expr::SETOF) return true;
         if (set_var(e)) return true;
         if (e->k == Expr::BINOP && (e->s == "\\cup" || e->s == "\\union" || e->s == "\\cap" || e->s == "\\intersect" || e->s == "\\"))
             return dynamic_set(e->a[0]) || dynamic_set(e->a[1]);
@@ -577,7 +611,60 @@ struct Compiler {
         return false;
     }
     // leave the 32-bit mask of a set expression on the stack
-    void ex_set(const EP &e) {
+    void ex_set(const EP &e0) {
+        const EP e = resolve_domain(e0);
+        if (e->k == Expr::SETOF) {   // {x \\in S : P}: the members of S for which P holds; {f : x \\in S}: the values f takes (all within 0..31)
+            const bool filter = e->s == "filter";
+            const EP dom = resolve_domain(e->a[0]);
+            std::vector<long long> elems;
+            if (!dynamic_set(dom) && !(dom->k == Expr::BINOP && dom->s == "..") && const_set(dom, elems)) {
+                emit(mc::VM_PUSH, 0);
+                for (long long x : elems) {
+                    if (filter && (x < 0 || x > 31)) cfail("only 0..31 can be members of a set value", e->pos);
+                    binds.push_back({e->bound, 0, true, x});
+                    if (filter) {
+                        ex(e->a[1]);
+                        const int skip = emit_jump(mc::VM_JZ);
+                        emit(mc::VM_PUSH, (int)(1u << x)); emit(mc::VM_OR);
+                        patch(skip);
+                    } else {
+                        ex(e->a[1]); emit(mc::VM_BIT); emit(mc::VM_OR);
+                    }
+                    binds.pop_back();
+                }
+                return;
+            }
+            // a state-dependent domain: an interval (walked from its lower to its upper bound) or a set value (its members among 0..31)
+            const bool interval = dom->k == Expr::BINOP && dom->s == "..";
+            const int tx = new_temp(e->pos), th = new_temp(e->pos), tacc = new_temp(e->pos);
+            if (interval) { ex(dom->a[0]); emit(mc::VM_STORET, tx); ex(dom->a[1]); emit(mc::VM_STORET, th); }
+            else { emit(mc::VM_PUSH, 0); emit(mc::VM_STORET, tx); ex_set(dom); emit(mc::VM_STORET, th); }
+            emit(mc::VM_PUSH, 0); emit(mc::VM_STORET, tacc);
+            const int loop = (int)c.size();
+            emit(mc::VM_LOADT, tx);
+            if (interval) emit(mc::VM_LOADT, th); else emit(mc::VM_PUSH, 31);
+            emit(mc::VM_LE);
+            const int jdone = emit_jump(mc::VM_JZ);
+            int jskip = -1;
+            if (!interval) { emit(mc::VM_LOADT, tx); emit(mc::VM_BIT); emit(mc::VM_LOADT, th); emit(mc::VM_AND); jskip = emit_jump(mc::VM_JZ); }
+            binds.push_back({e->bound, tx, false, 0});
+            if (filter) {
+                ex(e->a[1]);
+                const int no = emit_jump(mc::VM_JZ);
+                emit(mc::VM_LOADT, tacc); emit(mc::VM_LOADT, tx); emit(mc::VM_BIT); emit(mc::VM_OR); emit(mc::VM_STORET, tacc);
+                patch(no);
+            } else {
+                emit(mc::VM_LOADT, tacc); ex(e->a[1]); emit(mc::VM_BIT); emit(mc::VM_OR); emit(mc::VM_STORET, tacc);
+            }
+            binds.pop_back();
+            if (jskip >= 0) patch(jskip);
+            emit(mc::VM_LOADT, tx); emit(mc::VM_PUSH, 1); emit(mc::VM_ADD); emit(mc::VM_STORET, tx);
+            emit(mc::VM_JMP, loop);
+            patch(jdone);
+            emit(mc::VM_LOADT, tacc);
+            next_temp -= 3;
+            return;
+        }
         if (const VarInfo *v = set_var(e)) {
             if (proc && proc_locals.count(e->s) && proc->is_set && P.multi) { push_self(e->pos); emit_indexed(mc::VM_LOADX, *v, e->pos); }
             else emit(mc::VM_LOAD, v->base);
@@ -762,11 +849,24 @@ struct Compiler {
             ex(e->a[0]); emit(mc::VM_BIT); ex_set(e->a[1]); emit(mc::VM_AND); emit(mc::VM_PUSH, 0); emit(o == "\\in" ? mc::VM_NE : mc::VM_EQ);
             return;
         }
+        if (o == "<=>") {   // both sides are booleans (0 / 1)
+            ex(e->a[0]); emit(mc::VM_PUSH, 0); emit(mc::VM_NE);
+            ex(e->a[1]); emit(mc::VM_PUSH, 0); emit(mc::VM_NE);
+            emit(mc::VM_EQ);
+            return;
+        }
+        if ((o == "\\in" || o == "\\notin") && e->a[1]->k == Expr::ID && (e->a[1]->s == "Nat" || e->a[1]->s == "Int") && !var_index.count(e->a[1]->s)) {
+            ex(e->a[0]);                               // x \\in Nat (a TypeOK conjunct): x >= 0; every cell is an integer
+            if (e->a[1]->s == "Nat") { emit(mc::VM_PUSH, 0); emit(mc::VM_GE); }
+            else { emit(mc::VM_POP); emit(mc::VM_PUSH, 1); }
+            if (o == "\\notin") emit(mc::VM_NOT);
+            return;
+        }
         if (o == "\\in" || o == "\\notin") {
             const int t = new_temp(e->pos);
             ex(e->a[0]);
             emit(mc::VM_STORET, t);
-            member(t, e->a[1]);
+            member(t, resolve_domain(e->a[1]));
             if (o == "\\notin") emit(mc::VM_NOT);
             next_temp--;
             return;
@@ -822,10 +922,33 @@ struct Compiler {
     }
     void quant(const EP &e) {
         const bool all = e->s == "\\A";
-        const EP &dom = e->a[0];
+        const EP dom = resolve_domain(e->a[0]);
+        if (e->s == "CHOOSE" && !(dom->k == Expr::BINOP && dom->s == "..")) {
+            // CHOOSE x \in S : P over a set of small naturals (a set variable, {...}, a filter ...): the smallest member that satisfies P
+            const int tx = new_temp(e->pos), tm = new_temp(e->pos);
+            ex_set(dom); emit(mc::VM_STORET, tm);
+            emit(mc::VM_PUSH, 0); emit(mc::VM_STORET, tx);
+            const int loop = (int)c.size();
+            emit(mc::VM_LOADT, tx); emit(mc::VM_PUSH, 31); emit(mc::VM_LE);
+            const int jnone = emit_jump(mc::VM_JZ);
+            emit(mc::VM_LOADT, tx); emit(mc::VM_BIT); emit(mc::VM_LOADT, tm); emit(mc::VM_AND);
+            const int jskip = emit_jump(mc::VM_JZ);
+            binds.push_back({e->bound, tx, false, 0});
+            ex(e->a[1]);
+            binds.pop_back();
+            const int jhit = emit_jump(mc::VM_JNZ);
+            patch(jskip);
+            emit(mc::VM_LOADT, tx); emit(mc::VM_PUSH, 1); emit(mc::VM_ADD); emit(mc::VM_STORET, tx);
+            emit(mc::VM_JMP, loop);
+            patch(jnone);
+            emit(mc::VM_FAIL);
+            patch(jhit);
+            emit(mc::VM_LOADT, tx);
+            next_temp -= 2;
+            return;
+        }
         if (e->s == "CHOOSE") {
             // CHOOSE x \in a..b : P — TLC takes the first element (ascending) that satisfies P and raises an error when none does
-            if (!(dom->k == Expr::BINOP && dom->s == "..")) cfail("CHOOSE is supported over an integer interval a..b only", e->pos);
             const int tx = new_temp(e->pos), th = new_temp(e->pos);
             ex(dom->a[0]); emit(mc::VM_STORET, tx);
             ex(dom->a[1]); emit(mc::VM_STORET, th);
@@ -1270,15 +1393,16 @@ struct Compiler {
                 next_temp -= 1 + taken;
                 return (unsigned long long)v.cap * nb;
             }
+            const EP wdom = s->with_eq ? s->e : resolve_domain(s->e);   // (with x \\in DOMAIN f / DOMAIN q)
             if (s->with_eq) ex(s->e);
-            else if (dynamic_set(s->e)) {  // any of 0..31, enabled only for the members
+            else if (dynamic_set(wdom)) {  // any of 0..31, enabled only for the members
                 emit(mc::VM_CHOOSE, 32);
                 emit(mc::VM_STORET, t);
-                emit(mc::VM_LOADT, t); emit(mc::VM_BIT); ex_set(s->e); emit(mc::VM_AND); emit(mc::VM_AWAIT);
+                emit(mc::VM_LOADT, t); emit(mc::VM_BIT); ex_set(wdom); emit(mc::VM_AND); emit(mc::VM_AWAIT);
                 emit(mc::VM_LOADT, t);
                 n = 32;
-            } else if (dynamic_interval(s->e)) n = choose_interval(s->e, s->pos);
-            else n = choose_from(s->e, s->pos);
+            } else if (dynamic_interval(wdom)) n = choose_interval(wdom, s->pos);
+            else n = choose_from(wdom, s->pos);
             emit(mc::VM_STORET, t);
             binds.push_back({s->var, t, false, 0});
             const unsigned long long b = block(s->blocks[0]);
