@@ -22,7 +22,7 @@ variables msgs = {},
 
 define
   Voted(a, b, v) == [type |-> "2b", bal |-> b, acc |-> a, vbal |-> 0, val |-> v] \in msgs
-  ChosenAt(b, v) == \E a1 \in 1..NA : \E a2 \in 1..NA : a1 < a2 /\ Voted(a1, b, v) /\ Voted(a2, b, v)
+  ChosenAt(b, v) == 2 * Cardinality({a \in 1..NA : Voted(a, b, v)}) > NA
 end define;
 
 process Proposer \in (NA + 1)..(NA + NB)
@@ -80,7 +80,7 @@ VARIABLES msgs, maxBal, maxVBal, maxVal, pc
 (* define statement *)
 Voted(a, b, v) == [type |-> "2b", bal |-> b, acc |-> a, vbal |-> 0, val |-> v] \in msgs
 
-ChosenAt(b, v) == \E a1 \in 1..NA : \E a2 \in 1..NA : a1 < a2 /\ Voted(a1, b, v) /\ Voted(a2, b, v)
+ChosenAt(b, v) == 2 * Cardinality({a \in 1..NA : Voted(a, b, v)}) > NA
 
 VARIABLES promises, hb, hv, v
 
