@@ -1206,3 +1206,39 @@ Sel == (votes # {}) => (CHOOSE v \in votes : TRUE) \in votes
 Kind == CASE x < 100 -> TRUE [] OTHER -> FALSE
 ====
 """
+
+
+def test_operators_over_whole_variables_in_state_predicates():
+    """`Last(z) == z[Len(z)]`, `Sorted(z)`, `Size(t) == Cardinality(t)`, `Sum3(g)`: an operator whose argument is a whole sequence / set / set of
+    records / function variable — or an element box[p] of an array of sequences, p the caller's — is SUBSTITUTED into the invariant instead of
+    being evaluated to a number (state predicates only: inside an action the argument could name a value assigned earlier in the step)"""
+    r = _vm_equals_evaluator(OPS, ["Inv1", "Inv2", "Inv3", "Inv4"], {"N": 2})
+    assert (r["distinct"], r["verdict"]) == (13, "ok")
+    r = _vm_equals_evaluator(OPS.replace("Last(q) \\in 1..N", "Last(q) \\in 2..N"), ["Inv1"], {"N": 2})
+    assert r["verdict"] == "invariant"
+
+
+OPS = r"""---- MODULE ops ----
+EXTENDS Naturals, Sequences, FiniteSets
+CONSTANTS N
+(* --algorithm ops
+variables q = <<>>, box = [i \in 1..2 |-> <<>>], s = {}, f = [i \in 1..3 |-> 0], msgs = {};
+process P \in 1..N
+begin
+  A: q := Append(q, self);
+     box[self] := Append(box[self], self * 3);
+  B: s := s \cup {self};
+     f[self] := self;
+     msgs := msgs \cup {[k |-> self, v |-> self + 1]};
+end process
+end algorithm *)
+Last(z) == z[Len(z)]
+Sorted(z) == \A i \in 1..Len(z) : \A j \in 1..Len(z) : i < j => z[i] # z[j]
+Size(t) == Cardinality(t)
+Sum3(g) == g[1] + g[2] + g[3]
+Inv1 == (q # <<>>) => Last(q) \in 1..N
+Inv2 == Sorted(q) /\ Sorted(box[1]) /\ Sorted(box[2])
+Inv3 == Size(s) <= N /\ Size(msgs) <= N /\ Sum3(f) <= 6
+Inv4 == \A p \in 1..Len(q) % 3 : (box[p] # <<>>) => Last(box[p]) = p * 3
+====
+"""

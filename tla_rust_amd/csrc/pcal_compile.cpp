@@ -691,6 +691,29 @@ struct Compiler {
         cfail("expected a set: a set variable, {...}, a constant set, or \\cup / \\cap / \\ of those", e->pos);
     }
 
+    // an argument that names a whole sequence / set / set of records / function variable (or an element of an array of sequences)
+    bool whole_variable(const EP &a) {
+        if (seq_ref(a)) return true;
+        if (a->k != Expr::ID) return false;
+        for (const auto &b : binds) if (b.name == a->s) return false;
+        auto vi = var_index.find(a->s);
+        if (vi == var_index.end()) return false;
+        const VarInfo &v = P.vars[(size_t)vi->second];
+        return v.seq || v.set || v.rset || (v.array && !(proc && proc_locals.count(a->s)));
+    }
+    static EP subst_ids(const EP &e, std::map<std::string, EP> m) {
+        if (!e) return e;
+        if (e->k == Expr::ID) { auto it = m.find(e->s); return it == m.end() ? e : it->second; }
+        auto c = std::make_shared<Expr>(*e);
+        if ((e->k == Expr::QUANT || e->k == Expr::FUNCDEF || e->k == Expr::SETOF) && !e->bound.empty()) {
+            if (!c->a.empty()) c->a[0] = subst_ids(e->a[0], m);
+            m.erase(e->bound);
+            for (size_t j = 1; j < c->a.size(); j++) c->a[j] = subst_ids(e->a[j], m);
+            return c;
+        }
+        for (auto &x : c->a) x = subst_ids(x, m);
+        return c;
+    }
     // ---- expressions: leave one value on the stack
     void ex(const EP &e) {
         switch (e->k) {
@@ -763,9 +786,34 @@ struct Compiler {
             if (++inline_depth > 16) cfail("definitions nest too deeply (recursion?)", e->pos);
             std::vector<Bind> inner;
             const int temp0 = next_temp;
+            std::map<std::string, EP> whole;   // parameters that stand for a whole sequence / set / function variable: substituted, not evaluated
             for (size_t k = 0; k < e->a.size(); k++) {
                 long long cv;
                 if (const_scalar(e->a[k], cv)) { inner.push_back({def->params[k], 0, true, cv}); continue; }
+                if (!proc && whole_variable(e->a[k])) {   // (a state predicate: Last(q), IsSorted(box[i]), Size(msgs))
+                    EP arg = e->a[k];
+                    long long ci;
+                    if (arg->k == Expr::INDEX && const_scalar(arg->a[1], ci)) {   // box[i], i a constant of the caller (an unrolled quantifier's variable): its value
+                        auto c2 = std::make_shared<Expr>(*arg);
+                        auto lit = std::make_shared<Expr>();
+                        lit->k = Expr::NUM; lit->num = ci; lit->pos = arg->pos;
+                        c2->a[1] = lit;
+                        arg = c2;
+                    } else if (arg->k == Expr::INDEX) {   // box[i]: i is the caller's — evaluated here, named inside
+                        const int t = new_temp(e->pos);
+                        ex(arg->a[1]);
+                        emit(mc::VM_STORET, t);
+                        const std::string nm = "\001a" + std::to_string(t);
+                        inner.push_back({nm, t, false, 0});
+                        auto c2 = std::make_shared<Expr>(*arg);
+                        auto idn = std::make_shared<Expr>();
+                        idn->k = Expr::ID; idn->s = nm; idn->pos = arg->pos;
+                        c2->a[1] = idn;
+                        arg = c2;
+                    }
+                    whole[def->params[k]] = arg;
+                    continue;
+                }
                 const int t = new_temp(e->pos);
                 ex(e->a[k]);
                 emit(mc::VM_STORET, t);
@@ -776,7 +824,7 @@ struct Compiler {
             const Proc *sp = proc;
             proc = nullptr;
             emit(mc::VM_OLD_ON);   // the arguments were evaluated in the caller's context; the body reads unprimed variables
-            ex(def->body);
+            ex(whole.empty() ? def->body : subst_ids(def->body, whole));
             emit(mc::VM_OLD_OFF);
             proc = sp;
             binds = saved;
