@@ -376,3 +376,65 @@ def test_random_uniprocess_algorithm_translated_vs_compiled(seed, tmp_path):
     except AssertionError:
         print(text)
         raise
+
+
+class ExprGen(ChanGen):
+    """... plus the expression forms of the round's last hours inside the same random steps: CASE, LET, set filters and images, DOMAIN, CHOOSE over
+    a set, <=>, `\\in Nat` (a subclass again: the programs above, some of which the GPU tests run, stay what they were)"""
+
+    def __init__(self, seed):
+        super().__init__(seed + 200000)
+
+    def iexpr(self, env, depth=0):
+        if depth < 2 and self.r.random() < 0.22:
+            k = self.r.randrange(8)
+            a, b = self.iexpr(env, depth + 1), self.iexpr(env, depth + 1)
+            if k == 0:
+                return f"(CASE {self.cond(env, depth + 1)} -> {a} [] {self.cond(env, depth + 1)} -> {b} [] OTHER -> 0)"
+            if k == 1:
+                return f"(LET z_ == {a} IN (z_ + {b}) % 3)"
+            if k == 2:
+                return f"(Cardinality({{k_ \\in 0..2 : k_ <= {a}}}) % 3)"
+            if k == 3:
+                return f"Cardinality({{(k_ + {a}) % 2 : k_ \\in 0..1}})"
+            if k == 4 and self.use_set:
+                return "(IF s # {} THEN (CHOOSE k_ \\in s : TRUE) % 3 ELSE 0)"
+            if k == 5 and self.use_set:
+                return "Cardinality({k_ \\in s : k_ > 0})"
+            if k == 6 and self.use_fn:
+                return "(Cardinality(DOMAIN f) % 3)"
+            if k == 7 and self.use_seq:
+                return "Cardinality({k_ \\in DOMAIN q : q[k_] > 0})"
+        return super().iexpr(env, depth)
+
+    def cond(self, env, depth=0):
+        if depth < 2 and self.r.random() < 0.12:
+            if self.r.random() < 0.5:
+                return f"({self.cond(env, depth + 1)} <=> {self.cond(env, depth + 1)})"
+            return f"({self.iexpr(env, 2)} \\in Nat)"
+        return super().cond(env, depth)
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_algorithm_with_the_wider_expression_language(seed, tmp_path):
+    text, invs = ExprGen(seed).program()
+    try:
+        helpers.pcal_translate(text)
+        prog = helpers.ShimProgram(text, invs, {})
+    except RuntimeError as e:
+        assert str(e).strip(), text
+        pytest.skip(f"refused: {e}")
+    try:
+        r = helpers.shim_run("pcal", prog.params)
+    finally:
+        prog.close()
+    if r["distinct"] > MAX_STATES:
+        pytest.skip(f"{r['distinct']} states: too many for the Python evaluator in a unit test")
+    path = tmp_path / "Fz.tla"
+    path.write_text(text)
+    try:
+        test_pcal.test_compiled_program_vs_tla_evaluator(path, invs, {})
+        test_tlaeval.test_pluscal_translation_evaluated_vs_compiled_program(path, invs, {}, tmp_path)
+    except AssertionError:
+        print(text)
+        raise
