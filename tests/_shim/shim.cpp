@@ -66,6 +66,64 @@ struct ShimResult {
 template <class S>
 static uint64_t stored_fp(const typename S::Params &p, const uint64_t *w) { return S::fp_of(p, CWordRef{w, 1}); }
 
+// by-pairs interface (specs with PAIR_FAMILIES, engine_pairs.h): for every state the lowering visits, (1) the guard mask names every
+// enabled slot (and ONLY enabled slots, the spec's declared inexact slots aside: S::guard_is_exact), (2) every slot lies in exactly one
+// family and one round, (3) eval_pair<F> from the Summary gives eval's status and fingerprint, (4) write_pair gives apply's row
+template <class S, class = void>
+struct PairCheck {
+    template <class Ref>
+    static uint64_t mismatches(const typename S::Params &, typename S::Local &, Ref, int) { return 0; }
+};
+template <class S>
+struct PairCheck<S, decltype((void)S::PAIR_FAMILIES)> {
+    template <int F, class Ref>
+    static unsigned run(int fam, const typename S::Params &p, const typename S::Summary &q, Ref s, int slot, uint64_t &fp, typename S::PairOut &o) {
+        if constexpr (F < S::PAIR_FAMILIES) {
+            if (fam == F) return S::template eval_pair<F>(p, q, s, slot, fp, o);
+            return run<F + 1>(fam, p, q, s, slot, fp, o);
+        } else {
+            return 0;
+        }
+    }
+    template <class Ref>
+    static uint64_t mismatches(const typename S::Params &p, typename S::Local &l, Ref s, int ns) {
+        uint64_t bad = 0, glo = 0, ghi = 0;
+        S::guards(p, l, glo, ghi);
+        typename S::Summary q;
+        S::summarize(l, q);
+        unsigned per_round[S::PAIR_ROUNDS] = {};
+        for (int slot = 0; slot < ns; slot++) {
+            const bool g = slot < 64 ? (glo >> slot & 1u) : (ghi >> (slot - 64) & 1u);
+            int fam = -1, nfam = 0, nround = 0;
+            for (int f = 0; f < S::PAIR_FAMILIES; f++) {
+                const auto m = S::family_mask(f);
+                if (slot < 64 ? (m.lo >> slot & 1u) : (m.hi >> (slot - 64) & 1u)) { fam = f; nfam++; }
+            }
+            for (int r = 0; r < S::PAIR_ROUNDS; r++) {
+                const auto m = S::round_mask(r);
+                if (slot < 64 ? (m.lo >> slot & 1u) : (m.hi >> (slot - 64) & 1u)) { nround++; per_round[r]++; }
+            }
+            if (nfam != 1 || nround != 1 || fam != S::slot_family(slot)) bad++;
+            uint64_t f0 = 0, f1 = 0;
+            const unsigned st0 = S::eval(p, l, s, slot, f0);
+            if ((st0 & ST_ENABLED) && !g) bad++;                                  // an enabled slot the guards miss: a lost successor
+            if (!(st0 & ST_ENABLED) && g && S::guard_is_exact(slot)) bad++;       // (an idle lane, not an error of the search — but the contract says exact)
+            typename S::PairOut o;
+            const unsigned st1 = run<0>(fam, p, q, s, slot, f1, o);
+            if (st0 != st1) { bad++; continue; }
+            if (!(st0 & ST_ENABLED) || (st0 & ST_OVERFLOW)) continue;
+            if (f0 != f1) bad++;
+            uint64_t a[S::MAX_WORDS], b[S::MAX_WORDS];
+            S::apply(p, s, slot, WordRef{a, 1});
+            for (int w = 0; w < S::MAX_WORDS; w++) b[w] = ~0ull;
+            S::write_pair(p, s, o, WordRef{b, 1});
+            for (int w = 0; w < S::words(p); w++) if (a[w] != b[w]) { bad++; break; }
+        }
+        for (int r = 0; r < S::PAIR_ROUNDS; r++) if (per_round[r] > (unsigned)S::PAIR_ROUND_SLOTS) bad++;
+        return bad;
+    }
+};
+
 // expand-by-family interface (specs with NFAM): for every (state, slot) the family-pruned evaluation through the
 // guard must reproduce exactly what the generic evaluation does
 template <class S, class = void>
@@ -278,6 +336,7 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
             const unsigned ps = S::parent_status(prm, loc, s);
             if (ps & ST_INVARIANT) violation(ps, level);
             r->fp_mismatch += FamCheck<S>::mismatches(prm, loc, s, ns);
+            r->fp_mismatch += PairCheck<S>::mismatches(prm, loc, s, ns);
             r->fp_mismatch += DenseCheck<S>::mismatches(prm, loc, s);
             uint64_t nsucc = 0;
             for (int slot = 0; slot < ns; slot++) {

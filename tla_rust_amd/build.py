@@ -38,8 +38,8 @@ def build(force=False, verbose=False):
     if os.environ.get("TLAMC_PHASE_PROF"):   # per-phase cycle counters inside k_expand_family (profiles/phase_prof.py): a profiling build
         common.append("-DMC_PHASE_PROF")
     base = [CSRC / "engine.hip", CSRC / "engine_kernels.h", CSRC / "mc_common.h", CSRC / "spec_registry.h", PKG.parent / "include" / "tlamc.h"]
-    own = {0: ["spec_pluscal.h", "spec_raft.h", "spec_ssi.h", "spec_vm.h", "spec_paxos.h"], 7: ["spec_paxos.h"], 1: ["spec_pluscal.h"], 2: ["spec_raft.h"],
-           3: ["spec_raft.h"], 4: ["spec_raft.h"], 5: ["spec_ssi.h"], 6: ["spec_vm.h"]}
+    own = {0: ["spec_pluscal.h", "spec_raft.h", "spec_ssi.h", "spec_vm.h", "spec_paxos.h", "engine_pairs.h"], 7: ["spec_paxos.h"], 1: ["spec_pluscal.h"], 2: ["spec_raft.h"],
+           3: ["spec_raft.h"], 4: ["spec_raft.h"], 5: ["spec_ssi.h", "engine_pairs.h"], 6: ["spec_vm.h"]}
     jobs, objs = [], []
     for tu in range(8):
         obj = OUT / f"engine_tu{tu}.o"

@@ -59,6 +59,7 @@ static void set_error(const std::string &s) { mc_set_error_internal(s.c_str()); 
 
 }  // namespace mc
 #include "engine_kernels.h"   // namespace mc { ... every kernel ... }
+#include "engine_pairs.h"     // k_expand_pairs: the by-pairs expand + insert + write kernel (specs with S::PAIR_FAMILIES)
 namespace mc {
 
 // ------------------------------------------------------------------------------------- host side
@@ -322,7 +323,10 @@ struct Engine : EngineBase {
     // t3 — levels grow by at most 2.2 x — was best with every level in-wave, the 5-server model — 2.4 x and more on all 18 levels — with
     // none, 230.6 against 239.0 ms: the limit was 2.3.  Round 5: with the writer's scratch traffic gone the in-wave tail wins there too,
     // 191.9 / 192.1 against 205.0 / 203.0 ms at 2.3 (profiles/r05i_raft5_inwave_growth.jsonl); 10 = in effect every level)
-    bool inwave_ok() const { return UsesFamilies<S>::value && !use_matrix && !(cfg.flags & (MC_F_NOFAMILY | MC_F_NOINWAVE)); }
+    bool inwave_ok() const { return (UsesFamilies<S>::value || UsesPairs<S>::value) && !use_matrix && !(cfg.flags & (MC_F_NOFAMILY | MC_F_NOINWAVE)); }
+    // by-pairs specs (engine_pairs.h) write EVERY new state in the expand kernel: nothing ever reaches the new-list, so a fused run launches
+    // neither k_materialise nor k_commit for them
+    bool pairs_only() const { return UsesPairs<S>::value && inwave_ok(); }
     void set_inwave(RouteArgs &rt) const {
         if (!inwave_ok()) return;
         rt.arena_w = d_arena;
@@ -333,6 +337,7 @@ struct Engine : EngineBase {
     // materialise + commit of the chunk whose survivors are in new-list `parity`, on the second stream: it overlaps
     // the expansion of the next chunk (memory-bound next to latency-bound)
     void finish_materialise(uint64_t chunk_base, uint64_t ncols, unsigned parity, hipStream_t expanded_on = nullptr) {
+        if (pairs_only()) return;
         const unsigned bx = (unsigned)((ncols + 255) / 256);
         const unsigned gm = bx < 8 * 256 ? (bx + 7) / 8 : 256;
         hipEventRecord(ev_e[parity], expanded_on ? expanded_on : stream);
@@ -365,7 +370,7 @@ struct Engine : EngineBase {
             if (dl) hipLaunchKernelGGL(k_deadlock_slices, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)d_nsl,
                                        (uint64_t)0, (uint64_t)0, ncols, (const LevelCtl *)d_lc, d_ctr);
         });
-        timed(2, 0, [&] {
+        if (!pairs_only()) timed(2, 0, [&] {
             hipLaunchKernelGGL(k_materialise<S>, dim3(32, NSHARD), dim3(256), 0, stream, prm, d_arena, (uint64_t)0, d_newlist, seg_cap,
                                arena_cap, d_parent, d_pslot, d_ctr, 0u, (const LevelCtl *)d_lc, (const uint64_t *)d_newfp);
         });
@@ -504,7 +509,7 @@ struct Engine : EngineBase {
             // IN-WAVE WRITES, level by level (inwave_growth_limit above: a level that grows faster than the limit goes through the
             // new-list and k_materialise alone).  The level before this one says which kind it is; the allocation mode
             // (DevCounters::atomic_alloc) follows — nothing is in flight between two levels.
-            const bool lvl_inwave = inwave_ok() && (double)(hi - lo) <= inwave_growth_limit * (double)prev_frontier;
+            const bool lvl_inwave = inwave_ok() && (pairs_only() || (double)(hi - lo) <= inwave_growth_limit * (double)prev_frontier);
             if (inwave_ok() && lvl_inwave != alloc_atomic) {
                 hipLaunchKernelGGL(k_set_alloc_mode, dim3(1), dim3(1), 0, stream, d_ctr, lvl_inwave ? 1u : 0u);
                 alloc_atomic = lvl_inwave;

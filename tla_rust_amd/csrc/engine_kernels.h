@@ -1520,8 +1520,16 @@ k_deadlock_slices(const uint16_t *__restrict__ succ, uint64_t lo, uint64_t hi, u
     const unsigned long long vmin = wave_min_u64(viol);
     if ((threadIdx.x & 63) == 0 && vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
 }
+// (engine_pairs.h, included after this file)
+template <class S>
+static bool launch_expand_pairs(hipStream_t stream, typename S::Params prm, const uint64_t *arena, uint64_t lo, uint64_t hi, uint64_t ncols, uint64_t *table,
+                                uint64_t mask, uint32_t *newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags, RouteArgs rt, unsigned parity);
 template <class S, bool ROUTE, class... A>
 static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStream_t stream, unsigned slices, A... args) {
+    if constexpr (!ROUTE) {
+        // specs with the by-pairs protocol: the fused expand + insert + write kernel whenever the run writes in-wave (rt.arena_w)
+        if (by_family && launch_expand_pairs<S>(stream, args...)) return;
+    }
     if constexpr (UsesFamilies<S>::value) {
         if (by_family) {
             // MC_F_OCC3 (A/B): the register budget of 3 wavefronts per SIMD (no spills) instead of 4 (a dozen spilled VGPRs)

@@ -1,0 +1,260 @@
+// engine_pairs.h — k_expand_pairs: the fused expand + insert + WRITE kernel for specs whose successor is "parent + a small delta" and
+// whose action slots all have compile-time indices (S::PAIR_FAMILIES; round 6: examples/serializableSnapshotIsolation.tla — BASELINE
+// config 5 — whose 77 slots per state walked, one lane per state, every slot body for the whole wavefront whenever ONE lane was enabled:
+// 24.6 VALU + 11.9 SALU wave-instructions per generated successor, and a second kernel re-derived every new state from scratch).
+// Included by engine.hip only (inside namespace mc, after engine_kernels.h).  Its own file so that the stamp of a counter collection
+// (bench.py kernel_source_hash) of the raft kernels does not move when this kernel changes, and the other way round.
+//
+// One WAVEFRONT = one arena block of 64 parents; wavefronts are independent (no workgroup barrier, no shared state but the device
+// counters):
+//   load      lane = parent: the row in one coalesced round trip, staged in LDS; S::load builds the parent's tables, S::parent_status
+//             checks the invariants of the expanded state, S::summarize leaves the tables the actions read in LDS, S::guards yields
+//             the mask of slots whose guard holds (128 bits per lane)
+//   layout    per-family counts -> one 64-bit wave scan (16 bits per family) -> every lane scatters its enabled slots into the
+//             wavefront's pair list, FAMILY-MAJOR: entry = (slot << 6) | parent lane
+//   pass 1    batches of 64 pairs of ONE family: S::eval_pair<F> from the parent's Summary + row (LDS) -> status, fingerprint ->
+//             seen-set probe / insert, all 64 lanes at once; pairs the seen-set knew are struck from the list
+//   alloc     ONE atomicAdd(arena_next) per wavefront for the survivors of all its parents (~8 per parent on config 5: a word takes
+//             ~88 returning atomics per microsecond, MI355X_MICROARCH "dequeue", so one per batch would bound the kernel)
+//   pass 2    the same batches again, the survivors only: S::eval_pair<F> once more (the delta is a few dozen instructions; keeping
+//             16 bytes per pair through the probes instead would cost 20 KB of LDS per wavefront, i.e. the occupancy that hides the
+//             probes' latency) and S::write_pair: lanes = consecutive arena indices, whole rows of the word-major blocks; the
+//             parent's words come from LDS — no second read of the parent, no new-list, no k_materialise.
+// A wavefront whose 64 parents enable more pairs than the list holds (never seen on config 5) works in S::PAIR_ROUNDS rounds of at
+// most S::PAIR_ROUND_SLOTS slots per parent.
+#ifndef TLAMC_ENGINE_PAIRS_H
+#define TLAMC_ENGINE_PAIRS_H
+
+namespace mc {
+
+template <class S, class = void>
+struct UsesPairs : std::false_type {};
+template <class S>
+struct UsesPairs<S, decltype((void)S::PAIR_ROUNDS)> : std::true_type {};
+
+constexpr int PAIR_CAP = 1280;             // pair-list entries per wavefront
+constexpr unsigned PAIR_DEAD = 0xffffu;    // a pair the seen-set already knew (or that was not enabled / not in the model)
+#ifndef MC_PAIR_WAVES
+#define MC_PAIR_WAVES 4
+#endif
+
+template <class S>
+struct PairLds {
+    uint64_t row[S::MAX_WORDS][64];   // the 64 parents' rows, word-major like the arena block they came from
+    typename S::Summary sum[64];
+    uint16_t list[PAIR_CAP];
+    unsigned succ[2];                 // deadlock check: bit p = parent p has a successor
+};
+// a parent's row in LDS (address-space-qualified: ds_read_b64, not flat_load)
+struct LdsRow {
+    const __attribute__((address_space(3))) uint64_t *col;  // &row[0][parent]
+    __device__ __forceinline__ uint64_t get(int w) const { return col[w * 64]; }
+};
+// a row held in registers by the lane that loaded it (indices are compile-time constants after unrolling)
+template <int N>
+struct RegRow {
+    const uint64_t *r;
+    __device__ __forceinline__ uint64_t get(int w) const { return r[w]; }
+};
+
+template <class S, int WAVES = MC_PAIR_WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 4)
+k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
+               uint64_t *table, uint64_t mask, DevCounters *ctr, unsigned flags, RouteArgs rt) {
+    constexpr int NF = S::PAIR_FAMILIES, MW = S::MAX_WORDS;
+    static_assert(NF >= 1 && NF <= 4, "per-family counts travel as 16-bit fields of one 64-bit scan");
+    static_assert(S::PAIR_ROUND_SLOTS * 64 <= PAIR_CAP, "a round's pairs fit the list");
+    static_assert(S::TOTAL_SLOTS <= 128 && S::TOTAL_SLOTS < 1024, "guard mask: 128 bits; list entry: slot << 6 | lane in 16 bits");
+    __shared__ PairLds<S> lds[WAVES];
+    if (rt.lc) {
+        if (rt.lc->stop) return;
+        lo = rt.lc->lo;
+        hi = rt.lc->hi;
+        ncols = ((hi - (lo & ~63ull)) + 63) & ~63ull;
+    }
+    const unsigned lane = threadIdx.x & 63;
+    PairLds<S> &L = lds[threadIdx.x >> 6];
+    const uint64_t base = lo & ~63ull;
+    const uint64_t col = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;  // whole wavefronts leave together (ncols % 64 == 0); no barrier below
+    const uint64_t idx = base + col;
+    const bool active = idx >= lo && idx < hi;
+    const int W = S::words(prm);
+    const unsigned shard = blockIdx.x & (NSHARD - 1);
+    unsigned long long viol = ~0ull;
+    unsigned gen = 0, err = 0, cands = 0;
+
+    // ---- load: the row (coalesced: lane = state of one arena block), tables, invariants, guards
+    uint64_t glo = 0, ghi = 0;
+    {
+        const GlobalWords blk = uniform_ptr(arena + ((idx - lane) >> 6) * (uint64_t)W * 64);
+        uint64_t r[MW];
+#pragma unroll
+        for (int w = 0; w < MW; w++) r[w] = (active && w < W) ? blk[(unsigned)w * 64u + lane] : 0ull;
+#pragma unroll
+        for (int w = 0; w < MW; w++) L.row[w][lane] = r[w];
+        if (active) {
+            typename S::Local loc;
+            const RegRow<MW> rr{r};
+            S::load(prm, rr, loc);
+            const unsigned ps = S::parent_status(prm, loc, rr);
+            if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
+            typename S::Summary q;
+            S::summarize(loc, q);
+            L.sum[lane] = q;
+            if (!(flags & 64u)) S::guards(prm, loc, glo, ghi);  // (64 = ablation: load the parents only)
+        }
+    }
+    if (lane < 2) L.succ[lane] = 0;
+    const bool track_succ = (flags & MC_F_DEADLOCK) != 0;
+
+    // ---- rounds: all pairs at once when they fit the list, else S::PAIR_ROUNDS rounds
+    const unsigned total_all = wave_sum_u32((unsigned)__popcll(glo) + (unsigned)__popcll(ghi));
+    const bool single = total_all <= (unsigned)PAIR_CAP;
+    const int nrounds = single ? 1 : S::PAIR_ROUNDS;
+    for (int round = 0; round < nrounds; ++round) {
+        uint64_t mlo = glo, mhi = ghi;
+        if (!single) {
+            uint64_t rlo = 0, rhi = 0;
+            static_for<0, S::PAIR_ROUNDS>([&](auto rc) {
+                if (round == decltype(rc)::value) {
+                    constexpr auto rm = S::round_mask(decltype(rc)::value);
+                    rlo = rm.lo; rhi = rm.hi;
+                }
+            });
+            mlo &= rlo;
+            mhi &= rhi;
+        }
+        // per-family counts of this lane, 16 bits each; inclusive scan over the lanes
+        uint64_t cnt = 0;
+        static_for<0, NF>([&](auto fc) {
+            constexpr int F = decltype(fc)::value;
+            constexpr auto fm = S::family_mask(F);
+            cnt |= (uint64_t)((unsigned)__popcll(mlo & fm.lo) + (unsigned)__popcll(mhi & fm.hi)) << (16 * F);
+        });
+        uint64_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t u = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += u;
+        }
+        const uint64_t excl = incl - cnt;
+        const uint64_t tot = __shfl(incl, 63);
+        unsigned fs[NF + 1];  // family f's pairs: list[fs[f] .. fs[f + 1])
+        fs[0] = 0;
+#pragma unroll
+        for (int f = 0; f < NF; f++) fs[f + 1] = __builtin_amdgcn_readfirstlane(fs[f] + (unsigned)(tot >> (16 * f) & 0xffffu));
+        if (fs[NF] == 0) continue;
+        wave_lds_fence();  // (the previous round's list has been read)
+        static_for<0, NF>([&](auto fc) {
+            constexpr int F = decltype(fc)::value;
+            constexpr auto fm = S::family_mask(F);
+            unsigned pos = fs[F] + (unsigned)(excl >> (16 * F) & 0xffffu);
+            uint64_t a = mlo & fm.lo, b = mhi & fm.hi;
+            while (a) {
+                const unsigned s = (unsigned)__builtin_ctzll(a);
+                a &= a - 1;
+                L.list[pos++] = (uint16_t)((s << 6) | lane);
+            }
+            while (b) {
+                const unsigned s = 64u + (unsigned)__builtin_ctzll(b);
+                b &= b - 1;
+                L.list[pos++] = (uint16_t)((s << 6) | lane);
+            }
+        });
+        wave_lds_fence();
+
+        unsigned nsurv = 0;
+        unsigned long long out0 = 0;
+        bool write_ok = true;
+        for (int pass = 0; pass < 2; ++pass) {
+            unsigned run = 0;  // pass 2: survivors written so far
+            static_for<0, NF>([&](auto fc) {
+                constexpr int F = decltype(fc)::value;
+                for (unsigned b = fs[F]; b < fs[F + 1]; b += 64) {
+                    const unsigned i = b + lane;
+                    const bool mine = i < fs[F + 1];
+                    const unsigned e = mine ? (unsigned)L.list[i] : PAIR_DEAD;
+                    const bool live = e != PAIR_DEAD;
+                    const unsigned long long bl = __ballot(live);
+                    if (!bl) continue;
+                    const unsigned p = e & 63u;
+                    const int slot = (int)(e >> 6);
+                    unsigned st = 0;
+                    uint64_t fp = 0;
+                    typename S::PairOut po;
+                    const LdsRow row{(const __attribute__((address_space(3))) uint64_t *)&L.row[0][p]};
+                    if (live) st = S::template eval_pair<F>(prm, L.sum[p], row, slot, fp, po);
+                    if (pass == 0) {
+                        const uint64_t pidx = idx - lane + p;
+                        uint64_t key = 0;
+                        if (st & ST_ENABLED) {
+                            ++gen;
+                            if (track_succ) atomicOr(&L.succ[p >> 5], 1u << (p & 31u));
+                            if (st & ST_OVERFLOW) err |= DEV_EOVERFLOW;
+                            else if (st & ST_ASSERT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_ASSERT, 0));
+                            else if (st & ST_SPECERR) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_SPECERR, 0));
+                            else {
+                                if (st & ST_INVARIANT) viol = min(viol, viol_key(pidx, (unsigned)slot, VK_INVARIANT, st >> 8));
+                                if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) key = fp;
+                            }
+                        }
+                        bool is_new = false;
+                        if (key) {
+                            ++cands;
+                            is_new = (flags & 16u) ? false : seen_insert(table, mask, key, err);  // (16 = ablation: no probes)
+                        }
+                        if (live && !is_new) L.list[i] = (uint16_t)PAIR_DEAD;
+                        nsurv += (unsigned)__popcll(__ballot(is_new));
+                    } else if (write_ok) {
+                        const uint64_t oidx = out0 + run + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
+                        if (live) {
+                            S::write_pair(prm, row, po, arena_ref(rt.arena_w, oidx, W));
+                            if (rt.parent) { rt.parent[oidx] = (uint32_t)(idx - lane + p); rt.pslot[oidx] = (uint16_t)slot; }
+                        }
+                        run += (unsigned)__popcll(bl);
+                    }
+                }
+            });
+            if (pass == 0) {
+                if (!nsurv) break;
+                wave_lds_fence();  // the struck entries are visible to the lanes that read them in pass 2
+                if (lane == 0) out0 = atomicAdd(&ctr->arena_next, (unsigned long long)nsurv);
+                out0 = __shfl(out0, 0);
+                if (out0 + nsurv > rt.arena_cap) { err |= DEV_EARENA; write_ok = false; }
+            }
+        }
+    }
+
+    if (track_succ) {
+        wave_lds_fence();
+        if (active && !(L.succ[lane >> 5] >> (lane & 31u) & 1u)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
+    }
+    const unsigned gsum = wave_sum_u32(gen), csum = wave_sum_u32(cands);
+    const unsigned long long vmin = wave_min_u64(viol);
+    const unsigned eor = wave_or_u32(err);
+    if (lane == 0) {
+        if (gsum) atomicAdd(&ctr->generated[shard].v, (unsigned long long)gsum);
+        if (csum) atomicAdd(&ctr->cells[shard].v, (unsigned long long)csum);
+        if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
+        if (eor) atomicOr(&ctr->error, eor);
+    }
+}
+
+// launch_expand's door (declared in engine_kernels.h): true = launched
+template <class S>
+static bool launch_expand_pairs(hipStream_t stream, typename S::Params prm, const uint64_t *arena, uint64_t lo, uint64_t hi, uint64_t ncols, uint64_t *table,
+                                uint64_t mask, uint32_t *, uint64_t, DevCounters *ctr, unsigned flags, RouteArgs rt, unsigned) {
+    if constexpr (UsesPairs<S>::value) {
+        if (!rt.arena_w) return false;  // (route mode, the re-expansion ablation: the slot-by-slot kernel)
+        constexpr unsigned WG = 64u * MC_PAIR_WAVES;
+        hipLaunchKernelGGL((k_expand_pairs<S>), dim3((unsigned)((ncols + WG - 1) / WG)), dim3(WG), 0, stream, prm, arena, lo, hi, ncols, table, mask, ctr, flags, rt);
+        return true;
+    } else {
+        return false;
+    }
+}
+
+}  // namespace mc
+
+#endif  // TLAMC_ENGINE_PAIRS_H

@@ -264,24 +264,29 @@ struct SpecSsi {
         for (int o = 0; o < NT; o++) if (owners >> o & 1u) d.meta |= 1ull << (8 + 10 * o + 6);  // outConflict'[o] = TRUE
     }
 
-    MC_HD static unsigned compute(const Params &p, const Local &l, int slot, Delta &d, int &action) {
-        d.meta = l.meta; d.nev = 0; d.ev[0] = d.ev[1] = d.ev[2] = d.ev[3] = 0;
+    // The next-state relation by ACTION FAMILY (each a straight-line function the by-pairs kernel, engine_pairs.h, runs 64 lanes wide;
+    // compute() below dispatches a slot to its family for the slot-by-slot kernel, the writers and the host).  A family function
+    // returns false when the guard fails, true with the delta otherwise; finish_delta() closes an enabled delta.
+    //   family 0: Begin(txn) :423-426 | Commit(txn) :429-491 | ChooseToAbort(txn) :494-496 | LegitimateTermination :963,996
+    //   family 1: Read(txn, key) :525-626
+    //   family 2: StartWriteMayBlock(txn, key) :883-911 (choice c of the deadlock victim) | FinishBlockedWrite(txn) :923-927
+    MC_HD static bool compute_simple(const Params &p, const Local &l, int slot, Delta &d, int &action) {
         if (slot == NT * PER_TXN) {  // LegitimateTermination /\ UNCHANGED allvars :963,996
             action = SA_TERMINATED;
             const unsigned all = (1u << p.nt) - 1u;
-            return ((l.committed | l.aborted) & all) == all ? (unsigned)ST_ENABLED : 0u;
+            return ((l.committed | l.aborted) & all) == all;
         }
         const int txn = slot / PER_TXN, sub = slot % PER_TXN;
-        if (txn >= p.nt) return 0;
+        if (txn >= p.nt) return false;
         const unsigned me = m_txn(l.meta, txn);
         if (sub == 0) {  // Begin(txn) :423-426
             action = SA_BEGIN;
-            if (l.started >> txn & 1u) return 0;
+            if (l.started >> txn & 1u) return false;
             // SYMMETRY over TxnId: the representative of the successor's orbit begins the lowest unstarted transaction
             d_append(d, mk_event(OP_BEGIN, (p.sym & 1) ? (int)__builtin_popcount(l.started) : txn, 0, 0, 0));
         } else if (sub == 1) {  // Commit(txn) :429-491
             action = SA_COMMIT;
-            if (!can_do(l, txn)) return 0;
+            if (!can_do(l, txn)) return false;
             if (!p.textbook && t_in(me) && t_out(me)) internal_abort(d, txn, R_COMMIT);
             else {
                 d_append(d, mk_event(OP_COMMIT, txn, 0, 0, 0));
@@ -295,105 +300,125 @@ struct SpecSsi {
                     }
                 }
             }
-        } else if (sub == 2) {  // ChooseToAbort(txn) :494-496
+        } else {  // ChooseToAbort(txn) :494-496
             action = SA_ABORT;
-            if (!can_do(l, txn)) return 0;
+            if (!can_do(l, txn)) return false;
             internal_abort(d, txn, R_VOLUNTARY);
-        } else if (sub == 3) {  // FinishBlockedWrite(txn) :923-927
+        }
+        return true;
+    }
+    MC_HD static bool compute_read(const Params &p, const Local &l, int slot, Delta &d, int &action) {  // Read(txn, key) :525-626
+        const int txn = slot / PER_TXN, key = slot % PER_TXN - 4;
+        action = SA_READ;
+        if (txn >= p.nt || key >= p.nk || !can_do(l, txn) || (l.rkeys >> (4 * txn + key) & 1u)) return false;
+        const int ver = version_read_by(p, l, txn, key);
+        if (ver < 0) return false;  // no version yet: in particular an untouched key is never read, so Read needs no SYMMETRY alias
+        const unsigned newer = newer_versions(p, l, key, ver);
+        bool danger = false;
+#pragma unroll
+        for (int x = 0; x < NT; x++) if ((newer >> x & 1u) && (l.committed >> x & 1u) && t_out(m_txn(l.meta, x))) danger = true;
+        if (p.textbook) d_append(d, mk_event(OP_READ, txn, key, ver, 0));  // textbookSnapshotIsolation.tla:365-378
+        else if (danger) internal_abort(d, txn, R_READ);
+        else {
+            d_append(d, mk_event(OP_READ, txn, key, ver, 0));
+            unsigned lockers = 0;
+#pragma unroll
+            for (int x = 0; x < NT; x++) if (x < p.nt && x != txn && (t_xl(m_txn(l.meta, x)) >> key & 1u)) lockers |= 1u << x;
+#pragma unroll
+            for (int x = 0; x < NT; x++) if ((newer | lockers) >> x & 1u) d.meta |= 1ull << (8 + 10 * x + 5);  // inConflict'[x] = TRUE
+            d.meta |= (uint64_t)(1u << key) << (8 + 10 * txn + 7);                                                // SIREAD lock
+            if (newer | lockers) d.meta |= 1ull << (8 + 10 * txn + 6);                                            // outConflict'[txn]
+        }
+        return true;
+    }
+    MC_HD static bool compute_write(const Params &p, const Local &l, int slot, Delta &d, int &action) {
+        const int txn = slot / PER_TXN, sub = slot % PER_TXN;
+        if (txn >= p.nt) return false;
+        const unsigned me = m_txn(l.meta, txn);
+        unsigned anylocked = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++) anylocked |= t_xl(m_txn(l.meta, t));
+        if (sub == 3) {  // FinishBlockedWrite(txn) :923-927
             action = SA_FINISH;
             const unsigned key = t_wait(me);
-            if (key == NOLOCK) return 0;
-            unsigned anylocked = 0;
-#pragma unroll
-            for (int t = 0; t < NT; t++) anylocked |= t_xl(m_txn(l.meta, t));
-            if (anylocked >> key & 1u) return 0;
+            if (key == NOLOCK) return false;
+            if (anylocked >> key & 1u) return false;
             write_can_acquire(p, l, txn, (int)key, d);
-        } else if (sub < 4 + NK) {  // Read(txn, key) :525-626
-            const int key = sub - 4;
-            action = SA_READ;
-            if (key >= p.nk || !can_do(l, txn) || (l.rkeys >> (4 * txn + key) & 1u)) return 0;
-            const int ver = version_read_by(p, l, txn, key);
-            if (ver < 0) return 0;  // no version yet: in particular an untouched key is never read, so Read needs no SYMMETRY alias
-            const unsigned newer = newer_versions(p, l, key, ver);
-            bool danger = false;
-#pragma unroll
-            for (int x = 0; x < NT; x++) if ((newer >> x & 1u) && (l.committed >> x & 1u) && t_out(m_txn(l.meta, x))) danger = true;
-            if (p.textbook) d_append(d, mk_event(OP_READ, txn, key, ver, 0));  // textbookSnapshotIsolation.tla:365-378
-            else if (danger) internal_abort(d, txn, R_READ);
-            else {
-                d_append(d, mk_event(OP_READ, txn, key, ver, 0));
-                unsigned lockers = 0;
-#pragma unroll
-                for (int x = 0; x < NT; x++) if (x < p.nt && x != txn && (t_xl(m_txn(l.meta, x)) >> key & 1u)) lockers |= 1u << x;
-#pragma unroll
-                for (int x = 0; x < NT; x++) if ((newer | lockers) >> x & 1u) d.meta |= 1ull << (8 + 10 * x + 5);  // inConflict'[x] = TRUE
-                d.meta |= (uint64_t)(1u << key) << (8 + 10 * txn + 7);                                                // SIREAD lock
-                if (newer | lockers) d.meta |= 1ull << (8 + 10 * txn + 6);                                            // outConflict'[txn]
-            }
-        } else {  // StartWriteMayBlock(txn, key) :883-911, choice c of the deadlock victim
-            const int key = (sub - 4 - NK) / NT, c = (sub - 4 - NK) % NT;
-            action = SA_WRITE;
-            if (key >= p.nk || !can_do(l, txn) || (t_xl(me) >> key & 1u)) return 0;
-            if (p.sym & 2) {  // SYMMETRY over Key: writing an untouched key = writing the lowest untouched key
-                unsigned ks = l.rkeys | l.wkeys;
-                ks = (ks | ks >> 4 | ks >> 8 | ks >> 12) & 7u;
-                if (!(ks >> key & 1u)) {  // untouched: nobody wrote, locked or SIREAD-locked it, so :897-911 reduces to the plain write
-                    if (c) return 0;
-                    write_can_acquire(p, l, txn, (int)__builtin_popcount(ks), d);
-                    if (l.n + d.nev > HCAP) return ST_ENABLED | ST_OVERFLOW;
-                    d.meta = (d.meta & ~63ull) | (uint64_t)(l.n + d.nev);
-                    return ST_ENABLED;
-                }
-            }
-            unsigned anylocked = 0;
-#pragma unroll
-            for (int t = 0; t < NT; t++) anylocked |= t_xl(m_txn(l.meta, t));
-            if (writers_since(p, l, txn, key)) {  // lost First Committer Wins :897-905 (waitingForXLock unchanged = NoLock)
-                if (c) return 0;
-                d_append(d, mk_event(OP_ABORT, txn, 0, 0, R_FCW));
-                d.meta = m_set_txn(d.meta, txn, mk_txn(0, NOLOCK, 0, 0, 0));
-            } else if (anylocked >> key & 1u) {  // HelperWriteConflictsWithXLock :774-880
-                // follow "waits for the holder of" edges from txn (at most one per transaction)
-                unsigned path = 1u << txn;  // members of pathThatCyclesFromTxnToTxn, if it cycles
-                int from = txn;
-                unsigned want = (unsigned)key;
-                bool cycle = false;
-#pragma unroll
-                for (int step = 0; step < NT; step++) {
-                    int to = -1;
-#pragma unroll
-                    for (int t = 0; t < NT; t++) if (to < 0 && is_active(l, t) && (t_xl(m_txn(l.meta, t)) >> want & 1u)) to = t;
-                    if (to < 0) break;                 // dead end: no cycle
-                    if (to == txn) { cycle = true; break; }
-                    path |= 1u << to;
-                    from = to;
-                    want = t_wait(m_txn(l.meta, from));
-                    if (want == NOLOCK) break;
-                }
-                (void)from;
-                if (!cycle) {
-                    if (c) return 0;
-                    d.meta = m_set_txn(d.meta, txn, mk_txn(t_xl(me), (unsigned)key, t_in(me), t_out(me), t_sir(me)));
-                } else {  // \E to_abort \in Range(path) :851: c-th member in ascending order
-                    int victim = -1, seen = 0;
-#pragma unroll
-                    for (int t = 0; t < NT; t++) if (path >> t & 1u) { if (seen == c) victim = t; seen++; }
-                    if (victim < 0) return 0;
-                    d_append(d, mk_event(OP_ABORT, victim, 0, 0, R_DEADLOCK));
-                    if (victim == txn) d.meta = m_set_txn(d.meta, txn, mk_txn(0, t_wait(me), 0, 0, 0));
-                    else {
-                        d.meta = m_set_txn(d.meta, victim, mk_txn(0, NOLOCK, 0, 0, 0));
-                        d.meta = m_set_txn(d.meta, txn, mk_txn(t_xl(me), (unsigned)key, t_in(me), t_out(me), t_sir(me)));
-                    }
-                }
-            } else {
-                if (c) return 0;
-                write_can_acquire(p, l, txn, key, d);
+            return true;
+        }
+        // StartWriteMayBlock(txn, key) :883-911, choice c of the deadlock victim
+        const int key = (sub - 4 - NK) / NT, c = (sub - 4 - NK) % NT;
+        action = SA_WRITE;
+        if (key >= p.nk || !can_do(l, txn) || (t_xl(me) >> key & 1u)) return false;
+        if (p.sym & 2) {  // SYMMETRY over Key: writing an untouched key = writing the lowest untouched key
+            unsigned ks = l.rkeys | l.wkeys;
+            ks = (ks | ks >> 4 | ks >> 8 | ks >> 12) & 7u;
+            if (!(ks >> key & 1u)) {  // untouched: nobody wrote, locked or SIREAD-locked it, so :897-911 reduces to the plain write
+                if (c) return false;
+                write_can_acquire(p, l, txn, (int)__builtin_popcount(ks), d);
+                return true;
             }
         }
+        if (writers_since(p, l, txn, key)) {  // lost First Committer Wins :897-905 (waitingForXLock unchanged = NoLock)
+            if (c) return false;
+            d_append(d, mk_event(OP_ABORT, txn, 0, 0, R_FCW));
+            d.meta = m_set_txn(d.meta, txn, mk_txn(0, NOLOCK, 0, 0, 0));
+        } else if (anylocked >> key & 1u) {  // HelperWriteConflictsWithXLock :774-880
+            // follow "waits for the holder of" edges from txn (at most one per transaction)
+            unsigned path = 1u << txn;  // members of pathThatCyclesFromTxnToTxn, if it cycles
+            int from = txn;
+            unsigned want = (unsigned)key;
+            bool cycle = false;
+#pragma unroll
+            for (int step = 0; step < NT; step++) {
+                int to = -1;
+#pragma unroll
+                for (int t = 0; t < NT; t++) if (to < 0 && is_active(l, t) && (t_xl(m_txn(l.meta, t)) >> want & 1u)) to = t;
+                if (to < 0) break;                 // dead end: no cycle
+                if (to == txn) { cycle = true; break; }
+                path |= 1u << to;
+                from = to;
+                want = t_wait(m_txn(l.meta, from));
+                if (want == NOLOCK) break;
+            }
+            (void)from;
+            if (!cycle) {
+                if (c) return false;
+                d.meta = m_set_txn(d.meta, txn, mk_txn(t_xl(me), (unsigned)key, t_in(me), t_out(me), t_sir(me)));
+            } else {  // \E to_abort \in Range(path) :851: c-th member in ascending order
+                int victim = -1, seen = 0;
+#pragma unroll
+                for (int t = 0; t < NT; t++) if (path >> t & 1u) { if (seen == c) victim = t; seen++; }
+                if (victim < 0) return false;
+                d_append(d, mk_event(OP_ABORT, victim, 0, 0, R_DEADLOCK));
+                if (victim == txn) d.meta = m_set_txn(d.meta, txn, mk_txn(0, t_wait(me), 0, 0, 0));
+                else {
+                    d.meta = m_set_txn(d.meta, victim, mk_txn(0, NOLOCK, 0, 0, 0));
+                    d.meta = m_set_txn(d.meta, txn, mk_txn(t_xl(me), (unsigned)key, t_in(me), t_out(me), t_sir(me)));
+                }
+            }
+        } else {
+            if (c) return false;
+            write_can_acquire(p, l, txn, key, d);
+        }
+        return true;
+    }
+    MC_HD static void delta_init(const Local &l, Delta &d) { d.meta = l.meta; d.nev = 0; d.ev[0] = d.ev[1] = d.ev[2] = d.ev[3] = 0; }
+    MC_HD static unsigned finish_delta(const Local &l, Delta &d) {
         if (l.n + d.nev > HCAP) return ST_ENABLED | ST_OVERFLOW;
         d.meta = (d.meta & ~63ull) | (uint64_t)(l.n + d.nev);
         return ST_ENABLED;
+    }
+    MC_HD static int slot_family(int slot) {
+        if (slot == NT * PER_TXN) return 0;
+        const int sub = slot % PER_TXN;
+        return sub < 3 ? 0 : sub == 3 ? 2 : sub < 4 + NK ? 1 : 2;
+    }
+    MC_HD static unsigned compute(const Params &p, const Local &l, int slot, Delta &d, int &action) {
+        delta_init(l, d);
+        const int f = slot_family(slot);
+        const bool en = f == 0 ? compute_simple(p, l, slot, d, action) : f == 1 ? compute_read(p, l, slot, d, action) : compute_write(p, l, slot, d, action);
+        return en ? finish_delta(l, d) : 0u;
     }
 
     // the (at most two) history words the appended events land in
@@ -446,6 +471,135 @@ struct SpecSsi {
         for (int w = 1; w < MAX_WORDS; w++) f += hmix(out.get(w), salt_of((unsigned)w));
         out.set(W_FP, f);
         return st;
+    }
+
+    // ------------------------------------------------------------------ by-pairs protocol (engine_pairs.h: k_expand_pairs)
+    // The fused kernel of round 6.  Lane = parent builds the tables once (load), checks the invariants (parent_status) and computes a
+    // mask of the slots whose guard holds (guards: exact up to the deadlock-victim choices, see there); the enabled (parent, slot) PAIRS of
+    // the wavefront's 64 parents are then laid out family by family in LDS and evaluated 64 at a time — every lane busy, one family's
+    // code path — from the parent's Summary (the tables compute_* reads) and its row, both staged in LDS.  The same evaluation runs a
+    // second time for the pairs the seen-set accepted and writes their rows (the successor is parent + new meta + <= 2 history words).
+    static constexpr int PAIR_FAMILIES = 3;
+    static constexpr int PAIR_ROUNDS = NT;        // a wavefront whose pairs overflow its list works transaction by transaction
+    static constexpr int PAIR_ROUND_SLOTS = PER_TXN + 1;  // ... at most this many slots per parent and round
+    struct Summary {
+        uint32_t masks;  // started | committed << 4 | aborted << 8
+        uint32_t bidx, cidx, rkeys, wkeys, widx0, widx1, widx2;
+    };
+    MC_HD static void summarize(const Local &l, Summary &q) {
+        q.masks = l.started | l.committed << 4 | l.aborted << 8;
+        q.bidx = l.bidx; q.cidx = l.cidx; q.rkeys = l.rkeys; q.wkeys = l.wkeys;
+        q.widx0 = l.widx0; q.widx1 = l.widx1; q.widx2 = l.widx2;
+    }
+    // the fields of Local the family functions read (the read positions / versions are the invariants' only)
+    MC_HD static void local_of(const Summary &q, uint64_t fp, uint64_t meta, Local &l) {
+        l.fp = fp; l.meta = meta; l.n = m_len(meta);
+        l.started = q.masks & 15u; l.committed = q.masks >> 4 & 15u; l.aborted = q.masks >> 8 & 15u;
+        l.bidx = q.bidx; l.cidx = q.cidx; l.rkeys = q.rkeys; l.wkeys = q.wkeys;
+        l.widx0 = q.widx0; l.widx1 = q.widx1; l.widx2 = q.widx2;
+        l.ridx0 = l.ridx1 = l.ridx2 = l.rver0 = l.rver1 = l.rver2 = 0; l.abort_reasons = 0; l.wellformed = true;
+    }
+    // slots of family f / of round r (transaction r; the termination slot rides with transaction 0) as 128-bit masks (lo: slots 0..63,
+    // hi: 64..76); constexpr, so that the kernel's masks are immediates
+    struct SlotMask { uint64_t lo, hi; };
+    MC_HD static constexpr SlotMask family_mask(int f) {
+        SlotMask m{0, 0};
+        for (int s = 0; s < TOTAL_SLOTS; s++) {
+            const int sub = s % PER_TXN;
+            const int fam = s == NT * PER_TXN ? 0 : sub < 3 ? 0 : sub == 3 ? 2 : sub < 4 + NK ? 1 : 2;
+            if (fam == f) { if (s < 64) m.lo |= 1ull << s; else m.hi |= 1ull << (s - 64); }
+        }
+        return m;
+    }
+    MC_HD static constexpr SlotMask round_mask(int r) {
+        SlotMask m{0, 0};
+        for (int s = 0; s < TOTAL_SLOTS; s++)
+            if (s == NT * PER_TXN ? r == 0 : s / PER_TXN == r) { if (s < 64) m.lo |= 1ull << s; else m.hi |= 1ull << (s - 64); }
+        return m;
+    }
+    // GUARDS: bit s set <= compute(slot s) may be enabled; EXACT (bit s set <=> enabled) for every slot but the deadlock-victim choices
+    // c >= 1 of StartWriteMayBlock, which are offered whenever the key's holder is itself waiting (the cycle search stays in compute_write)
+    MC_HD static void guards(const Params &p, const Local &l, uint64_t &lo, uint64_t &hi) {
+        lo = hi = 0;
+        auto put = [&](int s) { if (s < 64) lo |= 1ull << s; else hi |= 1ull << (s - 64); };
+        const unsigned all = (1u << p.nt) - 1u;
+        if (((l.committed | l.aborted) & all) == all) put(NT * PER_TXN);
+        unsigned anylocked = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++) anylocked |= t_xl(m_txn(l.meta, t));
+        unsigned ks = l.rkeys | l.wkeys;  // keys touched (SYMMETRY over Key)
+        ks = (ks | ks >> 4 | ks >> 8 | ks >> 12) & 7u;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (t >= p.nt) continue;
+            const int b = t * PER_TXN;
+            const unsigned me = m_txn(l.meta, t);
+            if (!(l.started >> t & 1u)) put(b + 0);
+            const unsigned wk = t_wait(me);
+            if (wk != NOLOCK && !(anylocked >> wk & 1u)) put(b + 3);
+            if (!can_do(l, t)) continue;
+            put(b + 1);
+            put(b + 2);
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                if (k >= p.nk) continue;
+                if (!(l.rkeys >> (4 * t + k) & 1u) && version_read_by(p, l, t, k) >= 0) put(b + 4 + k);
+                if (t_xl(me) >> k & 1u) continue;
+                put(b + 4 + NK + NT * k);  // c = 0: always some successor (plain write / abort / block / first victim)
+                if ((p.sym & 2) && !(ks >> k & 1u)) continue;
+                if (!(anylocked >> k & 1u)) continue;
+                bool holder_waits = false;  // a cycle through k's holder needs the holder to wait for a lock itself
+#pragma unroll
+                for (int o = 0; o < NT; o++) if (is_active(l, o) && (t_xl(m_txn(l.meta, o)) >> k & 1u) && t_wait(m_txn(l.meta, o)) != NOLOCK) holder_waits = true;
+                if (holder_waits)
+                    for (int c = 1; c < p.nt; c++) put(b + 4 + NK + NT * k + c);
+            }
+        }
+    }
+    MC_HD static bool guard_is_exact(int slot) {  // every slot but the victim choices c >= 1 of StartWriteMayBlock
+        if (slot == NT * PER_TXN) return true;
+        const int sub = slot % PER_TXN;
+        return sub < 4 + NK || (sub - 4 - NK) % NT == 0;
+    }
+    // what a pair's evaluation hands to the writer: the successor's meta word and the (at most two) history words the events land in
+    struct PairOut {
+        uint64_t raw_fp, meta, newa, newb;  // raw_fp: word 0 of the successor (the raw additive sum; the seen-set key is fp_nonzero of it)
+        int wa, nev;
+    };
+    // evaluation of one (parent, slot) pair of family F from the parent's Summary + row (any Ref with get(w)); fp = successor's fingerprint
+    template <int F, class Ref>
+    MC_HD static unsigned eval_pair(const Params &p, const Summary &q, Ref row, int slot, uint64_t &fp, PairOut &o) {
+        Local l;
+        local_of(q, row.get(W_FP), row.get(W_META), l);
+        Delta d;
+        delta_init(l, d);
+        int action;
+        const bool en = F == 0 ? compute_simple(p, l, slot, d, action) : F == 1 ? compute_read(p, l, slot, d, action) : compute_write(p, l, slot, d, action);
+        if (!en) return 0;
+        const unsigned st = finish_delta(l, d);
+        if (st & ST_OVERFLOW) { fp = 1; return st; }
+        uint64_t olda;
+        touched(l, row, d, o.wa, olda, o.newa, o.newb);
+        o.meta = d.meta;
+        o.nev = d.nev;
+        uint64_t f = l.fp + hmix(d.meta, salt_of(W_META)) - hmix(l.meta, salt_of(W_META));
+        if (o.newa != olda) f += hmix(o.newa, salt_of((unsigned)(W_H0 + o.wa))) - hmix(olda, salt_of((unsigned)(W_H0 + o.wa)));
+        if (o.newb) f += hmix(o.newb, salt_of((unsigned)(W_H0 + o.wa + 1))) - hmix(0, salt_of((unsigned)(W_H0 + o.wa + 1)));
+        o.raw_fp = f;
+        fp = fp_nonzero(f);
+        return st;
+    }
+    template <class Ref>
+    MC_HD static void write_pair(const Params &, Ref row, const PairOut &o, WordRef out) {
+        out.set(W_FP, o.raw_fp);
+        out.set(W_META, o.meta);
+#pragma unroll
+        for (int w = 0; w < HWORDS; w++) {
+            uint64_t v = row.get(W_H0 + w);
+            if (o.nev && w == o.wa) v = o.newa;
+            if (o.newb && w == o.wa + 1) v = o.newb;
+            out.set(W_H0 + w, v);
+        }
     }
 
     // ------------------------------------------------------------------ invariants, per expanded state
