@@ -161,13 +161,111 @@ def comm_id(rank, world):
     return bytes(uid), store
 
 
-def kernel_source_hash():
-    """the stamp profiles/summarize_pmc.py puts into a PMC summary: the kernel sources the counters were collected on"""
+KERNEL_SOURCES = {"raft": ["engine_kernels.h", "spec_raft.h", "mc_common.h"],
+                  "ssi": ["engine_kernels.h", "engine_pairs.h", "spec_ssi.h", "mc_common.h"],
+                  "vm": ["engine_kernels.h", "spec_vm.h", "mc_common.h"]}
+
+
+def kernel_source_hash(spec="raft"):
+    """the stamp profiles/summarize_pmc.py puts into a PMC summary: the kernel sources of ONE spec the counters were collected on (the
+    engine's kernels + that spec's lowering; the by-pairs kernel has its own file, so that the raft stamp does not move with it)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tla_rust_amd/csrc/engine_kernels.h", "tla_rust_amd/csrc/spec_raft.h", "tla_rust_amd/csrc/mc_common.h"):
-        h.update((ROOT / f).read_bytes())
+    for f in KERNEL_SOURCES[spec]:
+        if (ROOT / "tla_rust_amd" / "csrc" / f).exists():
+            h.update((ROOT / "tla_rust_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
+
+
+def pmc_for(spec, stag, knames):
+    """the newest profiles/r*_pmc.json that was collected on THIS tree's kernel sources of `spec` and holds a kernel named knames[i]<..stag..>:
+    (file name, that kernel's counters) or (reason, None).  Counters of other kernels say nothing about the ones timed here."""
+    want = kernel_source_hash(spec)
+    seen = []
+    for f in sorted((ROOT / "profiles").glob("r*_pmc.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text())
+        except ValueError:
+            continue
+        src = d.get("__source__", {})
+        if src.get("spec", "raft") != spec:
+            continue
+        if src.get("hash") != want:
+            seen.append(f"{f.name} was collected on kernel sources {src.get('hash')}")
+            continue
+        k = next((v for kn in knames for n, v in d.items() if n.startswith(kn + "<") and stag in n), None)
+        if k is not None:
+            return f.name, k
+    return "none: " + ("; ".join(seen[:2]) if seen else f"no profiles/r*_pmc.json of spec {spec}") + f" (the timed sources are {want})", None
+
+
+def kernel_roofline(ks, dt, spec, stag, slots, arena_states, generated, expand_kernel, no_family=False, matrix=False, dense_table=False):
+    """The `roofline` object of a fused one-GPU run: the dominant kernel by summed HIP-event time, its algorithmic bytes over that time,
+    the measured traffic / L2 hit rate / instructions per successor from the separate rocprofv3 --pmc passes of the same command (when a
+    summary stamped with this tree's kernel sources exists), and the pipeline-level figure over the wall time of a step."""
+    W = ks["state_bytes"]
+    inwave = ks.get("inwave_states", 0)   # states the expand wavefronts wrote themselves: their W bytes are that kernel's
+    expanded, written = ks["expand"]["units"], ks["materialise"]["units"]   # states read as parents / states in the arena at the end
+    alg = {"expand": W * expanded + W * inwave, "insert": 8 * ks["cand_cells"], "materialise": W * (written - inwave)}
+    state_only = alg["expand"]
+    if not matrix:  # the seen-set insert is FUSED into the expand kernel: its 8 bytes per look-up (SURVEY 8d's G x 8 term, counted
+        alg["expand"] += 8 * ks["cand_cells"]   # on the in-model, state-changing successors: the ones that ARE looked up) are that kernel's
+    dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
+    ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
+    knames = {"expand": ("k_expand_insert",) if no_family else ("k_expand_family", "k_expand_pairs", "k_expand_insert"),
+              "insert": ("k_insert",), "materialise": ("k_materialise",)}[dom]
+    traffic, traffic_lower, l2_hit, l2_miss_rate, valu, salu, wait = None, None, None, None, None, None, None
+    traffic_src, k = pmc_for(spec, stag, knames)
+    if k is not None:
+        # FETCH_SIZE / WRITE_SIZE are in KB.  Calibration on this box (profiles/r02e_calib_*.json*, profiles/calib/calib_fetch.hip):
+        # FETCH_SIZE = read requests x 64 B; the arena's 8 B/lane row reads and 16 B/lane streaming reads are 128-B
+        # requests (FETCH_SIZE = exactly 1/2 of the known bytes, as MI355X_MICROARCH.md says), a random 64-byte seen-set
+        # bucket probe is ONE request (request size not observable); WRITE_SIZE equals the known bytes.  `traffic`
+        # applies the guide's x2 to every read request (upper bound), `traffic_lower` counts a probe's request as 64 B.
+        traffic = (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
+        traffic_lower = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
+        l2_hit = k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) if "TCC_HIT_sum" in k else None
+        if "TCC_MISS_sum" in k and ks[dom]["ms_total"]:   # (counters of ONE step against the timed step's kernel time: the same launches)
+            l2_miss_rate = k["TCC_MISS_sum"] / k["launches"] * ks[dom]["launches"] / (ks[dom]["ms_total"] * 1e-3) / 1e9
+        if "SQ_INSTS_VALU" in k and generated:   # wave-instructions per generated successor (the counter passes ran ONE step)
+            valu, salu = k["SQ_INSTS_VALU"] / generated, k.get("SQ_INSTS_SALU", 0) / generated
+        if "SQ_WAIT_ANY" in k and k.get("SQ_WAVE_CYCLES"):
+            wait = k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]
+        traffic_src = f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes of this command"
+    kernel_name = {"expand": expand_kernel, "insert": "k_insert", "materialise": f"k_materialise<{stag}>"}[dom]
+    # what the step really moves (a level-budgeted run never reads its last level): W x states read as parents + W x states written
+    # + 8 x look-ups, over the WALL time of a step; `pipeline_frac_2WD` = SURVEY.md 8d's literal (2 W D + 8 G), which charges a read of
+    # the unexpanded last level (87 % of config 5's states) and counts every generated successor as a look-up
+    moved = W * expanded + W * written + 8 * ks["cand_cells"]
+    return {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_lower": traffic_lower, "l2_hit_rate": l2_hit, "traffic_source": traffic_src,
+            "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
+            "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
+            "seen_set_lookups": ks["cand_cells"], "states_expanded": expanded, "states_written": written,
+            "inwave_states": inwave,
+            "alg_bytes": ("W x states expanded + W x states written in-wave + 8 x seen-set look-ups (in-model, state-changing successors; insert and write are fused into this kernel)" if dom == "expand" and not matrix
+                          else "W x units"),
+            "frac_state_bytes_only": (state_only / (ks[dom]["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == "expand" and ks[dom]["ms_total"] else None,
+            # the practical ceiling SURVEY 8d asks for: a probe moves a whole bucket (32 bytes in a sparse table, 64 in a full one)
+            "probe_bytes": 32 if slots >= 3 * arena_states and not dense_table else 64,
+            "kernel_ms": {k_: ks[k_]["ms_total"] for k_ in ("expand", "insert", "materialise")},
+            "valu_per_successor": valu, "salu_per_successor": salu, "wait_frac_of_wave_cycles": wait,
+            "pipeline_GBs": moved / dt / 1e9, "pipeline_frac": moved / dt / 1e9 / HBM_PEAK_GBS,
+            "pipeline_frac_2WD": (2 * W * written + 8 * generated) / dt / 1e9 / HBM_PEAK_GBS,
+            "pipeline_bytes": "W x states expanded + W x states written + 8 x seen-set look-ups over the wall time of a step (pipeline_frac_2WD: SURVEY 8d's literal 2 W D + 8 G)",
+            "state_bytes": W,
+            # the MEASURED random-access ceiling of the device (RANDOM_REQ_CEILING above) and what this kernel asks of the memory
+            # system: L2 misses (probes, rows, parent rows the writer comes back for) + memory-side atomics per second of kernel time
+            "random_access_ceiling_GBs": 32 * RANDOM_REQ_CEILING / 1e9, "random_access_ceiling_Greq_s": RANDOM_REQ_CEILING / 1e9,
+            "l2_miss_Greq_s": l2_miss_rate, "frac_of_request_ceiling": (l2_miss_rate / (RANDOM_REQ_CEILING / 1e9)) if l2_miss_rate else None,
+            "lookups_Gs": ks["cand_cells"] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if dom == "expand" and ks[dom]["ms_total"] else None}
+
+
+def expand_kernel_name(spec, params, no_family=False, matrix=False):
+    stag = "SpecSsi" if spec == "ssi" else "SpecRaft<%d>" % params[0]
+    if no_family or matrix or spec not in ("raft", "ssi"):
+        return stag, f"k_expand_insert<{stag}>"
+    return stag, (f"k_expand_family<{stag}>" if spec == "raft" else f"k_expand_pairs<{stag}>")
 
 
 def dist_roofline(state_bytes, distinct, generated, world, step_s):
@@ -314,12 +412,13 @@ def other_config(amd, device, key, steps=3):
         print(f"bench.py: {key}: run does not reproduce the golden state graph: got {got}, want {want}", file=sys.stderr)
         sys.exit(1)
     W, D, G = ks["state_bytes"], r.distinct, r.generated
+    stag, ek = expand_kernel_name(w["spec"], w["params"])
+    roof = kernel_roofline(ks, dt, w["spec"], stag, slots, G0["distinct"] + (1 << 20), G, ek)
     return {"workload": w["name"] + " — ONE GPU, fused engine (the 8-GPU form of this configuration is `bench.py --gpus 8 --workload " + key + "`)",
             "value": D / dt, "unit": "distinct states/s", "ms_per_step": 1e3 * dt, "steps": steps, "distinct": D, "generated": G, "depth": r.depth,
             "verdict": r.verdict, "state_bytes": W, "seen_set_load": D / float(slots), "inwave_states": ks.get("inwave_states", 0),
             "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
-            "pipeline_GBs": (2 * W * D + 8 * G) / dt / 1e9, "pipeline_frac": (2 * W * D + 8 * G) / dt / 1e9 / HBM_PEAK_GBS,
-            "alg_bytes": "SURVEY.md 8d: (2 W + 8 G/D) bytes per distinct state over the wall time of a step, against 8 TB/s",
+            "roofline": roof, "pipeline_GBs": roof["pipeline_GBs"], "pipeline_frac": roof["pipeline_frac"], "alg_bytes": roof["pipeline_bytes"],
             "golden": f"tests/golden/{w.get('golden_file', 'raft_levels.json')}:{w['golden']} (exact-dedup CPU oracle): counts and per-level counts equal"}
 
 
@@ -539,66 +638,9 @@ def main():
         comm.close()
     else:
         ks = eng.kernel_stats()
-        W = ks["state_bytes"]
-        STAG = "SpecSsi" if WORKLOAD["spec"] == "ssi" else "SpecRaft<%d>" % WORKLOAD["params"][0]   # the kernels' template argument
-        # algorithmic bytes per launch: expand reads W per frontier state,
-        # insert touches one 8-byte seen-set word per generated candidate, materialise writes W per new state
-        inwave = ks.get("inwave_states", 0)   # states the expand wavefronts wrote themselves (round 4): their W bytes are that kernel's
-        alg = {"expand": W * ks["expand"]["units"] + W * inwave, "insert": 8 * ks["cand_cells"], "materialise": W * (ks["materialise"]["units"] - inwave)}
-        state_only = alg["expand"]
-        if not a.matrix:  # the seen-set insert is FUSED into the expand kernel: its 8 bytes per look-up (SURVEY 8d's G x 8 term, counted
-            alg["expand"] += 8 * ks["cand_cells"]   # on the in-model, state-changing successors: the ones that ARE looked up) are that kernel's
-        dom = max(("expand", "insert", "materialise"), key=lambda k: ks[k]["ms_total"])
-        n_runs = a.steps  # stats are reset by every run(): they describe the last step
-        ach = alg[dom] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if ks[dom]["ms_total"] else 0.0
-        traffic, traffic_src, traffic_lower, l2_hit, l2_miss_rate = None, None, None, None, None
-        pmc = sorted(p for p in (ROOT / "profiles").glob("r*_pmc.json"))
-        if pmc:  # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same command
-            try:
-                d = json.loads(pmc[-1].read_text())
-                stamp = d.get("__source__", {}).get("hash")
-                if stamp != kernel_source_hash():   # counters of other kernels say nothing about the ones timed here
-                    raise ValueError(f"{pmc[-1].name} was collected on kernel sources {stamp}, the timed ones are {kernel_source_hash()}")
-                knames = {"expand": ("k_expand_insert",) if a.no_family else ("k_expand_family", "k_expand_insert"),
-                          "insert": ("k_insert",), "materialise": ("k_materialise",)}[dom]
-                k = next(v for kn in knames for n, v in d.items() if n.startswith(kn + "<") and STAG in n)
-                # FETCH_SIZE / WRITE_SIZE are in KB.  Calibration on this box (profiles/r02e_calib_*.json*, profiles/calib/calib_fetch.hip):
-                # FETCH_SIZE = read requests x 64 B; the arena's 8 B/lane row reads and 16 B/lane streaming reads are 128-B
-                # requests (FETCH_SIZE = exactly 1/2 of the known bytes, as MI355X_MICROARCH.md says), a random 64-byte seen-set
-                # bucket probe is ONE request (request size not observable); WRITE_SIZE equals the known bytes.  `traffic`
-                # applies the guide's x2 to every read request (upper bound), `traffic_lower` counts a probe's request as 64 B.
-                traffic = (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
-                traffic_lower = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024 / k["launches"]
-                l2_hit = k["TCC_HIT_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]) if "TCC_HIT_sum" in k else None
-                if "TCC_MISS_sum" in k and ks[dom]["ms_total"]:   # (counters of ONE step against the timed step's kernel time: the same 102 launches)
-                    l2_miss_rate = k["TCC_MISS_sum"] / k["launches"] * ks[dom]["launches"] / (ks[dom]["ms_total"] * 1e-3) / 1e9
-                traffic_src = f"profiles/{pmc[-1].name}: (2*FETCH_SIZE + WRITE_SIZE) per launch, separate --pmc passes of this command"
-            except Exception as e:  # noqa: BLE001
-                traffic, traffic_lower, l2_hit, l2_miss_rate = None, None, None, None
-                traffic_src = f"none: {e}"
-        kernel_name = {"expand": f"k_expand_insert<{STAG}>" if (a.no_family or a.matrix or WORKLOAD["spec"] != "raft") else f"k_expand_family<{STAG}>",
-                       "insert": "k_insert", "materialise": f"k_materialise<{STAG}>"}[dom]
-        line["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_lower": traffic_lower, "l2_hit_rate": l2_hit, "traffic_source": traffic_src,
-                            "launches": ks[dom]["launches"], "avg_launch_ms": ks[dom]["ms_total"] / max(1, ks[dom]["launches"]),
-                            "alg_bytes_per_launch": alg[dom] / max(1, ks[dom]["launches"]),
-                            "seen_set_lookups": ks["cand_cells"],
-                            "inwave_states": inwave,
-                            "alg_bytes": ("W x states expanded + W x states written in-wave + 8 x seen-set look-ups (in-model, state-changing successors; insert and write are fused into this kernel)" if dom == "expand" and not a.matrix
-                                          else "W x units"),
-                            "frac_state_bytes_only": (state_only / (ks[dom]["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == "expand" and ks[dom]["ms_total"] else None,
-                            # the practical ceiling SURVEY 8d asks for: a probe moves a whole bucket (32 bytes in a sparse table, 64 in a full one)
-                            "probe_bytes": 32 if slots >= 3 * (G0["distinct"] + (1 << 20)) and not a.dense_table else 64,
-                            "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
-                            # (2 W + 8 G/D) bytes per distinct state over the WALL time of a step
-                            "pipeline_GBs": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9,
-                            "pipeline_frac": (2 * W * D + 8 * G) / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
-                            "state_bytes": W,
-                            # the MEASURED random-access ceiling of the device (RANDOM_REQ_CEILING above) and what this kernel asks of the memory
-                            # system: L2 misses (probes, rows, parent rows the writer comes back for) + memory-side atomics per second of kernel time
-                            "random_access_ceiling_GBs": 32 * RANDOM_REQ_CEILING / 1e9, "random_access_ceiling_Greq_s": RANDOM_REQ_CEILING / 1e9,
-                            "l2_miss_Greq_s": l2_miss_rate, "frac_of_request_ceiling": (l2_miss_rate / (RANDOM_REQ_CEILING / 1e9)) if l2_miss_rate else None,
-                            "lookups_Gs": ks["cand_cells"] / (ks[dom]["ms_total"] * 1e-3) / 1e9 if dom == "expand" and ks[dom]["ms_total"] else None}
+        stag, ek = expand_kernel_name(WORKLOAD["spec"], WORKLOAD["params"], a.no_family, a.matrix)
+        line["roofline"] = kernel_roofline(ks, dt / a.steps, WORKLOAD["spec"], stag, slots, G0["distinct"] + (1 << 20), G, ek,
+                                           no_family=a.no_family, matrix=a.matrix, dense_table=a.dense_table)
         if not a.no_atomic_add and not a.max_distinct and a.workload == "t3":   # (the contract line carries both of north_star's workloads)
             eng.close()
             line["atomic_add"] = atomic_add_series(amd, local)

@@ -91,6 +91,10 @@ struct PairCheck<S, decltype((void)S::PAIR_FAMILIES)> {
         S::guards(p, l, glo, ghi);
         typename S::Summary q;
         S::summarize(l, q);
+        uint64_t staged[S::MAX_WORDS];  // the kernel's LDS copy of the row: word W_PAIR_BASE holds the pair base
+        for (int w = 0; w < S::MAX_WORDS; w++) staged[w] = w < S::words(p) ? s.get(w) : 0;
+        staged[S::W_PAIR_BASE] = S::pair_base(p, l, s);
+        const CWordRef srow{staged, 1};
         unsigned per_round[S::PAIR_ROUNDS] = {};
         for (int slot = 0; slot < ns; slot++) {
             const bool g = slot < 64 ? (glo >> slot & 1u) : (ghi >> (slot - 64) & 1u);
@@ -109,14 +113,14 @@ struct PairCheck<S, decltype((void)S::PAIR_FAMILIES)> {
             if ((st0 & ST_ENABLED) && !g) bad++;                                  // an enabled slot the guards miss: a lost successor
             if (!(st0 & ST_ENABLED) && g && S::guard_is_exact(slot)) bad++;       // (an idle lane, not an error of the search — but the contract says exact)
             typename S::PairOut o;
-            const unsigned st1 = run<0>(fam, p, q, s, slot, f1, o);
+            const unsigned st1 = run<0>(fam, p, q, srow, slot, f1, o);
             if (st0 != st1) { bad++; continue; }
             if (!(st0 & ST_ENABLED) || (st0 & ST_OVERFLOW)) continue;
             if (f0 != f1) bad++;
             uint64_t a[S::MAX_WORDS], b[S::MAX_WORDS];
             S::apply(p, s, slot, WordRef{a, 1});
             for (int w = 0; w < S::MAX_WORDS; w++) b[w] = ~0ull;
-            S::write_pair(p, s, o, WordRef{b, 1});
+            S::write_pair(p, srow, o, WordRef{b, 1});
             for (int w = 0; w < S::words(p); w++) if (a[w] != b[w]) { bad++; break; }
         }
         for (int r = 0; r < S::PAIR_ROUNDS; r++) if (per_round[r] > (unsigned)S::PAIR_ROUND_SLOTS) bad++;

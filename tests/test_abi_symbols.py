@@ -65,7 +65,9 @@ def test_the_counter_stamp_covers_device_code_only():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     src = (root / "bench.py").read_text()
-    assert "engine_kernels.h" in src[src.index("def kernel_source_hash"):src.index("def dist_roofline")]
+    assert all("engine_kernels.h" in v and "mc_common.h" in v for v in b.KERNEL_SOURCES.values()) and "engine_pairs.h" in b.KERNEL_SOURCES["ssi"]
+    assert "engine_pairs.h" not in b.KERNEL_SOURCES["raft"]   # (the by-pairs kernel has its own file: the raft stamp does not move with it)
+    assert len({b.kernel_source_hash(k) for k in b.KERNEL_SOURCES}) == len(b.KERNEL_SOURCES)
     assert "engine_kernels.h" in (root / "profiles" / "summarize_pmc.py").read_text()
     host, dev = (root / "tla_rust_amd" / "csrc" / "engine.hip").read_text(), (root / "tla_rust_amd" / "csrc" / "engine_kernels.h").read_text()
     assert "__global__" not in host, "a kernel in the host half"

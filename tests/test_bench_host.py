@@ -25,15 +25,20 @@ def test_every_workload_names_a_golden_case():
 
 
 def test_the_quoted_counter_summary_is_stamped_with_the_kernel_sources_of_this_tree():
-    """bench.py reads HBM traffic from the newest profiles/r*_pmc.json and refuses it (traffic = null) unless it was collected on
-    the kernel sources that are timed: a commit that touches engine.hip / spec_raft.h / mc_common.h without re-collecting the counters
-    shows up here (as a SKIP with the two hashes), not only in the driver's line"""
+    """bench.py reads HBM traffic from the newest profiles/r*_pmc.json of the workload's SPEC and refuses it (traffic = null) unless it was
+    collected on the kernel sources that are timed: a commit that touches the kernels without re-collecting the counters shows up here
+    (as a SKIP naming the stale summary), not only in the driver's line"""
     import pytest
     b = _bench()
-    newest = sorted((ROOT / "profiles").glob("r*_pmc.json"))[-1]
-    stamp = json.loads(newest.read_text())["__source__"]["hash"]
-    if stamp != b.kernel_source_hash():   # (between a kernel change and its next profile this is a state of work, not an error: the line then says traffic = null)
-        pytest.skip(f"{newest.name} was collected on kernel sources {stamp}, this tree's are {b.kernel_source_hash()}: re-run profiles/collect.sh")
+    stale = []
+    for spec, stag, kn in (("raft", "SpecRaft<3>", ("k_expand_family",)), ("raft", "SpecRaft<5>", ("k_expand_family",)), ("ssi", "SpecSsi", ("k_expand_pairs",))):
+        src, k = b.pmc_for(spec, stag, kn)
+        if k is None:   # (between a kernel change and its next profile this is a state of work, not an error: the line then says traffic = null)
+            stale.append(f"{stag}: {src}")
+        else:
+            assert k["launches"] > 0 and "FETCH_SIZE" in k and "WRITE_SIZE" in k, (stag, src)
+    if stale:
+        pytest.skip("; ".join(stale) + ": re-run profiles/collect.sh")
 
 
 def test_n_rank_roofline_object():

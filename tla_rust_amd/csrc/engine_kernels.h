@@ -198,9 +198,32 @@ k_init_cand(typename S::Params prm, uint64_t first, uint64_t count, uint64_t *__
 #define MC_NT_PROBE 0
 #endif
 typedef unsigned long long mc_ull2 __attribute__((ext_vector_type(2)));
-template <int SLOTS>
+// Round 6, MC_SEEN_ROTATE (default on; 0 = rounds 2-5's "first empty slot of the bucket"): a fingerprint's slots inside a bucket are
+// tried in ROTATED order, starting at slot j0 = bits 32.. of the fingerprint (the bucket comes from the low 32 bits, the owner rank of a
+// sharded run from the top 24).  Every prober follows the same sequence, so the linear-probing argument is unchanged — a fingerprint
+// lives in the first slot of ITS sequence that was empty when it arrived; a reader checks the whole bucket it fetched for a match
+// first — but now the slot a NEW fingerprint will take is known without reading the bucket, and it is empty with probability
+// 1 - load (with "first empty slot" it is slot 0, empty only while the whole bucket is: e^(-4 load)).  BLIND = true uses that: one
+// compare-and-swap at the home slot, unread — one trip to memory instead of two for a new state whose home slot is free, and for a
+// known one that sits there; only when the slot holds another fingerprint does the bucket get read.  For a search whose candidates
+// are mostly NEW (the SI models: 85 %) that halves the dependent round trips of an insert; where most candidates are duplicates
+// (raft: 75 %) a blind compare-and-swap turns an L2-cacheable read into a memory-side atomic, so those kernels keep reading first.
+#ifndef MC_SEEN_ROTATE
+#define MC_SEEN_ROTATE 1
+#endif
+template <int SLOTS, bool BLIND = false>
 __device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
     uint64_t bk = ((fp & 0xffffffffull) * nbuckets) >> 32;
+#if MC_SEEN_ROTATE
+    const unsigned j0 = (unsigned)(fp >> 32) & (unsigned)(SLOTS - 1);
+    if constexpr (BLIND) {
+        const unsigned long long cur = atomicCAS((unsigned long long *)&table[bk * SLOTS + j0], 0ull, (unsigned long long)fp);
+        if (cur == 0) return true;
+        if (cur == fp) return false;
+    }
+#else
+    static_assert(!BLIND, "a blind first compare-and-swap needs the rotated slot order");
+#endif
     for (int probe = 0; probe < 2048; ++probe) {
         const uint64_t b = bk * SLOTS;
         unsigned long long slot[SLOTS];
@@ -213,6 +236,25 @@ __device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets
 #pragma unroll
         for (int i = 0; i < SLOTS / 2; ++i) { const ulonglong2 v = line[i]; slot[2 * i] = v.x; slot[2 * i + 1] = v.y; }
 #endif
+#if MC_SEEN_ROTATE
+        unsigned zm = 0;   // bit i: slot i was empty when the bucket was read
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            hit |= slot[i] == fp;
+            zm |= (slot[i] == 0 ? 1u : 0u) << i;
+        }
+        if (hit) return false;
+        // the empty slots in this fingerprint's order: j0, j0 + 1, ... (mod SLOTS)
+        unsigned rot = ((zm >> j0) | (zm << (SLOTS - j0))) & ((1u << SLOTS) - 1u);
+        while (rot) {
+            const unsigned i = ((unsigned)__builtin_ctz(rot) + j0) & (unsigned)(SLOTS - 1);
+            const unsigned long long cur = atomicCAS((unsigned long long *)&table[b + i], 0ull, (unsigned long long)fp);
+            if (cur == 0) return true;
+            if (cur == fp) return false;
+            rot &= rot - 1;   // another fingerprint took it meanwhile: on to the next slot of the sequence
+        }
+#else
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             unsigned long long cur = slot[i];
@@ -220,6 +262,7 @@ __device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets
             if (cur == 0) return true;
             if (cur == fp) return false;
         }
+#endif
         bk = bk + 1 == nbuckets ? 0 : bk + 1;
     }
     err |= DEV_ETABLE;
@@ -230,9 +273,10 @@ constexpr uint64_t SEEN_SPARSE = 1ull << 63;
 #define MC_SPARSE_SLOTS 4
 #endif
 // (the parameter is still called `mask` in the kernels' signatures: it carries the bucket count and the mode bit)
+template <bool BLIND = false>
 __device__ __forceinline__ bool seen_insert(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
-    if (nbuckets & SEEN_SPARSE) return seen_insert_t<MC_SPARSE_SLOTS>(table, nbuckets & ~SEEN_SPARSE, fp, err);
-    return seen_insert_t<8>(table, nbuckets, fp, err);
+    if (nbuckets & SEEN_SPARSE) return seen_insert_t<MC_SPARSE_SLOTS, BLIND>(table, nbuckets & ~SEEN_SPARSE, fp, err);
+    return seen_insert_t<8, BLIND>(table, nbuckets, fp, err);
 }
 
 // The synchronous prober as a REAL function: the rare ways out of the split-phase probes of k_expand_family (a candidate whose
@@ -763,6 +807,9 @@ __device__ __forceinline__ unsigned owrap(unsigned x) {
 // tombstone, O_DEAD; anything else: the synchronous prober decides).  Only sparse tables (32-byte buckets) of fused runs.
 #ifndef MC_ASYNC_PROBE
 #define MC_ASYNC_PROBE 0
+#endif
+#if MC_ASYNC_PROBE && MC_SEEN_ROTATE
+#error "the split-phase probes (measured and not adopted in round 5) follow the first-empty-slot order: build them with -DMC_SEEN_ROTATE=0"
 #endif
 constexpr unsigned O_DEAD = 0xffffu;    // survivor-list tombstone: a tentative survivor that turned out to be known
 constexpr unsigned Q_DSP_SHIFT = 14;    // probe-ring entries: bits [14, 16) = 16-byte steps already taken past the home bucket's first half

@@ -40,7 +40,8 @@ constexpr unsigned PAIR_DEAD = 0xffffu;    // a pair the seen-set already knew (
 
 template <class S>
 struct PairLds {
-    uint64_t row[S::MAX_WORDS][64];   // the 64 parents' rows, word-major like the arena block they came from
+    uint64_t row[S::MAX_WORDS][64];   // the 64 parents' rows, word-major like the arena block they came from; word S::W_PAIR_BASE holds
+                                      // S::pair_base instead (the part of a successor's fingerprint its parent determines)
     typename S::Summary sum[64];
     uint16_t list[PAIR_CAP];
     unsigned succ[2];                 // deadlock check: bit p = parent p has a successor
@@ -56,6 +57,12 @@ struct RegRow {
     const uint64_t *r;
     __device__ __forceinline__ uint64_t get(int w) const { return r[w]; }
 };
+
+// specs whose candidates are mostly NEW states probe with a blind first compare-and-swap (S::BLIND_INSERT; seen_insert_t in engine_kernels.h)
+template <class S, class = void>
+struct BlindInsert : std::false_type {};
+template <class S>
+struct BlindInsert<S, decltype((void)S::BLIND_INSERT)> : std::integral_constant<bool, S::BLIND_INSERT && MC_SEEN_ROTATE> {};
 
 template <class S, int WAVES = MC_PAIR_WAVES>
 __global__ void __launch_bounds__(64 * WAVES, 4)
@@ -83,6 +90,10 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
     const unsigned shard = blockIdx.x & (NSHARD - 1);
     unsigned long long viol = ~0ull;
     unsigned gen = 0, err = 0, cands = 0;
+    // (profiling builds, -DMC_PHASE_PROF: cycles per phase, exclusive — 0 row load + S::load | 1 parent_status | 2 summarize, base, guards |
+    //  3 layout: scan + scatter | 8 pass 1: eval_pair | 9 seen-set probe / insert | 10 allocation | 11 pass 2: eval_pair | 12 write_pair |
+    //  7 epilogue; 24 / 25: pairs evaluated in pass 1 / 2; 40: wavefronts)
+    MC_PROF_DECL
 
     // ---- load: the row (coalesced: lane = state of one arena block), tables, invariants, guards
     uint64_t glo = 0, ghi = 0;
@@ -97,11 +108,14 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
             typename S::Local loc;
             const RegRow<MW> rr{r};
             S::load(prm, rr, loc);
+            MC_PROF(1);
             const unsigned ps = S::parent_status(prm, loc, rr);
             if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
+            MC_PROF(2);
             typename S::Summary q;
             S::summarize(loc, q);
             L.sum[lane] = q;
+            L.row[S::W_PAIR_BASE][lane] = S::pair_base(prm, loc, rr);
             if (!(flags & 64u)) S::guards(prm, loc, glo, ghi);  // (64 = ablation: load the parents only)
         }
     }
@@ -113,6 +127,7 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
     const bool single = total_all <= (unsigned)PAIR_CAP;
     const int nrounds = single ? 1 : S::PAIR_ROUNDS;
     for (int round = 0; round < nrounds; ++round) {
+        MC_PROF(3);
         uint64_t mlo = glo, mhi = ghi;
         if (!single) {
             uint64_t rlo = 0, rhi = 0;
@@ -184,8 +199,11 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
                     uint64_t fp = 0;
                     typename S::PairOut po;
                     const LdsRow row{(const __attribute__((address_space(3))) uint64_t *)&L.row[0][p]};
+                    MC_PROF(pass == 0 ? 8 : 11);
+                    MC_PROF_PAIRS(pass, (unsigned)__popcll(bl));
                     if (live) st = S::template eval_pair<F>(prm, L.sum[p], row, slot, fp, po);
                     if (pass == 0) {
+                        MC_PROF(9);
                         const uint64_t pidx = idx - lane + p;
                         uint64_t key = 0;
                         if (st & ST_ENABLED) {
@@ -202,11 +220,12 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
                         bool is_new = false;
                         if (key) {
                             ++cands;
-                            is_new = (flags & 16u) ? false : seen_insert(table, mask, key, err);  // (16 = ablation: no probes)
+                            is_new = (flags & 16u) ? false : seen_insert<BlindInsert<S>::value>(table, mask, key, err);  // (16 = ablation: no probes)
                         }
                         if (live && !is_new) L.list[i] = (uint16_t)PAIR_DEAD;
                         nsurv += (unsigned)__popcll(__ballot(is_new));
                     } else if (write_ok) {
+                        MC_PROF(12);
                         const uint64_t oidx = out0 + run + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
                         if (live) {
                             S::write_pair(prm, row, po, arena_ref(rt.arena_w, oidx, W));
@@ -217,6 +236,7 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
                 }
             });
             if (pass == 0) {
+                MC_PROF(10);
                 if (!nsurv) break;
                 wave_lds_fence();  // the struck entries are visible to the lanes that read them in pass 2
                 if (lane == 0) out0 = atomicAdd(&ctr->arena_next, (unsigned long long)nsurv);
@@ -226,6 +246,7 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
         }
     }
 
+    MC_PROF(7);
     if (track_succ) {
         wave_lds_fence();
         if (active && !(L.succ[lane >> 5] >> (lane & 31u) & 1u)) viol = min(viol, viol_key(idx, SLOT_NONE, VK_DEADLOCK, 0));
@@ -239,6 +260,7 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
         if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
         if (eor) atomicOr(&ctr->error, eor);
     }
+    MC_PROF_END;
 }
 
 // launch_expand's door (declared in engine_kernels.h): true = launched

@@ -88,6 +88,10 @@ struct SpecSsi {
     }
     MC_HD static unsigned idx6(uint32_t tab, int t) { return tab >> (6 * t) & 63u; }
 
+    // H: one word's contribution to the additive fingerprint.  Round 6: hmum (two 32 x 32 -> 64 multiply-accumulates) instead of fmix64
+    // (two 64-bit multiplies = a dozen quarter-rate instructions): the kernels of this spec are bound by VALU issue, and a successor's
+    // fingerprint is three to six of these
+    MC_HD static uint64_t H(uint64_t x, uint64_t salt) { return hmum(x, salt); }
     // ------------------------------------------------------------------ Init :938-943
     MC_HD static uint64_t num_init(const Params &) { return 1; }
     MC_HD static uint64_t init_meta() {
@@ -99,7 +103,7 @@ struct SpecSsi {
         for (int w = 0; w < MAX_WORDS; w++) out.set(w, 0);
         out.set(W_META, init_meta());
         uint64_t fp = 0;
-        for (int w = 1; w < MAX_WORDS; w++) fp += hmix(out.get(w), salt_of((unsigned)w));
+        for (int w = 1; w < MAX_WORDS; w++) fp += H(out.get(w), salt_of((unsigned)w));
         out.set(W_FP, fp);
     }
     template <class Ref>
@@ -107,7 +111,7 @@ struct SpecSsi {
     template <class Ref>
     MC_HD static uint64_t fp_recompute(const Params &, Ref s) {
         uint64_t fp = 0;
-        for (int w = 1; w < MAX_WORDS; w++) fp += hmix(s.get(w), salt_of((unsigned)w));
+        for (int w = 1; w < MAX_WORDS; w++) fp += H(s.get(w), salt_of((unsigned)w));
         return fp;
     }
     template <class Ref>
@@ -235,12 +239,11 @@ struct SpecSsi {
     // ------------------------------------------------------------------ successor = new meta + appended events
     struct Delta {
         uint64_t meta;
-        unsigned ev[4];
+        uint64_t ev;   // the appended events, 16 bits each, first one lowest (a step appends at most |TxnId| = 4: Commit + its losers)
         int nev;
     };
     MC_HD static void d_append(Delta &d, unsigned e) {
-        d.ev[0] = d.nev == 0 ? e : d.ev[0]; d.ev[1] = d.nev == 1 ? e : d.ev[1];
-        d.ev[2] = d.nev == 2 ? e : d.ev[2]; d.ev[3] = d.nev == 3 ? e : d.ev[3];
+        d.ev |= (uint64_t)e << (16 * d.nev);
         d.nev++;
     }
     // internalAbort(txn, reason) :406-416
@@ -403,7 +406,7 @@ struct SpecSsi {
         }
         return true;
     }
-    MC_HD static void delta_init(const Local &l, Delta &d) { d.meta = l.meta; d.nev = 0; d.ev[0] = d.ev[1] = d.ev[2] = d.ev[3] = 0; }
+    MC_HD static void delta_init(const Local &l, Delta &d) { d.meta = l.meta; d.nev = 0; d.ev = 0; }
     MC_HD static unsigned finish_delta(const Local &l, Delta &d) {
         if (l.n + d.nev > HCAP) return ST_ENABLED | ST_OVERFLOW;
         d.meta = (d.meta & ~63ull) | (uint64_t)(l.n + d.nev);
@@ -421,20 +424,14 @@ struct SpecSsi {
         return en ? finish_delta(l, d) : 0u;
     }
 
-    // the (at most two) history words the appended events land in
+    // the (at most two) history words the appended events land in: positions n .. n + nev - 1, four 16-bit events per word
     template <class Ref>
     MC_HD static void touched(const Local &l, Ref s, const Delta &d, int &wa, uint64_t &olda, uint64_t &newa, uint64_t &newb) {
         wa = l.n >> 2;
         olda = (d.nev && wa < HWORDS) ? s.get(W_H0 + wa) : 0;
-        newa = olda;
-        newb = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j >= d.nev) continue;
-            const int pos = l.n + j;
-            const uint64_t e = (uint64_t)d.ev[j] << (16 * (pos & 3));
-            if ((pos >> 2) == wa) newa |= e; else newb |= e;
-        }
+        const int sh = 16 * (l.n & 3);
+        newa = olda | d.ev << sh;
+        newb = sh ? d.ev >> (64 - sh) : 0;
     }
     template <class Ref>
     MC_HD static unsigned eval(const Params &p, Local &l, Ref s, int slot, uint64_t &fp) {
@@ -446,9 +443,9 @@ struct SpecSsi {
         int wa;
         uint64_t olda, newa, newb;
         touched(l, s, d, wa, olda, newa, newb);
-        uint64_t f = l.fp + hmix(d.meta, salt_of(W_META)) - hmix(l.meta, salt_of(W_META));
-        if (newa != olda) f += hmix(newa, salt_of((unsigned)(W_H0 + wa))) - hmix(olda, salt_of((unsigned)(W_H0 + wa)));
-        if (newb) f += hmix(newb, salt_of((unsigned)(W_H0 + wa + 1))) - hmix(0, salt_of((unsigned)(W_H0 + wa + 1)));
+        uint64_t f = l.fp + H(d.meta, salt_of(W_META)) - H(l.meta, salt_of(W_META));
+        if (newa != olda) f += H(newa, salt_of((unsigned)(W_H0 + wa))) - H(olda, salt_of((unsigned)(W_H0 + wa)));
+        if (newb) f += H(newb, salt_of((unsigned)(W_H0 + wa + 1))) - H(0, salt_of((unsigned)(W_H0 + wa + 1)));
         fp = fp_nonzero(f);
         return st;
     }
@@ -468,7 +465,7 @@ struct SpecSsi {
         if (d.nev) out.set(W_H0 + wa, newa);
         if (newb) out.set(W_H0 + wa + 1, newb);
         uint64_t f = 0;
-        for (int w = 1; w < MAX_WORDS; w++) f += hmix(out.get(w), salt_of((unsigned)w));
+        for (int w = 1; w < MAX_WORDS; w++) f += H(out.get(w), salt_of((unsigned)w));
         out.set(W_FP, f);
         return st;
     }
@@ -480,6 +477,10 @@ struct SpecSsi {
     // code path — from the parent's Summary (the tables compute_* reads) and its row, both staged in LDS.  The same evaluation runs a
     // second time for the pairs the seen-set accepted and writes their rows (the successor is parent + new meta + <= 2 history words).
     static constexpr int PAIR_FAMILIES = 3;
+#ifndef MC_SSI_BLIND
+#define MC_SSI_BLIND 0
+#endif
+    static constexpr bool BLIND_INSERT = MC_SSI_BLIND != 0;  // 85 % of the candidates of this search are new states (G / D = 1.19 on the 4 x 3 model)
     static constexpr int PAIR_ROUNDS = NT;        // a wavefront whose pairs overflow its list works transaction by transaction
     static constexpr int PAIR_ROUND_SLOTS = PER_TXN + 1;  // ... at most this many slots per parent and round
     struct Summary {
@@ -561,6 +562,18 @@ struct SpecSsi {
         const int sub = slot % PER_TXN;
         return sub < 4 + NK || (sub - 4 - NK) % NT == 0;
     }
+    // PAIR BASE: what every successor's fingerprint shares — the parent's sum without the terms of the three words a step can change
+    // (meta, the history word the next event lands in, the one after it).  A pair then adds three terms instead of taking three away
+    // and adding three; the parent's lane computes the base once, it waits in LDS beside the Summary.
+    static constexpr int W_PAIR_BASE = W_FP;  // word of the STAGED row (k_expand_pairs' LDS copy) that holds the base instead of the parent's own sum
+    template <class Ref>
+    MC_HD static uint64_t pair_base(const Params &, const Local &l, Ref row) {
+        const int wa = l.n >> 2;
+        uint64_t b = l.fp - H(l.meta, salt_of(W_META));
+        if (wa < HWORDS) b -= H(row.get(W_H0 + wa), salt_of((unsigned)(W_H0 + wa)));
+        if (wa + 1 < HWORDS) b -= H(0, salt_of((unsigned)(W_H0 + wa + 1)));   // (append-only: the word behind the last event's is empty)
+        return b;
+    }
     // what a pair's evaluation hands to the writer: the successor's meta word and the (at most two) history words the events land in
     struct PairOut {
         uint64_t raw_fp, meta, newa, newb;  // raw_fp: word 0 of the successor (the raw additive sum; the seen-set key is fp_nonzero of it)
@@ -569,8 +582,9 @@ struct SpecSsi {
     // evaluation of one (parent, slot) pair of family F from the parent's Summary + row (any Ref with get(w)); fp = successor's fingerprint
     template <int F, class Ref>
     MC_HD static unsigned eval_pair(const Params &p, const Summary &q, Ref row, int slot, uint64_t &fp, PairOut &o) {
+        const uint64_t base = row.get(W_PAIR_BASE);
         Local l;
-        local_of(q, row.get(W_FP), row.get(W_META), l);
+        local_of(q, 0, row.get(W_META), l);
         Delta d;
         delta_init(l, d);
         int action;
@@ -578,13 +592,16 @@ struct SpecSsi {
         if (!en) return 0;
         const unsigned st = finish_delta(l, d);
         if (st & ST_OVERFLOW) { fp = 1; return st; }
-        uint64_t olda;
-        touched(l, row, d, o.wa, olda, o.newa, o.newb);
-        o.meta = d.meta;
+        const int wa = l.n >> 2, sh = 16 * (l.n & 3);
+        const uint64_t olda = wa < HWORDS ? row.get(W_H0 + wa) : 0;
+        o.wa = wa;
         o.nev = d.nev;
-        uint64_t f = l.fp + hmix(d.meta, salt_of(W_META)) - hmix(l.meta, salt_of(W_META));
-        if (o.newa != olda) f += hmix(o.newa, salt_of((unsigned)(W_H0 + o.wa))) - hmix(olda, salt_of((unsigned)(W_H0 + o.wa)));
-        if (o.newb) f += hmix(o.newb, salt_of((unsigned)(W_H0 + o.wa + 1))) - hmix(0, salt_of((unsigned)(W_H0 + o.wa + 1)));
+        o.meta = d.meta;
+        o.newa = olda | d.ev << sh;
+        o.newb = sh ? d.ev >> (64 - sh) : 0;
+        uint64_t f = base + H(d.meta, salt_of(W_META));
+        if (wa < HWORDS) f += H(o.newa, salt_of((unsigned)(W_H0 + wa)));
+        if (wa + 1 < HWORDS) f += H(o.newb, salt_of((unsigned)(W_H0 + wa + 1)));
         o.raw_fp = f;
         fp = fp_nonzero(f);
         return st;
