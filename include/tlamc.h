@@ -191,6 +191,9 @@ int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms);
 /* profiling builds only (libtlamc.so compiled with -DMC_PHASE_PROF, profiles/phase_prof.sh): shader-clock cycles per phase of the
  * by-family expand kernel summed over all wavefronts since the last reset (48 words: layout in engine.hip); MC_ESTATE otherwise */
 int mc_engine_debug_phases(mc_engine *e, uint64_t *out48, int reset);
+/* profiling only: set / clear bits of the engine's flags between two calls (the A/B and ablation bits a kernel reads at run time) — e.g. run
+ * to a level normally, then time ONE more level (mc_engine_step) with an ablation bit on.  Never changes what a run without the bits computes. */
+int mc_engine_debug_flags(mc_engine *e, uint32_t set, uint32_t clear);
 void mc_engine_destroy(mc_engine *e);
 
 /* ------------------------------------------------------------------ sharded (multi-GPU) step API

@@ -128,6 +128,20 @@ struct PairCheck<S, decltype((void)S::PAIR_FAMILIES)> {
     }
 };
 
+// specs whose kernels evaluate the invariants of a stored state from what its last step can have changed (S::parent_status_step): the
+// verdict must be parent_status's on EVERY state the search expands or stops on — violating models included (the states of the level a
+// violation is found on were all generated from states that passed)
+template <class S, class = void>
+struct StepStatusCheck {
+    template <class Ref>
+    static uint64_t mismatch(const typename S::Params &, const typename S::Local &, Ref, unsigned) { return 0; }
+};
+template <class S>
+struct StepStatusCheck<S, decltype((void)S::STEP_STATUS)> {
+    template <class Ref>
+    static uint64_t mismatch(const typename S::Params &p, const typename S::Local &l, Ref s, unsigned full) { return S::parent_status_step(p, l, s) != full ? 1 : 0; }
+};
+
 // expand-by-family interface (specs with NFAM): for every (state, slot) the family-pruned evaluation through the
 // guard must reproduce exactly what the generic evaluation does
 template <class S, class = void>
@@ -339,6 +353,7 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
             const int ns = S::nslots(prm, loc);
             const unsigned ps = S::parent_status(prm, loc, s);
             if (ps & ST_INVARIANT) violation(ps, level);
+            r->fp_mismatch += StepStatusCheck<S>::mismatch(prm, loc, s, ps);
             r->fp_mismatch += FamCheck<S>::mismatches(prm, loc, s, ns);
             r->fp_mismatch += PairCheck<S>::mismatches(prm, loc, s, ns);
             r->fp_mismatch += DenseCheck<S>::mismatches(prm, loc, s);
@@ -381,6 +396,7 @@ static int run(S, const typename S::Params &prm, uint64_t max_levels, uint64_t m
             typename S::Local loc;
             S::load(prm, s, loc);
             const unsigned ps = S::parent_status(prm, loc, s);
+            r->fp_mismatch += StepStatusCheck<S>::mismatch(prm, loc, s, ps);
             if (ps & ST_INVARIANT) violation(ps, level);
         }
     }

@@ -305,3 +305,18 @@ def test_device_ssi_wellformedness_unit_tests(shim):
         flat = [x for e in events for x in e]
         st = lib.shim_ssi_history_status(2, 2, 1, 0, (C.c_int * len(flat))(*flat), len(events))
         assert bool(st & 8) == (not ok), events
+
+
+@pytest.mark.parametrize("params", [[3, 2, 127, f] for f in (1, 2, 3, 6, 7)] + [[2, 2, 127, 0, 1], [3, 2, 127, 0, 1], [3, 2, 96, 0, 1, 3],
+                                                                                 [3, 2, 127, 0, 0, 3], [3, 3, 127, 2, 0, 3], [4, 2, 127, 0], [2, 3, 127, 0]])
+def test_ssi_step_status_and_pair_protocol_equal_the_full_evaluation(shim, params):
+    """Round 6: the kernels (a) evaluate the invariants of a stored state from what its last step can have changed (parent_status_step) and
+    (b) expand through the by-pairs protocol (guards / eval_pair / write_pair).  The host build compares both with the full evaluation
+    (parent_status; eval / apply) on EVERY state the search expands or stops on — models that violate an invariant (plain snapshot isolation
+    is not serializable: the textbook model under the serializability invariants; the `find` targets) and SYMMETRY included — and counts
+    the differences in fp_mismatch."""
+    skew = params == [3, 2, 96, 0, 1, 3]   # textbook SI, 3 x 2, the two serializability invariants, SYMMETRY: 2.4 M orbits, write skew at depth 13
+    s = shim.shim_run("ssi", params, max_distinct=0 if skew else 250000)
+    assert s["fp_mismatch"] == 0, s
+    if skew:
+        assert (s["verdict"], s["violated_invariant"], s["trace_len"]) == ("invariant", 5, 13)   # two committed transactions in a cycle

@@ -1242,3 +1242,25 @@ Inv3 == Size(s) <= N /\ Size(msgs) <= N /\ Sum3(f) <= 6
 Inv4 == \A p \in 1..Len(q) % 3 : (box[p] # <<>>) => Last(box[p]) = p * 3
 ====
 """
+
+
+def test_let_substitution_does_not_capture_a_binder_of_the_same_name():
+    """`LET f(a) == \\E y \\in {1,2} : y + 1 = a IN \\E y \\in {2,3} : y = x /\\ f(y)` — the argument `y` of the call
+    is the OUTER quantifier's variable; substituted textually into f's body it used to land under f's own `\\E y` and mean the inner one
+    (ok = FALSE for x = 2, 3, and a translation that re-binds y, which SANY rejects).  The front-end now renames a binder whose variable is
+    free in a body substituted below it.  Two opinions that never see the substitution: (1) the invariant states the value the LET must
+    have; (2) the same algorithm with the operator in a `define` block (a real call, parameters bound by name) has the same state graph."""
+    def module(let):
+        expr = ("LET f(a) == \\E y \\in {1, 2} : y + 1 = a IN \\E y \\in {2, 3} : y = x /\\ f(y)" if let
+                else "\\E y \\in {2, 3} : y = x /\\ F(y)")
+        define = "" if let else "define F(a) == \\E y \\in {1, 2} : y + 1 = a end define;\n"
+        return ("---- MODULE cap ----\nEXTENDS Naturals\n(* --algorithm cap\nvariables x = 0, ok = FALSE, done = FALSE;\n" + define +
+                "begin\n  A: with v \\in 1..4 do x := v; end with;\n  B: ok := " + expr + ";\n     done := TRUE;\nend algorithm *)\n"
+                "Inv == done => (ok <=> x \\in {2, 3})\n====\n")
+    a = _vm_equals_evaluator(module(True), ["Inv"])
+    b = _vm_equals_evaluator(module(False), ["Inv"])
+    assert a["verdict"] == b["verdict"] == "ok"
+    assert (a["distinct"], a["generated"], a["levels"]) == (b["distinct"], b["generated"], b["levels"]) and a["distinct"] == 9
+    tr = helpers.pcal_translate(module(True))
+    tr = tr[tr.index("BEGIN TRANSLATION"):]
+    assert "\\E y_1 \\in {1, 2}" in tr and "\\E y \\in {1, 2}" not in tr, tr   # the inner binder is renamed, the outer `y` survives

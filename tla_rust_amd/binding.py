@@ -321,6 +321,13 @@ class Engine:
         _check(lib().mc_engine_debug_reexpand(self._h, extra_flags, C.byref(ms)), "mc_engine_debug_reexpand")
         return ms.value
 
+    def debug_flags(self, set=0, clear=0):
+        """profiling only (mc_engine_debug_flags): switch A/B / ablation bits of the engine's flags between two calls"""
+        L = lib()
+        L.mc_engine_debug_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.mc_engine_debug_flags.restype = C.c_int
+        _check(L.mc_engine_debug_flags(self._h, set, clear), "mc_engine_debug_flags")
+
     def kernel_stats(self):
         ks = KernelStats()
         _check(lib().mc_engine_kernel_stats(self._h, C.byref(ks)), "mc_engine_kernel_stats")

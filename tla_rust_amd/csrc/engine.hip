@@ -85,6 +85,7 @@ struct EngineBase {
     virtual int read_states(uint64_t first, uint64_t count, uint8_t *out) = 0;
     virtual int debug_reexpand(unsigned extra_flags, double *ms) = 0;
     virtual int debug_phases(uint64_t *out48, int reset) = 0;
+    virtual int debug_flags(uint32_t set, uint32_t clear) = 0;
     virtual int checkpoint(const char *path) = 0;
     virtual int restore(const char *path) = 0;
     virtual int shard_begin() = 0;
@@ -824,6 +825,7 @@ struct Engine : EngineBase {
     uint64_t last_distinct = 0;
     // Profiling aid: expand every resident state again (seen-set already full, so every probe hits)
     // with optional ablation flags; returns the kernel time.  State counts are not changed.
+    int debug_flags(uint32_t set, uint32_t clear) override { cfg.flags = (cfg.flags & ~clear) | set; return MC_OK; }
     int debug_phases(uint64_t *out48, int reset) override {
 #ifdef MC_PHASE_PROF
         HIP_TRY(hipSetDevice(cfg.device));
@@ -1794,6 +1796,7 @@ void mc_set_error_internal(const char *msg) { g_last_error = msg ? msg : ""; }
 int mc_engine_debug_reexpand(mc_engine *e, unsigned extra_flags, double *ms) { return e && ms ? e->impl->debug_reexpand(extra_flags, ms) : MC_EBADCFG; }
 // profiling builds only (-DMC_PHASE_PROF): cycles per phase of k_expand_family summed over all wavefronts since the last reset
 int mc_engine_debug_phases(mc_engine *e, uint64_t *out48, int reset) { return e && out48 ? e->impl->debug_phases(out48, reset) : MC_EBADCFG; }
+int mc_engine_debug_flags(mc_engine *e, uint32_t set, uint32_t clear) { return e ? e->impl->debug_flags(set, clear) : MC_EBADCFG; }
 // ---- sharded (multi-GPU) step API
 int mc_shard_begin(mc_engine *e) { return e ? e->impl->shard_begin() : MC_EBADCFG; }
 int mc_shard_begin_replicated(mc_engine *e, uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out,

@@ -90,6 +90,18 @@ MC_HD unsigned long long viol_key(uint64_t idx, unsigned slot, unsigned kind, un
 }
 MC_HD uint64_t viol_idx(unsigned long long key) { return (uint64_t)((key & ~VIOL_LATER) >> 24); }
 
+// Invariants of a STORED state (specs that check when a state is expanded): S::parent_status_step where a spec has one — the verdict of
+// S::parent_status computed from what the state's last step can have changed (spec_ssi.h) — else S::parent_status
+template <class S, class = void>
+struct HasStepStatus : std::false_type {};
+template <class S>
+struct HasStepStatus<S, decltype((void)S::STEP_STATUS)> : std::true_type {};
+template <class S, class Ref>
+__device__ __forceinline__ unsigned stored_state_status(const typename S::Params &prm, const typename S::Local &loc, Ref s) {
+    if constexpr (HasStepStatus<S>::value) return S::parent_status_step(prm, loc, s);
+    else return S::parent_status(prm, loc, s);
+}
+
 // ------------------------------------------------------------------------------------- expand
 template <class S>
 __global__ void __launch_bounds__(256)
@@ -211,8 +223,17 @@ typedef unsigned long long mc_ull2 __attribute__((ext_vector_type(2)));
 #ifndef MC_SEEN_ROTATE
 #define MC_SEEN_ROTATE 1
 #endif
-template <int SLOTS, bool BLIND = false>
-__device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err) {
+// PRE = true: the home bucket was read EARLIER (seen_load_home: the reader had other work between asking and needing it — the by-pairs
+// kernel evaluates its next batch meanwhile); `pre` holds its SLOTS words and the first round of the loop uses them instead of loading.
+template <int SLOTS>
+__device__ __forceinline__ void seen_load_home(const uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned long long (&pre)[SLOTS]) {
+    const uint64_t bk = ((fp & 0xffffffffull) * nbuckets) >> 32;
+    const ulonglong2 *line = reinterpret_cast<const ulonglong2 *>(table + bk * SLOTS);
+#pragma unroll
+    for (int i = 0; i < SLOTS / 2; ++i) { const ulonglong2 v = line[i]; pre[2 * i] = v.x; pre[2 * i + 1] = v.y; }
+}
+template <int SLOTS, bool BLIND = false, bool PRE = false>
+__device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets, uint64_t fp, unsigned &err, const unsigned long long *pre = nullptr) {
     uint64_t bk = ((fp & 0xffffffffull) * nbuckets) >> 32;
 #if MC_SEEN_ROTATE
     const unsigned j0 = (unsigned)(fp >> 32) & (unsigned)(SLOTS - 1);
@@ -227,6 +248,10 @@ __device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets
     for (int probe = 0; probe < 2048; ++probe) {
         const uint64_t b = bk * SLOTS;
         unsigned long long slot[SLOTS];
+        if (PRE && probe == 0) {
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) slot[i] = pre[i];
+        } else {
 #if MC_NT_PROBE & 1
         const mc_ull2 *line = reinterpret_cast<const mc_ull2 *>(table + b);
 #pragma unroll
@@ -236,6 +261,7 @@ __device__ __forceinline__ bool seen_insert_t(uint64_t *table, uint64_t nbuckets
 #pragma unroll
         for (int i = 0; i < SLOTS / 2; ++i) { const ulonglong2 v = line[i]; slot[2 * i] = v.x; slot[2 * i + 1] = v.y; }
 #endif
+        }
 #if MC_SEEN_ROTATE
         unsigned zm = 0;   // bit i: slot i was empty when the bucket was read
         bool hit = false;
@@ -479,7 +505,7 @@ k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         S::load(prm, s, loc);
         ns = S::nslots(prm, loc);
         if (sy == 0) {
-            const unsigned ps = S::parent_status(prm, loc, s);  // specs that check invariants per expanded state
+            const unsigned ps = stored_state_status<S>(prm, loc, s);  // specs that check invariants per expanded state
             if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
         }
     }
@@ -1477,7 +1503,17 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         unsigned incl = h;
         for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
         const unsigned excl = incl - h, total = __shfl(incl, 63);
+#if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
+        // ABLATION BUILD ONLY (profiles/tail_ablate.py: ONE level is timed, its output is garbage and is never expanded).  flags bit 21: every
+        // workgroup's survivors start on a 64-state boundary — every column store of the writer is one whole 512-byte row of a block: the
+        // most that sector-aligned allocation could ever give (the holes are left as they are)
+        if (w == 0 && lane == 0) {
+            if (flags & (1u << 21)) *wg_out0 = total ? ((atomicAdd(&ctr->arena_next, (unsigned long long)(((total + 63u) & ~63u) + 64u)) + 63ull) & ~63ull) : 0ull;
+            else *wg_out0 = total ? atomicAdd(&ctr->arena_next, (unsigned long long)total) : 0ull;
+        }
+#else
         if (w == 0 && lane == 0) *wg_out0 = total ? atomicAdd(&ctr->arena_next, (unsigned long long)total) : 0ull;
+#endif
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) ccnt[c] = __shfl(excl, c * WAVES + (int)w);  // where this wavefront's class-c survivors go
         for (unsigned t = 0; t < on; t += 64) {
@@ -1505,7 +1541,18 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 const unsigned e = mine ? wq[ref >> 9].o_ent[ref & 511u] : 0u;
                 const uint64_t sfp = mine ? wq[ref >> 9].o_fp[ref & 511u] : 0ull;
                 const uint64_t pidx = wg_idx0 + (ref >> 9) * 64u + (e & 63u), oidx = out0 + bt + lane;
+#if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
+                // flags bit 20: the writer reads "its parent" from the arena's first two blocks (same lanes, same instructions, every gather an
+                // L1 / L2 hit): the most that keeping the parent rows on the CU could give.  bit 22: every row is stored into the arena's LAST
+                // 64 states (same stores, no HBM write traffic to speak of).  bit 23: no writer at all (allocation only).
+                {
+                    const uint64_t rpidx = (flags & (1u << 20)) ? (uint64_t)((ref >> 9) * 64u + (e & 63u)) : pidx;
+                    const uint64_t woidx = (flags & (1u << 22)) ? (rt.arena_cap - 64u + (oidx & 63u)) : oidx;
+                    wave_write_survivors<S>(prm, arena, rpidx, mine && !(flags & (1u << 23)), e >> 6, sfp, rt.arena_w, woidx, fls[ref >> 9].sum[e & 63u]);
+                }
+#else
                 wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx, fls[ref >> 9].sum[e & 63u]);
+#endif
                 if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
             }
         }
@@ -1895,7 +1942,7 @@ k_check_frontier(typename S::Params prm, const uint64_t *__restrict__ arena, uin
         const CWordRef g = arena_cref(arena, idx, S::words(prm));
         typename S::Local loc;
         S::load(prm, g, loc);
-        const unsigned ps = S::parent_status(prm, loc, g);
+        const unsigned ps = stored_state_status<S>(prm, loc, g);
         if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
     }
     const unsigned long long vmin = wave_min_u64(viol);

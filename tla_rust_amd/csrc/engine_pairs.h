@@ -109,7 +109,7 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
             const RegRow<MW> rr{r};
             S::load(prm, rr, loc);
             MC_PROF(1);
-            const unsigned ps = S::parent_status(prm, loc, rr);
+            const unsigned ps = stored_state_status<S>(prm, loc, rr);
             if (ps & ST_INVARIANT) viol = viol_key(idx, SLOT_PARENT, VK_INVARIANT, ps >> 8);
             MC_PROF(2);
             typename S::Summary q;
@@ -182,6 +182,65 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
         unsigned nsurv = 0;
         unsigned long long out0 = 0;
         bool write_ok = true;
+        // PIPELINED PROBES (sparse tables: 32-byte buckets, rotated slot order).  An insert is two dependent trips to memory — read the
+        // bucket, compare-and-swap into the fingerprint's first empty slot — and the second one, a memory-side atomic, is the long one
+        // (call g: hiding the READ alone behind the next batch's evaluation changed nothing).  So a batch goes through three stations,
+        // one per loop iteration: its home buckets are asked for right after its evaluation (P1); an iteration later the buckets are
+        // looked at and the compare-and-swaps ISSUED, their return values left in flight (P2); another iteration later the returns are
+        // read: 0 = new, the fingerprint itself = somebody else's insert came first, anything else (another fingerprint took the slot,
+        // or the bucket was full) = the synchronous prober decides.  12 VGPRs of pipeline state; MC_PAIR_PIPE = 0 / 1: A/B (probe where
+        // evaluated / hide the read only).
+#ifndef MC_PAIR_PIPE
+#define MC_PAIR_PIPE 2
+#endif
+        const bool pipelined = MC_PAIR_PIPE && MC_SEEN_ROTATE && MC_SPARSE_SLOTS == 4 && (mask & SEEN_SPARSE) != 0;  // wave-uniform
+        const uint64_t nbk = mask & ~SEEN_SPARSE;
+        // (no "is the station occupied" flags: an empty station holds key 0 = no candidate, and every iteration walks both stations — a
+        //  path on which the buckets asked for earlier were never looked at would make the next load a write to registers with a load
+        //  still in flight, and the compiler would have to wait for everything right there)
+        unsigned long long p1_b[4] = {0ull, 0ull, 0ull, 0ull};
+        uint64_t p1_key = 0, p2_key = 0;
+        unsigned long long p2_ret = 0;
+        unsigned p1_i = 0, p2_i = 0;
+        bool p1_live = false, p2_live = false;
+        int p2_state = 0;  // 0: known (or no candidate) | 1: compare-and-swap in flight | 2: new (decided synchronously) | 3: ask the synchronous prober
+        auto finish_p2 = [&]() __attribute__((always_inline)) {  // station 3: read the compare-and-swaps' returns
+            bool is_new = p2_state == 2;
+            if (p2_state == 1) {
+                if (p2_ret == 0ull) is_new = true;
+                else if (p2_ret != p2_key) p2_state = 3;
+            }
+            if (p2_state == 3) is_new = seen_insert_t<4>(table, nbk, p2_key, err);
+            if (p2_live && !is_new) L.list[p2_i] = (uint16_t)PAIR_DEAD;
+            nsurv += (unsigned)__popcll(__ballot(is_new));
+            p2_state = 0; p2_live = false;
+        };
+        auto advance_p1 = [&]() __attribute__((always_inline)) {  // station 2: look at the buckets, issue the compare-and-swaps
+            p2_key = p1_key; p2_i = p1_i; p2_live = p1_live; p2_state = 0; p2_ret = 0;
+#if MC_SEEN_ROTATE
+            const unsigned j0 = (unsigned)(p1_key >> 32) & 3u;
+            unsigned zm = 0;
+            bool hit = false;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { hit |= p1_b[t] == p1_key; zm |= (p1_b[t] == 0ull ? 1u : 0u) << t; }
+            if (p1_key && !hit && !(flags & 16u)) {  // (16 = ablation: no probes)
+                const unsigned rot = ((zm >> j0) | (zm << (4u - j0))) & 15u;
+                if (rot) {
+                    const unsigned t = ((unsigned)__builtin_ctz(rot) + j0) & 3u;
+                    const uint64_t bk = ((p1_key & 0xffffffffull) * nbk) >> 32;
+                    p2_ret = atomicCAS((unsigned long long *)&table[bk * 4 + t], 0ull, (unsigned long long)p1_key);
+                    p2_state = 1;
+                } else {
+                    p2_state = 3;  // the home bucket is full: the probe goes on in the next one
+                }
+            }
+#endif
+            p1_key = 0; p1_live = false;
+            if (MC_PAIR_PIPE < 2) {  // A/B: wait for the compare-and-swap where it is issued
+                asm volatile("" : "+v"(p2_ret));
+                finish_p2();
+            }
+        };
         for (int pass = 0; pass < 2; ++pass) {
             unsigned run = 0;  // pass 2: survivors written so far
             static_for<0, NF>([&](auto fc) {
@@ -217,13 +276,21 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
                                 if (!(st & (ST_OUT_OF_MODEL | ST_SELFLOOP))) key = fp;
                             }
                         }
-                        bool is_new = false;
-                        if (key) {
-                            ++cands;
-                            is_new = (flags & 16u) ? false : seen_insert<BlindInsert<S>::value>(table, mask, key, err);  // (16 = ablation: no probes)
+                        if (key) ++cands;
+                        if (pipelined) {
+                            finish_p2();    // the batch two evaluations back: its compare-and-swaps have had a whole evaluation to return
+                            advance_p1();   // the batch before this one: its buckets have had a whole evaluation to arrive
+                            // station 1: this batch's buckets are asked for now, STRAIGHT into the pipeline registers (a copy would be a
+                            // use, and a use is a wait) and by every lane (a lane without a candidate reads bucket 0: a conditional
+                            // load becomes a select, i.e. a use)
+                            seen_load_home<4>(table, nbk, key, p1_b);
+                            p1_key = key; p1_i = i; p1_live = live;
+                        } else {
+                            bool is_new = false;
+                            if (key) is_new = (flags & 16u) ? false : seen_insert<BlindInsert<S>::value>(table, mask, key, err);
+                            if (live && !is_new) L.list[i] = (uint16_t)PAIR_DEAD;
+                            nsurv += (unsigned)__popcll(__ballot(is_new));
                         }
-                        if (live && !is_new) L.list[i] = (uint16_t)PAIR_DEAD;
-                        nsurv += (unsigned)__popcll(__ballot(is_new));
                     } else if (write_ok) {
                         MC_PROF(12);
                         const uint64_t oidx = out0 + run + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
@@ -235,6 +302,7 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
                     }
                 }
             });
+            if (pass == 0) { finish_p2(); advance_p1(); finish_p2(); }  // drain the pipeline
             if (pass == 0) {
                 MC_PROF(10);
                 if (!nsurv) break;

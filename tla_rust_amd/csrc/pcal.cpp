@@ -131,7 +131,7 @@ struct ParseError { std::string msg; };
 struct Parser {
     std::vector<Tok> t;
     size_t i = 0;
-    explicit Parser(std::vector<Tok> toks) : t(std::move(toks)) {}
+    explicit Parser(std::vector<Tok> toks) : t(std::move(toks)) { fresh_counter() = 0; }
     const Tok &cur() const { return t[i]; }
     const Tok &peek(size_t k = 1) const { return t[std::min(i + k, t.size() - 1)]; }
     bool is_sym(const char *s) const { return cur().t == Tok::SYM && cur().s == s; }
@@ -174,6 +174,24 @@ struct Parser {
     struct LetDef { std::string name; std::vector<std::string> params; EP body; };
     // e with the LET definitions substituted: a name without parameters by its body, f(args) by f's body with the parameters replaced;
     // `hidden` = names re-bound by a quantifier / function constructor on the way down
+    // identifiers that occur FREE in e (operator names of calls included): what a binder at the place of substitution could capture
+    static void free_ids(const EP &e, std::set<std::string> bound, std::set<std::string> &out) {
+        if (!e) return;
+        if ((e->k == Expr::ID || e->k == Expr::CALL) && !bound.count(e->s)) out.insert(e->s);
+        if ((e->k == Expr::QUANT || e->k == Expr::FUNCDEF || e->k == Expr::SETOF) && !e->bound.empty()) {
+            if (!e->a.empty()) free_ids(e->a[0], bound, out);   // the domain is outside the binding
+            bound.insert(e->bound);
+            for (size_t j = 1; j < e->a.size(); j++) free_ids(e->a[j], bound, out);
+            return;
+        }
+        for (auto &x : e->a) free_ids(x, bound, out);
+    }
+    static int &fresh_counter() { static thread_local int n = 0; return n; }
+    // e with the LET definitions substituted: a name without parameters by its body, f(args) by f's body with the parameters replaced;
+    // `hidden` = names re-bound by a quantifier / function constructor on the way down.  CAPTURE-AVOIDING: a binder
+    // whose variable occurs free in a body that is substituted below it — `LET f(a) == \E y \in S : y + 1 = a IN \E y \in T : f(y)`, or
+    // `LET a == y + 1 IN \E y \in S : a` — is renamed (y_1, y_2, ...) in its own scope first, so that the substituted `y` keeps meaning
+    // the outer one; the translation then prints the renamed binder, which SANY accepts.
     static EP let_subst(const EP &e, const std::vector<LetDef> &defs, std::set<std::string> hidden) {
         if (!e) return e;
         if (e->k == Expr::ID && !hidden.count(e->s))
@@ -194,8 +212,26 @@ struct Parser {
         auto c = std::make_shared<Expr>(*e);
         if ((e->k == Expr::QUANT || e->k == Expr::FUNCDEF || e->k == Expr::SETOF) && !e->bound.empty()) {
             if (!c->a.empty()) c->a[0] = let_subst(e->a[0], defs, hidden);   // the domain is outside the binding
-            hidden.insert(e->bound);
-            for (size_t j = 1; j < c->a.size(); j++) c->a[j] = let_subst(e->a[j], defs, hidden);
+            bool clash = false;
+            for (const auto &d : defs) {
+                if (hidden.count(d.name) || d.name == e->bound) continue;   // (a definition the binder itself shadows is not substituted below)
+                std::set<std::string> fr, bnd(d.params.begin(), d.params.end());
+                free_ids(d.body, bnd, fr);
+                if (fr.count(e->bound)) { clash = true; break; }
+            }
+            std::vector<EP> scope(e->a.begin() + (e->a.empty() ? 0 : 1), e->a.end());
+            if (clash) {
+                auto id = std::make_shared<Expr>();
+                id->k = Expr::ID;
+                id->pos = e->pos;
+                id->s = e->bound + "_" + std::to_string(++fresh_counter());
+                c->bound = id->s;
+                const std::vector<LetDef> ren{{e->bound, {}, id}};
+                for (auto &x : scope) x = let_subst(x, ren, {});
+            } else {
+                hidden.insert(e->bound);
+            }
+            for (size_t j = 1; j < c->a.size(); j++) c->a[j] = let_subst(scope[j - 1], defs, hidden);
             return c;
         }
         for (auto &x : c->a) x = let_subst(x, defs, hidden);

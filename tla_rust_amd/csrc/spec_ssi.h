@@ -38,6 +38,12 @@
 #include <stdio.h>
 #include <string.h>
 
+// MC_SSI_COMMIT_FAMILY (default on): Commit(txn) is a family of its own, LAST in the wavefront's pair list, so the states that end in a
+// `commit` lie together in the arena — and only the wavefronts of the next level that hold them evaluate the three invariants about
+// committed transactions (parent_status_step); 0 = A/B: Commit rides with Begin / ChooseToAbort
+#ifndef MC_SSI_COMMIT_FAMILY
+#define MC_SSI_COMMIT_FAMILY 1
+#endif
 namespace mc {
 
 struct SsiParams { int nt, nk, inv_mask, find, textbook, sym; };  // textbook = 1: examples/textbookSnapshotIsolation.tla; sym: cfg SYMMETRY
@@ -45,6 +51,12 @@ struct SsiParams { int nt, nk, inv_mask, find, textbook, sym; };  // textbook = 
 struct SpecSsi {
     using Params = SsiParams;
     static constexpr int NT = 4, NK = 3, HWORDS = 8, HCAP = 32;
+#ifndef MC_SSI_STEP_STATUS
+#define MC_SSI_STEP_STATUS 1   // (0 = A/B: the kernels evaluate every invariant of every stored state, as in rounds 1-5)
+#endif
+#if MC_SSI_STEP_STATUS
+    static constexpr bool STEP_STATUS = true;      // the kernels evaluate parent_status_step (below)
+#endif
     static constexpr bool CHECK_ON_EXPAND = true;  // invariants live in parent_status: the engine checks a run's last, unexpanded level too
     static constexpr int W_FP = 0, W_META = 1, W_H0 = 2;
     static constexpr int MAX_WORDS = 10;
@@ -129,6 +141,10 @@ struct SpecSsi {
         uint32_t rver0, rver1, rver2;          // per key: 2 bits per txn, version read
         uint32_t abort_reasons;                // bit r: some transaction aborted with reason r
         bool wellformed;
+        // the history's TAIL (parent_status_step): its last event, and whether it ends in `commit` followed by nothing but the aborts of
+        // that commit's losers (reason "First Committer Wins")
+        int tail_op, tail_t, tail_k;
+        bool tail_commit;
     };
     MC_HD static uint32_t pick3(uint32_t a, uint32_t b, uint32_t c, int k) { return k == 0 ? a : k == 1 ? b : c; }
     MC_HD static uint32_t widx(const Local &l, int k) { return pick3(l.widx0, l.widx1, l.widx2, k); }
@@ -145,6 +161,7 @@ struct SpecSsi {
         l.widx0 = l.widx1 = l.widx2 = l.ridx0 = l.ridx1 = l.ridx2 = l.rver0 = l.rver1 = l.rver2 = 0;
         l.abort_reasons = 0;
         l.wellformed = true;
+        l.tail_op = -1; l.tail_t = 0; l.tail_k = 0; l.tail_commit = false;
         // one pass over the history; WellFormedTransactionsInHistory (:1146-1179) is checked on the way
 #pragma unroll
         for (int w = 0; w < HWORDS; w++) {
@@ -157,6 +174,8 @@ struct SpecSsi {
                 const unsigned e = (unsigned)(word >> (16 * q)) & 0xffffu;
                 const int op = (int)(e & 7u), t = (int)(e >> 3 & 3u), k = (int)(e >> 5 & 3u);
                 const unsigned tb = 1u << t, pos = (unsigned)(i + 1);
+                l.tail_op = op; l.tail_t = t; l.tail_k = k;
+                l.tail_commit = op == OP_COMMIT || (l.tail_commit && op == OP_ABORT && (e >> 9 & 7u) == (unsigned)R_FCW);
                 const bool fin = ((l.committed | l.aborted) & tb) != 0, st = (l.started & tb) != 0;
                 if (fin) l.wellformed = false;  // nothing may follow commit / abort
                 if (op == OP_BEGIN) {
@@ -412,15 +431,16 @@ struct SpecSsi {
         d.meta = (d.meta & ~63ull) | (uint64_t)(l.n + d.nev);
         return ST_ENABLED;
     }
-    MC_HD static int slot_family(int slot) {
+    MC_HD static constexpr int slot_family(int slot) {
         if (slot == NT * PER_TXN) return 0;
         const int sub = slot % PER_TXN;
+        if (MC_SSI_COMMIT_FAMILY && sub == 1) return 3;
         return sub < 3 ? 0 : sub == 3 ? 2 : sub < 4 + NK ? 1 : 2;
     }
     MC_HD static unsigned compute(const Params &p, const Local &l, int slot, Delta &d, int &action) {
         delta_init(l, d);
         const int f = slot_family(slot);
-        const bool en = f == 0 ? compute_simple(p, l, slot, d, action) : f == 1 ? compute_read(p, l, slot, d, action) : compute_write(p, l, slot, d, action);
+        const bool en = (f == 0 || f == 3) ? compute_simple(p, l, slot, d, action) : f == 1 ? compute_read(p, l, slot, d, action) : compute_write(p, l, slot, d, action);
         return en ? finish_delta(l, d) : 0u;
     }
 
@@ -476,7 +496,7 @@ struct SpecSsi {
     // the wavefront's 64 parents are then laid out family by family in LDS and evaluated 64 at a time — every lane busy, one family's
     // code path — from the parent's Summary (the tables compute_* reads) and its row, both staged in LDS.  The same evaluation runs a
     // second time for the pairs the seen-set accepted and writes their rows (the successor is parent + new meta + <= 2 history words).
-    static constexpr int PAIR_FAMILIES = 3;
+    static constexpr int PAIR_FAMILIES = MC_SSI_COMMIT_FAMILY ? 4 : 3;
 #ifndef MC_SSI_BLIND
 #define MC_SSI_BLIND 0
 #endif
@@ -499,6 +519,7 @@ struct SpecSsi {
         l.bidx = q.bidx; l.cidx = q.cidx; l.rkeys = q.rkeys; l.wkeys = q.wkeys;
         l.widx0 = q.widx0; l.widx1 = q.widx1; l.widx2 = q.widx2;
         l.ridx0 = l.ridx1 = l.ridx2 = l.rver0 = l.rver1 = l.rver2 = 0; l.abort_reasons = 0; l.wellformed = true;
+        l.tail_op = -1; l.tail_t = 0; l.tail_k = 0; l.tail_commit = false;
     }
     // slots of family f / of round r (transaction r; the termination slot rides with transaction 0) as 128-bit masks (lo: slots 0..63,
     // hi: 64..76); constexpr, so that the kernel's masks are immediates
@@ -507,8 +528,7 @@ struct SpecSsi {
         SlotMask m{0, 0};
         for (int s = 0; s < TOTAL_SLOTS; s++) {
             const int sub = s % PER_TXN;
-            const int fam = s == NT * PER_TXN ? 0 : sub < 3 ? 0 : sub == 3 ? 2 : sub < 4 + NK ? 1 : 2;
-            if (fam == f) { if (s < 64) m.lo |= 1ull << s; else m.hi |= 1ull << (s - 64); }
+            if (slot_family(s) == f) { if (s < 64) m.lo |= 1ull << s; else m.hi |= 1ull << (s - 64); }
         }
         return m;
     }
@@ -588,7 +608,7 @@ struct SpecSsi {
         Delta d;
         delta_init(l, d);
         int action;
-        const bool en = F == 0 ? compute_simple(p, l, slot, d, action) : F == 1 ? compute_read(p, l, slot, d, action) : compute_write(p, l, slot, d, action);
+        const bool en = (F == 0 || F == 3) ? compute_simple(p, l, slot, d, action) : F == 1 ? compute_read(p, l, slot, d, action) : compute_write(p, l, slot, d, action);
         if (!en) return 0;
         const unsigned st = finish_delta(l, d);
         if (st & ST_OVERFLOW) { fp = 1; return st; }
@@ -637,10 +657,9 @@ struct SpecSsi {
         if (r2 & 8u) r2 |= r3;
         return (r0 & 1u) || (r1 & 2u) || (r2 & 4u) || (r3 & 8u);
     }
-    // returns ST_INVARIANT | id << 8, or 0
-    template <class Ref>
-    MC_HD static unsigned parent_status(const Params &p, const Local &l, Ref) {
-        const unsigned all = (1u << p.nt) - 1u;
+    // ---- the invariants in pieces (parent_status: all of them; parent_status_step: those the last step can have changed)
+    // CorrectnessOfHoldingXLocks :1302-1321, CorrectnessOfWaitingForXLock :1324-1330 (the lock variables) and well-formedness (from load)
+    MC_HD static unsigned inv_locks(const Params &p, const Local &l) {
         if ((p.inv_mask & 1) && !l.wellformed) return ST_INVARIANT | (0u << 8);
         if (p.inv_mask & 2) {  // CorrectnessOfHoldingXLocks :1302-1321
             bool ok = true;
@@ -659,34 +678,32 @@ struct SpecSsi {
 #pragma unroll
             for (int t = 0; t < NT; t++) if (t < p.nt && t_wait(m_txn(l.meta, t)) != NOLOCK && !is_active(l, t)) return ST_INVARIANT | (2u << 8);
         }
-        if (p.inv_mask & 8) {  // CorrectReadView :1215-1268
-            bool ok = true;
-#pragma unroll
-            for (int txn = 0; txn < NT; txn++) {
-#pragma unroll
-                for (int key = 0; key < NK; key++) {
-                    if (!(l.rkeys >> (4 * txn + key) & 1u)) continue;
-                    const unsigned ir = idx6(ridx(l, key), txn), itxnb = idx6(l.bidx, txn);
-                    const int ver = (int)(rver(l, key) >> (2 * txn) & 3u);
-                    if (ver != txn) {  // only committed reads
-                        const unsigned irfc = idx6(l.cidx, ver);
-                        if (!irfc || !(irfc < itxnb)) ok = false;
-                    }
-                    const unsigned iwkv = idx6(widx(l, key), ver);
-#pragma unroll
-                    for (int w = 0; w < NT; w++) {  // only up-to-date reads
-                        const unsigned wi = idx6(widx(l, key), w), ci = idx6(l.cidx, w);
-                        if (wi > iwkv && wi <= itxnb && ci && ci <= itxnb) ok = false;
-                    }
-                    const unsigned iw = idx6(widx(l, key), txn);
-                    if (iw) {  // key both read and written by txn
-                        if (ir < iw) { if (ver != latest_version(p, l, txn, key)) ok = false; }
-                        else if (ver != txn) ok = false;
-                    }
-                }
-            }
-            if (!ok) return ST_INVARIANT | (3u << 8);
+        return 0;
+    }
+    // CorrectReadView :1215-1268 for ONE read event: txn read key (the caller knows it did)
+    MC_HD static bool read_view_ok(const Params &p, const Local &l, int txn, int key) {
+        bool ok = true;
+        const unsigned ir = idx6(ridx(l, key), txn), itxnb = idx6(l.bidx, txn);
+        const int ver = (int)(rver(l, key) >> (2 * txn) & 3u);
+        if (ver != txn) {  // only committed reads
+            const unsigned irfc = idx6(l.cidx, ver);
+            if (!irfc || !(irfc < itxnb)) ok = false;
         }
+        const unsigned iwkv = idx6(widx(l, key), ver);
+#pragma unroll
+        for (int w = 0; w < NT; w++) {  // only up-to-date reads
+            const unsigned wi = idx6(widx(l, key), w), ci = idx6(l.cidx, w);
+            if (wi > iwkv && wi <= itxnb && ci && ci <= itxnb) ok = false;
+        }
+        const unsigned iw = idx6(widx(l, key), txn);
+        if (iw) {  // key both read and written by txn
+            if (ir < iw) { if (ver != latest_version(p, l, txn, key)) ok = false; }
+            else if (ver != txn) ok = false;
+        }
+        return ok;
+    }
+    // FirstCommitterWins :1271-1278, CahillSerializable :1379-1446, BernsteinSerializable :1505-1556: statements about COMMITTED transactions
+    MC_HD static unsigned inv_committed(const Params &p, const Local &l) {
         if (p.inv_mask & 16) {  // FirstCommitterWins :1271-1278 with AreConcurrent :1118-1133
 #pragma unroll
             for (int a = 0; a < NT; a++)
@@ -736,6 +753,9 @@ struct SpecSsi {
                 }
             if (has_cycle(adj)) return ST_INVARIANT | (6u << 8);
         }
+        return 0;
+    }
+    MC_HD static unsigned inv_find(const Params &p, const Local &l) {
         if (p.find >= 1 && p.find <= 6) {  // ~AtLeastNTxnsAbortedDueToReason(1, r) :1579-1582
             if (l.abort_reasons >> (p.find - 1) & 1u) return ST_INVARIANT | (7u << 8);
         } else if (p.find == 7) {  // ~AtLeastNTxnsAreWaitingForLocks(2) :1578
@@ -744,8 +764,50 @@ struct SpecSsi {
             for (int t = 0; t < NT; t++) n += (t < p.nt && t_wait(m_txn(l.meta, t)) != NOLOCK) ? 1 : 0;
             if (n >= 2) return ST_INVARIANT | (7u << 8);
         }
-        (void)all;
         return 0;
+    }
+    // returns ST_INVARIANT | id << 8, or 0: EVERY invariant of the state, whatever its history (known-answer tests, the host)
+    template <class Ref>
+    MC_HD static unsigned parent_status(const Params &p, const Local &l, Ref) {
+        if (const unsigned r = inv_locks(p, l)) return r;
+        if (p.inv_mask & 8) {  // CorrectReadView :1215-1268
+            bool ok = true;
+#pragma unroll
+            for (int txn = 0; txn < NT; txn++) {
+#pragma unroll
+                for (int key = 0; key < NK; key++) {
+                    if (!(l.rkeys >> (4 * txn + key) & 1u)) continue;
+                    if (!read_view_ok(p, l, txn, key)) ok = false;
+                }
+            }
+            if (!ok) return ST_INVARIANT | (3u << 8);
+        }
+        if (const unsigned r = inv_committed(p, l)) return r;
+        return inv_find(p, l);
+    }
+    // The same verdict for a state REACHED BY THE SEARCH, from what its last step can have changed (round 6; the kernels call this one:
+    // engine_kernels.h stored_state_status).  Every state the search stores was generated from a state that was expanded — i.e. checked —
+    // before (BFS: a violation ends the run at the end of its level), and the history is append-only, so the state's history is its
+    // predecessor's, which satisfied every invariant, plus the events of ONE step at its end:
+    //   * well-formedness and the two lock invariants read the lock variables: evaluated always (a few instructions);
+    //   * CorrectReadView is a statement per read event, whose terms are fixed from then on — the version read, commits and writes BEFORE
+    //     the reader began (a later commit lies after it) — except "key both read and written by txn", which a later WRITE of the same
+    //     (txn, key) completes: it can only have changed for the (txn, key) of a last event that is a READ or a WRITE;
+    //   * FirstCommitterWins and the two serialization graphs speak about COMMITTED transactions only, whose begin / commit positions,
+    //     read and write sets are final: they can only have changed if the last step committed somebody — the history ends in `commit`,
+    //     possibly followed by the First-Committer-Wins aborts of that commit's losers (taken conservatively: the same tail can also be
+    //     a commit followed by an unrelated lost write, where re-evaluating is merely redundant);
+    //   * a step that appends nothing (a write that blocks) re-evaluates its predecessor's tail: redundant, never wrong.
+    // tests/_shim (PairCheck) compares this with parent_status on every state the lowering visits, violating models included.
+    template <class Ref>
+    MC_HD static unsigned parent_status_step(const Params &p, const Local &l, Ref) {
+        if (const unsigned r = inv_locks(p, l)) return r;
+        if ((p.inv_mask & 8) && (l.tail_op == OP_READ || l.tail_op == OP_WRITE) && (l.rkeys >> (4 * l.tail_t + l.tail_k) & 1u) &&
+            !read_view_ok(p, l, l.tail_t, l.tail_k))
+            return ST_INVARIANT | (3u << 8);
+        if (l.tail_commit)
+            if (const unsigned r = inv_committed(p, l)) return r;
+        return inv_find(p, l);
     }
 
     // ------------------------------------------------------------------ host side
