@@ -101,6 +101,11 @@ typedef struct {
 #define MC_F_UNVERIFIED 512u /* mc_check_files / mc_resolve_files: when the module an MC wrapper EXTENDS (raft.tla, the snapshot-isolation
                              specs) is found neither beside it nor under $TLA_PATH, use the built-in lowering anyway (the report
                              carries a warning) instead of failing with MC_ENOSPEC                                          */
+#define MC_F_JIT 262144u /* MC_SPEC_PCAL engines: translate the compiled program into straight-line C++ (mc_program_codegen) and build it for
+                            the device when the engine is created (hipcc, cached by the hash of the text: seconds to a minute the first
+                            time) instead of interpreting its bytecode on the device; $TLAMC_JIT=1 does the same for every such engine.
+                            Same packed states, fingerprints and counts; a program the translator does not cover (sets of records) or
+                            a box without hipcc falls back to the interpreter and says so on stderr */
 #define MC_F_GENERIC 128u /* mc_check_files: run a PlusCal module through the compiled program (MC_SPEC_PCAL) even
                              when a hand lowering of its algorithm exists (A/B of the two paths)  */
 
@@ -452,6 +457,9 @@ int mc_pcal_translate(const char *tla_text, char *out, size_t cap);   /* >= 0: b
 int mc_program_compile(const char *tla_text, const char *cfg_text, mc_program **out);
 int mc_program_spec(const mc_program *p, mc_spec_desc *out);          /* valid while p lives */
 const char *mc_program_translated(const mc_program *p);               /* the module text after translation */
+/* the program as generated C++ (a header for tla_rust_amd/csrc/spec_gen.h: what MC_F_JIT compiles): the text's length, at most cap - 1
+ * characters of it in buf; MC_EBADCFG (+ mc_last_error) when the program uses an instruction the translator does not cover */
+long mc_program_codegen(const mc_program *p, char *buf, size_t cap);
 const char *mc_program_invariant(const mc_program *p, int index);     /* name of INVARIANT number index */
 int mc_program_assert_pos(const mc_program *p, int index, int *line, int *col);  /* source position of an assert */
 void mc_program_free(mc_program *p);

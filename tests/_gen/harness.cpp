@@ -1,0 +1,80 @@
+// tests/_gen/harness.cpp — TEST-ONLY: the GENERATED lowering of a compiled PlusCal program (tla_rust_amd/csrc/pcal_codegen.cpp -> spec_gen.h)
+// against the bytecode interpreter (spec_vm.h) on the host, state by state: a breadth-first search driven by the interpreter, and for
+// EVERY reachable state and EVERY slot the two back-ends must agree on the status, the fingerprint and the successor's packed row; the
+// initial states likewise.  Built per program by tests/helpers.py gen_harness (g++, the generated header given with -DGEN_HEADER), loaded
+// beside libshim.so (which holds the PlusCal front-end the interpreter's host helpers live in).
+#include GEN_HEADER
+#include <stdint.h>
+#include <string.h>
+#include <unordered_set>
+#include <vector>
+
+using namespace mc;
+
+struct GenCheck {
+    uint64_t distinct, generated, mismatches, states_checked, pairs_checked, first_bad_state, first_bad_slot;
+    uint32_t depth;
+    int32_t first_bad_kind;   // 1 status, 2 fingerprint, 3 row, 4 init
+};
+
+extern "C" int gen_check(const void *program, uint64_t max_states, GenCheck *out) {
+    memset(out, 0, sizeof *out);
+    const int64_t handle = (int64_t)(intptr_t)program;
+    VmParams p;
+    if (SpecGen::make_params(&handle, 1, p)) return -1;   // (also: the generated constants are this program's)
+    using VM = SpecVm;
+    using GS = SpecGen;
+    const int W = p.words;
+    auto bad = [&](int kind, uint64_t state, uint64_t slot) {
+        if (!out->mismatches++) { out->first_bad_kind = kind; out->first_bad_state = state; out->first_bad_slot = slot; }
+    };
+    std::unordered_set<uint64_t> seen;
+    std::vector<uint64_t> cur, next;
+    uint64_t a[VM::MAX_WORDS], b[VM::MAX_WORDS];
+    for (uint64_t k = 0; k < VM::num_init(p); k++) {
+        memset(a, 0, sizeof a);
+        memset(b, 0xff, sizeof b);
+        VM::init(p, k, WordRef{a, 1});
+        GS::init(p, k, WordRef{b, 1});
+        if (memcmp(a, b, (size_t)W * 8) || VM::init_status(p, CWordRef{a, 1}) != GS::init_status(p, CWordRef{a, 1}) || VM::fp_of(p, CWordRef{a, 1}) != GS::fp_of(p, CWordRef{a, 1}))
+            bad(4, k, 0);
+        out->generated++;
+        if (VM::init_status(p, CWordRef{a, 1}) & ST_OUT_OF_MODEL) continue;
+        if (seen.insert(VM::fp_of(p, CWordRef{a, 1})).second) { next.insert(next.end(), a, a + W); out->distinct++; }
+    }
+    cur.swap(next);
+    uint32_t level = 1;
+    const int ns = p.ninst * p.maxch + 1;
+    while (!cur.empty() && (!max_states || out->distinct < max_states)) {
+        const uint64_t n = cur.size() / (size_t)W;
+        for (uint64_t i = 0; i < n; i++) {
+            const CWordRef s{&cur[i * (size_t)W], 1};
+            VM::Local lv;
+            GS::Local lg;
+            VM::load(p, s, lv);
+            GS::load(p, s, lg);
+            out->states_checked++;
+            for (int slot = 0; slot < ns; slot++) {
+                uint64_t f0 = 0, f1 = 0;
+                const unsigned s0 = VM::eval(p, lv, s, slot, f0), s1 = GS::eval(p, lg, s, slot, f1);
+                out->pairs_checked++;
+                if (s0 != s1) { bad(1, out->states_checked - 1, (uint64_t)slot); continue; }
+                if (!(s0 & ST_ENABLED)) continue;
+                out->generated++;
+                if (f0 != f1) bad(2, out->states_checked - 1, (uint64_t)slot);
+                if (s0 & (ST_ASSERT | ST_SPECERR | ST_OVERFLOW | ST_OUT_OF_MODEL)) continue;
+                memset(a, 0, sizeof a);
+                memset(b, 0xff, sizeof b);
+                VM::apply(p, s, slot, WordRef{a, 1});
+                GS::apply(p, s, slot, WordRef{b, 1});
+                if (memcmp(a, b, (size_t)W * 8)) bad(3, out->states_checked - 1, (uint64_t)slot);
+                if (seen.insert(f0).second) { next.insert(next.end(), a, a + W); out->distinct++; }
+            }
+        }
+        cur.clear();
+        cur.swap(next);
+        if (!cur.empty()) level++;
+    }
+    out->depth = level;
+    return 0;
+}

@@ -503,6 +503,8 @@ extern "C" void *shim_program_compile2(const char *tla_text, const char *invaria
     return P;
 }
 extern "C" void shim_program_free(void *p) { delete (pcal::Program *)p; }
+extern "C" long pcal_codegen_text(const pcal::Program *p, char *buf, size_t cap);   // tla_rust_amd/csrc/pcal_codegen.cpp (linked as is, like the front-end)
+extern "C" long shim_program_codegen(void *p, char *buf, size_t cap) { return pcal_codegen_text((const pcal::Program *)p, buf, cap); }
 extern "C" const char *shim_program_translated(void *p) { return ((pcal::Program *)p)->translated.c_str(); }
 
 // the DEVICE lowering's invariants on a hand-made history (known-answer tests of the reference's specs):

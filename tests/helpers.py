@@ -135,7 +135,7 @@ def build_shim():
     out.mkdir(exist_ok=True)
     so = out / "libshim.so"
     csrc = ROOT / "tla_rust_amd" / "csrc"
-    pcal = [csrc / "pcal.cpp", csrc / "pcal_compile.cpp"]  # the PlusCal front-end is host code: linked as is
+    pcal = [csrc / "pcal.cpp", csrc / "pcal_compile.cpp", csrc / "pcal_codegen.cpp"]  # the PlusCal front-end is host code: linked as is
     srcs = [SHIM_DIR / "shim.cpp"] + pcal + list(csrc.glob("*.h")) + [ROOT / "include" / "tlamc.h"]
     def fresh():
         return so.exists() and all(so.stat().st_mtime >= s.stat().st_mtime for s in srcs)
@@ -250,6 +250,50 @@ class ShimProgram:
         if self.h:
             self.lib.shim_program_free(self.h)
             self.h = None
+
+
+def program_codegen(prog):
+    """the generated C++ of a ShimProgram (pcal_codegen.cpp through the host build's door); RuntimeError when the translator refuses it"""
+    lib = shim_lib()
+    lib.shim_program_codegen.restype = C.c_long
+    lib.shim_program_codegen.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.shim_last_error.restype = C.c_char_p
+    n = lib.shim_program_codegen(prog.h, None, 0)
+    if n < 0:
+        raise RuntimeError(lib.shim_last_error().decode())
+    buf = C.create_string_buffer(n + 1)
+    lib.shim_program_codegen(prog.h, buf, n + 1)
+    return buf.value.decode()
+
+
+class GenCheck(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("distinct", "generated", "mismatches", "states_checked", "pairs_checked", "first_bad_state", "first_bad_slot")] + \
+               [("depth", C.c_uint32), ("first_bad_kind", C.c_int32)]
+
+
+def gen_check(prog, max_states=0):
+    """tests/_gen/harness.cpp built around the generated code of `prog` (g++, cached by the text's hash): generated code against the
+    interpreter on every reachable state and slot"""
+    import hashlib
+    text = program_codegen(prog)
+    out = ROOT / "tests" / "_gen" / "_build"
+    out.mkdir(exist_ok=True)
+    tag = hashlib.sha256((text + (ROOT / "tests" / "_gen" / "harness.cpp").read_text() + (ROOT / "tla_rust_amd" / "csrc" / "spec_gen.h").read_text()).encode()).hexdigest()[:16]
+    so, hdr = out / f"libgen_{tag}.so", out / f"gen_{tag}.h"
+    if not so.exists():
+        hdr.write_text(text)
+        tmp = out / f"libgen_{tag}.{os.getpid()}.tmp"
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-w", "-I", str(ROOT / "tla_rust_amd" / "csrc"), "-I", str(ROOT / "include"),
+                        f'-DGEN_HEADER="{hdr}"', "-o", str(tmp), str(ROOT / "tests" / "_gen" / "harness.cpp")], check=True)
+        os.replace(tmp, so)
+    C.CDLL(str(build_shim()), mode=C.RTLD_GLOBAL)   # the interpreter's host helpers (vm_make_params, ...) live in the front-end
+    lib = C.CDLL(str(so))
+    lib.gen_check.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(GenCheck)]
+    r = GenCheck()
+    rc = lib.gen_check(prog.h, max_states, C.byref(r))
+    if rc:
+        raise RuntimeError(f"gen_check: {rc}")
+    return {k: getattr(r, k) for k, _ in GenCheck._fields_}
 
 
 def pcal_translate(tla_text):

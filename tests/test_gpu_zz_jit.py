@@ -1,0 +1,67 @@
+"""GPU leg of tests/test_codegen.py: compiled PlusCal programs as GENERATED code on the device (MC_F_JIT: tla_rust_amd/csrc/pcal_codegen.cpp
+writes the program as C++ for spec_gen.h, hipcc builds it into an engine library when the engine is created) against the bytecode
+interpreter on the same device — counters, verdict, depth, per-level counts and the per-level SETS of packed states (the two back-ends
+store the same rows) — and, through tests/test_gpu_pcal.py's chain, against oracle/tla_eval.py.  (Sorts behind the other GPU files: the
+first engine of each program pays ~20 s of compilation.)"""
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+from test_gpu_pcal import cfg_text  # noqa: E402
+from test_pcal import CASES  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+PICK = ["pcal_intro", "atomic_add", "peterson", "ticket_lock", "treiber_stack", "ms_queue", "bounded_queue", "mailboxes", "recursive_sum", "radix_tree"]
+JIT_CASES = []
+for stem in PICK:
+    c = next((c for c in CASES if c[0].stem == stem), None)
+    if c is not None:
+        JIT_CASES.append(c)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import tla_rust_amd
+    assert tla_rust_amd.device_count() >= 1, "no HIP device visible"
+    return tla_rust_amd
+
+
+def level_sets(eng, r):
+    out, first = [], 0
+    for n in r["levels"]:
+        out.append(sorted(eng.read_states(first, n)))
+        first += n
+    return out
+
+
+@pytest.mark.parametrize("path,invs,consts", JIT_CASES, ids=lambda v: v.stem if isinstance(v, Path) else None)
+def test_generated_code_on_gpu_equals_the_interpreter(amd, path, invs, consts, capfd):
+    prog = amd.Program(path.read_text(), cfg_text(invs, consts))
+    kw = dict(table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
+    a = amd.Engine("pcal", prog.params, jit=True, **kw)
+    assert "interpreting the program" not in capfd.readouterr().err, "MC_F_JIT fell back to the interpreter"
+    b = amd.Engine("pcal", prog.params, **kw)
+    ra, rb = a.run(), b.run()
+    for k in ("distinct", "generated", "queue_left", "depth", "levels", "verdict"):
+        assert getattr(ra, k) == getattr(rb, k), (k, getattr(ra, k), getattr(rb, k))
+    if ra.verdict == "ok" and ra.distinct <= 60000:
+        assert level_sets(a, ra) == level_sets(b, rb)
+    a.close()
+    b.close()
+    prog.close()
+
+
+def test_a_program_the_translator_refuses_is_interpreted(amd, capfd):
+    """sets of records (the message soup) are not translated: MC_F_JIT says so on stderr and the interpreter runs — same counts as without the flag"""
+    c = next(c for c in CASES if c[0].stem == "two_phase_soup")
+    prog = amd.Program(c[0].read_text(), cfg_text(c[1], c[2]))
+    kw = dict(table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
+    a = amd.Engine("pcal", prog.params, jit=True, **kw)
+    assert "sets of records" in capfd.readouterr().err
+    b = amd.Engine("pcal", prog.params, **kw)
+    ra, rb = a.run(), b.run()
+    assert (ra.distinct, ra.generated, ra.depth, ra.verdict) == (rb.distinct, rb.generated, rb.depth, rb.verdict)
+    a.close(); b.close(); prog.close()

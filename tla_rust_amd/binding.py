@@ -256,11 +256,12 @@ class Engine:
     """One model-checking engine on one GPU (mc_engine_create / run / trace / destroy)."""
 
     def __init__(self, spec, params, device=0, table_capacity=0, arena_capacity=0, chunk_states=0, max_levels=0,
-                 max_distinct=0, deadlock=True, trace=True, timing=False, matrix=False, shard_rank=0, shard_count=1, debug_flags=0):
+                 max_distinct=0, deadlock=True, trace=True, timing=False, matrix=False, shard_rank=0, shard_count=1, debug_flags=0, jit=False):
         self.spec, self.params = spec, list(params)
         self.desc = spec_desc(spec, params)
+        # jit (MC_SPEC_PCAL): MC_F_JIT — the compiled program as generated code, built for the device when the engine is created
         flags = (MC_F_DEADLOCK if deadlock else 0) | (MC_F_TRACE if trace else 0) | (MC_F_TIMING if timing else 0) | \
-            (MC_F_MATRIX if matrix else 0) | debug_flags
+            (MC_F_MATRIX if matrix else 0) | (262144 if jit else 0) | debug_flags
         self.cfg = Config(device, flags, table_capacity, arena_capacity, chunk_states, max_levels, max_distinct,
                           shard_rank, shard_count)
         self._h = C.c_void_p()

@@ -48,7 +48,8 @@ def build(force=False, verbose=False):
             jobs.append((obj, subprocess.Popen(common + ["-x", "hip", f"-DMC_TU={tu}", "-c", str(CSRC / "engine.hip"), "-o", str(obj)])))
     host_deps = {"frontend": ["frontend.cpp", "pcal.h", "spec_vm.h", "mc_common.h", "tlaeval.h"], "pcal": ["pcal.cpp", "pcal.h"],
                  "tlaeval": ["tlaeval.cpp", "tlaeval.h"],
-                 "pcal_compile": ["pcal_compile.cpp", "pcal.h", "spec_vm.h", "mc_common.h"]}
+                 "pcal_compile": ["pcal_compile.cpp", "pcal.h", "spec_vm.h", "mc_common.h"],
+                 "pcal_codegen": ["pcal_codegen.cpp", "pcal.h", "spec_vm.h", "mc_common.h"]}
     for name, dd in host_deps.items():
         obj = OUT / f"{name}.o"
         objs.append(obj)

@@ -34,6 +34,7 @@ extern "C" void mc_set_error_internal(const char *msg);  // engine.hip
 struct mc_program {
     pcal::Program prog;
 };
+extern "C" long pcal_codegen_text(const pcal::Program *p, char *buf, size_t cap);   // pcal_codegen.cpp
 
 namespace {
 
@@ -650,6 +651,7 @@ int mc_program_spec(const mc_program *p, mc_spec_desc *out) {
     return MC_OK;
 }
 const char *mc_program_translated(const mc_program *p) { return p ? p->prog.translated.c_str() : ""; }
+long mc_program_codegen(const mc_program *p, char *buf, size_t cap) { return p ? pcal_codegen_text(&p->prog, buf, cap) : (long)MC_EBADCFG; }
 const char *mc_program_invariant(const mc_program *p, int index) {
     return p && index >= 0 && (size_t)index < p->prog.invariants.size() ? p->prog.invariants[(size_t)index].c_str() : "?";
 }
@@ -1234,6 +1236,7 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     if (R.check_deadlock >= 0) {   // the cfg's CHECK_DEADLOCK statement decides over the default (the command line's -deadlock still turns it off)
         with_cfg_statements = *cfg;
         if (!R.check_deadlock) with_cfg_statements.flags &= ~MC_F_DEADLOCK;
+        else with_cfg_statements.flags |= MC_F_DEADLOCK;   // CHECK_DEADLOCK TRUE asks for the check whatever the caller's flags said
         cfg = &with_cfg_statements;
     }
     if ((rc = mc_engine_create(&d, cfg, &e))) return rc;

@@ -1,0 +1,448 @@
+// pcal_codegen.cpp — a compiled PlusCal program (pcal_compile.cpp: the bytecode image the interpreter of spec_vm.h runs) translated into
+// straight-line C++ for spec_gen.h, and the load-time build of that text into a gfx950 engine (north_star: "lowering each spec's
+// next-state relation to a fixed-width packed state vector so that successor generation runs as a ... HIP kernel"; VERDICT round 5,
+// next 3: "stop interpreting on the device").
+//
+// The translation is a static recompilation of the stack code: from every entry point (the labels of the algorithm, the enumeration of
+// the initial states, the invariants and constraints) the reachable instructions are walked once with an ABSTRACT stack — the depth is a
+// compile-time fact of well-formed code, so stack slot k becomes the C++ local s<k> and a temporary the local t<k> —, every jump target
+// becomes a C++ label, every instruction one or two statements.  What the interpreter indexes at run time is made static: a label
+// function is a template over the process INSTANCE (so `pc[self]` is the cell PC_BASE + INST and `self` a constant), an array or a
+// sequence indexed by a run-time value becomes a chain of selects over its (small, constant) extent, an array of sequences a switch
+// over the selected element.  The variable cells v[0 .. NV) are then only ever indexed by constants: after inlining, the compiler keeps
+// them in registers (the interpreter's per-lane arrays live in scratch memory: dynamic indexing).
+// Not translated (mc_program_codegen fails, the interpreter runs): sets of records (VM_RSADD / RSDEL / RSHAS).
+#include "pcal.h"
+#include "spec_vm.h"
+#include "../../include/tlamc.h"
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+extern "C" void mc_set_error_internal(const char *msg);   // engine.hip (the C ABI's last-error text)
+namespace mc {
+static void set_error(const std::string &m) { mc_set_error_internal(m.c_str()); }
+}
+
+namespace pcal {
+
+struct GenError { std::string msg; };
+
+namespace {
+
+using namespace mc;
+
+int operands(int op) {
+    switch (op) {
+    case VM_PUSH: case VM_LOAD: case VM_STORE: case VM_LOADT: case VM_STORET: case VM_JMP: case VM_JZ: case VM_JNZ: case VM_CHOOSE: case VM_ASSERT: case VM_SETPC: return 1;
+    case VM_LOADX: case VM_STOREX: case VM_LOADSEQ: case VM_STORESEQ: case VM_APPEND: case VM_TAIL: case VM_SEQCLR: case VM_SEQCOPY: case VM_SEQSEL: case VM_SEQLEN:
+    case VM_RSADD: case VM_RSDEL: case VM_RSHAS: return 3;
+    default: return 0;
+    }
+}
+
+struct AState {      // what is known at an instruction: stack depth, depth of "read the old variables" nesting, sequence selections on the stack
+    int depth = 0, old = 0;
+    std::map<int, std::pair<int, int>> sel;   // stack slot -> (n, stride) of the VM_SEQSEL that produced it
+    bool operator==(const AState &o) const { return depth == o.depth && old == o.old && sel == o.sel; }
+};
+
+struct Gen {
+    const std::vector<int> &c;
+    std::ostringstream out;
+    explicit Gen(const std::vector<int> &image) : c(image) {}
+    [[noreturn]] void fail(const std::string &m) { throw GenError{m}; }
+
+    static std::string S(int k) { return "s" + std::to_string(k); }
+    // the cell array a READ goes to: the state being built, or the state before the step inside a defined operator
+    static std::string RD(const AState &a) { return a.old > 0 ? "old" : "v"; }
+    // arr[base + i] for a run-time i in [0, n): a chain of selects (every index a constant)
+    // a variable cell: a NAMED member of the generated struct Cells (v.c12), not an array element — the compiler turned chains of selects
+    // over neighbouring array elements back into ONE load with a computed index ("switch.lookup"), and an array that is indexed by a
+    // variable anywhere lives in scratch memory everywhere (first device run: 565 GB of scratch traffic for 6.5 GB of states); a struct
+    // member cannot be indexed by a variable
+    static std::string CELL(const std::string &arr, int k) { return arr + ".c" + std::to_string(k); }
+    static std::string chain_load(const std::string &arr, int base, int n, const std::string &i) {
+        std::string e = CELL(arr, base + n - 1);
+        for (int k = n - 2; k >= 0; --k) e = "(" + i + " == " + std::to_string(k) + " ? " + CELL(arr, base + k) + " : " + e + ")";
+        return e;
+    }
+    static std::string chain_store(int base, int n, const std::string &i, const std::string &val) {
+        std::string s;
+        for (int k = 0; k < n; ++k) s += " " + CELL("v", base + k) + " = " + i + " == " + std::to_string(k) + " ? " + val + " : " + CELL("v", base + k) + ";";
+        return s;
+    }
+
+    // one entry point -> one function body (without the signature); `inst_templ`: label code (SELF_ / INST are template constants)
+    std::string body(int entry) {
+        std::map<int, AState> at;     // state BEFORE each reachable instruction
+        std::vector<int> work{entry};
+        at[entry] = AState{};
+        std::set<int> targets;
+        auto flow = [&](int pc, const AState &st) {
+            auto it = at.find(pc);
+            if (it == at.end()) { at[pc] = st; work.push_back(pc); }
+            else if (!(it->second == st)) fail("stack shapes differ at a join (pc " + std::to_string(pc) + ")");
+        };
+        int max_depth = 0, max_temp = -1;
+        while (!work.empty()) {
+            const int pc = work.back();
+            work.pop_back();
+            if (pc < 0 || pc >= (int)c.size()) fail("jump outside the image");
+            AState a = at[pc];
+            const int op = c[(size_t)pc], n = operands(op), next = pc + 1 + n;
+            auto pop = [&](int k) { for (int j = 0; j < k; ++j) { a.depth--; a.sel.erase(a.depth); } if (a.depth < 0) fail("stack underflow"); };
+            auto push = [&]() { a.sel.erase(a.depth); a.depth++; if (a.depth > 16) fail("stack deeper than 16"); };
+            const int o0 = n > 0 ? c[(size_t)pc + 1] : 0, o2 = n > 2 ? c[(size_t)pc + 3] : 0;
+            switch (op) {
+            case VM_HALT: case VM_FAIL: continue;
+            case VM_PUSH: case VM_SELF: case VM_LOAD: case VM_LOADT: case VM_CHOOSE: push(); break;
+            case VM_STORE: case VM_AWAIT: case VM_ASSERT: case VM_POP: pop(1); break;
+            case VM_STORET: pop(1); if (o0 > max_temp) max_temp = o0; break;
+            case VM_LOADX: pop(1); push(); break;
+            case VM_STOREX: pop(2); break;
+            case VM_ADD: case VM_SUB: case VM_MUL: case VM_DIV: case VM_MOD: case VM_EQ: case VM_NE: case VM_LT: case VM_LE: case VM_GT: case VM_GE:
+            case VM_OR: case VM_AND: case VM_ANDN: pop(2); push(); break;
+            case VM_NEG: case VM_NOT: case VM_BIT: case VM_POPCNT: pop(1); push(); break;
+            case VM_JMP: targets.insert(o0); flow(o0, a); continue;
+            case VM_JZ: case VM_JNZ: pop(1); targets.insert(o0); flow(o0, a); break;
+            case VM_SETPC: case VM_NOP: break;
+            case VM_OLD_ON: a.old++; break;
+            case VM_OLD_OFF: a.old--; if (a.old < 0) fail("unbalanced VM_OLD_OFF"); break;
+            case VM_SEQSEL: {
+                pop(1);
+                const int slot = a.depth;
+                push();
+                a.sel[slot] = {c[(size_t)pc + 2], c[(size_t)pc + 3]};   // (n, stride)
+                break;
+            }
+            case VM_SEQLEN: if (o2) { if (!a.sel.count(a.depth - 1)) fail("sequence selection lost"); pop(1); } push(); break;
+            case VM_LOADSEQ: if (o2) { if (!a.sel.count(a.depth - 1)) fail("sequence selection lost"); pop(1); } pop(1); push(); break;
+            case VM_STORESEQ: if (o2) { if (!a.sel.count(a.depth - 1)) fail("sequence selection lost"); pop(1); } pop(2); break;
+            case VM_APPEND: if (o2) { if (!a.sel.count(a.depth - 1)) fail("sequence selection lost"); pop(1); } pop(1); break;
+            case VM_TAIL: case VM_SEQCLR: if (o2) { if (!a.sel.count(a.depth - 1)) fail("sequence selection lost"); pop(1); } break;
+            case VM_SEQCOPY: break;
+            case VM_RSADD: case VM_RSDEL: case VM_RSHAS: fail("sets of records are not translated (VM_RSADD / VM_RSDEL / VM_RSHAS)");
+            default: fail("unknown instruction " + std::to_string(op));
+            }
+            if (a.depth > max_depth) max_depth = a.depth;
+            flow(next, a);
+        }
+        // ---- emission, in address order
+        std::ostringstream b;
+        b << "        int32_t";
+        for (int k = 0; k < (max_depth > 0 ? max_depth : 1); ++k) b << (k ? ", " : " ") << "s" << k << " = 0";
+        for (int k = 0; k <= max_temp; ++k) b << ", t" << k << " = 0";
+        b << ";\n        (void)s0; (void)&old; (void)aux; (void)result;\n";
+        int prev_next = entry;
+        bool prev_falls = true;
+        for (const auto &kv : at) {
+            const int pc = kv.first;
+            const AState &a = kv.second;
+            const int op = c[(size_t)pc], n = operands(op), next = pc + 1 + n;
+            if (prev_falls && pc != prev_next) b << "        goto L" << prev_next << ";\n";   // (the code between was not reachable from this entry)
+            if (targets.count(pc) || pc == entry) b << "    L" << pc << ": ;\n";
+            const int d = a.depth;
+            const int o0 = n > 0 ? c[(size_t)pc + 1] : 0, o1 = n > 1 ? c[(size_t)pc + 2] : 0, o2 = n > 2 ? c[(size_t)pc + 3] : 0;
+            const std::string top = S(d - 1), sec = S(d - 2), rd = RD(a);
+            auto I = [](int v) { return std::to_string(v); };
+            b << "        ";
+            prev_falls = true;
+            // a sequence instruction on element `sel` of an array of sequences: a switch over the element (constant bases inside)
+            auto seq_op = [&](bool indexed, int selslot, int base, auto &&emit_one) {
+                if (!indexed) { b << "{ " << emit_one(base) << " }"; return; }
+                const auto sl = a.sel.at(selslot);
+                b << "switch (" << S(selslot) << ") {";
+                for (int k = 0; k < sl.first; ++k) b << " case " << I(k * sl.second) << ": { " << emit_one(base + k * sl.second) << " } break;";
+                b << " default: return R_ERROR; }";
+            };
+            switch (op) {
+            case VM_HALT: b << "result = " << (d > 0 ? top : std::string("0")) << "; return ch == 0 ? R_OK : R_DISABLED;"; prev_falls = false; break;
+            case VM_FAIL: b << "return R_ERROR;"; prev_falls = false; break;
+            case VM_PUSH: b << S(d) << " = " << I(o0) << ";"; break;
+            case VM_SELF: b << S(d) << " = SELF_;"; break;
+            case VM_LOAD: b << S(d) << " = " << CELL(rd, o0) << ";"; break;
+            case VM_LOADT: b << S(d) << " = t" << I(o0) << ";"; break;
+            case VM_STORET: b << "t" << I(o0) << " = " << top << ";"; break;
+            case VM_STORE: b << CELL("v", o0) << " = " << top << ";"; break;
+            case VM_LOADX: b << "{ const int32_t i_ = " << top << " - (" << I(o1) << "); if (i_ < 0 || i_ >= " << I(o2) << ") return R_ERROR; " << top << " = "
+                             << chain_load(rd, o0, o2, "i_") << "; }"; break;
+            case VM_STOREX: b << "{ const int32_t val_ = " << top << ", i_ = " << sec << " - (" << I(o1) << "); if (i_ < 0 || i_ >= " << I(o2) << ") return R_ERROR;"
+                              << chain_store(o0, o2, "i_", "val_") << " }"; break;
+            case VM_ADD: b << "{ int32_t r_; if (__builtin_add_overflow(" << sec << ", " << top << ", &r_)) return R_ERROR; " << sec << " = r_; }"; break;
+            case VM_SUB: b << "{ int32_t r_; if (__builtin_sub_overflow(" << sec << ", " << top << ", &r_)) return R_ERROR; " << sec << " = r_; }"; break;
+            case VM_MUL: b << "{ int32_t r_; if (__builtin_mul_overflow(" << sec << ", " << top << ", &r_)) return R_ERROR; " << sec << " = r_; }"; break;
+            case VM_DIV: b << "{ const int32_t a_ = " << sec << ", b_ = " << top << "; if (b_ == 0 || (a_ == INT32_MIN && b_ == -1)) return R_ERROR; int32_t q_ = a_ / b_; "
+                              "if ((a_ % b_ != 0) && ((a_ < 0) != (b_ < 0))) --q_; " << sec << " = q_; }"; break;
+            case VM_MOD: b << "{ const int32_t a_ = " << sec << ", b_ = " << top << "; if (b_ <= 0) return R_ERROR; int32_t r_ = a_ % b_; if (r_ < 0) r_ += b_; " << sec << " = r_; }"; break;
+            case VM_NEG: b << "if (" << top << " == INT32_MIN) return R_ERROR; " << top << " = -" << top << ";"; break;
+            case VM_EQ: b << sec << " = " << sec << " == " << top << ";"; break;
+            case VM_NE: b << sec << " = " << sec << " != " << top << ";"; break;
+            case VM_LT: b << sec << " = " << sec << " < " << top << ";"; break;
+            case VM_LE: b << sec << " = " << sec << " <= " << top << ";"; break;
+            case VM_GT: b << sec << " = " << sec << " > " << top << ";"; break;
+            case VM_GE: b << sec << " = " << sec << " >= " << top << ";"; break;
+            case VM_NOT: b << top << " = !" << top << ";"; break;
+            case VM_JMP: b << "goto L" << I(o0) << ";"; prev_falls = false; break;
+            case VM_JZ: b << "if (!" << top << ") goto L" << I(o0) << ";"; break;
+            case VM_JNZ: b << "if (" << top << ") goto L" << I(o0) << ";"; break;
+            case VM_CHOOSE: b << S(d) << " = (int32_t)(ch % " << I(o0) << "ull); ch /= " << I(o0) << "ull;"; break;
+            case VM_AWAIT: b << "if (!" << top << ") return R_DISABLED;"; break;
+            case VM_ASSERT: b << "if (!" << top << ") { aux = " << I(o0) << "; return R_ASSERT; }"; break;
+            case VM_SETPC: b << "pc_cell<INST>(v) = " << I(o0) << ";"; break;
+            case VM_POP: case VM_NOP: case VM_OLD_ON: case VM_OLD_OFF: b << ";"; break;
+            case VM_BIT: b << "if (" << top << " < 0 || " << top << " > 31) return R_OVERFLOW; " << top << " = (int32_t)(1u << " << top << ");"; break;
+            case VM_OR: b << sec << " |= " << top << ";"; break;
+            case VM_AND: b << sec << " &= " << top << ";"; break;
+            case VM_ANDN: b << sec << " &= ~" << top << ";"; break;
+            case VM_POPCNT: b << top << " = (int32_t)__builtin_popcount((unsigned)" << top << ");"; break;
+            case VM_SEQSEL: b << "{ const int32_t i_ = " << top << " - (" << I(o0) << "); if (i_ < 0 || i_ >= " << I(o1) << ") return R_ERROR; " << top << " = i_ * " << I(o2) << "; }"; break;
+            case VM_SEQLEN: {
+                const int dst = o2 ? d - 1 : d;
+                seq_op(o2 != 0, d - 1, o0, [&](int B) { return S(dst) + " = " + CELL(rd, B) + ";"; });
+                break;
+            }
+            case VM_LOADSEQ: {
+                const int idx = o2 ? d - 2 : d - 1;
+                seq_op(o2 != 0, d - 1, o0, [&](int B) {
+                    return "const int32_t i_ = " + S(idx) + "; if (i_ < 1 || i_ > " + CELL(rd, B) + " || i_ > " + I(o1) + ") return R_ERROR; " + S(idx) + " = " +
+                           chain_load(rd, B + 1, o1, "(i_ - 1)") + ";";
+                });
+                break;
+            }
+            case VM_STORESEQ: {
+                const int val = o2 ? d - 2 : d - 1, idx = val - 1;
+                seq_op(o2 != 0, d - 1, o0, [&](int B) {
+                    return "const int32_t val_ = " + S(val) + ", i_ = " + S(idx) + "; if (i_ < 1 || i_ > " + CELL("v", B) + " || i_ > " + I(o1) + ") return R_ERROR;" +
+                           chain_store(B + 1, o1, "(i_ - 1)", "val_");
+                });
+                break;
+            }
+            case VM_APPEND: {
+                const int val = o2 ? d - 2 : d - 1;
+                seq_op(o2 != 0, d - 1, o0, [&](int B) {
+                    return "const int32_t val_ = " + S(val) + ", n_ = " + CELL("v", B) + "; if (n_ >= " + I(o1) + ") return R_OVERFLOW;" + chain_store(B + 1, o1, "n_", "val_") +
+                           " " + CELL("v", B) + " = n_ + 1;";
+                });
+                break;
+            }
+            case VM_TAIL:
+                seq_op(o2 != 0, d - 1, o0, [&](int B) {
+                    std::string s = "const int32_t n_ = " + CELL("v", B) + "; if (n_ < 1) return R_ERROR;";
+                    for (int k = 1; k < o1; ++k) s += " " + CELL("v", B + k) + " = " + I(k) + " < n_ ? " + CELL("v", B + k + 1) + " : 0;";
+                    s += " " + CELL("v", B + o1) + " = 0; " + CELL("v", B) + " = n_ - 1;";
+                    return s;
+                });
+                break;
+            case VM_SEQCLR:
+                seq_op(o2 != 0, d - 1, o0, [&](int B) {
+                    std::string s;
+                    for (int k = 0; k <= o1; ++k) s += " " + CELL("v", B + k) + " = 0;";
+                    return s;
+                });
+                break;
+            case VM_SEQCOPY:
+                for (int k = 0; k <= o2; ++k) b << " " << CELL("v", o0 + k) << " = " << CELL("v", o1 + k) << ";";
+                break;
+            default: fail("unknown instruction " + std::to_string(op));
+            }
+            b << "\n";
+            prev_next = next;
+        }
+        if (prev_falls) b << "        return R_ERROR;\n";
+        return b.str();
+    }
+
+    // labels instance `inst` can ever stand at: its first label (stored by the Init code) and everything VM_SETPC reaches from there
+    int ninst_ = 0;
+    std::set<int> labels_of(int inst, int pc_base, int init_entry, int label_tab, int nlabels) {
+        int first = -1;
+        for (int pc = init_entry; pc < (int)c.size();) {   // Init ends with  PUSH label; STORE pc_base + k  per instance, then HALT
+            const int op = c[(size_t)pc];
+            if (op == VM_HALT) break;
+            if (op == VM_PUSH && pc + 3 < (int)c.size() && c[(size_t)pc + 2] == VM_STORE && c[(size_t)pc + 3] == pc_base + inst) first = c[(size_t)pc + 1];
+            pc += 1 + operands(op);
+        }
+        if (first < 0) fail("no initial label for a process instance");
+        std::set<int> seen{first};
+        std::vector<int> todo{first};
+        while (!todo.empty()) {
+            const int l = todo.back();
+            todo.pop_back();
+            if (l < 0 || l >= nlabels) fail("label out of range");
+            const int e = c[(size_t)(label_tab + l)];
+            if (e < 0) continue;   // "Done"
+            // every instruction reachable from the label's entry
+            std::set<int> vis;
+            std::vector<int> w{e};
+            while (!w.empty()) {
+                const int pc = w.back();
+                w.pop_back();
+                if (!vis.insert(pc).second) continue;
+                const int op = c[(size_t)pc], n = operands(op);
+                if (op == VM_SETPC && seen.insert(c[(size_t)pc + 1]).second) todo.push_back(c[(size_t)pc + 1]);
+                if ((op == VM_STORE || op == VM_STOREX) && c[(size_t)pc + 1] >= pc_base && c[(size_t)pc + 1] < pc_base + ninst_)
+                    fail("a label stores a computed value into pc");   // (the label sets per instance would not be closed)
+                if (op == VM_HALT || op == VM_FAIL) continue;
+                if (op == VM_JMP) { w.push_back(c[(size_t)pc + 1]); continue; }
+                if (op == VM_JZ || op == VM_JNZ) w.push_back(c[(size_t)pc + 1]);
+                w.push_back(pc + 1 + n);
+            }
+        }
+        return seen;
+    }
+};
+
+}  // namespace
+
+std::string codegen(const Program &P) {
+    const std::vector<int> &c = P.image;
+    if (c.size() < (size_t)mc::VMH_SIZE || c[mc::VMH_MAGIC] != mc::VM_MAGIC) throw GenError{"not a program image"};
+    Gen g(c);
+    const int nv = c[mc::VMH_NV], ninst = c[mc::VMH_NINST], maxch = c[mc::VMH_MAXCH], pc_base = c[mc::VMH_PC_BASE], done = c[mc::VMH_DONE],
+              init_entry = c[mc::VMH_INIT_ENTRY], ninv = c[mc::VMH_NINV], ncon = c[mc::VMH_NCON], label_tab = c[mc::VMH_LABEL_TAB],
+              self_tab = c[mc::VMH_SELF_TAB], nlabels = c[mc::VMH_NLABELS];
+    const unsigned long long num_init = (unsigned long long)(uint32_t)c[mc::VMH_NUM_INIT_LO] | (unsigned long long)(uint32_t)c[mc::VMH_NUM_INIT_HI] << 32;
+    std::ostringstream o;
+    o << "// generated by tla_rust_amd/csrc/pcal_codegen.cpp from the compiled program of module " << P.module << ": do not edit\n"
+      << "#pragma once\n#include \"spec_gen.h\"\nnamespace mc {\nstruct GenProg {\n"
+      << "    static constexpr int NV = " << nv << ", NINST = " << ninst << ", MAXCH = " << maxch << ", PC_BASE = " << pc_base << ", DONE = " << done
+      << ", NINV = " << ninv << ", NCON = " << ncon << ";\n    static constexpr unsigned long long NUM_INIT = " << num_init << "ull;\n"
+      << "    enum { R_DISABLED = 0, R_OK = 1, R_ASSERT = 2, R_ERROR = 3, R_OVERFLOW = 4 };\n";
+    // entries: init, invariants, the labels
+    // the variable cells as named members; helpers spec_gen.h asks for (words <-> cells, the pc cell of an instance)
+    o << "    struct Cells {";
+    for (int k = 0; k < nv; ++k) o << " int32_t c" << k << ";";
+    o << " };\n    MC_HD static void zero(Cells &v) {";
+    for (int k = 0; k < nv; ++k) o << " v.c" << k << " = 0;";
+    o << " }\n    MC_HD static void to_words(const Cells &v, uint64_t *w) {";
+    for (int k = 0; k < (nv + 1) / 2; ++k) {
+        o << " w[" << k << "] = (uint64_t)(uint32_t)v.c" << 2 * k;
+        if (2 * k + 1 < nv) o << " | (uint64_t)(uint32_t)v.c" << 2 * k + 1 << " << 32";
+        o << ";";
+    }
+    o << " }\n    MC_HD static void from_words(const uint64_t *w, Cells &v) {";
+    for (int k = 0; k < nv; ++k) o << " v.c" << k << " = (int32_t)(uint32_t)(w[" << k / 2 << "]" << (k & 1 ? " >> 32" : "") << ");";
+    o << " }\n    template <int INST> MC_HD static int32_t &pc_cell(Cells &v) {";
+    for (int i = 0; i < ninst; ++i) o << " if constexpr (INST == " << i << ") return v.c" << pc_base + i << ";";
+    o << " }\n    template <int INST> MC_HD static int32_t pc_of(const Cells &v) {";
+    for (int i = 0; i < ninst; ++i) o << " if constexpr (INST == " << i << ") return v.c" << pc_base + i << ";";
+    o << " }\n";
+    o << "    MC_HD static int run_init(uint64_t &ch, Cells &v) {\n        constexpr int32_t SELF_ = 0; constexpr int INST = 0; const Cells &old = v; int aux = 0; int32_t result = 0;\n        (void)SELF_; (void)INST;\n"
+      << g.body(init_entry) << "    }\n";
+    for (int k = 0; k < ninv + ncon; ++k) {
+        o << "    MC_HD static int inv" << k << "(Cells &v, int32_t &result) {\n        constexpr int32_t SELF_ = 0; constexpr int INST = 0; const Cells &old = v; int aux = 0; uint64_t ch = 0;\n        (void)SELF_; (void)INST;\n"
+          << g.body(c[(size_t)mc::VMH_INV0 + (size_t)k]) << "    }\n";
+    }
+    o << "    MC_HD static int run_inv(int k, Cells &v, int32_t &result) {\n        switch (k) {\n";
+    for (int k = 0; k < ninv + ncon; ++k) o << "        case " << k << ": return inv" << k << "(v, result);\n";
+    o << "        default: return R_ERROR;\n        }\n    }\n";
+    g.ninst_ = ninst;
+    std::set<int> used;
+    std::vector<std::set<int>> per_inst;
+    for (int i = 0; i < ninst; ++i) {
+        per_inst.push_back(g.labels_of(i, pc_base, init_entry, label_tab, nlabels));
+        for (int l : per_inst.back()) if (c[(size_t)(label_tab + l)] >= 0) used.insert(l);
+    }
+    for (int l : used) {
+        o << "    template <int INST, int SELF_>\n    MC_HD static int label" << l << "(uint64_t &ch, Cells &v, const Cells &old, int32_t &result, int &aux) {\n"
+          << g.body(c[(size_t)(label_tab + l)]) << "    }\n";
+    }
+    o << "    template <int INST>\n    MC_HD static int run_inst(int32_t label, uint64_t &ch, Cells &v, const Cells &old, int &aux) {\n        int32_t result = 0;\n";
+    for (int i = 0; i < ninst; ++i) {
+        o << "        if constexpr (INST == " << i << ") {\n            switch (label) {\n";
+        for (int l : per_inst[(size_t)i])
+            if (c[(size_t)(label_tab + l)] >= 0) o << "            case " << l << ": return label" << l << "<" << i << ", " << c[(size_t)(self_tab + i)] << ">(ch, v, old, result, aux);\n";
+        o << "            default: return R_ERROR;   // (a label this instance cannot stand at)\n            }\n        }\n";
+    }
+    o << "        return R_DISABLED;\n    }\n};\nusing SpecGen = SpecGenT<GenProg>;\n}  // namespace mc\n";
+    return o.str();
+}
+
+}  // namespace pcal
+
+// ------------------------------------------------------------------------------------------------ C ABI + load-time build
+// (the C ABI around these two is in frontend.cpp, where mc_program is defined: mc_program_codegen; engine.hip's mc_engine_create calls
+//  mc_jit_factory with the program a MC_SPEC_PCAL descriptor carries)
+extern "C" long pcal_codegen_text(const pcal::Program *p, char *buf, size_t cap) {
+    if (!p) return MC_EBADCFG;
+    try {
+        const std::string s = pcal::codegen(*p);
+        if (buf && cap) { const size_t n = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(buf, s.data(), n); buf[n] = 0; }
+        return (long)s.size();
+    } catch (const pcal::GenError &e) {
+        mc::set_error(std::string("codegen: ") + e.msg);
+        return MC_EBADCFG;
+    }
+}
+
+namespace {
+uint64_t fnv(const std::string &s) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char ch : s) { h ^= ch; h *= 0x100000001b3ull; }
+    return h;
+}
+std::string dir_of_this_library() {
+    Dl_info info;
+    if (!dladdr((const void *)&pcal_codegen_text, &info) || !info.dli_fname) return "";
+    std::string f = info.dli_fname;
+    const size_t k = f.rfind('/');
+    return k == std::string::npos ? "." : f.substr(0, k);
+}
+bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+}  // namespace
+
+// Build (or find in the cache) the engine library of program `p` and return its factory: int (*)(const mc_spec_desc *, const mc_config *, mc::EngineBase **).
+// The library is engine.hip compiled as translation unit 9 around the generated header (hipcc --offload-arch=gfx950: seconds to a minute,
+// once per program text: the object is cached under $TLAMC_JIT_CACHE, default /tmp/tlamc_jit_<uid>, by the hash of the generated text and
+// of the engine sources).  nullptr + mc_last_error when the program cannot be translated or the compiler fails: the caller interprets.
+extern "C" void *mc_jit_factory(const void *program /* pcal::Program * */) {
+    std::string gen;
+    try {
+        gen = pcal::codegen(*reinterpret_cast<const pcal::Program *>(program));
+    } catch (const pcal::GenError &e) {
+        mc::set_error(std::string("codegen: ") + e.msg);
+        return nullptr;
+    }
+    const std::string lib = dir_of_this_library();                 // .../tla_rust_amd/_build
+    const std::string csrc = lib + "/../csrc", inc = lib + "/../../include";
+    if (!exists(csrc + "/engine.hip")) { mc::set_error("jit: the engine sources are not beside the library (" + csrc + ")"); return nullptr; }
+    uint64_t h = fnv(gen);
+    for (const char *f : {"/engine.hip", "/engine_kernels.h", "/engine_pairs.h", "/spec_gen.h", "/spec_vm.h", "/mc_common.h"}) {
+        struct stat st;
+        if (stat((csrc + f).c_str(), &st) == 0) h = (h ^ (uint64_t)st.st_mtime ^ ((uint64_t)st.st_size << 20)) * 0x100000001b3ull;
+    }
+    const char *cd = getenv("TLAMC_JIT_CACHE");
+    const std::string cache = cd && *cd ? cd : "/tmp/tlamc_jit_" + std::to_string((unsigned)getuid());
+    mkdir(cache.c_str(), 0700);
+    char tag[32];
+    snprintf(tag, sizeof tag, "%016llx", (unsigned long long)h);
+    const std::string so = cache + "/libtlamc_gen_" + tag + ".so", hdr = cache + "/gen_" + tag + ".h";
+    if (!exists(so)) {
+        FILE *f = fopen(hdr.c_str(), "w");
+        if (!f) { mc::set_error("jit: cannot write " + hdr); return nullptr; }
+        fwrite(gen.data(), 1, gen.size(), f);
+        fclose(f);
+        const char *hc = getenv("HIPCC");
+        const std::string tmp = so + "." + std::to_string((int)getpid()) + ".tmp";
+        const std::string cmd = std::string(hc && *hc ? hc : "/opt/rocm/bin/hipcc") + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-unused-result -w -I " + inc +
+                                " -I " + csrc + " -x hip -DMC_TU=9 -DMC_GEN_HEADER='\"" + hdr + "\"' " + csrc + "/engine.hip -o " + tmp + " -L" + lib + " -ltlamc -Wl,-rpath," + lib +
+                                " > " + cache + "/gen_" + tag + ".log 2>&1";
+        if (system(cmd.c_str()) != 0 || rename(tmp.c_str(), so.c_str()) != 0) {
+            mc::set_error("jit: hipcc failed (see " + cache + "/gen_" + tag + ".log)");
+            return nullptr;
+        }
+    }
+    void *dl = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) { mc::set_error(std::string("jit: dlopen: ") + dlerror()); return nullptr; }
+    void *fn = dlsym(dl, "mc_make_engine_gen");
+    if (!fn) mc::set_error("jit: the generated library has no mc_make_engine_gen");
+    return fn;
+}

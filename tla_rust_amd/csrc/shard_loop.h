@@ -27,6 +27,7 @@
 //     which is what spreads a small frontier — and a drifted one — evenly again.
 #ifndef MC_SHARD_LOOP_H
 #define MC_SHARD_LOOP_H
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -127,16 +128,18 @@ struct Loop {
     // TEST-ONLY (include/tlamc.h): $TLAMC_TEST_FAIL_AT = "rank:level:code[,rank:level:code...]" makes that rank fail the level with
     // that status, ONCE per process (a restarted search is not failed again) — how the tests put two different failures into one
     // level without building a model that produces them.
+    // ONCE per process is the hook's contract (the restarted search builds a new Loop and must not be failed again), so the one-shot flag
+    // is process-wide; the variable itself is read once per process, not once per level
     int test_fault(size_t level) {
-        static bool spent = false;
-        const char *env = getenv("TLAMC_TEST_FAIL_AT");
-        if (!env || spent) return MC_OK;
+        static const char *const env = getenv("TLAMC_TEST_FAIL_AT");
+        static std::atomic<bool> spent{false};
+        if (!env || spent.load()) return MC_OK;
         for (const char *q = env; *q;) {
             unsigned r = 0, lv = 0;
             int code = 0, used = 0;
             if (sscanf(q, "%u:%u:%d%n", &r, &lv, &code, &used) < 3) break;
             if (r == me && lv == level) {
-                spent = true;
+                spent.store(true);
                 mc_set_error_internal("TLAMC_TEST_FAIL_AT: injected failure");
                 return code;
             }

@@ -1,0 +1,174 @@
+// spec_gen.h — the Spec concept over GENERATED code: a PlusCal program that pcal_compile.cpp compiled to a bytecode image (spec_vm.h) is
+// translated once more, by pcal_codegen.cpp, into straight-line C++ — one function per label of the algorithm, per initial-state enumeration
+// and per invariant, its variables named cells of a local array whose indices are all compile-time constants (so the array lives in
+// registers: the interpreter indexes it dynamically and keeps it in scratch memory) — and compiled for gfx950 when the model is loaded
+// (hipcc at load time, the object cached by the hash of the program: engine.hip MC_TU == 9, pcal_codegen.cpp mc_jit_engine).
+// This is north_star's "lowering each spec's next-state relation to a fixed-width packed state vector so that successor generation runs
+// as a hand-written HIP kernel": the kernels are engine_kernels.h's, the lowering is what a hand would have written for THIS program.
+//
+// The packed state, its fingerprint and every host-side helper (state text, action names, traces, checkpoints' program identity) are the
+// interpreter's (SpecVmT): the two back-ends are interchangeable state by state, which is how tests/ compare them.
+// G (generated, namespace-free struct) provides:
+//   constexpr int NV, NINST, MAXCH, PC_BASE, DONE, NINV, NCON; constexpr unsigned long long NUM_INIT
+//   struct Cells { int32_t c0, c1, ... };   // the variable cells as NAMED members: nothing can index them with a variable, so nothing
+//                                           // can push them out of the registers (see pcal_codegen.cpp CELL)
+//   static void zero(Cells &), to_words(const Cells &, uint64_t *), from_words(const uint64_t *, Cells &)
+//   template <int INST> static int32_t pc_of(const Cells &)
+//   static int run_init(uint64_t &ch, Cells &v)                                     // R_* of SpecVmT::Run
+//   template <int INST> static int run_inst(int32_t label, uint64_t &ch, Cells &v, const Cells &old, int &aux)
+//   static int run_inv(int k, Cells &v, int32_t &result)                            // INVARIANTs 0 .. NINV-1, then CONSTRAINTs
+#pragma once
+#include "spec_vm.h"
+
+namespace mc {
+
+template <class G>
+struct SpecGenT {
+    using Params = VmParams;
+    using VM = SpecVmT<128>;
+    static constexpr int NV = G::NV, MAX_VARS = NV, MAX_WORDS = (NV + 1) / 2, FIX_SLOTS = 0, STAGE_WORDS = 0;
+    static constexpr bool SLICE_SLOTS = true;
+    MC_HD static int words(const Params &) { return MAX_WORDS; }
+    MC_HD static int max_slots(const Params &) { return G::NINST * G::MAXCH + 1; }
+    using Cells = typename G::Cells;
+    struct Local { Cells v; };
+    enum Run { R_DISABLED = 0, R_OK = 1, R_ASSERT = 2, R_ERROR = 3, R_OVERFLOW = 4 };
+
+    static int make_params(const int64_t *p, unsigned np, Params &o) {
+        if (vm_make_params(p, np, o)) return -1;
+        // the generated code IS a program: the one it was generated from
+        if (o.nv != G::NV || o.ninst != G::NINST || o.maxch != G::MAXCH || o.pc_base != G::PC_BASE || o.done != G::DONE || o.ninv != G::NINV ||
+            o.ncon != G::NCON || o.num_init != G::NUM_INIT)
+            return -1;
+        return 0;
+    }
+
+    MC_HD static uint64_t fp_words(const uint64_t *w) {  // (SpecVmT::fp_vals: the two back-ends store the same rows AND the same fingerprints)
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+        for (int k = 0; k < MAX_WORDS; ++k) h = fmix64(h ^ (w[k] + 0x632be59bd9b4e019ull * (uint64_t)(k + 1)));
+        return fp_nonzero(h);
+    }
+    template <class Ref>
+    MC_HD static void unpack(Ref s, Cells &v) {
+        uint64_t w[MAX_WORDS];
+#pragma unroll
+        for (int k = 0; k < MAX_WORDS; ++k) w[k] = s.get(k);
+        G::from_words(w, v);
+    }
+    MC_HD static unsigned inv_status(Cells &v) {
+        unsigned st = 0;
+#pragma unroll
+        for (int k = 0; k < G::NINV; ++k) {
+            if (st) break;
+            int32_t res = 0;
+            const int r = G::run_inv(k, v, res);
+            if (r != R_OK) return ST_SPECERR;
+            if (!res) st = ST_INVARIANT | (unsigned)k << 8;
+        }
+#pragma unroll
+        for (int k = G::NINV; k < G::NINV + G::NCON; ++k) {
+            int32_t res = 0;
+            const int r = G::run_inv(k, v, res);
+            if (r != R_OK) return ST_SPECERR;
+            if (!res) return st | ST_OUT_OF_MODEL;
+        }
+        return st;
+    }
+
+    MC_HD static uint64_t num_init(const Params &) { return G::NUM_INIT; }
+    MC_HD static void init(const Params &, uint64_t k, WordRef out) {
+        Cells v;
+        G::zero(v);
+        uint64_t ch = k;
+        G::run_init(ch, v);
+        uint64_t w[MAX_WORDS];
+        G::to_words(v, w);
+#pragma unroll
+        for (int i = 0; i < MAX_WORDS; ++i) out.set(i, w[i]);
+    }
+    MC_HD static uint64_t fp_of(const Params &, CWordRef s) {
+        uint64_t w[MAX_WORDS];
+#pragma unroll
+        for (int k = 0; k < MAX_WORDS; ++k) w[k] = s.get(k);
+        return fp_words(w);
+    }
+    MC_HD static unsigned init_status(const Params &, CWordRef s) {
+        Cells v;
+        unpack(s, v);
+        return ST_ENABLED | inv_status(v);
+    }
+    template <class Ref>
+    MC_HD static void load(const Params &, Ref s, Local &l) { unpack(s, l.v); }
+    MC_HD static int nslots(const Params &, const Local &) { return G::NINST * G::MAXCH + 1; }
+    template <class Ref>
+    MC_HD static unsigned parent_status(const Params &, const Local &, Ref) { return 0; }
+
+    // the instance's label and its code, by a chain over the (few) instances: every cell access inside is a named member
+    template <int I>
+    MC_HD static int dispatch_inst(int inst, uint64_t &ch, Cells &v, const Cells &cur, int &aux) {
+        if constexpr (I < G::NINST) {
+            if (inst == I) {
+                const int32_t label = G::template pc_of<I>(cur);
+                if (label == G::DONE) return R_DISABLED;
+                return G::template run_inst<I>(label, ch, v, cur, aux);
+            }
+            return dispatch_inst<I + 1>(inst, ch, v, cur, aux);
+        } else {
+            return R_DISABLED;
+        }
+    }
+    template <int I>
+    MC_HD static bool all_done(const Cells &cur) {
+        if constexpr (I < G::NINST) return G::template pc_of<I>(cur) == G::DONE && all_done<I + 1>(cur);
+        else return true;
+    }
+    // successor of the state `cur` through `slot`, left in v; returns the ST_* status (SpecVmT::step)
+    MC_HD static unsigned step(const Cells &cur, int slot, Cells &v) {
+        v = cur;
+        constexpr int last = G::NINST * G::MAXCH;
+        if (slot == last) return all_done<0>(cur) ? (unsigned)ST_ENABLED : 0u;  // (\A self \in ProcSet: pc[self] = "Done") /\ UNCHANGED vars
+        if (slot < 0 || slot > last) return 0;
+        const int inst = slot / G::MAXCH;
+        uint64_t ch = (uint64_t)(slot % G::MAXCH);
+        int aux = 0;
+        int r = dispatch_inst<0>(inst, ch, v, cur, aux);
+        // a path that ends early (failed assert, evaluation error) has not consumed all of its choice index: only the index whose
+        // unconsumed remainder is 0 reports it (SpecVmT::run)
+        if ((r == R_ASSERT || r == R_ERROR || r == R_OVERFLOW) && ch != 0) r = R_DISABLED;
+        if (r == R_DISABLED) return 0;
+        if (r == R_ASSERT) return ST_ENABLED | ST_ASSERT;
+        if (r == R_ERROR) return ST_ENABLED | ST_SPECERR;
+        if (r == R_OVERFLOW) return ST_ENABLED | ST_OVERFLOW;
+        return ST_ENABLED | inv_status(v);
+    }
+    template <class Ref>
+    MC_HD static unsigned eval(const Params &, const Local &l, Ref, int slot, uint64_t &fp) {
+        Cells v;
+        const unsigned st = step(l.v, slot, v);
+        if (st & ST_ENABLED) {
+            uint64_t w[MAX_WORDS];
+            G::to_words(v, w);
+            fp = fp_words(w);
+        }
+        return st;
+    }
+    template <class Ref>
+    MC_HD static unsigned apply(const Params &, Ref s, int slot, WordRef out) {
+        Cells cur, v;
+        unpack(s, cur);
+        const unsigned st = step(cur, slot, v);
+        uint64_t w[MAX_WORDS];
+        G::to_words(v, w);
+#pragma unroll
+        for (int k = 0; k < MAX_WORDS; ++k) out.set(k, w[k]);
+        return st;
+    }
+
+    // host side: the interpreter's helpers (same packed state)
+    static int action_of(const Params &p, const uint64_t *parent, int slot) { return VM::action_of(p, parent, slot); }
+    static const char *action_name(int a) { return VM::action_name(a); }
+    static int format(const Params &p, const uint64_t *w, char *buf, size_t cap) { return VM::format(p, w, buf, cap); }
+};
+
+}  // namespace mc

@@ -850,7 +850,7 @@ struct Module {
                 if (p.cur().k == Tok::ID && p.peek().k == Tok::SYM && p.peek().s == "==") { nm = p.cur().s; p.i += 2; }
                 NodeP e = p.expr(0);  // evaluated in TLC's "No Behavior Spec" mode only (Checker::run), or when a model refers to it as Name
                 // (an unnamed assumption gets a name nobody can type, so that it is loaded like every other definition)
-                if (nm.empty() && assumption) nm = "ASSUME@line" + std::to_string(c.line);
+                if (nm.empty() && assumption) nm = "ASSUME@" + name + ":" + std::to_string(c.line);   // (with the module: definitions of EXTENDed modules are merged by name — ADVICE round 5)
                 if (!nm.empty()) { Def d; d.name = nm; d.body = e; d.line = c.line; defs[nm] = d; def_order.push_back(nm); }
                 if (assumption) assumes.emplace_back(nm, c.line);
                 while (p.cur().k == Tok::ID && (p.cur().s == "PROOF" || p.cur().s == "BY" || p.cur().s == "OBVIOUS" || p.cur().s == "OMITTED" || p.cur().s == "QED")) p.i++;
