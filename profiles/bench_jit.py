@@ -25,9 +25,10 @@ if "pagecache" in which:
                  dict(table_capacity=1 << 27, arena_capacity=22 << 20, chunk_states=1 << 21), (g["distinct"], g["generated"], g["depth"])))
 for name, src, cfg, kw, want in JOBS:
     prog = amd.Program(src, cfg)
-    for jit in (True, False):
+    for jit, flags, label in ((True, 0, "generated code, pairs sorted by label (MC_F_JIT)"), (True, 32, "generated code, slot by slot (MC_F_JIT | MC_F_NOFAMILY)"),
+                              (False, 0, "bytecode interpreter")):
         t0 = time.perf_counter()
-        eng = amd.Engine("pcal", prog.params, trace=False, timing=True, jit=jit, **kw)
+        eng = amd.Engine("pcal", prog.params, trace=False, timing=True, jit=jit, debug_flags=flags, **kw)
         build_s = time.perf_counter() - t0
         best, r = 1e9, None
         for _ in range(3):
@@ -36,7 +37,7 @@ for name, src, cfg, kw, want in JOBS:
             best = min(best, time.perf_counter() - t0)
         ks = eng.kernel_stats()
         eng.close()
-        print(json.dumps(dict(workload=name, backend="generated code (MC_F_JIT)" if jit else "bytecode interpreter", distinct=r.distinct, generated=r.generated, depth=r.depth,
+        print(json.dumps(dict(workload=name, backend=label, distinct=r.distinct, generated=r.generated, depth=r.depth,
                               verdict=r.verdict, equals_expected=(r.distinct, r.generated, r.depth) == tuple(want), seconds=round(best, 4),
                               Mstates_s=round(r.distinct / best / 1e6, 1), Msuccessors_s=round(r.generated / best / 1e6, 1), engine_create_s=round(build_s, 2),
                               kernel_ms={k: round(ks[k]["ms_total"], 2) for k in ("expand", "insert", "materialise")}, state_bytes=ks["state_bytes"])), flush=True)

@@ -14,7 +14,7 @@ using namespace mc;
 struct GenCheck {
     uint64_t distinct, generated, mismatches, states_checked, pairs_checked, first_bad_state, first_bad_slot;
     uint32_t depth;
-    int32_t first_bad_kind;   // 1 status, 2 fingerprint, 3 row, 4 init
+    int32_t first_bad_kind;   // 1 status, 2 fingerprint, 3 row, 4 init, 5 guards miss an enabled slot, 6 key out of range, 7 eval_pair, 8 write_pair
 };
 
 extern "C" int gen_check(const void *program, uint64_t max_states, GenCheck *out) {
@@ -54,10 +54,30 @@ extern "C" int gen_check(const void *program, uint64_t max_states, GenCheck *out
             VM::load(p, s, lv);
             GS::load(p, s, lg);
             out->states_checked++;
+            uint64_t glo = 0, ghi = 0;   // the by-pairs protocol of the generated spec (engine_pairs.h): guards, key, eval_pair, write_pair
+            constexpr bool PAIRS = spec_gen_pairs_ok<GenProg>();   // (programs beyond the kernel's fixed sizes keep the slot-by-slot kernel)
+            if (PAIRS) GS::guards(p, lg, glo, ghi);
             for (int slot = 0; slot < ns; slot++) {
                 uint64_t f0 = 0, f1 = 0;
                 const unsigned s0 = VM::eval(p, lv, s, slot, f0), s1 = GS::eval(p, lg, s, slot, f1);
                 out->pairs_checked++;
+                if (PAIRS) {
+                    const bool g = slot < 64 ? (glo >> slot & 1u) : (ghi >> (slot - 64) & 1u);
+                    if ((s0 & ST_ENABLED) && !g) bad(5, out->states_checked - 1, (uint64_t)slot);   // an enabled slot the guards miss: a lost successor
+                    const int key = GS::pair_key(p, s, slot);
+                    if (key < 0 || key >= GenProg::NLABELS) bad(6, out->states_checked - 1, (uint64_t)slot);
+                    uint64_t f2 = 0;
+                    GS::PairOut po;
+                    const unsigned s2 = GS::eval_pair<0>(p, GS::Summary{}, s, slot, f2, po);
+                    if (s2 != s0 || ((s0 & ST_ENABLED) && f2 != f0)) bad(7, out->states_checked - 1, (uint64_t)slot);
+                    if ((s0 & ST_ENABLED) && !(s0 & (ST_ASSERT | ST_SPECERR | ST_OVERFLOW))) {
+                        memset(a, 0, sizeof a);
+                        memset(b, 0xff, sizeof b);
+                        VM::apply(p, s, slot, WordRef{a, 1});
+                        GS::write_pair(p, s, po, WordRef{b, 1});
+                        if (memcmp(a, b, (size_t)W * 8)) bad(8, out->states_checked - 1, (uint64_t)slot);
+                    }
+                }
                 if (s0 != s1) { bad(1, out->states_checked - 1, (uint64_t)slot); continue; }
                 if (!(s0 & ST_ENABLED)) continue;
                 out->generated++;

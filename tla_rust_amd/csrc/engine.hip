@@ -179,7 +179,7 @@ struct Engine : EngineBase {
     unsigned slices_for(uint64_t ncols, bool blind) const {
         // (a lowering asks for it with SLICE_SLOTS: worth it when one slot evaluation is expensive — the Paxos family's witness
         // enumeration, the bytecode interpreter; for atomic_add's two-instruction slots the slices only repeat the parent loads)
-        if (!WantsSlices<S>::value || S::FIX_SLOTS != 0 || UsesFamilies<S>::value || use_matrix || max_slots < 16 || no_slices) return 1;
+        if (!WantsSlices<S>::value || S::FIX_SLOTS != 0 || UsesFamilies<S>::value || pairs_only() || use_matrix || max_slots < 16 || no_slices) return 1;  // (the by-pairs kernel has no slices: its lanes are pairs already)
         const uint64_t waves = (ncols + 63) / 64;
         uint64_t sg = blind ? 32 : (16384 + waves - 1) / waves;  // a blind level launches its CAPACITY: the frontier itself is smaller
         if (sg > 32) sg = 32;

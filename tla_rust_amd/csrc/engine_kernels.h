@@ -444,8 +444,14 @@ struct WaveFilter : std::integral_constant<int, 0> {};
 template <class S>
 struct WaveFilter<S, decltype((void)S::WAVE_FILTER)> : std::integral_constant<int, S::WAVE_FILTER> {};
 
+// MC_EXPAND_INSERT_MINW (the generated-code translation unit sets it, pcal_codegen.cpp): wavefronts per SIMD the register allocation must leave
+// room for — a generated lowering keeps a whole state in registers twice (parent and successor) and would otherwise take the 512 a lone
+// wavefront may have
+#ifndef MC_EXPAND_INSERT_MINW
+#define MC_EXPAND_INSERT_MINW 1
+#endif
 template <class S, bool ROUTE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MC_EXPAND_INSERT_MINW)
 k_expand_insert(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
                 RouteArgs rt, unsigned parity) {

@@ -32,10 +32,27 @@ struct UsesPairs : std::false_type {};
 template <class S>
 struct UsesPairs<S, decltype((void)S::PAIR_ROUNDS)> : std::true_type {};
 
+// DYNAMIC KEYS (S::PAIR_KEYS): the code a pair runs is not a function of its slot alone but of the parent too — a generated PlusCal lowering
+// (spec_gen.h): slot = (process instance, choice), code = the LABEL that instance stands at in this parent.  The pair list is then laid
+// out by S::pair_key(parent row, slot) in [0, PAIR_KEYS), PAIR_KEYS <= 64, with a counting sort through an LDS histogram (two walks over
+// a lane's enabled slots: count, then claim positions), and evaluated as ONE family whose eval_pair switches on the key: inside a batch
+// of 64 pairs (almost) every lane takes the same case.  Slot-by-slot, a wavefront walked every label some parent stood at for every slot:
+// 14 000 lane-instructions per successor on the Michael-Scott queue model.
+template <class S, class = void>
+struct DynamicKeys : std::integral_constant<int, 0> {};
+template <class S>
+struct DynamicKeys<S, decltype((void)S::PAIR_KEYS)> : std::integral_constant<int, S::PAIR_KEYS> {};
+// specs without a pair base (the successor's fingerprint is computed from the whole successor): S::W_PAIR_BASE < 0
+template <class S>
+constexpr bool has_pair_base() { return S::W_PAIR_BASE >= 0; }
+
 constexpr int PAIR_CAP = 1280;             // pair-list entries per wavefront
 constexpr unsigned PAIR_DEAD = 0xffffu;    // a pair the seen-set already knew (or that was not enabled / not in the model)
 #ifndef MC_PAIR_WAVES
 #define MC_PAIR_WAVES 4
+#endif
+#ifndef MC_PAIR_MINW       // wavefronts per SIMD the register allocation leaves room for (the generated-code unit: 2 — a state twice in registers)
+#define MC_PAIR_MINW 4
 #endif
 
 template <class S>
@@ -45,6 +62,7 @@ struct PairLds {
     typename S::Summary sum[64];
     uint16_t list[PAIR_CAP];
     unsigned succ[2];                 // deadlock check: bit p = parent p has a successor
+    unsigned kcnt[DynamicKeys<S>::value > 0 ? DynamicKeys<S>::value : 1];   // dynamic keys: histogram, then the keys' cursors
 };
 // a parent's row in LDS (address-space-qualified: ds_read_b64, not flat_load)
 struct LdsRow {
@@ -65,13 +83,15 @@ template <class S>
 struct BlindInsert<S, decltype((void)S::BLIND_INSERT)> : std::integral_constant<bool, S::BLIND_INSERT && MC_SEEN_ROTATE> {};
 
 template <class S, int WAVES = MC_PAIR_WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 4)
+__global__ void __launch_bounds__(64 * WAVES, MC_PAIR_MINW)
 k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                uint64_t *table, uint64_t mask, DevCounters *ctr, unsigned flags, RouteArgs rt) {
     constexpr int NF = S::PAIR_FAMILIES, MW = S::MAX_WORDS;
     static_assert(NF >= 1 && NF <= 4, "per-family counts travel as 16-bit fields of one 64-bit scan");
     static_assert(S::PAIR_ROUND_SLOTS * 64 <= PAIR_CAP, "a round's pairs fit the list");
     static_assert(S::TOTAL_SLOTS <= 128 && S::TOTAL_SLOTS < 1024, "guard mask: 128 bits; list entry: slot << 6 | lane in 16 bits");
+    constexpr int KEYS = DynamicKeys<S>::value;
+    static_assert(KEYS <= 64 && (KEYS == 0 || NF == 1), "dynamic keys: one lane per key in the prefix sum, one family");
     __shared__ PairLds<S> lds[WAVES];
     if (rt.lc) {
         if (rt.lc->stop) return;
@@ -115,7 +135,7 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
             typename S::Summary q;
             S::summarize(loc, q);
             L.sum[lane] = q;
-            L.row[S::W_PAIR_BASE][lane] = S::pair_base(prm, loc, rr);
+            if constexpr (has_pair_base<S>()) L.row[S::W_PAIR_BASE][lane] = S::pair_base(prm, loc, rr);
             if (!(flags & 64u)) S::guards(prm, loc, glo, ghi);  // (64 = ablation: load the parents only)
         }
     }
@@ -140,6 +160,39 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
             mlo &= rlo;
             mhi &= rhi;
         }
+        unsigned fs[NF + 1];  // family f's pairs: list[fs[f] .. fs[f + 1])
+        fs[0] = 0;
+        if constexpr (KEYS > 0) {
+            // counting sort by S::pair_key: histogram in LDS, prefix over the keys (lane = key), positions claimed from the keys' cursors
+            const LdsRow myrow{(const __attribute__((address_space(3))) uint64_t *)&L.row[0][lane]};
+            wave_lds_fence();  // (the previous round's list has been read)
+            if (lane < (unsigned)KEYS) L.kcnt[lane] = 0;
+            wave_lds_fence();
+            for (uint64_t a = mlo; a; a &= a - 1) atomicAdd(&L.kcnt[S::pair_key(prm, myrow, (int)__builtin_ctzll(a))], 1u);
+            for (uint64_t b = mhi; b; b &= b - 1) atomicAdd(&L.kcnt[S::pair_key(prm, myrow, 64 + (int)__builtin_ctzll(b))], 1u);
+            wave_lds_fence();
+            const unsigned c = lane < (unsigned)KEYS ? L.kcnt[lane] : 0u;
+            unsigned incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned u = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += u;
+            }
+            fs[1] = __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
+            if (fs[1] == 0) continue;
+            wave_lds_fence();
+            if (lane < (unsigned)KEYS) L.kcnt[lane] = incl - c;
+            wave_lds_fence();
+            for (uint64_t a = mlo; a; a &= a - 1) {
+                const unsigned sl = (unsigned)__builtin_ctzll(a);
+                L.list[atomicAdd(&L.kcnt[S::pair_key(prm, myrow, (int)sl)], 1u)] = (uint16_t)((sl << 6) | lane);
+            }
+            for (uint64_t b = mhi; b; b &= b - 1) {
+                const unsigned sl = 64u + (unsigned)__builtin_ctzll(b);
+                L.list[atomicAdd(&L.kcnt[S::pair_key(prm, myrow, (int)sl)], 1u)] = (uint16_t)((sl << 6) | lane);
+            }
+            wave_lds_fence();
+        } else {
         // per-family counts of this lane, 16 bits each; inclusive scan over the lanes
         uint64_t cnt = 0;
         static_for<0, NF>([&](auto fc) {
@@ -155,8 +208,6 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
         }
         const uint64_t excl = incl - cnt;
         const uint64_t tot = __shfl(incl, 63);
-        unsigned fs[NF + 1];  // family f's pairs: list[fs[f] .. fs[f + 1])
-        fs[0] = 0;
 #pragma unroll
         for (int f = 0; f < NF; f++) fs[f + 1] = __builtin_amdgcn_readfirstlane(fs[f] + (unsigned)(tot >> (16 * f) & 0xffffu));
         if (fs[NF] == 0) continue;
@@ -178,6 +229,7 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
             }
         });
         wave_lds_fence();
+        }
 
         unsigned nsurv = 0;
         unsigned long long out0 = 0;

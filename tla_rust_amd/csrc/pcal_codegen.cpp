@@ -20,6 +20,8 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <algorithm>
+#include <functional>
 #include <map>
 #include <set>
 #include <sstream>
@@ -261,6 +263,29 @@ struct Gen {
     }
 
     // labels instance `inst` can ever stand at: its first label (stored by the Init code) and everything VM_SETPC reaches from there
+    // largest product of the VM_CHOOSE operands along a path from `entry` (capped at `cap`; a cycle counts as the cap)
+    long long max_choices(int entry, long long cap) {
+        std::map<int, long long> memo;
+        std::set<int> on_path;
+        std::function<long long(int)> go = [&](int pc) -> long long {
+            if (pc < 0 || pc >= (int)c.size()) return cap;
+            auto it = memo.find(pc);
+            if (it != memo.end()) return it->second;
+            if (!on_path.insert(pc).second) return cap;
+            const int op = c[(size_t)pc], n = operands(op);
+            long long r;
+            if (op == VM_HALT || op == VM_FAIL) r = 1;
+            else if (op == VM_JMP) r = go(c[(size_t)pc + 1]);
+            else if (op == VM_JZ || op == VM_JNZ) r = std::max(go(c[(size_t)pc + 1]), go(pc + 1 + n));
+            else if (op == VM_CHOOSE) r = std::min(cap, (long long)c[(size_t)pc + 1] * go(pc + 1 + n));
+            else r = go(pc + 1 + n);
+            on_path.erase(pc);
+            if (r > cap) r = cap;
+            memo[pc] = r;
+            return r;
+        };
+        return go(entry);
+    }
     int ninst_ = 0;
     std::set<int> labels_of(int inst, int pc_base, int init_entry, int label_tab, int nlabels) {
         int first = -1;
@@ -314,7 +339,7 @@ std::string codegen(const Program &P) {
     o << "// generated by tla_rust_amd/csrc/pcal_codegen.cpp from the compiled program of module " << P.module << ": do not edit\n"
       << "#pragma once\n#include \"spec_gen.h\"\nnamespace mc {\nstruct GenProg {\n"
       << "    static constexpr int NV = " << nv << ", NINST = " << ninst << ", MAXCH = " << maxch << ", PC_BASE = " << pc_base << ", DONE = " << done
-      << ", NINV = " << ninv << ", NCON = " << ncon << ";\n    static constexpr unsigned long long NUM_INIT = " << num_init << "ull;\n"
+      << ", NINV = " << ninv << ", NCON = " << ncon << ", NLABELS = " << nlabels << ";\n    static constexpr unsigned long long NUM_INIT = " << num_init << "ull;\n"
       << "    enum { R_DISABLED = 0, R_OK = 1, R_ASSERT = 2, R_ERROR = 3, R_OVERFLOW = 4 };\n";
     // entries: init, invariants, the labels
     // the variable cells as named members; helpers spec_gen.h asks for (words <-> cells, the pc cell of an instance)
@@ -355,6 +380,11 @@ std::string codegen(const Program &P) {
         o << "    template <int INST, int SELF_>\n    MC_HD static int label" << l << "(uint64_t &ch, Cells &v, const Cells &old, int32_t &result, int &aux) {\n"
           << g.body(c[(size_t)(label_tab + l)]) << "    }\n";
     }
+    // choices a label's code can consume: the largest product of VM_CHOOSE operands along a path from its entry (a choice index beyond
+    // it is never fully consumed, i.e. never enabled: the by-pairs kernel does not even queue it)
+    o << "    MC_HD static int nch(int32_t label) {\n        switch (label) {\n";
+    for (int l : used) o << "        case " << l << ": return " << g.max_choices(c[(size_t)(label_tab + l)], maxch) << ";\n";
+    o << "        default: return " << maxch << ";\n        }\n    }\n";
     o << "    template <int INST>\n    MC_HD static int run_inst(int32_t label, uint64_t &ch, Cells &v, const Cells &old, int &aux) {\n        int32_t result = 0;\n";
     for (int i = 0; i < ninst; ++i) {
         o << "        if constexpr (INST == " << i << ") {\n            switch (label) {\n";
@@ -433,7 +463,7 @@ extern "C" void *mc_jit_factory(const void *program /* pcal::Program * */) {
         const char *hc = getenv("HIPCC");
         const std::string tmp = so + "." + std::to_string((int)getpid()) + ".tmp";
         const std::string cmd = std::string(hc && *hc ? hc : "/opt/rocm/bin/hipcc") + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-unused-result -w -I " + inc +
-                                " -I " + csrc + " -x hip -DMC_TU=9 -DMC_GEN_HEADER='\"" + hdr + "\"' " + csrc + "/engine.hip -o " + tmp + " -L" + lib + " -ltlamc -Wl,-rpath," + lib +
+                                " -I " + csrc + " -x hip -DMC_TU=9 -DMC_EXPAND_INSERT_MINW=2 -DMC_PAIR_MINW=2 -DMC_PAIR_WAVES=1 -DMC_GEN_HEADER='\"" + hdr + "\"' " + csrc + "/engine.hip -o " + tmp + " -L" + lib + " -ltlamc -Wl,-rpath," + lib +
                                 " > " + cache + "/gen_" + tag + ".log 2>&1";
         if (system(cmd.c_str()) != 0 || rename(tmp.c_str(), so.c_str()) != 0) {
             mc::set_error("jit: hipcc failed (see " + cache + "/gen_" + tag + ".log)");

@@ -22,8 +22,21 @@
 
 namespace mc {
 
+// the by-pairs protocol's constants (engine_pairs.h), present only for programs the kernel's fixed sizes take: at most 128 slots (guard
+// mask), at most 64 labels (one lane per key in the prefix sum)
+template <class G, bool OK>
+struct SpecGenPairs {};
 template <class G>
-struct SpecGenT {
+struct SpecGenPairs<G, true> {
+    // (a wavefront whose parents enable more pairs than its list holds works in rounds of 20 consecutive slots: 20 x 64 = the list)
+    static constexpr int PAIR_FAMILIES = 1, TOTAL_SLOTS = G::NINST * G::MAXCH + 1, PAIR_ROUND_SLOTS = 20, PAIR_ROUNDS = (TOTAL_SLOTS + 19) / 20,
+                         PAIR_KEYS = G::NLABELS, W_PAIR_BASE = -1;
+};
+template <class G>
+constexpr bool spec_gen_pairs_ok() { return G::NINST * G::MAXCH + 1 <= 128 && G::NLABELS <= 64; }
+
+template <class G>
+struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
     using Params = VmParams;
     using VM = SpecVmT<128>;
     static constexpr int NV = G::NV, MAX_VARS = NV, MAX_WORDS = (NV + 1) / 2, FIX_SLOTS = 0, STAGE_WORDS = 0;
@@ -163,6 +176,64 @@ struct SpecGenT {
 #pragma unroll
         for (int k = 0; k < MAX_WORDS; ++k) out.set(k, w[k]);
         return st;
+    }
+
+    // ---- by-pairs protocol (engine_pairs.h, dynamic keys): the wavefront's enabled (parent, slot) pairs are sorted by the LABEL the slot's
+    // process instance stands at, so that a batch of 64 pairs runs one label's code
+    struct Summary {};
+    MC_HD static void summarize(const Local &, Summary &) {}
+    struct SlotMask { uint64_t lo, hi; };
+    MC_HD static constexpr SlotMask round_mask(int r) {  // round r: slots 20 r .. 20 r + 19
+        SlotMask m{0, 0};
+        for (int s = 20 * r; s < 20 * r + 20 && s < G::NINST * G::MAXCH + 1; s++) { if (s < 64) m.lo |= 1ull << s; else m.hi |= 1ull << (s - 64); }
+        return m;
+    }
+    template <int I>
+    MC_HD static void guards_inst(const Cells &cur, uint64_t &lo, uint64_t &hi) {
+        if constexpr (I < G::NINST) {
+            const int32_t label = G::template pc_of<I>(cur);
+            if (label != G::DONE) {
+                const int n = G::nch(label);   // choices the label's longest path consumes: an index beyond it cannot be fully consumed
+#pragma unroll
+                for (int c = 0; c < G::MAXCH; ++c)
+                    if (c < n) { const int s = I * G::MAXCH + c; if (s < 64) lo |= 1ull << s; else hi |= 1ull << (s - 64); }
+            }
+            guards_inst<I + 1>(cur, lo, hi);
+        }
+    }
+    // bit s set <= slot s may be enabled (an `await` or a shorter path can still disable it: the evaluation says so)
+    MC_HD static void guards(const Params &, const Local &l, uint64_t &lo, uint64_t &hi) {
+        lo = hi = 0;
+        guards_inst<0>(l.v, lo, hi);
+        constexpr int last = G::NINST * G::MAXCH;
+        if (all_done<0>(l.v)) { if (last < 64) lo |= 1ull << last; else hi |= 1ull << (last - 64); }
+    }
+    MC_HD static bool guard_is_exact(int) { return false; }
+    // the label slot's instance stands at, read from the parent's packed row (cell PC_BASE + inst: half of word (PC_BASE + inst) / 2)
+    template <class Ref>
+    MC_HD static int pair_key(const Params &, Ref row, int slot) {
+        if (slot >= G::NINST * G::MAXCH) return G::DONE;
+        const int cell = G::PC_BASE + slot / G::MAXCH;
+        const uint64_t w = row.get(cell >> 1);
+        const int32_t label = (int32_t)(uint32_t)(cell & 1 ? w >> 32 : w);
+        return label >= 0 && label < G::NLABELS ? label : G::DONE;
+    }
+    struct PairOut { uint64_t w[MAX_WORDS]; };   // the successor's packed row
+    template <int F, class Ref>
+    MC_HD static unsigned eval_pair(const Params &, const Summary &, Ref row, int slot, uint64_t &fp, PairOut &o) {
+        Cells cur, v;
+        unpack(row, cur);
+        const unsigned st = step(cur, slot, v);
+        if (st & ST_ENABLED) {
+            G::to_words(v, o.w);
+            fp = fp_words(o.w);
+        }
+        return st;
+    }
+    template <class Ref>
+    MC_HD static void write_pair(const Params &, Ref, const PairOut &o, WordRef out) {
+#pragma unroll
+        for (int k = 0; k < MAX_WORDS; ++k) out.set(k, o.w[k]);
     }
 
     // host side: the interpreter's helpers (same packed state)
