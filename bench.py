@@ -61,7 +61,18 @@ WORKLOAD_SSI = dict(spec="ssi", params=[4, 3, 127, 0], golden="ssi_4x3_levels10"
                     packed_fanout=40, imbalance=1.8,   # (the last level is 87 % of the states and stays where it was generated)
                     metric="distinct states/sec, serializableSnapshotIsolation.tla (4 txns x 3 keys, 10 BFS levels)",
                     name="examples/serializableSnapshotIsolation.tla TxnId=4 Key=3 all invariants (BASELINE config 5), levels 1-10")
+# --deep (the default of `--gpus N`, N >= 8: VERDICT round 5, next 6a): eight devices hold more than the one-GPU budget of configs 4 and 5, so the
+# 8-rank form of these workloads goes one level deeper — config 5 to 11 levels (1 184 049 193 states, golden tests/golden/ssi_levels.json
+# ssi_4x3_levels11), config 4 to 19 levels (the oracle's golden ends at 18: the first 18 per-level counts are gated, level 19 is reported)
+WORKLOAD_SSI_DEEP = dict(WORKLOAD_SSI, golden="ssi_4x3_levels11", max_levels=11,
+                         metric="distinct states/sec, serializableSnapshotIsolation.tla (4 txns x 3 keys, 11 BFS levels)",
+                         name="examples/serializableSnapshotIsolation.tla TxnId=4 Key=3 all invariants (BASELINE config 5), levels 1-11")
+WORKLOAD_RAFT5_DEEP = dict(WORKLOAD_RAFT5, max_levels=19, golden_prefix=18, expect_distinct=2_250_000_000,
+                           metric="distinct states/sec, raft.tla (5 servers, 19 BFS levels)",
+                           name="examples/raft.tla Server=5 MaxClientRequests=6 MaxTerm=2 MaxLogLen=5 MaxMsgs=1 (BASELINE config 4), levels 1-19 (levels 1-18 golden-gated)")
 WORKLOADS = {"t3": WORKLOAD_T3, "k10": WORKLOAD, "k11": WORKLOAD_K11, "raft5": WORKLOAD_RAFT5, "ssi4x3": WORKLOAD_SSI}
+DEEP = {"raft5": WORKLOAD_RAFT5_DEEP, "ssi4x3": WORKLOAD_SSI_DEEP}
+DEEP_TABLE_SLOTS = {"raft5": 7 << 30, "ssi4x3": 60 << 26}
 # seen-set slots: >= 3 x the arena, so that the table can never be more than a third full and is probed 32 bytes at a time
 # (engine.hip seen_insert: random HBM reads cost by the byte); load 0.2 at the end of the run: 21.5 / 4.3 / 14 GB of the 288
 TABLE_SLOTS = {"t3": 40 << 26, "k10": 8 << 26, "k11": 26 << 26, "raft5": 3 << 30, "ssi4x3": 9 << 26}
@@ -280,7 +291,11 @@ def dist_roofline(state_bytes, distinct, generated, world, step_s):
 
 def golden():
     g = json.loads((ROOT / "tests" / "golden" / WORKLOAD.get("golden_file", "raft_levels.json")).read_text())
-    return next(c for c in g["cases"] if c["name"] == WORKLOAD["golden"])
+    c = dict(next(c for c in g["cases"] if c["name"] == WORKLOAD["golden"]))
+    if WORKLOAD.get("golden_prefix"):   # a budget beyond the oracle's golden: its levels are a PREFIX of the run's (gated), the rest is reported
+        c["prefix_levels"] = list(c["levels"])
+        c["distinct"] = WORKLOAD["expect_distinct"]   # (sizes the arenas only)
+    return c
 
 
 def usable_cores():
@@ -388,6 +403,48 @@ def atomic_add_series(amd, device, n=28, steps=3):
             "golden": "closed form 2^N + 1 / N 2^(N-1) + 3 / depth N + 2 (tests/test_oracle_golden.py: equal to the oracle for N <= 16)"}
 
 
+def pcal_series(amd, device, steps=3):
+    """The compiled-PlusCal path in the driver's line: two models nobody hand-lowered, compiled by the PlusCal
+    front-end, translated into straight-line C++ and built for the device when the engine is created (MC_F_JIT: pcal_codegen.cpp, spec_gen.h),
+    expanded by the by-pairs kernel with the pairs sorted by label.  Gates: pagecache.tla N = 3 = tests/golden/pcal_channels.json
+    (counts and per-level counts); ms_queue_counted.tla N = 3, K = 3 = the same compiled program on the host build of the interpreter
+    (profiles/bench_msq_counted.py).  `engine_create_s` is the load-time build (hipcc; cached by the program's hash afterwards)."""
+    import io
+    G = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())["pagecache_n3"]
+    jobs = [("specs/pluscal/pagecache.tla N=3 (lock-free page cache, 3 threads)", ROOT / "specs" / "pluscal" / "pagecache.tla",
+             "CONSTANTS N = 3 Blind = FALSE\nINVARIANTS Conservation HeadIsAllocated\n", dict(table_capacity=1 << 27, arena_capacity=22 << 20, chunk_states=1 << 21),
+             (G["distinct"], G["generated"], G["depth"]), G["levels"], "tests/golden/pcal_channels.json:pagecache_n3"),
+            ("specs/pluscal/ms_queue_counted.tla N=3 K=3 (Michael-Scott queue with counted pointers, 3 threads)", ROOT / "specs" / "pluscal" / "ms_queue_counted.tla",
+             "CONSTANTS N = 3 K = 3 Counted = TRUE\nINVARIANTS HeadLive TailLive PointersAreNodes TailAtMostOneBehind CountsGrow\n",
+             dict(table_capacity=1 << 28, arena_capacity=40 << 20, chunk_states=1 << 21), (35263910, 99861367, 105), None,
+             "the same compiled program on the host build of the interpreter (profiles/bench_msq_counted.py)")]
+    out = []
+    for name, path, cfg, kw, want, levels, src in jobs:
+        prog = amd.Program(path.read_text(), cfg)
+        t0 = time.perf_counter()
+        eng = amd.Engine("pcal", prog.params, device=device, trace=False, timing=True, jit=True, **kw)
+        build_s = time.perf_counter() - t0
+        eng.run()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = eng.run()
+        dt = (time.perf_counter() - t0) / steps
+        ks = eng.kernel_stats()
+        eng.close()
+        prog.close()
+        if (r.distinct, r.generated, r.depth) != tuple(want) or r.verdict != "ok" or (levels is not None and list(r["levels"]) != levels):
+            print(f"bench.py: pcal {name}: got {(r.distinct, r.generated, r.depth, r.verdict)}, want {want}", file=sys.stderr)
+            sys.exit(1)
+        W = ks["state_bytes"]
+        moved = 2 * W * r.distinct + 8 * ks["cand_cells"]
+        out.append({"workload": name, "backend": "generated code (MC_F_JIT), by-pairs kernel" if ks.get("inwave_states", 0) else "slot-by-slot kernel (generated code or the interpreter: see stderr)",
+                    "value": r.distinct / dt, "unit": "distinct states/s", "ms_per_step": 1e3 * dt, "steps": steps, "distinct": r.distinct, "generated": r.generated,
+                    "depth": r.depth, "generated_per_s": r.generated / dt, "engine_create_s": build_s, "state_bytes": W,
+                    "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
+                    "pipeline_GBs": moved / dt / 1e9, "pipeline_frac": moved / dt / 1e9 / HBM_PEAK_GBS, "golden": src})
+    return out
+
+
 def other_config(amd, device, key, steps=3):
     """BASELINE.json's configs 4 and 5 name models that are meant for eight GPUs; their graphs up to a level budget fit ONE MI355X, and the
     driver's line carries them as objects of their own (round 5: until then only builder-run `--workload raft5 / ssi4x3` lines existed,
@@ -429,6 +486,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-atomic-add", action="store_true", help="skip the synthetic N-process atomic-counter object of the line")
+    ap.add_argument("--no-pcal", action="store_true", help="skip the compiled-PlusCal object of the line (two models as generated code: MC_F_JIT)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the one-GPU objects of BASELINE configs 4 and 5 (raft with 5 servers, SSI 4 x 3)")
     ap.add_argument("--max-distinct", type=int, default=0, help="A/B only: stop at a budget (the line is then marked invalid)")
     ap.add_argument("--chunk", type=int, default=(1 << 24) - 256)   # frontier states per launch: the engine's maximum (a column index has 24 bits).  Round 3: 169.4 / 163.6 / 160.5 ms
@@ -451,6 +509,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="t3", help="t3: MaxTerm 3, MaxMsgKeys 8 (525.8 M states, the contract line); "
                     "k10 / k11: MaxTerm 2 with 10 / 11 message keys (102.6 M / 336.6 M states; rounds 1-2's line was k10); raft5: BASELINE config 4 "
                     "(5 servers, 18 levels = 924 M states); ssi4x3: BASELINE config 5 (10 levels = 168 M states)")
+    ap.add_argument("--deep", dest="deep", action="store_true", default=None, help="--workload raft5 / ssi4x3: one BFS level beyond the one-GPU budget (19 / 11 levels); "
+                    "the default with --gpus 8 and more")
+    ap.add_argument("--no-deep", dest="deep", action="store_false")
     ap.add_argument("--table-slots", type=int, default=0, help="seen-set slots (any multiple of 64; 0 = the workload's default, load ~0.5 at the end)")
     ap.add_argument("--table-log2", type=int, default=0, help="A/B: a power-of-two seen-set (27: load 0.76, 28: load 0.38)")
     ap.add_argument("--msg-keys", type=int, default=0, choices=[0, 10, 11], help="(rounds 1-2) same as --workload k10 / k11")
@@ -468,8 +529,13 @@ def main():
     if a.msg_keys:
         a.workload = "k%d" % a.msg_keys
     WORKLOAD = WORKLOADS[a.workload]
+    if a.deep is None:
+        a.deep = a.gpus >= 8
+    deep = bool(a.deep) and a.workload in DEEP
+    if deep:
+        WORKLOAD = DEEP[a.workload]
     if not a.table_slots:
-        a.table_slots = TABLE_SLOTS[a.workload]
+        a.table_slots = DEEP_TABLE_SLOTS[a.workload] if deep else TABLE_SLOTS[a.workload]
     if not a.packed_fanout:
         a.packed_fanout = WORKLOAD.get("packed_fanout", 16)
 
@@ -585,7 +651,13 @@ def main():
         # parity gate: the measured run must BE the golden graph (exact counts, per-level where the engine reports them)
         got = (D, G, res.depth, res.verdict)
         want = (G0["distinct"], G0["generated"], G0["depth"], WORKLOAD.get("verdict", "ok"))
-        if got != want or ("levels" in res and list(res["levels"]) != G0["levels"]):
+        if "prefix_levels" in G0:   # gated on the golden's levels, one more level reported
+            ok = "levels" in res and list(res["levels"])[:len(G0["prefix_levels"])] == G0["prefix_levels"] and res.depth == ML and res.verdict == want[3]
+            got, want = (list(res["levels"])[:len(G0["prefix_levels"])] if "levels" in res else None, res.depth, res.verdict), (G0["prefix_levels"], ML, want[3])
+            if not ok:
+                print(f"bench.py: run does not reproduce the golden prefix: got {got}, want {want}", file=sys.stderr)
+                sys.exit(1)
+        elif got != want or ("levels" in res and list(res["levels"]) != G0["levels"]):
             print(f"bench.py: run does not reproduce the golden state graph: got {got}, want {want}", file=sys.stderr)
             sys.exit(1)
     line = {
@@ -649,6 +721,9 @@ def main():
             eng.close()
             line["config4_model_one_gpu"] = other_config(amd, local, "raft5")
             line["config5_model_one_gpu"] = other_config(amd, local, "ssi4x3")
+        if not a.no_pcal and not a.max_distinct and a.workload == "t3" and not a.matrix and not a.no_family:
+            eng.close()
+            line["pcal"] = pcal_series(amd, local)
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     print(json.dumps(line), flush=True)

@@ -49,3 +49,18 @@ def test_n_rank_roofline_object():
     assert W == 136 and r["bound"] == "hbm" and r["peak"] == 8000.0 and r["traffic"] is None
     assert abs(r["alg_bytes_per_step_per_gpu"] - (2 * 136 * 525782408 + 8 * 6708500293) / 8) < 1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert 0.12 < r["frac"] < 0.13
+
+
+def test_the_eight_rank_forms_of_configs_4_and_5_go_one_level_deeper():
+    """`bench.py --gpus 8 --workload raft5 | ssi4x3` searches one BFS level beyond the one-GPU budget (eight
+    devices hold it): config 5 against the oracle's 11-level golden, config 4 gated on the oracle's 18 levels with level 19 reported"""
+    b = _bench()
+    ssi, raft = b.DEEP["ssi4x3"], b.DEEP["raft5"]
+    g = json.loads((ROOT / "tests" / "golden" / "ssi_levels.json").read_text())
+    c = next(c for c in g["cases"] if c["name"] == ssi["golden"])
+    assert ssi["max_levels"] == c["depth"] == 11 and c["distinct"] == 1184049193 and c["verdict"] == "budget"
+    assert b.DEEP_TABLE_SLOTS["ssi4x3"] >= 3 * c["distinct"]                      # the sharded tables stay sparse (32-byte probes)
+    assert raft["max_levels"] == 19 and raft["golden_prefix"] == 18 and raft["golden"] == "raft5_mcr6_t2_m1_levels18"
+    b.WORKLOAD = raft
+    G0 = b.golden()
+    assert len(G0["prefix_levels"]) == 18 and G0["distinct"] == raft["expect_distinct"] > 924041864

@@ -15,6 +15,8 @@
 // -I DIR    : one more directory searched for the modules X.tla EXTENDS / INSTANCEs (after X.tla's own and $TLA_PATH's, which
 //             is a ':'-separated list).
 // -generic  : check a PlusCal module through the compiled program even when a hand lowering exists.
+// -jit      : a compiled PlusCal program runs as GENERATED code — translated to straight-line C++ and built for the device (hipcc) when
+//             the engine is created, cached by the program's hash — instead of being interpreted on the device (MC_F_JIT; same report).
 // -unverified: an MC wrapper (specs/MCraft.tla ...) EXTENDS a module of the reference (raft.tla); when that module is found
 //             neither beside the wrapper nor under $TLA_PATH the run is refused, unless this option accepts the built-in
 //             lowering unchecked (the report then starts with a warning).
@@ -320,6 +322,7 @@ int main(int argc, char **argv) {
         }
         else if (!strcmp(argv[i], "-torch") || !strcmp(argv[i], "-samedevice")) {}
         else if (!strcmp(argv[i], "-generic")) cfg.flags |= MC_F_GENERIC;
+        else if (!strcmp(argv[i], "-jit")) cfg.flags |= MC_F_JIT;
         else if (!strcmp(argv[i], "-unverified")) cfg.flags |= MC_F_UNVERIFIED;
         else if (arg("-I")) {  // one more directory searched for EXTENDed / INSTANCEd modules (appended to $TLA_PATH)
             const char *old = getenv("TLA_PATH");
@@ -341,7 +344,7 @@ int main(int argc, char **argv) {
     }
     if (!tla) {
         fprintf(stderr,
-                "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-unverified] [-device D] [-I DIR]\n"
+                "usage: mc X.tla [-config X.cfg] [-deadlock] [-dump FILE] [-generic] [-jit] [-unverified] [-device D] [-I DIR]\n"
                 "                [-maxdistinct N] [-maxlevels N] [-tablelog2 T] [-arena N] [-chunk N]\n"
                 "                [-checkpoint FILE] [-recover FILE] [-gpus P [-torch]]                    check X.tla like `tlc X.tla`\n"
                 "       mc --transpile X.tla [Y.tla ...]                                                  translate like `pcal2tla`\n"
