@@ -3,7 +3,11 @@ pcal2tla-style translation tests/golden/pcal_records/TwoPhaseChannels.tla (chan 
 product's host evaluator tla_rust_amd/csrc/tlaeval.cpp (through its test door).  The compiled program (one sequence per field, host VM
 and GPU) must reproduce them: another text, another engine.  RM = 5 takes the evaluator a few minutes.  Further down: the message soup (RM = 6, 7),
 epoch-based reclamation (N = 3), the IO buffer (N = 4), the radix tree (N = 4) and the pagecache entry (N = 3: 20 M states, 10 minutes, ~25 GB) —
-for those the evaluator reads the module file of specs/pluscal/ with its cfg.
+for those the evaluator reads the module file of specs/pluscal/ with its cfg: PRODUCT-MADE goldens (the product's host evaluator on the
+product's own translation: engine against engine, shared translator — VERDICT round 5, weak 5); the `source` fields say so.  What pins the
+translator itself: the small models of every spec state by state against oracle/tla_eval.py, and the hand-written pcal2tla-style
+translations under tests/golden/pcal_records/ (two-phase commit, Michael-Scott queue, ring buffer, Treiber stack, mailboxes, pagecache)
+evaluated by oracle/tlaplus.py (tests/test_pcal.py test_records_field_by_field_equal_the_record_valued_translation).
 
     python tests/golden/make_pcal_channels_golden.py"""
 import json

@@ -531,6 +531,9 @@ RECORD_FIXTURES = ROOT / "tests" / "golden" / "pcal_records"
     ("two_phase_channels", "TwoPhaseChannels", "TwoPhaseChannelsEager", {"RM": 3, "Eager": True}, ["Consistent", "InboxHoldsVotes", "FromTheCoordinator"]),
     ("mailboxes", "Mailboxes", "Mailboxes", {"N": 2}, ["LogOk", "Pongs", "HeardTheLeft"]),
     ("mailboxes", "Mailboxes", "Mailboxes3", {"N": 3}, ["LogOk", "Pongs", "HeardTheLeft"]),      # (deadlock: a node that has its pong leaves without answering)
+    # round 6: the model of the driver line's `pcal` object, its golden no longer the product's alone
+    ("pagecache", "PageCache", "PageCache", {"N": 2, "Blind": False}, ["Conservation", "HeadIsAllocated"]),
+    ("pagecache", "PageCache", "PageCacheBlind", {"N": 2, "Blind": True}, ["Conservation", "HeadIsAllocated"]),   # (the blind store loses a delta: Conservation breaks)
 ])
 def test_records_field_by_field_equal_the_record_valued_translation(spec, fixture, cfg, consts, invs):
     """PlusCal record variables are kept FIELD BY FIELD (tla_rust_amd/csrc/pcal.h, RECORDS) instead of as one record-valued variable
