@@ -20,6 +20,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 import helpers  # noqa: E402
 
 F = ROOT / "tests" / "golden" / "pcal_records"
+PM = "PRODUCT-MADE (engine against engine, NOT an oracle): the product's host evaluator (tla_rust_amd/csrc/tlaeval.cpp) on the product's own translation of "
 out = {}
 for rm, cells in ((4, 8), (5, 5)):
     with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
@@ -28,7 +29,7 @@ for rm, cells in ((4, 8), (5, 5)):
     r = helpers.tlaeval_run(F / "TwoPhaseChannels.tla", f.name, search=[])
     assert r["rc"] == 0 and r["verdict"] == 0, r
     out[f"two_phase_channels_rm{rm}"] = dict(RM=rm, seq_cells=cells, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
-                                             source="tlaeval.cpp on tests/golden/pcal_records/TwoPhaseChannels.tla (hand-written record-valued translation)")
+                                             source="PRODUCT host evaluator (tla_rust_amd/csrc/tlaeval.cpp) on the HAND-WRITTEN record-valued translation tests/golden/pcal_records/TwoPhaseChannels.tla (RM = 3 of the same text: oracle/tlaplus.py, tests/test_pcal.py)")
     print(rm, r["distinct"], r["generated"], r["depth"], r["seconds"])
 # the message SOUP (a set of records, specs/pluscal/two_phase_soup.tla): the translation keeps msgs the set pcal2tla keeps, so the text evaluated
 # here is the spec file itself; RM = 3 is also walked by oracle/tlaplus.py and oracle/tla_eval.py in tests/test_pcal.py
@@ -38,28 +39,28 @@ for rm in (6, 7):
     r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "two_phase_soup.tla", f.name, search=[])
     assert r["rc"] == 0 and r["verdict"] == 0, r
     out[f"two_phase_soup_rm{rm}"] = dict(RM=rm, seq_cells=rm + 1, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
-                                         source="tlaeval.cpp on specs/pluscal/two_phase_soup.tla (msgs one set-valued variable, as pcal2tla keeps it)")
+                                         source=PM + "specs/pluscal/two_phase_soup.tla (msgs one set-valued variable, as pcal2tla keeps it)")
     print("soup", rm, r["distinct"], r["generated"], r["depth"], r["seconds"])
 # epoch-based reclamation with three threads (specs/pluscal/epoch_gc.tla + .cfg): 33 s
 r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "epoch_gc.tla", ROOT / "specs" / "pluscal" / "epoch_gc.cfg", search=[])
 assert r["rc"] == 0 and r["verdict"] == 0, r
 out["epoch_gc_n3"] = dict(N=3, Grace=2, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
-                          source="tlaeval.cpp on specs/pluscal/epoch_gc.tla + epoch_gc.cfg")
+                          source=PM + "specs/pluscal/epoch_gc.tla + epoch_gc.cfg")
 # the lock-free IO buffer with four writers (specs/pluscal/io_buffer.tla + .cfg): 12 s
 r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "io_buffer.tla", ROOT / "specs" / "pluscal" / "io_buffer.cfg", search=[])
 assert r["rc"] == 0 and r["verdict"] == 0, r
 out["io_buffer_n4"] = dict(N=4, Cap=2, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
-                           source="tlaeval.cpp on specs/pluscal/io_buffer.tla + io_buffer.cfg")
+                           source=PM + "specs/pluscal/io_buffer.tla + io_buffer.cfg")
 # the radix tree with four inserters (specs/pluscal/radix_tree.tla, N = 4): about 100 s
 with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
     f.write("SPECIFICATION Spec\nCONSTANT N = 4\nCONSTANT Plain = FALSE\nINVARIANT InsertedKeysAreFound NoLeak ChildrenAreNodes\n")
 r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "radix_tree.tla", f.name, search=[])
 assert r["rc"] == 0 and r["verdict"] == 0, r
 out["radix_tree_n4"] = dict(N=4, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
-                            source="tlaeval.cpp on specs/pluscal/radix_tree.tla, N = 4, Plain = FALSE")
+                            source=PM + "specs/pluscal/radix_tree.tla, N = 4, Plain = FALSE")
 # the pagecache entry with three threads (specs/pluscal/pagecache.tla + .cfg): 20 M states, several minutes and a few GB
 r = helpers.tlaeval_run(ROOT / "specs" / "pluscal" / "pagecache.tla", ROOT / "specs" / "pluscal" / "pagecache.cfg", search=[])
 assert r["rc"] == 0 and r["verdict"] == 0, r
 out["pagecache_n3"] = dict(N=3, distinct=r["distinct"], generated=r["generated"], depth=r["depth"], levels=r["levels"],
-                           source="tlaeval.cpp on specs/pluscal/pagecache.tla + pagecache.cfg")
+                           source=PM + "specs/pluscal/pagecache.tla + pagecache.cfg")
 (ROOT / "tests" / "golden" / "pcal_channels.json").write_text(json.dumps(out, indent=1) + "\n")
