@@ -15,6 +15,7 @@ pub const MC_SPEC_PAXOS: u32 = 6; // examples/Paxos/Voting.tla, Paxos.tla under 
 pub const MC_F_GENERIC: u32 = 128;
 pub const MC_F_DEADLOCK: u32 = 1;
 pub const MC_F_TRACE: u32 = 2;
+pub const MC_F_JIT: u32 = 262144; // MC_SPEC_PCAL: the compiled program as generated code, built for the device when the engine is created
 pub const MC_MAX_LEVELS: usize = 4096;
 
 #[repr(C)]
@@ -58,6 +59,7 @@ extern "C" {
     pub fn mc_program_compile(tla_text: *const c_char, cfg_text: *const c_char, out: *mut *mut mc_program) -> c_int;
     pub fn mc_program_spec(p: *const mc_program, out: *mut mc_spec_desc) -> c_int;
     pub fn mc_program_translated(p: *const mc_program) -> *const c_char;
+    pub fn mc_program_codegen(p: *const mc_program, buf: *mut c_char, cap: usize) -> std::os::raw::c_long;
     pub fn mc_program_invariant(p: *const mc_program, index: c_int) -> *const c_char;
     pub fn mc_program_free(p: *mut mc_program);
     pub fn mc_state_bytes(spec: *const mc_spec_desc) -> usize;

@@ -315,3 +315,19 @@ def read_dump(path):
             lvl, txt = line.rstrip("\n").split(" ", 1)
             by_level.setdefault(int(lvl[1:]), []).append(txt)
     return {k: sorted(v) for k, v in by_level.items()}
+
+
+def run_with_master_port(make_cmd, tries=4, **kw):
+    """subprocess.run(make_cmd(port), ...) for a torch.distributed.run launch that needs a free rendezvous port.  A port found by bind(0) +
+    close can be taken again before the launcher's agent binds it (round 6: EADDRINUSE on the GPU box ended a `pytest -x` run): another
+    port is tried when the launcher says so."""
+    import socket
+    p = None
+    for _ in range(tries):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        p = subprocess.run(make_cmd(port), **kw)
+        if p.returncode == 0 or "EADDRINUSE" not in (p.stderr or "") + (p.stdout or ""):
+            return p
+    return p

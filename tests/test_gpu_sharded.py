@@ -184,16 +184,17 @@ def _mc_multi(world, *args, timeout=300):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable]
-    if world > 1:
-        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    cmd += ["-m", "tla_rust_amd.mc_multi"] + [str(a) for a in args]
-    if world > 1:
-        cmd += ["-backend", "gloo", "-device", "0"]      # one GPU box: the ranks share GPU 0, buckets staged over gloo
-    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
+    import helpers
+
+    def cmd(port):
+        c = [sys.executable]
+        if world > 1:
+            c += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+        c += ["-m", "tla_rust_amd.mc_multi"] + [str(a) for a in args]
+        if world > 1:
+            c += ["-backend", "gloo", "-device", "0"]      # one GPU box: the ranks share GPU 0, buckets staged over gloo
+        return c
+    return helpers.run_with_master_port(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
 
 
 @pytest.mark.parametrize("world", [1, 2])
@@ -365,12 +366,11 @@ def test_bench_under_the_drivers_launcher():
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--share-gpu", "--workload", "k10"],
-                       capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=str(root))
+    import helpers
+    p = helpers.run_with_master_port(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                   "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--share-gpu",
+                                                   "--workload", "k10"],
+                                     capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=str(root))
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     line = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
     c = line["config"]
@@ -398,13 +398,12 @@ def test_bench_under_a_launcher_at_world_size_1_is_the_fused_line():
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     lines = []
+    import helpers
     for extra in ([], ["--force-shard"]):
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                            str(root / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "k10", "--no-cpu-baseline"] + extra,
-                           capture_output=True, text=True, timeout=900, cwd=str(root))
+        p = helpers.run_with_master_port(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                                                       "--master-port", str(port), str(root / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "k10",
+                                                       "--no-cpu-baseline"] + extra,
+                                         capture_output=True, text=True, timeout=900, cwd=str(root))
         assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
         lines.append(json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{"))))
     fused, shard = lines
