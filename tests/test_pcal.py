@@ -534,6 +534,15 @@ RECORD_FIXTURES = ROOT / "tests" / "golden" / "pcal_records"
     # round 6: the model of the driver line's `pcal` object, its golden no longer the product's alone
     ("pagecache", "PageCache", "PageCache", {"N": 2, "Blind": False}, ["Conservation", "HeadIsAllocated"]),
     ("pagecache", "PageCache", "PageCacheBlind", {"N": 2, "Blind": True}, ["Conservation", "HeadIsAllocated"]),   # (the blind store loses a delta: Conservation breaks)
+    # ... and the other four specs whose large goldens were product-made (the same fixtures at the large sizes: tests/golden/pcal_oracle.json)
+    ("epoch_gc", "EpochGc", "EpochGc", {"N": 2, "Grace": 2}, ["HeadIsLive", "NoDanglingReader", "EpochInRange"]),
+    ("epoch_gc", "EpochGc", "EpochGcOneGrace", {"N": 2, "Grace": 1}, ["HeadIsLive", "NoDanglingReader", "EpochInRange"]),   # (one grace period: a pinned reader's node is freed)
+    ("io_buffer", "IoBuffer", "IoBuffer", {"N": 2, "Cap": 2, "Patient": True}, ["HeaderInRange", "SealedIsFull", "FlushedFull"]),
+    ("io_buffer", "IoBuffer", "IoBufferHasty", {"N": 3, "Cap": 2, "Patient": False}, ["HeaderInRange", "SealedIsFull", "FlushedFull"]),   # (flushed under a writer: the assert in Copy)
+    ("radix_tree", "RadixTree", "RadixTree", {"N": 2, "Plain": False}, ["InsertedKeysAreFound", "NoLeak", "ChildrenAreNodes"]),
+    ("radix_tree", "RadixTree", "RadixTreePlain", {"N": 3, "Plain": True}, ["InsertedKeysAreFound", "ChildrenAreNodes"]),   # (a plain store unlinks the first thread's subtree)
+    ("two_phase_soup", "TwoPhaseSoup", "TwoPhaseSoup", {"RM": 3, "Hasty": False}, ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages", "SoupIsSmall"]),
+    ("two_phase_soup", "TwoPhaseSoup", "TwoPhaseSoupHasty", {"RM": 3, "Hasty": True}, ["Consistent", "OneDecision", "PreparedWereSent", "KnownMessages"]),
 ])
 def test_records_field_by_field_equal_the_record_valued_translation(spec, fixture, cfg, consts, invs):
     """PlusCal record variables are kept FIELD BY FIELD (tla_rust_amd/csrc/pcal.h, RECORDS) instead of as one record-valued variable

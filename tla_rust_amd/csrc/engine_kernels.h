@@ -34,6 +34,9 @@ struct DevCounters {
     unsigned int max_slots;           // rows of the candidate matrix written by the current chunk
     unsigned int error;               // DEV_E* bits
     unsigned int atomic_alloc;        // see arena_next
+    // round 6: where the in-wave writers park the overflow of their survivor lists (65 new-list entries per chunk: 64 survivors + a
+    // link to the wavefront's chunk before; k_expand_family's tail).  Same segments and parities as n_new, which stays 0 in such a level
+    PaddedCounter n_side[2 * NSHARD];
 };
 enum : unsigned { DEV_ETABLE = 1u, DEV_EARENA = 2u, DEV_EOVERFLOW = 4u, DEV_EROUTE = 8u /* an exchange bucket of a sharded round is full */ };
 enum : unsigned { VK_INVARIANT = 1, VK_ASSERT = 2, VK_DEADLOCK = 3, VK_SPECERR = 4 };
@@ -948,6 +951,16 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     unsigned cas_obase = 0;
     unsigned long long casret = 0;   // what that compare-and-swap returns (per lane; waited for at its first use, one resolve step later)
     uint64_t *const land = probe_land[threadIdx.x >> 6];
+    // IN-WAVE OVERFLOW (round 6; MC_F_LISTOVERFLOW = rounds 4-5's form for A/B).  A wavefront whose survivor list is about to fill up used
+    // to push its 64 oldest survivors through the global new-list to k_materialise — a second kernel beside the expand, unsorted batches
+    // (every branch of the writer walked), the parents read again from HBM: 0.15 % of the contract workload's states but 11 % of the
+    // five-server model's (fan-out ~27 per parent, W = 192 B: 103 M states, a 93 - 109 ms kernel beside a 156 ms one).  Now the 64
+    // survivors are PARKED in the new-list's memory — 10 bytes per survivor instead of a row, as a chunk linked to the wavefront's chunk
+    // before (the wavefront keeps one position, no table) — and the workgroup's tail takes them back: after the round that writes
+    // what the lists hold, every wavefront refills its list from its chain (up to OCAP entries) and the tail runs again, until the
+    // chains are empty.  Same sort by action class, same writer, same allocation; nothing reaches k_materialise.
+    const bool spill = inwave && !ASYNC_BUILD && !(flags & (MC_F_LISTOVERFLOW | MC_F_WAVETAIL)) && rt.new_fp != nullptr;  // wave-uniform
+    uint32_t spill_last = 0;  // position + 1 of this wavefront's newest parked chunk in its new-list segment (0: none)
     MC_PROF_DECL
 
     auto flush_out = [&](unsigned take) __attribute__((always_inline)) {
@@ -956,11 +969,17 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         const unsigned e = lane < take ? Q.o_ent[owrap(ohead + lane)] : O_DEAD;
         const unsigned long long bl = __ballot(e != O_DEAD);
         unsigned long long pos = 0;
-        if (lane == 0 && bl) pos = atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)__popcll(bl));
-        pos = __shfl(pos, 0) + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
+        // (spill: a chunk is 64 entries + the link; same segment, a cursor of its own — k_materialise never sees these entries)
+        if (lane == 0 && bl) pos = spill ? atomicAdd(&ctr->n_side[pshard].v, 65ull) : atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)__popcll(bl));
+        const unsigned long long pos0 = wave_uniform_copy(pos);  // (lane 0's)
+        pos = pos0 + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
         if (e != O_DEAD) {
             seg[pos] = (uint32_t)(wave_col0 + (e & 63u)) | ((uint32_t)(e >> 6) << 24);
             if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos] = Q.o_fp[owrap(ohead + lane)];
+        }
+        if (spill) {
+            if (lane == 0) seg[pos0 + 64] = spill_last;
+            spill_last = (uint32_t)pos0 + 1u;
         }
         ohead = owrap(ohead + take);
         on -= take;
@@ -1488,6 +1507,8 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         }
         auto hist_at = [&](unsigned c, unsigned ww) -> unsigned & { return hist_base[ww * hist_stride + c]; };
         const unsigned w = threadIdx.x >> 6;
+        __shared__ unsigned wg_more_s[WAVES];  // wavefront w still has parked chunks after this round (see `spill`)
+        for (;;) {   // one round per refill of the survivor lists; a workgroup whose wavefronts parked nothing makes one
         // a wavefront counts its own survivors per class as soon as IT has finished — in the shadow of the wait for its siblings
         MC_PROF(16);      // (profiling builds: 16 = the counting sort, 4 = waiting at barrier (1), 17 = the writes)
         unsigned ccnt[NCLS];
@@ -1502,6 +1523,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         }
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) if (lane == 0) hist_at((unsigned)c, w) = ccnt[c];
+        if (lane == 0) wg_more_s[w] = spill_last;
         MC_PROF(4);
         __syncthreads();  // (1) no wavefront of the workgroup generates any more: the filters are free, the lists final, the counts there
         MC_PROF(16);
@@ -1509,6 +1531,9 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         unsigned incl = h;
         for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
         const unsigned excl = incl - h, total = __shfl(incl, 63);
+        bool wg_more = false;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) wg_more |= wg_more_s[ww] != 0u;
 #if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
         // ABLATION BUILD ONLY (profiles/tail_ablate.py: ONE level is timed, its output is garbage and is never expanded).  flags bit 21: every
         // workgroup's survivors start on a 64-state boundary — every column store of the writer is one whole 512-byte row of a block: the
@@ -1539,6 +1564,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         const unsigned long long out0 = *wg_out0;
         if (total && out0 + total > rt.arena_cap) {
             err |= DEV_EARENA;
+            break;  // (workgroup-uniform: out0 and total are the workgroup's)
         } else {
             const uint64_t wg_idx0 = base + (uint64_t)blockIdx.x * (64u * WAVES);
             for (unsigned bt = w * 64u; bt < total; bt += 64u * WAVES) {  // batch of 64 sorted survivors; the wavefronts take turns
@@ -1562,6 +1588,22 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
                 if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
             }
         }
+        if (!wg_more) break;  // (workgroup-uniform: every wavefront read the same wg_more_s after barrier (1))
+        // NEXT ROUND: the lists are spent; a wavefront with parked chunks takes up to OCAP survivors back, newest chunk first
+        __syncthreads();  // (3) nobody reads a list, the order or the counts of this round any more
+        ohead = 0;
+        on = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (the chunks were stored by this very wavefront)
+        while (spill_last && on + 64u <= (unsigned)OCAP) {
+            const uint64_t p0 = (uint64_t)spill_last - 1u;
+            const uint32_t se = seg[p0 + lane];
+            Q.o_ent[on + lane] = (uint16_t)(((se >> 24) << 6) | (se & 63u));
+            Q.o_fp[on + lane] = rt.new_fp[(uint64_t)pshard * seg_cap + p0 + lane];
+            spill_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg[p0 + 64]);
+            on += 64;
+        }
+        wave_lds_fence();
+        }  // (rounds)
         }  // (workgroup tail)
     } else if (on) {
         flush_out(on);
@@ -1905,7 +1947,7 @@ static __global__ void k_bump_arena_next(DevCounters *ctr, const uint32_t *n_dev
 }
 static __global__ void k_commit(DevCounters *ctr, unsigned parity) {
     unsigned long long n = 0;
-    for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[parity * NSHARD + t].v; ctr->n_new[parity * NSHARD + t].v = 0; }
+    for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[parity * NSHARD + t].v; ctr->n_new[parity * NSHARD + t].v = 0; ctr->n_side[parity * NSHARD + t].v = 0; }
     ctr->via_list += n;
     if (!ctr->atomic_alloc) ctr->arena_next += n;  // (atomic_alloc: k_materialise took the indices itself)
     ctr->max_slots = 0;
@@ -1964,7 +2006,7 @@ static __global__ void k_end_level(DevCounters *ctr, LevelCtl *lc) {
     if (lc->stop) return;
     {  // k_commit of new-list parity 0, folded in (one launch less per level)
         unsigned long long n = 0;
-        for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; }
+        for (int t = 0; t < NSHARD; t++) { n += ctr->n_new[t].v; ctr->n_new[t].v = 0; ctr->n_side[t].v = 0; }
         ctr->via_list += n;
         if (!ctr->atomic_alloc) ctr->arena_next += n;
         ctr->max_slots = 0;
