@@ -292,7 +292,10 @@ def dist_roofline(state_bytes, distinct, generated, world, step_s):
 def golden():
     g = json.loads((ROOT / "tests" / "golden" / WORKLOAD.get("golden_file", "raft_levels.json")).read_text())
     c = dict(next(c for c in g["cases"] if c["name"] == WORKLOAD["golden"]))
-    if WORKLOAD.get("golden_prefix"):   # a budget beyond the oracle's golden: its levels are a PREFIX of the run's (gated), the rest is reported
+    if WORKLOAD.get("reduced_levels"):  # --levels L (tests): the first L levels of the golden, all gated; sizes follow
+        c["prefix_levels"] = list(c["levels"][:WORKLOAD["reduced_levels"]])
+        c["distinct"] = sum(c["prefix_levels"])
+    elif WORKLOAD.get("golden_prefix"):   # a budget beyond the oracle's golden: its levels are a PREFIX of the run's (gated), the rest is reported
         c["prefix_levels"] = list(c["levels"])
         c["distinct"] = WORKLOAD["expect_distinct"]   # (sizes the arenas only)
     return c
@@ -512,6 +515,8 @@ def main():
     ap.add_argument("--deep", dest="deep", action="store_true", default=None, help="--workload raft5 / ssi4x3: one BFS level beyond the one-GPU budget (19 / 11 levels); "
                     "the default with --gpus 8 and more")
     ap.add_argument("--no-deep", dest="deep", action="store_false")
+    ap.add_argument("--levels", type=int, default=0, help="TEST ONLY: stop after this many BFS levels (a prefix of the workload's golden, every level gated; "
+                    "seen-set and arenas sized for it) — the 8-rank command lines of configs 4 and 5 on one shared GPU")
     ap.add_argument("--table-slots", type=int, default=0, help="seen-set slots (any multiple of 64; 0 = the workload's default, load ~0.5 at the end)")
     ap.add_argument("--table-log2", type=int, default=0, help="A/B: a power-of-two seen-set (27: load 0.76, 28: load 0.38)")
     ap.add_argument("--msg-keys", type=int, default=0, choices=[0, 10, 11], help="(rounds 1-2) same as --workload k10 / k11")
@@ -536,6 +541,10 @@ def main():
     deep = bool(a.deep) and a.workload in DEEP
     if deep:
         WORKLOAD = DEEP[a.workload]
+    if a.levels:   # the same command line at a reduced budget: L levels of the workload's golden, every one gated (tests/test_gpu_sharded.py)
+        WORKLOAD = dict(WORKLOAD, max_levels=a.levels, reduced_levels=a.levels, name=WORKLOAD["name"] + f" — REDUCED to {a.levels} levels (--levels: a functional run, not the benchmark)")
+        if not a.table_slots:
+            a.table_slots = max(1 << 22, (8 * golden()["distinct"]) // 64 * 64)
     if not a.table_slots:
         a.table_slots = DEEP_TABLE_SLOTS[a.workload] if deep else TABLE_SLOTS[a.workload]
     if not a.packed_fanout:

@@ -65,7 +65,7 @@ Init == (* Global variables *)
 
 P1(self) == /\ pc[self] = "P1"
             /\ Assert(even_sp[self] < 4, 
-                      "Failure of assertion at line 29, column 7.")
+                      "The call at line 29, column 7 needs more than the 4 stack frames this translation reserves for procedure even: raise TLAMC_PCAL_STACK (a capacity limit, not an assertion of the algorithm).")
             /\ even_ret1' = [even_ret1 EXCEPT ![self] = (IF even_sp[self] = 0 THEN 1 ELSE even_ret1[self])]
             /\ n_stk1' = [n_stk1 EXCEPT ![self] = (IF even_sp[self] = 0 THEN n[self] ELSE n_stk1[self])]
             /\ even_ret2' = [even_ret2 EXCEPT ![self] = (IF even_sp[self] = 1 THEN 1 ELSE even_ret2[self])]
@@ -122,7 +122,7 @@ O1_p2(self) == /\ pc[self] = "O1_p2"
 
 O2_p2(self) == /\ pc[self] = "O2_p2"
                /\ Assert(even_sp[self] < 4, 
-                         "Failure of assertion at line 24, column 7.")
+                         "The call at line 24, column 7 needs more than the 4 stack frames this translation reserves for procedure even: raise TLAMC_PCAL_STACK (a capacity limit, not an assertion of the algorithm).")
                /\ even_ret1' = [even_ret1 EXCEPT ![self] = (IF even_sp[self] = 0 THEN 2 ELSE even_ret1[self])]
                /\ n_stk1' = [n_stk1 EXCEPT ![self] = (IF even_sp[self] = 0 THEN n[self] ELSE n_stk1[self])]
                /\ even_ret2' = [even_ret2 EXCEPT ![self] = (IF even_sp[self] = 1 THEN 2 ELSE even_ret2[self])]
@@ -208,7 +208,7 @@ E1_p1(self) == /\ pc[self] = "E1_p1"
 
 E2_p1(self) == /\ pc[self] = "E2_p1"
                /\ Assert(odd_sp[self] < 4, 
-                         "Failure of assertion at line 15, column 7.")
+                         "The call at line 15, column 7 needs more than the 4 stack frames this translation reserves for procedure odd: raise TLAMC_PCAL_STACK (a capacity limit, not an assertion of the algorithm).")
                /\ odd_ret1' = [odd_ret1 EXCEPT ![self] = (IF odd_sp[self] = 0 THEN 1 ELSE odd_ret1[self])]
                /\ m_stk1' = [m_stk1 EXCEPT ![self] = (IF odd_sp[self] = 0 THEN m[self] ELSE m_stk1[self])]
                /\ odd_ret2' = [odd_ret2 EXCEPT ![self] = (IF odd_sp[self] = 1 THEN 1 ELSE odd_ret2[self])]

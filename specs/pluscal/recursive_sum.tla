@@ -58,7 +58,7 @@ Init == (* Global variables *)
 
 P1(self) == /\ pc[self] = "P1"
             /\ Assert(down_sp[self] < 4, 
-                      "Failure of assertion at line 26, column 7.")
+                      "The call at line 26, column 7 needs more than the 4 stack frames this translation reserves for procedure down: raise TLAMC_PCAL_STACK (a capacity limit, not an assertion of the algorithm).")
             /\ down_ret1' = [down_ret1 EXCEPT ![self] = (IF down_sp[self] = 0 THEN 1 ELSE down_ret1[self])]
             /\ n_stk1' = [n_stk1 EXCEPT ![self] = (IF down_sp[self] = 0 THEN n[self] ELSE n_stk1[self])]
             /\ kept_stk1' = [kept_stk1 EXCEPT ![self] = (IF down_sp[self] = 0 THEN kept[self] ELSE kept_stk1[self])]
@@ -156,7 +156,7 @@ D2_p1(self) == /\ pc[self] = "D2_p1"
 
 D3_p1(self) == /\ pc[self] = "D3_p1"
                /\ Assert(down_sp[self] < 4, 
-                         "Failure of assertion at line 20, column 7.")
+                         "The call at line 20, column 7 needs more than the 4 stack frames this translation reserves for procedure down: raise TLAMC_PCAL_STACK (a capacity limit, not an assertion of the algorithm).")
                /\ down_ret1' = [down_ret1 EXCEPT ![self] = (IF down_sp[self] = 0 THEN 2 ELSE down_ret1[self])]
                /\ n_stk1' = [n_stk1 EXCEPT ![self] = (IF down_sp[self] = 0 THEN n[self] ELSE n_stk1[self])]
                /\ kept_stk1' = [kept_stk1 EXCEPT ![self] = (IF down_sp[self] = 0 THEN kept[self] ELSE kept_stk1[self])]

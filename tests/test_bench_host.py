@@ -64,3 +64,7 @@ def test_the_eight_rank_forms_of_configs_4_and_5_go_one_level_deeper():
     b.WORKLOAD = raft
     G0 = b.golden()
     assert len(G0["prefix_levels"]) == 18 and G0["distinct"] == raft["expect_distinct"] > 924041864
+    # --levels L (tests/test_gpu_sharded.py: the same command lines on one shared GPU): a prefix of the same golden, sizes follow
+    b.WORKLOAD = dict(raft, max_levels=13, reduced_levels=13)
+    G0 = b.golden()
+    assert G0["prefix_levels"] == [1, 6, 40, 205, 775, 2851, 10000, 32015, 97215, 287510, 816406, 2225540, 5913945] and G0["distinct"] == sum(G0["prefix_levels"])

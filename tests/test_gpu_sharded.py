@@ -356,6 +356,31 @@ def test_bench_contract_invocation_with_several_ranks(world):
     assert x["exchange"] == "exact" and x["routed_candidates_per_step"] > 10 ** 8 and x["fp_answer_bytes_per_step"] == x["model_bytes_per_step"] and x["sent_over_model"] == 1.0
 
 
+@pytest.mark.parametrize("workload,levels,prefix", [
+    ("raft5", 13, [1, 6, 40, 205, 775, 2851, 10000, 32015, 97215, 287510, 816406, 2225540, 5913945]),
+    ("ssi4x3", 8, [1, 4, 32, 264, 2532, 24576, 236844, 2189052]),
+])
+def test_the_eight_rank_deep_command_lines_of_configs_4_and_5_at_a_reduced_budget(workload, levels, prefix):
+    """`python bench.py --gpus 8 --workload raft5 | ssi4x3` — eight ranks, --deep by default: the budgets the first
+    real 8-GPU run will use — here exactly those command lines with `--levels L` (a prefix of the same golden, every level gated by
+    bench.py itself; seen-set and arenas sized for it) and the eight ranks on this one GPU (--share-gpu + stand-in): the N-rank engine
+    walks BASELINE config 4's five-server raft model and config 5's 4 x 3 snapshot-isolation model through replicated, stay and move
+    levels and reproduces the oracle's per-level counts."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--workload", workload, "--steps", "1", "--warmup", "0", "--share-gpu",
+                        "--levels", str(levels)], capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=str(root))
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    line = json.loads(next(ln for ln in p.stdout.splitlines() if ln.startswith("{")))
+    c = line["config"]
+    assert line["n_gpus"] == 8 and c["distinct"] == sum(prefix) and c["depth"] == levels and c["verdict"] == "budget"
+    assert "REDUCED" in c["workload"] and "NOT_A_MEASUREMENT" in c
+    assert len(c["shares"]) == 8 and sum(c["shares"]) >= sum(prefix) and c["levels"]["stay_levels"] + c["levels"]["move_levels"] >= 1
+
+
 def test_bench_under_the_drivers_launcher():
     """the driver's N > 1 command line, word for word: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` — the communicator id travels through the launcher's own TCP store

@@ -310,7 +310,7 @@ struct Engine : EngineBase {
         return MC_OK;
     }
     int check_dev_error() {
-        if (h_ctr->error & DEV_EOVERFLOW) { set_error("packed-state capacity exceeded (raft messages / elections / allLogs slots, or a PlusCal sequence longer than its cells)"); return MC_EOVERFLOW; }
+        if (h_ctr->error & DEV_EOVERFLOW) { set_error("packed-state capacity exceeded (raft messages / elections / allLogs slots, or a PlusCal sequence longer than its cells, or a recursive PlusCal procedure deeper than $TLAMC_PCAL_STACK frames)"); return MC_EOVERFLOW; }
         if (h_ctr->error & DEV_ETABLE) { set_error("seen-set full: raise table_capacity"); return MC_ETABLEFULL; }
         if (h_ctr->error & DEV_EROUTE) { set_error("sharded round: an exchange bucket is full (raise the fan-out allowance / send capacity)"); return MC_EROUTE; }
         if (h_ctr->error & DEV_EARENA) { set_error("state arena full: raise arena_capacity"); return MC_EARENA; }

@@ -1251,6 +1251,9 @@ struct ProcExpander {
         chk->pos = at;
         chk->label = label;
         chk->e = bin("<", ident(rc.sp, at), num(D, at), at);   // call stack of procedure P deeper than D: raise TLAMC_PCAL_STACK
+        // (NOT an assertion of the algorithm — a capacity limit of this translation, like a sequence that outgrows its
+        //  cells: the compiled program reports MC_EOVERFLOW for it, and the text of the translation says what it is)
+        chk->var = "$stack " + s->var + " " + std::to_string(D);
         out.push_back(chk);
         // One step, its statements in an order in which none reads what an earlier one wrote — so they need not be ONE multiple
         // assignment (whose right-hand sides the compiled program would all have to hold in temporaries): first the frame (reads the
@@ -2627,6 +2630,12 @@ struct ActionGen {
             n->k = Node::ASSERT;
             n->text = pe(s->e, c, primed, shadow);
             n->text2 = "Failure of assertion at line " + std::to_string(s->pos.line) + ", column " + std::to_string(s->pos.col) + ".";
+            if (s->var.rfind("$stack ", 0) == 0) {   // the bounded call stack of a recursive procedure (expand_procedures)
+                const std::string rest = s->var.substr(7);
+                const size_t sp = rest.rfind(' ');
+                n->text2 = "The call at line " + std::to_string(s->pos.line) + ", column " + std::to_string(s->pos.col) + " needs more than the " + rest.substr(sp + 1) +
+                           " stack frames this translation reserves for procedure " + rest.substr(0, sp) + ": raise TLAMC_PCAL_STACK (a capacity limit, not an assertion of the algorithm).";
+            }
             o.items.push_back(n);
             break;
         }

@@ -1366,6 +1366,18 @@ struct Compiler {
         case Stmt::ASSIGN: assign(s); return 1;
         case Stmt::AWAIT: return await_action(s->e);
         case Stmt::ASSERT:
+            if (s->var.rfind("$stack ", 0) == 0) {
+                // the bounded call stack of a recursive procedure is full (pcal.cpp expand_procedures): a CAPACITY limit, reported like a
+                // sequence that outgrows its cells (R_OVERFLOW -> MC_EOVERFLOW), not as an assertion of the algorithm.
+                // With the instructions there are: VM_BIT refuses an element beyond 31 with R_OVERFLOW — (~cond) * 32 is 0 or 32.
+                ex(s->e);
+                emit(mc::VM_NOT);
+                emit(mc::VM_PUSH, 32);
+                emit(mc::VM_MUL);
+                emit(mc::VM_BIT);
+                emit(mc::VM_POP);
+                return 1;
+            }
             ex(s->e);
             emit(mc::VM_ASSERT, (int)P.asserts.size());
             P.asserts.push_back({s->pos.line, s->pos.col});
