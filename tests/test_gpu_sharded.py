@@ -358,7 +358,7 @@ def test_bench_contract_invocation_with_several_ranks(world):
 
 @pytest.mark.parametrize("workload,levels,prefix", [
     ("raft5", 13, [1, 6, 40, 205, 775, 2851, 10000, 32015, 97215, 287510, 816406, 2225540, 5913945]),
-    ("ssi4x3", 8, [1, 4, 32, 264, 2532, 24576, 236844, 2189052]),
+    ("ssi4x3", 9, [1, 4, 32, 264, 2532, 24576, 236844, 2189052, 18810792]),   # (eight ranks replicate up to a frontier of 2^18: level 8 is the first sharded expansion)
 ])
 def test_the_eight_rank_deep_command_lines_of_configs_4_and_5_at_a_reduced_budget(workload, levels, prefix):
     """`python bench.py --gpus 8 --workload raft5 | ssi4x3` — eight ranks, --deep by default: the budgets the first
