@@ -8,6 +8,9 @@ product's own translation: engine against engine, shared translator — VERDICT 
 translator itself: the small models of every spec state by state against oracle/tla_eval.py, and the hand-written pcal2tla-style
 translations under tests/golden/pcal_records/ (two-phase commit, Michael-Scott queue, ring buffer, Treiber stack, mailboxes, pagecache)
 evaluated by oracle/tlaplus.py (tests/test_pcal.py test_records_field_by_field_equal_the_record_valued_translation).
+Round 6, later: SIX of the entries made here (two_phase_channels_rm4, two_phase_soup_rm6 / rm7, epoch_gc_n3, io_buffer_n4, radix_tree_n4) also
+exist ORACLE-made — oracle/tlaplus.py on hand-written translations of the same algorithms, tests/golden/make_pcal_oracle_golden.py ->
+tests/golden/pcal_oracle.json — and tests/test_pcal.py asserts that the two files agree count for count and level by level.
 
     python tests/golden/make_pcal_channels_golden.py"""
 import json

@@ -234,6 +234,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipMalloc(&d_table, table_cap * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&d_cand, (size_t)(use_matrix ? max_slots : 1) * row_stride * sizeof(uint64_t)));
         seg_cap = (row_stride / NSHARD + 256) * max_slots;
+        seg_cap += seg_cap / 64 + 65;   // (round 6: an in-wave writer parks its overflow here as chunks of 64 entries + a link: 65 / 64 of the worst case)
         HIP_TRY(hipMalloc(&d_newlist, (size_t)2 * NSHARD * seg_cap * sizeof(uint32_t)));
         if (HasKnownFp<S>::value && !use_matrix) HIP_TRY(hipMalloc(&d_newfp, (size_t)2 * NSHARD * seg_cap * sizeof(uint64_t)));
         {
