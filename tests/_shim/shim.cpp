@@ -18,6 +18,8 @@
 #include <string>
 #include <unordered_set>
 #include <vector>
+#include <tuple>
+#include <algorithm>
 
 using namespace mc;
 
@@ -1139,6 +1141,74 @@ extern "C" int shim_probe_cache_sim(const mc_spec_desc *d, uint64_t max_levels, 
                     }
                 }
             }
+            cur.clear();
+            cur.swap(next);
+        }
+        return 0;
+    });
+}
+// ANALYSIS AID (profiles/probe_order_sim.py, round 6): how many seen-set look-ups does the wavefront's own duplicate filter (wfilt entries,
+// direct-mapped, cleared per 64 parents) answer, as a function of the ORDER in which a level's states lie in the arena?  mode 0: parent-major
+// (a parent's new states next to each other, in slot order: what a host BFS appends); mode 1: the device's — per workgroup of 128 parents
+// the survivors sorted by action class, inside a class by wavefront, then slot-major (the order in which the probe batches confirmed them);
+// mode 2: class-major like 1, but the survivors of one PARENT PAIR-GROUP of `group` parents kept together (group-major, then class).
+// out: candidates, filter hits, duplicates that reached the table, new states.
+template <class S, class = void>
+struct ShimSlotClass { static int of(int) { return 0; } };
+template <class S>
+struct ShimSlotClass<S, decltype((void)S::NCLS)> { static int of(int slot) { return S::slot_class(slot); } };
+extern "C" int shim_probe_order_sim(const mc_spec_desc *d, uint64_t max_levels, int mode, int wfilt, int group, uint64_t *out) {
+    return dispatch_spec(d, [&](auto spec, const auto &prm) {
+        using S = decltype(spec);
+        const int W = S::words(prm);
+        std::vector<uint64_t> cur, next;
+        FpSet seen;
+        uint64_t tmp[S::MAX_WORDS];
+        std::vector<uint64_t> filt((size_t)wfilt);
+        for (int q = 0; q < 4; q++) out[q] = 0;
+        for (uint64_t k = 0; k < S::num_init(prm); k++) {
+            S::init(prm, k, WordRef{tmp, 1});
+            if (S::init_status(prm, CWordRef{tmp, 1}) & ST_OUT_OF_MODEL) continue;
+            if (seen.insert(stored_fp<S>(prm, tmp)).second) next.insert(next.end(), tmp, tmp + W);
+        }
+        cur.swap(next);
+        struct Surv { int cls, wave, slot, lane; std::vector<uint64_t> row; };
+        for (uint64_t level = 1; !cur.empty() && (!max_levels || level < max_levels); level++) {
+            const uint64_t nstates = cur.size() / (size_t)W;
+            std::vector<Surv> wg;
+            auto flush_wg = [&]() {
+                if (mode == 1) std::stable_sort(wg.begin(), wg.end(), [](const Surv &a, const Surv &b) {
+                    return std::make_tuple(a.cls, a.wave, a.slot, a.lane) < std::make_tuple(b.cls, b.wave, b.slot, b.lane); });
+                else if (mode == 2) std::stable_sort(wg.begin(), wg.end(), [&](const Surv &a, const Surv &b) {
+                    return std::make_tuple((a.wave * 64 + a.lane) / group, a.cls, a.slot, a.lane) < std::make_tuple((b.wave * 64 + b.lane) / group, b.cls, b.slot, b.lane); });
+                for (auto &x : wg) next.insert(next.end(), x.row.begin(), x.row.end());
+                wg.clear();
+            };
+            for (uint64_t i = 0; i < nstates; i++) {
+                if ((i & 63) == 0) std::fill(filt.begin(), filt.end(), 0ull);
+                if ((i & 127) == 0) flush_wg();
+                CWordRef s{&cur[i * W], 1};
+                typename S::Local loc;
+                S::load(prm, s, loc);
+                const int ns = S::nslots(prm, loc);
+                for (int slot = 0; slot < ns; slot++) {
+                    uint64_t fp = 0;
+                    const unsigned st = S::eval(prm, loc, s, slot, fp);
+                    if (!(st & ST_ENABLED) || (st & (ST_OVERFLOW | ST_ASSERT | ST_SPECERR | ST_OUT_OF_MODEL | ST_SELFLOOP))) continue;
+                    out[0]++;
+                    const unsigned h = (unsigned)(fp >> 20) & (unsigned)(wfilt - 1);
+                    if (filt[h] == fp) { out[1]++; continue; }
+                    filt[h] = fp;
+                    if (seen.insert(fp).second) {
+                        out[3]++;
+                        S::apply(prm, s, slot, WordRef{tmp, 1});
+                        wg.push_back(Surv{ShimSlotClass<S>::of(slot), (int)((i >> 6) & 1), slot, (int)(i & 63), std::vector<uint64_t>(tmp, tmp + W)});
+                    } else {
+                        out[2]++;
+                    }
+                }
+            }
+            flush_wg();
             cur.clear();
             cur.swap(next);
         }
