@@ -80,6 +80,12 @@ __device__ __forceinline__ GlobalWords uniform_ptr(const uint64_t *p) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return (GlobalWords)(((uint64_t)hi << 32) | lo);
 }
+template <class T>
+__device__ __forceinline__ T *uniform_generic(T *p) {  // a wave-uniform pointer that arrived in vector registers (argument of an out-of-line function)
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T *)(((uint64_t)hi << 32) | lo);
+}
 MC_HD WordRef arena_ref(uint64_t *arena, uint64_t idx, int words) {
     return WordRef{arena + ((idx >> 6) * (uint64_t)words) * 64 + (idx & 63), 64};
 }
@@ -871,6 +877,146 @@ __device__ __forceinline__ void family_dispatch(int fam, Fn &&fn) {
     }
 }
 
+// ONE ROUND of the workgroup's tail (k_expand_family, in-wave writes): the wavefronts pool what their survivor lists hold, sort it by action
+// class, take the arena indices with one atomicAdd and write the rows.  Inlined into the kernel for the first round — the only one of a
+// workgroup whose wavefronts parked nothing — and into tail_more_rounds below for the others.  Returns whether another round is due
+// (some wavefront still has parked chunks; false also when the arena is full: err).  prof(phase): MC_PROF of a profiling build.
+template <class S, int WAVES, class FamLdsT, class Prof>
+__device__ __forceinline__ bool tail_round(const typename S::Params &prm, const uint64_t *arena, uint64_t *arena_w, uint64_t arena_cap, uint32_t *parent, uint16_t *pslot,
+                                           DevCounters *ctr, unsigned flags, FamQueues *wq, FamLdsT *fls, unsigned *hist_base, unsigned hist_stride,
+                                           unsigned long long *wg_out0, uint16_t *order, const unsigned *wg_park, unsigned w, unsigned lane, uint64_t wg_idx0,
+                                           unsigned ohead, unsigned on, unsigned &err, Prof &&prof) {
+        constexpr int NCLS = SlotClasses<S>::value;
+        FamQueues &Q = wq[w];
+        auto hist_at = [&](unsigned c, unsigned ww) -> unsigned & { return hist_base[ww * hist_stride + c]; };
+        (void)flags;
+        // a wavefront counts its own survivors per class as soon as IT has finished — in the shadow of the wait for its siblings
+        prof(16);      // (profiling builds: 16 = the counting sort, 4 = waiting at barrier (1), 17 = the writes)
+        unsigned ccnt[NCLS];
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
+        for (unsigned t = 0; t < on; t += 64) {
+            const bool valid = t + lane < on;
+            const unsigned e_ = valid ? Q.o_ent[owrap(ohead + t + lane)] : O_DEAD;
+            const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) ccnt[c] += (unsigned)__popcll(__ballot(cls == c));
+        }
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) if (lane == 0) hist_at((unsigned)c, w) = ccnt[c];
+        prof(4);
+        __syncthreads();  // (1) no wavefront of the workgroup generates any more: the filters are free, the lists final, the counts there
+        prof(16);
+        const unsigned h = lane < (unsigned)(NCLS * WAVES) ? hist_at(lane / WAVES, lane % WAVES) : 0u;
+        unsigned incl = h;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
+        const unsigned excl = incl - h, total = __shfl(incl, 63);
+        bool wg_more = false;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) wg_more |= wg_park[ww] != 0u;   // (written by its wavefront before barrier (1) or before barrier (3) of the round before)
+#if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
+        // ABLATION BUILD ONLY (profiles/tail_ablate.py: ONE level is timed, its output is garbage and is never expanded).  flags bit 21: every
+        // workgroup's survivors start on a 64-state boundary — every column store of the writer is one whole 512-byte row of a block: the
+        // most that sector-aligned allocation could ever give (the holes are left as they are)
+        if (w == 0 && lane == 0) {
+            if (flags & (1u << 21)) *wg_out0 = total ? ((atomicAdd(&ctr->arena_next, (unsigned long long)(((total + 63u) & ~63u) + 64u)) + 63ull) & ~63ull) : 0ull;
+            else *wg_out0 = total ? atomicAdd(&ctr->arena_next, (unsigned long long)total) : 0ull;
+        }
+#else
+        if (w == 0 && lane == 0) *wg_out0 = total ? atomicAdd(&ctr->arena_next, (unsigned long long)total) : 0ull;
+#endif
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) ccnt[c] = __shfl(excl, c * WAVES + (int)w);  // where this wavefront's class-c survivors go
+        for (unsigned t = 0; t < on; t += 64) {
+            const bool valid = t + lane < on;
+            const unsigned k = owrap(ohead + t + lane);
+            const unsigned e_ = valid ? Q.o_ent[k] : O_DEAD;
+            const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+                const unsigned long long b = __ballot(cls == c);
+                if (cls == c) order[ccnt[c] + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((w << 9) | k);
+                ccnt[c] += (unsigned)__popcll(b);
+            }
+        }
+        __syncthreads();  // (2) the order and the workgroup's first arena index are visible
+        prof(17);
+        const unsigned long long out0 = *wg_out0;
+        if (total && out0 + total > arena_cap) {
+            err |= DEV_EARENA;
+            return false;  // (workgroup-uniform: out0 and total are the workgroup's)
+        } else {
+            for (unsigned bt = w * 64u; bt < total; bt += 64u * WAVES) {  // batch of 64 sorted survivors; the wavefronts take turns
+                const bool mine = bt + lane < total;
+                const unsigned ref = mine ? order[bt + lane] : 0u;
+                const unsigned e = mine ? wq[ref >> 9].o_ent[ref & 511u] : 0u;
+                const uint64_t sfp = mine ? wq[ref >> 9].o_fp[ref & 511u] : 0ull;
+                const uint64_t pidx = wg_idx0 + (ref >> 9) * 64u + (e & 63u), oidx = out0 + bt + lane;
+#if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
+                // flags bit 20: the writer reads "its parent" from the arena's first two blocks (same lanes, same instructions, every gather an
+                // L1 / L2 hit): the most that keeping the parent rows on the CU could give.  bit 22: every row is stored into the arena's LAST
+                // 64 states (same stores, no HBM write traffic to speak of).  bit 23: no writer at all (allocation only).
+                {
+                    const uint64_t rpidx = (flags & (1u << 20)) ? (uint64_t)((ref >> 9) * 64u + (e & 63u)) : pidx;
+                    const uint64_t woidx = (flags & (1u << 22)) ? (arena_cap - 64u + (oidx & 63u)) : oidx;
+                    wave_write_survivors<S>(prm, arena, rpidx, mine && !(flags & (1u << 23)), e >> 6, sfp, arena_w, woidx, fls[ref >> 9].sum[e & 63u]);
+                }
+#else
+                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, arena_w, oidx, fls[ref >> 9].sum[e & 63u]);
+#endif
+                if (mine && parent) { parent[oidx] = (uint32_t)pidx; pslot[oidx] = (uint16_t)(e >> 6); }
+            }
+        }
+        return wg_more;
+}
+// ROUNDS 2 .. of the tail: every wavefront refills its list from its chain of parked chunks (up to OCAP survivors, newest chunk first) and
+// the round runs again, until the chains are empty.  Out of line — the exception (11 % of the five-server model's states, 0.15 % of the
+// contract workload's), and as a loop around the round in the kernel itself it cost the 3-server kernel 8 - 12 spilled VGPRs inside the
+// writer's batch loop (profiles/r06ze: 4 % of the contract line).  Returns DEV_E* bits.
+template <class S, int WAVES, class FamLdsT>
+__device__ __noinline__ unsigned tail_more_rounds(typename S::Params prm_v, const uint64_t *arena_v, uint64_t *arena_w_v, uint64_t arena_cap_v, uint32_t *parent_v,
+                                                  uint16_t *pslot_v, DevCounters *ctr_v, unsigned flags_v, FamQueues *wq_v, FamLdsT *fls_v, unsigned *hist_v,
+                                                  unsigned hist_stride_v, unsigned long long *wg_out0_v, uint16_t *order_v, unsigned *wg_park_v, uint64_t wg_idx0_v,
+                                                  const uint32_t *seg_v, const uint64_t *fps_v) {
+    const typename S::Params prm = wave_uniform_copy(prm_v);
+    const uint64_t *arena = uniform_generic(arena_v);
+    uint64_t *arena_w = uniform_generic(arena_w_v);
+    const uint64_t arena_cap = wave_uniform_copy(arena_cap_v), wg_idx0 = wave_uniform_copy(wg_idx0_v);
+    uint32_t *parent = uniform_generic(parent_v);
+    uint16_t *pslot = uniform_generic(pslot_v);
+    DevCounters *ctr = uniform_generic(ctr_v);
+    const unsigned flags = __builtin_amdgcn_readfirstlane(flags_v), hist_stride = __builtin_amdgcn_readfirstlane(hist_stride_v);
+    FamQueues *wq = uniform_generic(wq_v);     // (LDS through generic pointers: flat accesses — this path is the exception)
+    FamLdsT *fls = uniform_generic(fls_v);
+    unsigned *hist_base = uniform_generic(hist_v);
+    unsigned long long *wg_out0 = uniform_generic(wg_out0_v);
+    uint16_t *order = uniform_generic(order_v);
+    unsigned *wg_park = uniform_generic(wg_park_v);
+    const uint32_t *seg = uniform_generic(seg_v);
+    const uint64_t *fps = uniform_generic(fps_v);
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned err = 0;
+    for (;;) {
+        __syncthreads();  // (3) nobody reads a list, the order or the counts of the round before any more
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (the chunks were stored by this very wavefront)
+        unsigned on = 0;
+        unsigned park = (unsigned)__builtin_amdgcn_readfirstlane((int)wg_park[w]);
+        while (park && on + 64u <= (unsigned)OCAP) {
+            const uint64_t p0 = (uint64_t)park - 1u;
+            const uint32_t se = seg[p0 + lane];
+            wq[w].o_ent[on + lane] = (uint16_t)(((se >> 24) << 6) | (se & 63u));
+            wq[w].o_fp[on + lane] = fps[p0 + lane];
+            park = (unsigned)__builtin_amdgcn_readfirstlane((int)seg[p0 + 64]);
+            on += 64;
+        }
+        if (lane == 0) wg_park[w] = park;   // (read by every wavefront after barrier (1) of the round that begins here)
+        wave_lds_fence();
+        if (!tail_round<S, WAVES>(prm, arena, arena_w, arena_cap, parent, pslot, ctr, flags, wq, fls, hist_base, hist_stride, wg_out0, order, wg_park, w, lane,
+                                  wg_idx0, 0u, on, err, [](int) {})) break;
+    }
+    return err;
+}
+
 // NB = arena blocks (of 64 parents) one wavefront works through.  The family queues live across the blocks and are
 // drained once at the end, so the partially filled batches of the drain (up to one per family) are paid once per
 // NB * 64 parents instead of once per 64: phase B's lane utilisation goes from ~80 % (NB = 1) towards 95 % (NB = 4).
@@ -959,8 +1105,14 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     // before (the wavefront keeps one position, no table) — and the workgroup's tail takes them back: after the round that writes
     // what the lists hold, every wavefront refills its list from its chain (up to OCAP entries) and the tail runs again, until the
     // chains are empty.  Same sort by action class, same writer, same allocation; nothing reaches k_materialise.
-    const bool spill = inwave && !ASYNC_BUILD && !(flags & (MC_F_LISTOVERFLOW | MC_F_WAVETAIL)) && rt.new_fp != nullptr;  // wave-uniform
-    uint32_t spill_last = 0;  // position + 1 of this wavefront's newest parked chunk in its new-list segment (0: none)
+    // (its state lives in LDS, not in a register that would be live through the whole kernel: wg_park[w] = position + 1 of wavefront w's
+    //  newest parked chunk in its new-list segment, 0 = none — first try: one more scalar register and the refill loop cost the 3-server
+    //  kernel 8 spilled VGPRs and 4 % of the contract line)
+    __shared__ unsigned wg_park[WAVES];
+    if (lane == 0) wg_park[threadIdx.x >> 6] = 0u;
+    auto spill_on = [&]() __attribute__((always_inline)) -> bool {   // wave-uniform
+        return inwave && !ASYNC_BUILD && !(flags & (MC_F_LISTOVERFLOW | MC_F_WAVETAIL)) && rt.new_fp != nullptr;
+    };
     MC_PROF_DECL
 
     auto flush_out = [&](unsigned take) __attribute__((always_inline)) {
@@ -970,6 +1122,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         const unsigned long long bl = __ballot(e != O_DEAD);
         unsigned long long pos = 0;
         // (spill: a chunk is 64 entries + the link; same segment, a cursor of its own — k_materialise never sees these entries)
+        const bool spill = spill_on();
         if (lane == 0 && bl) pos = spill ? atomicAdd(&ctr->n_side[pshard].v, 65ull) : atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)__popcll(bl));
         const unsigned long long pos0 = wave_uniform_copy(pos);  // (lane 0's)
         pos = pos0 + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
@@ -978,8 +1131,11 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             if (rt.new_fp) rt.new_fp[(uint64_t)pshard * seg_cap + pos] = Q.o_fp[owrap(ohead + lane)];
         }
         if (spill) {
-            if (lane == 0) seg[pos0 + 64] = spill_last;
-            spill_last = (uint32_t)pos0 + 1u;
+            if (lane == 0) {
+                seg[pos0 + 64] = wg_park[threadIdx.x >> 6];
+                wg_park[threadIdx.x >> 6] = (uint32_t)pos0 + 1u;
+            }
+            wave_lds_fence();
         }
         ohead = owrap(ohead + take);
         on -= take;
@@ -1505,105 +1661,15 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             hist_stride = NCLS;
             wg_out0 = &wg_out0_s;
         }
-        auto hist_at = [&](unsigned c, unsigned ww) -> unsigned & { return hist_base[ww * hist_stride + c]; };
         const unsigned w = threadIdx.x >> 6;
-        __shared__ unsigned wg_more_s[WAVES];  // wavefront w still has parked chunks after this round (see `spill`)
-        for (;;) {   // one round per refill of the survivor lists; a workgroup whose wavefronts parked nothing makes one
-        // a wavefront counts its own survivors per class as soon as IT has finished — in the shadow of the wait for its siblings
-        MC_PROF(16);      // (profiling builds: 16 = the counting sort, 4 = waiting at barrier (1), 17 = the writes)
-        unsigned ccnt[NCLS];
-#pragma unroll
-        for (int c = 0; c < NCLS; ++c) ccnt[c] = 0;
-        for (unsigned t = 0; t < on; t += 64) {
-            const bool valid = t + lane < on;
-            const unsigned e_ = valid ? Q.o_ent[owrap(ohead + t + lane)] : O_DEAD;
-            const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
-#pragma unroll
-            for (int c = 0; c < NCLS; ++c) ccnt[c] += (unsigned)__popcll(__ballot(cls == c));
-        }
-#pragma unroll
-        for (int c = 0; c < NCLS; ++c) if (lane == 0) hist_at((unsigned)c, w) = ccnt[c];
-        if (lane == 0) wg_more_s[w] = spill_last;
-        MC_PROF(4);
-        __syncthreads();  // (1) no wavefront of the workgroup generates any more: the filters are free, the lists final, the counts there
-        MC_PROF(16);
-        const unsigned h = lane < (unsigned)(NCLS * WAVES) ? hist_at(lane / WAVES, lane % WAVES) : 0u;
-        unsigned incl = h;
-        for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
-        const unsigned excl = incl - h, total = __shfl(incl, 63);
-        bool wg_more = false;
-#pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww) wg_more |= wg_more_s[ww] != 0u;
-#if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
-        // ABLATION BUILD ONLY (profiles/tail_ablate.py: ONE level is timed, its output is garbage and is never expanded).  flags bit 21: every
-        // workgroup's survivors start on a 64-state boundary — every column store of the writer is one whole 512-byte row of a block: the
-        // most that sector-aligned allocation could ever give (the holes are left as they are)
-        if (w == 0 && lane == 0) {
-            if (flags & (1u << 21)) *wg_out0 = total ? ((atomicAdd(&ctr->arena_next, (unsigned long long)(((total + 63u) & ~63u) + 64u)) + 63ull) & ~63ull) : 0ull;
-            else *wg_out0 = total ? atomicAdd(&ctr->arena_next, (unsigned long long)total) : 0ull;
-        }
-#else
-        if (w == 0 && lane == 0) *wg_out0 = total ? atomicAdd(&ctr->arena_next, (unsigned long long)total) : 0ull;
-#endif
-#pragma unroll
-        for (int c = 0; c < NCLS; ++c) ccnt[c] = __shfl(excl, c * WAVES + (int)w);  // where this wavefront's class-c survivors go
-        for (unsigned t = 0; t < on; t += 64) {
-            const bool valid = t + lane < on;
-            const unsigned k = owrap(ohead + t + lane);
-            const unsigned e_ = valid ? Q.o_ent[k] : O_DEAD;
-            const int cls = e_ != O_DEAD ? SlotClasses<S>::of((int)(e_ >> 6)) : -1;
-#pragma unroll
-            for (int c = 0; c < NCLS; ++c) {
-                const unsigned long long b = __ballot(cls == c);
-                if (cls == c) order[ccnt[c] + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)((w << 9) | k);
-                ccnt[c] += (unsigned)__popcll(b);
-            }
-        }
-        __syncthreads();  // (2) the order and the workgroup's first arena index are visible
-        MC_PROF(17);
-        const unsigned long long out0 = *wg_out0;
-        if (total && out0 + total > rt.arena_cap) {
-            err |= DEV_EARENA;
-            break;  // (workgroup-uniform: out0 and total are the workgroup's)
-        } else {
+        {
             const uint64_t wg_idx0 = base + (uint64_t)blockIdx.x * (64u * WAVES);
-            for (unsigned bt = w * 64u; bt < total; bt += 64u * WAVES) {  // batch of 64 sorted survivors; the wavefronts take turns
-                const bool mine = bt + lane < total;
-                const unsigned ref = mine ? order[bt + lane] : 0u;
-                const unsigned e = mine ? wq[ref >> 9].o_ent[ref & 511u] : 0u;
-                const uint64_t sfp = mine ? wq[ref >> 9].o_fp[ref & 511u] : 0ull;
-                const uint64_t pidx = wg_idx0 + (ref >> 9) * 64u + (e & 63u), oidx = out0 + bt + lane;
-#if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
-                // flags bit 20: the writer reads "its parent" from the arena's first two blocks (same lanes, same instructions, every gather an
-                // L1 / L2 hit): the most that keeping the parent rows on the CU could give.  bit 22: every row is stored into the arena's LAST
-                // 64 states (same stores, no HBM write traffic to speak of).  bit 23: no writer at all (allocation only).
-                {
-                    const uint64_t rpidx = (flags & (1u << 20)) ? (uint64_t)((ref >> 9) * 64u + (e & 63u)) : pidx;
-                    const uint64_t woidx = (flags & (1u << 22)) ? (rt.arena_cap - 64u + (oidx & 63u)) : oidx;
-                    wave_write_survivors<S>(prm, arena, rpidx, mine && !(flags & (1u << 23)), e >> 6, sfp, rt.arena_w, woidx, fls[ref >> 9].sum[e & 63u]);
-                }
-#else
-                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, rt.arena_w, oidx, fls[ref >> 9].sum[e & 63u]);
-#endif
-                if (mine && rt.parent) { rt.parent[oidx] = (uint32_t)pidx; rt.pslot[oidx] = (uint16_t)(e >> 6); }
-            }
+            const bool more = tail_round<S, WAVES>(prm, arena, rt.arena_w, rt.arena_cap, rt.parent, rt.pslot, ctr, flags, &wq[0], &fls[0], hist_base, hist_stride, wg_out0,
+                                                   order, &wg_park[0], w, lane, wg_idx0, ohead, on, err, [&](int ph) { MC_PROF(ph); (void)ph; });
+            // (rounds 2 ..: a workgroup whose wavefronts parked survivors — out of line, see tail_more_rounds)
+            if (more) err |= tail_more_rounds<S, WAVES, FamLdsT>(prm, arena, rt.arena_w, rt.arena_cap, rt.parent, rt.pslot, ctr, flags, &wq[0], &fls[0], hist_base, hist_stride,
+                                                                 wg_out0, order, &wg_park[0], wg_idx0, seg, rt.new_fp + (uint64_t)pshard * seg_cap);
         }
-        if (!wg_more) break;  // (workgroup-uniform: every wavefront read the same wg_more_s after barrier (1))
-        // NEXT ROUND: the lists are spent; a wavefront with parked chunks takes up to OCAP survivors back, newest chunk first
-        __syncthreads();  // (3) nobody reads a list, the order or the counts of this round any more
-        ohead = 0;
-        on = 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (the chunks were stored by this very wavefront)
-        while (spill_last && on + 64u <= (unsigned)OCAP) {
-            const uint64_t p0 = (uint64_t)spill_last - 1u;
-            const uint32_t se = seg[p0 + lane];
-            Q.o_ent[on + lane] = (uint16_t)(((se >> 24) << 6) | (se & 63u));
-            Q.o_fp[on + lane] = rt.new_fp[(uint64_t)pshard * seg_cap + p0 + lane];
-            spill_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg[p0 + 64]);
-            on += 64;
-        }
-        wave_lds_fence();
-        }  // (rounds)
         }  // (workgroup tail)
     } else if (on) {
         flush_out(on);
