@@ -527,8 +527,8 @@ def main():
     ap.add_argument("--no-filter", action="store_true", help="A/B: without the per-wavefront duplicate filter in front of the seen-set")
     ap.add_argument("--sync-probe", action="store_true", help="A/B: resolve every batch of seen-set probes right where it is issued (MC_F_SYNCPROBE)")
     ap.add_argument("--wave-tail", action="store_true", help="A/B: in-wave writes by wavefront (no workgroup barrier) instead of by workgroup")
-    ap.add_argument("--list-overflow", action="store_true", help="A/B: the overflow of the in-wave writers' survivor lists through the new-list and k_materialise "
-                    "(rounds 4-5, MC_F_LISTOVERFLOW) instead of parked and written by the workgroup's own tail")
+    ap.add_argument("--park", action="store_true", help="A/B: the in-wave writers PARK the overflow of their survivor lists and the workgroup's own tail writes it in "
+                    "later rounds (MC_F_PARK: the PARK instantiation of the by-family kernel) instead of sending it through the new-list to k_materialise")
     ap.add_argument("--no-inwave", action="store_true", help="A/B: every new state through the new-list and k_materialise (rounds 1-3) instead of "
                     "being written by the expand wavefront that found it")
     a = ap.parse_args()
@@ -578,7 +578,7 @@ def main():
     comm = store = None
     if not use_dist:
         eng = amd.Engine(WORKLOAD["spec"], WORKLOAD["params"], device=local, table_capacity=slots, matrix=a.matrix,
-                         debug_flags=(32 if a.no_family else 0) | (2048 if a.occ3 else 0) | (8192 if a.no_filter else 0) | (65536 if a.no_inwave else 0) | (131072 if a.wave_tail else 0) | (4096 if a.sync_probe else 0) | (32768 if a.list_overflow else 0),
+                         debug_flags=(32 if a.no_family else 0) | (2048 if a.occ3 else 0) | (8192 if a.no_filter else 0) | (65536 if a.no_inwave else 0) | (131072 if a.wave_tail else 0) | (4096 if a.sync_probe else 0) | (32768 if a.park else 0),
                          arena_capacity=G0["distinct"] + (1 << 20), max_levels=ML,
                          chunk_states=a.chunk, max_distinct=a.max_distinct, trace=False, timing=True)
         run = eng.run

@@ -92,8 +92,9 @@ typedef struct {
 #define MC_F_NOINWAVE 65536u /* A/B only: every new state through the new-list and k_materialise (rounds 1-3) instead of being written by
                                 the expand wavefront that found it (round 4; by-family kernels of a fused run) */
 #define MC_F_WAVETAIL 131072u /* A/B only: in-wave writes by wavefront (no workgroup barrier) instead of by workgroup */
-#define MC_F_LISTOVERFLOW 32768u /* A/B only: a by-family wavefront whose survivor list fills up sends the overflow through the new-list to
-                                  * k_materialise (rounds 4-5) instead of writing a batch of one action class itself (round 6) */
+#define MC_F_PARK 32768u /* measured, not the default (round 6): a by-family wavefront whose survivor list fills up PARKS the overflow in the
+                           * new-list's memory and the workgroup's own tail writes it in later rounds (k_expand_family<.., PARK>), instead of
+                           * sending it through the new-list to k_materialise: every state is written in-wave, the step takes as long */
 #define MC_F_NOFILTER 8192u  /* A/B only: by-family expand kernel without the per-wavefront duplicate filter in front of the seen-set */
 #define MC_F_SYNCPROBE 4096u /* A/B only: the by-family expand kernel waits for every seen-set probe where it issues it (rounds 1-4) instead of
                               * resolving a batch of probes one batch later (round 5: split-phase probes, engine.hip MC_ASYNC_PROBE) */

@@ -197,6 +197,27 @@ def test_config4_model_one_billion_states_on_one_gpu(amd):
     assert (s.levels, s.distinct, s.generated, s.verdict) == (r.levels, r.distinct, r.generated, "budget") and st["stay_levels"] >= 3
 
 
+def test_parked_overflow_writes_every_state_in_wave(amd, oracle):
+    """MC_F_PARK (round 6): the PARK instantiation of the by-family kernel — a wavefront whose survivor list fills up
+    parks 64 survivors in the new-list's memory and the workgroup's own tail writes them in later rounds, nothing goes through
+    k_materialise.  Config 4's five-server model, 16 levels (158 M states; 11 % of them overflow the lists): the oracle's per-level counts,
+    and every state but Init's written in-wave; the same on a 3-server complete graph with a trace kept (parent pointers of parked states)."""
+    c = _golden("raft5_mcr6_t2_m1_levels18")
+    params = [5, 6, 2, 5, 1, 1, 18, 1, 4]
+    eng = amd.Engine("raft", params, table_capacity=1 << 30, arena_capacity=170_000_000, chunk_states=1 << 22, max_levels=16, trace=False, debug_flags=32768)
+    r = eng.run()
+    ks = eng.kernel_stats()
+    eng.close()
+    assert r.levels == c["levels"][:16] and r.verdict == "budget" and r.distinct == sum(c["levels"][:16])
+    assert ks["inwave_states"] == r.distinct - 1, ks
+    k = _golden("raft3_mcr4_t2_m1_k7_complete")
+    for flags in (32768, 0):
+        eng = amd.Engine("raft", oracle.raft_device_params(k["params"], 7, 1, 4), table_capacity=1 << 24, arena_capacity=2_400_000, chunk_states=1 << 16, trace=True, debug_flags=flags)
+        r = eng.run()
+        eng.close()
+        assert (r.distinct, r.generated, r.depth, r.verdict, r.levels) == (k["distinct"], k["generated"], k["depth"], "ok", k["levels"])
+
+
 def test_next_complete_graph_on_gpu(amd):
     """MaxMsgKeys = 11: 336 581 097 states / 3 913 649 887 generated / depth 35, the largest complete graph the exact-dedup oracle
     has verified (on the GPU box's host: the build container cannot hold it; tests/golden/raft_levels.json `source`).  116 GB arena."""

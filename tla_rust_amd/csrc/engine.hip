@@ -480,6 +480,10 @@ struct Engine : EngineBase {
         }
         int budget = 0;
         uint64_t via_seen = 0;
+        // PARKING (round 6, MC_F_PARK): the instantiation of the by-family kernel whose writers park the overflow of their survivor lists and
+        // write it themselves (k_expand_family<.., PARK>).  Measured (profiles/r06zb, zf, zg, zh): every state of the five-server model
+        // is written in-wave then (924 M instead of 821 M; k_materialise idle) and its step takes as long as before, or longer — not the default
+        const bool park_levels = (cfg.flags & MC_F_PARK) != 0;
         mat_list_hint = ~0ull >> 8;   // (unknown before the first large level: the full grid)
         mat_inwave_level = false;
         const uint64_t blind_max = chunk < (1ull << 16) ? chunk : (1ull << 16);
@@ -561,8 +565,9 @@ struct Engine : EngineBase {
                     const unsigned sg = slices_for(ncols, false);
                     const bool dl = sg > 1 && (cfg.flags & MC_F_DEADLOCK);
                     if (dl) { rt_new.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), es); }
+                    const unsigned lflags = cfg.flags | (lvl_inwave && park_levels ? MC_FI_PARK : 0u);
                     timed(0, c1 - c0, [&] {
-                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, es, sg, prm,
+                        launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), lflags, ncols, es, sg, prm,
                                                 (const uint64_t *)d_arena, c0, c1, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr,
                                                 cfg.flags, rt_new, parity);
                         if (dl) hipLaunchKernelGGL(k_deadlock_slices, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, es,

@@ -86,6 +86,14 @@ __device__ __forceinline__ T *uniform_generic(T *p) {  // a wave-uniform pointer
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return (T *)(((uint64_t)hi << 32) | lo);
 }
+// ... and one that is known to point into LDS, as an address-space-3 pointer (ds_ instructions; a flat access to LDS is slower and the
+// compiler's address-space inference does not see through a function argument)
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(3))) T *uniform_lds(T *p) {
+    typedef __attribute__((address_space(3))) T *LdsP;
+    const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(LdsP)p);
+    return (LdsP)(uintptr_t)a;
+}
 MC_HD WordRef arena_ref(uint64_t *arena, uint64_t idx, int words) {
     return WordRef{arena + ((idx >> 6) * (uint64_t)words) * 64 + (idx & 63), 64};
 }
@@ -418,6 +426,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Device-driven levels: while the frontier is small, the host enqueues a batch of levels back to back and the
 // kernels read the level's range from this block (no host round trip per level; see Engine::run).
 constexpr int BLIND_BATCH = 8;
+constexpr unsigned MC_FI_PARK = 1u << 19;  // internal flag bit of launch_expand (not in include/tlamc.h): the PARK instantiation of k_expand_family
 struct LevelCtl {
     unsigned long long lo, hi;        // frontier of the level about to be expanded
     unsigned long long max_states;    // a batched level handles at most this many states
@@ -881,14 +890,16 @@ __device__ __forceinline__ void family_dispatch(int fam, Fn &&fn) {
 // class, take the arena indices with one atomicAdd and write the rows.  Inlined into the kernel for the first round — the only one of a
 // workgroup whose wavefronts parked nothing — and into tail_more_rounds below for the others.  Returns whether another round is due
 // (some wavefront still has parked chunks; false also when the arena is full: err).  prof(phase): MC_PROF of a profiling build.
-template <class S, int WAVES, class FamLdsT, class Prof>
+// (the LDS pointers are template types: generic pointers in the kernel, where the compiler infers LDS, address-space-3 pointers in
+//  tail_more_rounds, where it cannot — a flat access to LDS is slower than a ds_ one)
+template <class S, int WAVES, bool PARK, class WQ, class FL, class HP, class OP, class RP, class PP, class Prof>
 __device__ __forceinline__ bool tail_round(const typename S::Params &prm, const uint64_t *arena, uint64_t *arena_w, uint64_t arena_cap, uint32_t *parent, uint16_t *pslot,
-                                           DevCounters *ctr, unsigned flags, FamQueues *wq, FamLdsT *fls, unsigned *hist_base, unsigned hist_stride,
-                                           unsigned long long *wg_out0, uint16_t *order, const unsigned *wg_park, unsigned w, unsigned lane, uint64_t wg_idx0,
+                                           DevCounters *ctr, unsigned flags, WQ wq, FL fls, HP hist_base, unsigned hist_stride,
+                                           OP wg_out0, RP order, PP wg_park, unsigned w, unsigned lane, uint64_t wg_idx0,
                                            unsigned ohead, unsigned on, unsigned &err, Prof &&prof) {
         constexpr int NCLS = SlotClasses<S>::value;
-        FamQueues &Q = wq[w];
-        auto hist_at = [&](unsigned c, unsigned ww) -> unsigned & { return hist_base[ww * hist_stride + c]; };
+        auto &Q = wq[w];
+        auto hist_at = [&](unsigned c, unsigned ww) -> auto & { return hist_base[ww * hist_stride + c]; };
         (void)flags;
         // a wavefront counts its own survivors per class as soon as IT has finished — in the shadow of the wait for its siblings
         prof(16);      // (profiling builds: 16 = the counting sort, 4 = waiting at barrier (1), 17 = the writes)
@@ -913,7 +924,7 @@ __device__ __forceinline__ bool tail_round(const typename S::Params &prm, const 
         const unsigned excl = incl - h, total = __shfl(incl, 63);
         bool wg_more = false;
 #pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww) wg_more |= wg_park[ww] != 0u;   // (written by its wavefront before barrier (1) or before barrier (3) of the round before)
+        for (int ww = 0; ww < WAVES; ++ww) if constexpr (PARK) wg_more |= wg_park[ww] != 0u;   // (written by its wavefront before barrier (1) or before barrier (3) of the round before)
 #if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
         // ABLATION BUILD ONLY (profiles/tail_ablate.py: ONE level is timed, its output is garbage and is never expanded).  flags bit 21: every
         // workgroup's survivors start on a 64-state boundary — every column store of the writer is one whole 512-byte row of a block: the
@@ -952,6 +963,8 @@ __device__ __forceinline__ bool tail_round(const typename S::Params &prm, const 
                 const unsigned e = mine ? wq[ref >> 9].o_ent[ref & 511u] : 0u;
                 const uint64_t sfp = mine ? wq[ref >> 9].o_fp[ref & 511u] : 0ull;
                 const uint64_t pidx = wg_idx0 + (ref >> 9) * 64u + (e & 63u), oidx = out0 + bt + lane;
+                typename S::Summary qsum;   // (the parent's Summary: copied word by word whatever address space `fls` points into)
+                __builtin_memcpy(&qsum, &fls[ref >> 9].sum[e & 63u], sizeof qsum);
 #if defined(MC_TAIL_ABLATE) && MC_TAIL_ABLATE
                 // flags bit 20: the writer reads "its parent" from the arena's first two blocks (same lanes, same instructions, every gather an
                 // L1 / L2 hit): the most that keeping the parent rows on the CU could give.  bit 22: every row is stored into the arena's LAST
@@ -959,10 +972,10 @@ __device__ __forceinline__ bool tail_round(const typename S::Params &prm, const 
                 {
                     const uint64_t rpidx = (flags & (1u << 20)) ? (uint64_t)((ref >> 9) * 64u + (e & 63u)) : pidx;
                     const uint64_t woidx = (flags & (1u << 22)) ? (arena_cap - 64u + (oidx & 63u)) : oidx;
-                    wave_write_survivors<S>(prm, arena, rpidx, mine && !(flags & (1u << 23)), e >> 6, sfp, arena_w, woidx, fls[ref >> 9].sum[e & 63u]);
+                    wave_write_survivors<S>(prm, arena, rpidx, mine && !(flags & (1u << 23)), e >> 6, sfp, arena_w, woidx, qsum);
                 }
 #else
-                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, arena_w, oidx, fls[ref >> 9].sum[e & 63u]);
+                wave_write_survivors<S>(prm, arena, pidx, mine, e >> 6, sfp, arena_w, oidx, qsum);
 #endif
                 if (mine && parent) { parent[oidx] = (uint32_t)pidx; pslot[oidx] = (uint16_t)(e >> 6); }
             }
@@ -986,12 +999,12 @@ __device__ __noinline__ unsigned tail_more_rounds(typename S::Params prm_v, cons
     uint16_t *pslot = uniform_generic(pslot_v);
     DevCounters *ctr = uniform_generic(ctr_v);
     const unsigned flags = __builtin_amdgcn_readfirstlane(flags_v), hist_stride = __builtin_amdgcn_readfirstlane(hist_stride_v);
-    FamQueues *wq = uniform_generic(wq_v);     // (LDS through generic pointers: flat accesses — this path is the exception)
-    FamLdsT *fls = uniform_generic(fls_v);
-    unsigned *hist_base = uniform_generic(hist_v);
-    unsigned long long *wg_out0 = uniform_generic(wg_out0_v);
-    uint16_t *order = uniform_generic(order_v);
-    unsigned *wg_park = uniform_generic(wg_park_v);
+    auto wq = uniform_lds(wq_v);               // (LDS pointers: address-space-3 pointers rebuilt from their 32-bit LDS addresses)
+    auto fls = uniform_lds(fls_v);
+    auto hist_base = uniform_lds(hist_v);
+    auto wg_out0 = uniform_lds(wg_out0_v);
+    auto order = uniform_lds(order_v);
+    auto wg_park = uniform_lds(wg_park_v);
     const uint32_t *seg = uniform_generic(seg_v);
     const uint64_t *fps = uniform_generic(fps_v);
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1011,7 +1024,7 @@ __device__ __noinline__ unsigned tail_more_rounds(typename S::Params prm_v, cons
         }
         if (lane == 0) wg_park[w] = park;   // (read by every wavefront after barrier (1) of the round that begins here)
         wave_lds_fence();
-        if (!tail_round<S, WAVES>(prm, arena, arena_w, arena_cap, parent, pslot, ctr, flags, wq, fls, hist_base, hist_stride, wg_out0, order, wg_park, w, lane,
+        if (!tail_round<S, WAVES, true>(prm, arena, arena_w, arena_cap, parent, pslot, ctr, flags, wq, fls, hist_base, hist_stride, wg_out0, order, wg_park, w, lane,
                                   wg_idx0, 0u, on, err, [](int) {})) break;
     }
     return err;
@@ -1031,7 +1044,11 @@ __device__ __noinline__ unsigned tail_more_rounds(typename S::Params prm_v, cons
 #ifndef MC_EXPAND_WAVES
 #define MC_EXPAND_WAVES 2
 #endif
-template <class S, bool ROUTE, int NB, int MINW = MC_EXPAND_MINW, int WAVES = MC_EXPAND_WAVES>
+// PARK (round 6): the instantiation whose in-wave writers park the overflow of their survivor lists and write it in later rounds of the
+// tail (see `spill` below).  A template parameter, not a flag: the parking code costs the kernel a dozen scalar registers and two spilled
+// VGPRs it should not pay on a model whose lists hardly ever fill up (the contract workload: 0.15 % of the states; profiles/r06zf, r06zg) —
+// and for the five-server model, whose lists do (11 %), the step is no shorter with every state written in-wave (r06zh): MC_F_PARK, not the default.
+template <class S, bool ROUTE, int NB, int MINW = MC_EXPAND_MINW, int WAVES = MC_EXPAND_WAVES, bool PARK = false>
 __global__ void __launch_bounds__(64 * WAVES, MINW)
 k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint64_t lo, uint64_t hi, uint64_t ncols,
                 uint64_t *table, uint64_t mask, uint32_t *__restrict__ newlist, uint64_t seg_cap, DevCounters *ctr, unsigned flags,
@@ -1097,7 +1114,7 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     unsigned cas_obase = 0;
     unsigned long long casret = 0;   // what that compare-and-swap returns (per lane; waited for at its first use, one resolve step later)
     uint64_t *const land = probe_land[threadIdx.x >> 6];
-    // IN-WAVE OVERFLOW (round 6; MC_F_LISTOVERFLOW = rounds 4-5's form for A/B).  A wavefront whose survivor list is about to fill up used
+    // IN-WAVE OVERFLOW, PARKED (round 6; the PARK instantiation, MC_F_PARK).  A wavefront whose survivor list is about to fill up used
     // to push its 64 oldest survivors through the global new-list to k_materialise — a second kernel beside the expand, unsorted batches
     // (every branch of the writer walked), the parents read again from HBM: 0.15 % of the contract workload's states but 11 % of the
     // five-server model's (fan-out ~27 per parent, W = 192 B: 103 M states, a 93 - 109 ms kernel beside a 156 ms one).  Now the 64
@@ -1108,10 +1125,16 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
     // (its state lives in LDS, not in a register that would be live through the whole kernel: wg_park[w] = position + 1 of wavefront w's
     //  newest parked chunk in its new-list segment, 0 = none — first try: one more scalar register and the refill loop cost the 3-server
     //  kernel 8 spilled VGPRs and 4 % of the contract line)
+    static_assert(!PARK || (!ROUTE && !ASYNC_BUILD), "parking: fused runs, synchronous probes");
     __shared__ unsigned wg_park[WAVES];
-    if (lane == 0) wg_park[threadIdx.x >> 6] = 0u;
+    if constexpr (PARK) { if (lane == 0) wg_park[threadIdx.x >> 6] = 0u; }
+    bool tail_more = false;   // workgroup-uniform: the tail's first round left parked chunks (the later rounds run at the kernel's very end)
+    // (the tail's class counts and first arena index: at function scope, the later rounds name them again)
+    __shared__ unsigned wg_hist_s[ASYNC_BUILD ? 1 : WAVES * SlotClasses<S>::value];
+    __shared__ unsigned long long wg_out0_s;
     auto spill_on = [&]() __attribute__((always_inline)) -> bool {   // wave-uniform
-        return inwave && !ASYNC_BUILD && !(flags & (MC_F_LISTOVERFLOW | MC_F_WAVETAIL)) && rt.new_fp != nullptr;
+        if constexpr (PARK) return inwave && !(flags & MC_F_WAVETAIL) && rt.new_fp != nullptr;
+        else return false;
     };
     MC_PROF_DECL
 
@@ -1124,7 +1147,9 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         // (spill: a chunk is 64 entries + the link; same segment, a cursor of its own — k_materialise never sees these entries)
         const bool spill = spill_on();
         if (lane == 0 && bl) pos = spill ? atomicAdd(&ctr->n_side[pshard].v, 65ull) : atomicAdd(&ctr->n_new[pshard].v, (unsigned long long)__popcll(bl));
-        const unsigned long long pos0 = wave_uniform_copy(pos);  // (lane 0's)
+        unsigned long long pos0;  // (lane 0's)
+        if constexpr (PARK) pos0 = wave_uniform_copy(pos);
+        else pos0 = __shfl(pos, 0);
         pos = pos0 + (unsigned)__popcll(bl & ((1ull << lane) - 1ull));
         if (e != O_DEAD) {
             seg[pos] = (uint32_t)(wave_col0 + (e & 63u)) | ((uint32_t)(e >> 6) << 24);
@@ -1655,8 +1680,6 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
             hist_stride = (unsigned)((ASYNC_BUILD ? 128 : 2) * 2);  // (32-bit words of one wavefront's landing area)
             wg_out0 = reinterpret_cast<unsigned long long *>(&probe_land[0][64]);
         } else {
-            __shared__ unsigned wg_hist_s[WAVES * NCLS];
-            __shared__ unsigned long long wg_out0_s;
             hist_base = wg_hist_s;
             hist_stride = NCLS;
             wg_out0 = &wg_out0_s;
@@ -1664,11 +1687,9 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         const unsigned w = threadIdx.x >> 6;
         {
             const uint64_t wg_idx0 = base + (uint64_t)blockIdx.x * (64u * WAVES);
-            const bool more = tail_round<S, WAVES>(prm, arena, rt.arena_w, rt.arena_cap, rt.parent, rt.pslot, ctr, flags, &wq[0], &fls[0], hist_base, hist_stride, wg_out0,
+            const bool more = tail_round<S, WAVES, PARK>(prm, arena, rt.arena_w, rt.arena_cap, rt.parent, rt.pslot, ctr, flags, &wq[0], &fls[0], hist_base, hist_stride, wg_out0,
                                                    order, &wg_park[0], w, lane, wg_idx0, ohead, on, err, [&](int ph) { MC_PROF(ph); (void)ph; });
-            // (rounds 2 ..: a workgroup whose wavefronts parked survivors — out of line, see tail_more_rounds)
-            if (more) err |= tail_more_rounds<S, WAVES, FamLdsT>(prm, arena, rt.arena_w, rt.arena_cap, rt.parent, rt.pslot, ctr, flags, &wq[0], &fls[0], hist_base, hist_stride,
-                                                                 wg_out0, order, &wg_park[0], wg_idx0, seg, rt.new_fp + (uint64_t)pshard * seg_cap);
+            tail_more = more;   // (rounds 2 ..: at the kernel's very end, when nothing of the wavefront's own state is live any more)
         }
         }  // (workgroup tail)
     } else if (on) {
@@ -1693,6 +1714,17 @@ k_expand_family(typename S::Params prm, const uint64_t *__restrict__ arena, uint
         if (cands) atomicAdd(&ctr->cells[shard].v, (unsigned long long)cands);
         if (vmin != ~0ull) atomicMin(&ctr->viol_key, vmin);
         if (eor) atomicOr(&ctr->error, eor);
+    }
+    if constexpr (PARK) {
+        // ROUNDS 2 .. of the tail (a workgroup whose wavefronts parked survivors): out of line (tail_more_rounds), and HERE — after the
+        // wavefront has handed in its counters — so that no value of the kernel is live across the call; every argument is a kernel
+        // argument or the address of a shared variable
+        if (tail_more) {
+            const unsigned e2 = tail_more_rounds<S, WAVES, FamLdsT>(prm, arena, rt.arena_w, rt.arena_cap, rt.parent, rt.pslot, ctr, flags, &wq[0], &fls[0], &wg_hist_s[0],
+                                                                    (unsigned)SlotClasses<S>::value, &wg_out0_s, reinterpret_cast<uint16_t *>(&fls[0].fq[0][0]), &wg_park[0],
+                                                                    base + (uint64_t)blockIdx.x * (64u * WAVES), seg, rt.new_fp + (uint64_t)pshard * seg_cap);
+            if (e2 && lane == 0) atomicOr(&ctr->error, e2);
+        }
     }
     MC_PROF_END;
 }
@@ -1742,6 +1774,12 @@ static void launch_expand(bool by_family, unsigned flags, uint64_t ncols, hipStr
         if (by_family) {
             // MC_F_OCC3 (A/B): the register budget of 3 wavefronts per SIMD (no spills) instead of 4 (a dozen spilled VGPRs)
             constexpr unsigned WG = 64u * MC_EXPAND_WAVES;   // columns (parents) per workgroup
+            if constexpr (!ROUTE) {
+                if (flags & MC_FI_PARK) {   // (set by the host's level loop, never by a caller: see k_expand_family's PARK)
+                    hipLaunchKernelGGL((k_expand_family<S, false, 1, MC_EXPAND_MINW, MC_EXPAND_WAVES, true>), dim3((unsigned)((ncols + WG - 1) / WG)), dim3(WG), 0, stream, args...);
+                    return;
+                }
+            }
             if (flags & MC_F_OCC3)
                 hipLaunchKernelGGL((k_expand_family<S, ROUTE, 1, 3>), dim3((unsigned)((ncols + WG - 1) / WG)), dim3(WG), 0, stream, args...);
             else
