@@ -474,7 +474,27 @@ def other_config(amd, device, key, steps=3):
     W, D, G = ks["state_bytes"], r.distinct, r.generated
     stag, ek = expand_kernel_name(w["spec"], w["params"])
     roof = kernel_roofline(ks, dt, w["spec"], stag, slots, G0["distinct"] + (1 << 20), G, ek)
-    return {"workload": w["name"] + " — ONE GPU, fused engine (the 8-GPU form of this configuration is `bench.py --gpus 8 --workload " + key + "`)",
+    park = None
+    if key == "raft5":
+        # the same steps through the PARK instantiation of the by-family kernel (MC_F_PARK, VERDICT round 5 next 5: every state written in-wave,
+        # nothing through k_materialise), timed beside the default inside the driver's own run: the A/B DESIGN.md quotes is re-measured every time
+        eng = amd.Engine(w["spec"], w["params"], device=device, table_capacity=slots, arena_capacity=G0["distinct"] + (1 << 20), max_levels=ML,
+                         chunk_states=(1 << 24) - 256, trace=False, timing=True, debug_flags=32768)
+        eng.run()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rp = eng.run()
+        dtp = (time.perf_counter() - t0) / steps
+        ksp = eng.kernel_stats()
+        eng.close()
+        if (rp.distinct, rp.generated, rp.depth, rp.verdict) != want or list(rp["levels"]) != G0["levels"]:
+            print(f"bench.py: {key} with MC_F_PARK: run does not reproduce the golden state graph", file=sys.stderr)
+            sys.exit(1)
+        park = {"flag": "MC_F_PARK (bench.py --park): the in-wave writers park the overflow of their survivor lists, the workgroup's tail writes it in later rounds",
+                "ms_per_step": 1e3 * dtp, "inwave_states": ksp.get("inwave_states", 0),
+                "kernel_ms": {k: ksp[k]["ms_total"] for k in ("expand", "insert", "materialise")}, "default": False}
+    return {**({"park_ab": park} if park else {}),
+            "workload": w["name"] + " — ONE GPU, fused engine (the 8-GPU form of this configuration is `bench.py --gpus 8 --workload " + key + "`)",
             "value": D / dt, "unit": "distinct states/s", "ms_per_step": 1e3 * dt, "steps": steps, "distinct": D, "generated": G, "depth": r.depth,
             "verdict": r.verdict, "state_bytes": W, "seen_set_load": D / float(slots), "inwave_states": ks.get("inwave_states", 0),
             "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
