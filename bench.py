@@ -448,7 +448,7 @@ def pcal_series(amd, device, steps=3):
     return out
 
 
-def other_config(amd, device, key, steps=3):
+def other_config(amd, device, key, steps=5):
     """BASELINE.json's configs 4 and 5 name models that are meant for eight GPUs; their graphs up to a level budget fit ONE MI355X, and the
     driver's line carries them as objects of their own (round 5: until then only builder-run `--workload raft5 / ssi4x3` lines existed,
     which nobody else measured).  Same engine, same gate as the main line: the run must reproduce the oracle's golden — counts and every
