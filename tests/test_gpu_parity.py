@@ -209,8 +209,8 @@ def test_parked_overflow_writes_every_state_in_wave(amd, oracle):
     ks = eng.kernel_stats()
     eng.close()
     assert r.levels == c["levels"][:16] and r.verdict == "budget" and r.distinct == sum(c["levels"][:16])
-    # (the batched small levels — up to 65 536 frontier states, a few thousand overflow survivors — keep the kernel without the parking code)
-    assert r.distinct - 20_000 <= ks["inwave_states"] < r.distinct, ks
+    # (everything but what Init enumerates; the batched small levels run the PARK instantiation too)
+    assert r.distinct - 64 <= ks["inwave_states"] < r.distinct, ks
     k = _golden("raft3_mcr4_t2_m1_k7_complete")
     for flags in (32768, 0):
         eng = amd.Engine("raft", oracle.raft_device_params(k["params"], 7, 1, 4), table_capacity=1 << 24, arena_capacity=2_400_000, chunk_states=1 << 16, trace=True, debug_flags=flags)

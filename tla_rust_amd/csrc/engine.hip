@@ -378,8 +378,9 @@ struct Engine : EngineBase {
         const unsigned sg = slices_for(ncols, true);
         const bool dl = sg > 1 && (cfg.flags & MC_F_DEADLOCK);
         if (dl) { rt.succ = d_nsl; hipMemsetAsync(d_nsl, 0, ncols * sizeof(uint16_t), stream); }
+        const unsigned lflags = cfg.flags | ((cfg.flags & MC_F_PARK) ? MC_FI_PARK : 0u);   // (the PARK instantiation, see run())
         timed(0, 0, [&] {
-            launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), cfg.flags, ncols, stream, sg, prm, (const uint64_t *)d_arena,
+            launch_expand<S, false>(!(cfg.flags & MC_F_NOFAMILY), lflags, ncols, stream, sg, prm, (const uint64_t *)d_arena,
                                     (uint64_t)0, (uint64_t)0, ncols, d_table, seen_arg(), d_newlist, seg_cap, d_ctr, cfg.flags, rt, 0u);
             if (dl) hipLaunchKernelGGL(k_deadlock_slices, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, (const uint16_t *)d_nsl,
                                        (uint64_t)0, (uint64_t)0, ncols, (const LevelCtl *)d_lc, d_ctr);
@@ -486,7 +487,12 @@ struct Engine : EngineBase {
         const bool park_levels = (cfg.flags & MC_F_PARK) != 0;
         mat_list_hint = ~0ull >> 8;   // (unknown before the first large level: the full grid)
         mat_inwave_level = false;
-        const uint64_t blind_max = chunk < (1ull << 16) ? chunk : (1ull << 16);
+        // (the largest frontier a batched level takes: 2^20 states since round 6 — 2^16 before; profiles/r06zm_blind_ab.jsonl: the contract
+        //  workload 128.7 / 127.5 -> 126.1 / 126.0 ms, the generated pagecache model 7.65 / 7.63 -> 7.42 / 7.44 — $TLAMC_BLIND_LOG2 = A/B knob.
+        //  Specs whose blind launches are sliced — the interpreter, the Paxos family: 32 slices of the level's CAPACITY — keep 2^16)
+        static const int blind_log2 = getenv("TLAMC_BLIND_LOG2") ? atoi(getenv("TLAMC_BLIND_LOG2")) : 20;
+        uint64_t blind_max = 1ull << (blind_log2 >= 10 && blind_log2 <= 23 && slices_for((1ull << 16) + 64, true) == 1 ? blind_log2 : 16);
+        if (chunk < blind_max) blind_max = chunk;
         while (hi > lo) {
             if (h_ctr->viol_key != ~0ull) break;
             if (stop_frontier && hi - lo >= stop_frontier) break;  // the caller continues this level sharded

@@ -449,6 +449,10 @@ extern "C" void *mc_jit_factory(const void *program /* pcal::Program * */) {
         struct stat st;
         if (stat((csrc + f).c_str(), &st) == 0) h = (h ^ (uint64_t)st.st_mtime ^ ((uint64_t)st.st_size << 20)) * 0x100000001b3ull;
     }
+    // (A/B knob: $TLAMC_JIT_DEFS replaces the register / workgroup shape of the by-pairs kernel in the generated unit; part of the cache key)
+    const char *jd = getenv("TLAMC_JIT_DEFS");
+    const std::string shape = jd && *jd ? jd : "-DMC_PAIR_MINW=2 -DMC_PAIR_WAVES=1";
+    h = (h ^ fnv(shape)) * 0x100000001b3ull;
     const char *cd = getenv("TLAMC_JIT_CACHE");
     const std::string cache = cd && *cd ? cd : "/tmp/tlamc_jit_" + std::to_string((unsigned)getuid());
     mkdir(cache.c_str(), 0700);
@@ -463,7 +467,7 @@ extern "C" void *mc_jit_factory(const void *program /* pcal::Program * */) {
         const char *hc = getenv("HIPCC");
         const std::string tmp = so + "." + std::to_string((int)getpid()) + ".tmp";
         const std::string cmd = std::string(hc && *hc ? hc : "/opt/rocm/bin/hipcc") + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-unused-result -w -I " + inc +
-                                " -I " + csrc + " -x hip -DMC_TU=9 -DMC_EXPAND_INSERT_MINW=2 -DMC_PAIR_MINW=2 -DMC_PAIR_WAVES=1 -DMC_GEN_HEADER='\"" + hdr + "\"' " + csrc + "/engine.hip -o " + tmp + " -L" + lib + " -ltlamc -Wl,-rpath," + lib +
+                                " -I " + csrc + " -x hip -DMC_TU=9 -DMC_EXPAND_INSERT_MINW=2 " + shape + " -DMC_GEN_HEADER='\"" + hdr + "\"' " + csrc + "/engine.hip -o " + tmp + " -L" + lib + " -ltlamc -Wl,-rpath," + lib +
                                 " > " + cache + "/gen_" + tag + ".log 2>&1";
         if (system(cmd.c_str()) != 0 || rename(tmp.c_str(), so.c_str()) != 0) {
             mc::set_error("jit: hipcc failed (see " + cache + "/gen_" + tag + ".log)");
