@@ -40,6 +40,7 @@ extern "C" {
     pub fn mc_engine_create(spec: *const mc_spec_desc, cfg: *const mc_config, out: *mut *mut mc_engine) -> c_int;
     pub fn mc_engine_run(e: *mut mc_engine, out: *mut mc_result) -> c_int;
     pub fn mc_engine_step(e: *mut mc_engine, levels: u32, out: *mut mc_result) -> c_int;
+    pub fn mc_engine_request_stop(e: *mut mc_engine) -> c_int;
     pub fn mc_engine_trace(e: *mut mc_engine, states: *mut u8, actions: *mut i32, n_inout: *mut usize) -> c_int;
     pub fn mc_engine_read_states(e: *mut mc_engine, first: u64, count: u64, out: *mut u8) -> c_int;
     // TLC's checkpoint / -recover (testout1:10): write / reload the states found so far; the next run continues

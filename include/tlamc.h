@@ -175,6 +175,11 @@ int mc_engine_step(mc_engine *e, uint32_t levels, mc_result *out);
  * `min_interval_seconds`, with the number of levels found so far and the three counters.  fn = NULL switches it off. */
 typedef void (*mc_progress_fn)(void *user, uint32_t levels, uint64_t generated, uint64_t distinct, uint64_t queue);
 int mc_engine_set_progress(mc_engine *e, mc_progress_fn fn, void *user, double min_interval_seconds);
+/* From inside a progress callback: the running mc_engine_run / mc_engine_step stops before its next BFS level as if its budget
+ * were spent (MC_V_BUDGET; everything searched so far stays resident, mc_engine_step continues it).  TLC has no counterpart (one
+ * interrupts it with ^C and -recover's from the last checkpoint); `mc` uses it to move a compiled PlusCal program from the device
+ * interpreter to generated code once that is built. */
+int mc_engine_request_stop(mc_engine *e);
 /* counterexample of the last run: states_out receives trace_len records of mc_state_bytes()
  * bytes each (plain word order), actions_out the action id that produced each state (-1 for
  * the initial state).  *n_inout: capacity in, count out. */

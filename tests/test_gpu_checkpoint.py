@@ -252,3 +252,28 @@ def test_counterexample_found_by_a_later_step(amd, oracle):
     tr = e.trace()
     assert len(tr) == r.trace_len and tr[0][0] == "Initial predicate" and "forced by deadlock-prevention" in tr[-1][1]
     e.close()
+
+
+def test_a_progress_callback_can_stop_the_run_and_steps_finish_it(amd, oracle):
+    """mc_engine_request_stop (round 6: how `mc` leaves the device interpreter once a program's generated code is built): called from a
+    progress callback, the run ends before its next BFS level like a run whose budget is spent — a prefix of the oracle's levels, verdict
+    "budget", the frontier left on the queue — and mc_engine_step continues it in place to the counters of one uninterrupted run"""
+    params = [2, 2, 127, 0]
+    o = oracle.oracle_run("ssi", params)
+    e = amd.Engine("ssi", params, table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 10)
+    calls = []
+    def fn(lv, g, d, q):
+        calls.append(lv)
+        if len(calls) == 1:
+            e.request_stop()
+    e.set_progress(fn, 0.0)
+    r = e.run()
+    assert calls and r.verdict == "budget" and 0 < len(r.levels) < len(o["levels"]) and r.levels == o["levels"][:len(r.levels)]
+    assert r.queue_left == r.levels[-1]
+    e.set_progress(None)
+    r = e.step(100)
+    assert (r.verdict, r.distinct, r.generated, r.depth, r.levels, r.queue_left) == \
+           (o["verdict"], o["distinct"], o["generated"], o["depth"], o["levels"], o["queue_left"])
+    r = e.run()                           # a request does not outlive its run
+    assert (r.verdict, r.distinct) == (o["verdict"], o["distinct"])
+    e.close()

@@ -72,3 +72,33 @@ def test_a_program_the_translator_refuses_is_interpreted(amd, capfd):
     ra, rb = a.run(), b.run()
     assert (ra.distinct, ra.generated, ra.depth, ra.verdict) == (rb.distinct, rb.generated, rb.depth, rb.verdict)
     a.close(); b.close(); prog.close()
+
+
+def test_mc_moves_a_long_search_to_generated_code_on_its_own(amd, tmp_path, capfd, monkeypatch):
+    """`mc X.tla` on a compiled PlusCal program starts on the device interpreter and, once the search has lasted $TLAMC_AUTOJIT_AFTER
+    seconds, builds the generated code beside it; when the library is there first, the run starts over with it (frontend.cpp).  Here the
+    library is in the cache already (a -jit run built it) and the wait is 0 s, so the move happens at the first report: same report text
+    and counters as the interpreter alone ($TLAMC_AUTOJIT=0) and as the golden."""
+    import json
+    import shutil
+    G = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())["pagecache_n3"]
+    tla = tmp_path / "pagecache.tla"
+    shutil.copy(ROOT / "specs" / "pluscal" / "pagecache.tla", tla)
+    cfg = tmp_path / "pagecache.cfg"
+    cfg.write_text("CONSTANTS N = 3 Blind = FALSE\nINVARIANTS Conservation HeadIsAllocated\n")
+    kw = dict(table_capacity=1 << 27, arena_capacity=22 << 20, chunk_states=1 << 21)
+    monkeypatch.setenv("TLAMC_JIT_CACHE", str(tmp_path / "cache"))
+    monkeypatch.setenv("TLAMC_JIT", "1")                      # generated code from the first state: builds the library
+    r0, rep0 = amd.check_files(tla, cfg, **kw)
+    assert "interpreting the program" not in capfd.readouterr().err
+    monkeypatch.delenv("TLAMC_JIT")
+    monkeypatch.setenv("TLAMC_AUTOJIT_AFTER", "0")
+    r1, rep1 = amd.check_files(tla, cfg, **kw)
+    err = capfd.readouterr().err
+    assert "starting over with it" in err, err
+    monkeypatch.setenv("TLAMC_AUTOJIT", "0")
+    r2, rep2 = amd.check_files(tla, cfg, **kw)
+    assert "starting over" not in capfd.readouterr().err
+    for r in (r0, r1, r2):
+        assert (r.verdict, r.distinct, r.generated, r.depth) == ("ok", G["distinct"], G["generated"], G["depth"])
+    assert r0.levels == r1.levels == r2.levels and rep0 == rep1 == rep2

@@ -114,6 +114,7 @@ def lib():
     L.mc_engine_run.argtypes = [C.c_void_p, C.POINTER(CResult)]
     L.mc_engine_step.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(CResult)]
     L.mc_engine_set_progress.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p, C.c_double]
+    L.mc_engine_request_stop.argtypes = [C.c_void_p]
     L.mc_engine_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
     L.mc_engine_kernel_stats.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
     L.mc_engine_read_states.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
@@ -421,6 +422,10 @@ class Engine:
         """fn(levels, generated, distinct, queue) between BFS levels of run(), at most once per interval (mc_engine_set_progress)"""
         self._progress = PROGRESS_FN(lambda _u, lv, g, d, q: fn(lv, g, d, q)) if fn else PROGRESS_FN()
         _check(lib().mc_engine_set_progress(self._h, self._progress, None, min_interval_seconds), "mc_engine_set_progress")
+
+    def request_stop(self):
+        """from inside a progress callback: the run stops before its next BFS level, verdict "budget" (mc_engine_request_stop)"""
+        _check(lib().mc_engine_request_stop(self._h), "mc_engine_request_stop")
 
     def shard_check_frontier(self):
         _check(lib().mc_shard_check_frontier(self._h), "mc_shard_check_frontier")

@@ -64,7 +64,7 @@ def build(force=False, verbose=False):
         if pr.wait() != 0:
             raise RuntimeError(f"hipcc failed for {obj.name}")
     if force or jobs or not LIB.exists():
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs] + ["-ldl"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs] + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

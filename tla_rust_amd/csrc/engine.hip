@@ -70,6 +70,7 @@ struct EngineBase {
     void *progress_user = nullptr;
     double progress_interval = 1.0;
     std::chrono::steady_clock::time_point progress_last;
+    bool stop_requested = false;  // mc_engine_request_stop (from a progress callback): run() stops before the next level, verdict "budget"
     void report_progress(uint32_t levels, uint64_t generated, uint64_t distinct, uint64_t queue) {
         if (!progress_fn) return;
         const auto now = std::chrono::steady_clock::now();
@@ -223,8 +224,10 @@ struct Engine : EngineBase {
         arena_cap = cfg.arena_capacity ? cfg.arena_capacity : (1ull << 22);
         arena_cap = (arena_cap + 63) & ~63ull;
         if (arena_cap >= (1ull << 32) - 1) { set_error("arena_capacity must be < 2^32 states"); return MC_EBADCFG; }
-        // a table that can never be more than a third full is probed 32 bytes at a time (seen_insert)
-        seen_sparse = table_cap >= 3 * arena_cap && table_cap / MC_SPARSE_SLOTS <= 0xffffffffull && !getenv("TLAMC_DENSE_TABLE");
+        // a table that can never be more than a third full is probed 32 bytes at a time (seen_insert); $TLAMC_SPARSE_RATIO = A/B knob
+        // for "a third" (slots per arena state, default 3)
+        static const double sparse_ratio = getenv("TLAMC_SPARSE_RATIO") && atof(getenv("TLAMC_SPARSE_RATIO")) >= 1.25 ? atof(getenv("TLAMC_SPARSE_RATIO")) : 3.0;
+        seen_sparse = (double)table_cap >= sparse_ratio * (double)arena_cap && table_cap / MC_SPARSE_SLOTS <= 0xffffffffull && !getenv("TLAMC_DENSE_TABLE");
         chunk = cfg.chunk_states ? cfg.chunk_states : (1ull << 18);
         chunk = (chunk + 255) & ~255ull;
         if (chunk > (1ull << 24) - 256) chunk = (1ull << 24) - 256;  // a column index must fit 24 bits (new-list entries: (slot << 24) | column)
@@ -417,6 +420,7 @@ struct Engine : EngineBase {
         out->violated_invariant = -1;
         memset(kstat, 0, sizeof kstat);
         have_viol = false;
+        stop_requested = false;
         have_run = false;  // set again on the success path only: a run that fails half-way (MC_EARENA, MC_ETABLEFULL, MC_EOVERFLOW)
                            // leaves fingerprints of an unfinished level in the seen-set — the next step / checkpoint must not continue it
         level_start.clear();
@@ -498,6 +502,7 @@ struct Engine : EngineBase {
             if (stop_frontier && hi - lo >= stop_frontier) break;  // the caller continues this level sharded
             if (cfg.max_levels && level >= cfg.max_levels) { budget = 1; break; }
             if (cfg.max_distinct && hi >= cfg.max_distinct) { budget = 1; break; }
+            if (stop_requested) { budget = 1; break; }
             if (!use_matrix && !(cfg.flags & MC_F_NOBATCH) && hi - lo <= blind_max) {
                 // Small frontier: BLIND_BATCH levels are enqueued back to back; the kernels take each level's range from
                 // LevelCtl and k_end_level applies the same stopping rules as this loop, so one host round trip covers
@@ -1773,6 +1778,11 @@ int mc_engine_set_progress(mc_engine *e, mc_progress_fn fn, void *user, double m
     e->impl->progress_fn = fn;
     e->impl->progress_user = user;
     e->impl->progress_interval = min_interval_seconds > 0 ? min_interval_seconds : 0.0;
+    return MC_OK;
+}
+int mc_engine_request_stop(mc_engine *e) {
+    if (!e) return MC_EBADCFG;
+    e->impl->stop_requested = true;
     return MC_OK;
 }
 int mc_engine_trace(mc_engine *e, uint8_t *states_out, int32_t *actions_out, size_t *n_inout) {

@@ -17,7 +17,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sys/stat.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <thread>
 #include <cmath>
 #include <fstream>
 #include <sstream>
@@ -1204,6 +1209,13 @@ static int host_evaluate(const char *tla_path, const char *cfg_path, const mc_co
     return MC_OK;
 }
 
+extern "C" void *mc_jit_factory(const void *program);   // pcal_codegen.cpp
+static bool jit_compiler_present() {
+    const char *hc = getenv("HIPCC");
+    struct stat st;   // (<unistd.h>'s access() is not to be had here: its R_OK macro collides with the interpreter's status names)
+    return stat(hc && *hc ? hc : "/opt/rocm/bin/hipcc", &st) == 0 && (st.st_mode & S_IXUSR);
+}
+
 int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_config *cfg, char *report, size_t report_cap,
                         mc_result *res, const char *dump_path, const char *recover_path, const char *checkpoint_path) {
     if (!tla_path || !cfg || !report || !report_cap || !res) return MC_EBADCFG;
@@ -1241,16 +1253,76 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     }
     if ((rc = mc_engine_create(&d, cfg, &e))) return rc;
     if (recover_path && (rc = mc_engine_restore(e, recover_path))) { mc_engine_destroy(e); return rc; }  // TLC -recover
-    if (cfg->flags & MC_F_PROGRESS) {  // testout2:4-259: one line per report, straight to stdout while the search runs
-        const char *iv = getenv("TLAMC_PROGRESS_INTERVAL");
-        mc_engine_set_progress(e, [](void *, uint32_t levels, uint64_t g, uint64_t dst, uint64_t q) {
-            printf("Progress(%u): %llu states generated, %llu distinct states found, %llu states left on queue.\n", levels,
-                   (unsigned long long)g, (unsigned long long)dst, (unsigned long long)q);
-            fflush(stdout);
-        }, nullptr, iv ? atof(iv) : 1.0);
+    const auto print_progress = [](void *, uint32_t levels, uint64_t g, uint64_t dst, uint64_t q) {
+        printf("Progress(%u): %llu states generated, %llu distinct states found, %llu states left on queue.\n", levels,
+               (unsigned long long)g, (unsigned long long)dst, (unsigned long long)q);
+        fflush(stdout);
+    };
+    const char *const piv = getenv("TLAMC_PROGRESS_INTERVAL");
+    const double progress_every = piv ? atof(piv) : 1.0;
+    // testout2:4-259: one line per report, straight to stdout while the search runs
+    if (cfg->flags & MC_F_PROGRESS) mc_engine_set_progress(e, print_progress, nullptr, progress_every);
+    // FROM THE INTERPRETER TO GENERATED CODE, on its own (round 6).  A compiled PlusCal program starts on the device interpreter — no
+    // compiler run, right for the models that finish in a blink — and once the search has lasted $TLAMC_AUTOJIT_AFTER seconds (default
+    // 1) the program's generated code is built beside it (mc_jit_factory on a thread of its own: hipcc, 5 - 9 s, cached).  When
+    // that library is there before the interpreter is done, the run stops at its next level (mc_engine_request_stop) and STARTS OVER
+    // as generated code: 50 - 100 x the interpreter's rate, so what is searched again costs a percent or two of what
+    // the interpreter had spent.  Same packed states, fingerprints, report.  Off: $TLAMC_AUTOJIT=0, -jit (generated code from the
+    // first state), -recover (the checkpointed engine continues), no compiler on the machine.
+    struct AutoJit {
+        mc_engine *e = nullptr;
+        std::chrono::steady_clock::time_point t0, last_print;
+        double after = 1.0, every = 1.0;
+        bool print = false, started = false, stopped = false;
+        const void *program = nullptr;
+        std::shared_ptr<std::atomic<int>> built;   // 0 = building, 1 = there, -1 = not to be had
+    } aj;
+    const char *const aje = getenv("TLAMC_AUTOJIT"), *const tje = getenv("TLAMC_JIT");
+    const bool auto_jit = generic && d.spec_id == MC_SPEC_PCAL && d.nparams >= 1 && d.params[0] && !(cfg->flags & MC_F_JIT) && !(tje && *tje && *tje != '0') &&
+                          !recover_path && !(aje && *aje == '0') && jit_compiler_present();
+    if (auto_jit) {
+        aj.e = e;
+        aj.t0 = aj.last_print = std::chrono::steady_clock::now();
+        const char *aa = getenv("TLAMC_AUTOJIT_AFTER");
+        aj.after = aa ? atof(aa) : 1.0;
+        aj.every = progress_every;
+        aj.print = (cfg->flags & MC_F_PROGRESS) != 0;
+        aj.program = (const void *)(intptr_t)d.params[0];
+        aj.built = std::make_shared<std::atomic<int>>(0);
+        mc_engine_set_progress(e, [](void *u, uint32_t levels, uint64_t g, uint64_t dst, uint64_t q) {
+            AutoJit &a = *(AutoJit *)u;
+            const auto now = std::chrono::steady_clock::now();
+            if (a.print && std::chrono::duration<double>(now - a.last_print).count() >= a.every) {
+                a.last_print = now;
+                printf("Progress(%u): %llu states generated, %llu distinct states found, %llu states left on queue.\n", levels,
+                       (unsigned long long)g, (unsigned long long)dst, (unsigned long long)q);
+                fflush(stdout);
+            }
+            if (!a.started && std::chrono::duration<double>(now - a.t0).count() >= a.after) {
+                a.started = true;
+                std::thread([built = a.built, program = a.program] { built->store(mc_jit_factory(program) ? 1 : -1); }).detach();
+            }
+            if (a.started && !a.stopped && a.built->load() == 1) {
+                a.stopped = true;
+                mc_engine_request_stop(a.e);
+            }
+        }, &aj, 0.02);
     }
     rc = mc_engine_run(e, res);
     if (rc) { mc_engine_destroy(e); return rc; }
+    if (auto_jit && aj.stopped && res->verdict == MC_V_BUDGET && !(cfg->max_levels && res->levels >= cfg->max_levels) &&
+        !(cfg->max_distinct && res->distinct >= cfg->max_distinct)) {
+        fprintf(stderr, "mc: %llu distinct states after %.1f s on the device interpreter; the program's generated code is built: starting over with it\n",
+                (unsigned long long)res->distinct, std::chrono::duration<double>(std::chrono::steady_clock::now() - aj.t0).count());
+        mc_engine_destroy(e);
+        e = nullptr;
+        mc_config with_jit = *cfg;
+        with_jit.flags |= MC_F_JIT;
+        if ((rc = mc_engine_create(&d, &with_jit, &e))) return rc;
+        if (cfg->flags & MC_F_PROGRESS) mc_engine_set_progress(e, print_progress, nullptr, progress_every);
+        rc = mc_engine_run(e, res);
+        if (rc) { mc_engine_destroy(e); return rc; }
+    }
     const bool clean = res->verdict == MC_V_OK || res->verdict == MC_V_BUDGET;
     if (checkpoint_path && clean && (rc = mc_engine_checkpoint(e, checkpoint_path))) { mc_engine_destroy(e); return rc; }
 

@@ -466,10 +466,12 @@ extern "C" void *mc_jit_factory(const void *program /* pcal::Program * */) {
         fclose(f);
         const char *hc = getenv("HIPCC");
         const std::string tmp = so + "." + std::to_string((int)getpid()) + ".tmp";
-        const std::string cmd = std::string(hc && *hc ? hc : "/opt/rocm/bin/hipcc") + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-unused-result -w -I " + inc +
+        // (the shell itself moves the finished object into place: a build whose process has gone — `mc` starts one beside the interpreter and
+        //  may be done before it — still completes the cache entry, and never leaves a half-written library under the final name)
+        const std::string cmd = "( " + std::string(hc && *hc ? hc : "/opt/rocm/bin/hipcc") + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-unused-result -w -I " + inc +
                                 " -I " + csrc + " -x hip -DMC_TU=9 -DMC_EXPAND_INSERT_MINW=2 " + shape + " -DMC_GEN_HEADER='\"" + hdr + "\"' " + csrc + "/engine.hip -o " + tmp + " -L" + lib + " -ltlamc -Wl,-rpath," + lib +
-                                " > " + cache + "/gen_" + tag + ".log 2>&1";
-        if (system(cmd.c_str()) != 0 || rename(tmp.c_str(), so.c_str()) != 0) {
+                                " && mv -f " + tmp + " " + so + " ) > " + cache + "/gen_" + tag + ".log 2>&1";
+        if (system(cmd.c_str()) != 0 || !exists(so)) {
             mc::set_error("jit: hipcc failed (see " + cache + "/gen_" + tag + ".log)");
             return nullptr;
         }
