@@ -104,6 +104,8 @@ def lib():
     # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both open the
     # GPU.  Loading torch first makes the dynamic linker resolve libtlamc.so's libamdhip64 (same SONAME)
     # to the copy torch already mapped, so device memory, streams and RCCL share one runtime.
+    # (multi-process GPU work — RCCL over xGMI — needs dmabuf IPC on this pool's driver; the variable must be there before the HSA runtime starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.path.exists("/dev/kfd"):  # (a box without a GPU never opens one: nothing to share, no reason to load torch's runtime)
         try:
             import torch  # noqa: F401

@@ -275,6 +275,7 @@ static int run_rank(const char *tla, const char *cfgp, mc_config cfg, int rank, 
 }
 
 int main(int argc, char **argv) {
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);   // (RCCL between processes needs dmabuf IPC on this driver; read when the HSA runtime starts)
     int gpus = 0;
     bool torch_door = false;
     for (int i = 1; i < argc; i++) {
