@@ -1264,7 +1264,7 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     if (cfg->flags & MC_F_PROGRESS) mc_engine_set_progress(e, print_progress, nullptr, progress_every);
     // FROM THE INTERPRETER TO GENERATED CODE, on its own (round 6).  A compiled PlusCal program starts on the device interpreter — no
     // compiler run, right for the models that finish in a blink — and once the search has lasted $TLAMC_AUTOJIT_AFTER seconds (default
-    // 1) the program's generated code is built beside it (mc_jit_factory on a thread of its own: hipcc, 5 - 9 s, cached).  When
+    // 0.3) the program's generated code is built beside it (mc_jit_factory on a thread of its own: hipcc, 5 - 9 s, cached).  When
     // that library is there before the interpreter is done, the run stops at its next level (mc_engine_request_stop) and STARTS OVER
     // as generated code: 50 - 100 x the interpreter's rate, so what is searched again costs a percent or two of what
     // the interpreter had spent.  Same packed states, fingerprints, report.  Off: $TLAMC_AUTOJIT=0, -jit (generated code from the
@@ -1284,7 +1284,7 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
         aj.e = e;
         aj.t0 = aj.last_print = std::chrono::steady_clock::now();
         const char *aa = getenv("TLAMC_AUTOJIT_AFTER");
-        aj.after = aa ? atof(aa) : 1.0;
+        aj.after = aa ? atof(aa) : 0.3;
         aj.every = progress_every;
         aj.print = (cfg->flags & MC_F_PROGRESS) != 0;
         aj.program = (const void *)(intptr_t)d.params[0];
@@ -1312,15 +1312,27 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
     if (rc) { mc_engine_destroy(e); return rc; }
     if (auto_jit && aj.stopped && res->verdict == MC_V_BUDGET && !(cfg->max_levels && res->levels >= cfg->max_levels) &&
         !(cfg->max_distinct && res->distinct >= cfg->max_distinct)) {
-        fprintf(stderr, "mc: %llu distinct states after %.1f s on the device interpreter; the program's generated code is built: starting over with it\n",
-                (unsigned long long)res->distinct, std::chrono::duration<double>(std::chrono::steady_clock::now() - aj.t0).count());
-        mc_engine_destroy(e);
-        e = nullptr;
+        const uint64_t had = res->distinct;
+        const double t_switch = std::chrono::duration<double>(std::chrono::steady_clock::now() - aj.t0).count();
         mc_config with_jit = *cfg;
         with_jit.flags |= MC_F_JIT;
-        if ((rc = mc_engine_create(&d, &with_jit, &e))) return rc;
+        // (the second engine beside the first when the device has room for both: giving 180 GB back to the driver and asking for them again
+        //  took 9 of a 20-second run, profiles/r06zq — the interpreter's engine is then destroyed after the search, where every run pays that)
+        mc_engine *old_e = e, *e2 = nullptr;
+        rc = mc_engine_create(&d, &with_jit, &e2);
+        if (rc) {
+            mc_engine_destroy(old_e);
+            old_e = nullptr;
+            if ((rc = mc_engine_create(&d, &with_jit, &e2))) return rc;
+        }
+        e = e2;
+        const double t_ready = std::chrono::duration<double>(std::chrono::steady_clock::now() - aj.t0).count();
         if (cfg->flags & MC_F_PROGRESS) mc_engine_set_progress(e, print_progress, nullptr, progress_every);
         rc = mc_engine_run(e, res);
+        fprintf(stderr, "mc: %llu distinct states after %.1f s on the device interpreter when the program's generated code was built: started over with it "
+                        "(engine %s after %.1f s, search %.2f s)\n", (unsigned long long)had, t_switch, old_e ? "beside the first" : "in the first one's place",
+                t_ready - t_switch, std::chrono::duration<double>(std::chrono::steady_clock::now() - aj.t0).count() - t_ready);
+        if (old_e) mc_engine_destroy(old_e);
         if (rc) { mc_engine_destroy(e); return rc; }
     }
     const bool clean = res->verdict == MC_V_OK || res->verdict == MC_V_BUDGET;

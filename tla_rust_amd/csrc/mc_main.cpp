@@ -18,7 +18,7 @@
 // -jit      : a compiled PlusCal program runs as GENERATED code — translated to straight-line C++ and built for the device (hipcc) when
 //             the engine is created, cached by the program's hash — instead of being interpreted on the device (MC_F_JIT; same report).
 //             Without it the search starts on the interpreter and moves to the generated code by itself when it lasts long enough for
-//             the build to finish first ($TLAMC_AUTOJIT_AFTER seconds before the build starts, default 1; $TLAMC_AUTOJIT=0: never).
+//             the build to finish first ($TLAMC_AUTOJIT_AFTER seconds before the build starts, default 0.3; $TLAMC_AUTOJIT=0: never).
 // -unverified: an MC wrapper (specs/MCraft.tla ...) EXTENDS a module of the reference (raft.tla); when that module is found
 //             neither beside the wrapper nor under $TLA_PATH the run is refused, unless this option accepts the built-in
 //             lowering unchecked (the report then starts with a warning).
