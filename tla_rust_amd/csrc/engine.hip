@@ -1758,8 +1758,10 @@ int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine *
         if (((cfg->flags & MC_F_JIT) || (ej && *ej && *ej != '0')) && spec->nparams >= 1 && spec->params[0]) {
             typedef int (*factory_t)(const mc_spec_desc *, const mc_config *, EngineBase **);
             factory_t fn = (factory_t)mc_jit_factory((const void *)(intptr_t)spec->params[0]);
-            if (fn) { rc = fn(spec, cfg, &impl); jit = rc == MC_OK; }
-            if (!jit) fprintf(stderr, "tlamc: MC_F_JIT: %s; interpreting the program on the device instead\n", g_last_error.c_str());
+            // (the library is there and ITS engine cannot be made — out of device memory, a bad configuration: the caller's error, the
+            //  interpreter's engine would meet it too; the interpreter stands in only for generated code that is not to be had)
+            if (fn) { rc = fn(spec, cfg, &impl); jit = true; }
+            else fprintf(stderr, "tlamc: MC_F_JIT: %s; interpreting the program on the device instead\n", g_last_error.c_str());
         }
         if (!jit) rc = mc_make_engine_6(spec, cfg, &impl);
         break;
