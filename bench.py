@@ -434,6 +434,7 @@ def pcal_series(amd, device, steps=3):
         dt = (time.perf_counter() - t0) / steps
         ks = eng.kernel_stats()
         eng.close()
+        W_public = amd.state_bytes("pcal", prog.params)   # the interpreter's row (32 bits per cell): what leaves the engine
         prog.close()
         if (r.distinct, r.generated, r.depth) != tuple(want) or r.verdict != "ok" or (levels is not None and list(r["levels"]) != levels):
             print(f"bench.py: pcal {name}: got {(r.distinct, r.generated, r.depth, r.verdict)}, want {want}", file=sys.stderr)
@@ -442,7 +443,7 @@ def pcal_series(amd, device, steps=3):
         moved = 2 * W * r.distinct + 8 * ks["cand_cells"]
         out.append({"workload": name, "backend": "generated code (MC_F_JIT), by-pairs kernel" if ks.get("inwave_states", 0) else "slot-by-slot kernel (generated code or the interpreter: see stderr)",
                     "value": r.distinct / dt, "unit": "distinct states/s", "ms_per_step": 1e3 * dt, "steps": steps, "distinct": r.distinct, "generated": r.generated,
-                    "depth": r.depth, "generated_per_s": r.generated / dt, "engine_create_s": build_s, "state_bytes": W,
+                    "depth": r.depth, "generated_per_s": r.generated / dt, "engine_create_s": build_s, "state_bytes": W, "state_bytes_interpreter": W_public,
                     "kernel_ms": {k: ks[k]["ms_total"] for k in ("expand", "insert", "materialise")},
                     "pipeline_GBs": moved / dt / 1e9, "pipeline_frac": moved / dt / 1e9 / HBM_PEAK_GBS, "golden": src})
     return out

@@ -268,7 +268,7 @@ def program_codegen(prog):
 
 class GenCheck(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("distinct", "generated", "mismatches", "states_checked", "pairs_checked", "first_bad_state", "first_bad_slot")] + \
-               [("depth", C.c_uint32), ("first_bad_kind", C.c_int32)]
+               [("depth", C.c_uint32), ("first_bad_kind", C.c_int32), ("stored_words", C.c_uint32), ("vm_words", C.c_uint32)]
 
 
 def gen_check(prog, max_states=0):

@@ -1,7 +1,8 @@
 """GPU leg of tests/test_codegen.py: compiled PlusCal programs as GENERATED code on the device (MC_F_JIT: tla_rust_amd/csrc/pcal_codegen.cpp
 writes the program as C++ for spec_gen.h, hipcc builds it into an engine library when the engine is created) against the bytecode
-interpreter on the same device — counters, verdict, depth, per-level counts and the per-level SETS of packed states (the two back-ends
-store the same rows) — and, through tests/test_gpu_pcal.py's chain, against oracle/tla_eval.py.  (Sorts behind the other GPU files: the
+interpreter on the same device — counters, verdict, depth, per-level counts, the per-level SETS of states and the counterexample of a violating
+model (rows LEAVE both back-ends in the interpreter's layout; the generated code STORES them packed to its cells' inferred ranges, so the
+comparison also proves pack + export on every state of these graphs) — and, through tests/test_gpu_pcal.py's chain, against oracle/tla_eval.py.  (Sorts behind the other GPU files: the
 first engine of each program pays ~20 s of compilation.)"""
 import sys
 from pathlib import Path
@@ -55,6 +56,9 @@ def test_generated_code_on_gpu_equals_the_interpreter(amd, path, invs, consts, c
     if ra.verdict == "ok" and ra.distinct <= 60000:
         want = level_sets(b, rb)
         assert level_sets(a, ra) == want and level_sets(c, rc) == want
+    if ra.verdict not in ("ok", "budget"):
+        tb = b.trace()
+        assert tb and a.trace() == tb and c.trace() == tb   # the same counterexample, state texts and action names
     a.close()
     b.close()
     c.close()
@@ -102,3 +106,52 @@ def test_mc_moves_a_long_search_to_generated_code_on_its_own(amd, tmp_path, capf
     for r in (r0, r1, r2):
         assert (r.verdict, r.distinct, r.generated, r.depth) == ("ok", G["distinct"], G["generated"], G["depth"])
     assert r0.levels == r1.levels == r2.levels and rep0 == rep1 == rep2
+
+
+def test_generated_code_stores_packed_rows_and_hands_out_the_interpreters(amd, tmp_path, capfd):
+    """Round 6: the generated code packs every cell into the bits of its inferred range (pcal_codegen.cpp "cell ranges"): the engine's
+    state_bytes shrink (two_phase_channels RM = 3: 45 words -> 6), mc_engine_read_states / traces still hand out mc_state_bytes(spec) per
+    state; $TLAMC_JIT_PACK=0 keeps the interpreter's rows (same counts either way); a checkpoint of packed rows is refused by the interpreter's
+    engine and continued by another engine of the same generated code; the sharded entry points refuse a packed engine."""
+    import os
+    c = next(c for c in CASES if c[0].stem == "two_phase_channels" and c[2].get("RM") == 3 and not c[2].get("Eager"))
+    prog = amd.Program(c[0].read_text(), cfg_text(c[1], c[2]))
+    kw = dict(table_capacity=1 << 20, arena_capacity=1 << 18, chunk_states=1 << 12)
+    b = amd.Engine("pcal", prog.params, timing=True, **kw)
+    rb = b.run()
+    public = amd.state_bytes("pcal", prog.params)
+    assert b.kernel_stats()["state_bytes"] == public
+    a = amd.Engine("pcal", prog.params, jit=True, timing=True, **kw)
+    ra = a.run()
+    assert "interpreting the program" not in capfd.readouterr().err
+    stored = a.kernel_stats()["state_bytes"]
+    assert stored * 3 <= public, (stored, public)
+    assert (ra.distinct, ra.generated, ra.depth, ra.levels) == (rb.distinct, rb.generated, rb.depth, rb.levels)
+    assert sorted(a.read_states(0, ra.distinct)) == sorted(b.read_states(0, rb.distinct))
+    with pytest.raises(RuntimeError, match="ONE GPU"):
+        a.shard_begin()
+    # checkpoint at a budget, continue in a second engine of the same code; the interpreter's engine refuses the file
+    a2 = amd.Engine("pcal", prog.params, jit=True, max_levels=6, **kw)
+    r2 = a2.run()
+    assert r2.verdict == "budget"
+    ck = tmp_path / "packed.ck"
+    a2.checkpoint(ck)
+    a3 = amd.Engine("pcal", prog.params, jit=True, **kw)
+    a3.restore(ck)
+    r3 = a3.run()
+    assert (r3.distinct, r3.generated, r3.depth, r3.verdict) == (rb.distinct, rb.generated, rb.depth, rb.verdict)
+    b2 = amd.Engine("pcal", prog.params, **kw)
+    with pytest.raises(RuntimeError, match="another"):
+        b2.restore(ck)
+    for e in (a, a2, a3, b, b2):
+        e.close()
+    os.environ["TLAMC_JIT_PACK"] = "0"
+    try:
+        d = amd.Engine("pcal", prog.params, jit=True, timing=True, **kw)
+        rd = d.run()
+        assert d.kernel_stats()["state_bytes"] == public
+        assert (rd.distinct, rd.generated, rd.depth, rd.levels) == (rb.distinct, rb.generated, rb.depth, rb.levels)
+        d.close()
+    finally:
+        del os.environ["TLAMC_JIT_PACK"]
+    prog.close()

@@ -148,6 +148,16 @@ struct KTimer {
     ~KTimer() { for (auto e : pool) hipEventDestroy(e); }
 };
 
+// specs whose stored row is not the row the C ABI hands out (spec_gen.h: generated code packs its cells): S::EXPORT_WORDS, S::export_row
+template <class S, class = void>
+struct HasExport : std::false_type {};
+template <class S>
+struct HasExport<S, decltype((void)S::EXPORT_WORDS)> : std::true_type {};
+template <class S, class = void>
+struct PackedRows : std::false_type {};
+template <class S>
+struct PackedRows<S, decltype((void)S::PACKED_ROWS)> : std::integral_constant<bool, S::PACKED_ROWS> {};
+
 template <class S>
 struct Engine : EngineBase {
     using Params = typename S::Params;
@@ -839,6 +849,9 @@ struct Engine : EngineBase {
         }
         const size_t n = acts.size();
         if (n > *n_inout) { *n_inout = n; set_error("trace buffer too small"); return MC_EBADCFG; }
+        if constexpr (HasExport<S>::value) {  // rows leave the engine in the spec's PUBLIC layout (generated code: the interpreter's row)
+            for (size_t k = 0; k < n; ++k) S::export_row(prm, &words[k * W], (uint64_t *)states_out + k * (size_t)S::EXPORT_WORDS);
+        } else
         memcpy(states_out, words.data(), n * W * sizeof(uint64_t));
         memcpy(actions_out, acts.data(), n * sizeof(int32_t));
         *n_inout = n;
@@ -854,8 +867,17 @@ struct Engine : EngineBase {
         for (uint64_t off = 0; off < count; off += piece) {
             const uint64_t n = count - off < piece ? count - off : piece;
             hipLaunchKernelGGL(k_gather_states, dim3((unsigned)((n * W + 255) / 256)), dim3(256), 0, stream, d_arena, W, first + off, n, tmp);
-            hipError_t e1 = hipMemcpyAsync(out + off * W * sizeof(uint64_t), tmp, n * W * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
-            hipError_t e2 = hipStreamSynchronize(stream);
+            hipError_t e1, e2;
+            if constexpr (HasExport<S>::value) {
+                std::vector<uint64_t> rows((size_t)n * W);
+                e1 = hipMemcpyAsync(rows.data(), tmp, n * W * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+                e2 = hipStreamSynchronize(stream);
+                if (e1 == hipSuccess && e2 == hipSuccess)
+                    for (uint64_t k = 0; k < n; ++k) S::export_row(prm, &rows[(size_t)k * W], (uint64_t *)out + (size_t)(off + k) * (size_t)S::EXPORT_WORDS);
+            } else {
+                e1 = hipMemcpyAsync(out + off * W * sizeof(uint64_t), tmp, n * W * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+                e2 = hipStreamSynchronize(stream);
+            }
             if (e1 != hipSuccess || e2 != hipSuccess) { hipFree(tmp); set_error("read_states: copy failed"); return MC_EHIP; }
         }
         hipFree(tmp);
@@ -968,6 +990,7 @@ struct Engine : EngineBase {
         for (auto &q : sl) { q.launched = false; q.keep_pending = false; q.pend_total = 0; q.moved = 0; q.count = 0; }
     }
     int shard_begin() override {
+        if constexpr (PackedRows<S>::value) { set_error("this engine of generated code stores rows packed to its program's cell ranges and serves ONE GPU: create a sharded engine with shard_count > 1 (or $TLAMC_JIT_PACK=0)"); return MC_EBADCFG; }
         if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
         sh_dup = 0;
         sh_resume = sh_ck_ok = false;
@@ -1003,6 +1026,7 @@ struct Engine : EngineBase {
     uint64_t sh_dup = 0;
     std::unique_ptr<mc_result> prefix_res{new mc_result()};
     int shard_begin_replicated(uint64_t min_frontier, uint64_t max_distinct, uint64_t max_levels, uint64_t *levels_out, uint32_t *nlevels) override {
+        if constexpr (PackedRows<S>::value) { set_error("this engine of generated code stores rows packed to its program's cell ranges and serves ONE GPU: create a sharded engine with shard_count > 1 (or $TLAMC_JIT_PACK=0)"); return MC_EBADCFG; }
         if (nranks() > 8) { set_error("at most 8 shards"); return MC_EBADCFG; }
         mc_result &res = *prefix_res;  // large (level table): not on the stack, and not shared between engines / threads
         sh_resume = sh_ck_ok = false;
@@ -1112,6 +1136,7 @@ struct Engine : EngineBase {
         return rc;
     }
     int shard_restore(const char *path) override {
+        if constexpr (PackedRows<S>::value) { set_error("this engine of generated code stores rows packed to its program's cell ranges and serves ONE GPU: create a sharded engine with shard_count > 1 (or $TLAMC_JIT_PACK=0)"); return MC_EBADCFG; }
         FILE *f = fopen(path, "rb");
         if (!f) { set_error(std::string("mc_shard_restore: cannot read ") + path); return MC_EPARSE; }
         FileCloser closer{f};
@@ -1625,7 +1650,7 @@ int mc_make_engine_4(const mc_spec_desc *, const mc_config *, mc::EngineBase **)
 int mc_make_engine_5(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
 int mc_make_engine_6(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
 int mc_make_engine_7(const mc_spec_desc *, const mc_config *, mc::EngineBase **);
-void *mc_jit_factory(const void *program);   // pcal_codegen.cpp: the factory of the engine library built from the program's generated code, or null
+void *mc_jit_factory_opts(const void *program, int pack);   // pcal_codegen.cpp: the factory of the engine library built from the program's generated code, or null
 #if MC_TU == 1 || MC_TU == -1
 int mc_make_engine_1(const mc_spec_desc *d, const mc_config *c, mc::EngineBase **out) {
     if (d->spec_id == MC_SPEC_ATOMIC_ADD) {
@@ -1713,6 +1738,7 @@ int mc_make_engine_gen(const mc_spec_desc *d, const mc_config *c, mc::EngineBase
     mixin(p.num_init);
     p.code = nullptr;   // the device never reads the image: the program IS the kernels
     const int rc = mc::make_engine<mc::SpecGen>(p, d, c, out);
+    if (mc::SpecGen::PACKED_ROWS) { mixin(0x7061636bu); mixin((uint32_t)mc::SpecGen::MAX_WORDS); }   // a checkpoint of packed rows is not the interpreter's
     if (!rc) (*out)->program_hash = ph ? ph : 1;
     return rc;
 }
@@ -1757,7 +1783,7 @@ int mc_engine_create(const mc_spec_desc *spec, const mc_config *cfg, mc_engine *
         bool jit = false;
         if (((cfg->flags & MC_F_JIT) || (ej && *ej && *ej != '0')) && spec->nparams >= 1 && spec->params[0]) {
             typedef int (*factory_t)(const mc_spec_desc *, const mc_config *, EngineBase **);
-            factory_t fn = (factory_t)mc_jit_factory((const void *)(intptr_t)spec->params[0]);
+            factory_t fn = (factory_t)mc_jit_factory_opts((const void *)(intptr_t)spec->params[0], cfg->shard_count > 1 ? 0 : 1);
             // (the library is there and ITS engine cannot be made — out of device memory, a bad configuration: the caller's error, the
             //  interpreter's engine would meet it too; the interpreter stands in only for generated code that is not to be had)
             if (fn) { rc = fn(spec, cfg, &impl); jit = true; }

@@ -6,13 +6,19 @@
 // This is north_star's "lowering each spec's next-state relation to a fixed-width packed state vector so that successor generation runs
 // as a hand-written HIP kernel": the kernels are engine_kernels.h's, the lowering is what a hand would have written for THIS program.
 //
-// The packed state, its fingerprint and every host-side helper (state text, action names, traces, checkpoints' program identity) are the
-// interpreter's (SpecVmT): the two back-ends are interchangeable state by state, which is how tests/ compare them.
+// Host-side helpers (state text, action names) are the interpreter's (SpecVmT), and so is the row that LEAVES an engine (traces,
+// mc_engine_read_states: export_row below): the two back-ends are interchangeable state by state, which is how tests/ compare them.  The row
+// an engine of generated code STORES — and fingerprints — is packed to the cells' inferred ranges when that saves words (G::PACKED).
 // G (generated, namespace-free struct) provides:
 //   constexpr int NV, NINST, MAXCH, PC_BASE, DONE, NINV, NCON; constexpr unsigned long long NUM_INIT
 //   struct Cells { int32_t c0, c1, ... };   // the variable cells as NAMED members: nothing can index them with a variable, so nothing
 //                                           // can push them out of the registers (see pcal_codegen.cpp CELL)
-//   static void zero(Cells &), to_words(const Cells &, uint64_t *), from_words(const uint64_t *, Cells &)
+//   constexpr int NW (words of a stored row), VMW (words of the interpreter's row); constexpr bool PACKED
+//   static void zero(Cells &), from_words(const uint64_t *, Cells &); static bool to_words(const Cells &, uint64_t *) — the STORED row: the
+//   interpreter's layout, or (round 6, PACKED) every cell in the bits its inferred range needs (pcal_codegen.cpp "cell ranges"); false = a
+//   value outside its cell's range (an evaluation error: never stored)
+//   static void cells_to_vm(const Cells &, uint64_t *), cells_from_vm(const uint64_t *, Cells &) — the interpreter's row: what leaves the engine
+//   template <class Ref> static int32_t pc_from_row(Ref row, int inst)
 //   template <int INST> static int32_t pc_of(const Cells &)
 //   static int run_init(uint64_t &ch, Cells &v)                                     // R_* of SpecVmT::Run
 //   template <int INST> static int run_inst(int32_t label, uint64_t &ch, Cells &v, const Cells &old, int &aux)
@@ -39,7 +45,9 @@ template <class G>
 struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
     using Params = VmParams;
     using VM = SpecVmT<128>;
-    static constexpr int NV = G::NV, MAX_VARS = NV, MAX_WORDS = (NV + 1) / 2, FIX_SLOTS = 0, STAGE_WORDS = 0;
+    static constexpr int NV = G::NV, MAX_VARS = NV, MAX_WORDS = G::NW, FIX_SLOTS = 0, STAGE_WORDS = 0;
+    static constexpr int EXPORT_WORDS = G::VMW;   // (engine.hip: rows leave the engine through export_row)
+    static constexpr bool PACKED_ROWS = G::PACKED;
     static constexpr bool SLICE_SLOTS = true;
     MC_HD static int words(const Params &) { return MAX_WORDS; }
     MC_HD static int max_slots(const Params &) { return G::NINST * G::MAXCH + 1; }
@@ -56,7 +64,7 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
         return 0;
     }
 
-    MC_HD static uint64_t fp_words(const uint64_t *w) {  // (SpecVmT::fp_vals: the two back-ends store the same rows AND the same fingerprints)
+    MC_HD static uint64_t fp_words(const uint64_t *w) {  // (SpecVmT::fp_vals over the stored row: the interpreter's fingerprints when the layout is the interpreter's)
         uint64_t h = 0x9e3779b97f4a7c15ull;
 #pragma unroll
         for (int k = 0; k < MAX_WORDS; ++k) h = fmix64(h ^ (w[k] + 0x632be59bd9b4e019ull * (uint64_t)(k + 1)));
@@ -96,7 +104,7 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
         uint64_t ch = k;
         G::run_init(ch, v);
         uint64_t w[MAX_WORDS];
-        G::to_words(v, w);
+        (void)G::to_words(v, w);   // (init_status below re-checks the stored row; a range miss would show as a state that is not the interpreter's)
 #pragma unroll
         for (int i = 0; i < MAX_WORDS; ++i) out.set(i, w[i]);
     }
@@ -161,7 +169,7 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
         const unsigned st = step(l.v, slot, v);
         if (st & ST_ENABLED) {
             uint64_t w[MAX_WORDS];
-            G::to_words(v, w);
+            if (!G::to_words(v, w)) return ST_ENABLED | ST_SPECERR;   // outside an inferred range: reported, never stored
             fp = fp_words(w);
         }
         return st;
@@ -172,7 +180,7 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
         unpack(s, cur);
         const unsigned st = step(cur, slot, v);
         uint64_t w[MAX_WORDS];
-        G::to_words(v, w);
+        (void)G::to_words(v, w);   // (eval decided that this successor is stored)
 #pragma unroll
         for (int k = 0; k < MAX_WORDS; ++k) out.set(k, w[k]);
         return st;
@@ -213,9 +221,7 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
     template <class Ref>
     MC_HD static int pair_key(const Params &, Ref row, int slot) {
         if (slot >= G::NINST * G::MAXCH) return G::DONE;
-        const int cell = G::PC_BASE + slot / G::MAXCH;
-        const uint64_t w = row.get(cell >> 1);
-        const int32_t label = (int32_t)(uint32_t)(cell & 1 ? w >> 32 : w);
+        const int32_t label = G::pc_from_row(row, slot / G::MAXCH);
         return label >= 0 && label < G::NLABELS ? label : G::DONE;
     }
     struct PairOut { uint64_t w[MAX_WORDS]; };   // the successor's packed row
@@ -225,7 +231,7 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
         unpack(row, cur);
         const unsigned st = step(cur, slot, v);
         if (st & ST_ENABLED) {
-            G::to_words(v, o.w);
+            if (!G::to_words(v, o.w)) return ST_ENABLED | ST_SPECERR;
             fp = fp_words(o.w);
         }
         return st;
@@ -236,10 +242,23 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
         for (int k = 0; k < MAX_WORDS; ++k) out.set(k, o.w[k]);
     }
 
-    // host side: the interpreter's helpers (same packed state)
-    static int action_of(const Params &p, const uint64_t *parent, int slot) { return VM::action_of(p, parent, slot); }
+    // host side: the interpreter's helpers, on the interpreter's row
+    MC_HD static void export_row(const Params &, const uint64_t *stored, uint64_t *vm_row) {
+        Cells v;
+        G::from_words(stored, v);
+        G::cells_to_vm(v, vm_row);
+    }
+    static int action_of(const Params &p, const uint64_t *parent, int slot) {
+        uint64_t vm[G::VMW];
+        export_row(p, parent, vm);
+        return VM::action_of(p, vm, slot);
+    }
     static const char *action_name(int a) { return VM::action_name(a); }
-    static int format(const Params &p, const uint64_t *w, char *buf, size_t cap) { return VM::format(p, w, buf, cap); }
+    static int format(const Params &p, const uint64_t *w, char *buf, size_t cap) {
+        uint64_t vm[G::VMW];
+        export_row(p, w, vm);
+        return VM::format(p, vm, buf, cap);
+    }
 };
 
 }  // namespace mc
