@@ -107,8 +107,13 @@ typedef struct {
 #define MC_F_JIT 262144u /* MC_SPEC_PCAL engines: translate the compiled program into straight-line C++ (mc_program_codegen) and build it for
                             the device when the engine is created (hipcc, cached by the hash of the text: seconds to a minute the first
                             time) instead of interpreting its bytecode on the device; $TLAMC_JIT=1 does the same for every such engine.
-                            Same packed states, fingerprints and counts; a program the translator does not cover (sets of records) or
-                            a box without hipcc falls back to the interpreter and says so on stderr */
+                            Same states and counts; the engine STORES its rows packed to the cells' inferred ranges (an interval analysis
+                            of the program; $TLAMC_JIT_PACK=0: 32 bits per cell like the interpreter) and hands them out — mc_engine_trace,
+                            mc_engine_read_states — as the interpreter's rows, mc_state_bytes(spec) each; a checkpoint of packed rows is
+                            continued by an engine of the same generated code only (mc_check_files' recover path tries that by itself);
+                            the mc_shard_* entry points refuse a packed engine (a config with shard_count > 1 is built unpacked).
+                            A program the translator does not cover (sets of records) or a box without hipcc falls back to the
+                            interpreter and says so on stderr */
 #define MC_F_GENERIC 128u /* mc_check_files: run a PlusCal module through the compiled program (MC_SPEC_PCAL) even
                              when a hand lowering of its algorithm exists (A/B of the two paths)  */
 

@@ -4,6 +4,7 @@ interpreter on the same device — counters, verdict, depth, per-level counts, t
 model (rows LEAVE both back-ends in the interpreter's layout; the generated code STORES them packed to its cells' inferred ranges, so the
 comparison also proves pack + export on every state of these graphs) — and, through tests/test_gpu_pcal.py's chain, against oracle/tla_eval.py.  (Sorts behind the other GPU files: the
 first engine of each program pays ~20 s of compilation.)"""
+import os
 import sys
 from pathlib import Path
 
@@ -155,3 +156,22 @@ def test_generated_code_stores_packed_rows_and_hands_out_the_interpreters(amd, t
     finally:
         del os.environ["TLAMC_JIT_PACK"]
     prog.close()
+
+
+def test_mc_recovers_a_checkpoint_of_generated_code(amd, tmp_path):
+    """`mc -checkpoint` of a run on generated code (here -jit; a long run moves there by itself) writes packed rows; `mc -recover` starts on the
+    interpreter's engine, which refuses the file, and continues with the generated code instead: the golden's counts at the end."""
+    import json
+    import subprocess
+    G = json.loads((ROOT / "tests" / "golden" / "pcal_channels.json").read_text())["pagecache_n3"]
+    mc = ROOT / "tla_rust_amd" / "_build" / "mc"
+    cfg = tmp_path / "pagecache.cfg"
+    cfg.write_text("CONSTANTS N = 3 Blind = FALSE\nINVARIANTS Conservation HeadIsAllocated\n")
+    ck = tmp_path / "pc.ck"
+    env = dict(os.environ, TLAMC_JIT_CACHE=str(tmp_path / "cache"))
+    common = [str(mc), str(ROOT / "specs" / "pluscal" / "pagecache.tla"), "-config", str(cfg), "-tablelog2", "27", "-arena", str(22 << 20), "-noprogress"]
+    a = subprocess.run(common + ["-jit", "-maxlevels", "20", "-checkpoint", str(ck)], env=env, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and ck.exists(), a.stdout + a.stderr
+    b = subprocess.run(common + ["-recover", str(ck)], env=env, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stdout + b.stderr
+    assert f"{G['generated']} states generated, {G['distinct']} distinct states found, 0 states left on queue." in b.stdout, b.stdout

@@ -1252,7 +1252,21 @@ int mc_check_files_ckpt(const char *tla_path, const char *cfg_path, const mc_con
         cfg = &with_cfg_statements;
     }
     if ((rc = mc_engine_create(&d, cfg, &e))) return rc;
-    if (recover_path && (rc = mc_engine_restore(e, recover_path))) { mc_engine_destroy(e); return rc; }  // TLC -recover
+    if (recover_path && (rc = mc_engine_restore(e, recover_path))) {  // TLC -recover
+        // a checkpoint written by the program's GENERATED code (a run that moved to it by itself, or -jit) holds rows packed to the cells'
+        // inferred ranges: the interpreter's engine refuses it (another program identity) and the generated code continues it
+        mc_engine *ej = nullptr;
+        mc_config with_jit = *cfg;
+        with_jit.flags |= MC_F_JIT;
+        const std::string first_error = mc_last_error();
+        if (rc == MC_EBADCFG && generic && d.spec_id == MC_SPEC_PCAL && !(cfg->flags & MC_F_JIT) && jit_compiler_present()) {
+            mc_engine_destroy(e);
+            e = nullptr;
+            if (mc_engine_create(&d, &with_jit, &ej) == MC_OK && mc_engine_restore(ej, recover_path) == MC_OK) { e = ej; rc = MC_OK; }
+            else { if (ej) mc_engine_destroy(ej); mc_set_error_internal(first_error.c_str()); }
+        }
+        if (rc) { if (e) mc_engine_destroy(e); return rc; }
+    }
     const auto print_progress = [](void *, uint32_t levels, uint64_t g, uint64_t dst, uint64_t q) {
         printf("Progress(%u): %llu states generated, %llu distinct states found, %llu states left on queue.\n", levels,
                (unsigned long long)g, (unsigned long long)dst, (unsigned long long)q);
