@@ -19,7 +19,8 @@ struct GenCheck {
     uint64_t distinct, generated, mismatches, states_checked, pairs_checked, first_bad_state, first_bad_slot;
     uint32_t depth;
     int32_t first_bad_kind;   // 1 status, 2 fingerprint, 3 row, 4 init, 5 guards miss an enabled slot, 6 key out of range, 7 eval_pair, 8 write_pair,
-                              // 9 a reachable state does not survive pack + export (a cell outside its inferred range)
+                              // 9 a reachable state does not survive pack + export (a cell outside its inferred range),
+                              // 10 two distinct states share a fingerprint of the generated code (or one state has two)
     uint32_t stored_words, vm_words;
 };
 
@@ -43,7 +44,7 @@ extern "C" int gen_check(const void *program, uint64_t max_states, GenCheck *out
     auto bad = [&](int kind, uint64_t state, uint64_t slot) {
         if (!out->mismatches++) { out->first_bad_kind = kind; out->first_bad_state = state; out->first_bad_slot = slot; }
     };
-    std::unordered_set<uint64_t> seen;
+    std::unordered_set<uint64_t> seen, gseen;   // the interpreter's fingerprints (they drive the search) / the generated code's
     std::vector<uint64_t> cur, next;
     uint64_t a[VM::MAX_WORDS], b[VM::MAX_WORDS], pa[VM::MAX_WORDS], back[VM::MAX_WORDS];
     // a == b in the layout the generated code stores (and, exported again, in the interpreter's)
@@ -63,7 +64,11 @@ extern "C" int gen_check(const void *program, uint64_t max_states, GenCheck *out
             bad(4, k, 0);
         out->generated++;
         if (VM::init_status(p, CWordRef{a, 1}) & ST_OUT_OF_MODEL) continue;
-        if (seen.insert(VM::fp_of(p, CWordRef{a, 1})).second) { next.insert(next.end(), a, a + W); out->distinct++; }
+        if (seen.insert(VM::fp_of(p, CWordRef{a, 1})).second) {
+            next.insert(next.end(), a, a + W);
+            out->distinct++;
+            if (!gseen.insert(GS::fp_of(p, CWordRef{b, 1})).second) bad(10, k, 0);
+        } else if (gseen.insert(GS::fp_of(p, CWordRef{b, 1})).second) bad(10, k, 0);
     }
     cur.swap(next);
     uint32_t level = 1;
@@ -120,7 +125,11 @@ extern "C" int gen_check(const void *program, uint64_t max_states, GenCheck *out
                 // (out-of-model successors are compared too: never stored, but evaluated — their rows must pack)
                 if (!same_row(a, b) || GS::fp_of(p, CWordRef{b, 1}) != f1) bad(f0 != f1 && !GenProg::PACKED ? 2 : 3, out->states_checked - 1, (uint64_t)slot);
                 if (s0 & ST_OUT_OF_MODEL) continue;
-                if (seen.insert(f0).second) { next.insert(next.end(), a, a + W); out->distinct++; }
+                if (seen.insert(f0).second) {
+                    next.insert(next.end(), a, a + W);
+                    out->distinct++;
+                    if (!gseen.insert(f1).second) bad(10, out->states_checked - 1, (uint64_t)slot);
+                } else if (gseen.insert(f1).second) bad(10, out->states_checked - 1, (uint64_t)slot);
             }
         }
         cur.clear();

@@ -278,13 +278,14 @@ def gen_check(prog, max_states=0):
     text = program_codegen(prog)
     out = ROOT / "tests" / "_gen" / "_build"
     out.mkdir(exist_ok=True)
-    tag = hashlib.sha256((text + (ROOT / "tests" / "_gen" / "harness.cpp").read_text() + (ROOT / "tla_rust_amd" / "csrc" / "spec_gen.h").read_text()).encode()).hexdigest()[:16]
+    defs = os.environ.get("GEN_CHECK_DEFS", "").split()   # (e.g. -DMC_GEN_FP_SUM=1: the A/B forms of spec_gen.h)
+    tag = hashlib.sha256((text + (ROOT / "tests" / "_gen" / "harness.cpp").read_text() + (ROOT / "tla_rust_amd" / "csrc" / "spec_gen.h").read_text() + " ".join(defs)).encode()).hexdigest()[:16]
     so, hdr = out / f"libgen_{tag}.so", out / f"gen_{tag}.h"
     if not so.exists():
         hdr.write_text(text)
         tmp = out / f"libgen_{tag}.{os.getpid()}.tmp"
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-w", "-I", str(ROOT / "tla_rust_amd" / "csrc"), "-I", str(ROOT / "include"),
-                        f'-DGEN_HEADER="{hdr}"', "-o", str(tmp), str(ROOT / "tests" / "_gen" / "harness.cpp")], check=True)
+                        f'-DGEN_HEADER="{hdr}"', *defs, "-o", str(tmp), str(ROOT / "tests" / "_gen" / "harness.cpp")], check=True)
         os.replace(tmp, so)
     C.CDLL(str(build_shim()), mode=C.RTLD_GLOBAL)   # the interpreter's host helpers (vm_make_params, ...) live in the front-end
     lib = C.CDLL(str(so))

@@ -26,6 +26,10 @@
 #pragma once
 #include "spec_vm.h"
 
+#ifndef MC_GEN_FP_SUM
+#define MC_GEN_FP_SUM 0
+#endif
+
 namespace mc {
 
 // the by-pairs protocol's constants (engine_pairs.h), present only for programs the kernel's fixed sizes take: at most 128 slots (guard
@@ -65,6 +69,17 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
     }
 
     MC_HD static uint64_t fp_words(const uint64_t *w) {  // (SpecVmT::fp_vals over the stored row: the interpreter's fingerprints when the layout is the interpreter's)
+#if MC_GEN_FP_SUM
+        // packed rows: the fingerprint is the sum of one hmum term per stored word (salted by the word's index; independent terms, two
+        // 32 x 32 -> 64 multiply-accumulates each: mc_common.h, the raft / SSI lowerings' H) and ONE fmix64 over the sum, instead of a chain
+        // of MAX_WORDS dependent fmix64 rounds (six quarter-rate multiplies each).  The interpreter's layout keeps the interpreter's fingerprints.
+        if constexpr (G::PACKED) {
+            uint64_t h = 0;
+#pragma unroll
+            for (int k = 0; k < MAX_WORDS; ++k) h += hmum(w[k], 0x632be59bd9b4e019ull * (uint64_t)(k + 1));
+            return fp_nonzero(fmix64(h ^ 0x9e3779b97f4a7c15ull));
+        }
+#endif
         uint64_t h = 0x9e3779b97f4a7c15ull;
 #pragma unroll
         for (int k = 0; k < MAX_WORDS; ++k) h = fmix64(h ^ (w[k] + 0x632be59bd9b4e019ull * (uint64_t)(k + 1)));
