@@ -24,6 +24,11 @@ struct GenCheck {
     uint32_t stored_words, vm_words;
 };
 
+template <class T>
+static int nkeys() {
+    if constexpr (spec_gen_pairs_ok<GenProg>()) return T::PAIR_KEYS;
+    else return GenProg::NLABELS;
+}
 // the interpreter's row -> the row the generated code stores; false: a cell is outside the range the analysis inferred
 static bool pack(const uint64_t *vm_row, uint64_t *stored) {
     GenProg::Cells v;
@@ -100,7 +105,7 @@ extern "C" int gen_check(const void *program, uint64_t max_states, GenCheck *out
                     const bool g = slot < 64 ? (glo >> slot & 1u) : (ghi >> (slot - 64) & 1u);
                     if ((s0 & ST_ENABLED) && !g) bad(5, out->states_checked - 1, (uint64_t)slot);   // an enabled slot the guards miss: a lost successor
                     const int key = GS::pair_key(p, gs, slot);
-                    if (key < 0 || key >= GenProg::NLABELS) bad(6, out->states_checked - 1, (uint64_t)slot);
+                    if (key < 0 || key >= nkeys<GS>()) bad(6, out->states_checked - 1, (uint64_t)slot);
                     uint64_t f2 = 0;
                     GS::PairOut po;
                     const unsigned s2 = GS::eval_pair<0>(p, GS::Summary{}, gs, slot, f2, po);

@@ -51,6 +51,9 @@ constexpr unsigned PAIR_DEAD = 0xffffu;    // a pair the seen-set already knew (
 #ifndef MC_PAIR_WAVES
 #define MC_PAIR_WAVES 4
 #endif
+#ifndef MC_PAIR_COMPACT    // 0 = A/B: pass 2 walks the list with its holes
+#define MC_PAIR_COMPACT 1
+#endif
 #ifndef MC_PAIR_MINW       // wavefronts per SIMD the register allocation leaves room for (the generated-code unit: 2 — a state twice in registers)
 #define MC_PAIR_MINW 4
 #endif
@@ -293,13 +296,17 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
                 finish_p2();
             }
         };
+        unsigned fe[NF];  // pass 2: family f's surviving pairs are list[fs[f] .. fe[f])
+#pragma unroll
+        for (int f = 0; f < NF; f++) fe[f] = fs[f + 1];
         for (int pass = 0; pass < 2; ++pass) {
             unsigned run = 0;  // pass 2: survivors written so far
             static_for<0, NF>([&](auto fc) {
                 constexpr int F = decltype(fc)::value;
-                for (unsigned b = fs[F]; b < fs[F + 1]; b += 64) {
+                const unsigned fend = pass == 0 ? fs[F + 1] : fe[F];
+                for (unsigned b = fs[F]; b < fend; b += 64) {
                     const unsigned i = b + lane;
-                    const bool mine = i < fs[F + 1];
+                    const bool mine = i < fend;
                     const unsigned e = mine ? (unsigned)L.list[i] : PAIR_DEAD;
                     const bool live = e != PAIR_DEAD;
                     const unsigned long long bl = __ballot(live);
@@ -359,6 +366,26 @@ k_expand_pairs(typename S::Params prm, const uint64_t *__restrict__ arena, uint6
                 MC_PROF(10);
                 if (!nsurv) break;
                 wave_lds_fence();  // the struck entries are visible to the lanes that read them in pass 2
+                // COMPACTION (round 6, last third).  Pass 2 walked the list as pass 1 left it — the struck pairs as holes: where a third of the
+                // candidates are new (the generated PlusCal models: 64 survivors of ~210 pairs per wavefront, profiles/r06zy) it evaluated 3.4
+                // batches with 19 live lanes each, as expensive as pass 1 for a third of the pairs.  When fewer than 3/4 of the pairs survive,
+                // every family's survivors are moved to the front of its range first (stable: the batches stay sorted by key; in place: a batch
+                // is read before anything is written, and writes land at or below the positions read), and pass 2 runs full batches.
+                if (MC_PAIR_COMPACT && nsurv * 4u < fs[NF] * 3u) {  // (wave-uniform)
+                    static_for<0, NF>([&](auto fc) {
+                        constexpr int F = decltype(fc)::value;
+                        unsigned wpos = fs[F];
+                        for (unsigned b = fs[F]; b < fs[F + 1]; b += 64) {
+                            const unsigned i = b + lane;
+                            const unsigned e = i < fs[F + 1] ? (unsigned)L.list[i] : PAIR_DEAD;
+                            const unsigned long long bl = __ballot(e != PAIR_DEAD);
+                            if (e != PAIR_DEAD) L.list[wpos + (unsigned)__popcll(bl & ((1ull << lane) - 1ull))] = (uint16_t)e;
+                            wpos += (unsigned)__popcll(bl);
+                        }
+                        fe[F] = wpos;
+                    });
+                    wave_lds_fence();
+                }
                 if (lane == 0) out0 = atomicAdd(&ctr->arena_next, (unsigned long long)nsurv);
                 out0 = __shfl(out0, 0);
                 if (out0 + nsurv > rt.arena_cap) { err |= DEV_EARENA; write_ok = false; }

@@ -706,6 +706,22 @@ std::string codegen(const Program &P, bool pack) {
     o << "    MC_HD static int nch(int32_t label) {\n        switch (label) {\n";
     for (int l : used) o << "        case " << l << ": return " << g.max_choices(c[(size_t)(label_tab + l)], maxch) << ";\n";
     o << "        default: return " << maxch << ";\n        }\n    }\n";
+    // the by-pairs kernel's sort key: one key per (instance, label the instance can stand at) + a last one ("Done", the terminating slot).  A label
+    // function is a template over the INSTANCE (its cells are named members): a batch of 64 pairs that stand at ONE label but belong to N
+    // different instances runs N copies of the label's code one after the other, each with 1 / N of the lanes.  Sorted by (instance, label)
+    // a batch runs one copy.  (spec_gen.h uses these keys while they fit the kernel's 64; the label alone beyond that.)
+    {
+        int nk = 0;
+        std::ostringstream sw;
+        for (int i = 0; i < ninst; ++i) {
+            sw << "        case " << i << ": switch (label) {";
+            for (int l : per_inst[(size_t)i])
+                if (c[(size_t)(label_tab + l)] >= 0) sw << " case " << l << ": return " << nk++ << ";";
+            sw << " default: break; } break;\n";
+        }
+        o << "    static constexpr int NKEYS = " << nk + 1 << ";\n    MC_HD static int key_of(int inst, int32_t label) {\n        switch (inst) {\n" << sw.str()
+          << "        default: break;\n        }\n        return NKEYS - 1;\n    }\n";
+    }
     o << "    template <int INST>\n    MC_HD static int run_inst(int32_t label, uint64_t &ch, Cells &v, const Cells &old, int &aux) {\n        int32_t result = 0;\n";
     for (int i = 0; i < ninst; ++i) {
         o << "        if constexpr (INST == " << i << ") {\n            switch (label) {\n";

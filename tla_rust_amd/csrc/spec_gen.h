@@ -29,6 +29,9 @@
 #ifndef MC_GEN_FP_SUM
 #define MC_GEN_FP_SUM 0
 #endif
+#ifndef MC_GEN_KEY_BY_INST   // 0 = A/B: the by-pairs kernel's pairs sorted by label alone (round 6 until its last third)
+#define MC_GEN_KEY_BY_INST 1
+#endif
 
 namespace mc {
 
@@ -40,7 +43,7 @@ template <class G>
 struct SpecGenPairs<G, true> {
     // (a wavefront whose parents enable more pairs than its list holds works in rounds of 20 consecutive slots: 20 x 64 = the list)
     static constexpr int PAIR_FAMILIES = 1, TOTAL_SLOTS = G::NINST * G::MAXCH + 1, PAIR_ROUND_SLOTS = 20, PAIR_ROUNDS = (TOTAL_SLOTS + 19) / 20,
-                         PAIR_KEYS = G::NLABELS, W_PAIR_BASE = -1;
+                         PAIR_KEYS = (MC_GEN_KEY_BY_INST && G::NKEYS <= 64) ? G::NKEYS : G::NLABELS, W_PAIR_BASE = -1;
 };
 template <class G>
 constexpr bool spec_gen_pairs_ok() { return G::NINST * G::MAXCH + 1 <= 128 && G::NLABELS <= 64; }
@@ -50,6 +53,7 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
     using Params = VmParams;
     using VM = SpecVmT<128>;
     static constexpr int NV = G::NV, MAX_VARS = NV, MAX_WORDS = G::NW, FIX_SLOTS = 0, STAGE_WORDS = 0;
+    static constexpr bool KEY_BY_INST = MC_GEN_KEY_BY_INST && G::NKEYS <= 64;   // pairs sorted by (instance, label): one copy of a label's code per batch
     static constexpr int EXPORT_WORDS = G::VMW;   // (engine.hip: rows leave the engine through export_row)
     static constexpr bool PACKED_ROWS = G::PACKED;
     static constexpr bool SLICE_SLOTS = true;
@@ -235,9 +239,15 @@ struct SpecGenT : SpecGenPairs<G, spec_gen_pairs_ok<G>()> {
     // the label slot's instance stands at, read from the parent's packed row (cell PC_BASE + inst: half of word (PC_BASE + inst) / 2)
     template <class Ref>
     MC_HD static int pair_key(const Params &, Ref row, int slot) {
-        if (slot >= G::NINST * G::MAXCH) return G::DONE;
-        const int32_t label = G::pc_from_row(row, slot / G::MAXCH);
-        return label >= 0 && label < G::NLABELS ? label : G::DONE;
+        if constexpr (KEY_BY_INST) {
+            if (slot >= G::NINST * G::MAXCH) return G::NKEYS - 1;
+            const int inst = slot / G::MAXCH;
+            return G::key_of(inst, G::pc_from_row(row, inst));
+        } else {
+            if (slot >= G::NINST * G::MAXCH) return G::DONE;
+            const int32_t label = G::pc_from_row(row, slot / G::MAXCH);
+            return label >= 0 && label < G::NLABELS ? label : G::DONE;
+        }
     }
     struct PairOut { uint64_t w[MAX_WORDS]; };   // the successor's packed row
     template <int F, class Ref>
