@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B build: libtlamc_ssiab.so = the library with the SSI translation unit (MC_TU = 5) compiled with extra defines ($1, e.g. -DMC_PAIR_COMPACT_Q=4).
+# A/B build: libtlamc_ssiab.so = the library with the SSI translation unit (MC_TU = 5) compiled with extra defines ($1, e.g. -DMC_PAIR_COMPACT=0, or a macro of an experiment's working tree).
 # Loaded with TLAMC_LIB=tla_rust_amd/_build/libtlamc_ssiab.so; never the product library.
 set -e
 cd "$(dirname "$0")/.."
