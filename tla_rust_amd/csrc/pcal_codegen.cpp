@@ -455,7 +455,7 @@ struct Ranges {
             case VM_PUSH: push(AV::cst(o0)); break;
             case VM_SELF: push(self); break;
             case VM_LOAD: push(load(o0)); break;
-            case VM_LOADT: if (o0 < 0 || o0 >= 16) fail("temporary out of range"); push(a.t[o0]); break;
+            case VM_LOADT: if (o0 < 0 || o0 >= 16) fail("temporary out of range"); push(a.t[o0].bot ? AV::top() : a.t[o0]); break;   // (never written on this path: anything)
             case VM_STORET: if (o0 < 0 || o0 >= 16) fail("temporary out of range"); a.t[o0] = pop().v; break;
             case VM_STORE: store(o0, pop().v); break;
             case VM_LOADX: { pop(); AV j; for (int k = 0; k < o2; ++k) j = av_join(j, load(o0 + k)); push(j); break; }
